@@ -1,1 +1,121 @@
-// kernel wrappers (filled in below)
+// oracle/ref_wrap_kernels.h -- TEST INFRASTRUCTURE, included by ref_wrap.cpp only.
+// extern "C" wrappers that ENTER the reference's own kernels (no arithmetic of their own beyond
+// buffer plumbing and the CTU loops of the picture-level callers, which are cited).
+#pragma once
+#include <vector>
+#include "CommonLib/Buffer.h"
+#include "CommonLib/Unit.h"
+#include "CommonLib/AdaptiveLoopFilter.h"
+#include "CommonLib/SampleAdaptiveOffset.h"
+#include "../include/vvcgpu.h"
+
+// simd: 0 = the reference's scalar functions, 1 = whatever table the reference installs on this CPU
+// (InitX86.cpp:58-170; AVX2 on the build/bench hosts).
+static ClpRng mkClp(int mn, int mx, int bd) { ClpRng c; c.min = mn; c.max = mx; c.bd = bd; c.n = 0; return c; }
+
+extern "C" {
+
+// ---------------------------------------------------------------------------------------------
+// ALF.  Mirrors the plumbing of AdaptiveLoopFilter::ALFProcess (AdaptiveLoopFilter.cpp:68-139): copy the
+// picture into a margin-3 temp, extendBorderPel(3), then per CTU deriveClassification + filterBlk.
+// planes: Y, Cb, Cr valid areas (4:2:0).  cls_out (optional): per-4x4 classIdx|transposeIdx<<8.
+// luma_coeff = m_coeffFinal (25 x 13), chroma_coeff = 7.
+int vtmref_alf_picture(int simd, const Pel* srcY, const Pel* srcCb, const Pel* srcCr,
+                       Pel* dstY, Pel* dstCb, Pel* dstCr, int w, int h, int ctu, int bd,
+                       int filterType, const int16_t* luma_coeff, const int16_t* chroma_coeff,
+                       const uint8_t* enY, const uint8_t* enCb, const uint8_t* enCr, uint16_t* cls_out)
+{
+  AdaptiveLoopFilter alf;
+  int ibd[MAX_NUM_CHANNEL_TYPE] = { bd, bd };
+  alf.create(w, h, CHROMA_420, ctu, ctu, 0, ibd);
+  if (!simd)
+  {
+    alf.m_deriveClassificationBlk = AdaptiveLoopFilter::deriveClassificationBlk;
+    alf.m_filter5x5Blk = AdaptiveLoopFilter::filterBlk<ALF_FILTER_5>;
+    alf.m_filter7x7Blk = AdaptiveLoopFilter::filterBlk<ALF_FILTER_7>;
+  }
+  const UnitArea picArea(CHROMA_420, Area(0, 0, w, h));
+  PelStorage tmp, rec;
+  tmp.create(CHROMA_420, Area(0, 0, w, h), ctu, MAX_ALF_FILTER_LENGTH >> 1, 0, false);
+  rec.create(picArea);
+  const Pel* s[3] = { srcY, srcCb, srcCr };
+  Pel* d[3] = { dstY, dstCb, dstCr };
+  for (int c = 0; c < 3; c++)
+  {
+    const int cw = c ? w / 2 : w, ch = c ? h / 2 : h;
+    rec.bufs[c].copyFrom(CPelBuf(s[c], cw, cw, ch));
+  }
+  tmp.copyFrom(rec);
+  PelUnitBuf tmpYuv = tmp.getBuf(picArea);
+  tmpYuv.extendBorderPel(MAX_ALF_FILTER_LENGTH >> 1);
+  PelUnitBuf recYuv = rec.getBuf(picArea);
+
+  std::vector<AlfClassifier*> rows(h);
+  std::vector<AlfClassifier> store((size_t)w * h);
+  for (int y = 0; y < h; y++) rows[y] = &store[(size_t)y * w];
+  ClpRng clp = mkClp(0, (1 << bd) - 1, bd);
+  std::vector<short> lc(luma_coeff, luma_coeff + 25 * 13), cc(chroma_coeff, chroma_coeff + 7);
+  const uint8_t* en[3] = { enY, enCb, enCr };
+  int ctuIdx = 0;
+  for (int yPos = 0; yPos < h; yPos += ctu)
+    for (int xPos = 0; xPos < w; xPos += ctu, ctuIdx++)
+    {
+      const int width = std::min(ctu, w - xPos), height = std::min(ctu, h - yPos);
+      if (!en[0] || en[0][ctuIdx])
+      {
+        Area blk(xPos, yPos, width, height);
+        alf.deriveClassification(rows.data(), tmpYuv.get(COMPONENT_Y), blk);
+        if (filterType == 0) alf.m_filter5x5Blk(rows.data(), recYuv, tmpYuv, blk, COMPONENT_Y, lc.data(), clp);
+        else                 alf.m_filter7x7Blk(rows.data(), recYuv, tmpYuv, blk, COMPONENT_Y, lc.data(), clp);
+        if (cls_out)
+          for (int y = yPos; y < yPos + height; y += 4)
+            for (int x = xPos; x < xPos + width; x += 4)
+              cls_out[(y >> 2) * (w >> 2) + (x >> 2)] = (uint16_t)(rows[y][x].classIdx | (rows[y][x].transposeIdx << 8));
+      }
+      for (int c = 1; c < 3; c++)
+        if (!en[c] || en[c][ctuIdx])
+        {
+          Area blk(xPos >> 1, yPos >> 1, width >> 1, height >> 1);
+          alf.m_filter5x5Blk(rows.data(), recYuv, tmpYuv, blk, ComponentID(c), cc.data(), clp);
+        }
+    }
+  for (int c = 0; c < 3; c++)
+  {
+    const int cw = c ? w / 2 : w, ch = c ? h / 2 : h;
+    PelBuf(d[c], cw, cw, ch).copyFrom(rec.bufs[c]);
+  }
+  alf.destroy();
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SAO apply.  Enters SampleAdaptiveOffset::offsetBlock (SampleAdaptiveOffset.cpp:292-508, protected -> reached
+// through a derived class) with the CTU loop of SAOProcess/offsetCTU (:510-612).  One component per call.
+struct SaoAccess : public SampleAdaptiveOffset
+{
+  using SampleAdaptiveOffset::offsetBlock;
+  void prep(int w) { m_signLineBuf1.resize(w + 2); m_signLineBuf2.resize(w + 2); }
+};
+int vtmref_sao_apply(const Pel* src, int sstride, Pel* dst, int dstride, int w, int h, int ctuW, int ctuH,
+                     int bd, const vvcgpu_sao_ctu* params, int clpMin, int clpMax)
+{
+  SaoAccess sao;
+  sao.prep(ctuW);
+  ClpRng clp = mkClp(clpMin, clpMax, bd);
+  int idx = 0;
+  for (int y = 0; y < h; y += ctuH)
+    for (int x = 0; x < w; x += ctuW, idx++)
+    {
+      const vvcgpu_sao_ctu& p = params[idx];
+      if (p.type < 0) continue;
+      int off[32];
+      for (int i = 0; i < 32; i++) off[i] = p.offset[i];
+      const int bw = std::min(ctuW, w - x), bh = std::min(ctuH, h - y);
+      sao.offsetBlock(bd, clp, p.type, off, src + y * sstride + x, dst + y * dstride + x, sstride, dstride, bw, bh,
+                      p.avail & 1, (p.avail >> 1) & 1, (p.avail >> 2) & 1, (p.avail >> 3) & 1,
+                      (p.avail >> 4) & 1, (p.avail >> 5) & 1, (p.avail >> 6) & 1, (p.avail >> 7) & 1);
+    }
+  return 0;
+}
+
+}  // extern "C"

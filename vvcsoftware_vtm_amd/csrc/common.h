@@ -1,0 +1,36 @@
+// common.h -- shared plumbing of the HIP hot-path library (gfx950 only).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+#include <string.h>
+#include "vvcgpu.h"
+
+typedef int16_t Pel;
+typedef int32_t TCoeff;
+
+void vvcgpu_set_error(const char* fmt, ...);
+
+#define VVC_CHECK_ARG(cond, ...)                                   \
+  do { if (!(cond)) { vvcgpu_set_error(__VA_ARGS__); return VVCGPU_E_ARG; } } while (0)
+
+#define VVC_HIP(call)                                                                        \
+  do { hipError_t e_ = (call); if (e_ != hipSuccess) {                                       \
+         vvcgpu_set_error("%s failed: %s (%s:%d)", #call, hipGetErrorString(e_), __FILE__, __LINE__); \
+         return VVCGPU_E_DEVICE; } } while (0)
+
+#define VVC_LAUNCH_CHECK()                                                                    \
+  do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) {                            \
+         vvcgpu_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+         return VVCGPU_E_DEVICE; } } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+
+__device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }
+__device__ __forceinline__ int sgn(int v) { return (v > 0) - (v < 0); }
+
+// 8 Pels = 16 bytes, the coalescing sweet spot for int16 planes (guide G13)
+typedef short pel8 __attribute__((ext_vector_type(8)));
+typedef short pel4 __attribute__((ext_vector_type(4)));
+typedef short pel2 __attribute__((ext_vector_type(2)));
+typedef int   int4v __attribute__((ext_vector_type(4)));
