@@ -85,6 +85,57 @@ int vvcgpu_sao_apply(const vvc_pel* src, int src_stride, vvc_pel* dst, int dst_s
                      int width, int height, int ctu_w, int ctu_h, int bit_depth,
                      const vvcgpu_sao_ctu* params, int clp_min, int clp_max, void* stream);
 
+/* ---- L1+L2: deblocking  (LoopFilter::loopFilterPic, LoopFilter.cpp:149-230: pass 1 all vertical edges,
+ *          pass 2 all horizontal edges; xEdgeFilterLuma :543-681, xEdgeFilterChroma :684-838,
+ *          xPelFilterLuma :856-916, xPelFilterChroma :928-949) -------------------------------------------
+ * In place on the three reconstruction planes (4:2:0).  The CU/TU/motion walk that decides WHICH edge
+ * segments are filtered and with which boundary strength (xDeblockCU :243-369, xGetBoundaryStrengthSingle
+ * :419-541) stays on the host; it is handed over as maps with one entry per 4x4 luma unit, row-major
+ * (height/4) x (width/4):
+ *   edge_ver[u] / edge_hor[u]: the 4-sample segment on the LEFT / TOP border of unit u
+ *        bits 0-1  luma   BS (0 = segment not filtered; only 8x8-grid positions may be non-zero)
+ *        bits 2-3  chroma BS (chroma is filtered when it is 2 and the edge lies on the 8-sample chroma grid)
+ *        bit  4    P side must not be modified (IPCM+pcm_loop_filter_disable / transquant bypass, :640-651)
+ *        bit  5    Q side must not be modified
+ *   qp_luma[u], qp_chroma[u]: QP of the CU covering unit u in the luma tree / chroma tree (CodingUnit::qp;
+ *        identical unless the slice uses the dual tree).
+ * width and height must be multiples of 8 (minimum CU size 4 with the 8x8 deblocking grid, TypeDef.h:60). */
+typedef struct vvcgpu_deblock_cfg {
+  int32_t bit_depth_luma, bit_depth_chroma;
+  int32_t beta_offset_div2, tc_offset_div2;     /* slice deblocking offsets            */
+  int32_t cb_qp_offset, cr_qp_offset;           /* PPS chroma QP offsets (:809)        */
+  int32_t clp_min[3], clp_max[3];               /* ClpRng per component                */
+} vvcgpu_deblock_cfg;
+int vvcgpu_deblock(vvc_pel* y, int stride_y, vvc_pel* cb, vvc_pel* cr, int stride_c, int width, int height,
+                   const uint8_t* edge_ver, const uint8_t* edge_hor, const int8_t* qp_luma,
+                   const int8_t* qp_chroma, const vvcgpu_deblock_cfg* cfg_host, void* stream);
+
+/* ---- S2: SAO statistics  (EncSampleAdaptiveOffset::getStatistics / getBlkStats,
+ *          EncoderLib/EncSampleAdaptiveOffset.cpp:278-330, 1122-1490; isCalculatePreDeblockSamples == false,
+ *          i.e. SAOLcuBoundary 0 as in all shipped cfgs) -------------------------------------------------
+ * One call per component.  org = original plane, rec = deblocked plane.
+ * out: per CTU (raster) 5 types x { int64 diff[32]; int64 count[32]; }  (SAOStatData, EncSampleAdaptiveOffset.h:53-80);
+ *      EO classes use indices 0..4 (edgeType + 2), BO the 32 bands.  320 int64 per CTU.
+ * avail: device array, one byte per CTU with the vvcgpu_sao_ctu.avail bit layout; only L (bit0), A (bit2) and
+ *      AL (bit4) are read -- right/below/above-right come from the picture geometry exactly as in :300-306.
+ * skip_lines_r / skip_lines_b: m_skipLinesR/B of the component (5/4 luma, 3/2 chroma; :122-128).        */
+int vvcgpu_sao_stats(const vvc_pel* org, int org_stride, const vvc_pel* rec, int rec_stride,
+                     int width, int height, int ctu_w, int ctu_h, int bit_depth, const uint8_t* avail,
+                     int skip_lines_r, int skip_lines_b, int64_t* out, void* stream);
+
+/* ---- A3: ALF covariance statistics  (EncAdaptiveLoopFilter::deriveStatsForFiltering / getBlkStats /
+ *          calcCovariance, EncoderLib/EncAdaptiveLoopFilter.cpp:1317-1515) ---------------------------------
+ * One call per (component, filter shape).  rec = deblocked+SAO plane (border replicated by the kernel, :250-252),
+ * org = original plane.  cls: A1 output for luma, NULL for chroma (single class).
+ * filter_type 0: 5x5 (N = 7 coefficients), 1: 7x7 (N = 13).
+ * out: per CTU (raster) x class (25 luma / 1 chroma): int64 E[N][N] (full symmetric), y[N], pixAcc
+ *      = N*N + N + 1 values (183 / 57).  The reference accumulates the same integers into doubles
+ *      (AlfCovariance, EncAdaptiveLoopFilter.h:46-52); all sums are < 2^53, so int64 is exact and
+ *      order-independent.                                                                             */
+int vvcgpu_alf_stats(const vvc_pel* org, int org_stride, const vvc_pel* rec, int rec_stride,
+                     int width, int height, int ctu_size, const uint16_t* cls, int filter_type,
+                     int64_t* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -7,6 +7,12 @@
 #include "CommonLib/Unit.h"
 #include "CommonLib/AdaptiveLoopFilter.h"
 #include "CommonLib/SampleAdaptiveOffset.h"
+#include "CommonLib/CodingStructure.h"
+#include "EncoderLib/CABACWriter.h"
+// The encoder-side statistics kernels are private members; the checker reaches them without touching the
+// reference sources because oracle/Makefile compiles THIS translation unit with g++ -fno-access-control.
+#include "EncoderLib/EncSampleAdaptiveOffset.h"
+#include "EncoderLib/EncAdaptiveLoopFilter.h"
 #include "../include/vvcgpu.h"
 
 // simd: 0 = the reference's scalar functions, 1 = whatever table the reference installs on this CPU
@@ -115,6 +121,87 @@ int vtmref_sao_apply(const Pel* src, int sstride, Pel* dst, int dstride, int w, 
                       p.avail & 1, (p.avail >> 1) & 1, (p.avail >> 2) & 1, (p.avail >> 3) & 1,
                       (p.avail >> 4) & 1, (p.avail >> 5) & 1, (p.avail >> 6) & 1, (p.avail >> 7) & 1);
     }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// SAO statistics.  Enters EncSampleAdaptiveOffset::getBlkStats (EncSampleAdaptiveOffset.cpp:1122-1490) with the
+// CTU loop and flag derivation of getStatistics (:278-330).  One component per call; out as vvcgpu_sao_stats.
+int vtmref_sao_stats(int comp, const Pel* org, int ostride, const Pel* rec, int rstride, int w, int h, int ctuW,
+                     int ctuH, int bd, const uint8_t* avail, int skipR, int skipB, int64_t* out)
+{
+  EncSampleAdaptiveOffset sao;
+  sao.m_signLineBuf1.resize(ctuW + 2);
+  sao.m_signLineBuf2.resize(ctuW + 2);
+  for (int t = 0; t < NUM_SAO_NEW_TYPES; t++) { sao.m_skipLinesR[comp][t] = skipR; sao.m_skipLinesB[comp][t] = skipB; }
+  SAOStatData st[NUM_SAO_NEW_TYPES];
+  int idx = 0;
+  for (int y = 0; y < h; y += ctuH)
+    for (int x = 0; x < w; x += ctuW, idx++)
+    {
+      const int bw = std::min(ctuW, w - x), bh = std::min(ctuH, h - y);
+      const int a = avail ? avail[idx] : ((x > 0 ? 1 : 0) | (y > 0 ? 4 : 0) | (x > 0 && y > 0 ? 16 : 0));
+      const bool right = x + ctuW < w, below = y + ctuH < h;
+      sao.getBlkStats(ComponentID(comp), bd, st, const_cast<Pel*>(rec) + y * rstride + x,
+                      const_cast<Pel*>(org) + y * ostride + x, rstride, ostride, bw, bh,
+                      a & 1, right, (a >> 2) & 1, below, (a >> 4) & 1, (y > 0) && right, false);
+      for (int t = 0; t < 5; t++)
+      {
+        memcpy(out + (int64_t)idx * 320 + t * 64, st[t].diff, 32 * sizeof(int64_t));
+        memcpy(out + (int64_t)idx * 320 + t * 64 + 32, st[t].count, 32 * sizeof(int64_t));
+      }
+    }
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// ALF statistics.  Enters EncAdaptiveLoopFilter::getBlkStats (EncAdaptiveLoopFilter.cpp:1394-1440) per CTU as
+// deriveStatsForFiltering does (:1317-1392), on a margin-3 border-extended copy (ALFProcess :248-252).
+// cls: per-4x4 classifier (NULL for chroma).  out as vvcgpu_alf_stats.
+int vtmref_alf_stats(const Pel* org, int ostride, const Pel* rec, int w, int h, int ctu, const uint16_t* cls,
+                     int filterType, int64_t* out)
+{
+  EncAdaptiveLoopFilter alf;
+  AlfFilterShape shape(filterType ? 7 : 5);
+  const int N = shape.numCoeff, nCls = cls ? 25 : 1, recSz = N * N + N + 1;
+  PelStorage tmp;
+  tmp.create(CHROMA_400, Area(0, 0, w, h), ctu, MAX_ALF_FILTER_LENGTH >> 1, 0, false);
+  tmp.bufs[0].copyFrom(CPelBuf(rec, w, w, h));
+  tmp.bufs[0].extendBorderPel(MAX_ALF_FILTER_LENGTH >> 1);
+  std::vector<AlfClassifier*> rows(h);
+  std::vector<AlfClassifier> store((size_t)w * h);
+  for (int y = 0; y < h; y++)
+  {
+    rows[y] = &store[(size_t)y * w];
+    if (cls) for (int x = 0; x < w; x++)
+    {
+      const uint16_t c = cls[(y >> 2) * (w >> 2) + (x >> 2)];
+      rows[y][x] = AlfClassifier(c & 0xff, c >> 8);
+    }
+  }
+  std::vector<AlfCovariance> cov(nCls);
+  for (auto& c : cov) c.create(N);
+  int idx = 0;
+  for (int y = 0; y < h; y += ctu)
+    for (int x = 0; x < w; x += ctu, idx++)
+    {
+      for (auto& c : cov) c.reset();
+      const CompArea area(COMPONENT_Y, CHROMA_400, Area(x, y, std::min(ctu, w - x), std::min(ctu, h - y)));
+      PelBuf r = tmp.bufs[0];
+      alf.getBlkStats(cov.data(), shape, cls ? rows.data() : nullptr, const_cast<Pel*>(org) + y * ostride + x, ostride,
+                      r.buf + y * r.stride + x, r.stride, area);
+      for (int c = 0; c < nCls; c++)
+      {
+        int64_t* a = out + ((int64_t)idx * nCls + c) * recSz;
+        for (int k = 0; k < N; k++)
+        {
+          for (int l = 0; l < N; l++) a[k * N + l] = (int64_t)cov[c].E[k][l];
+          a[N * N + k] = (int64_t)cov[c].y[k];
+        }
+        a[N * N + N] = (int64_t)cov[c].pixAcc;
+      }
+    }
+  for (auto& c : cov) c.destroy();
   return 0;
 }
 

@@ -47,3 +47,56 @@ def sao_params(rng, w, h, cw, ch, full_avail=True, types=None):
                     a |= 1 << k
             prm["avail"][j * nx + i] = a
     return prm
+
+
+def deblock_maps(rng, w, h, mode="cu"):
+    """Edge/BS/QP maps per 4x4 luma unit (see include/vvcgpu.h).  mode 'cu': a seeded quadtree CU grid with
+    intra/inter blocks and cbf-like BS; mode 'random': arbitrary map bytes (stress: off-grid edges, flags)."""
+    w4, h4 = w // 4, h // 4
+    ev = np.zeros((h4, w4), np.uint8)
+    eh = np.zeros((h4, w4), np.uint8)
+    qpl = np.zeros((h4, w4), np.int8)
+    qpc = np.zeros((h4, w4), np.int8)
+    if mode == "random":
+        ev[:] = rng.integers(0, 64, (h4, w4))
+        eh[:] = rng.integers(0, 64, (h4, w4))
+        # BS value 3 never occurs in the reference
+        for m in (ev, eh):
+            m[(m & 3) == 3] &= 0xFE
+            m[((m >> 2) & 3) == 3] &= 0xFB
+        qpl[:] = rng.integers(0, 64, (h4, w4))
+        qpc[:] = rng.integers(0, 64, (h4, w4))
+        return ev, eh, qpl, qpc
+    intra = np.zeros((h4, w4), bool)
+
+    def split(x, y, s):
+        if s > 8 and (s > 64 or rng.random() < 0.55):
+            for dy in (0, s // 2):
+                for dx in (0, s // 2):
+                    split(x + dx, y + dy, s // 2)
+            return
+        x1, y1 = min(x + s, w), min(y + s, h)
+        if x >= w or y >= h:
+            return
+        ux0, uy0, ux1, uy1 = x // 4, y // 4, x1 // 4, y1 // 4
+        isint = rng.random() < 0.3
+        intra[uy0:uy1, ux0:ux1] = isint
+        q = int(rng.integers(22, 46))
+        qpl[uy0:uy1, ux0:ux1] = q
+        qpc[uy0:uy1, ux0:ux1] = q if rng.random() < 0.7 else int(rng.integers(22, 46))
+        nf = rng.random() < 0.03
+        for uy in range(uy0, uy1):          # left border
+            if x > 0:
+                pi = intra[uy, ux0 - 1] or isint
+                bs = 2 if pi else int(rng.integers(0, 2))
+                ev[uy, ux0] = bs | ((2 if pi else 0) << 2) | (0x20 if nf else 0)
+        for ux in range(ux0, ux1):          # top border
+            if y > 0:
+                pi = intra[uy0 - 1, ux] or isint
+                bs = 2 if pi else int(rng.integers(0, 2))
+                eh[uy0, ux] = bs | ((2 if pi else 0) << 2) | (0x10 if nf and rng.random() < 0.5 else 0)
+
+    for y in range(0, h, 128):
+        for x in range(0, w, 128):
+            split(x, y, 128)
+    return ev, eh, qpl, qpc

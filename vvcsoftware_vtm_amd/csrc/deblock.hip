@@ -1,0 +1,328 @@
+// deblock.hip -- deblocking sample filters (L2) over host-derived edge/BS/QP maps (L1) for gfx950.
+//
+// Reference behaviour reproduced (bit-exact): LoopFilter::xEdgeFilterLuma / xEdgeFilterChroma /
+// xPelFilterLuma / xPelFilterChroma / xUseStrongFiltering / xCalcDP / xCalcDQ
+// (CommonLib/LoopFilter.cpp:543-980) in the pass order of loopFilterPic (:149-230): all vertical
+// edges of the picture, then all horizontal edges.
+//
+// Design: ONE kernel, ONE pass over HBM (2 x picture bytes + maps) instead of the reference's two passes.
+// Edges lie on an 8-sample grid and a filter touches at most 4 samples on each side, so a tile whose
+// origin is shifted by (-4,-4) from the grid contains the complete footprint of every edge it owns, in both
+// directions: the tile is staged in LDS, all vertical edges are filtered (LDS in place), barrier, all
+// horizontal edges are filtered on the result, barrier, tile written back.  No halo, no inter-workgroup
+// dependency, no second launch.  The same holds for chroma (8-sample chroma grid, 2 samples per side).
+#include "common.h"
+
+namespace {
+
+__constant__ uint8_t c_tc[66] = {
+  0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,1,1,1,1,1,1,1,1,1,2,2,2,2,3,3,3,3,4,4,4,5,5,6,6,7,8,9,10,11,13,14,16,18,20,22,24,
+  26,28,30,32,34,36,38,40,42,44,46,48 };
+__constant__ uint8_t c_beta[64] = {
+  0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,0,6,7,8,9,10,11,12,13,14,15,16,17,18,20,22,24,26,28,30,32,34,36,38,40,42,44,46,48,50,52,
+  54,56,58,60,62,64,66,68,70,72,74,76,78,80,82,84,86,88 };
+__constant__ uint8_t c_chromaScale420[70] = {
+  0,1,2,3,4,5,6,7,8,9,10,11,12,13,14,15,16,17,18,19,20,21,22,23,24,25,26,27,28,29,29,30,31,32,33,33,34,34,35,35,36,36,
+  37,37,38,39,40,41,42,43,44,45,46,47,48,49,50,51,52,53,54,55,56,57,58,59,60,61,62,63 };
+
+constexpr int TS = 64;        // tile size (samples) in both dimensions
+constexpr int TP = 72;        // LDS pitch (samples); 144-byte rows spread 4-row-apart segments over banks
+constexpr int MAXQP = 63, TCOFF = 2, QPMAPSZ = 70;
+
+struct Seg8 { int m[8]; };    // m[0..3] = P side (m0..m3), m[4..7] = Q side
+
+__device__ __forceinline__ void filter_luma_line(Seg8& v, int tc, bool sw, bool noP, bool noQ, int thrCut,
+                                                 bool fP, bool fQ, int cmin, int cmax)
+{
+  const int m0 = v.m[0], m1 = v.m[1], m2 = v.m[2], m3 = v.m[3], m4 = v.m[4], m5 = v.m[5], m6 = v.m[6], m7 = v.m[7];
+  int n1 = m1, n2 = m2, n3 = m3, n4 = m4, n5 = m5, n6 = m6;
+  if (sw)
+  {
+    n3 = clip3(m3 - 2 * tc, m3 + 2 * tc, (m1 + 2 * m2 + 2 * m3 + 2 * m4 + m5 + 4) >> 3);
+    n4 = clip3(m4 - 2 * tc, m4 + 2 * tc, (m2 + 2 * m3 + 2 * m4 + 2 * m5 + m6 + 4) >> 3);
+    n2 = clip3(m2 - 2 * tc, m2 + 2 * tc, (m1 + m2 + m3 + m4 + 2) >> 2);
+    n5 = clip3(m5 - 2 * tc, m5 + 2 * tc, (m3 + m4 + m5 + m6 + 2) >> 2);
+    n1 = clip3(m1 - 2 * tc, m1 + 2 * tc, (2 * m0 + 3 * m1 + m2 + m3 + m4 + 4) >> 3);
+    n6 = clip3(m6 - 2 * tc, m6 + 2 * tc, (m3 + m4 + m5 + 3 * m6 + 2 * m7 + 4) >> 3);
+    // the reference stores these into Pel without ClipPel (LoopFilter.cpp:871-876)
+    n1 = (short)n1; n2 = (short)n2; n3 = (short)n3; n4 = (short)n4; n5 = (short)n5; n6 = (short)n6;
+  }
+  else
+  {
+    int delta = (9 * (m4 - m3) - 3 * (m5 - m2) + 8) >> 4;
+    if (abs(delta) < thrCut)
+    {
+      delta = clip3(-tc, tc, delta);
+      n3 = clip3(cmin, cmax, m3 + delta);
+      n4 = clip3(cmin, cmax, m4 - delta);
+      const int tc2 = tc >> 1;
+      if (fP) n2 = clip3(cmin, cmax, m2 + clip3(-tc2, tc2, ((((m1 + m3 + 1) >> 1) - m2 + delta) >> 1)));
+      if (fQ) n5 = clip3(cmin, cmax, m5 + clip3(-tc2, tc2, ((((m6 + m4 + 1) >> 1) - m5 - delta) >> 1)));
+    }
+  }
+  if (noP) { n3 = m3; n2 = m2; n1 = m1; }
+  if (noQ) { n4 = m4; n5 = m5; n6 = m6; }
+  v.m[1] = n1; v.m[2] = n2; v.m[3] = n3; v.m[4] = n4; v.m[5] = n5; v.m[6] = n6;
+}
+
+__device__ __forceinline__ bool use_strong(const Seg8& v, int d, int beta, int tc)
+{
+  const int ds = abs(v.m[0] - v.m[3]) + abs(v.m[7] - v.m[4]);
+  return (ds < (beta >> 3)) && (d < (beta >> 2)) && (abs(v.m[3] - v.m[4]) < ((tc * 5 + 1) >> 1));
+}
+__device__ __forceinline__ int calc_dp(const Seg8& v) { return abs(v.m[1] - 2 * v.m[2] + v.m[3]); }
+__device__ __forceinline__ int calc_dq(const Seg8& v) { return abs(v.m[4] - 2 * v.m[5] + v.m[6]); }
+
+// Decide + filter one 4-line luma segment held in registers.
+__device__ __forceinline__ void luma_segment(Seg8 (&ln)[4], int bs, int qpP, int qpQ, bool noP, bool noQ,
+                                             const vvcgpu_deblock_cfg& c)
+{
+  const int qp = (qpP + qpQ + 1) >> 1;
+  const int scale = 1 << (c.bit_depth_luma - 8);
+  const int tc = c_tc[clip3(0, MAXQP + TCOFF, qp + TCOFF * (bs - 1) + (c.tc_offset_div2 << 1))] * scale;
+  const int beta = c_beta[clip3(0, MAXQP, qp + (c.beta_offset_div2 << 1))] * scale;
+  const int side = (beta + (beta >> 1)) >> 3, thrCut = tc * 10;
+  const int dp0 = calc_dp(ln[0]), dq0 = calc_dq(ln[0]), dp3 = calc_dp(ln[3]), dq3 = calc_dq(ln[3]);
+  const int d0 = dp0 + dq0, d3 = dp3 + dq3;
+  if (d0 + d3 < beta)
+  {
+    const bool fP = (dp0 + dp3) < side, fQ = (dq0 + dq3) < side;
+    const bool sw = use_strong(ln[0], 2 * d0, beta, tc) && use_strong(ln[3], 2 * d3, beta, tc);
+#pragma unroll
+    for (int i = 0; i < 4; i++) filter_luma_line(ln[i], tc, sw, noP, noQ, thrCut, fP, fQ, c.clp_min[0], c.clp_max[0]);
+  }
+}
+
+// Tile loader/writer: tile origin (ox, oy) may be negative / overhang; outside samples read as 0 and are never written.
+__device__ __forceinline__ void tile_load(short* lds, const Pel* plane, int stride, int w, int h, int ox, int oy,
+                                          int tid, int nthreads)
+{
+  const bool vec_ok = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(plane) & 7) == 0);
+  for (int v = tid; v < TS * (TS / 4); v += nthreads)
+  {
+    const int r = v / (TS / 4), c = (v - r * (TS / 4)) * 4;
+    const int y = oy + r, x = ox + c;
+    pel4 val = { 0, 0, 0, 0 };
+    if (y >= 0 && y < h)
+    {
+      const Pel* row = plane + (size_t)y * stride;
+      if (vec_ok && x >= 0 && x + 3 < w) val = *reinterpret_cast<const pel4*>(row + x);
+      else
+      {
+#pragma unroll
+        for (int k = 0; k < 4; k++) if (x + k >= 0 && x + k < w) val[k] = row[x + k];
+      }
+    }
+    *reinterpret_cast<pel4*>(lds + r * TP + c) = val;
+  }
+}
+__device__ __forceinline__ void tile_store(const short* lds, Pel* plane, int stride, int w, int h, int ox, int oy,
+                                           int tid, int nthreads)
+{
+  const bool vec_ok = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(plane) & 7) == 0);
+  for (int v = tid; v < TS * (TS / 4); v += nthreads)
+  {
+    const int r = v / (TS / 4), c = (v - r * (TS / 4)) * 4;
+    const int y = oy + r, x = ox + c;
+    if (y < 0 || y >= h) continue;
+    const pel4 val = *reinterpret_cast<const pel4*>(lds + r * TP + c);
+    Pel* row = plane + (size_t)y * stride;
+    if (vec_ok && x >= 0 && x + 3 < w) *reinterpret_cast<pel4*>(row + x) = val;
+    else
+    {
+#pragma unroll
+      for (int k = 0; k < 4; k++) if (x + k >= 0 && x + k < w) row[x + k] = val[k];
+    }
+  }
+}
+
+__global__ __launch_bounds__(128) void deblock_luma_kernel(Pel* __restrict__ Y, int stride, int w, int h,
+                                                           const uint8_t* __restrict__ edgeV,
+                                                           const uint8_t* __restrict__ edgeH,
+                                                           const int8_t* __restrict__ qpm, vvcgpu_deblock_cfg cfg)
+{
+  __shared__ short tile[TS * TP];
+  const int tid = threadIdx.x;
+  const int ox = blockIdx.x * TS - 4, oy = blockIdx.y * TS - 4;
+  const int w4 = w >> 2;
+  tile_load(tile, Y, stride, w, h, ox, oy, tid, 128);
+  __syncthreads();
+
+  // ---- pass 1: vertical edges.  task = (edge k: x = ox+4+8k, segment s: rows oy+4s .. +3)
+  {
+    const int k = tid & 7, s = tid >> 3;
+    const int x = ox + 4 + 8 * k, y = oy + 4 * s;
+    if (x > 0 && x < w && y >= 0 && y < h)
+    {
+      const int u = (y >> 2) * w4 + (x >> 2);
+      const int e = edgeV[u];
+      if (e & 3)
+      {
+        Seg8 ln[4];
+        short* p = tile + (4 * s) * TP + 8 * k;       // sample x-4 of row y
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+          const pel8 v = *reinterpret_cast<const pel8*>(p + i * TP);
+#pragma unroll
+          for (int j = 0; j < 8; j++) ln[i].m[j] = v[j];
+        }
+        luma_segment(ln, e & 3, qpm[u - 1], qpm[u], (e >> 4) & 1, (e >> 5) & 1, cfg);
+#pragma unroll
+        for (int i = 0; i < 4; i++)
+        {
+          pel8 v;
+#pragma unroll
+          for (int j = 0; j < 8; j++) v[j] = (short)ln[i].m[j];
+          *reinterpret_cast<pel8*>(p + i * TP) = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+
+  // ---- pass 2: horizontal edges.  task = (edge k: y = oy+4+8k, segment s: cols ox+4s .. +3)
+  {
+    const int s = tid & 15, k = tid >> 4;
+    const int y = oy + 4 + 8 * k, x = ox + 4 * s;
+    if (y > 0 && y < h && x >= 0 && x < w)
+    {
+      const int u = (y >> 2) * w4 + (x >> 2);
+      const int e = edgeH[u];
+      if (e & 3)
+      {
+        Seg8 ln[4];
+        short* p = tile + (8 * k) * TP + 4 * s;       // row y-4, col x
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+        {
+          const pel4 v = *reinterpret_cast<const pel4*>(p + j * TP);
+#pragma unroll
+          for (int i = 0; i < 4; i++) ln[i].m[j] = v[i];
+        }
+        luma_segment(ln, e & 3, qpm[u - w4], qpm[u], (e >> 4) & 1, (e >> 5) & 1, cfg);
+#pragma unroll
+        for (int j = 1; j < 7; j++)
+        {
+          pel4 v;
+#pragma unroll
+          for (int i = 0; i < 4; i++) v[i] = (short)ln[i].m[j];
+          *reinterpret_cast<pel4*>(p + j * TP) = v;
+        }
+      }
+    }
+  }
+  __syncthreads();
+  tile_store(tile, Y, stride, w, h, ox, oy, tid, 128);
+}
+
+__device__ __forceinline__ int chroma_tc(int qpP, int qpQ, int qpOff, const vvcgpu_deblock_cfg& c)
+{
+  int qp = ((qpP + qpQ + 1) >> 1) + qpOff;
+  if (qp >= QPMAPSZ) qp -= 6;
+  else if (qp >= 0) qp = c_chromaScale420[qp];
+  return c_tc[clip3(0, MAXQP + TCOFF, qp + TCOFF + (c.tc_offset_div2 << 1))] * (1 << (c.bit_depth_chroma - 8));
+}
+
+// Chroma plane (w,h are CHROMA dimensions).  blockIdx.z selects Cb / Cr.
+__global__ __launch_bounds__(128) void deblock_chroma_kernel(Pel* __restrict__ Cb, Pel* __restrict__ Cr, int stride,
+                                                             int w, int h, int w4 /* luma units per row */,
+                                                             const uint8_t* __restrict__ edgeV,
+                                                             const uint8_t* __restrict__ edgeH,
+                                                             const int8_t* __restrict__ qpm, vvcgpu_deblock_cfg cfg)
+{
+  __shared__ short tile[TS * TP];
+  const int tid = threadIdx.x;
+  const int comp = blockIdx.z;                       // 0 = Cb, 1 = Cr
+  Pel* plane = comp ? Cr : Cb;
+  const int qpOff = comp ? cfg.cr_qp_offset : cfg.cb_qp_offset;
+  const int cmin = cfg.clp_min[1 + comp], cmax = cfg.clp_max[1 + comp];
+  const int ox = blockIdx.x * TS - 4, oy = blockIdx.y * TS - 4;
+  tile_load(tile, plane, stride, w, h, ox, oy, tid, 128);
+  __syncthreads();
+
+  // pass 1: vertical edges at chroma x = ox+4+8k; segments of 2 rows (one luma unit): 8 edges x 32 segments
+  for (int t = tid; t < 256; t += 128)
+  {
+    const int k = t & 7, s = t >> 3;
+    const int x = ox + 4 + 8 * k, y = oy + 2 * s;
+    if (x > 0 && x < w && y >= 0 && y < h)
+    {
+      const int u = (y >> 1) * w4 + (x >> 1);        // luma unit: (2y)/4, (2x)/4
+      const int e = edgeV[u];
+      if (((e >> 2) & 3) > 1)
+      {
+        const int tc = chroma_tc(qpm[u - 1], qpm[u], qpOff, cfg);
+        const bool noP = (e >> 4) & 1, noQ = (e >> 5) & 1;
+        short* p = tile + (2 * s) * TP + 8 * k + 2;  // sample x-2 of row y
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+        {
+          short* q = p + i * TP;
+          const int m2 = q[0], m3 = q[1], m4 = q[2], m5 = q[3];
+          const int delta = clip3(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
+          if (!noP) q[1] = (short)clip3(cmin, cmax, m3 + delta);
+          if (!noQ) q[2] = (short)clip3(cmin, cmax, m4 - delta);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  // pass 2: horizontal edges at chroma y = oy+4+8k; segments of 2 columns: 8 edges x 32 segments
+  for (int t = tid; t < 256; t += 128)
+  {
+    const int s = t & 31, k = t >> 5;
+    const int y = oy + 4 + 8 * k, x = ox + 2 * s;
+    if (y > 0 && y < h && x >= 0 && x < w)
+    {
+      const int u = (y >> 1) * w4 + (x >> 1);
+      const int e = edgeH[u];
+      if (((e >> 2) & 3) > 1)
+      {
+        const int tc = chroma_tc(qpm[u - w4], qpm[u], qpOff, cfg);
+        const bool noP = (e >> 4) & 1, noQ = (e >> 5) & 1;
+        short* p = tile + (8 * k + 2) * TP + 2 * s;  // row y-2, col x
+#pragma unroll
+        for (int i = 0; i < 2; i++)
+        {
+          short* q = p + i;
+          const int m2 = q[0], m3 = q[TP], m4 = q[2 * TP], m5 = q[3 * TP];
+          const int delta = clip3(-tc, tc, ((((m4 - m3) << 2) + m2 - m5 + 4) >> 3));
+          if (!noP) q[TP] = (short)clip3(cmin, cmax, m3 + delta);
+          if (!noQ) q[2 * TP] = (short)clip3(cmin, cmax, m4 - delta);
+        }
+      }
+    }
+  }
+  __syncthreads();
+  tile_store(tile, plane, stride, w, h, ox, oy, tid, 128);
+}
+
+}  // namespace
+
+extern "C" int vvcgpu_deblock(vvc_pel* y, int stride_y, vvc_pel* cb, vvc_pel* cr, int stride_c, int width, int height,
+                              const uint8_t* edge_ver, const uint8_t* edge_hor, const int8_t* qp_luma,
+                              const int8_t* qp_chroma, const vvcgpu_deblock_cfg* cfg_host, void* stream)
+{
+  VVC_CHECK_ARG(y && edge_ver && edge_hor && qp_luma && cfg_host, "deblock: null pointer");
+  VVC_CHECK_ARG(width > 0 && height > 0 && (width & 7) == 0 && (height & 7) == 0,
+                "deblock: width/height must be positive multiples of 8 (got %dx%d)", width, height);
+  VVC_CHECK_ARG(stride_y >= width, "deblock: luma stride %d < width %d", stride_y, width);
+  VVC_CHECK_ARG((cb == nullptr) == (cr == nullptr), "deblock: Cb and Cr must both be given or both be NULL");
+  VVC_CHECK_ARG(!cb || (qp_chroma && stride_c >= width / 2), "deblock: chroma needs qp_chroma and stride >= width/2");
+  const vvcgpu_deblock_cfg cfg = *cfg_host;
+  VVC_CHECK_ARG(cfg.bit_depth_luma >= 8 && cfg.bit_depth_luma <= 10 && cfg.bit_depth_chroma >= 8 &&
+                cfg.bit_depth_chroma <= 10, "deblock: bit depths outside 8..10");
+  hipStream_t st = (hipStream_t)stream;
+  dim3 gl(cdiv(width + 4, TS), cdiv(height + 4, TS));
+  hipLaunchKernelGGL(deblock_luma_kernel, gl, dim3(128), 0, st, y, stride_y, width, height, edge_ver, edge_hor, qp_luma, cfg);
+  VVC_LAUNCH_CHECK();
+  if (cb)
+  {
+    dim3 gc(cdiv(width / 2 + 4, TS), cdiv(height / 2 + 4, TS), 2);
+    hipLaunchKernelGGL(deblock_chroma_kernel, gc, dim3(128), 0, st, cb, cr, stride_c, width / 2, height / 2, width >> 2,
+                       edge_ver, edge_hor, qp_chroma, cfg);
+    VVC_LAUNCH_CHECK();
+  }
+  return VVCGPU_OK;
+}

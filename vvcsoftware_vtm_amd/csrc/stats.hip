@@ -1,0 +1,360 @@
+// stats.hip -- encoder-side statistics kernels for gfx950: SAO class statistics (S2) and ALF covariance (A3).
+//
+// Reference behaviour reproduced (bit-exact integers):
+//   EncSampleAdaptiveOffset::getStatistics/getBlkStats  EncoderLib/EncSampleAdaptiveOffset.cpp:278-330,1122-1490
+//   EncAdaptiveLoopFilter::deriveStatsForFiltering/getBlkStats/calcCovariance  EncoderLib/EncAdaptiveLoopFilter.cpp:1317-1515
+// The reference accumulates the ALF products into doubles; every partial sum is an integer < 2^53, so the
+// int64 sums produced here convert to exactly the same doubles in any summation order.
+#include "common.h"
+
+namespace {
+
+// =====================================================================================================
+// S2: SAO statistics.  One workgroup per CTU; the deblocked tile (+1 halo) is staged once in LDS, each
+// thread walks one column segment with the five classifiers evaluated together, EO class counters live in
+// registers (statically indexed), BO bands in a packed 64-bit LDS histogram.
+// =====================================================================================================
+constexpr int SAO_MAX_CTU = 128;
+
+__global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ org, int ostride,
+                                                        const Pel* __restrict__ rec, int rstride, int w, int h,
+                                                        int ctuW, int ctuH, int wCtu, int boShift,
+                                                        const uint8_t* __restrict__ availMap, int skipR, int skipB,
+                                                        long long* __restrict__ out)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int pitch = ctuW + 2;
+  short* tile = reinterpret_cast<short*>(smem);                                   // (ctuH+2) x pitch
+  const int tileBytes = ((ctuH + 2) * pitch * 2 + 15) & ~15;
+  unsigned long long* bo = reinterpret_cast<unsigned long long*>(smem + tileBytes);   // 32 packed bands
+  int* eo = reinterpret_cast<int*>(smem + tileBytes + 32 * 8);                        // [4][5][2]
+
+  const int tid = threadIdx.x;
+  const int cx = blockIdx.x, cy = blockIdx.y;
+  const int x0 = cx * ctuW, y0 = cy * ctuH;
+  const int width = min(ctuW, w - x0), height = min(ctuH, h - y0);
+
+  for (int i = tid; i < (ctuH + 2) * pitch; i += 256)
+  {
+    const int r = i / pitch, c = i - r * pitch;
+    const int y = min(max(y0 + r - 1, 0), h - 1), x = min(max(x0 + c - 1, 0), w - 1);
+    tile[i] = rec[(size_t)y * rstride + x];
+  }
+  if (tid < 32) bo[tid] = 0ull;
+  if (tid < 40) eo[tid] = 0;
+  __syncthreads();
+
+  const int a = availMap ? availMap[cy * wCtu + cx] : ((cx > 0 ? 1 : 0) | (cy > 0 ? 4 : 0) | (cx > 0 && cy > 0 ? 16 : 0));
+  const bool left = a & 1, above = (a >> 2) & 1, aboveLeft = (a >> 4) & 1;
+  const bool right = x0 + ctuW < w, below = y0 + ctuH < h;
+  const int startXe = left ? 0 : 1, endXe = right ? width - skipR : width - 1;
+  const int endX90 = right ? width - skipR : width;              // also BO
+  const int endY0 = below ? height - skipB : height;             // EO_0 and BO
+  const int endYd = below ? height - skipB : height - 1;         // EO_90/135/45
+  const int startY90 = above ? 0 : 1;
+
+  const int groups = 256 / ctuW;
+  const int rpg = ctuH / groups;
+  const int x = tid % ctuW, g = tid / ctuW;
+  int cnt[4][5], dif[4][5];
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int e = 0; e < 5; e++) { cnt[t][e] = 0; dif[t][e] = 0; }
+
+  if (x < width)
+  {
+    const bool inXe = x >= startXe && x < endXe;
+    const bool inX90 = x < endX90;
+    const short* p = tile + (g * rpg) * pitch + x;        // row y-1, col x-1 (tile origin is (-1,-1))
+    int r0[3], r1[3], r2[3];
+#pragma unroll
+    for (int k = 0; k < 3; k++) { r0[k] = p[k]; r1[k] = p[pitch + k]; }
+    const int yEnd = min((g + 1) * rpg, height);
+    for (int y = g * rpg; y < yEnd; y++)
+    {
+      const short* q = p + (y - g * rpg + 2) * pitch;
+#pragma unroll
+      for (int k = 0; k < 3; k++) r2[k] = q[k];
+      const int c = r1[1];
+      const int d = (int)org[(size_t)(y0 + y) * ostride + x0 + x] - c;
+      const int sl = sgn(c - r1[0]), sr = sgn(c - r1[2]), su = sgn(c - r0[1]), sd = sgn(c - r2[1]);
+      const int sul = sgn(c - r0[0]), sdr = sgn(c - r2[2]), sur = sgn(c - r0[2]), sdl = sgn(c - r2[0]);
+      const int e[4] = { 2 + sl + sr, 2 + su + sd, 2 + sul + sdr, 2 + sur + sdl };
+      bool use[4];
+      use[0] = inXe && y < endY0;
+      use[1] = inX90 && y >= startY90 && y < endYd;
+      use[2] = y == 0 ? (x == 0 ? (aboveLeft && (above ? endXe : 1) > 0) : (above && x < endXe)) : (inXe && y < endYd);
+      use[3] = y == 0 ? (above && inXe) : (inXe && y < endYd);
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+        {
+          const bool hit = use[t] && e[t] == k;
+          cnt[t][k] += hit ? 1 : 0;
+          dif[t][k] += hit ? d : 0;
+        }
+      if (inX90 && y < endY0)
+        atomicAdd(&bo[c >> boShift], (1ull << 32) + (unsigned long long)(d + 1024));
+#pragma unroll
+      for (int k = 0; k < 3; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
+    }
+  }
+  // wave reduction of the 40 EO accumulators, then one LDS atomic per wave and value
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+#pragma unroll
+    for (int k = 0; k < 5; k++)
+    {
+      int c = cnt[t][k], d = dif[t][k];
+#pragma unroll
+      for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); d += __shfl_xor(d, o); }
+      if ((tid & 63) == 0) { atomicAdd(&eo[(t * 5 + k) * 2], d); atomicAdd(&eo[(t * 5 + k) * 2 + 1], c); }
+    }
+  __syncthreads();
+  long long* o = out + (size_t)(cy * wCtu + cx) * 320;
+  for (int i = tid; i < 320; i += 256)
+  {
+    const int t = i >> 6, isCount = (i >> 5) & 1, k = i & 31;
+    long long v = 0;
+    if (t < 4) { if (k < 5) v = eo[(t * 5 + k) * 2 + isCount]; }
+    else
+    {
+      const unsigned long long pk = bo[k];
+      const long long c = (long long)(pk >> 32);
+      v = isCount ? c : (long long)(pk & 0xffffffffull) - 1024 * c;
+    }
+    o[i] = v;
+  }
+}
+
+// =====================================================================================================
+// A3: ALF covariance.  One workgroup per 64x64 tile (256 blocks of 4x4, one per thread): the rec tile with a
+// 3-sample halo is staged in LDS (border replicated), each thread builds the 13 (7) symmetric tap sums of its
+// 16 pixels in the canonical (transposeIdx 0) order and accumulates the upper triangle of E, y and pixAcc in
+// registers with 24-bit integer MADs; the per-class buckets live in LDS (64-bit atomics, indices permuted by
+// the block's transposeIdx) and are flushed to the per-CTU output with 64-bit global atomics.
+// =====================================================================================================
+constexpr int AT = 64, AP = AT + 8, AR = AT + 6;
+
+template <int PITCH>
+__device__ __forceinline__ void load_tile_clamped(short* __restrict__ lds, const Pel* __restrict__ src,
+                                                  int stride, int w, int h, int x0, int y0, int rows,
+                                                  int tid, int nthreads)
+{
+  constexpr int VPR = PITCH / 4;
+  const int nvec = rows * VPR;
+  const bool vec_ok = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 7) == 0);
+  for (int v = tid; v < nvec; v += nthreads)
+  {
+    const int r = v / VPR, c = (v - r * VPR) * 4;
+    int y = y0 + r;
+    y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+    const int x = x0 + c;
+    const Pel* row = src + (size_t)y * stride;
+    pel4 val;
+    if (vec_ok && x >= 0 && x + 3 < w) val = *reinterpret_cast<const pel4*>(row + x);
+    else
+    {
+#pragma unroll
+      for (int k = 0; k < 4; k++) { int xx = x + k; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx); val[k] = row[xx]; }
+    }
+    *reinterpret_cast<pel4*>(lds + r * PITCH + c) = val;
+  }
+}
+
+// canonical tap index of offset (dy,dx), as in alf.hip (AdaptiveLoopFilter.cpp:600-636 == calcCovariance t=0)
+template <bool IS7>
+__device__ __forceinline__ constexpr int tapIndexS(int dy, int dx)
+{
+  if (dy < 0 || (dy == 0 && dx < 0)) { dy = -dy; dx = -dx; }
+  if (IS7)
+  {
+    if (dy == 3) return dx == 0 ? 0 : -1;
+    if (dy == 2) return dx == 1 ? 1 : dx == 0 ? 2 : dx == -1 ? 3 : -1;
+    if (dy == 1) return (dx >= -2 && dx <= 2) ? 6 - dx : -1;
+    return dx <= 3 ? 12 - dx : -1;
+  }
+  else
+  {
+    if (dy == 2) return dx == 0 ? 0 : -1;
+    if (dy == 1) return (dx >= -1 && dx <= 1) ? 2 - dx : -1;
+    if (dy == 0) return dx <= 2 ? 6 - dx : -1;
+    return -1;
+  }
+}
+
+template <bool IS7>
+__global__ __launch_bounds__(256) void alf_stats_kernel(const Pel* __restrict__ org, int ostride,
+                                                        const Pel* __restrict__ rec, int rstride, int w, int h,
+                                                        int ctu, int wCtu, const uint16_t* __restrict__ cls,
+                                                        int nCls, unsigned long long* __restrict__ out)
+{
+  constexpr int N = IS7 ? 13 : 7, R = IS7 ? 3 : 2;
+  constexpr int NT = N * (N + 1) / 2;            // upper triangle
+  constexpr int NB = NT + N + 1;                 // bucket entries: tri(E), y, pixAcc
+  constexpr int RECSZ = N * N + N + 1;
+  __shared__ short tile[AR * AP];
+  __shared__ unsigned long long bucket[25 * NB];
+  const int tid = threadIdx.x;
+  const int tx0 = blockIdx.x * AT, ty0 = blockIdx.y * AT;
+  load_tile_clamped<AP>(tile, rec, rstride, w, h, tx0 - 4, ty0 - 3, AR, tid, 256);
+  for (int i = tid; i < nCls * NB; i += 256) bucket[i] = 0ull;
+  __syncthreads();
+
+  const int bj = tid & 15, bi = tid >> 4;
+  const int bx = tx0 + 4 * bj, by = ty0 + 4 * bi;
+  if (bx < w && by < h)
+  {
+    int A[NT], Y[N], pix = 0;
+#pragma unroll
+    for (int i = 0; i < NT; i++) A[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) Y[i] = 0;
+
+#pragma unroll 1
+    for (int i = 0; i < 4; i++)                  // pixel row by+i (not unrolled: keeps E[4][N] live once)
+    {
+      int E[4][N];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+#pragma unroll
+        for (int k = 0; k < N; k++) E[j][k] = 0;
+      const short* p = tile + (4 * bi + i + 3 - R) * AP + 4 * bj;     // row by+i-R, col bx-4
+#pragma unroll
+      for (int r = 0; r <= 2 * R; r++)
+      {
+        int s[12];
+        const pel4 v0 = *reinterpret_cast<const pel4*>(p + r * AP);
+        const pel4 v1 = *reinterpret_cast<const pel4*>(p + r * AP + 4);
+        const pel4 v2 = *reinterpret_cast<const pel4*>(p + r * AP + 8);
+#pragma unroll
+        for (int k = 0; k < 4; k++) { s[k] = v0[k]; s[4 + k] = v1[k]; s[8 + k] = v2[k]; }
+        const int dy = r - R;
+#pragma unroll
+        for (int dx = -R; dx <= R; dx++)
+        {
+          const int k = tapIndexS<IS7>(dy, dx);
+          if (k < 0) continue;
+#pragma unroll
+          for (int j = 0; j < 4; j++) E[j][k] += s[4 + j + dx];
+        }
+      }
+      const pel4 ov = *reinterpret_cast<const pel4*>(org + (size_t)(by + i) * ostride + bx);
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+        const int yl = (int)ov[j] - (int)p[R * AP + 4 + j];
+        int idx = 0;
+#pragma unroll
+        for (int k = 0; k < N; k++)
+        {
+#pragma unroll
+          for (int l = k; l < N; l++) { A[idx] += __mul24(E[j][k], E[j][l]); idx++; }
+          Y[k] += __mul24(E[j][k], yl);
+        }
+        pix += __mul24(yl, yl);
+      }
+    }
+    // flush into the class bucket with the block's transpose permutation
+    int classIdx = 0, t = 0;
+    if (cls) { const uint16_t c = cls[(size_t)(by >> 2) * (w >> 2) + (bx >> 2)]; classIdx = c & 0xff; t = c >> 8; }
+    unsigned long long perm;                    // nibble k = coefficient index that canonical tap k feeds
+    if (IS7) perm = t == 0 ? 0xCBA9876543210ull : t == 1 ? 0xC62037B518A49ull : t == 2 ? 0xCBA9456781230ull : 0xC62015B734A89ull;
+    else     perm = t == 0 ? 0x6543210ull : t == 1 ? 0x6203514ull : t == 2 ? 0x6541230ull : 0x6201534ull;
+    unsigned long long* b = bucket + classIdx * NB;
+    int idx = 0;
+#pragma unroll
+    for (int k = 0; k < N; k++)
+    {
+      const int ck = (int)((perm >> (4 * k)) & 15);
+#pragma unroll
+      for (int l = k; l < N; l++)
+      {
+        const int cl = (int)((perm >> (4 * l)) & 15);
+        const int lo = min(ck, cl), hi = max(ck, cl);
+        // position of (lo,hi) in the row-major upper triangle
+        const int pos = lo * N - (lo * (lo - 1)) / 2 + (hi - lo);
+        atomicAdd(&b[pos], (unsigned long long)(long long)A[idx]);
+        idx++;
+      }
+      atomicAdd(&b[NT + ck], (unsigned long long)(long long)Y[k]);
+    }
+    atomicAdd(&b[NT + N], (unsigned long long)(long long)pix);
+  }
+  __syncthreads();
+  // flush LDS buckets to the CTU's record (a CTU is covered by several tiles -> global 64-bit atomics)
+  const int ctuIdx = (ty0 / ctu) * wCtu + tx0 / ctu;
+  unsigned long long* o = out + (size_t)ctuIdx * nCls * RECSZ;
+  for (int i = tid; i < nCls * NB; i += 256)
+  {
+    const unsigned long long v = bucket[i];
+    if (v == 0ull) continue;
+    const int c = i / NB, e = i - c * NB;
+    unsigned long long* oc = o + (size_t)c * RECSZ;
+    if (e < NT)
+    {
+      // invert pos -> (lo,hi)
+      int lo = 0, rem = e;
+      while (rem >= N - lo) { rem -= N - lo; lo++; }
+      const int hi = lo + rem;
+      atomicAdd(&oc[lo * N + hi], v);
+      if (hi != lo) atomicAdd(&oc[hi * N + lo], v);
+    }
+    else
+      atomicAdd(&oc[N * N + (e - NT)], v);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vvcgpu_sao_stats(const vvc_pel* org, int org_stride, const vvc_pel* rec, int rec_stride,
+                     int width, int height, int ctu_w, int ctu_h, int bit_depth, const uint8_t* avail,
+                     int skip_lines_r, int skip_lines_b, int64_t* out, void* stream)
+{
+  VVC_CHECK_ARG(org && rec && out, "sao_stats: null pointer");
+  VVC_CHECK_ARG(width > 0 && height > 0 && org_stride >= width && rec_stride >= width, "sao_stats: bad size/stride");
+  VVC_CHECK_ARG(ctu_w >= 16 && ctu_w <= SAO_MAX_CTU && (ctu_w & (ctu_w - 1)) == 0 && ctu_h >= 16 && ctu_h <= SAO_MAX_CTU &&
+                (ctu_h & (ctu_h - 1)) == 0, "sao_stats: CTU %dx%d must be a power of two in 16..128", ctu_w, ctu_h);
+  VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "sao_stats: bit depth %d outside 8..10", bit_depth);
+  VVC_CHECK_ARG(skip_lines_r >= 0 && skip_lines_b >= 0 && skip_lines_r < 16 && skip_lines_b < 16, "sao_stats: bad skip lines");
+  const int wCtu = cdiv(width, ctu_w), hCtu = cdiv(height, ctu_h);
+  const size_t tileBytes = (((size_t)(ctu_h + 2) * (ctu_w + 2) * 2) + 15) & ~(size_t)15;
+  const size_t smem = tileBytes + 32 * 8 + 40 * 4;
+  hipLaunchKernelGGL(sao_stats_kernel, dim3(wCtu, hCtu), dim3(256), smem, (hipStream_t)stream, org, org_stride, rec,
+                     rec_stride, width, height, ctu_w, ctu_h, wCtu, bit_depth - 5, avail, skip_lines_r, skip_lines_b,
+                     reinterpret_cast<long long*>(out));
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+int vvcgpu_alf_stats(const vvc_pel* org, int org_stride, const vvc_pel* rec, int rec_stride,
+                     int width, int height, int ctu_size, const uint16_t* cls, int filter_type,
+                     int64_t* out, void* stream)
+{
+  VVC_CHECK_ARG(org && rec && out, "alf_stats: null pointer");
+  VVC_CHECK_ARG(width > 0 && height > 0 && (width & 3) == 0 && (height & 3) == 0, "alf_stats: size must be a multiple of 4");
+  VVC_CHECK_ARG(org_stride >= width && rec_stride >= width && (org_stride & 3) == 0 && ((uintptr_t)org & 7) == 0,
+                "alf_stats: org needs stride %% 4 == 0 and 8-byte alignment");
+  VVC_CHECK_ARG(ctu_size >= AT ? (ctu_size % AT) == 0 : false, "alf_stats: ctu size %d must be a multiple of %d", ctu_size, AT);
+  VVC_CHECK_ARG(filter_type == 0 || filter_type == 1, "alf_stats: filter_type %d", filter_type);
+  const int nCls = cls ? 25 : 1;
+  const int N = filter_type ? 13 : 7;
+  const int wCtu = cdiv(width, ctu_size), hCtu = cdiv(height, ctu_size);
+  hipStream_t st = (hipStream_t)stream;
+  VVC_HIP(hipMemsetAsync(out, 0, sizeof(int64_t) * (size_t)(N * N + N + 1) * nCls * wCtu * hCtu, st));
+  dim3 grid(cdiv(width, AT), cdiv(height, AT));
+  if (filter_type)
+    hipLaunchKernelGGL(alf_stats_kernel<true>, grid, dim3(256), 0, st, org, org_stride, rec, rec_stride, width, height,
+                       ctu_size, wCtu, cls, nCls, reinterpret_cast<unsigned long long*>(out));
+  else
+    hipLaunchKernelGGL(alf_stats_kernel<false>, grid, dim3(256), 0, st, org, org_stride, rec, rec_stride, width, height,
+                       ctu_size, wCtu, cls, nCls, reinterpret_cast<unsigned long long*>(out));
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+}  // extern "C"

@@ -66,3 +66,57 @@ def sao_apply(src, dst, ctu_w, ctu_h, bit_depth, params_dev, clp=(0, 1023)):
     capi.call("vvcgpu_sao_apply", p, st, q, dt, w, h, ctu_w, ctu_h, bit_depth, capi.ptr(params_dev),
               clp[0], clp[1], _stream())
     return dst
+
+
+# ---- Deblocking (LoopFilter.cpp) ----------------------------------------------------------------
+class DeblockCfg(C.Structure):
+    """vvcgpu_deblock_cfg"""
+    _fields_ = [("bit_depth_luma", C.c_int32), ("bit_depth_chroma", C.c_int32),
+                ("beta_offset_div2", C.c_int32), ("tc_offset_div2", C.c_int32),
+                ("cb_qp_offset", C.c_int32), ("cr_qp_offset", C.c_int32),
+                ("clp_min", C.c_int32 * 3), ("clp_max", C.c_int32 * 3)]
+
+
+def deblock_cfg(bd=10, beta_off=0, tc_off=0, cb_off=0, cr_off=0):
+    mx = (1 << bd) - 1
+    return DeblockCfg(bd, bd, beta_off, tc_off, cb_off, cr_off, (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(mx, mx, mx))
+
+
+def deblock(Y, Cb, Cr, edge_ver, edge_hor, qp_luma, qp_chroma, cfg):
+    """In place.  Maps are uint8/int8 CUDA tensors of shape (H/4, W/4)."""
+    p, st, w, h = _plane(Y)
+    if Cb is not None:
+        pb, sc, _, _ = _plane(Cb)
+        pr, sc2, _, _ = _plane(Cr)
+        assert sc == sc2
+    else:
+        pb = pr = None
+        sc = 0
+    capi.call("vvcgpu_deblock", p, st, pb, pr, sc, w, h, capi.ptr(edge_ver), capi.ptr(edge_hor),
+              capi.ptr(qp_luma), capi.ptr(qp_chroma), C.byref(cfg), _stream())
+
+
+# ---- encoder-side statistics ----------------------------------------------------------------------
+def sao_stats(org, rec, ctu_w, ctu_h, bit_depth, avail=None, skip_r=5, skip_b=4):
+    """S2: returns int64 tensor (nCtu, 5 types, 2 {diff,count}, 32 classes)."""
+    po, so, w, h = _plane(org, "org")
+    pr, sr, w2, h2 = _plane(rec, "rec")
+    assert (w, h) == (w2, h2)
+    n = ((w + ctu_w - 1) // ctu_w) * ((h + ctu_h - 1) // ctu_h)
+    out = torch.empty((n, 5, 2, 32), dtype=torch.int64, device=org.device)
+    capi.call("vvcgpu_sao_stats", po, so, pr, sr, w, h, ctu_w, ctu_h, bit_depth, capi.ptr(avail), skip_r, skip_b,
+              capi.ptr(out), _stream())
+    return out
+
+
+def alf_stats(org, rec, ctu, cls, filter_type):
+    """A3: returns int64 tensor (nCtu, nClasses, N*N+N+1)."""
+    po, so, w, h = _plane(org, "org")
+    pr, sr, w2, h2 = _plane(rec, "rec")
+    assert (w, h) == (w2, h2)
+    n = ((w + ctu - 1) // ctu) * ((h + ctu - 1) // ctu)
+    N = 13 if filter_type else 7
+    ncls = 25 if cls is not None else 1
+    out = torch.empty((n, ncls, N * N + N + 1), dtype=torch.int64, device=org.device)
+    capi.call("vvcgpu_alf_stats", po, so, pr, sr, w, h, ctu, capi.ptr(cls), filter_type, capi.ptr(out), _stream())
+    return out
