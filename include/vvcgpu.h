@@ -136,6 +136,50 @@ int vvcgpu_alf_stats(const vvc_pel* org, int org_stride, const vvc_pel* rec, int
                      int width, int height, int ctu_size, const uint16_t* cls, int filter_type,
                      int64_t* out, void* stream);
 
+/* ---- D1/D2/D3: block distortion, batched  (RdCost::m_afpDistortFunc table, RdCost.h:104; scalar bodies
+ *          xGetSAD* RdCost.cpp:450-1000, xGetHADs :2855-2974 + xCalcHADs* :2205-2853, xGetSSE* :1820-2200;
+ *          SIMD twins x86/RdCostX86.h:215-432, 2292-2436) ------------------------------------------------------
+ * One descriptor per reference call `distFunc(DistParam)`: offsets are in elements from org_base / cur_base
+ * (two device allocations, e.g. the original picture and a reference picture or a fractional-plane buffer).
+ * kind 0 = SAD  (vertical subsampling: rows step 1<<sub_shift, sum <<= sub_shift, RdCost.cpp:466-492)
+ *      1 = HAD  (Hadamard SATD, tile selection of xGetHADs with isQtbt = true; rectangular tiles use the
+ *                reference's double arithmetic (int)(sad / sqrt(128.0) * 2), RdCost.cpp:2561,2698,2771,2850)
+ *      2 = SSE  (sum of squared differences; the chroma distortion weight of getDistPart stays on the host)
+ * out[i] is the Distortion (uint64) of descriptor i.  Bit depth <= 10 (the reference's SIMD precondition). */
+typedef struct vvcgpu_dist_desc {
+  int64_t org_off, cur_off;
+  int32_t org_stride, cur_stride;
+  int16_t w, h;
+  int16_t sub_shift;          /* SAD only */
+  int16_t reserved;
+} vvcgpu_dist_desc;
+int vvcgpu_dist_batch(int kind, const vvc_pel* org_base, const vvc_pel* cur_base, const vvcgpu_dist_desc* descs,
+                      int n, int bit_depth, uint64_t* out, void* stream);
+
+/* ---- D1 (search form): SAD surface of a block over a regular grid of integer positions
+ *          (the distFunc loops of InterSearch::xPatternSearch, InterSearch.cpp:1887-1935, and of the raster stage of
+ *          xTZSearch, :2159-2169, both through xTZSearchHelp/distFunc :249-343) --------------------------------
+ * All blocks of one call share w, h, sub_shift and the position grid  x = dx0 + i*sx (i < nx), y = dy0 + j*sy (j < ny),
+ * relative to (ref_x, ref_y) of the block.  Every probed sample must lie inside the reference plane's allocation
+ * (the reference clips MVs to the padded picture, Mv.cpp:64-80).  org samples may be any int16 (bi-pred refinement
+ * searches on 2*org - otherPred, InterSearch.cpp:1682-1692).
+ * sad_out: nblocks x ny x nx uint32, row-major (may be NULL when only `best` is wanted... it is still used as
+ *          scratch, so it must be provided).
+ * best (optional): per block the argmin of  sad + uint64(lambda * bits(x,y))  in the reference's scan order
+ *          (y outer, x inner, strict '<': InterSearch.cpp:1913-1925) with the MV-bit cost of RdCost.h:172-199.   */
+typedef struct vvcgpu_search_blk { int32_t org_x, org_y, ref_x, ref_y; } vvcgpu_search_blk;
+typedef struct vvcgpu_mvcost {
+  double  lambda;             /* m_motionLambda                         */
+  int32_t pred_hor, pred_ver; /* m_mvPredictor (after setPredictor)     */
+  int32_t cost_scale;         /* m_iCostScale                           */
+  int32_t imv_shift;          /* imvShift                               */
+} vvcgpu_mvcost;
+typedef struct vvcgpu_search_best { int32_t x, y; uint64_t cost; uint64_t sad; } vvcgpu_search_best;
+int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride,
+                      const vvcgpu_search_blk* blocks, int nblocks, int w, int h, int sub_shift,
+                      int dx0, int dy0, int nx, int ny, int sx, int sy, uint32_t* sad_out,
+                      const vvcgpu_mvcost* mvcost_host, vvcgpu_search_best* best, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

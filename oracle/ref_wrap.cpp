@@ -24,6 +24,11 @@ extern "C" {
 
 int vtmref_version(void) { return 21; }
 
+// The reference's global tables (g_aucLog2, transform matrices, scan orders ...) are built by initROM()
+// (CommonLib/Rom.cpp:206-460); EncLib::create / DecLib::create call it once (EncLib.cpp:86).  The kernel wrappers
+// need the same state, so the library builds it when loaded.  initROM is idempotent-guarded here only.
+static struct RomInit { RomInit() { initROM(); } } g_romInit;
+
 // Runs the reference encoder application class exactly as App/EncoderApp/encmain.cpp:79-189 does
 // (create -> parseCfg -> encode -> destroy).  argv[0] is ignored like a program name.
 int vtmref_encode(int argc, char** argv)

@@ -13,6 +13,7 @@
 // reference sources because oracle/Makefile compiles THIS translation unit with g++ -fno-access-control.
 #include "EncoderLib/EncSampleAdaptiveOffset.h"
 #include "EncoderLib/EncAdaptiveLoopFilter.h"
+#include "CommonLib/RdCost.h"
 #include "../include/vvcgpu.h"
 
 // simd: 0 = the reference's scalar functions, 1 = whatever table the reference installs on this CPU
@@ -203,6 +204,40 @@ int vtmref_alf_stats(const Pel* org, int ostride, const Pel* rec, int w, int h, 
     }
   for (auto& c : cov) c.destroy();
   return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Block distortion.  simd = 0: the scalar bodies RdCost::xGetSAD / xGetHADs / xGetSSE (RdCost.cpp:450,2855,1820);
+// simd = 1: the function the reference itself selects from m_afpDistortFunc (setDistParam, RdCost.cpp:204-366; the
+// table holds the SIMD kernels after RdCost::init(), :100-185).  kind 0 SAD, 1 HAD, 2 SSE.
+uint64_t vtmref_dist(int kind, int simd, const Pel* org, int os, const Pel* cur, int cs, int w, int h, int bd, int subShift)
+{
+  static RdCost* rc = nullptr;
+  if (!rc) { rc = new RdCost; rc->setUseQtbt(true); }
+  DistParam dp;
+  CPelBuf ob(org, os, w, h), cb(cur, cs, w, h);
+  if (kind == 2)
+  {
+    dp.isQtbt = true; dp.org = ob; dp.cur = cb; dp.step = 1; dp.bitDepth = bd; dp.compID = COMPONENT_Y;
+    if (!simd) return RdCost::xGetSSE(dp);
+    dp.distFunc = isPowerOf2(w) ? RdCost::m_afpDistortFunc[DF_SSE + g_aucLog2[w]] : RdCost::m_afpDistortFunc[DF_SSE];
+    return dp.distFunc(dp);
+  }
+  rc->setDistParam(dp, ob, cb, bd, COMPONENT_Y, kind == 1);
+  dp.subShift = kind == 0 ? subShift : 0;
+  if (!simd) return kind == 0 ? RdCost::xGetSAD(dp) : RdCost::xGetHADs(dp);
+  return dp.distFunc(dp);
+}
+
+// MV cost: RdCost::getCostOfVectorWithPredictor (RdCost.h:190-194)
+uint64_t vtmref_mvcost(const vvcgpu_mvcost* m, int x, int y)
+{
+  static RdCost* rc = nullptr;
+  if (!rc) rc = new RdCost;
+  rc->setPredictor(Mv(m->pred_hor, m->pred_ver));
+  rc->setCostScale(m->cost_scale);
+  rc->m_motionLambda = m->lambda;
+  return rc->getCostOfVectorWithPredictor(x, y, m->imv_shift);
 }
 
 }  // extern "C"

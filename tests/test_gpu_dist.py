@@ -1,0 +1,116 @@
+"""GPU parity: batched SAD / SATD / SSE and the SAD search surface vs the CPU oracle."""
+import ctypes as C
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oraclelib import oracle, p
+
+pytestmark = pytest.mark.gpu
+
+SIZES = [(w, h) for w in (4, 8, 12, 16, 24, 32, 48, 64, 128) for h in (4, 8, 16, 32, 64, 128)]
+
+
+def dev(a):
+    return torch.from_numpy(a).cuda()
+
+
+def make_descs(rng, planeW, planeH, kind, n_per_size=3):
+    from vvcsoftware_vtm_amd import ops
+    rows = []
+    for (w, h) in SIZES:
+        if kind == ops.HAD and w in (12, 24, 48) and (h % 4 or w % 4):
+            continue
+        for _ in range(n_per_size):
+            ox, oy = int(rng.integers(0, planeW - w)), int(rng.integers(0, planeH - h))
+            cx, cy = int(rng.integers(0, planeW - w)), int(rng.integers(0, planeH - h))
+            ss = 0
+            if kind == ops.SAD:
+                ss = int(rng.integers(0, 4))
+                while (h >> ss) < 2 or h % (1 << ss):
+                    ss -= 1
+                if w == 4 and h == 4:
+                    ss = 0          # reference SIMD quirk for 4x4 with subsampling (RdCostX86.h:331-351), see DESIGN.md
+            rows.append((oy * planeW + ox, cy * planeW + cx, planeW, planeW, w, h, ss, 0))
+    return np.array(rows, dtype=ops.DIST_DESC)
+
+
+@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("bd,data", [(10, "uniform"), (10, "smooth"), (8, "uniform"), (10, "extreme")])
+def test_dist_batch(kind, bd, data):
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(kind * 10 + bd)
+    W, H = 320, 256
+    org = cases.rand_plane(rng, H, W, bd, data)
+    cur = cases.rand_plane(rng, H, W, bd, data)
+    d = make_descs(rng, W, H, kind)
+    want = np.zeros(len(d), np.uint64)
+    oracle().orc_dist_batch(kind, p(org), p(cur), p(d), len(d), p(want))
+    got = ops.dist_batch(kind, dev(org), dev(cur), ops.struct_to_device(d), len(d), bd).cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want)
+
+
+def test_satd_f64_normalisation_boundaries():
+    """rect tiles: (int)(sad / sqrt(128.0) * 2) and sqrt(32.0) must be evaluated as divide-then-multiply in f64.
+    Sweep single-coefficient tiles so that `sad` takes every value in a range (DC-only residual => sad = N*|d|)."""
+    from vvcsoftware_vtm_amd import ops
+    rows, planes_o, planes_c = [], [], []
+    W = 16
+    org = np.zeros((8 * 1024, W), np.int16)
+    cur = np.zeros((8 * 1024, W), np.int16)
+    for v in range(1024):
+        org[8 * v:8 * v + 8, :] = v          # constant difference v over a 16x8 tile -> sad = 128*v ... plus one odd sample
+        org[8 * v, 0] += (v % 7)
+        rows.append((8 * v * W, 8 * v * W, W, W, 16, 8, 0, 0))
+        rows.append((8 * v * W, 8 * v * W, W, W, 8, 4, 0, 0))
+        rows.append((8 * v * W, 8 * v * W, W, W, 4, 8, 0, 0))
+    d = np.array(rows, dtype=ops.DIST_DESC)
+    want = np.zeros(len(d), np.uint64)
+    oracle().orc_dist_batch(1, p(org), p(cur), p(d), len(d), p(want))
+    got = ops.dist_batch(1, dev(org), dev(cur), ops.struct_to_device(d), len(d), 10).cpu().numpy().view(np.uint64)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("w,h,ss", [(16, 16, 1), (32, 32, 1), (64, 64, 1), (8, 8, 0), (4, 8, 0), (12, 16, 1), (128, 128, 0),
+                                    (24, 32, 2), (64, 32, 1)])
+@pytest.mark.parametrize("grid", [(-4, -4, 9, 9, 1, 1), (-20, -15, 9, 7, 5, 5), (-96, -96, 39, 39, 5, 5)])
+def test_sad_search(w, h, ss, grid):
+    from vvcsoftware_vtm_amd import ops
+    dx0, dy0, nx, ny, sx, sy = grid
+    rng = np.random.default_rng(w + h + nx)
+    bd, m = 10, 104
+    PW, PH = 256 + 2 * m, 192 + 2 * m                     # padded reference picture
+    org = cases.rand_plane(rng, 192, 256, bd, "smooth")
+    # bi-pred style pattern: values outside the sample range, incl. negatives (2*org - otherPred)
+    org = (2 * org.astype(np.int32) - cases.rand_plane(rng, 192, 256, bd, "smooth")).astype(np.int16)
+    refp = cases.rand_plane(rng, PH, PW, bd, "smooth")
+    nb = 6
+    blk = np.zeros(nb, ops.SEARCH_BLK)
+    for i in range(nb):
+        x, y = int(rng.integers(0, 256 - w)), int(rng.integers(0, 192 - h))
+        blk[i] = (x, y, m + x + int(rng.integers(-6, 7)), m + y + int(rng.integers(-6, 7)))
+    mv = ops.MvCost(float(rng.uniform(4, 60)), int(rng.integers(-40, 40)), int(rng.integers(-40, 40)), 2, 0)
+    want = np.zeros((nb, ny, nx), np.uint32)
+    wbest = np.zeros(nb, ops.SEARCH_BEST)
+    oracle().orc_sad_search(p(org), 256, p(refp), PW, p(blk), nb, w, h, ss, dx0, dy0, nx, ny, sx, sy, p(want),
+                            C.byref(mv), p(wbest))
+    sad, best = ops.sad_search(dev(org), dev(refp), ops.struct_to_device(blk), nb, w, h, ss, dx0, dy0, nx, ny, sx, sy, mv)
+    assert np.array_equal(sad.cpu().numpy().view(np.uint32), want)
+    gbest = best.cpu().numpy().view(ops.SEARCH_BEST)
+    assert np.array_equal(gbest, wbest)
+
+
+def test_sad_search_tie_rule():
+    """flat content: every position has the same SAD, the MV cost decides; equal costs keep the first in scan order."""
+    from vvcsoftware_vtm_amd import ops
+    org = np.full((64, 64), 500, np.int16)
+    refp = np.full((128, 128), 510, np.int16)
+    blk = np.array([(16, 16, 48, 48)], ops.SEARCH_BLK)
+    mv = ops.MvCost(0.0, 0, 0, 2, 0)                       # lambda 0 -> all costs equal
+    want = np.zeros((1, 9, 9), np.uint32)
+    wbest = np.zeros(1, ops.SEARCH_BEST)
+    oracle().orc_sad_search(p(org), 64, p(refp), 128, p(blk), 1, 16, 16, 0, -4, -4, 9, 9, 1, 1, p(want), C.byref(mv), p(wbest))
+    sad, best = ops.sad_search(dev(org), dev(refp), ops.struct_to_device(blk), 1, 16, 16, 0, -4, -4, 9, 9, 1, 1, mv)
+    gb = best.cpu().numpy().view(ops.SEARCH_BEST)
+    assert gb[0]["x"] == -4 and gb[0]["y"] == -4 and np.array_equal(gb, wbest)

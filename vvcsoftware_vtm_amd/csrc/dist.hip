@@ -1,0 +1,304 @@
+// dist.hip -- block distortion for gfx950: batched SAD / Hadamard-SATD / SSE (D1-D3) and the SAD search surface.
+//
+// Reference behaviour reproduced (bit-exact):
+//   RdCost::xGetSAD*  CommonLib/RdCost.cpp:450-1000   (SIMD twins x86/RdCostX86.h:215-432; no early exit)
+//   RdCost::xGetHADs  :2855-2974, xCalcHADs* :2205-2853 (rect tiles: (int)(sad / sqrt(128.0) * 2) in IEEE f64)
+//   RdCost::xGetSSE*  :1820-2200
+//   RdCost::getCostOfVectorWithPredictor / xGetExpGolombNumberOfBits   CommonLib/RdCost.h:172-199
+//   InterSearch::xPatternSearch scan order and tie rule               EncoderLib/InterSearch.cpp:1887-1935
+//
+// Design
+//   * batch kernel: one 64-lane wave per descriptor.  SATD maps one tile ROW to one lane: the horizontal
+//     Walsh-Hadamard runs in registers, the vertical one across lanes with xor-shuffles (no LDS), tiles of a
+//     block are spread over the lane groups of the wave, partial sums are combined with wave shuffles.
+//   * search kernel: one workgroup per (block, strip of search rows).  The reference window of the strip is
+//     staged ONCE in LDS as packed 16-bit pairs in two alignments (even / odd start) so that every position reads
+//     aligned dwords; samples are biased by 0x8000 so v_sad_u16 (2 abs-diffs per lane-op) is exact for any int16;
+//     one lane = one search position, the org pairs are LDS broadcasts.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Hadamard tile: TW columns in registers, TH rows across TH consecutive lanes.
+template <int TW, int TH>
+__device__ __forceinline__ unsigned long long satd_tiles(const Pel* org, int os, const Pel* cur, int cs, int w, int h, int lane)
+{
+  constexpr int GROUPS = 64 / TH;
+  const int row = lane % TH, grp = lane / TH;
+  const int tilesX = w / TW, nTiles = tilesX * (h / TH);
+  unsigned long long total = 0;
+  for (int t0 = 0; t0 < nTiles; t0 += GROUPS)
+  {
+    const int t = t0 + grp;
+    const bool active = t < nTiles;
+    int v[TW];
+    if (active)
+    {
+      const int ty = t / tilesX, tx = t - ty * tilesX;
+      const Pel* o = org + (size_t)(ty * TH + row) * os + tx * TW;
+      const Pel* c = cur + (size_t)(ty * TH + row) * cs + tx * TW;
+#pragma unroll
+      for (int x = 0; x < TW; x++) v[x] = (int)o[x] - (int)c[x];
+    }
+    else
+    {
+#pragma unroll
+      for (int x = 0; x < TW; x++) v[x] = 0;
+    }
+    // horizontal WHT in registers
+#pragma unroll
+    for (int len = 1; len < TW; len <<= 1)
+#pragma unroll
+      for (int i = 0; i < TW; i += 2 * len)
+#pragma unroll
+        for (int j = i; j < i + len; j++) { const int a = v[j], b = v[j + len]; v[j] = a + b; v[j + len] = a - b; }
+    // vertical WHT across the TH lanes of the group
+#pragma unroll
+    for (int len = 1; len < TH; len <<= 1)
+    {
+      const bool upper = row & len;
+#pragma unroll
+      for (int x = 0; x < TW; x++)
+      {
+        const int p = __shfl_xor(v[x], len);
+        v[x] = upper ? p - v[x] : v[x] + p;
+      }
+    }
+    int s = 0;
+#pragma unroll
+    for (int x = 0; x < TW; x++) s += abs(v[x]);
+#pragma unroll
+    for (int len = 1; len < TH; len <<= 1) s += __shfl_xor(s, len);
+    if (active && row == 0)
+    {
+      unsigned long long n;
+      if (TW == 2) n = (unsigned long long)s;
+      else if (TW == 4 && TH == 4) n = (unsigned long long)((s + 1) >> 1);
+      else if (TW == 8 && TH == 8) n = (unsigned long long)((s + 2) >> 2);
+      else if (TW * TH == 128) n = (unsigned long long)(int)((double)s / sqrt(16.0 * 8) * 2);   // RdCost.cpp:2561,2698
+      else n = (unsigned long long)(int)((double)s / sqrt(4.0 * 8) * 2);                        // :2771,2850
+      total += n;
+    }
+  }
+  return wave_sum_u64(total);
+}
+
+__global__ __launch_bounds__(256) void dist_batch_kernel(int kind, const Pel* __restrict__ orgBase,
+                                                         const Pel* __restrict__ curBase,
+                                                         const vvcgpu_dist_desc* __restrict__ descs, int n,
+                                                         unsigned long long* __restrict__ out)
+{
+  const int lane = threadIdx.x & 63;
+  const int di = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (di >= n) return;                                  // whole wave exits together
+  const vvcgpu_dist_desc d = descs[di];
+  const Pel* org = orgBase + d.org_off;
+  const Pel* cur = curBase + d.cur_off;
+  const int w = d.w, h = d.h, os = d.org_stride, cs = d.cur_stride;
+  unsigned long long res;
+  if (kind == 1)
+  {
+    if (w > h && (h & 7) == 0 && (w & 15) == 0)      res = satd_tiles<16, 8>(org, os, cur, cs, w, h, lane);
+    else if (w < h && (w & 7) == 0 && (h & 15) == 0) res = satd_tiles<8, 16>(org, os, cur, cs, w, h, lane);
+    else if (w > h && (h & 3) == 0 && (w & 7) == 0)  res = satd_tiles<8, 4>(org, os, cur, cs, w, h, lane);
+    else if (w < h && (w & 3) == 0 && (h & 7) == 0)  res = satd_tiles<4, 8>(org, os, cur, cs, w, h, lane);
+    else if ((h & 7) == 0 && (w & 7) == 0)           res = satd_tiles<8, 8>(org, os, cur, cs, w, h, lane);
+    else if ((h & 3) == 0 && (w & 3) == 0)           res = satd_tiles<4, 4>(org, os, cur, cs, w, h, lane);
+    else                                             res = satd_tiles<2, 2>(org, os, cur, cs, w, h, lane);
+  }
+  else
+  {
+    const int ss = kind == 0 ? d.sub_shift : 0;
+    const int rows = h >> ss;
+    unsigned long long acc = 0;
+    for (int idx = lane; idx < rows * w; idx += 64)
+    {
+      const int r = idx / w, x = idx - r * w;
+      const int df = (int)org[(size_t)(r << ss) * os + x] - (int)cur[(size_t)(r << ss) * cs + x];
+      acc += kind == 0 ? (unsigned)abs(df) : (unsigned)(df * df);
+    }
+    res = wave_sum_u64(acc) << ss;
+  }
+  if (lane == 0) out[di] = res;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// SAD search surface
+__global__ __launch_bounds__(256) void sad_search_kernel(const Pel* __restrict__ org, int os,
+                                                         const Pel* __restrict__ ref, int rs,
+                                                         const vvcgpu_search_blk* __restrict__ blocks, int w, int h,
+                                                         int subShift, int dx0, int dy0, int nx, int ny, int sx, int sy,
+                                                         int rowsPerStrip, int colsPerStrip, int pitchDw, unsigned* __restrict__ out)
+{
+  extern __shared__ __align__(16) unsigned lds[];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x, j0 = blockIdx.y * rowsPerStrip;
+  const int nj = min(rowsPerStrip, ny - j0);
+  const int i0 = blockIdx.z * colsPerStrip;
+  const int ni = min(colsPerStrip, nx - i0);
+  const vvcgpu_search_blk blk = blocks[b];
+  const int hs = h >> subShift, wp = w >> 1;
+  const int winRows = (nj - 1) * sy + h;
+  const int Ww = (ni - 1) * sx + w;
+  unsigned* orgL = lds;                              // hs x wp pairs
+  unsigned* refE = lds + ((hs * wp + 3) & ~3);       // winRows x pitchDw
+  unsigned* refO = refE + winRows * pitchDw;
+
+  const Pel* o = org + (size_t)blk.org_y * os + blk.org_x;
+  for (int i = tid; i < hs * wp; i += 256)
+  {
+    const int r = i / wp, k = i - r * wp;
+    const Pel* q = o + (size_t)(r << subShift) * os + 2 * k;
+    orgL[i] = ((unsigned)(unsigned short)q[0] | ((unsigned)(unsigned short)q[1] << 16)) ^ 0x80008000u;
+  }
+  const Pel* win = ref + (size_t)(blk.ref_y + dy0 + j0 * sy) * rs + blk.ref_x + dx0 + i0 * sx;
+  for (int i = tid; i < winRows * pitchDw; i += 256)
+  {
+    const int r = i / pitchDw, k = i - r * pitchDw;
+    const Pel* row = win + (size_t)r * rs;
+    const int x0 = min(2 * k, Ww - 1), x1 = min(2 * k + 1, Ww - 1), x2 = min(2 * k + 2, Ww - 1);
+    const unsigned p0 = (unsigned short)row[x0], p1 = (unsigned short)row[x1], p2 = (unsigned short)row[x2];
+    refE[i] = (p0 | (p1 << 16)) ^ 0x80008000u;
+    refO[i] = (p1 | (p2 << 16)) ^ 0x80008000u;
+  }
+  __syncthreads();
+
+  for (int p = tid; p < nj * ni; p += 256)
+  {
+    const int jj = p / ni, i = p - jj * ni;
+    const int cx = i * sx;
+    const unsigned* base = ((cx & 1) ? refO : refE) + (cx >> 1) + (jj * sy) * pitchDw;
+    unsigned acc = 0;
+    for (int r = 0; r < hs; r++)
+    {
+      const unsigned* rp = base + (r << subShift) * pitchDw;
+      const unsigned* op = orgL + r * wp;
+      int k = 0;
+      if ((wp & 3) == 0)                       // 16-byte aligned org rows -> 128-bit broadcast reads
+      for (; k + 4 <= wp; k += 4)
+      {
+        const uint4 ov = *reinterpret_cast<const uint4*>(op + k);        // broadcast read (same address in all lanes)
+        acc = __builtin_amdgcn_sad_u16(ov.x, rp[k], acc);
+        acc = __builtin_amdgcn_sad_u16(ov.y, rp[k + 1], acc);
+        acc = __builtin_amdgcn_sad_u16(ov.z, rp[k + 2], acc);
+        acc = __builtin_amdgcn_sad_u16(ov.w, rp[k + 3], acc);
+      }
+      for (; k < wp; k++) acc = __builtin_amdgcn_sad_u16(op[k], rp[k], acc);
+    }
+    out[((size_t)b * ny + j0 + jj) * nx + i0 + i] = acc << subShift;
+  }
+}
+
+__device__ __forceinline__ unsigned expgolomb_bits(int v)        // RdCost.h:172-184
+{
+  unsigned len = 1, t = (v <= 0) ? ((unsigned)(-v) << 1) + 1 : (unsigned)(v << 1);
+  while (t > 128u) { len += 14; t >>= 7; }
+  return len + ((31 - __clz((int)t)) << 1);
+}
+
+__global__ __launch_bounds__(256) void sad_best_kernel(const unsigned* __restrict__ sad, int nblocks, int dx0, int dy0,
+                                                       int nx, int ny, int sx, int sy, vvcgpu_mvcost mv,
+                                                       vvcgpu_search_best* __restrict__ best)
+{
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= nblocks) return;
+  const unsigned* s = sad + (size_t)b * nx * ny;
+  unsigned long long bc = ~0ull;
+  int bi = 0x7fffffff;
+  for (int idx = lane; idx < nx * ny; idx += 64)
+  {
+    const int j = idx / nx, i = idx - j * nx;
+    const int x = dx0 + i * sx, y = dy0 + j * sy;
+    const unsigned bits = expgolomb_bits(((x << mv.cost_scale) - mv.pred_hor) >> mv.imv_shift) +
+                          expgolomb_bits(((y << mv.cost_scale) - mv.pred_ver) >> mv.imv_shift);
+    const unsigned long long cost = (unsigned long long)s[idx] + (unsigned long long)(mv.lambda * (double)bits);
+    if (cost < bc) { bc = cost; bi = idx; }          // idx increases per lane -> first minimum kept
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1)
+  {
+    const unsigned long long oc = __shfl_xor(bc, o);
+    const int oi = __shfl_xor(bi, o);
+    if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
+  }
+  if (lane == 0)
+  {
+    const int j = bi / nx, i = bi - j * nx;
+    vvcgpu_search_best r;
+    r.x = dx0 + i * sx; r.y = dy0 + j * sy; r.cost = bc; r.sad = s[bi];
+    best[b] = r;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vvcgpu_dist_batch(int kind, const vvc_pel* org_base, const vvc_pel* cur_base, const vvcgpu_dist_desc* descs,
+                      int n, int bit_depth, uint64_t* out, void* stream)
+{
+  VVC_CHECK_ARG(kind >= 0 && kind <= 2, "dist_batch: kind %d", kind);
+  VVC_CHECK_ARG(n >= 0, "dist_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(org_base && cur_base && descs && out, "dist_batch: null pointer");
+  if (bit_depth > 10) { vvcgpu_set_error("dist_batch: bit depth %d > 10 is outside the precondition", bit_depth); return VVCGPU_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(dist_batch_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, kind, org_base, cur_base,
+                     descs, n, reinterpret_cast<unsigned long long*>(out));
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride,
+                      const vvcgpu_search_blk* blocks, int nblocks, int w, int h, int sub_shift,
+                      int dx0, int dy0, int nx, int ny, int sx, int sy, uint32_t* sad_out,
+                      const vvcgpu_mvcost* mvcost_host, vvcgpu_search_best* best, void* stream)
+{
+  VVC_CHECK_ARG(nblocks >= 0, "sad_search: nblocks %d", nblocks);
+  if (nblocks == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(org && ref && blocks && sad_out, "sad_search: null pointer");
+  VVC_CHECK_ARG(w >= 4 && w <= 128 && (w & 1) == 0 && h >= 4 && h <= 128, "sad_search: block %dx%d unsupported", w, h);
+  VVC_CHECK_ARG(sub_shift >= 0 && sub_shift <= 4 && (h >> sub_shift) >= 1 && (h & ((1 << sub_shift) - 1)) == 0,
+                "sad_search: sub_shift %d incompatible with height %d", sub_shift, h);
+  VVC_CHECK_ARG(nx > 0 && ny > 0 && sx > 0 && sy > 0, "sad_search: bad position grid");
+  VVC_CHECK_ARG((best == nullptr) == (mvcost_host == nullptr), "sad_search: best and mvcost must be given together");
+  const int hs = h >> sub_shift;
+  const size_t orgDw = ((size_t)hs * (w / 2) + 3) & ~(size_t)3;
+  const size_t budget = 60 * 1024;
+  // split the position grid into strips (rows first, then columns) until the staged window fits the LDS budget
+  int rowsPerStrip = ny, colsPerStrip = nx;
+  auto lds_bytes = [&](int rps, int cps) {
+    const size_t winRows = (size_t)(rps - 1) * sy + h;
+    const size_t pitch = (size_t)((cps - 1) * sx + w + 2) / 2 + 1;
+    return (orgDw + 2 * winRows * pitch) * 4;
+  };
+  while (lds_bytes(rowsPerStrip, colsPerStrip) > budget && rowsPerStrip > 1) rowsPerStrip = (rowsPerStrip + 1) / 2;
+  while (lds_bytes(rowsPerStrip, colsPerStrip) > budget && colsPerStrip > 1) colsPerStrip = (colsPerStrip + 1) / 2;
+  const int pitchDw = ((colsPerStrip - 1) * sx + w + 2) / 2 + 1;   // pairs per row (+1: rows do not alias banks exactly)
+  const size_t smem = lds_bytes(rowsPerStrip, colsPerStrip);
+  VVC_CHECK_ARG(smem <= 160 * 1024, "sad_search: a single position's window (%d x %d) does not fit LDS", w, h);
+  hipStream_t st = (hipStream_t)stream;
+  if (smem > 64 * 1024)
+    VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  dim3 grid(nblocks, cdiv(ny, rowsPerStrip), cdiv(nx, colsPerStrip));
+  hipLaunchKernelGGL(sad_search_kernel, grid, dim3(256), smem, st, org, org_stride, ref, ref_stride, blocks, w, h,
+                     sub_shift, dx0, dy0, nx, ny, sx, sy, rowsPerStrip, colsPerStrip, pitchDw, sad_out);
+  VVC_LAUNCH_CHECK();
+  if (best)
+  {
+    hipLaunchKernelGGL(sad_best_kernel, dim3(cdiv(nblocks, 4)), dim3(256), 0, st, sad_out, nblocks, dx0, dy0, nx, ny, sx,
+                       sy, *mvcost_host, best);
+    VVC_LAUNCH_CHECK();
+  }
+  return VVCGPU_OK;
+}
+
+}  // extern "C"

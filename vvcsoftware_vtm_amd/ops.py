@@ -120,3 +120,46 @@ def alf_stats(org, rec, ctu, cls, filter_type):
     out = torch.empty((n, ncls, N * N + N + 1), dtype=torch.int64, device=org.device)
     capi.call("vvcgpu_alf_stats", po, so, pr, sr, w, h, ctu, capi.ptr(cls), filter_type, capi.ptr(out), _stream())
     return out
+
+
+# ---- block distortion (RdCost) ---------------------------------------------------------------------
+DIST_DESC = np.dtype([("org_off", "<i8"), ("cur_off", "<i8"), ("org_stride", "<i4"), ("cur_stride", "<i4"),
+                      ("w", "<i2"), ("h", "<i2"), ("sub_shift", "<i2"), ("reserved", "<i2")])
+SEARCH_BLK = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4")])
+SEARCH_BEST = np.dtype([("x", "<i4"), ("y", "<i4"), ("cost", "<u8"), ("sad", "<u8")])
+SAD, HAD, SSE = 0, 1, 2
+
+
+class MvCost(C.Structure):
+    """vvcgpu_mvcost"""
+    _fields_ = [("lambda_", C.c_double), ("pred_hor", C.c_int32), ("pred_ver", C.c_int32),
+                ("cost_scale", C.c_int32), ("imv_shift", C.c_int32)]
+
+
+def struct_to_device(arr, device="cuda"):
+    return torch.from_numpy(arr.view(np.uint8).reshape(-1).copy()).to(device)
+
+
+def dist_batch(kind, org_base, cur_base, descs_dev, n, bit_depth=10):
+    """D1-D3: org_base / cur_base are int16 CUDA tensors (any shape, offsets are in elements from element 0)."""
+    out = torch.empty(n, dtype=torch.int64, device=org_base.device)
+    capi.call("vvcgpu_dist_batch", kind, capi.ptr(org_base), capi.ptr(cur_base), capi.ptr(descs_dev), n, bit_depth,
+              capi.ptr(out), _stream())
+    return out
+
+
+def sad_search(org, ref, blocks_dev, nblocks, w, h, sub_shift, dx0, dy0, nx, ny, sx, sy, mvcost=None):
+    """D1 search form.  org/ref: 2-D int16 planes (ref may be a view into a padded buffer; positions are relative to
+    the view's origin and may be negative as long as they stay inside the allocation).  Returns (sad[nblocks,ny,nx]
+    int32 tensor, best uint8 tensor or None)."""
+    po, so, _, _ = _plane(org, "org")
+    pr, sr, _, _ = _plane(ref, "ref")
+    sad = torch.empty((nblocks, ny, nx), dtype=torch.int32, device=org.device)
+    best = None
+    mv = None
+    if mvcost is not None:
+        best = torch.empty(nblocks * SEARCH_BEST.itemsize, dtype=torch.uint8, device=org.device)
+        mv = C.byref(mvcost)
+    capi.call("vvcgpu_sad_search", po, so, pr, sr, capi.ptr(blocks_dev), nblocks, w, h, sub_shift, dx0, dy0, nx, ny,
+              sx, sy, capi.ptr(sad), mv, capi.ptr(best), _stream())
+    return sad, best
