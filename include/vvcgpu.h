@@ -180,6 +180,82 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
                       int dx0, int dy0, int nx, int ny, int sx, int sy, uint32_t* sad_out,
                       const vvcgpu_mvcost* mvcost_host, vvcgpu_search_best* best, void* stream);
 
+/* ---- I1: interpolation filter table slots, batched  (InterpolationFilter::m_filterHor/m_filterVer[N][isFirst][isLast]
+ *          and m_filterCopy[isFirst][isLast], InterpolationFilter.h:84-86; bodies InterpolationFilter.cpp:205-379;
+ *          SIMD twins x86/InterpolationFilterX86.h:195-1125) ------------------------------------------------------
+ * One descriptor per reference call.  taps = 8, 4 or 2 (filter) or 0 (filterCopy, coeff ignored).  src_off addresses
+ * the first OUTPUT-aligned sample exactly as the reference's `src` argument does (the kernel steps back taps/2-1). */
+typedef struct vvcgpu_if_desc {
+  int64_t src_off, dst_off;           /* elements from src_base / dst_base */
+  int32_t src_stride, dst_stride;
+  int16_t w, h;
+  int8_t  taps, is_vertical, is_first, is_last;
+  int16_t coeff[8];
+  int16_t reserved[2];
+} vvcgpu_if_desc;
+int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_desc* descs, int n,
+                    int bit_depth, int clp_min, int clp_max, void* stream);
+
+/* ---- I3 (+B1): motion compensation of prediction blocks, batched  (InterPrediction::xPredInterBlk,
+ *          InterPrediction.cpp:480-547, uni: rndRes = true; bi: both lists with rndRes = false followed by
+ *          PelBuf::addAvg, :743-760 / Buffer.cpp:114-151).  Affine (xPredAffineBlk :550-722) is the same call with
+ *          one descriptor per 4x4 (2x2 chroma) sub-block and the sub-block MVs derived on the host. -----------------
+ * ref*_off: element offset (from ref0_base / ref1_base) of the block position displaced by the INTEGER part of the MV
+ *           (pu pos + (mv >> shift)); frac_x/frac_y in 1/16 (luma) or 1/32 (chroma) sample units as computed at
+ *           :497-504; is_luma selects the 8-tap table m_lumaFilter[16][8] or the 4-tap m_chromaFilter[32][4].
+ * bi = 0: dst = clipped uni-prediction from ref0.   bi = 1: dst = addAvg(pred(ref0), pred(ref1)).
+ * bi = 2: dst = the unrounded 14-bit intermediate of ref0 (what motionCompensation leaves in m_acYuvPred). */
+typedef struct vvcgpu_mc_desc {
+  int64_t ref0_off, ref1_off, dst_off;
+  int32_t ref0_stride, ref1_stride, dst_stride;
+  int16_t w, h;
+  int8_t  frac_x0, frac_y0, frac_x1, frac_y1;
+  int8_t  is_luma, bi;
+  int16_t reserved;
+} vvcgpu_mc_desc;
+int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base,
+                    const vvcgpu_mc_desc* descs, int n, int bit_depth, int clp_min, int clp_max, void* stream);
+
+/* ---- B1-B4: PelBuffer element-wise operations, batched  (g_pelBufOP table, Buffer.h:57-73: addAvg4/8, reco4/8,
+ *          linTf4/8; cores Buffer.cpp:50-94; plus AreaBuf::subtract Buffer.h:321-339, removeHighFreq :389-416,
+ *          copyClip Buffer.cpp:197-222) --------------------------------------------------------------------------
+ * op: 0 addAvg   dst = clip((s0 + s1 + offset) >> shift)
+ *     1 reco     dst = clip(s0 + s1)                      (dst may alias s0, DecCu.cpp:188)
+ *     2 linTf    dst = (scale*s0 >> shift) + offset, clipped when clip != 0   (shift < 0 shifts left)
+ *     3 subtract dst = s0 - s1
+ *     4 removeHighFreq  dst = 2*s0 - s1, clipped when clip != 0
+ *     5 copyClip dst = clip(s0)                                                                           */
+typedef struct vvcgpu_pelop_desc {
+  int64_t src0_off, src1_off, dst_off;
+  int32_t src0_stride, src1_stride, dst_stride;
+  int16_t w, h;
+} vvcgpu_pelop_desc;
+typedef struct vvcgpu_pelop_cfg { int32_t scale, shift, offset, clip, clp_min, clp_max; } vvcgpu_pelop_cfg;
+int vvcgpu_pelop_batch(int op, const vvc_pel* src0_base, const vvc_pel* src1_base, vvc_pel* dst_base,
+                       const vvcgpu_pelop_desc* descs, int n, const vvcgpu_pelop_cfg* cfg_host, void* stream);
+
+/* ---- T1/T2/T3: 2-D separable transforms, batched  (free functions xTrMxN_EMT / xITrMxN_EMT, TrQuant.cpp:138-310, as
+ *          called by TrQuant::xT / xIT :694-791 through the fastFwdTrans/fastInvTrans tables :72-84; transform skip
+ *          xTransformSkip / xITransformSkip :795-847, 1112-1163) ------------------------------------------------------
+ * tr_hor / tr_ver: 0 DCT-II (sizes 2..64), 1 DCT-VIII, 2 DST-VII (sizes 4..32) (TransType, TypeDef.h:402-410);
+ * tr_hor = 3 selects transform skip (tr_ver ignored).  Coefficients are W x H int32, contiguous (stride W), as the
+ * reference's CoeffBuf.  Zero-out as with useQTBT/m_rectTUs: columns/rows >= 32 are not computed and written as 0
+ * (forward, TrQuant.cpp:157-162) / not read (inverse, :755-759).  maxLog2TrDynamicRange is 15 (no extended precision).
+ * The integer matrices are the reference's run-time generated tables shipped as golden data (csrc/tr_tables.inc).   */
+typedef struct vvcgpu_tr_desc {
+  int64_t resi_off, coeff_off;          /* elements from resi_base (Pel) / coeff_base (TCoeff) */
+  int32_t resi_stride;
+  int16_t w, h;
+  int8_t  tr_hor, tr_ver;
+  int16_t reserved;
+} vvcgpu_tr_desc;
+int vvcgpu_tr_fwd_batch(const vvc_pel* resi_base, vvc_coef* coeff_base, const vvcgpu_tr_desc* descs, int n,
+                        int bit_depth, void* stream);
+int vvcgpu_tr_inv_batch(const vvc_coef* coeff_base, vvc_pel* resi_base, const vvcgpu_tr_desc* descs, int n,
+                        int bit_depth, void* stream);
+/* The shipped matrix [type][log2(N)-1] as N x N int16 (host copy; for the shim's table check against initROM()). */
+const int16_t* vvcgpu_tr_matrix_host(int type, int n);
+
 #ifdef __cplusplus
 }
 #endif

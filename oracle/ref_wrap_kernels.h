@@ -14,10 +14,21 @@
 #include "EncoderLib/EncSampleAdaptiveOffset.h"
 #include "EncoderLib/EncAdaptiveLoopFilter.h"
 #include "CommonLib/RdCost.h"
+#include "CommonLib/InterpolationFilter.h"
+#include "CommonLib/TrQuant.h"
+#include "CommonLib/TrQuant_EMT.h"
 #include "../include/vvcgpu.h"
 
 // simd: 0 = the reference's scalar functions, 1 = whatever table the reference installs on this CPU
 // (InitX86.cpp:58-170; AVX2 on the build/bench hosts).
+// free functions / tables of TrQuant.cpp (C++ linkage; signatures as compiled: HEVC_USE_4x4_DSTVII off, INTRA67_3MPM on, see nm of TrQuant.o)
+extern FwdTrans* fastFwdTrans[NUM_TRANS_TYPE][g_numTransformMatrixSizes];
+extern InvTrans* fastInvTrans[NUM_TRANS_TYPE][g_numTransformMatrixSizes];
+void xTrMxN_EMT(const int bitDepth, const Pel* residual, size_t stride, TCoeff* coeff, int iWidth, int iHeight,
+                const int maxLog2TrDynamicRange, const uint8_t ucMode, const uint8_t ucTrIdx, const bool useQTBT);
+void xITrMxN_EMT(const int bitDepth, const TCoeff* coeff, Pel* residual, size_t stride, int iWidth, int iHeight,
+                 uint32_t uiSkipWidth, uint32_t uiSkipHeight, const int maxLog2TrDynamicRange, uint8_t ucMode, uint8_t ucTrIdx);
+
 static ClpRng mkClp(int mn, int mx, int bd) { ClpRng c; c.min = mn; c.max = mx; c.bd = bd; c.n = 0; return c; }
 
 extern "C" {
@@ -238,6 +249,124 @@ uint64_t vtmref_mvcost(const vvcgpu_mvcost* m, int x, int y)
   rc->setCostScale(m->cost_scale);
   rc->m_motionLambda = m->lambda;
   return rc->getCostOfVectorWithPredictor(x, y, m->imv_shift);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Interpolation filter table slots (InterpolationFilter.h:84-86).  simd = 0: the scalar templates installed by the
+// constructor (InterpolationFilter.cpp:144-181); simd = 1: after initInterpolationFilter(true) (InitX86.cpp:59).
+static InterpolationFilter* getIF(int simd)
+{
+  static InterpolationFilter* f[2] = { nullptr, nullptr };
+  if (!f[simd]) { f[simd] = new InterpolationFilter; if (simd) f[simd]->initInterpolationFilter(true); }
+  return f[simd];
+}
+void vtmref_if_call(int simd, int N, int isVertical, int isFirst, int isLast, const Pel* src, int sstride, Pel* dst,
+                    int dstride, int w, int h, const int16_t* coeff, int bd, int clpMin, int clpMax)
+{
+  InterpolationFilter* f = getIF(simd);
+  ClpRng clp = mkClp(clpMin, clpMax, bd);
+  if (N == 0) { f->m_filterCopy[isFirst][isLast](clp, src, sstride, dst, dstride, w, h); return; }
+  const int idx = N == 8 ? 0 : N == 4 ? 1 : 2;
+  if (isVertical) f->m_filterVer[idx][isFirst][isLast](clp, src, sstride, dst, dstride, w, h, coeff);
+  else            f->m_filterHor[idx][isFirst][isLast](clp, src, sstride, dst, dstride, w, h, coeff);
+}
+
+// Prediction block: the three branches of InterPrediction::xPredInterBlk (InterPrediction.cpp:529-546) entered through the
+// reference's public InterpolationFilter::filterHor/filterVer (InterpolationFilter.cpp:472-545).  frac in 1/16 (luma) or
+// 1/32 (chroma 4:2:0) units; rndRes = !bi.
+void vtmref_pred_blk(int simd, const Pel* ref, int rs, Pel* dst, int ds, int w, int h, int xFrac, int yFrac, int isLuma,
+                     int rndRes, int bd, int clpMin, int clpMax)
+{
+  InterpolationFilter* f = getIF(simd);
+  ClpRng clp = mkClp(clpMin, clpMax, bd);
+  const ComponentID compID = isLuma ? COMPONENT_Y : COMPONENT_Cb;
+  const ChromaFormat chFmt = CHROMA_420;
+  if (yFrac == 0) f->filterHor(compID, ref, rs, dst, ds, w, h, xFrac, rndRes, chFmt, clp);
+  else if (xFrac == 0) f->filterVer(compID, ref, rs, dst, ds, w, h, yFrac, true, rndRes, chFmt, clp);
+  else
+  {
+    const int vFilterSize = isLuma ? NTAPS_LUMA : NTAPS_CHROMA;
+    std::vector<Pel> tmp((size_t)w * (h + vFilterSize - 1));
+    f->filterHor(compID, ref - ((vFilterSize >> 1) - 1) * rs, rs, tmp.data(), w, w, h + vFilterSize - 1, xFrac, false, chFmt, clp);
+    f->filterVer(compID, tmp.data() + ((vFilterSize >> 1) - 1) * w, w, dst, ds, w, h, yFrac, false, rndRes, chFmt, clp);
+  }
+}
+
+// PelBufferOps table (Buffer.h:57-73).  op 0 addAvg, 1 reco, 2 linTf; the 4/8 variant is chosen by width as
+// AreaBuf::addAvg/reconstruct/linearTransform do (Buffer.cpp:129-136, 237-244, 272-279).
+void vtmref_pelop(int simd, int op, const Pel* s0, int st0, const Pel* s1, int st1, Pel* dst, int dstStride, int w, int h,
+                  int scale, int shift, int offset, int clip, int bd, int clpMin, int clpMax)
+{
+  static PelBufferOps* ops[2] = { nullptr, nullptr };
+  if (!ops[simd]) { ops[simd] = new PelBufferOps; if (simd) ops[simd]->initPelBufOpsX86(); }
+  PelBufferOps& o = *ops[simd];
+  ClpRng clp = mkClp(clpMin, clpMax, bd);
+  const bool w8 = (w & 7) == 0;
+  if (op == 0) (w8 ? o.addAvg8 : o.addAvg4)(s0, st0, s1, st1, dst, dstStride, w, h, shift, offset, clp);
+  else if (op == 1) (w8 ? o.reco8 : o.reco4)(s0, st0, s1, st1, dst, dstStride, w, h, clp);
+  else (w8 ? o.linTf8 : o.linTf4)(s0, st0, dst, dstStride, w, h, scale, shift, offset, clp, clip);
+}
+
+// ---------------------------------------------------------------------------------------------
+// Transforms.  The 2-D entry points are the reference's free functions xTrMxN_EMT / xITrMxN_EMT (TrQuant.cpp:138-310),
+// i.e. exactly what TrQuant::xT / xIT call (:694-791).  trHor/trVer: 0 DCT2, 1 DCT8, 2 DST7 (TransType, TypeDef.h:402-410);
+// the (ucMode, ucTrIdx) pair that selects them is rebuilt as the reference's tables define it (g_aiTrSubsetInter, Rom.cpp:484).
+static int emtIdx(int trHor, int trVer, uint8_t& mode, uint8_t& idx)
+{
+  if (trHor == DCT2 && trVer == DCT2) { mode = INTER_MODE_IDX; idx = DCT2_EMT; return 0; }
+  if (trHor == DCT2 || trVer == DCT2) return -1;
+  mode = INTER_MODE_IDX;                       // g_aiTrSubsetInter = { DCT8, DST7 }: hor = [idx & 1], ver = [idx >> 1]
+  idx = (uint8_t)((trHor == DST7 ? 1 : 0) | ((trVer == DST7 ? 1 : 0) << 1));
+  return 0;
+}
+int vtmref_fwd_tr2d(int bd, const Pel* resi, int stride, TCoeff* coeff, int w, int h, int trHor, int trVer)
+{
+  uint8_t mode, idx;
+  if (emtIdx(trHor, trVer, mode, idx)) return -1;
+  xTrMxN_EMT(bd, resi, stride, coeff, w, h, 15, mode, idx, true);
+  return 0;
+}
+int vtmref_inv_tr2d(int bd, const TCoeff* coeff, Pel* resi, int stride, int w, int h, int trHor, int trVer)
+{
+  uint8_t mode, idx;
+  if (emtIdx(trHor, trVer, mode, idx)) return -1;
+  const int skipW = w > JVET_C0024_ZERO_OUT_TH ? w - JVET_C0024_ZERO_OUT_TH : 0;     // xIT, m_rectTUs branch (TrQuant.cpp:755-759)
+  const int skipH = h > JVET_C0024_ZERO_OUT_TH ? h - JVET_C0024_ZERO_OUT_TH : 0;
+  xITrMxN_EMT(bd, coeff, resi, stride, w, h, skipW, skipH, 15, mode, idx);
+  return 0;
+}
+// Effective 1-D matrices of the reference's fast transforms, obtained by pushing 2*identity through
+// fastFwdTrans / fastInvTrans with shift 1 (so the rounding returns the integer matrix entry exactly).
+// out: N x N int32, out[j*N + k] = weight of input sample k in output coefficient j (forward) /
+//      weight of coefficient j in output sample k (inverse).  Returns -1 when the slot is empty.
+int vtmref_tr_matrix(int type, int log2n, int inverse, int32_t* out)
+{
+  const int N = 1 << log2n;
+  std::vector<TCoeff> src((size_t)N * N, 0), dst((size_t)N * N, 0);
+  if (!inverse)
+  {
+    if (!fastFwdTrans[type][log2n - 1]) return -1;
+    for (int i = 0; i < N; i++) src[i * N + i] = 2;
+    fastFwdTrans[type][log2n - 1](src.data(), dst.data(), 1, N, 0, 0);
+    for (int j = 0; j < N; j++) for (int i = 0; i < N; i++) out[j * N + i] = dst[j * N + i];
+  }
+  else
+  {
+    if (!fastInvTrans[type][log2n - 1]) return -1;
+    for (int i = 0; i < N; i++) src[i * N + i] = 2;
+    fastInvTrans[type][log2n - 1](src.data(), dst.data(), 1, N, 0, 0, -(1 << 30), (1 << 30));
+    for (int i = 0; i < N; i++) for (int j = 0; j < N; j++) out[i * N + j] = dst[i * N + j];
+  }
+  return 0;
+}
+// raw generated tables g_aiTr{2..64}[type] (Rom.cpp:245-299)
+int vtmref_rom_matrix(int type, int log2n, int32_t* out)
+{
+  const int N = 1 << log2n;
+  const TMatrixCoeff* t = log2n == 1 ? g_aiTr2[type][0] : log2n == 2 ? g_aiTr4[type][0] : log2n == 3 ? g_aiTr8[type][0]
+                        : log2n == 4 ? g_aiTr16[type][0] : log2n == 5 ? g_aiTr32[type][0] : g_aiTr64[type][0];
+  for (int i = 0; i < N * N; i++) out[i] = t[i];
+  return 0;
 }
 
 }  // extern "C"

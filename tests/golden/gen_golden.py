@@ -1,0 +1,203 @@
+#!/usr/bin/env python3
+"""Generates tests/golden/*.npz: seeded inputs + the outputs of the COMPILED REFERENCE (oracle/_ref/libvtmref.so, built
+from /root/reference by oracle/Makefile) for every hot-path row.  Fixtures are data only (inputs, parameters, expected
+outputs).  Run in the build container; the fixtures travel with the repo and pin the CPU oracle (tests/test_oracle_golden.py)
+and, through it, the HIP kernels."""
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import cases  # noqa: E402
+from oraclelib import ref, p, SAO_DTYPE  # noqa: E402
+
+R = ref()
+R.vtmref_dist.restype = C.c_uint64
+R.vtmref_mvcost.restype = C.c_uint64
+
+
+def save(name, **kw):
+    path = os.path.join(HERE, name + ".npz")
+    np.savez_compressed(path, **kw)
+    print(name, os.path.getsize(path), "bytes")
+
+
+def gen_alf():
+    rng = np.random.default_rng(1001)
+    out = {}
+    for ci, (w, h, ctu, bd, kind) in enumerate([(136, 72, 64, 10, "smooth"), (64, 64, 32, 8, "uniform"), (128, 64, 128, 10, "uniform")]):
+        Y, Cb, Cr = (cases.rand_plane(rng, h, w, bd, kind), cases.rand_plane(rng, h // 2, w // 2, bd, kind),
+                     cases.rand_plane(rng, h // 2, w // 2, bd, kind))
+        lc, cc = cases.alf_coeffs(rng)
+        nx, ny = cases.n_ctus(w, h, ctu)
+        en = [rng.integers(0, 2, nx * ny).astype(np.uint8) for _ in range(3)]
+        en[0][0] = 1
+        for ft in (0, 1):
+            dY, dCb, dCr = Y.copy(), Cb.copy(), Cr.copy()
+            cls = np.zeros((h // 4, w // 4), np.uint16)
+            R.vtmref_alf_picture(1, p(Y), p(Cb), p(Cr), p(dY), p(dCb), p(dCr), w, h, ctu, bd, ft, p(lc), p(cc), p(en[0]), p(en[1]),
+                                 p(en[2]), p(cls))
+            k = "c%d_f%d_" % (ci, ft)
+            out.update({k + "dY": dY, k + "dCb": dCb, k + "dCr": dCr, k + "cls": cls})
+        # classification for the whole picture (all CTUs on)
+        cls = np.zeros((h // 4, w // 4), np.uint16)
+        dY, dCb, dCr = Y.copy(), Cb.copy(), Cr.copy()
+        R.vtmref_alf_picture(0, p(Y), p(Cb), p(Cr), p(dY), p(dCb), p(dCr), w, h, ctu, bd, 1, p(lc), p(cc), None, None, None, p(cls))
+        k = "c%d_" % ci
+        out.update({k + "Y": Y, k + "Cb": Cb, k + "Cr": Cr, k + "lc": lc, k + "cc": cc, k + "enY": en[0], k + "enCb": en[1],
+                    k + "enCr": en[2], k + "cls_all": cls, k + "meta": np.array([w, h, ctu, bd])})
+        # statistics (scalar reference path; exact integers)
+        org = cases.rand_plane(rng, h, w, bd, kind)
+        if ctu >= 64:
+            for ft in (0, 1):
+                N = 13 if ft else 7
+                st = np.zeros((nx * ny, 25, N * N + N + 1), np.int64)
+                R.vtmref_alf_stats(p(org), w, p(Y), w, h, ctu, p(cls), ft, p(st))
+                out[k + "stats_f%d" % ft] = st
+            out[k + "org"] = org
+    save("alf", **out)
+
+
+def gen_sao():
+    rng = np.random.default_rng(1002)
+    out = {}
+    for ci, (w, h, cw, bd, kind, full) in enumerate([(136, 72, 64, 10, "flat", True), (96, 72, 32, 8, "uniform", False),
+                                                     (130, 70, 64, 10, "extreme", False)]):
+        mx = (1 << bd) - 1
+        Y = cases.rand_plane(rng, h, w, bd, kind)
+        prm = cases.sao_params(rng, w, h, cw, cw, full)
+        d = Y.copy()
+        R.vtmref_sao_apply(p(Y), w, p(d), w, w, h, cw, cw, bd, p(prm), 0, mx)
+        org = cases.rand_plane(rng, h, w, bd, kind)
+        nx, ny = cases.n_ctus(w, h, cw)
+        st = np.zeros((nx * ny, 5, 2, 32), np.int64)
+        R.vtmref_sao_stats(0, p(org), w, p(Y), w, w, h, cw, cw, bd, None, 5, 4, p(st))
+        k = "c%d_" % ci
+        out.update({k + "Y": Y, k + "prm": prm.view(np.uint8), k + "out": d, k + "org": org, k + "stats": st,
+                    k + "meta": np.array([w, h, cw, bd])})
+    save("sao", **out)
+
+
+def gen_dist():
+    rng = np.random.default_rng(1003)
+    rows = []
+    W, H = 160, 144
+    out = {}
+    for bd in (8, 10):
+        org = cases.rand_plane(rng, H, W, bd, "smooth")
+        cur = cases.rand_plane(rng, H, W, bd, "smooth")
+        out["org%d" % bd], out["cur%d" % bd] = org, cur
+        for w in (4, 8, 12, 16, 24, 32, 48, 64, 128):
+            for h in (4, 8, 16, 32, 64, 128):
+                ox, oy, cx, cy = (int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1)),
+                                  int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1)))
+                po = C.c_void_p(org.ctypes.data + 2 * (oy * W + ox))
+                pc = C.c_void_p(cur.ctypes.data + 2 * (cy * W + cx))
+                for ss in range(0, 4):
+                    if (h >> ss) < 2 or (w == 4 and h == 4 and ss):
+                        continue
+                    rows.append((bd, 0, ox, oy, cx, cy, w, h, ss, R.vtmref_dist(0, 1, po, W, pc, W, w, h, bd, ss)))
+                rows.append((bd, 1, ox, oy, cx, cy, w, h, 0, R.vtmref_dist(1, 1, po, W, pc, W, w, h, bd, 0)))
+                rows.append((bd, 2, ox, oy, cx, cy, w, h, 0, R.vtmref_dist(2, 1, po, W, pc, W, w, h, bd, 0)))
+    out["rows"] = np.array(rows, dtype=np.int64)
+
+    class MV(C.Structure):
+        _fields_ = [("l", C.c_double), ("ph", C.c_int32), ("pv", C.c_int32), ("cs", C.c_int32), ("imv", C.c_int32)]
+    mvrows = []
+    for _ in range(300):
+        m = MV(float(rng.uniform(0.5, 200)), int(rng.integers(-2000, 2000)), int(rng.integers(-2000, 2000)),
+               int(rng.integers(0, 3)), int(rng.integers(0, 3)))
+        x, y = int(rng.integers(-500, 500)), int(rng.integers(-500, 500))
+        mvrows.append((m.l, m.ph, m.pv, m.cs, m.imv, x, y, R.vtmref_mvcost(C.byref(m), x, y)))
+    out["mvcost"] = np.array(mvrows, dtype=np.float64)
+    save("dist", **out)
+
+
+def gen_interp():
+    rng = np.random.default_rng(1004)
+    O_luma = np.array([[0, 0, 0, 64, 0, 0, 0, 0], [0, 1, -3, 63, 4, -2, 1, 0], [-1, 2, -5, 62, 8, -3, 1, 0], [-1, 3, -8, 60, 13, -4, 1, 0],
+                       [-1, 4, -10, 58, 17, -5, 1, 0], [-1, 4, -11, 52, 26, -8, 3, -1], [-1, 3, -9, 47, 31, -10, 4, -1],
+                       [-1, 4, -11, 45, 34, -10, 4, -1], [-1, 4, -11, 40, 40, -11, 4, -1]], np.int16)
+    out = {}
+    W, H, M = 96, 80, 8
+    for bd in (8, 10):
+        mx = (1 << bd) - 1
+        ref_ = cases.rand_plane(rng, H, W, bd, "smooth")
+        out["ref%d" % bd] = ref_
+        rows, outs = [], []
+        for (w, h) in [(4, 4), (8, 8), (16, 8), (12, 16), (32, 32), (17, 9)]:
+            for luma in (1, 0):
+                nf = 16 if luma else 32
+                for (fx, fy) in [(0, 0), (5 % nf, 0), (0, 9 % nf), (3, 7), (nf - 1, nf - 3)]:
+                    for rnd in (0, 1):
+                        x, y = int(rng.integers(M, W - w - M)), int(rng.integers(M, H - h - M))
+                        d = np.zeros((h, w), np.int16)
+                        R.vtmref_pred_blk(1, C.c_void_p(ref_.ctypes.data + 2 * (y * W + x)), W, p(d), w, w, h, fx, fy, luma, rnd, bd, 0, mx)
+                        rows.append((x, y, w, h, luma, fx, fy, rnd, len(outs)))
+                        outs.append(d.reshape(-1))
+        out["pred_rows%d" % bd] = np.array(rows, np.int32)
+        out["pred_out%d" % bd] = np.concatenate(outs)
+        out["pred_off%d" % bd] = np.cumsum([0] + [o.size for o in outs]).astype(np.int64)
+        # table slots incl. second-stage inputs (14-bit intermediates)
+        inter = rng.integers(-8192, 8192 + mx * 16, (H, W)).astype(np.int16)
+        out["inter%d" % bd] = inter
+        rows, outs = [], []
+        for (w, h) in [(4, 4), (8, 8), (24, 8), (17, 9)]:
+            for N in (0, 8, 4, 2):
+                for isV in (0, 1):
+                    for isF in (0, 1):
+                        for isL in (0, 1):
+                            if N and not isV and not isF:
+                                continue
+                            cf = np.zeros(8, np.int16)
+                            if N == 8:
+                                cf[:] = O_luma[int(rng.integers(1, 9))]
+                            elif N == 4:
+                                cf[:4] = [-4, 36, 36, -4]
+                            elif N == 2:
+                                cf[:2] = [40, 24]
+                            src = ref_ if isF else inter
+                            x, y = int(rng.integers(M, W - w - M)), int(rng.integers(M, H - h - M))
+                            d = np.zeros((h, w), np.int16)
+                            R.vtmref_if_call(1, N, isV, isF, isL, C.c_void_p(src.ctypes.data + 2 * (y * W + x)), W, p(d), w, w, h, p(cf), bd, 0, mx)
+                            rows.append([x, y, w, h, N, isV, isF, isL] + list(cf))
+                            outs.append(d.reshape(-1))
+        out["if_rows%d" % bd] = np.array(rows, np.int32)
+        out["if_out%d" % bd] = np.concatenate(outs)
+    save("interp", **out)
+
+
+def gen_transform():
+    rng = np.random.default_rng(1005)
+    out = {}
+    for bd in (8, 10):
+        mx = (1 << bd) - 1
+        rows, resis, coefs, invs = [], [], [], []
+        for w in (2, 4, 8, 16, 32, 64):
+            for h in (2, 4, 8, 16, 32, 64):
+                for (th, tv) in [(0, 0), (1, 1), (1, 2), (2, 1), (2, 2)]:
+                    if th and (w < 4 or h < 4 or w > 32 or h > 32):
+                        continue
+                    if w * h > 1024 and (th, tv) not in [(0, 0), (2, 2)]:
+                        continue
+                    r = rng.integers(-mx, mx + 1, (h, w)).astype(np.int16)
+                    c = np.zeros((h, w), np.int32)
+                    R.vtmref_fwd_tr2d(bd, p(r), w, p(c), w, h, th, tv)
+                    q = ((c >> 4) << 4).astype(np.int32)
+                    ri = np.zeros((h, w), np.int16)
+                    R.vtmref_inv_tr2d(bd, p(q), p(ri), w, w, h, th, tv)
+                    rows.append((w, h, th, tv))
+                    resis.append(r.reshape(-1)); coefs.append(c.reshape(-1)); invs.append(ri.reshape(-1))
+        out["rows%d" % bd] = np.array(rows, np.int32)
+        out["resi%d" % bd] = np.concatenate(resis)
+        out["coef%d" % bd] = np.concatenate(coefs)
+        out["inv%d" % bd] = np.concatenate(invs)
+    save("transform", **out)
+
+
+if __name__ == "__main__":
+    gen_alf(); gen_sao(); gen_dist(); gen_interp(); gen_transform()

@@ -1,0 +1,138 @@
+"""GPU parity: interpolation filter slots, MC prediction blocks (uni / bi / intermediate) and PelBuffer ops vs the oracle."""
+import ctypes as C
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oraclelib import oracle, p
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(a).cuda()
+
+
+def _coeff(rng, N):
+    O = oracle()
+    O.orc_luma_filter.restype = C.POINTER(C.c_int16 * 8)
+    O.orc_chroma_filter.restype = C.POINTER(C.c_int16 * 4)
+    if N == 8:
+        return list(O.orc_luma_filter(int(rng.integers(1, 16))).contents)
+    if N == 4:
+        return list(O.orc_chroma_filter(int(rng.integers(1, 32))).contents) + [0] * 4
+    if N == 2:
+        f = int(rng.integers(1, 63))
+        return [64 - f, f, 0, 0, 0, 0, 0, 0]
+    return [0] * 8
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("first", [0, 1])
+def test_if_batch(bd, first):
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(bd + first)
+    mx = (1 << bd) - 1
+    W, H, M = 400, 300, 8
+    if first:
+        src = cases.rand_plane(rng, H, W, bd, "uniform")
+    else:
+        src = rng.integers(-8192, 8192 + mx * 16, (H, W)).astype(np.int16)       # 14-bit intermediates
+    rows = []
+    doff = 0
+    for (w, h) in [(4, 4), (8, 8), (12, 16), (16, 16), (24, 8), (64, 64), (129, 17), (2, 2), (17, 9), (128, 32), (65, 72)]:
+        for N in (0, 8, 4, 2):
+            for isV in (0, 1):
+                for isL in (0, 1):
+                    if N and not isV and not first:
+                        continue
+                    x, y = int(rng.integers(M, W - w - M)), int(rng.integers(M, H - h - M))
+                    rows.append((y * W + x, doff, W, w + 1, w, h, N, isV, first, isL, _coeff(rng, N), [0, 0]))
+                    doff += (w + 1) * h
+    d = np.array(rows, dtype=ops.IF_DESC)
+    want = np.full(doff, -5, np.int16)
+    oracle().orc_if_batch(p(src), p(want), p(d), len(d), bd, 0, mx)
+    got = torch.full((doff,), -5, dtype=torch.int16, device="cuda")
+    ops.if_batch(dev(src), got, ops.struct_to_device(d), len(d), bd, (0, mx))
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("kind", ["smooth", "extreme"])
+def test_mc_batch(bd, kind):
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(bd)
+    mx = (1 << bd) - 1
+    W, H, M = 384, 256, 8
+    r0 = cases.rand_plane(rng, H, W, bd, kind)
+    r1 = cases.rand_plane(rng, H, W, bd, kind)
+    rows = []
+    doff = 0
+    sizes = [(4, 4), (8, 8), (8, 4), (16, 16), (12, 16), (32, 8), (24, 24), (64, 64), (128, 128), (2, 2), (4, 8), (48, 64)]
+    for (w, h) in sizes:
+        for luma in (1, 0):
+            nf = 16 if luma else 32
+            fracs = [(0, 0), (int(rng.integers(1, nf)), 0), (0, int(rng.integers(1, nf)))] + \
+                    [(int(rng.integers(1, nf)), int(rng.integers(1, nf))) for _ in range(2)]
+            for (fx, fy) in fracs:
+                for bi in (0, 1, 2):
+                    x0, y0 = int(rng.integers(M, W - w - M)), int(rng.integers(M, H - h - M))
+                    x1, y1 = int(rng.integers(M, W - w - M)), int(rng.integers(M, H - h - M))
+                    fx1, fy1 = int(rng.integers(0, nf)), int(rng.integers(0, nf))
+                    rows.append((y0 * W + x0, y1 * W + x1, doff, W, W, w, w, h, fx, fy, fx1, fy1, luma, bi, 0))
+                    doff += w * h
+    d = np.array(rows, dtype=ops.MC_DESC)
+    want = np.full(doff, -5, np.int16)
+    oracle().orc_mc_batch(p(r0), p(r1), p(want), p(d), len(d), bd, 0, mx)
+    got = torch.full((doff,), -5, dtype=torch.int16, device="cuda")
+    ops.mc_batch(dev(r0), dev(r1), got, ops.struct_to_device(d), len(d), bd, (0, mx))
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+@pytest.mark.parametrize("op", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("bd", [8, 10])
+def test_pelop_batch(op, bd):
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(op * 3 + bd)
+    mx = (1 << bd) - 1
+    W, H = 256, 160
+    if op == 0:
+        s0 = rng.integers(-8192, 8192 + mx * 16, (H, W)).astype(np.int16)
+        s1 = rng.integers(-8192, 8192 + mx * 16, (H, W)).astype(np.int16)
+        sh = max(2, 14 - bd) + 1
+        cfg = ops.PelopCfg(0, sh, (1 << (sh - 1)) + 2 * 8192, 1, 0, mx)
+    else:
+        s0 = cases.rand_plane(rng, H, W, bd)
+        s1 = rng.integers(-mx, mx + 1, (H, W)).astype(np.int16)
+        cfg = ops.PelopCfg(int(rng.integers(-40, 40)), int(rng.integers(0, 7)), int(rng.integers(-100, 100)), int(op % 2), 0, mx)
+    rows = []
+    doff = 0
+    for (w, h) in [(4, 4), (8, 8), (12, 8), (16, 4), (64, 64), (20, 12), (128, 128), (2, 6)]:
+        for _ in range(3):
+            x0, y0 = int(rng.integers(0, W - w)), int(rng.integers(0, H - h))
+            x1, y1 = int(rng.integers(0, W - w)), int(rng.integers(0, H - h))
+            rows.append((y0 * W + x0, y1 * W + x1, doff, W, W, w + 2, w, h))
+            doff += (w + 2) * h
+    d = np.array(rows, dtype=ops.PELOP_DESC)
+    want = np.full(doff, -5, np.int16)
+    oracle().orc_pelop_batch(op, p(s0), p(s1), p(want), p(d), len(d), C.byref(cfg))
+    got = torch.full((doff,), -5, dtype=torch.int16, device="cuda")
+    ops.pelop_batch(op, dev(s0), dev(s1), got, ops.struct_to_device(d), len(d), cfg)
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
+def test_reco_in_place_alias():
+    """reco with dst aliasing src0 (DecCu.cpp:188)."""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(1)
+    W, H = 128, 64
+    pred = cases.rand_plane(rng, H, W, 10)
+    resi = rng.integers(-600, 600, (H, W)).astype(np.int16)
+    d = np.array([(0, 0, 0, W, W, W, W, H)], dtype=ops.PELOP_DESC)
+    cfg = ops.PelopCfg(0, 0, 0, 1, 0, 1023)
+    want = pred.copy()
+    oracle().orc_pelop_batch(1, p(pred), p(resi), p(want), p(d), 1, C.byref(cfg))
+    g = dev(pred)
+    ops.pelop_batch(1, g, dev(resi), g, ops.struct_to_device(d), 1, cfg)
+    assert np.array_equal(g.cpu().numpy(), want)

@@ -1,0 +1,281 @@
+// interp.hip -- DCTIF interpolation (I1), motion compensation of prediction blocks (I3, incl. bi-pred average B1)
+//               and the PelBuffer element-wise operations (B1-B4) for gfx950.
+//
+// Reference behaviour reproduced (bit-exact, bit depth <= 10):
+//   InterpolationFilter::filter<N,isVertical,isFirst,isLast>   CommonLib/InterpolationFilter.cpp:290-379
+//   InterpolationFilter::filterCopy<isFirst,isLast>            :205-264
+//   InterPrediction::xPredInterBlk                             CommonLib/InterPrediction.cpp:480-547
+//   AreaBuf<Pel>::addAvg / reconstruct / linearTransform       CommonLib/Buffer.cpp:114-151, 225-293 (+ cores :50-94)
+//   AreaBuf::subtract / removeHighFreq / copyClip              CommonLib/Buffer.h:321-339, 389-416; Buffer.cpp:197-222
+//   `Pel val = (sum + offset) >> shift` narrows to int16 BEFORE the clip (InterpolationFilter.cpp:368).
+//
+// Design: one 64-lane wave per descriptor.  MC works on 16x16 sub-tiles: the (16+7)^2 reference window is staged once
+// in LDS, the horizontal pass writes the 14-bit intermediate to LDS (never to HBM -- the reference's m_filteredBlockTmp),
+// the vertical pass and, for bi-prediction, the second list and the average stay in registers.
+#include "common.h"
+
+namespace {
+
+__constant__ short c_lumaFilter[16][8] = {
+  {  0, 0,   0, 64,  0,   0,  0,  0 }, {  0, 1,  -3, 63,  4,  -2,  1,  0 }, { -1, 2,  -5, 62,  8,  -3,  1,  0 },
+  { -1, 3,  -8, 60, 13,  -4,  1,  0 }, { -1, 4, -10, 58, 17,  -5,  1,  0 }, { -1, 4, -11, 52, 26,  -8,  3, -1 },
+  { -1, 3,  -9, 47, 31, -10,  4, -1 }, { -1, 4, -11, 45, 34, -10,  4, -1 }, { -1, 4, -11, 40, 40, -11,  4, -1 },
+  { -1, 4, -10, 34, 45, -11,  4, -1 }, { -1, 4, -10, 31, 47,  -9,  3, -1 }, { -1, 3,  -8, 26, 52, -11,  4, -1 },
+  {  0, 1,  -5, 17, 58, -10,  4, -1 }, {  0, 1,  -4, 13, 60,  -8,  3, -1 }, {  0, 1,  -3,  8, 62,  -5,  2, -1 },
+  {  0, 1,  -2,  4, 63,  -3,  1,  0 } };
+__constant__ short c_chromaFilter[32][4] = {
+  {  0, 64,  0,  0 }, { -1, 63,  2,  0 }, { -2, 62,  4,  0 }, { -2, 60,  7, -1 }, { -2, 58, 10, -2 }, { -3, 57, 12, -2 },
+  { -4, 56, 14, -2 }, { -4, 55, 15, -2 }, { -4, 54, 16, -2 }, { -5, 53, 18, -2 }, { -6, 52, 20, -2 }, { -6, 49, 24, -3 },
+  { -6, 46, 28, -4 }, { -5, 44, 29, -4 }, { -4, 42, 30, -4 }, { -4, 39, 33, -4 }, { -4, 36, 36, -4 }, { -4, 33, 39, -4 },
+  { -4, 30, 42, -4 }, { -4, 29, 44, -5 }, { -4, 28, 46, -6 }, { -3, 24, 49, -6 }, { -2, 20, 52, -6 }, { -2, 18, 53, -5 },
+  { -2, 16, 54, -4 }, { -2, 15, 55, -4 }, { -2, 14, 56, -4 }, { -2, 12, 57, -3 }, { -2, 10, 58, -2 }, { -1,  7, 60, -2 },
+  {  0,  4, 62, -2 }, {  0,  2, 63, -1 } };
+
+constexpr int IF_INTERNAL_PREC = 14, IF_FILTER_PREC = 6, IF_INTERNAL_OFFS = 1 << 13;
+
+struct IfMode { int shift, offset; };
+__device__ __forceinline__ IfMode if_mode(bool isFirst, bool isLast, int bd)
+{
+  const int headRoom = max(2, IF_INTERNAL_PREC - bd);
+  IfMode m;
+  m.shift = IF_FILTER_PREC;
+  if (isLast) { m.shift += isFirst ? 0 : headRoom; m.offset = (1 << (m.shift - 1)) + (isFirst ? 0 : IF_INTERNAL_OFFS << IF_FILTER_PREC); }
+  else        { m.shift -= isFirst ? headRoom : 0; m.offset = isFirst ? -(IF_INTERNAL_OFFS << m.shift) : 0; }
+  return m;
+}
+__device__ __forceinline__ int if_copy(int s, bool isFirst, bool isLast, int bd, int cmin, int cmax)
+{
+  const int shift = max(2, IF_INTERNAL_PREC - bd);
+  if (isFirst == isLast) return s;
+  if (isFirst) return (short)((short)(s << shift) - (short)IF_INTERNAL_OFFS);
+  return clip3(cmin, cmax, (short)((s + IF_INTERNAL_OFFS + (1 << (shift - 1))) >> shift));
+}
+
+// ------------------------------------------------------------------------------------------------ I1
+__global__ __launch_bounds__(256) void if_batch_kernel(const Pel* __restrict__ srcBase, Pel* __restrict__ dstBase,
+                                                       const vvcgpu_if_desc* __restrict__ descs, int n, int bd,
+                                                       int cmin, int cmax)
+{
+  const int lane = threadIdx.x & 63;
+  const int di = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (di >= n) return;
+  const vvcgpu_if_desc d = descs[di];
+  const Pel* src = srcBase + d.src_off;
+  Pel* dst = dstBase + d.dst_off;
+  const int N = d.taps;
+  if (N == 0)
+  {
+    for (int i = lane; i < d.w * d.h; i += 64)
+    {
+      const int y = i / d.w, x = i - y * d.w;
+      dst[(size_t)y * d.dst_stride + x] = (short)if_copy(src[(size_t)y * d.src_stride + x], d.is_first, d.is_last, bd, cmin, cmax);
+    }
+    return;
+  }
+  const int cStride = d.is_vertical ? d.src_stride : 1;
+  src -= (N / 2 - 1) * cStride;
+  const IfMode m = if_mode(d.is_first, d.is_last, bd);
+  int c[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) c[k] = k < N ? d.coeff[k] : 0;
+  for (int i = lane; i < d.w * d.h; i += 64)
+  {
+    const int y = i / d.w, x = i - y * d.w;
+    const Pel* s = src + (size_t)y * d.src_stride + x;
+    int sum = 0;
+#pragma unroll
+    for (int k = 0; k < 8; k++) if (k < N) sum += s[k * cStride] * c[k];
+    int val = (short)((sum + m.offset) >> m.shift);
+    if (d.is_last) val = clip3(cmin, cmax, val);
+    dst[(size_t)y * d.dst_stride + x] = (short)val;
+  }
+}
+
+// ------------------------------------------------------------------------------------------------ I3
+constexpr int ST = 16;                 // sub-tile
+constexpr int WP = ST + 8;             // window pitch (samples)
+constexpr int WR = ST + 7;             // window rows
+
+__global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
+                                                      Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs,
+                                                      int bd, int cmin, int cmax)
+{
+  __shared__ short win[WR * WP];
+  __shared__ short tmp[WR * ST];
+  const int lane = threadIdx.x;
+  const vvcgpu_mc_desc d = descs[blockIdx.x];
+  const int N = d.is_luma ? 8 : 4, half = N / 2 - 1;
+  const bool rndRes = d.bi == 0;
+  const int nRef = d.bi == 1 ? 2 : 1;
+
+  for (int sy = 0; sy < d.h; sy += ST)
+    for (int sx = 0; sx < d.w; sx += ST)
+    {
+      const int tw = min(ST, d.w - sx), th = min(ST, d.h - sy);
+      const int npx = tw * th;
+      int pred[2][4];
+#pragma unroll
+      for (int r = 0; r < 2; r++)
+      {
+        if (r >= nRef) break;
+        const Pel* ref = (r ? ref1Base + d.ref1_off : ref0Base + d.ref0_off) + (size_t)sy * (r ? d.ref1_stride : d.ref0_stride) + sx;
+        const int rs = r ? d.ref1_stride : d.ref0_stride;
+        const int fx = r ? d.frac_x1 : d.frac_x0, fy = r ? d.frac_y1 : d.frac_y0;
+        const short* cx = d.is_luma ? c_lumaFilter[fx] : c_chromaFilter[fx];
+        const short* cy = d.is_luma ? c_lumaFilter[fy] : c_chromaFilter[fy];
+        // stage only what the branch needs: rows [-half, th+N-1-half) when fy != 0, cols likewise when fx != 0
+        const int r0 = fy ? -half : 0, nr = fy ? th + N - 1 : th;
+        const int c0 = fx ? -half : 0, nc = fx ? tw + N - 1 : tw;
+        __syncthreads();                               // previous users of win/tmp are done
+        for (int i = lane; i < nr * nc; i += 64)
+        {
+          const int rr = i / nc, cc = i - rr * nc;
+          win[rr * WP + cc] = ref[(ptrdiff_t)(r0 + rr) * rs + c0 + cc];
+        }
+        __syncthreads();
+        if (fx && fy)
+        {
+          const IfMode mh = if_mode(true, false, bd);
+          for (int i = lane; i < nr * tw; i += 64)
+          {
+            const int rr = i / tw, x = i - rr * tw;
+            int sum = 0;
+            for (int k = 0; k < N; k++) sum += win[rr * WP + x + k] * cx[k];
+            tmp[rr * ST + x] = (short)((sum + mh.offset) >> mh.shift);
+          }
+          __syncthreads();
+          const IfMode mv = if_mode(false, rndRes, bd);
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+          {
+            const int p = lane + 64 * j;
+            if (p < npx)
+            {
+              const int y = p / tw, x = p - y * tw;
+              int sum = 0;
+              for (int k = 0; k < N; k++) sum += tmp[(y + k) * ST + x] * cy[k];
+              int v = (short)((sum + mv.offset) >> mv.shift);
+              if (rndRes) v = clip3(cmin, cmax, v);
+              pred[r][j] = v;
+            }
+          }
+        }
+        else
+        {
+          const IfMode m1 = if_mode(true, rndRes, bd);
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+          {
+            const int p = lane + 64 * j;
+            if (p < npx)
+            {
+              const int y = p / tw, x = p - y * tw;
+              int v;
+              if (!fx && !fy) v = if_copy(win[y * WP + x], true, rndRes, bd, cmin, cmax);
+              else
+              {
+                int sum = 0;
+                if (fx) { for (int k = 0; k < N; k++) sum += win[y * WP + x + k] * cx[k]; }
+                else    { for (int k = 0; k < N; k++) sum += win[(y + k) * WP + x] * cy[k]; }
+                v = (short)((sum + m1.offset) >> m1.shift);
+                if (rndRes) v = clip3(cmin, cmax, v);
+              }
+              pred[r][j] = v;
+            }
+          }
+        }
+      }
+      Pel* dst = dstBase + d.dst_off + (size_t)sy * d.dst_stride + sx;
+      const int shiftNum = max(2, IF_INTERNAL_PREC - bd) + 1, offset = (1 << (shiftNum - 1)) + 2 * IF_INTERNAL_OFFS;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+        const int p = lane + 64 * j;
+        if (p < npx)
+        {
+          const int y = p / tw, x = p - y * tw;
+          int v = pred[0][j];
+          if (d.bi == 1) v = clip3(cmin, cmax, (pred[0][j] + pred[1][j] + offset) >> shiftNum);
+          dst[(size_t)y * d.dst_stride + x] = (short)v;
+        }
+      }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------ B1-B4
+__global__ __launch_bounds__(256) void pelop_batch_kernel(int op, const Pel* __restrict__ s0Base, const Pel* __restrict__ s1Base,
+                                                          Pel* dstBase, const vvcgpu_pelop_desc* __restrict__ descs, int n,
+                                                          vvcgpu_pelop_cfg c)
+{
+  const int lane = threadIdx.x & 63;
+  const int di = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (di >= n) return;
+  const vvcgpu_pelop_desc d = descs[di];
+  const Pel* s0 = s0Base + d.src0_off;
+  const Pel* s1 = s1Base ? s1Base + d.src1_off : nullptr;
+  Pel* dst = dstBase + d.dst_off;
+  for (int i = lane; i < d.w * d.h; i += 64)
+  {
+    const int y = i / d.w, x = i - y * d.w;
+    const int a = s0[(size_t)y * d.src0_stride + x];
+    const int b = s1 ? s1[(size_t)y * d.src1_stride + x] : 0;
+    int v;
+    switch (op)
+    {
+    case 0: v = clip3(c.clp_min, c.clp_max, (a + b + c.offset) >> c.shift); break;
+    case 1: v = clip3(c.clp_min, c.clp_max, a + b); break;
+    case 2: { const int t = (c.shift >= 0 ? (c.scale * a) >> c.shift : (c.scale * a) << -c.shift) + c.offset;
+              v = c.clip ? clip3(c.clp_min, c.clp_max, t) : t; } break;
+    case 3: v = a - b; break;
+    case 4: v = c.clip ? clip3(c.clp_min, c.clp_max, 2 * a - b) : 2 * a - b; break;
+    default: v = clip3(c.clp_min, c.clp_max, a); break;
+    }
+    dst[(size_t)y * d.dst_stride + x] = (short)v;
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_desc* descs, int n,
+                    int bit_depth, int clp_min, int clp_max, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "if_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(src_base && dst_base && descs, "if_batch: null pointer");
+  if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("if_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(if_batch_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, src_base, dst_base, descs, n,
+                     bit_depth, clp_min, clp_max);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base,
+                    const vvcgpu_mc_desc* descs, int n, int bit_depth, int clp_min, int clp_max, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "mc_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(ref0_base && dst_base && descs, "mc_batch: null pointer");
+  if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("mc_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(mc_batch_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, ref0_base, ref1_base ? ref1_base : ref0_base,
+                     dst_base, descs, bit_depth, clp_min, clp_max);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+int vvcgpu_pelop_batch(int op, const vvc_pel* src0_base, const vvc_pel* src1_base, vvc_pel* dst_base,
+                       const vvcgpu_pelop_desc* descs, int n, const vvcgpu_pelop_cfg* cfg_host, void* stream)
+{
+  VVC_CHECK_ARG(op >= 0 && op <= 5, "pelop_batch: op %d", op);
+  VVC_CHECK_ARG(n >= 0, "pelop_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(src0_base && dst_base && descs && cfg_host, "pelop_batch: null pointer");
+  VVC_CHECK_ARG(src1_base || op == 2 || op == 5, "pelop_batch: op %d needs src1", op);
+  hipLaunchKernelGGL(pelop_batch_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, op, src0_base, src1_base,
+                     dst_base, descs, n, *cfg_host);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+}  // extern "C"

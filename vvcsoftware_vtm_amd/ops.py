@@ -163,3 +163,50 @@ def sad_search(org, ref, blocks_dev, nblocks, w, h, sub_shift, dx0, dy0, nx, ny,
     capi.call("vvcgpu_sad_search", po, so, pr, sr, capi.ptr(blocks_dev), nblocks, w, h, sub_shift, dx0, dy0, nx, ny,
               sx, sy, capi.ptr(sad), mv, capi.ptr(best), _stream())
     return sad, best
+
+
+# ---- interpolation / MC / PelBuffer ops -------------------------------------------------------------
+IF_DESC = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("src_stride", "<i4"), ("dst_stride", "<i4"),
+                    ("w", "<i2"), ("h", "<i2"), ("taps", "i1"), ("is_vertical", "i1"), ("is_first", "i1"),
+                    ("is_last", "i1"), ("coeff", "<i2", (8,)), ("reserved", "<i2", (2,))])
+MC_DESC = np.dtype([("ref0_off", "<i8"), ("ref1_off", "<i8"), ("dst_off", "<i8"), ("ref0_stride", "<i4"),
+                    ("ref1_stride", "<i4"), ("dst_stride", "<i4"), ("w", "<i2"), ("h", "<i2"), ("frac_x0", "i1"),
+                    ("frac_y0", "i1"), ("frac_x1", "i1"), ("frac_y1", "i1"), ("is_luma", "i1"), ("bi", "i1"),
+                    ("reserved", "<i2")])
+PELOP_DESC = np.dtype([("src0_off", "<i8"), ("src1_off", "<i8"), ("dst_off", "<i8"), ("src0_stride", "<i4"),
+                       ("src1_stride", "<i4"), ("dst_stride", "<i4"), ("w", "<i2"), ("h", "<i2")])
+assert IF_DESC.itemsize == 48 and MC_DESC.itemsize == 48 and PELOP_DESC.itemsize == 40
+
+
+class PelopCfg(C.Structure):
+    _fields_ = [("scale", C.c_int32), ("shift", C.c_int32), ("offset", C.c_int32), ("clip", C.c_int32),
+                ("clp_min", C.c_int32), ("clp_max", C.c_int32)]
+
+
+def if_batch(src_base, dst_base, descs_dev, n, bit_depth=10, clp=(0, 1023)):
+    capi.call("vvcgpu_if_batch", capi.ptr(src_base), capi.ptr(dst_base), capi.ptr(descs_dev), n, bit_depth, clp[0], clp[1], _stream())
+
+
+def mc_batch(ref0_base, ref1_base, dst_base, descs_dev, n, bit_depth=10, clp=(0, 1023)):
+    capi.call("vvcgpu_mc_batch", capi.ptr(ref0_base), capi.ptr(ref1_base), capi.ptr(dst_base), capi.ptr(descs_dev), n,
+              bit_depth, clp[0], clp[1], _stream())
+
+
+def pelop_batch(op, src0_base, src1_base, dst_base, descs_dev, n, cfg):
+    capi.call("vvcgpu_pelop_batch", op, capi.ptr(src0_base), capi.ptr(src1_base), capi.ptr(dst_base), capi.ptr(descs_dev), n,
+              C.byref(cfg), _stream())
+
+
+# ---- transforms (TrQuant) ----------------------------------------------------------------------------
+TR_DESC = np.dtype([("resi_off", "<i8"), ("coeff_off", "<i8"), ("resi_stride", "<i4"), ("w", "<i2"), ("h", "<i2"),
+                    ("tr_hor", "i1"), ("tr_ver", "i1"), ("reserved", "<i2")])
+assert TR_DESC.itemsize == 24
+DCT2, DCT8, DST7, TSKIP = 0, 1, 2, 3
+
+
+def tr_fwd_batch(resi_base, coeff_base, descs_dev, n, bit_depth=10):
+    capi.call("vvcgpu_tr_fwd_batch", capi.ptr(resi_base), capi.ptr(coeff_base), capi.ptr(descs_dev), n, bit_depth, _stream())
+
+
+def tr_inv_batch(coeff_base, resi_base, descs_dev, n, bit_depth=10):
+    capi.call("vvcgpu_tr_inv_batch", capi.ptr(coeff_base), capi.ptr(resi_base), capi.ptr(descs_dev), n, bit_depth, _stream())
