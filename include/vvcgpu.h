@@ -40,6 +40,9 @@ int         vvcgpu_version(void);                 /* ABI version, currently 1 */
 const char* vvcgpu_last_error(void);              /* thread-local text of the last failure */
 int         vvcgpu_device_count(void);
 int         vvcgpu_set_device(int device);
+/* sizeof() of the parameter structs, for binding self-checks: 0 sao_ctu, 1 deblock_cfg, 2 dist_desc, 3 search_blk,
+ * 4 mvcost, 5 search_best, 6 if_desc, 7 mc_desc, 8 pelop_desc, 9 pelop_cfg, 10 tr_desc; -1 for unknown ids.          */
+int         vvcgpu_sizeof(int struct_id);
 
 /* ---- A1: ALF classification  (AdaptiveLoopFilter::deriveClassification, AdaptiveLoopFilter.cpp:274-463;
  *          table slot m_deriveClassificationBlk, AdaptiveLoopFilter.h:90) -----------------------
@@ -191,7 +194,7 @@ typedef struct vvcgpu_if_desc {
   int16_t w, h;
   int8_t  taps, is_vertical, is_first, is_last;
   int16_t coeff[8];
-  int16_t reserved[2];
+  int16_t reserved[4];                /* sizeof == 56 */
 } vvcgpu_if_desc;
 int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_desc* descs, int n,
                     int bit_depth, int clp_min, int clp_max, void* stream);
@@ -248,6 +251,7 @@ typedef struct vvcgpu_tr_desc {
   int16_t w, h;
   int8_t  tr_hor, tr_ver;
   int16_t reserved;
+  int32_t reserved2;                    /* sizeof == 32 */
 } vvcgpu_tr_desc;
 int vvcgpu_tr_fwd_batch(const vvc_pel* resi_base, vvc_coef* coeff_base, const vvcgpu_tr_desc* descs, int n,
                         int bit_depth, void* stream);

@@ -42,3 +42,17 @@ def test_version_and_error_text():
     assert b"alf_classify" in lib.vvcgpu_last_error()
     rc = lib.vvcgpu_sao_apply(C.c_void_p(16), 8, C.c_void_p(16), 8, 8, 8, 8, 8, 10, C.c_void_p(16), 0, 1023, None)
     assert rc == -1 and b"alias" in lib.vvcgpu_last_error()
+
+
+def test_struct_layouts_match_python_bindings():
+    """numpy / ctypes mirrors used by the host code have exactly the C sizes (no GPU needed; torch is imported lazily)."""
+    _ensure_built()
+    import numpy as np
+    from vvcsoftware_vtm_amd import ops
+    lib = capi.lib()
+    want = {0: ops.SAO_DTYPE.itemsize, 1: C.sizeof(ops.DeblockCfg), 2: ops.DIST_DESC.itemsize, 3: ops.SEARCH_BLK.itemsize,
+            4: C.sizeof(ops.MvCost), 5: ops.SEARCH_BEST.itemsize, 6: ops.IF_DESC.itemsize, 7: ops.MC_DESC.itemsize,
+            8: ops.PELOP_DESC.itemsize, 9: C.sizeof(ops.PelopCfg), 10: ops.TR_DESC.itemsize}
+    for k, v in want.items():
+        assert lib.vvcgpu_sizeof(k) == v, (k, lib.vvcgpu_sizeof(k), v)
+    assert lib.vvcgpu_sizeof(99) == -1

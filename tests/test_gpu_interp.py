@@ -48,7 +48,7 @@ def test_if_batch(bd, first):
                     if N and not isV and not first:
                         continue
                     x, y = int(rng.integers(M, W - w - M)), int(rng.integers(M, H - h - M))
-                    rows.append((y * W + x, doff, W, w + 1, w, h, N, isV, first, isL, _coeff(rng, N), [0, 0]))
+                    rows.append((y * W + x, doff, W, w + 1, w, h, N, isV, first, isL, _coeff(rng, N), [0, 0, 0, 0]))
                     doff += (w + 1) * h
     d = np.array(rows, dtype=ops.IF_DESC)
     want = np.full(doff, -5, np.int16)

@@ -33,7 +33,7 @@ def build(rng, bd, kind):
                 else:
                     r = rng.integers(-20, 20, (h, st))
                 resis.append(r.astype(np.int16).reshape(-1))
-                rows.append((roff, coff, st, w, h, th, tv, 0))
+                rows.append((roff, coff, st, w, h, th, tv, 0, 0))
                 roff += h * st
                 coff += w * h
     return np.array(rows, dtype=ops.TR_DESC), np.concatenate(resis), coff

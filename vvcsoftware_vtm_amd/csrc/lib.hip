@@ -22,6 +22,24 @@ int vvcgpu_device_count(void)
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+int vvcgpu_sizeof(int id)
+{
+  switch (id)
+  {
+  case 0: return (int)sizeof(vvcgpu_sao_ctu);
+  case 1: return (int)sizeof(vvcgpu_deblock_cfg);
+  case 2: return (int)sizeof(vvcgpu_dist_desc);
+  case 3: return (int)sizeof(vvcgpu_search_blk);
+  case 4: return (int)sizeof(vvcgpu_mvcost);
+  case 5: return (int)sizeof(vvcgpu_search_best);
+  case 6: return (int)sizeof(vvcgpu_if_desc);
+  case 7: return (int)sizeof(vvcgpu_mc_desc);
+  case 8: return (int)sizeof(vvcgpu_pelop_desc);
+  case 9: return (int)sizeof(vvcgpu_pelop_cfg);
+  case 10: return (int)sizeof(vvcgpu_tr_desc);
+  default: return -1;
+  }
+}
 int vvcgpu_set_device(int device)
 {
   VVC_HIP(hipSetDevice(device));

@@ -168,14 +168,14 @@ def sad_search(org, ref, blocks_dev, nblocks, w, h, sub_shift, dx0, dy0, nx, ny,
 # ---- interpolation / MC / PelBuffer ops -------------------------------------------------------------
 IF_DESC = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("src_stride", "<i4"), ("dst_stride", "<i4"),
                     ("w", "<i2"), ("h", "<i2"), ("taps", "i1"), ("is_vertical", "i1"), ("is_first", "i1"),
-                    ("is_last", "i1"), ("coeff", "<i2", (8,)), ("reserved", "<i2", (2,))])
+                    ("is_last", "i1"), ("coeff", "<i2", (8,)), ("reserved", "<i2", (4,))])
 MC_DESC = np.dtype([("ref0_off", "<i8"), ("ref1_off", "<i8"), ("dst_off", "<i8"), ("ref0_stride", "<i4"),
                     ("ref1_stride", "<i4"), ("dst_stride", "<i4"), ("w", "<i2"), ("h", "<i2"), ("frac_x0", "i1"),
                     ("frac_y0", "i1"), ("frac_x1", "i1"), ("frac_y1", "i1"), ("is_luma", "i1"), ("bi", "i1"),
                     ("reserved", "<i2")])
 PELOP_DESC = np.dtype([("src0_off", "<i8"), ("src1_off", "<i8"), ("dst_off", "<i8"), ("src0_stride", "<i4"),
                        ("src1_stride", "<i4"), ("dst_stride", "<i4"), ("w", "<i2"), ("h", "<i2")])
-assert IF_DESC.itemsize == 48 and MC_DESC.itemsize == 48 and PELOP_DESC.itemsize == 40
+assert IF_DESC.itemsize == 56 and MC_DESC.itemsize == 48 and PELOP_DESC.itemsize == 40
 
 
 class PelopCfg(C.Structure):
@@ -199,8 +199,8 @@ def pelop_batch(op, src0_base, src1_base, dst_base, descs_dev, n, cfg):
 
 # ---- transforms (TrQuant) ----------------------------------------------------------------------------
 TR_DESC = np.dtype([("resi_off", "<i8"), ("coeff_off", "<i8"), ("resi_stride", "<i4"), ("w", "<i2"), ("h", "<i2"),
-                    ("tr_hor", "i1"), ("tr_ver", "i1"), ("reserved", "<i2")])
-assert TR_DESC.itemsize == 24
+                    ("tr_hor", "i1"), ("tr_ver", "i1"), ("reserved", "<i2"), ("reserved2", "<i4")])
+assert TR_DESC.itemsize == 32
 DCT2, DCT8, DST7, TSKIP = 0, 1, 2, 3
 
 
