@@ -1,0 +1,194 @@
+#!/usr/bin/env python3
+"""bench.py -- hot-path throughput of the MI355X-native VTM pixel path (measurement M1 of SURVEY.md §8(d)).
+
+A "step" is one pass of the canonical per-picture hot-path workload (integer-ME SAD surfaces, bi-pred MC, residual +
+forward/inverse transforms + reconstruction, deblocking, SAO stats+apply, ALF classify+stats+filter) over ONE
+3840x2160 10-bit 4:2:0 picture whose planes are resident in HBM.  N > 1: one process per GPU, each rank works on its own
+pictures (random-access intra periods shard with no data-path collective); the boundary reconstructed
+picture of a chunk hand-over is exchanged point-to-point once per 32 pictures (RCCL).  value = pictures all ranks
+processed / max-over-ranks time.  This is NOT EncoderApp fps: the serial RDO control loop is outside the path.
+
+Prints ONE JSON line on rank 0."""
+import argparse
+import ctypes as C
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+
+
+def cpu_baseline(width, height, bd):
+    """VTM's own SIMD kernels (oracle/_ref/libvtmref.so, kind 'reference') or the scalar restatement (kind 'port') on the
+    host cores, on a bounded sample: the same workload on a 512x256 picture, scaled by the pixel ratio."""
+    from vvcsoftware_vtm_amd.workload import Workload
+    odir = os.path.join(ROOT, "oracle")
+    port_so = os.path.join(odir, "liboracle.so")
+    ref_so = os.path.join(odir, "_ref", "libvtmref.so")
+    if not os.path.exists(port_so):
+        return None
+    port = C.CDLL(port_so)
+    sw, sh = 512, 256
+    wl = Workload(sw, sh, bd, seed=7)
+    kind = "port"
+    lib = port
+    if os.path.exists(ref_so):
+        try:
+            lib = (port, C.CDLL(ref_so))
+            kind = "reference"
+        except OSError:
+            lib = port
+    t0 = time.perf_counter()
+    reps = 0
+    secs_tot = {}
+    while True:
+        _, secs = wl.run_cpu(lib, kind)
+        for k, v in secs.items():
+            secs_tot[k] = secs_tot.get(k, 0.0) + v
+        reps += 1
+        if time.perf_counter() - t0 > 12.0 or reps >= 20:
+            break
+    per_sample = sum(secs_tot.values()) / reps
+    scale = (width * height) / float(sw * sh)
+    fps = 1.0 / (per_sample * scale)
+    return {"value": fps, "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": "same canonical workload on a %dx%d picture (%d repetitions, %.2f s of CPU work), scaled by pixel count to %dx%d; "
+                      "deblocking and plane add/subtract use the scalar port (no reference entry point); "
+                      "stage seconds per sample: %s" % (sw, sh, reps, sum(secs_tot.values()), width, height,
+                                                        {k: round(v / reps, 4) for k, v in secs_tot.items()})}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from vvcsoftware_vtm_amd import capi, shard
+    from vvcsoftware_vtm_amd.workload import Workload
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    torch.cuda.set_device(local_rank)
+    capi.call("vvcgpu_set_device", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+
+    bd = 10
+    wl = Workload(args.width, args.height, bd, seed=20261003 + rank)
+    alg = wl.algorithmic_bytes()
+
+    class Timer:
+        def __init__(self):
+            self.ev = {}
+            self.on = False
+
+        def __call__(self, name):
+            return _Span(self, name)
+
+    class _Span:
+        def __init__(self, t, name):
+            self.t, self.name = t, name
+
+        def __enter__(self):
+            if self.t.on:
+                self.a = torch.cuda.Event(enable_timing=True)
+                self.b = torch.cuda.Event(enable_timing=True)
+                self.a.record()
+            return self
+
+        def __exit__(self, *a):
+            if self.t.on:
+                self.b.record()
+                self.t.ev.setdefault(self.name, []).append((self.a, self.b))
+            return False
+
+    timer = Timer()
+    state = None
+    for _ in range(args.warmup):
+        state, out = wl.run_gpu(state, timer)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    timer.on = True
+    t0 = time.perf_counter()
+    for step in range(args.steps):
+        state, out = wl.run_gpu(state, timer)
+        if world > 1 and step == 0:
+            # chunk hand-over: one reconstructed boundary picture per intra period (32 pictures), point-to-point
+            shard.exchange_boundary(out["final"], rank, world)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device="cuda")
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    # per-launch-group device times (HIP events on the stream the kernels were launched on)
+    kern_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in timer.ev.items()}
+    stage_ms = {}
+    for k, v in kern_ms.items():
+        stage_ms[k.split("/")[0]] = stage_ms.get(k.split("/")[0], 0.0) + v
+    dom = max(kern_ms, key=kern_ms.get)
+    dstage, dname = dom.split("/")
+    abytes = alg[dstage][dname]
+    achieved = abytes / (kern_ms[dom] * 1e-3) / 1e9
+    per_kernel = {}
+    for k, v in kern_ms.items():
+        s, n = k.split("/")
+        if n in alg.get(s, {}):
+            per_kernel[k] = {"ms": round(v, 4), "alg_MB": round(alg[s][n] / 1e6, 2), "GBps": round(alg[s][n] / (v * 1e-3) / 1e9, 1)}
+        else:
+            per_kernel[k] = {"ms": round(v, 4)}
+
+    if rank == 0:
+        res = {
+            "metric": "encoded frames/sec (bit-exact bitstream) at 4K10 RA QP32, 1/2/4/8 GPU",
+            "value": args.steps * world / dt,
+            "unit": "frames/s",
+            "n_gpus": world,
+            "steps": args.steps,
+            "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3,
+            "higher_is_better": True,
+            "scaling": "weak",
+            "vs_baseline": None,
+            "dtype": "int16",
+            "data": "synthetic",
+            "config": {"workload": "hot-path canonical per-picture workload (SURVEY 8(d) M1: ME SAD surfaces 16/32/64 +-4 & raster +-96, "
+                                   "bi-pred MC 16x16, residual+fwd/inv transforms+reco, deblock, SAO stats+apply, ALF classify+stats+filter) "
+                                   "on %dx%d 10-bit 4:2:0, planes resident in HBM; NOT EncoderApp fps (RDO control loop out of scope)" % (args.width, args.height),
+                       "width": args.width, "height": args.height, "bit_depth": bd,
+                       "parallelism": "one picture stream per GPU, intra-period sharding, p2p boundary picture per 32 pictures"},
+            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": kern_ms[dom]},
+            "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "kernels": per_kernel,
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            res["cpu_baseline"] = cpu_baseline(args.width, args.height, bd)
+        print(json.dumps(res))
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -369,4 +369,61 @@ int vtmref_rom_matrix(int type, int log2n, int32_t* out)
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Batch drivers for bench.py's cpu_baseline leg: plain loops over the same descriptors the GPU kernels take, every
+// arithmetic step done by the reference's own (SIMD-table) functions.
+int vtmref_sad_search(const Pel* org, int os, const Pel* ref, int rs, const vvcgpu_search_blk* blk, int nblk, int w, int h,
+                      int subShift, int dx0, int dy0, int nx, int ny, int sx, int sy, int bd, uint32_t* out)
+{
+  static RdCost* rc = nullptr;
+  if (!rc) { rc = new RdCost; rc->setUseQtbt(true); }
+  for (int b = 0; b < nblk; b++)
+  {
+    DistParam dp;
+    CPelBuf ob(org + blk[b].org_y * os + blk[b].org_x, os, w, h);
+    const Pel* refY = ref + (ptrdiff_t)blk[b].ref_y * rs + blk[b].ref_x;
+    rc->setDistParam(dp, ob, refY, rs, bd, COMPONENT_Y, 0);             // as xPatternSearch (InterSearch.cpp:1897)
+    dp.subShift = subShift;
+    for (int j = 0; j < ny; j++)
+      for (int i = 0; i < nx; i++)
+      {
+        dp.cur.buf = refY + (ptrdiff_t)(dy0 + j * sy) * rs + dx0 + i * sx;
+        out[((size_t)b * ny + j) * nx + i] = (uint32_t)dp.distFunc(dp);
+      }
+  }
+  return 0;
+}
+int vtmref_mc_batch(const Pel* ref0, const Pel* ref1, Pel* dst, const vvcgpu_mc_desc* d, int n, int bd, int clpMin, int clpMax)
+{
+  static PelBufferOps* ops = nullptr;
+  if (!ops) { ops = new PelBufferOps; ops->initPelBufOpsX86(); }
+  ClpRng clp = mkClp(clpMin, clpMax, bd);
+  std::vector<Pel> p0(128 * 128), p1(128 * 128);
+  for (int i = 0; i < n; i++)
+  {
+    const vvcgpu_mc_desc& m = d[i];
+    if (m.bi != 1) { vtmref_pred_blk(1, ref0 + m.ref0_off, m.ref0_stride, dst + m.dst_off, m.dst_stride, m.w, m.h, m.frac_x0, m.frac_y0, m.is_luma, m.bi == 0, bd, clpMin, clpMax); continue; }
+    vtmref_pred_blk(1, ref0 + m.ref0_off, m.ref0_stride, p0.data(), m.w, m.w, m.h, m.frac_x0, m.frac_y0, m.is_luma, 0, bd, clpMin, clpMax);
+    vtmref_pred_blk(1, ref1 + m.ref1_off, m.ref1_stride, p1.data(), m.w, m.w, m.h, m.frac_x1, m.frac_y1, m.is_luma, 0, bd, clpMin, clpMax);
+    const int shiftNum = std::max<int>(2, IF_INTERNAL_PREC - bd) + 1, offset = (1 << (shiftNum - 1)) + 2 * IF_INTERNAL_OFFS;
+    ((m.w & 7) == 0 ? ops->addAvg8 : ops->addAvg4)(p0.data(), m.w, p1.data(), m.w, dst + m.dst_off, m.dst_stride, m.w, m.h, shiftNum, offset, clp);
+  }
+  return 0;
+}
+int vtmref_tr_fwd_batch(const Pel* resi, TCoeff* coeff, const vvcgpu_tr_desc* d, int n, int bd)
+{
+  for (int i = 0; i < n; i++) vtmref_fwd_tr2d(bd, resi + d[i].resi_off, d[i].resi_stride, coeff + d[i].coeff_off, d[i].w, d[i].h, d[i].tr_hor, d[i].tr_ver);
+  return 0;
+}
+int vtmref_tr_inv_batch(const TCoeff* coeff, Pel* resi, const vvcgpu_tr_desc* d, int n, int bd)
+{
+  for (int i = 0; i < n; i++) vtmref_inv_tr2d(bd, coeff + d[i].coeff_off, resi + d[i].resi_off, d[i].resi_stride, d[i].w, d[i].h, d[i].tr_hor, d[i].tr_ver);
+  return 0;
+}
+int vtmref_dist_batch(int kind, const Pel* org, const Pel* cur, const vvcgpu_dist_desc* d, int n, int bd, uint64_t* out)
+{
+  for (int i = 0; i < n; i++) out[i] = vtmref_dist(kind, 1, org + d[i].org_off, d[i].org_stride, cur + d[i].cur_off, d[i].cur_stride, d[i].w, d[i].h, bd, d[i].sub_shift);
+  return 0;
+}
+
 }  // extern "C"

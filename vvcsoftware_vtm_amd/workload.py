@@ -1,0 +1,417 @@
+"""Canonical per-picture hot-path workload (measurement M1).
+
+Everything is derived from a seed: three synthetic frames (current = org, two references), block/PU/TU
+descriptors, deblocking maps, SAO and ALF parameters.  The same `Workload` object drives
+
+  * the HIP path (`run_gpu`, through vvcsoftware_vtm_amd.ops -> C ABI),
+  * the checkers (`run_cpu`, through ctypes function tables of oracle/liboracle.so or oracle/_ref/libvtmref.so) --
+    used only by tests/ and by bench.py's cpu_baseline leg.
+
+Stages (one picture = one step):
+  me     integer ME: SAD surface of every 16x16 / 32x32 / 64x64 block at the 81 positions of a +-4 full search and
+         at the 5-stride raster of a +-96 window (39x39), sub_shift 1 (FEN mode 2), with the MV-cost argmin
+  mc     bi-predictive MC of the whole picture as 16x16 PUs (luma 8-tap + chroma 4-tap) + addAvg
+  resi   residual = org - pred; forward + inverse transforms over a seeded tiling {64,32,16,8,4} in equal pixel
+         shares (DST-VII/DCT-VIII pairs on tiles <= 32) with a shift-only quantiser stand-in; reconstruction
+  dbk    deblocking with a seeded CU grid / BS / QP field
+  sao    SAO statistics + apply with seeded per-CTU parameters (all five types)
+  alf    ALF classification + covariance statistics (7x7 and 5x5 luma, 5x5 chroma) + 7x7 luma / 5x5 chroma filtering
+"""
+import ctypes as C
+import time
+
+import numpy as np
+
+from . import synth
+
+MARGIN = 144          # reference picture margin (maxCUWidth + 16, Picture.cpp:737-742)
+CTU = 128
+STAGES = ["me", "mc", "resi", "dbk", "sao", "alf"]
+
+DIST_DESC = np.dtype([("org_off", "<i8"), ("cur_off", "<i8"), ("org_stride", "<i4"), ("cur_stride", "<i4"),
+                      ("w", "<i2"), ("h", "<i2"), ("sub_shift", "<i2"), ("reserved", "<i2")])
+SEARCH_BLK = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4")])
+SEARCH_BEST = np.dtype([("x", "<i4"), ("y", "<i4"), ("cost", "<u8"), ("sad", "<u8")])
+MC_DESC = np.dtype([("ref0_off", "<i8"), ("ref1_off", "<i8"), ("dst_off", "<i8"), ("ref0_stride", "<i4"),
+                    ("ref1_stride", "<i4"), ("dst_stride", "<i4"), ("w", "<i2"), ("h", "<i2"), ("frac_x0", "i1"),
+                    ("frac_y0", "i1"), ("frac_x1", "i1"), ("frac_y1", "i1"), ("is_luma", "i1"), ("bi", "i1"),
+                    ("reserved", "<i2")])
+PELOP_DESC = np.dtype([("src0_off", "<i8"), ("src1_off", "<i8"), ("dst_off", "<i8"), ("src0_stride", "<i4"),
+                       ("src1_stride", "<i4"), ("dst_stride", "<i4"), ("w", "<i2"), ("h", "<i2")])
+TR_DESC = np.dtype([("resi_off", "<i8"), ("coeff_off", "<i8"), ("resi_stride", "<i4"), ("w", "<i2"), ("h", "<i2"),
+                    ("tr_hor", "i1"), ("tr_ver", "i1"), ("reserved", "<i2"), ("reserved2", "<i4")])
+SAO_DTYPE = np.dtype([("type", "i1"), ("avail", "u1"), ("offset", "<i2", (32,))])
+
+
+class MvCost(C.Structure):
+    _fields_ = [("lambda_", C.c_double), ("pred_hor", C.c_int32), ("pred_ver", C.c_int32),
+                ("cost_scale", C.c_int32), ("imv_shift", C.c_int32)]
+
+
+class PelopCfg(C.Structure):
+    _fields_ = [("scale", C.c_int32), ("shift", C.c_int32), ("offset", C.c_int32), ("clip", C.c_int32),
+                ("clp_min", C.c_int32), ("clp_max", C.c_int32)]
+
+
+class DeblockCfg(C.Structure):
+    _fields_ = [("bit_depth_luma", C.c_int32), ("bit_depth_chroma", C.c_int32),
+                ("beta_offset_div2", C.c_int32), ("tc_offset_div2", C.c_int32),
+                ("cb_qp_offset", C.c_int32), ("cr_qp_offset", C.c_int32),
+                ("clp_min", C.c_int32 * 3), ("clp_max", C.c_int32 * 3)]
+
+
+def _pad(plane, m):
+    return np.ascontiguousarray(np.pad(plane, m, mode="edge"))
+
+
+class Workload:
+    def __init__(self, width, height, bit_depth=10, seed=20261003, raster_range=96, me_sizes=(16, 32, 64)):
+        assert width % 8 == 0 and height % 8 == 0
+        self.w, self.h, self.bd = width, height, bit_depth
+        self.mx = (1 << bit_depth) - 1
+        self.seed = seed
+        self.raster_range = raster_range
+        rng = np.random.default_rng(seed)
+        frames = synth.gen_yuv(width, height, 3, bit_depth, seed)
+        to16 = lambda fr: [p.astype(np.int16) for p in fr]
+        self.ref1, self.ref0, self.org = to16(frames[0]), to16(frames[1]), to16(frames[2])
+        m, mc = MARGIN, MARGIN // 2
+        self.ref0_pad = [_pad(self.ref0[0], m), _pad(self.ref0[1], mc), _pad(self.ref0[2], mc)]
+        self.ref1_pad = [_pad(self.ref1[0], m), _pad(self.ref1[1], mc), _pad(self.ref1[2], mc)]
+        self.pw, self.pwc = width + 2 * m, width // 2 + 2 * mc
+
+        # ---- ME blocks ---------------------------------------------------------------------------------------
+        self.me = {}
+        for s in me_sizes:
+            xs, ys = np.arange(0, width - s + 1, s), np.arange(0, height - s + 1, s)
+            gx, gy = np.meshgrid(xs, ys)
+            blk = np.zeros(gx.size, SEARCH_BLK)
+            blk["org_x"], blk["org_y"] = gx.reshape(-1), gy.reshape(-1)
+            blk["ref_x"], blk["ref_y"] = blk["org_x"] + m, blk["org_y"] + m
+            self.me[s] = blk
+        nr = 2 * (raster_range // 5) + 1
+        self.me_grids = [(-4, -4, 9, 9, 1, 1), (-5 * (nr // 2), -5 * (nr // 2), nr, nr, 5, 5)]
+        self.mvcost = MvCost(float(np.sqrt(57.0)), 0, 0, 2, 0)
+
+        # ---- MC: bi-pred 16x16 PUs, quarter-pel MVs ----------------------------------------------------------
+        xs, ys = np.arange(0, width, 16), np.arange(0, height, 16)
+        gx, gy = np.meshgrid(xs, ys)
+        gx, gy = gx.reshape(-1), gy.reshape(-1)
+        n = gx.size
+        bw = np.minimum(16, width - gx).astype(np.int16)
+        bh = np.minimum(16, height - gy).astype(np.int16)
+        mv = rng.integers(-32, 33, (n, 4))                       # quarter-pel luma units: (x0, y0, x1, y1)
+        dl = np.zeros(n, MC_DESC)
+        dl["ref0_off"] = (gy + m + (mv[:, 1] >> 2)) * self.pw + gx + m + (mv[:, 0] >> 2)
+        dl["ref1_off"] = (gy + m + (mv[:, 3] >> 2)) * self.pw + gx + m + (mv[:, 2] >> 2)
+        dl["dst_off"] = gy * width + gx
+        dl["ref0_stride"] = dl["ref1_stride"] = self.pw
+        dl["dst_stride"] = width
+        dl["w"], dl["h"] = bw, bh
+        dl["frac_x0"], dl["frac_y0"] = (mv[:, 0] & 3) << 2, (mv[:, 1] & 3) << 2
+        dl["frac_x1"], dl["frac_y1"] = (mv[:, 2] & 3) << 2, (mv[:, 3] & 3) << 2
+        dl["is_luma"], dl["bi"] = 1, 1
+        dc = np.zeros(n, MC_DESC)
+        cx, cy = gx // 2, gy // 2
+        dc["ref0_off"] = (cy + mc + (mv[:, 1] >> 3)) * self.pwc + cx + mc + (mv[:, 0] >> 3)
+        dc["ref1_off"] = (cy + mc + (mv[:, 3] >> 3)) * self.pwc + cx + mc + (mv[:, 2] >> 3)
+        dc["dst_off"] = cy * (width // 2) + cx
+        dc["ref0_stride"] = dc["ref1_stride"] = self.pwc
+        dc["dst_stride"] = width // 2
+        dc["w"], dc["h"] = bw // 2, bh // 2
+        dc["frac_x0"], dc["frac_y0"] = (mv[:, 0] & 7) << 2, (mv[:, 1] & 7) << 2
+        dc["frac_x1"], dc["frac_y1"] = (mv[:, 2] & 7) << 2, (mv[:, 3] & 7) << 2
+        dc["is_luma"], dc["bi"] = 0, 1
+        self.mc_luma, self.mc_chroma = dl, dc
+
+        # ---- residual / transform tiling (luma) --------------------------------------------------------------
+        rows = []
+        coff = 0
+        sizes = [64, 32, 16, 8, 4]
+        ci = 0
+        for y0 in range(0, height - height % 64, 64):
+            for x0 in range(0, width - width % 64, 64):
+                s = sizes[ci % 5]
+                ci += 1
+                for ty in range(0, 64, s):
+                    for tx in range(0, 64, s):
+                        if s <= 32 and rng.random() < 0.5:
+                            th, tv = [(1, 1), (1, 2), (2, 1), (2, 2)][int(rng.integers(0, 4))]
+                        else:
+                            th, tv = 0, 0
+                        rows.append(((y0 + ty) * width + x0 + tx, coff, width, s, s, th, tv, 0, 0))
+                        coff += s * s
+        self.tr = np.array(rows, dtype=TR_DESC)
+        self.n_coef = coff
+        # plane-wide element-wise ops as one descriptor per 128-row band (w,h are int16 fields)
+        def bands(wp, hp):
+            r = []
+            for y0 in range(0, hp, 128):
+                for x0 in range(0, wp, 4096):
+                    r.append((y0 * wp + x0, y0 * wp + x0, y0 * wp + x0, wp, wp, wp, min(4096, wp - x0), min(128, hp - y0)))
+            return np.array(r, dtype=PELOP_DESC)
+        self.bands_luma = bands(width, height)
+        self.bands_chroma = bands(width // 2, height // 2)
+        self.cfg_sub = PelopCfg(0, 0, 0, 0, 0, self.mx)
+        self.cfg_reco = PelopCfg(0, 0, 0, 1, 0, self.mx)
+
+        # ---- deblocking maps: seeded CU grid -----------------------------------------------------------------
+        w4, h4 = width // 4, height // 4
+        cell = rng.choice(np.array([8, 16, 32, 64]), ((height + 63) // 64, (width + 63) // 64))
+        cu = np.repeat(np.repeat(cell, 16, axis=0), 16, axis=1)[:h4, :w4]          # CU size per 4x4 unit
+        ux, uy = np.meshgrid(np.arange(w4) * 4, np.arange(h4) * 4)
+        intra = np.repeat(np.repeat(rng.random(((height + 7) // 8, (width + 7) // 8)) < 0.3, 2, axis=0), 2, axis=1)[:h4, :w4]
+        bs_rand = rng.integers(0, 2, (h4, w4))
+        def edge_map(pos, shift_axis):
+            on = (pos % cu == 0) & (pos > 0)
+            nb = np.roll(intra, 1, axis=shift_axis)
+            either = intra | nb
+            bs = np.where(either, 2, bs_rand)
+            return np.where(on, bs | (np.where(either, 2, 0) << 2), 0).astype(np.uint8)
+        self.edge_ver, self.edge_hor = edge_map(ux, 1), edge_map(uy, 0)
+        self.qp_luma = np.repeat(np.repeat(rng.integers(26, 40, ((height + 7) // 8, (width + 7) // 8)), 2, axis=0), 2, axis=1)[:h4, :w4].astype(np.int8)
+        self.qp_chroma = self.qp_luma.copy()
+        self.dbk_cfg = DeblockCfg(bit_depth, bit_depth, 0, 0, 0, 0, (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(self.mx, self.mx, self.mx))
+
+        # ---- SAO / ALF parameters ----------------------------------------------------------------------------
+        self.nctu_x, self.nctu_y = (width + CTU - 1) // CTU, (height + CTU - 1) // CTU
+        nctu = self.nctu_x * self.nctu_y
+        self.sao = []
+        for comp in range(3):
+            prm = np.zeros(nctu, SAO_DTYPE)
+            prm["type"] = rng.integers(-1, 5, nctu)
+            prm["offset"] = rng.integers(-7, 8, (nctu, 32))
+            ix, iy = np.meshgrid(np.arange(self.nctu_x), np.arange(self.nctu_y))
+            L, R, A, B = ix > 0, ix < self.nctu_x - 1, iy > 0, iy < self.nctu_y - 1
+            av = (L * 1) | (R * 2) | (A * 4) | (B * 8) | ((A & L) * 16) | ((A & R) * 32) | ((B & L) * 64) | ((B & R) * 128)
+            prm["avail"] = av.reshape(-1).astype(np.uint8)
+            self.sao.append(prm)
+        lc = rng.integers(-40, 41, (25, 13)).astype(np.int16)
+        lc[:, 12] = 512 - 2 * lc[:, :12].sum(1)
+        cc = rng.integers(-40, 41, 7).astype(np.int16)
+        cc[6] = 512 - 2 * cc[:6].sum()
+        self.alf_luma_coeff, self.alf_chroma_coeff = lc, cc
+        self.alf_enable = [(rng.random(nctu) < 0.8).astype(np.uint8) for _ in range(3)]
+
+    # ------------------------------------------------------------------------------------------------------
+    def algorithmic_bytes(self):
+        """Algorithmic (compulsory) bytes per stage and per launch group, SURVEY.md §8(d) formulas."""
+        w, h = self.w, self.h
+        P = w * h * 3              # picture bytes (4:2:0, 16-bit samples)
+        Y = w * h * 2
+        out = {}
+        me = {}
+        for s, blk in self.me.items():
+            hs = s // 2
+            for (dx0, dy0, nx, ny, sx, sy) in self.me_grids:
+                Ww, Wh = (nx - 1) * sx + s, (ny - 1) * sy + s
+                me["sad_search_%dx%d_%dx%d" % (s, s, nx, ny)] = blk.size * (Ww * Wh * 2 + s * s * 2 + 4 * nx * ny)
+        out["me"] = me
+        nl = self.mc_luma.size
+        # per PU: two reference windows (W+7)^2 (luma) / (W/2+3)^2 (chroma, x2 components) + the written block
+        out["mc"] = {"mc_luma": nl * (2 * 23 * 23 * 2 + 16 * 16 * 2), "mc_chroma": 2 * nl * (2 * 11 * 11 * 2 + 8 * 8 * 2)}
+        ncoef = self.n_coef
+        out["resi"] = {"subtract": 3 * Y, "tr_fwd": ncoef * 6, "tr_inv": ncoef * 6, "reco": 3 * Y}
+        maps = (w // 4) * (h // 4) * 4
+        out["dbk"] = {"deblock": 2 * P + maps}
+        out["sao"] = {"sao_stats": 2 * P + self.nctu_x * self.nctu_y * 3 * 2560, "sao_apply": 2 * P}
+        nctu = self.nctu_x * self.nctu_y
+        out["alf"] = {"alf_classify": Y + Y // 16, "alf_stats": (2 * Y + Y // 16) * 2 + 2 * (P - Y) + nctu * 25 * (183 + 57) * 8 + nctu * 2 * 57 * 8,
+                      "alf_filter": 2 * P + Y // 16}
+        return out
+
+    # ------------------------------------------------------------------------------------------------------
+    def run_gpu(self, dev_state=None, timer=None):
+        """One step on the GPU through ops/C-ABI.  Returns (state, outputs dict of CUDA tensors)."""
+        import torch
+        from . import ops
+        T = timer or (lambda name: _NullCtx())
+        st = dev_state
+        if st is None:
+            d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            st = {"org": [d(p) for p in self.org], "ref0": [d(p) for p in self.ref0_pad], "ref1": [d(p) for p in self.ref1_pad],
+                  "me_blk": {s: ops.struct_to_device(b) for s, b in self.me.items()},
+                  "mc_luma": ops.struct_to_device(self.mc_luma), "mc_chroma": ops.struct_to_device(self.mc_chroma),
+                  "tr": ops.struct_to_device(self.tr), "bands_luma": ops.struct_to_device(self.bands_luma),
+                  "bands_chroma": ops.struct_to_device(self.bands_chroma),
+                  "edge_ver": d(self.edge_ver), "edge_hor": d(self.edge_hor), "qp_luma": d(self.qp_luma), "qp_chroma": d(self.qp_chroma),
+                  "sao": [ops.sao_params_to_device(p) for p in self.sao], "alf_en": [d(e) for e in self.alf_enable]}
+            e16 = lambda hh, ww: torch.empty((hh, ww), dtype=torch.int16, device="cuda")
+            w, h = self.w, self.h
+            st["pred"] = [e16(h, w), e16(h // 2, w // 2), e16(h // 2, w // 2)]
+            st["resi"] = e16(h, w)
+            st["resi2"] = torch.zeros((h, w), dtype=torch.int16, device="cuda")   # rows below the last 64-multiple stay 0
+            st["coef"] = torch.empty(self.n_coef, dtype=torch.int32, device="cuda")
+            st["rec"] = [e16(h, w), e16(h // 2, w // 2), e16(h // 2, w // 2)]
+            st["sao_out"] = [e16(h, w), e16(h // 2, w // 2), e16(h // 2, w // 2)]
+            st["alf_out"] = [e16(h, w), e16(h // 2, w // 2), e16(h // 2, w // 2)]
+        out = {}
+        bd, mx = self.bd, self.mx
+        cfg_mv = ops.MvCost(self.mvcost.lambda_, self.mvcost.pred_hor, self.mvcost.pred_ver, self.mvcost.cost_scale, self.mvcost.imv_shift)
+        # ---- me
+        for s in sorted(self.me):
+            for (dx0, dy0, nx, ny, sx, sy) in self.me_grids:
+                with T("me/sad_search_%dx%d_%dx%d" % (s, s, nx, ny)):
+                    sad, best = ops.sad_search(st["org"][0], st["ref0"][0], st["me_blk"][s], self.me[s].size, s, s, 1,
+                                               dx0, dy0, nx, ny, sx, sy, cfg_mv)
+                out["me_sad_%d_%d" % (s, nx)] = sad
+                out["me_best_%d_%d" % (s, nx)] = best
+        # ---- mc
+        with T("mc/mc_luma"):
+            ops.mc_batch(st["ref0"][0], st["ref1"][0], st["pred"][0], st["mc_luma"], self.mc_luma.size, bd, (0, mx))
+        with T("mc/mc_chroma"):
+            ops.mc_batch(st["ref0"][1], st["ref1"][1], st["pred"][1], st["mc_chroma"], self.mc_chroma.size, bd, (0, mx))
+            ops.mc_batch(st["ref0"][2], st["ref1"][2], st["pred"][2], st["mc_chroma"], self.mc_chroma.size, bd, (0, mx))
+        # ---- residual / transforms / reconstruction
+        sub = ops.PelopCfg(0, 0, 0, 0, 0, mx)
+        rec_cfg = ops.PelopCfg(0, 0, 0, 1, 0, mx)
+        with T("resi/subtract"):
+            ops.pelop_batch(3, st["org"][0], st["pred"][0], st["resi"], st["bands_luma"], self.bands_luma.size, sub)
+        with T("resi/tr_fwd"):
+            ops.tr_fwd_batch(st["resi"], st["coef"], st["tr"], self.tr.size, bd)
+        with T("resi/quant_standin"):
+            st["coef"].bitwise_right_shift_(4).bitwise_left_shift_(4)
+        with T("resi/tr_inv"):
+            ops.tr_inv_batch(st["coef"], st["resi2"], st["tr"], self.tr.size, bd)
+        with T("resi/reco"):
+            ops.pelop_batch(1, st["pred"][0], st["resi2"], st["rec"][0], st["bands_luma"], self.bands_luma.size, rec_cfg)
+            st["rec"][1].copy_(st["pred"][1])
+            st["rec"][2].copy_(st["pred"][2])
+        out["coef"] = st["coef"]
+        # ---- deblock (in place on rec)
+        dcfg = ops.deblock_cfg(bd)
+        with T("dbk/deblock"):
+            ops.deblock(st["rec"][0], st["rec"][1], st["rec"][2], st["edge_ver"], st["edge_hor"], st["qp_luma"], st["qp_chroma"], dcfg)
+        # ---- SAO
+        sao_stats = []
+        with T("sao/sao_stats"):
+            for c in range(3):
+                cs = CTU if c == 0 else CTU // 2
+                sao_stats.append(ops.sao_stats(st["org"][c], st["rec"][c], cs, cs, bd, None, 5 if c == 0 else 3, 4 if c == 0 else 2))
+        with T("sao/sao_apply"):
+            for c in range(3):
+                cs = CTU if c == 0 else CTU // 2
+                ops.sao_apply(st["rec"][c], st["sao_out"][c], cs, cs, bd, st["sao"][c], (0, mx))
+        out["sao_stats"] = sao_stats
+        # ---- ALF
+        with T("alf/alf_classify"):
+            cls = ops.alf_classify(st["sao_out"][0], bd)
+        with T("alf/alf_stats"):
+            a7 = ops.alf_stats(st["org"][0], st["sao_out"][0], CTU, cls, 1)
+            a5 = ops.alf_stats(st["org"][0], st["sao_out"][0], CTU, cls, 0)
+            ac = [ops.alf_stats(st["org"][c], st["sao_out"][c], CTU // 2, None, 0) for c in (1, 2)]
+        with T("alf/alf_filter"):
+            ops.alf_filter_luma(st["sao_out"][0], st["alf_out"][0], CTU, cls, 1, self.alf_luma_coeff, st["alf_en"][0], (0, mx))
+            for c in (1, 2):
+                ops.alf_filter_chroma(st["sao_out"][c], st["alf_out"][c], CTU // 2, self.alf_chroma_coeff, st["alf_en"][c], (0, mx))
+        out.update({"cls": cls, "alf_stats7": a7, "alf_stats5": a5, "alf_stats_c": ac, "final": st["alf_out"], "pred": st["pred"]})
+        return st, out
+
+    # ------------------------------------------------------------------------------------------------------
+    def run_cpu(self, lib, kind="port"):
+        """One step on the host through a checker library.  kind 'port': oracle/liboracle.so (orc_* names);
+        kind 'reference': oracle/_ref/libvtmref.so for every stage that has a reference entry point (deblocking and the
+        element-wise plane ops have none and use `port_lib`).  Returns (outputs dict of numpy arrays, seconds per stage)."""
+        P = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
+        port, refl = (lib, None) if kind == "port" else (lib[0], lib[1])
+        w, h, bd, mx = self.w, self.h, self.bd, self.mx
+        out, secs = {}, {}
+
+        def timed(name, fn):
+            t0 = time.perf_counter()
+            fn()
+            secs[name] = secs.get(name, 0.0) + time.perf_counter() - t0
+        # me
+        for s in sorted(self.me):
+            blk = self.me[s]
+            for (dx0, dy0, nx, ny, sx, sy) in self.me_grids:
+                sad = np.zeros((blk.size, ny, nx), np.uint32)
+                best = np.zeros(blk.size, SEARCH_BEST)
+                if refl is not None:
+                    timed("me", lambda: refl.vtmref_sad_search(P(self.org[0]), w, P(self.ref0_pad[0]), self.pw, P(blk), blk.size, s, s, 1,
+                                                                dx0, dy0, nx, ny, sx, sy, bd, P(sad)))
+                    best = None
+                else:
+                    timed("me", lambda: port.orc_sad_search(P(self.org[0]), w, P(self.ref0_pad[0]), self.pw, P(blk), blk.size, s, s, 1,
+                                                             dx0, dy0, nx, ny, sx, sy, P(sad), C.byref(self.mvcost), P(best)))
+                out["me_sad_%d_%d" % (s, nx)] = sad
+                out["me_best_%d_%d" % (s, nx)] = best
+        # mc
+        pred = [np.zeros((h, w), np.int16), np.zeros((h // 2, w // 2), np.int16), np.zeros((h // 2, w // 2), np.int16)]
+        f_mc = (lambda *a: refl.vtmref_mc_batch(*a)) if refl is not None else (lambda *a: port.orc_mc_batch(*a))
+        timed("mc", lambda: f_mc(P(self.ref0_pad[0]), P(self.ref1_pad[0]), P(pred[0]), P(self.mc_luma), self.mc_luma.size, bd, 0, mx))
+        for c in (1, 2):
+            timed("mc", lambda: f_mc(P(self.ref0_pad[c]), P(self.ref1_pad[c]), P(pred[c]), P(self.mc_chroma), self.mc_chroma.size, bd, 0, mx))
+        # residual / transform
+        resi = np.zeros((h, w), np.int16)
+        resi2 = np.zeros((h, w), np.int16)
+        coef = np.zeros(self.n_coef, np.int32)
+        timed("resi", lambda: port.orc_pelop_batch(3, P(self.org[0]), P(pred[0]), P(resi), P(self.bands_luma), self.bands_luma.size, C.byref(self.cfg_sub)))
+        if refl is not None:
+            timed("resi", lambda: refl.vtmref_tr_fwd_batch(P(resi), P(coef), P(self.tr), self.tr.size, bd))
+        else:
+            timed("resi", lambda: port.orc_tr_fwd_batch(P(resi), P(coef), P(self.tr), self.tr.size, bd))
+        coef[:] = (coef >> 4) << 4
+        if refl is not None:
+            timed("resi", lambda: refl.vtmref_tr_inv_batch(P(coef), P(resi2), P(self.tr), self.tr.size, bd))
+        else:
+            timed("resi", lambda: port.orc_tr_inv_batch(P(coef), P(resi2), P(self.tr), self.tr.size, bd))
+        rec = [np.zeros((h, w), np.int16), pred[1].copy(), pred[2].copy()]
+        timed("resi", lambda: port.orc_pelop_batch(1, P(pred[0]), P(resi2), P(rec[0]), P(self.bands_luma), self.bands_luma.size, C.byref(self.cfg_reco)))
+        out["coef"] = coef
+        # deblock (no reference entry point: port)
+        timed("dbk", lambda: port.orc_deblock(P(rec[0]), w, P(rec[1]), P(rec[2]), w // 2, w, h, P(self.edge_ver), P(self.edge_hor),
+                                              P(self.qp_luma), P(self.qp_chroma), C.byref(self.dbk_cfg)))
+        # sao
+        sao_stats, sao_out = [], []
+        for c in range(3):
+            cs = CTU if c == 0 else CTU // 2
+            pw_, ph_ = (w, h) if c == 0 else (w // 2, h // 2)
+            stt = np.zeros((self.nctu_x * self.nctu_y, 5, 2, 32), np.int64)
+            if refl is not None:
+                timed("sao", lambda: refl.vtmref_sao_stats(c, P(self.org[c]), pw_, P(rec[c]), pw_, pw_, ph_, cs, cs, bd, None, 5 if c == 0 else 3, 4 if c == 0 else 2, P(stt)))
+            else:
+                timed("sao", lambda: port.orc_sao_stats(P(self.org[c]), pw_, P(rec[c]), pw_, pw_, ph_, cs, cs, bd, None, 5 if c == 0 else 3, 4 if c == 0 else 2, P(stt)))
+            sao_stats.append(stt)
+            so = rec[c].copy()
+            f = refl.vtmref_sao_apply if refl is not None else port.orc_sao_apply
+            timed("sao", lambda: f(P(rec[c]), pw_, P(so), pw_, pw_, ph_, cs, cs, bd, P(self.sao[c]), 0, mx))
+            sao_out.append(so)
+        out["sao_stats"] = sao_stats
+        # alf
+        cls = np.zeros((h // 4, w // 4), np.uint16)
+        alf_out = [p.copy() for p in sao_out]
+        if refl is not None:
+            timed("alf", lambda: refl.vtmref_alf_picture(1, P(sao_out[0]), P(sao_out[1]), P(sao_out[2]), P(alf_out[0]), P(alf_out[1]), P(alf_out[2]),
+                                                         w, h, CTU, bd, 1, P(self.alf_luma_coeff), P(self.alf_chroma_coeff),
+                                                         P(self.alf_enable[0]), P(self.alf_enable[1]), P(self.alf_enable[2]), None))
+            timed("alf", lambda: port.orc_alf_classify(P(sao_out[0]), w, w, h, bd, P(cls)))   # picture-wide classifier for the stats
+        else:
+            timed("alf", lambda: port.orc_alf_classify(P(sao_out[0]), w, w, h, bd, P(cls)))
+            timed("alf", lambda: port.orc_alf_filter_luma(P(sao_out[0]), w, P(alf_out[0]), w, w, h, CTU, P(cls), 1, P(self.alf_luma_coeff), P(self.alf_enable[0]), 0, mx))
+            for c in (1, 2):
+                timed("alf", lambda: port.orc_alf_filter_chroma(P(sao_out[c]), w // 2, P(alf_out[c]), w // 2, w // 2, h // 2, CTU // 2, P(self.alf_chroma_coeff), P(self.alf_enable[c]), 0, mx))
+        nct = self.nctu_x * self.nctu_y
+        a7 = np.zeros((nct, 25, 183), np.int64)
+        a5 = np.zeros((nct, 25, 57), np.int64)
+        ac = [np.zeros((nct, 1, 57), np.int64) for _ in range(2)]
+        if refl is not None:
+            timed("alf", lambda: refl.vtmref_alf_stats(P(self.org[0]), w, P(sao_out[0]), w, h, CTU, P(cls), 1, P(a7)))
+            timed("alf", lambda: refl.vtmref_alf_stats(P(self.org[0]), w, P(sao_out[0]), w, h, CTU, P(cls), 0, P(a5)))
+            for i, c in enumerate((1, 2)):
+                timed("alf", lambda: refl.vtmref_alf_stats(P(self.org[c]), w // 2, P(sao_out[c]), w // 2, h // 2, CTU // 2, None, 0, P(ac[i])))
+        else:
+            timed("alf", lambda: port.orc_alf_stats(P(self.org[0]), w, P(sao_out[0]), w, w, h, CTU, P(cls), 1, P(a7)))
+            timed("alf", lambda: port.orc_alf_stats(P(self.org[0]), w, P(sao_out[0]), w, w, h, CTU, P(cls), 0, P(a5)))
+            for i, c in enumerate((1, 2)):
+                timed("alf", lambda: port.orc_alf_stats(P(self.org[c]), w // 2, P(sao_out[c]), w // 2, w // 2, h // 2, CTU // 2, None, 0, P(ac[i])))
+        out.update({"cls": cls, "alf_stats7": a7, "alf_stats5": a5, "alf_stats_c": ac, "final": alf_out, "pred": pred})
+        return out, secs
+
+
+class _NullCtx:
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *a):
+        return False
