@@ -43,7 +43,7 @@ def test_workload_matches_oracle_416x240():
 def test_workload_properties_1080p():
     from vvcsoftware_vtm_amd.workload import Workload
     from vvcsoftware_vtm_amd import ops
-    wl = Workload(1920, 1080, 10, seed=5, raster_range=20, me_sizes=(32,))
+    wl = Workload(1920, 1080, 10, seed=5, raster_range=40, me_sizes=(32,))
     st, out = wl.run_gpu()
     torch.cuda.synchronize()
     org = wl.org

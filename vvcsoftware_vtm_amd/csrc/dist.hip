@@ -132,11 +132,14 @@ __global__ __launch_bounds__(256) void dist_batch_kernel(int kind, const Pel* __
 
 // ---------------------------------------------------------------------------------------------------
 // SAD search surface
-__global__ __launch_bounds__(256) void sad_search_kernel(const Pel* __restrict__ org, int os,
+constexpr int SS_THREADS = 512;
+
+__global__ __launch_bounds__(SS_THREADS) void sad_search_kernel(const Pel* __restrict__ org, int os,
                                                          const Pel* __restrict__ ref, int rs,
                                                          const vvcgpu_search_blk* __restrict__ blocks, int w, int h,
                                                          int subShift, int dx0, int dy0, int nx, int ny, int sx, int sy,
-                                                         int rowsPerStrip, int colsPerStrip, int pitchDw, unsigned* __restrict__ out)
+                                                         int rowsPerStrip, int colsPerStrip, int pitchDw, int split,
+                                                         unsigned* __restrict__ out)
 {
   extern __shared__ __align__(16) unsigned lds[];
   const int tid = threadIdx.x;
@@ -153,47 +156,80 @@ __global__ __launch_bounds__(256) void sad_search_kernel(const Pel* __restrict__
   unsigned* refO = refE + winRows * pitchDw;
 
   const Pel* o = org + (size_t)blk.org_y * os + blk.org_x;
-  for (int i = tid; i < hs * wp; i += 256)
+  for (int i = tid; i < hs * wp; i += SS_THREADS)
   {
     const int r = i / wp, k = i - r * wp;
     const Pel* q = o + (size_t)(r << subShift) * os + 2 * k;
     orgL[i] = ((unsigned)(unsigned short)q[0] | ((unsigned)(unsigned short)q[1] << 16)) ^ 0x80008000u;
   }
-  const Pel* win = ref + (size_t)(blk.ref_y + dy0 + j0 * sy) * rs + blk.ref_x + dx0 + i0 * sx;
-  for (int i = tid; i < winRows * pitchDw; i += 256)
+  // Window fill.  Fast path: the plane is dword-addressable (even stride, 4-byte aligned base): one aligned global dword
+  // per staged pair, the second alignment is produced with a funnel shift instead of being loaded again.
+  const ptrdiff_t winOff = (ptrdiff_t)(blk.ref_y + dy0 + j0 * sy) * rs + blk.ref_x + dx0 + i0 * sx;
+  const bool fast = ((rs & 1) == 0) && ((reinterpret_cast<uintptr_t>(ref) & 3) == 0);
+  if (fast)
   {
-    const int r = i / pitchDw, k = i - r * pitchDw;
-    const Pel* row = win + (size_t)r * rs;
-    const int x0 = min(2 * k, Ww - 1), x1 = min(2 * k + 1, Ww - 1), x2 = min(2 * k + 2, Ww - 1);
-    const unsigned p0 = (unsigned short)row[x0], p1 = (unsigned short)row[x1], p2 = (unsigned short)row[x2];
-    refE[i] = (p0 | (p1 << 16)) ^ 0x80008000u;
-    refO[i] = (p1 | (p2 << 16)) ^ 0x80008000u;
+    const int odd = (int)(winOff & 1);
+    const unsigned* g = reinterpret_cast<const unsigned*>(ref + (winOff - odd));      // aligned pair that holds sample 0
+    const int rsDw = rs >> 1;
+    const int nPairs = ((Ww - 1 + odd) >> 1) + 1;         // aligned pairs that cover samples [0, Ww-1] (never load a dword without a window sample)
+    for (int i = tid; i < winRows * pitchDw; i += SS_THREADS)
+    {
+      const int r = i / pitchDw, k = i - r * pitchDw;
+      const unsigned* gr = g + (ptrdiff_t)r * rsDw;
+      const unsigned g0 = gr[min(k, nPairs - 1)], g1 = gr[min(k + 1, nPairs - 1)];
+      const unsigned sh = __builtin_amdgcn_alignbit(g1, g0, 16);       // (hi16 of g0, lo16 of g1)
+      refE[i] = (odd ? sh : g0) ^ 0x80008000u;
+      refO[i] = (odd ? g1 : sh) ^ 0x80008000u;
+    }
+  }
+  else
+  {
+    const Pel* win = ref + winOff;
+    for (int i = tid; i < winRows * pitchDw; i += SS_THREADS)
+    {
+      const int r = i / pitchDw, k = i - r * pitchDw;
+      const Pel* row = win + (size_t)r * rs;
+      const int x0 = min(2 * k, Ww - 1), x1 = min(2 * k + 1, Ww - 1), x2 = min(2 * k + 2, Ww - 1);
+      const unsigned p0 = (unsigned short)row[x0], p1 = (unsigned short)row[x1], p2 = (unsigned short)row[x2];
+      refE[i] = (p0 | (p1 << 16)) ^ 0x80008000u;
+      refO[i] = (p1 | (p2 << 16)) ^ 0x80008000u;
+    }
   }
   __syncthreads();
 
-  for (int p = tid; p < nj * ni; p += 256)
+  // task = (position, row class): `split` adjacent lanes share one position and take rows r = s, s+split, ...
+  const int nTasks = nj * ni * split;
+  const int sMask = split - 1;
+  const int sLog = 31 - __clz(split);
+  for (int t = tid; t < ((nTasks + 63) & ~63); t += SS_THREADS)
   {
+    const bool live = t < nTasks;
+    const int p = min(t, nTasks - 1) >> sLog, s = t & sMask;
     const int jj = p / ni, i = p - jj * ni;
     const int cx = i * sx;
     const unsigned* base = ((cx & 1) ? refO : refE) + (cx >> 1) + (jj * sy) * pitchDw;
     unsigned acc = 0;
-    for (int r = 0; r < hs; r++)
+    for (int r = s; r < hs; r += split)
     {
       const unsigned* rp = base + (r << subShift) * pitchDw;
       const unsigned* op = orgL + r * wp;
       int k = 0;
       if ((wp & 3) == 0)                       // 16-byte aligned org rows -> 128-bit broadcast reads
-      for (; k + 4 <= wp; k += 4)
       {
-        const uint4 ov = *reinterpret_cast<const uint4*>(op + k);        // broadcast read (same address in all lanes)
-        acc = __builtin_amdgcn_sad_u16(ov.x, rp[k], acc);
-        acc = __builtin_amdgcn_sad_u16(ov.y, rp[k + 1], acc);
-        acc = __builtin_amdgcn_sad_u16(ov.z, rp[k + 2], acc);
-        acc = __builtin_amdgcn_sad_u16(ov.w, rp[k + 3], acc);
+#pragma unroll 2
+        for (; k + 4 <= wp; k += 4)
+        {
+          const uint4 ov = *reinterpret_cast<const uint4*>(op + k);
+          acc = __builtin_amdgcn_sad_u16(ov.x, rp[k], acc);
+          acc = __builtin_amdgcn_sad_u16(ov.y, rp[k + 1], acc);
+          acc = __builtin_amdgcn_sad_u16(ov.z, rp[k + 2], acc);
+          acc = __builtin_amdgcn_sad_u16(ov.w, rp[k + 3], acc);
+        }
       }
       for (; k < wp; k++) acc = __builtin_amdgcn_sad_u16(op[k], rp[k], acc);
     }
-    out[((size_t)b * ny + j0 + jj) * nx + i0 + i] = acc << subShift;
+    for (int o2 = 1; o2 < split; o2 <<= 1) acc += __shfl_xor(acc, o2);
+    if (live && s == 0) out[((size_t)b * ny + j0 + jj) * nx + i0 + i] = acc << subShift;
   }
 }
 
@@ -272,25 +308,31 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
   VVC_CHECK_ARG((best == nullptr) == (mvcost_host == nullptr), "sad_search: best and mvcost must be given together");
   const int hs = h >> sub_shift;
   const size_t orgDw = ((size_t)hs * (w / 2) + 3) & ~(size_t)3;
-  const size_t budget = 60 * 1024;
-  // split the position grid into strips (rows first, then columns) until the staged window fits the LDS budget
+  // Split the position grid into strips (rows first, then columns) until the staged window fits the LDS budget that still
+  // lets two workgroups share a CU; then split each position over `split` lanes so that a strip fills the workgroup.
+  const size_t budget = 72 * 1024;
   int rowsPerStrip = ny, colsPerStrip = nx;
   auto lds_bytes = [&](int rps, int cps) {
     const size_t winRows = (size_t)(rps - 1) * sy + h;
-    const size_t pitch = (size_t)((cps - 1) * sx + w + 2) / 2 + 1;
+    const size_t pitch = (size_t)((cps - 1) * sx + w + 2) / 2 + 2;
     return (orgDw + 2 * winRows * pitch) * 4;
   };
   while (lds_bytes(rowsPerStrip, colsPerStrip) > budget && rowsPerStrip > 1) rowsPerStrip = (rowsPerStrip + 1) / 2;
   while (lds_bytes(rowsPerStrip, colsPerStrip) > budget && colsPerStrip > 1) colsPerStrip = (colsPerStrip + 1) / 2;
-  const int pitchDw = ((colsPerStrip - 1) * sx + w + 2) / 2 + 1;   // pairs per row (+1: rows do not alias banks exactly)
+  // even out the strips (e.g. 39 rows with a limit of 10 -> 4 strips of 10,10,10,9)
+  rowsPerStrip = cdiv(ny, cdiv(ny, rowsPerStrip));
+  colsPerStrip = cdiv(nx, cdiv(nx, colsPerStrip));
+  const int pitchDw = ((colsPerStrip - 1) * sx + w + 2) / 2 + 2;   // pairs per row (+ slack so rows do not alias banks exactly)
   const size_t smem = lds_bytes(rowsPerStrip, colsPerStrip);
   VVC_CHECK_ARG(smem <= 160 * 1024, "sad_search: a single position's window (%d x %d) does not fit LDS", w, h);
+  int split = 1;
+  while (split < 8 && split * 2 <= hs && rowsPerStrip * colsPerStrip * split * 2 <= SS_THREADS + SS_THREADS / 4) split *= 2;
   hipStream_t st = (hipStream_t)stream;
   if (smem > 64 * 1024)
     VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   dim3 grid(nblocks, cdiv(ny, rowsPerStrip), cdiv(nx, colsPerStrip));
-  hipLaunchKernelGGL(sad_search_kernel, grid, dim3(256), smem, st, org, org_stride, ref, ref_stride, blocks, w, h,
-                     sub_shift, dx0, dy0, nx, ny, sx, sy, rowsPerStrip, colsPerStrip, pitchDw, sad_out);
+  hipLaunchKernelGGL(sad_search_kernel, grid, dim3(SS_THREADS), smem, st, org, org_stride, ref, ref_stride, blocks, w, h,
+                     sub_shift, dx0, dy0, nx, ny, sx, sy, rowsPerStrip, colsPerStrip, pitchDw, split, sad_out);
   VVC_LAUNCH_CHECK();
   if (best)
   {

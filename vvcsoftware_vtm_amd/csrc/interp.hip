@@ -203,34 +203,56 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
 }
 
 // ------------------------------------------------------------------------------------------------ B1-B4
+__device__ __forceinline__ int pelop_apply(int op, int a, int b, const vvcgpu_pelop_cfg& c)
+{
+  switch (op)
+  {
+  case 0: return clip3(c.clp_min, c.clp_max, (a + b + c.offset) >> c.shift);
+  case 1: return clip3(c.clp_min, c.clp_max, a + b);
+  case 2: { const int t = (c.shift >= 0 ? (c.scale * a) >> c.shift : (c.scale * a) << -c.shift) + c.offset;
+            return c.clip ? clip3(c.clp_min, c.clp_max, t) : t; }
+  case 3: return a - b;
+  case 4: return c.clip ? clip3(c.clp_min, c.clp_max, 2 * a - b) : 2 * a - b;
+  default: return clip3(c.clp_min, c.clp_max, a);
+  }
+}
+
+// One workgroup per descriptor (the reference calls these per CU: up to 128x128 samples); rows are split over the
+// waves, each lane moves 8 samples (16 bytes) per access when the three operands allow it.
 __global__ __launch_bounds__(256) void pelop_batch_kernel(int op, const Pel* __restrict__ s0Base, const Pel* __restrict__ s1Base,
                                                           Pel* dstBase, const vvcgpu_pelop_desc* __restrict__ descs, int n,
                                                           vvcgpu_pelop_cfg c)
 {
-  const int lane = threadIdx.x & 63;
-  const int di = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (di >= n) return;
-  const vvcgpu_pelop_desc d = descs[di];
+  const int tid = threadIdx.x;
+  const vvcgpu_pelop_desc d = descs[blockIdx.x];
   const Pel* s0 = s0Base + d.src0_off;
   const Pel* s1 = s1Base ? s1Base + d.src1_off : nullptr;
   Pel* dst = dstBase + d.dst_off;
-  for (int i = lane; i < d.w * d.h; i += 64)
+  const bool vec = ((d.w & 7) == 0) && ((d.src0_stride & 7) == 0) && ((d.dst_stride & 7) == 0) &&
+                   ((reinterpret_cast<uintptr_t>(s0) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) &&
+                   (!s1 || (((d.src1_stride & 7) == 0) && ((reinterpret_cast<uintptr_t>(s1) & 15) == 0)));
+  if (vec)
+  {
+    const int wv = d.w >> 3;
+    for (int i = tid; i < wv * d.h; i += 256)
+    {
+      const int y = i / wv, x = (i - y * wv) << 3;
+      const pel8 a = *reinterpret_cast<const pel8*>(s0 + (size_t)y * d.src0_stride + x);
+      pel8 b = { 0, 0, 0, 0, 0, 0, 0, 0 };
+      if (s1) b = *reinterpret_cast<const pel8*>(s1 + (size_t)y * d.src1_stride + x);
+      pel8 r;
+#pragma unroll
+      for (int k = 0; k < 8; k++) r[k] = (short)pelop_apply(op, a[k], b[k], c);
+      *reinterpret_cast<pel8*>(dst + (size_t)y * d.dst_stride + x) = r;
+    }
+    return;
+  }
+  for (int i = tid; i < d.w * d.h; i += 256)
   {
     const int y = i / d.w, x = i - y * d.w;
     const int a = s0[(size_t)y * d.src0_stride + x];
     const int b = s1 ? s1[(size_t)y * d.src1_stride + x] : 0;
-    int v;
-    switch (op)
-    {
-    case 0: v = clip3(c.clp_min, c.clp_max, (a + b + c.offset) >> c.shift); break;
-    case 1: v = clip3(c.clp_min, c.clp_max, a + b); break;
-    case 2: { const int t = (c.shift >= 0 ? (c.scale * a) >> c.shift : (c.scale * a) << -c.shift) + c.offset;
-              v = c.clip ? clip3(c.clp_min, c.clp_max, t) : t; } break;
-    case 3: v = a - b; break;
-    case 4: v = c.clip ? clip3(c.clp_min, c.clp_max, 2 * a - b) : 2 * a - b; break;
-    default: v = clip3(c.clp_min, c.clp_max, a); break;
-    }
-    dst[(size_t)y * d.dst_stride + x] = (short)v;
+    dst[(size_t)y * d.dst_stride + x] = (short)pelop_apply(op, a, b, c);
   }
 }
 
@@ -272,7 +294,7 @@ int vvcgpu_pelop_batch(int op, const vvc_pel* src0_base, const vvc_pel* src1_bas
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(src0_base && dst_base && descs && cfg_host, "pelop_batch: null pointer");
   VVC_CHECK_ARG(src1_base || op == 2 || op == 5, "pelop_batch: op %d needs src1", op);
-  hipLaunchKernelGGL(pelop_batch_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, op, src0_base, src1_base,
+  hipLaunchKernelGGL(pelop_batch_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, op, src0_base, src1_base,
                      dst_base, descs, n, *cfg_host);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;

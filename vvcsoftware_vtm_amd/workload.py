@@ -143,12 +143,12 @@ class Workload:
                         coff += s * s
         self.tr = np.array(rows, dtype=TR_DESC)
         self.n_coef = coff
-        # plane-wide element-wise ops as one descriptor per 128-row band (w,h are int16 fields)
+        # plane-wide element-wise ops as one descriptor per CTU (the reference calls them per CU, <= 128x128)
         def bands(wp, hp):
             r = []
             for y0 in range(0, hp, 128):
-                for x0 in range(0, wp, 4096):
-                    r.append((y0 * wp + x0, y0 * wp + x0, y0 * wp + x0, wp, wp, wp, min(4096, wp - x0), min(128, hp - y0)))
+                for x0 in range(0, wp, 128):
+                    r.append((y0 * wp + x0, y0 * wp + x0, y0 * wp + x0, wp, wp, wp, min(128, wp - x0), min(128, hp - y0)))
             return np.array(r, dtype=PELOP_DESC)
         self.bands_luma = bands(width, height)
         self.bands_chroma = bands(width // 2, height // 2)
