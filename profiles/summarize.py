@@ -1,0 +1,71 @@
+#!/usr/bin/env python3
+"""Reduce rocprofv3 CSV output (gpurun_out/prof_*) to the per-launch-group summary committed under profiles/.
+
+  python profiles/summarize.py gpurun_out r01
+
+Groups dispatches by (kernel, grid size, LDS bytes) so that the six sad_search launches of one step stay separate; joins
+the FETCH_SIZE / WRITE_SIZE passes (collected in their own runs) by the same key.  FETCH_SIZE/WRITE_SIZE are in KiB;
+on gfx950 FETCH_SIZE under-reports wide coalesced reads by 2x (MI355X_MICROARCH.md, HBM section) -- both the raw and the
+corrected figure are listed."""
+import csv
+import os
+import shutil
+import sys
+from collections import defaultdict
+
+
+def short(name):
+    n = name.replace("(anonymous namespace)::", "")
+    return n.split("(")[0].replace("void ", "")
+
+
+def load_trace(path):
+    g = defaultdict(list)
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            key = (short(r["Kernel_Name"]), int(r["Grid_Size"]) if "Grid_Size" in r else int(r["Grid_Size_X"]) * int(r.get("Grid_Size_Y", 1)) * int(r.get("Grid_Size_Z", 1)),
+                   int(r.get("LDS_Block_Size", 0)))
+            g[key].append(int(r["End_Timestamp"]) - int(r["Start_Timestamp"]))
+    return g
+
+
+def load_pmc(path, counter):
+    g = defaultdict(list)
+    if not os.path.exists(path):
+        return g
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["Counter_Name"] != counter:
+                continue
+            key = (short(r["Kernel_Name"]), int(r["Grid_Size"]), int(r.get("LDS_Block_Size", 0)))
+            g[key].append(float(r["Counter_Value"]))
+    return g
+
+
+def main():
+    src, tag = sys.argv[1], sys.argv[2]
+    here = os.path.dirname(os.path.abspath(__file__))
+    kt = os.path.join(src, "prof_kt")
+    shutil.copy(os.path.join(kt, tag + "_kernel_stats.csv"), os.path.join(here, tag + "_kernel_stats.csv"))
+    tr = load_trace(os.path.join(kt, tag + "_kernel_trace.csv"))
+    fe = load_pmc(os.path.join(src, "prof_fetch", tag + "_counter_collection.csv"), "FETCH_SIZE")
+    wr = load_pmc(os.path.join(src, "prof_write", tag + "_counter_collection.csv"), "WRITE_SIZE")
+    rows = []
+    for key, d in tr.items():
+        f = fe.get(key, [])
+        w = wr.get(key, [])
+        rows.append((sum(d), key, len(d), sum(d) / len(d) / 1e3, (sum(f) / len(f)) if f else None, (sum(w) / len(w)) if w else None))
+    rows.sort(reverse=True)
+    out = os.path.join(here, tag + "_launch_groups.csv")
+    with open(out, "w") as fh:
+        fh.write("kernel,grid_threads,lds_bytes,calls,avg_us,fetch_KiB_raw,fetch_MB_x2_corrected,write_MB\n")
+        for tot, key, n, avg, f, w in rows:
+            fh.write("%s,%d,%d,%d,%.2f,%s,%s,%s\n" % (key[0], key[1], key[2], n, avg,
+                                                       "" if f is None else "%.1f" % f,
+                                                       "" if f is None else "%.2f" % (2 * f * 1024 / 1e6),
+                                                       "" if w is None else "%.2f" % (w * 1024 / 1e6)))
+    print(open(out).read())
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,77 @@
+"""N > 1 host path on CPU (gloo, world_size 2): intra-period sharding, the point-to-point boundary-picture hand-over and
+the gather of per-picture hashes (vvcsoftware_vtm_amd/shard.py).  No GPU, no data-path collective."""
+import os
+import socket
+import sys
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    from vvcsoftware_vtm_amd import shard
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    n_pictures = 160
+    mine = shard.chunk_assignment(n_pictures, world)[rank]
+    hashes = {}
+    g = torch.Generator().manual_seed(100 + rank)
+    last = None
+    for (a, b) in mine:
+        for poc in range(a, b):
+            planes = [torch.full((8, 8), poc, dtype=torch.int16), torch.full((4, 4), poc + 1, dtype=torch.int16)]
+            hashes[poc] = shard.picture_hash(planes)
+            last = planes
+    # hand-over: every rank passes the last reconstructed picture of its chunk to the next rank
+    got = shard.exchange_boundary(last, rank, world)
+    prev_last_poc = shard.chunk_assignment(n_pictures, world)[(rank - 1) % world][-1][1] - 1
+    ok = int(got[0][0, 0]) == prev_last_poc and int(got[1][0, 0]) == prev_last_poc + 1
+    merged = shard.gather_hashes(hashes, world)
+    dist.barrier()
+    if rank == 0:
+        q.put((ok, len(merged), sorted(merged)[:3], sorted(merged)[-1]))
+    else:
+        q.put((ok,))
+    dist.destroy_process_group()
+
+
+def test_chunk_assignment_covers_all_pictures_once():
+    sys.path.insert(0, ROOT)
+    from vvcsoftware_vtm_amd import shard
+    for world in (1, 2, 3, 8):
+        a = shard.chunk_assignment(65, world)
+        pocs = sorted(p for r in a for (s, e) in r for p in range(s, e))
+        assert pocs == list(range(65))
+        # chunks are whole intra periods and round-robin over ranks
+        assert all(s % shard.INTRA_PERIOD == 0 for r in a for (s, e) in r)
+        assert shard.boundary_owner(3, world) == 3 % world
+
+
+def test_two_process_shard_exchange_gather():
+    world = 2
+    port = _free_port()
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    res = [q.get(timeout=120) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assert all(r[0] for r in res)
+    full = [r for r in res if len(r) > 1][0]
+    assert full[1] == 160 and full[2] == [0, 1, 2] and full[3] == 159
