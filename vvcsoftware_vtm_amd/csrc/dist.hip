@@ -134,99 +134,114 @@ __global__ __launch_bounds__(256) void dist_batch_kernel(int kind, const Pel* __
 // SAD search surface
 constexpr int SS_THREADS = 512;
 
+// `groups` sub-workgroups of gsz = SS_THREADS / groups lanes each take one block (small windows: several blocks per
+// workgroup amortise launch / barrier cost); a group stages its own window slice of LDS.
 __global__ __launch_bounds__(SS_THREADS) void sad_search_kernel(const Pel* __restrict__ org, int os,
                                                          const Pel* __restrict__ ref, int rs,
-                                                         const vvcgpu_search_blk* __restrict__ blocks, int w, int h,
+                                                         const vvcgpu_search_blk* __restrict__ blocks, int nblocks, int w, int h,
                                                          int subShift, int dx0, int dy0, int nx, int ny, int sx, int sy,
                                                          int rowsPerStrip, int colsPerStrip, int pitchDw, int split,
-                                                         unsigned* __restrict__ out)
+                                                         int groups, int groupDw, unsigned* __restrict__ out)
 {
-  extern __shared__ __align__(16) unsigned lds[];
-  const int tid = threadIdx.x;
-  const int b = blockIdx.x, j0 = blockIdx.y * rowsPerStrip;
+  extern __shared__ __align__(16) unsigned lds_all[];
+  const int gsz = SS_THREADS / groups;
+  const int grp = threadIdx.x / gsz;
+  const int tid = threadIdx.x - grp * gsz, lane = tid & 63, wave = tid >> 6, nwaves = gsz >> 6;
+  unsigned* lds = lds_all + grp * groupDw;
+  const int b = blockIdx.x * groups + grp, j0 = blockIdx.y * rowsPerStrip;
+  const bool active = b < nblocks;
   const int nj = min(rowsPerStrip, ny - j0);
   const int i0 = blockIdx.z * colsPerStrip;
   const int ni = min(colsPerStrip, nx - i0);
-  const vvcgpu_search_blk blk = blocks[b];
   const int hs = h >> subShift, wp = w >> 1;
   const int winRows = (nj - 1) * sy + h;
   const int Ww = (ni - 1) * sx + w;
-  unsigned* orgL = lds;                              // hs x wp pairs
-  unsigned* refE = lds + ((hs * wp + 3) & ~3);       // winRows x pitchDw
-  unsigned* refO = refE + winRows * pitchDw;
-
-  const Pel* o = org + (size_t)blk.org_y * os + blk.org_x;
-  for (int i = tid; i < hs * wp; i += SS_THREADS)
+  unsigned* orgL = lds;                              // hs x wp pairs (biased)
+  unsigned* refL = lds + ((hs * wp + 3) & ~3);       // winRows x pitchDw ALIGNED pairs of the window (biased)
+  int odd = 0;
+  if (active)
   {
-    const int r = i / wp, k = i - r * wp;
-    const Pel* q = o + (size_t)(r << subShift) * os + 2 * k;
-    orgL[i] = ((unsigned)(unsigned short)q[0] | ((unsigned)(unsigned short)q[1] << 16)) ^ 0x80008000u;
-  }
-  // Window fill.  Fast path: the plane is dword-addressable (even stride, 4-byte aligned base): one aligned global dword
-  // per staged pair, the second alignment is produced with a funnel shift instead of being loaded again.
-  const ptrdiff_t winOff = (ptrdiff_t)(blk.ref_y + dy0 + j0 * sy) * rs + blk.ref_x + dx0 + i0 * sx;
-  const bool fast = ((rs & 1) == 0) && ((reinterpret_cast<uintptr_t>(ref) & 3) == 0);
-  if (fast)
-  {
-    const int odd = (int)(winOff & 1);
-    const unsigned* g = reinterpret_cast<const unsigned*>(ref + (winOff - odd));      // aligned pair that holds sample 0
-    const int rsDw = rs >> 1;
-    const int nPairs = ((Ww - 1 + odd) >> 1) + 1;         // aligned pairs that cover samples [0, Ww-1] (never load a dword without a window sample)
-    for (int i = tid; i < winRows * pitchDw; i += SS_THREADS)
+    const vvcgpu_search_blk blk = blocks[b];
+    const Pel* o = org + (size_t)blk.org_y * os + blk.org_x;
+    for (int k = lane; k < wp; k += 64)
+      for (int r = wave; r < hs; r += nwaves)
+      {
+        const Pel* q = o + (size_t)(r << subShift) * os + 2 * k;
+        orgL[r * wp + k] = ((unsigned)(unsigned short)q[0] | ((unsigned)(unsigned short)q[1] << 16)) ^ 0x80008000u;
+      }
+    // Window fill: ONE copy, as the aligned dword pairs of the plane (sample 0 of the window is the low or the high half
+    // of pair 0, `odd`); a position whose first sample sits in a high half re-pairs on the fly with v_alignbit.
+    const ptrdiff_t winOff = (ptrdiff_t)(blk.ref_y + dy0 + j0 * sy) * rs + blk.ref_x + dx0 + i0 * sx;
+    const bool fast = ((rs & 1) == 0) && ((reinterpret_cast<uintptr_t>(ref) & 3) == 0);
+    odd = fast ? (int)(winOff & 1) : 0;
+    const int nPairs = ((Ww - 1 + odd) >> 1) + 1;    // pairs that hold at least one window sample
+    if (fast)
     {
-      const int r = i / pitchDw, k = i - r * pitchDw;
-      const unsigned* gr = g + (ptrdiff_t)r * rsDw;
-      const unsigned g0 = gr[min(k, nPairs - 1)], g1 = gr[min(k + 1, nPairs - 1)];
-      const unsigned sh = __builtin_amdgcn_alignbit(g1, g0, 16);       // (hi16 of g0, lo16 of g1)
-      refE[i] = (odd ? sh : g0) ^ 0x80008000u;
-      refO[i] = (odd ? g1 : sh) ^ 0x80008000u;
+      const unsigned* g = reinterpret_cast<const unsigned*>(ref + (winOff - odd));
+      const int rsDw = rs >> 1;
+      for (int k = lane; k < pitchDw; k += 64)
+      {
+        const unsigned* gk = g + min(k, nPairs - 1) + (ptrdiff_t)wave * rsDw;
+        unsigned* lk = refL + wave * pitchDw + k;
+        for (int r = wave; r < winRows; r += nwaves, gk += (ptrdiff_t)nwaves * rsDw, lk += nwaves * pitchDw) *lk = *gk ^ 0x80008000u;
+      }
     }
-  }
-  else
-  {
-    const Pel* win = ref + winOff;
-    for (int i = tid; i < winRows * pitchDw; i += SS_THREADS)
+    else
     {
-      const int r = i / pitchDw, k = i - r * pitchDw;
-      const Pel* row = win + (size_t)r * rs;
-      const int x0 = min(2 * k, Ww - 1), x1 = min(2 * k + 1, Ww - 1), x2 = min(2 * k + 2, Ww - 1);
-      const unsigned p0 = (unsigned short)row[x0], p1 = (unsigned short)row[x1], p2 = (unsigned short)row[x2];
-      refE[i] = (p0 | (p1 << 16)) ^ 0x80008000u;
-      refO[i] = (p1 | (p2 << 16)) ^ 0x80008000u;
+      const Pel* win = ref + winOff;
+      for (int r = wave; r < winRows; r += nwaves)
+      {
+        const Pel* row = win + (ptrdiff_t)r * rs;
+        for (int k = lane; k < pitchDw; k += 64)
+        {
+          const unsigned p0 = (unsigned short)row[min(2 * k, Ww - 1)], p1 = (unsigned short)row[min(2 * k + 1, Ww - 1)];
+          refL[r * pitchDw + k] = (p0 | (p1 << 16)) ^ 0x80008000u;
+        }
+      }
     }
   }
   __syncthreads();
+  if (!active) return;
 
   // task = (position, row class): `split` adjacent lanes share one position and take rows r = s, s+split, ...
   const int nTasks = nj * ni * split;
   const int sMask = split - 1;
   const int sLog = 31 - __clz(split);
-  for (int t = tid; t < ((nTasks + 63) & ~63); t += SS_THREADS)
+  for (int t = tid; t < ((nTasks + 63) & ~63); t += gsz)
   {
     const bool live = t < nTasks;
     const int p = min(t, nTasks - 1) >> sLog, s = t & sMask;
     const int jj = p / ni, i = p - jj * ni;
-    const int cx = i * sx;
-    const unsigned* base = ((cx & 1) ? refO : refE) + (cx >> 1) + (jj * sy) * pitchDw;
+    const int cx = i * sx + odd;                        // first sample, counted from the low half of pair 0
+    const unsigned sh = (cx & 1) << 4;                   // 0: pairs are aligned; 16: re-pair (hi of g0, lo of g1)
+    const unsigned* base = refL + (cx >> 1) + (jj * sy) * pitchDw;
     unsigned acc = 0;
     for (int r = s; r < hs; r += split)
     {
       const unsigned* rp = base + (r << subShift) * pitchDw;
       const unsigned* op = orgL + r * wp;
+      unsigned g0 = rp[0];
       int k = 0;
-      if ((wp & 3) == 0)                       // 16-byte aligned org rows -> 128-bit broadcast reads
+      if ((wp & 3) == 0)                                 // 16-byte aligned org rows -> 128-bit broadcast reads
       {
 #pragma unroll 2
         for (; k + 4 <= wp; k += 4)
         {
           const uint4 ov = *reinterpret_cast<const uint4*>(op + k);
-          acc = __builtin_amdgcn_sad_u16(ov.x, rp[k], acc);
-          acc = __builtin_amdgcn_sad_u16(ov.y, rp[k + 1], acc);
-          acc = __builtin_amdgcn_sad_u16(ov.z, rp[k + 2], acc);
-          acc = __builtin_amdgcn_sad_u16(ov.w, rp[k + 3], acc);
+          const unsigned g1 = rp[k + 1], g2 = rp[k + 2], g3 = rp[k + 3], g4 = rp[k + 4];
+          acc = __builtin_amdgcn_sad_u16(ov.x, __builtin_amdgcn_alignbit(g1, g0, sh), acc);
+          acc = __builtin_amdgcn_sad_u16(ov.y, __builtin_amdgcn_alignbit(g2, g1, sh), acc);
+          acc = __builtin_amdgcn_sad_u16(ov.z, __builtin_amdgcn_alignbit(g3, g2, sh), acc);
+          acc = __builtin_amdgcn_sad_u16(ov.w, __builtin_amdgcn_alignbit(g4, g3, sh), acc);
+          g0 = g4;
         }
       }
-      for (; k < wp; k++) acc = __builtin_amdgcn_sad_u16(op[k], rp[k], acc);
+      for (; k < wp; k++)
+      {
+        const unsigned g1 = rp[k + 1];
+        acc = __builtin_amdgcn_sad_u16(op[k], __builtin_amdgcn_alignbit(g1, g0, sh), acc);
+        g0 = g1;
+      }
     }
     for (int o2 = 1; o2 < split; o2 <<= 1) acc += __shfl_xor(acc, o2);
     if (live && s == 0) out[((size_t)b * ny + j0 + jj) * nx + i0 + i] = acc << subShift;
@@ -308,31 +323,47 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
   VVC_CHECK_ARG((best == nullptr) == (mvcost_host == nullptr), "sad_search: best and mvcost must be given together");
   const int hs = h >> sub_shift;
   const size_t orgDw = ((size_t)hs * (w / 2) + 3) & ~(size_t)3;
-  // Split the position grid into strips (rows first, then columns) until the staged window fits the LDS budget that still
-  // lets two workgroups share a CU; then split each position over `split` lanes so that a strip fills the workgroup.
-  const size_t budget = 72 * 1024;
-  int rowsPerStrip = ny, colsPerStrip = nx;
+  // Strip selection: the staged window (one copy, + 2 pairs of slack per row) must fit an LDS budget that keeps three
+  // workgroups per CU when possible; among the feasible strip heights pick the one that fills the 512 lanes best
+  // (positions x row-split), preferring taller strips (less window re-staging).
+  auto pitch_of = [&](int cps) { return ((cps - 1) * sx + w + 1) / 2 + 3; };
   auto lds_bytes = [&](int rps, int cps) {
     const size_t winRows = (size_t)(rps - 1) * sy + h;
-    const size_t pitch = (size_t)((cps - 1) * sx + w + 2) / 2 + 2;
-    return (orgDw + 2 * winRows * pitch) * 4;
+    return (orgDw + winRows * (size_t)pitch_of(cps)) * 4;
   };
-  while (lds_bytes(rowsPerStrip, colsPerStrip) > budget && rowsPerStrip > 1) rowsPerStrip = (rowsPerStrip + 1) / 2;
-  while (lds_bytes(rowsPerStrip, colsPerStrip) > budget && colsPerStrip > 1) colsPerStrip = (colsPerStrip + 1) / 2;
-  // even out the strips (e.g. 39 rows with a limit of 10 -> 4 strips of 10,10,10,9)
-  rowsPerStrip = cdiv(ny, cdiv(ny, rowsPerStrip));
+  const size_t budget = 52 * 1024, hard = 150 * 1024;
+  int colsPerStrip = nx;
+  while (lds_bytes(1, colsPerStrip) > budget && colsPerStrip > 1) colsPerStrip = (colsPerStrip + 1) / 2;
   colsPerStrip = cdiv(nx, cdiv(nx, colsPerStrip));
-  const int pitchDw = ((colsPerStrip - 1) * sx + w + 2) / 2 + 2;   // pairs per row (+ slack so rows do not alias banks exactly)
-  const size_t smem = lds_bytes(rowsPerStrip, colsPerStrip);
-  VVC_CHECK_ARG(smem <= 160 * 1024, "sad_search: a single position's window (%d x %d) does not fit LDS", w, h);
-  int split = 1;
-  while (split < 8 && split * 2 <= hs && rowsPerStrip * colsPerStrip * split * 2 <= SS_THREADS + SS_THREADS / 4) split *= 2;
+  int rowsPerStrip = 1, split = 1;
+  double bestUtil = -1.0;
+  for (int rps = 1; rps <= ny; rps++)
+  {
+    if (lds_bytes(rps, colsPerStrip) > budget && rps > 1) break;
+    const int pos = rps * colsPerStrip;
+    int sp = 1;
+    if (pos > 128) while (sp < 8 && sp * 2 <= hs && pos * sp * 2 <= SS_THREADS) sp *= 2;   // small strips keep sp = 1 and share the workgroup
+    const int tasks = pos * sp;
+    const double util = (double)tasks / (double)(cdiv(tasks, SS_THREADS) * SS_THREADS);
+    if (util >= bestUtil - 0.02) { bestUtil = util > bestUtil ? util : bestUtil; rowsPerStrip = rps; split = sp; }
+  }
+  const int pitchDw = pitch_of(colsPerStrip);
+  const size_t groupBytes = (lds_bytes(rowsPerStrip, colsPerStrip) + 15) & ~(size_t)15;
+  // small windows: several blocks per workgroup (power-of-two groups of >= 64 lanes, each covering all its tasks at once)
+  int groups = 1;
+  {
+    const int tasks = rowsPerStrip * colsPerStrip * split;
+    while (groups < 8 && tasks <= SS_THREADS / (groups * 2) && groupBytes * groups * 2 <= 40 * 1024) groups *= 2;
+  }
+  const size_t smem = groupBytes * groups;
+  VVC_CHECK_ARG(smem <= hard, "sad_search: a single position's window (%d x %d) does not fit LDS", w, h);
   hipStream_t st = (hipStream_t)stream;
   if (smem > 64 * 1024)
     VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  dim3 grid(nblocks, cdiv(ny, rowsPerStrip), cdiv(nx, colsPerStrip));
-  hipLaunchKernelGGL(sad_search_kernel, grid, dim3(SS_THREADS), smem, st, org, org_stride, ref, ref_stride, blocks, w, h,
-                     sub_shift, dx0, dy0, nx, ny, sx, sy, rowsPerStrip, colsPerStrip, pitchDw, split, sad_out);
+  dim3 grid(cdiv(nblocks, groups), cdiv(ny, rowsPerStrip), cdiv(nx, colsPerStrip));
+  hipLaunchKernelGGL(sad_search_kernel, grid, dim3(SS_THREADS), smem, st, org, org_stride, ref, ref_stride, blocks, nblocks, w, h,
+                     sub_shift, dx0, dy0, nx, ny, sx, sy, rowsPerStrip, colsPerStrip, pitchDw, split, groups,
+                     (int)(groupBytes / 4), sad_out);
   VVC_LAUNCH_CHECK();
   if (best)
   {
