@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """bench.py -- hot-path throughput of the MI355X-native VTM pixel path (measurement M1 of SURVEY.md §8(d)).
 
-A "step" is one pass of the canonical per-picture hot-path workload (integer-ME SAD surfaces, bi-pred MC, residual +
+A "step" is one pass of the canonical per-picture hot-path workload (integer-ME SAD surfaces, fused fractional refinement, bi-pred MC, residual +
 forward/inverse transforms + reconstruction, deblocking, SAO stats+apply, ALF classify+stats+filter) over ONE
 3840x2160 10-bit 4:2:0 picture whose planes are resident in HBM.  N > 1: one process per GPU, each rank works on its own
 pictures (random-access intra periods shard with no data-path collective); the boundary reconstructed
@@ -172,7 +172,7 @@ def main():
             "vs_baseline": None,
             "dtype": "int16",
             "data": "synthetic",
-            "config": {"workload": "hot-path canonical per-picture workload (SURVEY 8(d) M1: ME SAD surfaces 16/32/64 +-4 & raster +-96, "
+            "config": {"workload": "hot-path canonical per-picture workload (SURVEY 8(d) M1: ME SAD surfaces 16/32/64 +-4 & raster +-96, fused half/quarter refinement 16x16 (9+9 SATD), "
                                    "bi-pred MC 16x16, residual+fwd/inv transforms+reco, deblock, SAO stats+apply, ALF classify+stats+filter) "
                                    "on %dx%d 10-bit 4:2:0, planes resident in HBM; NOT EncoderApp fps (RDO control loop out of scope)" % (args.width, args.height),
                        "width": args.width, "height": args.height, "bit_depth": bd,

@@ -41,7 +41,7 @@ const char* vvcgpu_last_error(void);              /* thread-local text of the la
 int         vvcgpu_device_count(void);
 int         vvcgpu_set_device(int device);
 /* sizeof() of the parameter structs, for binding self-checks: 0 sao_ctu, 1 deblock_cfg, 2 dist_desc, 3 search_blk,
- * 4 mvcost, 5 search_best, 6 if_desc, 7 mc_desc, 8 pelop_desc, 9 pelop_cfg, 10 tr_desc; -1 for unknown ids.          */
+ * 4 mvcost, 5 search_best, 6 if_desc, 7 mc_desc, 8 pelop_desc, 9 pelop_cfg, 10 tr_desc, 11 frac_blk, 12 frac_result; -1 for unknown ids.          */
 int         vvcgpu_sizeof(int struct_id);
 
 /* ---- A1: ALF classification  (AdaptiveLoopFilter::deriveClassification, AdaptiveLoopFilter.cpp:274-463;
@@ -259,6 +259,24 @@ int vvcgpu_tr_inv_batch(const vvc_coef* coeff_base, vvc_pel* resi_base, const vv
                         int bit_depth, void* stream);
 /* The shipped matrix [type][log2(N)-1] as N x N int16 (host copy; for the shim's table check against initROM()). */
 const int16_t* vvcgpu_tr_matrix_host(int type, int n);
+
+/* ---- I2 (+D2, D5): fractional-sample refinement of a PU, fused  (InterSearch::xPatternSearchFracDIF,
+ *          EncoderLib/InterSearch.cpp:2503-2552 = xExtDIFUpSamplingH :3813-3869 -> xPatternRefinement(half) :634-689 ->
+ *          xExtDIFUpSamplingQ :3882-4093 -> xPatternRefinement(quarter)) ------------------------------------------------
+ * The reference materialises up to 12 fractional planes (m_filteredBlock[4][4]) per PU and reference picture and then
+ * evaluates 9 half-sample and 9 quarter-sample candidates with distFunc (Hadamard when HadamardME is on) + MV cost.
+ * Here the planes never exist in HBM: every candidate block is interpolated in LDS (horizontal first-stage filter, then
+ * vertical last-stage filter, the exact stage flags of the reference) and consumed by the distortion directly.
+ * All blocks of one call share w, h.  ref_x/ref_y: block position displaced by the integer MV; mv_x/mv_y: that integer
+ * MV (rcMvInt, integer-sample units) for the MV cost.  mvcost_host: lambda and predictor (m_mvPredictor, quarter units);
+ * cost_scale/imv_shift are ignored (the reference uses scale 1 for the half stage and 0 for the quarter stage, shift 0).
+ * result: half_x/half_y in {-1,0,1} (rcMvHalf), qter_x/qter_y in {-1,0,1} (rcMvQter), cost = ruiCost of the quarter stage,
+ * cost_half = best cost of the half stage.  Candidate order and strict '<' tie rule as s_acMvRefineH/Q (:59-83).        */
+typedef struct vvcgpu_frac_blk { int32_t org_x, org_y, ref_x, ref_y, mv_x, mv_y; } vvcgpu_frac_blk;
+typedef struct vvcgpu_frac_result { int32_t half_x, half_y, qter_x, qter_y; uint64_t cost_half, cost; } vvcgpu_frac_result;
+int vvcgpu_frac_refine(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride,
+                       const vvcgpu_frac_blk* blocks, int nblocks, int w, int h, int bit_depth, int clp_min, int clp_max,
+                       int use_hadamard, const vvcgpu_mvcost* mvcost_host, vvcgpu_frac_result* results, void* stream);
 
 #ifdef __cplusplus
 }

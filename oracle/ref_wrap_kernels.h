@@ -17,6 +17,8 @@
 #include "CommonLib/InterpolationFilter.h"
 #include "CommonLib/TrQuant.h"
 #include "CommonLib/TrQuant_EMT.h"
+#include "EncoderLib/InterSearch.h"
+#include "EncoderLib/EncCfg.h"
 #include "../include/vvcgpu.h"
 
 // simd: 0 = the reference's scalar functions, 1 = whatever table the reference installs on this CPU
@@ -423,6 +425,48 @@ int vtmref_tr_inv_batch(const TCoeff* coeff, Pel* resi, const vvcgpu_tr_desc* d,
 int vtmref_dist_batch(int kind, const Pel* org, const Pel* cur, const vvcgpu_dist_desc* d, int n, int bd, uint64_t* out)
 {
   for (int i = 0; i < n; i++) out[i] = vtmref_dist(kind, 1, org + d[i].org_off, d[i].org_stride, cur + d[i].cur_off, d[i].cur_stride, d[i].w, d[i].h, bd, d[i].sub_shift);
+  return 0;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Fractional refinement: the reference's own xExtDIFUpSamplingH / xPatternRefinement / xExtDIFUpSamplingQ /
+// xPatternRefinement sequence of InterSearch::xPatternSearchFracDIF (InterSearch.cpp:2503-2552; the glue lines :2533-2549
+// are repeated here because the function itself needs a PredictionUnit).  Private members via -fno-access-control.
+int vtmref_frac_refine(const Pel* org, int os, const Pel* ref, int rs, const vvcgpu_frac_blk* blk, int n, int w, int h, int bd,
+                       int clpMin, int clpMax, int useHad, const vvcgpu_mvcost* mv, vvcgpu_frac_result* res)
+{
+  static InterSearch* is = nullptr;
+  static RdCost* rc = nullptr;
+  static EncCfg* cfg = nullptr;
+  if (!is)
+  {
+    is = new InterSearch; rc = new RdCost; cfg = new EncCfg;
+    rc->setUseQtbt(true);
+    is->InterPrediction::init(rc, CHROMA_420);
+    is->m_pcEncCfg = cfg;
+  }
+  cfg->setUseHADME(useHad != 0);
+  is->m_lumaClpRng = mkClp(clpMin, clpMax, bd);
+  rc->m_motionLambda = mv->lambda;
+  rc->setPredictor(Mv(mv->pred_hor, mv->pred_ver));
+  for (int b = 0; b < n; b++)
+  {
+    CPelBuf patternKey(org + blk[b].org_y * os + blk[b].org_x, os, w, h);
+    CPelBuf cPatternRoi(ref + (ptrdiff_t)blk[b].ref_y * rs + blk[b].ref_x, rs, w, h);
+    const Mv rcMvInt(blk[b].mv_x, blk[b].mv_y);
+    rc->setCostScale(1);
+    is->xExtDIFUpSamplingH(&cPatternRoi);
+    Mv rcMvHalf = rcMvInt; rcMvHalf <<= 1;
+    Mv baseRefMv(0, 0);
+    res[b].cost_half = is->xPatternRefinement(&patternKey, baseRefMv, 2, rcMvHalf, true);
+    rc->setCostScale(0);
+    is->xExtDIFUpSamplingQ(&cPatternRoi, rcMvHalf);
+    baseRefMv = rcMvHalf; baseRefMv <<= 1;
+    Mv rcMvQter = rcMvInt; rcMvQter <<= 1; rcMvQter += rcMvHalf; rcMvQter <<= 1;
+    res[b].cost = is->xPatternRefinement(&patternKey, baseRefMv, 1, rcMvQter, true);
+    res[b].half_x = rcMvHalf.getHor(); res[b].half_y = rcMvHalf.getVer();
+    res[b].qter_x = rcMvQter.getHor(); res[b].qter_y = rcMvQter.getVer();
+  }
   return 0;
 }
 

@@ -199,5 +199,38 @@ def gen_transform():
     save("transform", **out)
 
 
+def gen_frac():
+    rng = np.random.default_rng(1006)
+    FB = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4")])
+    FR = np.dtype([("half_x", "<i4"), ("half_y", "<i4"), ("qter_x", "<i4"), ("qter_y", "<i4"), ("cost_half", "<u8"), ("cost", "<u8")])
+
+    class MV(C.Structure):
+        _fields_ = [("l", C.c_double), ("ph", C.c_int32), ("pv", C.c_int32), ("cs", C.c_int32), ("imv", C.c_int32)]
+    out = {}
+    W, H, M = 128, 96, 16
+    for bd in (8, 10):
+        mx = (1 << bd) - 1
+        ref_ = cases.rand_plane(rng, H + 2 * M, W + 2 * M, bd, "smooth")
+        org = np.clip(ref_[M + 1:M + 1 + H, M + 2:M + 2 + W].astype(np.int32) + rng.integers(-6, 7, (H, W)), 0, mx).astype(np.int16)
+        org = np.ascontiguousarray(org)
+        out["ref%d" % bd], out["org%d" % bd] = ref_, org
+        rows = []
+        for (w, h) in [(4, 4), (8, 8), (16, 16), (16, 8), (8, 16), (32, 32), (64, 64), (8, 4), (32, 16)]:
+            for had in (1, 0):
+                nb = 4
+                blk = np.zeros(nb, FB)
+                for i in range(nb):
+                    x, y = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+                    mvx, mvy = int(rng.integers(-3, 4)), int(rng.integers(-3, 4))
+                    blk[i] = (x, y, M + x + mvx, M + y + mvy, mvx, mvy)
+                m = MV(float(rng.uniform(2, 40)), int(rng.integers(-20, 20)), int(rng.integers(-20, 20)), 0, 0)
+                res = np.zeros(nb, FR)
+                R.vtmref_frac_refine(p(org), W, p(ref_), W + 2 * M, p(blk), nb, w, h, bd, 0, mx, had, C.byref(m), p(res))
+                for i in range(nb):
+                    rows.append([bd, w, h, had, m.ph, m.pv] + [int(v) for v in blk[i]] + [int(res[i][k]) for k in FR.names] + [m.l])
+        out["rows%d" % bd] = np.array(rows, dtype=np.float64)
+    save("frac", **out)
+
+
 if __name__ == "__main__":
-    gen_alf(); gen_sao(); gen_dist(); gen_interp(); gen_transform()
+    gen_alf(); gen_sao(); gen_dist(); gen_interp(); gen_transform(); gen_frac()

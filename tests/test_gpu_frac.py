@@ -1,0 +1,39 @@
+"""GPU parity: fused fractional refinement (planes in LDS + 9+9 SATD/SAD candidates + MV cost) vs the CPU oracle."""
+import ctypes as C
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oraclelib import oracle, p
+
+pytestmark = pytest.mark.gpu
+
+
+def dev(a):
+    return torch.from_numpy(a).cuda()
+
+
+@pytest.mark.parametrize("w,h", [(4, 4), (8, 8), (16, 16), (16, 8), (8, 16), (32, 32), (64, 64), (8, 4), (4, 8), (32, 16),
+                                 (128, 128), (64, 32), (16, 64), (128, 64)])
+@pytest.mark.parametrize("bd,kind,had", [(10, "smooth", 1), (10, "uniform", 1), (8, "smooth", 1), (10, "smooth", 0)])
+def test_frac_refine(w, h, bd, kind, had):
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(w * 5 + h + bd + had)
+    mx = (1 << bd) - 1
+    W, H, M = 256, 224, 16
+    ref = cases.rand_plane(rng, H + 2 * M, W + 2 * M, bd, kind)
+    org = ref[M + 1:M + 1 + H, M + 2:M + 2 + W].astype(np.int32) + rng.integers(-6, 7, (H, W))
+    org = np.ascontiguousarray(np.clip(org, 0, mx).astype(np.int16))
+    nb = 9
+    blk = np.zeros(nb, ops.FRAC_BLK)
+    for i in range(nb):
+        x, y = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+        mvx, mvy = int(rng.integers(-3, 4)), int(rng.integers(-3, 4))
+        blk[i] = (x, y, M + x + mvx, M + y + mvy, mvx, mvy)
+    mv = ops.MvCost(float(rng.uniform(2, 40)), int(rng.integers(-20, 20)), int(rng.integers(-20, 20)), 0, 0)
+    want = np.zeros(nb, ops.FRAC_RESULT)
+    oracle().orc_frac_refine(p(org), W, p(ref), W + 2 * M, p(blk), nb, w, h, bd, 0, mx, had, C.byref(mv), p(want))
+    got = ops.frac_refine(dev(org), dev(ref), ops.struct_to_device(blk), nb, w, h, bd, mv, bool(had), (0, mx))
+    got = got.cpu().numpy().view(ops.FRAC_RESULT)
+    assert np.array_equal(got, want)

@@ -131,6 +131,27 @@ def test_transform_golden():
             pos += n
 
 
+def test_frac_refine_golden():
+    g = load("frac")
+    O = oracle()
+    FB = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4")])
+    FR = np.dtype([("half_x", "<i4"), ("half_y", "<i4"), ("qter_x", "<i4"), ("qter_y", "<i4"), ("cost_half", "<u8"), ("cost", "<u8")])
+
+    class MV(C.Structure):
+        _fields_ = [("l", C.c_double), ("ph", C.c_int32), ("pv", C.c_int32), ("cs", C.c_int32), ("imv", C.c_int32)]
+    for bd in (8, 10):
+        ref_, org = g["ref%d" % bd], g["org%d" % bd]
+        W = org.shape[1]
+        for r in g["rows%d" % bd]:
+            _, w, h, had, ph, pv = [int(v) for v in r[:6]]
+            blk = np.array([tuple(int(v) for v in r[6:12])], FB)
+            want = tuple(int(v) for v in r[12:18])
+            m = MV(float(r[18]), ph, pv, 0, 0)
+            res = np.zeros(1, FR)
+            O.orc_frac_refine(p(org), W, p(ref_), ref_.shape[1], p(blk), 1, w, h, bd, 0, (1 << bd) - 1, had, C.byref(m), p(res))
+            assert tuple(int(res[0][k]) for k in FR.names) == want, (bd, w, h, had)
+
+
 def test_transform_tables_golden_and_shipped():
     """restated initROM formulas == tables dumped from the compiled reference == table compiled into the HIP library."""
     from vvcsoftware_vtm_amd import capi

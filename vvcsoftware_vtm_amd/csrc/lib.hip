@@ -37,6 +37,8 @@ int vvcgpu_sizeof(int id)
   case 8: return (int)sizeof(vvcgpu_pelop_desc);
   case 9: return (int)sizeof(vvcgpu_pelop_cfg);
   case 10: return (int)sizeof(vvcgpu_tr_desc);
+  case 11: return (int)sizeof(vvcgpu_frac_blk);
+  case 12: return (int)sizeof(vvcgpu_frac_result);
   default: return -1;
   }
 }

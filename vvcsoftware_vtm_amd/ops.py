@@ -210,3 +210,18 @@ def tr_fwd_batch(resi_base, coeff_base, descs_dev, n, bit_depth=10):
 
 def tr_inv_batch(coeff_base, resi_base, descs_dev, n, bit_depth=10):
     capi.call("vvcgpu_tr_inv_batch", capi.ptr(coeff_base), capi.ptr(resi_base), capi.ptr(descs_dev), n, bit_depth, _stream())
+
+
+# ---- fused fractional refinement (InterSearch::xPatternSearchFracDIF) ---------------------------------------
+FRAC_BLK = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4")])
+FRAC_RESULT = np.dtype([("half_x", "<i4"), ("half_y", "<i4"), ("qter_x", "<i4"), ("qter_y", "<i4"), ("cost_half", "<u8"), ("cost", "<u8")])
+
+
+def frac_refine(org, ref, blocks_dev, nblocks, w, h, bit_depth, mvcost, use_hadamard=True, clp=(0, 1023)):
+    """I2+D2+D5: returns a uint8 CUDA tensor holding nblocks FRAC_RESULT records."""
+    po, so, _, _ = _plane(org, "org")
+    pr, sr, _, _ = _plane(ref, "ref")
+    res = torch.empty(nblocks * FRAC_RESULT.itemsize, dtype=torch.uint8, device=org.device)
+    capi.call("vvcgpu_frac_refine", po, so, pr, sr, capi.ptr(blocks_dev), nblocks, w, h, bit_depth, clp[0], clp[1],
+              1 if use_hadamard else 0, C.byref(mvcost), capi.ptr(res), _stream())
+    return res

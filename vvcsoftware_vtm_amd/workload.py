@@ -10,6 +10,8 @@ descriptors, deblocking maps, SAO and ALF parameters.  The same `Workload` objec
 Stages (one picture = one step):
   me     integer ME: SAD surface of every 16x16 / 32x32 / 64x64 block at the 81 positions of a +-4 full search and
          at the 5-stride raster of a +-96 window (39x39), sub_shift 1 (FEN mode 2), with the MV-cost argmin
+  frac   fused fractional refinement (half + quarter sample, 9 + 9 Hadamard candidates, MV cost) of every 16x16 block
+         around a seeded integer MV (the device form of xPatternSearchFracDIF; fractional planes stay in LDS)
   mc     bi-predictive MC of the whole picture as 16x16 PUs (luma 8-tap + chroma 4-tap) + addAvg
   resi   residual = org - pred; forward + inverse transforms over a seeded tiling {64,32,16,8,4} in equal pixel
          shares (DST-VII/DCT-VIII pairs on tiles <= 32) with a shift-only quantiser stand-in; reconstruction
@@ -26,7 +28,7 @@ from . import synth
 
 MARGIN = 144          # reference picture margin (maxCUWidth + 16, Picture.cpp:737-742)
 CTU = 128
-STAGES = ["me", "mc", "resi", "dbk", "sao", "alf"]
+STAGES = ["me", "frac", "mc", "resi", "dbk", "sao", "alf"]
 
 DIST_DESC = np.dtype([("org_off", "<i8"), ("cur_off", "<i8"), ("org_stride", "<i4"), ("cur_stride", "<i4"),
                       ("w", "<i2"), ("h", "<i2"), ("sub_shift", "<i2"), ("reserved", "<i2")])
@@ -41,6 +43,8 @@ PELOP_DESC = np.dtype([("src0_off", "<i8"), ("src1_off", "<i8"), ("dst_off", "<i
 TR_DESC = np.dtype([("resi_off", "<i8"), ("coeff_off", "<i8"), ("resi_stride", "<i4"), ("w", "<i2"), ("h", "<i2"),
                     ("tr_hor", "i1"), ("tr_ver", "i1"), ("reserved", "<i2"), ("reserved2", "<i4")])
 SAO_DTYPE = np.dtype([("type", "i1"), ("avail", "u1"), ("offset", "<i2", (32,))])
+FRAC_BLK = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4")])
+FRAC_RESULT = np.dtype([("half_x", "<i4"), ("half_y", "<i4"), ("qter_x", "<i4"), ("qter_y", "<i4"), ("cost_half", "<u8"), ("cost", "<u8")])
 
 
 class MvCost(C.Structure):
@@ -92,6 +96,21 @@ class Workload:
         nr = 2 * (raster_range // 5) + 1
         self.me_grids = [(-4, -4, 9, 9, 1, 1), (-5 * (nr // 2), -5 * (nr // 2), nr, nr, 5, 5)]
         self.mvcost = MvCost(float(np.sqrt(57.0)), 0, 0, 2, 0)
+
+        # ---- fractional refinement: every full 16x16 block around a seeded integer MV --------------------------
+        b16 = self.me[16] if 16 in self.me else None
+        if b16 is None:
+            xs, ys = np.arange(0, width - 15, 16), np.arange(0, height - 15, 16)
+            gx, gy = np.meshgrid(xs, ys)
+            b16 = np.zeros(gx.size, SEARCH_BLK)
+            b16["org_x"], b16["org_y"] = gx.reshape(-1), gy.reshape(-1)
+        fb = np.zeros(b16.size, FRAC_BLK)
+        imv = rng.integers(-8, 9, (b16.size, 2))
+        fb["org_x"], fb["org_y"] = b16["org_x"], b16["org_y"]
+        fb["mv_x"], fb["mv_y"] = imv[:, 0], imv[:, 1]
+        fb["ref_x"], fb["ref_y"] = b16["org_x"] + m + imv[:, 0], b16["org_y"] + m + imv[:, 1]
+        self.frac = fb
+        self.frac_mvcost = MvCost(float(np.sqrt(57.0)), 3, -2, 0, 0)
 
         # ---- MC: bi-pred 16x16 PUs, quarter-pel MVs ----------------------------------------------------------
         xs, ys = np.arange(0, width, 16), np.arange(0, height, 16)
@@ -207,6 +226,7 @@ class Workload:
                 Ww, Wh = (nx - 1) * sx + s, (ny - 1) * sy + s
                 me["sad_search_%dx%d_%dx%d" % (s, s, nx, ny)] = blk.size * (Ww * Wh * 2 + s * s * 2 + 4 * nx * ny)
         out["me"] = me
+        out["frac"] = {"frac_refine_16x16": self.frac.size * (24 * 24 * 2 + 16 * 16 * 2 + 32)}
         nl = self.mc_luma.size
         # per PU: two reference windows (W+7)^2 (luma) / (W/2+3)^2 (chroma, x2 components) + the written block
         out["mc"] = {"mc_luma": nl * (2 * 23 * 23 * 2 + 16 * 16 * 2), "mc_chroma": 2 * nl * (2 * 11 * 11 * 2 + 8 * 8 * 2)}
@@ -231,6 +251,7 @@ class Workload:
             d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
             st = {"org": [d(p) for p in self.org], "ref0": [d(p) for p in self.ref0_pad], "ref1": [d(p) for p in self.ref1_pad],
                   "me_blk": {s: ops.struct_to_device(b) for s, b in self.me.items()},
+                  "frac_blk": ops.struct_to_device(self.frac),
                   "mc_luma": ops.struct_to_device(self.mc_luma), "mc_chroma": ops.struct_to_device(self.mc_chroma),
                   "tr": ops.struct_to_device(self.tr), "bands_luma": ops.struct_to_device(self.bands_luma),
                   "bands_chroma": ops.struct_to_device(self.bands_chroma),
@@ -256,6 +277,10 @@ class Workload:
                                                dx0, dy0, nx, ny, sx, sy, cfg_mv)
                 out["me_sad_%d_%d" % (s, nx)] = sad
                 out["me_best_%d_%d" % (s, nx)] = best
+        # ---- frac
+        fmv = ops.MvCost(self.frac_mvcost.lambda_, self.frac_mvcost.pred_hor, self.frac_mvcost.pred_ver, 0, 0)
+        with T("frac/frac_refine_16x16"):
+            out["frac"] = ops.frac_refine(st["org"][0], st["ref0"][0], st["frac_blk"], self.frac.size, 16, 16, bd, fmv, True, (0, mx))
         # ---- mc
         with T("mc/mc_luma"):
             ops.mc_batch(st["ref0"][0], st["ref1"][0], st["pred"][0], st["mc_luma"], self.mc_luma.size, bd, (0, mx))
@@ -336,6 +361,15 @@ class Workload:
                                                              dx0, dy0, nx, ny, sx, sy, P(sad), C.byref(self.mvcost), P(best)))
                 out["me_sad_%d_%d" % (s, nx)] = sad
                 out["me_best_%d_%d" % (s, nx)] = best
+        # frac
+        fres = np.zeros(self.frac.size, FRAC_RESULT)
+        if refl is not None:
+            timed("frac", lambda: refl.vtmref_frac_refine(P(self.org[0]), w, P(self.ref0_pad[0]), self.pw, P(self.frac), self.frac.size, 16, 16, bd, 0, mx, 1,
+                                                          C.byref(self.frac_mvcost), P(fres)))
+        else:
+            timed("frac", lambda: port.orc_frac_refine(P(self.org[0]), w, P(self.ref0_pad[0]), self.pw, P(self.frac), self.frac.size, 16, 16, bd, 0, mx, 1,
+                                                       C.byref(self.frac_mvcost), P(fres)))
+        out["frac"] = fres
         # mc
         pred = [np.zeros((h, w), np.int16), np.zeros((h // 2, w // 2), np.int16), np.zeros((h // 2, w // 2), np.int16)]
         f_mc = (lambda *a: refl.vtmref_mc_batch(*a)) if refl is not None else (lambda *a: port.orc_mc_batch(*a))
