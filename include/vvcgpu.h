@@ -44,6 +44,20 @@ int         vvcgpu_set_device(int device);
  * 4 mvcost, 5 search_best, 6 if_desc, 7 mc_desc, 8 pelop_desc, 9 pelop_cfg, 10 tr_desc, 11 frac_blk, 12 frac_result; -1 for unknown ids.          */
 int         vvcgpu_sizeof(int struct_id);
 
+/* ---- device memory helpers for host-side callers (the reference keeps pictures in host memory; the shim stages them).
+ *      2-D copies take pitches in BYTES.  All are asynchronous on `stream` except vvcgpu_stream_sync. */
+int vvcgpu_malloc(void** dev_ptr, size_t bytes);
+int vvcgpu_free(void* dev_ptr);
+int vvcgpu_memcpy_h2d(void* dst_dev, const void* src_host, size_t bytes, void* stream);
+int vvcgpu_memcpy_d2h(void* dst_host, const void* src_dev, size_t bytes, void* stream);
+int vvcgpu_memcpy2d_h2d(void* dst_dev, size_t dst_pitch, const void* src_host, size_t src_pitch, size_t width_bytes,
+                        size_t height, void* stream);
+int vvcgpu_memcpy2d_d2h(void* dst_host, size_t dst_pitch, const void* src_dev, size_t src_pitch, size_t width_bytes,
+                        size_t height, void* stream);
+int vvcgpu_memcpy2d_d2d(void* dst_dev, size_t dst_pitch, const void* src_dev, size_t src_pitch, size_t width_bytes,
+                        size_t height, void* stream);
+int vvcgpu_stream_sync(void* stream);
+
 /* ---- A1: ALF classification  (AdaptiveLoopFilter::deriveClassification, AdaptiveLoopFilter.cpp:274-463;
  *          table slot m_deriveClassificationBlk, AdaptiveLoopFilter.h:90) -----------------------
  * src: luma plane after deblock+SAO (W x H valid samples, border replicated by the kernel exactly as

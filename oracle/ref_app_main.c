@@ -1,5 +1,6 @@
 /* oracle/ref_app_main.c -- TEST INFRASTRUCTURE.
- * Driver for the reference applications: `vtmref_app enc <EncoderApp args>` / `vtmref_app dec <DecoderApp args>`.
+ * Driver for the reference applications: `vtmref_app [--hip] enc <EncoderApp args>` / `vtmref_app [--hip] dec <DecoderApp args>`.
+ * --hip loads libvtmref_hip.so: the same reference objects with the in-loop filter entry points wrapped to the GPU shim.
  * The reference's own main() files need a cmake-generated header and are not built (oracle/Makefile);
  * the EncApp/DecApp classes are, inside libvtmref.so, and are entered through vtmref_encode/vtmref_decode
  * (oracle/ref_wrap.cpp), which follow App/EncoderApp/encmain.cpp:79-189 and App/DecoderApp/decmain.cpp. */
@@ -11,9 +12,11 @@
 #include <stdlib.h>
 typedef int (*appfn)(int, char**);
 int main(int argc, char** argv) {
-  if (argc < 2) { fprintf(stderr, "usage: %s enc|dec <args...>\n", argv[0]); return 2; }
+  if (argc < 2) { fprintf(stderr, "usage: %s [--hip] enc|dec <args...>\n", argv[0]); return 2; }
   char self[PATH_MAX]; if (!realpath(argv[0], self)) { perror("realpath"); return 2; }
-  char lib[PATH_MAX]; snprintf(lib, sizeof lib, "%s/libvtmref.so", dirname(self));
+  int hip = 0;
+  if (strcmp(argv[1], "--hip") == 0) { hip = 1; argv++; argc--; if (argc < 2) return 2; }
+  char lib[PATH_MAX]; snprintf(lib, sizeof lib, "%s/%s", dirname(self), hip ? "libvtmref_hip.so" : "libvtmref.so");
   void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
   if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
   appfn f = (appfn)dlsym(h, strcmp(argv[1], "enc") == 0 ? "vtmref_encode" : "vtmref_decode");

@@ -1,0 +1,62 @@
+#!/usr/bin/env python3
+"""Produces the bitstream fixtures with the COMPILED REFERENCE encoder (oracle/_ref/vtmref_app enc, CPU only):
+  tests/golden/bitstreams/*.bin  + manifest.json (md5 of each bitstream, md5 of the reference decoder's YUV output,
+  frame count, the exact command line).  The input clips are synthetic (vvcsoftware_vtm_amd.synth) and are regenerated
+  from their seed by the tests, so only the bitstreams (a few KB each) are committed.  Build container only."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from vvcsoftware_vtm_amd import synth  # noqa: E402
+
+APP = os.path.join(ROOT, "oracle", "_ref", "vtmref_app")
+CFG = "/root/reference/cfg"
+OUT = os.path.join(HERE, "bitstreams")
+
+CLIPS = [
+    # name, cfg, w, h, bd, frames, qp, seed
+    ("ra_208x120_10b_q32", "encoder_randomaccess_vtm.cfg", 208, 120, 10, 5, 32, 20261003),
+    ("ai_416x240_8b_q37", "encoder_intra_vtm.cfg", 416, 240, 8, 1, 37, 20261004),
+    # encoded with this repository's own small test cfg (travels with the repo, so the GPU box can re-run the ENCODER)
+    ("ldp_208x120_10b_q27", "@tests/golden/bitstreams/test_lowdelay.cfg", 208, 120, 10, 3, 27, 20261005),
+]
+
+
+def md5(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+
+def enc_args(name, cfg, w, h, bd, n, qp, yuv, binf, rec):
+    cfgpath = os.path.join(ROOT, cfg[1:]) if cfg.startswith("@") else os.path.join(CFG, cfg)
+    return ["-c", cfgpath, "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30", "-f", str(n), "-q", str(qp),
+            "--InputBitDepth=%d" % bd, "--InternalBitDepth=%d" % bd, "--OutputBitDepth=%d" % bd, "-b", binf, "-o", rec,
+            "--SEIDecodedPictureHash=1"]
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    man = {}
+    for (name, cfg, w, h, bd, n, qp, seed) in CLIPS:
+        yuv = "/tmp/%s.yuv" % name
+        synth.write_yuv(yuv, synth.gen_yuv(w, h, n, bd, seed), bd)
+        binf = os.path.join(OUT, name + ".bin")
+        rec = "/tmp/%s_rec.yuv" % name
+        args = enc_args(name, cfg, w, h, bd, n, qp, yuv, binf, rec)
+        subprocess.check_call([APP, "enc"] + args, stdout=open("/tmp/%s_enc.log" % name, "w"))
+        dec = "/tmp/%s_dec.yuv" % name
+        out = subprocess.check_output([APP, "dec", "-b", binf, "-o", dec, "-d", str(bd)], text=True)
+        assert "ERROR" not in out and out.count("(OK)") >= n, out
+        assert md5(dec) == md5(rec)
+        man[name] = {"cfg": cfg, "w": w, "h": h, "bd": bd, "frames": n, "qp": qp, "seed": seed,
+                     "bin_md5": md5(binf), "dec_yuv_md5": md5(dec), "bytes": os.path.getsize(binf)}
+        print(name, man[name])
+    json.dump(man, open(os.path.join(OUT, "manifest.json"), "w"), indent=1, sort_keys=True)
+
+
+if __name__ == "__main__":
+    main()

@@ -22,6 +22,22 @@ int vvcgpu_device_count(void)
   if (hipGetDeviceCount(&n) != hipSuccess) return 0;
   return n;
 }
+int vvcgpu_malloc(void** dev_ptr, size_t bytes)
+{
+  VVC_CHECK_ARG(dev_ptr, "malloc: null out pointer");
+  VVC_HIP(hipMalloc(dev_ptr, bytes ? bytes : 1));
+  return VVCGPU_OK;
+}
+int vvcgpu_free(void* p) { if (p) VVC_HIP(hipFree(p)); return VVCGPU_OK; }
+int vvcgpu_memcpy_h2d(void* d, const void* s, size_t n, void* st) { VVC_HIP(hipMemcpyAsync(d, s, n, hipMemcpyHostToDevice, (hipStream_t)st)); return VVCGPU_OK; }
+int vvcgpu_memcpy_d2h(void* d, const void* s, size_t n, void* st) { VVC_HIP(hipMemcpyAsync(d, s, n, hipMemcpyDeviceToHost, (hipStream_t)st)); return VVCGPU_OK; }
+int vvcgpu_memcpy2d_h2d(void* d, size_t dp, const void* s, size_t sp, size_t wb, size_t h, void* st)
+{ VVC_HIP(hipMemcpy2DAsync(d, dp, s, sp, wb, h, hipMemcpyHostToDevice, (hipStream_t)st)); return VVCGPU_OK; }
+int vvcgpu_memcpy2d_d2h(void* d, size_t dp, const void* s, size_t sp, size_t wb, size_t h, void* st)
+{ VVC_HIP(hipMemcpy2DAsync(d, dp, s, sp, wb, h, hipMemcpyDeviceToHost, (hipStream_t)st)); return VVCGPU_OK; }
+int vvcgpu_memcpy2d_d2d(void* d, size_t dp, const void* s, size_t sp, size_t wb, size_t h, void* st)
+{ VVC_HIP(hipMemcpy2DAsync(d, dp, s, sp, wb, h, hipMemcpyDeviceToDevice, (hipStream_t)st)); return VVCGPU_OK; }
+int vvcgpu_stream_sync(void* st) { VVC_HIP(hipStreamSynchronize((hipStream_t)st)); return VVCGPU_OK; }
 int vvcgpu_sizeof(int id)
 {
   switch (id)
