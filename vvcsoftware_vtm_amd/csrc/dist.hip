@@ -132,6 +132,32 @@ __global__ __launch_bounds__(256) void dist_batch_kernel(int kind, const Pel* __
 
 // ---------------------------------------------------------------------------------------------------
 // SAD search surface
+// Batched window fill: every lane keeps FB independent global loads in flight before the first LDS store (the simple
+// load->store loop serialises one L2 round trip per element and dominated the kernel).
+template <int FB>
+__device__ __forceinline__ void fill_window_pairs(unsigned* __restrict__ lds, const unsigned* __restrict__ g, int rsDw,
+                                                  int winRows, int pitchDw, int nPairs, int tid, int nthreads)
+{
+  const int total = winRows * pitchDw;
+  int e = tid, r = tid / pitchDw, k = tid - r * pitchDw;
+  const int dr = nthreads / pitchDw, dk = nthreads - dr * pitchDw;
+  for (int base = 0; base < total; base += FB * nthreads)
+  {
+    unsigned v[FB];
+    int idx[FB];
+#pragma unroll
+    for (int u = 0; u < FB; u++)
+    {
+      idx[u] = e < total ? e : -1;
+      v[u] = e < total ? g[(ptrdiff_t)r * rsDw + min(k, nPairs - 1)] : 0u;
+      e += nthreads; r += dr; k += dk;
+      if (k >= pitchDw) { k -= pitchDw; r++; }
+    }
+#pragma unroll
+    for (int u = 0; u < FB; u++) if (idx[u] >= 0) lds[idx[u]] = v[u] ^ 0x80008000u;
+  }
+}
+
 constexpr int SS_THREADS = 512;
 
 // `groups` sub-workgroups of gsz = SS_THREADS / groups lanes each take one block (small windows: several blocks per
@@ -178,13 +204,7 @@ __global__ __launch_bounds__(SS_THREADS) void sad_search_kernel(const Pel* __res
     if (fast)
     {
       const unsigned* g = reinterpret_cast<const unsigned*>(ref + (winOff - odd));
-      const int rsDw = rs >> 1;
-      for (int k = lane; k < pitchDw; k += 64)
-      {
-        const unsigned* gk = g + min(k, nPairs - 1) + (ptrdiff_t)wave * rsDw;
-        unsigned* lk = refL + wave * pitchDw + k;
-        for (int r = wave; r < winRows; r += nwaves, gk += (ptrdiff_t)nwaves * rsDw, lk += nwaves * pitchDw) *lk = *gk ^ 0x80008000u;
-      }
+      fill_window_pairs<8>(refL, g, rs >> 1, winRows, pitchDw, nPairs, tid, gsz);
     }
     else
     {
@@ -245,6 +265,130 @@ __global__ __launch_bounds__(SS_THREADS) void sad_search_kernel(const Pel* __res
     }
     for (int o2 = 1; o2 < split; o2 <<= 1) acc += __shfl_xor(acc, o2);
     if (live && s == 0) out[((size_t)b * ny + j0 + jj) * nx + i0 + i] = acc << subShift;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Raster specialisation (step 5 in both directions = iRaster of xTZSearch under the shipped cfgs, InterSearch.cpp:1979-2000).
+//   * LDS bank-conflict-free by construction: consecutive raster columns start 2.5 dwords apart, so 13 of them hit 13
+//     distinct banks {0,2,5,7,..,30}; the LDS row pitch is chosen = 13 or 19 (mod 32) so that the next raster ROW is shifted
+//     by exactly +-1 bank and fills the gaps.  A 32-lane half therefore carries 13 + 13 = 26 positions (two raster rows of
+//     one 13-column group) and every ds_read is conflict free; 6 lanes per half idle (a 2-way conflict would cost more).
+//   * the org block is wave-uniform: it is read with SCALAR loads straight from global memory (no LDS copy, no LDS
+//     bandwidth) and enters v_sad_u16 as an SGPR operand.
+// 16-byte window fill: lane loads one aligned uint4 (8 samples), FB of them in flight, and stores four LDS dwords.
+template <int FB>
+__device__ __forceinline__ void fill_window_quads(unsigned* __restrict__ lds, const uint4* __restrict__ g, int rsQ,
+                                                  int winRows, int pitchDw, int nQuads, int tid, int nthreads)
+{
+  const int total = winRows * nQuads;
+  int e = tid, r = tid / nQuads, q = tid - r * nQuads;
+  const int dr = nthreads / nQuads, dq = nthreads - dr * nQuads;
+  for (int base = 0; base < total; base += FB * nthreads)
+  {
+    uint4 v[FB];
+    int idx[FB];
+#pragma unroll
+    for (int u = 0; u < FB; u++)
+    {
+      idx[u] = e < total ? r * pitchDw + 4 * q : -1;
+      v[u] = e < total ? g[(ptrdiff_t)r * rsQ + q] : make_uint4(0, 0, 0, 0);
+      e += nthreads; r += dr; q += dq;
+      if (q >= nQuads) { q -= nQuads; r++; }
+    }
+#pragma unroll
+    for (int u = 0; u < FB; u++)
+      if (idx[u] >= 0)
+      {
+        unsigned* d = lds + idx[u];
+        d[0] = v[u].x ^ 0x80008000u; d[1] = v[u].y ^ 0x80008000u; d[2] = v[u].z ^ 0x80008000u; d[3] = v[u].w ^ 0x80008000u;
+      }
+  }
+}
+
+// rows [r0, r0+RB) of one position: RB*WP wave-uniform org pairs (scalar loads, issued together) against the lane's window rows
+template <int WP, int RB, bool OODD>
+__device__ __forceinline__ unsigned r5_rows(const unsigned* __restrict__ orgDw, int osDwStep, const unsigned* base, int ldsStep,
+                                            unsigned sh, unsigned acc)
+{
+  unsigned ov[RB][WP];
+#pragma unroll
+  for (int j = 0; j < RB; j++)
+  {
+    const unsigned* op = orgDw + (size_t)j * osDwStep;
+#pragma unroll
+    for (int k = 0; k < WP; k++)
+      ov[j][k] = (OODD ? ((op[k] >> 16) | (op[k + 1] << 16)) : op[k]) ^ 0x80008000u;
+  }
+#pragma unroll
+  for (int j = 0; j < RB; j++)
+  {
+    const unsigned* rp = base + j * ldsStep;
+    unsigned g[WP + 1];
+#pragma unroll
+    for (int k = 0; k <= WP; k++) g[k] = rp[k];
+#pragma unroll
+    for (int k = 0; k < WP; k++) acc = __builtin_amdgcn_sad_u16(ov[j][k], __builtin_amdgcn_alignbit(g[k + 1], g[k], sh), acc);
+  }
+  return acc;
+}
+
+// Raster specialisation (step 5 in both directions = iRaster of xTZSearch under the shipped cfgs, InterSearch.cpp:1979-2000).
+//   * LDS bank-conflict-free by construction: consecutive raster columns start 2.5 dwords apart, so 13 of them hit 13
+//     distinct banks {0,2,5,7,..,30}; the LDS row pitch is chosen = 13 or 19 (mod 32) so that the next raster ROW is shifted
+//     by exactly +-1 bank and fills the gaps.  A 32-lane half therefore carries 13 + 13 = 26 positions (two raster rows of
+//     one 13-column group) and every ds_read is conflict free; 6 lanes per half idle (a 2-way conflict would cost more).
+//   * the org block is wave-uniform: it is read with SCALAR loads straight from global memory (no LDS copy, no LDS
+//     bandwidth), RB rows at a time so that the loads overlap, and enters v_sad_u16 as an SGPR operand.
+//   * the window is staged with 16-byte global loads (QUADS) when the plane allows it.
+template <int WP, int RB, bool QUADS>
+__global__ __launch_bounds__(512) void sad_raster5_kernel(const Pel* __restrict__ org, int os,
+                                                          const Pel* __restrict__ ref, int rs,
+                                                          const vvcgpu_search_blk* __restrict__ blocks, int h, int subShift,
+                                                          int dx0, int dy0, int nx, int ny, int rowsPerStrip, int pitchDw, int dbg,
+                                                          unsigned* __restrict__ out)
+{
+  extern __shared__ __align__(16) unsigned refL[];
+  const int tid = threadIdx.x;
+  const int b = blockIdx.x, j0 = blockIdx.y * rowsPerStrip;
+  const int nj = min(rowsPerStrip, ny - j0);
+  const vvcgpu_search_blk blk = blocks[b];
+  const int hs = h >> subShift;
+  const int w = WP * 2;
+  const int winRows = (nj - 1) * 5 + h;
+  const int Ww = (nx - 1) * 5 + w;
+  const ptrdiff_t winOff = (ptrdiff_t)(blk.ref_y + dy0 + j0 * 5) * rs + blk.ref_x + dx0;
+  const int off = QUADS ? (int)(winOff & 7) : (int)(winOff & 1);       // samples between the aligned LDS row start and the window
+  if (!(dbg & 1))
+  {
+    if (QUADS) fill_window_quads<4>(refL, reinterpret_cast<const uint4*>(ref + (winOff - off)), rs >> 3, winRows, pitchDw,
+                                    ((Ww - 1 + off) >> 3) + 1, tid, (int)blockDim.x);
+    else       fill_window_pairs<8>(refL, reinterpret_cast<const unsigned*>(ref + (winOff - off)), rs >> 1, winRows, pitchDw,
+                                    ((Ww - 1 + off) >> 1) + 1, tid, (int)blockDim.x);
+  }
+  __syncthreads();
+
+  const int ncg = (nx + 12) / 13, nrp = (nj + 1) >> 1;
+  const int q = tid & 31, rowsel = q >= 13 ? 1 : 0, ic = q - 13 * rowsel;
+  const int oodd = blk.org_x & 1;                                        // block origin in the high half of a dword pair
+  const unsigned* orgDw = reinterpret_cast<const unsigned*>(org + (size_t)blk.org_y * os + blk.org_x - oodd);
+  const int osStep = (os >> 1) << subShift;                              // dwords between used org rows
+  const int ldsStep = pitchDw << subShift;
+  for (int hh = tid >> 5; hh < ncg * nrp; hh += blockDim.x >> 5)
+  {
+    const int rp = hh / ncg, cg = hh - rp * ncg;
+    const int i = cg * 13 + ic, jj = 2 * rp + rowsel;
+    const bool live = q < 26 && i < nx && jj < nj;
+    const int cx = (live ? i : 0) * 5 + off;
+    const unsigned sh = (cx & 1) << 4;
+    const unsigned* base = refL + (cx >> 1) + ((live ? jj : 0) * 5) * pitchDw;
+    unsigned acc = 0;
+    if (!(dbg & 2))
+    {
+      if (oodd) for (int r = 0; r < hs; r += RB) acc = r5_rows<WP, RB, true>(orgDw + (size_t)r * osStep, osStep, base + r * ldsStep, ldsStep, sh, acc);
+      else      for (int r = 0; r < hs; r += RB) acc = r5_rows<WP, RB, false>(orgDw + (size_t)r * osStep, osStep, base + r * ldsStep, ldsStep, sh, acc);
+    }
+    if (live) out[((size_t)b * ny + j0 + jj) * nx + i] = acc << subShift;
   }
 }
 
@@ -321,6 +465,54 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
                 "sad_search: sub_shift %d incompatible with height %d", sub_shift, h);
   VVC_CHECK_ARG(nx > 0 && ny > 0 && sx > 0 && sy > 0, "sad_search: bad position grid");
   VVC_CHECK_ARG((best == nullptr) == (mvcost_host == nullptr), "sad_search: best and mvcost must be given together");
+  hipStream_t st0 = (hipStream_t)stream;
+  if (sx == 5 && sy == 5 && (w == 16 || w == 32 || w == 64) && (org_stride & 1) == 0 && (ref_stride & 1) == 0 &&
+      ((uintptr_t)org & 3) == 0 && ((uintptr_t)ref & 3) == 0)
+  {
+    // (block origins must be even for the scalar org loads; checked on the device side would cost a divergent path, so the
+    //  caller contract is: org_x even -- true for every CU position, which are multiples of 4)
+    const int Ww = (nx - 1) * 5 + w;
+    const bool quads = ((ref_stride & 7) == 0) && (((uintptr_t)ref & 15) == 0);
+    // aligned row start is up to 7 samples (quads) / 1 sample (pairs) before the window; + one look-ahead pair; quad rows are
+    // stored whole, so the pitch also covers the last (partly used) quad
+    int pitch = quads ? (((Ww - 1 + 7) >> 3) + 1) * 4 + 1 : (Ww + 1) / 2 + 2;
+    while ((pitch & 31) != 13 && (pitch & 31) != 19) pitch++;
+    const int hsR = h >> sub_shift;
+    const size_t budgetR = 52 * 1024;
+    int rps = ny & ~1;
+    if (rps < 2) rps = ny;
+    while (rps > 2 && ((size_t)((rps - 1) * 5 + h) * pitch * 4 > budgetR)) rps -= 2;
+    const int nstrips = cdiv(ny, rps);
+    rps = cdiv(ny, nstrips);
+    if ((rps & 1) && rps < ny) rps++;
+    const size_t smemR = (size_t)((rps - 1) * 5 + h) * pitch * 4;
+    if (smemR <= 150 * 1024 && (hsR % 4) == 0)
+    {
+      const int halves = cdiv(nx, 13) * ((rps + 1) / 2);
+      int threads = ((halves * 32 + 63) / 64) * 64;
+      if (threads > 512) threads = 512;
+      if (threads < 128) threads = 128;
+      dim3 gridR(nblocks, cdiv(ny, rps));
+      static const int dbgMode = getenv("VVCGPU_DBG_R5") ? atoi(getenv("VVCGPU_DBG_R5")) : 0;   // timing experiments only
+#define LAUNCH_R5(WPV, RBV, QV)                                                                                                \
+      do {                                                                                                                     \
+        if (smemR > 64 * 1024)                                                                                                 \
+          VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster5_kernel<WPV, RBV, QV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemR)); \
+        hipLaunchKernelGGL((sad_raster5_kernel<WPV, RBV, QV>), gridR, dim3(threads), smemR, st0, org, org_stride, ref, ref_stride, blocks, h, \
+                           sub_shift, dx0, dy0, nx, ny, rps, pitch, dbgMode, sad_out);                                          \
+      } while (0)
+      if (quads) { if (w == 16) LAUNCH_R5(8, 4, true); else if (w == 32) LAUNCH_R5(16, 2, true); else LAUNCH_R5(32, 1, true); }
+      else       { if (w == 16) LAUNCH_R5(8, 4, false); else if (w == 32) LAUNCH_R5(16, 2, false); else LAUNCH_R5(32, 1, false); }
+#undef LAUNCH_R5
+      VVC_LAUNCH_CHECK();
+      if (best)
+      {
+        hipLaunchKernelGGL(sad_best_kernel, dim3(cdiv(nblocks, 4)), dim3(256), 0, st0, sad_out, nblocks, dx0, dy0, nx, ny, sx, sy, *mvcost_host, best);
+        VVC_LAUNCH_CHECK();
+      }
+      return VVCGPU_OK;
+    }
+  }
   const int hs = h >> sub_shift;
   const size_t orgDw = ((size_t)hs * (w / 2) + 3) & ~(size_t)3;
   // Strip selection: the staged window (one copy, + 2 pairs of slack per row) must fit an LDS budget that keeps three
