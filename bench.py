@@ -62,6 +62,28 @@ def cpu_baseline(width, height, bd):
                                                         {k: round(v / reps, 4) for k, v in secs_tot.items()})}
 
 
+def traffic_from_profile(kernel_hint, avg_ms):
+    """HBM traffic per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this same command
+    (profiles/rNN_launch_groups.csv, written by profiles/summarize.py: FETCH_SIZE x2-corrected for gfx950 + WRITE_SIZE).
+    The launch group is matched by kernel name and by the closest average duration.  None when no profile is committed."""
+    import csv
+    import glob
+    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_launch_groups.csv")))
+    if not files:
+        return None
+    best = None
+    with open(files[-1]) as f:
+        for r in csv.DictReader(f):
+            if kernel_hint not in r["kernel"] or not r["fetch_MB_x2_corrected"] or not r["write_MB"]:
+                continue
+            d = abs(float(r["avg_us"]) / 1e3 - avg_ms) / avg_ms
+            if best is None or d < best[0]:
+                best = (d, (float(r["fetch_MB_x2_corrected"]) + float(r["write_MB"])) * 1e6, os.path.basename(files[-1]))
+    if best is None or best[0] > 0.35:
+        return None
+    return {"bytes": best[1], "source": best[2]}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -158,6 +180,8 @@ def main():
         else:
             per_kernel[k] = {"ms": round(v, 4)}
 
+    hint = "sad_raster5" if ("39x39" in dname or "x39" in dname) else dname.split("_")[0] if dstage != "me" else "sad_search"
+    tr = traffic_from_profile(hint, kern_ms[dom]) if rank == 0 else None
     if rank == 0:
         res = {
             "metric": "encoded frames/sec (bit-exact bitstream) at 4K10 RA QP32, 1/2/4/8 GPU",
@@ -178,7 +202,8 @@ def main():
                        "width": args.width, "height": args.height, "bit_depth": bd,
                        "parallelism": "one picture stream per GPU, intra-period sharding, p2p boundary picture per 32 pictures"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": None,
+                         "frac": achieved / HBM_PEAK_GBS, "traffic": (tr["bytes"] if tr else None),
+                         "traffic_source": (tr["source"] if tr else None),
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": kern_ms[dom]},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "kernels": per_kernel,

@@ -101,6 +101,46 @@ def test_sad_search(w, h, ss, grid):
     assert np.array_equal(gbest, wbest)
 
 
+@pytest.mark.parametrize("w,h,ss,nx,ny", [(16, 16, 1, 39, 39), (32, 32, 1, 39, 39), (64, 64, 1, 39, 39), (128, 128, 0, 9, 7),
+                                          (16, 16, 1, 45, 23), (16, 8, 0, 4, 1), (64, 16, 2, 13, 40), (32, 64, 3, 1, 5)])
+def test_sad_search_best_only(w, h, ss, nx, ny):
+    """raster grids with sad_out = NULL (fused arg-min, no SAD surface): the best candidate equals the oracle's scan."""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(w * 3 + h + nx * 7 + ny)
+    bd, m = 10, 136
+    PW, PH = 320 + 2 * m, 256 + 2 * m
+    org = cases.rand_plane(rng, 256, 320, bd, "smooth")
+    org = (2 * org.astype(np.int32) - cases.rand_plane(rng, 256, 320, bd, "smooth")).astype(np.int16)
+    refp = cases.rand_plane(rng, PH, PW, bd, "smooth")
+    dx0, dy0 = -5 * (nx // 2), -5 * (ny // 2)
+    nb = 9
+    blk = np.zeros(nb, ops.SEARCH_BLK)
+    for i in range(nb):
+        x, y = int(rng.integers(0, (320 - w) // 2 + 1)) * 2, int(rng.integers(0, 256 - h + 1))
+        blk[i] = (x, y, m + x + int(rng.integers(-9, 10)), m + y + int(rng.integers(-9, 10)))
+    mv = ops.MvCost(float(rng.uniform(0.5, 90)), int(rng.integers(-60, 60)), int(rng.integers(-60, 60)), 2, 0)
+    want = np.zeros((nb, ny, nx), np.uint32)
+    wbest = np.zeros(nb, ops.SEARCH_BEST)
+    oracle().orc_sad_search(p(org), 320, p(refp), PW, p(blk), nb, w, h, ss, dx0, dy0, nx, ny, 5, 5, p(want), C.byref(mv), p(wbest))
+    sad, best = ops.sad_search(dev(org), dev(refp), ops.struct_to_device(blk), nb, w, h, ss, dx0, dy0, nx, ny, 5, 5, mv,
+                               want_sad=False)
+    assert sad is None
+    assert np.array_equal(best.cpu().numpy().view(ops.SEARCH_BEST), wbest)
+    # and with the surface as well: both outputs, same launch path
+    sad, best = ops.sad_search(dev(org), dev(refp), ops.struct_to_device(blk), nb, w, h, ss, dx0, dy0, nx, ny, 5, 5, mv)
+    assert np.array_equal(sad.cpu().numpy().view(np.uint32), want)
+    assert np.array_equal(best.cpu().numpy().view(ops.SEARCH_BEST), wbest)
+
+
+def test_sad_search_best_only_needs_raster():
+    from vvcsoftware_vtm_amd import ops, capi
+    z = torch.zeros((64, 64), dtype=torch.int16, device="cuda")
+    blk = ops.struct_to_device(np.array([(8, 8, 8, 8)], ops.SEARCH_BLK))
+    mv = ops.MvCost(1.0, 0, 0, 2, 0)
+    with pytest.raises(capi.VvcGpuError, match="sad_out may only be NULL"):
+        ops.sad_search(z, z, blk, 1, 8, 8, 0, -1, -1, 3, 3, 1, 1, mv, want_sad=False)
+
+
 def test_sad_search_tie_rule():
     """flat content: every position has the same SAD, the MV cost decides; equal costs keep the first in scan order."""
     from vvcsoftware_vtm_amd import ops

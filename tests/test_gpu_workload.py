@@ -31,6 +31,9 @@ def test_workload_matches_oracle_416x240():
     torch.cuda.synchronize()
     cout, _ = wl.run_cpu(oracle(), "port")
     for k in cout:
+        if gout[k] is None:
+            assert k.startswith("me_sad_")        # raster grids return the best candidate only (checked via me_best_*)
+            continue
         _cmp(k, gout[k], cout[k])
     # steady state: a second step on the resident state gives the same answer (no stale state between steps)
     st, gout1 = wl.run_gpu()

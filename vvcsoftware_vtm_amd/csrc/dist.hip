@@ -346,11 +346,17 @@ __global__ __launch_bounds__(512) void sad_raster5_kernel(const Pel* __restrict_
                                                           const Pel* __restrict__ ref, int rs,
                                                           const vvcgpu_search_blk* __restrict__ blocks, int h, int subShift,
                                                           int dx0, int dy0, int nx, int ny, int rowsPerStrip, int pitchDw, int dbg,
-                                                          unsigned* __restrict__ out)
+                                                          int nstrips, int total, unsigned* __restrict__ out)
 {
   extern __shared__ __align__(16) unsigned refL[];
   const int tid = threadIdx.x;
-  const int b = blockIdx.x, j0 = blockIdx.y * rowsPerStrip;
+  // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so workgroup L lands with L+8, L+16...
+  // Give each XCD one CONTIGUOUS run of (block, strip) items: the strips of one block and the windows of neighbouring
+  // blocks overlap heavily, and this way the overlap is found in that XCD's own L2 instead of being fetched 8 times.
+  const int chunk = (total + 7) >> 3;
+  const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (item >= total) return;
+  const int b = item / nstrips, j0 = (item - b * nstrips) * rowsPerStrip;
   const int nj = min(rowsPerStrip, ny - j0);
   const vvcgpu_search_blk blk = blocks[b];
   const int hs = h >> subShift;
@@ -397,6 +403,271 @@ __device__ __forceinline__ unsigned expgolomb_bits(int v)        // RdCost.h:172
   unsigned len = 1, t = (v <= 0) ? ((unsigned)(-v) << 1) + 1 : (unsigned)(v << 1);
   while (t > 128u) { len += 14; t >>= 7; }
   return len + ((31 - __clz((int)t)) << 1);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Raster kernel, second generation ("r5c"): same job as sad_raster5_kernel, built around the fact that this kernel is
+// bound by instruction ISSUE (scalar + vector), not by LDS or HBM: rocprofv3 showed v_sad_u16 to be ~15 % of the vector
+// instructions of the first version, the rest being window fill, addressing, realignment and the argmin.
+//   * raster columns are split into the four classes i = c (mod 4): inside a class consecutive columns start exactly
+//     20 samples = 5 aligned 8-byte LDS words apart and the sub-word offset o = (5 i + off) & 3 is the same for every
+//     column, so a wave that works on ONE class needs no per-lane realignment: the word index and (for odd o) one
+//     v_alignbit with a constant shift are compile-time choices (4 instantiations picked by a wave-uniform switch).
+//   * one lane owns TWO positions, columns i and i+2 (classes c and c+2): their windows start 10 samples apart, so the
+//     two share their 8-byte words (7 or 8 loaded instead of 5 + 5) and the same wave-uniform org row: the scalar work
+//     per position (org loads, bias xor, addressing, loop) is halved and the LDS reads drop by a quarter.
+//   * a 32-lane half carries 10 columns x 3 raster rows.  ds_read_b64 banks are (a/4) mod 64, i.e. 32 word slots; the
+//     10 columns sit on slots 5k and the row pitch is chosen = 20 or 44 (mod 64) dwords, which puts the next raster row
+//     (5 window rows further) 10 or 22 "column steps" away: the three rows interleave into 30 distinct slots and every
+//     ds_read_b64 is conflict free at 2 LDS cycles per 8 bytes.  Dead lanes re-read a live lane's address (broadcast).
+//   * blocks wider than 16 are walked as 16-sample chunks, so one code path serves w = 16..128.
+//   * the org rows are wave-uniform scalar loads; SMEM and LDS share lgkmcnt and SMEM returns out of order, so the
+//     loop is software pipelined by hand: wait for stage s, issue the loads of stage s+1, then do the SADs of stage s.
+//   * optional fused argmin: cost = SAD + motion-vector cost as in sad_best_kernel (the bit counts of the columns / rows
+//     and lambda * bits come from small LDS tables built once per workgroup), packed as (cost << 24 | scan index) and
+//     reduced with 64-bit min (wave shuffles -> LDS -> one global atomicMin per workgroup), so that the raster stage need
+//     not write the SAD surface at all when the caller only wants the best candidate (xTZSearch does).
+// One stage = two 16-sample chunk-rows for the lane's two positions i and i+2 (classes c and c+2, whose windows overlap:
+// their 8-byte words are shared, 7 or 8 words for the two instead of 5 + 5).
+struct R5cStage { unsigned ov[2][9]; unsigned long long d[2][8]; };         // [chunk-row of the stage][word]
+
+template <int OA, bool OODD>
+__device__ __forceinline__ void r5c_issue_row(unsigned (&ov)[9], unsigned long long (&d)[8], const unsigned* __restrict__ op, unsigned a)
+{
+#pragma unroll
+  for (int k = 0; k < (OODD ? 9 : 8); k++) ov[k] = op[k];
+  // single ds_read_b64 (2 LDS cycles each); left to the compiler they are merged into ds_read2_b64, which runs at half
+  // that rate.  The compiler cannot see that the destination registers stay busy until the explicit lgkmcnt(0) of the
+  // pipeline: r5c_compute pins every one of them live past it, and a word that is not needed is not loaded at all.
+  if (OA == 3)
+    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\tds_read_b64 %3, %8 offset:24\n\t"
+                 "ds_read_b64 %4, %8 offset:32\n\tds_read_b64 %5, %8 offset:40\n\tds_read_b64 %6, %8 offset:48\n\tds_read_b64 %7, %8 offset:56"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]) : "v"(a) : "memory");
+  else
+    asm volatile("ds_read_b64 %0, %7\n\tds_read_b64 %1, %7 offset:8\n\tds_read_b64 %2, %7 offset:16\n\tds_read_b64 %3, %7 offset:24\n\t"
+                 "ds_read_b64 %4, %7 offset:32\n\tds_read_b64 %5, %7 offset:40\n\tds_read_b64 %6, %7 offset:48"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]) : "v"(a) : "memory");
+}
+
+// acc0 / acc1 = positions i / i+2.  Class c+2 starts 10 samples after class c: for OA in {0,1} that is word +2 with
+// sub-word offset OA+2, for OA in {2,3} word +3 with offset OA-2 -- all compile-time.
+template <int OA, bool OODD>
+__device__ __forceinline__ void r5c_compute(const R5cStage& st, unsigned& acc0, unsigned& acc1)
+{
+  constexpr int NW = OA == 3 ? 8 : 7;
+  constexpr int OB = OA ^ 2, WB = OA < 2 ? 2 : 3;
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+  {
+    unsigned dd[16];
+#pragma unroll
+    for (int k = 0; k < NW; k++)
+    {
+      asm volatile("" :: "v"(st.d[j][k]));                  // whole 64-bit destination stays allocated until here
+      dd[2 * k] = (unsigned)st.d[j][k]; dd[2 * k + 1] = (unsigned)(st.d[j][k] >> 32);
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++)
+    {
+      const unsigned o = (OODD ? ((st.ov[j][k] >> 16) | (st.ov[j][k + 1] << 16)) : st.ov[j][k]) ^ 0x80008000u;
+      const int ia = k + (OA >> 1), ib = 2 * WB + k + (OB >> 1);
+      acc0 = __builtin_amdgcn_sad_u16(o, (OA & 1) ? __builtin_amdgcn_alignbit(dd[ia + 1], dd[ia], 16) : dd[ia], acc0);
+      acc1 = __builtin_amdgcn_sad_u16(o, (OB & 1) ? __builtin_amdgcn_alignbit(dd[ib + 1], dd[ib], 16) : dd[ib], acc1);
+    }
+  }
+}
+
+#define R5C_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)       /* lgkmcnt(0), vmcnt/expcnt untouched */
+
+// walks the hs x CH chunk-rows of the block; (oOff, lOff) = dword offsets of the current chunk-row in the org plane / window
+struct R5cCursor
+{
+  unsigned oOff, lOff; int ch;
+  __device__ __forceinline__ void advance(int CH, unsigned oRow, unsigned lRow)
+  {
+    ch++; oOff += 8; lOff += 8;
+    if (ch == CH) { ch = 0; oOff += oRow; lOff += lRow; }
+  }
+};
+
+template <int OA, bool OODD>
+__device__ __forceinline__ void r5c_issue(R5cStage& st, const unsigned* __restrict__ orgDw, unsigned base, R5cCursor& cur, int CH,
+                                          unsigned oRow, unsigned lRow)
+{
+#pragma unroll
+  for (int j = 0; j < 2; j++)
+  {
+    r5c_issue_row<OA, OODD>(st.ov[j], st.d[j], orgDw + cur.oOff, base + cur.lOff * 4u);
+    cur.advance(CH, oRow, lRow);
+  }
+}
+
+template <int OA, bool OODD>
+__device__ __forceinline__ void r5c_positions(const unsigned* __restrict__ orgDw, int osStep, unsigned base, int ldsStep,
+                                              int nStages, int CH, unsigned& acc0, unsigned& acc1)
+{
+  R5cStage A, B;
+  R5cCursor cur = { 0u, 0u, 0 };
+  const unsigned oRow = (unsigned)(osStep - 8 * CH), lRow = (unsigned)(ldsStep - 8 * CH);
+  r5c_issue<OA, OODD>(A, orgDw, base, cur, CH, oRow, lRow);
+  for (int s = 0; s < nStages; s += 2)
+  {
+    R5C_WAIT_LGKM0();
+    if (s + 1 < nStages) r5c_issue<OA, OODD>(B, orgDw, base, cur, CH, oRow, lRow);
+    __builtin_amdgcn_sched_barrier(0);
+    r5c_compute<OA, OODD>(A, acc0, acc1);
+    if (s + 1 >= nStages) break;
+    R5C_WAIT_LGKM0();
+    if (s + 2 < nStages) r5c_issue<OA, OODD>(A, orgDw, base, cur, CH, oRow, lRow);
+    __builtin_amdgcn_sched_barrier(0);
+    r5c_compute<OA, OODD>(B, acc0, acc1);
+  }
+}
+
+// window fill for r5c: thread = (row r0, quad q), walking down the rows with a constant stride so that the addressing per
+// 16-byte load is one add for the global offset and one for the LDS index; FB loads in flight.
+template <int FB>
+__device__ __forceinline__ void fill_window_cols(unsigned* __restrict__ lds, const uint4* __restrict__ g, int rsQ, int winRows,
+                                                 int pitchDw, int nQuads, int tid, int nthreads)
+{
+  const int r0 = (int)(((float)tid + 0.5f) * __frcp_rn((float)nQuads));   // tid / nQuads (tid < 1024, nQuads < 1024: exact)
+  const int q = tid - r0 * nQuads;
+  const int R = nthreads / nQuads;                                         // rows per pass; threads beyond R * nQuads idle
+  if (r0 >= R) return;
+  unsigned goff = (unsigned)(r0 * rsQ + q);
+  unsigned loff = (unsigned)(r0 * pitchDw + 4 * q);
+  const unsigned gstep = (unsigned)(R * rsQ), lstep = (unsigned)(R * pitchDw);
+  for (int r = r0; r < winRows; r += FB * R)
+  {
+    uint4 v[FB];
+#pragma unroll
+    for (int u = 0; u < FB; u++)
+      if (r + u * R < winRows) v[u] = g[goff + u * gstep];
+#pragma unroll
+    for (int u = 0; u < FB; u++)
+      if (r + u * R < winRows)
+      {
+        uint2* d = reinterpret_cast<uint2*>(lds + loff + u * lstep);       // pitch is even: 8-byte aligned
+        d[0] = make_uint2(v[u].x ^ 0x80008000u, v[u].y ^ 0x80008000u);
+        d[1] = make_uint2(v[u].z ^ 0x80008000u, v[u].w ^ 0x80008000u);
+      }
+    goff += FB * gstep; loff += FB * lstep;
+  }
+}
+
+__global__ __launch_bounds__(512) void sad_raster5c_kernel(const Pel* __restrict__ org, int os,
+                                                           const Pel* __restrict__ ref, int rs,
+                                                           const vvcgpu_search_blk* __restrict__ blocks, int w, int h, int subShift,
+                                                           int dx0, int dy0, int nx, int ny, int rowsPerStrip, int pitchDw,
+                                                           int nstrips, int total, int winBytes, vvcgpu_mvcost mv, int useBest,
+                                                           unsigned* __restrict__ out, vvcgpu_search_best* __restrict__ best)
+{
+  extern __shared__ __align__(16) unsigned refL[];
+  __shared__ unsigned long long wgKey;
+  const int tid = threadIdx.x;
+  const int chunk = (total + 7) >> 3;                                      // XCD-aware order, see sad_raster5_kernel
+  const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (item >= total) return;
+  const int b = item / nstrips, j0 = (item - b * nstrips) * rowsPerStrip;
+  const int nj = min(rowsPerStrip, ny - j0);
+  const vvcgpu_search_blk blk = blocks[b];
+  const int hs = h >> subShift;
+  const int winRows = (nj - 1) * 5 + h;
+  const int Ww = (nx - 1) * 5 + w;
+  const ptrdiff_t winOff = (ptrdiff_t)(blk.ref_y + dy0 + j0 * 5) * rs + blk.ref_x + dx0;
+  const int off = (int)(winOff & 7);
+  fill_window_cols<4>(refL, reinterpret_cast<const uint4*>(ref + (winOff - off)), rs >> 3, winRows, pitchDw,
+                      ((Ww - 1 + off) >> 3) + 1, tid, (int)blockDim.x);
+  unsigned char* bitsX = reinterpret_cast<unsigned char*>(refL) + winBytes;   // [nx] then [rowsPerStrip]
+  unsigned char* bitsY = bitsX + nx;
+  if (useBest)
+  {
+    if (tid == 0) wgKey = ~0ull;
+    for (int n = tid; n < nx + nj; n += (int)blockDim.x)
+    {
+      const int v = n < nx ? (((dx0 + n * 5) << mv.cost_scale) - mv.pred_hor) : (((dy0 + (j0 + n - nx) * 5) << mv.cost_scale) - mv.pred_ver);
+      bitsX[n] = (unsigned char)expgolomb_bits(v >> mv.imv_shift);
+    }
+  }
+  __syncthreads();
+
+  const int CH = w >> 4;
+  const int nStages = (hs * CH) >> 1;
+  const int ngrp = (nj + 5) / 6, ncg = (nx + 39) / 40;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
+  const int lane = tid & 63, q = lane & 31;
+  int m = (q * 26) >> 8;                                                    // q / 10
+  const int k = q - 10 * m;                                                 // lanes 30, 31: m = 3 -> dead, re-reading lanes 0, 1
+  const bool laneDead = m >= 3;
+  if (laneDead) m = 0;
+  const int oodd = blk.org_x & 1;
+  const unsigned* orgDw = reinterpret_cast<const unsigned*>(org + (size_t)blk.org_y * os + blk.org_x - oodd);
+  const int osStep = (os >> 1) << subShift;
+  const int ldsStep = pitchDw << subShift;
+  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)refL;
+  unsigned long long kmin = ~0ull;
+  for (int cg = 0; cg < ncg; cg++)
+    for (int it = wave; it < 2 * ngrp; it += nwaves)
+    {
+      const int c = it & 1, g = it >> 1;                                    // classes c and c + 2
+      const int jj = g * 6 + (lane >> 5) * 3 + m;
+      const int i0 = cg * 40 + 4 * k + c;                                   // positions i0 and i0 + 2
+      const bool rowLive = !laneDead && jj < nj;
+      const int cx = 5 * (i0 < nx ? i0 : c) + off;                          // dead lanes re-read a live lane's address (broadcast)
+      const unsigned base = ldsBase + (unsigned)(2 * (cx >> 2) + (min(jj, nj - 1) * 5) * pitchDw) * 4u;
+      const int OA = (c + off) & 3;                                         // == cx & 3 for every lane of the wave
+      unsigned acc0 = 0, acc1 = 0;
+#define R5C_CALL(OV)                                                                                                            \
+      do { if (oodd) r5c_positions<OV, true>(orgDw, osStep, base, ldsStep, nStages, CH, acc0, acc1);                              \
+           else      r5c_positions<OV, false>(orgDw, osStep, base, ldsStep, nStages, CH, acc0, acc1); } while (0)
+      if (OA == 0) R5C_CALL(0); else if (OA == 1) R5C_CALL(1); else if (OA == 2) R5C_CALL(2); else R5C_CALL(3);
+#undef R5C_CALL
+      if (rowLive)
+      {
+        const int idx0 = (j0 + jj) * nx + i0;
+        unsigned* o = out ? out + (size_t)b * ny * nx + idx0 : nullptr;
+        const unsigned by = useBest ? bitsY[jj] : 0u;
+#pragma unroll
+        for (int p = 0; p < 2; p++)
+          if (i0 + 2 * p < nx)
+          {
+            const unsigned v = (p ? acc1 : acc0) << subShift;
+            if (o) o[2 * p] = v;
+            if (useBest)
+            {
+              const unsigned bits = bitsX[i0 + 2 * p] + by;
+              const unsigned long long key = ((v + (unsigned long long)(mv.lambda * (double)bits)) << 24) | (unsigned)(idx0 + 2 * p);
+              kmin = key < kmin ? key : kmin;
+            }
+          }
+      }
+    }
+  if (useBest)
+  {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long ok = __shfl_xor(kmin, o); kmin = ok < kmin ? ok : kmin; }
+    if (lane == 0 && kmin != ~0ull) atomicMin(&wgKey, kmin);
+    __syncthreads();
+    if (tid == 0 && wgKey != ~0ull) atomicMin(reinterpret_cast<unsigned long long*>(&best[b].cost), wgKey);
+  }
+}
+
+// decodes the packed (cost << 24 | scan index) keys left in best[].cost by sad_raster5c_kernel
+__global__ __launch_bounds__(256) void sad_best_decode_kernel(int nblocks, int dx0, int dy0, int nx, int sx, int sy, vvcgpu_mvcost mv,
+                                                              vvcgpu_search_best* __restrict__ best)
+{
+  const int b = blockIdx.x * 256 + threadIdx.x;
+  if (b >= nblocks) return;
+  const unsigned long long key = best[b].cost;
+  const int idx = (int)(key & 0xFFFFFFu);
+  const unsigned long long cost = key >> 24;
+  const int j = idx / nx, i = idx - j * nx;
+  const int x = dx0 + i * sx, y = dy0 + j * sy;
+  const unsigned bits = expgolomb_bits(((x << mv.cost_scale) - mv.pred_hor) >> mv.imv_shift) +
+                        expgolomb_bits(((y << mv.cost_scale) - mv.pred_ver) >> mv.imv_shift);
+  vvcgpu_search_best r;
+  r.x = x; r.y = y; r.cost = cost; r.sad = cost - (unsigned long long)(mv.lambda * (double)bits);
+  best[b] = r;
 }
 
 __global__ __launch_bounds__(256) void sad_best_kernel(const unsigned* __restrict__ sad, int nblocks, int dx0, int dy0,
@@ -459,13 +730,57 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
 {
   VVC_CHECK_ARG(nblocks >= 0, "sad_search: nblocks %d", nblocks);
   if (nblocks == 0) return VVCGPU_OK;
-  VVC_CHECK_ARG(org && ref && blocks && sad_out, "sad_search: null pointer");
+  VVC_CHECK_ARG(org && ref && blocks && (sad_out || best), "sad_search: null pointer");
   VVC_CHECK_ARG(w >= 4 && w <= 128 && (w & 1) == 0 && h >= 4 && h <= 128, "sad_search: block %dx%d unsupported", w, h);
   VVC_CHECK_ARG(sub_shift >= 0 && sub_shift <= 4 && (h >> sub_shift) >= 1 && (h & ((1 << sub_shift) - 1)) == 0,
                 "sad_search: sub_shift %d incompatible with height %d", sub_shift, h);
   VVC_CHECK_ARG(nx > 0 && ny > 0 && sx > 0 && sy > 0, "sad_search: bad position grid");
   VVC_CHECK_ARG((best == nullptr) == (mvcost_host == nullptr), "sad_search: best and mvcost must be given together");
   hipStream_t st0 = (hipStream_t)stream;
+  static const int r5cOff = getenv("VVCGPU_NO_R5C") ? 1 : 0;              // A/B timing switch
+  if (!r5cOff && sx == 5 && sy == 5 && (w == 16 || w == 32 || w == 64 || w == 128) && (org_stride & 1) == 0 && (ref_stride & 7) == 0 &&
+      ((uintptr_t)org & 3) == 0 && ((uintptr_t)ref & 15) == 0 && (long long)nx * ny < (1 << 24) && nx >= 1)
+  {
+    static const int budgetKB = getenv("VVCGPU_R5C_KB") ? atoi(getenv("VVCGPU_R5C_KB")) : 78;
+    const int hsR = h >> sub_shift, chunks = w >> 4;
+    const int Ww = (nx - 1) * 5 + w;
+    int pitch = (((Ww - 1 + 7) >> 3) + 1) * 4;                             // whole 16-byte quads of the widest row
+    while ((pitch & 63) != 20 && (pitch & 63) != 44) pitch += 4;
+    const size_t budget = (size_t)budgetKB * 1024;
+    auto win_bytes = [&](int rps) { return (size_t)((rps - 1) * 5 + h) * pitch * 4 + 64; };    // + slack: a dead position's words end <= 64 B on
+    int nstrips = 1, rps = ny;                                             // fewest strips whose (3-row rounded) window fits
+    for (;; nstrips++)
+    {
+      rps = cdiv(cdiv(ny, nstrips), 3) * 3;
+      if (win_bytes(rps) <= budget || rps <= 3) break;
+    }
+    nstrips = cdiv(ny, rps);
+    const size_t winB = win_bytes(rps), smem = winB + (((size_t)nx + rps + 15) & ~(size_t)15);
+    if (smem <= 150 * 1024 && ((hsR * chunks) & 1) == 0 && nx + rps <= 4096)
+    {
+      const int items = 2 * cdiv(rps, 6);
+      const int threads = items >= 8 ? 512 : items * 64;
+      const int total = nblocks * nstrips;
+      vvcgpu_mvcost mv = {};
+      if (best)
+      {
+        mv = *mvcost_host;
+        VVC_HIP(hipMemsetAsync(best, 0xFF, (size_t)nblocks * sizeof(vvcgpu_search_best), st0));
+      }
+      if (smem > 48 * 1024)
+        VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster5c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(sad_raster5c_kernel, dim3(cdiv(total, 8) * 8), dim3(threads), smem, st0, org, org_stride, ref, ref_stride,
+                         blocks, w, h, sub_shift, dx0, dy0, nx, ny, rps, pitch, nstrips, total, (int)winB, mv, best ? 1 : 0, sad_out, best);
+      VVC_LAUNCH_CHECK();
+      if (best)
+      {
+        hipLaunchKernelGGL(sad_best_decode_kernel, dim3(cdiv(nblocks, 256)), dim3(256), 0, st0, nblocks, dx0, dy0, nx, sx, sy, mv, best);
+        VVC_LAUNCH_CHECK();
+      }
+      return VVCGPU_OK;
+    }
+  }
+  VVC_CHECK_ARG(sad_out, "sad_search: sad_out may only be NULL on the raster path (step 5, block width 16..128, aligned planes)");
   if (sx == 5 && sy == 5 && (w == 16 || w == 32 || w == 64) && (org_stride & 1) == 0 && (ref_stride & 1) == 0 &&
       ((uintptr_t)org & 3) == 0 && ((uintptr_t)ref & 3) == 0)
   {
@@ -492,14 +807,15 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       int threads = ((halves * 32 + 63) / 64) * 64;
       if (threads > 512) threads = 512;
       if (threads < 128) threads = 128;
-      dim3 gridR(nblocks, cdiv(ny, rps));
+      const int nstripsR = cdiv(ny, rps), totalR = nblocks * nstripsR;
+      dim3 gridR(cdiv(totalR, 8) * 8);
       static const int dbgMode = getenv("VVCGPU_DBG_R5") ? atoi(getenv("VVCGPU_DBG_R5")) : 0;   // timing experiments only
 #define LAUNCH_R5(WPV, RBV, QV)                                                                                                \
       do {                                                                                                                     \
         if (smemR > 64 * 1024)                                                                                                 \
           VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster5_kernel<WPV, RBV, QV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemR)); \
         hipLaunchKernelGGL((sad_raster5_kernel<WPV, RBV, QV>), gridR, dim3(threads), smemR, st0, org, org_stride, ref, ref_stride, blocks, h, \
-                           sub_shift, dx0, dy0, nx, ny, rps, pitch, dbgMode, sad_out);                                          \
+                           sub_shift, dx0, dy0, nx, ny, rps, pitch, dbgMode, nstripsR, totalR, sad_out);                                          \
       } while (0)
       if (quads) { if (w == 16) LAUNCH_R5(8, 4, true); else if (w == 32) LAUNCH_R5(16, 2, true); else LAUNCH_R5(32, 1, true); }
       else       { if (w == 16) LAUNCH_R5(8, 4, false); else if (w == 32) LAUNCH_R5(16, 2, false); else LAUNCH_R5(32, 1, false); }

@@ -117,6 +117,10 @@ __device__ __forceinline__ unsigned long long dist_lds(const short* org, const s
   return satd_lds<2, 2>(org, pred, w, h, lane, wave, nw);
 }
 
+// one wave per PU needs no workgroup barrier: LDS operations of a wave execute in order; the fence keeps the compiler from
+// moving LDS accesses across the point.  Four-wave groups (large PUs) use the real barrier.
+#define GROUP_SYNC() do { if (nw == 1) { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } else __syncthreads(); } while (0)
+
 struct FracLds { short* org; short* win; short* hpl; short* pred; unsigned long long* cost; int* sel; };
 
 // gsz lanes (1 or 4 waves) cooperate on one PU; all groups of the workgroup execute the same barrier sequence.
@@ -161,7 +165,7 @@ __global__ __launch_bounds__(256) void frac_refine_kernel(const Pel* __restrict_
     {
       const int qx = bx + cxi * step;
       const int ix = qx >> 2, fx = (qx & 3) << 2;
-      __syncthreads();                                           // window / previous users of hpl, pred done
+      GROUP_SYNC();                                           // window / previous users of hpl, pred done
       if (active)
       {
         // first-stage horizontal plane, rows -4 .. h+3 (h+8 rows), cols 0 .. w-1 at integer offset ix
@@ -183,7 +187,7 @@ __global__ __launch_bounds__(256) void frac_refine_kernel(const Pel* __restrict_
           L.hpl[i] = (short)v;
         }
       }
-      __syncthreads();
+      GROUP_SYNC();
       for (int cyi = -1; cyi <= 1; cyi++)
       {
         const int qy = by + cyi * step;
@@ -229,7 +233,7 @@ __global__ __launch_bounds__(256) void frac_refine_kernel(const Pel* __restrict_
             }
           }
         }
-        __syncthreads();
+        GROUP_SYNC();
         if (active)
         {
           const unsigned long long d = dist_lds(L.org, L.pred, w, h, useHad, lane, wave, nw);
@@ -242,7 +246,7 @@ __global__ __launch_bounds__(256) void frac_refine_kernel(const Pel* __restrict_
           }
           if (lane == 0) L.cost[16 + ci * 4 + wave] = d;              // per-wave partials, summed after the barrier
         }
-        __syncthreads();
+        GROUP_SYNC();
         if (active && tid == 0)
         {
           int ci = 0;
@@ -257,7 +261,7 @@ __global__ __launch_bounds__(256) void frac_refine_kernel(const Pel* __restrict_
         }
       }
     }
-    __syncthreads();
+    GROUP_SYNC();
     if (active && tid == 0)
     {
       unsigned long long best = ~0ull;
@@ -275,7 +279,7 @@ __global__ __launch_bounds__(256) void frac_refine_kernel(const Pel* __restrict_
       if (stage == 0) { results[b].half_x = dx; results[b].half_y = dy; results[b].cost_half = best; }
       else { results[b].qter_x = dx; results[b].qter_y = dy; results[b].cost = best; }
     }
-    __syncthreads();
+    GROUP_SYNC();
     if (stage == 0) { hx = L.sel[0]; hy = L.sel[1]; }
   }
 }
