@@ -555,7 +555,9 @@ __device__ __forceinline__ void fill_window_cols(unsigned* __restrict__ lds, con
   }
 }
 
-__global__ __launch_bounds__(512) void sad_raster5c_kernel(const Pel* __restrict__ org, int os,
+// MINW = waves per SIMD the register allocation must allow: 6 (<= 80 VGPRs) when three workgroups fit the CU's LDS, else 4
+template <int MINW>
+__global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const Pel* __restrict__ org, int os,
                                                            const Pel* __restrict__ ref, int rs,
                                                            const vvcgpu_search_blk* __restrict__ blocks, int w, int h, int subShift,
                                                            int dx0, int dy0, int nx, int ny, int rowsPerStrip, int pitchDw,
@@ -767,10 +769,15 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
         mv = *mvcost_host;
         VVC_HIP(hipMemsetAsync(best, 0xFF, (size_t)nblocks * sizeof(vvcgpu_search_best), st0));
       }
-      if (smem > 48 * 1024)
-        VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster5c_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      hipLaunchKernelGGL(sad_raster5c_kernel, dim3(cdiv(total, 8) * 8), dim3(threads), smem, st0, org, org_stride, ref, ref_stride,
-                         blocks, w, h, sub_shift, dx0, dy0, nx, ny, rps, pitch, nstrips, total, (int)winB, mv, best ? 1 : 0, sad_out, best);
+#define LAUNCH_R5C(MINW)                                                                                                        \
+      do {                                                                                                                      \
+        if (smem > 48 * 1024)                                                                                                   \
+          VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster5c_kernel<MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL(sad_raster5c_kernel<MINW>, dim3(cdiv(total, 8) * 8), dim3(threads), smem, st0, org, org_stride, ref, ref_stride, \
+                           blocks, w, h, sub_shift, dx0, dy0, nx, ny, rps, pitch, nstrips, total, (int)winB, mv, best ? 1 : 0, sad_out, best); \
+      } while (0)
+      if ((smem + 1024) * 3 <= 160 * 1024) LAUNCH_R5C(6); else LAUNCH_R5C(4);
+#undef LAUNCH_R5C
       VVC_LAUNCH_CHECK();
       if (best)
       {

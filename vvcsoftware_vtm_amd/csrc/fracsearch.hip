@@ -284,6 +284,292 @@ __global__ __launch_bounds__(256) void frac_refine_kernel(const Pel* __restrict_
   }
 }
 
+
+// ---------------------------------------------------------------------------------------------------
+// 16x16 specialisation (the PU size the canonical workload refines; 8x8 Hadamard tiles or SAD): one WAVE per PU, no
+// workgroup barriers, the candidate blocks never touch LDS.
+//   lane = (tile t = lane >> 4, row-quad rq = (lane >> 3) & 1, column c = lane & 7): the lane owns column x = 8 (t & 1) + c,
+//   rows y0 .. y0+3 with y0 = 8 (t >> 1) + 4 rq, so one 16-lane DPP row holds one 8x8 Hadamard tile.
+//   * window 24x24 and the 14-bit first-stage planes live in LDS (per wave); a plane is built by 48 lanes, each
+//     filtering 8 or 9 neighbouring outputs of one row from 8 dword reads; the two half-sample planes at integer
+//     offsets -1 / 0 are one 17-column plane, and the quarter stage reuses the half stage's plane for dx = 0.
+//   * per (plane, column) the lane loads its 12 plane rows ONCE and derives the three vertical candidates from
+//     registers; the residual goes straight into the Hadamard: rows in registers, the remaining row stage and the
+//     column stages with DPP (row_ror:8 for the row halves, quad_perm for xor 1 / 2, a row_shl:4 + row_shr:4
+//     pair for xor 4): the coefficients are those of RdCost::xCalcHADs8x8; the transposed tile orientation is harmless
+//     because H D H^T and H D^T H^T have the same absolute sum.
+//   * the quarter stage's centre candidate is the half stage's winner: its distortion is reused, not recomputed.
+template <int CTRL> __device__ __forceinline__ int dpp_mov(int v) { return __builtin_amdgcn_update_dpp(0, v, CTRL, 0xF, 0xF, false); }
+constexpr int DPP_XOR1 = 0xB1, DPP_XOR2 = 0x4E, DPP_HALF_MIRROR = 0x141, DPP_ROR8 = 0x128;
+
+template <int CTRL>
+__device__ __forceinline__ void had_cross(int (&v)[4], bool upper)
+{
+#pragma unroll
+  for (int j = 0; j < 4; j++) { const int p = dpp_mov<CTRL>(v[j]); v[j] = (upper ? -v[j] : v[j]) + p; }
+}
+
+// distortion of the candidate whose 4-row column segment is pred[]: wave-uniform result
+template <bool HAD>
+__device__ __forceinline__ unsigned f16_dist(const int (&orgv)[4], const int (&pred)[4], int lane)
+{
+  int d[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) d[j] = orgv[j] - pred[j];
+  int s;
+  if (HAD)
+  {
+    int v[4] = { d[0] + d[1], d[0] - d[1], d[2] + d[3], d[2] - d[3] };
+    { const int a0 = v[0] + v[2], a2 = v[0] - v[2], a1 = v[1] + v[3], a3 = v[1] - v[3]; v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3; }
+    had_cross<DPP_ROR8>(v, (lane & 8) != 0);
+    had_cross<DPP_XOR1>(v, (lane & 1) != 0);
+    had_cross<DPP_XOR2>(v, (lane & 2) != 0);
+    {                                              // xor 4: row_shl:4 into banks 0, 2 and row_shr:4 into banks 1, 3
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+        int p = __builtin_amdgcn_update_dpp(0, v[j], 0x104, 0xF, 0x5, false);
+        p = __builtin_amdgcn_update_dpp(p, v[j], 0x114, 0xF, 0xA, false);
+        v[j] = ((lane & 4) ? -v[j] : v[j]) + p;
+      }
+    }
+    s = abs(v[0]) + abs(v[1]) + abs(v[2]) + abs(v[3]);
+  }
+  else
+    s = abs(d[0]) + abs(d[1]) + abs(d[2]) + abs(d[3]);
+  s += dpp_mov<DPP_XOR1>(s); s += dpp_mov<DPP_XOR2>(s); s += dpp_mov<DPP_HALF_MIRROR>(s); s += dpp_mov<DPP_ROR8>(s);   // tile sum in all 16 lanes
+  unsigned t0 = (unsigned)__builtin_amdgcn_readlane(s, 0), t1 = (unsigned)__builtin_amdgcn_readlane(s, 16),
+           t2 = (unsigned)__builtin_amdgcn_readlane(s, 32), t3 = (unsigned)__builtin_amdgcn_readlane(s, 48);
+  if (HAD) return ((t0 + 2) >> 2) + ((t1 + 2) >> 2) + ((t2 + 2) >> 2) + ((t3 + 2) >> 2);           // xCalcHADs8x8: (sad + 2) >> 2 per tile
+  return t0 + t1 + t2 + t3;
+}
+
+// vertical (last-stage) filter of the lane's column: col[k] = plane row y0 - 4 + k, outputs rows y0 .. y0+3 at integer
+// row offset IY (-1 / 0) and quarter phase fy (0..3)
+template <int IY>
+__device__ __forceinline__ void f16_vert(const int (&col)[12], int fy, int headRoom, int cmin, int cmax, int (&out)[4])
+{
+  if (fy == 0)                                     // IY == 0 here
+  {
+#pragma unroll
+    for (int yy = 0; yy < 4; yy++) out[yy] = clip3(cmin, cmax, (int)(short)((col[4 + yy] + OFFS + (1 << (headRoom - 1))) >> headRoom));
+    return;
+  }
+  const short* cf = c_lumaF[fy << 2];
+  const int shift2 = 6 + headRoom, off2 = (1 << (shift2 - 1)) + (OFFS << 6);
+  int c8[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++) c8[k] = cf[k];
+#pragma unroll
+  for (int yy = 0; yy < 4; yy++)
+  {
+    int sum = off2;
+#pragma unroll
+    for (int k = 0; k < 8; k++) sum += col[IY + 1 + yy + k] * c8[k];
+    out[yy] = clip3(cmin, cmax, (int)(short)(sum >> shift2));
+  }
+}
+
+// first-stage plane into hp (pitch 18, plane column -1 at index 0): lanes 0..47 = (row r, segment); 16-column planes at
+// integer offset ix use outputs x = 0..15, the 17-column half plane (WIDE) x = -1..15.
+template <bool WIDE>
+__device__ __forceinline__ void f16_hplane(const short* __restrict__ win, short* __restrict__ hp, int ix, int fx, int headRoom, int lane)
+{
+  if (lane < 48)
+  {
+    const int r = lane >> 1, seg = lane & 1;
+    const unsigned* wr = reinterpret_cast<const unsigned*>(win + r * 26 + seg * 8);      // 16 samples = window cols 8 seg .. 8 seg + 15
+    int sm[16];
+#pragma unroll
+    for (int k = 0; k < 8; k++) { const unsigned u = wr[k]; sm[2 * k] = (int)(short)(u & 0xFFFF); sm[2 * k + 1] = (int)u >> 16; }
+    short* o = hp + r * 18 + 1 + seg * 8;
+    const int shift1 = 6 - headRoom, off1 = -(OFFS << shift1);
+    const short* cf = c_lumaF[fx << 2];
+    int c8[8];
+#pragma unroll
+    for (int k = 0; k < 8; k++) c8[k] = cf[k];
+    // output x (plane column) uses window cols x + ix + 1 .. x + ix + 8, i.e. sm[x - 8 seg + ix + 1 + k]
+    if (WIDE)                                      // ix = -1..0 folded into the 17 columns: column x' uses sm[x' - 8 seg + 1 + k]
+    {
+      if (seg == 0)
+      {
+#pragma unroll
+        for (int x = -1; x < 8; x++)
+        {
+          int sum = off1;
+#pragma unroll
+          for (int k = 0; k < 8; k++) sum += sm[x + 1 + k] * c8[k];
+          o[x] = (short)(sum >> shift1);
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int x = 0; x < 8; x++)
+        {
+          int sum = off1;
+#pragma unroll
+          for (int k = 0; k < 8; k++) sum += sm[x + 1 + k] * c8[k];
+          o[x] = (short)(sum >> shift1);
+        }
+      }
+    }
+    else if (fx == 0)
+    {
+#pragma unroll
+      for (int x = 0; x < 8; x++) o[x] = (short)((short)(sm[x + 4] << headRoom) - (short)OFFS);   // ix == 0
+    }
+    else if (ix == 0)
+    {
+#pragma unroll
+      for (int x = 0; x < 8; x++)
+      {
+        int sum = off1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) sum += sm[x + 1 + k] * c8[k];
+        o[x] = (short)(sum >> shift1);
+      }
+    }
+    else
+    {
+#pragma unroll
+      for (int x = 0; x < 8; x++)
+      {
+        int sum = off1;
+#pragma unroll
+        for (int k = 0; k < 8; k++) sum += sm[x + k] * c8[k];
+        o[x] = (short)(sum >> shift1);
+      }
+    }
+  }
+}
+
+#define WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+__device__ __forceinline__ int f16_idx(int dx, int dy, bool quarter)        // position of (dx, dy) in s_acMvRefineH / s_acMvRefineQ
+{
+  if (dx == 0) return dy == 0 ? 0 : dy < 0 ? 1 : 2;
+  if (!quarter) return dx < 0 ? (dy == 0 ? 3 : dy < 0 ? 5 : 7) : (dy == 0 ? 4 : dy < 0 ? 6 : 8);
+  return dx < 0 ? (dy < 0 ? 3 : dy == 0 ? 5 : 7) : (dy < 0 ? 4 : dy == 0 ? 6 : 8);
+}
+
+// arg-min of dist[i] + mvcost(candidate i) over the 9 candidates, first index on ties; lanes 0..8 carry one candidate each
+__device__ __forceinline__ void f16_best(const unsigned* dist, bool quarter, const vvcgpu_mvcost& mv, int baseX, int baseY, int scale,
+                                         int lane, int& bdx, int& bdy, unsigned long long& bcost, unsigned& bdist)
+{
+  const int li = lane < 9 ? lane : 0;
+  const int dx = quarter ? c_refQ[li][0] : c_refH[li][0], dy = quarter ? c_refQ[li][1] : c_refH[li][1];
+  const unsigned dl = dist[li];
+  unsigned long long c = lane < 9 ? (unsigned long long)dl + mv_cost(mv.lambda, mv.pred_hor, mv.pred_ver, scale, baseX + dx, baseY + dy) : ~0ull;
+  int bi = lane;
+#pragma unroll
+  for (int o = 1; o < 16; o <<= 1)
+  {
+    const unsigned long long oc = __shfl_xor(c, o);
+    const int oi = __shfl_xor(bi, o);
+    if (oc < c || (oc == c && oi < bi)) { c = oc; bi = oi; }
+  }
+  bi = __builtin_amdgcn_readfirstlane(bi);
+  bcost = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(c >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+  bdx = quarter ? c_refQ[bi][0] : c_refH[bi][0];
+  bdy = quarter ? c_refQ[bi][1] : c_refH[bi][1];
+  bdist = dist[bi];
+}
+
+template <bool HAD>
+__global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
+                                                     const vvcgpu_frac_blk* __restrict__ blocks, int nblocks, int bd, int cmin, int cmax,
+                                                     vvcgpu_mvcost mv, vvcgpu_frac_result* __restrict__ results)
+{
+  __shared__ __align__(16) short winS[4][24 * 26];
+  __shared__ __align__(16) short hplS[4][3][24 * 18];      // [0] integer plane, [1] half plane (17 cols), [2] quarter planes
+  __shared__ unsigned distS[4][16];                        // candidate distortions of the current stage (wave-uniform values)
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= nblocks) return;                                 // no workgroup barrier below
+  short* win = winS[wave];
+  short* hp0 = hplS[wave][0];
+  short* hp8 = hplS[wave][1];
+  short* hpq = hplS[wave][2];
+  const vvcgpu_frac_blk blk = blocks[b];
+  const int t = lane >> 4, x = 8 * (t & 1) + (lane & 7), y0 = 8 * (t >> 1) + 4 * ((lane >> 3) & 1);
+  int orgv[4];
+  {
+    const Pel* o = org + (size_t)(blk.org_y + y0) * os + blk.org_x + x;
+#pragma unroll
+    for (int j = 0; j < 4; j++) orgv[j] = o[(size_t)j * os];
+    const Pel* r0 = ref + (ptrdiff_t)(blk.ref_y - 4) * rs + blk.ref_x - 4;
+#pragma unroll
+    for (int u = 0; u < 9; u++)
+    {
+      const int i = lane + 64 * u, r = (i * 2731) >> 16, cc = i - r * 24;      // i / 24 for i < 576
+      win[r * 26 + cc] = r0[(ptrdiff_t)r * rs + cc];
+    }
+  }
+  const int headRoom = max(2, 14 - bd);
+  WAVE_SYNC();
+  f16_hplane<false>(win, hp0, 0, 0, headRoom, lane);
+  f16_hplane<true>(win, hp8, 0, 2, headRoom, lane);
+  WAVE_SYNC();
+
+  unsigned* dist = distS[wave];
+  int col[12], pred[4];
+  // ---- half stage: quarter offsets qx, qy in {-2, 0, 2}
+#pragma unroll
+  for (int dx = -1; dx <= 1; dx++)
+  {
+    const short* pc = dx == 0 ? hp0 + (y0 * 18 + 1 + x) : hp8 + (y0 * 18 + 1 + x + (dx < 0 ? -1 : 0));
+#pragma unroll
+    for (int k = 0; k < 12; k++) col[k] = pc[k * 18];
+    f16_vert<0>(col, 0, headRoom, cmin, cmax, pred);  dist[f16_idx(dx, 0, false)] = f16_dist<HAD>(orgv, pred, lane);
+    f16_vert<-1>(col, 2, headRoom, cmin, cmax, pred); dist[f16_idx(dx, -1, false)] = f16_dist<HAD>(orgv, pred, lane);
+    f16_vert<0>(col, 2, headRoom, cmin, cmax, pred);  dist[f16_idx(dx, 1, false)] = f16_dist<HAD>(orgv, pred, lane);
+  }
+  int hx, hy;
+  unsigned long long costH;
+  unsigned distH;
+  WAVE_SYNC();
+  f16_best(dist, false, mv, blk.mv_x << 1, blk.mv_y << 1, 1, lane, hx, hy, costH, distH);
+
+  // ---- quarter stage around (hx, hy): qx = 2 hx + dx, qy = 2 hy + dy
+#pragma unroll
+  for (int dx = -1; dx <= 1; dx++)
+  {
+    const int qx = 2 * hx + dx, ix = qx >> 2, fx = qx & 3;
+    const short* pc;
+    if (dx == 0) pc = hx == 0 ? hp0 + (y0 * 18 + 1 + x) : hp8 + (y0 * 18 + 1 + x + (hx < 0 ? -1 : 0));
+    else
+    {
+      WAVE_SYNC();                                          // previous readers of hpq are done
+      f16_hplane<false>(win, hpq, ix, fx, headRoom, lane);
+      WAVE_SYNC();
+      pc = hpq + (y0 * 18 + 1 + x);
+    }
+#pragma unroll
+    for (int k = 0; k < 12; k++) col[k] = pc[k * 18];
+#pragma unroll
+    for (int dy = -1; dy <= 1; dy++)
+    {
+      const int ci = f16_idx(dx, dy, true);
+      if (dx == 0 && dy == 0) { dist[ci] = distH; continue; }
+      const int qy = 2 * hy + dy, iy = qy >> 2, fy = qy & 3;
+      if (iy == 0) f16_vert<0>(col, fy, headRoom, cmin, cmax, pred); else f16_vert<-1>(col, fy, headRoom, cmin, cmax, pred);
+      dist[ci] = f16_dist<HAD>(orgv, pred, lane);
+    }
+  }
+  int qdx, qdy;
+  unsigned long long costQ;
+  unsigned distQ;
+  WAVE_SYNC();
+  f16_best(dist, true, mv, ((blk.mv_x << 1) + hx) << 1, ((blk.mv_y << 1) + hy) << 1, 0, lane, qdx, qdy, costQ, distQ);
+  if (lane == 0)
+  {
+    vvcgpu_frac_result r;
+    r.half_x = hx; r.half_y = hy; r.qter_x = qdx; r.qter_y = qdy; r.cost_half = costH; r.cost = costQ;
+    results[b] = r;
+  }
+}
+
 }  // namespace
 
 extern "C" int vvcgpu_frac_refine(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride,
@@ -304,6 +590,18 @@ extern "C" int vvcgpu_frac_refine(const vvc_pel* org, int org_stride, const vvc_
   const size_t smem = groupBytes * groups;
   VVC_CHECK_ARG(smem <= 160 * 1024, "frac_refine: LDS need %zu too large", smem);
   hipStream_t st = (hipStream_t)stream;
+  static const int f16Off = getenv("VVCGPU_NO_FRAC16") ? 1 : 0;           // A/B timing switch
+  if (w == 16 && h == 16 && !f16Off)
+  {
+    if (use_hadamard)
+      hipLaunchKernelGGL(frac16_kernel<true>, dim3(cdiv(nblocks, 4)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
+                         bit_depth, clp_min, clp_max, *mvcost_host, results);
+    else
+      hipLaunchKernelGGL(frac16_kernel<false>, dim3(cdiv(nblocks, 4)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
+                         bit_depth, clp_min, clp_max, *mvcost_host, results);
+    VVC_LAUNCH_CHECK();
+    return VVCGPU_OK;
+  }
   if (smem > 64 * 1024)
     VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frac_refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(frac_refine_kernel, dim3(cdiv(nblocks, groups)), dim3(256), smem, st, org, org_stride, ref, ref_stride, blocks,
