@@ -11,6 +11,9 @@ typedef int16_t Pel;
 typedef int32_t TCoeff;
 
 void vvcgpu_set_error(const char* fmt, ...);
+// Library-internal device scratch, cached per (device, stream): work on one stream is ordered, so the buffer of the previous
+// call on that stream is free again when the next call's kernels start.  Grow-only; returns nullptr (error text set) on failure.
+void* vvcgpu_scratch(hipStream_t stream, size_t bytes);
 
 #define VVC_CHECK_ARG(cond, ...)                                   \
   do { if (!(cond)) { vvcgpu_set_error(__VA_ARGS__); return VVCGPU_E_ARG; } } while (0)

@@ -1,5 +1,6 @@
 // lib.hip -- library-level entry points of the C ABI (include/vvcgpu.h).
 #include "common.h"
+#include <mutex>
 #include <stdarg.h>
 #include <string.h>
 
@@ -11,6 +12,38 @@ void vvcgpu_set_error(const char* fmt, ...)
   va_start(ap, fmt);
   vsnprintf(g_err, sizeof g_err, fmt, ap);
   va_end(ap);
+}
+
+namespace {
+struct ScratchSlot { int device; hipStream_t stream; void* ptr; size_t cap; };
+ScratchSlot g_scratch[64];
+int g_nScratch = 0;
+std::mutex g_scratchMutex;
+}
+
+void* vvcgpu_scratch(hipStream_t stream, size_t bytes)
+{
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { vvcgpu_set_error("hipGetDevice failed"); return nullptr; }
+  std::lock_guard<std::mutex> lock(g_scratchMutex);
+  ScratchSlot* slot = nullptr;
+  for (int i = 0; i < g_nScratch; i++)
+    if (g_scratch[i].device == dev && g_scratch[i].stream == stream) { slot = &g_scratch[i]; break; }
+  if (!slot)
+  {
+    if (g_nScratch == 64) { vvcgpu_set_error("scratch: more than 64 (device, stream) pairs in use"); return nullptr; }
+    slot = &g_scratch[g_nScratch++];
+    slot->device = dev; slot->stream = stream; slot->ptr = nullptr; slot->cap = 0;
+  }
+  if (slot->cap < bytes)
+  {
+    // the old buffer may still be in use by queued work of this stream: drain it before freeing
+    if (slot->ptr) { (void)hipStreamSynchronize(stream); (void)hipFree(slot->ptr); slot->ptr = nullptr; slot->cap = 0; }
+    const size_t cap = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    if (hipMalloc(&slot->ptr, cap) != hipSuccess) { slot->ptr = nullptr; vvcgpu_set_error("scratch: hipMalloc(%zu) failed", cap); return nullptr; }
+    slot->cap = cap;
+  }
+  return slot->ptr;
 }
 
 extern "C" {

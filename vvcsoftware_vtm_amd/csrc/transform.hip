@@ -6,10 +6,15 @@
 // `(sum + rnd) >> shift` between the stages (:214-215), inverse stages clipped to [-2^15, 2^15-1] (:253-256), zero-out of
 // columns/rows >= 32 (:157-162, :755-759); xTransformSkip / xITransformSkip (:795-847, :1112-1163).
 //
-// Design: one workgroup per TU, both 1-D stages inside the workgroup with the intermediate in LDS (the reference's
-// alloca'd `tmp`, never in HBM).  Products fit 24 x 24 bits (|coef| <= 362, data < 2^16), accumulation is exact int32.
-// One wave handles one output ROW/COLUMN index per iteration so the matrix row is wave-uniform (scalar loads) while
-// the data operand streams from LDS with an odd dword pitch (conflict-free).
+// Design: both 1-D stages of a TU run inside one wave with the intermediate in LDS (the reference's alloca'd `tmp`,
+// never in HBM); accumulation is exact int32.  A batch is served by two launches:
+//   * LARGE TUs (a side of 32 or 64): one wave per TU, lane = row / column, the matrix row of the current output index
+//     is wave-uniform (scalar loads); persistent grid-stride waves that skip the other descriptors.
+//   * SMALL TUs (both sides <= 16) and transform skip: a 4x4 TU would leave 60 of 64 lanes idle and, worse, a launch
+//     of one workgroup per TU is bound by the dispatcher (~1 workgroup/ns chip-wide: 0.5 ms for a 4K picture of 4x4
+//     TUs).  Here a 256-thread workgroup takes 64 consecutive descriptors, bins them by max(w, h) in LDS and gives
+//     every TU a group of 4 / 8 / 16 lanes (16 / 8 / 4 TUs per wave); the matrices of sizes <= 16 sit in LDS as int32,
+//     each lane group reading the rows of its own TU's transform types (same-address reads broadcast).
 #include "common.h"
 #include "tr_tables.inc"
 
@@ -19,211 +24,536 @@ namespace {
 // row a wave needs is always contiguous -> scalar (SGPR) loads.  Layout as VVC_TR_TABLES: size N at (N*N-4)/3.
 __device__ int d_tr32[3 * 5460];
 __device__ int d_tr32t[3 * 5460];
-__device__ short d_trTables[3 * 5460];
 
 __device__ __forceinline__ const int* tr32(int type, int n)  { return d_tr32  + type * 5460 + (n * n - 4) / 3; }
 __device__ __forceinline__ const int* tr32t(int type, int n) { return d_tr32t + type * 5460 + (n * n - 4) / 3; }
-__device__ __forceinline__ const short* tr16(int type, int n) { return d_trTables + type * 5460 + (n * n - 4) / 3; }
 __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
 
 constexpr int MAXN = 64;
 typedef short short2v __attribute__((ext_vector_type(2)));
 
-// ---- forward, stage 1: lane = row i; the row lives in registers as packed int16 pairs; T row j is wave-uniform.
-template <int W>
-__device__ __forceinline__ void fwd_stage1(const Pel* __restrict__ resi, int stride, int h, int lane, int wj, int s1,
-                                           const short* __restrict__ Th, int* __restrict__ tmpL, int ph)
-{
-  if (lane >= h) return;
-  const Pel* row = resi + (size_t)lane * stride;
-  int x[W];
-#pragma unroll
-  for (int k = 0; k < W; k++) x[k] = row[k];
-  const int rnd = 1 << (s1 - 1);
-  for (int j = 0; j < wj; j++)
-  {
-    const short* t = Th + j * W;                       // uniform address -> scalar loads
-    int sum = 0;
-#pragma unroll
-    for (int k = 0; k < W; k++) sum += __mul24(x[k], (int)t[k]);
-    tmpL[j * ph + lane] = (sum + rnd) >> s1;
-  }
-}
-// ---- forward, stage 2: lane = horizontal frequency i (< wj); its tmp row comes from LDS (odd pitch: conflict free)
-template <int H>
-__device__ __forceinline__ void fwd_stage2(const int* __restrict__ tmpL, int ph, int w, int wj, int hj, int lane, int s2,
-                                           const int* __restrict__ Tv, TCoeff* __restrict__ coeff)
-{
-  if (lane >= w) return;
-  if (lane >= wj) { for (int j = 0; j < H; j++) coeff[j * w + lane] = 0; return; }
-  int t[H];
-#pragma unroll
-  for (int k = 0; k < H; k++) t[k] = tmpL[lane * ph + k];
-  const int rnd = 1 << (s2 - 1);
-  for (int j = 0; j < hj; j++)
-  {
-    const int* tv = Tv + j * H;                        // uniform
-    int sum = 0;
-#pragma unroll
-    for (int k = 0; k < H; k++) sum += __mul24(t[k], tv[k]);
-    coeff[j * w + lane] = (sum + rnd) >> s2;
-  }
-  for (int j = hj; j < H; j++) coeff[j * w + lane] = 0;
-}
+__device__ __forceinline__ bool is_large_tu(const vvcgpu_tr_desc& d) { return d.tr_hor != 3 && (d.w > 16 || d.h > 16); }
 
-template <int W>
-__device__ __forceinline__ void fwd_dispatch_h(int h, const int* tmpL, int ph, int wj, int hj, int lane, int s2, int trVer, TCoeff* coeff)
+// ---------------------------------------------------------------------------------------------------
+// Small TUs (w, h <= 16) and transform skip: 64 descriptors per 256-thread workgroup, binned in LDS.
+constexpr int SM_DESCS = 64, SM_TAB = 376;          // per type: size 4 at 0, 8 at 16, 16 at 80, 2 at 336; padded for over-reads
+__device__ __forceinline__ int small_off(int n) { return n == 4 ? 0 : n == 8 ? 16 : n == 16 ? 80 : 336; }
+struct SmallShared
 {
-  switch (h)
+  vvcgpu_tr_desc d[SM_DESCS];
+  int tab[3][SM_TAB];                               // T[k][n]   (forward: row = output index)
+  int tabT[3][SM_TAB];                              // T^T       (inverse: row = output index)
+  int tmp[4][4 * 16 * 17];                          // per wave: P TUs x S x (S+1)
+  int cnt[4];                                       // bins: 0 transform skip, 1 S <= 4, 2 S = 8, 3 S = 16
+  unsigned char list[4][SM_DESCS];
+};
+
+__device__ __forceinline__ void small_tables(SmallShared& sh, int tid)
+{
+  for (int i = tid; i < 3 * SM_TAB; i += 256)
   {
-  case 2:  fwd_stage2<2>(tmpL, ph, W, wj, hj, lane, s2, tr32(trVer, 2), coeff); break;
-  case 4:  fwd_stage2<4>(tmpL, ph, W, wj, hj, lane, s2, tr32(trVer, 4), coeff); break;
-  case 8:  fwd_stage2<8>(tmpL, ph, W, wj, hj, lane, s2, tr32(trVer, 8), coeff); break;
-  case 16: fwd_stage2<16>(tmpL, ph, W, wj, hj, lane, s2, tr32(trVer, 16), coeff); break;
-  case 32: fwd_stage2<32>(tmpL, ph, W, wj, hj, lane, s2, tr32(trVer, 32), coeff); break;
-  default: fwd_stage2<64>(tmpL, ph, W, wj, hj, lane, s2, tr32(trVer, 64), coeff); break;
+    const int t = i / SM_TAB, e = i - t * SM_TAB;
+    int nsz = 0, o = 0;
+    if (e < 16) { nsz = 4; o = e; } else if (e < 80) { nsz = 8; o = e - 16; } else if (e < 336) { nsz = 16; o = e - 80; } else if (e < 340) { nsz = 2; o = e - 336; }
+    sh.tab[t][e] = nsz ? tr32(t, nsz)[o] : 0;
+    sh.tabT[t][e] = nsz ? tr32t(t, nsz)[o] : 0;
   }
 }
-
-template <int W>
-__device__ __forceinline__ void fwd_tu(const vvcgpu_tr_desc& d, const Pel* resi, TCoeff* coeff, int bd, int lane, int* tmpL)
+__device__ __forceinline__ void small_setup(SmallShared& sh, const vvcgpu_tr_desc* __restrict__ descs, int n, int batch, int tid)
 {
-  const int h = d.h, lw = ilog2(W), lh = ilog2(h);
-  const int s1 = lw + bd + 6 - 15 + 2, s2 = lh + 6 + 2;
-  const int wj = W > 32 ? 32 : W, hj = h > 32 ? 32 : h;
-  const int ph = h + 1;
-  fwd_stage1<W>(resi, d.resi_stride, h, lane, wj, s1, tr16(d.tr_hor, W), tmpL, ph);
+  __syncthreads();                                  // tables ready / previous batch done with d, list, cnt
+  if (tid < 4) sh.cnt[tid] = 0;
   __syncthreads();
-  fwd_dispatch_h<W>(h, tmpL, ph, wj, hj, lane, s2, d.tr_ver, coeff);
+  const int base = batch * SM_DESCS;
+  if (tid < SM_DESCS && base + tid < n)
+  {
+    const vvcgpu_tr_desc d = descs[base + tid];
+    sh.d[tid] = d;
+    const int S = max((int)d.w, (int)d.h);
+    const int bin = d.tr_hor == 3 ? 0 : S <= 4 ? 1 : S == 8 ? 2 : S == 16 ? 3 : -1;     // -1: large, the other launch
+    if (bin >= 0) sh.list[bin][atomicAdd(&sh.cnt[bin], 1)] = (unsigned char)tid;
+  }
+  __syncthreads();
 }
 
-// One wave per TU.
-__global__ __launch_bounds__(64) void tr_fwd_kernel(const Pel* __restrict__ resiBase, TCoeff* __restrict__ coeffBase,
-                                                    const vvcgpu_tr_desc* __restrict__ descs, int bd)
+#define TR_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+template <int S>
+__device__ __forceinline__ void fwd_small_group(SmallShared& sh, int bin, int grp, int lane, int wave, int bd,
+                                                const Pel* __restrict__ resiBase, TCoeff* __restrict__ coeffBase)
 {
-  __shared__ int tmpL[32 * (MAXN + 1)];            // tmp[j][i], j < 32 kept columns, pitch h+1
-  const int lane = threadIdx.x;
-  const vvcgpu_tr_desc d = descs[blockIdx.x];
+  constexpr int P = 64 / S;
+  const int g = lane / S, r = lane % S, li = grp * P + g;
+  const bool act = li < sh.cnt[bin];
+  const vvcgpu_tr_desc& d = sh.d[sh.list[bin][act ? li : 0]];
   const int w = d.w, h = d.h, lw = ilog2(w), lh = ilog2(h);
-  const Pel* resi = resiBase + d.resi_off;
-  TCoeff* coeff = coeffBase + d.coeff_off;
-  if (d.tr_hor == 3)
+  const int s1 = lw + bd + 6 - 15 + 2, s2 = lh + 6 + 2;
+  int* tmp = sh.tmp[wave] + g * (S * (S + 1));
+  if (act && r < h)                                 // stage 1 (horizontal): lane = row r
   {
+    const Pel* row = resiBase + d.resi_off + (size_t)r * d.resi_stride;
+    int x[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) x[k] = k < w ? (int)row[k] : 0;
+    const int* T = sh.tab[d.tr_hor] + small_off(w);
+    const int rnd = 1 << (s1 - 1);
+    for (int j = 0; j < w; j++)
+    {
+      int sum = 0;
+#pragma unroll
+      for (int k = 0; k < S; k++) sum += __mul24(x[k], T[j * w + k]);   // k >= w: x[k] = 0, T reads stay inside the padded table
+      tmp[j * (S + 1) + r] = (sum + rnd) >> s1;
+    }
+  }
+  TR_WAVE_SYNC();
+  if (act && r < w)                                 // stage 2 (vertical): lane = horizontal frequency r
+  {
+    int t[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) t[k] = k < h ? tmp[r * (S + 1) + k] : 0;
+    const int* T = sh.tab[d.tr_ver] + small_off(h);
+    const int rnd = 1 << (s2 - 1);
+    TCoeff* coeff = coeffBase + d.coeff_off;
+    for (int j = 0; j < h; j++)
+    {
+      int sum = 0;
+#pragma unroll
+      for (int k = 0; k < S; k++) sum += __mul24(t[k], T[j * h + k]);
+      coeff[j * w + r] = (sum + rnd) >> s2;
+    }
+  }
+  TR_WAVE_SYNC();
+}
+
+__global__ __launch_bounds__(256) void tr_fwd_small_kernel(const Pel* __restrict__ resiBase, TCoeff* __restrict__ coeffBase,
+                                                           const vvcgpu_tr_desc* __restrict__ descs, int n, int bd)
+{
+  __shared__ SmallShared sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  small_tables(sh, tid);
+  for (int batch = blockIdx.x; batch * SM_DESCS < n; batch += gridDim.x)
+  {
+  small_setup(sh, descs, n, batch, tid);
+  for (int q = 0; q < sh.cnt[0]; q++)                // transform skip: element-wise, whole workgroup
+  {
+    const vvcgpu_tr_desc& d = sh.d[sh.list[0][q]];
+    const int w = d.w, h = d.h, lw = ilog2(w), lh = ilog2(h);
     int shift = 15 - bd - ((lw + lh) >> 1), scale = 1;
     if ((lw + lh) & 1) { shift -= 8; scale = 181; }
-    for (int i = lane; i < w * h; i += 64)
+    const Pel* resi = resiBase + d.resi_off;
+    TCoeff* coeff = coeffBase + d.coeff_off;
+    for (int i = tid; i < w * h; i += 256)
     {
       const int y = i >> lw, x = i & (w - 1);
       const int v = resi[(size_t)y * d.resi_stride + x] * scale;
       coeff[i] = shift >= 0 ? v << shift : (v + (1 << (-shift - 1))) >> -shift;
     }
-    return;
   }
-  switch (w)
-  {
-  case 2:  fwd_tu<2>(d, resi, coeff, bd, lane, tmpL); break;
-  case 4:  fwd_tu<4>(d, resi, coeff, bd, lane, tmpL); break;
-  case 8:  fwd_tu<8>(d, resi, coeff, bd, lane, tmpL); break;
-  case 16: fwd_tu<16>(d, resi, coeff, bd, lane, tmpL); break;
-  case 32: fwd_tu<32>(d, resi, coeff, bd, lane, tmpL); break;
-  default: fwd_tu<64>(d, resi, coeff, bd, lane, tmpL); break;
+  for (int g = wave; g * 16 < sh.cnt[1]; g += 4) fwd_small_group<4>(sh, 1, g, lane, wave, bd, resiBase, coeffBase);
+  for (int g = wave; g * 8 < sh.cnt[2]; g += 4)  fwd_small_group<8>(sh, 2, g, lane, wave, bd, resiBase, coeffBase);
+  for (int g = wave; g * 4 < sh.cnt[3]; g += 4)  fwd_small_group<16>(sh, 3, g, lane, wave, bd, resiBase, coeffBase);
   }
 }
 
-// ---- inverse, stage 1 (vertical): lane = kept column i; its coefficient column is read coalesced across lanes.
-template <int H>
-__device__ __forceinline__ void inv_stage1(const TCoeff* __restrict__ coeff, int w, int wj, int lane, const int* __restrict__ TvT,
-                                           int* __restrict__ tmpL, int ph)
+template <int S, bool M24>
+__device__ __forceinline__ int inv_dot(const int (&c)[S], const int* T)
 {
-  constexpr int HJ = H > 32 ? 32 : H;
-  if (lane >= wj) return;
-  int c[HJ];
+  int sum = 0;
 #pragma unroll
-  for (int k = 0; k < HJ; k++) c[k] = coeff[k * w + lane];
-  for (int j = 0; j < H; j++)
-  {
-    const int* t = TvT + j * H;                        // TvT[j][k] = Tv[k][j], uniform
-    int sum = 0;
-#pragma unroll
-    for (int k = 0; k < HJ; k++) sum += c[k] * t[k];
-    tmpL[lane * ph + j] = clip3(-(1 << 15), (1 << 15) - 1, (sum + 256) >> 9);
-  }
-}
-// ---- inverse, stage 2 (horizontal): lane = row i
-template <int W>
-__device__ __forceinline__ void inv_stage2(const int* __restrict__ tmpL, int ph, int h, int lane, int s2, const int* __restrict__ ThT,
-                                           Pel* __restrict__ resi, int stride)
-{
-  constexpr int WJ = W > 32 ? 32 : W;
-  if (lane >= h) return;
-  int t[WJ];
-#pragma unroll
-  for (int k = 0; k < WJ; k++) t[k] = tmpL[k * ph + lane];
-  const int rnd = 1 << (s2 - 1);
-  Pel* row = resi + (size_t)lane * stride;
-  for (int j = 0; j < W; j++)
-  {
-    const int* th = ThT + j * W;                       // ThT[j][k] = Th[k][j], uniform
-    int sum = 0;
-#pragma unroll
-    for (int k = 0; k < WJ; k++) sum += t[k] * th[k];
-    row[j] = (short)clip3(-(1 << 15), (1 << 15) - 1, (sum + rnd) >> s2);
-  }
+  for (int k = 0; k < S; k++) sum += M24 ? __mul24(c[k], T[k]) : c[k] * T[k];
+  return sum;
 }
 
-template <int W>
-__device__ __forceinline__ void inv_tu(const vvcgpu_tr_desc& d, const TCoeff* coeff, Pel* resi, int bd, int lane, int* tmpL)
+template <int S>
+__device__ __forceinline__ void inv_small_group(SmallShared& sh, int bin, int grp, int lane, int wave, int bd,
+                                                const TCoeff* __restrict__ coeffBase, Pel* __restrict__ resiBase)
 {
-  const int h = d.h;
+  constexpr int P = 64 / S;
+  const int g = lane / S, r = lane % S, li = grp * P + g;
+  const bool act = li < sh.cnt[bin];
+  const vvcgpu_tr_desc& d = sh.d[sh.list[bin][act ? li : 0]];
+  const int w = d.w, h = d.h;
   const int s2 = (6 + 15 - 1) - bd + 2;
-  const int wj = W > 32 ? 32 : W;
-  const int ph = h + 1;
-  switch (h)
-  {
-  case 2:  inv_stage1<2>(coeff, W, wj, lane, tr32t(d.tr_ver, 2), tmpL, ph); break;
-  case 4:  inv_stage1<4>(coeff, W, wj, lane, tr32t(d.tr_ver, 4), tmpL, ph); break;
-  case 8:  inv_stage1<8>(coeff, W, wj, lane, tr32t(d.tr_ver, 8), tmpL, ph); break;
-  case 16: inv_stage1<16>(coeff, W, wj, lane, tr32t(d.tr_ver, 16), tmpL, ph); break;
-  case 32: inv_stage1<32>(coeff, W, wj, lane, tr32t(d.tr_ver, 32), tmpL, ph); break;
-  default: inv_stage1<64>(coeff, W, wj, lane, tr32t(d.tr_ver, 64), tmpL, ph); break;
+  int* tmp = sh.tmp[wave] + g * (S * (S + 1));
+  {                                                 // stage 1 (vertical): lane = column r
+    const bool on = act && r < w;
+    int c[S];
+    const TCoeff* coeff = coeffBase + d.coeff_off;
+    bool fits = true;
+#pragma unroll
+    for (int k = 0; k < S; k++) { c[k] = (on && k < h) ? coeff[k * w + r] : 0; fits = fits && (c[k] >= -(1 << 23)) && (c[k] < (1 << 23)); }
+    const int* T = sh.tabT[d.tr_ver] + small_off(h);
+    // 24-bit multiplies when every coefficient of the wave allows it (always, for quantiser output); exact 32-bit otherwise
+    if (__builtin_amdgcn_ballot_w64(!fits) == 0ull)
+    {
+      if (on) for (int j = 0; j < h; j++) tmp[r * (S + 1) + j] = clip3(-(1 << 15), (1 << 15) - 1, (inv_dot<S, true>(c, T + j * h) + 256) >> 9);
+    }
+    else
+    {
+      if (on) for (int j = 0; j < h; j++) tmp[r * (S + 1) + j] = clip3(-(1 << 15), (1 << 15) - 1, (inv_dot<S, false>(c, T + j * h) + 256) >> 9);
+    }
   }
-  __syncthreads();
-  inv_stage2<W>(tmpL, ph, h, lane, s2, tr32t(d.tr_hor, W), resi, d.resi_stride);
+  TR_WAVE_SYNC();
+  if (act && r < h)                                 // stage 2 (horizontal): lane = row r; tmp is clipped to 16 bits -> 24-bit multiplies
+  {
+    int t[S];
+#pragma unroll
+    for (int k = 0; k < S; k++) t[k] = k < w ? tmp[k * (S + 1) + r] : 0;
+    const int* T = sh.tabT[d.tr_hor] + small_off(w);
+    const int rnd = 1 << (s2 - 1);
+    Pel* row = resiBase + d.resi_off + (size_t)r * d.resi_stride;
+    for (int j = 0; j < w; j++) row[j] = (short)clip3(-(1 << 15), (1 << 15) - 1, (inv_dot<S, true>(t, T + j * w) + rnd) >> s2);
+  }
+  TR_WAVE_SYNC();
 }
 
-__global__ __launch_bounds__(64) void tr_inv_kernel(const TCoeff* __restrict__ coeffBase, Pel* __restrict__ resiBase,
-                                                    const vvcgpu_tr_desc* __restrict__ descs, int bd)
+__global__ __launch_bounds__(256) void tr_inv_small_kernel(const TCoeff* __restrict__ coeffBase, Pel* __restrict__ resiBase,
+                                                           const vvcgpu_tr_desc* __restrict__ descs, int n, int bd)
 {
-  __shared__ int tmpL[32 * (MAXN + 1)];            // tmp[i][j], i < 32 kept columns, pitch h+1
-  const int lane = threadIdx.x;
-  const vvcgpu_tr_desc d = descs[blockIdx.x];
-  const int w = d.w, h = d.h, lw = ilog2(w), lh = ilog2(h);
-  const TCoeff* coeff = coeffBase + d.coeff_off;
-  Pel* resi = resiBase + d.resi_off;
-  if (d.tr_hor == 3)
+  __shared__ SmallShared sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  small_tables(sh, tid);
+  for (int batch = blockIdx.x; batch * SM_DESCS < n; batch += gridDim.x)
   {
+  small_setup(sh, descs, n, batch, tid);
+  for (int q = 0; q < sh.cnt[0]; q++)
+  {
+    const vvcgpu_tr_desc& d = sh.d[sh.list[0][q]];
+    const int w = d.w, h = d.h, lw = ilog2(w), lh = ilog2(h);
     int shift = 15 - bd - ((lw + lh) >> 1), scale = 1;
     if ((lw + lh) & 1) { shift += 7; scale = 181; }
-    for (int i = lane; i < w * h; i += 64)
+    const TCoeff* coeff = coeffBase + d.coeff_off;
+    Pel* resi = resiBase + d.resi_off;
+    for (int i = tid; i < w * h; i += 256)
     {
       const int y = i >> lw, x = i & (w - 1);
       const int c = coeff[i] * scale;
       resi[(size_t)y * d.resi_stride + x] = (short)(shift >= 0 ? (c + (shift ? 1 << (shift - 1) : 0)) >> shift : c << -shift);
     }
-    return;
   }
-  switch (w)
-  {
-  case 2:  inv_tu<2>(d, coeff, resi, bd, lane, tmpL); break;
-  case 4:  inv_tu<4>(d, coeff, resi, bd, lane, tmpL); break;
-  case 8:  inv_tu<8>(d, coeff, resi, bd, lane, tmpL); break;
-  case 16: inv_tu<16>(d, coeff, resi, bd, lane, tmpL); break;
-  case 32: inv_tu<32>(d, coeff, resi, bd, lane, tmpL); break;
-  default: inv_tu<64>(d, coeff, resi, bd, lane, tmpL); break;
+  for (int g = wave; g * 16 < sh.cnt[1]; g += 4) inv_small_group<4>(sh, 1, g, lane, wave, bd, coeffBase, resiBase);
+  for (int g = wave; g * 8 < sh.cnt[2]; g += 4)  inv_small_group<8>(sh, 2, g, lane, wave, bd, coeffBase, resiBase);
+  for (int g = wave; g * 4 < sh.cnt[3]; g += 4)  inv_small_group<16>(sh, 3, g, lane, wave, bd, coeffBase, resiBase);
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Large TUs, fast path: 256-thread persistent workgroups, one wave per TU; every matrix (int16, 16-byte aligned rows)
+// resident in LDS, 16-bit operands packed in pairs and multiplied with v_dot2_i32_i16 (two exact MACs per instruction),
+// the matrix row of the current output index read with broadcast 16-byte LDS loads.  When a dimension has fewer than
+// 64 rows / columns the idle lanes take a share of the output indices.  Operands that do not fit 16 bits (never the
+// case for residuals / quantiser output) and odd row addresses fall back to the scalar-load stages above.
+constexpr int LG_TYPE = 1368;                       // shorts per type: size 2 at 0, 4 at 8, 8 at 24, 16 at 88, 32 at 344
+constexpr int LG_TAB = 3 * LG_TYPE + 4096;          // + DCT-II 64 at 3 * LG_TYPE
+__device__ __forceinline__ int lg_off(int type, int n)
+{
+  return n == 64 ? 3 * LG_TYPE : type * LG_TYPE + (n == 2 ? 0 : n == 4 ? 8 : n == 8 ? 24 : n == 16 ? 88 : 344);
+}
+__device__ __forceinline__ void lg_load(short* tab, const int* __restrict__ src32, int tid)
+{
+  for (int t = 0; t < 3; t++)
+    for (int n = 2; n <= 32; n <<= 1)
+      for (int e = tid; e < n * n; e += 256) tab[lg_off(t, n) + e] = (short)src32[t * 5460 + (n * n - 4) / 3 + e];
+  for (int e = tid; e < 4096; e += 256) tab[3 * LG_TYPE + e] = (short)src32[1364 + e];
+}
+
+// sum_k a[k] * T[k], k < N, a packed in pairs, T = LDS row of int16 (wave-uniform or per lane group)
+template <int N>
+__device__ __forceinline__ int dot_row(const unsigned (&ap)[(N + 1) / 2], const short* T)
+{
+  int sum = 0;
+  if (N >= 8)
+  {
+    const uint4* tr = reinterpret_cast<const uint4*>(T);
+#pragma unroll
+    for (int q = 0; q < N / 8; q++)
+    {
+      const uint4 t = tr[q];
+      sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, ap[4 * q]), __builtin_bit_cast(short2v, t.x), sum, false);
+      sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, ap[4 * q + 1]), __builtin_bit_cast(short2v, t.y), sum, false);
+      sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, ap[4 * q + 2]), __builtin_bit_cast(short2v, t.z), sum, false);
+      sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, ap[4 * q + 3]), __builtin_bit_cast(short2v, t.w), sum, false);
+    }
+  }
+  else
+  {
+    const unsigned* tr = reinterpret_cast<const unsigned*>(T);
+#pragma unroll
+    for (int q = 0; q < N / 2; q++) sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(short2v, ap[q]), __builtin_bit_cast(short2v, tr[q]), sum, false);
+  }
+  return sum;
+}
+__device__ __forceinline__ unsigned pack16(int lo, int hi) { return ((unsigned)lo & 0xFFFFu) | ((unsigned)hi << 16); }
+__device__ __forceinline__ bool fits16(int v) { return v == (int)(short)v; }
+
+// forward stage 1: lane = row; returns (wave-uniform) whether every intermediate fits 16 bits
+template <int W>
+__device__ __forceinline__ bool fwd_stage1_fast(const Pel* __restrict__ resi, int stride, int h, int lane, int s1, const short* T,
+                                                int* __restrict__ tmpL, int ph)
+{
+  constexpr int WJ = W > 32 ? 32 : W;
+  bool ok = true;
+  if (lane < h)
+  {
+    const unsigned* row = reinterpret_cast<const unsigned*>(resi + (size_t)lane * stride);
+    unsigned xp[W / 2];
+#pragma unroll
+    for (int m = 0; m < W / 2; m++) xp[m] = row[m];
+    const int rnd = 1 << (s1 - 1);
+#pragma unroll 2
+    for (int j = 0; j < WJ; j++)
+    {
+      const int v = (dot_row<W>(xp, T + j * W) + rnd) >> s1;
+      tmpL[j * ph + lane] = v;
+      ok = ok && fits16(v);
+    }
+  }
+  return __builtin_amdgcn_ballot_w64(!ok) == 0ull;
+}
+// forward stage 2: lane = (horizontal frequency i < wj, share g of the output rows)
+template <int H>
+__device__ __forceinline__ void fwd_stage2_fast(const int* __restrict__ tmpL, int ph, int w, int wj, int lane, int s2, const short* T,
+                                                TCoeff* __restrict__ coeff)
+{
+  constexpr int HJ = H > 32 ? 32 : H;
+  const int i = lane & (wj - 1), g = lane / wj, G = 64 / wj, jPer = HJ / G;     // wj < 32 only with h >= 32: HJ = 32 >= G
+  unsigned tp[H / 2];
+#pragma unroll
+  for (int m = 0; m < H / 2; m++) tp[m] = pack16(tmpL[i * ph + 2 * m], tmpL[i * ph + 2 * m + 1]);
+  const int rnd = 1 << (s2 - 1);
+#pragma unroll 2
+  for (int jj = 0; jj < jPer; jj++)
+  {
+    const int j = g * jPer + jj;
+    coeff[j * w + i] = (dot_row<H>(tp, T + j * H) + rnd) >> s2;
+  }
+}
+// Slow generic stages for the cases the packed 16-bit path cannot take (rows at odd addresses, operands beyond 16 bits:
+// neither occurs for encoder residuals / quantiser output).  Plain loops, exact 32-bit arithmetic, no register arrays.
+__device__ __noinline__ void fwd_stage1_slow(const Pel* __restrict__ resi, int stride, int w, int h, int lane, int wj, int s1,
+                                             const short* T, int* __restrict__ tmpL, int ph)
+{
+  if (lane >= h) return;
+  const Pel* row = resi + (size_t)lane * stride;
+  const int rnd = 1 << (s1 - 1);
+#pragma unroll 1
+  for (int j = 0; j < wj; j++)
+  {
+    int sum = 0;
+#pragma unroll 1
+    for (int k = 0; k < w; k++) sum += (int)row[k] * (int)T[j * w + k];
+    tmpL[j * ph + lane] = (sum + rnd) >> s1;
+  }
+}
+__device__ __noinline__ void fwd_stage2_slow(const int* __restrict__ tmpL, int ph, int w, int h, int wj, int hj, int lane, int s2,
+                                             const short* T, TCoeff* __restrict__ coeff)
+{
+  if (lane >= w) return;
+  const int rnd = 1 << (s2 - 1);
+#pragma unroll 1
+  for (int j = 0; j < h; j++)
+  {
+    int v = 0;
+    if (lane < wj && j < hj)
+    {
+      int sum = 0;
+#pragma unroll 1
+      for (int k = 0; k < h; k++) sum += tmpL[lane * ph + k] * (int)T[j * h + k];
+      v = (sum + rnd) >> s2;
+    }
+    coeff[j * w + lane] = v;
+  }
+}
+__device__ __noinline__ void inv_stage1_slow(const TCoeff* __restrict__ coeff, int w, int h, int wj, int hj, int lane, const short* TT,
+                                             int* __restrict__ tmpL, int ph)
+{
+  if (lane >= wj) return;
+#pragma unroll 1
+  for (int j = 0; j < h; j++)
+  {
+    int sum = 0;
+#pragma unroll 1
+    for (int k = 0; k < hj; k++) sum += coeff[k * w + lane] * (int)TT[j * h + k];
+    tmpL[lane * ph + j] = clip3(-(1 << 15), (1 << 15) - 1, (sum + 256) >> 9);
+  }
+}
+
+template <int W>
+__device__ __forceinline__ void fwd_tu_large(const vvcgpu_tr_desc& d, const Pel* resi, TCoeff* coeff, int bd, int lane, int* tmpL,
+                                             const short* tab)
+{
+  const int h = d.h, lw = ilog2(W), lh = ilog2(h);
+  const int s1 = lw + bd + 6 - 15 + 2, s2 = lh + 6 + 2;
+  const int wj = W > 32 ? 32 : W, hj = h > 32 ? 32 : h;
+  const int ph = h + 1;
+  const bool aligned = (((uintptr_t)resi | (uintptr_t)(d.resi_stride * 2)) & 3) == 0;
+  bool fast = false;
+  if (aligned) fast = fwd_stage1_fast<W>(resi, d.resi_stride, h, lane, s1, tab + lg_off(d.tr_hor, W), tmpL, ph);
+  else fwd_stage1_slow(resi, d.resi_stride, W, h, lane, wj, s1, tab + lg_off(d.tr_hor, W), tmpL, ph);
+  TR_WAVE_SYNC();
+  if (fast)
+  {
+    const short* Tv = tab + lg_off(d.tr_ver, h);
+    switch (h)
+    {
+    case 2:  fwd_stage2_fast<2>(tmpL, ph, W, wj, lane, s2, Tv, coeff); break;
+    case 4:  fwd_stage2_fast<4>(tmpL, ph, W, wj, lane, s2, Tv, coeff); break;
+    case 8:  fwd_stage2_fast<8>(tmpL, ph, W, wj, lane, s2, Tv, coeff); break;
+    case 16: fwd_stage2_fast<16>(tmpL, ph, W, wj, lane, s2, Tv, coeff); break;
+    case 32: fwd_stage2_fast<32>(tmpL, ph, W, wj, lane, s2, Tv, coeff); break;
+    default: fwd_stage2_fast<64>(tmpL, ph, W, wj, lane, s2, Tv, coeff); break;
+    }
+    // zero-out: rows >= hj (contiguous) and columns >= wj of the kept rows
+    for (int e = hj * W + lane; e < h * W; e += 64) coeff[e] = 0;
+    if (W > 32) for (int e = lane; e < hj * 32; e += 64) coeff[(e >> 5) * W + 32 + (e & 31)] = 0;
+  }
+  else fwd_stage2_slow(tmpL, ph, W, h, wj, hj, lane, s2, tab + lg_off(d.tr_ver, h), coeff);
+  TR_WAVE_SYNC();
+}
+
+__global__ __launch_bounds__(256, 3) void tr_fwd_large_kernel(const Pel* __restrict__ resiBase, TCoeff* __restrict__ coeffBase,
+                                                           const vvcgpu_tr_desc* __restrict__ descs, const int* __restrict__ list, int bd)
+{
+  __shared__ __align__(16) short tab[LG_TAB];
+  __shared__ int tmpAll[4][32 * (MAXN + 1)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cnt = list[0];
+  if ((int)blockIdx.x * 4 >= cnt) return;
+  lg_load(tab, d_tr32, tid);
+  __syncthreads();
+  int* tmpL = tmpAll[wave];
+  for (int k = blockIdx.x * 4 + wave; k < cnt; k += gridDim.x * 4)
+  {
+    const vvcgpu_tr_desc d = descs[list[1 + k]];
+    const Pel* resi = resiBase + d.resi_off;
+    TCoeff* coeff = coeffBase + d.coeff_off;
+    switch (d.w)
+    {
+    case 2:  fwd_tu_large<2>(d, resi, coeff, bd, lane, tmpL, tab); break;
+    case 4:  fwd_tu_large<4>(d, resi, coeff, bd, lane, tmpL, tab); break;
+    case 8:  fwd_tu_large<8>(d, resi, coeff, bd, lane, tmpL, tab); break;
+    case 16: fwd_tu_large<16>(d, resi, coeff, bd, lane, tmpL, tab); break;
+    case 32: fwd_tu_large<32>(d, resi, coeff, bd, lane, tmpL, tab); break;
+    default: fwd_tu_large<64>(d, resi, coeff, bd, lane, tmpL, tab); break;
+    }
+  }
+}
+
+// inverse stage 1 (vertical): lane = (kept column i < wj, share g of the output rows); false when a coefficient needs > 16 bits
+template <int H>
+__device__ __forceinline__ bool inv_stage1_fast(const TCoeff* __restrict__ coeff, int w, int wj, int lane, const short* TT,
+                                                int* __restrict__ tmpL, int ph)
+{
+  constexpr int HJ = H > 32 ? 32 : H;
+  const int i = lane & (wj - 1), g = lane / wj, G = 64 / wj, jPer = H / G;
+  int c[HJ];
+  bool ok = true;
+#pragma unroll
+  for (int k = 0; k < HJ; k++) { c[k] = coeff[k * w + i]; ok = ok && fits16(c[k]); }
+  if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) return false;
+  unsigned cp[(HJ + 1) / 2];
+#pragma unroll
+  for (int m = 0; m < HJ / 2; m++) cp[m] = pack16(c[2 * m], c[2 * m + 1]);
+#pragma unroll 2
+  for (int jj = 0; jj < jPer; jj++)
+  {
+    const int j = g * jPer + jj;
+    tmpL[i * ph + j] = clip3(-(1 << 15), (1 << 15) - 1, (dot_row<HJ>(cp, TT + j * H) + 256) >> 9);
+  }
+  return true;
+}
+// inverse stage 2 (horizontal): lane = (row r < h, share g of the output columns); tmp is clipped to 16 bits by stage 1
+template <int W>
+__device__ __forceinline__ void inv_stage2_fast(const int* __restrict__ tmpL, int ph, int h, int lane, int s2, const short* TT,
+                                                Pel* __restrict__ resi, int stride)
+{
+  constexpr int WJ = W > 32 ? 32 : W;
+  const int r = lane & (h - 1), g = lane / h, G = 64 / h, jPer = W / G;
+  unsigned tp[(WJ + 1) / 2];
+#pragma unroll
+  for (int m = 0; m < WJ / 2; m++) tp[m] = pack16(tmpL[(2 * m) * ph + r], tmpL[(2 * m + 1) * ph + r]);
+  const int rnd = 1 << (s2 - 1);
+  Pel* row = resi + (size_t)r * stride;
+#pragma unroll 2
+  for (int jj = 0; jj < jPer; jj++)
+  {
+    const int j = g * jPer + jj;
+    row[j] = (short)clip3(-(1 << 15), (1 << 15) - 1, (dot_row<WJ>(tp, TT + j * W) + rnd) >> s2);
+  }
+}
+template <int W>
+__device__ __forceinline__ void inv_tu_large(const vvcgpu_tr_desc& d, const TCoeff* coeff, Pel* resi, int bd, int lane, int* tmpL,
+                                             const short* tabT)
+{
+  const int h = d.h;
+  const int s2 = (6 + 15 - 1) - bd + 2;
+  const int wj = W > 32 ? 32 : W;
+  const int ph = h + 1;
+  const short* TvT = tabT + lg_off(d.tr_ver, h);
+  bool fast;
+  switch (h)
+  {
+  case 2:  fast = inv_stage1_fast<2>(coeff, W, wj, lane, TvT, tmpL, ph); break;
+  case 4:  fast = inv_stage1_fast<4>(coeff, W, wj, lane, TvT, tmpL, ph); break;
+  case 8:  fast = inv_stage1_fast<8>(coeff, W, wj, lane, TvT, tmpL, ph); break;
+  case 16: fast = inv_stage1_fast<16>(coeff, W, wj, lane, TvT, tmpL, ph); break;
+  case 32: fast = inv_stage1_fast<32>(coeff, W, wj, lane, TvT, tmpL, ph); break;
+  default: fast = inv_stage1_fast<64>(coeff, W, wj, lane, TvT, tmpL, ph); break;
+  }
+  if (!fast) inv_stage1_slow(coeff, W, h, wj, h > 32 ? 32 : h, lane, TvT, tmpL, ph);
+  TR_WAVE_SYNC();
+  inv_stage2_fast<W>(tmpL, ph, h, lane, s2, tabT + lg_off(d.tr_hor, W), resi, d.resi_stride);
+  TR_WAVE_SYNC();
+}
+
+__global__ __launch_bounds__(256, 3) void tr_inv_large_kernel(const TCoeff* __restrict__ coeffBase, Pel* __restrict__ resiBase,
+                                                           const vvcgpu_tr_desc* __restrict__ descs, const int* __restrict__ list, int bd)
+{
+  __shared__ __align__(16) short tabT[LG_TAB];
+  __shared__ int tmpAll[4][32 * (MAXN + 1)];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int cnt = list[0];
+  if ((int)blockIdx.x * 4 >= cnt) return;
+  lg_load(tabT, d_tr32t, tid);
+  __syncthreads();
+  int* tmpL = tmpAll[wave];
+  for (int k = blockIdx.x * 4 + wave; k < cnt; k += gridDim.x * 4)
+  {
+    const vvcgpu_tr_desc d = descs[list[1 + k]];
+    const TCoeff* coeff = coeffBase + d.coeff_off;
+    Pel* resi = resiBase + d.resi_off;
+    switch (d.w)
+    {
+    case 2:  inv_tu_large<2>(d, coeff, resi, bd, lane, tmpL, tabT); break;
+    case 4:  inv_tu_large<4>(d, coeff, resi, bd, lane, tmpL, tabT); break;
+    case 8:  inv_tu_large<8>(d, coeff, resi, bd, lane, tmpL, tabT); break;
+    case 16: inv_tu_large<16>(d, coeff, resi, bd, lane, tmpL, tabT); break;
+    case 32: inv_tu_large<32>(d, coeff, resi, bd, lane, tmpL, tabT); break;
+    default: inv_tu_large<64>(d, coeff, resi, bd, lane, tmpL, tabT); break;
+    }
+  }
+}
+
+// indices of the large TUs of a batch: list[0] = count, list[1..] = descriptor indices (order irrelevant: TUs are independent)
+__global__ __launch_bounds__(256) void tr_collect_large_kernel(const vvcgpu_tr_desc* __restrict__ descs, int n, int* __restrict__ list)
+{
+  const int ti = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  bool lg = false;
+  if (ti < n)
+  {
+    const int* f = reinterpret_cast<const int*>(descs + ti) + 5;            // bytes 20..27: w, h, tr_hor, tr_ver
+    const int wh = f[0], tt = f[1];
+    lg = (signed char)(tt & 0xFF) != 3 && ((short)(wh & 0xFFFF) > 16 || (wh >> 16) > 16);
+  }
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(lg);
+  int base = 0;
+  if (lane == 0 && m) base = atomicAdd(&list[0], (int)__popcll(m));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (lg) list[1 + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = ti;
+}
+
 static bool g_tablesUploaded[64] = { false };
+static const int g_smallGrid = getenv("VVCGPU_TR_SMALLGRID") ? atoi(getenv("VVCGPU_TR_SMALLGRID")) : 1280;   // tuning switch
 
 static int ensure_tables()
 {
@@ -232,7 +562,6 @@ static int ensure_tables()
   if (dev < 0 || dev >= 64) { vvcgpu_set_error("device index %d out of range", dev); return VVCGPU_E_DEVICE; }
   if (!g_tablesUploaded[dev])
   {
-    VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_trTables), VVC_TR_TABLES, sizeof(VVC_TR_TABLES)));
     static int t32[3 * 5460], t32t[3 * 5460];
     for (int t = 0; t < 3; t++)
       for (int n = 2; n <= 64; n <<= 1)
@@ -268,7 +597,15 @@ int vvcgpu_tr_fwd_batch(const vvc_pel* resi_base, vvc_coef* coeff_base, const vv
   if (rc) return rc > 0 ? VVCGPU_OK : rc;
   const int rt = ensure_tables();
   if (rt) return rt;
-  hipLaunchKernelGGL(tr_fwd_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, resi_base, coeff_base, descs, bit_depth);
+  hipStream_t st = (hipStream_t)stream;
+  int* list = nullptr;                               // cached per-stream scratch: indices of the large TUs
+  list = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * ((size_t)n + 1)));
+  if (!list) return VVCGPU_E_DEVICE;
+  VVC_HIP(hipMemsetAsync(list, 0, sizeof(int), st));
+  const int nb = cdiv(n, SM_DESCS), nl = cdiv(n, 4);
+  hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, descs, n, list);
+  hipLaunchKernelGGL(tr_fwd_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, resi_base, coeff_base, descs, n, bit_depth);
+  hipLaunchKernelGGL(tr_fwd_large_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, resi_base, coeff_base, descs, list, bit_depth);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
@@ -280,7 +617,15 @@ int vvcgpu_tr_inv_batch(const vvc_coef* coeff_base, vvc_pel* resi_base, const vv
   if (rc) return rc > 0 ? VVCGPU_OK : rc;
   const int rt = ensure_tables();
   if (rt) return rt;
-  hipLaunchKernelGGL(tr_inv_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, coeff_base, resi_base, descs, bit_depth);
+  hipStream_t st = (hipStream_t)stream;
+  int* list = nullptr;
+  list = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * ((size_t)n + 1)));
+  if (!list) return VVCGPU_E_DEVICE;
+  VVC_HIP(hipMemsetAsync(list, 0, sizeof(int), st));
+  const int nb = cdiv(n, SM_DESCS), nl = cdiv(n, 4);
+  hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, descs, n, list);
+  hipLaunchKernelGGL(tr_inv_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, coeff_base, resi_base, descs, n, bit_depth);
+  hipLaunchKernelGGL(tr_inv_large_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, coeff_base, resi_base, descs, list, bit_depth);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
