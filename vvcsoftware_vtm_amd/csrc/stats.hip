@@ -137,6 +137,8 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ 
 // the block's transposeIdx) and are flushed to the per-CTU output with 64-bit global atomics.
 // =====================================================================================================
 constexpr int AT = 64, AP = AT + 8, AR = AT + 6;
+typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+typedef short short2v __attribute__((ext_vector_type(2)));
 
 template <int PITCH>
 __device__ __forceinline__ void load_tile_clamped(short* __restrict__ lds, const Pel* __restrict__ src,
@@ -214,23 +216,26 @@ __global__ __launch_bounds__(256) void alf_stats_kernel(const Pel* __restrict__ 
     for (int i = 0; i < N; i++) Y[i] = 0;
 
 #pragma unroll 1
-    for (int i = 0; i < 4; i++)                  // pixel row by+i (not unrolled: keeps E[4][N] live once)
+    for (int i = 0; i < 4; i++)                  // pixel row by+i (not unrolled: one row of tap sums live at a time)
     {
-      int E[4][N];
+      // two horizontally adjacent pixels share every instruction: tap sums are built as packed 16-bit pairs
+      // (v_pk_add_u16, <= 2 * 1023) and multiplied with v_dot2_i32_i16 (two exact MACs per instruction)
+      us2 E[2][N];
 #pragma unroll
-      for (int j = 0; j < 4; j++)
+      for (int jp = 0; jp < 2; jp++)
 #pragma unroll
-        for (int k = 0; k < N; k++) E[j][k] = 0;
+        for (int k = 0; k < N; k++) E[jp][k] = us2{ 0, 0 };
       const short* p = tile + (4 * bi + i + 3 - R) * AP + 4 * bj;     // row by+i-R, col bx-4
+      unsigned cen[2];
 #pragma unroll
       for (int r = 0; r <= 2 * R; r++)
       {
-        int s[12];
-        const pel4 v0 = *reinterpret_cast<const pel4*>(p + r * AP);
-        const pel4 v1 = *reinterpret_cast<const pel4*>(p + r * AP + 4);
-        const pel4 v2 = *reinterpret_cast<const pel4*>(p + r * AP + 8);
-#pragma unroll
-        for (int k = 0; k < 4; k++) { s[k] = v0[k]; s[4 + k] = v1[k]; s[8 + k] = v2[k]; }
+        unsigned d[6];                                                // samples bx-4 .. bx+7 as pairs
+        const uint2 v0 = *reinterpret_cast<const uint2*>(p + r * AP);
+        const uint2 v1 = *reinterpret_cast<const uint2*>(p + r * AP + 4);
+        const uint2 v2 = *reinterpret_cast<const uint2*>(p + r * AP + 8);
+        d[0] = v0.x; d[1] = v0.y; d[2] = v1.x; d[3] = v1.y; d[4] = v2.x; d[5] = v2.y;
+        if (r == R) { cen[0] = d[2]; cen[1] = d[3]; }
         const int dy = r - R;
 #pragma unroll
         for (int dx = -R; dx <= R; dx++)
@@ -238,23 +243,29 @@ __global__ __launch_bounds__(256) void alf_stats_kernel(const Pel* __restrict__ 
           const int k = tapIndexS<IS7>(dy, dx);
           if (k < 0) continue;
 #pragma unroll
-          for (int j = 0; j < 4; j++) E[j][k] += s[4 + j + dx];
+          for (int jp = 0; jp < 2; jp++)
+          {
+            const int s0 = 4 + 2 * jp + dx;                           // first sample of the pair (compile-time)
+            const unsigned pr = (s0 & 1) ? __builtin_amdgcn_alignbit(d[(s0 + 1) >> 1], d[(s0 - 1) >> 1], 16) : d[s0 >> 1];
+            E[jp][k] += __builtin_bit_cast(us2, pr);
+          }
         }
       }
-      const pel4 ov = *reinterpret_cast<const pel4*>(org + (size_t)(by + i) * ostride + bx);
+      const uint2 ov = *reinterpret_cast<const uint2*>(org + (size_t)(by + i) * ostride + bx);
 #pragma unroll
-      for (int j = 0; j < 4; j++)
+      for (int jp = 0; jp < 2; jp++)
       {
-        const int yl = (int)ov[j] - (int)p[R * AP + 4 + j];
+        const short2v yl = __builtin_bit_cast(short2v, jp ? ov.y : ov.x) - __builtin_bit_cast(short2v, cen[jp]);
         int idx = 0;
 #pragma unroll
         for (int k = 0; k < N; k++)
         {
+          const short2v ek = __builtin_bit_cast(short2v, E[jp][k]);
 #pragma unroll
-          for (int l = k; l < N; l++) { A[idx] += __mul24(E[j][k], E[j][l]); idx++; }
-          Y[k] += __mul24(E[j][k], yl);
+          for (int l = k; l < N; l++) { A[idx] = __builtin_amdgcn_sdot2(ek, __builtin_bit_cast(short2v, E[jp][l]), A[idx], false); idx++; }
+          Y[k] = __builtin_amdgcn_sdot2(ek, yl, Y[k], false);
         }
-        pix += __mul24(yl, yl);
+        pix = __builtin_amdgcn_sdot2(yl, yl, pix, false);
       }
     }
     // flush into the class bucket with the block's transpose permutation
