@@ -6,8 +6,8 @@
 // are available (availability of a neighbour in an adjacent CTU = that CTU-direction's flag), c otherwise.
 //
 // Design: pure streaming stencil.  One thread = 8 horizontally adjacent samples (one 16-byte load/store)
-// x 4 rows; the rows above/below come from a rolling register window, the two horizontal halo samples
-// per row from 2-byte loads that hit L1/L2.  dst receives the complete picture (offset or copied
+// x 4 rows; its six rows (one above, one below) are loaded up front into a register window, the two horizontal halo
+// samples per row with 2-byte loads that hit L1/L2.  dst receives the complete picture (offset or copied
 // samples), so the reference's whole-picture temp copy (:587) never touches HBM.
 #include "common.h"
 
@@ -19,19 +19,17 @@ struct SaoGeom { int gx, gy, rows, x0, y0, x1, y1, w, h, avail, clpMin, clpMax; 
 
 // Edge-offset body with the class direction as a compile-time constant (keeps the 3-row register
 // window statically indexed -> no scratch).  Neighbour a = (x+DXA, y+DYA), b = (x-DXA, y-DYA).
-template <int DXA, int DYA, typename LoadRow, typename StoreRow>
+template <int DXA, int DYA, typename StoreRow>
 __device__ __forceinline__ void eo_rows(const SaoGeom& g, int off0, int off1, int off2, int off3, int off4,
-                                        LoadRow load_row, StoreRow store_row)
+                                        const int (&win)[SAO_ROWS + 2][10], StoreRow store_row)
 {
   const bool availL = g.avail & 1, availR = (g.avail >> 1) & 1, availA = (g.avail >> 2) & 1, availB = (g.avail >> 3) & 1;
   const bool availAL = (g.avail >> 4) & 1, availAR = (g.avail >> 5) & 1, availBL = (g.avail >> 6) & 1, availBR = (g.avail >> 7) & 1;
-  int up[10], cur[10], dn[10];
-  if (DYA != 0) load_row(max(g.gy - 1, 0), up);
-  load_row(g.gy, cur);
-  for (int r = 0; r < g.rows; r++)
+#pragma unroll
+  for (int r = 0; r < SAO_ROWS; r++)
   {
+    if (r >= g.rows) break;
     const int y = g.gy + r;
-    if (DYA != 0) load_row(min(y + 1, g.h - 1), dn);
     const bool topOut = (DYA != 0) && (y - 1 < g.y0);     // a's row is in the CTU above
     const bool botOut = (DYA != 0) && (y + 1 >= g.y1);    // b's row is in the CTU below
     int o[8];
@@ -39,9 +37,9 @@ __device__ __forceinline__ void eo_rows(const SaoGeom& g, int off0, int off1, in
     for (int k = 0; k < 8; k++)
     {
       const int x = g.gx + k;
-      const int c = cur[1 + k];
-      const int a = DYA == 0 ? cur[1 + k + DXA] : up[1 + k + DXA];
-      const int b = DYA == 0 ? cur[1 + k - DXA] : dn[1 + k - DXA];
+      const int c = win[r + 1][1 + k];
+      const int a = DYA == 0 ? win[r + 1][1 + k + DXA] : win[r][1 + k + DXA];
+      const int b = DYA == 0 ? win[r + 1][1 + k - DXA] : win[r + 2][1 + k - DXA];
       const int hxA = DXA == 0 ? 0 : ((x + DXA < g.x0) ? -1 : (x + DXA >= g.x1 ? 1 : 0));
       const int hxB = DXA == 0 ? 0 : ((x - DXA < g.x0) ? -1 : (x - DXA >= g.x1 ? 1 : 0));
       bool okA, okB;
@@ -54,13 +52,6 @@ __device__ __forceinline__ void eo_rows(const SaoGeom& g, int off0, int off1, in
       o[k] = (okA && okB) ? clip3(g.clpMin, g.clpMax, c + of) : c;
     }
     store_row(y, o);
-    if (DYA != 0)
-    {
-#pragma unroll
-      for (int k = 0; k < 10; k++) { up[k] = cur[k]; cur[k] = dn[k]; }
-    }
-    else if (r + 1 < g.rows)
-      load_row(y + 1, cur);
   }
 }
 
@@ -68,10 +59,15 @@ __global__ __launch_bounds__(256) void sao_apply_kernel(const Pel* __restrict__ 
                                                         Pel* __restrict__ dst, int dstride, int w, int h,
                                                         int ctuW, int ctuH, int wCtu, int boShift,
                                                         const vvcgpu_sao_ctu* __restrict__ params,
-                                                        int clpMin, int clpMax)
+                                                        int clpMin, int clpMax, int tpcShift, int nWaveCols)
 {
-  const int gx = (blockIdx.x * 64 + threadIdx.x) * 8;           // first sample of this thread
-  const int gy = (blockIdx.y * 4 + threadIdx.y) * SAO_ROWS;     // first row
+  // a wave covers (8 << tpcShift) samples x (64 >> tpcShift) thread rows: with a power-of-two CTU width that is exactly
+  // one CTU column, so the SAO type is wave-uniform and only one of the five type bodies runs (a wave that straddles
+  // several CTUs executes them one after the other)
+  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wcol = wv % nWaveCols, wrow = wv / nWaveCols;
+  const int gx = ((wcol << tpcShift) + (lane & ((1 << tpcShift) - 1))) * 8;           // first sample of this thread
+  const int gy = (wrow * (64 >> tpcShift) + (lane >> tpcShift)) * SAO_ROWS;           // first row
   if (gx >= w || gy >= h) return;
   const int n = min(8, w - gx);                                 // valid samples (w need not be a multiple of 8)
   const int cx = gx / ctuW, cy = gy / ctuH;
@@ -83,22 +79,28 @@ __global__ __launch_bounds__(256) void sao_apply_kernel(const Pel* __restrict__ 
   const bool vec = (n == 8) && ((sstride & 7) == 0) && ((dstride & 7) == 0) &&
                    ((reinterpret_cast<uintptr_t>(src) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0);
 
-  auto load_row = [&](int y, int* s) {   // s[0..9] = samples gx-1 .. gx+8 of row y (clamped reads, unused if unavailable)
+  // all SAO_ROWS + 2 rows of the thread (gy-1 .. gy+SAO_ROWS, clamped to the picture) are loaded up front: one exposure to
+  // memory latency instead of one per row (a chroma plane is only ~1 workgroup per CU, nothing else hides it)
+  int win[SAO_ROWS + 2][10];                        // [row][samples gx-1 .. gx+8]
+#pragma unroll
+  for (int i = 0; i < SAO_ROWS + 2; i++)
+  {
+    const int y = min(max(gy - 1 + i, 0), h - 1);
     const Pel* row = src + (size_t)y * sstride;
     if (vec)
     {
       const pel8 v = *reinterpret_cast<const pel8*>(row + gx);
 #pragma unroll
-      for (int k = 0; k < 8; k++) s[1 + k] = v[k];
+      for (int k = 0; k < 8; k++) win[i][1 + k] = v[k];
     }
     else
     {
 #pragma unroll
-      for (int k = 0; k < 8; k++) s[1 + k] = row[min(gx + k, w - 1)];
+      for (int k = 0; k < 8; k++) win[i][1 + k] = row[min(gx + k, w - 1)];
     }
-    s[0] = row[max(gx - 1, 0)];
-    s[9] = row[min(gx + 8, w - 1)];
-  };
+    win[i][0] = row[max(gx - 1, 0)];
+    win[i][9] = row[min(gx + 8, w - 1)];
+  }
   auto store_row = [&](int y, const int* o) {
     Pel* row = dst + (size_t)y * dstride;
     if (vec)
@@ -118,18 +120,20 @@ __global__ __launch_bounds__(256) void sao_apply_kernel(const Pel* __restrict__ 
   const int rows = min(SAO_ROWS, h - gy);
   if (type < 0)
   {
-    for (int r = 0; r < rows; r++) { int s[10]; load_row(gy + r, s); store_row(gy + r, s + 1); }
+#pragma unroll
+    for (int r = 0; r < SAO_ROWS; r++) if (r < rows) store_row(gy + r, &win[r + 1][1]);
     return;
   }
   if (type == 4)
   {
     const int16_t* off = prm->offset;
-    for (int r = 0; r < rows; r++)
-    {
-      int s[10], o[8];
-      load_row(gy + r, s);
 #pragma unroll
-      for (int k = 0; k < 8; k++) o[k] = clip3(clpMin, clpMax, s[1 + k] + off[s[1 + k] >> boShift]);
+    for (int r = 0; r < SAO_ROWS; r++)
+    {
+      if (r >= rows) break;
+      int o[8];
+#pragma unroll
+      for (int k = 0; k < 8; k++) o[k] = clip3(clpMin, clpMax, win[r + 1][1 + k] + off[win[r + 1][1 + k] >> boShift]);
       store_row(gy + r, o);
     }
     return;
@@ -139,10 +143,10 @@ __global__ __launch_bounds__(256) void sao_apply_kernel(const Pel* __restrict__ 
   const int off0 = op[0], off1 = op[1], off2 = op[2], off3 = op[3], off4 = op[4];
   switch (type)
   {
-  case 0:  eo_rows<-1, 0>(g, off0, off1, off2, off3, off4, load_row, store_row); break;
-  case 1:  eo_rows<0, -1>(g, off0, off1, off2, off3, off4, load_row, store_row); break;
-  case 2:  eo_rows<-1, -1>(g, off0, off1, off2, off3, off4, load_row, store_row); break;
-  default: eo_rows<1, -1>(g, off0, off1, off2, off3, off4, load_row, store_row); break;
+  case 0:  eo_rows<-1, 0>(g, off0, off1, off2, off3, off4, win, store_row); break;
+  case 1:  eo_rows<0, -1>(g, off0, off1, off2, off3, off4, win, store_row); break;
+  case 2:  eo_rows<-1, -1>(g, off0, off1, off2, off3, off4, win, store_row); break;
+  default: eo_rows<1, -1>(g, off0, off1, off2, off3, off4, win, store_row); break;
   }
 }
 
@@ -159,10 +163,12 @@ extern "C" int vvcgpu_sao_apply(const vvc_pel* src, int src_stride, vvc_pel* dst
   VVC_CHECK_ARG(ctu_w >= 8 && ctu_h >= 4 && (ctu_w & 7) == 0 && (ctu_h & 3) == 0,
                 "sao_apply: CTU %dx%d must be a multiple of 8x4", ctu_w, ctu_h);
   VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "sao_apply: bit depth %d outside 8..10", bit_depth);
-  dim3 block(64, 4);
-  dim3 grid(cdiv(width, 64 * 8), cdiv(height, 4 * SAO_ROWS));
-  hipLaunchKernelGGL(sao_apply_kernel, grid, block, 0, (hipStream_t)stream, src, src_stride, dst, dst_stride, width,
-                     height, ctu_w, ctu_h, cdiv(width, ctu_w), bit_depth - 5, params, clp_min, clp_max);
+  int tpcShift = 6;                                                    // threads across a wave: one CTU width when that is a power of two
+  if ((ctu_w & (ctu_w - 1)) == 0 && ctu_w <= 512) { tpcShift = 0; while ((8 << tpcShift) < ctu_w) tpcShift++; }
+  const int nWaveCols = cdiv(width, 8 << tpcShift), nWaveRows = cdiv(height, (64 >> tpcShift) * SAO_ROWS);
+  hipLaunchKernelGGL(sao_apply_kernel, dim3(cdiv(nWaveCols * nWaveRows, 4)), dim3(256), 0, (hipStream_t)stream, src, src_stride, dst,
+                     dst_stride, width, height, ctu_w, ctu_h, cdiv(width, ctu_w), bit_depth - 5, params, clp_min, clp_max, tpcShift,
+                     nWaveCols);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
