@@ -96,14 +96,151 @@ constexpr int ST = 16;                 // sub-tile
 constexpr int WP = ST + 8;             // window pitch (samples)
 constexpr int WR = ST + 7;             // window rows
 
+__device__ __forceinline__ bool mc_is_fast(int is_luma, int w, int h) { return is_luma ? (w == 16 && h == 16) : (w == 8 && h == 8); }
+
+// Fast path: the whole PU is one S x S tile (16x16 luma / 8x8 chroma, what the canonical workload predicts): every loop
+// bound and divisor is a compile-time constant, the filter taps sit in registers, one wave per PU with wave-local LDS (no
+// workgroup barriers), four PUs per 256-thread workgroup.  Same arithmetic as the generic kernel below.
+template <int N, int S>
+__device__ __forceinline__ void mc_tile_fast(const vvcgpu_mc_desc& d, const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
+                                             Pel* __restrict__ dstBase, int bd, int cmin, int cmax, int lane, short* win, short* tmp)
+{
+  constexpr int half = N / 2 - 1, NR = S + N - 1, PW = S + 8;            // window rows / pitch
+  constexpr int OUT = S * S / 64;                                        // outputs per lane (4 for 16x16, 1 for 8x8)
+  const bool rndRes = d.bi == 0;
+  const int nRef = d.bi == 1 ? 2 : 1;
+  int pred[2][OUT];
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+  {
+    if (r >= nRef) break;
+    const int rs = r ? d.ref1_stride : d.ref0_stride;
+    const Pel* ref = r ? ref1Base + d.ref1_off : ref0Base + d.ref0_off;
+    const int fx = r ? d.frac_x1 : d.frac_x0, fy = r ? d.frac_y1 : d.frac_y0;
+    const short* cxp = N == 8 ? c_lumaFilter[fx] : c_chromaFilter[fx];
+    const short* cyp = N == 8 ? c_lumaFilter[fy] : c_chromaFilter[fy];
+    int cx[N], cy[N];
+#pragma unroll
+    for (int k = 0; k < N; k++) { cx[k] = cxp[k]; cy[k] = cyp[k]; }
+    // stage only what the branch needs (the reference reads nothing else): rows -half.. when fy, cols -half.. when fx
+    const int r0 = fy ? -half : 0, nr = fy ? NR : S;
+    const int c0 = fx ? -half : 0, nc = fx ? NR : S;
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < (NR * NR + 63) / 64; u++)
+    {
+      const int i = lane + 64 * u;
+      const int rr = fx ? (i * (65536 / NR + 1)) >> 16 : i / S, cc = i - rr * (fx ? NR : S);
+      if (rr < nr) win[rr * PW + cc] = ref[(ptrdiff_t)(r0 + rr) * rs + c0 + cc];
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (fx && fy)
+    {
+      const IfMode mh = if_mode(true, false, bd);
+#pragma unroll
+      for (int u = 0; u < (NR * S + 63) / 64; u++)
+      {
+        const int i = lane + 64 * u, rr = i / S, x = i % S;
+        if (rr < NR)
+        {
+          int sum = 0;
+#pragma unroll
+          for (int k = 0; k < N; k++) sum += win[rr * PW + x + k] * cx[k];
+          tmp[rr * S + x] = (short)((sum + mh.offset) >> mh.shift);
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+      const IfMode mv = if_mode(false, rndRes, bd);
+#pragma unroll
+      for (int j = 0; j < OUT; j++)
+      {
+        const int p = lane + 64 * j, y = p / S, x = p % S;
+        int sum = 0;
+#pragma unroll
+        for (int k = 0; k < N; k++) sum += tmp[(y + k) * S + x] * cy[k];
+        int v = (short)((sum + mv.offset) >> mv.shift);
+        if (rndRes) v = clip3(cmin, cmax, v);
+        pred[r][j] = v;
+      }
+    }
+    else
+    {
+      const IfMode m1 = if_mode(true, rndRes, bd);
+#pragma unroll
+      for (int j = 0; j < OUT; j++)
+      {
+        const int p = lane + 64 * j, y = p / S, x = p % S;
+        int v;
+        if (!fx && !fy) v = if_copy(win[y * PW + x], true, rndRes, bd, cmin, cmax);
+        else
+        {
+          int sum = 0;
+          if (fx) {
+#pragma unroll
+            for (int k = 0; k < N; k++) sum += win[y * PW + x + k] * cx[k];
+          } else {
+#pragma unroll
+            for (int k = 0; k < N; k++) sum += win[(y + k) * PW + x] * cy[k];
+          }
+          v = (short)((sum + m1.offset) >> m1.shift);
+          if (rndRes) v = clip3(cmin, cmax, v);
+        }
+        pred[r][j] = v;
+      }
+    }
+  }
+  Pel* dst = dstBase + d.dst_off;
+  const int shiftNum = max(2, IF_INTERNAL_PREC - bd) + 1, offset = (1 << (shiftNum - 1)) + 2 * IF_INTERNAL_OFFS;
+#pragma unroll
+  for (int j = 0; j < OUT; j++)
+  {
+    const int p = lane + 64 * j, y = p / S, x = p % S;
+    int v = pred[0][j];
+    if (d.bi == 1) v = clip3(cmin, cmax, (pred[0][j] + pred[1][j] + offset) >> shiftNum);
+    dst[(size_t)y * d.dst_stride + x] = (short)v;
+  }
+}
+
+__global__ __launch_bounds__(256) void mc_fast_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
+                                                      Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs, int n,
+                                                      int bd, int cmin, int cmax)
+{
+  __shared__ short winS[4][23 * 24];
+  __shared__ short tmpS[4][23 * 16];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int di = blockIdx.x * 4 + wave;
+  if (di >= n) return;
+  const vvcgpu_mc_desc d = descs[di];
+  if (!mc_is_fast(d.is_luma, d.w, d.h)) return;
+  if (d.is_luma) mc_tile_fast<8, 16>(d, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, winS[wave], tmpS[wave]);
+  else mc_tile_fast<4, 8>(d, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, winS[wave], tmpS[wave]);
+}
+
+// indices of the PUs the fast kernel does not cover: list[0] = count, list[1..] = descriptor indices
+__global__ __launch_bounds__(256) void mc_collect_kernel(const vvcgpu_mc_desc* __restrict__ descs, int n, int* __restrict__ list)
+{
+  const int ti = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  bool slow = false;
+  if (ti < n) slow = !mc_is_fast(descs[ti].is_luma, descs[ti].w, descs[ti].h);
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(slow);
+  int base = 0;
+  if (lane == 0 && m) base = atomicAdd(&list[0], (int)__popcll(m));
+  base = __builtin_amdgcn_readfirstlane(base);
+  if (slow) list[1 + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = ti;
+}
+
+// generic kernel: any size, one wave per PU, persistent over the list of PUs left by mc_collect_kernel
 __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
                                                       Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs,
-                                                      int bd, int cmin, int cmax)
+                                                      const int* __restrict__ list, int bd, int cmin, int cmax)
 {
   __shared__ short win[WR * WP];
   __shared__ short tmp[WR * ST];
   const int lane = threadIdx.x;
-  const vvcgpu_mc_desc d = descs[blockIdx.x];
+  const int cnt = list[0];
+  for (int li = blockIdx.x; li < cnt; li += gridDim.x)
+  {
+  const vvcgpu_mc_desc d = descs[list[1 + li]];
   const int N = d.is_luma ? 8 : 4, half = N / 2 - 1;
   const bool rndRes = d.bi == 0;
   const int nRef = d.bi == 1 ? 2 : 1;
@@ -200,6 +337,7 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
         }
       }
     }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ B1-B4
@@ -280,8 +418,15 @@ int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel*
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(ref0_base && dst_base && descs, "mc_batch: null pointer");
   if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("mc_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(mc_batch_kernel, dim3(n), dim3(64), 0, (hipStream_t)stream, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     dst_base, descs, bit_depth, clp_min, clp_max);
+  hipStream_t st = (hipStream_t)stream;
+  int* list = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * ((size_t)n + 1)));
+  if (!list) return VVCGPU_E_DEVICE;
+  VVC_HIP(hipMemsetAsync(list, 0, sizeof(int), st));
+  hipLaunchKernelGGL(mc_collect_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, descs, n, list);
+  hipLaunchKernelGGL(mc_fast_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
+                     dst_base, descs, n, bit_depth, clp_min, clp_max);
+  hipLaunchKernelGGL(mc_batch_kernel, dim3(n < 8192 ? n : 8192), dim3(64), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
+                     dst_base, descs, list, bit_depth, clp_min, clp_max);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
