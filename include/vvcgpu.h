@@ -180,12 +180,10 @@ int vvcgpu_dist_batch(int kind, const vvc_pel* org_base, const vvc_pel* cur_base
  * relative to (ref_x, ref_y) of the block.  Every probed sample must lie inside the reference plane's allocation
  * (the reference clips MVs to the padded picture, Mv.cpp:64-80).  org samples may be any int16 (bi-pred refinement
  * searches on 2*org - otherPred, InterSearch.cpp:1682-1692).
- * sad_out: nblocks x ny x nx uint32, row-major.  May be NULL (with best != NULL) on RASTER grids -- sx = sy = 5,
- *          w in {16,32,64,128}, even (h >> sub_shift) * w/16, org_stride even, ref_stride a multiple of 8, org 4-byte and
- *          ref 16-byte aligned -- where the arg-min is fused into the SAD kernel and no surface is written (what the raster
- *          loop of xTZSearch keeps, InterSearch.cpp:1979-2000); other grids use it as scratch for the arg-min and
- *          return VVCGPU_E_ARG without it.  The fused arg-min packs (cost << 24 | scan index): cost < 2^40 and
- *          nx * ny < 2^24 are preconditions of that path (motion lambda * MV bits stays below 2^20 in the reference).
+ * sad_out: nblocks x ny x nx uint32, row-major.  May be NULL when only `best` is wanted (what xPatternSearch and the raster
+ *          loop of xTZSearch keep, InterSearch.cpp:1887-1935, 1979-2000): the arg-min is fused into the SAD kernels and no
+ *          surface is written.  The fused arg-min packs (cost << 24 | scan index): cost < 2^40 and nx * ny < 2^24 are
+ *          preconditions whenever `best` is given (motion lambda * MV bits stays below 2^20 in the reference).
  * best (optional): per block the argmin of  sad + uint64(lambda * bits(x,y))  in the reference's scan order
  *          (y outer, x inner, strict '<': InterSearch.cpp:1913-1925) with the MV-bit cost of RdCost.h:172-199.   */
 typedef struct vvcgpu_search_blk { int32_t org_x, org_y, ref_x, ref_y; } vvcgpu_search_blk;

@@ -158,6 +158,13 @@ __device__ __forceinline__ void fill_window_pairs(unsigned* __restrict__ lds, co
   }
 }
 
+__device__ __forceinline__ unsigned expgolomb_bits(int v)        // RdCost.h:172-184
+{
+  unsigned len = 1, t = (v <= 0) ? ((unsigned)(-v) << 1) + 1 : (unsigned)(v << 1);
+  while (t > 128u) { len += 14; t >>= 7; }
+  return len + ((31 - __clz((int)t)) << 1);
+}
+
 constexpr int SS_THREADS = 512;
 
 // `groups` sub-workgroups of gsz = SS_THREADS / groups lanes each take one block (small windows: several blocks per
@@ -167,7 +174,8 @@ __global__ __launch_bounds__(SS_THREADS) void sad_search_kernel(const Pel* __res
                                                          const vvcgpu_search_blk* __restrict__ blocks, int nblocks, int w, int h,
                                                          int subShift, int dx0, int dy0, int nx, int ny, int sx, int sy,
                                                          int rowsPerStrip, int colsPerStrip, int pitchDw, int split,
-                                                         int groups, int groupDw, unsigned* __restrict__ out)
+                                                         int groups, int groupDw, vvcgpu_mvcost mv, int useBest,
+                                                         unsigned* __restrict__ out, vvcgpu_search_best* __restrict__ best)
 {
   extern __shared__ __align__(16) unsigned lds_all[];
   const int gsz = SS_THREADS / groups;
@@ -224,6 +232,7 @@ __global__ __launch_bounds__(SS_THREADS) void sad_search_kernel(const Pel* __res
   if (!active) return;
 
   // task = (position, row class): `split` adjacent lanes share one position and take rows r = s, s+split, ...
+  unsigned long long kmin = ~0ull;
   const int nTasks = nj * ni * split;
   const int sMask = split - 1;
   const int sLog = 31 - __clz(split);
@@ -264,149 +273,31 @@ __global__ __launch_bounds__(SS_THREADS) void sad_search_kernel(const Pel* __res
       }
     }
     for (int o2 = 1; o2 < split; o2 <<= 1) acc += __shfl_xor(acc, o2);
-    if (live && s == 0) out[((size_t)b * ny + j0 + jj) * nx + i0 + i] = acc << subShift;
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------
-// Raster specialisation (step 5 in both directions = iRaster of xTZSearch under the shipped cfgs, InterSearch.cpp:1979-2000).
-//   * LDS bank-conflict-free by construction: consecutive raster columns start 2.5 dwords apart, so 13 of them hit 13
-//     distinct banks {0,2,5,7,..,30}; the LDS row pitch is chosen = 13 or 19 (mod 32) so that the next raster ROW is shifted
-//     by exactly +-1 bank and fills the gaps.  A 32-lane half therefore carries 13 + 13 = 26 positions (two raster rows of
-//     one 13-column group) and every ds_read is conflict free; 6 lanes per half idle (a 2-way conflict would cost more).
-//   * the org block is wave-uniform: it is read with SCALAR loads straight from global memory (no LDS copy, no LDS
-//     bandwidth) and enters v_sad_u16 as an SGPR operand.
-// 16-byte window fill: lane loads one aligned uint4 (8 samples), FB of them in flight, and stores four LDS dwords.
-template <int FB>
-__device__ __forceinline__ void fill_window_quads(unsigned* __restrict__ lds, const uint4* __restrict__ g, int rsQ,
-                                                  int winRows, int pitchDw, int nQuads, int tid, int nthreads)
-{
-  const int total = winRows * nQuads;
-  int e = tid, r = tid / nQuads, q = tid - r * nQuads;
-  const int dr = nthreads / nQuads, dq = nthreads - dr * nQuads;
-  for (int base = 0; base < total; base += FB * nthreads)
-  {
-    uint4 v[FB];
-    int idx[FB];
-#pragma unroll
-    for (int u = 0; u < FB; u++)
+    if (live && s == 0)
     {
-      idx[u] = e < total ? r * pitchDw + 4 * q : -1;
-      v[u] = e < total ? g[(ptrdiff_t)r * rsQ + q] : make_uint4(0, 0, 0, 0);
-      e += nthreads; r += dr; q += dq;
-      if (q >= nQuads) { q -= nQuads; r++; }
-    }
-#pragma unroll
-    for (int u = 0; u < FB; u++)
-      if (idx[u] >= 0)
+      const int idx = (j0 + jj) * nx + i0 + i;
+      if (out) out[(size_t)b * ny * nx + idx] = acc << subShift;
+      if (useBest)                                                      // fused arg-min, see sad_raster5c_kernel
       {
-        unsigned* d = lds + idx[u];
-        d[0] = v[u].x ^ 0x80008000u; d[1] = v[u].y ^ 0x80008000u; d[2] = v[u].z ^ 0x80008000u; d[3] = v[u].w ^ 0x80008000u;
+        const int x = dx0 + (i0 + i) * sx, y = dy0 + (j0 + jj) * sy;
+        const unsigned bits = expgolomb_bits(((x << mv.cost_scale) - mv.pred_hor) >> mv.imv_shift) +
+                              expgolomb_bits(((y << mv.cost_scale) - mv.pred_ver) >> mv.imv_shift);
+        const unsigned long long key = (((unsigned long long)(acc << subShift) + (unsigned long long)(mv.lambda * (double)bits)) << 24) | (unsigned)idx;
+        kmin = key < kmin ? key : kmin;
       }
-  }
-}
-
-// rows [r0, r0+RB) of one position: RB*WP wave-uniform org pairs (scalar loads, issued together) against the lane's window rows
-template <int WP, int RB, bool OODD>
-__device__ __forceinline__ unsigned r5_rows(const unsigned* __restrict__ orgDw, int osDwStep, const unsigned* base, int ldsStep,
-                                            unsigned sh, unsigned acc)
-{
-  unsigned ov[RB][WP];
-#pragma unroll
-  for (int j = 0; j < RB; j++)
-  {
-    const unsigned* op = orgDw + (size_t)j * osDwStep;
-#pragma unroll
-    for (int k = 0; k < WP; k++)
-      ov[j][k] = (OODD ? ((op[k] >> 16) | (op[k + 1] << 16)) : op[k]) ^ 0x80008000u;
-  }
-#pragma unroll
-  for (int j = 0; j < RB; j++)
-  {
-    const unsigned* rp = base + j * ldsStep;
-    unsigned g[WP + 1];
-#pragma unroll
-    for (int k = 0; k <= WP; k++) g[k] = rp[k];
-#pragma unroll
-    for (int k = 0; k < WP; k++) acc = __builtin_amdgcn_sad_u16(ov[j][k], __builtin_amdgcn_alignbit(g[k + 1], g[k], sh), acc);
-  }
-  return acc;
-}
-
-// Raster specialisation (step 5 in both directions = iRaster of xTZSearch under the shipped cfgs, InterSearch.cpp:1979-2000).
-//   * LDS bank-conflict-free by construction: consecutive raster columns start 2.5 dwords apart, so 13 of them hit 13
-//     distinct banks {0,2,5,7,..,30}; the LDS row pitch is chosen = 13 or 19 (mod 32) so that the next raster ROW is shifted
-//     by exactly +-1 bank and fills the gaps.  A 32-lane half therefore carries 13 + 13 = 26 positions (two raster rows of
-//     one 13-column group) and every ds_read is conflict free; 6 lanes per half idle (a 2-way conflict would cost more).
-//   * the org block is wave-uniform: it is read with SCALAR loads straight from global memory (no LDS copy, no LDS
-//     bandwidth), RB rows at a time so that the loads overlap, and enters v_sad_u16 as an SGPR operand.
-//   * the window is staged with 16-byte global loads (QUADS) when the plane allows it.
-template <int WP, int RB, bool QUADS>
-__global__ __launch_bounds__(512) void sad_raster5_kernel(const Pel* __restrict__ org, int os,
-                                                          const Pel* __restrict__ ref, int rs,
-                                                          const vvcgpu_search_blk* __restrict__ blocks, int h, int subShift,
-                                                          int dx0, int dy0, int nx, int ny, int rowsPerStrip, int pitchDw, int dbg,
-                                                          int nstrips, int total, unsigned* __restrict__ out)
-{
-  extern __shared__ __align__(16) unsigned refL[];
-  const int tid = threadIdx.x;
-  // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so workgroup L lands with L+8, L+16...
-  // Give each XCD one CONTIGUOUS run of (block, strip) items: the strips of one block and the windows of neighbouring
-  // blocks overlap heavily, and this way the overlap is found in that XCD's own L2 instead of being fetched 8 times.
-  const int chunk = (total + 7) >> 3;
-  const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-  if (item >= total) return;
-  const int b = item / nstrips, j0 = (item - b * nstrips) * rowsPerStrip;
-  const int nj = min(rowsPerStrip, ny - j0);
-  const vvcgpu_search_blk blk = blocks[b];
-  const int hs = h >> subShift;
-  const int w = WP * 2;
-  const int winRows = (nj - 1) * 5 + h;
-  const int Ww = (nx - 1) * 5 + w;
-  const ptrdiff_t winOff = (ptrdiff_t)(blk.ref_y + dy0 + j0 * 5) * rs + blk.ref_x + dx0;
-  const int off = QUADS ? (int)(winOff & 7) : (int)(winOff & 1);       // samples between the aligned LDS row start and the window
-  if (!(dbg & 1))
-  {
-    if (QUADS) fill_window_quads<4>(refL, reinterpret_cast<const uint4*>(ref + (winOff - off)), rs >> 3, winRows, pitchDw,
-                                    ((Ww - 1 + off) >> 3) + 1, tid, (int)blockDim.x);
-    else       fill_window_pairs<8>(refL, reinterpret_cast<const unsigned*>(ref + (winOff - off)), rs >> 1, winRows, pitchDw,
-                                    ((Ww - 1 + off) >> 1) + 1, tid, (int)blockDim.x);
-  }
-  __syncthreads();
-
-  const int ncg = (nx + 12) / 13, nrp = (nj + 1) >> 1;
-  const int q = tid & 31, rowsel = q >= 13 ? 1 : 0, ic = q - 13 * rowsel;
-  const int oodd = blk.org_x & 1;                                        // block origin in the high half of a dword pair
-  const unsigned* orgDw = reinterpret_cast<const unsigned*>(org + (size_t)blk.org_y * os + blk.org_x - oodd);
-  const int osStep = (os >> 1) << subShift;                              // dwords between used org rows
-  const int ldsStep = pitchDw << subShift;
-  for (int hh = tid >> 5; hh < ncg * nrp; hh += blockDim.x >> 5)
-  {
-    const int rp = hh / ncg, cg = hh - rp * ncg;
-    const int i = cg * 13 + ic, jj = 2 * rp + rowsel;
-    const bool live = q < 26 && i < nx && jj < nj;
-    const int cx = (live ? i : 0) * 5 + off;
-    const unsigned sh = (cx & 1) << 4;
-    const unsigned* base = refL + (cx >> 1) + ((live ? jj : 0) * 5) * pitchDw;
-    unsigned acc = 0;
-    if (!(dbg & 2))
-    {
-      if (oodd) for (int r = 0; r < hs; r += RB) acc = r5_rows<WP, RB, true>(orgDw + (size_t)r * osStep, osStep, base + r * ldsStep, ldsStep, sh, acc);
-      else      for (int r = 0; r < hs; r += RB) acc = r5_rows<WP, RB, false>(orgDw + (size_t)r * osStep, osStep, base + r * ldsStep, ldsStep, sh, acc);
     }
-    if (live) out[((size_t)b * ny + j0 + jj) * nx + i] = acc << subShift;
   }
-}
-
-__device__ __forceinline__ unsigned expgolomb_bits(int v)        // RdCost.h:172-184
-{
-  unsigned len = 1, t = (v <= 0) ? ((unsigned)(-v) << 1) + 1 : (unsigned)(v << 1);
-  while (t > 128u) { len += 14; t >>= 7; }
-  return len + ((31 - __clz((int)t)) << 1);
+  if (useBest)
+  {
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { const unsigned long long ok = __shfl_xor(kmin, o); kmin = ok < kmin ? ok : kmin; }
+    if (lane == 0 && kmin != ~0ull) atomicMin(reinterpret_cast<unsigned long long*>(&best[b].cost), kmin);
+  }
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Raster kernel, second generation ("r5c"): same job as sad_raster5_kernel, built around the fact that this kernel is
+// Raster kernel ("r5c": step 5 in both directions = iRaster of xTZSearch under the shipped cfgs, InterSearch.cpp:1979-2000),
+// third generation of this kernel, built around the fact that it is
 // bound by instruction ISSUE (scalar + vector), not by LDS or HBM: rocprofv3 showed v_sad_u16 to be ~15 % of the vector
 // instructions of the first version, the rest being window fill, addressing, realignment and the argmin.
 //   * raster columns are split into the four classes i = c (mod 4): inside a class consecutive columns start exactly
@@ -423,7 +314,7 @@ __device__ __forceinline__ unsigned expgolomb_bits(int v)        // RdCost.h:172
 //   * blocks wider than 16 are walked as 16-sample chunks, so one code path serves w = 16..128.
 //   * the org rows are wave-uniform scalar loads; SMEM and LDS share lgkmcnt and SMEM returns out of order, so the
 //     loop is software pipelined by hand: wait for stage s, issue the loads of stage s+1, then do the SADs of stage s.
-//   * optional fused argmin: cost = SAD + motion-vector cost as in sad_best_kernel (the bit counts of the columns / rows
+//   * optional fused argmin: cost = SAD + motion-vector cost (the bit counts of the columns / rows
 //     and lambda * bits come from small LDS tables built once per workgroup), packed as (cost << 24 | scan index) and
 //     reduced with 64-bit min (wave shuffles -> LDS -> one global atomicMin per workgroup), so that the raster stage need
 //     not write the SAD surface at all when the caller only wants the best candidate (xTZSearch does).
@@ -567,7 +458,10 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const Pel* __re
   extern __shared__ __align__(16) unsigned refL[];
   __shared__ unsigned long long wgKey;
   const int tid = threadIdx.x;
-  const int chunk = (total + 7) >> 3;                                      // XCD-aware order, see sad_raster5_kernel
+  // XCD-aware order (speed only): workgroups are dealt round-robin over the 8 XCDs, so workgroup L lands with L+8, L+16...
+  // Give each XCD one CONTIGUOUS run of (block, strip) items: the strips of one block and the windows of neighbouring
+  // blocks overlap heavily, and this way the overlap is found in that XCD's own L2 instead of being fetched 8 times.
+  const int chunk = (total + 7) >> 3;
   const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
   if (item >= total) return;
   const int b = item / nstrips, j0 = (item - b * nstrips) * rowsPerStrip;
@@ -672,41 +566,6 @@ __global__ __launch_bounds__(256) void sad_best_decode_kernel(int nblocks, int d
   best[b] = r;
 }
 
-__global__ __launch_bounds__(256) void sad_best_kernel(const unsigned* __restrict__ sad, int nblocks, int dx0, int dy0,
-                                                       int nx, int ny, int sx, int sy, vvcgpu_mvcost mv,
-                                                       vvcgpu_search_best* __restrict__ best)
-{
-  const int lane = threadIdx.x & 63;
-  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (b >= nblocks) return;
-  const unsigned* s = sad + (size_t)b * nx * ny;
-  unsigned long long bc = ~0ull;
-  int bi = 0x7fffffff;
-  for (int idx = lane; idx < nx * ny; idx += 64)
-  {
-    const int j = idx / nx, i = idx - j * nx;
-    const int x = dx0 + i * sx, y = dy0 + j * sy;
-    const unsigned bits = expgolomb_bits(((x << mv.cost_scale) - mv.pred_hor) >> mv.imv_shift) +
-                          expgolomb_bits(((y << mv.cost_scale) - mv.pred_ver) >> mv.imv_shift);
-    const unsigned long long cost = (unsigned long long)s[idx] + (unsigned long long)(mv.lambda * (double)bits);
-    if (cost < bc) { bc = cost; bi = idx; }          // idx increases per lane -> first minimum kept
-  }
-#pragma unroll
-  for (int o = 32; o > 0; o >>= 1)
-  {
-    const unsigned long long oc = __shfl_xor(bc, o);
-    const int oi = __shfl_xor(bi, o);
-    if (oc < bc || (oc == bc && oi < bi)) { bc = oc; bi = oi; }
-  }
-  if (lane == 0)
-  {
-    const int j = bi / nx, i = bi - j * nx;
-    vvcgpu_search_best r;
-    r.x = dx0 + i * sx; r.y = dy0 + j * sy; r.cost = bc; r.sad = s[bi];
-    best[b] = r;
-  }
-}
-
 }  // namespace
 
 extern "C" {
@@ -787,55 +646,7 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       return VVCGPU_OK;
     }
   }
-  VVC_CHECK_ARG(sad_out, "sad_search: sad_out may only be NULL on the raster path (step 5, block width 16..128, aligned planes)");
-  if (sx == 5 && sy == 5 && (w == 16 || w == 32 || w == 64) && (org_stride & 1) == 0 && (ref_stride & 1) == 0 &&
-      ((uintptr_t)org & 3) == 0 && ((uintptr_t)ref & 3) == 0)
-  {
-    // (block origins must be even for the scalar org loads; checked on the device side would cost a divergent path, so the
-    //  caller contract is: org_x even -- true for every CU position, which are multiples of 4)
-    const int Ww = (nx - 1) * 5 + w;
-    const bool quads = ((ref_stride & 7) == 0) && (((uintptr_t)ref & 15) == 0);
-    // aligned row start is up to 7 samples (quads) / 1 sample (pairs) before the window; + one look-ahead pair; quad rows are
-    // stored whole, so the pitch also covers the last (partly used) quad
-    int pitch = quads ? (((Ww - 1 + 7) >> 3) + 1) * 4 + 1 : (Ww + 1) / 2 + 2;
-    while ((pitch & 31) != 13 && (pitch & 31) != 19) pitch++;
-    const int hsR = h >> sub_shift;
-    const size_t budgetR = 52 * 1024;
-    int rps = ny & ~1;
-    if (rps < 2) rps = ny;
-    while (rps > 2 && ((size_t)((rps - 1) * 5 + h) * pitch * 4 > budgetR)) rps -= 2;
-    const int nstrips = cdiv(ny, rps);
-    rps = cdiv(ny, nstrips);
-    if ((rps & 1) && rps < ny) rps++;
-    const size_t smemR = (size_t)((rps - 1) * 5 + h) * pitch * 4;
-    if (smemR <= 150 * 1024 && (hsR % 4) == 0)
-    {
-      const int halves = cdiv(nx, 13) * ((rps + 1) / 2);
-      int threads = ((halves * 32 + 63) / 64) * 64;
-      if (threads > 512) threads = 512;
-      if (threads < 128) threads = 128;
-      const int nstripsR = cdiv(ny, rps), totalR = nblocks * nstripsR;
-      dim3 gridR(cdiv(totalR, 8) * 8);
-      static const int dbgMode = getenv("VVCGPU_DBG_R5") ? atoi(getenv("VVCGPU_DBG_R5")) : 0;   // timing experiments only
-#define LAUNCH_R5(WPV, RBV, QV)                                                                                                \
-      do {                                                                                                                     \
-        if (smemR > 64 * 1024)                                                                                                 \
-          VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster5_kernel<WPV, RBV, QV>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemR)); \
-        hipLaunchKernelGGL((sad_raster5_kernel<WPV, RBV, QV>), gridR, dim3(threads), smemR, st0, org, org_stride, ref, ref_stride, blocks, h, \
-                           sub_shift, dx0, dy0, nx, ny, rps, pitch, dbgMode, nstripsR, totalR, sad_out);                                          \
-      } while (0)
-      if (quads) { if (w == 16) LAUNCH_R5(8, 4, true); else if (w == 32) LAUNCH_R5(16, 2, true); else LAUNCH_R5(32, 1, true); }
-      else       { if (w == 16) LAUNCH_R5(8, 4, false); else if (w == 32) LAUNCH_R5(16, 2, false); else LAUNCH_R5(32, 1, false); }
-#undef LAUNCH_R5
-      VVC_LAUNCH_CHECK();
-      if (best)
-      {
-        hipLaunchKernelGGL(sad_best_kernel, dim3(cdiv(nblocks, 4)), dim3(256), 0, st0, sad_out, nblocks, dx0, dy0, nx, ny, sx, sy, *mvcost_host, best);
-        VVC_LAUNCH_CHECK();
-      }
-      return VVCGPU_OK;
-    }
-  }
+  VVC_CHECK_ARG(!best || (long long)nx * ny < (1 << 24), "sad_search: the arg-min packs the scan index into 24 bits (nx * ny = %lld)", (long long)nx * ny);
   const int hs = h >> sub_shift;
   const size_t orgDw = ((size_t)hs * (w / 2) + 3) & ~(size_t)3;
   // Strip selection: the staged window (one copy, + 2 pairs of slack per row) must fit an LDS budget that keeps three
@@ -870,20 +681,37 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
     const int tasks = rowsPerStrip * colsPerStrip * split;
     while (groups < 8 && tasks <= SS_THREADS / (groups * 2) && groupBytes * groups * 2 <= 40 * 1024) groups *= 2;
   }
+  if (groups > 1 && split == 1)
+  {
+    // a dense small grid rarely fills the group's lanes in whole passes (81 positions on 128 lanes): let `split` adjacent
+    // lanes share a position, each taking every split-th row, when that lowers the lane-row iterations
+    const int gszH = SS_THREADS / groups, pos = rowsPerStrip * colsPerStrip;
+    long bestCost = (long)cdiv(pos, gszH) * gszH * hs;
+    for (int sp = 2; sp <= 8 && sp <= hs && (hs % sp) == 0; sp *= 2)
+    {
+      const long cost = (long)cdiv(pos * sp, gszH) * gszH * (hs / sp) + (long)pos * sp;      // + the shuffle reduction
+      if (cost < bestCost) { bestCost = cost; split = sp; }
+    }
+  }
   const size_t smem = groupBytes * groups;
   VVC_CHECK_ARG(smem <= hard, "sad_search: a single position's window (%d x %d) does not fit LDS", w, h);
   hipStream_t st = (hipStream_t)stream;
   if (smem > 64 * 1024)
     VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_search_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   dim3 grid(cdiv(nblocks, groups), cdiv(ny, rowsPerStrip), cdiv(nx, colsPerStrip));
+  vvcgpu_mvcost mvg = {};
+  if (best)
+  {
+    mvg = *mvcost_host;
+    VVC_HIP(hipMemsetAsync(best, 0xFF, (size_t)nblocks * sizeof(vvcgpu_search_best), st));
+  }
   hipLaunchKernelGGL(sad_search_kernel, grid, dim3(SS_THREADS), smem, st, org, org_stride, ref, ref_stride, blocks, nblocks, w, h,
                      sub_shift, dx0, dy0, nx, ny, sx, sy, rowsPerStrip, colsPerStrip, pitchDw, split, groups,
-                     (int)(groupBytes / 4), sad_out);
+                     (int)(groupBytes / 4), mvg, best ? 1 : 0, sad_out, best);
   VVC_LAUNCH_CHECK();
   if (best)
   {
-    hipLaunchKernelGGL(sad_best_kernel, dim3(cdiv(nblocks, 4)), dim3(256), 0, st, sad_out, nblocks, dx0, dy0, nx, ny, sx,
-                       sy, *mvcost_host, best);
+    hipLaunchKernelGGL(sad_best_decode_kernel, dim3(cdiv(nblocks, 256)), dim3(256), 0, st, nblocks, dx0, dy0, nx, sx, sy, mvg, best);
     VVC_LAUNCH_CHECK();
   }
   return VVCGPU_OK;

@@ -152,7 +152,7 @@ def sad_search(org, ref, blocks_dev, nblocks, w, h, sub_shift, dx0, dy0, nx, ny,
     """D1 search form.  org/ref: 2-D int16 planes (ref may be a view into a padded buffer; positions are relative to
     the view's origin and may be negative as long as they stay inside the allocation).  Returns (sad[nblocks,ny,nx]
     int32 tensor, best uint8 tensor or None).  want_sad=False asks for the best candidate only (sad_out = NULL in the
-    C ABI: raster grids only, what xTZSearch's raster loop keeps); the first return value is then None."""
+    C ABI, what xPatternSearch / xTZSearch keep); the first return value is then None."""
     po, so, _, _ = _plane(org, "org")
     pr, sr, _, _ = _plane(ref, "ref")
     sad = torch.empty((nblocks, ny, nx), dtype=torch.int32, device=org.device) if want_sad else None

@@ -224,8 +224,8 @@ class Workload:
             hs = s // 2
             for (dx0, dy0, nx, ny, sx, sy) in self.me_grids:
                 Ww, Wh = (nx - 1) * sx + s, (ny - 1) * sy + s
-                # raster grids (step 5) return the best candidate only (24 B per block), the others the SAD surface too
-                outb = 24 if sx == 5 else 4 * nx * ny + 24
+                # every search returns the best candidate only (24 B per block): xPatternSearch / xTZSearch keep nothing else
+                outb = 24
                 me["sad_search_%dx%d_%dx%d" % (s, s, nx, ny)] = blk.size * (Ww * Wh * 2 + s * s * 2 + outb)
         out["me"] = me
         out["frac"] = {"frac_refine_16x16": self.frac.size * (24 * 24 * 2 + 16 * 16 * 2 + 32)}
@@ -275,9 +275,10 @@ class Workload:
         for s in sorted(self.me):
             for (dx0, dy0, nx, ny, sx, sy) in self.me_grids:
                 with T("me/sad_search_%dx%d_%dx%d" % (s, s, nx, ny)):
-                    # the raster stage of xTZSearch keeps only the best candidate (InterSearch.cpp:1979-2000): no SAD surface
+                    # xPatternSearch and the raster stage of xTZSearch keep only the best candidate
+                    # (InterSearch.cpp:1887-1935, 1979-2000): no SAD surface
                     sad, best = ops.sad_search(st["org"][0], st["ref0"][0], st["me_blk"][s], self.me[s].size, s, s, 1,
-                                               dx0, dy0, nx, ny, sx, sy, cfg_mv, want_sad=(sx != 5))
+                                               dx0, dy0, nx, ny, sx, sy, cfg_mv, want_sad=False)
                 out["me_sad_%d_%d" % (s, nx)] = sad
                 out["me_best_%d_%d" % (s, nx)] = best
         # ---- frac
