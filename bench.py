@@ -151,6 +151,7 @@ def main():
     torch.cuda.synchronize()
     if timer.ev:
         warm = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in timer.ev.items()}
+        warm = {k: v for k, v in warm.items() if k.split('/')[1] in alg.get(k.split('/')[0], {})}
         timer.only = max(warm, key=warm.get)
     timer.ev = {}
     if world > 1:
@@ -176,6 +177,7 @@ def main():
     # dominant kernel: device time over the timed region (HIP events on the stream the kernels were launched on)
     timed_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in timer.ev.items()}
     # table of all launch groups: a separate, untimed pass with an event pair around every group
+    timer_only_name = timer.only
     timer.only, timer.ev = None, {}
     for _ in range(min(args.steps, 5)):
         state, out = wl.run_gpu(state, timer)
@@ -185,7 +187,8 @@ def main():
     stage_ms = {}
     for k, v in kern_ms.items():
         stage_ms[k.split("/")[0]] = stage_ms.get(k.split("/")[0], 0.0) + v
-    dom = max(kern_ms, key=kern_ms.get)
+    cand = {k: v for k, v in (timed_ms if timer_only_name else kern_ms).items() if k.split('/')[1] in alg.get(k.split('/')[0], {})}
+    dom = max(cand, key=cand.get)
     dstage, dname = dom.split("/")
     abytes = alg[dstage][dname]
     achieved = abytes / (kern_ms[dom] * 1e-3) / 1e9
