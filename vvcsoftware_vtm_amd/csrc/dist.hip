@@ -320,24 +320,36 @@ __global__ __launch_bounds__(SS_THREADS) void sad_search_kernel(const Pel* __res
 //     not write the SAD surface at all when the caller only wants the best candidate (xTZSearch does).
 // One stage = two 16-sample chunk-rows for the lane's two positions i and i+2 (classes c and c+2, whose windows overlap:
 // their 8-byte words are shared, 7 or 8 words for the two instead of 5 + 5).
-struct R5cStage { unsigned ov[2][9]; unsigned long long d[2][8]; };         // [chunk-row of the stage][word]
+// full 8-byte words in d[], plus the two half words at the ends of the span that are only half used (x0 = high dword of word 0
+// when OA >= 2, x1 = low dword of the last word when OA is 0 or 3): 13-14 VGPRs per chunk-row instead of 16, which is what
+// lets the kernel fit 80 VGPRs (6 waves per SIMD) without scratch.
+struct R5cStage { unsigned ov[2][9]; unsigned long long d[2][7]; unsigned x0[2], x1[2]; };
 
 template <int OA, bool OODD>
-__device__ __forceinline__ void r5c_issue_row(unsigned (&ov)[9], unsigned long long (&d)[8], const unsigned* __restrict__ op, unsigned a)
+__device__ __forceinline__ void r5c_issue_row(unsigned (&ov)[9], unsigned long long (&d)[7], unsigned& x0, unsigned& x1,
+                                              const unsigned* __restrict__ op, unsigned a)
 {
 #pragma unroll
   for (int k = 0; k < (OODD ? 9 : 8); k++) ov[k] = op[k];
   // single ds_read_b64 (2 LDS cycles each); left to the compiler they are merged into ds_read2_b64, which runs at half
   // that rate.  The compiler cannot see that the destination registers stay busy until the explicit lgkmcnt(0) of the
-  // pipeline: r5c_compute pins every one of them live past it, and a word that is not needed is not loaded at all.
-  if (OA == 3)
-    asm volatile("ds_read_b64 %0, %8\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\tds_read_b64 %3, %8 offset:24\n\t"
-                 "ds_read_b64 %4, %8 offset:32\n\tds_read_b64 %5, %8 offset:40\n\tds_read_b64 %6, %8 offset:48\n\tds_read_b64 %7, %8 offset:56"
-                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(d[7]) : "v"(a) : "memory");
-  else
+  // pipeline: r5c_compute pins every one of them live past it, and nothing that is not needed is loaded.
+  if (OA == 0)        // words 0..5, low half of word 6
+    asm volatile("ds_read_b64 %0, %7\n\tds_read_b64 %1, %7 offset:8\n\tds_read_b64 %2, %7 offset:16\n\tds_read_b64 %3, %7 offset:24\n\t"
+                 "ds_read_b64 %4, %7 offset:32\n\tds_read_b64 %5, %7 offset:40\n\tds_read_b32 %6, %7 offset:48"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(x1) : "v"(a) : "memory");
+  else if (OA == 1)   // words 0..6
     asm volatile("ds_read_b64 %0, %7\n\tds_read_b64 %1, %7 offset:8\n\tds_read_b64 %2, %7 offset:16\n\tds_read_b64 %3, %7 offset:24\n\t"
                  "ds_read_b64 %4, %7 offset:32\n\tds_read_b64 %5, %7 offset:40\n\tds_read_b64 %6, %7 offset:48"
                  : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]) : "v"(a) : "memory");
+  else if (OA == 2)   // high half of word 0, words 1..6
+    asm volatile("ds_read_b32 %0, %7 offset:4\n\tds_read_b64 %1, %7 offset:8\n\tds_read_b64 %2, %7 offset:16\n\tds_read_b64 %3, %7 offset:24\n\t"
+                 "ds_read_b64 %4, %7 offset:32\n\tds_read_b64 %5, %7 offset:40\n\tds_read_b64 %6, %7 offset:48"
+                 : "=&v"(x0), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]) : "v"(a) : "memory");
+  else                // high half of word 0, words 1..6, low half of word 7
+    asm volatile("ds_read_b32 %0, %8 offset:4\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\tds_read_b64 %3, %8 offset:24\n\t"
+                 "ds_read_b64 %4, %8 offset:32\n\tds_read_b64 %5, %8 offset:40\n\tds_read_b64 %6, %8 offset:48\n\tds_read_b32 %7, %8 offset:56"
+                 : "=&v"(x0), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(x1) : "v"(a) : "memory");
 }
 
 // acc0 / acc1 = positions i / i+2.  Class c+2 starts 10 samples after class c: for OA in {0,1} that is word +2 with
@@ -345,22 +357,27 @@ __device__ __forceinline__ void r5c_issue_row(unsigned (&ov)[9], unsigned long l
 template <int OA, bool OODD>
 __device__ __forceinline__ void r5c_compute(const R5cStage& st, unsigned& acc0, unsigned& acc1)
 {
-  constexpr int NW = OA == 3 ? 8 : 7;
   constexpr int OB = OA ^ 2, WB = OA < 2 ? 2 : 3;
+  constexpr int W0 = OA >= 2 ? 1 : 0;                       // first word held in d[]
+  constexpr int NF = OA == 1 ? 7 : 6;                       // full words in d[]
 #pragma unroll
   for (int j = 0; j < 2; j++)
   {
     unsigned dd[16];
 #pragma unroll
-    for (int k = 0; k < NW; k++)
+    for (int k = 0; k < NF; k++)
     {
       asm volatile("" :: "v"(st.d[j][k]));                  // whole 64-bit destination stays allocated until here
-      dd[2 * k] = (unsigned)st.d[j][k]; dd[2 * k + 1] = (unsigned)(st.d[j][k] >> 32);
+      dd[2 * (W0 + k)] = (unsigned)st.d[j][k]; dd[2 * (W0 + k) + 1] = (unsigned)(st.d[j][k] >> 32);
     }
+    if (OA >= 2) { asm volatile("" :: "v"(st.x0[j])); dd[1] = st.x0[j]; }
+    if (OA == 0) { asm volatile("" :: "v"(st.x1[j])); dd[12] = st.x1[j]; }
+    if (OA == 3) { asm volatile("" :: "v"(st.x1[j])); dd[14] = st.x1[j]; }
 #pragma unroll
     for (int k = 0; k < 8; k++)
     {
-      const unsigned o = (OODD ? ((st.ov[j][k] >> 16) | (st.ov[j][k + 1] << 16)) : st.ov[j][k]) ^ 0x80008000u;
+      // odd block origin: funnel the wave-uniform pair down by one sample (a 64-bit scalar shift)
+      const unsigned o = (OODD ? (unsigned)(((((unsigned long long)st.ov[j][k + 1]) << 32) | st.ov[j][k]) >> 16) : st.ov[j][k]) ^ 0x80008000u;
       const int ia = k + (OA >> 1), ib = 2 * WB + k + (OB >> 1);
       acc0 = __builtin_amdgcn_sad_u16(o, (OA & 1) ? __builtin_amdgcn_alignbit(dd[ia + 1], dd[ia], 16) : dd[ia], acc0);
       acc1 = __builtin_amdgcn_sad_u16(o, (OB & 1) ? __builtin_amdgcn_alignbit(dd[ib + 1], dd[ib], 16) : dd[ib], acc1);
@@ -388,7 +405,7 @@ __device__ __forceinline__ void r5c_issue(R5cStage& st, const unsigned* __restri
 #pragma unroll
   for (int j = 0; j < 2; j++)
   {
-    r5c_issue_row<OA, OODD>(st.ov[j], st.d[j], orgDw + cur.oOff, base + cur.lOff * 4u);
+    r5c_issue_row<OA, OODD>(st.ov[j], st.d[j], st.x0[j], st.x1[j], orgDw + cur.oOff, base + cur.lOff * 4u);
     cur.advance(CH, oRow, lRow);
   }
 }
@@ -491,34 +508,43 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const Pel* __re
   const int nStages = (hs * CH) >> 1;
   const int ngrp = (nj + 5) / 6, ncg = (nx + 39) / 40;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
-  const int lane = tid & 63, q = lane & 31;
-  int m = (q * 26) >> 8;                                                    // q / 10
-  const int k = q - 10 * m;                                                 // lanes 30, 31: m = 3 -> dead, re-reading lanes 0, 1
-  const bool laneDead = m >= 3;
-  if (laneDead) m = 0;
+  const int lane = tid & 63;
   const int oodd = blk.org_x & 1;
   const unsigned* orgDw = reinterpret_cast<const unsigned*>(org + (size_t)blk.org_y * os + blk.org_x - oodd);
   const int osStep = (os >> 1) << subShift;
   const int ldsStep = pitchDw << subShift;
   const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)refL;
   unsigned long long kmin = ~0ull;
+  // lane -> (column k of 10, raster row m of 3) of its half; lanes 30, 31 of a half (m = 3) are dead and re-read lanes 0, 1.
+  // The mapping is re-derived from an opaque copy of the lane id after the SAD loop, so that none of it has to stay in
+  // registers across the loop (the kernel sits right at the 80-VGPR limit of 6 waves per SIMD).
+  auto lane_map = [](int ln, int& k, int& m, bool& dead) { const int q = ln & 31; m = (q * 26) >> 8; k = q - 10 * m; dead = m >= 3; if (dead) m = 0; };
   for (int cg = 0; cg < ncg; cg++)
     for (int it = wave; it < 2 * ngrp; it += nwaves)
     {
       const int c = it & 1, g = it >> 1;                                    // classes c and c + 2
-      const int jj = g * 6 + (lane >> 5) * 3 + m;
-      const int i0 = cg * 40 + 4 * k + c;                                   // positions i0 and i0 + 2
-      const bool rowLive = !laneDead && jj < nj;
-      const int cx = 5 * (i0 < nx ? i0 : c) + off;                          // dead lanes re-read a live lane's address (broadcast)
-      const unsigned base = ldsBase + (unsigned)(2 * (cx >> 2) + (min(jj, nj - 1) * 5) * pitchDw) * 4u;
       const int OA = (c + off) & 3;                                         // == cx & 3 for every lane of the wave
       unsigned acc0 = 0, acc1 = 0;
+      {
+        int k, m; bool dead;
+        lane_map(lane, k, m, dead);
+        const int jj = g * 6 + (lane >> 5) * 3 + m;
+        const int i0 = cg * 40 + 4 * k + c;                                 // positions i0 and i0 + 2
+        const int cx = 5 * (i0 < nx ? i0 : c) + off;                        // dead lanes re-read a live lane's address (broadcast)
+        const unsigned base = ldsBase + (unsigned)(2 * (cx >> 2) + (min(jj, nj - 1) * 5) * pitchDw) * 4u;
 #define R5C_CALL(OV)                                                                                                            \
-      do { if (oodd) r5c_positions<OV, true>(orgDw, osStep, base, ldsStep, nStages, CH, acc0, acc1);                              \
-           else      r5c_positions<OV, false>(orgDw, osStep, base, ldsStep, nStages, CH, acc0, acc1); } while (0)
-      if (OA == 0) R5C_CALL(0); else if (OA == 1) R5C_CALL(1); else if (OA == 2) R5C_CALL(2); else R5C_CALL(3);
+        do { if (oodd) r5c_positions<OV, true>(orgDw, osStep, base, ldsStep, nStages, CH, acc0, acc1);                            \
+             else      r5c_positions<OV, false>(orgDw, osStep, base, ldsStep, nStages, CH, acc0, acc1); } while (0)
+        if (OA == 0) R5C_CALL(0); else if (OA == 1) R5C_CALL(1); else if (OA == 2) R5C_CALL(2); else R5C_CALL(3);
 #undef R5C_CALL
-      if (rowLive)
+      }
+      int lane2 = lane;
+      asm volatile("" : "+v"(lane2));                                       // opaque: forces the re-derivation below
+      int k, m; bool dead;
+      lane_map(lane2, k, m, dead);
+      const int jj = g * 6 + (lane2 >> 5) * 3 + m;
+      const int i0 = cg * 40 + 4 * k + c;
+      if (!dead && jj < nj)
       {
         const int idx0 = (j0 + jj) * nx + i0;
         unsigned* o = out ? out + (size_t)b * ny * nx + idx0 : nullptr;
