@@ -337,6 +337,33 @@ int vtmref_inv_tr2d(int bd, const TCoeff* coeff, Pel* resi, int stride, int w, i
   xITrMxN_EMT(bd, coeff, resi, stride, w, h, skipW, skipH, 15, mode, idx);
   return 0;
 }
+// Transform skip: TrQuant::xTransformSkip / xITransformSkip (TrQuant.cpp:795-847, 1112-1163) are private members taking a
+// TransformUnit; they only read tu.blocks[compID], tu.cs->sps (bit depth, dynamic range, range-extension flags, all default:
+// no extended precision, no residual rotation).  A zero-filled CodingStructure with just `sps` set is enough for that.
+int vtmref_transform_skip(int inverse, int bd, Pel* resi, int stride, TCoeff* coef, int w, int h)
+{
+  static SPS* sps = nullptr;
+  static CodingStructure* cs = nullptr;
+  static TrQuant* tq = nullptr;
+  if (!sps)
+  {
+    sps = new SPS;
+    cs = static_cast<CodingStructure*>(calloc(1, sizeof(CodingStructure)));
+    cs->sps = sps;
+    tq = new TrQuant;
+  }
+  sps->setBitDepth(CHANNEL_TYPE_LUMA, bd);
+  TransformUnit tu(CHROMA_400, Area(0, 0, w, h));
+  tu.cs = cs;
+  if (!inverse) tq->xTransformSkip(tu, COMPONENT_Y, CPelBuf(resi, stride, w, h), coef);
+  else
+  {
+    const CCoeffBuf cb(coef, w, w, h);
+    PelBuf rb(resi, stride, w, h);
+    tq->xITransformSkip(cb, rb, tu, COMPONENT_Y);
+  }
+  return 0;
+}
 // Effective 1-D matrices of the reference's fast transforms, obtained by pushing 2*identity through
 // fastFwdTrans / fastInvTrans with shift 1 (so the rounding returns the integer matrix entry exactly).
 // out: N x N int32, out[j*N + k] = weight of input sample k in output coefficient j (forward) /
@@ -414,12 +441,16 @@ int vtmref_mc_batch(const Pel* ref0, const Pel* ref1, Pel* dst, const vvcgpu_mc_
 }
 int vtmref_tr_fwd_batch(const Pel* resi, TCoeff* coeff, const vvcgpu_tr_desc* d, int n, int bd)
 {
-  for (int i = 0; i < n; i++) vtmref_fwd_tr2d(bd, resi + d[i].resi_off, d[i].resi_stride, coeff + d[i].coeff_off, d[i].w, d[i].h, d[i].tr_hor, d[i].tr_ver);
+  for (int i = 0; i < n; i++)
+    if (d[i].tr_hor == 3) vtmref_transform_skip(0, bd, const_cast<Pel*>(resi + d[i].resi_off), d[i].resi_stride, coeff + d[i].coeff_off, d[i].w, d[i].h);
+    else vtmref_fwd_tr2d(bd, resi + d[i].resi_off, d[i].resi_stride, coeff + d[i].coeff_off, d[i].w, d[i].h, d[i].tr_hor, d[i].tr_ver);
   return 0;
 }
 int vtmref_tr_inv_batch(const TCoeff* coeff, Pel* resi, const vvcgpu_tr_desc* d, int n, int bd)
 {
-  for (int i = 0; i < n; i++) vtmref_inv_tr2d(bd, coeff + d[i].coeff_off, resi + d[i].resi_off, d[i].resi_stride, d[i].w, d[i].h, d[i].tr_hor, d[i].tr_ver);
+  for (int i = 0; i < n; i++)
+    if (d[i].tr_hor == 3) vtmref_transform_skip(1, bd, resi + d[i].resi_off, d[i].resi_stride, const_cast<TCoeff*>(coeff + d[i].coeff_off), d[i].w, d[i].h);
+    else vtmref_inv_tr2d(bd, coeff + d[i].coeff_off, resi + d[i].resi_off, d[i].resi_stride, d[i].w, d[i].h, d[i].tr_hor, d[i].tr_ver);
   return 0;
 }
 int vtmref_dist_batch(int kind, const Pel* org, const Pel* cur, const vvcgpu_dist_desc* d, int n, int bd, uint64_t* out)

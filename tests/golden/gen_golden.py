@@ -199,6 +199,32 @@ def gen_transform():
     save("transform", **out)
 
 
+def gen_tskip():
+    """transform skip through the reference's own TrQuant::xTransformSkip / xITransformSkip (private members, entered by
+    oracle/ref_wrap_kernels.h:vtmref_transform_skip): every W x H in 2..64 incl. the sqrt(2)-scaled rectangular shapes."""
+    rng = np.random.default_rng(1007)
+    out = {}
+    for bd in (8, 10):
+        mx = (1 << bd) - 1
+        rows, resis, coefs, cins, invs = [], [], [], [], []
+        for w in (2, 4, 8, 16, 32, 64):
+            for h in (2, 4, 8, 16, 32, 64):
+                r = rng.integers(-mx, mx + 1, (h, w)).astype(np.int16)
+                c = np.zeros((h, w), np.int32)
+                R.vtmref_transform_skip(0, bd, p(r), w, p(c), w, h)
+                q = rng.integers(-32768, 32768, (h, w)).astype(np.int32)
+                ri = np.zeros((h, w), np.int16)
+                R.vtmref_transform_skip(1, bd, p(ri), w, p(q), w, h)
+                rows.append((w, h))
+                resis.append(r.reshape(-1)); coefs.append(c.reshape(-1)); cins.append(q.reshape(-1)); invs.append(ri.reshape(-1))
+        out["rows%d" % bd] = np.array(rows, np.int32)
+        out["resi%d" % bd] = np.concatenate(resis)
+        out["coef%d" % bd] = np.concatenate(coefs)
+        out["cin%d" % bd] = np.concatenate(cins)
+        out["inv%d" % bd] = np.concatenate(invs)
+    save("tskip", **out)
+
+
 def gen_frac():
     rng = np.random.default_rng(1006)
     FB = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4")])
@@ -233,4 +259,7 @@ def gen_frac():
 
 
 if __name__ == "__main__":
-    gen_alf(); gen_sao(); gen_dist(); gen_interp(); gen_transform(); gen_frac()
+    only = sys.argv[1:]
+    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_frac):
+        if not only or fn.__name__[4:] in only:
+            fn()

@@ -131,6 +131,26 @@ def test_transform_golden():
             pos += n
 
 
+def test_transform_skip_golden():
+    """T3 pinned: restatement == TrQuant::xTransformSkip / xITransformSkip of the compiled reference."""
+    g = load("tskip")
+    O = oracle()
+    for bd in (8, 10):
+        pos = 0
+        for (w, h) in g["rows%d" % bd]:
+            w, h = int(w), int(h)
+            n = w * h
+            r = g["resi%d" % bd][pos:pos + n].copy()
+            c = np.zeros(n, np.int32)
+            O.orc_tr_fwd(p(r), w, p(c), w, h, 3, 0, bd)
+            assert np.array_equal(c, g["coef%d" % bd][pos:pos + n]), (bd, w, h)
+            q = g["cin%d" % bd][pos:pos + n].copy()
+            ri = np.zeros(n, np.int16)
+            O.orc_tr_inv(p(q), p(ri), w, w, h, 3, 0, bd)
+            assert np.array_equal(ri, g["inv%d" % bd][pos:pos + n]), (bd, w, h)
+            pos += n
+
+
 def test_frac_refine_golden():
     g = load("frac")
     O = oracle()
