@@ -574,6 +574,106 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const Pel* __re
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Dense small grids (step 1 in both directions, nx * ny <= 256: the +-4 window of xPatternSearch): the (block, position)
+// pairs of G = 256 / (nx ny) blocks are laid flat over the 256 lanes of a workgroup (81 positions: 3 blocks, 95 % of the
+// lanes busy, where one block per 128 lanes would leave a third idle); each block's org and window sit in LDS as biased
+// 16-bit pairs, the org row is a broadcast 16-byte LDS read per lane group.  A block is finished by exactly one workgroup,
+// so the arg-min needs no global atomic, no memset and no decode pass: per-block 64-bit LDS min, then one lane writes the
+// finished vvcgpu_search_best.
+__global__ __launch_bounds__(256) void sad_dense_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
+                                                        const vvcgpu_search_blk* __restrict__ blocks, int nblocks, int w, int h,
+                                                        int subShift, int dx0, int dy0, int nx, int ny, int pitchDw, int blkDw, int G,
+                                                        int npos, unsigned recipNpos, unsigned recipNx, vvcgpu_mvcost mv, int useBest,
+                                                        unsigned* __restrict__ out, vvcgpu_search_best* __restrict__ best)
+{
+  extern __shared__ __align__(16) unsigned ldsD[];
+  __shared__ unsigned long long keyL[32];
+  __shared__ int oddL[32];
+  const int tid = threadIdx.x;
+  const int b0 = blockIdx.x * G;
+  const int hs = h >> subShift, wp = w >> 1, lwp = 31 - __clz(wp);
+  const int winRows = ny - 1 + h, Ww = nx - 1 + w;
+  const int orgDw = (hs * wp + 3) & ~3;
+  if (tid < 32) keyL[tid] = ~0ull;
+  for (int g = 0; g < G && b0 + g < nblocks; g++)
+  {
+    const vvcgpu_search_blk blk = blocks[b0 + g];
+    unsigned* orgL = ldsD + g * blkDw;
+    unsigned* refL = orgL + orgDw;
+    const Pel* o = org + (size_t)blk.org_y * os + blk.org_x;
+    for (int e = tid; e < hs * wp; e += 256)
+    {
+      const int r = e >> lwp, k = e & (wp - 1);
+      const Pel* q = o + (size_t)(r << subShift) * os + 2 * k;
+      orgL[e] = ((unsigned)(unsigned short)q[0] | ((unsigned)(unsigned short)q[1] << 16)) ^ 0x80008000u;
+    }
+    const ptrdiff_t winOff = (ptrdiff_t)(blk.ref_y + dy0) * rs + blk.ref_x + dx0;
+    const int odd = (int)(winOff & 1);
+    if (tid == 0) oddL[g] = odd;
+    const int nPairs = ((Ww - 1 + odd) >> 1) + 1;
+    const unsigned* gp = reinterpret_cast<const unsigned*>(ref + (winOff - odd));
+    const int rsDw = rs >> 1;
+    for (int r = tid >> 4; r < winRows; r += 16)
+      for (int k = tid & 15; k < nPairs; k += 16)
+        refL[r * pitchDw + k] = gp[(ptrdiff_t)r * rsDw + k] ^ 0x80008000u;
+  }
+  __syncthreads();
+
+  const int g = (int)(((unsigned)tid * recipNpos) >> 16), p = tid - g * npos;
+  const bool live = g < G && b0 + g < nblocks;
+  if (live)
+  {
+    const int j = (int)(((unsigned)p * recipNx) >> 16), i = p - j * nx;
+    const unsigned* orgL = ldsD + g * blkDw;
+    const int cx = i + oddL[g];
+    const unsigned sh = (cx & 1) << 4;
+    const unsigned* base = orgL + orgDw + (cx >> 1) + j * pitchDw;
+    unsigned acc = 0;
+    for (int r = 0; r < hs; r++)
+    {
+      const unsigned* rp = base + (r << subShift) * pitchDw;
+      const unsigned* op = orgL + r * wp;
+      unsigned g0 = rp[0];
+#pragma unroll 2
+      for (int k = 0; k < wp; k += 4)
+      {
+        const uint4 ov = *reinterpret_cast<const uint4*>(op + k);
+        const unsigned g1 = rp[k + 1], g2 = rp[k + 2], g3 = rp[k + 3], g4 = rp[k + 4];
+        acc = __builtin_amdgcn_sad_u16(ov.x, __builtin_amdgcn_alignbit(g1, g0, sh), acc);
+        acc = __builtin_amdgcn_sad_u16(ov.y, __builtin_amdgcn_alignbit(g2, g1, sh), acc);
+        acc = __builtin_amdgcn_sad_u16(ov.z, __builtin_amdgcn_alignbit(g3, g2, sh), acc);
+        acc = __builtin_amdgcn_sad_u16(ov.w, __builtin_amdgcn_alignbit(g4, g3, sh), acc);
+        g0 = g4;
+      }
+    }
+    acc <<= subShift;
+    if (out) out[((size_t)(b0 + g) * ny + j) * nx + i] = acc;
+    if (useBest)
+    {
+      const int x = dx0 + i, y = dy0 + j;
+      const unsigned bits = expgolomb_bits(((x << mv.cost_scale) - mv.pred_hor) >> mv.imv_shift) +
+                            expgolomb_bits(((y << mv.cost_scale) - mv.pred_ver) >> mv.imv_shift);
+      atomicMin(&keyL[g], (((unsigned long long)acc + (unsigned long long)(mv.lambda * (double)bits)) << 24) | (unsigned)p);
+    }
+  }
+  if (!useBest) return;
+  __syncthreads();
+  if (tid < G && b0 + tid < nblocks)
+  {
+    const unsigned long long key = keyL[tid];
+    const int idx = (int)(key & 0xFFFFFFu);
+    const unsigned long long cost = key >> 24;
+    const int j = idx / nx, i = idx - j * nx;
+    const int x = dx0 + i, y = dy0 + j;
+    const unsigned bits = expgolomb_bits(((x << mv.cost_scale) - mv.pred_hor) >> mv.imv_shift) +
+                          expgolomb_bits(((y << mv.cost_scale) - mv.pred_ver) >> mv.imv_shift);
+    vvcgpu_search_best r;
+    r.x = x; r.y = y; r.cost = cost; r.sad = cost - (unsigned long long)(mv.lambda * (double)bits);
+    best[b0 + tid] = r;
+  }
+}
+
 // decodes the packed (cost << 24 | scan index) keys left in best[].cost by sad_raster5c_kernel
 __global__ __launch_bounds__(256) void sad_best_decode_kernel(int nblocks, int dx0, int dy0, int nx, int sx, int sy, vvcgpu_mvcost mv,
                                                               vvcgpu_search_best* __restrict__ best)
@@ -624,6 +724,32 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
   VVC_CHECK_ARG(nx > 0 && ny > 0 && sx > 0 && sy > 0, "sad_search: bad position grid");
   VVC_CHECK_ARG((best == nullptr) == (mvcost_host == nullptr), "sad_search: best and mvcost must be given together");
   hipStream_t st0 = (hipStream_t)stream;
+  static const int denseOff = getenv("VVCGPU_NO_DENSE") ? 1 : 0;          // A/B timing switch
+  if (!denseOff && sx == 1 && sy == 1 && nx * ny <= 256 && w >= 8 && w <= 128 && (w & (w - 1)) == 0 && (ref_stride & 1) == 0 &&
+      ((uintptr_t)ref & 3) == 0)
+  {
+    const int npos = nx * ny, hsD = h >> sub_shift, wp = w >> 1;
+    int pitch = (nx - 1 + w + 1) / 2 + 1;                                   // pairs of the widest row + one look-ahead pair
+    while ((pitch & 31) != 5 && (pitch & 31) != 27) pitch++;                // consecutive rows 5 banks apart: distinct banks for a wave's ~8 rows
+    const int orgDw = (hsD * wp + 3) & ~3;
+    const int blkDw = (orgDw + (ny - 1 + h) * pitch + 4 + 3) & ~3;
+    int G = 256 / npos;
+    if (G > 32) G = 32;
+    while (G > 1 && (size_t)G * blkDw * 4 > 60 * 1024) G--;
+    const size_t smem = (size_t)G * blkDw * 4;
+    if (smem <= 150 * 1024)
+    {
+      vvcgpu_mvcost mv = {};
+      if (best) mv = *mvcost_host;
+      if (smem > 48 * 1024)
+        VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_dense_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(sad_dense_kernel, dim3(cdiv(nblocks, G)), dim3(256), smem, st0, org, org_stride, ref, ref_stride, blocks, nblocks,
+                         w, h, sub_shift, dx0, dy0, nx, ny, pitch, blkDw, G, npos, 65536u / (unsigned)npos + 1u, 65536u / (unsigned)nx + 1u,
+                         mv, best ? 1 : 0, sad_out, best);
+      VVC_LAUNCH_CHECK();
+      return VVCGPU_OK;
+    }
+  }
   static const int r5cOff = getenv("VVCGPU_NO_R5C") ? 1 : 0;              // A/B timing switch
   if (!r5cOff && sx == 5 && sy == 5 && (w == 16 || w == 32 || w == 64 || w == 128) && (org_stride & 1) == 0 && (ref_stride & 7) == 0 &&
       ((uintptr_t)org & 3) == 0 && ((uintptr_t)ref & 15) == 0 && (long long)nx * ny < (1 << 24) && nx >= 1)
