@@ -16,9 +16,17 @@ int main(int argc, char** argv) {
   char self[PATH_MAX]; if (!realpath(argv[0], self)) { perror("realpath"); return 2; }
   int hip = 0;
   if (strcmp(argv[1], "--hip") == 0) { hip = 1; argv++; argc--; if (argc < 2) return 2; }
-  char lib[PATH_MAX]; snprintf(lib, sizeof lib, "%s/%s", dirname(self), hip ? "libvtmref_hip.so" : "libvtmref.so");
+  const char* dir = dirname(self);     /* may modify `self`: called once */
+  char lib[PATH_MAX]; snprintf(lib, sizeof lib, "%s/%s", dir, hip ? "libvtmref_hip.so" : "libvtmref.so");
+  void* hk = NULL;
+  if (hip) {   /* interposes the two encoder-statistics entry points ld --wrap cannot reach (oracle/ref_hooks.cpp) */
+    char hooks[PATH_MAX]; snprintf(hooks, sizeof hooks, "%s/libvtmhooks.so", dir);
+    hk = dlopen(hooks, RTLD_NOW | RTLD_GLOBAL);
+    if (!hk) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+  }
   void* h = dlopen(lib, RTLD_NOW | RTLD_GLOBAL);
   if (!h) { fprintf(stderr, "dlopen: %s\n", dlerror()); return 2; }
+  if (hk) { void (*st)(void*) = (void (*)(void*))dlsym(hk, "vtmhooks_set_target"); if (!st) return 2; st(h); }
   appfn f = (appfn)dlsym(h, strcmp(argv[1], "enc") == 0 ? "vtmref_encode" : "vtmref_decode");
   if (!f) { fprintf(stderr, "dlsym: %s\n", dlerror()); return 2; }
   return f(argc - 1, argv + 1);

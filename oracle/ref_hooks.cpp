@@ -1,0 +1,42 @@
+// oracle/ref_hooks.cpp -- TEST INFRASTRUCTURE (part of the reference drop-in harness, see vtm_hip_shim.cpp).
+// EncSampleAdaptiveOffset::getStatistics and EncAdaptiveLoopFilter::deriveStatsForFiltering are called from inside their own
+// translation units (EncSampleAdaptiveOffset.cpp:227, EncAdaptiveLoopFilter.cpp:260), where GNU ld --wrap does not reach.  The
+// reference objects are position independent, so those calls are PLT calls to interposable symbols: this tiny library, loaded
+// with RTLD_GLOBAL ahead of libvtmref_hip.so, defines the two symbols, offers the call to the GPU shim and otherwise forwards
+// to the reference's own definition (looked up in the handle the driver passes to vtmhooks_set_target).  No reference header is
+// needed: `this` and references are pointers.
+#include <dlfcn.h>
+#include <cstdio>
+#include <cstdlib>
+
+#define SAO_SYM "_ZN23EncSampleAdaptiveOffset13getStatisticsERSt6vectorIPP11SAOStatDataSaIS3_EER7UnitBufIsES9_R15CodingStructureb"
+#define ALF_SYM "_ZN21EncAdaptiveLoopFilter23deriveStatsForFilteringER7UnitBufIsES2_"
+
+extern "C" {
+typedef void (*sao_real_t)(void*, void*, void*, void*, void*, bool);
+typedef int (*sao_shim_t)(void*, void*, void*, void*, void*, bool);
+typedef void (*alf_real_t)(void*, void*, void*);
+typedef int (*alf_shim_t)(void*, void*, void*);
+
+void hook_sao_stats(void* self, void* blkStats, void* org, void* src, void* cs, bool pre) asm(SAO_SYM);
+void hook_alf_stats(void* self, void* org, void* rec) asm(ALF_SYM);
+
+static void* g_target = nullptr;                 // dlopen handle of libvtmref_hip.so (holds the reference's own definitions)
+void vtmhooks_set_target(void* handle) { g_target = handle; }
+static void* must(void* p, const char* what) { if (!p) { fprintf(stderr, "ref_hooks: %s not found\n", what); abort(); } return p; }
+
+void hook_sao_stats(void* self, void* blkStats, void* org, void* src, void* cs, bool pre)
+{
+  static sao_shim_t shim = (sao_shim_t)dlsym(RTLD_DEFAULT, "vvcshim_sao_stats");
+  static sao_real_t real = (sao_real_t)must(g_target ? dlsym(g_target, SAO_SYM) : nullptr, SAO_SYM);
+  if (shim && shim(self, blkStats, org, src, cs, pre)) return;
+  real(self, blkStats, org, src, cs, pre);
+}
+void hook_alf_stats(void* self, void* org, void* rec)
+{
+  static alf_shim_t shim = (alf_shim_t)dlsym(RTLD_DEFAULT, "vvcshim_alf_stats");
+  static alf_real_t real = (alf_real_t)must(g_target ? dlsym(g_target, ALF_SYM) : nullptr, ALF_SYM);
+  if (shim && shim(self, org, rec)) return;
+  real(self, org, rec);
+}
+}

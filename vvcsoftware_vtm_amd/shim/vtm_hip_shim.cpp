@@ -22,6 +22,8 @@
 #include "CommonLib/LoopFilter.h"
 #include "CommonLib/SampleAdaptiveOffset.h"
 #include "CommonLib/AdaptiveLoopFilter.h"
+#include "EncoderLib/EncSampleAdaptiveOffset.h"
+#include "EncoderLib/EncAdaptiveLoopFilter.h"
 #include "vvcgpu.h"
 
 #define VVCGPU(call) do { if ((call) != 0) THROW("vvcgpu: " << vvcgpu_last_error()); } while (0)
@@ -33,6 +35,13 @@ void wrap_SAOProcess(SampleAdaptiveOffset*, CodingStructure&, SAOBlkParam*) asm(
 void real_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) asm("__real__ZN18AdaptiveLoopFilter10ALFProcessER15CodingStructureR13AlfSliceParam");
 void wrap_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) asm("__wrap__ZN18AdaptiveLoopFilter10ALFProcessER15CodingStructureR13AlfSliceParam");
 
+// The two encoder-statistics entry points are called from inside their own translation unit, where ld --wrap does not reach;
+// those calls go through the PLT (the objects are -fPIC), so oracle/ref_hooks.cpp, loaded ahead of this library, pre-empts the
+// symbols and asks the two functions below first (1 = done on the GPU, 0 = run the reference's own body).
+extern "C" int vvcshim_sao_stats(EncSampleAdaptiveOffset* self, std::vector<SAOStatData**>* blkStats, PelUnitBuf* orgYuv, PelUnitBuf* srcYuv,
+                                 CodingStructure* cs, bool isCalculatePreDeblockSamples);
+extern "C" int vvcshim_alf_stats(EncAdaptiveLoopFilter* self, PelUnitBuf* orgYuv, PelUnitBuf* recYuv);
+
 namespace {
 
 bool shimEnabled()
@@ -41,8 +50,9 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[3] = { 0, 0, 0 };
-struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld\n", g_calls[0], g_calls[1], g_calls[2]); } } g_report;
+long g_calls[5] = { 0, 0, 0, 0, 0 };
+struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld\n",
+                                                       g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -331,4 +341,123 @@ void wrap_ALFProcess(AdaptiveLoopFilter* self, CodingStructure& cs, AlfSlicePara
                                     alfSliceParam.chromaCoeff, g_flags[c].ptr, self->m_clpRngs.comp[c].min, self->m_clpRngs.comp[c].max, nullptr));
   g_b.download(rec);
   g_calls[2]++;
+}
+
+// ---- encoder statistics -------------------------------------------------------------------------------------
+// EncSampleAdaptiveOffset::getStatistics (EncSampleAdaptiveOffset.cpp:278-330): per CTU and component the five SAOStatData
+// of getBlkStats.  The skip-line counts are the same for every type unless pre-deblock samples are used (:124-168), which
+// falls through to the reference.
+int vvcshim_sao_stats(EncSampleAdaptiveOffset* self, std::vector<SAOStatData**>* blkStatsP, PelUnitBuf* orgYuvP, PelUnitBuf* srcYuvP,
+                      CodingStructure* csP, bool isCalculatePreDeblockSamples)
+{
+  std::vector<SAOStatData**>& blkStats = *blkStatsP;
+  PelUnitBuf& orgYuv = *orgYuvP;
+  PelUnitBuf& srcYuv = *srcYuvP;
+  CodingStructure& cs = *csP;
+  bool uniform = true;
+  for (int c = 0; c < 3; c++)
+    for (int t = 1; t < NUM_SAO_NEW_TYPES; t++)
+      uniform = uniform && self->m_skipLinesR[c][t] == self->m_skipLinesR[c][0] && self->m_skipLinesB[c][t] == self->m_skipLinesB[c][0];
+  if (!shimEnabled() || isCalculatePreDeblockSamples || !uniform) return 0;
+  const PreCalcValues& pcv = *cs.pcv;
+  const int nCtu = pcv.sizeInCtus;
+  std::vector<uint8_t> avail(nCtu);
+  int idx = 0;
+  for (uint32_t yPos = 0; yPos < pcv.lumaHeight; yPos += pcv.maxCUHeight)
+    for (uint32_t xPos = 0; xPos < pcv.lumaWidth; xPos += pcv.maxCUWidth, idx++)
+    {
+      bool l, a, al;
+      const UnitArea area(cs.area.chromaFormat, Area(xPos, yPos, std::min<uint32_t>(pcv.maxCUWidth, pcv.lumaWidth - xPos), std::min<uint32_t>(pcv.maxCUHeight, pcv.lumaHeight - yPos)));
+      self->deriveLoopFilterBoundaryAvailibility(cs, area.Y(), l, a, al);
+      avail[idx] = (uint8_t)((l ? 1 : 0) | (a ? 4 : 0) | (al ? 16 : 0));
+    }
+  static DevArray<uint8_t> dAvail;
+  static DevArray<int64_t> dOut;
+  dAvail.upload(avail.data(), avail.size());
+  dOut.reserve((size_t)nCtu * 320);
+  g_a.upload(orgYuv);
+  g_b.upload(srcYuv);
+  std::vector<int64_t> out((size_t)nCtu * 320);
+  const int numberOfComponents = getNumberValidComponents(pcv.chrFormat);
+  for (int c = 0; c < numberOfComponents; c++)
+  {
+    const ComponentID compID = ComponentID(c);
+    const int cw = pcv.maxCUWidth >> getComponentScaleX(compID, pcv.chrFormat), ch = pcv.maxCUHeight >> getComponentScaleY(compID, pcv.chrFormat);
+    VVCGPU(vvcgpu_sao_stats(g_a.p[c], g_a.stride[c], g_b.p[c], g_b.stride[c], g_a.w[c], g_a.h[c], cw, ch,
+                            cs.sps->getBitDepth(toChannelType(compID)), dAvail.ptr, self->m_skipLinesR[c][0], self->m_skipLinesB[c][0], dOut.ptr, nullptr));
+    VVCGPU(vvcgpu_memcpy_d2h(out.data(), dOut.ptr, out.size() * sizeof(int64_t), nullptr));
+    VVCGPU(vvcgpu_stream_sync(nullptr));
+    for (int i = 0; i < nCtu; i++)
+      for (int t = 0; t < NUM_SAO_NEW_TYPES; t++)
+      {
+        SAOStatData& st = blkStats[i][compID][t];
+        memcpy(st.diff, &out[(size_t)i * 320 + t * 64], 32 * sizeof(int64_t));
+        memcpy(st.count, &out[(size_t)i * 320 + t * 64 + 32], 32 * sizeof(int64_t));
+      }
+  }
+  g_calls[3]++;
+  return 1;
+}
+
+// EncAdaptiveLoopFilter::deriveStatsForFiltering (EncAdaptiveLoopFilter.cpp:1317-1392): per CTU, component and filter shape
+// the AlfCovariance of getBlkStats, plus the frame sums.  recYuv is the border-extended temporary picture (ALFProcess
+// :248-252); the kernel replicates the picture border itself, which is what extendBorderPel stored there.
+int vvcshim_alf_stats(EncAdaptiveLoopFilter* self, PelUnitBuf* orgYuvP, PelUnitBuf* recYuvP)
+{
+  PelUnitBuf& orgYuv = *orgYuvP;
+  PelUnitBuf& recYuv = *recYuvP;
+  const bool square = self->m_maxCUWidth == self->m_maxCUHeight && (self->m_maxCUWidth % 128) == 0 && self->m_chromaFormat == CHROMA_420;
+  if (!shimEnabled() || !square) return 0;
+  const int numberOfComponents = getNumberValidComponents(self->m_chromaFormat);
+  const int nCtu = self->m_numCTUsInPic;
+  g_a.upload(orgYuv);
+  g_b.upload(recYuv);
+  // classifier of the luma plane as one uint16 per 4x4 block (class | transposeIdx << 8)
+  const int w4 = self->m_picWidth >> 2, h4 = self->m_picHeight >> 2;
+  std::vector<uint16_t> cls((size_t)w4 * h4);
+  for (int y = 0; y < h4; y++)
+    for (int x = 0; x < w4; x++)
+    {
+      const AlfClassifier& c = self->m_classifier[4 * y][4 * x];
+      cls[(size_t)y * w4 + x] = (uint16_t)(c.classIdx | (c.transposeIdx << 8));
+    }
+  g_cls.upload(cls.data(), cls.size());
+  static DevArray<int64_t> dOut;
+  std::vector<int64_t> out;
+  for (int channelIdx = 0; channelIdx < getNumberValidChannels(self->m_chromaFormat); channelIdx++)
+    for (int shape = 0; shape != (int)self->m_filterShapes[channelIdx].size(); shape++)
+      for (int classIdx = 0; classIdx < (channelIdx == 0 ? MAX_NUM_ALF_CLASSES : 1); classIdx++)
+        self->m_alfCovarianceFrame[channelIdx][shape][classIdx].reset();
+  for (int c = 0; c < numberOfComponents; c++)
+  {
+    const ChannelType chType = toChannelType(ComponentID(c));
+    const int nCls = c ? 1 : MAX_NUM_ALF_CLASSES;
+    for (int shape = 0; shape != (int)self->m_filterShapes[chType].size(); shape++)
+    {
+      const int N = self->m_filterShapes[chType][shape].numCoeff, recSz = N * N + N + 1;
+      CHECK(N != 7 && N != 13, "unexpected ALF filter shape");
+      const size_t n = (size_t)nCtu * nCls * recSz;
+      dOut.reserve(n);
+      out.resize(n);
+      VVCGPU(vvcgpu_alf_stats(g_a.p[c], g_a.stride[c], g_b.p[c], g_b.stride[c], g_a.w[c], g_a.h[c], self->m_maxCUWidth >> (c ? 1 : 0),
+                              c ? nullptr : g_cls.ptr, N == 13 ? 1 : 0, dOut.ptr, nullptr));
+      VVCGPU(vvcgpu_memcpy_d2h(out.data(), dOut.ptr, n * sizeof(int64_t), nullptr));
+      VVCGPU(vvcgpu_stream_sync(nullptr));
+      for (int i = 0; i < nCtu; i++)
+        for (int k = 0; k < nCls; k++)
+        {
+          AlfCovariance& cov = self->m_alfCovariance[c][shape][i][k];
+          const int64_t* r = &out[((size_t)i * nCls + k) * recSz];
+          for (int a = 0; a < N; a++)
+          {
+            for (int b = 0; b < N; b++) cov.E[a][b] = (double)r[a * N + b];
+            cov.y[a] = (double)r[N * N + a];
+          }
+          cov.pixAcc = (double)r[N * N + N];
+          self->m_alfCovarianceFrame[chType][shape][k] += cov;
+        }
+    }
+  }
+  g_calls[4]++;
+  return 1;
 }
