@@ -72,3 +72,26 @@ def test_workload_properties_1080p():
     for p in out["final"]:
         v = p.cpu().numpy()
         assert v.min() >= 0 and v.max() <= 1023
+
+
+def test_overlapped_schedule_equals_serial():
+    """the multi-stream schedule (bench default) produces exactly the outputs of the serial one, step after step."""
+    from vvcsoftware_vtm_amd.workload import Workload
+    wl = Workload(832, 480, 10, seed=3)
+    st, ser = wl.run_gpu()
+    torch.cuda.synchronize()
+    keys = [k for k, v in ser.items() if v is not None]
+    ref = {}
+    for k in keys:
+        v = ser[k]
+        ref[k] = [t.cpu().clone() for t in v] if isinstance(v, (list, tuple)) else v.cpu().clone()
+    for _ in range(3):
+        st, ov = wl.run_gpu(st, overlap=True)
+        torch.cuda.synchronize()
+        for k in keys:
+            g = ov[k]
+            if isinstance(g, (list, tuple)):
+                for a, b in zip(g, ref[k]):
+                    assert torch.equal(a.cpu(), b), k
+            else:
+                assert torch.equal(g.cpu(), ref[k]), k

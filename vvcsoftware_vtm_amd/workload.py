@@ -243,8 +243,15 @@ class Workload:
         return out
 
     # ------------------------------------------------------------------------------------------------------
-    def run_gpu(self, dev_state=None, timer=None):
-        """One step on the GPU through ops/C-ABI.  Returns (state, outputs dict of CUDA tensors)."""
+    def run_gpu(self, dev_state=None, timer=None, overlap=False):
+        """One step on the GPU through ops/C-ABI.  Returns (state, outputs dict of CUDA tensors).
+
+        overlap=False: every launch on the current stream, in stage order.
+        overlap=True: the stages' real dependencies only.  The searches, the fractional refinement and the statistics do not
+        feed the reconstruction chain (mc -> residual -> transforms -> reco -> deblock -> SAO -> ALF), so they run on three
+        side HIP streams beside it; each of these kernels alone leaves SIMDs idle while its workgroups stage their windows /
+        tiles, and concurrent kernels fill those gaps.  The 16x16 raster search (the dominant kernel) is launched first and
+        alone, so its event-timed duration stays comparable with the serial schedule."""
         import torch
         from . import ops
         T = timer or (lambda name: _NullCtx())
@@ -271,20 +278,66 @@ class Workload:
         out = {}
         bd, mx = self.bd, self.mx
         cfg_mv = ops.MvCost(self.mvcost.lambda_, self.mvcost.pred_hor, self.mvcost.pred_ver, self.mvcost.cost_scale, self.mvcost.imv_shift)
-        # ---- me
-        for s in sorted(self.me):
-            for (dx0, dy0, nx, ny, sx, sy) in self.me_grids:
-                with T("me/sad_search_%dx%d_%dx%d" % (s, s, nx, ny)):
-                    # xPatternSearch and the raster stage of xTZSearch keep only the best candidate
-                    # (InterSearch.cpp:1887-1935, 1979-2000): no SAD surface
-                    sad, best = ops.sad_search(st["org"][0], st["ref0"][0], st["me_blk"][s], self.me[s].size, s, s, 1,
-                                               dx0, dy0, nx, ny, sx, sy, cfg_mv, want_sad=False)
-                out["me_sad_%d_%d" % (s, nx)] = sad
-                out["me_best_%d_%d" % (s, nx)] = best
-        # ---- frac
         fmv = ops.MvCost(self.frac_mvcost.lambda_, self.frac_mvcost.pred_hor, self.frac_mvcost.pred_ver, 0, 0)
-        with T("frac/frac_refine_16x16"):
-            out["frac"] = ops.frac_refine(st["org"][0], st["ref0"][0], st["frac_blk"], self.frac.size, 16, 16, bd, fmv, True, (0, mx))
+        main = torch.cuda.current_stream()
+        if overlap and "streams" not in st:
+            st["streams"] = [torch.cuda.Stream() for _ in range(3)]
+        side = st["streams"] if overlap else [main, main, main]
+
+        class _On:                                  # run a block on a side stream after the given events of other streams
+            def __init__(self, stream, *events):
+                self.stream, self.events = stream, events
+
+            def __enter__(self):
+                self.ctx = torch.cuda.stream(self.stream)
+                self.ctx.__enter__()
+                for e in self.events:
+                    if e is not None:
+                        self.stream.wait_event(e)
+
+            def __exit__(self, *a):
+                return self.ctx.__exit__(*a)
+
+        def mark():                                 # event on the current stream (None in the serial schedule)
+            if not overlap:
+                return None
+            e = torch.cuda.Event()
+            e.record()
+            return e
+
+        def search(s, grid):
+            dx0, dy0, nx, ny, sx, sy = grid
+            with T("me/sad_search_%dx%d_%dx%d" % (s, s, nx, ny)):
+                # xPatternSearch and the raster stage of xTZSearch keep only the best candidate
+                # (InterSearch.cpp:1887-1935, 1979-2000): no SAD surface
+                sad, best = ops.sad_search(st["org"][0], st["ref0"][0], st["me_blk"][s], self.me[s].size, s, s, 1,
+                                           dx0, dy0, nx, ny, sx, sy, cfg_mv, want_sad=False)
+            out["me_sad_%d_%d" % (s, nx)] = sad
+            out["me_best_%d_%d" % (s, nx)] = best
+
+        sizes = sorted(self.me)
+        dense, raster = self.me_grids[0], self.me_grids[1]
+        # ---- me / frac.  Serial order: per size the +-4 grid, then the raster.  Overlapped: the first size's raster alone on
+        # the main stream, everything else on side streams 0 / 1 after it.
+        if not overlap:
+            for s in sizes:
+                search(s, dense)
+                search(s, raster)
+            with T("frac/frac_refine_16x16"):
+                out["frac"] = ops.frac_refine(st["org"][0], st["ref0"][0], st["frac_blk"], self.frac.size, 16, 16, bd, fmv, True, (0, mx))
+        else:
+            search(sizes[0], raster)
+            e_first = mark()
+            with _On(side[0], e_first):
+                for s in sizes[1::2]:
+                    search(s, raster)
+                for s in sizes:
+                    search(s, dense)
+            with _On(side[1], e_first):
+                for s in sizes[2::2]:
+                    search(s, raster)
+                with T("frac/frac_refine_16x16"):
+                    out["frac"] = ops.frac_refine(st["org"][0], st["ref0"][0], st["frac_blk"], self.frac.size, 16, 16, bd, fmv, True, (0, mx))
         # ---- mc
         with T("mc/mc_luma"):
             ops.mc_batch(st["ref0"][0], st["ref1"][0], st["pred"][0], st["mc_luma"], self.mc_luma.size, bd, (0, mx))
@@ -311,28 +364,37 @@ class Workload:
         dcfg = ops.deblock_cfg(bd)
         with T("dbk/deblock"):
             ops.deblock(st["rec"][0], st["rec"][1], st["rec"][2], st["edge_ver"], st["edge_hor"], st["qp_luma"], st["qp_chroma"], dcfg)
-        # ---- SAO
+        e_dbk = mark()
+        # ---- SAO (the statistics only read the deblocked picture: side stream 2)
         sao_stats = []
-        with T("sao/sao_stats"):
-            for c in range(3):
-                cs = CTU if c == 0 else CTU // 2
-                sao_stats.append(ops.sao_stats(st["org"][c], st["rec"][c], cs, cs, bd, None, 5 if c == 0 else 3, 4 if c == 0 else 2))
+        with _On(side[2], e_dbk):
+            with T("sao/sao_stats"):
+                for c in range(3):
+                    cs = CTU if c == 0 else CTU // 2
+                    sao_stats.append(ops.sao_stats(st["org"][c], st["rec"][c], cs, cs, bd, None, 5 if c == 0 else 3, 4 if c == 0 else 2))
         with T("sao/sao_apply"):
             for c in range(3):
                 cs = CTU if c == 0 else CTU // 2
                 ops.sao_apply(st["rec"][c], st["sao_out"][c], cs, cs, bd, st["sao"][c], (0, mx))
         out["sao_stats"] = sao_stats
-        # ---- ALF
+        # ---- ALF (the covariances read the SAO output and the classifier: side stream 2)
         with T("alf/alf_classify"):
             cls = ops.alf_classify(st["sao_out"][0], bd)
-        with T("alf/alf_stats"):
-            a7 = ops.alf_stats(st["org"][0], st["sao_out"][0], CTU, cls, 1)
-            a5 = ops.alf_stats(st["org"][0], st["sao_out"][0], CTU, cls, 0)
-            ac = [ops.alf_stats(st["org"][c], st["sao_out"][c], CTU // 2, None, 0) for c in (1, 2)]
+        e_cls = mark()
+        with _On(side[2], e_cls):
+            with T("alf/alf_stats"):
+                a7 = ops.alf_stats(st["org"][0], st["sao_out"][0], CTU, cls, 1)
+                a5 = ops.alf_stats(st["org"][0], st["sao_out"][0], CTU, cls, 0)
+                ac = [ops.alf_stats(st["org"][c], st["sao_out"][c], CTU // 2, None, 0) for c in (1, 2)]
         with T("alf/alf_filter"):
             ops.alf_filter_luma(st["sao_out"][0], st["alf_out"][0], CTU, cls, 1, self.alf_luma_coeff, st["alf_en"][0], (0, mx))
             for c in (1, 2):
                 ops.alf_filter_chroma(st["sao_out"][c], st["alf_out"][c], CTU // 2, self.alf_chroma_coeff, st["alf_en"][c], (0, mx))
+        if overlap:                                 # join: the step is complete (and its buffers reusable) when `main` is
+            for sd in side:
+                e = torch.cuda.Event()
+                e.record(sd)
+                main.wait_event(e)
         out.update({"cls": cls, "alf_stats7": a7, "alf_stats5": a5, "alf_stats_c": ac, "final": st["alf_out"], "pred": st["pred"]})
         return st, out
 
