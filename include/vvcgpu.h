@@ -273,6 +273,28 @@ int vvcgpu_tr_fwd_batch(const vvc_pel* resi_base, vvc_coef* coeff_base, const vv
                         int bit_depth, void* stream);
 int vvcgpu_tr_inv_batch(const vvc_coef* coeff_base, vvc_pel* resi_base, const vvcgpu_tr_desc* descs, int n,
                         int bit_depth, void* stream);
+/* ---- N1 (first "next" row): de-quantisation fused with the inverse transform at the ABI
+ *          (TrQuant::invTransformNxN = m_quant->dequant + xIT, TrQuant.cpp:559-571; Quant::dequant, Quant.cpp:277-428 with
+ *          flat scaling; dependent quantisation DQIntern::Quantizer::dequantBlock, DepQuant.cpp:708-785) ---------------
+ * One descriptor per TU; binary compatible with vvcgpu_tr_desc (level_off sits where coeff_off does).  level_base holds
+ * the entropy-decoded levels, W x H int32 contiguous.  qp = QpParam::Qp of the component (bit-depth offset included).
+ * dep_quant = 1 replays the 4-state machine over the diagonal 4x4-grouped scan (state transitions 32040, :782).
+ * coeff_out (required workspace, same offsets as level_base; the reference's m_plTempCoeff) receives the de-quantised
+ * coefficients; the two steps are separate launches for now.  Intermediate products are formed in 64 bits (the reference's `int` cannot overflow for levels in
+ * the entropy-coding range +-32768, which is the precondition).                                                          */
+typedef struct vvcgpu_dqtr_desc {
+  int64_t resi_off, level_off;          /* elements from resi_base (Pel) / level_base (TCoeff) */
+  int32_t resi_stride;
+  int16_t w, h;
+  int8_t  tr_hor, tr_ver;               /* as vvcgpu_tr_desc; tr_hor = 3: transform skip */
+  int8_t  dep_quant;                    /* 0: Quant::dequant, 1: dependent quantisation */
+  int8_t  reserved;
+  int32_t qp;                           /* sizeof == 32 */
+} vvcgpu_dqtr_desc;
+int vvcgpu_dequant_tr_inv_batch(const vvc_coef* level_base, vvc_pel* resi_base, const vvcgpu_dqtr_desc* descs, int n,
+                                int bit_depth, vvc_coef* coeff_out, void* stream);
+/* The coefficient scan the library replays (host copy, out[scanIdx] = raster position; w, h in 2..64 powers of two). */
+int vvcgpu_scan_order_host(int w, int h, uint16_t* out);
 /* The shipped matrix [type][log2(N)-1] as N x N int16 (host copy; for the shim's table check against initROM()). */
 const int16_t* vvcgpu_tr_matrix_host(int type, int n);
 

@@ -17,6 +17,7 @@
 #include "CommonLib/InterpolationFilter.h"
 #include "CommonLib/TrQuant.h"
 #include "CommonLib/TrQuant_EMT.h"
+#include "CommonLib/DepQuant.h"
 #include "EncoderLib/InterSearch.h"
 #include "EncoderLib/EncCfg.h"
 #include "../include/vvcgpu.h"
@@ -362,6 +363,51 @@ int vtmref_transform_skip(int inverse, int bd, Pel* resi, int stride, TCoeff* co
     PelBuf rb(resi, stride, w, h);
     tq->xITransformSkip(cb, rb, tu, COMPONENT_Y);
   }
+  return 0;
+}
+// De-quantisation (next row N1): Quant::dequant (Quant.cpp:277-428, flat scaling) and the dependent-quantisation state
+// machine DQIntern::Quantizer::dequantBlock (DepQuant.cpp:708-785) through DepQuant::dequant (:1423-1433).  Both take a
+// TransformUnit; the zero-filled CodingStructure of vtmref_transform_skip plus a Slice (DepQuant flag) and a CodingUnit
+// (prediction mode, read for the scaling-list type only) is all they look at.  qp = QpParam::Qp (bit-depth offset included).
+int vtmref_dequant(int depQuant, int bd, int qp, int transformSkip, const TCoeff* level, TCoeff* out, int w, int h)
+{
+  static SPS* sps = nullptr;
+  static CodingStructure* cs = nullptr;
+  static Slice* slice = nullptr;
+  static DepQuant* dq = nullptr;
+  static CodingUnit* cu = nullptr;
+  if (!sps)
+  {
+    sps = new SPS;
+    cs = static_cast<CodingStructure*>(calloc(1, sizeof(CodingStructure)));
+    slice = new Slice;
+    cs->sps = sps;
+    cs->slice = slice;
+    dq = new DepQuant(nullptr, false);
+    dq->init(64, false, false, false);
+    cu = new CodingUnit;
+    cu->predMode = MODE_INTER;
+  }
+  sps->setBitDepth(CHANNEL_TYPE_LUMA, bd);
+  slice->setDepQuantEnabledFlag(depQuant != 0);
+  TransformUnit tu(CHROMA_400, Area(0, 0, w, h));
+  tu.cs = cs;
+  tu.cu = cu;
+  tu.m_coeffs[COMPONENT_Y] = const_cast<TCoeff*>(level);
+  tu.transformSkip[COMPONENT_Y] = transformSkip != 0;
+  QpParam* q = static_cast<QpParam*>(malloc(sizeof(QpParam)));
+  q->Qp = qp; q->per = qp / 6; q->rem = qp % 6;
+  CoeffBuf dst(out, w, w, h);
+  dq->dequant(tu, dst, COMPONENT_Y, *q);
+  free(q);
+  return 0;
+}
+// diagonal 4x4-grouped coefficient scan of a W x H block (g_scanOrder[SCAN_GROUPED_4x4][SCAN_DIAG], Rom.cpp): out[scanIdx] = raster position
+int vtmref_scan_order(int w, int h, uint32_t* out)
+{
+  const unsigned* scan = g_scanOrder[SCAN_GROUPED_4x4][SCAN_DIAG][gp_sizeIdxInfo->idxFrom(w)][gp_sizeIdxInfo->idxFrom(h)];
+  if (!scan) return -1;
+  for (int i = 0; i < w * h; i++) out[i] = scan[i];
   return 0;
 }
 // Effective 1-D matrices of the reference's fast transforms, obtained by pushing 2*identity through

@@ -1,0 +1,98 @@
+// oracle/restate/quant.cpp -- TEST INFRASTRUCTURE: scalar restatement of the de-quantisers (next row N1).
+//   scan order      g_scanOrder[SCAN_GROUPED_4x4][SCAN_DIAG]            CommonLib/Rom.cpp:357-405 (ScanGenerator, diagonal)
+//   Quant::dequant  (flat scaling, HM_QTBT_AS_IN_JEM_QUANT)             CommonLib/Quant.cpp:277-428
+//   dependent quantisation  DQIntern::Quantizer::dequantBlock           CommonLib/DepQuant.cpp:708-785
+//   getTransformShift                                                    CommonLib/ChromaFormat.h:117-120
+// Pinned against the compiled reference by tests/golden/dequant.npz (tests/test_oracle_golden.py).
+#include "orc_common.h"
+#include <vector>
+
+static inline int ilog2q(int v) { int l = 0; while ((1 << l) < v) l++; return l; }
+static const int kInvQuantScales[6] = { 40, 45, 51, 57, 64, 72 };               // g_invQuantScales, Rom.cpp:470-473
+
+// diagonal scan of a cw x ch grid: diagonals x + y = d, each walked from its bottom-left end upwards
+static void diagScan(int cw, int ch, std::vector<int>& xs, std::vector<int>& ys)
+{
+  xs.clear(); ys.clear();
+  for (int d = 0; d < cw + ch - 1; d++)
+    for (int y = std::min(d, ch - 1); y >= 0; y--)
+    {
+      const int x = d - y;
+      if (x < cw) { xs.push_back(x); ys.push_back(y); }
+    }
+}
+
+ORC_API int orc_scan_order(int w, int h, uint32_t* out)
+{
+  const int lg = ((w & 3) + (h & 3)) > 0 ? 1 : 2;                                 // 2x2 groups when a side is 2 (:360-361)
+  const int gw = 1 << lg, gh = 1 << lg;
+  std::vector<int> gx, gy, px, py;
+  diagScan(w >> lg, h >> lg, gx, gy);
+  diagScan(gw, gh, px, py);
+  int n = 0;
+  for (size_t g = 0; g < gx.size(); g++)
+    for (size_t k = 0; k < px.size(); k++)
+      out[n++] = (uint32_t)((gy[g] * gh + py[k]) * w + gx[g] * gw + px[k]);
+  return 0;
+}
+
+ORC_API int orc_dequant(int depQuant, int bd, int qp, int transformSkip, const TCoeff* level, TCoeff* out, int w, int h)
+{
+  (void)transformSkip;                                                            // only matters with extended precision (off)
+  const int n = w * h, lw = ilog2q(w), lh = ilog2q(h);
+  const int transformShift = 15 - bd - ((lw + lh) >> 1);
+  const bool sqrt2 = ((lw + lh) & 1) != 0;                                        // needsSqrt2Scale == needsBlockSizeTrafoScale here
+  const int64_t minT = -(1 << 15), maxT = (1 << 15) - 1;
+  if (!depQuant)
+  {
+    const int per = qp / 6, rem = qp % 6;
+    const int rightShift = (sqrt2 ? 8 : 0) + (6 - (transformShift + per));
+    const int64_t scale = (int64_t)kInvQuantScales[rem] * (sqrt2 ? 181 : 1);
+    const int targetBits = std::min(16, 32 + rightShift - 7);
+    const int64_t inMin = -(1ll << (targetBits - 1)), inMax = (1ll << (targetBits - 1)) - 1;
+    for (int i = 0; i < n; i++)
+    {
+      const int64_t c = std::min(std::max((int64_t)level[i], inMin), inMax);
+      const int64_t v = rightShift > 0 ? (c * scale + (1ll << (rightShift - 1))) >> rightShift : (c * scale) << -rightShift;
+      out[i] = (TCoeff)std::min(std::max(v, minT), maxT);
+    }
+    return 0;
+  }
+  std::vector<uint32_t> scan(n);
+  orc_scan_order(w, h, scan.data());
+  for (int i = 0; i < n; i++) out[i] = 0;
+  const int qpDQ = qp + 1, qpPer = qpDQ / 6, qpRem = qpDQ - 6 * qpPer;
+  int shift = 6 + 1 - qpPer - transformShift + (sqrt2 ? 8 : 0);
+  int64_t invQScale = (int64_t)kInvQuantScales[qpRem] * (sqrt2 ? 181 : 1);
+  if (shift < 0) { invQScale <<= -shift; shift = 0; }
+  const int64_t add = (1ll << shift) >> 1;
+  int state = 0;
+  for (int scanIdx = n - 1; scanIdx >= 0; scanIdx--)                              // zeros above the last level keep state 0
+  {
+    const int pos = (int)scan[scanIdx];
+    const int lv = level[pos];
+    if (lv)
+    {
+      const int64_t qIdx = ((int64_t)lv << 1) + (lv > 0 ? -(state >> 1) : (state >> 1));
+      out[pos] = (TCoeff)std::min(std::max((qIdx * invQScale + add) >> shift, minT), maxT);
+    }
+    state = (32040 >> ((state << 2) + ((lv & 1) << 1))) & 3;
+  }
+  return 0;
+}
+
+extern "C" int orc_tr_inv(const TCoeff* coeff, Pel* resi, int stride, int w, int h, int trHor, int trVer, int bd);
+
+ORC_API int orc_dequant_tr_inv_batch(const TCoeff* levelBase, Pel* resiBase, const vvcgpu_dqtr_desc* d, int n, int bd, TCoeff* coeffOut)
+{
+  std::vector<TCoeff> tmp;
+  for (int i = 0; i < n; i++)
+  {
+    const int cnt = d[i].w * d[i].h;
+    tmp.resize(cnt);
+    TCoeff* c = coeffOut ? coeffOut + d[i].level_off : tmp.data();
+    orc_dequant(d[i].dep_quant, bd, d[i].qp, d[i].tr_hor == 3, levelBase + d[i].level_off, c, d[i].w, d[i].h);
+    orc_tr_inv(c, resiBase + d[i].resi_off, d[i].resi_stride, d[i].w, d[i].h, d[i].tr_hor, d[i].tr_ver, bd);
+  }
+  return 0;
+}

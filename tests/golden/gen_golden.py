@@ -225,6 +225,42 @@ def gen_tskip():
     save("tskip", **out)
 
 
+def gen_dequant():
+    """next row N1: Quant::dequant and the dependent-quantisation state machine of the compiled reference (DepQuant::dequant),
+    every W x H, several QPs, sparse / dense / full-range levels; plus the coefficient scans themselves."""
+    rng = np.random.default_rng(1009)
+    out = {}
+    scans = []
+    for w in (2, 4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            sc = np.zeros(w * h, np.uint32)
+            assert R.vtmref_scan_order(w, h, p(sc)) == 0
+            scans.append(sc.astype(np.uint16))
+    out["scan"] = np.concatenate(scans)
+    for bd in (8, 10):
+        rows, lvs, outs = [], [], []
+        for w in (2, 4, 8, 16, 32, 64):
+            for h in (2, 4, 8, 16, 32, 64):
+                for qp in (1, 17, 22 + (bd - 8) * 6, 37, 51 + (bd - 8) * 6):
+                    for dq in (0, 1):
+                        kind = int(rng.integers(0, 3))
+                        if kind == 0:
+                            lv = rng.integers(-40, 41, w * h)
+                        elif kind == 1:
+                            lv = rng.integers(-6, 7, w * h) * (rng.random(w * h) < 0.2)
+                        else:
+                            lv = rng.integers(-32768, 32768, w * h)
+                        lv = lv.astype(np.int32)
+                        o = np.zeros(w * h, np.int32)
+                        R.vtmref_dequant(dq, bd, qp, 0, p(lv), p(o), w, h)
+                        rows.append((w, h, qp, dq))
+                        lvs.append(lv); outs.append(o)
+        out["rows%d" % bd] = np.array(rows, np.int32)
+        out["level%d" % bd] = np.concatenate(lvs)
+        out["coef%d" % bd] = np.concatenate(outs)
+    save("dequant", **out)
+
+
 def gen_frac():
     rng = np.random.default_rng(1006)
     FB = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4")])
@@ -260,6 +296,6 @@ def gen_frac():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_frac):
+    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_frac):
         if not only or fn.__name__[4:] in only:
             fn()

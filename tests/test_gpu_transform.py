@@ -106,6 +106,51 @@ def test_tr_many_tus_shuffled():
     assert np.array_equal(gres.cpu().numpy(), wres)
 
 
+@pytest.mark.parametrize("bd", [8, 10])
+def test_dequant_tr_inv(bd):
+    """N1: de-quantisation (scalar and dependent quantisation, every shape, several QPs) + inverse transform vs the oracle."""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(40 + bd)
+    rows = []
+    roff = loff = 0
+    for w in (2, 4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            for (th, tv) in PAIRS:
+                if th in (1, 2) and (w < 4 or h < 4 or w > 32 or h > 32):
+                    continue
+                for dq in (0, 1):
+                    qp = int(rng.integers(0, 52 + (bd - 8) * 6))
+                    st = w + 4
+                    rows.append((roff, loff, st, w, h, th, tv, dq, 0, qp))
+                    roff += h * st
+                    loff += w * h
+    d = np.array(rows, dtype=ops.DQTR_DESC)
+    lv = (rng.integers(-30, 31, loff) * (rng.random(loff) < 0.35)).astype(np.int32)
+    lv[::977] = rng.integers(-3000, 3000, lv[::977].size)
+    wres = np.full(roff, 11, np.int16)
+    wcoef = np.full(loff, 3, np.int32)
+    oracle().orc_dequant_tr_inv_batch(p(lv), p(wres), p(d), len(d), bd, p(wcoef))
+    gres = torch.full((roff,), 11, dtype=torch.int16, device="cuda")
+    gcoef = torch.full((loff,), 3, dtype=torch.int32, device="cuda")
+    ops.dequant_tr_inv_batch(dev(lv), gres, ops.struct_to_device(d), len(d), bd, gcoef)
+    assert np.array_equal(gcoef.cpu().numpy(), wcoef)
+    assert np.array_equal(gres.cpu().numpy(), wres)
+
+
+def test_scan_order_host_matches_golden():
+    import ctypes as C
+    import os
+    from vvcsoftware_vtm_amd import capi
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "dequant.npz"))
+    pos = 0
+    for w in (2, 4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            sc = np.zeros(w * h, np.uint16)
+            assert capi.lib().vvcgpu_scan_order_host(w, h, sc.ctypes.data_as(C.c_void_p)) == 0
+            assert np.array_equal(sc, g["scan"][pos:pos + w * h]), (w, h)
+            pos += w * h
+
+
 def test_shipped_tables_match_golden():
     """the table inside the library == tests/golden/tr_tables.npz (dumped from the compiled reference)."""
     import ctypes as C

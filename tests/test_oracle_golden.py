@@ -151,6 +151,29 @@ def test_transform_skip_golden():
             pos += n
 
 
+def test_dequant_golden():
+    """N1 pinned: scans, Quant::dequant and the dependent-quantisation state machine == the compiled reference."""
+    g = load("dequant")
+    O = oracle()
+    pos = 0
+    for w in (2, 4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            sc = np.zeros(w * h, np.uint32)
+            O.orc_scan_order(w, h, p(sc))
+            assert np.array_equal(sc.astype(np.uint16), g["scan"][pos:pos + w * h]), (w, h)
+            pos += w * h
+    for bd in (8, 10):
+        pos = 0
+        for (w, h, qp, dq) in g["rows%d" % bd]:
+            w, h, qp, dq = int(w), int(h), int(qp), int(dq)
+            n = w * h
+            lv = g["level%d" % bd][pos:pos + n].copy()
+            o = np.zeros(n, np.int32)
+            O.orc_dequant(dq, bd, qp, 0, p(lv), p(o), w, h)
+            assert np.array_equal(o, g["coef%d" % bd][pos:pos + n]), (bd, w, h, qp, dq)
+            pos += n
+
+
 def test_frac_refine_golden():
     g = load("frac")
     O = oracle()

@@ -41,3 +41,22 @@ t0 = time.perf_counter()
 for _ in range(200): ops.tr_fwd_batch(resi, coef, dd, 1, 10)
 t1 = time.perf_counter(); torch.cuda.synchronize()
 print("host time per call %.1f us" % ((t1 - t0) / 200 * 1e6))
+# N1: de-quantisation + inverse transform on the mixed TU list of the canonical workload
+rows = []; coff = 0; ci = 0
+sizes = [4, 8, 16, 32, 64]
+for y0 in range(0, H - H % 64, 64):
+    for x0 in range(0, W - W % 64, 64):
+        s = sizes[ci % 5]; ci += 1
+        for ty in range(0, 64, s):
+            for tx in range(0, 64, s):
+                rows.append(((y0 + ty) * W + x0 + tx, coff, W, s, s, 0, 0, (ci + tx // s) & 1, 0, 32 + 12)); coff += s * s
+d = np.array(rows, dtype=ops.DQTR_DESC); dd = ops.struct_to_device(d)
+lv = (torch.randint(-20, 21, (coff,), dtype=torch.int32, device="cuda") * (torch.rand(coff, device="cuda") < 0.3)).to(torch.int32)
+tmp = torch.empty(coff, dtype=torch.int32, device="cuda"); out = torch.empty_like(resi)
+fn = lambda: ops.dequant_tr_inv_batch(lv, out, dd, d.size, 10, tmp)
+for _ in range(3): fn()
+a = torch.cuda.Event(enable_timing=True); b = torch.cuda.Event(enable_timing=True)
+a.record()
+for _ in range(10): fn()
+b.record(); torch.cuda.synchronize()
+print("dequant+inv mix n=%d  %.4f ms (levels 33 MB in, residual 16.6 MB out)" % (d.size, a.elapsed_time(b) / 10))

@@ -88,6 +88,7 @@ int vvcgpu_sizeof(int id)
   case 10: return (int)sizeof(vvcgpu_tr_desc);
   case 11: return (int)sizeof(vvcgpu_frac_blk);
   case 12: return (int)sizeof(vvcgpu_frac_result);
+  case 13: return (int)sizeof(vvcgpu_dqtr_desc);
   default: return -1;
   }
 }

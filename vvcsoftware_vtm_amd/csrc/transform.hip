@@ -552,8 +552,118 @@ __global__ __launch_bounds__(256) void tr_collect_large_kernel(const vvcgpu_tr_d
   if (lg) list[1 + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = ti;
 }
 
+// ---------------------------------------------------------------------------------------------------
+// N1: de-quantisation in front of the inverse transform (vvcgpu_dequant_tr_inv_batch).
+//   Quant::dequant (Quant.cpp:277-428, flat scaling): an element-wise map.
+//   Dependent quantisation (DepQuant.cpp:708-785): the reconstruction level of a coefficient depends on a 4-state
+//   machine driven by the parities of the levels before it in (reverse) scan order.  The transition of one level is a
+//   map {0..3} -> {0..3} (8 bits); maps compose associatively, so a wave walks the scan in 64 contiguous chunks: every lane
+//   composes the maps of its chunk, an inclusive wave scan of the composed maps gives each lane its entry state, and a
+//   second walk reconstructs the levels.  (Zero levels above the last significant one keep state 0, so the walk can
+//   start at the end of the scan instead of searching the last level as the reference does.)
+__device__ unsigned short d_scan[15876];            // diagonal 4x4-grouped scans of all W x H in 2..64, [log2 w - 1][log2 h - 1]
+__device__ int d_scanOff[36];
+
+__device__ __forceinline__ unsigned dq_compose(unsigned first, unsigned then)     // map applied first, then the second one
+{
+  unsigned r = 0;
+#pragma unroll
+  for (int s = 0; s < 4; s++) r |= ((then >> (2 * ((first >> (2 * s)) & 3))) & 3) << (2 * s);
+  return r;
+}
+
+__global__ __launch_bounds__(256) void dequant_kernel(const TCoeff* __restrict__ levelBase, TCoeff* __restrict__ coeffBase,
+                                                      const vvcgpu_dqtr_desc* __restrict__ descs, int n, int bd)
+{
+  const int lane = threadIdx.x & 63;
+  const int ti = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ti >= n) return;
+  const vvcgpu_dqtr_desc d = descs[ti];
+  const int w = d.w, h = d.h, cnt = w * h, lw = ilog2(w), lh = ilog2(h);
+  const TCoeff* level = levelBase + d.level_off;
+  TCoeff* out = coeffBase + d.level_off;
+  const int transformShift = 15 - bd - ((lw + lh) >> 1);
+  const bool sqrt2 = ((lw + lh) & 1) != 0;
+  const long long minT = -(1 << 15), maxT = (1 << 15) - 1;
+  if (!d.dep_quant)
+  {
+    const int per = d.qp / 6, rem = d.qp - 6 * per;
+    const int rightShift = (sqrt2 ? 8 : 0) + (6 - (transformShift + per));
+    const int invq = rem == 0 ? 40 : rem == 1 ? 45 : rem == 2 ? 51 : rem == 3 ? 57 : rem == 4 ? 64 : 72;
+    const long long scale = (long long)invq * (sqrt2 ? 181 : 1);
+    const int targetBits = min(16, 32 + rightShift - 7);
+    const long long inMin = -(1ll << (targetBits - 1)), inMax = (1ll << (targetBits - 1)) - 1;
+    for (int i = lane; i < cnt; i += 64)
+    {
+      const long long c = min(max((long long)level[i], inMin), inMax);
+      const long long v = rightShift > 0 ? (c * scale + (1ll << (rightShift - 1))) >> rightShift : (c * scale) << -rightShift;
+      out[i] = (TCoeff)min(max(v, minT), maxT);
+    }
+    return;
+  }
+  const unsigned short* scan = d_scan + d_scanOff[(lw - 1) * 6 + (lh - 1)];
+  const int qpDQ = d.qp + 1, qpPer = qpDQ / 6, qpRem = qpDQ - 6 * qpPer;
+  int shift = 6 + 1 - qpPer - transformShift + (sqrt2 ? 8 : 0);
+  const int invq = qpRem == 0 ? 40 : qpRem == 1 ? 45 : qpRem == 2 ? 51 : qpRem == 3 ? 57 : qpRem == 4 ? 64 : 72;
+  long long invQScale = (long long)invq * (sqrt2 ? 181 : 1);
+  if (shift < 0) { invQScale <<= -shift; shift = 0; }
+  const long long add = (1ll << shift) >> 1;
+  // lane l owns processing steps t in [l * C, (l + 1) * C), step t = scan index cnt - 1 - t
+  const int C = (cnt + 63) >> 6;
+  const int t0 = lane * C, t1 = min(t0 + C, cnt);
+  constexpr unsigned F0 = 0xD8u, F1 = 0x72u, ID = 0xE4u;     // parity 0: 0->0 1->2 2->1 3->3; parity 1: 0->2 1->0 2->3 3->1 (from 32040)
+  unsigned m = ID;
+  for (int t = t0; t < t1; t++)
+  {
+    const int lv = level[scan[cnt - 1 - t]];
+    m = dq_compose(m, (lv & 1) ? F1 : F0);
+  }
+  unsigned incl = m;                                         // inclusive scan over the lanes
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1)
+  {
+    const unsigned prev = __shfl_up(incl, o);
+    if (lane >= o) incl = dq_compose(prev, incl);
+  }
+  const unsigned excl = __shfl_up(incl, 1);
+  int state = lane == 0 ? 0 : (int)(excl & 3);               // entry state = (maps of all earlier lanes)(0)
+  for (int t = t0; t < t1; t++)
+  {
+    const int pos = scan[cnt - 1 - t];
+    const int lv = level[pos];
+    long long v = 0;
+    if (lv)
+    {
+      const long long qIdx = ((long long)lv << 1) + (lv > 0 ? -(state >> 1) : (state >> 1));
+      v = min(max((qIdx * invQScale + add) >> shift, minT), maxT);
+    }
+    out[pos] = (TCoeff)v;
+    state = (32040 >> ((state << 2) + ((lv & 1) << 1))) & 3;
+  }
+}
+
 static bool g_tablesUploaded[64] = { false };
 static const int g_smallGrid = getenv("VVCGPU_TR_SMALLGRID") ? atoi(getenv("VVCGPU_TR_SMALLGRID")) : 1280;   // tuning switch
+
+// diagonal 4x4-grouped coefficient scan (Rom.cpp:357-405): groups of 4x4 (2x2 when a side is 2) visited along the diagonals
+// x + y = d from the bottom-left end upwards, the positions inside a group likewise
+static void host_scan_order(int w, int h, uint16_t* out)
+{
+  const int lg = ((w & 3) + (h & 3)) > 0 ? 1 : 2, g = 1 << lg, gwN = w >> lg, ghN = h >> lg;
+  int n = 0;
+  for (int D = 0; D < gwN + ghN - 1; D++)
+    for (int gy = (D < ghN - 1 ? D : ghN - 1); gy >= 0; gy--)
+    {
+      const int gx = D - gy;
+      if (gx >= gwN) continue;
+      for (int dd = 0; dd < 2 * g - 1; dd++)
+        for (int y = (dd < g - 1 ? dd : g - 1); y >= 0; y--)
+        {
+          const int x = dd - y;
+          if (x < g) out[n++] = (uint16_t)((gy * g + y) * w + gx * g + x);
+        }
+    }
+}
 
 static int ensure_tables()
 {
@@ -572,6 +682,12 @@ static int ensure_tables()
       }
     VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_tr32), t32, sizeof(t32)));
     VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_tr32t), t32t, sizeof(t32t)));
+    static uint16_t scan[15876];
+    int off[36], o = 0;
+    for (int a = 0; a < 6; a++)
+      for (int b = 0; b < 6; b++) { off[a * 6 + b] = o; host_scan_order(2 << a, 2 << b, scan + o); o += (2 << a) * (2 << b); }
+    VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_scan), scan, sizeof(scan)));
+    VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_scanOff), off, sizeof(off)));
     g_tablesUploaded[dev] = true;
   }
   return VVCGPU_OK;
@@ -627,6 +743,28 @@ int vvcgpu_tr_inv_batch(const vvc_coef* coeff_base, vvc_pel* resi_base, const vv
   hipLaunchKernelGGL(tr_inv_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, coeff_base, resi_base, descs, n, bit_depth);
   hipLaunchKernelGGL(tr_inv_large_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, coeff_base, resi_base, descs, list, bit_depth);
   VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+int vvcgpu_dequant_tr_inv_batch(const vvc_coef* level_base, vvc_pel* resi_base, const vvcgpu_dqtr_desc* descs, int n,
+                                int bit_depth, vvc_coef* coeff_out, void* stream)
+{
+  static_assert(sizeof(vvcgpu_dqtr_desc) == sizeof(vvcgpu_tr_desc), "descriptor layouts must stay interchangeable");
+  const int rc = check_descs_args(level_base, resi_base, descs, n, bit_depth, "dequant_tr_inv_batch");
+  if (rc) return rc > 0 ? VVCGPU_OK : rc;
+  VVC_CHECK_ARG(coeff_out && coeff_out != level_base, "dequant_tr_inv_batch: coeff_out (workspace for the de-quantised coefficients) is required");
+  const int rt = ensure_tables();
+  if (rt) return rt;
+  hipLaunchKernelGGL(dequant_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, level_base, coeff_out, descs, n, bit_depth);
+  VVC_LAUNCH_CHECK();
+  // the descriptor is binary compatible with vvcgpu_tr_desc: the inverse transforms read the de-quantised coefficients at level_off
+  return vvcgpu_tr_inv_batch(coeff_out, resi_base, reinterpret_cast<const vvcgpu_tr_desc*>(descs), n, bit_depth, stream);
+}
+
+int vvcgpu_scan_order_host(int w, int h, uint16_t* out)
+{
+  if (!out || w < 2 || w > 64 || h < 2 || h > 64 || (w & (w - 1)) || (h & (h - 1))) return VVCGPU_E_ARG;
+  host_scan_order(w, h, out);
   return VVCGPU_OK;
 }
 

@@ -218,6 +218,17 @@ FRAC_BLK = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref
 FRAC_RESULT = np.dtype([("half_x", "<i4"), ("half_y", "<i4"), ("qter_x", "<i4"), ("qter_y", "<i4"), ("cost_half", "<u8"), ("cost", "<u8")])
 
 
+DQTR_DESC = np.dtype([("resi_off", "<i8"), ("level_off", "<i8"), ("resi_stride", "<i4"), ("w", "<i2"), ("h", "<i2"),
+                      ("tr_hor", "i1"), ("tr_ver", "i1"), ("dep_quant", "i1"), ("reserved", "i1"), ("qp", "<i4")])
+assert DQTR_DESC.itemsize == 32
+
+
+def dequant_tr_inv_batch(level_base, resi_base, descs_dev, n, bit_depth, coeff_out):
+    """N1: de-quantisation + inverse transform.  coeff_out: int32 workspace, same offsets as level_base."""
+    capi.call("vvcgpu_dequant_tr_inv_batch", capi.ptr(level_base), capi.ptr(resi_base), capi.ptr(descs_dev), n, bit_depth,
+              capi.ptr(coeff_out), _stream())
+
+
 def frac_refine(org, ref, blocks_dev, nblocks, w, h, bit_depth, mvcost, use_hadamard=True, clp=(0, 1023)):
     """I2+D2+D5: returns a uint8 CUDA tensor holding nblocks FRAC_RESULT records."""
     po, so, _, _ = _plane(org, "org")
