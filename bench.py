@@ -163,7 +163,7 @@ def main():
     t0 = time.perf_counter()
     for step in range(args.steps):
         state, out = wl.run_gpu(state, timer, overlap=overlap)
-        if world > 1 and step == 0:
+        if world > 1 and step % shard.INTRA_PERIOD == 0:
             # chunk hand-over: one reconstructed boundary picture per intra period (32 pictures), point-to-point
             shard.exchange_boundary(out["final"], rank, world)
     torch.cuda.synchronize()
@@ -175,6 +175,9 @@ def main():
         t = torch.tensor([dt], dtype=torch.float64, device="cuda")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+
+    # final gather of per-picture output hashes (control path, outside the timed region)
+    hashes = shard.gather_hashes({"rank%d" % rank: shard.picture_hash(out["final"])}, world)
 
     # dominant kernel: device time over the timed region (HIP events on the stream the kernels were launched on)
     timed_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in timer.ev.items()}
@@ -230,6 +233,7 @@ def main():
                          "frac": achieved / HBM_PEAK_GBS, "traffic": (tr["bytes"] if tr else None),
                          "traffic_source": (tr["source"] if tr else None),
                          "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": kern_ms[dom]},
+            "picture_hashes": {"gathered": len(hashes), "rank0_md5": hashes.get("rank0")},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "kernels": per_kernel,
         }
