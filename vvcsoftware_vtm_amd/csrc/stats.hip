@@ -26,8 +26,8 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ 
   const int pitch = ctuW + 2;
   short* tile = reinterpret_cast<short*>(smem);                                   // (ctuH+2) x pitch
   const int tileBytes = ((ctuH + 2) * pitch * 2 + 15) & ~15;
-  unsigned long long* bo = reinterpret_cast<unsigned long long*>(smem + tileBytes);   // 32 packed bands
-  int* eo = reinterpret_cast<int*>(smem + tileBytes + 32 * 8);                        // [4][5][2]
+  unsigned long long* bo = reinterpret_cast<unsigned long long*>(smem + tileBytes);   // 8 replicas x 32 packed bands (same-band atomics serialise)
+  int* eo = reinterpret_cast<int*>(smem + tileBytes + 8 * 32 * 8);                    // [4][5][2]
 
   const int tid = threadIdx.x;
   const int cx = blockIdx.x, cy = blockIdx.y;
@@ -40,7 +40,7 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ 
     const int y = min(max(y0 + r - 1, 0), h - 1), x = min(max(x0 + c - 1, 0), w - 1);
     tile[i] = rec[(size_t)y * rstride + x];
   }
-  if (tid < 32) bo[tid] = 0ull;
+  bo[tid] = 0ull;                                                                      // 256 threads = 8 x 32
   if (tid < 40) eo[tid] = 0;
   __syncthreads();
 
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ 
           dif[t][k] += hit ? d : 0;
         }
       if (inX90 && y < endY0)
-        atomicAdd(&bo[c >> boShift], (1ull << 32) + (unsigned long long)(d + 1024));
+        atomicAdd(&bo[(tid & 7) * 32 + (c >> boShift)], (1ull << 32) + (unsigned long long)(d + 1024));
 #pragma unroll
       for (int k = 0; k < 3; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
     }
@@ -121,7 +121,8 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ 
     if (t < 4) { if (k < 5) v = eo[(t * 5 + k) * 2 + isCount]; }
     else
     {
-      const unsigned long long pk = bo[k];
+      unsigned long long pk = 0ull;
+      for (int r = 0; r < 8; r++) pk += bo[r * 32 + k];
       const long long c = (long long)(pk >> 32);
       v = isCount ? c : (long long)(pk & 0xffffffffull) - 1024 * c;
     }
@@ -198,11 +199,14 @@ __global__ __launch_bounds__(256) void alf_stats_kernel(const Pel* __restrict__ 
   constexpr int NB = NT + N + 1;                 // bucket entries: tri(E), y, pixAcc
   constexpr int RECSZ = N * N + N + 1;
   __shared__ short tile[AR * AP];
-  __shared__ unsigned long long bucket[25 * NB];
+  // REP replicas of the class buckets, picked by the low lane bits: neighbouring blocks mostly share class and transpose, and
+  // same-address LDS atomics serialise -- REP copies divide that queue; they are summed when the tile is flushed
+  constexpr int REP = IS7 ? 2 : 4;              // 7x7: 2 x 21 KB keeps two workgroups per CU
+  __shared__ unsigned long long bucket[REP * 25 * NB];
   const int tid = threadIdx.x;
   const int tx0 = blockIdx.x * AT, ty0 = blockIdx.y * AT;
   load_tile_clamped<AP>(tile, rec, rstride, w, h, tx0 - 4, ty0 - 3, AR, tid, 256);
-  for (int i = tid; i < nCls * NB; i += 256) bucket[i] = 0ull;
+  for (int i = tid; i < REP * 25 * NB; i += 256) bucket[i] = 0ull;
   __syncthreads();
 
   const int bj = tid & 15, bi = tid >> 4;
@@ -274,7 +278,9 @@ __global__ __launch_bounds__(256) void alf_stats_kernel(const Pel* __restrict__ 
     unsigned long long perm;                    // nibble k = coefficient index that canonical tap k feeds
     if (IS7) perm = t == 0 ? 0xCBA9876543210ull : t == 1 ? 0xC62037B518A49ull : t == 2 ? 0xCBA9456781230ull : 0xC62015B734A89ull;
     else     perm = t == 0 ? 0x6543210ull : t == 1 ? 0x6203514ull : t == 2 ? 0x6541230ull : 0x6201534ull;
-    unsigned long long* b = bucket + classIdx * NB;
+    // without a classifier (chroma) every block feeds class 0: spread over all REP * 25 slots instead
+    constexpr int SLOTS1 = 1 << (31 - __builtin_clz(REP * 25));           // largest power of two <= REP * 25
+    unsigned long long* b = bucket + (cls ? (tid & (REP - 1)) * 25 + classIdx : (tid & (SLOTS1 - 1))) * NB;
     int idx = 0;
 #pragma unroll
     for (int k = 0; k < N; k++)
@@ -300,7 +306,17 @@ __global__ __launch_bounds__(256) void alf_stats_kernel(const Pel* __restrict__ 
   unsigned long long* o = out + (size_t)ctuIdx * nCls * RECSZ;
   for (int i = tid; i < nCls * NB; i += 256)
   {
-    const unsigned long long v = bucket[i];
+    unsigned long long v = 0ull;
+    if (cls)
+    {
+#pragma unroll
+      for (int r = 0; r < REP; r++) v += bucket[r * 25 * NB + i];
+    }
+    else
+    {
+      constexpr int SLOTS1 = 1 << (31 - __builtin_clz(REP * 25));
+      for (int r = 0; r < SLOTS1; r++) v += bucket[r * NB + i];     // i < NB here (nCls == 1)
+    }
     if (v == 0ull) continue;
     const int c = i / NB, e = i - c * NB;
     unsigned long long* oc = o + (size_t)c * RECSZ;
@@ -334,7 +350,7 @@ int vvcgpu_sao_stats(const vvc_pel* org, int org_stride, const vvc_pel* rec, int
   VVC_CHECK_ARG(skip_lines_r >= 0 && skip_lines_b >= 0 && skip_lines_r < 16 && skip_lines_b < 16, "sao_stats: bad skip lines");
   const int wCtu = cdiv(width, ctu_w), hCtu = cdiv(height, ctu_h);
   const size_t tileBytes = (((size_t)(ctu_h + 2) * (ctu_w + 2) * 2) + 15) & ~(size_t)15;
-  const size_t smem = tileBytes + 32 * 8 + 40 * 4;
+  const size_t smem = tileBytes + 8 * 32 * 8 + 40 * 4;
   hipLaunchKernelGGL(sao_stats_kernel, dim3(wCtu, hCtu), dim3(256), smem, (hipStream_t)stream, org, org_stride, rec,
                      rec_stride, width, height, ctu_w, ctu_h, wCtu, bit_depth - 5, avail, skip_lines_r, skip_lines_b,
                      reinterpret_cast<long long*>(out));
