@@ -56,11 +56,13 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ 
   const int groups = 256 / ctuW;
   const int rpg = ctuH / groups;
   const int x = tid % ctuW, g = tid / ctuW;
-  int cnt[4][5], dif[4][5];
+  // per (EO class, category) one packed accumulator: count in bits 20.., sum of (d + 1024) below (a thread walks <= 64 rows:
+  // 64 * 2047 < 2^20) -- one compare, one select, one add per category instead of two selects and two adds
+  unsigned acc[4][5];
 #pragma unroll
   for (int t = 0; t < 4; t++)
 #pragma unroll
-    for (int e = 0; e < 5; e++) { cnt[t][e] = 0; dif[t][e] = 0; }
+    for (int e = 0; e < 5; e++) acc[t][e] = 0u;
 
   if (x < width)
   {
@@ -86,15 +88,14 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ 
       use[1] = inX90 && y >= startY90 && y < endYd;
       use[2] = y == 0 ? (x == 0 ? (aboveLeft && (above ? endXe : 1) > 0) : (above && x < endXe)) : (inXe && y < endYd);
       use[3] = y == 0 ? (above && inXe) : (inXe && y < endYd);
+      const unsigned val = (1u << 20) | (unsigned)(d + 1024);
 #pragma unroll
       for (int t = 0; t < 4; t++)
+      {
+        const unsigned vt = use[t] ? val : 0u;
 #pragma unroll
-        for (int k = 0; k < 5; k++)
-        {
-          const bool hit = use[t] && e[t] == k;
-          cnt[t][k] += hit ? 1 : 0;
-          dif[t][k] += hit ? d : 0;
-        }
+        for (int k = 0; k < 5; k++) acc[t][k] += e[t] == k ? vt : 0u;
+      }
       if (inX90 && y < endY0)
         atomicAdd(&bo[(tid & 7) * 32 + (c >> boShift)], (1ull << 32) + (unsigned long long)(d + 1024));
 #pragma unroll
@@ -107,7 +108,7 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ 
 #pragma unroll
     for (int k = 0; k < 5; k++)
     {
-      int c = cnt[t][k], d = dif[t][k];
+      int c = (int)(acc[t][k] >> 20), d = (int)(acc[t][k] & 0xFFFFFu) - 1024 * c;
 #pragma unroll
       for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); d += __shfl_xor(d, o); }
       if ((tid & 63) == 0) { atomicAdd(&eo[(t * 5 + k) * 2], d); atomicAdd(&eo[(t * 5 + k) * 2 + 1], c); }
