@@ -64,13 +64,13 @@ def test_decoder_fallthrough_matches(tmp_path):
 
 
 @needs_ref
-def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path):
+@pytest.mark.parametrize("name", ["ldp_208x120_10b_q27", "ai_416x240_8b_q37own"])
+def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
     """the reference ENCODER with deblocking, the SAO statistics (getStatistics) and the ALF covariances
-    (deriveStatsForFiltering) computed on the GPU inside its loop: every SAO / ALF decision and therefore the bitstream must be
+    (deriveStatsForFiltering), the per-CTU SAO offsetting (offsetCTU) and the three ALF table slots computed on the GPU inside its loop: every SAO / ALF decision and therefore the bitstream must be
     byte-identical to the fixture produced by the unmodified CPU encoder."""
     sys.path.insert(0, ROOT)
     from vvcsoftware_vtm_amd import synth
-    name = "ldp_208x120_10b_q27"
     m = manifest()[name]
     yuv = str(tmp_path / "in.yuv")
     synth.write_yuv(yuv, synth.gen_yuv(m["w"], m["h"], m["frames"], m["bd"], m["seed"]), m["bd"])
@@ -87,3 +87,8 @@ def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path):
     assert line, r.stderr[-1000:]
     calls = [int(x) for x in line[-1].replace(",", " ").split() if x.isdigit()]
     assert calls[0] >= m["frames"] and calls[3] >= m["frames"] and calls[4] >= m["frames"], line[-1]
+    # per-CTU SAO offsetCTU, and the ALF table slots (m_filter5x5Blk / m_filter7x7Blk / m_deriveClassificationBlk) installed
+    # where the reference installs its SIMD functions
+    assert calls[5] > 0 and calls[7] > 0, line[-1]
+    if name.startswith("ai_"):
+        assert calls[6] > 0, line[-1]          # on this clip the encoder enables ALF: the filter table slots ran

@@ -35,6 +35,13 @@ void wrap_SAOProcess(SampleAdaptiveOffset*, CodingStructure&, SAOBlkParam*) asm(
 void real_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) asm("__real__ZN18AdaptiveLoopFilter10ALFProcessER15CodingStructureR13AlfSliceParam");
 void wrap_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) asm("__wrap__ZN18AdaptiveLoopFilter10ALFProcessER15CodingStructureR13AlfSliceParam");
 
+void real_initAlfX86(AdaptiveLoopFilter*) asm("__real__ZN18AdaptiveLoopFilter25initAdaptiveLoopFilterX86Ev");
+void wrap_initAlfX86(AdaptiveLoopFilter*) asm("__wrap__ZN18AdaptiveLoopFilter25initAdaptiveLoopFilterX86Ev");
+void real_offsetCTU(SampleAdaptiveOffset*, const UnitArea&, const CPelUnitBuf&, PelUnitBuf&, SAOBlkParam&, CodingStructure&)
+  asm("__real__ZN20SampleAdaptiveOffset9offsetCTUERK8UnitAreaRK7UnitBufIKsERS3_IsER11SAOBlkParamR15CodingStructure");
+void wrap_offsetCTU(SampleAdaptiveOffset*, const UnitArea&, const CPelUnitBuf&, PelUnitBuf&, SAOBlkParam&, CodingStructure&)
+  asm("__wrap__ZN20SampleAdaptiveOffset9offsetCTUERK8UnitAreaRK7UnitBufIKsERS3_IsER11SAOBlkParamR15CodingStructure");
+
 // The two encoder-statistics entry points are called from inside their own translation unit, where ld --wrap does not reach;
 // those calls go through the PLT (the objects are -fPIC), so oracle/ref_hooks.cpp, loaded ahead of this library, pre-empts the
 // symbols and asks the two functions below first (1 = done on the GPU, 0 = run the reference's own body).
@@ -50,9 +57,10 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[5] = { 0, 0, 0, 0, 0 };
-struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld\n",
-                                                       g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4]); } } g_report;
+long g_calls[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld\n",
+                                                       g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -460,4 +468,149 @@ int vvcshim_alf_stats(EncAdaptiveLoopFilter* self, PelUnitBuf* orgYuvP, PelUnitB
   }
   g_calls[4]++;
   return 1;
+}
+
+namespace {
+// ---- per-block entry points ------------------------------------------------------------------------------------
+// A device plane the size of the component; only the block and its halo are uploaded, the kernel runs over the plane (the
+// rest is don't-care) and only the block comes back.  Slow by construction (one synchronous round trip per CTU): these hooks
+// exist to prove the table-slot / per-CTU boundaries bit-exact inside the reference encoder, not to be fast -- the batched
+// picture-level entry points above are the production form.
+struct BlockPlanes
+{
+  vvc_pel* src = nullptr; vvc_pel* dst = nullptr; int w = 0, h = 0, stride = 0;
+  void ensure(int pw, int ph)
+  {
+    if (pw == w && ph == h) return;
+    if (src) { VVCGPU(vvcgpu_free(src)); VVCGPU(vvcgpu_free(dst)); }
+    stride = (pw + 63) & ~63;
+    VVCGPU(vvcgpu_malloc((void**)&src, (size_t)stride * ph * sizeof(vvc_pel)));
+    VVCGPU(vvcgpu_malloc((void**)&dst, (size_t)stride * ph * sizeof(vvc_pel)));
+    w = pw; h = ph;
+  }
+  // rows [y0, y1) x cols [x0, x1) of a host plane whose sample (0,0) is `origin`
+  void upload(const Pel* origin, int hstride, int x0, int y0, int x1, int y1)
+  {
+    VVCGPU(vvcgpu_memcpy2d_h2d(src + (size_t)y0 * stride + x0, stride * sizeof(vvc_pel), origin + (ptrdiff_t)y0 * hstride + x0,
+                               hstride * sizeof(Pel), (size_t)(x1 - x0) * sizeof(Pel), y1 - y0, nullptr));
+  }
+  void download(Pel* origin, int hstride, int x0, int y0, int x1, int y1)
+  {
+    VVCGPU(vvcgpu_memcpy2d_d2h(origin + (ptrdiff_t)y0 * hstride + x0, hstride * sizeof(Pel), dst + (size_t)y0 * stride + x0,
+                               stride * sizeof(vvc_pel), (size_t)(x1 - x0) * sizeof(Pel), y1 - y0, nullptr));
+    VVCGPU(vvcgpu_stream_sync(nullptr));
+  }
+};
+BlockPlanes g_blk;
+
+// table slots m_filter5x5Blk / m_filter7x7Blk (AdaptiveLoopFilter.h:91-92; installed by the constructor, AdaptiveLoopFilter.cpp:57-63)
+template <int IS7>
+void gpuFilterBlk(AlfClassifier** classifier, const PelUnitBuf& recDst, const CPelUnitBuf& recSrc, const Area& blk, const ComponentID compId,
+                  short* filterSet, const ClpRng& clpRng)
+{
+  const CPelBuf& srcB = recSrc.get(compId);
+  const PelBuf& dstB = recDst.get(compId);
+  const int pw = dstB.width, ph = dstB.height;
+  g_blk.ensure(pw, ph);
+  const int x0 = std::max(0, (int)blk.x - 3), y0 = std::max(0, (int)blk.y - 3);
+  const int x1 = std::min(pw, (int)(blk.x + blk.width) + 3), y1 = std::min(ph, (int)(blk.y + blk.height) + 3);
+  g_blk.upload(srcB.buf, srcB.stride, x0, y0, x1, y1);
+  if (isLuma(compId))
+  {
+    const int w4 = pw >> 2, h4 = ph >> 2;
+    static std::vector<uint16_t> cls;
+    cls.assign((size_t)w4 * h4, 0);
+    for (int y = blk.y; y < (int)(blk.y + blk.height); y += 4)
+      for (int x = blk.x; x < (int)(blk.x + blk.width); x += 4)
+        cls[(size_t)(y >> 2) * w4 + (x >> 2)] = (uint16_t)(classifier[y][x].classIdx | (classifier[y][x].transposeIdx << 8));
+    g_cls.upload(cls.data(), cls.size());
+    VVCGPU(vvcgpu_alf_filter_luma(g_blk.src, g_blk.stride, g_blk.dst, g_blk.stride, pw, ph, 128, g_cls.ptr, IS7, filterSet, nullptr,
+                                  clpRng.min, clpRng.max, nullptr));
+  }
+  else
+    VVCGPU(vvcgpu_alf_filter_chroma(g_blk.src, g_blk.stride, g_blk.dst, g_blk.stride, pw, ph, 64, filterSet, nullptr, clpRng.min, clpRng.max, nullptr));
+  g_blk.download(dstB.buf, dstB.stride, blk.x, blk.y, blk.x + blk.width, blk.y + blk.height);
+  g_calls[6]++;
+}
+
+// table slot m_deriveClassificationBlk (AdaptiveLoopFilter.h:90; called per 32x32 block, AdaptiveLoopFilter.cpp:277-290)
+void gpuDeriveClassificationBlk(AlfClassifier** classifier, int** laplacian[NUM_DIRECTIONS], const CPelBuf& srcLuma, const Area& blk, const int shift)
+{
+  (void)laplacian;
+  const int pw = srcLuma.width, ph = srcLuma.height;
+  g_blk.ensure(pw, ph);
+  // the classifier reads 2 rows / columns around each 4x4 block's 8x8 window: halo 4 covers it (the picture border is replicated
+  // by the kernel exactly as extendBorderPel stored it in the reference's temporary picture)
+  const int x0 = std::max(0, (int)blk.x - 4), y0 = std::max(0, (int)blk.y - 4);
+  const int x1 = std::min(pw, (int)(blk.x + blk.width) + 4), y1 = std::min(ph, (int)(blk.y + blk.height) + 4);
+  g_blk.upload(srcLuma.buf, srcLuma.stride, x0, y0, x1, y1);
+  const int w4 = pw >> 2, h4 = ph >> 2;
+  g_cls.reserve((size_t)w4 * h4);
+  VVCGPU(vvcgpu_alf_classify(g_blk.src, g_blk.stride, pw, ph, shift - 4, g_cls.ptr, nullptr));
+  static std::vector<uint16_t> cls;
+  cls.resize((size_t)w4 * h4);
+  VVCGPU(vvcgpu_memcpy_d2h(cls.data(), g_cls.ptr, cls.size() * sizeof(uint16_t), nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  for (int y = blk.y; y < (int)(blk.y + blk.height); y += 4)
+    for (int x = blk.x; x < (int)(blk.x + blk.width); x += 4)
+    {
+      const uint16_t c = cls[(size_t)(y >> 2) * w4 + (x >> 2)];
+      const AlfClassifier v((uint8_t)(c & 0xff), (uint8_t)(c >> 8));
+      for (int yy = 0; yy < 4; yy++)
+        for (int xx = 0; xx < 4; xx++) classifier[y + yy][x + xx] = v;
+    }
+  g_calls[7]++;
+}
+}  // namespace
+
+// AdaptiveLoopFilter::initAdaptiveLoopFilterX86 (x86/InitX86.cpp) is where the reference installs its SIMD table slots: the
+// hook lets it do that, then replaces the three slots with the GPU-backed functions.
+void wrap_initAlfX86(AdaptiveLoopFilter* self)
+{
+  real_initAlfX86(self);
+  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return;
+  self->m_filter5x5Blk = gpuFilterBlk<0>;
+  self->m_filter7x7Blk = gpuFilterBlk<1>;
+  self->m_deriveClassificationBlk = gpuDeriveClassificationBlk;
+}
+
+// SampleAdaptiveOffset::offsetCTU (SampleAdaptiveOffset.cpp:510-573) as the encoder calls it per CTU from decideBlkParams.
+void wrap_offsetCTU(SampleAdaptiveOffset* self, const UnitArea& area, const CPelUnitBuf& src, PelUnitBuf& res, SAOBlkParam& saoblkParam, CodingStructure& cs)
+{
+  if (!shimEnabled()) { real_offsetCTU(self, area, src, res, saoblkParam, cs); return; }
+  const int numberOfComponents = getNumberValidComponents(area.chromaFormat);
+  bool allOff = true;
+  for (int c = 0; c < numberOfComponents; c++) allOff = allOff && saoblkParam[c].modeIdc == SAO_MODE_OFF;
+  if (allOff) return;
+  bool l, r, a, b, al, ar, bl, br;
+  self->deriveLoopFilterBoundaryAvailibility(cs, area.Y(), l, r, a, b, al, ar, bl, br);
+  const uint8_t avail = (uint8_t)((l ? 1 : 0) | (r ? 2 : 0) | (a ? 4 : 0) | (b ? 8 : 0) | (al ? 16 : 0) | (ar ? 32 : 0) | (bl ? 64 : 0) | (br ? 128 : 0));
+  const PreCalcValues& pcv = *cs.pcv;
+  for (int c = 0; c < numberOfComponents; c++)
+  {
+    const ComponentID compID = ComponentID(c);
+    const SAOOffset& o = saoblkParam[c];
+    if (o.modeIdc == SAO_MODE_OFF) continue;
+    const CompArea& ca = area.block(compID);
+    const CPelBuf& srcB = src.get(compID);
+    PelBuf& dstB = res.get(compID);
+    const int pw = srcB.width, ph = srcB.height;
+    g_blk.ensure(pw, ph);
+    const int x0 = std::max(0, (int)ca.x - 1), y0 = std::max(0, (int)ca.y - 1);
+    const int x1 = std::min(pw, (int)(ca.x + ca.width) + 1), y1 = std::min(ph, (int)(ca.y + ca.height) + 1);
+    g_blk.upload(srcB.buf, srcB.stride, x0, y0, x1, y1);
+    const int cw = pcv.maxCUWidth >> getComponentScaleX(compID, pcv.chrFormat), ch = pcv.maxCUHeight >> getComponentScaleY(compID, pcv.chrFormat);
+    const int wCtu = (pw + cw - 1) / cw, hCtu = (ph + ch - 1) / ch;
+    std::vector<vvcgpu_sao_ctu> prm((size_t)wCtu * hCtu);
+    for (auto& q : prm) { q.type = -1; q.avail = 0; for (int k = 0; k < 32; k++) q.offset[k] = 0; }
+    vvcgpu_sao_ctu& q = prm[(size_t)(ca.y / ch) * wCtu + ca.x / cw];
+    q.type = (int8_t)o.typeIdc;
+    q.avail = avail;
+    for (int k = 0; k < (o.typeIdc == SAO_TYPE_BO ? 32 : (int)NUM_SAO_EO_CLASSES); k++) q.offset[k] = (int16_t)o.offset[k];
+    g_sao.upload(prm.data(), prm.size());
+    VVCGPU(vvcgpu_sao_apply(g_blk.src, g_blk.stride, g_blk.dst, g_blk.stride, pw, ph, cw, ch, cs.sps->getBitDepth(toChannelType(compID)), g_sao.ptr,
+                            cs.slice->clpRng(compID).min, cs.slice->clpRng(compID).max, nullptr));
+    g_blk.download(dstB.buf, dstB.stride, ca.x, ca.y, ca.x + ca.width, ca.y + ca.height);
+  }
+  g_calls[5]++;
 }
