@@ -90,5 +90,8 @@ def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
     # per-CTU SAO offsetCTU, and the ALF table slots (m_filter5x5Blk / m_filter7x7Blk / m_deriveClassificationBlk) installed
     # where the reference installs its SIMD functions
     assert calls[5] > 0 and calls[7] > 0, line[-1]
+    if name.startswith("ldp_"):
+        assert calls[8] > 0, line[-1]          # RdCost table slot DF_SAD64 (64-wide motion search SADs) ran on the GPU
+    print(line[-1])
     if name.startswith("ai_"):
         assert calls[6] > 0, line[-1]          # on this clip the encoder enables ALF: the filter table slots ran

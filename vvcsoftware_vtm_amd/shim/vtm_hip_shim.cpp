@@ -24,6 +24,7 @@
 #include "CommonLib/AdaptiveLoopFilter.h"
 #include "EncoderLib/EncSampleAdaptiveOffset.h"
 #include "EncoderLib/EncAdaptiveLoopFilter.h"
+#include "CommonLib/RdCost.h"
 #include "vvcgpu.h"
 
 #define VVCGPU(call) do { if ((call) != 0) THROW("vvcgpu: " << vvcgpu_last_error()); } while (0)
@@ -35,6 +36,8 @@ void wrap_SAOProcess(SampleAdaptiveOffset*, CodingStructure&, SAOBlkParam*) asm(
 void real_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) asm("__real__ZN18AdaptiveLoopFilter10ALFProcessER15CodingStructureR13AlfSliceParam");
 void wrap_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) asm("__wrap__ZN18AdaptiveLoopFilter10ALFProcessER15CodingStructureR13AlfSliceParam");
 
+void real_initRdCostX86(RdCost*) asm("__real__ZN6RdCost13initRdCostX86Ev");
+void wrap_initRdCostX86(RdCost*) asm("__wrap__ZN6RdCost13initRdCostX86Ev");
 void real_initAlfX86(AdaptiveLoopFilter*) asm("__real__ZN18AdaptiveLoopFilter25initAdaptiveLoopFilterX86Ev");
 void wrap_initAlfX86(AdaptiveLoopFilter*) asm("__wrap__ZN18AdaptiveLoopFilter25initAdaptiveLoopFilterX86Ev");
 void real_offsetCTU(SampleAdaptiveOffset*, const UnitArea&, const CPelUnitBuf&, PelUnitBuf&, SAOBlkParam&, CodingStructure&)
@@ -57,10 +60,11 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+long g_calls[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
-                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld\n",
-                                                       g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7]); } } g_report;
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld\n",
+                                                       g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
+                                                       g_calls[8], g_calls[9]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -613,4 +617,45 @@ void wrap_offsetCTU(SampleAdaptiveOffset* self, const UnitArea& area, const CPel
     g_blk.download(dstB.buf, dstB.stride, ca.x, ca.y, ca.x + ca.width, ca.y + ca.height);
   }
   g_calls[5]++;
+}
+
+// ---- RdCost distortion table slots (m_afpDistortFunc[], RdCost.h:104; installed by RdCost::init -> initRdCostX86) --------
+// Only the 64-sample-wide SAD and Hadamard slots are redirected: every call is a synchronous round trip, and the encoder
+// makes a few ten thousand 64-wide calls on the test clips but tens of millions of narrower ones.
+namespace {
+FpDistFunc g_cpuDist[2] = { nullptr, nullptr };
+DevArray<vvc_pel> g_dOrg, g_dCur;
+DevArray<vvcgpu_dist_desc> g_dDesc;
+DevArray<uint64_t> g_dOut;
+
+template <int KIND>
+Distortion gpuDist64(const DistParam& p)
+{
+  const int w = p.org.width, h = p.org.height;
+  if (p.applyWeight || p.useMR || p.step != 1 || p.bitDepth > 10 || w != 64 || h > 128) return g_cpuDist[KIND](p);
+  g_dOrg.reserve((size_t)64 * 128);
+  g_dCur.reserve((size_t)64 * 128);
+  g_dOut.reserve(1);
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_dOrg.ptr, 64 * sizeof(vvc_pel), p.org.buf, p.org.stride * sizeof(Pel), 64 * sizeof(Pel), h, nullptr));
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_dCur.ptr, 64 * sizeof(vvc_pel), p.cur.buf, p.cur.stride * sizeof(Pel), 64 * sizeof(Pel), h, nullptr));
+  vvcgpu_dist_desc d;
+  memset(&d, 0, sizeof d);
+  d.org_stride = 64; d.cur_stride = 64; d.w = 64; d.h = (int16_t)h; d.sub_shift = (int16_t)(KIND == 0 ? p.subShift : 0);
+  g_dDesc.upload(&d, 1);
+  VVCGPU(vvcgpu_dist_batch(KIND, g_dOrg.ptr, g_dCur.ptr, g_dDesc.ptr, 1, p.bitDepth, g_dOut.ptr, nullptr));
+  uint64_t out = 0;
+  VVCGPU(vvcgpu_memcpy_d2h(&out, g_dOut.ptr, sizeof out, nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  g_calls[8 + KIND]++;
+  return (Distortion)out;
+}
+}  // namespace
+
+void wrap_initRdCostX86(RdCost* self)
+{
+  real_initRdCostX86(self);
+  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return;
+  if (!g_cpuDist[0]) { g_cpuDist[0] = RdCost::m_afpDistortFunc[DF_SAD64]; g_cpuDist[1] = RdCost::m_afpDistortFunc[DF_HAD64]; }
+  RdCost::m_afpDistortFunc[DF_SAD64] = gpuDist64<0>;
+  RdCost::m_afpDistortFunc[DF_HAD64] = gpuDist64<1>;
 }
