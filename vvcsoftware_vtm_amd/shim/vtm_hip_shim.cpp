@@ -25,6 +25,7 @@
 #include "EncoderLib/EncSampleAdaptiveOffset.h"
 #include "EncoderLib/EncAdaptiveLoopFilter.h"
 #include "CommonLib/RdCost.h"
+#include "CommonLib/InterpolationFilter.h"
 #include "vvcgpu.h"
 
 #define VVCGPU(call) do { if ((call) != 0) THROW("vvcgpu: " << vvcgpu_last_error()); } while (0)
@@ -36,6 +37,8 @@ void wrap_SAOProcess(SampleAdaptiveOffset*, CodingStructure&, SAOBlkParam*) asm(
 void real_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) asm("__real__ZN18AdaptiveLoopFilter10ALFProcessER15CodingStructureR13AlfSliceParam");
 void wrap_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) asm("__wrap__ZN18AdaptiveLoopFilter10ALFProcessER15CodingStructureR13AlfSliceParam");
 
+void real_initIfX86(InterpolationFilter*) asm("__real__ZN19InterpolationFilter26initInterpolationFilterX86Ev");
+void wrap_initIfX86(InterpolationFilter*) asm("__wrap__ZN19InterpolationFilter26initInterpolationFilterX86Ev");
 void real_initRdCostX86(RdCost*) asm("__real__ZN6RdCost13initRdCostX86Ev");
 void wrap_initRdCostX86(RdCost*) asm("__wrap__ZN6RdCost13initRdCostX86Ev");
 void real_initAlfX86(AdaptiveLoopFilter*) asm("__real__ZN18AdaptiveLoopFilter25initAdaptiveLoopFilterX86Ev");
@@ -60,11 +63,11 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[10] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+long g_calls[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
-                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld\n",
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
-                                                       g_calls[8], g_calls[9]); } } g_report;
+                                                       g_calls[8], g_calls[9], g_calls[10]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -658,4 +661,57 @@ void wrap_initRdCostX86(RdCost* self)
   if (!g_cpuDist[0]) { g_cpuDist[0] = RdCost::m_afpDistortFunc[DF_SAD64]; g_cpuDist[1] = RdCost::m_afpDistortFunc[DF_HAD64]; }
   RdCost::m_afpDistortFunc[DF_SAD64] = gpuDist64<0>;
   RdCost::m_afpDistortFunc[DF_HAD64] = gpuDist64<1>;
+}
+
+// ---- InterpolationFilter table slots (m_filterHor / m_filterVer [N][isFirst][isLast], InterpolationFilter.h:84-86; installed by
+// initInterpolationFilter -> initInterpolationFilterX86).  Calls narrower than 64 samples stay on the reference's own
+// function (same reason as the distortion slots: one round trip per call).
+namespace {
+typedef void (*IfFn)(const ClpRng&, Pel const*, int, Pel*, int, int, int, TFilterCoeff const*);
+IfFn g_cpuIf[2][3][2][2];                      // [vertical][N index][isFirst][isLast]
+DevArray<vvc_pel> g_ifSrc, g_ifDst;
+DevArray<vvcgpu_if_desc> g_ifDesc;
+
+template <int VER, int NI, int FIRST, int LAST>
+void gpuIf(const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, TFilterCoeff const* coeff)
+{
+  if (width < 64 || clpRng.bd > 10 || width > 256 || height > 256) { g_cpuIf[VER][NI][FIRST][LAST](clpRng, src, srcStride, dst, dstStride, width, height, coeff); return; }
+  constexpr int N = NI == 0 ? 8 : NI == 1 ? 4 : 2, before = N / 2 - 1, after = N / 2;
+  const int cols = VER ? width : width + before + after, rows = VER ? height + before + after : height;
+  const int sp = (cols + 7) & ~7, dp = (width + 7) & ~7;
+  g_ifSrc.reserve((size_t)sp * rows);
+  g_ifDst.reserve((size_t)dp * height);
+  const Pel* first = VER ? src - (ptrdiff_t)before * srcStride : src - before;
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_ifSrc.ptr, sp * sizeof(vvc_pel), first, srcStride * sizeof(Pel), (size_t)cols * sizeof(Pel), rows, nullptr));
+  vvcgpu_if_desc d;
+  memset(&d, 0, sizeof d);
+  d.src_off = VER ? (int64_t)before * sp : before;          // the first output-aligned sample, as the slot's `src`
+  d.dst_off = 0; d.src_stride = sp; d.dst_stride = dp; d.w = (int16_t)width; d.h = (int16_t)height;
+  d.taps = N; d.is_vertical = VER; d.is_first = FIRST; d.is_last = LAST;
+  for (int k = 0; k < N; k++) d.coeff[k] = coeff[k];
+  g_ifDesc.upload(&d, 1);
+  VVCGPU(vvcgpu_if_batch(g_ifSrc.ptr, g_ifDst.ptr, g_ifDesc.ptr, 1, clpRng.bd, clpRng.min, clpRng.max, nullptr));
+  VVCGPU(vvcgpu_memcpy2d_d2h(dst, dstStride * sizeof(Pel), g_ifDst.ptr, dp * sizeof(vvc_pel), (size_t)width * sizeof(Pel), height, nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  g_calls[10]++;
+}
+template <int VER, int NI>
+void installIf(IfFn (&slots)[3][2][2])
+{
+  IfFn gpu[2][2] = { { gpuIf<VER, NI, 0, 0>, gpuIf<VER, NI, 0, 1> }, { gpuIf<VER, NI, 1, 0>, gpuIf<VER, NI, 1, 1> } };
+  for (int f = 0; f < 2; f++)
+    for (int l = 0; l < 2; l++)
+    {
+      if (slots[NI][f][l] != gpu[f][l]) g_cpuIf[VER][NI][f][l] = slots[NI][f][l];
+      slots[NI][f][l] = gpu[f][l];
+    }
+}
+}  // namespace
+
+void wrap_initIfX86(InterpolationFilter* self)
+{
+  real_initIfX86(self);
+  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return;
+  installIf<0, 0>(self->m_filterHor); installIf<0, 1>(self->m_filterHor); installIf<0, 2>(self->m_filterHor);
+  installIf<1, 0>(self->m_filterVer); installIf<1, 1>(self->m_filterVer); installIf<1, 2>(self->m_filterVer);
 }
