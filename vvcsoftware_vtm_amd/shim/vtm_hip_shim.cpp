@@ -39,6 +39,8 @@ void wrap_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) asm(
 
 void real_initIfX86(InterpolationFilter*) asm("__real__ZN19InterpolationFilter26initInterpolationFilterX86Ev");
 void wrap_initIfX86(InterpolationFilter*) asm("__wrap__ZN19InterpolationFilter26initInterpolationFilterX86Ev");
+void real_initPelBufX86(PelBufferOps*) asm("__real__ZN12PelBufferOps16initPelBufOpsX86Ev");
+void wrap_initPelBufX86(PelBufferOps*) asm("__wrap__ZN12PelBufferOps16initPelBufOpsX86Ev");
 void real_initRdCostX86(RdCost*) asm("__real__ZN6RdCost13initRdCostX86Ev");
 void wrap_initRdCostX86(RdCost*) asm("__wrap__ZN6RdCost13initRdCostX86Ev");
 void real_initAlfX86(AdaptiveLoopFilter*) asm("__real__ZN18AdaptiveLoopFilter25initAdaptiveLoopFilterX86Ev");
@@ -63,11 +65,11 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[11] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+long g_calls[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
-                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld\n",
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
-                                                       g_calls[8], g_calls[9], g_calls[10]); } } g_report;
+                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -714,4 +716,53 @@ void wrap_initIfX86(InterpolationFilter* self)
   if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return;
   installIf<0, 0>(self->m_filterHor); installIf<0, 1>(self->m_filterHor); installIf<0, 2>(self->m_filterHor);
   installIf<1, 0>(self->m_filterVer); installIf<1, 1>(self->m_filterVer); installIf<1, 2>(self->m_filterVer);
+}
+
+// ---- PelBufferOps table slots (g_pelBufOP.addAvg8 / reco8 / linTf8, Buffer.h:57-73; installed by the PelBufferOps constructor ->
+// initPelBufOpsX86).  The "8" slots serve every width that is a multiple of 8; calls narrower than 64 stay on the reference.
+namespace {
+struct CpuPel { decltype(PelBufferOps::addAvg8) addAvg8 = nullptr; decltype(PelBufferOps::reco8) reco8 = nullptr; decltype(PelBufferOps::linTf8) linTf8 = nullptr; } g_cpuPel;
+DevArray<vvc_pel> g_p0, g_p1, g_pd;
+DevArray<vvcgpu_pelop_desc> g_pDesc;
+
+bool gpuPelop(int op, const Pel* s0, int st0, const Pel* s1, int st1, Pel* dst, int dstStride, int w, int h, const vvcgpu_pelop_cfg& cfg)
+{
+  if (w < 64 || w > 128 || h > 128) return false;
+  const int pitch = 128;
+  g_p0.reserve((size_t)pitch * 128); g_p1.reserve((size_t)pitch * 128); g_pd.reserve((size_t)pitch * 128);
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_p0.ptr, pitch * sizeof(vvc_pel), s0, st0 * sizeof(Pel), (size_t)w * sizeof(Pel), h, nullptr));
+  if (s1) VVCGPU(vvcgpu_memcpy2d_h2d(g_p1.ptr, pitch * sizeof(vvc_pel), s1, st1 * sizeof(Pel), (size_t)w * sizeof(Pel), h, nullptr));
+  vvcgpu_pelop_desc d;
+  memset(&d, 0, sizeof d);
+  d.src0_stride = d.src1_stride = d.dst_stride = pitch; d.w = (int16_t)w; d.h = (int16_t)h;
+  g_pDesc.upload(&d, 1);
+  VVCGPU(vvcgpu_pelop_batch(op, g_p0.ptr, s1 ? g_p1.ptr : nullptr, g_pd.ptr, g_pDesc.ptr, 1, &cfg, nullptr));
+  VVCGPU(vvcgpu_memcpy2d_d2h(dst, dstStride * sizeof(Pel), g_pd.ptr, pitch * sizeof(vvc_pel), (size_t)w * sizeof(Pel), h, nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  g_calls[11]++;
+  return true;
+}
+void gpuAddAvg8(const Pel* s0, int st0, const Pel* s1, int st1, Pel* dst, int ds, int w, int h, int shift, int offset, const ClpRng& clp)
+{
+  const vvcgpu_pelop_cfg cfg = { 0, shift, offset, 1, clp.min, clp.max };
+  if (!gpuPelop(0, s0, st0, s1, st1, dst, ds, w, h, cfg)) g_cpuPel.addAvg8(s0, st0, s1, st1, dst, ds, w, h, shift, offset, clp);
+}
+void gpuReco8(const Pel* s0, int st0, const Pel* s1, int st1, Pel* dst, int ds, int w, int h, const ClpRng& clp)
+{
+  const vvcgpu_pelop_cfg cfg = { 0, 0, 0, 1, clp.min, clp.max };
+  if (!gpuPelop(1, s0, st0, s1, st1, dst, ds, w, h, cfg)) g_cpuPel.reco8(s0, st0, s1, st1, dst, ds, w, h, clp);
+}
+void gpuLinTf8(const Pel* s0, int st0, Pel* dst, int ds, int w, int h, int scale, int shift, int offset, const ClpRng& clp, bool bClip)
+{
+  const vvcgpu_pelop_cfg cfg = { scale, shift, offset, bClip ? 1 : 0, clp.min, clp.max };
+  if (!gpuPelop(2, s0, st0, nullptr, 0, dst, ds, w, h, cfg)) g_cpuPel.linTf8(s0, st0, dst, ds, w, h, scale, shift, offset, clp, bClip);
+}
+}  // namespace
+
+void wrap_initPelBufX86(PelBufferOps* self)
+{
+  real_initPelBufX86(self);
+  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return;
+  if (self->addAvg8 != gpuAddAvg8) { g_cpuPel.addAvg8 = self->addAvg8; g_cpuPel.reco8 = self->reco8; g_cpuPel.linTf8 = self->linTf8; }
+  self->addAvg8 = gpuAddAvg8; self->reco8 = gpuReco8; self->linTf8 = gpuLinTf8;
 }
