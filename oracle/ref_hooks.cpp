@@ -11,6 +11,9 @@
 
 #define SAO_SYM "_ZN23EncSampleAdaptiveOffset13getStatisticsERSt6vectorIPP11SAOStatDataSaIS3_EER7UnitBufIsES9_R15CodingStructureb"
 #define ALF_SYM "_ZN21EncAdaptiveLoopFilter23deriveStatsForFilteringER7UnitBufIsES2_"
+// the 2-D transforms are free functions called from TrQuant::xT / xIT in their own translation unit (TrQuant.cpp:694-791)
+#define TRF_SYM "_Z10xTrMxN_EMTiPKsmPiiiihhb"
+#define TRI_SYM "_Z11xITrMxN_EMTiPKiPsmiijjihh"
 
 extern "C" {
 typedef void (*sao_real_t)(void*, void*, void*, void*, void*, bool);
@@ -18,6 +21,12 @@ typedef int (*sao_shim_t)(void*, void*, void*, void*, void*, bool);
 typedef void (*alf_real_t)(void*, void*, void*);
 typedef int (*alf_shim_t)(void*, void*, void*);
 
+typedef void (*trf_real_t)(int, const short*, size_t, int*, int, int, int, unsigned char, unsigned char, bool);
+typedef int (*trf_shim_t)(int, const short*, size_t, int*, int, int, int, unsigned char, unsigned char, bool);
+typedef void (*tri_real_t)(int, const int*, short*, size_t, int, int, unsigned, unsigned, int, unsigned char, unsigned char);
+typedef int (*tri_shim_t)(int, const int*, short*, size_t, int, int, unsigned, unsigned, int, unsigned char, unsigned char);
+void hook_tr_fwd(int bd, const short* resi, size_t stride, int* coeff, int w, int h, int maxLog2, unsigned char mode, unsigned char idx, bool qtbt) asm(TRF_SYM);
+void hook_tr_inv(int bd, const int* coeff, short* resi, size_t stride, int w, int h, unsigned skipW, unsigned skipH, int maxLog2, unsigned char mode, unsigned char idx) asm(TRI_SYM);
 void hook_sao_stats(void* self, void* blkStats, void* org, void* src, void* cs, bool pre) asm(SAO_SYM);
 void hook_alf_stats(void* self, void* org, void* rec) asm(ALF_SYM);
 
@@ -38,5 +47,19 @@ void hook_alf_stats(void* self, void* org, void* rec)
   static alf_real_t real = (alf_real_t)must(g_target ? dlsym(g_target, ALF_SYM) : nullptr, ALF_SYM);
   if (shim && shim(self, org, rec)) return;
   real(self, org, rec);
+}
+void hook_tr_fwd(int bd, const short* resi, size_t stride, int* coeff, int w, int h, int maxLog2, unsigned char mode, unsigned char idx, bool qtbt)
+{
+  static trf_shim_t shim = (trf_shim_t)dlsym(RTLD_DEFAULT, "vvcshim_tr_fwd");
+  static trf_real_t real = (trf_real_t)must(g_target ? dlsym(g_target, TRF_SYM) : nullptr, TRF_SYM);
+  if (shim && shim(bd, resi, stride, coeff, w, h, maxLog2, mode, idx, qtbt)) return;
+  real(bd, resi, stride, coeff, w, h, maxLog2, mode, idx, qtbt);
+}
+void hook_tr_inv(int bd, const int* coeff, short* resi, size_t stride, int w, int h, unsigned skipW, unsigned skipH, int maxLog2, unsigned char mode, unsigned char idx)
+{
+  static tri_shim_t shim = (tri_shim_t)dlsym(RTLD_DEFAULT, "vvcshim_tr_inv");
+  static tri_real_t real = (tri_real_t)must(g_target ? dlsym(g_target, TRI_SYM) : nullptr, TRI_SYM);
+  if (shim && shim(bd, coeff, resi, stride, w, h, skipW, skipH, maxLog2, mode, idx)) return;
+  real(bd, coeff, resi, stride, w, h, skipW, skipH, maxLog2, mode, idx);
 }
 }

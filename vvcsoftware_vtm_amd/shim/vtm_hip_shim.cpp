@@ -26,6 +26,7 @@
 #include "EncoderLib/EncAdaptiveLoopFilter.h"
 #include "CommonLib/RdCost.h"
 #include "CommonLib/InterpolationFilter.h"
+#include "CommonLib/Rom.h"
 #include "vvcgpu.h"
 
 #define VVCGPU(call) do { if ((call) != 0) THROW("vvcgpu: " << vvcgpu_last_error()); } while (0)
@@ -65,11 +66,11 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[12] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+long g_calls[14] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
-                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld\n",
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
-                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11]); } } g_report;
+                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -765,4 +766,63 @@ void wrap_initPelBufX86(PelBufferOps* self)
   if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return;
   if (self->addAvg8 != gpuAddAvg8) { g_cpuPel.addAvg8 = self->addAvg8; g_cpuPel.reco8 = self->reco8; g_cpuPel.linTf8 = self->linTf8; }
   self->addAvg8 = gpuAddAvg8; self->reco8 = gpuReco8; self->linTf8 = gpuLinTf8;
+}
+
+// ---- 2-D transforms xTrMxN_EMT / xITrMxN_EMT (TrQuant.cpp:138-310), pre-empted by oracle/ref_hooks.cpp like the statistics.
+// TUs with a side of 32 or 64 go to the GPU (one round trip each); the transform pair is derived from (ucMode, ucTrIdx) with the
+// reference's own tables exactly as :183-214 does.
+namespace {
+DevArray<vvc_pel> g_tResi;
+DevArray<vvc_coef> g_tCoef;
+DevArray<vvcgpu_tr_desc> g_tDesc;
+bool trTypes(unsigned char ucMode, unsigned char ucTrIdx, int& hor, int& ver)
+{
+  hor = ver = DCT2;
+  if (ucTrIdx != DCT2_EMT)
+  {
+    if (ucMode != INTER_MODE_IDX) { hor = g_aiTrSubsetIntra[g_aucTrSetHorz[ucMode]][ucTrIdx & 1]; ver = g_aiTrSubsetIntra[g_aucTrSetVert[ucMode]][ucTrIdx >> 1]; }
+    else { hor = g_aiTrSubsetInter[ucTrIdx & 1]; ver = g_aiTrSubsetInter[ucTrIdx >> 1]; }
+  }
+  return (hor == DCT2 || hor == DCT8 || hor == DST7) && (ver == DCT2 || ver == DCT8 || ver == DST7);
+}
+int trCode(int t) { return t == DCT2 ? 0 : t == DCT8 ? 1 : 2; }
+}  // namespace
+
+extern "C" int vvcshim_tr_fwd(int bd, const Pel* resi, size_t stride, TCoeff* coeff, int w, int h, int maxLog2, unsigned char ucMode, unsigned char ucTrIdx, bool useQTBT)
+{
+  int hor, ver;
+  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES") || !useQTBT || maxLog2 != 15 || bd > 10 || (w < 32 && h < 32) || !trTypes(ucMode, ucTrIdx, hor, ver)) return 0;
+  g_tResi.reserve((size_t)64 * 64);
+  g_tCoef.reserve((size_t)64 * 64);
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_tResi.ptr, (size_t)w * sizeof(vvc_pel), resi, stride * sizeof(Pel), (size_t)w * sizeof(Pel), h, nullptr));
+  vvcgpu_tr_desc d;
+  memset(&d, 0, sizeof d);
+  d.resi_stride = w; d.w = (int16_t)w; d.h = (int16_t)h; d.tr_hor = (int8_t)trCode(hor); d.tr_ver = (int8_t)trCode(ver);
+  g_tDesc.upload(&d, 1);
+  VVCGPU(vvcgpu_tr_fwd_batch(g_tResi.ptr, g_tCoef.ptr, g_tDesc.ptr, 1, bd, nullptr));
+  VVCGPU(vvcgpu_memcpy_d2h(coeff, g_tCoef.ptr, (size_t)w * h * sizeof(TCoeff), nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  g_calls[12]++;
+  return 1;
+}
+
+extern "C" int vvcshim_tr_inv(int bd, const TCoeff* coeff, Pel* resi, size_t stride, int w, int h, unsigned skipW, unsigned skipH, int maxLog2,
+                              unsigned char ucMode, unsigned char ucTrIdx)
+{
+  int hor, ver;
+  const unsigned zw = w > 32 ? w - 32 : 0, zh = h > 32 ? h - 32 : 0;         // the zero-out the kernels assume (xIT, :755-759)
+  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES") || maxLog2 != 15 || bd > 10 || (w < 32 && h < 32) || skipW != zw || skipH != zh ||
+      !trTypes(ucMode, ucTrIdx, hor, ver)) return 0;
+  g_tResi.reserve((size_t)64 * 64);
+  g_tCoef.reserve((size_t)64 * 64);
+  VVCGPU(vvcgpu_memcpy_h2d(g_tCoef.ptr, coeff, (size_t)w * h * sizeof(TCoeff), nullptr));
+  vvcgpu_tr_desc d;
+  memset(&d, 0, sizeof d);
+  d.resi_stride = w; d.w = (int16_t)w; d.h = (int16_t)h; d.tr_hor = (int8_t)trCode(hor); d.tr_ver = (int8_t)trCode(ver);
+  g_tDesc.upload(&d, 1);
+  VVCGPU(vvcgpu_tr_inv_batch(g_tCoef.ptr, g_tResi.ptr, g_tDesc.ptr, 1, bd, nullptr));
+  VVCGPU(vvcgpu_memcpy2d_d2h(resi, stride * sizeof(Pel), g_tResi.ptr, (size_t)w * sizeof(vvc_pel), (size_t)w * sizeof(Pel), h, nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  g_calls[13]++;
+  return 1;
 }
