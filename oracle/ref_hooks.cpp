@@ -14,6 +14,8 @@
 // the 2-D transforms are free functions called from TrQuant::xT / xIT in their own translation unit (TrQuant.cpp:694-791)
 #define TRF_SYM "_Z10xTrMxN_EMTiPKsmPiiiihhb"
 #define TRI_SYM "_Z11xITrMxN_EMTiPKiPsmiijjihh"
+// the fractional motion refinement, called from xMotionEstimation in its own translation unit (InterSearch.cpp:1816)
+#define FRAC_SYM "_ZN11InterSearch21xPatternSearchFracDIFERK14PredictionUnit10RefPicListiRNS_17IntTZSearchStructERK2MvRS6_S9_Rm"
 
 extern "C" {
 typedef void (*sao_real_t)(void*, void*, void*, void*, void*, bool);
@@ -27,6 +29,9 @@ typedef void (*tri_real_t)(int, const int*, short*, size_t, int, int, unsigned, 
 typedef int (*tri_shim_t)(int, const int*, short*, size_t, int, int, unsigned, unsigned, int, unsigned char, unsigned char);
 void hook_tr_fwd(int bd, const short* resi, size_t stride, int* coeff, int w, int h, int maxLog2, unsigned char mode, unsigned char idx, bool qtbt) asm(TRF_SYM);
 void hook_tr_inv(int bd, const int* coeff, short* resi, size_t stride, int w, int h, unsigned skipW, unsigned skipH, int maxLog2, unsigned char mode, unsigned char idx) asm(TRI_SYM);
+typedef void (*frac_real_t)(void*, void*, int, int, void*, void*, void*, void*, void*);
+typedef int (*frac_shim_t)(void*, void*, int, int, void*, void*, void*, void*, void*);
+void hook_frac(void* self, void* pu, int list, int refIdx, void* cStruct, void* mvInt, void* mvHalf, void* mvQter, void* cost) asm(FRAC_SYM);
 void hook_sao_stats(void* self, void* blkStats, void* org, void* src, void* cs, bool pre) asm(SAO_SYM);
 void hook_alf_stats(void* self, void* org, void* rec) asm(ALF_SYM);
 
@@ -61,5 +66,12 @@ void hook_tr_inv(int bd, const int* coeff, short* resi, size_t stride, int w, in
   static tri_real_t real = (tri_real_t)must(g_target ? dlsym(g_target, TRI_SYM) : nullptr, TRI_SYM);
   if (shim && shim(bd, coeff, resi, stride, w, h, skipW, skipH, maxLog2, mode, idx)) return;
   real(bd, coeff, resi, stride, w, h, skipW, skipH, maxLog2, mode, idx);
+}
+void hook_frac(void* self, void* pu, int list, int refIdx, void* cStruct, void* mvInt, void* mvHalf, void* mvQter, void* cost)
+{
+  static frac_shim_t shim = (frac_shim_t)dlsym(RTLD_DEFAULT, "vvcshim_frac");
+  static frac_real_t real = (frac_real_t)must(g_target ? dlsym(g_target, FRAC_SYM) : nullptr, FRAC_SYM);
+  if (shim && shim(self, pu, list, refIdx, cStruct, mvInt, mvHalf, mvQter, cost)) return;
+  real(self, pu, list, refIdx, cStruct, mvInt, mvHalf, mvQter, cost);
 }
 }

@@ -27,6 +27,8 @@
 #include "CommonLib/RdCost.h"
 #include "CommonLib/InterpolationFilter.h"
 #include "CommonLib/Rom.h"
+#include "EncoderLib/InterSearch.h"
+#include "EncoderLib/EncCfg.h"
 #include "vvcgpu.h"
 
 #define VVCGPU(call) do { if ((call) != 0) THROW("vvcgpu: " << vvcgpu_last_error()); } while (0)
@@ -66,11 +68,11 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[14] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+long g_calls[15] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
-                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld\n",
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
-                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13]); } } g_report;
+                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -824,5 +826,54 @@ extern "C" int vvcshim_tr_inv(int bd, const TCoeff* coeff, Pel* resi, size_t str
   VVCGPU(vvcgpu_memcpy2d_d2h(resi, stride * sizeof(Pel), g_tResi.ptr, (size_t)w * sizeof(vvc_pel), (size_t)w * sizeof(Pel), h, nullptr));
   VVCGPU(vvcgpu_stream_sync(nullptr));
   g_calls[13]++;
+  return 1;
+}
+
+// ---- InterSearch::xPatternSearchFracDIF (InterSearch.cpp:2503-2552), pre-empted by oracle/ref_hooks.cpp: the fused
+// half/quarter-sample refinement kernel replaces xExtDIFUpSamplingH/Q + 2 x xPatternRefinement for one PU.
+namespace {
+DevArray<vvc_pel> g_fOrg, g_fRef;
+DevArray<vvcgpu_frac_blk> g_fBlk;
+DevArray<vvcgpu_frac_result> g_fRes;
+}
+
+extern "C" int vvcshim_frac(InterSearch* self, const PredictionUnit* pu, int /*eRefPicList*/, int /*iRefIdx*/, InterSearch::IntTZSearchStruct* cs,
+                            const Mv* mvInt, Mv* mvHalf, Mv* mvQter, Distortion* cost)
+{
+  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return 0;
+  const CPelBuf& key = *cs->pcPatternKey;
+  const int w = key.width, h = key.height, bd = self->m_lumaClpRng.bd;
+#if JVET_K0157
+  const bool intOnly = cs->imvShift || (pu->cs->sps->getSpsNext().getUseCompositeRef() && cs->zeroMV);
+#else
+  const bool intOnly = cs->imvShift != 0;
+#endif
+  if (intOnly || bd > 10 || bd < 8 || (w & 3) || (h & 3) || w < 4 || h < 4 || w > 128 || h > 128) return 0;
+  const int ww = w + 9, wh = h + 9, wp = (ww + 7) & ~7;                    // window: rows/cols -4 .. +4 around the integer position
+  g_fOrg.reserve((size_t)128 * 128);
+  g_fRef.reserve((size_t)144 * 144);
+  g_fBlk.reserve(1); g_fRes.reserve(1);
+  const Pel* ref = cs->piRefY + mvInt->getHor() + (ptrdiff_t)mvInt->getVer() * cs->iRefStride;
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_fOrg.ptr, (size_t)w * sizeof(vvc_pel), key.buf, key.stride * sizeof(Pel), (size_t)w * sizeof(Pel), h, nullptr));
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_fRef.ptr, (size_t)wp * sizeof(vvc_pel), ref - 4 - 4 * (ptrdiff_t)cs->iRefStride, cs->iRefStride * sizeof(Pel),
+                             (size_t)ww * sizeof(Pel), wh, nullptr));
+  const vvcgpu_frac_blk blk = { 0, 0, 4, 4, mvInt->getHor(), mvInt->getVer() };
+  g_fBlk.upload(&blk, 1);
+  vvcgpu_mvcost mv;
+  memset(&mv, 0, sizeof mv);
+  mv.lambda = self->m_pcRdCost->m_motionLambda;
+  mv.pred_hor = self->m_pcRdCost->m_mvPredictor.getHor();
+  mv.pred_ver = self->m_pcRdCost->m_mvPredictor.getVer();
+  const bool had = self->m_pcEncCfg->getUseHADME() && !pu->cu->transQuantBypass;
+  VVCGPU(vvcgpu_frac_refine(g_fOrg.ptr, w, g_fRef.ptr, wp, g_fBlk.ptr, 1, w, h, bd, self->m_lumaClpRng.min, self->m_lumaClpRng.max, had ? 1 : 0,
+                            &mv, g_fRes.ptr, nullptr));
+  vvcgpu_frac_result r;
+  VVCGPU(vvcgpu_memcpy_d2h(&r, g_fRes.ptr, sizeof r, nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  *mvHalf = Mv(r.half_x, r.half_y);
+  *mvQter = Mv(r.qter_x, r.qter_y);
+  *cost = (Distortion)r.cost;
+  self->m_pcRdCost->setCostScale(0);                                        // the state the reference leaves behind (:2543)
+  g_calls[14]++;
   return 1;
 }
