@@ -14,6 +14,8 @@
 // the 2-D transforms are free functions called from TrQuant::xT / xIT in their own translation unit (TrQuant.cpp:694-791)
 #define TRF_SYM "_Z10xTrMxN_EMTiPKsmPiiiihhb"
 #define TRI_SYM "_Z11xITrMxN_EMTiPKiPsmiijjihh"
+// the full integer search (FastSearch 0), called from xMotionEstimation in its own translation unit
+#define FS_SYM "_ZN11InterSearch14xPatternSearchERNS_17IntTZSearchStructER2MvRm"
 // the fractional motion refinement, called from xMotionEstimation in its own translation unit (InterSearch.cpp:1816)
 #define FRAC_SYM "_ZN11InterSearch21xPatternSearchFracDIFERK14PredictionUnit10RefPicListiRNS_17IntTZSearchStructERK2MvRS6_S9_Rm"
 
@@ -32,6 +34,9 @@ void hook_tr_inv(int bd, const int* coeff, short* resi, size_t stride, int w, in
 typedef void (*frac_real_t)(void*, void*, int, int, void*, void*, void*, void*, void*);
 typedef int (*frac_shim_t)(void*, void*, int, int, void*, void*, void*, void*, void*);
 void hook_frac(void* self, void* pu, int list, int refIdx, void* cStruct, void* mvInt, void* mvHalf, void* mvQter, void* cost) asm(FRAC_SYM);
+typedef void (*fs_real_t)(void*, void*, void*, void*);
+typedef int (*fs_shim_t)(void*, void*, void*, void*);
+void hook_fullsearch(void* self, void* cStruct, void* mv, void* sad) asm(FS_SYM);
 void hook_sao_stats(void* self, void* blkStats, void* org, void* src, void* cs, bool pre) asm(SAO_SYM);
 void hook_alf_stats(void* self, void* org, void* rec) asm(ALF_SYM);
 
@@ -73,5 +78,12 @@ void hook_frac(void* self, void* pu, int list, int refIdx, void* cStruct, void* 
   static frac_real_t real = (frac_real_t)must(g_target ? dlsym(g_target, FRAC_SYM) : nullptr, FRAC_SYM);
   if (shim && shim(self, pu, list, refIdx, cStruct, mvInt, mvHalf, mvQter, cost)) return;
   real(self, pu, list, refIdx, cStruct, mvInt, mvHalf, mvQter, cost);
+}
+void hook_fullsearch(void* self, void* cStruct, void* mv, void* sad)
+{
+  static fs_shim_t shim = (fs_shim_t)dlsym(RTLD_DEFAULT, "vvcshim_fullsearch");
+  static fs_real_t real = (fs_real_t)must(g_target ? dlsym(g_target, FS_SYM) : nullptr, FS_SYM);
+  if (shim && shim(self, cStruct, mv, sad)) return;
+  real(self, cStruct, mv, sad);
 }
 }

@@ -25,6 +25,7 @@ CLIPS = [
     # encoded with this repository's own small test cfg (travels with the repo, so the GPU box can re-run the ENCODER)
     ("ldp_208x120_10b_q27", "@tests/golden/bitstreams/test_lowdelay.cfg", 208, 120, 10, 3, 27, 20261005),
     # all-intra 8-bit: the encoder switches ALF on, so the ALF filter table slots run inside the encoder as well
+    ("ldpfs_208x120_10b_q32", "@tests/golden/bitstreams/test_fullsearch.cfg", 208, 120, 10, 2, 32, 20261007),
     ("ai_416x240_8b_q37own", "@tests/golden/bitstreams/test_intra.cfg", 416, 240, 8, 1, 37, 20261004),
 ]
 

@@ -64,7 +64,7 @@ def test_decoder_fallthrough_matches(tmp_path):
 
 
 @needs_ref
-@pytest.mark.parametrize("name", ["ldp_208x120_10b_q27", "ai_416x240_8b_q37own"])
+@pytest.mark.parametrize("name", ["ldp_208x120_10b_q27", "ai_416x240_8b_q37own", "ldpfs_208x120_10b_q32"])
 def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
     """the reference ENCODER with deblocking, the SAO statistics (getStatistics) and the ALF covariances
     (deriveStatsForFiltering), the per-CTU SAO offsetting (offsetCTU) and the three ALF table slots computed on the GPU inside its loop: every SAO / ALF decision and therefore the bitstream must be
@@ -90,6 +90,8 @@ def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
     # per-CTU SAO offsetCTU, and the ALF table slots (m_filter5x5Blk / m_filter7x7Blk / m_deriveClassificationBlk) installed
     # where the reference installs its SIMD functions
     assert calls[5] > 0 and calls[7] > 0, line[-1]
+    if name.startswith("ldpfs_"):
+        assert calls[15] > 0, line[-1]         # xPatternSearch: full search = vvcgpu_sad_search with the fused arg-min
     if name.startswith("ldp_"):
         assert calls[8] > 0, line[-1]          # RdCost table slot DF_SAD64 (64-wide motion search SADs) ran on the GPU
         assert calls[10] > 0, line[-1]         # InterpolationFilter table slots (64-wide calls) ran on the GPU

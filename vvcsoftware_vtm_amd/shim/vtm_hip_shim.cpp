@@ -68,11 +68,11 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[15] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+long g_calls[16] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
-                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld\n",
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
-                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14]); } } g_report;
+                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -875,5 +875,53 @@ extern "C" int vvcshim_frac(InterSearch* self, const PredictionUnit* pu, int /*e
   *cost = (Distortion)r.cost;
   self->m_pcRdCost->setCostScale(0);                                        // the state the reference leaves behind (:2543)
   g_calls[14]++;
+  return 1;
+}
+
+// ---- InterSearch::xPatternSearch (InterSearch.cpp:1886-1935; FastSearch 0), pre-empted by oracle/ref_hooks.cpp: one call of
+// vvcgpu_sad_search (SAD surface over the search range + fused arg-min with the MV cost) replaces the double loop.
+namespace {
+DevArray<vvc_pel> g_sOrg, g_sRef;
+DevArray<vvcgpu_search_blk> g_sBlk;
+DevArray<vvcgpu_search_best> g_sBest;
+}
+
+extern "C" int vvcshim_fullsearch(InterSearch* self, InterSearch::IntTZSearchStruct* cs, Mv* rcMv, Distortion* ruiSAD)
+{
+  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return 0;
+  const CPelBuf& key = *cs->pcPatternKey;
+  const int w = key.width, h = key.height, bd = self->m_lumaClpRng.bd;
+  const InterSearch::SearchRange& sr = cs->searchRange;
+  const int nx = sr.right - sr.left + 1, ny = sr.bottom - sr.top + 1;
+  // the reference's own parameter set-up (sub-sampling decision included)
+  self->m_pcRdCost->setDistParam(self->m_cDistParam, key, cs->piRefY, cs->iRefStride, bd, COMPONENT_Y, cs->subShiftMode);
+  const int ss = self->m_cDistParam.subShift;
+  if (bd > 10 || (w & 1) || w < 4 || h < 4 || w > 128 || h > 128 || nx < 1 || ny < 1 || (long long)nx * ny >= (1 << 24) ||
+      (h & ((1 << ss) - 1)) || self->m_cDistParam.useMR || self->m_cDistParam.applyWeight) return 0;
+  const int ww = nx - 1 + w, wh = ny - 1 + h, wp = (ww + 7) & ~7;
+  g_sOrg.reserve((size_t)w * h);
+  g_sRef.reserve((size_t)wp * wh);
+  g_sBlk.reserve(1); g_sBest.reserve(1);
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_sOrg.ptr, (size_t)w * sizeof(vvc_pel), key.buf, key.stride * sizeof(Pel), (size_t)w * sizeof(Pel), h, nullptr));
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_sRef.ptr, (size_t)wp * sizeof(vvc_pel), cs->piRefY + sr.left + (ptrdiff_t)sr.top * cs->iRefStride,
+                             cs->iRefStride * sizeof(Pel), (size_t)ww * sizeof(Pel), wh, nullptr));
+  const vvcgpu_search_blk blk = { 0, 0, -sr.left, -sr.top };                // window sample (0,0) is displacement (sr.left, sr.top)
+  g_sBlk.upload(&blk, 1);
+  vvcgpu_mvcost mv;
+  memset(&mv, 0, sizeof mv);
+  mv.lambda = self->m_pcRdCost->m_motionLambda;
+  mv.pred_hor = self->m_pcRdCost->m_mvPredictor.getHor();
+  mv.pred_ver = self->m_pcRdCost->m_mvPredictor.getVer();
+  mv.cost_scale = self->m_pcRdCost->m_iCostScale;
+  mv.imv_shift = cs->imvShift;
+  VVCGPU(vvcgpu_sad_search(g_sOrg.ptr, w, g_sRef.ptr, wp, g_sBlk.ptr, 1, w, h, ss, sr.left, sr.top, nx, ny, 1, 1, nullptr, &mv, g_sBest.ptr, nullptr));
+  vvcgpu_search_best b;
+  VVCGPU(vvcgpu_memcpy_d2h(&b, g_sBest.ptr, sizeof b, nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  rcMv->set(b.x, b.y);
+  cs->uiBestSad = (Distortion)b.cost;
+  *ruiSAD = (Distortion)b.sad;
+  self->m_cDistParam.maximumDistortionForEarlyExit = (Distortion)b.cost;    // the state the reference's loop leaves behind (:1918)
+  g_calls[15]++;
   return 1;
 }
