@@ -93,7 +93,7 @@ def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
     if name.startswith("ldpfs_"):
         assert calls[15] > 0, line[-1]         # xPatternSearch: full search = vvcgpu_sad_search with the fused arg-min
     if name.startswith("ldp_"):
-        assert calls[8] > 0, line[-1]          # RdCost table slot DF_SAD64 (64-wide motion search SADs) ran on the GPU
+        assert calls[8] > 0 and calls[17] > 0, line[-1]   # RdCost table slots DF_SAD64 and DF_SSE64 (64-wide blocks) ran on the GPU
         assert calls[10] > 0, line[-1]         # InterpolationFilter table slots (64-wide calls) ran on the GPU
         assert calls[11] > 0, line[-1]         # PelBufferOps table slots (addAvg8 / reco8 / linTf8, 64-wide calls)
         assert calls[14] > 0, line[-1]         # xPatternSearchFracDIF: the fused half/quarter refinement kernel, every inter PU

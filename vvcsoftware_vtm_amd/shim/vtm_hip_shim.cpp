@@ -74,11 +74,11 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[17] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+long g_calls[18] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
-                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld\n",
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
-                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16]); } } g_report;
+                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -637,7 +637,7 @@ void wrap_offsetCTU(SampleAdaptiveOffset* self, const UnitArea& area, const CPel
 // Only the 64-sample-wide SAD and Hadamard slots are redirected: every call is a synchronous round trip, and the encoder
 // makes a few ten thousand 64-wide calls on the test clips but tens of millions of narrower ones.
 namespace {
-FpDistFunc g_cpuDist[2] = { nullptr, nullptr };
+FpDistFunc g_cpuDist[3] = { nullptr, nullptr, nullptr };   // SAD64, HAD64, SSE64
 DevArray<vvc_pel> g_dOrg, g_dCur;
 DevArray<vvcgpu_dist_desc> g_dDesc;
 DevArray<uint64_t> g_dOut;
@@ -660,7 +660,7 @@ Distortion gpuDist64(const DistParam& p)
   uint64_t out = 0;
   VVCGPU(vvcgpu_memcpy_d2h(&out, g_dOut.ptr, sizeof out, nullptr));
   VVCGPU(vvcgpu_stream_sync(nullptr));
-  g_calls[8 + KIND]++;
+  g_calls[KIND == 2 ? 17 : 8 + KIND]++;
   return (Distortion)out;
 }
 }  // namespace
@@ -669,9 +669,10 @@ void wrap_initRdCostX86(RdCost* self)
 {
   real_initRdCostX86(self);
   if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return;
-  if (!g_cpuDist[0]) { g_cpuDist[0] = RdCost::m_afpDistortFunc[DF_SAD64]; g_cpuDist[1] = RdCost::m_afpDistortFunc[DF_HAD64]; }
+  if (!g_cpuDist[0]) { g_cpuDist[0] = RdCost::m_afpDistortFunc[DF_SAD64]; g_cpuDist[1] = RdCost::m_afpDistortFunc[DF_HAD64]; g_cpuDist[2] = RdCost::m_afpDistortFunc[DF_SSE64]; }
   RdCost::m_afpDistortFunc[DF_SAD64] = gpuDist64<0>;
   RdCost::m_afpDistortFunc[DF_HAD64] = gpuDist64<1>;
+  RdCost::m_afpDistortFunc[DF_SSE64] = gpuDist64<2>;
 }
 
 // ---- InterpolationFilter table slots (m_filterHor / m_filterVer [N][isFirst][isLast], InterpolationFilter.h:84-86; installed by
