@@ -295,6 +295,33 @@ int vvcgpu_dequant_tr_inv_batch(const vvc_coef* level_base, vvc_pel* resi_base, 
                                 int bit_depth, vvc_coef* coeff_out, void* stream);
 /* The coefficient scan the library replays (host copy, out[scanIdx] = raster position; w, h in 2..64 powers of two). */
 int vvcgpu_scan_order_host(int w, int h, uint16_t* out);
+/* ---- N3 ("next" row): affine gradient search kernels  (AffineGradientSearch table slots m_HorizontalSobelFilter /
+ *          m_VerticalSobelFilter / m_EqualCoeffComputer, AffineGradientSearch.h:50-54; bodies AffineGradientSearch.cpp:66-174;
+ *          called per iteration of xAffineMotionEstimation, InterSearch.cpp:3456-3534) --------------------------------
+ * sobel: deriv = 3x3 Sobel response of the W x H prediction block (horizontal: [-1 0 1; -2 0 2; -1 0 1], vertical its
+ *        transpose); the outermost ring repeats the nearest interior value (:83-96, :116-129).  w, h >= 3.
+ * equal_coeff: out[col+1][row] = sum iC[col]*iC[row], out[col+1][P] = sum (iC[col]*resi) << 3 over the block, P = 4 or 6
+ *        parameters, iC built from the two derivative planes and the sample position (:139-157); out is n x 7 x 7 int64
+ *        (row 0 and unused columns are written as 0; the reference ACCUMULATES into a zeroed matrix, the caller adds).
+ *        The residue is indexed with the DERIVATIVE stride, as the reference does (:144 uses `idx` for both).           */
+typedef struct vvcgpu_afg_desc {
+  int64_t pred_off, deriv_off;          /* elements from pred_base (Pel) / deriv_base (int32) */
+  int32_t pred_stride, deriv_stride;
+  int16_t w, h;
+  int32_t reserved;                     /* sizeof == 32 */
+} vvcgpu_afg_desc;
+int vvcgpu_affine_sobel_batch(int vertical, const vvc_pel* pred_base, int32_t* deriv_base, const vvcgpu_afg_desc* descs, int n,
+                              void* stream);
+typedef struct vvcgpu_afe_desc {
+  int64_t resi_off, deriv_off;          /* elements from resi_base (Pel) / derivx_base, derivy_base (int32, same offset) */
+  int32_t deriv_stride;                 /* also the stride of the residue block */
+  int16_t w, h;
+  int32_t six_param;                    /* 0: 4-parameter model, 1: 6-parameter model */
+  int32_t reserved;                     /* sizeof == 32 */
+} vvcgpu_afe_desc;
+int vvcgpu_affine_equal_coeff_batch(const vvc_pel* resi_base, const int32_t* derivx_base, const int32_t* derivy_base,
+                                    const vvcgpu_afe_desc* descs, int n, int64_t* out, void* stream);
+
 /* The shipped matrix [type][log2(N)-1] as N x N int16 (host copy; for the shim's table check against initROM()). */
 const int16_t* vvcgpu_tr_matrix_host(int type, int n);
 

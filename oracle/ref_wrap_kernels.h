@@ -18,6 +18,7 @@
 #include "CommonLib/TrQuant.h"
 #include "CommonLib/TrQuant_EMT.h"
 #include "CommonLib/DepQuant.h"
+#include "CommonLib/AffineGradientSearch.h"
 #include "EncoderLib/InterSearch.h"
 #include "EncoderLib/EncCfg.h"
 #include "../include/vvcgpu.h"
@@ -408,6 +409,27 @@ int vtmref_scan_order(int w, int h, uint32_t* out)
   const unsigned* scan = g_scanOrder[SCAN_GROUPED_4x4][SCAN_DIAG][gp_sizeIdxInfo->idxFrom(w)][gp_sizeIdxInfo->idxFrom(h)];
   if (!scan) return -1;
   for (int i = 0; i < w * h; i++) out[i] = scan[i];
+  return 0;
+}
+// Affine gradient search kernels (next row N3): the scalar bodies (simd = 0) or the table slots the constructor installs
+// (initAffineGradientSearchX86: SIMD twins, simd = 1).  AffineGradientSearch.h:50-54.
+int vtmref_affine_sobel(int simd, int vertical, const Pel* pred, int predStride, int32_t* deriv, int derivStride, int w, int h)
+{
+  static AffineGradientSearch ags;
+  Pel* p = const_cast<Pel*>(pred);
+  if (!simd) { if (!vertical) AffineGradientSearch::xHorizontalSobelFilter(p, predStride, deriv, derivStride, w, h); else AffineGradientSearch::xVerticalSobelFilter(p, predStride, deriv, derivStride, w, h); }
+  else { if (!vertical) ags.m_HorizontalSobelFilter(p, predStride, deriv, derivStride, w, h); else ags.m_VerticalSobelFilter(p, predStride, deriv, derivStride, w, h); }
+  return 0;
+}
+int vtmref_affine_equal_coeff(int simd, const Pel* resi, int32_t* gx, int32_t* gy, int derivStride, int w, int h, int sixParam, int64_t* out)
+{
+  static AffineGradientSearch ags;
+  int64_t eq[7][7];
+  memset(eq, 0, sizeof eq);
+  int* pp[2] = { gx, gy };
+  if (!simd) AffineGradientSearch::xEqualCoeffComputer(const_cast<Pel*>(resi), derivStride, pp, derivStride, eq, w, h, sixParam != 0);
+  else ags.m_EqualCoeffComputer(const_cast<Pel*>(resi), derivStride, pp, derivStride, eq, w, h, sixParam != 0);
+  memcpy(out, eq, sizeof eq);
   return 0;
 }
 // Effective 1-D matrices of the reference's fast transforms, obtained by pushing 2*identity through

@@ -261,6 +261,30 @@ def gen_dequant():
     save("dequant", **out)
 
 
+def gen_affine():
+    """next row N3: Sobel derivative planes and equal-coefficient sums from the compiled reference's SIMD table slots."""
+    rng = np.random.default_rng(1011)
+    out = {}
+    rows, preds, gxs, gys, resis, eqs = [], [], [], [], [], []
+    for (w, h) in [(16, 16), (16, 32), (32, 16), (64, 64), (128, 64), (16, 8), (8, 16), (128, 128), (32, 32)]:
+        pred = rng.integers(0, 1024, (h, w)).astype(np.int16)
+        gx = np.zeros((h, w), np.int32)
+        gy = np.zeros((h, w), np.int32)
+        R.vtmref_affine_sobel(1, 0, p(pred), w, p(gx), w, w, h)
+        R.vtmref_affine_sobel(1, 1, p(pred), w, p(gy), w, w, h)
+        resi = rng.integers(-1023, 1024, (h, w)).astype(np.int16)
+        for six in (0, 1):
+            eq = np.zeros(49, np.int64)
+            R.vtmref_affine_equal_coeff(1, p(resi), p(gx), p(gy), w, w, h, six, p(eq))
+            eqs.append(eq)
+        rows.append((w, h))
+        preds.append(pred.reshape(-1)); gxs.append(gx.reshape(-1)); gys.append(gy.reshape(-1)); resis.append(resi.reshape(-1))
+    out["rows"] = np.array(rows, np.int32)
+    out["pred"] = np.concatenate(preds); out["gx"] = np.concatenate(gxs); out["gy"] = np.concatenate(gys)
+    out["resi"] = np.concatenate(resis); out["eq"] = np.concatenate(eqs)
+    save("affine", **out)
+
+
 def gen_frac():
     rng = np.random.default_rng(1006)
     FB = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4")])
@@ -296,6 +320,6 @@ def gen_frac():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_frac):
+    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac):
         if not only or fn.__name__[4:] in only:
             fn()

@@ -52,7 +52,7 @@ def test_struct_layouts_match_python_bindings():
     lib = capi.lib()
     want = {0: ops.SAO_DTYPE.itemsize, 1: C.sizeof(ops.DeblockCfg), 2: ops.DIST_DESC.itemsize, 3: ops.SEARCH_BLK.itemsize,
             4: C.sizeof(ops.MvCost), 5: ops.SEARCH_BEST.itemsize, 6: ops.IF_DESC.itemsize, 7: ops.MC_DESC.itemsize,
-            8: ops.PELOP_DESC.itemsize, 9: C.sizeof(ops.PelopCfg), 10: ops.TR_DESC.itemsize, 13: ops.DQTR_DESC.itemsize,
+            8: ops.PELOP_DESC.itemsize, 9: C.sizeof(ops.PelopCfg), 10: ops.TR_DESC.itemsize, 13: ops.DQTR_DESC.itemsize, 14: ops.AFG_DESC.itemsize, 15: ops.AFE_DESC.itemsize,
             11: ops.FRAC_BLK.itemsize, 12: ops.FRAC_RESULT.itemsize}
     for k, v in want.items():
         assert lib.vvcgpu_sizeof(k) == v, (k, lib.vvcgpu_sizeof(k), v)

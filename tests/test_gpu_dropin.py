@@ -97,6 +97,7 @@ def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
         assert calls[10] > 0, line[-1]         # InterpolationFilter table slots (64-wide calls) ran on the GPU
         assert calls[11] > 0, line[-1]         # PelBufferOps table slots (addAvg8 / reco8 / linTf8, 64-wide calls)
         assert calls[14] > 0, line[-1]         # xPatternSearchFracDIF: the fused half/quarter refinement kernel, every inter PU
+        assert calls[18] > 0 and calls[19] > 0, line[-1]   # affine gradient table slots (Sobel planes, equal coefficients)
     assert calls[12] > 0 and calls[16] > 0, line[-1]   # forward transforms (32/64-side TUs); de-quantisation + inverse (every TU)
     print(line[-1])
     if name.startswith("ai_"):

@@ -174,6 +174,27 @@ def test_dequant_golden():
             pos += n
 
 
+def test_affine_gradient_golden():
+    """N3 pinned: restatement == the compiled reference's SIMD table slots (Sobel planes, equal-coefficient sums)."""
+    g = load("affine")
+    O = oracle()
+    pos = 0
+    for n, (w, h) in enumerate(g["rows"]):
+        w, h = int(w), int(h)
+        cnt = w * h
+        pred = g["pred"][pos:pos + cnt].copy()
+        gx = np.zeros(cnt, np.int32); gy = np.zeros(cnt, np.int32)
+        O.orc_affine_sobel(0, p(pred), w, p(gx), w, w, h)
+        O.orc_affine_sobel(1, p(pred), w, p(gy), w, w, h)
+        assert np.array_equal(gx, g["gx"][pos:pos + cnt]) and np.array_equal(gy, g["gy"][pos:pos + cnt]), (w, h)
+        resi = g["resi"][pos:pos + cnt].copy()
+        for six in (0, 1):
+            eq = np.zeros(49, np.int64)
+            O.orc_affine_equal_coeff(p(resi), p(gx), p(gy), w, w, h, six, p(eq))
+            assert np.array_equal(eq, g["eq"][(2 * n + six) * 49:(2 * n + six + 1) * 49]), (w, h, six)
+        pos += cnt
+
+
 def test_frac_refine_golden():
     g = load("frac")
     O = oracle()

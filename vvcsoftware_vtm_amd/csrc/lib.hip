@@ -89,6 +89,8 @@ int vvcgpu_sizeof(int id)
   case 11: return (int)sizeof(vvcgpu_frac_blk);
   case 12: return (int)sizeof(vvcgpu_frac_result);
   case 13: return (int)sizeof(vvcgpu_dqtr_desc);
+  case 14: return (int)sizeof(vvcgpu_afg_desc);
+  case 15: return (int)sizeof(vvcgpu_afe_desc);
   default: return -1;
   }
 }

@@ -218,6 +218,26 @@ FRAC_BLK = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref
 FRAC_RESULT = np.dtype([("half_x", "<i4"), ("half_y", "<i4"), ("qter_x", "<i4"), ("qter_y", "<i4"), ("cost_half", "<u8"), ("cost", "<u8")])
 
 
+AFG_DESC = np.dtype([("pred_off", "<i8"), ("deriv_off", "<i8"), ("pred_stride", "<i4"), ("deriv_stride", "<i4"), ("w", "<i2"), ("h", "<i2"),
+                     ("reserved", "<i4")])
+AFE_DESC = np.dtype([("resi_off", "<i8"), ("deriv_off", "<i8"), ("deriv_stride", "<i4"), ("w", "<i2"), ("h", "<i2"), ("six_param", "<i4"),
+                     ("reserved", "<i4")])
+assert AFG_DESC.itemsize == 32 and AFE_DESC.itemsize == 32
+
+
+def affine_sobel_batch(vertical, pred_base, deriv_base, descs_dev, n):
+    """N3: Sobel derivative planes of prediction blocks (table slots m_HorizontalSobelFilter / m_VerticalSobelFilter)."""
+    capi.call("vvcgpu_affine_sobel_batch", int(vertical), capi.ptr(pred_base), capi.ptr(deriv_base), capi.ptr(descs_dev), n, _stream())
+
+
+def affine_equal_coeff_batch(resi_base, gx_base, gy_base, descs_dev, n):
+    """N3: normal-equation sums of the affine model (table slot m_EqualCoeffComputer) -> int64 tensor [n, 7, 7]."""
+    out = torch.empty((n, 7, 7), dtype=torch.int64, device=resi_base.device)
+    capi.call("vvcgpu_affine_equal_coeff_batch", capi.ptr(resi_base), capi.ptr(gx_base), capi.ptr(gy_base), capi.ptr(descs_dev), n,
+              capi.ptr(out), _stream())
+    return out
+
+
 DQTR_DESC = np.dtype([("resi_off", "<i8"), ("level_off", "<i8"), ("resi_stride", "<i4"), ("w", "<i2"), ("h", "<i2"),
                       ("tr_hor", "i1"), ("tr_ver", "i1"), ("dep_quant", "i1"), ("reserved", "i1"), ("qp", "<i4")])
 assert DQTR_DESC.itemsize == 32

@@ -31,6 +31,7 @@
 #include "EncoderLib/EncCfg.h"
 #include "CommonLib/TrQuant.h"
 #include "CommonLib/DepQuant.h"
+#include "CommonLib/AffineGradientSearch.h"
 #include "vvcgpu.h"
 
 #define VVCGPU(call) do { if ((call) != 0) THROW("vvcgpu: " << vvcgpu_last_error()); } while (0)
@@ -50,6 +51,8 @@ void real_invTransformNxN(TrQuant*, TransformUnit&, const ComponentID&, PelBuf&,
   asm("__real__ZN7TrQuant15invTransformNxNER13TransformUnitRK11ComponentIDR7AreaBufIsERK7QpParam");
 void wrap_invTransformNxN(TrQuant*, TransformUnit&, const ComponentID&, PelBuf&, const QpParam&)
   asm("__wrap__ZN7TrQuant15invTransformNxNER13TransformUnitRK11ComponentIDR7AreaBufIsERK7QpParam");
+void real_initAgsX86(AffineGradientSearch*) asm("__real__ZN20AffineGradientSearch27initAffineGradientSearchX86Ev");
+void wrap_initAgsX86(AffineGradientSearch*) asm("__wrap__ZN20AffineGradientSearch27initAffineGradientSearchX86Ev");
 void real_initRdCostX86(RdCost*) asm("__real__ZN6RdCost13initRdCostX86Ev");
 void wrap_initRdCostX86(RdCost*) asm("__wrap__ZN6RdCost13initRdCostX86Ev");
 void real_initAlfX86(AdaptiveLoopFilter*) asm("__real__ZN18AdaptiveLoopFilter25initAdaptiveLoopFilterX86Ev");
@@ -74,11 +77,11 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[18] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+long g_calls[20] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
-                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld\n",
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
-                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17]); } } g_report;
+                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -971,4 +974,58 @@ void wrap_invTransformNxN(TrQuant* self, TransformUnit& tu, const ComponentID& c
   VVCGPU(vvcgpu_memcpy2d_d2h(pResi.buf, pResi.stride * sizeof(Pel), g_qResi.ptr, (size_t)w * sizeof(vvc_pel), (size_t)w * sizeof(Pel), h, nullptr));
   VVCGPU(vvcgpu_stream_sync(nullptr));
   g_calls[16]++;
+}
+
+// ---- AffineGradientSearch table slots (AffineGradientSearch.h:50-54; installed by the constructor -> initAffineGradientSearchX86):
+// next row N3.  One PU per call.
+namespace {
+DevArray<vvc_pel> g_aPred, g_aResi;
+DevArray<int32_t> g_aGx, g_aGy;
+DevArray<vvcgpu_afg_desc> g_aGd;
+DevArray<vvcgpu_afe_desc> g_aEd;
+DevArray<int64_t> g_aOut;
+
+template <int VER>
+void gpuSobel(Pel* const pPred, const int predStride, int* const pDerivate, const int derivateBufStride, const int width, const int height)
+{
+  g_aPred.reserve((size_t)128 * 128); g_aGx.reserve((size_t)128 * 128);
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_aPred.ptr, (size_t)width * sizeof(vvc_pel), pPred, predStride * sizeof(Pel), (size_t)width * sizeof(Pel), height, nullptr));
+  vvcgpu_afg_desc d;
+  memset(&d, 0, sizeof d);
+  d.pred_stride = width; d.deriv_stride = width; d.w = (int16_t)width; d.h = (int16_t)height;
+  g_aGd.upload(&d, 1);
+  VVCGPU(vvcgpu_affine_sobel_batch(VER, g_aPred.ptr, g_aGx.ptr, g_aGd.ptr, 1, nullptr));
+  VVCGPU(vvcgpu_memcpy2d_d2h(pDerivate, derivateBufStride * sizeof(int), g_aGx.ptr, (size_t)width * sizeof(int), (size_t)width * sizeof(int), height, nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  g_calls[18]++;
+}
+void gpuEqualCoeff(Pel* pResidue, int /*residueStride*/, int** ppDerivate, int derivateBufStride, int64_t (*pEqualCoeff)[7], int width, int height, bool b6Param)
+{
+  g_aResi.reserve((size_t)128 * 128); g_aGx.reserve((size_t)128 * 128); g_aGy.reserve((size_t)128 * 128); g_aOut.reserve(49);
+  // the reference indexes the residue with the derivative stride (AffineGradientSearch.cpp:144)
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_aResi.ptr, (size_t)width * sizeof(vvc_pel), pResidue, derivateBufStride * sizeof(Pel), (size_t)width * sizeof(Pel), height, nullptr));
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_aGx.ptr, (size_t)width * sizeof(int), ppDerivate[0], derivateBufStride * sizeof(int), (size_t)width * sizeof(int), height, nullptr));
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_aGy.ptr, (size_t)width * sizeof(int), ppDerivate[1], derivateBufStride * sizeof(int), (size_t)width * sizeof(int), height, nullptr));
+  vvcgpu_afe_desc d;
+  memset(&d, 0, sizeof d);
+  d.deriv_stride = width; d.w = (int16_t)width; d.h = (int16_t)height; d.six_param = b6Param ? 1 : 0;
+  g_aEd.upload(&d, 1);
+  VVCGPU(vvcgpu_affine_equal_coeff_batch(g_aResi.ptr, g_aGx.ptr, g_aGy.ptr, g_aEd.ptr, 1, g_aOut.ptr, nullptr));
+  int64_t out[49];
+  VVCGPU(vvcgpu_memcpy_d2h(out, g_aOut.ptr, sizeof out, nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  const int P = b6Param ? 6 : 4;
+  for (int col = 0; col < P; col++)
+    for (int row = 0; row <= P; row++) pEqualCoeff[col + 1][row] += out[(col + 1) * 7 + row];
+  g_calls[19]++;
+}
+}  // namespace
+
+void wrap_initAgsX86(AffineGradientSearch* self)
+{
+  real_initAgsX86(self);
+  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return;
+  self->m_HorizontalSobelFilter = gpuSobel<0>;
+  self->m_VerticalSobelFilter = gpuSobel<1>;
+  self->m_EqualCoeffComputer = gpuEqualCoeff;
 }
