@@ -41,7 +41,8 @@ const char* vvcgpu_last_error(void);              /* thread-local text of the la
 int         vvcgpu_device_count(void);
 int         vvcgpu_set_device(int device);
 /* sizeof() of the parameter structs, for binding self-checks: 0 sao_ctu, 1 deblock_cfg, 2 dist_desc, 3 search_blk,
- * 4 mvcost, 5 search_best, 6 if_desc, 7 mc_desc, 8 pelop_desc, 9 pelop_cfg, 10 tr_desc, 11 frac_blk, 12 frac_result; -1 for unknown ids.          */
+ * 4 mvcost, 5 search_best, 6 if_desc, 7 mc_desc, 8 pelop_desc, 9 pelop_cfg, 10 tr_desc, 11 frac_blk, 12 frac_result,
+ * 13 dqtr_desc, 14 afg_desc, 15 afe_desc, 16 tz_pu, 17 tz_cfg; -1 for unknown ids.          */
 int         vvcgpu_sizeof(int struct_id);
 
 /* ---- device memory helpers for host-side callers (the reference keeps pictures in host memory; the shim stages them).
@@ -321,6 +322,42 @@ typedef struct vvcgpu_afe_desc {
 } vvcgpu_afe_desc;
 int vvcgpu_affine_equal_coeff_batch(const vvc_pel* resi_base, const int32_t* derivx_base, const int32_t* derivy_base,
                                     const vvcgpu_afe_desc* descs, int n, int64_t* out, void* stream);
+
+/* ---- N2 ("next" row): integer-sample TZ search of whole PUs, on the device  (InterSearch::xTZSearch,
+ *          EncoderLib/InterSearch.cpp:1971-2252, with xTZSearchHelp :249-343, xTZ2PointSearch :349-374,
+ *          xTZ8PointDiamondSearch :431-632, xSetSearchRange :1820-1883, clipMv CommonLib/Mv.cpp:64-80) -----------------
+ * One wavefront walks one PU through the complete reference control flow (start point / zero vector / 2Nx2N predictor,
+ * search range, first diamond rounds, zero neighbourhood, 2-point search, raster, star refinement); the up-to-16 candidates
+ * of one diamond round (64 raster points) are evaluated together, and the arg-min keeps the reference's visiting order
+ * and strict '<' rule, so position, cost and SAD are those of the sequential search.
+ * Per PU: start_x/start_y = rcMv on entry (quarter units, before clipMv); pred2_x/pred2_y = *pIntegerMv2Nx2NPred (integer
+ * units) when flag VVCGPU_TZ_PRED2; pos_x/pos_y = pu.cu->lumaPos(); pred_hor/pred_ver = m_mvPredictor (quarter units);
+ * sub_shift = DistParam::subShift as set by RdCost::setDistParam for subShiftMode 0/2 (RdCost.cpp:256-283; mode 1 is
+ * MESEARCH_SELECTIVE only and not served); VVCGPU_TZ_EXTENDED / VVCGPU_TZ_FAST = bExtendedSettings / bFastSettings.
+ * cfg: lambda, cost_scale (2 in xMotionEstimation), imv_shift, search_range (m_iSearchRange), first_search_stop
+ * (FastMEAssumingSmootherMV), picture and CTU size for clipMv, and the rectangle of reference samples that may be read
+ * [ref_x0, ref_x1) x [ref_y0, ref_y1) in plane coordinates: the reference probes positions up to search_range / 2 beyond
+ * the clipped range (zero-neighbourhood test) and relies on the picture margin; probes are clamped to the rectangle here,
+ * so a too small margin gives a wrong SAD, never a fault.  Composite reference (JVET_K0157 inCtuSearch) and MR-SAD
+ * (weighted prediction) are not served.  results: x, y = rcMv (integer units), cost = uiBestSad, sad = ruiSAD.          */
+enum { VVCGPU_TZ_PRED2 = 1, VVCGPU_TZ_EXTENDED = 2, VVCGPU_TZ_FAST = 4 };
+typedef struct vvcgpu_tz_pu {
+  int32_t org_x, org_y, ref_x, ref_y;
+  int32_t start_x, start_y, pred2_x, pred2_y;
+  int32_t pos_x, pos_y, pred_hor, pred_ver;
+  int16_t w, h, sub_shift, flags;
+  int32_t reserved[2];                  /* sizeof == 64 */
+} vvcgpu_tz_pu;
+typedef struct vvcgpu_tz_cfg {
+  double  lambda;
+  int32_t cost_scale, imv_shift;
+  int32_t search_range, first_search_stop;
+  int32_t pic_w, pic_h, max_cu_w, max_cu_h;
+  int32_t ref_x0, ref_y0, ref_x1, ref_y1;
+} vvcgpu_tz_cfg;
+int vvcgpu_tz_search_batch(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride,
+                           const vvcgpu_tz_pu* pus, int n, const vvcgpu_tz_cfg* cfg_host,
+                           vvcgpu_search_best* results, void* stream);
 
 /* The shipped matrix [type][log2(N)-1] as N x N int16 (host copy; for the shim's table check against initROM()). */
 const int16_t* vvcgpu_tr_matrix_host(int type, int n);

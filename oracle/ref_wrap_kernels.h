@@ -569,4 +569,59 @@ int vtmref_frac_refine(const Pel* org, int os, const Pel* ref, int rs, const vvc
   return 0;
 }
 
+// ---------------------------------------------------------------------------------------------
+// Integer TZ search: the reference's own InterSearch::xTZSearch (InterSearch.cpp:1971-2252) on a PredictionUnit that
+// carries exactly what the function reads (pu.cu->lumaPos(), pu.cs->sps).  sub_shift is mapped back to the subShiftMode
+// that RdCost::setDistParam (RdCost.cpp:256-283) turns into it; a PU for which no mode gives it returns -1.
+int vtmref_tz_search(const Pel* org, int os, const Pel* ref, int rs, const vvcgpu_tz_pu* pus, int n, const vvcgpu_tz_cfg* c,
+                     int bd, vvcgpu_search_best* out)
+{
+  static InterSearch* is = nullptr;
+  static RdCost* rc = nullptr;
+  static EncCfg* cfg = nullptr;
+  static SPS* sps = nullptr;
+  static CodingStructure* cs = nullptr;
+  if (!is)
+  {
+    is = new InterSearch; rc = new RdCost; cfg = new EncCfg; sps = new SPS;
+    rc->setUseQtbt(true);
+    is->InterPrediction::init(rc, CHROMA_420);
+    is->m_pcEncCfg = cfg;
+    is->m_pcRdCost = rc;
+    cs = (CodingStructure*)calloc(1, sizeof(CodingStructure));     // only cs->sps is read
+    cs->sps = sps;
+  }
+  sps->setPicWidthInLumaSamples(c->pic_w); sps->setPicHeightInLumaSamples(c->pic_h);
+  sps->setMaxCUWidth(c->max_cu_w); sps->setMaxCUHeight(c->max_cu_h);
+  cfg->setFastMEAssumingSmootherMVEnabled(c->first_search_stop != 0);
+  is->m_iSearchRange = c->search_range;
+  is->m_lumaClpRng = mkClp(0, (1 << bd) - 1, bd);
+  rc->m_motionLambda = c->lambda;
+  rc->setCostScale(c->cost_scale);
+  for (int i = 0; i < n; i++)
+  {
+    const vvcgpu_tz_pu& p = pus[i];
+    const int mode2 = (p.h > 8 && p.w <= 64) ? 1 : 0;
+    int mode;
+    if (p.sub_shift == 0) mode = 0; else if (p.sub_shift == mode2) mode = 2; else return -1;
+    CodingUnit cu; cu.UnitArea::operator=(UnitArea(CHROMA_420, Area(p.pos_x, p.pos_y, p.w, p.h)));
+    PredictionUnit pu; pu.UnitArea::operator=(cu); pu.cu = &cu; pu.cs = cs;
+    CPelBuf patternKey(org + (ptrdiff_t)p.org_y * os + p.org_x, os, p.w, p.h);
+    InterSearch::IntTZSearchStruct st;
+    st.pcPatternKey = &patternKey;
+    st.piRefY = ref + (ptrdiff_t)p.ref_y * rs + p.ref_x;
+    st.iRefStride = rs;
+    st.imvShift = c->imv_shift;
+    st.subShiftMode = mode;
+    st.inCtuSearch = false; st.zeroMV = false;
+    rc->setPredictor(Mv(p.pred_hor, p.pred_ver));
+    Mv mv(p.start_x, p.start_y);
+    Mv pred2(p.pred2_x, p.pred2_y);
+    Distortion sad = 0;
+    is->xTZSearch(pu, st, mv, sad, (p.flags & VVCGPU_TZ_PRED2) ? &pred2 : nullptr, (p.flags & VVCGPU_TZ_EXTENDED) != 0, (p.flags & VVCGPU_TZ_FAST) != 0);
+    out[i].x = mv.getHor(); out[i].y = mv.getVer(); out[i].cost = st.uiBestSad; out[i].sad = sad;
+  }
+  return 0;
+}
+
 }  // extern "C"

@@ -100,3 +100,52 @@ def deblock_maps(rng, w, h, mode="cu"):
         for x in range(0, w, 128):
             split(x, y, 128)
     return ev, eh, qpl, qpc
+
+
+# ---- N2: integer TZ search ------------------------------------------------------------------------------------------
+TZ_PU = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4"), ("start_x", "<i4"), ("start_y", "<i4"),
+                  ("pred2_x", "<i4"), ("pred2_y", "<i4"), ("pos_x", "<i4"), ("pos_y", "<i4"), ("pred_hor", "<i4"), ("pred_ver", "<i4"),
+                  ("w", "<i2"), ("h", "<i2"), ("sub_shift", "<i2"), ("flags", "<i2"), ("reserved", "<i4", (2,))])
+TZ_CFG = np.dtype([("lambda", "<f8"), ("cost_scale", "<i4"), ("imv_shift", "<i4"), ("search_range", "<i4"), ("first_search_stop", "<i4"),
+                   ("pic_w", "<i4"), ("pic_h", "<i4"), ("max_cu_w", "<i4"), ("max_cu_h", "<i4"),
+                   ("ref_x0", "<i4"), ("ref_y0", "<i4"), ("ref_x1", "<i4"), ("ref_y1", "<i4")])
+BEST = np.dtype([("x", "<i4"), ("y", "<i4"), ("cost", "<u8"), ("sad", "<u8")])
+assert TZ_PU.itemsize == 64 and TZ_CFG.itemsize == 56 and BEST.itemsize == 24
+
+
+def tz_planes(rng, W, H, M, bd, motion=(7, -5), noise=3):
+    """ref: (H+2M) x (W+2M) blob texture (the padded reference picture); org: the picture displaced by `motion` + noise,
+    so that searches have a real optimum away from most start vectors."""
+    from scipy.ndimage import gaussian_filter
+    mx = (1 << bd) - 1
+    f = gaussian_filter(rng.normal(0, 1, (H + 2 * M, W + 2 * M)), 2.5) * 6 + gaussian_filter(rng.normal(0, 1, (H + 2 * M, W + 2 * M)), 9) * 30
+    ref = np.clip(np.rint((f * 0.12 + 0.5) * mx), 0, mx).astype(np.int16)
+    dx, dy = motion
+    org = ref[M + dy:M + dy + H, M + dx:M + dx + W].astype(np.int32) + rng.integers(-noise, noise + 1, (H, W)) * (1 << (bd - 8))
+    return np.ascontiguousarray(np.clip(org, 0, mx).astype(np.int16)), ref
+
+
+def tz_pus(rng, n, W, H, M, sizes, flags_choices=(0, 1, 2, 3, 4, 5), spread=40, sub_mode2=None):
+    pus = np.zeros(n, TZ_PU)
+    for i in range(n):
+        w, h = sizes[int(rng.integers(0, len(sizes)))]
+        x = int(rng.integers(0, (W - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, (H - h) // 4 + 1)) * 4
+        r = pus[i]
+        r["org_x"], r["org_y"], r["ref_x"], r["ref_y"], r["pos_x"], r["pos_y"] = x, y, M + x, M + y, x, y
+        far = rng.random() < 0.3
+        s = spread * 4 if far else 24
+        r["start_x"], r["start_y"] = int(rng.integers(-s, s + 1)), int(rng.integers(-s, s + 1))
+        r["pred2_x"], r["pred2_y"] = int(rng.integers(-12, 13)), int(rng.integers(-12, 13))
+        r["pred_hor"], r["pred_ver"] = int(r["start_x"]) + int(rng.integers(-8, 9)), int(r["start_y"]) + int(rng.integers(-8, 9))
+        r["w"], r["h"] = w, h
+        m2 = bool(rng.integers(0, 2)) if sub_mode2 is None else sub_mode2
+        r["sub_shift"] = 1 if (m2 and h > 8 and w <= 64) else 0
+        r["flags"] = flags_choices[int(rng.integers(0, len(flags_choices)))]
+    return pus
+
+
+def tz_cfg(W, H, M, lam, search_range=64, first_stop=0, max_cu=128, cost_scale=2, imv_shift=0):
+    c = np.zeros(1, TZ_CFG)
+    c[0] = (lam, cost_scale, imv_shift, search_range, first_stop, W, H, max_cu, max_cu, 0, 0, W + 2 * M, H + 2 * M)
+    return c

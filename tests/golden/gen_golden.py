@@ -318,8 +318,27 @@ def gen_frac():
     save("frac", **out)
 
 
+def gen_tzsearch():
+    """next row N2: the reference's own InterSearch::xTZSearch on blob-texture planes with a true displacement."""
+    rng = np.random.default_rng(1007)
+    out = {}
+    W, H, M = 192, 128, 160
+    sizes = [(8, 8), (16, 16), (32, 32), (64, 64), (128, 128), (16, 8), (8, 16), (32, 64), (4, 8), (64, 16), (128, 64), (12, 16), (24, 32)]
+    for k, (bd, motion) in enumerate([(8, (7, -5)), (10, (-21, 13))]):
+        org, ref_ = cases.tz_planes(rng, W, H, M, bd, motion)
+        out["org%d" % k], out["ref%d" % k], out["bd%d" % k] = org, ref_, np.array(bd)
+        for j, (rng_, stop) in enumerate([(64, 0), (96, 1), (8, 0)]):
+            n = 40
+            pus = cases.tz_pus(rng, n, W, H, M, sizes)
+            cfg = cases.tz_cfg(W, H, M, float(rng.uniform(4, 60)), search_range=rng_, first_stop=stop)
+            res = np.zeros(n, cases.BEST)
+            assert R.vtmref_tz_search(p(org), W, p(ref_), W + 2 * M, p(pus), n, p(cfg), bd, p(res)) == 0
+            out["pus%d_%d" % (k, j)], out["cfg%d_%d" % (k, j)], out["res%d_%d" % (k, j)] = pus, cfg, res
+    save("tzsearch", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac):
+    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac, gen_tzsearch):
         if not only or fn.__name__[4:] in only:
             fn()

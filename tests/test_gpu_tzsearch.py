@@ -1,0 +1,120 @@
+"""GPU parity: integer TZ search of whole PUs (next row N2, vvcgpu_tz_search_batch) vs the CPU oracle and the golden
+vectors of the compiled reference's own InterSearch::xTZSearch."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oraclelib import oracle, p
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(__file__), "golden")
+SIZES = [(8, 8), (16, 16), (32, 32), (64, 64), (128, 128), (16, 8), (8, 16), (32, 64), (4, 8), (64, 16), (128, 64), (12, 16), (24, 32),
+         (4, 4), (48, 64), (64, 128), (8, 64)]
+
+
+def dev(a):
+    return torch.from_numpy(a).cuda()
+
+
+def run_gpu(org, ref_, pus, cfg):
+    from vvcsoftware_vtm_amd import ops
+    assert ops.TZ_PU == cases.TZ_PU and ops.TZ_CFG == cases.TZ_CFG
+    best = ops.tz_search_batch(dev(org), dev(ref_), ops.struct_to_device(pus), len(pus), cfg)
+    torch.cuda.synchronize()
+    return best.cpu().numpy().view(cases.BEST)
+
+
+def run_oracle(org, ref_, pus, cfg):
+    got = np.zeros(len(pus), cases.BEST)
+    oracle().orc_tz_search(p(org), org.shape[1], p(ref_), ref_.shape[1], p(pus), len(pus), p(cfg), p(got))
+    return got
+
+
+def test_tz_search_golden():
+    g = np.load(os.path.join(G, "tzsearch.npz"))
+    for k in range(2):
+        org, ref_ = g["org%d" % k], g["ref%d" % k]
+        for j in range(3):
+            pus, cfg, want = np.ascontiguousarray(g["pus%d_%d" % (k, j)]), np.ascontiguousarray(g["cfg%d_%d" % (k, j)]), g["res%d_%d" % (k, j)]
+            got = run_gpu(org, ref_, pus, cfg)
+            assert np.array_equal(got, want), (k, j, np.nonzero(got != want)[0][:5])
+
+
+@pytest.mark.parametrize("bd,srange,stop", [(8, 64, 0), (10, 96, 1), (10, 32, 0), (8, 8, 1), (10, 256, 0)])
+def test_tz_search_vs_oracle(bd, srange, stop):
+    rng = np.random.default_rng(bd * 1000 + srange)
+    W, H, M = 320, 256, 160
+    org, ref_ = cases.tz_planes(rng, W, H, M, bd, motion=(int(rng.integers(-30, 31)), int(rng.integers(-30, 31))))
+    n = 300
+    pus = cases.tz_pus(rng, n, W, H, M, SIZES)
+    cfg = cases.tz_cfg(W, H, M, float(rng.uniform(4, 60)), search_range=srange, first_stop=stop)
+    want, got = run_oracle(org, ref_, pus, cfg), run_gpu(org, ref_, pus, cfg)
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:8]
+
+
+def test_tz_search_edges():
+    """PUs on every picture border with start vectors far outside (clipMv + search-range clipping), a flat block (all costs
+    tie: the visiting order decides), imv shift 2, and a margin too small for the probes (clamped reads, oracle does the same)."""
+    rng = np.random.default_rng(99)
+    W, H, M = 256, 128, 144
+    org, ref_ = cases.tz_planes(rng, W, H, M, 10, motion=(-9, 4))
+    rows = []
+    for (x, y) in [(0, 0), (W - 64, 0), (0, H - 64), (W - 64, H - 64), (W - 16, 48), (96, H - 8)]:
+        for (sx, sy) in [(-2000, -2000), (2000, 2000), (-2000, 2000), (0, 0), (37, -91)]:
+            for fl in (0, 2, 4, 1, 3):
+                w, h = (64, 64) if x % 64 == 0 and y % 64 == 0 else ((16, 16) if x == W - 16 else (32, 8))
+                rows.append((x, y, M + x, M + y, sx, sy, -300, 300, x, y, sx // 2, sy // 2, w, h, 1 if (h > 8 and w <= 64) else 0, fl, (0, 0)))
+    pus = np.array(rows, dtype=cases.TZ_PU)
+    for kw in (dict(), dict(imv_shift=2), dict(search_range=16)):
+        cfg = cases.tz_cfg(W, H, M, 23.5, **{**dict(search_range=64), **kw})
+        assert np.array_equal(run_gpu(org, ref_, pus, cfg), run_oracle(org, ref_, pus, cfg)), kw
+    # flat content: every SAD equal, MV cost and visiting order decide
+    flat_o = np.full((H, W), 512, np.int16); flat_r = np.full((H + 2 * M, W + 2 * M), 500, np.int16)
+    cfg = cases.tz_cfg(W, H, M, 40.0)
+    assert np.array_equal(run_gpu(flat_o, flat_r, pus, cfg), run_oracle(flat_o, flat_r, pus, cfg))
+    # readable rectangle smaller than the probes need: both sides clamp the read position the same way
+    cfg = cases.tz_cfg(W, H, M, 23.5)
+    cfg["ref_x0"], cfg["ref_y0"], cfg["ref_x1"], cfg["ref_y1"] = M - 4, M - 4, M + W + 4, M + H + 4
+    assert np.array_equal(run_gpu(org, ref_, pus, cfg), run_oracle(org, ref_, pus, cfg))
+
+
+def test_tz_search_full_size():
+    """bench picture size (3840x2160, every 64x64 and 16x16 PU position of a sparse grid): a random subset is checked against
+    the oracle, and every result satisfies the size-independent invariants  cost - sad == MV cost of the winner  and
+    winner inside the clipped search window around one of the start candidates."""
+    import ctypes as C
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(3)
+    W, H, M = 3840, 2160, 160
+    org, ref_ = cases.tz_planes(rng, W, H, M, 10, motion=(11, -6))
+    xs, ys = np.meshgrid(np.arange(0, W - 63, 64), np.arange(0, H - 63, 64))
+    n = xs.size
+    pus = np.zeros(2 * n, cases.TZ_PU)
+    pus["org_x"], pus["org_y"] = np.tile(xs.ravel(), 2), np.tile(ys.ravel(), 2)
+    pus["ref_x"], pus["ref_y"] = pus["org_x"] + M, pus["org_y"] + M
+    pus["pos_x"], pus["pos_y"] = pus["org_x"], pus["org_y"]
+    pus["w"][:n], pus["h"][:n], pus["sub_shift"][:n] = 64, 64, 1
+    pus["w"][n:], pus["h"][n:], pus["sub_shift"][n:] = 16, 16, 0
+    pus["start_x"], pus["start_y"] = rng.integers(-60, 61, 2 * n), rng.integers(-60, 61, 2 * n)
+    pus["pred_hor"], pus["pred_ver"] = pus["start_x"], pus["start_y"]
+    pus["flags"] = rng.integers(0, 2, 2 * n) * 2
+    cfg = cases.tz_cfg(W, H, M, 30.0, search_range=96)
+    best = ops.tz_search_batch(dev(org), dev(ref_), ops.struct_to_device(pus), 2 * n, cfg)
+    torch.cuda.synchronize()
+    got = best.cpu().numpy().view(cases.BEST)
+    pick = rng.choice(2 * n, 160, replace=False)
+    want = run_oracle(org, ref_, np.ascontiguousarray(pus[pick]), cfg)
+    assert np.array_equal(got[pick], want)
+    O = oracle()
+    O.orc_mvcost.restype = C.c_uint64
+    for i in rng.choice(2 * n, 400, replace=False):
+        m = ops.MvCost(30.0, int(pus["pred_hor"][i]), int(pus["pred_ver"][i]), 2, 0)
+        assert int(got["cost"][i]) - int(got["sad"][i]) == int(O.orc_mvcost(C.byref(m), int(got["x"][i]), int(got["y"][i])))
+    sx, sy = (pus["start_x"] + 2) >> 2, (pus["start_y"] + 2) >> 2
+    near_start = (np.abs(got["x"] - sx) <= 96) & (np.abs(got["y"] - sy) <= 96)
+    near_zero = (np.abs(got["x"]) <= 96) & (np.abs(got["y"]) <= 96)
+    assert np.all(near_start | near_zero)
+    assert np.mean((got["x"] == 11) & (got["y"] == -6)) > 0.5     # most searches find the true displacement

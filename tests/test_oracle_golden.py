@@ -234,3 +234,22 @@ def test_transform_tables_golden_and_shipped():
             # the identities the reference's 4-point fast forms rely on (TrQuant_EMT.cpp:1654-1662)
             if N == 4 and t == 2:
                 assert want[0][0] + want[0][1] == want[0][3]
+
+
+def test_tz_search_golden():
+    """next row N2: restated xTZSearch vs the compiled reference's own InterSearch::xTZSearch (position, cost, SAD)."""
+    g = load("tzsearch")
+    import cases
+    O = oracle()
+    moved = 0
+    for k in range(2):
+        org, ref_, bd = g["org%d" % k], g["ref%d" % k], int(g["bd%d" % k])
+        for j in range(3):
+            pus, cfg, want = g["pus%d_%d" % (k, j)], g["cfg%d_%d" % (k, j)], g["res%d_%d" % (k, j)]
+            assert pus.dtype == cases.TZ_PU and cfg.dtype == cases.TZ_CFG
+            got = np.zeros(len(pus), cases.BEST)
+            pus, cfg = np.ascontiguousarray(pus), np.ascontiguousarray(cfg)
+            O.orc_tz_search(p(org), org.shape[1], p(ref_), ref_.shape[1], p(pus), len(pus), p(cfg), p(got))
+            assert np.array_equal(got, want), (k, j, np.nonzero(got != want)[0][:5])
+            moved += int(np.sum((want["x"] != 0) | (want["y"] != 0)))
+    assert moved > 100      # the fixture's searches really leave the zero vector

@@ -91,6 +91,8 @@ int vvcgpu_sizeof(int id)
   case 13: return (int)sizeof(vvcgpu_dqtr_desc);
   case 14: return (int)sizeof(vvcgpu_afg_desc);
   case 15: return (int)sizeof(vvcgpu_afe_desc);
+  case 16: return (int)sizeof(vvcgpu_tz_pu);
+  case 17: return (int)sizeof(vvcgpu_tz_cfg);
   default: return -1;
   }
 }

@@ -166,6 +166,30 @@ def sad_search(org, ref, blocks_dev, nblocks, w, h, sub_shift, dx0, dy0, nx, ny,
     return sad, best
 
 
+# ---- N2: integer TZ search of whole PUs (InterSearch::xTZSearch) ---------------------------------------------
+TZ_PU = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4"), ("start_x", "<i4"), ("start_y", "<i4"),
+                  ("pred2_x", "<i4"), ("pred2_y", "<i4"), ("pos_x", "<i4"), ("pos_y", "<i4"), ("pred_hor", "<i4"), ("pred_ver", "<i4"),
+                  ("w", "<i2"), ("h", "<i2"), ("sub_shift", "<i2"), ("flags", "<i2"), ("reserved", "<i4", (2,))])
+TZ_CFG = np.dtype([("lambda", "<f8"), ("cost_scale", "<i4"), ("imv_shift", "<i4"), ("search_range", "<i4"), ("first_search_stop", "<i4"),
+                   ("pic_w", "<i4"), ("pic_h", "<i4"), ("max_cu_w", "<i4"), ("max_cu_h", "<i4"),
+                   ("ref_x0", "<i4"), ("ref_y0", "<i4"), ("ref_x1", "<i4"), ("ref_y1", "<i4")])
+assert TZ_PU.itemsize == 64 and TZ_CFG.itemsize == 56
+TZ_PRED2, TZ_EXTENDED, TZ_FAST = 1, 2, 4
+
+
+def tz_search_batch(org, ref, pus_dev, n, cfg):
+    """N2: xTZSearch for n PUs (one wavefront each).  org/ref: 2-D int16 planes (ref = the whole padded reference plane,
+    PU positions in plane coordinates); pus_dev: TZ_PU records on the device; cfg: one-element TZ_CFG numpy record (host).
+    Returns SEARCH_BEST records as a uint8 tensor: x, y (integer MV), cost (uiBestSad), sad (ruiSAD)."""
+    po, so, _, _ = _plane(org, "org")
+    pr, sr, _, _ = _plane(ref, "ref")
+    cfg = np.ascontiguousarray(cfg)
+    assert cfg.dtype == TZ_CFG and cfg.size == 1
+    best = torch.empty(n * SEARCH_BEST.itemsize, dtype=torch.uint8, device=org.device)
+    capi.call("vvcgpu_tz_search_batch", po, so, pr, sr, capi.ptr(pus_dev), n, C.c_void_p(cfg.ctypes.data), capi.ptr(best), _stream())
+    return best
+
+
 # ---- interpolation / MC / PelBuffer ops -------------------------------------------------------------
 IF_DESC = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("src_stride", "<i4"), ("dst_stride", "<i4"),
                     ("w", "<i2"), ("h", "<i2"), ("taps", "i1"), ("is_vertical", "i1"), ("is_first", "i1"),
