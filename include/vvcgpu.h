@@ -338,7 +338,8 @@ int vvcgpu_affine_equal_coeff_batch(const vvc_pel* resi_base, const int32_t* der
  * (FastMEAssumingSmootherMV), picture and CTU size for clipMv, and the rectangle of reference samples that may be read
  * [ref_x0, ref_x1) x [ref_y0, ref_y1) in plane coordinates: the reference probes positions up to search_range / 2 beyond
  * the clipped range (zero-neighbourhood test) and relies on the picture margin; probes are clamped to the rectangle here,
- * so a too small margin gives a wrong SAD, never a fault.  Composite reference (JVET_K0157 inCtuSearch) and MR-SAD
+ * so a too small margin gives a wrong SAD, never a fault; the plane allocation must extend 4 bytes beyond the rectangle's last sample
+ * (reference rows are read as aligned dwords) and reference samples must be non-negative (picture samples).  Composite reference (JVET_K0157 inCtuSearch) and MR-SAD
  * (weighted prediction) are not served.  results: x, y = rcMv (integer units), cost = uiBestSad, sad = ruiSAD.          */
 enum { VVCGPU_TZ_PRED2 = 1, VVCGPU_TZ_EXTENDED = 2, VVCGPU_TZ_FAST = 4 };
 typedef struct vvcgpu_tz_pu {
@@ -354,6 +355,8 @@ typedef struct vvcgpu_tz_cfg {
   int32_t search_range, first_search_stop;
   int32_t pic_w, pic_h, max_cu_w, max_cu_h;
   int32_t ref_x0, ref_y0, ref_x1, ref_y1;
+  int32_t wg_per_pu;                    /* 0: one wavefront per PU (PUs up to about 32x32); 1: one workgroup of four per PU   */
+  int32_t reserved;                     /* sizeof == 64 */
 } vvcgpu_tz_cfg;
 int vvcgpu_tz_search_batch(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride,
                            const vvcgpu_tz_pu* pus, int n, const vvcgpu_tz_cfg* cfg_host,

@@ -16,6 +16,8 @@
 #define TRI_SYM "_Z11xITrMxN_EMTiPKiPsmiijjihh"
 // the full integer search (FastSearch 0), called from xMotionEstimation in its own translation unit
 #define FS_SYM "_ZN11InterSearch14xPatternSearchERNS_17IntTZSearchStructER2MvRm"
+// the integer TZ search, called from xPatternSearchFast / xMotionEstimation in its own translation unit (InterSearch.cpp:1764, 1962)
+#define TZ_SYM "_ZN11InterSearch9xTZSearchERK14PredictionUnitRNS_17IntTZSearchStructER2MvRmPKS5_bb"
 // the fractional motion refinement, called from xMotionEstimation in its own translation unit (InterSearch.cpp:1816)
 #define FRAC_SYM "_ZN11InterSearch21xPatternSearchFracDIFERK14PredictionUnit10RefPicListiRNS_17IntTZSearchStructERK2MvRS6_S9_Rm"
 
@@ -37,6 +39,9 @@ void hook_frac(void* self, void* pu, int list, int refIdx, void* cStruct, void* 
 typedef void (*fs_real_t)(void*, void*, void*, void*);
 typedef int (*fs_shim_t)(void*, void*, void*, void*);
 void hook_fullsearch(void* self, void* cStruct, void* mv, void* sad) asm(FS_SYM);
+typedef void (*tz_real_t)(void*, void*, void*, void*, void*, const void*, bool, bool);
+typedef int (*tz_shim_t)(void*, void*, void*, void*, void*, const void*, bool, bool);
+void hook_tzsearch(void* self, void* pu, void* cStruct, void* mv, void* sad, const void* pred2, bool ext, bool fast) asm(TZ_SYM);
 void hook_sao_stats(void* self, void* blkStats, void* org, void* src, void* cs, bool pre) asm(SAO_SYM);
 void hook_alf_stats(void* self, void* org, void* rec) asm(ALF_SYM);
 
@@ -85,5 +90,17 @@ void hook_fullsearch(void* self, void* cStruct, void* mv, void* sad)
   static fs_real_t real = (fs_real_t)must(g_target ? dlsym(g_target, FS_SYM) : nullptr, FS_SYM);
   if (shim && shim(self, cStruct, mv, sad)) return;
   real(self, cStruct, mv, sad);
+}
+static tz_real_t tz_real() { static tz_real_t real = (tz_real_t)must(g_target ? dlsym(g_target, TZ_SYM) : nullptr, TZ_SYM); return real; }
+void hook_tzsearch(void* self, void* pu, void* cStruct, void* mv, void* sad, const void* pred2, bool ext, bool fast)
+{
+  static tz_shim_t shim = (tz_shim_t)dlsym(RTLD_DEFAULT, "vvcshim_tzsearch");
+  if (shim && shim(self, pu, cStruct, mv, sad, pred2, ext, fast)) return;
+  tz_real()(self, pu, cStruct, mv, sad, pred2, ext, fast);
+}
+// the reference's own body, for the shim's optional A/B check (VVCGPU_SHIM_TZ_VERIFY)
+void vtmhooks_real_tzsearch(void* self, void* pu, void* cStruct, void* mv, void* sad, const void* pred2, bool ext, bool fast)
+{
+  tz_real()(self, pu, cStruct, mv, sad, pred2, ext, fast);
 }
 }

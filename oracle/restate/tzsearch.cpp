@@ -15,6 +15,10 @@
 extern "C" uint64_t orc_mvcost(const vvcgpu_mvcost* m, int x, int y);
 extern "C" uint64_t orc_sad(const Pel* org, int os, const Pel* cur, int cs, int w, int h, int subShift);
 
+// visit statistics of the last orc_tz_search call (probes, rounds, raster probes) -- for the measurement notes in DESIGN.md
+static uint64_t g_stat[3];
+ORC_API void orc_tz_stats(uint64_t* out) { out[0] = g_stat[0]; out[1] = g_stat[1]; out[2] = g_stat[2]; }
+
 namespace {
 
 struct Range { int left, right, top, bottom; };
@@ -25,6 +29,7 @@ struct Tz
   const vvcgpu_tz_pu* pu; const vvcgpu_tz_cfg* cfg; vvcgpu_mvcost mc;
   Range sr;
   uint64_t bestSad; int bestX, bestY; unsigned bestDist, bestRound; int pointNr;
+  bool countRaster = false;
 
   void clip(int& hor, int& ver) const                       // Mv.cpp:64-80, quarter units
   {
@@ -39,6 +44,7 @@ struct Tz
   void probe(int x, int y, int pn, unsigned dist)             // :320-342
   {
     // the read position is clamped to the rectangle the caller declared readable (include/vvcgpu.h, N2)
+    g_stat[0]++; if (dist >= 5 && pn == 0 && countRaster) g_stat[2]++;
     const int px = clip3i(cfg->ref_x0, cfg->ref_x1 - pu->w, pu->ref_x + x), py = clip3i(cfg->ref_y0, cfg->ref_y1 - pu->h, pu->ref_y + y);
     uint64_t sad = orc_sad(org + (ptrdiff_t)pu->org_y * os + pu->org_x, os, ref + (ptrdiff_t)py * rs + px, rs, pu->w, pu->h, pu->sub_shift);
     if (sad < bestSad)
@@ -99,6 +105,7 @@ struct Tz
   void diamond(int sx, int sy, int d, bool corners)
   {
     bestRound += 1;                                            // :444
+    g_stat[1]++;
     for (int c = 0; c < 16; c++)
     {
       int x, y, pn; unsigned dd;
@@ -163,17 +170,18 @@ struct Tz
     {
       int win = raster; Range l = sr;
       if (!((int)bestDist >= raster)) { win++; l.left /= 2; l.right /= 2; l.top /= 2; l.bottom /= 2; }
-      bestDist = win;
+      bestDist = win; countRaster = true; g_stat[1]++;
       for (int y = l.top; y <= l.bottom; y += win)
         for (int x = l.left; x <= l.right; x += win) probe(x, y, 0, win);
     }
     else if ((int)bestDist >= raster)                          // :2158-2171
     {
-      bestDist = raster;
+      bestDist = raster; countRaster = true; g_stat[1]++;
       for (int y = sr.top; y <= sr.bottom; y += raster)
         for (int x = sr.left; x <= sr.right; x += raster) probe(x, y, 0, raster);
     }
 
+    countRaster = false;
     while (bestDist > 0)                                       // :2207-2241 star refinement
     {
       startX = bestX; startY = bestY; bestDist = 0; pointNr = 0;
@@ -193,6 +201,7 @@ struct Tz
 ORC_API int orc_tz_search(const Pel* org, int os, const Pel* ref, int rs, const vvcgpu_tz_pu* pus, int n, const vvcgpu_tz_cfg* cfg,
                           vvcgpu_search_best* out)
 {
+  g_stat[0] = g_stat[1] = g_stat[2] = 0;
   for (int i = 0; i < n; i++)
   {
     Tz t; t.org = org; t.os = os; t.ref = ref; t.rs = rs; t.pu = pus + i; t.cfg = cfg;

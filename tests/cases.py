@@ -108,9 +108,9 @@ TZ_PU = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y"
                   ("w", "<i2"), ("h", "<i2"), ("sub_shift", "<i2"), ("flags", "<i2"), ("reserved", "<i4", (2,))])
 TZ_CFG = np.dtype([("lambda", "<f8"), ("cost_scale", "<i4"), ("imv_shift", "<i4"), ("search_range", "<i4"), ("first_search_stop", "<i4"),
                    ("pic_w", "<i4"), ("pic_h", "<i4"), ("max_cu_w", "<i4"), ("max_cu_h", "<i4"),
-                   ("ref_x0", "<i4"), ("ref_y0", "<i4"), ("ref_x1", "<i4"), ("ref_y1", "<i4")])
+                   ("ref_x0", "<i4"), ("ref_y0", "<i4"), ("ref_x1", "<i4"), ("ref_y1", "<i4"), ("wg_per_pu", "<i4"), ("reserved", "<i4")])
 BEST = np.dtype([("x", "<i4"), ("y", "<i4"), ("cost", "<u8"), ("sad", "<u8")])
-assert TZ_PU.itemsize == 64 and TZ_CFG.itemsize == 56 and BEST.itemsize == 24
+assert TZ_PU.itemsize == 64 and TZ_CFG.itemsize == 64 and BEST.itemsize == 24
 
 
 def tz_planes(rng, W, H, M, bd, motion=(7, -5), noise=3):
@@ -145,7 +145,7 @@ def tz_pus(rng, n, W, H, M, sizes, flags_choices=(0, 1, 2, 3, 4, 5), spread=40, 
     return pus
 
 
-def tz_cfg(W, H, M, lam, search_range=64, first_stop=0, max_cu=128, cost_scale=2, imv_shift=0):
+def tz_cfg(W, H, M, lam, search_range=64, first_stop=0, max_cu=128, cost_scale=2, imv_shift=0, wg_per_pu=0):
     c = np.zeros(1, TZ_CFG)
-    c[0] = (lam, cost_scale, imv_shift, search_range, first_stop, W, H, max_cu, max_cu, 0, 0, W + 2 * M, H + 2 * M)
+    c[0] = (lam, cost_scale, imv_shift, search_range, first_stop, W, H, max_cu, max_cu, 0, 0, W + 2 * M, H + 2 * M, wg_per_pu, 0)
     return c

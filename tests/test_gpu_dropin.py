@@ -80,7 +80,7 @@ def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
     r = subprocess.run([APP, "--hip", "enc", "-c", cfg, "-i", yuv, "-wdt", str(m["w"]), "-hgt", str(m["h"]), "-fr", "30",
                         "-f", str(m["frames"]), "-q", str(m["qp"]), "--InputBitDepth=%d" % m["bd"], "--InternalBitDepth=%d" % m["bd"],
                         "--OutputBitDepth=%d" % m["bd"], "-b", binf, "-o", str(tmp_path / "rec.yuv"), "--SEIDecodedPictureHash=1"],
-                       capture_output=True, text=True, timeout=1200)
+                       capture_output=True, text=True, timeout=1200, env=dict(os.environ, VVCGPU_SHIM_TZ_VERIFY="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert md5(binf) == m["bin_md5"]
     line = [l for l in r.stderr.splitlines() if "[vvcgpu shim]" in l]
@@ -98,6 +98,8 @@ def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
         assert calls[11] > 0, line[-1]         # PelBufferOps table slots (addAvg8 / reco8 / linTf8, 64-wide calls)
         assert calls[14] > 0, line[-1]         # xPatternSearchFracDIF: the fused half/quarter refinement kernel, every inter PU
         assert calls[18] > 0 and calls[19] > 0, line[-1]   # affine gradient table slots (Sobel planes, equal coefficients)
+        assert calls[20] > 0, line[-1]         # xTZSearch: the whole integer TZ search of every PU on the device (next row N2)
+        assert "TZ mismatch" not in r.stderr, r.stderr[-2000:]
     assert calls[12] > 0 and calls[16] > 0, line[-1]   # forward transforms (32/64-side TUs); de-quantisation + inverse (every TU)
     print(line[-1])
     if name.startswith("ai_"):

@@ -20,11 +20,17 @@ def dev(a):
 
 
 def run_gpu(org, ref_, pus, cfg):
+    """both team shapes (one wavefront / one workgroup per PU) must agree; returns the result"""
     from vvcsoftware_vtm_amd import ops
     assert ops.TZ_PU == cases.TZ_PU and ops.TZ_CFG == cases.TZ_CFG
-    best = ops.tz_search_batch(dev(org), dev(ref_), ops.struct_to_device(pus), len(pus), cfg)
-    torch.cuda.synchronize()
-    return best.cpu().numpy().view(cases.BEST)
+    out = []
+    for team in (0, 1):
+        c = cfg.copy(); c["wg_per_pu"] = team
+        best = ops.tz_search_batch(dev(org), dev(ref_), ops.struct_to_device(pus), len(pus), c)
+        torch.cuda.synchronize()
+        out.append(best.cpu().numpy().view(cases.BEST))
+    assert np.array_equal(out[0], out[1]), np.nonzero(out[0] != out[1])[0][:8]
+    return out[0]
 
 
 def run_oracle(org, ref_, pus, cfg):
@@ -71,6 +77,11 @@ def test_tz_search_edges():
     for kw in (dict(), dict(imv_shift=2), dict(search_range=16)):
         cfg = cases.tz_cfg(W, H, M, 23.5, **{**dict(search_range=64), **kw})
         assert np.array_equal(run_gpu(org, ref_, pus, cfg), run_oracle(org, ref_, pus, cfg)), kw
+    # negative original samples (bi-prediction searches on 2 * org - otherPred, InterSearch.cpp:1682-1692)
+    org2 = (2 * org.astype(np.int32) - rng.integers(0, 1024, org.shape)).astype(np.int16)
+    assert org2.min() < 0
+    cfg = cases.tz_cfg(W, H, M, 23.5)
+    assert np.array_equal(run_gpu(org2, ref_, pus, cfg), run_oracle(org2, ref_, pus, cfg))
     # flat content: every SAD equal, MV cost and visiting order decide
     flat_o = np.full((H, W), 512, np.int16); flat_r = np.full((H + 2 * M, W + 2 * M), 500, np.int16)
     cfg = cases.tz_cfg(W, H, M, 40.0)

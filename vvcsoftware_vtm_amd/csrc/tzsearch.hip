@@ -9,10 +9,13 @@
 //   RdCost::getCostOfVectorWithPredictor CommonLib/RdCost.h:172-199
 //
 // Design: the search is a short, data-dependent chain of "rounds" (one probe, a diamond of <= 16 probes, two neighbours, a
-// raster of up to ~1500 probes).  One wavefront owns one PU and keeps the whole search state wave-uniform; within a round
-// the probes are independent, so the wave evaluates them together: LX lanes span a row of the block (coalesced reads),
-// 64 / LX probes run side by side, and a round becomes a 64-bit min over  cost << 16 | visiting index  -- the reference's
-// strict '<' in visiting order.  No data leaves the wave, no barrier is needed, and PUs of any size mix in one launch.
+// raster of up to ~1500 probes).  A team of lanes -- one wavefront (TEAM 1, small PUs) or one workgroup of four (TEAM 4, large
+// PUs) -- owns one PU and keeps the whole search state uniform; within a round the probes are independent, so the team
+// evaluates them together: the (sub-sampled) original block sits in LDS as packed pairs, LX = w / 4 lanes span a row with one
+// 4-sample quad each (8-byte LDS read, aligned dword reads of the reference row + v_alignbit for odd positions, two
+// v_sad_u16), RP lane groups split the rows when a round has few probes, and the remaining lanes take further probes.  A
+// round then is a 64-bit min over  cost << 16 | visiting index  -- the reference's strict '<' in visiting order.
+// PUs of any size mix in one launch; blocks that do not fit the team's LDS slice fall back to sample-wise reads.
 #include "common.h"
 
 namespace {
@@ -44,9 +47,16 @@ constexpr unsigned D1X = pack_tab(kD1X, 2, 1), D1Y = pack_tab(kD1Y, 2, 1), D8X =
 
 struct TzRange { int left, right, top, bottom; };
 
-struct TzWave
+// one round of probes: 0 single (x, y) | 1 diamond around (x, y) at distance d | 2 the two neighbours of the best point (x, y)
+// with point number d | 3 raster over `win` with step d, nx columns
+struct TzRound { int kind, n, x, y, d, corners, nx; unsigned rnx; TzRange win; };   // rnx = ceil(2^32 / nx)
+
+constexpr int TZ_LDS_DWORDS = 8192;     // 32 KB: 8 KB per wavefront (TEAM 1: 64x64 / 64x128 sub-sampled) or all of it (TEAM 4: 128x128)
+
+template <int TEAM>
+struct TzTeam
 {
-  // per PU, wave-uniform
+  // per PU, team-uniform
   const Pel* org; const Pel* ref; int os, rs;
   int w, h, subShift, refX, refY;
   int rx0, ry0, rx1, ry1;               // clamp rectangle for the block origin
@@ -54,8 +64,13 @@ struct TzWave
   double lambda; int predHor, predVer, costScale, imvShift;
   TzRange sr;
   unsigned long long bestSad; int bestX, bestY, pointNr; unsigned bestDist, bestRound;
-  // lane mapping
-  int lx, lc, LX, CP;
+  // team mapping
+  int tl;                               // lane within the team (TL = 64 * TEAM lanes)
+  int LX;                               // lanes along a row (power of two >= w / 4)
+  const unsigned* orgL;                 // LDS copy of the sub-sampled block (packed pairs, row pitch w / 2 dwords), or nullptr
+  unsigned bias;                        // 0x80008000 when the block holds negative samples (both sides are biased then)
+  unsigned long long* keyL;             // TEAM 4: one slot per wavefront
+  static constexpr int TL = 64 * TEAM;
 
   __device__ __forceinline__ void clip(int& hor, int& ver) const
   {
@@ -68,68 +83,25 @@ struct TzWave
     return (unsigned long long)(lambda * (double)bits);
   }
 
-  // this lane's share of the SAD of the probe at (x, y): columns lx, lx + LX, ... of every (1 << subShift)-th row
-  __device__ __forceinline__ unsigned partial_sad(int x, int y) const
+  // candidate c of the round: position, point number, distance; false = not visited (the nested range tests of :431-632, :349-374)
+  __device__ __forceinline__ bool candidate(const TzRound& R, int c, int& x, int& y, int& pn, unsigned& dd) const
   {
-    const int px = min(max(refX + x, rx0), rx1), py = min(max(refY + y, ry0), ry1);
-    const Pel* o = org + lx;
-    const Pel* r = ref + (ptrdiff_t)py * rs + px + lx;
-    const int ostep = os << subShift, rstep = rs << subShift, rows = h >> subShift;
-    unsigned acc = 0;
-    if (w <= LX)
+    if (R.kind == 0) { x = R.x; y = R.y; pn = 0; dd = 0; return true; }
+    if (R.kind == 3)
     {
-      if (lx < w)
-        for (int j = 0; j < rows; j++, o += ostep, r += rstep) acc += (unsigned)abs((int)o[0] - (int)r[0]);
+      const int j = R.nx > 1 ? (int)__umulhi((unsigned)c, R.rnx) : c, i = c - j * R.nx;     // exact for c, nx < 2^16
+      x = R.win.left + i * R.d; y = R.win.top + j * R.d; pn = 0; dd = (unsigned)R.d;
+      return true;
     }
-    else
+    if (R.kind == 2)
     {
-      for (int j = 0; j < rows; j++, o += ostep, r += rstep)
-        for (int k = 0; k + lx < w; k += LX) acc += (unsigned)abs((int)o[k] - (int)r[k]);
+      const int p = R.d;
+      x = R.x + (int)(((c == 0 ? P2X0 : P2X1) >> (2 * p)) & 3u) - 1;
+      y = R.y + (int)(((c == 0 ? P2Y0 : P2Y1) >> (2 * p)) & 3u) - 1;
+      pn = 0; dd = 2;
+      return x >= sr.left && x <= sr.right && y >= sr.top && y <= sr.bottom;
     }
-    return acc;
-  }
-
-  // one round: candidates 0 .. n-1 in visiting order; cand(c, x, y, pn, dd) -> visited?
-  template <class F>
-  __device__ __forceinline__ void round(int n, F cand)
-  {
-    unsigned long long key = ~0ull;
-    for (int c0 = 0; c0 < n; c0 += CP)
-    {
-      const int c = c0 + lc;
-      int x = 0, y = 0, pn = 0; unsigned dd = 0;
-      const bool valid = c < n && cand(c, x, y, pn, dd);
-      if (__ballot(valid) == 0ull) continue;
-      unsigned s = valid ? partial_sad(x, y) : 0u;
-      for (int m = 1; m < LX; m <<= 1) s += (unsigned)__shfl_xor((int)s, m);
-      if (valid)
-      {
-        const unsigned long long cost = ((unsigned long long)s << subShift) + mvcost(x, y);
-        key = min(key, (cost << 16) | (unsigned)c);
-      }
-    }
-    for (int m = LX; m < 64; m <<= 1)
-    {
-      const unsigned long long o = __shfl_xor(key, m);
-      key = min(key, o);
-    }
-    key = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(key >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)key);
-    if (key != ~0ull && (key >> 16) < bestSad)
-    {
-      int x, y, pn; unsigned dd;
-      cand((int)(key & 0xFFFFu), x, y, pn, dd);
-      bestSad = key >> 16; bestX = x; bestY = y; bestDist = dd; bestRound = 0; pointNr = pn;
-    }
-  }
-
-  __device__ __forceinline__ void probe(int x, int y)
-  {
-    round(1, [=](int, int& cx, int& cy, int& pn, unsigned& dd) { cx = x; cy = y; pn = 0; dd = 0; return true; });
-  }
-
-  // candidate c of the diamond round (sx, sy, d): the nested range tests of :431-632 in visiting order
-  __device__ __forceinline__ bool diamond_cand(int c, int sx, int sy, int d, bool corners, int& x, int& y, int& pn, unsigned& dd) const
-  {
+    const int sx = R.x, sy = R.y, d = R.d;
     bool ok;
     int ox, oy;          // direction of the candidate relative to the start: decides which range tests apply
     if (d <= 8)
@@ -140,7 +112,7 @@ struct TzWave
       {
         ox = (int)((D1X >> (2 * cc)) & 3u) - 1;
         oy = (int)((D1Y >> (2 * cc)) & 3u) - 1;
-        if (ox != 0 && oy != 0 && !corners) ok = false;
+        if (ox != 0 && oy != 0 && !R.corners) ok = false;
         x = sx + ox; y = sy + oy; pn = cc + 1; dd = 1;
       }
       else
@@ -177,33 +149,166 @@ struct TzWave
     return ok;
   }
 
-  __device__ __forceinline__ void diamond(int sx, int sy, int d, bool corners)
+  // this lane's share of the SADs of NP probes: quad lx of rows rp, rp + RP, ... of the sub-sampled block.  The NP probes share
+  // the LDS read of the original quad and keep NP x (unroll) row reads in flight.
+  template <int NP>
+  __device__ __forceinline__ void partial_sad(const int (&x)[NP], const int (&y)[NP], int lx, int rp, int RP, unsigned (&acc)[NP]) const
   {
-    bestRound += 1;
-    round(d <= 8 ? 8 : 16, [=](int c, int& x, int& y, int& pn, unsigned& dd) { return diamond_cand(c, sx, sy, d, corners, x, y, pn, dd); });
+    const int rows = h >> subShift, rstep = rs << subShift;
+#pragma unroll
+    for (int u = 0; u < NP; u++) acc[u] = 0;
+    if (orgL)
+    {
+      if (4 * lx >= w) return;
+      const int halfW = w >> 1;
+      const Pel* r[NP];
+#pragma unroll
+      for (int u = 0; u < NP; u++)
+      {
+        const int px = min(max(refX + x[u], rx0), rx1), py = min(max(refY + y[u], ry0), ry1);
+        r[u] = ref + (ptrdiff_t)py * rs + px + 4 * lx + (ptrdiff_t)rp * rstep;
+      }
+      const unsigned* o = orgL + rp * halfW + 2 * lx;
+      const ptrdiff_t rinc = (ptrdiff_t)RP * rstep; const int oinc = RP * halfW;
+      if ((rs & 1) == 0)
+      {
+        // even row pitch: a probe keeps its dword phase on every row -> aligned pointer and shift are set up once
+        const unsigned* g[NP]; unsigned sh[NP];
+#pragma unroll
+        for (int u = 0; u < NP; u++)
+        {
+          const uintptr_t a = reinterpret_cast<uintptr_t>(r[u]);
+          g[u] = reinterpret_cast<const unsigned*>(a & ~(uintptr_t)3);
+          sh[u] = (unsigned)(a & 2) << 3;
+        }
+        const ptrdiff_t ginc = rinc >> 1;
+        if (bias == 0u)
+        {
+#pragma unroll 2
+          for (int j = rp; j < rows; j += RP, o += oinc)
+          {
+            const uint2 ov = *reinterpret_cast<const uint2*>(o);
+#pragma unroll
+            for (int u = 0; u < NP; u++)
+            {
+              const unsigned g0 = g[u][0], g1 = g[u][1], g2 = sh[u] ? g[u][2] : 0u;
+              acc[u] = __builtin_amdgcn_sad_u16(ov.x, __builtin_amdgcn_alignbit(g1, g0, sh[u]), acc[u]);
+              acc[u] = __builtin_amdgcn_sad_u16(ov.y, __builtin_amdgcn_alignbit(g2, g1, sh[u]), acc[u]);
+              g[u] += ginc;
+            }
+          }
+        }
+        else
+        {
+          for (int j = rp; j < rows; j += RP, o += oinc)
+          {
+            const uint2 ov = *reinterpret_cast<const uint2*>(o);
+#pragma unroll
+            for (int u = 0; u < NP; u++)
+            {
+              const unsigned g0 = g[u][0], g1 = g[u][1], g2 = sh[u] ? g[u][2] : 0u;
+              acc[u] = __builtin_amdgcn_sad_u16(ov.x, __builtin_amdgcn_alignbit(g1, g0, sh[u]) ^ 0x80008000u, acc[u]);
+              acc[u] = __builtin_amdgcn_sad_u16(ov.y, __builtin_amdgcn_alignbit(g2, g1, sh[u]) ^ 0x80008000u, acc[u]);
+              g[u] += ginc;
+            }
+          }
+        }
+        return;
+      }
+      for (int j = rp; j < rows; j += RP, o += oinc)           // odd row pitch: the phase alternates
+      {
+        const uint2 ov = *reinterpret_cast<const uint2*>(o);
+#pragma unroll
+        for (int u = 0; u < NP; u++)
+        {
+          const uintptr_t a = reinterpret_cast<uintptr_t>(r[u]);
+          const unsigned* g = reinterpret_cast<const unsigned*>(a & ~(uintptr_t)3);
+          const unsigned sh = (unsigned)(a & 2) << 3;
+          const unsigned g0 = g[0], g1 = g[1], g2 = sh ? g[2] : 0u;
+          acc[u] = __builtin_amdgcn_sad_u16(ov.x, __builtin_amdgcn_alignbit(g1, g0, sh) ^ bias, acc[u]);
+          acc[u] = __builtin_amdgcn_sad_u16(ov.y, __builtin_amdgcn_alignbit(g2, g1, sh) ^ bias, acc[u]);
+          r[u] += rinc;
+        }
+      }
+      return;
+    }
+    // block too large for the LDS slice: sample-wise
+    const int ostep = os << subShift;
+#pragma unroll
+    for (int u = 0; u < NP; u++)
+    {
+      const int px = min(max(refX + x[u], rx0), rx1), py = min(max(refY + y[u], ry0), ry1);
+      for (int j = rp; j < rows; j += RP)
+      {
+        const Pel* o = org + (ptrdiff_t)j * ostep + 4 * lx;
+        const Pel* rr = ref + (ptrdiff_t)py * rs + px + (ptrdiff_t)j * rstep + 4 * lx;
+        for (int k = 0; k + 4 * lx < w; k += 4 * LX)
+#pragma unroll
+          for (int v = 0; v < 4; v++) acc[u] += (unsigned)abs((int)o[k + v] - (int)rr[k + v]);
+      }
+    }
   }
 
-  __device__ __forceinline__ void two_point()
+  // candidates c0 + lc + u * CPT (u < NP) of the round -> running key
+  template <int NP>
+  __device__ __forceinline__ void pass(const TzRound& R, int c0, int CPT, int G, int lc, int lx, int rp, int RP, unsigned long long& key) const
   {
-    const int p = pointNr, bx = bestX, by = bestY;
-    const TzRange r = sr;
-    round(2, [=](int c, int& x, int& y, int& pn, unsigned& dd) {
-      x = bx + (int)(((c == 0 ? P2X0 : P2X1) >> (2 * p)) & 3u) - 1;
-      y = by + (int)(((c == 0 ? P2Y0 : P2Y1) >> (2 * p)) & 3u) - 1;
-      pn = 0; dd = 2;
-      return x >= r.left && x <= r.right && y >= r.top && y <= r.bottom;
-    });
+    int x[NP], y[NP], c[NP]; bool valid[NP]; unsigned s[NP];
+    bool any = false;
+#pragma unroll
+    for (int u = 0; u < NP; u++)
+    {
+      int pn; unsigned dd;
+      c[u] = c0 + u * CPT + lc; x[u] = 0; y[u] = 0;
+      valid[u] = c[u] < R.n && candidate(R, c[u], x[u], y[u], pn, dd);
+      any |= valid[u];
+    }
+    if (__ballot(any) == 0ull) return;
+    partial_sad<NP>(x, y, lx, rp, RP, s);                   // probes that are not visited read a clamped position and are dropped
+#pragma unroll
+    for (int u = 0; u < NP; u++)
+    {
+      for (int m = 1; m < G; m <<= 1) s[u] += (unsigned)__shfl_xor((int)s[u], m);
+      if (valid[u])
+      {
+        const unsigned long long cost = ((unsigned long long)s[u] << subShift) + mvcost(x[u], y[u]);
+        key = min(key, (cost << 16) | (unsigned)c[u]);
+      }
+    }
   }
 
-  __device__ __forceinline__ void raster(TzRange l, int win)
+  __device__ __forceinline__ void round(const TzRound& R)
   {
-    if (l.right < l.left || l.bottom < l.top) return;
-    const int nx = (l.right - l.left) / win + 1, ny = (l.bottom - l.top) / win + 1;
-    round(nx * ny, [=](int c, int& x, int& y, int& pn, unsigned& dd) {
-      const int j = c / nx, i = c - j * nx;
-      x = l.left + i * win; y = l.top + j * win; pn = 0; dd = (unsigned)win;
-      return true;
-    });
+    // lanes per probe G = LX * RP: split the rows RP ways while the team has lanes to spare for this round
+    const int rows = h >> subShift, n = R.n;
+    int RP = 1;
+    while (LX * RP * 2 <= 64 && RP * 2 <= rows && LX * RP * 2 * n <= TL) RP <<= 1;
+    const int G = LX * RP, CPT = TL / G;
+    const int sub = tl & (G - 1), lx = sub & (LX - 1), rp = sub / LX, lc = tl / G;
+    unsigned long long key = ~0ull;
+    int c0 = 0;
+    for (; c0 + 4 * CPT <= n; c0 += 4 * CPT) pass<4>(R, c0, CPT, G, lc, lx, rp, RP, key);
+    for (; c0 < n; c0 += CPT) pass<1>(R, c0, CPT, G, lc, lx, rp, RP, key);
+    for (int m = G; m < 64; m <<= 1)
+    {
+      const unsigned long long o = __shfl_xor(key, m);
+      key = min(key, o);
+    }
+    if (TEAM == 4)
+    {
+      const int wave = threadIdx.x >> 6;
+      __syncthreads();                                   // the slots of the previous round have been read
+      if ((threadIdx.x & 63) == 0) keyL[wave] = key;
+      __syncthreads();
+      key = min(min(keyL[0], keyL[1]), min(keyL[2], keyL[3]));
+    }
+    key = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(key >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)key);
+    if (key != ~0ull && (key >> 16) < bestSad)
+    {
+      int x, y, pn; unsigned dd;
+      candidate(R, (int)(key & 0xFFFFu), x, y, pn, dd);
+      bestSad = key >> 16; bestX = x; bestY = y; bestDist = dd; bestRound = 0; pointNr = pn;
+    }
   }
 
   __device__ __forceinline__ void set_range(int bx, int by, int range)
@@ -216,80 +321,151 @@ struct TzWave
   }
 };
 
+template <int TEAM>
 __global__ __launch_bounds__(256) void tz_search_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
                                                         const vvcgpu_tz_pu* __restrict__ pus, int n, vvcgpu_tz_cfg cfg,
                                                         vvcgpu_search_best* __restrict__ results)
 {
-  const int lane = threadIdx.x & 63;
-  const int b = __builtin_amdgcn_readfirstlane(blockIdx.x * 4 + (threadIdx.x >> 6));
-  if (b >= n) return;
+  __shared__ unsigned orgL[TZ_LDS_DWORDS];
+  __shared__ unsigned long long keyL[4];
+  __shared__ int negL[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = __builtin_amdgcn_readfirstlane(TEAM == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave);
+  if (b >= n) return;                                          // TEAM 4: the whole workgroup leaves; TEAM 1: no barrier is used
   const vvcgpu_tz_pu pu = pus[b];
 
-  TzWave s;
+  TzTeam<TEAM> s;
   s.org = org + (ptrdiff_t)pu.org_y * os + pu.org_x; s.ref = ref; s.os = os; s.rs = rs;
   s.w = pu.w; s.h = pu.h; s.subShift = pu.sub_shift; s.refX = pu.ref_x; s.refY = pu.ref_y;
   s.rx0 = cfg.ref_x0; s.ry0 = cfg.ref_y0; s.rx1 = cfg.ref_x1 - pu.w; s.ry1 = cfg.ref_y1 - pu.h;
   s.horMax = (cfg.pic_w + 8 - pu.pos_x - 1) << 2; s.horMin = (-cfg.max_cu_w - 8 - pu.pos_x + 1) << 2;
   s.verMax = (cfg.pic_h + 8 - pu.pos_y - 1) << 2; s.verMin = (-cfg.max_cu_h - 8 - pu.pos_y + 1) << 2;
   s.lambda = cfg.lambda; s.predHor = pu.pred_hor; s.predVer = pu.pred_ver; s.costScale = cfg.cost_scale; s.imvShift = cfg.imv_shift;
-  int LX = 64; while (LX > 4 && LX > pu.w) LX >>= 1;         // lanes along a row: largest power of two <= min(w, 64), >= 4
-  if (LX > pu.w) LX = 4;
-  s.LX = LX; s.CP = 64 / LX; s.lx = lane & (LX - 1); s.lc = lane / LX;
+  s.tl = TEAM == 4 ? (int)threadIdx.x : lane;
+  int LX = 1; while (4 * LX < pu.w) LX <<= 1;                 // quads along a row, rounded up to a power of two (w <= 128 -> LX <= 32)
+  s.LX = LX;
+  s.keyL = keyL;
+
+  // the sub-sampled original block -> LDS as packed pairs (w is a multiple of 4: VVC block widths are 4, 8, 12, 16, 24, ...)
+  {
+    const int rows = pu.h >> pu.sub_shift, halfW = pu.w >> 1, ndw = rows * halfW;
+    const int slice = TEAM == 4 ? TZ_LDS_DWORDS : TZ_LDS_DWORDS / 4;
+    unsigned* dst = orgL + (TEAM == 4 ? 0 : wave * slice);
+    const bool fits = ndw <= slice && (pu.w & 3) == 0;
+    int neg = 0;
+    if (fits)
+    {
+      const int ostep = os << pu.sub_shift;
+      for (int i = s.tl; i < ndw; i += s.TL)
+      {
+        const int j = i / halfW, k = i - j * halfW;
+        const Pel* o = s.org + (ptrdiff_t)j * ostep + 2 * k;
+        const int a = o[0], c = o[1];
+        neg |= (a | c) < 0;
+        dst[i] = ((unsigned)a & 0xFFFFu) | ((unsigned)c << 16);
+      }
+    }
+    neg = __ballot(neg != 0) != 0ull;
+    if (TEAM == 4)
+    {
+      if (lane == 0) negL[wave] = neg;
+      __syncthreads();
+      neg = negL[0] | negL[1] | negL[2] | negL[3];
+    }
+    s.bias = neg ? 0x80008000u : 0u;
+    if (fits && neg)
+      for (int i = s.tl; i < ndw; i += s.TL) dst[i] ^= 0x80008000u;
+    if (TEAM == 4) __syncthreads();
+    else { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); }   // one wavefront: LDS is in order
+    s.orgL = fits ? dst : nullptr;
+  }
 
   const bool ext = (pu.flags & VVCGPU_TZ_EXTENDED) != 0, fast = (pu.flags & VVCGPU_TZ_FAST) != 0;
   const int rasterStep = fast ? 8 : 5, range = cfg.search_range;
 
   int mx = pu.start_x, my = pu.start_y;
   s.clip(mx, my); mx = (mx + 2) >> 2; my = (my + 2) >> 2;
+  int p2x = pu.pred2_x << 2, p2y = pu.pred2_y << 2;
+  s.clip(p2x, p2y); p2x = (p2x + 2) >> 2; p2y = (p2y + 2) >> 2;
   s.bestSad = ~0ull >> 16; s.bestX = s.bestY = 0; s.bestDist = 0; s.bestRound = 0; s.pointNr = 0;
   s.sr = TzRange{ 0, 0, 0, 0 };
-  s.probe(mx, my);
-  if (!fast && (mx != 0 || my != 0) && (s.bestX != 0 || s.bestY != 0)) s.probe(0, 0);
-  if (pu.flags & VVCGPU_TZ_PRED2)
-  {
-    int px = pu.pred2_x << 2, py = pu.pred2_y << 2;
-    s.clip(px, py); px = (px + 2) >> 2; py = (py + 2) >> 2;
-    if ((mx != px || my != py) && (px != s.bestX || py != s.bestY)) s.probe(px, py);
-  }
-  s.set_range(s.bestX, s.bestY, range >> (fast ? 1 : 0));
 
-  int startX = s.bestX, startY = s.bestY;
-  const bool bestCandidateZero = s.bestX == 0 && s.bestY == 0;
-  for (int d = 1; d <= range; d *= 2)
+  // xTZSearch (:1971-2252) as a state machine: every state prepares at most one round, so the probe code exists once
+  enum { START, ZERO, PRED2, RANGE, FIRST, FIRST_STOP, ZERO_NBH, TWO_POINT, RASTER, STAR_BEGIN, STAR, STAR_STOP, STAR_TWO_POINT, DONE };
+  int state = START, d = 1, startX = 0, startY = 0;
+  bool bestCandidateZero = false;
+  while (state != DONE)
   {
-    s.diamond(startX, startY, d, ext);
-    if (cfg.first_search_stop && s.bestRound >= 3) break;
-  }
-  if (ext && !bestCandidateZero)
-    for (int d = 1; d <= (range >> 1); d *= 2) s.diamond(0, 0, d, false);
-
-  if (s.bestDist == 1) { s.bestDist = 0; s.two_point(); }
-
-  if (ext)
-  {
-    int win = rasterStep; TzRange l = s.sr;
-    if (!((int)s.bestDist >= rasterStep)) { win++; l.left /= 2; l.right /= 2; l.top /= 2; l.bottom /= 2; }
-    s.bestDist = (unsigned)win;
-    s.raster(l, win);
-  }
-  else if ((int)s.bestDist >= rasterStep)
-  {
-    s.bestDist = (unsigned)rasterStep;
-    s.raster(s.sr, rasterStep);
-  }
-
-  while (s.bestDist > 0)
-  {
-    startX = s.bestX; startY = s.bestY; s.bestDist = 0; s.pointNr = 0;
-    for (int d = 1; d < range + 1; d *= 2)
+    TzRound R;
+    R.kind = 0; R.n = 0; R.x = 0; R.y = 0; R.d = 0; R.corners = 0; R.nx = 1; R.rnx = 0; R.win = s.sr;
+    switch (state)
     {
-      s.diamond(startX, startY, d, ext);
-      if (fast && s.bestRound >= 2) break;
+    case START:                                                // :2023
+      R.n = 1; R.x = mx; R.y = my; state = ZERO; break;
+    case ZERO:                                                 // :2026-2034
+      if (!fast && (mx != 0 || my != 0) && (s.bestX != 0 || s.bestY != 0)) { R.n = 1; }
+      state = PRED2; break;
+    case PRED2:                                                // :2038-2051
+      if ((pu.flags & VVCGPU_TZ_PRED2) && (mx != p2x || my != p2y) && (p2x != s.bestX || p2y != s.bestY)) { R.n = 1; R.x = p2x; R.y = p2y; }
+      state = RANGE; break;
+    case RANGE:                                                // :2052-2070
+      s.set_range(s.bestX, s.bestY, range >> (fast ? 1 : 0));
+      startX = s.bestX; startY = s.bestY; bestCandidateZero = s.bestX == 0 && s.bestY == 0; d = 1;
+      state = FIRST; break;
+    case FIRST:                                                // :2072-2088
+      if (d <= range) { s.bestRound += 1; R.kind = 1; R.n = d <= 8 ? 8 : 16; R.x = startX; R.y = startY; R.d = d; R.corners = ext; d *= 2; state = FIRST_STOP; }
+      else { d = 1; state = ZERO_NBH; }
+      break;
+    case FIRST_STOP:
+      if (cfg.first_search_stop && s.bestRound >= 3) { d = 1; state = ZERO_NBH; } else state = FIRST;
+      break;
+    case ZERO_NBH:                                             // :2111-2126 (the :2090-2109 branch is dead: both of its flags are bExtendedSettings)
+      if (ext && !bestCandidateZero && d <= (range >> 1)) { s.bestRound += 1; R.kind = 1; R.n = d <= 8 ? 8 : 16; R.d = d; d *= 2; }
+      else state = TWO_POINT;
+      break;
+    case TWO_POINT:                                            // :2129-2133
+      if (s.bestDist == 1) { s.bestDist = 0; R.kind = 2; R.n = 2; R.x = s.bestX; R.y = s.bestY; R.d = s.pointNr; }
+      state = RASTER; break;
+    case RASTER:                                               // :2136-2171
+    {
+      int step = 0; TzRange l = s.sr;
+      if (ext)
+      {
+        step = rasterStep;
+        if (!((int)s.bestDist >= rasterStep)) { step++; l.left /= 2; l.right /= 2; l.top /= 2; l.bottom /= 2; }
+      }
+      else if ((int)s.bestDist >= rasterStep) step = rasterStep;
+      if (step)
+      {
+        s.bestDist = (unsigned)step;
+        if (l.right >= l.left && l.bottom >= l.top)
+        {
+          R.kind = 3; R.d = step; R.win = l; R.nx = (l.right - l.left) / step + 1;
+          R.n = R.nx * ((l.bottom - l.top) / step + 1);
+          R.rnx = R.nx > 1 ? (unsigned)(0x100000000ull / (unsigned)R.nx) + 1u : 0u;
+        }
+      }
+      state = STAR_BEGIN; break;
     }
-    if (s.bestDist == 1) { s.bestDist = 0; if (s.pointNr != 0) s.two_point(); }
+    case STAR_BEGIN:                                           // :2207-2214
+      if (s.bestDist > 0) { startX = s.bestX; startY = s.bestY; s.bestDist = 0; s.pointNr = 0; d = 1; state = STAR; }
+      else state = DONE;
+      break;
+    case STAR:                                                 // :2215-2229
+      if (d < range + 1) { s.bestRound += 1; R.kind = 1; R.n = d <= 8 ? 8 : 16; R.x = startX; R.y = startY; R.d = d; R.corners = ext; d *= 2; state = STAR_STOP; }
+      else state = STAR_TWO_POINT;
+      break;
+    case STAR_STOP:
+      state = (fast && s.bestRound >= 2) ? STAR_TWO_POINT : STAR; break;
+    case STAR_TWO_POINT:                                       // :2231-2240
+      if (s.bestDist == 1) { s.bestDist = 0; if (s.pointNr != 0) { R.kind = 2; R.n = 2; R.x = s.bestX; R.y = s.bestY; R.d = s.pointNr; } }
+      state = STAR_BEGIN; break;
+    default: state = DONE; break;
+    }
+    if (R.n > 0) s.round(R);
   }
 
-  if (lane == 0)
+  if (s.tl == 0)
   {
     vvcgpu_search_best r;
     r.x = s.bestX; r.y = s.bestY; r.cost = s.bestSad; r.sad = s.bestSad - s.mvcost(s.bestX, s.bestY);
@@ -318,7 +494,10 @@ int vvcgpu_tz_search_batch(const vvc_pel* org, int org_stride, const vvc_pel* re
   VVC_CHECK_ARG(c.ref_x1 - c.ref_x0 >= 128 && c.ref_y1 - c.ref_y0 >= 128 && c.ref_x0 >= 0 && c.ref_y0 >= 0 && c.ref_x1 <= ref_stride,
                 "tz_search_batch: readable rectangle [%d,%d)x[%d,%d) (stride %d) must hold a 128x128 block", c.ref_x0, c.ref_x1, c.ref_y0, c.ref_y1,
                 ref_stride);
-  hipLaunchKernelGGL(tz_search_kernel, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, org, org_stride, ref, ref_stride, pus, n, c, results);
+  if (c.wg_per_pu)
+    hipLaunchKernelGGL(tz_search_kernel<4>, dim3(n), dim3(256), 0, (hipStream_t)stream, org, org_stride, ref, ref_stride, pus, n, c, results);
+  else
+    hipLaunchKernelGGL(tz_search_kernel<1>, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, org, org_stride, ref, ref_stride, pus, n, c, results);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

@@ -10,6 +10,7 @@
 // -fno-access-control); only the sample arithmetic moves to the GPU.  Compiled only where the reference headers exist
 // (oracle/Makefile, target `ref`); the C ABI of vvcgpu.h is the only interface to the device.
 // Environment: VVCGPU_SHIM=0 falls through to the reference implementation (A/B runs with one binary).
+#include <dlfcn.h>
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
@@ -77,11 +78,11 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[20] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+long g_calls[21] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
-                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld\n",
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
-                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19]); } } g_report;
+                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -933,6 +934,92 @@ extern "C" int vvcshim_fullsearch(InterSearch* self, InterSearch::IntTZSearchStr
   *ruiSAD = (Distortion)b.sad;
   self->m_cDistParam.maximumDistortionForEarlyExit = (Distortion)b.cost;    // the state the reference's loop leaves behind (:1918)
   g_calls[15]++;
+  return 1;
+}
+
+// ---- InterSearch::xTZSearch (InterSearch.cpp:1971-2252): the whole integer TZ search of one PU = vvcgpu_tz_search_batch with
+// one PU (next row N2).  Called from xPatternSearchFast / xMotionEstimation in its own translation unit -> pre-empted by
+// oracle/ref_hooks.cpp.  The window uploaded is the set of block origins the reference itself may probe: the clipMv box
+// (Mv.cpp:64-80) cut to the start candidates +- search range, plus the unclipped zero neighbourhood (:2111-2126).
+namespace {
+DevArray<vvc_pel> g_zOrg, g_zRef;
+DevArray<vvcgpu_tz_pu> g_zPu;
+DevArray<vvcgpu_search_best> g_zBest;
+}
+
+extern "C" int vvcshim_tzsearch(InterSearch* self, const PredictionUnit* pu, InterSearch::IntTZSearchStruct* cs, Mv* rcMv, Distortion* ruiSAD,
+                                const Mv* pInt2Nx2N, bool bExtended, bool bFast)
+{
+  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return 0;
+  static const long limit = getenv("VVCGPU_SHIM_TZ_LIMIT") ? atol(getenv("VVCGPU_SHIM_TZ_LIMIT")) : 0;
+  if (limit > 0 && g_calls[20] >= limit) return 0;
+  const CPelBuf& key = *cs->pcPatternKey;
+  const int w = key.width, h = key.height, bd = self->m_lumaClpRng.bd;
+  const SPS& sps = *pu->cs->sps;
+  const int range = self->m_iSearchRange;
+  if (cs->subShiftMode == 1 || w < 4 || h < 4 || w > 128 || h > 128 || range < 1 || range > 256 || rcMv->highPrec ||
+      self->m_cDistParam.useMR || self->m_cDistParam.applyWeight || sps.getSpsNext().getUseCompositeRef())
+    return 0;
+  self->m_pcRdCost->setDistParam(self->m_cDistParam, key, cs->piRefY, cs->iRefStride, bd, COMPONENT_Y, cs->subShiftMode);   // :2017
+  const int ss = self->m_cDistParam.subShift;
+  if (h & ((1 << ss) - 1)) return 0;
+  const Position pos = pu->cu->lumaPos();
+  const int picW = sps.getPicWidthInLumaSamples(), picH = sps.getPicHeightInLumaSamples(), cuW = sps.getMaxCUWidth(), cuH = sps.getMaxCUHeight();
+  // integer start candidates exactly as the kernel derives them
+  const int hMin = -cuW - 8 - pos.x + 1, hMax = picW + 8 - pos.x - 1, vMin = -cuH - 8 - pos.y + 1, vMax = picH + 8 - pos.y - 1;
+  auto clipq = [](int v, int lo, int hi) { return std::min(hi << 2, std::max(lo << 2, v)); };
+  int cx[3] = { (clipq(rcMv->getHor(), hMin, hMax) + 2) >> 2, 0, 0 }, cy[3] = { (clipq(rcMv->getVer(), vMin, vMax) + 2) >> 2, 0, 0 };
+  if (pInt2Nx2N) { cx[2] = std::min(hMax, std::max(hMin, pInt2Nx2N->getHor())); cy[2] = std::min(vMax, std::max(vMin, pInt2Nx2N->getVer())); }
+  int x0 = std::min(cx[0], std::min(cx[1], cx[2])) - range, x1 = std::max(cx[0], std::max(cx[1], cx[2])) + range;
+  int y0 = std::min(cy[0], std::min(cy[1], cy[2])) - range, y1 = std::max(cy[0], std::max(cy[1], cy[2])) + range;
+  x0 = std::max(x0, hMin); x1 = std::min(x1, hMax); y0 = std::max(y0, vMin); y1 = std::min(y1, vMax);
+  const int zr = range >> 1;                                           // zero neighbourhood, not clipped by the reference
+  x0 = std::min(x0, -zr); x1 = std::max(x1, zr); y0 = std::min(y0, -zr); y1 = std::max(y1, zr);
+  const int ww = x1 - x0 + w, wh = y1 - y0 + h, wp = (ww + 7) & ~7;
+  if (ww < 128 || wh < 128) return 0;
+  g_zOrg.reserve((size_t)w * h);
+  g_zRef.reserve((size_t)wp * wh);
+  g_zBest.reserve(1);
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_zOrg.ptr, (size_t)w * sizeof(vvc_pel), key.buf, key.stride * sizeof(Pel), (size_t)w * sizeof(Pel), h, nullptr));
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_zRef.ptr, (size_t)wp * sizeof(vvc_pel), cs->piRefY + x0 + (ptrdiff_t)y0 * cs->iRefStride,
+                             cs->iRefStride * sizeof(Pel), (size_t)ww * sizeof(Pel), wh, nullptr));
+  vvcgpu_tz_pu p;
+  memset(&p, 0, sizeof p);
+  p.ref_x = -x0; p.ref_y = -y0;                                        // window sample (0,0) is displacement (x0, y0)
+  p.start_x = rcMv->getHor(); p.start_y = rcMv->getVer();
+  if (pInt2Nx2N) { p.pred2_x = pInt2Nx2N->getHor(); p.pred2_y = pInt2Nx2N->getVer(); }
+  p.pos_x = pos.x; p.pos_y = pos.y;
+  p.pred_hor = self->m_pcRdCost->m_mvPredictor.getHor(); p.pred_ver = self->m_pcRdCost->m_mvPredictor.getVer();
+  p.w = (int16_t)w; p.h = (int16_t)h; p.sub_shift = (int16_t)ss;
+  p.flags = (int16_t)((pInt2Nx2N ? VVCGPU_TZ_PRED2 : 0) | (bExtended ? VVCGPU_TZ_EXTENDED : 0) | (bFast ? VVCGPU_TZ_FAST : 0));
+  g_zPu.upload(&p, 1);
+  vvcgpu_tz_cfg c;
+  memset(&c, 0, sizeof c);
+  c.lambda = self->m_pcRdCost->m_motionLambda; c.cost_scale = self->m_pcRdCost->m_iCostScale; c.imv_shift = cs->imvShift;
+  c.search_range = range; c.first_search_stop = self->m_pcEncCfg->getFastMEAssumingSmootherMVEnabled() ? 1 : 0;
+  c.pic_w = picW; c.pic_h = picH; c.max_cu_w = cuW; c.max_cu_h = cuH;
+  c.ref_x0 = 0; c.ref_y0 = 0; c.ref_x1 = ww; c.ref_y1 = wh;
+  c.wg_per_pu = w * h > 1024 ? 1 : 0;
+  VVCGPU(vvcgpu_tz_search_batch(g_zOrg.ptr, w, g_zRef.ptr, wp, g_zPu.ptr, 1, &c, g_zBest.ptr, nullptr));
+  vvcgpu_search_best b;
+  VVCGPU(vvcgpu_memcpy_d2h(&b, g_zBest.ptr, sizeof b, nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  if (getenv("VVCGPU_SHIM_TZ_VERIFY"))                                 // debugging aid: run the reference's own body on the same input and compare
+  {
+    typedef void (*real_t)(InterSearch*, const PredictionUnit*, InterSearch::IntTZSearchStruct*, Mv*, Distortion*, const Mv*, bool, bool);
+    static real_t real = (real_t)dlsym(RTLD_DEFAULT, "vtmhooks_real_tzsearch");
+    Mv mv2 = *rcMv; Distortion sad2 = 0;
+    if (real) real(self, pu, cs, &mv2, &sad2, pInt2Nx2N, bExtended, bFast);
+    if (mv2.getHor() != b.x || mv2.getVer() != b.y || sad2 != (Distortion)b.sad || cs->uiBestSad != (Distortion)b.cost)
+      fprintf(stderr, "[vvcgpu shim] TZ mismatch: gpu (%d,%d) cost %llu sad %llu  ref (%d,%d) cost %llu sad %llu  w %d h %d pos %d,%d start %d,%d flags %d\n",
+              b.x, b.y, (unsigned long long)b.cost, (unsigned long long)b.sad, mv2.getHor(), mv2.getVer(), (unsigned long long)cs->uiBestSad,
+              (unsigned long long)sad2, w, h, pos.x, pos.y, p.start_x, p.start_y, p.flags);
+  }
+  rcMv->set(b.x, b.y);
+  cs->uiBestSad = (Distortion)b.cost; cs->iBestX = b.x; cs->iBestY = b.y;
+  *ruiSAD = (Distortion)b.sad;
+  self->m_cDistParam.maximumDistortionForEarlyExit = (Distortion)b.cost;
+  g_calls[20]++;
   return 1;
 }
 
