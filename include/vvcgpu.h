@@ -383,6 +383,15 @@ int vvcgpu_frac_refine(const vvc_pel* org, int org_stride, const vvc_pel* ref, i
                        const vvcgpu_frac_blk* blocks, int nblocks, int w, int h, int bit_depth, int clp_min, int clp_max,
                        int use_hadamard, const vvcgpu_mvcost* mvcost_host, vvcgpu_frac_result* results, void* stream);
 
+/* N2, chained: integer TZ search followed by the fused fractional refinement (I2) of the same PUs, on one stream with no host
+ * round trip -- the device form of InterSearch::xMotionEstimation's  xPatternSearchFast -> xPatternSearchFracDIF  sequence
+ * (InterSearch.cpp:1775-1816).  All PUs of one call share w x h (the refinement kernel's rule); every PU keeps its own
+ * predictor (pred_hor / pred_ver) in both stages.  int_results as vvcgpu_tz_search_batch, frac_results as vvcgpu_frac_refine;
+ * the final vector is  (int << 2) + (half << 1) + qter  (:1813-1815).                                                     */
+int vvcgpu_me_batch(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride, const vvcgpu_tz_pu* pus, int n, int w, int h,
+                    const vvcgpu_tz_cfg* cfg_host, int bit_depth, int clp_min, int clp_max, int use_hadamard,
+                    vvcgpu_search_best* int_results, vvcgpu_frac_result* frac_results, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -129,3 +129,30 @@ def test_tz_search_full_size():
     near_zero = (np.abs(got["x"]) <= 96) & (np.abs(got["y"]) <= 96)
     assert np.all(near_start | near_zero)
     assert np.mean((got["x"] == 11) & (got["y"] == -6)) > 0.5     # most searches find the true displacement
+
+
+@pytest.mark.parametrize("w,h,had", [(16, 16, 1), (32, 32, 1), (8, 16, 0), (64, 64, 1)])
+def test_me_batch_chain(w, h, had):
+    """vvcgpu_me_batch = TZ search + fused fractional refinement on one stream, every PU with its own predictor:
+    equals the oracle's xTZSearch restatement followed by its xPatternSearchFracDIF restatement PU by PU."""
+    import ctypes as C
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(w * 100 + h)
+    W, H, M, bd = 384, 256, 160, 10
+    org, ref_ = cases.tz_planes(rng, W, H, M, bd, motion=(5, -3))
+    n = 120
+    pus = cases.tz_pus(rng, n, W, H, M, [(w, h)], flags_choices=(0, 1, 2))
+    cfg = cases.tz_cfg(W, H, M, 17.25, search_range=64)
+    best, frac = ops.me_batch(dev(org), dev(ref_), ops.struct_to_device(pus), n, w, h, cfg, bd, use_hadamard=bool(had))
+    torch.cuda.synchronize()
+    gb, gf = best.cpu().numpy().view(cases.BEST), frac.cpu().numpy().view(ops.FRAC_RESULT)
+    wb = run_oracle(org, ref_, pus, cfg)
+    assert np.array_equal(gb, wb)
+    O = oracle()
+    for i in range(n):
+        blk = np.array([(pus["org_x"][i], pus["org_y"][i], pus["ref_x"][i] + wb["x"][i], pus["ref_y"][i] + wb["y"][i], wb["x"][i], wb["y"][i])],
+                       ops.FRAC_BLK)
+        m = ops.MvCost(17.25, int(pus["pred_hor"][i]), int(pus["pred_ver"][i]), 0, 0)
+        res = np.zeros(1, ops.FRAC_RESULT)
+        O.orc_frac_refine(p(org), W, p(ref_), ref_.shape[1], p(blk), 1, w, h, bd, 0, (1 << bd) - 1, had, C.byref(m), p(res))
+        assert gf[i] == res[0], (i, gf[i], res[0])

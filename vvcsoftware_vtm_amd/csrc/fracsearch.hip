@@ -126,7 +126,8 @@ struct FracLds { short* org; short* win; short* hpl; short* pred; unsigned long 
 // gsz lanes (1 or 4 waves) cooperate on one PU; all groups of the workgroup execute the same barrier sequence.
 __global__ __launch_bounds__(256) void frac_refine_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
                                                           const vvcgpu_frac_blk* __restrict__ blocks, int nblocks, int w, int h,
-                                                          int bd, int cmin, int cmax, int useHad, vvcgpu_mvcost mv, int groups,
+                                                          int bd, int cmin, int cmax, int useHad, vvcgpu_mvcost mv,
+                                                          const int* __restrict__ preds, int groups,
                                                           int groupBytes, vvcgpu_frac_result* __restrict__ results)
 {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -149,6 +150,7 @@ __global__ __launch_bounds__(256) void frac_refine_kernel(const Pel* __restrict_
   if (active)
   {
     blk = blocks[b];
+    if (preds) { mv.pred_hor = preds[2 * b]; mv.pred_ver = preds[2 * b + 1]; }     // per-PU predictor (vvcgpu_me_batch)
     const Pel* o = org + (size_t)blk.org_y * os + blk.org_x;
     for (int i = tid; i < w * h; i += gsz) { const int y = i / w, x = i - y * w; L.org[i] = o[(size_t)y * os + x]; }
     const Pel* r0 = ref + (ptrdiff_t)(blk.ref_y - 4) * rs + blk.ref_x - 4;
@@ -479,7 +481,8 @@ __device__ __forceinline__ void f16_best(const unsigned* dist, bool quarter, con
 template <bool HAD>
 __global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
                                                      const vvcgpu_frac_blk* __restrict__ blocks, int nblocks, int bd, int cmin, int cmax,
-                                                     vvcgpu_mvcost mv, vvcgpu_frac_result* __restrict__ results)
+                                                     vvcgpu_mvcost mv, const int* __restrict__ preds,
+                                                     vvcgpu_frac_result* __restrict__ results)
 {
   __shared__ __align__(16) short winS[4][24 * 26];
   __shared__ __align__(16) short hplS[4][3][24 * 18];      // [0] integer plane, [1] half plane (17 cols), [2] quarter planes
@@ -492,6 +495,7 @@ __global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org
   short* hp8 = hplS[wave][1];
   short* hpq = hplS[wave][2];
   const vvcgpu_frac_blk blk = blocks[b];
+  if (preds) { mv.pred_hor = preds[2 * b]; mv.pred_ver = preds[2 * b + 1]; }
   const int t = lane >> 4, x = 8 * (t & 1) + (lane & 7), y0 = 8 * (t >> 1) + 4 * ((lane >> 3) & 1);
   int orgv[4];
   {
@@ -572,10 +576,11 @@ __global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org
 
 }  // namespace
 
-extern "C" int vvcgpu_frac_refine(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride,
-                                  const vvcgpu_frac_blk* blocks, int nblocks, int w, int h, int bit_depth, int clp_min,
-                                  int clp_max, int use_hadamard, const vvcgpu_mvcost* mvcost_host,
-                                  vvcgpu_frac_result* results, void* stream)
+// shared by vvcgpu_frac_refine and vvcgpu_me_batch (tzsearch.hip); preds: optional per-block MV predictors (hor, ver) on the device
+int vvcgpu_frac_refine_launch(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride,
+                              const vvcgpu_frac_blk* blocks, int nblocks, int w, int h, int bit_depth, int clp_min,
+                              int clp_max, int use_hadamard, const vvcgpu_mvcost* mvcost_host, const int* preds,
+                              vvcgpu_frac_result* results, void* stream)
 {
   VVC_CHECK_ARG(nblocks >= 0, "frac_refine: nblocks %d", nblocks);
   if (nblocks == 0) return VVCGPU_OK;
@@ -595,17 +600,26 @@ extern "C" int vvcgpu_frac_refine(const vvc_pel* org, int org_stride, const vvc_
   {
     if (use_hadamard)
       hipLaunchKernelGGL(frac16_kernel<true>, dim3(cdiv(nblocks, 4)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
-                         bit_depth, clp_min, clp_max, *mvcost_host, results);
+                         bit_depth, clp_min, clp_max, *mvcost_host, preds, results);
     else
       hipLaunchKernelGGL(frac16_kernel<false>, dim3(cdiv(nblocks, 4)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
-                         bit_depth, clp_min, clp_max, *mvcost_host, results);
+                         bit_depth, clp_min, clp_max, *mvcost_host, preds, results);
     VVC_LAUNCH_CHECK();
     return VVCGPU_OK;
   }
   if (smem > 64 * 1024)
     VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(frac_refine_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   hipLaunchKernelGGL(frac_refine_kernel, dim3(cdiv(nblocks, groups)), dim3(256), smem, st, org, org_stride, ref, ref_stride, blocks,
-                     nblocks, w, h, bit_depth, clp_min, clp_max, use_hadamard, *mvcost_host, groups, (int)groupBytes, results);
+                     nblocks, w, h, bit_depth, clp_min, clp_max, use_hadamard, *mvcost_host, preds, groups, (int)groupBytes, results);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
+}
+
+extern "C" int vvcgpu_frac_refine(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride,
+                                  const vvcgpu_frac_blk* blocks, int nblocks, int w, int h, int bit_depth, int clp_min,
+                                  int clp_max, int use_hadamard, const vvcgpu_mvcost* mvcost_host,
+                                  vvcgpu_frac_result* results, void* stream)
+{
+  return vvcgpu_frac_refine_launch(org, org_stride, ref, ref_stride, blocks, nblocks, w, h, bit_depth, clp_min, clp_max, use_hadamard,
+                                   mvcost_host, nullptr, results, stream);
 }

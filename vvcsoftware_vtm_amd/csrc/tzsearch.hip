@@ -473,6 +473,20 @@ __global__ __launch_bounds__(256) void tz_search_kernel(const Pel* __restrict__ 
   }
 }
 
+// TZ results -> the block list of the fractional refinement (reference block displaced by the integer MV, :1816) + per-PU predictors
+__global__ __launch_bounds__(256) void tz_to_frac_kernel(const vvcgpu_tz_pu* __restrict__ pus, const vvcgpu_search_best* __restrict__ best, int n,
+                                                         vvcgpu_frac_blk* __restrict__ blk, int* __restrict__ preds)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const vvcgpu_tz_pu p = pus[i];
+  const int bx = best[i].x, by = best[i].y;
+  vvcgpu_frac_blk f;
+  f.org_x = p.org_x; f.org_y = p.org_y; f.ref_x = p.ref_x + bx; f.ref_y = p.ref_y + by; f.mv_x = bx; f.mv_y = by;
+  blk[i] = f;
+  preds[2 * i] = p.pred_hor; preds[2 * i + 1] = p.pred_ver;
+}
+
 }  // namespace
 
 extern "C" {
@@ -500,6 +514,28 @@ int vvcgpu_tz_search_batch(const vvc_pel* org, int org_stride, const vvc_pel* re
     hipLaunchKernelGGL(tz_search_kernel<1>, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, org, org_stride, ref, ref_stride, pus, n, c, results);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
+}
+
+int vvcgpu_me_batch(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride, const vvcgpu_tz_pu* pus, int n, int w, int h,
+                    const vvcgpu_tz_cfg* cfg_host, int bit_depth, int clp_min, int clp_max, int use_hadamard,
+                    vvcgpu_search_best* int_results, vvcgpu_frac_result* frac_results, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "me_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(cfg_host && int_results && frac_results, "me_batch: null pointer");
+  int rc = vvcgpu_tz_search_batch(org, org_stride, ref, ref_stride, pus, n, cfg_host, int_results, stream);
+  if (rc != VVCGPU_OK) return rc;
+  hipStream_t st = (hipStream_t)stream;
+  unsigned char* scratch = static_cast<unsigned char*>(vvcgpu_scratch(st, (size_t)n * (sizeof(vvcgpu_frac_blk) + 2 * sizeof(int))));
+  if (!scratch) return VVCGPU_E_DEVICE;
+  vvcgpu_frac_blk* blk = reinterpret_cast<vvcgpu_frac_blk*>(scratch);
+  int* preds = reinterpret_cast<int*>(scratch + (size_t)n * sizeof(vvcgpu_frac_blk));
+  hipLaunchKernelGGL(tz_to_frac_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, pus, int_results, n, blk, preds);
+  VVC_LAUNCH_CHECK();
+  vvcgpu_mvcost mv;
+  mv.lambda = cfg_host->lambda; mv.pred_hor = 0; mv.pred_ver = 0; mv.cost_scale = 0; mv.imv_shift = 0;
+  return vvcgpu_frac_refine_launch(org, org_stride, ref, ref_stride, blk, n, w, h, bit_depth, clp_min, clp_max, use_hadamard, &mv, preds,
+                                   frac_results, stream);
 }
 
 }  // extern "C"

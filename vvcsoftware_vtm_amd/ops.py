@@ -190,6 +190,20 @@ def tz_search_batch(org, ref, pus_dev, n, cfg):
     return best
 
 
+def me_batch(org, ref, pus_dev, n, w, h, cfg, bit_depth, use_hadamard=True):
+    """N2 chained: TZ search + fused fractional refinement of the same PUs (xPatternSearchFast -> xPatternSearchFracDIF).
+    Returns (SEARCH_BEST uint8 tensor, FRAC_RESULT uint8 tensor)."""
+    po, so, _, _ = _plane(org, "org")
+    pr, sr, _, _ = _plane(ref, "ref")
+    cfg = np.ascontiguousarray(cfg)
+    assert cfg.dtype == TZ_CFG and cfg.size == 1
+    best = torch.empty(n * SEARCH_BEST.itemsize, dtype=torch.uint8, device=org.device)
+    frac = torch.empty(n * FRAC_RESULT.itemsize, dtype=torch.uint8, device=org.device)
+    capi.call("vvcgpu_me_batch", po, so, pr, sr, capi.ptr(pus_dev), n, w, h, C.c_void_p(cfg.ctypes.data), bit_depth, 0, (1 << bit_depth) - 1,
+              1 if use_hadamard else 0, capi.ptr(best), capi.ptr(frac), _stream())
+    return best, frac
+
+
 # ---- interpolation / MC / PelBuffer ops -------------------------------------------------------------
 IF_DESC = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("src_stride", "<i4"), ("dst_stride", "<i4"),
                     ("w", "<i2"), ("h", "<i2"), ("taps", "i1"), ("is_vertical", "i1"), ("is_first", "i1"),
