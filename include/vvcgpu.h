@@ -362,6 +362,20 @@ int vvcgpu_tz_search_batch(const vvc_pel* org, int org_stride, const vvc_pel* re
                            const vvcgpu_tz_pu* pus, int n, const vvcgpu_tz_cfg* cfg_host,
                            vvcgpu_search_best* results, void* stream);
 
+/* ---- N4 ("next" row, picture-level passes): border extension and picture hash --------------------------------------------
+ * vvcgpu_extend_border: Picture::extendPicBorder (CommonLib/Picture.cpp:996-1041) for one plane: every sample of the margin
+ *   becomes the nearest picture sample (left/right columns replicated, then whole rows replicated upwards/downwards).
+ *   plane points to sample (0,0) INSIDE the padded allocation; margins are in samples of this plane (the reference shifts the
+ *   luma margin by the chroma scale, :1010-1011).
+ * vvcgpu_picture_hash: the per-plane digests of CommonLib/PicYuvMD5.cpp -- method 1 (HASHTYPE_CRC): compCRC :83-125, CRC-16
+ *   CCITT over the low byte then (bit depth > 8) the high byte of every sample in raster order, 16 zero bits appended;
+ *   method 2 (HASHTYPE_CHECKSUM): compChecksum :143-169.  The CRC is linear over GF(2): every lane reduces 8 samples, lane and
+ *   block remainders are shifted to their position by multiplication with x^n mod P and XORed.  out: one uint32 on the device
+ *   (CRC in the low 16 bits).  method 0 (MD5, calcMD5 :181-207) is a serial chain of 64-byte blocks per plane and is NOT
+ *   offered on the device (VVCGPU_E_UNSUPPORTED).                                                                          */
+int vvcgpu_extend_border(vvc_pel* plane, int stride, int w, int h, int margin_x, int margin_y, void* stream);
+int vvcgpu_picture_hash(int method, const vvc_pel* plane, int stride, int w, int h, int bit_depth, uint32_t* out, void* stream);
+
 /* The shipped matrix [type][log2(N)-1] as N x N int16 (host copy; for the shim's table check against initROM()). */
 const int16_t* vvcgpu_tr_matrix_host(int type, int n);
 

@@ -625,3 +625,45 @@ int vtmref_tz_search(const Pel* org, int os, const Pel* ref, int rs, const vvcgp
 }
 
 }  // extern "C"
+
+// ---------------------------------------------------------------------------------------------
+// Picture-level passes (next row N4): the reference's own Picture::extendPicBorder on a real Picture, and compCRC /
+// compChecksum (PicYuvMD5.cpp).  planes in: three unpadded planes (4:2:0); out: the three padded planes, margins included.
+uint32_t compCRC(int bitdepth, const Pel* plane, uint32_t width, uint32_t height, uint32_t stride, PictureHash& digest);
+uint32_t compChecksum(int bitdepth, const Pel* plane, uint32_t width, uint32_t height, uint32_t stride, PictureHash& digest, const BitDepths&);
+extern "C" {
+int vtmref_extend_border(const Pel* y, const Pel* cb, const Pel* cr, int w, int h, int maxCU, int margin, Pel* oy, Pel* ocb, Pel* ocr)
+{
+  Picture pic;
+  pic.create(CHROMA_420, Size(w, h), maxCU, margin, true);
+  pic.cs = (CodingStructure*)calloc(1, sizeof(CodingStructure));       // extendPicBorder reads cs->area.chromaFormat only
+  const_cast<ChromaFormat&>(pic.cs->area.chromaFormat) = CHROMA_420;
+  const Pel* in[3] = { y, cb, cr }; Pel* out[3] = { oy, ocb, ocr };
+  for (int c = 0; c < 3; c++)
+  {
+    PelBuf b = pic.getRecoBuf().get(ComponentID(c));
+    for (int j = 0; j < (int)b.height; j++) memcpy(b.buf + (ptrdiff_t)j * b.stride, in[c] + (size_t)j * b.width, b.width * sizeof(Pel));
+  }
+  pic.m_bIsBorderExtended = false;
+  pic.extendPicBorder();
+  for (int c = 0; c < 3; c++)
+  {
+    PelBuf b = pic.getRecoBuf().get(ComponentID(c));
+    const int m = c ? margin >> 1 : margin, pw = b.width + 2 * m, ph = b.height + 2 * m;
+    for (int j = 0; j < ph; j++) memcpy(out[c] + (size_t)j * pw, b.buf + (ptrdiff_t)(j - m) * b.stride - m, pw * sizeof(Pel));
+  }
+  free(pic.cs); pic.cs = nullptr;
+  pic.destroy();
+  return 0;
+}
+uint32_t vtmref_crc(int bd, const Pel* plane, int stride, int w, int h)
+{
+  PictureHash d; compCRC(bd, plane, w, h, stride, d);
+  return ((uint32_t)d.hash[0] << 8) | d.hash[1];
+}
+uint32_t vtmref_checksum(int bd, const Pel* plane, int stride, int w, int h)
+{
+  PictureHash d; BitDepths bds; compChecksum(bd, plane, w, h, stride, d, bds);
+  return ((uint32_t)d.hash[0] << 24) | ((uint32_t)d.hash[1] << 16) | ((uint32_t)d.hash[2] << 8) | d.hash[3];
+}
+}

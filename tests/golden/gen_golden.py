@@ -337,8 +337,28 @@ def gen_tzsearch():
     save("tzsearch", **out)
 
 
+def gen_picture():
+    """next row N4, picture-level passes: Picture::extendPicBorder on a real Picture; compCRC / compChecksum."""
+    rng = np.random.default_rng(1008)
+    out = {}
+    for k, (w, h, bd, margin) in enumerate([(64, 32, 8, 16), (200, 120, 10, 80), (136, 72, 8, 144), (208, 120, 10, 144)]):
+        mx = (1 << bd) - 1
+        planes = [rng.integers(0, mx + 1, (h >> (c > 0), w >> (c > 0))).astype(np.int16) for c in range(3)]
+        outs = [np.zeros((pl.shape[0] + 2 * (margin >> (c > 0)), pl.shape[1] + 2 * (margin >> (c > 0))), np.int16) for c, pl in enumerate(planes)]
+        R.vtmref_extend_border(p(planes[0]), p(planes[1]), p(planes[2]), w, h, 128, margin, p(outs[0]), p(outs[1]), p(outs[2]))
+        out["meta%d" % k] = np.array([w, h, bd, margin])
+        for c in range(3):
+            out["in%d_%d" % (k, c)] = planes[c]
+            # the padded result is np.pad(mode="edge") of the input iff the reference did what the restatement says; keep a digest
+            out["padsum%d_%d" % (k, c)] = np.array([int(outs[c].astype(np.int64).sum()), int((outs[c].astype(np.int64) * np.arange(outs[c].size).reshape(outs[c].shape) % 65521).sum())])
+            assert np.array_equal(outs[c], np.pad(planes[c], margin >> (c > 0), mode="edge"))
+            out["crc%d_%d" % (k, c)] = np.array(R.vtmref_crc(bd, p(planes[c]), planes[c].shape[1], planes[c].shape[1], planes[c].shape[0]) & 0xffffffff, np.uint32)
+            out["sum%d_%d" % (k, c)] = np.array(R.vtmref_checksum(bd, p(planes[c]), planes[c].shape[1], planes[c].shape[1], planes[c].shape[0]) & 0xffffffff, np.uint32)
+    save("picture", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac, gen_tzsearch):
+    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac, gen_tzsearch, gen_picture):
         if not only or fn.__name__[4:] in only:
             fn()

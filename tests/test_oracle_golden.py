@@ -253,3 +253,23 @@ def test_tz_search_golden():
             assert np.array_equal(got, want), (k, j, np.nonzero(got != want)[0][:5])
             moved += int(np.sum((want["x"] != 0) | (want["y"] != 0)))
     assert moved > 100      # the fixture's searches really leave the zero vector
+
+
+def test_picture_passes_golden():
+    """next row N4: restated extendPicBorder / compCRC / compChecksum vs the compiled reference (Picture::extendPicBorder on a real
+    Picture: the fixture generator asserted that its output is the edge-replicated input, and stores digests of it)."""
+    g = load("picture")
+    O = oracle()
+    for k in range(4):
+        w, h, bd, margin = [int(v) for v in g["meta%d" % k]]
+        for c in range(3):
+            pl = np.ascontiguousarray(g["in%d_%d" % (k, c)])
+            m = margin >> (c > 0)
+            buf = np.full((pl.shape[0] + 2 * m, pl.shape[1] + 2 * m), -7, np.int16)
+            buf[m:m + pl.shape[0], m:m + pl.shape[1]] = pl
+            O.orc_extend_border(C.c_void_p(buf.ctypes.data + (m * buf.shape[1] + m) * 2), buf.shape[1], pl.shape[1], pl.shape[0], m, m)
+            assert np.array_equal(buf, np.pad(pl, m, mode="edge"))
+            b64 = buf.astype(np.int64)
+            assert [int(b64.sum()), int((b64 * np.arange(buf.size).reshape(buf.shape) % 65521).sum())] == [int(v) for v in g["padsum%d_%d" % (k, c)]]
+            assert (O.orc_crc(bd, p(pl), pl.shape[1], pl.shape[1], pl.shape[0]) & 0xffffffff) == int(g["crc%d_%d" % (k, c)])
+            assert (O.orc_checksum(bd, p(pl), pl.shape[1], pl.shape[1], pl.shape[0]) & 0xffffffff) == int(g["sum%d_%d" % (k, c)])

@@ -204,6 +204,26 @@ def me_batch(org, ref, pus_dev, n, w, h, cfg, bit_depth, use_hadamard=True):
     return best, frac
 
 
+# ---- N4 picture-level passes: border extension, picture hash -------------------------------------------------
+HASH_CRC, HASH_CHECKSUM = 1, 2
+
+
+def extend_border(padded, margin_x, margin_y):
+    """Picture::extendPicBorder for one plane.  padded: 2-D int16 tensor holding the picture with its margins."""
+    assert padded.dim() == 2 and padded.dtype == torch.int16 and padded.stride(1) == 1
+    h, w = padded.shape[0] - 2 * margin_y, padded.shape[1] - 2 * margin_x
+    origin = padded.data_ptr() + (margin_y * padded.stride(0) + margin_x) * 2
+    capi.call("vvcgpu_extend_border", C.c_void_p(origin), padded.stride(0), w, h, margin_x, margin_y, _stream())
+
+
+def picture_hash(method, plane, bit_depth):
+    """compCRC (method 1) / compChecksum (method 2) of one plane -> 1-element int32 tensor (device), bits as uint32."""
+    pp, sp, w, h = _plane(plane, "plane")
+    out = torch.zeros(1, dtype=torch.int32, device=plane.device)
+    capi.call("vvcgpu_picture_hash", method, pp, sp, w, h, bit_depth, capi.ptr(out), _stream())
+    return out
+
+
 # ---- interpolation / MC / PelBuffer ops -------------------------------------------------------------
 IF_DESC = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("src_stride", "<i4"), ("dst_stride", "<i4"),
                     ("w", "<i2"), ("h", "<i2"), ("taps", "i1"), ("is_vertical", "i1"), ("is_first", "i1"),
