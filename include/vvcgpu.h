@@ -42,7 +42,7 @@ int         vvcgpu_device_count(void);
 int         vvcgpu_set_device(int device);
 /* sizeof() of the parameter structs, for binding self-checks: 0 sao_ctu, 1 deblock_cfg, 2 dist_desc, 3 search_blk,
  * 4 mvcost, 5 search_best, 6 if_desc, 7 mc_desc, 8 pelop_desc, 9 pelop_cfg, 10 tr_desc, 11 frac_blk, 12 frac_result,
- * 13 dqtr_desc, 14 afg_desc, 15 afe_desc, 16 tz_pu, 17 tz_cfg; -1 for unknown ids.          */
+ * 13 dqtr_desc, 14 afg_desc, 15 afe_desc, 16 tz_pu, 17 tz_cfg, 18 intra_desc; -1 for unknown ids.          */
 int         vvcgpu_sizeof(int struct_id);
 
 /* ---- device memory helpers for host-side callers (the reference keeps pictures in host memory; the shim stages them).
@@ -375,6 +375,29 @@ int vvcgpu_tz_search_batch(const vvc_pel* org, int org_stride, const vvc_pel* re
  *   offered on the device (VVCGPU_E_UNSUPPORTED).                                                                          */
 int vvcgpu_extend_border(vvc_pel* plane, int stride, int w, int h, int margin_x, int margin_y, void* stream);
 int vvcgpu_picture_hash(int method, const vvc_pel* plane, int stride, int w, int h, int bit_depth, uint32_t* out, void* stream);
+
+/* ---- N4 ("next" row): intra sample prediction  (IntraPrediction::predIntraAng, CommonLib/IntraPrediction.cpp:251-347 =
+ *          xPredIntraPlanar :424-477 | xPredIntraDc :482-493 | xPredIntraAng :540-773 with wide-angle mapping :213-231, followed by
+ *          the simplified PDPC; optional xFilterReferenceSamples :1071-1104 in front) ---------------------------------------
+ * One descriptor per prediction block (a TU of the intra PU), any mix of sizes and modes in one call.  The caller gathers the
+ * reference samples (xFillReferenceSamples, :807-1004: availability and substitution are control logic over the coding
+ * structure) and hands them over PACKED:  refs[0] = top-left, refs[1 .. T] = the row above, refs[T + 1 .. T + L] = the column to
+ * the left, with T / L = m_topRefLength / m_leftRefLength of setReferenceArrayLengths (:233-249; vvcgpu_intra_ref_lengths).
+ * mode = PU::getFinalIntraMode (0 planar, 1 DC, 2..66 angular; the wide-angle remapping happens inside, as in the reference).
+ * filter_refs = the decision of useFilteredIntraRefSamples (:1107-1150).  w, h: powers of two 4..64 (the reference predicts per
+ * TU, <= 64; its DC divisor table g_aucLog2 ends at 128).  clp_min / clp_max: slice clip range of the component.  CCLM
+ * (predIntraChromaLM, JVET_K0190) is not built.                                                                             */
+typedef struct vvcgpu_intra_desc {
+  int64_t ref_off, dst_off;             /* samples, relative to refs_base / dst_base */
+  int32_t dst_stride;
+  int16_t w, h;
+  int8_t  mode, filter_refs;
+  int16_t reserved;
+  int32_t reserved2;                    /* sizeof == 32 */
+} vvcgpu_intra_desc;
+int vvcgpu_intra_ref_lengths(int w, int h, int* top_len, int* left_len);
+int vvcgpu_intra_pred_batch(const vvc_pel* refs_base, vvc_pel* dst_base, const vvcgpu_intra_desc* descs, int n, int clp_min, int clp_max,
+                            void* stream);
 
 /* The shipped matrix [type][log2(N)-1] as N x N int16 (host copy; for the shim's table check against initROM()). */
 const int16_t* vvcgpu_tr_matrix_host(int type, int n);

@@ -667,3 +667,57 @@ uint32_t vtmref_checksum(int bd, const Pel* plane, int stride, int w, int h)
   return ((uint32_t)d.hash[0] << 24) | ((uint32_t)d.hash[1] << 16) | ((uint32_t)d.hash[2] << 8) | d.hash[3];
 }
 }
+
+// ---------------------------------------------------------------------------------------------
+// Intra sample prediction (next row N4): the reference's own IntraPrediction::predIntraAng (mode switch + PDPC) on a luma
+// PredictionUnit whose CodingStructure carries what the function reads (sps, pcv flags, slice clip range), with the packed
+// reference samples (refs[0] top-left, refs[1..T] above, refs[T+1..T+L] left) unpacked into the 2-D predictor buffer the
+// reference uses; filter != 0 runs its xFilterReferenceSamples first and predicts from the filtered buffer.
+extern "C" {
+int vtmref_intra_ref_lengths(int w, int h, int* topLen, int* leftLen)
+{
+  static IntraPrediction ip;
+  ip.setReferenceArrayLengths(CompArea(COMPONENT_Y, CHROMA_420, Area(0, 0, w, h)));
+  *topLen = ip.m_topRefLength; *leftLen = ip.m_leftRefLength;
+  return 0;
+}
+int vtmref_intra_pred(const Pel* refs, Pel* dst, int dstStride, int w, int h, int dirMode, int clpMin, int clpMax, int bd, int filter, Pel* refsOut)
+{
+  static IntraPrediction* ip = nullptr;
+  static SPS* sps = nullptr; static Slice* slice = nullptr; static CodingStructure* cs = nullptr; static PreCalcValues* pcv = nullptr;
+  if (!ip)
+  {
+    ip = new IntraPrediction; ip->init(CHROMA_420, bd);
+    sps = new SPS; slice = new Slice;
+    sps->getSpsNext().setUseQTBT(true);
+    cs = (CodingStructure*)calloc(1, sizeof(CodingStructure));
+    pcv = (PreCalcValues*)calloc(1, sizeof(PreCalcValues));
+    const_cast<bool&>(pcv->rectCUs) = true; const_cast<bool&>(pcv->noChroma2x2) = false;
+    cs->sps = sps; cs->slice = slice; cs->pcv = pcv;
+  }
+  sps->setBitDepth(CHANNEL_TYPE_LUMA, bd);
+  slice->m_clpRngs.comp[COMPONENT_Y] = mkClp(clpMin, clpMax, bd);
+  const CompArea area(COMPONENT_Y, CHROMA_420, Area(0, 0, w, h));
+  ip->setReferenceArrayLengths(area);
+  const int T = ip->m_topRefLength, L = ip->m_leftRefLength, stride = T + 1;
+  Pel* unf = ip->m_piYuvExt[COMPONENT_Y][PRED_BUF_UNFILTERED];
+  Pel* fil = ip->m_piYuvExt[COMPONENT_Y][PRED_BUF_FILTERED];
+  for (int x = 0; x <= T; x++) unf[x] = refs[x];
+  for (int y = 1; y <= L; y++) unf[y * stride] = refs[T + y];
+  if (filter)
+  {
+    ip->xFilterReferenceSamples(unf, fil, area, *sps);
+    if (refsOut)
+    {
+      for (int x = 0; x <= T; x++) refsOut[x] = fil[x];
+      for (int y = 1; y <= L; y++) refsOut[T + y] = fil[y * stride];
+    }
+  }
+  CodingUnit cu; cu.UnitArea::operator=(UnitArea(CHROMA_420, Area(0, 0, w, h))); cu.cs = cs; cu.chromaFormat = CHROMA_420;
+  PredictionUnit pu; pu.UnitArea::operator=(cu); pu.cu = &cu; pu.cs = cs; pu.chromaFormat = CHROMA_420;
+  pu.intraDir[0] = dirMode; pu.intraDir[1] = dirMode;
+  PelBuf pred(dst, dstStride, w, h);
+  ip->predIntraAng(COMPONENT_Y, pred, pu, filter != 0);
+  return 0;
+}
+}

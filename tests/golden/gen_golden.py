@@ -357,8 +357,39 @@ def gen_picture():
     save("picture", **out)
 
 
+def gen_intra():
+    """next row N4: the reference's own IntraPrediction::predIntraAng (+ xFilterReferenceSamples) per block shape x mode."""
+    rng = np.random.default_rng(1009)
+    out = {}
+    shapes = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 16), (16, 4), (8, 32), (32, 8), (16, 64), (64, 16), (4, 64), (64, 4), (32, 16)]
+    rows, refs_all, pred_all = [], [], []
+    for si, (w, h) in enumerate(shapes):
+        t, l = C.c_int(), C.c_int()
+        R.vtmref_intra_ref_lengths(w, h, C.byref(t), C.byref(l))
+        T, L = t.value, l.value
+        modes = range(67) if w * h < 4096 else [0, 1, 2, 3, 10, 18, 19, 34, 49, 50, 58, 66]
+        for mode in modes:
+            bd = 8 if (mode + si) % 3 == 0 else 10
+            mx = (1 << bd) - 1
+            kind = (mode + si) % 3
+            if kind == 0:
+                refs = rng.integers(0, mx + 1, T + L + 1).astype(np.int16)
+            elif kind == 1:
+                refs = np.clip(np.cumsum(rng.integers(-6, 7, T + L + 1)) + mx // 2, 0, mx).astype(np.int16)
+            else:
+                refs = rng.choice(np.array([0, mx], np.int16), T + L + 1)
+            filt = (mode + si) & 1
+            pred = np.zeros((h, w), np.int16)
+            R.vtmref_intra_pred(p(refs), p(pred), w, w, h, mode, 0, mx, bd, filt, None)
+            rows.append((w, h, mode, bd, filt, T, L, sum(len(r) for r in refs_all), sum(x.size for x in pred_all)))
+            refs_all.append(refs); pred_all.append(pred.reshape(-1))
+    out["rows"] = np.array(rows, np.int64)
+    out["refs"] = np.concatenate(refs_all); out["pred"] = np.concatenate(pred_all)
+    save("intra", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac, gen_tzsearch, gen_picture):
+    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac, gen_tzsearch, gen_picture, gen_intra):
         if not only or fn.__name__[4:] in only:
             fn()

@@ -273,3 +273,25 @@ def test_picture_passes_golden():
             assert [int(b64.sum()), int((b64 * np.arange(buf.size).reshape(buf.shape) % 65521).sum())] == [int(v) for v in g["padsum%d_%d" % (k, c)]]
             assert (O.orc_crc(bd, p(pl), pl.shape[1], pl.shape[1], pl.shape[0]) & 0xffffffff) == int(g["crc%d_%d" % (k, c)])
             assert (O.orc_checksum(bd, p(pl), pl.shape[1], pl.shape[1], pl.shape[0]) & 0xffffffff) == int(g["sum%d_%d" % (k, c)])
+
+
+def test_intra_pred_golden():
+    """next row N4: restated predIntraAng (planar / DC / angular incl. wide angles, PDPC, reference filter) vs the compiled reference."""
+    g = load("intra")
+    O = oracle()
+    refs_all, pred_all = g["refs"], g["pred"]
+    seen = set()
+    for (w, h, mode, bd, filt, T, L, ro, po) in g["rows"]:
+        t, l = C.c_int(), C.c_int()
+        O.orc_intra_ref_lengths(int(w), int(h), C.byref(t), C.byref(l))
+        assert (t.value, l.value) == (T, L)
+        refs = np.ascontiguousarray(refs_all[ro:ro + T + L + 1])
+        if filt:
+            f = np.zeros_like(refs)
+            O.orc_intra_filter_refs(p(refs), p(f), int(w), int(h))
+            refs = f
+        pred = np.zeros((h, w), np.int16)
+        O.orc_intra_pred(p(refs), p(pred), int(w), int(w), int(h), int(mode), 0, (1 << int(bd)) - 1)
+        assert np.array_equal(pred.reshape(-1), pred_all[po:po + w * h]), (w, h, mode, bd, filt)
+        seen.add(int(mode))
+    assert seen == set(range(67))

@@ -1,0 +1,199 @@
+// intra.hip -- intra sample predictors (next row N4) for gfx950: planar, DC, 65 angular modes with wide-angle mapping, the
+// simplified PDPC, and the [1 2 1] reference sample filter.
+//
+// Reference behaviour reproduced (bit-exact):
+//   IntraPrediction::predIntraAng (mode switch + PDPC, JVET_K0063)   CommonLib/IntraPrediction.cpp:251-347
+//   xGetPredValDc :173-211, getWideAngle / setReferenceArrayLengths :213-249, xPredIntraPlanar :424-477,
+//   xPredIntraAng :540-773 (linear interpolation iff deltaFract != 0, angular PDPC), xFilterReferenceSamples :1071-1104
+//
+// Design: the reference walks rows with running sums and early `break`s; every prediction sample is in fact a closed form of
+// (x, y) and a handful of reference samples, so one wavefront takes one PU, stages the <= 257 reference samples (optionally
+// filtered) and the projected main reference in LDS, and every lane computes samples independently, iterating in destination
+// order so that stores coalesce for horizontal modes too.  Four PUs per workgroup, no workgroup barrier.
+#include "common.h"
+
+namespace {
+
+__constant__ short kAng[27]    = { 0, 1, 2, 3, 5, 7, 9, 11, 13, 15, 17, 19, 21, 23, 26, 29, 32, 35, 39, 45, 49, 54, 60, 68, 79, 93, 114 };
+__constant__ short kInvAng[27] = { 0, 8192, 4096, 2731, 1638, 1170, 910, 745, 630, 546, 482, 431, 390, 356, 315, 282, 256, 234, 210, 182, 167, 152, 137, 120,
+                                   104, 88, 72 };
+enum { PLANAR = 0, DC = 1, HOR = 18, DIA = 34, VER = 50, VDIA = 66 };
+
+constexpr int REF_MAX = 160;            // >= longest side reference + 2 (2 * 64 + 22 + 1)
+constexpr int NEG_MAX = 64;             // projected samples left of the main reference
+
+__device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
+__device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
+
+__global__ __launch_bounds__(256) void intra_pred_kernel(const Pel* __restrict__ refsBase, Pel* __restrict__ dstBase,
+                                                         const vvcgpu_intra_desc* __restrict__ descs, int n, int clpMin, int clpMax)
+{
+  __shared__ short topS[4][REF_MAX], leftS[4][REF_MAX], tmpS[4][2 * REF_MAX], mainS[4][NEG_MAX + REF_MAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= n) return;                                       // no workgroup barrier below
+  const vvcgpu_intra_desc d = descs[b];
+  const int w = d.w, h = d.h, mode = d.mode;
+  const int log2W = ilog2(w), log2H = ilog2(h);
+  int T = w << 1, L = h << 1;                               // setReferenceArrayLengths :233-249
+  {
+    const int ratio = min(2, abs(log2W - log2H));
+    if (w > h) L += (w >> ratio) - h + ((w + 31) >> 5);
+    else if (h > w) T += (h >> ratio) - w + ((h + 31) >> 5);
+  }
+  short* top = topS[wave];                                  // top[0] = top-left, top[1 + x]
+  short* left = leftS[wave];                                // left[0] = top-left, left[1 + y]
+  const Pel* refs = refsBase + d.ref_off;
+  if (!d.filter_refs)
+  {
+    for (int i = lane; i <= T; i += 64) top[i] = refs[i];
+    for (int i = lane; i <= L; i += 64) left[i] = i == 0 ? refs[0] : refs[T + i];
+  }
+  else
+  {
+    // regular reference sample filter along the chain  left[L] .. left[1], top-left, top[1] .. top[T]; the two ends stay
+    short* c = tmpS[wave];                                  // chain position L + i for top[i], L - i for left[i]
+    for (int i = lane; i <= T + L; i += 64) c[i] = i <= L ? (i == L ? refs[0] : refs[T + (L - i)]) : refs[i - L];
+    wave_sync();
+    for (int i = lane; i <= T + L; i += 64)
+    {
+      const int v = (i == 0 || i == T + L) ? c[i] : (c[i - 1] + 2 * c[i] + c[i + 1] + 2) >> 2;
+      if (i <= L) left[L - i] = (short)v;
+      if (i >= L) top[i - L] = (short)v;
+    }
+  }
+  wave_sync();
+
+  Pel* dst = dstBase + d.dst_off;
+  const int ds = d.dst_stride, count = w * h;
+  const int scale = (log2W - 2 + log2H - 2 + 2) >> 2;
+  const int topLeft = top[0];
+
+  if (mode == PLANAR || mode == DC)
+  {
+    int dc = 0;
+    if (mode == DC)                                         // :173-211
+    {
+      int sum = 0;
+      if (w >= h) for (int i = lane; i < w; i += 64) sum += top[1 + i];
+      if (w <= h) for (int i = lane; i < h; i += 64) sum += left[1 + i];
+#pragma unroll
+      for (int m = 1; m < 64; m <<= 1) sum += __shfl_xor(sum, m);
+      const int denom = (w == h) ? (w << 1) : max(w, h);
+      dc = (short)((sum + (denom >> 1)) >> ilog2(denom));
+    }
+    const int bottomLeft = left[h + 1], topRight = top[w + 1];
+    for (int i = lane; i < count; i += 64)
+    {
+      const int y = i >> log2W, x = i & (w - 1);
+      const int l = left[y + 1], t = top[x + 1];
+      const int wT = 32 >> min(31, (y << 1) >> scale), wL = 32 >> min(31, (x << 1) >> scale);
+      int v;
+      if (mode == PLANAR)                                   // :424-477 + PDPC :293-307
+      {
+        const int horPred = (l << log2W) + (x + 1) * (topRight - l), vertPred = (t << log2H) + (y + 1) * (bottomLeft - t);
+        const int p = (short)(((horPred << log2H) + (vertPred << log2W) + count) >> (1 + log2W + log2H));
+        v = (wL * l + wT * t + (64 - wL - wT) * p + 32) >> 6;
+      }
+      else                                                  // PDPC :308-323
+      {
+        const int wTL = (wL >> 4) + (wT >> 4);
+        v = (wL * l + wT * t - wTL * topLeft + (64 - wL - wT + wTL) * dc + 32) >> 6;
+      }
+      dst[(ptrdiff_t)y * ds + x] = (Pel)min(max(v, clpMin), clpMax);
+    }
+    return;
+  }
+
+  // angular :545-773
+  int predMode = mode;                                      // getWideAngle :213-231
+  {
+    const int modeShift = (min(2, abs(log2W - log2H)) << 2) + 2;
+    if (w > h && predMode < 2 + modeShift) predMode += VDIA - 1;
+    else if (h > w && predMode > VDIA - modeShift) predMode -= VDIA - 1;
+  }
+  const bool isVer = predMode >= DIA;
+  const int angMode = isVer ? predMode - VER : -(predMode - HOR);
+  const int absAngMode = abs(angMode);
+  const int invAngle = kInvAng[absAngMode], angle = (angMode < 0 ? -1 : 1) * (int)kAng[absAngMode];
+  const short* mainR = isVer ? top : left;                  // index 0 = top-left
+  const short* sideR = isVer ? left : top;
+  const int H = isVer ? h : w, log2Wm = isVer ? log2W : log2H;   // block in the orientation of the main reference
+  const int sideLen = isVer ? L : T;
+  short* mainX = mainS[wave] + NEG_MAX;                     // main reference with the projected extension to the left (:588-609)
+  if (angle < 0)
+  {
+    const int mainLen = (isVer ? w : h) + 1;
+    for (int i = lane; i <= mainLen; i += 64) mainX[i] = mainR[i];
+    const int lowest = (H * angle) >> 5;                    // k runs -1 ... > lowest
+    for (int k = -1 - lane; k > lowest; k -= 64) mainX[k] = sideR[(128 + (-k) * invAngle) >> 8];
+    wave_sync();
+    mainR = mainX;
+  }
+  const bool pdpcCorner = predMode == 2 || predMode == VDIA;
+  const bool pdpcNear = !pdpcCorner && ((predMode >= VDIA - 8) || (predMode <= 2 + 8));
+  const bool pdpcHV = angle == 0;                           // HOR / VER: PDPC of predIntraAng :324-346
+  for (int i = lane; i < count; i += 64)
+  {
+    const int dy = i >> log2W, dx = i & (w - 1);
+    const int x = isVer ? dx : dy, y = isVer ? dy : dx;     // coordinates in the orientation of the main reference
+    const int deltaPos = (y + 1) * angle, deltaInt = deltaPos >> 5, deltaFract = deltaPos & 31;
+    int v;
+    if (deltaFract) v = (short)(((32 - deltaFract) * mainR[x + deltaInt + 1] + deltaFract * mainR[x + deltaInt + 2] + 16) >> 5);
+    else v = mainR[x + deltaInt + 1];
+    if (pdpcHV)
+    {
+      // in destination coordinates: HOR uses the row above, VER the column to the left
+      if (mode == HOR) { const int wT = 32 >> min(31, (dy << 1) >> scale); v = (wT * top[dx + 1] - wT * topLeft + 64 * v + 32) >> 6; }
+      else             { const int wL = 32 >> min(31, (dx << 1) >> scale); v = (wL * left[dy + 1] - wL * topLeft + 64 * v + 32) >> 6; }
+      v = min(max(v, clpMin), clpMax);
+    }
+    else if (pdpcCorner)                                    // :697-711
+    {
+      const int wT = 16 >> min(31, (y << 1) >> scale), wL = 16 >> min(31, (x << 1) >> scale);
+      if (wT + wL != 0)
+      {
+        const int c = x + y + 1;
+        const int l = wL != 0 ? sideR[c + 1] : 0, t = wT != 0 ? mainR[c + 1] : 0;
+        v = min(max((wL * l + wT * t + (64 - wL - wT) * v + 32) >> 6, clpMin), clpMax);
+      }
+    }
+    else if (pdpcNear)                                      // :717-743
+    {
+      const int deltaPos0 = (2 + (x + 1) * invAngle) >> 2, deltaFrac0 = deltaPos0 & 63, deltay = y + (deltaPos0 >> 6) + 1;
+      const int wL = 32 >> min(31, (x << 1) >> scale);
+      if (deltay <= sideLen - 1 && wL != 0)
+      {
+        const int l = (short)(((64 - deltaFrac0) * sideR[deltay] + deltaFrac0 * sideR[deltay + 1] + 32) >> 6);
+        v = min(max((wL * l + (64 - wL) * v + 32) >> 6, clpMin), clpMax);
+      }
+    }
+    (void)log2Wm;
+    dst[(ptrdiff_t)dy * ds + dx] = (Pel)v;
+  }
+}
+
+}  // namespace
+
+extern "C" int vvcgpu_intra_ref_lengths(int w, int h, int* top_len, int* left_len)
+{
+  VVC_CHECK_ARG(top_len && left_len && w >= 4 && h >= 4 && w <= 64 && h <= 64 && !(w & (w - 1)) && !(h & (h - 1)), "intra_ref_lengths: %dx%d", w, h);
+  int lw = 0, lh = 0; while ((1 << (lw + 1)) <= w) lw++; while ((1 << (lh + 1)) <= h) lh++;
+  const int ratio = abs(lw - lh) < 2 ? abs(lw - lh) : 2;
+  *left_len = h << 1; *top_len = w << 1;
+  if (w > h) *left_len += (w >> ratio) - h + ((w + 31) >> 5);
+  else if (h > w) *top_len += (h >> ratio) - w + ((h + 31) >> 5);
+  return VVCGPU_OK;
+}
+
+extern "C" int vvcgpu_intra_pred_batch(const vvc_pel* refs_base, vvc_pel* dst_base, const vvcgpu_intra_desc* descs, int n, int clp_min,
+                                       int clp_max, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "intra_pred_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(refs_base && dst_base && descs, "intra_pred_batch: null pointer");
+  VVC_CHECK_ARG(clp_min <= clp_max && clp_min >= -32768 && clp_max <= 32767, "intra_pred_batch: clip range %d..%d", clp_min, clp_max);
+  hipLaunchKernelGGL(intra_pred_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, refs_base, dst_base, descs, n, clp_min, clp_max);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}

@@ -93,6 +93,7 @@ int vvcgpu_sizeof(int id)
   case 15: return (int)sizeof(vvcgpu_afe_desc);
   case 16: return (int)sizeof(vvcgpu_tz_pu);
   case 17: return (int)sizeof(vvcgpu_tz_cfg);
+  case 18: return (int)sizeof(vvcgpu_intra_desc);
   default: return -1;
   }
 }

@@ -224,6 +224,23 @@ def picture_hash(method, plane, bit_depth):
     return out
 
 
+# ---- N4 intra sample prediction ----------------------------------------------------------------------------
+INTRA_DESC = np.dtype([("ref_off", "<i8"), ("dst_off", "<i8"), ("dst_stride", "<i4"), ("w", "<i2"), ("h", "<i2"), ("mode", "i1"),
+                       ("filter_refs", "i1"), ("reserved", "<i2"), ("reserved2", "<i4")])
+assert INTRA_DESC.itemsize == 32
+
+
+def intra_ref_lengths(w, h):
+    t, l = C.c_int(), C.c_int()
+    capi.call("vvcgpu_intra_ref_lengths", w, h, C.byref(t), C.byref(l))
+    return t.value, l.value
+
+
+def intra_pred_batch(refs_base, dst_base, descs_dev, n, clp=(0, 1023)):
+    """N4: IntraPrediction::predIntraAng for n blocks (packed reference samples in, prediction blocks out)."""
+    capi.call("vvcgpu_intra_pred_batch", capi.ptr(refs_base), capi.ptr(dst_base), capi.ptr(descs_dev), n, clp[0], clp[1], _stream())
+
+
 # ---- interpolation / MC / PelBuffer ops -------------------------------------------------------------
 IF_DESC = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("src_stride", "<i4"), ("dst_stride", "<i4"),
                     ("w", "<i2"), ("h", "<i2"), ("taps", "i1"), ("is_vertical", "i1"), ("is_first", "i1"),
