@@ -17,7 +17,7 @@ namespace {
 
 constexpr unsigned CRC_POLY = 0x1021u;
 
-__device__ __forceinline__ unsigned gf_mul(unsigned a, unsigned b)       // a * b mod P, 16-bit operands
+__host__ __device__ inline unsigned gf_mul(unsigned a, unsigned b)       // a * b mod P, 16-bit operands
 {
   unsigned r = 0;
 #pragma unroll
@@ -28,9 +28,9 @@ __device__ __forceinline__ unsigned gf_mul(unsigned a, unsigned b)       // a * 
   }
   return r;
 }
-__device__ __forceinline__ unsigned gf_xpow(unsigned long long n)        // x^n mod P
+__host__ __device__ inline unsigned gf_pow(unsigned base, unsigned long long n)   // base^n mod P
 {
-  unsigned r = 1, b = 2;                                                  // b = x
+  unsigned r = 1, b = base;
   while (n)
   {
     if (n & 1ull) r = gf_mul(r, b);
@@ -43,8 +43,12 @@ __device__ __forceinline__ unsigned gf_xpow(unsigned long long n)        // x^n 
 constexpr int CRC_SPL = 8;                    // samples per lane and step
 constexpr int CRC_BLOCK = 64 * CRC_SPL;       // samples per wavefront and step
 
-__global__ __launch_bounds__(256) void crc_kernel(const Pel* __restrict__ plane, int stride, int w, int h, int bps, int blocksPerWave,
-                                                  unsigned* __restrict__ out)
+struct CrcConsts { unsigned laneBase, blockShift, waveBase, initTerm; };   // x^(bits of 8 samples), x^(bits of a block), x^(bits of a wavefront's blocks), 0xffff * x^(8N+16)
+
+// The message is padded IN FRONT with zero samples up to nWaves * blocksPerWave blocks (a zero register stays zero on zero
+// input), so every wavefront owns exactly blocksPerWave blocks and its share is shifted by a power of one constant.
+__global__ __launch_bounds__(256) void crc_kernel(const Pel* __restrict__ plane, int stride, int w, int h, int bps, int blocksPerWave, int nWaves,
+                                                  CrcConsts k, int vec, unsigned* __restrict__ out)
 {
   __shared__ unsigned short tab[256];                     // tab[v] = v * x^16 mod P
   {
@@ -53,46 +57,62 @@ __global__ __launch_bounds__(256) void crc_kernel(const Pel* __restrict__ plane,
     tab[threadIdx.x] = (unsigned short)v;
   }
   __syncthreads();
-  const long long N = (long long)w * h;
-  const long long nBlocks = (N + CRC_BLOCK - 1) / CRC_BLOCK;
-  const long long pad = nBlocks * CRC_BLOCK - N;          // virtual zero samples in front: they leave a zero register at zero
   const int lane = threadIdx.x & 63;
-  const long long wave = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
-  const long long b0 = wave * blocksPerWave, b1 = min(nBlocks, b0 + blocksPerWave);
-  if (b0 >= nBlocks) return;
-  const unsigned laneShift = gf_xpow((unsigned long long)8 * bps * CRC_SPL * (63 - lane));     // moves the lane's bytes to their place in the block
-  const unsigned blockShift = gf_xpow((unsigned long long)8 * bps * CRC_BLOCK);
+  const int wave = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (wave >= nWaves) return;
+  const long long N = (long long)w * h;
+  const long long pad = (long long)nWaves * blocksPerWave * CRC_BLOCK - N;
+  const unsigned laneShift = gf_pow(k.laneBase, (unsigned)(63 - lane));      // moves the lane's bytes to their place in the block
   unsigned acc = 0;                                       // register of this wavefront's blocks so far (lane-uniform)
-  for (long long b = b0; b < b1; b++)
+  for (int bi = 0; bi < blocksPerWave; bi++)
   {
-    const long long v0 = b * CRC_BLOCK + (long long)lane * CRC_SPL - pad;      // first real sample index of the lane (may be < 0)
-    unsigned s = 0;
-    long long i = v0;
-    int y = 0, x = 0;
-    if (i >= 0) { y = (int)(i / w); x = (int)(i - (long long)y * w); }
-#pragma unroll
-    for (int k = 0; k < CRC_SPL; k++, i++)
+    const long long blockEnd = ((long long)wave * blocksPerWave + bi + 1) * CRC_BLOCK - pad;
+    if (blockEnd <= 0) continue;                          // wholly inside the padding: contributes zero to a zero register
+    const long long v0 = blockEnd - CRC_BLOCK + (long long)lane * CRC_SPL;     // first sample index of the lane (may be < 0)
+    unsigned pel[CRC_SPL];
+    if (vec)                                              // w, stride multiples of 8, 16-byte aligned plane: the 8 samples are one aligned uint4
     {
-      unsigned pel = 0;
-      if (i >= 0)
+      uint4 q = make_uint4(0, 0, 0, 0);
+      if (v0 >= 0)
       {
-        pel = (unsigned short)plane[(size_t)y * stride + x];
-        if (++x == w) { x = 0; y++; }
+        const int y = (int)(v0 / w), x = (int)(v0 - (long long)y * w);
+        q = *reinterpret_cast<const uint4*>(plane + (size_t)y * stride + x);
       }
-      else if (i == -1) { y = 0; x = 0; }
-      s = (((s << 8) | (pel & 0xFFu)) ^ tab[s >> 8]) & 0xFFFFu;
-      if (bps == 2) s = (((s << 8) | (pel >> 8)) ^ tab[s >> 8]) & 0xFFFFu;
+      pel[0] = q.x & 0xFFFFu; pel[1] = q.x >> 16; pel[2] = q.y & 0xFFFFu; pel[3] = q.y >> 16;
+      pel[4] = q.z & 0xFFFFu; pel[5] = q.z >> 16; pel[6] = q.w & 0xFFFFu; pel[7] = q.w >> 16;
+    }
+    else
+    {
+      long long i = v0;
+      int y = 0, x = 0;
+      if (i >= 0) { y = (int)(i / w); x = (int)(i - (long long)y * w); }
+#pragma unroll
+      for (int j = 0; j < CRC_SPL; j++, i++)
+      {
+        pel[j] = 0;
+        if (i >= 0)
+        {
+          pel[j] = (unsigned short)plane[(size_t)y * stride + x];
+          if (++x == w) { x = 0; y++; }
+        }
+      }
+    }
+    unsigned s = 0;
+#pragma unroll
+    for (int j = 0; j < CRC_SPL; j++)
+    {
+      s = (((s << 8) | (pel[j] & 0xFFu)) ^ tab[s >> 8]) & 0xFFFFu;
+      if (bps == 2) s = (((s << 8) | (pel[j] >> 8)) ^ tab[s >> 8]) & 0xFFFFu;
     }
     s = gf_mul(s, laneShift);
 #pragma unroll
     for (int m = 1; m < 64; m <<= 1) s ^= (unsigned)__shfl_xor((int)s, m);
-    acc = gf_mul(acc, blockShift) ^ s;
+    acc = gf_mul(acc, k.blockShift) ^ s;
   }
   if (lane == 0)
   {
-    const unsigned long long bytesAfter = (unsigned long long)(nBlocks - b1) * CRC_BLOCK * bps;
-    unsigned r = gf_mul(acc, gf_xpow(8ull * bytesAfter + 16ull));
-    if (wave == 0) r ^= gf_mul(0xFFFFu, gf_xpow(8ull * (unsigned long long)N * bps + 16ull));     // the 0xffff start value
+    unsigned r = gf_mul(gf_mul(acc, gf_pow(k.waveBase, (unsigned)(nWaves - 1 - wave))), CRC_POLY);    // * x^16: the appended zero bits
+    if (wave == 0) r ^= k.initTerm;                       // the 0xffff start value, shifted through the whole message
     atomicXor(out, r);
   }
 }
@@ -100,13 +120,15 @@ __global__ __launch_bounds__(256) void crc_kernel(const Pel* __restrict__ plane,
 __global__ __launch_bounds__(256) void checksum_kernel(const Pel* __restrict__ plane, int stride, int w, int h, int twoBytes,
                                                        unsigned* __restrict__ out)
 {
+  __shared__ unsigned part[4];
   unsigned sum = 0;
-  for (int y = blockIdx.y; y < h; y += gridDim.y)
+  for (int y = blockIdx.x; y < h; y += gridDim.x)
   {
     const Pel* row = plane + (size_t)y * stride;
-    for (int x = blockIdx.x * 256 + threadIdx.x; x < w; x += gridDim.x * 256)
+    const unsigned ym = (unsigned)(y & 0xff) ^ (unsigned)(y >> 8);
+    for (int x = threadIdx.x; x < w; x += 256)
     {
-      const unsigned mask = ((unsigned)(x & 0xff) ^ (unsigned)(y & 0xff) ^ (unsigned)(x >> 8) ^ (unsigned)(y >> 8)) & 0xFFu;   // uint8_t xor_mask (:150)
+      const unsigned mask = ((unsigned)(x & 0xff) ^ (unsigned)(x >> 8) ^ ym) & 0xFFu;     // uint8_t xor_mask (:150)
       const int pel = row[x];
       sum += (unsigned)((pel & 0xff) ^ (int)mask);
       if (twoBytes) sum += (unsigned)((pel >> 8) ^ (int)mask);
@@ -114,7 +136,9 @@ __global__ __launch_bounds__(256) void checksum_kernel(const Pel* __restrict__ p
   }
 #pragma unroll
   for (int m = 1; m < 64; m <<= 1) sum += (unsigned)__shfl_xor((int)sum, m);
-  if ((threadIdx.x & 63) == 0) atomicAdd(out, sum);
+  if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = sum;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(out, part[0] + part[1] + part[2] + part[3]);
 }
 
 // every margin sample = nearest picture sample; one thread per margin sample, rows of the padded plane
@@ -161,17 +185,23 @@ int vvcgpu_picture_hash(int method, const vvc_pel* plane, int stride, int w, int
   VVC_HIP(hipMemsetAsync(out, 0, sizeof(uint32_t), st));
   if (method == 1)
   {
+    const int bps = bit_depth > 8 ? 2 : 1;
     const long long N = (long long)w * h, nBlocks = (N + CRC_BLOCK - 1) / CRC_BLOCK;
-    // ~2048 wavefronts fill the chip; fewer for small planes
-    long long waves = nBlocks < 2048 ? nBlocks : 2048;
+    // ~1024 wavefronts (one per SIMD); fewer for small planes
+    long long waves = nBlocks < 1024 ? nBlocks : 1024;
     const int bpw = (int)((nBlocks + waves - 1) / waves);
     waves = (nBlocks + bpw - 1) / bpw;
-    hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, plane, stride, w, h, bit_depth > 8 ? 2 : 1, bpw, out);
+    CrcConsts k;
+    k.laneBase = gf_pow(2u, 8ull * bps * CRC_SPL);
+    k.blockShift = gf_pow(2u, 8ull * bps * CRC_BLOCK);
+    k.waveBase = gf_pow(k.blockShift, (unsigned long long)bpw);
+    k.initTerm = gf_mul(0xFFFFu, gf_pow(2u, 8ull * (unsigned long long)N * bps + 16ull));
+    const int vec = (w % 8 == 0 && stride % 8 == 0 && (reinterpret_cast<uintptr_t>(plane) & 15) == 0) ? 1 : 0;
+    hipLaunchKernelGGL(crc_kernel, dim3((unsigned)((waves + 3) / 4)), dim3(256), 0, st, plane, stride, w, h, bps, bpw, (int)waves, k, vec, out);
   }
   else
   {
-    const int gy = h < 1024 ? h : 1024;
-    hipLaunchKernelGGL(checksum_kernel, dim3(cdiv(w, 1024) > 0 ? cdiv(w, 1024) : 1, gy), dim3(256), 0, st, plane, stride, w, h, bit_depth > 8 ? 1 : 0, out);
+    hipLaunchKernelGGL(checksum_kernel, dim3(h < 1024 ? h : 1024), dim3(256), 0, st, plane, stride, w, h, bit_depth > 8 ? 1 : 0, out);
   }
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
