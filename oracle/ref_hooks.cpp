@@ -18,6 +18,9 @@
 #define FS_SYM "_ZN11InterSearch14xPatternSearchERNS_17IntTZSearchStructER2MvRm"
 // the integer TZ search, called from xPatternSearchFast / xMotionEstimation in its own translation unit (InterSearch.cpp:1764, 1962)
 #define TZ_SYM "_ZN11InterSearch9xTZSearchERK14PredictionUnitRNS_17IntTZSearchStructER2MvRmPKS5_bb"
+// the picture hashes, called from calcAndPrintHashStatus in their own translation unit (PicYuvMD5.cpp:228-240) and from the encoder's SEI writer
+#define CRC_SYM "_Z7calcCRCRK7UnitBufIKsER11PictureHashRK9BitDepths"
+#define SUM_SYM "_Z12calcChecksumRK7UnitBufIKsER11PictureHashRK9BitDepths"
 // the fractional motion refinement, called from xMotionEstimation in its own translation unit (InterSearch.cpp:1816)
 #define FRAC_SYM "_ZN11InterSearch21xPatternSearchFracDIFERK14PredictionUnit10RefPicListiRNS_17IntTZSearchStructERK2MvRS6_S9_Rm"
 
@@ -42,6 +45,10 @@ void hook_fullsearch(void* self, void* cStruct, void* mv, void* sad) asm(FS_SYM)
 typedef void (*tz_real_t)(void*, void*, void*, void*, void*, const void*, bool, bool);
 typedef int (*tz_shim_t)(void*, void*, void*, void*, void*, const void*, bool, bool);
 void hook_tzsearch(void* self, void* pu, void* cStruct, void* mv, void* sad, const void* pred2, bool ext, bool fast) asm(TZ_SYM);
+typedef unsigned (*hash_real_t)(const void*, void*, const void*);
+typedef int (*hash_shim_t)(int, const void*, void*, const void*);
+unsigned hook_crc(const void* pic, void* digest, const void* bitDepths) asm(CRC_SYM);
+unsigned hook_checksum(const void* pic, void* digest, const void* bitDepths) asm(SUM_SYM);
 void hook_sao_stats(void* self, void* blkStats, void* org, void* src, void* cs, bool pre) asm(SAO_SYM);
 void hook_alf_stats(void* self, void* org, void* rec) asm(ALF_SYM);
 
@@ -102,5 +109,19 @@ void hook_tzsearch(void* self, void* pu, void* cStruct, void* mv, void* sad, con
 void vtmhooks_real_tzsearch(void* self, void* pu, void* cStruct, void* mv, void* sad, const void* pred2, bool ext, bool fast)
 {
   tz_real()(self, pu, cStruct, mv, sad, pred2, ext, fast);
+}
+unsigned hook_crc(const void* pic, void* digest, const void* bitDepths)
+{
+  static hash_shim_t shim = (hash_shim_t)dlsym(RTLD_DEFAULT, "vvcshim_pichash");
+  static hash_real_t real = (hash_real_t)must(g_target ? dlsym(g_target, CRC_SYM) : nullptr, CRC_SYM);
+  if (shim) { const int n = shim(1, pic, digest, bitDepths); if (n) return (unsigned)n; }
+  return real(pic, digest, bitDepths);
+}
+unsigned hook_checksum(const void* pic, void* digest, const void* bitDepths)
+{
+  static hash_shim_t shim = (hash_shim_t)dlsym(RTLD_DEFAULT, "vvcshim_pichash");
+  static hash_real_t real = (hash_real_t)must(g_target ? dlsym(g_target, SUM_SYM) : nullptr, SUM_SYM);
+  if (shim) { const int n = shim(2, pic, digest, bitDepths); if (n) return (unsigned)n; }
+  return real(pic, digest, bitDepths);
 }
 }

@@ -27,6 +27,9 @@ CLIPS = [
     # all-intra 8-bit: the encoder switches ALF on, so the ALF filter table slots run inside the encoder as well
     ("ldpfs_208x120_10b_q32", "@tests/golden/bitstreams/test_fullsearch.cfg", 208, 120, 10, 2, 32, 20261007),
     ("ai_416x240_8b_q37own", "@tests/golden/bitstreams/test_intra.cfg", 416, 240, 8, 1, 37, 20261004),
+    # picture hash SEI of type CRC (2) / checksum (3) instead of MD5: the hash kernels run inside the reference encoder and decoder
+    ("ldpcrc_208x120_10b_q32", "@tests/golden/bitstreams/test_lowdelay.cfg", 208, 120, 10, 2, 32, 20261008, 2),
+    ("aisum_208x120_8b_q37", "@tests/golden/bitstreams/test_intra.cfg", 208, 120, 8, 1, 37, 20261009, 3),
 ]
 
 
@@ -34,22 +37,27 @@ def md5(path):
     return hashlib.md5(open(path, "rb").read()).hexdigest()
 
 
-def enc_args(name, cfg, w, h, bd, n, qp, yuv, binf, rec):
+def enc_args(name, cfg, w, h, bd, n, qp, yuv, binf, rec, hash_type=1):
     cfgpath = os.path.join(ROOT, cfg[1:]) if cfg.startswith("@") else os.path.join(CFG, cfg)
     return ["-c", cfgpath, "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30", "-f", str(n), "-q", str(qp),
             "--InputBitDepth=%d" % bd, "--InternalBitDepth=%d" % bd, "--OutputBitDepth=%d" % bd, "-b", binf, "-o", rec,
-            "--SEIDecodedPictureHash=1"]
+            "--SEIDecodedPictureHash=%d" % hash_type]
 
 
 def main():
     os.makedirs(OUT, exist_ok=True)
-    man = {}
-    for (name, cfg, w, h, bd, n, qp, seed) in CLIPS:
+    mpath = os.path.join(OUT, "manifest.json")
+    only = sys.argv[1:]
+    man = json.load(open(mpath)) if only and os.path.exists(mpath) else {}
+    for clip in CLIPS:
+        (name, cfg, w, h, bd, n, qp, seed), hash_type = clip[:8], (clip[8] if len(clip) > 8 else 1)
+        if only and name not in only:
+            continue
         yuv = "/tmp/%s.yuv" % name
         synth.write_yuv(yuv, synth.gen_yuv(w, h, n, bd, seed), bd)
         binf = os.path.join(OUT, name + ".bin")
         rec = "/tmp/%s_rec.yuv" % name
-        args = enc_args(name, cfg, w, h, bd, n, qp, yuv, binf, rec)
+        args = enc_args(name, cfg, w, h, bd, n, qp, yuv, binf, rec, hash_type)
         subprocess.check_call([APP, "enc"] + args, stdout=open("/tmp/%s_enc.log" % name, "w"))
         dec = "/tmp/%s_dec.yuv" % name
         out = subprocess.check_output([APP, "dec", "-b", binf, "-o", dec, "-d", str(bd)], text=True)
@@ -57,8 +65,10 @@ def main():
         assert md5(dec) == md5(rec)
         man[name] = {"cfg": cfg, "w": w, "h": h, "bd": bd, "frames": n, "qp": qp, "seed": seed,
                      "bin_md5": md5(binf), "dec_yuv_md5": md5(dec), "bytes": os.path.getsize(binf)}
+        if hash_type != 1:
+            man[name]["hash"] = hash_type
         print(name, man[name])
-    json.dump(man, open(os.path.join(OUT, "manifest.json"), "w"), indent=1, sort_keys=True)
+    json.dump(man, open(mpath, "w"), indent=1, sort_keys=True)
 
 
 if __name__ == "__main__":

@@ -49,6 +49,11 @@ def test_decoder_inloop_chain_on_gpu(name, tmp_path):
     assert line, r.stderr[-1000:]
     calls = [int(x) for x in line[-1].replace(",", " ").split() if x.isdigit()]
     assert calls[0] >= m["frames"]            # one deblocking call per picture
+    assert calls[21] > 0, line[-1]            # IntraPrediction::predIntraAng of the intra TUs ran on the GPU (next row N4)
+    if m["frames"] > 1:
+        assert calls[22] > 0, line[-1]        # Picture::extendPicBorder of the reference pictures
+    if m.get("hash", 1) != 1:
+        assert calls[23] >= m["frames"], line[-1]   # the CRC / checksum that produced every (OK) above came from vvcgpu_picture_hash
 
 
 @needs_ref
@@ -64,7 +69,7 @@ def test_decoder_fallthrough_matches(tmp_path):
 
 
 @needs_ref
-@pytest.mark.parametrize("name", ["ldp_208x120_10b_q27", "ai_416x240_8b_q37own", "ldpfs_208x120_10b_q32"])
+@pytest.mark.parametrize("name", ["ldp_208x120_10b_q27", "ai_416x240_8b_q37own", "ldpfs_208x120_10b_q32", "ldpcrc_208x120_10b_q32", "aisum_208x120_8b_q37"])
 def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
     """the reference ENCODER with deblocking, the SAO statistics (getStatistics) and the ALF covariances
     (deriveStatsForFiltering), the per-CTU SAO offsetting (offsetCTU) and the three ALF table slots computed on the GPU inside its loop: every SAO / ALF decision and therefore the bitstream must be
@@ -79,7 +84,7 @@ def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
     binf = str(tmp_path / "out.bin")
     r = subprocess.run([APP, "--hip", "enc", "-c", cfg, "-i", yuv, "-wdt", str(m["w"]), "-hgt", str(m["h"]), "-fr", "30",
                         "-f", str(m["frames"]), "-q", str(m["qp"]), "--InputBitDepth=%d" % m["bd"], "--InternalBitDepth=%d" % m["bd"],
-                        "--OutputBitDepth=%d" % m["bd"], "-b", binf, "-o", str(tmp_path / "rec.yuv"), "--SEIDecodedPictureHash=1"],
+                        "--OutputBitDepth=%d" % m["bd"], "-b", binf, "-o", str(tmp_path / "rec.yuv"), "--SEIDecodedPictureHash=%d" % m.get("hash", 1)],
                        capture_output=True, text=True, timeout=1200, env=dict(os.environ, VVCGPU_SHIM_TZ_VERIFY="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert md5(binf) == m["bin_md5"]
@@ -90,9 +95,9 @@ def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
     # per-CTU SAO offsetCTU, and the ALF table slots (m_filter5x5Blk / m_filter7x7Blk / m_deriveClassificationBlk) installed
     # where the reference installs its SIMD functions
     assert calls[5] > 0 and calls[7] > 0, line[-1]
-    if name.startswith("ldpfs_"):
+    if name.startswith("ldpfs_") :
         assert calls[15] > 0, line[-1]         # xPatternSearch: full search = vvcgpu_sad_search with the fused arg-min
-    if name.startswith("ldp_"):
+    if name.startswith("ldp_") or name.startswith("ldpcrc_"):
         assert calls[8] > 0 and calls[17] > 0, line[-1]   # RdCost table slots DF_SAD64 and DF_SSE64 (64-wide blocks) ran on the GPU
         assert calls[10] > 0, line[-1]         # InterpolationFilter table slots (64-wide calls) ran on the GPU
         assert calls[11] > 0, line[-1]         # PelBufferOps table slots (addAvg8 / reco8 / linTf8, 64-wide calls)
@@ -101,6 +106,11 @@ def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
         assert calls[20] > 0, line[-1]         # xTZSearch: the whole integer TZ search of every PU on the device (next row N2)
         assert "TZ mismatch" not in r.stderr, r.stderr[-2000:]
     assert calls[12] > 0 and calls[16] > 0, line[-1]   # forward transforms (32/64-side TUs); de-quantisation + inverse (every TU)
+    assert calls[21] > 0, line[-1]             # predIntraAng: every intra mode candidate of the first calls (capped, VVCGPU_SHIM_INTRA_LIMIT)
+    if m["frames"] > 1:
+        assert calls[22] > 0, line[-1]         # extendPicBorder of every reference picture
+    if m.get("hash", 1) != 1:
+        assert calls[23] >= m["frames"], line[-1]   # the hash SEI payload itself was computed by vvcgpu_picture_hash
     print(line[-1])
     if name.startswith("ai_"):
         assert calls[6] > 0, line[-1]          # on this clip the encoder enables ALF: the filter table slots ran

@@ -31,6 +31,7 @@
 #include "EncoderLib/InterSearch.h"
 #include "EncoderLib/EncCfg.h"
 #include "CommonLib/TrQuant.h"
+#include "CommonLib/IntraPrediction.h"
 #include "CommonLib/DepQuant.h"
 #include "CommonLib/AffineGradientSearch.h"
 #include "vvcgpu.h"
@@ -63,6 +64,13 @@ void real_offsetCTU(SampleAdaptiveOffset*, const UnitArea&, const CPelUnitBuf&, 
 void wrap_offsetCTU(SampleAdaptiveOffset*, const UnitArea&, const CPelUnitBuf&, PelUnitBuf&, SAOBlkParam&, CodingStructure&)
   asm("__wrap__ZN20SampleAdaptiveOffset9offsetCTUERK8UnitAreaRK7UnitBufIKsERS3_IsER11SAOBlkParamR15CodingStructure");
 
+void real_predIntraAng(IntraPrediction*, const ComponentID, PelBuf&, const PredictionUnit&, const bool)
+  asm("__real__ZN15IntraPrediction12predIntraAngE11ComponentIDR7AreaBufIsERK14PredictionUnitb");
+void wrap_predIntraAng(IntraPrediction*, const ComponentID, PelBuf&, const PredictionUnit&, const bool)
+  asm("__wrap__ZN15IntraPrediction12predIntraAngE11ComponentIDR7AreaBufIsERK14PredictionUnitb");
+void real_extendPicBorder(Picture*) asm("__real__ZN7Picture15extendPicBorderEv");
+void wrap_extendPicBorder(Picture*) asm("__wrap__ZN7Picture15extendPicBorderEv");
+
 // The two encoder-statistics entry points are called from inside their own translation unit, where ld --wrap does not reach;
 // those calls go through the PLT (the objects are -fPIC), so oracle/ref_hooks.cpp, loaded ahead of this library, pre-empts the
 // symbols and asks the two functions below first (1 = done on the GPU, 0 = run the reference's own body).
@@ -78,11 +86,11 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[21] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+long g_calls[24] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
-                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld\n",
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld, IntraPred %ld, Border %ld, Hash %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
-                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20]); } } g_report;
+                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20], g_calls[21], g_calls[22], g_calls[23]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -1021,6 +1029,100 @@ extern "C" int vvcshim_tzsearch(InterSearch* self, const PredictionUnit* pu, Int
   self->m_cDistParam.maximumDistortionForEarlyExit = (Distortion)b.cost;
   g_calls[20]++;
   return 1;
+}
+
+// ---- IntraPrediction::predIntraAng (IntraPrediction.cpp:251-347): one TU's intra prediction = vvcgpu_intra_pred_batch with
+// one descriptor (next row N4).  The reference samples are taken from the predictor buffer the reference filled (and, when
+// useFilteredPredSamples, already filtered) and packed as top-left | above | left.
+namespace {
+DevArray<vvc_pel> g_iRefs, g_iPred;
+DevArray<vvcgpu_intra_desc> g_iDesc;
+}
+
+void wrap_predIntraAng(IntraPrediction* self, const ComponentID compId, PelBuf& piPred, const PredictionUnit& pu, const bool useFiltered)
+{
+  const ComponentID compID = MAP_CHROMA(compId);
+  const ChannelType chType = toChannelType(compID);
+  const int w = piPred.width, h = piPred.height;
+  static const long limit = getenv("VVCGPU_SHIM_INTRA_LIMIT") ? atol(getenv("VVCGPU_SHIM_INTRA_LIMIT")) : 60000;
+  bool ok = shimEnabled() && !getenv("VVCGPU_SHIM_NO_TABLES") && w >= 4 && h >= 4 && w <= 64 && h <= 64 && !(w & (w - 1)) && !(h & (h - 1)) &&
+            !(limit > 0 && g_calls[21] >= limit);
+  int T = 0, L = 0;
+  if (ok) { VVCGPU(vvcgpu_intra_ref_lengths(w, h, &T, &L)); ok = T == self->m_topRefLength && L == self->m_leftRefLength; }
+  const uint32_t mode = ok ? PU::getFinalIntraMode(pu, chType) : 0;
+  if (!ok || mode > VDIA_IDX) { real_predIntraAng(self, compId, piPred, pu, useFiltered); return; }
+  const Pel* src = self->getPredictorPtr(compID, useFiltered);
+  const int stride = T + 1;
+  std::vector<vvc_pel> refs((size_t)T + L + 1);
+  for (int x = 0; x <= T; x++) refs[x] = src[x];
+  for (int y = 1; y <= L; y++) refs[T + y] = src[(size_t)y * stride];
+  g_iRefs.upload(refs.data(), refs.size());
+  g_iPred.reserve((size_t)64 * 64);
+  vvcgpu_intra_desc d;
+  memset(&d, 0, sizeof d);
+  d.dst_stride = w; d.w = (int16_t)w; d.h = (int16_t)h; d.mode = (int8_t)mode; d.filter_refs = 0;
+  g_iDesc.upload(&d, 1);
+  const ClpRng& clp = pu.cu->cs->slice->clpRng(compID);
+  VVCGPU(vvcgpu_intra_pred_batch(g_iRefs.ptr, g_iPred.ptr, g_iDesc.ptr, 1, clp.min, clp.max, nullptr));
+  VVCGPU(vvcgpu_memcpy2d_d2h(piPred.buf, piPred.stride * sizeof(Pel), g_iPred.ptr, (size_t)w * sizeof(vvc_pel), (size_t)w * sizeof(Pel), h, nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  g_calls[21]++;
+}
+
+// ---- Picture::extendPicBorder (Picture.cpp:996-1041): the padded reconstruction planes go to the device, every margin is
+// produced by vvcgpu_extend_border, and the planes come back (next row N4).
+namespace { DevArray<vvc_pel> g_bPlane; }
+
+void wrap_extendPicBorder(Picture* self)
+{
+  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) { real_extendPicBorder(self); return; }
+  if (self->m_bIsBorderExtended) return;
+  for (int comp = 0; comp < (int)getNumberValidComponents(self->cs->area.chromaFormat); comp++)
+  {
+    const ComponentID compID = ComponentID(comp);
+    PelBuf p = self->getRecoBuf().get(compID);
+    const int mx = self->margin >> getComponentScaleX(compID, self->cs->area.chromaFormat);
+    const int my = self->margin >> getComponentScaleY(compID, self->cs->area.chromaFormat);
+    const int pw = p.width + 2 * mx, ph = p.height + 2 * my;
+    g_bPlane.reserve((size_t)pw * ph);
+    // only the picture area is sent: the margins are produced on the device
+    VVCGPU(vvcgpu_memcpy2d_h2d(g_bPlane.ptr + (size_t)my * pw + mx, (size_t)pw * sizeof(vvc_pel), p.buf, p.stride * sizeof(Pel),
+                               (size_t)p.width * sizeof(Pel), p.height, nullptr));
+    VVCGPU(vvcgpu_extend_border(g_bPlane.ptr + (size_t)my * pw + mx, pw, p.width, p.height, mx, my, nullptr));
+    VVCGPU(vvcgpu_memcpy2d_d2h(p.buf - (ptrdiff_t)my * p.stride - mx, p.stride * sizeof(Pel), g_bPlane.ptr, (size_t)pw * sizeof(vvc_pel),
+                               (size_t)pw * sizeof(Pel), ph, nullptr));
+    VVCGPU(vvcgpu_stream_sync(nullptr));
+  }
+  self->m_bIsBorderExtended = true;
+  g_calls[22]++;
+}
+
+// ---- calcCRC / calcChecksum (PicYuvMD5.cpp:127-181): per-component digests by vvcgpu_picture_hash (next row N4).  Pre-empted
+// by oracle/ref_hooks.cpp (calcAndPrintHashStatus calls them inside their own translation unit).  MD5 stays on the reference.
+namespace { DevArray<vvc_pel> g_hPlane; DevArray<uint32_t> g_hOut; }
+
+extern "C" int vvcshim_pichash(int method, const CPelUnitBuf* pic, PictureHash* digest, const BitDepths* bitDepths)
+{
+  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return 0;
+  digest->hash.clear();
+  for (uint32_t chan = 0; chan < (uint32_t)pic->bufs.size(); chan++)
+  {
+    const ComponentID compID = ComponentID(chan);
+    const CPelBuf area = pic->get(compID);
+    const int st = (area.width + 7) & ~7;
+    g_hPlane.reserve((size_t)st * area.height);
+    g_hOut.reserve(1);
+    VVCGPU(vvcgpu_memcpy2d_h2d(g_hPlane.ptr, (size_t)st * sizeof(vvc_pel), area.buf, area.stride * sizeof(Pel), (size_t)area.width * sizeof(Pel),
+                               area.height, nullptr));
+    VVCGPU(vvcgpu_picture_hash(method, g_hPlane.ptr, st, area.width, area.height, bitDepths->recon[toChannelType(compID)], g_hOut.ptr, nullptr));
+    uint32_t v = 0;
+    VVCGPU(vvcgpu_memcpy_d2h(&v, g_hOut.ptr, sizeof v, nullptr));
+    VVCGPU(vvcgpu_stream_sync(nullptr));
+    if (method == 1) { digest->hash.push_back((v >> 8) & 0xff); digest->hash.push_back(v & 0xff); }
+    else { digest->hash.push_back((v >> 24) & 0xff); digest->hash.push_back((v >> 16) & 0xff); digest->hash.push_back((v >> 8) & 0xff); digest->hash.push_back(v & 0xff); }
+  }
+  g_calls[23]++;
+  return method == 1 ? 2 : 4;
 }
 
 // ---- TrQuant::invTransformNxN (TrQuant.cpp:586-628): de-quantisation + inverse transform / transform skip of one TU =
