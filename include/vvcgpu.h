@@ -42,7 +42,7 @@ int         vvcgpu_device_count(void);
 int         vvcgpu_set_device(int device);
 /* sizeof() of the parameter structs, for binding self-checks: 0 sao_ctu, 1 deblock_cfg, 2 dist_desc, 3 search_blk,
  * 4 mvcost, 5 search_best, 6 if_desc, 7 mc_desc, 8 pelop_desc, 9 pelop_cfg, 10 tr_desc, 11 frac_blk, 12 frac_result,
- * 13 dqtr_desc, 14 afg_desc, 15 afe_desc, 16 tz_pu, 17 tz_cfg, 18 intra_desc; -1 for unknown ids.          */
+ * 13 dqtr_desc, 14 afg_desc, 15 afe_desc, 16 tz_pu, 17 tz_cfg, 18 intra_desc, 19 cclm_desc; -1 for unknown ids.          */
 int         vvcgpu_sizeof(int struct_id);
 
 /* ---- device memory helpers for host-side callers (the reference keeps pictures in host memory; the shim stages them).
@@ -398,6 +398,24 @@ typedef struct vvcgpu_intra_desc {
 int vvcgpu_intra_ref_lengths(int w, int h, int* top_len, int* left_len);
 int vvcgpu_intra_pred_batch(const vvc_pel* refs_base, vvc_pel* dst_base, const vvcgpu_intra_desc* descs, int n, int clp_min, int clp_max,
                             void* stream);
+
+/* N4, CCLM: cross-component linear model prediction of a chroma block  (IntraPrediction::xGetLumaRecPixels :1283-1581, the
+ * JVET_K0190 branch, + xGetLMParameters :1597-1857 + predIntraChromaLM :390-403).  4:2:0 only.  luma_off: the co-located luma
+ * block's top-left sample in the luma RECONSTRUCTION plane (rows -2, -1 are read when above_avail, columns -3 .. -1 when left_avail);
+ * nb_off: reconstructed chroma neighbours of this component in nb_base, the w samples above followed by the h samples to the left
+ * (what getPredictorPtr(compID) holds in row 0 / column 0); above_avail / left_avail: the reference's bAboveAvaillable /
+ * bLeftAvaillable (ALL units of that side available, :1633-1637 -- control logic over the coding structure, decided by the
+ * caller); w, h: chroma block, powers of two 2..64.                                                                        */
+typedef struct vvcgpu_cclm_desc {
+  int64_t luma_off, nb_off, dst_off;
+  int32_t luma_stride, dst_stride;
+  int16_t w, h;
+  int8_t  above_avail, left_avail;
+  int16_t reserved;
+  int32_t reserved2[2];                 /* sizeof == 48 */
+} vvcgpu_cclm_desc;
+int vvcgpu_cclm_pred_batch(const vvc_pel* luma_base, const vvc_pel* nb_base, vvc_pel* dst_base, const vvcgpu_cclm_desc* descs, int n,
+                           int bit_depth_luma, int bit_depth_chroma, int clp_min, int clp_max, void* stream);
 
 /* The shipped matrix [type][log2(N)-1] as N x N int16 (host copy; for the shim's table check against initROM()). */
 const int16_t* vvcgpu_tr_matrix_host(int type, int n);

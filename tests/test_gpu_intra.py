@@ -100,3 +100,58 @@ def test_intra_pred_full_picture_property():
     got = out.cpu().numpy()
     want = np.repeat(np.repeat(vals.reshape(H // B, W // B), B, axis=0), B, axis=1)
     assert np.array_equal(got, want)
+
+
+def test_cclm_golden_and_random():
+    """CCLM (vvcgpu_cclm_pred_batch): (1) the 938 blocks captured from the reference's own predIntraChromaLM, all in one launch;
+    (2) random luma / neighbours for every chroma shape x availability combination against the oracle."""
+    from vvcsoftware_vtm_amd import ops
+    from test_oracle_golden import cclm_records
+    for bd in (8, 10):
+        recs = [r for r in cclm_records() if r[5] == bd]
+        assert recs
+        d = np.zeros(len(recs), ops.CCLM_DESC)
+        lo = no = po = 0
+        wins, nbs, wants = [], [], []
+        for i, (w, h, above, left, bdl, bdc, cmin, cmax, lw, lh, win, nb, want) in enumerate(recs):
+            d[i] = (lo + 2 * lw + 3, no, po, lw, w, w, h, above, left, 0, (0, 0))
+            wins.append(win); nbs.append(nb); wants.append(want)
+            lo += win.size; no += nb.size; po += want.size
+            clp = (cmin, cmax)
+        out = torch.zeros(po, dtype=torch.int16, device="cuda")
+        ops.cclm_pred_batch(dev(np.concatenate(wins)), dev(np.concatenate(nbs)), out, ops.struct_to_device(d), len(d), bd, bd, clp)
+        assert np.array_equal(out.cpu().numpy(), np.concatenate(wants))
+    rng = np.random.default_rng(8)
+    O = oracle()
+    bd, clp = 10, (4, 1000)
+    descs, lum, nbs, wants = [], [], [], []
+    lo = no = po = 0
+    for w in (2, 4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            for above in (0, 1):
+                for left in (0, 1):
+                    lw, lh = 2 * w + 3, 2 * h + 2
+                    kind = (w + h + above) % 3
+                    if kind == 0:
+                        win = rng.integers(0, 1024, lw * lh).astype(np.int16)
+                        nb = rng.integers(0, 1024, w + h).astype(np.int16)
+                    elif kind == 1:                       # correlated chroma = 0.6 luma + 200: a real linear model
+                        win = np.clip(rng.normal(500, 120, lw * lh), 0, 1023).astype(np.int16)
+                        nb = np.clip(0.6 * rng.normal(500, 120, w + h) + 200, 0, 1023).astype(np.int16)
+                    else:
+                        win = rng.choice(np.array([0, 1023], np.int16), lw * lh)
+                        nb = rng.choice(np.array([0, 1023], np.int16), w + h)
+                    want = np.zeros((h, w), np.int16)
+                    O.orc_cclm_pred(C.c_void_p(win.ctypes.data + (2 * lw + 3) * 2), lw, p(nb), C.c_void_p(nb.ctypes.data + 2 * w), p(want), w, w, h,
+                                    above, left, bd, bd, clp[0], clp[1])
+                    descs.append((lo + 2 * lw + 3, no, po, lw, w, w, h, above, left, 0, (0, 0)))
+                    lum.append(win); nbs.append(nb); wants.append(want.reshape(-1))
+                    lo += win.size; no += nb.size; po += want.size
+    d = np.array(descs, ops.CCLM_DESC)
+    out = torch.zeros(po, dtype=torch.int16, device="cuda")
+    ops.cclm_pred_batch(dev(np.concatenate(lum)), dev(np.concatenate(nbs)), out, ops.struct_to_device(d), len(d), bd, bd, clp)
+    got, want = out.cpu().numpy(), np.concatenate(wants)
+    if not np.array_equal(got, want):
+        bad = np.nonzero(got != want)[0][0]
+        k = int(np.searchsorted(d["dst_off"], bad, side="right")) - 1
+        raise AssertionError("first mismatch in desc %s" % (d[k],))

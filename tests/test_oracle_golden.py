@@ -295,3 +295,29 @@ def test_intra_pred_golden():
         assert np.array_equal(pred.reshape(-1), pred_all[po:po + w * h]), (w, h, mode, bd, filt)
         seen.add(int(mode))
     assert seen == set(range(67))
+
+
+def cclm_records():
+    g = load("cclm")
+    hdr, win, nb, pred = g["hdr"], g["win"], g["nb"], g["pred"]
+    wo = no = po = 0
+    for (w, h, above, left, bdl, bdc, cmin, cmax, lw, lh) in hdr:
+        yield (int(w), int(h), int(above), int(left), int(bdl), int(bdc), int(cmin), int(cmax), int(lw), int(lh),
+               np.ascontiguousarray(win[wo:wo + lw * lh]), np.ascontiguousarray(nb[no:no + w + h]), pred[po:po + w * h])
+        wo += lw * lh; no += w + h; po += w * h
+
+
+def test_cclm_golden():
+    """next row N4, CCLM: restated xGetLumaRecPixels + xGetLMParameters + predIntraChromaLM vs blocks captured from the reference's own
+    predIntraChromaLM inside reference encoder runs (tests/golden/gen_cclm.py)."""
+    O = oracle()
+    n = 0
+    combos = set()
+    for (w, h, above, left, bdl, bdc, cmin, cmax, lw, lh, win, nb, want) in cclm_records():
+        got = np.zeros((h, w), np.int16)
+        origin = C.c_void_p(win.ctypes.data + (2 * lw + 3) * 2)
+        O.orc_cclm_pred(origin, lw, p(nb), C.c_void_p(nb.ctypes.data + 2 * w), p(got), w, w, h, above, left, bdl, bdc, cmin, cmax)
+        assert np.array_equal(got.reshape(-1), want), (w, h, above, left, bdc)
+        n += 1
+        combos.add((w, h, above, left))
+    assert n > 500 and len(combos) > 50

@@ -173,6 +173,101 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const Pel* __restrict__
   }
 }
 
+
+// ---- CCLM (JVET_K0190): xGetLumaRecPixels :1283-1581 + xGetLMParameters :1597-1857 + predIntraChromaLM :390-403 -------------
+// One wavefront per chroma block.  The down-sampled luma is never stored: neighbours are produced for the parameter sums and the
+// inner samples on the fly for the final linear map (6 luma reads per chroma sample, all L1/L2 hits of one small region).
+__device__ __forceinline__ int floor_log2(unsigned x) { return 31 - __clz((int)x); }     // x > 0
+
+__global__ __launch_bounds__(256) void cclm_pred_kernel(const Pel* __restrict__ lumaBase, const Pel* __restrict__ nbBase, Pel* __restrict__ dstBase,
+                                                        const vvcgpu_cclm_desc* __restrict__ descs, int n, int bdLuma, int bdChroma, int clpMin,
+                                                        int clpMax)
+{
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= n) return;
+  const vvcgpu_cclm_desc d = descs[b];
+  const int w = d.w, h = d.h, rs = d.luma_stride, rs2 = rs * 2;
+  const bool aboveAvail = d.above_avail != 0, leftAvail = d.left_avail != 0;
+  const Pel* luma = lumaBase + d.luma_off;
+  const Pel* nbAbove = nbBase + d.nb_off;
+  const Pel* nbLeft = nbAbove + w;
+  auto six = [&](const Pel* p) { return (p[0] * 2 + p[-1] + p[1] + p[rs] * 2 + p[rs - 1] + p[rs + 1] + 4) >> 3; };
+  auto two = [&](const Pel* p) { return (p[0] + p[rs] + 1) >> 1; };
+
+  int a = 0, bb = 1 << (bdChroma - 1), shift = 0;
+  if (aboveAvail || leftAvail)
+  {
+    int x = 0, y = 0, xx = 0, xy = 0, countShift = 0;
+    const int minDim = (leftAvail && aboveAvail) ? min(w, h) : (leftAvail ? h : w);
+    const int lgMin = floor_log2((unsigned)minDim);
+    if (aboveAvail)
+    {
+      for (int j = lane; j < minDim; j += 64)
+      {
+        const int idx = (j * w) >> lgMin;
+        const Pel* p = luma - rs2 + 2 * idx;
+        const int s = (idx == 0 && !leftAvail) ? two(p) : six(p), c = nbAbove[idx];
+        x += s; y += c; xx += s * s; xy += s * c;
+      }
+      countShift = lgMin;
+    }
+    if (leftAvail)
+    {
+      for (int i = lane; i < minDim; i += 64)
+      {
+        const int idx = (i * h) >> lgMin;
+        const int s = six(luma + (ptrdiff_t)idx * rs2 - 2), c = nbLeft[idx];
+        x += s; y += c; xx += s * s; xy += s * c;
+      }
+      countShift += aboveAvail ? 1 : lgMin;
+    }
+#pragma unroll
+    for (int m = 1; m < 64; m <<= 1) { x += __shfl_xor(x, m); y += __shfl_xor(y, m); xx += __shfl_xor(xx, m); xy += __shfl_xor(xy, m); }
+    const int tempShift = bdChroma + countShift - 15;
+    if (tempShift > 0)
+    {
+      const int r = 1 << (tempShift - 1);
+      x = (x + r) >> tempShift; y = (y + r) >> tempShift; xx = (xx + r) >> tempShift; xy = (xy + r) >> tempShift;
+      countShift -= tempShift;
+    }
+    const int avgX = x >> countShift, avgY = y >> countShift;
+    const int rErrX = x & ((1 << countShift) - 1), rErrY = y & ((1 << countShift) - 1);
+    const int iB = 7;
+    shift = 13 - iB;
+    if (countShift == 0) { a = 0; bb = 1 << (bdChroma - 1); shift = 0; }
+    else
+    {
+      const int a1 = xy - ((avgX * avgY) << countShift) - avgX * rErrY - avgY * rErrX;
+      const int a2 = xx - ((avgX * avgX) << countShift) - 2 * avgX * rErrX;
+      int sA1 = a1 == 0 ? 0 : floor_log2((unsigned)abs(a1)) - (bdChroma - 2);
+      int sA2 = a2 == 0 ? 0 : floor_log2((unsigned)abs(a2)) - 5;
+      sA1 = max(sA1, 0); sA2 = max(sA2, 0);
+      const int sA = sA2 + (bdChroma + 4) - shift - sA1;
+      const int a2s = a2 >> sA2, a1s = a1 >> sA1;
+      if (a2s >= 32) a = (int)((unsigned)a1s * (unsigned)(((1 << (bdLuma + 4)) + a2s / 2) / a2s));     // m_auShiftLM[a2s - 32]
+      else a = 0;
+      if (sA < 0) a = (int)((unsigned)a << -sA); else a = a >> sA;
+      a = min(max(a, -(1 << (15 - iB))), (1 << (15 - iB)) - 1);
+      a = a * (1 << iB);
+      int nn = 0;
+      if (a != 0) nn = (short)(floor_log2((unsigned)(abs(a) + ((a < 0 ? -1 : 1) - 1) / 2)) - 5);
+      shift = (shift + iB) - nn;
+      a = a >> nn;
+      bb = avgY - ((a * avgX) >> shift);
+    }
+  }
+  Pel* dst = dstBase + d.dst_off;
+  const int lgW = floor_log2((unsigned)w);
+  for (int i = lane; i < w * h; i += 64)
+  {
+    const int yy = i >> lgW, xq = i & (w - 1);
+    const Pel* p = luma + (ptrdiff_t)yy * rs2 + 2 * xq;
+    const int s = (short)((xq == 0 && !leftAvail) ? two(p) : six(p));
+    dst[(ptrdiff_t)yy * d.dst_stride + xq] = (Pel)min(max(((a * s) >> shift) + bb, clpMin), clpMax);
+  }
+}
+
 }  // namespace
 
 extern "C" int vvcgpu_intra_ref_lengths(int w, int h, int* top_len, int* left_len)
@@ -194,6 +289,21 @@ extern "C" int vvcgpu_intra_pred_batch(const vvc_pel* refs_base, vvc_pel* dst_ba
   VVC_CHECK_ARG(refs_base && dst_base && descs, "intra_pred_batch: null pointer");
   VVC_CHECK_ARG(clp_min <= clp_max && clp_min >= -32768 && clp_max <= 32767, "intra_pred_batch: clip range %d..%d", clp_min, clp_max);
   hipLaunchKernelGGL(intra_pred_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, refs_base, dst_base, descs, n, clp_min, clp_max);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+extern "C" int vvcgpu_cclm_pred_batch(const vvc_pel* luma_base, const vvc_pel* nb_base, vvc_pel* dst_base, const vvcgpu_cclm_desc* descs, int n,
+                                      int bit_depth_luma, int bit_depth_chroma, int clp_min, int clp_max, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "cclm_pred_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(luma_base && nb_base && dst_base && descs, "cclm_pred_batch: null pointer");
+  VVC_CHECK_ARG(bit_depth_luma >= 8 && bit_depth_luma <= 12 && bit_depth_chroma >= 8 && bit_depth_chroma <= 12, "cclm_pred_batch: bit depths %d %d",
+                bit_depth_luma, bit_depth_chroma);
+  VVC_CHECK_ARG(clp_min <= clp_max, "cclm_pred_batch: clip range");
+  hipLaunchKernelGGL(cclm_pred_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, luma_base, nb_base, dst_base, descs, n, bit_depth_luma,
+                     bit_depth_chroma, clp_min, clp_max);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

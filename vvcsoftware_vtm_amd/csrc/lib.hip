@@ -94,6 +94,7 @@ int vvcgpu_sizeof(int id)
   case 16: return (int)sizeof(vvcgpu_tz_pu);
   case 17: return (int)sizeof(vvcgpu_tz_cfg);
   case 18: return (int)sizeof(vvcgpu_intra_desc);
+  case 19: return (int)sizeof(vvcgpu_cclm_desc);
   default: return -1;
   }
 }

@@ -241,6 +241,17 @@ def intra_pred_batch(refs_base, dst_base, descs_dev, n, clp=(0, 1023)):
     capi.call("vvcgpu_intra_pred_batch", capi.ptr(refs_base), capi.ptr(dst_base), capi.ptr(descs_dev), n, clp[0], clp[1], _stream())
 
 
+CCLM_DESC = np.dtype([("luma_off", "<i8"), ("nb_off", "<i8"), ("dst_off", "<i8"), ("luma_stride", "<i4"), ("dst_stride", "<i4"), ("w", "<i2"),
+                      ("h", "<i2"), ("above_avail", "i1"), ("left_avail", "i1"), ("reserved", "<i2"), ("reserved2", "<i4", (2,))])
+assert CCLM_DESC.itemsize == 48
+
+
+def cclm_pred_batch(luma_base, nb_base, dst_base, descs_dev, n, bd_luma=10, bd_chroma=10, clp=(0, 1023)):
+    """N4: CCLM chroma prediction (xGetLumaRecPixels + xGetLMParameters + predIntraChromaLM) for n chroma blocks."""
+    capi.call("vvcgpu_cclm_pred_batch", capi.ptr(luma_base), capi.ptr(nb_base), capi.ptr(dst_base), capi.ptr(descs_dev), n, bd_luma, bd_chroma,
+              clp[0], clp[1], _stream())
+
+
 # ---- interpolation / MC / PelBuffer ops -------------------------------------------------------------
 IF_DESC = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("src_stride", "<i4"), ("dst_stride", "<i4"),
                     ("w", "<i2"), ("h", "<i2"), ("taps", "i1"), ("is_vertical", "i1"), ("is_first", "i1"),

@@ -15,6 +15,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <vector>
+#include <map>
 
 #include "CommonLib/CommonDef.h"
 #include "CommonLib/CodingStructure.h"
@@ -68,6 +69,10 @@ void real_predIntraAng(IntraPrediction*, const ComponentID, PelBuf&, const Predi
   asm("__real__ZN15IntraPrediction12predIntraAngE11ComponentIDR7AreaBufIsERK14PredictionUnitb");
 void wrap_predIntraAng(IntraPrediction*, const ComponentID, PelBuf&, const PredictionUnit&, const bool)
   asm("__wrap__ZN15IntraPrediction12predIntraAngE11ComponentIDR7AreaBufIsERK14PredictionUnitb");
+void real_predIntraChromaLM(IntraPrediction*, const ComponentID, PelBuf&, const PredictionUnit&, const CompArea&, int)
+  asm("__real__ZN15IntraPrediction17predIntraChromaLME11ComponentIDR7AreaBufIsERK14PredictionUnitRK8CompAreai");
+void wrap_predIntraChromaLM(IntraPrediction*, const ComponentID, PelBuf&, const PredictionUnit&, const CompArea&, int)
+  asm("__wrap__ZN15IntraPrediction17predIntraChromaLME11ComponentIDR7AreaBufIsERK14PredictionUnitRK8CompAreai");
 void real_extendPicBorder(Picture*) asm("__real__ZN7Picture15extendPicBorderEv");
 void wrap_extendPicBorder(Picture*) asm("__wrap__ZN7Picture15extendPicBorderEv");
 
@@ -86,11 +91,11 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[24] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+long g_calls[25] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
-                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld, IntraPred %ld, Border %ld, Hash %ld\n",
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld, IntraPred %ld, Border %ld, Hash %ld, CCLM %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
-                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20], g_calls[21], g_calls[22], g_calls[23]); } } g_report;
+                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20], g_calls[21], g_calls[22], g_calls[23], g_calls[24]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -1067,6 +1072,110 @@ void wrap_predIntraAng(IntraPrediction* self, const ComponentID compId, PelBuf& 
   VVCGPU(vvcgpu_memcpy2d_d2h(piPred.buf, piPred.stride * sizeof(Pel), g_iPred.ptr, (size_t)w * sizeof(vvc_pel), (size_t)w * sizeof(Pel), h, nullptr));
   VVCGPU(vvcgpu_stream_sync(nullptr));
   g_calls[21]++;
+}
+
+// ---- IntraPrediction::predIntraChromaLM (IntraPrediction.cpp:390-403, after xGetLumaRecPixels :1283-1581): CCLM prediction of one
+// chroma block = vvcgpu_cclm_pred_batch with one descriptor (next row N4), recomputed from the luma reconstruction (the
+// reference's m_piTemp is not used).  VVCGPU_SHIM_CCLM_VERIFY=1: every call is also run through the reference's own body and
+// compared.  VVCGPU_CCLM_DUMP=<file>: inputs and the reference's outputs of real calls are appended to <file> (fixture capture,
+// tests/golden/gen_cclm.py; works without a GPU).
+namespace {
+DevArray<vvc_pel> g_cLuma, g_cNb, g_cPred;
+DevArray<vvcgpu_cclm_desc> g_cDesc;
+
+// IntraPrediction.cpp:1162-1219 in the reference's own public API: number of available units along one side
+int sideUnitsAvailable(const CodingUnit& cu, ChannelType chType, const Position& posLT, int units, int unit, bool above)
+{
+  const CodingStructure& cs = *cu.cs;
+  const bool constrained = cs.pps->getConstrainedIntraPred();
+  int n = 0;
+  for (int k = 0; k < units; k++)
+  {
+    const Position refPos = above ? posLT.offset(k * unit, -1) : posLT.offset(-1, k * unit);
+    const CodingUnit* nb = cs.isDecomp(refPos, chType) ? cs.getCURestricted(refPos, cu, chType) : nullptr;
+    if (nb && (!constrained || CU::isIntra(*nb))) n++;
+    else if (!nb) return n;
+  }
+  return n;
+}
+}
+
+void wrap_predIntraChromaLM(IntraPrediction* self, const ComponentID compID, PelBuf& piPred, const PredictionUnit& pu, const CompArea& chromaArea, int intraDir)
+{
+  const char* dump = getenv("VVCGPU_CCLM_DUMP");
+  const bool gpu = shimEnabled() && !getenv("VVCGPU_SHIM_NO_TABLES");
+  const int w = chromaArea.width, h = chromaArea.height;
+  bool ok = (gpu || dump) && pu.chromaFormat == CHROMA_420 && w >= 2 && h >= 2 && w <= 64 && h <= 64 && !(w & (w - 1)) && !(h & (h - 1)) &&
+            (int)piPred.width == w && (int)piPred.height == h;
+  bool aboveAvail = false, leftAvail = false;
+  if (ok)
+  {
+    const CodingUnit& cu = *pu.cu;
+    const int unit = (1 << MIN_CU_LOG2) >> getComponentScaleX(chromaArea.compID, pu.chromaFormat);
+    aboveAvail = sideUnitsAvailable(cu, CHANNEL_TYPE_CHROMA, chromaArea.pos(), w / unit, unit, true) == w / unit;        // :1633-1637
+    leftAvail = sideUnitsAvailable(cu, CHANNEL_TYPE_CHROMA, chromaArea.pos(), h / unit, unit, false) == h / unit;
+    if (!isChroma(pu.chType))
+    {
+      // single tree: xGetLumaRecPixels decided its 2-tap / 6-tap taps in the luma domain (:1351-1371); serve only when both views agree
+      const CompArea lumaArea(COMPONENT_Y, pu.chromaFormat, chromaArea.lumaPos(), recalcSize(pu.chromaFormat, CHANNEL_TYPE_CHROMA, CHANNEL_TYPE_LUMA, chromaArea.size()));
+      const int lu = 1 << MIN_CU_LOG2;
+      const bool a2 = sideUnitsAvailable(cu, CHANNEL_TYPE_LUMA, lumaArea.pos(), lumaArea.width / lu, lu, true) == (int)lumaArea.width / lu;
+      const bool l2 = sideUnitsAvailable(cu, CHANNEL_TYPE_LUMA, lumaArea.pos(), lumaArea.height / lu, lu, false) == (int)lumaArea.height / lu;
+      ok = a2 == aboveAvail && l2 == leftAvail;
+    }
+  }
+  if (!ok) { real_predIntraChromaLM(self, compID, piPred, pu, chromaArea, intraDir); return; }
+  const CompArea lumaArea(COMPONENT_Y, pu.chromaFormat, chromaArea.lumaPos(), recalcSize(pu.chromaFormat, CHANNEL_TYPE_CHROMA, CHANNEL_TYPE_LUMA, chromaArea.size()));
+  const CPelBuf src = pu.cs->picture->getRecoBuf(lumaArea);
+  const int lw = 2 * w + 3, lh = 2 * h + 2;                       // luma window: columns -3 .. 2w-1, rows -2 .. 2h-1 (inside the picture margin)
+  std::vector<vvc_pel> win((size_t)lw * lh), nb((size_t)w + h), ref((size_t)w * h);
+  for (int y = 0; y < lh; y++) memcpy(&win[(size_t)y * lw], src.buf + (ptrdiff_t)(y - 2) * src.stride - 3, lw * sizeof(Pel));
+  const Pel* cur = self->getPredictorPtr(compID);
+  const int cstride = self->m_topRefLength + 1;
+  for (int i = 0; i < w; i++) nb[i] = cur[1 + i];
+  for (int j = 0; j < h; j++) nb[w + j] = cur[(size_t)cstride * (j + 1)];
+  const int bdL = pu.cs->sps->getBitDepth(CHANNEL_TYPE_LUMA), bdC = pu.cs->sps->getBitDepth(CHANNEL_TYPE_CHROMA);
+  const ClpRng& clp = pu.cs->slice->clpRng(compID);
+  if (dump)
+  {
+    real_predIntraChromaLM(self, compID, piPred, pu, chromaArea, intraDir);
+    static FILE* f = fopen(dump, "ab");
+    static std::map<int, int> seen;
+    const int key = (w << 10) | (h << 2) | (aboveAvail ? 2 : 0) | (leftAvail ? 1 : 0);
+    if (f && seen[key]++ < 6)
+    {
+      const int32_t hdr[10] = { w, h, aboveAvail, leftAvail, bdL, bdC, clp.min, clp.max, lw, lh };
+      fwrite(hdr, sizeof hdr, 1, f);
+      fwrite(win.data(), sizeof(vvc_pel), win.size(), f);
+      fwrite(nb.data(), sizeof(vvc_pel), nb.size(), f);
+      for (int y = 0; y < h; y++) fwrite(piPred.buf + (size_t)y * piPred.stride, sizeof(Pel), w, f);
+      fflush(f);
+    }
+    return;
+  }
+  g_cLuma.upload(win.data(), win.size());
+  g_cNb.upload(nb.data(), nb.size());
+  g_cPred.reserve((size_t)64 * 64);
+  vvcgpu_cclm_desc d;
+  memset(&d, 0, sizeof d);
+  d.luma_off = (int64_t)2 * lw + 3; d.luma_stride = lw; d.dst_stride = w; d.w = (int16_t)w; d.h = (int16_t)h;
+  d.above_avail = aboveAvail; d.left_avail = leftAvail;
+  g_cDesc.upload(&d, 1);
+  VVCGPU(vvcgpu_cclm_pred_batch(g_cLuma.ptr, g_cNb.ptr, g_cPred.ptr, g_cDesc.ptr, 1, bdL, bdC, clp.min, clp.max, nullptr));
+  VVCGPU(vvcgpu_memcpy_d2h(ref.data(), g_cPred.ptr, ref.size() * sizeof(vvc_pel), nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  if (getenv("VVCGPU_SHIM_CCLM_VERIFY"))
+  {
+    real_predIntraChromaLM(self, compID, piPred, pu, chromaArea, intraDir);
+    for (int y = 0; y < h; y++)
+      if (memcmp(piPred.buf + (size_t)y * piPred.stride, &ref[(size_t)y * w], w * sizeof(Pel)))
+      {
+        fprintf(stderr, "[vvcgpu shim] CCLM mismatch: %dx%d above %d left %d comp %d row %d\n", w, h, aboveAvail, leftAvail, (int)compID, y);
+        break;
+      }
+  }
+  for (int y = 0; y < h; y++) memcpy(piPred.buf + (size_t)y * piPred.stride, &ref[(size_t)y * w], w * sizeof(Pel));
+  g_calls[24]++;
 }
 
 // ---- Picture::extendPicBorder (Picture.cpp:996-1041): the padded reconstruction planes go to the device, every margin is
