@@ -163,12 +163,15 @@ int vvcgpu_alf_stats(const vvc_pel* org, int org_stride, const vvc_pel* rec, int
  *      1 = HAD  (Hadamard SATD, tile selection of xGetHADs with isQtbt = true; rectangular tiles use the
  *                reference's double arithmetic (int)(sad / sqrt(128.0) * 2), RdCost.cpp:2561,2698,2771,2850)
  *      2 = SSE  (sum of squared differences; the chroma distortion weight of getDistPart stays on the host)
+ *      3 = MR-SAD  (row D4: xGetMRSAD and its size twins, RdCost.cpp:1008-1815: offset = sum(org - cur) / N over the sub-sampled
+ *                block, truncating; sum |org - cur - offset| << sub_shift -- the m_afpDistortFunc[DF_MRSAD..] entries for useMR)
+ *      4 = MR-HAD  (xGetMRHADs :3433-3446: kind 1 on org - Pel(meanDiff))
  * out[i] is the Distortion (uint64) of descriptor i.  Bit depth <= 10 (the reference's SIMD precondition). */
 typedef struct vvcgpu_dist_desc {
   int64_t org_off, cur_off;
   int32_t org_stride, cur_stride;
   int16_t w, h;
-  int16_t sub_shift;          /* SAD only */
+  int16_t sub_shift;          /* SAD / MR-SAD only */
   int16_t reserved;
 } vvcgpu_dist_desc;
 int vvcgpu_dist_batch(int kind, const vvc_pel* org_base, const vvc_pel* cur_base, const vvcgpu_dist_desc* descs,

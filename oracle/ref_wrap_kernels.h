@@ -238,6 +238,14 @@ uint64_t vtmref_dist(int kind, int simd, const Pel* org, int os, const Pel* cur,
     dp.distFunc = isPowerOf2(w) ? RdCost::m_afpDistortFunc[DF_SSE + g_aucLog2[w]] : RdCost::m_afpDistortFunc[DF_SSE];
     return dp.distFunc(dp);
   }
+  if (kind == 3 || kind == 4)                                   // D4: the mean-removed table entries setDistParam selects for useMR (RdCost.cpp:222, 296)
+  {
+    dp.useMR = true;
+    rc->setDistParam(dp, ob, cb, bd, COMPONENT_Y, kind == 4);
+    dp.subShift = kind == 3 ? subShift : 0;
+    if (!simd) return kind == 3 ? RdCost::xGetMRSAD(dp) : RdCost::xGetMRHADs(dp);
+    return dp.distFunc(dp);
+  }
   rc->setDistParam(dp, ob, cb, bd, COMPONENT_Y, kind == 1);
   dp.subShift = kind == 0 ? subShift : 0;
   if (!simd) return kind == 0 ? RdCost::xGetSAD(dp) : RdCost::xGetHADs(dp);

@@ -73,6 +73,34 @@ ORC_API uint64_t orc_satd(const Pel* org, int os, const Pel* cur, int cs, int w,
   return sum;
 }
 
+// D4: mean-removed SAD (RdCost::xGetMRSAD, RdCost.cpp:1008-1052; the size-specific twins xGetMRSAD4..64 :1055-1815 unroll the same sums;
+// the early exit only fires for a finite maximumDistortionForEarlyExit and is not part of the value) and mean-removed SATD
+// (xGetMRHADs :3433-3446: org - Pel(meanDiff) through xGetHADs).  Both divisions truncate towards zero (C integer division).
+ORC_API uint64_t orc_mrsad(const Pel* org, int os, const Pel* cur, int cs, int w, int h, int subShift)
+{
+  const int step = 1 << subShift;
+  int32_t deltaSum = 0;
+  for (int y = 0; y < h; y += step)
+    for (int x = 0; x < w; x++) deltaSum += org[y * os + x] - cur[y * cs + x];
+  const Pel offset = (Pel)(deltaSum / (w * (h >> subShift)));
+  uint64_t sum = 0;
+  for (int y = 0; y < h; y += step)
+    for (int x = 0; x < w; x++) sum += abs(org[y * os + x] - cur[y * cs + x] - offset);
+  return sum << subShift;
+}
+
+ORC_API uint64_t orc_mrsatd(const Pel* org, int os, const Pel* cur, int cs, int w, int h)
+{
+  int64_t acc = 0;
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) acc += org[y * os + x] - cur[y * cs + x];
+  const Pel offset = (Pel)(acc / (w * h));                                           // AreaBuf::meanDiff, Buffer.h:469-491
+  std::vector<Pel> mod((size_t)w * h);
+  for (int y = 0; y < h; y++)
+    for (int x = 0; x < w; x++) mod[(size_t)y * w + x] = (Pel)(org[y * os + x] - offset);   // AreaBuf::subtract on Pel
+  return orc_satd(mod.data(), w, cur, cs, w, h);
+}
+
 ORC_API int orc_dist_batch(int kind, const Pel* orgBase, const Pel* curBase, const vvcgpu_dist_desc* d, int n, uint64_t* out)
 {
   for (int i = 0; i < n; i++)
@@ -80,7 +108,9 @@ ORC_API int orc_dist_batch(int kind, const Pel* orgBase, const Pel* curBase, con
     const Pel* o = orgBase + d[i].org_off; const Pel* c = curBase + d[i].cur_off;
     out[i] = kind == 0 ? orc_sad(o, d[i].org_stride, c, d[i].cur_stride, d[i].w, d[i].h, d[i].sub_shift)
            : kind == 1 ? orc_satd(o, d[i].org_stride, c, d[i].cur_stride, d[i].w, d[i].h)
-                       : orc_sse(o, d[i].org_stride, c, d[i].cur_stride, d[i].w, d[i].h);
+           : kind == 2 ? orc_sse(o, d[i].org_stride, c, d[i].cur_stride, d[i].w, d[i].h)
+           : kind == 3 ? orc_mrsad(o, d[i].org_stride, c, d[i].cur_stride, d[i].w, d[i].h, d[i].sub_shift)
+                       : orc_mrsatd(o, d[i].org_stride, c, d[i].cur_stride, d[i].w, d[i].h);
   }
   return 0;
 }

@@ -101,8 +101,10 @@ def gen_dist():
                     if (h >> ss) < 2 or (w == 4 and h == 4 and ss):
                         continue
                     rows.append((bd, 0, ox, oy, cx, cy, w, h, ss, R.vtmref_dist(0, 1, po, W, pc, W, w, h, bd, ss)))
+                    rows.append((bd, 3, ox, oy, cx, cy, w, h, ss, R.vtmref_dist(3, 1, po, W, pc, W, w, h, bd, ss)))     # D4: MR-SAD table entry
                 rows.append((bd, 1, ox, oy, cx, cy, w, h, 0, R.vtmref_dist(1, 1, po, W, pc, W, w, h, bd, 0)))
                 rows.append((bd, 2, ox, oy, cx, cy, w, h, 0, R.vtmref_dist(2, 1, po, W, pc, W, w, h, bd, 0)))
+                rows.append((bd, 4, ox, oy, cx, cy, w, h, 0, R.vtmref_dist(4, 1, po, W, pc, W, w, h, bd, 0)))          # D4: MR-SATD
     out["rows"] = np.array(rows, dtype=np.int64)
 
     class MV(C.Structure):

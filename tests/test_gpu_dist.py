@@ -20,23 +20,23 @@ def make_descs(rng, planeW, planeH, kind, n_per_size=3):
     from vvcsoftware_vtm_amd import ops
     rows = []
     for (w, h) in SIZES:
-        if kind == ops.HAD and w in (12, 24, 48) and (h % 4 or w % 4):
+        if kind in (ops.HAD, ops.MRHAD) and w in (12, 24, 48) and (h % 4 or w % 4):
             continue
         for _ in range(n_per_size):
             ox, oy = int(rng.integers(0, planeW - w)), int(rng.integers(0, planeH - h))
             cx, cy = int(rng.integers(0, planeW - w)), int(rng.integers(0, planeH - h))
             ss = 0
-            if kind == ops.SAD:
+            if kind in (ops.SAD, ops.MRSAD):
                 ss = int(rng.integers(0, 4))
                 while (h >> ss) < 2 or h % (1 << ss):
                     ss -= 1
-                if w == 4 and h == 4:
+                if w == 4 and h == 4 and kind == ops.SAD:
                     ss = 0          # reference SIMD quirk for 4x4 with subsampling (RdCostX86.h:331-351), see DESIGN.md
             rows.append((oy * planeW + ox, cy * planeW + cx, planeW, planeW, w, h, ss, 0))
     return np.array(rows, dtype=ops.DIST_DESC)
 
 
-@pytest.mark.parametrize("kind", [0, 1, 2])
+@pytest.mark.parametrize("kind", [0, 1, 2, 3, 4])
 @pytest.mark.parametrize("bd,data", [(10, "uniform"), (10, "smooth"), (8, "uniform"), (10, "extreme")])
 def test_dist_batch(kind, bd, data):
     from vvcsoftware_vtm_amd import ops

@@ -63,7 +63,7 @@ def test_sao_golden():
 def test_dist_golden():
     g = load("dist")
     O = oracle()
-    for f in ("orc_sad", "orc_satd", "orc_sse", "orc_mvcost"):
+    for f in ("orc_sad", "orc_satd", "orc_sse", "orc_mvcost", "orc_mrsad", "orc_mrsatd"):
         getattr(O, f).restype = C.c_uint64
     W = g["org10"].shape[1]
     for row in g["rows"]:
@@ -71,8 +71,10 @@ def test_dist_golden():
         org, cur = g["org%d" % bd], g["cur%d" % bd]
         po = C.c_void_p(org.ctypes.data + 2 * (oy * W + ox))
         pc = C.c_void_p(cur.ctypes.data + 2 * (cy * W + cx))
-        got = O.orc_sad(po, W, pc, W, w, h, ss) if kind == 0 else O.orc_satd(po, W, pc, W, w, h) if kind == 1 else O.orc_sse(po, W, pc, W, w, h)
+        got = (O.orc_sad(po, W, pc, W, w, h, ss) if kind == 0 else O.orc_satd(po, W, pc, W, w, h) if kind == 1 else O.orc_sse(po, W, pc, W, w, h) if kind == 2
+               else O.orc_mrsad(po, W, pc, W, w, h, ss) if kind == 3 else O.orc_mrsatd(po, W, pc, W, w, h))
         assert got == want, (bd, kind, w, h, ss)
+    assert {int(r[1]) for r in g["rows"]} == {0, 1, 2, 3, 4}
 
     class MV(C.Structure):
         _fields_ = [("l", C.c_double), ("ph", C.c_int32), ("pv", C.c_int32), ("cs", C.c_int32), ("imv", C.c_int32)]

@@ -29,7 +29,7 @@ __device__ __forceinline__ unsigned long long wave_sum_u64(unsigned long long v)
 // ---------------------------------------------------------------------------------------------------
 // Hadamard tile: TW columns in registers, TH rows across TH consecutive lanes.
 template <int TW, int TH>
-__device__ __forceinline__ unsigned long long satd_tiles(const Pel* org, int os, const Pel* cur, int cs, int w, int h, int lane)
+__device__ __forceinline__ unsigned long long satd_tiles(const Pel* org, int os, const Pel* cur, int cs, int w, int h, int lane, int offset = 0)
 {
   constexpr int GROUPS = 64 / TH;
   const int row = lane % TH, grp = lane / TH;
@@ -46,7 +46,7 @@ __device__ __forceinline__ unsigned long long satd_tiles(const Pel* org, int os,
       const Pel* o = org + (size_t)(ty * TH + row) * os + tx * TW;
       const Pel* c = cur + (size_t)(ty * TH + row) * cs + tx * TW;
 #pragma unroll
-      for (int x = 0; x < TW; x++) v[x] = (int)o[x] - (int)c[x];
+      for (int x = 0; x < TW; x++) v[x] = (int)(Pel)((int)o[x] - offset) - (int)c[x];      // offset != 0: D4, org - Pel(meanDiff) kept as Pel
     }
     else
     {
@@ -104,26 +104,40 @@ __global__ __launch_bounds__(256) void dist_batch_kernel(int kind, const Pel* __
   const Pel* cur = curBase + d.cur_off;
   const int w = d.w, h = d.h, os = d.org_stride, cs = d.cur_stride;
   unsigned long long res;
-  if (kind == 1)
+  int offset = 0;
+  const int ssSad = (kind == 0 || kind == 3) ? d.sub_shift : 0;
+  if (kind >= 3)                                          // D4: mean difference over the (sub-sampled, MR-SAD only) block, truncating division
   {
-    if (w > h && (h & 7) == 0 && (w & 15) == 0)      res = satd_tiles<16, 8>(org, os, cur, cs, w, h, lane);
-    else if (w < h && (w & 7) == 0 && (h & 15) == 0) res = satd_tiles<8, 16>(org, os, cur, cs, w, h, lane);
-    else if (w > h && (h & 3) == 0 && (w & 7) == 0)  res = satd_tiles<8, 4>(org, os, cur, cs, w, h, lane);
-    else if (w < h && (w & 3) == 0 && (h & 7) == 0)  res = satd_tiles<4, 8>(org, os, cur, cs, w, h, lane);
-    else if ((h & 7) == 0 && (w & 7) == 0)           res = satd_tiles<8, 8>(org, os, cur, cs, w, h, lane);
-    else if ((h & 3) == 0 && (w & 3) == 0)           res = satd_tiles<4, 4>(org, os, cur, cs, w, h, lane);
-    else                                             res = satd_tiles<2, 2>(org, os, cur, cs, w, h, lane);
+    const int rows = h >> ssSad;
+    long long acc = 0;
+    for (int idx = lane; idx < rows * w; idx += 64)
+    {
+      const int r = idx / w, x = idx - r * w;
+      acc += (int)org[(size_t)(r << ssSad) * os + x] - (int)cur[(size_t)(r << ssSad) * cs + x];
+    }
+    acc = (long long)wave_sum_u64((unsigned long long)acc);
+    offset = (int)(Pel)(kind == 3 ? (int)acc / (w * rows) : (int)(acc / (long long)(w * h)));
+  }
+  if (kind == 1 || kind == 4)
+  {
+    if (w > h && (h & 7) == 0 && (w & 15) == 0)      res = satd_tiles<16, 8>(org, os, cur, cs, w, h, lane, offset);
+    else if (w < h && (w & 7) == 0 && (h & 15) == 0) res = satd_tiles<8, 16>(org, os, cur, cs, w, h, lane, offset);
+    else if (w > h && (h & 3) == 0 && (w & 7) == 0)  res = satd_tiles<8, 4>(org, os, cur, cs, w, h, lane, offset);
+    else if (w < h && (w & 3) == 0 && (h & 7) == 0)  res = satd_tiles<4, 8>(org, os, cur, cs, w, h, lane, offset);
+    else if ((h & 7) == 0 && (w & 7) == 0)           res = satd_tiles<8, 8>(org, os, cur, cs, w, h, lane, offset);
+    else if ((h & 3) == 0 && (w & 3) == 0)           res = satd_tiles<4, 4>(org, os, cur, cs, w, h, lane, offset);
+    else                                             res = satd_tiles<2, 2>(org, os, cur, cs, w, h, lane, offset);
   }
   else
   {
-    const int ss = kind == 0 ? d.sub_shift : 0;
+    const int ss = ssSad;
     const int rows = h >> ss;
     unsigned long long acc = 0;
     for (int idx = lane; idx < rows * w; idx += 64)
     {
       const int r = idx / w, x = idx - r * w;
-      const int df = (int)org[(size_t)(r << ss) * os + x] - (int)cur[(size_t)(r << ss) * cs + x];
-      acc += kind == 0 ? (unsigned)abs(df) : (unsigned)(df * df);
+      const int df = (int)org[(size_t)(r << ss) * os + x] - (int)cur[(size_t)(r << ss) * cs + x] - offset;
+      acc += kind == 2 ? (unsigned)(df * df) : (unsigned)abs(df);
     }
     res = wave_sum_u64(acc) << ss;
   }
@@ -699,7 +713,7 @@ extern "C" {
 int vvcgpu_dist_batch(int kind, const vvc_pel* org_base, const vvc_pel* cur_base, const vvcgpu_dist_desc* descs,
                       int n, int bit_depth, uint64_t* out, void* stream)
 {
-  VVC_CHECK_ARG(kind >= 0 && kind <= 2, "dist_batch: kind %d", kind);
+  VVC_CHECK_ARG(kind >= 0 && kind <= 4, "dist_batch: kind %d", kind);
   VVC_CHECK_ARG(n >= 0, "dist_batch: n %d", n);
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(org_base && cur_base && descs && out, "dist_batch: null pointer");

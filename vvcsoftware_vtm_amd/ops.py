@@ -127,7 +127,7 @@ DIST_DESC = np.dtype([("org_off", "<i8"), ("cur_off", "<i8"), ("org_stride", "<i
                       ("w", "<i2"), ("h", "<i2"), ("sub_shift", "<i2"), ("reserved", "<i2")])
 SEARCH_BLK = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4")])
 SEARCH_BEST = np.dtype([("x", "<i4"), ("y", "<i4"), ("cost", "<u8"), ("sad", "<u8")])
-SAD, HAD, SSE = 0, 1, 2
+SAD, HAD, SSE, MRSAD, MRHAD = 0, 1, 2, 3, 4
 
 
 class MvCost(C.Structure):
