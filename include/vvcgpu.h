@@ -42,7 +42,7 @@ int         vvcgpu_device_count(void);
 int         vvcgpu_set_device(int device);
 /* sizeof() of the parameter structs, for binding self-checks: 0 sao_ctu, 1 deblock_cfg, 2 dist_desc, 3 search_blk,
  * 4 mvcost, 5 search_best, 6 if_desc, 7 mc_desc, 8 pelop_desc, 9 pelop_cfg, 10 tr_desc, 11 frac_blk, 12 frac_result,
- * 13 dqtr_desc, 14 afg_desc, 15 afe_desc, 16 tz_pu, 17 tz_cfg, 18 intra_desc, 19 cclm_desc; -1 for unknown ids.          */
+ * 13 dqtr_desc, 14 afg_desc, 15 afe_desc, 16 tz_pu, 17 tz_cfg, 18 intra_desc, 19 cclm_desc, 20 intra_fill_desc; -1 for unknown ids.          */
 int         vvcgpu_sizeof(int struct_id);
 
 /* ---- device memory helpers for host-side callers (the reference keeps pictures in host memory; the shim stages them).
@@ -401,6 +401,24 @@ typedef struct vvcgpu_intra_desc {
 int vvcgpu_intra_ref_lengths(int w, int h, int* top_len, int* left_len);
 int vvcgpu_intra_pred_batch(const vvc_pel* refs_base, vvc_pel* dst_base, const vvcgpu_intra_desc* descs, int n, int clp_min, int clp_max,
                             void* stream);
+
+/* N4, reference sample gathering: IntraPrediction::xFillReferenceSamples (:807-1004) for the packed layout above.  rec_off: the
+ * block's top-left sample in the reconstruction plane; flags_off: the reference's neighborFlags of the block in flags_base, one
+ * byte per unit in chain order  below-left (bottom first) ... left ... top-left ... above ... above-right,
+ * ceil(L / unit_h) + 1 + ceil(T / unit_w) entries (the availability walk over the coding structure, :853-858, stays with the
+ * caller); unit_w / unit_h: pcv.minCUWidth / Height shifted by the component scale (:824-826).  Unavailable units are padded
+ * exactly like the reference's line buffer; with nothing available every sample is 1 << (bit_depth - 1).  ref_off: where the
+ * T + L + 1 packed samples go in refs_base -- feed them to vvcgpu_intra_pred_batch.                                         */
+typedef struct vvcgpu_intra_fill_desc {
+  int64_t rec_off, flags_off, ref_off;
+  int32_t rec_stride;
+  int16_t w, h;
+  int8_t  unit_w, unit_h;
+  int16_t reserved;
+  int32_t reserved2;                    /* sizeof == 40 */
+} vvcgpu_intra_fill_desc;
+int vvcgpu_intra_fill_refs_batch(const vvc_pel* rec_base, const uint8_t* flags_base, vvc_pel* refs_base, const vvcgpu_intra_fill_desc* descs,
+                                 int n, int bit_depth, void* stream);
 
 /* N4, CCLM: cross-component linear model prediction of a chroma block  (IntraPrediction::xGetLumaRecPixels :1283-1581, the
  * JVET_K0190 branch, + xGetLMParameters :1597-1857 + predIntraChromaLM :390-403).  4:2:0 only.  luma_off: the co-located luma

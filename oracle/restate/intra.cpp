@@ -151,3 +151,39 @@ ORC_API int orc_intra_pred(const Pel* refs, Pel* dst, int dstStride, int w, int 
   }
   return 0;
 }
+
+// ---- reference sample gathering: IntraPrediction::xFillReferenceSamples :807-1004 ----------------------------------------------
+// flags[0 .. totalUnits): the reference's neighborFlags, chain order bottom-left ... left ... top-left ... above ... above-right
+// (left units are uh samples high, the top-left and above units uw samples wide).  rec points at the block's top-left sample in
+// the reconstruction.  Output packed like the predictors' input (refs[0] top-left, then T above, then L left).
+// The reference pads through a line buffer: an unavailable unit repeats the last sample of the unit before it (after that one
+// was padded itself), and a leading run of unavailable units repeats the first sample of the first available unit.  In closed
+// form: every sample of an unavailable unit equals one fixed sample of the nearest available unit.
+ORC_API int orc_intra_fill_refs(const Pel* rec, int recStride, const uint8_t* flags, Pel* refs, int w, int h, int uw, int uh, int bitDepth)
+{
+  int T, L; orc_intra_ref_lengths(w, h, &T, &L);
+  const int aboveUnits = (T + uw - 1) / uw, leftUnits = (L + uh - 1) / uh, total = aboveUnits + leftUnits + 1;
+  const Pel dc = (Pel)(1 << (bitDepth - 1));
+  int numAvail = 0, first = -1;
+  for (int u = 0; u < total; u++) if (flags[u]) { numAvail++; if (first < 0) first = u; }
+  // recon sample `o` (0 = first in chain order) of unit u
+  auto unitSample = [&](int u, int o) -> Pel
+  {
+    if (u < leftUnits) { const int y = (leftUnits - u) * uh - 1 - o; return rec[(ptrdiff_t)y * recStride - 1]; }      // chain order runs upwards
+    if (u == leftUnits) return rec[-recStride - 1];
+    return rec[-recStride + (u - leftUnits - 1) * uw + o];
+  };
+  auto unitLen = [&](int u) { return u < leftUnits ? uh : uw; };
+  auto value = [&](int u, int o) -> Pel
+  {
+    if (numAvail == 0) return dc;
+    if (flags[u]) return unitSample(u, o);
+    int p = u - 1;
+    while (p >= 0 && !flags[p]) p--;
+    if (p >= 0) return unitSample(p, unitLen(p) - 1);
+    return unitSample(first, 0);
+  };
+  for (int p = 0; p <= T; p++) { const int q = uw - 1 + p; refs[p] = value(leftUnits + q / uw, q % uw); }
+  for (int i = 1; i <= L; i++) { const int k = leftUnits * uh - i; refs[T + i] = value(k / uh, k % uh); }
+  return 0;
+}

@@ -155,3 +155,65 @@ def test_cclm_golden_and_random():
         bad = np.nonzero(got != want)[0][0]
         k = int(np.searchsorted(d["dst_off"], bad, side="right")) - 1
         raise AssertionError("first mismatch in desc %s" % (d[k],))
+
+
+def test_intra_fill_refs_golden_and_random():
+    """xFillReferenceSamples on the device: (1) the 1584 calls captured from the reference, one launch; (2) random availability
+    patterns (none, all, random runs) for every block shape and both unit sizes against the oracle; (3) chained with
+    vvcgpu_intra_pred_batch: reconstruction + flags -> prediction, equal to the oracle's fill -> (filter) -> predict."""
+    from vvcsoftware_vtm_amd import ops
+    from test_oracle_golden import intra_fill_records
+    O = oracle()
+    for bd in (8, 10):
+        recs = [r for r in intra_fill_records() if r[4] == bd]
+        d = np.zeros(len(recs), ops.INTRA_FILL_DESC)
+        planes, flags_all, wants = [], [], []
+        po = fo = ro = 0
+        for i, (w, h, uw, uh, _, T, L, flags, plane, want) in enumerate(recs):
+            d[i] = (po + plane.shape[1] + 1, fo, ro, plane.shape[1], w, h, uw, uh, 0, 0)
+            planes.append(plane.reshape(-1)); flags_all.append(flags); wants.append(want)
+            po += plane.size; fo += flags.size; ro += want.size
+        out = torch.zeros(ro, dtype=torch.int16, device="cuda")
+        ops.intra_fill_refs_batch(dev(np.concatenate(planes)), dev(np.concatenate(flags_all)), out, ops.struct_to_device(d), len(d), bd)
+        assert np.array_equal(out.cpu().numpy(), np.concatenate(wants))
+
+    rng = np.random.default_rng(21)
+    bd = 10
+    W, H = 512, 384
+    rec = rng.integers(0, 1024, (H, W)).astype(np.int16)
+    fdescs, flags_all, wants, pdescs, pwants = [], [], [], [], []
+    fo = ro = po = 0
+    for (w, h) in SHAPES:
+        T, L = ops.intra_ref_lengths(w, h)
+        for unit in (4, 2):
+            aboveUnits, leftUnits = (T + unit - 1) // unit, (L + unit - 1) // unit
+            total = aboveUnits + leftUnits + 1
+            for pat in range(6):
+                if pat == 0:
+                    flags = np.zeros(total, np.uint8)
+                elif pat == 1:
+                    flags = np.ones(total, np.uint8)
+                elif pat == 2:                               # only something far along the chain is available
+                    flags = np.zeros(total, np.uint8); flags[int(rng.integers(total // 2, total))] = 1
+                else:                                        # random runs
+                    flags = np.repeat(rng.integers(0, 2, total).astype(np.uint8), int(rng.integers(1, 5)))[:total].copy()
+                x0, y0 = int(rng.integers(140, W - 200)), int(rng.integers(140, H - 200))
+                want = np.zeros(T + L + 1, np.int16)
+                O.orc_intra_fill_refs(C.c_void_p(rec.ctypes.data + (y0 * W + x0) * 2), W, p(flags), p(want), w, h, unit, unit, bd)
+                fdescs.append((y0 * W + x0, fo, ro, W, w, h, unit, unit, 0, 0))
+                mode, filt = int(rng.integers(0, 67)), int(rng.integers(0, 2))
+                src = want
+                if filt:
+                    src = np.zeros_like(want); O.orc_intra_filter_refs(p(want), p(src), w, h)
+                pw = np.zeros((h, w), np.int16)
+                O.orc_intra_pred(p(src), p(pw), w, w, h, mode, 0, 1023)
+                pdescs.append((ro, po, w, w, h, mode, filt, 0, 0))
+                flags_all.append(flags); wants.append(want); pwants.append(pw.reshape(-1))
+                fo += total; ro += want.size; po += pw.size
+    fd, pd = np.array(fdescs, ops.INTRA_FILL_DESC), np.array(pdescs, ops.INTRA_DESC)
+    refs = torch.zeros(ro, dtype=torch.int16, device="cuda")
+    pred = torch.zeros(po, dtype=torch.int16, device="cuda")
+    ops.intra_fill_refs_batch(dev(rec), dev(np.concatenate(flags_all)), refs, ops.struct_to_device(fd), len(fd), bd)
+    ops.intra_pred_batch(refs, pred, ops.struct_to_device(pd), len(pd))
+    assert np.array_equal(refs.cpu().numpy(), np.concatenate(wants))
+    assert np.array_equal(pred.cpu().numpy(), np.concatenate(pwants))

@@ -323,3 +323,32 @@ def test_cclm_golden():
         n += 1
         combos.add((w, h, above, left))
     assert n > 500 and len(combos) > 50
+
+
+def intra_fill_records():
+    g = load("intra_fill")
+    hdr, flags, top, left, out = g["hdr"], g["flags"], g["top"], g["left"], g["out"]
+    fo = to = lo = oo = 0
+    for (w, h, uw, uh, bd, T, L, total) in hdr:
+        w, h, uw, uh, bd, T, L, total = [int(v) for v in (w, h, uw, uh, bd, T, L, total)]
+        topN, leftN = 1 + ((T + uw - 1) // uw) * uw, ((L + uh - 1) // uh) * uh
+        # rebuild a small reconstruction plane: row 0 = the row above (from x = -1), column 0 = the column to the left
+        plane = np.zeros((leftN + 1, topN), np.int16)
+        plane[0, :] = top[to:to + topN]
+        plane[1:, 0] = left[lo:lo + leftN]
+        yield w, h, uw, uh, bd, T, L, np.ascontiguousarray(flags[fo:fo + total]), plane, out[oo:oo + T + L + 1]
+        fo += total; to += topN; lo += leftN; oo += T + L + 1
+
+
+def test_intra_fill_refs_golden():
+    """next row N4: restated xFillReferenceSamples vs samples captured from the reference's own function inside encoder runs
+    (tests/golden/gen_intra_fill.py): 1584 calls, most of them with partially available neighbours."""
+    O = oracle()
+    n = partial = 0
+    for (w, h, uw, uh, bd, T, L, flags, plane, want) in intra_fill_records():
+        got = np.zeros(T + L + 1, np.int16)
+        O.orc_intra_fill_refs(C.c_void_p(plane.ctypes.data + (plane.shape[1] + 1) * 2), plane.shape[1], p(flags), p(got), w, h, uw, uh, bd)
+        assert np.array_equal(got, want), (w, h, uw, uh, flags.tolist())
+        n += 1
+        partial += 0 < int(flags.sum()) < len(flags)
+    assert n > 1000 and partial > 500

@@ -174,6 +174,62 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const Pel* __restrict__
 }
 
 
+// ---- reference sample gathering: xFillReferenceSamples :807-1004 ---------------------------------------------------------------
+// One wavefront per block.  The reference pads through a line buffer (an unavailable unit repeats the last sample of the unit
+// before it, a leading unavailable run repeats the first sample of the first available unit); in closed form every sample of an
+// unavailable unit is one fixed sample of the nearest available unit, so each lane resolves its output samples independently.
+__global__ __launch_bounds__(256) void intra_fill_refs_kernel(const Pel* __restrict__ recBase, const unsigned char* __restrict__ flagsBase,
+                                                              Pel* __restrict__ refsBase, const vvcgpu_intra_fill_desc* __restrict__ descs, int n,
+                                                              int bitDepth)
+{
+  __shared__ short srcUnit[4][192];                      // per unit: the unit that provides its samples (itself when available), or -1
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= n) return;
+  const vvcgpu_intra_fill_desc d = descs[b];
+  const int w = d.w, h = d.h, uw = d.unit_w, uh = d.unit_h, rs = d.rec_stride;
+  int T = w << 1, L = h << 1;
+  {
+    const int lw = ilog2(w), lh = ilog2(h), ratio = min(2, abs(lw - lh));
+    if (w > h) L += (w >> ratio) - h + ((w + 31) >> 5);
+    else if (h > w) T += (h >> ratio) - w + ((h + 31) >> 5);
+  }
+  const int aboveUnits = (T + uw - 1) / uw, leftUnits = (L + uh - 1) / uh, total = aboveUnits + leftUnits + 1;
+  const unsigned char* flags = flagsBase + d.flags_off;
+  short* su = srcUnit[wave];
+  int firstLocal = 0x7fff;
+  for (int u = lane; u < total; u += 64)
+  {
+    int p = u;
+    while (p >= 0 && !flags[p]) p--;
+    su[u] = (short)p;                                     // nearest available unit at or before u, -1 if none
+    if (flags[u]) firstLocal = min(firstLocal, u);
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) firstLocal = min(firstLocal, __shfl_xor(firstLocal, m));
+  wave_sync();
+  const int first = firstLocal;                           // 0x7fff: nothing available
+  const Pel* rec = recBase + d.rec_off;
+  Pel* refs = refsBase + d.ref_off;
+  const int dc = 1 << (bitDepth - 1);
+  for (int i = lane; i <= T + L; i += 64)
+  {
+    int u, o;
+    if (i <= T) { const int q = uw - 1 + i; u = leftUnits + q / uw; o = q % uw; }
+    else { const int k = leftUnits * uh - (i - T); u = k / uh; o = k % uh; }
+    int v = dc;
+    if (first != 0x7fff)
+    {
+      int s = su[u];
+      if (s != u) { if (s >= 0) o = (s < leftUnits ? uh : uw) - 1; else { s = first; o = 0; } }
+      if (s < leftUnits) v = rec[(ptrdiff_t)((leftUnits - s) * uh - 1 - o) * rs - 1];
+      else if (s == leftUnits) v = rec[-rs - 1];
+      else v = rec[-rs + (s - leftUnits - 1) * uw + o];
+    }
+    refs[i] = (Pel)v;
+  }
+}
+
 // ---- CCLM (JVET_K0190): xGetLumaRecPixels :1283-1581 + xGetLMParameters :1597-1857 + predIntraChromaLM :390-403 -------------
 // One wavefront per chroma block.  The down-sampled luma is never stored: neighbours are produced for the parameter sums and the
 // inner samples on the fly for the final linear map (6 luma reads per chroma sample, all L1/L2 hits of one small region).
@@ -304,6 +360,18 @@ extern "C" int vvcgpu_cclm_pred_batch(const vvc_pel* luma_base, const vvc_pel* n
   VVC_CHECK_ARG(clp_min <= clp_max, "cclm_pred_batch: clip range");
   hipLaunchKernelGGL(cclm_pred_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, luma_base, nb_base, dst_base, descs, n, bit_depth_luma,
                      bit_depth_chroma, clp_min, clp_max);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+extern "C" int vvcgpu_intra_fill_refs_batch(const vvc_pel* rec_base, const uint8_t* flags_base, vvc_pel* refs_base, const vvcgpu_intra_fill_desc* descs,
+                                            int n, int bit_depth, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "intra_fill_refs_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(rec_base && flags_base && refs_base && descs, "intra_fill_refs_batch: null pointer");
+  VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 12, "intra_fill_refs_batch: bit depth %d", bit_depth);
+  hipLaunchKernelGGL(intra_fill_refs_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, rec_base, flags_base, refs_base, descs, n, bit_depth);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

@@ -95,6 +95,7 @@ int vvcgpu_sizeof(int id)
   case 17: return (int)sizeof(vvcgpu_tz_cfg);
   case 18: return (int)sizeof(vvcgpu_intra_desc);
   case 19: return (int)sizeof(vvcgpu_cclm_desc);
+  case 20: return (int)sizeof(vvcgpu_intra_fill_desc);
   default: return -1;
   }
 }

@@ -252,6 +252,16 @@ def cclm_pred_batch(luma_base, nb_base, dst_base, descs_dev, n, bd_luma=10, bd_c
               clp[0], clp[1], _stream())
 
 
+INTRA_FILL_DESC = np.dtype([("rec_off", "<i8"), ("flags_off", "<i8"), ("ref_off", "<i8"), ("rec_stride", "<i4"), ("w", "<i2"), ("h", "<i2"),
+                            ("unit_w", "i1"), ("unit_h", "i1"), ("reserved", "<i2"), ("reserved2", "<i4")])
+assert INTRA_FILL_DESC.itemsize == 40
+
+
+def intra_fill_refs_batch(rec_base, flags_base, refs_base, descs_dev, n, bit_depth=10):
+    """N4: xFillReferenceSamples for n blocks: reconstruction + unit availability flags -> packed reference samples."""
+    capi.call("vvcgpu_intra_fill_refs_batch", capi.ptr(rec_base), capi.ptr(flags_base), capi.ptr(refs_base), capi.ptr(descs_dev), n, bit_depth, _stream())
+
+
 # ---- interpolation / MC / PelBuffer ops -------------------------------------------------------------
 IF_DESC = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("src_stride", "<i4"), ("dst_stride", "<i4"),
                     ("w", "<i2"), ("h", "<i2"), ("taps", "i1"), ("is_vertical", "i1"), ("is_first", "i1"),

@@ -16,6 +16,7 @@
 #include <cstring>
 #include <vector>
 #include <map>
+#include <string>
 
 #include "CommonLib/CommonDef.h"
 #include "CommonLib/CodingStructure.h"
@@ -73,6 +74,10 @@ void real_predIntraChromaLM(IntraPrediction*, const ComponentID, PelBuf&, const 
   asm("__real__ZN15IntraPrediction17predIntraChromaLME11ComponentIDR7AreaBufIsERK14PredictionUnitRK8CompAreai");
 void wrap_predIntraChromaLM(IntraPrediction*, const ComponentID, PelBuf&, const PredictionUnit&, const CompArea&, int)
   asm("__wrap__ZN15IntraPrediction17predIntraChromaLME11ComponentIDR7AreaBufIsERK14PredictionUnitRK8CompAreai");
+void real_initIntraPatternChType(IntraPrediction*, const CodingUnit&, const CompArea&, const bool)
+  asm("__real__ZN15IntraPrediction22initIntraPatternChTypeERK10CodingUnitRK8CompAreab");
+void wrap_initIntraPatternChType(IntraPrediction*, const CodingUnit&, const CompArea&, const bool)
+  asm("__wrap__ZN15IntraPrediction22initIntraPatternChTypeERK10CodingUnitRK8CompAreab");
 void real_extendPicBorder(Picture*) asm("__real__ZN7Picture15extendPicBorderEv");
 void wrap_extendPicBorder(Picture*) asm("__wrap__ZN7Picture15extendPicBorderEv");
 
@@ -91,11 +96,11 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[25] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+long g_calls[26] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
-                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld, IntraPred %ld, Border %ld, Hash %ld, CCLM %ld\n",
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld, IntraPred %ld, Border %ld, Hash %ld, CCLM %ld, IntraRefs %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
-                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20], g_calls[21], g_calls[22], g_calls[23], g_calls[24]); } } g_report;
+                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20], g_calls[21], g_calls[22], g_calls[23], g_calls[24], g_calls[25]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -1176,6 +1181,111 @@ void wrap_predIntraChromaLM(IntraPrediction* self, const ComponentID compID, Pel
   }
   for (int y = 0; y < h; y++) memcpy(piPred.buf + (size_t)y * piPred.stride, &ref[(size_t)y * w], w * sizeof(Pel));
   g_calls[24]++;
+}
+
+// ---- IntraPrediction::initIntraPatternChType (IntraPrediction.cpp:787-805): the reference sample gathering xFillReferenceSamples
+// (:807-1004) = vvcgpu_intra_fill_refs_batch with one descriptor (next row N4).  The availability walk (:853-858) is redone here
+// with the reference's public CodingStructure API; the [1 2 1] filter of step 2 stays with the reference's own function (the
+// device filter is part of vvcgpu_intra_pred_batch and proven there).  VVCGPU_SHIM_FILL_VERIFY=1: A/B check against the
+// reference's own body; VVCGPU_FILL_DUMP=<file>: fixture capture (tests/golden/gen_intra_fill.py; works without a GPU).
+namespace {
+DevArray<vvc_pel> g_fRec, g_fRefs;
+DevArray<uint8_t> g_fFlags;
+DevArray<vvcgpu_intra_fill_desc> g_fDesc;
+
+bool unitAvailable(const CodingUnit& cu, ChannelType chType, const Position& refPos, bool& noCU)
+{
+  const CodingStructure& cs = *cu.cs;
+  const CodingUnit* nb = cs.isDecomp(refPos, chType) ? cs.getCURestricted(refPos, cu, chType) : nullptr;
+  noCU = nb == nullptr;
+  return nb && (!cs.pps->getConstrainedIntraPred() || CU::isIntra(*nb));
+}
+}
+
+void wrap_initIntraPatternChType(IntraPrediction* self, const CodingUnit& cu, const CompArea& area, const bool bFilterRefSamples)
+{
+  const char* dump = getenv("VVCGPU_FILL_DUMP");
+  const bool gpu = shimEnabled() && !getenv("VVCGPU_SHIM_NO_TABLES");
+  const int w = area.width, h = area.height;
+  static const long limit = getenv("VVCGPU_SHIM_FILL_LIMIT") ? atol(getenv("VVCGPU_SHIM_FILL_LIMIT")) : 60000;
+  if (!(gpu || dump) || w < 4 || h < 4 || w > 64 || h > 64 || (w & (w - 1)) || (h & (h - 1)) || (gpu && !dump && limit > 0 && g_calls[25] >= limit))
+  { real_initIntraPatternChType(self, cu, area, bFilterRefSamples); return; }
+  const CodingStructure& cs = *cu.cs;
+  const ChannelType chType = toChannelType(area.compID);
+  const PreCalcValues& pcv = *cs.pcv;
+  self->setReferenceArrayLengths(area);
+  const int T = self->m_topRefLength, L = self->m_leftRefLength, stride = T + 1;
+  const bool noShift = pcv.noChroma2x2 && area.width == 4;
+  const int uw = pcv.minCUWidth >> (noShift ? 0 : getComponentScaleX(area.compID, cs.sps->getChromaFormatIdc()));
+  const int uh = pcv.minCUHeight >> (noShift ? 0 : getComponentScaleY(area.compID, cs.sps->getChromaFormatIdc()));
+  const int aboveUnits = (T + uw - 1) / uw, leftUnits = (L + uh - 1) / uh, total = aboveUnits + leftUnits + 1;
+  const int numAbove = std::max(w / uw, 1), numLeft = std::max(h / uh, 1);
+  std::vector<uint8_t> flags(total, 0);
+  {
+    // :853-858 -- each walk stops at the first position without a coding unit
+    const Position posLT = area, posRT = area.topRight(), posLB = area.bottomLeft();
+    bool noCU;
+    flags[leftUnits] = unitAvailable(cu, chType, posLT.offset(-1, -1), noCU);
+    for (int k = 0; k < numAbove; k++) { const bool a = unitAvailable(cu, chType, posLT.offset(k * uw, -1), noCU); if (a) flags[leftUnits + 1 + k] = 1; else if (noCU) break; }
+    for (int k = 0; k < aboveUnits - numAbove; k++) { const bool a = unitAvailable(cu, chType, posRT.offset(uw + k * uw, -1), noCU); if (a) flags[leftUnits + 1 + numAbove + k] = 1; else if (noCU) break; }
+    for (int k = 0; k < numLeft; k++) { const bool a = unitAvailable(cu, chType, posLT.offset(-1, k * uh), noCU); if (a) flags[leftUnits - 1 - k] = 1; else if (noCU) break; }
+    for (int k = 0; k < leftUnits - numLeft; k++) { const bool a = unitAvailable(cu, chType, posLB.offset(-1, uh + k * uh), noCU); if (a) flags[leftUnits - 1 - numLeft - k] = 1; else if (noCU) break; }
+  }
+  const CPelBuf reco = cs.picture->getRecoBuf(area);
+  // the samples the gathering may read: the row above from x = -1 and the column to the left (whole units)
+  const int topN = 1 + aboveUnits * uw, leftN = leftUnits * uh;
+  const int bd = cs.sps->getBitDepth(chType);
+  Pel* unf = self->m_piYuvExt[area.compID][PRED_BUF_UNFILTERED];
+  if (dump)
+  {
+    real_initIntraPatternChType(self, cu, area, bFilterRefSamples);
+    static FILE* f = fopen(dump, "ab");
+    static std::map<std::string, int> seen;
+    std::string key = std::to_string(w) + "x" + std::to_string(h) + ":" + std::to_string(uw) + ":" + std::string(flags.begin(), flags.end());
+    for (auto& c : key) if (c == 0) c = '0'; else if (c == 1) c = '1';
+    if (f && seen[key]++ < 2)
+    {
+      const int32_t hdr[8] = { w, h, uw, uh, bd, T, L, total };
+      fwrite(hdr, sizeof hdr, 1, f);
+      fwrite(flags.data(), 1, total, f);
+      std::vector<Pel> top(topN), left(leftN), out((size_t)T + L + 1);
+      // unavailable units may lie outside the decoded area: record zeros for them (never read by a correct implementation)
+      for (int x = 0; x < topN; x++) { const int u = x == 0 ? leftUnits : leftUnits + 1 + (x - 1) / uw; top[x] = flags[u] ? reco.buf[-(ptrdiff_t)reco.stride - 1 + x] : 0; }
+      for (int y = 0; y < leftN; y++) { const int u = leftUnits - 1 - y / uh; left[y] = flags[u] ? reco.buf[(ptrdiff_t)y * reco.stride - 1] : 0; }
+      for (int x = 0; x <= T; x++) out[x] = unf[x];
+      for (int y = 1; y <= L; y++) out[T + y] = unf[(size_t)y * stride];
+      fwrite(top.data(), sizeof(Pel), top.size(), f); fwrite(left.data(), sizeof(Pel), left.size(), f); fwrite(out.data(), sizeof(Pel), out.size(), f);
+      fflush(f);
+    }
+    return;
+  }
+  // window: row -1 (topN samples from x = -1), then rows 0 .. leftN-1 with the single column x = -1 -> a (leftN + 1) x topN plane
+  std::vector<vvc_pel> win((size_t)(leftN + 1) * topN, 0);
+  for (int x = 0; x < topN; x++) { const int u = x == 0 ? leftUnits : leftUnits + 1 + (x - 1) / uw; if (flags[u]) win[x] = reco.buf[-(ptrdiff_t)reco.stride - 1 + x]; }
+  for (int y = 0; y < leftN; y++) { const int u = leftUnits - 1 - y / uh; if (flags[u]) win[(size_t)(y + 1) * topN] = reco.buf[(ptrdiff_t)y * reco.stride - 1]; }
+  g_fRec.upload(win.data(), win.size());
+  g_fFlags.upload(flags.data(), flags.size());
+  g_fRefs.reserve((size_t)T + L + 1);
+  vvcgpu_intra_fill_desc d;
+  memset(&d, 0, sizeof d);
+  d.rec_off = topN + 1; d.rec_stride = topN; d.w = (int16_t)w; d.h = (int16_t)h; d.unit_w = (int8_t)uw; d.unit_h = (int8_t)uh;
+  g_fDesc.upload(&d, 1);
+  VVCGPU(vvcgpu_intra_fill_refs_batch(g_fRec.ptr, g_fFlags.ptr, g_fRefs.ptr, g_fDesc.ptr, 1, bd, nullptr));
+  std::vector<vvc_pel> refs((size_t)T + L + 1);
+  VVCGPU(vvcgpu_memcpy_d2h(refs.data(), g_fRefs.ptr, refs.size() * sizeof(vvc_pel), nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  if (getenv("VVCGPU_SHIM_FILL_VERIFY"))
+  {
+    real_initIntraPatternChType(self, cu, area, false);
+    bool same = true;
+    for (int x = 0; x <= T && same; x++) same = unf[x] == refs[x];
+    for (int y = 1; y <= L && same; y++) same = unf[(size_t)y * stride] == refs[T + y];
+    if (!same) fprintf(stderr, "[vvcgpu shim] intra reference sample mismatch: %dx%d comp %d unit %dx%d\n", w, h, (int)area.compID, uw, uh);
+  }
+  for (int x = 0; x <= T; x++) unf[x] = refs[x];
+  for (int y = 1; y <= L; y++) unf[(size_t)y * stride] = refs[T + y];
+  if (bFilterRefSamples) self->xFilterReferenceSamples(unf, self->m_piYuvExt[area.compID][PRED_BUF_FILTERED], area, *cs.sps);
+  g_calls[25]++;
 }
 
 // ---- Picture::extendPicBorder (Picture.cpp:996-1041): the padded reconstruction planes go to the device, every margin is
