@@ -42,7 +42,7 @@ int         vvcgpu_device_count(void);
 int         vvcgpu_set_device(int device);
 /* sizeof() of the parameter structs, for binding self-checks: 0 sao_ctu, 1 deblock_cfg, 2 dist_desc, 3 search_blk,
  * 4 mvcost, 5 search_best, 6 if_desc, 7 mc_desc, 8 pelop_desc, 9 pelop_cfg, 10 tr_desc, 11 frac_blk, 12 frac_result,
- * 13 dqtr_desc, 14 afg_desc, 15 afe_desc, 16 tz_pu, 17 tz_cfg, 18 intra_desc, 19 cclm_desc, 20 intra_fill_desc; -1 for unknown ids.          */
+ * 13 dqtr_desc, 14 afg_desc, 15 afe_desc, 16 tz_pu, 17 tz_cfg, 18 intra_desc, 19 cclm_desc, 20 intra_fill_desc, 21 imv_pu, 22 imv_result; -1 for unknown ids.          */
 int         vvcgpu_sizeof(int struct_id);
 
 /* ---- device memory helpers for host-side callers (the reference keeps pictures in host memory; the shim stages them).
@@ -458,6 +458,31 @@ typedef struct vvcgpu_frac_result { int32_t half_x, half_y, qter_x, qter_y; uint
 int vvcgpu_frac_refine(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride,
                        const vvcgpu_frac_blk* blocks, int nblocks, int w, int h, int bit_depth, int clp_min, int clp_max,
                        int use_hadamard, const vvcgpu_mvcost* mvcost_host, vvcgpu_frac_result* results, void* stream);
+
+/* N2, AMVR: integer / 4-sample refinement of the integer search result with both AMVP candidates
+ * (InterSearch::xPatternSearchIntRefine, InterSearch.cpp:2408-2501; taken instead of the fractional refinement when cu.imv != 0).
+ * 9 positions (the input vector and its 8 neighbours at distance 1 << imv_shift) x num_cand predictors; distortion = SATD
+ * (use_hadamard: getUseHADME() && !transQuantBypass) or SAD at the clipped position, times `weight` in double precision and
+ * truncated (:2456), + the MV cost against that predictor; strict '<' in visiting order.  Per PU: mv = rcMv on entry (integer
+ * units), cand = amvpInfo.mvCand[0..1] (quarter units), idx_cost = m_auiMVPIdxCost[0..1][AMVP_MAX_NUM_CANDS], mvp_idx / bits =
+ * riMVPIdx / ruiBits on entry.  Result: mv (quarter units), mvp_idx, bits = ruiBits, cost = ruiCost on exit.  cfg: the fields
+ * lambda, imv_shift (1 or 2 + ...: 2 for integer, 4 for 4-sample in quarter units), picture geometry and readable rectangle of
+ * vvcgpu_tz_cfg are used.                                                                                                  */
+typedef struct vvcgpu_imv_pu {
+  int32_t org_x, org_y, ref_x, ref_y;
+  int32_t mv_x, mv_y;
+  int32_t cand_x[2], cand_y[2];
+  int32_t pos_x, pos_y;
+  uint32_t idx_cost[2];
+  uint32_t bits;
+  int16_t w, h;
+  int8_t  num_cand, mvp_idx;
+  int16_t reserved;
+  int32_t reserved2;                    /* sizeof == 72 */
+} vvcgpu_imv_pu;
+typedef struct vvcgpu_imv_result { int32_t mv_x, mv_y, mvp_idx; uint32_t bits; uint64_t cost; } vvcgpu_imv_result;
+int vvcgpu_imv_refine_batch(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride, const vvcgpu_imv_pu* pus, int n,
+                            const vvcgpu_tz_cfg* cfg_host, int use_hadamard, double weight, vvcgpu_imv_result* results, void* stream);
 
 /* N2, chained: integer TZ search followed by the fused fractional refinement (I2) of the same PUs, on one stream with no host
  * round trip -- the device form of InterSearch::xMotionEstimation's  xPatternSearchFast -> xPatternSearchFracDIF  sequence

@@ -729,3 +729,50 @@ int vtmref_intra_pred(const Pel* refs, Pel* dst, int dstStride, int w, int h, in
   return 0;
 }
 }
+
+// ---------------------------------------------------------------------------------------------
+// AMVR integer refinement: the reference's own InterSearch::xPatternSearchIntRefine (InterSearch.cpp:2408-2501).
+extern "C" int vtmref_imv_refine(const Pel* org, int os, const Pel* ref, int rs, const vvcgpu_imv_pu* pus, int n, const vvcgpu_tz_cfg* c, int bd,
+                                 int useHad, double weight, vvcgpu_imv_result* out)
+{
+  static InterSearch* is = nullptr;
+  static RdCost* rc = nullptr;
+  static EncCfg* cfg = nullptr;
+  static SPS* sps = nullptr;
+  static CodingStructure* cs = nullptr;
+  if (!is)
+  {
+    is = new InterSearch; rc = new RdCost; cfg = new EncCfg; sps = new SPS;
+    rc->setUseQtbt(true);
+    is->InterPrediction::init(rc, CHROMA_420);
+    is->m_pcEncCfg = cfg; is->m_pcRdCost = rc;
+    cs = (CodingStructure*)calloc(1, sizeof(CodingStructure));
+    cs->sps = sps;
+  }
+  sps->setPicWidthInLumaSamples(c->pic_w); sps->setPicHeightInLumaSamples(c->pic_h);
+  sps->setMaxCUWidth(c->max_cu_w); sps->setMaxCUHeight(c->max_cu_h);
+  cfg->setUseHADME(useHad != 0);
+  is->m_lumaClpRng = mkClp(0, (1 << bd) - 1, bd);
+  rc->m_motionLambda = c->lambda;
+  for (int i = 0; i < n; i++)
+  {
+    const vvcgpu_imv_pu& p = pus[i];
+    CodingUnit cu; cu.UnitArea::operator=(UnitArea(CHROMA_420, Area(p.pos_x, p.pos_y, p.w, p.h)));
+    cu.imv = c->imv_shift == 2 ? 1 : 2; cu.transQuantBypass = false; cu.cs = cs;
+    PredictionUnit pu; pu.UnitArea::operator=(cu); pu.cu = &cu; pu.cs = cs;
+    CPelBuf patternKey(org + (ptrdiff_t)p.org_y * os + p.org_x, os, p.w, p.h);
+    InterSearch::IntTZSearchStruct st;
+    st.pcPatternKey = &patternKey;
+    st.piRefY = ref + (ptrdiff_t)p.ref_y * rs + p.ref_x;
+    st.iRefStride = rs; st.imvShift = c->imv_shift; st.subShiftMode = 0; st.inCtuSearch = false; st.zeroMV = false;
+    AMVPInfo amvp;
+    amvp.numCand = p.num_cand;
+    for (int k = 0; k < 2; k++) amvp.mvCand[k] = Mv(p.cand_x[k], p.cand_y[k]);
+    for (int k = 0; k < 2; k++) is->m_auiMVPIdxCost[k][AMVP_MAX_NUM_CANDS] = p.idx_cost[k];
+    Mv mv(p.mv_x, p.mv_y), mvPred = amvp.mvCand[p.mvp_idx];
+    int mvpIdx = p.mvp_idx; uint32_t bits = p.bits; Distortion cost = 0;
+    is->xPatternSearchIntRefine(pu, st, mv, mvPred, mvpIdx, bits, cost, amvp, weight);
+    out[i].mv_x = mv.getHor(); out[i].mv_y = mv.getVer(); out[i].mvp_idx = mvpIdx; out[i].bits = bits; out[i].cost = cost;
+  }
+  return 0;
+}

@@ -209,3 +209,67 @@ ORC_API int orc_tz_search(const Pel* org, int os, const Pel* ref, int rs, const 
   }
   return 0;
 }
+
+
+// ---- InterSearch::xPatternSearchIntRefine :2408-2501 (AMVR) ------------------------------------------------------------------
+extern "C" uint64_t orc_satd(const Pel* org, int os, const Pel* cur, int cs, int w, int h);
+extern "C" uint32_t orc_expgolomb_bits(int v);
+
+ORC_API int orc_imv_refine(const Pel* org, int os, const Pel* ref, int rs, const vvcgpu_imv_pu* pus, int n, const vvcgpu_tz_cfg* cfg,
+                           int useHad, double weight, vvcgpu_imv_result* out)
+{
+  static const int testPos[9][2] = { { 0, 0 }, { -1, -1 }, { -1, 0 }, { -1, 1 }, { 0, -1 }, { 0, 1 }, { 1, -1 }, { 1, 0 }, { 1, 1 } };
+  for (int i = 0; i < n; i++)
+  {
+    const vvcgpu_imv_pu& p = pus[i];
+    const int sh = cfg->imv_shift, mvOffset = 1 << sh;
+    auto clipq = [&](int& hor, int& ver)                          // clipMv, quarter units
+    {
+      const int horMax = (cfg->pic_w + 8 - p.pos_x - 1) << 2, horMin = (-cfg->max_cu_w - 8 - p.pos_x + 1) << 2;
+      const int verMax = (cfg->pic_h + 8 - p.pos_y - 1) << 2, verMin = (-cfg->max_cu_h - 8 - p.pos_y + 1) << 2;
+      hor = std::min(horMax, std::max(horMin, hor)); ver = std::min(verMax, std::max(verMin, ver));
+    };
+    auto bitsOf = [&](int x, int y, int c) { return orc_expgolomb_bits((x - p.cand_x[c]) >> sh) + orc_expgolomb_bits((y - p.cand_y[c]) >> sh); };   // cost scale 0
+    const int mvx = p.mv_x << 2, mvy = p.mv_y << 2;               // :2418
+    int baseX[2], baseY[2];
+    for (int c = 0; c < 2; c++)                                   // cBaseMvd, rounded (roundMV, Mv.cpp:44-52)
+    {
+      const int off = 1 << (sh - 1);
+      baseX[c] = (((mvx - p.cand_x[c]) + off) >> sh) << sh;
+      baseY[c] = (((mvy - p.cand_y[c]) + off) >> sh) << sh;
+    }
+    uint64_t bestDist = ~0ull, satd = 0;
+    int bestX = mvx, bestY = mvy, bestIdx = p.mvp_idx, bestBits = 0;
+    for (int pos = 0; pos < 9; pos++)
+    {
+      int tx[2] = { 0, 0 }, ty[2] = { 0, 0 };
+      for (int c = 0; c < p.num_cand; c++)
+      {
+        tx[c] = testPos[pos][0] * mvOffset + baseX[c] + p.cand_x[c];
+        ty[c] = testPos[pos][1] * mvOffset + baseY[c] + p.cand_y[c];
+        uint64_t dist;
+        if (c == 0 || tx[0] != tx[1] || ty[0] != ty[1])
+        {
+          int cx = tx[c], cy = ty[c];
+          clipq(cx, cy);
+          const int px = clip3i(cfg->ref_x0, cfg->ref_x1 - p.w, p.ref_x + (cx >> 2)), py = clip3i(cfg->ref_y0, cfg->ref_y1 - p.h, p.ref_y + (cy >> 2));
+          const Pel* o = org + (ptrdiff_t)p.org_y * os + p.org_x;
+          const Pel* r = ref + (ptrdiff_t)py * rs + px;
+          const uint64_t d = useHad ? orc_satd(o, os, r, rs, p.w, p.h) : orc_sad(o, os, r, rs, p.w, p.h, 0);
+          dist = satd = (uint64_t)((double)d * weight);           // :2456
+        }
+        else dist = satd;
+        const uint32_t mvBits = bitsOf(tx[c], ty[c], c);
+        const int iMvBits = (int)(p.idx_cost[c] + mvBits);
+        dist += (uint64_t)(cfg->lambda * mvBits);
+        if (dist < bestDist) { bestDist = dist; bestX = tx[c]; bestY = ty[c]; bestIdx = c; bestBits = iMvBits; }
+      }
+    }
+    uint32_t bits = p.bits - p.idx_cost[p.mvp_idx];               // :2427
+    bits += (uint32_t)bestBits;
+    out[i].cost = bestDist - (uint64_t)(cfg->lambda * (uint32_t)bestBits) + (uint64_t)(cfg->lambda * bits);   // :2493
+    bits += bitsOf(bestX, bestY, bestIdx);                        // :2496
+    out[i].mv_x = bestX; out[i].mv_y = bestY; out[i].mvp_idx = bestIdx; out[i].bits = bits;
+  }
+  return 0;
+}

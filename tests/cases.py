@@ -149,3 +149,36 @@ def tz_cfg(W, H, M, lam, search_range=64, first_stop=0, max_cu=128, cost_scale=2
     c = np.zeros(1, TZ_CFG)
     c[0] = (lam, cost_scale, imv_shift, search_range, first_stop, W, H, max_cu, max_cu, 0, 0, W + 2 * M, H + 2 * M, wg_per_pu, 0)
     return c
+
+
+# ---- N2: AMVR integer refinement -----------------------------------------------------------------------------------
+IMV_PU = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4"),
+                   ("cand_x", "<i4", (2,)), ("cand_y", "<i4", (2,)), ("pos_x", "<i4"), ("pos_y", "<i4"), ("idx_cost", "<u4", (2,)), ("bits", "<u4"),
+                   ("w", "<i2"), ("h", "<i2"), ("num_cand", "i1"), ("mvp_idx", "i1"), ("reserved", "<i2"), ("reserved2", "<i4")])
+IMV_RESULT = np.dtype([("mv_x", "<i4"), ("mv_y", "<i4"), ("mvp_idx", "<i4"), ("bits", "<u4"), ("cost", "<u8")])
+assert IMV_PU.itemsize == 72 and IMV_RESULT.itemsize == 24
+
+
+def imv_pus(rng, n, W, H, M, sizes, imv_shift):
+    """PUs whose AMVP candidates satisfy what the encoder guarantees on entry (mv - cand is a multiple of 4 quarter units)."""
+    pus = np.zeros(n, IMV_PU)
+    for i in range(n):
+        w, h = sizes[int(rng.integers(0, len(sizes)))]
+        x = int(rng.integers(0, (W - w) // 4 + 1)) * 4
+        y = int(rng.integers(0, (H - h) // 4 + 1)) * 4
+        r = pus[i]
+        r["org_x"], r["org_y"], r["ref_x"], r["ref_y"], r["pos_x"], r["pos_y"] = x, y, M + x, M + y, x, y
+        r["mv_x"], r["mv_y"] = int(rng.integers(-40, 41)), int(rng.integers(-40, 41))
+        step = 1 << imv_shift
+        for c in range(2):
+            r["cand_x"][c] = (int(rng.integers(-60, 61)) * step) // 1 if rng.random() < 0.5 else int(rng.integers(-50, 51)) * 4
+            r["cand_y"][c] = int(rng.integers(-50, 51)) * 4
+            r["cand_x"][c] = (int(r["cand_x"][c]) // 4) * 4
+        if rng.random() < 0.25:
+            r["cand_x"][1], r["cand_y"][1] = r["cand_x"][0], r["cand_y"][0]          # equal candidates: the SATD is reused (:2449-2461)
+        r["num_cand"] = 2 if rng.random() < 0.85 else 1
+        r["mvp_idx"] = int(rng.integers(0, int(r["num_cand"])))
+        r["idx_cost"] = (1, 1) if r["num_cand"] == 2 else (0, 0)
+        r["bits"] = int(rng.integers(8, 40))
+        r["w"], r["h"] = w, h
+    return pus

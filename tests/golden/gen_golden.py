@@ -390,8 +390,26 @@ def gen_intra():
     save("intra", **out)
 
 
+def gen_imv():
+    """next row N2 (AMVR): the reference's own InterSearch::xPatternSearchIntRefine."""
+    rng = np.random.default_rng(1010)
+    out = {}
+    W, H, M = 192, 128, 160
+    sizes = [(8, 8), (16, 16), (32, 32), (64, 64), (16, 8), (8, 16), (32, 64), (4, 8), (64, 16), (128, 64), (8, 4), (4, 4)]
+    org, ref_ = cases.tz_planes(rng, W, H, M, 10, (6, -9))
+    out["org"], out["ref"] = org, ref_
+    for j, (sh, had, wgt) in enumerate([(2, 1, 1.0), (4, 1, 0.5), (2, 0, 1.37), (4, 0, 1.0)]):
+        n = 60
+        pus = cases.imv_pus(rng, n, W, H, M, sizes, sh)
+        cfg = cases.tz_cfg(W, H, M, float(rng.uniform(4, 60)), imv_shift=sh)
+        res = np.zeros(n, cases.IMV_RESULT)
+        R.vtmref_imv_refine(p(org), W, p(ref_), W + 2 * M, p(pus), n, p(cfg), 10, had, C.c_double(wgt), p(res))
+        out["pus%d" % j], out["cfg%d" % j], out["res%d" % j], out["par%d" % j] = pus, cfg, res, np.array([sh, had, wgt])
+    save("imv", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac, gen_tzsearch, gen_picture, gen_intra):
+    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac, gen_tzsearch, gen_picture, gen_intra, gen_imv):
         if not only or fn.__name__[4:] in only:
             fn()

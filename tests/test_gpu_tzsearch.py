@@ -156,3 +156,30 @@ def test_me_batch_chain(w, h, had):
         res = np.zeros(1, ops.FRAC_RESULT)
         O.orc_frac_refine(p(org), W, p(ref_), ref_.shape[1], p(blk), 1, w, h, bd, 0, (1 << bd) - 1, had, C.byref(m), p(res))
         assert gf[i] == res[0], (i, gf[i], res[0])
+
+
+def test_imv_refine_golden_and_oracle():
+    """AMVR integer refinement (vvcgpu_imv_refine_batch): golden vectors of the reference's xPatternSearchIntRefine, then random
+    PUs (all shapes, both resolutions, SATD / SAD, weights, equal candidates, one candidate) against the oracle."""
+    import ctypes as C
+    from vvcsoftware_vtm_amd import ops
+    assert ops.IMV_PU == cases.IMV_PU and ops.IMV_RESULT == cases.IMV_RESULT
+    g = np.load(os.path.join(G, "imv.npz"))
+    org, ref_ = g["org"], g["ref"]
+    for j in range(4):
+        pus, cfg, want = np.ascontiguousarray(g["pus%d" % j]), np.ascontiguousarray(g["cfg%d" % j]), g["res%d" % j]
+        sh, had, wgt = g["par%d" % j]
+        out = ops.imv_refine_batch(dev(org), dev(ref_), ops.struct_to_device(pus), len(pus), cfg, bool(had), float(wgt))
+        assert np.array_equal(out.cpu().numpy().view(cases.IMV_RESULT), want), j
+    rng = np.random.default_rng(31)
+    W, H, M = 320, 256, 160
+    org, ref_ = cases.tz_planes(rng, W, H, M, 10, motion=(-13, 8))
+    for (sh, had, wgt) in [(2, 1, 1.0), (4, 1, 0.75), (2, 0, 1.0), (4, 0, 2.0)]:
+        n = 250
+        pus = cases.imv_pus(rng, n, W, H, M, SIZES, sh)
+        cfg = cases.tz_cfg(W, H, M, float(rng.uniform(4, 60)), imv_shift=sh)
+        want = np.zeros(n, cases.IMV_RESULT)
+        oracle().orc_imv_refine(p(org), W, p(ref_), ref_.shape[1], p(pus), n, p(cfg), had, C.c_double(wgt), p(want))
+        out = ops.imv_refine_batch(dev(org), dev(ref_), ops.struct_to_device(pus), n, cfg, bool(had), wgt)
+        got = out.cpu().numpy().view(cases.IMV_RESULT)
+        assert np.array_equal(got, want), (sh, had, np.nonzero(got != want)[0][:5])

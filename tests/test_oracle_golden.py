@@ -352,3 +352,17 @@ def test_intra_fill_refs_golden():
         n += 1
         partial += 0 < int(flags.sum()) < len(flags)
     assert n > 1000 and partial > 500
+
+
+def test_imv_refine_golden():
+    """next row N2 (AMVR): restated xPatternSearchIntRefine vs the compiled reference's own function."""
+    import cases
+    g = load("imv")
+    O = oracle()
+    org, ref_ = g["org"], g["ref"]
+    for j in range(4):
+        pus, cfg, want = np.ascontiguousarray(g["pus%d" % j]), np.ascontiguousarray(g["cfg%d" % j]), g["res%d" % j]
+        sh, had, wgt = g["par%d" % j]
+        got = np.zeros(len(pus), cases.IMV_RESULT)
+        O.orc_imv_refine(p(org), org.shape[1], p(ref_), ref_.shape[1], p(pus), len(pus), p(cfg), int(had), C.c_double(float(wgt)), p(got))
+        assert np.array_equal(got, want), (j, np.nonzero(got != want)[0][:5])

@@ -706,6 +706,93 @@ __global__ __launch_bounds__(256) void sad_best_decode_kernel(int nblocks, int d
   best[b] = r;
 }
 
+
+// ---- AMVR integer refinement: InterSearch::xPatternSearchIntRefine (InterSearch.cpp:2408-2501) -------------------------------
+// One wavefront per PU: the <= 18 (position, predictor) pairs are visited in the reference's order; each distortion is computed
+// by the whole wavefront with the SATD / SAD code of vvcgpu_dist_batch.
+__device__ __forceinline__ unsigned long long block_dist(bool had, const Pel* org, int os, const Pel* cur, int cs, int w, int h, int lane)
+{
+  if (had)
+  {
+    if (w > h && (h & 7) == 0 && (w & 15) == 0)      return satd_tiles<16, 8>(org, os, cur, cs, w, h, lane);
+    else if (w < h && (w & 7) == 0 && (h & 15) == 0) return satd_tiles<8, 16>(org, os, cur, cs, w, h, lane);
+    else if (w > h && (h & 3) == 0 && (w & 7) == 0)  return satd_tiles<8, 4>(org, os, cur, cs, w, h, lane);
+    else if (w < h && (w & 3) == 0 && (h & 7) == 0)  return satd_tiles<4, 8>(org, os, cur, cs, w, h, lane);
+    else if ((h & 7) == 0 && (w & 7) == 0)           return satd_tiles<8, 8>(org, os, cur, cs, w, h, lane);
+    else if ((h & 3) == 0 && (w & 3) == 0)           return satd_tiles<4, 4>(org, os, cur, cs, w, h, lane);
+    return satd_tiles<2, 2>(org, os, cur, cs, w, h, lane);
+  }
+  unsigned long long acc = 0;
+  for (int idx = lane; idx < h * w; idx += 64)
+  {
+    const int r = idx / w, x = idx - r * w;
+    acc += (unsigned)abs((int)org[(size_t)r * os + x] - (int)cur[(size_t)r * cs + x]);
+  }
+  return wave_sum_u64(acc);
+}
+
+__global__ __launch_bounds__(256) void imv_refine_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
+                                                         const vvcgpu_imv_pu* __restrict__ pus, int n, vvcgpu_tz_cfg cfg, int useHad, double weight,
+                                                         vvcgpu_imv_result* __restrict__ results)
+{
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= n) return;
+  const vvcgpu_imv_pu p = pus[b];
+  const int sh = cfg.imv_shift, mvOffset = 1 << sh;
+  const int horMax = (cfg.pic_w + 8 - p.pos_x - 1) << 2, horMin = (-cfg.max_cu_w - 8 - p.pos_x + 1) << 2;
+  const int verMax = (cfg.pic_h + 8 - p.pos_y - 1) << 2, verMin = (-cfg.max_cu_h - 8 - p.pos_y + 1) << 2;
+  const int mvx = p.mv_x << 2, mvy = p.mv_y << 2;
+  int baseX[2], baseY[2];
+#pragma unroll
+  for (int c = 0; c < 2; c++)
+  {
+    const int off = 1 << (sh - 1);
+    baseX[c] = (((mvx - p.cand_x[c]) + off) >> sh) << sh;
+    baseY[c] = (((mvy - p.cand_y[c]) + off) >> sh) << sh;
+  }
+  const Pel* o = org + (ptrdiff_t)p.org_y * os + p.org_x;
+  unsigned long long bestDist = ~0ull, satd = 0;
+  int bestX = mvx, bestY = mvy, bestIdx = p.mvp_idx, bestBits = 0;
+  for (int pos = 0; pos < 9; pos++)
+  {
+    // testPos order: centre, then the 3 x 3 neighbourhood row by row in (x = -1, 0, 1) major order (:2429)
+    const int q = pos == 0 ? 4 : (pos <= 4 ? pos - 1 : pos);       // index into the 3 x 3 grid, x-major
+    const int dx = q / 3 - 1, dy = q % 3 - 1;
+    int tx[2] = { 0, 0 }, ty[2] = { 0, 0 };
+    for (int c = 0; c < p.num_cand; c++)
+    {
+      const int candX = c == 0 ? p.cand_x[0] : p.cand_x[1], candY = c == 0 ? p.cand_y[0] : p.cand_y[1];
+      tx[c] = dx * mvOffset + (c == 0 ? baseX[0] : baseX[1]) + candX;
+      ty[c] = dy * mvOffset + (c == 0 ? baseY[0] : baseY[1]) + candY;
+      unsigned long long dist;
+      if (c == 0 || tx[0] != tx[1] || ty[0] != ty[1])
+      {
+        const int cx = min(horMax, max(horMin, tx[c])), cy = min(verMax, max(verMin, ty[c]));
+        const int px = min(max(p.ref_x + (cx >> 2), cfg.ref_x0), cfg.ref_x1 - p.w), py = min(max(p.ref_y + (cy >> 2), cfg.ref_y0), cfg.ref_y1 - p.h);
+        const unsigned long long d = block_dist(useHad != 0, o, os, ref + (ptrdiff_t)py * rs + px, rs, p.w, p.h, lane);
+        dist = satd = (unsigned long long)((double)d * weight);
+      }
+      else dist = satd;
+      const unsigned mvBits = expgolomb_bits((tx[c] - candX) >> sh) + expgolomb_bits((ty[c] - candY) >> sh);
+      const int iMvBits = (int)((c == 0 ? p.idx_cost[0] : p.idx_cost[1]) + mvBits);
+      dist += (unsigned long long)(cfg.lambda * (double)mvBits);
+      if (dist < bestDist) { bestDist = dist; bestX = tx[c]; bestY = ty[c]; bestIdx = c; bestBits = iMvBits; }
+    }
+  }
+  if (lane == 0)
+  {
+    unsigned bits = p.bits - (p.mvp_idx == 0 ? p.idx_cost[0] : p.idx_cost[1]);
+    bits += (unsigned)bestBits;
+    vvcgpu_imv_result r;
+    r.cost = bestDist - (unsigned long long)(cfg.lambda * (double)(unsigned)bestBits) + (unsigned long long)(cfg.lambda * (double)bits);
+    const int candX = bestIdx == 0 ? p.cand_x[0] : p.cand_x[1], candY = bestIdx == 0 ? p.cand_y[0] : p.cand_y[1];
+    bits += expgolomb_bits((bestX - candX) >> sh) + expgolomb_bits((bestY - candY) >> sh);
+    r.mv_x = bestX; r.mv_y = bestY; r.mvp_idx = bestIdx; r.bits = bits;
+    results[b] = r;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -880,6 +967,24 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
     hipLaunchKernelGGL(sad_best_decode_kernel, dim3(cdiv(nblocks, 256)), dim3(256), 0, st, nblocks, dx0, dy0, nx, sx, sy, mvg, best);
     VVC_LAUNCH_CHECK();
   }
+  return VVCGPU_OK;
+}
+
+int vvcgpu_imv_refine_batch(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride, const vvcgpu_imv_pu* pus, int n,
+                            const vvcgpu_tz_cfg* cfg_host, int use_hadamard, double weight, vvcgpu_imv_result* results, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "imv_refine_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(org && ref && pus && cfg_host && results, "imv_refine_batch: null pointer");
+  const vvcgpu_tz_cfg c = *cfg_host;
+  VVC_CHECK_ARG(c.imv_shift >= 1 && c.imv_shift <= 6, "imv_refine_batch: imv_shift %d (2 = integer, 4 = four-sample resolution)", c.imv_shift);
+  VVC_CHECK_ARG(c.lambda >= 0.0 && c.lambda < 1048576.0 && weight >= 0.0 && weight <= 16.0, "imv_refine_batch: lambda / weight out of range");
+  VVC_CHECK_ARG(c.pic_w > 0 && c.pic_h > 0 && c.max_cu_w > 0 && c.max_cu_h > 0, "imv_refine_batch: picture geometry");
+  VVC_CHECK_ARG(c.ref_x1 - c.ref_x0 >= 128 && c.ref_y1 - c.ref_y0 >= 128 && c.ref_x0 >= 0 && c.ref_y0 >= 0 && c.ref_x1 <= ref_stride,
+                "imv_refine_batch: readable rectangle");
+  hipLaunchKernelGGL(imv_refine_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, org, org_stride, ref, ref_stride, pus, n, c, use_hadamard,
+                     weight, results);
+  VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
 

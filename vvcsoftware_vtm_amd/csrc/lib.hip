@@ -96,6 +96,8 @@ int vvcgpu_sizeof(int id)
   case 18: return (int)sizeof(vvcgpu_intra_desc);
   case 19: return (int)sizeof(vvcgpu_cclm_desc);
   case 20: return (int)sizeof(vvcgpu_intra_fill_desc);
+  case 21: return (int)sizeof(vvcgpu_imv_pu);
+  case 22: return (int)sizeof(vvcgpu_imv_result);
   default: return -1;
   }
 }

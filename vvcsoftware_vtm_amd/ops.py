@@ -262,6 +262,25 @@ def intra_fill_refs_batch(rec_base, flags_base, refs_base, descs_dev, n, bit_dep
     capi.call("vvcgpu_intra_fill_refs_batch", capi.ptr(rec_base), capi.ptr(flags_base), capi.ptr(refs_base), capi.ptr(descs_dev), n, bit_depth, _stream())
 
 
+IMV_PU = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4"),
+                   ("cand_x", "<i4", (2,)), ("cand_y", "<i4", (2,)), ("pos_x", "<i4"), ("pos_y", "<i4"), ("idx_cost", "<u4", (2,)), ("bits", "<u4"),
+                   ("w", "<i2"), ("h", "<i2"), ("num_cand", "i1"), ("mvp_idx", "i1"), ("reserved", "<i2"), ("reserved2", "<i4")])
+IMV_RESULT = np.dtype([("mv_x", "<i4"), ("mv_y", "<i4"), ("mvp_idx", "<i4"), ("bits", "<u4"), ("cost", "<u8")])
+assert IMV_PU.itemsize == 72 and IMV_RESULT.itemsize == 24
+
+
+def imv_refine_batch(org, ref, pus_dev, n, cfg, use_hadamard=True, weight=1.0):
+    """N2 (AMVR): xPatternSearchIntRefine for n PUs -> IMV_RESULT records (uint8 tensor)."""
+    po, so, _, _ = _plane(org, "org")
+    pr, sr, _, _ = _plane(ref, "ref")
+    cfg = np.ascontiguousarray(cfg)
+    assert cfg.dtype == TZ_CFG and cfg.size == 1
+    out = torch.empty(n * IMV_RESULT.itemsize, dtype=torch.uint8, device=org.device)
+    capi.call("vvcgpu_imv_refine_batch", po, so, pr, sr, capi.ptr(pus_dev), n, C.c_void_p(cfg.ctypes.data), 1 if use_hadamard else 0, C.c_double(weight),
+              capi.ptr(out), _stream())
+    return out
+
+
 # ---- interpolation / MC / PelBuffer ops -------------------------------------------------------------
 IF_DESC = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("src_stride", "<i4"), ("dst_stride", "<i4"),
                     ("w", "<i2"), ("h", "<i2"), ("taps", "i1"), ("is_vertical", "i1"), ("is_first", "i1"),
