@@ -50,6 +50,9 @@ for size in (16, 32, 64):
     got = best.cpu().numpy().view(cases.BEST)
     line = "%dx%d: %d PUs  gpu %.3f ms  %.2f M PU/s  found %.0f%%" % (size, size, n, ms, n / ms / 1e3, 100 * np.mean((got["x"] == 11) & (got["y"] == -6)))
     k = min(a.cpu_sample, n)
+    if k == 0:
+        print(line)
+        continue
     pick = np.ascontiguousarray(pus[rng.choice(n, k, replace=False)])
     res = np.zeros(k, cases.BEST)
     oracle().orc_tz_search(p(org), W, p(ref_), W + 2 * M, p(pick), k, p(cfg), p(res))
