@@ -42,7 +42,7 @@ int         vvcgpu_device_count(void);
 int         vvcgpu_set_device(int device);
 /* sizeof() of the parameter structs, for binding self-checks: 0 sao_ctu, 1 deblock_cfg, 2 dist_desc, 3 search_blk,
  * 4 mvcost, 5 search_best, 6 if_desc, 7 mc_desc, 8 pelop_desc, 9 pelop_cfg, 10 tr_desc, 11 frac_blk, 12 frac_result,
- * 13 dqtr_desc, 14 afg_desc, 15 afe_desc, 16 tz_pu, 17 tz_cfg, 18 intra_desc, 19 cclm_desc, 20 intra_fill_desc, 21 imv_pu, 22 imv_result; -1 for unknown ids.          */
+ * 13 dqtr_desc, 14 afg_desc, 15 afe_desc, 16 tz_pu, 17 tz_cfg, 18 intra_desc, 19 cclm_desc, 20 intra_fill_desc, 21 imv_pu, 22 imv_result, 23 quant_desc; -1 for unknown ids.          */
 int         vvcgpu_sizeof(int struct_id);
 
 /* ---- device memory helpers for host-side callers (the reference keeps pictures in host memory; the shim stages them).
@@ -437,6 +437,22 @@ typedef struct vvcgpu_cclm_desc {
 } vvcgpu_cclm_desc;
 int vvcgpu_cclm_pred_batch(const vvc_pel* luma_base, const vvc_pel* nb_base, vvc_pel* dst_base, const vvcgpu_cclm_desc* descs, int n,
                            int bit_depth_luma, int bit_depth_chroma, int clp_min, int clp_max, void* stream);
+
+/* N1, forward direction without RDOQ: scalar quantisation of transform coefficients  (Quant::quant, Quant.cpp:721-834: level =
+ * (|c| * g_quantScales[qp % 6] * whScale + add) >> qBits with add = (intra slice ? 171 : 85) << (qBits - 9), flat scaling) and,
+ * when the slice enables it, sign bit hiding per 4x4 coefficient group (xSignBitHidingHDQ :142-273, JVET_K0072 keeps it for
+ * slices without dependent quantisation).  abs_sum[i] = uiAbsSum of TU i (sum of the magnitudes before hiding).  The rate-
+ * distortion optimised quantisers (QuantRDOQ, the DepQuant trellis) walk CABAC context state sequentially and are NOT built.  */
+typedef struct vvcgpu_quant_desc {
+  int64_t coeff_off, level_off;         /* in elements of coeff_base / level_base; both blocks are w x h, row pitch w */
+  int16_t w, h;                         /* powers of two 2..64 */
+  int8_t  intra_slice, sign_hiding;
+  int16_t reserved;
+  int32_t qp;                           /* QpParam::Qp (bit-depth offset included) */
+  int32_t reserved2;                    /* sizeof == 32 */
+} vvcgpu_quant_desc;
+int vvcgpu_quant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const vvcgpu_quant_desc* descs, int n, int bit_depth, uint32_t* abs_sum,
+                       void* stream);
 
 /* The shipped matrix [type][log2(N)-1] as N x N int16 (host copy; for the shim's table check against initROM()). */
 const int16_t* vvcgpu_tr_matrix_host(int type, int n);

@@ -776,3 +776,42 @@ extern "C" int vtmref_imv_refine(const Pel* org, int os, const Pel* ref, int rs,
   }
   return 0;
 }
+
+// ---------------------------------------------------------------------------------------------
+// Forward scalar quantisation without RDOQ: the reference's own Quant::quant (Quant.cpp:721-834, incl. xSignBitHidingHDQ) on a
+// TransformUnit like vtmref_dequant's; the Ctx argument is only used by the RDOQ / trellis overrides.
+extern "C" uint32_t vtmref_quant(const TCoeff* coef, TCoeff* level, int w, int h, int bd, int qp, int intraSlice, int signHiding)
+{
+  static SPS* sps = nullptr;
+  static CodingStructure* cs = nullptr;
+  static Slice* slice = nullptr;
+  static Quant* q = nullptr;
+  static CodingUnit* cu = nullptr;
+  static Ctx* ctx = nullptr;
+  if (!sps)
+  {
+    sps = new SPS;
+    cs = static_cast<CodingStructure*>(calloc(1, sizeof(CodingStructure)));
+    slice = new Slice;
+    cs->sps = sps; cs->slice = slice;
+    PreCalcValues* pcv = static_cast<PreCalcValues*>(calloc(1, sizeof(PreCalcValues)));     // CoeffCodingContext reads pcv->rectCUs
+    const_cast<bool&>(pcv->rectCUs) = true;
+    cs->pcv = pcv;
+    q = new Quant(nullptr);
+    cu = new CodingUnit; cu->predMode = MODE_INTER;
+    ctx = new Ctx;
+  }
+  sps->setBitDepth(CHANNEL_TYPE_LUMA, bd);
+  slice->setSliceType(intraSlice ? I_SLICE : P_SLICE);
+  slice->setSignDataHidingEnabledFlag(signHiding != 0);
+  TransformUnit tu(CHROMA_400, Area(0, 0, w, h));
+  tu.cs = cs; tu.cu = cu;
+  tu.m_coeffs[COMPONENT_Y] = level;
+  tu.transformSkip[COMPONENT_Y] = false;
+  QpParam* qpp = static_cast<QpParam*>(malloc(sizeof(QpParam)));
+  qpp->Qp = qp; qpp->per = qp / 6; qpp->rem = qp % 6;
+  TCoeff absSum = 0;
+  q->Quant::quant(tu, COMPONENT_Y, CCoeffBuf(coef, w, w, h), absSum, *qpp, *ctx);
+  free(qpp);
+  return (uint32_t)absSum;
+}

@@ -96,3 +96,74 @@ ORC_API int orc_dequant_tr_inv_batch(const TCoeff* levelBase, Pel* resiBase, con
   }
   return 0;
 }
+
+
+// ---- forward scalar quantisation without RDOQ: Quant::quant (Quant.cpp:721-834) + sign bit hiding xSignBitHidingHDQ (:142-273) ----
+// flat scaling (g_quantScales, Quant.cpp), HM_QTBT_AS_IN_JEM_QUANT block-size scale for sqrt(2) shapes; scan = diagonal 4x4-grouped.
+
+ORC_API uint32_t orc_quant(const TCoeff* coef, TCoeff* level, int w, int h, int bd, int qp, int intraSlice, int signHiding)
+{
+  static const int quantScales[6] = { 26214, 23302, 20560, 18396, 16384, 14564 };
+  int lw = 0, lh = 0; while ((1 << (lw + 1)) <= w) lw++; while ((1 << (lh + 1)) <= h) lh++;
+  const int per = qp / 6, rem = qp % 6, n = w * h;
+  int transformShift = 15 - bd - ((lw + lh) >> 1);
+  int whScale = 1;
+  if ((lw + lh) & 1) { transformShift += 7; whScale = 181; }
+  const int qBits = 14 + per + transformShift, qBits8 = qBits - 8;
+  const int64_t add = (int64_t)(intraSlice ? 171 : 85) << (qBits - 9);
+  std::vector<TCoeff> deltaU(n);
+  uint32_t absSum = 0;
+  for (int i = 0; i < n; i++)
+  {
+    const TCoeff c = coef[i];
+    const int64_t tmp = (int64_t)std::abs(c) * quantScales[rem];
+    const TCoeff q = (TCoeff)((tmp * whScale + add) >> qBits);
+    deltaU[i] = (TCoeff)((tmp * whScale - ((int64_t)q << qBits)) >> qBits8);
+    absSum += q;
+    level[i] = clip3i(-32768, 32767, c < 0 ? -q : q);
+  }
+  if (!(signHiding && w >= 4 && h >= 4 && (int32_t)absSum >= 2)) return absSum;     // uiAbsSum is a TCoeff (int) in the reference
+  std::vector<uint32_t> scan(n);
+  orc_scan_order(w, h, scan.data());
+  const int TMAX = 0x7fffffff;
+  int lastCG = -1;
+  for (int subSet = (n - 1) >> 4; subSet >= 0; subSet--)
+  {
+    const int subPos = subSet << 4;
+    int first = 16, last = -1, sum = 0;
+    for (int k = 15; k >= 0; k--) if (level[scan[k + subPos]]) { last = k; break; }
+    for (int k = 0; k < 16; k++) if (level[scan[k + subPos]]) { first = k; break; }
+    for (int k = first; k <= last; k++) sum += level[scan[k + subPos]];
+    if (last >= 0 && lastCG == -1) lastCG = 1;
+    if (last - first >= 4)
+    {
+      const unsigned signbit = level[scan[subPos + first]] > 0 ? 0 : 1;
+      if (signbit != (unsigned)(sum & 1))
+      {
+        int curCost = TMAX, minCostInc = TMAX, minPos = -1, finalChange = 0, curChange = 0;
+        for (int k = (lastCG == 1 ? last : 15); k >= 0; k--)
+        {
+          const int pos = scan[k + subPos];
+          if (level[pos] != 0)
+          {
+            if (deltaU[pos] > 0) { curCost = -deltaU[pos]; curChange = 1; }
+            else if (k == first && std::abs(level[pos]) == 1) curCost = TMAX;
+            else { curCost = deltaU[pos]; curChange = -1; }
+          }
+          else if (k < first)
+          {
+            const unsigned thisSign = coef[pos] >= 0 ? 0 : 1;
+            if (thisSign != signbit) curCost = TMAX;
+            else { curCost = -deltaU[pos]; curChange = 1; }
+          }
+          else { curCost = -deltaU[pos]; curChange = 1; }
+          if (curCost < minCostInc) { minCostInc = curCost; finalChange = curChange; minPos = pos; }
+        }
+        if (level[minPos] == 32767 || level[minPos] == -32768) finalChange = -1;
+        if (coef[minPos] >= 0) level[minPos] += finalChange; else level[minPos] -= finalChange;
+      }
+    }
+    if (lastCG == 1) lastCG = 0;
+  }
+  return absSum;
+}

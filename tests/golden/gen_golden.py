@@ -408,8 +408,29 @@ def gen_imv():
     save("imv", **out)
 
 
+def gen_quant():
+    """next row N1 (forward, no RDOQ): the reference's own Quant::quant incl. sign bit hiding."""
+    rng = np.random.default_rng(1011)
+    R.vtmref_quant.restype = C.c_uint32
+    rows, coefs, levels = [], [], []
+    off = 0
+    for w in (2, 4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            for it in range(4):
+                bd = 8 if it % 2 else 10
+                qp = int(rng.integers(4, 50 + (bd - 8) * 6))
+                n = w * h
+                coef = (rng.normal(0, 400 * (1 + 3 * it), n) * (rng.random(n) < (0.25 + 0.25 * it))).astype(np.int32)
+                intra, sbh = int(rng.integers(0, 2)), int(it != 3)
+                lv = np.zeros(n, np.int32)
+                s = R.vtmref_quant(p(coef), p(lv), w, h, bd, qp, intra, sbh)
+                rows.append((w, h, bd, qp, intra, sbh, off, s))
+                coefs.append(coef); levels.append(lv); off += n
+    save("quant", rows=np.array(rows, np.int64), coef=np.concatenate(coefs), level=np.concatenate(levels))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac, gen_tzsearch, gen_picture, gen_intra, gen_imv):
+    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac, gen_tzsearch, gen_picture, gen_intra, gen_imv, gen_quant):
         if not only or fn.__name__[4:] in only:
             fn()

@@ -164,3 +164,49 @@ def test_shipped_tables_match_golden():
             N = 1 << lg
             a = np.ctypeslib.as_array(lib.vvcgpu_tr_matrix_host(t, N), shape=(N * N,)).reshape(N, N)
             assert np.array_equal(a, g["%s_%d" % (nm, N)])
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+def test_quant_forward(bd):
+    """N1 forward: Quant::quant without RDOQ + sign bit hiding, every TU shape, all in one launch, vs the oracle; then the
+    golden vectors of the compiled reference."""
+    import ctypes as C
+    import os
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(70 + bd)
+    O = oracle()
+    O.orc_quant.restype = C.c_uint32
+    rows, coefs, wants, sums = [], [], [], []
+    off = 0
+    for w in (2, 4, 8, 16, 32, 64):
+        for h in (2, 4, 8, 16, 32, 64):
+            for it in range(6):
+                n = w * h
+                qp = int(rng.integers(0, 52 + (bd - 8) * 6))
+                if it == 0:
+                    coef = rng.integers(-2 ** 21, 2 ** 21, n)
+                elif it == 1:
+                    coef = rng.integers(-3, 4, n) * 37                       # many levels of 0 / 1: the hiding corner cases
+                else:
+                    coef = rng.normal(0, 300 * it, n) * (rng.random(n) < 0.2 * it)
+                coef = coef.astype(np.int32)
+                intra, sbh = int(rng.integers(0, 2)), int(it != 5)
+                lv = np.zeros(n, np.int32)
+                sums.append(O.orc_quant(p(coef), p(lv), w, h, bd, qp, intra, sbh))
+                rows.append((off, off, w, h, intra, sbh, 0, qp, 0))
+                coefs.append(coef); wants.append(lv); off += n
+    d = np.array(rows, dtype=ops.QUANT_DESC)
+    level = torch.full((off,), 7, dtype=torch.int32, device="cuda")
+    got_sum = ops.quant_batch(dev(np.concatenate(coefs)), level, ops.struct_to_device(d), len(d), bd)
+    assert np.array_equal(got_sum.cpu().numpy().view(np.uint32), np.array(sums, np.uint32))
+    assert np.array_equal(level.cpu().numpy(), np.concatenate(wants))
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "quant.npz"))
+    sel = [r for r in g["rows"] if r[2] == bd]
+    d = np.array([(r[6], r[6], r[0], r[1], r[4], r[5], 0, r[3], 0) for r in sel], dtype=ops.QUANT_DESC)
+    level = torch.zeros(g["coef"].size, dtype=torch.int32, device="cuda")
+    got_sum = ops.quant_batch(dev(np.ascontiguousarray(g["coef"])), level, ops.struct_to_device(d), len(d), bd)
+    got = level.cpu().numpy()
+    for i, r in enumerate(sel):
+        n = int(r[0] * r[1])
+        assert np.array_equal(got[r[6]:r[6] + n], g["level"][r[6]:r[6] + n]), tuple(r)
+        assert int(got_sum.cpu().numpy().view(np.uint32)[i]) == int(r[7])

@@ -366,3 +366,22 @@ def test_imv_refine_golden():
         got = np.zeros(len(pus), cases.IMV_RESULT)
         O.orc_imv_refine(p(org), org.shape[1], p(ref_), ref_.shape[1], p(pus), len(pus), p(cfg), int(had), C.c_double(float(wgt)), p(got))
         assert np.array_equal(got, want), (j, np.nonzero(got != want)[0][:5])
+
+
+def test_quant_golden():
+    """next row N1, forward: restated Quant::quant (+ sign bit hiding) vs the compiled reference."""
+    g = load("quant")
+    O = oracle()
+    O.orc_quant.restype = C.c_uint32
+    hidden = 0
+    for (w, h, bd, qp, intra, sbh, off, s) in g["rows"]:
+        n = int(w * h)
+        coef = np.ascontiguousarray(g["coef"][off:off + n])
+        lv = np.zeros(n, np.int32)
+        assert O.orc_quant(p(coef), p(lv), int(w), int(h), int(bd), int(qp), int(intra), int(sbh)) == int(s)
+        assert np.array_equal(lv, g["level"][off:off + n]), (w, h, bd, qp, intra, sbh)
+        if sbh:
+            plain = np.zeros(n, np.int32)
+            O.orc_quant(p(coef), p(plain), int(w), int(h), int(bd), int(qp), int(intra), 0)
+            hidden += int(np.any(plain != lv))
+    assert hidden > 30          # the fixture really exercises the hiding adjustment

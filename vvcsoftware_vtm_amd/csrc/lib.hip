@@ -98,6 +98,7 @@ int vvcgpu_sizeof(int id)
   case 20: return (int)sizeof(vvcgpu_intra_fill_desc);
   case 21: return (int)sizeof(vvcgpu_imv_pu);
   case 22: return (int)sizeof(vvcgpu_imv_result);
+  case 23: return (int)sizeof(vvcgpu_quant_desc);
   default: return -1;
   }
 }

@@ -642,6 +642,128 @@ __global__ __launch_bounds__(256) void dequant_kernel(const TCoeff* __restrict__
   }
 }
 
+// ---- forward scalar quantisation without RDOQ: Quant::quant (Quant.cpp:721-834) + xSignBitHidingHDQ (:142-273) ---------------
+// One wavefront per TU.  Without sign hiding the map is element-wise.  With it, a lane owns whole coefficient groups (16
+// coefficients in scan order): it quantises them into registers, decides the hiding adjustment of the group locally (the groups
+// are independent once it is known which one is the last with a non-zero level) and writes each level once.
+struct QuantParams { int qBits, qBits8, scale, whScale; long long add; };
+
+__device__ __forceinline__ int quant_one(const QuantParams& q, int c, int& deltaU)
+{
+  const long long tmp = (long long)abs(c) * q.scale * q.whScale;
+  const int mag = (int)((tmp + q.add) >> q.qBits);
+  deltaU = (int)((tmp - ((long long)mag << q.qBits)) >> q.qBits8);
+  return mag;
+}
+
+__global__ __launch_bounds__(256) void quant_kernel(const TCoeff* __restrict__ coeffBase, TCoeff* __restrict__ levelBase,
+                                                    const vvcgpu_quant_desc* __restrict__ descs, int n, int bd, unsigned* __restrict__ absSumOut)
+{
+  const int lane = threadIdx.x & 63;
+  const int ti = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (ti >= n) return;
+  const vvcgpu_quant_desc d = descs[ti];
+  const int w = d.w, h = d.h, cnt = w * h, lw = ilog2(w), lh = ilog2(h);
+  const TCoeff* coef = coeffBase + d.coeff_off;
+  TCoeff* level = levelBase + d.level_off;
+  QuantParams q;
+  {
+    const int per = d.qp / 6, rem = d.qp - 6 * per;
+    int transformShift = 15 - bd - ((lw + lh) >> 1);
+    q.whScale = 1;
+    if ((lw + lh) & 1) { transformShift += 7; q.whScale = 181; }
+    q.qBits = 14 + per + transformShift; q.qBits8 = q.qBits - 8;
+    q.scale = rem == 0 ? 26214 : rem == 1 ? 23302 : rem == 2 ? 20560 : rem == 3 ? 18396 : rem == 4 ? 16384 : 14564;
+    q.add = (long long)(d.intra_slice ? 171 : 85) << (q.qBits - 9);
+  }
+  const bool sbh = d.sign_hiding && w >= 4 && h >= 4;
+  // pass 1: sum of magnitudes (uiAbsSum, a 32-bit int in the reference) and, for sign hiding, the last group with a level
+  int sum = 0, lastGroup = -1;
+  const unsigned short* scan = d_scan + d_scanOff[(lw - 1) * 6 + (lh - 1)];
+  if (!sbh)
+  {
+    for (int i = lane; i < cnt; i += 64)
+    {
+      int du; const int c = coef[i];
+      const int mag = quant_one(q, c, du);
+      sum += mag;
+      level[i] = min(max(c < 0 ? -mag : mag, -32768), 32767);
+    }
+  }
+  else
+  {
+    for (int g = lane; g < (cnt >> 4); g += 64)
+    {
+      bool any = false;
+#pragma unroll 4
+      for (int k = 0; k < 16; k++) { int du; const int mag = quant_one(q, coef[scan[(g << 4) + k]], du); sum += mag; any |= mag != 0; }
+      if (any) lastGroup = g;
+    }
+  }
+#pragma unroll
+  for (int m = 1; m < 64; m <<= 1) { sum += __shfl_xor(sum, m); lastGroup = max(lastGroup, __shfl_xor(lastGroup, m)); }
+  if (lane == 0) absSumOut[ti] = (unsigned)sum;
+  if (!sbh) return;
+  const bool hide = sum >= 2;
+  for (int g = lane; g < (cnt >> 4); g += 64)
+  {
+    int lv[16], du[16], cf[16], pos[16];
+    int first = 16, last = -1, ssum = 0;
+#pragma unroll
+    for (int k = 0; k < 16; k++)
+    {
+      pos[k] = scan[(g << 4) + k];
+      cf[k] = coef[pos[k]];
+      const int mag = quant_one(q, cf[k], du[k]);
+      lv[k] = min(max(cf[k] < 0 ? -mag : mag, -32768), 32767);
+      if (lv[k]) { if (first == 16) first = k; last = k; }
+    }
+    if (hide && last - first >= 4)
+    {
+#pragma unroll
+      for (int k = 0; k < 16; k++) if (k >= first && k <= last) ssum += lv[k];
+      int firstLv = 0;
+#pragma unroll
+      for (int k = 0; k < 16; k++) if (k == first) firstLv = lv[k];
+      const unsigned signbit = firstLv > 0 ? 0u : 1u;
+      if (signbit != (unsigned)(ssum & 1))
+      {
+        const int TMAX = 0x7fffffff;
+        int minCost = TMAX, minK = -1, finalChange = 0, curChange = 0;
+        const int start = (g == lastGroup) ? last : 15;
+#pragma unroll
+        for (int k = 15; k >= 0; k--)
+        {
+          if (k > start) continue;
+          int cost;
+          if (lv[k] != 0)
+          {
+            if (du[k] > 0) { cost = -du[k]; curChange = 1; }
+            else if (k == first && abs(lv[k]) == 1) cost = TMAX;
+            else { cost = du[k]; curChange = -1; }
+          }
+          else if (k < first)
+          {
+            if ((cf[k] >= 0 ? 0u : 1u) != signbit) cost = TMAX;
+            else { cost = -du[k]; curChange = 1; }
+          }
+          else { cost = -du[k]; curChange = 1; }
+          if (cost < minCost) { minCost = cost; finalChange = curChange; minK = k; }
+        }
+#pragma unroll
+        for (int k = 0; k < 16; k++)
+          if (k == minK)
+          {
+            if (lv[k] == 32767 || lv[k] == -32768) finalChange = -1;
+            lv[k] += cf[k] >= 0 ? finalChange : -finalChange;
+          }
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < 16; k++) level[pos[k]] = lv[k];
+  }
+}
+
 static bool g_tablesUploaded[64] = { false };
 static const int g_smallGrid = getenv("VVCGPU_TR_SMALLGRID") ? atoi(getenv("VVCGPU_TR_SMALLGRID")) : 1280;   // tuning switch
 
@@ -759,6 +881,20 @@ int vvcgpu_dequant_tr_inv_batch(const vvc_coef* level_base, vvc_pel* resi_base, 
   VVC_LAUNCH_CHECK();
   // the descriptor is binary compatible with vvcgpu_tr_desc: the inverse transforms read the de-quantised coefficients at level_off
   return vvcgpu_tr_inv_batch(coeff_out, resi_base, reinterpret_cast<const vvcgpu_tr_desc*>(descs), n, bit_depth, stream);
+}
+
+int vvcgpu_quant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const vvcgpu_quant_desc* descs, int n, int bit_depth, uint32_t* abs_sum,
+                       void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "quant_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(coeff_base && level_base && descs && abs_sum, "quant_batch: null pointer");
+  VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "quant_batch: bit depth %d outside 8..10", bit_depth);
+  const int rt = ensure_tables();
+  if (rt) return rt;
+  hipLaunchKernelGGL(quant_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coeff_base, level_base, descs, n, bit_depth, abs_sum);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
 }
 
 int vvcgpu_scan_order_host(int w, int h, uint16_t* out)

@@ -281,6 +281,18 @@ def imv_refine_batch(org, ref, pus_dev, n, cfg, use_hadamard=True, weight=1.0):
     return out
 
 
+QUANT_DESC = np.dtype([("coeff_off", "<i8"), ("level_off", "<i8"), ("w", "<i2"), ("h", "<i2"), ("intra_slice", "i1"), ("sign_hiding", "i1"),
+                       ("reserved", "<i2"), ("qp", "<i4"), ("reserved2", "<i4")])
+assert QUANT_DESC.itemsize == 32
+
+
+def quant_batch(coeff_base, level_base, descs_dev, n, bit_depth=10):
+    """N1 forward: Quant::quant without RDOQ (+ sign bit hiding) for n TUs -> abs-sum int32 tensor [n] (bits as uint32)."""
+    out = torch.zeros(n, dtype=torch.int32, device=coeff_base.device)
+    capi.call("vvcgpu_quant_batch", capi.ptr(coeff_base), capi.ptr(level_base), capi.ptr(descs_dev), n, bit_depth, capi.ptr(out), _stream())
+    return out
+
+
 # ---- interpolation / MC / PelBuffer ops -------------------------------------------------------------
 IF_DESC = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("src_stride", "<i4"), ("dst_stride", "<i4"),
                     ("w", "<i2"), ("h", "<i2"), ("taps", "i1"), ("is_vertical", "i1"), ("is_first", "i1"),
