@@ -4,21 +4,23 @@
 // xEqualCoeffComputer (CommonLib/AffineGradientSearch.cpp:66-174; SIMD twins x86/AffineGradientSearchX86.h:72-312), the three
 // table slots of AffineGradientSearch.h:50-54.
 //
-// Design: one workgroup per PU.  Sobel: every output sample is the 3x3 response at the nearest INTERIOR position (that is what
+// Design: one wavefront per PU.  Sobel: every output sample is the 3x3 response at the nearest INTERIOR position (that is what
 // the reference's ring-copy rules amount to), so the ring needs no second pass.  Equal coefficients: every lane walks its
-// share of the block with the <= 6 x 7 sums in 64-bit registers, then wave shuffles and a small LDS stage combine them.
+// share of the block with the <= 6 x 7 sums in 64-bit registers, then one transposed wave reduction (63 shuffles for all sums).
 #include "common.h"
 
 namespace {
 
 __global__ __launch_bounds__(256) void affine_sobel_kernel(int vertical, const Pel* __restrict__ predBase, int* __restrict__ derivBase,
-                                                           const vvcgpu_afg_desc* __restrict__ descs)
+                                                           const vvcgpu_afg_desc* __restrict__ descs, int n)
 {
-  const vvcgpu_afg_desc d = descs[blockIdx.x];
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);      // one wavefront per PU
+  if (b >= n) return;
+  const vvcgpu_afg_desc d = descs[b];
   const Pel* pred = predBase + d.pred_off;
   int* deriv = derivBase + d.deriv_off;
   const int w = d.w, h = d.h, ps = d.pred_stride;
-  for (int i = threadIdx.x; i < w * h; i += 256)
+  for (int i = threadIdx.x & 63; i < w * h; i += 64)
   {
     const int j = i / w, k = i - j * w;
     const int y = min(max(j, 1), h - 2), x = min(max(k, 1), w - 2);
@@ -34,7 +36,7 @@ template <int P>
 __device__ __forceinline__ void eq_accumulate(const Pel* __restrict__ resi, const int* __restrict__ gx, const int* __restrict__ gy, int stride,
                                               int w, int h, int tid, long long (&acc)[P][P + 1])
 {
-  for (int i = tid; i < w * h; i += 256)
+  for (int i = tid; i < w * h; i += 64)
   {
     const int j = i / w, k = i - j * w;
     const int idx = j * stride + k;
@@ -53,47 +55,65 @@ __device__ __forceinline__ void eq_accumulate(const Pel* __restrict__ resi, cons
   }
 }
 
-template <int P>
-__device__ __forceinline__ void eq_block(const vvcgpu_afe_desc& d, const Pel* resiBase, const int* gxBase, const int* gyBase, long long* out,
-                                         long long (*part)[48])
+// Sum M = 64 (or 32) per-lane values over the wavefront with a halving butterfly: at every step a lane keeps one half of its
+// values and hands the other half to its partner, so 63 (31 + 1) shuffles replace 6 per value; lane L ends with the total of value L.
+template <int M>
+__device__ __forceinline__ long long wave_transpose_sum(long long (&v)[M], int lane)
 {
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  static_assert(M == 64 || M == 32, "M");
+#pragma unroll
+  for (int s = M / 2, len = M; s > 0; s >>= 1, len >>= 1)
+  {
+    const bool up = (lane & s) != 0;
+#pragma unroll
+    for (int i = 0; i < len / 2; i++)
+    {
+      const long long keep = up ? v[i + len / 2] : v[i], send = up ? v[i] : v[i + len / 2];
+      v[i] = keep + __shfl_xor(send, s);
+    }
+  }
+  if (M == 32) v[0] += __shfl_xor(v[0], 32);
+  return v[0];
+}
+
+// one wavefront per PU: every lane accumulates its samples, one transposed reduction, lanes 0 .. P (P + 1) - 1 hold the sums
+template <int P>
+__device__ __forceinline__ void eq_block(const vvcgpu_afe_desc& d, const Pel* resiBase, const int* gxBase, const int* gyBase, long long* out, int lane)
+{
   long long acc[P][P + 1];
 #pragma unroll
   for (int c = 0; c < P; c++)
 #pragma unroll
     for (int r = 0; r <= P; r++) acc[c][r] = 0;
-  eq_accumulate<P>(resiBase + d.resi_off, gxBase + d.deriv_off, gyBase + d.deriv_off, d.deriv_stride, d.w, d.h, tid, acc);
+  eq_accumulate<P>(resiBase + d.resi_off, gxBase + d.deriv_off, gyBase + d.deriv_off, d.deriv_stride, d.w, d.h, lane, acc);
+  constexpr int M = P == 6 ? 64 : 32;
+  long long v[M];
 #pragma unroll
-  for (int c = 0; c < P; c++)
-#pragma unroll
-    for (int r = 0; r <= P; r++)
-    {
-      long long v = acc[c][r];
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
-      if (lane == 0) part[wave][c * 7 + r] = v;
-    }
-  __syncthreads();
-  if (tid < 49)
+  for (int i = 0; i < M; i++) v[i] = i < P * (P + 1) ? acc[i / (P + 1)][i % (P + 1)] : 0;
+  const long long total = wave_transpose_sum<M>(v, lane);       // lane L: sum of value L = acc[L / (P + 1)][L % (P + 1)]
+  // out[row7][col7]; rows 1..P hold the equations, everything else is zero
+  if (lane < 49)
   {
-    const int row7 = tid / 7, col7 = tid - row7 * 7;       // out[row7][col7]; rows 1..P hold the equations
-    long long v = 0;
-    if (row7 >= 1 && row7 <= P && col7 <= P)
-      for (int k = 0; k < 4; k++) v += part[k][(row7 - 1) * 7 + col7];
-    out[tid] = v;
+    const int row7 = lane / 7, col7 = lane - row7 * 7;
+    const bool used = row7 >= 1 && row7 <= P && col7 <= P;
+    const int src = used ? (row7 - 1) * (P + 1) + col7 : 0;
+    long long val = __shfl(total, src);
+    out[lane] = used ? val : 0;
   }
+  else (void)__shfl(total, 0);
 }
 
 __global__ __launch_bounds__(256) void affine_equal_coeff_kernel(const Pel* __restrict__ resiBase, const int* __restrict__ gxBase,
-                                                                 const int* __restrict__ gyBase, const vvcgpu_afe_desc* __restrict__ descs,
+                                                                 const int* __restrict__ gyBase, const vvcgpu_afe_desc* __restrict__ descs, int n,
                                                                  long long* __restrict__ out)
 {
-  __shared__ long long part[4][48];
-  const vvcgpu_afe_desc d = descs[blockIdx.x];
-  long long* o = out + (size_t)blockIdx.x * 49;
-  if (d.six_param) eq_block<6>(d, resiBase, gxBase, gyBase, o, part);
-  else             eq_block<4>(d, resiBase, gxBase, gyBase, o, part);
+  const int lane = threadIdx.x & 63;
+  const int b = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (b >= n) return;
+  const vvcgpu_afe_desc d = descs[b];
+  long long* o = out + (size_t)b * 49;
+  if (d.six_param) eq_block<6>(d, resiBase, gxBase, gyBase, o, lane);
+  else             eq_block<4>(d, resiBase, gxBase, gyBase, o, lane);
 }
 
 }  // namespace
@@ -106,7 +126,7 @@ int vvcgpu_affine_sobel_batch(int vertical, const vvc_pel* pred_base, int32_t* d
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(pred_base && deriv_base && descs, "affine_sobel_batch: null pointer");
   VVC_CHECK_ARG(vertical == 0 || vertical == 1, "affine_sobel_batch: vertical %d", vertical);
-  hipLaunchKernelGGL(affine_sobel_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, vertical, pred_base, deriv_base, descs);
+  hipLaunchKernelGGL(affine_sobel_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, vertical, pred_base, deriv_base, descs, n);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
@@ -117,7 +137,7 @@ int vvcgpu_affine_equal_coeff_batch(const vvc_pel* resi_base, const int32_t* der
   VVC_CHECK_ARG(n >= 0, "affine_equal_coeff_batch: n %d", n);
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(resi_base && derivx_base && derivy_base && descs && out, "affine_equal_coeff_batch: null pointer");
-  hipLaunchKernelGGL(affine_equal_coeff_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, resi_base, derivx_base, derivy_base, descs,
+  hipLaunchKernelGGL(affine_equal_coeff_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, resi_base, derivx_base, derivy_base, descs, n,
                      reinterpret_cast<long long*>(out));
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
