@@ -222,7 +222,7 @@ def main():
             "dtype": "int16",
             "data": "synthetic",
             "config": {"workload": "hot-path canonical per-picture workload (SURVEY 8(d) M1: ME SAD surfaces 16/32/64 +-4 & raster +-96, fused half/quarter refinement 16x16 (9+9 SATD), "
-                                   "bi-pred MC 16x16, residual+fwd/inv transforms+reco, deblock, SAO stats+apply, ALF classify+stats+filter) "
+                                   "bi-pred MC 16x16, residual+fwd transform+quantiser (Quant::quant, sign hiding)+dequant+inv transform+reco, deblock, SAO stats+apply, ALF classify+stats+filter) "
                                    "on %dx%d 10-bit 4:2:0, planes resident in HBM; NOT EncoderApp fps (RDO control loop out of scope)" % (args.width, args.height),
                        "width": args.width, "height": args.height, "bit_depth": bd,
                        "schedule": ("serial: one HIP stream, stage order" if args.serial else

@@ -815,3 +815,21 @@ extern "C" uint32_t vtmref_quant(const TCoeff* coef, TCoeff* level, int w, int h
   free(qpp);
   return (uint32_t)absSum;
 }
+// batched forms for the canonical workload's CPU leg (bench.py cpu_baseline, tests)
+extern "C" int vtmref_quant_batch(const TCoeff* coeffBase, TCoeff* levelBase, const vvcgpu_quant_desc* d, int n, int bd, uint32_t* absSum)
+{
+  for (int i = 0; i < n; i++)
+    absSum[i] = vtmref_quant(coeffBase + d[i].coeff_off, levelBase + d[i].level_off, d[i].w, d[i].h, bd, d[i].qp, d[i].intra_slice, d[i].sign_hiding);
+  return 0;
+}
+extern "C" int vtmref_dequant_tr_inv_batch(const TCoeff* levelBase, Pel* resiBase, const vvcgpu_dqtr_desc* d, int n, int bd, TCoeff* coeffOut)
+{
+  for (int i = 0; i < n; i++)
+  {
+    TCoeff* c = coeffOut + d[i].level_off;
+    vtmref_dequant(d[i].dep_quant, bd, d[i].qp, d[i].tr_hor == 3, levelBase + d[i].level_off, c, d[i].w, d[i].h);
+    if (d[i].tr_hor == 3) vtmref_transform_skip(1, bd, resiBase + d[i].resi_off, d[i].resi_stride, c, d[i].w, d[i].h);
+    else vtmref_inv_tr2d(bd, c, resiBase + d[i].resi_off, d[i].resi_stride, d[i].w, d[i].h, d[i].tr_hor, d[i].tr_ver);
+  }
+  return 0;
+}

@@ -167,3 +167,10 @@ ORC_API uint32_t orc_quant(const TCoeff* coef, TCoeff* level, int w, int h, int 
   }
   return absSum;
 }
+
+ORC_API int orc_quant_batch(const TCoeff* coeffBase, TCoeff* levelBase, const vvcgpu_quant_desc* d, int n, int bd, uint32_t* absSum)
+{
+  for (int i = 0; i < n; i++)
+    absSum[i] = orc_quant(coeffBase + d[i].coeff_off, levelBase + d[i].level_off, d[i].w, d[i].h, bd, d[i].qp, d[i].intra_slice, d[i].sign_hiding);
+  return 0;
+}

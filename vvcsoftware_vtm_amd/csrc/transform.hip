@@ -643,9 +643,8 @@ __global__ __launch_bounds__(256) void dequant_kernel(const TCoeff* __restrict__
 }
 
 // ---- forward scalar quantisation without RDOQ: Quant::quant (Quant.cpp:721-834) + xSignBitHidingHDQ (:142-273) ---------------
-// One wavefront per TU.  Without sign hiding the map is element-wise.  With it, a lane owns whole coefficient groups (16
-// coefficients in scan order): it quantises them into registers, decides the hiding adjustment of the group locally (the groups
-// are independent once it is known which one is the last with a non-zero level) and writes each level once.
+// Without sign hiding the map is element-wise.  With it, the coefficient groups (16 coefficients in scan order) are independent
+// once the TU's abs-sum and its last group with a level are known: pass 1 finds both, pass 2 decides every group's adjustment.
 struct QuantParams { int qBits, qBits8, scale, whScale; long long add; };
 
 __device__ __forceinline__ int quant_one(const QuantParams& q, int c, int& deltaU)
@@ -656,14 +655,16 @@ __device__ __forceinline__ int quant_one(const QuantParams& q, int c, int& delta
   return mag;
 }
 
-__global__ __launch_bounds__(256) void quant_kernel(const TCoeff* __restrict__ coeffBase, TCoeff* __restrict__ levelBase,
-                                                    const vvcgpu_quant_desc* __restrict__ descs, int n, int bd, unsigned* __restrict__ absSumOut)
+// TUs of up to 256 coefficients are handled by 16 lanes each, four side by side in a wavefront (a step = one coefficient group of
+// each; most of a picture's TUs are small, so this fills the lanes and shares the set-up); larger TUs take the whole wavefront
+// (four coefficient groups per step).
+template <bool LARGE>
+__device__ __forceinline__ void quant_tu(const TCoeff* __restrict__ coeffBase, TCoeff* __restrict__ levelBase, const vvcgpu_quant_desc& d, bool live,
+                                         int ti, int bd, unsigned* __restrict__ absSumOut, int lane)
 {
-  const int lane = threadIdx.x & 63;
-  const int ti = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ti >= n) return;
-  const vvcgpu_quant_desc d = descs[ti];
-  const int w = d.w, h = d.h, cnt = w * h, lw = ilog2(w), lh = ilog2(h);
+  constexpr int LPT = LARGE ? 64 : 16;
+  const int k = lane & 15, slot = lane >> 4, tl = lane & (LPT - 1);
+  const int w = d.w, h = d.h, cnt = live ? w * h : 0, lw = ilog2(w), lh = ilog2(h);
   const TCoeff* coef = coeffBase + d.coeff_off;
   TCoeff* level = levelBase + d.level_off;
   QuantParams q;
@@ -677,91 +678,109 @@ __global__ __launch_bounds__(256) void quant_kernel(const TCoeff* __restrict__ c
     q.add = (long long)(d.intra_slice ? 171 : 85) << (q.qBits - 9);
   }
   const bool sbh = d.sign_hiding && w >= 4 && h >= 4;
-  // pass 1: sum of magnitudes (uiAbsSum, a 32-bit int in the reference) and, for sign hiding, the last group with a level
-  int sum = 0, lastGroup = -1;
   const unsigned short* scan = d_scan + d_scanOff[(lw - 1) * 6 + (lh - 1)];
-  if (!sbh)
+  int maxCnt = cnt;                                         // the wavefront runs as many steps as its largest TU needs
+#pragma unroll
+  for (int m = LPT; m < 64; m <<= 1) maxCnt = max(maxCnt, __shfl_xor(maxCnt, m));
+  if (maxCnt == 0) return;
+  int sum = 0;
+  if (!sbh || !live)
   {
-    for (int i = lane; i < cnt; i += 64)
+    // element-wise (sign hiding off): levels are final
+    for (int s0 = 0; s0 < maxCnt; s0 += LPT)
     {
-      int du; const int c = coef[i];
-      const int mag = quant_one(q, c, du);
-      sum += mag;
-      level[i] = min(max(c < 0 ? -mag : mag, -32768), 32767);
-    }
-  }
-  else
-  {
-    for (int g = lane; g < (cnt >> 4); g += 64)
-    {
-      bool any = false;
-#pragma unroll 4
-      for (int k = 0; k < 16; k++) { int du; const int mag = quant_one(q, coef[scan[(g << 4) + k]], du); sum += mag; any |= mag != 0; }
-      if (any) lastGroup = g;
-    }
-  }
-#pragma unroll
-  for (int m = 1; m < 64; m <<= 1) { sum += __shfl_xor(sum, m); lastGroup = max(lastGroup, __shfl_xor(lastGroup, m)); }
-  if (lane == 0) absSumOut[ti] = (unsigned)sum;
-  if (!sbh) return;
-  const bool hide = sum >= 2;
-  for (int g = lane; g < (cnt >> 4); g += 64)
-  {
-    int lv[16], du[16], cf[16], pos[16];
-    int first = 16, last = -1, ssum = 0;
-#pragma unroll
-    for (int k = 0; k < 16; k++)
-    {
-      pos[k] = scan[(g << 4) + k];
-      cf[k] = coef[pos[k]];
-      const int mag = quant_one(q, cf[k], du[k]);
-      lv[k] = min(max(cf[k] < 0 ? -mag : mag, -32768), 32767);
-      if (lv[k]) { if (first == 16) first = k; last = k; }
-    }
-    if (hide && last - first >= 4)
-    {
-#pragma unroll
-      for (int k = 0; k < 16; k++) if (k >= first && k <= last) ssum += lv[k];
-      int firstLv = 0;
-#pragma unroll
-      for (int k = 0; k < 16; k++) if (k == first) firstLv = lv[k];
-      const unsigned signbit = firstLv > 0 ? 0u : 1u;
-      if (signbit != (unsigned)(ssum & 1))
+      const int si = s0 + tl;
+      if (si < cnt && !sbh)
       {
-        const int TMAX = 0x7fffffff;
-        int minCost = TMAX, minK = -1, finalChange = 0, curChange = 0;
-        const int start = (g == lastGroup) ? last : 15;
-#pragma unroll
-        for (int k = 15; k >= 0; k--)
-        {
-          if (k > start) continue;
-          int cost;
-          if (lv[k] != 0)
-          {
-            if (du[k] > 0) { cost = -du[k]; curChange = 1; }
-            else if (k == first && abs(lv[k]) == 1) cost = TMAX;
-            else { cost = du[k]; curChange = -1; }
-          }
-          else if (k < first)
-          {
-            if ((cf[k] >= 0 ? 0u : 1u) != signbit) cost = TMAX;
-            else { cost = -du[k]; curChange = 1; }
-          }
-          else { cost = -du[k]; curChange = 1; }
-          if (cost < minCost) { minCost = cost; finalChange = curChange; minK = k; }
-        }
-#pragma unroll
-        for (int k = 0; k < 16; k++)
-          if (k == minK)
-          {
-            if (lv[k] == 32767 || lv[k] == -32768) finalChange = -1;
-            lv[k] += cf[k] >= 0 ? finalChange : -finalChange;
-          }
+        int du; const int c = coef[si];
+        const int mag = quant_one(q, c, du);
+        sum += mag;
+        level[si] = min(max(c < 0 ? -mag : mag, -32768), 32767);
       }
     }
-#pragma unroll
-    for (int k = 0; k < 16; k++) level[pos[k]] = lv[k];
   }
+  // Sign hiding, ONE pass from the end of the scan: the first coefficient group met with a level is the reference's "last" group
+  // (:183-186), every other group searches all 16 positions.  The reference hides only if uiAbsSum >= 2; a group that qualifies
+  // (last - first >= 4) has two levels, so the test can only fail when the 32-bit sum wrapped -- handled after the loop.
+  // 16 lanes per coefficient group; the sequential search for the cheapest parity fix (:196-262, the highest scan position wins
+  // ties) is a 16-lane min over (cost, -position).
+  bool foundLast = false, fixedAny = false;
+  const int steps = (maxCnt + LPT - 1) / LPT;
+  for (int st = steps - 1; st >= 0; st--)
+  {
+    const int si = st * LPT + tl;
+    const bool in = sbh && live && si < cnt;
+    const int pos = in ? scan[si] : 0;
+    const int c = in ? coef[pos] : 0;
+    int du;
+    const int mag = quant_one(q, c, du);
+    sum += in ? mag : 0;
+    int lv = min(max(c < 0 ? -mag : mag, -32768), 32767);
+    const unsigned long long nzAll = __ballot(lv != 0);
+    const unsigned nz = (unsigned)((nzAll >> (16 * slot)) & 0xFFFFull);
+    // is this lane's group the last one with a level?  no earlier-met (= later in scan order) group of this TU had one
+    bool isLast;
+    if (LARGE)
+    {
+      const unsigned long long higher = slot == 3 ? 0ull : (nzAll >> (16 * (slot + 1)));
+      isLast = !foundLast && nz != 0 && higher == 0ull;
+      foundLast = foundLast || nzAll != 0ull;
+    }
+    else { isLast = !foundLast && nz != 0; foundLast = foundLast || nz != 0; }
+    const int first = nz ? __ffs((int)nz) - 1 : 16, last = nz ? 31 - __clz((int)nz) : -1;
+    int ssum = lv;
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) ssum += __shfl_xor(ssum, m);
+    const int firstLv = __shfl(lv, (lane & 48) + (first & 15));
+    const unsigned signbit = firstLv > 0 ? 0u : 1u;
+    const bool fix = last - first >= 4 && signbit != (unsigned)(ssum & 1);
+    const int start = isLast ? last : 15;
+    const int TMAX = 0x7fffffff;
+    int cost = TMAX, change = 0;
+    if (k <= start)
+    {
+      if (lv != 0)
+      {
+        if (du > 0) { cost = -du; change = 1; }
+        else if (!(k == first && abs(lv) == 1)) { cost = du; change = -1; }
+      }
+      else if (k < first) { if ((c >= 0 ? 0u : 1u) == signbit) { cost = -du; change = 1; } }
+      else { cost = -du; change = 1; }
+    }
+    long long key = ((long long)cost << 5) + (15 - k);
+#pragma unroll
+    for (int m = 1; m < 16; m <<= 1) { const long long o = __shfl_xor(key, m); key = min(key, o); }
+    if (fix && k == 15 - (int)(key & 31))
+    {
+      if (lv == 32767 || lv == -32768) change = -1;
+      lv += c >= 0 ? change : -change;
+    }
+    fixedAny = fixedAny || (fix && in);
+    if (in) level[pos] = lv;
+  }
+#pragma unroll
+  for (int m = 1; m < LPT; m <<= 1) sum += __shfl_xor(sum, m);
+  if (live && tl == 0) absSumOut[ti] = (unsigned)sum;
+  // uiAbsSum is a 32-bit int in the reference: if it wrapped below 2 no hiding happened there -- rewrite the plain levels
+  if (sbh && live && sum < 2 && __ballot(fixedAny) != 0ull)
+    for (int s0 = 0; s0 < cnt; s0 += LPT)
+    {
+      const int si = s0 + tl;
+      if (si < cnt) { int du; const int c = coef[si]; const int mag = quant_one(q, c, du); level[si] = min(max(c < 0 ? -mag : mag, -32768), 32767); }
+    }
+}
+
+// two launches: <false> takes the small TUs (four per wavefront), <true> the large ones (one per wavefront); each skips the other class
+template <bool LARGE>
+__global__ __launch_bounds__(256) void quant_kernel(const TCoeff* __restrict__ coeffBase, TCoeff* __restrict__ levelBase,
+                                                    const vvcgpu_quant_desc* __restrict__ descs, int n, int bd, unsigned* __restrict__ absSumOut)
+{
+  const int lane = threadIdx.x & 63;
+  const int ti = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (LARGE ? 1 : 4) + (LARGE ? 0 : (lane >> 4));
+  const vvcgpu_quant_desc d = descs[ti < n ? ti : n - 1];
+  const bool live = ti < n && ((int)d.w * d.h > 256) == LARGE;
+  if (__ballot(live) == 0ull) return;
+  quant_tu<LARGE>(coeffBase, levelBase, d, live, ti, bd, absSumOut, lane);
 }
 
 static bool g_tablesUploaded[64] = { false };
@@ -892,7 +911,8 @@ int vvcgpu_quant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const v
   VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "quant_batch: bit depth %d outside 8..10", bit_depth);
   const int rt = ensure_tables();
   if (rt) return rt;
-  hipLaunchKernelGGL(quant_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coeff_base, level_base, descs, n, bit_depth, abs_sum);
+  hipLaunchKernelGGL(quant_kernel<false>, dim3(cdiv(n, 16)), dim3(256), 0, (hipStream_t)stream, coeff_base, level_base, descs, n, bit_depth, abs_sum);
+  hipLaunchKernelGGL(quant_kernel<true>, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coeff_base, level_base, descs, n, bit_depth, abs_sum);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

@@ -14,7 +14,8 @@ Stages (one picture = one step):
          around a seeded integer MV (the device form of xPatternSearchFracDIF; fractional planes stay in LDS)
   mc     bi-predictive MC of the whole picture as 16x16 PUs (luma 8-tap + chroma 4-tap) + addAvg
   resi   residual = org - pred; forward + inverse transforms over a seeded tiling {64,32,16,8,4} in equal pixel
-         shares (DST-VII/DCT-VIII pairs on tiles <= 32) with a shift-only quantiser stand-in; reconstruction
+         shares (DST-VII/DCT-VIII pairs on tiles <= 32), scalar quantisation with sign bit hiding (Quant::quant, no RDOQ) at
+         QP 32, de-quantisation (Quant::dequant); reconstruction
   dbk    deblocking with a seeded CU grid / BS / QP field
   sao    SAO statistics + apply with seeded per-CTU parameters (all five types)
   alf    ALF classification + covariance statistics (7x7 and 5x5 luma, 5x5 chroma) + 7x7 luma / 5x5 chroma filtering
@@ -45,6 +46,13 @@ TR_DESC = np.dtype([("resi_off", "<i8"), ("coeff_off", "<i8"), ("resi_stride", "
 SAO_DTYPE = np.dtype([("type", "i1"), ("avail", "u1"), ("offset", "<i2", (32,))])
 FRAC_BLK = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4"), ("mv_x", "<i4"), ("mv_y", "<i4")])
 FRAC_RESULT = np.dtype([("half_x", "<i4"), ("half_y", "<i4"), ("qter_x", "<i4"), ("qter_y", "<i4"), ("cost_half", "<u8"), ("cost", "<u8")])
+
+
+QUANT_DESC = np.dtype([("coeff_off", "<i8"), ("level_off", "<i8"), ("w", "<i2"), ("h", "<i2"), ("intra_slice", "i1"), ("sign_hiding", "i1"),
+                       ("reserved", "<i2"), ("qp", "<i4"), ("reserved2", "<i4")])
+DQTR_DESC = np.dtype([("resi_off", "<i8"), ("level_off", "<i8"), ("resi_stride", "<i4"), ("w", "<i2"), ("h", "<i2"),
+                      ("tr_hor", "i1"), ("tr_ver", "i1"), ("dep_quant", "i1"), ("reserved", "i1"), ("qp", "<i4")])
+assert QUANT_DESC.itemsize == 32 and DQTR_DESC.itemsize == 32
 
 
 class MvCost(C.Structure):
@@ -162,6 +170,14 @@ class Workload:
                         coff += s * s
         self.tr = np.array(rows, dtype=TR_DESC)
         self.n_coef = coff
+        # quantiser between the transforms: Quant::quant without RDOQ (P slice, sign bit hiding) and Quant::dequant at QP 32
+        qp = 32 + 6 * (bit_depth - 8)
+        self.quant = np.zeros(self.tr.size, QUANT_DESC)
+        self.quant["coeff_off"] = self.quant["level_off"] = self.tr["coeff_off"]
+        self.quant["w"], self.quant["h"], self.quant["sign_hiding"], self.quant["qp"] = self.tr["w"], self.tr["h"], 1, qp
+        self.dqtr = np.zeros(self.tr.size, DQTR_DESC)
+        self.dqtr["resi_off"], self.dqtr["level_off"], self.dqtr["resi_stride"] = self.tr["resi_off"], self.tr["coeff_off"], self.tr["resi_stride"]
+        self.dqtr["w"], self.dqtr["h"], self.dqtr["tr_hor"], self.dqtr["tr_ver"], self.dqtr["qp"] = self.tr["w"], self.tr["h"], self.tr["tr_hor"], self.tr["tr_ver"], qp
         # plane-wide element-wise ops as one descriptor per CTU (the reference calls them per CU, <= 128x128)
         def bands(wp, hp):
             r = []
@@ -233,7 +249,7 @@ class Workload:
         # per PU: two reference windows (W+7)^2 (luma) / (W/2+3)^2 (chroma, x2 components) + the written block
         out["mc"] = {"mc_luma": nl * (2 * 23 * 23 * 2 + 16 * 16 * 2), "mc_chroma": 2 * nl * (2 * 11 * 11 * 2 + 8 * 8 * 2)}
         ncoef = self.n_coef
-        out["resi"] = {"subtract": 3 * Y, "tr_fwd": ncoef * 6, "tr_inv": ncoef * 6, "reco": 3 * Y}
+        out["resi"] = {"subtract": 3 * Y, "tr_fwd": ncoef * 6, "quant": ncoef * 8, "dequant_tr_inv": ncoef * 6, "reco": 3 * Y}
         maps = (w // 4) * (h // 4) * 4
         out["dbk"] = {"deblock": 2 * P + maps}
         out["sao"] = {"sao_stats": 2 * P + self.nctu_x * self.nctu_y * 3 * 2560, "sao_apply": 2 * P}
@@ -272,6 +288,9 @@ class Workload:
             st["resi"] = e16(h, w)
             st["resi2"] = torch.zeros((h, w), dtype=torch.int16, device="cuda")   # rows below the last 64-multiple stay 0
             st["coef"] = torch.empty(self.n_coef, dtype=torch.int32, device="cuda")
+            st["level"] = torch.empty(self.n_coef, dtype=torch.int32, device="cuda")
+            st["dqcoef"] = torch.empty(self.n_coef, dtype=torch.int32, device="cuda")
+            st["quant"], st["dqtr"] = ops.struct_to_device(self.quant), ops.struct_to_device(self.dqtr)
             st["rec"] = [e16(h, w), e16(h // 2, w // 2), e16(h // 2, w // 2)]
             st["sao_out"] = [e16(h, w), e16(h // 2, w // 2), e16(h // 2, w // 2)]
             st["alf_out"] = [e16(h, w), e16(h // 2, w // 2), e16(h // 2, w // 2)]
@@ -351,15 +370,15 @@ class Workload:
             ops.pelop_batch(3, st["org"][0], st["pred"][0], st["resi"], st["bands_luma"], self.bands_luma.size, sub)
         with T("resi/tr_fwd"):
             ops.tr_fwd_batch(st["resi"], st["coef"], st["tr"], self.tr.size, bd)
-        with T("resi/quant_standin"):
-            st["coef"].bitwise_right_shift_(4).bitwise_left_shift_(4)
-        with T("resi/tr_inv"):
-            ops.tr_inv_batch(st["coef"], st["resi2"], st["tr"], self.tr.size, bd)
+        with T("resi/quant"):
+            out["abs_sum"] = ops.quant_batch(st["coef"], st["level"], st["quant"], self.tr.size, bd)
+        with T("resi/dequant_tr_inv"):
+            ops.dequant_tr_inv_batch(st["level"], st["resi2"], st["dqtr"], self.tr.size, bd, st["dqcoef"])
         with T("resi/reco"):
             ops.pelop_batch(1, st["pred"][0], st["resi2"], st["rec"][0], st["bands_luma"], self.bands_luma.size, rec_cfg)
             st["rec"][1].copy_(st["pred"][1])
             st["rec"][2].copy_(st["pred"][2])
-        out["coef"] = st["coef"]
+        out["coef"] = st["level"]
         # ---- deblock (in place on rec)
         dcfg = ops.deblock_cfg(bd)
         with T("dbk/deblock"):
@@ -451,11 +470,15 @@ class Workload:
             timed("resi", lambda: refl.vtmref_tr_fwd_batch(P(resi), P(coef), P(self.tr), self.tr.size, bd))
         else:
             timed("resi", lambda: port.orc_tr_fwd_batch(P(resi), P(coef), P(self.tr), self.tr.size, bd))
-        coef[:] = (coef >> 4) << 4
+        level, dqcoef, abs_sum = np.zeros(self.n_coef, np.int32), np.zeros(self.n_coef, np.int32), np.zeros(self.tr.size, np.uint32)
         if refl is not None:
-            timed("resi", lambda: refl.vtmref_tr_inv_batch(P(coef), P(resi2), P(self.tr), self.tr.size, bd))
+            timed("resi", lambda: refl.vtmref_quant_batch(P(coef), P(level), P(self.quant), self.tr.size, bd, P(abs_sum)))
+            timed("resi", lambda: refl.vtmref_dequant_tr_inv_batch(P(level), P(resi2), P(self.dqtr), self.tr.size, bd, P(dqcoef)))
         else:
-            timed("resi", lambda: port.orc_tr_inv_batch(P(coef), P(resi2), P(self.tr), self.tr.size, bd))
+            timed("resi", lambda: port.orc_quant_batch(P(coef), P(level), P(self.quant), self.tr.size, bd, P(abs_sum)))
+            timed("resi", lambda: port.orc_dequant_tr_inv_batch(P(level), P(resi2), P(self.dqtr), self.tr.size, bd, P(dqcoef)))
+        coef = level
+        out["abs_sum"] = abs_sum
         rec = [np.zeros((h, w), np.int16), pred[1].copy(), pred[2].copy()]
         timed("resi", lambda: port.orc_pelop_batch(1, P(pred[0]), P(resi2), P(rec[0]), P(self.bands_luma), self.bands_luma.size, C.byref(self.cfg_reco)))
         out["coef"] = coef
