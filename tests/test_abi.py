@@ -53,7 +53,37 @@ def test_struct_layouts_match_python_bindings():
     want = {0: ops.SAO_DTYPE.itemsize, 1: C.sizeof(ops.DeblockCfg), 2: ops.DIST_DESC.itemsize, 3: ops.SEARCH_BLK.itemsize,
             4: C.sizeof(ops.MvCost), 5: ops.SEARCH_BEST.itemsize, 6: ops.IF_DESC.itemsize, 7: ops.MC_DESC.itemsize,
             8: ops.PELOP_DESC.itemsize, 9: C.sizeof(ops.PelopCfg), 10: ops.TR_DESC.itemsize, 13: ops.DQTR_DESC.itemsize, 14: ops.AFG_DESC.itemsize, 15: ops.AFE_DESC.itemsize,
-            11: ops.FRAC_BLK.itemsize, 12: ops.FRAC_RESULT.itemsize}
+            11: ops.FRAC_BLK.itemsize, 12: ops.FRAC_RESULT.itemsize, 16: ops.TZ_PU.itemsize, 17: ops.TZ_CFG.itemsize, 18: ops.INTRA_DESC.itemsize,
+            19: ops.CCLM_DESC.itemsize, 20: ops.INTRA_FILL_DESC.itemsize, 21: ops.IMV_PU.itemsize, 22: ops.IMV_RESULT.itemsize, 23: ops.QUANT_DESC.itemsize}
     for k, v in want.items():
         assert lib.vvcgpu_sizeof(k) == v, (k, lib.vvcgpu_sizeof(k), v)
     assert lib.vvcgpu_sizeof(99) == -1
+
+
+def test_next_row_entry_points_validate_arguments_without_a_device():
+    """every "next"-row batch entry point: n == 0 is a no-op that succeeds, a null array with n > 0 is refused with a message
+    naming the function -- all before any device work (this container has no GPU)."""
+    _ensure_built()
+    lib = capi.lib()
+    nul = None
+    calls = {
+        "vvcgpu_tz_search_batch": lambda n: lib.vvcgpu_tz_search_batch(nul, 8, nul, 8, nul, n, nul, nul, nul),
+        "vvcgpu_me_batch": lambda n: lib.vvcgpu_me_batch(nul, 8, nul, 8, nul, n, 16, 16, nul, 10, 0, 1023, 1, nul, nul, nul),
+        "vvcgpu_imv_refine_batch": lambda n: lib.vvcgpu_imv_refine_batch(nul, 8, nul, 8, nul, n, nul, 1, C.c_double(1.0), nul, nul),
+        "vvcgpu_dequant_tr_inv_batch": lambda n: lib.vvcgpu_dequant_tr_inv_batch(nul, nul, nul, n, 10, nul, nul),
+        "vvcgpu_quant_batch": lambda n: lib.vvcgpu_quant_batch(nul, nul, nul, n, 10, nul, nul),
+        "vvcgpu_affine_sobel_batch": lambda n: lib.vvcgpu_affine_sobel_batch(0, nul, nul, nul, n, nul),
+        "vvcgpu_affine_equal_coeff_batch": lambda n: lib.vvcgpu_affine_equal_coeff_batch(nul, nul, nul, nul, n, nul, nul),
+        "vvcgpu_intra_pred_batch": lambda n: lib.vvcgpu_intra_pred_batch(nul, nul, nul, n, 0, 1023, nul),
+        "vvcgpu_intra_fill_refs_batch": lambda n: lib.vvcgpu_intra_fill_refs_batch(nul, nul, nul, nul, n, 10, nul),
+        "vvcgpu_cclm_pred_batch": lambda n: lib.vvcgpu_cclm_pred_batch(nul, nul, nul, nul, n, 10, 10, 0, 1023, nul),
+    }
+    for name, f in calls.items():
+        assert f(0) == 0, name
+        assert f(3) == -1, name
+        assert name[len("vvcgpu_"):].encode() in lib.vvcgpu_last_error(), (name, lib.vvcgpu_last_error())
+    assert lib.vvcgpu_extend_border(nul, 8, 8, 8, 1, 1, nul) == -1
+    assert lib.vvcgpu_picture_hash(0, C.c_void_p(16), 8, 8, 8, 10, C.c_void_p(16), nul) != 0 and b"MD5" in lib.vvcgpu_last_error()
+    t, l = C.c_int(), C.c_int()
+    assert lib.vvcgpu_intra_ref_lengths(64, 4, C.byref(t), C.byref(l)) == 0 and (t.value, l.value) == (128, 22)
+    assert lib.vvcgpu_intra_ref_lengths(128, 128, C.byref(t), C.byref(l)) == -1
