@@ -42,7 +42,8 @@ int         vvcgpu_device_count(void);
 int         vvcgpu_set_device(int device);
 /* sizeof() of the parameter structs, for binding self-checks: 0 sao_ctu, 1 deblock_cfg, 2 dist_desc, 3 search_blk,
  * 4 mvcost, 5 search_best, 6 if_desc, 7 mc_desc, 8 pelop_desc, 9 pelop_cfg, 10 tr_desc, 11 frac_blk, 12 frac_result,
- * 13 dqtr_desc, 14 afg_desc, 15 afe_desc, 16 tz_pu, 17 tz_cfg, 18 intra_desc, 19 cclm_desc, 20 intra_fill_desc, 21 imv_pu, 22 imv_result, 23 quant_desc; -1 for unknown ids.          */
+ * 13 dqtr_desc, 14 afg_desc, 15 afe_desc, 16 tz_pu, 17 tz_cfg, 18 intra_desc, 19 cclm_desc, 20 intra_fill_desc, 21 imv_pu, 22 imv_result, 23 quant_desc,
+ * 24 dq_rates, 25 depquant_desc; -1 for unknown ids.          */
 int         vvcgpu_sizeof(int struct_id);
 
 /* ---- device memory helpers for host-side callers (the reference keeps pictures in host memory; the shim stages them).
@@ -453,6 +454,36 @@ typedef struct vvcgpu_quant_desc {
 } vvcgpu_quant_desc;
 int vvcgpu_quant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const vvcgpu_quant_desc* descs, int n, int bit_depth, uint32_t* abs_sum,
                        void* stream);
+
+/* N1, the rate-distortion optimised quantiser of the default configuration: dependent quantisation as a 4-state trellis
+ * (DQIntern::DepQuant::quant, CommonLib/DepQuant.cpp:1323-1391 with xDecideAndUpdate :1252-1320, State :861-1102, CommonCtx::update
+ * :1104-1164, Quantizer::initQuantBlock / preQuantCoeff :647-706, :786-808).  The trellis is sequential along the scan but
+ * independent between TUs.  The CABAC side enters as RATE TABLES: what DQIntern::RateEstimator (:335-485) derives from the
+ * current context states -- last-position bits per column / row (incl. the cbf bit difference), coded-sub-block flag bits,
+ * significance bits of the three state-dependent context sets, and the greater-than / parity bit sums -- in 2^-15 bit units
+ * (SCALE_BITS); the caller fills one vvcgpu_dq_rates per (component, TU width x height class) and points TUs at it.
+ * luma != 0 selects the luma template context offsets (:566-577).  lambda = Quant::m_dLambda of the component.
+ * level_out receives the signed levels (row pitch w), abs_sum[i] the sum of absolute levels.  ws: device workspace of
+ * vvcgpu_depquant_workspace_bytes(total coefficient count of the batch) bytes (trellis decisions and the per-state context
+ * memory of every TU).                                                                                                   */
+typedef struct vvcgpu_dq_rates {
+  int32_t last_x[64], last_y[64];       /* m_lastBitsX / m_lastBitsY                                     */
+  int32_t sig_sbb[2][2];                /* m_sigSbbFracBits[ctx].intBits[bin]                            */
+  int32_t sig[3][18][2];                /* m_sigFracBits[ctxSet][ctx].intBits[bin]                       */
+  int32_t gtx[21][7];                   /* m_gtxFracBits[ctx].bits[0..6]                                 */
+} vvcgpu_dq_rates;
+typedef struct vvcgpu_depquant_desc {
+  int64_t coeff_off, level_off;         /* elements of coeff_base / level_base, blocks are w x h with row pitch w */
+  double  lambda;
+  int32_t qp;                           /* QpParam::Qp                                                   */
+  int32_t rates_idx;                    /* index into the rates array                                    */
+  int16_t w, h;                         /* powers of two 4..64 (2-wide chroma blocks are not served)     */
+  int8_t  luma;
+  int8_t  reserved[3];                  /* sizeof == 40 */
+} vvcgpu_depquant_desc;
+size_t vvcgpu_depquant_workspace_bytes(size_t total_coeffs, int n);
+int vvcgpu_depquant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const vvcgpu_depquant_desc* descs, int n,
+                          const vvcgpu_dq_rates* rates, int bit_depth, uint32_t* abs_sum, void* ws, size_t ws_bytes, void* stream);
 
 /* The shipped matrix [type][log2(N)-1] as N x N int16 (host copy; for the shim's table check against initROM()). */
 const int16_t* vvcgpu_tr_matrix_host(int type, int n);

@@ -429,8 +429,41 @@ def gen_quant():
     save("quant", rows=np.array(rows, np.int64), coef=np.concatenate(coefs), level=np.concatenate(levels))
 
 
+def gen_depquant():
+    """next row N1: the reference's own DepQuant::quant (dependent-quantisation trellis), luma and chroma TUs, with the rate tables
+    the reference derived from its CABAC contexts (re-derived through Ctx's public FracBitsAccess by the wrapper)."""
+    rng = np.random.default_rng(1012)
+    R.vtmref_depquant.restype = C.c_uint32
+    RATES = np.dtype([("last_x", "<i4", (64,)), ("last_y", "<i4", (64,)), ("sig_sbb", "<i4", (2, 2)), ("sig", "<i4", (3, 18, 2)), ("gtx", "<i4", (21, 7))])
+    rows, coefs, levels, rates = [], [], [], []
+    off = 0
+    shapes = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (16, 4), (4, 16), (32, 8), (8, 32), (64, 16), (16, 64), (32, 64), (16, 8)]
+    for (w, h) in shapes:
+        for comp in (0, 1):
+            if comp and max(w, h) > 32:
+                continue
+            for it in range(4 if w * h <= 1024 else 2):
+                bd = 8 if it % 2 else 10
+                qp = int(rng.integers(10, 46 + (bd - 8) * 6))
+                n = w * h
+                yy, xx = np.mgrid[0:h, 0:w]
+                decay = np.exp(-(xx / w * 3 + yy / h * 3))
+                kind = it % 3
+                coef = rng.normal(0, [4000, 600, 15000][kind], (h, w)) * decay * (1 if kind < 2 else (rng.random((h, w)) < 0.2))
+                coef = np.ascontiguousarray(coef.astype(np.int32).reshape(-1))
+                lam = float(rng.uniform(5, 400))
+                cq, init = int(rng.integers(20, 45)), int(rng.integers(0, 3))
+                rt = np.zeros(1, RATES)
+                lv = np.zeros(n, np.int32)
+                s = R.vtmref_depquant(p(coef), p(lv), w, h, comp, bd, qp, C.c_double(lam), cq, init, p(rt))
+                rows.append((w, h, comp, bd, qp, off, s, len(rates)))
+                rates.append(rt[0]); coefs.append(coef); levels.append(lv); off += n
+                rows[-1] = rows[-1] + (lam,)
+    save("depquant", rows=np.array(rows, np.float64), coef=np.concatenate(coefs), level=np.concatenate(levels), rates=np.array(rates, RATES))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac, gen_tzsearch, gen_picture, gen_intra, gen_imv, gen_quant):
+    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac, gen_tzsearch, gen_picture, gen_intra, gen_imv, gen_quant, gen_depquant):
         if not only or fn.__name__[4:] in only:
             fn()

@@ -385,3 +385,26 @@ def test_quant_golden():
             O.orc_quant(p(coef), p(plain), int(w), int(h), int(bd), int(qp), int(intra), 0)
             hidden += int(np.any(plain != lv))
     assert hidden > 30          # the fixture really exercises the hiding adjustment
+
+
+def depquant_rows():
+    g = load("depquant")
+    for r in g["rows"]:
+        w, h, comp, bd, qp, off, s, ri = [int(v) for v in r[:8]]
+        yield w, h, comp, bd, qp, off, s, ri, float(r[8]), g
+
+
+def test_depquant_golden():
+    """next row N1: the restated dependent-quantisation trellis vs the compiled reference's own DepQuant::quant."""
+    O = oracle()
+    O.orc_depquant.restype = C.c_uint32
+    n = nz = 0
+    for (w, h, comp, bd, qp, off, s, ri, lam, g) in depquant_rows():
+        coef = np.ascontiguousarray(g["coef"][off:off + w * h])
+        rt = np.ascontiguousarray(g["rates"][ri:ri + 1])
+        lv = np.zeros(w * h, np.int32)
+        assert O.orc_depquant(p(coef), p(lv), w, h, 1 - comp, bd, qp, C.c_double(lam), p(rt)) == s
+        assert np.array_equal(lv, g["level"][off:off + w * h]), (w, h, comp, bd, qp)
+        n += 1
+        nz += int(np.count_nonzero(lv))
+    assert n > 80 and nz > 5000

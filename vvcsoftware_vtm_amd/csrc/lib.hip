@@ -99,6 +99,8 @@ int vvcgpu_sizeof(int id)
   case 21: return (int)sizeof(vvcgpu_imv_pu);
   case 22: return (int)sizeof(vvcgpu_imv_result);
   case 23: return (int)sizeof(vvcgpu_quant_desc);
+  case 24: return (int)sizeof(vvcgpu_dq_rates);
+  case 25: return (int)sizeof(vvcgpu_depquant_desc);
   default: return -1;
   }
 }

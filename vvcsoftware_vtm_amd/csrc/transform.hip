@@ -783,6 +783,391 @@ __global__ __launch_bounds__(256) void quant_kernel(const TCoeff* __restrict__ c
   quant_tu<LARGE>(coeffBase, levelBase, d, live, ti, bd, absSumOut, lane);
 }
 
+// ---- dependent-quantisation trellis: DQIntern::DepQuant::quant (DepQuant.cpp:1323-1391) ---------------------------------------
+// The trellis is a sequential walk down the scan with four states; TUs are independent.  FOUR LANES own one TU, lane k carries
+// trellis state k (its previous-position state and its skip state live in the lane's registers), sixteen TUs share a wavefront.
+// Per scan position: every lane prices the transitions LEAVING its state (two quantisation candidates + zero), the three 64-bit
+// costs entering decision k are gathered with quad shuffles in the reference's comparison order (:1222-1249, strict '<'), the
+// winner's template context (16 abs levels + 16 context seeds = 12 dwords) is pulled from the source lane, and the new rates are
+// looked up in the caller's rate tables.  Decisions (absLevel << 4 | prevId + 2) go to the workspace for the back-trace; the
+// per-state sub-block memory of CommonCtx (:828-858) lives in the workspace as well and is touched only at sub-block ends.
+__device__ unsigned short d_dqInv[15876];           // raster position -> scan id, same layout as d_scan
+__device__ short d_dqMaxDist[15876];                // NbInfoOut::maxDist (relative) per scan id  (:205-228)
+
+struct DqState
+{
+  long long rdCost;
+  unsigned lev[4];                    // 16 abs levels of the current sub-block (bytes)
+  unsigned cti[8];                    // 16 template-context seeds (u16): sumNum | sumAbs1 << 3 | min(127, sumAbs) << 8
+  int numSigSbb, refSbbCtxId;
+  int sbb0, sbb1, sig0, sig1;
+  int cb[7];
+  int goRice;
+};
+
+__device__ __forceinline__ unsigned dq_get_byte(const unsigned (&a)[4], int j)
+{
+  const int d = j >> 2;
+  const unsigned v = d == 0 ? a[0] : d == 1 ? a[1] : d == 2 ? a[2] : a[3];
+  return (v >> ((j & 3) * 8)) & 0xFFu;
+}
+__device__ __forceinline__ void dq_set_byte(unsigned (&a)[4], int j, unsigned val)
+{
+  const int d = j >> 2, sh = (j & 3) * 8;
+#pragma unroll
+  for (int i = 0; i < 4; i++) if (i == d) a[i] = (a[i] & ~(0xFFu << sh)) | (val << sh);
+}
+__device__ __forceinline__ unsigned dq_get_u16(const unsigned (&c)[8], int j)
+{
+  const int d = j >> 1;
+  unsigned v = c[0];
+#pragma unroll
+  for (int i = 1; i < 8; i++) v = d == i ? c[i] : v;
+  return (v >> ((j & 1) * 16)) & 0xFFFFu;
+}
+__device__ __forceinline__ int dq_level_bits(const int (&cb)[7], int goRice, unsigned level)       // State::getLevelBits :909-931
+{
+  const unsigned idx = level < 5 ? level : 5 + ((level - 5) & 1);
+  int bits = cb[0];
+#pragma unroll
+  for (int i = 1; i < 7; i++) bits = idx == (unsigned)i ? cb[i] : bits;
+  if (level < 5) return bits;
+  const unsigned value = (level - 5) >> 1;
+  const unsigned range = goRice == 0 ? 6u : goRice == 1 ? 5u : goRice == 2 ? 6u : 3u;              // g_auiGoRiceRange
+  const unsigned thres = range << goRice;
+  if (value < thres) return bits + (int)(((value >> goRice) + 1 + goRice) << 15);
+  unsigned length = goRice, delta = 1u << length, valLeft = value - thres;
+  while (valLeft >= delta) { valLeft -= delta; delta = 1u << (++length); }
+  return bits + (int)((range + 1 + (length << 1) - goRice) << 15);
+}
+__device__ __forceinline__ long long dq_shfl64(long long v, int src) { return __shfl(v, src); }
+
+__global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict__ coeffBase, TCoeff* __restrict__ levelBase,
+                                                       const vvcgpu_depquant_desc* __restrict__ descs, int n,
+                                                       const vvcgpu_dq_rates* __restrict__ ratesBase, int bd, unsigned* __restrict__ absSumOut,
+                                                       unsigned* __restrict__ wsDec, unsigned char* __restrict__ wsCtx)
+{
+  const int lane = threadIdx.x & 63, k = lane & 3, qbase = lane & ~3;
+  const int ti = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 16 + (lane >> 2);
+  const bool live = ti < n;
+  const vvcgpu_depquant_desc d = descs[live ? ti : n - 1];
+  const int w = d.w, h = d.h, N = w * h, lw = ilog2(w), lh = ilog2(h);
+  const int widthInSbb = w >> 2, heightInSbb = h >> 2, numSbb = N >> 4;
+  const bool luma = d.luma != 0;
+  const TCoeff* coef = coeffBase + d.coeff_off;
+  TCoeff* level = levelBase + d.level_off;
+  const vvcgpu_dq_rates* rt = ratesBase + d.rates_idx;
+  const int tabOff = d_scanOff[(lw - 1) * 6 + (lh - 1)];
+  const unsigned short* scan = d_scan + tabOff;
+  const unsigned short* inv = d_dqInv + tabOff;
+  const short* maxDist = d_dqMaxDist + tabOff;
+  unsigned* dec = wsDec + (size_t)d.coeff_off * 4;                         // [scanIdx][4]
+  unsigned char* ctxMem = wsCtx + (size_t)(d.coeff_off >> 4) * 8 * 17;     // 8 x { sbbFlags[numSbb], levels[N] }
+  const int chunk = numSbb + N;
+
+  // Quantizer::initQuantBlock :647-706 (the same IEEE double arithmetic)
+  int qShift, maxQIdx, thresLast, distShift;
+  long long qAdd, qScale, distAdd, distStepAdd, distOrgFact;
+  {
+    const int qpDQ = d.qp + 1, qpPer = qpDQ / 6, qpRem = qpDQ - 6 * qpPer;
+    const bool sqrt2 = ((lw + lh) & 1) != 0;
+    const int transformShift = 15 - bd - ((lw + lh) >> 1);
+    const int qs = qpRem == 0 ? 26214 : qpRem == 1 ? 23302 : qpRem == 2 ? 20560 : qpRem == 3 ? 18396 : qpRem == 4 ? 16384 : 14564;
+    qShift = 14 - 1 + qpPer + transformShift;
+    qAdd = -((3ll << qShift) >> 1);
+    const int invShift = 6 + 1 - qpPer - transformShift + (sqrt2 ? 8 : 0);
+    qScale = sqrt2 ? (qs * 181) >> 7 : qs;
+    const unsigned qIdxBD = min(16u, (unsigned)(32 + invShift - 6 - 1));
+    maxQIdx = (1 << (qIdxBD - 1)) - 4;
+    thresLast = (int)((3ll << qShift) / (4 * qScale));
+    const int nomDShift = 15 - 2 * transformShift + qShift;
+    const double qScale2 = (double)((long long)qs * qs);
+    const double nomDistFactor = nomDShift < 0 ? 1.0 / ((double)(1ll << (-nomDShift)) * qScale2 * d.lambda) : (double)(1ll << nomDShift) / (qScale2 * d.lambda);
+    const long long pow2dfShift = (long long)(nomDistFactor * qScale2) + 1;
+    int dfShift = 0;
+    while ((1ull << dfShift) < (unsigned long long)pow2dfShift && dfShift < 63) dfShift++;
+    distShift = 62 + qShift - 2 * 15 - dfShift;
+    distAdd = (1ll << distShift) >> 1;
+    distStepAdd = (long long)(nomDistFactor * (double)(1ll << (distShift + qShift)) + .5);
+    distOrgFact = (long long)(nomDistFactor * (double)(1ll << (distShift + 1)) + .5);
+  }
+
+  // first tested position :1337-1349 (four lanes split the search), levels start as zero
+  int first = -1;
+  if (live)
+  {
+    for (int i = k; i < N; i += 4) level[i] = 0;
+    for (int i = N - 1 - k; i >= 0; i -= 4) if (abs(coef[scan[i]]) > thresLast) { first = i; break; }
+  }
+  first = max(first, __shfl_xor(first, 1));
+  first = max(first, __shfl_xor(first, 2));
+  int maxFirst = first;
+#pragma unroll
+  for (int m = 4; m < 64; m <<= 1) maxFirst = max(maxFirst, __shfl_xor(maxFirst, m));
+  if (live && first < 0 && k == 0) absSumOut[ti] = 0;
+  if (maxFirst < 0) return;
+
+  const int sigSet = max(k - 1, 0);                                       // RateEstimator::sigFlagBits(stateId) :282-285
+  DqState P, S;                                                           // previous-position state k, skip state k
+  {
+    P.rdCost = 0x7FFFFFFFFFFFFFFFll >> 1; P.numSigSbb = 0; P.refSbbCtxId = -1; P.goRice = 0; P.sbb0 = P.sbb1 = 0;
+    P.sig0 = rt->sig[sigSet][0][0]; P.sig1 = rt->sig[sigSet][0][1];
+#pragma unroll
+    for (int i = 0; i < 7; i++) P.cb[i] = rt->gtx[0][i];
+#pragma unroll
+    for (int i = 0; i < 4; i++) P.lev[i] = 0;
+#pragma unroll
+    for (int i = 0; i < 8; i++) P.cti[i] = 0;
+    S = P;
+  }
+  int startCb[7];
+#pragma unroll
+  for (int i = 0; i < 7; i++) startCb[i] = rt->gtx[0][i];
+  int curCtx = 0;                                                         // which half of the sub-block memory is "current"
+  long long finalCost = 0;
+
+  for (int scanIdx = maxFirst; scanIdx >= 0; scanIdx--)
+  {
+    const bool act = live && scanIdx <= first;                            // quad-uniform
+    const int sIdx = act ? scanIdx : 0;
+    const int pos = scan[sIdx], px = pos & (w - 1), py = pos >> lw;
+    const int insidePos = sIdx & 15;
+    const bool eosbb = insidePos == 0, sosbb = insidePos == 15;
+    const bool socsbb = sosbb && sIdx > 16 && sIdx < N - 1;
+    const bool eocsbb = eosbb && sIdx > 0 && sIdx < N - 16;
+    const int spt = socsbb ? 1 : (eocsbb ? 2 : 0);
+    const int lastOffset = rt->last_x[px] + rt->last_y[py];
+
+    // Quantizer::preQuantCoeff :786-808
+    long long pqDist[4]; int pqAbs[4];
+    {
+      const long long scaledOrg = (long long)abs(coef[pos]) * qScale;
+      int qIdx = max(1, min(maxQIdx, (int)((scaledOrg + qAdd) >> qShift)));
+      long long scaledAdd = qIdx * distStepAdd - scaledOrg * distOrgFact;
+#pragma unroll
+      for (int i = 0; i < 4; i++)
+      {
+        const int slot = qIdx & 3;
+        const long long dd = (scaledAdd * qIdx + distAdd) >> distShift;
+        const int al = (++qIdx) >> 1;
+#pragma unroll
+        for (int t = 0; t < 4; t++) if (t == slot) { pqDist[t] = dd; pqAbs[t] = al; }
+        scaledAdd += distStepAdd;
+      }
+    }
+
+    // transitions leaving state k: state 0: pq0 -> dec0, pq2 -> dec2; state 1: pq2 -> dec0, pq0 -> dec2; state 2: pq3 -> dec1, pq1 -> dec3;
+    // state 3: pq1 -> dec1, pq3 -> dec3; the zero transition goes to dec0 / dec2 / dec1 / dec3  (:1229-1240)
+    const int lowIdx = k == 0 ? 0 : k == 1 ? 2 : k == 2 ? 3 : 1, highIdx = lowIdx ^ 2;
+    const long long INF = 0x7FFFFFFFFFFFFFFFll;
+    long long cLow, cHigh, cZero = INF;
+    {
+      int extra1 = 0, extra0 = 0; bool zeroOk = true;
+      if (spt == 0) { extra1 = P.sig1; extra0 = P.sig0; }
+      else if (spt == 1) { extra1 = P.sbb1 + P.sig1; extra0 = P.sbb1 + P.sig0; }
+      else if (P.numSigSbb) { extra1 = P.sig1; extra0 = P.sig0; }
+      else zeroOk = false;
+      long long dl = pqDist[0]; int al = pqAbs[0], ah = pqAbs[0]; long long dh = pqDist[0];
+#pragma unroll
+      for (int t = 1; t < 4; t++) { if (t == lowIdx) { dl = pqDist[t]; al = pqAbs[t]; } if (t == highIdx) { dh = pqDist[t]; ah = pqAbs[t]; } }
+      if (lowIdx == 0) { dl = pqDist[0]; al = pqAbs[0]; }
+      if (highIdx == 0) { dh = pqDist[0]; ah = pqAbs[0]; }
+      cLow = P.rdCost + dl + dq_level_bits(P.cb, P.goRice, (unsigned)al) + extra1;
+      cHigh = P.rdCost + dh + dq_level_bits(P.cb, P.goRice, (unsigned)ah) + extra1;
+      if (zeroOk) cZero = P.rdCost + extra0;
+    }
+    // decision k: sources a = 0 / 2, b = a + 1; k < 2 takes their "low" transitions, k >= 2 the "high" ones
+    const int a = (k & 1) * 2, b = a + 1;
+    const long long aLow = dq_shfl64(cLow, qbase + a), aHigh = dq_shfl64(cHigh, qbase + a), aZero = dq_shfl64(cZero, qbase + a);
+    const long long bLow = dq_shfl64(cLow, qbase + b), bHigh = dq_shfl64(cHigh, qbase + b), bZero = dq_shfl64(cZero, qbase + b);
+    long long dCost = INF >> 2; int dAbs = -1, dPrev = -2;
+    {
+      // pq index of the transition a -> k and b -> k
+      const int ia = k == 0 ? 0 : k == 2 ? 2 : k == 1 ? 3 : 1, ib = ia ^ 2;
+      int absA = pqAbs[0], absB = pqAbs[0];
+#pragma unroll
+      for (int t = 1; t < 4; t++) { if (t == ia) absA = pqAbs[t]; if (t == ib) absB = pqAbs[t]; }
+      const long long cA = k < 2 ? aLow : aHigh, cB = k < 2 ? bLow : bHigh;
+      if (k < 2)
+      {
+        if (cA < dCost) { dCost = cA; dAbs = absA; dPrev = a; }
+        if (aZero < dCost) { dCost = aZero; dAbs = 0; dPrev = a; }
+        if (cB < dCost) { dCost = cB; dAbs = absB; dPrev = b; }
+      }
+      else
+      {
+        if (cA < dCost) { dCost = cA; dAbs = absA; dPrev = a; }
+        if (cB < dCost) { dCost = cB; dAbs = absB; dPrev = b; }
+        if (bZero < dCost) { dCost = bZero; dAbs = 0; dPrev = b; }
+      }
+      if (spt == 2) { const long long c = S.rdCost + S.sbb0; if (c < dCost) { dCost = c; dAbs = 0; dPrev = 4 + k; } }          // checkRdCostSkipSbb
+      if ((k & 1) == 0)                                                                                               // checkRdCostStart (decisions 0, 2)
+      {
+        const int as = k == 0 ? pqAbs[0] : pqAbs[2];
+        const long long c = (k == 0 ? pqDist[0] : pqDist[2]) + lastOffset + dq_level_bits(startCb, 0, (unsigned)as);
+        if (c < dCost) { dCost = c; dAbs = as; dPrev = -1; }
+      }
+    }
+    if (act) dec[(size_t)sIdx * 4 + k] = ((unsigned)max(dAbs, 0) << 4) | (unsigned)(dPrev + 2);
+    if (sIdx == 0) finalCost = dCost;
+
+    // ---- state update (:1259-1318); every lane pulls its winner's context from the source lane
+    DqState C = P;                                                         // becomes the new previous state
+    if (sIdx > 0)
+    {
+      const int nxt = sIdx - 1, npos = scan[nxt], nx = npos & (w - 1), ny = npos >> lw, diag = nx + ny;
+      const int sigOff = luma ? (diag < 2 ? 12 : diag < 5 ? 6 : 0) : (diag < 2 ? 6 : 0);
+      const int gtxOff = luma ? (diag < 1 ? 16 : diag < 3 ? 11 : diag < 10 ? 6 : 1) : (diag < 1 ? 6 : 1);
+      const int nextInside = nxt & 15;
+      // source of the copied context: lane dPrev (0..3), own skip state (4 + k) or nothing
+      const int srcLane = qbase + (dPrev >= 0 && dPrev < 4 ? dPrev : k);
+      unsigned lv[4], ct[8]; int sNum, sRef, sSbb0, sSbb1;
+#pragma unroll
+      for (int i = 0; i < 4; i++) lv[i] = (unsigned)__shfl((int)P.lev[i], srcLane);
+#pragma unroll
+      for (int i = 0; i < 8; i++) ct[i] = (unsigned)__shfl((int)P.cti[i], srcLane);
+      sNum = __shfl(P.numSigSbb, srcLane); sRef = __shfl(P.refSbbCtxId, srcLane);
+      sSbb0 = __shfl(P.sbb0, srcLane); sSbb1 = __shfl(P.sbb1, srcLane);
+      if (dPrev >= 4) { sNum = S.numSigSbb; sRef = S.refSbbCtxId;
+#pragma unroll
+        for (int i = 0; i < 4; i++) lv[i] = S.lev[i]; }
+      C.rdCost = dCost;
+      if (dPrev > -2)
+      {
+        int sumAbs, sumAbs1, sumNum;
+        if (!eosbb)                                                        // State::updateState :1004-1068
+        {
+          if (dPrev >= 0) { C.numSigSbb = sNum + (dAbs != 0); C.refSbbCtxId = sRef; C.sbb0 = sSbb0; C.sbb1 = sSbb1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) C.lev[i] = lv[i];
+#pragma unroll
+            for (int i = 0; i < 8; i++) C.cti[i] = ct[i]; }
+          else { C.numSigSbb = 1; C.refSbbCtxId = -1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) C.lev[i] = 0;
+#pragma unroll
+            for (int i = 0; i < 8; i++) C.cti[i] = 0; }
+          dq_set_byte(C.lev, insidePos, (unsigned)min(255, dAbs));
+          const unsigned tinit = dq_get_u16(C.cti, nextInside);
+          sumAbs = (int)(tinit >> 8); sumAbs1 = (int)((tinit >> 3) & 31); sumNum = (int)(tinit & 7);
+          // in-sub-block template neighbours of the next position: right, right + 1, below-right, below, below + 1  (:139-168)
+          const int cx[5] = { nx + 1, nx + 2, nx + 1, nx, nx }, cy[5] = { ny, ny, ny + 1, ny + 1, ny + 2 };
+          const int beg = nxt & ~15;
+#pragma unroll
+          for (int t = 0; t < 5; t++)
+            if (cx[t] < w && cy[t] < h)
+            {
+              const int rel = (int)inv[cy[t] * w + cx[t]] - beg;
+              if (rel > 0 && rel < 16) { const int v = (int)dq_get_byte(C.lev, rel); sumAbs += v; sumAbs1 += min(4 - (v & 1), v); sumNum += v != 0; }
+            }
+        }
+        else                                                               // State::updateStateEOS :1071-1102 + CommonCtx::update :1104-1164
+        {
+          if (dPrev >= 0) { C.numSigSbb = sNum + (dAbs != 0);
+#pragma unroll
+            for (int i = 0; i < 4; i++) C.lev[i] = lv[i]; }
+          else { C.numSigSbb = 1;
+#pragma unroll
+            for (int i = 0; i < 4; i++) C.lev[i] = 0; }
+          dq_set_byte(C.lev, insidePos, (unsigned)min(255, dAbs));
+          const int prevRef = dPrev >= 0 ? sRef : -1;
+          const int newCur = curCtx ^ 1;                                    // CommonCtx::swap before the four updates
+          unsigned char* flags = ctxMem + (size_t)(newCur * 4 + k) * chunk;
+          unsigned char* lev = flags + numSbb;
+          const int setCp = maxDist[sIdx - 1];
+          if (act)
+          {
+            if (prevRef >= 0)
+            {
+              const unsigned char* pf = ctxMem + (size_t)(curCtx * 4 + prevRef) * chunk;
+              const unsigned char* pl = pf + numSbb;
+              for (int i = 0; i < numSbb; i++) flags[i] = pf[i];
+              for (int i = 0; i < setCp; i++) lev[sIdx + i] = pl[sIdx + i];
+            }
+            else
+            {
+              for (int i = 0; i < numSbb; i++) flags[i] = 0;
+              for (int i = 0; i < setCp; i++) lev[sIdx + i] = 0;
+            }
+            const int sbbPos = (py >> 2) * widthInSbb + (px >> 2);
+            flags[sbbPos] = C.numSigSbb != 0;
+#pragma unroll
+            for (int i = 0; i < 4; i++) *reinterpret_cast<unsigned*>(lev + sIdx + 4 * i) = C.lev[i];     // sIdx is a multiple of 16
+          }
+          const int nsx = nx >> 2, nsy = ny >> 2, nsp = nsy * widthInSbb + nsx;
+          const int right = nsx < widthInSbb - 1 ? nsp + 1 : 0, below = nsy < heightInSbb - 1 ? nsp + widthInSbb : 0;
+          int sigNSbb = 0;
+          if (act) sigNSbb = ((right ? flags[right] : 0) || (below ? flags[below] : 0)) ? 1 : 0;
+          C.numSigSbb = 0; C.refSbbCtxId = k;
+          C.sbb0 = rt->sig_sbb[sigNSbb][0]; C.sbb1 = rt->sig_sbb[sigNSbb][1];
+          // template seeds of the sixteen positions of the next sub-block from the levels outside it (:1131-1160)
+          const int scanBeg = sIdx - 16;
+#pragma unroll
+          for (int i = 0; i < 8; i++) C.cti[i] = 0;
+          if (act)
+            for (int i = 0; i < 16; i++)
+            {
+              const int p2 = scan[scanBeg + i], x2 = p2 & (w - 1), y2 = p2 >> lw;
+              const int cx[5] = { x2 + 1, x2 + 2, x2 + 1, x2, x2 }, cy[5] = { y2, y2, y2 + 1, y2 + 1, y2 + 2 };
+              int sA = 0, sA1 = 0, sN = 0;
+#pragma unroll
+              for (int t = 0; t < 5; t++)
+                if (cx[t] < w && cy[t] < h)
+                {
+                  const int id = inv[cy[t] * w + cx[t]];
+                  if (id - scanBeg >= 16) { const int v = lev[id]; sA += v; sA1 += min(4 - (v & 1), v); sN += v != 0; }
+                }
+              const unsigned seed = (unsigned)(sN + (sA1 << 3) + (min(127, sA) << 8));
+#pragma unroll
+              for (int j = 0; j < 8; j++) if (j == (i >> 1)) C.cti[j] |= seed << ((i & 1) * 16);
+            }
+#pragma unroll
+          for (int i = 0; i < 4; i++) C.lev[i] = 0;
+          const unsigned tinit = dq_get_u16(C.cti, nextInside);
+          sumNum = (int)(tinit & 7); sumAbs1 = (int)((tinit >> 3) & 31); sumAbs = (int)(tinit >> 8);
+        }
+        const int sumGt1 = sumAbs1 - sumNum;
+        sumAbs -= sumNum;
+        const int sc = sigOff + min(sumAbs1, 5), gc = gtxOff + min(sumGt1, 4);
+        C.sig0 = rt->sig[sigSet][sc][0]; C.sig1 = rt->sig[sigSet][sc][1];
+#pragma unroll
+        for (int i = 0; i < 7; i++) C.cb[i] = rt->gtx[gc][i];
+        const int ga = min(sumAbs, 31);
+        C.goRice = ga < 12 ? 0 : ga < 25 ? 1 : 2;                          // g_auiGoRicePars
+      }
+      if (eosbb) { __threadfence_block(); }
+    }
+    if (act)
+    {
+      if (sIdx > 0 && eosbb) curCtx ^= 1;
+      if (socsbb) S = P;                                                   // swap( m_prevStates, m_skipStates ) :1314-1317
+      P = C;
+    }
+  }
+
+  // ---- best final state and back-trace :1368-1390.  Lane 0 of the quad walks; decisions 4..7 are implicit: at a sub-block end they
+  // are a copy of decisions 0..3 (:1269), elsewhere { level 0, same skip id } (startDec :1218)
+  long long c1 = dq_shfl64(finalCost, qbase + 1), c2 = dq_shfl64(finalCost, qbase + 2), c3 = dq_shfl64(finalCost, qbase + 3);
+  if (!live || first < 0 || k != 0) return;
+  int prevId = -2; long long minCost = 0;
+  if (finalCost < minCost) { prevId = 0; minCost = finalCost; }
+  if (c1 < minCost) { prevId = 1; minCost = c1; }
+  if (c2 < minCost) { prevId = 2; minCost = c2; }
+  if (c3 < minCost) { prevId = 3; minCost = c3; }
+  unsigned absSum = 0;
+  for (int scanIdx = 0; prevId >= 0; scanIdx++)
+  {
+    int al, nextPrev;
+    if (prevId >= 4 && (scanIdx & 15) != 0) { al = 0; nextPrev = prevId; }
+    else { const unsigned v = dec[(size_t)scanIdx * 4 + (prevId & 3)]; al = (int)(v >> 4); nextPrev = (int)(v & 15) - 2; }
+    const int pos = scan[scanIdx];
+    level[pos] = coef[pos] < 0 ? -al : al;
+    absSum += (unsigned)al;
+    prevId = nextPrev;
+  }
+  absSumOut[ti] = absSum;
+}
+
 static bool g_tablesUploaded[64] = { false };
 static const int g_smallGrid = getenv("VVCGPU_TR_SMALLGRID") ? atoi(getenv("VVCGPU_TR_SMALLGRID")) : 1280;   // tuning switch
 
@@ -829,6 +1214,32 @@ static int ensure_tables()
       for (int b = 0; b < 6; b++) { off[a * 6 + b] = o; host_scan_order(2 << a, 2 << b, scan + o); o += (2 << a) * (2 << b); }
     VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_scan), scan, sizeof(scan)));
     VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_scanOff), off, sizeof(off)));
+    // dependent quantisation: raster -> scan id, and NbInfoOut::maxDist (DepQuant.cpp:205-228: running maximum over the scan of the
+    // farthest template neighbour outside the sub-block, relative to the scan id)
+    static uint16_t invs[15876];
+    static int16_t maxd[15876];
+    for (int a = 0; a < 6; a++)
+      for (int b = 0; b < 6; b++)
+      {
+        const int W = 2 << a, H = 2 << b, N = W * H, o0 = off[a * 6 + b];
+        const int grp = ((W & 3) || (H & 3)) ? 4 : 16;
+        for (int i = 0; i < N; i++) invs[o0 + scan[o0 + i]] = (uint16_t)i;
+        int run = 0;
+        for (int i = 0; i < N; i++)
+        {
+          const int r = scan[o0 + i], x = r % W, y = r / W, beg = i - (i & (grp - 1));
+          const int cx[5] = { x + 1, x + 2, x + 1, x, x }, cy[5] = { y, y, y + 1, y + 1, y + 2 };
+          for (int t = 0; t < 5; t++)
+            if (cx[t] < W && cy[t] < H)
+            {
+              const int id = invs[o0 + cy[t] * W + cx[t]];
+              if (id - beg >= grp && id > run) run = id;
+            }
+          maxd[o0 + i] = (int16_t)(run - i);
+        }
+      }
+    VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_dqInv), invs, sizeof(invs)));
+    VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_dqMaxDist), maxd, sizeof(maxd)));
     g_tablesUploaded[dev] = true;
   }
   return VVCGPU_OK;
@@ -913,6 +1324,33 @@ int vvcgpu_quant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const v
   if (rt) return rt;
   hipLaunchKernelGGL(quant_kernel<false>, dim3(cdiv(n, 16)), dim3(256), 0, (hipStream_t)stream, coeff_base, level_base, descs, n, bit_depth, abs_sum);
   hipLaunchKernelGGL(quant_kernel<true>, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coeff_base, level_base, descs, n, bit_depth, abs_sum);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+size_t vvcgpu_depquant_workspace_bytes(size_t total_coeffs, int n)
+{
+  (void)n;
+  const size_t c = (total_coeffs + 15) & ~(size_t)15;
+  return c * 16 + (c / 16) * 8 * 17 + 256;                 // decisions (4 x u32 per position) + 8 x { sbbFlags, levels } per TU
+}
+
+int vvcgpu_depquant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const vvcgpu_depquant_desc* descs, int n,
+                          const vvcgpu_dq_rates* rates, int bit_depth, uint32_t* abs_sum, void* ws, size_t ws_bytes, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "depquant_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(coeff_base && level_base && descs && rates && abs_sum && ws, "depquant_batch: null pointer");
+  VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "depquant_batch: bit depth %d outside 8..10", bit_depth);
+  VVC_CHECK_ARG(ws_bytes >= 512 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, "depquant_batch: workspace too small or unaligned");
+  const int rt = ensure_tables();
+  if (rt) return rt;
+  // the workspace is split as vvcgpu_depquant_workspace_bytes lays it out: c * 16 bytes of decisions, then the context memory
+  const size_t c = ((ws_bytes - 256) * 16 / (16 * 16 + 8 * 17)) & ~(size_t)15;
+  unsigned* dec = static_cast<unsigned*>(ws);
+  unsigned char* ctx = static_cast<unsigned char*>(ws) + c * 16;
+  hipLaunchKernelGGL(depquant_kernel, dim3(cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, coeff_base, level_base, descs, n, rates, bit_depth,
+                     abs_sum, dec, ctx);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

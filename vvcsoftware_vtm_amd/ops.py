@@ -293,6 +293,24 @@ def quant_batch(coeff_base, level_base, descs_dev, n, bit_depth=10):
     return out
 
 
+DQ_RATES = np.dtype([("last_x", "<i4", (64,)), ("last_y", "<i4", (64,)), ("sig_sbb", "<i4", (2, 2)), ("sig", "<i4", (3, 18, 2)), ("gtx", "<i4", (21, 7))])
+DEPQUANT_DESC = np.dtype([("coeff_off", "<i8"), ("level_off", "<i8"), ("lambda", "<f8"), ("qp", "<i4"), ("rates_idx", "<i4"), ("w", "<i2"), ("h", "<i2"),
+                          ("luma", "i1"), ("reserved", "i1", (3,))])
+assert DEPQUANT_DESC.itemsize == 40 and DQ_RATES.itemsize == 4 * (128 + 4 + 108 + 147)
+
+
+def depquant_batch(coeff_base, level_base, descs_dev, n, rates_dev, total_coeffs, bit_depth=10):
+    """N1: dependent-quantisation trellis (DQIntern::DepQuant::quant) for n TUs -> abs-sum int32 tensor [n] (bits as uint32)."""
+    lib = capi.lib()
+    lib.vvcgpu_depquant_workspace_bytes.restype = C.c_size_t
+    nbytes = int(lib.vvcgpu_depquant_workspace_bytes(C.c_size_t(total_coeffs), n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=coeff_base.device)
+    out = torch.zeros(n, dtype=torch.int32, device=coeff_base.device)
+    capi.call("vvcgpu_depquant_batch", capi.ptr(coeff_base), capi.ptr(level_base), capi.ptr(descs_dev), n, capi.ptr(rates_dev), bit_depth,
+              capi.ptr(out), capi.ptr(ws), C.c_size_t(nbytes), _stream())
+    return out
+
+
 # ---- interpolation / MC / PelBuffer ops -------------------------------------------------------------
 IF_DESC = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("src_stride", "<i4"), ("dst_stride", "<i4"),
                     ("w", "<i2"), ("h", "<i2"), ("taps", "i1"), ("is_vertical", "i1"), ("is_first", "i1"),
