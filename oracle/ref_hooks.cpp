@@ -21,6 +21,8 @@
 // the picture hashes, called from calcAndPrintHashStatus in their own translation unit (PicYuvMD5.cpp:228-240) and from the encoder's SEI writer
 #define CRC_SYM "_Z7calcCRCRK7UnitBufIKsER11PictureHashRK9BitDepths"
 #define SUM_SYM "_Z12calcChecksumRK7UnitBufIKsER11PictureHashRK9BitDepths"
+// the dependent-quantisation trellis: a virtual function, reached through the vtable (dynamic relocation against this symbol)
+#define DQ_SYM "_ZN8DepQuant5quantER13TransformUnitRK11ComponentIDRK7AreaBufIKiERiRK7QpParamRK3Ctx"
 // the fractional motion refinement, called from xMotionEstimation in its own translation unit (InterSearch.cpp:1816)
 #define FRAC_SYM "_ZN11InterSearch21xPatternSearchFracDIFERK14PredictionUnit10RefPicListiRNS_17IntTZSearchStructERK2MvRS6_S9_Rm"
 
@@ -49,6 +51,9 @@ typedef unsigned (*hash_real_t)(const void*, void*, const void*);
 typedef int (*hash_shim_t)(int, const void*, void*, const void*);
 unsigned hook_crc(const void* pic, void* digest, const void* bitDepths) asm(CRC_SYM);
 unsigned hook_checksum(const void* pic, void* digest, const void* bitDepths) asm(SUM_SYM);
+typedef void (*dq_real_t)(void*, void*, const void*, const void*, void*, const void*, const void*);
+typedef int (*dq_shim_t)(void*, void*, const void*, const void*, void*, const void*, const void*);
+void hook_depquant(void* self, void* tu, const void* compID, const void* src, void* absSum, const void* qp, const void* ctx) asm(DQ_SYM);
 void hook_sao_stats(void* self, void* blkStats, void* org, void* src, void* cs, bool pre) asm(SAO_SYM);
 void hook_alf_stats(void* self, void* org, void* rec) asm(ALF_SYM);
 
@@ -123,5 +128,16 @@ unsigned hook_checksum(const void* pic, void* digest, const void* bitDepths)
   static hash_real_t real = (hash_real_t)must(g_target ? dlsym(g_target, SUM_SYM) : nullptr, SUM_SYM);
   if (shim) { const int n = shim(2, pic, digest, bitDepths); if (n) return (unsigned)n; }
   return real(pic, digest, bitDepths);
+}
+static dq_real_t dq_real() { static dq_real_t real = (dq_real_t)must(g_target ? dlsym(g_target, DQ_SYM) : nullptr, DQ_SYM); return real; }
+void hook_depquant(void* self, void* tu, const void* compID, const void* src, void* absSum, const void* qp, const void* ctx)
+{
+  static dq_shim_t shim = (dq_shim_t)dlsym(RTLD_DEFAULT, "vvcshim_depquant");
+  if (shim && shim(self, tu, compID, src, absSum, qp, ctx)) return;
+  dq_real()(self, tu, compID, src, absSum, qp, ctx);
+}
+void vtmhooks_real_depquant(void* self, void* tu, const void* compID, const void* src, void* absSum, const void* qp, const void* ctx)
+{
+  dq_real()(self, tu, compID, src, absSum, qp, ctx);
 }
 }

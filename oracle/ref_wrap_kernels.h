@@ -2,6 +2,8 @@
 // extern "C" wrappers that ENTER the reference's own kernels (no arithmetic of their own beyond
 // buffer plumbing and the CTU loops of the picture-level callers, which are cited).
 #pragma once
+#include "CommonLib/UnitTools.h"
+#include "CommonLib/ContextModelling.h"
 #include <vector>
 #include "CommonLib/Buffer.h"
 #include "CommonLib/Unit.h"
@@ -835,6 +837,57 @@ extern "C" int vtmref_dequant_tr_inv_batch(const TCoeff* levelBase, Pel* resiBas
 }
 
 // ---------------------------------------------------------------------------------------------
+// rate tables of the dependent-quantisation trellis from a CABAC context object: DQIntern::RateEstimator::initCtx (DepQuant.cpp:371-485)
+// re-expressed with Ctx's public FracBitsAccess (the estimator class itself is private to DepQuant.cpp).  Shared with the drop-in shim.
+void vtmref_dq_rates_from_ctx(const TransformUnit& tu, ComponentID compID, const Ctx& ctxRef, vvcgpu_dq_rates* rt)
+{
+  {
+    const Ctx* ctx = &ctxRef;
+    const ChannelType chType = toChannelType(compID);
+    const int w = tu.blocks[compID].width, h = tu.blocks[compID].height;
+    const FracBitsAccess& fb = ctx->getFracBitsAcess();
+    memset(rt, 0, sizeof *rt);
+    // :379-426
+    int32_t cbfDelta;
+    if (compID == COMPONENT_Y && !CU::isIntra(*tu.cu) && !tu.depth) { const BinFracBits b = fb.getFracBitsArray(Ctx::QtRootCbf()); cbfDelta = int32_t(b.intBits[1]) - int32_t(b.intBits[0]); }
+    else { const BinFracBits b = fb.getFracBitsArray(Ctx::QtCbf[compID](DeriveCtx::CtxQtCbf(compID, tu.depth, tu.cbf[COMPONENT_Cb]))); cbfDelta = int32_t(b.intBits[1]) - int32_t(b.intBits[0]); }
+    static const unsigned prefixCtx[] = { 0, 0, 0, 3, 6, 10, 15, 21 };
+    for (unsigned xy = 0; xy < 2; xy++)
+    {
+      const int32_t bitOffset = xy ? cbfDelta : 0;
+      int32_t* lastBits = xy ? rt->last_y : rt->last_x;
+      const unsigned size = xy ? h : w, log2Size = g_aucNextLog2[size];
+      const CtxSet& set = (xy ? Ctx::LastY : Ctx::LastX)[chType];
+      const unsigned lastShift = compID == COMPONENT_Y ? (log2Size + 1) >> 2 : Clip3<unsigned>(0, 2, size >> 3);
+      const unsigned lastOffset = compID == COMPONENT_Y ? prefixCtx[log2Size] : 0;
+      uint32_t ctxBits[LAST_SIGNIFICANT_GROUPS], sum = 0;
+      const unsigned maxCtxId = g_uiGroupIdx[size - 1];
+      for (unsigned id = 0; id < maxCtxId; id++)
+      {
+        const BinFracBits b = fb.getFracBitsArray(set(lastOffset + (id >> lastShift)));
+        ctxBits[id] = sum + b.intBits[0] + (id > 3 ? ((id - 2) >> 1) << SCALE_BITS : 0) + bitOffset;
+        sum += b.intBits[1];
+      }
+      ctxBits[maxCtxId] = sum + (maxCtxId > 3 ? ((maxCtxId - 2) >> 1) << SCALE_BITS : 0) + bitOffset;
+      for (unsigned pos = 0; pos < size; pos++) lastBits[pos] = ctxBits[g_uiGroupIdx[pos]];
+    }
+    for (unsigned c = 0; c < 2; c++) { const BinFracBits b = fb.getFracBitsArray(Ctx::SigCoeffGroup[chType](c)); rt->sig_sbb[c][0] = b.intBits[0]; rt->sig_sbb[c][1] = b.intBits[1]; }
+    const unsigned numSig = compID == COMPONENT_Y ? 18 : 12, numGtx = compID == COMPONENT_Y ? 21 : 11;
+    for (unsigned s = 0; s < 3; s++)
+      for (unsigned c = 0; c < numSig; c++) { const BinFracBits b = fb.getFracBitsArray(Ctx::SigFlag[chType + 2 * s](c)); rt->sig[s][c][0] = b.intBits[0]; rt->sig[s][c][1] = b.intBits[1]; }
+    for (unsigned c = 0; c < numGtx; c++)
+    {
+      const BinFracBits par = fb.getFracBitsArray(Ctx::ParFlag[chType](c)), gt1 = fb.getFracBitsArray(Ctx::GtxFlag[2 + chType](c)),
+                        gt2 = fb.getFracBitsArray(Ctx::GtxFlag[chType](c));
+      const int32_t par0 = (1 << SCALE_BITS) + int32_t(par.intBits[0]), par1 = (1 << SCALE_BITS) + int32_t(par.intBits[1]);
+      int32_t* o = rt->gtx[c];
+      o[0] = 0; o[1] = par0 + gt1.intBits[0]; o[2] = par1 + gt1.intBits[0];
+      o[3] = par0 + gt1.intBits[1] + gt2.intBits[0]; o[4] = par1 + gt1.intBits[1] + gt2.intBits[0];
+      o[5] = par0 + gt1.intBits[1] + gt2.intBits[1]; o[6] = par1 + gt1.intBits[1] + gt2.intBits[1];
+    }
+  }
+}
+
 // Dependent-quantisation trellis (next row N1): the reference's own DepQuant::quant (DepQuant.cpp:1411-1421 -> DQIntern::DepQuant::quant)
 // on a luma (comp 0) or Cb (comp 1) TransformUnit of an inter CU at depth 0, with a real CABAC context object initialised for
 // (ctxQp, initId).  The rate tables the reference derives inside (DQIntern::RateEstimator, private to DepQuant.cpp) are re-derived
@@ -878,48 +931,6 @@ extern "C" uint32_t vtmref_depquant(const TCoeff* coef, TCoeff* level, int w, in
   TCoeff absSum = 0;
   dq->quant(tu, compID, CCoeffBuf(coef, w, w, h), absSum, *q, *ctx);
   free(q);
-  if (rt)
-  {
-    const FracBitsAccess& fb = ctx->getFracBitsAcess();
-    memset(rt, 0, sizeof *rt);
-    // :379-426
-    int32_t cbfDelta;
-    if (compID == COMPONENT_Y) { const BinFracBits b = fb.getFracBitsArray(Ctx::QtRootCbf()); cbfDelta = int32_t(b.intBits[1]) - int32_t(b.intBits[0]); }
-    else { const BinFracBits b = fb.getFracBitsArray(Ctx::QtCbf[compID](DeriveCtx::CtxQtCbf(compID, tu.depth, tu.cbf[COMPONENT_Cb]))); cbfDelta = int32_t(b.intBits[1]) - int32_t(b.intBits[0]); }
-    static const unsigned prefixCtx[] = { 0, 0, 0, 3, 6, 10, 15, 21 };
-    for (unsigned xy = 0; xy < 2; xy++)
-    {
-      const int32_t bitOffset = xy ? cbfDelta : 0;
-      int32_t* lastBits = xy ? rt->last_y : rt->last_x;
-      const unsigned size = xy ? h : w, log2Size = g_aucNextLog2[size];
-      const CtxSet& set = (xy ? Ctx::LastY : Ctx::LastX)[chType];
-      const unsigned lastShift = compID == COMPONENT_Y ? (log2Size + 1) >> 2 : Clip3<unsigned>(0, 2, size >> 3);
-      const unsigned lastOffset = compID == COMPONENT_Y ? prefixCtx[log2Size] : 0;
-      uint32_t ctxBits[LAST_SIGNIFICANT_GROUPS], sum = 0;
-      const unsigned maxCtxId = g_uiGroupIdx[size - 1];
-      for (unsigned id = 0; id < maxCtxId; id++)
-      {
-        const BinFracBits b = fb.getFracBitsArray(set(lastOffset + (id >> lastShift)));
-        ctxBits[id] = sum + b.intBits[0] + (id > 3 ? ((id - 2) >> 1) << SCALE_BITS : 0) + bitOffset;
-        sum += b.intBits[1];
-      }
-      ctxBits[maxCtxId] = sum + (maxCtxId > 3 ? ((maxCtxId - 2) >> 1) << SCALE_BITS : 0) + bitOffset;
-      for (unsigned pos = 0; pos < size; pos++) lastBits[pos] = ctxBits[g_uiGroupIdx[pos]];
-    }
-    for (unsigned c = 0; c < 2; c++) { const BinFracBits b = fb.getFracBitsArray(Ctx::SigCoeffGroup[chType](c)); rt->sig_sbb[c][0] = b.intBits[0]; rt->sig_sbb[c][1] = b.intBits[1]; }
-    const unsigned numSig = compID == COMPONENT_Y ? 18 : 12, numGtx = compID == COMPONENT_Y ? 21 : 11;
-    for (unsigned s = 0; s < 3; s++)
-      for (unsigned c = 0; c < numSig; c++) { const BinFracBits b = fb.getFracBitsArray(Ctx::SigFlag[chType + 2 * s](c)); rt->sig[s][c][0] = b.intBits[0]; rt->sig[s][c][1] = b.intBits[1]; }
-    for (unsigned c = 0; c < numGtx; c++)
-    {
-      const BinFracBits par = fb.getFracBitsArray(Ctx::ParFlag[chType](c)), gt1 = fb.getFracBitsArray(Ctx::GtxFlag[2 + chType](c)),
-                        gt2 = fb.getFracBitsArray(Ctx::GtxFlag[chType](c));
-      const int32_t par0 = (1 << SCALE_BITS) + int32_t(par.intBits[0]), par1 = (1 << SCALE_BITS) + int32_t(par.intBits[1]);
-      int32_t* o = rt->gtx[c];
-      o[0] = 0; o[1] = par0 + gt1.intBits[0]; o[2] = par1 + gt1.intBits[0];
-      o[3] = par0 + gt1.intBits[1] + gt2.intBits[0]; o[4] = par1 + gt1.intBits[1] + gt2.intBits[0];
-      o[5] = par0 + gt1.intBits[1] + gt2.intBits[1]; o[6] = par1 + gt1.intBits[1] + gt2.intBits[1];
-    }
-  }
+  if (rt) vtmref_dq_rates_from_ctx(tu, compID, *ctx, rt);
   return (uint32_t)absSum;
 }

@@ -5,6 +5,7 @@ N1: vvcgpu_dequant_tr_inv_batch on one TU per 8x8 / 16x16 / 32x32 tile of the pi
     DepQuant::dequant + xITrMxN_EMT on one host core on a sample.
 N3: vvcgpu_affine_sobel_batch (both planes) + vvcgpu_affine_equal_coeff_batch on one PU per 16x16 / 64x64 tile, reference SIMD
     table slots on one core beside it."""
+import ctypes as C
 import os
 import sys
 import time
@@ -60,6 +61,35 @@ for B in (8, 16, 32):
             R.vtmref_inv_tr2d(bd, p(out), p(r16), B, B, B, int(d["tr_hor"][i]), int(d["tr_ver"][i]))
         dt = time.perf_counter() - t
         line += "  | reference DepQuant::dequant + xITrMxN_EMT 1 core %.2f us/TU -> x%.0f" % (dt / k * 1e6, (n / ms / 1e3) / (k / dt / 1e6))
+    print(line)
+
+
+# ---- N1: dependent-quantisation trellis, rate tables and coefficient statistics from the committed golden fixture
+g = np.load(os.path.join(ROOT, "tests", "golden", "depquant.npz"))
+rates = np.ascontiguousarray(g["rates"][:4]).view(ops.DQ_RATES)
+if R is not None:
+    R.vtmref_depquant.restype = C.c_uint32
+for B in (8, 16, 32):
+    n = (W // B) * (H // B)
+    yy, xx = np.mgrid[0:B, 0:B]
+    decay = np.exp(-(xx / B * 3 + yy / B * 3)).reshape(-1)
+    coef = (rng.normal(0, 1500, (n, B * B)) * decay).astype(np.int32).reshape(-1)
+    d = np.zeros(n, ops.DEPQUANT_DESC)
+    d["coeff_off"] = d["level_off"] = np.arange(n) * B * B
+    d["lambda"], d["qp"], d["rates_idx"], d["w"], d["h"], d["luma"] = 60.0, 44, rng.integers(0, 4, n), B, B, 1
+    dc, dd, dr = torch.from_numpy(coef).cuda(), ops.struct_to_device(d), ops.struct_to_device(rates)
+    level = torch.zeros(n * B * B, dtype=torch.int32, device="cuda")
+    ms = gpu_ms(lambda: ops.depquant_batch(dc, level, dd, n, dr, n * B * B, bd), reps=3)
+    nzf = float((level != 0).float().mean().cpu())
+    line = "N1 DepQuant trellis %2dx%-2d: %6d TUs %.3f ms  %.2f M TU/s  (%.0f%% non-zero levels)" % (B, B, n, ms, n / ms / 1e3, 100 * nzf)
+    if R is not None:
+        k = 1500
+        lv = np.zeros(B * B, np.int32)
+        t = time.perf_counter()
+        for i in range(k):
+            R.vtmref_depquant(p(coef[i * B * B:(i + 1) * B * B]), p(lv), B, B, 0, bd, 44, C.c_double(60.0), 32, 0, None)
+        dt = time.perf_counter() - t
+        line += "  | reference DepQuant::quant 1 core %.2f us/TU -> x%.0f" % (dt / k * 1e6, (n / ms / 1e3) / (k / dt / 1e6))
     print(line)
 
 pred = rng.integers(0, 1024, (H, W)).astype(np.int16)

@@ -856,14 +856,30 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   const bool luma = d.luma != 0;
   const TCoeff* coef = coeffBase + d.coeff_off;
   TCoeff* level = levelBase + d.level_off;
-  const vvcgpu_dq_rates* rt = ratesBase + d.rates_idx;
+  // The rate tables are looked up on the critical path of every step: up to eight distinct tables of a workgroup are staged in LDS
+  // (slot = index & 7, first come first served); a TU whose table did not get a slot reads it from global memory.  Generic
+  // pointers address either.
+  __shared__ vvcgpu_dq_rates rtCache[8];
+  __shared__ int rtSlot[8];
+  if (threadIdx.x < 8) rtSlot[threadIdx.x] = -1;
+  __syncthreads();
+  if (live && k == 0) atomicCAS(&rtSlot[d.rates_idx & 7], -1, d.rates_idx);
+  __syncthreads();
+  for (int sl = 0; sl < 8; sl++)
+    if (rtSlot[sl] >= 0)
+    {
+      const int* src = reinterpret_cast<const int*>(ratesBase + rtSlot[sl]);
+      int* dst = reinterpret_cast<int*>(&rtCache[sl]);
+      for (int i = threadIdx.x; i < (int)(sizeof(vvcgpu_dq_rates) / 4); i += 256) dst[i] = src[i];
+    }
+  __syncthreads();
+  const vvcgpu_dq_rates* rt = (live && rtSlot[d.rates_idx & 7] == d.rates_idx) ? &rtCache[d.rates_idx & 7] : ratesBase + d.rates_idx;
   const int tabOff = d_scanOff[(lw - 1) * 6 + (lh - 1)];
   const unsigned short* scan = d_scan + tabOff;
   const unsigned short* inv = d_dqInv + tabOff;
   const short* maxDist = d_dqMaxDist + tabOff;
   unsigned* dec = wsDec + (size_t)d.coeff_off * 4;                         // [scanIdx][4]
-  unsigned char* ctxMem = wsCtx + (size_t)(d.coeff_off >> 4) * 8 * 17;     // 8 x { sbbFlags[numSbb], levels[N] }
-  const int chunk = numSbb + N;
+  unsigned char* ctxMem = wsCtx + (size_t)d.coeff_off * 8;                  // 8 x levels[N]: CommonCtx's per-state sub-block memory (:828-858)
 
   // Quantizer::initQuantBlock :647-706 (the same IEEE double arithmetic)
   int qShift, maxQIdx, thresLast, distShift;
@@ -924,6 +940,9 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
 #pragma unroll
   for (int i = 0; i < 7; i++) startCb[i] = rt->gtx[0][i];
   int curCtx = 0;                                                         // which half of the sub-block memory is "current"
+  unsigned Fcur[8];                                                       // coded-sub-block flags (bit per sub-block) of context slot k, current half
+#pragma unroll
+  for (int i = 0; i < 8; i++) Fcur[i] = 0;
   long long finalCost = 0;
 
   for (int scanIdx = maxFirst; scanIdx >= 0; scanIdx--)
@@ -937,6 +956,21 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     const bool eocsbb = eosbb && sIdx > 0 && sIdx < N - 16;
     const int spt = socsbb ? 1 : (eocsbb ? 2 : 0);
     const int lastOffset = rt->last_x[px] + rt->last_y[py];
+    // state-independent data of the NEXT position (context offsets, its in-sub-block template neighbours :139-168): loaded here so that
+    // the table latency overlaps the cost arithmetic below
+    const int nxt = max(sIdx - 1, 0), npos = scan[nxt], nx = npos & (w - 1), ny = npos >> lw;
+    int nbRel[5];
+    {
+      const int cx[5] = { nx + 1, nx + 2, nx + 1, nx, nx }, cy[5] = { ny, ny, ny + 1, ny + 1, ny + 2 };
+      const int beg = nxt & ~15;
+#pragma unroll
+      for (int t = 0; t < 5; t++)
+      {
+        const bool in = cx[t] < w && cy[t] < h;
+        const int rel = in ? (int)inv[cy[t] * w + cx[t]] - beg : 0;
+        nbRel[t] = (rel > 0 && rel < 16) ? rel : 0;
+      }
+    }
 
     // Quantizer::preQuantCoeff :786-808
     long long pqDist[4]; int pqAbs[4];
@@ -1015,7 +1049,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     DqState C = P;                                                         // becomes the new previous state
     if (sIdx > 0)
     {
-      const int nxt = sIdx - 1, npos = scan[nxt], nx = npos & (w - 1), ny = npos >> lw, diag = nx + ny;
+      const int diag = nx + ny;
       const int sigOff = luma ? (diag < 2 ? 12 : diag < 5 ? 6 : 0) : (diag < 2 ? 6 : 0);
       const int gtxOff = luma ? (diag < 1 ? 16 : diag < 3 ? 11 : diag < 10 ? 6 : 1) : (diag < 1 ? 6 : 1);
       const int nextInside = nxt & 15;
@@ -1031,6 +1065,15 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
       if (dPrev >= 4) { sNum = S.numSigSbb; sRef = S.refSbbCtxId;
 #pragma unroll
         for (int i = 0; i < 4; i++) lv[i] = S.lev[i]; }
+      // sub-block flags of the inherited context slot: a register pull from the lane that owns the slot (slot id = lane in the quad);
+      // done by the whole quad (the branch below diverges inside a quad)
+      unsigned nf[8];
+      if (eosbb)
+      {
+        const int pr = dPrev >= 0 ? sRef : -1;
+#pragma unroll
+        for (int i = 0; i < 8; i++) { const unsigned v = (unsigned)__shfl((int)Fcur[i], qbase + max(pr, 0)); nf[i] = pr >= 0 ? v : 0u; }
+      }
       C.rdCost = dCost;
       if (dPrev > -2)
       {
@@ -1050,16 +1093,9 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
           dq_set_byte(C.lev, insidePos, (unsigned)min(255, dAbs));
           const unsigned tinit = dq_get_u16(C.cti, nextInside);
           sumAbs = (int)(tinit >> 8); sumAbs1 = (int)((tinit >> 3) & 31); sumNum = (int)(tinit & 7);
-          // in-sub-block template neighbours of the next position: right, right + 1, below-right, below, below + 1  (:139-168)
-          const int cx[5] = { nx + 1, nx + 2, nx + 1, nx, nx }, cy[5] = { ny, ny, ny + 1, ny + 1, ny + 2 };
-          const int beg = nxt & ~15;
 #pragma unroll
           for (int t = 0; t < 5; t++)
-            if (cx[t] < w && cy[t] < h)
-            {
-              const int rel = (int)inv[cy[t] * w + cx[t]] - beg;
-              if (rel > 0 && rel < 16) { const int v = (int)dq_get_byte(C.lev, rel); sumAbs += v; sumAbs1 += min(4 - (v & 1), v); sumNum += v != 0; }
-            }
+            if (nbRel[t]) { const int v = (int)dq_get_byte(C.lev, nbRel[t]); sumAbs += v; sumAbs1 += min(4 - (v & 1), v); sumNum += v != 0; }
         }
         else                                                               // State::updateStateEOS :1071-1102 + CommonCtx::update :1104-1164
         {
@@ -1072,32 +1108,35 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
           dq_set_byte(C.lev, insidePos, (unsigned)min(255, dAbs));
           const int prevRef = dPrev >= 0 ? sRef : -1;
           const int newCur = curCtx ^ 1;                                    // CommonCtx::swap before the four updates
-          unsigned char* flags = ctxMem + (size_t)(newCur * 4 + k) * chunk;
-          unsigned char* lev = flags + numSbb;
+          unsigned char* lev = ctxMem + (size_t)(newCur * 4 + k) * N;
           const int setCp = maxDist[sIdx - 1];
           if (act)
           {
             if (prevRef >= 0)
             {
-              const unsigned char* pf = ctxMem + (size_t)(curCtx * 4 + prevRef) * chunk;
-              const unsigned char* pl = pf + numSbb;
-              for (int i = 0; i < numSbb; i++) flags[i] = pf[i];
-              for (int i = 0; i < setCp; i++) lev[sIdx + i] = pl[sIdx + i];
+              const unsigned char* pl = ctxMem + (size_t)(curCtx * 4 + prevRef) * N;
+              for (int i = 0; i < setCp; i += 16) *reinterpret_cast<uint4*>(lev + sIdx + i) = *reinterpret_cast<const uint4*>(pl + sIdx + i);
             }
             else
-            {
-              for (int i = 0; i < numSbb; i++) flags[i] = 0;
-              for (int i = 0; i < setCp; i++) lev[sIdx + i] = 0;
-            }
+              for (int i = 0; i < setCp; i += 16) *reinterpret_cast<uint4*>(lev + sIdx + i) = make_uint4(0, 0, 0, 0);
+            *reinterpret_cast<uint4*>(lev + sIdx) = make_uint4(C.lev[0], C.lev[1], C.lev[2], C.lev[3]);     // sIdx is a multiple of 16
+          }
+          {
             const int sbbPos = (py >> 2) * widthInSbb + (px >> 2);
-            flags[sbbPos] = C.numSigSbb != 0;
 #pragma unroll
-            for (int i = 0; i < 4; i++) *reinterpret_cast<unsigned*>(lev + sIdx + 4 * i) = C.lev[i];     // sIdx is a multiple of 16
+            for (int i = 0; i < 8; i++) if (i == (sbbPos >> 5)) nf[i] = (nf[i] & ~(1u << (sbbPos & 31))) | ((C.numSigSbb != 0 ? 1u : 0u) << (sbbPos & 31));
           }
           const int nsx = nx >> 2, nsy = ny >> 2, nsp = nsy * widthInSbb + nsx;
           const int right = nsx < widthInSbb - 1 ? nsp + 1 : 0, below = nsy < heightInSbb - 1 ? nsp + widthInSbb : 0;
-          int sigNSbb = 0;
-          if (act) sigNSbb = ((right ? flags[right] : 0) || (below ? flags[below] : 0)) ? 1 : 0;
+          unsigned fr = nf[0], fb = nf[0];
+#pragma unroll
+          for (int i = 1; i < 8; i++) { fr = (right >> 5) == i ? nf[i] : fr; fb = (below >> 5) == i ? nf[i] : fb; }
+          const int sigNSbb = ((right && ((fr >> (right & 31)) & 1u)) || (below && ((fb >> (below & 31)) & 1u))) ? 1 : 0;
+          if (act)
+          {
+#pragma unroll
+            for (int i = 0; i < 8; i++) Fcur[i] = nf[i];
+          }
           C.numSigSbb = 0; C.refSbbCtxId = k;
           C.sbb0 = rt->sig_sbb[sigNSbb][0]; C.sbb1 = rt->sig_sbb[sigNSbb][1];
           // template seeds of the sixteen positions of the next sub-block from the levels outside it (:1131-1160)
@@ -1332,7 +1371,7 @@ size_t vvcgpu_depquant_workspace_bytes(size_t total_coeffs, int n)
 {
   (void)n;
   const size_t c = (total_coeffs + 15) & ~(size_t)15;
-  return c * 16 + (c / 16) * 8 * 17 + 256;                 // decisions (4 x u32 per position) + 8 x { sbbFlags, levels } per TU
+  return c * 16 + c * 8 + 256;                             // decisions (4 x u32 per position) + 8 level histories per TU
 }
 
 int vvcgpu_depquant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const vvcgpu_depquant_desc* descs, int n,
@@ -1346,7 +1385,7 @@ int vvcgpu_depquant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, cons
   const int rt = ensure_tables();
   if (rt) return rt;
   // the workspace is split as vvcgpu_depquant_workspace_bytes lays it out: c * 16 bytes of decisions, then the context memory
-  const size_t c = ((ws_bytes - 256) * 16 / (16 * 16 + 8 * 17)) & ~(size_t)15;
+  const size_t c = ((ws_bytes - 256) / 24) & ~(size_t)15;
   unsigned* dec = static_cast<unsigned*>(ws);
   unsigned char* ctx = static_cast<unsigned char*>(ws) + c * 16;
   hipLaunchKernelGGL(depquant_kernel, dim3(cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, coeff_base, level_base, descs, n, rates, bit_depth,

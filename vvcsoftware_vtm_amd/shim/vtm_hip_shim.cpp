@@ -78,6 +78,11 @@ void real_initIntraPatternChType(IntraPrediction*, const CodingUnit&, const Comp
   asm("__real__ZN15IntraPrediction22initIntraPatternChTypeERK10CodingUnitRK8CompAreab");
 void wrap_initIntraPatternChType(IntraPrediction*, const CodingUnit&, const CompArea&, const bool)
   asm("__wrap__ZN15IntraPrediction22initIntraPatternChTypeERK10CodingUnitRK8CompAreab");
+// DepQuant::quant is virtual: it is reached through the vtable (a dynamic relocation against the symbol), so it is pre-empted by
+// oracle/ref_hooks.cpp like the statistics entry points, not by ld --wrap
+extern "C" int vvcshim_depquant(DepQuant* self, TransformUnit* tu, const ComponentID* compID, const CCoeffBuf* pSrc, TCoeff* uiAbsSum, const QpParam* cQP,
+                                const Ctx* ctx);
+void vtmref_dq_rates_from_ctx(const TransformUnit& tu, ComponentID compID, const Ctx& ctx, vvcgpu_dq_rates* rt);   // oracle/ref_wrap_kernels.h
 void real_extendPicBorder(Picture*) asm("__real__ZN7Picture15extendPicBorderEv");
 void wrap_extendPicBorder(Picture*) asm("__wrap__ZN7Picture15extendPicBorderEv");
 
@@ -96,11 +101,11 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[26] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+long g_calls[27] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
-                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld, IntraPred %ld, Border %ld, Hash %ld, CCLM %ld, IntraRefs %ld\n",
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld, IntraPred %ld, Border %ld, Hash %ld, CCLM %ld, IntraRefs %ld, DepQuant %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
-                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20], g_calls[21], g_calls[22], g_calls[23], g_calls[24], g_calls[25]); } } g_report;
+                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20], g_calls[21], g_calls[22], g_calls[23], g_calls[24], g_calls[25], g_calls[26]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -1286,6 +1291,62 @@ void wrap_initIntraPatternChType(IntraPrediction* self, const CodingUnit& cu, co
   for (int y = 1; y <= L; y++) unf[(size_t)y * stride] = refs[T + y];
   if (bFilterRefSamples) self->xFilterReferenceSamples(unf, self->m_piYuvExt[area.compID][PRED_BUF_FILTERED], area, *cs.sps);
   g_calls[25]++;
+}
+
+// ---- DepQuant::quant (DepQuant.cpp:1411-1421): the dependent-quantisation trellis of one TU = vvcgpu_depquant_batch with one
+// descriptor (next row N1).  The rate tables are derived from the call's own CABAC context object (vtmref_dq_rates_from_ctx, the
+// reference's RateEstimator re-expressed with Ctx's public access).  An encoder quantises every rate-distortion candidate: the
+// first VVCGPU_SHIM_DEPQUANT_LIMIT calls (default 20000, 0 = all) are served; VVCGPU_SHIM_DEPQUANT_VERIFY=1 A/B-checks each one.
+namespace {
+DevArray<vvc_coef> g_dqCoef, g_dqLevel;
+DevArray<vvcgpu_depquant_desc> g_dqDesc;
+DevArray<vvcgpu_dq_rates> g_dqRates;
+DevArray<uint32_t> g_dqSum;
+DevArray<uint8_t> g_dqWs;
+}
+
+extern "C" int vvcshim_depquant(DepQuant* self, TransformUnit* tuP, const ComponentID* compIDP, const CCoeffBuf* pSrcP, TCoeff* uiAbsSumP, const QpParam* cQPP,
+                                const Ctx* ctxP)
+{
+  TransformUnit& tu = *tuP; const ComponentID& compID = *compIDP; const CCoeffBuf& pSrc = *pSrcP; TCoeff& uiAbsSum = *uiAbsSumP;
+  const QpParam& cQP = *cQPP; const Ctx& ctx = *ctxP;
+  const CompArea& area = tu.blocks[compID];
+  const int w = area.width, h = area.height, n = w * h;
+  const int bd = tu.cs->sps->getBitDepth(toChannelType(compID));
+  static const long limit = getenv("VVCGPU_SHIM_DEPQUANT_LIMIT") ? atol(getenv("VVCGPU_SHIM_DEPQUANT_LIMIT")) : 20000;
+  const bool ok = shimEnabled() && !getenv("VVCGPU_SHIM_NO_TABLES") && tu.cs->slice->getDepQuantEnabledFlag() && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
+                  !(w & (w - 1)) && !(h & (h - 1)) && bd >= 8 && bd <= 10 && (int)pSrc.stride == w && !(limit > 0 && g_calls[26] >= limit) &&
+                  !tu.cs->sps->getSpsRangeExtension().getExtendedPrecisionProcessingFlag();
+  if (!ok) return 0;
+  vvcgpu_dq_rates rt;
+  vtmref_dq_rates_from_ctx(tu, compID, ctx, &rt);
+  vvcgpu_depquant_desc d;
+  memset(&d, 0, sizeof d);
+  d.lambda = self->getLambda(); d.qp = cQP.Qp; d.w = (int16_t)w; d.h = (int16_t)h; d.luma = compID == COMPONENT_Y;
+  g_dqCoef.upload(pSrc.buf, n); g_dqLevel.reserve(n); g_dqDesc.upload(&d, 1); g_dqRates.upload(&rt, 1); g_dqSum.reserve(1);
+  const size_t wsBytes = vvcgpu_depquant_workspace_bytes((size_t)n, 1);
+  g_dqWs.reserve(wsBytes + 16);
+  VVCGPU(vvcgpu_depquant_batch(g_dqCoef.ptr, g_dqLevel.ptr, g_dqDesc.ptr, 1, g_dqRates.ptr, bd, g_dqSum.ptr, g_dqWs.ptr, wsBytes, nullptr));
+  std::vector<TCoeff> lv(n);
+  uint32_t sum = 0;
+  VVCGPU(vvcgpu_memcpy_d2h(lv.data(), g_dqLevel.ptr, (size_t)n * sizeof(TCoeff), nullptr));
+  VVCGPU(vvcgpu_memcpy_d2h(&sum, g_dqSum.ptr, sizeof sum, nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  CoeffBuf dst = tu.getCoeffs(compID);
+  if (getenv("VVCGPU_SHIM_DEPQUANT_VERIFY"))
+  {
+    TCoeff refSum = 0;
+    typedef void (*real_t)(DepQuant*, TransformUnit*, const ComponentID*, const CCoeffBuf*, TCoeff*, const QpParam*, const Ctx*);
+    static real_t real = (real_t)dlsym(RTLD_DEFAULT, "vtmhooks_real_depquant");
+    if (real) real(self, &tu, &compID, &pSrc, &refSum, &cQP, &ctx);
+    bool same = (uint32_t)refSum == sum;
+    for (int y = 0; y < h && same; y++) same = memcmp(dst.buf + (size_t)y * dst.stride, &lv[(size_t)y * w], w * sizeof(TCoeff)) == 0;
+    if (!same) fprintf(stderr, "[vvcgpu shim] DepQuant mismatch: %dx%d comp %d qp %d lambda %f sum %u vs %d\n", w, h, (int)compID, cQP.Qp, d.lambda, sum, (int)refSum);
+  }
+  for (int y = 0; y < h; y++) memcpy(dst.buf + (size_t)y * dst.stride, &lv[(size_t)y * w], w * sizeof(TCoeff));
+  uiAbsSum = (TCoeff)sum;
+  g_calls[26]++;
+  return 1;
 }
 
 // ---- Picture::extendPicBorder (Picture.cpp:996-1041): the padded reconstruction planes go to the device, every margin is
