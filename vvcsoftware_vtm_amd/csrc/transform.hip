@@ -794,30 +794,44 @@ __global__ __launch_bounds__(256) void quant_kernel(const TCoeff* __restrict__ c
 __device__ unsigned short d_dqInv[15876];           // raster position -> scan id, same layout as d_scan
 __device__ short d_dqMaxDist[15876];                // NbInfoOut::maxDist (relative) per scan id  (:205-228)
 
+// Small per-lane tables are ext-vector VALUES, not arrays: element selects then stay register selects (with arrays LLVM rewrites a
+// select of loads into a load through a selected address, which pins the whole state struct in scratch memory).
+typedef unsigned dq_u4 __attribute__((ext_vector_type(4)));
+typedef unsigned dq_u8 __attribute__((ext_vector_type(8)));
+typedef int dq_i8 __attribute__((ext_vector_type(8)));
+typedef long long dq_l4 __attribute__((ext_vector_type(4)));
+typedef int dq_i4 __attribute__((ext_vector_type(4)));
+
 struct DqState
 {
   long long rdCost;
-  unsigned lev[4];                    // 16 abs levels of the current sub-block (bytes)
-  unsigned cti[8];                    // 16 template-context seeds (u16): sumNum | sumAbs1 << 3 | min(127, sumAbs) << 8
+  dq_u4 lev;                          // 16 abs levels of the current sub-block (bytes)
+  dq_u8 cti;                          // 16 template-context seeds (u16): sumNum | sumAbs1 << 3 | min(127, sumAbs) << 8
   int numSigSbb, refSbbCtxId;
   int sbb0, sbb1, sig0, sig1;
-  int cb[7];
+  dq_i8 cb;                           // coefficient bit sums [0..6]
   int goRice;
 };
 
-__device__ __forceinline__ unsigned dq_get_byte(const unsigned (&a)[4], int j)
+// member-wise copy: a whole-struct assignment also copies the padding through scratch memory
+__device__ __forceinline__ void dq_copy(DqState& d, const DqState& s)
+{
+  d.rdCost = s.rdCost; d.lev = s.lev; d.cti = s.cti; d.numSigSbb = s.numSigSbb; d.refSbbCtxId = s.refSbbCtxId;
+  d.sbb0 = s.sbb0; d.sbb1 = s.sbb1; d.sig0 = s.sig0; d.sig1 = s.sig1; d.cb = s.cb; d.goRice = s.goRice;
+}
+__device__ __forceinline__ unsigned dq_get_byte(const dq_u4 a, int j)
 {
   const int d = j >> 2;
   const unsigned v = d == 0 ? a[0] : d == 1 ? a[1] : d == 2 ? a[2] : a[3];
   return (v >> ((j & 3) * 8)) & 0xFFu;
 }
-__device__ __forceinline__ void dq_set_byte(unsigned (&a)[4], int j, unsigned val)
+__device__ __forceinline__ void dq_set_byte(dq_u4& a, int j, unsigned val)
 {
   const int d = j >> 2, sh = (j & 3) * 8;
 #pragma unroll
-  for (int i = 0; i < 4; i++) if (i == d) a[i] = (a[i] & ~(0xFFu << sh)) | (val << sh);
+  for (int i = 0; i < 4; i++) { const unsigned m = i == d ? 0xFFu << sh : 0u; a[i] = (a[i] & ~m) | ((val << sh) & m); }   // no conditional store: keeps the array in registers
 }
-__device__ __forceinline__ unsigned dq_get_u16(const unsigned (&c)[8], int j)
+__device__ __forceinline__ unsigned dq_get_u16(const dq_u8 c, int j)
 {
   const int d = j >> 1;
   unsigned v = c[0];
@@ -825,7 +839,7 @@ __device__ __forceinline__ unsigned dq_get_u16(const unsigned (&c)[8], int j)
   for (int i = 1; i < 8; i++) v = d == i ? c[i] : v;
   return (v >> ((j & 1) * 16)) & 0xFFFFu;
 }
-__device__ __forceinline__ int dq_level_bits(const int (&cb)[7], int goRice, unsigned level)       // State::getLevelBits :909-931
+__device__ __forceinline__ int dq_level_bits(const dq_i8 cb, int goRice, unsigned level)       // State::getLevelBits :909-931
 {
   const unsigned idx = level < 5 ? level : 5 + ((level - 5) & 1);
   int bits = cb[0];
@@ -928,54 +942,64 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   {
     P.rdCost = 0x7FFFFFFFFFFFFFFFll >> 1; P.numSigSbb = 0; P.refSbbCtxId = -1; P.goRice = 0; P.sbb0 = P.sbb1 = 0;
     P.sig0 = rt->sig[sigSet][0][0]; P.sig1 = rt->sig[sigSet][0][1];
+    P.lev = dq_u4{ 0, 0, 0, 0 }; P.cti = dq_u8{ 0, 0, 0, 0, 0, 0, 0, 0 }; P.cb = dq_i8{ 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
     for (int i = 0; i < 7; i++) P.cb[i] = rt->gtx[0][i];
-#pragma unroll
-    for (int i = 0; i < 4; i++) P.lev[i] = 0;
-#pragma unroll
-    for (int i = 0; i < 8; i++) P.cti[i] = 0;
-    S = P;
+    dq_copy(S, P);
   }
-  int startCb[7];
+  dq_i8 startCb = { 0, 0, 0, 0, 0, 0, 0, 0 };
 #pragma unroll
   for (int i = 0; i < 7; i++) startCb[i] = rt->gtx[0][i];
   int curCtx = 0;                                                         // which half of the sub-block memory is "current"
-  unsigned Fcur[8];                                                       // coded-sub-block flags (bit per sub-block) of context slot k, current half
+  dq_u8 Fcur;                                                             // coded-sub-block flags (bit per sub-block) of context slot k, current half
 #pragma unroll
   for (int i = 0; i < 8; i++) Fcur[i] = 0;
   long long finalCost = 0;
 
+  // State-independent per-position data is fetched ONE STEP AHEAD (scan position, |coefficient|, the in-sub-block template neighbours
+  // of the position after it :139-168), so that no table or coefficient load sits on the serial chain of a step.
+  auto clampIdx = [&](int si) { return min(max(si, 0), N - 1); };
+  auto templateRels = [&](int si, dq_i8& rel)                  // in-sub-block neighbour positions (1..15, 0 = none) of scan position si
+  {
+    const int p2 = scan[si], x2 = p2 & (w - 1), y2 = p2 >> lw, beg = si & ~15;
+    const int cx[5] = { x2 + 1, x2 + 2, x2 + 1, x2, x2 }, cy[5] = { y2, y2, y2 + 1, y2 + 1, y2 + 2 };
+#pragma unroll
+    for (int t = 0; t < 5; t++)
+    {
+      const bool in = cx[t] < w && cy[t] < h;
+      const int r = in ? (int)inv[cy[t] * w + cx[t]] - beg : 0;
+      rel[t] = (r > 0 && r < 16) ? r : 0;
+    }
+  };
+  int curPos = scan[clampIdx(maxFirst)], curAbs = abs(coef[curPos]);
+  int nxtPos = scan[clampIdx(maxFirst - 1)];
+  dq_i8 nbRel = { 0, 0, 0, 0, 0, 0, 0, 0 };
+  templateRels(clampIdx(maxFirst - 1), nbRel);
+
   for (int scanIdx = maxFirst; scanIdx >= 0; scanIdx--)
   {
     const bool act = live && scanIdx <= first;                            // quad-uniform
-    const int sIdx = act ? scanIdx : 0;
-    const int pos = scan[sIdx], px = pos & (w - 1), py = pos >> lw;
+    const int sIdx = clampIdx(scanIdx);                                   // inactive quads compute on valid indices and discard
+    const int pos = curPos, px = pos & (w - 1), py = pos >> lw;
     const int insidePos = sIdx & 15;
     const bool eosbb = insidePos == 0, sosbb = insidePos == 15;
     const bool socsbb = sosbb && sIdx > 16 && sIdx < N - 1;
     const bool eocsbb = eosbb && sIdx > 0 && sIdx < N - 16;
     const int spt = socsbb ? 1 : (eocsbb ? 2 : 0);
     const int lastOffset = rt->last_x[px] + rt->last_y[py];
-    // state-independent data of the NEXT position (context offsets, its in-sub-block template neighbours :139-168): loaded here so that
-    // the table latency overlaps the cost arithmetic below
-    const int nxt = max(sIdx - 1, 0), npos = scan[nxt], nx = npos & (w - 1), ny = npos >> lw;
-    int nbRel[5];
-    {
-      const int cx[5] = { nx + 1, nx + 2, nx + 1, nx, nx }, cy[5] = { ny, ny, ny + 1, ny + 1, ny + 2 };
-      const int beg = nxt & ~15;
-#pragma unroll
-      for (int t = 0; t < 5; t++)
-      {
-        const bool in = cx[t] < w && cy[t] < h;
-        const int rel = in ? (int)inv[cy[t] * w + cx[t]] - beg : 0;
-        nbRel[t] = (rel > 0 && rel < 16) ? rel : 0;
-      }
-    }
+    const int nxt = max(sIdx - 1, 0), nx = nxtPos & (w - 1), ny = nxtPos >> lw;
+    const int coefAbs = curAbs;
+    // prefetch for the next step
+    const int pfAbs = abs(coef[nxtPos]);
+    const int pfIdx = clampIdx(scanIdx - 2);
+    const int pfPos = scan[pfIdx];
+    dq_i8 pfRel = { 0, 0, 0, 0, 0, 0, 0, 0 };
+    templateRels(pfIdx, pfRel);
 
     // Quantizer::preQuantCoeff :786-808
-    long long pqDist[4]; int pqAbs[4];
+    dq_l4 pqDist = { 0, 0, 0, 0 }; dq_i4 pqAbs = { 0, 0, 0, 0 };
     {
-      const long long scaledOrg = (long long)abs(coef[pos]) * qScale;
+      const long long scaledOrg = (long long)coefAbs * qScale;
       int qIdx = max(1, min(maxQIdx, (int)((scaledOrg + qAdd) >> qShift)));
       long long scaledAdd = qIdx * distStepAdd - scaledOrg * distOrgFact;
 #pragma unroll
@@ -985,7 +1009,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
         const long long dd = (scaledAdd * qIdx + distAdd) >> distShift;
         const int al = (++qIdx) >> 1;
 #pragma unroll
-        for (int t = 0; t < 4; t++) if (t == slot) { pqDist[t] = dd; pqAbs[t] = al; }
+        for (int t = 0; t < 4; t++) { pqDist[t] = t == slot ? dd : pqDist[t]; pqAbs[t] = t == slot ? al : pqAbs[t]; }
         scaledAdd += distStepAdd;
       }
     }
@@ -1043,10 +1067,10 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
       }
     }
     if (act) dec[(size_t)sIdx * 4 + k] = ((unsigned)max(dAbs, 0) << 4) | (unsigned)(dPrev + 2);
-    if (sIdx == 0) finalCost = dCost;
+    if (scanIdx == 0) finalCost = dCost;
 
     // ---- state update (:1259-1318); every lane pulls its winner's context from the source lane
-    DqState C = P;                                                         // becomes the new previous state
+    DqState C; dq_copy(C, P);                                              // becomes the new previous state
     if (sIdx > 0)
     {
       const int diag = nx + ny;
@@ -1055,7 +1079,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
       const int nextInside = nxt & 15;
       // source of the copied context: lane dPrev (0..3), own skip state (4 + k) or nothing
       const int srcLane = qbase + (dPrev >= 0 && dPrev < 4 ? dPrev : k);
-      unsigned lv[4], ct[8]; int sNum, sRef, sSbb0, sSbb1;
+      dq_u4 lv = { 0, 0, 0, 0 }; dq_u8 ct = { 0, 0, 0, 0, 0, 0, 0, 0 }; int sNum, sRef, sSbb0, sSbb1;
 #pragma unroll
       for (int i = 0; i < 4; i++) lv[i] = (unsigned)__shfl((int)P.lev[i], srcLane);
 #pragma unroll
@@ -1067,7 +1091,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
         for (int i = 0; i < 4; i++) lv[i] = S.lev[i]; }
       // sub-block flags of the inherited context slot: a register pull from the lane that owns the slot (slot id = lane in the quad);
       // done by the whole quad (the branch below diverges inside a quad)
-      unsigned nf[8];
+      dq_u8 nf = { 0, 0, 0, 0, 0, 0, 0, 0 };
       if (eosbb)
       {
         const int pr = dPrev >= 0 ? sRef : -1;
@@ -1124,7 +1148,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
           {
             const int sbbPos = (py >> 2) * widthInSbb + (px >> 2);
 #pragma unroll
-            for (int i = 0; i < 8; i++) if (i == (sbbPos >> 5)) nf[i] = (nf[i] & ~(1u << (sbbPos & 31))) | ((C.numSigSbb != 0 ? 1u : 0u) << (sbbPos & 31));
+            for (int i = 0; i < 8; i++) { const unsigned m = i == (sbbPos >> 5) ? 1u << (sbbPos & 31) : 0u; nf[i] = (nf[i] & ~m) | (C.numSigSbb != 0 ? m : 0u); }
           }
           const int nsx = nx >> 2, nsy = ny >> 2, nsp = nsy * widthInSbb + nsx;
           const int right = nsx < widthInSbb - 1 ? nsp + 1 : 0, below = nsy < heightInSbb - 1 ? nsp + widthInSbb : 0;
@@ -1144,6 +1168,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
 #pragma unroll
           for (int i = 0; i < 8; i++) C.cti[i] = 0;
           if (act)
+#pragma unroll
             for (int i = 0; i < 16; i++)
             {
               const int p2 = scan[scanBeg + i], x2 = p2 & (w - 1), y2 = p2 >> lw;
@@ -1158,7 +1183,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
                 }
               const unsigned seed = (unsigned)(sN + (sA1 << 3) + (min(127, sA) << 8));
 #pragma unroll
-              for (int j = 0; j < 8; j++) if (j == (i >> 1)) C.cti[j] |= seed << ((i & 1) * 16);
+              for (int j = 0; j < 8; j++) C.cti[j] |= j == (i >> 1) ? seed << ((i & 1) * 16) : 0u;
             }
 #pragma unroll
           for (int i = 0; i < 4; i++) C.lev[i] = 0;
@@ -1179,9 +1204,10 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     if (act)
     {
       if (sIdx > 0 && eosbb) curCtx ^= 1;
-      if (socsbb) S = P;                                                   // swap( m_prevStates, m_skipStates ) :1314-1317
-      P = C;
+      if (socsbb) dq_copy(S, P);                                           // swap( m_prevStates, m_skipStates ) :1314-1317
+      dq_copy(P, C);
     }
+    curPos = nxtPos; curAbs = pfAbs; nxtPos = pfPos; nbRel = pfRel;
   }
 
   // ---- best final state and back-trace :1368-1390.  Lane 0 of the quad walks; decisions 4..7 are implicit: at a sub-block end they
