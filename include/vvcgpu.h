@@ -463,9 +463,10 @@ int vvcgpu_quant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const v
  * significance bits of the three state-dependent context sets, and the greater-than / parity bit sums -- in 2^-15 bit units
  * (SCALE_BITS); the caller fills one vvcgpu_dq_rates per (component, TU width x height class) and points TUs at it.
  * luma != 0 selects the luma template context offsets (:566-577).  lambda = Quant::m_dLambda of the component.
- * level_out receives the signed levels (row pitch w), abs_sum[i] the sum of absolute levels.  ws: device workspace of
- * vvcgpu_depquant_workspace_bytes(total coefficient count of the batch) bytes (trellis decisions and the per-state context
- * memory of every TU).                                                                                                   */
+ * level_out receives the signed levels (row pitch w), abs_sum[i] the sum of absolute levels.  total_coeffs: extent of the
+ * coefficient buffer the descriptors address (coeff_off + w * h <= total_coeffs, coeff_off a multiple of 16, blocks disjoint);
+ * ws: device workspace of vvcgpu_depquant_workspace_bytes(total_coeffs, n) bytes, 16-byte aligned (trellis decisions and the
+ * per-state level histories, both indexed by coeff_off).                                                                                                */
 typedef struct vvcgpu_dq_rates {
   int32_t last_x[64], last_y[64];       /* m_lastBitsX / m_lastBitsY                                     */
   int32_t sig_sbb[2][2];                /* m_sigSbbFracBits[ctx].intBits[bin]                            */
@@ -483,7 +484,8 @@ typedef struct vvcgpu_depquant_desc {
 } vvcgpu_depquant_desc;
 size_t vvcgpu_depquant_workspace_bytes(size_t total_coeffs, int n);
 int vvcgpu_depquant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const vvcgpu_depquant_desc* descs, int n,
-                          const vvcgpu_dq_rates* rates, int bit_depth, uint32_t* abs_sum, void* ws, size_t ws_bytes, void* stream);
+                          const vvcgpu_dq_rates* rates, int bit_depth, uint32_t* abs_sum, size_t total_coeffs, void* ws, size_t ws_bytes,
+                          void* stream);
 
 /* The shipped matrix [type][log2(N)-1] as N x N int16 (host copy; for the shim's table check against initROM()). */
 const int16_t* vvcgpu_tr_matrix_host(int type, int n);

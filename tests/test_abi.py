@@ -72,7 +72,7 @@ def test_next_row_entry_points_validate_arguments_without_a_device():
         "vvcgpu_imv_refine_batch": lambda n: lib.vvcgpu_imv_refine_batch(nul, 8, nul, 8, nul, n, nul, 1, C.c_double(1.0), nul, nul),
         "vvcgpu_dequant_tr_inv_batch": lambda n: lib.vvcgpu_dequant_tr_inv_batch(nul, nul, nul, n, 10, nul, nul),
         "vvcgpu_quant_batch": lambda n: lib.vvcgpu_quant_batch(nul, nul, nul, n, 10, nul, nul),
-        "vvcgpu_depquant_batch": lambda n: lib.vvcgpu_depquant_batch(nul, nul, nul, n, nul, 10, nul, nul, C.c_size_t(0), nul),
+        "vvcgpu_depquant_batch": lambda n: lib.vvcgpu_depquant_batch(nul, nul, nul, n, nul, 10, nul, C.c_size_t(0), nul, C.c_size_t(0), nul),
         "vvcgpu_affine_sobel_batch": lambda n: lib.vvcgpu_affine_sobel_batch(0, nul, nul, nul, n, nul),
         "vvcgpu_affine_equal_coeff_batch": lambda n: lib.vvcgpu_affine_equal_coeff_batch(nul, nul, nul, nul, n, nul, nul),
         "vvcgpu_intra_pred_batch": lambda n: lib.vvcgpu_intra_pred_batch(nul, nul, nul, n, 0, 1023, nul),

@@ -1401,17 +1401,20 @@ size_t vvcgpu_depquant_workspace_bytes(size_t total_coeffs, int n)
 }
 
 int vvcgpu_depquant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const vvcgpu_depquant_desc* descs, int n,
-                          const vvcgpu_dq_rates* rates, int bit_depth, uint32_t* abs_sum, void* ws, size_t ws_bytes, void* stream)
+                          const vvcgpu_dq_rates* rates, int bit_depth, uint32_t* abs_sum, size_t total_coeffs, void* ws, size_t ws_bytes,
+                          void* stream)
 {
   VVC_CHECK_ARG(n >= 0, "depquant_batch: n %d", n);
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(coeff_base && level_base && descs && rates && abs_sum && ws, "depquant_batch: null pointer");
   VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "depquant_batch: bit depth %d outside 8..10", bit_depth);
-  VVC_CHECK_ARG(ws_bytes >= 512 && (reinterpret_cast<uintptr_t>(ws) & 15) == 0, "depquant_batch: workspace too small or unaligned");
+  VVC_CHECK_ARG(total_coeffs >= 16 && ws_bytes >= vvcgpu_depquant_workspace_bytes(total_coeffs, n) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+                "depquant_batch: workspace of %zu bytes for %zu coefficients is too small (need %zu) or unaligned", ws_bytes, total_coeffs,
+                vvcgpu_depquant_workspace_bytes(total_coeffs, n));
   const int rt = ensure_tables();
   if (rt) return rt;
-  // the workspace is split as vvcgpu_depquant_workspace_bytes lays it out: c * 16 bytes of decisions, then the context memory
-  const size_t c = ((ws_bytes - 256) / 24) & ~(size_t)15;
+  // the workspace is split as vvcgpu_depquant_workspace_bytes lays it out: c * 16 bytes of decisions, then the level histories
+  const size_t c = (total_coeffs + 15) & ~(size_t)15;
   unsigned* dec = static_cast<unsigned*>(ws);
   unsigned char* ctx = static_cast<unsigned char*>(ws) + c * 16;
   hipLaunchKernelGGL(depquant_kernel, dim3(cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, coeff_base, level_base, descs, n, rates, bit_depth,

@@ -307,7 +307,7 @@ def depquant_batch(coeff_base, level_base, descs_dev, n, rates_dev, total_coeffs
     ws = torch.empty(nbytes, dtype=torch.uint8, device=coeff_base.device)
     out = torch.zeros(n, dtype=torch.int32, device=coeff_base.device)
     capi.call("vvcgpu_depquant_batch", capi.ptr(coeff_base), capi.ptr(level_base), capi.ptr(descs_dev), n, capi.ptr(rates_dev), bit_depth,
-              capi.ptr(out), capi.ptr(ws), C.c_size_t(nbytes), _stream())
+              capi.ptr(out), C.c_size_t(total_coeffs), capi.ptr(ws), C.c_size_t(nbytes), _stream())
     return out
 
 

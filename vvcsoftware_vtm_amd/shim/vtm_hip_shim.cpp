@@ -1326,7 +1326,7 @@ extern "C" int vvcshim_depquant(DepQuant* self, TransformUnit* tuP, const Compon
   g_dqCoef.upload(pSrc.buf, n); g_dqLevel.reserve(n); g_dqDesc.upload(&d, 1); g_dqRates.upload(&rt, 1); g_dqSum.reserve(1);
   const size_t wsBytes = vvcgpu_depquant_workspace_bytes((size_t)n, 1);
   g_dqWs.reserve(wsBytes + 16);
-  VVCGPU(vvcgpu_depquant_batch(g_dqCoef.ptr, g_dqLevel.ptr, g_dqDesc.ptr, 1, g_dqRates.ptr, bd, g_dqSum.ptr, g_dqWs.ptr, wsBytes, nullptr));
+  VVCGPU(vvcgpu_depquant_batch(g_dqCoef.ptr, g_dqLevel.ptr, g_dqDesc.ptr, 1, g_dqRates.ptr, bd, g_dqSum.ptr, (size_t)n, g_dqWs.ptr, wsBytes, nullptr));
   std::vector<TCoeff> lv(n);
   uint32_t sum = 0;
   VVCGPU(vvcgpu_memcpy_d2h(lv.data(), g_dqLevel.ptr, (size_t)n * sizeof(TCoeff), nullptr));
