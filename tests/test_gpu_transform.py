@@ -269,3 +269,37 @@ def test_depquant_trellis():
     got_sum = ops.depquant_batch(dev(np.concatenate(coefs)), level, ops.struct_to_device(d), len(d), ops.struct_to_device(rates), off, 10)
     assert np.array_equal(got_sum.cpu().numpy().view(np.uint32), np.array(sums, np.uint32))
     assert np.array_equal(level.cpu().numpy(), np.concatenate(wants))
+
+
+def test_depquant_full_size():
+    """bench picture size: every 16x16 TU of a 3840x2160 picture (32400 TUs, 8.3 M coefficients) in one launch.  Size-independent
+    properties: abs_sum[i] == sum |level| of TU i; levels keep the sign of their coefficient; a TU whose coefficients are all
+    below the trellis threshold stays zero; a random subset equals the oracle."""
+    import ctypes as C
+    import os
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(123)
+    g = np.load(os.path.join(os.path.dirname(__file__), "golden", "depquant.npz"))
+    rates = np.ascontiguousarray(g["rates"][:4]).view(ops.DQ_RATES)
+    B, n = 16, (3840 // 16) * (2160 // 16)
+    yy, xx = np.mgrid[0:B, 0:B]
+    decay = np.exp(-(xx / B * 3 + yy / B * 3)).reshape(-1)
+    coef = (rng.normal(0, 1500, (n, B * B)) * decay).astype(np.int32)
+    coef[::7] = rng.integers(-2, 3, (coef[::7].shape))                  # every seventh TU: nothing above the threshold
+    d = np.zeros(n, ops.DEPQUANT_DESC)
+    d["coeff_off"] = d["level_off"] = np.arange(n) * B * B
+    d["lambda"], d["qp"], d["rates_idx"], d["w"], d["h"], d["luma"] = 60.0, 44, rng.integers(0, 4, n), B, B, 1
+    level = torch.full((n * B * B,), 5, dtype=torch.int32, device="cuda")
+    sums = ops.depquant_batch(dev(coef.reshape(-1)), level, ops.struct_to_device(d), n, ops.struct_to_device(rates), n * B * B, 10)
+    lv = level.cpu().numpy().reshape(n, B * B)
+    s = sums.cpu().numpy().view(np.uint32)
+    assert np.array_equal(np.abs(lv).sum(1).astype(np.uint32), s)
+    assert np.all((lv == 0) | (np.sign(lv) == np.sign(coef)))
+    assert np.all(lv[::7] == 0) and np.count_nonzero(lv) > n * 20
+    O = oracle()
+    O.orc_depquant.restype = C.c_uint32
+    for i in rng.choice(n, 60, replace=False):
+        want = np.zeros(B * B, np.int32)
+        ws = O.orc_depquant(p(np.ascontiguousarray(coef[i])), p(want), B, B, 1, 10, 44, C.c_double(60.0),
+                            C.c_void_p(rates.ctypes.data + int(d["rates_idx"][i]) * ops.DQ_RATES.itemsize))
+        assert ws == s[i] and np.array_equal(want, lv[i]), i

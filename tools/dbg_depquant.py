@@ -3,7 +3,7 @@ import os; R=os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.pa
 from oraclelib import oracle, ref, p
 from vvcsoftware_vtm_amd import ops
 O=oracle(); O.orc_depquant.restype=C.c_uint32
-rng=np.random.default_rng(4)
+rng=np.random.default_rng(int(sys.argv[1]) if len(sys.argv)>1 else 4)
 shapes=[(4,4),(8,8),(16,16),(32,32),(4,8),(8,4),(16,4),(4,16),(32,8),(8,32),(64,16),(16,64),(64,64),(32,64),(8,16)]
 # synthetic but plausible rate tables
 rates=np.zeros(2,ops.DQ_RATES)
