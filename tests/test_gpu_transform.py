@@ -294,7 +294,7 @@ def test_depquant_full_size():
     lv = level.cpu().numpy().reshape(n, B * B)
     s = sums.cpu().numpy().view(np.uint32)
     assert np.array_equal(np.abs(lv).sum(1).astype(np.uint32), s)
-    assert np.all((lv == 0) | (np.sign(lv) == np.sign(coef)))
+    assert np.all((lv == 0) | ((lv < 0) == (coef < 0)))                   # a zero coefficient may still get a (positive) level
     assert np.all(lv[::7] == 0) and np.count_nonzero(lv) > n * 20
     O = oracle()
     O.orc_depquant.restype = C.c_uint32
