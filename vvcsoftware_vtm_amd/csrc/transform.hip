@@ -770,17 +770,34 @@ __device__ __forceinline__ void quant_tu(const TCoeff* __restrict__ coeffBase, T
     }
 }
 
-// two launches: <false> takes the small TUs (four per wavefront), <true> the large ones (one per wavefront); each skips the other class
-template <bool LARGE>
-__global__ __launch_bounds__(256) void quant_kernel(const TCoeff* __restrict__ coeffBase, TCoeff* __restrict__ levelBase,
-                                                    const vvcgpu_quant_desc* __restrict__ descs, int n, int bd, unsigned* __restrict__ absSumOut)
+// two launches: the first takes the small TUs (four per wavefront) and lists the large ones; the second walks that list, one large
+// TU per wavefront at a time (a persistent grid: no empty workgroups for the many small TUs of a picture)
+__global__ __launch_bounds__(256) void quant_small_kernel(const TCoeff* __restrict__ coeffBase, TCoeff* __restrict__ levelBase,
+                                                          const vvcgpu_quant_desc* __restrict__ descs, int n, int bd, unsigned* __restrict__ absSumOut,
+                                                          int* __restrict__ largeList)
 {
   const int lane = threadIdx.x & 63;
-  const int ti = (blockIdx.x * 4 + (threadIdx.x >> 6)) * (LARGE ? 1 : 4) + (LARGE ? 0 : (lane >> 4));
+  const int ti = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4 + (lane >> 4);
   const vvcgpu_quant_desc d = descs[ti < n ? ti : n - 1];
-  const bool live = ti < n && ((int)d.w * d.h > 256) == LARGE;
+  const bool large = (int)d.w * d.h > 256;
+  if (ti < n && large && (lane & 15) == 0) largeList[1 + atomicAdd(&largeList[0], 1)] = ti;
+  const bool live = ti < n && !large;
   if (__ballot(live) == 0ull) return;
-  quant_tu<LARGE>(coeffBase, levelBase, d, live, ti, bd, absSumOut, lane);
+  quant_tu<false>(coeffBase, levelBase, d, live, ti, bd, absSumOut, lane);
+}
+
+__global__ __launch_bounds__(256) void quant_large_kernel(const TCoeff* __restrict__ coeffBase, TCoeff* __restrict__ levelBase,
+                                                          const vvcgpu_quant_desc* __restrict__ descs, int bd, unsigned* __restrict__ absSumOut,
+                                                          const int* __restrict__ largeList)
+{
+  const int lane = threadIdx.x & 63;
+  const int count = largeList[0], waves = gridDim.x * 4;
+  for (int i = blockIdx.x * 4 + (threadIdx.x >> 6); i < count; i += waves)
+  {
+    const int ti = largeList[1 + i];
+    const vvcgpu_quant_desc d = descs[ti];
+    quant_tu<true>(coeffBase, levelBase, d, true, ti, bd, absSumOut, lane);
+  }
 }
 
 // ---- dependent-quantisation trellis: DQIntern::DepQuant::quant (DepQuant.cpp:1323-1391) ---------------------------------------
@@ -1387,8 +1404,13 @@ int vvcgpu_quant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const v
   VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "quant_batch: bit depth %d outside 8..10", bit_depth);
   const int rt = ensure_tables();
   if (rt) return rt;
-  hipLaunchKernelGGL(quant_kernel<false>, dim3(cdiv(n, 16)), dim3(256), 0, (hipStream_t)stream, coeff_base, level_base, descs, n, bit_depth, abs_sum);
-  hipLaunchKernelGGL(quant_kernel<true>, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, coeff_base, level_base, descs, n, bit_depth, abs_sum);
+  hipStream_t st = (hipStream_t)stream;
+  int* list = static_cast<int*>(vvcgpu_scratch(st, ((size_t)n + 1) * sizeof(int)));
+  if (!list) return VVCGPU_E_DEVICE;
+  VVC_HIP(hipMemsetAsync(list, 0, sizeof(int), st));
+  hipLaunchKernelGGL(quant_small_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, coeff_base, level_base, descs, n, bit_depth, abs_sum, list);
+  const int nl = cdiv(n, 4);
+  hipLaunchKernelGGL(quant_large_kernel, dim3(nl < 512 ? nl : 512), dim3(256), 0, st, coeff_base, level_base, descs, bit_depth, abs_sum, list);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
