@@ -51,6 +51,8 @@ struct TzRange { int left, right, top, bottom; };
 // with point number d | 3 raster over `win` with step d, nx columns
 struct TzRound { int kind, n, x, y, d, corners, nx; unsigned rnx; TzRange win; };   // rnx = ceil(2^32 / nx)
 
+constexpr int TZ_SEG_REGS = 6;            // raster rounds: dwords per lane of one staged chunk (6 x 64 dwords of LDS per wavefront)
+constexpr int TZ_SEG_DWORDS = 64 * TZ_SEG_REGS / 2;   // longest reference segment of one block row (two rows per chunk at least)
 constexpr int TZ_LDS_DWORDS = 8192;     // 32 KB: 8 KB per wavefront (TEAM 1: 64x64 / 64x128 sub-sampled) or all of it (TEAM 4: 128x128)
 
 template <int TEAM>
@@ -70,6 +72,7 @@ struct TzTeam
   const unsigned* orgL;                 // LDS copy of the sub-sampled block (packed pairs, row pitch w / 2 dwords), or nullptr
   unsigned bias;                        // 0x80008000 when the block holds negative samples (both sides are biased then)
   unsigned long long* keyL;             // TEAM 4: one slot per wavefront
+  unsigned* segL;                       // this wavefront's raster chunk (64 * TZ_SEG_REGS dwords)
   static constexpr int TL = 64 * TEAM;
 
   __device__ __forceinline__ void clip(int& hor, int& ver) const
@@ -277,6 +280,92 @@ struct TzTeam
     }
   }
 
+
+  // Raster round, one raster row (fixed y) at a time: the probes of a row are step samples apart, so their block rows overlap in
+  // memory.  The wavefront stages the contiguous reference segment ((nx - 1) * step + w samples) of several block rows in LDS with
+  // coalesced dword loads (the next chunk is in flight in registers while the current one is consumed), lane i then takes probe i
+  // of the raster row: broadcast 16-byte reads of the original row, dword reads of the segment at its own offset + v_alignbit for
+  // odd offsets.  A wavefront executes in order, so its private LDS chunk needs no second buffer.  TEAM 4 deals the raster rows to
+  // its four wavefronts.  Returns false (generic path) when the block is not LDS-resident, narrower than 32 (measured: the generic
+  // path with its full lane use is faster there) or not a multiple of 8 wide, a segment does not fit, a probe would be clamped, or a raster row has more than 64 probes.
+  __device__ __forceinline__ bool raster_rows(const TzRound& R, unsigned long long& key)
+  {
+    const int step = R.d, nx = R.nx, ny = R.n / R.nx;
+    if (!orgL || nx > 64 || w < 32 || (w & 7) || (rs & 1) || (((nx - 1) * step + w + 3) >> 1) > TZ_SEG_DWORDS) return false;
+    if (refX + R.win.left < rx0 || refX + R.win.left + (nx - 1) * step > rx1 || refY + R.win.top < ry0 || refY + R.win.top + (ny - 1) * step > ry1) return false;
+    const int lane = tl & 63, wave = TEAM == 4 ? tl >> 6 : 0;
+    const int rows = h >> subShift, halfW = w >> 1;
+    const ptrdiff_t gstep = ((ptrdiff_t)rs << subShift) >> 1;             // dwords between block rows
+    const Pel* first = ref + (ptrdiff_t)(refY + R.win.top) * rs + refX + R.win.left;
+    const int pOff = (int)((reinterpret_cast<uintptr_t>(first) & 2) >> 1); // sample 0 of a segment sits at LDS sample pOff (rs is even: same on every row)
+    const int nd = (pOff + (nx - 1) * step + w + 1) >> 1;                 // dwords that hold samples some probe reads
+    const unsigned rnd = (unsigned)(0x100000000ull / (unsigned)nd) + 1u;  // i / nd == umulhi(i, rnd) for the i used here
+    const int RB = min(rows, (64 * TZ_SEG_REGS) / nd);                    // block rows per chunk (nd <= TZ_SEG_DWORDS: at least 2)
+    int ldRow[TZ_SEG_REGS], ldCol[TZ_SEG_REGS];
+#pragma unroll
+    for (int k = 0; k < TZ_SEG_REGS; k++)
+    {
+      const int i = lane + 64 * k;
+      ldRow[k] = (int)__umulhi((unsigned)i, rnd); ldCol[k] = i - ldRow[k] * nd;
+      if (ldRow[k] >= RB) ldRow[k] = -1;
+    }
+    const bool live = lane < nx;
+    const int x = R.win.left + lane * step;
+    const int myOff = lane * step + pOff, myDw = myOff >> 1;
+    const unsigned sh = (unsigned)(myOff & 1) << 4;
+    const int chunks = (rows + RB - 1) / RB, total = ((ny - wave + TEAM - 1) / TEAM) * chunks;   // chunks this wavefront walks
+    unsigned pf[TZ_SEG_REGS];
+    auto fetch = [&](int t)                                                 // chunk t of this wavefront -> registers
+    {
+      const int j = wave + (t / chunks) * TEAM, r0 = (t % chunks) * RB;
+      const unsigned* g = reinterpret_cast<const unsigned*>(reinterpret_cast<uintptr_t>(first + (ptrdiff_t)j * step * rs) & ~(uintptr_t)3);
+#pragma unroll
+      for (int k = 0; k < TZ_SEG_REGS; k++)
+        pf[k] = (ldRow[k] >= 0 && r0 + ldRow[k] < rows) ? g[(ptrdiff_t)(r0 + ldRow[k]) * gstep + ldCol[k]] : 0u;
+    };
+    if (total > 0) fetch(0);
+    unsigned acc = 0;
+    for (int t = 0; t < total; t++)
+    {
+      const int jj = t / chunks, c = t - jj * chunks, r0 = c * RB;
+#pragma unroll
+      for (int k = 0; k < TZ_SEG_REGS; k++) if (ldRow[k] >= 0) segL[lane + 64 * k] = pf[k] ^ bias;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
+      if (t + 1 < total) fetch(t + 1);
+      if (live)
+      {
+        const int nr = min(RB, rows - r0);
+        for (int r = 0; r < nr; r++)
+        {
+          const unsigned* o = orgL + (r0 + r) * halfW;
+          const unsigned* sp = segL + r * nd + myDw;
+          unsigned d0 = sp[0];
+          for (int k = 0; k < halfW; k += 4)
+          {
+            const uint4 ov = *reinterpret_cast<const uint4*>(o + k);
+            const unsigned d1 = sp[k + 1], d2 = sp[k + 2], d3 = sp[k + 3], d4 = sp[k + 4];
+            acc = __builtin_amdgcn_sad_u16(ov.x, __builtin_amdgcn_alignbit(d1, d0, sh), acc);
+            acc = __builtin_amdgcn_sad_u16(ov.y, __builtin_amdgcn_alignbit(d2, d1, sh), acc);
+            acc = __builtin_amdgcn_sad_u16(ov.z, __builtin_amdgcn_alignbit(d3, d2, sh), acc);
+            acc = __builtin_amdgcn_sad_u16(ov.w, __builtin_amdgcn_alignbit(d4, d3, sh), acc);
+            d0 = d4;
+          }
+        }
+        if (c == chunks - 1)
+        {
+          const int j = wave + jj * TEAM, y = R.win.top + j * step;
+          const unsigned long long cost = ((unsigned long long)acc << subShift) + mvcost(x, y);
+          key = min(key, (cost << 16) | (unsigned)(j * nx + lane));
+          acc = 0;
+        }
+      }
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier();
+    }
+    // fold the lanes of this wavefront (the tail of round() folds across groups of G lanes only)
+    for (int m = 1; m < 64; m <<= 1) { const unsigned long long ok = __shfl_xor(key, m); key = min(key, ok); }
+    return true;
+  }
+
   __device__ __forceinline__ void round(const TzRound& R)
   {
     // lanes per probe G = LX * RP: split the rows RP ways while the team has lanes to spare for this round
@@ -287,6 +376,7 @@ struct TzTeam
     const int sub = tl & (G - 1), lx = sub & (LX - 1), rp = sub / LX, lc = tl / G;
     unsigned long long key = ~0ull;
     int c0 = 0;
+    if (R.kind == 3 && raster_rows(R, key)) c0 = n;           // raster round through per-row LDS segments
     for (; c0 + 4 * CPT <= n; c0 += 4 * CPT) pass<4>(R, c0, CPT, G, lc, lx, rp, RP, key);
     for (; c0 < n; c0 += CPT) pass<1>(R, c0, CPT, G, lc, lx, rp, RP, key);
     for (int m = G; m < 64; m <<= 1)
@@ -326,9 +416,10 @@ __global__ __launch_bounds__(256) void tz_search_kernel(const Pel* __restrict__ 
                                                         const vvcgpu_tz_pu* __restrict__ pus, int n, vvcgpu_tz_cfg cfg,
                                                         vvcgpu_search_best* __restrict__ results)
 {
-  __shared__ unsigned orgL[TZ_LDS_DWORDS];
+  __shared__ __attribute__((aligned(16))) unsigned orgL[TZ_LDS_DWORDS];
   __shared__ unsigned long long keyL[4];
   __shared__ int negL[4];
+  __shared__ unsigned segS[4][64 * TZ_SEG_REGS + 4];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int b = __builtin_amdgcn_readfirstlane(TEAM == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave);
   if (b >= n) return;                                          // TEAM 4: the whole workgroup leaves; TEAM 1: no barrier is used
@@ -345,6 +436,7 @@ __global__ __launch_bounds__(256) void tz_search_kernel(const Pel* __restrict__ 
   int LX = 1; while (4 * LX < pu.w) LX <<= 1;                 // quads along a row, rounded up to a power of two (w <= 128 -> LX <= 32)
   s.LX = LX;
   s.keyL = keyL;
+  s.segL = segS[wave];
 
   // the sub-sampled original block -> LDS as packed pairs (w is a multiple of 4: VVC block widths are 4, 8, 12, 16, 24, ...)
   {
