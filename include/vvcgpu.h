@@ -487,6 +487,40 @@ int vvcgpu_depquant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, cons
                           const vvcgpu_dq_rates* rates, int bit_depth, uint32_t* abs_sum, size_t total_coeffs, void* ws, size_t ws_bytes,
                           void* stream);
 
+/* N1, the rate-distortion optimised quantiser used where the trellis is not (dependent quantisation off, and transform-skip
+ * blocks): QuantRDOQ::xRateDistOptQuant, CommonLib/QuantRDOQ.cpp:694-1409 with xGetCodedLevel :107-162, xGetICRate :235-313,
+ * xGetRateLast :407-421, xGetErrScaleCoeff :482-506 and the JVET_K0072 template contexts (CommonLib/ContextModelling.h:135-219);
+ * what QuantRDOQ::quant :652-690 dispatches to for blocks wider and higher than 2.  The decision chain of one TU is sequential (each
+ * level changes the contexts of the following ones); TUs are independent.  All costs are IEEE doubles evaluated in the reference's
+ * order.  The CABAC side enters as the fractional-bit tables (FracBitsAccess, 2^-15 bit units) the function reads:
+ *   sig[ofs]      Ctx::SigFlag[chType]( ofs )                 (sigCtxIdAbs with state 0; 18 luma / 12 chroma offsets)
+ *   par/gt1/gt2   Ctx::ParFlag[chType], Ctx::GtxFlag[2 + chType], Ctx::GtxFlag[chType] ( ctxOffsetAbs: 21 luma / 11 chroma offsets )
+ *   sig_group[c]  Ctx::SigCoeffGroup[chType]( c )
+ *   last_x/last_y the prefix tables lastBitsX / lastBitsY as built at :1172-1200
+ *   cbf           Ctx::QtRootCbf() (luma of an inter CU at depth 0) or Ctx::QtCbf[compID]( CtxQtCbf ) :1134-1160
+ * sign_hiding = slice->getSignDataHidingEnabledFlag().  lambda = Quant::m_dLambda.  Layout rules, abs_sum and the workspace as
+ * for vvcgpu_depquant_batch (workspace: the per-coefficient cost / rate-delta arrays m_pdCostCoeff ... m_deltaU of the reference). */
+typedef struct vvcgpu_rdoq_rates {
+  int32_t sig[18][2];
+  int32_t par[21][2], gt1[21][2], gt2[21][2];
+  int32_t sig_group[2][2];
+  int32_t last_x[14], last_y[14];
+  int32_t cbf[2];                       /* sizeof == 784 */
+} vvcgpu_rdoq_rates;
+typedef struct vvcgpu_rdoq_desc {
+  int64_t coeff_off, level_off;         /* elements of coeff_base / level_base, blocks are w x h with row pitch w */
+  double  lambda;
+  int32_t qp;                           /* QpParam::Qp                                                   */
+  int32_t rates_idx;                    /* index into the rates array                                    */
+  int16_t w, h;                         /* powers of two 4..64                                           */
+  int8_t  luma, sign_hiding;
+  int8_t  reserved[2];                  /* sizeof == 40 */
+} vvcgpu_rdoq_desc;
+size_t vvcgpu_rdoq_workspace_bytes(size_t total_coeffs, int n);
+int vvcgpu_rdoq_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const vvcgpu_rdoq_desc* descs, int n,
+                      const vvcgpu_rdoq_rates* rates, int bit_depth, uint32_t* abs_sum, size_t total_coeffs, void* ws, size_t ws_bytes,
+                      void* stream);
+
 /* The shipped matrix [type][log2(N)-1] as N x N int16 (host copy; for the shim's table check against initROM()). */
 const int16_t* vvcgpu_tr_matrix_host(int type, int n);
 

@@ -888,6 +888,81 @@ void vtmref_dq_rates_from_ctx(const TransformUnit& tu, ComponentID compID, const
   }
 }
 
+// fractional-bit tables QuantRDOQ::xRateDistOptQuant reads (QuantRDOQ.cpp:694-1409), gathered from a CABAC context object.  Shared with the drop-in shim.
+void vtmref_rdoq_rates_from_ctx(const TransformUnit& tu, ComponentID compID, const Ctx& ctxRef, vvcgpu_rdoq_rates* rt)
+{
+  const ChannelType chType = toChannelType(compID);
+  const FracBitsAccess& fb = ctxRef.getFracBitsAcess();
+  memset(rt, 0, sizeof *rt);
+  auto put = [&](int32_t* o, unsigned ctxId) { const BinFracBits b = fb.getFracBitsArray(ctxId); o[0] = b.intBits[0]; o[1] = b.intBits[1]; };
+  const unsigned numSig = chType == CHANNEL_TYPE_LUMA ? 18 : 12, numGtx = chType == CHANNEL_TYPE_LUMA ? 21 : 11;
+  for (unsigned c = 0; c < numSig; c++) put(rt->sig[c], Ctx::SigFlag[chType](c));
+  for (unsigned c = 0; c < numGtx; c++) { put(rt->par[c], Ctx::ParFlag[chType](c)); put(rt->gt1[c], Ctx::GtxFlag[2 + chType](c)); put(rt->gt2[c], Ctx::GtxFlag[chType](c)); }
+  for (unsigned c = 0; c < 2; c++) put(rt->sig_group[c], Ctx::SigCoeffGroup[chType](c));
+  if (compID == COMPONENT_Y && !CU::isIntra(*tu.cu) && tu.depth == 0) put(rt->cbf, Ctx::QtRootCbf());
+  else put(rt->cbf, Ctx::QtCbf[compID](DeriveCtx::CtxQtCbf(compID, tu.depth, tu.cbf[COMPONENT_Cb])));
+  CoeffCodingContext cctx(tu, compID, false);
+  const int dim[2] = { (int)tu.blocks[compID].width, (int)tu.blocks[compID].height };
+  for (int xy = 0; xy < 2; xy++)                                                   // :1172-1200
+  {
+    int32_t* o = xy ? rt->last_y : rt->last_x;
+    int bits = 0, id;
+    for (id = 0; id < (int)g_uiGroupIdx[dim[xy] - 1]; id++)
+    {
+      const BinFracBits b = fb.getFracBitsArray(xy ? cctx.lastYCtxId(id) : cctx.lastXCtxId(id));
+      o[id] = bits + b.intBits[0]; bits += b.intBits[1];
+    }
+    o[id] = bits;
+  }
+}
+
+// Rate-distortion optimised quantiser (next row N1): the reference's own QuantRDOQ::quant (QuantRDOQ.cpp:652-690 -> xRateDistOptQuant)
+// on a luma (comp 0) or Cb (comp 1) TransformUnit at depth 0 of an inter (intra = 0) or intra CU, with a real CABAC context object
+// initialised for (ctxQp, initId); the fractional-bit tables it reads are handed back for the restatement / the kernel.
+extern "C" uint32_t vtmref_rdoq(const TCoeff* coef, TCoeff* level, int w, int h, int comp, int bd, int qp, double lambda, int ctxQp, int initId,
+                                int intra, int signHiding, int transformSkip, vvcgpu_rdoq_rates* rt)
+{
+  static SPS* sps = nullptr;
+  static CodingStructure* cs = nullptr;
+  static Slice* slice = nullptr;
+  static QuantRDOQ* rq = nullptr;
+  static CodingUnit* cu = nullptr;
+  static Ctx* ctx = nullptr;
+  if (!sps)
+  {
+    sps = new SPS;
+    cs = static_cast<CodingStructure*>(calloc(1, sizeof(CodingStructure)));
+    slice = new Slice;
+    cs->sps = sps; cs->slice = slice;
+    PreCalcValues* pcv = static_cast<PreCalcValues*>(calloc(1, sizeof(PreCalcValues)));
+    const_cast<bool&>(pcv->rectCUs) = true;
+    cs->pcv = pcv;
+    rq = new QuantRDOQ(nullptr);
+    rq->init(64, true, true, false);
+    cu = new CodingUnit;
+    ctx = new Ctx(static_cast<const BinProbModel_Std*>(nullptr));
+  }
+  const ComponentID compID = comp ? COMPONENT_Cb : COMPONENT_Y;
+  sps->setBitDepth(CHANNEL_TYPE_LUMA, bd); sps->setBitDepth(CHANNEL_TYPE_CHROMA, bd);
+  slice->setDepQuantEnabledFlag(false);
+  slice->setSignDataHidingEnabledFlag(signHiding != 0);
+  cu->predMode = intra ? MODE_INTRA : MODE_INTER;
+  ctx->init(ctxQp, initId);
+  TransformUnit tu(comp ? CHROMA_420 : CHROMA_400, comp ? Area(0, 0, 2 * w, 2 * h) : Area(0, 0, w, h));
+  tu.cs = cs; tu.cu = cu; tu.depth = 0;
+  tu.cbf[COMPONENT_Y] = tu.cbf[COMPONENT_Cb] = tu.cbf[COMPONENT_Cr] = 0;
+  tu.m_coeffs[compID] = level;
+  tu.transformSkip[compID] = transformSkip != 0;
+  QpParam* q = static_cast<QpParam*>(malloc(sizeof(QpParam)));
+  q->Qp = qp; q->per = qp / 6; q->rem = qp % 6;
+  rq->setLambda(lambda);
+  TCoeff absSum = 0;
+  rq->quant(tu, compID, CCoeffBuf(coef, w, w, h), absSum, *q, *ctx);
+  free(q);
+  if (rt) vtmref_rdoq_rates_from_ctx(tu, compID, *ctx, rt);
+  return (uint32_t)absSum;
+}
+
 // Dependent-quantisation trellis (next row N1): the reference's own DepQuant::quant (DepQuant.cpp:1411-1421 -> DQIntern::DepQuant::quant)
 // on a luma (comp 0) or Cb (comp 1) TransformUnit of an inter CU at depth 0, with a real CABAC context object initialised for
 // (ctxQp, initId).  The rate tables the reference derives inside (DQIntern::RateEstimator, private to DepQuant.cpp) are re-derived

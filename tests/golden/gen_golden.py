@@ -462,8 +462,46 @@ def gen_depquant():
     save("depquant", rows=np.array(rows, np.float64), coef=np.concatenate(coefs), level=np.concatenate(levels), rates=np.array(rates, RATES))
 
 
+def gen_rdoq():
+    """next row N1: the reference's own QuantRDOQ::quant (xRateDistOptQuant), luma and chroma TUs of inter and intra CUs, sign hiding on
+    and off, transform-skip flagged 4x4 blocks, with the fractional-bit tables gathered from the same CABAC context object."""
+    rng = np.random.default_rng(1013)
+    R.vtmref_rdoq.restype = C.c_uint32
+    RATES = np.dtype([("sig", "<i4", (18, 2)), ("par", "<i4", (21, 2)), ("gt1", "<i4", (21, 2)), ("gt2", "<i4", (21, 2)), ("sig_group", "<i4", (2, 2)),
+                      ("last_x", "<i4", (14,)), ("last_y", "<i4", (14,)), ("cbf", "<i4", (2,))])
+    assert RATES.itemsize == 784
+    rows, coefs, levels, rates = [], [], [], []
+    off = 0
+    shapes = [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 8), (8, 4), (16, 4), (4, 16), (32, 8), (8, 32), (64, 16), (16, 64), (32, 64), (16, 8)]
+    for (w, h) in shapes:
+        for comp in (0, 1):
+            if comp and max(w, h) > 32:
+                continue
+            for it in range(6 if w * h <= 1024 else 3):
+                bd = 8 if it % 2 else 10
+                qp = int(rng.integers(10, 46 + (bd - 8) * 6))
+                n = w * h
+                yy, xx = np.mgrid[0:h, 0:w]
+                decay = np.exp(-(xx / w * 3 + yy / h * 3))
+                kind = it % 3
+                coef = rng.normal(0, [4000, 600, 15000][kind], (h, w)) * decay * (1 if kind < 2 else (rng.random((h, w)) < 0.2))
+                ts = int(w == 4 and h == 4 and it >= 4)
+                if ts:
+                    coef = rng.normal(0, 300, (h, w))            # transform-skip residuals have no decay
+                coef = np.ascontiguousarray(coef.astype(np.int32).reshape(-1))
+                lam = float(rng.uniform(5, 400))
+                cq, init = int(rng.integers(20, 45)), int(rng.integers(0, 3))
+                intra, sbh = int(rng.integers(0, 2)), int(it % 3 != 1)
+                rt = np.zeros(1, RATES)
+                lv = np.zeros(n, np.int32)
+                s = R.vtmref_rdoq(p(coef), p(lv), w, h, comp, bd, qp, C.c_double(lam), cq, init, intra, sbh, ts, p(rt))
+                rows.append((w, h, comp, bd, qp, off, s, len(rates), lam, sbh))
+                rates.append(rt[0]); coefs.append(coef); levels.append(lv); off += n
+    save("rdoq", rows=np.array(rows, np.float64), coef=np.concatenate(coefs), level=np.concatenate(levels), rates=np.array(rates, RATES))
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac, gen_tzsearch, gen_picture, gen_intra, gen_imv, gen_quant, gen_depquant):
+    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac, gen_tzsearch, gen_picture, gen_intra, gen_imv, gen_quant, gen_depquant, gen_rdoq):
         if not only or fn.__name__[4:] in only:
             fn()

@@ -303,3 +303,65 @@ def test_depquant_full_size():
         ws = O.orc_depquant(p(np.ascontiguousarray(coef[i])), p(want), B, B, 1, 10, 44, C.c_double(60.0),
                             C.c_void_p(rates.ctypes.data + int(d["rates_idx"][i]) * ops.DQ_RATES.itemsize))
         assert ws == s[i] and np.array_equal(want, lv[i]), i
+
+
+def test_rdoq():
+    """N1: the rate-distortion optimised quantiser on the device.  (1) golden vectors of the compiled reference's QuantRDOQ::quant (luma and
+    chroma, sign hiding on and off, per bit depth one launch with mixed TU shapes, four TUs per wavefront); (2) random TUs incl. all-zero
+    blocks, full-range coefficients, lambda extremes and a single level at the end of the scan against the oracle."""
+    import ctypes as C
+    from vvcsoftware_vtm_amd import ops
+    from test_oracle_golden import rdoq_rows
+    rows = list(rdoq_rows())
+    g = rows[0][-1]
+    rates_dev = ops.struct_to_device(np.ascontiguousarray(g["rates"]).view(ops.RDOQ_RATES))
+    coef_dev = dev(np.ascontiguousarray(g["coef"]))
+    total = g["coef"].size
+    for bd in (8, 10):
+        sel = [r for r in rows if r[3] == bd]
+        d = np.array([(r[5], r[5], r[8], r[4], r[7], r[0], r[1], 1 - r[2], r[9], (0, 0)) for r in sel], dtype=ops.RDOQ_DESC)
+        level = torch.full((total,), 9, dtype=torch.int32, device="cuda")
+        sums = ops.rdoq_batch(coef_dev, level, ops.struct_to_device(d), len(d), rates_dev, total, bd).cpu().numpy().view(np.uint32)
+        got = level.cpu().numpy()
+        for i, r in enumerate(sel):
+            n = r[0] * r[1]
+            assert np.array_equal(got[r[5]:r[5] + n], g["level"][r[5]:r[5] + n]), r[:8]
+            assert int(sums[i]) == r[6]
+    rng = np.random.default_rng(91)
+    O = oracle()
+    O.orc_rdoq.restype = C.c_uint32
+    rates = np.ascontiguousarray(g["rates"][:8]).view(ops.RDOQ_RATES)
+    descs, coefs, wants, sums = [], [], [], []
+    off = 0
+    for (w, h) in [(4, 4), (8, 8), (16, 16), (32, 32), (64, 64), (4, 32), (32, 4), (8, 64), (64, 8), (16, 32), (4, 64), (64, 4)]:
+        for it in range(15 if w * h <= 256 else (5 if w * h <= 1024 else 2)):
+            n = w * h
+            qp = int(rng.integers(0, 63))
+            lam = float([0.7, 30.0, 250.0, 4000.0][it % 4])
+            yy, xx = np.mgrid[0:h, 0:w]
+            decay = np.exp(-(xx / w * 2.5 + yy / h * 2.5))
+            kind = it % 5
+            if kind == 0:
+                coef = rng.normal(0, 2500, (h, w)) * decay
+            elif kind == 1:
+                coef = rng.integers(-3, 4, (h, w))                          # nothing quantises to a level at most QPs
+            elif kind == 2:
+                coef = rng.integers(-32768, 32768, (h, w))                  # full 16-bit range everywhere
+            elif kind == 3:
+                coef = rng.normal(0, 9000, (h, w)) * (rng.random((h, w)) < 0.1)
+            else:
+                coef = np.zeros((h, w)); coef[-1, -1] = 20000                # a single level at the very end of the scan
+            coef = np.ascontiguousarray(coef.astype(np.int32).reshape(-1))
+            ri, luma, sbh = int(rng.integers(0, 8)), int(rng.integers(0, 2)), int(rng.integers(0, 2))
+            lv = np.zeros(n, np.int32)
+            sums.append(O.orc_rdoq(p(coef), p(lv), w, h, luma, 10, qp, C.c_double(lam), sbh, C.c_void_p(rates.ctypes.data + ri * ops.RDOQ_RATES.itemsize)))
+            descs.append((off, off, lam, qp, ri, w, h, luma, sbh, (0, 0)))
+            coefs.append(coef); wants.append(lv); off += n
+    d = np.array(descs, dtype=ops.RDOQ_DESC)
+    level = torch.full((off,), 9, dtype=torch.int32, device="cuda")
+    got_sum = ops.rdoq_batch(dev(np.concatenate(coefs)), level, ops.struct_to_device(d), len(d), ops.struct_to_device(rates), off, 10)
+    got = level.cpu().numpy()
+    want = np.concatenate(wants)
+    bad = [i for i, r in enumerate(descs) if not np.array_equal(got[r[0]:r[0] + r[5] * r[6]], want[r[0]:r[0] + r[5] * r[6]])]
+    assert not bad, [descs[i][2:] for i in bad[:6]]
+    assert np.array_equal(got_sum.cpu().numpy().view(np.uint32), np.array(sums, np.uint32))

@@ -408,3 +408,30 @@ def test_depquant_golden():
         n += 1
         nz += int(np.count_nonzero(lv))
     assert n > 80 and nz > 5000
+
+
+def rdoq_rows():
+    g = load("rdoq")
+    for r in g["rows"]:
+        w, h, comp, bd, qp, off, s, ri = [int(v) for v in r[:8]]
+        yield w, h, comp, bd, qp, off, s, ri, float(r[8]), int(r[9]), g
+
+
+def test_rdoq_golden():
+    """next row N1: the restated rate-distortion optimised quantiser vs the compiled reference's own QuantRDOQ::quant."""
+    O = oracle()
+    O.orc_rdoq.restype = C.c_uint32
+    n = nz = changed = 0
+    for (w, h, comp, bd, qp, off, s, ri, lam, sbh, g) in rdoq_rows():
+        coef = np.ascontiguousarray(g["coef"][off:off + w * h])
+        rt = np.ascontiguousarray(g["rates"][ri:ri + 1])
+        lv = np.full(w * h, 77, np.int32)
+        assert O.orc_rdoq(p(coef), p(lv), w, h, 1 - comp, bd, qp, C.c_double(lam), sbh, p(rt)) == s, (w, h, comp, bd, qp)
+        assert np.array_equal(lv, g["level"][off:off + w * h]), (w, h, comp, bd, qp)
+        n += 1
+        nz += int(np.count_nonzero(lv))
+        if sbh:
+            plain = np.zeros(w * h, np.int32)
+            O.orc_rdoq(p(coef), p(plain), w, h, 1 - comp, bd, qp, C.c_double(lam), 0, p(rt))
+            changed += int(np.any(plain != lv))
+    assert n > 100 and nz > 5000 and changed > 20          # the fixture exercises the sign-hiding adjustment too

@@ -101,6 +101,8 @@ int vvcgpu_sizeof(int id)
   case 23: return (int)sizeof(vvcgpu_quant_desc);
   case 24: return (int)sizeof(vvcgpu_dq_rates);
   case 25: return (int)sizeof(vvcgpu_depquant_desc);
+  case 26: return (int)sizeof(vvcgpu_rdoq_rates);
+  case 27: return (int)sizeof(vvcgpu_rdoq_desc);
   default: return -1;
   }
 }

@@ -1250,6 +1250,326 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   absSumOut[ti] = absSum;
 }
 
+// ---- N1: rate-distortion optimised quantiser (QuantRDOQ::xRateDistOptQuant, QuantRDOQ.cpp:694-1409) -------------------------
+// Sixteen lanes per TU, lane k = position k of the current 4x4 coefficient group.  What the reference does one coefficient at a
+// time splits into: per-coefficient quantities (parallel), the level decisions (each reads the five template neighbours: the
+// anti-diagonals of a group are independent, so seven steps decide sixteen levels; neighbours inside the group travel by lane
+// shuffles, those in earlier groups are read back from the level buffer), and the running cost sums, which are IEEE double
+// additions in scan order and therefore stay a serial chain (evaluated by every lane of the team alike, operands by shuffle).
+// All double arithmetic is written in the reference's order with contraction off.
+#pragma clang fp contract(off)
+
+constexpr unsigned long long rdoq_pack_kofpos()
+{
+  // lane (scan index inside a 4x4 group) of in-group position y * 4 + x, from the diagonal scan
+  unsigned long long v = 0; int k = 0;
+  for (int d = 0; d < 7; d++)
+    for (int y = (d < 3 ? d : 3); y >= 0; y--)
+    {
+      const int x = d - y;
+      if (x > 3) continue;
+      v |= (unsigned long long)k << (4 * (y * 4 + x)); k++;
+    }
+  return v;
+}
+constexpr unsigned long long RDOQ_KOFPOS = rdoq_pack_kofpos();
+
+struct RdoqBits { int par0, par1, gt10, gt11, gt20, gt21; };
+
+__device__ __forceinline__ int rdoq_ic_rate(unsigned a, const RdoqBits& b, int rice)              // xGetICRate :235-313
+{
+  if (a == 0) return 0;
+  int rate = 32768;
+  if (a >= 5)
+  {
+    unsigned symbol = (a - 5) >> 1;
+    const int thr = rice == 1 ? 5 : 6;                                                              // g_auiGoRiceRange[0..2]
+    if (symbol < (unsigned)(thr << rice)) rate += (int)((symbol >> rice) + 1 + rice) << 15;
+    else
+    {
+      // the escape loop (:279-286) ends at length = floor(log2(symbol' + 2^rice)), symbol' = symbol - (thr << rice)
+      const int length = 31 - __clz((int)(symbol - (unsigned)(thr << rice) + (1u << rice)));
+      rate += (thr + length + 1 - rice + length) << 15;
+    }
+    rate += (((a - 1) & 1) ? b.par1 : b.par0) + b.gt11 + b.gt21;
+  }
+  else if (a == 1) rate += b.par0 + b.gt10;
+  else if (a == 2) rate += b.par1 + b.gt10;
+  else if (a == 3) rate += b.par0 + b.gt11 + b.gt20;
+  else rate += b.par1 + b.gt11 + b.gt20;
+  return rate;
+}
+
+__device__ __forceinline__ double rdoq_shfl(double v, int src) { return __shfl(v, src); }
+
+__global__ __launch_bounds__(256) void rdoq_kernel(const TCoeff* __restrict__ coeffBase, TCoeff* __restrict__ levelBase,
+                                                   const vvcgpu_rdoq_desc* __restrict__ descs, int n, const vvcgpu_rdoq_rates* __restrict__ rates,
+                                                   int bd, unsigned* __restrict__ absSumOut, double* __restrict__ wsD, int* __restrict__ wsI,
+                                                   double* __restrict__ wsCG, unsigned char* __restrict__ wsSG, size_t c)
+{
+  const int ti = (int)((blockIdx.x * 256u + threadIdx.x) >> 4), k = threadIdx.x & 15, tb = threadIdx.x & 48;
+  if (ti >= n) return;                                                                              // whole teams leave
+  const vvcgpu_rdoq_desc d = descs[ti];
+  const int w = d.w, h = d.h, lw = ilog2(w), lh = ilog2(h), numCG = (w * h) >> 4, wig = w >> 2, hig = h >> 2;
+  const unsigned short* scan = d_scan + d_scanOff[(lw - 1) * 6 + (lh - 1)];
+  const TCoeff* src = coeffBase + d.coeff_off;
+  TCoeff* dst = levelBase + d.level_off;
+  const vvcgpu_rdoq_rates* rt = rates + d.rates_idx;
+  const double lambda = d.lambda;
+  const bool luma = d.luma != 0;
+  const int per = d.qp / 6, rem = d.qp - 6 * per;
+  const int transformShift = 15 - bd - ((lw + lh) >> 1);
+  const bool sqrt2 = ((lw + lh) & 1) != 0;
+  const int qBits = 14 + per + transformShift;
+  const int qs = rem == 0 ? 26214 : rem == 1 ? 23302 : rem == 2 ? 20560 : rem == 3 ? 18396 : rem == 4 ? 16384 : 14564;     // g_quantScales
+  const int quantCoef = sqrt2 ? (qs * 181) >> 7 : qs;
+  const double errScale = ldexp(1.0, 15 - 2 * transformShift + (sqrt2 ? 1 : 0)) / quantCoef / quantCoef;                  // xGetErrScaleCoeff :482-506
+  const int half = 1 << (qBits - 1);
+  // workspace, indexed by coeff_off + scan position (coeff_off is a multiple of 16: the sixteen lanes write one line)
+  double* wCoeff = wsD + d.coeff_off; double* wSig = wsD + c + d.coeff_off; double* wCoeff0 = wsD + 2 * c + d.coeff_off;
+  int* wUp = wsI + d.coeff_off; int* wDown = wsI + c + d.coeff_off; int* wSigDelta = wsI + 2 * c + d.coeff_off; int* wDeltaU = wsI + 3 * c + d.coeff_off;
+  double* wCG = wsCG + (d.coeff_off >> 4);
+  unsigned char* wSG = wsSG + (d.coeff_off >> 4);
+
+  double blockUncoded = 0, baseCost = 0;
+  int cgLastScanPos = -1, lastScanPos = -1;
+  for (int subSet = numCG - 1; subSet >= 0; subSet--)
+  {
+    const int sp = (subSet << 4) + k, pos = scan[sp], x = pos & (w - 1), y = pos >> lw, x4 = x & 3, y4 = y & 3, diag4 = x4 + y4;
+    const int cgX = x >> 2, cgY = y >> 2, cgPos = cgY * wig + cgX;
+    const int sigRight = cgX + 1 < wig ? wSG[cgPos + 1] : 0, sigLower = cgY + 1 < hig ? wSG[cgPos + wig] : 0;
+    const int sg0 = rt->sig_group[sigRight | sigLower][0], sg1 = rt->sig_group[sigRight | sigLower][1];
+    // ---- per coefficient :830-843
+    const long long tmpLevel = (long long)abs(src[pos]) * quantCoef;
+    const int levelDouble = (int)min(tmpLevel, (long long)0x7FFFFFFF - half);
+    const unsigned maxAbs = min(32767u, (unsigned)((levelDouble + half) >> qBits));
+    const double err0 = (double)levelDouble;
+    const double cost0 = err0 * err0 * errScale;
+    if (lastScanPos < 0)
+    {
+      const unsigned m = (unsigned)(__ballot(maxAbs > 0) >> tb) & 0xFFFFu;
+      if (m) { lastScanPos = (subSet << 4) + 31 - __clz((int)m); cgLastScanPos = subSet; }
+    }
+    const bool inRange = lastScanPos >= 0 && sp <= lastScanPos, isLast = sp == lastScanPos;
+    // ---- template neighbours (x+1,y) (x+2,y) (x+1,y+1) (x,y+1) (x,y+2): validity as nested at ContextModelling.h:144-164
+    const bool v0 = x < w - 1, v1 = x < w - 2, v2 = v0 && y < h - 1, v3 = y < h - 1, v4 = y < h - 2;
+    const bool in0 = x4 < 3, in1 = x4 < 2, in2 = x4 < 3 && y4 < 3, in3 = y4 < 3, in4 = y4 < 2;
+    int nb0 = (v0 && !in0) ? dst[pos + 1] : 0, nb1 = (v1 && !in1) ? dst[pos + 2] : 0, nb2 = (v2 && !in2) ? dst[pos + w + 1] : 0,
+        nb3 = (v3 && !in3) ? dst[pos + w] : 0, nb4 = (v4 && !in4) ? dst[pos + 2 * w] : 0;
+    const int p4 = y4 * 4 + x4;
+    const int l0 = tb + (int)((RDOQ_KOFPOS >> (4 * ((p4 + 1) & 15))) & 15), l1 = tb + (int)((RDOQ_KOFPOS >> (4 * ((p4 + 2) & 15))) & 15),
+              l2 = tb + (int)((RDOQ_KOFPOS >> (4 * ((p4 + 5) & 15))) & 15), l3 = tb + (int)((RDOQ_KOFPOS >> (4 * ((p4 + 4) & 15))) & 15),
+              l4 = tb + (int)((RDOQ_KOFPOS >> (4 * ((p4 + 8) & 15))) & 15);
+    int level = 0, incUp = 0, incDown = 0, sigDelta = 0, deltaU = 0;
+    double costCoeff = 0, costSig = 0;
+    for (int dg = 6; dg >= 0; dg--)
+    {
+      const int t0 = __shfl(level, l0), t1 = __shfl(level, l1), t2 = __shfl(level, l2), t3 = __shfl(level, l3), t4 = __shfl(level, l4);
+      if (diag4 == dg && inRange)
+      {
+        int sumAbs = 0, numPos = 0, sumGo = 0;
+        auto upd = [&](bool valid, int a) { if (valid) { sumAbs += min(4 - (a & 1), a); numPos += a != 0; sumGo += a - (a != 0); } };
+        upd(v0, in0 ? t0 : nb0); upd(v1, in1 ? t1 : nb1); upd(v2, in2 ? t2 : nb2); upd(v3, in3 ? t3 : nb3); upd(v4, in4 ? t4 : nb4);
+        int ctxSig = 0, ofs = 0;
+        if (!isLast)
+        {
+          const int diag = x + y;
+          ctxSig = min(sumAbs, 5) + (diag < 2 ? 6 : 0) + ((luma && diag < 5) ? 6 : 0);
+          ofs = min(sumAbs - numPos, 4) + 1 + (diag == 0 ? (luma ? 15 : 5) : (luma ? (diag < 3 ? 10 : (diag < 10 ? 5 : 0)) : 0));
+        }
+        const int sm = min(sumGo, 31), rice = sm < 12 ? 0 : sm < 25 ? 1 : 2;                       // g_auiGoRicePars
+        const RdoqBits b = { rt->par[ofs][0], rt->par[ofs][1], rt->gt1[ofs][0], rt->gt1[ofs][1], rt->gt2[ofs][0], rt->gt2[ofs][1] };
+        const int sig0 = rt->sig[ctxSig][0], sig1 = rt->sig[ctxSig][1];
+        // xGetCodedLevel :107-162
+        double codedCost; unsigned best = 0; bool done = false;
+        if (!isLast && maxAbs < 3)
+        {
+          costSig = lambda * sig0;
+          codedCost = cost0 + costSig;
+          done = maxAbs == 0;
+        }
+        else codedCost = 1.7976931348623157e308;
+        if (!done)
+        {
+          const double currSig = isLast ? 0.0 : lambda * sig1;
+          const int minAbs = maxAbs > 1 ? (int)maxAbs - 1 : 1;
+          for (int a = (int)maxAbs; a >= minAbs; a--)
+          {
+            const double err = (double)(levelDouble - (int)((unsigned)a << qBits));
+            double cost = err * err * errScale + lambda * rdoq_ic_rate((unsigned)a, b, rice);
+            cost += currSig;
+            if (cost < codedCost) { best = (unsigned)a; codedCost = cost; costSig = currSig; }
+          }
+        }
+        costCoeff = codedCost;
+        if (!isLast) sigDelta = sig1 - sig0;
+        deltaU = (levelDouble - (int)(best << qBits)) >> (qBits - 8);
+        if (best > 0)
+        {
+          const int now = rdoq_ic_rate(best, b, rice);
+          incUp = rdoq_ic_rate(best + 1, b, rice) - now;
+          incDown = rdoq_ic_rate(best - 1, b, rice) - now;
+        }
+        else incUp = b.par0 + b.gt10;
+        level = (int)best;
+      }
+    }
+    // ---- the running sums of the group, scan order fifteen down to zero :1023-1041
+    double sigCost = 0, sigCost0 = 0, codedLevelAndDist = 0, uncodedDist = 0; int nnzBeforePos0 = 0;
+    const unsigned nzMask = (unsigned)(__ballot(level != 0) >> tb) & 0xFFFFu;
+    for (int kk = 15; kk >= 0; kk--)
+    {
+      const double cc = rdoq_shfl(costCoeff, tb + kk), c0 = rdoq_shfl(cost0, tb + kk), cs = rdoq_shfl(costSig, tb + kk);
+      blockUncoded += c0;
+      baseCost += (lastScanPos >= 0 && (subSet << 4) + kk <= lastScanPos) ? cc : c0;
+      sigCost += cs;
+      if (kk == 0) sigCost0 = cs;
+      if ((nzMask >> kk) & 1u) { codedLevelAndDist += cc - cs; uncodedDist += c0; if (kk != 0) nnzBeforePos0++; }
+    }
+    bool sigGroup = nzMask != 0;
+    double cgSig = 0;
+    if (cgLastScanPos >= 0)
+    {
+      if (subSet)
+      {
+        if (!sigGroup)
+        {
+          baseCost += lambda * sg0 - sigCost;
+          cgSig = lambda * sg0;
+        }
+        else if (subSet < cgLastScanPos)
+        {
+          if (nnzBeforePos0 == 0) { baseCost -= sigCost0; sigCost -= sigCost0; }
+          double costZeroCG = baseCost;
+          baseCost += lambda * sg1;
+          costZeroCG += lambda * sg0;
+          cgSig = lambda * sg1;
+          costZeroCG += uncodedDist;
+          costZeroCG -= codedLevelAndDist;
+          costZeroCG -= sigCost;
+          if (costZeroCG < baseCost)
+          {
+            sigGroup = false;
+            baseCost = costZeroCG;
+            cgSig = lambda * sg0;
+            if (level) { level = 0; costCoeff = cost0; costSig = 0; }
+          }
+        }
+      }
+      else sigGroup = true;
+    }
+    dst[pos] = level;
+    wCoeff[sp] = costCoeff; wSig[sp] = costSig; wCoeff0[sp] = cost0;
+    wUp[sp] = incUp; wDown[sp] = incDown; wSigDelta[sp] = sigDelta; wDeltaU[sp] = deltaU;
+    if (k == 0) { wSG[cgPos] = sigGroup ? 1 : 0; wCG[subSet] = cgSig; }
+    __threadfence_block();                                                 // levels and group flags are read by other lanes of the team later
+  }
+  if (lastScanPos < 0) { if (k == 0) absSumOut[ti] = 0; return; }
+
+  // ---- last position :1127-1262 (serial chain on the base cost; ends at the first level above one)
+  double bestCost = blockUncoded + lambda * rt->cbf[0];
+  baseCost += lambda * rt->cbf[1];
+  int bestLastIdxP1 = 0;
+  bool foundLast = false;
+  for (int cg = cgLastScanPos; cg >= 0 && !foundLast; cg--)
+  {
+    baseCost -= wCG[cg];
+    const int sp = (cg << 4) + k, pos = scan[sp], px = pos & (w - 1), py = pos >> lw;
+    if (!wSG[(py >> 2) * wig + (px >> 2)]) continue;
+    const int lvl = dst[pos];
+    const double cc = wCoeff[sp], cs = wSig[sp], c0 = wCoeff0[sp];
+    const int gx = px < 4 ? px : (2 * (31 - __clz(px))) + ((px >> (30 - __clz(px))) & 1), gy = py < 4 ? py : (2 * (31 - __clz(py))) + ((py >> (30 - __clz(py))) & 1);   // g_uiGroupIdx
+    double rl = rt->last_x[gx] + rt->last_y[gy];                                    // xGetRateLast :407-421
+    if (gx > 3) rl += 32768.0 * ((gx - 2) >> 1);
+    if (gy > 3) rl += 32768.0 * ((gy - 2) >> 1);
+    const double costLast = lambda * rl;
+    for (int kk = 15; kk >= 0; kk--)
+    {
+      const int l = __shfl(lvl, tb + kk);
+      const double cck = rdoq_shfl(cc, tb + kk), csk = rdoq_shfl(cs, tb + kk), c0k = rdoq_shfl(c0, tb + kk), clk = rdoq_shfl(costLast, tb + kk);
+      if ((cg << 4) + kk > lastScanPos) continue;
+      if (l)
+      {
+        const double total = baseCost + clk - csk;
+        if (total < bestCost) { bestLastIdxP1 = (cg << 4) + kk + 1; bestCost = total; }
+        if (l > 1) { foundLast = true; break; }
+        baseCost -= cck;
+        baseCost += c0k;
+      }
+      else baseCost -= csk;
+    }
+  }
+
+  // ---- signs, the positions beyond the chosen last one, the sum of levels :1263-1276
+  unsigned absSum = 0;
+  for (int cg = 0; cg <= cgLastScanPos; cg++)
+  {
+    const int sp = (cg << 4) + k, pos = scan[sp];
+    const int lvl = sp < bestLastIdxP1 ? dst[pos] : 0;
+    absSum += (unsigned)lvl;
+    dst[pos] = src[pos] < 0 ? -lvl : lvl;
+  }
+  for (int m = 1; m < 16; m <<= 1) absSum += (unsigned)__shfl_xor((int)absSum, m);
+  if (k == 0) absSumOut[ti] = absSum;
+
+  // ---- sign bit hiding :1278-1406: every group on its own; lane = candidate position
+  if (!d.sign_hiding || (int)absSum < 2) return;
+  const double inv = rem == 0 ? 40.0 : rem == 1 ? 45.0 : rem == 2 ? 51.0 : rem == 3 ? 57.0 : rem == 4 ? 64.0 : 72.0;               // g_invQuantScales
+  const long long rdFactor = (long long)(inv * inv * (1 << (2 * per)) / lambda / 16 / 1 + 0.5);
+  int lastCG = -1;
+  for (int subSet = cgLastScanPos; subSet >= 0; subSet--)
+  {
+    const int sp = (subSet << 4) + k, pos = scan[sp];
+    const int lvl = dst[pos];
+    const unsigned m = (unsigned)(__ballot(lvl != 0) >> tb) & 0xFFFFu;
+    const int lastNZ = m ? 31 - __clz((int)m) : -1, firstNZ = m ? __ffs((int)m) - 1 : 16;
+    int sum = lvl;
+    for (int s = 1; s < 16; s <<= 1) sum += __shfl_xor(sum, s);
+    if (lastNZ >= 0 && lastCG == -1) lastCG = 1;
+    if (lastNZ - firstNZ >= 4)
+    {
+      const unsigned signbit = __shfl(lvl, tb + firstNZ) > 0 ? 0u : 1u;
+      if (signbit != (unsigned)(sum & 1))
+      {
+        const long long MAXC = 0x7FFFFFFFFFFFFFFFll;
+        long long curCost = MAXC; int curChange = 0;
+        if (k <= (lastCG == 1 ? lastNZ : 15))
+        {
+          const int dU = wDeltaU[sp], up = wUp[sp], down = wDown[sp], sd = wSigDelta[sp];
+          if (lvl != 0)
+          {
+            const long long costUp = rdFactor * (-dU) + up;
+            long long costDown = rdFactor * dU + down - (abs(lvl) == 1 ? sd : 0);
+            if (lastCG == 1 && lastNZ == k && abs(lvl) == 1) costDown -= 4 << 15;
+            if (costUp < costDown) { curCost = costUp; curChange = 1; }
+            else { curChange = -1; curCost = (k == firstNZ && abs(lvl) == 1) ? MAXC : costDown; }
+          }
+          else
+          {
+            curCost = rdFactor * (-(long long)abs(dU)) + (1 << 15) + up + sd;
+            curChange = 1;
+            if (k < firstNZ && (src[pos] >= 0 ? 0u : 1u) != signbit) curCost = MAXC;
+          }
+        }
+        // minimum cost; among equals the position visited first (the highest) stays
+        long long bc = curCost; int bk = k;
+        for (int s = 1; s < 16; s <<= 1)
+        {
+          const long long oc = __shfl_xor(bc, s); const int ok = __shfl_xor(bk, s);
+          if (oc < bc || (oc == bc && ok > bk)) { bc = oc; bk = ok; }
+        }
+        if (bk == k && bc != MAXC)
+        {
+          int change = curChange;
+          if (lvl == 32767 || lvl == -32768) change = -1;
+          dst[pos] = src[pos] >= 0 ? lvl + change : lvl - change;
+        }
+      }
+    }
+    if (lastCG == 1) lastCG = 0;
+  }
+}
+
 static bool g_tablesUploaded[64] = { false };
 static const int g_smallGrid = getenv("VVCGPU_TR_SMALLGRID") ? atoi(getenv("VVCGPU_TR_SMALLGRID")) : 1280;   // tuning switch
 
@@ -1441,6 +1761,39 @@ int vvcgpu_depquant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, cons
   unsigned char* ctx = static_cast<unsigned char*>(ws) + c * 16;
   hipLaunchKernelGGL(depquant_kernel, dim3(cdiv(n, 64)), dim3(256), 0, (hipStream_t)stream, coeff_base, level_base, descs, n, rates, bit_depth,
                      abs_sum, dec, ctx);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+size_t vvcgpu_rdoq_workspace_bytes(size_t total_coeffs, int n)
+{
+  (void)n;
+  const size_t c = (total_coeffs + 15) & ~(size_t)15;
+  return c * 24 + c * 16 + (c >> 4) * 8 + (c >> 4) + 256;  // three cost arrays, four rate-delta arrays, per group: flag cost + flag
+}
+
+int vvcgpu_rdoq_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const vvcgpu_rdoq_desc* descs, int n,
+                      const vvcgpu_rdoq_rates* rates, int bit_depth, uint32_t* abs_sum, size_t total_coeffs, void* ws, size_t ws_bytes,
+                      void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "rdoq_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(coeff_base && level_base && descs && rates && abs_sum && ws, "rdoq_batch: null pointer");
+  VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "rdoq_batch: bit depth %d outside 8..10", bit_depth);
+  VVC_CHECK_ARG(total_coeffs >= 16 && ws_bytes >= vvcgpu_rdoq_workspace_bytes(total_coeffs, n) && (reinterpret_cast<uintptr_t>(ws) & 15) == 0,
+                "rdoq_batch: workspace of %zu bytes for %zu coefficients is too small (need %zu) or unaligned", ws_bytes, total_coeffs,
+                vvcgpu_rdoq_workspace_bytes(total_coeffs, n));
+  const int rt = ensure_tables();
+  if (rt) return rt;
+  const size_t c = (total_coeffs + 15) & ~(size_t)15;
+  unsigned char* base = static_cast<unsigned char*>(ws);
+  double* wsD = reinterpret_cast<double*>(base);
+  int* wsI = reinterpret_cast<int*>(base + c * 24);
+  double* wsCG = reinterpret_cast<double*>(base + c * 40);
+  unsigned char* wsSG = base + c * 40 + (c >> 4) * 8;
+  // (a group flag is always written before a left / upper neighbour group reads it: the workspace needs no clearing)
+  hipLaunchKernelGGL(rdoq_kernel, dim3(cdiv(n, 16)), dim3(256), 0, (hipStream_t)stream, coeff_base, level_base, descs, n, rates, bit_depth,
+                     abs_sum, wsD, wsI, wsCG, wsSG, c);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

@@ -311,6 +311,25 @@ def depquant_batch(coeff_base, level_base, descs_dev, n, rates_dev, total_coeffs
     return out
 
 
+RDOQ_RATES = np.dtype([("sig", "<i4", (18, 2)), ("par", "<i4", (21, 2)), ("gt1", "<i4", (21, 2)), ("gt2", "<i4", (21, 2)), ("sig_group", "<i4", (2, 2)),
+                       ("last_x", "<i4", (14,)), ("last_y", "<i4", (14,)), ("cbf", "<i4", (2,))])
+RDOQ_DESC = np.dtype([("coeff_off", "<i8"), ("level_off", "<i8"), ("lambda", "<f8"), ("qp", "<i4"), ("rates_idx", "<i4"), ("w", "<i2"), ("h", "<i2"),
+                      ("luma", "i1"), ("sign_hiding", "i1"), ("reserved", "i1", (2,))])
+assert RDOQ_DESC.itemsize == 40 and RDOQ_RATES.itemsize == 784
+
+
+def rdoq_batch(coeff_base, level_base, descs_dev, n, rates_dev, total_coeffs, bit_depth=10):
+    """N1: rate-distortion optimised quantiser (QuantRDOQ::xRateDistOptQuant) for n TUs -> abs-sum int32 tensor [n] (bits as uint32)."""
+    lib = capi.lib()
+    lib.vvcgpu_rdoq_workspace_bytes.restype = C.c_size_t
+    nbytes = int(lib.vvcgpu_rdoq_workspace_bytes(C.c_size_t(total_coeffs), n))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=coeff_base.device)
+    out = torch.zeros(n, dtype=torch.int32, device=coeff_base.device)
+    capi.call("vvcgpu_rdoq_batch", capi.ptr(coeff_base), capi.ptr(level_base), capi.ptr(descs_dev), n, capi.ptr(rates_dev), bit_depth,
+              capi.ptr(out), C.c_size_t(total_coeffs), capi.ptr(ws), C.c_size_t(nbytes), _stream())
+    return out
+
+
 # ---- interpolation / MC / PelBuffer ops -------------------------------------------------------------
 IF_DESC = np.dtype([("src_off", "<i8"), ("dst_off", "<i8"), ("src_stride", "<i4"), ("dst_stride", "<i4"),
                     ("w", "<i2"), ("h", "<i2"), ("taps", "i1"), ("is_vertical", "i1"), ("is_first", "i1"),
