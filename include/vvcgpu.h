@@ -487,8 +487,8 @@ int vvcgpu_depquant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, cons
                           const vvcgpu_dq_rates* rates, int bit_depth, uint32_t* abs_sum, size_t total_coeffs, void* ws, size_t ws_bytes,
                           void* stream);
 
-/* N1, the rate-distortion optimised quantiser used where the trellis is not (dependent quantisation off, and transform-skip
- * blocks): QuantRDOQ::xRateDistOptQuant, CommonLib/QuantRDOQ.cpp:694-1409 with xGetCodedLevel :107-162, xGetICRate :235-313,
+/* N1, the rate-distortion optimised quantiser used when dependent quantisation is off (DepQuant::quant hands the TU over,
+ * CommonLib/DepQuant.cpp:1411-1421): QuantRDOQ::xRateDistOptQuant, CommonLib/QuantRDOQ.cpp:694-1409 with xGetCodedLevel :107-162, xGetICRate :235-313,
  * xGetRateLast :407-421, xGetErrScaleCoeff :482-506 and the JVET_K0072 template contexts (CommonLib/ContextModelling.h:135-219);
  * what QuantRDOQ::quant :652-690 dispatches to for blocks wider and higher than 2.  The decision chain of one TU is sequential (each
  * level changes the contexts of the following ones); TUs are independent.  All costs are IEEE doubles evaluated in the reference's

@@ -23,6 +23,7 @@
 #define SUM_SYM "_Z12calcChecksumRK7UnitBufIKsER11PictureHashRK9BitDepths"
 // the dependent-quantisation trellis: a virtual function, reached through the vtable (dynamic relocation against this symbol)
 #define DQ_SYM "_ZN8DepQuant5quantER13TransformUnitRK11ComponentIDRK7AreaBufIKiERiRK7QpParamRK3Ctx"
+#define RQ_SYM "_ZN9QuantRDOQ5quantER13TransformUnitRK11ComponentIDRK7AreaBufIKiERiRK7QpParamRK3Ctx"
 // the fractional motion refinement, called from xMotionEstimation in its own translation unit (InterSearch.cpp:1816)
 #define FRAC_SYM "_ZN11InterSearch21xPatternSearchFracDIFERK14PredictionUnit10RefPicListiRNS_17IntTZSearchStructERK2MvRS6_S9_Rm"
 
@@ -54,6 +55,7 @@ unsigned hook_checksum(const void* pic, void* digest, const void* bitDepths) asm
 typedef void (*dq_real_t)(void*, void*, const void*, const void*, void*, const void*, const void*);
 typedef int (*dq_shim_t)(void*, void*, const void*, const void*, void*, const void*, const void*);
 void hook_depquant(void* self, void* tu, const void* compID, const void* src, void* absSum, const void* qp, const void* ctx) asm(DQ_SYM);
+void hook_rdoq(void* self, void* tu, const void* compID, const void* src, void* absSum, const void* qp, const void* ctx) asm(RQ_SYM);
 void hook_sao_stats(void* self, void* blkStats, void* org, void* src, void* cs, bool pre) asm(SAO_SYM);
 void hook_alf_stats(void* self, void* org, void* rec) asm(ALF_SYM);
 
@@ -139,5 +141,17 @@ void hook_depquant(void* self, void* tu, const void* compID, const void* src, vo
 void vtmhooks_real_depquant(void* self, void* tu, const void* compID, const void* src, void* absSum, const void* qp, const void* ctx)
 {
   dq_real()(self, tu, compID, src, absSum, qp, ctx);
+}
+// QuantRDOQ::quant: virtual as well, and called by DepQuant::quant (qualified, through the PLT) when dependent quantisation is off
+static dq_real_t rq_real() { static dq_real_t real = (dq_real_t)must(g_target ? dlsym(g_target, RQ_SYM) : nullptr, RQ_SYM); return real; }
+void hook_rdoq(void* self, void* tu, const void* compID, const void* src, void* absSum, const void* qp, const void* ctx)
+{
+  static dq_shim_t shim = (dq_shim_t)dlsym(RTLD_DEFAULT, "vvcshim_rdoq");
+  if (shim && shim(self, tu, compID, src, absSum, qp, ctx)) return;
+  rq_real()(self, tu, compID, src, absSum, qp, ctx);
+}
+void vtmhooks_real_rdoq(void* self, void* tu, const void* compID, const void* src, void* absSum, const void* qp, const void* ctx)
+{
+  rq_real()(self, tu, compID, src, absSum, qp, ctx);
 }
 }

@@ -30,6 +30,8 @@ CLIPS = [
     # picture hash SEI of type CRC (2) / checksum (3) instead of MD5: the hash kernels run inside the reference encoder and decoder
     ("ldpcrc_208x120_10b_q32", "@tests/golden/bitstreams/test_lowdelay.cfg", 208, 120, 10, 2, 32, 20261008, 2),
     ("aisum_208x120_8b_q37", "@tests/golden/bitstreams/test_intra.cfg", 208, 120, 8, 1, 37, 20261009, 3),
+    # dependent quantisation off, sign hiding on: every TU goes through QuantRDOQ::xRateDistOptQuant incl. its sign-hiding pass
+    ("ldprdoq_208x120_10b_q32", "@tests/golden/bitstreams/test_lowdelay.cfg", 208, 120, 10, 2, 32, 20261010, 1, ["--DepQuant=0", "--SignHideFlag=1"]),
 ]
 
 
@@ -37,11 +39,11 @@ def md5(path):
     return hashlib.md5(open(path, "rb").read()).hexdigest()
 
 
-def enc_args(name, cfg, w, h, bd, n, qp, yuv, binf, rec, hash_type=1):
+def enc_args(name, cfg, w, h, bd, n, qp, yuv, binf, rec, hash_type=1, extra=()):
     cfgpath = os.path.join(ROOT, cfg[1:]) if cfg.startswith("@") else os.path.join(CFG, cfg)
     return ["-c", cfgpath, "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30", "-f", str(n), "-q", str(qp),
             "--InputBitDepth=%d" % bd, "--InternalBitDepth=%d" % bd, "--OutputBitDepth=%d" % bd, "-b", binf, "-o", rec,
-            "--SEIDecodedPictureHash=%d" % hash_type]
+            "--SEIDecodedPictureHash=%d" % hash_type] + list(extra)
 
 
 def main():
@@ -50,14 +52,14 @@ def main():
     only = sys.argv[1:]
     man = json.load(open(mpath)) if only and os.path.exists(mpath) else {}
     for clip in CLIPS:
-        (name, cfg, w, h, bd, n, qp, seed), hash_type = clip[:8], (clip[8] if len(clip) > 8 else 1)
+        (name, cfg, w, h, bd, n, qp, seed), hash_type, extra = clip[:8], (clip[8] if len(clip) > 8 else 1), (clip[9] if len(clip) > 9 else [])
         if only and name not in only:
             continue
         yuv = "/tmp/%s.yuv" % name
         synth.write_yuv(yuv, synth.gen_yuv(w, h, n, bd, seed), bd)
         binf = os.path.join(OUT, name + ".bin")
         rec = "/tmp/%s_rec.yuv" % name
-        args = enc_args(name, cfg, w, h, bd, n, qp, yuv, binf, rec, hash_type)
+        args = enc_args(name, cfg, w, h, bd, n, qp, yuv, binf, rec, hash_type, extra)
         subprocess.check_call([APP, "enc"] + args, stdout=open("/tmp/%s_enc.log" % name, "w"))
         dec = "/tmp/%s_dec.yuv" % name
         out = subprocess.check_output([APP, "dec", "-b", binf, "-o", dec, "-d", str(bd)], text=True)
@@ -67,6 +69,8 @@ def main():
                      "bin_md5": md5(binf), "dec_yuv_md5": md5(dec), "bytes": os.path.getsize(binf)}
         if hash_type != 1:
             man[name]["hash"] = hash_type
+        if extra:
+            man[name]["extra"] = list(extra)
         print(name, man[name])
     json.dump(man, open(mpath, "w"), indent=1, sort_keys=True)
 

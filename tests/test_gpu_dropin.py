@@ -71,7 +71,7 @@ def test_decoder_fallthrough_matches(tmp_path):
 
 
 @needs_ref
-@pytest.mark.parametrize("name", ["ldp_208x120_10b_q27", "ai_416x240_8b_q37own", "ldpfs_208x120_10b_q32", "ldpcrc_208x120_10b_q32", "aisum_208x120_8b_q37"])
+@pytest.mark.parametrize("name", ["ldp_208x120_10b_q27", "ai_416x240_8b_q37own", "ldpfs_208x120_10b_q32", "ldpcrc_208x120_10b_q32", "aisum_208x120_8b_q37", "ldprdoq_208x120_10b_q32"])
 def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
     """the reference ENCODER with deblocking, the SAO statistics (getStatistics) and the ALF covariances
     (deriveStatsForFiltering), the per-CTU SAO offsetting (offsetCTU) and the three ALF table slots computed on the GPU inside its loop: every SAO / ALF decision and therefore the bitstream must be
@@ -86,8 +86,8 @@ def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
     binf = str(tmp_path / "out.bin")
     r = subprocess.run([APP, "--hip", "enc", "-c", cfg, "-i", yuv, "-wdt", str(m["w"]), "-hgt", str(m["h"]), "-fr", "30",
                         "-f", str(m["frames"]), "-q", str(m["qp"]), "--InputBitDepth=%d" % m["bd"], "--InternalBitDepth=%d" % m["bd"],
-                        "--OutputBitDepth=%d" % m["bd"], "-b", binf, "-o", str(tmp_path / "rec.yuv"), "--SEIDecodedPictureHash=%d" % m.get("hash", 1)],
-                       capture_output=True, text=True, timeout=1200, env=dict(os.environ, VVCGPU_SHIM_TZ_VERIFY="1", VVCGPU_SHIM_CCLM_VERIFY="1", VVCGPU_SHIM_FILL_VERIFY="1", VVCGPU_SHIM_DEPQUANT_VERIFY="1"))
+                        "--OutputBitDepth=%d" % m["bd"], "-b", binf, "-o", str(tmp_path / "rec.yuv"), "--SEIDecodedPictureHash=%d" % m.get("hash", 1)] + m.get("extra", []),
+                       capture_output=True, text=True, timeout=1200, env=dict(os.environ, VVCGPU_SHIM_TZ_VERIFY="1", VVCGPU_SHIM_CCLM_VERIFY="1", VVCGPU_SHIM_FILL_VERIFY="1", VVCGPU_SHIM_DEPQUANT_VERIFY="1", VVCGPU_SHIM_RDOQ_VERIFY="1"))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert md5(binf) == m["bin_md5"]
     line = [l for l in r.stderr.splitlines() if "[vvcgpu shim]" in l]
@@ -111,7 +111,11 @@ def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
     assert calls[21] > 0, line[-1]             # predIntraAng: every intra mode candidate of the first calls (capped, VVCGPU_SHIM_INTRA_LIMIT)
     assert calls[24] > 0 and "CCLM mismatch" not in r.stderr, line[-1] + r.stderr[-1500:]   # predIntraChromaLM on the GPU, A/B-checked per call
     assert calls[25] > 0 and "reference sample mismatch" not in r.stderr, line[-1] + r.stderr[-1500:]   # xFillReferenceSamples on the GPU, A/B-checked
-    assert calls[26] > 0 and "DepQuant mismatch" not in r.stderr, line[-1] + r.stderr[-1500:]   # the dependent-quantisation trellis on the GPU, A/B-checked
+    if "--DepQuant=0" in m.get("extra", []):
+        # dependent quantisation off: DepQuant::quant hands every TU to QuantRDOQ::quant (DepQuant.cpp:1411-1421); capped by VVCGPU_SHIM_RDOQ_LIMIT, A/B-checked per call
+        assert calls[26] == 0 and calls[27] >= 20000 and "RDOQ mismatch" not in r.stderr, line[-1] + r.stderr[-1500:]
+    else:
+        assert calls[26] > 0 and "DepQuant mismatch" not in r.stderr, line[-1] + r.stderr[-1500:]   # the dependent-quantisation trellis on the GPU, A/B-checked
     if m["frames"] > 1:
         assert calls[22] > 0, line[-1]         # extendPicBorder of every reference picture
     if m.get("hash", 1) != 1:

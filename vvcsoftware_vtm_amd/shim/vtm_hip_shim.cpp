@@ -83,6 +83,9 @@ void wrap_initIntraPatternChType(IntraPrediction*, const CodingUnit&, const Comp
 extern "C" int vvcshim_depquant(DepQuant* self, TransformUnit* tu, const ComponentID* compID, const CCoeffBuf* pSrc, TCoeff* uiAbsSum, const QpParam* cQP,
                                 const Ctx* ctx);
 void vtmref_dq_rates_from_ctx(const TransformUnit& tu, ComponentID compID, const Ctx& ctx, vvcgpu_dq_rates* rt);   // oracle/ref_wrap_kernels.h
+extern "C" int vvcshim_rdoq(QuantRDOQ* self, TransformUnit* tu, const ComponentID* compID, const CCoeffBuf* pSrc, TCoeff* uiAbsSum, const QpParam* cQP,
+                            const Ctx* ctx);
+void vtmref_rdoq_rates_from_ctx(const TransformUnit& tu, ComponentID compID, const Ctx& ctx, vvcgpu_rdoq_rates* rt);
 void real_extendPicBorder(Picture*) asm("__real__ZN7Picture15extendPicBorderEv");
 void wrap_extendPicBorder(Picture*) asm("__wrap__ZN7Picture15extendPicBorderEv");
 
@@ -101,11 +104,11 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
-long g_calls[27] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+long g_calls[28] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
-                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld, IntraPred %ld, Border %ld, Hash %ld, CCLM %ld, IntraRefs %ld, DepQuant %ld\n",
+                                                       "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld, IntraPred %ld, Border %ld, Hash %ld, CCLM %ld, IntraRefs %ld, DepQuant %ld, RDOQ %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
-                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20], g_calls[21], g_calls[22], g_calls[23], g_calls[24], g_calls[25], g_calls[26]); } } g_report;
+                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20], g_calls[21], g_calls[22], g_calls[23], g_calls[24], g_calls[25], g_calls[26], g_calls[27]); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -1346,6 +1349,60 @@ extern "C" int vvcshim_depquant(DepQuant* self, TransformUnit* tuP, const Compon
   for (int y = 0; y < h; y++) memcpy(dst.buf + (size_t)y * dst.stride, &lv[(size_t)y * w], w * sizeof(TCoeff));
   uiAbsSum = (TCoeff)sum;
   g_calls[26]++;
+  return 1;
+}
+
+// ---- QuantRDOQ::quant (QuantRDOQ.cpp:652-690 -> xRateDistOptQuant): the rate-distortion optimised quantiser every TU goes through when
+// dependent quantisation is off (DepQuant::quant, DepQuant.cpp:1411-1421), one TU per call here (next row N1).
+namespace {
+DevArray<vvcgpu_rdoq_desc> g_rqDesc;
+DevArray<vvcgpu_rdoq_rates> g_rqRates;
+}
+
+extern "C" int vvcshim_rdoq(QuantRDOQ* self, TransformUnit* tuP, const ComponentID* compIDP, const CCoeffBuf* pSrcP, TCoeff* uiAbsSumP, const QpParam* cQPP,
+                            const Ctx* ctxP)
+{
+  TransformUnit& tu = *tuP; const ComponentID& compID = *compIDP; const CCoeffBuf& pSrc = *pSrcP; TCoeff& uiAbsSum = *uiAbsSumP;
+  const QpParam& cQP = *cQPP; const Ctx& ctx = *ctxP;
+  const CompArea& area = tu.blocks[compID];
+  const int w = area.width, h = area.height, n = w * h;
+  const int bd = tu.cs->sps->getBitDepth(toChannelType(compID));
+  static const long limit = getenv("VVCGPU_SHIM_RDOQ_LIMIT") ? atol(getenv("VVCGPU_SHIM_RDOQ_LIMIT")) : 20000;
+  const bool useRDOQ = tu.transformSkip[compID] ? self->m_useRDOQTS : self->m_useRDOQ;               // the dispatch of :652-690
+  const bool ok = shimEnabled() && !getenv("VVCGPU_SHIM_NO_TABLES") && useRDOQ && !self->m_useSelectiveRDOQ && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
+                  !(w & (w - 1)) && !(h & (h - 1)) && bd >= 8 && bd <= 10 && (int)pSrc.stride == w && !(limit > 0 && g_calls[27] >= limit) &&
+                  !tu.cs->sps->getSpsRangeExtension().getExtendedPrecisionProcessingFlag();
+  if (!ok) return 0;
+  vvcgpu_rdoq_rates rt;
+  vtmref_rdoq_rates_from_ctx(tu, compID, ctx, &rt);
+  vvcgpu_rdoq_desc d;
+  memset(&d, 0, sizeof d);
+  d.lambda = self->getLambda(); d.qp = cQP.Qp; d.w = (int16_t)w; d.h = (int16_t)h; d.luma = compID == COMPONENT_Y;
+  d.sign_hiding = tu.cs->slice->getSignDataHidingEnabledFlag();
+  g_dqCoef.upload(pSrc.buf, n); g_dqLevel.reserve(n); g_rqDesc.upload(&d, 1); g_rqRates.upload(&rt, 1); g_dqSum.reserve(1);
+  const size_t wsBytes = vvcgpu_rdoq_workspace_bytes((size_t)n, 1);
+  g_dqWs.reserve(wsBytes + 16);
+  VVCGPU(vvcgpu_rdoq_batch(g_dqCoef.ptr, g_dqLevel.ptr, g_rqDesc.ptr, 1, g_rqRates.ptr, bd, g_dqSum.ptr, (size_t)n, g_dqWs.ptr, wsBytes, nullptr));
+  std::vector<TCoeff> lv(n);
+  uint32_t sum = 0;
+  VVCGPU(vvcgpu_memcpy_d2h(lv.data(), g_dqLevel.ptr, (size_t)n * sizeof(TCoeff), nullptr));
+  VVCGPU(vvcgpu_memcpy_d2h(&sum, g_dqSum.ptr, sizeof sum, nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  CoeffBuf dst = tu.getCoeffs(compID);
+  if (getenv("VVCGPU_SHIM_RDOQ_VERIFY"))
+  {
+    TCoeff refSum = uiAbsSum;
+    typedef void (*real_t)(QuantRDOQ*, TransformUnit*, const ComponentID*, const CCoeffBuf*, TCoeff*, const QpParam*, const Ctx*);
+    static real_t real = (real_t)dlsym(RTLD_DEFAULT, "vtmhooks_real_rdoq");
+    if (real) real(self, &tu, &compID, &pSrc, &refSum, &cQP, &ctx);
+    bool same = (uint32_t)refSum == (uint32_t)uiAbsSum + sum;
+    for (int y = 0; y < h && same; y++) same = memcmp(dst.buf + (size_t)y * dst.stride, &lv[(size_t)y * w], w * sizeof(TCoeff)) == 0;
+    if (!same) fprintf(stderr, "[vvcgpu shim] RDOQ mismatch: %dx%d comp %d ts %d qp %d lambda %f sbh %d sum %u vs %d\n", w, h, (int)compID, (int)tu.transformSkip[compID], cQP.Qp,
+                       d.lambda, (int)d.sign_hiding, sum, (int)refSum);
+  }
+  for (int y = 0; y < h; y++) memcpy(dst.buf + (size_t)y * dst.stride, &lv[(size_t)y * w], w * sizeof(TCoeff));
+  uiAbsSum += (TCoeff)sum;                                                       // the reference adds to the caller's sum (:1271)
+  g_calls[27]++;
   return 1;
 }
 
