@@ -92,6 +92,34 @@ for B in (8, 16, 32):
         line += "  | reference DepQuant::quant 1 core %.2f us/TU -> x%.0f" % (dt / k * 1e6, (n / ms / 1e3) / (k / dt / 1e6))
     print(line)
 
+# ---- N1: rate-distortion optimised quantiser (dependent quantisation off), rate tables from the committed golden fixture
+gq = np.load(os.path.join(ROOT, "tests", "golden", "rdoq.npz"))
+rq_rates = np.ascontiguousarray(gq["rates"][:4]).view(ops.RDOQ_RATES)
+if R is not None:
+    R.vtmref_rdoq.restype = C.c_uint32
+for B in (4, 8, 16, 32):
+    n = (W // B) * (H // B) if B > 4 else (W // 8) * (H // 8)
+    yy, xx = np.mgrid[0:B, 0:B]
+    decay = np.exp(-(xx / B * 3 + yy / B * 3)).reshape(-1)
+    coef = (rng.normal(0, 1500, (n, B * B)) * decay).astype(np.int32).reshape(-1)
+    d = np.zeros(n, ops.RDOQ_DESC)
+    d["coeff_off"] = d["level_off"] = np.arange(n) * B * B
+    d["lambda"], d["qp"], d["rates_idx"], d["w"], d["h"], d["luma"], d["sign_hiding"] = 60.0, 44, rng.integers(0, 4, n), B, B, 1, 1
+    dc, dd, dr = torch.from_numpy(coef).cuda(), ops.struct_to_device(d), ops.struct_to_device(rq_rates)
+    level = torch.zeros(n * B * B, dtype=torch.int32, device="cuda")
+    ms = gpu_ms(lambda: ops.rdoq_batch(dc, level, dd, n, dr, n * B * B, bd), reps=3)
+    nzf = float((level != 0).float().mean().cpu())
+    line = "N1 RDOQ + sign hiding %2dx%-2d: %6d TUs %.3f ms  %.2f M TU/s  (%.0f%% non-zero levels)" % (B, B, n, ms, n / ms / 1e3, 100 * nzf)
+    if R is not None:
+        k = 1500
+        lv = np.zeros(B * B, np.int32)
+        t = time.perf_counter()
+        for i in range(k):
+            R.vtmref_rdoq(p(coef[i * B * B:(i + 1) * B * B]), p(lv), B, B, 0, bd, 44, C.c_double(60.0), 32, 0, 0, 1, 0, None)
+        dt = time.perf_counter() - t
+        line += "  | reference QuantRDOQ::quant 1 core %.2f us/TU -> x%.0f" % (dt / k * 1e6, (n / ms / 1e3) / (k / dt / 1e6))
+    print(line)
+
 pred = rng.integers(0, 1024, (H, W)).astype(np.int16)
 resi = rng.integers(-255, 256, H * W).astype(np.int16)
 for B in (16, 64):
