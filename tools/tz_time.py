@@ -21,13 +21,14 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--cpu-sample", type=int, default=1500)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--team", type=int, default=0, help="cfg.wg_per_pu")
+ap.add_argument("--range", type=int, default=96, help="cfg.search_range")
 ap.add_argument("--near", action="store_true", help="start vectors within +-2 samples of the true displacement (the raster stage is rarely entered)")
 a = ap.parse_args()
 rng = np.random.default_rng(11)
 W, H, M = 3840, 2160, 160
 org, ref_ = cases.tz_planes(rng, W, H, M, 10, motion=(11, -6))
 dorg, dref = torch.from_numpy(org).cuda(), torch.from_numpy(ref_).cuda()
-cfg = cases.tz_cfg(W, H, M, 30.0, search_range=96, wg_per_pu=a.team)
+cfg = cases.tz_cfg(W, H, M, 30.0, search_range=a.range, wg_per_pu=a.team)
 for size in (16, 32, 64):
     xs, ys = np.meshgrid(np.arange(0, W - size + 1, size), np.arange(0, H - size + 1, size))
     n = xs.size

@@ -281,64 +281,85 @@ struct TzTeam
   }
 
 
-  // Raster round, one raster row (fixed y) at a time: the probes of a row are step samples apart, so their block rows overlap in
-  // memory.  The wavefront stages the contiguous reference segment ((nx - 1) * step + w samples) of several block rows in LDS with
-  // coalesced dword loads (the next chunk is in flight in registers while the current one is consumed), lane i then takes probe i
-  // of the raster row: broadcast 16-byte reads of the original row, dword reads of the segment at its own offset + v_alignbit for
-  // odd offsets.  A wavefront executes in order, so its private LDS chunk needs no second buffer.  TEAM 4 deals the raster rows to
-  // its four wavefronts.  Returns false (generic path) when the block is not LDS-resident, narrower than 32 (measured: the generic
-  // path with its full lane use is faster there) or not a multiple of 8 wide, a segment does not fit, a probe would be clamped, or a raster row has more than 64 probes.
+  // Raster round through wave-private LDS.  The probes of a raster row (fixed y) are step samples apart, so their block rows overlap in
+  // memory: a pass takes K raster rows x T probes (K * T <= 64 lanes; long raster rows are cut into tiles of T, short ones are taken
+  // K at a time), stages for several block rows the K contiguous reference segments ((T - 1) * step + w samples each) in LDS with
+  // coalesced dword loads (the next chunk is in flight in registers while the current one is consumed), and lane (jj, i) evaluates
+  // its probe from LDS: broadcast 16-byte reads of the original row, dword reads of the segment at its own offset + v_alignbit for
+  // odd offsets.  A wavefront executes in order, so its private chunk needs no second buffer.  TEAM 4 deals the passes to its four
+  // wavefronts.  Returns false (generic path) when the block is not LDS-resident, narrower than 32 (measured: the generic path with
+  // its full lane use is faster there) or not a multiple of 8 wide, a segment does not fit, or a probe would be clamped.
   __device__ __forceinline__ bool raster_rows(const TzRound& R, unsigned long long& key)
   {
     const int step = R.d, nx = R.nx, ny = R.n / R.nx;
-    if (!orgL || nx > 64 || w < 32 || (w & 7) || (rs & 1) || (((nx - 1) * step + w + 3) >> 1) > TZ_SEG_DWORDS) return false;
+    if (!orgL || w < 32 || (w & 7) || (rs & 1) || step < 1) return false;
     if (refX + R.win.left < rx0 || refX + R.win.left + (nx - 1) * step > rx1 || refY + R.win.top < ry0 || refY + R.win.top + (ny - 1) * step > ry1) return false;
+    const int ntiles = (nx + 63) >> 6, T = (nx + ntiles - 1) / ntiles;     // probes per tile, balanced
+    const int nd = ((T - 1) * step + w + 2) >> 1;                          // dwords of one segment, whatever its sub-dword phase
+    if (nd > TZ_SEG_DWORDS) return false;
+    const int K = max(1, min(min(64 / T, ny), (64 * TZ_SEG_REGS) / (2 * nd)));     // raster rows per pass (at least two block rows per chunk)
     const int lane = tl & 63, wave = TEAM == 4 ? tl >> 6 : 0;
     const int rows = h >> subShift, halfW = w >> 1;
     const ptrdiff_t gstep = ((ptrdiff_t)rs << subShift) >> 1;             // dwords between block rows
     const Pel* first = ref + (ptrdiff_t)(refY + R.win.top) * rs + refX + R.win.left;
-    const int pOff = (int)((reinterpret_cast<uintptr_t>(first) & 2) >> 1); // sample 0 of a segment sits at LDS sample pOff (rs is even: same on every row)
-    const int nd = (pOff + (nx - 1) * step + w + 1) >> 1;                 // dwords that hold samples some probe reads
+    const int RB = min(rows, (64 * TZ_SEG_REGS) / (K * nd));              // block rows per chunk
     const unsigned rnd = (unsigned)(0x100000000ull / (unsigned)nd) + 1u;  // i / nd == umulhi(i, rnd) for the i used here
-    const int RB = min(rows, (64 * TZ_SEG_REGS) / nd);                    // block rows per chunk (nd <= TZ_SEG_DWORDS: at least 2)
-    int ldRow[TZ_SEG_REGS], ldCol[TZ_SEG_REGS];
+    const unsigned rK = (unsigned)(0x100000000ull / (unsigned)K) + 1u, rT = (unsigned)(0x100000000ull / (unsigned)T) + 1u;
+    // staging: dword lane + 64 k of the chunk = (block row, segment, column)
+    int ldRow[TZ_SEG_REGS], ldSeg[TZ_SEG_REGS], ldCol[TZ_SEG_REGS];
 #pragma unroll
     for (int k = 0; k < TZ_SEG_REGS; k++)
     {
-      const int i = lane + 64 * k;
-      ldRow[k] = (int)__umulhi((unsigned)i, rnd); ldCol[k] = i - ldRow[k] * nd;
+      const int i = lane + 64 * k, rsg = (int)__umulhi((unsigned)i, rnd);
+      ldCol[k] = i - rsg * nd;
+      ldRow[k] = K > 1 ? (int)__umulhi((unsigned)rsg, rK) : rsg; ldSeg[k] = rsg - ldRow[k] * K;
       if (ldRow[k] >= RB) ldRow[k] = -1;
     }
-    const bool live = lane < nx;
-    const int x = R.win.left + lane * step;
-    const int myOff = lane * step + pOff, myDw = myOff >> 1;
-    const unsigned sh = (unsigned)(myOff & 1) << 4;
-    const int chunks = (rows + RB - 1) / RB, total = ((ny - wave + TEAM - 1) / TEAM) * chunks;   // chunks this wavefront walks
+    const int jj = T < 64 ? (int)__umulhi((unsigned)lane, rT) : 0, ii = lane - jj * T;     // this lane's probe of a pass
+    const int groups = (ny + K - 1) / K, chunks = (rows + RB - 1) / RB;
     unsigned pf[TZ_SEG_REGS];
-    auto fetch = [&](int t)                                                 // chunk t of this wavefront -> registers
+    // a wavefront walks (pass, chunk) pairs; the pair after the current one is tracked by increments (no divisions in the loop)
+    struct Pos { int g, q, c; };
+    auto advance = [&](Pos& p) { if (++p.c == chunks) { p.c = 0; p.q += TEAM; while (p.q >= ntiles) { p.q -= ntiles; p.g++; } } };
+    auto fetch = [&](const Pos& p)                                          // chunk -> registers
     {
-      const int j = wave + (t / chunks) * TEAM, r0 = (t % chunks) * RB;
-      const unsigned* g = reinterpret_cast<const unsigned*>(reinterpret_cast<uintptr_t>(first + (ptrdiff_t)j * step * rs) & ~(uintptr_t)3);
+      const int r0 = p.c * RB;
+      const Pel* org0 = first + (ptrdiff_t)(p.g * K) * step * rs + p.q * T * step;
+      const int nxq = min(T, nx - p.q * T), pOff = (int)((reinterpret_cast<uintptr_t>(org0) & 2) >> 1);
+      const int need = (pOff + (nxq - 1) * step + w + 1) >> 1;             // dwords that hold samples some probe of the tile reads
+      const unsigned* gp = reinterpret_cast<const unsigned*>(reinterpret_cast<uintptr_t>(org0) & ~(uintptr_t)3);
 #pragma unroll
       for (int k = 0; k < TZ_SEG_REGS; k++)
-        pf[k] = (ldRow[k] >= 0 && r0 + ldRow[k] < rows) ? g[(ptrdiff_t)(r0 + ldRow[k]) * gstep + ldCol[k]] : 0u;
+      {
+        const bool on = ldRow[k] >= 0 && r0 + ldRow[k] < rows && p.g * K + ldSeg[k] < ny;
+        pf[k] = on ? gp[(ptrdiff_t)ldSeg[k] * step * (rs >> 1) + (ptrdiff_t)(r0 + ldRow[k]) * gstep + min(ldCol[k], need - 1)] : 0u;
+      }
     };
-    if (total > 0) fetch(0);
+    Pos cur = { 0, wave, 0 };
+    while (cur.q >= ntiles) { cur.q -= ntiles; cur.g++; }
+    Pos nxt = cur;
+    if (cur.g < groups) fetch(cur);
     unsigned acc = 0;
-    for (int t = 0; t < total; t++)
+    while (cur.g < groups)
     {
-      const int jj = t / chunks, c = t - jj * chunks, r0 = c * RB;
+      const int r0 = cur.c * RB, g = cur.g, q = cur.q, c = cur.c;
 #pragma unroll
       for (int k = 0; k < TZ_SEG_REGS; k++) if (ldRow[k] >= 0) segL[lane + 64 * k] = pf[k] ^ bias;
       __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier();
-      if (t + 1 < total) fetch(t + 1);
-      if (live)
+      advance(nxt);
+      if (nxt.g < groups) fetch(nxt);
+      const int j = g * K + jj, i = q * T + ii;
+      if (jj < K && j < ny && ii < T && i < nx)
       {
+        const Pel* org0 = first + (ptrdiff_t)(g * K) * step * rs + q * T * step;
+        const int pOff = (int)((reinterpret_cast<uintptr_t>(org0) & 2) >> 1);
+        const int myOff = ii * step + pOff, myDw = myOff >> 1;
+        const unsigned sh = (unsigned)(myOff & 1) << 4;
         const int nr = min(RB, rows - r0);
         for (int r = 0; r < nr; r++)
         {
           const unsigned* o = orgL + (r0 + r) * halfW;
-          const unsigned* sp = segL + r * nd + myDw;
+          const unsigned* sp = segL + (r * K + jj) * nd + myDw;
           unsigned d0 = sp[0];
           for (int k = 0; k < halfW; k += 4)
           {
@@ -353,13 +374,13 @@ struct TzTeam
         }
         if (c == chunks - 1)
         {
-          const int j = wave + jj * TEAM, y = R.win.top + j * step;
-          const unsigned long long cost = ((unsigned long long)acc << subShift) + mvcost(x, y);
-          key = min(key, (cost << 16) | (unsigned)(j * nx + lane));
+          const unsigned long long cost = ((unsigned long long)acc << subShift) + mvcost(R.win.left + i * step, R.win.top + j * step);
+          key = min(key, (cost << 16) | (unsigned)(j * nx + i));
           acc = 0;
         }
       }
       __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront"); __builtin_amdgcn_wave_barrier();
+      cur = nxt;
     }
     // fold the lanes of this wavefront (the tail of round() folds across groups of G lanes only)
     for (int m = 1; m < 64; m <<= 1) { const unsigned long long ok = __shfl_xor(key, m); key = min(key, ok); }
