@@ -31,6 +31,8 @@ CLIPS = [
     ("ldpcrc_208x120_10b_q32", "@tests/golden/bitstreams/test_lowdelay.cfg", 208, 120, 10, 2, 32, 20261008, 2),
     ("aisum_208x120_8b_q37", "@tests/golden/bitstreams/test_intra.cfg", 208, 120, 8, 1, 37, 20261009, 3),
     # dependent quantisation off, sign hiding on: every TU goes through QuantRDOQ::xRateDistOptQuant incl. its sign-hiding pass
+    # hierarchical-B random access (own cfg, GOP 4): bi-predictive search / compensation inside the encoder
+    ("rab_208x120_10b_q32", "@tests/golden/bitstreams/test_randomaccess.cfg", 208, 120, 10, 9, 32, 20261011),
     ("ldprdoq_208x120_10b_q32", "@tests/golden/bitstreams/test_lowdelay.cfg", 208, 120, 10, 2, 32, 20261010, 1, ["--DepQuant=0", "--SignHideFlag=1"]),
 ]
 

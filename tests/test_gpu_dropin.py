@@ -71,7 +71,7 @@ def test_decoder_fallthrough_matches(tmp_path):
 
 
 @needs_ref
-@pytest.mark.parametrize("name", ["ldp_208x120_10b_q27", "ai_416x240_8b_q37own", "ldpfs_208x120_10b_q32", "ldpcrc_208x120_10b_q32", "aisum_208x120_8b_q37", "ldprdoq_208x120_10b_q32"])
+@pytest.mark.parametrize("name", ["ldp_208x120_10b_q27", "ai_416x240_8b_q37own", "ldpfs_208x120_10b_q32", "ldpcrc_208x120_10b_q32", "aisum_208x120_8b_q37", "ldprdoq_208x120_10b_q32", "rab_208x120_10b_q32"])
 def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
     """the reference ENCODER with deblocking, the SAO statistics (getStatistics) and the ALF covariances
     (deriveStatsForFiltering), the per-CTU SAO offsetting (offsetCTU) and the three ALF table slots computed on the GPU inside its loop: every SAO / ALF decision and therefore the bitstream must be
@@ -107,6 +107,9 @@ def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
         assert calls[18] > 0 and calls[19] > 0, line[-1]   # affine gradient table slots (Sobel planes, equal coefficients)
         assert calls[20] > 0, line[-1]         # xTZSearch: the whole integer TZ search of every PU on the device (next row N2)
         assert "TZ mismatch" not in r.stderr, r.stderr[-2000:]
+    if name.startswith("rab_"):
+        # hierarchical-B random access: uni- and bi-predictive searches of every B picture (fractional refinement, TZ search)
+        assert calls[14] > 0 and calls[20] > 0 and "TZ mismatch" not in r.stderr, line[-1] + r.stderr[-1500:]
     assert calls[12] > 0 and calls[16] > 0, line[-1]   # forward transforms (32/64-side TUs); de-quantisation + inverse (every TU)
     assert calls[21] > 0, line[-1]             # predIntraAng: every intra mode candidate of the first calls (capped, VVCGPU_SHIM_INTRA_LIMIT)
     assert calls[24] > 0 and "CCLM mismatch" not in r.stderr, line[-1] + r.stderr[-1500:]   # predIntraChromaLM on the GPU, A/B-checked per call

@@ -43,10 +43,28 @@ def test_workload_matches_oracle_416x240():
         _cmp(k + "#2", gout2[k], cout[k])
 
 
-def test_workload_properties_1080p():
+@pytest.mark.parametrize("qp", [22, 27, 37])
+def test_workload_matches_oracle_qp_sweep(qp):
+    """BASELINE configs[2] quotes QP 22 / 27 / 32 / 37: the quantiser, the de-quantiser, the motion-cost lambda and the
+    deblocking QP field follow the base QP; every output is compared with the oracle (QP 32 is the test above)."""
+    from vvcsoftware_vtm_amd.workload import Workload
+    wl = Workload(416, 240, 10, seed=13 + qp, raster_range=20, qp=qp)
+    _, gout = wl.run_gpu()
+    torch.cuda.synchronize()
+    cout, _ = wl.run_cpu(oracle(), "port")
+    for k in cout:
+        if gout[k] is None:
+            assert k.startswith("me_sad_")
+            continue
+        _cmp(k, gout[k], cout[k])
+
+
+@pytest.mark.parametrize("width,height,me,qp", [(1920, 1080, 32, 32), (3840, 2160, 64, 22), (3840, 2160, 16, 37), (7680, 4320, 64, 32)])
+def test_workload_properties_full_size(width, height, me, qp):
+    """size-independent properties at the picture sizes of BASELINE configs[1..4] (1080p, 4K at the ends of the QP sweep, 8K)."""
     from vvcsoftware_vtm_amd.workload import Workload
     from vvcsoftware_vtm_amd import ops
-    wl = Workload(1920, 1080, 10, seed=5, raster_range=40, me_sizes=(32,))
+    wl = Workload(width, height, 10, seed=5, raster_range=40, me_sizes=(me,), qp=qp)
     st, out = wl.run_gpu()
     torch.cuda.synchronize()
     org = wl.org
@@ -62,16 +80,24 @@ def test_workload_properties_1080p():
     tot = 0
     for j in range(ny):
         for i in range(nx):
-            wdt, hgt = min(128, 1920 - 128 * i), min(128, 1080 - 128 * j)
+            wdt, hgt = min(128, width - 128 * i), min(128, height - 128 * j)
             tot += (wdt - 5 if i < nx - 1 else wdt) * (hgt - 4 if j < ny - 1 else hgt)
     assert int(s[:, 4, 1, :].sum()) == tot
     # ME: the best candidate lies on the grid and its cost covers its SAD
-    b = out["me_best_32_9"].cpu().numpy().view(ops.SEARCH_BEST)
+    b = out["me_best_%d_9" % me].cpu().numpy().view(ops.SEARCH_BEST)
     assert np.all(np.abs(b["x"]) <= 4) and np.all(np.abs(b["y"]) <= 4) and np.all(b["cost"] >= b["sad"])
     # deblock + SAO + ALF never leave the sample range
     for p in out["final"]:
         v = p.cpu().numpy()
         assert v.min() >= 0 and v.max() <= 1023
+    # the overlapped (bench) schedule on the resident state reproduces the serial step bit for bit at this size
+    fin = [p.cpu().clone() for p in out["final"]]
+    coef = out["coef"].cpu().clone()
+    st, ov = wl.run_gpu(st, overlap=True)
+    torch.cuda.synchronize()
+    assert torch.equal(ov["coef"].cpu(), coef)
+    for a, b2 in zip(ov["final"], fin):
+        assert torch.equal(a.cpu(), b2)
 
 
 def test_overlapped_schedule_equals_serial():

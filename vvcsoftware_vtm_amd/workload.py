@@ -77,12 +77,13 @@ def _pad(plane, m):
 
 
 class Workload:
-    def __init__(self, width, height, bit_depth=10, seed=20261003, raster_range=96, me_sizes=(16, 32, 64)):
+    def __init__(self, width, height, bit_depth=10, seed=20261003, raster_range=96, me_sizes=(16, 32, 64), qp=32):
         assert width % 8 == 0 and height % 8 == 0
         self.w, self.h, self.bd = width, height, bit_depth
         self.mx = (1 << bit_depth) - 1
         self.seed = seed
         self.raster_range = raster_range
+        self.qp = qp                                   # base QP (BASELINE configs: 22 / 27 / 32 / 37); quantiser, de-quantiser and the deblocking QP field follow it
         rng = np.random.default_rng(seed)
         frames = synth.gen_yuv(width, height, 3, bit_depth, seed)
         to16 = lambda fr: [p.astype(np.int16) for p in fr]
@@ -103,7 +104,8 @@ class Workload:
             self.me[s] = blk
         nr = 2 * (raster_range // 5) + 1
         self.me_grids = [(-4, -4, 9, 9, 1, 1), (-5 * (nr // 2), -5 * (nr // 2), nr, nr, 5, 5)]
-        self.mvcost = MvCost(float(np.sqrt(57.0)), 0, 0, 2, 0)
+        lam = float(np.sqrt(57.0 * 2.0 ** ((self.qp - 32) / 3.0)))     # sqrt(lambda) of the motion cost, doubling every 3 QP steps
+        self.mvcost = MvCost(lam, 0, 0, 2, 0)
 
         # ---- fractional refinement: every full 16x16 block around a seeded integer MV --------------------------
         b16 = self.me[16] if 16 in self.me else None
@@ -118,7 +120,7 @@ class Workload:
         fb["mv_x"], fb["mv_y"] = imv[:, 0], imv[:, 1]
         fb["ref_x"], fb["ref_y"] = b16["org_x"] + m + imv[:, 0], b16["org_y"] + m + imv[:, 1]
         self.frac = fb
-        self.frac_mvcost = MvCost(float(np.sqrt(57.0)), 3, -2, 0, 0)
+        self.frac_mvcost = MvCost(lam, 3, -2, 0, 0)
 
         # ---- MC: bi-pred 16x16 PUs, quarter-pel MVs ----------------------------------------------------------
         xs, ys = np.arange(0, width, 16), np.arange(0, height, 16)
@@ -170,8 +172,8 @@ class Workload:
                         coff += s * s
         self.tr = np.array(rows, dtype=TR_DESC)
         self.n_coef = coff
-        # quantiser between the transforms: Quant::quant without RDOQ (P slice, sign bit hiding) and Quant::dequant at QP 32
-        qp = 32 + 6 * (bit_depth - 8)
+        # quantiser between the transforms: Quant::quant without RDOQ (P slice, sign bit hiding) and Quant::dequant at the base QP
+        qp = self.qp + 6 * (bit_depth - 8)
         self.quant = np.zeros(self.tr.size, QUANT_DESC)
         self.quant["coeff_off"] = self.quant["level_off"] = self.tr["coeff_off"]
         self.quant["w"], self.quant["h"], self.quant["sign_hiding"], self.quant["qp"] = self.tr["w"], self.tr["h"], 1, qp
@@ -204,7 +206,7 @@ class Workload:
             bs = np.where(either, 2, bs_rand)
             return np.where(on, bs | (np.where(either, 2, 0) << 2), 0).astype(np.uint8)
         self.edge_ver, self.edge_hor = edge_map(ux, 1), edge_map(uy, 0)
-        self.qp_luma = np.repeat(np.repeat(rng.integers(26, 40, ((height + 7) // 8, (width + 7) // 8)), 2, axis=0), 2, axis=1)[:h4, :w4].astype(np.int8)
+        self.qp_luma = np.repeat(np.repeat(rng.integers(self.qp - 6, self.qp + 8, ((height + 7) // 8, (width + 7) // 8)), 2, axis=0), 2, axis=1)[:h4, :w4].astype(np.int8)
         self.qp_chroma = self.qp_luma.copy()
         self.dbk_cfg = DeblockCfg(bit_depth, bit_depth, 0, 0, 0, 0, (C.c_int32 * 3)(0, 0, 0), (C.c_int32 * 3)(self.mx, self.mx, self.mx))
 
