@@ -337,14 +337,14 @@ __global__ __launch_bounds__(SS_THREADS) void sad_search_kernel(const Pel* __res
 // full 8-byte words in d[], plus the two half words at the ends of the span that are only half used (x0 = high dword of word 0
 // when OA >= 2, x1 = low dword of the last word when OA is 0 or 3): 13-14 VGPRs per chunk-row instead of 16, which is what
 // lets the kernel fit 80 VGPRs (6 waves per SIMD) without scratch.
-struct R5cStage { unsigned ov[2][9]; unsigned long long d[2][7]; unsigned x0[2], x1[2]; };
+struct R5cStage { unsigned ov[2][8]; unsigned long long d[2][7]; unsigned x0[2], x1[2]; };
 
-template <int OA, bool OODD>
-__device__ __forceinline__ void r5c_issue_row(unsigned (&ov)[9], unsigned long long (&d)[7], unsigned& x0, unsigned& x1,
+template <int OA>
+__device__ __forceinline__ void r5c_issue_row(unsigned (&ov)[8], unsigned long long (&d)[7], unsigned& x0, unsigned& x1,
                                               const unsigned* __restrict__ op, unsigned a)
 {
 #pragma unroll
-  for (int k = 0; k < (OODD ? 9 : 8); k++) ov[k] = op[k];
+  for (int k = 0; k < 8; k++) ov[k] = op[k];
   // single ds_read_b64 (2 LDS cycles each); left to the compiler they are merged into ds_read2_b64, which runs at half
   // that rate.  The compiler cannot see that the destination registers stay busy until the explicit lgkmcnt(0) of the
   // pipeline: r5c_compute pins every one of them live past it, and nothing that is not needed is loaded.
@@ -366,14 +366,20 @@ __device__ __forceinline__ void r5c_issue_row(unsigned (&ov)[9], unsigned long l
                  : "=&v"(x0), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(x1) : "v"(a) : "memory");
 }
 
-// acc0 / acc1 = positions i / i+2.  Class c+2 starts 10 samples after class c: for OA in {0,1} that is word +2 with
-// sub-word offset OA+2, for OA in {2,3} word +3 with offset OA-2 -- all compile-time.
-template <int OA, bool OODD>
+// acc0 / acc1 = positions i / i+2.  Class c+2 starts 10 samples after class c: dword (OA + 10) >> 1 of the span, same parity.
+// The org row comes PACKED (r5c_pack_org_kernel): already biased, and in two layouts per 16-sample chunk --
+//   even: dword k = samples (2k, 2k+1);
+//   odd : dword k < 7 = samples (2k+1, 2k+2), dword 7 = (15 | 0 << 16)
+// so that a position whose window starts on an ODD sample needs no realignment of its nine window dwords: the seven inner
+// ones pair up with the shifted org pairs as they are, and the two half-used end dwords are merged by ONE v_perm/v_bfi
+// (low half of the last, high half of the first) against the org pair (15, 0): 8 v_sad_u16 + 1 merge per position and
+// chunk-row instead of 8 + 8, and no scalar work on the org row at all (no bias xor, no funnel shift for odd block origins).
+template <int OA>
 __device__ __forceinline__ void r5c_compute(const R5cStage& st, unsigned& acc0, unsigned& acc1)
 {
-  constexpr int OB = OA ^ 2, WB = OA < 2 ? 2 : 3;
   constexpr int W0 = OA >= 2 ? 1 : 0;                       // first word held in d[]
   constexpr int NF = OA == 1 ? 7 : 6;                       // full words in d[]
+  constexpr int IA = OA >> 1, IB = (OA + 10) >> 1;          // first dword of the two positions
 #pragma unroll
   for (int j = 0; j < 2; j++)
   {
@@ -387,62 +393,74 @@ __device__ __forceinline__ void r5c_compute(const R5cStage& st, unsigned& acc0, 
     if (OA >= 2) { asm volatile("" :: "v"(st.x0[j])); dd[1] = st.x0[j]; }
     if (OA == 0) { asm volatile("" :: "v"(st.x1[j])); dd[12] = st.x1[j]; }
     if (OA == 3) { asm volatile("" :: "v"(st.x1[j])); dd[14] = st.x1[j]; }
-#pragma unroll
-    for (int k = 0; k < 8; k++)
+    if (OA & 1)
     {
-      // odd block origin: funnel the wave-uniform pair down by one sample (a 64-bit scalar shift)
-      const unsigned o = (OODD ? (unsigned)(((((unsigned long long)st.ov[j][k + 1]) << 32) | st.ov[j][k]) >> 16) : st.ov[j][k]) ^ 0x80008000u;
-      const int ia = k + (OA >> 1), ib = 2 * WB + k + (OB >> 1);
-      acc0 = __builtin_amdgcn_sad_u16(o, (OA & 1) ? __builtin_amdgcn_alignbit(dd[ia + 1], dd[ia], 16) : dd[ia], acc0);
-      acc1 = __builtin_amdgcn_sad_u16(o, (OB & 1) ? __builtin_amdgcn_alignbit(dd[ib + 1], dd[ib], 16) : dd[ib], acc1);
+#pragma unroll
+      for (int k = 0; k < 7; k++)
+      {
+        acc0 = __builtin_amdgcn_sad_u16(st.ov[j][k], dd[IA + 1 + k], acc0);
+        acc1 = __builtin_amdgcn_sad_u16(st.ov[j][k], dd[IB + 1 + k], acc1);
+      }
+      acc0 = __builtin_amdgcn_sad_u16(st.ov[j][7], (dd[IA + 8] & 0xFFFFu) | (dd[IA] & 0xFFFF0000u), acc0);
+      acc1 = __builtin_amdgcn_sad_u16(st.ov[j][7], (dd[IB + 8] & 0xFFFFu) | (dd[IB] & 0xFFFF0000u), acc1);
+    }
+    else
+    {
+#pragma unroll
+      for (int k = 0; k < 8; k++)
+      {
+        acc0 = __builtin_amdgcn_sad_u16(st.ov[j][k], dd[IA + k], acc0);
+        acc1 = __builtin_amdgcn_sad_u16(st.ov[j][k], dd[IB + k], acc1);
+      }
     }
   }
 }
 
 #define R5C_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)       /* lgkmcnt(0), vmcnt/expcnt untouched */
 
-// walks the hs x CH chunk-rows of the block; (oOff, lOff) = dword offsets of the current chunk-row in the org plane / window
+// walks the hs x CH chunk-rows of the block; (oOff, lOff) = dword offsets of the current chunk-row in the packed org / window
+// (the packed org rows follow each other without a gap: 8 dwords per chunk-row, always)
 struct R5cCursor
 {
   unsigned oOff, lOff; int ch;
-  __device__ __forceinline__ void advance(int CH, unsigned oRow, unsigned lRow)
+  __device__ __forceinline__ void advance(int CH, unsigned lRow)
   {
     ch++; oOff += 8; lOff += 8;
-    if (ch == CH) { ch = 0; oOff += oRow; lOff += lRow; }
+    if (ch == CH) { ch = 0; lOff += lRow; }
   }
 };
 
-template <int OA, bool OODD>
+template <int OA>
 __device__ __forceinline__ void r5c_issue(R5cStage& st, const unsigned* __restrict__ orgDw, unsigned base, R5cCursor& cur, int CH,
-                                          unsigned oRow, unsigned lRow)
+                                          unsigned lRow)
 {
 #pragma unroll
   for (int j = 0; j < 2; j++)
   {
-    r5c_issue_row<OA, OODD>(st.ov[j], st.d[j], st.x0[j], st.x1[j], orgDw + cur.oOff, base + cur.lOff * 4u);
-    cur.advance(CH, oRow, lRow);
+    r5c_issue_row<OA>(st.ov[j], st.d[j], st.x0[j], st.x1[j], orgDw + cur.oOff, base + cur.lOff * 4u);
+    cur.advance(CH, lRow);
   }
 }
 
-template <int OA, bool OODD>
-__device__ __forceinline__ void r5c_positions(const unsigned* __restrict__ orgDw, int osStep, unsigned base, int ldsStep,
+template <int OA>
+__device__ __forceinline__ void r5c_positions(const unsigned* __restrict__ orgDw, unsigned base, int ldsStep,
                                               int nStages, int CH, unsigned& acc0, unsigned& acc1)
 {
   R5cStage A, B;
   R5cCursor cur = { 0u, 0u, 0 };
-  const unsigned oRow = (unsigned)(osStep - 8 * CH), lRow = (unsigned)(ldsStep - 8 * CH);
-  r5c_issue<OA, OODD>(A, orgDw, base, cur, CH, oRow, lRow);
+  const unsigned lRow = (unsigned)(ldsStep - 8 * CH);
+  r5c_issue<OA>(A, orgDw, base, cur, CH, lRow);
   for (int s = 0; s < nStages; s += 2)
   {
     R5C_WAIT_LGKM0();
-    if (s + 1 < nStages) r5c_issue<OA, OODD>(B, orgDw, base, cur, CH, oRow, lRow);
+    if (s + 1 < nStages) r5c_issue<OA>(B, orgDw, base, cur, CH, lRow);
     __builtin_amdgcn_sched_barrier(0);
-    r5c_compute<OA, OODD>(A, acc0, acc1);
+    r5c_compute<OA>(A, acc0, acc1);
     if (s + 1 >= nStages) break;
     R5C_WAIT_LGKM0();
-    if (s + 2 < nStages) r5c_issue<OA, OODD>(A, orgDw, base, cur, CH, oRow, lRow);
+    if (s + 2 < nStages) r5c_issue<OA>(A, orgDw, base, cur, CH, lRow);
     __builtin_amdgcn_sched_barrier(0);
-    r5c_compute<OA, OODD>(B, acc0, acc1);
+    r5c_compute<OA>(B, acc0, acc1);
   }
 }
 
@@ -477,9 +495,32 @@ __device__ __forceinline__ void fill_window_cols(unsigned* __restrict__ lds, con
   }
 }
 
+// org rows of the raster kernel, packed per block: [block][layout even | odd][hs rows][w / 2 dwords], biased (^ 0x8000 per
+// sample), row sub-sampling and odd block origins resolved here.  Layouts per 16-sample chunk: see r5c_compute.
+// One thread per output dword; 2 * hs * w / 2 dwords per block.
+__global__ __launch_bounds__(256) void r5c_pack_org_kernel(const Pel* __restrict__ org, int os, const vvcgpu_search_blk* __restrict__ blocks,
+                                                           int nblocks, int w, int hs, int subShift, unsigned* __restrict__ packed)
+{
+  const unsigned perLayout = (unsigned)(hs * (w >> 1)), perBlock = 2u * perLayout;
+  const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (gid >= (size_t)nblocks * perBlock) return;
+  const int b = (int)(gid / perBlock);
+  const unsigned r0 = (unsigned)(gid - (size_t)b * perBlock);
+  const unsigned odd = r0 >= perLayout ? 1u : 0u, r1 = r0 - odd * perLayout;
+  const int row = (int)(r1 / (unsigned)(w >> 1)), dwInRow = (int)(r1 - (unsigned)row * (unsigned)(w >> 1));
+  const int chunk = dwInRow >> 3, k = dwInRow & 7;
+  const vvcgpu_search_blk blk = blocks[b];
+  const Pel* o = org + (size_t)(blk.org_y + (row << subShift)) * os + blk.org_x + 16 * chunk;
+  int a, c;
+  if (!odd) { a = 2 * k; c = 2 * k + 1; }
+  else if (k < 7) { a = 2 * k + 1; c = 2 * k + 2; }
+  else { a = 15; c = 0; }
+  packed[gid] = ((unsigned)(unsigned short)o[a] | ((unsigned)(unsigned short)o[c] << 16)) ^ 0x80008000u;
+}
+
 // MINW = waves per SIMD the register allocation must allow: 6 (<= 80 VGPRs) when three workgroups fit the CU's LDS, else 4
 template <int MINW>
-__global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const Pel* __restrict__ org, int os,
+__global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const unsigned* __restrict__ orgPacked,
                                                            const Pel* __restrict__ ref, int rs,
                                                            const vvcgpu_search_blk* __restrict__ blocks, int w, int h, int subShift,
                                                            int dx0, int dy0, int nx, int ny, int rowsPerStrip, int pitchDw,
@@ -523,9 +564,8 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const Pel* __re
   const int ngrp = (nj + 5) / 6, ncg = (nx + 39) / 40;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
   const int lane = tid & 63;
-  const int oodd = blk.org_x & 1;
-  const unsigned* orgDw = reinterpret_cast<const unsigned*>(org + (size_t)blk.org_y * os + blk.org_x - oodd);
-  const int osStep = (os >> 1) << subShift;
+  const unsigned layoutDw = (unsigned)(hs * (w >> 1));                     // one packed layout of the block (even, then odd)
+  const unsigned* orgDw = orgPacked + (size_t)b * 2u * layoutDw;
   const int ldsStep = pitchDw << subShift;
   const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)refL;
   unsigned long long kmin = ~0ull;
@@ -546,9 +586,7 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const Pel* __re
         const int i0 = cg * 40 + 4 * k + c;                                 // positions i0 and i0 + 2
         const int cx = 5 * (i0 < nx ? i0 : c) + off;                        // dead lanes re-read a live lane's address (broadcast)
         const unsigned base = ldsBase + (unsigned)(2 * (cx >> 2) + (min(jj, nj - 1) * 5) * pitchDw) * 4u;
-#define R5C_CALL(OV)                                                                                                            \
-        do { if (oodd) r5c_positions<OV, true>(orgDw, osStep, base, ldsStep, nStages, CH, acc0, acc1);                            \
-             else      r5c_positions<OV, false>(orgDw, osStep, base, ldsStep, nStages, CH, acc0, acc1); } while (0)
+#define R5C_CALL(OV) r5c_positions<OV>(orgDw + ((OV) & 1) * layoutDw, base, ldsStep, nStages, CH, acc0, acc1)
         if (OA == 0) R5C_CALL(0); else if (OA == 1) R5C_CALL(1); else if (OA == 2) R5C_CALL(2); else R5C_CALL(3);
 #undef R5C_CALL
       }
@@ -875,6 +913,12 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       const int items = 2 * cdiv(rps, 6);
       const int threads = items >= 8 ? 512 : items * 64;
       const int total = nblocks * nstrips;
+      const size_t packedDw = (size_t)nblocks * 2 * hsR * (w >> 1);
+      unsigned* packed = static_cast<unsigned*>(vvcgpu_scratch(st0, packedDw * sizeof(unsigned)));
+      if (!packed) return VVCGPU_E_DEVICE;
+      hipLaunchKernelGGL(r5c_pack_org_kernel, dim3((unsigned)((packedDw + 255) / 256)), dim3(256), 0, st0, org, org_stride, blocks, nblocks,
+                         w, hsR, sub_shift, packed);
+      VVC_LAUNCH_CHECK();
       vvcgpu_mvcost mv = {};
       if (best)
       {
@@ -885,7 +929,7 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       do {                                                                                                                      \
         if (smem > 48 * 1024)                                                                                                   \
           VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster5c_kernel<MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL(sad_raster5c_kernel<MINW>, dim3(cdiv(total, 8) * 8), dim3(threads), smem, st0, org, org_stride, ref, ref_stride, \
+        hipLaunchKernelGGL(sad_raster5c_kernel<MINW>, dim3(cdiv(total, 8) * 8), dim3(threads), smem, st0, packed, ref, ref_stride, \
                            blocks, w, h, sub_shift, dx0, dy0, nx, ny, rps, pitch, nstrips, total, (int)winB, mv, best ? 1 : 0, sad_out, best); \
       } while (0)
       if ((smem + 1024) * 3 <= 160 * 1024) LAUNCH_R5C(6); else LAUNCH_R5C(4);
