@@ -339,7 +339,8 @@ __global__ __launch_bounds__(SS_THREADS) void sad_search_kernel(const Pel* __res
 // lets the kernel fit 80 VGPRs (6 waves per SIMD) without scratch.
 struct R5cStage { unsigned ov[2][8]; unsigned long long d[2][7]; unsigned x0[2], x1[2]; };
 
-template <int OA>
+// ADD = constant byte offset folded into the ds_read immediates (the second chunk-row of a stage, 32 bytes on in the same row)
+template <int OA, int ADD>
 __device__ __forceinline__ void r5c_issue_row(unsigned (&ov)[8], unsigned long long (&d)[7], unsigned& x0, unsigned& x1,
                                               const unsigned* __restrict__ op, unsigned a)
 {
@@ -348,22 +349,34 @@ __device__ __forceinline__ void r5c_issue_row(unsigned (&ov)[8], unsigned long l
   // single ds_read_b64 (2 LDS cycles each); left to the compiler they are merged into ds_read2_b64, which runs at half
   // that rate.  The compiler cannot see that the destination registers stay busy until the explicit lgkmcnt(0) of the
   // pipeline: r5c_compute pins every one of them live past it, and nothing that is not needed is loaded.
+#define R5C_OFFS "i"(ADD), "i"(ADD + 4), "i"(ADD + 8), "i"(ADD + 16), "i"(ADD + 24), "i"(ADD + 32), "i"(ADD + 40), "i"(ADD + 48), "i"(ADD + 56)
+  //                %9        %10          %11          %12           %13           %14           %15           %16           %17   (after 8 outputs + address)
   if (OA == 0)        // words 0..5, low half of word 6
-    asm volatile("ds_read_b64 %0, %7\n\tds_read_b64 %1, %7 offset:8\n\tds_read_b64 %2, %7 offset:16\n\tds_read_b64 %3, %7 offset:24\n\t"
-                 "ds_read_b64 %4, %7 offset:32\n\tds_read_b64 %5, %7 offset:40\n\tds_read_b32 %6, %7 offset:48"
-                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(x1) : "v"(a) : "memory");
+  {
+    unsigned dummy;
+    asm volatile("ds_read_b64 %0, %8 offset:%9\n\tds_read_b64 %1, %8 offset:%11\n\tds_read_b64 %2, %8 offset:%12\n\tds_read_b64 %3, %8 offset:%13\n\t"
+                 "ds_read_b64 %4, %8 offset:%14\n\tds_read_b64 %5, %8 offset:%15\n\tds_read_b32 %6, %8 offset:%16"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(x1), "=&v"(dummy) : "v"(a), R5C_OFFS : "memory");
+  }
   else if (OA == 1)   // words 0..6
-    asm volatile("ds_read_b64 %0, %7\n\tds_read_b64 %1, %7 offset:8\n\tds_read_b64 %2, %7 offset:16\n\tds_read_b64 %3, %7 offset:24\n\t"
-                 "ds_read_b64 %4, %7 offset:32\n\tds_read_b64 %5, %7 offset:40\n\tds_read_b64 %6, %7 offset:48"
-                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]) : "v"(a) : "memory");
+  {
+    unsigned dummy;
+    asm volatile("ds_read_b64 %0, %8 offset:%9\n\tds_read_b64 %1, %8 offset:%11\n\tds_read_b64 %2, %8 offset:%12\n\tds_read_b64 %3, %8 offset:%13\n\t"
+                 "ds_read_b64 %4, %8 offset:%14\n\tds_read_b64 %5, %8 offset:%15\n\tds_read_b64 %6, %8 offset:%16"
+                 : "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(d[6]), "=&v"(dummy) : "v"(a), R5C_OFFS : "memory");
+  }
   else if (OA == 2)   // high half of word 0, words 1..6
-    asm volatile("ds_read_b32 %0, %7 offset:4\n\tds_read_b64 %1, %7 offset:8\n\tds_read_b64 %2, %7 offset:16\n\tds_read_b64 %3, %7 offset:24\n\t"
-                 "ds_read_b64 %4, %7 offset:32\n\tds_read_b64 %5, %7 offset:40\n\tds_read_b64 %6, %7 offset:48"
-                 : "=&v"(x0), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]) : "v"(a) : "memory");
+  {
+    unsigned dummy;
+    asm volatile("ds_read_b32 %0, %8 offset:%10\n\tds_read_b64 %1, %8 offset:%11\n\tds_read_b64 %2, %8 offset:%12\n\tds_read_b64 %3, %8 offset:%13\n\t"
+                 "ds_read_b64 %4, %8 offset:%14\n\tds_read_b64 %5, %8 offset:%15\n\tds_read_b64 %6, %8 offset:%16"
+                 : "=&v"(x0), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(dummy) : "v"(a), R5C_OFFS : "memory");
+  }
   else                // high half of word 0, words 1..6, low half of word 7
-    asm volatile("ds_read_b32 %0, %8 offset:4\n\tds_read_b64 %1, %8 offset:8\n\tds_read_b64 %2, %8 offset:16\n\tds_read_b64 %3, %8 offset:24\n\t"
-                 "ds_read_b64 %4, %8 offset:32\n\tds_read_b64 %5, %8 offset:40\n\tds_read_b64 %6, %8 offset:48\n\tds_read_b32 %7, %8 offset:56"
-                 : "=&v"(x0), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(x1) : "v"(a) : "memory");
+    asm volatile("ds_read_b32 %0, %8 offset:%10\n\tds_read_b64 %1, %8 offset:%11\n\tds_read_b64 %2, %8 offset:%12\n\tds_read_b64 %3, %8 offset:%13\n\t"
+                 "ds_read_b64 %4, %8 offset:%14\n\tds_read_b64 %5, %8 offset:%15\n\tds_read_b64 %6, %8 offset:%16\n\tds_read_b32 %7, %8 offset:%17"
+                 : "=&v"(x0), "=&v"(d[0]), "=&v"(d[1]), "=&v"(d[2]), "=&v"(d[3]), "=&v"(d[4]), "=&v"(d[5]), "=&v"(x1) : "v"(a), R5C_OFFS : "memory");
+#undef R5C_OFFS
 }
 
 // acc0 / acc1 = positions i / i+2.  Class c+2 starts 10 samples after class c: dword (OA + 10) >> 1 of the span, same parity.
@@ -416,49 +429,53 @@ __device__ __forceinline__ void r5c_compute(const R5cStage& st, unsigned& acc0, 
   }
 }
 
+#define R5C_COST_N 132                                            /* expgolomb_bits <= 65 per component */
 #define R5C_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)       /* lgkmcnt(0), vmcnt/expcnt untouched */
 
-// walks the hs x CH chunk-rows of the block; (oOff, lOff) = dword offsets of the current chunk-row in the packed org / window
-// (the packed org rows follow each other without a gap: 8 dwords per chunk-row, always)
-struct R5cCursor
-{
-  unsigned oOff, lOff; int ch;
-  __device__ __forceinline__ void advance(int CH, unsigned lRow)
-  {
-    ch++; oOff += 8; lOff += 8;
-    if (ch == CH) { ch = 0; lOff += lRow; }
-  }
-};
+// walks the hs x CH chunk-rows of the block, one stage = two chunk-rows at a time: oOff = dword offset of the current chunk-row of the packed org
+// (8 dwords per chunk-row, rows without a gap), lOff = byte offset of the current chunk-row in the window
+struct R5cCursor { unsigned oOff; unsigned lOff; int ch; };
 
-template <int OA>
+// CH1: 16-wide blocks, the two chunk-rows of a stage are two window rows; otherwise (CH even) they are neighbours in one
+// row and the second one is reached through the ds_read immediate offsets (one address add per stage)
+template <int OA, bool CH1>
 __device__ __forceinline__ void r5c_issue(R5cStage& st, const unsigned* __restrict__ orgDw, unsigned base, R5cCursor& cur, int CH,
-                                          unsigned lRow)
+                                          unsigned ldsStepB, unsigned lRowB)
 {
-#pragma unroll
-  for (int j = 0; j < 2; j++)
+  const unsigned a = base + cur.lOff;
+  const unsigned* op = orgDw + cur.oOff;                                  // wave-uniform: scalar loads
+  r5c_issue_row<OA, 0>(st.ov[0], st.d[0], st.x0[0], st.x1[0], op, a);
+  if (CH1)
   {
-    r5c_issue_row<OA>(st.ov[j], st.d[j], st.x0[j], st.x1[j], orgDw + cur.oOff, base + cur.lOff * 4u);
-    cur.advance(CH, lRow);
+    r5c_issue_row<OA, 0>(st.ov[1], st.d[1], st.x0[1], st.x1[1], op + 8, a + ldsStepB);
+    cur.lOff += 2 * ldsStepB;
   }
+  else
+  {
+    r5c_issue_row<OA, 32>(st.ov[1], st.d[1], st.x0[1], st.x1[1], op + 8, a);
+    cur.ch += 2; cur.lOff += 64;
+    if (cur.ch == CH) { cur.ch = 0; cur.lOff += lRowB; }
+  }
+  cur.oOff += 16;
 }
 
-template <int OA>
+template <int OA, bool CH1>
 __device__ __forceinline__ void r5c_positions(const unsigned* __restrict__ orgDw, unsigned base, int ldsStep,
                                               int nStages, int CH, unsigned& acc0, unsigned& acc1)
 {
   R5cStage A, B;
   R5cCursor cur = { 0u, 0u, 0 };
-  const unsigned lRow = (unsigned)(ldsStep - 8 * CH);
-  r5c_issue<OA>(A, orgDw, base, cur, CH, lRow);
+  const unsigned ldsStepB = (unsigned)ldsStep * 4u, lRowB = (unsigned)(ldsStep - 8 * CH) * 4u;
+  r5c_issue<OA, CH1>(A, orgDw, base, cur, CH, ldsStepB, lRowB);
   for (int s = 0; s < nStages; s += 2)
   {
     R5C_WAIT_LGKM0();
-    if (s + 1 < nStages) r5c_issue<OA>(B, orgDw, base, cur, CH, lRow);
+    if (s + 1 < nStages) r5c_issue<OA, CH1>(B, orgDw, base, cur, CH, ldsStepB, lRowB);
     __builtin_amdgcn_sched_barrier(0);
     r5c_compute<OA>(A, acc0, acc1);
     if (s + 1 >= nStages) break;
     R5C_WAIT_LGKM0();
-    if (s + 2 < nStages) r5c_issue<OA>(A, orgDw, base, cur, CH, lRow);
+    if (s + 2 < nStages) r5c_issue<OA, CH1>(A, orgDw, base, cur, CH, ldsStepB, lRowB);
     __builtin_amdgcn_sched_barrier(0);
     r5c_compute<OA>(B, acc0, acc1);
   }
@@ -548,9 +565,13 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const unsigned*
                       ((Ww - 1 + off) >> 3) + 1, tid, (int)blockDim.x);
   unsigned char* bitsX = reinterpret_cast<unsigned char*>(refL) + winBytes;   // [nx] then [rowsPerStrip]
   unsigned char* bitsY = bitsX + nx;
+  // lambda * bits as a table over the bit count (<= 2 * 65): the double-precision product, its truncation and the 64-bit
+  // conversion are done once per workgroup and entry instead of twice per lane and wave item
+  unsigned long long* costTab = reinterpret_cast<unsigned long long*>(bitsX + ((nx + rowsPerStrip + 15) & ~15));
   if (useBest)
   {
     if (tid == 0) wgKey = ~0ull;
+    for (int n = tid; n < R5C_COST_N; n += (int)blockDim.x) costTab[n] = (unsigned long long)(mv.lambda * (double)n);
     for (int n = tid; n < nx + nj; n += (int)blockDim.x)
     {
       const int v = n < nx ? (((dx0 + n * 5) << mv.cost_scale) - mv.pred_hor) : (((dy0 + (j0 + n - nx) * 5) << mv.cost_scale) - mv.pred_ver);
@@ -586,7 +607,9 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const unsigned*
         const int i0 = cg * 40 + 4 * k + c;                                 // positions i0 and i0 + 2
         const int cx = 5 * (i0 < nx ? i0 : c) + off;                        // dead lanes re-read a live lane's address (broadcast)
         const unsigned base = ldsBase + (unsigned)(2 * (cx >> 2) + (min(jj, nj - 1) * 5) * pitchDw) * 4u;
-#define R5C_CALL(OV) r5c_positions<OV>(orgDw + ((OV) & 1) * layoutDw, base, ldsStep, nStages, CH, acc0, acc1)
+#define R5C_CALL(OV)                                                                                                            \
+        do { if (CH == 1) r5c_positions<OV, true>(orgDw + ((OV) & 1) * layoutDw, base, ldsStep, nStages, CH, acc0, acc1);          \
+             else         r5c_positions<OV, false>(orgDw + ((OV) & 1) * layoutDw, base, ldsStep, nStages, CH, acc0, acc1); } while (0)
         if (OA == 0) R5C_CALL(0); else if (OA == 1) R5C_CALL(1); else if (OA == 2) R5C_CALL(2); else R5C_CALL(3);
 #undef R5C_CALL
       }
@@ -610,7 +633,7 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const unsigned*
             if (useBest)
             {
               const unsigned bits = bitsX[i0 + 2 * p] + by;
-              const unsigned long long key = ((v + (unsigned long long)(mv.lambda * (double)bits)) << 24) | (unsigned)(idx0 + 2 * p);
+              const unsigned long long key = ((v + costTab[bits]) << 24) | (unsigned)(idx0 + 2 * p);
               kmin = key < kmin ? key : kmin;
             }
           }
@@ -907,7 +930,7 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       if (win_bytes(rps) <= budget || rps <= 3) break;
     }
     nstrips = cdiv(ny, rps);
-    const size_t winB = win_bytes(rps), smem = winB + (((size_t)nx + rps + 15) & ~(size_t)15);
+    const size_t winB = win_bytes(rps), smem = winB + (((size_t)nx + rps + 15) & ~(size_t)15) + R5C_COST_N * sizeof(unsigned long long);
     if (smem <= 150 * 1024 && ((hsR * chunks) & 1) == 0 && nx + rps <= 4096)
     {
       const int items = 2 * cdiv(rps, 6);
