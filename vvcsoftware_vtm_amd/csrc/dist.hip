@@ -429,6 +429,28 @@ __device__ __forceinline__ void r5c_compute(const R5cStage& st, unsigned& acc0, 
   }
 }
 
+// minimum of a 32-bit value over the wavefront with DPP row operations (no LDS traffic, 6 VALU); the result is wave-uniform
+__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
+{
+#define WMIN_STEP(CTRL, ROWMASK) v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROWMASK, 0xF, false))
+  WMIN_STEP(0xB1, 0xF);      // quad_perm [1,0,3,2]
+  WMIN_STEP(0x4E, 0xF);      // quad_perm [2,3,0,1]
+  WMIN_STEP(0x141, 0xF);     // row_half_mirror
+  WMIN_STEP(0x140, 0xF);     // row_mirror: every lane of a 16-lane row holds the row's minimum
+  WMIN_STEP(0x142, 0xA);     // row_bcast15 into rows 1 and 3
+  WMIN_STEP(0x143, 0xC);     // row_bcast31 into rows 2 and 3: lane 63 holds the minimum of all four rows
+#undef WMIN_STEP
+  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
+}
+// 64-bit minimum as two 32-bit passes: the high words first, then the low words of the lanes that hold the minimal high word
+__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
+{
+  const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
+  const unsigned hmin = wave_min_u32(hi);
+  const unsigned lmin = wave_min_u32(hi == hmin ? lo : 0xFFFFFFFFu);
+  return ((unsigned long long)hmin << 32) | lmin;
+}
+
 #define R5C_COST_N 132                                            /* expgolomb_bits <= 65 per component */
 #define R5C_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)       /* lgkmcnt(0), vmcnt/expcnt untouched */
 
@@ -541,7 +563,7 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const unsigned*
                                                            const Pel* __restrict__ ref, int rs,
                                                            const vvcgpu_search_blk* __restrict__ blocks, int w, int h, int subShift,
                                                            int dx0, int dy0, int nx, int ny, int rowsPerStrip, int pitchDw,
-                                                           int nstrips, int total, int winBytes, vvcgpu_mvcost mv, int useBest,
+                                                           int nstrips, unsigned invStrips, int total, int winBytes, vvcgpu_mvcost mv, int useBest,
                                                            unsigned* __restrict__ out, vvcgpu_search_best* __restrict__ best)
 {
   extern __shared__ __align__(16) unsigned refL[];
@@ -553,7 +575,7 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const unsigned*
   const int chunk = (total + 7) >> 3;
   const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
   if (item >= total) return;
-  const int b = item / nstrips, j0 = (item - b * nstrips) * rowsPerStrip;
+  const int b = nstrips == 1 ? item : (int)__umulhi((unsigned)item, invStrips), j0 = (item - b * nstrips) * rowsPerStrip;   // item / nstrips (item < 2^32 / nstrips)
   const int nj = min(rowsPerStrip, ny - j0);
   const vvcgpu_search_blk blk = blocks[b];
   const int hs = h >> subShift;
@@ -641,8 +663,7 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const unsigned*
     }
   if (useBest)
   {
-#pragma unroll
-    for (int o = 32; o > 0; o >>= 1) { const unsigned long long ok = __shfl_xor(kmin, o); kmin = ok < kmin ? ok : kmin; }
+    kmin = wave_min_u64(kmin);
     if (lane == 0 && kmin != ~0ull) atomicMin(&wgKey, kmin);
     __syncthreads();
     if (tid == 0 && wgKey != ~0ull) atomicMin(reinterpret_cast<unsigned long long*>(&best[b].cost), wgKey);
@@ -931,7 +952,8 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
     }
     nstrips = cdiv(ny, rps);
     const size_t winB = win_bytes(rps), smem = winB + (((size_t)nx + rps + 15) & ~(size_t)15) + R5C_COST_N * sizeof(unsigned long long);
-    if (smem <= 150 * 1024 && ((hsR * chunks) & 1) == 0 && nx + rps <= 4096)
+    if (smem <= 150 * 1024 && ((hsR * chunks) & 1) == 0 && nx + rps <= 4096 &&
+        (unsigned long long)nblocks * nstrips * nstrips < (1ull << 32))   // item decode by multiply-high (and total fits an int)
     {
       const int items = 2 * cdiv(rps, 6);
       const int threads = items >= 8 ? 512 : items * 64;
@@ -953,7 +975,7 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
         if (smem > 48 * 1024)                                                                                                   \
           VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster5c_kernel<MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
         hipLaunchKernelGGL(sad_raster5c_kernel<MINW>, dim3(cdiv(total, 8) * 8), dim3(threads), smem, st0, packed, ref, ref_stride, \
-                           blocks, w, h, sub_shift, dx0, dy0, nx, ny, rps, pitch, nstrips, total, (int)winB, mv, best ? 1 : 0, sad_out, best); \
+                           blocks, w, h, sub_shift, dx0, dy0, nx, ny, rps, pitch, nstrips, 0xFFFFFFFFu / (unsigned)nstrips + 1u, total, (int)winB, mv, best ? 1 : 0, sad_out, best); \
       } while (0)
       if ((smem + 1024) * 3 <= 160 * 1024) LAUNCH_R5C(6); else LAUNCH_R5C(4);
 #undef LAUNCH_R5C
