@@ -583,7 +583,7 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const unsigned*
   const int Ww = (nx - 1) * 5 + w;
   const ptrdiff_t winOff = (ptrdiff_t)(blk.ref_y + dy0 + j0 * 5) * rs + blk.ref_x + dx0;
   const int off = (int)(winOff & 7);
-  fill_window_cols<4>(refL, reinterpret_cast<const uint4*>(ref + (winOff - off)), rs >> 3, winRows, pitchDw,
+  fill_window_cols<8>(refL, reinterpret_cast<const uint4*>(ref + (winOff - off)), rs >> 3, winRows, pitchDw,
                       ((Ww - 1 + off) >> 3) + 1, tid, (int)blockDim.x);
   unsigned char* bitsX = reinterpret_cast<unsigned char*>(refL) + winBytes;   // [nx] then [rowsPerStrip]
   unsigned char* bitsY = bitsX + nx;
@@ -645,20 +645,22 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const unsigned*
       {
         const int idx0 = (j0 + jj) * nx + i0;
         unsigned* o = out ? out + (size_t)b * ny * nx + idx0 : nullptr;
-        const unsigned by = useBest ? bitsY[jj] : 0u;
-#pragma unroll
-        for (int p = 0; p < 2; p++)
-          if (i0 + 2 * p < nx)
-          {
-            const unsigned v = (p ? acc1 : acc0) << subShift;
-            if (o) o[2 * p] = v;
-            if (useBest)
-            {
-              const unsigned bits = bitsX[i0 + 2 * p] + by;
-              const unsigned long long key = ((v + costTab[bits]) << 24) | (unsigned)(idx0 + 2 * p);
-              kmin = key < kmin ? key : kmin;
-            }
-          }
+        const unsigned v0 = acc0 << subShift, v1 = acc1 << subShift;
+        const bool in0 = i0 < nx, in1 = i0 + 2 < nx;
+        if (o)
+        {
+          if (in0) o[0] = v0;
+          if (in1) o[2] = v1;
+        }
+        if (useBest)
+        {
+          // all three bit counts first, then both table entries: two dependent LDS round trips for the lane's two positions
+          const unsigned by = bitsY[jj], bx0 = bitsX[in0 ? i0 : 0], bx1 = bitsX[in1 ? i0 + 2 : 0];
+          const unsigned long long c0 = costTab[bx0 + by], c1 = costTab[bx1 + by];
+          const unsigned long long key0 = ((v0 + c0) << 24) | (unsigned)idx0, key1 = ((v1 + c1) << 24) | (unsigned)(idx0 + 2);
+          if (in0) kmin = key0 < kmin ? key0 : kmin;
+          if (in1) kmin = key1 < kmin ? key1 : kmin;
+        }
       }
     }
   if (useBest)
