@@ -311,9 +311,11 @@ __global__ __launch_bounds__(SS_THREADS) void sad_search_kernel(const Pel* __res
 
 // ---------------------------------------------------------------------------------------------------
 // Raster kernel ("r5c": step 5 in both directions = iRaster of xTZSearch under the shipped cfgs, InterSearch.cpp:1979-2000),
-// third generation of this kernel, built around the fact that it is
+// fourth generation of this kernel, built around the fact that it is
 // bound by instruction ISSUE (scalar + vector), not by LDS or HBM: rocprofv3 showed v_sad_u16 to be ~15 % of the vector
-// instructions of the first version, the rest being window fill, addressing, realignment and the argmin.
+// instructions of the first version, the rest being window fill, addressing, realignment and the argmin.  (VOP3 instructions
+// such as v_sad_u16 issue once per 4 cycles and SIMD, tools/micro/valu_rate.hip; every scalar instruction costs the wave a
+// 4-cycle issue slot as well, SQ_ACTIVE_INST_SCA.)
 //   * raster columns are split into the four classes i = c (mod 4): inside a class consecutive columns start exactly
 //     20 samples = 5 aligned 8-byte LDS words apart and the sub-word offset o = (5 i + off) & 3 is the same for every
 //     column, so a wave that works on ONE class needs no per-lane realignment: the word index and (for odd o) one
@@ -326,11 +328,14 @@ __global__ __launch_bounds__(SS_THREADS) void sad_search_kernel(const Pel* __res
 //     (5 window rows further) 10 or 22 "column steps" away: the three rows interleave into 30 distinct slots and every
 //     ds_read_b64 is conflict free at 2 LDS cycles per 8 bytes.  Dead lanes re-read a live lane's address (broadcast).
 //   * blocks wider than 16 are walked as 16-sample chunks, so one code path serves w = 16..128.
-//   * the org rows are wave-uniform scalar loads; SMEM and LDS share lgkmcnt and SMEM returns out of order, so the
+//   * the org rows are wave-uniform scalar loads from a PACKED copy of the block (r5c_pack_org_kernel, a few microseconds per
+//     launch): biased, row sub-sampling and odd origins resolved, in an even and an odd-shifted layout, so that the hot loop
+//     has no scalar work on the org row and an odd window offset costs one merge instead of eight realignments
+//     (r5c_compute); SMEM and LDS share lgkmcnt and SMEM returns out of order, so the
 //     loop is software pipelined by hand: wait for stage s, issue the loads of stage s+1, then do the SADs of stage s.
 //   * optional fused argmin: cost = SAD + motion-vector cost (the bit counts of the columns / rows
 //     and lambda * bits come from small LDS tables built once per workgroup), packed as (cost << 24 | scan index) and
-//     reduced with 64-bit min (wave shuffles -> LDS -> one global atomicMin per workgroup), so that the raster stage need
+//     reduced with 64-bit min (DPP row operations -> LDS -> one global atomicMin per workgroup), so that the raster stage need
 //     not write the SAD surface at all when the caller only wants the best candidate (xTZSearch does).
 // One stage = two 16-sample chunk-rows for the lane's two positions i and i+2 (classes c and c+2, whose windows overlap:
 // their 8-byte words are shared, 7 or 8 words for the two instead of 5 + 5).
