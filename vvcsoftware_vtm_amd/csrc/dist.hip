@@ -487,11 +487,10 @@ __device__ __forceinline__ void r5c_issue(R5cStage& st, const unsigned* __restri
 }
 
 template <int OA, bool CH1>
-__device__ __forceinline__ void r5c_positions(const unsigned* __restrict__ orgDw, unsigned base, int ldsStep,
+__device__ __forceinline__ void r5c_positions(const unsigned* __restrict__ orgDw, unsigned base, int ldsStep, R5cCursor cur,
                                               int nStages, int CH, unsigned& acc0, unsigned& acc1)
 {
   R5cStage A, B;
-  R5cCursor cur = { 0u, 0u, 0 };
   const unsigned ldsStepB = (unsigned)ldsStep * 4u, lRowB = (unsigned)(ldsStep - 8 * CH) * 4u;
   r5c_issue<OA, CH1>(A, orgDw, base, cur, CH, ldsStepB, lRowB);
   for (int s = 0; s < nStages; s += 2)
@@ -563,8 +562,11 @@ __global__ __launch_bounds__(256) void r5c_pack_org_kernel(const Pel* __restrict
 }
 
 // MINW = waves per SIMD the register allocation must allow: 6 (<= 80 VGPRs) when three workgroups fit the CU's LDS, else 4
-template <int MINW>
-__global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const unsigned* __restrict__ orgPacked,
+// split = 2 (wide blocks whose strip gives few wave items): two waves share one item, each walks half of the block's rows; the
+// partial sums meet in LDS after the loop (the host guarantees one item per wave), which doubles the waves per SIMD where the
+// window size, not the registers, limits the occupancy.
+template <int MAXT, int MINW, bool SPLIT>
+__global__ __launch_bounds__(MAXT, MINW) void sad_raster5c_kernel(const unsigned* __restrict__ orgPacked,
                                                            const Pel* __restrict__ ref, int rs,
                                                            const vvcgpu_search_blk* __restrict__ blocks, int w, int h, int subShift,
                                                            int dx0, int dy0, int nx, int ny, int rowsPerStrip, int pitchDw,
@@ -621,25 +623,9 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const unsigned*
   // The mapping is re-derived from an opaque copy of the lane id after the SAD loop, so that none of it has to stay in
   // registers across the loop (the kernel sits right at the 80-VGPR limit of 6 waves per SIMD).
   auto lane_map = [](int ln, int& k, int& m, bool& dead) { const int q = ln & 31; m = (q * 26) >> 8; k = q - 10 * m; dead = m >= 3; if (dead) m = 0; };
-  for (int cg = 0; cg < ncg; cg++)
-    for (int it = wave; it < 2 * ngrp; it += nwaves)
-    {
-      const int c = it & 1, g = it >> 1;                                    // classes c and c + 2
-      const int OA = (c + off) & 3;                                         // == cx & 3 for every lane of the wave
-      unsigned acc0 = 0, acc1 = 0;
-      {
-        int k, m; bool dead;
-        lane_map(lane, k, m, dead);
-        const int jj = g * 6 + (lane >> 5) * 3 + m;
-        const int i0 = cg * 40 + 4 * k + c;                                 // positions i0 and i0 + 2
-        const int cx = 5 * (i0 < nx ? i0 : c) + off;                        // dead lanes re-read a live lane's address (broadcast)
-        const unsigned base = ldsBase + (unsigned)(2 * (cx >> 2) + (min(jj, nj - 1) * 5) * pitchDw) * 4u;
-#define R5C_CALL(OV)                                                                                                            \
-        do { if (CH == 1) r5c_positions<OV, true>(orgDw + ((OV) & 1) * layoutDw, base, ldsStep, nStages, CH, acc0, acc1);          \
-             else         r5c_positions<OV, false>(orgDw + ((OV) & 1) * layoutDw, base, ldsStep, nStages, CH, acc0, acc1); } while (0)
-        if (OA == 0) R5C_CALL(0); else if (OA == 1) R5C_CALL(1); else if (OA == 2) R5C_CALL(2); else R5C_CALL(3);
-#undef R5C_CALL
-      }
+  // epilogue of one wave item (classes c and c + 2 of row group g, column group cg): SAD surface and / or the packed arg-min key
+  auto finish = [&](int c, int g, int cg, unsigned acc0, unsigned acc1)
+  {
       int lane2 = lane;
       asm volatile("" : "+v"(lane2));                                       // opaque: forces the re-derivation below
       int k, m; bool dead;
@@ -667,7 +653,48 @@ __global__ __launch_bounds__(512, MINW) void sad_raster5c_kernel(const unsigned*
           if (in1) kmin = key1 < kmin ? key1 : kmin;
         }
       }
+  };
+  constexpr int split = SPLIT ? 2 : 1;
+  const int chShift = 31 - __clz(CH);
+  unsigned keep0 = 0, keep1 = 0; int keepIt = -1;
+  for (int cg = 0; cg < ncg; cg++)
+    for (int it = wave; it < 2 * ngrp * split; it += nwaves)
+    {
+      const int half = split == 2 ? (it & 1) : 0, it2 = split == 2 ? (it >> 1) : it;
+      const int c = it2 & 1, g = it2 >> 1;                                  // classes c and c + 2
+      const int nSt = split == 2 ? (nStages >> 1) : nStages;
+      const int cr0 = 2 * half * nSt, ch0 = cr0 & (CH - 1);                 // first chunk-row of this wave's share
+      const R5cCursor cur0 = { (unsigned)cr0 * 8u, (unsigned)((cr0 >> chShift) * ldsStep + ch0 * 8) * 4u, ch0 };
+      const int OA = (c + off) & 3;                                         // == cx & 3 for every lane of the wave
+      unsigned acc0 = 0, acc1 = 0;
+      {
+        int k, m; bool dead;
+        lane_map(lane, k, m, dead);
+        const int jj = g * 6 + (lane >> 5) * 3 + m;
+        const int i0 = cg * 40 + 4 * k + c;                                 // positions i0 and i0 + 2
+        const int cx = 5 * (i0 < nx ? i0 : c) + off;                        // dead lanes re-read a live lane's address (broadcast)
+        const unsigned base = ldsBase + (unsigned)(2 * (cx >> 2) + (min(jj, nj - 1) * 5) * pitchDw) * 4u;
+#define R5C_CALL(OV)                                                                                                            \
+        do { if (CH == 1) r5c_positions<OV, true>(orgDw + ((OV) & 1) * layoutDw, base, ldsStep, cur0, nSt, CH, acc0, acc1);          \
+             else         r5c_positions<OV, false>(orgDw + ((OV) & 1) * layoutDw, base, ldsStep, cur0, nSt, CH, acc0, acc1); } while (0)
+        if (OA == 0) R5C_CALL(0); else if (OA == 1) R5C_CALL(1); else if (OA == 2) R5C_CALL(2); else R5C_CALL(3);
+#undef R5C_CALL
+      }
+      if (split == 2) { keep0 = acc0; keep1 = acc1; keepIt = it; }          // one item per wave (host): combined below
+      else finish(c, g, cg, acc0, acc1);
     }
+  if (split == 2)
+  {
+    __syncthreads();                                                        // every wave is done with the window: reuse its first bytes
+    uint2* xch = reinterpret_cast<uint2*>(refL);
+    if (keepIt >= 0 && (keepIt & 1)) xch[(keepIt >> 1) * 64 + lane] = make_uint2(keep0, keep1);
+    __syncthreads();
+    if (keepIt >= 0 && !(keepIt & 1))
+    {
+      const uint2 o = xch[(keepIt >> 1) * 64 + lane];
+      finish((keepIt >> 1) & 1, keepIt >> 2, 0, keep0 + o.x, keep1 + o.y);
+    }
+  }
   if (useBest)
   {
     kmin = wave_min_u64(kmin);
@@ -957,13 +984,22 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       rps = cdiv(cdiv(ny, nstrips), 3) * 3;
       if (win_bytes(rps) <= budget || rps <= 3) break;
     }
+    static const int splitOff = getenv("VVCGPU_R5C_NOSPLIT") ? 1 : 0;          // A/B timing switches
+    static const int split32On = getenv("VVCGPU_R5C_SPLIT32") ? 1 : 0;
+    // experiment: strips of at most 18 raster rows give at most 6 wave items, which the two-waves-per-item form of the kernel
+    // turns into 12 waves per workgroup (6 per SIMD with two workgroups per CU)
+    // (measured: 32-wide blocks lose more to the extra window rows than they gain, 0.315 vs 0.292 ms at 4K -- off by default)
+    if (!splitOff && split32On && chunks >= 2 && rps > 18 && nx <= 40)
+      rps = cdiv(cdiv(ny, cdiv(ny, 18)), 3) * 3;
     nstrips = cdiv(ny, rps);
     const size_t winB = win_bytes(rps), smem = winB + (((size_t)nx + rps + 15) & ~(size_t)15) + R5C_COST_N * sizeof(unsigned long long);
     if (smem <= 150 * 1024 && ((hsR * chunks) & 1) == 0 && nx + rps <= 4096 &&
         (unsigned long long)nblocks * nstrips * nstrips < (1ull << 32))   // item decode by multiply-high (and total fits an int)
     {
       const int items = 2 * cdiv(rps, 6);
-      const int threads = items >= 8 ? 512 : items * 64;
+      // wide blocks, few items per strip: two waves per item (see the kernel) -- one item per wave, at most 12 waves
+      const int split = (!splitOff && chunks >= 2 && items <= 6 && nx <= 40 && (((hsR * chunks) >> 1) & 1) == 0) ? 2 : 1;
+      const int threads = split == 2 ? items * 2 * 64 : (items >= 8 ? 512 : items * 64);
       const int total = nblocks * nstrips;
       const size_t packedDw = (size_t)nblocks * 2 * hsR * (w >> 1);
       unsigned* packed = static_cast<unsigned*>(vvcgpu_scratch(st0, packedDw * sizeof(unsigned)));
@@ -977,14 +1013,15 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
         mv = *mvcost_host;
         VVC_HIP(hipMemsetAsync(best, 0xFF, (size_t)nblocks * sizeof(vvcgpu_search_best), st0));
       }
-#define LAUNCH_R5C(MINW)                                                                                                        \
+#define LAUNCH_R5C(MAXT, MINW, SPL)                                                                                                  \
       do {                                                                                                                      \
+        auto kfn = sad_raster5c_kernel<MAXT, MINW, SPL>;                                                                             \
         if (smem > 48 * 1024)                                                                                                   \
-          VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster5c_kernel<MINW>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-        hipLaunchKernelGGL(sad_raster5c_kernel<MINW>, dim3(cdiv(total, 8) * 8), dim3(threads), smem, st0, packed, ref, ref_stride, \
+          VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+        hipLaunchKernelGGL(kfn, dim3(cdiv(total, 8) * 8), dim3(threads), smem, st0, packed, ref, ref_stride, \
                            blocks, w, h, sub_shift, dx0, dy0, nx, ny, rps, pitch, nstrips, 0xFFFFFFFFu / (unsigned)nstrips + 1u, total, (int)winB, mv, best ? 1 : 0, sad_out, best); \
       } while (0)
-      if ((smem + 1024) * 3 <= 160 * 1024) LAUNCH_R5C(6); else LAUNCH_R5C(4);
+      if (split == 2) LAUNCH_R5C(768, 6, true); else if ((smem + 1024) * 3 <= 160 * 1024) LAUNCH_R5C(512, 6, false); else LAUNCH_R5C(512, 4, false);
 #undef LAUNCH_R5C
       VVC_LAUNCH_CHECK();
       if (best)
