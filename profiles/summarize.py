@@ -60,7 +60,8 @@ def main():
     with open(out, "w") as fh:
         fh.write("kernel,grid_threads,lds_bytes,calls,avg_us,fetch_KiB_raw,fetch_MB_x2_corrected,write_MB\n")
         for tot, key, n, avg, f, w in rows:
-            fh.write("%s,%d,%d,%d,%.2f,%s,%s,%s\n" % (key[0], key[1], key[2], n, avg,
+            kname = '"%s"' % key[0] if "," in key[0] else key[0]       # template argument lists contain commas: quote the field
+            fh.write("%s,%d,%d,%d,%.2f,%s,%s,%s\n" % (kname, key[1], key[2], n, avg,
                                                        "" if f is None else "%.1f" % f,
                                                        "" if f is None else "%.2f" % (2 * f * 1024 / 1e6),
                                                        "" if w is None else "%.2f" % (w * 1024 / 1e6)))
