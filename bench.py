@@ -1,18 +1,26 @@
 #!/usr/bin/env python3
 """bench.py -- hot-path throughput of the MI355X-native VTM pixel path (measurement M1 of SURVEY.md §8(d)).
 
-A "step" is one pass of the canonical per-picture hot-path workload (integer-ME SAD surfaces, fused fractional refinement, bi-pred MC, residual +
-forward/inverse transforms + reconstruction, deblocking, SAO stats+apply, ALF classify+stats+filter) over ONE
-3840x2160 10-bit 4:2:0 picture whose planes are resident in HBM.  N > 1: one process per GPU, each rank works on its own
-pictures (random-access intra periods shard with no data-path collective); the boundary reconstructed
-picture of a chunk hand-over is exchanged point-to-point once per 32 pictures (RCCL).  value = pictures all ranks
-processed / max-over-ranks time.  This is NOT EncoderApp fps: the serial RDO control loop is outside the path.
+A "step" is one INTRA PERIOD of the random-access structure: `--pictures-per-step` (default 32) passes of the canonical
+per-picture hot-path workload (integer-ME SAD searches, fused fractional refinement, bi-pred MC, residual + forward
+transform + quantiser + de-quantiser + inverse transform + reconstruction, deblocking, SAO stats+apply, ALF
+classify+stats+filter) over 3840x2160 10-bit 4:2:0 pictures whose planes are resident in HBM, followed by the chunk
+hand-over: the last reconstructed picture of the intra period becomes a reference picture of the NEXT chunk (copied into a
+padded DPB slot, borders extended on the device, Picture::extendPicBorder).  N > 1: one process per GPU, rank r works on
+intra periods r, r+N, ... (random-access intra periods shard with no data-path collective); the hand-over
+picture then travels point-to-point to the next rank (RCCL send/recv over xGMI) once per step and is installed there.
+value = pictures all ranks processed / max-over-ranks time.  This is NOT EncoderApp fps: the serial RDO control loop is
+outside the path (M1 must never be presented as encoder fps).
 
-Prints ONE JSON line on rank 0."""
+`python bench.py --gpus N` without a torch.distributed environment starts the N ranks itself (torch.distributed.run, before
+anything touches a GPU).  Prints ONE JSON line on rank 0."""
 import argparse
 import ctypes as C
+import hashlib
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -20,80 +28,150 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
+# vector-instruction issue: one VALU wave-instruction per ~4.4 cycles and SIMD (tools/micro/valu_rate.hip on MI355X: v_sad_u16
+# 4.94 cycles with one wave per SIMD, 4.4 with two), 1024 SIMDs at 2.4 GHz
+VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4.4
+BASELINE_METRIC = "encoded frames/sec (bit-exact bitstream) at 4K10 RA QP32, 1/2/4/8 GPU"
 
 
-def cpu_baseline(width, height, bd):
-    """VTM's own SIMD kernels (oracle/_ref/libvtmref.so, kind 'reference') or the scalar restatement (kind 'port') on the
-    host cores, on a bounded sample: the same workload on a 512x256 picture, scaled by the pixel ratio."""
-    from vvcsoftware_vtm_amd.workload import Workload
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--pictures-per-step", type=int, default=32, help="pictures of one intra period (one hand-over per step)")
+    ap.add_argument("--width", type=int, default=3840)
+    ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--serial", action="store_true", help="one stream, stage order (default: independent stages on side streams)")
+    ap.add_argument("--dry-launch", action="store_true",
+                    help="launcher check without a GPU: start the ranks (gloo), verify the world size, hand one dummy boundary picture round the ring")
+    return ap.parse_args()
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def launch_ranks(args):
+    """Parent of a multi-GPU run started as plain `python bench.py --gpus N`: starts N worker processes under
+    torch.distributed.run as CHILDREN (this process has not touched a GPU and never execs) and returns their exit code."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def lib_digest():
+    """sha256 over the HIP sources of libvvcgpu.so: a committed rocprofv3 profile is only quoted when it was taken from the same kernels."""
+    from vvcsoftware_vtm_amd import build
+    h = hashlib.sha256()
+    for p in build.sources() + build.headers():
+        with open(p, "rb") as f:
+            h.update(os.path.basename(p).encode())
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def profile_traffic():
+    """-> ({launch-group kernel name: [(avg_us, hbm_bytes)]}, source file) from the newest committed rocprofv3 PMC summary
+    (profiles/rNN_launch_groups.csv: FETCH_SIZE x2-corrected for gfx950 + WRITE_SIZE, collected in separate passes), or
+    ({}, None) when that profile was taken from different kernel sources (profiles/rNN_meta.json `lib_digest`)."""
+    import csv
+    import glob
+    metas = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_meta.json")))
+    if not metas:
+        return {}, None
+    meta = json.load(open(metas[-1]))
+    if meta.get("lib_digest") != lib_digest():
+        return {}, None
+    path = os.path.join(ROOT, "profiles", meta["launch_groups"])
+    if not os.path.exists(path):
+        return {}, None
+    out = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r["fetch_MB_x2_corrected"] and r["write_MB"]:
+                out.setdefault(r["kernel"], []).append((float(r["avg_us"]), (float(r["fetch_MB_x2_corrected"]) + float(r["write_MB"])) * 1e6))
+    return out, os.path.basename(path)
+
+
+def cpu_baseline(wl, budget_s=25.0):
+    """VTM's own SIMD kernels (oracle/_ref/libvtmref.so, kind 'reference') or the scalar restatement (kind 'port') on ONE host
+    core over the bench's own workload object (the whole 3840x2160 picture, no extrapolation) when one pass fits the budget;
+    the scalar port falls back to a 960x544 picture of the same workload scaled by pixel count."""
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    from workload_cpu import run_cpu                      # checker side (tests/), timed here as the reported CPU baseline
     odir = os.path.join(ROOT, "oracle")
     port_so = os.path.join(odir, "liboracle.so")
     ref_so = os.path.join(odir, "_ref", "libvtmref.so")
     if not os.path.exists(port_so):
         return None
     port = C.CDLL(port_so)
-    sw, sh = 512, 256
-    wl = Workload(sw, sh, bd, seed=7)
-    kind = "port"
-    lib = port
+    kind, lib = "port", port
     if os.path.exists(ref_so):
         try:
-            lib = (port, C.CDLL(ref_so))
-            kind = "reference"
+            lib, kind = (port, C.CDLL(ref_so)), "reference"
         except OSError:
-            lib = port
+            pass
+    scale, sample_wl = 1.0, wl
+    if kind == "port":
+        from vvcsoftware_vtm_amd.workload import Workload
+        sample_wl = Workload(960, 544, wl.bd, seed=wl.seed, qp=wl.qp)
+        scale = (wl.w * wl.h) / float(960 * 544)
     t0 = time.perf_counter()
-    reps = 0
-    secs_tot = {}
+    reps, secs_tot = 0, {}
     while True:
-        _, secs = wl.run_cpu(lib, kind)
+        _, secs = run_cpu(sample_wl, lib, kind)
         for k, v in secs.items():
             secs_tot[k] = secs_tot.get(k, 0.0) + v
         reps += 1
-        if time.perf_counter() - t0 > 12.0:
+        el = time.perf_counter() - t0
+        if el + el / reps > budget_s:
             break
-    per_sample = sum(secs_tot.values()) / reps
-    scale = (width * height) / float(sw * sh)
-    fps = 1.0 / (per_sample * scale)
-    return {"value": fps, "unit": "frames/s", "cores": 1, "kind": kind,
-            "sample": "same canonical workload on a %dx%d picture (%d repetitions, %.2f s of CPU work), scaled by pixel count to %dx%d; "
-                      "deblocking and plane add/subtract use the scalar port (no reference entry point); "
-                      "stage seconds per sample: %s" % (sw, sh, reps, sum(secs_tot.values()), width, height,
-                                                        {k: round(v / reps, 4) for k, v in secs_tot.items()})}
+    per_picture = sum(secs_tot.values()) / reps * scale
+    what = ("the bench's own %dx%d workload object, every stage, %d repetition(s)" % (wl.w, wl.h, reps) if scale == 1.0 else
+            "same workload on a 960x544 picture (%d repetitions), scaled by pixel count to %dx%d" % (reps, wl.w, wl.h))
+    return {"value": 1.0 / per_picture, "unit": "frames/s", "cores": 1, "kind": kind,
+            "sample": "%s, %.1f s of CPU work; deblocking and plane add/subtract use the scalar port (no reference entry point); "
+                      "stage seconds per picture: %s" % (what, sum(secs_tot.values()), {k: round(v / reps * scale, 4) for k, v in secs_tot.items()})}
 
 
-def traffic_from_profile(kernel_hint, avg_ms):
-    """HBM traffic per launch of the dominant kernel, from the committed rocprofv3 PMC passes of this same command
-    (profiles/rNN_launch_groups.csv, written by profiles/summarize.py: FETCH_SIZE x2-corrected for gfx950 + WRITE_SIZE).
-    The launch group is matched by kernel name and by the closest average duration.  None when no profile is committed."""
-    import csv
-    import glob
-    files = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_launch_groups.csv")))
-    if not files:
-        return None
-    best = None
-    with open(files[-1]) as f:
-        for r in csv.DictReader(f):
-            if kernel_hint not in r["kernel"] or not r["fetch_MB_x2_corrected"] or not r["write_MB"]:
-                continue
-            d = abs(float(r["avg_us"]) / 1e3 - avg_ms) / avg_ms
-            if best is None or d < best[0]:
-                best = (d, (float(r["fetch_MB_x2_corrected"]) + float(r["write_MB"])) * 1e6, os.path.basename(files[-1]))
-    if best is None or best[0] > 0.35:
-        return None
-    return {"bytes": best[1], "source": best[2]}
+def dry_launch(args):
+    """Launcher check on CPU (gloo): every rank joins, the world size equals --gpus, one dummy boundary picture goes round the ring."""
+    import torch
+    import torch.distributed as dist
+    from vvcsoftware_vtm_amd import shard
+    world, rank = int(os.environ.get("WORLD_SIZE", "1")), int(os.environ.get("RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but the launcher started %d rank(s)" % (args.gpus, world))
+    if world > 1:
+        dist.init_process_group("gloo")
+        assert dist.get_world_size() == args.gpus
+    planes = [torch.full((8, 8), rank, dtype=torch.int16), torch.full((4, 4), rank + 100, dtype=torch.int16)]
+    got = shard.exchange_boundary(planes, rank, world)
+    ok = int(got[0][0, 0]) == (rank - 1) % world and int(got[1][0, 0]) == (rank - 1) % world + 100
+    seen = [None] * world
+    if world > 1:
+        dist.all_gather_object(seen, (rank, ok))
+        dist.destroy_process_group()
+    else:
+        seen = [(rank, ok)]
+    if rank == 0:
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_seen": sorted(r for r, _ in seen), "handover_ok": all(o for _, o in seen)}))
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--width", type=int, default=3840)
-    ap.add_argument("--height", type=int, default=2160)
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--serial", action="store_true", help="one stream, stage order (default: independent stages on side streams)")
-    args = ap.parse_args()
+    args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(launch_ranks(args))                      # nothing GPU-related has been imported or called at this point
+    if args.dry_launch:
+        return dry_launch(args)
 
     import torch
     import torch.distributed as dist
@@ -103,17 +181,22 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit("bench.py: --gpus %d but WORLD_SIZE is %d (start it as `python bench.py --gpus %d`, or under "
+                         "torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
     torch.cuda.set_device(local_rank)
     capi.call("vvcgpu_set_device", local_rank)
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
-    assert world == args.gpus or world == 1, "launch with torch.distributed.run --nproc-per-node N for --gpus N"
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit("bench.py: RCCL sees %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
     bd = 10
     wl = Workload(args.width, args.height, bd, seed=20261003 + rank)
     alg = wl.algorithmic_bytes()
+    pps = args.pictures_per_step
 
     class Timer:
         def __init__(self):
@@ -143,29 +226,40 @@ def main():
             return False
 
     timer = Timer()
-    state = None
-    # Warmup.  Its last step is bracketed per launch group to find the dominant kernel; in the timed region only THAT
-    # kernel carries HIP events (an event pair per launch group would put ~40 markers into every step).
     overlap = not args.serial
-    for i in range(args.warmup):
-        timer.on = (i == args.warmup - 1)
-        state, out = wl.run_gpu(state, timer, overlap=overlap and not timer.on)     # the bracketed step runs serially
+
+    # ---- picture 0 on a fresh state: the md5 the 4K parity test pins (tests/golden/bench_md5.json), then one serial, bracketed
+    # picture to find the dominant launch group (in the timed region only THAT group carries HIP events: an event pair per
+    # launch group would put ~40 markers into every picture)
+    state, out = wl.run_gpu(None, None, overlap=overlap)
     torch.cuda.synchronize()
-    if timer.ev:
-        warm = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in timer.ev.items()}
-        warm = {k: v for k, v in warm.items() if k.split('/')[1] in alg.get(k.split('/')[0], {})}
-        timer.only = max(warm, key=warm.get)
-    timer.ev = {}
+    first_md5 = shard.picture_hash(out["final"])
+    timer.on = True
+    state, out = wl.run_gpu(state, timer, overlap=False)
+    torch.cuda.synchronize()
+    warm = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in timer.ev.items()}
+    warm = {k: v for k, v in warm.items() if k.split('/')[1] in alg.get(k.split('/')[0], {})}
+    timer.only = max(warm, key=warm.get)
+    timer.ev, timer.on = {}, False
+
+    def one_step(tm):
+        """one intra period: pps pictures, then the chunk hand-over (next rank's reference picture; own picture at N = 1)"""
+        nonlocal state, out
+        for _ in range(pps):
+            state, out = wl.run_gpu(state, tm, overlap=overlap)
+        boundary = shard.exchange_boundary(out["final"], rank, world)
+        shard.install_reference(boundary, state["ref1"], wl.margins())
+
+    for _ in range(args.warmup):
+        one_step(None)
+    torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     timer.on = True
     t0 = time.perf_counter()
-    for step in range(args.steps):
-        state, out = wl.run_gpu(state, timer, overlap=overlap)
-        if world > 1 and step % shard.INTRA_PERIOD == 0:
-            # chunk hand-over: one reconstructed boundary picture per intra period (32 pictures), point-to-point
-            shard.exchange_boundary(out["final"], rank, world)
+    for _ in range(args.steps):
+        one_step(timer)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -181,36 +275,61 @@ def main():
 
     # dominant kernel: device time over the timed region (HIP events on the stream the kernels were launched on)
     timed_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in timer.ev.items()}
-    # table of all launch groups: a separate, untimed pass with an event pair around every group
-    timer_only_name = timer.only
+    n_timed = {k: len(v) for k, v in timer.ev.items()}
+    # table of all launch groups: a separate, untimed pass (serial schedule) with an event pair around every group
+    dom_name = timer.only
     timer.only, timer.ev = None, {}
-    for _ in range(min(args.steps, 5)):
-        state, out = wl.run_gpu(state, timer)
+    for _ in range(5):
+        state, out = wl.run_gpu(state, timer, overlap=False)
     torch.cuda.synchronize()
     kern_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in timer.ev.items()}
     kern_ms.update(timed_ms)
     stage_ms = {}
     for k, v in kern_ms.items():
         stage_ms[k.split("/")[0]] = stage_ms.get(k.split("/")[0], 0.0) + v
-    cand = {k: v for k, v in (timed_ms if timer_only_name else kern_ms).items() if k.split('/')[1] in alg.get(k.split('/')[0], {})}
-    dom = max(cand, key=cand.get)
+    dom = dom_name
     dstage, dname = dom.split("/")
     abytes = alg[dstage][dname]
     achieved = abytes / (kern_ms[dom] * 1e-3) / 1e9
+    uniq = wl.unique_bytes()
+    useful = wl.useful_sad_insts()
+    prof, prof_src = profile_traffic() if rank == 0 else ({}, None)
+    hint = wl.profile_kernel_hint(dom)
+
+    def hbm_of(group, ms):
+        """HBM bytes per launch of the dominant launch group's main kernel from the committed profile: rows of that kernel, the one
+        whose average duration is closest (and within 35 %)"""
+        if group != dom or hint is None:
+            return None
+        cands = [c for k, v in prof.items() if hint in k for c in v]
+        if not cands:
+            return None
+        best = min(cands, key=lambda c: abs(c[0] - ms * 1e3))
+        return best[1] if abs(best[0] - ms * 1e3) <= 0.35 * ms * 1e3 else None
+
     per_kernel = {}
     for k, v in kern_ms.items():
         s, n = k.split("/")
+        e = {"ms": round(v, 4)}
         if n in alg.get(s, {}):
-            per_kernel[k] = {"ms": round(v, 4), "alg_MB": round(alg[s][n] / 1e6, 2), "GBps": round(alg[s][n] / (v * 1e-3) / 1e9, 1)}
-        else:
-            per_kernel[k] = {"ms": round(v, 4)}
+            e.update({"alg_MB": round(alg[s][n] / 1e6, 2), "alg_GBps": round(alg[s][n] / (v * 1e-3) / 1e9, 1)})
+        if n in uniq.get(s, {}):
+            e["unique_MB"] = round(uniq[s][n] / 1e6, 2)
+            e["unique_frac"] = round(uniq[s][n] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        hb = hbm_of(k, v)
+        if hb is not None:
+            e["hbm_MB"] = round(hb / 1e6, 2)
+            e["hbm_frac"] = round(hb / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
+        if k in useful:
+            e["issue_frac"] = round(useful[k] / (v * 1e-3) / VALU_ISSUE_PEAK, 4)
+        per_kernel[k] = e
 
-    hint = "sad_raster5" if ("39x39" in dname or "x39" in dname) else dname.split("_")[0] if dstage != "me" else "sad_search"
-    tr = traffic_from_profile(hint, kern_ms[dom]) if rank == 0 else None
     if rank == 0:
+        pictures = args.steps * pps * world
+        dk = per_kernel[dom]
         res = {
-            "metric": "encoded frames/sec (bit-exact bitstream) at 4K10 RA QP32, 1/2/4/8 GPU",
-            "value": args.steps * world / dt,
+            "metric": BASELINE_METRIC + " [M1: hot-path pictures/s of the kernels behind the call sites, NOT EncoderApp fps]",
+            "value": pictures / dt,
             "unit": "frames/s",
             "n_gpus": world,
             "steps": args.steps,
@@ -221,24 +340,34 @@ def main():
             "vs_baseline": None,
             "dtype": "int16",
             "data": "synthetic",
-            "config": {"workload": "hot-path canonical per-picture workload (SURVEY 8(d) M1: ME SAD surfaces 16/32/64 +-4 & raster +-96, fused half/quarter refinement 16x16 (9+9 SATD), "
+            "config": {"workload": "hot-path canonical per-picture workload (SURVEY 8(d) M1: ME SAD searches 16/32/64 +-4 & raster +-96, fused half/quarter refinement 16x16 (9+9 SATD), "
                                    "bi-pred MC 16x16, residual+fwd transform+quantiser (Quant::quant, sign hiding)+dequant+inv transform+reco, deblock, SAO stats+apply, ALF classify+stats+filter) "
-                                   "on %dx%d 10-bit 4:2:0, planes resident in HBM; NOT EncoderApp fps (RDO control loop out of scope)" % (args.width, args.height),
-                       "width": args.width, "height": args.height, "bit_depth": bd,
+                                   "on %dx%d 10-bit 4:2:0 (BASELINE configs[3] picture format; configs[1] is the same workload at 1920x1080), planes resident in HBM; "
+                                   "step = one intra period of %d pictures + hand-over of the last reconstructed picture as the next chunk's reference; "
+                                   "NOT EncoderApp fps (RDO control loop out of scope)" % (args.width, args.height, pps),
+                       "width": args.width, "height": args.height, "bit_depth": bd, "pictures_per_step": pps, "ms_per_picture": dt / (args.steps * pps) * 1e3,
                        "schedule": ("serial: one HIP stream, stage order" if args.serial else
                                     "overlap: reconstruction chain on the main stream, searches / refinement / statistics on three side streams "
                                     "(their real dependencies only); the dominant kernel is launched first and alone"),
-                       "parallelism": "one picture stream per GPU, intra-period sharding, p2p boundary picture per 32 pictures"},
+                       "parallelism": "one chunk stream per GPU (intra-period sharding), one point-to-point boundary picture per step; no data-path collective"},
             "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS, "traffic": (tr["bytes"] if tr else None),
-                         "traffic_source": (tr["source"] if tr else None),
-                         "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": kern_ms[dom]},
-            "picture_hashes": {"gathered": len(hashes), "rank0_md5": hashes.get("rank0")},
+                         "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": (dk["hbm_MB"] * 1e6 if "hbm_MB" in dk else None), "traffic_source": prof_src if "hbm_MB" in dk else None,
+                         "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": kern_ms[dom], "launches_timed": n_timed.get(dom, 0),
+                         "note": "achieved/frac follow SURVEY 8(d) (algorithmic bytes of the launch / time); hbm_frac is the counter traffic "
+                                 "(FETCH_SIZE x2 + WRITE_SIZE of the committed profile, when it was taken from these kernel sources) / time / peak; "
+                                 "unique_frac counts every sample the launch must touch once; issue_frac = useful v_sad_u16 wave-instructions / time "
+                                 "against the measured vector issue rate (one per 4.4 cycles and SIMD)",
+                         "hbm_frac": dk.get("hbm_frac"), "unique_frac": dk.get("unique_frac"), "issue_frac": dk.get("issue_frac")},
+            "picture_hashes": {"gathered": len(hashes), "rank0_first_picture_md5": first_md5, "rank0_last_picture_md5": hashes.get("rank0")},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
+            "serial_kernel_ms_per_picture": round(sum(stage_ms.values()), 4),
             "kernels": per_kernel,
+            "lib_digest": lib_digest(),
+            "encoder_fps_m3": "see profiles/*_m3_encoder.txt (reference encoder with and without the library, measured separately; never this line's value)",
         }
         if world == 1 and not args.no_cpu_baseline:
-            res["cpu_baseline"] = cpu_baseline(args.width, args.height, bd)
+            res["cpu_baseline"] = cpu_baseline(wl)
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

@@ -58,14 +58,24 @@ def main():
     rows.sort(reverse=True)
     out = os.path.join(here, tag + "_launch_groups.csv")
     with open(out, "w") as fh:
-        fh.write("kernel,grid_threads,lds_bytes,calls,avg_us,fetch_KiB_raw,fetch_MB_x2_corrected,write_MB\n")
+        fh.write("kernel,grid_threads,lds_bytes,calls,avg_us,fetch_KiB_raw,fetch_MB_x2_corrected,write_MB,hbm_GBps,hbm_frac_of_8TBps\n")
         for tot, key, n, avg, f, w in rows:
             kname = '"%s"' % key[0] if "," in key[0] else key[0]       # template argument lists contain commas: quote the field
-            fh.write("%s,%d,%d,%d,%.2f,%s,%s,%s\n" % (kname, key[1], key[2], n, avg,
-                                                       "" if f is None else "%.1f" % f,
-                                                       "" if f is None else "%.2f" % (2 * f * 1024 / 1e6),
-                                                       "" if w is None else "%.2f" % (w * 1024 / 1e6)))
+            hbm = None if (f is None or w is None) else (2 * f + w) * 1024 / (avg * 1e-6) / 1e9       # counter traffic / time
+            fh.write("%s,%d,%d,%d,%.2f,%s,%s,%s,%s,%s\n" % (kname, key[1], key[2], n, avg,
+                                                             "" if f is None else "%.1f" % f,
+                                                             "" if f is None else "%.2f" % (2 * f * 1024 / 1e6),
+                                                             "" if w is None else "%.2f" % (w * 1024 / 1e6),
+                                                             "" if hbm is None else "%.1f" % hbm,
+                                                             "" if hbm is None else "%.4f" % (hbm / 8000.0)))
     print(open(out).read())
+    # which kernel sources the profile was taken from: bench.py quotes `traffic` from it only while they are unchanged
+    import json
+    sys.path.insert(0, os.path.dirname(here))
+    import bench
+    with open(os.path.join(here, tag + "_meta.json"), "w") as fh:
+        json.dump({"tag": tag, "lib_digest": bench.lib_digest(), "launch_groups": tag + "_launch_groups.csv",
+                   "command": "rocprofv3 --kernel-trace --stats / --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) -- python3 bench.py --serial (tools/profile_round.sh)"}, fh, indent=1)
 
 
 if __name__ == "__main__":

@@ -4,6 +4,7 @@ import torch
 
 import cases
 from oraclelib import oracle, p
+from workload_cpu import run_cpu
 
 
 def run():
@@ -29,7 +30,7 @@ def run():
     wl = Workload(416, 240, 10, seed=7, raster_range=40)
     _, gout = wl.run_gpu(overlap=True)
     torch.cuda.synchronize()
-    cout, _ = wl.run_cpu(oracle(), "port")
+    cout, _ = run_cpu(wl, oracle(), "port")
     for k in ("final", "coef", "cls", "frac", "me_best_16_17", "me_best_64_9", "sao_stats", "alf_stats7"):
         g, c = gout[k], cout[k]
         if isinstance(c, (list, tuple)):

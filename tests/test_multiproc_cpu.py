@@ -75,3 +75,31 @@ def test_two_process_shard_exchange_gather():
     assert all(r[0] for r in res)
     full = [r for r in res if len(r) > 1][0]
     assert full[1] == 160 and full[2] == [0, 1, 2] and full[3] == 159
+
+
+def _run_bench(args, env_extra=None, timeout=300):
+    import json
+    import subprocess
+    env = dict(os.environ)
+    for k in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    env.update(env_extra or {})
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")] + args, capture_output=True, text=True, env=env, timeout=timeout)
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    return r.returncode, (json.loads(lines[-1]) if lines else None), r.stderr
+
+
+def test_bench_gpus2_starts_two_ranks_by_itself():
+    """`python bench.py --gpus 2` with no torch.distributed environment starts the two ranks itself (before anything touches a GPU);
+    --dry-launch keeps the ranks on gloo/CPU: both join, the world size is checked, a boundary picture goes round the ring."""
+    rc, res, err = _run_bench(["--gpus", "2", "--dry-launch"])
+    assert rc == 0, err
+    assert res == {"dry_launch": True, "n_gpus": 2, "ranks_seen": [0, 1], "handover_ok": True}
+
+
+def test_bench_refuses_a_world_that_is_not_gpus():
+    """--gpus N inside a launcher environment with a different WORLD_SIZE fails loudly instead of measuring one GPU"""
+    rc, res, err = _run_bench(["--gpus", "2", "--dry-launch"], {"WORLD_SIZE": "1", "RANK": "0"})
+    assert rc != 0 and res is None and "--gpus 2" in err
+    rc, res, err = _run_bench(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
+    assert rc != 0 and res is None and "WORLD_SIZE is 2" in err

@@ -52,3 +52,14 @@ def gather_hashes(local_hashes, world):
     for d in out:
         merged.update(d)
     return merged
+
+
+def install_reference(planes, ref_padded, margins):
+    """Chunk hand-over, receiving side: the boundary picture becomes a reference picture of this rank's next chunk -- copied into
+    the padded DPB slot `ref_padded` (one 2-D int16 tensor per component, margins (mx, my) per component) and border-extended on
+    the device (Picture::extendPicBorder, vvcgpu_extend_border).  Device tensors only: there is no host form of this step."""
+    from . import ops
+    for p, r, (mx, my) in zip(planes, ref_padded, margins):
+        h, w = p.shape
+        r[my:my + h, mx:mx + w].copy_(p)
+        ops.extend_border(r, mx, my)

@@ -4,8 +4,8 @@ Everything is derived from a seed: three synthetic frames (current = org, two re
 descriptors, deblocking maps, SAO and ALF parameters.  The same `Workload` object drives
 
   * the HIP path (`run_gpu`, through vvcsoftware_vtm_amd.ops -> C ABI),
-  * the checkers (`run_cpu`, through ctypes function tables of oracle/liboracle.so or oracle/_ref/libvtmref.so) --
-    used only by tests/ and by bench.py's cpu_baseline leg.
+  * the checkers (tests/workload_cpu.py `run_cpu`: oracle/liboracle.so or oracle/_ref/libvtmref.so over the same object) --
+    test infrastructure, not part of this package.
 
 Stages (one picture = one step):
   me     integer ME: SAD surface of every 16x16 / 32x32 / 64x64 block at the 81 positions of a +-4 full search and
@@ -21,7 +21,6 @@ Stages (one picture = one step):
   alf    ALF classification + covariance statistics (7x7 and 5x5 luma, 5x5 chroma) + 7x7 luma / 5x5 chroma filtering
 """
 import ctypes as C
-import time
 
 import numpy as np
 
@@ -260,6 +259,40 @@ class Workload:
                       "alf_filter": 2 * P + Y // 16}
         return out
 
+    def unique_bytes(self):
+        """Bytes a launch must touch at least once (every sample of its inputs and outputs counted ONCE, however many blocks'
+        windows overlap it): the figure the counter traffic (FETCH_SIZE x2 + WRITE_SIZE) is to be compared with."""
+        w, h = self.w, self.h
+        P, Y = w * h * 3, w * h * 2
+        out = {s: dict(v) for s, v in self.algorithmic_bytes().items()}
+        for s, blk in self.me.items():
+            for (dx0, dy0, nx, ny, sx, sy) in self.me_grids:
+                out["me"]["sad_search_%dx%d_%dx%d" % (s, s, nx, ny)] = (w + (nx - 1) * sx) * (h + (ny - 1) * sy) * 2 + Y + blk.size * 24
+        out["frac"] = {"frac_refine_16x16": 2 * Y + self.frac.size * 32}
+        out["mc"] = {"mc_luma": 3 * Y, "mc_chroma": 3 * (P - Y)}
+        return out
+
+    def useful_sad_insts(self):
+        """launch group -> v_sad_u16 wave-instructions its arithmetic needs (2 abs-differences per lane-operation, 64 lanes): the
+        numerator of the issue-rate roofline of the search kernels."""
+        out = {}
+        for s, blk in self.me.items():
+            for (dx0, dy0, nx, ny, sx, sy) in self.me_grids:
+                out["me/sad_search_%dx%d_%dx%d" % (s, s, nx, ny)] = blk.size * nx * ny * s * (s >> 1) / 2.0 / 64.0
+        return out
+
+    def profile_kernel_hint(self, group):
+        """name (substring) of the rocprofv3 kernel that does the work of a launch group (None: not mapped)"""
+        stage, name = group.split("/")
+        if stage == "me":
+            return "sad_raster5" if name.endswith("%dx%d" % (self.me_grids[1][2], self.me_grids[1][3])) else "sad_dense_kernel"
+        return {"frac_refine_16x16": "frac16_kernel", "mc_luma": "mc_fast_kernel", "mc_chroma": "mc_fast_kernel", "deblock": "deblock_luma_kernel",
+                "sao_stats": "sao_stats_kernel", "sao_apply": "sao_apply_kernel", "alf_classify": "alf_classify_kernel",
+                "alf_stats": "alf_stats_kernel<true>", "alf_filter": "alf_filter_kernel<true", "resi_chain": "resi_chain"}.get(name)
+
+    def margins(self):
+        return [(MARGIN, MARGIN), (MARGIN // 2, MARGIN // 2), (MARGIN // 2, MARGIN // 2)]
+
     # ------------------------------------------------------------------------------------------------------
     def run_gpu(self, dev_state=None, timer=None, overlap=False):
         """One step on the GPU through ops/C-ABI.  Returns (state, outputs dict of CUDA tensors).
@@ -418,120 +451,6 @@ class Workload:
                 main.wait_event(e)
         out.update({"cls": cls, "alf_stats7": a7, "alf_stats5": a5, "alf_stats_c": ac, "final": st["alf_out"], "pred": st["pred"]})
         return st, out
-
-    # ------------------------------------------------------------------------------------------------------
-    def run_cpu(self, lib, kind="port"):
-        """One step on the host through a checker library.  kind 'port': oracle/liboracle.so (orc_* names);
-        kind 'reference': oracle/_ref/libvtmref.so for every stage that has a reference entry point (deblocking and the
-        element-wise plane ops have none and use `port_lib`).  Returns (outputs dict of numpy arrays, seconds per stage)."""
-        P = lambda a: None if a is None else C.c_void_p(a.ctypes.data)
-        port, refl = (lib, None) if kind == "port" else (lib[0], lib[1])
-        w, h, bd, mx = self.w, self.h, self.bd, self.mx
-        out, secs = {}, {}
-
-        def timed(name, fn):
-            t0 = time.perf_counter()
-            fn()
-            secs[name] = secs.get(name, 0.0) + time.perf_counter() - t0
-        # me
-        for s in sorted(self.me):
-            blk = self.me[s]
-            for (dx0, dy0, nx, ny, sx, sy) in self.me_grids:
-                sad = np.zeros((blk.size, ny, nx), np.uint32)
-                best = np.zeros(blk.size, SEARCH_BEST)
-                if refl is not None:
-                    timed("me", lambda: refl.vtmref_sad_search(P(self.org[0]), w, P(self.ref0_pad[0]), self.pw, P(blk), blk.size, s, s, 1,
-                                                                dx0, dy0, nx, ny, sx, sy, bd, P(sad)))
-                    best = None
-                else:
-                    timed("me", lambda: port.orc_sad_search(P(self.org[0]), w, P(self.ref0_pad[0]), self.pw, P(blk), blk.size, s, s, 1,
-                                                             dx0, dy0, nx, ny, sx, sy, P(sad), C.byref(self.mvcost), P(best)))
-                out["me_sad_%d_%d" % (s, nx)] = sad
-                out["me_best_%d_%d" % (s, nx)] = best
-        # frac
-        fres = np.zeros(self.frac.size, FRAC_RESULT)
-        if refl is not None:
-            timed("frac", lambda: refl.vtmref_frac_refine(P(self.org[0]), w, P(self.ref0_pad[0]), self.pw, P(self.frac), self.frac.size, 16, 16, bd, 0, mx, 1,
-                                                          C.byref(self.frac_mvcost), P(fres)))
-        else:
-            timed("frac", lambda: port.orc_frac_refine(P(self.org[0]), w, P(self.ref0_pad[0]), self.pw, P(self.frac), self.frac.size, 16, 16, bd, 0, mx, 1,
-                                                       C.byref(self.frac_mvcost), P(fres)))
-        out["frac"] = fres
-        # mc
-        pred = [np.zeros((h, w), np.int16), np.zeros((h // 2, w // 2), np.int16), np.zeros((h // 2, w // 2), np.int16)]
-        f_mc = (lambda *a: refl.vtmref_mc_batch(*a)) if refl is not None else (lambda *a: port.orc_mc_batch(*a))
-        timed("mc", lambda: f_mc(P(self.ref0_pad[0]), P(self.ref1_pad[0]), P(pred[0]), P(self.mc_luma), self.mc_luma.size, bd, 0, mx))
-        for c in (1, 2):
-            timed("mc", lambda: f_mc(P(self.ref0_pad[c]), P(self.ref1_pad[c]), P(pred[c]), P(self.mc_chroma), self.mc_chroma.size, bd, 0, mx))
-        # residual / transform
-        resi = np.zeros((h, w), np.int16)
-        resi2 = np.zeros((h, w), np.int16)
-        coef = np.zeros(self.n_coef, np.int32)
-        timed("resi", lambda: port.orc_pelop_batch(3, P(self.org[0]), P(pred[0]), P(resi), P(self.bands_luma), self.bands_luma.size, C.byref(self.cfg_sub)))
-        if refl is not None:
-            timed("resi", lambda: refl.vtmref_tr_fwd_batch(P(resi), P(coef), P(self.tr), self.tr.size, bd))
-        else:
-            timed("resi", lambda: port.orc_tr_fwd_batch(P(resi), P(coef), P(self.tr), self.tr.size, bd))
-        level, dqcoef, abs_sum = np.zeros(self.n_coef, np.int32), np.zeros(self.n_coef, np.int32), np.zeros(self.tr.size, np.uint32)
-        if refl is not None:
-            timed("resi", lambda: refl.vtmref_quant_batch(P(coef), P(level), P(self.quant), self.tr.size, bd, P(abs_sum)))
-            timed("resi", lambda: refl.vtmref_dequant_tr_inv_batch(P(level), P(resi2), P(self.dqtr), self.tr.size, bd, P(dqcoef)))
-        else:
-            timed("resi", lambda: port.orc_quant_batch(P(coef), P(level), P(self.quant), self.tr.size, bd, P(abs_sum)))
-            timed("resi", lambda: port.orc_dequant_tr_inv_batch(P(level), P(resi2), P(self.dqtr), self.tr.size, bd, P(dqcoef)))
-        coef = level
-        out["abs_sum"] = abs_sum
-        rec = [np.zeros((h, w), np.int16), pred[1].copy(), pred[2].copy()]
-        timed("resi", lambda: port.orc_pelop_batch(1, P(pred[0]), P(resi2), P(rec[0]), P(self.bands_luma), self.bands_luma.size, C.byref(self.cfg_reco)))
-        out["coef"] = coef
-        # deblock (no reference entry point: port)
-        timed("dbk", lambda: port.orc_deblock(P(rec[0]), w, P(rec[1]), P(rec[2]), w // 2, w, h, P(self.edge_ver), P(self.edge_hor),
-                                              P(self.qp_luma), P(self.qp_chroma), C.byref(self.dbk_cfg)))
-        # sao
-        sao_stats, sao_out = [], []
-        for c in range(3):
-            cs = CTU if c == 0 else CTU // 2
-            pw_, ph_ = (w, h) if c == 0 else (w // 2, h // 2)
-            stt = np.zeros((self.nctu_x * self.nctu_y, 5, 2, 32), np.int64)
-            if refl is not None:
-                timed("sao", lambda: refl.vtmref_sao_stats(c, P(self.org[c]), pw_, P(rec[c]), pw_, pw_, ph_, cs, cs, bd, None, 5 if c == 0 else 3, 4 if c == 0 else 2, P(stt)))
-            else:
-                timed("sao", lambda: port.orc_sao_stats(P(self.org[c]), pw_, P(rec[c]), pw_, pw_, ph_, cs, cs, bd, None, 5 if c == 0 else 3, 4 if c == 0 else 2, P(stt)))
-            sao_stats.append(stt)
-            so = rec[c].copy()
-            f = refl.vtmref_sao_apply if refl is not None else port.orc_sao_apply
-            timed("sao", lambda: f(P(rec[c]), pw_, P(so), pw_, pw_, ph_, cs, cs, bd, P(self.sao[c]), 0, mx))
-            sao_out.append(so)
-        out["sao_stats"] = sao_stats
-        # alf
-        cls = np.zeros((h // 4, w // 4), np.uint16)
-        alf_out = [p.copy() for p in sao_out]
-        if refl is not None:
-            timed("alf", lambda: refl.vtmref_alf_picture(1, P(sao_out[0]), P(sao_out[1]), P(sao_out[2]), P(alf_out[0]), P(alf_out[1]), P(alf_out[2]),
-                                                         w, h, CTU, bd, 1, P(self.alf_luma_coeff), P(self.alf_chroma_coeff),
-                                                         P(self.alf_enable[0]), P(self.alf_enable[1]), P(self.alf_enable[2]), None))
-            timed("alf", lambda: port.orc_alf_classify(P(sao_out[0]), w, w, h, bd, P(cls)))   # picture-wide classifier for the stats
-        else:
-            timed("alf", lambda: port.orc_alf_classify(P(sao_out[0]), w, w, h, bd, P(cls)))
-            timed("alf", lambda: port.orc_alf_filter_luma(P(sao_out[0]), w, P(alf_out[0]), w, w, h, CTU, P(cls), 1, P(self.alf_luma_coeff), P(self.alf_enable[0]), 0, mx))
-            for c in (1, 2):
-                timed("alf", lambda: port.orc_alf_filter_chroma(P(sao_out[c]), w // 2, P(alf_out[c]), w // 2, w // 2, h // 2, CTU // 2, P(self.alf_chroma_coeff), P(self.alf_enable[c]), 0, mx))
-        nct = self.nctu_x * self.nctu_y
-        a7 = np.zeros((nct, 25, 183), np.int64)
-        a5 = np.zeros((nct, 25, 57), np.int64)
-        ac = [np.zeros((nct, 1, 57), np.int64) for _ in range(2)]
-        if refl is not None:
-            timed("alf", lambda: refl.vtmref_alf_stats(P(self.org[0]), w, P(sao_out[0]), w, h, CTU, P(cls), 1, P(a7)))
-            timed("alf", lambda: refl.vtmref_alf_stats(P(self.org[0]), w, P(sao_out[0]), w, h, CTU, P(cls), 0, P(a5)))
-            for i, c in enumerate((1, 2)):
-                timed("alf", lambda: refl.vtmref_alf_stats(P(self.org[c]), w // 2, P(sao_out[c]), w // 2, h // 2, CTU // 2, None, 0, P(ac[i])))
-        else:
-            timed("alf", lambda: port.orc_alf_stats(P(self.org[0]), w, P(sao_out[0]), w, w, h, CTU, P(cls), 1, P(a7)))
-            timed("alf", lambda: port.orc_alf_stats(P(self.org[0]), w, P(sao_out[0]), w, w, h, CTU, P(cls), 0, P(a5)))
-            for i, c in enumerate((1, 2)):
-                timed("alf", lambda: port.orc_alf_stats(P(self.org[c]), w // 2, P(sao_out[c]), w // 2, w // 2, h // 2, CTU // 2, None, 0, P(ac[i])))
-        out.update({"cls": cls, "alf_stats7": a7, "alf_stats5": a5, "alf_stats_c": ac, "final": alf_out, "pred": pred})
-        return out, secs
 
 
 class _NullCtx:
