@@ -170,3 +170,53 @@ def test_sad_search_tie_rule():
     sad, best = ops.sad_search(dev(org), dev(refp), ops.struct_to_device(blk), 1, 16, 16, 0, -4, -4, 9, 9, 1, 1, mv)
     gb = best.cpu().numpy().view(ops.SEARCH_BEST)
     assert gb[0]["x"] == -4 and gb[0]["y"] == -4 and np.array_equal(gb, wbest)
+
+
+@pytest.mark.parametrize("h,ss,nx,ny,content", [(16, 1, 39, 39, "smooth"), (16, 1, 39, 39, "flat"), (16, 0, 17, 9, "smooth"), (8, 0, 40, 5, "noise"),
+                                               (32, 2, 7, 30, "smooth"), (16, 1, 1, 1, "smooth")])
+def test_sad_search_group_runs(h, ss, nx, ny, content):
+    """16-wide blocks on a 5-stride raster take the GROUP kernel (one staged window per run of horizontal neighbours, up to 8 blocks):
+    lists that mix full runs, short runs, runs broken by a vertical / horizontal offset, isolated blocks and a ragged tail; `flat`
+    content makes every SAD equal, so the motion-vector cost and the first-in-scan-order rule decide across lanes, units and strips."""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(h + 3 * nx + ny)
+    bd, m = 10, 136
+    W, H = 448, 192
+    PW, PH = W + 2 * m, H + 2 * m
+    if content == "flat":
+        org = np.full((H, W), 400, np.int16)
+        refp = np.full((PH, PW), 391, np.int16)
+    else:
+        org = cases.rand_plane(rng, H, W, bd, content)
+        refp = cases.rand_plane(rng, PH, PW, bd, content)
+    rows = []
+    def run(x0, y0, n, dx=0, dy=0):
+        for t in range(n):
+            rows.append((x0 + 16 * t, y0, m + x0 + 16 * t + dx, m + y0 + dy))
+    run(0, 0, 8); run(128, 0, 8, 3, -2); run(256, 0, 5, -7, 5)          # full groups and a 5-run (then the list continues elsewhere)
+    run(0, 32, 3, 1, 1); rows.append((48, 32, m + 48 + 2, m + 32 + 1))   # 3-run, then a block whose ref_x is off by one: run breaks
+    run(64, 32, 2, 1, 2); run(96, 32, 13, -1, -1)                        # vertical offset differs / a 13-run crossing group boundaries
+    for _ in range(6):                                                   # isolated blocks (even org x: the packed org rows are dword loads)
+        x, y = int(rng.integers(0, (W - 16) // 2)) * 2, int(rng.integers(0, H - h))
+        rows.append((x, y, m + x + int(rng.integers(-9, 10)), m + y + int(rng.integers(-9, 10))))
+    run(16, 96, 7, 0, 0)                                                 # ragged tail: nblocks is not a multiple of 8
+    blk = np.array(rows, dtype=ops.SEARCH_BLK)
+    blk = blk[blk["org_y"] + h <= H]
+    nb = blk.size
+    dx0, dy0 = -5 * (nx // 2), -5 * (ny // 2)
+    lam = 0.0 if content == "flat" and ny == 39 and False else float(rng.uniform(0.5, 90))
+    mv = ops.MvCost(lam, int(rng.integers(-60, 60)), int(rng.integers(-60, 60)), 2, 0)
+    want = np.zeros((nb, ny, nx), np.uint32)
+    wbest = np.zeros(nb, ops.SEARCH_BEST)
+    oracle().orc_sad_search(p(org), W, p(refp), PW, p(blk), nb, 16, h, ss, dx0, dy0, nx, ny, 5, 5, p(want), C.byref(mv), p(wbest))
+    sad, best = ops.sad_search(dev(org), dev(refp), ops.struct_to_device(blk), nb, 16, h, ss, dx0, dy0, nx, ny, 5, 5, mv, want_sad=False)
+    assert sad is None
+    assert np.array_equal(best.cpu().numpy().view(ops.SEARCH_BEST), wbest)
+    # lambda 0: the cost is the SAD alone -> on flat content EVERY position ties and the very first one must win
+    mv0 = ops.MvCost(0.0, 0, 0, 2, 0)
+    oracle().orc_sad_search(p(org), W, p(refp), PW, p(blk), nb, 16, h, ss, dx0, dy0, nx, ny, 5, 5, p(want), C.byref(mv0), p(wbest))
+    sad, best = ops.sad_search(dev(org), dev(refp), ops.struct_to_device(blk), nb, 16, h, ss, dx0, dy0, nx, ny, 5, 5, mv0, want_sad=False)
+    gb = best.cpu().numpy().view(ops.SEARCH_BEST)
+    assert np.array_equal(gb, wbest)
+    if content == "flat":
+        assert np.all(gb["x"] == dx0) and np.all(gb["y"] == dy0)

@@ -705,6 +705,137 @@ __global__ __launch_bounds__(MAXT, MINW) void sad_raster5c_kernel(const unsigned
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Raster kernel, GROUP form for 16-wide blocks ("r5g").  PMC of sad_raster5c_kernel on a 3840x2160 picture of 16x16 blocks
+// (profiles/r02a_pmc_sq.csv): 331 vector + 278 scalar instructions per wave item for the 128 v_sad_u16 that are the work -- a wave item
+// of a 16x16 block is only four software-pipeline stages long, so the window fill (every block stages its own 206-column window), the
+// item set-up (lane map, LDS address, cost table look-ups) and the arg-min epilogue outweigh the SAD loop.  Here a workgroup serves a
+// GROUP of up to 8 blocks that are horizontal neighbours in the reference picture (the caller's list order; runs are detected on the
+// device, a group that is not one run is served run by run):
+//   * ONE window for the run: (nx - 1) 5 + 16 n columns instead of n ((nx - 1) 5 + 16) -- 4.2x less fill for n = 8, nx = 39;
+//   * a wave item is (classes c / c + 2, row group, SUB-RUN of up to four blocks): block t of the run sees the same lane -> position
+//     map shifted by 16 t samples = 32 t bytes of LDS, so the set-up and the cost look-ups are paid once per four blocks and the
+//     per-block epilogue is 16 vector instructions (32-bit cost, packed (cost << 24 | scan index) key, one 64-bit compare);
+//   * the lower LDS demand per block allows strips of 12 raster rows (two full row groups: 36 + 3 rows of a 39-row raster in 42 row
+//     slots instead of 48) at three workgroups per CU.
+// Everything else (row pitch 20 / 44 mod 64 dwords, column classes, packed org rows as scalar operands, stage pipeline) is the r5c form.
+constexpr int R5G_MAXNB = 8;
+constexpr unsigned R5G_INVALID = 0x60000000u;          // cost of a position outside the raster: above every valid cost (SAD < 2^27, lambda * bits < 2^30), below 2^31
+
+// Per lane and block the two candidates (positions i0, i0 + 2) are folded into ONE 32-bit word, cost << 1 | (0: i0, 1: i0 + 2): the
+// caller passes c0 = cost offset << 1 and c1 = cost offset << 1 | 1, so the fold is two shift-adds and a minimum.  Scan order inside a
+// unit is lane order (see the lane map), so the wave's arg-min is a 32-bit minimum followed by "first lane that holds it".
+template <int OA>
+__device__ __forceinline__ void r5g_subrun(const unsigned* __restrict__ orgBlk, unsigned layoutDw, unsigned base, int ldsStep, int nStages, int nt,
+                                           int subShift1, unsigned c0, unsigned c1, unsigned (&kmin)[4])
+{
+  const R5cCursor cur0 = { 0u, 0u, 0 };
+#pragma unroll
+  for (int t = 0; t < 4; t++)
+  {
+    if (t >= nt) break;                                                      // wave-uniform
+    unsigned acc0 = 0, acc1 = 0;
+    r5c_positions<OA, true>(orgBlk + (size_t)t * 2u * layoutDw + (OA & 1) * layoutDw, base + 32u * t, ldsStep, cur0, nStages, 1, acc0, acc1);
+    kmin[t] = min((acc0 << subShift1) + c0, (acc1 << subShift1) + c1);
+  }
+}
+
+// One wave = one unit (classes c / c + 2, row group g, sub-run of up to four blocks) of the current run; the host launches
+// 64 * 2 * ceil(rowsPerStrip / 6) * ceil(nbg / 4) threads and guarantees nx <= 40 (one column group) and a best-candidate-only search.
+__global__ __launch_bounds__(1024, 6) void sad_raster5g_kernel(const unsigned* __restrict__ orgPacked, const Pel* __restrict__ ref, int rs,
+                                                               const vvcgpu_search_blk* __restrict__ blocks, int nblocks, int nbg, int h, int subShift,
+                                                               int dx0, int dy0, int nx, int ny, int rowsPerStrip, int pitchDw,
+                                                               int nstrips, unsigned invStrips, int total, int winBytes, vvcgpu_mvcost mv,
+                                                               vvcgpu_search_best* __restrict__ best)
+{
+  extern __shared__ __align__(16) unsigned refL[];
+  __shared__ unsigned long long wgKey[R5G_MAXNB];
+  const int tid = threadIdx.x;
+  const int chunk = (total + 7) >> 3;                                          // XCD-aware order, as r5c
+  const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (item >= total) return;
+  const int q = nstrips == 1 ? item : (int)__umulhi((unsigned)item, invStrips), j0 = (item - q * nstrips) * rowsPerStrip;
+  const int nj = min(rowsPerStrip, ny - j0);
+  const int b0 = q * nbg, nbk = min(nbg, nblocks - b0);
+  const int hs = h >> subShift;
+  const int winRows = (nj - 1) * 5 + h;
+  unsigned char* bitsX = reinterpret_cast<unsigned char*>(refL) + winBytes;   // [nx] then [rowsPerStrip]
+  unsigned char* bitsY = bitsX + nx;
+  unsigned* costTab = reinterpret_cast<unsigned*>(bitsX + ((nx + rowsPerStrip + 15) & ~15));   // lambda * bits, truncated (the host checked it stays below 2^30)
+  for (int n = tid; n < R5C_COST_N; n += (int)blockDim.x) costTab[n] = (unsigned)(unsigned long long)(mv.lambda * (double)n);
+  for (int n = tid; n < nx + nj; n += (int)blockDim.x)
+  {
+    const int v = n < nx ? (((dx0 + n * 5) << mv.cost_scale) - mv.pred_hor) : (((dy0 + (j0 + n - nx) * 5) << mv.cost_scale) - mv.pred_ver);
+    bitsX[n] = (unsigned char)expgolomb_bits(v >> mv.imv_shift);
+  }
+  const int nStages = hs >> 1;
+  const int ngrp = (nj + 5) / 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned layoutDw = (unsigned)(hs * 8);                                // one packed layout of a 16-wide block (even, then odd)
+  const int ldsStep = pitchDw << subShift;
+  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)refL;
+
+  for (int k0 = 0; k0 < nbk; )
+  {
+    // run of horizontal neighbours starting at block k0 (wave-uniform scalar loads)
+    const int rx = blocks[b0 + k0].ref_x, ry = blocks[b0 + k0].ref_y;
+    int n = 1;
+    while (k0 + n < nbk && blocks[b0 + k0 + n].ref_y == ry && blocks[b0 + k0 + n].ref_x == rx + 16 * n) n++;
+    const ptrdiff_t winOff = (ptrdiff_t)(ry + dy0 + j0 * 5) * rs + rx + dx0;
+    const int off = (int)(winOff & 7);
+    if (k0 > 0) __syncthreads();                                               // every wave is done with the previous run's window and keys
+    fill_window_cols<8>(refL, reinterpret_cast<const uint4*>(ref + (winOff - off)), rs >> 3, winRows, pitchDw,
+                        (((nx - 1) * 5 + 16 * n - 1 + off) >> 3) + 1, tid, (int)blockDim.x);
+    if (tid < R5G_MAXNB) wgKey[tid] = ~0ull;
+    __syncthreads();
+
+    const int nsub = (n + 3) >> 2;                                            // sub-runs of up to four blocks
+    const int it = wave / nsub, t0 = (wave - it * nsub) * 4, nt = min(4, n - t0);
+    if (it < 2 * ngrp)
+    {
+      const int c = it & 1, g = it >> 1;                                      // classes c and c + 2, row group g
+      const int OA = (c + off) & 3;
+      const int lane = tid & 63, ql = lane & 31, m0 = (ql * 26) >> 8, kk = ql - 10 * m0;
+      const bool dead = m0 >= 3;
+      const int jj = g * 6 + (lane >> 5) * 3 + (dead ? 0 : m0);
+      const int i0 = 4 * kk + c;                                              // positions i0 and i0 + 2
+      const int cx = 5 * (i0 < nx ? i0 : c) + off;                            // dead lanes re-read a live lane's address (broadcast)
+      const int jc = min(jj, nj - 1);
+      const unsigned base = ldsBase + (unsigned)(2 * (cx >> 2) + (jc * 5) * pitchDw) * 4u + 32u * (unsigned)t0;
+      const bool live = !dead && jj < nj;
+      const bool in0 = live && i0 < nx, in1 = live && i0 + 2 < nx;
+      const unsigned by = bitsY[jc], bx0 = bitsX[in0 ? i0 : 0], bx1 = bitsX[in1 ? i0 + 2 : 0];
+      const unsigned c0 = (in0 ? costTab[bx0 + by] : R5G_INVALID) << 1, c1 = ((in1 ? costTab[bx1 + by] : R5G_INVALID) << 1) | 1u;
+      const int bFirst = b0 + k0 + t0;
+      const unsigned* orgBlk = orgPacked + (size_t)bFirst * 2u * layoutDw;
+      unsigned kmin[4];
+      if (OA == 0)      r5g_subrun<0>(orgBlk, layoutDw, base, ldsStep, nStages, nt, subShift + 1, c0, c1, kmin);
+      else if (OA == 1) r5g_subrun<1>(orgBlk, layoutDw, base, ldsStep, nStages, nt, subShift + 1, c0, c1, kmin);
+      else if (OA == 2) r5g_subrun<2>(orgBlk, layoutDw, base, ldsStep, nStages, nt, subShift + 1, c0, c1, kmin);
+      else              r5g_subrun<3>(orgBlk, layoutDw, base, ldsStep, nStages, nt, subShift + 1, c0, c1, kmin);
+      // arg-min of the unit per block: 32-bit minimum, then the first lane that holds it (lane order = scan order: the lane map puts
+      // (row half, row, column) in that significance); every unit holds valid positions, so the minimum is a valid cost
+      int lane2 = tid & 63;
+      asm volatile("" : "+v"(lane2));                                         // re-derive the lane's scan index after the loops instead of keeping it live
+      const int ql2 = lane2 & 31, m2 = (ql2 * 26) >> 8;
+      const unsigned idx0 = (unsigned)((j0 + min(g * 6 + (lane2 >> 5) * 3 + m2, nj - 1)) * nx + 4 * (ql2 - 10 * m2) + c);
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+      {
+        if (t >= nt) break;
+        const unsigned km = wave_min_u32(kmin[t]);
+        const unsigned long long hit = __ballot(kmin[t] == km);
+        const int src = __builtin_ctzll(hit);
+        const unsigned idx = (unsigned)__builtin_amdgcn_readlane((int)idx0, src) + ((km & 1u) << 1);
+        if ((tid & 63) == 0) atomicMin(&wgKey[t0 + t], ((unsigned long long)(km >> 1) << 24) | idx);
+      }
+    }
+    __syncthreads();
+    if (tid < n) atomicMin(reinterpret_cast<unsigned long long*>(&best[b0 + k0 + tid].cost), wgKey[tid]);
+    k0 += n;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Dense small grids (step 1 in both directions, nx * ny <= 256: the +-4 window of xPatternSearch): the (block, position)
 // pairs of G = 256 / (nx ny) blocks are laid flat over the 256 lanes of a workgroup (81 positions: 3 blocks, 95 % of the
 // lanes busy, where one block per 128 lanes would leave a third idle); each block's org and window sit in LDS as biased
@@ -968,6 +1099,50 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
     }
   }
   static const int r5cOff = getenv("VVCGPU_NO_R5C") ? 1 : 0;              // A/B timing switch
+  static const int r5gOff = getenv("VVCGPU_NO_R5G") ? 1 : 0;              // A/B timing switch: 16-wide blocks through the per-block r5c form
+  if (!r5cOff && !r5gOff && sx == 5 && sy == 5 && w == 16 && (org_stride & 1) == 0 && (ref_stride & 7) == 0 &&
+      ((uintptr_t)org & 3) == 0 && ((uintptr_t)ref & 15) == 0 && (long long)nx * ny < (1 << 24) && nx >= 1 &&
+      best && !sad_out && nx <= 40 && mvcost_host->lambda >= 0.0 && mvcost_host->lambda < 8.0e6)   // 32-bit cost: SAD < 2^27, lambda * bits < 2^30
+  {
+    static const int nbgEnv = getenv("VVCGPU_R5G_NB") ? atoi(getenv("VVCGPU_R5G_NB")) : R5G_MAXNB;
+    static const int rpsEnv = getenv("VVCGPU_R5G_RPS") ? atoi(getenv("VVCGPU_R5G_RPS")) : 0;
+    static const int budgetKB = getenv("VVCGPU_R5G_KB") ? atoi(getenv("VVCGPU_R5G_KB")) : 50;
+    const int nbg = nbgEnv < 1 ? 1 : nbgEnv > R5G_MAXNB ? R5G_MAXNB : nbgEnv;
+    const int hsR = h >> sub_shift;
+    const int Ww = (nx - 1) * 5 + 16 * nbg;
+    int pitch = (((Ww - 1 + 7) >> 3) + 1) * 4;
+    while ((pitch & 63) != 20 && (pitch & 63) != 44) pitch += 4;
+    auto win_bytes = [&](int rps) { return (size_t)((rps - 1) * 5 + h) * pitch * 4 + 64; };
+    int rps = 6;                                                           // whole row groups (6 raster rows) per strip, as many as the budget allows
+    while (rps + 6 <= ny + 5 && rps + 6 <= 24 && win_bytes(rps + 6) <= (size_t)budgetKB * 1024) rps += 6;
+    if (rpsEnv > 0) rps = cdiv(rpsEnv, 3) * 3;
+    if (rps >= ny) rps = cdiv(ny, 3) * 3;
+    const int nstrips = cdiv(ny, rps);
+    const size_t winB = win_bytes(rps), smem = winB + (((size_t)nx + rps + 15) & ~(size_t)15) + R5C_COST_N * sizeof(unsigned);
+    const int ngroups = cdiv(nblocks, nbg);
+    if (smem <= 150 * 1024 && (hsR & 1) == 0 && hsR >= 2 && nx + rps <= 4096 && (unsigned long long)ngroups * nstrips * nstrips < (1ull << 32))
+    {
+      const int nsub = cdiv(nbg, 4), units = 2 * cdiv(rps, 6) * nsub;
+      const int threads = 64 * units;                                     // one wave per unit (<= 16: rps <= 24, nbg <= 8)
+      const int total = ngroups * nstrips;
+      const size_t packedDw = (size_t)nblocks * 2 * hsR * 8;
+      unsigned* packed = static_cast<unsigned*>(vvcgpu_scratch(st0, packedDw * sizeof(unsigned)));
+      if (!packed) return VVCGPU_E_DEVICE;
+      hipLaunchKernelGGL(r5c_pack_org_kernel, dim3((unsigned)((packedDw + 255) / 256)), dim3(256), 0, st0, org, org_stride, blocks, nblocks,
+                         w, hsR, sub_shift, packed);
+      VVC_LAUNCH_CHECK();
+      const vvcgpu_mvcost mv = *mvcost_host;
+      VVC_HIP(hipMemsetAsync(best, 0xFF, (size_t)nblocks * sizeof(vvcgpu_search_best), st0));
+      if (smem > 48 * 1024)
+        VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster5g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      hipLaunchKernelGGL(sad_raster5g_kernel, dim3(cdiv(total, 8) * 8), dim3(threads), smem, st0, packed, ref, ref_stride, blocks, nblocks, nbg, h, sub_shift,
+                         dx0, dy0, nx, ny, rps, pitch, nstrips, 0xFFFFFFFFu / (unsigned)nstrips + 1u, total, (int)winB, mv, best);
+      VVC_LAUNCH_CHECK();
+      hipLaunchKernelGGL(sad_best_decode_kernel, dim3(cdiv(nblocks, 256)), dim3(256), 0, st0, nblocks, dx0, dy0, nx, sx, sy, mv, best);
+      VVC_LAUNCH_CHECK();
+      return VVCGPU_OK;
+    }
+  }
   if (!r5cOff && sx == 5 && sy == 5 && (w == 16 || w == 32 || w == 64 || w == 128) && (org_stride & 1) == 0 && (ref_stride & 7) == 0 &&
       ((uintptr_t)org & 3) == 0 && ((uintptr_t)ref & 15) == 0 && (long long)nx * ny < (1 << 24) && nx >= 1)
   {
