@@ -822,11 +822,15 @@ __global__ __launch_bounds__(1024, 6) void sad_raster5g_kernel(const unsigned* _
       for (int t = 0; t < 4; t++)
       {
         if (t >= nt) break;
-        const unsigned km = wave_min_u32(kmin[t]);
-        const unsigned long long hit = __ballot(kmin[t] == km);
+        // cost first, then the lane, then the lane's own candidate bit: (lane, candidate) is the scan order, the candidate bit must
+        // not take part in the minimum across lanes
+        const unsigned cst = kmin[t] >> 1;
+        const unsigned km = wave_min_u32(cst);
+        const unsigned long long hit = __ballot(cst == km);
         const int src = __builtin_ctzll(hit);
-        const unsigned idx = (unsigned)__builtin_amdgcn_readlane((int)idx0, src) + ((km & 1u) << 1);
-        if ((tid & 63) == 0) atomicMin(&wgKey[t0 + t], ((unsigned long long)(km >> 1) << 24) | idx);
+        const unsigned sel = (unsigned)__builtin_amdgcn_readlane((int)kmin[t], src) & 1u;
+        const unsigned idx = (unsigned)__builtin_amdgcn_readlane((int)idx0, src) + (sel << 1);
+        if ((tid & 63) == 0) atomicMin(&wgKey[t0 + t], ((unsigned long long)km << 24) | idx);
       }
     }
     __syncthreads();
