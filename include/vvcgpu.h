@@ -298,6 +298,31 @@ typedef struct vvcgpu_dqtr_desc {
 } vvcgpu_dqtr_desc;
 int vvcgpu_dequant_tr_inv_batch(const vvc_coef* level_base, vvc_pel* resi_base, const vvcgpu_dqtr_desc* descs, int n,
                                 int bit_depth, vvc_coef* coeff_out, void* stream);
+/* ---- fused residual chain of one TU  (InterSearch::xEstimateInterResidualQT, EncoderLib/InterSearch.cpp:4254-4504:
+ *          residual = org - pred (CodingStructure::getResiBuf / subtract, CommonLib/Buffer.h:321-339), TrQuant::transformNxN :4409
+ *          = xT (TrQuant.cpp:694-739) + Quant::quant (Quant.cpp:721-834, sign bit hiding :142-273), TrQuant::invTransformNxN :4497
+ *          = Quant::dequant (Quant.cpp:277-428) + xIT (TrQuant.cpp:743-791), reconstruction clip(pred + resi') (Buffer.cpp:66-79)) ----
+ * What vvcgpu_pelop_batch(subtract) -> vvcgpu_tr_fwd_batch -> vvcgpu_quant_batch -> vvcgpu_dequant_tr_inv_batch -> vvcgpu_pelop_batch(reco)
+ * compute for the same TUs, in ONE pass: the residual, the coefficients and the de-quantised coefficients never leave the chip; per TU the
+ * levels (W x H int32 contiguous at level_off, zero outside the kept 32 x 32 low-frequency region), their absolute sum (abs_sum[i], as
+ * Quant::quant's uiAbsSum) and the reconstructed samples are written once.  Bit-exact with that sequence (tests/test_gpu_resichain.py).
+ * Preconditions: org / pred samples within the bit depth (|residual| <= 1023), tr_hor / tr_ver in 0..2 (transform skip and RDPCM TUs go
+ * through the separate entry points), qp as vvcgpu_quant_desc.  TUs of 16 / 32 / 64 squared run their four 1-D stages on the matrix cores
+ * (v_mfma_f32_16x16x32_f16 on exact integer limbs), 4 x 4 and 8 x 8 in lane groups, every other shape on a generic wave-per-TU path.       */
+typedef struct vvcgpu_resi_chain_desc {
+  int64_t org_off, pred_off, rec_off;   /* elements from org_base / pred_base / rec_base (Pel) */
+  int64_t level_off;                    /* elements from level_base (TCoeff) */
+  int32_t org_stride, pred_stride, rec_stride;
+  int16_t w, h;                         /* 2..64, powers of two */
+  int8_t  tr_hor, tr_ver;               /* 0 DCT-II, 1 DCT-VIII, 2 DST-VII */
+  int8_t  intra_slice;                  /* quantiser rounding offset 171 (I slice) or 85, as vvcgpu_quant_desc */
+  int8_t  sign_hiding;
+  int32_t qp;                           /* QpParam::Qp of the component (bit-depth offset included) */
+  int32_t reserved[2];                  /* sizeof == 64 */
+} vvcgpu_resi_chain_desc;
+int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, vvc_pel* rec_base, vvc_coef* level_base,
+                            const vvcgpu_resi_chain_desc* descs, int n, int bit_depth, int clp_min, int clp_max, uint32_t* abs_sum,
+                            void* stream);
 /* The coefficient scan the library replays (host copy, out[scanIdx] = raster position; w, h in 2..64 powers of two). */
 int vvcgpu_scan_order_host(int w, int h, uint16_t* out);
 /* ---- N3 ("next" row): affine gradient search kernels  (AffineGradientSearch table slots m_HorizontalSobelFilter /

@@ -1,0 +1,142 @@
+"""vvcgpu_resi_chain_batch (residual -> T1 -> Quant::quant -> Quant::dequant -> T2 -> reconstruction in one pass) against the oracle's
+restatement of the five separate steps (orc_pelop_batch / orc_tr_fwd_batch / orc_quant_batch / orc_dequant_tr_inv_batch / orc_pelop_batch),
+each of which is pinned against the compiled reference (tests/test_oracle_golden.py)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+import torch
+
+import cases
+from oraclelib import oracle, p
+
+pytestmark = pytest.mark.gpu
+
+TR_DESC = np.dtype([("resi_off", "<i8"), ("coeff_off", "<i8"), ("resi_stride", "<i4"), ("w", "<i2"), ("h", "<i2"),
+                    ("tr_hor", "i1"), ("tr_ver", "i1"), ("reserved", "<i2"), ("reserved2", "<i4")])
+QUANT_DESC = np.dtype([("coeff_off", "<i8"), ("level_off", "<i8"), ("w", "<i2"), ("h", "<i2"), ("intra_slice", "i1"), ("sign_hiding", "i1"),
+                       ("reserved", "<i2"), ("qp", "<i4"), ("reserved2", "<i4")])
+DQTR_DESC = np.dtype([("resi_off", "<i8"), ("level_off", "<i8"), ("resi_stride", "<i4"), ("w", "<i2"), ("h", "<i2"),
+                      ("tr_hor", "i1"), ("tr_ver", "i1"), ("dep_quant", "i1"), ("reserved", "i1"), ("qp", "<i4")])
+PELOP_DESC = np.dtype([("src0_off", "<i8"), ("src1_off", "<i8"), ("dst_off", "<i8"), ("src0_stride", "<i4"),
+                       ("src1_stride", "<i4"), ("dst_stride", "<i4"), ("w", "<i2"), ("h", "<i2")])
+
+
+class PelopCfg(C.Structure):
+    _fields_ = [("scale", C.c_int32), ("shift", C.c_int32), ("offset", C.c_int32), ("clip", C.c_int32),
+                ("clp_min", C.c_int32), ("clp_max", C.c_int32)]
+
+
+def oracle_chain(org, pred, tus, bd, W):
+    """tus: list of (x, y, w, h, tr_hor, tr_ver, qp, intra, sbh) -> (levels, abs_sum, rec)"""
+    H = org.shape[0]
+    mx = (1 << bd) - 1
+    n = len(tus)
+    tr = np.zeros(n, TR_DESC); qd = np.zeros(n, QUANT_DESC); dq = np.zeros(n, DQTR_DESC); bands = np.zeros(n, PELOP_DESC)
+    coff = 0
+    for i, (x, y, w, h, th, tv, qp, intra, sbh) in enumerate(tus):
+        tr[i] = (y * W + x, coff, W, w, h, th, tv, 0, 0)
+        qd[i] = (coff, coff, w, h, intra, sbh, 0, qp, 0)
+        dq[i] = (y * W + x, coff, W, w, h, th, tv, 0, 0, qp)
+        bands[i] = (y * W + x, y * W + x, y * W + x, W, W, W, w, h)
+        coff += w * h
+    resi = np.zeros((H, W), np.int16); resi2 = np.zeros((H, W), np.int16)
+    coef = np.zeros(coff, np.int32); level = np.zeros(coff, np.int32); dqc = np.zeros(coff, np.int32); abs_sum = np.zeros(n, np.uint32)
+    rec = pred.copy()
+    o = oracle()
+    o.orc_pelop_batch(3, p(org), p(pred), p(resi), p(bands), n, C.byref(PelopCfg(0, 0, 0, 0, 0, mx)))
+    o.orc_tr_fwd_batch(p(resi), p(coef), p(tr), n, bd)
+    o.orc_quant_batch(p(coef), p(level), p(qd), n, bd, p(abs_sum))
+    o.orc_dequant_tr_inv_batch(p(level), p(resi2), p(dq), n, bd, p(dqc))
+    o.orc_pelop_batch(1, p(pred), p(resi2), p(rec), p(bands), n, C.byref(PelopCfg(0, 0, 0, 1, 0, mx)))
+    return level, abs_sum, rec, tr["coeff_off"].copy()
+
+
+def gpu_chain(org, pred, tus, bd, W, coffs):
+    from vvcsoftware_vtm_amd import ops
+    n = len(tus)
+    d = np.zeros(n, ops.RC_DESC)
+    for i, (x, y, w, h, th, tv, qp, intra, sbh) in enumerate(tus):
+        d[i] = (y * W + x, y * W + x, y * W + x, coffs[i], W, W, W, w, h, th, tv, intra, sbh, qp, (0, 0))
+    total = int(sum(t[2] * t[3] for t in tus))
+    dorg, dpred = torch.from_numpy(org).cuda(), torch.from_numpy(pred).cuda()
+    drec = dpred.clone()
+    dlevel = torch.full((total,), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+    a = ops.resi_chain_batch(dorg, dpred, drec, dlevel, ops.struct_to_device(d), n, bd, (0, (1 << bd) - 1))
+    torch.cuda.synchronize()
+    return dlevel.cpu().numpy(), a.cpu().numpy().view(np.uint32), drec.cpu().numpy()
+
+
+def tile(W, H, shapes, rng, qps, bd, types_small=True):
+    """non-overlapping TUs: the plane is cut into 64x64 cells, each cell tiled with one shape"""
+    tus = []
+    ci = 0
+    for y0 in range(0, H, 64):
+        for x0 in range(0, W, 64):
+            w, h = shapes[ci % len(shapes)]
+            ci += 1
+            for ty in range(0, 64, h):
+                for tx in range(0, 64, w):
+                    th = int(rng.integers(0, 3)) if w <= 32 and w >= 4 else 0
+                    tv = int(rng.integers(0, 3)) if h <= 32 and h >= 4 else 0
+                    tus.append((x0 + tx, y0 + ty, w, h, th, tv, int(rng.choice(qps)) + 6 * (bd - 8), int(rng.integers(0, 2)), int(rng.integers(0, 4) != 0)))
+    return tus
+
+
+@pytest.mark.parametrize("bd,content", [(10, "smooth"), (10, "uniform"), (8, "smooth"), (10, "extreme")])
+def test_resi_chain_squares(bd, content):
+    """the shapes of the canonical workload (64 ... 4 squared, every transform pair, QP 22..37, sign hiding on / off, both slice types)"""
+    rng = np.random.default_rng(bd * 5 + len(content))
+    W, H = 448, 192
+    org = cases.rand_plane(rng, H, W, bd, content)
+    pred = cases.rand_plane(rng, H, W, bd, "smooth" if content != "extreme" else "extreme")
+    if content == "smooth":                      # small residual: many zero levels, sparse coefficient groups (last-group logic)
+        pred = np.clip(org + rng.integers(-6, 7, org.shape), 0, (1 << bd) - 1).astype(np.int16)
+    tus = tile(W, H, [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4)], rng, [22, 27, 32, 37, 45], bd)
+    lv, asum, rec, coffs = oracle_chain(org, pred, tus, bd, W)
+    glv, gsum, grec = gpu_chain(org, pred, tus, bd, W, coffs)
+    assert np.array_equal(gsum, asum)
+    assert np.array_equal(glv, lv)
+    assert np.array_equal(grec, rec)
+
+
+def test_resi_chain_rectangles_and_chroma_shapes():
+    """every other W x H in 2..64 takes the generic path: rectangles with 2:1 ... 16:1 aspect, 2-wide chroma TUs"""
+    rng = np.random.default_rng(77)
+    bd, W, H = 10, 512, 128
+    org = cases.rand_plane(rng, H, W, bd, "smooth")
+    pred = np.clip(org + rng.integers(-40, 41, org.shape), 0, 1023).astype(np.int16)
+    shapes = [(64, 32), (32, 64), (16, 32), (32, 16), (8, 16), (4, 64), (64, 4), (16, 4), (4, 8), (8, 4), (2, 8), (8, 2), (2, 2), (16, 64), (32, 8), (2, 32)]
+    tus = tile(W, H, shapes, rng, [27, 32, 37], bd)
+    lv, asum, rec, coffs = oracle_chain(org, pred, tus, bd, W)
+    glv, gsum, grec = gpu_chain(org, pred, tus, bd, W, coffs)
+    assert np.array_equal(gsum, asum)
+    assert np.array_equal(glv, lv)
+    assert np.array_equal(grec, rec)
+
+
+def test_resi_chain_residual_outside_range_falls_back():
+    """samples outside the bit depth (|residual| > 1023) leave the matrix-core path's exactness range: those TUs are served by the generic path"""
+    rng = np.random.default_rng(5)
+    bd, W, H = 10, 192, 64
+    org = rng.integers(-3000, 3000, (H, W)).astype(np.int16)
+    pred = rng.integers(0, 1024, (H, W)).astype(np.int16)
+    tus = tile(W, H, [(64, 64), (32, 32), (16, 16)], rng, [32], bd)
+    lv, asum, rec, coffs = oracle_chain(org, pred, tus, bd, W)
+    glv, gsum, grec = gpu_chain(org, pred, tus, bd, W, coffs)
+    assert np.array_equal(gsum, asum) and np.array_equal(glv, lv) and np.array_equal(grec, rec)
+
+
+def test_resi_chain_rejects_transform_skip_descriptor():
+    from vvcsoftware_vtm_amd import ops
+    bd, W, H = 10, 64, 64
+    org = np.full((H, W), 500, np.int16)
+    tus = [(0, 0, 4, 4, 3, 0, 32 + 12, 0, 1), (8, 0, 4, 4, 0, 0, 32 + 12, 0, 1)]
+    d = np.zeros(2, ops.RC_DESC)
+    for i, (x, y, w, h, th, tv, qp, intra, sbh) in enumerate(tus):
+        d[i] = (y * W + x, y * W + x, y * W + x, 16 * i, W, W, W, w, h, th, tv, intra, sbh, qp, (0, 0))
+    t = torch.from_numpy(org).cuda()
+    rec = t.clone()
+    lvl = torch.zeros(32, dtype=torch.int32, device="cuda")
+    a = ops.resi_chain_batch(t, t.clone(), rec, lvl, ops.struct_to_device(d), 2, bd).cpu().numpy().view(np.uint32)
+    assert a[0] == 0xFFFFFFFF and a[1] == 0

@@ -190,3 +190,16 @@ def test_bench_workload_4k_matches_oracle():
     c2, _ = run_cpu(wl, (oracle(), ref()), "reference") if ref_available() else run_cpu(wl, oracle(), "port")
     for k in ("pred", "coef", "final", "cls", "alf_stats7"):
         _cmp(k + "#handover", g2[k], c2[k])
+
+
+def test_fused_residual_chain_equals_separate_entry_points():
+    """vvcgpu_resi_chain_batch inside the workload (default) against the five separate entry points it replaces, on the same step"""
+    from vvcsoftware_vtm_amd.workload import Workload
+    a = Workload(832, 480, 10, seed=9, raster_range=20, me_sizes=(16,))
+    b = Workload(832, 480, 10, seed=9, raster_range=20, me_sizes=(16,), fused_resi=False)
+    _, oa = a.run_gpu()
+    _, ob = b.run_gpu()
+    torch.cuda.synchronize()
+    assert torch.equal(oa["coef"], ob["coef"]) and torch.equal(oa["abs_sum"], ob["abs_sum"])
+    for x, y in zip(oa["final"], ob["final"]):
+        assert torch.equal(x, y)

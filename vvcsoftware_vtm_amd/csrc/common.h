@@ -18,6 +18,11 @@ int vvcgpu_frac_refine_launch(const vvc_pel* org, int org_stride, const vvc_pel*
                               int w, int h, int bit_depth, int clp_min, int clp_max, int use_hadamard, const vvcgpu_mvcost* mvcost_host,
                               const int* preds, vvcgpu_frac_result* results, void* stream);
 
+// device addresses (current device) of the transform matrices as int32 (tr32[type][size] row-major T[k][n] at type * 5460 + (n n - 4) / 3, tr32t its
+// transpose), of the raster position -> scan index tables (dqInv + scanOff[(log2 w - 1) * 6 + log2 h - 1]); uploaded on first use (transform.hip)
+struct VvcTrTables { const int* tr32; const int* tr32t; const unsigned short* dqInv; const int* scanOff; };
+int vvcgpu_tr_tables(VvcTrTables* out);
+
 #define VVC_CHECK_ARG(cond, ...)                                   \
   do { if (!(cond)) { vvcgpu_set_error(__VA_ARGS__); return VVCGPU_E_ARG; } } while (0)
 

@@ -1,0 +1,897 @@
+// resichain.hip -- the residual chain of a TU in one pass (vvcgpu_resi_chain_batch):
+//   residual = org - pred -> forward transform (xTrMxN_EMT, TrQuant.cpp:138-220) -> Quant::quant with sign bit hiding (Quant.cpp:721-834,
+//   :142-273) -> Quant::dequant (Quant.cpp:277-428) -> inverse transform (xITrMxN_EMT, TrQuant.cpp:238-310) -> clip(pred + resi')
+// i.e. what InterSearch::xEstimateInterResidualQT does per TU between :4409 (transformNxN) and :4504 (distortion of the reconstruction).
+// The separate entry points (vvcgpu_pelop_batch / tr_fwd / quant / dequant_tr_inv / pelop) move the residual, the coefficients and the
+// de-quantised coefficients through HBM five times; here they stay in registers / LDS, the levels and the reconstruction are written once.
+//
+// Three kernels behind one entry point, fed by a device-side classification of the descriptor list:
+//   * 16 / 32 / 64 squared: ONE WAVE PER TU, all four 1-D stages on the matrix cores.  v_mfma_f32_16x16x32_f16 accumulates in f32, which is
+//     exact for integers below 2^24: the matrix entries (|c| <= 362) and the residual (|x| <= 1023) are exact f16 values and a 64-term row sum
+//     stays below 2^24; the 16-bit intermediates of the later stages are split into two signed 8-bit limbs (t = 256 hi + lo), one MFMA chain per
+//     limb, recombined in int32 with the reference's rounding shift and clipping.  The result tile of one stage is the operand of the next
+//     WITHOUT leaving the lane: a 16x16 result has its column on the lane and four consecutive rows in registers, the next product sums over
+//     that row index, and the k order of an MFMA is free as long as both operands agree -- so the matrix operand is read from LDS in the
+//     k order the result registers already have.  (forward: M1 = X Th^T, C = Tv M1; inverse: Y1^T = Cq^T Tv, R^T = Th^T Y1^T: every product
+//     sums over the row index of the previous result.)
+//   * 4 x 4 and 8 x 8: lane groups of 4 / 8 lanes per TU (16 / 8 TUs per wave), integer multiply-adds, the two transposes through wave-private LDS.
+//   * every other shape (rectangles, 2-wide chroma): generic wave-per-TU path through LDS buffers (correct for every W x H in 2..64, slow).
+// The quantiser works in the layout all three produce -- a lane holds four vertically consecutive coefficients of one column, an aligned quad
+// of lanes holds a 4x4 coefficient group: sign bit hiding is decided per quad with DPP quad permutes.
+#include "common.h"
+
+namespace {
+
+typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h4 __attribute__((ext_vector_type(4)));
+typedef float f4 __attribute__((ext_vector_type(4)));
+typedef vvcgpu_resi_chain_desc RcDesc;
+
+__device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
+#define RC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
+
+// ---- work lists (device): hdr[0..5] = counts of the classes 64, 32, 16, 8, 4, generic; hdr[6] = work counter of the matrix-core kernel
+constexpr int RC_HDR = 8;
+enum { RC_C64 = 0, RC_C32, RC_C16, RC_C8, RC_C4, RC_CGEN, RC_NCLS };
+
+__device__ __forceinline__ int rc_class(const RcDesc& d)
+{
+  if (d.w == d.h)
+  {
+    if (d.w == 64) return RC_C64;
+    if (d.w == 32) return RC_C32;
+    if (d.w == 16) return RC_C16;
+    if (d.w == 8) return RC_C8;
+    if (d.w == 4) return RC_C4;
+  }
+  return RC_CGEN;
+}
+
+__global__ __launch_bounds__(256) void rc_classify_kernel(const RcDesc* __restrict__ descs, int n, int* __restrict__ hdr, int* __restrict__ lists,
+                                                          unsigned* __restrict__ absSum)
+{
+  const int ti = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  int cls = -1;
+  if (ti < n)
+  {
+    const RcDesc d = descs[ti];
+    const bool ok = d.tr_hor >= 0 && d.tr_hor <= 2 && d.tr_ver >= 0 && d.tr_ver <= 2 && d.w >= 2 && d.w <= 64 && d.h >= 2 && d.h <= 64 &&
+                    (d.w & (d.w - 1)) == 0 && (d.h & (d.h - 1)) == 0 && (d.w <= 32 || d.tr_hor == 0) && (d.h <= 32 || d.tr_ver == 0);
+    if (ok) cls = rc_class(d);
+    else absSum[ti] = 0xFFFFFFFFu;                                           // precondition violated: TU not served, marked
+  }
+#pragma unroll
+  for (int k = 0; k < RC_NCLS; k++)
+  {
+    const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == k);
+    if (m == 0ull) continue;
+    int base = 0;
+    if (lane == 0) base = atomicAdd(&hdr[k], (int)__popcll(m));
+    base = __builtin_amdgcn_readfirstlane(base);
+    if (cls == k) lists[(size_t)k * n + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = ti;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Quantiser / de-quantiser of one TU (flat scaling lists)
+struct RcQ
+{
+  unsigned mul;                       // quantiser scale * (181 for 2:1 shapes)
+  int qBits, qBits8;
+  long long add;
+  int dqScale, rightShift, inMin, inMax;
+  bool sbh;
+};
+__device__ __forceinline__ RcQ rc_qparams(int w, int h, int qp, int bd, int intraSlice, int signHiding)
+{
+  RcQ q;
+  const int lw = ilog2(w), lh = ilog2(h), per = qp / 6, rem = qp - 6 * per;
+  const int transformShift = 15 - bd - ((lw + lh) >> 1);
+  const bool sqrt2 = ((lw + lh) & 1) != 0;
+  const int scale = rem == 0 ? 26214 : rem == 1 ? 23302 : rem == 2 ? 20560 : rem == 3 ? 18396 : rem == 4 ? 16384 : 14564;
+  q.mul = (unsigned)scale * (sqrt2 ? 181u : 1u);
+  q.qBits = 14 + per + transformShift + (sqrt2 ? 7 : 0);
+  q.qBits8 = q.qBits - 8;
+  q.add = (long long)(intraSlice ? 171 : 85) << (q.qBits - 9);
+  const int invq = rem == 0 ? 40 : rem == 1 ? 45 : rem == 2 ? 51 : rem == 3 ? 57 : rem == 4 ? 64 : 72;
+  q.dqScale = invq * (sqrt2 ? 181 : 1);
+  q.rightShift = (sqrt2 ? 8 : 0) + (6 - (transformShift + per));
+  const int targetBits = min(16, 32 + q.rightShift - 7);
+  q.inMin = -(1 << (targetBits - 1)); q.inMax = (1 << (targetBits - 1)) - 1;
+  q.sbh = signHiding && w >= 4 && h >= 4;
+  return q;
+}
+__device__ __forceinline__ int rc_quant_one(const RcQ& q, int c, int& deltaU, int& mag)
+{
+  const unsigned long long tmp = (unsigned long long)(unsigned)abs(c) * q.mul;
+  mag = (int)((tmp + (unsigned long long)q.add) >> q.qBits);
+  deltaU = (int)((long long)(tmp - ((unsigned long long)(unsigned)mag << q.qBits)) >> q.qBits8);
+  return min(max(c < 0 ? -mag : mag, -32768), 32767);
+}
+__device__ __forceinline__ int rc_dequant_one(const RcQ& q, int lv)
+{
+  const long long c = min(max(lv, q.inMin), q.inMax);
+  const long long v = q.rightShift > 0 ? (c * q.dqScale + (1ll << (q.rightShift - 1))) >> q.rightShift : (c * q.dqScale) << -q.rightShift;
+  return (int)min(max(v, -32768ll), 32767ll);
+}
+
+__device__ __forceinline__ unsigned quad_or(unsigned v)
+{
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);      // quad_perm [1,0,3,2]
+  v |= (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);      // quad_perm [2,3,0,1]
+  return v;
+}
+__device__ __forceinline__ int quad_min(int v)
+{
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0xB1, 0xF, 0xF, false));
+  v = min(v, __builtin_amdgcn_update_dpp(0, v, 0x4E, 0xF, 0xF, false));
+  return v;
+}
+__device__ __forceinline__ int wave_max_i32(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = max(v, __shfl_xor(v, o));
+  return v;
+}
+__device__ __forceinline__ int wave_sum_i32(int v)
+{
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// scan position (diagonal 4x4 scan: 0 4 1 8 5 2 12 9 6 3 13 10 7 14 11 15 in raster terms) of (row r, column x) inside a coefficient group
+__device__ __forceinline__ int rc_kpos(int r, int x)
+{
+  const unsigned tab = r == 0 ? 0x9520u : r == 1 ? 0xC841u : r == 2 ? 0xEB73u : 0xFDA6u;
+  return (int)((tab >> (4 * x)) & 15u);
+}
+
+// any level of the quad's coefficient group non-zero?
+__device__ __forceinline__ bool rc_cg_nonzero(const int (&lv)[4])
+{
+  return quad_or((unsigned)((lv[0] | lv[1] | lv[2] | lv[3]) != 0)) != 0u;
+}
+
+// Sign bit hiding of one coefficient group (xSignBitHidingHDQ, Quant.cpp:142-273; logic as quant_tu in transform.hip, which is pinned against
+// the reference): the lane holds rows 0..3 of column x = lane & 3 of the group; cf = coefficients, du = the quantiser's deltaU.
+__device__ __forceinline__ void rc_sbh_quad(int (&lv)[4], const int (&du)[4], const int (&cf)[4], bool isLast, int lane)
+{
+  const int x = lane & 3;
+  unsigned mA = 0, mB = 0;                                    // mA: non-zero (low half) | odd (high half) per scan position; mB: negative
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+  {
+    const int k = rc_kpos(r, x);
+    if (lv[r] != 0) mA |= 1u << k;
+    if (lv[r] & 1) mA |= 0x10000u << k;
+    if (lv[r] < 0) mB |= 1u << k;
+  }
+  mA = quad_or(mA); mB = quad_or(mB);
+  const unsigned nz = mA & 0xFFFFu;
+  const int first = nz ? __ffs((int)nz) - 1 : 16, last = nz ? 31 - __clz((int)nz) : -1;
+  const unsigned parity = (unsigned)__popc(mA >> 16) & 1u;
+  const unsigned signbit = nz ? ((mB >> first) & 1u) : 1u;
+  const bool fix = last - first >= 4 && signbit != parity;
+  const int start = isLast ? last : 15;
+  constexpr int BIG = 1 << 20;
+  int bestKey = BIG * 32, bestChange = 0, bestR = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++)
+  {
+    const int k = rc_kpos(r, x);
+    int cost = BIG, change = 0;
+    if (k <= start)
+    {
+      if (lv[r] != 0)
+      {
+        if (du[r] > 0) { cost = -du[r]; change = 1; }
+        else if (!(k == first && abs(lv[r]) == 1)) { cost = du[r]; change = -1; }
+      }
+      else if (k < first) { if ((cf[r] >= 0 ? 0u : 1u) == signbit) { cost = -du[r]; change = 1; } }
+      else { cost = -du[r]; change = 1; }
+    }
+    const int key = cost * 32 + (15 - k);
+    if (key < bestKey) { bestKey = key; bestChange = change; bestR = r; }
+  }
+  const int qmin = quad_min(bestKey);
+  if (fix && bestKey == qmin)                                 // keys are distinct inside a group (the scan position is part of the key)
+  {
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+      if (r == bestR)
+      {
+        int change = bestChange;
+        if (lv[r] == 32767 || lv[r] == -32768) change = -1;
+        lv[r] += cf[r] >= 0 ? change : -change;
+      }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Matrix-core path: f16 copies of the matrices in LDS.  Per type t and size n in {16, 32}: T (row-major T[j][k]) and its transpose; for 64
+// DCT-II only.  Rows are padded by 16 bytes, which spreads the 16 rows read by one ds_read_b64 / b128 over all banks.
+constexpr int RC_S16 = 16 * 24, RC_S32 = 32 * 40, RC_S64 = 64 * 72;                  // halves per matrix copy (row pitch n + 8)
+constexpr int RC_TYPE = 2 * RC_S16 + 2 * RC_S32;
+constexpr int RC_TAB_HALVES = 3 * RC_TYPE + 2 * RC_S64;
+__device__ __forceinline__ int rc_tab_off(int type, int n, int transposed)
+{
+  if (n == 64) return 3 * RC_TYPE + transposed * RC_S64;
+  return type * RC_TYPE + (n == 16 ? transposed * RC_S16 : 2 * RC_S16 + transposed * RC_S32);
+}
+__device__ __forceinline__ void rc_load_tables(_Float16* tab, const int* __restrict__ tr32, const int* __restrict__ tr32t, int tid, int nthreads)
+{
+  for (int t = 0; t < 3; t++)
+    for (int n = 16; n <= 32; n <<= 1)
+      for (int e = tid; e < n * n; e += nthreads)
+      {
+        const int r = e / n, k = e - r * n, src = t * 5460 + (n * n - 4) / 3 + e;
+        tab[rc_tab_off(t, n, 0) + r * (n + 8) + k] = (_Float16)tr32[src];
+        tab[rc_tab_off(t, n, 1) + r * (n + 8) + k] = (_Float16)tr32t[src];
+      }
+  for (int e = tid; e < 4096; e += nthreads)
+  {
+    const int r = e >> 6, k = e & 63;
+    tab[rc_tab_off(0, 64, 0) + r * 72 + k] = (_Float16)tr32[1364 + e];
+    tab[rc_tab_off(0, 64, 1) + r * 72 + k] = (_Float16)tr32t[1364 + e];
+  }
+}
+
+// matrix operand of a product whose OTHER operand is a result tile: row `row` of the LDS matrix, the eight k values of k-step s in result-tile
+// order -- k = 32 s + 4 g + j (j < 4, tile 2 s) and 32 s + 16 + 4 g + (j - 4) (tile 2 s + 1)
+__device__ __forceinline__ h8 rc_mat_frag32(const _Float16* mat, int pitch, int row, int s, int g)
+{
+  const h4 a = *reinterpret_cast<const h4*>(mat + row * pitch + 32 * s + 4 * g);
+  const h4 b = *reinterpret_cast<const h4*>(mat + row * pitch + 32 * s + 16 + 4 * g);
+  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ h4 rc_mat_frag16(const _Float16* mat, int pitch, int row, int g)
+{
+  return *reinterpret_cast<const h4*>(mat + row * pitch + 4 * g);
+}
+
+// 16-bit signed integer -> two signed 8-bit limbs as f16 (v = 256 hi + lo, lo in [-128, 127], hi in [-128, 128])
+__device__ __forceinline__ void rc_limbs(int v, _Float16& hi, _Float16& lo)
+{
+  const int l = (int)(signed char)v;
+  lo = (_Float16)(short)l;
+  hi = (_Float16)(short)((v - l) >> 8);
+}
+
+// K-step bookkeeping of a product with inner dimension KD: one 16x16x16 step for KD = 16, KD / 32 steps of 16x16x32 otherwise
+template <int KD> struct RcK { static constexpr int STEPS = KD == 16 ? 1 : KD / 32; };
+
+// D += A B for one 16x16 tile over all k-steps; operands as fragment arrays per k-step (h8) or one h4 when the inner dimension is 16
+template <int KD>
+__device__ __forceinline__ f4 rc_mma(const h8 (&a)[RcK<KD>::STEPS], const h8 (&b)[RcK<KD>::STEPS], f4 acc)
+{
+  if (KD == 16)
+  {
+    const h4 a4 = __builtin_shufflevector(a[0], a[0], 0, 1, 2, 3), b4 = __builtin_shufflevector(b[0], b[0], 0, 1, 2, 3);
+    return __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc, 0, 0, 0);
+  }
+#pragma unroll
+  for (int s = 0; s < RcK<KD>::STEPS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s], b[s], acc, 0, 0, 0);
+  return acc;
+}
+
+// fragments (per k-step) of the matrix operand `row` of an LDS matrix with inner dimension KD, in result-tile k order
+template <int KD>
+__device__ __forceinline__ void rc_mat_frags(h8 (&f)[RcK<KD>::STEPS], const _Float16* mat, int row, int g)
+{
+  if (KD == 16)
+  {
+    const h4 a = rc_mat_frag16(mat, KD + 8, row, g);
+    f[0] = __builtin_shufflevector(a, a, 0, 1, 2, 3, 0, 1, 2, 3);
+  }
+  else
+  {
+#pragma unroll
+    for (int s = 0; s < RcK<KD>::STEPS; s++) f[s] = rc_mat_frag32(mat, KD + 8, row, s, g);
+  }
+}
+
+// fragments of a RESULT-derived operand: tiles t[0 .. KD/16) (four registers each: rows 4 g .. 4 g + 3 of tile), one limb (hi or lo) of each
+template <int KD>
+__device__ __forceinline__ void rc_tile_frags(h8 (&fh)[RcK<KD>::STEPS], h8 (&fl)[RcK<KD>::STEPS], const int (*t)[4])
+{
+  if (KD == 16)
+  {
+    _Float16 h[4], l[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) rc_limbs(t[0][j], h[j], l[j]);
+    fh[0] = h8{ h[0], h[1], h[2], h[3], h[0], h[1], h[2], h[3] };
+    fl[0] = h8{ l[0], l[1], l[2], l[3], l[0], l[1], l[2], l[3] };
+  }
+  else
+  {
+#pragma unroll
+    for (int s = 0; s < RcK<KD>::STEPS; s++)
+    {
+      _Float16 h[8], l[8];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { rc_limbs(t[2 * s][j], h[j], l[j]); rc_limbs(t[2 * s + 1][j], h[4 + j], l[4 + j]); }
+      fh[s] = h8{ h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7] };
+      fl[s] = h8{ l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7] };
+    }
+  }
+}
+
+// One TU of N x N (N = 16, 32, 64) on the matrix cores.  Returns false (nothing written) when a residual sample lies outside +-1023
+// (precondition violated: the caller's generic path takes the TU).
+template <int N>
+__device__ __forceinline__ bool rc_tu_mfma(const RcDesc& d, const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                           TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int ti, int bd, int clpMin, int clpMax,
+                                           const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff, int lane)
+{
+  constexpr int NJ = N > 32 ? 32 : N;                 // kept frequencies per dimension (zero-out beyond 32)
+  constexpr int RT = N / 16, JT = NJ / 16;            // tiles along a full / a kept dimension
+  constexpr int LN = N == 16 ? 4 : N == 32 ? 5 : 6;
+  const int c = lane & 15, g = lane >> 4;
+  const Pel* org = orgBase + d.org_off;
+  const Pel* pred = predBase + d.pred_off;
+  const _Float16* Th = tab + rc_tab_off(d.tr_hor, N, 0);
+  const _Float16* ThT = tab + rc_tab_off(d.tr_hor, N, 1);
+  const _Float16* Tv = tab + rc_tab_off(d.tr_ver, N, 0);
+  const _Float16* TvT = tab + rc_tab_off(d.tr_ver, N, 1);
+
+  // ---- stage F1: M1[r][j1] = sum_k X[r][k] Th[j1][k]      (A = X from memory, B = Th rows from LDS, natural k order on both)
+  f4 m1[RT][JT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+    for (int jt = 0; jt < JT; jt++) m1[rt][jt] = f4{ 0.f, 0.f, 0.f, 0.f };
+  bool inRange = true;
+  if (N == 16)
+  {
+    const pel4 o = *reinterpret_cast<const pel4*>(org + (size_t)c * d.org_stride + 4 * g);
+    const pel4 p = *reinterpret_cast<const pel4*>(pred + (size_t)c * d.pred_stride + 4 * g);
+    h4 a;
+#pragma unroll
+    for (int j = 0; j < 4; j++) { const int x = (int)o[j] - (int)p[j]; inRange = inRange && x >= -1023 && x <= 1023; a[j] = (_Float16)(short)x; }
+    const h4 b = *reinterpret_cast<const h4*>(Th + c * 24 + 4 * g);
+    m1[0][0] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, m1[0][0], 0, 0, 0);
+  }
+  else
+  {
+    pel8 o[RT][N / 32], p[RT][N / 32];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+      for (int s = 0; s < N / 32; s++)
+      {
+        o[rt][s] = *reinterpret_cast<const pel8*>(org + (size_t)(16 * rt + c) * d.org_stride + 32 * s + 8 * g);
+        p[rt][s] = *reinterpret_cast<const pel8*>(pred + (size_t)(16 * rt + c) * d.pred_stride + 32 * s + 8 * g);
+      }
+#pragma unroll
+    for (int s = 0; s < N / 32; s++)
+    {
+      h8 b[JT];
+#pragma unroll
+      for (int jt = 0; jt < JT; jt++) b[jt] = *reinterpret_cast<const h8*>(Th + (16 * jt + c) * (N + 8) + 32 * s + 8 * g);
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+      {
+        h8 a;
+#pragma unroll
+        for (int j = 0; j < 8; j++) { const int x = (int)o[rt][s][j] - (int)p[rt][s][j]; inRange = inRange && x >= -1023 && x <= 1023; a[j] = (_Float16)(short)x; }
+#pragma unroll
+        for (int jt = 0; jt < JT; jt++) m1[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[jt], m1[rt][jt], 0, 0, 0);
+      }
+    }
+  }
+  if (__builtin_amdgcn_ballot_w64(!inRange) != 0ull) return false;
+
+  // rounding shift between the forward stages (TrQuant.cpp:151-152, 214): the result tile holds M1[16 rt + 4 g + reg][16 jt + c]
+  const int s1 = LN + bd + 6 - 15 + 2, s2 = LN + 6 + 2;
+  int t1[JT][RT][4];                                   // [column tile][row tile]: the row tiles are the k dimension of the next product
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++)
+#pragma unroll
+    for (int jt = 0; jt < JT; jt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) t1[jt][rt][r] = ((int)m1[rt][jt][r] + (1 << (s1 - 1))) >> s1;
+
+  // ---- stage F2: C[j2][j1] = sum_r Tv[j2][r] M1[r][j1]     (A = Tv rows from LDS in result-tile k order, B = M1 limbs)
+  int cf[JT][JT][4];                                   // [row tile of C (j2)][column tile (j1)]
+  {
+    h8 bh[JT][RcK<N>::STEPS], bl[JT][RcK<N>::STEPS];
+#pragma unroll
+    for (int jt = 0; jt < JT; jt++) rc_tile_frags<N>(bh[jt], bl[jt], t1[jt]);
+#pragma unroll
+    for (int mt = 0; mt < JT; mt++)
+    {
+      h8 a[RcK<N>::STEPS];
+      rc_mat_frags<N>(a, Tv, 16 * mt + c, g);
+#pragma unroll
+      for (int jt = 0; jt < JT; jt++)
+      {
+        const f4 hi = rc_mma<N>(a, bh[jt], f4{ 0.f, 0.f, 0.f, 0.f }), lo = rc_mma<N>(a, bl[jt], f4{ 0.f, 0.f, 0.f, 0.f });
+#pragma unroll
+        for (int r = 0; r < 4; r++) cf[mt][jt][r] = ((((int)hi[r]) << 8) + (int)lo[r] + (1 << (s2 - 1))) >> s2;
+      }
+    }
+  }
+
+  // ---- quantiser: tile (mt, jt) holds rows 16 mt + 4 g + reg, column 16 jt + c; the quad c >> 2 of row group g is one coefficient group
+  const RcQ q = rc_qparams(N, N, d.qp, bd, d.intra_slice, d.sign_hiding);
+  const unsigned short* inv = dqInv + scanOff[(LN - 1) * 6 + (LN - 1)];
+  int lv[JT][JT][4], du[JT][JT][4];
+  int sum = 0, lastCg = -1, cgIdx[JT][JT];
+#pragma unroll
+  for (int mt = 0; mt < JT; mt++)
+#pragma unroll
+    for (int jt = 0; jt < JT; jt++)
+    {
+#pragma unroll
+      for (int r = 0; r < 4; r++) { int mag; lv[mt][jt][r] = rc_quant_one(q, cf[mt][jt][r], du[mt][jt][r], mag); sum += mag; }
+      cgIdx[mt][jt] = (int)inv[(16 * mt + 4 * g) * N + 16 * jt + (c & ~3)] >> 4;
+      if (rc_cg_nonzero(lv[mt][jt])) lastCg = max(lastCg, cgIdx[mt][jt]);
+    }
+  lastCg = wave_max_i32(lastCg);
+  sum = wave_sum_i32(sum);
+  if (lane == 0) absSumOut[ti] = (unsigned)sum;
+  TCoeff* level = levelBase + d.level_off;
+#pragma unroll
+  for (int mt = 0; mt < JT; mt++)
+#pragma unroll
+    for (int jt = 0; jt < JT; jt++)
+    {
+      if (q.sbh) rc_sbh_quad(lv[mt][jt], du[mt][jt], cf[mt][jt], cgIdx[mt][jt] == lastCg, lane);
+#pragma unroll
+      for (int r = 0; r < 4; r++) level[(16 * mt + 4 * g + r) * N + 16 * jt + c] = lv[mt][jt][r];
+    }
+  if (N == 64)                                          // zero-out region of the level array: columns >= 32 of rows < 32, then rows >= 32
+  {
+    const int4v z = { 0, 0, 0, 0 };
+    for (int e = lane; e < 32 * 8; e += 64) *reinterpret_cast<int4v*>(level + (e >> 3) * 64 + 32 + 4 * (e & 7)) = z;
+    for (int e = lane; e < 32 * 16; e += 64) *reinterpret_cast<int4v*>(level + 32 * 64 + 4 * e) = z;
+  }
+
+  // ---- de-quantiser; stage I1 (vertical): Y1T[i][r] = sum_k Cq[k][i] Tv[k][r]   (A = Cq^T: the result tile read as X^T -- row = its column c,
+  //      k = its rows; B = rows of Tv^T from LDS in result-tile k order)
+  int y1[RT][JT][4];                                   // [column tile (r)][row tile (i)]: the row tiles are the k dimension of the last product
+  {
+    int cq[JT][JT][4];                                 // [column tile (i)][row tile (k)]
+#pragma unroll
+    for (int mt = 0; mt < JT; mt++)
+#pragma unroll
+      for (int jt = 0; jt < JT; jt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) cq[jt][mt][r] = rc_dequant_one(q, lv[mt][jt][r]);
+    h8 ah[JT][RcK<NJ>::STEPS], al[JT][RcK<NJ>::STEPS];
+#pragma unroll
+    for (int it = 0; it < JT; it++) rc_tile_frags<NJ>(ah[it], al[it], cq[it]);
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++)
+    {
+      h8 b[RcK<NJ>::STEPS];
+      // rows of Tv^T have pitch N + 8; only k < NJ is read
+      if (NJ == 16) { const h4 v = rc_mat_frag16(TvT, N + 8, 16 * rt + c, g); b[0] = __builtin_shufflevector(v, v, 0, 1, 2, 3, 0, 1, 2, 3); }
+      else
+      {
+#pragma unroll
+        for (int s = 0; s < RcK<NJ>::STEPS; s++) b[s] = rc_mat_frag32(TvT, N + 8, 16 * rt + c, s, g);
+      }
+#pragma unroll
+      for (int it = 0; it < JT; it++)
+      {
+        const f4 hi = rc_mma<NJ>(ah[it], b, f4{ 0.f, 0.f, 0.f, 0.f }), lo = rc_mma<NJ>(al[it], b, f4{ 0.f, 0.f, 0.f, 0.f });
+#pragma unroll
+        for (int r = 0; r < 4; r++) y1[rt][it][r] = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[r]) << 8) + (int)lo[r] + 256) >> 9);
+      }
+    }
+  }
+
+  // ---- stage I2 (horizontal): RT[x][r] = sum_i Th[i][x] Y1T[i][r]   (A = rows of Th^T from LDS, B = Y1T limbs); the result tile holds
+  //      R[r = 16 rt + c][x = 16 xt + 4 g + reg]: four consecutive samples of one row per lane
+  const int s2i = (6 + 15 - 1) - bd + 2;
+  Pel* rec = recBase + d.rec_off;
+  {
+    h8 bh[RT][RcK<NJ>::STEPS], bl[RT][RcK<NJ>::STEPS];
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) rc_tile_frags<NJ>(bh[rt], bl[rt], y1[rt]);
+#pragma unroll
+    for (int xt = 0; xt < RT; xt++)
+    {
+      h8 a[RcK<NJ>::STEPS];
+      if (NJ == 16) { const h4 v = rc_mat_frag16(ThT, N + 8, 16 * xt + c, g); a[0] = __builtin_shufflevector(v, v, 0, 1, 2, 3, 0, 1, 2, 3); }
+      else
+      {
+#pragma unroll
+        for (int s = 0; s < RcK<NJ>::STEPS; s++) a[s] = rc_mat_frag32(ThT, N + 8, 16 * xt + c, s, g);
+      }
+#pragma unroll
+      for (int rt = 0; rt < RT; rt++)
+      {
+        const f4 hi = rc_mma<NJ>(a, bh[rt], f4{ 0.f, 0.f, 0.f, 0.f }), lo = rc_mma<NJ>(a, bl[rt], f4{ 0.f, 0.f, 0.f, 0.f });
+        const pel4 pv = *reinterpret_cast<const pel4*>(pred + (size_t)(16 * rt + c) * d.pred_stride + 16 * xt + 4 * g);
+        pel4 out;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+          const int resi = (short)clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[r]) << 8) + (int)lo[r] + (1 << (s2i - 1))) >> s2i);
+          out[r] = (short)clip3(clpMin, clpMax, (int)pv[r] + resi);
+        }
+        *reinterpret_cast<pel4*>(rec + (size_t)(16 * rt + c) * d.rec_stride + 16 * xt + 4 * g) = out;
+      }
+    }
+  }
+  return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Generic path: one wave per TU, any W x H in 2..64; the residual / intermediates / coefficients live in two LDS buffers of the wave.
+// Matrices come from global memory (int32 tables).  Exact 32-bit arithmetic as the reference's `int` loops.
+__device__ __forceinline__ const int* rc_t32(const int* tr32, int type, int n) { return tr32 + type * 5460 + (n * n - 4) / 3; }
+
+__device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                              TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int ti, int bd, int clpMin, int clpMax,
+                              const int* __restrict__ tr32, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
+                              int* bufA, int* bufB, int lane)
+{
+  const int w = d.w, h = d.h, lw = ilog2(w), lh = ilog2(h);
+  const int wj = w > 32 ? 32 : w, hj = h > 32 ? 32 : h;
+  const Pel* org = orgBase + d.org_off;
+  const Pel* pred = predBase + d.pred_off;
+  const int* Th = rc_t32(tr32, d.tr_hor, w);
+  const int* Tv = rc_t32(tr32, d.tr_ver, h);
+  for (int e = lane; e < w * h; e += 64)
+  {
+    const int r = e >> lw, k = e & (w - 1);
+    bufA[e] = (int)org[(size_t)r * d.org_stride + k] - (int)pred[(size_t)r * d.pred_stride + k];
+  }
+  RC_WAVE_SYNC();
+  const int s1 = lw + bd + 6 - 15 + 2, s2 = lh + 6 + 2;
+  for (int e = lane; e < wj * h; e += 64)                // F1: bufB[j * h + r]
+  {
+    const int j = e >> lh, r = e & (h - 1);
+    int sum = 0;
+    for (int k = 0; k < w; k++) sum += bufA[r * w + k] * Th[j * w + k];
+    bufB[e] = (sum + (1 << (s1 - 1))) >> s1;
+  }
+  RC_WAVE_SYNC();
+  for (int e = lane; e < w * h; e += 64)                 // F2: coefficients, raster, zero outside the kept region
+  {
+    const int j2 = e >> lw, j1 = e & (w - 1);
+    int v = 0;
+    if (j2 < hj && j1 < wj)
+    {
+      int sum = 0;
+      for (int r = 0; r < h; r++) sum += bufB[j1 * h + r] * Tv[j2 * h + r];
+      v = (sum + (1 << (s2 - 1))) >> s2;
+    }
+    bufA[e] = v;
+  }
+  RC_WAVE_SYNC();
+  // quantiser: lane = column (chunks of 64 columns never occur: w <= 64), four rows per pass
+  const RcQ q = rc_qparams(w, h, d.qp, bd, d.intra_slice, d.sign_hiding);
+  TCoeff* level = levelBase + d.level_off;
+  int sum = 0;
+  if (!q.sbh)
+  {
+    for (int e = lane; e < w * h; e += 64)
+    {
+      int duu, mag;
+      const int l = rc_quant_one(q, bufA[e], duu, mag);
+      sum += mag;
+      level[e] = l;
+      bufA[e] = rc_dequant_one(q, l);
+    }
+  }
+  else
+  {
+    const unsigned short* inv = dqInv + scanOff[(lw - 1) * 6 + (lh - 1)];
+    const int col = lane & (w - 1), rowsPerPass = 4 * (64 >> lw);          // narrow TUs: several groups of 4 rows side by side in the wave
+    const int rsub = (lane >> lw) * 4;
+    int lastCg = -1;
+    for (int r0 = 0; r0 < h; r0 += rowsPerPass)
+    {
+      const int row = r0 + rsub;
+      int lv[4], duu[4];
+      const bool on = row < h;
+#pragma unroll
+      for (int r = 0; r < 4; r++) { int mag; lv[r] = rc_quant_one(q, on ? bufA[(row + r) * w + col] : 0, duu[r], mag); sum += on ? mag : 0; }
+      const bool nz = rc_cg_nonzero(lv);
+      if (on && nz) lastCg = max(lastCg, (int)inv[row * w + (col & ~3)] >> 4);
+    }
+    lastCg = wave_max_i32(lastCg);
+    for (int r0 = 0; r0 < h; r0 += rowsPerPass)
+    {
+      const int row = r0 + rsub;
+      const bool on = row < h;
+      int lv[4], duu[4], cfv[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) { int mag; cfv[r] = on ? bufA[(row + r) * w + col] : 0; lv[r] = rc_quant_one(q, cfv[r], duu[r], mag); }
+      const int cg = on ? (int)inv[row * w + (col & ~3)] >> 4 : -2;
+      rc_sbh_quad(lv, duu, cfv, cg == lastCg, lane);
+      if (on)
+      {
+#pragma unroll
+        for (int r = 0; r < 4; r++) { level[(row + r) * w + col] = lv[r]; bufA[(row + r) * w + col] = rc_dequant_one(q, lv[r]); }
+      }
+    }
+  }
+  sum = wave_sum_i32(sum);
+  if (lane == 0) absSumOut[ti] = (unsigned)sum;
+  RC_WAVE_SYNC();
+  for (int e = lane; e < wj * h; e += 64)                // I1 (vertical): bufB[i * h + r] = clip(sum_k Cq[k][i] Tv[k][r])
+  {
+    const int i = e >> lh, r = e & (h - 1);
+    int acc = 0;
+    for (int k = 0; k < hj; k++) acc += bufA[k * w + i] * Tv[k * h + r];
+    bufB[e] = clip3(-(1 << 15), (1 << 15) - 1, (acc + 256) >> 9);
+  }
+  RC_WAVE_SYNC();
+  const int s2i = (6 + 15 - 1) - bd + 2;
+  Pel* rec = recBase + d.rec_off;
+  for (int e = lane; e < w * h; e += 64)                 // I2 (horizontal) + reconstruction
+  {
+    const int r = e >> lw, x = e & (w - 1);
+    int acc = 0;
+    for (int i = 0; i < wj; i++) acc += bufB[i * h + r] * Th[i * w + x];
+    const int resi = (short)clip3(-(1 << 15), (1 << 15) - 1, (acc + (1 << (s2i - 1))) >> s2i);
+    rec[(size_t)r * d.rec_stride + x] = (short)clip3(clpMin, clpMax, (int)pred[(size_t)r * d.pred_stride + x] + resi);
+  }
+  RC_WAVE_SYNC();
+}
+
+// ---------------------------------------------------------------------------------------------------
+// matrix-core kernel: persistent waves, one TU per wave at a time, largest TUs first (work counter hdr[6])
+__global__ __launch_bounds__(256, 2) void rc_mfma_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                                         TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs, int n,
+                                                         int* __restrict__ hdr, const int* __restrict__ lists, int* __restrict__ fallback,
+                                                         unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax, VvcTrTables tb)
+{
+  __shared__ __align__(16) _Float16 tab[RC_TAB_HALVES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int c64 = hdr[RC_C64], c32 = hdr[RC_C32], c16 = hdr[RC_C16], total = c64 + c32 + c16;
+  if ((int)blockIdx.x * 4 >= total) return;
+  rc_load_tables(tab, tb.tr32, tb.tr32t, tid, 256);
+  __syncthreads();
+  for (;;)
+  {
+    int item = 0;
+    if (lane == 0) item = atomicAdd(&hdr[6], 1);
+    item = __builtin_amdgcn_readfirstlane(item);
+    if (item >= total) break;
+    bool done;
+    int ti;
+    if (item < c64)
+    {
+      ti = lists[(size_t)RC_C64 * n + item];
+      done = rc_tu_mfma<64>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
+    }
+    else if (item < c64 + c32)
+    {
+      ti = lists[(size_t)RC_C32 * n + item - c64];
+      done = rc_tu_mfma<32>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
+    }
+    else
+    {
+      ti = lists[(size_t)RC_C16 * n + item - c64 - c32];
+      done = rc_tu_mfma<16>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
+    }
+    if (!done && lane == 0) fallback[1 + atomicAdd(&fallback[0], 1)] = ti;      // residual outside +-1023: the generic kernel takes it
+  }
+}
+
+// generic kernel: the class-`generic` list, then (second launch) the fall-back list of the matrix-core kernel
+__global__ __launch_bounds__(64) void rc_generic_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                                        TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs,
+                                                        const int* __restrict__ count, const int* __restrict__ list,
+                                                        unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax, VvcTrTables tb)
+{
+  __shared__ int bufA[4096], bufB[4096];
+  const int cnt = count[0];
+  for (int k = blockIdx.x; k < cnt; k += gridDim.x)
+  {
+    const int ti = list[k];
+    rc_tu_generic(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, bufA, bufB,
+                  (int)threadIdx.x);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 4 x 4 and 8 x 8: lane groups of S lanes per TU, G = 64 / S TUs per wave.  Forward: lane = row (stage 1), transposed through LDS, lane = column
+// (stage 2, quantiser, de-quantiser, vertical inverse stage), transposed back, lane = row (horizontal inverse stage + reconstruction: the
+// prediction row is still in the lane's registers).
+struct RcSmallTab { int t[3][16 + 64]; int tt[3][16 + 64]; };       // per type: size 4 at 0, size 8 at 16; tt = transposes
+
+template <int S>
+__device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
+                                               const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                               TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
+                                               const RcSmallTab& tabs, int* tmpL, int lane)
+{
+  constexpr int G = 64 / S, LS = S == 4 ? 2 : 3, TO = S == 4 ? 0 : 16;
+  typedef short pelS __attribute__((ext_vector_type(S)));
+  const int tg = lane / S, li = lane % S;
+  const int k = item * G + tg;
+  const bool act = k < cnt;
+  const int ti = list[act ? k : 0];
+  const RcDesc d = descs[ti];
+  int* tt = tmpL + tg * (S * (S + 1));
+  const int* Th = tabs.t[d.tr_hor] + TO;
+  const int* Tv = tabs.t[d.tr_ver] + TO;
+  const int* ThT = tabs.tt[d.tr_hor] + TO;
+  const int* TvT = tabs.tt[d.tr_ver] + TO;
+  // stage F1: lane = row li
+  const pelS o = *reinterpret_cast<const pelS*>(orgBase + d.org_off + (size_t)li * d.org_stride);
+  const pelS p = *reinterpret_cast<const pelS*>(predBase + d.pred_off + (size_t)li * d.pred_stride);
+  const int s1 = LS + bd + 6 - 15 + 2, s2 = LS + 6 + 2;
+  {
+    int x[S];
+#pragma unroll
+    for (int j = 0; j < S; j++) x[j] = (int)o[j] - (int)p[j];
+#pragma unroll
+    for (int j = 0; j < S; j++)
+    {
+      int sum = 0;
+#pragma unroll
+      for (int kk = 0; kk < S; kk++) sum += x[kk] * Th[j * S + kk];
+      tt[j * (S + 1) + li] = (sum + (1 << (s1 - 1))) >> s1;
+    }
+  }
+  RC_WAVE_SYNC();
+  // stage F2: lane = column li (horizontal frequency), registers = rows
+  int cf[S];
+  {
+    int t[S];
+#pragma unroll
+    for (int r = 0; r < S; r++) t[r] = tt[li * (S + 1) + r];
+#pragma unroll
+    for (int j = 0; j < S; j++)
+    {
+      int sum = 0;
+#pragma unroll
+      for (int r = 0; r < S; r++) sum += t[r] * Tv[j * S + r];
+      cf[j] = (sum + (1 << (s2 - 1))) >> s2;
+    }
+  }
+  RC_WAVE_SYNC();
+  // quantiser (coefficient groups: rows 4 R .. 4 R + 3 x the lane's aligned quad)
+  const RcQ q = rc_qparams(S, S, d.qp, bd, d.intra_slice, d.sign_hiding);
+  int lv[S], du[S], sum = 0;
+#pragma unroll
+  for (int j = 0; j < S; j++) { int mag; lv[j] = rc_quant_one(q, cf[j], du[j], mag); sum += mag; }
+#pragma unroll
+  for (int m = 1; m < S; m <<= 1) sum += __shfl_xor(sum, m);
+  if (act && li == 0) absSumOut[ti] = (unsigned)sum;
+  if (q.sbh)
+  {
+    // coefficient-group scan index inside the TU: 4x4: one group; 8x8: (cx, cy) -> 2 cx + cy (diagonal scan of the 2 x 2 group grid)
+    int lastCg = -1;
+#pragma unroll
+    for (int R = 0; R < S / 4; R++)
+    {
+      int l4[4] = { lv[4 * R], lv[4 * R + 1], lv[4 * R + 2], lv[4 * R + 3] };
+      if (rc_cg_nonzero(l4)) lastCg = max(lastCg, 2 * (li >> 2) + R);
+    }
+    if (S == 8) lastCg = max(lastCg, __shfl_xor(lastCg, 4));
+#pragma unroll
+    for (int R = 0; R < S / 4; R++)
+    {
+      int l4[4] = { lv[4 * R], lv[4 * R + 1], lv[4 * R + 2], lv[4 * R + 3] };
+      const int d4[4] = { du[4 * R], du[4 * R + 1], du[4 * R + 2], du[4 * R + 3] };
+      const int c4[4] = { cf[4 * R], cf[4 * R + 1], cf[4 * R + 2], cf[4 * R + 3] };
+      rc_sbh_quad(l4, d4, c4, 2 * (li >> 2) + R == lastCg, lane);
+#pragma unroll
+      for (int r = 0; r < 4; r++) lv[4 * R + r] = l4[r];
+    }
+  }
+  if (act)
+  {
+    TCoeff* level = levelBase + d.level_off;
+#pragma unroll
+    for (int j = 0; j < S; j++) level[j * S + li] = lv[j];
+  }
+  // de-quantiser + stage I1 (vertical): y[r] = clip(sum_k Cq[k] Tv[k][r]); written transposed: tt[r][column li]
+  {
+    int cq[S];
+#pragma unroll
+    for (int j = 0; j < S; j++) cq[j] = rc_dequant_one(q, lv[j]);
+#pragma unroll
+    for (int r = 0; r < S; r++)
+    {
+      int acc = 0;
+#pragma unroll
+      for (int kk = 0; kk < S; kk++) acc += cq[kk] * TvT[r * S + kk];
+      tt[r * (S + 1) + li] = clip3(-(1 << 15), (1 << 15) - 1, (acc + 256) >> 9);
+    }
+  }
+  RC_WAVE_SYNC();
+  // stage I2 (horizontal): lane = row li
+  const int s2i = (6 + 15 - 1) - bd + 2;
+  {
+    int y[S];
+#pragma unroll
+    for (int i = 0; i < S; i++) y[i] = tt[li * (S + 1) + i];
+    pelS out;
+#pragma unroll
+    for (int x = 0; x < S; x++)
+    {
+      int acc = 0;
+#pragma unroll
+      for (int i = 0; i < S; i++) acc += y[i] * ThT[x * S + i];
+      const int resi = (short)clip3(-(1 << 15), (1 << 15) - 1, (acc + (1 << (s2i - 1))) >> s2i);
+      out[x] = (short)clip3(clpMin, clpMax, (int)p[x] + resi);
+    }
+    if (act) *reinterpret_cast<pelS*>(recBase + d.rec_off + (size_t)li * d.rec_stride) = out;
+  }
+  RC_WAVE_SYNC();
+}
+
+__global__ __launch_bounds__(256) void rc_small_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                                       TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs, int n,
+                                                       const int* __restrict__ hdr, const int* __restrict__ lists,
+                                                       unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax, VvcTrTables tb)
+{
+  __shared__ RcSmallTab tabs;
+  __shared__ int tmpAll[4][8 * 8 * 9];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c8 = hdr[RC_C8], c4 = hdr[RC_C4];
+  const int items8 = (c8 + 7) >> 3, items4 = (c4 + 15) >> 4, total = items8 + items4;
+  if ((int)blockIdx.x * 4 >= total) return;
+  for (int e = tid; e < 3 * 80; e += 256)
+  {
+    const int t = e / 80, o = e - t * 80, nsz = o < 16 ? 4 : 8, oo = o < 16 ? o : o - 16;
+    tabs.t[t][o] = tb.tr32[t * 5460 + (nsz * nsz - 4) / 3 + oo];
+    tabs.tt[t][o] = tb.tr32t[t * 5460 + (nsz * nsz - 4) / 3 + oo];
+  }
+  __syncthreads();
+  for (int item = blockIdx.x * 4 + wave; item < total; item += gridDim.x * 4)
+  {
+    if (item < items8)
+      rc_small_group<8>(descs, lists + (size_t)RC_C8 * n, c8, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+    else
+      rc_small_group<4>(descs, lists + (size_t)RC_C4 * n, c4, item - items8, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, vvc_pel* rec_base, vvc_coef* level_base,
+                            const vvcgpu_resi_chain_desc* descs, int n, int bit_depth, int clp_min, int clp_max, uint32_t* abs_sum, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "resi_chain_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(org_base && pred_base && rec_base && level_base && descs && abs_sum, "resi_chain_batch: null pointer");
+  VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "resi_chain_batch: bit depth %d outside 8..10", bit_depth);
+  VVC_CHECK_ARG(clp_min <= clp_max, "resi_chain_batch: clipping range");
+  VvcTrTables tb;
+  const int rt = vvcgpu_tr_tables(&tb);
+  if (rt) return rt;
+  hipStream_t st = (hipStream_t)stream;
+  // scratch: header, the six class lists, the fall-back list of the matrix-core kernel
+  const size_t ints = RC_HDR + (size_t)RC_NCLS * n + 1 + (size_t)n;
+  int* ws = static_cast<int*>(vvcgpu_scratch(st, ints * sizeof(int)));
+  if (!ws) return VVCGPU_E_DEVICE;
+  int* hdr = ws;
+  int* lists = ws + RC_HDR;
+  int* fallback = lists + (size_t)RC_NCLS * n;
+  VVC_HIP(hipMemsetAsync(hdr, 0, RC_HDR * sizeof(int), st));
+  VVC_HIP(hipMemsetAsync(fallback, 0, sizeof(int), st));
+  hipLaunchKernelGGL(rc_classify_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, descs, n, hdr, lists, abs_sum);
+  VVC_LAUNCH_CHECK();
+  const int wgM = cdiv(n, 4) < 512 ? cdiv(n, 4) : 512;
+  hipLaunchKernelGGL(rc_mfma_kernel, dim3(wgM), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, fallback, abs_sum,
+                     bit_depth, clp_min, clp_max, tb);
+  VVC_LAUNCH_CHECK();
+  const int wgS = cdiv(n, 32) < 2048 ? cdiv(n, 32) : 2048;
+  hipLaunchKernelGGL(rc_small_kernel, dim3(wgS), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, abs_sum,
+                     bit_depth, clp_min, clp_max, tb);
+  VVC_LAUNCH_CHECK();
+  const int wgG = n < 1024 ? n : 1024;
+  hipLaunchKernelGGL(rc_generic_kernel, dim3(wgG), dim3(64), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_CGEN,
+                     lists + (size_t)RC_CGEN * n, abs_sum, bit_depth, clp_min, clp_max, tb);
+  VVC_LAUNCH_CHECK();
+  hipLaunchKernelGGL(rc_generic_kernel, dim3(64), dim3(64), 0, st, org_base, pred_base, rec_base, level_base, descs, fallback, fallback + 1, abs_sum,
+                     bit_depth, clp_min, clp_max, tb);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+}  // extern "C"

@@ -17,6 +17,7 @@
 //     each lane group reading the rows of its own TU's transform types (same-address reads broadcast).
 #include "common.h"
 #include "tr_tables.inc"
+#include <mutex>
 
 namespace {
 
@@ -1571,6 +1572,7 @@ __global__ __launch_bounds__(256) void rdoq_kernel(const TCoeff* __restrict__ co
 }
 
 static bool g_tablesUploaded[64] = { false };
+static std::mutex g_tablesMutex;            // the C ABI may be entered from several host threads: one uploads, the others wait
 static const int g_smallGrid = getenv("VVCGPU_TR_SMALLGRID") ? atoi(getenv("VVCGPU_TR_SMALLGRID")) : 1280;   // tuning switch
 
 // diagonal 4x4-grouped coefficient scan (Rom.cpp:357-405): groups of 4x4 (2x2 when a side is 2) visited along the diagonals
@@ -1598,6 +1600,7 @@ static int ensure_tables()
   int dev = 0;
   VVC_HIP(hipGetDevice(&dev));
   if (dev < 0 || dev >= 64) { vvcgpu_set_error("device index %d out of range", dev); return VVCGPU_E_DEVICE; }
+  std::lock_guard<std::mutex> lock(g_tablesMutex);
   if (!g_tablesUploaded[dev])
   {
     static int t32[3 * 5460], t32t[3 * 5460];
@@ -1657,6 +1660,19 @@ static int check_descs_args(const void* a, const void* b, const void* d, int n, 
 }
 
 }  // namespace
+
+// device addresses of the golden tables on the current device, for the kernels of other translation units (resichain.hip)
+int vvcgpu_tr_tables(VvcTrTables* out)
+{
+  const int rt = ensure_tables();
+  if (rt) return rt;
+  void* p = nullptr;
+  VVC_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(d_tr32)));      out->tr32 = static_cast<const int*>(p);
+  VVC_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(d_tr32t)));     out->tr32t = static_cast<const int*>(p);
+  VVC_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(d_dqInv)));     out->dqInv = static_cast<const unsigned short*>(p);
+  VVC_HIP(hipGetSymbolAddress(&p, HIP_SYMBOL(d_scanOff)));   out->scanOff = static_cast<const int*>(p);
+  return VVCGPU_OK;
+}
 
 extern "C" {
 

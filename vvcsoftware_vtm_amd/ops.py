@@ -421,3 +421,19 @@ def frac_refine(org, ref, blocks_dev, nblocks, w, h, bit_depth, mvcost, use_hada
     capi.call("vvcgpu_frac_refine", po, so, pr, sr, capi.ptr(blocks_dev), nblocks, w, h, bit_depth, clp[0], clp[1],
               1 if use_hadamard else 0, C.byref(mvcost), capi.ptr(res), _stream())
     return res
+
+
+# ---- fused residual chain (InterSearch::xEstimateInterResidualQT per TU) ------------------------------------
+RC_DESC = np.dtype([("org_off", "<i8"), ("pred_off", "<i8"), ("rec_off", "<i8"), ("level_off", "<i8"), ("org_stride", "<i4"), ("pred_stride", "<i4"),
+                    ("rec_stride", "<i4"), ("w", "<i2"), ("h", "<i2"), ("tr_hor", "i1"), ("tr_ver", "i1"), ("intra_slice", "i1"), ("sign_hiding", "i1"),
+                    ("qp", "<i4"), ("reserved", "<i4", (2,))])
+assert RC_DESC.itemsize == 64
+
+
+def resi_chain_batch(org_base, pred_base, rec_base, level_base, descs_dev, n, bit_depth=10, clp=(0, 1023)):
+    """subtract -> forward transform -> Quant::quant -> Quant::dequant -> inverse transform -> reconstruction of n TUs in one pass.
+    Returns the abs-sum int32 tensor [n] (bits as uint32; 0xFFFFFFFF marks a TU outside the entry point's preconditions)."""
+    out = torch.zeros(n, dtype=torch.int32, device=org_base.device)
+    capi.call("vvcgpu_resi_chain_batch", capi.ptr(org_base), capi.ptr(pred_base), capi.ptr(rec_base), capi.ptr(level_base), capi.ptr(descs_dev), n,
+              bit_depth, clp[0], clp[1], capi.ptr(out), _stream())
+    return out

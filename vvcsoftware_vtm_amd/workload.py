@@ -15,7 +15,8 @@ Stages (one picture = one step):
   mc     bi-predictive MC of the whole picture as 16x16 PUs (luma 8-tap + chroma 4-tap) + addAvg
   resi   residual = org - pred; forward + inverse transforms over a seeded tiling {64,32,16,8,4} in equal pixel
          shares (DST-VII/DCT-VIII pairs on tiles <= 32), scalar quantisation with sign bit hiding (Quant::quant, no RDOQ) at
-         QP 32, de-quantisation (Quant::dequant); reconstruction
+         QP 32, de-quantisation (Quant::dequant); reconstruction -- one pass per TU (vvcgpu_resi_chain_batch; `fused_resi=False`
+         runs the five separate entry points instead: same outputs)
   dbk    deblocking with a seeded CU grid / BS / QP field
   sao    SAO statistics + apply with seeded per-CTU parameters (all five types)
   alf    ALF classification + covariance statistics (7x7 and 5x5 luma, 5x5 chroma) + 7x7 luma / 5x5 chroma filtering
@@ -51,7 +52,10 @@ QUANT_DESC = np.dtype([("coeff_off", "<i8"), ("level_off", "<i8"), ("w", "<i2"),
                        ("reserved", "<i2"), ("qp", "<i4"), ("reserved2", "<i4")])
 DQTR_DESC = np.dtype([("resi_off", "<i8"), ("level_off", "<i8"), ("resi_stride", "<i4"), ("w", "<i2"), ("h", "<i2"),
                       ("tr_hor", "i1"), ("tr_ver", "i1"), ("dep_quant", "i1"), ("reserved", "i1"), ("qp", "<i4")])
-assert QUANT_DESC.itemsize == 32 and DQTR_DESC.itemsize == 32
+RC_DESC = np.dtype([("org_off", "<i8"), ("pred_off", "<i8"), ("rec_off", "<i8"), ("level_off", "<i8"), ("org_stride", "<i4"), ("pred_stride", "<i4"),
+                    ("rec_stride", "<i4"), ("w", "<i2"), ("h", "<i2"), ("tr_hor", "i1"), ("tr_ver", "i1"), ("intra_slice", "i1"), ("sign_hiding", "i1"),
+                    ("qp", "<i4"), ("reserved", "<i4", (2,))])
+assert QUANT_DESC.itemsize == 32 and DQTR_DESC.itemsize == 32 and RC_DESC.itemsize == 64
 
 
 class MvCost(C.Structure):
@@ -76,12 +80,13 @@ def _pad(plane, m):
 
 
 class Workload:
-    def __init__(self, width, height, bit_depth=10, seed=20261003, raster_range=96, me_sizes=(16, 32, 64), qp=32):
+    def __init__(self, width, height, bit_depth=10, seed=20261003, raster_range=96, me_sizes=(16, 32, 64), qp=32, fused_resi=True):
         assert width % 8 == 0 and height % 8 == 0
         self.w, self.h, self.bd = width, height, bit_depth
         self.mx = (1 << bit_depth) - 1
         self.seed = seed
         self.raster_range = raster_range
+        self.fused_resi = fused_resi                   # residual chain as ONE pass (vvcgpu_resi_chain_batch) or as its five separate entry points
         self.qp = qp                                   # base QP (BASELINE configs: 22 / 27 / 32 / 37); quantiser, de-quantiser and the deblocking QP field follow it
         rng = np.random.default_rng(seed)
         frames = synth.gen_yuv(width, height, 3, bit_depth, seed)
@@ -179,6 +184,14 @@ class Workload:
         self.dqtr = np.zeros(self.tr.size, DQTR_DESC)
         self.dqtr["resi_off"], self.dqtr["level_off"], self.dqtr["resi_stride"] = self.tr["resi_off"], self.tr["coeff_off"], self.tr["resi_stride"]
         self.dqtr["w"], self.dqtr["h"], self.dqtr["tr_hor"], self.dqtr["tr_ver"], self.dqtr["qp"] = self.tr["w"], self.tr["h"], self.tr["tr_hor"], self.tr["tr_ver"], qp
+        # the same TUs for the fused chain (residual -> T1 -> quant -> dequant -> T2 -> reconstruction in one pass)
+        self.rc = np.zeros(self.tr.size, RC_DESC)
+        self.rc["org_off"] = self.rc["pred_off"] = self.rc["rec_off"] = self.tr["resi_off"]
+        self.rc["level_off"] = self.tr["coeff_off"]
+        self.rc["org_stride"] = self.rc["pred_stride"] = self.rc["rec_stride"] = width
+        self.rc["w"], self.rc["h"], self.rc["tr_hor"], self.rc["tr_ver"] = self.tr["w"], self.tr["h"], self.tr["tr_hor"], self.tr["tr_ver"]
+        self.rc["sign_hiding"], self.rc["qp"] = 1, qp
+        self.tiled_w, self.tiled_h = width - width % 64, height - height % 64      # the TU tiling covers whole 64x64 cells only
         # plane-wide element-wise ops as one descriptor per CTU (the reference calls them per CU, <= 128x128)
         def bands(wp, hp):
             r = []
@@ -250,7 +263,9 @@ class Workload:
         # per PU: two reference windows (W+7)^2 (luma) / (W/2+3)^2 (chroma, x2 components) + the written block
         out["mc"] = {"mc_luma": nl * (2 * 23 * 23 * 2 + 16 * 16 * 2), "mc_chroma": 2 * nl * (2 * 11 * 11 * 2 + 8 * 8 * 2)}
         ncoef = self.n_coef
-        out["resi"] = {"subtract": 3 * Y, "tr_fwd": ncoef * 6, "quant": ncoef * 8, "dequant_tr_inv": ncoef * 6, "reco": 3 * Y}
+        out["resi"] = {"subtract": 3 * Y, "tr_fwd": ncoef * 6, "quant": ncoef * 8, "dequant_tr_inv": ncoef * 6, "reco": 3 * Y,
+                       # fused: org + pred in, levels + reconstruction out per covered sample; the rest of the plane is copied
+                       "resi_chain": ncoef * (2 + 2 + 4 + 2) + 2 * (Y - 2 * ncoef) + 2 * (P - Y)}
         maps = (w // 4) * (h // 4) * 4
         out["dbk"] = {"deblock": 2 * P + maps}
         out["sao"] = {"sao_stats": 2 * P + self.nctu_x * self.nctu_y * 3 * 2560, "sao_apply": 2 * P}
@@ -326,6 +341,7 @@ class Workload:
             st["level"] = torch.empty(self.n_coef, dtype=torch.int32, device="cuda")
             st["dqcoef"] = torch.empty(self.n_coef, dtype=torch.int32, device="cuda")
             st["quant"], st["dqtr"] = ops.struct_to_device(self.quant), ops.struct_to_device(self.dqtr)
+            st["rc"] = ops.struct_to_device(self.rc)
             st["rec"] = [e16(h, w), e16(h // 2, w // 2), e16(h // 2, w // 2)]
             st["sao_out"] = [e16(h, w), e16(h // 2, w // 2), e16(h // 2, w // 2)]
             st["alf_out"] = [e16(h, w), e16(h // 2, w // 2), e16(h // 2, w // 2)]
@@ -399,20 +415,31 @@ class Workload:
             ops.mc_batch(st["ref0"][1], st["ref1"][1], st["pred"][1], st["mc_chroma"], self.mc_chroma.size, bd, (0, mx))
             ops.mc_batch(st["ref0"][2], st["ref1"][2], st["pred"][2], st["mc_chroma"], self.mc_chroma.size, bd, (0, mx))
         # ---- residual / transforms / reconstruction
-        sub = ops.PelopCfg(0, 0, 0, 0, 0, mx)
-        rec_cfg = ops.PelopCfg(0, 0, 0, 1, 0, mx)
-        with T("resi/subtract"):
-            ops.pelop_batch(3, st["org"][0], st["pred"][0], st["resi"], st["bands_luma"], self.bands_luma.size, sub)
-        with T("resi/tr_fwd"):
-            ops.tr_fwd_batch(st["resi"], st["coef"], st["tr"], self.tr.size, bd)
-        with T("resi/quant"):
-            out["abs_sum"] = ops.quant_batch(st["coef"], st["level"], st["quant"], self.tr.size, bd)
-        with T("resi/dequant_tr_inv"):
-            ops.dequant_tr_inv_batch(st["level"], st["resi2"], st["dqtr"], self.tr.size, bd, st["dqcoef"])
-        with T("resi/reco"):
-            ops.pelop_batch(1, st["pred"][0], st["resi2"], st["rec"][0], st["bands_luma"], self.bands_luma.size, rec_cfg)
-            st["rec"][1].copy_(st["pred"][1])
-            st["rec"][2].copy_(st["pred"][2])
+        if self.fused_resi:
+            with T("resi/resi_chain"):
+                out["abs_sum"] = ops.resi_chain_batch(st["org"][0], st["pred"][0], st["rec"][0], st["level"], st["rc"], self.tr.size, bd, (0, mx))
+                # outside the TU tiling the residual is zero: reconstruction = prediction (already clipped by the MC stage)
+                if self.tiled_h < self.h:
+                    st["rec"][0][self.tiled_h:, :].copy_(st["pred"][0][self.tiled_h:, :])
+                if self.tiled_w < self.w:
+                    st["rec"][0][:self.tiled_h, self.tiled_w:].copy_(st["pred"][0][:self.tiled_h, self.tiled_w:])
+                st["rec"][1].copy_(st["pred"][1])
+                st["rec"][2].copy_(st["pred"][2])
+        else:
+            sub = ops.PelopCfg(0, 0, 0, 0, 0, mx)
+            rec_cfg = ops.PelopCfg(0, 0, 0, 1, 0, mx)
+            with T("resi/subtract"):
+                ops.pelop_batch(3, st["org"][0], st["pred"][0], st["resi"], st["bands_luma"], self.bands_luma.size, sub)
+            with T("resi/tr_fwd"):
+                ops.tr_fwd_batch(st["resi"], st["coef"], st["tr"], self.tr.size, bd)
+            with T("resi/quant"):
+                out["abs_sum"] = ops.quant_batch(st["coef"], st["level"], st["quant"], self.tr.size, bd)
+            with T("resi/dequant_tr_inv"):
+                ops.dequant_tr_inv_batch(st["level"], st["resi2"], st["dqtr"], self.tr.size, bd, st["dqcoef"])
+            with T("resi/reco"):
+                ops.pelop_batch(1, st["pred"][0], st["resi2"], st["rec"][0], st["bands_luma"], self.bands_luma.size, rec_cfg)
+                st["rec"][1].copy_(st["pred"][1])
+                st["rec"][2].copy_(st["pred"][2])
         out["coef"] = st["level"]
         # ---- deblock (in place on rec)
         dcfg = ops.deblock_cfg(bd)
