@@ -19,6 +19,7 @@
 // The quantiser works in the layout all three produce -- a lane holds four vertically consecutive coefficients of one column, an aligned quad
 // of lanes holds a 4x4 coefficient group: sign bit hiding is decided per quad with DPP quad permutes.
 #include "common.h"
+#include <mutex>
 
 namespace {
 
@@ -30,7 +31,7 @@ typedef vvcgpu_resi_chain_desc RcDesc;
 __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
 #define RC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-// ---- work lists (device): hdr[0..5] = counts of the classes 64, 32, 16, 8, 4, generic; hdr[6] = work counter of the matrix-core kernel
+// ---- work lists (device): hdr[0..5] = counts of the classes 64, 32, 16, 8, 4, generic
 constexpr int RC_HDR = 8;
 enum { RC_C64 = 0, RC_C32, RC_C16, RC_C8, RC_C4, RC_CGEN, RC_NCLS };
 
@@ -47,28 +48,49 @@ __device__ __forceinline__ int rc_class(const RcDesc& d)
   return RC_CGEN;
 }
 
-__global__ __launch_bounds__(256) void rc_classify_kernel(const RcDesc* __restrict__ descs, int n, int* __restrict__ hdr, int* __restrict__ lists,
-                                                          unsigned* __restrict__ absSum)
+// Same-address device-scope atomics retire at ~12 ns each (MI355X_MICROARCH.md, row 'fanin'): one atomic per wave and class made this kernel
+// 50 us for a 4K picture's 138 k TUs.  Here a workgroup of 1024 threads walks a contiguous slice of the list twice: pass 1 counts per class in
+// LDS, ONE global atomic per class reserves the slice's range of every list, pass 2 writes the indices (LDS counters give the positions).
+constexpr int RC_CLS_WGS = 128;
+__global__ __launch_bounds__(1024) void rc_classify_kernel(const RcDesc* __restrict__ descs, int n, int* __restrict__ hdr, int* __restrict__ lists,
+                                                           unsigned* __restrict__ absSum)
 {
-  const int ti = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
-  int cls = -1;
-  if (ti < n)
+  __shared__ int cnt[RC_NCLS], base[RC_NCLS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = min(n, lo + per);
+  if (tid < RC_NCLS) cnt[tid] = 0;
+  __syncthreads();
+  for (int pass = 0; pass < 2; pass++)
   {
-    const RcDesc d = descs[ti];
-    const bool ok = d.tr_hor >= 0 && d.tr_hor <= 2 && d.tr_ver >= 0 && d.tr_ver <= 2 && d.w >= 2 && d.w <= 64 && d.h >= 2 && d.h <= 64 &&
-                    (d.w & (d.w - 1)) == 0 && (d.h & (d.h - 1)) == 0 && (d.w <= 32 || d.tr_hor == 0) && (d.h <= 32 || d.tr_ver == 0);
-    if (ok) cls = rc_class(d);
-    else absSum[ti] = 0xFFFFFFFFu;                                           // precondition violated: TU not served, marked
-  }
+    for (int t0 = lo; t0 < hi; t0 += 1024)
+    {
+      const int ti = t0 + tid;
+      int cls = -1;
+      if (ti < hi)
+      {
+        const int* f = reinterpret_cast<const int*>(descs + ti) + 11;          // bytes 44..51: w, h, tr_hor, tr_ver, intra_slice, sign_hiding
+        const int wh = f[0], tt = f[1];
+        RcDesc d;
+        d.w = (short)(wh & 0xFFFF); d.h = (short)(wh >> 16); d.tr_hor = (signed char)(tt & 0xFF); d.tr_ver = (signed char)((tt >> 8) & 0xFF);
+        const bool ok = d.tr_hor >= 0 && d.tr_hor <= 2 && d.tr_ver >= 0 && d.tr_ver <= 2 && d.w >= 2 && d.w <= 64 && d.h >= 2 && d.h <= 64 &&
+                        (d.w & (d.w - 1)) == 0 && (d.h & (d.h - 1)) == 0 && (d.w <= 32 || d.tr_hor == 0) && (d.h <= 32 || d.tr_ver == 0);
+        if (ok) cls = rc_class(d);
+        else if (pass == 0) absSum[ti] = 0xFFFFFFFFu;                          // precondition violated: TU not served, marked
+      }
 #pragma unroll
-  for (int k = 0; k < RC_NCLS; k++)
-  {
-    const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == k);
-    if (m == 0ull) continue;
-    int base = 0;
-    if (lane == 0) base = atomicAdd(&hdr[k], (int)__popcll(m));
-    base = __builtin_amdgcn_readfirstlane(base);
-    if (cls == k) lists[(size_t)k * n + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = ti;
+      for (int k = 0; k < RC_NCLS; k++)
+      {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == k);
+        if (m == 0ull) continue;
+        int b = 0;
+        if (lane == 0) b = atomicAdd(&cnt[k], (int)__popcll(m));
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (pass == 1 && cls == k) lists[(size_t)k * n + base[k] + b + (int)__popcll(m & ((1ull << lane) - 1ull))] = ti;
+      }
+    }
+    __syncthreads();
+    if (pass == 0 && tid < RC_NCLS) { base[tid] = cnt[tid] ? atomicAdd(&hdr[tid], cnt[tid]) : 0; cnt[tid] = 0; }
+    __syncthreads();
   }
 }
 
@@ -219,8 +241,10 @@ __device__ __forceinline__ int rc_tab_off(int type, int n, int transposed)
   if (n == 64) return 3 * RC_TYPE + transposed * RC_S64;
   return type * RC_TYPE + (n == 16 ? transposed * RC_S16 : 2 * RC_S16 + transposed * RC_S32);
 }
-__device__ __forceinline__ void rc_load_tables(_Float16* tab, const int* __restrict__ tr32, const int* __restrict__ tr32t, int tid, int nthreads)
+// the LDS image is built ONCE per device in global memory (rc_build_tables_kernel) and copied by every workgroup with 16-byte loads
+__global__ __launch_bounds__(256) void rc_build_tables_kernel(_Float16* __restrict__ tab, const int* __restrict__ tr32, const int* __restrict__ tr32t)
 {
+  const int tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
   for (int t = 0; t < 3; t++)
     for (int n = 16; n <= 32; n <<= 1)
       for (int e = tid; e < n * n; e += nthreads)
@@ -235,6 +259,17 @@ __device__ __forceinline__ void rc_load_tables(_Float16* tab, const int* __restr
     tab[rc_tab_off(0, 64, 0) + r * 72 + k] = (_Float16)tr32[1364 + e];
     tab[rc_tab_off(0, 64, 1) + r * 72 + k] = (_Float16)tr32t[1364 + e];
   }
+}
+__device__ __forceinline__ void rc_load_tables(_Float16* tab, const _Float16* __restrict__ image, int tid)
+{
+  constexpr int NV = RC_TAB_HALVES / 8;                                        // 16-byte vectors
+  const uint4* src = reinterpret_cast<const uint4*>(image);
+  uint4* dst = reinterpret_cast<uint4*>(tab);
+  uint4 v[(NV + 255) / 256];
+#pragma unroll
+  for (int u = 0; u < (NV + 255) / 256; u++) if (tid + 256 * u < NV) v[u] = src[tid + 256 * u];
+#pragma unroll
+  for (int u = 0; u < (NV + 255) / 256; u++) if (tid + 256 * u < NV) dst[tid + 256 * u] = v[u];
 }
 
 // matrix operand of a product whose OTHER operand is a result tile: row `row` of the LDS matrix, the eight k values of k-step s in result-tile
@@ -637,41 +672,27 @@ __device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// matrix-core kernel: persistent waves, one TU per wave at a time, largest TUs first (work counter hdr[6])
-__global__ __launch_bounds__(256, 2) void rc_mfma_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
-                                                         TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs, int n,
-                                                         int* __restrict__ hdr, const int* __restrict__ lists, int* __restrict__ fallback,
-                                                         unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax, VvcTrTables tb)
+// matrix-core kernels, one per TU size (their register needs differ): persistent waves, wave i takes the TUs i, i + waves, ... of the class
+// list -- a shared work counter would be one same-address atomic per TU (~12 ns each: 100 us for a 4K picture)
+template <int N>
+__global__ __launch_bounds__(256, N == 64 ? 2 : 3) void rc_mfma_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase,
+                                                                        Pel* __restrict__ recBase, TCoeff* __restrict__ levelBase,
+                                                                        const RcDesc* __restrict__ descs, const int* __restrict__ count,
+                                                                        const int* __restrict__ list, int* __restrict__ fallback,
+                                                                        unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
+                                                                        const _Float16* __restrict__ image, const unsigned short* __restrict__ dqInv,
+                                                                        const int* __restrict__ scanOff)
 {
   __shared__ __align__(16) _Float16 tab[RC_TAB_HALVES];
   const int tid = threadIdx.x, lane = tid & 63;
-  const int c64 = hdr[RC_C64], c32 = hdr[RC_C32], c16 = hdr[RC_C16], total = c64 + c32 + c16;
+  const int total = count[0];
   if ((int)blockIdx.x * 4 >= total) return;
-  rc_load_tables(tab, tb.tr32, tb.tr32t, tid, 256);
+  rc_load_tables(tab, image, tid);
   __syncthreads();
-  for (;;)
+  for (int item = blockIdx.x * 4 + (tid >> 6); item < total; item += gridDim.x * 4)
   {
-    int item = 0;
-    if (lane == 0) item = atomicAdd(&hdr[6], 1);
-    item = __builtin_amdgcn_readfirstlane(item);
-    if (item >= total) break;
-    bool done;
-    int ti;
-    if (item < c64)
-    {
-      ti = lists[(size_t)RC_C64 * n + item];
-      done = rc_tu_mfma<64>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
-    }
-    else if (item < c64 + c32)
-    {
-      ti = lists[(size_t)RC_C32 * n + item - c64];
-      done = rc_tu_mfma<32>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
-    }
-    else
-    {
-      ti = lists[(size_t)RC_C16 * n + item - c64 - c32];
-      done = rc_tu_mfma<16>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
-    }
+    const int ti = list[item];
+    const bool done = rc_tu_mfma<N>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, dqInv, scanOff, lane);
     if (!done && lane == 0) fallback[1 + atomicAdd(&fallback[0], 1)] = ti;      // residual outside +-1023: the generic kernel takes it
   }
 }
@@ -822,7 +843,7 @@ __device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs,
   RC_WAVE_SYNC();
 }
 
-__global__ __launch_bounds__(256) void rc_small_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+__global__ __launch_bounds__(256, 3) void rc_small_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                        TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs, int n,
                                                        const int* __restrict__ hdr, const int* __restrict__ lists,
                                                        unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax, VvcTrTables tb)
@@ -865,7 +886,28 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
   const int rt = vvcgpu_tr_tables(&tb);
   if (rt) return rt;
   hipStream_t st = (hipStream_t)stream;
-  // scratch: header, the six class lists, the fall-back list of the matrix-core kernel
+  // f16 LDS image of the matrices: built once per device
+  static std::mutex imageMutex;
+  static _Float16* images[64] = { nullptr };
+  int dev = 0;
+  VVC_HIP(hipGetDevice(&dev));
+  VVC_CHECK_ARG(dev >= 0 && dev < 64, "resi_chain_batch: device index %d", dev);
+  const _Float16* image;
+  {
+    std::lock_guard<std::mutex> lock(imageMutex);
+    if (!images[dev])
+    {
+      void* p = nullptr;
+      VVC_HIP(hipMalloc(&p, RC_TAB_HALVES * sizeof(_Float16)));
+      VVC_HIP(hipMemsetAsync(p, 0, RC_TAB_HALVES * sizeof(_Float16), st));      // row padding
+      hipLaunchKernelGGL(rc_build_tables_kernel, dim3(16), dim3(256), 0, st, static_cast<_Float16*>(p), tb.tr32, tb.tr32t);
+      VVC_LAUNCH_CHECK();
+      VVC_HIP(hipStreamSynchronize(st));                  // other streams may use the image right after this call returns
+      images[dev] = static_cast<_Float16*>(p);
+    }
+    image = images[dev];
+  }
+  // scratch: header, the six class lists, the fall-back list of the matrix-core kernels
   const size_t ints = RC_HDR + (size_t)RC_NCLS * n + 1 + (size_t)n;
   int* ws = static_cast<int*>(vvcgpu_scratch(st, ints * sizeof(int)));
   if (!ws) return VVCGPU_E_DEVICE;
@@ -874,11 +916,16 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
   int* fallback = lists + (size_t)RC_NCLS * n;
   VVC_HIP(hipMemsetAsync(hdr, 0, RC_HDR * sizeof(int), st));
   VVC_HIP(hipMemsetAsync(fallback, 0, sizeof(int), st));
-  hipLaunchKernelGGL(rc_classify_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, descs, n, hdr, lists, abs_sum);
+  hipLaunchKernelGGL(rc_classify_kernel, dim3(n < 1024 * RC_CLS_WGS ? cdiv(n, 1024) : RC_CLS_WGS), dim3(1024), 0, st, descs, n, hdr, lists, abs_sum);
   VVC_LAUNCH_CHECK();
-  const int wgM = cdiv(n, 4) < 512 ? cdiv(n, 4) : 512;
-  hipLaunchKernelGGL(rc_mfma_kernel, dim3(wgM), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, fallback, abs_sum,
-                     bit_depth, clp_min, clp_max, tb);
+  const int wgM = cdiv(n, 4) < 1024 ? cdiv(n, 4) : 1024;
+#define RC_LAUNCH_MFMA(N, CLS)                                                                                                              \
+  hipLaunchKernelGGL(rc_mfma_kernel<N>, dim3(wgM), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + CLS,           \
+                     lists + (size_t)CLS * n, fallback, abs_sum, bit_depth, clp_min, clp_max, image, tb.dqInv, tb.scanOff)
+  RC_LAUNCH_MFMA(64, RC_C64);
+  RC_LAUNCH_MFMA(32, RC_C32);
+  RC_LAUNCH_MFMA(16, RC_C16);
+#undef RC_LAUNCH_MFMA
   VVC_LAUNCH_CHECK();
   const int wgS = cdiv(n, 32) < 2048 ? cdiv(n, 32) : 2048;
   hipLaunchKernelGGL(rc_small_kernel, dim3(wgS), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, abs_sum,
