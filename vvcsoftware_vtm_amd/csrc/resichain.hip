@@ -260,16 +260,24 @@ __global__ __launch_bounds__(256) void rc_build_tables_kernel(_Float16* __restri
     tab[rc_tab_off(0, 64, 1) + r * 72 + k] = (_Float16)tr32t[1364 + e];
   }
 }
+// copies the matrices a TU size needs: sizes 16 / 32: the T and T^T copies of that size for the three types; 64: the DCT-II pair
+template <int N>
 __device__ __forceinline__ void rc_load_tables(_Float16* tab, const _Float16* __restrict__ image, int tid)
 {
-  constexpr int NV = RC_TAB_HALVES / 8;                                        // 16-byte vectors
-  const uint4* src = reinterpret_cast<const uint4*>(image);
-  uint4* dst = reinterpret_cast<uint4*>(tab);
-  uint4 v[(NV + 255) / 256];
+  constexpr int SZ = N == 16 ? 2 * RC_S16 : N == 32 ? 2 * RC_S32 : 2 * RC_S64;  // halves per type (T and T^T are adjacent)
+  constexpr int NT = N == 64 ? 1 : 3, NV = SZ / 8;
 #pragma unroll
-  for (int u = 0; u < (NV + 255) / 256; u++) if (tid + 256 * u < NV) v[u] = src[tid + 256 * u];
+  for (int t = 0; t < NT; t++)
+  {
+    const int off = rc_tab_off(t, N, 0);
+    const uint4* src = reinterpret_cast<const uint4*>(image + off);
+    uint4* dst = reinterpret_cast<uint4*>(tab + off);
+    uint4 v[(NV + 255) / 256];
 #pragma unroll
-  for (int u = 0; u < (NV + 255) / 256; u++) if (tid + 256 * u < NV) dst[tid + 256 * u] = v[u];
+    for (int u = 0; u < (NV + 255) / 256; u++) if (tid + 256 * u < NV) v[u] = src[tid + 256 * u];
+#pragma unroll
+    for (int u = 0; u < (NV + 255) / 256; u++) if (tid + 256 * u < NV) dst[tid + 256 * u] = v[u];
+  }
 }
 
 // matrix operand of a product whose OTHER operand is a result tile: row `row` of the LDS matrix, the eight k values of k-step s in result-tile
@@ -678,8 +686,8 @@ template <int N>
 __global__ __launch_bounds__(256, N == 64 ? 2 : 3) void rc_mfma_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase,
                                                                         Pel* __restrict__ recBase, TCoeff* __restrict__ levelBase,
                                                                         const RcDesc* __restrict__ descs, const int* __restrict__ count,
-                                                                        const int* __restrict__ list, int* __restrict__ fallback,
-                                                                        unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
+                                                                        const int* __restrict__ list, int* __restrict__ fbCount,
+                                                                        int* __restrict__ fbList, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                                                         const _Float16* __restrict__ image, const unsigned short* __restrict__ dqInv,
                                                                         const int* __restrict__ scanOff)
 {
@@ -687,27 +695,28 @@ __global__ __launch_bounds__(256, N == 64 ? 2 : 3) void rc_mfma_kernel(const Pel
   const int tid = threadIdx.x, lane = tid & 63;
   const int total = count[0];
   if ((int)blockIdx.x * 4 >= total) return;
-  rc_load_tables(tab, image, tid);
+  rc_load_tables<N>(tab, image, tid);
   __syncthreads();
   for (int item = blockIdx.x * 4 + (tid >> 6); item < total; item += gridDim.x * 4)
   {
     const int ti = list[item];
     const bool done = rc_tu_mfma<N>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, dqInv, scanOff, lane);
-    if (!done && lane == 0) fallback[1 + atomicAdd(&fallback[0], 1)] = ti;      // residual outside +-1023: the generic kernel takes it
+    if (!done && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti;                 // residual outside +-1023: the generic kernel takes it
   }
 }
 
-// generic kernel: the class-`generic` list, then (second launch) the fall-back list of the matrix-core kernel
+// generic kernel: the class-`generic` list, then the fall-back list of the matrix-core kernels (TUs whose residual left +-1023)
 __global__ __launch_bounds__(64) void rc_generic_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                         TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs,
-                                                        const int* __restrict__ count, const int* __restrict__ list,
+                                                        const int* __restrict__ countA, const int* __restrict__ listA,
+                                                        const int* __restrict__ countB, const int* __restrict__ listB,
                                                         unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax, VvcTrTables tb)
 {
   __shared__ int bufA[4096], bufB[4096];
-  const int cnt = count[0];
-  for (int k = blockIdx.x; k < cnt; k += gridDim.x)
+  const int ca = countA[0], cb = countB[0];
+  for (int k = blockIdx.x; k < ca + cb; k += gridDim.x)
   {
-    const int ti = list[k];
+    const int ti = k < ca ? listA[k] : listB[k - ca];
     rc_tu_generic(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, bufA, bufB,
                   (int)threadIdx.x);
   }
@@ -843,16 +852,17 @@ __device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs,
   RC_WAVE_SYNC();
 }
 
-__global__ __launch_bounds__(256, 3) void rc_small_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
-                                                       TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs, int n,
-                                                       const int* __restrict__ hdr, const int* __restrict__ lists,
+template <int S>
+__global__ __launch_bounds__(256, S == 4 ? 6 : 3) void rc_small_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                                       TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs,
+                                                       const int* __restrict__ count, const int* __restrict__ list,
                                                        unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax, VvcTrTables tb)
 {
   __shared__ RcSmallTab tabs;
   __shared__ int tmpAll[4][8 * 8 * 9];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c8 = hdr[RC_C8], c4 = hdr[RC_C4];
-  const int items8 = (c8 + 7) >> 3, items4 = (c4 + 15) >> 4, total = items8 + items4;
+  const int cnt = count[0];
+  const int total = (cnt + 64 / S - 1) / (64 / S);
   if ((int)blockIdx.x * 4 >= total) return;
   for (int e = tid; e < 3 * 80; e += 256)
   {
@@ -862,11 +872,62 @@ __global__ __launch_bounds__(256, 3) void rc_small_kernel(const Pel* __restrict_
   }
   __syncthreads();
   for (int item = blockIdx.x * 4 + wave; item < total; item += gridDim.x * 4)
+    rc_small_group<S>(descs, list, cnt, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+}
+
+// All five size classes in ONE launch.  Each class alone is bound by the latency of a TU, not by throughput (405 64x64 TUs are 405 waves:
+// 20 us; 6480 16x16 TUs: 14 us; ...), and kernels on one stream run one after the other (82 us for the five launches at 4K).  Here a workgroup
+// walks "slots" (four wave items of one class), longest classes first, so short items fill the machine while the long ones run.
+__global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                                          TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs, int n,
+                                                          const int* __restrict__ hdr, const int* __restrict__ lists, int* __restrict__ fbCount,
+                                                          int* __restrict__ fbList, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
+                                                          const _Float16* __restrict__ image, VvcTrTables tb)
+{
+  __shared__ __align__(16) _Float16 tab[RC_TAB_HALVES];
+  __shared__ RcSmallTab tabs;
+  __shared__ int tmpAll[4][8 * 8 * 9];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int c64 = hdr[RC_C64], c32 = hdr[RC_C32], c16 = hdr[RC_C16], c8 = hdr[RC_C8], c4 = hdr[RC_C4];
+  const int i8 = (c8 + 7) >> 3, i4 = (c4 + 15) >> 4;                          // wave items of the lane-group classes
+  const int s64 = (c64 + 3) >> 2, s32 = (c32 + 3) >> 2, s8 = (i8 + 3) >> 2, s16 = (c16 + 3) >> 2, s4 = (i4 + 3) >> 2;
+  const int e64 = s64, e32 = e64 + s32, e8 = e32 + s8, e16 = e8 + s16, total = e16 + s4;
+  if ((int)blockIdx.x >= total) return;
+  rc_load_tables<16>(tab, image, tid);
+  rc_load_tables<32>(tab, image, tid);
+  rc_load_tables<64>(tab, image, tid);
+  for (int e = tid; e < 3 * 80; e += 256)
   {
-    if (item < items8)
-      rc_small_group<8>(descs, lists + (size_t)RC_C8 * n, c8, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+    const int t = e / 80, o = e - t * 80, nsz = o < 16 ? 4 : 8, oo = o < 16 ? o : o - 16;
+    tabs.t[t][o] = tb.tr32[t * 5460 + (nsz * nsz - 4) / 3 + oo];
+    tabs.tt[t][o] = tb.tr32t[t * 5460 + (nsz * nsz - 4) / 3 + oo];
+  }
+  __syncthreads();
+  for (int slot = blockIdx.x; slot < total; slot += gridDim.x)
+  {
+    if (slot < e32 || (slot >= e8 && slot < e16))                             // matrix-core classes: one TU per wave
+    {
+      const int cls = slot < e64 ? RC_C64 : slot < e32 ? RC_C32 : RC_C16;
+      const int item = (slot - (cls == RC_C64 ? 0 : cls == RC_C32 ? e64 : e8)) * 4 + wave;
+      const int cnt = cls == RC_C64 ? c64 : cls == RC_C32 ? c32 : c16;
+      if (item >= cnt) continue;
+      const int ti = lists[(size_t)cls * n + item];
+      bool done;
+      if (cls == RC_C64)      done = rc_tu_mfma<64>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
+      else if (cls == RC_C32) done = rc_tu_mfma<32>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
+      else                    done = rc_tu_mfma<16>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
+      if (!done && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti;             // residual outside +-1023: the generic kernel takes it
+    }
+    else if (slot < e8)
+    {
+      const int item = (slot - e32) * 4 + wave;
+      if (item < i8) rc_small_group<8>(descs, lists + (size_t)RC_C8 * n, c8, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+    }
     else
-      rc_small_group<4>(descs, lists + (size_t)RC_C4 * n, c4, item - items8, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+    {
+      const int item = (slot - e16) * 4 + wave;
+      if (item < i4) rc_small_group<4>(descs, lists + (size_t)RC_C4 * n, c4, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+    }
   }
 }
 
@@ -907,36 +968,46 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
     }
     image = images[dev];
   }
-  // scratch: header, the six class lists, the fall-back list of the matrix-core kernels
-  const size_t ints = RC_HDR + (size_t)RC_NCLS * n + 1 + (size_t)n;
+  // scratch: header (class counts, then the fall-back count), the six class lists, the fall-back list of the matrix-core kernels
+  const size_t ints = RC_HDR + (size_t)RC_NCLS * n + (size_t)n;
   int* ws = static_cast<int*>(vvcgpu_scratch(st, ints * sizeof(int)));
   if (!ws) return VVCGPU_E_DEVICE;
   int* hdr = ws;
   int* lists = ws + RC_HDR;
-  int* fallback = lists + (size_t)RC_NCLS * n;
+  int* fbCount = hdr + 7;
+  int* fbList = lists + (size_t)RC_NCLS * n;
   VVC_HIP(hipMemsetAsync(hdr, 0, RC_HDR * sizeof(int), st));
-  VVC_HIP(hipMemsetAsync(fallback, 0, sizeof(int), st));
   hipLaunchKernelGGL(rc_classify_kernel, dim3(n < 1024 * RC_CLS_WGS ? cdiv(n, 1024) : RC_CLS_WGS), dim3(1024), 0, st, descs, n, hdr, lists, abs_sum);
   VVC_LAUNCH_CHECK();
-  const int wgM = cdiv(n, 4) < 1024 ? cdiv(n, 4) : 1024;
+  // (measured: forking the size classes onto library-owned side streams and joining them with events is SLOWER than launching them back to
+  // back on the caller's stream, 0.158 vs 0.115 ms at 4K -- a cross-stream event costs more than these 20 us kernels gain)
+  static const int separate = getenv("VVCGPU_RC_SEPARATE") ? 1 : 0;           // A/B timing switch: one launch per size class
+  if (!separate)
+  {
+    hipLaunchKernelGGL(rc_chain_kernel, dim3(512), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, fbCount, fbList,
+                       abs_sum, bit_depth, clp_min, clp_max, image, tb);
+    VVC_LAUNCH_CHECK();
+  }
+  else
+  {
+    const int wgM = cdiv(n, 4) < 1024 ? cdiv(n, 4) : 1024;
 #define RC_LAUNCH_MFMA(N, CLS)                                                                                                              \
-  hipLaunchKernelGGL(rc_mfma_kernel<N>, dim3(wgM), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + CLS,           \
-                     lists + (size_t)CLS * n, fallback, abs_sum, bit_depth, clp_min, clp_max, image, tb.dqInv, tb.scanOff)
-  RC_LAUNCH_MFMA(64, RC_C64);
-  RC_LAUNCH_MFMA(32, RC_C32);
-  RC_LAUNCH_MFMA(16, RC_C16);
+    hipLaunchKernelGGL(rc_mfma_kernel<N>, dim3(wgM), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + CLS,         \
+                       lists + (size_t)CLS * n, fbCount, fbList, abs_sum, bit_depth, clp_min, clp_max, image, tb.dqInv, tb.scanOff)
+    RC_LAUNCH_MFMA(64, RC_C64);
+    RC_LAUNCH_MFMA(32, RC_C32);
+    RC_LAUNCH_MFMA(16, RC_C16);
 #undef RC_LAUNCH_MFMA
-  VVC_LAUNCH_CHECK();
-  const int wgS = cdiv(n, 32) < 2048 ? cdiv(n, 32) : 2048;
-  hipLaunchKernelGGL(rc_small_kernel, dim3(wgS), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, abs_sum,
-                     bit_depth, clp_min, clp_max, tb);
-  VVC_LAUNCH_CHECK();
+    const int wg8 = cdiv(n, 32) < 2048 ? cdiv(n, 32) : 2048, wg4 = cdiv(n, 64) < 2048 ? cdiv(n, 64) : 2048;
+    hipLaunchKernelGGL(rc_small_kernel<8>, dim3(wg8), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_C8,
+                       lists + (size_t)RC_C8 * n, abs_sum, bit_depth, clp_min, clp_max, tb);
+    hipLaunchKernelGGL(rc_small_kernel<4>, dim3(wg4), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_C4,
+                       lists + (size_t)RC_C4 * n, abs_sum, bit_depth, clp_min, clp_max, tb);
+    VVC_LAUNCH_CHECK();
+  }
   const int wgG = n < 1024 ? n : 1024;
   hipLaunchKernelGGL(rc_generic_kernel, dim3(wgG), dim3(64), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_CGEN,
-                     lists + (size_t)RC_CGEN * n, abs_sum, bit_depth, clp_min, clp_max, tb);
-  VVC_LAUNCH_CHECK();
-  hipLaunchKernelGGL(rc_generic_kernel, dim3(64), dim3(64), 0, st, org_base, pred_base, rec_base, level_base, descs, fallback, fallback + 1, abs_sum,
-                     bit_depth, clp_min, clp_max, tb);
+                     lists + (size_t)RC_CGEN * n, fbCount, fbList, abs_sum, bit_depth, clp_min, clp_max, tb);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
