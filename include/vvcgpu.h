@@ -323,6 +323,28 @@ typedef struct vvcgpu_resi_chain_desc {
 int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, vvc_pel* rec_base, vvc_coef* level_base,
                             const vvcgpu_resi_chain_desc* descs, int n, int bit_depth, int clp_min, int clp_max, uint32_t* abs_sum,
                             void* stream);
+/* ---- picture-level forms of the in-loop entry points: the three planes of a 4:2:0 picture in ONE launch each.  A chroma plane of a 4K picture is
+ *          about one workgroup per CU, so a launch of its own costs its latency floor; these are also the forms a binding uses that keeps the
+ *          reconstruction resident on the device across loopFilterPic -> SAOProcess -> ALFProcess (EncGOP.cpp:2122-2153, DecLib.cpp:506-533).
+ * Same arithmetic and preconditions as the per-plane entry points they bundle (vvcgpu_sao_apply, vvcgpu_sao_stats, vvcgpu_alf_filter_luma /
+ * _chroma, vvcgpu_alf_stats); width / height are the luma size, chroma planes are half size, ctu_size is the luma CTU size.            */
+typedef struct vvcgpu_planes { vvc_pel* p[3]; int32_t stride[3]; } vvcgpu_planes;     /* Y, Cb, Cr: device pointers, strides in samples */
+int vvcgpu_sao_apply_picture(const vvcgpu_planes* src, const vvcgpu_planes* dst, int width, int height, int ctu_size, int bit_depth,
+                             const vvcgpu_sao_ctu* params_y, const vvcgpu_sao_ctu* params_cb, const vvcgpu_sao_ctu* params_cr,
+                             int clp_min, int clp_max, void* stream);
+/* out_y / out_cb / out_cr as vvcgpu_sao_stats' out (nCtu x 5 x 2 x 32 int64 each); skip lines: luma (r, b), chroma (r, b) */
+int vvcgpu_sao_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec, int width, int height, int ctu_size, int bit_depth,
+                             const uint8_t* avail, int skip_r_luma, int skip_b_luma, int skip_r_chroma, int skip_b_chroma,
+                             int64_t* out_y, int64_t* out_cb, int64_t* out_cr, void* stream);
+/* luma with the per-4x4 classifier and filter_type (0: 5x5, 1: 7x7), chroma always 5x5 with one filter; enable_* may be NULL (all CTUs on) */
+int vvcgpu_alf_filter_picture(const vvcgpu_planes* src, const vvcgpu_planes* dst, int width, int height, int ctu_size, const uint16_t* cls,
+                              int filter_type, const int16_t* luma_coeff_host, const int16_t* chroma_coeff_host, const uint8_t* enable_y,
+                              const uint8_t* enable_cb, const uint8_t* enable_cr, int clp_min, int clp_max, void* stream);
+/* the four covariance sets EncAdaptiveLoopFilter::deriveStatsForFiltering builds per picture (EncAdaptiveLoopFilter.cpp:1317-1392): luma 7x7
+ * (out7: nCtu x 25 x 183) and luma 5x5 (out5: nCtu x 25 x 57) per class, Cb and Cr 5x5 (nCtu x 1 x 57 each).  The 5x5 diamond is a sub-diamond of
+ * the 7x7 one under every transposition, so the luma 5x5 set is gathered from the 7x7 sums instead of being accumulated a second time.   */
+int vvcgpu_alf_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec, int width, int height, int ctu_size, const uint16_t* cls,
+                             int64_t* out7, int64_t* out5, int64_t* out_cb, int64_t* out_cr, void* stream);
 /* The coefficient scan the library replays (host copy, out[scanIdx] = raster position; w, h in 2..64 powers of two). */
 int vvcgpu_scan_order_host(int w, int h, uint16_t* out);
 /* ---- N3 ("next" row): affine gradient search kernels  (AffineGradientSearch table slots m_HorizontalSobelFilter /

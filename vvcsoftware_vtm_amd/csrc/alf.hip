@@ -166,16 +166,14 @@ __device__ __forceinline__ constexpr int tapIndex(int dy, int dx)
 }
 
 template <bool IS7, bool LUMA>
-__global__ __launch_bounds__(128) void alf_filter_kernel(const Pel* __restrict__ src, int sstride,
+__device__ __forceinline__ void alf_filter_body(const int bidx, const int bidy, short* tile, short* scoef, const Pel* __restrict__ src, int sstride,
                                                          Pel* __restrict__ dst, int dstride, int w, int h,
                                                          int ctu, int wCtu, const uint16_t* __restrict__ cls,
-                                                         AlfCoeffs coeffs, const uint8_t* __restrict__ ctuEnable,
+                                                         const AlfCoeffs& coeffs, const uint8_t* __restrict__ ctuEnable,
                                                          int clpMin, int clpMax)
 {
-  __shared__ short tile[FR * FP];
-  __shared__ short scoef[25 * 13 + 3];
   const int tid = threadIdx.x;
-  const int tx0 = blockIdx.x * FW, ty0 = blockIdx.y * FH;
+  const int tx0 = bidx * FW, ty0 = bidy * FH;
   load_tile_clamped<FP>(tile, src, sstride, w, h, tx0 - 4, ty0 - 3, FR, tid, 128);
   for (int i = tid; i < (LUMA ? 25 * 13 : 7); i += 128) scoef[i] = coeffs.c[i];
   __syncthreads();
@@ -267,6 +265,42 @@ __global__ __launch_bounds__(128) void alf_filter_kernel(const Pel* __restrict__
   }
 }
 
+template <bool IS7, bool LUMA>
+__global__ __launch_bounds__(128) void alf_filter_kernel(const Pel* __restrict__ src, int sstride, Pel* __restrict__ dst, int dstride, int w, int h,
+                                                         int ctu, int wCtu, const uint16_t* __restrict__ cls, AlfCoeffs coeffs,
+                                                         const uint8_t* __restrict__ ctuEnable, int clpMin, int clpMax)
+{
+  __shared__ short tile[FR * FP];
+  __shared__ short scoef[25 * 13 + 3];
+  alf_filter_body<IS7, LUMA>((int)blockIdx.x, (int)blockIdx.y, tile, scoef, src, sstride, dst, dstride, w, h, ctu, wCtu, cls, coeffs, ctuEnable, clpMin, clpMax);
+}
+
+// luma (classifier-driven 7x7 or 5x5) and both chroma planes (5x5, one filter) of a picture in one launch
+struct AlfPlane { const Pel* src; Pel* dst; const uint8_t* enable; int sstride, dstride; };
+struct AlfFilter3 { AlfPlane a[3]; const uint16_t* cls; int w, h, ctu, glx, nLuma, gcx, gcy, clpMin, clpMax; AlfCoeffs luma; short chroma[8]; };
+template <bool IS7>
+__global__ __launch_bounds__(128) void alf_filter_picture_kernel(AlfFilter3 p)
+{
+  __shared__ short tile[FR * FP];
+  __shared__ short scoef[25 * 13 + 3];
+  const int b = blockIdx.x;
+  if (b < p.nLuma)
+    alf_filter_body<IS7, true>(b % p.glx, b / p.glx, tile, scoef, p.a[0].src, p.a[0].sstride, p.a[0].dst, p.a[0].dstride, p.w, p.h, p.ctu, (p.w + p.ctu - 1) / p.ctu,
+                               p.cls, p.luma, p.a[0].enable, p.clpMin, p.clpMax);
+  else
+  {
+    const int c = b - p.nLuma, per = p.gcx * p.gcy, z = c / per, r = c - z * per;
+    const AlfPlane& a = z ? p.a[2] : p.a[1];
+    AlfCoeffs cc;
+#pragma unroll
+    for (int i = 0; i < 7; i++) cc.c[i] = p.chroma[i];
+    const int ctuC = p.ctu >> 1, wc = p.w >> 1;
+    alf_filter_body<false, false>(r % p.gcx, r / p.gcx, tile, scoef, a.src, a.sstride, a.dst, a.dstride, wc, p.h >> 1, ctuC, (wc + ctuC - 1) / ctuC,
+                                  nullptr, cc, a.enable, p.clpMin, p.clpMax);
+  }
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -335,6 +369,36 @@ int vvcgpu_alf_filter_chroma(const vvc_pel* src, int src_stride, vvc_pel* dst, i
 {
   return alf_filter_common(false, src, src_stride, dst, dst_stride, width, height, ctu_size, nullptr, 0,
                            coeff_host, ctu_enable, clp_min, clp_max, stream);
+}
+
+int vvcgpu_alf_filter_picture(const vvcgpu_planes* src, const vvcgpu_planes* dst, int width, int height, int ctu_size, const uint16_t* cls,
+                              int filter_type, const int16_t* luma_coeff_host, const int16_t* chroma_coeff_host, const uint8_t* enable_y,
+                              const uint8_t* enable_cb, const uint8_t* enable_cr, int clp_min, int clp_max, void* stream)
+{
+  VVC_CHECK_ARG(src && dst && cls && luma_coeff_host && chroma_coeff_host, "alf_filter_picture: null pointer");
+  VVC_CHECK_ARG(width > 0 && height > 0 && (width & 7) == 0 && (height & 7) == 0, "alf_filter_picture: width/height must be multiples of 8 (got %dx%d)", width, height);
+  VVC_CHECK_ARG(ctu_size >= 8 && (ctu_size & 7) == 0, "alf_filter_picture: bad ctu size %d", ctu_size);
+  VVC_CHECK_ARG(filter_type == 0 || filter_type == 1, "alf_filter_picture: filter_type %d", filter_type);
+  AlfFilter3 p;
+  memset(&p, 0, sizeof p);
+  const uint8_t* en[3] = { enable_y, enable_cb, enable_cr };
+  for (int c = 0; c < 3; c++)
+  {
+    const int w = c ? width >> 1 : width;
+    VVC_CHECK_ARG(src->p[c] && dst->p[c] && src->p[c] != dst->p[c] && src->stride[c] >= w && dst->stride[c] >= w && (dst->stride[c] & 3) == 0 &&
+                  ((uintptr_t)dst->p[c] & 7) == 0, "alf_filter_picture: plane %d (dst needs stride %% 4 == 0 and 8-byte alignment)", c);
+    p.a[c] = AlfPlane{ src->p[c], dst->p[c], en[c], src->stride[c], dst->stride[c] };
+  }
+  memcpy(p.luma.c, luma_coeff_host, sizeof(int16_t) * 25 * 13);
+  memcpy(p.chroma, chroma_coeff_host, sizeof(int16_t) * 7);
+  p.cls = cls; p.w = width; p.h = height; p.ctu = ctu_size; p.clpMin = clp_min; p.clpMax = clp_max;
+  p.glx = cdiv(width, FW); p.nLuma = p.glx * cdiv(height, FH);
+  p.gcx = cdiv(width >> 1, FW); p.gcy = cdiv(height >> 1, FH);
+  const int total = p.nLuma + 2 * p.gcx * p.gcy;
+  if (filter_type) hipLaunchKernelGGL(alf_filter_picture_kernel<true>, dim3(total), dim3(128), 0, (hipStream_t)stream, p);
+  else             hipLaunchKernelGGL(alf_filter_picture_kernel<false>, dim3(total), dim3(128), 0, (hipStream_t)stream, p);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
 }
 
 }  // extern "C"

@@ -136,14 +136,13 @@ __device__ __forceinline__ void tile_store(const short* lds, Pel* plane, int str
   }
 }
 
-__global__ __launch_bounds__(128) void deblock_luma_kernel(Pel* __restrict__ Y, int stride, int w, int h,
+__device__ __forceinline__ void deblock_luma_body(const dim3 bid, short* tile, Pel* __restrict__ Y, int stride, int w, int h,
                                                            const uint8_t* __restrict__ edgeV,
                                                            const uint8_t* __restrict__ edgeH,
                                                            const int8_t* __restrict__ qpm, vvcgpu_deblock_cfg cfg)
 {
-  __shared__ short tile[TS * TP];
   const int tid = threadIdx.x;
-  const int ox = blockIdx.x * TS - 4, oy = blockIdx.y * TS - 4;
+  const int ox = bid.x * TS - 4, oy = bid.y * TS - 4;
   const int w4 = w >> 2;
   tile_load(tile, Y, stride, w, h, ox, oy, tid, 128);
   __syncthreads();
@@ -225,19 +224,18 @@ __device__ __forceinline__ int chroma_tc(int qpP, int qpQ, int qpOff, const vvcg
 }
 
 // Chroma plane (w,h are CHROMA dimensions).  blockIdx.z selects Cb / Cr.
-__global__ __launch_bounds__(128) void deblock_chroma_kernel(Pel* __restrict__ Cb, Pel* __restrict__ Cr, int stride,
+__device__ __forceinline__ void deblock_chroma_body(const dim3 bid, short* tile, Pel* __restrict__ Cb, Pel* __restrict__ Cr, int stride,
                                                              int w, int h, int w4 /* luma units per row */,
                                                              const uint8_t* __restrict__ edgeV,
                                                              const uint8_t* __restrict__ edgeH,
                                                              const int8_t* __restrict__ qpm, vvcgpu_deblock_cfg cfg)
 {
-  __shared__ short tile[TS * TP];
   const int tid = threadIdx.x;
-  const int comp = blockIdx.z;                       // 0 = Cb, 1 = Cr
+  const int comp = bid.z;                       // 0 = Cb, 1 = Cr
   Pel* plane = comp ? Cr : Cb;
   const int qpOff = comp ? cfg.cr_qp_offset : cfg.cb_qp_offset;
   const int cmin = cfg.clp_min[1 + comp], cmax = cfg.clp_max[1 + comp];
-  const int ox = blockIdx.x * TS - 4, oy = blockIdx.y * TS - 4;
+  const int ox = bid.x * TS - 4, oy = bid.y * TS - 4;
   tile_load(tile, plane, stride, w, h, ox, oy, tid, 128);
   __syncthreads();
 
@@ -298,6 +296,23 @@ __global__ __launch_bounds__(128) void deblock_chroma_kernel(Pel* __restrict__ C
   tile_store(tile, plane, stride, w, h, ox, oy, tid, 128);
 }
 
+// luma and both chroma planes in ONE launch: the chroma planes alone are ~1 workgroup per CU, a launch of their own costs its latency floor
+__global__ __launch_bounds__(128) void deblock_picture_kernel(Pel* __restrict__ Y, int strideY, Pel* __restrict__ Cb, Pel* __restrict__ Cr, int strideC,
+                                                              int w, int h, int glx, int nLuma, int gcx, int gcy,
+                                                              const uint8_t* __restrict__ edgeV, const uint8_t* __restrict__ edgeH,
+                                                              const int8_t* __restrict__ qpLuma, const int8_t* __restrict__ qpChroma,
+                                                              vvcgpu_deblock_cfg cfg)
+{
+  __shared__ short tile[TS * TP];
+  const int b = blockIdx.x;
+  if (b < nLuma) deblock_luma_body(dim3(b % glx, b / glx, 0), tile, Y, strideY, w, h, edgeV, edgeH, qpLuma, cfg);
+  else
+  {
+    const int c = b - nLuma, per = gcx * gcy, z = c / per, r = c - z * per;
+    deblock_chroma_body(dim3(r % gcx, r / gcx, z), tile, Cb, Cr, strideC, w >> 1, h >> 1, w >> 2, edgeV, edgeH, qpChroma, cfg);
+  }
+}
+
 }  // namespace
 
 extern "C" int vvcgpu_deblock(vvc_pel* y, int stride_y, vvc_pel* cb, vvc_pel* cr, int stride_c, int width, int height,
@@ -314,15 +329,11 @@ extern "C" int vvcgpu_deblock(vvc_pel* y, int stride_y, vvc_pel* cb, vvc_pel* cr
   VVC_CHECK_ARG(cfg.bit_depth_luma >= 8 && cfg.bit_depth_luma <= 10 && cfg.bit_depth_chroma >= 8 &&
                 cfg.bit_depth_chroma <= 10, "deblock: bit depths outside 8..10");
   hipStream_t st = (hipStream_t)stream;
-  dim3 gl(cdiv(width + 4, TS), cdiv(height + 4, TS));
-  hipLaunchKernelGGL(deblock_luma_kernel, gl, dim3(128), 0, st, y, stride_y, width, height, edge_ver, edge_hor, qp_luma, cfg);
+  const int glx = cdiv(width + 4, TS), gly = cdiv(height + 4, TS);
+  const int gcx = cdiv(width / 2 + 4, TS), gcy = cdiv(height / 2 + 4, TS);
+  const int nLuma = glx * gly, nChroma = cb ? 2 * gcx * gcy : 0;
+  hipLaunchKernelGGL(deblock_picture_kernel, dim3(nLuma + nChroma), dim3(128), 0, st, y, stride_y, cb, cr, stride_c, width, height, glx, nLuma, gcx, gcy,
+                     edge_ver, edge_hor, qp_luma, qp_chroma, cfg);
   VVC_LAUNCH_CHECK();
-  if (cb)
-  {
-    dim3 gc(cdiv(width / 2 + 4, TS), cdiv(height / 2 + 4, TS), 2);
-    hipLaunchKernelGGL(deblock_chroma_kernel, gc, dim3(128), 0, st, cb, cr, stride_c, width / 2, height / 2, width >> 2,
-                       edge_ver, edge_hor, qp_chroma, cfg);
-    VVC_LAUNCH_CHECK();
-  }
   return VVCGPU_OK;
 }

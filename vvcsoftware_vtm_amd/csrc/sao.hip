@@ -55,7 +55,7 @@ __device__ __forceinline__ void eo_rows(const SaoGeom& g, int off0, int off1, in
   }
 }
 
-__global__ __launch_bounds__(256) void sao_apply_kernel(const Pel* __restrict__ src, int sstride,
+__device__ __forceinline__ void sao_apply_body(const int bidx, const Pel* __restrict__ src, int sstride,
                                                         Pel* __restrict__ dst, int dstride, int w, int h,
                                                         int ctuW, int ctuH, int wCtu, int boShift,
                                                         const vvcgpu_sao_ctu* __restrict__ params,
@@ -64,7 +64,7 @@ __global__ __launch_bounds__(256) void sao_apply_kernel(const Pel* __restrict__ 
   // a wave covers (8 << tpcShift) samples x (64 >> tpcShift) thread rows: with a power-of-two CTU width that is exactly
   // one CTU column, so the SAO type is wave-uniform and only one of the five type bodies runs (a wave that straddles
   // several CTUs executes them one after the other)
-  const int wv = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+  const int wv = bidx * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
   const int wcol = wv % nWaveCols, wrow = wv / nWaveCols;
   const int gx = ((wcol << tpcShift) + (lane & ((1 << tpcShift) - 1))) * 8;           // first sample of this thread
   const int gy = (wrow * (64 >> tpcShift) + (lane >> tpcShift)) * SAO_ROWS;           // first row
@@ -150,6 +150,27 @@ __global__ __launch_bounds__(256) void sao_apply_kernel(const Pel* __restrict__ 
   }
 }
 
+__global__ __launch_bounds__(256) void sao_apply_kernel(const Pel* __restrict__ src, int sstride, Pel* __restrict__ dst, int dstride, int w, int h,
+                                                        int ctuW, int ctuH, int wCtu, int boShift, const vvcgpu_sao_ctu* __restrict__ params,
+                                                        int clpMin, int clpMax, int tpcShift, int nWaveCols)
+{
+  sao_apply_body((int)blockIdx.x, src, sstride, dst, dstride, w, h, ctuW, ctuH, wCtu, boShift, params, clpMin, clpMax, tpcShift, nWaveCols);
+}
+
+// the three planes of a picture in one launch (a chroma plane alone is ~1 workgroup per CU: its own launch costs a latency floor)
+struct SaoPlaneArgs { const Pel* src; Pel* dst; const vvcgpu_sao_ctu* params; int sstride, dstride, w, h, ctuW, ctuH, wCtu, tpcShift, nWaveCols, wgEnd; };
+struct SaoApply3 { SaoPlaneArgs a[3]; int boShift, clpMin, clpMax; };
+__global__ __launch_bounds__(256) void sao_apply_picture_kernel(SaoApply3 p)
+{
+  const int b = blockIdx.x;
+  const int c = b < p.a[0].wgEnd ? 0 : b < p.a[1].wgEnd ? 1 : 2;
+  const SaoPlaneArgs& a = c == 0 ? p.a[0] : c == 1 ? p.a[1] : p.a[2];
+  const int first = c == 0 ? 0 : c == 1 ? p.a[0].wgEnd : p.a[1].wgEnd;
+  sao_apply_body(b - first, a.src, a.sstride, a.dst, a.dstride, a.w, a.h, a.ctuW, a.ctuH, a.wCtu, p.boShift, a.params, p.clpMin, p.clpMax, a.tpcShift,
+                 a.nWaveCols);
+}
+
+
 }  // namespace
 
 extern "C" int vvcgpu_sao_apply(const vvc_pel* src, int src_stride, vvc_pel* dst, int dst_stride,
@@ -169,6 +190,33 @@ extern "C" int vvcgpu_sao_apply(const vvc_pel* src, int src_stride, vvc_pel* dst
   hipLaunchKernelGGL(sao_apply_kernel, dim3(cdiv(nWaveCols * nWaveRows, 4)), dim3(256), 0, (hipStream_t)stream, src, src_stride, dst,
                      dst_stride, width, height, ctu_w, ctu_h, cdiv(width, ctu_w), bit_depth - 5, params, clp_min, clp_max, tpcShift,
                      nWaveCols);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+extern "C" int vvcgpu_sao_apply_picture(const vvcgpu_planes* src, const vvcgpu_planes* dst, int width, int height, int ctu_size, int bit_depth,
+                                        const vvcgpu_sao_ctu* params_y, const vvcgpu_sao_ctu* params_cb, const vvcgpu_sao_ctu* params_cr,
+                                        int clp_min, int clp_max, void* stream)
+{
+  VVC_CHECK_ARG(src && dst && params_y && params_cb && params_cr, "sao_apply_picture: null pointer");
+  VVC_CHECK_ARG(width > 0 && height > 0 && (width & 1) == 0 && (height & 1) == 0, "sao_apply_picture: bad size %dx%d", width, height);
+  VVC_CHECK_ARG(ctu_size >= 16 && (ctu_size & 15) == 0, "sao_apply_picture: CTU size %d", ctu_size);
+  VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "sao_apply_picture: bit depth %d outside 8..10", bit_depth);
+  SaoApply3 p;
+  const vvcgpu_sao_ctu* prm[3] = { params_y, params_cb, params_cr };
+  int end = 0;
+  for (int c = 0; c < 3; c++)
+  {
+    const int w = c ? width >> 1 : width, h = c ? height >> 1 : height, ctu = c ? ctu_size >> 1 : ctu_size;
+    VVC_CHECK_ARG(src->p[c] && dst->p[c] && src->p[c] != dst->p[c] && src->stride[c] >= w && dst->stride[c] >= w, "sao_apply_picture: plane %d", c);
+    int tpcShift = 6;
+    if ((ctu & (ctu - 1)) == 0 && ctu <= 512) { tpcShift = 0; while ((8 << tpcShift) < ctu) tpcShift++; }
+    const int nWaveCols = cdiv(w, 8 << tpcShift), nWaveRows = cdiv(h, (64 >> tpcShift) * SAO_ROWS);
+    end += cdiv(nWaveCols * nWaveRows, 4);
+    p.a[c] = SaoPlaneArgs{ src->p[c], dst->p[c], prm[c], src->stride[c], dst->stride[c], w, h, ctu, ctu, cdiv(w, ctu), tpcShift, nWaveCols, end };
+  }
+  p.boShift = bit_depth - 5; p.clpMin = clp_min; p.clpMax = clp_max;
+  hipLaunchKernelGGL(sao_apply_picture_kernel, dim3(end), dim3(256), 0, (hipStream_t)stream, p);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

@@ -16,7 +16,7 @@ namespace {
 // =====================================================================================================
 constexpr int SAO_MAX_CTU = 128;
 
-__global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ org, int ostride,
+__device__ __forceinline__ void sao_stats_body(const int cx, const int cy, const int nthreads, const Pel* __restrict__ org, int ostride,
                                                         const Pel* __restrict__ rec, int rstride, int w, int h,
                                                         int ctuW, int ctuH, int wCtu, int boShift,
                                                         const uint8_t* __restrict__ availMap, int skipR, int skipB,
@@ -26,21 +26,20 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ 
   const int pitch = ctuW + 2;
   short* tile = reinterpret_cast<short*>(smem);                                   // (ctuH+2) x pitch
   const int tileBytes = ((ctuH + 2) * pitch * 2 + 15) & ~15;
-  unsigned long long* bo = reinterpret_cast<unsigned long long*>(smem + tileBytes);   // 8 replicas x 32 packed bands (same-band atomics serialise)
-  int* eo = reinterpret_cast<int*>(smem + tileBytes + 8 * 32 * 8);                    // [4][5][2]
+  unsigned long long* bo = reinterpret_cast<unsigned long long*>(smem + tileBytes);   // 16 replicas x 32 packed bands (same-band atomics serialise)
+  int* eo = reinterpret_cast<int*>(smem + tileBytes + 16 * 32 * 8);                   // [4][5][2]
 
   const int tid = threadIdx.x;
-  const int cx = blockIdx.x, cy = blockIdx.y;
   const int x0 = cx * ctuW, y0 = cy * ctuH;
   const int width = min(ctuW, w - x0), height = min(ctuH, h - y0);
 
-  for (int i = tid; i < (ctuH + 2) * pitch; i += 256)
+  for (int i = tid; i < (ctuH + 2) * pitch; i += nthreads)
   {
     const int r = i / pitch, c = i - r * pitch;
     const int y = min(max(y0 + r - 1, 0), h - 1), x = min(max(x0 + c - 1, 0), w - 1);
     tile[i] = rec[(size_t)y * rstride + x];
   }
-  bo[tid] = 0ull;                                                                      // 256 threads = 8 x 32
+  for (int i = tid; i < 16 * 32; i += nthreads) bo[i] = 0ull;
   if (tid < 40) eo[tid] = 0;
   __syncthreads();
 
@@ -53,7 +52,7 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ 
   const int endYd = below ? height - skipB : height - 1;         // EO_90/135/45
   const int startY90 = above ? 0 : 1;
 
-  const int groups = 256 / ctuW;
+  const int groups = nthreads / ctuW;
   const int rpg = ctuH / groups;
   const int x = tid % ctuW, g = tid / ctuW;
   // per (EO class, category) one packed accumulator: count in bits 20.., sum of (d + 1024) below (a thread walks <= 64 rows:
@@ -97,7 +96,7 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ 
         for (int k = 0; k < 5; k++) acc[t][k] += e[t] == k ? vt : 0u;
       }
       if (inX90 && y < endY0)
-        atomicAdd(&bo[(tid & 7) * 32 + (c >> boShift)], (1ull << 32) + (unsigned long long)(d + 1024));
+        atomicAdd(&bo[(tid & 15) * 32 + (c >> boShift)], (1ull << 32) + (unsigned long long)(d + 1024));
 #pragma unroll
       for (int k = 0; k < 3; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
     }
@@ -115,7 +114,7 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ 
     }
   __syncthreads();
   long long* o = out + (size_t)(cy * wCtu + cx) * 320;
-  for (int i = tid; i < 320; i += 256)
+  for (int i = tid; i < 320; i += nthreads)
   {
     const int t = i >> 6, isCount = (i >> 5) & 1, k = i & 31;
     long long v = 0;
@@ -123,13 +122,36 @@ __global__ __launch_bounds__(256) void sao_stats_kernel(const Pel* __restrict__ 
     else
     {
       unsigned long long pk = 0ull;
-      for (int r = 0; r < 8; r++) pk += bo[r * 32 + k];
+      for (int r = 0; r < 16; r++) pk += bo[r * 32 + k];
       const long long c = (long long)(pk >> 32);
       v = isCount ? c : (long long)(pk & 0xffffffffull) - 1024 * c;
     }
     o[i] = v;
   }
 }
+
+// one plane per launch (vvcgpu_sao_stats): 1024 threads per CTU -- a thread walks 16 rows of a 128 x 128 CTU instead of 64 (the row walk is
+// the critical path of the workgroup and a 4K picture has only 510 luma CTUs for 256 CUs)
+__global__ __launch_bounds__(1024) void sao_stats_kernel(const Pel* __restrict__ org, int ostride, const Pel* __restrict__ rec, int rstride, int w, int h,
+                                                         int ctuW, int ctuH, int wCtu, int boShift, const uint8_t* __restrict__ availMap, int skipR,
+                                                         int skipB, long long* __restrict__ out)
+{
+  sao_stats_body((int)blockIdx.x, (int)blockIdx.y, (int)blockDim.x, org, ostride, rec, rstride, w, h, ctuW, ctuH, wCtu, boShift, availMap, skipR, skipB, out);
+}
+
+// the three planes of a picture in one launch
+struct SaoStatsPlane { const Pel* org; const Pel* rec; long long* out; int ostride, rstride, w, h, ctu, wCtu, skipR, skipB, wgEnd; };
+struct SaoStats3 { SaoStatsPlane a[3]; const uint8_t* avail; int boShift; };
+__global__ __launch_bounds__(1024) void sao_stats_picture_kernel(SaoStats3 p)
+{
+  const int b = blockIdx.x;
+  const int c = b < p.a[0].wgEnd ? 0 : b < p.a[1].wgEnd ? 1 : 2;
+  const SaoStatsPlane& a = c == 0 ? p.a[0] : c == 1 ? p.a[1] : p.a[2];
+  const int r = b - (c == 0 ? 0 : c == 1 ? p.a[0].wgEnd : p.a[1].wgEnd);
+  sao_stats_body(r % a.wCtu, r / a.wCtu, (int)blockDim.x, a.org, a.ostride, a.rec, a.rstride, a.w, a.h, a.ctu, a.ctu, a.wCtu, p.boShift, p.avail, a.skipR,
+                 a.skipB, a.out);
+}
+
 
 // =====================================================================================================
 // A3: ALF covariance.  One workgroup per 64x64 tile (256 blocks of 4x4, one per thread): the rec tile with a
@@ -190,7 +212,7 @@ __device__ __forceinline__ constexpr int tapIndexS(int dy, int dx)
 }
 
 template <bool IS7>
-__global__ __launch_bounds__(256) void alf_stats_kernel(const Pel* __restrict__ org, int ostride,
+__device__ __forceinline__ void alf_stats_body(const int bidx, const int bidy, const Pel* __restrict__ org, int ostride,
                                                         const Pel* __restrict__ rec, int rstride, int w, int h,
                                                         int ctu, int wCtu, const uint16_t* __restrict__ cls,
                                                         int nCls, unsigned long long* __restrict__ out)
@@ -205,7 +227,7 @@ __global__ __launch_bounds__(256) void alf_stats_kernel(const Pel* __restrict__ 
   constexpr int REP = IS7 ? 2 : 4;              // 7x7: 2 x 21 KB keeps two workgroups per CU
   __shared__ unsigned long long bucket[REP * 25 * NB];
   const int tid = threadIdx.x;
-  const int tx0 = blockIdx.x * AT, ty0 = blockIdx.y * AT;
+  const int tx0 = bidx * AT, ty0 = bidy * AT;
   load_tile_clamped<AP>(tile, rec, rstride, w, h, tx0 - 4, ty0 - 3, AR, tid, 256);
   for (int i = tid; i < REP * 25 * NB; i += 256) bucket[i] = 0ull;
   __syncthreads();
@@ -335,6 +357,48 @@ __global__ __launch_bounds__(256) void alf_stats_kernel(const Pel* __restrict__ 
   }
 }
 
+template <bool IS7>
+__global__ __launch_bounds__(256) void alf_stats_kernel(const Pel* __restrict__ org, int ostride, const Pel* __restrict__ rec, int rstride, int w, int h,
+                                                        int ctu, int wCtu, const uint16_t* __restrict__ cls, int nCls, unsigned long long* __restrict__ out)
+{
+  alf_stats_body<IS7>((int)blockIdx.x, (int)blockIdx.y, org, ostride, rec, rstride, w, h, ctu, wCtu, cls, nCls, out);
+}
+
+// both chroma planes (5x5, no classifier) in one launch: blockIdx.z selects the plane
+__global__ __launch_bounds__(256) void alf_stats_chroma2_kernel(const Pel* __restrict__ orgCb, const Pel* __restrict__ orgCr, int ostride,
+                                                                const Pel* __restrict__ recCb, const Pel* __restrict__ recCr, int rstride, int w, int h,
+                                                                int ctu, int wCtu, unsigned long long* __restrict__ outCb, unsigned long long* __restrict__ outCr)
+{
+  const bool cr = blockIdx.z != 0;
+  alf_stats_body<false>((int)blockIdx.x, (int)blockIdx.y, cr ? orgCr : orgCb, ostride, cr ? recCr : recCb, rstride, w, h, ctu, wCtu, nullptr, 1, cr ? outCr : outCb);
+}
+
+// The 5x5 diamond is the centre of the 7x7 diamond under every transposition, so the 5x5 covariance record of a class is a sub-matrix of its 7x7
+// record: coefficient i of the 5x5 filter is coefficient SIG[i] of the 7x7 filter (tap (2,0) -> 2, (1,1) -> 5, (1,0) -> 6, (1,-1) -> 7, (0,2) -> 10,
+// (0,1) -> 11, centre -> 12).  One thread per output entry; also zeroes nothing: every entry of out5 is written.
+__global__ __launch_bounds__(256) void alf_stats_5from7_kernel(const unsigned long long* __restrict__ out7, unsigned long long* __restrict__ out5, int nRecords)
+{
+  const int gid = blockIdx.x * 256 + threadIdx.x;
+  if (gid >= nRecords * 57) return;
+  const int rec = gid / 57, e = gid - rec * 57;
+  const int sig[7] = { 2, 5, 6, 7, 10, 11, 12 };
+  const unsigned long long* r7 = out7 + (size_t)rec * 183;
+  unsigned long long v;
+  if (e < 49) v = r7[sig[e / 7] * 13 + sig[e % 7]];
+  else if (e < 56) v = r7[169 + sig[e - 49]];
+  else v = r7[182];
+  out5[gid] = v;
+}
+
+__global__ __launch_bounds__(256) void zero3_kernel(unsigned long long* a, size_t na, unsigned long long* b, size_t nb, unsigned long long* c, size_t nc)
+{
+  const size_t gid = (size_t)blockIdx.x * 256 + threadIdx.x, stride = (size_t)gridDim.x * 256;
+  for (size_t i = gid; i < na; i += stride) a[i] = 0ull;
+  for (size_t i = gid; i < nb; i += stride) b[i] = 0ull;
+  for (size_t i = gid; i < nc; i += stride) c[i] = 0ull;
+}
+
+
 }  // namespace
 
 extern "C" {
@@ -351,8 +415,12 @@ int vvcgpu_sao_stats(const vvc_pel* org, int org_stride, const vvc_pel* rec, int
   VVC_CHECK_ARG(skip_lines_r >= 0 && skip_lines_b >= 0 && skip_lines_r < 16 && skip_lines_b < 16, "sao_stats: bad skip lines");
   const int wCtu = cdiv(width, ctu_w), hCtu = cdiv(height, ctu_h);
   const size_t tileBytes = (((size_t)(ctu_h + 2) * (ctu_w + 2) * 2) + 15) & ~(size_t)15;
-  const size_t smem = tileBytes + 8 * 32 * 8 + 40 * 4;
-  hipLaunchKernelGGL(sao_stats_kernel, dim3(wCtu, hCtu), dim3(256), smem, (hipStream_t)stream, org, org_stride, rec,
+  const size_t smem = tileBytes + 16 * 32 * 8 + 40 * 4;
+  if (smem > 48 * 1024)
+    VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sao_stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  int nthreads = 1024;                                       // groups = nthreads / ctu_w row groups of ctu_h / groups rows: keep >= 4 rows per thread
+  while (nthreads > 256 && (nthreads / ctu_w) * 4 > ctu_h) nthreads >>= 1;
+  hipLaunchKernelGGL(sao_stats_kernel, dim3(wCtu, hCtu), dim3(nthreads), smem, (hipStream_t)stream, org, org_stride, rec,
                      rec_stride, width, height, ctu_w, ctu_h, wCtu, bit_depth - 5, avail, skip_lines_r, skip_lines_b,
                      reinterpret_cast<long long*>(out));
   VVC_LAUNCH_CHECK();
@@ -381,6 +449,69 @@ int vvcgpu_alf_stats(const vvc_pel* org, int org_stride, const vvc_pel* rec, int
   else
     hipLaunchKernelGGL(alf_stats_kernel<false>, grid, dim3(256), 0, st, org, org_stride, rec, rec_stride, width, height,
                        ctu_size, wCtu, cls, nCls, reinterpret_cast<unsigned long long*>(out));
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+int vvcgpu_sao_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec, int width, int height, int ctu_size, int bit_depth,
+                             const uint8_t* avail, int skip_r_luma, int skip_b_luma, int skip_r_chroma, int skip_b_chroma,
+                             int64_t* out_y, int64_t* out_cb, int64_t* out_cr, void* stream)
+{
+  VVC_CHECK_ARG(org && rec && out_y && out_cb && out_cr, "sao_stats_picture: null pointer");
+  VVC_CHECK_ARG(width > 0 && height > 0 && (width & 1) == 0 && (height & 1) == 0, "sao_stats_picture: bad size %dx%d", width, height);
+  VVC_CHECK_ARG(ctu_size >= 32 && ctu_size <= SAO_MAX_CTU && (ctu_size & (ctu_size - 1)) == 0, "sao_stats_picture: CTU size %d must be 32, 64 or 128", ctu_size);
+  VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "sao_stats_picture: bit depth %d outside 8..10", bit_depth);
+  VVC_CHECK_ARG(skip_r_luma >= 0 && skip_b_luma >= 0 && skip_r_luma < 16 && skip_b_luma < 16 && skip_r_chroma >= 0 && skip_b_chroma >= 0 &&
+                skip_r_chroma < 16 && skip_b_chroma < 16, "sao_stats_picture: bad skip lines");
+  SaoStats3 p;
+  int64_t* outs[3] = { out_y, out_cb, out_cr };
+  int end = 0;
+  for (int c = 0; c < 3; c++)
+  {
+    const int w = c ? width >> 1 : width, h = c ? height >> 1 : height, ctu = c ? ctu_size >> 1 : ctu_size;
+    VVC_CHECK_ARG(org->p[c] && rec->p[c] && org->stride[c] >= w && rec->stride[c] >= w, "sao_stats_picture: plane %d", c);
+    const int wCtu = cdiv(w, ctu), hCtu = cdiv(h, ctu);
+    end += wCtu * hCtu;
+    p.a[c] = SaoStatsPlane{ org->p[c], rec->p[c], reinterpret_cast<long long*>(outs[c]), org->stride[c], rec->stride[c], w, h, ctu, wCtu,
+                            c ? skip_r_chroma : skip_r_luma, c ? skip_b_chroma : skip_b_luma, end };
+  }
+  p.avail = avail; p.boShift = bit_depth - 5;
+  // workgroup size: the chroma CTU (ctu / 2 wide) sets the row groups; every thread keeps at least two rows
+  int nthreads = 1024;
+  while (nthreads > 256 && (nthreads / (ctu_size >> 1)) * 2 > (ctu_size >> 1)) nthreads >>= 1;
+  const size_t tileBytes = (((size_t)(ctu_size + 2) * (ctu_size + 2) * 2) + 15) & ~(size_t)15;
+  const size_t smem = tileBytes + 16 * 32 * 8 + 40 * 4;
+  if (smem > 48 * 1024)
+    VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sao_stats_picture_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  hipLaunchKernelGGL(sao_stats_picture_kernel, dim3(end), dim3(nthreads), smem, (hipStream_t)stream, p);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+int vvcgpu_alf_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec, int width, int height, int ctu_size, const uint16_t* cls,
+                             int64_t* out7, int64_t* out5, int64_t* out_cb, int64_t* out_cr, void* stream)
+{
+  VVC_CHECK_ARG(org && rec && cls && out7 && out5 && out_cb && out_cr, "alf_stats_picture: null pointer");
+  VVC_CHECK_ARG(width > 0 && height > 0 && (width & 7) == 0 && (height & 7) == 0, "alf_stats_picture: size must be a multiple of 8");
+  VVC_CHECK_ARG(ctu_size >= 2 * AT && (ctu_size % (2 * AT)) == 0, "alf_stats_picture: ctu size %d must be a multiple of %d", ctu_size, 2 * AT);
+  for (int c = 0; c < 3; c++)
+  {
+    const int w = c ? width >> 1 : width;
+    VVC_CHECK_ARG(org->p[c] && rec->p[c] && org->stride[c] >= w && rec->stride[c] >= w && (org->stride[c] & 3) == 0 && ((uintptr_t)org->p[c] & 7) == 0,
+                  "alf_stats_picture: plane %d (org needs stride %% 4 == 0 and 8-byte alignment)", c);
+  }
+  VVC_CHECK_ARG(org->stride[1] == org->stride[2] && rec->stride[1] == rec->stride[2], "alf_stats_picture: Cb and Cr strides must match");
+  hipStream_t st = (hipStream_t)stream;
+  const int wCtu = cdiv(width, ctu_size), hCtu = cdiv(height, ctu_size), nCtu = wCtu * hCtu;
+  unsigned long long* o7 = reinterpret_cast<unsigned long long*>(out7);
+  unsigned long long* ocb = reinterpret_cast<unsigned long long*>(out_cb);
+  unsigned long long* ocr = reinterpret_cast<unsigned long long*>(out_cr);
+  hipLaunchKernelGGL(zero3_kernel, dim3(512), dim3(256), 0, st, o7, (size_t)nCtu * 25 * 183, ocb, (size_t)nCtu * 57, ocr, (size_t)nCtu * 57);
+  hipLaunchKernelGGL(alf_stats_kernel<true>, dim3(cdiv(width, AT), cdiv(height, AT)), dim3(256), 0, st, org->p[0], org->stride[0], rec->p[0], rec->stride[0],
+                     width, height, ctu_size, wCtu, cls, 25, o7);
+  hipLaunchKernelGGL(alf_stats_chroma2_kernel, dim3(cdiv(width >> 1, AT), cdiv(height >> 1, AT), 2), dim3(256), 0, st, org->p[1], org->p[2], org->stride[1],
+                     rec->p[1], rec->p[2], rec->stride[1], width >> 1, height >> 1, ctu_size >> 1, wCtu, ocb, ocr);
+  hipLaunchKernelGGL(alf_stats_5from7_kernel, dim3(cdiv(nCtu * 25 * 57, 256)), dim3(256), 0, st, o7, reinterpret_cast<unsigned long long*>(out5), nCtu * 25);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

@@ -437,3 +437,59 @@ def resi_chain_batch(org_base, pred_base, rec_base, level_base, descs_dev, n, bi
     capi.call("vvcgpu_resi_chain_batch", capi.ptr(org_base), capi.ptr(pred_base), capi.ptr(rec_base), capi.ptr(level_base), capi.ptr(descs_dev), n,
               bit_depth, clp[0], clp[1], capi.ptr(out), _stream())
     return out
+
+
+# ---- picture-level forms of the in-loop entry points (three planes, one launch each) ------------------------
+class Planes(C.Structure):
+    """vvcgpu_planes"""
+    _fields_ = [("p", C.c_void_p * 3), ("stride", C.c_int32 * 3)]
+
+
+def planes(ts):
+    """three 2-D int16 CUDA tensors (Y, Cb, Cr) -> vvcgpu_planes"""
+    pl = Planes()
+    for i, t in enumerate(ts):
+        assert t.is_cuda and t.dtype == torch.int16 and t.dim() == 2 and t.stride(1) == 1
+        pl.p[i] = t.data_ptr()
+        pl.stride[i] = t.stride(0)
+    return pl
+
+
+def sao_apply_picture(src, dst, ctu, bit_depth, params_dev, clp=(0, 1023)):
+    h, w = src[0].shape
+    capi.call("vvcgpu_sao_apply_picture", C.byref(planes(src)), C.byref(planes(dst)), w, h, ctu, bit_depth, capi.ptr(params_dev[0]),
+              capi.ptr(params_dev[1]), capi.ptr(params_dev[2]), clp[0], clp[1], _stream())
+    return dst
+
+
+def sao_stats_picture(org, rec, ctu, bit_depth, avail=None, skip_luma=(5, 4), skip_chroma=(3, 2)):
+    """-> [int64 tensor (nCtu, 5, 2, 32)] x 3"""
+    h, w = org[0].shape
+    n = ((w + ctu - 1) // ctu) * ((h + ctu - 1) // ctu)
+    outs = [torch.empty((n, 5, 2, 32), dtype=torch.int64, device=org[0].device) for _ in range(3)]
+    capi.call("vvcgpu_sao_stats_picture", C.byref(planes(org)), C.byref(planes(rec)), w, h, ctu, bit_depth, capi.ptr(avail), skip_luma[0], skip_luma[1],
+              skip_chroma[0], skip_chroma[1], capi.ptr(outs[0]), capi.ptr(outs[1]), capi.ptr(outs[2]), _stream())
+    return outs
+
+
+def alf_filter_picture(src, dst, ctu, cls, filter_type, luma_coeff, chroma_coeff, enable=(None, None, None), clp=(0, 1023)):
+    h, w = src[0].shape
+    lc = np.ascontiguousarray(luma_coeff, dtype=np.int16)
+    cc = np.ascontiguousarray(chroma_coeff, dtype=np.int16)
+    assert lc.size == 25 * 13 and cc.size == 7
+    capi.call("vvcgpu_alf_filter_picture", C.byref(planes(src)), C.byref(planes(dst)), w, h, ctu, capi.ptr(cls), filter_type,
+              C.c_void_p(lc.ctypes.data), C.c_void_p(cc.ctypes.data), capi.ptr(enable[0]), capi.ptr(enable[1]), capi.ptr(enable[2]), clp[0], clp[1], _stream())
+    return dst
+
+
+def alf_stats_picture(org, rec, ctu, cls):
+    """-> (luma 7x7 (nCtu, 25, 183), luma 5x5 (nCtu, 25, 57), [Cb (nCtu, 1, 57), Cr (nCtu, 1, 57)]) int64 tensors"""
+    h, w = org[0].shape
+    n = ((w + ctu - 1) // ctu) * ((h + ctu - 1) // ctu)
+    dev = org[0].device
+    a7 = torch.empty((n, 25, 183), dtype=torch.int64, device=dev)
+    a5 = torch.empty((n, 25, 57), dtype=torch.int64, device=dev)
+    ac = [torch.empty((n, 1, 57), dtype=torch.int64, device=dev) for _ in range(2)]
+    capi.call("vvcgpu_alf_stats_picture", C.byref(planes(org)), C.byref(planes(rec)), w, h, ctu, capi.ptr(cls), capi.ptr(a7), capi.ptr(a5),
+              capi.ptr(ac[0]), capi.ptr(ac[1]), _stream())
+    return a7, a5, ac

@@ -446,17 +446,12 @@ class Workload:
         with T("dbk/deblock"):
             ops.deblock(st["rec"][0], st["rec"][1], st["rec"][2], st["edge_ver"], st["edge_hor"], st["qp_luma"], st["qp_chroma"], dcfg)
         e_dbk = mark()
-        # ---- SAO (the statistics only read the deblocked picture: side stream 2)
-        sao_stats = []
+        # ---- SAO (the statistics only read the deblocked picture: side stream 2); picture-level entry points: three planes per launch
         with _On(side[2], e_dbk):
             with T("sao/sao_stats"):
-                for c in range(3):
-                    cs = CTU if c == 0 else CTU // 2
-                    sao_stats.append(ops.sao_stats(st["org"][c], st["rec"][c], cs, cs, bd, None, 5 if c == 0 else 3, 4 if c == 0 else 2))
+                sao_stats = ops.sao_stats_picture(st["org"], st["rec"], CTU, bd)
         with T("sao/sao_apply"):
-            for c in range(3):
-                cs = CTU if c == 0 else CTU // 2
-                ops.sao_apply(st["rec"][c], st["sao_out"][c], cs, cs, bd, st["sao"][c], (0, mx))
+            ops.sao_apply_picture(st["rec"], st["sao_out"], CTU, bd, st["sao"], (0, mx))
         out["sao_stats"] = sao_stats
         # ---- ALF (the covariances read the SAO output and the classifier: side stream 2)
         with T("alf/alf_classify"):
@@ -464,13 +459,9 @@ class Workload:
         e_cls = mark()
         with _On(side[2], e_cls):
             with T("alf/alf_stats"):
-                a7 = ops.alf_stats(st["org"][0], st["sao_out"][0], CTU, cls, 1)
-                a5 = ops.alf_stats(st["org"][0], st["sao_out"][0], CTU, cls, 0)
-                ac = [ops.alf_stats(st["org"][c], st["sao_out"][c], CTU // 2, None, 0) for c in (1, 2)]
+                a7, a5, ac = ops.alf_stats_picture(st["org"], st["sao_out"], CTU, cls)
         with T("alf/alf_filter"):
-            ops.alf_filter_luma(st["sao_out"][0], st["alf_out"][0], CTU, cls, 1, self.alf_luma_coeff, st["alf_en"][0], (0, mx))
-            for c in (1, 2):
-                ops.alf_filter_chroma(st["sao_out"][c], st["alf_out"][c], CTU // 2, self.alf_chroma_coeff, st["alf_en"][c], (0, mx))
+            ops.alf_filter_picture(st["sao_out"], st["alf_out"], CTU, cls, 1, self.alf_luma_coeff, self.alf_chroma_coeff, st["alf_en"], (0, mx))
         if overlap:                                 # join: the step is complete (and its buffers reusable) when `main` is
             for sd in side:
                 e = torch.cuda.Event()
