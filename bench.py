@@ -241,12 +241,18 @@ def main():
     warm = {k: v for k, v in warm.items() if k.split('/')[1] in alg.get(k.split('/')[0], {})}
     timer.only = max(warm, key=warm.get)
     timer.ev, timer.on = {}, False
+    # the overlapped schedule launches ONE search group first and alone: make it the dominant one when that is a search, so that its
+    # event-timed duration in the timed region is a kernel time (any other dominant group is quoted from the serial pass below)
+    alone = None
+    if timer.only.startswith("me/sad_search_"):
+        sz, grid = timer.only[len("me/sad_search_"):].split("_")
+        alone = (int(sz.split("x")[0]), 0 if grid == "9x9" else 1)
 
     def one_step(tm):
         """one intra period: pps pictures, then the chunk hand-over (next rank's reference picture; own picture at N = 1)"""
         nonlocal state, out
         for _ in range(pps):
-            state, out = wl.run_gpu(state, tm, overlap=overlap)
+            state, out = wl.run_gpu(state, tm, overlap=overlap, alone=alone)
         boundary = shard.exchange_boundary(out["final"], rank, world)
         shard.install_reference(boundary, state["ref1"], wl.margins())
 
@@ -283,7 +289,10 @@ def main():
         state, out = wl.run_gpu(state, timer, overlap=False)
     torch.cuda.synchronize()
     kern_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in timer.ev.items()}
-    kern_ms.update(timed_ms)
+    if alone is not None or args.serial:
+        kern_ms.update(timed_ms)                          # measured over the timed region, launched alone
+    else:
+        n_timed = {}                                      # dominant group runs beside other kernels in the overlapped schedule: serial-pass time
     stage_ms = {}
     for k, v in kern_ms.items():
         stage_ms[k.split("/")[0]] = stage_ms.get(k.split("/")[0], 0.0) + v

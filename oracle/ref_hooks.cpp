@@ -27,7 +27,15 @@
 // the fractional motion refinement, called from xMotionEstimation in its own translation unit (InterSearch.cpp:1816)
 #define FRAC_SYM "_ZN11InterSearch21xPatternSearchFracDIFERK14PredictionUnit10RefPicListiRNS_17IntTZSearchStructERK2MvRS6_S9_Rm"
 
+// the two deblocking sample filters, called per CU edge from LoopFilter::xDeblockCU in their own translation unit (LoopFilter.cpp:340-347)
+#define EFL_SYM "_ZN10LoopFilter15xEdgeFilterLumaERK10CodingUnit14DeblockEdgeDiri"
+#define EFC_SYM "_ZN10LoopFilter17xEdgeFilterChromaERK10CodingUnit14DeblockEdgeDiri"
+
 extern "C" {
+typedef void (*ef_real_t)(void*, const void*, int, int);
+typedef int (*ef_shim_t)(void*, const void*, int, int, int);
+void hook_edge_luma(void* self, const void* cu, int dir, int edge) asm(EFL_SYM);
+void hook_edge_chroma(void* self, const void* cu, int dir, int edge) asm(EFC_SYM);
 typedef void (*sao_real_t)(void*, void*, void*, void*, void*, bool);
 typedef int (*sao_shim_t)(void*, void*, void*, void*, void*, bool);
 typedef void (*alf_real_t)(void*, void*, void*);
@@ -63,6 +71,21 @@ static void* g_target = nullptr;                 // dlopen handle of libvtmref_h
 void vtmhooks_set_target(void* handle) { g_target = handle; }
 static void* must(void* p, const char* what) { if (!p) { fprintf(stderr, "ref_hooks: %s not found\n", what); abort(); } return p; }
 
+// (1 = the shim recorded the edge for the device-side filter, 0 = run the reference's own sample filter)
+void hook_edge_luma(void* self, const void* cu, int dir, int edge)
+{
+  static ef_shim_t shim = (ef_shim_t)dlsym(RTLD_DEFAULT, "vvcshim_edge_filter");
+  static ef_real_t real = (ef_real_t)must(g_target ? dlsym(g_target, EFL_SYM) : nullptr, EFL_SYM);
+  if (shim && shim(self, cu, dir, edge, 0)) return;
+  real(self, cu, dir, edge);
+}
+void hook_edge_chroma(void* self, const void* cu, int dir, int edge)
+{
+  static ef_shim_t shim = (ef_shim_t)dlsym(RTLD_DEFAULT, "vvcshim_edge_filter");
+  static ef_real_t real = (ef_real_t)must(g_target ? dlsym(g_target, EFC_SYM) : nullptr, EFC_SYM);
+  if (shim && shim(self, cu, dir, edge, 1)) return;
+  real(self, cu, dir, edge);
+}
 void hook_sao_stats(void* self, void* blkStats, void* org, void* src, void* cs, bool pre)
 {
   static sao_shim_t shim = (sao_shim_t)dlsym(RTLD_DEFAULT, "vvcshim_sao_stats");

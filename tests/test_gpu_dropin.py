@@ -124,5 +124,34 @@ def test_encoder_with_gpu_inloop_is_bitstream_exact(tmp_path, name):
     if m.get("hash", 1) != 1:
         assert calls[23] >= m["frames"], line[-1]   # the hash SEI payload itself was computed by vvcgpu_picture_hash
     print(line[-1])
+    # production form of the picture-level binding: the reconstruction goes up once per picture (after CTU coding), the original once (for the
+    # SAO / ALF statistics), and the filtered picture comes down once, however many stages ran in between
+    res = [l for l in r.stderr.splitlines() if "[vvcgpu resident]" in l]
+    assert res and "resident form on" in res[-1], r.stderr[-1000:]
+    pics, ups, downs = [int(x) for x in res[-1].replace(",", " ").replace("(", " ").split() if x.isdigit()][:3]
+    assert pics == m["frames"] and downs == m["frames"] and ups <= 2 * m["frames"], res[-1]
+    print(res[-1])
     if name.startswith("ai_"):
         assert calls[6] > 0, line[-1]          # on this clip the encoder enables ALF: the filter table slots ran
+
+
+@needs_ref
+def test_encoder_per_call_form_still_exact(tmp_path):
+    """VVCGPU_SHIM_RESIDENT=0: every picture-level hook uploads and downloads the picture itself (the round-1 proof form) -- same bitstream"""
+    sys.path.insert(0, ROOT)
+    from vvcsoftware_vtm_amd import synth
+    name = "ai_416x240_8b_q37own"
+    m = manifest()[name]
+    yuv = str(tmp_path / "in.yuv")
+    synth.write_yuv(yuv, synth.gen_yuv(m["w"], m["h"], m["frames"], m["bd"], m["seed"]), m["bd"])
+    cfg = os.path.join(ROOT, m["cfg"][1:])
+    binf = str(tmp_path / "out.bin")
+    r = subprocess.run([APP, "--hip", "enc", "-c", cfg, "-i", yuv, "-wdt", str(m["w"]), "-hgt", str(m["h"]), "-fr", "30",
+                        "-f", str(m["frames"]), "-q", str(m["qp"]), "--InputBitDepth=%d" % m["bd"], "--InternalBitDepth=%d" % m["bd"],
+                        "--OutputBitDepth=%d" % m["bd"], "-b", binf, "-o", str(tmp_path / "rec.yuv"), "--SEIDecodedPictureHash=%d" % m.get("hash", 1)] + m.get("extra", []),
+                       capture_output=True, text=True, timeout=1200, env=dict(os.environ, VVCGPU_SHIM_RESIDENT="0", VVCGPU_SHIM_NO_TABLES="1"))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert md5(binf) == m["bin_md5"]
+    res = [l for l in r.stderr.splitlines() if "[vvcgpu resident]" in l]
+    assert res and "resident form off" in res[-1]
+

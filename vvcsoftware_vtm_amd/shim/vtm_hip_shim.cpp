@@ -47,6 +47,15 @@ void wrap_SAOProcess(SampleAdaptiveOffset*, CodingStructure&, SAOBlkParam*) asm(
 void real_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) asm("__real__ZN18AdaptiveLoopFilter10ALFProcessER15CodingStructureR13AlfSliceParam");
 void wrap_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) asm("__wrap__ZN18AdaptiveLoopFilter10ALFProcessER15CodingStructureR13AlfSliceParam");
 
+void real_EncSAOProcess(EncSampleAdaptiveOffset*, CodingStructure&, bool*, const double*, const bool, const double, const double, bool, bool)
+  asm("__real__ZN23EncSampleAdaptiveOffset10SAOProcessER15CodingStructurePbPKdbddbb");
+void wrap_EncSAOProcess(EncSampleAdaptiveOffset*, CodingStructure&, bool*, const double*, const bool, const double, const double, bool, bool)
+  asm("__wrap__ZN23EncSampleAdaptiveOffset10SAOProcessER15CodingStructurePbPKdbddbb");
+void real_EncALFProcess(EncAdaptiveLoopFilter*, CodingStructure&, const double*, AlfSliceParam&)
+  asm("__real__ZN21EncAdaptiveLoopFilter10ALFProcessER15CodingStructurePKdR13AlfSliceParam");
+void wrap_EncALFProcess(EncAdaptiveLoopFilter*, CodingStructure&, const double*, AlfSliceParam&)
+  asm("__wrap__ZN21EncAdaptiveLoopFilter10ALFProcessER15CodingStructurePKdR13AlfSliceParam");
+
 void real_initIfX86(InterpolationFilter*) asm("__real__ZN19InterpolationFilter26initInterpolationFilterX86Ev");
 void wrap_initIfX86(InterpolationFilter*) asm("__wrap__ZN19InterpolationFilter26initInterpolationFilterX86Ev");
 void real_initPelBufX86(PelBufferOps*) asm("__real__ZN12PelBufferOps16initPelBufOpsX86Ev");
@@ -104,11 +113,15 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
+extern long g_resUploads, g_resDownloads, g_resPictures;
+bool residentEnabled();
 long g_calls[28] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
                                                        "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld, IntraPred %ld, Border %ld, Hash %ld, CCLM %ld, IntraRefs %ld, DepQuant %ld, RDOQ %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
-                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20], g_calls[21], g_calls[22], g_calls[23], g_calls[24], g_calls[25], g_calls[26], g_calls[27]); } } g_report;
+                                                       g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20], g_calls[21], g_calls[22], g_calls[23], g_calls[24], g_calls[25], g_calls[26], g_calls[27]);
+                            if (shimEnabled()) fprintf(stderr, "[vvcgpu resident] in-loop chain: %ld pictures, %ld picture uploads (reconstruction / original), %ld picture downloads, resident form %s\n",
+                                                       g_resPictures, g_resUploads, g_resDownloads, residentEnabled() ? "on" : "off"); } } g_report;
 
 // ---- device-resident picture (three planes), re-used across calls
 struct DevPlanes
@@ -159,143 +172,129 @@ DevArray<int8_t> g_qpY, g_qpC;
 DevArray<vvcgpu_sao_ctu> g_sao;
 DevArray<uint16_t> g_cls;
 
+// ---- PRODUCTION FORM of the picture-level binding: the reconstruction stays on the device from loopFilterPic to the end of ALFProcess
+// (encoder: EncGOP.cpp:2122-2153, decoder: DecLib.cpp:506-533).  One upload of the reconstruction (and, in the encoder, of the original)
+// after CTU coding, one download after the last enabled stage; in between only maps, SAO / ALF parameters and statistics cross the bus.
+// The encoder's per-CTU calls inside its decision loops (offsetCTU in decideBlkParams, the ALF table slots in alfEncoder) only RECORD what
+// they were asked to do; the picture-level kernels run once when the stage returns.  VVCGPU_SHIM_RESIDENT=0 restores the per-call form.
+bool residentEnabled()
+{
+  static int on = -1;
+  if (on < 0) { const char* e = getenv("VVCGPU_SHIM_RESIDENT"); on = (e && e[0] == '0') ? 0 : 1; }
+  return on == 1;
+}
+struct Resident
+{
+  bool dirty = false;                 // the device holds a newer reconstruction than the host picture
+  int cur = 0;                        // which of g_a / g_b holds it
+  const Picture* pic = nullptr;       // picture the device copy belongs to
+  bool orgUp = false;                 // g_org holds this picture's original
+  bool clsUp = false;                 // g_cls holds the classifier of the device copy
+  bool saoCollect = false, alfCollect = false;
+  std::vector<vvcgpu_sao_ctu> sao[3]; // SAO parameters recorded from offsetCTU
+  bool saoAny = false;
+} g_res;
+long g_resUploads = 0, g_resDownloads = 0, g_resPictures = 0;   // picture transfers of the in-loop chain (reconstruction + original up, reconstruction down)
+DevPlanes g_org;
+DevArray<vvcgpu_sao_ctu> g_sao3[3];
+DevPlanes& resCur() { return g_res.cur ? g_b : g_a; }
+DevPlanes& resOther() { return g_res.cur ? g_a : g_b; }
+vvcgpu_planes asPlanes(DevPlanes& d) { vvcgpu_planes p; for (int c = 0; c < 3; c++) { p.p[c] = d.p[c]; p.stride[c] = d.stride[c]; } return p; }
+// the host picture must be current (a stage that cannot be served on the device is about to read it)
+void residentSyncHost(CodingStructure& cs)
+{
+  if (!g_res.dirty) return;
+  resCur().download(cs.getRecoBuf());
+  g_res.dirty = false; g_resDownloads++;
+}
+bool pcmOrBypass(const CodingStructure& cs) { return (cs.sps->getUsePCM() && cs.sps->getPCMFilterDisableFlag()) || cs.pps->getTransquantBypassEnabledFlag(); }
+
 inline uint32_t rasterIdx(const Position& pos, const PreCalcValues& pcv)
 {
   return ((pos.x & pcv.maxCUWidthMask) >> pcv.minCUWidthLog2) + ((pos.y & pcv.maxCUHeightMask) >> pcv.minCUHeightLog2) * pcv.partsInCtuWidth;
 }
 
-// The edge / boundary-strength derivation of LoopFilter::xDeblockCU (LoopFilter.cpp:243-369), with the two sample-filter
-// calls (:340-347) replaced by recording what they would have filtered.  Every decision is made by the reference's own
-// xSetLoopfilterParam / xSetEdgefilterMultiple / xGetBoundaryStrengthSingle on its own scratch arrays.
-void recordCU(LoopFilter& lf, CodingUnit& cu, const DeblockEdgeDir edgeDir, std::vector<uint8_t>& emap, int w4)
+// Deblocking maps.  The reference's OWN loopFilterPic runs (CTU loops, xDeblockCU with the edge flags and boundary strengths, LoopFilter.cpp
+// :149-369); its two sample filters xEdgeFilterLuma / xEdgeFilterChroma (:340-347) are pre-empted by oracle/ref_hooks.cpp and land in
+// vvcshim_edge_filter below, which only RECORDS which 4-sample segments they were asked to filter and with which strength (read from the
+// reference's own m_aapucBS).  The sample arithmetic then runs once per picture on the device.
+struct EdgeRecorder
 {
-  const PreCalcValues& pcv = *cu.cs->pcv;
-  const Area area = cu.Y().valid() ? cu.Y() : Area(recalcPosition(cu.chromaFormat, cu.chType, CHANNEL_TYPE_LUMA, cu.blocks[cu.chType].pos()),
-                                                   recalcSize(cu.chromaFormat, cu.chType, CHANNEL_TYPE_LUMA, cu.blocks[cu.chType].size()));
-  lf.xSetLoopfilterParam(cu);
-  for (auto& currTU : CU::traverseTUs(cu))
-  {
-    const Area& areaTu = cu.Y().valid() ? currTU.block(COMPONENT_Y) : area;
-    lf.xSetEdgefilterMultiple(cu, EDGE_VER, areaTu, lf.m_stLFCUParam.internalEdge);
-    lf.xSetEdgefilterMultiple(cu, EDGE_HOR, areaTu, lf.m_stLFCUParam.internalEdge);
-  }
-  for (auto& currPU : CU::traversePUs(cu))
-  {
-    const Area& areaPu = cu.Y().valid() ? currPU.block(COMPONENT_Y) : area;
-    const bool xOff = currPU.blocks[cu.chType].x != cu.blocks[cu.chType].x;
-    const bool yOff = currPU.blocks[cu.chType].y != cu.blocks[cu.chType].y;
-    lf.xSetEdgefilterMultiple(cu, EDGE_VER, areaPu, (xOff ? lf.m_stLFCUParam.internalEdge : lf.m_stLFCUParam.leftEdge), xOff);
-    lf.xSetEdgefilterMultiple(cu, EDGE_HOR, areaPu, (yOff ? lf.m_stLFCUParam.internalEdge : lf.m_stLFCUParam.topEdge), yOff);
-  }
-  if (cu.affine)
-  {
-    const int widthInBaseUnits = cu.Y().width >> pcv.minCUWidthLog2;
-    for (uint32_t edgeIdx = 1; edgeIdx < (uint32_t)widthInBaseUnits; edgeIdx++)
-      lf.xSetEdgefilterMultiple(cu, EDGE_VER, Area(cu.Y().x + edgeIdx * pcv.minCUWidth, cu.Y().y, pcv.minCUWidth, cu.Y().height), lf.m_stLFCUParam.internalEdge, 1);
-    const int heightInBaseUnits = cu.Y().height >> pcv.minCUHeightLog2;
-    for (uint32_t edgeIdx = 1; edgeIdx < (uint32_t)heightInBaseUnits; edgeIdx++)
-      lf.xSetEdgefilterMultiple(cu, EDGE_HOR, Area(cu.Y().x, cu.Y().y + edgeIdx * pcv.minCUHeight, cu.Y().width, pcv.minCUHeight), lf.m_stLFCUParam.internalEdge, 1);
-  }
-  const unsigned uiPelsInPart = pcv.minCUWidth;
-  for (int y = 0; y < (int)area.height; y += uiPelsInPart)
-    for (int x = 0; x < (int)area.width; x += uiPelsInPart)
-    {
-      unsigned uiBSCheck = 1;
-      if (!pcv.noRQT && uiPelsInPart == 4)
-        uiBSCheck = ((edgeDir == EDGE_VER) && (x % 8 == 0)) || ((edgeDir == EDGE_HOR) && (y % 8 == 0));
-      const Position localPos{ area.x + x, area.y + y };
-      const unsigned idx = rasterIdx(localPos, pcv);
-      if (lf.m_aapbEdgeFilter[edgeDir][idx] && uiBSCheck)
-        lf.m_aapucBS[edgeDir][idx] = lf.xGetBoundaryStrengthSingle(cu, edgeDir, localPos);
-    }
-  // 8x8 deblocking grid (:313-324)
-  if (edgeDir == EDGE_HOR) { if ((cu.block(COMPONENT_Y).y % 8) != 0) return; }
-  else                     { if ((cu.block(COMPONENT_Y).x % 8) != 0) return; }
+  bool on = false;
+  int w4 = 0, h4 = 0;
+  std::vector<uint8_t> ev, eh;
+} g_rec;
 
-  const unsigned shiftFactor = edgeDir == EDGE_VER ? ::getComponentScaleX(COMPONENT_Cb, pcv.chrFormat) : ::getComponentScaleY(COMPONENT_Cb, pcv.chrFormat);
-  const bool bAlwaysDoChroma = pcv.chrFormat == CHROMA_444 || pcv.noRQT;
-  unsigned orthogonalLength = 1, orthogonalIncrement = 1;
-  if (cu.blocks[COMPONENT_Y].valid())
-  {
-    if ((cu.blocks[COMPONENT_Y].height > 64) && (edgeDir == EDGE_HOR)) { orthogonalIncrement = 64 / 4; orthogonalLength = cu.blocks[COMPONENT_Y].height / 4; }
-    if ((cu.blocks[COMPONENT_Y].width > 64) && (edgeDir == EDGE_VER))  { orthogonalIncrement = 64 / 4; orthogonalLength = cu.blocks[COMPONENT_Y].width / 4; }
-  }
-  const SPS& sps = *cu.cs->sps;
-  const PPS& pps = *cu.cs->pps;
-  const bool bPCMFilter = sps.getUsePCM() && sps.getPCMFilterDisableFlag();
-  const Position lumaPos = area.pos();
-  const Size lumaSize = area.size();
-  const unsigned numParts = (edgeDir == EDGE_VER) ? lumaSize.height / pcv.minCUHeight : lumaSize.width / pcv.minCUWidth;
-  for (unsigned edge = 0; edge < orthogonalLength; edge += orthogonalIncrement)
-  {
-    const bool doLuma = cu.blocks[COMPONENT_Y].valid();
-    const bool doChroma = cu.blocks[COMPONENT_Cb].valid() && pcv.chrFormat != CHROMA_400 &&
-                          (bAlwaysDoChroma || (uiPelsInPart > DEBLOCK_SMALLEST_BLOCK) || (edge % ((DEBLOCK_SMALLEST_BLOCK << shiftFactor) / uiPelsInPart)) == 0);
-    for (unsigned iIdx = 0; iIdx < numParts; iIdx++)
-    {
-      const Position pos = (edgeDir == EDGE_VER) ? Position{ lumaPos.x + (int)edge * 4, lumaPos.y + (int)iIdx * 4 }
-                                                 : Position{ lumaPos.x + (int)iIdx * 4, lumaPos.y + (int)edge * 4 };
-      const unsigned bs = lf.m_aapucBS[edgeDir][rasterIdx(pos, pcv)];
-      if (!bs) continue;
-      uint8_t e = 0;
-      if (doLuma) e |= (uint8_t)(bs & 3);
-      if (doChroma && bs > 1) e |= (uint8_t)((bs & 3) << 2);
-      if (bPCMFilter || pps.getTransquantBypassEnabledFlag())
-      {
-        const Position posP = (edgeDir == EDGE_VER) ? pos.offset(-1, 0) : pos.offset(0, -1);
-        const CodingUnit& cuP = *cu.cs->getCU(cu.Y().valid() ? posP : recalcPosition(cu.chromaFormat, CHANNEL_TYPE_LUMA, cu.chType, posP), cu.chType);
-        bool noP = bPCMFilter && cuP.ipcm, noQ = bPCMFilter && cu.ipcm;
-        if (pps.getTransquantBypassEnabledFlag()) { noP = noP || cuP.transQuantBypass; noQ = noQ || cu.transQuantBypass; }
-        e |= (noP ? 0x10 : 0) | (noQ ? 0x20 : 0);
-      }
-      // in the dual tree the luma pass and the chroma pass record into different bit fields of the same unit
-      emap[(pos.y >> 2) * w4 + (pos.x >> 2)] |= e;
-    }
-  }
-}
-
-void buildDeblockMaps(LoopFilter& lf, CodingStructure& cs, std::vector<uint8_t>& ev, std::vector<uint8_t>& eh,
-                      std::vector<int8_t>& qy, std::vector<int8_t>& qc)
+// QP of the CU that covers each 4x4 luma unit (what xEdgeFilterLuma / Chroma read as cuP.qp / cuQ.qp), per tree in a dual-tree slice
+void buildQpMaps(CodingStructure& cs, std::vector<int8_t>& qy, std::vector<int8_t>& qc)
 {
   const PreCalcValues& pcv = *cs.pcv;
   const int w4 = pcv.lumaWidth >> 2, h4 = pcv.lumaHeight >> 2;
-  ev.assign((size_t)w4 * h4, 0); eh.assign((size_t)w4 * h4, 0);
   qy.assign((size_t)w4 * h4, 0); qc.assign((size_t)w4 * h4, 0);
   const bool dual = CS::isDualITree(cs);
-  for (int dir = 0; dir < 2; dir++)
+  for (const CodingUnit* cu : cs.cus)
   {
-    const DeblockEdgeDir edgeDir = dir == 0 ? EDGE_VER : EDGE_HOR;
-    std::vector<uint8_t>& emap = dir == 0 ? ev : eh;
-    for (int y = 0; y < (int)pcv.heightInCtus; y++)
-      for (int x = 0; x < (int)pcv.widthInCtus; x++)
+    const Area a = cu->Y().valid() ? (Area)cu->Y()
+                 : Area(recalcPosition(cu->chromaFormat, cu->chType, CHANNEL_TYPE_LUMA, cu->blocks[cu->chType].pos()),
+                        recalcSize(cu->chromaFormat, cu->chType, CHANNEL_TYPE_LUMA, cu->blocks[cu->chType].size()));
+    const bool chromaTree = dual && cu->chType == CH_C;
+    for (int uy = a.y >> 2; uy < std::min<int>((a.y + a.height) >> 2, h4); uy++)
+      for (int ux = a.x >> 2; ux < std::min<int>((a.x + a.width) >> 2, w4); ux++)
       {
-        const UnitArea ctuArea(pcv.chrFormat, Area(x << pcv.maxCUWidthLog2, y << pcv.maxCUHeightLog2, pcv.maxCUWidth, pcv.maxCUWidth));
-        for (int tree = 0; tree < (dual ? 2 : 1); tree++)
-        {
-          memset(lf.m_aapucBS[edgeDir].data(), 0, lf.m_aapucBS[edgeDir].byte_size());
-          memset(lf.m_aapbEdgeFilter[edgeDir].data(), false, lf.m_aapbEdgeFilter[edgeDir].byte_size());
-          const ChannelType ch = tree == 0 ? CH_L : CH_C;
-          for (auto& currCU : cs.traverseCUs(CS::getArea(cs, ctuArea, ch), ch))
-          {
-            if (dir == 0)
-            {
-              const Area a = currCU.Y().valid() ? (Area)currCU.Y()
-                           : Area(recalcPosition(currCU.chromaFormat, currCU.chType, CHANNEL_TYPE_LUMA, currCU.blocks[currCU.chType].pos()),
-                                  recalcSize(currCU.chromaFormat, currCU.chType, CHANNEL_TYPE_LUMA, currCU.blocks[currCU.chType].size()));
-              for (int uy = a.y >> 2; uy < std::min<int>((a.y + a.height) >> 2, h4); uy++)
-                for (int ux = a.x >> 2; ux < std::min<int>((a.x + a.width) >> 2, w4); ux++)
-                {
-                  if (tree == 0) { qy[uy * w4 + ux] = (int8_t)currCU.qp; if (!dual) qc[uy * w4 + ux] = (int8_t)currCU.qp; }
-                  else qc[uy * w4 + ux] = (int8_t)currCU.qp;
-                }
-            }
-            recordCU(lf, currCU, edgeDir, emap, w4);
-          }
-        }
+        if (!chromaTree) { qy[uy * w4 + ux] = (int8_t)cu->qp; if (!dual) qc[uy * w4 + ux] = (int8_t)cu->qp; }
+        else qc[uy * w4 + ux] = (int8_t)cu->qp;
       }
   }
 }
 
+}  // namespace
+
+// one xEdgeFilterLuma / xEdgeFilterChroma call of the reference: the segments along CU edge `iEdge` (4-sample units), LoopFilter.cpp:543-600, 684-760
+extern "C" int vvcshim_edge_filter(LoopFilter* self, const CodingUnit* cuP, int edgeDirI, int iEdge, int chroma)
+{
+  if (!g_rec.on) return 0;
+  const CodingUnit& cu = *cuP;
+  const DeblockEdgeDir edgeDir = (DeblockEdgeDir)edgeDirI;
+  const PreCalcValues& pcv = *cu.cs->pcv;
+  const Position lumaPos = cu.Y().valid() ? cu.Y().pos() : recalcPosition(cu.chromaFormat, cu.chType, CHANNEL_TYPE_LUMA, cu.blocks[cu.chType].pos());
+  const Size lumaSize = cu.Y().valid() ? cu.Y().size() : recalcSize(cu.chromaFormat, cu.chType, CHANNEL_TYPE_LUMA, cu.blocks[cu.chType].size());
+  if (chroma)
+  {
+    // chroma edges lie on the 8-sample chroma grid (:716-724)
+    const unsigned pelsH = pcv.minCUWidth >> ::getComponentScaleX(COMPONENT_Cb, pcv.chrFormat), pelsV = pcv.minCUHeight >> ::getComponentScaleY(COMPONENT_Cb, pcv.chrFormat);
+    const unsigned ridx = rasterIdx(lumaPos, pcv);
+    const unsigned edgeNumVert = ridx % pcv.partsInCtuWidth + iEdge, edgeNumHor = ridx / pcv.partsInCtuWidth + iEdge;
+    if (pelsH < DEBLOCK_SMALLEST_BLOCK && pelsV < DEBLOCK_SMALLEST_BLOCK &&
+        (((edgeNumVert % (DEBLOCK_SMALLEST_BLOCK / pelsH)) && edgeDir == EDGE_VER) || ((edgeNumHor % (DEBLOCK_SMALLEST_BLOCK / pelsV)) && edgeDir == EDGE_HOR)))
+      return 1;
+  }
+  const unsigned numParts = pcv.rectCUs ? (edgeDir == EDGE_VER ? lumaSize.height / pcv.minCUHeight : lumaSize.width / pcv.minCUWidth) : pcv.partsInCtuWidth >> cu.qtDepth;
+  const int unit = pcv.minCUWidth;
+  const SPS& sps = *cu.cs->sps;
+  const PPS& pps = *cu.cs->pps;
+  const bool pcmFilter = sps.getUsePCM() && sps.getPCMFilterDisableFlag();
+  std::vector<uint8_t>& emap = edgeDir == EDGE_VER ? g_rec.ev : g_rec.eh;
+  for (unsigned i = 0; i < numParts; i++)
+  {
+    const Position pos = edgeDir == EDGE_VER ? Position{ lumaPos.x + iEdge * unit, lumaPos.y + (int)i * unit } : Position{ lumaPos.x + (int)i * unit, lumaPos.y + iEdge * unit };
+    const unsigned bs = self->m_aapucBS[edgeDir][rasterIdx(pos, pcv)];
+    if (!bs || (chroma && bs <= 1)) continue;
+    uint8_t e = chroma ? (uint8_t)((bs & 3) << 2) : (uint8_t)(bs & 3);
+    if (pcmFilter || pps.getTransquantBypassEnabledFlag())              // sides the filter must leave untouched (:607-623, :790-806)
+    {
+      const Position posP = edgeDir == EDGE_VER ? pos.offset(-1, 0) : pos.offset(0, -1);
+      const CodingUnit& cuPside = *cu.cs->getCU(cu.Y().valid() ? posP : recalcPosition(cu.chromaFormat, CHANNEL_TYPE_LUMA, cu.chType, posP), cu.chType);
+      bool noP = pcmFilter && cuPside.ipcm, noQ = pcmFilter && cu.ipcm;
+      if (pps.getTransquantBypassEnabledFlag()) { noP = noP || cuPside.transQuantBypass; noQ = noQ || cu.transQuantBypass; }
+      e |= (noP ? 0x10 : 0) | (noQ ? 0x20 : 0);
+    }
+    const int ux = pos.x >> 2, uy = pos.y >> 2;
+    if (ux < g_rec.w4 && uy < g_rec.h4) emap[(size_t)uy * g_rec.w4 + ux] |= e;   // dual tree: luma and chroma passes fill different bit fields
+  }
+  return 1;
+}
+
+namespace {
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
@@ -304,11 +303,20 @@ void wrap_loopFilterPic(LoopFilter* self, CodingStructure& cs)
   if (!shimEnabled()) { real_loopFilterPic(self, cs); return; }
   const PreCalcValues& pcv = *cs.pcv;
   CHECK(pcv.chrFormat != CHROMA_420, "vvcgpu shim: only 4:2:0");
-  std::vector<uint8_t> ev, eh; std::vector<int8_t> qy, qc;
-  buildDeblockMaps(*self, cs, ev, eh, qy, qc);
+  // the reference's own walk with the sample filters recording (see vvcshim_edge_filter)
+  g_rec.w4 = pcv.lumaWidth >> 2; g_rec.h4 = pcv.lumaHeight >> 2;
+  g_rec.ev.assign((size_t)g_rec.w4 * g_rec.h4, 0); g_rec.eh.assign((size_t)g_rec.w4 * g_rec.h4, 0);
+  g_rec.on = true;
+  real_loopFilterPic(self, cs);
+  g_rec.on = false;
+  std::vector<int8_t> qy, qc;
+  buildQpMaps(cs, qy, qc);
   PelUnitBuf rec = cs.getRecoBuf();
+  g_res = Resident();
+  g_res.pic = cs.picture;
   g_a.upload(rec);
-  g_edgeV.upload(ev.data(), ev.size()); g_edgeH.upload(eh.data(), eh.size());
+  g_resUploads++; g_resPictures++;
+  g_edgeV.upload(g_rec.ev.data(), g_rec.ev.size()); g_edgeH.upload(g_rec.eh.data(), g_rec.eh.size());
   g_qpY.upload(qy.data(), qy.size()); g_qpC.upload(qc.data(), qc.size());
   vvcgpu_deblock_cfg cfg;
   cfg.bit_depth_luma = cs.sps->getBitDepth(CHANNEL_TYPE_LUMA); cfg.bit_depth_chroma = cs.sps->getBitDepth(CHANNEL_TYPE_CHROMA);
@@ -318,26 +326,22 @@ void wrap_loopFilterPic(LoopFilter* self, CodingStructure& cs)
   if (!cs.slice->getDeblockingFilterDisable())
     VVCGPU(vvcgpu_deblock(g_a.p[0], g_a.stride[0], g_a.p[1], g_a.p[2], g_a.stride[1], pcv.lumaWidth, pcv.lumaHeight,
                           g_edgeV.ptr, g_edgeH.ptr, g_qpY.ptr, g_qpC.ptr, &cfg, nullptr));
-  g_a.download(rec);
   g_calls[0]++;
+  // resident form: a later stage of the chain will run for this picture (SAOProcess / ALFProcess are called whenever the SPS enables them,
+  // EncGOP.cpp:2129,2150, DecLib.cpp:521,528) -> the deblocked picture stays on the device
+  const bool more = (cs.sps->getUseSAO() || cs.sps->getUseALF()) && residentEnabled() && !pcmOrBypass(cs) && (pcv.lumaWidth & 7) == 0 && (pcv.lumaHeight & 7) == 0;
+  g_res.dirty = true;
+  if (!more) residentSyncHost(cs);
 }
 
-void wrap_SAOProcess(SampleAdaptiveOffset* self, CodingStructure& cs, SAOBlkParam* saoBlkParams)
+namespace {
+// SAO parameters of the whole picture, as the kernels take them (type -1 = off; offsetCTU skips a CTU whose components are all off, :513-525)
+void saoParamsFromPicture(SampleAdaptiveOffset* self, CodingStructure& cs, const SAOBlkParam* blk, std::vector<vvcgpu_sao_ctu> (&prm)[3])
 {
-  if (!shimEnabled()) { real_SAOProcess(self, cs, saoBlkParams); return; }
-  CHECK(!saoBlkParams, "No parameters present");
-  self->xReconstructBlkSAOParams(cs, saoBlkParams);                      // merge resolution + de-quantisation (:262-290)
-  bool any = false;
-  for (int c = 0; c < 3; c++) any = any || self->m_picSAOEnabled[c];
-  if (!any) return;
   const PreCalcValues& pcv = *cs.pcv;
-  PelUnitBuf rec = cs.getRecoBuf();
-  g_a.upload(rec);
-  g_b.ensure(rec);
   const int nCtu = pcv.sizeInCtus;
-  std::vector<vvcgpu_sao_ctu> prm(nCtu);
-  std::vector<uint8_t> avail(nCtu);
   int idx = 0;
+  std::vector<uint8_t> avail(nCtu);
   for (uint32_t yPos = 0; yPos < pcv.lumaHeight; yPos += pcv.maxCUHeight)
     for (uint32_t xPos = 0; xPos < pcv.lumaWidth; xPos += pcv.maxCUWidth, idx++)
     {
@@ -347,56 +351,179 @@ void wrap_SAOProcess(SampleAdaptiveOffset* self, CodingStructure& cs, SAOBlkPara
     }
   for (int c = 0; c < 3; c++)
   {
-    const ComponentID compID = ComponentID(c);
+    prm[c].resize(nCtu);
     for (int i = 0; i < nCtu; i++)
     {
-      const SAOOffset& o = cs.picture->getSAO()[i][compID];
-      // offsetCTU skips the whole CTU when every component is off (:513-525); a per-component OFF is skipped at :541
-      prm[i].type = (int8_t)(o.modeIdc == SAO_MODE_OFF ? -1 : o.typeIdc);
-      prm[i].avail = avail[i];
-      for (int k = 0; k < 32; k++) prm[i].offset[k] = 0;
+      const SAOOffset& o = blk[i][ComponentID(c)];
+      vvcgpu_sao_ctu& q = prm[c][i];
+      q.type = (int8_t)(o.modeIdc == SAO_MODE_OFF ? -1 : o.typeIdc);
+      q.avail = avail[i];
+      for (int k = 0; k < 32; k++) q.offset[k] = 0;
       if (o.modeIdc != SAO_MODE_OFF)
-      {
-        if (o.typeIdc == SAO_TYPE_BO) for (int k = 0; k < 32; k++) prm[i].offset[k] = (int16_t)o.offset[k];
-        else for (int k = 0; k < NUM_SAO_EO_CLASSES; k++) prm[i].offset[k] = (int16_t)o.offset[k];
-      }
+        for (int k = 0; k < (o.typeIdc == SAO_TYPE_BO ? 32 : (int)NUM_SAO_EO_CLASSES); k++) q.offset[k] = (int16_t)o.offset[k];
     }
-    g_sao.upload(prm.data(), prm.size());
-    const int cw = pcv.maxCUWidth >> (c ? 1 : 0), ch = pcv.maxCUHeight >> (c ? 1 : 0);
-    VVCGPU(vvcgpu_sao_apply(g_a.p[c], g_a.stride[c], g_b.p[c], g_b.stride[c], g_a.w[c], g_a.h[c], cw, ch,
-                            cs.sps->getBitDepth(toChannelType(compID)), g_sao.ptr, cs.slice->clpRng(compID).min, cs.slice->clpRng(compID).max, nullptr));
-    VVCGPU(vvcgpu_stream_sync(nullptr));       // prm / g_sao are re-used for the next component
   }
-  g_b.download(rec);
-  self->xPCMLFDisableProcess(cs);
-  g_calls[1]++;
+}
+// current device picture -> the other buffer with SAO applied (one launch for the three planes)
+void saoApplyResident(CodingStructure& cs, std::vector<vvcgpu_sao_ctu> (&prm)[3])
+{
+  const PreCalcValues& pcv = *cs.pcv;
+  for (int c = 0; c < 3; c++) g_sao3[c].upload(prm[c].data(), prm[c].size());
+  resOther().ensure(cs.getRecoBuf());
+  vvcgpu_planes src = asPlanes(resCur()), dst = asPlanes(resOther());
+  // one clipping range serves the three planes when the bit depths agree (always, in the shipped cfgs); otherwise plane by plane
+  const ClpRng& cl = cs.slice->clpRng(COMPONENT_Y);
+  bool same = cs.sps->getBitDepth(CHANNEL_TYPE_LUMA) == cs.sps->getBitDepth(CHANNEL_TYPE_CHROMA);
+  for (int c = 1; c < 3; c++) same = same && cs.slice->clpRng(ComponentID(c)).min == cl.min && cs.slice->clpRng(ComponentID(c)).max == cl.max;
+  if (same && pcv.maxCUWidth == pcv.maxCUHeight)
+    VVCGPU(vvcgpu_sao_apply_picture(&src, &dst, pcv.lumaWidth, pcv.lumaHeight, pcv.maxCUWidth, cs.sps->getBitDepth(CHANNEL_TYPE_LUMA), g_sao3[0].ptr, g_sao3[1].ptr,
+                                    g_sao3[2].ptr, cl.min, cl.max, nullptr));
+  else
+    for (int c = 0; c < 3; c++)
+    {
+      const ComponentID compID = ComponentID(c);
+      VVCGPU(vvcgpu_sao_apply(resCur().p[c], resCur().stride[c], resOther().p[c], resOther().stride[c], resCur().w[c], resCur().h[c],
+                              pcv.maxCUWidth >> (c ? 1 : 0), pcv.maxCUHeight >> (c ? 1 : 0), cs.sps->getBitDepth(toChannelType(compID)), g_sao3[c].ptr,
+                              cs.slice->clpRng(compID).min, cs.slice->clpRng(compID).max, nullptr));
+    }
+  g_res.cur ^= 1;
+  g_res.dirty = true;
+  g_res.clsUp = false;
+}
+// make the device copy current for `cs` (a stage entered without a preceding resident stage uploads the host picture)
+void residentEnsure(CodingStructure& cs)
+{
+  if (g_res.dirty && g_res.pic == cs.picture) return;
+  g_res = Resident();
+  g_res.pic = cs.picture;
+  g_a.upload(cs.getRecoBuf());
+  g_resUploads++;
+}
+void alfFilterResident(CodingStructure& cs, AdaptiveLoopFilter* self, AlfSliceParam& alfSliceParam)
+{
+  const PreCalcValues& pcv = *cs.pcv;
+  const int nCtu = pcv.sizeInCtus;
+  // a component that is off for the slice keeps its samples: all-zero CTU flags make the kernel copy it
+  std::vector<uint8_t> zero(nCtu, 0);
+  for (int c = 0; c < 3; c++)
+    g_flags[c].upload(alfSliceParam.enabledFlag[c] ? cs.picture->getAlfCtuEnableFlag(c) : zero.data(), nCtu);
+  if (!g_res.clsUp)
+  {
+    g_cls.reserve((size_t)(pcv.lumaWidth >> 2) * (pcv.lumaHeight >> 2));
+    VVCGPU(vvcgpu_alf_classify(resCur().p[0], resCur().stride[0], resCur().w[0], resCur().h[0], cs.sps->getBitDepth(CHANNEL_TYPE_LUMA), g_cls.ptr, nullptr));
+    g_res.clsUp = true;
+  }
+  resOther().ensure(cs.getRecoBuf());
+  vvcgpu_planes src = asPlanes(resCur()), dst = asPlanes(resOther());
+  const ClpRng& cl = self->m_clpRngs.comp[0];
+  bool same = true;
+  for (int c = 1; c < 3; c++) same = same && self->m_clpRngs.comp[c].min == cl.min && self->m_clpRngs.comp[c].max == cl.max;
+  if (same && (pcv.lumaWidth & 7) == 0 && (pcv.lumaHeight & 7) == 0)
+    VVCGPU(vvcgpu_alf_filter_picture(&src, &dst, pcv.lumaWidth, pcv.lumaHeight, pcv.maxCUWidth, g_cls.ptr, alfSliceParam.lumaFilterType == ALF_FILTER_7 ? 1 : 0,
+                                     self->m_coeffFinal, alfSliceParam.chromaCoeff, g_flags[0].ptr, g_flags[1].ptr, g_flags[2].ptr, cl.min, cl.max, nullptr));
+  else
+  {
+    VVCGPU(vvcgpu_alf_filter_luma(resCur().p[0], resCur().stride[0], resOther().p[0], resOther().stride[0], resCur().w[0], resCur().h[0], pcv.maxCUWidth, g_cls.ptr,
+                                  alfSliceParam.lumaFilterType == ALF_FILTER_7 ? 1 : 0, self->m_coeffFinal, g_flags[0].ptr,
+                                  self->m_clpRngs.comp[0].min, self->m_clpRngs.comp[0].max, nullptr));
+    for (int c = 1; c < 3; c++)
+      VVCGPU(vvcgpu_alf_filter_chroma(resCur().p[c], resCur().stride[c], resOther().p[c], resOther().stride[c], resCur().w[c], resCur().h[c], pcv.maxCUWidth >> 1,
+                                      alfSliceParam.chromaCoeff, g_flags[c].ptr, self->m_clpRngs.comp[c].min, self->m_clpRngs.comp[c].max, nullptr));
+  }
+  g_res.cur ^= 1;
+  g_res.dirty = true;
+}
+}  // namespace
+
+// decoder: SampleAdaptiveOffset::SAOProcess (SampleAdaptiveOffset.cpp:564-612)
+void wrap_SAOProcess(SampleAdaptiveOffset* self, CodingStructure& cs, SAOBlkParam* saoBlkParams)
+{
+  if (!shimEnabled()) { real_SAOProcess(self, cs, saoBlkParams); return; }
+  CHECK(!saoBlkParams, "No parameters present");
+  self->xReconstructBlkSAOParams(cs, saoBlkParams);                      // merge resolution + de-quantisation (:262-290)
+  bool any = false;
+  for (int c = 0; c < 3; c++) any = any || self->m_picSAOEnabled[c];
+  const bool keep = residentEnabled() && cs.sps->getUseALF() && !pcmOrBypass(cs);     // ALFProcess follows (DecLib.cpp:528)
+  if (any)
+  {
+    residentEnsure(cs);
+    std::vector<vvcgpu_sao_ctu> prm[3];
+    saoParamsFromPicture(self, cs, cs.picture->getSAO(), prm);
+    saoApplyResident(cs, prm);
+    g_calls[1]++;
+  }
+  if (!keep) residentSyncHost(cs);
+  if (!g_res.dirty) self->xPCMLFDisableProcess(cs);                      // touches samples of PCM / lossless CUs only: never in the resident form
 }
 
+// decoder: AdaptiveLoopFilter::ALFProcess (AdaptiveLoopFilter.cpp:68-139)
 void wrap_ALFProcess(AdaptiveLoopFilter* self, CodingStructure& cs, AlfSliceParam& alfSliceParam)
 {
   if (!shimEnabled()) { real_ALFProcess(self, cs, alfSliceParam); return; }
-  if (!alfSliceParam.enabledFlag[COMPONENT_Y] && !alfSliceParam.enabledFlag[COMPONENT_Cb] && !alfSliceParam.enabledFlag[COMPONENT_Cr]) return;
+  if (!alfSliceParam.enabledFlag[COMPONENT_Y] && !alfSliceParam.enabledFlag[COMPONENT_Cb] && !alfSliceParam.enabledFlag[COMPONENT_Cr])
+  {
+    residentSyncHost(cs);
+    return;
+  }
   alfSliceParam.filterShapes = self->m_filterShapes;
   self->m_clpRngs = cs.slice->getClpRngs();
   self->reconstructCoeff(alfSliceParam, CHANNEL_TYPE_LUMA);
   self->reconstructCoeff(alfSliceParam, CHANNEL_TYPE_CHROMA);
-  const PreCalcValues& pcv = *cs.pcv;
-  PelUnitBuf rec = cs.getRecoBuf();
-  g_a.upload(rec);
-  g_b.ensure(rec);
-  const int nCtu = pcv.sizeInCtus;
-  for (int c = 0; c < 3; c++) g_flags[c].upload(cs.picture->getAlfCtuEnableFlag(c), nCtu);
-  g_cls.reserve((size_t)(pcv.lumaWidth >> 2) * (pcv.lumaHeight >> 2));
-  const int bd = cs.sps->getBitDepth(CHANNEL_TYPE_LUMA);
-  VVCGPU(vvcgpu_alf_classify(g_a.p[0], g_a.stride[0], g_a.w[0], g_a.h[0], bd, g_cls.ptr, nullptr));
-  VVCGPU(vvcgpu_alf_filter_luma(g_a.p[0], g_a.stride[0], g_b.p[0], g_b.stride[0], g_a.w[0], g_a.h[0], pcv.maxCUWidth, g_cls.ptr,
-                                alfSliceParam.lumaFilterType == ALF_FILTER_7 ? 1 : 0, self->m_coeffFinal, g_flags[0].ptr,
-                                self->m_clpRngs.comp[0].min, self->m_clpRngs.comp[0].max, nullptr));
-  for (int c = 1; c < 3; c++)
-    VVCGPU(vvcgpu_alf_filter_chroma(g_a.p[c], g_a.stride[c], g_b.p[c], g_b.stride[c], g_a.w[c], g_a.h[c], pcv.maxCUWidth >> 1,
-                                    alfSliceParam.chromaCoeff, g_flags[c].ptr, self->m_clpRngs.comp[c].min, self->m_clpRngs.comp[c].max, nullptr));
-  g_b.download(rec);
+  residentEnsure(cs);
+  alfFilterResident(cs, self, alfSliceParam);
+  residentSyncHost(cs);
   g_calls[2]++;
+}
+
+// encoder: EncSampleAdaptiveOffset::SAOProcess (EncSampleAdaptiveOffset.cpp:213-253).  The reference's own body runs: its statistics
+// come from the device copy (vvcshim_sao_stats), its per-CTU offsetCTU calls inside decideBlkParams (:1033,1055) only record the chosen
+// parameters (wrap_offsetCTU), and the picture is filtered once when it returns.
+void wrap_EncSAOProcess(EncSampleAdaptiveOffset* self, CodingStructure& cs, bool* sliceEnabled, const double* lambdas, const bool testDisable,
+                        const double rate, const double rateChroma, bool isPreDBF, bool greedy)
+{
+  const bool resident = shimEnabled() && residentEnabled() && g_res.dirty && g_res.pic == cs.picture && !isPreDBF && !pcmOrBypass(cs);
+  if (!resident)
+  {
+    if (shimEnabled()) residentSyncHost(cs);
+    real_EncSAOProcess(self, cs, sliceEnabled, lambdas, testDisable, rate, rateChroma, isPreDBF, greedy);
+    return;
+  }
+  const int nCtu = cs.pcv->sizeInCtus;
+  for (int c = 0; c < 3; c++)
+  {
+    g_res.sao[c].assign(nCtu, vvcgpu_sao_ctu());
+    for (auto& q : g_res.sao[c]) { q.type = -1; q.avail = 0; for (int k = 0; k < 32; k++) q.offset[k] = 0; }
+  }
+  g_res.saoAny = false;
+  g_res.saoCollect = true;
+  real_EncSAOProcess(self, cs, sliceEnabled, lambdas, testDisable, rate, rateChroma, isPreDBF, greedy);
+  g_res.saoCollect = false;
+  if (g_res.saoAny) { saoApplyResident(cs, g_res.sao); g_calls[1]++; }
+  if (!cs.sps->getUseALF()) residentSyncHost(cs);
+}
+
+// encoder: EncAdaptiveLoopFilter::ALFProcess (EncAdaptiveLoopFilter.cpp:221-268).  The reference's own body runs: classification and
+// covariances come from the device copy (table slot / vvcshim_alf_stats), the per-CTU filter slots called at the end of alfEncoder (:421-450)
+// record nothing but the fact, and the picture is filtered once with the final coefficients and CTU flags when it returns.
+void wrap_EncALFProcess(EncAdaptiveLoopFilter* self, CodingStructure& cs, const double* lambdas, AlfSliceParam& alfSliceParam)
+{
+  const bool resident = shimEnabled() && residentEnabled() && g_res.dirty && g_res.pic == cs.picture && !pcmOrBypass(cs) &&
+                        self->m_maxCUWidth == self->m_maxCUHeight && (self->m_maxCUWidth % 128) == 0 && self->m_chromaFormat == CHROMA_420;
+  if (!resident)
+  {
+    if (shimEnabled()) residentSyncHost(cs);
+    real_EncALFProcess(self, cs, lambdas, alfSliceParam);
+    return;
+  }
+  g_res.alfCollect = true;
+  real_EncALFProcess(self, cs, lambdas, alfSliceParam);
+  g_res.alfCollect = false;
+  if (alfSliceParam.enabledFlag[COMPONENT_Y] || alfSliceParam.enabledFlag[COMPONENT_Cb] || alfSliceParam.enabledFlag[COMPONENT_Cr])
+  {
+    alfFilterResident(cs, self, alfSliceParam);
+    g_calls[2]++;
+  }
+  residentSyncHost(cs);
 }
 
 // ---- encoder statistics -------------------------------------------------------------------------------------
@@ -430,11 +557,38 @@ int vvcshim_sao_stats(EncSampleAdaptiveOffset* self, std::vector<SAOStatData**>*
   static DevArray<uint8_t> dAvail;
   static DevArray<int64_t> dOut;
   dAvail.upload(avail.data(), avail.size());
+  const int numberOfComponents = getNumberValidComponents(pcv.chrFormat);
+  if (g_res.saoCollect && g_res.dirty && numberOfComponents == 3 && pcv.maxCUWidth == pcv.maxCUHeight && pcv.maxCUWidth >= 32 &&
+      cs.sps->getBitDepth(CHANNEL_TYPE_LUMA) == cs.sps->getBitDepth(CHANNEL_TYPE_CHROMA) &&
+      self->m_skipLinesR[1][0] == self->m_skipLinesR[2][0] && self->m_skipLinesB[1][0] == self->m_skipLinesB[2][0])
+  {
+    // resident form: the deblocked picture is already on the device; the original goes up once per picture; one launch for the three planes
+    if (!g_res.orgUp) { g_org.upload(orgYuv); g_res.orgUp = true; g_resUploads++; }
+    dOut.reserve((size_t)nCtu * 320 * 3);
+    vvcgpu_planes o = asPlanes(g_org), r = asPlanes(resCur());
+    VVCGPU(vvcgpu_sao_stats_picture(&o, &r, pcv.lumaWidth, pcv.lumaHeight, pcv.maxCUWidth, cs.sps->getBitDepth(CHANNEL_TYPE_LUMA), dAvail.ptr,
+                                    self->m_skipLinesR[0][0], self->m_skipLinesB[0][0], self->m_skipLinesR[1][0], self->m_skipLinesB[1][0],
+                                    dOut.ptr, dOut.ptr + (size_t)nCtu * 320, dOut.ptr + (size_t)nCtu * 640, nullptr));
+    std::vector<int64_t> out3((size_t)nCtu * 320 * 3);
+    VVCGPU(vvcgpu_memcpy_d2h(out3.data(), dOut.ptr, out3.size() * sizeof(int64_t), nullptr));
+    VVCGPU(vvcgpu_stream_sync(nullptr));
+    for (int c = 0; c < 3; c++)
+      for (int i = 0; i < nCtu; i++)
+        for (int t = 0; t < NUM_SAO_NEW_TYPES; t++)
+        {
+          SAOStatData& st = blkStats[i][c][t];
+          memcpy(st.diff, &out3[(size_t)c * nCtu * 320 + (size_t)i * 320 + t * 64], 32 * sizeof(int64_t));
+          memcpy(st.count, &out3[(size_t)c * nCtu * 320 + (size_t)i * 320 + t * 64 + 32], 32 * sizeof(int64_t));
+        }
+    g_calls[3]++;
+    return 1;
+  }
+  residentSyncHost(cs);                                  // per-call form: works on the host pictures it is handed
+  if (g_res.saoCollect) return 0;                        // (the stage was entered resident but cannot be served so: reference body on the synced host picture)
   dOut.reserve((size_t)nCtu * 320);
   g_a.upload(orgYuv);
   g_b.upload(srcYuv);
   std::vector<int64_t> out((size_t)nCtu * 320);
-  const int numberOfComponents = getNumberValidComponents(pcv.chrFormat);
   for (int c = 0; c < numberOfComponents; c++)
   {
     const ComponentID compID = ComponentID(c);
@@ -466,6 +620,51 @@ int vvcshim_alf_stats(EncAdaptiveLoopFilter* self, PelUnitBuf* orgYuvP, PelUnitB
   if (!shimEnabled() || !square) return 0;
   const int numberOfComponents = getNumberValidComponents(self->m_chromaFormat);
   const int nCtu = self->m_numCTUsInPic;
+  if (g_res.alfCollect && g_res.dirty && numberOfComponents == 3 && (self->m_picWidth & 7) == 0 && (self->m_picHeight & 7) == 0 &&
+      self->m_filterShapes[CHANNEL_TYPE_LUMA].size() == 2 && self->m_filterShapes[CHANNEL_TYPE_CHROMA].size() == 1 &&
+      self->m_filterShapes[CHANNEL_TYPE_LUMA][0].numCoeff == 7 && self->m_filterShapes[CHANNEL_TYPE_LUMA][1].numCoeff == 13)
+  {
+    // resident form: original, SAO output and classifier are on the device; the four covariance sets come from one entry point
+    if (!g_res.orgUp) { g_org.upload(orgYuv); g_res.orgUp = true; g_resUploads++; }
+    static DevArray<int64_t> dAll;
+    const size_t n7 = (size_t)nCtu * 25 * 183, n5 = (size_t)nCtu * 25 * 57, nc = (size_t)nCtu * 57;
+    dAll.reserve(n7 + n5 + 2 * nc);
+    vvcgpu_planes o = asPlanes(g_org), r = asPlanes(resCur());
+    VVCGPU(vvcgpu_alf_stats_picture(&o, &r, self->m_picWidth, self->m_picHeight, self->m_maxCUWidth, g_cls.ptr, dAll.ptr, dAll.ptr + n7, dAll.ptr + n7 + n5,
+                                    dAll.ptr + n7 + n5 + nc, nullptr));
+    std::vector<int64_t> all(n7 + n5 + 2 * nc);
+    VVCGPU(vvcgpu_memcpy_d2h(all.data(), dAll.ptr, all.size() * sizeof(int64_t), nullptr));
+    VVCGPU(vvcgpu_stream_sync(nullptr));
+    for (int channelIdx = 0; channelIdx < 2; channelIdx++)
+      for (int shape = 0; shape != (int)self->m_filterShapes[channelIdx].size(); shape++)
+        for (int classIdx = 0; classIdx < (channelIdx == 0 ? MAX_NUM_ALF_CLASSES : 1); classIdx++)
+          self->m_alfCovarianceFrame[channelIdx][shape][classIdx].reset();
+    auto fill = [&](int c, int shape, const int64_t* base, int nCls, int N)
+    {
+      const int recSz = N * N + N + 1;
+      const ChannelType chType = toChannelType(ComponentID(c));
+      for (int i = 0; i < nCtu; i++)
+        for (int k = 0; k < nCls; k++)
+        {
+          AlfCovariance& cov = self->m_alfCovariance[c][shape][i][k];
+          const int64_t* r = base + ((size_t)i * nCls + k) * recSz;
+          for (int a = 0; a < N; a++)
+          {
+            for (int b = 0; b < N; b++) cov.E[a][b] = (double)r[a * N + b];
+            cov.y[a] = (double)r[N * N + a];
+          }
+          cov.pixAcc = (double)r[N * N + N];
+          self->m_alfCovarianceFrame[chType][shape][k] += cov;
+        }
+    };
+    fill(0, 0, all.data() + n7, 25, 7);               // luma shape 0 = 5x5, shape 1 = 7x7 (m_filterShapes order)
+    fill(0, 1, all.data(), 25, 13);
+    fill(1, 0, all.data() + n7 + n5, 1, 7);
+    fill(2, 0, all.data() + n7 + n5 + nc, 1, 7);
+    g_calls[4]++;
+    return 1;
+  }
+  if (g_res.alfCollect) return 0;                        // entered resident but not servable so: reference body (the host temp picture was synced at entry)
   g_a.upload(orgYuv);
   g_b.upload(recYuv);
   // classifier of the luma plane as one uint16 per 4x4 block (class | transposeIdx << 8)
@@ -550,12 +749,17 @@ struct BlockPlanes
   }
 };
 BlockPlanes g_blk;
+// the reference's own table entries (what initAdaptiveLoopFilterX86 installed), for the picture-level-only configuration
+void (*g_cpuAlfFilter[2])(AlfClassifier**, const PelUnitBuf&, const CPelUnitBuf&, const Area&, const ComponentID, short*, const ClpRng&) = { nullptr, nullptr };
+void (*g_cpuAlfClassify)(AlfClassifier**, int**[NUM_DIRECTIONS], const CPelBuf&, const Area&, const int) = nullptr;
 
 // table slots m_filter5x5Blk / m_filter7x7Blk (AdaptiveLoopFilter.h:91-92; installed by the constructor, AdaptiveLoopFilter.cpp:57-63)
 template <int IS7>
 void gpuFilterBlk(AlfClassifier** classifier, const PelUnitBuf& recDst, const CPelUnitBuf& recSrc, const Area& blk, const ComponentID compId,
                   short* filterSet, const ClpRng& clpRng)
 {
+  if (g_res.alfCollect) { g_calls[6]++; return; }        // resident form: the picture is filtered once when ALFProcess returns (wrap_EncALFProcess)
+  if (g_cpuAlfFilter[IS7] && getenv("VVCGPU_SHIM_NO_TABLES")) { g_cpuAlfFilter[IS7](classifier, recDst, recSrc, blk, compId, filterSet, clpRng); return; }
   const CPelBuf& srcB = recSrc.get(compId);
   const PelBuf& dstB = recDst.get(compId);
   const int pw = dstB.width, ph = dstB.height;
@@ -586,6 +790,30 @@ void gpuDeriveClassificationBlk(AlfClassifier** classifier, int** laplacian[NUM_
 {
   (void)laplacian;
   const int pw = srcLuma.width, ph = srcLuma.height;
+  if (g_res.alfCollect)
+  {
+    // resident form: ONE classification of the device picture per ALFProcess (the first slot call); the host array is filled for the whole
+    // picture from it, so the reference's later per-block calls find their result already there
+    if (g_res.clsUp) return;
+    const int w4 = pw >> 2, h4 = ph >> 2;
+    g_cls.reserve((size_t)w4 * h4);
+    VVCGPU(vvcgpu_alf_classify(resCur().p[0], resCur().stride[0], pw, ph, shift - 4, g_cls.ptr, nullptr));
+    std::vector<uint16_t> all((size_t)w4 * h4);
+    VVCGPU(vvcgpu_memcpy_d2h(all.data(), g_cls.ptr, all.size() * sizeof(uint16_t), nullptr));
+    VVCGPU(vvcgpu_stream_sync(nullptr));
+    for (int y = 0; y < ph; y += 4)
+      for (int x = 0; x < pw; x += 4)
+      {
+        const uint16_t c = all[(size_t)(y >> 2) * w4 + (x >> 2)];
+        const AlfClassifier v((uint8_t)(c & 0xff), (uint8_t)(c >> 8));
+        for (int yy = 0; yy < 4; yy++)
+          for (int xx = 0; xx < 4; xx++) classifier[y + yy][x + xx] = v;
+      }
+    g_res.clsUp = true;
+    g_calls[7]++;
+    return;
+  }
+  if (g_cpuAlfClassify && getenv("VVCGPU_SHIM_NO_TABLES")) { g_cpuAlfClassify(classifier, laplacian, srcLuma, blk, shift); return; }
   g_blk.ensure(pw, ph);
   // the classifier reads 2 rows / columns around each 4x4 block's 8x8 window: halo 4 covers it (the picture border is replicated
   // by the kernel exactly as extendBorderPel stored it in the reference's temporary picture)
@@ -616,7 +844,8 @@ void gpuDeriveClassificationBlk(AlfClassifier** classifier, int** laplacian[NUM_
 void wrap_initAlfX86(AdaptiveLoopFilter* self)
 {
   real_initAlfX86(self);
-  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return;
+  if (!shimEnabled() || (getenv("VVCGPU_SHIM_NO_TABLES") && !residentEnabled())) return;   // the resident picture-level form needs the three slots (deferred)
+  g_cpuAlfFilter[0] = self->m_filter5x5Blk; g_cpuAlfFilter[1] = self->m_filter7x7Blk; g_cpuAlfClassify = self->m_deriveClassificationBlk;
   self->m_filter5x5Blk = gpuFilterBlk<0>;
   self->m_filter7x7Blk = gpuFilterBlk<1>;
   self->m_deriveClassificationBlk = gpuDeriveClassificationBlk;
@@ -626,6 +855,30 @@ void wrap_initAlfX86(AdaptiveLoopFilter* self)
 void wrap_offsetCTU(SampleAdaptiveOffset* self, const UnitArea& area, const CPelUnitBuf& src, PelUnitBuf& res, SAOBlkParam& saoblkParam, CodingStructure& cs)
 {
   if (!shimEnabled()) { real_offsetCTU(self, area, src, res, saoblkParam, cs); return; }
+  if (g_res.saoCollect)
+  {
+    // resident form: record the CTU's reconstructed parameters; the picture is filtered once when SAOProcess returns (wrap_EncSAOProcess)
+    const PreCalcValues& pcvR = *cs.pcv;
+    const int ctu = (area.Y().y / pcvR.maxCUHeight) * pcvR.widthInCtus + area.Y().x / pcvR.maxCUWidth;
+    bool l, r, a, b, al, ar, bl, br;
+    self->deriveLoopFilterBoundaryAvailibility(cs, area.Y(), l, r, a, b, al, ar, bl, br);
+    const uint8_t av = (uint8_t)((l ? 1 : 0) | (r ? 2 : 0) | (a ? 4 : 0) | (b ? 8 : 0) | (al ? 16 : 0) | (ar ? 32 : 0) | (bl ? 64 : 0) | (br ? 128 : 0));
+    for (int c = 0; c < 3; c++)
+    {
+      const SAOOffset& o = saoblkParam[c];
+      vvcgpu_sao_ctu& q = g_res.sao[c][ctu];
+      q.type = (int8_t)(o.modeIdc == SAO_MODE_OFF ? -1 : o.typeIdc);
+      q.avail = av;
+      for (int k = 0; k < 32; k++) q.offset[k] = 0;
+      if (o.modeIdc != SAO_MODE_OFF)
+      {
+        for (int k = 0; k < (o.typeIdc == SAO_TYPE_BO ? 32 : (int)NUM_SAO_EO_CLASSES); k++) q.offset[k] = (int16_t)o.offset[k];
+        g_res.saoAny = true;
+      }
+    }
+    g_calls[5]++;
+    return;
+  }
   const int numberOfComponents = getNumberValidComponents(area.chromaFormat);
   bool allOff = true;
   for (int c = 0; c < numberOfComponents; c++) allOff = allOff && saoblkParam[c].modeIdc == SAO_MODE_OFF;
