@@ -33,6 +33,8 @@ CLIPS = [
     # dependent quantisation off, sign hiding on: every TU goes through QuantRDOQ::xRateDistOptQuant incl. its sign-hiding pass
     # hierarchical-B random access (own cfg, GOP 4): bi-predictive search / compensation inside the encoder
     ("rab_208x120_10b_q32", "@tests/golden/bitstreams/test_randomaccess.cfg", 208, 120, 10, 9, 32, 20261011),
+    # the reference's random-access parameter VALUES (GOP 16, intra period 32, search range 384 + ASR, IMV 2) in a repo-owned cfg: 17 pictures
+    ("ragop16_416x240_10b_q32", "@tests/golden/bitstreams/test_ra_gop16.cfg", 416, 240, 10, 17, 32, 20261012),
     ("ldprdoq_208x120_10b_q32", "@tests/golden/bitstreams/test_lowdelay.cfg", 208, 120, 10, 2, 32, 20261010, 1, ["--DepQuant=0", "--SignHideFlag=1"]),
 ]
 

@@ -36,42 +36,75 @@ def md5(path):
     return hashlib.md5(open(path, "rb").read()).hexdigest()
 
 
-def run(name, m, hip, tmp):
+LEGS = {  # label -> (use the drop-in library, VVCGPU_SHIM_HOOKS level, description)
+    "cpu": (0, None, "own SIMD kernels, 1 host core"),
+    "pic": (1, "pic", "library bound in, picture-level hooks only (resident reconstruction: deblock, SAO stats + apply, ALF classify + stats + filter)"),
+    "pu":  (1, "pu", "picture-level hooks + whole-PU searches (xTZSearch, xPatternSearchFracDIF, xPatternSearch), one round trip per PU"),
+    "all": (1, "all", "every hook, block-level table slots included (one synchronous round trip per call: the proof form)"),
+}
+
+
+def run(m, leg, tmp, limits0=False):
+    hip, level, _ = LEGS[leg]
     yuv = os.path.join(tmp, "in.yuv")
     if not os.path.exists(yuv):
         synth.write_yuv(yuv, synth.gen_yuv(m["w"], m["h"], m["frames"], m["bd"], m["seed"]), m["bd"])
     cfg = os.path.join(ROOT, m["cfg"][1:])
-    binf = os.path.join(tmp, "out_%d.bin" % hip)
+    binf = os.path.join(tmp, "out_%s.bin" % leg)
     cmd = [APP] + (["--hip"] if hip else []) + ["enc", "-c", cfg, "-i", yuv, "-wdt", str(m["w"]), "-hgt", str(m["h"]), "-fr", "30",
            "-f", str(m["frames"]), "-q", str(m["qp"]), "--InputBitDepth=%d" % m["bd"], "--InternalBitDepth=%d" % m["bd"],
            "--OutputBitDepth=%d" % m["bd"], "-b", binf, "-o", os.path.join(tmp, "rec.yuv"),
            "--SEIDecodedPictureHash=%d" % m.get("hash", 1)] + m.get("extra", [])
+    env = dict(os.environ)
+    if level:
+        env["VVCGPU_SHIM_HOOKS"] = level
+    if limits0:                                           # every call of the capped hooks is served (nightly-style run)
+        for k in ("INTRA", "FILL", "DEPQUANT", "RDOQ", "DQIT", "TZ"):
+            env["VVCGPU_SHIM_%s_LIMIT" % k] = "0"
     t0 = time.perf_counter()
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=3000)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=3300, env=env)
     dt = time.perf_counter() - t0
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    shim = [l for l in r.stderr.splitlines() if "[vvcgpu shim]" in l]
-    return dt, md5(binf) == m["bin_md5"], (shim[-1] if shim else "")
+    shim = [l for l in r.stderr.splitlines() if "[vvcgpu shim]" in l or "[vvcgpu resident]" in l]
+    return dt, md5(binf), shim
 
 
 def main():
-    name = "rab_208x120_10b_q32"
-    m = json.load(open(os.path.join(BS, "manifest.json")))[name]
-    print("M3: reference encoder (VTM 2.1 objects, unmodified), fixture %s: %dx%d %d-bit, %d pictures, QP %d, hierarchical-B random access (own cfg)"
-          % (name, m["w"], m["h"], m["bd"], m["frames"], m["qp"]))
-    proj_only = "--projection-only" in sys.argv
-    if proj_only:
-        sys.argv.remove("--projection-only")
+    import argparse
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--fixture", default="ragop16_416x240_10b_q32")
+    ap.add_argument("--legs", default="cpu,pic,pu")
+    ap.add_argument("--big", action="store_true", help="1920x1080, 3 pictures with the fixture's cfg (no committed bitstream: the legs are compared with the cpu leg)")
+    ap.add_argument("--uncapped", action="store_true", help="lift the call caps of the block-level hooks (leg all)")
+    ap.add_argument("--projection-only", action="store_true")
+    ap.add_argument("bench", nargs="?")
+    a = ap.parse_args()
+    if a.bench:
+        sys.argv = [sys.argv[0], a.bench]
+    else:
+        sys.argv = [sys.argv[0]]
+    if a.projection_only:
+        return projection()
+    m = dict(json.load(open(os.path.join(BS, "manifest.json")))[a.fixture])
+    want = m["bin_md5"]
+    if a.big:
+        m.update(w=1920, h=1080, frames=3)
+        want = None
+    print("M3: reference encoder (VTM 2.1 objects, unmodified), %s: %dx%d %d-bit, %d pictures, QP %d, cfg %s"
+          % (a.fixture + (" (picture size raised)" if a.big else ""), m["w"], m["h"], m["bd"], m["frames"], m["qp"], m["cfg"]))
     with tempfile.TemporaryDirectory() as tmp:
-        if proj_only:
-            return projection()
-        t_cpu, ok_cpu, _ = run(name, m, 0, tmp)
-        print("  (a) own SIMD kernels, 1 host core           : %7.2f s  = %.3f pictures/s   bitstream == fixture: %s" % (t_cpu, m["frames"] / t_cpu, ok_cpu))
-        t_hip, ok_hip, shim = run(name, m, 1, tmp)
-        print("  (b) drop-in library bound in (per-call round trips): %7.2f s  = %.3f pictures/s   bitstream == fixture: %s" % (t_hip, m["frames"] / t_hip, ok_hip))
-        print("      " + shim.strip())
-        print("      (b)/(a) wall time = %.2f: the block-level hooks make one synchronous launch + copy per call and exist to prove the boundary;" % (t_hip / t_cpu))
-        print("      the batched picture-level entry points (what bench.py times) are the production form.")
+        base = None
+        for leg in a.legs.split(","):
+            dt, h, shim = run(m, leg, tmp, a.uncapped and leg == "all")
+            if want is None and leg == "cpu":
+                want = h
+            ok = "n/a (no cpu leg)" if want is None else str(h == want)
+            if leg == "cpu":
+                base = dt
+            print("  (%-3s) %-70s: %8.2f s = %.3f pictures/s   bitstream identical: %s%s"
+                  % (leg, LEGS[leg][2][:70], dt, m["frames"] / dt, ok, "" if base is None or leg == "cpu" else "   wall time / cpu leg = %.2f" % (dt / base)))
+            for l in shim:
+                print("        " + l.strip())
     projection()
 
 

@@ -37,6 +37,7 @@
 #include "CommonLib/DepQuant.h"
 #include "CommonLib/AffineGradientSearch.h"
 #include "vvcgpu.h"
+#include "vtm_rates.h"
 
 #define VVCGPU(call) do { if ((call) != 0) THROW("vvcgpu: " << vvcgpu_last_error()); } while (0)
 
@@ -91,10 +92,8 @@ void wrap_initIntraPatternChType(IntraPrediction*, const CodingUnit&, const Comp
 // oracle/ref_hooks.cpp like the statistics entry points, not by ld --wrap
 extern "C" int vvcshim_depquant(DepQuant* self, TransformUnit* tu, const ComponentID* compID, const CCoeffBuf* pSrc, TCoeff* uiAbsSum, const QpParam* cQP,
                                 const Ctx* ctx);
-void vtmref_dq_rates_from_ctx(const TransformUnit& tu, ComponentID compID, const Ctx& ctx, vvcgpu_dq_rates* rt);   // oracle/ref_wrap_kernels.h
 extern "C" int vvcshim_rdoq(QuantRDOQ* self, TransformUnit* tu, const ComponentID* compID, const CCoeffBuf* pSrc, TCoeff* uiAbsSum, const QpParam* cQP,
                             const Ctx* ctx);
-void vtmref_rdoq_rates_from_ctx(const TransformUnit& tu, ComponentID compID, const Ctx& ctx, vvcgpu_rdoq_rates* rt);
 void real_extendPicBorder(Picture*) asm("__real__ZN7Picture15extendPicBorderEv");
 void wrap_extendPicBorder(Picture*) asm("__wrap__ZN7Picture15extendPicBorderEv");
 
@@ -107,6 +106,18 @@ extern "C" int vvcshim_alf_stats(EncAdaptiveLoopFilter* self, PelUnitBuf* orgYuv
 
 namespace {
 
+// which hooks serve calls: 0 = picture-level entry points only (VVCGPU_SHIM_HOOKS=pic, or the older VVCGPU_SHIM_NO_TABLES=1), 1 = + the whole-PU
+// searches (xTZSearch, xPatternSearchFracDIF, xPatternSearch: VVCGPU_SHIM_HOOKS=pu), 2 = every block-level hook as well (default)
+int hookLevel()
+{
+  static int lv = -1;
+  if (lv < 0)
+  {
+    const char* e = getenv("VVCGPU_SHIM_HOOKS");
+    lv = getenv("VVCGPU_SHIM_NO_TABLES") ? 0 : !e ? 2 : !strcmp(e, "pic") ? 0 : !strcmp(e, "pu") ? 1 : 2;
+  }
+  return lv;
+}
 bool shimEnabled()
 {
   static int on = -1;
@@ -759,7 +770,7 @@ void gpuFilterBlk(AlfClassifier** classifier, const PelUnitBuf& recDst, const CP
                   short* filterSet, const ClpRng& clpRng)
 {
   if (g_res.alfCollect) { g_calls[6]++; return; }        // resident form: the picture is filtered once when ALFProcess returns (wrap_EncALFProcess)
-  if (g_cpuAlfFilter[IS7] && getenv("VVCGPU_SHIM_NO_TABLES")) { g_cpuAlfFilter[IS7](classifier, recDst, recSrc, blk, compId, filterSet, clpRng); return; }
+  if (g_cpuAlfFilter[IS7] && (hookLevel() < 2)) { g_cpuAlfFilter[IS7](classifier, recDst, recSrc, blk, compId, filterSet, clpRng); return; }
   const CPelBuf& srcB = recSrc.get(compId);
   const PelBuf& dstB = recDst.get(compId);
   const int pw = dstB.width, ph = dstB.height;
@@ -813,7 +824,7 @@ void gpuDeriveClassificationBlk(AlfClassifier** classifier, int** laplacian[NUM_
     g_calls[7]++;
     return;
   }
-  if (g_cpuAlfClassify && getenv("VVCGPU_SHIM_NO_TABLES")) { g_cpuAlfClassify(classifier, laplacian, srcLuma, blk, shift); return; }
+  if (g_cpuAlfClassify && (hookLevel() < 2)) { g_cpuAlfClassify(classifier, laplacian, srcLuma, blk, shift); return; }
   g_blk.ensure(pw, ph);
   // the classifier reads 2 rows / columns around each 4x4 block's 8x8 window: halo 4 covers it (the picture border is replicated
   // by the kernel exactly as extendBorderPel stored it in the reference's temporary picture)
@@ -844,7 +855,7 @@ void gpuDeriveClassificationBlk(AlfClassifier** classifier, int** laplacian[NUM_
 void wrap_initAlfX86(AdaptiveLoopFilter* self)
 {
   real_initAlfX86(self);
-  if (!shimEnabled() || (getenv("VVCGPU_SHIM_NO_TABLES") && !residentEnabled())) return;   // the resident picture-level form needs the three slots (deferred)
+  if (!shimEnabled() || ((hookLevel() < 2) && !residentEnabled())) return;   // the resident picture-level form needs the three slots (deferred)
   g_cpuAlfFilter[0] = self->m_filter5x5Blk; g_cpuAlfFilter[1] = self->m_filter7x7Blk; g_cpuAlfClassify = self->m_deriveClassificationBlk;
   self->m_filter5x5Blk = gpuFilterBlk<0>;
   self->m_filter7x7Blk = gpuFilterBlk<1>;
@@ -951,7 +962,7 @@ Distortion gpuDist64(const DistParam& p)
 void wrap_initRdCostX86(RdCost* self)
 {
   real_initRdCostX86(self);
-  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return;
+  if (!shimEnabled() || (hookLevel() < 2)) return;
   if (!g_cpuDist[0]) { g_cpuDist[0] = RdCost::m_afpDistortFunc[DF_SAD64]; g_cpuDist[1] = RdCost::m_afpDistortFunc[DF_HAD64]; g_cpuDist[2] = RdCost::m_afpDistortFunc[DF_SSE64]; }
   RdCost::m_afpDistortFunc[DF_SAD64] = gpuDist64<0>;
   RdCost::m_afpDistortFunc[DF_HAD64] = gpuDist64<1>;
@@ -1006,7 +1017,7 @@ void installIf(IfFn (&slots)[3][2][2])
 void wrap_initIfX86(InterpolationFilter* self)
 {
   real_initIfX86(self);
-  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return;
+  if (!shimEnabled() || (hookLevel() < 2)) return;
   installIf<0, 0>(self->m_filterHor); installIf<0, 1>(self->m_filterHor); installIf<0, 2>(self->m_filterHor);
   installIf<1, 0>(self->m_filterVer); installIf<1, 1>(self->m_filterVer); installIf<1, 2>(self->m_filterVer);
 }
@@ -1055,7 +1066,7 @@ void gpuLinTf8(const Pel* s0, int st0, Pel* dst, int ds, int w, int h, int scale
 void wrap_initPelBufX86(PelBufferOps* self)
 {
   real_initPelBufX86(self);
-  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return;
+  if (!shimEnabled() || (hookLevel() < 2)) return;
   if (self->addAvg8 != gpuAddAvg8) { g_cpuPel.addAvg8 = self->addAvg8; g_cpuPel.reco8 = self->reco8; g_cpuPel.linTf8 = self->linTf8; }
   self->addAvg8 = gpuAddAvg8; self->reco8 = gpuReco8; self->linTf8 = gpuLinTf8;
 }
@@ -1083,7 +1094,7 @@ int trCode(int t) { return t == DCT2 ? 0 : t == DCT8 ? 1 : 2; }
 extern "C" int vvcshim_tr_fwd(int bd, const Pel* resi, size_t stride, TCoeff* coeff, int w, int h, int maxLog2, unsigned char ucMode, unsigned char ucTrIdx, bool useQTBT)
 {
   int hor, ver;
-  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES") || !useQTBT || maxLog2 != 15 || bd > 10 || (w < 32 && h < 32) || !trTypes(ucMode, ucTrIdx, hor, ver)) return 0;
+  if (!shimEnabled() || (hookLevel() < 2) || !useQTBT || maxLog2 != 15 || bd > 10 || (w < 32 && h < 32) || !trTypes(ucMode, ucTrIdx, hor, ver)) return 0;
   g_tResi.reserve((size_t)64 * 64);
   g_tCoef.reserve((size_t)64 * 64);
   VVCGPU(vvcgpu_memcpy2d_h2d(g_tResi.ptr, (size_t)w * sizeof(vvc_pel), resi, stride * sizeof(Pel), (size_t)w * sizeof(Pel), h, nullptr));
@@ -1103,7 +1114,7 @@ extern "C" int vvcshim_tr_inv(int bd, const TCoeff* coeff, Pel* resi, size_t str
 {
   int hor, ver;
   const unsigned zw = w > 32 ? w - 32 : 0, zh = h > 32 ? h - 32 : 0;         // the zero-out the kernels assume (xIT, :755-759)
-  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES") || maxLog2 != 15 || bd > 10 || (w < 32 && h < 32) || skipW != zw || skipH != zh ||
+  if (!shimEnabled() || (hookLevel() < 2) || maxLog2 != 15 || bd > 10 || (w < 32 && h < 32) || skipW != zw || skipH != zh ||
       !trTypes(ucMode, ucTrIdx, hor, ver)) return 0;
   g_tResi.reserve((size_t)64 * 64);
   g_tCoef.reserve((size_t)64 * 64);
@@ -1130,7 +1141,7 @@ DevArray<vvcgpu_frac_result> g_fRes;
 extern "C" int vvcshim_frac(InterSearch* self, const PredictionUnit* pu, int /*eRefPicList*/, int /*iRefIdx*/, InterSearch::IntTZSearchStruct* cs,
                             const Mv* mvInt, Mv* mvHalf, Mv* mvQter, Distortion* cost)
 {
-  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return 0;
+  if (!shimEnabled() || hookLevel() < 1) return 0;
   const CPelBuf& key = *cs->pcPatternKey;
   const int w = key.width, h = key.height, bd = self->m_lumaClpRng.bd;
 #if JVET_K0157
@@ -1178,7 +1189,7 @@ DevArray<vvcgpu_search_best> g_sBest;
 
 extern "C" int vvcshim_fullsearch(InterSearch* self, InterSearch::IntTZSearchStruct* cs, Mv* rcMv, Distortion* ruiSAD)
 {
-  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return 0;
+  if (!shimEnabled() || hookLevel() < 1) return 0;
   const CPelBuf& key = *cs->pcPatternKey;
   const int w = key.width, h = key.height, bd = self->m_lumaClpRng.bd;
   const InterSearch::SearchRange& sr = cs->searchRange;
@@ -1229,7 +1240,7 @@ DevArray<vvcgpu_search_best> g_zBest;
 extern "C" int vvcshim_tzsearch(InterSearch* self, const PredictionUnit* pu, InterSearch::IntTZSearchStruct* cs, Mv* rcMv, Distortion* ruiSAD,
                                 const Mv* pInt2Nx2N, bool bExtended, bool bFast)
 {
-  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return 0;
+  if (!shimEnabled() || hookLevel() < 1) return 0;
   static const long limit = getenv("VVCGPU_SHIM_TZ_LIMIT") ? atol(getenv("VVCGPU_SHIM_TZ_LIMIT")) : 0;
   if (limit > 0 && g_calls[20] >= limit) return 0;
   const CPelBuf& key = *cs->pcPatternKey;
@@ -1316,7 +1327,7 @@ void wrap_predIntraAng(IntraPrediction* self, const ComponentID compId, PelBuf& 
   const ChannelType chType = toChannelType(compID);
   const int w = piPred.width, h = piPred.height;
   static const long limit = getenv("VVCGPU_SHIM_INTRA_LIMIT") ? atol(getenv("VVCGPU_SHIM_INTRA_LIMIT")) : 60000;
-  bool ok = shimEnabled() && !getenv("VVCGPU_SHIM_NO_TABLES") && w >= 4 && h >= 4 && w <= 64 && h <= 64 && !(w & (w - 1)) && !(h & (h - 1)) &&
+  bool ok = shimEnabled() && !(hookLevel() < 2) && w >= 4 && h >= 4 && w <= 64 && h <= 64 && !(w & (w - 1)) && !(h & (h - 1)) &&
             !(limit > 0 && g_calls[21] >= limit);
   int T = 0, L = 0;
   if (ok) { VVCGPU(vvcgpu_intra_ref_lengths(w, h, &T, &L)); ok = T == self->m_topRefLength && L == self->m_leftRefLength; }
@@ -1369,7 +1380,7 @@ int sideUnitsAvailable(const CodingUnit& cu, ChannelType chType, const Position&
 void wrap_predIntraChromaLM(IntraPrediction* self, const ComponentID compID, PelBuf& piPred, const PredictionUnit& pu, const CompArea& chromaArea, int intraDir)
 {
   const char* dump = getenv("VVCGPU_CCLM_DUMP");
-  const bool gpu = shimEnabled() && !getenv("VVCGPU_SHIM_NO_TABLES");
+  const bool gpu = shimEnabled() && !(hookLevel() < 2);
   const int w = chromaArea.width, h = chromaArea.height;
   bool ok = (gpu || dump) && pu.chromaFormat == CHROMA_420 && w >= 2 && h >= 2 && w <= 64 && h <= 64 && !(w & (w - 1)) && !(h & (h - 1)) &&
             (int)piPred.width == w && (int)piPred.height == h;
@@ -1466,7 +1477,7 @@ bool unitAvailable(const CodingUnit& cu, ChannelType chType, const Position& ref
 void wrap_initIntraPatternChType(IntraPrediction* self, const CodingUnit& cu, const CompArea& area, const bool bFilterRefSamples)
 {
   const char* dump = getenv("VVCGPU_FILL_DUMP");
-  const bool gpu = shimEnabled() && !getenv("VVCGPU_SHIM_NO_TABLES");
+  const bool gpu = shimEnabled() && !(hookLevel() < 2);
   const int w = area.width, h = area.height;
   static const long limit = getenv("VVCGPU_SHIM_FILL_LIMIT") ? atol(getenv("VVCGPU_SHIM_FILL_LIMIT")) : 60000;
   if (!(gpu || dump) || w < 4 || h < 4 || w > 64 || h > 64 || (w & (w - 1)) || (h & (h - 1)) || (gpu && !dump && limit > 0 && g_calls[25] >= limit))
@@ -1570,7 +1581,7 @@ extern "C" int vvcshim_depquant(DepQuant* self, TransformUnit* tuP, const Compon
   const int w = area.width, h = area.height, n = w * h;
   const int bd = tu.cs->sps->getBitDepth(toChannelType(compID));
   static const long limit = getenv("VVCGPU_SHIM_DEPQUANT_LIMIT") ? atol(getenv("VVCGPU_SHIM_DEPQUANT_LIMIT")) : 20000;
-  const bool ok = shimEnabled() && !getenv("VVCGPU_SHIM_NO_TABLES") && tu.cs->slice->getDepQuantEnabledFlag() && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
+  const bool ok = shimEnabled() && !(hookLevel() < 2) && tu.cs->slice->getDepQuantEnabledFlag() && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
                   !(w & (w - 1)) && !(h & (h - 1)) && bd >= 8 && bd <= 10 && (int)pSrc.stride == w && !(limit > 0 && g_calls[26] >= limit) &&
                   !tu.cs->sps->getSpsRangeExtension().getExtendedPrecisionProcessingFlag();
   if (!ok) return 0;
@@ -1622,7 +1633,7 @@ extern "C" int vvcshim_rdoq(QuantRDOQ* self, TransformUnit* tuP, const Component
   const int bd = tu.cs->sps->getBitDepth(toChannelType(compID));
   static const long limit = getenv("VVCGPU_SHIM_RDOQ_LIMIT") ? atol(getenv("VVCGPU_SHIM_RDOQ_LIMIT")) : 20000;
   const bool useRDOQ = tu.transformSkip[compID] ? self->m_useRDOQTS : self->m_useRDOQ;               // the dispatch of :652-690
-  const bool ok = shimEnabled() && !getenv("VVCGPU_SHIM_NO_TABLES") && useRDOQ && !self->m_useSelectiveRDOQ && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
+  const bool ok = shimEnabled() && !(hookLevel() < 2) && useRDOQ && !self->m_useSelectiveRDOQ && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
                   !(w & (w - 1)) && !(h & (h - 1)) && bd >= 8 && bd <= 10 && (int)pSrc.stride == w && !(limit > 0 && g_calls[27] >= limit) &&
                   !tu.cs->sps->getSpsRangeExtension().getExtendedPrecisionProcessingFlag();
   if (!ok) return 0;
@@ -1665,7 +1676,7 @@ namespace { DevArray<vvc_pel> g_bPlane; }
 
 void wrap_extendPicBorder(Picture* self)
 {
-  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) { real_extendPicBorder(self); return; }
+  if (!shimEnabled() || (hookLevel() < 2)) { real_extendPicBorder(self); return; }
   if (self->m_bIsBorderExtended) return;
   for (int comp = 0; comp < (int)getNumberValidComponents(self->cs->area.chromaFormat); comp++)
   {
@@ -1693,7 +1704,7 @@ namespace { DevArray<vvc_pel> g_hPlane; DevArray<uint32_t> g_hOut; }
 
 extern "C" int vvcshim_pichash(int method, const CPelUnitBuf* pic, PictureHash* digest, const BitDepths* bitDepths)
 {
-  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return 0;
+  if (!shimEnabled() || (hookLevel() < 2)) return 0;
   digest->hash.clear();
   for (uint32_t chan = 0; chan < (uint32_t)pic->bufs.size(); chan++)
   {
@@ -1729,7 +1740,7 @@ void wrap_invTransformNxN(TrQuant* self, TransformUnit& tu, const ComponentID& c
   const int w = area.width, h = area.height;
   const int bd = tu.cs->sps->getBitDepth(toChannelType(compID));
   int hor = DCT2, ver = DCT2;
-  bool ok = shimEnabled() && !getenv("VVCGPU_SHIM_NO_TABLES") && !tu.cu->transQuantBypass && !CU::isRDPCMEnabled(*tu.cu) && bd <= 10 && bd >= 8 &&
+  bool ok = shimEnabled() && !(hookLevel() < 2) && !tu.cu->transQuantBypass && !CU::isRDPCMEnabled(*tu.cu) && bd <= 10 && bd >= 8 &&
             self->m_rectTUs && tu.cs->sps->getMaxLog2TrDynamicRange(toChannelType(compID)) == 15 && w >= 2 && h >= 2 && w <= 64 && h <= 64 &&
             !(w & (w - 1)) && !(h & (h - 1));
   // an encoder reconstructs a TU for every rate-distortion candidate (1.2 - 1.7 million calls on the 2-3 frame test clips, all
@@ -1803,7 +1814,7 @@ void gpuEqualCoeff(Pel* pResidue, int /*residueStride*/, int** ppDerivate, int d
 void wrap_initAgsX86(AffineGradientSearch* self)
 {
   real_initAgsX86(self);
-  if (!shimEnabled() || getenv("VVCGPU_SHIM_NO_TABLES")) return;
+  if (!shimEnabled() || (hookLevel() < 2)) return;
   self->m_HorizontalSobelFilter = gpuSobel<0>;
   self->m_VerticalSobelFilter = gpuSobel<1>;
   self->m_EqualCoeffComputer = gpuEqualCoeff;
