@@ -323,6 +323,42 @@ typedef struct vvcgpu_resi_chain_desc {
 int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, vvc_pel* rec_base, vvc_coef* level_base,
                             const vvcgpu_resi_chain_desc* descs, int n, int bit_depth, int clp_min, int clp_max, uint32_t* abs_sum,
                             void* stream);
+/* ---- T3: residual DPCM of transform-skipped / lossless TUs  (TrQuant::applyForwardRDPCM, CommonLib/TrQuant.cpp:991-1045, with
+ *          Quant::transformSkipQuantOneSample / invTrSkipDeQuantOneSample, Quant.cpp:911-1090; TrQuant::invRdpcmNxN, TrQuant.cpp:632-688).
+ *          A range-extension tool (CU::isRDPCMEnabled, UnitTools.cpp:105-108): off in the shipped cfgs, here for completeness of row T3. --------
+ * mode: 0 off, 1 horizontal, 2 vertical (RDPCMMode).  fwd: per sample delta = residual - reconstructed running sum of its line, level =
+ * transform-skip quantiser of the delta (rounding offset 256 when mode != 0, else 171 / 85 by slice type), coefficient index reversed when
+ * `rotate` (TU::isNonTransformedResidualRotated); lossless: level = delta.  abs_sum[i] = sum |level| (32-bit, as the reference's uiAbsSum).
+ * inv: in place, every sample after the first of a line becomes the clipped running sum of the line.                                        */
+typedef struct vvcgpu_rdpcm_desc {
+  int64_t resi_off, coeff_off;          /* elements from resi_base (Pel) / coeff_base (TCoeff, W x H contiguous) */
+  int32_t resi_stride;
+  int16_t w, h;
+  int8_t  mode, lossless, rotate, intra_slice;
+  int32_t qp;                           /* QpParam::Qp */
+  int32_t reserved;                     /* sizeof == 40 */
+} vvcgpu_rdpcm_desc;
+int vvcgpu_rdpcm_fwd_batch(const vvc_pel* resi_base, vvc_coef* coeff_base, const vvcgpu_rdpcm_desc* descs, int n, int bit_depth, uint32_t* abs_sum,
+                           void* stream);
+int vvcgpu_rdpcm_inv_batch(vvc_pel* resi_base, const vvcgpu_rdpcm_desc* descs, int n, void* stream);
+/* ---- I3: affine sub-block motion vectors on the device  (InterPrediction::xPredAffineBlk, CommonLib/InterPrediction.cpp:550-722: the per
+ *          4x4 (chroma 2x2) sub-block vector from the control-point vectors, roundAffineMv (Mv.cpp:56-61), the clip of :675-676, the split into
+ *          integer position and 1/16 (chroma 1/32) phase :681-701) -------------------------------------------------------------------------
+ * One vvcgpu_affine_pu per PU; the kernel writes one vvcgpu_mc_desc per sub-block (w/4 x h/4 of them, row-major, starting at first_desc), ready for
+ * vvcgpu_mc_batch: the caller no longer derives sub-block vectors on the host.  Control-point vectors are in 1/16 luma sample units (Mv::setHighPrec).
+ * comp 0: luma descriptors (4x4), 1: chroma descriptors (2x2, phase in 1/32).  ref_origin: position of picture sample (0,0) inside the reference
+ * plane of that component (its margin), so that ref offsets address the padded plane.  bi = 1: both lists (ref0 / ref1), else list 0 only
+ * (bi field of the descriptors: 1 / 0).                                                                                                     */
+typedef struct vvcgpu_affine_pu {
+  int32_t pos_x, pos_y;                 /* luma position of the PU */
+  int16_t w, h;                         /* luma size */
+  int16_t six_param, bi;
+  int32_t mv[2][3][2];                  /* [list][LT, RT, LB][hor, ver] */
+  int64_t dst_off;                      /* elements from dst_base of the component */
+  int32_t dst_stride, first_desc;       /* sizeof == 80 */
+} vvcgpu_affine_pu;
+int vvcgpu_affine_subblock_descs(const vvcgpu_affine_pu* pus, int n, int comp, int pic_w, int pic_h, int max_cu_w, int max_cu_h,
+                                 int ref_origin_x, int ref_origin_y, int ref0_stride, int ref1_stride, vvcgpu_mc_desc* out, void* stream);
 /* ---- picture-level forms of the in-loop entry points: the three planes of a 4:2:0 picture in ONE launch each.  A chroma plane of a 4K picture is
  *          about one workgroup per CU, so a launch of its own costs its latency floor; these are also the forms a binding uses that keeps the
  *          reconstruction resident on the device across loopFilterPic -> SAOProcess -> ALFProcess (EncGOP.cpp:2122-2153, DecLib.cpp:506-533).

@@ -376,6 +376,126 @@ int vtmref_transform_skip(int inverse, int bd, Pel* resi, int stride, TCoeff* co
   }
   return 0;
 }
+// Residual DPCM (row T3): the reference's own TrQuant::applyForwardRDPCM / invRdpcmNxN (TrQuant.cpp:991-1045, 632-688; private, reached with
+// -fno-access-control) on a TransformUnit of an INTER CU (the mode then comes from tu.rdpcm, no PredictionUnit is read).  The zero-filled
+// CodingStructure carries the SPS (bit depth, range-extension flags), the slice type and the residual buffer applyForwardRDPCM fetches itself.
+int vtmref_rdpcm(int inverse, int bd, int qp, int mode, int lossless, int rotate, int intraSlice, Pel* resi, int stride, int w, int h, TCoeff* coef,
+                 uint32_t* absSum)
+{
+  static SPS* sps = nullptr;
+  static PPS* pps = nullptr;
+  static CodingStructure* cs = nullptr;
+  static Slice* slice = nullptr;
+  static TrQuant* tq = nullptr;
+  static CodingUnit* cu = nullptr;
+  if (!sps)
+  {
+    sps = new SPS; pps = new PPS; slice = new Slice;
+    cs = static_cast<CodingStructure*>(calloc(1, sizeof(CodingStructure)));
+    cs->sps = sps; cs->pps = pps; cs->slice = slice;
+    cs->parent = cs;                                    // a "sub-structure": getBuf does not fold the position into a CTU
+    tq = new TrQuant;
+    tq->init(nullptr, 64, false, false, false, true, false, true);     // plain Quant (no RDOQ): the one-sample functions are Quant's own
+    cu = new CodingUnit;
+    cu->cs = cs;
+  }
+  sps->setBitDepth(CHANNEL_TYPE_LUMA, bd);
+  sps->getSpsRangeExtension().setRdpcmEnabledFlag(RDPCM_SIGNAL_EXPLICIT, true);
+  sps->getSpsRangeExtension().setRdpcmEnabledFlag(RDPCM_SIGNAL_IMPLICIT, true);
+  sps->getSpsRangeExtension().setTransformSkipRotationEnabledFlag(rotate != 0);
+  slice->setSliceType(intraSlice ? I_SLICE : B_SLICE);
+  // the rotation applies to 4-wide intra TUs only (TU::isNonTransformedResidualRotated): intra prediction mode for `rotate`, inter otherwise
+  cu->predMode = rotate ? MODE_INTRA : MODE_INTER;
+  cu->transQuantBypass = lossless != 0;
+  TransformUnit tu(CHROMA_400, Area(0, 0, w, h));
+  tu.cs = cs; tu.cu = cu;
+  tu.m_coeffs[COMPONENT_Y] = coef;
+  tu.transformSkip[COMPONENT_Y] = lossless ? 0 : 1;
+  tu.rdpcm[COMPONENT_Y] = RDPCMMode(mode);
+  const_cast<UnitArea&>(cs->area) = UnitArea(CHROMA_400, Area(0, 0, w, h));
+  cs->m_resi.chromaFormat = CHROMA_400;
+  cs->m_resi.bufs.clear();
+  cs->m_resi.bufs.push_back(PelBuf(resi, stride, w, h));
+  QpParam* q = static_cast<QpParam*>(malloc(sizeof(QpParam)));
+  q->Qp = qp; q->per = qp / 6; q->rem = qp % 6;
+  if (!inverse)
+  {
+    TCoeff sum = 0;
+    tq->applyForwardRDPCM(tu, COMPONENT_Y, *q, sum, RDPCMMode(mode));
+    *absSum = (uint32_t)sum;
+  }
+  else
+  {
+    PelBuf rb(resi, stride, w, h);
+    tq->invRdpcmNxN(tu, COMPONENT_Y, rb);
+  }
+  free(q);
+  return 0;
+}
+// Affine motion compensation of one component of a PU by the reference's own InterPrediction::xPredAffineBlk (InterPrediction.cpp:550-722;
+// private): sub-block vector derivation + the interpolation of every sub-block, from a real Picture filled with the given planes.  mv6 = LT, RT, LB
+// as (hor, ver) in 1/16 sample.  bi = 0: final rounded prediction; bi = 1: the 14-bit intermediate of a bi-predictive list.
+int vtmref_affine_pred(int comp, int picW, int picH, int bd, const Pel* recY, const Pel* recCb, const Pel* recCr, int posX, int posY, int w, int h,
+                       const int* mv6, int sixParam, int bi, Pel* dst, int dstStride)
+{
+  static SPS* sps = nullptr;
+  static CodingStructure* cs = nullptr;
+  static PreCalcValues* pcv = nullptr;
+  static CodingUnit* cu = nullptr;
+  static InterPrediction* ip = nullptr;
+  static RdCost* rc = nullptr;
+  if (!sps)
+  {
+    sps = new SPS;
+    cs = static_cast<CodingStructure*>(calloc(1, sizeof(CodingStructure)));
+    cs->sps = sps;
+    cu = new CodingUnit;
+    cu->cs = cs;
+    rc = new RdCost;
+    ip = new InterPrediction;
+    ip->init(rc, CHROMA_420);
+  }
+  sps->setBitDepth(CHANNEL_TYPE_LUMA, bd); sps->setBitDepth(CHANNEL_TYPE_CHROMA, bd);
+  sps->setPicWidthInLumaSamples(picW); sps->setPicHeightInLumaSamples(picH);
+  sps->setMaxCUWidth(128); sps->setMaxCUHeight(128);
+  delete pcv;
+  pcv = new PreCalcValues(*sps, *(new PPS), true);
+  cs->pcv = pcv;
+  Picture pic;
+  pic.create(CHROMA_420, Size(picW, picH), 128, 128 + 16, false);
+  pic.cs = (CodingStructure*)calloc(1, sizeof(CodingStructure));
+  const_cast<ChromaFormat&>(pic.cs->area.chromaFormat) = CHROMA_420;
+  const Pel* in[3] = { recY, recCb, recCr };
+  for (int c = 0; c < 3; c++)
+  {
+    PelBuf b = pic.getRecoBuf().get(ComponentID(c));
+    for (int j = 0; j < (int)b.height; j++) memcpy(b.buf + (ptrdiff_t)j * b.stride, in[c] + (size_t)j * b.width, b.width * sizeof(Pel));
+  }
+  pic.m_bIsBorderExtended = false;
+  pic.extendPicBorder();
+  const UnitArea ua(CHROMA_420, Area(posX, posY, w, h));
+  PredictionUnit pu(ua);
+  pu.cs = cs; pu.cu = cu; pu.chromaFormat = CHROMA_420;
+  static_cast<UnitArea&>(*cu) = ua;
+  cu->affine = true;
+  cu->affineType = sixParam ? AFFINEMODEL_6PARAM : AFFINEMODEL_4PARAM;
+  Mv mv[3];
+  for (int k = 0; k < 3; k++) mv[k] = Mv(mv6[2 * k], mv6[2 * k + 1], true);
+  std::vector<Pel> scratch[3];
+  PelUnitBuf dstPic;
+  dstPic.chromaFormat = CHROMA_420;
+  for (int c = 0; c < 3; c++)
+  {
+    const int cw = c ? w >> 1 : w, ch = c ? h >> 1 : h;
+    if (c == comp) dstPic.bufs.push_back(PelBuf(dst, dstStride, cw, ch));
+    else { scratch[c].assign((size_t)cw * ch, 0); dstPic.bufs.push_back(PelBuf(scratch[c].data(), cw, cw, ch)); }
+  }
+  ClpRng clp = mkClp(0, (1 << bd) - 1, bd);
+  ip->xPredAffineBlk(ComponentID(comp), pu, &pic, mv, dstPic, bi != 0, clp);
+  free(pic.cs); pic.cs = nullptr;
+  pic.destroy();
+  return 0;
+}
 // De-quantisation (next row N1): Quant::dequant (Quant.cpp:277-428, flat scaling) and the dependent-quantisation state
 // machine DQIntern::Quantizer::dequantBlock (DepQuant.cpp:708-785) through DepQuant::dequant (:1423-1433).  Both take a
 // TransformUnit; the zero-filled CodingStructure of vtmref_transform_skip plus a Slice (DepQuant flag) and a CodingUnit

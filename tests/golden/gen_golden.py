@@ -263,6 +263,64 @@ def gen_dequant():
     save("dequant", **out)
 
 
+def gen_rdpcm():
+    """residual DPCM (row T3) through the reference's own TrQuant::applyForwardRDPCM / invRdpcmNxN (oracle/ref_wrap_kernels.h:vtmref_rdpcm):
+    every mode x lossless x rotation (4-wide) x slice type at 8 and 10 bit, small and saturating residuals."""
+    rng = np.random.default_rng(1021)
+    rows, resis, coefs, sums, invin, invout = [], [], [], [], [], []
+    for bd in (8, 10):
+        for (w, h) in [(4, 4), (8, 8), (16, 16), (32, 32), (4, 8), (8, 4), (4, 16), (16, 4), (32, 8)]:
+            for mode in (0, 1, 2):
+                for lossless in (0, 1):
+                    for rot in ((0, 1) if w == 4 else (0,)):
+                        for intra in (0, 1):
+                            qp = int(rng.integers(12, 45)) + 6 * (bd - 8)
+                            amp = int(rng.choice([3, 40, 600, 1023]))
+                            r = rng.integers(-amp, amp + 1, (h, w)).astype(np.int16)
+                            c = np.zeros(w * h, np.int32)
+                            sm = np.zeros(1, np.uint32)
+                            rin = r.copy()                         # (a named array: the pointer must outlive the call)
+                            R.vtmref_rdpcm(0, bd, qp, mode, lossless, rot, intra, p(rin), w, w, h, p(c), p(sm))
+                            a = rng.integers(-3000, 3000, (h, w)).astype(np.int16)
+                            b = a.copy()
+                            if rot == 0:
+                                cdum, sdum = np.zeros(w * h, np.int32), np.zeros(1, np.uint32)
+                                R.vtmref_rdpcm(1, bd, qp, mode, lossless, 0, intra, p(b), w, w, h, p(cdum), p(sdum))
+                            rows.append((bd, w, h, mode, lossless, rot, intra, qp))
+                            resis.append(r.reshape(-1)); coefs.append(c); sums.append(int(sm[0])); invin.append(a.reshape(-1)); invout.append(b.reshape(-1))
+    save("rdpcm", rows=np.array(rows, np.int32), resi=np.concatenate(resis), coef=np.concatenate(coefs), abs_sum=np.array(sums, np.uint32),
+         inv_in=np.concatenate(invin), inv_out=np.concatenate(invout))
+
+
+def gen_affine_mv():
+    """affine sub-block vectors (row I3), pinned end to end: the reference's own InterPrediction::xPredAffineBlk (vtmref_affine_pred) predicts
+    luma, Cb and Cr of PUs with 4- and 6-parameter models from seeded planes; the tests derive the sub-block descriptors and run the
+    (separately pinned) block interpolation on them -- equal predictions pin the vectors, their rounding, clipping and the phase split."""
+    rng = np.random.default_rng(1022)
+    W, H, bd = 256, 128, 10
+    Y = rng.integers(0, 1024, (H, W)).astype(np.int16)
+    Cb = rng.integers(0, 1024, (H // 2, W // 2)).astype(np.int16)
+    Cr = rng.integers(0, 1024, (H // 2, W // 2)).astype(np.int16)
+    rows, preds = [], []
+    for trial in range(120):
+        w, h = int(rng.choice([8, 16, 32, 64, 128])), int(rng.choice([8, 16, 32, 64, 128]))
+        px, py = int(rng.integers(0, (W - w) // 4 + 1)) * 4, int(rng.integers(0, (H - h) // 4 + 1)) * 4
+        six = int(rng.integers(0, 2))
+        amp = int(rng.choice([8, 64, 400, 3000]))
+        mv = rng.integers(-amp, amp + 1, (3, 2)).astype(np.int32)
+        if trial % 7 == 0:
+            mv[1] = mv[0]; mv[2] = mv[0]
+        if trial % 11 == 0:
+            mv[0] = (-4000, 3000); mv[1] = (-4007, 3001); mv[2] = (-3990, 3005)
+        rows.append((px, py, w, h, six) + tuple(int(v) for v in mv.reshape(-1)))
+        for comp in range(3):
+            c = 1 if comp else 0
+            want = np.zeros((h >> c, w >> c), np.int16)
+            R.vtmref_affine_pred(comp, W, H, bd, p(Y), p(Cb), p(Cr), px, py, w, h, p(np.ascontiguousarray(mv.reshape(-1))), six, 0, p(want), w >> c)
+            preds.append(want.reshape(-1))
+    save("affine_mv", Y=Y, Cb=Cb, Cr=Cr, rows=np.array(rows, np.int32), pred=np.concatenate(preds))
+
+
 def gen_affine():
     """next row N3: Sobel derivative planes and equal-coefficient sums from the compiled reference's SIMD table slots."""
     rng = np.random.default_rng(1011)
@@ -502,6 +560,6 @@ def gen_rdoq():
 
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_frac, gen_tzsearch, gen_picture, gen_intra, gen_imv, gen_quant, gen_depquant, gen_rdoq):
+    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_rdpcm, gen_affine_mv, gen_frac, gen_tzsearch, gen_picture, gen_intra, gen_imv, gen_quant, gen_depquant, gen_rdoq):
         if not only or fn.__name__[4:] in only:
             fn()

@@ -1,0 +1,109 @@
+"""T3 residual DPCM and I3 affine sub-block vectors on the GPU against the golden vectors of the compiled reference (tests/golden/rdpcm.npz:
+TrQuant::applyForwardRDPCM / invRdpcmNxN; tests/golden/affine_mv.npz: InterPrediction::xPredAffineBlk) and against the oracle on fresh inputs."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from oraclelib import oracle, p
+
+pytestmark = pytest.mark.gpu
+G = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+
+
+def dev(a):
+    return torch.from_numpy(np.ascontiguousarray(a)).cuda()
+
+
+def test_rdpcm_golden():
+    from vvcsoftware_vtm_amd import ops
+    g = np.load(os.path.join(G, "rdpcm.npz"))
+    rows = g["rows"]
+    for bd in (8, 10):
+        sel = np.nonzero(rows[:, 0] == bd)[0]
+        offs = np.concatenate([[0], np.cumsum(rows[:, 1] * rows[:, 2])])
+        d = np.zeros(sel.size, ops.RDPCM_DESC)
+        for k, i in enumerate(sel):
+            _, w, h, mode, lossless, rot, intra, qp = rows[i]
+            d[k] = (offs[i], offs[i], w, w, h, mode, lossless, rot, intra, qp, 0, 0)
+        coef = torch.zeros(g["coef"].size, dtype=torch.int32, device="cuda")
+        s = ops.rdpcm_fwd_batch(dev(g["resi"]), coef, ops.struct_to_device(d), sel.size, bd).cpu().numpy().view(np.uint32)
+        c = coef.cpu().numpy()
+        for k, i in enumerate(sel):
+            assert np.array_equal(c[offs[i]:offs[i + 1]], g["coef"][offs[i]:offs[i + 1]]), rows[i]
+        assert np.array_equal(s, g["abs_sum"][sel])
+        # inverse, in place (rotation does not apply to it)
+        keep = [k for k, i in enumerate(sel) if rows[i][5] == 0]
+        r = dev(g["inv_in"])
+        ops.rdpcm_inv_batch(r, ops.struct_to_device(d[keep]), len(keep))
+        r = r.cpu().numpy()
+        for k in keep:
+            i = sel[k]
+            assert np.array_equal(r[offs[i]:offs[i + 1]], g["inv_out"][offs[i]:offs[i + 1]]), rows[i]
+
+
+def test_rdpcm_strided_blocks_vs_oracle():
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(8)
+    W, H, bd = 192, 96, 10
+    plane = rng.integers(-700, 701, (H, W)).astype(np.int16)
+    rows, off = [], 0
+    for y in range(0, H, 32):
+        for x in range(0, W, 32):
+            w, h = int(rng.choice([4, 8, 16, 32])), int(rng.choice([4, 8, 16, 32]))
+            rows.append((y * W + x, off, W, w, h, int(rng.integers(0, 3)), int(rng.integers(0, 2)), 0, int(rng.integers(0, 2)), int(rng.integers(20, 50)), 0, 0))
+            off += w * h
+    d = np.array(rows, dtype=ops.RDPCM_DESC)
+    want = np.zeros(off, np.int32); ws = np.zeros(d.size, np.uint32)
+    oracle().orc_rdpcm_fwd_batch(p(plane), p(want), p(d), d.size, bd, p(ws))
+    coef = torch.zeros(off, dtype=torch.int32, device="cuda")
+    s = ops.rdpcm_fwd_batch(dev(plane), coef, ops.struct_to_device(d), d.size, bd)
+    assert np.array_equal(coef.cpu().numpy(), want) and np.array_equal(s.cpu().numpy().view(np.uint32), ws)
+    inv = plane.copy()
+    oracle().orc_rdpcm_inv_batch(p(inv), p(d), d.size)
+    t = dev(plane)
+    ops.rdpcm_inv_batch(t, ops.struct_to_device(d), d.size)
+    assert np.array_equal(t.cpu().numpy(), inv)
+
+
+def test_affine_subblock_vectors_golden():
+    """the device-derived sub-block descriptors, interpolated by vvcgpu_mc_batch, reproduce the reference's own xPredAffineBlk prediction"""
+    from vvcsoftware_vtm_amd import ops
+    g = np.load(os.path.join(G, "affine_mv.npz"))
+    W, H, bd, M = 256, 128, 10, 144
+    planes = [g["Y"], g["Cb"], g["Cr"]]
+    pads = [np.ascontiguousarray(np.pad(pl, M >> (1 if c else 0), mode="edge")) for c, pl in enumerate(planes)]
+    dpads = [dev(a) for a in pads]
+    rows = g["rows"]
+    pos = 0
+    for comp in range(3):
+        c = 1 if comp else 0
+        pus = np.zeros(rows.shape[0], ops.AFFINE_PU)
+        first, dst_off = 0, 0
+        for i, r in enumerate(rows):
+            px, py, w, h, six = r[:5]
+            mv = np.zeros((2, 3, 2), np.int32); mv[0] = r[5:11].reshape(3, 2)
+            pus[i] = (px, py, w, h, six, 0, mv, dst_off, w >> c, first)
+            first += (w // 4) * (h // 4)
+            dst_off += (w >> c) * (h >> c)
+        descs = ops.affine_subblock_descs(ops.struct_to_device(pus), rows.shape[0], first, c, W, H, (M >> c, M >> c), pads[comp].shape[1], pads[comp].shape[1])
+        # against the oracle's derivation, field by field
+        want_d = np.zeros(first, ops.MC_DESC)
+        oracle().orc_affine_subblock_descs(p(pus), rows.shape[0], c, W, H, 128, 128, M >> c, M >> c, pads[comp].shape[1], pads[comp].shape[1], p(want_d))
+        assert np.array_equal(descs.cpu().numpy().view(ops.MC_DESC), want_d)
+        dst = torch.zeros(dst_off, dtype=torch.int16, device="cuda")
+        ops.mc_batch(dpads[comp], dpads[comp], dst, descs, first, bd, (0, 1023))
+        got = dst.cpu().numpy()
+        # golden predictions are stored PU by PU, component by component
+        o = 0
+        for i, r in enumerate(rows):
+            w, h = int(r[2]), int(r[3])
+            base = sum(((int(q[2]) * int(q[3])) + 2 * ((int(q[2]) >> 1) * (int(q[3]) >> 1))) for q in rows[:i])
+            if comp == 1:
+                base += w * h
+            elif comp == 2:
+                base += w * h + (w >> 1) * (h >> 1)
+            n = (w >> c) * (h >> c)
+            assert np.array_equal(got[o:o + n], g["pred"][base:base + n]), (i, comp)
+            o += n

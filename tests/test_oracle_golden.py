@@ -435,3 +435,51 @@ def test_rdoq_golden():
             O.orc_rdoq(p(coef), p(plain), w, h, 1 - comp, bd, qp, C.c_double(lam), 0, p(rt))
             changed += int(np.any(plain != lv))
     assert n > 100 and nz > 5000 and changed > 20          # the fixture exercises the sign-hiding adjustment too
+
+
+def test_rdpcm_golden():
+    """oracle/restate/rdpcm.cpp == TrQuant::applyForwardRDPCM / invRdpcmNxN of the compiled reference (tests/golden/rdpcm.npz)"""
+    g = np.load(os.path.join(G, "rdpcm.npz"))
+    RD = np.dtype([("resi_off", "<i8"), ("coeff_off", "<i8"), ("resi_stride", "<i4"), ("w", "<i2"), ("h", "<i2"), ("mode", "i1"), ("lossless", "i1"),
+                   ("rotate", "i1"), ("intra_slice", "i1"), ("qp", "<i4"), ("reserved", "<i4"), ("pad", "<i4")])
+    rows = g["rows"]
+    offs = np.concatenate([[0], np.cumsum(rows[:, 1] * rows[:, 2])])
+    for i, (bd, w, h, mode, lossless, rot, intra, qp) in enumerate(rows):
+        d = np.zeros(1, RD); d[0] = (0, 0, w, w, h, mode, lossless, rot, intra, qp, 0, 0)
+        resi = np.ascontiguousarray(g["resi"][offs[i]:offs[i + 1]])
+        c = np.zeros(w * h, np.int32); sm = np.zeros(1, np.uint32)
+        oracle().orc_rdpcm_fwd_batch(p(resi), p(c), p(d), 1, int(bd), p(sm))
+        assert np.array_equal(c, g["coef"][offs[i]:offs[i + 1]]) and sm[0] == g["abs_sum"][i], rows[i]
+        if rot == 0:
+            a = np.ascontiguousarray(g["inv_in"][offs[i]:offs[i + 1]])
+            oracle().orc_rdpcm_inv_batch(p(a), p(d), 1)
+            assert np.array_equal(a, g["inv_out"][offs[i]:offs[i + 1]]), rows[i]
+
+
+def test_affine_subblock_vectors_golden():
+    """oracle/restate/rdpcm.cpp:orc_affine_subblock_descs + the (pinned) block interpolation == InterPrediction::xPredAffineBlk of the compiled
+    reference on 120 PUs x 3 components (tests/golden/affine_mv.npz)"""
+    g = np.load(os.path.join(G, "affine_mv.npz"))
+    AP = np.dtype([("pos_x", "<i4"), ("pos_y", "<i4"), ("w", "<i2"), ("h", "<i2"), ("six_param", "<i2"), ("bi", "<i2"), ("mv", "<i4", (2, 3, 2)),
+                   ("dst_off", "<i8"), ("dst_stride", "<i4"), ("first_desc", "<i4")])
+    MC = np.dtype([("ref0_off", "<i8"), ("ref1_off", "<i8"), ("dst_off", "<i8"), ("ref0_stride", "<i4"), ("ref1_stride", "<i4"), ("dst_stride", "<i4"),
+                   ("w", "<i2"), ("h", "<i2"), ("frac_x0", "i1"), ("frac_y0", "i1"), ("frac_x1", "i1"), ("frac_y1", "i1"), ("is_luma", "i1"), ("bi", "i1"),
+                   ("reserved", "<i2")])
+    W, H, bd, M = 256, 128, 10, 144
+    pads = [np.ascontiguousarray(np.pad(g[k], M >> (1 if c else 0), mode="edge")) for c, k in enumerate(("Y", "Cb", "Cr"))]
+    o = 0
+    for r in g["rows"]:
+        px, py, w, h, six = [int(v) for v in r[:5]]
+        for comp in range(3):
+            c = 1 if comp else 0
+            mv = np.zeros((2, 3, 2), np.int32); mv[0] = r[5:11].reshape(3, 2)
+            pu = np.zeros(1, AP); pu[0] = (px, py, w, h, six, 0, mv, 0, w >> c, 0)
+            nd = (w // 4) * (h // 4)
+            d = np.zeros(nd, MC)
+            oracle().orc_affine_subblock_descs(p(pu), 1, c, W, H, 128, 128, M >> c, M >> c, pads[comp].shape[1], pads[comp].shape[1], p(d))
+            got = np.zeros((h >> c) * (w >> c), np.int16)
+            oracle().orc_mc_batch(p(pads[comp]), p(pads[comp]), p(got), p(d), nd, bd, 0, 1023)
+            n = got.size
+            assert np.array_equal(got, g["pred"][o:o + n]), (r.tolist(), comp)
+            o += n
+

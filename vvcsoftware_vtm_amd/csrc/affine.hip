@@ -116,6 +116,54 @@ __global__ __launch_bounds__(256) void affine_equal_coeff_kernel(const Pel* __re
   else             eq_block<4>(d, resiBase, gxBase, gyBase, o, lane);
 }
 
+// ---- affine sub-block motion vectors: the derivation loop of InterPrediction::xPredAffineBlk (InterPrediction.cpp:618-701) per sub-block, both lists
+__global__ __launch_bounds__(256) void affine_subblock_descs_kernel(const vvcgpu_affine_pu* __restrict__ pus, int n, int comp, int picW, int picH,
+                                                                    int maxCuW, int maxCuH, int orgX, int orgY, int rs0, int rs1,
+                                                                    vvcgpu_mc_desc* __restrict__ out)
+{
+  const int pi = blockIdx.x;
+  if (pi >= n) return;
+  const vvcgpu_affine_pu pu = pus[pi];
+  const int sc = comp ? 1 : 0;                                          // 4:2:0 component scale
+  const int bw = 4 >> sc, bh = 4 >> sc;                                  // AFFINE_MIN_BLOCK_SIZE, scaled (:585-586, :619-620)
+  const int cxW = pu.w >> sc, cxH = pu.h >> sc;
+  const int nbx = cxW / bw, nby = cxH / bh;
+  const int iBit = 7, shift = iBit - 4 + 2 + 2;                          // MAX_CU_DEPTH; :658
+  const int lgW = 31 - __clz(cxW), lgH = 31 - __clz(cxH);
+  const int horMax = (picW + 8 - pu.pos_x - 1) << 4, horMin = (-maxCuW - 8 - pu.pos_x + 1) << 4;
+  const int verMax = (picH + 8 - pu.pos_y - 1) << 4, verMin = (-maxCuH - 8 - pu.pos_y + 1) << 4;
+  for (int sb = threadIdx.x; sb < nbx * nby; sb += blockDim.x)
+  {
+    const int bxI = sb % nbx, byI = sb / nbx, wq = bxI * bw, hq = byI * bh;
+    vvcgpu_mc_desc d;
+    d.w = (int16_t)bw; d.h = (int16_t)bh; d.is_luma = comp ? 0 : 1; d.bi = pu.bi ? 1 : 0; d.reserved = 0;
+    d.dst_off = pu.dst_off + (int64_t)hq * pu.dst_stride + wq; d.dst_stride = pu.dst_stride;
+    d.ref0_stride = rs0; d.ref1_stride = rs1; d.ref1_off = 0; d.frac_x1 = 0; d.frac_y1 = 0;
+#pragma unroll
+    for (int l = 0; l < 2; l++)
+    {
+      if (l == 1 && !pu.bi) break;
+      const int ltx = pu.mv[l][0][0], lty = pu.mv[l][0][1];
+      const int dHorX = (pu.mv[l][1][0] - ltx) << (iBit - lgW), dHorY = (pu.mv[l][1][1] - lty) << (iBit - lgW);
+      int dVerX, dVerY;
+      if (pu.six_param) { dVerX = (pu.mv[l][2][0] - ltx) << (iBit - lgH); dVerY = (pu.mv[l][2][1] - lty) << (iBit - lgH); }
+      else { dVerX = -dHorY; dVerY = dHorX; }
+      int mh = (ltx << iBit) + dHorX * ((bw >> 1) + wq) + dVerX * ((bh >> 1) + hq);
+      int mvv = (lty << iBit) + dHorY * ((bw >> 1) + wq) + dVerY * ((bh >> 1) + hq);
+      const int off = 1 << (shift - 1);                                  // roundAffineMv
+      mh = mh >= 0 ? (mh + off) >> shift : -((-mh + off) >> shift);
+      mvv = mvv >= 0 ? (mvv + off) >> shift : -((-mvv + off) >> shift);
+      mh = min(horMax, max(horMin, mh));
+      mvv = min(verMax, max(verMin, mvv));
+      const int xInt = mh >> (4 + sc), xFrac = mh & (sc ? 31 : 15), yInt = mvv >> (4 + sc), yFrac = mvv & (sc ? 31 : 15);
+      const int64_t refOff = (int64_t)((pu.pos_y >> sc) + hq + yInt + orgY) * (l ? rs1 : rs0) + (pu.pos_x >> sc) + wq + xInt + orgX;
+      if (l == 0) { d.ref0_off = refOff; d.frac_x0 = (int8_t)xFrac; d.frac_y0 = (int8_t)yFrac; }
+      else        { d.ref1_off = refOff; d.frac_x1 = (int8_t)xFrac; d.frac_y1 = (int8_t)yFrac; }
+    }
+    out[pu.first_desc + sb] = d;
+  }
+}
+
 }  // namespace
 
 extern "C" {
@@ -139,6 +187,20 @@ int vvcgpu_affine_equal_coeff_batch(const vvc_pel* resi_base, const int32_t* der
   VVC_CHECK_ARG(resi_base && derivx_base && derivy_base && descs && out, "affine_equal_coeff_batch: null pointer");
   hipLaunchKernelGGL(affine_equal_coeff_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, resi_base, derivx_base, derivy_base, descs, n,
                      reinterpret_cast<long long*>(out));
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+int vvcgpu_affine_subblock_descs(const vvcgpu_affine_pu* pus, int n, int comp, int pic_w, int pic_h, int max_cu_w, int max_cu_h,
+                                 int ref_origin_x, int ref_origin_y, int ref0_stride, int ref1_stride, vvcgpu_mc_desc* out, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "affine_subblock_descs: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(pus && out, "affine_subblock_descs: null pointer");
+  VVC_CHECK_ARG(comp == 0 || comp == 1, "affine_subblock_descs: comp %d", comp);
+  VVC_CHECK_ARG(pic_w > 0 && pic_h > 0 && max_cu_w > 0 && max_cu_h > 0 && ref0_stride > 0 && ref1_stride > 0, "affine_subblock_descs: geometry");
+  hipLaunchKernelGGL(affine_subblock_descs_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, pus, n, comp, pic_w, pic_h, max_cu_w, max_cu_h,
+                     ref_origin_x, ref_origin_y, ref0_stride, ref1_stride, out);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

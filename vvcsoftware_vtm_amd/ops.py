@@ -493,3 +493,34 @@ def alf_stats_picture(org, rec, ctu, cls):
     capi.call("vvcgpu_alf_stats_picture", C.byref(planes(org)), C.byref(planes(rec)), w, h, ctu, capi.ptr(cls), capi.ptr(a7), capi.ptr(a5),
               capi.ptr(ac[0]), capi.ptr(ac[1]), _stream())
     return a7, a5, ac
+
+
+# ---- T3 residual DPCM, I3 affine sub-block vectors -------------------------------------------------------------
+RDPCM_DESC = np.dtype([("resi_off", "<i8"), ("coeff_off", "<i8"), ("resi_stride", "<i4"), ("w", "<i2"), ("h", "<i2"), ("mode", "i1"), ("lossless", "i1"),
+                       ("rotate", "i1"), ("intra_slice", "i1"), ("qp", "<i4"), ("reserved", "<i4"), ("pad", "<i4")])
+AFFINE_PU = np.dtype([("pos_x", "<i4"), ("pos_y", "<i4"), ("w", "<i2"), ("h", "<i2"), ("six_param", "<i2"), ("bi", "<i2"), ("mv", "<i4", (2, 3, 2)),
+                      ("dst_off", "<i8"), ("dst_stride", "<i4"), ("first_desc", "<i4")])
+MC_DESC = np.dtype([("ref0_off", "<i8"), ("ref1_off", "<i8"), ("dst_off", "<i8"), ("ref0_stride", "<i4"), ("ref1_stride", "<i4"), ("dst_stride", "<i4"),
+                    ("w", "<i2"), ("h", "<i2"), ("frac_x0", "i1"), ("frac_y0", "i1"), ("frac_x1", "i1"), ("frac_y1", "i1"), ("is_luma", "i1"), ("bi", "i1"),
+                    ("reserved", "<i2")])
+assert RDPCM_DESC.itemsize == 40 and AFFINE_PU.itemsize == 80 and MC_DESC.itemsize == 48
+
+
+def rdpcm_fwd_batch(resi_base, coeff_base, descs_dev, n, bit_depth=10):
+    """TrQuant::applyForwardRDPCM for n TUs -> abs-sum int32 tensor [n] (bits as uint32)"""
+    out = torch.zeros(n, dtype=torch.int32, device=resi_base.device)
+    capi.call("vvcgpu_rdpcm_fwd_batch", capi.ptr(resi_base), capi.ptr(coeff_base), capi.ptr(descs_dev), n, bit_depth, capi.ptr(out), _stream())
+    return out
+
+
+def rdpcm_inv_batch(resi_base, descs_dev, n):
+    """TrQuant::invRdpcmNxN, in place"""
+    capi.call("vvcgpu_rdpcm_inv_batch", capi.ptr(resi_base), capi.ptr(descs_dev), n, _stream())
+
+
+def affine_subblock_descs(pus_dev, n, n_descs, comp, pic_w, pic_h, ref_origin, ref0_stride, ref1_stride, max_cu=128):
+    """sub-block MC descriptors (uint8 tensor of n_descs vvcgpu_mc_desc) of n affine PUs, on the device"""
+    out = torch.zeros(n_descs * MC_DESC.itemsize, dtype=torch.uint8, device=pus_dev.device)
+    capi.call("vvcgpu_affine_subblock_descs", capi.ptr(pus_dev), n, comp, pic_w, pic_h, max_cu, max_cu, ref_origin[0], ref_origin[1], ref0_stride,
+              ref1_stride, capi.ptr(out), _stream())
+    return out
