@@ -93,7 +93,7 @@ def test_affine_subblock_vectors_golden():
         oracle().orc_affine_subblock_descs(p(pus), rows.shape[0], c, W, H, 128, 128, M >> c, M >> c, pads[comp].shape[1], pads[comp].shape[1], p(want_d))
         assert np.array_equal(descs.cpu().numpy().view(ops.MC_DESC), want_d)
         dst = torch.zeros(dst_off, dtype=torch.int16, device="cuda")
-        ops.mc_batch(dpads[comp], dpads[comp], dst, descs, first, bd, (0, 1023))
+        ops.mc_batch(dpads[comp], dpads[comp], dst, descs, int(first), bd, (0, 1023))
         got = dst.cpu().numpy()
         # golden predictions are stored PU by PU, component by component
         o = 0

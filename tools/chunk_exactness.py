@@ -1,0 +1,178 @@
+#!/usr/bin/env python3
+"""Multi-GPU exactness experiment (CPU only, build container): is chunk-parallel encoding by intra period byte-exact with the sequential encode?
+
+  A = the reference encoder on N pictures, sequentially                                   (oracle/_ref/vtmref_app enc)
+  B = the same encoder RE-ENTERED at an intra-period boundary with the reference's own mechanism: pictures with POC < P are taken from A
+      (--DebugBitstream=A.bin --DebugPOC=P: decoded, not encoded), pictures with POC >= P are encoded fresh -- what a worker that starts at the
+      chunk boundary with the hand-over pictures in its DPB does   (EncGOP.cpp:1146-1300)
+
+The tool splits both streams into NAL units, pairs them in order, parses every slice header up to the reference-picture-set signalling
+(HLSWriter::codeSliceHeader, EncoderLib/VLCWriter.cpp:891-988: first_slice_segment_in_pic_flag, [no_output_of_prior_pics_flag], pps id, slice type,
+pic_order_cnt_lsb (8 bits), short_term_ref_pic_set_sps_flag, then the SPS index or an explicitly coded set) and reports, for every NAL unit whose
+bytes differ, which field differs first.  Then the stitch test: the access units A coded before the boundary followed by the access units B coded
+after it must decode (reference decoder, hash SEI checked) to exactly the pictures of A.
+
+usage: python tools/chunk_exactness.py [--frames 65] [--poc 33] > profiles/rNN_chunk_exactness.txt"""
+import argparse
+import hashlib
+import os
+import subprocess
+import sys
+import tempfile
+import time
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+from vvcsoftware_vtm_amd import synth  # noqa: E402
+
+APP = os.path.join(ROOT, "oracle", "_ref", "vtmref_app")
+CFG = os.path.join(ROOT, "tests", "golden", "bitstreams", "test_ra_gop16.cfg")
+
+
+def md5(path):
+    return hashlib.md5(open(path, "rb").read()).hexdigest()
+
+
+def nal_units(data):
+    """Annex B byte stream -> list of NAL unit payloads (start codes stripped)"""
+    out, i, n = [], 0, len(data)
+    starts = []
+    while i + 3 <= n:
+        if data[i] == 0 and data[i + 1] == 0 and data[i + 2] == 1:
+            starts.append(i + 3)
+            i += 3
+        else:
+            i += 1
+    for k, s in enumerate(starts):
+        e = starts[k + 1] - 3 if k + 1 < len(starts) else n
+        while e > s and data[e - 1] == 0:          # trailing zero bytes belong to the next start code
+            e -= 1
+        out.append(data[s:e])
+    return out
+
+
+class Bits:
+    def __init__(self, nal):
+        rb, z = bytearray(), 0
+        for b in nal[2:]:                            # skip the two NAL header bytes; drop emulation prevention bytes
+            if z >= 2 and b == 3:
+                z = 0
+                continue
+            rb.append(b)
+            z = z + 1 if b == 0 else 0
+        self.d, self.p = bytes(rb), 0
+
+    def u(self, n):
+        v = 0
+        for _ in range(n):
+            v = (v << 1) | ((self.d[self.p >> 3] >> (7 - (self.p & 7))) & 1)
+            self.p += 1
+        return v
+
+    def ue(self):
+        z = 0
+        while self.u(1) == 0:
+            z += 1
+        return (1 << z) - 1 + (self.u(z) if z else 0)
+
+
+def slice_header(nal, num_rps_sps):
+    t = (nal[0] >> 1) & 0x3F
+    if t > 21 or (10 <= t <= 15):
+        return None
+    b = Bits(nal)
+    h = {"nal_type": t, "first_slice": b.u(1)}
+    if 16 <= t <= 23:
+        h["no_output_of_prior_pics"] = b.u(1)
+    h["pps_id"] = b.ue()
+    h["slice_type"] = b.ue()
+    if t not in (19, 20):
+        h["poc_lsb"] = b.u(8)
+        h["rps_sps_flag"] = b.u(1)
+        if h["rps_sps_flag"]:
+            nb = 0
+            while (1 << nb) < num_rps_sps:
+                nb += 1
+            h["rps_idx"] = b.u(nb) if nb else 0
+        else:
+            h["rps"] = "coded explicitly in the slice header"
+    h["bit_pos_after_rps_start"] = b.p
+    return h
+
+
+def encode(yuv, binf, rec, frames, extra, tmp):
+    cmd = [APP, "enc", "-c", CFG, "-i", yuv, "-wdt", "416", "-hgt", "240", "-fr", "30", "-f", str(frames), "-q", "32", "--InputBitDepth=8",
+           "--InternalBitDepth=8", "--OutputBitDepth=8", "-b", binf, "-o", rec, "--SEIDecodedPictureHash=1"] + extra
+    t0 = time.perf_counter()
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=3500)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    return time.perf_counter() - t0, r.stdout
+
+
+def decode(binf, out):
+    r = subprocess.run([APP, "dec", "-b", binf, "-o", out, "-d", "8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ERROR" not in r.stdout, r.stdout[-1500:]
+    return r.stdout.count("(OK)")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--frames", type=int, default=65)
+    ap.add_argument("--poc", type=int, default=33)
+    ap.add_argument("--keep", default=None, help="directory to keep (and re-use) the streams in")
+    a = ap.parse_args()
+    with tempfile.TemporaryDirectory() as tmp0:
+        tmp = a.keep or tmp0
+        os.makedirs(tmp, exist_ok=True)
+        yuv = os.path.join(tmp, "in.yuv")
+        synth.write_yuv(yuv, synth.gen_yuv(416, 240, a.frames, 8, 20261013), 8)
+        A, B = os.path.join(tmp, "A.bin"), os.path.join(tmp, "B.bin")
+        ta = tb = float("nan")
+        if not (os.path.exists(A) and os.path.exists(B)):
+            ta, _ = encode(yuv, A, os.path.join(tmp, "A_rec.yuv"), a.frames, [], tmp)
+            tb, _ = encode(yuv, B, os.path.join(tmp, "B_rec.yuv"), a.frames, ["--DebugBitstream=" + A, "--DebugPOC=%d" % a.poc], tmp)
+        da, db = open(A, "rb").read(), open(B, "rb").read()
+        print("chunk exactness: %d pictures 416x240 8-bit, cfg test_ra_gop16.cfg (GOP 16, intra period 32), QP 32" % a.frames)
+        print("  A sequential encode           : %6.1f s, %d bytes, md5 %s" % (ta, len(da), hashlib.md5(da).hexdigest()))
+        print("  B re-entered at POC %-3d        : %6.1f s, %d bytes, md5 %s   (POC < %d decoded from A, the rest encoded)" % (a.poc, tb, len(db), hashlib.md5(db).hexdigest(), a.poc))
+        na, nb = nal_units(da), nal_units(db)
+        print("  NAL units: A %d, B %d; byte-identical streams: %s" % (len(na), len(nb), da == db))
+        # the SPS of this cfg carries GOPSize + 1 reference picture sets (EncLib::xInitRPS: one per GOP entry + the intra set)
+        num_rps = 17
+        ndiff = 0
+        first_b_idx = None
+        for i, (x, y) in enumerate(zip(na, nb)):
+            hx, hy = slice_header(x, num_rps), slice_header(y, num_rps)
+            if hx and first_b_idx is None and "poc_lsb" in hx and hx["poc_lsb"] >= a.poc and hx["nal_type"] < 16:
+                first_b_idx = i
+            if x == y:
+                continue
+            ndiff += 1
+            nbytes = sum(1 for p, q in zip(x, y) if p != q) + abs(len(x) - len(y))
+            first = next((k for k, (p, q) in enumerate(zip(x, y)) if p != q), min(len(x), len(y)))
+            print("  NAL %3d differs: %d byte(s), first at byte %d of the NAL unit, sizes %d / %d" % (i, nbytes, first, len(x), len(y)))
+            if hx and hy:
+                keys = [k for k in hx if hx.get(k) != hy.get(k)]
+                print("      A: %s" % hx)
+                print("      B: %s" % hy)
+                print("      first differing slice-header field(s): %s" % (", ".join(keys) if keys else "none up to the RPS (difference lies behind it)"))
+        if ndiff == 0:
+            print("  no NAL unit differs: the re-entered encode is BYTE-EXACT")
+        # stitch: A's NAL units coded before the first re-encoded picture + B's from there on
+        cut = first_b_idx if first_b_idx is not None else len(na)
+        # step back to the start of that access unit (its leading SEI / parameter-set NAL units: types >= 32)
+        while cut > 0 and ((nb[cut - 1][0] >> 1) & 0x3F) >= 32:
+            cut -= 1
+        S = os.path.join(tmp, "S.bin")
+        with open(S, "wb") as f:
+            for u in na[:cut] + nb[cut:]:
+                f.write(b"\x00\x00\x00\x01" + u)
+        oka = decode(A, os.path.join(tmp, "A_dec.yuv"))
+        oks = decode(S, os.path.join(tmp, "S_dec.yuv"))
+        print("  stitch: A's first %d NAL units + B's remaining %d -> decoder: %d / %d picture hashes (OK); decoded YUV identical to A's: %s"
+              % (cut, len(nb) - cut, oks, oka, md5(os.path.join(tmp, "S_dec.yuv")) == md5(os.path.join(tmp, "A_dec.yuv"))))
+        print("  recon of A == recon of B (encoder side): %s" % (md5(os.path.join(tmp, "A_rec.yuv")) == md5(os.path.join(tmp, "B_rec.yuv"))))
+
+
+if __name__ == "__main__":
+    main()

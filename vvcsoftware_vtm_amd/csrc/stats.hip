@@ -33,11 +33,11 @@ __device__ __forceinline__ void sao_stats_body(const int cx, const int cy, const
   const int x0 = cx * ctuW, y0 = cy * ctuH;
   const int width = min(ctuW, w - x0), height = min(ctuH, h - y0);
 
-  for (int i = tid; i < (ctuH + 2) * pitch; i += nthreads)
+  // staging by rows: a wave takes whole tile rows, its lanes the columns (no division by the run-time pitch per element)
+  for (int r = tid >> 6; r < ctuH + 2; r += nthreads >> 6)
   {
-    const int r = i / pitch, c = i - r * pitch;
-    const int y = min(max(y0 + r - 1, 0), h - 1), x = min(max(x0 + c - 1, 0), w - 1);
-    tile[i] = rec[(size_t)y * rstride + x];
+    const Pel* row = rec + (size_t)min(max(y0 + r - 1, 0), h - 1) * rstride;
+    for (int c = tid & 63; c < pitch; c += 64) tile[r * pitch + c] = row[min(max(x0 + c - 1, 0), w - 1)];
   }
   for (int i = tid; i < 16 * 32; i += nthreads) bo[i] = 0ull;
   if (tid < 40) eo[tid] = 0;
@@ -55,8 +55,9 @@ __device__ __forceinline__ void sao_stats_body(const int cx, const int cy, const
   const int groups = nthreads / ctuW;
   const int rpg = ctuH / groups;
   const int x = tid % ctuW, g = tid / ctuW;
-  // per (EO class, category) one packed accumulator: count in bits 20.., sum of (d + 1024) below (a thread walks <= 64 rows:
-  // 64 * 2047 < 2^20) -- one compare, one select, one add per category instead of two selects and two adds
+  // per (EO class, category) one packed accumulator: count in bits 21.., sum of (d + 1024) below -- one compare, one select, one add
+  // per category instead of two selects and two adds.  A thread walks <= 16 rows (host), so even the sum over the 64 lanes of a wave
+  // stays inside the fields (sum <= 1024 * 2047 < 2^21, count <= 1024 < 2^11): the wave reduction below works on the packed words.
   unsigned acc[4][5];
 #pragma unroll
   for (int t = 0; t < 4; t++)
@@ -79,21 +80,29 @@ __device__ __forceinline__ void sao_stats_body(const int cx, const int cy, const
       for (int k = 0; k < 3; k++) r2[k] = q[k];
       const int c = r1[1];
       const int d = (int)org[(size_t)(y0 + y) * ostride + x0 + x] - c;
-      const int sl = sgn(c - r1[0]), sr = sgn(c - r1[2]), su = sgn(c - r0[1]), sd = sgn(c - r2[1]);
-      const int sul = sgn(c - r0[0]), sdr = sgn(c - r2[2]), sur = sgn(c - r0[2]), sdl = sgn(c - r2[0]);
+      // sign(c - n) as a 3-way clamp of the difference (one v_med3 after the subtraction)
+      auto sg = [](int v) { int r; asm("v_med3_i32 %0, %1, -1, 1" : "=v"(r) : "v"(v)); return r; };
+      const int sl = sg(c - r1[0]), sr = sg(c - r1[2]), su = sg(c - r0[1]), sd = sg(c - r2[1]);
+      const int sul = sg(c - r0[0]), sdr = sg(c - r2[2]), sur = sg(c - r0[2]), sdl = sg(c - r2[0]);
       const int e[4] = { 2 + sl + sr, 2 + su + sd, 2 + sul + sdr, 2 + sur + sdl };
       bool use[4];
       use[0] = inXe && y < endY0;
       use[1] = inX90 && y >= startY90 && y < endYd;
       use[2] = y == 0 ? (x == 0 ? (aboveLeft && (above ? endXe : 1) > 0) : (above && x < endXe)) : (inXe && y < endYd);
       use[3] = y == 0 ? (above && inXe) : (inXe && y < endYd);
-      const unsigned val = (1u << 20) | (unsigned)(d + 1024);
+      const unsigned val = (1u << 21) | (unsigned)(d + 1024);
+      // category select without compares: m = one-hot of the category (0 when the sample is not used by this class), bit k of it
+      // times the packed value goes into accumulator k -- a bit-field extract and a 24-bit multiply-add per category (val < 2^22)
 #pragma unroll
       for (int t = 0; t < 4; t++)
       {
-        const unsigned vt = use[t] ? val : 0u;
+        const unsigned m = (use[t] ? 1u : 0u) << e[t];
 #pragma unroll
-        for (int k = 0; k < 5; k++) acc[t][k] += e[t] == k ? vt : 0u;
+        for (int k = 0; k < 5; k++)
+        {
+          const unsigned bit = (m >> k) & 1u;                // the compiler would turn a multiply by 0 / 1 back into mask, and, add
+          asm("v_mad_u32_u24 %0, %1, %2, %0" : "+v"(acc[t][k]) : "v"(bit), "v"(val));
+        }
       }
       if (inX90 && y < endY0)
         atomicAdd(&bo[(tid & 15) * 32 + (c >> boShift)], (1ull << 32) + (unsigned long long)(d + 1024));
@@ -101,17 +110,37 @@ __device__ __forceinline__ void sao_stats_body(const int cx, const int cy, const
       for (int k = 0; k < 3; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
     }
   }
-  // wave reduction of the 40 EO accumulators, then one LDS atomic per wave and value
+  // wave reduction of the 20 packed accumulators as a halving butterfly: at every step a lane keeps one half of its values and sends the
+  // other half to its partner (lane ^ 32, 16, 8, 4, 2), so 10 + 5 + 3 + 2 + 1 + 1 = 22 exchanges do what 20 full 6-step reductions of
+  // count and sum (240 exchanges) did; afterwards lane l holds the wave total of accumulator 10 b5 + 5 b4 + 3 b3 + 2 b2 + b1.
+  {
+    const int lane = tid & 63;
+    const unsigned* v = &acc[0][0];
+    unsigned a10[10], a5[5], a3[3], a2[2];
+    { const bool hi = lane & 32;
 #pragma unroll
-  for (int t = 0; t < 4; t++)
+      for (int i = 0; i < 10; i++) a10[i] = (hi ? v[i + 10] : v[i]) + (unsigned)__shfl_xor((int)(hi ? v[i] : v[i + 10]), 32); }
+    { const bool hi = lane & 16;
 #pragma unroll
-    for (int k = 0; k < 5; k++)
+      for (int i = 0; i < 5; i++) a5[i] = (hi ? a10[i + 5] : a10[i]) + (unsigned)__shfl_xor((int)(hi ? a10[i] : a10[i + 5]), 16); }
+    { const bool hi = lane & 8;
+#pragma unroll
+      for (int i = 0; i < 3; i++) { const unsigned lo_v = a5[i], hi_v = i + 3 < 5 ? a5[i + 3] : 0u; a3[i] = (hi ? hi_v : lo_v) + (unsigned)__shfl_xor((int)(hi ? lo_v : hi_v), 8); } }
+    { const bool hi = lane & 4;
+#pragma unroll
+      for (int i = 0; i < 2; i++) { const unsigned lo_v = a3[i], hi_v = i + 2 < 3 ? a3[i + 2] : 0u; a2[i] = (hi ? hi_v : lo_v) + (unsigned)__shfl_xor((int)(hi ? lo_v : hi_v), 4); } }
+    const bool hi1 = lane & 2;
+    unsigned a1 = (hi1 ? a2[1] : a2[0]) + (unsigned)__shfl_xor((int)(hi1 ? a2[0] : a2[1]), 2);
+    a1 += (unsigned)__shfl_xor((int)a1, 1);
+    const int sub3 = ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);              // index inside the group of three (3 = padding)
+    const int k5 = ((lane >> 3) & 1) * 3 + sub3;                              // index inside the group of five (>= 5 = padding)
+    if (!(lane & 1) && sub3 < 3 && k5 < 5)
     {
-      int c = (int)(acc[t][k] >> 20), d = (int)(acc[t][k] & 0xFFFFFu) - 1024 * c;
-#pragma unroll
-      for (int o = 32; o > 0; o >>= 1) { c += __shfl_xor(c, o); d += __shfl_xor(d, o); }
-      if ((tid & 63) == 0) { atomicAdd(&eo[(t * 5 + k) * 2], d); atomicAdd(&eo[(t * 5 + k) * 2 + 1], c); }
+      const int idx = ((lane >> 5) & 1) * 10 + ((lane >> 4) & 1) * 5 + k5;   // == t * 5 + k
+      const int c = (int)(a1 >> 21), d = (int)(a1 & 0x1FFFFFu) - 1024 * c;
+      atomicAdd(&eo[idx * 2], d); atomicAdd(&eo[idx * 2 + 1], c);
     }
+  }
   __syncthreads();
   long long* o = out + (size_t)(cy * wCtu + cx) * 320;
   for (int i = tid; i < 320; i += nthreads)
