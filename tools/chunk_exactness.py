@@ -76,16 +76,33 @@ class Bits:
         return (1 << z) - 1 + (self.u(z) if z else 0)
 
 
-def slice_header(nal, num_rps_sps):
+def se(b):
+    k = b.ue()
+    return (k + 1) >> 1 if k & 1 else -(k >> 1)
+
+
+def pps_fields(nal):
+    """HLSWriter::codePPS (VLCWriter.cpp:215-240): the fields the slice header parse depends on"""
+    b = Bits(nal)
+    p = {"pps_id": b.ue(), "sps_id": b.ue(), "output_flag_present": b.u(1), "num_extra_slice_header_bits": b.u(3), "cabac_init_present": b.u(1)}
+    p["num_ref_idx_default"] = (b.ue() + 1, b.ue() + 1)
+    return p
+
+
+def slice_header(nal, num_rps_sps, pps=None, cfg=None):
+    """HLSWriter::codeSliceHeader (VLCWriter.cpp:891-1303) as this repository's cfg produces it: no long-term pictures, no weighted
+    prediction, no list modification, SAO / ALF / TMVP / DepQuant / QTBT / SubPuMvp on, slice chroma QP offsets present (dual tree),
+    no deblocking control, loop filter across slices signalled.  With ALF switched on for the slice the parse stops at alf()."""
     t = (nal[0] >> 1) & 0x3F
     if t > 21 or (10 <= t <= 15):
         return None
+    cfg = cfg or {}
     b = Bits(nal)
     h = {"nal_type": t, "first_slice": b.u(1)}
     if 16 <= t <= 23:
         h["no_output_of_prior_pics"] = b.u(1)
     h["pps_id"] = b.ue()
-    h["slice_type"] = b.ue()
+    h["slice_type"] = b.ue()                      # 0 B, 1 P, 2 I
     if t not in (19, 20):
         h["poc_lsb"] = b.u(8)
         h["rps_sps_flag"] = b.u(1)
@@ -96,7 +113,49 @@ def slice_header(nal, num_rps_sps):
             h["rps_idx"] = b.u(nb) if nb else 0
         else:
             h["rps"] = "coded explicitly in the slice header"
-    h["bit_pos_after_rps_start"] = b.p
+            return h
+        h["slice_temporal_mvp_enabled_flag"] = b.u(1)
+    h["slice_sao_luma_flag"] = b.u(1)
+    h["slice_sao_chroma_flag"] = b.u(1)
+    h["alf_slice_enable_flag"] = b.u(1)
+    if h["alf_slice_enable_flag"] or pps is None:
+        h["parsed_to_bit"] = b.p
+        return h
+    intra = h["slice_type"] == 2
+    nref = list(pps["num_ref_idx_default"])
+    if not intra:
+        h["num_ref_idx_active_override_flag"] = b.u(1)
+        if h["num_ref_idx_active_override_flag"]:
+            nref[0] = b.ue() + 1
+            if h["slice_type"] == 0:
+                nref[1] = b.ue() + 1
+            h["num_ref_idx_active"] = tuple(nref)
+        if h["slice_type"] == 0:
+            h["mvd_l1_zero_flag"] = b.u(1)
+        if pps["cabac_init_present"]:
+            h["cabac_init_flag"] = b.u(1)
+        if h.get("slice_temporal_mvp_enabled_flag"):
+            col_l0 = 1
+            if h["slice_type"] == 0:
+                col_l0 = h["collocated_from_l0_flag"] = b.u(1)
+            if nref[0 if col_l0 else 1] > 1:
+                h["collocated_ref_idx"] = b.ue()
+    h["dep_quant_enable_flag"] = b.u(1)
+    if not h["dep_quant_enable_flag"]:
+        h["sign_data_hiding_enable_flag"] = b.u(1)
+    if not intra:
+        h["max_binary_tree_unit_size"] = b.ue()
+        h["seven_minus_max_num_merge_cand" if cfg.get("subpumvp", 1) else "five_minus_max_num_merge_cand"] = b.ue()
+    h["slice_qp_delta"] = se(b)
+    h["slice_cb_qp_offset"] = se(b)
+    h["slice_cr_qp_offset"] = se(b)
+    h["slice_loop_filter_across_slices_enabled_flag"] = b.u(1)
+    if not intra and cfg.get("subpumvp", 1):
+        h["slice_atmvp_subblk_size_enable_flag"] = b.u(1)
+        if h["slice_atmvp_subblk_size_enable_flag"]:
+            h["log2_slice_sub_pu_tmvp_size_minus2"] = b.u(3)
+    h["alignment_ok"] = b.u(1) == 1 and all(b.u(1) == 0 for _ in range((-b.p) % 8))     # byte_alignment(): a one, then zeros
+    h["header_bits"] = b.p
     return h
 
 
@@ -119,6 +178,7 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=65)
     ap.add_argument("--poc", type=int, default=33)
+    ap.add_argument("--enc", action="append", default=[], help="extra encoder option for both encodes, e.g. --enc=--SubPuMvp=0")
     ap.add_argument("--keep", default=None, help="directory to keep (and re-use) the streams in")
     a = ap.parse_args()
     with tempfile.TemporaryDirectory() as tmp0:
@@ -129,20 +189,23 @@ def main():
         A, B = os.path.join(tmp, "A.bin"), os.path.join(tmp, "B.bin")
         ta = tb = float("nan")
         if not (os.path.exists(A) and os.path.exists(B)):
-            ta, _ = encode(yuv, A, os.path.join(tmp, "A_rec.yuv"), a.frames, [], tmp)
-            tb, _ = encode(yuv, B, os.path.join(tmp, "B_rec.yuv"), a.frames, ["--DebugBitstream=" + A, "--DebugPOC=%d" % a.poc], tmp)
+            ta, _ = encode(yuv, A, os.path.join(tmp, "A_rec.yuv"), a.frames, a.enc, tmp)
+            tb, _ = encode(yuv, B, os.path.join(tmp, "B_rec.yuv"), a.frames, a.enc + ["--DebugBitstream=" + A, "--DebugPOC=%d" % a.poc], tmp)
         da, db = open(A, "rb").read(), open(B, "rb").read()
-        print("chunk exactness: %d pictures 416x240 8-bit, cfg test_ra_gop16.cfg (GOP 16, intra period 32), QP 32" % a.frames)
+        print("chunk exactness: %d pictures 416x240 8-bit, cfg test_ra_gop16.cfg (GOP 16, intra period 32), QP 32%s" % (a.frames, (", " + " ".join(a.enc)) if a.enc else ""))
         print("  A sequential encode           : %6.1f s, %d bytes, md5 %s" % (ta, len(da), hashlib.md5(da).hexdigest()))
         print("  B re-entered at POC %-3d        : %6.1f s, %d bytes, md5 %s   (POC < %d decoded from A, the rest encoded)" % (a.poc, tb, len(db), hashlib.md5(db).hexdigest(), a.poc))
         na, nb = nal_units(da), nal_units(db)
         print("  NAL units: A %d, B %d; byte-identical streams: %s" % (len(na), len(nb), da == db))
         # the SPS of this cfg carries GOPSize + 1 reference picture sets (EncLib::xInitRPS: one per GOP entry + the intra set)
         num_rps = 17
+        pps = next(pps_fields(u) for u in na if ((u[0] >> 1) & 0x3F) == 34)
+        cfg = {"subpumvp": 0 if any("SubPuMvp=0" in e for e in a.enc) else 1}
+        print("  PPS: %s" % pps)
         ndiff = 0
         first_b_idx = None
         for i, (x, y) in enumerate(zip(na, nb)):
-            hx, hy = slice_header(x, num_rps), slice_header(y, num_rps)
+            hx, hy = slice_header(x, num_rps, pps, cfg), slice_header(y, num_rps, pps, cfg)
             if hx and first_b_idx is None and "poc_lsb" in hx and hx["poc_lsb"] >= a.poc and hx["nal_type"] < 16:
                 first_b_idx = i
             if x == y:
@@ -155,7 +218,7 @@ def main():
                 keys = [k for k in hx if hx.get(k) != hy.get(k)]
                 print("      A: %s" % hx)
                 print("      B: %s" % hy)
-                print("      first differing slice-header field(s): %s" % (", ".join(keys) if keys else "none up to the RPS (difference lies behind it)"))
+                print("      first differing slice-header field(s): %s" % (", ".join(keys) if keys else "none (alf() data or slice data)"))
         if ndiff == 0:
             print("  no NAL unit differs: the re-entered encode is BYTE-EXACT")
         # stitch: A's NAL units coded before the first re-encoded picture + B's from there on

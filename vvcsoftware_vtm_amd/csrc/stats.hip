@@ -240,6 +240,68 @@ __device__ __forceinline__ constexpr int tapIndexS(int dy, int dx)
   }
 }
 
+// covariance sums of one 4x4 block in the canonical (transposeIdx 0) tap order: blk = LDS tile at (row by - 3, column bx - 4) of a tile
+// with row pitch PITCH samples, orgBlk = the original at (by, bx).  A = upper triangle of E (row-major), Y = cross terms, pix = sum d^2.
+template <bool IS7, int PITCH>
+__device__ __forceinline__ void alf_block_acc(const short* __restrict__ blk, const Pel* __restrict__ orgBlk, int ostride,
+                                              int (&A)[(IS7 ? 13 : 7) * ((IS7 ? 13 : 7) + 1) / 2], int (&Y)[IS7 ? 13 : 7], int& pix)
+{
+  constexpr int N = IS7 ? 13 : 7, R = IS7 ? 3 : 2;
+#pragma unroll 1
+  for (int i = 0; i < 4; i++)                  // pixel row by+i (not unrolled: one row of tap sums live at a time)
+  {
+    // two horizontally adjacent pixels share every instruction: tap sums are built as packed 16-bit pairs
+    // (v_pk_add_u16, <= 2 * 1023) and multiplied with v_dot2_i32_i16 (two exact MACs per instruction)
+    us2 E[2][N];
+#pragma unroll
+    for (int jp = 0; jp < 2; jp++)
+#pragma unroll
+      for (int k = 0; k < N; k++) E[jp][k] = us2{ 0, 0 };
+    const short* p = blk + (i + 3 - R) * PITCH;     // row by+i-R, col bx-4
+    unsigned cen[2];
+#pragma unroll
+    for (int r = 0; r <= 2 * R; r++)
+    {
+      unsigned d[6];                                                // samples bx-4 .. bx+7 as pairs
+      const uint2 v0 = *reinterpret_cast<const uint2*>(p + r * PITCH);
+      const uint2 v1 = *reinterpret_cast<const uint2*>(p + r * PITCH + 4);
+      const uint2 v2 = *reinterpret_cast<const uint2*>(p + r * PITCH + 8);
+      d[0] = v0.x; d[1] = v0.y; d[2] = v1.x; d[3] = v1.y; d[4] = v2.x; d[5] = v2.y;
+      if (r == R) { cen[0] = d[2]; cen[1] = d[3]; }
+      const int dy = r - R;
+#pragma unroll
+      for (int dx = -R; dx <= R; dx++)
+      {
+        const int k = tapIndexS<IS7>(dy, dx);
+        if (k < 0) continue;
+#pragma unroll
+        for (int jp = 0; jp < 2; jp++)
+        {
+          const int s0 = 4 + 2 * jp + dx;                           // first sample of the pair (compile-time)
+          const unsigned pr = (s0 & 1) ? __builtin_amdgcn_alignbit(d[(s0 + 1) >> 1], d[(s0 - 1) >> 1], 16) : d[s0 >> 1];
+          E[jp][k] += __builtin_bit_cast(us2, pr);
+        }
+      }
+    }
+    const uint2 ov = *reinterpret_cast<const uint2*>(orgBlk + (size_t)i * ostride);
+#pragma unroll
+    for (int jp = 0; jp < 2; jp++)
+    {
+      const short2v yl = __builtin_bit_cast(short2v, jp ? ov.y : ov.x) - __builtin_bit_cast(short2v, cen[jp]);
+      int idx = 0;
+#pragma unroll
+      for (int k = 0; k < N; k++)
+      {
+        const short2v ek = __builtin_bit_cast(short2v, E[jp][k]);
+#pragma unroll
+        for (int l = k; l < N; l++) { A[idx] = __builtin_amdgcn_sdot2(ek, __builtin_bit_cast(short2v, E[jp][l]), A[idx], false); idx++; }
+        Y[k] = __builtin_amdgcn_sdot2(ek, yl, Y[k], false);
+      }
+      pix = __builtin_amdgcn_sdot2(yl, yl, pix, false);
+    }
+  }
+}
+
 template <bool IS7>
 __device__ __forceinline__ void alf_stats_body(const int bidx, const int bidy, const Pel* __restrict__ org, int ostride,
                                                         const Pel* __restrict__ rec, int rstride, int w, int h,
@@ -271,59 +333,7 @@ __device__ __forceinline__ void alf_stats_body(const int bidx, const int bidy, c
 #pragma unroll
     for (int i = 0; i < N; i++) Y[i] = 0;
 
-#pragma unroll 1
-    for (int i = 0; i < 4; i++)                  // pixel row by+i (not unrolled: one row of tap sums live at a time)
-    {
-      // two horizontally adjacent pixels share every instruction: tap sums are built as packed 16-bit pairs
-      // (v_pk_add_u16, <= 2 * 1023) and multiplied with v_dot2_i32_i16 (two exact MACs per instruction)
-      us2 E[2][N];
-#pragma unroll
-      for (int jp = 0; jp < 2; jp++)
-#pragma unroll
-        for (int k = 0; k < N; k++) E[jp][k] = us2{ 0, 0 };
-      const short* p = tile + (4 * bi + i + 3 - R) * AP + 4 * bj;     // row by+i-R, col bx-4
-      unsigned cen[2];
-#pragma unroll
-      for (int r = 0; r <= 2 * R; r++)
-      {
-        unsigned d[6];                                                // samples bx-4 .. bx+7 as pairs
-        const uint2 v0 = *reinterpret_cast<const uint2*>(p + r * AP);
-        const uint2 v1 = *reinterpret_cast<const uint2*>(p + r * AP + 4);
-        const uint2 v2 = *reinterpret_cast<const uint2*>(p + r * AP + 8);
-        d[0] = v0.x; d[1] = v0.y; d[2] = v1.x; d[3] = v1.y; d[4] = v2.x; d[5] = v2.y;
-        if (r == R) { cen[0] = d[2]; cen[1] = d[3]; }
-        const int dy = r - R;
-#pragma unroll
-        for (int dx = -R; dx <= R; dx++)
-        {
-          const int k = tapIndexS<IS7>(dy, dx);
-          if (k < 0) continue;
-#pragma unroll
-          for (int jp = 0; jp < 2; jp++)
-          {
-            const int s0 = 4 + 2 * jp + dx;                           // first sample of the pair (compile-time)
-            const unsigned pr = (s0 & 1) ? __builtin_amdgcn_alignbit(d[(s0 + 1) >> 1], d[(s0 - 1) >> 1], 16) : d[s0 >> 1];
-            E[jp][k] += __builtin_bit_cast(us2, pr);
-          }
-        }
-      }
-      const uint2 ov = *reinterpret_cast<const uint2*>(org + (size_t)(by + i) * ostride + bx);
-#pragma unroll
-      for (int jp = 0; jp < 2; jp++)
-      {
-        const short2v yl = __builtin_bit_cast(short2v, jp ? ov.y : ov.x) - __builtin_bit_cast(short2v, cen[jp]);
-        int idx = 0;
-#pragma unroll
-        for (int k = 0; k < N; k++)
-        {
-          const short2v ek = __builtin_bit_cast(short2v, E[jp][k]);
-#pragma unroll
-          for (int l = k; l < N; l++) { A[idx] = __builtin_amdgcn_sdot2(ek, __builtin_bit_cast(short2v, E[jp][l]), A[idx], false); idx++; }
-          Y[k] = __builtin_amdgcn_sdot2(ek, yl, Y[k], false);
-        }
-        pix = __builtin_amdgcn_sdot2(yl, yl, pix, false);
-      }
-    }
+    alf_block_acc<IS7, AP>(tile + (4 * bi) * AP + 4 * bj, org + (size_t)by * ostride + bx, ostride, A, Y, pix);
     // flush into the class bucket with the block's transpose permutation
     int classIdx = 0, t = 0;
     if (cls) { const uint16_t c = cls[(size_t)(by >> 2) * (w >> 2) + (bx >> 2)]; classIdx = c & 0xff; t = c >> 8; }
@@ -400,6 +410,187 @@ __global__ __launch_bounds__(256) void alf_stats_chroma2_kernel(const Pel* __res
 {
   const bool cr = blockIdx.z != 0;
   alf_stats_body<false>((int)blockIdx.x, (int)blockIdx.y, cr ? orgCr : orgCb, ostride, cr ? recCr : recCb, rstride, w, h, ctu, wCtu, nullptr, 1, cr ? outCr : outCb);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Picture form of A3 (vvcgpu_alf_stats_picture): ONE workgroup of 512 threads per CTU, so a CTU's records are finished inside its
+// workgroup -- no zero-fill pass, no 64-bit global atomics (the tile form above adds 25 x 183 partial sums per 64x64 tile into the
+// CTU's record: 9 M global atomics for a 4K picture) and no 5x5-from-7x7 pass: the workgroup writes the 7x7 and the 5x5 record of
+// every class directly.  Luma workgroup: the CTU with its 3-sample halo in LDS, four replicas of the 25 class buckets, two vertically
+// adjacent 4x4 blocks per thread (flushed once when they share class and transposition); the (tap pair, transposition) -> bucket slot
+// map is a 4 x 105 table in LDS, built once per workgroup, instead of nibble extraction and triangle index arithmetic per atomic.
+// Chroma workgroup: both chroma CTUs (no classifier), one block per thread.
+// ---------------------------------------------------------------------------------------------------
+constexpr int ACT = 512;                         // threads per CTU workgroup
+constexpr int AC_REP = 4;                        // luma bucket replicas
+constexpr int AC_NB7 = 91 + 13 + 1;              // bucket entries 7x7: tri(E), y, pixAcc
+constexpr int AC_NB5 = 28 + 7 + 1;
+constexpr int AC_CREP = 16;                      // chroma bucket replicas per plane
+
+template <int C> struct AlfCtuLds
+{
+  static constexpr int P = C + 8, ROWS = C + 6;                          // luma tile
+  static constexpr int tileBytes = (ROWS * P * 2 + 15) & ~15;
+  static constexpr int tabBytes = (4 * (AC_NB7 - 1) * 2 + 15) & ~15;      // u16 byte offsets, [t][idx]
+  static constexpr int bucketBytes = AC_REP * 25 * AC_NB7 * 8;
+  static constexpr int lumaBytes = tileBytes + tabBytes + bucketBytes;
+  static constexpr int CP = C / 2 + 8, CROWS = C / 2 + 6;                // chroma tiles (two planes)
+  static constexpr int ctileBytes = (CROWS * CP * 2 + 15) & ~15;
+  static constexpr int chromaBytes = 2 * ctileBytes + 2 * AC_CREP * AC_NB5 * 8;
+  static constexpr int bytes = lumaBytes > chromaBytes ? lumaBytes : chromaBytes;
+};
+
+struct AlfStatsPic
+{
+  const Pel* org[3]; const Pel* rec[3]; int ostride[3], rstride[3];
+  int w, h, wCtu, nCtu;
+  const uint16_t* cls;
+  unsigned long long* out7; unsigned long long* out5; unsigned long long* outC[2];
+};
+
+template <int C>
+__device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, unsigned char* smem)
+{
+  using L = AlfCtuLds<C>;
+  constexpr int P = L::P, N = 13, NT = 91, NB = AC_NB7, BPR = C / 4;     // blocks per CTU row
+  short* tile = reinterpret_cast<short*>(smem);
+  unsigned short* posTab = reinterpret_cast<unsigned short*>(smem + L::tileBytes);
+  unsigned long long* bucket = reinterpret_cast<unsigned long long*>(smem + L::tileBytes + L::tabBytes);
+  const int tid = threadIdx.x;
+  const int x0 = (ctuIdx % a.wCtu) * C, y0 = (ctuIdx / a.wCtu) * C;
+  load_tile_clamped<P>(tile, a.rec[0], a.rstride[0], a.w, a.h, x0 - 4, y0 - 3, L::ROWS, tid, ACT);
+  for (int i = tid; i < AC_REP * 25 * NB; i += ACT) bucket[i] = 0ull;
+  // slot table: entry idx of the canonical order (upper triangle row-major, then y) under transposition t lands at byte offset tab[t][idx]
+  for (int i = tid; i < 4 * (NB - 1); i += ACT)
+  {
+    const int t = i / (NB - 1), idx = i - t * (NB - 1);
+    const unsigned long long perm = t == 0 ? 0xCBA9876543210ull : t == 1 ? 0xC62037B518A49ull : t == 2 ? 0xCBA9456781230ull : 0xC62015B734A89ull;
+    int pos;
+    if (idx < NT)
+    {
+      int k = 0, rem = idx;
+      while (rem >= N - k) { rem -= N - k; k++; }
+      const int l = k + rem;
+      const int ck = (int)((perm >> (4 * k)) & 15), cl = (int)((perm >> (4 * l)) & 15);
+      const int lo = min(ck, cl), hi = max(ck, cl);
+      pos = lo * N - (lo * (lo - 1)) / 2 + (hi - lo);
+    }
+    else
+      pos = NT + (int)((perm >> (4 * (idx - NT))) & 15);
+    posTab[i] = (unsigned short)(pos * 8);
+  }
+  __syncthreads();
+
+  constexpr int S = C >= 128 ? (BPR * BPR) / ACT : 1;                     // blocks per thread, vertically adjacent
+  const int bj = tid % BPR, bi0 = (tid / BPR) * S;
+  if (bi0 < BPR)
+  {
+    int A[NT], Y[N], pix = 0;
+#pragma unroll
+    for (int i = 0; i < NT; i++) A[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) Y[i] = 0;
+    int key = -1;                                                         // class | transposition << 8 of the sums held in registers
+#pragma unroll 1
+    for (int s = 0; s <= S; s++)
+    {
+      const int bx = x0 + 4 * bj, by = y0 + 4 * (bi0 + s);
+      const bool have = s < S && bx < a.w && by < a.h;
+      const int k2 = have ? (int)a.cls[(size_t)(by >> 2) * (a.w >> 2) + (bx >> 2)] : -1;
+      if (key >= 0 && k2 != key)
+      {
+        // flush the registers into the class bucket of the replica picked by the low lane bits (neighbouring blocks mostly share the
+        // class; same-address LDS atomics serialise)
+        const unsigned short* pt = posTab + (key >> 8) * (NB - 1);
+        unsigned char* b = reinterpret_cast<unsigned char*>(bucket + ((tid & (AC_REP - 1)) * 25 + (key & 0xff)) * NB);
+#pragma unroll
+        for (int i = 0; i < NT; i++) { atomicAdd(reinterpret_cast<unsigned long long*>(b + pt[i]), (unsigned long long)(long long)A[i]); A[i] = 0; }
+#pragma unroll
+        for (int i = 0; i < N; i++) { atomicAdd(reinterpret_cast<unsigned long long*>(b + pt[NT + i]), (unsigned long long)(long long)Y[i]); Y[i] = 0; }
+        atomicAdd(reinterpret_cast<unsigned long long*>(b + (NT + N) * 8), (unsigned long long)(long long)pix); pix = 0;
+      }
+      key = k2;
+      if (have)
+        alf_block_acc<true, P>(tile + (4 * (bi0 + s)) * P + 4 * bj, a.org[0] + (size_t)by * a.ostride[0] + bx, a.ostride[0], A, Y, pix);
+    }
+  }
+  __syncthreads();
+  // records: 7x7 (13 x 13 + 13 + 1 = 183 entries per class) and its 5x5 sub-record (coefficient i of 5x5 = coefficient sig[i] of 7x7)
+  auto entry7 = [&](int c, int e) -> unsigned long long
+  {
+    int pos;
+    if (e < N * N) { const int r = e / N, q = e - r * N, lo = min(r, q), hi = max(r, q); pos = lo * N - (lo * (lo - 1)) / 2 + (hi - lo); }
+    else pos = NT + (e - N * N);
+    unsigned long long v = 0ull;
+#pragma unroll
+    for (int r = 0; r < AC_REP; r++) v += bucket[(r * 25 + c) * NB + pos];
+    return v;
+  };
+  unsigned long long* o7 = a.out7 + (size_t)ctuIdx * 25 * 183;
+  for (int i = tid; i < 25 * 183; i += ACT) { const int c = i / 183; o7[i] = entry7(c, i - c * 183); }
+  unsigned long long* o5 = a.out5 + (size_t)ctuIdx * 25 * 57;
+  for (int i = tid; i < 25 * 57; i += ACT)
+  {
+    const int c = i / 57, e = i - c * 57;
+    const int sig[7] = { 2, 5, 6, 7, 10, 11, 12 };
+    o5[i] = entry7(c, e < 49 ? sig[e / 7] * 13 + sig[e % 7] : e < 56 ? 169 + sig[e - 49] : 182);
+  }
+}
+
+template <int C>
+__device__ __forceinline__ void alf_ctu_chroma(const AlfStatsPic& a, int ctuIdx, unsigned char* smem)
+{
+  using L = AlfCtuLds<C>;
+  constexpr int P = L::CP, C2 = C / 2, N = 7, NT = 28, NB = AC_NB5, BPR = C2 / 4;
+  const int tid = threadIdx.x;
+  const int w2 = a.w >> 1, h2 = a.h >> 1;
+  const int x0 = (ctuIdx % a.wCtu) * C2, y0 = (ctuIdx / a.wCtu) * C2;
+  unsigned long long* bucket = reinterpret_cast<unsigned long long*>(smem + 2 * L::ctileBytes);       // [plane][replica][NB]
+  for (int c = 0; c < 2; c++)
+    load_tile_clamped<P>(reinterpret_cast<short*>(smem + c * L::ctileBytes), a.rec[1 + c], a.rstride[1 + c], w2, h2, x0 - 4, y0 - 3, L::CROWS, tid, ACT);
+  for (int i = tid; i < 2 * AC_CREP * NB; i += ACT) bucket[i] = 0ull;
+  __syncthreads();
+  constexpr int NBLK = BPR * BPR;                                        // blocks per plane: 256 (C = 128) or 64
+  for (int q = tid; q < 2 * NBLK; q += ACT)
+  {
+    const int c = q / NBLK, blk = q - c * NBLK, bj = blk % BPR, bi = blk / BPR;
+    const int bx = x0 + 4 * bj, by = y0 + 4 * bi;
+    if (bx >= w2 || by >= h2) continue;
+    int A[NT], Y[N], pix = 0;
+#pragma unroll
+    for (int i = 0; i < NT; i++) A[i] = 0;
+#pragma unroll
+    for (int i = 0; i < N; i++) Y[i] = 0;
+    alf_block_acc<false, P>(reinterpret_cast<const short*>(smem + c * L::ctileBytes) + (4 * bi) * P + 4 * bj,
+                            a.org[1 + c] + (size_t)by * a.ostride[1 + c] + bx, a.ostride[1 + c], A, Y, pix);
+    unsigned long long* b = bucket + (c * AC_CREP + (tid & (AC_CREP - 1))) * NB;
+#pragma unroll
+    for (int i = 0; i < NT; i++) atomicAdd(&b[i], (unsigned long long)(long long)A[i]);
+#pragma unroll
+    for (int i = 0; i < N; i++) atomicAdd(&b[NT + i], (unsigned long long)(long long)Y[i]);
+    atomicAdd(&b[NT + N], (unsigned long long)(long long)pix);
+  }
+  __syncthreads();
+  for (int i = tid; i < 2 * 57; i += ACT)
+  {
+    const int c = i / 57, e = i - c * 57;
+    int pos;
+    if (e < N * N) { const int r = e / N, q = e - r * N, lo = min(r, q), hi = max(r, q); pos = lo * N - (lo * (lo - 1)) / 2 + (hi - lo); }
+    else pos = NT + (e - N * N);
+    unsigned long long v = 0ull;
+    for (int r = 0; r < AC_CREP; r++) v += bucket[(c * AC_CREP + r) * NB + pos];
+    a.outC[c][(size_t)ctuIdx * 57 + e] = v;
+  }
+}
+
+// workgroups [0, nCtu): luma CTUs (the long ones first), [nCtu, 2 nCtu): the chroma CTU pairs
+template <int C>
+__global__ __launch_bounds__(ACT) void alf_stats_picture_kernel(AlfStatsPic a)
+{
+  extern __shared__ __align__(16) unsigned char alfSmem[];
+  const int b = blockIdx.x;
+  if (b < a.nCtu) alf_ctu_luma<C>(a, b, alfSmem);
+  else            alf_ctu_chroma<C>(a, b - a.nCtu, alfSmem);
 }
 
 // The 5x5 diamond is the centre of the 7x7 diamond under every transposition, so the 5x5 covariance record of a class is a sub-matrix of its 7x7
@@ -522,7 +713,7 @@ int vvcgpu_alf_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec,
 {
   VVC_CHECK_ARG(org && rec && cls && out7 && out5 && out_cb && out_cr, "alf_stats_picture: null pointer");
   VVC_CHECK_ARG(width > 0 && height > 0 && (width & 7) == 0 && (height & 7) == 0, "alf_stats_picture: size must be a multiple of 8");
-  VVC_CHECK_ARG(ctu_size >= 2 * AT && (ctu_size % (2 * AT)) == 0, "alf_stats_picture: ctu size %d must be a multiple of %d", ctu_size, 2 * AT);
+  VVC_CHECK_ARG(ctu_size == 64 || (ctu_size >= 2 * AT && (ctu_size % (2 * AT)) == 0), "alf_stats_picture: ctu size %d must be 64 or a multiple of %d", ctu_size, 2 * AT);
   for (int c = 0; c < 3; c++)
   {
     const int w = c ? width >> 1 : width;
@@ -535,6 +726,26 @@ int vvcgpu_alf_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec,
   unsigned long long* o7 = reinterpret_cast<unsigned long long*>(out7);
   unsigned long long* ocb = reinterpret_cast<unsigned long long*>(out_cb);
   unsigned long long* ocr = reinterpret_cast<unsigned long long*>(out_cr);
+  if (ctu_size == 128 || ctu_size == 64)
+  {
+    // CTU form: one launch, every record written by the workgroup that owns the CTU
+    AlfStatsPic a;
+    for (int c = 0; c < 3; c++) { a.org[c] = org->p[c]; a.rec[c] = rec->p[c]; a.ostride[c] = org->stride[c]; a.rstride[c] = rec->stride[c]; }
+    a.w = width; a.h = height; a.wCtu = wCtu; a.nCtu = nCtu; a.cls = cls;
+    a.out7 = o7; a.out5 = reinterpret_cast<unsigned long long*>(out5); a.outC[0] = ocb; a.outC[1] = ocr;
+    if (ctu_size == 128)
+    {
+      VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alf_stats_picture_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, AlfCtuLds<128>::bytes));
+      hipLaunchKernelGGL(alf_stats_picture_kernel<128>, dim3(2 * nCtu), dim3(ACT), AlfCtuLds<128>::bytes, st, a);
+    }
+    else
+    {
+      VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alf_stats_picture_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, AlfCtuLds<64>::bytes));
+      hipLaunchKernelGGL(alf_stats_picture_kernel<64>, dim3(2 * nCtu), dim3(ACT), AlfCtuLds<64>::bytes, st, a);
+    }
+    VVC_LAUNCH_CHECK();
+    return VVCGPU_OK;
+  }
   hipLaunchKernelGGL(zero3_kernel, dim3(512), dim3(256), 0, st, o7, (size_t)nCtu * 25 * 183, ocb, (size_t)nCtu * 57, ocr, (size_t)nCtu * 57);
   hipLaunchKernelGGL(alf_stats_kernel<true>, dim3(cdiv(width, AT), cdiv(height, AT)), dim3(256), 0, st, org->p[0], org->stride[0], rec->p[0], rec->stride[0],
                      width, height, ctu_size, wCtu, cls, 25, o7);
