@@ -1,0 +1,79 @@
+"""C3: chunk-parallel encoding by intra period.  The streams under tests/golden/chunk were made by tools/chunk_exactness.py
+with the compiled reference encoder: A = sequential, B = re-entered at the intra-period boundary (pictures before it taken from A).
+
+Parcat-style stitch (the reference's App/Parcat concatenates independently produced chunks NAL unit by NAL unit): the access units A coded
+before the boundary followed by the access units B coded from it on must decode, hash SEI checked, to a valid sequence -- and to exactly the
+pictures of A when the re-entered encode is byte-exact."""
+import hashlib
+import os
+import subprocess
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+import chunk_exactness as ce  # noqa: E402
+
+G = os.path.join(ROOT, "tests", "golden", "chunk")
+pytestmark = pytest.mark.skipif(not os.path.exists(ce.APP), reason="oracle/_ref/vtmref_app not built (make -C oracle ref)")
+
+
+def _decode(path, out):
+    r = subprocess.run([ce.APP, "dec", "-b", path, "-o", out, "-d", "8"], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "ERROR" not in r.stdout, r.stdout[-1500:]
+    return r.stdout.count("(OK)"), hashlib.md5(open(out, "rb").read()).hexdigest()
+
+
+def _stitch(tmp_path, name, poc=33):
+    da, db = open(os.path.join(G, name + "_A.bin"), "rb").read(), open(os.path.join(G, name + "_B.bin"), "rb").read()
+    na, nb = ce.nal_units(da), ce.nal_units(db)
+    assert len(na) == len(nb) == 132
+    pps = next(ce.pps_fields(u) for u in na if ((u[0] >> 1) & 0x3F) == 34)
+    cfg = {"subpumvp": 0 if name == "noatmvp" else 1}
+    hdr = [(ce.slice_header(x, 17, pps, cfg), ce.slice_header(y, 17, pps, cfg)) for x, y in zip(na, nb)]
+    # every slice header the parser finishes must end on the byte alignment pattern: the field list is complete for this cfg
+    for hx, hy in hdr:
+        for h in (hx, hy):
+            assert h is None or h.get("alignment_ok", True), h
+    cut = next(i for i, (hx, _) in enumerate(hdr) if hx and hx.get("poc_lsb", 0) >= poc and hx["nal_type"] < 16)
+    while cut > 0 and ((nb[cut - 1][0] >> 1) & 0x3F) >= 32:
+        cut -= 1
+    assert na[:cut] == nb[:cut]                                  # B carries A's units up to the boundary unchanged
+    s = str(tmp_path / "S.bin")
+    with open(s, "wb") as f:
+        for u in na[:cut] + nb[cut:]:
+            f.write(b"\x00\x00\x00\x01" + u)
+    ok_s, md5_s = _decode(s, str(tmp_path / "S.yuv"))
+    ok_a, md5_a = _decode(os.path.join(G, name + "_A.bin"), str(tmp_path / "A.yuv"))
+    first = None
+    for (hx, hy), x, y in zip(hdr, na, nb):
+        if x != y and hx and hy:
+            keys = [k for k in hx if hx.get(k) != hy.get(k) and k not in ("header_bits", "alignment_ok")]
+            first = keys[0] if keys else "slice data"
+            break
+    return da == db, ok_s, ok_a, md5_s == md5_a, first
+
+
+def test_stitch_is_exact_without_atmvp(tmp_path):
+    """SubPuMvp 0: the chunk that starts at the intra-period boundary with the hand-over pictures produces the sequential encoder's bytes"""
+    exact, ok_s, ok_a, same, first = _stitch(tmp_path, "noatmvp")
+    assert exact and first is None
+    assert ok_s == ok_a == 65 and same
+
+
+def test_stitch_decodes_and_names_the_state_with_atmvp(tmp_path):
+    """SubPuMvp 1 (the fixture cfg): the stitched stream is a valid stream (65 hash-checked pictures) but not the sequential one; the first
+    field that differs is the slice's ATMVP sub-block size, which EncSlice derives from statistics of earlier ENCODED pictures of the
+    temporal layer (EncSlice.cpp:1250-1294, EncCu::m_subMergeBlkSize / Num) -- encoder state a chunk worker would have to be handed"""
+    exact, ok_s, ok_a, same, first = _stitch(tmp_path, "atmvp")
+    assert not exact and not same
+    assert ok_s == ok_a == 65
+    assert first == "slice_atmvp_subblk_size_enable_flag"
+
+
+@pytest.mark.skipif(not os.environ.get("VVCGPU_NIGHTLY"), reason="re-encodes 2 x 65 pictures with the reference encoder (about 5 minutes): VVCGPU_NIGHTLY=1")
+def test_nightly_reencode_is_exact_without_atmvp(tmp_path):
+    exact, same, fields = ce.run(enc=["--SubPuMvp=0", "--MaxNumMergeCand=5"], keep=str(tmp_path), out=lambda *a: None)
+    assert exact and same and not fields
+    assert open(tmp_path / "A.bin", "rb").read() == open(os.path.join(G, "noatmvp_A.bin"), "rb").read()

@@ -159,8 +159,8 @@ def slice_header(nal, num_rps_sps, pps=None, cfg=None):
     return h
 
 
-def encode(yuv, binf, rec, frames, extra, tmp):
-    cmd = [APP, "enc", "-c", CFG, "-i", yuv, "-wdt", "416", "-hgt", "240", "-fr", "30", "-f", str(frames), "-q", "32", "--InputBitDepth=8",
+def encode(yuv, binf, rec, frames, extra, size):
+    cmd = [APP, "enc", "-c", CFG, "-i", yuv, "-wdt", str(size[0]), "-hgt", str(size[1]), "-fr", "30", "-f", str(frames), "-q", "32", "--InputBitDepth=8",
            "--InternalBitDepth=8", "--OutputBitDepth=8", "-b", binf, "-o", rec, "--SEIDecodedPictureHash=1"] + extra
     t0 = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=3500)
@@ -174,25 +174,38 @@ def decode(binf, out):
     return r.stdout.count("(OK)")
 
 
+def run(frames=65, poc=33, enc=(), keep=None, size=(416, 240), out=print):
+    """returns (byte_exact, stitched_pictures_identical, first differing fields)"""
+    a = argparse.Namespace(frames=frames, poc=poc, enc=list(enc), keep=keep, size=size)
+    return experiment(a, out)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--frames", type=int, default=65)
     ap.add_argument("--poc", type=int, default=33)
     ap.add_argument("--enc", action="append", default=[], help="extra encoder option for both encodes, e.g. --enc=--SubPuMvp=0")
     ap.add_argument("--keep", default=None, help="directory to keep (and re-use) the streams in")
+    ap.add_argument("--size", default="416x240")
     a = ap.parse_args()
+    a.size = tuple(int(v) for v in a.size.split("x"))
+    experiment(a, print)
+
+
+def experiment(a, print):
+    fields = []
     with tempfile.TemporaryDirectory() as tmp0:
         tmp = a.keep or tmp0
         os.makedirs(tmp, exist_ok=True)
         yuv = os.path.join(tmp, "in.yuv")
-        synth.write_yuv(yuv, synth.gen_yuv(416, 240, a.frames, 8, 20261013), 8)
+        synth.write_yuv(yuv, synth.gen_yuv(a.size[0], a.size[1], a.frames, 8, 20261013), 8)
         A, B = os.path.join(tmp, "A.bin"), os.path.join(tmp, "B.bin")
         ta = tb = float("nan")
         if not (os.path.exists(A) and os.path.exists(B)):
-            ta, _ = encode(yuv, A, os.path.join(tmp, "A_rec.yuv"), a.frames, a.enc, tmp)
-            tb, _ = encode(yuv, B, os.path.join(tmp, "B_rec.yuv"), a.frames, a.enc + ["--DebugBitstream=" + A, "--DebugPOC=%d" % a.poc], tmp)
+            ta, _ = encode(yuv, A, os.path.join(tmp, "A_rec.yuv"), a.frames, a.enc, a.size)
+            tb, _ = encode(yuv, B, os.path.join(tmp, "B_rec.yuv"), a.frames, a.enc + ["--DebugBitstream=" + A, "--DebugPOC=%d" % a.poc], a.size)
         da, db = open(A, "rb").read(), open(B, "rb").read()
-        print("chunk exactness: %d pictures 416x240 8-bit, cfg test_ra_gop16.cfg (GOP 16, intra period 32), QP 32%s" % (a.frames, (", " + " ".join(a.enc)) if a.enc else ""))
+        print("chunk exactness: %d pictures %dx%d 8-bit," % (a.frames, a.size[0], a.size[1]) + " cfg test_ra_gop16.cfg (GOP 16, intra period 32), QP 32%s" % ((", " + " ".join(a.enc)) if a.enc else ""))
         print("  A sequential encode           : %6.1f s, %d bytes, md5 %s" % (ta, len(da), hashlib.md5(da).hexdigest()))
         print("  B re-entered at POC %-3d        : %6.1f s, %d bytes, md5 %s   (POC < %d decoded from A, the rest encoded)" % (a.poc, tb, len(db), hashlib.md5(db).hexdigest(), a.poc))
         na, nb = nal_units(da), nal_units(db)
@@ -215,10 +228,10 @@ def main():
             first = next((k for k, (p, q) in enumerate(zip(x, y)) if p != q), min(len(x), len(y)))
             print("  NAL %3d differs: %d byte(s), first at byte %d of the NAL unit, sizes %d / %d" % (i, nbytes, first, len(x), len(y)))
             if hx and hy:
-                keys = [k for k in hx if hx.get(k) != hy.get(k)]
-                print("      A: %s" % hx)
-                print("      B: %s" % hy)
-                print("      first differing slice-header field(s): %s" % (", ".join(keys) if keys else "none (alf() data or slice data)"))
+                keys = [k for k in list(hx) + [k for k in hy if k not in hx] if hx.get(k) != hy.get(k) and k not in ("header_bits", "alignment_ok")]
+                fields.append(keys[0] if keys else "slice data")
+                print("      POC lsb %d, nal type %d: %s" % (hx.get("poc_lsb", 0), hx["nal_type"], "; ".join("%s A=%s B=%s" % (k, hx.get(k), hy.get(k)) for k in keys)
+                                                             if keys else "slice header identical (the difference is in alf() or the slice data)"))
         if ndiff == 0:
             print("  no NAL unit differs: the re-entered encode is BYTE-EXACT")
         # stitch: A's NAL units coded before the first re-encoded picture + B's from there on
@@ -234,7 +247,12 @@ def main():
         oks = decode(S, os.path.join(tmp, "S_dec.yuv"))
         print("  stitch: A's first %d NAL units + B's remaining %d -> decoder: %d / %d picture hashes (OK); decoded YUV identical to A's: %s"
               % (cut, len(nb) - cut, oks, oka, md5(os.path.join(tmp, "S_dec.yuv")) == md5(os.path.join(tmp, "A_dec.yuv"))))
-        print("  recon of A == recon of B (encoder side): %s" % (md5(os.path.join(tmp, "A_rec.yuv")) == md5(os.path.join(tmp, "B_rec.yuv"))))
+        same = md5(os.path.join(tmp, "S_dec.yuv")) == md5(os.path.join(tmp, "A_dec.yuv"))
+        if os.path.exists(os.path.join(tmp, "A_rec.yuv")):
+            print("  recon of A == recon of B (encoder side): %s" % (md5(os.path.join(tmp, "A_rec.yuv")) == md5(os.path.join(tmp, "B_rec.yuv"))))
+        if fields:
+            print("  FIRST differing slice-header field, in coding order: %s" % fields[0])
+        return da == db, same and oks == oka == a.frames, fields
 
 
 if __name__ == "__main__":
