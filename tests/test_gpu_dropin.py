@@ -155,3 +155,55 @@ def test_encoder_per_call_form_still_exact(tmp_path):
     res = [l for l in r.stderr.splitlines() if "[vvcgpu resident]" in l]
     assert res and "resident form off" in res[-1]
 
+
+
+def _encode_fixture(tmp_path, name, env):
+    sys.path.insert(0, ROOT)
+    from vvcsoftware_vtm_amd import synth
+    m = manifest()[name]
+    yuv = str(tmp_path / "in.yuv")
+    synth.write_yuv(yuv, synth.gen_yuv(m["w"], m["h"], m["frames"], m["bd"], m["seed"]), m["bd"])
+    cfg = os.path.join(ROOT, m["cfg"][1:])
+    binf = str(tmp_path / "out.bin")
+    r = subprocess.run([APP, "--hip", "enc", "-c", cfg, "-i", yuv, "-wdt", str(m["w"]), "-hgt", str(m["h"]), "-fr", "30",
+                        "-f", str(m["frames"]), "-q", str(m["qp"]), "--InputBitDepth=%d" % m["bd"], "--InternalBitDepth=%d" % m["bd"],
+                        "--OutputBitDepth=%d" % m["bd"], "-b", binf, "-o", str(tmp_path / "rec.yuv"), "--SEIDecodedPictureHash=%d" % m.get("hash", 1)] + m.get("extra", []),
+                       capture_output=True, text=True, timeout=3300, env=dict(os.environ, **env))
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert md5(binf) == m["bin_md5"]
+
+    def numbers(tag):
+        line = [l for l in r.stderr.splitlines() if tag in l]
+        assert line, r.stderr[-1000:]
+        return [int(x) for x in line[-1].split(":", 2)[-1].replace(",", " ").replace("(", " ").split() if x.isdigit()], line[-1]
+    return m, r, numbers
+
+
+@needs_ref
+def test_encoder_random_access_gop16_fixture(tmp_path):
+    """the repository's random-access cfg with the reference's RA values (GOP 16, hierarchical B, search range 384 -> minimum window 96,
+    bi-prediction refinement, DepQuant, SAO, ALF; tests/golden/bitstreams/test_ra_gop16.cfg), 17 pictures of 416x240: the production form
+    of the binding (picture-level hooks on the device-resident reconstruction) must reproduce the CPU encoder's bitstream"""
+    m, r, numbers = _encode_fixture(tmp_path, "ragop16_416x240_10b_q32", {"VVCGPU_SHIM_HOOKS": "pic"})
+    calls, line = numbers("[vvcgpu shim]")
+    assert calls[0] == m["frames"] and calls[3] == m["frames"] and calls[4] == m["frames"] and calls[7] >= m["frames"], line
+    assert sum(calls[8:22]) == 0, line                   # no block- or PU-level hook at this level
+    (pics, ups, downs), res = numbers("[vvcgpu resident]")[0][:3], numbers("[vvcgpu resident]")[1]
+    assert pics == m["frames"] and downs == m["frames"] and ups <= 2 * m["frames"] and "resident form on" in res, res
+
+
+@needs_ref
+@pytest.mark.skipif(not os.environ.get("VVCGPU_NIGHTLY"), reason="nightly-style run (minutes of synchronous round trips): VVCGPU_NIGHTLY=1")
+@pytest.mark.parametrize("name,level", [("rab_208x120_10b_q32", "all"), ("ragop16_416x240_10b_q32", "pu")])
+def test_nightly_uncapped_hooks(tmp_path, name, level):
+    """call caps lifted (VVCGPU_SHIM_*_LIMIT=0): every eligible call of every hook is served by the library, none is left to the CPU by a cap"""
+    env = {"VVCGPU_SHIM_HOOKS": level}
+    env.update({"VVCGPU_SHIM_%s_LIMIT" % k: "0" for k in ("INTRA", "FILL", "DEPQUANT", "RDOQ", "DQIT", "TZ")})
+    m, r, numbers = _encode_fixture(tmp_path, name, env)
+    capped, line = numbers("[vvcgpu caps]")
+    assert capped[-6:] == [0] * 6, line
+    calls, cl = numbers("[vvcgpu shim]")
+    assert calls[14] > 0 and calls[20] > 0, cl
+    if level == "all":
+        assert calls[16] > 60000 and calls[21] > 60000 and calls[26] > 20000, cl      # beyond the default caps
+    print(cl)

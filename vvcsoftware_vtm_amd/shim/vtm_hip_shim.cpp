@@ -127,10 +127,15 @@ bool shimEnabled()
 extern long g_resUploads, g_resDownloads, g_resPictures;
 bool residentEnabled();
 long g_calls[28] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
+// calls an (eligible) hook left to the CPU because its call cap was reached: TZSearch, IntraPred, IntraRefs, DepQuant, RDOQ, DequantIT
+long g_capped[6] = { 0, 0, 0, 0, 0, 0 };
+static inline bool capped(long limit, long calls, int slot) { if (limit > 0 && calls >= limit) { g_capped[slot]++; return true; } return false; }
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
                                                        "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld, IntraPred %ld, Border %ld, Hash %ld, CCLM %ld, IntraRefs %ld, DepQuant %ld, RDOQ %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
                                                        g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20], g_calls[21], g_calls[22], g_calls[23], g_calls[24], g_calls[25], g_calls[26], g_calls[27]);
+                            if (shimEnabled()) fprintf(stderr, "[vvcgpu caps] eligible calls left to the CPU by a call cap (VVCGPU_SHIM_*_LIMIT, 0 = none): TZSearch %ld, IntraPred %ld, IntraRefs %ld, DepQuant %ld, RDOQ %ld, DequantIT %ld\n",
+                                                       g_capped[0], g_capped[1], g_capped[2], g_capped[3], g_capped[4], g_capped[5]);
                             if (shimEnabled()) fprintf(stderr, "[vvcgpu resident] in-loop chain: %ld pictures, %ld picture uploads (reconstruction / original), %ld picture downloads, resident form %s\n",
                                                        g_resPictures, g_resUploads, g_resDownloads, residentEnabled() ? "on" : "off"); } } g_report;
 
@@ -1242,7 +1247,7 @@ extern "C" int vvcshim_tzsearch(InterSearch* self, const PredictionUnit* pu, Int
 {
   if (!shimEnabled() || hookLevel() < 1) return 0;
   static const long limit = getenv("VVCGPU_SHIM_TZ_LIMIT") ? atol(getenv("VVCGPU_SHIM_TZ_LIMIT")) : 0;
-  if (limit > 0 && g_calls[20] >= limit) return 0;
+  if (capped(limit, g_calls[20], 0)) return 0;
   const CPelBuf& key = *cs->pcPatternKey;
   const int w = key.width, h = key.height, bd = self->m_lumaClpRng.bd;
   const SPS& sps = *pu->cs->sps;
@@ -1328,7 +1333,7 @@ void wrap_predIntraAng(IntraPrediction* self, const ComponentID compId, PelBuf& 
   const int w = piPred.width, h = piPred.height;
   static const long limit = getenv("VVCGPU_SHIM_INTRA_LIMIT") ? atol(getenv("VVCGPU_SHIM_INTRA_LIMIT")) : 60000;
   bool ok = shimEnabled() && !(hookLevel() < 2) && w >= 4 && h >= 4 && w <= 64 && h <= 64 && !(w & (w - 1)) && !(h & (h - 1)) &&
-            !(limit > 0 && g_calls[21] >= limit);
+            !capped(limit, g_calls[21], 1);
   int T = 0, L = 0;
   if (ok) { VVCGPU(vvcgpu_intra_ref_lengths(w, h, &T, &L)); ok = T == self->m_topRefLength && L == self->m_leftRefLength; }
   const uint32_t mode = ok ? PU::getFinalIntraMode(pu, chType) : 0;
@@ -1480,7 +1485,7 @@ void wrap_initIntraPatternChType(IntraPrediction* self, const CodingUnit& cu, co
   const bool gpu = shimEnabled() && !(hookLevel() < 2);
   const int w = area.width, h = area.height;
   static const long limit = getenv("VVCGPU_SHIM_FILL_LIMIT") ? atol(getenv("VVCGPU_SHIM_FILL_LIMIT")) : 60000;
-  if (!(gpu || dump) || w < 4 || h < 4 || w > 64 || h > 64 || (w & (w - 1)) || (h & (h - 1)) || (gpu && !dump && limit > 0 && g_calls[25] >= limit))
+  if (!(gpu || dump) || w < 4 || h < 4 || w > 64 || h > 64 || (w & (w - 1)) || (h & (h - 1)) || (gpu && !dump && capped(limit, g_calls[25], 2)))
   { real_initIntraPatternChType(self, cu, area, bFilterRefSamples); return; }
   const CodingStructure& cs = *cu.cs;
   const ChannelType chType = toChannelType(area.compID);
@@ -1582,7 +1587,7 @@ extern "C" int vvcshim_depquant(DepQuant* self, TransformUnit* tuP, const Compon
   const int bd = tu.cs->sps->getBitDepth(toChannelType(compID));
   static const long limit = getenv("VVCGPU_SHIM_DEPQUANT_LIMIT") ? atol(getenv("VVCGPU_SHIM_DEPQUANT_LIMIT")) : 20000;
   const bool ok = shimEnabled() && !(hookLevel() < 2) && tu.cs->slice->getDepQuantEnabledFlag() && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
-                  !(w & (w - 1)) && !(h & (h - 1)) && bd >= 8 && bd <= 10 && (int)pSrc.stride == w && !(limit > 0 && g_calls[26] >= limit) &&
+                  !(w & (w - 1)) && !(h & (h - 1)) && bd >= 8 && bd <= 10 && (int)pSrc.stride == w && !capped(limit, g_calls[26], 3) &&
                   !tu.cs->sps->getSpsRangeExtension().getExtendedPrecisionProcessingFlag();
   if (!ok) return 0;
   vvcgpu_dq_rates rt;
@@ -1634,7 +1639,7 @@ extern "C" int vvcshim_rdoq(QuantRDOQ* self, TransformUnit* tuP, const Component
   static const long limit = getenv("VVCGPU_SHIM_RDOQ_LIMIT") ? atol(getenv("VVCGPU_SHIM_RDOQ_LIMIT")) : 20000;
   const bool useRDOQ = tu.transformSkip[compID] ? self->m_useRDOQTS : self->m_useRDOQ;               // the dispatch of :652-690
   const bool ok = shimEnabled() && !(hookLevel() < 2) && useRDOQ && !self->m_useSelectiveRDOQ && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
-                  !(w & (w - 1)) && !(h & (h - 1)) && bd >= 8 && bd <= 10 && (int)pSrc.stride == w && !(limit > 0 && g_calls[27] >= limit) &&
+                  !(w & (w - 1)) && !(h & (h - 1)) && bd >= 8 && bd <= 10 && (int)pSrc.stride == w && !capped(limit, g_calls[27], 4) &&
                   !tu.cs->sps->getSpsRangeExtension().getExtendedPrecisionProcessingFlag();
   if (!ok) return 0;
   vvcgpu_rdoq_rates rt;
@@ -1746,7 +1751,7 @@ void wrap_invTransformNxN(TrQuant* self, TransformUnit& tu, const ComponentID& c
   // an encoder reconstructs a TU for every rate-distortion candidate (1.2 - 1.7 million calls on the 2-3 frame test clips, all
   // verified byte-exact once); routine runs redirect the first VVCGPU_SHIM_DQIT_LIMIT calls (default 60000, 0 = no limit)
   static const long limit = getenv("VVCGPU_SHIM_DQIT_LIMIT") ? atol(getenv("VVCGPU_SHIM_DQIT_LIMIT")) : 60000;
-  if (limit > 0 && g_calls[16] >= limit) ok = false;
+  if (ok && capped(limit, g_calls[16], 5)) ok = false;
   const bool ts = tu.transformSkip[compID] != 0;
   if (ok && !ts) ok = trTypes(self->getEmtMode(tu, compID), self->getEmtTrIdx(tu, compID), hor, ver);
   if (!ok) { real_invTransformNxN(self, tu, compID, pResi, cQP); return; }
