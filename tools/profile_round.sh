@@ -11,6 +11,7 @@ rocprofv3 --pmc SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_INSTS_VALU SQ_INSTS_SA
 rocprofv3 --pmc SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT SQ_INSTS_VALU_MFMA_MOPS_I8 SQ_VALU_MFMA_BUSY_CYCLES --kernel-trace --output-format csv -d gpurun_out/pmc_sq2 -o p -- python3 tools/run_stage.py --reps 2 > gpurun_out/pmc_sq2.log 2>&1 &&
 python3 profiles/summarize.py gpurun_out $TAG > gpurun_out/summarize.log 2>&1 &&
 python3 profiles/summarize_pmc.py gpurun_out $TAG >> gpurun_out/summarize.log 2>&1 &&
+python3 tools/mfma_vs_dot2.py > profiles/${TAG}_mfma_vs_dot2.txt 2> gpurun_out/mfma_vs_dot2.err &&
 python3 bench.py --steps 10 --warmup 3 > gpurun_out/${TAG}_bench_n1.json 2> gpurun_out/bench.err
 mkdir -p gpurun_out/profiles_out && cp profiles/${TAG}_* gpurun_out/profiles_out/ 2>/dev/null
 cp gpurun_out/${TAG}_bench_n1.json gpurun_out/profiles_out/ 2>/dev/null
