@@ -939,6 +939,195 @@ __global__ __launch_bounds__(256) void sad_dense_kernel(const Pel* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// Dense 9 x 9 grid, ROW form ("d9"): the +-4 window of xPatternSearch around a predictor for blocks made of 16 x 16 tiles with 2:1 row
+// sub-sampling.  sad_dense_kernel gives every position its own lane, so each v_sad_u16 costs one LDS dword for the window and a share of
+// the org read, plus a funnel shift for odd positions: it is LDS-bound at a tenth of the vector issue rate.  Here a lane owns a whole ROW
+// of the position grid for one 16 x 16 UNIT of a block (nine lanes per unit, seven units per wave): a window row is read once
+// (13 dwords) and serves all positions of the lane -- the even ones straight from the dwords G[k], the odd ones from the shifted stream
+// H[k] = (G[k+1], G[k]) >> 16, built once per row (12 funnel shifts instead of 32).  A unit whose window starts on an odd sample needs
+// positions t = 1..9 of the aligned row instead of 0..8: every lane accumulates the ten sums t = 0..9 and picks its nine at the end, so
+// lanes of different parity run the same code (80 v_sad_u16 + 12 shifts per row and lane; LDS traffic per v_sad_u16 drops 7x).  The
+// window is staged with aligned 8-byte loads and written one dword down when it starts in the upper half of its 8-byte word; the eight
+// org rows sit in the four spare dwords of the 20-dword row pitch (rows of a unit's nine lanes fall on distinct banks).  Blocks wider or
+// taller than 16 are split into units; their partial sums meet in LDS before the arg-min.
+constexpr int D9_PITCH = 20, D9_ROWS = 24, D9_UNIT_DW = D9_ROWS * D9_PITCH;
+struct D9Meta { long long refOff, orgOff; int ds, par, valid, pad; };
+
+__global__ __launch_bounds__(384) void sad_dense9_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
+                                                        const vvcgpu_search_blk* __restrict__ blocks, int nblocks, int tilesX, int upb, int G,
+                                                        int dx0, int dy0, vvcgpu_mvcost mv, int useBest,
+                                                        unsigned* __restrict__ out, vvcgpu_search_best* __restrict__ best)
+{
+  extern __shared__ __align__(16) unsigned ldsN[];
+  const int T = (int)blockDim.x, tid = threadIdx.x;
+  const int U = G * upb;
+  D9Meta* meta = reinterpret_cast<D9Meta*>(ldsN + U * D9_UNIT_DW);                            // [U]
+  unsigned long long* costTab = reinterpret_cast<unsigned long long*>(meta + U);              // [R5C_COST_N]
+  unsigned long long* keyL = costTab + R5C_COST_N;                                            // [G]
+  unsigned* sums = reinterpret_cast<unsigned*>(keyL + G);                                     // [G * 81] (upb > 1)
+  unsigned char* bitsXY = reinterpret_cast<unsigned char*>(sums + (upb > 1 ? G * 81 : 0));    // [9] x, [9] y
+  const int b0 = blockIdx.x * G;
+  if (tid < U)
+  {
+    const int g = tid / upb, t = tid - g * upb, ty = t / tilesX, tx = t - ty * tilesX;
+    D9Meta m = {};
+    m.valid = b0 + g < nblocks;
+    if (m.valid)
+    {
+      const vvcgpu_search_blk blk = blocks[b0 + g];
+      const long long winOff = (long long)(blk.ref_y + dy0 + 16 * ty) * rs + blk.ref_x + dx0 + 16 * tx;
+      const int o = (int)(((long long)(reinterpret_cast<uintptr_t>(ref) >> 1) + winOff) & 3);   // samples above the 8-byte boundary below the window start
+      m.refOff = winOff - o; m.ds = o >> 1; m.par = o & 1;
+      m.orgOff = (long long)(blk.org_y + 16 * ty) * os + blk.org_x + 16 * tx;
+    }
+    meta[tid] = m;
+  }
+  if (useBest)
+  {
+    for (int n = tid; n < R5C_COST_N; n += T) costTab[n] = (unsigned long long)(mv.lambda * (double)n);
+    if (tid < 18)
+    {
+      const int v = tid < 9 ? (((dx0 + tid) << mv.cost_scale) - mv.pred_hor) : (((dy0 + tid - 9) << mv.cost_scale) - mv.pred_ver);
+      bitsXY[tid] = (unsigned char)expgolomb_bits(v >> mv.imv_shift);
+    }
+    if (tid < G) keyL[tid] = ~0ull;
+  }
+  if (upb > 1)
+    for (int n = tid; n < G * 81; n += T) sums[n] = 0u;
+  __syncthreads();
+
+  // window: 24 rows x 7 aligned 8-byte loads per unit, stored so that LDS dword 0 of a row = samples (winOff - par, winOff - par + 1);
+  // org: eight sub-sampled rows of 8 biased pairs in the spare dwords 16..19 of window rows 2 r (pairs 0..3) and 2 r + 1 (pairs 4..7).
+  // EVERY load of a thread (<= 20 window words, <= 8 org pairs) is issued before the first store: one memory round trip for the staging, one
+  // for the block list in front of it.  (Measured at 4K: staging alone 24 - 36 us per launch, the SAD loop alone 16.)
+  constexpr int FBW = 20, FBO = 8;
+  const int nW = U * (D9_ROWS * 7), nO = U * 64;
+  for (int e0 = tid, f0 = tid; e0 < nW || f0 < nO; e0 += FBW * T, f0 += FBO * T)
+  {
+    uint2 v[FBW]; int dstHi[FBW]; unsigned skipLo = 0u;                    // dstHi = LDS index of the HIGH dword (>= 0), -1 = nothing to store
+    unsigned short lo[FBO], hi[FBO]; int dst[FBO];
+#pragma unroll
+    for (int i = 0; i < FBW; i++)
+    {
+      const int e = e0 + i * T;
+      dstHi[i] = -1;
+      if (e < nW)
+      {
+        const int u = (int)__umulhi((unsigned)e, 25565282u), rem = e - u * (D9_ROWS * 7);             // e / 168, exact for e < 2^24
+        const int r = (int)(((unsigned)rem * 9363u) >> 16), q = rem - r * 7;                        // rem / 7 (rem < 168)
+        const D9Meta m = meta[u];
+        if (m.valid)
+        {
+          v[i] = *reinterpret_cast<const uint2*>(ref + (m.refOff + (long long)r * rs + 4 * q));
+          dstHi[i] = u * D9_UNIT_DW + r * D9_PITCH + 2 * q - m.ds + 1;
+          if (2 * q - m.ds < 0) skipLo |= 1u << i;                                                  // the low dword falls off the row
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FBO; i++)
+    {
+      const int e = f0 + i * T;
+      dst[i] = -1;
+      if (e < nO)
+      {
+        const int u = e >> 6, rem = e & 63, r = rem >> 3, k = rem & 7;
+        const D9Meta m = meta[u];
+        if (m.valid)
+        {
+          const Pel* q = org + (m.orgOff + (long long)(2 * r) * os + 2 * k);
+          lo[i] = (unsigned short)q[0]; hi[i] = (unsigned short)q[1];
+          dst[i] = u * D9_UNIT_DW + (2 * r + (k >> 2)) * D9_PITCH + 16 + (k & 3);
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < FBW; i++)
+      if (dstHi[i] >= 0)
+      {
+        if (!(skipLo & (1u << i))) ldsN[dstHi[i] - 1] = v[i].x ^ 0x80008000u;
+        ldsN[dstHi[i]] = v[i].y ^ 0x80008000u;
+      }
+#pragma unroll
+    for (int i = 0; i < FBO; i++)
+      if (dst[i] >= 0) ldsN[dst[i]] = ((unsigned)lo[i] | ((unsigned)hi[i] << 16)) ^ 0x80008000u;
+  }
+  __syncthreads();
+
+  const int u = (int)(((unsigned)tid * 7282u) >> 16), j = tid - 9 * u;                          // tid / 9 (tid < 384)
+  if (u < U && meta[u].valid)
+  {
+    const unsigned* base = ldsN + u * D9_UNIT_DW;
+    unsigned Tt[10];
+#pragma unroll
+    for (int t = 0; t < 10; t++) Tt[t] = 0u;
+#pragma unroll 2
+    for (int r = 0; r < 8; r++)
+    {
+      const unsigned* row = base + (j + 2 * r) * D9_PITCH;
+      const uint4 a = *reinterpret_cast<const uint4*>(row), b = *reinterpret_cast<const uint4*>(row + 4), c = *reinterpret_cast<const uint4*>(row + 8);
+      const unsigned Gd[13] = { a.x, a.y, a.z, a.w, b.x, b.y, b.z, b.w, c.x, c.y, c.z, c.w, row[12] };
+      const uint4 o0 = *reinterpret_cast<const uint4*>(base + (2 * r) * D9_PITCH + 16), o1 = *reinterpret_cast<const uint4*>(base + (2 * r + 1) * D9_PITCH + 16);
+      const unsigned O[8] = { o0.x, o0.y, o0.z, o0.w, o1.x, o1.y, o1.z, o1.w };
+      unsigned Hd[12];
+#pragma unroll
+      for (int k = 0; k < 12; k++) Hd[k] = __builtin_amdgcn_alignbit(Gd[k + 1], Gd[k], 16);
+#pragma unroll
+      for (int t = 0; t < 10; t++)
+#pragma unroll
+        for (int k = 0; k < 8; k++) Tt[t] = __builtin_amdgcn_sad_u16(O[k], (t & 1) ? Hd[(t >> 1) + k] : Gd[(t >> 1) + k], Tt[t]);
+    }
+    const bool par = meta[u].par != 0;
+    const int g = u / upb;
+    unsigned long long kmin = ~0ull;
+#pragma unroll
+    for (int x = 0; x < 9; x++)
+    {
+      const unsigned sad = (par ? Tt[x + 1] : Tt[x]) << 1;                                     // the row sub-sampling shift of the reference
+      if (upb > 1) atomicAdd(&sums[g * 81 + j * 9 + x], sad);
+      else
+      {
+        if (out) out[(size_t)(b0 + g) * 81 + j * 9 + x] = sad;
+        if (useBest)
+        {
+          const unsigned long long key = (((unsigned long long)sad + costTab[bitsXY[x] + bitsXY[9 + j]]) << 24) | (unsigned)(j * 9 + x);
+          kmin = key < kmin ? key : kmin;
+        }
+      }
+    }
+    if (upb == 1 && useBest) atomicMin(&keyL[g], kmin);
+  }
+  if (upb > 1)
+  {
+    __syncthreads();
+    for (int e = tid; e < G * 81; e += T)
+    {
+      const int g = e / 81, pidx = e - g * 81;
+      if (b0 + g >= nblocks) continue;
+      const unsigned sad = sums[e];
+      if (out) out[(size_t)(b0 + g) * 81 + pidx] = sad;
+      if (useBest)
+      {
+        const int jj = pidx / 9, x = pidx - jj * 9;
+        atomicMin(&keyL[g], (((unsigned long long)sad + costTab[bitsXY[x] + bitsXY[9 + jj]]) << 24) | (unsigned)pidx);
+      }
+    }
+  }
+  if (!useBest) return;
+  __syncthreads();
+  if (tid < G && b0 + tid < nblocks)
+  {
+    const unsigned long long key = keyL[tid];
+    const int idx = (int)(key & 0xFFFFFFu);
+    const unsigned long long cost = key >> 24;
+    const int jj = idx / 9, i = idx - jj * 9;
+    vvcgpu_search_best r;
+    r.x = dx0 + i; r.y = dy0 + jj; r.cost = cost; r.sad = cost - costTab[bitsXY[i] + bitsXY[9 + jj]];
+    best[b0 + tid] = r;
+  }
+}
+
 // decodes the packed (cost << 24 | scan index) keys left in best[].cost by sad_raster5c_kernel
 __global__ __launch_bounds__(256) void sad_best_decode_kernel(int nblocks, int dx0, int dy0, int nx, int sx, int sy, vvcgpu_mvcost mv,
                                                               vvcgpu_search_best* __restrict__ best)
@@ -1077,6 +1266,34 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
   VVC_CHECK_ARG((best == nullptr) == (mvcost_host == nullptr), "sad_search: best and mvcost must be given together");
   hipStream_t st0 = (hipStream_t)stream;
   static const int denseOff = getenv("VVCGPU_NO_DENSE") ? 1 : 0;          // A/B timing switch
+  static const int d9Off = getenv("VVCGPU_NO_D9") ? 1 : 0;                // A/B timing switch: 9 x 9 grids through sad_dense_kernel
+  if (!denseOff && !d9Off && sx == 1 && sy == 1 && nx == 9 && ny == 9 && sub_shift == 1 && (w & 15) == 0 && (h & 15) == 0 && w <= 64 && h <= 64 &&
+      (ref_stride & 3) == 0 && (!best || (mvcost_host->lambda >= 0.0 && mvcost_host->lambda < 1.0e9)))
+  {
+    const int tilesX = w >> 4, upb = tilesX * (h >> 4);
+    // workgroup size: the one of 256 / 320 / 384 threads that keeps most lanes busy (nine lanes per unit, whole blocks per workgroup)
+    // Workgroup size.  Measured (profiles/r02_dense9.txt): the staging is bound by memory-level parallelism (87 % of the L2 requests miss, ~1.2 TB/s of
+    // scattered 128-byte lines whatever the kernel does), so several small workgroups in different phases beat one large one: 128 threads = 14 units.
+    // 64 x 64 blocks (16 units each) would need 320 threads for two blocks and lose; they stay with sad_dense_kernel.
+    static const int tEnv = getenv("VVCGPU_D9_T") ? atoi(getenv("VVCGPU_D9_T")) : 0;   // experiment: workgroup size
+    int T = 128, G = upb <= 4 ? (128 / 9) / upb : 0;
+    if (tEnv >= 64 && tEnv <= 384 && (tEnv & 63) == 0 && (tEnv / 9) / upb > 0) { T = tEnv; G = (tEnv / 9) / upb; }
+    if (G > 0)
+    {
+      const int U = G * upb;
+      const size_t smem = (size_t)U * D9_UNIT_DW * 4 + (size_t)U * sizeof(D9Meta) + R5C_COST_N * 8 + (size_t)G * 8 + (upb > 1 ? (size_t)G * 81 * 4 : 0) + 32;
+      vvcgpu_mvcost mv = {};
+      if (best) mv = *mvcost_host;
+      if (smem > 48 * 1024)
+        VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_dense9_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+      static const int trace = getenv("VVCGPU_TRACE_PATH") ? 1 : 0;
+      if (trace) fprintf(stderr, "[vvcgpu] sad_search %dx%d 9x9: row form, %d threads, %d blocks per workgroup, %zu B LDS\n", w, h, T, G, smem);
+      hipLaunchKernelGGL(sad_dense9_kernel, dim3(cdiv(nblocks, G)), dim3(T), smem, st0, org, org_stride, ref, ref_stride, blocks, nblocks, tilesX, upb, G,
+                         dx0, dy0, mv, best ? 1 : 0, sad_out, best);
+      VVC_LAUNCH_CHECK();
+      return VVCGPU_OK;
+    }
+  }
   if (!denseOff && sx == 1 && sy == 1 && nx * ny <= 256 && w >= 8 && w <= 128 && (w & (w - 1)) == 0 && (ref_stride & 1) == 0 &&
       ((uintptr_t)ref & 3) == 0)
   {
