@@ -705,6 +705,229 @@ __global__ __launch_bounds__(MAXT, MINW) void sad_raster5c_kernel(const unsigned
 }
 
 // ---------------------------------------------------------------------------------------------------
+// Raster kernel, QUAD form ("r5q").  PMC of the r5c form at 4K (profiles/r02_pmc_sq.csv): the vector pipe and the LDS pipe are both ~60 %
+// busy -- a lane reads 13-14 dwords of window per chunk-row for the 16 v_sad_u16 of its two positions (3.4 B per v_sad_u16; four SIMDs at
+// full rate would need 197 B/clk of the CU's 128).  Here a lane owns FOUR consecutive raster columns 4k .. 4k+3 (all four alignment
+// classes): their windows start 0 / 5 / 10 / 15 samples into the same span of 31 + 16 samples, so 16 (17) dwords serve 32 v_sad_u16 --
+// 2 B per v_sad_u16.  Columns on an odd sample use the odd-shifted org layout and one merge, exactly as in r5c; the two layouts of the
+// org row are both held as scalar operands (16 SGPRs per chunk-row).  One stage = ONE chunk-row (17 VGPRs, two stages in flight).
+// A wave item is a row group of six raster rows (10 column groups x 3 rows per 32-lane half, the r5c lane map and bank analysis
+// unchanged: the ds_read_b64 of step n reads slot 5k + n); items are twice as heavy as in r5c and half as many, so the rows of a block
+// are split over up to four waves (SPLIT), the partial sums meeting in LDS after the loop.
+struct R5qStage { unsigned ovE[8], ovO[8]; unsigned long long d[8]; unsigned x1; };
+
+template <int OA>
+__device__ __forceinline__ void r5q_issue(R5qStage& st, const unsigned* __restrict__ opE, const unsigned* __restrict__ opO, unsigned a)
+{
+#pragma unroll
+  for (int k = 0; k < 8; k++) { st.ovE[k] = opE[k]; st.ovO[k] = opO[k]; }
+  // words 0..7 of the span (dwords 0..15); OA >= 2 also needs dword 16.  Single ds_read_b64 on purpose (see r5c_issue_row).
+  if (OA < 2)
+  {
+    unsigned dummy;
+    asm volatile("ds_read_b64 %0, %9\n\tds_read_b64 %1, %9 offset:8\n\tds_read_b64 %2, %9 offset:16\n\tds_read_b64 %3, %9 offset:24\n\t"
+                 "ds_read_b64 %4, %9 offset:32\n\tds_read_b64 %5, %9 offset:40\n\tds_read_b64 %6, %9 offset:48\n\tds_read_b64 %7, %9 offset:56"
+                 : "=&v"(st.d[0]), "=&v"(st.d[1]), "=&v"(st.d[2]), "=&v"(st.d[3]), "=&v"(st.d[4]), "=&v"(st.d[5]), "=&v"(st.d[6]), "=&v"(st.d[7]), "=&v"(dummy)
+                 : "v"(a) : "memory");
+  }
+  else
+    asm volatile("ds_read_b64 %0, %9\n\tds_read_b64 %1, %9 offset:8\n\tds_read_b64 %2, %9 offset:16\n\tds_read_b64 %3, %9 offset:24\n\t"
+                 "ds_read_b64 %4, %9 offset:32\n\tds_read_b64 %5, %9 offset:40\n\tds_read_b64 %6, %9 offset:48\n\tds_read_b64 %7, %9 offset:56\n\t"
+                 "ds_read_b32 %8, %9 offset:64"
+                 : "=&v"(st.d[0]), "=&v"(st.d[1]), "=&v"(st.d[2]), "=&v"(st.d[3]), "=&v"(st.d[4]), "=&v"(st.d[5]), "=&v"(st.d[6]), "=&v"(st.d[7]), "=&v"(st.x1)
+                 : "v"(a) : "memory");
+}
+
+// position m of the lane starts OA + 5 m samples into the span: dword I = (OA + 5 m) >> 1, parity P = (OA + 5 m) & 1
+template <int OA>
+__device__ __forceinline__ void r5q_compute(const R5qStage& st, unsigned (&acc)[4])
+{
+  unsigned dd[17];
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+  {
+    asm volatile("" :: "v"(st.d[k]));                     // whole 64-bit destination stays allocated until here
+    dd[2 * k] = (unsigned)st.d[k]; dd[2 * k + 1] = (unsigned)(st.d[k] >> 32);
+  }
+  if (OA >= 2) { asm volatile("" :: "v"(st.x1)); dd[16] = st.x1; } else dd[16] = 0u;
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+  {
+    constexpr int dummy = 0; (void)dummy;
+    const int s = OA + 5 * m, I = s >> 1;
+    if (s & 1)
+    {
+#pragma unroll
+      for (int k = 0; k < 7; k++) acc[m] = __builtin_amdgcn_sad_u16(st.ovO[k], dd[I + 1 + k], acc[m]);
+      acc[m] = __builtin_amdgcn_sad_u16(st.ovO[7], (dd[I + 8] & 0xFFFFu) | (dd[I] & 0xFFFF0000u), acc[m]);
+    }
+    else
+    {
+#pragma unroll
+      for (int k = 0; k < 8; k++) acc[m] = __builtin_amdgcn_sad_u16(st.ovE[k], dd[I + k], acc[m]);
+    }
+  }
+}
+
+// walks nStages chunk-rows starting at chunk-row cr0 of the block (CH chunks per row)
+template <int OA>
+__device__ __forceinline__ void r5q_positions(const unsigned* __restrict__ orgE, const unsigned* __restrict__ orgO, unsigned base, int ldsStep, int CH,
+                                              int cr0, int nStages, unsigned (&acc)[4])
+{
+  R5qStage A, B;
+  const int chShift = 31 - __clz(CH);
+  int ch = cr0 & (CH - 1);
+  unsigned oOff = (unsigned)cr0 * 8u;
+  unsigned lOff = (unsigned)((cr0 >> chShift) * ldsStep + ch * 8) * 4u;
+  const unsigned rowAdv = (unsigned)(ldsStep - 8 * (CH - 1)) * 4u;          // from the last chunk of a row to the first of the next sampled row
+  auto issue = [&](R5qStage& st)
+  {
+    r5q_issue<OA>(st, orgE + oOff, orgO + oOff, base + lOff);
+    oOff += 8u; ch++;
+    if (ch == CH) { ch = 0; lOff += rowAdv; } else lOff += 32u;
+  };
+  issue(A);
+  for (int s = 0; s < nStages; s += 2)
+  {
+    R5C_WAIT_LGKM0();
+    if (s + 1 < nStages) issue(B);
+    __builtin_amdgcn_sched_barrier(0);
+    r5q_compute<OA>(A, acc);
+    if (s + 1 >= nStages) break;
+    R5C_WAIT_LGKM0();
+    if (s + 2 < nStages) issue(A);
+    __builtin_amdgcn_sched_barrier(0);
+    r5q_compute<OA>(B, acc);
+  }
+}
+
+template <int MAXT, int MINW, int SPLIT>
+__global__ __launch_bounds__(MAXT, MINW) void sad_raster5q_kernel(const unsigned* __restrict__ orgPacked,
+                                                           const Pel* __restrict__ ref, int rs,
+                                                           const vvcgpu_search_blk* __restrict__ blocks, int w, int h, int subShift,
+                                                           int dx0, int dy0, int nx, int ny, int rowsPerStrip, int pitchDw,
+                                                           int nstrips, unsigned invStrips, int total, int winBytes, vvcgpu_mvcost mv, int useBest,
+                                                           unsigned* __restrict__ out, vvcgpu_search_best* __restrict__ best)
+{
+  extern __shared__ __align__(16) unsigned refL[];
+  __shared__ unsigned long long wgKey;
+  const int tid = threadIdx.x;
+  const int chunk = (total + 7) >> 3;                                       // XCD-aware order, as r5c
+  const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (item >= total) return;
+  const int b = nstrips == 1 ? item : (int)__umulhi((unsigned)item, invStrips), j0 = (item - b * nstrips) * rowsPerStrip;
+  const int nj = min(rowsPerStrip, ny - j0);
+  const vvcgpu_search_blk blk = blocks[b];
+  const int hs = h >> subShift;
+  const int winRows = (nj - 1) * 5 + h;
+  const int Ww = (nx - 1) * 5 + w;
+  const ptrdiff_t winOff = (ptrdiff_t)(blk.ref_y + dy0 + j0 * 5) * rs + blk.ref_x + dx0;
+  const int off = (int)(winOff & 7);
+  fill_window_cols<8>(refL, reinterpret_cast<const uint4*>(ref + (winOff - off)), rs >> 3, winRows, pitchDw,
+                      ((Ww - 1 + off) >> 3) + 1, tid, (int)blockDim.x);
+  unsigned char* bitsX = reinterpret_cast<unsigned char*>(refL) + winBytes;   // [nx] then [rowsPerStrip]
+  unsigned char* bitsY = bitsX + nx;
+  unsigned long long* costTab = reinterpret_cast<unsigned long long*>(bitsX + ((nx + rowsPerStrip + 15) & ~15));
+  if (useBest)
+  {
+    if (tid == 0) wgKey = ~0ull;
+    for (int n = tid; n < R5C_COST_N; n += (int)blockDim.x) costTab[n] = (unsigned long long)(mv.lambda * (double)n);
+    for (int n = tid; n < nx + nj; n += (int)blockDim.x)
+    {
+      const int v = n < nx ? (((dx0 + n * 5) << mv.cost_scale) - mv.pred_hor) : (((dy0 + (j0 + n - nx) * 5) << mv.cost_scale) - mv.pred_ver);
+      bitsX[n] = (unsigned char)expgolomb_bits(v >> mv.imv_shift);
+    }
+  }
+  __syncthreads();
+
+  const int CH = w >> 4;
+  const int nStages = hs * CH;                                                // chunk-rows of the block
+  const int ngrp = (nj + 5) / 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
+  const int lane = tid & 63;
+  const unsigned layoutDw = (unsigned)(hs * (w >> 1));
+  const unsigned* orgE = orgPacked + (size_t)b * 2u * layoutDw;
+  const unsigned* orgO = orgE + layoutDw;
+  const int ldsStep = pitchDw << subShift;
+  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)refL;
+  const int OA = off & 3;                                                     // sub-word offset of column 4 k: the same for every lane
+  unsigned long long kmin = ~0ull;
+  auto lane_map = [](int ln, int& k, int& m, bool& dead) { const int q = ln & 31; m = (q * 26) >> 8; k = q - 10 * m; dead = m >= 3; if (dead) m = 0; };
+  auto finish = [&](int g, const unsigned (&acc)[4])
+  {
+    int lane2 = lane;
+    asm volatile("" : "+v"(lane2));                                           // opaque: the lane map is re-derived here instead of being kept live
+    int k, m; bool dead;
+    lane_map(lane2, k, m, dead);
+    const int jj = g * 6 + (lane2 >> 5) * 3 + m;
+    const int i0 = 4 * k;
+    if (!dead && jj < nj && i0 < nx)
+    {
+      const int idx0 = (j0 + jj) * nx + i0;
+      unsigned* o = out ? out + (size_t)b * ny * nx + idx0 : nullptr;
+      const unsigned by = useBest ? bitsY[jj] : 0u;
+#pragma unroll
+      for (int q = 0; q < 4; q++)
+      {
+        if (i0 + q >= nx) break;
+        const unsigned v = acc[q] << subShift;
+        if (o) o[q] = v;
+        if (useBest)
+        {
+          const unsigned long long key = ((v + costTab[bitsX[i0 + q] + by]) << 24) | (unsigned)(idx0 + q);
+          kmin = key < kmin ? key : kmin;
+        }
+      }
+    }
+  };
+  unsigned keep[4] = { 0u, 0u, 0u, 0u }; int keepIt = -1;
+  for (int it = wave; it < ngrp * SPLIT; it += nwaves)
+  {
+    const int part = SPLIT == 1 ? 0 : it % SPLIT, g = SPLIT == 1 ? it : it / SPLIT;
+    const int nSt = nStages / SPLIT;
+    unsigned acc[4] = { 0u, 0u, 0u, 0u };
+    {
+      int k, m; bool dead;
+      lane_map(lane, k, m, dead);
+      const int jj = g * 6 + (lane >> 5) * 3 + m;
+      const int i0 = 4 * k;
+      const int cx = 5 * (i0 < nx ? i0 : 0) + off;                           // dead lanes re-read a live lane's address (broadcast)
+      const unsigned base = ldsBase + (unsigned)(2 * (cx >> 2) + (min(jj, nj - 1) * 5) * pitchDw) * 4u;
+      if (OA == 0)      r5q_positions<0>(orgE, orgO, base, ldsStep, CH, part * nSt, nSt, acc);
+      else if (OA == 1) r5q_positions<1>(orgE, orgO, base, ldsStep, CH, part * nSt, nSt, acc);
+      else if (OA == 2) r5q_positions<2>(orgE, orgO, base, ldsStep, CH, part * nSt, nSt, acc);
+      else              r5q_positions<3>(orgE, orgO, base, ldsStep, CH, part * nSt, nSt, acc);
+    }
+    if (SPLIT > 1) { keep[0] = acc[0]; keep[1] = acc[1]; keep[2] = acc[2]; keep[3] = acc[3]; keepIt = it; }   // one item per wave (host)
+    else finish(g, acc);
+  }
+  if (SPLIT > 1)
+  {
+    __syncthreads();                                                          // every wave is done with the window: its first bytes are re-used
+    uint4* xch = reinterpret_cast<uint4*>(refL);
+    if (keepIt >= 0 && (keepIt % SPLIT) != 0) xch[((keepIt / SPLIT) * (SPLIT - 1) + (keepIt % SPLIT) - 1) * 64 + lane] = make_uint4(keep[0], keep[1], keep[2], keep[3]);
+    __syncthreads();
+    if (keepIt >= 0 && (keepIt % SPLIT) == 0)
+    {
+#pragma unroll
+      for (int p = 1; p < SPLIT; p++)
+      {
+        const uint4 o = xch[((keepIt / SPLIT) * (SPLIT - 1) + p - 1) * 64 + lane];
+        keep[0] += o.x; keep[1] += o.y; keep[2] += o.z; keep[3] += o.w;
+      }
+      finish(keepIt / SPLIT, keep);
+    }
+  }
+  if (useBest)
+  {
+    kmin = wave_min_u64(kmin);
+    if (lane == 0 && kmin != ~0ull) atomicMin(&wgKey, kmin);
+    __syncthreads();
+    if (tid == 0 && wgKey != ~0ull) atomicMin(reinterpret_cast<unsigned long long*>(&best[b].cost), wgKey);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Raster kernel, GROUP form for 16-wide blocks ("r5g").  PMC of sad_raster5c_kernel on a 3840x2160 picture of 16x16 blocks
 // (profiles/r02a_pmc_sq.csv): 331 vector + 278 scalar instructions per wave item for the 128 v_sad_u16 that are the work -- a wave item
 // of a 16x16 block is only four software-pipeline stages long, so the window fill (every block stages its own 206-column window), the
@@ -1392,6 +1615,48 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
     if (smem <= 150 * 1024 && ((hsR * chunks) & 1) == 0 && nx + rps <= 4096 &&
         (unsigned long long)nblocks * nstrips * nstrips < (1ull << 32))   // item decode by multiply-high (and total fits an int)
     {
+      // quad form (four columns per lane): items are row groups only; the block's chunk-rows are split over 1 / 2 / 4 waves so that a
+      // workgroup has 8 - 12 waves
+      static const int r5qOff = getenv("VVCGPU_NO_R5Q") ? 1 : 0;              // A/B timing switch
+      static const int r5qSplit = getenv("VVCGPU_R5Q_SPLIT") ? atoi(getenv("VVCGPU_R5Q_SPLIT")) : 0;
+      if (!r5qOff && nx <= 40)
+      {
+        const int itemsQ = cdiv(rps, 6), nSt = hsR * chunks;
+        int splitQ = 1;
+        while (splitQ < 4 && itemsQ * splitQ * 2 <= 12 && (nSt % (splitQ * 2)) == 0 && nSt / (splitQ * 2) >= 4) splitQ *= 2;
+        if ((r5qSplit == 1 || r5qSplit == 2 || r5qSplit == 4) && (nSt % r5qSplit) == 0 && itemsQ * r5qSplit <= 16) splitQ = r5qSplit;
+        const int threadsQ = itemsQ * splitQ * 64;
+        const int totalQ = nblocks * nstrips;
+        const size_t packedDwQ = (size_t)nblocks * 2 * hsR * (w >> 1);
+        unsigned* packedQ = static_cast<unsigned*>(vvcgpu_scratch(st0, packedDwQ * sizeof(unsigned)));
+        if (!packedQ) return VVCGPU_E_DEVICE;
+        hipLaunchKernelGGL(r5c_pack_org_kernel, dim3((unsigned)((packedDwQ + 255) / 256)), dim3(256), 0, st0, org, org_stride, blocks, nblocks,
+                           w, hsR, sub_shift, packedQ);
+        VVC_LAUNCH_CHECK();
+        vvcgpu_mvcost mvq = {};
+        if (best)
+        {
+          mvq = *mvcost_host;
+          VVC_HIP(hipMemsetAsync(best, 0xFF, (size_t)nblocks * sizeof(vvcgpu_search_best), st0));
+        }
+#define LAUNCH_R5Q(SPL)                                                                                                          \
+        do {                                                                                                                    \
+          auto kfn = sad_raster5q_kernel<1024, 4, SPL>;                                                                          \
+          if (smem > 48 * 1024)                                                                                                 \
+            VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+          hipLaunchKernelGGL(kfn, dim3(cdiv(totalQ, 8) * 8), dim3(threadsQ), smem, st0, packedQ, ref, ref_stride,               \
+                             blocks, w, h, sub_shift, dx0, dy0, nx, ny, rps, pitch, nstrips, 0xFFFFFFFFu / (unsigned)nstrips + 1u, totalQ, (int)winB, mvq, best ? 1 : 0, sad_out, best); \
+        } while (0)
+        if (splitQ == 4) LAUNCH_R5Q(4); else if (splitQ == 2) LAUNCH_R5Q(2); else LAUNCH_R5Q(1);
+#undef LAUNCH_R5Q
+        VVC_LAUNCH_CHECK();
+        if (best)
+        {
+          hipLaunchKernelGGL(sad_best_decode_kernel, dim3(cdiv(nblocks, 256)), dim3(256), 0, st0, nblocks, dx0, dy0, nx, sx, sy, mvq, best);
+          VVC_LAUNCH_CHECK();
+        }
+        return VVCGPU_OK;
+      }
       const int items = 2 * cdiv(rps, 6);
       // wide blocks, few items per strip: two waves per item (see the kernel) -- one item per wave, at most 12 waves
       const int split = (!splitOff && chunks >= 2 && items <= 6 && nx <= 40 && (((hsR * chunks) >> 1) & 1) == 0) ? 2 : 1;
