@@ -541,8 +541,9 @@ __device__ __forceinline__ void fill_window_cols(unsigned* __restrict__ lds, con
 // org rows of the raster kernel, packed per block: [block][layout even | odd][hs rows][w / 2 dwords], biased (^ 0x8000 per
 // sample), row sub-sampling and odd block origins resolved here.  Layouts per 16-sample chunk: see r5c_compute.
 // One thread per output dword; 2 * hs * w / 2 dwords per block.
+// interleave != 0 (quad form): [block][chunk-row][even 8 | odd 8] -- both layouts of a chunk-row are one 64-byte scalar load
 __global__ __launch_bounds__(256) void r5c_pack_org_kernel(const Pel* __restrict__ org, int os, const vvcgpu_search_blk* __restrict__ blocks,
-                                                           int nblocks, int w, int hs, int subShift, unsigned* __restrict__ packed)
+                                                           int nblocks, int w, int hs, int subShift, unsigned* __restrict__ packed, int interleave = 0)
 {
   const unsigned perLayout = (unsigned)(hs * (w >> 1)), perBlock = 2u * perLayout;
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -558,7 +559,8 @@ __global__ __launch_bounds__(256) void r5c_pack_org_kernel(const Pel* __restrict
   if (!odd) { a = 2 * k; c = 2 * k + 1; }
   else if (k < 7) { a = 2 * k + 1; c = 2 * k + 2; }
   else { a = 15; c = 0; }
-  packed[gid] = ((unsigned)(unsigned short)o[a] | ((unsigned)(unsigned short)o[c] << 16)) ^ 0x80008000u;
+  const size_t dst = interleave ? (size_t)b * perBlock + (size_t)((row * (w >> 4) + chunk) * 16 + (int)odd * 8 + k) : gid;
+  packed[dst] = ((unsigned)(unsigned short)o[a] | ((unsigned)(unsigned short)o[c] << 16)) ^ 0x80008000u;
 }
 
 // MINW = waves per SIMD the register allocation must allow: 6 (<= 80 VGPRs) when three workgroups fit the CU's LDS, else 4
@@ -714,13 +716,16 @@ __global__ __launch_bounds__(MAXT, MINW) void sad_raster5c_kernel(const unsigned
 // A wave item is a row group of six raster rows (10 column groups x 3 rows per 32-lane half, the r5c lane map and bank analysis
 // unchanged: the ds_read_b64 of step n reads slot 5k + n); items are twice as heavy as in r5c and half as many, so the rows of a block
 // are split over up to four waves (SPLIT), the partial sums meeting in LDS after the loop.
+// Measured (profiles/r02_raster_parts.txt): equal to the pair form for 32-wide blocks, 4 % faster for 64-wide ones -- with the window staging
+// taken out the SAD loop alone is 90 % of the kernel time and its executed vector instructions (v_sad_u16 incl. lane / row / column padding
+// + 28 % moves and merges) x 4.4 cycles account for that time: the loop is bound by the VOP3 issue rate, not by LDS.
 struct R5qStage { unsigned ovE[8], ovO[8]; unsigned long long d[8]; unsigned x1; };
 
 template <int OA>
-__device__ __forceinline__ void r5q_issue(R5qStage& st, const unsigned* __restrict__ opE, const unsigned* __restrict__ opO, unsigned a)
+__device__ __forceinline__ void r5q_issue(R5qStage& st, const unsigned* __restrict__ op, unsigned a)
 {
 #pragma unroll
-  for (int k = 0; k < 8; k++) { st.ovE[k] = opE[k]; st.ovO[k] = opO[k]; }
+  for (int k = 0; k < 8; k++) { st.ovE[k] = op[k]; st.ovO[k] = op[8 + k]; }        // wave-uniform: one 64-byte scalar load
   // words 0..7 of the span (dwords 0..15); OA >= 2 also needs dword 16.  Single ds_read_b64 on purpose (see r5c_issue_row).
   if (OA < 2)
   {
@@ -771,19 +776,19 @@ __device__ __forceinline__ void r5q_compute(const R5qStage& st, unsigned (&acc)[
 
 // walks nStages chunk-rows starting at chunk-row cr0 of the block (CH chunks per row)
 template <int OA>
-__device__ __forceinline__ void r5q_positions(const unsigned* __restrict__ orgE, const unsigned* __restrict__ orgO, unsigned base, int ldsStep, int CH,
+__device__ __forceinline__ void r5q_positions(const unsigned* __restrict__ orgQ, unsigned base, int ldsStep, int CH,
                                               int cr0, int nStages, unsigned (&acc)[4])
 {
   R5qStage A, B;
   const int chShift = 31 - __clz(CH);
   int ch = cr0 & (CH - 1);
-  unsigned oOff = (unsigned)cr0 * 8u;
+  unsigned oOff = (unsigned)cr0 * 16u;
   unsigned lOff = (unsigned)((cr0 >> chShift) * ldsStep + ch * 8) * 4u;
   const unsigned rowAdv = (unsigned)(ldsStep - 8 * (CH - 1)) * 4u;          // from the last chunk of a row to the first of the next sampled row
   auto issue = [&](R5qStage& st)
   {
-    r5q_issue<OA>(st, orgE + oOff, orgO + oOff, base + lOff);
-    oOff += 8u; ch++;
+    r5q_issue<OA>(st, orgQ + oOff, base + lOff);
+    oOff += 16u; ch++;
     if (ch == CH) { ch = 0; lOff += rowAdv; } else lOff += 32u;
   };
   issue(A);
@@ -846,8 +851,7 @@ __global__ __launch_bounds__(MAXT, MINW) void sad_raster5q_kernel(const unsigned
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
   const int lane = tid & 63;
   const unsigned layoutDw = (unsigned)(hs * (w >> 1));
-  const unsigned* orgE = orgPacked + (size_t)b * 2u * layoutDw;
-  const unsigned* orgO = orgE + layoutDw;
+  const unsigned* orgQ = orgPacked + (size_t)b * 2u * layoutDw;             // interleaved layout: 16 dwords per chunk-row
   const int ldsStep = pitchDw << subShift;
   const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)refL;
   const int OA = off & 3;                                                     // sub-word offset of column 4 k: the same for every lane
@@ -893,10 +897,10 @@ __global__ __launch_bounds__(MAXT, MINW) void sad_raster5q_kernel(const unsigned
       const int i0 = 4 * k;
       const int cx = 5 * (i0 < nx ? i0 : 0) + off;                           // dead lanes re-read a live lane's address (broadcast)
       const unsigned base = ldsBase + (unsigned)(2 * (cx >> 2) + (min(jj, nj - 1) * 5) * pitchDw) * 4u;
-      if (OA == 0)      r5q_positions<0>(orgE, orgO, base, ldsStep, CH, part * nSt, nSt, acc);
-      else if (OA == 1) r5q_positions<1>(orgE, orgO, base, ldsStep, CH, part * nSt, nSt, acc);
-      else if (OA == 2) r5q_positions<2>(orgE, orgO, base, ldsStep, CH, part * nSt, nSt, acc);
-      else              r5q_positions<3>(orgE, orgO, base, ldsStep, CH, part * nSt, nSt, acc);
+      if (OA == 0)      r5q_positions<0>(orgQ, base, ldsStep, CH, part * nSt, nSt, acc);
+      else if (OA == 1) r5q_positions<1>(orgQ, base, ldsStep, CH, part * nSt, nSt, acc);
+      else if (OA == 2) r5q_positions<2>(orgQ, base, ldsStep, CH, part * nSt, nSt, acc);
+      else              r5q_positions<3>(orgQ, base, ldsStep, CH, part * nSt, nSt, acc);
     }
     if (SPLIT > 1) { keep[0] = acc[0]; keep[1] = acc[1]; keep[2] = acc[2]; keep[3] = acc[3]; keepIt = it; }   // one item per wave (host)
     else finish(g, acc);
@@ -1631,7 +1635,7 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
         unsigned* packedQ = static_cast<unsigned*>(vvcgpu_scratch(st0, packedDwQ * sizeof(unsigned)));
         if (!packedQ) return VVCGPU_E_DEVICE;
         hipLaunchKernelGGL(r5c_pack_org_kernel, dim3((unsigned)((packedDwQ + 255) / 256)), dim3(256), 0, st0, org, org_stride, blocks, nblocks,
-                           w, hsR, sub_shift, packedQ);
+                           w, hsR, sub_shift, packedQ, 1);
         VVC_LAUNCH_CHECK();
         vvcgpu_mvcost mvq = {};
         if (best)
