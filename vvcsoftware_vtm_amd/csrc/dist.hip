@@ -1614,6 +1614,10 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
     // (measured: 32-wide blocks lose more to the extra window rows than they gain, 0.315 vs 0.292 ms at 4K -- off by default)
     if (!splitOff && split32On && chunks >= 2 && rps > 18 && nx <= 40)
       rps = cdiv(cdiv(ny, cdiv(ny, 18)), 3) * 3;
+    // (measured: choosing the strip height for the fewest six-row groups -- 39 rows of 64-wide blocks as 12 + 12 + 12 + 3, 7 groups instead
+    // of the 8 of 15 + 15 + 9 -- loses: 201 vs 185 us, a fourth strip's staging and 8 instead of 12 waves per workgroup)
+    static const int rpsEnvC = getenv("VVCGPU_R5C_RPS") ? atoi(getenv("VVCGPU_R5C_RPS")) : 0;   // experiment: strip height
+    if (rpsEnvC >= 3 && (rpsEnvC % 3) == 0 && win_bytes(rpsEnvC) <= budget) rps = rpsEnvC;
     nstrips = cdiv(ny, rps);
     const size_t winB = win_bytes(rps), smem = winB + (((size_t)nx + rps + 15) & ~(size_t)15) + R5C_COST_N * sizeof(unsigned long long);
     if (smem <= 150 * 1024 && ((hsR * chunks) & 1) == 0 && nx + rps <= 4096 &&
@@ -1627,8 +1631,8 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       {
         const int itemsQ = cdiv(rps, 6), nSt = hsR * chunks;
         int splitQ = 1;
-        while (splitQ < 4 && itemsQ * splitQ * 2 <= 12 && (nSt % (splitQ * 2)) == 0 && nSt / (splitQ * 2) >= 4) splitQ *= 2;
-        if ((r5qSplit == 1 || r5qSplit == 2 || r5qSplit == 4) && (nSt % r5qSplit) == 0 && itemsQ * r5qSplit <= 16) splitQ = r5qSplit;
+        while (splitQ < 8 && itemsQ * splitQ * 2 <= 12 && (nSt % (splitQ * 2)) == 0 && nSt / (splitQ * 2) >= 8) splitQ *= 2;
+        if ((r5qSplit == 1 || r5qSplit == 2 || r5qSplit == 4 || r5qSplit == 8) && (nSt % r5qSplit) == 0 && itemsQ * r5qSplit <= 16) splitQ = r5qSplit;
         const int threadsQ = itemsQ * splitQ * 64;
         const int totalQ = nblocks * nstrips;
         const size_t packedDwQ = (size_t)nblocks * 2 * hsR * (w >> 1);
@@ -1651,7 +1655,7 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
           hipLaunchKernelGGL(kfn, dim3(cdiv(totalQ, 8) * 8), dim3(threadsQ), smem, st0, packedQ, ref, ref_stride,               \
                              blocks, w, h, sub_shift, dx0, dy0, nx, ny, rps, pitch, nstrips, 0xFFFFFFFFu / (unsigned)nstrips + 1u, totalQ, (int)winB, mvq, best ? 1 : 0, sad_out, best); \
         } while (0)
-        if (splitQ == 4) LAUNCH_R5Q(4); else if (splitQ == 2) LAUNCH_R5Q(2); else LAUNCH_R5Q(1);
+        if (splitQ == 8) LAUNCH_R5Q(8); else if (splitQ == 4) LAUNCH_R5Q(4); else if (splitQ == 2) LAUNCH_R5Q(2); else LAUNCH_R5Q(1);
 #undef LAUNCH_R5Q
         VVC_LAUNCH_CHECK();
         if (best)
