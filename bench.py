@@ -101,6 +101,26 @@ def profile_traffic():
     return out, os.path.basename(path)
 
 
+def profile_valu():
+    """-> {kernel name: [(avg_us, SQ_INSTS_VALU per launch)]} from the SQ counter summary of the same committed profile (profiles/rNN_pmc_sq.csv),
+    {} when there is none for these kernel sources"""
+    import csv
+    import glob
+    metas = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_meta.json")))
+    if not metas:
+        return {}
+    meta = json.load(open(metas[-1]))
+    path = os.path.join(ROOT, "profiles", meta.get("pmc_sq", meta.get("tag", "") + "_pmc_sq.csv"))
+    if meta.get("lib_digest") != lib_digest() or not os.path.exists(path):
+        return {}
+    out = {}
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            if r.get("SQ_INSTS_VALU") and float(r["avg_us"]) > 0:
+                out.setdefault(r["kernel"], []).append((float(r["avg_us"]), float(r["SQ_INSTS_VALU"])))
+    return out
+
+
 def cpu_baseline(wl, budget_s=25.0):
     """VTM's own SIMD kernels (oracle/_ref/libvtmref.so, kind 'reference') or the scalar restatement (kind 'port') on ONE host
     core over the bench's own workload object (the whole 3840x2160 picture, no extrapolation) when one pass fits the budget;
@@ -303,7 +323,18 @@ def main():
     uniq = wl.unique_bytes()
     useful = wl.useful_sad_insts()
     prof, prof_src = profile_traffic() if rank == 0 else ({}, None)
+    pvalu = profile_valu() if rank == 0 else {}
     hint = wl.profile_kernel_hint(dom)
+
+    def valu_busy_of(group, ms):
+        """executed vector instructions of the launch group's main kernel (committed SQ counter profile; the row whose duration is closest and
+        within 35 %) x the measured issue interval / time: how busy the vector pipes are, padding and bookkeeping instructions included"""
+        h = wl.profile_kernel_hint(group)
+        cands = [c for k, v in pvalu.items() if h and h in k for c in v]
+        if not cands:
+            return None
+        best = min(cands, key=lambda c: abs(c[0] - ms * 1e3))
+        return best[1] / (best[0] * 1e-6) / VALU_ISSUE_PEAK if abs(best[0] - ms * 1e3) <= 0.35 * ms * 1e3 else None
 
     def hbm_of(group, ms):
         """HBM bytes per launch of the dominant launch group's main kernel from the committed profile: rows of that kernel, the one
@@ -331,6 +362,9 @@ def main():
             e["hbm_frac"] = round(hb / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if k in useful:
             e["issue_frac"] = round(useful[k] / (v * 1e-3) / VALU_ISSUE_PEAK, 4)
+        vb = valu_busy_of(k, v)
+        if vb is not None:
+            e["valu_busy"] = round(vb, 4)
         per_kernel[k] = e
 
     if rank == 0:
@@ -366,8 +400,9 @@ def main():
                          "note": "achieved/frac follow SURVEY 8(d) (algorithmic bytes of the launch / time); hbm_frac is the counter traffic "
                                  "(FETCH_SIZE x2 + WRITE_SIZE of the committed profile, when it was taken from these kernel sources) / time / peak; "
                                  "unique_frac counts every sample the launch must touch once; issue_frac = useful v_sad_u16 wave-instructions / time "
-                                 "against the measured vector issue rate (one per 4.4 cycles and SIMD)",
-                         "hbm_frac": dk.get("hbm_frac"), "unique_frac": dk.get("unique_frac"), "issue_frac": dk.get("issue_frac")},
+                                 "against the measured vector issue rate (one per 4.4 cycles and SIMD); valu_busy = ALL executed vector instructions "
+                                 "(SQ_INSTS_VALU of the committed counter profile) against the same rate",
+                         "hbm_frac": dk.get("hbm_frac"), "unique_frac": dk.get("unique_frac"), "issue_frac": dk.get("issue_frac"), "valu_busy": dk.get("valu_busy")},
             "picture_hashes": {"gathered": len(hashes), "rank0_first_picture_md5": first_md5, "rank0_last_picture_md5": hashes.get("rank0")},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "serial_kernel_ms_per_picture": round(sum(stage_ms.values()), 4),

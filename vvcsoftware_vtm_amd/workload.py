@@ -300,10 +300,10 @@ class Workload:
         """name (substring) of the rocprofv3 kernel that does the work of a launch group (None: not mapped)"""
         stage, name = group.split("/")
         if stage == "me":
-            return "sad_raster5" if name.endswith("%dx%d" % (self.me_grids[1][2], self.me_grids[1][3])) else "sad_dense_kernel"
-        return {"frac_refine_16x16": "frac16_kernel", "mc_luma": "mc_fast_kernel", "mc_chroma": "mc_fast_kernel", "deblock": "deblock_luma_kernel",
-                "sao_stats": "sao_stats_kernel", "sao_apply": "sao_apply_kernel", "alf_classify": "alf_classify_kernel",
-                "alf_stats": "alf_stats_kernel<true>", "alf_filter": "alf_filter_kernel<true", "resi_chain": "resi_chain"}.get(name)
+            return "sad_raster5" if name.endswith("%dx%d" % (self.me_grids[1][2], self.me_grids[1][3])) else "sad_dense"
+        return {"frac_refine_16x16": "frac16_kernel", "mc_luma": "mc_fast_kernel", "mc_chroma": "mc_fast_kernel", "deblock": "deblock_picture_kernel",
+                "sao_stats": "sao_stats_picture_kernel", "sao_apply": "sao_apply_picture_kernel", "alf_classify": "alf_classify_kernel",
+                "alf_stats": "alf_stats_picture_kernel", "alf_filter": "alf_filter_picture_kernel", "resi_chain": "rc_chain_kernel"}.get(name)
 
     def margins(self):
         return [(MARGIN, MARGIN), (MARGIN // 2, MARGIN // 2), (MARGIN // 2, MARGIN // 2)]
