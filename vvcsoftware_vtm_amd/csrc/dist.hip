@@ -540,27 +540,51 @@ __device__ __forceinline__ void fill_window_cols(unsigned* __restrict__ lds, con
 
 // org rows of the raster kernel, packed per block: [block][layout even | odd][hs rows][w / 2 dwords], biased (^ 0x8000 per
 // sample), row sub-sampling and odd block origins resolved here.  Layouts per 16-sample chunk: see r5c_compute.
-// One thread per output dword; 2 * hs * w / 2 dwords per block.
-// interleave != 0 (quad form): [block][chunk-row][even 8 | odd 8] -- both layouts of a chunk-row are one 64-byte scalar load
+// interleave != 0 (quad form): [block][chunk-row][even 8 | odd 8] -- both layouts of a chunk-row are one 64-byte scalar load.
+// One thread per 16-sample chunk-row: 8 dword loads (16 sample loads when the chunk is not 4-byte aligned) issued together, both layouts
+// built in registers, four 16-byte stores (one thread per output dword with two sample loads each took 13 - 16 us per 4K launch).
+// initBest != nullptr: the arg-min keys of the raster kernels start at all-ones (saves the separate fill launch).
 __global__ __launch_bounds__(256) void r5c_pack_org_kernel(const Pel* __restrict__ org, int os, const vvcgpu_search_blk* __restrict__ blocks,
-                                                           int nblocks, int w, int hs, int subShift, unsigned* __restrict__ packed, int interleave = 0)
+                                                           int nblocks, int w, int hs, int subShift, unsigned* __restrict__ packed, int interleave,
+                                                           unsigned long long* __restrict__ initBest)
 {
-  const unsigned perLayout = (unsigned)(hs * (w >> 1)), perBlock = 2u * perLayout;
+  const int CH = w >> 4, perBlockUnits = hs * CH;
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-  if (gid >= (size_t)nblocks * perBlock) return;
-  const int b = (int)(gid / perBlock);
-  const unsigned r0 = (unsigned)(gid - (size_t)b * perBlock);
-  const unsigned odd = r0 >= perLayout ? 1u : 0u, r1 = r0 - odd * perLayout;
-  const int row = (int)(r1 / (unsigned)(w >> 1)), dwInRow = (int)(r1 - (unsigned)row * (unsigned)(w >> 1));
-  const int chunk = dwInRow >> 3, k = dwInRow & 7;
+  if (initBest)
+    for (size_t i = gid; i < (size_t)nblocks * 3; i += (size_t)gridDim.x * blockDim.x) initBest[i] = ~0ull;
+  if (gid >= (size_t)nblocks * perBlockUnits) return;
+  const int b = (int)(gid / (unsigned)perBlockUnits), rem = (int)(gid - (size_t)b * perBlockUnits);
+  const int row = rem / CH, chunk = rem - row * CH;
   const vvcgpu_search_blk blk = blocks[b];
   const Pel* o = org + (size_t)(blk.org_y + (row << subShift)) * os + blk.org_x + 16 * chunk;
-  int a, c;
-  if (!odd) { a = 2 * k; c = 2 * k + 1; }
-  else if (k < 7) { a = 2 * k + 1; c = 2 * k + 2; }
-  else { a = 15; c = 0; }
-  const size_t dst = interleave ? (size_t)b * perBlock + (size_t)((row * (w >> 4) + chunk) * 16 + (int)odd * 8 + k) : gid;
-  packed[dst] = ((unsigned)(unsigned short)o[a] | ((unsigned)(unsigned short)o[c] << 16)) ^ 0x80008000u;
+  unsigned d[8];
+  if ((reinterpret_cast<uintptr_t>(o) & 3) == 0)
+  {
+    const unsigned* q = reinterpret_cast<const unsigned*>(o);
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = q[k];
+  }
+  else
+  {
+    unsigned short sm[16];
+#pragma unroll
+    for (int k = 0; k < 16; k++) sm[k] = (unsigned short)o[k];
+#pragma unroll
+    for (int k = 0; k < 8; k++) d[k] = (unsigned)sm[2 * k] | ((unsigned)sm[2 * k + 1] << 16);
+  }
+  unsigned E[8], O[8];
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+  {
+    E[k] = d[k] ^ 0x80008000u;
+    O[k] = __builtin_amdgcn_alignbit(d[(k + 1) & 7], d[k], 16) ^ 0x80008000u;          // k < 7: samples (2k+1, 2k+2); k = 7: (15, 0)
+  }
+  const unsigned perLayout = (unsigned)(hs * (w >> 1));
+  unsigned* pe; unsigned* po;
+  if (interleave) { pe = packed + (size_t)b * 2u * perLayout + (size_t)(row * CH + chunk) * 16; po = pe + 8; }
+  else            { pe = packed + (size_t)b * 2u * perLayout + (size_t)row * (w >> 1) + chunk * 8; po = pe + perLayout; }
+  reinterpret_cast<uint4*>(pe)[0] = make_uint4(E[0], E[1], E[2], E[3]); reinterpret_cast<uint4*>(pe)[1] = make_uint4(E[4], E[5], E[6], E[7]);
+  reinterpret_cast<uint4*>(po)[0] = make_uint4(O[0], O[1], O[2], O[3]); reinterpret_cast<uint4*>(po)[1] = make_uint4(O[4], O[5], O[6], O[7]);
 }
 
 // MINW = waves per SIMD the register allocation must allow: 6 (<= 80 VGPRs) when three workgroups fit the CU's LDS, else 4
@@ -1576,11 +1600,10 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       const size_t packedDw = (size_t)nblocks * 2 * hsR * 8;
       unsigned* packed = static_cast<unsigned*>(vvcgpu_scratch(st0, packedDw * sizeof(unsigned)));
       if (!packed) return VVCGPU_E_DEVICE;
-      hipLaunchKernelGGL(r5c_pack_org_kernel, dim3((unsigned)((packedDw + 255) / 256)), dim3(256), 0, st0, org, org_stride, blocks, nblocks,
-                         w, hsR, sub_shift, packed);
+      hipLaunchKernelGGL(r5c_pack_org_kernel, dim3((unsigned)(((size_t)nblocks * hsR * (w >> 4) + 255) / 256)), dim3(256), 0, st0, org, org_stride, blocks, nblocks,
+                         w, hsR, sub_shift, packed, 0, reinterpret_cast<unsigned long long*>(best));
       VVC_LAUNCH_CHECK();
       const vvcgpu_mvcost mv = *mvcost_host;
-      VVC_HIP(hipMemsetAsync(best, 0xFF, (size_t)nblocks * sizeof(vvcgpu_search_best), st0));
       if (smem > 48 * 1024)
         VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster5g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
       hipLaunchKernelGGL(sad_raster5g_kernel, dim3(cdiv(total, 8) * 8), dim3(threads), smem, st0, packed, ref, ref_stride, blocks, nblocks, nbg, h, sub_shift,
@@ -1638,15 +1661,11 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
         const size_t packedDwQ = (size_t)nblocks * 2 * hsR * (w >> 1);
         unsigned* packedQ = static_cast<unsigned*>(vvcgpu_scratch(st0, packedDwQ * sizeof(unsigned)));
         if (!packedQ) return VVCGPU_E_DEVICE;
-        hipLaunchKernelGGL(r5c_pack_org_kernel, dim3((unsigned)((packedDwQ + 255) / 256)), dim3(256), 0, st0, org, org_stride, blocks, nblocks,
-                           w, hsR, sub_shift, packedQ, 1);
+        hipLaunchKernelGGL(r5c_pack_org_kernel, dim3((unsigned)(((size_t)nblocks * hsR * (w >> 4) + 255) / 256)), dim3(256), 0, st0, org, org_stride, blocks, nblocks,
+                           w, hsR, sub_shift, packedQ, 1, reinterpret_cast<unsigned long long*>(best));
         VVC_LAUNCH_CHECK();
         vvcgpu_mvcost mvq = {};
-        if (best)
-        {
-          mvq = *mvcost_host;
-          VVC_HIP(hipMemsetAsync(best, 0xFF, (size_t)nblocks * sizeof(vvcgpu_search_best), st0));
-        }
+        if (best) mvq = *mvcost_host;
 #define LAUNCH_R5Q(SPL)                                                                                                          \
         do {                                                                                                                    \
           auto kfn = sad_raster5q_kernel<1024, 4, SPL>;                                                                          \
@@ -1673,15 +1692,11 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       const size_t packedDw = (size_t)nblocks * 2 * hsR * (w >> 1);
       unsigned* packed = static_cast<unsigned*>(vvcgpu_scratch(st0, packedDw * sizeof(unsigned)));
       if (!packed) return VVCGPU_E_DEVICE;
-      hipLaunchKernelGGL(r5c_pack_org_kernel, dim3((unsigned)((packedDw + 255) / 256)), dim3(256), 0, st0, org, org_stride, blocks, nblocks,
-                         w, hsR, sub_shift, packed);
+      hipLaunchKernelGGL(r5c_pack_org_kernel, dim3((unsigned)(((size_t)nblocks * hsR * (w >> 4) + 255) / 256)), dim3(256), 0, st0, org, org_stride, blocks, nblocks,
+                         w, hsR, sub_shift, packed, 0, reinterpret_cast<unsigned long long*>(best));
       VVC_LAUNCH_CHECK();
       vvcgpu_mvcost mv = {};
-      if (best)
-      {
-        mv = *mvcost_host;
-        VVC_HIP(hipMemsetAsync(best, 0xFF, (size_t)nblocks * sizeof(vvcgpu_search_best), st0));
-      }
+      if (best) mv = *mvcost_host;
 #define LAUNCH_R5C(MAXT, MINW, SPL)                                                                                                  \
       do {                                                                                                                      \
         auto kfn = sad_raster5c_kernel<MAXT, MINW, SPL>;                                                                             \
