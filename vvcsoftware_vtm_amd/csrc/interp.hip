@@ -203,44 +203,38 @@ __device__ __forceinline__ void mc_tile_fast(const vvcgpu_mc_desc& d, const Pel*
 
 __global__ __launch_bounds__(256) void mc_fast_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
                                                       Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs, int n,
-                                                      int bd, int cmin, int cmax)
+                                                      int bd, int cmin, int cmax, int* __restrict__ list, int* __restrict__ count,
+                                                      int* __restrict__ nextCount)
 {
   __shared__ short winS[4][23 * 24];
   __shared__ short tmpS[4][23 * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int di = blockIdx.x * 4 + wave;
+  if (blockIdx.x == 0 && threadIdx.x == 0) *nextCount = 0;        // the counter of the NEXT call on this stream (its last user has finished)
   if (di >= n) return;
   const vvcgpu_mc_desc d = descs[di];
-  if (!mc_is_fast(d.is_luma, d.w, d.h)) return;
+  if (!mc_is_fast(d.is_luma, d.w, d.h))
+  {
+    // left to the generic kernel behind this one: list[0] = count, list[1..] = descriptor indices (no atomic at all when every PU is fast)
+    if (lane == 0) list[atomicAdd(count, 1)] = di;
+    return;
+  }
   if (d.is_luma) mc_tile_fast<8, 16>(d, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, winS[wave], tmpS[wave]);
   else mc_tile_fast<4, 8>(d, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, winS[wave], tmpS[wave]);
 }
 
-// indices of the PUs the fast kernel does not cover: list[0] = count, list[1..] = descriptor indices
-__global__ __launch_bounds__(256) void mc_collect_kernel(const vvcgpu_mc_desc* __restrict__ descs, int n, int* __restrict__ list)
-{
-  const int ti = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
-  bool slow = false;
-  if (ti < n) slow = !mc_is_fast(descs[ti].is_luma, descs[ti].w, descs[ti].h);
-  const unsigned long long m = __builtin_amdgcn_ballot_w64(slow);
-  int base = 0;
-  if (lane == 0 && m) base = atomicAdd(&list[0], (int)__popcll(m));
-  base = __builtin_amdgcn_readfirstlane(base);
-  if (slow) list[1 + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = ti;
-}
-
-// generic kernel: any size, one wave per PU, persistent over the list of PUs left by mc_collect_kernel
+// generic kernel: any size, one wave per PU, persistent over the list of PUs the fast kernel left
 __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
                                                       Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs,
-                                                      const int* __restrict__ list, int bd, int cmin, int cmax)
+                                                      const int* __restrict__ list, const int* __restrict__ count, int bd, int cmin, int cmax)
 {
   __shared__ short win[WR * WP];
   __shared__ short tmp[WR * ST];
   const int lane = threadIdx.x;
-  const int cnt = list[0];
+  const int cnt = *count;
   for (int li = blockIdx.x; li < cnt; li += gridDim.x)
   {
-  const vvcgpu_mc_desc d = descs[list[1 + li]];
+  const vvcgpu_mc_desc d = descs[list[li]];
   const int N = d.is_luma ? 8 : 4, half = N / 2 - 1;
   const bool rndRes = d.bi == 0;
   const int nRef = d.bi == 1 ? 2 : 1;
@@ -419,14 +413,15 @@ int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel*
   VVC_CHECK_ARG(ref0_base && dst_base && descs, "mc_batch: null pointer");
   if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("mc_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
-  int* list = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * ((size_t)n + 1)));
+  int* list = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * (size_t)n));
   if (!list) return VVCGPU_E_DEVICE;
-  VVC_HIP(hipMemsetAsync(list, 0, sizeof(int), st));
-  hipLaunchKernelGGL(mc_collect_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, descs, n, list);
+  int cur = 0;
+  int* counters = vvcgpu_counters(st, &cur);                                // zeroed counter for this call; the kernel clears the other one
+  if (!counters) return VVCGPU_E_DEVICE;
   hipLaunchKernelGGL(mc_fast_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     dst_base, descs, n, bit_depth, clp_min, clp_max);
-  hipLaunchKernelGGL(mc_batch_kernel, dim3(n < 8192 ? n : 8192), dim3(64), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     dst_base, descs, list, bit_depth, clp_min, clp_max);
+                     dst_base, descs, n, bit_depth, clp_min, clp_max, list, counters + 16 * cur, counters + 16 * (cur ^ 1));
+  hipLaunchKernelGGL(mc_batch_kernel, dim3(n < 2048 ? n : 2048), dim3(64), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
+                     dst_base, descs, list, counters + 16 * cur, bit_depth, clp_min, clp_max);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

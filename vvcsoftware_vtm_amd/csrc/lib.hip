@@ -46,6 +46,36 @@ void* vvcgpu_scratch(hipStream_t stream, size_t bytes)
   return slot->ptr;
 }
 
+// Two persistent work counters per (device, stream), zero when handed out: a launch that needs a zeroed counter takes counter `cur` and clears
+// counter `cur ^ 1` for the next call inside its own kernel (the previous user of that one has finished: same stream), so no fill launch is
+// needed in front of it.  Returns a device pointer to int[2][16] (64-byte lines) and the index to use; nullptr on failure.
+namespace {
+struct CounterSlot { int device; hipStream_t stream; int* ptr; int cur; };
+CounterSlot g_counters[64];
+int g_nCounters = 0;
+}
+int* vvcgpu_counters(hipStream_t stream, int* cur)
+{
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { vvcgpu_set_error("hipGetDevice failed"); return nullptr; }
+  std::lock_guard<std::mutex> lock(g_scratchMutex);
+  CounterSlot* slot = nullptr;
+  for (int i = 0; i < g_nCounters; i++)
+    if (g_counters[i].device == dev && g_counters[i].stream == stream) { slot = &g_counters[i]; break; }
+  if (!slot)
+  {
+    if (g_nCounters == 64) { vvcgpu_set_error("counters: more than 64 (device, stream) pairs in use"); return nullptr; }
+    void* p = nullptr;
+    if (hipMalloc(&p, 2 * 16 * sizeof(int)) != hipSuccess) { vvcgpu_set_error("counters: hipMalloc failed"); return nullptr; }
+    if (hipMemset(p, 0, 2 * 16 * sizeof(int)) != hipSuccess) { (void)hipFree(p); vvcgpu_set_error("counters: hipMemset failed"); return nullptr; }
+    slot = &g_counters[g_nCounters++];
+    slot->device = dev; slot->stream = stream; slot->ptr = static_cast<int*>(p); slot->cur = 0;
+  }
+  *cur = slot->cur;
+  slot->cur ^= 1;
+  return slot->ptr;
+}
+
 extern "C" {
 int vvcgpu_version(void) { return 1; }
 const char* vvcgpu_last_error(void) { return g_err; }
