@@ -210,7 +210,7 @@ __global__ __launch_bounds__(256) void mc_fast_kernel(const Pel* __restrict__ re
   __shared__ short tmpS[4][23 * 16];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int di = blockIdx.x * 4 + wave;
-  if (blockIdx.x == 0 && threadIdx.x == 0) *nextCount = 0;        // the counter of the NEXT call on this stream (its last user has finished)
+  if (blockIdx.x == 0 && threadIdx.x < 16) nextCount[threadIdx.x] = 0;   // the WHOLE counter set of the next call on this stream (vvcgpu_counters protocol)
   if (di >= n) return;
   const vvcgpu_mc_desc d = descs[di];
   if (!mc_is_fast(d.is_luma, d.w, d.h))

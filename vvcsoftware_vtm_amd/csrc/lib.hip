@@ -48,7 +48,8 @@ void* vvcgpu_scratch(hipStream_t stream, size_t bytes)
 
 // Two persistent work counters per (device, stream), zero when handed out: a launch that needs a zeroed counter takes counter `cur` and clears
 // counter `cur ^ 1` for the next call inside its own kernel (the previous user of that one has finished: same stream), so no fill launch is
-// needed in front of it.  Returns a device pointer to int[2][16] (64-byte lines) and the index to use; nullptr on failure.
+// needed in front of it.  EVERY user clears all 16 ints of the other set, whatever it uses of its own.  Returns a device pointer to
+// int[2][16] (64-byte lines) and the index to use; nullptr on failure.
 namespace {
 struct CounterSlot { int device; hipStream_t stream; int* ptr; int cur; };
 CounterSlot g_counters[64];

@@ -53,8 +53,9 @@ __device__ __forceinline__ int rc_class(const RcDesc& d)
 // LDS, ONE global atomic per class reserves the slice's range of every list, pass 2 writes the indices (LDS counters give the positions).
 constexpr int RC_CLS_WGS = 128;
 __global__ __launch_bounds__(1024) void rc_classify_kernel(const RcDesc* __restrict__ descs, int n, int* __restrict__ hdr, int* __restrict__ lists,
-                                                           unsigned* __restrict__ absSum)
+                                                           unsigned* __restrict__ absSum, int* __restrict__ nextHdr)
 {
+  if (blockIdx.x == 0 && threadIdx.x < 16) nextHdr[threadIdx.x] = 0;         // the header of the NEXT call on this stream (vvcgpu_counters)
   __shared__ int cnt[RC_NCLS], base[RC_NCLS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = min(n, lo + per);
@@ -969,15 +970,20 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
     image = images[dev];
   }
   // scratch: header (class counts, then the fall-back count), the six class lists, the fall-back list of the matrix-core kernels
-  const size_t ints = RC_HDR + (size_t)RC_NCLS * n + (size_t)n;
+  const size_t ints = (size_t)RC_NCLS * n + (size_t)n;
   int* ws = static_cast<int*>(vvcgpu_scratch(st, ints * sizeof(int)));
   if (!ws) return VVCGPU_E_DEVICE;
-  int* hdr = ws;
-  int* lists = ws + RC_HDR;
+  // the header lives in the stream's persistent zeroed counters: this call's set is clean, the classifier clears the other set for the next
+  // call (no fill launch in front of the chain)
+  int cur = 0;
+  int* counters = vvcgpu_counters(st, &cur);
+  if (!counters) return VVCGPU_E_DEVICE;
+  int* hdr = counters + 16 * cur;
+  int* lists = ws;
   int* fbCount = hdr + 7;
   int* fbList = lists + (size_t)RC_NCLS * n;
-  VVC_HIP(hipMemsetAsync(hdr, 0, RC_HDR * sizeof(int), st));
-  hipLaunchKernelGGL(rc_classify_kernel, dim3(n < 1024 * RC_CLS_WGS ? cdiv(n, 1024) : RC_CLS_WGS), dim3(1024), 0, st, descs, n, hdr, lists, abs_sum);
+  hipLaunchKernelGGL(rc_classify_kernel, dim3(n < 1024 * RC_CLS_WGS ? cdiv(n, 1024) : RC_CLS_WGS), dim3(1024), 0, st, descs, n, hdr, lists, abs_sum,
+                     counters + 16 * (cur ^ 1));
   VVC_LAUNCH_CHECK();
   // (measured: forking the size classes onto library-owned side streams and joining them with events is SLOWER than launching them back to
   // back on the caller's stream, 0.158 vs 0.115 ms at 4K -- a cross-stream event costs more than these 20 us kernels gain)

@@ -433,7 +433,7 @@ assert RC_DESC.itemsize == 64
 def resi_chain_batch(org_base, pred_base, rec_base, level_base, descs_dev, n, bit_depth=10, clp=(0, 1023)):
     """subtract -> forward transform -> Quant::quant -> Quant::dequant -> inverse transform -> reconstruction of n TUs in one pass.
     Returns the abs-sum int32 tensor [n] (bits as uint32; 0xFFFFFFFF marks a TU outside the entry point's preconditions)."""
-    out = torch.zeros(n, dtype=torch.int32, device=org_base.device)
+    out = torch.empty(n, dtype=torch.int32, device=org_base.device)       # every entry is written by the library
     capi.call("vvcgpu_resi_chain_batch", capi.ptr(org_base), capi.ptr(pred_base), capi.ptr(rec_base), capi.ptr(level_base), capi.ptr(descs_dev), n,
               bit_depth, clp[0], clp[1], capi.ptr(out), _stream())
     return out
