@@ -140,3 +140,65 @@ def test_resi_chain_rejects_transform_skip_descriptor():
     lvl = torch.zeros(32, dtype=torch.int32, device="cuda")
     a = ops.resi_chain_batch(t, t.clone(), rec, lvl, ops.struct_to_device(d), 2, bd).cpu().numpy().view(np.uint32)
     assert a[0] == 0xFFFFFFFF and a[1] == 0
+
+
+def test_stream_counters_survive_interleaved_entry_points():
+    """vvcgpu_resi_chain_batch and vvcgpu_mc_batch take their zeroed work counters from the stream's persistent pair (lib.hip: vvcgpu_counters) and
+    each call clears the other set for the next one.  Calls of both kinds in every order, with lists that leave different counts behind
+    (a chain with TUs of every class and fall-back TUs, then one with a single class; MC lists with and without PUs for the generic kernel),
+    must all give the oracle's results."""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(4242)
+    bd, W, H = 10, 256, 128
+    mx = (1 << bd) - 1
+    org = cases.rand_plane(rng, H, W, bd, "uniform")
+    pred = np.clip(org + rng.integers(-30, 31, org.shape), 0, mx).astype(np.int16)
+    wild = rng.integers(-3000, 3000, (H, W)).astype(np.int16)                       # |residual| > 1023: fall-back list of the chain
+    tus_all = tile(W, H, [(64, 64), (32, 32), (16, 16), (8, 8), (4, 4), (16, 8)], rng, [27, 37], bd)
+    tus_one = tile(W, H, [(8, 8)], rng, [32], bd)
+    want = {}
+    for name, (o_, tus) in {"all": (org, tus_all), "one": (org, tus_one), "wild": (wild, tus_all)}.items():
+        want[name] = oracle_chain(o_, pred, tus, bd, W)
+
+    # MC lists: ref = a padded plane, 16x16 luma PUs (fast kernel) with and without a few 32x8 PUs (generic kernel)
+    M = 16
+    ref = np.ascontiguousarray(np.pad(cases.rand_plane(rng, H, W, bd, "smooth"), M, mode="edge"))
+    RS = W + 2 * M
+
+    def mc_list(extra):
+        rows, dst_off = [], 0
+        for y in range(0, H, 16):
+            for x in range(0, W // 2, 16):
+                rows.append(((y + M) * RS + x + M + int(rng.integers(-3, 4)), 0, dst_off, RS, RS, 16, 16, 16, int(rng.integers(0, 4)), int(rng.integers(0, 4)), 0, 0, 1, 0, 0))
+                dst_off += 256
+        for k in range(extra):
+            rows.append(((M + 8 * k) * RS + M + 64, 0, dst_off, RS, RS, 32, 32, 8, 1 + k % 3, 2, 0, 0, 1, 0, 0))
+            dst_off += 256
+        d = np.zeros(len(rows), ops.MC_DESC)
+        for i, r in enumerate(rows):
+            d[i] = r
+        return d, dst_off
+
+    def mc_oracle(d, total):
+        out = np.zeros(total, np.int16)
+        oracle().orc_mc_batch(p(ref), p(ref), p(out), p(d), d.size, bd, 0, mx)
+        return out
+
+    mc = {k: mc_list(e) for k, e in (("fast", 0), ("mixed", 5))}
+    mc_want = {k: mc_oracle(*v) for k, v in mc.items()}
+    dref = torch.from_numpy(ref).cuda()
+
+    def run_chain(name):
+        o_, tus = {"all": (org, tus_all), "one": (org, tus_one), "wild": (wild, tus_all)}[name]
+        lv, asum, rec, coffs = want[name]
+        glv, gsum, grec = gpu_chain(o_, pred, tus, bd, W, coffs)
+        assert np.array_equal(gsum, asum) and np.array_equal(glv, lv) and np.array_equal(grec, rec), name
+
+    def run_mc(name):
+        d, total = mc[name]
+        dst = torch.zeros(total, dtype=torch.int16, device="cuda")
+        ops.mc_batch(dref, dref, dst, ops.struct_to_device(d), d.size, bd, (0, mx))
+        assert np.array_equal(dst.cpu().numpy(), mc_want[name]), name
+
+    for step in ["all", "mixed", "one", "wild", "wild", "fast", "mixed", "mixed", "all", "one", "fast", "all"]:
+        (run_mc if step in mc else run_chain)(step)
