@@ -1091,6 +1091,120 @@ __global__ __launch_bounds__(1024, 6) void sad_raster5g_kernel(const unsigned* _
 }
 
 // ---------------------------------------------------------------------------------------------------
+// GROUP form with QUAD columns ("r5gq"): the shared window, run detection and per-block keys of r5g, the four-columns-per-lane SAD loop of
+// r5q.  A unit = (row group of six raster rows, sub-run of up to TWO blocks): the same work per wave as r5g's (two column classes, four
+// blocks), but the loop spends 70 vector instructions per 64 v_sad_u16 instead of r5g's ~100, and the per-block epilogue folds four
+// candidates into one 32-bit word (cost << 2 | candidate: cost < 2^30, the host checks lambda).  PMC of r5g: 813 vector instructions per
+// unit for 512 v_sad_u16; here ~600 for the same 512.
+constexpr unsigned R5GQ_INVALID = 0x30000000u;         // above every valid cost (SAD << 1 < 2^20, lambda * bits < 2^29), below 2^30
+
+__global__ __launch_bounds__(1024, 6) void sad_raster5gq_kernel(const unsigned* __restrict__ orgPacked, const Pel* __restrict__ ref, int rs,
+                                                                const vvcgpu_search_blk* __restrict__ blocks, int nblocks, int nbg, int h, int subShift,
+                                                                int dx0, int dy0, int nx, int ny, int rowsPerStrip, int pitchDw,
+                                                                int nstrips, unsigned invStrips, int total, int winBytes, vvcgpu_mvcost mv,
+                                                                vvcgpu_search_best* __restrict__ best)
+{
+  extern __shared__ __align__(16) unsigned refL[];
+  __shared__ unsigned long long wgKey[R5G_MAXNB];
+  const int tid = threadIdx.x;
+  const int chunk = (total + 7) >> 3;                                          // XCD-aware order, as r5c
+  const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
+  if (item >= total) return;
+  const int q = nstrips == 1 ? item : (int)__umulhi((unsigned)item, invStrips), j0 = (item - q * nstrips) * rowsPerStrip;
+  const int nj = min(rowsPerStrip, ny - j0);
+  const int b0 = q * nbg, nbk = min(nbg, nblocks - b0);
+  const int hs = h >> subShift;
+  const int winRows = (nj - 1) * 5 + h;
+  unsigned char* bitsX = reinterpret_cast<unsigned char*>(refL) + winBytes;   // [nx] then [rowsPerStrip]
+  unsigned char* bitsY = bitsX + nx;
+  unsigned* costTab = reinterpret_cast<unsigned*>(bitsX + ((nx + rowsPerStrip + 15) & ~15));   // lambda * bits, truncated (host: below 2^29)
+  for (int n = tid; n < R5C_COST_N; n += (int)blockDim.x) costTab[n] = (unsigned)(unsigned long long)(mv.lambda * (double)n);
+  for (int n = tid; n < nx + nj; n += (int)blockDim.x)
+  {
+    const int v = n < nx ? (((dx0 + n * 5) << mv.cost_scale) - mv.pred_hor) : (((dy0 + (j0 + n - nx) * 5) << mv.cost_scale) - mv.pred_ver);
+    bitsX[n] = (unsigned char)expgolomb_bits(v >> mv.imv_shift);
+  }
+  const int ngrp = (nj + 5) / 6;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const unsigned layoutDw = (unsigned)(hs * 8);                                // one layout of a 16-wide block; a block = 2 layouts, interleaved per chunk-row
+  const int ldsStep = pitchDw << subShift;
+  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)refL;
+
+  for (int k0 = 0; k0 < nbk; )
+  {
+    const int rx = blocks[b0 + k0].ref_x, ry = blocks[b0 + k0].ref_y;
+    int n = 1;
+    while (k0 + n < nbk && blocks[b0 + k0 + n].ref_y == ry && blocks[b0 + k0 + n].ref_x == rx + 16 * n) n++;
+    const ptrdiff_t winOff = (ptrdiff_t)(ry + dy0 + j0 * 5) * rs + rx + dx0;
+    const int off = (int)(winOff & 7);
+    if (k0 > 0) __syncthreads();                                               // every wave is done with the previous run's window and keys
+    fill_window_cols<8>(refL, reinterpret_cast<const uint4*>(ref + (winOff - off)), rs >> 3, winRows, pitchDw,
+                        (((nx - 1) * 5 + 16 * n - 1 + off) >> 3) + 1, tid, (int)blockDim.x);
+    if (tid < R5G_MAXNB) wgKey[tid] = ~0ull;
+    __syncthreads();
+
+    const int nsub = (n + 1) >> 1;                                            // sub-runs of up to two blocks
+    const int g = wave / nsub, t0 = (wave - g * nsub) * 2, nt = min(2, n - t0);
+    if (g < ngrp)
+    {
+      const int OA = off & 3;
+      const int lane = tid & 63, ql = lane & 31, m0 = (ql * 26) >> 8, kk = ql - 10 * m0;
+      const bool dead = m0 >= 3;
+      const int jj = g * 6 + (lane >> 5) * 3 + (dead ? 0 : m0);
+      const int i0 = 4 * kk;                                                  // positions i0 .. i0 + 3
+      const int cx = 5 * (i0 < nx ? i0 : 0) + off;                            // dead lanes re-read a live lane's address (broadcast)
+      const int jc = min(jj, nj - 1);
+      const unsigned base = ldsBase + (unsigned)(2 * (cx >> 2) + (jc * 5) * pitchDw) * 4u + 32u * (unsigned)t0;
+      const bool live = !dead && jj < nj;
+      const unsigned by = bitsY[jc];
+      unsigned cst[4];
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+      {
+        const bool in = live && i0 + m < nx;
+        cst[m] = ((in ? costTab[bitsX[in ? i0 + m : 0] + by] : R5GQ_INVALID) << 2) | (unsigned)m;
+      }
+      const unsigned* orgBlk = orgPacked + (size_t)(b0 + k0 + t0) * 2u * layoutDw;
+      unsigned kmin[2];
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+      {
+        if (t >= nt) break;                                                    // wave-uniform
+        unsigned acc[4] = { 0u, 0u, 0u, 0u };
+        const unsigned* oq = orgBlk + (size_t)t * 2u * layoutDw;
+        const unsigned bt = base + 32u * t;
+        if (OA == 0)      r5q_positions<0>(oq, bt, ldsStep, 1, 0, hs, acc);
+        else if (OA == 1) r5q_positions<1>(oq, bt, ldsStep, 1, 0, hs, acc);
+        else if (OA == 2) r5q_positions<2>(oq, bt, ldsStep, 1, 0, hs, acc);
+        else              r5q_positions<3>(oq, bt, ldsStep, 1, 0, hs, acc);
+        const int sh = subShift + 2;
+        kmin[t] = min(min((acc[0] << sh) + cst[0], (acc[1] << sh) + cst[1]), min((acc[2] << sh) + cst[2], (acc[3] << sh) + cst[3]));
+      }
+      int lane2 = tid & 63;
+      asm volatile("" : "+v"(lane2));                                         // re-derive the lane's scan index after the loops instead of keeping it live
+      const int ql2 = lane2 & 31, m2 = (ql2 * 26) >> 8;
+      const unsigned idx0 = (unsigned)((j0 + min(g * 6 + (lane2 >> 5) * 3 + m2, nj - 1)) * nx + 4 * (ql2 - 10 * m2));
+#pragma unroll
+      for (int t = 0; t < 2; t++)
+      {
+        if (t >= nt) break;
+        // cost first, then the lane (lane order = scan order), then the lane's own candidate bits: they must not take part in the minimum across lanes
+        const unsigned c = kmin[t] >> 2;
+        const unsigned km = wave_min_u32(c);
+        const unsigned long long hit = __ballot(c == km);
+        const int src = __builtin_ctzll(hit);
+        const unsigned sel = (unsigned)__builtin_amdgcn_readlane((int)kmin[t], src) & 3u;
+        const unsigned idx = (unsigned)__builtin_amdgcn_readlane((int)idx0, src) + sel;
+        if ((tid & 63) == 0) atomicMin(&wgKey[t0 + t], ((unsigned long long)km << 24) | idx);
+      }
+    }
+    __syncthreads();
+    if (tid < n) atomicMin(reinterpret_cast<unsigned long long*>(&best[b0 + k0 + tid].cost), wgKey[tid]);
+    k0 += n;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
 // Dense small grids (step 1 in both directions, nx * ny <= 256: the +-4 window of xPatternSearch): the (block, position)
 // pairs of G = 256 / (nx ny) blocks are laid flat over the 256 lanes of a workgroup (81 positions: 3 blocks, 95 % of the
 // lanes busy, where one block per 128 lanes would leave a third idle); each block's org and window sit in LDS as biased
@@ -1594,20 +1708,32 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
     const int ngroups = cdiv(nblocks, nbg);
     if (smem <= 150 * 1024 && (hsR & 1) == 0 && hsR >= 2 && nx + rps <= 4096 && (unsigned long long)ngroups * nstrips * nstrips < (1ull << 32))
     {
-      const int nsub = cdiv(nbg, 4), units = 2 * cdiv(rps, 6) * nsub;
+      static const int gqOff = getenv("VVCGPU_NO_R5GQ") ? 1 : 0;           // A/B timing switch: pair columns (r5g) instead of quad columns (r5gq)
+      const bool gq = !gqOff && mvcost_host->lambda < 4.0e6;                // cost << 2 | candidate in 32 bits: lambda * bits < 2^29
+      const int units = gq ? cdiv(rps, 6) * cdiv(nbg, 2) : 2 * cdiv(rps, 6) * cdiv(nbg, 4);
       const int threads = 64 * units;                                     // one wave per unit (<= 16: rps <= 24, nbg <= 8)
       const int total = ngroups * nstrips;
       const size_t packedDw = (size_t)nblocks * 2 * hsR * 8;
       unsigned* packed = static_cast<unsigned*>(vvcgpu_scratch(st0, packedDw * sizeof(unsigned)));
       if (!packed) return VVCGPU_E_DEVICE;
       hipLaunchKernelGGL(r5c_pack_org_kernel, dim3((unsigned)(((size_t)nblocks * hsR * (w >> 4) + 255) / 256)), dim3(256), 0, st0, org, org_stride, blocks, nblocks,
-                         w, hsR, sub_shift, packed, 0, reinterpret_cast<unsigned long long*>(best));
+                         w, hsR, sub_shift, packed, gq ? 1 : 0, reinterpret_cast<unsigned long long*>(best));
       VVC_LAUNCH_CHECK();
       const vvcgpu_mvcost mv = *mvcost_host;
-      if (smem > 48 * 1024)
-        VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster5g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      hipLaunchKernelGGL(sad_raster5g_kernel, dim3(cdiv(total, 8) * 8), dim3(threads), smem, st0, packed, ref, ref_stride, blocks, nblocks, nbg, h, sub_shift,
-                         dx0, dy0, nx, ny, rps, pitch, nstrips, 0xFFFFFFFFu / (unsigned)nstrips + 1u, total, (int)winB, mv, best);
+      if (gq)
+      {
+        if (smem > 48 * 1024)
+          VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster5gq_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(sad_raster5gq_kernel, dim3(cdiv(total, 8) * 8), dim3(threads), smem, st0, packed, ref, ref_stride, blocks, nblocks, nbg, h, sub_shift,
+                           dx0, dy0, nx, ny, rps, pitch, nstrips, 0xFFFFFFFFu / (unsigned)nstrips + 1u, total, (int)winB, mv, best);
+      }
+      else
+      {
+        if (smem > 48 * 1024)
+          VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster5g_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+        hipLaunchKernelGGL(sad_raster5g_kernel, dim3(cdiv(total, 8) * 8), dim3(threads), smem, st0, packed, ref, ref_stride, blocks, nblocks, nbg, h, sub_shift,
+                           dx0, dy0, nx, ny, rps, pitch, nstrips, 0xFFFFFFFFu / (unsigned)nstrips + 1u, total, (int)winB, mv, best);
+      }
       VVC_LAUNCH_CHECK();
       hipLaunchKernelGGL(sad_best_decode_kernel, dim3(cdiv(nblocks, 256)), dim3(256), 0, st0, nblocks, dx0, dy0, nx, sx, sy, mv, best);
       VVC_LAUNCH_CHECK();
