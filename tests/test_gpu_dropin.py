@@ -207,3 +207,23 @@ def test_nightly_uncapped_hooks(tmp_path, name, level):
     if level == "all":
         assert calls[16] > 60000 and calls[21] > 60000 and calls[26] > 20000, cl      # beyond the default caps
     print(cl)
+
+
+@needs_ref
+@pytest.mark.skipif(not os.environ.get("VVCGPU_NIGHTLY"), reason="nightly-style run (millions of synchronous round trips): VVCGPU_NIGHTLY=1")
+@pytest.mark.parametrize("name", ["ldpcrc_208x120_10b_q32"])
+def test_nightly_table_slots_every_width(tmp_path, name):
+    """VVCGPU_SHIM_HOOKS=slots: the function-pointer tables of SURVEY 8(b) taken literally -- EVERY distortion slot (SAD / HAD / SSE of every width,
+    DF_SAD12/24/48 included), every interpolation slot and the PelBuffer slots serve calls of every width through the library, while the reference's own
+    searches, transforms and quantisers run on the host and issue those calls.  The bitstream must not change."""
+    m, r, numbers = _encode_fixture(tmp_path, name, {"VVCGPU_SHIM_HOOKS": "slots"})
+    widths, wl = numbers("[vvcgpu slots]")
+    # the line lists the width classes by name (4, 8, 12-16, 24-32, 48-64, 128) followed by the counts: take the count after every second colon
+    counts = [int(x) for x in wl.split("width:", 1)[1].replace(",", " ").split() if x.isdigit() and not x.endswith(":")]
+    served = [int(t.split(":")[1]) for t in wl.split("width:", 1)[1].split(",")]
+    assert len(served) == 6 and all(v > 0 for v in served[:5]), wl          # widths 4 .. 64 all carried traffic
+    calls, cl = numbers("[vvcgpu shim]")
+    assert calls[8] > 100000 and calls[9] > 10000 and calls[10] > 10000 and calls[11] > 1000, cl     # SAD, HAD, interpolation, PelBuffer slots
+    assert calls[14] == 0 and calls[20] == 0 and calls[26] == 0, cl       # no PU-level or N1 hooks in this mode: the reference's own code issued the calls
+    print(wl)
+    print(cl)

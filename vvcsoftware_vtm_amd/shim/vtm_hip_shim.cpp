@@ -114,10 +114,14 @@ int hookLevel()
   if (lv < 0)
   {
     const char* e = getenv("VVCGPU_SHIM_HOOKS");
-    lv = getenv("VVCGPU_SHIM_NO_TABLES") ? 0 : !e ? 2 : !strcmp(e, "pic") ? 0 : !strcmp(e, "pu") ? 1 : 2;
+    // pic: picture-level hooks only; pu: + whole-PU searches; all (default): + block-level table slots (64-wide calls) and the N1 / N4 hooks;
+    // slots: picture-level hooks + the x86 function-pointer tables of SURVEY 8(b) for calls of EVERY width (no PU / N1 / N4 hooks, so that the
+    // reference's own searches and transforms issue their table-slot calls): the literal boundary, one synchronous round trip per call
+    lv = getenv("VVCGPU_SHIM_NO_TABLES") ? 0 : !e ? 2 : !strcmp(e, "pic") ? 0 : !strcmp(e, "pu") ? 1 : !strcmp(e, "slots") ? 3 : 2;
   }
   return lv;
 }
+static inline bool allWidths() { return hookLevel() == 3; }
 bool shimEnabled()
 {
   static int on = -1;
@@ -129,11 +133,14 @@ bool residentEnabled();
 long g_calls[28] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 // calls an (eligible) hook left to the CPU because its call cap was reached: TZSearch, IntraPred, IntraRefs, DepQuant, RDOQ, DequantIT
 long g_capped[6] = { 0, 0, 0, 0, 0, 0 };
+long g_distWidth[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };          // distortion calls served in the every-width form, by width class: 4, 8, 12-16, 24-32, 48-64, 128
 static inline bool capped(long limit, long calls, int slot) { if (limit > 0 && calls >= limit) { g_capped[slot]++; return true; } return false; }
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
                                                        "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld, IntraPred %ld, Border %ld, Hash %ld, CCLM %ld, IntraRefs %ld, DepQuant %ld, RDOQ %ld\n",
                                                        g_calls[0], g_calls[1], g_calls[2], g_calls[3], g_calls[4], g_calls[5], g_calls[6], g_calls[7],
                                                        g_calls[8], g_calls[9], g_calls[10], g_calls[11], g_calls[12], g_calls[13], g_calls[14], g_calls[15], g_calls[16], g_calls[17], g_calls[18], g_calls[19], g_calls[20], g_calls[21], g_calls[22], g_calls[23], g_calls[24], g_calls[25], g_calls[26], g_calls[27]);
+                            if (shimEnabled() && hookLevel() == 3) fprintf(stderr, "[vvcgpu slots] distortion calls served by width: 4: %ld, 8: %ld, 12-16: %ld, 24-32: %ld, 48-64: %ld, 128: %ld\n",
+                                                       g_distWidth[0], g_distWidth[1], g_distWidth[2], g_distWidth[3], g_distWidth[4], g_distWidth[5]);
                             if (shimEnabled()) fprintf(stderr, "[vvcgpu caps] eligible calls left to the CPU by a call cap (VVCGPU_SHIM_*_LIMIT, 0 = none): TZSearch %ld, IntraPred %ld, IntraRefs %ld, DepQuant %ld, RDOQ %ld, DequantIT %ld\n",
                                                        g_capped[0], g_capped[1], g_capped[2], g_capped[3], g_capped[4], g_capped[5]);
                             if (shimEnabled()) fprintf(stderr, "[vvcgpu resident] in-loop chain: %ld pictures, %ld picture uploads (reconstruction / original), %ld picture downloads, resident form %s\n",
@@ -962,12 +969,50 @@ Distortion gpuDist64(const DistParam& p)
   g_calls[KIND == 2 ? 17 : 8 + KIND]++;
   return (Distortion)out;
 }
+
+// every-width form (VVCGPU_SHIM_HOOKS=slots): one wrapper per table slot, so that a call the library does not take goes back to exactly
+// the function the reference had installed in that slot.  SLOT = DFunc index 0..26: SSE 0-7, SAD 8-15, HAD 16-23, SAD12/24/48 24-26.
+FpDistFunc g_cpuDistAll[27];
+template <int SLOT>
+Distortion gpuDistSlot(const DistParam& p)
+{
+  constexpr int KIND = SLOT < 8 ? 2 : (SLOT < 16 || SLOT >= 24) ? 0 : 1;
+  const int w = p.org.width, h = p.org.height;
+  // the reference's 4-wide SIMD SAD ignores the row sub-sampling: those calls stay where they are
+  if (p.applyWeight || p.useMR || p.step != 1 || p.bitDepth > 10 || w < 4 || h < 4 || (w & 1) || w > 128 || h > 128 || (KIND == 0 && w == 4 && p.subShift) ||
+      (KIND == 0 && p.subShift && (h & ((1 << p.subShift) - 1))))
+    return g_cpuDistAll[SLOT](p);
+  const int pitch = (w + 7) & ~7;
+  g_dOrg.reserve((size_t)128 * 128);
+  g_dCur.reserve((size_t)128 * 128);
+  g_dOut.reserve(1);
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_dOrg.ptr, pitch * sizeof(vvc_pel), p.org.buf, p.org.stride * sizeof(Pel), (size_t)w * sizeof(Pel), h, nullptr));
+  VVCGPU(vvcgpu_memcpy2d_h2d(g_dCur.ptr, pitch * sizeof(vvc_pel), p.cur.buf, p.cur.stride * sizeof(Pel), (size_t)w * sizeof(Pel), h, nullptr));
+  vvcgpu_dist_desc d;
+  memset(&d, 0, sizeof d);
+  d.org_stride = pitch; d.cur_stride = pitch; d.w = (int16_t)w; d.h = (int16_t)h; d.sub_shift = (int16_t)(KIND == 0 ? p.subShift : 0);
+  g_dDesc.upload(&d, 1);
+  VVCGPU(vvcgpu_dist_batch(KIND, g_dOrg.ptr, g_dCur.ptr, g_dDesc.ptr, 1, p.bitDepth, g_dOut.ptr, nullptr));
+  uint64_t out = 0;
+  VVCGPU(vvcgpu_memcpy_d2h(&out, g_dOut.ptr, sizeof out, nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  g_calls[KIND == 2 ? 17 : 8 + KIND]++;
+  g_distWidth[w <= 4 ? 0 : w <= 8 ? 1 : w <= 16 ? 2 : w <= 32 ? 3 : w <= 64 ? 4 : 5]++;
+  return (Distortion)out;
+}
+template <int SLOT> struct InstallDist { static void run() { g_cpuDistAll[SLOT] = RdCost::m_afpDistortFunc[SLOT]; RdCost::m_afpDistortFunc[SLOT] = gpuDistSlot<SLOT>; InstallDist<SLOT - 1>::run(); } };
+template <> struct InstallDist<-1> { static void run() {} };
 }  // namespace
 
 void wrap_initRdCostX86(RdCost* self)
 {
   real_initRdCostX86(self);
   if (!shimEnabled() || (hookLevel() < 2)) return;
+  if (allWidths())
+  {
+    if (RdCost::m_afpDistortFunc[DF_SAD64] != gpuDistSlot<DF_SAD64>) InstallDist<26>::run();
+    return;
+  }
   if (!g_cpuDist[0]) { g_cpuDist[0] = RdCost::m_afpDistortFunc[DF_SAD64]; g_cpuDist[1] = RdCost::m_afpDistortFunc[DF_HAD64]; g_cpuDist[2] = RdCost::m_afpDistortFunc[DF_SSE64]; }
   RdCost::m_afpDistortFunc[DF_SAD64] = gpuDist64<0>;
   RdCost::m_afpDistortFunc[DF_HAD64] = gpuDist64<1>;
@@ -986,7 +1031,7 @@ DevArray<vvcgpu_if_desc> g_ifDesc;
 template <int VER, int NI, int FIRST, int LAST>
 void gpuIf(const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, TFilterCoeff const* coeff)
 {
-  if (width < 64 || clpRng.bd > 10 || width > 256 || height > 256) { g_cpuIf[VER][NI][FIRST][LAST](clpRng, src, srcStride, dst, dstStride, width, height, coeff); return; }
+  if (width < (allWidths() ? 2 : 64) || clpRng.bd > 10 || width > 256 || height > 256) { g_cpuIf[VER][NI][FIRST][LAST](clpRng, src, srcStride, dst, dstStride, width, height, coeff); return; }
   constexpr int N = NI == 0 ? 8 : NI == 1 ? 4 : 2, before = N / 2 - 1, after = N / 2;
   const int cols = VER ? width : width + before + after, rows = VER ? height + before + after : height;
   const int sp = (cols + 7) & ~7, dp = (width + 7) & ~7;
@@ -1036,7 +1081,7 @@ DevArray<vvcgpu_pelop_desc> g_pDesc;
 
 bool gpuPelop(int op, const Pel* s0, int st0, const Pel* s1, int st1, Pel* dst, int dstStride, int w, int h, const vvcgpu_pelop_cfg& cfg)
 {
-  if (w < 64 || w > 128 || h > 128) return false;
+  if (w < (allWidths() ? 8 : 64) || w > 128 || h > 128) return false;
   const int pitch = 128;
   g_p0.reserve((size_t)pitch * 128); g_p1.reserve((size_t)pitch * 128); g_pd.reserve((size_t)pitch * 128);
   VVCGPU(vvcgpu_memcpy2d_h2d(g_p0.ptr, pitch * sizeof(vvc_pel), s0, st0 * sizeof(Pel), (size_t)w * sizeof(Pel), h, nullptr));
@@ -1099,7 +1144,7 @@ int trCode(int t) { return t == DCT2 ? 0 : t == DCT8 ? 1 : 2; }
 extern "C" int vvcshim_tr_fwd(int bd, const Pel* resi, size_t stride, TCoeff* coeff, int w, int h, int maxLog2, unsigned char ucMode, unsigned char ucTrIdx, bool useQTBT)
 {
   int hor, ver;
-  if (!shimEnabled() || (hookLevel() < 2) || !useQTBT || maxLog2 != 15 || bd > 10 || (w < 32 && h < 32) || !trTypes(ucMode, ucTrIdx, hor, ver)) return 0;
+  if (!shimEnabled() || (hookLevel() != 2) || !useQTBT || maxLog2 != 15 || bd > 10 || (w < 32 && h < 32) || !trTypes(ucMode, ucTrIdx, hor, ver)) return 0;
   g_tResi.reserve((size_t)64 * 64);
   g_tCoef.reserve((size_t)64 * 64);
   VVCGPU(vvcgpu_memcpy2d_h2d(g_tResi.ptr, (size_t)w * sizeof(vvc_pel), resi, stride * sizeof(Pel), (size_t)w * sizeof(Pel), h, nullptr));
@@ -1119,7 +1164,7 @@ extern "C" int vvcshim_tr_inv(int bd, const TCoeff* coeff, Pel* resi, size_t str
 {
   int hor, ver;
   const unsigned zw = w > 32 ? w - 32 : 0, zh = h > 32 ? h - 32 : 0;         // the zero-out the kernels assume (xIT, :755-759)
-  if (!shimEnabled() || (hookLevel() < 2) || maxLog2 != 15 || bd > 10 || (w < 32 && h < 32) || skipW != zw || skipH != zh ||
+  if (!shimEnabled() || (hookLevel() != 2) || maxLog2 != 15 || bd > 10 || (w < 32 && h < 32) || skipW != zw || skipH != zh ||
       !trTypes(ucMode, ucTrIdx, hor, ver)) return 0;
   g_tResi.reserve((size_t)64 * 64);
   g_tCoef.reserve((size_t)64 * 64);
@@ -1146,7 +1191,7 @@ DevArray<vvcgpu_frac_result> g_fRes;
 extern "C" int vvcshim_frac(InterSearch* self, const PredictionUnit* pu, int /*eRefPicList*/, int /*iRefIdx*/, InterSearch::IntTZSearchStruct* cs,
                             const Mv* mvInt, Mv* mvHalf, Mv* mvQter, Distortion* cost)
 {
-  if (!shimEnabled() || hookLevel() < 1) return 0;
+  if (!shimEnabled() || hookLevel() < 1 || hookLevel() == 3) return 0;
   const CPelBuf& key = *cs->pcPatternKey;
   const int w = key.width, h = key.height, bd = self->m_lumaClpRng.bd;
 #if JVET_K0157
@@ -1194,7 +1239,7 @@ DevArray<vvcgpu_search_best> g_sBest;
 
 extern "C" int vvcshim_fullsearch(InterSearch* self, InterSearch::IntTZSearchStruct* cs, Mv* rcMv, Distortion* ruiSAD)
 {
-  if (!shimEnabled() || hookLevel() < 1) return 0;
+  if (!shimEnabled() || hookLevel() < 1 || hookLevel() == 3) return 0;
   const CPelBuf& key = *cs->pcPatternKey;
   const int w = key.width, h = key.height, bd = self->m_lumaClpRng.bd;
   const InterSearch::SearchRange& sr = cs->searchRange;
@@ -1245,7 +1290,7 @@ DevArray<vvcgpu_search_best> g_zBest;
 extern "C" int vvcshim_tzsearch(InterSearch* self, const PredictionUnit* pu, InterSearch::IntTZSearchStruct* cs, Mv* rcMv, Distortion* ruiSAD,
                                 const Mv* pInt2Nx2N, bool bExtended, bool bFast)
 {
-  if (!shimEnabled() || hookLevel() < 1) return 0;
+  if (!shimEnabled() || hookLevel() < 1 || hookLevel() == 3) return 0;
   static const long limit = getenv("VVCGPU_SHIM_TZ_LIMIT") ? atol(getenv("VVCGPU_SHIM_TZ_LIMIT")) : 0;
   if (capped(limit, g_calls[20], 0)) return 0;
   const CPelBuf& key = *cs->pcPatternKey;
@@ -1332,7 +1377,7 @@ void wrap_predIntraAng(IntraPrediction* self, const ComponentID compId, PelBuf& 
   const ChannelType chType = toChannelType(compID);
   const int w = piPred.width, h = piPred.height;
   static const long limit = getenv("VVCGPU_SHIM_INTRA_LIMIT") ? atol(getenv("VVCGPU_SHIM_INTRA_LIMIT")) : 60000;
-  bool ok = shimEnabled() && !(hookLevel() < 2) && w >= 4 && h >= 4 && w <= 64 && h <= 64 && !(w & (w - 1)) && !(h & (h - 1)) &&
+  bool ok = shimEnabled() && !(hookLevel() != 2) && w >= 4 && h >= 4 && w <= 64 && h <= 64 && !(w & (w - 1)) && !(h & (h - 1)) &&
             !capped(limit, g_calls[21], 1);
   int T = 0, L = 0;
   if (ok) { VVCGPU(vvcgpu_intra_ref_lengths(w, h, &T, &L)); ok = T == self->m_topRefLength && L == self->m_leftRefLength; }
@@ -1385,7 +1430,7 @@ int sideUnitsAvailable(const CodingUnit& cu, ChannelType chType, const Position&
 void wrap_predIntraChromaLM(IntraPrediction* self, const ComponentID compID, PelBuf& piPred, const PredictionUnit& pu, const CompArea& chromaArea, int intraDir)
 {
   const char* dump = getenv("VVCGPU_CCLM_DUMP");
-  const bool gpu = shimEnabled() && !(hookLevel() < 2);
+  const bool gpu = shimEnabled() && !(hookLevel() != 2);
   const int w = chromaArea.width, h = chromaArea.height;
   bool ok = (gpu || dump) && pu.chromaFormat == CHROMA_420 && w >= 2 && h >= 2 && w <= 64 && h <= 64 && !(w & (w - 1)) && !(h & (h - 1)) &&
             (int)piPred.width == w && (int)piPred.height == h;
@@ -1482,7 +1527,7 @@ bool unitAvailable(const CodingUnit& cu, ChannelType chType, const Position& ref
 void wrap_initIntraPatternChType(IntraPrediction* self, const CodingUnit& cu, const CompArea& area, const bool bFilterRefSamples)
 {
   const char* dump = getenv("VVCGPU_FILL_DUMP");
-  const bool gpu = shimEnabled() && !(hookLevel() < 2);
+  const bool gpu = shimEnabled() && !(hookLevel() != 2);
   const int w = area.width, h = area.height;
   static const long limit = getenv("VVCGPU_SHIM_FILL_LIMIT") ? atol(getenv("VVCGPU_SHIM_FILL_LIMIT")) : 60000;
   if (!(gpu || dump) || w < 4 || h < 4 || w > 64 || h > 64 || (w & (w - 1)) || (h & (h - 1)) || (gpu && !dump && capped(limit, g_calls[25], 2)))
@@ -1586,7 +1631,7 @@ extern "C" int vvcshim_depquant(DepQuant* self, TransformUnit* tuP, const Compon
   const int w = area.width, h = area.height, n = w * h;
   const int bd = tu.cs->sps->getBitDepth(toChannelType(compID));
   static const long limit = getenv("VVCGPU_SHIM_DEPQUANT_LIMIT") ? atol(getenv("VVCGPU_SHIM_DEPQUANT_LIMIT")) : 20000;
-  const bool ok = shimEnabled() && !(hookLevel() < 2) && tu.cs->slice->getDepQuantEnabledFlag() && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
+  const bool ok = shimEnabled() && !(hookLevel() != 2) && tu.cs->slice->getDepQuantEnabledFlag() && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
                   !(w & (w - 1)) && !(h & (h - 1)) && bd >= 8 && bd <= 10 && (int)pSrc.stride == w && !capped(limit, g_calls[26], 3) &&
                   !tu.cs->sps->getSpsRangeExtension().getExtendedPrecisionProcessingFlag();
   if (!ok) return 0;
@@ -1638,7 +1683,7 @@ extern "C" int vvcshim_rdoq(QuantRDOQ* self, TransformUnit* tuP, const Component
   const int bd = tu.cs->sps->getBitDepth(toChannelType(compID));
   static const long limit = getenv("VVCGPU_SHIM_RDOQ_LIMIT") ? atol(getenv("VVCGPU_SHIM_RDOQ_LIMIT")) : 20000;
   const bool useRDOQ = tu.transformSkip[compID] ? self->m_useRDOQTS : self->m_useRDOQ;               // the dispatch of :652-690
-  const bool ok = shimEnabled() && !(hookLevel() < 2) && useRDOQ && !self->m_useSelectiveRDOQ && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
+  const bool ok = shimEnabled() && !(hookLevel() != 2) && useRDOQ && !self->m_useSelectiveRDOQ && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
                   !(w & (w - 1)) && !(h & (h - 1)) && bd >= 8 && bd <= 10 && (int)pSrc.stride == w && !capped(limit, g_calls[27], 4) &&
                   !tu.cs->sps->getSpsRangeExtension().getExtendedPrecisionProcessingFlag();
   if (!ok) return 0;
@@ -1681,7 +1726,7 @@ namespace { DevArray<vvc_pel> g_bPlane; }
 
 void wrap_extendPicBorder(Picture* self)
 {
-  if (!shimEnabled() || (hookLevel() < 2)) { real_extendPicBorder(self); return; }
+  if (!shimEnabled() || (hookLevel() != 2)) { real_extendPicBorder(self); return; }
   if (self->m_bIsBorderExtended) return;
   for (int comp = 0; comp < (int)getNumberValidComponents(self->cs->area.chromaFormat); comp++)
   {
@@ -1709,7 +1754,7 @@ namespace { DevArray<vvc_pel> g_hPlane; DevArray<uint32_t> g_hOut; }
 
 extern "C" int vvcshim_pichash(int method, const CPelUnitBuf* pic, PictureHash* digest, const BitDepths* bitDepths)
 {
-  if (!shimEnabled() || (hookLevel() < 2)) return 0;
+  if (!shimEnabled() || (hookLevel() != 2)) return 0;
   digest->hash.clear();
   for (uint32_t chan = 0; chan < (uint32_t)pic->bufs.size(); chan++)
   {
@@ -1745,7 +1790,7 @@ void wrap_invTransformNxN(TrQuant* self, TransformUnit& tu, const ComponentID& c
   const int w = area.width, h = area.height;
   const int bd = tu.cs->sps->getBitDepth(toChannelType(compID));
   int hor = DCT2, ver = DCT2;
-  bool ok = shimEnabled() && !(hookLevel() < 2) && !tu.cu->transQuantBypass && !CU::isRDPCMEnabled(*tu.cu) && bd <= 10 && bd >= 8 &&
+  bool ok = shimEnabled() && !(hookLevel() != 2) && !tu.cu->transQuantBypass && !CU::isRDPCMEnabled(*tu.cu) && bd <= 10 && bd >= 8 &&
             self->m_rectTUs && tu.cs->sps->getMaxLog2TrDynamicRange(toChannelType(compID)) == 15 && w >= 2 && h >= 2 && w <= 64 && h <= 64 &&
             !(w & (w - 1)) && !(h & (h - 1));
   // an encoder reconstructs a TU for every rate-distortion candidate (1.2 - 1.7 million calls on the 2-3 frame test clips, all
