@@ -218,9 +218,7 @@ def test_nightly_table_slots_every_width(tmp_path, name):
     searches, transforms and quantisers run on the host and issue those calls.  The bitstream must not change."""
     m, r, numbers = _encode_fixture(tmp_path, name, {"VVCGPU_SHIM_HOOKS": "slots"})
     widths, wl = numbers("[vvcgpu slots]")
-    # the line lists the width classes by name (4, 8, 12-16, 24-32, 48-64, 128) followed by the counts: take the count after every second colon
-    counts = [int(x) for x in wl.split("width:", 1)[1].replace(",", " ").split() if x.isdigit() and not x.endswith(":")]
-    served = [int(t.split(":")[1]) for t in wl.split("width:", 1)[1].split(",")]
+    served = [int(t.split(":")[1]) for t in wl.split("width:", 1)[1].split(",")]      # "4: n, 8: n, 12-16: n, 24-32: n, 48-64: n, 128: n"
     assert len(served) == 6 and all(v > 0 for v in served[:5]), wl          # widths 4 .. 64 all carried traffic
     calls, cl = numbers("[vvcgpu shim]")
     assert calls[8] > 100000 and calls[9] > 10000 and calls[10] > 10000 and calls[11] > 1000, cl     # SAD, HAD, interpolation, PelBuffer slots
