@@ -173,7 +173,9 @@ def test_sad_search_tie_rule():
 
 
 @pytest.mark.parametrize("h,ss,nx,ny,content", [(16, 1, 39, 39, "smooth"), (16, 1, 39, 39, "flat"), (16, 1, 39, 39, "ties"), (16, 0, 20, 13, "ties"), (16, 0, 17, 9, "smooth"), (8, 0, 40, 5, "extreme"),
-                                               (32, 2, 7, 30, "smooth"), (16, 1, 1, 1, "smooth")])
+                                               (32, 2, 7, 30, "smooth"), (16, 1, 1, 1, "smooth"),
+                                               # lambda x bits beyond 2^29 / 2^30: the quad group form hands over to the pair group form, that one to the per-block form
+                                               (16, 1, 39, 39, "ties-lambda5e6"), (16, 1, 39, 39, "flat-lambda2e7")])
 def test_sad_search_group_runs(h, ss, nx, ny, content):
     """16-wide blocks on a 5-stride raster take the GROUP kernel (one staged window per run of horizontal neighbours, up to 8 blocks):
     lists that mix full runs, short runs, runs broken by a vertical / horizontal offset, isolated blocks and a ragged tail; `flat`
@@ -183,6 +185,10 @@ def test_sad_search_group_runs(h, ss, nx, ny, content):
     bd, m = 10, 136
     W, H = 448, 192
     PW, PH = W + 2 * m, H + 2 * m
+    big_lambda = None
+    if "-lambda" in content:
+        content, lam_s = content.split("-lambda")
+        big_lambda = float(lam_s)
     if content == "flat":
         org = np.full((H, W), 400, np.int16)
         refp = np.full((PH, PW), 391, np.int16)
@@ -207,7 +213,7 @@ def test_sad_search_group_runs(h, ss, nx, ny, content):
     blk = blk[blk["org_y"] + h <= H]
     nb = blk.size
     dx0, dy0 = -5 * (nx // 2), -5 * (ny // 2)
-    lam = float(rng.uniform(0.5, 90))
+    lam = float(rng.uniform(0.5, 90)) if big_lambda is None else big_lambda
     mv = ops.MvCost(lam, int(rng.integers(-60, 60)), int(rng.integers(-60, 60)), 2, 0)
     want = np.zeros((nb, ny, nx), np.uint32)
     wbest = np.zeros(nb, ops.SEARCH_BEST)
