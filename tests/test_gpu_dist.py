@@ -117,6 +117,8 @@ def test_sad_search_best_only(w, h, ss, nx, ny):
     blk = np.zeros(nb, ops.SEARCH_BLK)
     for i in range(nb):
         x, y = int(rng.integers(0, (320 - w) // 2 + 1)) * 2, int(rng.integers(0, 256 - h + 1))
+        if i % 3 == 2 and x + 1 + w <= 320:
+            x += 1                         # odd block origin: the org packing takes its sample-wise path
         blk[i] = (x, y, m + x + int(rng.integers(-9, 10)), m + y + int(rng.integers(-9, 10)))
     mv = ops.MvCost(float(rng.uniform(0.5, 90)), int(rng.integers(-60, 60)), int(rng.integers(-60, 60)), 2, 0)
     want = np.zeros((nb, ny, nx), np.uint32)
@@ -205,9 +207,10 @@ def test_sad_search_group_runs(h, ss, nx, ny, content):
     run(0, 0, 8); run(128, 0, 8, 3, -2); run(256, 0, 5, -7, 5)          # full groups and a 5-run (then the list continues elsewhere)
     run(0, 32, 3, 1, 1); rows.append((48, 32, m + 48 + 2, m + 32 + 1))   # 3-run, then a block whose ref_x is off by one: run breaks
     run(64, 32, 2, 1, 2); run(96, 32, 13, -1, -1)                        # vertical offset differs / a 13-run crossing group boundaries
-    for _ in range(6):                                                   # isolated blocks (even org x: the packed org rows are dword loads)
-        x, y = int(rng.integers(0, (W - 16) // 2)) * 2, int(rng.integers(0, H - h))
+    for _ in range(6):                                                   # isolated blocks, even and odd columns
+        x, y = int(rng.integers(0, W - 16)), int(rng.integers(0, H - h))
         rows.append((x, y, m + x + int(rng.integers(-9, 10)), m + y + int(rng.integers(-9, 10))))
+    run(33, 64, 6, 2, -3)                                                # a run on odd sample columns (sample-wise org packing)
     run(16, 96, 7, 0, 0)                                                 # ragged tail: nblocks is not a multiple of 8
     blk = np.array(rows, dtype=ops.SEARCH_BLK)
     blk = blk[blk["org_y"] + h <= H]
