@@ -835,7 +835,7 @@ __global__ __launch_bounds__(MAXT, MINW) void sad_raster5q_kernel(const unsigned
                                                            const Pel* __restrict__ ref, int rs,
                                                            const vvcgpu_search_blk* __restrict__ blocks, int w, int h, int subShift,
                                                            int dx0, int dy0, int nx, int ny, int rowsPerStrip, int pitchDw,
-                                                           int nstrips, unsigned invStrips, int total, int winBytes, vvcgpu_mvcost mv, int useBest,
+                                                           int nstrips, unsigned invStrips, int total, int winBytes, int maxRows, vvcgpu_mvcost mv, int useBest,
                                                            unsigned* __restrict__ out, vvcgpu_search_best* __restrict__ best)
 {
   extern __shared__ __align__(16) unsigned refL[];
@@ -844,8 +844,8 @@ __global__ __launch_bounds__(MAXT, MINW) void sad_raster5q_kernel(const unsigned
   const int chunk = (total + 7) >> 3;                                       // XCD-aware order, as r5c
   const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
   if (item >= total) return;
-  const int b = nstrips == 1 ? item : (int)__umulhi((unsigned)item, invStrips), j0 = (item - b * nstrips) * rowsPerStrip;
-  const int nj = min(rowsPerStrip, ny - j0);
+  const int b = nstrips == 1 ? item : (int)__umulhi((unsigned)item, invStrips), strip = item - b * nstrips, j0 = strip * rowsPerStrip;
+  const int nj = strip == nstrips - 1 ? ny - j0 : rowsPerStrip;                // the last strip takes the remainder (<= maxRows, may exceed rowsPerStrip)
   const vvcgpu_search_blk blk = blocks[b];
   const int hs = h >> subShift;
   const int winRows = (nj - 1) * 5 + h;
@@ -856,7 +856,7 @@ __global__ __launch_bounds__(MAXT, MINW) void sad_raster5q_kernel(const unsigned
                       ((Ww - 1 + off) >> 3) + 1, tid, (int)blockDim.x);
   unsigned char* bitsX = reinterpret_cast<unsigned char*>(refL) + winBytes;   // [nx] then [rowsPerStrip]
   unsigned char* bitsY = bitsX + nx;
-  unsigned long long* costTab = reinterpret_cast<unsigned long long*>(bitsX + ((nx + rowsPerStrip + 15) & ~15));
+  unsigned long long* costTab = reinterpret_cast<unsigned long long*>(bitsX + ((nx + maxRows + 15) & ~15));
   if (useBest)
   {
     if (tid == 0) wgKey = ~0ull;
@@ -1778,12 +1778,29 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       static const int r5qSplit = getenv("VVCGPU_R5Q_SPLIT") ? atoi(getenv("VVCGPU_R5Q_SPLIT")) : 0;
       if (!r5qOff && nx <= 40)
       {
-        const int itemsQ = cdiv(rps, 6), nSt = hsR * chunks;
+        // A wave item is a group of SIX raster rows: 15 + 15 + 9 rows are 3 + 3 + 2 groups for 6.5 groups of work.  When whole groups per
+        // strip with the remainder in the LAST strip give fewer groups in no more strips and the same window (39 rows of 64-wide blocks:
+        // 12 + 12 + 15 = 2 + 2 + 3 groups), take that split.
+        int rpsQ = rps, nstripsQ = nstrips, lastQ = ny - (nstrips - 1) * rps;
+        {
+          const int groupsNow = (nstrips - 1) * cdiv(rps, 6) + cdiv(lastQ, 6);
+          for (int r = (rps / 6) * 6; r >= 6; r -= 6)
+          {
+            const int ns = ny / r;
+            if (ns < 1) continue;
+            const int last = ny - (ns - 1) * r;
+            const int groups = (ns - 1) * (r / 6) + cdiv(last, 6);
+            if (ns <= nstrips && win_bytes(last) <= budget && last <= 24 && groups < groupsNow) { rpsQ = r; nstripsQ = ns; lastQ = last; break; }
+          }
+        }
+        const int maxRowsQ = rpsQ > lastQ ? rpsQ : lastQ;
+        const size_t winBQ = win_bytes(maxRowsQ), smemQ = winBQ + (((size_t)nx + maxRowsQ + 15) & ~(size_t)15) + R5C_COST_N * sizeof(unsigned long long);
+        const int itemsQ = cdiv(maxRowsQ, 6), nSt = hsR * chunks;
         int splitQ = 1;
         while (splitQ < 8 && itemsQ * splitQ * 2 <= 12 && (nSt % (splitQ * 2)) == 0 && nSt / (splitQ * 2) >= 8) splitQ *= 2;
         if ((r5qSplit == 1 || r5qSplit == 2 || r5qSplit == 4 || r5qSplit == 8) && (nSt % r5qSplit) == 0 && itemsQ * r5qSplit <= 16) splitQ = r5qSplit;
         const int threadsQ = itemsQ * splitQ * 64;
-        const int totalQ = nblocks * nstrips;
+        const int totalQ = nblocks * nstripsQ;
         const size_t packedDwQ = (size_t)nblocks * 2 * hsR * (w >> 1);
         unsigned* packedQ = static_cast<unsigned*>(vvcgpu_scratch(st0, packedDwQ * sizeof(unsigned)));
         if (!packedQ) return VVCGPU_E_DEVICE;
@@ -1795,10 +1812,10 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
 #define LAUNCH_R5Q(SPL)                                                                                                          \
         do {                                                                                                                    \
           auto kfn = sad_raster5q_kernel<1024, 4, SPL>;                                                                          \
-          if (smem > 48 * 1024)                                                                                                 \
-            VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
-          hipLaunchKernelGGL(kfn, dim3(cdiv(totalQ, 8) * 8), dim3(threadsQ), smem, st0, packedQ, ref, ref_stride,               \
-                             blocks, w, h, sub_shift, dx0, dy0, nx, ny, rps, pitch, nstrips, 0xFFFFFFFFu / (unsigned)nstrips + 1u, totalQ, (int)winB, mvq, best ? 1 : 0, sad_out, best); \
+          if (smemQ > 48 * 1024)                                                                                                \
+            VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemQ)); \
+          hipLaunchKernelGGL(kfn, dim3(cdiv(totalQ, 8) * 8), dim3(threadsQ), smemQ, st0, packedQ, ref, ref_stride,              \
+                             blocks, w, h, sub_shift, dx0, dy0, nx, ny, rpsQ, pitch, nstripsQ, 0xFFFFFFFFu / (unsigned)nstripsQ + 1u, totalQ, (int)winBQ, maxRowsQ, mvq, best ? 1 : 0, sad_out, best); \
         } while (0)
         if (splitQ == 8) LAUNCH_R5Q(8); else if (splitQ == 4) LAUNCH_R5Q(4); else if (splitQ == 2) LAUNCH_R5Q(2); else LAUNCH_R5Q(1);
 #undef LAUNCH_R5Q
