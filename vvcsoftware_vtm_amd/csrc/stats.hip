@@ -499,10 +499,20 @@ __device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, u
       const int k2 = have ? (int)a.cls[(size_t)(by >> 2) * (a.w >> 2) + (bx >> 2)] : -1;
       if (key >= 0 && k2 != key)
       {
-        // flush the registers into the class bucket of the replica picked by the low lane bits (neighbouring blocks mostly share the
-        // class; same-address LDS atomics serialise)
-        const unsigned short* pt = posTab + (key >> 8) * (NB - 1);
-        unsigned char* b = reinterpret_cast<unsigned char*>(bucket + ((tid & (AC_REP - 1)) * 25 + (key & 0xff)) * NB);
+        // flush the registers into the class bucket.  Same-address LDS atomics serialise, and neighbouring blocks mostly share the class
+        // (bench picture: 94 %) while the transposition varies: lanes with the SAME transposition hit the same slots, so the replica is
+        // the lane's rank among the flushing lanes of its transposition (even spread: at most ceil(n_t / 4) lanes per address)
+        const int tcur = key >> 8;
+        const unsigned long long below = (1ull << (tid & 63)) - 1ull;
+        int rank = 0;
+#pragma unroll
+        for (int tt = 0; tt < 4; tt++)
+        {
+          const unsigned long long m = __ballot(tcur == tt);
+          if (tcur == tt) rank = (int)__popcll(m & below);
+        }
+        const unsigned short* pt = posTab + tcur * (NB - 1);
+        unsigned char* b = reinterpret_cast<unsigned char*>(bucket + ((rank & (AC_REP - 1)) * 25 + (key & 0xff)) * NB);
 #pragma unroll
         for (int i = 0; i < NT; i++) { atomicAdd(reinterpret_cast<unsigned long long*>(b + pt[i]), (unsigned long long)(long long)A[i]); A[i] = 0; }
 #pragma unroll
