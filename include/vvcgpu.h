@@ -443,7 +443,10 @@ typedef struct vvcgpu_tz_cfg {
   int32_t pic_w, pic_h, max_cu_w, max_cu_h;
   int32_t ref_x0, ref_y0, ref_x1, ref_y1;
   int32_t wg_per_pu;                    /* 0: one wavefront per PU (PUs up to about 32x32); 1: one workgroup of four per PU   */
-  int32_t reserved;                     /* sizeof == 64 */
+  int32_t uniform_pu;                   /* 0: PUs of any size.  h << 16 | w (16 / 32 / 64 each): the caller states that the PUs of the batch are w x h with
+                                           2:1 row sub-sampling; the raster stage (iRaster 5, InterSearch.cpp:2159-2169) then runs as its own launch
+                                           between two launches of the search (a PU that does not match, or whose raster touches the border of the
+                                           readable rectangle, keeps the one-launch form: results are identical either way).  sizeof == 64 */
 } vvcgpu_tz_cfg;
 int vvcgpu_tz_search_batch(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride,
                            const vvcgpu_tz_pu* pus, int n, const vvcgpu_tz_cfg* cfg_host,

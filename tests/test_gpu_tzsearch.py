@@ -183,3 +183,28 @@ def test_imv_refine_golden_and_oracle():
         out = ops.imv_refine_batch(dev(org), dev(ref_), ops.struct_to_device(pus), n, cfg, bool(had), wgt)
         got = out.cpu().numpy().view(cases.IMV_RESULT)
         assert np.array_equal(got, want), (sh, had, np.nonzero(got != want)[0][:5])
+
+
+@pytest.mark.parametrize("w,h", [(16, 16), (32, 32), (64, 64), (32, 16), (16, 64)])
+@pytest.mark.parametrize("srange,bd", [(96, 10), (64, 8)])
+def test_tz_search_split_form(w, h, srange, bd):
+    """cfg.uniform_pu = h << 16 | w (every PU of the batch is w x h, 2:1 row sub-sampling): the raster stage runs as the quad raster kernel between
+    two launches of the state machine.  Same results as the oracle (and therefore as the one-launch form) for PUs all over the picture --
+    interior ones whose raster is handed over, border ones whose clamped probes keep the in-kernel raster, PUs of the extended / fast
+    settings (raster step 6 / 8: not handed over), PUs that never reach the raster stage -- and a few PUs of ANOTHER size in the same batch
+    (they must simply stay on the in-kernel path)."""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(w * 7 + h + srange)
+    W, H, M = 448, 320, 160
+    org, ref_ = cases.tz_planes(rng, W, H, M, bd, motion=(int(rng.integers(-20, 21)), int(rng.integers(-20, 21))))
+    n = 260
+    pus = cases.tz_pus(rng, n, W, H, M, [(w, h)], sub_mode2=True)
+    assert np.all(pus["sub_shift"][pus["h"] > 8] == 1)
+    other = cases.tz_pus(rng, 12, W, H, M, [(8, 8), (64, 32), (16, 32)], sub_mode2=True)
+    pus = np.concatenate([pus, other])
+    cfg = cases.tz_cfg(W, H, M, float(rng.uniform(4, 60)), search_range=srange)
+    want = run_oracle(org, ref_, pus, cfg)
+    cfg_split = cfg.copy()
+    cfg_split["reserved"] = (h << 16) | w               # vvcgpu_tz_cfg.uniform_pu (numpy field name of the fixtures)
+    got = run_gpu(org, ref_, pus, cfg_split)
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:8]

@@ -22,6 +22,7 @@ ap.add_argument("--cpu-sample", type=int, default=1500)
 ap.add_argument("--reps", type=int, default=5)
 ap.add_argument("--team", type=int, default=0, help="cfg.wg_per_pu")
 ap.add_argument("--range", type=int, default=96, help="cfg.search_range")
+ap.add_argument("--split", action="store_true", help="cfg.uniform_pu = h << 16 | w: uniform batch, the raster stage as its own launch")
 ap.add_argument("--near", action="store_true", help="start vectors within +-2 samples of the true displacement (the raster stage is rarely entered)")
 a = ap.parse_args()
 rng = np.random.default_rng(11)
@@ -43,6 +44,7 @@ for size in (16, 32, 64):
         pus["start_x"], pus["start_y"] = rng.integers(-40, 41, n), rng.integers(-40, 41, n)
     pus["pred_hor"], pus["pred_ver"] = pus["start_x"], pus["start_y"]
     dp = ops.struct_to_device(pus)
+    cfg["reserved"] = ((size << 16) | size) if a.split else 0       # vvcgpu_tz_cfg.uniform_pu
     best = ops.tz_search_batch(dorg, dref, dp, n, cfg)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -53,7 +55,7 @@ for size in (16, 32, 64):
     torch.cuda.synchronize()
     ms = e0.elapsed_time(e1) / a.reps
     got = best.cpu().numpy().view(cases.BEST)
-    line = "%dx%d: %d PUs  gpu %.3f ms  %.2f M PU/s  found %.0f%%" % (size, size, n, ms, n / ms / 1e3, 100 * np.mean((got["x"] == 11) & (got["y"] == -6)))
+    line = ("split " if a.split else "") + "%dx%d: %d PUs  gpu %.3f ms  %.2f M PU/s  found %.0f%%" % (size, size, n, ms, n / ms / 1e3, 100 * np.mean((got["x"] == 11) & (got["y"] == -6)))
     k = min(a.cpu_sample, n)
     if k == 0:
         print(line)

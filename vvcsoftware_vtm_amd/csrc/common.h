@@ -19,6 +19,15 @@ int vvcgpu_frac_refine_launch(const vvc_pel* org, int org_stride, const vvc_pel*
                               int w, int h, int bit_depth, int clp_min, int clp_max, int use_hadamard, const vvcgpu_mvcost* mvcost_host,
                               const int* preds, vvcgpu_frac_result* results, void* stream);
 
+// Raster stage of whole-PU TZ searches as its own launch (tzsearch.hip -> dist.hip): one record per PU, written on the device.  An active
+// PU's raster is the nx x ny grid of step 5 whose position (0, 0) is the motion vector (x0, y0); blocks[] holds the block's origin in the
+// original and the reference position of the ZERO vector (as in vvcgpu_sad_search); the best candidate comes back as the packed
+// key (cost << 24 | j * nx + i) in best[].cost (all-ones: no candidate).  Every PU of the launch is w x h with row sub-sampling sub_shift.
+struct VvcRasterPer { int active, nx, ny, x0, y0, pred_hor, pred_ver, reserved; };
+int vvcgpu_raster_per_block_launch(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride, const vvcgpu_search_blk* blocks,
+                                   const VvcRasterPer* per, int nblocks, int w, int h, int sub_shift, int nx_max, int ny_max,
+                                   const vvcgpu_mvcost* mvcost_host, vvcgpu_search_best* best, unsigned* packed_workspace, hipStream_t stream);
+
 // device addresses (current device) of the transform matrices as int32 (tr32[type][size] row-major T[k][n] at type * 5460 + (n n - 4) / 3, tr32t its
 // transpose), of the raster position -> scan index tables (dqInv + scanOff[(log2 w - 1) * 6 + log2 h - 1]); uploaded on first use (transform.hip)
 struct VvcTrTables { const int* tr32; const int* tr32t; const unsigned short* dqInv; const int* scanOff; };

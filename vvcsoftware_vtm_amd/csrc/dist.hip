@@ -546,7 +546,7 @@ __device__ __forceinline__ void fill_window_cols(unsigned* __restrict__ lds, con
 // initBest != nullptr: the arg-min keys of the raster kernels start at all-ones (saves the separate fill launch).
 __global__ __launch_bounds__(256) void r5c_pack_org_kernel(const Pel* __restrict__ org, int os, const vvcgpu_search_blk* __restrict__ blocks,
                                                            int nblocks, int w, int hs, int subShift, unsigned* __restrict__ packed, int interleave,
-                                                           unsigned long long* __restrict__ initBest)
+                                                           unsigned long long* __restrict__ initBest, const VvcRasterPer* __restrict__ per = nullptr)
 {
   const int CH = w >> 4, perBlockUnits = hs * CH;
   const size_t gid = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -555,6 +555,7 @@ __global__ __launch_bounds__(256) void r5c_pack_org_kernel(const Pel* __restrict
   if (gid >= (size_t)nblocks * perBlockUnits) return;
   const int b = (int)(gid / (unsigned)perBlockUnits), rem = (int)(gid - (size_t)b * perBlockUnits);
   const int row = rem / CH, chunk = rem - row * CH;
+  if (per && !per[b].active) return;                                         // per-block form: a block that takes no part may not even be w x h
   const vvcgpu_search_blk blk = blocks[b];
   const Pel* o = org + (size_t)(blk.org_y + (row << subShift)) * os + blk.org_x + 16 * chunk;
   unsigned d[8];
@@ -834,9 +835,9 @@ template <int MAXT, int MINW, int SPLIT>
 __global__ __launch_bounds__(MAXT, MINW) void sad_raster5q_kernel(const unsigned* __restrict__ orgPacked,
                                                            const Pel* __restrict__ ref, int rs,
                                                            const vvcgpu_search_blk* __restrict__ blocks, int w, int h, int subShift,
-                                                           int dx0, int dy0, int nx, int ny, int rowsPerStrip, int pitchDw,
+                                                           int dx0, int dy0, int nxU, int nyU, int rowsPerStrip, int pitchDw,
                                                            int nstrips, unsigned invStrips, int total, int winBytes, int maxRows, vvcgpu_mvcost mv, int useBest,
-                                                           unsigned* __restrict__ out, vvcgpu_search_best* __restrict__ best)
+                                                           unsigned* __restrict__ out, vvcgpu_search_best* __restrict__ best, const VvcRasterPer* __restrict__ per)
 {
   extern __shared__ __align__(16) unsigned refL[];
   __shared__ unsigned long long wgKey;
@@ -845,7 +846,17 @@ __global__ __launch_bounds__(MAXT, MINW) void sad_raster5q_kernel(const unsigned
   const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
   if (item >= total) return;
   const int b = nstrips == 1 ? item : (int)__umulhi((unsigned)item, invStrips), strip = item - b * nstrips, j0 = strip * rowsPerStrip;
-  const int nj = strip == nstrips - 1 ? ny - j0 : rowsPerStrip;                // the last strip takes the remainder (<= maxRows, may exceed rowsPerStrip)
+  // per != nullptr (raster stage of whole-PU TZ searches): grid size, grid origin and predictor per block; inactive blocks and strips below
+  // the block's grid leave at once (before any barrier)
+  int nx = nxU, ny = nyU;
+  if (per)
+  {
+    const VvcRasterPer pb = per[b];
+    if (!pb.active) return;
+    nx = pb.nx; ny = pb.ny; dx0 = pb.x0; dy0 = pb.y0; mv.pred_hor = pb.pred_hor; mv.pred_ver = pb.pred_ver;
+  }
+  const int nj = strip == nstrips - 1 ? ny - j0 : min(rowsPerStrip, ny - j0);  // the last strip takes the remainder (<= maxRows, may exceed rowsPerStrip)
+  if (nj <= 0) return;
   const vvcgpu_search_blk blk = blocks[b];
   const int hs = h >> subShift;
   const int winRows = (nj - 1) * 5 + h;
@@ -1815,7 +1826,7 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
           if (smemQ > 48 * 1024)                                                                                                \
             VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smemQ)); \
           hipLaunchKernelGGL(kfn, dim3(cdiv(totalQ, 8) * 8), dim3(threadsQ), smemQ, st0, packedQ, ref, ref_stride,              \
-                             blocks, w, h, sub_shift, dx0, dy0, nx, ny, rpsQ, pitch, nstripsQ, 0xFFFFFFFFu / (unsigned)nstripsQ + 1u, totalQ, (int)winBQ, maxRowsQ, mvq, best ? 1 : 0, sad_out, best); \
+                             blocks, w, h, sub_shift, dx0, dy0, nx, ny, rpsQ, pitch, nstripsQ, 0xFFFFFFFFu / (unsigned)nstripsQ + 1u, totalQ, (int)winBQ, maxRowsQ, mvq, best ? 1 : 0, sad_out, best, nullptr); \
         } while (0)
         if (splitQ == 8) LAUNCH_R5Q(8); else if (splitQ == 4) LAUNCH_R5Q(4); else if (splitQ == 2) LAUNCH_R5Q(2); else LAUNCH_R5Q(1);
 #undef LAUNCH_R5Q
@@ -1949,3 +1960,51 @@ int vvcgpu_imv_refine_batch(const vvc_pel* org, int org_stride, const vvc_pel* r
 }
 
 }  // extern "C"
+
+// Raster stage of whole-PU TZ searches (tzsearch.hip): the quad raster kernel with per-block grids.  No decode pass: the caller reads the keys.
+int vvcgpu_raster_per_block_launch(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride, const vvcgpu_search_blk* blocks,
+                                   const VvcRasterPer* per, int nblocks, int w, int h, int sub_shift, int nx_max, int ny_max,
+                                   const vvcgpu_mvcost* mvcost_host, vvcgpu_search_best* best, unsigned* packed, hipStream_t st0)
+{
+  VVC_CHECK_ARG((w == 16 || w == 32 || w == 64) && (h & 15) == 0 && h >= 16 && h <= 64 && nx_max >= 1 && nx_max <= 40 && ny_max >= 1 && ny_max <= 40,
+                "raster_per_block: %dx%d blocks, %dx%d grid", w, h, nx_max, ny_max);
+  VVC_CHECK_ARG((org_stride & 1) == 0 && (ref_stride & 7) == 0 && ((uintptr_t)org & 3) == 0 && ((uintptr_t)ref & 15) == 0, "raster_per_block: alignment");
+  const int hsR = h >> sub_shift, chunks = w >> 4;
+  VVC_CHECK_ARG(hsR >= 2 && ((hsR * chunks) & 1) == 0, "raster_per_block: sub_shift %d", sub_shift);
+  const int Ww = (nx_max - 1) * 5 + w;
+  int pitch = (((Ww - 1 + 7) >> 3) + 1) * 4;
+  while ((pitch & 63) != 20 && (pitch & 63) != 44) pitch += 4;
+  static const int kbEnv = getenv("VVCGPU_TZ_RASTER_KB") ? atoi(getenv("VVCGPU_TZ_RASTER_KB")) : 0;   // experiment: window budget
+  const size_t budget = (size_t)(kbEnv > 0 ? kbEnv : 78) * 1024;
+  auto win_bytes = [&](int rps) { return (size_t)((rps - 1) * 5 + h) * pitch * 4 + 64; };
+  int nstrips = 1, rps = ny_max;
+  for (;; nstrips++)
+  {
+    rps = cdiv(cdiv(ny_max, nstrips), 3) * 3;
+    if (win_bytes(rps) <= budget || rps <= 3) break;
+  }
+  nstrips = cdiv(ny_max, rps);
+  const int lastRows = ny_max - (nstrips - 1) * rps, maxRows = rps > lastRows ? rps : lastRows;
+  const size_t winB = win_bytes(maxRows), smem = winB + (((size_t)nx_max + maxRows + 15) & ~(size_t)15) + R5C_COST_N * sizeof(unsigned long long);
+  const int items = cdiv(maxRows, 6), nSt = hsR * chunks;
+  int split = 1;
+  while (split < 8 && items * split * 2 <= 12 && (nSt % (split * 2)) == 0 && nSt / (split * 2) >= 8) split *= 2;
+  const int threads = items * split * 64, total = nblocks * nstrips;
+  // packed: the caller's workspace of nblocks * 2 * (h >> sub_shift) * (w / 2) dwords (the per-stream scratch belongs to the caller here)
+  hipLaunchKernelGGL(r5c_pack_org_kernel, dim3((unsigned)(((size_t)nblocks * hsR * (w >> 4) + 255) / 256)), dim3(256), 0, st0, org, org_stride, blocks, nblocks,
+                     w, hsR, sub_shift, packed, 1, reinterpret_cast<unsigned long long*>(best), per);
+  VVC_LAUNCH_CHECK();
+  const vvcgpu_mvcost mv = *mvcost_host;
+#define LAUNCH_R5QT(SPL)                                                                                                        \
+  do {                                                                                                                        \
+    auto kfn = sad_raster5q_kernel<1024, 4, SPL>;                                                                              \
+    if (smem > 48 * 1024)                                                                                                     \
+      VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kfn), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
+    hipLaunchKernelGGL(kfn, dim3(cdiv(total, 8) * 8), dim3(threads), smem, st0, packed, ref, ref_stride, blocks, w, h, sub_shift, 0, 0, nx_max, ny_max, rps, \
+                       pitch, nstrips, 0xFFFFFFFFu / (unsigned)nstrips + 1u, total, (int)winB, maxRows, mv, 1, (unsigned*)nullptr, best, per); \
+  } while (0)
+  if (split == 8) LAUNCH_R5QT(8); else if (split == 4) LAUNCH_R5QT(4); else if (split == 2) LAUNCH_R5QT(2); else LAUNCH_R5QT(1);
+#undef LAUNCH_R5QT
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}

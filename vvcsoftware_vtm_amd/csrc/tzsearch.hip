@@ -432,10 +432,15 @@ struct TzTeam
   }
 };
 
+// state of a PU whose raster stage runs as its own launch (split form, see vvcgpu_tz_search_batch)
+struct TzSave { unsigned long long bestSad; int bestX, bestY; unsigned bestDist, bestRound; int pointNr, deferred; int left, top, right, bottom; int x0, y0, nx, ny; int reserved; int pad; };
+
 template <int TEAM>
 __global__ __launch_bounds__(256) void tz_search_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
                                                         const vvcgpu_tz_pu* __restrict__ pus, int n, vvcgpu_tz_cfg cfg,
-                                                        vvcgpu_search_best* __restrict__ results)
+                                                        vvcgpu_search_best* __restrict__ results, int phase, TzSave* __restrict__ save,
+                                                        vvcgpu_search_blk* __restrict__ rblk, VvcRasterPer* __restrict__ rper,
+                                                        const vvcgpu_search_best* __restrict__ rbest)
 {
   __shared__ __attribute__((aligned(16))) unsigned orgL[TZ_LDS_DWORDS];
   __shared__ unsigned long long keyL[4];
@@ -445,6 +450,7 @@ __global__ __launch_bounds__(256) void tz_search_kernel(const Pel* __restrict__ 
   const int b = __builtin_amdgcn_readfirstlane(TEAM == 4 ? (int)blockIdx.x : (int)blockIdx.x * 4 + wave);
   if (b >= n) return;                                          // TEAM 4: the whole workgroup leaves; TEAM 1: no barrier is used
   const vvcgpu_tz_pu pu = pus[b];
+  if (phase == 2 && !save[b].deferred) return;                 // finished in the first launch (team-uniform)
 
   TzTeam<TEAM> s;
   s.org = org + (ptrdiff_t)pu.org_y * os + pu.org_x; s.ref = ref; s.os = os; s.rs = rs;
@@ -507,6 +513,21 @@ __global__ __launch_bounds__(256) void tz_search_kernel(const Pel* __restrict__ 
   enum { START, ZERO, PRED2, RANGE, FIRST, FIRST_STOP, ZERO_NBH, TWO_POINT, RASTER, STAR_BEGIN, STAR, STAR_STOP, STAR_TWO_POINT, DONE };
   int state = START, d = 1, startX = 0, startY = 0;
   bool bestCandidateZero = false;
+  if (phase == 2)
+  {
+    // resume behind the raster stage: the state of the first launch, then the raster launch's best candidate under the round rule
+    // (strictly better than what the earlier rounds found; the raster's own ties were resolved in visiting order by its key)
+    const TzSave sv = save[b];
+    s.bestSad = sv.bestSad; s.bestX = sv.bestX; s.bestY = sv.bestY; s.bestDist = sv.bestDist; s.bestRound = sv.bestRound; s.pointNr = sv.pointNr;
+    s.sr.left = sv.left; s.sr.top = sv.top; s.sr.right = sv.right; s.sr.bottom = sv.bottom;
+    const unsigned long long key = rbest[b].cost;
+    if (key != ~0ull && (key >> 24) < s.bestSad)
+    {
+      const int idx = (int)(key & 0xFFFFFFu), j = idx / sv.nx, i = idx - j * sv.nx;
+      s.bestSad = key >> 24; s.bestX = sv.x0 + 5 * i; s.bestY = sv.y0 + 5 * j; s.bestDist = 5u; s.bestRound = 0; s.pointNr = 0;
+    }
+    state = STAR_BEGIN;
+  }
   while (state != DONE)
   {
     TzRound R;
@@ -556,6 +577,25 @@ __global__ __launch_bounds__(256) void tz_search_kernel(const Pel* __restrict__ 
           R.kind = 3; R.d = step; R.win = l; R.nx = (l.right - l.left) / step + 1;
           R.n = R.nx * ((l.bottom - l.top) / step + 1);
           R.rnx = R.nx > 1 ? (unsigned)(0x100000000ull / (unsigned)R.nx) + 1u : 0u;
+          // first launch of the split form: a plain step-5 raster whose every probe lies inside the readable rectangle (no clamping of the
+          // block origin) is left to the raster launch; this PU resumes behind it in the third launch
+          const int ny = (l.bottom - l.top) / step + 1;
+          // (the raster kernel stages whole 16-byte words of the window rows: 8 samples of slack on both sides)
+          if (phase == 1 && step == 5 && R.nx <= 40 && ny <= 40 && pu.w == (cfg.uniform_pu & 0xFFFF) && pu.h == ((cfg.uniform_pu >> 16) & 0xFFFF) && pu.sub_shift == 1 &&
+              s.refX + l.left - 8 >= s.rx0 && s.refX + l.left + (R.nx - 1) * 5 + 8 <= s.rx1 && s.refY + l.top >= s.ry0 && s.refY + l.top + (ny - 1) * 5 <= s.ry1)
+          {
+            if (s.tl == 0)
+            {
+              TzSave sv;
+              sv.bestSad = s.bestSad; sv.bestX = s.bestX; sv.bestY = s.bestY; sv.bestDist = s.bestDist; sv.bestRound = s.bestRound; sv.pointNr = s.pointNr;
+              sv.left = s.sr.left; sv.top = s.sr.top; sv.right = s.sr.right; sv.bottom = s.sr.bottom;
+              sv.x0 = l.left; sv.y0 = l.top; sv.nx = R.nx; sv.ny = ny; sv.deferred = 1; sv.reserved = 0;
+              save[b] = sv;
+              rblk[b] = vvcgpu_search_blk{ pu.org_x, pu.org_y, pu.ref_x, pu.ref_y };       // reference position of the zero vector, as in vvcgpu_sad_search
+              rper[b] = VvcRasterPer{ 1, R.nx, ny, l.left, l.top, pu.pred_hor, pu.pred_ver, 0 };
+            }
+            return;                                            // team-uniform
+          }
         }
       }
       state = STAR_BEGIN; break;
@@ -583,6 +623,7 @@ __global__ __launch_bounds__(256) void tz_search_kernel(const Pel* __restrict__ 
     vvcgpu_search_best r;
     r.x = s.bestX; r.y = s.bestY; r.cost = s.bestSad; r.sad = s.bestSad - s.mvcost(s.bestX, s.bestY);
     results[b] = r;
+    if (phase == 1) { save[b].deferred = 0; rper[b].active = 0; rblk[b] = vvcgpu_search_blk{ pu.org_x, pu.org_y, pu.ref_x, pu.ref_y }; }
   }
 }
 
@@ -621,10 +662,43 @@ int vvcgpu_tz_search_batch(const vvc_pel* org, int org_stride, const vvc_pel* re
   VVC_CHECK_ARG(c.ref_x1 - c.ref_x0 >= 128 && c.ref_y1 - c.ref_y0 >= 128 && c.ref_x0 >= 0 && c.ref_y0 >= 0 && c.ref_x1 <= ref_stride,
                 "tz_search_batch: readable rectangle [%d,%d)x[%d,%d) (stride %d) must hold a 128x128 block", c.ref_x0, c.ref_x1, c.ref_y0, c.ref_y1,
                 ref_stride);
-  if (c.wg_per_pu)
-    hipLaunchKernelGGL(tz_search_kernel<4>, dim3(n), dim3(256), 0, (hipStream_t)stream, org, org_stride, ref, ref_stride, pus, n, c, results);
-  else
-    hipLaunchKernelGGL(tz_search_kernel<1>, dim3((n + 3) / 4), dim3(256), 0, (hipStream_t)stream, org, org_stride, ref, ref_stride, pus, n, c, results);
+  hipStream_t st = (hipStream_t)stream;
+  auto launch = [&](int phase, TzSave* save, vvcgpu_search_blk* rblk, VvcRasterPer* rper, const vvcgpu_search_best* rbest)
+  {
+    if (c.wg_per_pu)
+      hipLaunchKernelGGL(tz_search_kernel<4>, dim3(n), dim3(256), 0, st, org, org_stride, ref, ref_stride, pus, n, c, results, phase, save, rblk, rper, rbest);
+    else
+      hipLaunchKernelGGL(tz_search_kernel<1>, dim3((n + 3) / 4), dim3(256), 0, st, org, org_stride, ref, ref_stride, pus, n, c, results, phase, save, rblk, rper, rbest);
+  };
+  // Split form (cfg.uniform_pu = h << 16 | w: the caller states that EVERY PU of the batch is w x h with 2:1 row sub-sampling): the raster stage,
+  // 86 % of the probes of a search that enters it, runs as the quad raster kernel of dist.hip between two launches of the state machine --
+  // the in-kernel raster round works one wavefront per PU at ~8 % of the v_sad_u16 issue rate, the raster kernel at ~60 %.
+  static const int splitOff = getenv("VVCGPU_TZ_NO_SPLIT") ? 1 : 0;           // A/B timing switch
+  const int uw = c.uniform_pu & 0xFFFF, uh = (c.uniform_pu >> 16) & 0xFFFF;
+  const int gridMax = (2 * c.search_range) / 5 + 1;
+  if (!splitOff && c.uniform_pu != 0 && (uw == 16 || uw == 32 || uw == 64) && (uh == 16 || uh == 32 || uh == 64) && gridMax <= 40 &&
+      (org_stride & 1) == 0 && (ref_stride & 7) == 0 && ((uintptr_t)org & 3) == 0 && ((uintptr_t)ref & 15) == 0)
+  {
+    const size_t packedDw = (size_t)n * 2 * (uh >> 1) * (uw >> 1);
+    const size_t bytes = (size_t)n * (sizeof(TzSave) + sizeof(vvcgpu_search_blk) + sizeof(VvcRasterPer) + sizeof(vvcgpu_search_best)) + packedDw * 4 + 256;
+    unsigned char* ws = static_cast<unsigned char*>(vvcgpu_scratch(st, bytes));
+    if (!ws) return VVCGPU_E_DEVICE;
+    TzSave* save = reinterpret_cast<TzSave*>(ws);
+    vvcgpu_search_best* rbest = reinterpret_cast<vvcgpu_search_best*>(save + n);
+    VvcRasterPer* rper = reinterpret_cast<VvcRasterPer*>(rbest + n);
+    vvcgpu_search_blk* rblk = reinterpret_cast<vvcgpu_search_blk*>(rper + n);
+    unsigned* packed = reinterpret_cast<unsigned*>((reinterpret_cast<uintptr_t>(rblk + n) + 63) & ~(uintptr_t)63);
+    launch(1, save, rblk, rper, nullptr);
+    VVC_LAUNCH_CHECK();
+    vvcgpu_mvcost mv;
+    mv.lambda = c.lambda; mv.pred_hor = 0; mv.pred_ver = 0; mv.cost_scale = c.cost_scale; mv.imv_shift = c.imv_shift;
+    const int rc = vvcgpu_raster_per_block_launch(org, org_stride, ref, ref_stride, rblk, rper, n, uw, uh, 1, gridMax, gridMax, &mv, rbest, packed, st);
+    if (rc != VVCGPU_OK) return rc;
+    launch(2, save, rblk, rper, rbest);
+    VVC_LAUNCH_CHECK();
+    return VVCGPU_OK;
+  }
+  launch(0, nullptr, nullptr, nullptr, nullptr);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
@@ -636,7 +710,9 @@ int vvcgpu_me_batch(const vvc_pel* org, int org_stride, const vvc_pel* ref, int 
   VVC_CHECK_ARG(n >= 0, "me_batch: n %d", n);
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(cfg_host && int_results && frac_results, "me_batch: null pointer");
-  int rc = vvcgpu_tz_search_batch(org, org_stride, ref, ref_stride, pus, n, cfg_host, int_results, stream);
+  vvcgpu_tz_cfg cfgu = *cfg_host;
+  if (cfgu.uniform_pu == 0 && (w == 16 || w == 32 || w == 64) && (h == 16 || h == 32 || h == 64)) cfgu.uniform_pu = (h << 16) | w;   // the chain's PUs are w x h
+  int rc = vvcgpu_tz_search_batch(org, org_stride, ref, ref_stride, pus, n, &cfgu, int_results, stream);
   if (rc != VVCGPU_OK) return rc;
   hipStream_t st = (hipStream_t)stream;
   unsigned char* scratch = static_cast<unsigned char*>(vvcgpu_scratch(st, (size_t)n * (sizeof(vvcgpu_frac_blk) + 2 * sizeof(int))));

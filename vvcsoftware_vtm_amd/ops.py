@@ -172,7 +172,7 @@ TZ_PU = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y"
                   ("w", "<i2"), ("h", "<i2"), ("sub_shift", "<i2"), ("flags", "<i2"), ("reserved", "<i4", (2,))])
 TZ_CFG = np.dtype([("lambda", "<f8"), ("cost_scale", "<i4"), ("imv_shift", "<i4"), ("search_range", "<i4"), ("first_search_stop", "<i4"),
                    ("pic_w", "<i4"), ("pic_h", "<i4"), ("max_cu_w", "<i4"), ("max_cu_h", "<i4"),
-                   ("ref_x0", "<i4"), ("ref_y0", "<i4"), ("ref_x1", "<i4"), ("ref_y1", "<i4"), ("wg_per_pu", "<i4"), ("reserved", "<i4")])
+                   ("ref_x0", "<i4"), ("ref_y0", "<i4"), ("ref_x1", "<i4"), ("ref_y1", "<i4"), ("wg_per_pu", "<i4"), ("reserved", "<i4")])   # "reserved" = vvcgpu_tz_cfg.uniform_pu (the field keeps its name: the golden fixtures store this dtype)
 assert TZ_PU.itemsize == 64 and TZ_CFG.itemsize == 64
 TZ_PRED2, TZ_EXTENDED, TZ_FAST = 1, 2, 4
 
