@@ -438,11 +438,11 @@ struct TzSave { unsigned long long bestSad; int bestX, bestY; unsigned bestDist,
 template <int TEAM>
 __global__ __launch_bounds__(256) void tz_search_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
                                                         const vvcgpu_tz_pu* __restrict__ pus, int n, vvcgpu_tz_cfg cfg,
-                                                        vvcgpu_search_best* __restrict__ results, int phase, TzSave* __restrict__ save,
+                                                        vvcgpu_search_best* __restrict__ results, int ldsDwords, int phase, TzSave* __restrict__ save,
                                                         vvcgpu_search_blk* __restrict__ rblk, VvcRasterPer* __restrict__ rper,
                                                         const vvcgpu_search_best* __restrict__ rbest)
 {
-  __shared__ __attribute__((aligned(16))) unsigned orgL[TZ_LDS_DWORDS];
+  extern __shared__ __attribute__((aligned(16))) unsigned orgL[];          // ldsDwords dwords: the sub-sampled original block(s) of the team
   __shared__ unsigned long long keyL[4];
   __shared__ int negL[4];
   __shared__ unsigned segS[4][64 * TZ_SEG_REGS + 4];
@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void tz_search_kernel(const Pel* __restrict__ 
   // the sub-sampled original block -> LDS as packed pairs (w is a multiple of 4: VVC block widths are 4, 8, 12, 16, 24, ...)
   {
     const int rows = pu.h >> pu.sub_shift, halfW = pu.w >> 1, ndw = rows * halfW;
-    const int slice = TEAM == 4 ? TZ_LDS_DWORDS : TZ_LDS_DWORDS / 4;
+    const int slice = TEAM == 4 ? ldsDwords : ldsDwords / 4;
     unsigned* dst = orgL + (TEAM == 4 ? 0 : wave * slice);
     const bool fits = ndw <= slice && (pu.w & 3) == 0;
     int neg = 0;
@@ -663,12 +663,25 @@ int vvcgpu_tz_search_batch(const vvc_pel* org, int org_stride, const vvc_pel* re
                 "tz_search_batch: readable rectangle [%d,%d)x[%d,%d) (stride %d) must hold a 128x128 block", c.ref_x0, c.ref_x1, c.ref_y0, c.ref_y1,
                 ref_stride);
   hipStream_t st = (hipStream_t)stream;
+  // LDS for the teams' original blocks: 32 KB serve any PU (8 KB per wavefront: 64x128 sub-sampled; one workgroup per PU: 128x128); with the
+  // caller's word that the PUs are w x h the allocation shrinks to what they need (16x16: 1 KB per workgroup), which doubles the resident
+  // wavefronts of this latency-bound kernel (a PU that is larger after all reads its block sample-wise: correct, slower)
+  int ldsDwords = TZ_LDS_DWORDS;
+  {
+    const int uw0 = c.uniform_pu & 0xFFFF, uh0 = (c.uniform_pu >> 16) & 0xFFFF;
+    if (c.uniform_pu != 0 && uw0 >= 4 && uh0 >= 4 && uw0 <= 128 && uh0 <= 128)
+    {
+      const int per = (((uh0 >> 1) * (uw0 >> 1)) + 63) & ~63;
+      ldsDwords = c.wg_per_pu ? per : 4 * per;
+      if (ldsDwords > TZ_LDS_DWORDS) ldsDwords = TZ_LDS_DWORDS;
+    }
+  }
   auto launch = [&](int phase, TzSave* save, vvcgpu_search_blk* rblk, VvcRasterPer* rper, const vvcgpu_search_best* rbest)
   {
     if (c.wg_per_pu)
-      hipLaunchKernelGGL(tz_search_kernel<4>, dim3(n), dim3(256), 0, st, org, org_stride, ref, ref_stride, pus, n, c, results, phase, save, rblk, rper, rbest);
+      hipLaunchKernelGGL(tz_search_kernel<4>, dim3(n), dim3(256), (size_t)ldsDwords * 4, st, org, org_stride, ref, ref_stride, pus, n, c, results, ldsDwords, phase, save, rblk, rper, rbest);
     else
-      hipLaunchKernelGGL(tz_search_kernel<1>, dim3((n + 3) / 4), dim3(256), 0, st, org, org_stride, ref, ref_stride, pus, n, c, results, phase, save, rblk, rper, rbest);
+      hipLaunchKernelGGL(tz_search_kernel<1>, dim3((n + 3) / 4), dim3(256), (size_t)ldsDwords * 4, st, org, org_stride, ref, ref_stride, pus, n, c, results, ldsDwords, phase, save, rblk, rper, rbest);
   };
   // Split form (cfg.uniform_pu = h << 16 | w: the caller states that EVERY PU of the batch is w x h with 2:1 row sub-sampling): the raster stage,
   // 86 % of the probes of a search that enters it, runs as the quad raster kernel of dist.hip between two launches of the state machine --
