@@ -219,6 +219,49 @@ __device__ __forceinline__ void load_tile_clamped(short* __restrict__ lds, const
   }
 }
 
+// the same in two halves, NB vectors per thread: tile_fetch issues every load into registers, tile_store writes them to LDS -- the simple
+// loop pays one trip to memory per iteration, and a caller can put other work between the halves
+template <int PITCH, int NB>
+__device__ __forceinline__ void tile_fetch(pel4 (&val)[NB], const Pel* __restrict__ src, int stride, int w, int h, int x0, int y0, int rows,
+                                           int tid, int nthreads)
+{
+  constexpr int VPR = PITCH / 4;
+  const int nvec = rows * VPR;
+  const bool vec_ok = ((stride & 3) == 0) && ((reinterpret_cast<uintptr_t>(src) & 7) == 0);
+#pragma unroll
+  for (int u = 0; u < NB; u++)
+  {
+    const int v = tid + u * nthreads;
+    val[u] = pel4{ 0, 0, 0, 0 };
+    if (v >= nvec) continue;
+    const int r = v / VPR, c = (v - r * VPR) * 4;
+    int y = y0 + r;
+    y = y < 0 ? 0 : (y >= h ? h - 1 : y);
+    const int x = x0 + c;
+    const Pel* row = src + (size_t)y * stride;
+    if (vec_ok && x >= 0 && x + 3 < w) val[u] = *reinterpret_cast<const pel4*>(row + x);
+    else
+    {
+#pragma unroll
+      for (int k = 0; k < 4; k++) { int xx = x + k; xx = xx < 0 ? 0 : (xx >= w ? w - 1 : xx); val[u][k] = row[xx]; }
+    }
+  }
+}
+template <int PITCH, int NB>
+__device__ __forceinline__ void tile_store(short* __restrict__ lds, const pel4 (&val)[NB], int rows, int tid, int nthreads)
+{
+  constexpr int VPR = PITCH / 4;
+  const int nvec = rows * VPR;
+#pragma unroll
+  for (int u = 0; u < NB; u++)
+  {
+    const int v = tid + u * nthreads;
+    if (v >= nvec) continue;
+    const int r = v / VPR, c = (v - r * VPR) * 4;
+    *reinterpret_cast<pel4*>(lds + r * PITCH + c) = val[u];
+  }
+}
+
 // canonical tap index of offset (dy,dx), as in alf.hip (AdaptiveLoopFilter.cpp:600-636 == calcCovariance t=0)
 template <bool IS7>
 __device__ __forceinline__ constexpr int tapIndexS(int dy, int dx)
@@ -421,22 +464,23 @@ __global__ __launch_bounds__(256) void alf_stats_chroma2_kernel(const Pel* __res
 // map is a 4 x 105 table in LDS, built once per workgroup, instead of nibble extraction and triangle index arithmetic per atomic.
 // Chroma workgroup: both chroma CTUs (no classifier), one block per thread.
 // ---------------------------------------------------------------------------------------------------
-constexpr int ACT = 512;                         // threads per CTU workgroup
-constexpr int AC_REP = 4;                        // luma bucket replicas
-constexpr int AC_NB7 = 91 + 13 + 1;              // bucket entries 7x7: tri(E), y, pixAcc
-constexpr int AC_NB5 = 28 + 7 + 1;
-constexpr int AC_CREP = 16;                      // chroma bucket replicas per plane
+constexpr int ACT = 512;                          // threads per CTU workgroup
+constexpr int AC_REC7 = 13 * 13 + 13 + 1;        // luma record: E, y, pixAcc
 
 template <int C> struct AlfCtuLds
 {
   static constexpr int P = C + 8, ROWS = C + 6;                          // luma tile
   static constexpr int tileBytes = (ROWS * P * 2 + 15) & ~15;
-  static constexpr int tabBytes = (4 * (AC_NB7 - 1) * 2 + 15) & ~15;      // u16 byte offsets, [t][idx]
-  static constexpr int bucketBytes = AC_REP * 25 * AC_NB7 * 8;
-  static constexpr int lumaBytes = tileBytes + tabBytes + bucketBytes;
+  static constexpr int zeroBytes = (3 * P * 2 + 16 + 15) & ~15;          // four rows of zeros at the tile's pitch: what an empty slot of a step reads
+  static constexpr int bucketBytes = 25 * AC_REC7 * 8;                   // one 64-bit record per class
+  static constexpr int MAXSTEPS = (C / 4) * (C / 4) / 4 + 25;            // steps of four blocks, every class padded to whole steps
+  static constexpr int listBytes = MAXSTEPS * 4 * 4;                     // u32 per slot: centre sample index | transposition << 16 | block << 18
+  static constexpr int stepClsBytes = (MAXSTEPS + 15) & ~15;
+  static constexpr int stageBytes = (ACT / 64) * 128;                    // per wave: the org rows of the current step (4 blocks x 4 rows x 8 bytes)
+  static constexpr int lumaBytes = tileBytes + zeroBytes + bucketBytes + listBytes + stepClsBytes + stageBytes + 64 * 4;
   static constexpr int CP = C / 2 + 8, CROWS = C / 2 + 6;                // chroma tiles (two planes)
   static constexpr int ctileBytes = (CROWS * CP * 2 + 15) & ~15;
-  static constexpr int chromaBytes = 2 * ctileBytes + 2 * AC_CREP * AC_NB5 * 8;
+  static constexpr int chromaBytes = 2 * ctileBytes + 2 * 57 * 8;
   static constexpr int bytes = lumaBytes > chromaBytes ? lumaBytes : chromaBytes;
 };
 
@@ -448,159 +492,343 @@ struct AlfStatsPic
   unsigned long long* out7; unsigned long long* out5; unsigned long long* outC[2];
 };
 
+typedef int alf_i4 __attribute__((ext_vector_type(4)));
+
+// Luma CTU on the matrix cores.  The statistics of a class are the Gram matrix of x = (s_0 .. s_11, centre, org - rec) over the pixels of the
+// class's blocks (s_k = the two samples of tap pair k, in FILTER coefficient order, i.e. behind the block's transposition): E = X X^T restricted
+// to 13 x 13, y = its column 13, pixAcc = entry (13, 13).  Values need 11 bits (+ sign for org - rec), so x = 256 H + L with L = the low byte read
+// as SIGNED (the matrix cores multiply signed bytes) and H = (x + 128) >> 8 in [-4, 8] = the high byte of x + 128: both limbs are byte picks
+// (v_perm_b32), no masks or shifts; four v_mfma_i32_16x16x64_i8 per step of 64 pixels accumulate L L^T, H L^T, L H^T and H H^T exactly in int32
+// (a whole CTU of one class stays below 2^29), and E = 65536 HH + 256 (HL + LH) + LL is formed in 64 bits when a class is finished.
+//   * the CTU's 4x4 blocks are counting-sorted by class in LDS; a class is padded to whole steps of four blocks;
+//   * lane (c, g) of a step builds variable c for the 16 pixels of block g: two unaligned 4-sample reads per row from the LDS tile (offset of
+//     the tap that the block's transposition puts at coefficient c), one v_pk_add_u16, limb split, byte pack -- the SAME registers are the A
+//     and the B operand, so the k order inside the instruction does not matter;
+//   * the eight waves take contiguous ranges of steps; a wave adds its accumulators to the class's 64-bit LDS record when the class changes
+//     (distinct addresses inside a wave, so the LDS atomics do not serialise).
+// The old form (per-lane upper-triangle accumulation with v_dot2, ~1100 vector instructions and 105 serialising LDS atomics per block) took
+// 83 us for a 3840x2160 picture; see DESIGN.md for the measured time of this one.
 template <int C>
 __device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, unsigned char* smem)
 {
   using L = AlfCtuLds<C>;
-  constexpr int P = L::P, N = 13, NT = 91, NB = AC_NB7, BPR = C / 4;     // blocks per CTU row
+  constexpr int P = L::P, BPR = C / 4, NBLK = BPR * BPR, S = (NBLK + ACT - 1) / ACT, NW = ACT / 64;
+  constexpr int oZero = L::tileBytes, oBucket = oZero + L::zeroBytes, oList = oBucket + L::bucketBytes, oStepCls = oList + L::listBytes,
+                oStage = oStepCls + L::stepClsBytes, oCnt = oStage + L::stageBytes;
+  constexpr unsigned CEN_ZERO = (unsigned)(oZero / 2), EMPTY = CEN_ZERO | 0x80000000u;     // empty slot: centre in the zero rows, flag in bit 31
   short* tile = reinterpret_cast<short*>(smem);
-  unsigned short* posTab = reinterpret_cast<unsigned short*>(smem + L::tileBytes);
-  unsigned long long* bucket = reinterpret_cast<unsigned long long*>(smem + L::tileBytes + L::tabBytes);
+  unsigned long long* bucket = reinterpret_cast<unsigned long long*>(smem + oBucket);
+  unsigned* list = reinterpret_cast<unsigned*>(smem + oList);
+  unsigned char* stepCls = smem + oStepCls;
+  int* cnt = reinterpret_cast<int*>(smem + oCnt);                          // [32] counts, [32] first step of the class
+  int* start = cnt + 32;
   const int tid = threadIdx.x;
   const int x0 = (ctuIdx % a.wCtu) * C, y0 = (ctuIdx / a.wCtu) * C;
-  load_tile_clamped<P>(tile, a.rec[0], a.rstride[0], a.w, a.h, x0 - 4, y0 - 3, L::ROWS, tid, ACT);
-  for (int i = tid; i < AC_REP * 25 * NB; i += ACT) bucket[i] = 0ull;
-  // slot table: entry idx of the canonical order (upper triangle row-major, then y) under transposition t lands at byte offset tab[t][idx]
-  for (int i = tid; i < 4 * (NB - 1); i += ACT)
   {
-    const int t = i / (NB - 1), idx = i - t * (NB - 1);
-    const unsigned long long perm = t == 0 ? 0xCBA9876543210ull : t == 1 ? 0xC62037B518A49ull : t == 2 ? 0xCBA9456781230ull : 0xC62015B734A89ull;
-    int pos;
-    if (idx < NT)
+    constexpr int NBT = (L::ROWS * (P / 4) + ACT - 1) / ACT;
+    pel4 tv[NBT];
+    tile_fetch<P, NBT>(tv, a.rec[0], a.rstride[0], a.w, a.h, x0 - 4, y0 - 3, L::ROWS, tid, ACT);
+    tile_store<P, NBT>(tile, tv, L::ROWS, tid, ACT);
+  }
+  for (int i = tid; i < L::zeroBytes / 4; i += ACT) reinterpret_cast<unsigned*>(smem + oZero)[i] = 0u;
+  for (int i = tid; i < 25 * AC_REC7; i += ACT) bucket[i] = 0ull;
+  for (int i = tid; i < L::MAXSTEPS * 4; i += ACT) list[i] = EMPTY;
+  if (tid < 64) cnt[tid] = 0;
+  __syncthreads();
+  int myKey[S], myPos[S];
+#pragma unroll
+  for (int s = 0; s < S; s++)
+  {
+    // column-major thread -> block map: the lanes of a wave are vertical neighbours, so the four blocks of a step mostly are too -- their
+    // tile rows sit 16 LDS banks apart (4 rows x 68 dwords), while horizontal neighbours (2 banks apart) collide four-way in every tile read
+    const int blk = tid + s * ACT, bi = blk % BPR, bj = blk / BPR;
+    const int bx = x0 + 4 * bj, by = y0 + 4 * bi;
+    myKey[s] = -1; myPos[s] = 0;
+    if (blk < NBLK && bx < a.w && by < a.h) myKey[s] = (int)a.cls[(size_t)(by >> 2) * (a.w >> 2) + (bx >> 2)];
+    // position inside the class: one LDS atomic per wave and distinct class (neighbouring blocks mostly share the class, and same-address
+    // atomics serialise), the lanes of a class take consecutive positions behind the returned base
+    const int myC = myKey[s] < 0 ? -1 : (myKey[s] & 0xff);
+    unsigned long long todo = __ballot(myC >= 0);
+    while (todo)
     {
-      int k = 0, rem = idx;
-      while (rem >= N - k) { rem -= N - k; k++; }
-      const int l = k + rem;
-      const int ck = (int)((perm >> (4 * k)) & 15), cl = (int)((perm >> (4 * l)) & 15);
-      const int lo = min(ck, cl), hi = max(ck, cl);
-      pos = lo * N - (lo * (lo - 1)) / 2 + (hi - lo);
+      const int leader = __builtin_ctzll(todo);
+      const int cc = __shfl(myC, leader);
+      const unsigned long long m = __ballot(myC == cc);
+      int base = 0;
+      if ((tid & 63) == leader) base = atomicAdd(&cnt[cc], (int)__popcll(m));
+      base = __shfl(base, leader);
+      if (myC == cc) myPos[s] = base + (int)__popcll(m & ((1ull << (tid & 63)) - 1ull));
+      todo &= ~m;
     }
-    else
-      pos = NT + (int)((perm >> (4 * (idx - NT))) & 15);
-    posTab[i] = (unsigned short)(pos * 8);
+  }
+  __syncthreads();
+  if (tid == 0)
+  {
+    int acc = 0;
+    for (int c = 0; c < 25; c++) { start[c] = acc; acc += (cnt[c] + 3) >> 2; }
+    start[25] = acc;
+  }
+  __syncthreads();
+  const int T = start[25];
+#pragma unroll
+  for (int s = 0; s < S; s++)
+    if (myKey[s] >= 0)
+    {
+      const int blk = tid + s * ACT, bi = blk % BPR, bj = blk / BPR;
+      list[start[myKey[s] & 0xff] * 4 + myPos[s]] = (unsigned)((4 * bi + 3) * P + 4 * bj + 4) | (unsigned)((myKey[s] >> 8) & 3) << 16 | (unsigned)(bi * BPR + bj) << 18;
+    }
+  for (int st = tid; st < T; st += ACT)
+  {
+    int c = 0;
+    while (st >= start[c + 1]) c++;
+    stepCls[st] = (unsigned char)c;
   }
   __syncthreads();
 
-  constexpr int S = C >= 128 ? (BPR * BPR) / ACT : 1;                     // blocks per thread, vertically adjacent
-  const int bj = tid % BPR, bi0 = (tid / BPR) * S;
-  if (bi0 < BPR)
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4;
+  // sample offset of the tap that transposition t puts at coefficient c (geometric tap k sits at coefficient perm_t[k])
+  constexpr int geoDy[13] = { 3, 2, 2, 2, 1, 1, 1, 1, 1, 0, 0, 0, 0 }, geoDx[13] = { 0, 1, 0, -1, 2, 1, 0, -1, -2, 3, 2, 1, 0 };
+  int offT[4] = { 0, 0, 0, 0 };
+#pragma unroll
+  for (int t = 0; t < 4; t++)
   {
-    int A[NT], Y[N], pix = 0;
+    const unsigned long long perm = t == 0 ? 0xCBA9876543210ull : t == 1 ? 0xC62037B518A49ull : t == 2 ? 0xCBA9456781230ull : 0xC62015B734A89ull;
 #pragma unroll
-    for (int i = 0; i < NT; i++) A[i] = 0;
+    for (int k = 0; k < 12; k++)
+      if ((int)((perm >> (4 * k)) & 15) == c) offT[t] = geoDy[k] * P + geoDx[k];
+  }
+  // second operand of the pair sum: + for the taps, 0 for the centre, - for org - rec (first operand = org there)
+  const unsigned sgn = c < 12 ? 0x00010001u : (c == 12 ? 0u : 0xFFFFFFFFu);
+  const bool isD = c == 13, dead = c >= 14;
+  const int s0 = (wv * T) / NW, s1 = ((wv + 1) * T) / NW;
+  alf_i4 LLa = { 0, 0, 0, 0 }, HLa = { 0, 0, 0, 0 }, LHa = { 0, 0, 0, 0 }, HHa = { 0, 0, 0, 0 };
+  int cur = -1;
+  auto flush = [&](int cl)
+  {
 #pragma unroll
-    for (int i = 0; i < N; i++) Y[i] = 0;
-    int key = -1;                                                         // class | transposition << 8 of the sums held in registers
-#pragma unroll 1
-    for (int s = 0; s <= S; s++)
+    for (int r = 0; r < 4; r++)
     {
-      const int bx = x0 + 4 * bj, by = y0 + 4 * (bi0 + s);
-      const bool have = s < S && bx < a.w && by < a.h;
-      const int k2 = have ? (int)a.cls[(size_t)(by >> 2) * (a.w >> 2) + (bx >> 2)] : -1;
-      if (key >= 0 && k2 != key)
+      const int row = 4 * g + r;
+      const long long v = (long long)HHa[r] * 65536 + (long long)(HLa[r] + LHa[r]) * 256 + (long long)LLa[r];
+      int e = -1;
+      if (row < 13 && c < 13) e = row * 13 + c;
+      else if (row == 13 && c < 13) e = 169 + c;
+      else if (row == 13 && c == 13) e = 182;
+      if (e >= 0) atomicAdd(&bucket[cl * AC_REC7 + e], (unsigned long long)v);
+    }
+    LLa = HLa = LHa = HHa = alf_i4{ 0, 0, 0, 0 };
+  };
+  // org rows of a step (four blocks x four rows of 8 bytes) are loaded FOUR steps ahead by lanes 0..15 (lane 4 g + i: row i of block g), kept
+  // in registers, and written to the wave's 128-byte LDS stage when their step comes: the org - rec lanes read their first operand there
+  // (row pitch 8 bytes) exactly as the other lanes read theirs in the tile (row pitch 2 P bytes)
+  const unsigned stageOff = (unsigned)(oStage + wv * 128);
+  const Pel* orgRowBase = a.org[0] + (size_t)(y0 + (lane & 3)) * a.ostride[0] + x0;
+  const unsigned rowStep = isD ? 8u : (unsigned)(2 * P);
+  auto issue = [&](int stp, uint2& dst)
+  {
+    dst = make_uint2(0u, 0u);
+    if (lane < 16 && stp < s1)
+    {
+      const unsigned e2 = list[stp * 4 + (lane >> 2)];
+      if ((int)e2 >= 0)
       {
-        // flush the registers into the class bucket.  Same-address LDS atomics serialise, and neighbouring blocks mostly share the class
-        // (bench picture: 94 %) while the transposition varies: lanes with the SAME transposition hit the same slots, so the replica is
-        // the lane's rank among the flushing lanes of its transposition (even spread: at most ceil(n_t / 4) lanes per address)
-        const int tcur = key >> 8;
-        const unsigned long long below = (1ull << (tid & 63)) - 1ull;
-        int rank = 0;
-#pragma unroll
-        for (int tt = 0; tt < 4; tt++)
-        {
-          const unsigned long long m = __ballot(tcur == tt);
-          if (tcur == tt) rank = (int)__popcll(m & below);
-        }
-        const unsigned short* pt = posTab + tcur * (NB - 1);
-        unsigned char* b = reinterpret_cast<unsigned char*>(bucket + ((rank & (AC_REP - 1)) * 25 + (key & 0xff)) * NB);
-#pragma unroll
-        for (int i = 0; i < NT; i++) { atomicAdd(reinterpret_cast<unsigned long long*>(b + pt[i]), (unsigned long long)(long long)A[i]); A[i] = 0; }
-#pragma unroll
-        for (int i = 0; i < N; i++) { atomicAdd(reinterpret_cast<unsigned long long*>(b + pt[NT + i]), (unsigned long long)(long long)Y[i]); Y[i] = 0; }
-        atomicAdd(reinterpret_cast<unsigned long long*>(b + (NT + N) * 8), (unsigned long long)(long long)pix); pix = 0;
+        const unsigned blk2 = e2 >> 18;
+        dst = *reinterpret_cast<const uint2*>(orgRowBase + (size_t)(4 * (blk2 / BPR)) * a.ostride[0] + 4 * (blk2 % BPR));
       }
-      key = k2;
-      if (have)
-        alf_block_acc<true, P>(tile + (4 * (bi0 + s)) * P + 4 * bj, a.org[0] + (size_t)by * a.ostride[0] + bx, a.ostride[0], A, Y, pix);
+    }
+  };
+  auto step = [&](int st, const uint2& orgRow)
+  {
+    const int cl = __builtin_amdgcn_readfirstlane((int)stepCls[st]);
+    if (cl != cur) { if (cur >= 0) flush(cur); cur = cl; }
+    if (lane < 16) *reinterpret_cast<uint2*>(smem + stageOff + lane * 8) = orgRow;
+    const unsigned e = list[st * 4 + g];
+    const int t = (int)(e >> 16) & 3;
+    const int offLo = (t & 1) ? offT[1] : offT[0], offHi = (t & 1) ? offT[3] : offT[2];
+    const int off = (int)e < 0 ? 0 : ((t & 2) ? offHi : offLo);           // empty slot: both operands in the zero rows
+    const int cen = dead ? (int)CEN_ZERO : (int)(e & 0xFFFFu);
+    const int ap = cen + off, am = cen - off;                               // first samples of the two 4-sample rows (row i: + i P); cen is even
+    const unsigned sh = (unsigned)(off & 1) << 4;
+    const unsigned adP = isD ? (stageOff + (unsigned)g * 32u) : (unsigned)(ap >> 1) << 2;
+    const unsigned adM = (unsigned)(am >> 1) << 2;
+    alf_i4 aL, aH;
+#pragma unroll
+    for (int i = 0; i < 4; i++)
+    {
+      const unsigned* dp = reinterpret_cast<const unsigned*>(smem + adP + i * rowStep);
+      const unsigned* dm = reinterpret_cast<const unsigned*>(smem + adM + i * 2 * P);
+      const unsigned p0 = dp[0], p1 = dp[1], p2 = dp[2], m0 = dm[0], m1 = dm[1], m2 = dm[2];
+      const unsigned P01 = __builtin_amdgcn_alignbit(p1, p0, sh), P23 = __builtin_amdgcn_alignbit(p2, p1, sh);
+      const unsigned M01 = __builtin_amdgcn_alignbit(m1, m0, sh), M23 = __builtin_amdgcn_alignbit(m2, m1, sh);
+      const us2 v01 = __builtin_bit_cast(us2, P01) + __builtin_bit_cast(us2, M01) * __builtin_bit_cast(us2, sgn);
+      const us2 v23 = __builtin_bit_cast(us2, P23) + __builtin_bit_cast(us2, M23) * __builtin_bit_cast(us2, sgn);
+      const us2 bias = { 128, 128 };
+      const us2 h01 = v01 + bias, h23 = v23 + bias;
+      aL[i] = (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, v23), __builtin_bit_cast(unsigned, v01), 0x06040200u);   // low bytes, signed
+      aH[i] = (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, h23), __builtin_bit_cast(unsigned, h01), 0x07050301u);   // (v + 128) >> 8
+    }
+    LLa = __builtin_amdgcn_mfma_i32_16x16x64_i8(aL, aL, LLa, 0, 0, 0);
+    HHa = __builtin_amdgcn_mfma_i32_16x16x64_i8(aH, aH, HHa, 0, 0, 0);
+    HLa = __builtin_amdgcn_mfma_i32_16x16x64_i8(aH, aL, HLa, 0, 0, 0);
+    LHa = __builtin_amdgcn_mfma_i32_16x16x64_i8(aL, aH, LHa, 0, 0, 0);
+  };
+  uint2 ring[4];
+#pragma unroll
+  for (int u = 0; u < 4; u++) issue(s0 + u, ring[u]);
+  for (int st = s0; st < s1; st += 4)
+  {
+#pragma unroll
+    for (int u = 0; u < 4; u++)
+    {
+      if (st + u < s1)                                                      // wave-uniform
+      {
+        step(st + u, ring[u]);
+        issue(st + u + 4, ring[u]);
+      }
     }
   }
+  if (cur >= 0) flush(cur);
   __syncthreads();
   // records: 7x7 (13 x 13 + 13 + 1 = 183 entries per class) and its 5x5 sub-record (coefficient i of 5x5 = coefficient sig[i] of 7x7)
-  auto entry7 = [&](int c, int e) -> unsigned long long
-  {
-    int pos;
-    if (e < N * N) { const int r = e / N, q = e - r * N, lo = min(r, q), hi = max(r, q); pos = lo * N - (lo * (lo - 1)) / 2 + (hi - lo); }
-    else pos = NT + (e - N * N);
-    unsigned long long v = 0ull;
-#pragma unroll
-    for (int r = 0; r < AC_REP; r++) v += bucket[(r * 25 + c) * NB + pos];
-    return v;
-  };
-  unsigned long long* o7 = a.out7 + (size_t)ctuIdx * 25 * 183;
-  for (int i = tid; i < 25 * 183; i += ACT) { const int c = i / 183; o7[i] = entry7(c, i - c * 183); }
+  unsigned long long* o7 = a.out7 + (size_t)ctuIdx * 25 * AC_REC7;
+  for (int i = tid; i < 25 * AC_REC7; i += ACT) o7[i] = bucket[i];
   unsigned long long* o5 = a.out5 + (size_t)ctuIdx * 25 * 57;
   for (int i = tid; i < 25 * 57; i += ACT)
   {
-    const int c = i / 57, e = i - c * 57;
+    const int cc = i / 57, e = i - cc * 57;
     const int sig[7] = { 2, 5, 6, 7, 10, 11, 12 };
-    o5[i] = entry7(c, e < 49 ? sig[e / 7] * 13 + sig[e % 7] : e < 56 ? 169 + sig[e - 49] : 182);
+    o5[i] = bucket[cc * AC_REC7 + (e < 49 ? sig[e / 7] * 13 + sig[e % 7] : e < 56 ? 169 + sig[e - 49] : 182)];
   }
+}
+
+// Chroma CTU pair, same form: the 16 variables are (six tap pairs, centre, org - rec) of Cb and of Cr at the same pixel, so one Gram matrix holds
+// the Cb record in its upper-left and the Cr record in its lower-right 8 x 8 (the cross terms are dropped).  No classes, no transposition.
+// what the chroma part of a CTU needs from memory, requested BEFORE the luma part runs: the org rows of every step of this wave
+// (lanes 0..31: plane, block, row) and this thread's share of the two reconstruction tiles
+template <int C> struct AlfChromaPre
+{
+  using L = AlfCtuLds<C>;
+  static constexpr int NS = (C / 8) * (C / 8) / 4, NW = ACT / 64, NSW = (NS + NW - 1) / NW, NBT = (L::CROWS * (L::CP / 4) + ACT - 1) / ACT;
+  uint2 orgR[NSW];
+  pel4 tv[2][NBT];
+};
+
+template <int C>
+__device__ __forceinline__ void alf_chroma_prefetch(const AlfStatsPic& a, int ctuIdx, AlfChromaPre<C>& pre)
+{
+  using L = AlfCtuLds<C>;
+  using PR = AlfChromaPre<C>;
+  constexpr int C2 = C / 2, BPR = C2 / 4;
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int w2 = a.w >> 1, h2 = a.h >> 1;
+  const int x0 = (ctuIdx % a.wCtu) * C2, y0 = (ctuIdx / a.wCtu) * C2;
+  const int s0 = (wv * PR::NS) / PR::NW, s1 = ((wv + 1) * PR::NS) / PR::NW;
+  const int pl2 = (lane >> 4) & 1, g2 = (lane >> 2) & 3, i2 = lane & 3;
+#pragma unroll
+  for (int u = 0; u < PR::NSW; u++)
+  {
+    pre.orgR[u] = make_uint2(0u, 0u);
+    const int blk = (s0 + u) * 4 + g2, bi = blk / BPR, bj = blk % BPR;
+    if (lane < 32 && s0 + u < s1 && x0 + 4 * bj < w2 && y0 + 4 * bi < h2)
+      pre.orgR[u] = *reinterpret_cast<const uint2*>(a.org[1 + pl2] + (size_t)(y0 + 4 * bi + i2) * a.ostride[1 + pl2] + x0 + 4 * bj);
+  }
+#pragma unroll
+  for (int q = 0; q < 2; q++)
+    tile_fetch<L::CP, PR::NBT>(pre.tv[q], a.rec[1 + q], a.rstride[1 + q], w2, h2, x0 - 4, y0 - 3, L::CROWS, tid, ACT);
 }
 
 template <int C>
-__device__ __forceinline__ void alf_ctu_chroma(const AlfStatsPic& a, int ctuIdx, unsigned char* smem)
+__device__ __forceinline__ void alf_ctu_chroma(const AlfStatsPic& a, int ctuIdx, unsigned char* smem, const AlfChromaPre<C>& pre)
 {
   using L = AlfCtuLds<C>;
-  constexpr int P = L::CP, C2 = C / 2, N = 7, NT = 28, NB = AC_NB5, BPR = C2 / 4;
+  constexpr int P = L::CP, C2 = C / 2, BPR = C2 / 4, NBLK = BPR * BPR, NS = NBLK / 4, NW = ACT / 64, NSW = (NS + NW - 1) / NW;
+  constexpr int oBucket = 2 * L::ctileBytes, oStage = oBucket + 2 * 57 * 8 + 16;
+  static_assert(NS % NW == 0 || NS < NW, "chroma steps per wave");
   const int tid = threadIdx.x;
   const int w2 = a.w >> 1, h2 = a.h >> 1;
   const int x0 = (ctuIdx % a.wCtu) * C2, y0 = (ctuIdx / a.wCtu) * C2;
-  unsigned long long* bucket = reinterpret_cast<unsigned long long*>(smem + 2 * L::ctileBytes);       // [plane][replica][NB]
-  for (int c = 0; c < 2; c++)
-    load_tile_clamped<P>(reinterpret_cast<short*>(smem + c * L::ctileBytes), a.rec[1 + c], a.rstride[1 + c], w2, h2, x0 - 4, y0 - 3, L::CROWS, tid, ACT);
-  for (int i = tid; i < 2 * AC_CREP * NB; i += ACT) bucket[i] = 0ull;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6), lane = tid & 63, c = lane & 15, g = lane >> 4, pl = c >> 3, cc = c & 7;
+  const int s0 = (wv * NS) / NW, s1 = ((wv + 1) * NS) / NW;
+  unsigned long long* bucket = reinterpret_cast<unsigned long long*>(smem + oBucket);       // [plane][57]
+#pragma unroll
+  for (int q = 0; q < 2; q++) tile_store<P, AlfChromaPre<C>::NBT>(reinterpret_cast<short*>(smem + q * L::ctileBytes), pre.tv[q], L::CROWS, tid, ACT);
+  for (int i = tid; i < 2 * 57; i += ACT) bucket[i] = 0ull;
   __syncthreads();
-  constexpr int NBLK = BPR * BPR;                                        // blocks per plane: 256 (C = 128) or 64
-  for (int q = tid; q < 2 * NBLK; q += ACT)
+  constexpr int geoDy[7] = { 2, 1, 1, 1, 0, 0, 0 }, geoDx[7] = { 0, 1, 0, -1, 2, 1, 0 };
+  int off = 0;
+#pragma unroll
+  for (int k = 0; k < 6; k++) if (cc == k) off = geoDy[k] * P + geoDx[k];
+  const unsigned sgn = cc < 6 ? 0x00010001u : (cc == 6 ? 0u : 0xFFFFFFFFu);
+  const bool isD = cc == 7;
+  const unsigned tileOff = (unsigned)(pl * L::ctileBytes), stageOff = (unsigned)(oStage + wv * 256);
+  const unsigned rowStep = isD ? 8u : (unsigned)(2 * P);
+  const unsigned sh = (unsigned)(off & 1) << 4;
+  alf_i4 LLa = { 0, 0, 0, 0 }, HLa = { 0, 0, 0, 0 }, LHa = { 0, 0, 0, 0 }, HHa = { 0, 0, 0, 0 };
+#pragma unroll
+  for (int u = 0; u < NSW; u++)
   {
-    const int c = q / NBLK, blk = q - c * NBLK, bj = blk % BPR, bi = blk / BPR;
-    const int bx = x0 + 4 * bj, by = y0 + 4 * bi;
-    if (bx >= w2 || by >= h2) continue;
-    int A[NT], Y[N], pix = 0;
+    const int st = s0 + u;
+    if (st < s1)                                                            // wave-uniform
+    {
+      if (lane < 32) *reinterpret_cast<uint2*>(smem + stageOff + lane * 8) = pre.orgR[u];
+      const int blk = st * 4 + g, bi = blk / BPR, bj = blk % BPR;
+      const bool valid = x0 + 4 * bj < w2 && y0 + 4 * bi < h2;
+      const int cen = (4 * bi + 3) * P + 4 * bj + 4;
+      const int ap = cen + off, am = cen - off;
+      const unsigned adP = isD ? stageOff + (unsigned)(pl * 128 + g * 32) : tileOff + ((unsigned)(ap >> 1) << 2);
+      const unsigned adM = tileOff + ((unsigned)(am >> 1) << 2);
+      alf_i4 aL, aH;
 #pragma unroll
-    for (int i = 0; i < NT; i++) A[i] = 0;
+      for (int i = 0; i < 4; i++)
+      {
+        const unsigned* dp = reinterpret_cast<const unsigned*>(smem + adP + i * rowStep);
+        const unsigned* dm = reinterpret_cast<const unsigned*>(smem + adM + i * 2 * P);
+        const unsigned p0 = dp[0], p1 = dp[1], p2 = dp[2], m0 = dm[0], m1 = dm[1], m2 = dm[2];
+        const unsigned P01 = __builtin_amdgcn_alignbit(p1, p0, sh), P23 = __builtin_amdgcn_alignbit(p2, p1, sh);
+        const unsigned M01 = __builtin_amdgcn_alignbit(m1, m0, sh), M23 = __builtin_amdgcn_alignbit(m2, m1, sh);
+        const us2 v01 = __builtin_bit_cast(us2, P01) + __builtin_bit_cast(us2, M01) * __builtin_bit_cast(us2, sgn);
+        const us2 v23 = __builtin_bit_cast(us2, P23) + __builtin_bit_cast(us2, M23) * __builtin_bit_cast(us2, sgn);
+        const us2 bias = { 128, 128 };
+        const us2 h01 = v01 + bias, h23 = v23 + bias;
+        aL[i] = (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, v23), __builtin_bit_cast(unsigned, v01), 0x06040200u);
+        aH[i] = (int)__builtin_amdgcn_perm(__builtin_bit_cast(unsigned, h23), __builtin_bit_cast(unsigned, h01), 0x07050301u);
+      }
+      if (!valid) { aL = alf_i4{ 0, 0, 0, 0 }; aH = alf_i4{ 0, 0, 0, 0 }; }
+      LLa = __builtin_amdgcn_mfma_i32_16x16x64_i8(aL, aL, LLa, 0, 0, 0);
+      HHa = __builtin_amdgcn_mfma_i32_16x16x64_i8(aH, aH, HHa, 0, 0, 0);
+      HLa = __builtin_amdgcn_mfma_i32_16x16x64_i8(aH, aL, HLa, 0, 0, 0);
+      LHa = __builtin_amdgcn_mfma_i32_16x16x64_i8(aL, aH, LHa, 0, 0, 0);
+    }
+  }
 #pragma unroll
-    for (int i = 0; i < N; i++) Y[i] = 0;
-    alf_block_acc<false, P>(reinterpret_cast<const short*>(smem + c * L::ctileBytes) + (4 * bi) * P + 4 * bj,
-                            a.org[1 + c] + (size_t)by * a.ostride[1 + c] + bx, a.ostride[1 + c], A, Y, pix);
-    unsigned long long* b = bucket + (c * AC_CREP + (tid & (AC_CREP - 1))) * NB;
-#pragma unroll
-    for (int i = 0; i < NT; i++) atomicAdd(&b[i], (unsigned long long)(long long)A[i]);
-#pragma unroll
-    for (int i = 0; i < N; i++) atomicAdd(&b[NT + i], (unsigned long long)(long long)Y[i]);
-    atomicAdd(&b[NT + N], (unsigned long long)(long long)pix);
+  for (int r = 0; r < 4; r++)
+  {
+    const int row = 4 * g + r, r7 = row & 7;
+    const long long v = (long long)HHa[r] * 65536 + (long long)(HLa[r] + LHa[r]) * 256 + (long long)LLa[r];
+    int e = -1;
+    if ((row >> 3) == pl)
+    {
+      if (r7 < 7 && cc < 7) e = r7 * 7 + cc;
+      else if (r7 == 7 && cc < 7) e = 49 + cc;
+      else if (r7 == 7 && cc == 7) e = 56;
+    }
+    if (e >= 0 && s1 > s0) atomicAdd(&bucket[pl * 57 + e], (unsigned long long)v);
   }
   __syncthreads();
-  for (int i = tid; i < 2 * 57; i += ACT)
-  {
-    const int c = i / 57, e = i - c * 57;
-    int pos;
-    if (e < N * N) { const int r = e / N, q = e - r * N, lo = min(r, q), hi = max(r, q); pos = lo * N - (lo * (lo - 1)) / 2 + (hi - lo); }
-    else pos = NT + (e - N * N);
-    unsigned long long v = 0ull;
-    for (int r = 0; r < AC_CREP; r++) v += bucket[(c * AC_CREP + r) * NB + pos];
-    a.outC[c][(size_t)ctuIdx * 57 + e] = v;
-  }
+  for (int i = tid; i < 2 * 57; i += ACT) a.outC[i / 57][(size_t)ctuIdx * 57 + (i % 57)] = bucket[i];
 }
 
-// workgroups [0, nCtu): luma CTUs (the long ones first), [nCtu, 2 nCtu): the chroma CTU pairs
+// one workgroup per CTU: luma, then the CTU's chroma pair in the same LDS (the chroma tiles and records lie inside the luma tile's bytes, which
+// are free behind the barrier that ends the luma steps; the luma records are still being written out from their own region meanwhile).
+// As workgroups of their own the chroma pairs were a second round of 80 KB workgroups behind the luma round: 10 us of a 56 us launch.
 template <int C>
 __global__ __launch_bounds__(ACT) void alf_stats_picture_kernel(AlfStatsPic a)
 {
   extern __shared__ __align__(16) unsigned char alfSmem[];
-  const int b = blockIdx.x;
-  if (b < a.nCtu) alf_ctu_luma<C>(a, b, alfSmem);
-  else            alf_ctu_chroma<C>(a, b - a.nCtu, alfSmem);
+  AlfChromaPre<C> pre;
+  alf_chroma_prefetch<C>(a, blockIdx.x, pre);
+  alf_ctu_luma<C>(a, blockIdx.x, alfSmem);
+  alf_ctu_chroma<C>(a, blockIdx.x, alfSmem, pre);
 }
 
 // The 5x5 diamond is the centre of the 7x7 diamond under every transposition, so the 5x5 covariance record of a class is a sub-matrix of its 7x7
@@ -746,12 +974,12 @@ int vvcgpu_alf_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec,
     if (ctu_size == 128)
     {
       VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alf_stats_picture_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, AlfCtuLds<128>::bytes));
-      hipLaunchKernelGGL(alf_stats_picture_kernel<128>, dim3(2 * nCtu), dim3(ACT), AlfCtuLds<128>::bytes, st, a);
+      hipLaunchKernelGGL(alf_stats_picture_kernel<128>, dim3(nCtu), dim3(ACT), AlfCtuLds<128>::bytes, st, a);
     }
     else
     {
       VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alf_stats_picture_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, AlfCtuLds<64>::bytes));
-      hipLaunchKernelGGL(alf_stats_picture_kernel<64>, dim3(2 * nCtu), dim3(ACT), AlfCtuLds<64>::bytes, st, a);
+      hipLaunchKernelGGL(alf_stats_picture_kernel<64>, dim3(nCtu), dim3(ACT), AlfCtuLds<64>::bytes, st, a);
     }
     VVC_LAUNCH_CHECK();
     return VVCGPU_OK;
