@@ -363,10 +363,13 @@ __global__ __launch_bounds__(256) void pelop_batch_kernel(int op, const Pel* __r
   const bool vec = ((d.w & 7) == 0) && ((d.src0_stride & 7) == 0) && ((d.dst_stride & 7) == 0) &&
                    ((reinterpret_cast<uintptr_t>(s0) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) &&
                    (!s1 || (((d.src1_stride & 7) == 0) && ((reinterpret_cast<uintptr_t>(s1) & 15) == 0)));
+  // gridDim.y workgroups share a descriptor (host: few descriptors = plane-sized bands): each takes a contiguous share of the rows
+  const int rows = (d.h + (int)gridDim.y - 1) / (int)gridDim.y, y0 = (int)blockIdx.y * rows, y1 = min(d.h, y0 + rows);
+  if (y0 >= y1) return;
   if (vec)
   {
     const int wv = d.w >> 3;
-    for (int i = tid; i < wv * d.h; i += 256)
+    for (int i = tid + y0 * wv; i < wv * y1; i += 256)
     {
       const int y = i / wv, x = (i - y * wv) << 3;
       const pel8 a = *reinterpret_cast<const pel8*>(s0 + (size_t)y * d.src0_stride + x);
@@ -379,7 +382,7 @@ __global__ __launch_bounds__(256) void pelop_batch_kernel(int op, const Pel* __r
     }
     return;
   }
-  for (int i = tid; i < d.w * d.h; i += 256)
+  for (int i = tid + y0 * d.w; i < d.w * y1; i += 256)
   {
     const int y = i / d.w, x = i - y * d.w;
     const int a = s0[(size_t)y * d.src0_stride + x];
@@ -434,7 +437,7 @@ int vvcgpu_pelop_batch(int op, const vvc_pel* src0_base, const vvc_pel* src1_bas
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(src0_base && dst_base && descs && cfg_host, "pelop_batch: null pointer");
   VVC_CHECK_ARG(src1_base || op == 2 || op == 5, "pelop_batch: op %d needs src1", op);
-  hipLaunchKernelGGL(pelop_batch_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, op, src0_base, src1_base,
+  hipLaunchKernelGGL(pelop_batch_kernel, dim3(n, n < 2048 ? 4 : 1), dim3(256), 0, (hipStream_t)stream, op, src0_base, src1_base,
                      dst_base, descs, n, *cfg_host);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
