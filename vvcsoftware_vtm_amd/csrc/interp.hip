@@ -437,7 +437,7 @@ int vvcgpu_pelop_batch(int op, const vvc_pel* src0_base, const vvc_pel* src1_bas
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(src0_base && dst_base && descs && cfg_host, "pelop_batch: null pointer");
   VVC_CHECK_ARG(src1_base || op == 2 || op == 5, "pelop_batch: op %d needs src1", op);
-  hipLaunchKernelGGL(pelop_batch_kernel, dim3(n, n < 2048 ? 4 : 1), dim3(256), 0, (hipStream_t)stream, op, src0_base, src1_base,
+  hipLaunchKernelGGL(pelop_batch_kernel, dim3(n, n < 2048 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, op, src0_base, src1_base,
                      dst_base, descs, n, *cfg_host);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;

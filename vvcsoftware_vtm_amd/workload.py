@@ -425,8 +425,9 @@ class Workload:
                     st["rec"][0][self.tiled_h:, :].copy_(st["pred"][0][self.tiled_h:, :])
                 if self.tiled_w < self.w:
                     st["rec"][0][:self.tiled_h, self.tiled_w:].copy_(st["pred"][0][:self.tiled_h, self.tiled_w:])
-                st["rec"][1].copy_(st["pred"][1])
-                st["rec"][2].copy_(st["pred"][2])
+                # chroma carries no residual in this workload: reconstruction = clipped prediction (B4 copyClip, what xReconInter does for cbf == 0)
+                for c in (1, 2):
+                    ops.pelop_batch(5, st["pred"][c], st["pred"][c], st["rec"][c], st["bands_chroma"], self.bands_chroma.size, self.cfg_reco)
         else:
             sub = ops.PelopCfg(0, 0, 0, 0, 0, mx)
             rec_cfg = ops.PelopCfg(0, 0, 0, 1, 0, mx)
