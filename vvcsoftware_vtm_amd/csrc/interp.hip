@@ -201,26 +201,221 @@ __device__ __forceinline__ void mc_tile_fast(const vvcgpu_mc_desc& d, const Pel*
   }
 }
 
+typedef short mc_s2 __attribute__((ext_vector_type(2)));
+// ---------------------------------------------------------------------------------------------------
+// Fast path, packed form.  G lanes serve one PU (64: a 16x16 luma PU per wave; 32: two 8x8 chroma PUs per wave, one per half).
+//   * window staging: a lane loads EIGHT bytes at the 4-byte-aligned address of its dword and shifts by the window's sub-dword phase
+//     (`v_alignbit`), so LDS holds the window sample-aligned, 2 samples per dword, row pitch WD dwords -- 5 load instructions per reference
+//     for the 23 x 23 luma window instead of 9 two-byte ones, both references requested before either is used.  Rows / columns that the
+//     reference's branch does not read (fy == 0: rows outside the block, fx == 0: columns outside) are not loaded: their taps are 0.
+//     A staged row may start up to one sample left of and end up to two samples right of the columns the reference touches (in the same row).
+//   * both passes are the same code: a lane takes FOUR consecutive outputs along the filter direction from 11 (7) consecutive samples =
+//     three (two) aligned ds_read_b64, pairs D_m = (s[2m], s[2m+1]) are the dwords themselves, the odd pairs E_m one `v_alignbit` each, and
+//     every output is N/2 `v_dot2_i32_i16` -- the first pass writes the 14-bit intermediate TRANSPOSED (tmpT[x][row]) so that the second
+//     pass reads its column as a row.  The unit filter (frac 0) through the same code equals the reference's copy / single-pass branches
+//     bit for bit ((64 t) >> 6 == t, and (2^h S - 2^19) >> 6 == (S - 2^(19-h)) >> (6-h)) except ONE: a rounded (bi == 0) horizontal-only
+//     filter, whose first pass therefore takes the last-stage rounding and whose second pass copies.
+//   * the block leaves through LDS as rows: one 8-byte store per lane.
+template <int N, int S, int G>
+__device__ __forceinline__ void mc_tile_dot2(const vvcgpu_mc_desc& d, bool active, const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
+                                             Pel* __restrict__ dstBase, int bd, int cmin, int cmax, int gl, unsigned* win, short* tmpT, short* outL)
+{
+  constexpr int half = N / 2 - 1, NR = S + N - 1, WD = (NR + 2) / 2 + ((((NR + 2) / 2) & 1) ? 1 : 0);     // dwords per window row (even: 8-byte reads)
+  constexpr int TP = 2 * WD;                                             // tmpT pitch in samples
+  constexpr int NG = S / 4, NP = N / 2, ND = NP + 2;                     // output groups per line, coefficient pairs, dwords read per lane
+  constexpr int HITEMS = NR * NG, VITEMS = S * NG, LOADS = NR * WD;
+  if (!active) return;                                                    // (the wave barriers below only order this wave's own LDS accesses)
+  const int hr = max(2, IF_INTERNAL_PREC - bd);
+  const bool rndRes = d.bi == 0;
+  const int nRef = d.bi == 1 ? 2 : 1;
+  // stage both windows
+  uint2 ld[2][(LOADS + G - 1) / G];
+  unsigned phase[2] = { 0u, 0u };                                         // bit u: load u starts on an odd sample (odd strides: per row)
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+  {
+    const int rs = r ? d.ref1_stride : d.ref0_stride;
+    const Pel* ref = (r ? ref1Base + d.ref1_off : ref0Base + d.ref0_off) - (ptrdiff_t)half * rs - half;       // window origin
+    const int fx = r ? d.frac_x1 : d.frac_x0, fy = r ? d.frac_y1 : d.frac_y0;
+#pragma unroll
+    for (int u = 0; u < (LOADS + G - 1) / G; u++)
+    {
+      const int i = gl + G * u, rr = i / WD, dw = i - rr * WD;
+      ld[r][u] = make_uint2(0u, 0u);
+      // samples 2 dw, 2 dw + 1 of the window row; needed when the row and one of the two columns are
+      const bool rowOk = fy ? rr < NR : (rr >= half && rr < half + S);
+      const bool colOk = fx ? 2 * dw < NR : (2 * dw + 1 >= half && 2 * dw < half + S);
+      if (active && r < nRef && i < LOADS && rowOk && colOk)
+      {
+        const unsigned char* a = reinterpret_cast<const unsigned char*>(ref + (ptrdiff_t)rr * rs) + 4 * dw;
+        const unsigned* a4 = reinterpret_cast<const unsigned*>(reinterpret_cast<uintptr_t>(a) & ~(uintptr_t)3);
+        ld[r][u].x = a4[0];
+        if (reinterpret_cast<uintptr_t>(a) & 2) { ld[r][u].y = a4[1]; phase[r] |= 1u << u; }
+      }
+    }
+  }
+  int pred[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+#pragma unroll
+  for (int r = 0; r < 2; r++)
+  {
+    if (r >= nRef) break;                                                 // uniform per group; the other half of a chroma wave follows its own d
+    const int fx = r ? d.frac_x1 : d.frac_x0, fy = r ? d.frac_y1 : d.frac_y0;
+    const unsigned* cxp = reinterpret_cast<const unsigned*>(N == 8 ? c_lumaFilter[fx] : c_chromaFilter[fx]);
+    const unsigned* cyp = reinterpret_cast<const unsigned*>(N == 8 ? c_lumaFilter[fy] : c_chromaFilter[fy]);
+    unsigned cx[NP], cy[NP];
+#pragma unroll
+    for (int m = 0; m < NP; m++) { cx[m] = cxp[m]; cy[m] = cyp[m]; }
+    const bool hOnly = rndRes && fy == 0 && fx != 0;                      // the one branch the two-pass form does not reproduce: see above
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+#pragma unroll
+    for (int u = 0; u < (LOADS + G - 1) / G; u++)
+    {
+      const int i = gl + G * u;
+      if (i < LOADS) win[i] = (phase[r] >> u) & 1u ? __builtin_amdgcn_alignbit(ld[r][u].y, ld[r][u].x, 16) : ld[r][u].x;
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    // four outputs from ND consecutive dwords
+    auto four = [&](const unsigned (&D)[ND], const unsigned (&c)[NP], int (&o)[4])
+    {
+      unsigned E[ND - 1];
+#pragma unroll
+      for (int m = 0; m < ND - 1; m++) E[m] = __builtin_amdgcn_alignbit(D[m + 1], D[m], 16);
+      o[0] = o[1] = o[2] = o[3] = 0;
+#pragma unroll
+      for (int m = 0; m < NP; m++)
+      {
+        const mc_s2 cm = __builtin_bit_cast(mc_s2, c[m]);
+        o[0] = __builtin_amdgcn_sdot2(__builtin_bit_cast(mc_s2, D[m]), cm, o[0], false);
+        o[1] = __builtin_amdgcn_sdot2(__builtin_bit_cast(mc_s2, E[m]), cm, o[1], false);
+        o[2] = __builtin_amdgcn_sdot2(__builtin_bit_cast(mc_s2, D[m + 1]), cm, o[2], false);
+        o[3] = __builtin_amdgcn_sdot2(__builtin_bit_cast(mc_s2, E[m + 1]), cm, o[3], false);
+      }
+    };
+    {
+      const int shift1 = hOnly ? IF_FILTER_PREC : IF_FILTER_PREC - hr;
+      const int off1 = hOnly ? (1 << (IF_FILTER_PREC - 1)) : -(IF_INTERNAL_OFFS << shift1);
+#pragma unroll
+      for (int u = 0; u < (HITEMS + G - 1) / G; u++)
+      {
+        const int it = gl + G * u, rr = it / NG, g = it - rr * NG;
+        if (it < HITEMS)
+        {
+          unsigned D[ND];
+          const uint2* wp = reinterpret_cast<const uint2*>(win + rr * WD + 2 * g);
+#pragma unroll
+          for (int m = 0; m < ND / 2; m++) { const uint2 q = wp[m]; D[2 * m] = q.x; D[2 * m + 1] = q.y; }
+          int o[4];
+          four(D, cx, o);
+#pragma unroll
+          for (int j = 0; j < 4; j++)
+          {
+            int t = (short)((o[j] + off1) >> shift1);
+            if (hOnly) t = clip3(cmin, cmax, t);
+            tmpT[(4 * g + j) * TP + rr] = (short)t;
+          }
+        }
+      }
+    }
+    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+    if (gl < VITEMS)
+    {
+      const int x = gl % S, yg = gl / S;
+      if (hOnly)
+      {
+#pragma unroll
+        for (int j = 0; j < 4; j++) pred[r][j] = tmpT[x * TP + half + 4 * yg + j];
+      }
+      else
+      {
+        unsigned D[ND];
+        const uint2* tp = reinterpret_cast<const uint2*>(tmpT + x * TP + 4 * yg);
+#pragma unroll
+        for (int m = 0; m < ND / 2; m++) { const uint2 q = tp[m]; D[2 * m] = q.x; D[2 * m + 1] = q.y; }
+        int o[4];
+        four(D, cy, o);
+        const int shift2 = rndRes ? IF_FILTER_PREC + hr : IF_FILTER_PREC;
+        const int off2 = rndRes ? (1 << (shift2 - 1)) + (IF_INTERNAL_OFFS << IF_FILTER_PREC) : 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+          int v = (short)((o[j] + off2) >> shift2);
+          if (rndRes) v = clip3(cmin, cmax, v);
+          pred[r][j] = v;
+        }
+      }
+    }
+  }
+  // average, rows through LDS, 8-byte stores
+  const int shiftNum = max(2, IF_INTERNAL_PREC - bd) + 1, offset = (1 << (shiftNum - 1)) + 2 * IF_INTERNAL_OFFS;
+  if (gl < VITEMS)
+  {
+    const int x = gl % S, yg = gl / S;
+#pragma unroll
+    for (int j = 0; j < 4; j++)
+    {
+      int v = pred[0][j];
+      if (d.bi == 1) v = clip3(cmin, cmax, (pred[0][j] + pred[1][j] + offset) >> shiftNum);
+      outL[(4 * yg + j) * S + x] = (short)v;
+    }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  if (active && gl < VITEMS)
+  {
+    const int row = gl / NG, seg = gl - row * NG;
+    Pel* o = dstBase + d.dst_off + (ptrdiff_t)row * d.dst_stride + 4 * seg;
+    const uint2 v = *reinterpret_cast<const uint2*>(outL + row * S + 4 * seg);
+    if ((reinterpret_cast<uintptr_t>(o) & 7) == 0) *reinterpret_cast<uint2*>(o) = v;
+    else { o[0] = (short)(v.x & 0xFFFF); o[1] = (short)(v.x >> 16); o[2] = (short)(v.y & 0xFFFF); o[3] = (short)(v.y >> 16); }
+  }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+}
+
+// a wave takes the descriptor pair (2 w, 2 w + 1): two fast chroma PUs share the wave (one per half), fast luma PUs follow one another,
+// everything else is left to the generic kernel
+constexpr int MC_LDS_DW = 23 * 12 + 16 * 12 + 128;                       // per wave: window, transposed intermediate, output rows (luma sizes)
 __global__ __launch_bounds__(256) void mc_fast_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
                                                       Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs, int n,
                                                       int bd, int cmin, int cmax, int* __restrict__ list, int* __restrict__ count,
-                                                      int* __restrict__ nextCount)
+                                                      int* __restrict__ nextCount, int oldForm)
 {
-  __shared__ short winS[4][23 * 24];
-  __shared__ short tmpS[4][23 * 16];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int di = blockIdx.x * 4 + wave;
+  __shared__ __align__(16) unsigned ldsAll[4][MC_LDS_DW];
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (blockIdx.x == 0 && threadIdx.x < 16) nextCount[threadIdx.x] = 0;   // the WHOLE counter set of the next call on this stream (vvcgpu_counters protocol)
-  if (di >= n) return;
-  const vvcgpu_mc_desc d = descs[di];
-  if (!mc_is_fast(d.is_luma, d.w, d.h))
+  const int i0 = (blockIdx.x * 4 + wave) * 2;
+  if (i0 >= n) return;
+  unsigned* L = ldsAll[wave];
+  const bool two = i0 + 1 < n;
+  const vvcgpu_mc_desc d0 = descs[i0], d1 = descs[two ? i0 + 1 : i0];
+  const bool f0 = mc_is_fast(d0.is_luma, d0.w, d0.h), f1 = two && mc_is_fast(d1.is_luma, d1.w, d1.h);
+  if (!oldForm && f0 && f1 && !d0.is_luma && !d1.is_luma)
   {
-    // left to the generic kernel behind this one: list[0] = count, list[1..] = descriptor indices (no atomic at all when every PU is fast)
-    if (lane == 0) list[atomicAdd(count, 1)] = di;
+    const bool hi = lane >= 32;
+    vvcgpu_mc_desc d = d0;
+    if (hi) d = d1;
+    unsigned* Lh = L + (hi ? MC_LDS_DW / 2 : 0);
+    mc_tile_dot2<4, 8, 32>(d, true, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane & 31, Lh, reinterpret_cast<short*>(Lh + 11 * 6), reinterpret_cast<short*>(Lh + 11 * 6 + 8 * 6));
     return;
   }
-  if (d.is_luma) mc_tile_fast<8, 16>(d, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, winS[wave], tmpS[wave]);
-  else mc_tile_fast<4, 8>(d, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, winS[wave], tmpS[wave]);
+#pragma unroll 1
+  for (int k = 0; k < 2; k++)
+  {
+    if (k && !two) break;
+    const vvcgpu_mc_desc& d = k ? d1 : d0;
+    if (!(k ? f1 : f0))
+    {
+      // left to the generic kernel behind this one: list[0] = count, list[1..] = descriptor indices (no atomic at all when every PU is fast)
+      if (lane == 0) list[atomicAdd(count, 1)] = i0 + k;
+      continue;
+    }
+    if (oldForm)
+    {
+      short* winS = reinterpret_cast<short*>(L);
+      if (d.is_luma) mc_tile_fast<8, 16>(d, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, winS, winS + 23 * 24);
+      else mc_tile_fast<4, 8>(d, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, winS, winS + 23 * 24);
+    }
+    else if (d.is_luma) mc_tile_dot2<8, 16, 64>(d, true, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, L, reinterpret_cast<short*>(L + 23 * 12), reinterpret_cast<short*>(L + 23 * 12 + 16 * 12));
+    else mc_tile_dot2<4, 8, 32>(d, lane < 32, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane & 31, L, reinterpret_cast<short*>(L + 11 * 6), reinterpret_cast<short*>(L + 11 * 6 + 8 * 6));
+  }
 }
 
 // generic kernel: any size, one wave per PU, persistent over the list of PUs the fast kernel left
@@ -421,8 +616,9 @@ int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel*
   int cur = 0;
   int* counters = vvcgpu_counters(st, &cur);                                // zeroed counter for this call; the kernel clears the other one
   if (!counters) return VVCGPU_E_DEVICE;
-  hipLaunchKernelGGL(mc_fast_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     dst_base, descs, n, bit_depth, clp_min, clp_max, list, counters + 16 * cur, counters + 16 * (cur ^ 1));
+  static const int mcOld = getenv("VVCGPU_MC_OLD") ? 1 : 0;               // A/B timing switch: the sample-wise fast path
+  hipLaunchKernelGGL(mc_fast_kernel, dim3(cdiv(n, 8)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
+                     dst_base, descs, n, bit_depth, clp_min, clp_max, list, counters + 16 * cur, counters + 16 * (cur ^ 1), mcOld);
   hipLaunchKernelGGL(mc_batch_kernel, dim3(n < 2048 ? n : 2048), dim3(64), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
                      dst_base, descs, list, counters + 16 * cur, bit_depth, clp_min, clp_max);
   VVC_LAUNCH_CHECK();
