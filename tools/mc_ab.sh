@@ -1,7 +1,6 @@
-# usage (GPU box): bash tools/mc_ab.sh -- kernel times of the MC launches of the canonical workload: packed fast path against the sample-wise one (VVCGPU_MC_OLD=1)
+# usage (GPU box): bash tools/mc_ab.sh -- kernel times of the MC launches of the canonical workload in isolation (luma, Cb, Cr; fast + generic kernel)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for v in new old; do
-  unset VVCGPU_MC_OLD; if [ $v = old ]; then export VVCGPU_MC_OLD=1; fi
+for v in now; do
   rm -rf gpurun_out/prof_mc
   rocprofv3 --kernel-trace --output-format csv -d gpurun_out/prof_mc -o t -- python3 tools/run_stage.py --only mc/ --reps 6 > gpurun_out/mc_run.log 2>&1
   echo "variant $v"

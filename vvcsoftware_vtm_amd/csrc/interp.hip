@@ -98,109 +98,6 @@ constexpr int WR = ST + 7;             // window rows
 
 __device__ __forceinline__ bool mc_is_fast(int is_luma, int w, int h) { return is_luma ? (w == 16 && h == 16) : (w == 8 && h == 8); }
 
-// Fast path: the whole PU is one S x S tile (16x16 luma / 8x8 chroma, what the canonical workload predicts): every loop
-// bound and divisor is a compile-time constant, the filter taps sit in registers, one wave per PU with wave-local LDS (no
-// workgroup barriers), four PUs per 256-thread workgroup.  Same arithmetic as the generic kernel below.
-template <int N, int S>
-__device__ __forceinline__ void mc_tile_fast(const vvcgpu_mc_desc& d, const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
-                                             Pel* __restrict__ dstBase, int bd, int cmin, int cmax, int lane, short* win, short* tmp)
-{
-  constexpr int half = N / 2 - 1, NR = S + N - 1, PW = S + 8;            // window rows / pitch
-  constexpr int OUT = S * S / 64;                                        // outputs per lane (4 for 16x16, 1 for 8x8)
-  const bool rndRes = d.bi == 0;
-  const int nRef = d.bi == 1 ? 2 : 1;
-  int pred[2][OUT];
-#pragma unroll
-  for (int r = 0; r < 2; r++)
-  {
-    if (r >= nRef) break;
-    const int rs = r ? d.ref1_stride : d.ref0_stride;
-    const Pel* ref = r ? ref1Base + d.ref1_off : ref0Base + d.ref0_off;
-    const int fx = r ? d.frac_x1 : d.frac_x0, fy = r ? d.frac_y1 : d.frac_y0;
-    const short* cxp = N == 8 ? c_lumaFilter[fx] : c_chromaFilter[fx];
-    const short* cyp = N == 8 ? c_lumaFilter[fy] : c_chromaFilter[fy];
-    int cx[N], cy[N];
-#pragma unroll
-    for (int k = 0; k < N; k++) { cx[k] = cxp[k]; cy[k] = cyp[k]; }
-    // stage only what the branch needs (the reference reads nothing else): rows -half.. when fy, cols -half.. when fx
-    const int r0 = fy ? -half : 0, nr = fy ? NR : S;
-    const int c0 = fx ? -half : 0, nc = fx ? NR : S;
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-#pragma unroll
-    for (int u = 0; u < (NR * NR + 63) / 64; u++)
-    {
-      const int i = lane + 64 * u;
-      const int rr = fx ? (i * (65536 / NR + 1)) >> 16 : i / S, cc = i - rr * (fx ? NR : S);
-      if (rr < nr) win[rr * PW + cc] = ref[(ptrdiff_t)(r0 + rr) * rs + c0 + cc];
-    }
-    __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-    if (fx && fy)
-    {
-      const IfMode mh = if_mode(true, false, bd);
-#pragma unroll
-      for (int u = 0; u < (NR * S + 63) / 64; u++)
-      {
-        const int i = lane + 64 * u, rr = i / S, x = i % S;
-        if (rr < NR)
-        {
-          int sum = 0;
-#pragma unroll
-          for (int k = 0; k < N; k++) sum += win[rr * PW + x + k] * cx[k];
-          tmp[rr * S + x] = (short)((sum + mh.offset) >> mh.shift);
-        }
-      }
-      __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-      const IfMode mv = if_mode(false, rndRes, bd);
-#pragma unroll
-      for (int j = 0; j < OUT; j++)
-      {
-        const int p = lane + 64 * j, y = p / S, x = p % S;
-        int sum = 0;
-#pragma unroll
-        for (int k = 0; k < N; k++) sum += tmp[(y + k) * S + x] * cy[k];
-        int v = (short)((sum + mv.offset) >> mv.shift);
-        if (rndRes) v = clip3(cmin, cmax, v);
-        pred[r][j] = v;
-      }
-    }
-    else
-    {
-      const IfMode m1 = if_mode(true, rndRes, bd);
-#pragma unroll
-      for (int j = 0; j < OUT; j++)
-      {
-        const int p = lane + 64 * j, y = p / S, x = p % S;
-        int v;
-        if (!fx && !fy) v = if_copy(win[y * PW + x], true, rndRes, bd, cmin, cmax);
-        else
-        {
-          int sum = 0;
-          if (fx) {
-#pragma unroll
-            for (int k = 0; k < N; k++) sum += win[y * PW + x + k] * cx[k];
-          } else {
-#pragma unroll
-            for (int k = 0; k < N; k++) sum += win[(y + k) * PW + x] * cy[k];
-          }
-          v = (short)((sum + m1.offset) >> m1.shift);
-          if (rndRes) v = clip3(cmin, cmax, v);
-        }
-        pred[r][j] = v;
-      }
-    }
-  }
-  Pel* dst = dstBase + d.dst_off;
-  const int shiftNum = max(2, IF_INTERNAL_PREC - bd) + 1, offset = (1 << (shiftNum - 1)) + 2 * IF_INTERNAL_OFFS;
-#pragma unroll
-  for (int j = 0; j < OUT; j++)
-  {
-    const int p = lane + 64 * j, y = p / S, x = p % S;
-    int v = pred[0][j];
-    if (d.bi == 1) v = clip3(cmin, cmax, (pred[0][j] + pred[1][j] + offset) >> shiftNum);
-    dst[(size_t)y * d.dst_stride + x] = (short)v;
-  }
-}
-
 typedef short mc_s2 __attribute__((ext_vector_type(2)));
 // ---------------------------------------------------------------------------------------------------
 // Fast path, packed form.  G lanes serve one PU (64: a 16x16 luma PU per wave; 32: two 8x8 chroma PUs per wave, one per half).
@@ -216,21 +113,23 @@ typedef short mc_s2 __attribute__((ext_vector_type(2)));
 //     bit for bit ((64 t) >> 6 == t, and (2^h S - 2^19) >> 6 == (S - 2^(19-h)) >> (6-h)) except ONE: a rounded (bi == 0) horizontal-only
 //     filter, whose first pass therefore takes the last-stage rounding and whose second pass copies.
 //   * the block leaves through LDS as rows: one 8-byte store per lane.
-template <int N, int S, int G>
-__device__ __forceinline__ void mc_tile_dot2(const vvcgpu_mc_desc& d, bool active, const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
-                                             Pel* __restrict__ dstBase, int bd, int cmin, int cmax, int gl, unsigned* win, short* tmpT, short* outL)
+template <int N, int S, int G> struct McStaged
 {
-  constexpr int half = N / 2 - 1, NR = S + N - 1, WD = (NR + 2) / 2 + ((((NR + 2) / 2) & 1) ? 1 : 0);     // dwords per window row (even: 8-byte reads)
-  constexpr int TP = 2 * WD;                                             // tmpT pitch in samples
-  constexpr int NG = S / 4, NP = N / 2, ND = NP + 2;                     // output groups per line, coefficient pairs, dwords read per lane
-  constexpr int HITEMS = NR * NG, VITEMS = S * NG, LOADS = NR * WD;
-  if (!active) return;                                                    // (the wave barriers below only order this wave's own LDS accesses)
-  const int hr = max(2, IF_INTERNAL_PREC - bd);
-  const bool rndRes = d.bi == 0;
+  static constexpr int NR = S + N - 1, WD = (NR + 2) / 2 + ((((NR + 2) / 2) & 1) ? 1 : 0), NL = (NR * WD + G - 1) / G;
+  uint2 ld[2][NL];
+  unsigned phase[2];                                                      // bit u: load u starts on an odd sample (odd strides: per row)
+};
+
+// requests both windows of a PU (see mc_tile_dot2)
+template <int N, int S, int G>
+__device__ __forceinline__ void mc_stage(const vvcgpu_mc_desc& d, bool active, const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base, int gl,
+                                         McStaged<N, S, G>& st)
+{
+  constexpr int half = N / 2 - 1, NR = S + N - 1, WD = McStaged<N, S, G>::WD, LOADS = NR * WD;
   const int nRef = d.bi == 1 ? 2 : 1;
-  // stage both windows
-  uint2 ld[2][(LOADS + G - 1) / G];
-  unsigned phase[2] = { 0u, 0u };                                         // bit u: load u starts on an odd sample (odd strides: per row)
+  auto& ld = st.ld;
+  auto& phase = st.phase;
+  phase[0] = phase[1] = 0u;
 #pragma unroll
   for (int r = 0; r < 2; r++)
   {
@@ -254,6 +153,22 @@ __device__ __forceinline__ void mc_tile_dot2(const vvcgpu_mc_desc& d, bool activ
       }
     }
   }
+}
+
+template <int N, int S, int G>
+__device__ __forceinline__ void mc_tile_dot2(const vvcgpu_mc_desc& d, bool active, const McStaged<N, S, G>& st, Pel* __restrict__ dstBase, int bd, int cmin, int cmax,
+                                             int gl, unsigned* win, short* tmpT, short* outL)
+{
+  constexpr int half = N / 2 - 1, NR = S + N - 1, WD = McStaged<N, S, G>::WD;                              // dwords per window row (even: 8-byte reads)
+  constexpr int TP = 2 * WD;                                             // tmpT pitch in samples
+  constexpr int NG = S / 4, NP = N / 2, ND = NP + 2;                     // output groups per line, coefficient pairs, dwords read per lane
+  constexpr int HITEMS = NR * NG, VITEMS = S * NG, LOADS = NR * WD;
+  if (!active) return;                                                    // (the wave barriers below only order this wave's own LDS accesses)
+  const int hr = max(2, IF_INTERNAL_PREC - bd);
+  const bool rndRes = d.bi == 0;
+  const int nRef = d.bi == 1 ? 2 : 1;
+  const auto& ld = st.ld;
+  const auto& phase = st.phase;
   int pred[2][4] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
 #pragma unroll
   for (int r = 0; r < 2; r++)
@@ -373,10 +288,10 @@ __device__ __forceinline__ void mc_tile_dot2(const vvcgpu_mc_desc& d, bool activ
 // a wave takes the descriptor pair (2 w, 2 w + 1): two fast chroma PUs share the wave (one per half), fast luma PUs follow one another,
 // everything else is left to the generic kernel
 constexpr int MC_LDS_DW = 23 * 12 + 16 * 12 + 128;                       // per wave: window, transposed intermediate, output rows (luma sizes)
-__global__ __launch_bounds__(256) void mc_fast_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
+__global__ __launch_bounds__(256, 6) void mc_fast_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
                                                       Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs, int n,
                                                       int bd, int cmin, int cmax, int* __restrict__ list, int* __restrict__ count,
-                                                      int* __restrict__ nextCount, int oldForm)
+                                                      int* __restrict__ nextCount)
 {
   __shared__ __align__(16) unsigned ldsAll[4][MC_LDS_DW];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
@@ -387,13 +302,25 @@ __global__ __launch_bounds__(256) void mc_fast_kernel(const Pel* __restrict__ re
   const bool two = i0 + 1 < n;
   const vvcgpu_mc_desc d0 = descs[i0], d1 = descs[two ? i0 + 1 : i0];
   const bool f0 = mc_is_fast(d0.is_luma, d0.w, d0.h), f1 = two && mc_is_fast(d1.is_luma, d1.w, d1.h);
-  if (!oldForm && f0 && f1 && !d0.is_luma && !d1.is_luma)
+  if (f0 && f1 && !d0.is_luma && !d1.is_luma)
   {
     const bool hi = lane >= 32;
     vvcgpu_mc_desc d = d0;
     if (hi) d = d1;
     unsigned* Lh = L + (hi ? MC_LDS_DW / 2 : 0);
-    mc_tile_dot2<4, 8, 32>(d, true, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane & 31, Lh, reinterpret_cast<short*>(Lh + 11 * 6), reinterpret_cast<short*>(Lh + 11 * 6 + 8 * 6));
+    McStaged<4, 8, 32> st;
+    mc_stage<4, 8, 32>(d, true, ref0Base, ref1Base, lane & 31, st);
+    mc_tile_dot2<4, 8, 32>(d, true, st, dstBase, bd, cmin, cmax, lane & 31, Lh, reinterpret_cast<short*>(Lh + 11 * 6), reinterpret_cast<short*>(Lh + 11 * 6 + 8 * 6));
+    return;
+  }
+  if (f0 && f1 && d0.is_luma && d1.is_luma)
+  {
+    // both PUs' windows are requested before the first PU is computed: the second PU does not wait for memory again
+    McStaged<8, 16, 64> sa, sb;
+    mc_stage<8, 16, 64>(d0, true, ref0Base, ref1Base, lane, sa);
+    mc_stage<8, 16, 64>(d1, true, ref0Base, ref1Base, lane, sb);
+    mc_tile_dot2<8, 16, 64>(d0, true, sa, dstBase, bd, cmin, cmax, lane, L, reinterpret_cast<short*>(L + 23 * 12), reinterpret_cast<short*>(L + 23 * 12 + 16 * 12));
+    mc_tile_dot2<8, 16, 64>(d1, true, sb, dstBase, bd, cmin, cmax, lane, L, reinterpret_cast<short*>(L + 23 * 12), reinterpret_cast<short*>(L + 23 * 12 + 16 * 12));
     return;
   }
 #pragma unroll 1
@@ -407,14 +334,18 @@ __global__ __launch_bounds__(256) void mc_fast_kernel(const Pel* __restrict__ re
       if (lane == 0) list[atomicAdd(count, 1)] = i0 + k;
       continue;
     }
-    if (oldForm)
+    if (d.is_luma)
     {
-      short* winS = reinterpret_cast<short*>(L);
-      if (d.is_luma) mc_tile_fast<8, 16>(d, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, winS, winS + 23 * 24);
-      else mc_tile_fast<4, 8>(d, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, winS, winS + 23 * 24);
+      McStaged<8, 16, 64> st;
+      mc_stage<8, 16, 64>(d, true, ref0Base, ref1Base, lane, st);
+      mc_tile_dot2<8, 16, 64>(d, true, st, dstBase, bd, cmin, cmax, lane, L, reinterpret_cast<short*>(L + 23 * 12), reinterpret_cast<short*>(L + 23 * 12 + 16 * 12));
     }
-    else if (d.is_luma) mc_tile_dot2<8, 16, 64>(d, true, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, L, reinterpret_cast<short*>(L + 23 * 12), reinterpret_cast<short*>(L + 23 * 12 + 16 * 12));
-    else mc_tile_dot2<4, 8, 32>(d, lane < 32, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane & 31, L, reinterpret_cast<short*>(L + 11 * 6), reinterpret_cast<short*>(L + 11 * 6 + 8 * 6));
+    else
+    {
+      McStaged<4, 8, 32> st;
+      mc_stage<4, 8, 32>(d, lane < 32, ref0Base, ref1Base, lane & 31, st);
+      mc_tile_dot2<4, 8, 32>(d, lane < 32, st, dstBase, bd, cmin, cmax, lane & 31, L, reinterpret_cast<short*>(L + 11 * 6), reinterpret_cast<short*>(L + 11 * 6 + 8 * 6));
+    }
   }
 }
 
@@ -616,9 +547,8 @@ int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel*
   int cur = 0;
   int* counters = vvcgpu_counters(st, &cur);                                // zeroed counter for this call; the kernel clears the other one
   if (!counters) return VVCGPU_E_DEVICE;
-  static const int mcOld = getenv("VVCGPU_MC_OLD") ? 1 : 0;               // A/B timing switch: the sample-wise fast path
   hipLaunchKernelGGL(mc_fast_kernel, dim3(cdiv(n, 8)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     dst_base, descs, n, bit_depth, clp_min, clp_max, list, counters + 16 * cur, counters + 16 * (cur ^ 1), mcOld);
+                     dst_base, descs, n, bit_depth, clp_min, clp_max, list, counters + 16 * cur, counters + 16 * (cur ^ 1));
   hipLaunchKernelGGL(mc_batch_kernel, dim3(n < 2048 ? n : 2048), dim3(64), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
                      dst_base, descs, list, counters + 16 * cur, bit_depth, clp_min, clp_max);
   VVC_LAUNCH_CHECK();
