@@ -228,7 +228,10 @@ int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_
  *           (pu pos + (mv >> shift)); frac_x/frac_y in 1/16 (luma) or 1/32 (chroma) sample units as computed at
  *           :497-504; is_luma selects the 8-tap table m_lumaFilter[16][8] or the 4-tap m_chromaFilter[32][4].
  * bi = 0: dst = clipped uni-prediction from ref0.   bi = 1: dst = addAvg(pred(ref0), pred(ref1)).
- * bi = 2: dst = the unrounded 14-bit intermediate of ref0 (what motionCompensation leaves in m_acYuvPred). */
+ * bi = 2: dst = the unrounded 14-bit intermediate of ref0 (what motionCompensation leaves in m_acYuvPred).
+ * Reads: the rows / columns the reference's branch reads ((N - 1) extra rows only when frac_y != 0, columns likewise), as whole aligned
+ * dwords -- i.e. up to one sample left of and two samples right of them IN THE SAME ROW (the x86 filters over-read the same way:
+ * picture margins cover it).  16x16 luma and 8x8 chroma PUs take the packed fast path; every result is bit-equal to the reference. */
 typedef struct vvcgpu_mc_desc {
   int64_t ref0_off, ref1_off, dst_off;
   int32_t ref0_stride, ref1_stride, dst_stride;
