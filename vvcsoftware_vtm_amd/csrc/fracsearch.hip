@@ -321,21 +321,33 @@ __device__ __forceinline__ unsigned f16_dist(const int (&orgv)[4], const int (&p
   int s;
   if (HAD)
   {
-    int v[4] = { d[0] + d[1], d[0] - d[1], d[2] + d[3], d[2] - d[3] };
-    { const int a0 = v[0] + v[2], a2 = v[0] - v[2], a1 = v[1] + v[3], a3 = v[1] - v[3]; v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3; }
-    had_cross<DPP_ROR8>(v, (lane & 8) != 0);
-    had_cross<DPP_XOR1>(v, (lane & 1) != 0);
-    had_cross<DPP_XOR2>(v, (lane & 2) != 0);
-    {                                              // xor 4: row_shl:4 into banks 0, 2 and row_shr:4 into banks 1, 3
-#pragma unroll
-      for (int j = 0; j < 4; j++)
-      {
-        int p = __builtin_amdgcn_update_dpp(0, v[j], 0x104, 0xF, 0x5, false);
-        p = __builtin_amdgcn_update_dpp(p, v[j], 0x114, 0xF, 0xA, false);
-        v[j] = ((lane & 4) ? -v[j] : v[j]) + p;
-      }
-    }
-    s = abs(v[0]) + abs(v[1]) + abs(v[2]) + abs(v[3]);
+    // 8x8 Hadamard in PACKED 16-bit: |d| <= 1023 grows by 2 per stage, so five of the six stages fit int16 (32 x 1023 = 32736), and the
+    // sixth is never formed: |a + b| + |a - b| = 2 max(|a|, |b|), i.e. every lane adds max(|own|, |partner|) and the pair is counted twice.
+    // The lane's four rows are two dwords; a butterfly with the partner lane is one DPP move + one v_pk_mad_i16 (own x (+-1) + partner).
+    const pel2 one = { 1, 1 }, mone = { -1, -1 }, pm = { 1, -1 };
+    pel2 q0 = { (short)d[0], (short)d[1] }, q1 = { (short)d[2], (short)d[3] };
+    auto rot = [](pel2 v) { const unsigned u = __builtin_bit_cast(unsigned, v); return __builtin_bit_cast(pel2, __builtin_amdgcn_alignbit(u, u, 16)); };
+    q0 = rot(q0) + q0 * pm;                                               // (d0 + d1, d0 - d1)
+    q1 = rot(q1) + q1 * pm;
+    { const pel2 a = q0 + q1, b = q0 - q1; q0 = a; q1 = b; }
+    auto cross = [&](auto mov, bool upper)
+    {
+      const pel2 sg = upper ? mone : one;
+      q0 = __builtin_bit_cast(pel2, mov(__builtin_bit_cast(int, q0))) + q0 * sg;
+      q1 = __builtin_bit_cast(pel2, mov(__builtin_bit_cast(int, q1))) + q1 * sg;
+    };
+    cross([](int v) { return dpp_mov<DPP_ROR8>(v); }, (lane & 8) != 0);
+    cross([](int v) { return dpp_mov<DPP_XOR1>(v); }, (lane & 1) != 0);
+    cross([](int v) { return dpp_mov<DPP_XOR2>(v); }, (lane & 2) != 0);
+    auto xor4 = [](int v)                                                 // row_shl:4 into banks 0, 2 and row_shr:4 into banks 1, 3
+    {
+      int p = __builtin_amdgcn_update_dpp(0, v, 0x104, 0xF, 0x5, false);
+      return __builtin_amdgcn_update_dpp(p, v, 0x114, 0xF, 0xA, false);
+    };
+    const pel2 a0 = __builtin_elementwise_max(q0, -q0), a1 = __builtin_elementwise_max(q1, -q1);
+    const pel2 m0 = __builtin_elementwise_max(a0, __builtin_bit_cast(pel2, xor4(__builtin_bit_cast(int, a0))));
+    const pel2 m1 = __builtin_elementwise_max(a1, __builtin_bit_cast(pel2, xor4(__builtin_bit_cast(int, a1))));
+    s = (int)m0[0] + (int)m0[1] + (int)m1[0] + (int)m1[1];
   }
   else
     s = abs(d[0]) + abs(d[1]) + abs(d[2]) + abs(d[3]);
