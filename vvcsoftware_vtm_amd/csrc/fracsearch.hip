@@ -358,102 +358,123 @@ __device__ __forceinline__ unsigned f16_dist(const int (&orgv)[4], const int (&p
   return t0 + t1 + t2 + t3;
 }
 
-// vertical (last-stage) filter of the lane's column: col[k] = plane row y0 - 4 + k, outputs rows y0 .. y0+3 at integer
-// row offset IY (-1 / 0) and quarter phase fy (0..3)
-template <int IY>
-__device__ __forceinline__ void f16_vert(const int (&col)[12], int fy, int headRoom, int cmin, int cmax, int (&out)[4])
+// The first-stage planes are kept TRANSPOSED in LDS (hpT[column + 1][plane row], 24 rows per column, plane row 0 = picture row -4), so the
+// lane's column is 12 consecutive samples = three aligned ds_read_b64, and they arrive as the dword pairs that v_dot2_i32_i16 wants:
+// D[m] = (col[2m], col[2m+1]); the odd pairs E[m] = (col[2m+1], col[2m+2]) cost one v_alignbit each, once per column for its three candidates.
+constexpr int HPT = 24;                                                   // samples per column of a transposed plane
+struct F16Col { unsigned D[6], E[5]; };
+__device__ __forceinline__ void f16_load_col(const short* __restrict__ pcT, F16Col& c)
 {
-  if (fy == 0)                                     // IY == 0 here
-  {
+  const uint2* q = reinterpret_cast<const uint2*>(pcT);
 #pragma unroll
-    for (int yy = 0; yy < 4; yy++) out[yy] = clip3(cmin, cmax, (int)(short)((col[4 + yy] + OFFS + (1 << (headRoom - 1))) >> headRoom));
-    return;
-  }
-  const short* cf = c_lumaF[fy << 2];
-  const int shift2 = 6 + headRoom, off2 = (1 << (shift2 - 1)) + (OFFS << 6);
-  int c8[8];
+  for (int m = 0; m < 3; m++) { const uint2 v = q[m]; c.D[2 * m] = v.x; c.D[2 * m + 1] = v.y; }
 #pragma unroll
-  for (int k = 0; k < 8; k++) c8[k] = cf[k];
-#pragma unroll
-  for (int yy = 0; yy < 4; yy++)
-  {
-    int sum = off2;
-#pragma unroll
-    for (int k = 0; k < 8; k++) sum += col[IY + 1 + yy + k] * c8[k];
-    out[yy] = clip3(cmin, cmax, (int)(short)(sum >> shift2));
-  }
+  for (int m = 0; m < 5; m++) c.E[m] = __builtin_amdgcn_alignbit(c.D[m + 1], c.D[m], 16);
 }
 
-// first-stage plane into hp (pitch 18, plane column -1 at index 0): lanes 0..47 = (row r, segment); 16-column planes at
-// integer offset ix use outputs x = 0..15, the 17-column half plane (WIDE) x = -1..15.
+// vertical (last-stage) filter of the lane's column: col[k] = plane row y0 + k, outputs rows y0 .. y0+3 at integer row offset IY (-1 / 0)
+// and quarter phase fy (0..3): out[yy] = sum_k col[IY + 1 + yy + k] c[k]
+template <int IY>
+__device__ __forceinline__ void f16_vert(const F16Col& col, int fy, int headRoom, int cmin, int cmax, int (&out)[4])
+{
+  if (fy == 0)                                     // IY == 0 here: samples col[4 .. 7]
+  {
+#pragma unroll
+    for (int yy = 0; yy < 4; yy++)
+    {
+      const unsigned d = col.D[2 + (yy >> 1)];
+      const int v = (yy & 1) ? (int)d >> 16 : (int)(short)(d & 0xFFFF);
+      out[yy] = clip3(cmin, cmax, (int)(short)((v + OFFS + (1 << (headRoom - 1))) >> headRoom));
+    }
+    return;
+  }
+  const unsigned* cf = reinterpret_cast<const unsigned*>(c_lumaF[fy << 2]);
+  const int shift2 = 6 + headRoom, off2 = (1 << (shift2 - 1)) + (OFFS << 6);
+  int sum[4] = { off2, off2, off2, off2 };
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+  {
+    const pel2 cm = __builtin_bit_cast(pel2, cf[m]);
+    if (IY < 0)                                    // starts col[0], col[1], col[2], col[3]
+    {
+      sum[0] = __builtin_amdgcn_sdot2(__builtin_bit_cast(pel2, col.D[m]), cm, sum[0], false);
+      sum[1] = __builtin_amdgcn_sdot2(__builtin_bit_cast(pel2, col.E[m]), cm, sum[1], false);
+      sum[2] = __builtin_amdgcn_sdot2(__builtin_bit_cast(pel2, col.D[m + 1]), cm, sum[2], false);
+      sum[3] = __builtin_amdgcn_sdot2(__builtin_bit_cast(pel2, col.E[m + 1]), cm, sum[3], false);
+    }
+    else                                           // starts col[1] .. col[4]
+    {
+      sum[0] = __builtin_amdgcn_sdot2(__builtin_bit_cast(pel2, col.E[m]), cm, sum[0], false);
+      sum[1] = __builtin_amdgcn_sdot2(__builtin_bit_cast(pel2, col.D[m + 1]), cm, sum[1], false);
+      sum[2] = __builtin_amdgcn_sdot2(__builtin_bit_cast(pel2, col.E[m + 1]), cm, sum[2], false);
+      sum[3] = __builtin_amdgcn_sdot2(__builtin_bit_cast(pel2, col.D[m + 2]), cm, sum[3], false);
+    }
+  }
+#pragma unroll
+  for (int yy = 0; yy < 4; yy++) out[yy] = clip3(cmin, cmax, (int)(short)(sum[yy] >> shift2));
+}
+
+// first-stage plane into hpT (transposed, column index = plane column + 1): lanes 0..47 = (row r, segment); 16-column planes at
+// integer offset ix use outputs x = 0..15, the 17-column half plane (WIDE) x = -1..15.  A lane filters 8 (9) neighbouring outputs of its
+// row from 8 dword reads: output with first tap at sample st of the lane's 16 is four v_dot2 over D[st/2 ..] (st even) or E[(st-1)/2 ..].
 template <bool WIDE>
-__device__ __forceinline__ void f16_hplane(const short* __restrict__ win, short* __restrict__ hp, int ix, int fx, int headRoom, int lane)
+__device__ __forceinline__ void f16_hplane(const short* __restrict__ win, short* __restrict__ hpT, int ix, int fx, int headRoom, int lane)
 {
   if (lane < 48)
   {
     const int r = lane >> 1, seg = lane & 1;
     const unsigned* wr = reinterpret_cast<const unsigned*>(win + r * 26 + seg * 8);      // 16 samples = window cols 8 seg .. 8 seg + 15
-    int sm[16];
+    unsigned D[8], E[7];
 #pragma unroll
-    for (int k = 0; k < 8; k++) { const unsigned u = wr[k]; sm[2 * k] = (int)(short)(u & 0xFFFF); sm[2 * k + 1] = (int)u >> 16; }
-    short* o = hp + r * 18 + 1 + seg * 8;
+    for (int k = 0; k < 8; k++) D[k] = wr[k];
+#pragma unroll
+    for (int k = 0; k < 7; k++) E[k] = __builtin_amdgcn_alignbit(D[k + 1], D[k], 16);
+    short* o = hpT + (1 + seg * 8) * HPT + r;                                            // column x of this segment: o[x * HPT]
     const int shift1 = 6 - headRoom, off1 = -(OFFS << shift1);
-    const short* cf = c_lumaF[fx << 2];
-    int c8[8];
+    const unsigned* cf = reinterpret_cast<const unsigned*>(c_lumaF[fx << 2]);
+    pel2 c2[4];
 #pragma unroll
-    for (int k = 0; k < 8; k++) c8[k] = cf[k];
-    // output x (plane column) uses window cols x + ix + 1 .. x + ix + 8, i.e. sm[x - 8 seg + ix + 1 + k]
-    if (WIDE)                                      // ix = -1..0 folded into the 17 columns: column x' uses sm[x' - 8 seg + 1 + k]
+    for (int m = 0; m < 4; m++) c2[m] = __builtin_bit_cast(pel2, cf[m]);
+    auto tap8 = [&](int st) -> int                                                     // st: compile-time after unrolling
+    {
+      int sum = off1;
+#pragma unroll
+      for (int m = 0; m < 4; m++)
+        sum = __builtin_amdgcn_sdot2(__builtin_bit_cast(pel2, (st & 1) ? E[(st >> 1) + m] : D[(st >> 1) + m]), c2[m], sum, false);
+      return sum >> shift1;
+    };
+    if (WIDE)                                      // ix = -1..0 folded into the 17 columns: column x' starts at sample x' - 8 seg + 1
     {
       if (seg == 0)
       {
 #pragma unroll
-        for (int x = -1; x < 8; x++)
-        {
-          int sum = off1;
-#pragma unroll
-          for (int k = 0; k < 8; k++) sum += sm[x + 1 + k] * c8[k];
-          o[x] = (short)(sum >> shift1);
-        }
+        for (int x = -1; x < 8; x++) o[x * HPT] = (short)tap8(x + 1);
       }
       else
       {
 #pragma unroll
-        for (int x = 0; x < 8; x++)
-        {
-          int sum = off1;
-#pragma unroll
-          for (int k = 0; k < 8; k++) sum += sm[x + 1 + k] * c8[k];
-          o[x] = (short)(sum >> shift1);
-        }
+        for (int x = 0; x < 8; x++) o[x * HPT] = (short)tap8(x + 1);
       }
     }
     else if (fx == 0)
     {
 #pragma unroll
-      for (int x = 0; x < 8; x++) o[x] = (short)((short)(sm[x + 4] << headRoom) - (short)OFFS);   // ix == 0
+      for (int x = 0; x < 8; x++)                                                        // ix == 0: sample x + 4
+      {
+        const unsigned d = D[(x + 4) >> 1];
+        const int sv = (x & 1) ? (int)d >> 16 : (int)(short)(d & 0xFFFF);
+        o[x * HPT] = (short)((short)(sv << headRoom) - (short)OFFS);
+      }
     }
     else if (ix == 0)
     {
 #pragma unroll
-      for (int x = 0; x < 8; x++)
-      {
-        int sum = off1;
-#pragma unroll
-        for (int k = 0; k < 8; k++) sum += sm[x + 1 + k] * c8[k];
-        o[x] = (short)(sum >> shift1);
-      }
+      for (int x = 0; x < 8; x++) o[x * HPT] = (short)tap8(x + 1);
     }
     else
     {
 #pragma unroll
-      for (int x = 0; x < 8; x++)
-      {
-        int sum = off1;
-#pragma unroll
-        for (int k = 0; k < 8; k++) sum += sm[x + k] * c8[k];
-        o[x] = (short)(sum >> shift1);
-      }
+      for (int x = 0; x < 8; x++) o[x * HPT] = (short)tap8(x);
     }
   }
 }
@@ -529,14 +550,14 @@ __global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org
   WAVE_SYNC();
 
   unsigned* dist = distS[wave];
-  int col[12], pred[4];
+  F16Col col;
+  int pred[4];
   // ---- half stage: quarter offsets qx, qy in {-2, 0, 2}
 #pragma unroll
   for (int dx = -1; dx <= 1; dx++)
   {
-    const short* pc = dx == 0 ? hp0 + (y0 * 18 + 1 + x) : hp8 + (y0 * 18 + 1 + x + (dx < 0 ? -1 : 0));
-#pragma unroll
-    for (int k = 0; k < 12; k++) col[k] = pc[k * 18];
+    const short* pc = dx == 0 ? hp0 + ((1 + x) * HPT + y0) : hp8 + ((1 + x + (dx < 0 ? -1 : 0)) * HPT + y0);
+    f16_load_col(pc, col);
     f16_vert<0>(col, 0, headRoom, cmin, cmax, pred);  dist[f16_idx(dx, 0, false)] = f16_dist<HAD>(orgv, pred, lane);
     f16_vert<-1>(col, 2, headRoom, cmin, cmax, pred); dist[f16_idx(dx, -1, false)] = f16_dist<HAD>(orgv, pred, lane);
     f16_vert<0>(col, 2, headRoom, cmin, cmax, pred);  dist[f16_idx(dx, 1, false)] = f16_dist<HAD>(orgv, pred, lane);
@@ -553,16 +574,15 @@ __global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org
   {
     const int qx = 2 * hx + dx, ix = qx >> 2, fx = qx & 3;
     const short* pc;
-    if (dx == 0) pc = hx == 0 ? hp0 + (y0 * 18 + 1 + x) : hp8 + (y0 * 18 + 1 + x + (hx < 0 ? -1 : 0));
+    if (dx == 0) pc = hx == 0 ? hp0 + ((1 + x) * HPT + y0) : hp8 + ((1 + x + (hx < 0 ? -1 : 0)) * HPT + y0);
     else
     {
       WAVE_SYNC();                                          // previous readers of hpq are done
       f16_hplane<false>(win, hpq, ix, fx, headRoom, lane);
       WAVE_SYNC();
-      pc = hpq + (y0 * 18 + 1 + x);
+      pc = hpq + ((1 + x) * HPT + y0);
     }
-#pragma unroll
-    for (int k = 0; k < 12; k++) col[k] = pc[k * 18];
+    f16_load_col(pc, col);
 #pragma unroll
     for (int dy = -1; dy <= 1; dy++)
     {
