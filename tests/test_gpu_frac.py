@@ -16,7 +16,7 @@ def dev(a):
 
 @pytest.mark.parametrize("w,h", [(4, 4), (8, 8), (16, 16), (16, 8), (8, 16), (32, 32), (64, 64), (8, 4), (4, 8), (32, 16),
                                  (128, 128), (64, 32), (16, 64), (128, 64)])
-@pytest.mark.parametrize("bd,kind,had", [(10, "smooth", 1), (10, "uniform", 1), (8, "smooth", 1), (10, "smooth", 0)])
+@pytest.mark.parametrize("bd,kind,had", [(10, "smooth", 1), (10, "uniform", 1), (8, "smooth", 1), (10, "smooth", 0), (10, "extreme", 1)])
 def test_frac_refine(w, h, bd, kind, had):
     from vvcsoftware_vtm_amd import ops
     rng = np.random.default_rng(w * 5 + h + bd + had)
@@ -36,4 +36,32 @@ def test_frac_refine(w, h, bd, kind, had):
     oracle().orc_frac_refine(p(org), W, p(ref), W + 2 * M, p(blk), nb, w, h, bd, 0, mx, had, C.byref(mv), p(want))
     got = ops.frac_refine(dev(org), dev(ref), ops.struct_to_device(blk), nb, w, h, bd, mv, bool(had), (0, mx))
     got = got.cpu().numpy().view(ops.FRAC_RESULT)
+    assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("pattern", ["flat", "checker", "random"])
+def test_frac16_hadamard_at_the_int16_bound(pattern):
+    """16x16 PUs take the packed 16-bit Hadamard (five stages in int16, the last as 2 max(|a|, |b|)): residuals of +-1023 in the patterns that
+    put the largest coefficients into one place (flat: DC = 64 x 1023; checkerboards: the highest frequency) and random full-range content"""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(7)
+    bd, mx, W, H, M, w, h = 10, 1023, 128, 96, 16, 16, 16
+    if pattern == "flat":
+        ref = np.zeros((H + 2 * M, W + 2 * M), np.int16); org = np.full((H, W), mx, np.int16)
+    elif pattern == "checker":
+        yy, xx = np.mgrid[0:H + 2 * M, 0:W + 2 * M]
+        ref = (((yy + xx) & 1) * mx).astype(np.int16)
+        org = np.ascontiguousarray((((yy + xx + 1) & 1) * mx).astype(np.int16)[M:M + H, M:M + W])
+    else:
+        ref = (rng.integers(0, 2, (H + 2 * M, W + 2 * M)) * mx).astype(np.int16)
+        org = (rng.integers(0, 2, (H, W)) * mx).astype(np.int16)
+    nb = 12
+    blk = np.zeros(nb, ops.FRAC_BLK)
+    for i in range(nb):
+        x, y = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+        blk[i] = (x, y, M + x, M + y, 0, 0)
+    mv = ops.MvCost(4.0, 0, 0, 0, 0)
+    want = np.zeros(nb, ops.FRAC_RESULT)
+    oracle().orc_frac_refine(p(org), W, p(ref), W + 2 * M, p(blk), nb, w, h, bd, 0, mx, 1, C.byref(mv), p(want))
+    got = ops.frac_refine(dev(org), dev(ref), ops.struct_to_device(blk), nb, w, h, bd, mv, True, (0, mx)).cpu().numpy().view(ops.FRAC_RESULT)
     assert np.array_equal(got, want)

@@ -59,8 +59,8 @@ def test_if_batch(bd, first):
 
 
 @pytest.mark.parametrize("bd", [8, 10])
-@pytest.mark.parametrize("kind,W", [("smooth", 384), ("extreme", 384), ("smooth", 387)])      # odd stride: the window's dword phase alternates per row
-def test_mc_batch(bd, kind, W):
+@pytest.mark.parametrize("kind,W,doff0", [("smooth", 384, 0), ("extreme", 384, 0), ("smooth", 387, 3)])   # odd stride: the window's dword phase alternates
+def test_mc_batch(bd, kind, W, doff0):                                                                         # per row; doff0 = 3: no 8-byte aligned output row
     from vvcsoftware_vtm_amd import ops
     rng = np.random.default_rng(bd)
     mx = (1 << bd) - 1
@@ -68,7 +68,7 @@ def test_mc_batch(bd, kind, W):
     r0 = cases.rand_plane(rng, H, W, bd, kind)
     r1 = cases.rand_plane(rng, H, W, bd, kind)
     rows = []
-    doff = 0
+    doff = doff0
     sizes = [(4, 4), (8, 8), (8, 4), (16, 16), (12, 16), (32, 8), (24, 24), (64, 64), (128, 128), (2, 2), (4, 8), (48, 64)]
     for (w, h) in sizes:
         for luma in (1, 0):
