@@ -1,6 +1,6 @@
 # usage (GPU box): bash tools/r5q_ab.sh -- A/B timing of the 39 x 39 raster searches: quad form (sad_raster5q_kernel) against the pair form (VVCGPU_NO_R5Q=1)
 cd /tmp && export TMPDIR=/tmp; cd $GRAFT_REPO_ROOT
-for v in q:0 nt:0; do
+for v in q:0; do
   unset VVCGPU_NO_R5Q VVCGPU_R5Q_SPLIT VVCGPU_R5C_RPS VVCGPU_NO_R5GQ VVCGPU_R5Q_NOTOUCH
   case $v in old:*) export VVCGPU_NO_R5Q=1;; rps15:*) export VVCGPU_R5C_RPS=15;; g:*) export VVCGPU_NO_R5GQ=1;; nt:*) export VVCGPU_R5Q_NOTOUCH=1;; esac
   t=${v#*:}; if [ "$t" != "0" ]; then export VVCGPU_R5Q_SPLIT=$t; fi
