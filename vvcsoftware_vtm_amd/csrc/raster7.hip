@@ -326,8 +326,7 @@ __device__ __forceinline__ void r7_dma_rows(unsigned char* ring, int ringRow0, i
   }
 }
 
-// step record (16 bytes, LDS): bp = first block, info = nb | nParts << 8, (wx, wy) = window origin of slab 0 in samples
-struct R7Rec { int bp, info, wx, wy; };
+struct R7Rec { int v[8]; };          // step record (32 bytes, LDS): written once per chunk of steps, see the kernel
 
 constexpr int R7_SVC = R7_WAVES - 2;           // service wave: arg-min pass of the finished step, beside the others' SAD loops of the next one
 constexpr int R7_TAIL = R7_WAVES - 1;          // the wave that runs the tail items
@@ -384,7 +383,9 @@ __global__ __launch_bounds__(R7_THREADS, 4) void sad_raster7_kernel(const unsign
   bool nextReady = false;                                                         // the rows of the coming (step, slab) are in the ring / in flight
   int buf = 0;                                                                    // surface of the current step
   int svcBp = 0, svcNb = 0, svcBuf = 0;                                           // the finished step whose surface waits for the service wave
-  unsigned long long tPrev = 0;                                                   // (diagnostic launches)
+  // diagnostic launches (VVCGPU_R7_DIAG): cycles between stamps 0 .. 7 of a phase, summed in registers, written once at the end
+  unsigned long long dT[8] = { 0, 0, 0, 0, 0, 0, 0, 0 }, dPrev = 0; unsigned dN = 0;
+#define R7_STAMP(i) do { if (diag) { const unsigned long long t_ = __builtin_readcyclecounter(); if (dPrev) dT[i] += t_ - dPrev; dPrev = t_; } } while (0)
   unsigned svcNeg = 0;                                                            // service wave: negBlk of the finished step's block t in lane t
 
   // the thread's two surface entries (tid, tid + 1024: the same in every step) with their motion-vector cost uint32(lambda * bits)
@@ -432,9 +433,51 @@ __global__ __launch_bounds__(R7_THREADS, 4) void sad_raster7_kernel(const unsign
     svcNb = 0;
   };
 
+  // the pending arg-min pass: the finished step whose surface has not been scanned yet (scanned by every wave behind its SAD runs of the
+  // NEXT phase, so that the pass's LDS round trip and its two wave reductions run beside the other waves' SAD loops)
+  int argBp = 0, argNb = 0, argBuf = 0; unsigned argNeg = 0;
+  auto argmin_pass = [&]()
+  {
+    for (int t = 0; t < argNb; t++)
+    {
+      unsigned* st = surf + (argBuf * NB + t) * SPA;
+      unsigned v0 = 0u, v1 = 0u;
+      if (tid < SPA) { v0 = st[tid]; st[tid] = 0u; }
+      if (tid + R7_THREADS < SPA) { v1 = st[tid + R7_THREADS]; st[tid + R7_THREADS] = 0u; }
+      if (out)                                                                 // the surface leaves with the constant of the clamped original
+      {
+        const unsigned nk = negBlk[argBp + t];
+        unsigned* ob = out + (size_t)(argBp + t) * npos;
+        if (pc0 != 0x7FFFFFFFu) { const int jj = r7_div(tid, p.pwM), ii = tid - jj * PW; ob[jj * p.nx + ii] = (v0 + nk) << ss; }
+        if (pc1 != 0x7FFFFFFFu) { const int e = tid + R7_THREADS, jj = r7_div(e, p.pwM), ii = e - jj * PW; ob[jj * p.nx + ii] = (v1 + nk) << ss; }
+      }
+      if (p.useBest)
+      {
+        const unsigned c0 = (v0 << ss) + pc0, c1 = (v1 << ss) + pc1;
+        const unsigned c = min(c0, c1);                                        // entry tid comes first in scan order: it wins a tie
+        const unsigned e = c1 < c0 ? (unsigned)(tid + R7_THREADS) : (unsigned)tid;
+        const unsigned vv = c1 < c0 ? v1 : v0;
+        const unsigned cmin = r7_wave_min_u32(c);
+        const unsigned emin = r7_wave_min_u32(c == cmin ? e : 0xFFFFFFFFu);
+        const unsigned vw = (unsigned)__builtin_amdgcn_readlane((int)vv, (int)__builtin_ctzll(__ballot(c == cmin && e == emin)));
+        if (lane == 0)
+        {
+          waveKey[(argBuf * NB + t) * R7_WAVES + wave] = ((unsigned long long)cmin << 32) | emin;
+          waveV[(argBuf * NB + t) * R7_WAVES + wave] = vw;
+        }
+      }
+    }
+    argNb = 0;
+  };
+
+  __builtin_amdgcn_s_setprio(2);
+  bool carryChained = false;                                                      // chain bit of a chunk's first step (known from the chunk before)
+  const int winStepRows = p.nSlab * SH;
   for (int qc = q0; qc < q1; qc += CS - 1)
   {
-    // ---- records of steps [qc, qc + CS): one thread per (step, block) reads its descriptor, thread (step, 0 .. ) writes the records
+    // ---- records of steps [qc, qc + CS): everything a step needs, decided once by one thread per step (the waves then read 32 bytes):
+    //   A = { first block, nb | parts << 8 | chained << 16 | next chained << 17 | pieces << 20 | off << 28, source address of slab 0 }
+    //   B = { first block of the next step or -1 }
     const int nLocal = min(CS, q1 - qc);
     __syncthreads();                                                              // the previous chunk's records are no longer read
     if (tid < CS * NB)
@@ -452,49 +495,79 @@ __global__ __launch_bounds__(R7_THREADS, 4) void sad_raster7_kernel(const unsign
     if (tid < CS * NB)
     {
       const int s = r7_div(tid, p.nbM), t = tid - s * NB;
-      R7Rec r = { 0, 0, 0, 0 };
-      if (s < nLocal)
+      // (nb, adjacent, first block) of local step ls
+      auto shape = [&](int ls, int& b0, int& nbStep, bool& adj)
       {
-        const int q = qc + s, x = q / nRowsL, y = q - x * nRowsL, b0 = y * G + x * NB;
-        int nbStep = min(NB, min(G - x * NB, n - b0));
+        const int q = qc + ls, x = q / nRowsL, y = q - x * nRowsL;
+        b0 = y * G + x * NB;
+        nbStep = min(NB, min(G - x * NB, n - b0));
         if (nbStep < 0) nbStep = 0;
-        bool adj = true;
-        const vvcgpu_search_blk d0 = dsc[s * NB];
+        adj = true;
+        const vvcgpu_search_blk d0 = dsc[ls * NB];
         for (int k = 1; k < nbStep; k++)
         {
-          const vvcgpu_search_blk dk = dsc[s * NB + k];
+          const vvcgpu_search_blk dk = dsc[ls * NB + k];
           adj = adj && dk.ref_x == d0.ref_x + k * W && dk.ref_y == d0.ref_y;
         }
+      };
+      // step lb continues the chain of step la: both one part of the same width, same columns, window one block height further down
+      auto chains = [&](int la, int lb)
+      {
+        if (la < 0 || lb >= nLocal) return false;
+        int b0a, nba, b0b, nbb; bool aa, ab;
+        shape(la, b0a, nba, aa); shape(lb, b0b, nbb, ab);
+        const vvcgpu_search_blk da = dsc[la * NB], db = dsc[lb * NB];
+        return aa && ab && nba > 0 && nba == nbb && da.ref_x == db.ref_x && db.ref_y == da.ref_y + winStepRows;
+      };
+      int4v ra = { 0, 0, 0, 0 }, rb = { -1, 0, 0, 0 };
+      if (s < nLocal)
+      {
+        int b0, nbStep; bool adj;
+        shape(s, b0, nbStep, adj);
         const vvcgpu_search_blk dt = dsc[tid];
-        r.bp = b0 + t;
-        r.info = adj ? (nbStep | (nbStep > 0 ? 1 << 8 : 0)) : (1 | nbStep << 8);
-        r.wx = dt.ref_x + p.dx0; r.wy = dt.ref_y + p.dy0;
+        const int nbRec = adj ? nbStep : 1, parts = adj ? (nbStep > 0 ? 1 : 0) : nbStep;
+        const long long wx = (long long)dt.ref_x + p.dx0, wy = (long long)dt.ref_y + p.dy0;
+        const int off = (int)(wx & 7);
+        const int pieces = (((p.nx - 1) * 5 + nbRec * W + off) * 2 + 15) >> 4;
+        const unsigned long long src = (unsigned long long)(size_t)(ref + wy * p.rs + (wx - off));
+        const int ch = (t == 0 && chains(s - 1, s)) ? 1 : 0, chn = (t == 0 && chains(s, s + 1)) ? 1 : 0;
+        ra = int4v{ b0 + t, nbRec | parts << 8 | ch << 16 | chn << 17 | pieces << 20 | off << 28, (int)(unsigned)src, (int)(unsigned)(src >> 32) };
+        if (s + 1 < nLocal)
+        {
+          int b1, nb1; bool a1;
+          shape(s + 1, b1, nb1, a1);
+          if (nb1 > 0) rb.x = b1;
+        }
       }
-      recs[tid] = r;
+      reinterpret_cast<int4v*>(recs)[2 * tid] = ra;
+      reinterpret_cast<int4v*>(recs)[2 * tid + 1] = rb;
     }
     __syncthreads();
     const bool lastChunk = qc + CS >= q1;
     const int nProc = lastChunk ? nLocal : CS - 1;                                // the chunk's last step is the next chunk's first
     for (int s = 0; s < nProc; s++)
     {
-      const int info0 = __builtin_amdgcn_readfirstlane(recs[s * NB].info);
-      const int nParts = info0 >> 8;
+      const int4v A0 = reinterpret_cast<const int4v*>(recs)[2 * s * NB];
+      const int info0 = __builtin_amdgcn_readfirstlane(A0.y);
+      const int nParts = (info0 >> 8) & 255;
       for (int part = 0; part < nParts; part++)
       {
-        const R7Rec R = recs[s * NB + part];
-        const int bp = __builtin_amdgcn_readfirstlane(R.bp), nb = __builtin_amdgcn_readfirstlane(R.info) & 255;
-        const int wx = __builtin_amdgcn_readfirstlane(R.wx), wy0 = __builtin_amdgcn_readfirstlane(R.wy);
-        const int off = wx & 7, OA = off & 3;
-        const int pieces = (((p.nx - 1) * 5 + nb * W + off) * 2 + 15) >> 4;
+        const int4v A = reinterpret_cast<const int4v*>(recs)[2 * (s * NB + part)];
+        const int bp = __builtin_amdgcn_readfirstlane(A.x), info = __builtin_amdgcn_readfirstlane(A.y);
+        const unsigned long long srcA = (unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(A.z) | ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane(A.w) << 32);
+        const int nb = info & 255, pieces = (info >> 20) & 63, off = (info >> 28) & 7, OA = off & 3;
+        const bool chainedIn = part == 0 && (s == 0 ? carryChained : ((info >> 16) & 1) != 0);
+        const bool chainsOn = part + 1 == nParts && ((info >> 17) & 1) != 0;
+        const int nbp = part + 1 == nParts ? __builtin_amdgcn_readfirstlane(reinterpret_cast<const int4v*>(recs)[2 * (s * NB) + 1].x) : -1;
+        R7_STAMP(0);
         // service wave: the sums of the negative parts of this step's blocks (lane t: block t), requested now, used behind the step's last barrier
         unsigned negReq = 0;
         if (wave == R7_SVC && lane < nb) negReq = negBlk[bp + lane];
         unsigned* sf = surf + buf * NB * SPA;
         for (int slab = 0; slab < p.nSlab; slab++)
         {
-          const int wy = wy0 + slab * SH;
-          const Pel* src = ref + (long long)wy * p.rs + (wx - off);
-          if (nextReady) { ringTop += SH; if (ringTop >= RR) ringTop -= RR; }
+          const Pel* src = reinterpret_cast<const Pel*>((size_t)srcA) + (size_t)slab * SH * p.rs;
+          if (slab > 0 || chainedIn) { ringTop += SH; if (ringTop >= RR) ringTop -= RR; }
           else
           {
             __syncthreads();                                                      // nobody reads the ring any more
@@ -503,48 +576,31 @@ __global__ __launch_bounds__(R7_THREADS, 4) void sad_raster7_kernel(const unsign
             __syncthreads();                                                      // (waits for the DMA: vmcnt(0) in front of the barrier)
           }
           // the SH new rows of the coming (step, slab), if it continues this chain: in flight during the SAD loop
-          bool ok = false;
-          int nbp = -1;                                                           // first block of the coming step (its packed rows are requested below)
-          if (slab + 1 < p.nSlab) ok = true;
-          else if (part + 1 == nParts && s + 1 < nLocal)
-          {
-            const R7Rec N = recs[(s + 1) * NB];
-            const int nInfo = __builtin_amdgcn_readfirstlane(N.info), nwx = __builtin_amdgcn_readfirstlane(N.wx), nwy = __builtin_amdgcn_readfirstlane(N.wy);
-            ok = (nInfo >> 8) == 1 && (nInfo & 255) == nb && nwx == wx && nwy == wy + SH;
-            if ((nInfo >> 8) >= 1) nbp = __builtin_amdgcn_readfirstlane(N.bp);
-          }
-          if (ok)
+          if (slab + 1 < p.nSlab || chainsOn)
           {
             int r0 = ringTop + p.winRows; if (r0 >= RR) r0 -= RR;
             if (!(p.dbg & 4)) r7_dma_rows(ring, r0, SH, RR, src + (size_t)p.winRows * p.rs, p.rs, pieces, wave, lane, R7_SVC);
           }
-          nextReady = ok;
+          R7_STAMP(1);
           // the packed rows of the coming (step, slab) into this XCD's L2 (the SAD loop's scalar loads then miss the scalar cache only)
           unsigned pf = 0u;
           if (wave < R7_SVC)
           {
             const unsigned* nxt = slab + 1 < p.nSlab ? packed + ((size_t)bp * perBlkAll + (size_t)(slab + 1) * S) * 16
                                                       : (nbp >= 0 ? packed + (size_t)nbp * perBlkAll * 16 : nullptr);
-            const int lines = nb * S;                                              // 64-byte lines (slab 0 of a block follows the previous block's last slab)
             const int li = wave * 64 + lane;
-            if (nxt && li < lines && !(p.dbg & 4))
-            {
-              const size_t o = slab + 1 < p.nSlab ? (size_t)(li >> lgS) * perBlkAll * 16 + (size_t)(li & (S - 1)) * 16 : (size_t)(li >> lgS) * perBlkAll * 16 + (size_t)(li & (S - 1)) * 16;
-              pf = nxt[o];                                                         // used (as a dummy) behind the barrier: no wait before it
-            }
+            if (nxt && li < nb * S && !(p.dbg & 4)) pf = nxt[(size_t)(li >> lgS) * perBlkAll * 16 + (size_t)(li & (S - 1)) * 16];   // used (as a dummy) behind the barrier
           }
 
-          // ---- the service wave first scans the surface of the step before (its adds were complete at the last barrier)
-          unsigned long long tS0 = 0, tS1 = 0, tS2 = 0;
-          if (diag) { tS0 = __builtin_readcyclecounter(); if (blockIdx.x == 0 && lane == 0 && tPrev) diag[wave * 4 + 3] += tS0 - tPrev; }
+          // ---- the service wave first writes the records of the step whose wave keys were complete at the last barrier
+          R7_STAMP(2);
           const int svcBlocks = svcNb;
-          if (wave == R7_SVC && svcNb > 0 && !(p.dbg & 2) && p.useBest)
+          if (wave == R7_SVC && svcNb > 0 && p.useBest)
           {
-            __builtin_amdgcn_s_setprio(3);                                        // a short latency chain beside three older waves in their SAD loops
             final_reduce();
-            __builtin_amdgcn_s_setprio(0);
           }
           svcNb = 0;
+          R7_STAMP(3);
 
           // ---- SAD loop: the (block, group, chunk-row) space of the step in 16 runs; the service wave and the tail wave get shorter ones
           {
@@ -562,7 +618,8 @@ __global__ __launch_bounds__(R7_THREADS, 4) void sad_raster7_kernel(const unsign
               if (p.dbg & 1) f = fEnd;
             }
             const int colU = 8 * (off >> 2);
-            if (diag) tS1 = __builtin_readcyclecounter();
+            R7_STAMP(4);
+            __builtin_amdgcn_s_setprio(0);                                        // (the serial parts of a phase run at priority 2: see below)
             if (p.tailP && wave == R7_TAIL && !(p.dbg & 1))
             {
               const int ui = r7_div(lane, p.tpM), ph = lane - ui * p.tailP;
@@ -601,56 +658,43 @@ __global__ __launch_bounds__(R7_THREADS, 4) void sad_raster7_kernel(const unsign
               f += len;
             }
           }
+          R7_STAMP(5);
+          __builtin_amdgcn_s_setprio(2);                                          // scalar / latency chains from here to the next SAD runs: a wave in them is not starved by the SIMD's other waves
+          // ---- the arg-min pass of the step BEFORE, behind this phase's SAD runs (its surface was complete at the last barrier); its keys are
+          // complete at the barrier below
+          const int argBlocks = argNb;
+          if (argNb > 0 && !(p.dbg & 2)) { svcBp = argBp; svcBuf = argBuf; svcNeg = argNeg; argmin_pass(); }
+          argNb = 0;
+          R7_STAMP(6);
           R7_WAIT_LGKM0();                                                        // the flushes (inline asm: not counted by the compiler)
-          if (diag) tS2 = __builtin_readcyclecounter();
-          __syncthreads();                                                        // the step's barrier: surface complete, rows free, DMA landed
+          __syncthreads();                                                        // the phase's barrier: surface complete, rows free, DMA landed, keys complete
           asm volatile("" :: "v"(pf));
-          if (diag && blockIdx.x == 0 && lane == 0)                               // diagnostic launch only (VVCGPU_R7_DIAG): cycles per phase and wave
-          {
-            const unsigned long long tS3 = __builtin_readcyclecounter();
-            diag[wave * 4 + 0] += tS1 - tS0; diag[wave * 4 + 1] += tS2 - tS1; diag[wave * 4 + 2] += tS3 - tS2; diag[64 + wave] += 1;
-          }
-          if (diag) tPrev = __builtin_readcyclecounter();
+          if (argBlocks > 0 && !(p.dbg & 2)) svcNb = argBlocks;                   // (svcNeg was latched when that step finished)
+          R7_STAMP(7);
+          dN++;
         }
-        // ---- arg-min pass (all threads, no barrier behind it: the next step adds to the other surface): every wave leaves one key per block
-        for (int t = 0; t < ((p.dbg & 2) ? 0 : nb); t++)
-        {
-          unsigned* st = sf + t * SPA;
-          unsigned v0 = 0u, v1 = 0u;
-          if (tid < SPA) { v0 = st[tid]; st[tid] = 0u; }
-          if (tid + R7_THREADS < SPA) { v1 = st[tid + R7_THREADS]; st[tid + R7_THREADS] = 0u; }
-          if (out)                                                                 // the surface leaves with the constant of the clamped original
-          {
-            const unsigned nk = negBlk[bp + t];
-            unsigned* ob = out + (size_t)(bp + t) * npos;
-            if (pc0 != 0x7FFFFFFFu) { const int jj = r7_div(tid, p.pwM), ii = tid - jj * PW; ob[jj * p.nx + ii] = (v0 + nk) << ss; }
-            if (pc1 != 0x7FFFFFFFu) { const int e = tid + R7_THREADS, jj = r7_div(e, p.pwM), ii = e - jj * PW; ob[jj * p.nx + ii] = (v1 + nk) << ss; }
-          }
-          if (p.useBest)
-          {
-            const unsigned c0 = (v0 << ss) + pc0, c1 = (v1 << ss) + pc1;
-            const unsigned c = min(c0, c1);                                        // entry tid comes first in scan order: it wins a tie
-            const unsigned e = c1 < c0 ? (unsigned)(tid + R7_THREADS) : (unsigned)tid;
-            const unsigned vv = c1 < c0 ? v1 : v0;
-            const unsigned cmin = r7_wave_min_u32(c);
-            const unsigned emin = r7_wave_min_u32(c == cmin ? e : 0xFFFFFFFFu);
-            const unsigned vw = (unsigned)__builtin_amdgcn_readlane((int)vv, (int)__builtin_ctzll(__ballot(c == cmin && e == emin)));
-            if (lane == 0)
-            {
-              waveKey[(buf * NB + t) * R7_WAVES + wave] = ((unsigned long long)cmin << 32) | emin;
-              waveV[(buf * NB + t) * R7_WAVES + wave] = vw;
-            }
-          }
-        }
-        if (diag && blockIdx.x == 0 && lane == 0) { const unsigned long long tA = __builtin_readcyclecounter(); diag[80 + wave] += tA - tPrev; }
-        svcBp = bp; svcNb = (p.dbg & 2) ? 0 : nb; svcBuf = buf; svcNeg = negReq;
+        // the step is complete: its surface waits for the arg-min pass (behind the next phase's SAD runs)
+        argBp = bp; argNb = nb; argBuf = buf; argNeg = negReq;
         buf ^= 1;
       }
     }
+    if (!lastChunk) carryChained = ((__builtin_amdgcn_readfirstlane(reinterpret_cast<const int4v*>(recs)[2 * (CS - 1) * NB].y) >> 16) & 1) != 0;
     if (lastChunk) break;
   }
-  __syncthreads();                                                                // the last step's keys
+  // drain: the records of the step before the last, then the last step's arg-min pass, a barrier, its records
   if (wave == R7_SVC && svcNb > 0 && p.useBest) final_reduce();
+  svcNb = 0;
+  const int lastBlocks = (p.dbg & 2) ? 0 : argNb;
+  if (lastBlocks > 0) { svcBp = argBp; svcBuf = argBuf; svcNeg = argNeg; argmin_pass(); }
+  __syncthreads();
+  svcNb = lastBlocks;
+  if (wave == R7_SVC && svcNb > 0 && p.useBest) final_reduce();
+  if (diag && blockIdx.x == 0 && lane == 0)
+  {
+    for (int i = 0; i < 8; i++) diag[wave * 8 + i] = dT[i];
+    diag[128 + wave] = dN;
+  }
+#undef R7_STAMP
 }
 
 }  // namespace
@@ -684,7 +728,7 @@ int vvcgpu_raster7_launch(const vvc_pel* org, int org_stride, const vvc_pel* ref
     if (rem > 0 && rem <= 32 && nFull >= 1 && !tailOff) { p.tailRem = rem; p.tailP = 64 / rem; }
     else if (rem > 0) return 1;                                                           // (a partial group in the scalar form: not built -- strip kernels)
   }
-  p.SP = ny * 4 * p.nq; p.SPpad = (p.SP + 63) & ~63;
+  p.SP = ny * 4 * p.nq; p.SPpad = p.SP;
   if (p.SPpad > 2 * R7_THREADS) return 1;                                           // two surface entries per thread
   const int pitchSamples = R7_P / 2;
   if ((nx - 1) * 5 + w + 7 > pitchSamples - 8) return 1;
@@ -704,7 +748,7 @@ int vvcgpu_raster7_launch(const vvc_pel* org, int org_stride, const vvc_pel* ref
     size_t o = (size_t)p.RR * R7_P;
     p.surfOff = (int)o; o += (size_t)2 * NB * p.SPpad * 4;
     p.keyOff = (int)o; o += (size_t)2 * NB * R7_WAVES * 12;
-    p.recOff = (int)o; o += (size_t)p.CS * NB * 16;
+    p.recOff = (int)o; o += (size_t)p.CS * NB * 32;
     p.dscOff = (int)o; o += (size_t)p.CS * NB * 16;
     p.miscOff = (int)o; o += 16;                                                    // the list's row length
     smem = o;                                                                       // (a span that ends past the last ring row reads surface bytes: harmless)
@@ -716,7 +760,7 @@ int vvcgpu_raster7_launch(const vvc_pel* org, int org_stride, const vvc_pel* ref
   const int hs = h >> sub_shift, perBlk = hs * CHh;
   const size_t packedDw = (size_t)nblocks * perBlk * 16, negDw = ((size_t)nblocks + 1) & ~(size_t)1;
   static const int diagOn = getenv("VVCGPU_R7_DIAG") ? 1 : 0;                           // diagnostic build path: phase cycles of workgroup 0 to stderr (synchronises)
-  const size_t diagDw = diagOn ? 2 * 96 : 0;
+  const size_t diagDw = diagOn ? 2 * 160 : 0;
   unsigned* scratch = static_cast<unsigned*>(vvcgpu_scratch(st, (packedDw + negDw + diagDw) * sizeof(unsigned)));
   if (!scratch) return VVCGPU_E_DEVICE;
   p.rs = ref_stride; p.nblocks = nblocks;
@@ -742,7 +786,7 @@ int vvcgpu_raster7_launch(const vvc_pel* org, int org_stride, const vvc_pel* ref
     fprintf(stderr, "[vvcgpu] sad_search %dx%d %dx%d raster: ring form, %d blocks per step, %d + %d slab rows, %d groups%s, %s, %zu B LDS, %d workgroups\n", w, h, nx, ny, NB,
             p.winRows, SH, p.nGroups, p.tailP ? " + tail item" : "", "two surfaces", smem, grid);
   unsigned long long* dg = diagOn ? reinterpret_cast<unsigned long long*>(scratch + packedDw + negDw) : nullptr;
-  if (dg) VVC_HIP(hipMemsetAsync(dg, 0, 96 * 8, st));
+  if (dg) VVC_HIP(hipMemsetAsync(dg, 0, 160 * 8, st));
 #define R7_LAUNCH(LG)                                                                                                             \
   do {                                                                                                                            \
     VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_raster7_kernel<LG>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem)); \
@@ -753,14 +797,17 @@ int vvcgpu_raster7_launch(const vvc_pel* org, int org_stride, const vvc_pel* ref
   VVC_LAUNCH_CHECK();
   if (dg)
   {
-    unsigned long long h[96];
+    unsigned long long h[160];
     VVC_HIP(hipMemcpyAsync(h, dg, sizeof h, hipMemcpyDeviceToHost, st));
     VVC_HIP(hipStreamSynchronize(st));
-    fprintf(stderr, "[vvcgpu] r7 diag %dx%d (workgroup 0, cycles per (step, slab), mean over %llu): wave: barrier -> step set-up (arg-min pass, records) | set-up + key reduce | SAD runs | wait at the barrier\n", w, h, h[64]);
+    fprintf(stderr, "[vvcgpu] r7 diag %dx%d (workgroup 0, mean cycles per phase over %llu phases), per wave:\n"
+                    "   barrier->records read | DMA rows issued | prefetch issued | key reduce | run split | SAD runs | arg-min pass | wait at the barrier\n", w, h, h[128]);
     for (int wv = 0; wv < R7_WAVES; wv++)
     {
-      const double nn = (double)(h[64 + wv] ? h[64 + wv] : 1);
-      fprintf(stderr, "   wave %2d: (arg-min pass %6.0f) %7.0f | %7.0f | %7.0f | %7.0f\n", wv, (double)h[80 + wv] / nn, (double)h[wv * 4 + 3] / nn, (double)h[wv * 4] / nn, (double)h[wv * 4 + 1] / nn, (double)h[wv * 4 + 2] / nn);
+      const double nn = (double)(h[128 + wv] ? h[128 + wv] : 1);
+      fprintf(stderr, "   wave %2d:", wv);
+      for (int i = 0; i < 8; i++) fprintf(stderr, " %7.0f", (double)h[wv * 8 + i] / nn);
+      fprintf(stderr, "\n");
     }
   }
   return 0;
