@@ -59,6 +59,13 @@ int vvcgpu_memcpy2d_d2h(void* dst_host, size_t dst_pitch, const void* src_dev, s
 int vvcgpu_memcpy2d_d2d(void* dst_dev, size_t dst_pitch, const void* src_dev, size_t src_pitch, size_t width_bytes,
                         size_t height, void* stream);
 int vvcgpu_stream_sync(void* stream);
+/* Library-internal per-stream resources (work lists, packed search blocks, counters) are created on the first call that needs them and kept
+ * for later calls on the same (device, stream).  A host that creates streams per thread / job calls vvcgpu_stream_release(stream) before it
+ * destroys a stream: the call waits for the stream's queued work and frees what the library holds for it (any number of streams may come and
+ * go).  vvcgpu_shutdown() does the same for every stream of every device (e.g. before unloading the library).  Both return VVCGPU_OK when
+ * there was nothing to free. */
+int vvcgpu_stream_release(void* stream);
+int vvcgpu_shutdown(void);
 
 /* ---- A1: ALF classification  (AdaptiveLoopFilter::deriveClassification, AdaptiveLoopFilter.cpp:274-463;
  *          table slot m_deriveClassificationBlk, AdaptiveLoopFilter.h:90) -----------------------
@@ -230,7 +237,7 @@ int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_
  * bi = 0: dst = clipped uni-prediction from ref0.   bi = 1: dst = addAvg(pred(ref0), pred(ref1)).
  * bi = 2: dst = the unrounded 14-bit intermediate of ref0 (what motionCompensation leaves in m_acYuvPred).
  * Reads: the rows / columns the reference's branch reads ((N - 1) extra rows only when frac_y != 0, columns likewise), as whole aligned
- * dwords -- i.e. up to one sample left of and two samples right of them IN THE SAME ROW (the x86 filters over-read the same way:
+ * dwords -- i.e. at most ONE sample left of and one sample right of them IN THE SAME ROW (the x86 filters over-read further:
  * picture margins cover it).  16x16 luma and 8x8 chroma PUs take the packed fast path; every result is bit-equal to the reference. */
 typedef struct vvcgpu_mc_desc {
   int64_t ref0_off, ref1_off, dst_off;

@@ -23,7 +23,7 @@ _ref = None
 def oracle():
     global _oracle
     if _oracle is None:
-        so = os.path.join(ORACLE_DIR, "liboracle.so")
+        so = os.path.join(ORACLE_DIR, os.environ.get("ORACLE_SO", "liboracle.so"))     # ORACLE_SO: the sanitizer build (tests/test_oracle_asan.py)
         if not os.path.exists(so):
             subprocess.check_call(["make", "-C", ORACLE_DIR, "restate"], stdout=subprocess.DEVNULL)
         _oracle = C.CDLL(so)

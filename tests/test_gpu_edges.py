@@ -72,3 +72,41 @@ def test_inloop_chain_on_ragged_pictures(w, h):
         wcls = np.zeros((h // 4, w // 4), np.uint16)
         oracle().orc_alf_classify(p(src), w, w, h, bd, p(wcls))
         assert np.array_equal(cls.reshape(wcls.shape), wcls)
+
+
+def test_many_short_lived_streams():
+    """A host that creates a stream per job: 100 streams come and go, each running calls that use the library's per-stream resources
+    (work lists + persistent counters of vvcgpu_mc_batch, packed blocks of the raster search), released with vvcgpu_stream_release before
+    the stream is destroyed.  The 65th stream used to fail for good (fixed table of 64 slots, never reclaimed)."""
+    from vvcsoftware_vtm_amd import ops, capi
+    rng = np.random.default_rng(5)
+    bd, mx, M = 10, 1023, 16
+    W, H = 64, 48
+    ref = dev(np.ascontiguousarray(np.pad(cases.rand_plane(rng, H, W, bd, "smooth"), M, mode="edge")))
+    n = (W // 16) * (H // 16)
+    d = np.zeros(n, ops.MC_DESC)
+    gx, gy = np.meshgrid(np.arange(0, W, 16), np.arange(0, H, 16))
+    d["ref0_off"] = d["ref1_off"] = ((gy.reshape(-1) + M) * (W + 2 * M) + gx.reshape(-1) + M)
+    d["dst_off"] = gy.reshape(-1) * W + gx.reshape(-1)
+    d["ref0_stride"] = d["ref1_stride"] = W + 2 * M
+    d["dst_stride"], d["w"], d["h"], d["is_luma"], d["bi"] = W, 16, 16, 1, 1
+    d["frac_x0"], d["frac_y1"] = 4, 8
+    dd = ops.struct_to_device(d)
+    want = None
+    for i in range(100):
+        s = torch.cuda.Stream()
+        with torch.cuda.stream(s):
+            out = torch.zeros((H, W), dtype=torch.int16, device="cuda")
+            ops.mc_batch(ref, ref, out, dd, n, bd, (0, mx))
+            s.synchronize()
+            got = out.cpu().numpy()
+            if want is None:
+                want = got
+            assert np.array_equal(got, want), i
+            capi.call("vvcgpu_stream_release", C.c_void_p(s.cuda_stream))
+        del s
+    capi.call("vvcgpu_shutdown")
+    out = torch.zeros((H, W), dtype=torch.int16, device="cuda")           # the library keeps working after a shutdown (resources come back on demand)
+    ops.mc_batch(ref, ref, out, dd, n, bd, (0, mx))
+    torch.cuda.synchronize()
+    assert np.array_equal(out.cpu().numpy(), want)

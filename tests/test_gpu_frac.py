@@ -65,3 +65,35 @@ def test_frac16_hadamard_at_the_int16_bound(pattern):
     oracle().orc_frac_refine(p(org), W, p(ref), W + 2 * M, p(blk), nb, w, h, bd, 0, mx, 1, C.byref(mv), p(want))
     got = ops.frac_refine(dev(org), dev(ref), ops.struct_to_device(blk), nb, w, h, bd, mv, True, (0, mx)).cpu().numpy().view(ops.FRAC_RESULT)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("w,h", [(16, 16), (32, 32), (8, 8)])
+@pytest.mark.parametrize("kind", ["bipred", "extreme"])
+def test_frac_refine_bipred_original(w, h, kind):
+    """Bi-predictive refinement hands in 2 org - otherPred (InterSearch.cpp:1682-1692, ClipForBiPredMEEnabled off by default): samples in
+    [-1023, 2046], so |org - pred| reaches 2046 and the packed 16-bit Hadamard of the 16x16 kernel does not hold -- such PUs take its
+    32-bit form (a wave-uniform test of the original's range); mixed lists, so both forms run in one launch."""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(w + 31 * h + len(kind))
+    bd, mx, W, H, M = 10, 1023, 192, 160, 16
+    ref = cases.rand_plane(rng, H + 2 * M, W + 2 * M, bd, "smooth")
+    base = cases.rand_plane(rng, H, W, bd, "smooth").astype(np.int32)
+    if kind == "bipred":
+        org = 2 * base - cases.rand_plane(rng, H, W, bd, "uniform")
+    else:                                                        # the corners of the range, in checkerboards (largest Hadamard sums)
+        yy, xx = np.mgrid[0:H, 0:W]
+        org = np.where((yy + xx) & 1, 2046, -1023)
+    org[:, :W // 2] = np.clip(org[:, :W // 2], 0, mx)          # left half in range: those PUs keep the packed form
+    org = np.ascontiguousarray(org.astype(np.int16))
+    assert org.min() < 0 and org.max() > mx
+    nb = 24
+    blk = np.zeros(nb, ops.FRAC_BLK)
+    for i in range(nb):
+        x, y = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+        mvx, mvy = int(rng.integers(-3, 4)), int(rng.integers(-3, 4))
+        blk[i] = (x, y, M + x + mvx, M + y + mvy, mvx, mvy)
+    mv = ops.MvCost(float(rng.uniform(2, 40)), int(rng.integers(-20, 20)), int(rng.integers(-20, 20)), 0, 0)
+    want = np.zeros(nb, ops.FRAC_RESULT)
+    oracle().orc_frac_refine(p(org), W, p(ref), W + 2 * M, p(blk), nb, w, h, bd, 0, mx, 1, C.byref(mv), p(want))
+    got = ops.frac_refine(dev(org), dev(ref), ops.struct_to_device(blk), nb, w, h, bd, mv, True, (0, mx)).cpu().numpy().view(ops.FRAC_RESULT)
+    assert np.array_equal(got, want)

@@ -1,5 +1,6 @@
+import os
 import sys, numpy as np, torch
-sys.path.insert(0, '/root/repo')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vvcsoftware_vtm_amd.workload import Workload
 wl = Workload(3840, 2160, 10)
 st, out = wl.run_gpu(None, None)

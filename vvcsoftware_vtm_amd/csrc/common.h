@@ -15,6 +15,7 @@ void vvcgpu_set_error(const char* fmt, ...);
 // call on that stream is free again when the next call's kernels start.  Grow-only; returns nullptr (error text set) on failure.
 void* vvcgpu_scratch(hipStream_t stream, size_t bytes);
 int* vvcgpu_counters(hipStream_t stream, int* cur);     // two persistent zeroed work counters per (device, stream), see lib.hip
+void vvcgpu_counters_failed(hipStream_t stream);       // a launch that took a counter set failed: both sets are cleared before their next use
 int vvcgpu_frac_refine_launch(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride, const vvcgpu_frac_blk* blocks, int nblocks,
                               int w, int h, int bit_depth, int clp_min, int clp_max, int use_hadamard, const vvcgpu_mvcost* mvcost_host,
                               const int* preds, vvcgpu_frac_result* results, void* stream);
@@ -48,6 +49,13 @@ int vvcgpu_tr_tables(VvcTrTables* out);
 
 #define VVC_LAUNCH_CHECK()                                                                    \
   do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) {                            \
+         vvcgpu_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
+         return VVCGPU_E_DEVICE; } } while (0)
+
+// the same for launches that own a counter set of vvcgpu_counters: a failure leaves the sets in an unknown state
+#define VVC_LAUNCH_CHECK_COUNTERS(st)                                                         \
+  do { hipError_t e_ = hipGetLastError(); if (e_ != hipSuccess) {                            \
+         vvcgpu_counters_failed(st);                                                         \
          vvcgpu_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
          return VVCGPU_E_DEVICE; } } while (0)
 

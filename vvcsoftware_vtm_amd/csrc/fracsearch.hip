@@ -312,14 +312,32 @@ __device__ __forceinline__ void had_cross(int (&v)[4], bool upper)
 }
 
 // distortion of the candidate whose 4-row column segment is pred[]: wave-uniform result
+// wide (wave-uniform): some |org - pred| of this PU may exceed 1023 (a bi-predictive original 2 org - otherPred reaches [-1023, 2046]):
+// the Hadamard then runs in 32-bit registers (had_cross), the packed form below holds only for |d| <= 1023.
 template <bool HAD>
-__device__ __forceinline__ unsigned f16_dist(const int (&orgv)[4], const int (&pred)[4], int lane)
+__device__ __forceinline__ unsigned f16_dist(const int (&orgv)[4], const int (&pred)[4], int lane, bool wide)
 {
   int d[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) d[j] = orgv[j] - pred[j];
   int s;
-  if (HAD)
+  if (HAD && wide)
+  {
+    int v[4] = { d[0] + d[1], d[0] - d[1], d[2] + d[3], d[2] - d[3] };
+    { const int a0 = v[0] + v[2], a2 = v[0] - v[2], a1 = v[1] + v[3], a3 = v[1] - v[3]; v[0] = a0; v[1] = a1; v[2] = a2; v[3] = a3; }
+    had_cross<DPP_ROR8>(v, (lane & 8) != 0);
+    had_cross<DPP_XOR1>(v, (lane & 1) != 0);
+    had_cross<DPP_XOR2>(v, (lane & 2) != 0);
+#pragma unroll
+    for (int j = 0; j < 4; j++)                    // xor 4: row_shl:4 into banks 0, 2 and row_shr:4 into banks 1, 3
+    {
+      int p = __builtin_amdgcn_update_dpp(0, v[j], 0x104, 0xF, 0x5, false);
+      p = __builtin_amdgcn_update_dpp(p, v[j], 0x114, 0xF, 0xA, false);
+      v[j] = ((lane & 4) ? -v[j] : v[j]) + p;
+    }
+    s = abs(v[0]) + abs(v[1]) + abs(v[2]) + abs(v[3]);
+  }
+  else if (HAD)
   {
     // 8x8 Hadamard in PACKED 16-bit: |d| <= 1023 grows by 2 per stage, so five of the six stages fit int16 (32 x 1023 = 32736), and the
     // sixth is never formed: |a + b| + |a - b| = 2 max(|a|, |b|), i.e. every lane adds max(|own|, |partner|) and the pair is counted twice.
@@ -543,6 +561,8 @@ __global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org
       win[r * 26 + cc] = r0[(ptrdiff_t)r * rs + cc];
     }
   }
+  // predictions are clipped to [cmin, cmax]: |org - pred| <= 1023 for every candidate iff org lies in [cmax - 1023, cmin + 1023]
+  const bool wide = __ballot(min(min(orgv[0], orgv[1]), min(orgv[2], orgv[3])) < cmax - 1023 || max(max(orgv[0], orgv[1]), max(orgv[2], orgv[3])) > cmin + 1023) != 0ull;
   const int headRoom = max(2, 14 - bd);
   WAVE_SYNC();
   f16_hplane<false>(win, hp0, 0, 0, headRoom, lane);
@@ -558,9 +578,9 @@ __global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org
   {
     const short* pc = dx == 0 ? hp0 + ((1 + x) * HPT + y0) : hp8 + ((1 + x + (dx < 0 ? -1 : 0)) * HPT + y0);
     f16_load_col(pc, col);
-    f16_vert<0>(col, 0, headRoom, cmin, cmax, pred);  dist[f16_idx(dx, 0, false)] = f16_dist<HAD>(orgv, pred, lane);
-    f16_vert<-1>(col, 2, headRoom, cmin, cmax, pred); dist[f16_idx(dx, -1, false)] = f16_dist<HAD>(orgv, pred, lane);
-    f16_vert<0>(col, 2, headRoom, cmin, cmax, pred);  dist[f16_idx(dx, 1, false)] = f16_dist<HAD>(orgv, pred, lane);
+    f16_vert<0>(col, 0, headRoom, cmin, cmax, pred);  dist[f16_idx(dx, 0, false)] = f16_dist<HAD>(orgv, pred, lane, wide);
+    f16_vert<-1>(col, 2, headRoom, cmin, cmax, pred); dist[f16_idx(dx, -1, false)] = f16_dist<HAD>(orgv, pred, lane, wide);
+    f16_vert<0>(col, 2, headRoom, cmin, cmax, pred);  dist[f16_idx(dx, 1, false)] = f16_dist<HAD>(orgv, pred, lane, wide);
   }
   int hx, hy;
   unsigned long long costH;
@@ -590,7 +610,7 @@ __global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org
       if (dx == 0 && dy == 0) { dist[ci] = distH; continue; }
       const int qy = 2 * hy + dy, iy = qy >> 2, fy = qy & 3;
       if (iy == 0) f16_vert<0>(col, fy, headRoom, cmin, cmax, pred); else f16_vert<-1>(col, fy, headRoom, cmin, cmax, pred);
-      dist[ci] = f16_dist<HAD>(orgv, pred, lane);
+      dist[ci] = f16_dist<HAD>(orgv, pred, lane, wide);
     }
   }
   int qdx, qdy;

@@ -14,34 +14,51 @@ void vvcgpu_set_error(const char* fmt, ...)
   va_end(ap);
 }
 
+// ---- per-(device, stream) resources: scratch buffer + two persistent zeroed counter sets.  One table behind one mutex; slots are created on
+// first use, released by vvcgpu_stream_release (a host that makes streams per job calls it before destroying the stream) or all at once by
+// vvcgpu_shutdown.  A buffer that has been outgrown is NOT freed on the spot -- another host thread may just have received it for the same
+// stream -- but parked in the slot's retired list until the slot is released.
+#include <vector>
 namespace {
-struct ScratchSlot { int device; hipStream_t stream; void* ptr; size_t cap; };
-ScratchSlot g_scratch[64];
-int g_nScratch = 0;
-std::mutex g_scratchMutex;
+struct StreamSlot
+{
+  int device; hipStream_t stream;
+  void* ptr; size_t cap;                  // scratch
+  std::vector<void*> retired;             // outgrown scratch buffers (freed with the slot)
+  int* counters; int cur; bool dirty;     // int[2][16]; dirty: a launch that owned a set failed -- both sets are cleared before the next use
+};
+std::vector<StreamSlot> g_slots;
+std::mutex g_slotMutex;
+
+StreamSlot* find_slot(int dev, hipStream_t stream, bool create)
+{
+  for (auto& s : g_slots)
+    if (s.device == dev && s.stream == stream) return &s;
+  if (!create) return nullptr;
+  g_slots.push_back(StreamSlot{ dev, stream, nullptr, 0, {}, nullptr, 0, false });
+  return &g_slots.back();
+}
+void free_slot(StreamSlot& s)             // caller holds the mutex, the slot's device is current, its stream is idle
+{
+  if (s.ptr) (void)hipFree(s.ptr);
+  for (void* q : s.retired) (void)hipFree(q);
+  if (s.counters) (void)hipFree(s.counters);
+}
 }
 
 void* vvcgpu_scratch(hipStream_t stream, size_t bytes)
 {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { vvcgpu_set_error("hipGetDevice failed"); return nullptr; }
-  std::lock_guard<std::mutex> lock(g_scratchMutex);
-  ScratchSlot* slot = nullptr;
-  for (int i = 0; i < g_nScratch; i++)
-    if (g_scratch[i].device == dev && g_scratch[i].stream == stream) { slot = &g_scratch[i]; break; }
-  if (!slot)
-  {
-    if (g_nScratch == 64) { vvcgpu_set_error("scratch: more than 64 (device, stream) pairs in use"); return nullptr; }
-    slot = &g_scratch[g_nScratch++];
-    slot->device = dev; slot->stream = stream; slot->ptr = nullptr; slot->cap = 0;
-  }
+  std::lock_guard<std::mutex> lock(g_slotMutex);
+  StreamSlot* slot = find_slot(dev, stream, true);
   if (slot->cap < bytes)
   {
-    // the old buffer may still be in use by queued work of this stream: drain it before freeing
-    if (slot->ptr) { (void)hipStreamSynchronize(stream); (void)hipFree(slot->ptr); slot->ptr = nullptr; slot->cap = 0; }
     const size_t cap = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
-    if (hipMalloc(&slot->ptr, cap) != hipSuccess) { slot->ptr = nullptr; vvcgpu_set_error("scratch: hipMalloc(%zu) failed", cap); return nullptr; }
-    slot->cap = cap;
+    void* p = nullptr;
+    if (hipMalloc(&p, cap) != hipSuccess) { vvcgpu_set_error("scratch: hipMalloc(%zu) failed", cap); return nullptr; }
+    if (slot->ptr) slot->retired.push_back(slot->ptr);          // may still be in use by queued work or by a concurrent caller: parked, not freed
+    slot->ptr = p; slot->cap = cap;
   }
   return slot->ptr;
 }
@@ -49,32 +66,36 @@ void* vvcgpu_scratch(hipStream_t stream, size_t bytes)
 // Two persistent work counters per (device, stream), zero when handed out: a launch that needs a zeroed counter takes counter `cur` and clears
 // counter `cur ^ 1` for the next call inside its own kernel (the previous user of that one has finished: same stream), so no fill launch is
 // needed in front of it.  EVERY user clears all 16 ints of the other set, whatever it uses of its own.  Returns a device pointer to
-// int[2][16] (64-byte lines) and the index to use; nullptr on failure.
-namespace {
-struct CounterSlot { int device; hipStream_t stream; int* ptr; int cur; };
-CounterSlot g_counters[64];
-int g_nCounters = 0;
-}
+// int[2][16] (64-byte lines) and the index to use; nullptr on failure.  A caller whose launches fail after this call reports it with
+// vvcgpu_counters_failed: the sets are then cleared by a memset on the stream in front of the next user.
 int* vvcgpu_counters(hipStream_t stream, int* cur)
 {
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { vvcgpu_set_error("hipGetDevice failed"); return nullptr; }
-  std::lock_guard<std::mutex> lock(g_scratchMutex);
-  CounterSlot* slot = nullptr;
-  for (int i = 0; i < g_nCounters; i++)
-    if (g_counters[i].device == dev && g_counters[i].stream == stream) { slot = &g_counters[i]; break; }
-  if (!slot)
+  std::lock_guard<std::mutex> lock(g_slotMutex);
+  StreamSlot* slot = find_slot(dev, stream, true);
+  if (!slot->counters)
   {
-    if (g_nCounters == 64) { vvcgpu_set_error("counters: more than 64 (device, stream) pairs in use"); return nullptr; }
     void* p = nullptr;
     if (hipMalloc(&p, 2 * 16 * sizeof(int)) != hipSuccess) { vvcgpu_set_error("counters: hipMalloc failed"); return nullptr; }
     if (hipMemset(p, 0, 2 * 16 * sizeof(int)) != hipSuccess) { (void)hipFree(p); vvcgpu_set_error("counters: hipMemset failed"); return nullptr; }
-    slot = &g_counters[g_nCounters++];
-    slot->device = dev; slot->stream = stream; slot->ptr = static_cast<int*>(p); slot->cur = 0;
+    slot->counters = static_cast<int*>(p); slot->cur = 0; slot->dirty = false;
+  }
+  if (slot->dirty)
+  {
+    if (hipMemsetAsync(slot->counters, 0, 2 * 16 * sizeof(int), stream) != hipSuccess) { vvcgpu_set_error("counters: hipMemsetAsync failed"); return nullptr; }
+    slot->dirty = false; slot->cur = 0;
   }
   *cur = slot->cur;
   slot->cur ^= 1;
-  return slot->ptr;
+  return slot->counters;
+}
+void vvcgpu_counters_failed(hipStream_t stream)
+{
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess) return;
+  std::lock_guard<std::mutex> lock(g_slotMutex);
+  if (StreamSlot* slot = find_slot(dev, stream, false)) slot->dirty = true;
 }
 
 extern "C" {
@@ -140,6 +161,36 @@ int vvcgpu_sizeof(int id)
 int vvcgpu_set_device(int device)
 {
   VVC_HIP(hipSetDevice(device));
+  return VVCGPU_OK;
+}
+int vvcgpu_stream_release(void* stream)
+{
+  int dev = 0;
+  VVC_HIP(hipGetDevice(&dev));
+  VVC_HIP(hipStreamSynchronize((hipStream_t)stream));                    // queued work may still read the buffers
+  std::lock_guard<std::mutex> lock(g_slotMutex);
+  for (size_t i = 0; i < g_slots.size(); i++)
+    if (g_slots[i].device == dev && g_slots[i].stream == (hipStream_t)stream)
+    {
+      free_slot(g_slots[i]);
+      g_slots.erase(g_slots.begin() + (ptrdiff_t)i);
+      break;
+    }
+  return VVCGPU_OK;
+}
+int vvcgpu_shutdown(void)
+{
+  int dev0 = 0;
+  VVC_HIP(hipGetDevice(&dev0));
+  std::lock_guard<std::mutex> lock(g_slotMutex);
+  for (auto& s : g_slots)
+  {
+    if (hipSetDevice(s.device) != hipSuccess) continue;
+    (void)hipDeviceSynchronize();
+    free_slot(s);
+  }
+  g_slots.clear();
+  VVC_HIP(hipSetDevice(dev0));
   return VVCGPU_OK;
 }
 }

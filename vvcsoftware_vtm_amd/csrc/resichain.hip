@@ -959,12 +959,23 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
     std::lock_guard<std::mutex> lock(imageMutex);
     if (!images[dev])
     {
+      // built on the null stream with blocking calls (not on the caller's stream: that would serialise every other thread's first call behind
+      // a stream of unknown length); the buffer is released again if any step fails
       void* p = nullptr;
       VVC_HIP(hipMalloc(&p, RC_TAB_HALVES * sizeof(_Float16)));
-      VVC_HIP(hipMemsetAsync(p, 0, RC_TAB_HALVES * sizeof(_Float16), st));      // row padding
-      hipLaunchKernelGGL(rc_build_tables_kernel, dim3(16), dim3(256), 0, st, static_cast<_Float16*>(p), tb.tr32, tb.tr32t);
-      VVC_LAUNCH_CHECK();
-      VVC_HIP(hipStreamSynchronize(st));                  // other streams may use the image right after this call returns
+      hipError_t e = hipMemset(p, 0, RC_TAB_HALVES * sizeof(_Float16));          // row padding
+      if (e == hipSuccess)
+      {
+        hipLaunchKernelGGL(rc_build_tables_kernel, dim3(16), dim3(256), 0, (hipStream_t)0, static_cast<_Float16*>(p), tb.tr32, tb.tr32t);
+        e = hipGetLastError();
+      }
+      if (e == hipSuccess) e = hipDeviceSynchronize();     // other streams may use the image right after this call returns
+      if (e != hipSuccess)
+      {
+        (void)hipFree(p);
+        vvcgpu_set_error("resi_chain_batch: building the f16 table image failed: %s", hipGetErrorString(e));
+        return VVCGPU_E_DEVICE;
+      }
       images[dev] = static_cast<_Float16*>(p);
     }
     image = images[dev];
@@ -984,7 +995,7 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
   int* fbList = lists + (size_t)RC_NCLS * n;
   hipLaunchKernelGGL(rc_classify_kernel, dim3(n < 1024 * RC_CLS_WGS ? cdiv(n, 1024) : RC_CLS_WGS), dim3(1024), 0, st, descs, n, hdr, lists, abs_sum,
                      counters + 16 * (cur ^ 1));
-  VVC_LAUNCH_CHECK();
+  VVC_LAUNCH_CHECK_COUNTERS(st);
   // (measured: forking the size classes onto library-owned side streams and joining them with events is SLOWER than launching them back to
   // back on the caller's stream, 0.158 vs 0.115 ms at 4K -- a cross-stream event costs more than these 20 us kernels gain)
   static const int separate = getenv("VVCGPU_RC_SEPARATE") ? 1 : 0;           // A/B timing switch: one launch per size class
@@ -992,7 +1003,7 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
   {
     hipLaunchKernelGGL(rc_chain_kernel, dim3(512), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, fbCount, fbList,
                        abs_sum, bit_depth, clp_min, clp_max, image, tb);
-    VVC_LAUNCH_CHECK();
+    VVC_LAUNCH_CHECK_COUNTERS(st);
   }
   else
   {
@@ -1009,12 +1020,12 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
                        lists + (size_t)RC_C8 * n, abs_sum, bit_depth, clp_min, clp_max, tb);
     hipLaunchKernelGGL(rc_small_kernel<4>, dim3(wg4), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_C4,
                        lists + (size_t)RC_C4 * n, abs_sum, bit_depth, clp_min, clp_max, tb);
-    VVC_LAUNCH_CHECK();
+    VVC_LAUNCH_CHECK_COUNTERS(st);
   }
   const int wgG = n < 1024 ? n : 1024;
   hipLaunchKernelGGL(rc_generic_kernel, dim3(wgG), dim3(64), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_CGEN,
                      lists + (size_t)RC_CGEN * n, fbCount, fbList, abs_sum, bit_depth, clp_min, clp_max, tb);
-  VVC_LAUNCH_CHECK();
+  VVC_LAUNCH_CHECK_COUNTERS(st);
   return VVCGPU_OK;
 }
 
