@@ -28,9 +28,17 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: HBM3E 8.0 TB/s spec (6.29 TB/s measured copy)
-# vector-instruction issue: one VALU wave-instruction per ~4.4 cycles and SIMD (tools/micro/valu_rate.hip on MI355X: v_sad_u16
-# 4.94 cycles with one wave per SIMD, 4.4 with two), 1024 SIMDs at 2.4 GHz
-VALU_ISSUE_PEAK = 1024 * 2.4e9 / 4.4
+# Issue model of the search kernels, per OPERATION (profiles/r03_valu_rate.txt, tools/micro/valu_rate.hip on MI355X): v_sad_u16 -- the only
+# two-sample SAD instruction for 10-bit data -- and every other half-rate operation (v_bfi, v_alignbit, v_pk_*, v_dot2, v_max) issue once per
+# 1.75 ns and SIMD from four waves per SIMD on, the whole chip busy (1.82 ns with two waves); full-rate operations (v_add_u32, v_and_b32)
+# once per 0.94 ns.  The encoding (VOP2 / VOP3) is not what decides: v_add_u32_e64 1.0 ns, v_max_u32 (VOP2) 1.71 ns.
+N_SIMD = 1024
+SAD_ISSUE_NS = 1.75
+SAD_ISSUE_PEAK = N_SIMD / (SAD_ISSUE_NS * 1e-9)          # v_sad_u16 wave-instructions per second, whole chip
+# the same instruction inside the kernels' real stage body (LDS reads and scalar loads beside it: the chip drops to 2.0 - 2.26 GHz) costs
+# 2.2 - 2.5 ns (profiles/r03_sadloop_rate.txt): no LDS-fed v_sad_u16 kernel gets beyond ~0.7 - 0.8 of SAD_ISSUE_PEAK
+SAD_STAGE_BODY_NS = 2.46
+SQ_CLOCK_HZ = 2.4e9                                        # SQ_ACTIVE_INST_* count quad-cycles: busy fraction below is against the maximum clock
 BASELINE_METRIC = "encoded frames/sec (bit-exact bitstream) at 4K10 RA QP32, 1/2/4/8 GPU"
 
 
@@ -102,8 +110,8 @@ def profile_traffic():
 
 
 def profile_valu():
-    """-> {kernel name: [(avg_us, SQ_INSTS_VALU per launch)]} from the SQ counter summary of the same committed profile (profiles/rNN_pmc_sq.csv),
-    {} when there is none for these kernel sources"""
+    """-> {kernel name: [(avg_us, SQ_INSTS_VALU per launch, SQ_ACTIVE_INST_VALU per launch)]} from the SQ counter summary of the same committed profile
+    (profiles/rNN_pmc_sq.csv), {} when there is none for these kernel sources"""
     import csv
     import glob
     metas = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_meta.json")))
@@ -117,7 +125,7 @@ def profile_valu():
     with open(path) as f:
         for r in csv.DictReader(f):
             if r.get("SQ_INSTS_VALU") and float(r["avg_us"]) > 0:
-                out.setdefault(r["kernel"], []).append((float(r["avg_us"]), float(r["SQ_INSTS_VALU"])))
+                out.setdefault(r["kernel"], []).append((float(r["avg_us"]), float(r["SQ_INSTS_VALU"]), float(r.get("SQ_ACTIVE_INST_VALU") or 0.0)))
     return out
 
 
@@ -327,14 +335,17 @@ def main():
     hint = wl.profile_kernel_hint(dom)
 
     def valu_busy_of(group, ms):
-        """executed vector instructions of the launch group's main kernel (committed SQ counter profile; the row whose duration is closest and
-        within 35 %) x the measured issue interval / time: how busy the vector pipes are, padding and bookkeeping instructions included"""
+        """fraction of the SIMD cycles in which a vector instruction of the launch group's main kernel executes: SQ_ACTIVE_INST_VALU (quad-cycles,
+        summed over the SIMDs) of the committed counter profile (the row whose duration is closest and within 35 %) x 4 / (1024 SIMDs x time x 2.4 GHz).
+        A measured busy count, so it cannot exceed 1; it reads LOW when the chip runs below 2.4 GHz (the searches hold ~2.0 GHz)."""
         h = wl.profile_kernel_hint(group)
         cands = [c for k, v in pvalu.items() if h and h in k for c in v]
         if not cands:
-            return None
+            return None, None
         best = min(cands, key=lambda c: abs(c[0] - ms * 1e3))
-        return best[1] / (best[0] * 1e-6) / VALU_ISSUE_PEAK if abs(best[0] - ms * 1e3) <= 0.35 * ms * 1e3 else None
+        if abs(best[0] - ms * 1e3) > 0.35 * ms * 1e3 or best[2] <= 0:
+            return None, None
+        return min(1.0, best[2] * 4.0 / (N_SIMD * best[0] * 1e-6 * SQ_CLOCK_HZ)), best[1]
 
     def hbm_of(group, ms):
         """HBM bytes per launch of the dominant launch group's main kernel from the committed profile: rows of that kernel, the one
@@ -361,15 +372,42 @@ def main():
             e["hbm_MB"] = round(hb / 1e6, 2)
             e["hbm_frac"] = round(hb / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
         if k in useful:
-            e["issue_frac"] = round(useful[k] / (v * 1e-3) / VALU_ISSUE_PEAK, 4)
-        vb = valu_busy_of(k, v)
+            e["issue_frac"] = round(useful[k] / (v * 1e-3) / SAD_ISSUE_PEAK, 4)
+        vb, ninst = valu_busy_of(k, v)
         if vb is not None:
             e["valu_busy"] = round(vb, 4)
+            e["valu_insts_M"] = round(ninst / 1e6, 2)
+            if k in useful:
+                e["useful_share_of_valu"] = round(useful[k] / ninst, 4)       # needed v_sad_u16 / executed vector instructions
         per_kernel[k] = e
 
     if rank == 0:
         pictures = args.steps * pps * world
         dk = per_kernel[dom]
+        ms_pic = dt / (args.steps * pps) * 1e3
+        uniq_total = sum(v for st_ in uniq.values() for v in st_.values() if isinstance(v, (int, float)))
+        alg_frac = achieved / HBM_PEAK_GBS
+        common = {"kernel": dom, "traffic": (dk["hbm_MB"] * 1e6 if "hbm_MB" in dk else None), "traffic_source": prof_src if "hbm_MB" in dk else None,
+                  "avg_launch_ms": kern_ms[dom], "launches_timed": n_timed.get(dom, 0),
+                  "alg_bytes_per_launch": abytes, "alg_GBps": achieved, "alg_frac": alg_frac,
+                  "hbm_frac": dk.get("hbm_frac"), "unique_frac": dk.get("unique_frac"), "valu_busy": dk.get("valu_busy"),
+                  "picture_unique_MB": round(uniq_total / 1e6, 1), "picture_unique_frac": round(uniq_total / (ms_pic * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
+        if dom in useful:
+            # the dominant kernel is a SAD search: bound by the issue rate of v_sad_u16, not by HBM (its window lives in LDS; counter traffic is
+            # a few per cent of the peak).  achieved / peak in wave-instructions per second; alg_* keeps SURVEY 8(d)'s algorithmic-byte figure.
+            ach = useful[dom] / (kern_ms[dom] * 1e-3)
+            roofline = dict(common, bound="valu-issue", achieved=ach / 1e9, peak=SAD_ISSUE_PEAK / 1e9, unit="G v_sad_u16 wave-instructions/s", frac=ach / SAD_ISSUE_PEAK,
+                            issue_frac=ach / SAD_ISSUE_PEAK, stage_body_frac=ach / (N_SIMD / (SAD_STAGE_BODY_NS * 1e-9)),
+                            note="frac = useful v_sad_u16 wave-instructions of the launch (positions x samples / 2 / 64) / time against one v_sad_u16 per 1.75 ns and SIMD "
+                                 "(profiles/r03_valu_rate.txt: per-operation issue intervals at 1 .. 8 waves per SIMD); stage_body_frac prices the same count at the 2.46 ns the "
+                                 "instruction costs inside the kernels' real stage body (LDS reads + scalar loads beside it, chip at 2.0 GHz: profiles/r03_sadloop_rate.txt); "
+                                 "valu_busy = SQ_ACTIVE_INST_VALU x 4 / (SIMDs x time x 2.4 GHz) of the committed counter profile (cannot exceed 1); alg_frac = SURVEY 8(d) "
+                                 "algorithmic bytes / time / 8 TB/s (every window sample counted once per position that reads it: not bytes that move); hbm_frac = counter "
+                                 "traffic by request size (TCC_EA0_RDREQ_32B/64B/128B + WRITE_SIZE) / time / peak; picture_unique_frac = every byte a picture's launches "
+                                 "must touch once / ms_per_picture / 8 TB/s")
+        else:
+            roofline = dict(common, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=alg_frac,
+                            note="achieved/frac follow SURVEY 8(d) (algorithmic bytes of the launch / time); hbm_frac = counter traffic by request size / time / peak")
         res = {
             "metric": BASELINE_METRIC + " [M1: hot-path pictures/s of the kernels behind the call sites, NOT EncoderApp fps]",
             "value": pictures / dt,
@@ -388,21 +426,12 @@ def main():
                                    "on %dx%d 10-bit 4:2:0 (BASELINE configs[3] picture format; configs[1] is the same workload at 1920x1080), planes resident in HBM; "
                                    "step = one intra period of %d pictures + hand-over of the last reconstructed picture as the next chunk's reference; "
                                    "NOT EncoderApp fps (RDO control loop out of scope)" % (args.width, args.height, pps),
-                       "width": args.width, "height": args.height, "bit_depth": bd, "pictures_per_step": pps, "ms_per_picture": dt / (args.steps * pps) * 1e3,
+                       "width": args.width, "height": args.height, "bit_depth": bd, "pictures_per_step": pps, "ms_per_picture": ms_pic,
                        "schedule": ("serial: one HIP stream, stage order" if args.serial else
                                     "overlap: reconstruction chain on the main stream, searches / refinement / statistics on three side streams "
                                     "(their real dependencies only); the dominant kernel is launched first and alone"),
                        "parallelism": "one chunk stream per GPU (intra-period sharding), one point-to-point boundary picture per step; no data-path collective"},
-            "roofline": {"bound": "hbm", "kernel": dom, "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s",
-                         "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": (dk["hbm_MB"] * 1e6 if "hbm_MB" in dk else None), "traffic_source": prof_src if "hbm_MB" in dk else None,
-                         "algorithmic_bytes_per_launch": abytes, "avg_launch_ms": kern_ms[dom], "launches_timed": n_timed.get(dom, 0),
-                         "note": "achieved/frac follow SURVEY 8(d) (algorithmic bytes of the launch / time); hbm_frac is the counter traffic "
-                                 "(FETCH_SIZE x2 + WRITE_SIZE of the committed profile, when it was taken from these kernel sources) / time / peak; "
-                                 "unique_frac counts every sample the launch must touch once; issue_frac = useful v_sad_u16 wave-instructions / time "
-                                 "against the measured vector issue rate (one per 4.4 cycles and SIMD); valu_busy = ALL executed vector instructions "
-                                 "(SQ_INSTS_VALU of the committed counter profile) against the same rate",
-                         "hbm_frac": dk.get("hbm_frac"), "unique_frac": dk.get("unique_frac"), "issue_frac": dk.get("issue_frac"), "valu_busy": dk.get("valu_busy")},
+            "roofline": roofline,
             "picture_hashes": {"gathered": len(hashes), "rank0_first_picture_md5": first_md5, "rank0_last_picture_md5": hashes.get("rank0")},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "serial_kernel_ms_per_picture": round(sum(stage_ms.values()), 4),

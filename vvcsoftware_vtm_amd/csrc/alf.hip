@@ -58,12 +58,15 @@ __device__ __forceinline__ void load_tile_clamped(short* __restrict__ lds, const
 }
 
 __global__ __launch_bounds__(320) void alf_classify_kernel(const Pel* __restrict__ src, int stride, int w, int h,
-                                                           int shift, uint16_t* __restrict__ cls)
+                                                           int shift, uint16_t* __restrict__ cls, int gx, int total, int xcd)
 {
   __shared__ short tile[CR * CP];
   __shared__ int quad[QN * QN * 4];
   const int tid = threadIdx.x;
-  const int tx0 = blockIdx.x * CT, ty0 = blockIdx.y * CT;
+  const int b = vvc_xcd_index((int)blockIdx.x, total, xcd);                 // tiles in raster order, one contiguous run per XCD
+  if (b < 0) return;
+  const int by = b / gx, bx = b - by * gx;
+  const int tx0 = bx * CT, ty0 = by * CT;
   load_tile_clamped<CP>(tile, src, stride, w, h, tx0 - 4, ty0 - 3, CR, tid, 320);
   __syncthreads();
 
@@ -277,13 +280,14 @@ __global__ __launch_bounds__(128) void alf_filter_kernel(const Pel* __restrict__
 
 // luma (classifier-driven 7x7 or 5x5) and both chroma planes (5x5, one filter) of a picture in one launch
 struct AlfPlane { const Pel* src; Pel* dst; const uint8_t* enable; int sstride, dstride; };
-struct AlfFilter3 { AlfPlane a[3]; const uint16_t* cls; int w, h, ctu, glx, nLuma, gcx, gcy, clpMin, clpMax; AlfCoeffs luma; short chroma[8]; };
+struct AlfFilter3 { AlfPlane a[3]; const uint16_t* cls; int w, h, ctu, glx, nLuma, gcx, gcy, clpMin, clpMax, total, xcd; AlfCoeffs luma; short chroma[8]; };
 template <bool IS7>
 __global__ __launch_bounds__(128) void alf_filter_picture_kernel(AlfFilter3 p)
 {
   __shared__ short tile[FR * FP];
   __shared__ short scoef[25 * 13 + 3];
-  const int b = blockIdx.x;
+  const int b = vvc_xcd_index2((int)blockIdx.x, p.nLuma, p.total, p.xcd);
+  if (b < 0) return;
   if (b < p.nLuma)
     alf_filter_body<IS7, true>(b % p.glx, b / p.glx, tile, scoef, p.a[0].src, p.a[0].sstride, p.a[0].dst, p.a[0].dstride, p.w, p.h, p.ctu, (p.w + p.ctu - 1) / p.ctu,
                                p.cls, p.luma, p.a[0].enable, p.clpMin, p.clpMax);
@@ -313,9 +317,9 @@ int vvcgpu_alf_classify(const vvc_pel* src, int src_stride, int width, int heigh
                 "alf_classify: width/height must be positive multiples of 4 (got %dx%d)", width, height);
   VVC_CHECK_ARG(src_stride >= width, "alf_classify: stride %d < width %d", src_stride, width);
   VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "alf_classify: bit depth %d outside 8..10", bit_depth);
-  dim3 grid(cdiv(width, CT), cdiv(height, CT));
-  hipLaunchKernelGGL(alf_classify_kernel, grid, dim3(320), 0, (hipStream_t)stream, src, src_stride, width, height,
-                     bit_depth + 4, cls);
+  const int gx = cdiv(width, CT), total = gx * cdiv(height, CT), xcd = vvc_xcd_on();
+  hipLaunchKernelGGL(alf_classify_kernel, dim3(vvc_xcd_grid(total, xcd)), dim3(320), 0, (hipStream_t)stream, src, src_stride, width, height,
+                     bit_depth + 4, cls, gx, total, xcd);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
@@ -395,8 +399,9 @@ int vvcgpu_alf_filter_picture(const vvcgpu_planes* src, const vvcgpu_planes* dst
   p.glx = cdiv(width, FW); p.nLuma = p.glx * cdiv(height, FH);
   p.gcx = cdiv(width >> 1, FW); p.gcy = cdiv(height >> 1, FH);
   const int total = p.nLuma + 2 * p.gcx * p.gcy;
-  if (filter_type) hipLaunchKernelGGL(alf_filter_picture_kernel<true>, dim3(total), dim3(128), 0, (hipStream_t)stream, p);
-  else             hipLaunchKernelGGL(alf_filter_picture_kernel<false>, dim3(total), dim3(128), 0, (hipStream_t)stream, p);
+  p.total = total; p.xcd = vvc_xcd_on();
+  if (filter_type) hipLaunchKernelGGL(alf_filter_picture_kernel<true>, dim3(vvc_xcd_grid2(p.nLuma, total, p.xcd)), dim3(128), 0, (hipStream_t)stream, p);
+  else             hipLaunchKernelGGL(alf_filter_picture_kernel<false>, dim3(vvc_xcd_grid2(p.nLuma, total, p.xcd)), dim3(128), 0, (hipStream_t)stream, p);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

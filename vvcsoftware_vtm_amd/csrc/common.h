@@ -59,6 +59,33 @@ int vvcgpu_tr_tables(VvcTrTables* out);
          vvcgpu_set_error("kernel launch failed: %s (%s:%d)", hipGetErrorString(e_), __FILE__, __LINE__); \
          return VVCGPU_E_DEVICE; } } while (0)
 
+// XCD-aware order of a one-dimensional grid (speed only, never correctness): workgroups are dealt round-robin over the 8 XCDs, each with its own L2.
+// A picture pass whose neighbouring tiles share halo lines gives every XCD one CONTIGUOUS run of the logical tile indices, so that a 128-byte
+// line is fetched from the fabric by one L2 instead of by up to three (profiles/r03_fabric_requests.csv: the picture passes read 1.6 - 3.1 x
+// their planes, every request a whole 128-byte line).  Launch vvc_xcd_grid(total) workgroups; padding workgroups get -1 and leave.
+// VVCGPU_NO_XCD_ORDER=1 (read per call) keeps the plain order: A/B switch.
+static inline int vvc_xcd_on() { return getenv("VVCGPU_NO_XCD_ORDER") ? 0 : 1; }
+static inline int vvc_xcd_grid(int total, int on) { return on ? ((total + 7) >> 3) << 3 : total; }
+// two index ranges [0, nA) and [nA, total) (luma tiles, then chroma tiles), each spread over the XCDs on its own: the heavy and the light part of a
+// launch both reach every XCD
+static inline int vvc_xcd_grid2(int nA, int total, int on) { return on ? vvc_xcd_grid(nA, 1) + vvc_xcd_grid(total - nA, 1) : total; }
+#ifdef __HIPCC__
+__device__ __forceinline__ int vvc_xcd_index(int bid, int total, int on)
+{
+  if (!on) return bid;
+  const int chunk = (total + 7) >> 3, i = (bid & 7) * chunk + (bid >> 3);
+  return i < total ? i : -1;
+}
+__device__ __forceinline__ int vvc_xcd_index2(int bid, int nA, int total, int on)
+{
+  if (!on) return bid;
+  const int gridA = ((nA + 7) >> 3) << 3;
+  if (bid < gridA) return vvc_xcd_index(bid, nA, 1);
+  const int i = vvc_xcd_index(bid - gridA, total - nA, 1);
+  return i < 0 ? -1 : nA + i;
+}
+#endif
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 
 __device__ __forceinline__ int clip3(int lo, int hi, int v) { return min(max(v, lo), hi); }

@@ -301,10 +301,11 @@ __global__ __launch_bounds__(128) void deblock_picture_kernel(Pel* __restrict__ 
                                                               int w, int h, int glx, int nLuma, int gcx, int gcy,
                                                               const uint8_t* __restrict__ edgeV, const uint8_t* __restrict__ edgeH,
                                                               const int8_t* __restrict__ qpLuma, const int8_t* __restrict__ qpChroma,
-                                                              vvcgpu_deblock_cfg cfg)
+                                                              vvcgpu_deblock_cfg cfg, int total, int xcd)
 {
   __shared__ short tile[TS * TP];
-  const int b = blockIdx.x;
+  const int b = vvc_xcd_index2((int)blockIdx.x, nLuma, total, xcd);
+  if (b < 0) return;
   if (b < nLuma) deblock_luma_body(dim3(b % glx, b / glx, 0), tile, Y, strideY, w, h, edgeV, edgeH, qpLuma, cfg);
   else
   {
@@ -332,8 +333,9 @@ extern "C" int vvcgpu_deblock(vvc_pel* y, int stride_y, vvc_pel* cb, vvc_pel* cr
   const int glx = cdiv(width + 4, TS), gly = cdiv(height + 4, TS);
   const int gcx = cdiv(width / 2 + 4, TS), gcy = cdiv(height / 2 + 4, TS);
   const int nLuma = glx * gly, nChroma = cb ? 2 * gcx * gcy : 0;
-  hipLaunchKernelGGL(deblock_picture_kernel, dim3(nLuma + nChroma), dim3(128), 0, st, y, stride_y, cb, cr, stride_c, width, height, glx, nLuma, gcx, gcy,
-                     edge_ver, edge_hor, qp_luma, qp_chroma, cfg);
+  const int xcd = vvc_xcd_on();
+  hipLaunchKernelGGL(deblock_picture_kernel, dim3(vvc_xcd_grid2(nLuma, nLuma + nChroma, xcd)), dim3(128), 0, st, y, stride_y, cb, cr, stride_c, width, height, glx, nLuma, gcx, gcy,
+                     edge_ver, edge_hor, qp_luma, qp_chroma, cfg, nLuma + nChroma, xcd);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

@@ -533,14 +533,15 @@ template <bool HAD>
 __global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
                                                      const vvcgpu_frac_blk* __restrict__ blocks, int nblocks, int bd, int cmin, int cmax,
                                                      vvcgpu_mvcost mv, const int* __restrict__ preds,
-                                                     vvcgpu_frac_result* __restrict__ results)
+                                                     vvcgpu_frac_result* __restrict__ results, int nWg, int xcd)
 {
   __shared__ __align__(16) short winS[4][24 * 26];
   __shared__ __align__(16) short hplS[4][3][24 * 18];      // [0] integer plane, [1] half plane (17 cols), [2] quarter planes
   __shared__ unsigned distS[4][16];                        // candidate distortions of the current stage (wave-uniform values)
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x * 4 + wave;
-  if (b >= nblocks) return;                                 // no workgroup barrier below
+  const int wg = vvc_xcd_index((int)blockIdx.x, nWg, xcd);
+  const int b = wg * 4 + wave;
+  if (wg < 0 || b >= nblocks) return;                       // no workgroup barrier below
   short* win = winS[wave];
   short* hp0 = hplS[wave][0];
   short* hp8 = hplS[wave][1];
@@ -650,12 +651,13 @@ int vvcgpu_frac_refine_launch(const vvc_pel* org, int org_stride, const vvc_pel*
   static const int f16Off = getenv("VVCGPU_NO_FRAC16") ? 1 : 0;           // A/B timing switch
   if (w == 16 && h == 16 && !f16Off)
   {
+    const int xcd = vvc_xcd_on();
     if (use_hadamard)
-      hipLaunchKernelGGL(frac16_kernel<true>, dim3(cdiv(nblocks, 4)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
-                         bit_depth, clp_min, clp_max, *mvcost_host, preds, results);
+      hipLaunchKernelGGL(frac16_kernel<true>, dim3(vvc_xcd_grid(cdiv(nblocks, 4), xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
+                         bit_depth, clp_min, clp_max, *mvcost_host, preds, results, cdiv(nblocks, 4), xcd);
     else
-      hipLaunchKernelGGL(frac16_kernel<false>, dim3(cdiv(nblocks, 4)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
-                         bit_depth, clp_min, clp_max, *mvcost_host, preds, results);
+      hipLaunchKernelGGL(frac16_kernel<false>, dim3(vvc_xcd_grid(cdiv(nblocks, 4), xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
+                         bit_depth, clp_min, clp_max, *mvcost_host, preds, results, cdiv(nblocks, 4), xcd);
     VVC_LAUNCH_CHECK();
     return VVCGPU_OK;
   }

@@ -299,12 +299,14 @@ constexpr int MC_LDS_DW = 23 * 12 + 16 * 12 + 128;                       // per 
 __global__ __launch_bounds__(256, 6) void mc_fast_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
                                                       Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs, int n,
                                                       int bd, int cmin, int cmax, int* __restrict__ list, int* __restrict__ count,
-                                                      int* __restrict__ nextCount)
+                                                      int* __restrict__ nextCount, int nWg, int xcd)
 {
   __shared__ __align__(16) unsigned ldsAll[4][MC_LDS_DW];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
   if (blockIdx.x == 0 && threadIdx.x < 16) nextCount[threadIdx.x] = 0;   // the WHOLE counter set of the next call on this stream (vvcgpu_counters protocol)
-  const int i0 = (blockIdx.x * 4 + wave) * 2;
+  const int wg = vvc_xcd_index((int)blockIdx.x, nWg, xcd);           // neighbouring PUs (shared window lines) in one XCD's L2
+  if (wg < 0) return;
+  const int i0 = (wg * 4 + wave) * 2;
   if (i0 >= n) return;
   unsigned* L = ldsAll[wave];
   const bool two = i0 + 1 < n;
@@ -555,8 +557,9 @@ int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel*
   int cur = 0;
   int* counters = vvcgpu_counters(st, &cur);                                // zeroed counter for this call; the kernel clears the other one
   if (!counters) return VVCGPU_E_DEVICE;
-  hipLaunchKernelGGL(mc_fast_kernel, dim3(cdiv(n, 8)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     dst_base, descs, n, bit_depth, clp_min, clp_max, list, counters + 16 * cur, counters + 16 * (cur ^ 1));
+  const int xcd = vvc_xcd_on();
+  hipLaunchKernelGGL(mc_fast_kernel, dim3(vvc_xcd_grid(cdiv(n, 8), xcd)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
+                     dst_base, descs, n, bit_depth, clp_min, clp_max, list, counters + 16 * cur, counters + 16 * (cur ^ 1), cdiv(n, 8), xcd);
   hipLaunchKernelGGL(mc_batch_kernel, dim3(n < 2048 ? n : 2048), dim3(64), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
                      dst_base, descs, list, counters + 16 * cur, bit_depth, clp_min, clp_max);
   VVC_LAUNCH_CHECK_COUNTERS(st);

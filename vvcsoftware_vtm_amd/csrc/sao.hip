@@ -159,10 +159,11 @@ __global__ __launch_bounds__(256) void sao_apply_kernel(const Pel* __restrict__ 
 
 // the three planes of a picture in one launch (a chroma plane alone is ~1 workgroup per CU: its own launch costs a latency floor)
 struct SaoPlaneArgs { const Pel* src; Pel* dst; const vvcgpu_sao_ctu* params; int sstride, dstride, w, h, ctuW, ctuH, wCtu, tpcShift, nWaveCols, wgEnd; };
-struct SaoApply3 { SaoPlaneArgs a[3]; int boShift, clpMin, clpMax; };
+struct SaoApply3 { SaoPlaneArgs a[3]; int boShift, clpMin, clpMax, total, xcd; };
 __global__ __launch_bounds__(256) void sao_apply_picture_kernel(SaoApply3 p)
 {
-  const int b = blockIdx.x;
+  const int b = vvc_xcd_index2((int)blockIdx.x, p.a[0].wgEnd, p.total, p.xcd);
+  if (b < 0) return;
   const int c = b < p.a[0].wgEnd ? 0 : b < p.a[1].wgEnd ? 1 : 2;
   const SaoPlaneArgs& a = c == 0 ? p.a[0] : c == 1 ? p.a[1] : p.a[2];
   const int first = c == 0 ? 0 : c == 1 ? p.a[0].wgEnd : p.a[1].wgEnd;
@@ -216,7 +217,8 @@ extern "C" int vvcgpu_sao_apply_picture(const vvcgpu_planes* src, const vvcgpu_p
     p.a[c] = SaoPlaneArgs{ src->p[c], dst->p[c], prm[c], src->stride[c], dst->stride[c], w, h, ctu, ctu, cdiv(w, ctu), tpcShift, nWaveCols, end };
   }
   p.boShift = bit_depth - 5; p.clpMin = clp_min; p.clpMax = clp_max;
-  hipLaunchKernelGGL(sao_apply_picture_kernel, dim3(end), dim3(256), 0, (hipStream_t)stream, p);
+  p.total = end; p.xcd = vvc_xcd_on();
+  hipLaunchKernelGGL(sao_apply_picture_kernel, dim3(vvc_xcd_grid2(p.a[0].wgEnd, end, p.xcd)), dim3(256), 0, (hipStream_t)stream, p);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

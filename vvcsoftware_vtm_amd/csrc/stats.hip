@@ -170,10 +170,11 @@ __global__ __launch_bounds__(1024) void sao_stats_kernel(const Pel* __restrict__
 
 // the three planes of a picture in one launch
 struct SaoStatsPlane { const Pel* org; const Pel* rec; long long* out; int ostride, rstride, w, h, ctu, wCtu, skipR, skipB, wgEnd; };
-struct SaoStats3 { SaoStatsPlane a[3]; const uint8_t* avail; int boShift; };
+struct SaoStats3 { SaoStatsPlane a[3]; const uint8_t* avail; int boShift, total, xcd; };
 __global__ __launch_bounds__(1024) void sao_stats_picture_kernel(SaoStats3 p)
 {
-  const int b = blockIdx.x;
+  const int b = vvc_xcd_index2((int)blockIdx.x, p.a[0].wgEnd, p.total, p.xcd);
+  if (b < 0) return;
   const int c = b < p.a[0].wgEnd ? 0 : b < p.a[1].wgEnd ? 1 : 2;
   const SaoStatsPlane& a = c == 0 ? p.a[0] : c == 1 ? p.a[1] : p.a[2];
   const int r = b - (c == 0 ? 0 : c == 1 ? p.a[0].wgEnd : p.a[1].wgEnd);
@@ -487,7 +488,7 @@ template <int C> struct AlfCtuLds
 struct AlfStatsPic
 {
   const Pel* org[3]; const Pel* rec[3]; int ostride[3], rstride[3];
-  int w, h, wCtu, nCtu;
+  int w, h, wCtu, nCtu, xcd;
   const uint16_t* cls;
   unsigned long long* out7; unsigned long long* out5; unsigned long long* outC[2];
 };
@@ -826,9 +827,11 @@ __global__ __launch_bounds__(ACT) void alf_stats_picture_kernel(AlfStatsPic a)
 {
   extern __shared__ __align__(16) unsigned char alfSmem[];
   AlfChromaPre<C> pre;
-  alf_chroma_prefetch<C>(a, blockIdx.x, pre);
-  alf_ctu_luma<C>(a, blockIdx.x, alfSmem);
-  alf_ctu_chroma<C>(a, blockIdx.x, alfSmem, pre);
+  const int ctuIdx = vvc_xcd_index((int)blockIdx.x, a.nCtu, a.xcd);
+  if (ctuIdx < 0) return;
+  alf_chroma_prefetch<C>(a, ctuIdx, pre);
+  alf_ctu_luma<C>(a, ctuIdx, alfSmem);
+  alf_ctu_chroma<C>(a, ctuIdx, alfSmem, pre);
 }
 
 // The 5x5 diamond is the centre of the 7x7 diamond under every transposition, so the 5x5 covariance record of a class is a sub-matrix of its 7x7
@@ -941,7 +944,8 @@ int vvcgpu_sao_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec,
   const size_t smem = tileBytes + 16 * 32 * 8 + 40 * 4;
   if (smem > 48 * 1024)
     VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sao_stats_picture_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  hipLaunchKernelGGL(sao_stats_picture_kernel, dim3(end), dim3(nthreads), smem, (hipStream_t)stream, p);
+  p.total = end; p.xcd = vvc_xcd_on();
+  hipLaunchKernelGGL(sao_stats_picture_kernel, dim3(vvc_xcd_grid2(p.a[0].wgEnd, end, p.xcd)), dim3(nthreads), smem, (hipStream_t)stream, p);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
@@ -969,17 +973,17 @@ int vvcgpu_alf_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec,
     // CTU form: one launch, every record written by the workgroup that owns the CTU
     AlfStatsPic a;
     for (int c = 0; c < 3; c++) { a.org[c] = org->p[c]; a.rec[c] = rec->p[c]; a.ostride[c] = org->stride[c]; a.rstride[c] = rec->stride[c]; }
-    a.w = width; a.h = height; a.wCtu = wCtu; a.nCtu = nCtu; a.cls = cls;
+    a.w = width; a.h = height; a.wCtu = wCtu; a.nCtu = nCtu; a.cls = cls; a.xcd = vvc_xcd_on();
     a.out7 = o7; a.out5 = reinterpret_cast<unsigned long long*>(out5); a.outC[0] = ocb; a.outC[1] = ocr;
     if (ctu_size == 128)
     {
       VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alf_stats_picture_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, AlfCtuLds<128>::bytes));
-      hipLaunchKernelGGL(alf_stats_picture_kernel<128>, dim3(nCtu), dim3(ACT), AlfCtuLds<128>::bytes, st, a);
+      hipLaunchKernelGGL(alf_stats_picture_kernel<128>, dim3(vvc_xcd_grid(nCtu, a.xcd)), dim3(ACT), AlfCtuLds<128>::bytes, st, a);
     }
     else
     {
       VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alf_stats_picture_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, AlfCtuLds<64>::bytes));
-      hipLaunchKernelGGL(alf_stats_picture_kernel<64>, dim3(nCtu), dim3(ACT), AlfCtuLds<64>::bytes, st, a);
+      hipLaunchKernelGGL(alf_stats_picture_kernel<64>, dim3(vvc_xcd_grid(nCtu, a.xcd)), dim3(ACT), AlfCtuLds<64>::bytes, st, a);
     }
     VVC_LAUNCH_CHECK();
     return VVCGPU_OK;
