@@ -182,8 +182,11 @@ def dry_launch(args):
         dist.init_process_group("gloo")
         assert dist.get_world_size() == args.gpus
     planes = [torch.full((8, 8), rank, dtype=torch.int16), torch.full((4, 4), rank + 100, dtype=torch.int16)]
-    got = shard.exchange_boundary(planes, rank, world)
+    rec = shard.empty_side_record()
+    rec["sub_merge_blk_num"][0, 3] = 1000 + rank
+    got, grec = shard.exchange_boundary(planes, rank, world, record=rec, return_record=True)
     ok = int(got[0][0, 0]) == (rank - 1) % world and int(got[1][0, 0]) == (rank - 1) % world + 100
+    ok = ok and (world == 1 or int(grec["sub_merge_blk_num"][0, 3]) == 1000 + (rank - 1) % world)
     seen = [None] * world
     if world > 1:
         dist.all_gather_object(seen, (rank, ok))
@@ -276,16 +279,32 @@ def main():
         sz, grid = timer.only[len("me/sad_search_"):].split("_")
         alone = (int(sz.split("x")[0]), 0 if grid == "9x9" else 1)
 
+    pending = [None]
+
     def one_step(tm):
-        """one intra period: pps pictures, then the chunk hand-over (next rank's reference picture; own picture at N = 1)"""
+        """one intra period: pps pictures, then the chunk hand-over (next rank's reference picture + the 88-byte side record; own picture at N = 1).
+        Asynchronous: the receives from rank r - 1 are posted when the chunk starts, the sends when the boundary picture exists, and the wait comes
+        only where the NEXT chunk first needs the picture (its reference slot is installed in front of its first picture) -- a rank never waits for
+        its neighbour at a step boundary."""
         nonlocal state, out
+        if pending[0] is not None:                          # the hand-over of the chunk before: needed now
+            boundary, _rec = pending[0].wait()
+            shard.install_reference(boundary, state["ref1"], wl.margins())
+        h = shard.Handover(out["final"], rank, world).post_recv()
         for _ in range(pps):
             state, out = wl.run_gpu(state, tm, overlap=overlap, alone=alone)
-        boundary = shard.exchange_boundary(out["final"], rank, world)
-        shard.install_reference(boundary, state["ref1"], wl.margins())
+        h.send(out["final"], shard.empty_side_record())     # (the kernels carry no encoder statistics: the record of a fresh encoder travels)
+        pending[0] = h
+
+    def finish_steps():
+        if pending[0] is not None:
+            boundary, _rec = pending[0].wait()
+            shard.install_reference(boundary, state["ref1"], wl.margins())
+            pending[0] = None
 
     for _ in range(args.warmup):
         one_step(None)
+    finish_steps()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -294,6 +313,7 @@ def main():
     t0 = time.perf_counter()
     for _ in range(args.steps):
         one_step(timer)
+    finish_steps()                                          # the last hand-over belongs to the timed region
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()

@@ -19,6 +19,53 @@
 #include "DecApp.h"
 
 #include "ref_wrap_kernels.h"
+#include "EncoderLib/EncSlice.h"
+#include "EncoderLib/EncCu.h"
+
+// ---- chunk hand-over side record: the encoder state OUTSIDE the decoded picture buffer that a worker starting at an
+// intra-period boundary needs to reproduce the sequential encoder -- the per-temporal-layer ATMVP statistics of EncCu (EncCu.h:119-122, filled by
+// CABACWriter.cpp:543-552, consumed by EncSlice.cpp:1250-1306).  EncGOP calls EncSlice::compressSlice from another translation unit, so GNU ld
+// --wrap reaches it (oracle/Makefile).  Environment (tools/chunk_exactness.py, tests/test_chunk_stitch.py):
+//   VVCGPU_ATMVP_POC=P     the boundary: the record belongs to the slice with POC == P (the first picture the re-entered run codes itself;
+//                          pictures before it IN CODING ORDER, e.g. POC 48/40/36/34 for P = 33, are decoded from the sequential stream)
+//   VVCGPU_ATMVP_DUMP=file the sequential run writes the record (22 uint32: size[10], num[10], prevPOC, clear flag) when it reaches that slice
+//   VVCGPU_ATMVP_LOAD=file the re-entered run installs the record before it codes that slice
+extern "C" void __real__ZN8EncSlice13compressSliceEP7Picturebb(EncSlice* self, Picture* pic, bool entire, bool fastDqp);
+extern "C" void __wrap__ZN8EncSlice13compressSliceEP7Picturebb(EncSlice* self, Picture* pic, bool entire, bool fastDqp)
+{
+  static int done = 0;
+  const char* pocS = getenv("VVCGPU_ATMVP_POC");
+  if (!done && pocS && pic->getPOC() == atoi(pocS))
+  {
+    done = 1;
+    EncCu* cu = self->m_pcCuEncoder;
+    unsigned rec[22];
+    if (const char* f = getenv("VVCGPU_ATMVP_DUMP"))
+    {
+      for (int i = 0; i < 10; i++) { rec[i] = cu->m_subMergeBlkSize[i]; rec[10 + i] = cu->m_subMergeBlkNum[i]; }
+      rec[20] = cu->m_prevPOC; rec[21] = cu->m_clearSubMergeStatic ? 1u : 0u;
+      if (FILE* fp = fopen(f, "wb")) { fwrite(rec, sizeof rec, 1, fp); fclose(fp); }
+    }
+    if (const char* f = getenv("VVCGPU_ATMVP_LOAD"))
+    {
+      FILE* fp = fopen(f, "rb");
+      if (fp && fread(rec, sizeof rec, 1, fp) == 1)
+      {
+        for (int i = 0; i < 10; i++) { cu->m_subMergeBlkSize[i] = rec[i]; cu->m_subMergeBlkNum[i] = rec[10 + i]; }
+        cu->m_prevPOC = rec[20]; cu->m_clearSubMergeStatic = rec[21] != 0;
+      }
+      if (fp) fclose(fp);
+    }
+  }
+  if (getenv("VVCGPU_ATMVP_TRACE"))
+  {
+    EncCu* cu = self->m_pcCuEncoder;
+    fprintf(stderr, "[atmvp] poc %d prev %d clear %d num", pic->getPOC(), cu->m_prevPOC, (int)cu->m_clearSubMergeStatic);
+    for (int i = 0; i < 6; i++) fprintf(stderr, " %u/%u", cu->m_subMergeBlkSize[i], cu->m_subMergeBlkNum[i]);
+    fprintf(stderr, "\n");
+  }
+  __real__ZN8EncSlice13compressSliceEP7Picturebb(self, pic, entire, fastDqp);
+}
 
 extern "C" {
 

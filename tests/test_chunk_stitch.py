@@ -77,3 +77,28 @@ def test_nightly_reencode_is_exact_without_atmvp(tmp_path):
     exact, same, fields = ce.run(enc=["--SubPuMvp=0", "--MaxNumMergeCand=5"], keep=str(tmp_path), out=lambda *a: None)
     assert exact and same and not fields
     assert open(tmp_path / "A.bin", "rb").read() == open(os.path.join(G, "noatmvp_A.bin"), "rb").read()
+
+
+def test_side_record_fixture_is_the_sequential_encoders_state():
+    """tests/golden/chunk/atmvp_record_poc33.bin is the 88-byte record the sequential encode (A) wrote when it reached POC 33, the first picture
+    the re-entered run codes itself (oracle/ref_wrap.cpp, VVCGPU_ATMVP_DUMP).  It parses as shard.SIDE_RECORD; the layers with statistics are the
+    ones coded between the intra picture and the boundary (POC 48/40/36/34 -> temporal layers 0..3; layer 0 clears, EncSlice.cpp:1256-1260)."""
+    import numpy as np
+    from vvcsoftware_vtm_amd import shard
+    rec = np.fromfile(os.path.join(G, "atmvp_record_poc33.bin"), dtype=shard.SIDE_RECORD)
+    assert rec.size == 1
+    assert rec["sub_merge_blk_size"][0].tolist() == [0, 4160, 6720, 2432, 0, 0, 0, 0, 0, 0]
+    assert rec["sub_merge_blk_num"][0].tolist() == [0, 2, 7, 3, 0, 0, 0, 0, 0, 0]
+    assert int(rec["prev_poc"][0]) == 32 and int(rec["clear_sub_merge_static"][0]) == 0
+    # the same bytes survive the tensor form the hand-over sends
+    assert shard.side_record_from_tensor(shard.side_record_tensor(rec)).tobytes() == rec.tobytes()
+
+
+@pytest.mark.skipif(not os.environ.get("VVCGPU_NIGHTLY"), reason="re-encodes 2 x 65 pictures with the reference encoder (about 5 minutes): VVCGPU_NIGHTLY=1")
+def test_nightly_reencode_with_side_record_is_exact_with_atmvp(tmp_path):
+    """SubPuMvp 1: the re-entered encode that installs the side record before its first picture produces the sequential encoder's bytes
+    (profiles/r03_chunk_record.txt holds the run)"""
+    exact, rec = ce.run_with_record(keep=str(tmp_path), out=lambda *a: None)
+    assert exact
+    assert rec == open(os.path.join(G, "atmvp_record_poc33.bin"), "rb").read()
+    assert open(tmp_path / "A.bin", "rb").read() == open(os.path.join(G, "atmvp_A.bin"), "rb").read()

@@ -25,7 +25,7 @@ def _worker(rank, world, port, q):
     from vvcsoftware_vtm_amd import shard
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    n_pictures = 160
+    n_pictures = 64 * world                              # two intra periods per rank
     mine = shard.chunk_assignment(n_pictures, world)[rank]
     hashes = {}
     g = torch.Generator().manual_seed(100 + rank)
@@ -35,10 +35,24 @@ def _worker(rank, world, port, q):
             planes = [torch.full((8, 8), poc, dtype=torch.int16), torch.full((4, 4), poc + 1, dtype=torch.int16)]
             hashes[poc] = shard.picture_hash(planes)
             last = planes
-    # hand-over: every rank passes the last reconstructed picture of its chunk to the next rank
-    got = shard.exchange_boundary(last, rank, world)
+    # hand-over: every rank passes the last reconstructed picture of its chunk AND the side record to the next rank.  Asynchronous form: the
+    # receives are posted first, "work" happens, the sends follow, the wait comes last -- and rank 0 sends late on purpose: nobody but its
+    # successor may be held up by that
+    h = shard.Handover(last, rank, world).post_recv()
+    rec = shard.empty_side_record()
+    rec["sub_merge_blk_size"][0, 2] = 7000 + rank
+    rec["prev_poc"] = mine[-1][1] - 1
+    if rank == 0:
+        import time
+        time.sleep(0.5)
+    h.send(last, rec)
+    got, grec = h.wait()
     prev_last_poc = shard.chunk_assignment(n_pictures, world)[(rank - 1) % world][-1][1] - 1
     ok = int(got[0][0, 0]) == prev_last_poc and int(got[1][0, 0]) == prev_last_poc + 1
+    ok = ok and int(grec["sub_merge_blk_size"][0, 2]) == 7000 + (rank - 1) % world and int(grec["prev_poc"][0]) == prev_last_poc
+    # the synchronous wrapper gives the same picture
+    got2 = shard.exchange_boundary(last, rank, world)
+    ok = ok and bool((got2[0] == got[0]).all())
     merged = shard.gather_hashes(hashes, world)
     dist.barrier()
     if rank == 0:
@@ -60,8 +74,11 @@ def test_chunk_assignment_covers_all_pictures_once():
         assert shard.boundary_owner(3, world) == 3 % world
 
 
-def test_two_process_shard_exchange_gather():
-    world = 2
+import pytest
+
+
+@pytest.mark.parametrize("world", [2, 8])
+def test_shard_exchange_gather(world):
     port = _free_port()
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
@@ -74,7 +91,17 @@ def test_two_process_shard_exchange_gather():
         assert p.exitcode == 0
     assert all(r[0] for r in res)
     full = [r for r in res if len(r) > 1][0]
-    assert full[1] == 160 and full[2] == [0, 1, 2] and full[3] == 159
+    assert full[1] == 64 * world and full[2] == [0, 1, 2] and full[3] == 64 * world - 1
+
+
+def test_side_record_layout():
+    sys.path.insert(0, ROOT)
+    from vvcsoftware_vtm_amd import shard
+    r = shard.empty_side_record()
+    assert r.nbytes == 88 and int(r["prev_poc"][0]) == 0xFFFFFFFF
+    t = shard.side_record_tensor(r)
+    assert t.dtype == torch.uint8 and t.numel() == 88
+    assert shard.side_record_from_tensor(t).tobytes() == r.tobytes()
 
 
 def _run_bench(args, env_extra=None, timeout=300):

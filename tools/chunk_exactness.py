@@ -159,13 +159,37 @@ def slice_header(nal, num_rps_sps, pps=None, cfg=None):
     return h
 
 
-def encode(yuv, binf, rec, frames, extra, size):
+def encode(yuv, binf, rec, frames, extra, size, env=None):
     cmd = [APP, "enc", "-c", CFG, "-i", yuv, "-wdt", str(size[0]), "-hgt", str(size[1]), "-fr", "30", "-f", str(frames), "-q", "32", "--InputBitDepth=8",
            "--InternalBitDepth=8", "--OutputBitDepth=8", "-b", binf, "-o", rec, "--SEIDecodedPictureHash=1"] + extra
     t0 = time.perf_counter()
-    r = subprocess.run(cmd, capture_output=True, text=True, timeout=3500)
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=3500, env=dict(os.environ, **(env or {})))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     return time.perf_counter() - t0, r.stdout
+
+
+def run_with_record(frames=65, poc=33, keep=None, size=(416, 240), out=print):
+    """The same experiment with the chunk hand-over SIDE RECORD (vvcsoftware_vtm_amd/shard.py SIDE_RECORD: the per-layer ATMVP statistics of the
+    sequential encoder at the boundary, oracle/ref_wrap.cpp): A writes the record when it reaches the first slice with POC >= poc, C is re-entered
+    at the boundary like B but installs the record before it codes that slice.  Returns (C byte-identical to A, record bytes)."""
+    with tempfile.TemporaryDirectory() as tmp0:
+        tmp = keep or tmp0
+        os.makedirs(tmp, exist_ok=True)
+        yuv = os.path.join(tmp, "in.yuv")
+        synth.write_yuv(yuv, synth.gen_yuv(size[0], size[1], frames, 8, 20261013), 8)
+        A, C, R = os.path.join(tmp, "A.bin"), os.path.join(tmp, "C.bin"), os.path.join(tmp, "record.bin")
+        ta, _ = encode(yuv, A, os.path.join(tmp, "A_rec.yuv"), frames, [], size, env={"VVCGPU_ATMVP_POC": str(poc), "VVCGPU_ATMVP_DUMP": R})
+        tc, _ = encode(yuv, C, os.path.join(tmp, "C_rec.yuv"), frames, ["--DebugBitstream=" + A, "--DebugPOC=%d" % poc], size,
+                       env={"VVCGPU_ATMVP_POC": str(poc), "VVCGPU_ATMVP_LOAD": R})
+        da, dc, rec = open(A, "rb").read(), open(C, "rb").read(), open(R, "rb").read()
+        out("chunk exactness with the side record: %d pictures %dx%d, SubPuMvp 1 (fixture cfg), boundary POC %d" % (frames, size[0], size[1], poc))
+        out("  A sequential encode (writes the record)  : %6.1f s, %d bytes, md5 %s" % (ta, len(da), hashlib.md5(da).hexdigest()))
+        out("  C re-entered, record installed           : %6.1f s, %d bytes, md5 %s" % (tc, len(dc), hashlib.md5(dc).hexdigest()))
+        import struct
+        v = struct.unpack("<22I", rec)
+        out("  record (%d bytes): subMergeBlkSize %s  subMergeBlkNum %s  prevPOC %d  clear %d" % (len(rec), list(v[:10]), list(v[10:20]), v[20], v[21]))
+        out("  C byte-identical to A: %s" % (da == dc))
+        return da == dc, rec
 
 
 def decode(binf, out):
@@ -187,8 +211,12 @@ def main():
     ap.add_argument("--enc", action="append", default=[], help="extra encoder option for both encodes, e.g. --enc=--SubPuMvp=0")
     ap.add_argument("--keep", default=None, help="directory to keep (and re-use) the streams in")
     ap.add_argument("--size", default="416x240")
+    ap.add_argument("--record", action="store_true", help="the run with the hand-over side record instead (A writes it, C installs it)")
     a = ap.parse_args()
     a.size = tuple(int(v) for v in a.size.split("x"))
+    if a.record:
+        run_with_record(a.frames, a.poc, a.keep, a.size)
+        return
     experiment(a, print)
 
 
