@@ -19,32 +19,37 @@
 // The quantiser works in the layout all three produce -- a lane holds four vertically consecutive coefficients of one column, an aligned quad
 // of lanes holds a 4x4 coefficient group: sign bit hiding is decided per quad with DPP quad permutes.
 #include "common.h"
+#include "mfma_tr.h"
 #include <mutex>
 
 namespace {
 
-typedef _Float16 h8 __attribute__((ext_vector_type(8)));
-typedef _Float16 h4 __attribute__((ext_vector_type(4)));
-typedef float f4 __attribute__((ext_vector_type(4)));
 typedef vvcgpu_resi_chain_desc RcDesc;
 
 __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
 #define RC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
-// ---- work lists (device): hdr[0..5] = counts of the classes 64, 32, 16, 8, 4, generic
-constexpr int RC_HDR = 8;
-enum { RC_C64 = 0, RC_C32, RC_C16, RC_C8, RC_C4, RC_CGEN, RC_NCLS };
+// ---- work lists (device): hdr[0 .. RC_NCLS) = counts of the classes, hdr[RC_FB] = count of the fall-back list
+constexpr int RC_HDR = 16;
+enum { RC_C64 = 0, RC_C32, RC_C16, RC_C8, RC_C4, RC_CGEN, RC_R6432, RC_R3264, RC_R6416, RC_R1664, RC_R3216, RC_R1632, RC_NCLS };
+constexpr int RC_FB = RC_NCLS;
+static_assert(RC_FB < RC_HDR, "the header is one 16-int counter set of vvcgpu_counters");
 
 __device__ __forceinline__ int rc_class(const RcDesc& d)
 {
-  if (d.w == d.h)
+  const int w = d.w, h = d.h;
+  if (w == h)
   {
-    if (d.w == 64) return RC_C64;
-    if (d.w == 32) return RC_C32;
-    if (d.w == 16) return RC_C16;
-    if (d.w == 8) return RC_C8;
-    if (d.w == 4) return RC_C4;
+    if (w == 64) return RC_C64;
+    if (w == 32) return RC_C32;
+    if (w == 16) return RC_C16;
+    if (w == 8) return RC_C8;
+    if (w == 4) return RC_C4;
+    return RC_CGEN;
   }
+  if (w == 64) return h == 32 ? RC_R6432 : h == 16 ? RC_R6416 : RC_CGEN;
+  if (w == 32) return h == 64 ? RC_R3264 : h == 16 ? RC_R3216 : RC_CGEN;
+  if (w == 16) return h == 64 ? RC_R1664 : h == 32 ? RC_R1632 : RC_CGEN;
   return RC_CGEN;
 }
 
@@ -232,17 +237,8 @@ __device__ __forceinline__ void rc_sbh_quad(int (&lv)[4], const int (&du)[4], co
 }
 
 // ---------------------------------------------------------------------------------------------------
-// Matrix-core path: f16 copies of the matrices in LDS.  Per type t and size n in {16, 32}: T (row-major T[j][k]) and its transpose; for 64
-// DCT-II only.  Rows are padded by 16 bytes, which spreads the 16 rows read by one ds_read_b64 / b128 over all banks.
-constexpr int RC_S16 = 16 * 24, RC_S32 = 32 * 40, RC_S64 = 64 * 72;                  // halves per matrix copy (row pitch n + 8)
-constexpr int RC_TYPE = 2 * RC_S16 + 2 * RC_S32;
-constexpr int RC_TAB_HALVES = 3 * RC_TYPE + 2 * RC_S64;
-__device__ __forceinline__ int rc_tab_off(int type, int n, int transposed)
-{
-  if (n == 64) return 3 * RC_TYPE + transposed * RC_S64;
-  return type * RC_TYPE + (n == 16 ? transposed * RC_S16 : 2 * RC_S16 + transposed * RC_S32);
-}
-// the LDS image is built ONCE per device in global memory (rc_build_tables_kernel) and copied by every workgroup with 16-byte loads
+// Matrix-core path (stages and the LDS matrix image: mfma_tr.h).  The image is built ONCE per device in global memory (rc_build_tables_kernel)
+// and copied by every workgroup with 16-byte loads.
 __global__ __launch_bounds__(256) void rc_build_tables_kernel(_Float16* __restrict__ tab, const int* __restrict__ tr32, const int* __restrict__ tr32t)
 {
   const int tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
@@ -261,306 +257,127 @@ __global__ __launch_bounds__(256) void rc_build_tables_kernel(_Float16* __restri
     tab[rc_tab_off(0, 64, 1) + r * 72 + k] = (_Float16)tr32t[1364 + e];
   }
 }
-// copies the matrices a TU size needs: sizes 16 / 32: the T and T^T copies of that size for the three types; 64: the DCT-II pair
-template <int N>
-__device__ __forceinline__ void rc_load_tables(_Float16* tab, const _Float16* __restrict__ image, int tid)
-{
-  constexpr int SZ = N == 16 ? 2 * RC_S16 : N == 32 ? 2 * RC_S32 : 2 * RC_S64;  // halves per type (T and T^T are adjacent)
-  constexpr int NT = N == 64 ? 1 : 3, NV = SZ / 8;
-#pragma unroll
-  for (int t = 0; t < NT; t++)
-  {
-    const int off = rc_tab_off(t, N, 0);
-    const uint4* src = reinterpret_cast<const uint4*>(image + off);
-    uint4* dst = reinterpret_cast<uint4*>(tab + off);
-    uint4 v[(NV + 255) / 256];
-#pragma unroll
-    for (int u = 0; u < (NV + 255) / 256; u++) if (tid + 256 * u < NV) v[u] = src[tid + 256 * u];
-#pragma unroll
-    for (int u = 0; u < (NV + 255) / 256; u++) if (tid + 256 * u < NV) dst[tid + 256 * u] = v[u];
-  }
-}
 
-// matrix operand of a product whose OTHER operand is a result tile: row `row` of the LDS matrix, the eight k values of k-step s in result-tile
-// order -- k = 32 s + 4 g + j (j < 4, tile 2 s) and 32 s + 16 + 4 g + (j - 4) (tile 2 s + 1)
-__device__ __forceinline__ h8 rc_mat_frag32(const _Float16* mat, int pitch, int row, int s, int g)
-{
-  const h4 a = *reinterpret_cast<const h4*>(mat + row * pitch + 32 * s + 4 * g);
-  const h4 b = *reinterpret_cast<const h4*>(mat + row * pitch + 32 * s + 16 + 4 * g);
-  return __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
-}
-__device__ __forceinline__ h4 rc_mat_frag16(const _Float16* mat, int pitch, int row, int g)
-{
-  return *reinterpret_cast<const h4*>(mat + row * pitch + 4 * g);
-}
-
-// 16-bit signed integer -> two signed 8-bit limbs as f16 (v = 256 hi + lo, lo in [-128, 127], hi in [-128, 128])
-__device__ __forceinline__ void rc_limbs(int v, _Float16& hi, _Float16& lo)
-{
-  const int l = (int)(signed char)v;
-  lo = (_Float16)(short)l;
-  hi = (_Float16)(short)((v - l) >> 8);
-}
-
-// K-step bookkeeping of a product with inner dimension KD: one 16x16x16 step for KD = 16, KD / 32 steps of 16x16x32 otherwise
-template <int KD> struct RcK { static constexpr int STEPS = KD == 16 ? 1 : KD / 32; };
-
-// D += A B for one 16x16 tile over all k-steps; operands as fragment arrays per k-step (h8) or one h4 when the inner dimension is 16
-template <int KD>
-__device__ __forceinline__ f4 rc_mma(const h8 (&a)[RcK<KD>::STEPS], const h8 (&b)[RcK<KD>::STEPS], f4 acc)
-{
-  if (KD == 16)
-  {
-    const h4 a4 = __builtin_shufflevector(a[0], a[0], 0, 1, 2, 3), b4 = __builtin_shufflevector(b[0], b[0], 0, 1, 2, 3);
-    return __builtin_amdgcn_mfma_f32_16x16x16f16(a4, b4, acc, 0, 0, 0);
-  }
-#pragma unroll
-  for (int s = 0; s < RcK<KD>::STEPS; s++) acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[s], b[s], acc, 0, 0, 0);
-  return acc;
-}
-
-// fragments (per k-step) of the matrix operand `row` of an LDS matrix with inner dimension KD, in result-tile k order
-template <int KD>
-__device__ __forceinline__ void rc_mat_frags(h8 (&f)[RcK<KD>::STEPS], const _Float16* mat, int row, int g)
-{
-  if (KD == 16)
-  {
-    const h4 a = rc_mat_frag16(mat, KD + 8, row, g);
-    f[0] = __builtin_shufflevector(a, a, 0, 1, 2, 3, 0, 1, 2, 3);
-  }
-  else
-  {
-#pragma unroll
-    for (int s = 0; s < RcK<KD>::STEPS; s++) f[s] = rc_mat_frag32(mat, KD + 8, row, s, g);
-  }
-}
-
-// fragments of a RESULT-derived operand: tiles t[0 .. KD/16) (four registers each: rows 4 g .. 4 g + 3 of tile), one limb (hi or lo) of each
-template <int KD>
-__device__ __forceinline__ void rc_tile_frags(h8 (&fh)[RcK<KD>::STEPS], h8 (&fl)[RcK<KD>::STEPS], const int (*t)[4])
-{
-  if (KD == 16)
-  {
-    _Float16 h[4], l[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) rc_limbs(t[0][j], h[j], l[j]);
-    fh[0] = h8{ h[0], h[1], h[2], h[3], h[0], h[1], h[2], h[3] };
-    fl[0] = h8{ l[0], l[1], l[2], l[3], l[0], l[1], l[2], l[3] };
-  }
-  else
-  {
-#pragma unroll
-    for (int s = 0; s < RcK<KD>::STEPS; s++)
-    {
-      _Float16 h[8], l[8];
-#pragma unroll
-      for (int j = 0; j < 4; j++) { rc_limbs(t[2 * s][j], h[j], l[j]); rc_limbs(t[2 * s + 1][j], h[4 + j], l[4 + j]); }
-      fh[s] = h8{ h[0], h[1], h[2], h[3], h[4], h[5], h[6], h[7] };
-      fl[s] = h8{ l[0], l[1], l[2], l[3], l[4], l[5], l[6], l[7] };
-    }
-  }
-}
-
-// One TU of N x N (N = 16, 32, 64) on the matrix cores.  Returns false (nothing written) when a residual sample lies outside +-1023
+// One TU of W x H (W, H in {16, 32, 64}) on the matrix cores.  Returns false (nothing written) when a residual sample lies outside +-1023
 // (precondition violated: the caller's generic path takes the TU).
-template <int N>
+template <int W, int H>
 __device__ __forceinline__ bool rc_tu_mfma(const RcDesc& d, const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                            TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int ti, int bd, int clpMin, int clpMax,
                                            const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff, int lane)
 {
-  constexpr int NJ = N > 32 ? 32 : N;                 // kept frequencies per dimension (zero-out beyond 32)
-  constexpr int RT = N / 16, JT = NJ / 16;            // tiles along a full / a kept dimension
-  constexpr int LN = N == 16 ? 4 : N == 32 ? 5 : 6;
+  typedef MtShape<W, H> S;
+  constexpr int LW = W == 16 ? 4 : W == 32 ? 5 : 6, LH = H == 16 ? 4 : H == 32 ? 5 : 6;
   const int c = lane & 15, g = lane >> 4;
   const Pel* org = orgBase + d.org_off;
   const Pel* pred = predBase + d.pred_off;
-  const _Float16* Th = tab + rc_tab_off(d.tr_hor, N, 0);
-  const _Float16* ThT = tab + rc_tab_off(d.tr_hor, N, 1);
-  const _Float16* Tv = tab + rc_tab_off(d.tr_ver, N, 0);
-  const _Float16* TvT = tab + rc_tab_off(d.tr_ver, N, 1);
+  const _Float16* Th = tab + rc_tab_off(d.tr_hor, W, 0);
+  const _Float16* ThT = tab + rc_tab_off(d.tr_hor, W, 1);
+  const _Float16* Tv = tab + rc_tab_off(d.tr_ver, H, 0);
+  const _Float16* TvT = tab + rc_tab_off(d.tr_ver, H, 1);
 
-  // ---- stage F1: M1[r][j1] = sum_k X[r][k] Th[j1][k]      (A = X from memory, B = Th rows from LDS, natural k order on both)
-  f4 m1[RT][JT];
-#pragma unroll
-  for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-    for (int jt = 0; jt < JT; jt++) m1[rt][jt] = f4{ 0.f, 0.f, 0.f, 0.f };
+  // ---- residual fragments of stage F1 (A = X from memory, natural k order)
+  h8 x[S::RT][S::XS];
   bool inRange = true;
-  if (N == 16)
+  if (W == 16)
   {
-    const pel4 o = *reinterpret_cast<const pel4*>(org + (size_t)c * d.org_stride + 4 * g);
-    const pel4 p = *reinterpret_cast<const pel4*>(pred + (size_t)c * d.pred_stride + 4 * g);
-    h4 a;
 #pragma unroll
-    for (int j = 0; j < 4; j++) { const int x = (int)o[j] - (int)p[j]; inRange = inRange && x >= -1023 && x <= 1023; a[j] = (_Float16)(short)x; }
-    const h4 b = *reinterpret_cast<const h4*>(Th + c * 24 + 4 * g);
-    m1[0][0] = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, m1[0][0], 0, 0, 0);
+    for (int rt = 0; rt < S::RT; rt++)
+    {
+      const pel4 o = *reinterpret_cast<const pel4*>(org + (size_t)(16 * rt + c) * d.org_stride + 4 * g);
+      const pel4 p = *reinterpret_cast<const pel4*>(pred + (size_t)(16 * rt + c) * d.pred_stride + 4 * g);
+      _Float16 a[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { const int v = (int)o[j] - (int)p[j]; inRange = inRange && v >= -1023 && v <= 1023; a[j] = (_Float16)(short)v; }
+      x[rt][0] = h8{ a[0], a[1], a[2], a[3], a[0], a[1], a[2], a[3] };
+    }
   }
   else
   {
-    pel8 o[RT][N / 32], p[RT][N / 32];
+    pel8 o[S::RT][S::XS], p[S::RT][S::XS];
 #pragma unroll
-    for (int rt = 0; rt < RT; rt++)
+    for (int rt = 0; rt < S::RT; rt++)
 #pragma unroll
-      for (int s = 0; s < N / 32; s++)
+      for (int s = 0; s < S::XS; s++)
       {
         o[rt][s] = *reinterpret_cast<const pel8*>(org + (size_t)(16 * rt + c) * d.org_stride + 32 * s + 8 * g);
         p[rt][s] = *reinterpret_cast<const pel8*>(pred + (size_t)(16 * rt + c) * d.pred_stride + 32 * s + 8 * g);
       }
 #pragma unroll
-    for (int s = 0; s < N / 32; s++)
-    {
-      h8 b[JT];
+    for (int rt = 0; rt < S::RT; rt++)
 #pragma unroll
-      for (int jt = 0; jt < JT; jt++) b[jt] = *reinterpret_cast<const h8*>(Th + (16 * jt + c) * (N + 8) + 32 * s + 8 * g);
+      for (int s = 0; s < S::XS; s++)
 #pragma unroll
-      for (int rt = 0; rt < RT; rt++)
-      {
-        h8 a;
-#pragma unroll
-        for (int j = 0; j < 8; j++) { const int x = (int)o[rt][s][j] - (int)p[rt][s][j]; inRange = inRange && x >= -1023 && x <= 1023; a[j] = (_Float16)(short)x; }
-#pragma unroll
-        for (int jt = 0; jt < JT; jt++) m1[rt][jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, b[jt], m1[rt][jt], 0, 0, 0);
-      }
-    }
+        for (int j = 0; j < 8; j++)
+        {
+          const int v = (int)o[rt][s][j] - (int)p[rt][s][j];
+          inRange = inRange && v >= -1023 && v <= 1023;
+          x[rt][s][j] = (_Float16)(short)v;
+        }
   }
   if (__builtin_amdgcn_ballot_w64(!inRange) != 0ull) return false;
 
-  // rounding shift between the forward stages (TrQuant.cpp:151-152, 214): the result tile holds M1[16 rt + 4 g + reg][16 jt + c]
-  const int s1 = LN + bd + 6 - 15 + 2, s2 = LN + 6 + 2;
-  int t1[JT][RT][4];                                   // [column tile][row tile]: the row tiles are the k dimension of the next product
-#pragma unroll
-  for (int rt = 0; rt < RT; rt++)
-#pragma unroll
-    for (int jt = 0; jt < JT; jt++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) t1[jt][rt][r] = ((int)m1[rt][jt][r] + (1 << (s1 - 1))) >> s1;
+  // rounding shifts of the forward stages (TrQuant.cpp:151-152, 214)
+  const int s1 = LW + bd + 6 - 15 + 2, s2 = LH + 6 + 2;
+  int t1[S::JT][S::RT][4];                             // [column tile][row tile]: the row tiles are the k dimension of the next product
+  mt_fwd1<W, H>(t1, x, Th, s1, c, g);
+  int cf[S::IT][S::JT][4];                             // [row tile of C (vertical frequency)][column tile (horizontal frequency)]
+  mt_fwd2<W, H>(cf, t1, Tv, s2, c, g);
 
-  // ---- stage F2: C[j2][j1] = sum_r Tv[j2][r] M1[r][j1]     (A = Tv rows from LDS in result-tile k order, B = M1 limbs)
-  int cf[JT][JT][4];                                   // [row tile of C (j2)][column tile (j1)]
-  {
-    h8 bh[JT][RcK<N>::STEPS], bl[JT][RcK<N>::STEPS];
+  // ---- quantiser: tile (it, jt) holds rows 16 it + 4 g + reg, column 16 jt + c; the quad c >> 2 of row group g is one coefficient group
+  const RcQ q = rc_qparams(W, H, d.qp, bd, d.intra_slice, d.sign_hiding);
+  const unsigned short* inv = dqInv + scanOff[(LW - 1) * 6 + (LH - 1)];
+  int lv[S::IT][S::JT][4], du[S::IT][S::JT][4];
+  int sum = 0, lastCg = -1, cgIdx[S::IT][S::JT];
 #pragma unroll
-    for (int jt = 0; jt < JT; jt++) rc_tile_frags<N>(bh[jt], bl[jt], t1[jt]);
+  for (int it = 0; it < S::IT; it++)
 #pragma unroll
-    for (int mt = 0; mt < JT; mt++)
-    {
-      h8 a[RcK<N>::STEPS];
-      rc_mat_frags<N>(a, Tv, 16 * mt + c, g);
-#pragma unroll
-      for (int jt = 0; jt < JT; jt++)
-      {
-        const f4 hi = rc_mma<N>(a, bh[jt], f4{ 0.f, 0.f, 0.f, 0.f }), lo = rc_mma<N>(a, bl[jt], f4{ 0.f, 0.f, 0.f, 0.f });
-#pragma unroll
-        for (int r = 0; r < 4; r++) cf[mt][jt][r] = ((((int)hi[r]) << 8) + (int)lo[r] + (1 << (s2 - 1))) >> s2;
-      }
-    }
-  }
-
-  // ---- quantiser: tile (mt, jt) holds rows 16 mt + 4 g + reg, column 16 jt + c; the quad c >> 2 of row group g is one coefficient group
-  const RcQ q = rc_qparams(N, N, d.qp, bd, d.intra_slice, d.sign_hiding);
-  const unsigned short* inv = dqInv + scanOff[(LN - 1) * 6 + (LN - 1)];
-  int lv[JT][JT][4], du[JT][JT][4];
-  int sum = 0, lastCg = -1, cgIdx[JT][JT];
-#pragma unroll
-  for (int mt = 0; mt < JT; mt++)
-#pragma unroll
-    for (int jt = 0; jt < JT; jt++)
+    for (int jt = 0; jt < S::JT; jt++)
     {
 #pragma unroll
-      for (int r = 0; r < 4; r++) { int mag; lv[mt][jt][r] = rc_quant_one(q, cf[mt][jt][r], du[mt][jt][r], mag); sum += mag; }
-      cgIdx[mt][jt] = (int)inv[(16 * mt + 4 * g) * N + 16 * jt + (c & ~3)] >> 4;
-      if (rc_cg_nonzero(lv[mt][jt])) lastCg = max(lastCg, cgIdx[mt][jt]);
+      for (int r = 0; r < 4; r++) { int mag; lv[it][jt][r] = rc_quant_one(q, cf[it][jt][r], du[it][jt][r], mag); sum += mag; }
+      cgIdx[it][jt] = (int)inv[(16 * it + 4 * g) * W + 16 * jt + (c & ~3)] >> 4;
+      if (rc_cg_nonzero(lv[it][jt])) lastCg = max(lastCg, cgIdx[it][jt]);
     }
   lastCg = wave_max_i32(lastCg);
   sum = wave_sum_i32(sum);
   if (lane == 0) absSumOut[ti] = (unsigned)sum;
   TCoeff* level = levelBase + d.level_off;
 #pragma unroll
-  for (int mt = 0; mt < JT; mt++)
+  for (int it = 0; it < S::IT; it++)
 #pragma unroll
-    for (int jt = 0; jt < JT; jt++)
+    for (int jt = 0; jt < S::JT; jt++)
     {
-      if (q.sbh) rc_sbh_quad(lv[mt][jt], du[mt][jt], cf[mt][jt], cgIdx[mt][jt] == lastCg, lane);
+      if (q.sbh) rc_sbh_quad(lv[it][jt], du[it][jt], cf[it][jt], cgIdx[it][jt] == lastCg, lane);
 #pragma unroll
-      for (int r = 0; r < 4; r++) level[(16 * mt + 4 * g + r) * N + 16 * jt + c] = lv[mt][jt][r];
+      for (int r = 0; r < 4; r++) level[(16 * it + 4 * g + r) * W + 16 * jt + c] = lv[it][jt][r];
     }
-  if (N == 64)                                          // zero-out region of the level array: columns >= 32 of rows < 32, then rows >= 32
-  {
-    const int4v z = { 0, 0, 0, 0 };
-    for (int e = lane; e < 32 * 8; e += 64) *reinterpret_cast<int4v*>(level + (e >> 3) * 64 + 32 + 4 * (e & 7)) = z;
-    for (int e = lane; e < 32 * 16; e += 64) *reinterpret_cast<int4v*>(level + 32 * 64 + 4 * e) = z;
-  }
+  // zero-out region of the level array: columns >= 32 of the kept rows, then the rows >= 32
+  const int4v z = { 0, 0, 0, 0 };
+  if (W == 64) for (int e = lane; e < S::HJ * 8; e += 64) *reinterpret_cast<int4v*>(level + (e >> 3) * 64 + 32 + 4 * (e & 7)) = z;
+  if (H == 64) for (int e = lane; e < 32 * W / 4; e += 64) *reinterpret_cast<int4v*>(level + 32 * W + 4 * e) = z;
 
-  // ---- de-quantiser; stage I1 (vertical): Y1T[i][r] = sum_k Cq[k][i] Tv[k][r]   (A = Cq^T: the result tile read as X^T -- row = its column c,
-  //      k = its rows; B = rows of Tv^T from LDS in result-tile k order)
-  int y1[RT][JT][4];                                   // [column tile (r)][row tile (i)]: the row tiles are the k dimension of the last product
+  // ---- de-quantiser, inverse stages, reconstruction
+  int y1[S::RT][S::JT][4];                             // [row tile (r)][frequency tile (i)]: the frequency tiles are the k dimension of the last product
   {
-    int cq[JT][JT][4];                                 // [column tile (i)][row tile (k)]
+    int cq[S::JT][S::IT][4];                           // [column tile (i)][row tile (k)]
 #pragma unroll
-    for (int mt = 0; mt < JT; mt++)
+    for (int it = 0; it < S::IT; it++)
 #pragma unroll
-      for (int jt = 0; jt < JT; jt++)
+      for (int jt = 0; jt < S::JT; jt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) cq[jt][mt][r] = rc_dequant_one(q, lv[mt][jt][r]);
-    h8 ah[JT][RcK<NJ>::STEPS], al[JT][RcK<NJ>::STEPS];
-#pragma unroll
-    for (int it = 0; it < JT; it++) rc_tile_frags<NJ>(ah[it], al[it], cq[it]);
-#pragma unroll
-    for (int rt = 0; rt < RT; rt++)
-    {
-      h8 b[RcK<NJ>::STEPS];
-      // rows of Tv^T have pitch N + 8; only k < NJ is read
-      if (NJ == 16) { const h4 v = rc_mat_frag16(TvT, N + 8, 16 * rt + c, g); b[0] = __builtin_shufflevector(v, v, 0, 1, 2, 3, 0, 1, 2, 3); }
-      else
-      {
-#pragma unroll
-        for (int s = 0; s < RcK<NJ>::STEPS; s++) b[s] = rc_mat_frag32(TvT, N + 8, 16 * rt + c, s, g);
-      }
-#pragma unroll
-      for (int it = 0; it < JT; it++)
-      {
-        const f4 hi = rc_mma<NJ>(ah[it], b, f4{ 0.f, 0.f, 0.f, 0.f }), lo = rc_mma<NJ>(al[it], b, f4{ 0.f, 0.f, 0.f, 0.f });
-#pragma unroll
-        for (int r = 0; r < 4; r++) y1[rt][it][r] = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[r]) << 8) + (int)lo[r] + 256) >> 9);
-      }
-    }
+        for (int r = 0; r < 4; r++) cq[jt][it][r] = rc_dequant_one(q, lv[it][jt][r]);
+    mt_inv1<W, H>(y1, cq, TvT, c, g);
   }
-
-  // ---- stage I2 (horizontal): RT[x][r] = sum_i Th[i][x] Y1T[i][r]   (A = rows of Th^T from LDS, B = Y1T limbs); the result tile holds
-  //      R[r = 16 rt + c][x = 16 xt + 4 g + reg]: four consecutive samples of one row per lane
   const int s2i = (6 + 15 - 1) - bd + 2;
   Pel* rec = recBase + d.rec_off;
+  mt_inv2<W, H>(y1, ThT, s2i, c, g, [&](int rt, int xt, const int (&resi)[4])
   {
-    h8 bh[RT][RcK<NJ>::STEPS], bl[RT][RcK<NJ>::STEPS];
+    const pel4 pv = *reinterpret_cast<const pel4*>(pred + (size_t)(16 * rt + c) * d.pred_stride + 16 * xt + 4 * g);
+    pel4 out;
 #pragma unroll
-    for (int rt = 0; rt < RT; rt++) rc_tile_frags<NJ>(bh[rt], bl[rt], y1[rt]);
-#pragma unroll
-    for (int xt = 0; xt < RT; xt++)
-    {
-      h8 a[RcK<NJ>::STEPS];
-      if (NJ == 16) { const h4 v = rc_mat_frag16(ThT, N + 8, 16 * xt + c, g); a[0] = __builtin_shufflevector(v, v, 0, 1, 2, 3, 0, 1, 2, 3); }
-      else
-      {
-#pragma unroll
-        for (int s = 0; s < RcK<NJ>::STEPS; s++) a[s] = rc_mat_frag32(ThT, N + 8, 16 * xt + c, s, g);
-      }
-#pragma unroll
-      for (int rt = 0; rt < RT; rt++)
-      {
-        const f4 hi = rc_mma<NJ>(a, bh[rt], f4{ 0.f, 0.f, 0.f, 0.f }), lo = rc_mma<NJ>(a, bl[rt], f4{ 0.f, 0.f, 0.f, 0.f });
-        const pel4 pv = *reinterpret_cast<const pel4*>(pred + (size_t)(16 * rt + c) * d.pred_stride + 16 * xt + 4 * g);
-        pel4 out;
-#pragma unroll
-        for (int r = 0; r < 4; r++)
-        {
-          const int resi = (short)clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[r]) << 8) + (int)lo[r] + (1 << (s2i - 1))) >> s2i);
-          out[r] = (short)clip3(clpMin, clpMax, (int)pv[r] + resi);
-        }
-        *reinterpret_cast<pel4*>(rec + (size_t)(16 * rt + c) * d.rec_stride + 16 * xt + 4 * g) = out;
-      }
-    }
-  }
+    for (int r = 0; r < 4; r++) out[r] = (short)clip3(clpMin, clpMax, (int)pv[r] + (int)(short)resi[r]);
+    *reinterpret_cast<pel4*>(rec + (size_t)(16 * rt + c) * d.rec_stride + 16 * xt + 4 * g) = out;
+  });
   return true;
 }
 
@@ -683,8 +500,8 @@ __device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, 
 // ---------------------------------------------------------------------------------------------------
 // matrix-core kernels, one per TU size (their register needs differ): persistent waves, wave i takes the TUs i, i + waves, ... of the class
 // list -- a shared work counter would be one same-address atomic per TU (~12 ns each: 100 us for a 4K picture)
-template <int N>
-__global__ __launch_bounds__(256, N == 64 ? 2 : 3) void rc_mfma_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase,
+template <int W, int H>
+__global__ __launch_bounds__(256, W * H >= 2048 ? 2 : 3) void rc_mfma_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase,
                                                                         Pel* __restrict__ recBase, TCoeff* __restrict__ levelBase,
                                                                         const RcDesc* __restrict__ descs, const int* __restrict__ count,
                                                                         const int* __restrict__ list, int* __restrict__ fbCount,
@@ -696,12 +513,13 @@ __global__ __launch_bounds__(256, N == 64 ? 2 : 3) void rc_mfma_kernel(const Pel
   const int tid = threadIdx.x, lane = tid & 63;
   const int total = count[0];
   if ((int)blockIdx.x * 4 >= total) return;
-  rc_load_tables<N>(tab, image, tid);
+  rc_load_tables<W>(tab, image, tid);
+  if (H != W) rc_load_tables<H>(tab, image, tid);
   __syncthreads();
   for (int item = blockIdx.x * 4 + (tid >> 6); item < total; item += gridDim.x * 4)
   {
     const int ti = list[item];
-    const bool done = rc_tu_mfma<N>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, dqInv, scanOff, lane);
+    const bool done = rc_tu_mfma<W, H>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, dqInv, scanOff, lane);
     if (!done && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti;                 // residual outside +-1023: the generic kernel takes it
   }
 }
@@ -889,14 +707,21 @@ __global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict_
   __shared__ RcSmallTab tabs;
   __shared__ int tmpAll[4][8 * 8 * 9];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int c64 = hdr[RC_C64], c32 = hdr[RC_C32], c16 = hdr[RC_C16], c8 = hdr[RC_C8], c4 = hdr[RC_C4];
-  const int i8 = (c8 + 7) >> 3, i4 = (c4 + 15) >> 4;                          // wave items of the lane-group classes
-  const int s64 = (c64 + 3) >> 2, s32 = (c32 + 3) >> 2, s8 = (i8 + 3) >> 2, s16 = (c16 + 3) >> 2, s4 = (i4 + 3) >> 2;
-  const int e64 = s64, e32 = e64 + s32, e8 = e32 + s8, e16 = e8 + s16, total = e16 + s4;
+  // slots (four wave items of one entry) in the order below: the longest items first, so that the short ones fill the machine while they run
+  constexpr int NORD = 11;
+  constexpr int ordCls[NORD] = { RC_C64, RC_R6432, RC_R3264, RC_C32, RC_R6416, RC_R1664, RC_C8, RC_R3216, RC_R1632, RC_C16, RC_C4 };
+  int cnt[NORD], items[NORD], end[NORD];
+  int total = 0;
+#pragma unroll
+  for (int k = 0; k < NORD; k++)
+  {
+    cnt[k] = hdr[ordCls[k]];
+    items[k] = ordCls[k] == RC_C8 ? (cnt[k] + 7) >> 3 : ordCls[k] == RC_C4 ? (cnt[k] + 15) >> 4 : cnt[k];   // lane-group classes: 8 / 16 TUs per item
+    total += (items[k] + 3) >> 2;
+    end[k] = total;
+  }
   if ((int)blockIdx.x >= total) return;
-  rc_load_tables<16>(tab, image, tid);
-  rc_load_tables<32>(tab, image, tid);
-  rc_load_tables<64>(tab, image, tid);
+  rc_load_all_tables(tab, image, tid);
   for (int e = tid; e < 3 * 80; e += 256)
   {
     const int t = e / 80, o = e - t * 80, nsz = o < 16 ? 4 : 8, oo = o < 16 ? o : o - 16;
@@ -906,33 +731,60 @@ __global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict_
   __syncthreads();
   for (int slot = blockIdx.x; slot < total; slot += gridDim.x)
   {
-    if (slot < e32 || (slot >= e8 && slot < e16))                             // matrix-core classes: one TU per wave
+    int k = 0, start = 0;
+#pragma unroll
+    for (int j = 0; j < NORD - 1; j++) if (slot >= end[j]) { k = j + 1; start = end[j]; }
+    const int item = (slot - start) * 4 + wave;
+    bool done = true;
+    int ti = 0;
+#define RC_MF(K, W_, H_)                                                                                                                      \
+    case K: if (item < cnt[K]) { ti = lists[(size_t)ordCls[K] * n + item];                                                                    \
+        done = rc_tu_mfma<W_, H_>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane); } break;
+    switch (k)
     {
-      const int cls = slot < e64 ? RC_C64 : slot < e32 ? RC_C32 : RC_C16;
-      const int item = (slot - (cls == RC_C64 ? 0 : cls == RC_C32 ? e64 : e8)) * 4 + wave;
-      const int cnt = cls == RC_C64 ? c64 : cls == RC_C32 ? c32 : c16;
-      if (item >= cnt) continue;
-      const int ti = lists[(size_t)cls * n + item];
-      bool done;
-      if (cls == RC_C64)      done = rc_tu_mfma<64>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
-      else if (cls == RC_C32) done = rc_tu_mfma<32>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
-      else                    done = rc_tu_mfma<16>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
-      if (!done && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti;             // residual outside +-1023: the generic kernel takes it
+    RC_MF(0, 64, 64) RC_MF(1, 64, 32) RC_MF(2, 32, 64) RC_MF(3, 32, 32) RC_MF(4, 64, 16) RC_MF(5, 16, 64) RC_MF(7, 32, 16) RC_MF(8, 16, 32) RC_MF(9, 16, 16)
+    case 6: if (item < items[6]) rc_small_group<8>(descs, lists + (size_t)RC_C8 * n, cnt[6], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    default: if (item < items[10]) rc_small_group<4>(descs, lists + (size_t)RC_C4 * n, cnt[10], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
     }
-    else if (slot < e8)
-    {
-      const int item = (slot - e32) * 4 + wave;
-      if (item < i8) rc_small_group<8>(descs, lists + (size_t)RC_C8 * n, c8, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
-    }
-    else
-    {
-      const int item = (slot - e16) * 4 + wave;
-      if (item < i4) rc_small_group<4>(descs, lists + (size_t)RC_C4 * n, c4, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
-    }
+#undef RC_MF
+    if (!done && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti;               // residual outside +-1023: the generic kernel takes it
   }
 }
 
 }  // namespace
+
+// f16 LDS image of the matrices (mfma_tr.h): built once per device
+const _Float16* vvcgpu_mfma_image(const VvcTrTables& tb)
+{
+  static std::mutex imageMutex;
+  static _Float16* images[64] = { nullptr };
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { vvcgpu_set_error("mfma image: device index"); return nullptr; }
+  std::lock_guard<std::mutex> lock(imageMutex);
+  if (!images[dev])
+  {
+    // built on the null stream with blocking calls (not on the caller's stream: that would serialise every other thread's first call behind
+    // a stream of unknown length); the buffer is released again if any step fails
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, RC_TAB_HALVES * sizeof(_Float16));
+    if (e != hipSuccess) { vvcgpu_set_error("mfma image: hipMalloc failed: %s", hipGetErrorString(e)); return nullptr; }
+    e = hipMemset(p, 0, RC_TAB_HALVES * sizeof(_Float16));          // row padding
+    if (e == hipSuccess)
+    {
+      hipLaunchKernelGGL(rc_build_tables_kernel, dim3(16), dim3(256), 0, (hipStream_t)0, static_cast<_Float16*>(p), tb.tr32, tb.tr32t);
+      e = hipGetLastError();
+    }
+    if (e == hipSuccess) e = hipDeviceSynchronize();     // other streams may use the image right after this call returns
+    if (e != hipSuccess)
+    {
+      (void)hipFree(p);
+      vvcgpu_set_error("building the f16 table image failed: %s", hipGetErrorString(e));
+      return nullptr;
+    }
+    images[dev] = static_cast<_Float16*>(p);
+  }
+  return images[dev];
+}
 
 extern "C" {
 
@@ -948,38 +800,8 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
   const int rt = vvcgpu_tr_tables(&tb);
   if (rt) return rt;
   hipStream_t st = (hipStream_t)stream;
-  // f16 LDS image of the matrices: built once per device
-  static std::mutex imageMutex;
-  static _Float16* images[64] = { nullptr };
-  int dev = 0;
-  VVC_HIP(hipGetDevice(&dev));
-  VVC_CHECK_ARG(dev >= 0 && dev < 64, "resi_chain_batch: device index %d", dev);
-  const _Float16* image;
-  {
-    std::lock_guard<std::mutex> lock(imageMutex);
-    if (!images[dev])
-    {
-      // built on the null stream with blocking calls (not on the caller's stream: that would serialise every other thread's first call behind
-      // a stream of unknown length); the buffer is released again if any step fails
-      void* p = nullptr;
-      VVC_HIP(hipMalloc(&p, RC_TAB_HALVES * sizeof(_Float16)));
-      hipError_t e = hipMemset(p, 0, RC_TAB_HALVES * sizeof(_Float16));          // row padding
-      if (e == hipSuccess)
-      {
-        hipLaunchKernelGGL(rc_build_tables_kernel, dim3(16), dim3(256), 0, (hipStream_t)0, static_cast<_Float16*>(p), tb.tr32, tb.tr32t);
-        e = hipGetLastError();
-      }
-      if (e == hipSuccess) e = hipDeviceSynchronize();     // other streams may use the image right after this call returns
-      if (e != hipSuccess)
-      {
-        (void)hipFree(p);
-        vvcgpu_set_error("resi_chain_batch: building the f16 table image failed: %s", hipGetErrorString(e));
-        return VVCGPU_E_DEVICE;
-      }
-      images[dev] = static_cast<_Float16*>(p);
-    }
-    image = images[dev];
-  }
+  const _Float16* image = vvcgpu_mfma_image(tb);
+  if (!image) return VVCGPU_E_DEVICE;
   // scratch: header (class counts, then the fall-back count), the six class lists, the fall-back list of the matrix-core kernels
   const size_t ints = (size_t)RC_NCLS * n + (size_t)n;
   int* ws = static_cast<int*>(vvcgpu_scratch(st, ints * sizeof(int)));
@@ -991,7 +813,7 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
   if (!counters) return VVCGPU_E_DEVICE;
   int* hdr = counters + 16 * cur;
   int* lists = ws;
-  int* fbCount = hdr + 7;
+  int* fbCount = hdr + RC_FB;
   int* fbList = lists + (size_t)RC_NCLS * n;
   hipLaunchKernelGGL(rc_classify_kernel, dim3(n < 1024 * RC_CLS_WGS ? cdiv(n, 1024) : RC_CLS_WGS), dim3(1024), 0, st, descs, n, hdr, lists, abs_sum,
                      counters + 16 * (cur ^ 1));
@@ -1008,12 +830,12 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
   else
   {
     const int wgM = cdiv(n, 4) < 1024 ? cdiv(n, 4) : 1024;
-#define RC_LAUNCH_MFMA(N, CLS)                                                                                                              \
-    hipLaunchKernelGGL(rc_mfma_kernel<N>, dim3(wgM), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + CLS,         \
+#define RC_LAUNCH_MFMA(W_, H_, CLS)                                                                                                             \
+    hipLaunchKernelGGL((rc_mfma_kernel<W_, H_>), dim3(wgM), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + CLS,         \
                        lists + (size_t)CLS * n, fbCount, fbList, abs_sum, bit_depth, clp_min, clp_max, image, tb.dqInv, tb.scanOff)
-    RC_LAUNCH_MFMA(64, RC_C64);
-    RC_LAUNCH_MFMA(32, RC_C32);
-    RC_LAUNCH_MFMA(16, RC_C16);
+    RC_LAUNCH_MFMA(64, 64, RC_C64); RC_LAUNCH_MFMA(64, 32, RC_R6432); RC_LAUNCH_MFMA(32, 64, RC_R3264);
+    RC_LAUNCH_MFMA(32, 32, RC_C32); RC_LAUNCH_MFMA(64, 16, RC_R6416); RC_LAUNCH_MFMA(16, 64, RC_R1664);
+    RC_LAUNCH_MFMA(32, 16, RC_R3216); RC_LAUNCH_MFMA(16, 32, RC_R1632); RC_LAUNCH_MFMA(16, 16, RC_C16);
 #undef RC_LAUNCH_MFMA
     const int wg8 = cdiv(n, 32) < 2048 ? cdiv(n, 32) : 2048, wg4 = cdiv(n, 64) < 2048 ? cdiv(n, 64) : 2048;
     hipLaunchKernelGGL(rc_small_kernel<8>, dim3(wg8), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_C8,

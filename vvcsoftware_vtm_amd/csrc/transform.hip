@@ -16,6 +16,7 @@
 //     every TU a group of 4 / 8 / 16 lanes (16 / 8 / 4 TUs per wave); the matrices of sizes <= 16 sit in LDS as int32,
 //     each lane group reading the rows of its own TU's transform types (same-address reads broadcast).
 #include "common.h"
+#include "mfma_tr.h"
 #include "tr_tables.inc"
 #include <mutex>
 
@@ -167,7 +168,7 @@ __device__ __forceinline__ int inv_dot(const int (&c)[S], const int* T)
 
 template <int S>
 __device__ __forceinline__ void inv_small_group(SmallShared& sh, int bin, int grp, int lane, int wave, int bd,
-                                                const TCoeff* __restrict__ coeffBase, Pel* __restrict__ resiBase)
+                                                const TCoeff* __restrict__ coeffBase, Pel* __restrict__ resiBase, const int* ldsCoef = nullptr)
 {
   constexpr int P = 64 / S;
   const int g = lane / S, r = lane % S, li = grp * P + g;
@@ -179,7 +180,7 @@ __device__ __forceinline__ void inv_small_group(SmallShared& sh, int bin, int gr
   {                                                 // stage 1 (vertical): lane = column r
     const bool on = act && r < w;
     int c[S];
-    const TCoeff* coeff = coeffBase + d.coeff_off;
+    const TCoeff* coeff = ldsCoef ? ldsCoef + g * (S * S) : coeffBase + d.coeff_off;     // fused de-quantiser: the group's TUs sit in LDS, S x S ints each
     bool fits = true;
 #pragma unroll
     for (int k = 0; k < S; k++) { c[k] = (on && k < h) ? coeff[k * w + r] : 0; fits = fits && (c[k] >= -(1 << 23)) && (c[k] < (1 << 23)); }
@@ -484,7 +485,7 @@ __device__ __forceinline__ void inv_stage2_fast(const int* __restrict__ tmpL, in
 }
 template <int W>
 __device__ __forceinline__ void inv_tu_large(const vvcgpu_tr_desc& d, const TCoeff* coeff, Pel* resi, int bd, int lane, int* tmpL,
-                                             const short* tabT)
+                                             const short* tabT, int pitch = W)            // pitch: row pitch of `coeff` (the fused de-quantiser keeps wj)
 {
   const int h = d.h;
   const int s2 = (6 + 15 - 1) - bd + 2;
@@ -494,14 +495,14 @@ __device__ __forceinline__ void inv_tu_large(const vvcgpu_tr_desc& d, const TCoe
   bool fast;
   switch (h)
   {
-  case 2:  fast = inv_stage1_fast<2>(coeff, W, wj, lane, TvT, tmpL, ph); break;
-  case 4:  fast = inv_stage1_fast<4>(coeff, W, wj, lane, TvT, tmpL, ph); break;
-  case 8:  fast = inv_stage1_fast<8>(coeff, W, wj, lane, TvT, tmpL, ph); break;
-  case 16: fast = inv_stage1_fast<16>(coeff, W, wj, lane, TvT, tmpL, ph); break;
-  case 32: fast = inv_stage1_fast<32>(coeff, W, wj, lane, TvT, tmpL, ph); break;
-  default: fast = inv_stage1_fast<64>(coeff, W, wj, lane, TvT, tmpL, ph); break;
+  case 2:  fast = inv_stage1_fast<2>(coeff, pitch, wj, lane, TvT, tmpL, ph); break;
+  case 4:  fast = inv_stage1_fast<4>(coeff, pitch, wj, lane, TvT, tmpL, ph); break;
+  case 8:  fast = inv_stage1_fast<8>(coeff, pitch, wj, lane, TvT, tmpL, ph); break;
+  case 16: fast = inv_stage1_fast<16>(coeff, pitch, wj, lane, TvT, tmpL, ph); break;
+  case 32: fast = inv_stage1_fast<32>(coeff, pitch, wj, lane, TvT, tmpL, ph); break;
+  default: fast = inv_stage1_fast<64>(coeff, pitch, wj, lane, TvT, tmpL, ph); break;
   }
-  if (!fast) inv_stage1_slow(coeff, W, h, wj, h > 32 ? 32 : h, lane, TvT, tmpL, ph);
+  if (!fast) inv_stage1_slow(coeff, pitch, h, wj, h > 32 ? 32 : h, lane, TvT, tmpL, ph);
   TR_WAVE_SYNC();
   inv_stage2_fast<W>(tmpL, ph, h, lane, s2, tabT + lg_off(d.tr_hor, W), resi, d.resi_stride);
   TR_WAVE_SYNC();
@@ -535,22 +536,178 @@ __global__ __launch_bounds__(256, 3) void tr_inv_large_kernel(const TCoeff* __re
   }
 }
 
-// indices of the large TUs of a batch: list[0] = count, list[1..] = descriptor indices (order irrelevant: TUs are independent)
-__global__ __launch_bounds__(256) void tr_collect_large_kernel(const vvcgpu_tr_desc* __restrict__ descs, int n, int* __restrict__ list)
+// ---------------------------------------------------------------------------------------------------
+// Large TUs whose sides are both 16, 32 or 64: the stages of mfma_tr.h on the matrix cores, one wave per TU.  A TU the matrix-core form
+// cannot take (residual outside +-1023 / a coefficient beyond 16 bits / rows not 16-byte aligned) is appended to the list of the dot2 kernels,
+// which run behind this one.
+template <int W, int H>
+__device__ __forceinline__ bool fwd_tu_mfma(const Pel* __restrict__ resi, int stride, int trHor, int trVer, TCoeff* __restrict__ coeff, int bd, int lane,
+                                            const _Float16* tab)
+{
+  typedef MtShape<W, H> S;
+  constexpr int LW = W == 16 ? 4 : W == 32 ? 5 : 6, LH = H == 16 ? 4 : H == 32 ? 5 : 6;
+  const int c = lane & 15, g = lane >> 4;
+  if ((((uintptr_t)resi | (uintptr_t)((size_t)stride * 2)) & (W == 16 ? 7u : 15u)) != 0) return false;
+  h8 x[S::RT][S::XS];
+  bool inRange = true;
+  if (W == 16)
+  {
+#pragma unroll
+    for (int rt = 0; rt < S::RT; rt++)
+    {
+      const pel4 v = *reinterpret_cast<const pel4*>(resi + (size_t)(16 * rt + c) * stride + 4 * g);
+      _Float16 a[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) { inRange = inRange && v[j] >= -1023 && v[j] <= 1023; a[j] = (_Float16)v[j]; }
+      x[rt][0] = h8{ a[0], a[1], a[2], a[3], a[0], a[1], a[2], a[3] };
+    }
+  }
+  else
+  {
+#pragma unroll
+    for (int rt = 0; rt < S::RT; rt++)
+#pragma unroll
+      for (int s = 0; s < S::XS; s++)
+      {
+        const pel8 v = *reinterpret_cast<const pel8*>(resi + (size_t)(16 * rt + c) * stride + 32 * s + 8 * g);
+#pragma unroll
+        for (int j = 0; j < 8; j++) { inRange = inRange && v[j] >= -1023 && v[j] <= 1023; x[rt][s][j] = (_Float16)v[j]; }
+      }
+  }
+  if (__builtin_amdgcn_ballot_w64(!inRange) != 0ull) return false;
+  const _Float16* Th = tab + rc_tab_off(trHor, W, 0);
+  const _Float16* Tv = tab + rc_tab_off(trVer, H, 0);
+  const int s1 = LW + bd + 6 - 15 + 2, s2 = LH + 6 + 2;
+  int t1[S::JT][S::RT][4];
+  mt_fwd1<W, H>(t1, x, Th, s1, c, g);
+  int cf[S::IT][S::JT][4];
+  mt_fwd2<W, H>(cf, t1, Tv, s2, c, g);
+#pragma unroll
+  for (int it = 0; it < S::IT; it++)
+#pragma unroll
+    for (int jt = 0; jt < S::JT; jt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) coeff[(16 * it + 4 * g + r) * W + 16 * jt + c] = cf[it][jt][r];
+  // zero-out: columns >= 32 of the kept rows, then the rows >= 32 (TrQuant.cpp:157-162)
+  const int4v z = { 0, 0, 0, 0 };
+  if (W == 64) for (int e = lane; e < S::HJ * 8; e += 64) *reinterpret_cast<int4v*>(coeff + (e >> 3) * 64 + 32 + 4 * (e & 7)) = z;
+  if (H == 64) for (int e = lane; e < 32 * W / 4; e += 64) *reinterpret_cast<int4v*>(coeff + 32 * W + 4 * e) = z;
+  return true;
+}
+
+// coeff: global or LDS, row pitch `pitch`; only the kept region (columns < WJ, rows < HJ) is read
+template <int W, int H>
+__device__ __forceinline__ bool inv_tu_mfma(const TCoeff* coeff, int pitch, Pel* __restrict__ resi, int stride, int trHor, int trVer, int bd, int lane,
+                                            const _Float16* tab)
+{
+  typedef MtShape<W, H> S;
+  const int c = lane & 15, g = lane >> 4;
+  int cq[S::JT][S::IT][4];
+  bool ok = true;
+#pragma unroll
+  for (int jt = 0; jt < S::JT; jt++)
+#pragma unroll
+    for (int it = 0; it < S::IT; it++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) { const int v = coeff[(16 * it + 4 * g + r) * pitch + 16 * jt + c]; ok = ok && fits16(v); cq[jt][it][r] = v; }
+  if (__builtin_amdgcn_ballot_w64(!ok) != 0ull) return false;
+  const _Float16* ThT = tab + rc_tab_off(trHor, W, 1);
+  const _Float16* TvT = tab + rc_tab_off(trVer, H, 1);
+  int y1[S::RT][S::JT][4];
+  mt_inv1<W, H>(y1, cq, TvT, c, g);
+  const int s2 = (6 + 15 - 1) - bd + 2;
+  const bool aligned = (((uintptr_t)resi | (uintptr_t)((size_t)stride * 2)) & 7u) == 0;
+  mt_inv2<W, H>(y1, ThT, s2, c, g, [&](int rt, int xt, const int (&v)[4])
+  {
+    Pel* dst = resi + (size_t)(16 * rt + c) * stride + 16 * xt + 4 * g;
+    if (aligned) *reinterpret_cast<pel4*>(dst) = pel4{ (short)v[0], (short)v[1], (short)v[2], (short)v[3] };
+    else
+    {
+#pragma unroll
+      for (int r = 0; r < 4; r++) dst[r] = (short)v[r];
+    }
+  });
+  return true;
+}
+
+// shape key of the matrix-core forms: both sides in {16, 32, 64}, not 16 x 16 (the lane-group kernels take that)
+__device__ __forceinline__ bool is_mfma_shape(int w, int h) { return (w == 16 || w == 32 || w == 64) && (h == 16 || h == 32 || h == 64) && (w > 16 || h > 16); }
+
+#define TR_MFMA_SHAPES(X) X(64, 64) X(64, 32) X(32, 64) X(32, 32) X(64, 16) X(16, 64) X(32, 16) X(16, 32)
+
+// lists: mfmaCount[0] TUs at mfmaList[0 ..]; failures are appended to large[1 + large[0]++]
+__global__ __launch_bounds__(256, 2) void tr_fwd_mfma_kernel(const Pel* __restrict__ resiBase, TCoeff* __restrict__ coeffBase,
+                                                             const vvcgpu_tr_desc* __restrict__ descs, const int* __restrict__ mfmaCount,
+                                                             const int* __restrict__ mfmaList, int* __restrict__ large, int bd,
+                                                             const _Float16* __restrict__ image)
+{
+  __shared__ __align__(16) _Float16 tab[RC_TAB_HALVES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int cnt = mfmaCount[0];
+  if ((int)blockIdx.x * 4 >= cnt) return;
+  rc_load_all_tables(tab, image, tid);
+  __syncthreads();
+  for (int k = blockIdx.x * 4 + (tid >> 6); k < cnt; k += gridDim.x * 4)
+  {
+    const int ti = mfmaList[k];
+    const vvcgpu_tr_desc d = descs[ti];
+    const Pel* resi = resiBase + d.resi_off;
+    TCoeff* coeff = coeffBase + d.coeff_off;
+    bool done = false;
+#define X(W_, H_) if (d.w == W_ && d.h == H_) done = fwd_tu_mfma<W_, H_>(resi, d.resi_stride, d.tr_hor, d.tr_ver, coeff, bd, lane, tab);
+    TR_MFMA_SHAPES(X)
+#undef X
+    if (!done && lane == 0) large[1 + atomicAdd(&large[0], 1)] = ti;
+  }
+}
+__global__ __launch_bounds__(256, 2) void tr_inv_mfma_kernel(const TCoeff* __restrict__ coeffBase, Pel* __restrict__ resiBase,
+                                                             const vvcgpu_tr_desc* __restrict__ descs, const int* __restrict__ mfmaCount,
+                                                             const int* __restrict__ mfmaList, int* __restrict__ large, int bd,
+                                                             const _Float16* __restrict__ image)
+{
+  __shared__ __align__(16) _Float16 tab[RC_TAB_HALVES];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int cnt = mfmaCount[0];
+  if ((int)blockIdx.x * 4 >= cnt) return;
+  rc_load_all_tables(tab, image, tid);
+  __syncthreads();
+  for (int k = blockIdx.x * 4 + (tid >> 6); k < cnt; k += gridDim.x * 4)
+  {
+    const int ti = mfmaList[k];
+    const vvcgpu_tr_desc d = descs[ti];
+    const TCoeff* coeff = coeffBase + d.coeff_off;
+    Pel* resi = resiBase + d.resi_off;
+    bool done = false;
+#define X(W_, H_) if (d.w == W_ && d.h == H_) done = inv_tu_mfma<W_, H_>(coeff, W_, resi, d.resi_stride, d.tr_hor, d.tr_ver, bd, lane, tab);
+    TR_MFMA_SHAPES(X)
+#undef X
+    if (!done && lane == 0) large[1 + atomicAdd(&large[0], 1)] = ti;
+  }
+}
+
+// indices of the large TUs of a batch, in two lists (order irrelevant: TUs are independent): ws[0] = count of the matrix-core list (entries at
+// ws[2 + n ..]), ws[1] = count of the dot2 list (entries at ws[2 ..]: `large` = ws + 1 is a count followed by its entries)
+__global__ __launch_bounds__(256) void tr_collect_large_kernel(const vvcgpu_tr_desc* __restrict__ descs, int n, int* __restrict__ ws, int useMfma)
 {
   const int ti = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
-  bool lg = false;
+  bool lg = false, mf = false;
   if (ti < n)
   {
     const int* f = reinterpret_cast<const int*>(descs + ti) + 5;            // bytes 20..27: w, h, tr_hor, tr_ver
     const int wh = f[0], tt = f[1];
-    lg = (signed char)(tt & 0xFF) != 3 && ((short)(wh & 0xFFFF) > 16 || (wh >> 16) > 16);
+    const int w = (short)(wh & 0xFFFF), h = wh >> 16;
+    lg = (signed char)(tt & 0xFF) != 3 && (w > 16 || h > 16);
+    mf = lg && useMfma && is_mfma_shape(w, h);
+    lg = lg && !mf;
   }
-  const unsigned long long m = __builtin_amdgcn_ballot_w64(lg);
-  int base = 0;
-  if (lane == 0 && m) base = atomicAdd(&list[0], (int)__popcll(m));
+  const unsigned long long m = __builtin_amdgcn_ballot_w64(lg), m2 = __builtin_amdgcn_ballot_w64(mf);
+  int base = 0, base2 = 0;
+  if (lane == 0 && m) base = atomicAdd(&ws[1], (int)__popcll(m));
+  if (lane == 0 && m2) base2 = atomicAdd(&ws[0], (int)__popcll(m2));
   base = __builtin_amdgcn_readfirstlane(base);
-  if (lg) list[1 + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = ti;
+  base2 = __builtin_amdgcn_readfirstlane(base2);
+  if (lg) ws[2 + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = ti;
+  if (mf) ws[2 + n + base2 + (int)__popcll(m2 & ((1ull << lane) - 1ull))] = ti;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1650,6 +1807,9 @@ static int ensure_tables()
   return VVCGPU_OK;
 }
 
+// A/B switch (read per call): VVCGPU_TR_NO_MFMA=1 keeps every large TU on the dot2 kernels
+static int tr_use_mfma() { return getenv("VVCGPU_TR_NO_MFMA") ? 0 : 1; }
+
 static int check_descs_args(const void* a, const void* b, const void* d, int n, int bd, const char* who)
 {
   VVC_CHECK_ARG(n >= 0, "%s: n %d", who, n);
@@ -1684,14 +1844,19 @@ int vvcgpu_tr_fwd_batch(const vvc_pel* resi_base, vvc_coef* coeff_base, const vv
   const int rt = ensure_tables();
   if (rt) return rt;
   hipStream_t st = (hipStream_t)stream;
-  int* list = nullptr;                               // cached per-stream scratch: indices of the large TUs
-  list = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * ((size_t)n + 1)));
-  if (!list) return VVCGPU_E_DEVICE;
-  VVC_HIP(hipMemsetAsync(list, 0, sizeof(int), st));
+  VvcTrTables tb;
+  const int rtb = vvcgpu_tr_tables(&tb);
+  if (rtb) return rtb;
+  const _Float16* image = vvcgpu_mfma_image(tb);
+  if (!image) return VVCGPU_E_DEVICE;
+  int* ws = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * (2 * (size_t)n + 2)));   // cached per-stream scratch: the two lists of large TUs
+  if (!ws) return VVCGPU_E_DEVICE;
+  VVC_HIP(hipMemsetAsync(ws, 0, 2 * sizeof(int), st));
   const int nb = cdiv(n, SM_DESCS), nl = cdiv(n, 4);
-  hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, descs, n, list);
+  hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, descs, n, ws, tr_use_mfma());
   hipLaunchKernelGGL(tr_fwd_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, resi_base, coeff_base, descs, n, bit_depth);
-  hipLaunchKernelGGL(tr_fwd_large_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, resi_base, coeff_base, descs, list, bit_depth);
+  hipLaunchKernelGGL(tr_fwd_mfma_kernel, dim3(nl < 512 ? nl : 512), dim3(256), 0, st, resi_base, coeff_base, descs, ws, ws + 2 + n, ws + 1, bit_depth, image);
+  hipLaunchKernelGGL(tr_fwd_large_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, resi_base, coeff_base, descs, ws + 1, bit_depth);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
@@ -1704,14 +1869,19 @@ int vvcgpu_tr_inv_batch(const vvc_coef* coeff_base, vvc_pel* resi_base, const vv
   const int rt = ensure_tables();
   if (rt) return rt;
   hipStream_t st = (hipStream_t)stream;
-  int* list = nullptr;
-  list = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * ((size_t)n + 1)));
-  if (!list) return VVCGPU_E_DEVICE;
-  VVC_HIP(hipMemsetAsync(list, 0, sizeof(int), st));
+  VvcTrTables tb;
+  const int rtb = vvcgpu_tr_tables(&tb);
+  if (rtb) return rtb;
+  const _Float16* image = vvcgpu_mfma_image(tb);
+  if (!image) return VVCGPU_E_DEVICE;
+  int* ws = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * (2 * (size_t)n + 2)));   // cached per-stream scratch: the two lists of large TUs
+  if (!ws) return VVCGPU_E_DEVICE;
+  VVC_HIP(hipMemsetAsync(ws, 0, 2 * sizeof(int), st));
   const int nb = cdiv(n, SM_DESCS), nl = cdiv(n, 4);
-  hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, descs, n, list);
+  hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, descs, n, ws, tr_use_mfma());
   hipLaunchKernelGGL(tr_inv_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, coeff_base, resi_base, descs, n, bit_depth);
-  hipLaunchKernelGGL(tr_inv_large_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, coeff_base, resi_base, descs, list, bit_depth);
+  hipLaunchKernelGGL(tr_inv_mfma_kernel, dim3(nl < 512 ? nl : 512), dim3(256), 0, st, coeff_base, resi_base, descs, ws, ws + 2 + n, ws + 1, bit_depth, image);
+  hipLaunchKernelGGL(tr_inv_large_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, coeff_base, resi_base, descs, ws + 1, bit_depth);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
