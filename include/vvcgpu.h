@@ -294,8 +294,9 @@ int vvcgpu_tr_inv_batch(const vvc_coef* coeff_base, vvc_pel* resi_base, const vv
  * One descriptor per TU; binary compatible with vvcgpu_tr_desc (level_off sits where coeff_off does).  level_base holds
  * the entropy-decoded levels, W x H int32 contiguous.  qp = QpParam::Qp of the component (bit-depth offset included).
  * dep_quant = 1 replays the 4-state machine over the diagonal 4x4-grouped scan (state transitions 32040, :782).
- * coeff_out (required workspace, same offsets as level_base; the reference's m_plTempCoeff) receives the de-quantised
- * coefficients; the two steps are separate launches for now.  Intermediate products are formed in 64 bits (the reference's `int` cannot overflow for levels in
+ * ONE launch: the de-quantiser and the inverse transform of a TU run in the same wave, the de-quantised coefficients stay in LDS.
+ * coeff_out (optional, may be NULL; same offsets as level_base; the reference's m_plTempCoeff) additionally receives the de-quantised
+ * coefficients.  Intermediate products are formed in 64 bits (the reference's `int` cannot overflow for levels in
  * the entropy-coding range +-32768, which is the precondition).                                                          */
 typedef struct vvcgpu_dqtr_desc {
   int64_t resi_off, level_off;          /* elements from resi_base (Pel) / level_base (TCoeff) */

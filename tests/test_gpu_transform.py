@@ -135,6 +135,35 @@ def test_dequant_tr_inv(bd):
     ops.dequant_tr_inv_batch(dev(lv), gres, ops.struct_to_device(d), len(d), bd, gcoef)
     assert np.array_equal(gcoef.cpu().numpy(), wcoef)
     assert np.array_equal(gres.cpu().numpy(), wres)
+    # without the coefficient output (they stay in LDS), and in shuffled order (mixed phases inside one workgroup's batch)
+    perm = rng.permutation(len(d))
+    gres2 = torch.full((roff,), 11, dtype=torch.int16, device="cuda")
+    ops.dequant_tr_inv_batch(dev(lv), gres2, ops.struct_to_device(np.ascontiguousarray(d[perm])), len(d), bd, None)
+    assert np.array_equal(gres2.cpu().numpy(), wres)
+
+
+def test_dequant_tr_inv_long_homogeneous_batches():
+    """the shapes of tools/n13_time.py (many TUs of one size: 64 / 16 / 4 descriptors per workgroup), aligned rows: vector stores of the
+    matrix-core form, every transform pair, both quantisers"""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(77)
+    bd = 10
+    for (w, h, n) in ((8, 8, 5000), (16, 16, 3000), (32, 32, 900), (64, 32, 300), (16, 64, 300), (4, 4, 9000), (32, 8, 700)):
+        d = np.zeros(n, ops.DQTR_DESC)
+        d["resi_off"] = d["level_off"] = np.arange(n) * w * h
+        d["resi_stride"], d["w"], d["h"] = w, w, h
+        pair = rng.integers(0, 3, n) if max(w, h) <= 32 and min(w, h) >= 4 else np.zeros(n, np.int64)
+        d["tr_hor"] = np.where(pair == 0, 0, np.where(pair == 1, 2, 1))
+        d["tr_ver"] = np.where(pair == 0, 0, np.where(pair == 1, 2, 2))
+        d["dep_quant"] = rng.integers(0, 2, n)
+        d["qp"] = rng.integers(22, 38, n)
+        lv = (rng.integers(-12, 13, n * w * h) * (rng.random(n * w * h) < 0.35)).astype(np.int32)
+        wres = np.zeros(n * w * h, np.int16)
+        wcoef = np.zeros(n * w * h, np.int32)
+        oracle().orc_dequant_tr_inv_batch(p(lv), p(wres), p(d), n, bd, p(wcoef))
+        gres = torch.zeros(n * w * h, dtype=torch.int16, device="cuda")
+        ops.dequant_tr_inv_batch(dev(lv), gres, ops.struct_to_device(d), n, bd, None)
+        assert np.array_equal(gres.cpu().numpy(), wres), (w, h)
 
 
 def test_scan_order_host_matches_golden():

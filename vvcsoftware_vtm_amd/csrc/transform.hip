@@ -32,6 +32,13 @@ __device__ __forceinline__ const int* tr32t(int type, int n) { return d_tr32t + 
 __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
 
 constexpr int MAXN = 64;
+// address-space-qualified views: behind a real call a plain pointer is a FLAT pointer -- every LDS access becomes a flat_load / flat_store that the
+// compiler can neither batch nor reorder against the global loads beside it (measured: the staging loop alone ran one memory round trip per element)
+typedef __attribute__((address_space(3))) int LdsInt;
+typedef const __attribute__((address_space(1))) int GlbCInt;
+typedef __attribute__((address_space(1))) int GlbInt;
+typedef __attribute__((address_space(1))) short GlbPel;
+
 typedef short short2v __attribute__((ext_vector_type(2)));
 
 __device__ __forceinline__ bool is_large_tu(const vvcgpu_tr_desc& d) { return d.tr_hor != 3 && (d.w > 16 || d.h > 16); }
@@ -596,8 +603,8 @@ __device__ __forceinline__ bool fwd_tu_mfma(const Pel* __restrict__ resi, int st
 }
 
 // coeff: global or LDS, row pitch `pitch`; only the kept region (columns < WJ, rows < HJ) is read
-template <int W, int H>
-__device__ __forceinline__ bool inv_tu_mfma(const TCoeff* coeff, int pitch, Pel* __restrict__ resi, int stride, int trHor, int trVer, int bd, int lane,
+template <int W, int H, class CP>
+__device__ __forceinline__ bool inv_tu_mfma(CP coeff, int pitch, Pel* __restrict__ resi, int stride, int trHor, int trVer, int bd, int lane,
                                             const _Float16* tab)
 {
   typedef MtShape<W, H> S;
@@ -678,7 +685,7 @@ __global__ __launch_bounds__(256, 2) void tr_inv_mfma_kernel(const TCoeff* __res
     const TCoeff* coeff = coeffBase + d.coeff_off;
     Pel* resi = resiBase + d.resi_off;
     bool done = false;
-#define X(W_, H_) if (d.w == W_ && d.h == H_) done = inv_tu_mfma<W_, H_>(coeff, W_, resi, d.resi_stride, d.tr_hor, d.tr_ver, bd, lane, tab);
+#define X(W_, H_) if (d.w == W_ && d.h == H_) done = inv_tu_mfma<W_, H_>((GlbCInt*)coeff, W_, resi, d.resi_stride, d.tr_hor, d.tr_ver, bd, lane, tab);
     TR_MFMA_SHAPES(X)
 #undef X
     if (!done && lane == 0) large[1 + atomicAdd(&large[0], 1)] = ti;
@@ -797,6 +804,384 @@ __global__ __launch_bounds__(256) void dequant_kernel(const TCoeff* __restrict__
     }
     out[pos] = (TCoeff)v;
     state = (32040 >> ((state << 2) + ((lv & 1) << 1))) & 3;
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// N1 in ONE launch: de-quantiser and inverse transform of a TU in the same wave, the de-quantised coefficients in LDS (the separate form above
+// wrote them to a workspace in HBM and read them back in a second and third launch).  A workgroup takes `per` consecutive descriptors and serves
+// them in phases: transform skip and the lane-group sizes (<= 16), then the matrix-core shapes, then the remaining large shapes; the tables of
+// the phases share one LDS region and are reloaded only when a workgroup's phase changes (homogeneous batches: never).
+struct DqP
+{
+  int dep, rightShift, shift;
+  long long scale, inMin, inMax, invQScale, add;
+};
+__device__ __forceinline__ DqP dq_params(const vvcgpu_dqtr_desc& d, int bd, int lw, int lh)
+{
+  DqP q;
+  const int transformShift = 15 - bd - ((lw + lh) >> 1);
+  const bool sqrt2 = ((lw + lh) & 1) != 0;
+  q.dep = d.dep_quant;
+  {
+    const int per = d.qp / 6, rem = d.qp - 6 * per;
+    q.rightShift = (sqrt2 ? 8 : 0) + (6 - (transformShift + per));
+    const int invq = rem == 0 ? 40 : rem == 1 ? 45 : rem == 2 ? 51 : rem == 3 ? 57 : rem == 4 ? 64 : 72;
+    q.scale = (long long)invq * (sqrt2 ? 181 : 1);
+    const int targetBits = min(16, 32 + q.rightShift - 7);
+    q.inMin = -(1ll << (targetBits - 1)); q.inMax = (1ll << (targetBits - 1)) - 1;
+  }
+  {
+    const int qpDQ = d.qp + 1, qpPer = qpDQ / 6, qpRem = qpDQ - 6 * qpPer;
+    int shift = 6 + 1 - qpPer - transformShift + (sqrt2 ? 8 : 0);
+    const int invq = qpRem == 0 ? 40 : qpRem == 1 ? 45 : qpRem == 2 ? 51 : qpRem == 3 ? 57 : qpRem == 4 ? 64 : 72;
+    long long s = (long long)invq * (sqrt2 ? 181 : 1);
+    if (shift < 0) { s <<= -shift; shift = 0; }
+    q.invQScale = s; q.shift = shift; q.add = (1ll << shift) >> 1;
+  }
+  return q;
+}
+__device__ __forceinline__ int dq_scalar(const DqP& q, int lv)
+{
+  const long long c = min(max((long long)lv, q.inMin), q.inMax);
+  const long long v = q.rightShift > 0 ? (c * q.scale + (1ll << (q.rightShift - 1))) >> q.rightShift : (c * q.scale) << -q.rightShift;
+  return (int)min(max(v, -(1ll << 15)), (1ll << 15) - 1);
+}
+
+// De-quantises one TU with a group of L lanes (L = 4, 8, 16: L TUs ... 64 / L TUs side by side in the wave; L = 64: the whole wave).  lig = lane
+// index inside the group; act = the group has a TU (all lanes of the wave must call: the scan uses shuffles).  The levels of the kept region
+// (x < wj, y < hj) are first staged in `stage` (LDS, row pitch wj); levels outside it (64-wide / 64-high TUs only) are read from memory.
+// `sink(pos, x, y, v)` receives every de-quantised coefficient (pos = raster index y w + x), each exactly once.
+// position of a scan index without the table (host_scan_order below is the definition): coefficient groups of g x g (g = 4, or 2 when a side is 2)
+// in up-right diagonal order over the gw x gh grid, the same order inside a group.  dq_cg: group index -> (gy << 8 | gx).
+__device__ __forceinline__ int dq_cg(int c, int gw, int gh)
+{
+  int D = 0, rem = c;
+  for (;;)
+  {
+    const int len = min(D, gh - 1) - max(0, D - gw + 1) + 1;
+    if (rem < len) break;
+    rem -= len; D++;
+  }
+  const int gy = min(D, gh - 1) - rem;
+  return (gy << 8) | (D - gy);
+}
+struct DqScan
+{
+  int lg, gw, gh, cur, ox, oy;                               // cur: the group (ox, oy) belongs to
+  __device__ __forceinline__ void init(int w, int h) { lg = ((w | h) & 3) ? 1 : 2; gw = w >> lg; gh = h >> lg; cur = -1; ox = oy = 0; }
+  __device__ __forceinline__ void pos(int s, int& x, int& y)
+  {
+    const int c = s >> (2 * lg), k = s & ((1 << (2 * lg)) - 1);
+    if (c != cur) { const int o = dq_cg(c, gw, gh); cur = c; ox = (o & 255) << lg; oy = (o >> 8) << lg; }
+    // in-group offsets of scan position k: 4 x 4: x 0010120123123233, y 0102103210321323; 2 x 2: x 0011, y 0101 (two bits each, k = 0 lowest)
+    const unsigned kx = lg == 2 ? 0xFB9E4910u : 0x50u, ky = lg == 2 ? 0xEDB1B184u : 0x44u;
+    x = ox + (int)((kx >> (2 * k)) & 3); y = oy + (int)((ky >> (2 * k)) & 3);
+  }
+};
+
+// De-quantises one TU with a group of L lanes (L = 4, 8, 16: 64 / L TUs side by side in the wave; L = 64: the whole wave).  lig = lane
+// index inside the group; act = the group has a TU (all lanes of the wave must call: the scan uses shuffles).  The levels of the kept region
+// (x < wj, y < hj) are first staged in `stage` (LDS, row pitch wj); levels outside it (64-wide / 64-high TUs only) are read from memory.
+// `sink(pos, x, y, v)` receives every de-quantised coefficient (pos = raster index y w + x), each exactly once.
+template <int L, class Sink>
+__device__ __forceinline__ void dq_group(const vvcgpu_dqtr_desc& d, const TCoeff* __restrict__ levelFlat, int bd, int lig, bool act, int* stageFlat, Sink sink)
+{
+  GlbCInt* level = (GlbCInt*)levelFlat;
+  LdsInt* stage = (LdsInt*)stageFlat;
+  const int w = act ? d.w : 2, h = act ? d.h : 2, lw = ilog2(w), lh = ilog2(h);
+  const int wj = w > 32 ? 32 : w, hj = h > 32 ? 32 : h, lwj = ilog2(wj);
+  const int cnt = act ? w * h : 0, kept = act ? wj * hj : 0;
+  for (int e0 = lig; e0 < kept; e0 += 16 * L)                // all loads of a pass in flight before the first LDS store
+  {
+    int v[16];
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int e = e0 + u * L; v[u] = e < kept ? level[((e >> lwj) << lw) + (e & (wj - 1))] : 0; }
+#pragma unroll
+    for (int u = 0; u < 16; u++) { const int e = e0 + u * L; if (e < kept) stage[e] = v[u]; }
+  }
+  TR_WAVE_SYNC();
+  const DqP q = dq_params(d, bd, lw, lh);
+  if (!act || !q.dep)
+  {
+    for (int pos = lig; pos < cnt; pos += L)
+    {
+      const int y = pos >> lw, x = pos & (w - 1);
+      const bool in = x < wj && y < hj;
+      const int lv = in ? stage[y * wj + x] : level[pos];
+      sink(pos, x, y, dq_scalar(q, lv));
+    }
+  }
+  const bool dep = act && q.dep;
+  // ---- dependent quantisation.  The 4-state machine (transitions 32040, DepQuant.cpp:782) is LINEAR over GF(2): with the state written as
+  // (hi, lo), step t maps it to (parity_t ^ lo, hi).  Entering step t, hi = xor of the parities of the earlier steps of the OTHER step parity
+  // (t - 1, t - 3, ...) and lo = xor of those of the same parity (t - 2, t - 4, ...), and only hi enters the reconstruction (state >> 1).  So a
+  // lane needs two prefix xors: every lane folds the parities of its own steps by step parity, a ballot + popcount gives the prefix over the
+  // lanes of the group, and the second pass reconstructs.  Steps run from the END of the scan (step t = scan index cnt - 1 - t; zero levels above
+  // the last significant one leave state 0 untouched, so no search for the last level is needed).
+  const bool cg4 = ((w | h) & 3) == 0;
+  const int laneId = (int)__builtin_amdgcn_mbcnt_hi(~0u, __builtin_amdgcn_mbcnt_lo(~0u, 0u));
+  const unsigned long long below = ((1ull << lig) - 1ull) << (laneId - lig);      // the lanes of my group in front of me
+  const bool fast32 = q.invQScale < (1ll << 14) && q.shift < 30;                     // |2 lv +- 1| < 2^17: the product stays inside 31 bits
+  const int scale32 = (int)q.invQScale, add32 = (int)q.add;
+  auto recon = [&](int lv, int hi) -> int
+  {
+    if (lv == 0) return 0;
+    const int qIdx = 2 * lv + (lv > 0 ? -hi : hi);
+    if (fast32) return min(max((qIdx * scale32 + add32) >> q.shift, -(1 << 15)), (1 << 15) - 1);
+    return (int)min(max(((long long)qIdx * q.invQScale + q.add) >> q.shift, -(1ll << 15)), (1ll << 15) - 1);
+  };
+  if (__builtin_amdgcn_ballot_w64(dep && !cg4) == 0ull)
+  {
+    // coefficient groups of 4 x 4 (every shape without a side of 2): a lane takes whole groups -- 16 levels in registers, the in-group scan unrolled
+    constexpr int rasterOf[16] = { 0, 4, 1, 8, 5, 2, 12, 9, 6, 3, 13, 10, 7, 14, 11, 15 };      // scan position k -> y * 4 + x inside the group
+    const int nCg = dep ? cnt >> 4 : 0, m = nCg > L ? nCg / L : 1;                              // groups per lane (power of two)
+    const int gw = w >> 2, gh = h >> 2;
+    auto load16 = [&](int T, int (&r)[16], int& ox, int& oy)
+    {
+      const int o = dq_cg(nCg - 1 - T, gw, gh);
+      ox = (o & 255) << 2; oy = (o >> 8) << 2;
+      if (ox < wj && oy < hj)
+      {
+#pragma unroll
+        for (int y = 0; y < 4; y++)
+        {
+          const int4v v = *reinterpret_cast<const __attribute__((address_space(3))) int4v*>(stage + (oy + y) * wj + ox);
+          r[4 * y] = v.x; r[4 * y + 1] = v.y; r[4 * y + 2] = v.z; r[4 * y + 3] = v.w;
+        }
+      }
+      else
+      {
+#pragma unroll
+        for (int i = 0; i < 16; i++) r[i] = level[((oy + (i >> 2)) << lw) + ox + (i & 3)];
+      }
+    };
+    int r[16], ox = 0, oy = 0;
+    int a0 = 0, a1 = 0;                                      // xor of the levels at even / odd steps (bit 0 is the parity)
+    for (int j = 0; j < m; j++)
+    {
+      const int T = lig * m + j;
+      if (T < nCg)
+      {
+        load16(T, r, ox, oy);
+#pragma unroll
+        for (int k = 0; k < 16; k++) { if (k & 1) a0 ^= r[rasterOf[k]]; else a1 ^= r[rasterOf[k]]; }      // step t = 16 T + 15 - k: even for odd k
+      }
+    }
+    const unsigned long long B0 = __builtin_amdgcn_ballot_w64((a0 & 1) != 0), B1 = __builtin_amdgcn_ballot_w64((a1 & 1) != 0);
+    int x0 = (int)__popcll(B0 & below) & 1, x1 = (int)__popcll(B1 & below) & 1;
+    for (int j = 0; j < m; j++)
+    {
+      const int T = lig * m + j;
+      if (T < nCg)
+      {
+        if (m > 1) load16(T, r, ox, oy);
+#pragma unroll
+        for (int k = 15; k >= 0; k--)
+        {
+          const int i = rasterOf[k], lv = r[i], x = ox + (i & 3), y = oy + (i >> 2);
+          const int hi = (k & 1) ? x1 : x0;                 // even step (odd k): xor over the odd steps before it
+          sink((y << lw) + x, x, y, recon(lv, hi));
+          if (k & 1) x0 ^= lv & 1; else x1 ^= lv & 1;
+        }
+      }
+    }
+  }
+  else
+  {
+    // some TU of the wave has a side of 2 (groups of 2 x 2): every TU of the wave goes step by step through the analytic scan
+    const bool on = dep;
+    const int C = on ? (cnt + L - 1) / L : 0;
+    const int t0 = lig * C, t1 = min(t0 + C, on ? cnt : 0);
+    DqScan sc;
+    sc.init(w, h);
+    int a0 = 0, a1 = 0;
+    for (int t = t0; t < t1; t++)
+    {
+      int x, y;
+      sc.pos(cnt - 1 - t, x, y);
+      const int lv = (x < wj && y < hj) ? stage[y * wj + x] : level[(y << lw) + x];
+      if (t & 1) a1 ^= lv; else a0 ^= lv;
+    }
+    const unsigned long long B0 = __builtin_amdgcn_ballot_w64((a0 & 1) != 0), B1 = __builtin_amdgcn_ballot_w64((a1 & 1) != 0);
+    int x0 = (int)__popcll(B0 & below) & 1, x1 = (int)__popcll(B1 & below) & 1;
+    for (int t = t0; t < t1; t++)
+    {
+      int x, y;
+      sc.pos(cnt - 1 - t, x, y);
+      const int lv = (x < wj && y < hj) ? stage[y * wj + x] : level[(y << lw) + x];
+      sink((y << lw) + x, x, y, recon(lv, (t & 1) ? x0 : x1));
+      if (t & 1) x1 ^= lv & 1; else x0 ^= lv & 1;
+    }
+  }
+  TR_WAVE_SYNC();
+}
+
+constexpr int DQ_UNI = ((LG_TAB * 2 + 15) & ~15) + 4 * 32 * (MAXN + 1) * 4;       // the largest phase: int16 matrices + four wave buffers of the dot2 form
+static_assert(DQ_UNI >= (int)sizeof(SmallShared) && DQ_UNI >= RC_TAB_HALVES * 2, "phase region");
+
+template <int S>
+__device__ __noinline__ void dq_small_group(SmallShared& sh, int bin, int grp, int lane, int wave, int bd, const TCoeff* __restrict__ levelBase,
+                                               Pel* __restrict__ resiBase, TCoeff* __restrict__ coeffOut, int* coefW)
+{
+  constexpr int P = 64 / S, L = S;
+  const int g = lane / S, lig = lane % S, li = grp * P + g;
+  const bool act = li < sh.cnt[bin];
+  const vvcgpu_dqtr_desc& d = reinterpret_cast<const vvcgpu_dqtr_desc&>(sh.d[sh.list[bin][act ? li : 0]]);
+  int* stageF = coefW + g * (S * S);
+  LdsInt* stage = (LdsInt*)stageF;
+  const int w = d.w;
+  GlbInt* out = coeffOut ? (GlbInt*)(coeffOut + d.level_off) : nullptr;
+  dq_group<L>(d, levelBase + d.level_off, bd, lig, act, stageF, [&](int pos, int x, int y, int v)
+  {
+    stage[y * w + x] = v;                                    // w <= 16: the kept region is the TU, pitch w
+    if (out) out[pos] = v;
+  });
+  inv_small_group<S>(sh, bin, grp, lane, wave, bd, nullptr, resiBase, coefW);
+}
+
+// shape dispatch of the fused kernel as real calls (inlined into one kernel the eight matrix-core bodies and the six dot2 bodies crash hipcc's simplifycfg)
+__device__ __noinline__ bool dq_inv_mfma(int w, int h, const TCoeff* coef, Pel* resi, int stride, int trHor, int trVer, int bd, int lane, const _Float16* ftab)
+{
+  bool done = false;
+#define X(W_, H_) if (w == W_ && h == H_) done = inv_tu_mfma<W_, H_>((const LdsInt*)coef, W_ > 32 ? 32 : W_, resi, stride, trHor, trVer, bd, lane, ftab);
+  TR_MFMA_SHAPES(X)
+#undef X
+  return done;
+}
+__device__ __noinline__ void dq_inv_large(const vvcgpu_tr_desc& d, const TCoeff* coef, Pel* resi, int bd, int lane, int* tmpL, const short* tabT, int wj)
+{
+  switch (d.w)
+  {
+  case 2:  inv_tu_large<2>(d, coef, resi, bd, lane, tmpL, tabT, wj); break;
+  case 4:  inv_tu_large<4>(d, coef, resi, bd, lane, tmpL, tabT, wj); break;
+  case 8:  inv_tu_large<8>(d, coef, resi, bd, lane, tmpL, tabT, wj); break;
+  case 16: inv_tu_large<16>(d, coef, resi, bd, lane, tmpL, tabT, wj); break;
+  case 32: inv_tu_large<32>(d, coef, resi, bd, lane, tmpL, tabT, wj); break;
+  default: inv_tu_large<64>(d, coef, resi, bd, lane, tmpL, tabT, wj); break;
+  }
+}
+
+// one TU of each phase as a real call (see above)
+__device__ __noinline__ void dq_ts_tu(const vvcgpu_dqtr_desc& d, const TCoeff* __restrict__ levelBase, Pel* __restrict__ resiBase, TCoeff* __restrict__ coeffOut,
+                                      int bd, int lane, int* coefW)
+{
+  const int lw = ilog2(d.w), lh = ilog2(d.h);
+  int shift = 15 - bd - ((lw + lh) >> 1), scale = 1;
+  if ((lw + lh) & 1) { shift += 7; scale = 181; }
+  GlbPel* resi = (GlbPel*)(resiBase + d.resi_off);
+  GlbInt* out = coeffOut ? (GlbInt*)(coeffOut + d.level_off) : nullptr;
+  const int stride = d.resi_stride;
+  dq_group<64>(d, levelBase + d.level_off, bd, lane, true, coefW, [&](int pos, int x, int y, int v)
+  {
+    if (out) out[pos] = v;
+    const int c = v * scale;
+    resi[(size_t)y * stride + x] = (short)(shift >= 0 ? (c + (shift ? 1 << (shift - 1) : 0)) >> shift : c << -shift);
+  });
+}
+// de-quantises into coefW (kept region, pitch wj) and, if asked, into coeffOut
+__device__ __noinline__ void dq_large_stage(const vvcgpu_dqtr_desc& d, const TCoeff* __restrict__ levelBase, TCoeff* __restrict__ coeffOut, int bd, int lane,
+                                            int* coefW)
+{
+  const int wj = d.w > 32 ? 32 : d.w;
+  GlbInt* out = coeffOut ? (GlbInt*)(coeffOut + d.level_off) : nullptr;
+  LdsInt* cw = (LdsInt*)coefW;
+  dq_group<64>(d, levelBase + d.level_off, bd, lane, true, coefW, [&](int pos, int x, int y, int v)
+  {
+    if (x < wj && y < 32) cw[y * wj + x] = v;
+    if (out) out[pos] = v;
+  });
+}
+
+__global__ __launch_bounds__(256, 2) void dqtr_fused_kernel(const TCoeff* __restrict__ levelBase, Pel* __restrict__ resiBase,
+                                                            const vvcgpu_dqtr_desc* __restrict__ descs, int n, int per, int bd,
+                                                            TCoeff* __restrict__ coeffOut, const _Float16* __restrict__ image, int useMfma)
+{
+  __shared__ __align__(16) unsigned char uni[DQ_UNI];
+  __shared__ __align__(16) int coef[4][1024];                // per wave: the kept region of a large TU / the TUs of a lane-group item
+  __shared__ int cntM, cntL, cntS[4];
+  __shared__ unsigned char listM[SM_DESCS], listL[SM_DESCS], binOf[SM_DESCS];
+  SmallShared& sh = *reinterpret_cast<SmallShared*>(uni);
+  _Float16* ftab = reinterpret_cast<_Float16*>(uni);
+  short* tabT = reinterpret_cast<short*>(uni);
+  int* tmpAll = reinterpret_cast<int*>(uni + ((LG_TAB * 2 + 15) & ~15));
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int* coefW = coef[wave];
+  int curTab = 0;                                            // 0 nothing, 1 lane-group tables, 2 f16 matrices, 3 int16 matrices (workgroup-uniform)
+  for (int batch = blockIdx.x; batch * per < n; batch += gridDim.x)
+  {
+    const int base = batch * per;
+    __syncthreads();                                         // the previous batch is done with the lists and the phase region
+    if (tid < 4) cntS[tid] = 0;
+    if (tid == 0) { cntM = 0; cntL = 0; }
+    __syncthreads();
+    // the descriptor copies and lists of the lane-group phase live in the phase region: only a batch that has such TUs touches it, so a run of
+    // large-TU batches keeps its matrices
+    if (tid < per && base + tid < n)
+    {
+      const vvcgpu_tr_desc d = reinterpret_cast<const vvcgpu_tr_desc*>(descs)[base + tid];
+      const int S = max((int)d.w, (int)d.h);
+      const int bin = d.tr_hor == 3 ? 0 : S <= 4 ? 1 : S == 8 ? 2 : S == 16 ? 3 : -1;
+      if (bin >= 0) { const int k = atomicAdd(&cntS[bin], 1); binOf[tid] = (unsigned char)(bin * 64 + k); }
+      else
+      {
+        binOf[tid] = 255;
+        if (useMfma && is_mfma_shape(d.w, d.h)) listM[atomicAdd(&cntM, 1)] = (unsigned char)tid;
+        else listL[atomicAdd(&cntL, 1)] = (unsigned char)tid;
+      }
+    }
+    __syncthreads();
+    const int anySmall = cntS[0] + cntS[1] + cntS[2] + cntS[3];
+    if (anySmall)
+    {
+      if (curTab > 1) { curTab = 0; }                        // the matrices are about to be overwritten
+      if (tid < 4) sh.cnt[tid] = cntS[tid];
+      if (tid < per && base + tid < n && binOf[tid] != 255)
+      {
+        sh.d[tid] = reinterpret_cast<const vvcgpu_tr_desc*>(descs)[base + tid];
+        sh.list[binOf[tid] >> 6][binOf[tid] & 63] = (unsigned char)tid;
+      }
+      __syncthreads();
+    }
+    if (anySmall)
+    {
+      if (curTab != 1) { small_tables(sh, tid); curTab = 1; __syncthreads(); }
+      for (int q = wave; q < sh.cnt[0]; q += 4)              // transform skip: the de-quantised value goes straight through the element-wise inverse
+        dq_ts_tu(reinterpret_cast<const vvcgpu_dqtr_desc&>(sh.d[sh.list[0][q]]), levelBase, resiBase, coeffOut, bd, lane, coefW);
+      for (int g = wave; g * 16 < sh.cnt[1]; g += 4) dq_small_group<4>(sh, 1, g, lane, wave, bd, levelBase, resiBase, coeffOut, coefW);
+      for (int g = wave; g * 8 < sh.cnt[2]; g += 4)  dq_small_group<8>(sh, 2, g, lane, wave, bd, levelBase, resiBase, coeffOut, coefW);
+      for (int g = wave; g * 4 < sh.cnt[3]; g += 4)  dq_small_group<16>(sh, 3, g, lane, wave, bd, levelBase, resiBase, coeffOut, coefW);
+    }
+    if (cntM)
+    {
+      if (curTab != 2)
+      {
+        __syncthreads();                                     // the lane-group phase is done with the region
+        rc_load_all_tables(ftab, image, tid); curTab = 2;
+        __syncthreads();
+      }
+      for (int q = wave; q < cntM; q += 4)
+      {
+        const vvcgpu_dqtr_desc d = descs[base + listM[q]];
+        dq_large_stage(d, levelBase, coeffOut, bd, lane, coefW);
+        const bool done = dq_inv_mfma(d.w, d.h, coefW, resiBase + d.resi_off, d.resi_stride, d.tr_hor, d.tr_ver, bd, lane, ftab);
+        if (!done && lane == 0) listL[atomicAdd(&cntL, 1)] = listM[q];          // a coefficient beyond 16 bits: the dot2 form's exact 32-bit stage takes the TU
+        TR_WAVE_SYNC();
+      }
+    }
+    __syncthreads();
+    if (cntL)
+    {
+      if (curTab != 3) { lg_load(tabT, d_tr32t, tid); curTab = 3; __syncthreads(); }
+      int* tmpL = tmpAll + wave * (32 * (MAXN + 1));
+      for (int q = wave; q < cntL; q += 4)
+      {
+        const vvcgpu_dqtr_desc dq = descs[base + listL[q]];
+        const vvcgpu_tr_desc& d = reinterpret_cast<const vvcgpu_tr_desc&>(dq);
+        dq_large_stage(dq, levelBase, coeffOut, bd, lane, coefW);
+        dq_inv_large(d, coefW, resiBase + d.resi_off, bd, lane, tmpL, tabT, d.w > 32 ? 32 : d.w);
+      }
+    }
   }
 }
 
@@ -1892,13 +2277,32 @@ int vvcgpu_dequant_tr_inv_batch(const vvc_coef* level_base, vvc_pel* resi_base, 
   static_assert(sizeof(vvcgpu_dqtr_desc) == sizeof(vvcgpu_tr_desc), "descriptor layouts must stay interchangeable");
   const int rc = check_descs_args(level_base, resi_base, descs, n, bit_depth, "dequant_tr_inv_batch");
   if (rc) return rc > 0 ? VVCGPU_OK : rc;
-  VVC_CHECK_ARG(coeff_out && coeff_out != level_base, "dequant_tr_inv_batch: coeff_out (workspace for the de-quantised coefficients) is required");
+  VVC_CHECK_ARG(coeff_out != level_base, "dequant_tr_inv_batch: coeff_out must not alias the levels");
   const int rt = ensure_tables();
   if (rt) return rt;
-  hipLaunchKernelGGL(dequant_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, level_base, coeff_out, descs, n, bit_depth);
+  hipStream_t st = (hipStream_t)stream;
+  static const int separate = getenv("VVCGPU_DQTR_SEPARATE") ? 1 : 0;         // A/B timing switch: the former three-step form (needs coeff_out)
+  if (separate && coeff_out)
+  {
+    hipLaunchKernelGGL(dequant_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, level_base, coeff_out, descs, n, bit_depth);
+    VVC_LAUNCH_CHECK();
+    // the descriptor is binary compatible with vvcgpu_tr_desc: the inverse transforms read the de-quantised coefficients at level_off
+    return vvcgpu_tr_inv_batch(coeff_out, resi_base, reinterpret_cast<const vvcgpu_tr_desc*>(descs), n, bit_depth, stream);
+  }
+  VvcTrTables tb;
+  const int rtb = vvcgpu_tr_tables(&tb);
+  if (rtb) return rtb;
+  const _Float16* image = vvcgpu_mfma_image(tb);
+  if (!image) return VVCGPU_E_DEVICE;
+  // descriptors per workgroup: 64 when the batch is long (lane-group TUs need many per wave), fewer when that would leave compute units idle
+  int per = SM_DESCS;
+  while (per > 4 && cdiv(n, per) < 1024) per >>= 1;
+  if (const char* e = getenv("VVCGPU_DQTR_PER")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) per = v; }   // tuning switch
+  const int nb = cdiv(n, per);
+  hipLaunchKernelGGL(dqtr_fused_kernel, dim3(nb < 512 ? nb : 512), dim3(256), 0, st, level_base, resi_base, descs, n, per, bit_depth, coeff_out, image,
+                     tr_use_mfma());
   VVC_LAUNCH_CHECK();
-  // the descriptor is binary compatible with vvcgpu_tr_desc: the inverse transforms read the de-quantised coefficients at level_off
-  return vvcgpu_tr_inv_batch(coeff_out, resi_base, reinterpret_cast<const vvcgpu_tr_desc*>(descs), n, bit_depth, stream);
+  return VVCGPU_OK;
 }
 
 int vvcgpu_quant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, const vvcgpu_quant_desc* descs, int n, int bit_depth, uint32_t* abs_sum,

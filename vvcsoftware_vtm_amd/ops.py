@@ -407,10 +407,11 @@ DQTR_DESC = np.dtype([("resi_off", "<i8"), ("level_off", "<i8"), ("resi_stride",
 assert DQTR_DESC.itemsize == 32
 
 
-def dequant_tr_inv_batch(level_base, resi_base, descs_dev, n, bit_depth, coeff_out):
-    """N1: de-quantisation + inverse transform.  coeff_out: int32 workspace, same offsets as level_base."""
+def dequant_tr_inv_batch(level_base, resi_base, descs_dev, n, bit_depth, coeff_out=None):
+    """N1: de-quantisation + inverse transform in one launch.  coeff_out (optional): int32, same offsets as level_base, receives the de-quantised
+    coefficients (the reference's m_plTempCoeff); None: they never leave the chip."""
     capi.call("vvcgpu_dequant_tr_inv_batch", capi.ptr(level_base), capi.ptr(resi_base), capi.ptr(descs_dev), n, bit_depth,
-              capi.ptr(coeff_out), _stream())
+              capi.ptr(coeff_out) if coeff_out is not None else None, _stream())
 
 
 def frac_refine(org, ref, blocks_dev, nblocks, w, h, bit_depth, mvcost, use_hadamard=True, clp=(0, 1023)):
