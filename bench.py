@@ -51,6 +51,7 @@ def parse_args():
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-real-mix", action="store_true", help="skip the real-shape block (kernels_real_mix)")
     ap.add_argument("--serial", action="store_true", help="one stream, stage order (default: independent stages on side streams)")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check without a GPU: start the ranks (gloo), verify the world size, hand one dummy boundary picture round the ring")
@@ -461,6 +462,14 @@ def main():
         }
         if world == 1 and not args.no_cpu_baseline:
             res["cpu_baseline"] = cpu_baseline(wl)
+        if world == 1 and not args.no_real_mix:
+            # the batch entry points on the call-signature mix of a real encode (tests/golden/trace_*.npz: 80 % of the calls are 4 or 8 wide) next to
+            # the same number of samples in 16 x 16 blocks: the canonical workload above is squares only (vvcsoftware_vtm_amd/shape_mix.py)
+            from vvcsoftware_vtm_amd import shape_mix
+            del wl
+            torch.cuda.empty_cache()
+            res["kernels_real_mix"] = {"trace": os.path.basename(shape_mix.TRACE), "samples_per_batch": 1 << 21, "square": 16,
+                                       "entries": shape_mix.run(1 << 21, reps=3)}
         print(json.dumps(res))
     if world > 1:
         dist.destroy_process_group()

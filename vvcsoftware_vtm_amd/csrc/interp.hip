@@ -52,22 +52,32 @@ __device__ __forceinline__ int if_copy(int s, bool isFirst, bool isLast, int bd,
 }
 
 // ------------------------------------------------------------------------------------------------ I1
-__global__ __launch_bounds__(256) void if_batch_kernel(const Pel* __restrict__ srcBase, Pel* __restrict__ dstBase,
-                                                       const vvcgpu_if_desc* __restrict__ descs, int n, int bd,
-                                                       int cmin, int cmax)
+// four samples of a row, the widest load the address allows
+__device__ __forceinline__ void if_load4(const Pel* p, int (&v)[4])
 {
-  const int lane = threadIdx.x & 63;
-  const int di = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (di >= n) return;
-  const vvcgpu_if_desc d = descs[di];
+  const uintptr_t a = (uintptr_t)p;
+  if ((a & 7) == 0) { const pel4 q = *reinterpret_cast<const pel4*>(p); v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; }
+  else if ((a & 3) == 0)
+  {
+    const pel2 q0 = *reinterpret_cast<const pel2*>(p), q1 = *reinterpret_cast<const pel2*>(p + 2);
+    v[0] = q0[0]; v[1] = q0[1]; v[2] = q1[0]; v[3] = q1[1];
+  }
+  else { v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3]; }
+}
+
+// one descriptor by a group of G lanes (lane = index inside the group)
+template <int G>
+__device__ __forceinline__ void if_one(const vvcgpu_if_desc& d, const Pel* __restrict__ srcBase, Pel* __restrict__ dstBase, int lane, bool act, int bd,
+                                       int cmin, int cmax)
+{
   const Pel* src = srcBase + d.src_off;
   Pel* dst = dstBase + d.dst_off;
-  const int N = d.taps;
+  const int N = d.taps, w = d.w, count = act ? w * d.h : 0;
   if (N == 0)
   {
-    for (int i = lane; i < d.w * d.h; i += 64)
+    for (int i = lane; i < count; i += G)
     {
-      const int y = i / d.w, x = i - y * d.w;
+      const int y = i / w, x = i - y * w;
       dst[(size_t)y * d.dst_stride + x] = (short)if_copy(src[(size_t)y * d.src_stride + x], d.is_first, d.is_last, bd, cmin, cmax);
     }
     return;
@@ -78,9 +88,59 @@ __global__ __launch_bounds__(256) void if_batch_kernel(const Pel* __restrict__ s
   int c[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) c[k] = k < N ? d.coeff[k] : 0;
-  for (int i = lane; i < d.w * d.h; i += 64)
+  if ((w & 3) == 0)
   {
-    const int y = i / d.w, x = i - y * d.w;
+    // four consecutive outputs of a row per lane: N + 3 samples (horizontal) or N loads of four samples (vertical) instead of 4 N two-byte loads
+    const int upr = w >> 2, units = act ? upr * d.h : 0;
+    for (int u = lane; u < units; u += G)
+    {
+      const int y = u / upr, x = (u - y * upr) << 2;
+      const Pel* s = src + (size_t)y * d.src_stride + x;
+      int sum[4] = { 0, 0, 0, 0 };
+      if (d.is_vertical)
+      {
+#pragma unroll
+        for (int k = 0; k < 8; k++)
+          if (k < N)
+          {
+            int v[4];
+            if_load4(s + (size_t)k * d.src_stride, v);
+#pragma unroll
+            for (int j = 0; j < 4; j++) sum[j] += v[j] * c[k];
+          }
+      }
+      else
+      {
+        int v[12];                                        // exactly the N + 3 samples the four outputs read: nothing beyond the reference's window
+        {
+          int q[4];
+          if_load4(s, q); v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
+          if (N == 8) { if_load4(s + 4, q); v[4] = q[0]; v[5] = q[1]; v[6] = q[2]; v[7] = q[3]; v[8] = s[8]; v[9] = s[9]; v[10] = s[10]; }
+          else if (N == 4) { v[4] = s[4]; v[5] = s[5]; v[6] = s[6]; }
+          else v[4] = s[4];
+        }
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+#pragma unroll
+          for (int k = 0; k < 8; k++) if (k < N) sum[j] += v[j + k] * c[k];
+      }
+      pel4 o;
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+        int val = (short)((sum[j] + m.offset) >> m.shift);
+        if (d.is_last) val = clip3(cmin, cmax, val);
+        o[j] = (short)val;
+      }
+      Pel* dp = dst + (size_t)y * d.dst_stride + x;
+      if (((uintptr_t)dp & 7) == 0) *reinterpret_cast<pel4*>(dp) = o;
+      else { dp[0] = o[0]; dp[1] = o[1]; dp[2] = o[2]; dp[3] = o[3]; }
+    }
+    return;
+  }
+  for (int i = lane; i < count; i += G)
+  {
+    const int y = i / w, x = i - y * w;
     const Pel* s = src + (size_t)y * d.src_stride + x;
     int sum = 0;
 #pragma unroll
@@ -89,6 +149,26 @@ __global__ __launch_bounds__(256) void if_batch_kernel(const Pel* __restrict__ s
     if (d.is_last) val = clip3(cmin, cmax, val);
     dst[(size_t)y * d.dst_stride + x] = (short)val;
   }
+}
+
+// A wave takes four consecutive descriptors: side by side with 16 lanes each when all four have at most 256 samples (the reference encoder's
+// table-slot calls are mostly 4 wide: tests/golden/trace_*.npz), one after the other with 64 lanes otherwise.
+__global__ __launch_bounds__(256) void if_batch_kernel(const Pel* __restrict__ srcBase, Pel* __restrict__ dstBase,
+                                                       const vvcgpu_if_desc* __restrict__ descs, int n, int bd,
+                                                       int cmin, int cmax)
+{
+  const int lane = threadIdx.x & 63;
+  const int d0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
+  if (d0 >= n) return;
+  const int g = lane >> 4;
+  const bool act = d0 + g < n;
+  const vvcgpu_if_desc mine = descs[act ? d0 + g : d0];
+  if (__builtin_amdgcn_ballot_w64((int)mine.w * (int)mine.h > 256) == 0ull)
+  {
+    if_one<16>(mine, srcBase, dstBase, lane & 15, act, bd, cmin, cmax);
+    return;
+  }
+  for (int k = 0; k < 4 && d0 + k < n; k++) if_one<64>(descs[d0 + k], srcBase, dstBase, lane, true, bd, cmin, cmax);
 }
 
 // ------------------------------------------------------------------------------------------------ I3
@@ -485,27 +565,21 @@ __device__ __forceinline__ int pelop_apply(int op, int a, int b, const vvcgpu_pe
   }
 }
 
-// One workgroup per descriptor (the reference calls these per CU: up to 128x128 samples); rows are split over the
-// waves, each lane moves 8 samples (16 bytes) per access when the three operands allow it.
-__global__ __launch_bounds__(256) void pelop_batch_kernel(int op, const Pel* __restrict__ s0Base, const Pel* __restrict__ s1Base,
-                                                          Pel* dstBase, const vvcgpu_pelop_desc* __restrict__ descs, int n,
-                                                          vvcgpu_pelop_cfg c)
+// rows [y0, y1) of one descriptor by `nthr` threads (t = index among them); each lane moves 8 samples (16 bytes) per access when the three
+// operands allow it
+__device__ __forceinline__ void pelop_one(int op, const vvcgpu_pelop_desc& d, const Pel* __restrict__ s0Base, const Pel* __restrict__ s1Base, Pel* dstBase,
+                                          const vvcgpu_pelop_cfg& c, int t, int nthr, int y0, int y1)
 {
-  const int tid = threadIdx.x;
-  const vvcgpu_pelop_desc d = descs[blockIdx.x];
   const Pel* s0 = s0Base + d.src0_off;
   const Pel* s1 = s1Base ? s1Base + d.src1_off : nullptr;
   Pel* dst = dstBase + d.dst_off;
   const bool vec = ((d.w & 7) == 0) && ((d.src0_stride & 7) == 0) && ((d.dst_stride & 7) == 0) &&
                    ((reinterpret_cast<uintptr_t>(s0) & 15) == 0) && ((reinterpret_cast<uintptr_t>(dst) & 15) == 0) &&
                    (!s1 || (((d.src1_stride & 7) == 0) && ((reinterpret_cast<uintptr_t>(s1) & 15) == 0)));
-  // gridDim.y workgroups share a descriptor (host: few descriptors = plane-sized bands): each takes a contiguous share of the rows
-  const int rows = (d.h + (int)gridDim.y - 1) / (int)gridDim.y, y0 = (int)blockIdx.y * rows, y1 = min(d.h, y0 + rows);
-  if (y0 >= y1) return;
   if (vec)
   {
     const int wv = d.w >> 3;
-    for (int i = tid + y0 * wv; i < wv * y1; i += 256)
+    for (int i = t + y0 * wv; i < wv * y1; i += nthr)
     {
       const int y = i / wv, x = (i - y * wv) << 3;
       const pel8 a = *reinterpret_cast<const pel8*>(s0 + (size_t)y * d.src0_stride + x);
@@ -518,13 +592,51 @@ __global__ __launch_bounds__(256) void pelop_batch_kernel(int op, const Pel* __r
     }
     return;
   }
-  for (int i = tid + y0 * d.w; i < d.w * y1; i += 256)
+  for (int i = t + y0 * d.w; i < d.w * y1; i += nthr)
   {
     const int y = i / d.w, x = i - y * d.w;
     const int a = s0[(size_t)y * d.src0_stride + x];
     const int b = s1 ? s1[(size_t)y * d.src1_stride + x] : 0;
     dst[(size_t)y * d.dst_stride + x] = (short)pelop_apply(op, a, b, c);
   }
+}
+
+// perWg == 1: one workgroup per descriptor (the reference calls these per CU: up to 128x128 samples; few descriptors = plane-sized bands: gridDim.y
+// workgroups share a descriptor, each takes a contiguous share of the rows).  perWg > 1 (long lists: blocks): a workgroup takes perWg consecutive
+// descriptors, one per wave at a time -- a workgroup per 8 x 4 block is bound by the dispatcher.
+__global__ __launch_bounds__(256) void pelop_batch_kernel(int op, const Pel* __restrict__ s0Base, const Pel* __restrict__ s1Base,
+                                                          Pel* dstBase, const vvcgpu_pelop_desc* __restrict__ descs, int n,
+                                                          vvcgpu_pelop_cfg c, int perWg)
+{
+  const int tid = threadIdx.x;
+  if (perWg > 1)                                          // a wave takes four consecutive descriptors: side by side with 16 lanes each when all
+  {                                                       // four have at most 256 samples, one after the other with 64 lanes otherwise
+    const int lane = tid & 63, g = lane >> 4;
+    for (int k0 = (tid >> 6) * 4; k0 < perWg; k0 += 16)
+    {
+      const int d0 = blockIdx.x * perWg + k0;
+      if (d0 >= n) break;
+      const bool act = d0 + g < n;
+      const vvcgpu_pelop_desc mine = descs[act ? d0 + g : d0];
+      if (__builtin_amdgcn_ballot_w64((int)mine.w * (int)mine.h > 256) == 0ull)
+      {
+        if (act) pelop_one(op, mine, s0Base, s1Base, dstBase, c, lane & 15, 16, 0, mine.h);
+      }
+      else
+      {
+        for (int k = 0; k < 4 && d0 + k < n; k++)
+        {
+          const vvcgpu_pelop_desc d = descs[d0 + k];
+          pelop_one(op, d, s0Base, s1Base, dstBase, c, lane, 64, 0, d.h);
+        }
+      }
+    }
+    return;
+  }
+  const vvcgpu_pelop_desc d = descs[blockIdx.x];
+  const int rows = (d.h + (int)gridDim.y - 1) / (int)gridDim.y, y0 = (int)blockIdx.y * rows, y1 = min(d.h, y0 + rows);
+  if (y0 >= y1) return;
+  pelop_one(op, d, s0Base, s1Base, dstBase, c, tid, 256, y0, y1);
 }
 
 }  // namespace
@@ -538,7 +650,7 @@ int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(src_base && dst_base && descs, "if_batch: null pointer");
   if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("if_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(if_batch_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, src_base, dst_base, descs, n,
+  hipLaunchKernelGGL(if_batch_kernel, dim3(cdiv(n, 16)), dim3(256), 0, (hipStream_t)stream, src_base, dst_base, descs, n,
                      bit_depth, clp_min, clp_max);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
@@ -574,8 +686,9 @@ int vvcgpu_pelop_batch(int op, const vvc_pel* src0_base, const vvc_pel* src1_bas
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(src0_base && dst_base && descs && cfg_host, "pelop_batch: null pointer");
   VVC_CHECK_ARG(src1_base || op == 2 || op == 5, "pelop_batch: op %d needs src1", op);
-  hipLaunchKernelGGL(pelop_batch_kernel, dim3(n, n < 2048 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, op, src0_base, src1_base,
-                     dst_base, descs, n, *cfg_host);
+  const int perWg = n < 8192 ? 1 : 16;
+  hipLaunchKernelGGL(pelop_batch_kernel, dim3(cdiv(n, perWg), n < 2048 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, op, src0_base, src1_base,
+                     dst_base, descs, n, *cfg_host, perWg);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

@@ -525,19 +525,22 @@ __global__ __launch_bounds__(256, W * H >= 2048 ? 2 : 3) void rc_mfma_kernel(con
 }
 
 // generic kernel: the class-`generic` list, then the fall-back list of the matrix-core kernels (TUs whose residual left +-1023)
-__global__ __launch_bounds__(64) void rc_generic_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+// WAVES waves per workgroup, each with its own pair of CAP-int buffers.  <4096, 1>: any TU (the fall-back list: up to 64 x 64).  <512, 4>: the
+// class-`generic` list, whose TUs have a side of at most 8 (both sides >= 16 are matrix-core classes), i.e. at most 64 x 8 samples: eight times
+// the waves per compute unit of the single-wave form (LDS bound: 32 KB per wave against 4 KB).
+template <int CAP, int WAVES>
+__global__ __launch_bounds__(64 * WAVES) void rc_generic_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                         TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs,
                                                         const int* __restrict__ countA, const int* __restrict__ listA,
-                                                        const int* __restrict__ countB, const int* __restrict__ listB,
                                                         unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax, VvcTrTables tb)
 {
-  __shared__ int bufA[4096], bufB[4096];
-  const int ca = countA[0], cb = countB[0];
-  for (int k = blockIdx.x; k < ca + cb; k += gridDim.x)
+  __shared__ int bufA[WAVES][CAP], bufB[WAVES][CAP];
+  const int ca = countA[0], wave = threadIdx.x >> 6;
+  for (int k = blockIdx.x * WAVES + wave; k < ca; k += gridDim.x * WAVES)
   {
-    const int ti = k < ca ? listA[k] : listB[k - ca];
-    rc_tu_generic(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, bufA, bufB,
-                  (int)threadIdx.x);
+    const int ti = listA[k];
+    rc_tu_generic(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, bufA[wave],
+                  bufB[wave], (int)threadIdx.x & 63);
   }
 }
 
@@ -844,9 +847,11 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
                        lists + (size_t)RC_C4 * n, abs_sum, bit_depth, clp_min, clp_max, tb);
     VVC_LAUNCH_CHECK_COUNTERS(st);
   }
-  const int wgG = n < 1024 ? n : 1024;
-  hipLaunchKernelGGL(rc_generic_kernel, dim3(wgG), dim3(64), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_CGEN,
-                     lists + (size_t)RC_CGEN * n, fbCount, fbList, abs_sum, bit_depth, clp_min, clp_max, tb);
+  const int wgS = cdiv(n, 4) < 2048 ? cdiv(n, 4) : 2048, wgG = n < 1024 ? n : 1024;
+  hipLaunchKernelGGL((rc_generic_kernel<512, 4>), dim3(wgS), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_CGEN,
+                     lists + (size_t)RC_CGEN * n, abs_sum, bit_depth, clp_min, clp_max, tb);
+  hipLaunchKernelGGL((rc_generic_kernel<4096, 1>), dim3(wgG), dim3(64), 0, st, org_base, pred_base, rec_base, level_base, descs, fbCount, fbList,
+                     abs_sum, bit_depth, clp_min, clp_max, tb);
   VVC_LAUNCH_CHECK_COUNTERS(st);
   return VVCGPU_OK;
 }

@@ -68,7 +68,7 @@ __device__ __forceinline__ void small_tables(SmallShared& sh, int tid)
     sh.tabT[t][e] = nsz ? tr32t(t, nsz)[o] : 0;
   }
 }
-__device__ __forceinline__ void small_setup(SmallShared& sh, const vvcgpu_tr_desc* __restrict__ descs, int n, int batch, int tid)
+__device__ __forceinline__ void small_setup(SmallShared& sh, const vvcgpu_tr_desc* __restrict__ descs, int n, int batch, int tid, int useMfma)
 {
   __syncthreads();                                  // tables ready / previous batch done with d, list, cnt
   if (tid < 4) sh.cnt[tid] = 0;
@@ -79,7 +79,8 @@ __device__ __forceinline__ void small_setup(SmallShared& sh, const vvcgpu_tr_des
     const vvcgpu_tr_desc d = descs[base + tid];
     sh.d[tid] = d;
     const int S = max((int)d.w, (int)d.h);
-    const int bin = d.tr_hor == 3 ? 0 : S <= 4 ? 1 : S == 8 ? 2 : S == 16 ? 3 : -1;     // -1: large, the other launch
+    int bin = d.tr_hor == 3 ? 0 : S <= 4 ? 1 : S == 8 ? 2 : S == 16 ? 3 : -1;           // -1: large, the other launches
+    if (useMfma && bin == 3 && d.w == 16 && d.h == 16) bin = -1;                           // 16 x 16 runs on the matrix cores
     if (bin >= 0) sh.list[bin][atomicAdd(&sh.cnt[bin], 1)] = (unsigned char)tid;
   }
   __syncthreads();
@@ -135,14 +136,14 @@ __device__ __forceinline__ void fwd_small_group(SmallShared& sh, int bin, int gr
 }
 
 __global__ __launch_bounds__(256) void tr_fwd_small_kernel(const Pel* __restrict__ resiBase, TCoeff* __restrict__ coeffBase,
-                                                           const vvcgpu_tr_desc* __restrict__ descs, int n, int bd)
+                                                           const vvcgpu_tr_desc* __restrict__ descs, int n, int bd, int useMfma)
 {
   __shared__ SmallShared sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   small_tables(sh, tid);
   for (int batch = blockIdx.x; batch * SM_DESCS < n; batch += gridDim.x)
   {
-  small_setup(sh, descs, n, batch, tid);
+  small_setup(sh, descs, n, batch, tid, useMfma);
   for (int q = 0; q < sh.cnt[0]; q++)                // transform skip: element-wise, whole workgroup
   {
     const vvcgpu_tr_desc& d = sh.d[sh.list[0][q]];
@@ -217,14 +218,14 @@ __device__ __forceinline__ void inv_small_group(SmallShared& sh, int bin, int gr
 }
 
 __global__ __launch_bounds__(256) void tr_inv_small_kernel(const TCoeff* __restrict__ coeffBase, Pel* __restrict__ resiBase,
-                                                           const vvcgpu_tr_desc* __restrict__ descs, int n, int bd)
+                                                           const vvcgpu_tr_desc* __restrict__ descs, int n, int bd, int useMfma)
 {
   __shared__ SmallShared sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   small_tables(sh, tid);
   for (int batch = blockIdx.x; batch * SM_DESCS < n; batch += gridDim.x)
   {
-  small_setup(sh, descs, n, batch, tid);
+  small_setup(sh, descs, n, batch, tid, useMfma);
   for (int q = 0; q < sh.cnt[0]; q++)
   {
     const vvcgpu_tr_desc& d = sh.d[sh.list[0][q]];
@@ -637,10 +638,10 @@ __device__ __forceinline__ bool inv_tu_mfma(CP coeff, int pitch, Pel* __restrict
   return true;
 }
 
-// shape key of the matrix-core forms: both sides in {16, 32, 64}, not 16 x 16 (the lane-group kernels take that)
-__device__ __forceinline__ bool is_mfma_shape(int w, int h) { return (w == 16 || w == 32 || w == 64) && (h == 16 || h == 32 || h == 64) && (w > 16 || h > 16); }
+// shapes of the matrix-core forms: both sides in {16, 32, 64}
+__device__ __forceinline__ bool is_mfma_shape(int w, int h) { return (w == 16 || w == 32 || w == 64) && (h == 16 || h == 32 || h == 64); }
 
-#define TR_MFMA_SHAPES(X) X(64, 64) X(64, 32) X(32, 64) X(32, 32) X(64, 16) X(16, 64) X(32, 16) X(16, 32)
+#define TR_MFMA_SHAPES(X) X(64, 64) X(64, 32) X(32, 64) X(32, 32) X(64, 16) X(16, 64) X(32, 16) X(16, 32) X(16, 16)
 
 // lists: mfmaCount[0] TUs at mfmaList[0 ..]; failures are appended to large[1 + large[0]++]
 __global__ __launch_bounds__(256, 2) void tr_fwd_mfma_kernel(const Pel* __restrict__ resiBase, TCoeff* __restrict__ coeffBase,
@@ -694,27 +695,34 @@ __global__ __launch_bounds__(256, 2) void tr_inv_mfma_kernel(const TCoeff* __res
 
 // indices of the large TUs of a batch, in two lists (order irrelevant: TUs are independent): ws[0] = count of the matrix-core list (entries at
 // ws[2 + n ..]), ws[1] = count of the dot2 list (entries at ws[2 ..]: `large` = ws + 1 is a count followed by its entries)
-__global__ __launch_bounds__(256) void tr_collect_large_kernel(const vvcgpu_tr_desc* __restrict__ descs, int n, int* __restrict__ ws, int useMfma)
+// (same-address device atomics retire at ~12 ns each: one per wave made this kernel 35 us for 137 k descriptors; here a 1024-thread workgroup
+// aggregates its 16 waves in LDS and reserves its range of each list with ONE atomic)
+__global__ __launch_bounds__(1024) void tr_collect_large_kernel(const vvcgpu_tr_desc* __restrict__ descs, int n, int* __restrict__ ws, int useMfma)
 {
-  const int ti = blockIdx.x * 256 + threadIdx.x, lane = threadIdx.x & 63;
+  __shared__ int wcnt[2][16], gbase[2];
+  const int ti = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   bool lg = false, mf = false;
   if (ti < n)
   {
     const int* f = reinterpret_cast<const int*>(descs + ti) + 5;            // bytes 20..27: w, h, tr_hor, tr_ver
     const int wh = f[0], tt = f[1];
     const int w = (short)(wh & 0xFFFF), h = wh >> 16;
-    lg = (signed char)(tt & 0xFF) != 3 && (w > 16 || h > 16);
-    mf = lg && useMfma && is_mfma_shape(w, h);
-    lg = lg && !mf;
+    const bool tr = (signed char)(tt & 0xFF) != 3;
+    mf = tr && useMfma && is_mfma_shape(w, h);
+    lg = tr && !mf && (w > 16 || h > 16);
   }
   const unsigned long long m = __builtin_amdgcn_ballot_w64(lg), m2 = __builtin_amdgcn_ballot_w64(mf);
-  int base = 0, base2 = 0;
-  if (lane == 0 && m) base = atomicAdd(&ws[1], (int)__popcll(m));
-  if (lane == 0 && m2) base2 = atomicAdd(&ws[0], (int)__popcll(m2));
-  base = __builtin_amdgcn_readfirstlane(base);
-  base2 = __builtin_amdgcn_readfirstlane(base2);
-  if (lg) ws[2 + base + (int)__popcll(m & ((1ull << lane) - 1ull))] = ti;
-  if (mf) ws[2 + n + base2 + (int)__popcll(m2 & ((1ull << lane) - 1ull))] = ti;
+  if (lane == 0) { wcnt[0][wave] = (int)__popcll(m); wcnt[1][wave] = (int)__popcll(m2); }
+  __syncthreads();
+  if (threadIdx.x < 2)
+  {
+    int tot = 0;
+    for (int k = 0; k < 16; k++) { const int c = wcnt[threadIdx.x][k]; wcnt[threadIdx.x][k] = tot; tot += c; }
+    gbase[threadIdx.x] = tot ? atomicAdd(&ws[1 - threadIdx.x], tot) : 0;  // ws[1]: dot2 list, ws[0]: matrix-core list
+  }
+  __syncthreads();
+  if (lg) ws[2 + gbase[0] + wcnt[0][wave] + (int)__popcll(m & ((1ull << lane) - 1ull))] = ti;
+  if (mf) ws[2 + n + gbase[1] + wcnt[1][wave] + (int)__popcll(m2 & ((1ull << lane) - 1ull))] = ti;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1121,7 +1129,8 @@ __global__ __launch_bounds__(256, 2) void dqtr_fused_kernel(const TCoeff* __rest
     {
       const vvcgpu_tr_desc d = reinterpret_cast<const vvcgpu_tr_desc*>(descs)[base + tid];
       const int S = max((int)d.w, (int)d.h);
-      const int bin = d.tr_hor == 3 ? 0 : S <= 4 ? 1 : S == 8 ? 2 : S == 16 ? 3 : -1;
+      int bin = d.tr_hor == 3 ? 0 : S <= 4 ? 1 : S == 8 ? 2 : S == 16 ? 3 : -1;
+      if (useMfma && bin == 3 && d.w == 16 && d.h == 16) bin = -1;
       if (bin >= 0) { const int k = atomicAdd(&cntS[bin], 1); binOf[tid] = (unsigned char)(bin * 64 + k); }
       else
       {
@@ -2238,8 +2247,8 @@ int vvcgpu_tr_fwd_batch(const vvc_pel* resi_base, vvc_coef* coeff_base, const vv
   if (!ws) return VVCGPU_E_DEVICE;
   VVC_HIP(hipMemsetAsync(ws, 0, 2 * sizeof(int), st));
   const int nb = cdiv(n, SM_DESCS), nl = cdiv(n, 4);
-  hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, descs, n, ws, tr_use_mfma());
-  hipLaunchKernelGGL(tr_fwd_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, resi_base, coeff_base, descs, n, bit_depth);
+  hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 1024)), dim3(1024), 0, st, descs, n, ws, tr_use_mfma());
+  hipLaunchKernelGGL(tr_fwd_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, resi_base, coeff_base, descs, n, bit_depth, tr_use_mfma());
   hipLaunchKernelGGL(tr_fwd_mfma_kernel, dim3(nl < 512 ? nl : 512), dim3(256), 0, st, resi_base, coeff_base, descs, ws, ws + 2 + n, ws + 1, bit_depth, image);
   hipLaunchKernelGGL(tr_fwd_large_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, resi_base, coeff_base, descs, ws + 1, bit_depth);
   VVC_LAUNCH_CHECK();
@@ -2263,8 +2272,8 @@ int vvcgpu_tr_inv_batch(const vvc_coef* coeff_base, vvc_pel* resi_base, const vv
   if (!ws) return VVCGPU_E_DEVICE;
   VVC_HIP(hipMemsetAsync(ws, 0, 2 * sizeof(int), st));
   const int nb = cdiv(n, SM_DESCS), nl = cdiv(n, 4);
-  hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 256)), dim3(256), 0, st, descs, n, ws, tr_use_mfma());
-  hipLaunchKernelGGL(tr_inv_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, coeff_base, resi_base, descs, n, bit_depth);
+  hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 1024)), dim3(1024), 0, st, descs, n, ws, tr_use_mfma());
+  hipLaunchKernelGGL(tr_inv_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, coeff_base, resi_base, descs, n, bit_depth, tr_use_mfma());
   hipLaunchKernelGGL(tr_inv_mfma_kernel, dim3(nl < 512 ? nl : 512), dim3(256), 0, st, coeff_base, resi_base, descs, ws, ws + 2 + n, ws + 1, bit_depth, image);
   hipLaunchKernelGGL(tr_inv_large_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, coeff_base, resi_base, descs, ws + 1, bit_depth);
   VVC_LAUNCH_CHECK();

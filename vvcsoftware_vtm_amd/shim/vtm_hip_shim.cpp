@@ -128,6 +128,31 @@ bool shimEnabled()
   if (on < 0) { const char* e = getenv("VVCGPU_SHIM"); on = (e && e[0] == '0') ? 0 : 1; }
   return on == 1;
 }
+// Call trace (test infrastructure for tools/shape_mix_time.py and tests/golden/trace_*.npz): VVCGPU_SHIM_TRACE=file appends one record of six
+// int32 per hooked block-level call -- entry, width, height and three entry-specific parameters, SHAPES AND PARAMETERS ONLY, no samples.  With
+// VVCGPU_SHIM_TRACE_ONLY=1 the hooks record and hand every call back to the reference's own function: no GPU is touched (the trace can be taken
+// on a host without one); use it with VVCGPU_SHIM_HOOKS=slots so that the reference's searches and transforms issue their table-slot calls.
+// entries: 0 distortion slot (a = 0 SAD / 1 Hadamard / 2 SSE, b = row sub-sampling shift, c = bit depth); 1 interpolation slot (a = taps,
+// b = vertical | isFirst << 1 | isLast << 2); 2 PelBuffer slot (a = 0 addAvg / 1 reco / 2 linTf); 3 xTrMxN_EMT (a, b = horizontal / vertical
+// type 0 DCT-II 1 DCT-VIII 2 DST-VII); 4 xITrMxN_EMT; 5 invTransformNxN (a = component, b = transform skip, c = dependent quantisation);
+// 6 DepQuant::quant (a = component, b = QP); 7 QuantRDOQ::quant; 8 predIntraAng (a = component, b = mode)
+FILE* g_trace = nullptr;
+int traceMode()
+{
+  static int mode = -1;
+  if (mode < 0)
+  {
+    const char* f = getenv("VVCGPU_SHIM_TRACE");
+    mode = 0;
+    if (f && (g_trace = fopen(f, "wb"))) mode = getenv("VVCGPU_SHIM_TRACE_ONLY") ? 2 : 1;
+  }
+  return mode;
+}
+static inline void traceRec(int entry, int w, int h, int a = 0, int b = 0, int c = 0)
+{
+  if (traceMode()) { const int32_t r[6] = { entry, w, h, a, b, c }; fwrite(r, sizeof r, 1, g_trace); }
+}
+bool gpuEnabled() { return shimEnabled() && traceMode() != 2; }       // the hooks that drive the GPU; table-slot INSTALLS stay on shimEnabled()
 extern long g_resUploads, g_resDownloads, g_resPictures;
 bool residentEnabled();
 long g_calls[28] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
@@ -323,7 +348,7 @@ namespace {
 // ---------------------------------------------------------------------------------------------------------------
 void wrap_loopFilterPic(LoopFilter* self, CodingStructure& cs)
 {
-  if (!shimEnabled()) { real_loopFilterPic(self, cs); return; }
+  if (!gpuEnabled()) { real_loopFilterPic(self, cs); return; }
   const PreCalcValues& pcv = *cs.pcv;
   CHECK(pcv.chrFormat != CHROMA_420, "vvcgpu shim: only 4:2:0");
   // the reference's own walk with the sample filters recording (see vvcshim_edge_filter)
@@ -461,7 +486,7 @@ void alfFilterResident(CodingStructure& cs, AdaptiveLoopFilter* self, AlfSlicePa
 // decoder: SampleAdaptiveOffset::SAOProcess (SampleAdaptiveOffset.cpp:564-612)
 void wrap_SAOProcess(SampleAdaptiveOffset* self, CodingStructure& cs, SAOBlkParam* saoBlkParams)
 {
-  if (!shimEnabled()) { real_SAOProcess(self, cs, saoBlkParams); return; }
+  if (!gpuEnabled()) { real_SAOProcess(self, cs, saoBlkParams); return; }
   CHECK(!saoBlkParams, "No parameters present");
   self->xReconstructBlkSAOParams(cs, saoBlkParams);                      // merge resolution + de-quantisation (:262-290)
   bool any = false;
@@ -482,7 +507,7 @@ void wrap_SAOProcess(SampleAdaptiveOffset* self, CodingStructure& cs, SAOBlkPara
 // decoder: AdaptiveLoopFilter::ALFProcess (AdaptiveLoopFilter.cpp:68-139)
 void wrap_ALFProcess(AdaptiveLoopFilter* self, CodingStructure& cs, AlfSliceParam& alfSliceParam)
 {
-  if (!shimEnabled()) { real_ALFProcess(self, cs, alfSliceParam); return; }
+  if (!gpuEnabled()) { real_ALFProcess(self, cs, alfSliceParam); return; }
   if (!alfSliceParam.enabledFlag[COMPONENT_Y] && !alfSliceParam.enabledFlag[COMPONENT_Cb] && !alfSliceParam.enabledFlag[COMPONENT_Cr])
   {
     residentSyncHost(cs);
@@ -504,10 +529,10 @@ void wrap_ALFProcess(AdaptiveLoopFilter* self, CodingStructure& cs, AlfSlicePara
 void wrap_EncSAOProcess(EncSampleAdaptiveOffset* self, CodingStructure& cs, bool* sliceEnabled, const double* lambdas, const bool testDisable,
                         const double rate, const double rateChroma, bool isPreDBF, bool greedy)
 {
-  const bool resident = shimEnabled() && residentEnabled() && g_res.dirty && g_res.pic == cs.picture && !isPreDBF && !pcmOrBypass(cs);
+  const bool resident = gpuEnabled() && residentEnabled() && g_res.dirty && g_res.pic == cs.picture && !isPreDBF && !pcmOrBypass(cs);
   if (!resident)
   {
-    if (shimEnabled()) residentSyncHost(cs);
+    if (gpuEnabled()) residentSyncHost(cs);
     real_EncSAOProcess(self, cs, sliceEnabled, lambdas, testDisable, rate, rateChroma, isPreDBF, greedy);
     return;
   }
@@ -530,11 +555,11 @@ void wrap_EncSAOProcess(EncSampleAdaptiveOffset* self, CodingStructure& cs, bool
 // record nothing but the fact, and the picture is filtered once with the final coefficients and CTU flags when it returns.
 void wrap_EncALFProcess(EncAdaptiveLoopFilter* self, CodingStructure& cs, const double* lambdas, AlfSliceParam& alfSliceParam)
 {
-  const bool resident = shimEnabled() && residentEnabled() && g_res.dirty && g_res.pic == cs.picture && !pcmOrBypass(cs) &&
+  const bool resident = gpuEnabled() && residentEnabled() && g_res.dirty && g_res.pic == cs.picture && !pcmOrBypass(cs) &&
                         self->m_maxCUWidth == self->m_maxCUHeight && (self->m_maxCUWidth % 128) == 0 && self->m_chromaFormat == CHROMA_420;
   if (!resident)
   {
-    if (shimEnabled()) residentSyncHost(cs);
+    if (gpuEnabled()) residentSyncHost(cs);
     real_EncALFProcess(self, cs, lambdas, alfSliceParam);
     return;
   }
@@ -564,7 +589,7 @@ int vvcshim_sao_stats(EncSampleAdaptiveOffset* self, std::vector<SAOStatData**>*
   for (int c = 0; c < 3; c++)
     for (int t = 1; t < NUM_SAO_NEW_TYPES; t++)
       uniform = uniform && self->m_skipLinesR[c][t] == self->m_skipLinesR[c][0] && self->m_skipLinesB[c][t] == self->m_skipLinesB[c][0];
-  if (!shimEnabled() || isCalculatePreDeblockSamples || !uniform) return 0;
+  if (!gpuEnabled() || isCalculatePreDeblockSamples || !uniform) return 0;
   const PreCalcValues& pcv = *cs.pcv;
   const int nCtu = pcv.sizeInCtus;
   std::vector<uint8_t> avail(nCtu);
@@ -640,7 +665,7 @@ int vvcshim_alf_stats(EncAdaptiveLoopFilter* self, PelUnitBuf* orgYuvP, PelUnitB
   PelUnitBuf& orgYuv = *orgYuvP;
   PelUnitBuf& recYuv = *recYuvP;
   const bool square = self->m_maxCUWidth == self->m_maxCUHeight && (self->m_maxCUWidth % 128) == 0 && self->m_chromaFormat == CHROMA_420;
-  if (!shimEnabled() || !square) return 0;
+  if (!gpuEnabled() || !square) return 0;
   const int numberOfComponents = getNumberValidComponents(self->m_chromaFormat);
   const int nCtu = self->m_numCTUsInPic;
   if (g_res.alfCollect && g_res.dirty && numberOfComponents == 3 && (self->m_picWidth & 7) == 0 && (self->m_picHeight & 7) == 0 &&
@@ -867,7 +892,7 @@ void gpuDeriveClassificationBlk(AlfClassifier** classifier, int** laplacian[NUM_
 void wrap_initAlfX86(AdaptiveLoopFilter* self)
 {
   real_initAlfX86(self);
-  if (!shimEnabled() || ((hookLevel() < 2) && !residentEnabled())) return;   // the resident picture-level form needs the three slots (deferred)
+  if (!gpuEnabled() || ((hookLevel() < 2) && !residentEnabled())) return;   // the resident picture-level form needs the three slots (deferred)
   g_cpuAlfFilter[0] = self->m_filter5x5Blk; g_cpuAlfFilter[1] = self->m_filter7x7Blk; g_cpuAlfClassify = self->m_deriveClassificationBlk;
   self->m_filter5x5Blk = gpuFilterBlk<0>;
   self->m_filter7x7Blk = gpuFilterBlk<1>;
@@ -877,7 +902,7 @@ void wrap_initAlfX86(AdaptiveLoopFilter* self)
 // SampleAdaptiveOffset::offsetCTU (SampleAdaptiveOffset.cpp:510-573) as the encoder calls it per CTU from decideBlkParams.
 void wrap_offsetCTU(SampleAdaptiveOffset* self, const UnitArea& area, const CPelUnitBuf& src, PelUnitBuf& res, SAOBlkParam& saoblkParam, CodingStructure& cs)
 {
-  if (!shimEnabled()) { real_offsetCTU(self, area, src, res, saoblkParam, cs); return; }
+  if (!gpuEnabled()) { real_offsetCTU(self, area, src, res, saoblkParam, cs); return; }
   if (g_res.saoCollect)
   {
     // resident form: record the CTU's reconstructed parameters; the picture is filtered once when SAOProcess returns (wrap_EncSAOProcess)
@@ -978,6 +1003,8 @@ Distortion gpuDistSlot(const DistParam& p)
 {
   constexpr int KIND = SLOT < 8 ? 2 : (SLOT < 16 || SLOT >= 24) ? 0 : 1;
   const int w = p.org.width, h = p.org.height;
+  traceRec(0, w, h, KIND, KIND == 0 ? p.subShift : 0, p.bitDepth);
+  if (traceMode() == 2) return g_cpuDistAll[SLOT](p);
   // the reference's 4-wide SIMD SAD ignores the row sub-sampling: those calls stay where they are
   if (p.applyWeight || p.useMR || p.step != 1 || p.bitDepth > 10 || w < 4 || h < 4 || (w & 1) || w > 128 || h > 128 || (KIND == 0 && w == 4 && p.subShift) ||
       (KIND == 0 && p.subShift && (h & ((1 << p.subShift) - 1))))
@@ -1031,7 +1058,8 @@ DevArray<vvcgpu_if_desc> g_ifDesc;
 template <int VER, int NI, int FIRST, int LAST>
 void gpuIf(const ClpRng& clpRng, Pel const* src, int srcStride, Pel* dst, int dstStride, int width, int height, TFilterCoeff const* coeff)
 {
-  if (width < (allWidths() ? 2 : 64) || clpRng.bd > 10 || width > 256 || height > 256) { g_cpuIf[VER][NI][FIRST][LAST](clpRng, src, srcStride, dst, dstStride, width, height, coeff); return; }
+  traceRec(1, width, height, NI == 0 ? 8 : NI == 1 ? 4 : 2, VER | FIRST << 1 | LAST << 2, clpRng.bd);
+  if (traceMode() == 2 || width < (allWidths() ? 2 : 64) || clpRng.bd > 10 || width > 256 || height > 256) { g_cpuIf[VER][NI][FIRST][LAST](clpRng, src, srcStride, dst, dstStride, width, height, coeff); return; }
   constexpr int N = NI == 0 ? 8 : NI == 1 ? 4 : 2, before = N / 2 - 1, after = N / 2;
   const int cols = VER ? width : width + before + after, rows = VER ? height + before + after : height;
   const int sp = (cols + 7) & ~7, dp = (width + 7) & ~7;
@@ -1081,7 +1109,8 @@ DevArray<vvcgpu_pelop_desc> g_pDesc;
 
 bool gpuPelop(int op, const Pel* s0, int st0, const Pel* s1, int st1, Pel* dst, int dstStride, int w, int h, const vvcgpu_pelop_cfg& cfg)
 {
-  if (w < (allWidths() ? 8 : 64) || w > 128 || h > 128) return false;
+  traceRec(2, w, h, op);
+  if (traceMode() == 2 || w < (allWidths() ? 8 : 64) || w > 128 || h > 128) return false;
   const int pitch = 128;
   g_p0.reserve((size_t)pitch * 128); g_p1.reserve((size_t)pitch * 128); g_pd.reserve((size_t)pitch * 128);
   VVCGPU(vvcgpu_memcpy2d_h2d(g_p0.ptr, pitch * sizeof(vvc_pel), s0, st0 * sizeof(Pel), (size_t)w * sizeof(Pel), h, nullptr));
@@ -1144,7 +1173,8 @@ int trCode(int t) { return t == DCT2 ? 0 : t == DCT8 ? 1 : 2; }
 extern "C" int vvcshim_tr_fwd(int bd, const Pel* resi, size_t stride, TCoeff* coeff, int w, int h, int maxLog2, unsigned char ucMode, unsigned char ucTrIdx, bool useQTBT)
 {
   int hor, ver;
-  if (!shimEnabled() || (hookLevel() != 2) || !useQTBT || maxLog2 != 15 || bd > 10 || (w < 32 && h < 32) || !trTypes(ucMode, ucTrIdx, hor, ver)) return 0;
+  if (traceMode() && trTypes(ucMode, ucTrIdx, hor, ver)) traceRec(3, w, h, trCode(hor), trCode(ver), bd);
+  if (!gpuEnabled() || (hookLevel() != 2) || !useQTBT || maxLog2 != 15 || bd > 10 || (w < 32 && h < 32) || !trTypes(ucMode, ucTrIdx, hor, ver)) return 0;
   g_tResi.reserve((size_t)64 * 64);
   g_tCoef.reserve((size_t)64 * 64);
   VVCGPU(vvcgpu_memcpy2d_h2d(g_tResi.ptr, (size_t)w * sizeof(vvc_pel), resi, stride * sizeof(Pel), (size_t)w * sizeof(Pel), h, nullptr));
@@ -1164,7 +1194,8 @@ extern "C" int vvcshim_tr_inv(int bd, const TCoeff* coeff, Pel* resi, size_t str
 {
   int hor, ver;
   const unsigned zw = w > 32 ? w - 32 : 0, zh = h > 32 ? h - 32 : 0;         // the zero-out the kernels assume (xIT, :755-759)
-  if (!shimEnabled() || (hookLevel() != 2) || maxLog2 != 15 || bd > 10 || (w < 32 && h < 32) || skipW != zw || skipH != zh ||
+  if (traceMode() && trTypes(ucMode, ucTrIdx, hor, ver)) traceRec(4, w, h, trCode(hor), trCode(ver), bd);
+  if (!gpuEnabled() || (hookLevel() != 2) || maxLog2 != 15 || bd > 10 || (w < 32 && h < 32) || skipW != zw || skipH != zh ||
       !trTypes(ucMode, ucTrIdx, hor, ver)) return 0;
   g_tResi.reserve((size_t)64 * 64);
   g_tCoef.reserve((size_t)64 * 64);
@@ -1191,7 +1222,7 @@ DevArray<vvcgpu_frac_result> g_fRes;
 extern "C" int vvcshim_frac(InterSearch* self, const PredictionUnit* pu, int /*eRefPicList*/, int /*iRefIdx*/, InterSearch::IntTZSearchStruct* cs,
                             const Mv* mvInt, Mv* mvHalf, Mv* mvQter, Distortion* cost)
 {
-  if (!shimEnabled() || hookLevel() < 1 || hookLevel() == 3) return 0;
+  if (!gpuEnabled() || hookLevel() < 1 || hookLevel() == 3) return 0;
   const CPelBuf& key = *cs->pcPatternKey;
   const int w = key.width, h = key.height, bd = self->m_lumaClpRng.bd;
 #if JVET_K0157
@@ -1239,7 +1270,7 @@ DevArray<vvcgpu_search_best> g_sBest;
 
 extern "C" int vvcshim_fullsearch(InterSearch* self, InterSearch::IntTZSearchStruct* cs, Mv* rcMv, Distortion* ruiSAD)
 {
-  if (!shimEnabled() || hookLevel() < 1 || hookLevel() == 3) return 0;
+  if (!gpuEnabled() || hookLevel() < 1 || hookLevel() == 3) return 0;
   const CPelBuf& key = *cs->pcPatternKey;
   const int w = key.width, h = key.height, bd = self->m_lumaClpRng.bd;
   const InterSearch::SearchRange& sr = cs->searchRange;
@@ -1290,7 +1321,7 @@ DevArray<vvcgpu_search_best> g_zBest;
 extern "C" int vvcshim_tzsearch(InterSearch* self, const PredictionUnit* pu, InterSearch::IntTZSearchStruct* cs, Mv* rcMv, Distortion* ruiSAD,
                                 const Mv* pInt2Nx2N, bool bExtended, bool bFast)
 {
-  if (!shimEnabled() || hookLevel() < 1 || hookLevel() == 3) return 0;
+  if (!gpuEnabled() || hookLevel() < 1 || hookLevel() == 3) return 0;
   static const long limit = getenv("VVCGPU_SHIM_TZ_LIMIT") ? atol(getenv("VVCGPU_SHIM_TZ_LIMIT")) : 0;
   if (capped(limit, g_calls[20], 0)) return 0;
   const CPelBuf& key = *cs->pcPatternKey;
@@ -1377,7 +1408,8 @@ void wrap_predIntraAng(IntraPrediction* self, const ComponentID compId, PelBuf& 
   const ChannelType chType = toChannelType(compID);
   const int w = piPred.width, h = piPred.height;
   static const long limit = getenv("VVCGPU_SHIM_INTRA_LIMIT") ? atol(getenv("VVCGPU_SHIM_INTRA_LIMIT")) : 60000;
-  bool ok = shimEnabled() && !(hookLevel() != 2) && w >= 4 && h >= 4 && w <= 64 && h <= 64 && !(w & (w - 1)) && !(h & (h - 1)) &&
+  if (traceMode()) traceRec(8, w, h, (int)compID, (int)PU::getFinalIntraMode(pu, chType));
+  bool ok = gpuEnabled() && !(hookLevel() != 2) && w >= 4 && h >= 4 && w <= 64 && h <= 64 && !(w & (w - 1)) && !(h & (h - 1)) &&
             !capped(limit, g_calls[21], 1);
   int T = 0, L = 0;
   if (ok) { VVCGPU(vvcgpu_intra_ref_lengths(w, h, &T, &L)); ok = T == self->m_topRefLength && L == self->m_leftRefLength; }
@@ -1430,7 +1462,7 @@ int sideUnitsAvailable(const CodingUnit& cu, ChannelType chType, const Position&
 void wrap_predIntraChromaLM(IntraPrediction* self, const ComponentID compID, PelBuf& piPred, const PredictionUnit& pu, const CompArea& chromaArea, int intraDir)
 {
   const char* dump = getenv("VVCGPU_CCLM_DUMP");
-  const bool gpu = shimEnabled() && !(hookLevel() != 2);
+  const bool gpu = gpuEnabled() && !(hookLevel() != 2);
   const int w = chromaArea.width, h = chromaArea.height;
   bool ok = (gpu || dump) && pu.chromaFormat == CHROMA_420 && w >= 2 && h >= 2 && w <= 64 && h <= 64 && !(w & (w - 1)) && !(h & (h - 1)) &&
             (int)piPred.width == w && (int)piPred.height == h;
@@ -1527,7 +1559,7 @@ bool unitAvailable(const CodingUnit& cu, ChannelType chType, const Position& ref
 void wrap_initIntraPatternChType(IntraPrediction* self, const CodingUnit& cu, const CompArea& area, const bool bFilterRefSamples)
 {
   const char* dump = getenv("VVCGPU_FILL_DUMP");
-  const bool gpu = shimEnabled() && !(hookLevel() != 2);
+  const bool gpu = gpuEnabled() && !(hookLevel() != 2);
   const int w = area.width, h = area.height;
   static const long limit = getenv("VVCGPU_SHIM_FILL_LIMIT") ? atol(getenv("VVCGPU_SHIM_FILL_LIMIT")) : 60000;
   if (!(gpu || dump) || w < 4 || h < 4 || w > 64 || h > 64 || (w & (w - 1)) || (h & (h - 1)) || (gpu && !dump && capped(limit, g_calls[25], 2)))
@@ -1631,7 +1663,8 @@ extern "C" int vvcshim_depquant(DepQuant* self, TransformUnit* tuP, const Compon
   const int w = area.width, h = area.height, n = w * h;
   const int bd = tu.cs->sps->getBitDepth(toChannelType(compID));
   static const long limit = getenv("VVCGPU_SHIM_DEPQUANT_LIMIT") ? atol(getenv("VVCGPU_SHIM_DEPQUANT_LIMIT")) : 20000;
-  const bool ok = shimEnabled() && !(hookLevel() != 2) && tu.cs->slice->getDepQuantEnabledFlag() && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
+  traceRec(6, w, h, (int)compID, cQP.Qp);
+  const bool ok = gpuEnabled() && !(hookLevel() != 2) && tu.cs->slice->getDepQuantEnabledFlag() && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
                   !(w & (w - 1)) && !(h & (h - 1)) && bd >= 8 && bd <= 10 && (int)pSrc.stride == w && !capped(limit, g_calls[26], 3) &&
                   !tu.cs->sps->getSpsRangeExtension().getExtendedPrecisionProcessingFlag();
   if (!ok) return 0;
@@ -1683,7 +1716,8 @@ extern "C" int vvcshim_rdoq(QuantRDOQ* self, TransformUnit* tuP, const Component
   const int bd = tu.cs->sps->getBitDepth(toChannelType(compID));
   static const long limit = getenv("VVCGPU_SHIM_RDOQ_LIMIT") ? atol(getenv("VVCGPU_SHIM_RDOQ_LIMIT")) : 20000;
   const bool useRDOQ = tu.transformSkip[compID] ? self->m_useRDOQTS : self->m_useRDOQ;               // the dispatch of :652-690
-  const bool ok = shimEnabled() && !(hookLevel() != 2) && useRDOQ && !self->m_useSelectiveRDOQ && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
+  traceRec(7, w, h, (int)compID, cQP.Qp);
+  const bool ok = gpuEnabled() && !(hookLevel() != 2) && useRDOQ && !self->m_useSelectiveRDOQ && w >= 4 && h >= 4 && w <= 64 && h <= 64 &&
                   !(w & (w - 1)) && !(h & (h - 1)) && bd >= 8 && bd <= 10 && (int)pSrc.stride == w && !capped(limit, g_calls[27], 4) &&
                   !tu.cs->sps->getSpsRangeExtension().getExtendedPrecisionProcessingFlag();
   if (!ok) return 0;
@@ -1726,7 +1760,7 @@ namespace { DevArray<vvc_pel> g_bPlane; }
 
 void wrap_extendPicBorder(Picture* self)
 {
-  if (!shimEnabled() || (hookLevel() != 2)) { real_extendPicBorder(self); return; }
+  if (!gpuEnabled() || (hookLevel() != 2)) { real_extendPicBorder(self); return; }
   if (self->m_bIsBorderExtended) return;
   for (int comp = 0; comp < (int)getNumberValidComponents(self->cs->area.chromaFormat); comp++)
   {
@@ -1754,7 +1788,7 @@ namespace { DevArray<vvc_pel> g_hPlane; DevArray<uint32_t> g_hOut; }
 
 extern "C" int vvcshim_pichash(int method, const CPelUnitBuf* pic, PictureHash* digest, const BitDepths* bitDepths)
 {
-  if (!shimEnabled() || (hookLevel() != 2)) return 0;
+  if (!gpuEnabled() || (hookLevel() != 2)) return 0;
   digest->hash.clear();
   for (uint32_t chan = 0; chan < (uint32_t)pic->bufs.size(); chan++)
   {
@@ -1790,7 +1824,8 @@ void wrap_invTransformNxN(TrQuant* self, TransformUnit& tu, const ComponentID& c
   const int w = area.width, h = area.height;
   const int bd = tu.cs->sps->getBitDepth(toChannelType(compID));
   int hor = DCT2, ver = DCT2;
-  bool ok = shimEnabled() && !(hookLevel() != 2) && !tu.cu->transQuantBypass && !CU::isRDPCMEnabled(*tu.cu) && bd <= 10 && bd >= 8 &&
+  traceRec(5, w, h, (int)compID, tu.transformSkip[compID] != 0, dynamic_cast<DepQuant*>(self->m_quant) != nullptr && tu.cs->slice->getDepQuantEnabledFlag());
+  bool ok = gpuEnabled() && !(hookLevel() != 2) && !tu.cu->transQuantBypass && !CU::isRDPCMEnabled(*tu.cu) && bd <= 10 && bd >= 8 &&
             self->m_rectTUs && tu.cs->sps->getMaxLog2TrDynamicRange(toChannelType(compID)) == 15 && w >= 2 && h >= 2 && w <= 64 && h <= 64 &&
             !(w & (w - 1)) && !(h & (h - 1));
   // an encoder reconstructs a TU for every rate-distortion candidate (1.2 - 1.7 million calls on the 2-3 frame test clips, all
@@ -1864,7 +1899,7 @@ void gpuEqualCoeff(Pel* pResidue, int /*residueStride*/, int** ppDerivate, int d
 void wrap_initAgsX86(AffineGradientSearch* self)
 {
   real_initAgsX86(self);
-  if (!shimEnabled() || (hookLevel() < 2)) return;
+  if (!gpuEnabled() || (hookLevel() < 2)) return;
   self->m_HorizontalSobelFilter = gpuSobel<0>;
   self->m_VerticalSobelFilter = gpuSobel<1>;
   self->m_EqualCoeffComputer = gpuEqualCoeff;
