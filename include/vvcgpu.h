@@ -500,6 +500,23 @@ int vvcgpu_intra_ref_lengths(int w, int h, int* top_len, int* left_len);
 int vvcgpu_intra_pred_batch(const vvc_pel* refs_base, vvc_pel* dst_base, const vvcgpu_intra_desc* descs, int n, int clp_min, int clp_max,
                             void* stream);
 
+/* N4, intra mode pre-selection  (IntraSearch::estIntraPredLumaQT, EncoderLib/IntraSearch.cpp:397-480: for every candidate mode
+ *          predIntraAng into the prediction buffer, then distParam.distFunc = the Hadamard distortion RdCost::xGetHADs against the
+ *          original, :423-433 and the second round :470-480) -- one descriptor per (block, candidate mode): the prediction of
+ *          vvcgpu_intra_pred_batch goes into LDS and only out[i] = xGetHADs(org, pred) (what vvcgpu_dist_batch kind 1 returns for the
+ *          same two blocks) leaves the chip.  The mode bits and the candidate lists (xFracModeBitsIntra, updateCandList) stay with
+ *          the caller.  refs as vvcgpu_intra_desc; org_off / org_stride: the block in the original plane.                            */
+typedef struct vvcgpu_intra_satd_desc {
+  int64_t ref_off, org_off;             /* samples, relative to refs_base / org_base */
+  int32_t org_stride;
+  int16_t w, h;                         /* powers of two 4..64 */
+  int8_t  mode, filter_refs;
+  int16_t reserved;
+  int32_t reserved2;                    /* sizeof == 32 */
+} vvcgpu_intra_satd_desc;
+int vvcgpu_intra_satd_batch(const vvc_pel* refs_base, const vvc_pel* org_base, const vvcgpu_intra_satd_desc* descs, int n, int clp_min,
+                            int clp_max, uint64_t* out, void* stream);
+
 /* N4, reference sample gathering: IntraPrediction::xFillReferenceSamples (:807-1004) for the packed layout above.  rec_off: the
  * block's top-left sample in the reconstruction plane; flags_off: the reference's neighborFlags of the block in flags_base, one
  * byte per unit in chain order  below-left (bottom first) ... left ... top-left ... above ... above-right,

@@ -102,6 +102,48 @@ def test_intra_pred_full_picture_property():
     assert np.array_equal(got, want)
 
 
+@pytest.mark.parametrize("bd", [8, 10])
+def test_intra_satd_batch_equals_predict_then_hadamard(bd):
+    """intra mode pre-selection (IntraSearch.cpp:397-480): the fused entry against the oracle's predIntraAng followed by its xGetHADs, every block
+    shape 4..64 (squares and rectangles), every mode, filtered and unfiltered references"""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(90 + bd)
+    mx = (1 << bd) - 1
+    shapes = [(w, h) for w in (4, 8, 16, 32, 64) for h in (4, 8, 16, 32, 64)]
+    rows, refs_all, roff, ooff = [], [], 0, 0
+    for (w, h) in shapes:
+        T, L = ops.intra_ref_lengths(w, h)
+        for mode in list(range(0, 67, 3)) + [1, 2, 18, 34, 50, 66]:
+            base = int(rng.integers(0, mx))
+            refs_all.append(np.clip(base + rng.integers(-60, 61, T + L + 1), 0, mx).astype(np.int16))
+            rows.append((roff, ooff, w + 8, w, h, mode, int(rng.integers(0, 2)), 0, 0))
+            roff += T + L + 1
+            ooff += (w + 8) * h
+    sd = np.array(rows, dtype=ops.INTRA_SATD_DESC)
+    refs = np.concatenate(refs_all)
+    org = rng.integers(0, mx + 1, ooff).astype(np.int16)
+    # oracle: predict every candidate into its own buffer, then the Hadamard distortion of (org, pred)
+    O = oracle()
+    pred = np.zeros(ooff, np.int16)
+    for i, r in enumerate(sd):
+        w, h = int(r["w"]), int(r["h"])
+        src = refs_all[i]
+        if r["filter_refs"]:
+            src = np.zeros_like(refs_all[i])
+            O.orc_intra_filter_refs(p(refs_all[i]), p(src), w, h)
+        blk = np.zeros((h, w + 8), np.int16)
+        O.orc_intra_pred(p(src), p(blk), w + 8, w, h, int(r["mode"]), 0, mx)
+        pred[int(r["org_off"]):int(r["org_off"]) + blk.size] = blk.reshape(-1)
+    dd = np.zeros(len(sd), ops.DIST_DESC)
+    dd["org_off"] = dd["cur_off"] = sd["org_off"]
+    dd["org_stride"] = dd["cur_stride"] = sd["org_stride"]
+    dd["w"], dd["h"] = sd["w"], sd["h"]
+    want = np.zeros(len(sd), np.uint64)
+    oracle().orc_dist_batch(1, p(org), p(pred), p(dd), len(dd), p(want))
+    got = ops.intra_satd_batch(dev(refs), dev(org), ops.struct_to_device(sd), len(sd), clp=(0, mx))
+    assert np.array_equal(got.cpu().numpy().view(np.uint64), want)
+
+
 def test_cclm_golden_and_random():
     """CCLM (vvcgpu_cclm_pred_batch): (1) the 938 blocks captured from the reference's own predIntraChromaLM, all in one launch;
     (2) random luma / neighbours for every chroma shape x availability combination against the oracle."""

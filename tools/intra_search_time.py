@@ -64,6 +64,19 @@ ev[3].record(); torch.cuda.synchronize()
 t = [ev[i].elapsed_time(ev[i + 1]) for i in range(3)]
 print("intra mode pre-selection, %d blocks x 67 modes: fill %.3f ms, predict %.3f ms (%.0f M predictions/s), SATD %.3f ms; total %.3f ms" %
       (nb, t[0], t[1], nb * 67 / t[1] / 1e3, t[2], sum(t)))
+# the fused entry (round 3): predict -> SATD in one launch, the prediction stays in LDS
+sd = np.zeros(nb * 67, ops.INTRA_SATD_DESC)
+sd["ref_off"], sd["org_off"], sd["org_stride"], sd["w"], sd["h"] = pd["ref_off"], dd["org_off"], W, B, B
+sd["mode"], sd["filter_refs"] = pd["mode"], pd["filter_refs"]
+d_sd = ops.struct_to_device(sd)
+cost2 = ops.intra_satd_batch(refs, d_org, d_sd, nb * 67); torch.cuda.synchronize()
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(5):
+    cost2 = ops.intra_satd_batch(refs, d_org, d_sd, nb * 67)
+e1.record(); torch.cuda.synchronize()
+print("vvcgpu_intra_satd_batch (predict + SATD fused, one launch): %.3f ms against predict + SATD %.3f ms; costs %s" %
+      (e0.elapsed_time(e1) / 5, t[1] + t[2], "identical" if torch.equal(cost, cost2) else "DIFFER"))
 best = cost.view(nb, 67).argmin(1).cpu().numpy()
 print("best-mode histogram (planar, DC, angular):", int((best == 0).sum()), int((best == 1).sum()), int((best > 1).sum()))
 # oracle check of a sample

@@ -11,6 +11,7 @@
 // filtered) and the projected main reference in LDS, and every lane computes samples independently, iterating in destination
 // order so that stores coalesce for horizontal modes too.  Four PUs per workgroup, no workgroup barrier.
 #include "common.h"
+#include "dist_dev.h"
 
 namespace {
 
@@ -25,14 +26,11 @@ constexpr int NEG_MAX = 64;             // projected samples left of the main re
 __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
 __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); }
 
-__global__ __launch_bounds__(256) void intra_pred_kernel(const Pel* __restrict__ refsBase, Pel* __restrict__ dstBase,
-                                                         const vvcgpu_intra_desc* __restrict__ descs, int n, int clpMin, int clpMax)
+// One prediction block by one wave: predIntraAng into `dst` (row pitch ds; global memory or the wave's LDS tile).  top / left / tmp / mainBuf:
+// the wave's LDS work arrays (REF_MAX, REF_MAX, 2 REF_MAX, NEG_MAX + REF_MAX shorts).
+__device__ __forceinline__ void intra_pred_block(const vvcgpu_intra_desc& d, const Pel* __restrict__ refsBase, Pel* dst, int ds, int clpMin, int clpMax, int lane,
+                                                 short* top, short* left, short* tmpBuf, short* mainBuf)
 {
-  __shared__ short topS[4][REF_MAX], leftS[4][REF_MAX], tmpS[4][2 * REF_MAX], mainS[4][NEG_MAX + REF_MAX];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int b = blockIdx.x * 4 + wave;
-  if (b >= n) return;                                       // no workgroup barrier below
-  const vvcgpu_intra_desc d = descs[b];
   const int w = d.w, h = d.h, mode = d.mode;
   const int log2W = ilog2(w), log2H = ilog2(h);
   int T = w << 1, L = h << 1;                               // setReferenceArrayLengths :233-249
@@ -41,8 +39,7 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const Pel* __restrict__
     if (w > h) L += (w >> ratio) - h + ((w + 31) >> 5);
     else if (h > w) T += (h >> ratio) - w + ((h + 31) >> 5);
   }
-  short* top = topS[wave];                                  // top[0] = top-left, top[1 + x]
-  short* left = leftS[wave];                                // left[0] = top-left, left[1 + y]
+  // top[0] = top-left, top[1 + x]; left[0] = top-left, left[1 + y]
   const Pel* refs = refsBase + d.ref_off;
   if (!d.filter_refs)
   {
@@ -52,7 +49,7 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const Pel* __restrict__
   else
   {
     // regular reference sample filter along the chain  left[L] .. left[1], top-left, top[1] .. top[T]; the two ends stay
-    short* c = tmpS[wave];                                  // chain position L + i for top[i], L - i for left[i]
+    short* c = tmpBuf;                                      // chain position L + i for top[i], L - i for left[i]
     for (int i = lane; i <= T + L; i += 64) c[i] = i <= L ? (i == L ? refs[0] : refs[T + (L - i)]) : refs[i - L];
     wave_sync();
     for (int i = lane; i <= T + L; i += 64)
@@ -64,8 +61,7 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const Pel* __restrict__
   }
   wave_sync();
 
-  Pel* dst = dstBase + d.dst_off;
-  const int ds = d.dst_stride, count = w * h;
+  const int count = w * h;
   const int scale = (log2W - 2 + log2H - 2 + 2) >> 2;
   const int topLeft = top[0];
 
@@ -120,7 +116,7 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const Pel* __restrict__
   const short* sideR = isVer ? left : top;
   const int H = isVer ? h : w, log2Wm = isVer ? log2W : log2H;   // block in the orientation of the main reference
   const int sideLen = isVer ? L : T;
-  short* mainX = mainS[wave] + NEG_MAX;                     // main reference with the projected extension to the left (:588-609)
+  short* mainX = mainBuf + NEG_MAX;                         // main reference with the projected extension to the left (:588-609)
   if (angle < 0)
   {
     const int mainLen = (isVer ? w : h) + 1;
@@ -171,6 +167,37 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const Pel* __restrict__
     (void)log2Wm;
     dst[(ptrdiff_t)dy * ds + dx] = (Pel)v;
   }
+}
+
+__global__ __launch_bounds__(256) void intra_pred_kernel(const Pel* __restrict__ refsBase, Pel* __restrict__ dstBase,
+                                                         const vvcgpu_intra_desc* __restrict__ descs, int n, int clpMin, int clpMax)
+{
+  __shared__ short topS[4][REF_MAX], leftS[4][REF_MAX], tmpS[4][2 * REF_MAX], mainS[4][NEG_MAX + REF_MAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= n) return;                                       // no workgroup barrier below
+  const vvcgpu_intra_desc d = descs[b];
+  intra_pred_block(d, refsBase, dstBase + d.dst_off, d.dst_stride, clpMin, clpMax, lane, topS[wave], leftS[wave], tmpS[wave], mainS[wave]);
+}
+
+// ---- intra mode pre-selection (IntraSearch::estIntraPredLumaQT, EncoderLib/IntraSearch.cpp:397-480): predIntraAng of one candidate mode into
+// the wave's LDS tile, then the Hadamard distortion against the original (distParam.distFunc = xGetHADs) -- the prediction never reaches HBM.
+__global__ __launch_bounds__(256) void intra_satd_kernel(const Pel* __restrict__ refsBase, const Pel* __restrict__ orgBase,
+                                                         const vvcgpu_intra_satd_desc* __restrict__ descs, int n, int clpMin, int clpMax,
+                                                         unsigned long long* __restrict__ out)
+{
+  __shared__ short topS[4][REF_MAX], leftS[4][REF_MAX], tmpS[4][2 * REF_MAX], mainS[4][NEG_MAX + REF_MAX];
+  __shared__ __align__(16) short predS[4][64 * 64];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= n) return;                                       // no workgroup barrier below
+  const vvcgpu_intra_satd_desc s = descs[b];
+  vvcgpu_intra_desc d;
+  d.ref_off = s.ref_off; d.dst_off = 0; d.dst_stride = s.w; d.w = s.w; d.h = s.h; d.mode = s.mode; d.filter_refs = s.filter_refs;
+  intra_pred_block(d, refsBase, predS[wave], s.w, clpMin, clpMax, lane, topS[wave], leftS[wave], tmpS[wave], mainS[wave]);
+  wave_sync();
+  const unsigned long long res = satd_block<64>(orgBase + s.org_off, s.org_stride, predS[wave], s.w, s.w, s.h, lane);
+  if (lane == 0) out[b] = res;
 }
 
 
@@ -345,6 +372,19 @@ extern "C" int vvcgpu_intra_pred_batch(const vvc_pel* refs_base, vvc_pel* dst_ba
   VVC_CHECK_ARG(refs_base && dst_base && descs, "intra_pred_batch: null pointer");
   VVC_CHECK_ARG(clp_min <= clp_max && clp_min >= -32768 && clp_max <= 32767, "intra_pred_batch: clip range %d..%d", clp_min, clp_max);
   hipLaunchKernelGGL(intra_pred_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, refs_base, dst_base, descs, n, clp_min, clp_max);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+extern "C" int vvcgpu_intra_satd_batch(const vvc_pel* refs_base, const vvc_pel* org_base, const vvcgpu_intra_satd_desc* descs, int n, int clp_min,
+                                       int clp_max, uint64_t* out, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "intra_satd_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(refs_base && org_base && descs && out, "intra_satd_batch: null pointer");
+  VVC_CHECK_ARG(clp_min <= clp_max && clp_min >= -32768 && clp_max <= 32767, "intra_satd_batch: clip range %d..%d", clp_min, clp_max);
+  hipLaunchKernelGGL(intra_satd_kernel, dim3(cdiv(n, 4)), dim3(256), 0, (hipStream_t)stream, refs_base, org_base, descs, n, clp_min, clp_max,
+                     reinterpret_cast<unsigned long long*>(out));
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

@@ -155,6 +155,7 @@ int vvcgpu_sizeof(int id)
   case 25: return (int)sizeof(vvcgpu_depquant_desc);
   case 26: return (int)sizeof(vvcgpu_rdoq_rates);
   case 27: return (int)sizeof(vvcgpu_rdoq_desc);
+  case 28: return (int)sizeof(vvcgpu_intra_satd_desc);
   default: return -1;
   }
 }

@@ -236,6 +236,18 @@ def intra_ref_lengths(w, h):
     return t.value, l.value
 
 
+INTRA_SATD_DESC = np.dtype([("ref_off", "<i8"), ("org_off", "<i8"), ("org_stride", "<i4"), ("w", "<i2"), ("h", "<i2"), ("mode", "i1"),
+                            ("filter_refs", "i1"), ("reserved", "<i2"), ("reserved2", "<i4")])
+assert INTRA_SATD_DESC.itemsize == 32
+
+
+def intra_satd_batch(refs_base, org_base, descs_dev, n, clp=(0, 1023)):
+    """N4: intra mode pre-selection -- Hadamard distortion of predIntraAng(mode) against the original, one value per (block, mode)."""
+    out = torch.empty(n, dtype=torch.int64, device=org_base.device)
+    capi.call("vvcgpu_intra_satd_batch", capi.ptr(refs_base), capi.ptr(org_base), capi.ptr(descs_dev), n, clp[0], clp[1], capi.ptr(out), _stream())
+    return out
+
+
 def intra_pred_batch(refs_base, dst_base, descs_dev, n, clp=(0, 1023)):
     """N4: IntraPrediction::predIntraAng for n blocks (packed reference samples in, prediction blocks out)."""
     capi.call("vvcgpu_intra_pred_batch", capi.ptr(refs_base), capi.ptr(dst_base), capi.ptr(descs_dev), n, clp[0], clp[1], _stream())
