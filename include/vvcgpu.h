@@ -249,6 +249,15 @@ typedef struct vvcgpu_mc_desc {
 } vvcgpu_mc_desc;
 int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base,
                     const vvcgpu_mc_desc* descs, int n, int bit_depth, int clp_min, int clp_max, void* stream);
+/* "predict a candidate -> distortion against the original" in one pass: the cost of an AMVP candidate (InterSearch::xGetTemplateCost,
+ * EncoderLib/InterSearch.cpp:1606-1640: motionCompensation of the candidate vector, then getDistPart(DF_SAD)) and of a merge candidate
+ * (EncCu::xCheckRDCostMerge2Nx2N, EncoderLib/EncCu.cpp:1565-1592: motionCompensation of the candidate, then the Hadamard distParam.distFunc).
+ * Descriptors as vvcgpu_mc_batch with bi = 0 or 1, EXCEPT that dst_off / dst_stride address the ORIGINAL block in org_base and `reserved` is the
+ * row sub-sampling shift of the SAD (DistParam::subShift; 0 for the other kinds).  kind: 0 SAD, 1 Hadamard (xGetHADs), 2 SSE.  out[i] = what
+ * vvcgpu_mc_batch followed by vvcgpu_dist_batch(kind) returns for the pair; the prediction stays in LDS.  w, h <= 128.  The vector bits of
+ * the candidates (getCostOfVectorWithPredictor) and the candidate lists stay with the caller.                                               */
+int vvcgpu_mc_dist_batch(int kind, const vvc_pel* ref0_base, const vvc_pel* ref1_base, const vvc_pel* org_base, const vvcgpu_mc_desc* descs, int n,
+                         int bit_depth, int clp_min, int clp_max, uint64_t* out, void* stream);
 
 /* ---- B1-B4: PelBuffer element-wise operations, batched  (g_pelBufOP table, Buffer.h:57-73: addAvg4/8, reco4/8,
  *          linTf4/8; cores Buffer.cpp:50-94; plus AreaBuf::subtract Buffer.h:321-339, removeHighFreq :389-416,

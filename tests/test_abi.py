@@ -78,6 +78,7 @@ def test_next_row_entry_points_validate_arguments_without_a_device():
         "vvcgpu_affine_sobel_batch": lambda n: lib.vvcgpu_affine_sobel_batch(0, nul, nul, nul, n, nul),
         "vvcgpu_affine_equal_coeff_batch": lambda n: lib.vvcgpu_affine_equal_coeff_batch(nul, nul, nul, nul, n, nul, nul),
         "vvcgpu_intra_pred_batch": lambda n: lib.vvcgpu_intra_pred_batch(nul, nul, nul, n, 0, 1023, nul),
+        "vvcgpu_mc_dist_batch": lambda n: lib.vvcgpu_mc_dist_batch(0, nul, nul, nul, nul, n, 10, 0, 1023, nul, nul),
         "vvcgpu_intra_satd_batch": lambda n: lib.vvcgpu_intra_satd_batch(nul, nul, nul, n, 0, 1023, nul, nul),
         "vvcgpu_intra_fill_refs_batch": lambda n: lib.vvcgpu_intra_fill_refs_batch(nul, nul, nul, nul, n, 10, nul),
         "vvcgpu_cclm_pred_batch": lambda n: lib.vvcgpu_cclm_pred_batch(nul, nul, nul, nul, n, 10, 10, 0, 1023, nul),

@@ -13,6 +13,7 @@
 // in LDS, the horizontal pass writes the 14-bit intermediate to LDS (never to HBM -- the reference's m_filteredBlockTmp),
 // the vertical pass and, for bi-prediction, the second list and the average stay in registers.
 #include "common.h"
+#include "dist_dev.h"
 
 namespace {
 
@@ -439,18 +440,23 @@ __global__ __launch_bounds__(256, 6) void mc_fast_kernel(const Pel* __restrict__
   }
 }
 
-// generic kernel: any size, one wave per PU, persistent over the list of PUs the fast kernel left
+// generic kernel: any size, one wave per PU, persistent over the list of PUs the fast kernel left.
+// DIST (vvcgpu_mc_dist_batch): the prediction goes into an LDS tile instead of dst, and the wave returns its distortion against the original
+// (descriptor field dst_off / dst_stride = the original block, reserved = row sub-sampling shift of the SAD); list == nullptr: every descriptor.
+template <bool DIST>
 __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
                                                       Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs,
-                                                      const int* __restrict__ list, const int* __restrict__ count, int bd, int cmin, int cmax)
+                                                      const int* __restrict__ list, const int* __restrict__ count, int bd, int cmin, int cmax,
+                                                      int nDirect, int distKind, const Pel* __restrict__ orgBase, unsigned long long* __restrict__ out)
 {
   __shared__ short win[WR * WP];
   __shared__ short tmp[WR * ST];
+  __shared__ __align__(16) short predT[DIST ? 128 * 128 : 8];
   const int lane = threadIdx.x;
-  const int cnt = *count;
+  const int cnt = list ? *count : nDirect;
   for (int li = blockIdx.x; li < cnt; li += gridDim.x)
   {
-  const vvcgpu_mc_desc d = descs[list[li]];
+  const vvcgpu_mc_desc d = descs[list ? list[li] : li];
   const int N = d.is_luma ? 8 : 4, half = N / 2 - 1;
   const bool rndRes = d.bi == 0;
   const int nRef = d.bi == 1 ? 2 : 1;
@@ -532,7 +538,8 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
           }
         }
       }
-      Pel* dst = dstBase + d.dst_off + (size_t)sy * d.dst_stride + sx;
+      Pel* dst = DIST ? predT + sy * d.w + sx : dstBase + d.dst_off + (size_t)sy * d.dst_stride + sx;
+      const int dstStride = DIST ? (int)d.w : d.dst_stride;
       const int shiftNum = max(2, IF_INTERNAL_PREC - bd) + 1, offset = (1 << (shiftNum - 1)) + 2 * IF_INTERNAL_OFFS;
 #pragma unroll
       for (int j = 0; j < 4; j++)
@@ -543,10 +550,32 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
           const int y = p / tw, x = p - y * tw;
           int v = pred[0][j];
           if (d.bi == 1) v = clip3(cmin, cmax, (pred[0][j] + pred[1][j] + offset) >> shiftNum);
-          dst[(size_t)y * d.dst_stride + x] = (short)v;
+          dst[(size_t)y * dstStride + x] = (short)v;
         }
       }
     }
+  if (DIST)
+  {
+    __syncthreads();                                   // the tile is complete
+    const Pel* org = orgBase + d.dst_off;
+    const int os = d.dst_stride, w = d.w, h = d.h;
+    unsigned long long res;
+    if (distKind == 1) res = satd_block<64>(org, os, predT, w, w, h, lane);
+    else
+    {
+      const int ss = distKind == 0 ? d.reserved : 0, rows = h >> ss;
+      unsigned long long acc = 0;
+      for (int i = lane; i < rows * w; i += 64)
+      {
+        const int r = i / w, x = i - r * w;
+        const int df = (int)org[(size_t)(r << ss) * os + x] - (int)predT[(r << ss) * w + x];
+        acc += distKind == 2 ? (unsigned)(df * df) : (unsigned)abs(df);
+      }
+      res = wave_sum_u64(acc) << ss;
+    }
+    if (lane == 0) out[li] = res;
+    __syncthreads();                                   // before the next descriptor overwrites the tile
+  }
   }
 }
 
@@ -672,9 +701,23 @@ int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel*
   const int xcd = vvc_xcd_on();
   hipLaunchKernelGGL(mc_fast_kernel, dim3(vvc_xcd_grid(cdiv(n, 8), xcd)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
                      dst_base, descs, n, bit_depth, clp_min, clp_max, list, counters + 16 * cur, counters + 16 * (cur ^ 1), cdiv(n, 8), xcd);
-  hipLaunchKernelGGL(mc_batch_kernel, dim3(n < 2048 ? n : 2048), dim3(64), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     dst_base, descs, list, counters + 16 * cur, bit_depth, clp_min, clp_max);
+  hipLaunchKernelGGL(mc_batch_kernel<false>, dim3(n < 2048 ? n : 2048), dim3(64), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
+                     dst_base, descs, list, counters + 16 * cur, bit_depth, clp_min, clp_max, 0, 0, nullptr, nullptr);
   VVC_LAUNCH_CHECK_COUNTERS(st);
+  return VVCGPU_OK;
+}
+
+int vvcgpu_mc_dist_batch(int kind, const vvc_pel* ref0_base, const vvc_pel* ref1_base, const vvc_pel* org_base, const vvcgpu_mc_desc* descs, int n,
+                         int bit_depth, int clp_min, int clp_max, uint64_t* out, void* stream)
+{
+  VVC_CHECK_ARG(kind >= 0 && kind <= 2, "mc_dist_batch: kind %d (0 SAD, 1 Hadamard, 2 SSE)", kind);
+  VVC_CHECK_ARG(n >= 0, "mc_dist_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(ref0_base && org_base && descs && out, "mc_dist_batch: null pointer");
+  if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("mc_dist_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
+  hipLaunchKernelGGL(mc_batch_kernel<true>, dim3(n < 4096 ? n : 4096), dim3(64), 0, (hipStream_t)stream, ref0_base, ref1_base ? ref1_base : ref0_base,
+                     nullptr, descs, nullptr, nullptr, bit_depth, clp_min, clp_max, n, kind, org_base, reinterpret_cast<unsigned long long*>(out));
+  VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
 

@@ -369,6 +369,15 @@ def mc_batch(ref0_base, ref1_base, dst_base, descs_dev, n, bit_depth=10, clp=(0,
               bit_depth, clp[0], clp[1], _stream())
 
 
+def mc_dist_batch(kind, ref0_base, ref1_base, org_base, descs_dev, n, bit_depth=10, clp=(0, 1023)):
+    """predict a candidate (descriptors as mc_batch, dst_off / dst_stride = the original block, reserved = SAD row sub-sampling shift) and return
+    its distortion against the original: int64 tensor [n]."""
+    out = torch.empty(n, dtype=torch.int64, device=org_base.device)
+    capi.call("vvcgpu_mc_dist_batch", kind, capi.ptr(ref0_base), capi.ptr(ref1_base), capi.ptr(org_base), capi.ptr(descs_dev), n, bit_depth,
+              clp[0], clp[1], capi.ptr(out), _stream())
+    return out
+
+
 def pelop_batch(op, src0_base, src1_base, dst_base, descs_dev, n, cfg):
     capi.call("vvcgpu_pelop_batch", op, capi.ptr(src0_base), capi.ptr(src1_base), capi.ptr(dst_base), capi.ptr(descs_dev), n,
               C.byref(cfg), _stream())
