@@ -31,7 +31,7 @@ __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
 
 // ---- work lists (device): hdr[0 .. RC_NCLS) = counts of the classes, hdr[RC_FB] = count of the fall-back list
 constexpr int RC_HDR = 16;
-enum { RC_C64 = 0, RC_C32, RC_C16, RC_C8, RC_C4, RC_CGEN, RC_R6432, RC_R3264, RC_R6416, RC_R1664, RC_R3216, RC_R1632, RC_NCLS };
+enum { RC_C64 = 0, RC_C32, RC_C16, RC_C8, RC_C4, RC_CGEN, RC_R6432, RC_R3264, RC_R6416, RC_R1664, RC_R3216, RC_R1632, RC_R84, RC_R48, RC_NCLS };
 constexpr int RC_FB = RC_NCLS;
 static_assert(RC_FB < RC_HDR, "the header is one 16-int counter set of vvcgpu_counters");
 
@@ -50,6 +50,8 @@ __device__ __forceinline__ int rc_class(const RcDesc& d)
   if (w == 64) return h == 32 ? RC_R6432 : h == 16 ? RC_R6416 : RC_CGEN;
   if (w == 32) return h == 64 ? RC_R3264 : h == 16 ? RC_R3216 : RC_CGEN;
   if (w == 16) return h == 64 ? RC_R1664 : h == 32 ? RC_R1632 : RC_CGEN;
+  if (w == 8 && h == 4) return RC_R84;
+  if (w == 4 && h == 8) return RC_R48;
   return RC_CGEN;
 }
 
@@ -385,18 +387,21 @@ __device__ __forceinline__ bool rc_tu_mfma(const RcDesc& d, const Pel* __restric
 // Generic path: one wave per TU, any W x H in 2..64; the residual / intermediates / coefficients live in two LDS buffers of the wave.
 // Matrices come from global memory (int32 tables).  Exact 32-bit arithmetic as the reference's `int` loops.
 __device__ __forceinline__ const int* rc_t32(const int* tr32, int type, int n) { return tr32 + type * 5460 + (n * n - 4) / 3; }
+// LDS copy of the matrices the generic path reads (rc_generic_kernel<512, 4>): per type the sizes 2 .. 32 (1364 ints), then DCT-II 64
+constexpr int RC_GT_TYPE = 1364, RC_GT_INTS = 3 * RC_GT_TYPE + 4096;
+__device__ __forceinline__ const int* rc_t32_lds(const int* tabL, int type, int n) { return n == 64 ? tabL + 3 * RC_GT_TYPE : tabL + type * RC_GT_TYPE + (n * n - 4) / 3; }
 
 __device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                               TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int ti, int bd, int clpMin, int clpMax,
                               const int* __restrict__ tr32, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
-                              int* bufA, int* bufB, int lane)
+                              int* bufA, int* bufB, int lane, const int* tabL = nullptr)
 {
   const int w = d.w, h = d.h, lw = ilog2(w), lh = ilog2(h);
   const int wj = w > 32 ? 32 : w, hj = h > 32 ? 32 : h;
   const Pel* org = orgBase + d.org_off;
   const Pel* pred = predBase + d.pred_off;
-  const int* Th = rc_t32(tr32, d.tr_hor, w);
-  const int* Tv = rc_t32(tr32, d.tr_ver, h);
+  const int* Th = tabL ? rc_t32_lds(tabL, d.tr_hor, w) : rc_t32(tr32, d.tr_hor, w);      // the matrix entries sit on the inner loops: LDS when the kernel has a copy
+  const int* Tv = tabL ? rc_t32_lds(tabL, d.tr_ver, h) : rc_t32(tr32, d.tr_ver, h);
   for (int e = lane; e < w * h; e += 64)
   {
     const int r = e >> lw, k = e & (w - 1);
@@ -535,12 +540,20 @@ __global__ __launch_bounds__(64 * WAVES) void rc_generic_kernel(const Pel* __res
                                                         unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax, VvcTrTables tb)
 {
   __shared__ int bufA[WAVES][CAP], bufB[WAVES][CAP];
+  __shared__ int tabL[WAVES > 1 ? RC_GT_INTS : 1];
   const int ca = countA[0], wave = threadIdx.x >> 6;
+  if ((int)blockIdx.x * WAVES >= ca) return;
+  if (WAVES > 1)
+  {
+    for (int e = threadIdx.x; e < RC_GT_INTS; e += 64 * WAVES)
+      tabL[e] = e < 3 * RC_GT_TYPE ? tb.tr32[(e / RC_GT_TYPE) * 5460 + e % RC_GT_TYPE] : tb.tr32[1364 + e - 3 * RC_GT_TYPE];
+    __syncthreads();
+  }
   for (int k = blockIdx.x * WAVES + wave; k < ca; k += gridDim.x * WAVES)
   {
     const int ti = listA[k];
     rc_tu_generic(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, bufA[wave],
-                  bufB[wave], (int)threadIdx.x & 63);
+                  bufB[wave], (int)threadIdx.x & 63, WAVES > 1 ? tabL : nullptr);
   }
 }
 
@@ -674,6 +687,137 @@ __device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs,
   RC_WAVE_SYNC();
 }
 
+// 8 x 4 and 4 x 8 (the most frequent rectangles of a real encode: tests/golden/trace_*.npz): the same scheme with 8 lanes per TU -- lane = row
+// in the horizontal stages (H rows), lane = column in the vertical stages and the quantiser (W columns; the other lanes of the group idle there).
+// The TU has two coefficient groups side by side (8 x 4) or one above the other (4 x 8): the group's scan index is its position.
+template <int W, int H>
+__device__ __forceinline__ void rc_rect_group(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
+                                              const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                              TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
+                                              const RcSmallTab& tabs, int* tmpL, int lane)
+{
+  constexpr int L = 8, G = 64 / L, LW = W == 4 ? 2 : 3, LH = H == 4 ? 2 : 3, TOW = W == 4 ? 0 : 16, TOH = H == 4 ? 0 : 16;
+  typedef short pelW __attribute__((ext_vector_type(W)));
+  const int tg = lane / L, li = lane % L;
+  const int k = item * G + tg;
+  const bool act = k < cnt;
+  const int ti = list[act ? k : 0];
+  const RcDesc d = descs[ti];
+  int* tt = tmpL + tg * (L * (L + 1));
+  const int* Th = tabs.t[d.tr_hor] + TOW;
+  const int* Tv = tabs.t[d.tr_ver] + TOH;
+  const int* ThT = tabs.tt[d.tr_hor] + TOW;
+  const int* TvT = tabs.tt[d.tr_ver] + TOH;
+  const bool isRow = li < H, isCol = li < W;
+  const int rr = isRow ? li : 0;
+  // stage F1: lane = row
+  const pelW o = *reinterpret_cast<const pelW*>(orgBase + d.org_off + (size_t)rr * d.org_stride);
+  const pelW p = *reinterpret_cast<const pelW*>(predBase + d.pred_off + (size_t)rr * d.pred_stride);
+  const int s1 = LW + bd + 6 - 15 + 2, s2 = LH + 6 + 2;
+  if (isRow)
+  {
+    int x[W];
+#pragma unroll
+    for (int j = 0; j < W; j++) x[j] = (int)o[j] - (int)p[j];
+#pragma unroll
+    for (int j = 0; j < W; j++)
+    {
+      int sum = 0;
+#pragma unroll
+      for (int kk = 0; kk < W; kk++) sum += x[kk] * Th[j * W + kk];
+      tt[j * (L + 1) + li] = (sum + (1 << (s1 - 1))) >> s1;
+    }
+  }
+  RC_WAVE_SYNC();
+  // stage F2: lane = column (horizontal frequency), registers = rows
+  int cf[H];
+  {
+    int t[H];
+#pragma unroll
+    for (int r = 0; r < H; r++) t[r] = isCol ? tt[li * (L + 1) + r] : 0;
+#pragma unroll
+    for (int j = 0; j < H; j++)
+    {
+      int sum = 0;
+#pragma unroll
+      for (int r = 0; r < H; r++) sum += t[r] * Tv[j * H + r];
+      cf[j] = (sum + (1 << (s2 - 1))) >> s2;
+    }
+  }
+  RC_WAVE_SYNC();
+  // quantiser (coefficient groups: rows 4 R .. 4 R + 3 x the lane's aligned quad); idle lanes carry zeros
+  const RcQ q = rc_qparams(W, H, d.qp, bd, d.intra_slice, d.sign_hiding);
+  int lv[H], du[H], sum = 0;
+#pragma unroll
+  for (int j = 0; j < H; j++) { int mag; lv[j] = rc_quant_one(q, cf[j], du[j], mag); sum += mag; }
+#pragma unroll
+  for (int m = 1; m < L; m <<= 1) sum += __shfl_xor(sum, m);
+  if (act && li == 0) absSumOut[ti] = (unsigned)sum;
+  if (q.sbh)
+  {
+    int lastCg = -1;
+#pragma unroll
+    for (int R = 0; R < H / 4; R++)
+    {
+      int l4[4] = { lv[4 * R], lv[4 * R + 1], lv[4 * R + 2], lv[4 * R + 3] };
+      if (rc_cg_nonzero(l4)) lastCg = max(lastCg, (W == 8 ? (li >> 2) : 0) + R);
+    }
+    lastCg = max(lastCg, __shfl_xor(lastCg, 4));
+#pragma unroll
+    for (int R = 0; R < H / 4; R++)
+    {
+      int l4[4] = { lv[4 * R], lv[4 * R + 1], lv[4 * R + 2], lv[4 * R + 3] };
+      const int d4[4] = { du[4 * R], du[4 * R + 1], du[4 * R + 2], du[4 * R + 3] };
+      const int c4[4] = { cf[4 * R], cf[4 * R + 1], cf[4 * R + 2], cf[4 * R + 3] };
+      rc_sbh_quad(l4, d4, c4, (W == 8 ? (li >> 2) : 0) + R == lastCg, lane);
+#pragma unroll
+      for (int r = 0; r < 4; r++) lv[4 * R + r] = l4[r];
+    }
+  }
+  if (act && isCol)
+  {
+    TCoeff* level = levelBase + d.level_off;
+#pragma unroll
+    for (int j = 0; j < H; j++) level[j * W + li] = lv[j];
+  }
+  // de-quantiser + stage I1 (vertical), written transposed: tt[r][column]
+  if (isCol)
+  {
+    int cq[H];
+#pragma unroll
+    for (int j = 0; j < H; j++) cq[j] = rc_dequant_one(q, lv[j]);
+#pragma unroll
+    for (int r = 0; r < H; r++)
+    {
+      int acc = 0;
+#pragma unroll
+      for (int kk = 0; kk < H; kk++) acc += cq[kk] * TvT[r * H + kk];
+      tt[r * (L + 1) + li] = clip3(-(1 << 15), (1 << 15) - 1, (acc + 256) >> 9);
+    }
+  }
+  RC_WAVE_SYNC();
+  // stage I2 (horizontal): lane = row
+  const int s2i = (6 + 15 - 1) - bd + 2;
+  if (isRow)
+  {
+    int y[W];
+#pragma unroll
+    for (int i = 0; i < W; i++) y[i] = tt[li * (L + 1) + i];
+    pelW out;
+#pragma unroll
+    for (int x = 0; x < W; x++)
+    {
+      int acc = 0;
+#pragma unroll
+      for (int i = 0; i < W; i++) acc += y[i] * ThT[x * W + i];
+      const int resi = (short)clip3(-(1 << 15), (1 << 15) - 1, (acc + (1 << (s2i - 1))) >> s2i);
+      out[x] = (short)clip3(clpMin, clpMax, (int)p[x] + resi);
+    }
+    if (act) *reinterpret_cast<pelW*>(recBase + d.rec_off + (size_t)li * d.rec_stride) = out;
+  }
+  RC_WAVE_SYNC();
+}
+
 template <int S>
 __global__ __launch_bounds__(256, S == 4 ? 6 : 3) void rc_small_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                        TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs,
@@ -684,7 +828,8 @@ __global__ __launch_bounds__(256, S == 4 ? 6 : 3) void rc_small_kernel(const Pel
   __shared__ int tmpAll[4][8 * 8 * 9];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int cnt = count[0];
-  const int total = (cnt + 64 / S - 1) / (64 / S);
+  constexpr int PER = S == 4 ? 16 : 8;                                          // TUs per wave item (S = 84 / 48: the 8 x 4 / 4 x 8 rectangles)
+  const int total = (cnt + PER - 1) / PER;
   if ((int)blockIdx.x * 4 >= total) return;
   for (int e = tid; e < 3 * 80; e += 256)
   {
@@ -694,7 +839,11 @@ __global__ __launch_bounds__(256, S == 4 ? 6 : 3) void rc_small_kernel(const Pel
   }
   __syncthreads();
   for (int item = blockIdx.x * 4 + wave; item < total; item += gridDim.x * 4)
-    rc_small_group<S>(descs, list, cnt, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+  {
+    if (S == 84)      rc_rect_group<8, 4>(descs, list, cnt, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+    else if (S == 48) rc_rect_group<4, 8>(descs, list, cnt, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+    else              rc_small_group<(S > 8 ? 8 : S)>(descs, list, cnt, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+  }
 }
 
 // All five size classes in ONE launch.  Each class alone is bound by the latency of a TU, not by throughput (405 64x64 TUs are 405 waves:
@@ -711,15 +860,15 @@ __global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict_
   __shared__ int tmpAll[4][8 * 8 * 9];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   // slots (four wave items of one entry) in the order below: the longest items first, so that the short ones fill the machine while they run
-  constexpr int NORD = 11;
-  constexpr int ordCls[NORD] = { RC_C64, RC_R6432, RC_R3264, RC_C32, RC_R6416, RC_R1664, RC_C8, RC_R3216, RC_R1632, RC_C16, RC_C4 };
+  constexpr int NORD = 13;
+  constexpr int ordCls[NORD] = { RC_C64, RC_R6432, RC_R3264, RC_C32, RC_R6416, RC_R1664, RC_C8, RC_R3216, RC_R1632, RC_C16, RC_C4, RC_R84, RC_R48 };
   int cnt[NORD], items[NORD], end[NORD];
   int total = 0;
 #pragma unroll
   for (int k = 0; k < NORD; k++)
   {
     cnt[k] = hdr[ordCls[k]];
-    items[k] = ordCls[k] == RC_C8 ? (cnt[k] + 7) >> 3 : ordCls[k] == RC_C4 ? (cnt[k] + 15) >> 4 : cnt[k];   // lane-group classes: 8 / 16 TUs per item
+    items[k] = (ordCls[k] == RC_C8 || ordCls[k] == RC_R84 || ordCls[k] == RC_R48) ? (cnt[k] + 7) >> 3 : ordCls[k] == RC_C4 ? (cnt[k] + 15) >> 4 : cnt[k];   // lane-group classes: 8 / 16 TUs per item
     total += (items[k] + 3) >> 2;
     end[k] = total;
   }
@@ -747,7 +896,9 @@ __global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict_
     {
     RC_MF(0, 64, 64) RC_MF(1, 64, 32) RC_MF(2, 32, 64) RC_MF(3, 32, 32) RC_MF(4, 64, 16) RC_MF(5, 16, 64) RC_MF(7, 32, 16) RC_MF(8, 16, 32) RC_MF(9, 16, 16)
     case 6: if (item < items[6]) rc_small_group<8>(descs, lists + (size_t)RC_C8 * n, cnt[6], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
-    default: if (item < items[10]) rc_small_group<4>(descs, lists + (size_t)RC_C4 * n, cnt[10], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 10: if (item < items[10]) rc_small_group<4>(descs, lists + (size_t)RC_C4 * n, cnt[10], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 11: if (item < items[11]) rc_rect_group<8, 4>(descs, lists + (size_t)RC_R84 * n, cnt[11], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    default: if (item < items[12]) rc_rect_group<4, 8>(descs, lists + (size_t)RC_R48 * n, cnt[12], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
     }
 #undef RC_MF
     if (!done && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti;               // residual outside +-1023: the generic kernel takes it
@@ -845,9 +996,13 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
                        lists + (size_t)RC_C8 * n, abs_sum, bit_depth, clp_min, clp_max, tb);
     hipLaunchKernelGGL(rc_small_kernel<4>, dim3(wg4), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_C4,
                        lists + (size_t)RC_C4 * n, abs_sum, bit_depth, clp_min, clp_max, tb);
+    hipLaunchKernelGGL(rc_small_kernel<84>, dim3(wg8), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_R84,
+                       lists + (size_t)RC_R84 * n, abs_sum, bit_depth, clp_min, clp_max, tb);
+    hipLaunchKernelGGL(rc_small_kernel<48>, dim3(wg8), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_R48,
+                       lists + (size_t)RC_R48 * n, abs_sum, bit_depth, clp_min, clp_max, tb);
     VVC_LAUNCH_CHECK_COUNTERS(st);
   }
-  const int wgS = cdiv(n, 4) < 2048 ? cdiv(n, 4) : 2048, wgG = n < 1024 ? n : 1024;
+  const int wgS = cdiv(n, 4) < 768 ? cdiv(n, 4) : 768, wgG = n < 1024 ? n : 1024;
   hipLaunchKernelGGL((rc_generic_kernel<512, 4>), dim3(wgS), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_CGEN,
                      lists + (size_t)RC_CGEN * n, abs_sum, bit_depth, clp_min, clp_max, tb);
   hipLaunchKernelGGL((rc_generic_kernel<4096, 1>), dim3(wgG), dim3(64), 0, st, org_base, pred_base, rec_base, level_base, descs, fbCount, fbList,
