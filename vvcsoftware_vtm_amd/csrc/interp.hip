@@ -452,11 +452,46 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
   __shared__ short win[WR * WP];
   __shared__ short tmp[WR * ST];
   __shared__ __align__(16) short predT[DIST ? 128 * 128 : 8];
+  __shared__ __align__(16) unsigned tileL[DIST ? 4 : MC_LDS_DW];
   const int lane = threadIdx.x;
   const int cnt = list ? *count : nDirect;
   for (int li = blockIdx.x; li < cnt; li += gridDim.x)
   {
   const vvcgpu_mc_desc d = descs[list ? list[li] : li];
+  // a PU whose sides are multiples of the packed path's tile (16 luma / 8 chroma samples) is a grid of tiles with the same fractional phase: the
+  // wave walks them with the packed code of the fast kernel (here, not there: inlined into the fast kernel the loop cost it its 80-VGPR budget and
+  // the MC stage of the canonical workload went from 0.075 to 0.18 ms)
+  if (!DIST && (d.w % (d.is_luma ? 16 : 8)) == 0 && (d.h % (d.is_luma ? 16 : 8)) == 0)
+  {
+    const int T = d.is_luma ? 16 : 8, tx = d.w / T, nt = tx * (d.h / T);
+    auto tile = [&](int t) { vvcgpu_mc_desc q = d; const int y = (t / tx) * T, x = (t - (t / tx) * tx) * T; q.w = q.h = (short)T;
+                             q.ref0_off += (int64_t)y * d.ref0_stride + x; q.ref1_off += (int64_t)y * d.ref1_stride + x; q.dst_off += (int64_t)y * d.dst_stride + x; return q; };
+    unsigned* L = tileL;
+    if (d.is_luma)
+    {
+      for (int t = 0; t < nt; t++)
+      {
+        const vvcgpu_mc_desc q = tile(t);
+        McStaged<8, 16, 64> st;
+        mc_stage<8, 16, 64>(q, true, ref0Base, ref1Base, lane, st);
+        mc_tile_dot2<8, 16, 64>(q, true, st, dstBase, bd, cmin, cmax, lane, L, reinterpret_cast<short*>(L + 23 * 12), reinterpret_cast<short*>(L + 23 * 12 + 16 * 12));
+      }
+    }
+    else
+    {
+      const bool hi = lane >= 32;                            // two chroma tiles side by side in the wave's halves
+      unsigned* Lh = L + (hi ? MC_LDS_DW / 2 : 0);
+      for (int t = 0; t < nt; t += 2)
+      {
+        const bool on = t + (hi ? 1 : 0) < nt;
+        const vvcgpu_mc_desc q = tile(on ? t + (hi ? 1 : 0) : t);
+        McStaged<4, 8, 32> st;
+        mc_stage<4, 8, 32>(q, on, ref0Base, ref1Base, lane & 31, st);
+        mc_tile_dot2<4, 8, 32>(q, on, st, dstBase, bd, cmin, cmax, lane & 31, Lh, reinterpret_cast<short*>(Lh + 11 * 6), reinterpret_cast<short*>(Lh + 11 * 6 + 8 * 6));
+      }
+    }
+    continue;
+  }
   const int N = d.is_luma ? 8 : 4, half = N / 2 - 1;
   const bool rndRes = d.bi == 0;
   const int nRef = d.bi == 1 ? 2 : 1;
