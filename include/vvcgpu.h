@@ -237,8 +237,9 @@ int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_
  * bi = 0: dst = clipped uni-prediction from ref0.   bi = 1: dst = addAvg(pred(ref0), pred(ref1)).
  * bi = 2: dst = the unrounded 14-bit intermediate of ref0 (what motionCompensation leaves in m_acYuvPred).
  * Reads: the rows / columns the reference's branch reads ((N - 1) extra rows only when frac_y != 0, columns likewise), as whole aligned
- * dwords -- i.e. at most ONE sample left of and one sample right of them IN THE SAME ROW (the x86 filters over-read further:
- * picture margins cover it).  16x16 luma and 8x8 chroma PUs take the packed fast path; every result is bit-equal to the reference. */
+ * dwords -- i.e. at most TWO samples left of and two samples right of them IN THE SAME ROW (the x86 filters over-read further:
+ * picture margins cover it).  16x16 luma and 8x8 chroma PUs take the packed fast path; PUs that are grids of such tiles walk it tile by tile;
+ * every result is bit-equal to the reference. */
 typedef struct vvcgpu_mc_desc {
   int64_t ref0_off, ref1_off, dst_off;
   int32_t ref0_stride, ref1_stride, dst_stride;

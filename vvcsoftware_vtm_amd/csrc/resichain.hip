@@ -530,30 +530,43 @@ __global__ __launch_bounds__(256, W * H >= 2048 ? 2 : 3) void rc_mfma_kernel(con
 }
 
 // generic kernel: the class-`generic` list, then the fall-back list of the matrix-core kernels (TUs whose residual left +-1023)
-// WAVES waves per workgroup, each with its own pair of CAP-int buffers.  <4096, 1>: any TU (the fall-back list: up to 64 x 64).  <512, 4>: the
-// class-`generic` list, whose TUs have a side of at most 8 (both sides >= 16 are matrix-core classes), i.e. at most 64 x 8 samples: eight times
-// the waves per compute unit of the single-wave form (LDS bound: 32 KB per wave against 4 KB).
-template <int CAP, int WAVES>
-__global__ __launch_bounds__(64 * WAVES) void rc_generic_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+// The class-`generic` list holds TUs with a side of at most 8 (both sides >= 16 are matrix-core classes), i.e. at most 64 x 8 samples: 512-int
+// buffers, four waves per workgroup (eight times the waves per compute unit of a 4096-int single-wave form).  The fall-back list of the
+// matrix-core classes (a residual outside +-1023) holds TUs of up to 64 x 64.
+// ONE launch for both lists (an empty launch still costs ~4.6 us of a 4K picture): workgroups [0, wgSmall) serve the class-`generic` list,
+// four waves with 512-int buffers each and the matrices in LDS; the workgroups behind them serve the fall-back list with ONE wave and
+// 4096-int buffers (the other three waves leave at once).  The two forms share the LDS bytes.
+__global__ __launch_bounds__(256) void rc_generic_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                         TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs,
                                                         const int* __restrict__ countA, const int* __restrict__ listA,
+                                                        const int* __restrict__ countB, const int* __restrict__ listB, int wgSmall,
                                                         unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax, VvcTrTables tb)
 {
-  __shared__ int bufA[WAVES][CAP], bufB[WAVES][CAP];
-  __shared__ int tabL[WAVES > 1 ? RC_GT_INTS : 1];
-  const int ca = countA[0], wave = threadIdx.x >> 6;
-  if ((int)blockIdx.x * WAVES >= ca) return;
-  if (WAVES > 1)
+  constexpr int SMALL_INTS = 2 * 4 * 512 + RC_GT_INTS, BIG_INTS = 2 * 4096;
+  __shared__ int lds[SMALL_INTS > BIG_INTS ? SMALL_INTS : BIG_INTS];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+  if ((int)blockIdx.x < wgSmall)
   {
-    for (int e = threadIdx.x; e < RC_GT_INTS; e += 64 * WAVES)
+    const int ca = countA[0];
+    if ((int)blockIdx.x * 4 >= ca) return;
+    int* tabL = lds + 2 * 4 * 512;
+    for (int e = threadIdx.x; e < RC_GT_INTS; e += 256)
       tabL[e] = e < 3 * RC_GT_TYPE ? tb.tr32[(e / RC_GT_TYPE) * 5460 + e % RC_GT_TYPE] : tb.tr32[1364 + e - 3 * RC_GT_TYPE];
     __syncthreads();
+    for (int k = blockIdx.x * 4 + wave; k < ca; k += wgSmall * 4)
+    {
+      const int ti = listA[k];
+      rc_tu_generic(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, lds + wave * 1024,
+                    lds + wave * 1024 + 512, lane, tabL);
+    }
+    return;
   }
-  for (int k = blockIdx.x * WAVES + wave; k < ca; k += gridDim.x * WAVES)
+  if (wave != 0) return;
+  const int cb = countB[0], nBig = (int)gridDim.x - wgSmall;
+  for (int k = (int)blockIdx.x - wgSmall; k < cb; k += nBig)
   {
-    const int ti = listA[k];
-    rc_tu_generic(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, bufA[wave],
-                  bufB[wave], (int)threadIdx.x & 63, WAVES > 1 ? tabL : nullptr);
+    const int ti = listB[k];
+    rc_tu_generic(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, lds, lds + 4096, lane);
   }
 }
 
@@ -1002,11 +1015,9 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
                        lists + (size_t)RC_R48 * n, abs_sum, bit_depth, clp_min, clp_max, tb);
     VVC_LAUNCH_CHECK_COUNTERS(st);
   }
-  const int wgS = cdiv(n, 4) < 768 ? cdiv(n, 4) : 768, wgG = n < 1024 ? n : 1024;
-  hipLaunchKernelGGL((rc_generic_kernel<512, 4>), dim3(wgS), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_CGEN,
-                     lists + (size_t)RC_CGEN * n, abs_sum, bit_depth, clp_min, clp_max, tb);
-  hipLaunchKernelGGL((rc_generic_kernel<4096, 1>), dim3(wgG), dim3(64), 0, st, org_base, pred_base, rec_base, level_base, descs, fbCount, fbList,
-                     abs_sum, bit_depth, clp_min, clp_max, tb);
+  const int wgS = cdiv(n, 4) < 768 ? cdiv(n, 4) : 768, wgG = n < 512 ? n : 512;
+  hipLaunchKernelGGL(rc_generic_kernel, dim3(wgS + wgG), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_CGEN,
+                     lists + (size_t)RC_CGEN * n, fbCount, fbList, wgS, abs_sum, bit_depth, clp_min, clp_max, tb);
   VVC_LAUNCH_CHECK_COUNTERS(st);
   return VVCGPU_OK;
 }
