@@ -21,8 +21,10 @@ __device__ __forceinline__ unsigned long long group_sum_u64(unsigned long long v
 
 // ---------------------------------------------------------------------------------------------------
 // Hadamard tile: TW columns in registers, TH rows across TH consecutive lanes.  `lane` = lane index inside a group of G lanes that share the block.
-template <int TW, int TH, int G = 64>
-__device__ __forceinline__ unsigned long long satd_tiles(const Pel* org, int os, const Pel* cur, int cs, int w, int h, int lane, int offset = 0)
+// CurPtr: the type of the second block's pointer (plain, or address-space qualified when the caller keeps it in LDS: a plain pointer to LDS costs
+// flat loads).
+template <int TW, int TH, int G = 64, class CurPtr = const Pel*>
+__device__ __forceinline__ unsigned long long satd_tiles(const Pel* org, int os, CurPtr cur, int cs, int w, int h, int lane, int offset = 0)
 {
   constexpr int GROUPS = G / TH;
   const int row = lane % TH, grp = lane / TH;
@@ -37,7 +39,7 @@ __device__ __forceinline__ unsigned long long satd_tiles(const Pel* org, int os,
     {
       const int ty = t / tilesX, tx = t - ty * tilesX;
       const Pel* o = org + (size_t)(ty * TH + row) * os + tx * TW;
-      const Pel* c = cur + (size_t)(ty * TH + row) * cs + tx * TW;
+      CurPtr c = cur + (size_t)(ty * TH + row) * cs + tx * TW;
 #pragma unroll
       for (int x = 0; x < TW; x++) v[x] = (int)(Pel)((int)o[x] - offset) - (int)c[x];      // offset != 0: D4, org - Pel(meanDiff) kept as Pel
     }
@@ -84,15 +86,17 @@ __device__ __forceinline__ unsigned long long satd_tiles(const Pel* org, int os,
   return group_sum_u64<G>(total);
 }
 
-// Hadamard SATD of a w x h block with the reference's tile choice (xGetHADs :2855-2974); lane = index inside a group of G lanes
-template <int G>
-__device__ __forceinline__ unsigned long long satd_block(const Pel* org, int os, const Pel* cur, int cs, int w, int h, int lane, int offset = 0)
+// Hadamard SATD of a w x h block with the reference's tile choice (xGetHADs :2855-2974); lane = index inside a group of G lanes.  hSel (default h):
+// the height the tile choice is made for, when [org, cur] is a band of h rows of a taller block (h a multiple of the chosen tile height).
+template <int G, class CurPtr = const Pel*>
+__device__ __forceinline__ unsigned long long satd_block(const Pel* org, int os, CurPtr cur, int cs, int w, int h, int lane, int offset = 0, int hSel = 0)
 {
-  if (w > h && (h & 7) == 0 && (w & 15) == 0)      return satd_tiles<16, 8, G>(org, os, cur, cs, w, h, lane, offset);
-  else if (w < h && (w & 7) == 0 && (h & 15) == 0) return satd_tiles<8, 16, G>(org, os, cur, cs, w, h, lane, offset);
-  else if (w > h && (h & 3) == 0 && (w & 7) == 0)  return satd_tiles<8, 4, G>(org, os, cur, cs, w, h, lane, offset);
-  else if (w < h && (w & 3) == 0 && (h & 7) == 0)  return satd_tiles<4, 8, G>(org, os, cur, cs, w, h, lane, offset);
-  else if ((h & 7) == 0 && (w & 7) == 0)           return satd_tiles<8, 8, G>(org, os, cur, cs, w, h, lane, offset);
-  else if ((h & 3) == 0 && (w & 3) == 0)           return satd_tiles<4, 4, G>(org, os, cur, cs, w, h, lane, offset);
-  return satd_tiles<2, 2, G>(org, os, cur, cs, w, h, lane, offset);
+  const int hs = hSel ? hSel : h;
+  if (w > hs && (hs & 7) == 0 && (w & 15) == 0)      return satd_tiles<16, 8, G, CurPtr>(org, os, cur, cs, w, h, lane, offset);
+  else if (w < hs && (w & 7) == 0 && (hs & 15) == 0) return satd_tiles<8, 16, G, CurPtr>(org, os, cur, cs, w, h, lane, offset);
+  else if (w > hs && (hs & 3) == 0 && (w & 7) == 0)  return satd_tiles<8, 4, G, CurPtr>(org, os, cur, cs, w, h, lane, offset);
+  else if (w < hs && (w & 3) == 0 && (hs & 7) == 0)  return satd_tiles<4, 8, G, CurPtr>(org, os, cur, cs, w, h, lane, offset);
+  else if ((hs & 7) == 0 && (w & 7) == 0)            return satd_tiles<8, 8, G, CurPtr>(org, os, cur, cs, w, h, lane, offset);
+  else if ((hs & 3) == 0 && (w & 3) == 0)            return satd_tiles<4, 4, G, CurPtr>(org, os, cur, cs, w, h, lane, offset);
+  return satd_tiles<2, 2, G, CurPtr>(org, os, cur, cs, w, h, lane, offset);
 }

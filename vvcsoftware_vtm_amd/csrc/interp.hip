@@ -596,7 +596,8 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
     const Pel* org = orgBase + d.dst_off;
     const int os = d.dst_stride, w = d.w, h = d.h;
     unsigned long long res;
-    if (distKind == 1) res = satd_block<64>(org, os, predT, w, w, h, lane);
+    typedef const __attribute__((address_space(3))) short* LdsPel;
+    if (distKind == 1) res = satd_block<64, LdsPel>(org, os, (LdsPel)predT, w, w, h, lane);
     else
     {
       const int ss = distKind == 0 ? d.reserved : 0, rows = h >> ss;

@@ -28,8 +28,9 @@ __device__ __forceinline__ void wave_sync() { __builtin_amdgcn_fence(__ATOMIC_AC
 
 // One prediction block by one wave: predIntraAng into `dst` (row pitch ds; global memory or the wave's LDS tile).  top / left / tmp / mainBuf:
 // the wave's LDS work arrays (REF_MAX, REF_MAX, 2 REF_MAX, NEG_MAX + REF_MAX shorts).
+// Rows [y0, y1) only (default: the whole block); dst addresses row y0.
 __device__ __forceinline__ void intra_pred_block(const vvcgpu_intra_desc& d, const Pel* __restrict__ refsBase, Pel* dst, int ds, int clpMin, int clpMax, int lane,
-                                                 short* top, short* left, short* tmpBuf, short* mainBuf)
+                                                 short* top, short* left, short* tmpBuf, short* mainBuf, int y0 = 0, int y1 = 1 << 30)
 {
   const int w = d.w, h = d.h, mode = d.mode;
   const int log2W = ilog2(w), log2H = ilog2(h);
@@ -79,7 +80,7 @@ __device__ __forceinline__ void intra_pred_block(const vvcgpu_intra_desc& d, con
       dc = (short)((sum + (denom >> 1)) >> ilog2(denom));
     }
     const int bottomLeft = left[h + 1], topRight = top[w + 1];
-    for (int i = lane; i < count; i += 64)
+    for (int i = y0 * w + lane; i < min(y1, h) * w; i += 64)
     {
       const int y = i >> log2W, x = i & (w - 1);
       const int l = left[y + 1], t = top[x + 1];
@@ -96,7 +97,7 @@ __device__ __forceinline__ void intra_pred_block(const vvcgpu_intra_desc& d, con
         const int wTL = (wL >> 4) + (wT >> 4);
         v = (wL * l + wT * t - wTL * topLeft + (64 - wL - wT + wTL) * dc + 32) >> 6;
       }
-      dst[(ptrdiff_t)y * ds + x] = (Pel)min(max(v, clpMin), clpMax);
+      dst[(ptrdiff_t)(y - y0) * ds + x] = (Pel)min(max(v, clpMin), clpMax);
     }
     return;
   }
@@ -129,7 +130,7 @@ __device__ __forceinline__ void intra_pred_block(const vvcgpu_intra_desc& d, con
   const bool pdpcCorner = predMode == 2 || predMode == VDIA;
   const bool pdpcNear = !pdpcCorner && ((predMode >= VDIA - 8) || (predMode <= 2 + 8));
   const bool pdpcHV = angle == 0;                           // HOR / VER: PDPC of predIntraAng :324-346
-  for (int i = lane; i < count; i += 64)
+  for (int i = y0 * w + lane; i < min(y1, h) * w; i += 64)
   {
     const int dy = i >> log2W, dx = i & (w - 1);
     const int x = isVer ? dx : dy, y = isVer ? dy : dx;     // coordinates in the orientation of the main reference
@@ -165,7 +166,7 @@ __device__ __forceinline__ void intra_pred_block(const vvcgpu_intra_desc& d, con
       }
     }
     (void)log2Wm;
-    dst[(ptrdiff_t)dy * ds + dx] = (Pel)v;
+    dst[(ptrdiff_t)(dy - y0) * ds + dx] = (Pel)v;
   }
 }
 
@@ -182,6 +183,10 @@ __global__ __launch_bounds__(256) void intra_pred_kernel(const Pel* __restrict__
 
 // ---- intra mode pre-selection (IntraSearch::estIntraPredLumaQT, EncoderLib/IntraSearch.cpp:397-480): predIntraAng of one candidate mode into
 // the wave's LDS tile, then the Hadamard distortion against the original (distParam.distFunc = xGetHADs) -- the prediction never reaches HBM.
+// Measured at 4K (31 k blocks of 16 x 16 x 67 modes, tools/intra_search_time.py): 2.55 ms against 1.17 + 1.13 ms for prediction and distortion as two
+// launches -- the fused form saves 2 GB of prediction traffic but its waves (prediction AND Hadamard code: 100+ VGPRs, a 32 KB tile per
+// workgroup) are latency-bound at a quarter of the separate kernels' occupancy.  Variants tried: a 1024-sample band tile with the Hadamard code
+// inlined (187 VGPRs, 5.1 ms), the same with the distortion as a real call and a 128-VGPR cap (3.0 ms), 80-VGPR cap (spills, 9.8 ms).
 __global__ __launch_bounds__(256) void intra_satd_kernel(const Pel* __restrict__ refsBase, const Pel* __restrict__ orgBase,
                                                          const vvcgpu_intra_satd_desc* __restrict__ descs, int n, int clpMin, int clpMax,
                                                          unsigned long long* __restrict__ out)
@@ -196,7 +201,8 @@ __global__ __launch_bounds__(256) void intra_satd_kernel(const Pel* __restrict__
   d.ref_off = s.ref_off; d.dst_off = 0; d.dst_stride = s.w; d.w = s.w; d.h = s.h; d.mode = s.mode; d.filter_refs = s.filter_refs;
   intra_pred_block(d, refsBase, predS[wave], s.w, clpMin, clpMax, lane, topS[wave], leftS[wave], tmpS[wave], mainS[wave]);
   wave_sync();
-  const unsigned long long res = satd_block<64>(orgBase + s.org_off, s.org_stride, predS[wave], s.w, s.w, s.h, lane);
+  typedef const __attribute__((address_space(3))) short* LdsPel;
+  const unsigned long long res = satd_block<64, LdsPel>(orgBase + s.org_off, s.org_stride, (LdsPel)predS[wave], s.w, s.w, s.h, lane);
   if (lane == 0) out[b] = res;
 }
 
