@@ -130,6 +130,42 @@ def profile_valu():
     return out
 
 
+def profile_launches():
+    """-> every kernel launch of ONE picture of the serial schedule from the committed rocprofv3 kernel trace of these kernel sources
+    (profiles/rNN_launch_groups.csv: name, launches per picture, average us), the small fixed-cost ones included -- the launch groups of `kernels{}`
+    bracket several launches each (org packing + memset + raster + key decode, classifier + chain + generic, fast + generic MC).  None without a
+    matching profile."""
+    import csv
+    import glob
+    import re
+    metas = sorted(glob.glob(os.path.join(ROOT, "profiles", "r*_meta.json")))
+    if not metas:
+        return None
+    meta = json.load(open(metas[-1]))
+    path = os.path.join(ROOT, "profiles", meta["launch_groups"])
+    if meta.get("lib_digest") != lib_digest() or not os.path.exists(path):
+        return None
+    rows, pictures = [], None
+    with open(path) as f:
+        for r in csv.DictReader(f):
+            k = r["kernel"]
+            if k.startswith("at::") or "elementwise" in k:
+                continue
+            m = re.search(r"(\d*)([a-z][a-z0-9_]*_kernel)", k)        # readable name out of a (possibly mangled) symbol
+            name = (m.group(2) if m else k[:48]) + (k[k.index("<"):k.index(">") + 1] if "<" in k and ">" in k else "")
+            rows.append((name, int(r["calls"]), float(r["avg_us"])))
+    # pictures of the profiled run = calls of a once-per-picture kernel
+    for k, c, _ in rows:
+        if "rc_chain_kernel" in k:
+            pictures = c
+    if not pictures:
+        return None
+    out = [{"kernel": k, "per_picture": round(c / pictures, 2), "avg_us": round(u, 2)} for k, c, u in rows if c >= pictures // 2]
+    small = sum(e["per_picture"] * e["avg_us"] for e in out if e["avg_us"] < 15.0)
+    return {"source": os.path.basename(path), "launches_per_picture": round(sum(e["per_picture"] for e in out), 1),
+            "serial_us_per_picture": round(sum(e["per_picture"] * e["avg_us"] for e in out), 1), "launches_under_15us_total_us": round(small, 1), "launches": out}
+
+
 def cpu_baseline(wl, budget_s=25.0):
     """VTM's own SIMD kernels (oracle/_ref/libvtmref.so, kind 'reference') or the scalar restatement (kind 'port') on ONE host
     core over the bench's own workload object (the whole 3840x2160 picture, no extrapolation) when one pass fits the budget;
@@ -457,6 +493,7 @@ def main():
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "serial_kernel_ms_per_picture": round(sum(stage_ms.values()), 4),
             "kernels": per_kernel,
+            "kernel_launches": profile_launches(),
             "lib_digest": lib_digest(),
             "encoder_fps_m3": "see profiles/*_m3_encoder.txt (reference encoder with and without the library, measured separately; never this line's value)",
         }
