@@ -80,6 +80,10 @@ static struct RomInit { RomInit() { initROM(); } } g_romInit;
 // (create -> parseCfg -> encode -> destroy).  argv[0] is ignored like a program name.
 int vtmref_encode(int argc, char** argv)
 {
+  // the SIMD selector is read before anything else, as App/EncoderApp/encmain.cpp:97-105 does (the tables are filled by constructors); the library
+  // built from a tree that carries integration/vtm-2.1-hip.patch accepts --SIMD=HIP here
+  for (int i = 1; i < argc; i++)
+    if (!strncmp(argv[i], "--SIMD=", 7)) read_x86_extension_flags(std::string(argv[i] + 7));
   EncApp* app = new EncApp;
   app->create();
   try
@@ -107,6 +111,13 @@ int vtmref_encode(int argc, char** argv)
 int vtmref_decode(int argc, char** argv)
 {
   int rc = 0;
+  for (int i = 1; i < argc; i++)                            // the decoder application has no SIMD option of its own: taken out of the list here
+    if (!strncmp(argv[i], "--SIMD=", 7))
+    {
+      read_x86_extension_flags(std::string(argv[i] + 7));
+      for (int k = i; k + 1 < argc; k++) argv[k] = argv[k + 1];
+      argc--; i--;
+    }
   DecApp* app = new DecApp;
   if (!app->parseCfg(argc, argv)) return 1;
   clock_t t0 = clock();

@@ -157,7 +157,7 @@ def test_encoder_per_call_form_still_exact(tmp_path):
 
 
 
-def _encode_fixture(tmp_path, name, env):
+def _encode_fixture(tmp_path, name, env, flag="--hip", extra=()):
     sys.path.insert(0, ROOT)
     from vvcsoftware_vtm_amd import synth
     m = manifest()[name]
@@ -165,9 +165,9 @@ def _encode_fixture(tmp_path, name, env):
     synth.write_yuv(yuv, synth.gen_yuv(m["w"], m["h"], m["frames"], m["bd"], m["seed"]), m["bd"])
     cfg = os.path.join(ROOT, m["cfg"][1:])
     binf = str(tmp_path / "out.bin")
-    r = subprocess.run([APP, "--hip", "enc", "-c", cfg, "-i", yuv, "-wdt", str(m["w"]), "-hgt", str(m["h"]), "-fr", "30",
+    r = subprocess.run([APP, flag, "enc", "-c", cfg, "-i", yuv, "-wdt", str(m["w"]), "-hgt", str(m["h"]), "-fr", "30",
                         "-f", str(m["frames"]), "-q", str(m["qp"]), "--InputBitDepth=%d" % m["bd"], "--InternalBitDepth=%d" % m["bd"],
-                        "--OutputBitDepth=%d" % m["bd"], "-b", binf, "-o", str(tmp_path / "rec.yuv"), "--SEIDecodedPictureHash=%d" % m.get("hash", 1)] + m.get("extra", []),
+                        "--OutputBitDepth=%d" % m["bd"], "-b", binf, "-o", str(tmp_path / "rec.yuv"), "--SEIDecodedPictureHash=%d" % m.get("hash", 1)] + m.get("extra", []) + list(extra),
                        capture_output=True, text=True, timeout=3300, env=dict(os.environ, **env))
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
     assert md5(binf) == m["bin_md5"]
@@ -225,3 +225,41 @@ def test_nightly_table_slots_every_width(tmp_path, name):
     assert calls[14] == 0 and calls[20] == 0 and calls[26] == 0, cl       # no PU-level or N1 hooks in this mode: the reference's own code issued the calls
     print(wl)
     print(cl)
+
+
+SELLIB = os.path.join(ROOT, "oracle", "_ref", "libvtmref_hipsel.so")
+needs_sel = pytest.mark.skipif(not (os.path.exists(APP) and os.path.exists(SELLIB)), reason="oracle/_ref/libvtmref_hipsel.so not built (make -C oracle ref)")
+
+
+@needs_sel
+def test_patched_tree_selector_encoder(tmp_path):
+    """the binding WITHOUT linker tricks: the reference built from a tree that carries integration/vtm-2.1-hip.patch (SIMD= selector value HIP, one line
+    at the top of the five InitX86 table functions and of the picture-level in-loop entry points; bodies in integration/InitHIP.cpp).  With --SIMD=HIP the
+    whole in-loop chain runs on the device-resident picture and the bitstream is the fixture's, byte for byte; without it the same library is the
+    plain CPU encoder (no GPU call at all)."""
+    m, r, numbers = _encode_fixture(tmp_path, "ragop16_416x240_10b_q32", {"VVCGPU_SHIM_HOOKS": "pic"}, flag="--hipsel", extra=["--SIMD=HIP"])
+    calls, line = numbers("[vvcgpu shim]")
+    assert calls[0] == m["frames"] and calls[3] == m["frames"] and calls[4] == m["frames"] and calls[7] >= m["frames"], line
+    (pics, ups, downs), res = numbers("[vvcgpu resident]")[0][:3], numbers("[vvcgpu resident]")[1]
+    assert pics == m["frames"] and downs == m["frames"] and "resident form on" in res, res
+    m, r, numbers = _encode_fixture(tmp_path, "ldp_208x120_10b_q27", {}, flag="--hipsel")
+    calls, line = numbers("[vvcgpu shim]")
+    assert sum(calls) == 0, line
+
+
+@needs_sel
+def test_patched_tree_selector_table_slots_and_decoder(tmp_path):
+    """--SIMD=HIP at the default hook level: the five function-pointer tables carry the library's slots (64-wide distortion, interpolation and
+    PelBuffer calls, ALF table slots); then the decoder of the same library on the fixture stream"""
+    m, r, numbers = _encode_fixture(tmp_path, "ldp_208x120_10b_q27", {}, flag="--hipsel", extra=["--SIMD=HIP"])
+    calls, line = numbers("[vvcgpu shim]")
+    assert calls[0] == m["frames"] and calls[8] + calls[9] + calls[10] + calls[11] > 0, line
+    name = "ldp_208x120_10b_q27"
+    out = str(tmp_path / "dec.yuv")
+    r = subprocess.run([APP, "--hipsel", "dec", "-b", os.path.join(BS, name + ".bin"), "-o", out, "-d", str(m["bd"]), "--SIMD=HIP"],
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-2000:]
+    assert "ERROR" not in r.stdout and r.stdout.count("(OK)") >= m["frames"], r.stdout[-2000:]
+    assert md5(out) == m["dec_yuv_md5"]
+    line = [l for l in r.stderr.splitlines() if "[vvcgpu shim]" in l]
+    assert line and int(line[-1].replace(",", " ").split("deblock")[1].split()[0]) >= m["frames"], r.stderr[-600:]

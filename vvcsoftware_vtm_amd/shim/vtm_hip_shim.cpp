@@ -41,61 +41,71 @@
 
 #define VVCGPU(call) do { if ((call) != 0) THROW("vvcgpu: " << vvcgpu_last_error()); } while (0)
 
-void real_loopFilterPic(LoopFilter*, CodingStructure&) asm("__real__ZN10LoopFilter13loopFilterPicER15CodingStructure");
-void wrap_loopFilterPic(LoopFilter*, CodingStructure&) asm("__wrap__ZN10LoopFilter13loopFilterPicER15CodingStructure");
-void real_SAOProcess(SampleAdaptiveOffset*, CodingStructure&, SAOBlkParam*) asm("__real__ZN20SampleAdaptiveOffset10SAOProcessER15CodingStructureP11SAOBlkParam");
-void wrap_SAOProcess(SampleAdaptiveOffset*, CodingStructure&, SAOBlkParam*) asm("__wrap__ZN20SampleAdaptiveOffset10SAOProcessER15CodingStructureP11SAOBlkParam");
-void real_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) asm("__real__ZN18AdaptiveLoopFilter10ALFProcessER15CodingStructureR13AlfSliceParam");
-void wrap_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) asm("__wrap__ZN18AdaptiveLoopFilter10ALFProcessER15CodingStructureR13AlfSliceParam");
+// Two ways into this file.  (1) GNU ld --wrap (oracle/Makefile, target `ref`): wrap_X is the symbol __wrap_<X>, real_X the symbol __real_<X> -- the
+// reference's objects are linked unmodified.  (2) VVCSHIM_SOURCE_HOOKS (integration/InitHIP.cpp, for a reference tree that carries
+// integration/vtm-2.1-hip.patch): the patched functions call wrap_X themselves when SIMD=HIP is selected, and real_X (defined there) re-enters the
+// patched function with its hook disarmed -- no linker tricks.
+#ifdef VVCSHIM_SOURCE_HOOKS
+#define VVCSHIM_SYM(x)
+#else
+#define VVCSHIM_SYM(x) asm(x)
+#endif
+
+void real_loopFilterPic(LoopFilter*, CodingStructure&) VVCSHIM_SYM("__real__ZN10LoopFilter13loopFilterPicER15CodingStructure");
+void wrap_loopFilterPic(LoopFilter*, CodingStructure&) VVCSHIM_SYM("__wrap__ZN10LoopFilter13loopFilterPicER15CodingStructure");
+void real_SAOProcess(SampleAdaptiveOffset*, CodingStructure&, SAOBlkParam*) VVCSHIM_SYM("__real__ZN20SampleAdaptiveOffset10SAOProcessER15CodingStructureP11SAOBlkParam");
+void wrap_SAOProcess(SampleAdaptiveOffset*, CodingStructure&, SAOBlkParam*) VVCSHIM_SYM("__wrap__ZN20SampleAdaptiveOffset10SAOProcessER15CodingStructureP11SAOBlkParam");
+void real_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) VVCSHIM_SYM("__real__ZN18AdaptiveLoopFilter10ALFProcessER15CodingStructureR13AlfSliceParam");
+void wrap_ALFProcess(AdaptiveLoopFilter*, CodingStructure&, AlfSliceParam&) VVCSHIM_SYM("__wrap__ZN18AdaptiveLoopFilter10ALFProcessER15CodingStructureR13AlfSliceParam");
 
 void real_EncSAOProcess(EncSampleAdaptiveOffset*, CodingStructure&, bool*, const double*, const bool, const double, const double, bool, bool)
-  asm("__real__ZN23EncSampleAdaptiveOffset10SAOProcessER15CodingStructurePbPKdbddbb");
+  VVCSHIM_SYM("__real__ZN23EncSampleAdaptiveOffset10SAOProcessER15CodingStructurePbPKdbddbb");
 void wrap_EncSAOProcess(EncSampleAdaptiveOffset*, CodingStructure&, bool*, const double*, const bool, const double, const double, bool, bool)
-  asm("__wrap__ZN23EncSampleAdaptiveOffset10SAOProcessER15CodingStructurePbPKdbddbb");
+  VVCSHIM_SYM("__wrap__ZN23EncSampleAdaptiveOffset10SAOProcessER15CodingStructurePbPKdbddbb");
 void real_EncALFProcess(EncAdaptiveLoopFilter*, CodingStructure&, const double*, AlfSliceParam&)
-  asm("__real__ZN21EncAdaptiveLoopFilter10ALFProcessER15CodingStructurePKdR13AlfSliceParam");
+  VVCSHIM_SYM("__real__ZN21EncAdaptiveLoopFilter10ALFProcessER15CodingStructurePKdR13AlfSliceParam");
 void wrap_EncALFProcess(EncAdaptiveLoopFilter*, CodingStructure&, const double*, AlfSliceParam&)
-  asm("__wrap__ZN21EncAdaptiveLoopFilter10ALFProcessER15CodingStructurePKdR13AlfSliceParam");
+  VVCSHIM_SYM("__wrap__ZN21EncAdaptiveLoopFilter10ALFProcessER15CodingStructurePKdR13AlfSliceParam");
 
-void real_initIfX86(InterpolationFilter*) asm("__real__ZN19InterpolationFilter26initInterpolationFilterX86Ev");
-void wrap_initIfX86(InterpolationFilter*) asm("__wrap__ZN19InterpolationFilter26initInterpolationFilterX86Ev");
-void real_initPelBufX86(PelBufferOps*) asm("__real__ZN12PelBufferOps16initPelBufOpsX86Ev");
-void wrap_initPelBufX86(PelBufferOps*) asm("__wrap__ZN12PelBufferOps16initPelBufOpsX86Ev");
+void real_initIfX86(InterpolationFilter*) VVCSHIM_SYM("__real__ZN19InterpolationFilter26initInterpolationFilterX86Ev");
+void wrap_initIfX86(InterpolationFilter*) VVCSHIM_SYM("__wrap__ZN19InterpolationFilter26initInterpolationFilterX86Ev");
+void real_initPelBufX86(PelBufferOps*) VVCSHIM_SYM("__real__ZN12PelBufferOps16initPelBufOpsX86Ev");
+void wrap_initPelBufX86(PelBufferOps*) VVCSHIM_SYM("__wrap__ZN12PelBufferOps16initPelBufOpsX86Ev");
 void real_invTransformNxN(TrQuant*, TransformUnit&, const ComponentID&, PelBuf&, const QpParam&)
-  asm("__real__ZN7TrQuant15invTransformNxNER13TransformUnitRK11ComponentIDR7AreaBufIsERK7QpParam");
+  VVCSHIM_SYM("__real__ZN7TrQuant15invTransformNxNER13TransformUnitRK11ComponentIDR7AreaBufIsERK7QpParam");
 void wrap_invTransformNxN(TrQuant*, TransformUnit&, const ComponentID&, PelBuf&, const QpParam&)
-  asm("__wrap__ZN7TrQuant15invTransformNxNER13TransformUnitRK11ComponentIDR7AreaBufIsERK7QpParam");
-void real_initAgsX86(AffineGradientSearch*) asm("__real__ZN20AffineGradientSearch27initAffineGradientSearchX86Ev");
-void wrap_initAgsX86(AffineGradientSearch*) asm("__wrap__ZN20AffineGradientSearch27initAffineGradientSearchX86Ev");
-void real_initRdCostX86(RdCost*) asm("__real__ZN6RdCost13initRdCostX86Ev");
-void wrap_initRdCostX86(RdCost*) asm("__wrap__ZN6RdCost13initRdCostX86Ev");
-void real_initAlfX86(AdaptiveLoopFilter*) asm("__real__ZN18AdaptiveLoopFilter25initAdaptiveLoopFilterX86Ev");
-void wrap_initAlfX86(AdaptiveLoopFilter*) asm("__wrap__ZN18AdaptiveLoopFilter25initAdaptiveLoopFilterX86Ev");
+  VVCSHIM_SYM("__wrap__ZN7TrQuant15invTransformNxNER13TransformUnitRK11ComponentIDR7AreaBufIsERK7QpParam");
+void real_initAgsX86(AffineGradientSearch*) VVCSHIM_SYM("__real__ZN20AffineGradientSearch27initAffineGradientSearchX86Ev");
+void wrap_initAgsX86(AffineGradientSearch*) VVCSHIM_SYM("__wrap__ZN20AffineGradientSearch27initAffineGradientSearchX86Ev");
+void real_initRdCostX86(RdCost*) VVCSHIM_SYM("__real__ZN6RdCost13initRdCostX86Ev");
+void wrap_initRdCostX86(RdCost*) VVCSHIM_SYM("__wrap__ZN6RdCost13initRdCostX86Ev");
+void real_initAlfX86(AdaptiveLoopFilter*) VVCSHIM_SYM("__real__ZN18AdaptiveLoopFilter25initAdaptiveLoopFilterX86Ev");
+void wrap_initAlfX86(AdaptiveLoopFilter*) VVCSHIM_SYM("__wrap__ZN18AdaptiveLoopFilter25initAdaptiveLoopFilterX86Ev");
 void real_offsetCTU(SampleAdaptiveOffset*, const UnitArea&, const CPelUnitBuf&, PelUnitBuf&, SAOBlkParam&, CodingStructure&)
-  asm("__real__ZN20SampleAdaptiveOffset9offsetCTUERK8UnitAreaRK7UnitBufIKsERS3_IsER11SAOBlkParamR15CodingStructure");
+  VVCSHIM_SYM("__real__ZN20SampleAdaptiveOffset9offsetCTUERK8UnitAreaRK7UnitBufIKsERS3_IsER11SAOBlkParamR15CodingStructure");
 void wrap_offsetCTU(SampleAdaptiveOffset*, const UnitArea&, const CPelUnitBuf&, PelUnitBuf&, SAOBlkParam&, CodingStructure&)
-  asm("__wrap__ZN20SampleAdaptiveOffset9offsetCTUERK8UnitAreaRK7UnitBufIKsERS3_IsER11SAOBlkParamR15CodingStructure");
+  VVCSHIM_SYM("__wrap__ZN20SampleAdaptiveOffset9offsetCTUERK8UnitAreaRK7UnitBufIKsERS3_IsER11SAOBlkParamR15CodingStructure");
 
 void real_predIntraAng(IntraPrediction*, const ComponentID, PelBuf&, const PredictionUnit&, const bool)
-  asm("__real__ZN15IntraPrediction12predIntraAngE11ComponentIDR7AreaBufIsERK14PredictionUnitb");
+  VVCSHIM_SYM("__real__ZN15IntraPrediction12predIntraAngE11ComponentIDR7AreaBufIsERK14PredictionUnitb");
 void wrap_predIntraAng(IntraPrediction*, const ComponentID, PelBuf&, const PredictionUnit&, const bool)
-  asm("__wrap__ZN15IntraPrediction12predIntraAngE11ComponentIDR7AreaBufIsERK14PredictionUnitb");
+  VVCSHIM_SYM("__wrap__ZN15IntraPrediction12predIntraAngE11ComponentIDR7AreaBufIsERK14PredictionUnitb");
 void real_predIntraChromaLM(IntraPrediction*, const ComponentID, PelBuf&, const PredictionUnit&, const CompArea&, int)
-  asm("__real__ZN15IntraPrediction17predIntraChromaLME11ComponentIDR7AreaBufIsERK14PredictionUnitRK8CompAreai");
+  VVCSHIM_SYM("__real__ZN15IntraPrediction17predIntraChromaLME11ComponentIDR7AreaBufIsERK14PredictionUnitRK8CompAreai");
 void wrap_predIntraChromaLM(IntraPrediction*, const ComponentID, PelBuf&, const PredictionUnit&, const CompArea&, int)
-  asm("__wrap__ZN15IntraPrediction17predIntraChromaLME11ComponentIDR7AreaBufIsERK14PredictionUnitRK8CompAreai");
+  VVCSHIM_SYM("__wrap__ZN15IntraPrediction17predIntraChromaLME11ComponentIDR7AreaBufIsERK14PredictionUnitRK8CompAreai");
 void real_initIntraPatternChType(IntraPrediction*, const CodingUnit&, const CompArea&, const bool)
-  asm("__real__ZN15IntraPrediction22initIntraPatternChTypeERK10CodingUnitRK8CompAreab");
+  VVCSHIM_SYM("__real__ZN15IntraPrediction22initIntraPatternChTypeERK10CodingUnitRK8CompAreab");
 void wrap_initIntraPatternChType(IntraPrediction*, const CodingUnit&, const CompArea&, const bool)
-  asm("__wrap__ZN15IntraPrediction22initIntraPatternChTypeERK10CodingUnitRK8CompAreab");
+  VVCSHIM_SYM("__wrap__ZN15IntraPrediction22initIntraPatternChTypeERK10CodingUnitRK8CompAreab");
 // DepQuant::quant is virtual: it is reached through the vtable (a dynamic relocation against the symbol), so it is pre-empted by
 // oracle/ref_hooks.cpp like the statistics entry points, not by ld --wrap
 extern "C" int vvcshim_depquant(DepQuant* self, TransformUnit* tu, const ComponentID* compID, const CCoeffBuf* pSrc, TCoeff* uiAbsSum, const QpParam* cQP,
                                 const Ctx* ctx);
 extern "C" int vvcshim_rdoq(QuantRDOQ* self, TransformUnit* tu, const ComponentID* compID, const CCoeffBuf* pSrc, TCoeff* uiAbsSum, const QpParam* cQP,
                             const Ctx* ctx);
-void real_extendPicBorder(Picture*) asm("__real__ZN7Picture15extendPicBorderEv");
-void wrap_extendPicBorder(Picture*) asm("__wrap__ZN7Picture15extendPicBorderEv");
+void real_extendPicBorder(Picture*) VVCSHIM_SYM("__real__ZN7Picture15extendPicBorderEv");
+void wrap_extendPicBorder(Picture*) VVCSHIM_SYM("__wrap__ZN7Picture15extendPicBorderEv");
 
 // The two encoder-statistics entry points are called from inside their own translation unit, where ld --wrap does not reach;
 // those calls go through the PLT (the objects are -fPIC), so oracle/ref_hooks.cpp, loaded ahead of this library, pre-empts the
