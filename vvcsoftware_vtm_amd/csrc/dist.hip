@@ -36,7 +36,7 @@ __device__ __forceinline__ void dist_load4(const Pel* p, int (&v)[4])
 // one descriptor by a group of G lanes (lane = index inside the group); the result is valid in every lane of the group
 template <int G>
 __device__ __forceinline__ unsigned long long dist_one(int kind, const vvcgpu_dist_desc& d, const Pel* __restrict__ orgBase, const Pel* __restrict__ curBase,
-                                                       int lane, bool act)
+                                                       int lane, bool act, int hSel = 0)      // hSel: height of the whole block when d is a band of it (Hadamard tile choice)
 {
   const Pel* org = orgBase + d.org_off;
   const Pel* cur = curBase + d.cur_off;
@@ -58,7 +58,7 @@ __device__ __forceinline__ unsigned long long dist_one(int kind, const vvcgpu_di
   }
   if (kind == 1 || kind == 4)
   {
-    res = satd_block<G>(org, os, cur, cs, w, h, lane, offset);
+    res = satd_block<G>(org, os, cur, cs, w, h, lane, offset, hSel);
   }
   else
   {
@@ -94,12 +94,20 @@ __device__ __forceinline__ unsigned long long dist_one(int kind, const vvcgpu_di
 
 // A wave takes FOUR consecutive descriptors.  The reference encoder's calls are mostly narrow (tests/golden/trace_*.npz: 4- and 8-wide blocks are
 // 80 % of the distortion calls): when all four blocks have at most 128 samples, each gets 16 lanes and the four run side by side; otherwise
-// the wave serves them one after the other with all 64 lanes.
+// the wave serves them one after the other with all 64 lanes.  HEAVY blocks (more than 2048 samples, SAD / Hadamard / SSE) are not computed
+// here: one wave needs ~60 us for a 128 x 128 block, which was the run time of the whole launch on a real call mix -- they are listed, their result is
+// zeroed, and dist_heavy_kernel splits each into bands of >= 16 rows over as many waves, summing with 64-bit atomics.
+constexpr int DIST_HEAVY = 2048;
+__device__ __forceinline__ int dist_band_rows(int w) { return max(16, ((DIST_HEAVY / w) + 15) & ~15); }
+__device__ __forceinline__ bool dist_is_heavy(int kind, int w, int h) { return kind <= 2 && w * h > DIST_HEAVY && (h & 15) == 0 && h <= 8 * dist_band_rows(w); }
+
 __global__ __launch_bounds__(256) void dist_batch_kernel(int kind, const Pel* __restrict__ orgBase,
                                                          const Pel* __restrict__ curBase,
                                                          const vvcgpu_dist_desc* __restrict__ descs, int n,
-                                                         unsigned long long* __restrict__ out)
+                                                         unsigned long long* __restrict__ out, int* __restrict__ heavyCount, int* __restrict__ heavyList,
+                                                         int* __restrict__ nextCounters)
 {
+  if (blockIdx.x == 0 && threadIdx.x < 16) nextCounters[threadIdx.x] = 0;       // the counter set of the next call on this stream (vvcgpu_counters)
   const int lane = threadIdx.x & 63;
   const int d0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
   if (d0 >= n) return;                                  // whole wave exits together
@@ -113,11 +121,39 @@ __global__ __launch_bounds__(256) void dist_batch_kernel(int kind, const Pel* __
     if (act && lig == 0) out[d0 + g] = res;
     return;
   }
+  int nHeavy = 0, heavyIdx[4];
   for (int k = 0; k < 4 && d0 + k < n; k++)
   {
     const vvcgpu_dist_desc d = descs[d0 + k];
+    if (dist_is_heavy(kind, d.w, d.h)) { heavyIdx[nHeavy++] = d0 + k; continue; }
     const unsigned long long res = dist_one<64>(kind, d, orgBase, curBase, lane, true);
     if (lane == 0) out[d0 + k] = res;
+  }
+  if (nHeavy && lane == 0)                              // ONE atomic per wave (same-address atomics retire at ~12 ns each)
+  {
+    const int base = atomicAdd(heavyCount, nHeavy);
+    for (int k = 0; k < nHeavy; k++) { out[heavyIdx[k]] = 0ull; heavyList[base + k] = heavyIdx[k]; }
+  }
+}
+
+// one wave per (heavy block, band of rows); up to 8 bands per block (128 rows / 16)
+__global__ __launch_bounds__(256) void dist_heavy_kernel(int kind, const Pel* __restrict__ orgBase, const Pel* __restrict__ curBase,
+                                                         const vvcgpu_dist_desc* __restrict__ descs, unsigned long long* __restrict__ out,
+                                                         const int* __restrict__ heavyCount, const int* __restrict__ heavyList)
+{
+  const int lane = threadIdx.x & 63;
+  const int cnt = heavyCount[0], waves = gridDim.x * 4;
+  for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < cnt * 8; p += waves)
+  {
+    const int di = heavyList[p >> 3], band = p & 7;
+    vvcgpu_dist_desc d = descs[di];
+    const int hFull = d.h, br = dist_band_rows(d.w), r0 = band * br;
+    if (r0 >= hFull) continue;
+    d.org_off += (int64_t)r0 * d.org_stride;
+    d.cur_off += (int64_t)r0 * d.cur_stride;
+    d.h = (int16_t)min(br, hFull - r0);
+    const unsigned long long res = dist_one<64>(kind, d, orgBase, curBase, lane, true, hFull);
+    if (lane == 0) atomicAdd(&out[di], res);
   }
 }
 
@@ -1615,9 +1651,18 @@ int vvcgpu_dist_batch(int kind, const vvc_pel* org_base, const vvc_pel* cur_base
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(org_base && cur_base && descs && out, "dist_batch: null pointer");
   if (bit_depth > 10) { vvcgpu_set_error("dist_batch: bit depth %d > 10 is outside the precondition", bit_depth); return VVCGPU_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(dist_batch_kernel, dim3(cdiv(n, 16)), dim3(256), 0, (hipStream_t)stream, kind, org_base, cur_base,
-                     descs, n, reinterpret_cast<unsigned long long*>(out));
-  VVC_LAUNCH_CHECK();
+  hipStream_t st = (hipStream_t)stream;
+  int* heavyList = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * (size_t)n));
+  if (!heavyList) return VVCGPU_E_DEVICE;
+  int cur = 0;
+  int* counters = vvcgpu_counters(st, &cur);                                  // zeroed counter for this call; the kernel clears the other set
+  if (!counters) return VVCGPU_E_DEVICE;
+  hipLaunchKernelGGL(dist_batch_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, kind, org_base, cur_base,
+                     descs, n, reinterpret_cast<unsigned long long*>(out), counters + 16 * cur, heavyList, counters + 16 * (cur ^ 1));
+  if (kind <= 2)                                                              // blocks of more than 2048 samples: bands over many waves (none: the launch leaves at once)
+    hipLaunchKernelGGL(dist_heavy_kernel, dim3(n * 2 < 1024 ? (n * 2 > 0 ? n * 2 : 1) : 1024), dim3(256), 0, st, kind, org_base, cur_base, descs,
+                       reinterpret_cast<unsigned long long*>(out), counters + 16 * cur, heavyList);
+  VVC_LAUNCH_CHECK_COUNTERS(st);
   return VVCGPU_OK;
 }
 

@@ -67,13 +67,15 @@ __device__ __forceinline__ void if_load4(const Pel* p, int (&v)[4])
 }
 
 // one descriptor by a group of G lanes (lane = index inside the group)
+// rows [y0, y1) only (default: all of them): dist-like band splitting of heavy calls
 template <int G>
 __device__ __forceinline__ void if_one(const vvcgpu_if_desc& d, const Pel* __restrict__ srcBase, Pel* __restrict__ dstBase, int lane, bool act, int bd,
-                                       int cmin, int cmax)
+                                       int cmin, int cmax, int y0 = 0, int y1 = 1 << 20)
 {
-  const Pel* src = srcBase + d.src_off;
-  Pel* dst = dstBase + d.dst_off;
-  const int N = d.taps, w = d.w, count = act ? w * d.h : 0;
+  const int hh = min((int)d.h, y1) - y0;
+  const Pel* src = srcBase + d.src_off + (ptrdiff_t)y0 * d.src_stride;
+  Pel* dst = dstBase + d.dst_off + (ptrdiff_t)y0 * d.dst_stride;
+  const int N = d.taps, w = d.w, count = act ? w * hh : 0;
   if (N == 0)
   {
     for (int i = lane; i < count; i += G)
@@ -92,7 +94,7 @@ __device__ __forceinline__ void if_one(const vvcgpu_if_desc& d, const Pel* __res
   if ((w & 3) == 0)
   {
     // four consecutive outputs of a row per lane: N + 3 samples (horizontal) or N loads of four samples (vertical) instead of 4 N two-byte loads
-    const int upr = w >> 2, units = act ? upr * d.h : 0;
+    const int upr = w >> 2, units = act ? upr * hh : 0;
     for (int u = lane; u < units; u += G)
     {
       const int y = u / upr, x = (u - y * upr) << 2;
@@ -153,11 +155,17 @@ __device__ __forceinline__ void if_one(const vvcgpu_if_desc& d, const Pel* __res
 }
 
 // A wave takes four consecutive descriptors: side by side with 16 lanes each when all four have at most 256 samples (the reference encoder's
-// table-slot calls are mostly 4 wide: tests/golden/trace_*.npz), one after the other with 64 lanes otherwise.
+// table-slot calls are mostly 4 wide: tests/golden/trace_*.npz), one after the other with 64 lanes otherwise.  HEAVY calls (more than 2048
+// samples) are listed for if_heavy_kernel, which splits them into bands of rows over many waves: one wave needs ~70 us for 128 x 135 samples, and that
+// was the run time of the whole launch on a real call mix.
+constexpr int IF_HEAVY = 2048, IF_HEAVY_FILTER = 512;   // the filter does 8 multiply-adds per sample: its heavy threshold is lower than the element-wise ops'
+// a heavy call is cut into at most 16 bands of rows: band height = 2048 samples' worth, more when that would give more than 16
+__device__ __forceinline__ int if_band_rows(int w, int h) { return max(max(4, IF_HEAVY / w), (h + 15) >> 4); }
 __global__ __launch_bounds__(256) void if_batch_kernel(const Pel* __restrict__ srcBase, Pel* __restrict__ dstBase,
                                                        const vvcgpu_if_desc* __restrict__ descs, int n, int bd,
-                                                       int cmin, int cmax)
+                                                       int cmin, int cmax, int* __restrict__ heavyCount, int* __restrict__ heavyList, int* __restrict__ nextCounters)
 {
+  if (blockIdx.x == 0 && threadIdx.x < 16) nextCounters[threadIdx.x] = 0;       // the counter set of the next call on this stream (vvcgpu_counters)
   const int lane = threadIdx.x & 63;
   const int d0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
   if (d0 >= n) return;
@@ -169,7 +177,31 @@ __global__ __launch_bounds__(256) void if_batch_kernel(const Pel* __restrict__ s
     if_one<16>(mine, srcBase, dstBase, lane & 15, act, bd, cmin, cmax);
     return;
   }
-  for (int k = 0; k < 4 && d0 + k < n; k++) if_one<64>(descs[d0 + k], srcBase, dstBase, lane, true, bd, cmin, cmax);
+  int nHeavy = 0, heavyIdx[4];
+  for (int k = 0; k < 4 && d0 + k < n; k++)
+  {
+    const vvcgpu_if_desc d = descs[d0 + k];
+    if ((int)d.w * (int)d.h > IF_HEAVY_FILTER) { heavyIdx[nHeavy++] = d0 + k; continue; }
+    if_one<64>(d, srcBase, dstBase, lane, true, bd, cmin, cmax);
+  }
+  if (nHeavy && lane == 0)                              // ONE atomic per wave (same-address atomics retire at ~12 ns each)
+  {
+    const int base = atomicAdd(heavyCount, nHeavy);
+    for (int k = 0; k < nHeavy; k++) heavyList[base + k] = heavyIdx[k];
+  }
+}
+// one wave per (heavy call, band of rows)
+__global__ __launch_bounds__(256) void if_heavy_kernel(const Pel* __restrict__ srcBase, Pel* __restrict__ dstBase, const vvcgpu_if_desc* __restrict__ descs,
+                                                       int bd, int cmin, int cmax, const int* __restrict__ heavyCount, const int* __restrict__ heavyList)
+{
+  const int lane = threadIdx.x & 63;
+  const int cnt = heavyCount[0], waves = gridDim.x * 4;
+  for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < cnt * 16; p += waves)       // pair p = (item p >> 4, band p & 15)
+  {
+    const vvcgpu_if_desc d = descs[heavyList[p >> 4]];
+    const int br = max(max(2, IF_HEAVY_FILTER / d.w), (d.h + 15) >> 4), r0 = (p & 15) * br;
+    if (r0 < d.h) if_one<64>(d, srcBase, dstBase, lane, true, bd, cmin, cmax, r0, r0 + br);
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ I3
@@ -672,9 +704,11 @@ __device__ __forceinline__ void pelop_one(int op, const vvcgpu_pelop_desc& d, co
 // descriptors, one per wave at a time -- a workgroup per 8 x 4 block is bound by the dispatcher.
 __global__ __launch_bounds__(256) void pelop_batch_kernel(int op, const Pel* __restrict__ s0Base, const Pel* __restrict__ s1Base,
                                                           Pel* dstBase, const vvcgpu_pelop_desc* __restrict__ descs, int n,
-                                                          vvcgpu_pelop_cfg c, int perWg)
+                                                          vvcgpu_pelop_cfg c, int perWg, int* __restrict__ heavyCount, int* __restrict__ heavyList,
+                                                          int* __restrict__ nextCounters)
 {
   const int tid = threadIdx.x;
+  if (nextCounters && blockIdx.x == 0 && blockIdx.y == 0 && tid < 16) nextCounters[tid] = 0;   // the counter set of the next call on this stream
   if (perWg > 1)                                          // a wave takes four consecutive descriptors: side by side with 16 lanes each when all
   {                                                       // four have at most 256 samples, one after the other with 64 lanes otherwise
     const int lane = tid & 63, g = lane >> 4;
@@ -690,10 +724,17 @@ __global__ __launch_bounds__(256) void pelop_batch_kernel(int op, const Pel* __r
       }
       else
       {
+        int nHeavy = 0, heavyIdx[4];
         for (int k = 0; k < 4 && d0 + k < n; k++)
         {
           const vvcgpu_pelop_desc d = descs[d0 + k];
+          if ((int)d.w * (int)d.h > IF_HEAVY) { heavyIdx[nHeavy++] = d0 + k; continue; }    // bands over many waves (pelop_heavy_kernel): one wave per 128 x 128 block was the launch's run time
           pelop_one(op, d, s0Base, s1Base, dstBase, c, lane, 64, 0, d.h);
+        }
+        if (nHeavy && lane == 0)
+        {
+          const int base = atomicAdd(heavyCount, nHeavy);
+          for (int k = 0; k < nHeavy; k++) heavyList[base + k] = heavyIdx[k];
         }
       }
     }
@@ -703,6 +744,21 @@ __global__ __launch_bounds__(256) void pelop_batch_kernel(int op, const Pel* __r
   const int rows = (d.h + (int)gridDim.y - 1) / (int)gridDim.y, y0 = (int)blockIdx.y * rows, y1 = min(d.h, y0 + rows);
   if (y0 >= y1) return;
   pelop_one(op, d, s0Base, s1Base, dstBase, c, tid, 256, y0, y1);
+}
+
+// one wave per (heavy block, band of rows)
+__global__ __launch_bounds__(256) void pelop_heavy_kernel(int op, const Pel* __restrict__ s0Base, const Pel* __restrict__ s1Base, Pel* dstBase,
+                                                          const vvcgpu_pelop_desc* __restrict__ descs, vvcgpu_pelop_cfg c,
+                                                          const int* __restrict__ heavyCount, const int* __restrict__ heavyList)
+{
+  const int lane = threadIdx.x & 63;
+  const int cnt = heavyCount[0], waves = gridDim.x * 4;
+  for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < cnt * 16; p += waves)
+  {
+    const vvcgpu_pelop_desc d = descs[heavyList[p >> 4]];
+    const int br = if_band_rows(d.w, d.h), r0 = (p & 15) * br;
+    if (r0 < d.h) pelop_one(op, d, s0Base, s1Base, dstBase, c, lane, 64, r0, min((int)d.h, r0 + br));
+  }
 }
 
 }  // namespace
@@ -716,9 +772,16 @@ int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(src_base && dst_base && descs, "if_batch: null pointer");
   if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("if_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(if_batch_kernel, dim3(cdiv(n, 16)), dim3(256), 0, (hipStream_t)stream, src_base, dst_base, descs, n,
-                     bit_depth, clp_min, clp_max);
-  VVC_LAUNCH_CHECK();
+  hipStream_t st = (hipStream_t)stream;
+  int* heavyList = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * (size_t)n));
+  if (!heavyList) return VVCGPU_E_DEVICE;
+  int cur = 0;
+  int* counters = vvcgpu_counters(st, &cur);
+  if (!counters) return VVCGPU_E_DEVICE;
+  hipLaunchKernelGGL(if_batch_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, src_base, dst_base, descs, n,
+                     bit_depth, clp_min, clp_max, counters + 16 * cur, heavyList, counters + 16 * (cur ^ 1));
+  hipLaunchKernelGGL(if_heavy_kernel, dim3(1024), dim3(256), 0, st, src_base, dst_base, descs, bit_depth, clp_min, clp_max, counters + 16 * cur, heavyList);
+  VVC_LAUNCH_CHECK_COUNTERS(st);
   return VVCGPU_OK;
 }
 
@@ -767,8 +830,23 @@ int vvcgpu_pelop_batch(int op, const vvc_pel* src0_base, const vvc_pel* src1_bas
   VVC_CHECK_ARG(src0_base && dst_base && descs && cfg_host, "pelop_batch: null pointer");
   VVC_CHECK_ARG(src1_base || op == 2 || op == 5, "pelop_batch: op %d needs src1", op);
   const int perWg = n < 8192 ? 1 : 16;
-  hipLaunchKernelGGL(pelop_batch_kernel, dim3(cdiv(n, perWg), n < 2048 ? 8 : 1), dim3(256), 0, (hipStream_t)stream, op, src0_base, src1_base,
-                     dst_base, descs, n, *cfg_host, perWg);
+  hipStream_t st = (hipStream_t)stream;
+  int* heavyList = nullptr; int* counters = nullptr; int cur = 0;
+  if (perWg > 1)                                          // long lists: heavy blocks go to a list and a second launch
+  {
+    heavyList = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * (size_t)n));
+    if (!heavyList) return VVCGPU_E_DEVICE;
+    counters = vvcgpu_counters(st, &cur);
+    if (!counters) return VVCGPU_E_DEVICE;
+  }
+  hipLaunchKernelGGL(pelop_batch_kernel, dim3(cdiv(n, perWg), n < 2048 ? 8 : 1), dim3(256), 0, st, op, src0_base, src1_base,
+                     dst_base, descs, n, *cfg_host, perWg, counters ? counters + 16 * cur : nullptr, heavyList, counters ? counters + 16 * (cur ^ 1) : nullptr);
+  if (perWg > 1)
+  {
+    hipLaunchKernelGGL(pelop_heavy_kernel, dim3(1024), dim3(256), 0, st, op, src0_base, src1_base, dst_base, descs, *cfg_host, counters + 16 * cur, heavyList);
+    VVC_LAUNCH_CHECK_COUNTERS(st);
+    return VVCGPU_OK;
+  }
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
