@@ -106,7 +106,7 @@ def test_resi_chain_rectangles_and_chroma_shapes():
     bd, W, H = 10, 512, 128
     org = cases.rand_plane(rng, H, W, bd, "smooth")
     pred = np.clip(org + rng.integers(-40, 41, org.shape), 0, 1023).astype(np.int16)
-    shapes = [(64, 32), (32, 64), (16, 32), (32, 16), (64, 16), (8, 16), (4, 64), (64, 4), (16, 4), (4, 8), (8, 4), (2, 8), (8, 2), (2, 2), (16, 64), (32, 8), (2, 32)]
+    shapes = [(64, 32), (32, 64), (16, 32), (32, 16), (64, 16), (8, 16), (16, 8), (4, 16), (4, 64), (64, 4), (16, 4), (4, 8), (8, 4), (2, 8), (8, 2), (2, 2), (16, 64), (32, 8), (2, 32)]
     tus = tile(W, H, shapes, rng, [27, 32, 37], bd)
     lv, asum, rec, coffs = oracle_chain(org, pred, tus, bd, W)
     glv, gsum, grec = gpu_chain(org, pred, tus, bd, W, coffs)
