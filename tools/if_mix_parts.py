@@ -1,5 +1,13 @@
-import numpy as np, torch, sys
-sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""Where the interpolation calls of the real shape mix (tests/golden/trace_*.npz) spend their time: vvcgpu_if_batch on sub-sets of the mix
+(call count of every sub-set as in the full 8.4 M-sample batch).  usage: python tools/if_mix_parts.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vvcsoftware_vtm_amd import ops, shape_mix as sm
 hist,_=sm.load_trace()
 sig=sm.signatures(hist,'interp',lambda w,h,a,b,c: 2<=w<=256 and h<=256)

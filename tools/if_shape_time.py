@@ -1,5 +1,13 @@
-import numpy as np, torch, sys
-sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""vvcgpu_if_batch on homogeneous lists (121 k calls of one shape / direction) and on two-shape lists, shuffled and sorted: the per-call floor of the
+batch kernel without the real mix's heavy calls.  usage: python tools/if_shape_time.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vvcsoftware_vtm_amd import ops, shape_mix as sm
 rng=np.random.default_rng(1)
 def run(calls,label):

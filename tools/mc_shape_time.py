@@ -1,5 +1,13 @@
-import numpy as np, torch, sys
-sys.path.insert(0,'/root/repo')
+#!/usr/bin/env python3
+"""vvcgpu_mc_batch (bi-prediction, luma) on a 4K picture tiled with 16x16 / 32x32 / 64x64 PUs: the packed fast path against the tile walker of the generic
+kernel.  usage: python tools/mc_shape_time.py"""
+import os
+import sys
+
+import numpy as np
+import torch
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from vvcsoftware_vtm_amd import ops
 rng=np.random.default_rng(1)
 W,H=3840+64,2160+64
