@@ -27,6 +27,8 @@ HOOKS = {
     ],
     "CommonLib/LoopFilter.cpp": [
         (r"^void LoopFilter::loopFilterPic\(", ["  if( vvcHipEnter( VVC_HIP_LOOPFILTER ) ) { wrap_loopFilterPic( this, cs ); return; }"]),
+        (r"^void LoopFilter::xEdgeFilterLuma\(", ["  if( vvcHipSelected() && vvcshim_edge_filter( this, &cu, (int) edgeDir, iEdge, 0 ) ) return;"]),
+        (r"^void LoopFilter::xEdgeFilterChroma\(", ["  if( vvcHipSelected() && vvcshim_edge_filter( this, &cu, (int) edgeDir, iEdge, 1 ) ) return;"]),
     ],
     "CommonLib/SampleAdaptiveOffset.cpp": [
         (r"^void SampleAdaptiveOffset::offsetCTU\(", ["  if( vvcHipEnter( VVC_HIP_OFFSETCTU ) ) { wrap_offsetCTU( this, area, src, res, saoblkParam, cs ); return; }"]),
@@ -42,6 +44,34 @@ HOOKS = {
             "#endif"]),
         (r"^void EncSampleAdaptiveOffset::getStatistics\(", ["  if( vvcHipSelected() && vvcshim_sao_stats( this, &blkStats, &orgYuv, &srcYuv, &cs, isCalculatePreDeblockSamples ) ) return;"]),
     ],
+    "CommonLib/TrQuant.cpp": [
+        (r"^void xTrMxN_EMT\(", ["  if( vvcHipSelected() && vvcshim_tr_fwd( bitDepth, residual, stride, coeff, iWidth, iHeight, maxLog2TrDynamicRange, ucMode, ucTrIdx, useQTBT ) ) return;"]),
+        (r"^void xITrMxN_EMT\(", ["  if( vvcHipSelected() && vvcshim_tr_inv( bitDepth, coeff, residual, stride, iWidth, iHeight, uiSkipWidth, uiSkipHeight, maxLog2TrDynamicRange, ucMode, ucTrIdx ) ) return;"]),
+        (r"^void TrQuant::invTransformNxN\(", ["  if( vvcHipEnter( VVC_HIP_INVTR ) ) { wrap_invTransformNxN( this, tu, compID, pResi, cQP ); return; }"]),
+    ],
+    "CommonLib/IntraPrediction.cpp": [
+        (r"^void IntraPrediction::predIntraAng\(", ["  if( vvcHipEnter( VVC_HIP_PREDANG ) ) { wrap_predIntraAng( this, compId, piPred, pu, useFilteredPredSamples ); return; }"]),
+        (r"^void IntraPrediction::predIntraChromaLM\(", ["  if( vvcHipEnter( VVC_HIP_PREDLM ) ) { wrap_predIntraChromaLM( this, compID, piPred, pu, chromaArea, intraDir ); return; }"]),
+        (r"^void IntraPrediction::initIntraPatternChType\(", ["  if( vvcHipEnter( VVC_HIP_INITPATTERN ) ) { wrap_initIntraPatternChType( this, cu, area, bFilterRefSamples ); return; }"]),
+    ],
+    "CommonLib/Picture.cpp": [
+        (r"^void Picture::extendPicBorder\(", ["  if( vvcHipEnter( VVC_HIP_EXTEND ) ) { wrap_extendPicBorder( this ); return; }"]),
+    ],
+    "CommonLib/PicYuvMD5.cpp": [
+        (r"^uint32_t calcCRC\(", ["  if( vvcHipSelected() ) { const int n = vvcshim_pichash( 1, &pic, &digest, &bitDepths ); if( n ) return (uint32_t) n; }"]),
+        (r"^uint32_t calcChecksum\(", ["  if( vvcHipSelected() ) { const int n = vvcshim_pichash( 2, &pic, &digest, &bitDepths ); if( n ) return (uint32_t) n; }"]),
+    ],
+    "CommonLib/DepQuant.cpp": [
+        (r"^void DepQuant::quant\(", ["  if( vvcHipSelected() && vvcshim_depquant( this, &tu, &compID, &pSrc, &uiAbsSum, &cQP, &ctx ) ) return;"]),
+    ],
+    "CommonLib/QuantRDOQ.cpp": [
+        (r"^void QuantRDOQ::quant\(", ["  if( vvcHipSelected() && vvcshim_rdoq( this, &tu, &compID, &pSrc, &uiAbsSum, &cQP, &ctx ) ) return;"]),
+    ],
+    "EncoderLib/InterSearch.cpp": [
+        (r"^void InterSearch::xPatternSearch\(", ["  if( vvcHipSelected() && vvcshim_fullsearch( this, &cStruct, &rcMv, &ruiSAD ) ) return;"]),
+        (r"^void InterSearch::xTZSearch\(", ["  if( vvcHipSelected() && vvcshim_tzsearch( this, &pu, &cStruct, &rcMv, &ruiSAD, pIntegerMv2Nx2NPred, bExtendedSettings, bFastSettings ) ) return;"]),
+        (r"^void InterSearch::xPatternSearchFracDIF\(", ["  if( vvcHipSelected() && vvcshim_frac( this, &pu, (int) eRefPicList, iRefIdx, &cStruct, &rcMvInt, &rcMvHalf, &rcMvQter, &ruiCost ) ) return;"]),
+    ],
     "EncoderLib/EncAdaptiveLoopFilter.cpp": [
         (r"^void EncAdaptiveLoopFilter::ALFProcess\(", ["  if( vvcHipEnter( VVC_HIP_ENCALF ) ) { wrap_EncALFProcess( this, cs, lambdas, alfSliceParam ); return; }"]),
         (r"^void EncAdaptiveLoopFilter::deriveStatsForFiltering\(", ["  if( vvcHipSelected() && vvcshim_alf_stats( this, &orgYuv, &recYuv ) ) return;"]),
@@ -53,7 +83,7 @@ SELECTOR = ("CommonLib/x86/CommonDefX86.cpp", r"^X86_VEXT read_x86_extension_fla
 
 
 def after_brace(lines, start):
-    for i in range(start, min(start + 12, len(lines))):
+    for i in range(start, min(start + 16, len(lines))):
         if lines[i].strip() == "{":
             return i + 1
     raise SystemExit("no opening brace behind line %d" % (start + 1))

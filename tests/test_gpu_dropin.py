@@ -234,7 +234,7 @@ needs_sel = pytest.mark.skipif(not (os.path.exists(APP) and os.path.exists(SELLI
 @needs_sel
 def test_patched_tree_selector_encoder(tmp_path):
     """the binding WITHOUT linker tricks: the reference built from a tree that carries integration/vtm-2.1-hip.patch (SIMD= selector value HIP, one line
-    at the top of the five InitX86 table functions and of the picture-level in-loop entry points; bodies in integration/InitHIP.cpp).  With --SIMD=HIP the
+    at the top of every hooked function; bodies in integration/InitHIP.cpp).  With --SIMD=HIP the
     whole in-loop chain runs on the device-resident picture and the bitstream is the fixture's, byte for byte; without it the same library is the
     plain CPU encoder (no GPU call at all)."""
     m, r, numbers = _encode_fixture(tmp_path, "ragop16_416x240_10b_q32", {"VVCGPU_SHIM_HOOKS": "pic"}, flag="--hipsel", extra=["--SIMD=HIP"])
@@ -254,6 +254,8 @@ def test_patched_tree_selector_table_slots_and_decoder(tmp_path):
     m, r, numbers = _encode_fixture(tmp_path, "ldp_208x120_10b_q27", {}, flag="--hipsel", extra=["--SIMD=HIP"])
     calls, line = numbers("[vvcgpu shim]")
     assert calls[0] == m["frames"] and calls[8] + calls[9] + calls[10] + calls[11] > 0, line
+    # the "next" rows through their source hooks: transforms, fractional refinement, de-quantiser + T2, whole-PU TZ search, intra prediction, borders
+    assert calls[12] + calls[13] > 0 and calls[14] > 0 and calls[16] > 0 and calls[20] > 0 and calls[21] > 0 and calls[22] > 0, line
     name = "ldp_208x120_10b_q27"
     out = str(tmp_path / "dec.yuv")
     r = subprocess.run([APP, "--hipsel", "dec", "-b", os.path.join(BS, name + ".bin"), "-o", out, "-d", str(m["bd"]), "--SIMD=HIP"],
@@ -263,3 +265,5 @@ def test_patched_tree_selector_table_slots_and_decoder(tmp_path):
     assert md5(out) == m["dec_yuv_md5"]
     line = [l for l in r.stderr.splitlines() if "[vvcgpu shim]" in l]
     assert line and int(line[-1].replace(",", " ").split("deblock")[1].split()[0]) >= m["frames"], r.stderr[-600:]
+    calls = [int(x) for x in line[-1].replace(",", " ").split() if x.isdigit()]
+    assert calls[21] > 0 and calls[25] > 0 and calls[22] > 0, line[-1]        # intra prediction, reference gathering, border extension on the device

@@ -15,7 +15,7 @@ PATCH = os.path.join(ROOT, "integration", "vtm-2.1-hip.patch")
 def test_patch_holds_only_added_lines():
     body = [l for l in open(PATCH).read().splitlines() if not l.startswith(("--- ", "+++ ", "@@ "))]
     assert body and all(l.startswith("+") for l in body)              # zero context, nothing removed: no reference text in the repository
-    assert sum("vvcHipEnter(" in l for l in body) == 11 and sum("vvcshim_" in l for l in body) == 2
+    assert sum("vvcHipEnter(" in l for l in body) == 16 and sum("vvcshim_" in l for l in body) == 13
 
 
 @pytest.mark.skipif(not os.path.isdir(os.path.join(REF, "source", "Lib")), reason="reference tree not present")
@@ -24,7 +24,7 @@ def test_patch_is_reproducible_and_applies(tmp_path):
     assert r.returncode == 0, r.stderr
     assert r.stdout == open(PATCH).read()
     files = sorted({l.split()[1][2:] for l in r.stdout.splitlines() if l.startswith("--- ")})
-    assert len(files) == 7
+    assert len(files) == 14
     for f in files:
         os.makedirs(os.path.dirname(tmp_path / f), exist_ok=True)
         shutil.copy(os.path.join(REF, f), tmp_path / f)
