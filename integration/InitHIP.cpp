@@ -7,9 +7,9 @@
 // boundary -- and (c) the same line at the top of the functions of the "next" rows the harness binds (xTrMxN_EMT / xITrMxN_EMT,
 // TrQuant::invTransformNxN, DepQuant::quant, QuantRDOQ::quant, the three InterSearch searches, the intra predictors, Picture::extendPicBorder,
 // the CRC / checksum picture hashes, LoopFilter::xEdgeFilterLuma / Chroma).  No linker options: the bodies are the same code the --wrap harness runs (vtm_hip_shim.cpp, compiled here in its source-hook form).
-// Build: this file with -fno-access-control (it calls the reference's private helpers), link -lvvcgpu.
+// Build: this file with -fno-access-control (it calls the reference's private helpers) -I<repo>/include -I<repo>/vvcsoftware_vtm_amd/shim, link -lvvcgpu.
 #define VVCSHIM_SOURCE_HOOKS 1
-#include "../vvcsoftware_vtm_amd/shim/vtm_hip_shim.cpp"
+#include "vtm_hip_shim.cpp"       // found through -I<repo>/vvcsoftware_vtm_amd/shim
 #include "InitHIP.h"
 
 namespace {
