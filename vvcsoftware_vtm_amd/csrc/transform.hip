@@ -1375,18 +1375,17 @@ struct DqState
 {
   long long rdCost;
   dq_u4 lev;                          // 16 abs levels of the current sub-block (bytes)
-  dq_u8 cti;                          // 16 template-context seeds (u16): sumNum | sumAbs1 << 3 | min(127, sumAbs) << 8
-  int numSigSbb, refSbbCtxId;
+  int numSigSbb, refSbbCtxId;         // refSbbCtxId also names the LDS slot with the 16 template-context seeds of the sub-block (-1: all zero)
   int sbb0, sbb1, sig0, sig1;
-  dq_i8 cb;                           // coefficient bit sums [0..6]
+  int gc;                             // row of the greater-than-x rate table (coefficient bit sums [0..6])
   int goRice;
 };
 
 // member-wise copy: a whole-struct assignment also copies the padding through scratch memory
 __device__ __forceinline__ void dq_copy(DqState& d, const DqState& s)
 {
-  d.rdCost = s.rdCost; d.lev = s.lev; d.cti = s.cti; d.numSigSbb = s.numSigSbb; d.refSbbCtxId = s.refSbbCtxId;
-  d.sbb0 = s.sbb0; d.sbb1 = s.sbb1; d.sig0 = s.sig0; d.sig1 = s.sig1; d.cb = s.cb; d.goRice = s.goRice;
+  d.rdCost = s.rdCost; d.lev = s.lev; d.numSigSbb = s.numSigSbb; d.refSbbCtxId = s.refSbbCtxId;
+  d.sbb0 = s.sbb0; d.sbb1 = s.sbb1; d.sig0 = s.sig0; d.sig1 = s.sig1; d.gc = s.gc; d.goRice = s.goRice;
 }
 __device__ __forceinline__ unsigned dq_get_byte(const dq_u4 a, int j)
 {
@@ -1408,12 +1407,11 @@ __device__ __forceinline__ unsigned dq_get_u16(const dq_u8 c, int j)
   for (int i = 1; i < 8; i++) v = d == i ? c[i] : v;
   return (v >> ((j & 1) * 16)) & 0xFFFFu;
 }
-__device__ __forceinline__ int dq_level_bits(const dq_i8 cb, int goRice, unsigned level)       // State::getLevelBits :909-931
+typedef const __attribute__((address_space(3))) vvcgpu_dq_rates* DqLdsRates;
+__device__ __forceinline__ int dq_level_bits(DqLdsRates rt, int gc, int goRice, unsigned level)       // State::getLevelBits :909-931
 {
   const unsigned idx = level < 5 ? level : 5 + ((level - 5) & 1);
-  int bits = cb[0];
-#pragma unroll
-  for (int i = 1; i < 7; i++) bits = idx == (unsigned)i ? cb[i] : bits;
+  const int bits = rt->gtx[gc][idx];
   if (level < 5) return bits;
   const unsigned value = (level - 5) >> 1;
   const unsigned range = goRice == 0 ? 6u : goRice == 1 ? 5u : goRice == 2 ? 6u : 3u;              // g_auiGoRiceRange
@@ -1461,7 +1459,10 @@ struct DqRec
   unsigned misc, pad;                 // neighbour positions 5 x 4 bits | sigOff << 20 | gtxOff << 24
 };
 static_assert(sizeof(DqRec) == 64, "DqRec");
-constexpr int DQ_REC_BYTES = 64 * 16 * (int)sizeof(DqRec);                // 64 quads per workgroup x 16 positions
+constexpr int DQ_REC_N = 8;                                               // positions filled at a time (half a sub-block)
+constexpr int DQ_SEED_BYTES = 5 * 32;                                     // per TU: the seeds of context slots 0..3 + an all-zero slot
+constexpr int DQ_LDS_BYTES = 64 * (DQ_REC_N * (int)sizeof(DqRec) + DQ_SEED_BYTES);   // 64 quads per workgroup
+constexpr int DQ_RT_SLOTS = 16;
 
 __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict__ coeffBase, TCoeff* __restrict__ levelBase,
                                                        const vvcgpu_depquant_desc* __restrict__ descs, int n,
@@ -1477,24 +1478,6 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   const bool luma = d.luma != 0;
   const TCoeff* coef = coeffBase + d.coeff_off;
   TCoeff* level = levelBase + d.level_off;
-  // The rate tables are looked up on the critical path of every step: up to eight distinct tables of a workgroup are staged in LDS
-  // (slot = index & 7, first come first served); a TU whose table did not get a slot reads it from global memory.  Generic
-  // pointers address either.
-  __shared__ vvcgpu_dq_rates rtCache[8];
-  __shared__ int rtSlot[8];
-  if (threadIdx.x < 8) rtSlot[threadIdx.x] = -1;
-  __syncthreads();
-  if (live && k == 0) atomicCAS(&rtSlot[d.rates_idx & 7], -1, d.rates_idx);
-  __syncthreads();
-  for (int sl = 0; sl < 8; sl++)
-    if (rtSlot[sl] >= 0)
-    {
-      const int* src = reinterpret_cast<const int*>(ratesBase + rtSlot[sl]);
-      int* dst = reinterpret_cast<int*>(&rtCache[sl]);
-      for (int i = threadIdx.x; i < (int)(sizeof(vvcgpu_dq_rates) / 4); i += 256) dst[i] = src[i];
-    }
-  __syncthreads();
-  const vvcgpu_dq_rates* rt = (live && rtSlot[d.rates_idx & 7] == d.rates_idx) ? &rtCache[d.rates_idx & 7] : ratesBase + d.rates_idx;
   const int tabOff = d_scanOff[(lw - 1) * 6 + (lh - 1)];
   const unsigned short* scan = d_scan + tabOff;
   const unsigned short* inv = d_dqInv + tabOff;
@@ -1538,10 +1521,26 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   }
   first = max(first, __shfl_xor(first, 1));
   first = max(first, __shfl_xor(first, 2));
-  int maxFirst = first;
+  if (live && first < 0 && k == 0) absSumOut[ti] = 0;
+
+  // LDS: per quad the position records and the template seeds of its four context slots; per workgroup the rate tables.  The tables
+  // are looked up on the critical path of every step, so the walk only ever reads them from LDS: up to DQ_RT_SLOTS distinct tables of
+  // the workgroup's 64 TUs are staged per pass, TUs whose table found no slot walk in the next pass (one pass unless a caller
+  // mixes more than sixteen tables inside 64 consecutive TUs).
+  extern __shared__ __align__(16) unsigned char dqSmem[];
+  DqRec* const recTu = reinterpret_cast<DqRec*>(dqSmem) + (threadIdx.x >> 2) * DQ_REC_N;
+  unsigned* const seedTu = reinterpret_cast<unsigned*>(dqSmem + 64 * DQ_REC_N * sizeof(DqRec)) + (threadIdx.x >> 2) * (DQ_SEED_BYTES / 4);
+  __shared__ vvcgpu_dq_rates rtCache[DQ_RT_SLOTS];
+  __shared__ int rtSlot[DQ_RT_SLOTS];
+  __shared__ int rtPending;
+#pragma unroll
+  for (int i = 0; i < DQ_SEED_BYTES / 4 / 4; i++) seedTu[k * (DQ_SEED_BYTES / 4 / 4) + i] = 0u;
+
+  auto walk = [&](const bool run, DqLdsRates rt)
+  {
+  int maxFirst = run ? first : -1;
 #pragma unroll
   for (int m = 4; m < 64; m <<= 1) maxFirst = max(maxFirst, __shfl_xor(maxFirst, m));
-  if (live && first < 0 && k == 0) absSumOut[ti] = 0;
   if (maxFirst < 0) return;
 
   const int sigSet = max(k - 1, 0);                                       // RateEstimator::sigFlagBits(stateId) :282-285
@@ -1549,22 +1548,15 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   {
     P.rdCost = 0x7FFFFFFFFFFFFFFFll >> 1; P.numSigSbb = 0; P.refSbbCtxId = -1; P.goRice = 0; P.sbb0 = P.sbb1 = 0;
     P.sig0 = rt->sig[sigSet][0][0]; P.sig1 = rt->sig[sigSet][0][1];
-    P.lev = dq_u4{ 0, 0, 0, 0 }; P.cti = dq_u8{ 0, 0, 0, 0, 0, 0, 0, 0 }; P.cb = dq_i8{ 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-    for (int i = 0; i < 7; i++) P.cb[i] = rt->gtx[0][i];
+    P.lev = dq_u4{ 0, 0, 0, 0 }; P.gc = 0;
     dq_copy(S, P);
   }
-  dq_i8 startCb = { 0, 0, 0, 0, 0, 0, 0, 0 };
-#pragma unroll
-  for (int i = 0; i < 7; i++) startCb[i] = rt->gtx[0][i];
   int curCtx = 0;                                                         // which half of the sub-block memory is "current"
   dq_u8 Fcur;                                                             // coded-sub-block flags (bit per sub-block) of context slot k, current half
 #pragma unroll
   for (int i = 0; i < 8; i++) Fcur[i] = 0;
   long long finalCost = 0;
 
-  extern __shared__ __align__(16) unsigned char dqSmem[];
-  DqRec* const recTu = reinterpret_cast<DqRec*>(dqSmem) + (threadIdx.x >> 2) * 16;
   auto fillRec = [&](int si)
   {
     const int p = scan[si], x = p & (w - 1), y = p >> lw;
@@ -1602,12 +1594,12 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     const int sigOff = luma ? (diag < 2 ? 12 : diag < 5 ? 6 : 0) : (diag < 2 ? 6 : 0);
     const int gtxOff = luma ? (diag < 1 ? 16 : diag < 3 ? 11 : diag < 10 ? 6 : 1) : (diag < 1 ? 6 : 1);
     misc |= (unsigned)sigOff << 20 | (unsigned)gtxOff << 24;
-    DqRec* r = recTu + (si & 15);
+    DqRec* r = recTu + (si & (DQ_REC_N - 1));
 #pragma unroll
     for (int t = 0; t < 4; t++) r->dist[t] = pqDist[t];
     *reinterpret_cast<uint2*>(r->ab) = make_uint2((unsigned)pqAbs[0] | (unsigned)pqAbs[1] << 16, (unsigned)pqAbs[2] | (unsigned)pqAbs[3] << 16);
-    r->start[0] = pqDist[0] + lastOffset + dq_level_bits(startCb, 0, (unsigned)pqAbs[0]);
-    r->start[1] = pqDist[2] + lastOffset + dq_level_bits(startCb, 0, (unsigned)pqAbs[2]);
+    r->start[0] = pqDist[0] + lastOffset + dq_level_bits(rt, 0, 0, (unsigned)pqAbs[0]);
+    r->start[1] = pqDist[2] + lastOffset + dq_level_bits(rt, 0, 0, (unsigned)pqAbs[2]);
     r->misc = misc;
   };
   // transitions leaving state k: state 0: pq0 -> dec0, pq2 -> dec2; state 1: pq2 -> dec0, pq0 -> dec2; state 2: pq3 -> dec1, pq1 -> dec3;
@@ -1628,7 +1620,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
 
   for (int scanIdx = maxFirst; scanIdx >= 0; scanIdx--)
   {
-    const bool act = live && scanIdx <= first;                            // quad-uniform
+    const bool act = run && scanIdx <= first;                             // quad-uniform
     const int sIdx = scanIdx;                                             // inactive quads compute on valid indices and discard
     const int insidePos = sIdx & 15;
     const bool eosbb = insidePos == 0, sosbb = insidePos == 15;
@@ -1636,16 +1628,17 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     const bool eocsbb = eosbb && sIdx > 0 && sIdx < N - 16;
     const int spt = socsbb ? 1 : (eocsbb ? 2 : 0);
     const int nxt = max(sIdx - 1, 0);
-    if (sosbb || scanIdx == maxFirst)                                     // wave-uniform: the walk enters a sub-block
+    const int recPos = sIdx & (DQ_REC_N - 1);
+    if (recPos == DQ_REC_N - 1 || scanIdx == maxFirst)                    // wave-uniform: the walk enters a group of positions
     {
-      const int beg = sIdx & ~15;
+      const int beg = sIdx & ~(DQ_REC_N - 1);
 #pragma unroll 1
-      for (int j = k; j < 16; j += 4) fillRec(beg + j);
+      for (int j = k; j < DQ_REC_N; j += 4) fillRec(beg + j);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
-      R = loadRec(insidePos);
+      R = loadRec(recPos);
     }
     else R = Rn;
-    if (!eosbb) Rn = loadRec(insidePos - 1);                              // the next step's record is in flight during this one
+    if (recPos != 0) Rn = loadRec(recPos - 1);                            // the next step's record is in flight during this one
 
     const long long INF = 0x7FFFFFFFFFFFFFFFll;
     long long cLow, cHigh, cZero = INF;
@@ -1655,8 +1648,8 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
       else if (spt == 1) { extra1 = P.sbb1 + P.sig1; extra0 = P.sbb1 + P.sig0; }
       else if (P.numSigSbb) { extra1 = P.sig1; extra0 = P.sig0; }
       else zeroOk = false;
-      cLow = P.rdCost + R.dl + dq_level_bits(P.cb, P.goRice, (unsigned)abOf(R.ab, lowIdx)) + extra1;
-      cHigh = P.rdCost + R.dh + dq_level_bits(P.cb, P.goRice, (unsigned)abOf(R.ab, highIdx)) + extra1;
+      cLow = P.rdCost + R.dl + dq_level_bits(rt, P.gc, P.goRice, (unsigned)abOf(R.ab, lowIdx)) + extra1;
+      cHigh = P.rdCost + R.dh + dq_level_bits(rt, P.gc, P.goRice, (unsigned)abOf(R.ab, highIdx)) + extra1;
       if (zeroOk) cZero = P.rdCost + extra0;
     }
     // decision k: sources a = 0 / 2, b = a + 1; k < 2 takes their "low" transitions, k >= 2 the "high" ones.  The source lanes are a fixed
@@ -1696,11 +1689,9 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
       const int nextInside = nxt & 15;
       // source of the copied context: lane dPrev (0..3), own skip state (4 + k) or nothing
       const int srcLane = qbase + (dPrev >= 0 && dPrev < 4 ? dPrev : k);
-      dq_u4 lv = { 0, 0, 0, 0 }; dq_u8 ct = { 0, 0, 0, 0, 0, 0, 0, 0 }; int sNum, sRef, sSbb0, sSbb1;
+      dq_u4 lv = { 0, 0, 0, 0 }; int sNum, sRef, sSbb0, sSbb1;
 #pragma unroll
       for (int i = 0; i < 4; i++) lv[i] = (unsigned)__shfl((int)P.lev[i], srcLane);
-#pragma unroll
-      for (int i = 0; i < 8; i++) ct[i] = (unsigned)__shfl((int)P.cti[i], srcLane);
       sNum = __shfl(P.numSigSbb, srcLane); sRef = __shfl(P.refSbbCtxId, srcLane);
       sSbb0 = __shfl(P.sbb0, srcLane); sSbb1 = __shfl(P.sbb1, srcLane);
       if (dPrev >= 4) { sNum = S.numSigSbb; sRef = S.refSbbCtxId;
@@ -1723,16 +1714,14 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
         {
           if (dPrev >= 0) { C.numSigSbb = sNum + (dAbs != 0); C.refSbbCtxId = sRef; C.sbb0 = sSbb0; C.sbb1 = sSbb1;
 #pragma unroll
-            for (int i = 0; i < 4; i++) C.lev[i] = lv[i];
-#pragma unroll
-            for (int i = 0; i < 8; i++) C.cti[i] = ct[i]; }
+            for (int i = 0; i < 4; i++) C.lev[i] = lv[i]; }
           else { C.numSigSbb = 1; C.refSbbCtxId = -1;
 #pragma unroll
-            for (int i = 0; i < 4; i++) C.lev[i] = 0;
-#pragma unroll
-            for (int i = 0; i < 8; i++) C.cti[i] = 0; }
+            for (int i = 0; i < 4; i++) C.lev[i] = 0; }
           dq_set_byte(C.lev, insidePos, (unsigned)min(255, dAbs));
-          const unsigned tinit = dq_get_u16(C.cti, nextInside);
+          // the seeds of a sub-block belong to the context slot that was current when the walk entered it; every state that descends
+          // from it reads the same sixteen values (slot 4 = zeros: a path that started inside the sub-block)
+          const unsigned tinit = reinterpret_cast<const unsigned short*>(seedTu)[(C.refSbbCtxId < 0 ? 4 : C.refSbbCtxId) * 16 + nextInside];
           sumAbs = (int)(tinit >> 8); sumAbs1 = (int)((tinit >> 3) & 31); sumNum = (int)(tinit & 7);
 #pragma unroll
           for (int t = 0; t < 5; t++)
@@ -1788,8 +1777,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
           // neighbour outside a 4x4 sub-block lies in the sub-block to its right, below it or below-right of it, whose sixteen levels
           // are sixteen consecutive bytes of the history (scan order): three 16-byte loads and compile-time byte picks replace eighty
           // dependent byte loads behind eighty table look-ups (13.6 us per sub-block end, a fifth of the kernel).
-#pragma unroll
-          for (int i = 0; i < 8; i++) C.cti[i] = 0;
+          dq_u8 cti = { 0, 0, 0, 0, 0, 0, 0, 0 };
           if (act)
           {
             const int bx = nsx * 4, by = nsy * 4;
@@ -1824,20 +1812,21 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
                 if (X > 3 && Y > 3) sum += cD; else if (X > 3) sum += cR[Y][X - 4]; else if (Y > 3) sum += cB[Y - 4][X];
               }
               const unsigned seed = (sum & 0xFFu) | (min(127u, sum >> 8) << 8);
-              C.cti[i >> 1] |= seed << ((i & 1) * 16);
+              cti[i >> 1] |= seed << ((i & 1) * 16);
             }
+            *reinterpret_cast<uint4*>(seedTu + k * 8) = make_uint4(cti[0], cti[1], cti[2], cti[3]);
+            *reinterpret_cast<uint4*>(seedTu + k * 8 + 4) = make_uint4(cti[4], cti[5], cti[6], cti[7]);
           }
 #pragma unroll
           for (int i = 0; i < 4; i++) C.lev[i] = 0;
-          const unsigned tinit = dq_get_u16(C.cti, nextInside);
+          const unsigned tinit = dq_get_u16(cti, nextInside);
           sumNum = (int)(tinit & 7); sumAbs1 = (int)((tinit >> 3) & 31); sumAbs = (int)(tinit >> 8);
         }
         const int sumGt1 = sumAbs1 - sumNum;
         sumAbs -= sumNum;
         const int sc = sigOff + min(sumAbs1, 5), gc = gtxOff + min(sumGt1, 4);
         C.sig0 = rt->sig[sigSet][sc][0]; C.sig1 = rt->sig[sigSet][sc][1];
-#pragma unroll
-        for (int i = 0; i < 7; i++) C.cb[i] = rt->gtx[gc][i];
+        C.gc = gc;
         const int ga = min(sumAbs, 31);
         C.goRice = ga < 12 ? 0 : ga < 25 ? 1 : 2;                          // g_auiGoRicePars
       }
@@ -1854,7 +1843,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   // ---- best final state and back-trace :1368-1390.  Lane 0 of the quad walks; decisions 4..7 are implicit: at a sub-block end they
   // are a copy of decisions 0..3 (:1269), elsewhere { level 0, same skip id } (startDec :1218)
   long long c1 = dq_shfl64(finalCost, qbase + 1), c2 = dq_shfl64(finalCost, qbase + 2), c3 = dq_shfl64(finalCost, qbase + 3);
-  if (!live || first < 0 || k != 0) return;
+  if (!run || k != 0) return;
   int prevId = -2; long long minCost = 0;
   if (finalCost < minCost) { prevId = 0; minCost = finalCost; }
   if (c1 < minCost) { prevId = 1; minCost = c1; }
@@ -1872,6 +1861,42 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     prevId = nextPrev;
   }
   absSumOut[ti] = absSum;
+  };
+
+  bool done = !(live && first >= 0);
+  for (;;)
+  {
+    if (threadIdx.x < DQ_RT_SLOTS) rtSlot[threadIdx.x] = -1;
+    if (threadIdx.x == 0) rtPending = 0;
+    __syncthreads();
+    int mySlot = -1;
+    if (!done && k == 0)
+    {
+      for (int t = 0; t < DQ_RT_SLOTS && mySlot < 0; t++)
+      {
+        const int sl = (d.rates_idx + t) & (DQ_RT_SLOTS - 1);
+        const int old = atomicCAS(&rtSlot[sl], -1, d.rates_idx);
+        if (old == -1 || old == d.rates_idx) mySlot = sl;
+      }
+      if (mySlot < 0) rtPending = 1;
+    }
+    mySlot = __shfl(mySlot, qbase);
+    __syncthreads();
+    const bool more = rtPending != 0;
+    for (int sl = 0; sl < DQ_RT_SLOTS; sl++)
+      if (rtSlot[sl] >= 0)
+      {
+        const int* src = reinterpret_cast<const int*>(ratesBase + rtSlot[sl]);
+        int* dst = reinterpret_cast<int*>(&rtCache[sl]);
+        for (int i = threadIdx.x; i < (int)(sizeof(vvcgpu_dq_rates) / 4); i += 256) dst[i] = src[i];
+      }
+    __syncthreads();
+    const bool run = !done && mySlot >= 0;
+    walk(run, (DqLdsRates)&rtCache[max(mySlot, 0)]);
+    done = done || run;
+    if (!more) break;
+    __syncthreads();
+  }
 }
 
 // ---- N1: rate-distortion optimised quantiser (QuantRDOQ::xRateDistOptQuant, QuantRDOQ.cpp:694-1409) -------------------------
@@ -2430,8 +2455,8 @@ int vvcgpu_depquant_batch(const vvc_coef* coeff_base, vvc_coef* level_base, cons
   const size_t c = (total_coeffs + 15) & ~(size_t)15;
   unsigned* dec = static_cast<unsigned*>(ws);
   unsigned char* ctx = static_cast<unsigned char*>(ws) + c * 16;
-  VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(depquant_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_REC_BYTES));
-  hipLaunchKernelGGL(depquant_kernel, dim3(cdiv(n, 64)), dim3(256), DQ_REC_BYTES, (hipStream_t)stream, coeff_base, level_base, descs, n, rates, bit_depth,
+  VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(depquant_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, DQ_LDS_BYTES));
+  hipLaunchKernelGGL(depquant_kernel, dim3(cdiv(n, 64)), dim3(256), DQ_LDS_BYTES, (hipStream_t)stream, coeff_base, level_base, descs, n, rates, bit_depth,
                      abs_sum, dec, ctx);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
