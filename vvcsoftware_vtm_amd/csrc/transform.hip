@@ -1375,6 +1375,7 @@ struct DqState
 {
   long long rdCost;
   dq_u4 lev;                          // 16 abs levels of the current sub-block (bytes)
+  dq_u4 aux;                          // per level min(4 - (v & 1), v) | (v != 0) << 5: what it adds to sumAbs1 and sumNum of a template
   int numSigSbb, refSbbCtxId;         // refSbbCtxId also names the LDS slot with the 16 template-context seeds of the sub-block (-1: all zero)
   int sbb0, sbb1, sig0, sig1;
   int gc;                             // row of the greater-than-x rate table (coefficient bit sums [0..6])
@@ -1384,7 +1385,7 @@ struct DqState
 // member-wise copy: a whole-struct assignment also copies the padding through scratch memory
 __device__ __forceinline__ void dq_copy(DqState& d, const DqState& s)
 {
-  d.rdCost = s.rdCost; d.lev = s.lev; d.numSigSbb = s.numSigSbb; d.refSbbCtxId = s.refSbbCtxId;
+  d.rdCost = s.rdCost; d.lev = s.lev; d.aux = s.aux; d.numSigSbb = s.numSigSbb; d.refSbbCtxId = s.refSbbCtxId;
   d.sbb0 = s.sbb0; d.sbb1 = s.sbb1; d.sig0 = s.sig0; d.sig1 = s.sig1; d.gc = s.gc; d.goRice = s.goRice;
 }
 __device__ __forceinline__ unsigned dq_get_byte(const dq_u4 a, int j)
@@ -1456,9 +1457,12 @@ struct DqRec
   long long dist[4];                  // pqData.deltaDist by slot (qIdx & 3)
   unsigned short ab[4];               // pqData.absLevel by slot
   long long start[2];                 // decision 0 / decision 2
-  unsigned misc, pad;                 // neighbour positions 5 x 4 bits | sigOff << 20 | gtxOff << 24
+  unsigned misc;                      // neighbour positions 5 x 4 bits | sigOff << 20 | gtxOff << 24
+  // v_perm_b32 selectors that pick the five neighbours out of the sixteen level bytes: group A = neighbours 0..3, group B = neighbour 4;
+  // Lo reads bytes 0..7, Hi bytes 8..15, selector 12 (= constant zero) where the neighbour is in the other half or does not exist
+  unsigned selLoA, selHiA, selLoB, selHiB, pad;
 };
-static_assert(sizeof(DqRec) == 64, "DqRec");
+static_assert(sizeof(DqRec) == 80, "DqRec");
 constexpr int DQ_REC_N = 8;                                               // positions filled at a time (half a sub-block)
 constexpr int DQ_SEED_BYTES = 5 * 32;                                     // per TU: the seeds of context slots 0..3 + an all-zero slot
 constexpr int DQ_LDS_BYTES = 64 * (DQ_REC_N * (int)sizeof(DqRec) + DQ_SEED_BYTES);   // 64 quads per workgroup
@@ -1548,7 +1552,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   {
     P.rdCost = 0x7FFFFFFFFFFFFFFFll >> 1; P.numSigSbb = 0; P.refSbbCtxId = -1; P.goRice = 0; P.sbb0 = P.sbb1 = 0;
     P.sig0 = rt->sig[sigSet][0][0]; P.sig1 = rt->sig[sigSet][0][1];
-    P.lev = dq_u4{ 0, 0, 0, 0 }; P.gc = 0;
+    P.lev = dq_u4{ 0, 0, 0, 0 }; P.aux = dq_u4{ 0, 0, 0, 0 }; P.gc = 0;
     dq_copy(S, P);
   }
   int curCtx = 0;                                                         // which half of the sub-block memory is "current"
@@ -1593,8 +1597,17 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     const int diag = x2 + y2;
     const int sigOff = luma ? (diag < 2 ? 12 : diag < 5 ? 6 : 0) : (diag < 2 ? 6 : 0);
     const int gtxOff = luma ? (diag < 1 ? 16 : diag < 3 ? 11 : diag < 10 ? 6 : 1) : (diag < 1 ? 6 : 1);
+    unsigned selLo[2] = { 0x0C0C0C0Cu, 0x0C0C0C0Cu }, selHi[2] = { 0x0C0C0C0Cu, 0x0C0C0C0Cu };
+#pragma unroll
+    for (int t = 0; t < 5; t++)
+    {
+      const unsigned rel = (misc >> (4 * t)) & 15u, sh = (unsigned)(t & 3) * 8u, m = 0xFFu << sh;
+      if (rel != 0u && rel < 8u) selLo[t >> 2] = (selLo[t >> 2] & ~m) | (rel << sh);
+      if (rel >= 8u) selHi[t >> 2] = (selHi[t >> 2] & ~m) | ((rel - 8u) << sh);
+    }
     misc |= (unsigned)sigOff << 20 | (unsigned)gtxOff << 24;
     DqRec* r = recTu + (si & (DQ_REC_N - 1));
+    r->selLoA = selLo[0]; r->selHiA = selHi[0]; r->selLoB = selLo[1]; r->selHiB = selHi[1];
 #pragma unroll
     for (int t = 0; t < 4; t++) r->dist[t] = pqDist[t];
     *reinterpret_cast<uint2*>(r->ab) = make_uint2((unsigned)pqAbs[0] | (unsigned)pqAbs[1] << 16, (unsigned)pqAbs[2] | (unsigned)pqAbs[3] << 16);
@@ -1605,18 +1618,19 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   // transitions leaving state k: state 0: pq0 -> dec0, pq2 -> dec2; state 1: pq2 -> dec0, pq0 -> dec2; state 2: pq3 -> dec1, pq1 -> dec3;
   // state 3: pq1 -> dec1, pq3 -> dec3; the zero transition goes to dec0 / dec2 / dec1 / dec3  (:1229-1240)
   const int lowIdx = k == 0 ? 0 : k == 1 ? 2 : k == 2 ? 3 : 1, highIdx = lowIdx ^ 2;
-  struct DqRecRegs { long long dl, dh, start; uint2 ab; unsigned misc; };
+  struct DqRecRegs { long long dl, dh, start; uint2 ab; unsigned misc; uint4 sel; };
   auto loadRec = [&](int inside)
   {
     const DqRec* r = recTu + inside;
     DqRecRegs v;
     v.dl = r->dist[lowIdx]; v.dh = r->dist[highIdx]; v.start = r->start[k >> 1];
     v.ab = *reinterpret_cast<const uint2*>(r->ab); v.misc = r->misc;
+    v.sel = make_uint4(r->selLoA, r->selHiA, r->selLoB, r->selHiB);
     return v;
   };
   auto abOf = [](uint2 ab, int t) { return (int)(((t < 2 ? ab.x : ab.y) >> ((t & 1) * 16)) & 0xFFFFu); };
   DqRecRegs R, Rn;
-  Rn.dl = Rn.dh = Rn.start = 0; Rn.ab = make_uint2(0, 0); Rn.misc = 0;
+  Rn.dl = Rn.dh = Rn.start = 0; Rn.ab = make_uint2(0, 0); Rn.misc = 0; Rn.sel = make_uint4(0, 0, 0, 0);
 
   for (int scanIdx = maxFirst; scanIdx >= 0; scanIdx--)
   {
@@ -1689,9 +1703,12 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
       const int nextInside = nxt & 15;
       // source of the copied context: lane dPrev (0..3), own skip state (4 + k) or nothing
       const int srcLane = qbase + (dPrev >= 0 && dPrev < 4 ? dPrev : k);
-      dq_u4 lv = { 0, 0, 0, 0 }; int sNum, sRef, sSbb0, sSbb1;
+      dq_u4 lv = { 0, 0, 0, 0 }, ax = { 0, 0, 0, 0 }; int sNum, sRef, sSbb0, sSbb1;
 #pragma unroll
       for (int i = 0; i < 4; i++) lv[i] = (unsigned)__shfl((int)P.lev[i], srcLane);
+      if (!eosbb)
+#pragma unroll
+        for (int i = 0; i < 4; i++) ax[i] = (unsigned)__shfl((int)P.aux[i], srcLane);
       sNum = __shfl(P.numSigSbb, srcLane); sRef = __shfl(P.refSbbCtxId, srcLane);
       sSbb0 = __shfl(P.sbb0, srcLane); sSbb1 = __shfl(P.sbb1, srcLane);
       if (dPrev >= 4) { sNum = S.numSigSbb; sRef = S.refSbbCtxId;
@@ -1714,20 +1731,27 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
         {
           if (dPrev >= 0) { C.numSigSbb = sNum + (dAbs != 0); C.refSbbCtxId = sRef; C.sbb0 = sSbb0; C.sbb1 = sSbb1;
 #pragma unroll
-            for (int i = 0; i < 4; i++) C.lev[i] = lv[i]; }
+            for (int i = 0; i < 4; i++) { C.lev[i] = lv[i]; C.aux[i] = ax[i]; } }
           else { C.numSigSbb = 1; C.refSbbCtxId = -1;
 #pragma unroll
-            for (int i = 0; i < 4; i++) C.lev[i] = 0; }
-          dq_set_byte(C.lev, insidePos, (unsigned)min(255, dAbs));
+            for (int i = 0; i < 4; i++) { C.lev[i] = 0; C.aux[i] = 0; } }
+          const unsigned lvNew = (unsigned)min(255, dAbs);
+          dq_set_byte(C.lev, insidePos, lvNew);
+          dq_set_byte(C.aux, insidePos, min(4u - (lvNew & 1u), lvNew) | (lvNew != 0u ? 32u : 0u));
           // the seeds of a sub-block belong to the context slot that was current when the walk entered it; every state that descends
           // from it reads the same sixteen values (slot 4 = zeros: a path that started inside the sub-block)
           const unsigned tinit = reinterpret_cast<const unsigned short*>(seedTu)[(C.refSbbCtxId < 0 ? 4 : C.refSbbCtxId) * 16 + nextInside];
           sumAbs = (int)(tinit >> 8); sumAbs1 = (int)((tinit >> 3) & 31); sumNum = (int)(tinit & 7);
-#pragma unroll
-          for (int t = 0; t < 5; t++)
+          // the five template neighbours inside the sub-block: four byte permutes pick them out of the sixteen levels (and out of their
+          // sumAbs1 / sumNum contributions), v_sad_u8 against zero adds the picked bytes up
           {
-            const int rel = (int)((R.misc >> (4 * t)) & 15u);
-            if (rel) { const int v = (int)dq_get_byte(C.lev, rel); sumAbs += v; sumAbs1 += min(4 - (v & 1), v); sumNum += v != 0; }
+            const unsigned nA = __builtin_amdgcn_perm(C.lev[1], C.lev[0], R.sel.x) | __builtin_amdgcn_perm(C.lev[3], C.lev[2], R.sel.y);
+            const unsigned nB = __builtin_amdgcn_perm(C.lev[1], C.lev[0], R.sel.z) | __builtin_amdgcn_perm(C.lev[3], C.lev[2], R.sel.w);
+            const unsigned xA = __builtin_amdgcn_perm(C.aux[1], C.aux[0], R.sel.x) | __builtin_amdgcn_perm(C.aux[3], C.aux[2], R.sel.y);
+            const unsigned xB = __builtin_amdgcn_perm(C.aux[1], C.aux[0], R.sel.z) | __builtin_amdgcn_perm(C.aux[3], C.aux[2], R.sel.w);
+            sumAbs = (int)__builtin_amdgcn_sad_u8(nB, 0u, __builtin_amdgcn_sad_u8(nA, 0u, (unsigned)sumAbs));
+            const unsigned sx = __builtin_amdgcn_sad_u8(xB, 0u, __builtin_amdgcn_sad_u8(xA, 0u, 0u));
+            sumAbs1 += (int)(sx & 31u); sumNum += (int)(sx >> 5);
           }
         }
         else                                                               // State::updateStateEOS :1071-1102 + CommonCtx::update :1104-1164
@@ -1818,7 +1842,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
             *reinterpret_cast<uint4*>(seedTu + k * 8 + 4) = make_uint4(cti[4], cti[5], cti[6], cti[7]);
           }
 #pragma unroll
-          for (int i = 0; i < 4; i++) C.lev[i] = 0;
+          for (int i = 0; i < 4; i++) { C.lev[i] = 0; C.aux[i] = 0; }
           const unsigned tinit = dq_get_u16(cti, nextInside);
           sumNum = (int)(tinit & 7); sumAbs1 = (int)((tinit >> 3) & 31); sumAbs = (int)(tinit >> 8);
         }
