@@ -1561,10 +1561,9 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   for (int i = 0; i < 8; i++) Fcur[i] = 0;
   long long finalCost = 0;
 
-  auto fillRec = [&](int si)
+  auto fillRec = [&](int si, int p, int coefAbs)
   {
-    const int p = scan[si], x = p & (w - 1), y = p >> lw;
-    const int coefAbs = abs(coef[p]);
+    const int x = p & (w - 1), y = p >> lw;
     // Quantizer::preQuantCoeff :786-808
     dq_l4 pqDist = { 0, 0, 0, 0 }; dq_i4 pqAbs = { 0, 0, 0, 0 };
     {
@@ -1630,6 +1629,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   };
   auto abOf = [](uint2 ab, int t) { return (int)(((t < 2 ? ab.x : ab.y) >> ((t & 1) * 16)) & 0xFFFFu); };
   DqRecRegs R, Rn;
+  int pfPos[2] = { 0, 0 }, pfAbs[2] = { 0, 0 };
   Rn.dl = Rn.dh = Rn.start = 0; Rn.ab = make_uint2(0, 0); Rn.misc = 0; Rn.sel = make_uint4(0, 0, 0, 0);
 
   for (int scanIdx = maxFirst; scanIdx >= 0; scanIdx--)
@@ -1646,10 +1646,18 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     if (recPos == DQ_REC_N - 1 || scanIdx == maxFirst)                    // wave-uniform: the walk enters a group of positions
     {
       const int beg = sIdx & ~(DQ_REC_N - 1);
-#pragma unroll 1
-      for (int j = k; j < DQ_REC_N; j += 4) fillRec(beg + j);
+      static_assert(DQ_REC_N == 8, "two records per lane");
+      if (scanIdx == maxFirst)
+#pragma unroll
+        for (int j = 0; j < 2; j++) { pfPos[j] = scan[beg + k + 4 * j]; pfAbs[j] = abs(coef[pfPos[j]]); }
+#pragma unroll
+      for (int j = 0; j < 2; j++) fillRec(beg + k + 4 * j, pfPos[j], pfAbs[j]);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
       R = loadRec(recPos);
+      // the coefficients of the NEXT group are the one stream of a TU that comes from HBM: requested here, used eight steps later
+      const int nb = max(beg - DQ_REC_N, 0);
+#pragma unroll
+      for (int j = 0; j < 2; j++) { pfPos[j] = scan[nb + k + 4 * j]; pfAbs[j] = abs(coef[pfPos[j]]); }
     }
     else R = Rn;
     if (recPos != 0) Rn = loadRec(recPos - 1);                            // the next step's record is in flight during this one
@@ -1806,10 +1814,18 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
           {
             const int bx = nsx * 4, by = nsy * 4;
             const bool hasR = nsx + 1 < widthInSbb, hasB = nsy + 1 < heightInSbb;
-            uint4 LR = make_uint4(0, 0, 0, 0), LB = LR, LD = LR;
-            if (hasR) LR = *reinterpret_cast<const uint4*>(lev + (inv[by * w + bx + 4] & ~15));
-            if (hasB) LB = *reinterpret_cast<const uint4*>(lev + (inv[(by + 4) * w + bx] & ~15));
-            if (hasR && hasB) LD = *reinterpret_cast<const uint4*>(lev + (inv[(by + 4) * w + bx + 4] & ~15));
+            // read from the history this state inherits (what the copy above writes into its own slot: the loads need not wait for it)
+            const unsigned char* hist = ctxMem + (size_t)(curCtx * 4 + max(prevRef, 0)) * N;
+            // (the sub-block that just ended is not in it yet: its levels are still in C.lev)
+            const uint4 own = make_uint4(C.lev[0], C.lev[1], C.lev[2], C.lev[3]), zero4 = make_uint4(0, 0, 0, 0);
+            auto sbbLevels = [&](bool exists, int rasterPos)
+            {
+              if (!exists) return zero4;
+              const int base = inv[rasterPos] & ~15;
+              if (base == sIdx) return own;
+              return prevRef >= 0 ? *reinterpret_cast<const uint4*>(hist + base) : zero4;
+            };
+            const uint4 LR = sbbLevels(hasR, by * w + bx + 4), LB = sbbLevels(hasB, (by + 4) * w + bx), LD = sbbLevels(hasR && hasB, (by + 4) * w + bx + 4);
             auto pick = [](const uint4& v, int j) { const unsigned q = j < 4 ? v.x : j < 8 ? v.y : j < 12 ? v.z : v.w; return (q >> ((j & 3) * 8)) & 0xFFu; };
             // contribution of one neighbour level to (sumNum | sumAbs1 << 3 | sumAbs << 8): at most five are added, the fields do not carry
             auto cv = [](unsigned v) { return (v != 0u ? 1u : 0u) + (min(4u - (v & 1u), v) << 3) + (v << 8); };
