@@ -1414,13 +1414,13 @@ __device__ __forceinline__ int dq_level_bits(DqLdsRates rt, int gc, int goRice, 
   const unsigned idx = level < 5 ? level : 5 + ((level - 5) & 1);
   const int bits = rt->gtx[gc][idx];
   if (level < 5) return bits;
+  // escape part; the prefix loop of :924-929 ends at length = floor(log2(value - thres + 2^goRice))
   const unsigned value = (level - 5) >> 1;
   const unsigned range = goRice == 0 ? 6u : goRice == 1 ? 5u : goRice == 2 ? 6u : 3u;              // g_auiGoRiceRange
   const unsigned thres = range << goRice;
-  if (value < thres) return bits + (int)(((value >> goRice) + 1 + goRice) << 15);
-  unsigned length = goRice, delta = 1u << length, valLeft = value - thres;
-  while (valLeft >= delta) { valLeft -= delta; delta = 1u << (++length); }
-  return bits + (int)((range + 1 + (length << 1) - goRice) << 15);
+  const unsigned length = 31u - (unsigned)__clz((int)(value - thres + (1u << goRice)));
+  const unsigned esc = value < thres ? (value >> goRice) + 1 + goRice : range + 1 + (length << 1) - goRice;
+  return bits + (int)(esc << 15);
 }
 __device__ __forceinline__ long long dq_shfl64(long long v, int src) { return __shfl(v, src); }
 // quad permutation with a compile-time pattern (v_mov_b32 dpp quad_perm): no LDS round trip on the cost chain
@@ -1545,7 +1545,8 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   int maxFirst = run ? first : -1;
 #pragma unroll
   for (int m = 4; m < 64; m <<= 1) maxFirst = max(maxFirst, __shfl_xor(maxFirst, m));
-  if (maxFirst < 0) return;
+  maxFirst = __builtin_amdgcn_readfirstlane(maxFirst);                    // the walk's position is the same in every lane: keep it (and what
+  if (maxFirst < 0) return;                                               // derives from it) in scalar registers
 
   const int sigSet = max(k - 1, 0);                                       // RateEstimator::sigFlagBits(stateId) :282-285
   DqState P, S;                                                           // previous-position state k, skip state k
@@ -1555,6 +1556,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     P.lev = dq_u4{ 0, 0, 0, 0 }; P.aux = dq_u4{ 0, 0, 0, 0 }; P.gc = 0;
     dq_copy(S, P);
   }
+  DqState P0; dq_copy(P0, P);
   int curCtx = 0;                                                         // which half of the sub-block memory is "current"
   dq_u8 Fcur;                                                             // coded-sub-block flags (bit per sub-block) of context slot k, current half
 #pragma unroll
@@ -1642,6 +1644,14 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     const bool eocsbb = eosbb && sIdx > 0 && sIdx < N - 16;
     const int spt = socsbb ? 1 : (eocsbb ? 2 : 0);
     const int nxt = max(sIdx - 1, 0);
+    // a quad that is not active yet (scanIdx > first) computes along and its state is whatever that leaves: it starts from the
+    // initial state at its first tested position (instead of guarding every state copy of every step)
+    if (scanIdx == first)
+    {
+      dq_copy(P, P0); dq_copy(S, P0); curCtx = 0;
+#pragma unroll
+      for (int i = 0; i < 8; i++) Fcur[i] = 0;
+    }
     const int recPos = sIdx & (DQ_REC_N - 1);
     if (recPos == DQ_REC_N - 1 || scanIdx == maxFirst)                    // wave-uniform: the walk enters a group of positions
     {
@@ -1684,19 +1694,14 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
       // pq index of the transition a -> k and b -> k
       const int ia = k == 0 ? 0 : k == 2 ? 2 : k == 1 ? 3 : 1, ib = ia ^ 2;
       const int absA = abOf(R.ab, ia), absB = abOf(R.ab, ib);
-      const long long cA = k < 2 ? aLow : aHigh, cB = k < 2 ? bLow : bHigh;
-      if (k < 2)
-      {
-        if (cA < dCost) { dCost = cA; dAbs = absA; dPrev = a; }
-        if (aZero < dCost) { dCost = aZero; dAbs = 0; dPrev = a; }
-        if (cB < dCost) { dCost = cB; dAbs = absB; dPrev = b; }
-      }
-      else
-      {
-        if (cA < dCost) { dCost = cA; dAbs = absA; dPrev = a; }
-        if (cB < dCost) { dCost = cB; dAbs = absB; dPrev = b; }
-        if (bZero < dCost) { dCost = bZero; dAbs = 0; dPrev = b; }
-      }
+      // comparison order (strict '<'): k < 2: a, a's zero, b; k >= 2: a, b, b's zero -- as selects, the two orders share one code path
+      const bool lo = k < 2;
+      const long long cA = lo ? aLow : aHigh, cB = lo ? bLow : bHigh;
+      const long long c2 = lo ? aZero : cB, c3 = lo ? cB : bZero;
+      const int abs2 = lo ? 0 : absB, prev2 = lo ? a : b, abs3 = lo ? absB : 0;
+      if (cA < dCost) { dCost = cA; dAbs = absA; dPrev = a; }
+      if (c2 < dCost) { dCost = c2; dAbs = abs2; dPrev = prev2; }
+      if (c3 < dCost) { dCost = c3; dAbs = abs3; dPrev = b; }
       if (spt == 2) { const long long c = S.rdCost + S.sbb0; if (c < dCost) { dCost = c; dAbs = 0; dPrev = 4 + k; } }          // checkRdCostSkipSbb
       if ((k & 1) == 0 && R.start < dCost) { dCost = R.start; dAbs = abOf(R.ab, k); dPrev = -1; }                     // checkRdCostStart (decisions 0, 2)
     }
@@ -1798,11 +1803,8 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
 #pragma unroll
           for (int i = 1; i < 8; i++) { fr = (right >> 5) == i ? nf[i] : fr; fb = (below >> 5) == i ? nf[i] : fb; }
           const int sigNSbb = ((right && ((fr >> (right & 31)) & 1u)) || (below && ((fb >> (below & 31)) & 1u))) ? 1 : 0;
-          if (act)
-          {
 #pragma unroll
-            for (int i = 0; i < 8; i++) Fcur[i] = nf[i];
-          }
+          for (int i = 0; i < 8; i++) Fcur[i] = nf[i];
           C.numSigSbb = 0; C.refSbbCtxId = k;
           C.sbb0 = rt->sig_sbb[sigNSbb][0]; C.sbb1 = rt->sig_sbb[sigNSbb][1];
           // template seeds of the sixteen positions of the next sub-block from the levels outside it (:1131-1160).  Every template
@@ -1872,12 +1874,9 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
       }
       if (eosbb) { __threadfence_block(); }
     }
-    if (act)
-    {
-      if (sIdx > 0 && eosbb) curCtx ^= 1;
-      if (socsbb) dq_copy(S, P);                                           // swap( m_prevStates, m_skipStates ) :1314-1317
-      dq_copy(P, C);
-    }
+    if (sIdx > 0 && eosbb) curCtx ^= 1;
+    if (socsbb) dq_copy(S, P);                                             // swap( m_prevStates, m_skipStates ) :1314-1317
+    dq_copy(P, C);
   }
 
   // ---- best final state and back-trace :1368-1390.  Lane 0 of the quad walks; decisions 4..7 are implicit: at a sub-block end they
