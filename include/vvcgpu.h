@@ -431,6 +431,25 @@ typedef struct vvcgpu_afe_desc {
 int vvcgpu_affine_equal_coeff_batch(const vvc_pel* resi_base, const int32_t* derivx_base, const int32_t* derivy_base,
                                     const vvcgpu_afe_desc* descs, int n, int64_t* out, void* stream);
 
+/* One iteration of the affine gradient search behind its prediction (the loop body of InterSearch::xAffineMotionEstimation, InterSearch.cpp:3456-3534:
+ * xPredAffineBlk with the current control-point vectors, error = org - pred, the two Sobel planes, the normal-equation sums, and the distortion of
+ * that prediction for the cost check) in one call: sub-block vectors (as vvcgpu_affine_subblock_descs, luma, list 0 only: pu.bi must be 0), the
+ * sub-block prediction (as vvcgpu_mc_batch, left in pred_base at pu.dst_off / pu.dst_stride), then ONE pass over the PU that writes neither a
+ * residue nor a derivative plane.  PUs: both sides 16..128 (AFFINE_MIN_BLOCK_SIZE sub-blocks of 4x4).  For a bi-predictive search org_base holds the
+ * caller's "2 org - other prediction" block, as in the reference.  pu.first_desc: index of the PU's first sub-block in subblock_ws (n_subblocks
+ * entries = sum of (w / 4) (h / 4), device memory the call may overwrite).  coeff_out: n x 7 x 7 int64 as vvcgpu_affine_equal_coeff_batch;
+ * dist_out (may be NULL): n x uint64, dist_kind 0 SAD / 1 Hadamard (what xAffineMotionEstimation's cost uses) of org against the prediction.
+ * The caller solves the 4 x 4 / 6 x 6 system and updates the vectors on the host (double arithmetic, InterSearch.cpp:3536-3600).                    */
+typedef struct vvcgpu_affine_iter {
+  vvcgpu_affine_pu pu;
+  int64_t org_off;                      /* elements from org_base */
+  int32_t org_stride, reserved;         /* sizeof == 96 */
+} vvcgpu_affine_iter;
+int vvcgpu_affine_me_iter_batch(const vvc_pel* org_base, const vvc_pel* ref_base, vvc_pel* pred_base, const vvcgpu_affine_iter* items, int n,
+                                int n_subblocks, vvcgpu_mc_desc* subblock_ws, int dist_kind, int pic_w, int pic_h, int max_cu_w, int max_cu_h,
+                                int ref_origin_x, int ref_origin_y, int ref_stride, int bit_depth, int clp_min, int clp_max, int64_t* coeff_out,
+                                uint64_t* dist_out, void* stream);
+
 /* ---- N2 ("next" row): integer-sample TZ search of whole PUs, on the device  (InterSearch::xTZSearch,
  *          EncoderLib/InterSearch.cpp:1971-2252, with xTZSearchHelp :249-343, xTZ2PointSearch :349-374,
  *          xTZ8PointDiamondSearch :431-632, xSetSearchRange :1820-1883, clipMv CommonLib/Mv.cpp:64-80) -----------------

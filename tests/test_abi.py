@@ -55,7 +55,7 @@ def test_struct_layouts_match_python_bindings():
             8: ops.PELOP_DESC.itemsize, 9: C.sizeof(ops.PelopCfg), 10: ops.TR_DESC.itemsize, 13: ops.DQTR_DESC.itemsize, 14: ops.AFG_DESC.itemsize, 15: ops.AFE_DESC.itemsize,
             11: ops.FRAC_BLK.itemsize, 12: ops.FRAC_RESULT.itemsize, 16: ops.TZ_PU.itemsize, 17: ops.TZ_CFG.itemsize, 18: ops.INTRA_DESC.itemsize,
             19: ops.CCLM_DESC.itemsize, 20: ops.INTRA_FILL_DESC.itemsize, 21: ops.IMV_PU.itemsize, 22: ops.IMV_RESULT.itemsize, 23: ops.QUANT_DESC.itemsize, 24: ops.DQ_RATES.itemsize, 25: ops.DEPQUANT_DESC.itemsize,
-            26: ops.RDOQ_RATES.itemsize, 27: ops.RDOQ_DESC.itemsize, 28: ops.INTRA_SATD_DESC.itemsize}
+            26: ops.RDOQ_RATES.itemsize, 27: ops.RDOQ_DESC.itemsize, 28: ops.INTRA_SATD_DESC.itemsize, 29: ops.AFFINE_ITER.itemsize}
     for k, v in want.items():
         assert lib.vvcgpu_sizeof(k) == v, (k, lib.vvcgpu_sizeof(k), v)
     assert lib.vvcgpu_sizeof(99) == -1
@@ -77,6 +77,7 @@ def test_next_row_entry_points_validate_arguments_without_a_device():
         "vvcgpu_rdoq_batch": lambda n: lib.vvcgpu_rdoq_batch(nul, nul, nul, n, nul, 10, nul, C.c_size_t(0), nul, C.c_size_t(0), nul),
         "vvcgpu_affine_sobel_batch": lambda n: lib.vvcgpu_affine_sobel_batch(0, nul, nul, nul, n, nul),
         "vvcgpu_affine_equal_coeff_batch": lambda n: lib.vvcgpu_affine_equal_coeff_batch(nul, nul, nul, nul, n, nul, nul),
+        "vvcgpu_affine_me_iter_batch": lambda n: lib.vvcgpu_affine_me_iter_batch(nul, nul, nul, nul, n, n, nul, 1, 64, 64, 128, 128, 0, 0, 64, 10, 0, 1023, nul, nul, nul),
         "vvcgpu_intra_pred_batch": lambda n: lib.vvcgpu_intra_pred_batch(nul, nul, nul, n, 0, 1023, nul),
         "vvcgpu_mc_dist_batch": lambda n: lib.vvcgpu_mc_dist_batch(0, nul, nul, nul, nul, n, 10, 0, 1023, nul, nul),
         "vvcgpu_intra_satd_batch": lambda n: lib.vvcgpu_intra_satd_batch(nul, nul, nul, n, 0, 1023, nul, nul),

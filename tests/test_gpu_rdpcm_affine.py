@@ -107,3 +107,60 @@ def test_affine_subblock_vectors_golden():
             n = (w >> c) * (h >> c)
             assert np.array_equal(got[o:o + n], g["pred"][base:base + n]), (i, comp)
             o += n
+
+
+def test_affine_me_iteration_fused():
+    """vvcgpu_affine_me_iter_batch (sub-block vectors -> prediction -> error, Sobel planes, equation sums and distortion in one pass) against the
+    oracle's chain of the same steps: orc_affine_subblock_descs -> orc_mc_batch -> org - pred -> orc_affine_sobel_batch x2 ->
+    orc_affine_equal_coeff_batch, orc_dist_batch.  PUs and control-point vectors of the reference's own affine fixture, 4- and 6-parameter."""
+    from vvcsoftware_vtm_amd import ops
+    g = np.load(os.path.join(G, "affine_mv.npz"))
+    W, H, bd, M = 256, 128, 10, 144
+    ref = np.ascontiguousarray(np.pad(g["Y"], M, mode="edge"))
+    rng = np.random.default_rng(5)
+    org = np.clip(g["Y"].astype(np.int32) + rng.integers(-40, 41, g["Y"].shape), 0, 1023).astype(np.int16)
+    org[:, 128:] = (2 * org[:, 128:].astype(np.int32) - rng.integers(0, 1024, org[:, 128:].shape)).astype(np.int16)   # "2 org - other prediction" blocks
+    rows = [r for r in g["rows"] if r[2] >= 16 and r[3] >= 16]
+    assert len(rows) >= 8 and any(r[4] for r in rows) and not all(r[4] for r in rows)
+    for kind in (1, 0):
+        items = np.zeros(len(rows), ops.AFFINE_ITER)
+        first, dst_off = 0, 0
+        for i, r in enumerate(rows):
+            px, py, w, h, six = (int(v) for v in r[:5])
+            mv = np.zeros((2, 3, 2), np.int32); mv[0] = r[5:11].reshape(3, 2)
+            items[i]["pu"] = (px, py, w, h, six, 0, mv, dst_off, w, first)
+            items[i]["org_off"], items[i]["org_stride"] = py * W + px, W
+            first += (w // 4) * (h // 4)
+            dst_off += w * h
+        # oracle chain
+        pus = np.ascontiguousarray(items["pu"])
+        wd = np.zeros(first, ops.MC_DESC)
+        oracle().orc_affine_subblock_descs(p(pus), len(rows), 0, W, H, 128, 128, M, M, ref.shape[1], ref.shape[1], p(wd))
+        wpred = np.zeros(dst_off, np.int16)
+        oracle().orc_mc_batch(p(ref), p(ref), p(wpred), p(wd), int(first), bd, 0, 1023)
+        resi = np.zeros(dst_off, np.int16)
+        gd, ed, dd = [], [], []
+        for it in items:
+            w, h, o = int(it["pu"]["w"]), int(it["pu"]["h"]), int(it["pu"]["dst_off"])
+            y, x = divmod(int(it["org_off"]), W)
+            resi[o:o + w * h] = (org[y:y + h, x:x + w].astype(np.int32) - wpred[o:o + w * h].reshape(h, w)).astype(np.int16).reshape(-1)
+            gd.append((o, o, w, w, w, h, 0)); ed.append((o, o, w, w, h, int(it["pu"]["six_param"]), 0))
+            dd.append((int(it["org_off"]), o, W, w, w, h, 0, 0))
+        gd, ed, dd = np.array(gd, dtype=ops.AFG_DESC), np.array(ed, dtype=ops.AFE_DESC), np.array(dd, dtype=ops.DIST_DESC)
+        wx = np.zeros(dst_off, np.int32); wy = np.zeros(dst_off, np.int32)
+        oracle().orc_affine_sobel_batch(0, p(wpred), p(wx), p(gd), len(gd))
+        oracle().orc_affine_sobel_batch(1, p(wpred), p(wy), p(gd), len(gd))
+        wcoef = np.zeros((len(ed), 49), np.int64)
+        oracle().orc_affine_equal_coeff_batch(p(resi), p(wx), p(wy), p(ed), len(ed), p(wcoef))
+        wdist = np.zeros(len(dd), np.uint64)
+        oracle().orc_dist_batch(kind, p(org), p(wpred), p(dd), len(dd), p(wdist))
+        # device
+        pred = torch.zeros(dst_off, dtype=torch.int16, device="cuda")
+        coef, dist = ops.affine_me_iter_batch(dev(org), dev(ref), pred, ops.struct_to_device(items), len(rows), int(first), kind, W, H, (M, M),
+                                              ref.shape[1], bd, (0, 1023))
+        assert np.array_equal(pred.cpu().numpy(), wpred)
+        assert np.array_equal(coef.cpu().numpy().reshape(len(rows), 49), wcoef)
+        assert np.array_equal(dist.cpu().numpy().view(np.uint64), wdist), kind
+    coef2, none = ops.affine_me_iter_batch(dev(org), dev(ref), pred, ops.struct_to_device(items), len(rows), int(first), 0, W, H, (M, M), ref.shape[1],
+                                           bd, (0, 1023), want_dist=False)
+    assert none is None and np.array_equal(coef2.cpu().numpy().reshape(len(rows), 49), wcoef)

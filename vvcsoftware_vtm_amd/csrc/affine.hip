@@ -8,6 +8,7 @@
 // the reference's ring-copy rules amount to), so the ring needs no second pass.  Equal coefficients: every lane walks its
 // share of the block with the <= 6 x 7 sums in 64-bit registers, then one transposed wave reduction (63 shuffles for all sums).
 #include "common.h"
+#include "dist_dev.h"
 
 namespace {
 
@@ -117,13 +118,13 @@ __global__ __launch_bounds__(256) void affine_equal_coeff_kernel(const Pel* __re
 }
 
 // ---- affine sub-block motion vectors: the derivation loop of InterPrediction::xPredAffineBlk (InterPrediction.cpp:618-701) per sub-block, both lists
-__global__ __launch_bounds__(256) void affine_subblock_descs_kernel(const vvcgpu_affine_pu* __restrict__ pus, int n, int comp, int picW, int picH,
+__global__ __launch_bounds__(256) void affine_subblock_descs_kernel(const vvcgpu_affine_pu* __restrict__ pus, int puBytes, int n, int comp, int picW, int picH,
                                                                     int maxCuW, int maxCuH, int orgX, int orgY, int rs0, int rs1,
                                                                     vvcgpu_mc_desc* __restrict__ out)
 {
   const int pi = blockIdx.x;
   if (pi >= n) return;
-  const vvcgpu_affine_pu pu = pus[pi];
+  const vvcgpu_affine_pu pu = *reinterpret_cast<const vvcgpu_affine_pu*>(reinterpret_cast<const char*>(pus) + (size_t)pi * puBytes);   // puBytes: array stride
   const int sc = comp ? 1 : 0;                                          // 4:2:0 component scale
   const int bw = 4 >> sc, bh = 4 >> sc;                                  // AFFINE_MIN_BLOCK_SIZE, scaled (:585-586, :619-620)
   const int cxW = pu.w >> sc, cxH = pu.h >> sc;
@@ -164,6 +165,95 @@ __global__ __launch_bounds__(256) void affine_subblock_descs_kernel(const vvcgpu
   }
 }
 
+// ---- one iteration of the affine gradient search (InterSearch::xAffineMotionEstimation, InterSearch.cpp:3456-3534) behind its prediction: error,
+// both Sobel planes and the normal-equation sums in ONE pass over the PU, plus the distortion of the prediction the next cost check needs.
+// One workgroup per PU: the prediction is staged in LDS once; a sample's two derivatives come from the same eight neighbours (nearest interior
+// position, as affine_sobel_kernel), no derivative plane and no residue plane is written.
+constexpr int AFI_MAX = 128;
+typedef const __attribute__((address_space(3))) Pel* AfiLdsPel;
+
+template <int P>
+__device__ __forceinline__ void afi_equations(const vvcgpu_affine_iter& d, const Pel* __restrict__ org, const Pel* predL, int w, int h, long long* out,
+                                              long long (*red)[64], int tid)
+{
+  const int lane = tid & 63, wave = tid >> 6;
+  long long acc[P][P + 1];
+#pragma unroll
+  for (int c = 0; c < P; c++)
+#pragma unroll
+    for (int r = 0; r <= P; r++) acc[c][r] = 0;
+  for (int i = tid; i < w * h; i += 256)
+  {
+    const int j = i / w, k = i - j * w;
+    const int yy = min(max(j, 1), h - 2), xx = min(max(k, 1), w - 2);
+    const Pel* c = predL + yy * w + xx;
+    const int x = c[1 - w] - c[-1 - w] + (c[1] << 1) - (c[-1] << 1) + c[1 + w] - c[-1 + w];
+    const int y = c[w - 1] - c[-w - 1] + (c[w] << 1) - (c[-w] << 1) + c[w + 1] - c[-w + 1];
+    int iC[P];
+    if (P == 4) { iC[0] = x; iC[1] = k * x + j * y; iC[2] = y; iC[3] = j * x - k * y; }
+    else        { iC[0] = x; iC[1] = k * x; iC[2] = y; iC[3] = k * y; iC[4] = j * x; iC[5] = j * y; }
+    const long long r = (long long)(Pel)((int)org[(size_t)j * d.org_stride + k] - (int)predL[j * w + k]);      // the error block is a Pel block
+#pragma unroll
+    for (int col = 0; col < P; col++)
+    {
+#pragma unroll
+      for (int row = 0; row < P; row++) acc[col][row] += (long long)iC[col] * iC[row];
+      acc[col][P] += ((long long)iC[col] * r) << 3;
+    }
+  }
+  constexpr int M = P == 6 ? 64 : 32;
+  long long v[M];
+#pragma unroll
+  for (int i = 0; i < M; i++) v[i] = i < P * (P + 1) ? acc[i / (P + 1)][i % (P + 1)] : 0;
+  red[wave][lane] = wave_transpose_sum<M>(v, lane);             // lane L: this wave's sum of value L
+  __syncthreads();
+  if (tid < 49)
+  {
+    const int row7 = tid / 7, col7 = tid - row7 * 7;
+    const bool used = row7 >= 1 && row7 <= P && col7 <= P;
+    const int src = used ? (row7 - 1) * (P + 1) + col7 : 0;
+    out[tid] = used ? red[0][src] + red[1][src] + red[2][src] + red[3][src] : 0;
+  }
+}
+
+__global__ __launch_bounds__(256) void affine_iter_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase,
+                                                          const vvcgpu_affine_iter* __restrict__ items, int n, int distKind,
+                                                          long long* __restrict__ coeffOut, unsigned long long* __restrict__ distOut)
+{
+  __shared__ __align__(16) Pel predL[AFI_MAX * AFI_MAX];
+  __shared__ long long red[4][64];
+  __shared__ unsigned long long distW[4];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const vvcgpu_affine_iter d = items[blockIdx.x];
+  const int w = d.pu.w, h = d.pu.h;
+  const Pel* org = orgBase + d.org_off;
+  const Pel* pred = predBase + d.pu.dst_off;
+  for (int i = tid; i < w * h; i += 256) { const int j = i / w, k = i - j * w; predL[i] = pred[(size_t)j * d.pu.dst_stride + k]; }
+  __syncthreads();
+  if (distOut)
+  {
+    // bands of sixteen rows: every Hadamard tile of an affine PU (both sides >= 16) is at most sixteen rows high, the tile shape is the whole PU's
+    unsigned long long sum = 0;
+    for (int b = wave; b * 16 < h; b += 4)
+    {
+      const Pel* o = org + (size_t)b * 16 * d.org_stride;
+      AfiLdsPel c = (AfiLdsPel)predL + b * 16 * w;
+      if (distKind == 1) sum += satd_block<64, AfiLdsPel>(o, d.org_stride, c, w, w, 16, lane, 0, h);
+      else
+      {
+        unsigned s = 0;
+        for (int i = lane; i < 16 * w; i += 64) { const int j = i / w, k = i - j * w; s += (unsigned)abs((int)o[(size_t)j * d.org_stride + k] - (int)c[j * w + k]); }
+        sum += wave_sum_u64(s);
+      }
+    }
+    if (lane == 0) distW[wave] = sum;
+  }
+  long long* out = coeffOut + (size_t)blockIdx.x * 49;
+  if (d.pu.six_param) afi_equations<6>(d, org, predL, w, h, out, red, tid);
+  else                afi_equations<4>(d, org, predL, w, h, out, red, tid);
+  if (distOut && tid == 0) distOut[blockIdx.x] = distW[0] + distW[1] + distW[2] + distW[3];       // behind the barrier of afi_equations
+}
+
 }  // namespace
 
 extern "C" {
@@ -199,8 +289,32 @@ int vvcgpu_affine_subblock_descs(const vvcgpu_affine_pu* pus, int n, int comp, i
   VVC_CHECK_ARG(pus && out, "affine_subblock_descs: null pointer");
   VVC_CHECK_ARG(comp == 0 || comp == 1, "affine_subblock_descs: comp %d", comp);
   VVC_CHECK_ARG(pic_w > 0 && pic_h > 0 && max_cu_w > 0 && max_cu_h > 0 && ref0_stride > 0 && ref1_stride > 0, "affine_subblock_descs: geometry");
-  hipLaunchKernelGGL(affine_subblock_descs_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, pus, n, comp, pic_w, pic_h, max_cu_w, max_cu_h,
+  hipLaunchKernelGGL(affine_subblock_descs_kernel, dim3(n), dim3(256), 0, (hipStream_t)stream, pus, (int)sizeof(vvcgpu_affine_pu), n, comp, pic_w, pic_h, max_cu_w, max_cu_h,
                      ref_origin_x, ref_origin_y, ref0_stride, ref1_stride, out);
+  VVC_LAUNCH_CHECK();
+  return VVCGPU_OK;
+}
+
+int vvcgpu_affine_me_iter_batch(const vvc_pel* org_base, const vvc_pel* ref_base, vvc_pel* pred_base, const vvcgpu_affine_iter* items, int n,
+                                int n_subblocks, vvcgpu_mc_desc* subblock_ws, int dist_kind, int pic_w, int pic_h, int max_cu_w, int max_cu_h,
+                                int ref_origin_x, int ref_origin_y, int ref_stride, int bit_depth, int clp_min, int clp_max, int64_t* coeff_out,
+                                uint64_t* dist_out, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "affine_me_iter_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(org_base && ref_base && pred_base && items && subblock_ws && coeff_out, "affine_me_iter_batch: null pointer");
+  VVC_CHECK_ARG(n_subblocks >= n, "affine_me_iter_batch: n_subblocks %d for %d PUs", n_subblocks, n);
+  VVC_CHECK_ARG(dist_kind == 0 || dist_kind == 1, "affine_me_iter_batch: dist_kind %d (0 SAD, 1 Hadamard)", dist_kind);
+  VVC_CHECK_ARG(pic_w > 0 && pic_h > 0 && max_cu_w > 0 && max_cu_h > 0 && ref_stride > 0, "affine_me_iter_batch: geometry");
+  hipStream_t st = (hipStream_t)stream;
+  // sub-block vectors -> sub-block prediction (the entry points a caller would chain itself) -> everything that reads the prediction, fused
+  hipLaunchKernelGGL(affine_subblock_descs_kernel, dim3(n), dim3(256), 0, st, reinterpret_cast<const vvcgpu_affine_pu*>(items), (int)sizeof(vvcgpu_affine_iter),
+                     n, 0, pic_w, pic_h, max_cu_w, max_cu_h, ref_origin_x, ref_origin_y, ref_stride, ref_stride, subblock_ws);
+  VVC_LAUNCH_CHECK();
+  const int rc = vvcgpu_mc_batch(ref_base, ref_base, pred_base, subblock_ws, n_subblocks, bit_depth, clp_min, clp_max, stream);
+  if (rc != VVCGPU_OK) return rc;
+  hipLaunchKernelGGL(affine_iter_kernel, dim3(n), dim3(256), 0, st, org_base, pred_base, items, n, dist_kind, reinterpret_cast<long long*>(coeff_out),
+                     reinterpret_cast<unsigned long long*>(dist_out));
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

@@ -156,6 +156,7 @@ int vvcgpu_sizeof(int id)
   case 26: return (int)sizeof(vvcgpu_rdoq_rates);
   case 27: return (int)sizeof(vvcgpu_rdoq_desc);
   case 28: return (int)sizeof(vvcgpu_intra_satd_desc);
+  case 29: return (int)sizeof(vvcgpu_affine_iter);
   default: return -1;
   }
 }

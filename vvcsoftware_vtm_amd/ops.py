@@ -540,6 +540,23 @@ def rdpcm_inv_batch(resi_base, descs_dev, n):
     capi.call("vvcgpu_rdpcm_inv_batch", capi.ptr(resi_base), capi.ptr(descs_dev), n, _stream())
 
 
+AFFINE_ITER = np.dtype([("pu", AFFINE_PU), ("org_off", "<i8"), ("org_stride", "<i4"), ("reserved", "<i4")])
+assert AFFINE_ITER.itemsize == 96
+
+
+def affine_me_iter_batch(org_base, ref_base, pred_base, items_dev, n, n_subblocks, dist_kind, pic_w, pic_h, ref_origin, ref_stride,
+                         bit_depth=10, clp=(0, 1023), max_cu=128, want_dist=True):
+    """one iteration of the affine gradient search behind its prediction (loop body of xAffineMotionEstimation): the prediction is left in
+    pred_base; -> (equation sums int64 [n, 7, 7], distortion int64 [n] or None)"""
+    ws = torch.empty(n_subblocks * MC_DESC.itemsize, dtype=torch.uint8, device=org_base.device)
+    coeff = torch.empty((n, 7, 7), dtype=torch.int64, device=org_base.device)
+    dist = torch.empty(n, dtype=torch.int64, device=org_base.device) if want_dist else None
+    capi.call("vvcgpu_affine_me_iter_batch", capi.ptr(org_base), capi.ptr(ref_base), capi.ptr(pred_base), capi.ptr(items_dev), n, n_subblocks,
+              capi.ptr(ws), dist_kind, pic_w, pic_h, max_cu, max_cu, ref_origin[0], ref_origin[1], ref_stride, bit_depth, clp[0], clp[1],
+              capi.ptr(coeff), capi.ptr(dist) if want_dist else None, _stream())
+    return coeff, dist
+
+
 def affine_subblock_descs(pus_dev, n, n_descs, comp, pic_w, pic_h, ref_origin, ref0_stride, ref1_stride, max_cu=128):
     """sub-block MC descriptors (uint8 tensor of n_descs vvcgpu_mc_desc) of n affine PUs, on the device"""
     out = torch.zeros(n_descs * MC_DESC.itemsize, dtype=torch.uint8, device=pus_dev.device)
