@@ -169,10 +169,11 @@ __global__ __launch_bounds__(256) void affine_subblock_descs_kernel(const vvcgpu
 // both Sobel planes and the normal-equation sums in ONE pass over the PU, plus the distortion of the prediction the next cost check needs.
 // One workgroup per PU: the prediction is staged in LDS once; a sample's two derivatives come from the same eight neighbours (nearest interior
 // position, as affine_sobel_kernel), no derivative plane and no residue plane is written.
-constexpr int AFI_MAX = 128;
+constexpr int AFI_MAX = 128, AFI_WAVE_MAX = 1024;          // PUs of up to AFI_WAVE_MAX samples are served by one wavefront each, larger ones by a workgroup
 typedef const __attribute__((address_space(3))) Pel* AfiLdsPel;
 
-template <int P>
+// NT = 64: the wavefront owns the PU; NT = 256: the four wavefronts of the workgroup share it and their sums meet in `red`
+template <int P, int NT>
 __device__ __forceinline__ void afi_equations(const vvcgpu_affine_iter& d, const Pel* __restrict__ org, const Pel* predL, int w, int h, long long* out,
                                               long long (*red)[64], int tid)
 {
@@ -182,7 +183,7 @@ __device__ __forceinline__ void afi_equations(const vvcgpu_affine_iter& d, const
   for (int c = 0; c < P; c++)
 #pragma unroll
     for (int r = 0; r <= P; r++) acc[c][r] = 0;
-  for (int i = tid; i < w * h; i += 256)
+  for (int i = tid; i < w * h; i += NT)
   {
     const int j = i / w, k = i - j * w;
     const int yy = min(max(j, 1), h - 2), xx = min(max(k, 1), w - 2);
@@ -205,17 +206,45 @@ __device__ __forceinline__ void afi_equations(const vvcgpu_affine_iter& d, const
   long long v[M];
 #pragma unroll
   for (int i = 0; i < M; i++) v[i] = i < P * (P + 1) ? acc[i / (P + 1)][i % (P + 1)] : 0;
-  red[wave][lane] = wave_transpose_sum<M>(v, lane);             // lane L: this wave's sum of value L
-  __syncthreads();
-  if (tid < 49)
+  const long long total = wave_transpose_sum<M>(v, lane);       // lane L: this wave's sum of value L
+  const int row7 = lane / 7, col7 = lane - row7 * 7;
+  const bool used = row7 >= 1 && row7 <= P && col7 <= P;
+  const int src = used ? (row7 - 1) * (P + 1) + col7 : 0;
+  if (NT == 64)
   {
-    const int row7 = tid / 7, col7 = tid - row7 * 7;
-    const bool used = row7 >= 1 && row7 <= P && col7 <= P;
-    const int src = used ? (row7 - 1) * (P + 1) + col7 : 0;
-    out[tid] = used ? red[0][src] + red[1][src] + red[2][src] + red[3][src] : 0;
+    const long long val = __shfl(total, src & 63);
+    if (lane < 49) out[lane] = used ? val : 0;
+  }
+  else
+  {
+    red[wave][lane] = total;
+    __syncthreads();
+    if (tid < 49) out[tid] = used ? red[0][src] + red[1][src] + red[2][src] + red[3][src] : 0;
   }
 }
 
+// distortion of rows [r0, r1) x 16 of the PU against the prediction in LDS, by one wavefront
+__device__ __forceinline__ unsigned long long afi_dist(const vvcgpu_affine_iter& d, const Pel* __restrict__ org, const Pel* predL, int w, int h,
+                                                       int distKind, int band0, int bandStep, int lane)
+{
+  // bands of sixteen rows: every Hadamard tile of an affine PU (both sides >= 16) is at most sixteen rows high, the tile shape is the whole PU's
+  unsigned long long sum = 0;
+  for (int b = band0; b * 16 < h; b += bandStep)
+  {
+    const Pel* o = org + (size_t)b * 16 * d.org_stride;
+    AfiLdsPel c = (AfiLdsPel)predL + b * 16 * w;
+    if (distKind == 1) sum += satd_block<64, AfiLdsPel>(o, d.org_stride, c, w, w, 16, lane, 0, h);
+    else
+    {
+      unsigned s = 0;
+      for (int i = lane; i < 16 * w; i += 64) { const int j = i / w, k = i - j * w; s += (unsigned)abs((int)o[(size_t)j * d.org_stride + k] - (int)c[j * w + k]); }
+      sum += wave_sum_u64(s);
+    }
+  }
+  return sum;
+}
+
+// PUs of more than AFI_WAVE_MAX samples: one workgroup each (the others leave at once)
 __global__ __launch_bounds__(256) void affine_iter_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase,
                                                           const vvcgpu_affine_iter* __restrict__ items, int n, int distKind,
                                                           long long* __restrict__ coeffOut, unsigned long long* __restrict__ distOut)
@@ -226,32 +255,47 @@ __global__ __launch_bounds__(256) void affine_iter_kernel(const Pel* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const vvcgpu_affine_iter d = items[blockIdx.x];
   const int w = d.pu.w, h = d.pu.h;
+  if (w * h <= AFI_WAVE_MAX) return;
   const Pel* org = orgBase + d.org_off;
   const Pel* pred = predBase + d.pu.dst_off;
   for (int i = tid; i < w * h; i += 256) { const int j = i / w, k = i - j * w; predL[i] = pred[(size_t)j * d.pu.dst_stride + k]; }
   __syncthreads();
   if (distOut)
   {
-    // bands of sixteen rows: every Hadamard tile of an affine PU (both sides >= 16) is at most sixteen rows high, the tile shape is the whole PU's
-    unsigned long long sum = 0;
-    for (int b = wave; b * 16 < h; b += 4)
-    {
-      const Pel* o = org + (size_t)b * 16 * d.org_stride;
-      AfiLdsPel c = (AfiLdsPel)predL + b * 16 * w;
-      if (distKind == 1) sum += satd_block<64, AfiLdsPel>(o, d.org_stride, c, w, w, 16, lane, 0, h);
-      else
-      {
-        unsigned s = 0;
-        for (int i = lane; i < 16 * w; i += 64) { const int j = i / w, k = i - j * w; s += (unsigned)abs((int)o[(size_t)j * d.org_stride + k] - (int)c[j * w + k]); }
-        sum += wave_sum_u64(s);
-      }
-    }
+    const unsigned long long sum = afi_dist(d, org, predL, w, h, distKind, wave, 4, lane);
     if (lane == 0) distW[wave] = sum;
   }
   long long* out = coeffOut + (size_t)blockIdx.x * 49;
-  if (d.pu.six_param) afi_equations<6>(d, org, predL, w, h, out, red, tid);
-  else                afi_equations<4>(d, org, predL, w, h, out, red, tid);
+  if (d.pu.six_param) afi_equations<6, 256>(d, org, predL, w, h, out, red, tid);
+  else                afi_equations<4, 256>(d, org, predL, w, h, out, red, tid);
   if (distOut && tid == 0) distOut[blockIdx.x] = distW[0] + distW[1] + distW[2] + distW[3];       // behind the barrier of afi_equations
+}
+
+// the small PUs: one wavefront each, four per workgroup
+__global__ __launch_bounds__(256) void affine_iter_small_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase,
+                                                                const vvcgpu_affine_iter* __restrict__ items, int n, int distKind,
+                                                                long long* __restrict__ coeffOut, unsigned long long* __restrict__ distOut)
+{
+  __shared__ __align__(16) Pel predAll[4][AFI_WAVE_MAX];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int b = blockIdx.x * 4 + wave;
+  if (b >= n) return;
+  const vvcgpu_affine_iter d = items[b];
+  const int w = d.pu.w, h = d.pu.h;
+  if (w * h > AFI_WAVE_MAX) return;
+  Pel* predL = predAll[wave];
+  const Pel* org = orgBase + d.org_off;
+  const Pel* pred = predBase + d.pu.dst_off;
+  for (int i = lane; i < w * h; i += 64) { const int j = i / w, k = i - j * w; predL[i] = pred[(size_t)j * d.pu.dst_stride + k]; }
+  __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
+  if (distOut)
+  {
+    const unsigned long long sum = afi_dist(d, org, predL, w, h, distKind, 0, 1, lane);
+    if (lane == 0) distOut[b] = sum;
+  }
+  long long* out = coeffOut + (size_t)b * 49;
+  if (d.pu.six_param) afi_equations<6, 64>(d, org, predL, w, h, out, nullptr, lane);
+  else                afi_equations<4, 64>(d, org, predL, w, h, out, nullptr, lane);
 }
 
 }  // namespace
@@ -313,6 +357,9 @@ int vvcgpu_affine_me_iter_batch(const vvc_pel* org_base, const vvc_pel* ref_base
   VVC_LAUNCH_CHECK();
   const int rc = vvcgpu_mc_batch(ref_base, ref_base, pred_base, subblock_ws, n_subblocks, bit_depth, clp_min, clp_max, stream);
   if (rc != VVCGPU_OK) return rc;
+  // every PU is served by exactly one of the two: by size, which only the device knows
+  hipLaunchKernelGGL(affine_iter_small_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, org_base, pred_base, items, n, dist_kind,
+                     reinterpret_cast<long long*>(coeff_out), reinterpret_cast<unsigned long long*>(dist_out));
   hipLaunchKernelGGL(affine_iter_kernel, dim3(n), dim3(256), 0, st, org_base, pred_base, items, n, dist_kind, reinterpret_cast<long long*>(coeff_out),
                      reinterpret_cast<unsigned long long*>(dist_out));
   VVC_LAUNCH_CHECK();

@@ -412,12 +412,10 @@ __device__ __forceinline__ void mc_tile_dot2(const vvcgpu_mc_desc& d, bool activ
 constexpr int MC_LDS_DW = 23 * 12 + 16 * 12 + 128;                       // per wave: window, transposed intermediate, output rows (luma sizes)
 __global__ __launch_bounds__(256, 6) void mc_fast_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
                                                       Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs, int n,
-                                                      int bd, int cmin, int cmax, int* __restrict__ list, int* __restrict__ count,
-                                                      int* __restrict__ nextCount, int nWg, int xcd)
+                                                      int bd, int cmin, int cmax, int nWg, int xcd)
 {
   __shared__ __align__(16) unsigned ldsAll[4][MC_LDS_DW];
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  if (blockIdx.x == 0 && threadIdx.x < 16) nextCount[threadIdx.x] = 0;   // the WHOLE counter set of the next call on this stream (vvcgpu_counters protocol)
   const int wg = vvc_xcd_index((int)blockIdx.x, nWg, xcd);           // neighbouring PUs (shared window lines) in one XCD's L2
   if (wg < 0) return;
   const int i0 = (wg * 4 + wave) * 2;
@@ -452,12 +450,7 @@ __global__ __launch_bounds__(256, 6) void mc_fast_kernel(const Pel* __restrict__
   {
     if (k && !two) break;
     const vvcgpu_mc_desc& d = k ? d1 : d0;
-    if (!(k ? f1 : f0))
-    {
-      // left to the generic kernel behind this one: list[0] = count, list[1..] = descriptor indices (no atomic at all when every PU is fast)
-      if (lane == 0) list[atomicAdd(count, 1)] = i0 + k;
-      continue;
-    }
+    if (!(k ? f1 : f0)) continue;                                        // left to the generic kernel behind this one (it applies the same test)
     if (d.is_luma)
     {
       McStaged<8, 16, 64> st;
@@ -479,7 +472,7 @@ __global__ __launch_bounds__(256, 6) void mc_fast_kernel(const Pel* __restrict__
 template <bool DIST>
 __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
                                                       Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs,
-                                                      const int* __restrict__ list, const int* __restrict__ count, int bd, int cmin, int cmax,
+                                                      int bd, int cmin, int cmax,
                                                       int nDirect, int distKind, const Pel* __restrict__ orgBase, unsigned long long* __restrict__ out)
 {
   __shared__ short win[WR * WP];
@@ -487,10 +480,27 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
   __shared__ __align__(16) short predT[DIST ? 128 * 128 : 8];
   __shared__ __align__(16) unsigned tileL[DIST ? 4 : MC_LDS_DW];
   const int lane = threadIdx.x;
-  const int cnt = list ? *count : nDirect;
-  for (int li = blockIdx.x; li < cnt; li += gridDim.x)
+  // !DIST: a wave looks at 64 descriptors at a time, one per lane, and serves those the fast kernel leaves.  (A list of them filled by the fast
+  // kernel cost one same-address atomic per PU: 6 of the 7 ms of an affine prediction of 518 k 4x4 sub-blocks.)
+  constexpr int STEP = DIST ? 1 : 64;
+  for (int base0 = (int)blockIdx.x * STEP; base0 < nDirect; base0 += (int)gridDim.x * STEP)
   {
-  const vvcgpu_mc_desc d = descs[list ? list[li] : li];
+  unsigned long long todo = 1ull;
+  if (!DIST)
+  {
+    bool mine = false;
+    if (base0 + lane < nDirect)
+    {
+      const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(descs + base0 + lane) + 32);     // dst_stride | w, h | phases | is_luma, bi
+      mine = !mc_is_fast((int)(signed char)(q.w & 0xFFu), (int)(short)(q.y & 0xFFFFu), (int)(short)(q.y >> 16));
+    }
+    todo = __builtin_amdgcn_ballot_w64(mine);
+  }
+  while (todo)
+  {
+  const int li = base0 + (DIST ? 0 : (int)__builtin_ctzll(todo));
+  todo &= todo - 1ull;
+  const vvcgpu_mc_desc d = descs[li];
   // a PU whose sides are multiples of the packed path's tile (16 luma / 8 chroma samples) is a grid of tiles with the same fractional phase: the
   // wave walks them with the packed code of the fast kernel (here, not there: inlined into the fast kernel the loop cost it its 80-VGPR budget and
   // the MC stage of the canonical workload went from 0.075 to 0.18 ms)
@@ -646,6 +656,7 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
     __syncthreads();                                   // before the next descriptor overwrites the tile
   }
   }
+  }
 }
 
 // ------------------------------------------------------------------------------------------------ B1-B4
@@ -793,17 +804,12 @@ int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel*
   VVC_CHECK_ARG(ref0_base && dst_base && descs, "mc_batch: null pointer");
   if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("mc_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
-  int* list = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * (size_t)n));
-  if (!list) return VVCGPU_E_DEVICE;
-  int cur = 0;
-  int* counters = vvcgpu_counters(st, &cur);                                // zeroed counter for this call; the kernel clears the other one
-  if (!counters) return VVCGPU_E_DEVICE;
   const int xcd = vvc_xcd_on();
   hipLaunchKernelGGL(mc_fast_kernel, dim3(vvc_xcd_grid(cdiv(n, 8), xcd)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     dst_base, descs, n, bit_depth, clp_min, clp_max, list, counters + 16 * cur, counters + 16 * (cur ^ 1), cdiv(n, 8), xcd);
-  hipLaunchKernelGGL(mc_batch_kernel<false>, dim3(n < 2048 ? n : 2048), dim3(64), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     dst_base, descs, list, counters + 16 * cur, bit_depth, clp_min, clp_max, 0, 0, nullptr, nullptr);
-  VVC_LAUNCH_CHECK_COUNTERS(st);
+                     dst_base, descs, n, bit_depth, clp_min, clp_max, cdiv(n, 8), xcd);
+  hipLaunchKernelGGL(mc_batch_kernel<false>, dim3(cdiv(n, 64) < 8192 ? cdiv(n, 64) : 8192), dim3(64), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
+                     dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr);
+  VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
 
@@ -816,7 +822,7 @@ int vvcgpu_mc_dist_batch(int kind, const vvc_pel* ref0_base, const vvc_pel* ref1
   VVC_CHECK_ARG(ref0_base && org_base && descs && out, "mc_dist_batch: null pointer");
   if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("mc_dist_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
   hipLaunchKernelGGL(mc_batch_kernel<true>, dim3(n < 4096 ? n : 4096), dim3(64), 0, (hipStream_t)stream, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     nullptr, descs, nullptr, nullptr, bit_depth, clp_min, clp_max, n, kind, org_base, reinterpret_cast<unsigned long long*>(out));
+                     nullptr, descs, bit_depth, clp_min, clp_max, n, kind, org_base, reinterpret_cast<unsigned long long*>(out));
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
