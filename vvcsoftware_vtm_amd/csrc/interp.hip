@@ -473,23 +473,25 @@ template <bool DIST>
 __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
                                                       Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs,
                                                       int bd, int cmin, int cmax,
-                                                      int nDirect, int distKind, const Pel* __restrict__ orgBase, unsigned long long* __restrict__ out)
+                                                      int nDirect, int distKind, const Pel* __restrict__ orgBase, unsigned long long* __restrict__ out, int chunk)
 {
   __shared__ short win[WR * WP];
   __shared__ short tmp[WR * ST];
   __shared__ __align__(16) short predT[DIST ? 128 * 128 : 8];
   __shared__ __align__(16) unsigned tileL[DIST ? 4 : MC_LDS_DW];
   const int lane = threadIdx.x;
-  // !DIST: a wave looks at 64 descriptors at a time, one per lane, and serves those the fast kernel leaves.  (A list of them filled by the fast
-  // kernel cost one same-address atomic per PU: 6 of the 7 ms of an affine prediction of 518 k 4x4 sub-blocks.)
-  constexpr int STEP = DIST ? 1 : 64;
+  // !DIST: a wave looks at `chunk` consecutive descriptors at a time, one per lane, and serves those the fast kernel leaves.  (A list of them filled
+  // by the fast kernel cost one same-address atomic per PU: 6 of the 7 ms of an affine prediction of 518 k 4x4 sub-blocks.)  chunk (host): 64 for
+  // long lists, down to 1 for short ones -- a wave serves its PUs one after the other, and a short list of large PUs needs every wave it can get
+  // (1947 PUs of 64x64 in chunks of 64: 31 busy waves, 2.2 ms instead of 0.08).
+  const int STEP = DIST ? 1 : chunk;
   for (int base0 = (int)blockIdx.x * STEP; base0 < nDirect; base0 += (int)gridDim.x * STEP)
   {
   unsigned long long todo = 1ull;
   if (!DIST)
   {
     bool mine = false;
-    if (base0 + lane < nDirect)
+    if (lane < chunk && base0 + lane < nDirect)
     {
       const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(descs + base0 + lane) + 32);     // dst_stride | w, h | phases | is_luma, bi
       mine = !mc_is_fast((int)(signed char)(q.w & 0xFFu), (int)(short)(q.y & 0xFFFFu), (int)(short)(q.y >> 16));
@@ -807,8 +809,9 @@ int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel*
   const int xcd = vvc_xcd_on();
   hipLaunchKernelGGL(mc_fast_kernel, dim3(vvc_xcd_grid(cdiv(n, 8), xcd)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
                      dst_base, descs, n, bit_depth, clp_min, clp_max, cdiv(n, 8), xcd);
-  hipLaunchKernelGGL(mc_batch_kernel<false>, dim3(cdiv(n, 64) < 8192 ? cdiv(n, 64) : 8192), dim3(64), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr);
+  const int chunk = n >= 64 * 8192 ? 64 : (n + 8191) / 8192;            // ~8192 waves: 32 per CU
+  hipLaunchKernelGGL(mc_batch_kernel<false>, dim3(cdiv(n, chunk) < 8192 ? cdiv(n, chunk) : 8192), dim3(64), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
+                     dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
@@ -822,7 +825,7 @@ int vvcgpu_mc_dist_batch(int kind, const vvc_pel* ref0_base, const vvc_pel* ref1
   VVC_CHECK_ARG(ref0_base && org_base && descs && out, "mc_dist_batch: null pointer");
   if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("mc_dist_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
   hipLaunchKernelGGL(mc_batch_kernel<true>, dim3(n < 4096 ? n : 4096), dim3(64), 0, (hipStream_t)stream, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     nullptr, descs, bit_depth, clp_min, clp_max, n, kind, org_base, reinterpret_cast<unsigned long long*>(out));
+                     nullptr, descs, bit_depth, clp_min, clp_max, n, kind, org_base, reinterpret_cast<unsigned long long*>(out), 1);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
