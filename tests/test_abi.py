@@ -77,6 +77,7 @@ def test_next_row_entry_points_validate_arguments_without_a_device():
         "vvcgpu_rdoq_batch": lambda n: lib.vvcgpu_rdoq_batch(nul, nul, nul, n, nul, 10, nul, C.c_size_t(0), nul, C.c_size_t(0), nul),
         "vvcgpu_affine_sobel_batch": lambda n: lib.vvcgpu_affine_sobel_batch(0, nul, nul, nul, n, nul),
         "vvcgpu_affine_equal_coeff_batch": lambda n: lib.vvcgpu_affine_equal_coeff_batch(nul, nul, nul, nul, n, nul, nul),
+        "vvcgpu_affine_pred_batch": lambda n: lib.vvcgpu_affine_pred_batch(nul, nul, nul, nul, n, n, nul, 0, 64, 64, 128, 128, 0, 0, 64, 64, 10, 0, 1023, nul),
         "vvcgpu_affine_me_iter_batch": lambda n: lib.vvcgpu_affine_me_iter_batch(nul, nul, nul, nul, n, n, nul, 1, 64, 64, 128, 128, 0, 0, 64, 10, 0, 1023, nul, nul, nul),
         "vvcgpu_intra_pred_batch": lambda n: lib.vvcgpu_intra_pred_batch(nul, nul, nul, n, 0, 1023, nul),
         "vvcgpu_mc_dist_batch": lambda n: lib.vvcgpu_mc_dist_batch(0, nul, nul, nul, nul, n, 10, 0, 1023, nul, nul),

@@ -300,6 +300,9 @@ __global__ __launch_bounds__(256) void affine_iter_small_kernel(const Pel* __res
 
 }  // namespace
 
+extern "C" __attribute__((visibility("hidden"))) int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base, const vvcgpu_mc_desc* descs, int n, int bit_depth,
+                                    int clp_min, int clp_max, void* stream, bool skip_fast, bool sub44);       // interp.hip (not part of the ABI)
+
 extern "C" {
 
 int vvcgpu_affine_sobel_batch(int vertical, const vvc_pel* pred_base, int32_t* deriv_base, const vvcgpu_afg_desc* descs, int n, void* stream)
@@ -339,6 +342,22 @@ int vvcgpu_affine_subblock_descs(const vvcgpu_affine_pu* pus, int n, int comp, i
   return VVCGPU_OK;
 }
 
+int vvcgpu_affine_pred_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base, const vvcgpu_affine_pu* pus, int n, int n_subblocks,
+                             vvcgpu_mc_desc* subblock_ws, int comp, int pic_w, int pic_h, int max_cu_w, int max_cu_h, int ref_origin_x, int ref_origin_y,
+                             int ref0_stride, int ref1_stride, int bit_depth, int clp_min, int clp_max, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "affine_pred_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(ref0_base && dst_base && pus && subblock_ws, "affine_pred_batch: null pointer");
+  VVC_CHECK_ARG(n_subblocks >= n, "affine_pred_batch: n_subblocks %d for %d PUs", n_subblocks, n);
+  const int rc = vvcgpu_affine_subblock_descs(pus, n, comp, pic_w, pic_h, max_cu_w, max_cu_h, ref_origin_x, ref_origin_y, ref0_stride, ref1_stride, subblock_ws,
+                                              stream);
+  if (rc != VVCGPU_OK) return rc;
+  // luma: every descriptor is a 4x4 block -- no fast-kernel launch, the packed 4x4 variant of the generic kernel; chroma (2x2): the plain one
+  return vvcgpu_mc_batch_impl(ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, subblock_ws, n_subblocks, bit_depth, clp_min, clp_max, stream, comp == 0,
+                              comp == 0);
+}
+
 int vvcgpu_affine_me_iter_batch(const vvc_pel* org_base, const vvc_pel* ref_base, vvc_pel* pred_base, const vvcgpu_affine_iter* items, int n,
                                 int n_subblocks, vvcgpu_mc_desc* subblock_ws, int dist_kind, int pic_w, int pic_h, int max_cu_w, int max_cu_h,
                                 int ref_origin_x, int ref_origin_y, int ref_stride, int bit_depth, int clp_min, int clp_max, int64_t* coeff_out,
@@ -355,7 +374,7 @@ int vvcgpu_affine_me_iter_batch(const vvc_pel* org_base, const vvc_pel* ref_base
   hipLaunchKernelGGL(affine_subblock_descs_kernel, dim3(n), dim3(256), 0, st, reinterpret_cast<const vvcgpu_affine_pu*>(items), (int)sizeof(vvcgpu_affine_iter),
                      n, 0, pic_w, pic_h, max_cu_w, max_cu_h, ref_origin_x, ref_origin_y, ref_stride, ref_stride, subblock_ws);
   VVC_LAUNCH_CHECK();
-  const int rc = vvcgpu_mc_batch(ref_base, ref_base, pred_base, subblock_ws, n_subblocks, bit_depth, clp_min, clp_max, stream);
+  const int rc = vvcgpu_mc_batch_impl(ref_base, ref_base, pred_base, subblock_ws, n_subblocks, bit_depth, clp_min, clp_max, stream, true, true);   // 4x4 luma only
   if (rc != VVCGPU_OK) return rc;
   // every PU is served by exactly one of the two: by size, which only the device knows
   hipLaunchKernelGGL(affine_iter_small_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, org_base, pred_base, items, n, dist_kind,

@@ -466,10 +466,44 @@ __global__ __launch_bounds__(256, 6) void mc_fast_kernel(const Pel* __restrict__
   }
 }
 
+// four 4x4 luma PUs side by side, sixteen lanes each, through the packed code of the fast kernel (N = 8 taps, tile 4, 16 lanes: 11 window rows of
+// 6 dwords, 11 first-pass items, 4 second-pass items per PU).  Affine prediction is made of these: a whole wave per sub-block through the
+// sample-wise body was 0.6 ms for the 518 k sub-blocks of a 4K picture.  Only in the SUB44 variant of the generic kernel (the affine entry points
+// launch it): with this path the kernel needs 214 VGPRs instead of 127 -- inline or as a real call -- which costs every other PU size a wave per SIMD.
+constexpr int MC44_DW = 11 * 6 + 4 * 6 + 8;                               // per group: window, transposed intermediate (4 x 12 shorts), output (16 shorts)
+__device__ __forceinline__ void mc_luma4x4_chunk(unsigned long long todo44, const vvcgpu_mc_desc* __restrict__ descs, const Pel* __restrict__ ref0Base,
+                                                 const Pel* __restrict__ ref1Base, Pel* __restrict__ dstBase, int bd, int cmin, int cmax, int lane, unsigned* tileL)
+{
+  unsigned* L = tileL + (lane >> 4) * MC44_DW;
+  const int gl = lane & 15;
+  // the next four PUs' descriptors and windows are requested before the current four are computed
+  auto pick = [&](int& sel)
+  {
+    const int firstSel = (int)__builtin_ctzll(todo44);
+    sel = -1;
+#pragma unroll
+    for (int k = 0; k < 4; k++)
+      if (todo44) { const int b = (int)__builtin_ctzll(todo44); todo44 &= todo44 - 1ull; if (k == (lane >> 4)) sel = b; }
+    return descs[sel >= 0 ? sel : firstSel];
+  };
+  int selC, selN = -1;
+  vvcgpu_mc_desc dC = pick(selC), dN = dC;
+  McStaged<8, 4, 16> sC, sN;
+  mc_stage<8, 4, 16>(dC, selC >= 0, ref0Base, ref1Base, gl, sC);
+  for (;;)
+  {
+    const bool more = todo44 != 0ull;
+    if (more) { dN = pick(selN); mc_stage<8, 4, 16>(dN, selN >= 0, ref0Base, ref1Base, gl, sN); }
+    mc_tile_dot2<8, 4, 16>(dC, selC >= 0, sC, dstBase, bd, cmin, cmax, gl, L, reinterpret_cast<short*>(L + 11 * 6), reinterpret_cast<short*>(L + 11 * 6 + 4 * 6));
+    if (!more) break;
+    dC = dN; selC = selN; sC = sN;
+  }
+}
+
 // generic kernel: any size, one wave per PU, persistent over the list of PUs the fast kernel left.
 // DIST (vvcgpu_mc_dist_batch): the prediction goes into an LDS tile instead of dst, and the wave returns its distortion against the original
 // (descriptor field dst_off / dst_stride = the original block, reserved = row sub-sampling shift of the SAD); list == nullptr: every descriptor.
-template <bool DIST>
+template <bool DIST, bool SUB44 = false>
 __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
                                                       Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs,
                                                       int bd, int cmin, int cmax,
@@ -490,13 +524,18 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
   unsigned long long todo = 1ull;
   if (!DIST)
   {
-    bool mine = false;
+    bool mine = false, sub44 = false;
     if (lane < chunk && base0 + lane < nDirect)
     {
       const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(descs + base0 + lane) + 32);     // dst_stride | w, h | phases | is_luma, bi
-      mine = !mc_is_fast((int)(signed char)(q.w & 0xFFu), (int)(short)(q.y & 0xFFFFu), (int)(short)(q.y >> 16));
+      const int isLuma = (int)(signed char)(q.w & 0xFFu), qw = (int)(short)(q.y & 0xFFFFu), qh = (int)(short)(q.y >> 16);
+      mine = !mc_is_fast(isLuma, qw, qh);
+      sub44 = SUB44 && isLuma && qw == 4 && qh == 4;
     }
     todo = __builtin_amdgcn_ballot_w64(mine);
+    unsigned long long todo44 = __builtin_amdgcn_ballot_w64(sub44);        // 4x4 luma (affine sub-blocks): four at a time, see mc_luma4x4_quad
+    todo &= ~todo44;
+    if (SUB44 && todo44) mc_luma4x4_chunk(todo44, descs + base0, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, tileL);
   }
   while (todo)
   {
@@ -798,8 +837,19 @@ int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_
   return VVCGPU_OK;
 }
 
+// skip_fast: the caller knows that no descriptor is one of the fast kernel's shapes (affine sub-blocks): its launch is left out -- 65 k workgroups
+// that only look at their descriptors and leave cost 80 us for the 518 k sub-blocks of a 4K picture
+__attribute__((visibility("hidden"))) int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base,
+                         const vvcgpu_mc_desc* descs, int n, int bit_depth, int clp_min, int clp_max, void* stream, bool skip_fast, bool sub44);
+
 int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base,
                     const vvcgpu_mc_desc* descs, int n, int bit_depth, int clp_min, int clp_max, void* stream)
+{
+  return vvcgpu_mc_batch_impl(ref0_base, ref1_base, dst_base, descs, n, bit_depth, clp_min, clp_max, stream, false, false);
+}
+
+int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base,
+                         const vvcgpu_mc_desc* descs, int n, int bit_depth, int clp_min, int clp_max, void* stream, bool skip_fast, bool sub44)
 {
   VVC_CHECK_ARG(n >= 0, "mc_batch: n %d", n);
   if (n == 0) return VVCGPU_OK;
@@ -807,11 +857,16 @@ int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel*
   if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("mc_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
   const int xcd = vvc_xcd_on();
-  hipLaunchKernelGGL(mc_fast_kernel, dim3(vvc_xcd_grid(cdiv(n, 8), xcd)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     dst_base, descs, n, bit_depth, clp_min, clp_max, cdiv(n, 8), xcd);
+  if (!skip_fast)
+    hipLaunchKernelGGL(mc_fast_kernel, dim3(vvc_xcd_grid(cdiv(n, 8), xcd)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
+                       dst_base, descs, n, bit_depth, clp_min, clp_max, cdiv(n, 8), xcd);
   const int chunk = n >= 64 * 8192 ? 64 : (n + 8191) / 8192;            // ~8192 waves: 32 per CU
-  hipLaunchKernelGGL(mc_batch_kernel<false>, dim3(cdiv(n, chunk) < 8192 ? cdiv(n, chunk) : 8192), dim3(64), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk);
+  if (sub44)
+    hipLaunchKernelGGL((mc_batch_kernel<false, true>), dim3(cdiv(n, chunk) < 8192 ? cdiv(n, chunk) : 8192), dim3(64), 0, st, ref0_base,
+                       ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk);
+  else
+    hipLaunchKernelGGL((mc_batch_kernel<false, false>), dim3(cdiv(n, chunk) < 8192 ? cdiv(n, chunk) : 8192), dim3(64), 0, st, ref0_base,
+                       ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
@@ -824,7 +879,7 @@ int vvcgpu_mc_dist_batch(int kind, const vvc_pel* ref0_base, const vvc_pel* ref1
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(ref0_base && org_base && descs && out, "mc_dist_batch: null pointer");
   if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("mc_dist_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
-  hipLaunchKernelGGL(mc_batch_kernel<true>, dim3(n < 4096 ? n : 4096), dim3(64), 0, (hipStream_t)stream, ref0_base, ref1_base ? ref1_base : ref0_base,
+  hipLaunchKernelGGL((mc_batch_kernel<true, false>), dim3(n < 4096 ? n : 4096), dim3(64), 0, (hipStream_t)stream, ref0_base, ref1_base ? ref1_base : ref0_base,
                      nullptr, descs, bit_depth, clp_min, clp_max, n, kind, org_base, reinterpret_cast<unsigned long long*>(out), 1);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;

@@ -557,6 +557,14 @@ def affine_me_iter_batch(org_base, ref_base, pred_base, items_dev, n, n_subblock
     return coeff, dist
 
 
+def affine_pred_batch(ref0_base, ref1_base, dst_base, pus_dev, n, n_subblocks, comp, pic_w, pic_h, ref_origin, ref0_stride, ref1_stride,
+                      bit_depth=10, clp=(0, 1023), max_cu=128):
+    """xPredAffineBlk for a list of PUs: sub-block vectors + their interpolation in one call (luma: four 4x4 sub-blocks per wavefront)"""
+    ws = torch.empty(n_subblocks * MC_DESC.itemsize, dtype=torch.uint8, device=dst_base.device)
+    capi.call("vvcgpu_affine_pred_batch", capi.ptr(ref0_base), capi.ptr(ref1_base), capi.ptr(dst_base), capi.ptr(pus_dev), n, n_subblocks, capi.ptr(ws),
+              comp, pic_w, pic_h, max_cu, max_cu, ref_origin[0], ref_origin[1], ref0_stride, ref1_stride, bit_depth, clp[0], clp[1], _stream())
+
+
 def affine_subblock_descs(pus_dev, n, n_descs, comp, pic_w, pic_h, ref_origin, ref0_stride, ref1_stride, max_cu=128):
     """sub-block MC descriptors (uint8 tensor of n_descs vvcgpu_mc_desc) of n affine PUs, on the device"""
     out = torch.zeros(n_descs * MC_DESC.itemsize, dtype=torch.uint8, device=pus_dev.device)
