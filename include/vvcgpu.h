@@ -383,7 +383,7 @@ int vvcgpu_affine_subblock_descs(const vvcgpu_affine_pu* pus, int n, int comp, i
 /* The whole of xPredAffineBlk for a list of PUs in one call: vvcgpu_affine_subblock_descs into subblock_ws (n_subblocks = sum of the PUs' sub-block
  * counts, device memory the call overwrites), then their interpolation as vvcgpu_mc_batch does it -- for luma with four 4x4 sub-blocks per wavefront
  * through the packed filter code (a list of 4x4 descriptors handed to vvcgpu_mc_batch itself goes one sub-block per wavefront: 0.6 ms instead of
- * 0.14 for the 518 k sub-blocks of a 4K picture).  Arguments as the two calls it bundles; ref1_base may be NULL when no PU has bi = 1.          */
+ * 0.15 for the 518 k sub-blocks of a 4K picture).  Arguments as the two calls it bundles; ref1_base may be NULL when no PU has bi = 1.          */
 int vvcgpu_affine_pred_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base, const vvcgpu_affine_pu* pus, int n, int n_subblocks,
                              vvcgpu_mc_desc* subblock_ws, int comp, int pic_w, int pic_h, int max_cu_w, int max_cu_h, int ref_origin_x, int ref_origin_y,
                              int ref0_stride, int ref1_stride, int bit_depth, int clp_min, int clp_max, void* stream);

@@ -64,6 +64,17 @@ for B in (16, 32, 64, 128):
     def fused():
         return ops.affine_me_iter_batch(org, ref, pred, di, n, n * nsb, 1, W, H, (M, M), PW, bd, (0, 1023))
 
+    def pred_chain():
+        descs = ops.affine_subblock_descs(pus, n, n * nsb, 0, W, H, (M, M), PW, PW)
+        ops.mc_batch(ref, ref, pred, descs, n * nsb, bd, (0, 1023))
+
+    def pred_one():
+        ops.affine_pred_batch(ref, None, pred, pus, n, n * nsb, 0, W, H, (M, M), PW, PW, bd, (0, 1023))
+
+    pred_chain(); a = pred.clone(); pred.zero_(); pred_one()
+    assert torch.equal(a, pred)
+    print("affine prediction   %3dx%-3d: %6d PUs  descriptors + vvcgpu_mc_batch %.3f ms   vvcgpu_affine_pred_batch %.3f ms" % (B, B, n, timed(pred_chain), timed(pred_one)),
+          flush=True)
     c0, d0 = chain()
     c1, d1 = fused()
     assert torch.equal(c0.reshape(-1), c1.reshape(-1)) and torch.equal(d0.reshape(-1).to(torch.int64), d1.reshape(-1))
