@@ -90,6 +90,32 @@ def test_mc_batch(bd, kind, W, doff0):                                          
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+def test_mc_batch_long_mixed_list():
+    """a list long enough that a wavefront of the generic kernel looks at several descriptors at a time (n > 8192: chunks of 2 .. 64), with the fast
+    kernel's shapes (16x16 luma, 8x8 chroma) and everything else mixed at random: every PU is served exactly once, by the right kernel"""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(41)
+    bd, mx, W, H, M = 10, 1023, 512, 384, 8
+    r0, r1 = cases.rand_plane(rng, H, W, bd, "smooth"), cases.rand_plane(rng, H, W, bd, "uniform")
+    shapes = [(16, 16, 1), (8, 8, 0), (4, 4, 1), (8, 8, 1), (4, 8, 1), (16, 8, 1), (4, 4, 0), (32, 32, 1), (2, 2, 0), (16, 16, 0)]
+    pick = rng.choice(len(shapes), 21000, p=[0.35, 0.25, 0.1, 0.06, 0.05, 0.05, 0.05, 0.03, 0.03, 0.03])
+    rows, doff = [], 0
+    for k in pick:
+        w, h, luma = shapes[k]
+        nf = 16 if luma else 32
+        x0, y0 = int(rng.integers(M, W - w - M)), int(rng.integers(M, H - h - M))
+        x1, y1 = int(rng.integers(M, W - w - M)), int(rng.integers(M, H - h - M))
+        rows.append((y0 * W + x0, y1 * W + x1, doff, W, W, w, w, h, int(rng.integers(0, nf)), int(rng.integers(0, nf)), int(rng.integers(0, nf)),
+                     int(rng.integers(0, nf)), luma, int(rng.integers(0, 2)), 0))
+        doff += w * h
+    d = np.array(rows, dtype=ops.MC_DESC)
+    want = np.full(doff, -5, np.int16)
+    oracle().orc_mc_batch(p(r0), p(r1), p(want), p(d), len(d), bd, 0, mx)
+    got = torch.full((doff,), -5, dtype=torch.int16, device="cuda")
+    ops.mc_batch(dev(r0), dev(r1), got, ops.struct_to_device(d), len(d), bd, (0, mx))
+    assert np.array_equal(got.cpu().numpy(), want)
+
+
 @pytest.mark.parametrize("kind", [0, 1, 2])
 @pytest.mark.parametrize("bd", [8, 10])
 def test_mc_dist_batch_equals_predict_then_distortion(kind, bd):
