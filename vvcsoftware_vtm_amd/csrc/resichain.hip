@@ -413,6 +413,7 @@ __device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, 
   {
     const int j = e >> lh, r = e & (h - 1);
     int sum = 0;
+#pragma unroll 4
     for (int k = 0; k < w; k++) sum += bufA[r * w + k] * Th[j * w + k];
     bufB[e] = (sum + (1 << (s1 - 1))) >> s1;
   }
@@ -424,6 +425,7 @@ __device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, 
     if (j2 < hj && j1 < wj)
     {
       int sum = 0;
+#pragma unroll 4
       for (int r = 0; r < h; r++) sum += bufB[j1 * h + r] * Tv[j2 * h + r];
       v = (sum + (1 << (s2 - 1))) >> s2;
     }
@@ -485,6 +487,7 @@ __device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, 
   {
     const int i = e >> lh, r = e & (h - 1);
     int acc = 0;
+#pragma unroll 4
     for (int k = 0; k < hj; k++) acc += bufA[k * w + i] * Tv[k * h + r];
     bufB[e] = clip3(-(1 << 15), (1 << 15) - 1, (acc + 256) >> 9);
   }
@@ -495,6 +498,7 @@ __device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, 
   {
     const int r = e >> lw, x = e & (w - 1);
     int acc = 0;
+#pragma unroll 4
     for (int i = 0; i < wj; i++) acc += bufB[i * h + r] * Th[i * w + x];
     const int resi = (short)clip3(-(1 << 15), (1 << 15) - 1, (acc + (1 << (s2i - 1))) >> s2i);
     rec[(size_t)r * d.rec_stride + x] = (short)clip3(clpMin, clpMax, (int)pred[(size_t)r * d.pred_stride + x] + resi);
