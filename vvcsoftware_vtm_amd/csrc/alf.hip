@@ -15,6 +15,7 @@
 //   * filtering: one thread per 4x4 block (the granularity at which coefficients change), 10 input rows
 //     streamed through registers into 16 accumulators; the class's coefficients are permuted once per block.
 #include "common.h"
+#include <cstddef>
 
 namespace {
 
@@ -172,13 +173,15 @@ template <bool IS7, bool LUMA>
 __device__ __forceinline__ void alf_filter_body(const int bidx, const int bidy, short* tile, short* scoef, const Pel* __restrict__ src, int sstride,
                                                          Pel* __restrict__ dst, int dstride, int w, int h,
                                                          int ctu, int wCtu, const uint16_t* __restrict__ cls,
-                                                         const AlfCoeffs& coeffs, const uint8_t* __restrict__ ctuEnable,
+                                                         const int16_t* __restrict__ coeffs, const uint8_t* __restrict__ ctuEnable,
                                                          int clpMin, int clpMax)
 {
   const int tid = threadIdx.x;
   const int tx0 = bidx * FW, ty0 = bidy * FH;
   load_tile_clamped<FP>(tile, src, sstride, w, h, tx0 - 4, ty0 - 3, FR, tid, 128);
-  for (int i = tid; i < (LUMA ? 25 * 13 : 7); i += 128) scoef[i] = coeffs.c[i];
+  // `coeffs` points INTO the kernel-argument segment (alf_kernarg): indexing the by-value argument with the thread index made every lane copy the
+  // whole 650-byte struct to scratch memory first (656 bytes of private segment per lane; no measurable time at 4K, but no reason to keep it)
+  for (int i = tid; i < (LUMA ? 25 * 13 : 7); i += 128) scoef[i] = coeffs[i];
   __syncthreads();
 
   // 16 x 8 blocks of 4x4 per tile, one per thread
@@ -268,6 +271,17 @@ __device__ __forceinline__ void alf_filter_body(const int bidx, const int bidy, 
   }
 }
 
+// address of a by-value kernel argument inside the kernel-argument segment (byte offset as laid out by the C struct rules)
+__device__ __forceinline__ const int16_t* alf_kernarg(size_t off)
+{
+#if defined(__HIP_DEVICE_COMPILE__)
+  return reinterpret_cast<const int16_t*>((const char*)__builtin_amdgcn_kernarg_segment_ptr() + off);
+#else
+  (void)off; return nullptr;
+#endif
+}
+struct AlfFilterArgs { const Pel* src; int sstride; Pel* dst; int dstride, w, h, ctu, wCtu; const uint16_t* cls; AlfCoeffs coeffs; };   // mirrors alf_filter_kernel's arguments
+
 template <bool IS7, bool LUMA>
 __global__ __launch_bounds__(128) void alf_filter_kernel(const Pel* __restrict__ src, int sstride, Pel* __restrict__ dst, int dstride, int w, int h,
                                                          int ctu, int wCtu, const uint16_t* __restrict__ cls, AlfCoeffs coeffs,
@@ -275,7 +289,9 @@ __global__ __launch_bounds__(128) void alf_filter_kernel(const Pel* __restrict__
 {
   __shared__ short tile[FR * FP];
   __shared__ short scoef[25 * 13 + 3];
-  alf_filter_body<IS7, LUMA>((int)blockIdx.x, (int)blockIdx.y, tile, scoef, src, sstride, dst, dstride, w, h, ctu, wCtu, cls, coeffs, ctuEnable, clpMin, clpMax);
+  (void)coeffs;
+  alf_filter_body<IS7, LUMA>((int)blockIdx.x, (int)blockIdx.y, tile, scoef, src, sstride, dst, dstride, w, h, ctu, wCtu, cls,
+                             alf_kernarg(offsetof(AlfFilterArgs, coeffs)), ctuEnable, clpMin, clpMax);
 }
 
 // luma (classifier-driven 7x7 or 5x5) and both chroma planes (5x5, one filter) of a picture in one launch
@@ -290,17 +306,14 @@ __global__ __launch_bounds__(128) void alf_filter_picture_kernel(AlfFilter3 p)
   if (b < 0) return;
   if (b < p.nLuma)
     alf_filter_body<IS7, true>(b % p.glx, b / p.glx, tile, scoef, p.a[0].src, p.a[0].sstride, p.a[0].dst, p.a[0].dstride, p.w, p.h, p.ctu, (p.w + p.ctu - 1) / p.ctu,
-                               p.cls, p.luma, p.a[0].enable, p.clpMin, p.clpMax);
+                               p.cls, alf_kernarg(offsetof(AlfFilter3, luma)), p.a[0].enable, p.clpMin, p.clpMax);
   else
   {
     const int c = b - p.nLuma, per = p.gcx * p.gcy, z = c / per, r = c - z * per;
     const AlfPlane& a = z ? p.a[2] : p.a[1];
-    AlfCoeffs cc;
-#pragma unroll
-    for (int i = 0; i < 7; i++) cc.c[i] = p.chroma[i];
     const int ctuC = p.ctu >> 1, wc = p.w >> 1;
     alf_filter_body<false, false>(r % p.gcx, r / p.gcx, tile, scoef, a.src, a.sstride, a.dst, a.dstride, wc, p.h >> 1, ctuC, (wc + ctuC - 1) / ctuC,
-                                  nullptr, cc, a.enable, p.clpMin, p.clpMax);
+                                  nullptr, alf_kernarg(offsetof(AlfFilter3, chroma)), a.enable, p.clpMin, p.clpMax);
   }
 }
 
