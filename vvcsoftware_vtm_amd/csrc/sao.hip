@@ -17,14 +17,36 @@ constexpr int SAO_ROWS = 4;
 
 struct SaoGeom { int gx, gy, rows, x0, y0, x1, y1, w, h, avail, clpMin, clpMax; };
 
-// Edge-offset body with the class direction as a compile-time constant (keeps the 3-row register
-// window statically indexed -> no scratch).  Neighbour a = (x+DXA, y+DYA), b = (x-DXA, y-DYA).
+// Edge-offset body with the class direction as a compile-time constant (keeps the 3-row register window statically indexed -> no scratch).
+// Neighbour a = (x+DXA, y+DYA), b = (x-DXA, y-DYA).
+// Which samples take an offset depends on the thread only through a few bits: neighbour a (b) of column k lies left of / inside / right of the
+// CTU -- three 8-bit column masks per thread -- and above / inside / below it per row.  They are folded into one 8-bit "use" mask per row before
+// the sample loop, which is then: two differences, two v_med3 (sign), the offset by a bit-field extract from the five offsets packed as 6-bit
+// fields, add, clip, and a v_bfi that keeps the sample where the mask bit is clear.  (The form this replaces evaluated the position tests and a
+// compare-select sign per sample: ~40 vector instructions per sample, the kernel's arithmetic took as long as its memory traffic.)
+// Offsets outside [-32, 31] (not reachable from the reference at 8 - 10 bits, but the ABI takes any int16) go through a select chain instead.
 template <int DXA, int DYA, typename StoreRow>
 __device__ __forceinline__ void eo_rows(const SaoGeom& g, int off0, int off1, int off2, int off3, int off4,
                                         const int (&win)[SAO_ROWS + 2][10], StoreRow store_row)
 {
-  const bool availL = g.avail & 1, availR = (g.avail >> 1) & 1, availA = (g.avail >> 2) & 1, availB = (g.avail >> 3) & 1;
-  const bool availAL = (g.avail >> 4) & 1, availAR = (g.avail >> 5) & 1, availBL = (g.avail >> 6) & 1, availBR = (g.avail >> 7) & 1;
+  // 0 / -1 masks of the neighbour CTUs' availability
+  const int avL = -(g.avail & 1), avR = -((g.avail >> 1) & 1), avA = -((g.avail >> 2) & 1), avB = -((g.avail >> 3) & 1);
+  const int avAL = -((g.avail >> 4) & 1), avAR = -((g.avail >> 5) & 1), avBL = -((g.avail >> 6) & 1), avBR = -((g.avail >> 7) & 1);
+  // columns k whose neighbour a (b) lies left of / inside / right of the CTU
+  int aL = 0, aR = 0, bL = 0, bR = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+  {
+    const int x = g.gx + k;
+    if (DXA != 0)
+    {
+      if (x + DXA < g.x0) aL |= 1 << k; else if (x + DXA >= g.x1) aR |= 1 << k;
+      if (x - DXA < g.x0) bL |= 1 << k; else if (x - DXA >= g.x1) bR |= 1 << k;
+    }
+  }
+  const int aIn = 0xFF & ~(aL | aR), bIn = 0xFF & ~(bL | bR);
+  const bool fits = (unsigned)(off0 + 32) < 64u && (unsigned)(off1 + 32) < 64u && (unsigned)(off2 + 32) < 64u && (unsigned)(off3 + 32) < 64u && (unsigned)(off4 + 32) < 64u;
+  const unsigned packed = (unsigned)(off0 & 63) | (unsigned)(off1 & 63) << 6 | (unsigned)(off2 & 63) << 12 | (unsigned)(off3 & 63) << 18 | (unsigned)(off4 & 63) << 24;
 #pragma unroll
   for (int r = 0; r < SAO_ROWS; r++)
   {
@@ -32,24 +54,26 @@ __device__ __forceinline__ void eo_rows(const SaoGeom& g, int off0, int off1, in
     const int y = g.gy + r;
     const bool topOut = (DYA != 0) && (y - 1 < g.y0);     // a's row is in the CTU above
     const bool botOut = (DYA != 0) && (y + 1 >= g.y1);    // b's row is in the CTU below
+    const int okA = topOut ? ((aIn & avA) | (aL & avAL) | (aR & avAR)) : (aIn | (aL & avL) | (aR & avR));
+    const int okB = botOut ? ((bIn & avB) | (bL & avBL) | (bR & avBR)) : (bIn | (bL & avL) | (bR & avR));
+    const int use = okA & okB;
     int o[8];
 #pragma unroll
     for (int k = 0; k < 8; k++)
     {
-      const int x = g.gx + k;
       const int c = win[r + 1][1 + k];
       const int a = DYA == 0 ? win[r + 1][1 + k + DXA] : win[r][1 + k + DXA];
       const int b = DYA == 0 ? win[r + 1][1 + k - DXA] : win[r + 2][1 + k - DXA];
-      const int hxA = DXA == 0 ? 0 : ((x + DXA < g.x0) ? -1 : (x + DXA >= g.x1 ? 1 : 0));
-      const int hxB = DXA == 0 ? 0 : ((x - DXA < g.x0) ? -1 : (x - DXA >= g.x1 ? 1 : 0));
-      bool okA, okB;
-      if (!topOut) okA = hxA == 0 ? true : (hxA < 0 ? availL : availR);
-      else         okA = hxA == 0 ? availA : (hxA < 0 ? availAL : availAR);
-      if (!botOut) okB = hxB == 0 ? true : (hxB < 0 ? availL : availR);
-      else         okB = hxB == 0 ? availB : (hxB < 0 ? availBL : availBR);
-      const int e = sgn(c - a) + sgn(c - b);
-      const int of = e == -2 ? off0 : e == -1 ? off1 : e == 0 ? off2 : e == 1 ? off3 : off4;
-      o[k] = (okA && okB) ? clip3(g.clpMin, g.clpMax, c + of) : c;
+      int sa, sb;
+      asm("v_med3_i32 %0, %1, -1, 1" : "=v"(sa) : "v"(c - a));
+      asm("v_med3_i32 %0, %1, -1, 1" : "=v"(sb) : "v"(c - b));
+      const int e = sa + sb;
+      int of;
+      if (fits) of = __builtin_amdgcn_sbfe((int)packed, (unsigned)(e * 6 + 12), 6u);
+      else      of = e == -2 ? off0 : e == -1 ? off1 : e == 0 ? off2 : e == 1 ? off3 : off4;
+      const int t = clip3(g.clpMin, g.clpMax, c + of);
+      const int m = __builtin_amdgcn_sbfe(use, (unsigned)k, 1u);            // -1: this sample takes the offset
+      o[k] = (t & m) | (c & ~m);
     }
     store_row(y, o);
   }
