@@ -101,6 +101,25 @@ def test_sao_apply(w, h, cw, ch, bd, kind, full):
     assert np.array_equal(dst.cpu().numpy(), want)
 
 
+def test_sao_apply_wide_offsets_and_narrow_clip():
+    """offsets the packed 6-bit form cannot hold (the ABI takes any int16: the kernel falls back to a select chain per CTU), mixed with CTUs whose
+    offsets fit; and a clipping range narrower than the sample range -- a sample that takes no offset must come through unclipped"""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(77)
+    w, h, c, bd = 320, 192, 64, 10
+    Y = cases.rand_plane(rng, h, w, bd, "uniform")
+    prm = cases.sao_params(rng, w, h, c, c, False, types=[0, 1, 2, 3, 4])
+    big = rng.random(prm.size) < 0.5
+    prm["offset"][big] = rng.integers(-300, 301, (int(big.sum()), 32))
+    prm["offset"][~big, :5] = rng.choice(np.array([-32, -31, 31, 0, 7]), (int((~big).sum()), 5))      # the edges of the packed range
+    for (cmin, cmax) in ((0, 1023), (64, 940)):
+        want = Y.copy()
+        oracle().orc_sao_apply(p(Y), w, p(want), w, w, h, c, c, bd, p(prm), cmin, cmax)
+        dst = torch.full((h, w), -1, dtype=torch.int16, device="cuda")
+        ops.sao_apply(dev(Y), dst, c, c, bd, ops.sao_params_to_device(prm), (cmin, cmax))
+        assert np.array_equal(dst.cpu().numpy(), want), (cmin, cmax)
+
+
 def test_sao_each_type_alone():
     from vvcsoftware_vtm_amd import ops
     rng = np.random.default_rng(3)
