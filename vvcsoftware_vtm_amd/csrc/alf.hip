@@ -75,30 +75,37 @@ __global__ __launch_bounds__(320) void alf_classify_kernel(const Pel* __restrict
   {
     const int qi = tid / QN, qj = tid - qi * QN;
     // quad region: picture rows ty0 + 4qi - 2 .. +3, cols tx0 + 4qj - 2 .. +3  ->  LDS row 4qi+1, col 4qj+2
-    const short* p = tile + (4 * qi) * CP + 4 * qj + 1;   // top-left of the 6x6 neighbourhood
-    int sv = 0, sh = 0, sd0 = 0, sd1 = 0;
-    int r0[6], r1[6], r2[6];
-#pragma unroll
-    for (int k = 0; k < 6; k++) { r0[k] = p[k]; r1[k] = p[CP + k]; }
+    // Two samples per instruction: a row of the 6x6 neighbourhood (columns 4qj+1 .. 4qj+6) is four aligned dwords, its five sample pairs
+    // P0..P4 = (s0,s1) .. (s4,s5) are two of the dwords and three v_alignbit; |2c - a - b| of a pair of samples is ONE v_sad_u16 of the
+    // doubled centre pair against the packed sum of the two neighbour pairs (samples are non-negative, <= 15 bits: nothing wraps), which also
+    // accumulates.  18 instructions per row of four samples instead of 64.
+    const unsigned* base = reinterpret_cast<const unsigned*>(tile + (4 * qi) * CP + 4 * qj);
+    unsigned sv = 0, sh = 0, sd0 = 0, sd1 = 0;
+    unsigned A[5], B[5], C[5];                        // pairs of the rows above / at / below the centre row
+    auto loadRow = [&](int r, unsigned (&P)[5])
+    {
+      const uint2 lo = *reinterpret_cast<const uint2*>(base + r * (CP / 2)), hi = *reinterpret_cast<const uint2*>(base + r * (CP / 2) + 2);
+      P[0] = __builtin_amdgcn_alignbit(lo.y, lo.x, 16); P[1] = lo.y; P[2] = __builtin_amdgcn_alignbit(hi.x, lo.y, 16); P[3] = hi.x;
+      P[4] = __builtin_amdgcn_alignbit(hi.y, hi.x, 16);
+    };
+    typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+    auto padd = [](unsigned a, unsigned b) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(us2v, a) + __builtin_bit_cast(us2v, b)); };
+    loadRow(0, A); loadRow(1, B);
 #pragma unroll
     for (int y = 0; y < 4; y++)
     {
+      loadRow(y + 2, C);
+      // centre row = B: centres (s1,s2) = B[1], (s3,s4) = B[3]
+      const unsigned c01 = padd(B[1], B[1]), c23 = padd(B[3], B[3]);
+      sv  = __builtin_amdgcn_sad_u16(c01, padd(A[1], C[1]), sv);   sv  = __builtin_amdgcn_sad_u16(c23, padd(A[3], C[3]), sv);
+      sh  = __builtin_amdgcn_sad_u16(c01, padd(B[0], B[2]), sh);   sh  = __builtin_amdgcn_sad_u16(c23, padd(B[2], B[4]), sh);
+      sd0 = __builtin_amdgcn_sad_u16(c01, padd(A[0], C[2]), sd0);  sd0 = __builtin_amdgcn_sad_u16(c23, padd(A[2], C[4]), sd0);
+      sd1 = __builtin_amdgcn_sad_u16(c01, padd(C[0], A[2]), sd1);  sd1 = __builtin_amdgcn_sad_u16(c23, padd(C[2], A[4]), sd1);
 #pragma unroll
-      for (int k = 0; k < 6; k++) r2[k] = p[(y + 2) * CP + k];
-#pragma unroll
-      for (int x = 1; x <= 4; x++)
-      {
-        const int c2 = r1[x] << 1;
-        sv  += abs(c2 - r0[x] - r2[x]);
-        sh  += abs(c2 - r1[x + 1] - r1[x - 1]);
-        sd0 += abs(c2 - r0[x - 1] - r2[x + 1]);
-        sd1 += abs(c2 - r2[x - 1] - r0[x + 1]);
-      }
-#pragma unroll
-      for (int k = 0; k < 6; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
+      for (int k = 0; k < 5; k++) { A[k] = B[k]; B[k] = C[k]; }
     }
     int* q = quad + tid * 4;
-    q[0] = sv; q[1] = sh; q[2] = sd0; q[3] = sd1;
+    q[0] = (int)sv; q[1] = (int)sh; q[2] = (int)sd0; q[3] = (int)sd1;
   }
   __syncthreads();
 
