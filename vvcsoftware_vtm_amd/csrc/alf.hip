@@ -243,28 +243,58 @@ __device__ __forceinline__ void alf_filter_body(const int bidx, const int bidy, 
 #pragma unroll
     for (int j = 0; j < 4; j++) acc[i][j] = 0;
 
+  // Two taps per instruction: the taps of one diamond row (dy fixed, dx = -wid .. wid) are taken in pairs (dx, dx + 1) -- the last one with a zero
+  // partner -- as packed 16-bit coefficient pairs, built once per block; a tile row arrives as six dwords = the even sample pairs E[m] = (s[2m],
+  // s[2m+1]), the odd pairs O[m] = (s[2m+1], s[2m+2]) cost one v_alignbit each, and a pair of taps on a pair of samples is one v_dot2_i32_i16:
+  // 16 of them per output sample of the 7x7 diamond instead of 25 multiply-adds, and no unpacking of the row into 32-bit registers.
+  typedef short s2v __attribute__((ext_vector_type(2)));
+  unsigned cpk[2 * R + 1][R + 1];                       // [dy + R][pair]
+#pragma unroll
+  for (int dy = -R; dy <= R; dy++)
+  {
+    const int wid = R - (dy < 0 ? -dy : dy);
+#pragma unroll
+    for (int q = 0; q <= R; q++)
+    {
+      const int dx0 = -wid + 2 * q;
+      unsigned v = 0;
+      if (dx0 <= wid)
+      {
+        const int ka = tapIndex<IS7>(dy, dx0);
+        v = (unsigned)f[ka] & 0xFFFFu;
+        if (dx0 + 1 <= wid) v |= (unsigned)f[tapIndex<IS7>(dy, dx0 + 1)] << 16;
+      }
+      cpk[dy + R][q] = v;
+    }
+  }
 #pragma unroll
   for (int r = 0; r < 4 + 2 * R; r++)
   {
     // input row by - R + r, columns bx-4 .. bx+7
-    int s[12];
-    const pel4 v0 = *reinterpret_cast<const pel4*>(p + r * FP);
-    const pel4 v1 = *reinterpret_cast<const pel4*>(p + r * FP + 4);
-    const pel4 v2 = *reinterpret_cast<const pel4*>(p + r * FP + 8);
+    unsigned E[6], O[5];
+    const uint2 v0 = *reinterpret_cast<const uint2*>(p + r * FP), v1 = *reinterpret_cast<const uint2*>(p + r * FP + 4), v2 = *reinterpret_cast<const uint2*>(p + r * FP + 8);
+    E[0] = v0.x; E[1] = v0.y; E[2] = v1.x; E[3] = v1.y; E[4] = v2.x; E[5] = v2.y;
 #pragma unroll
-    for (int k = 0; k < 4; k++) { s[k] = v0[k]; s[4 + k] = v1[k]; s[8 + k] = v2[k]; }
+    for (int m = 0; m < 5; m++) O[m] = __builtin_amdgcn_alignbit(E[m + 1], E[m], 16);
 #pragma unroll
     for (int i = 0; i < 4; i++)
     {
       const int dy = r - R - i;
       if (dy < -R || dy > R) continue;
+      const int wid = R - (dy < 0 ? -dy : dy);
 #pragma unroll
-      for (int dx = -R; dx <= R; dx++)
+      for (int q = 0; q <= R; q++)
       {
-        const int k = tapIndex<IS7>(dy, dx);
-        if (k < 0) continue;
+        const int dx0 = -wid + 2 * q;
+        if (dx0 > wid) continue;
+        const s2v cp = __builtin_bit_cast(s2v, cpk[dy + R][q]);
 #pragma unroll
-        for (int j = 0; j < 4; j++) acc[i][j] += f[k] * s[4 + j + dx];
+        for (int j = 0; j < 4; j++)
+        {
+          const int idx = 4 + j + dx0;                  // first sample of the pair
+          const unsigned sp = (idx & 1) ? O[(idx - 1) >> 1] : E[idx >> 1];
+          acc[i][j] = __builtin_amdgcn_sdot2(__builtin_bit_cast(s2v, sp), cp, acc[i][j], false);
+        }
       }
     }
   }
