@@ -221,9 +221,16 @@ def dry_launch(args):
     planes = [torch.full((8, 8), rank, dtype=torch.int16), torch.full((4, 4), rank + 100, dtype=torch.int16)]
     rec = shard.empty_side_record()
     rec["sub_merge_blk_num"][0, 3] = 1000 + rank
-    got, grec = shard.exchange_boundary(planes, rank, world, record=rec, return_record=True)
+    # the form the RCCL run takes: ONE grouped batch_isend_irecv per hand-over (forced on gloo here), nothing posted early
+    h = shard.Handover(planes, rank, world, batched=True).post_recv()
+    early = list(h.issued)
+    got, grec = h.send(planes, rec).wait()
     ok = int(got[0][0, 0]) == (rank - 1) % world and int(got[1][0, 0]) == (rank - 1) % world + 100
     ok = ok and (world == 1 or int(grec["sub_merge_blk_num"][0, 3]) == 1000 + (rank - 1) % world)
+    ok = ok and early == [] and (world == 1 or h.issued == [("batch", 6)])
+    # and the plain gloo form (receives posted at chunk start) gives the same picture
+    got2 = shard.exchange_boundary(planes, rank, world, record=rec)
+    ok = ok and bool((got2[0] == got[0]).all())
     seen = [None] * world
     if world > 1:
         dist.all_gather_object(seen, (rank, ok))
@@ -231,7 +238,8 @@ def dry_launch(args):
     else:
         seen = [(rank, ok)]
     if rank == 0:
-        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_seen": sorted(r for r, _ in seen), "handover_ok": all(o for _, o in seen)}))
+        print(json.dumps({"dry_launch": True, "n_gpus": world, "ranks_seen": sorted(r for r, _ in seen), "handover_ok": all(o for _, o in seen),
+                          "p2p": "one batch_isend_irecv per hand-over"}))
 
 
 def main():
@@ -318,26 +326,29 @@ def main():
 
     pending = [None]
 
-    def one_step(tm):
-        """one intra period: pps pictures, then the chunk hand-over (next rank's reference picture + the 88-byte side record; own picture at N = 1).
-        Asynchronous: the receives from rank r - 1 are posted when the chunk starts, the sends when the boundary picture exists, and the wait comes
-        only where the NEXT chunk first needs the picture (its reference slot is installed in front of its first picture) -- a rank never waits for
-        its neighbour at a step boundary."""
-        nonlocal state, out
-        if pending[0] is not None:                          # the hand-over of the chunk before: needed now
-            boundary, _rec = pending[0].wait()
-            shard.install_reference(boundary, state["ref1"], wl.margins())
-        h = shard.Handover(out["final"], rank, world).post_recv()
-        for _ in range(pps):
-            state, out = wl.run_gpu(state, tm, overlap=overlap, alone=alone)
-        h.send(out["final"], shard.empty_side_record())     # (the kernels carry no encoder statistics: the record of a fresh encoder travels)
-        pending[0] = h
-
-    def finish_steps():
+    def install_pending():
+        """in front of the first motion compensation that reads the boundary picture: the current (main) stream waits for the transfer, then the
+        picture is copied into the padded reference slot and border-extended on the device"""
         if pending[0] is not None:
             boundary, _rec = pending[0].wait()
             shard.install_reference(boundary, state["ref1"], wl.margins())
             pending[0] = None
+
+    def one_step(tm):
+        """one intra period: pps pictures, then the chunk hand-over (next rank's reference picture + the 88-byte side record; own picture at N = 1).
+        The receive from rank r - 1 and the send to rank r + 1 are issued as ONE grouped RCCL operation when the boundary picture exists
+        (shard.Handover: no unbatched point-to-point on the eagerly initialised group); the wait comes only where the NEXT chunk first needs the
+        picture -- in front of the motion compensation of its first picture, behind that picture's searches -- so a rank never waits at a step boundary."""
+        nonlocal state, out
+        h = shard.Handover(out["final"], rank, world).post_recv()
+        for i in range(pps):
+            state, out = wl.run_gpu(state, tm, overlap=overlap, alone=alone, pre_mc=install_pending if i == 0 else None)
+        install_pending()                                   # (pps == 0 guard; a no-op otherwise)
+        h.send(out["final"], shard.empty_side_record())     # (the kernels carry no encoder statistics: the record of a fresh encoder travels)
+        pending[0] = h
+
+    def finish_steps():
+        install_pending()
 
     for _ in range(args.warmup):
         one_step(None)

@@ -1,0 +1,87 @@
+#!/usr/bin/env python3
+"""Captures the deblocking fixtures from the COMPILED REFERENCE (CPU only, shim disabled; build container only): the reference encoder runs on
+synthetic clips with VVCGPU_DEBLOCK_DUMP set, and the harness' loopFilterPic hook (vvcsoftware_vtm_amd/shim/vtm_hip_shim.cpp:dumpDeblock) writes,
+for every picture, the planes in front of LoopFilter::loopFilterPic, the (edge, BS) and QP maps recorded from the reference's OWN xDeblockCU walk
+(oracle/ref_hooks.cpp pre-empts xEdgeFilterLuma / xEdgeFilterChroma for that walk), the slice / PPS parameters, and the planes behind the
+reference's OWN second, unhooked loopFilterPic (LoopFilter.cpp:149-230, 543-980).
+
+Kept in tests/golden/deblock.npz:
+  * from a 17-picture random-access encode (GOP 16, 128x128 CTUs, affine, 416x240 10 bit): the inter picture with the most affine CUs and the one
+    with the most CUs wider / taller than 64 samples (transform-edge splits at 64, LoopFilter.cpp:326-343);
+  * one 1920x1080 10-bit intra picture (dual tree: separate luma / chroma walks).
+The planes behind the filter are stored as (post - pre) in int8 where it fits (deblocking moves a sample by a few units), the planes in front as
+int16; np.savez_compressed."""
+import os
+import struct
+import subprocess
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+from vvcsoftware_vtm_amd import synth  # noqa: E402
+
+APP = os.path.join(ROOT, "oracle", "_ref", "vtmref_app")
+HDR = ["magic", "poc", "w", "h", "bd_luma", "bd_chroma", "beta_offset_div2", "tc_offset_div2", "cb_qp_offset", "cr_qp_offset",
+       "clp_min0", "clp_min1", "clp_min2", "clp_max0", "clp_max1", "clp_max2", "disabled", "slice_type", "n_cu", "n_cu_gt64", "n_affine", "dual_tree",
+       "r0", "r1"]
+
+
+def capture(name, cfg, w, h, bd, frames, qp, seed, extra=()):
+    yuv, dump = "/tmp/dbk_%s.yuv" % name, "/tmp/dbk_%s.bin" % name
+    if os.path.exists(dump):
+        os.remove(dump)
+    synth.write_yuv(yuv, synth.gen_yuv(w, h, frames, bd, seed), bd)
+    env = dict(os.environ, VVCGPU_SHIM="0", VVCGPU_DEBLOCK_DUMP=dump)
+    subprocess.check_call([APP, "--hip", "enc", "-c", os.path.join(ROOT, cfg), "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30", "-f", str(frames),
+                           "-q", str(qp), "--InputBitDepth=%d" % bd, "--InternalBitDepth=%d" % bd, "--OutputBitDepth=%d" % bd, "-b", "/tmp/dbk_%s.vvc" % name,
+                           "-o", "/dev/null"] + list(extra), env=env, stdout=subprocess.DEVNULL)
+    data = open(dump, "rb").read()
+    pos, recs = 0, []
+    while pos < len(data):
+        hdr = dict(zip(HDR, struct.unpack_from("<24i", data, pos)))
+        pos += 96
+        assert hdr["magic"] == 0x314b4244
+        W, H = hdr["w"], hdr["h"]
+        n4 = (W // 4) * (H // 4)
+        r = {"hdr": hdr}
+        for k, dt in (("ev", "u1"), ("eh", "u1"), ("qp_luma", "i1"), ("qp_chroma", "i1")):
+            r[k] = np.frombuffer(data, dt, n4, pos).reshape(H // 4, W // 4).copy()
+            pos += n4
+        for grp in ("pre", "post"):
+            for c, (ww, hh) in enumerate(((W, H), (W // 2, H // 2), (W // 2, H // 2))):
+                r["%s%d" % (grp, c)] = np.frombuffer(data, "<i2", ww * hh, pos).reshape(hh, ww).copy()
+                pos += 2 * ww * hh
+        recs.append(r)
+    return recs
+
+
+def main():
+    ra = capture("ra", "tests/golden/bitstreams/test_ra_gop16.cfg", 416, 240, 10, 17, 32, 20261012)
+    inter = [r for r in ra if r["hdr"]["slice_type"] != 2]
+    pick = [max(inter, key=lambda r: r["hdr"]["n_affine"]), max(inter, key=lambda r: (r["hdr"]["n_cu_gt64"], -r["hdr"]["poc"]))]
+    if pick[0] is pick[1]:
+        pick[1] = sorted(inter, key=lambda r: (r["hdr"]["n_cu_gt64"], -r["hdr"]["poc"]))[-2]
+    ai = capture("ai1080", "tests/golden/bitstreams/test_intra.cfg", 1920, 1080, 10, 1, 37, 20261021)
+    pick.append(ai[0])
+    out = {"n": np.int32(len(pick)), "hdr_fields": np.array(HDR)}
+    for i, r in enumerate(pick):
+        out["hdr%d" % i] = np.array([r["hdr"][k] for k in HDR], np.int32)
+        for k in ("ev", "eh", "qp_luma", "qp_chroma", "pre0", "pre1", "pre2"):
+            out["%s_%d" % (k, i)] = r[k]
+        for c in range(3):
+            d = r["post%d" % c].astype(np.int32) - r["pre%d" % c].astype(np.int32)
+            out["delta%d_%d" % (c, i)] = d.astype(np.int8) if np.abs(d).max() < 128 else d.astype(np.int16)
+        print("picture %d: poc %d %dx%d slice type %d, %d CUs (%d > 64, %d affine), dual tree %d, %d / %d filtered vertical / horizontal 4x4 edge units, "
+              "%d luma samples changed" % (i, r["hdr"]["poc"], r["hdr"]["w"], r["hdr"]["h"], r["hdr"]["slice_type"], r["hdr"]["n_cu"], r["hdr"]["n_cu_gt64"],
+                                           r["hdr"]["n_affine"], r["hdr"]["dual_tree"], int((r["ev"] != 0).sum()), int((r["eh"] != 0).sum()),
+                                           int((r["post0"] != r["pre0"]).sum())))
+    path = os.path.join(HERE, "deblock.npz")
+    np.savez_compressed(path, **out)
+    print("deblock.npz", os.path.getsize(path), "bytes")
+
+
+if __name__ == "__main__":
+    main()

@@ -50,9 +50,16 @@ def _worker(rank, world, port, q):
     prev_last_poc = shard.chunk_assignment(n_pictures, world)[(rank - 1) % world][-1][1] - 1
     ok = int(got[0][0, 0]) == prev_last_poc and int(got[1][0, 0]) == prev_last_poc + 1
     ok = ok and int(grec["sub_merge_blk_size"][0, 2]) == 7000 + (rank - 1) % world and int(grec["prev_poc"][0]) == prev_last_poc
+    ok = ok and h.issued == [("irecv", 1)] * 3 + [("isend", 1)] * 3
     # the synchronous wrapper gives the same picture
     got2 = shard.exchange_boundary(last, rank, world)
     ok = ok and bool((got2[0] == got[0]).all())
+    # the RCCL form on gloo: nothing posted early, ONE grouped operation (3 receives + 3 sends) when the boundary picture exists
+    hb = shard.Handover(last, rank, world, batched=True).post_recv()
+    ok = ok and hb.issued == []
+    got3, grec3 = hb.send(last, rec).wait()
+    ok = ok and hb.issued == [("batch", 6)] and bool((got3[0] == got[0]).all()) and bool((got3[1] == got[1]).all())
+    ok = ok and grec3.tobytes() == grec.tobytes()
     merged = shard.gather_hashes(hashes, world)
     dist.barrier()
     if rank == 0:
@@ -121,7 +128,7 @@ def test_bench_gpus2_starts_two_ranks_by_itself():
     --dry-launch keeps the ranks on gloo/CPU: both join, the world size is checked, a boundary picture goes round the ring."""
     rc, res, err = _run_bench(["--gpus", "2", "--dry-launch"])
     assert rc == 0, err
-    assert res == {"dry_launch": True, "n_gpus": 2, "ranks_seen": [0, 1], "handover_ok": True}
+    assert res == {"dry_launch": True, "n_gpus": 2, "ranks_seen": [0, 1], "handover_ok": True, "p2p": "one batch_isend_irecv per hand-over"}
 
 
 def test_bench_refuses_a_world_that_is_not_gpus():
@@ -130,3 +137,48 @@ def test_bench_refuses_a_world_that_is_not_gpus():
     assert rc != 0 and res is None and "--gpus 2" in err
     rc, res, err = _run_bench(["--gpus", "4"], {"WORLD_SIZE": "2", "RANK": "0", "LOCAL_RANK": "0"})
     assert rc != 0 and res is None and "WORLD_SIZE is 2" in err
+
+
+def test_no_unbatched_p2p_on_rccl(monkeypatch):
+    """On an RCCL group initialised with `device_id=` unbatched point-to-point operations are serialised with everything else on the communicator:
+    a receive posted at chunk start would sit in front of the rank's own send on every rank of the ring.  `shard.Handover` must therefore reach the
+    backend through ONE dist.batch_isend_irecv per hand-over and never through dist.isend / dist.irecv -- checked here with the backend reported as
+    nccl and the three entry points replaced by recorders (no GPU needed)."""
+    sys.path.insert(0, ROOT)
+    from vvcsoftware_vtm_amd import shard
+    calls = []
+
+    class _Work:
+        def wait(self):
+            calls.append("wait")
+
+    monkeypatch.setattr(shard, "_backend", lambda group=None: "nccl")
+    monkeypatch.setattr(dist, "isend", lambda *a, **k: (_ for _ in ()).throw(AssertionError("unbatched isend on RCCL")))
+    monkeypatch.setattr(dist, "irecv", lambda *a, **k: (_ for _ in ()).throw(AssertionError("unbatched irecv on RCCL")))
+
+    def batch(ops):
+        calls.append(("batch", [(o.op.__name__ if hasattr(o.op, "__name__") else "op", o.peer) for o in ops]))
+        return [_Work()]
+
+    class _Op:
+        def __init__(self, op, tensor, peer, group=None):
+            self.op, self.tensor, self.peer = op, tensor, peer
+
+    monkeypatch.setattr(dist, "P2POp", _Op)
+    monkeypatch.setattr(dist, "batch_isend_irecv", batch)
+    planes = [torch.zeros((8, 8), dtype=torch.int16), torch.zeros((4, 4), dtype=torch.int16), torch.zeros((4, 4), dtype=torch.int16)]
+    for world, rank in ((2, 0), (2, 1), (8, 3)):
+        calls.clear()
+        h = shard.Handover(planes, rank, world).post_recv()
+        assert calls == [] and h.batched
+        h.send(planes, shard.empty_side_record())
+        assert len(calls) == 1 and calls[0][0] == "batch"
+        peers = [p for _, p in calls[0][1]]
+        assert peers == [(rank - 1) % world] * 4 + [(rank + 1) % world] * 4          # receives first, then sends: one group
+        h.wait()
+        assert calls[-1] == "wait"
+    # asking for the unbatched form on RCCL is refused outright
+    with pytest.raises(RuntimeError):
+        shard.Handover(planes, 0, 2, batched=False)
+    with pytest.raises(RuntimeError):
+        shard._unbatched(dist.irecv, planes[0], 1)

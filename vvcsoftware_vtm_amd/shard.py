@@ -1,6 +1,6 @@
 """Multi-GPU partitioning of the hot path: random-access intra periods are self-contained, so rank r
 processes the pictures of intra periods r, r+world, ...; the only data-path exchange is ONE reconstructed boundary
-(CRA) picture per chunk hand-over, point-to-point (RCCL send/recv over one xGMI link; gloo in the CPU tests).
+(CRA) picture per chunk hand-over, point-to-point (one grouped RCCL send/recv per hand-over over one xGMI link; gloo in the CPU tests).
 No all-reduce / ring collective exists anywhere on the path."""
 import hashlib
 
@@ -44,58 +44,109 @@ def boundary_owner(chunk_index, world):
     return chunk_index % world
 
 
-class Handover:
-    """One chunk hand-over in flight: the receives from rank r - 1 are posted when the chunk STARTS (`post_recv`), the sends to rank r + 1 when the
-    boundary picture exists (`send`), and `wait` is called only in front of the first use of the received picture (the first motion compensation of
-    the next chunk) -- a rank never waits for its neighbour at a step boundary, only for data it is about to read.  The side record travels with
-    the planes.  world == 1: the picture is handed to the rank itself without any communication."""
+def _backend(group=None):
+    return str(dist.get_backend(group)).lower() if dist.is_available() and dist.is_initialized() else None
 
-    def __init__(self, like_planes, rank, world, with_record=True):
+
+def _unbatched(op, tensor, peer, group=None):
+    """dist.isend / dist.irecv as single operations -- gloo only.  On an RCCL group (initialised with `device_id=`, i.e. eagerly) an unbatched
+    point-to-point operation is serialised with every other operation of the communicator: an early receive would sit in front of the rank's own
+    send on every rank of the ring and nobody would ever send.  Refused here so that it cannot come back by accident."""
+    if _backend(group) != "gloo":
+        raise RuntimeError("shard: unbatched %s on backend %r -- point-to-point on RCCL goes through ONE dist.batch_isend_irecv per hand-over"
+                           % (op.__name__, _backend(group)))
+    return op(tensor, peer, group=group)
+
+
+def _wire(t):
+    """the tensor as the backend sees it: RCCL has no 16-bit integer type (ProcessGroupNCCL refuses `Short`), so sample planes travel as the bytes
+    they are -- a uint8 view of the same memory, no copy"""
+    return t if t.dtype == torch.uint8 else t.view(torch.uint8)
+
+
+class Handover:
+    """One chunk hand-over in flight (the exchange unit of the reference's file-based analogue, EncGOP.cpp:1146-1300 DebugBitstream re-entry; the state
+    that travels beside the picture is EncCu.h:119-122, `SIDE_RECORD`).
+
+    `post_recv` at the start of a chunk prepares the receive buffers, `send` is called when the boundary picture exists, `wait` only in front of the
+    first use of the received picture (the first motion compensation of the next chunk: `Workload.run_gpu(pre_mc=...)`) -- a rank never waits at a
+    step boundary, only for data it is about to read.  How the operations reach the backend:
+
+    * RCCL (`nccl`): nothing is posted early.  `send` issues the receives from rank r - 1 and the sends to rank r + 1 of this hand-over as ONE
+      grouped `dist.batch_isend_irecv` (ncclGroupStart .. End): inside a group the communicator's stream order does not put a rank's receive in
+      front of its own send, so the ring cannot wait on itself at any world size (2 included, where both directions share one peer).  The transfer
+      (24.9 MB at 4K, ~0.16 ms on one xGMI link) runs on the communicator's stream behind the kernels that produced the picture and beside the next
+      chunk's searches.
+    * gloo (CPU tests): no stream order exists, the receives are really posted at chunk start and the sends are single operations.
+      `batched=True` forces the grouped form on gloo too, so the CPU tests walk the code path RCCL takes.
+
+    world == 1: the picture is handed to the rank itself without communication -- unless `loopback` is set, which sends it to rank 0 itself through
+    the backend (RCCL accepts a grouped send + receive to the own rank): the one-GPU test of the tensor / stream handling of the N > 1 path.
+    The side record travels with the planes."""
+
+    def __init__(self, like_planes, rank, world, with_record=True, group=None, batched=None, loopback=False):
         self.rank, self.world = rank, world
         self.recv_planes = None
         self.recv_record = None
         self.reqs = []
         self.like = like_planes
         self.with_record = with_record
+        self.group = group
+        self.comm = world > 1 or loopback
+        self.batched = (_backend(group) != "gloo") if batched is None else bool(batched)
+        if self.comm and not self.batched and _backend(group) != "gloo":
+            raise RuntimeError("shard.Handover: batched=False needs the gloo backend (have %r)" % _backend(group))
+        self.issued = []                                  # what went to the backend, in order: ("batch", n_ops) | ("irecv", 1) | ("isend", 1)
 
     def post_recv(self):
-        if self.world == 1:
+        if not self.comm:
             return self
         src = (self.rank - 1) % self.world
         self.recv_planes = [torch.empty_like(p) for p in self.like]
-        for q in self.recv_planes:
-            self.reqs.append(dist.irecv(q, src))
         if self.with_record:
             self.recv_record = torch.empty(SIDE_RECORD.itemsize, dtype=torch.uint8, device=self.like[0].device)
-            self.reqs.append(dist.irecv(self.recv_record, src))
+        if not self.batched:
+            for q in self.recv_planes + ([self.recv_record] if self.with_record else []):
+                self.reqs.append(_unbatched(dist.irecv, _wire(q), src, self.group))
+                self.issued.append(("irecv", 1))
         return self
 
     def send(self, planes, record=None):
-        if self.world == 1:
+        if not self.comm:
             self.recv_planes = planes
             self.recv_record = None if record is None else side_record_tensor(record, planes[0].device)
             return self
-        dst = (self.rank + 1) % self.world
-        self._keep = [p.contiguous() for p in planes]                 # alive until the sends complete
-        for p in self._keep:
-            self.reqs.append(dist.isend(p, dst))
+        if self.recv_planes is None:
+            self.post_recv()
+        src, dst = (self.rank - 1) % self.world, (self.rank + 1) % self.world
+        self._keep = [p.contiguous() for p in planes]                 # alive (and unmodified by the caller) until wait()
         if self.with_record:
-            self._rec = side_record_tensor(record if record is not None else empty_side_record(), planes[0].device)
-            self.reqs.append(dist.isend(self._rec, dst))
+            self._keep.append(side_record_tensor(record if record is not None else empty_side_record(), planes[0].device))
+        if self.batched:
+            recvs = self.recv_planes + ([self.recv_record] if self.with_record else [])
+            ops = [dist.P2POp(dist.irecv, _wire(q), src, self.group) for q in recvs] + [dist.P2POp(dist.isend, _wire(p), dst, self.group) for p in self._keep]
+            self.reqs += dist.batch_isend_irecv(ops)
+            self.issued.append(("batch", len(ops)))
+        else:
+            for p in self._keep:
+                self.reqs.append(_unbatched(dist.isend, _wire(p), dst, self.group))
+                self.issued.append(("isend", 1))
         return self
 
     def wait(self):
+        """makes the CURRENT stream wait for the transfer (RCCL) / blocks until it is done (gloo); returns (planes, record)"""
         for r in self.reqs:
             r.wait()
         self.reqs = []
+        self._keep = None
         rec = None if self.recv_record is None else side_record_from_tensor(self.recv_record)
         return self.recv_planes, rec
 
 
-def exchange_boundary(planes, rank, world, tag=0, record=None, return_record=False):
+def exchange_boundary(planes, rank, world, tag=0, record=None, return_record=False, batched=None, loopback=False):
     """Ring hand-over of the reconstructed boundary picture (+ the side record): rank r sends to (r+1) % world and receives from (r-1) % world.
     Synchronous form (post, send, wait in one call); the asynchronous form is `Handover`.  Returns the received planes (and the record when asked)."""
-    h = Handover(planes, rank, world, with_record=True).post_recv().send(planes, record)
+    h = Handover(planes, rank, world, with_record=True, batched=batched, loopback=loopback).post_recv().send(planes, record)
     got, rec = h.wait()
     return (got, rec) if return_record else got
 

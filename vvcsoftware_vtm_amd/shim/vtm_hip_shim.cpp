@@ -353,11 +353,58 @@ extern "C" int vvcshim_edge_filter(LoopFilter* self, const CodingUnit* cuP, int 
 }
 
 namespace {
+// Fixture capture for tests/golden/deblock.npz (tests/golden/gen_deblock.py; CPU only, build container): VVCGPU_DEBLOCK_DUMP=<file> appends, for every
+// picture the reference deblocks, (1) the planes in front of LoopFilter::loopFilterPic, (2) the (edge, BS) maps and QP maps recorded from the
+// reference's OWN xDeblockCU walk -- exactly what vvcgpu_deblock takes inside the drop-in harness -- and the slice / PPS parameters, (3) the planes
+// behind the reference's OWN loopFilterPic (its own xEdgeFilterLuma / xEdgeFilterChroma: the recorder is off for that second walk).
+// Record: int32 hdr[24] = { magic 'DBK1', poc, lumaW, lumaH, bdY, bdC, betaOffDiv2, tcOffDiv2, cbQpOff, crQpOff, clpMin[3], clpMax[3], disabled,
+// sliceType, #CUs, #CUs wider or taller than 64, #affine CUs, dual tree, 0, 0 }, ev[w4 h4] u8, eh[w4 h4] u8, qpY[w4 h4] i8, qpC[w4 h4] i8,
+// pre Y / Cb / Cr (int16, unpadded), post Y / Cb / Cr.
+void dumpDeblock(LoopFilter* self, CodingStructure& cs, const char* path)
+{
+  const PreCalcValues& pcv = *cs.pcv;
+  CHECK(pcv.chrFormat != CHROMA_420, "vvcgpu shim: only 4:2:0");
+  g_rec.w4 = pcv.lumaWidth >> 2; g_rec.h4 = pcv.lumaHeight >> 2;
+  g_rec.ev.assign((size_t)g_rec.w4 * g_rec.h4, 0); g_rec.eh.assign((size_t)g_rec.w4 * g_rec.h4, 0);
+  g_rec.on = true;
+  real_loopFilterPic(self, cs);                  // walk 1: sample filters pre-empted, edges recorded, planes untouched
+  g_rec.on = false;
+  std::vector<int8_t> qy, qc;
+  buildQpMaps(cs, qy, qc);
+  PelUnitBuf rec = cs.getRecoBuf();
+  std::vector<Pel> pre[3], post[3];
+  auto grab = [&](std::vector<Pel> (&dst)[3]) {
+    for (int c = 0; c < 3; c++)
+    {
+      const PelBuf& b = rec.bufs[c];
+      dst[c].resize((size_t)b.width * b.height);
+      for (unsigned y = 0; y < b.height; y++) memcpy(&dst[c][(size_t)y * b.width], b.buf + (size_t)y * b.stride, b.width * sizeof(Pel));
+    }
+  };
+  grab(pre);
+  real_loopFilterPic(self, cs);                  // walk 2: the reference's own sample filters (the slice's disable flag acts inside, per CU)
+  grab(post);
+  int nBig = 0, nAff = 0;
+  for (const CodingUnit* cu : cs.cus) { if (cu->blocks[cu->chType].width > 64 || cu->blocks[cu->chType].height > 64 || (cu->Y().valid() && (cu->Y().width > 64 || cu->Y().height > 64))) nBig++; if (cu->affine) nAff++; }
+  int32_t hdr[24] = { 0x314b4244, cs.slice->getPOC(), (int32_t)pcv.lumaWidth, (int32_t)pcv.lumaHeight, cs.sps->getBitDepth(CHANNEL_TYPE_LUMA), cs.sps->getBitDepth(CHANNEL_TYPE_CHROMA),
+                      cs.slice->getDeblockingFilterBetaOffsetDiv2(), cs.slice->getDeblockingFilterTcOffsetDiv2(), cs.pps->getQpOffset(COMPONENT_Cb), cs.pps->getQpOffset(COMPONENT_Cr),
+                      0, 0, 0, 0, 0, 0, cs.slice->getDeblockingFilterDisable() ? 1 : 0, (int32_t)cs.slice->getSliceType(), (int32_t)cs.cus.size(), nBig, nAff, CS::isDualITree(cs) ? 1 : 0, 0, 0 };
+  for (int c = 0; c < 3; c++) { hdr[10 + c] = cs.slice->clpRng(ComponentID(c)).min; hdr[13 + c] = cs.slice->clpRng(ComponentID(c)).max; }
+  FILE* f = fopen(path, "ab");
+  CHECK(!f, "vvcgpu shim: cannot open VVCGPU_DEBLOCK_DUMP file");
+  fwrite(hdr, sizeof hdr, 1, f);
+  fwrite(g_rec.ev.data(), 1, g_rec.ev.size(), f); fwrite(g_rec.eh.data(), 1, g_rec.eh.size(), f);
+  fwrite(qy.data(), 1, qy.size(), f); fwrite(qc.data(), 1, qc.size(), f);
+  for (int c = 0; c < 3; c++) fwrite(pre[c].data(), sizeof(Pel), pre[c].size(), f);
+  for (int c = 0; c < 3; c++) fwrite(post[c].data(), sizeof(Pel), post[c].size(), f);
+  fclose(f);
+}
 }  // namespace
 
 // ---------------------------------------------------------------------------------------------------------------
 void wrap_loopFilterPic(LoopFilter* self, CodingStructure& cs)
 {
+  if (const char* dump = getenv("VVCGPU_DEBLOCK_DUMP")) { dumpDeblock(self, cs, dump); return; }
   if (!gpuEnabled()) { real_loopFilterPic(self, cs); return; }
   const PreCalcValues& pcv = *cs.pcv;
   CHECK(pcv.chrFormat != CHROMA_420, "vvcgpu shim: only 4:2:0");

@@ -346,7 +346,7 @@ class Workload:
         return [(MARGIN, MARGIN), (MARGIN // 2, MARGIN // 2), (MARGIN // 2, MARGIN // 2)]
 
     # ------------------------------------------------------------------------------------------------------
-    def run_gpu(self, dev_state=None, timer=None, overlap=False, alone=None):
+    def run_gpu(self, dev_state=None, timer=None, overlap=False, alone=None, pre_mc=None):
         """One step on the GPU through ops/C-ABI.  Returns (state, outputs dict of CUDA tensors).
 
         overlap=False: every launch on the current stream, in stage order.
@@ -355,7 +355,9 @@ class Workload:
         side HIP streams beside it; each of these kernels alone leaves SIMDs idle while its workgroups stage their windows /
         tiles, and concurrent kernels fill those gaps.  ONE search launch group runs first and alone on the main stream, so that
         its event-timed duration is a kernel time and not a share of an overlapped interval: `alone` = (block size, grid index)
-        names it (bench.py passes the dominant one); default: the first size's raster search."""
+        names it (bench.py passes the dominant one); default: the first size's raster search.
+        `pre_mc`: called on the main stream right before the motion compensation, the first reader of the second reference picture
+        (bench.py installs the boundary picture of a chunk hand-over there: the searches in front of it do not wait for the transfer)."""
         import torch
         from . import ops
         T = timer or (lambda name: _NullCtx())
@@ -457,6 +459,8 @@ class Workload:
                 with T("frac/frac_refine_16x16"):
                     out["frac"] = ops.frac_refine(st["org"][0], st["ref0"][0], st["frac_blk"], self.frac.size, 16, 16, bd, fmv, True, (0, mx))
         # ---- mc
+        if pre_mc is not None:
+            pre_mc()
         with T("mc/mc_picture"):                  # offsets in the list are relative to the luma planes; the chroma planes follow
             ops.mc_batch(st["ref0"][0], st["ref1"][0], st["pred"][0], st["mc_pic"], self.mc_pic.size, bd, (0, mx))
         # ---- residual / transforms / reconstruction
