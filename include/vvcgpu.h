@@ -43,7 +43,7 @@ int         vvcgpu_set_device(int device);
 /* sizeof() of the parameter structs, for binding self-checks: 0 sao_ctu, 1 deblock_cfg, 2 dist_desc, 3 search_blk,
  * 4 mvcost, 5 search_best, 6 if_desc, 7 mc_desc, 8 pelop_desc, 9 pelop_cfg, 10 tr_desc, 11 frac_blk, 12 frac_result,
  * 13 dqtr_desc, 14 afg_desc, 15 afe_desc, 16 tz_pu, 17 tz_cfg, 18 intra_desc, 19 cclm_desc, 20 intra_fill_desc, 21 imv_pu, 22 imv_result, 23 quant_desc,
- * 24 dq_rates, 25 depquant_desc; -1 for unknown ids.          */
+ * 24 dq_rates, 25 depquant_desc, 26 rdoq_rates, 27 rdoq_desc, 28 intra_satd_desc, 29 affine_iter, 30 me_hier_cfg; -1 for unknown ids.          */
 int         vvcgpu_sizeof(int struct_id);
 
 /* ---- device memory helpers for host-side callers (the reference keeps pictures in host memory; the shim stages them).
@@ -210,6 +210,33 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
                       const vvcgpu_search_blk* blocks, int nblocks, int w, int h, int sub_shift,
                       int dx0, int dy0, int nx, int ny, int sx, int sy, uint32_t* sad_out,
                       const vvcgpu_mvcost* mvcost_host, vvcgpu_search_best* best, void* stream);
+
+/* ---- D1 + D5, hierarchical form: the step-5 raster stage of xTZSearch (InterSearch.cpp:2159-2169) AND the +-dense_range full search of
+ *          xPatternSearch (:1886-1935) for EVERY 16x16, 32x32 and 64x64 block of a regular block grid, in one launch ---------------------------
+ * The blocks of a CU tree that share the displacement grid and the MV predictor: the SAD of a 32x32 / 64x64 block at a displacement is the exact
+ * sum of the SADs of its 16x16 sub-blocks at that displacement (same rows under row sub-sampling), so each 16x16 SAD is computed ONCE and the
+ * larger blocks are sums.  Per block the result equals vvcgpu_sad_search on that block with
+ *   raster: dx0 = dy0 = -5 (raster_range / 5), nx = ny = 2 (raster_range / 5) + 1, sx = sy = 5;   dense: dx0 = dy0 = -dense_range, nx = ny = 2 dense_range + 1,
+ * the same sub_shift and mvcost (cost, arg-min in visiting order, strict '<').
+ * Grid: 16x16 block (i, j), i < n16x, j < n16y, has its origin at (org_x + 16 i, org_y + 16 j) in the original and its zero-vector position at
+ * (ref_x + 16 i, ref_y + 16 j) in the reference plane; 32x32 block (i, j) covers 16x16 blocks (2i .. 2i+1, 2j .. 2j+1), i < n16x / 2, j < n16y / 2
+ * (whole blocks only), 64x64 likewise with 4.  Results: raster_best[0 / 1 / 2] = arrays of n16x n16y / (n16x/2)(n16y/2) / (n16x/4)(n16y/4) records
+ * for the 16 / 32 / 64 blocks, row-major; dense_best[] likewise (NULL with dense_range 0).  Arrays of sizes that have no block may be NULL.
+ * Reads of the reference plane: exactly the samples the per-size searches of the existing blocks read (window of +-5 (raster_range / 5) around
+ * every block).  Preconditions of the kernel: raster_step 5, raster_range <= 99 (39 x 39 positions), dense_range <= 4, sub_shift 0 or 1, org_stride
+ * even, ref_stride a multiple of 8, org 4-byte and ref 16-byte aligned, 0 <= lambda < 4e6; anything else returns VVCGPU_E_UNSUPPORTED (nothing
+ * launched) and the caller takes vvcgpu_sad_search per size.                                                                                  */
+typedef struct vvcgpu_me_hier_cfg {
+  int32_t org_x, org_y;       /* grid origin in the original plane */
+  int32_t ref_x, ref_y;       /* zero-vector position of the grid origin in the reference plane */
+  int32_t n16x, n16y;         /* 16x16 blocks of the grid */
+  int32_t sub_shift;          /* rows step 1 << sub_shift (DistParam::subShift) */
+  int32_t raster_range;       /* iSearchRange of the raster stage */
+  int32_t raster_step;        /* iRaster: 5 */
+  int32_t dense_range;        /* BipredSearchRange of xPatternSearch; 0 = no dense grid */
+} vvcgpu_me_hier_cfg;
+int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride, const vvcgpu_me_hier_cfg* cfg_host,
+                          const vvcgpu_mvcost* mvcost_host, vvcgpu_search_best* const* raster_best, vvcgpu_search_best* const* dense_best, void* stream);
 
 /* ---- I1: interpolation filter table slots, batched  (InterpolationFilter::m_filterHor/m_filterVer[N][isFirst][isLast]
  *          and m_filterCopy[isFirst][isLast], InterpolationFilter.h:84-86; bodies InterpolationFilter.cpp:205-379;

@@ -9,8 +9,9 @@ Kept in tests/golden/deblock.npz:
   * from a 17-picture random-access encode (GOP 16, 128x128 CTUs, affine, 416x240 10 bit): the inter picture with the most affine CUs and the one
     with the most CUs wider / taller than 64 samples (transform-edge splits at 64, LoopFilter.cpp:326-343);
   * one 1920x1080 10-bit intra picture (dual tree: separate luma / chroma walks).
-The planes behind the filter are stored as (post - pre) in int8 where it fits (deblocking moves a sample by a few units), the planes in front as
-int16; np.savez_compressed."""
+The planes behind the filter are stored as (post - pre) in int8 where it fits (deblocking moves a sample by a few units); the planes in front as the
+low / high bytes of their horizontal-then-vertical differences modulo 2^16 (`pack_plane`; tests/cases.py:unpack_plane undoes it with two cumulative
+sums) -- a third smaller after np.savez_compressed than the int16 samples."""
 import os
 import struct
 import subprocess
@@ -29,11 +30,16 @@ HDR = ["magic", "poc", "w", "h", "bd_luma", "bd_chroma", "beta_offset_div2", "tc
        "r0", "r1"]
 
 
-def capture(name, cfg, w, h, bd, frames, qp, seed, extra=()):
+def pack_plane(p):
+    d = np.diff(np.diff(p.astype(np.int64), axis=1, prepend=0), axis=0, prepend=0) & 0xFFFF
+    return (d & 0xFF).astype(np.uint8), (d >> 8).astype(np.uint8)
+
+
+def capture(name, cfg, w, h, bd, frames, qp, seed, extra=(), warp=None, noise=6.0):
     yuv, dump = "/tmp/dbk_%s.yuv" % name, "/tmp/dbk_%s.bin" % name
     if os.path.exists(dump):
         os.remove(dump)
-    synth.write_yuv(yuv, synth.gen_yuv(w, h, frames, bd, seed), bd)
+    synth.write_yuv(yuv, synth.gen_yuv(w, h, frames, bd, seed, warp=warp, noise=noise), bd)
     env = dict(os.environ, VVCGPU_SHIM="0", VVCGPU_DEBLOCK_DUMP=dump)
     subprocess.check_call([APP, "--hip", "enc", "-c", os.path.join(ROOT, cfg), "-i", yuv, "-wdt", str(w), "-hgt", str(h), "-fr", "30", "-f", str(frames),
                            "-q", str(qp), "--InputBitDepth=%d" % bd, "--InternalBitDepth=%d" % bd, "--OutputBitDepth=%d" % bd, "-b", "/tmp/dbk_%s.vvc" % name,
@@ -59,18 +65,21 @@ def capture(name, cfg, w, h, bd, frames, qp, seed, extra=()):
 
 
 def main():
-    ra = capture("ra", "tests/golden/bitstreams/test_ra_gop16.cfg", 416, 240, 10, 17, 32, 20261012)
+    # rotating + zooming content with little noise: the encoder's affine tools win CUs (their 4x4 sub-block edges enter the walk, LoopFilter.cpp:268-284)
+    ra = capture("ra", "tests/golden/bitstreams/test_ra_gop16.cfg", 416, 240, 10, 17, 32, 20261012, warp=(0.35, 1.004), noise=1.5)
     inter = [r for r in ra if r["hdr"]["slice_type"] != 2]
     pick = [max(inter, key=lambda r: r["hdr"]["n_affine"]), max(inter, key=lambda r: (r["hdr"]["n_cu_gt64"], -r["hdr"]["poc"]))]
     if pick[0] is pick[1]:
         pick[1] = sorted(inter, key=lambda r: (r["hdr"]["n_cu_gt64"], -r["hdr"]["poc"]))[-2]
-    ai = capture("ai1080", "tests/golden/bitstreams/test_intra.cfg", 1920, 1080, 10, 1, 37, 20261021)
+    ai = capture("ai1080", "tests/golden/bitstreams/test_intra.cfg", 1920, 1080, 10, 1, 42, 20261021)
     pick.append(ai[0])
     out = {"n": np.int32(len(pick)), "hdr_fields": np.array(HDR)}
     for i, r in enumerate(pick):
         out["hdr%d" % i] = np.array([r["hdr"][k] for k in HDR], np.int32)
-        for k in ("ev", "eh", "qp_luma", "qp_chroma", "pre0", "pre1", "pre2"):
+        for k in ("ev", "eh", "qp_luma", "qp_chroma"):
             out["%s_%d" % (k, i)] = r[k]
+        for c in range(3):
+            out["pre%d_lo_%d" % (c, i)], out["pre%d_hi_%d" % (c, i)] = pack_plane(r["pre%d" % c])
         for c in range(3):
             d = r["post%d" % c].astype(np.int32) - r["pre%d" % c].astype(np.int32)
             out["delta%d_%d" % (c, i)] = d.astype(np.int8) if np.abs(d).max() < 128 else d.astype(np.int16)

@@ -1,0 +1,50 @@
+#!/usr/bin/env python3
+"""4K timing: the hierarchical search (one launch, every 16x16 SAD once) against the six per-size searches it replaces (GPU box)."""
+import sys, os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+import torch
+from vvcsoftware_vtm_amd import ops
+from vvcsoftware_vtm_amd.workload import Workload, MARGIN
+
+W, H = (int(sys.argv[1]), int(sys.argv[2])) if len(sys.argv) > 2 else (3840, 2160)
+wl = Workload(W, H, 10)
+d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+org, ref = d(wl.org[0]), d(wl.ref0_pad[0])
+mv = ops.MvCost(wl.mvcost.lambda_, 0, 0, 2, 0)
+blks = {s: ops.struct_to_device(b) for s, b in wl.me.items()}
+
+
+def timeit(fn, reps=20):
+    for _ in range(3):
+        fn()
+    torch.cuda.synchronize()
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        fn()
+    b.record()
+    torch.cuda.synchronize()
+    return a.elapsed_time(b) / reps * 1e3
+
+
+def per_size():
+    out = {}
+    for s in (16, 32, 64):
+        out[(s, 39)] = ops.sad_search(org, ref, blks[s], wl.me[s].size, s, s, 1, -95, -95, 39, 39, 5, 5, mv, want_sad=False)[1]
+        out[(s, 9)] = ops.sad_search(org, ref, blks[s], wl.me[s].size, s, s, 1, -4, -4, 9, 9, 1, 1, mv, want_sad=False)[1]
+    return out
+
+
+def hier(dense=4):
+    return ops.me_hier_search(org, ref, (0, 0), (MARGIN, MARGIN), W // 16, H // 16, 1, 96, dense, mv)
+
+
+want = per_size()
+r, dn = hier()
+torch.cuda.synchronize()
+for k, s in enumerate((16, 32, 64)):
+    print("equal raster %d: %s   dense: %s" % (s, torch.equal(r[k], want[(s, 39)]), torch.equal(dn[k], want[(s, 9)])))
+print("per-size searches (6 launch groups): %.1f us" % timeit(per_size))
+print("hierarchical, raster + dense       : %.1f us" % timeit(hier))
+print("hierarchical, raster only          : %.1f us" % timeit(lambda: hier(0)))

@@ -17,6 +17,7 @@
 //     one lane = one search position, the org pairs are LDS broadcasts.
 #include "common.h"
 #include "dist_dev.h"
+#include "raster_dev.h"
 
 namespace {
 
@@ -183,13 +184,6 @@ __device__ __forceinline__ void fill_window_pairs(unsigned* __restrict__ lds, co
 #pragma unroll
     for (int u = 0; u < FB; u++) if (idx[u] >= 0) lds[idx[u]] = v[u] ^ 0x80008000u;
   }
-}
-
-__device__ __forceinline__ unsigned expgolomb_bits(int v)        // RdCost.h:172-184
-{
-  unsigned len = 1, t = (v <= 0) ? ((unsigned)(-v) << 1) + 1 : (unsigned)(v << 1);
-  while (t > 128u) { len += 14; t >>= 7; }
-  return len + ((31 - __clz((int)t)) << 1);
 }
 
 constexpr int SS_THREADS = 512;
@@ -447,31 +441,6 @@ __device__ __forceinline__ void r5c_compute(const R5cStage& st, unsigned& acc0, 
   }
 }
 
-// minimum of a 32-bit value over the wavefront with DPP row operations (no LDS traffic, 6 VALU); the result is wave-uniform
-__device__ __forceinline__ unsigned wave_min_u32(unsigned v)
-{
-#define WMIN_STEP(CTRL, ROWMASK) v = min(v, (unsigned)__builtin_amdgcn_update_dpp(-1, (int)v, CTRL, ROWMASK, 0xF, false))
-  WMIN_STEP(0xB1, 0xF);      // quad_perm [1,0,3,2]
-  WMIN_STEP(0x4E, 0xF);      // quad_perm [2,3,0,1]
-  WMIN_STEP(0x141, 0xF);     // row_half_mirror
-  WMIN_STEP(0x140, 0xF);     // row_mirror: every lane of a 16-lane row holds the row's minimum
-  WMIN_STEP(0x142, 0xA);     // row_bcast15 into rows 1 and 3
-  WMIN_STEP(0x143, 0xC);     // row_bcast31 into rows 2 and 3: lane 63 holds the minimum of all four rows
-#undef WMIN_STEP
-  return (unsigned)__builtin_amdgcn_readlane((int)v, 63);
-}
-// 64-bit minimum as two 32-bit passes: the high words first, then the low words of the lanes that hold the minimal high word
-__device__ __forceinline__ unsigned long long wave_min_u64(unsigned long long k)
-{
-  const unsigned hi = (unsigned)(k >> 32), lo = (unsigned)k;
-  const unsigned hmin = wave_min_u32(hi);
-  const unsigned lmin = wave_min_u32(hi == hmin ? lo : 0xFFFFFFFFu);
-  return ((unsigned long long)hmin << 32) | lmin;
-}
-
-#define R5C_COST_N 132                                            /* expgolomb_bits <= 65 per component */
-#define R5C_WAIT_LGKM0() __builtin_amdgcn_s_waitcnt(0xC07F)       /* lgkmcnt(0), vmcnt/expcnt untouched */
-
 // walks the hs x CH chunk-rows of the block, one stage = two chunk-rows at a time: oOff = dword offset of the current chunk-row of the packed org
 // (8 dwords per chunk-row, rows without a gap), lOff = byte offset of the current chunk-row in the window
 struct R5cCursor { unsigned oOff; unsigned lOff; int ch; };
@@ -517,37 +486,6 @@ __device__ __forceinline__ void r5c_positions(const unsigned* __restrict__ orgDw
     if (s + 2 < nStages) r5c_issue<OA, CH1>(A, orgDw, base, cur, CH, ldsStepB, lRowB);
     __builtin_amdgcn_sched_barrier(0);
     r5c_compute<OA>(B, acc0, acc1);
-  }
-}
-
-// window fill for r5c: thread = (row r0, quad q), walking down the rows with a constant stride so that the addressing per
-// 16-byte load is one add for the global offset and one for the LDS index; FB loads in flight.
-template <int FB>
-__device__ __forceinline__ void fill_window_cols(unsigned* __restrict__ lds, const uint4* __restrict__ g, int rsQ, int winRows,
-                                                 int pitchDw, int nQuads, int tid, int nthreads)
-{
-  const int r0 = (int)(((float)tid + 0.5f) * __frcp_rn((float)nQuads));   // tid / nQuads (tid < 1024, nQuads < 1024: exact)
-  const int q = tid - r0 * nQuads;
-  const int R = nthreads / nQuads;                                         // rows per pass; threads beyond R * nQuads idle
-  if (r0 >= R) return;
-  unsigned goff = (unsigned)(r0 * rsQ + q);
-  unsigned loff = (unsigned)(r0 * pitchDw + 4 * q);
-  const unsigned gstep = (unsigned)(R * rsQ), lstep = (unsigned)(R * pitchDw);
-  for (int r = r0; r < winRows; r += FB * R)
-  {
-    uint4 v[FB];
-#pragma unroll
-    for (int u = 0; u < FB; u++)
-      if (r + u * R < winRows) v[u] = g[goff + u * gstep];
-#pragma unroll
-    for (int u = 0; u < FB; u++)
-      if (r + u * R < winRows)
-      {
-        uint2* d = reinterpret_cast<uint2*>(lds + loff + u * lstep);       // pitch is even: 8-byte aligned
-        d[0] = make_uint2(v[u].x ^ 0x80008000u, v[u].y ^ 0x80008000u);
-        d[1] = make_uint2(v[u].z ^ 0x80008000u, v[u].w ^ 0x80008000u);
-      }
-    goff += FB * gstep; loff += FB * lstep;
   }
 }
 
@@ -757,93 +695,6 @@ __global__ __launch_bounds__(MAXT, MINW) void sad_raster5c_kernel(const unsigned
 // Measured (profiles/r02_raster_parts.txt): equal to the pair form for 32-wide blocks, 4 % faster for 64-wide ones -- with the window staging
 // taken out the SAD loop alone is 90 % of the kernel time and its executed vector instructions (v_sad_u16 incl. lane / row / column padding
 // + 28 % moves and merges) x 4.4 cycles account for that time: the loop is bound by the VOP3 issue rate, not by LDS.
-struct R5qStage { unsigned ovE[8], ovO[8]; unsigned long long d[8]; unsigned x1; };
-
-template <int OA>
-__device__ __forceinline__ void r5q_issue(R5qStage& st, const unsigned* __restrict__ op, unsigned a)
-{
-#pragma unroll
-  for (int k = 0; k < 8; k++) { st.ovE[k] = op[k]; st.ovO[k] = op[8 + k]; }        // wave-uniform: one 64-byte scalar load
-  // words 0..7 of the span (dwords 0..15); OA >= 2 also needs dword 16.  Single ds_read_b64 on purpose (see r5c_issue_row).
-  if (OA < 2)
-  {
-    unsigned dummy;
-    asm volatile("ds_read_b64 %0, %9\n\tds_read_b64 %1, %9 offset:8\n\tds_read_b64 %2, %9 offset:16\n\tds_read_b64 %3, %9 offset:24\n\t"
-                 "ds_read_b64 %4, %9 offset:32\n\tds_read_b64 %5, %9 offset:40\n\tds_read_b64 %6, %9 offset:48\n\tds_read_b64 %7, %9 offset:56"
-                 : "=&v"(st.d[0]), "=&v"(st.d[1]), "=&v"(st.d[2]), "=&v"(st.d[3]), "=&v"(st.d[4]), "=&v"(st.d[5]), "=&v"(st.d[6]), "=&v"(st.d[7]), "=&v"(dummy)
-                 : "v"(a) : "memory");
-  }
-  else
-    asm volatile("ds_read_b64 %0, %9\n\tds_read_b64 %1, %9 offset:8\n\tds_read_b64 %2, %9 offset:16\n\tds_read_b64 %3, %9 offset:24\n\t"
-                 "ds_read_b64 %4, %9 offset:32\n\tds_read_b64 %5, %9 offset:40\n\tds_read_b64 %6, %9 offset:48\n\tds_read_b64 %7, %9 offset:56\n\t"
-                 "ds_read_b32 %8, %9 offset:64"
-                 : "=&v"(st.d[0]), "=&v"(st.d[1]), "=&v"(st.d[2]), "=&v"(st.d[3]), "=&v"(st.d[4]), "=&v"(st.d[5]), "=&v"(st.d[6]), "=&v"(st.d[7]), "=&v"(st.x1)
-                 : "v"(a) : "memory");
-}
-
-// position m of the lane starts OA + 5 m samples into the span: dword I = (OA + 5 m) >> 1, parity P = (OA + 5 m) & 1
-template <int OA>
-__device__ __forceinline__ void r5q_compute(const R5qStage& st, unsigned (&acc)[4])
-{
-  unsigned dd[17];
-#pragma unroll
-  for (int k = 0; k < 8; k++)
-  {
-    asm volatile("" :: "v"(st.d[k]));                     // whole 64-bit destination stays allocated until here
-    dd[2 * k] = (unsigned)st.d[k]; dd[2 * k + 1] = (unsigned)(st.d[k] >> 32);
-  }
-  if (OA >= 2) { asm volatile("" :: "v"(st.x1)); dd[16] = st.x1; } else dd[16] = 0u;
-#pragma unroll
-  for (int m = 0; m < 4; m++)
-  {
-    constexpr int dummy = 0; (void)dummy;
-    const int s = OA + 5 * m, I = s >> 1;
-    if (s & 1)
-    {
-#pragma unroll
-      for (int k = 0; k < 7; k++) acc[m] = __builtin_amdgcn_sad_u16(st.ovO[k], dd[I + 1 + k], acc[m]);
-      acc[m] = __builtin_amdgcn_sad_u16(st.ovO[7], (dd[I + 8] & 0xFFFFu) | (dd[I] & 0xFFFF0000u), acc[m]);
-    }
-    else
-    {
-#pragma unroll
-      for (int k = 0; k < 8; k++) acc[m] = __builtin_amdgcn_sad_u16(st.ovE[k], dd[I + k], acc[m]);
-    }
-  }
-}
-
-// walks nStages chunk-rows starting at chunk-row cr0 of the block (CH chunks per row)
-template <int OA>
-__device__ __forceinline__ void r5q_positions(const unsigned* __restrict__ orgQ, unsigned base, int ldsStep, int CH,
-                                              int cr0, int nStages, unsigned (&acc)[4])
-{
-  R5qStage A, B;
-  const int chShift = 31 - __clz(CH);
-  int ch = cr0 & (CH - 1);
-  unsigned oOff = (unsigned)cr0 * 16u;
-  unsigned lOff = (unsigned)((cr0 >> chShift) * ldsStep + ch * 8) * 4u;
-  const unsigned rowAdv = (unsigned)(ldsStep - 8 * (CH - 1)) * 4u;          // from the last chunk of a row to the first of the next sampled row
-  auto issue = [&](R5qStage& st)
-  {
-    r5q_issue<OA>(st, orgQ + oOff, base + lOff);
-    oOff += 16u; ch++;
-    if (ch == CH) { ch = 0; lOff += rowAdv; } else lOff += 32u;
-  };
-  issue(A);
-  for (int s = 0; s < nStages; s += 2)
-  {
-    R5C_WAIT_LGKM0();
-    if (s + 1 < nStages) issue(B);
-    __builtin_amdgcn_sched_barrier(0);
-    r5q_compute<OA>(A, acc);
-    if (s + 1 >= nStages) break;
-    R5C_WAIT_LGKM0();
-    if (s + 2 < nStages) issue(A);
-    __builtin_amdgcn_sched_barrier(0);
-    r5q_compute<OA>(B, acc);
-  }
-}
-
 template <int MAXT, int MINW, int SPLIT>
 __global__ __launch_bounds__(MAXT, MINW) void sad_raster5q_kernel(const unsigned* __restrict__ orgPacked,
                                                            const Pel* __restrict__ ref, int rs,

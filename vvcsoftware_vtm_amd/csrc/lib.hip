@@ -157,6 +157,7 @@ int vvcgpu_sizeof(int id)
   case 27: return (int)sizeof(vvcgpu_rdoq_desc);
   case 28: return (int)sizeof(vvcgpu_intra_satd_desc);
   case 29: return (int)sizeof(vvcgpu_affine_iter);
+  case 30: return (int)sizeof(vvcgpu_me_hier_cfg);
   default: return -1;
   }
 }

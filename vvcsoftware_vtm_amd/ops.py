@@ -166,6 +166,26 @@ def sad_search(org, ref, blocks_dev, nblocks, w, h, sub_shift, dx0, dy0, nx, ny,
     return sad, best
 
 
+class MeHierCfg(C.Structure):
+    _fields_ = [("org_x", C.c_int32), ("org_y", C.c_int32), ("ref_x", C.c_int32), ("ref_y", C.c_int32), ("n16x", C.c_int32), ("n16y", C.c_int32),
+                ("sub_shift", C.c_int32), ("raster_range", C.c_int32), ("raster_step", C.c_int32), ("dense_range", C.c_int32)]
+
+
+def me_hier_search(org, ref, org_xy, ref_xy, n16x, n16y, sub_shift, raster_range, dense_range, mvcost, raster_step=5):
+    """D1 + D5 hierarchical form (vvcgpu_me_hier_search): the step-5 raster and the +-dense_range grid of every 16x16 / 32x32 / 64x64 block of the grid
+    in one launch.  Returns (raster, dense): two lists of three SEARCH_BEST uint8 tensors (16, 32, 64; None where the grid has no block of the size,
+    dense = None with dense_range 0)."""
+    po, so, _, _ = _plane(org, "org")
+    pr, sr, _, _ = _plane(ref, "ref")
+    cfg = MeHierCfg(org_xy[0], org_xy[1], ref_xy[0], ref_xy[1], n16x, n16y, sub_shift, raster_range, raster_step, dense_range)
+    counts = [n16x * n16y, (n16x // 2) * (n16y // 2), (n16x // 4) * (n16y // 4)]
+    mk = lambda: [torch.empty(n * SEARCH_BEST.itemsize, dtype=torch.uint8, device=org.device) if n else None for n in counts]
+    raster, dense = mk(), (mk() if dense_range else None)
+    arr = lambda ts: (C.c_void_p * 3)(*[capi.ptr(t) for t in ts])
+    capi.call("vvcgpu_me_hier_search", po, so, pr, sr, C.byref(cfg), C.byref(mvcost), arr(raster), arr(dense) if dense else None, _stream())
+    return raster, dense
+
+
 # ---- N2: integer TZ search of whole PUs (InterSearch::xTZSearch) ---------------------------------------------
 TZ_PU = np.dtype([("org_x", "<i4"), ("org_y", "<i4"), ("ref_x", "<i4"), ("ref_y", "<i4"), ("start_x", "<i4"), ("start_y", "<i4"),
                   ("pred2_x", "<i4"), ("pred2_y", "<i4"), ("pos_x", "<i4"), ("pos_y", "<i4"), ("pred_hor", "<i4"), ("pred_ver", "<i4"),

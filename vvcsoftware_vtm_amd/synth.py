@@ -23,7 +23,10 @@ def _powerlaw_field(h, w, rng, alpha=1.2):
     return fld
 
 
-def gen_yuv(W, H, N, bd=10, seed=20261003):
+def gen_yuv(W, H, N, bd=10, seed=20261003, warp=None, noise=6.0):
+    """`warp` = (degrees, zoom) per frame: the background of frame n is the field rotated by n * degrees about the picture centre and scaled by
+    zoom ** n instead of panned (content for the affine tools of the encoder; used by tests/golden/gen_deblock.py only -- the default clip is
+    unchanged).  `noise`: standard deviation of the per-frame noise at 10 bit."""
     rng = np.random.default_rng(seed)
     mid = 1 << (bd - 1)
     mx = (1 << bd) - 1
@@ -35,11 +38,19 @@ def gen_yuv(W, H, N, bd=10, seed=20261003):
         oy, ox = 100 - 2 * n, 100 - 1 * n           # pan (+1,+2) px/frame of the content
         oy %= 200
         ox %= 200
-        y = big[oy:oy + H, ox:ox + W].copy()
+        if warp is None:
+            y = big[oy:oy + H, ox:ox + W].copy()
+        else:
+            from scipy import ndimage
+            a, z = np.deg2rad(warp[0] * n), warp[1] ** n
+            yy, xx = np.meshgrid(np.arange(H) - H / 2.0, np.arange(W) - W / 2.0, indexing="ij")
+            sy = (np.cos(a) * yy - np.sin(a) * xx) / z + H / 2.0 + 100.0
+            sx = (np.sin(a) * yy + np.cos(a) * xx) / z + W / 2.0 + 100.0
+            y = ndimage.map_coordinates(big, [sy, sx], order=3, mode="reflect")
         py = (H // 2 - 48 - 4 * n) % max(1, H - 96)
         px = (W // 4 + 3 * n) % max(1, W - 64)
         y[py:py + 96, px:px + 64] = obj
-        y += rng.normal(0.0, 6.0 * 2.0 ** (bd - 10), size=y.shape)
+        y += rng.normal(0.0, noise * 2.0 ** (bd - 10), size=y.shape)
         Y = np.clip(np.rint(y), 0, mx).astype(np.uint16)
         ys = Y.astype(np.float64)
         sub = (ys[0::2, 0::2] + ys[1::2, 0::2] + ys[0::2, 1::2] + ys[1::2, 1::2]) / 4.0
