@@ -182,3 +182,27 @@ def imv_pus(rng, n, W, H, M, sizes, imv_shift):
         r["bits"] = int(rng.integers(8, 40))
         r["w"], r["h"] = w, h
     return pus
+
+
+def unpack_plane(lo, hi):
+    """inverse of tests/golden/gen_deblock.py:pack_plane: low / high bytes of the horizontal-then-vertical differences modulo 2^16 -> int16 plane"""
+    d = lo.astype(np.int64) | (hi.astype(np.int64) << 8)
+    v = np.cumsum(np.cumsum(d, axis=0), axis=1) & 0xFFFF
+    return v.astype(np.uint16).view(np.int16)
+
+
+def deblock_golden():
+    """-> list of pictures of tests/golden/deblock.npz (the compiled reference's own loopFilterPic: planes in front, the maps its xDeblockCU walk
+    produced, slice / PPS parameters, planes behind): dicts with hdr (field -> int), ev, eh, qp_luma, qp_chroma, pre[3], post[3]"""
+    import os
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "deblock.npz"))
+    fields = [str(f) for f in z["hdr_fields"]]
+    pics = []
+    for i in range(int(z["n"])):
+        r = {"hdr": dict(zip(fields, (int(v) for v in z["hdr%d" % i])))}
+        for k in ("ev", "eh", "qp_luma", "qp_chroma"):
+            r[k] = np.ascontiguousarray(z["%s_%d" % (k, i)])
+        r["pre"] = [np.ascontiguousarray(unpack_plane(z["pre%d_lo_%d" % (c, i)], z["pre%d_hi_%d" % (c, i)])) for c in range(3)]
+        r["post"] = [(r["pre"][c].astype(np.int32) + z["delta%d_%d" % (c, i)]).astype(np.int16) for c in range(3)]
+        pics.append(r)
+    return pics

@@ -483,3 +483,24 @@ def test_affine_subblock_vectors_golden():
             assert np.array_equal(got, g["pred"][o:o + n]), (r.tolist(), comp)
             o += n
 
+
+
+def test_deblock_golden():
+    """L1 + L2: the restatement (oracle/restate/deblock.cpp) on the planes in front of the compiled reference's LoopFilter::loopFilterPic, with the
+    (edge, BS) / QP maps recorded from the reference's own xDeblockCU walk, equals the planes behind the reference's own sample filters
+    (LoopFilter.cpp:149-230, 543-980; fixture: tests/golden/gen_deblock.py) -- inter pictures with affine 4x4 sub-block edges and CUs beyond 64
+    samples (transform-edge splits), and a 1920x1080 dual-tree intra picture with non-zero beta / tc / chroma QP offsets."""
+    import cases
+    from vvcsoftware_vtm_amd.workload import DeblockCfg
+    pics = cases.deblock_golden()
+    assert len(pics) == 3
+    assert pics[0]["hdr"]["n_affine"] > 50 and pics[1]["hdr"]["n_cu_gt64"] > 8 and pics[2]["hdr"]["w"] == 1920 and pics[2]["hdr"]["dual_tree"] == 1
+    for r in pics:
+        h = r["hdr"]
+        cfg = DeblockCfg(h["bd_luma"], h["bd_chroma"], h["beta_offset_div2"], h["tc_offset_div2"], h["cb_qp_offset"], h["cr_qp_offset"],
+                         (C.c_int32 * 3)(h["clp_min0"], h["clp_min1"], h["clp_min2"]), (C.c_int32 * 3)(h["clp_max0"], h["clp_max1"], h["clp_max2"]))
+        Y, Cb, Cr = (x.copy() for x in r["pre"])
+        oracle().orc_deblock(p(Y), h["w"], p(Cb), p(Cr), h["w"] // 2, h["w"], h["h"], p(r["ev"]), p(r["eh"]), p(r["qp_luma"]), p(r["qp_chroma"]), C.byref(cfg))
+        assert not np.array_equal(Y, r["pre"][0])
+        for got, want, name in zip((Y, Cb, Cr), r["post"], "Y Cb Cr".split()):
+            assert np.array_equal(got, want), "poc %d %s: %d samples differ" % (h["poc"], name, int((got != want).sum()))
