@@ -62,8 +62,10 @@ int vvcgpu_stream_sync(void* stream);
 /* Library-internal per-stream resources (work lists, packed search blocks, counters) are created on the first call that needs them and kept
  * for later calls on the same (device, stream).  A host that creates streams per thread / job calls vvcgpu_stream_release(stream) before it
  * destroys a stream: the call waits for the stream's queued work and frees what the library holds for it (any number of streams may come and
- * go).  vvcgpu_shutdown() does the same for every stream of every device (e.g. before unloading the library).  Both return VVCGPU_OK when
- * there was nothing to free. */
+ * go; the stream's slot is found whichever device is current).  vvcgpu_shutdown() does the same for every stream of every device (e.g. before
+ * unloading the library).  Both return VVCGPU_OK when there was nothing to free and VVCGPU_E_DEVICE when a device could not be reached (what
+ * could not be freed is kept, not leaked).  The scratch of a stream grows geometrically; a buffer it has outgrown is freed as soon as the work
+ * queued before the growth has completed.  One host thread drives a stream at a time (per-thread streams for concurrent callers). */
 int vvcgpu_stream_release(void* stream);
 int vvcgpu_shutdown(void);
 
@@ -283,7 +285,10 @@ int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel*
  * Descriptors as vvcgpu_mc_batch with bi = 0 or 1, EXCEPT that dst_off / dst_stride address the ORIGINAL block in org_base and `reserved` is the
  * row sub-sampling shift of the SAD (DistParam::subShift; 0 for the other kinds).  kind: 0 SAD, 1 Hadamard (xGetHADs), 2 SSE.  out[i] = what
  * vvcgpu_mc_batch followed by vvcgpu_dist_batch(kind) returns for the pair; the prediction stays in LDS.  w, h <= 128.  The vector bits of
- * the candidates (getCostOfVectorWithPredictor) and the candidate lists stay with the caller.                                               */
+ * the candidates (getCostOfVectorWithPredictor) and the candidate lists stay with the caller.  Descriptors live in device memory, so the library
+ * cannot validate them on the host: a descriptor outside the contract (w or h outside 1..128, bi outside 0..1) is skipped and its out[i] is the
+ * sentinel ~0 (UINT64_MAX); the same sentinel convention holds for vvcgpu_intra_satd_batch (w, h outside 1..64) and for the distortion output of
+ * vvcgpu_affine_me_iter_batch (w, h outside 1..128).  The descriptor array of vvcgpu_mc_batch / vvcgpu_mc_dist_batch is 16-byte aligned.       */
 int vvcgpu_mc_dist_batch(int kind, const vvc_pel* ref0_base, const vvc_pel* ref1_base, const vvc_pel* org_base, const vvcgpu_mc_desc* descs, int n,
                          int bit_depth, int clp_min, int clp_max, uint64_t* out, void* stream);
 

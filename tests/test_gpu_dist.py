@@ -234,54 +234,3 @@ def test_sad_search_group_runs(h, ss, nx, ny, content):
         assert np.all(gb["x"] == dx0) and np.all(gb["y"] == dy0)
 
 
-@pytest.mark.parametrize("w,h,ss,nx,ny,content", [(32, 32, 1, 39, 39, "smooth"), (64, 64, 1, 39, 39, "smooth"), (16, 16, 1, 39, 39, "ties"), (32, 32, 1, 39, 39, "flat"),
-                                                   (64, 32, 1, 39, 39, "bipred"), (32, 64, 0, 25, 39, "bipred"), (16, 8, 0, 40, 13, "extreme"), (32, 16, 2, 7, 30, "smooth"),
-                                                   (64, 128, 1, 33, 20, "smooth"), (16, 16, 1, 1, 1, "smooth")])
-def test_sad_search_ring_form(w, h, ss, nx, ny, content, monkeypatch):
-    """The ring form of the step-5 raster (csrc/raster7.hip, on request: VVCGPU_R7=1) against the oracle: a regular grid of blocks (chains of
-    vertically adjacent windows, several workgroup ranges), the same list shuffled (every link broken: full window fills), runs broken
-    by one-sample offsets, `bipred` originals 2 org - pred with negative samples (the clamped-original constant), surface output."""
-    from vvcsoftware_vtm_amd import ops
-    monkeypatch.setenv("VVCGPU_R7", "1")
-    rng = np.random.default_rng(w + 3 * h + 5 * nx + ny)
-    bd, m = 10, 112
-    gx, gy = (5, 9) if w * h <= 1024 else (4, 5)
-    W, H = gx * w + 16, gy * h
-    PW, PH = ((W + 2 * m + 7) // 8) * 8, H + 2 * m
-    if content == "flat":
-        org = np.full((H, W), 400, np.int16)
-        refp = np.full((PH, PW), 391, np.int16)
-    elif content == "ties":
-        org = (400 + 8 * rng.integers(0, 2, (H, W))).astype(np.int16)
-        refp = (400 + 8 * rng.integers(0, 2, (PH // 40 + 1, PW // 40 + 1)).repeat(40, 0).repeat(40, 1)[:PH, :PW]).astype(np.int16)
-    elif content == "bipred":
-        org = (2 * cases.rand_plane(rng, H, W, bd, "smooth").astype(np.int32) - cases.rand_plane(rng, H, W, bd, "uniform")).astype(np.int16)
-        refp = cases.rand_plane(rng, PH, PW, bd, "smooth")
-        assert org.min() < 0
-    else:
-        org = cases.rand_plane(rng, H, W, bd, content)
-        refp = cases.rand_plane(rng, PH, PW, bd, content)
-    grid = [(x * w, y * h, m + x * w + 3, m + y * h - 2) for y in range(gy) for x in range(gx)]
-    lists = {"grid": list(grid)}
-    sh = list(grid)
-    rng.shuffle(sh)
-    lists["shuffled"] = sh
-    br = list(grid)
-    br[3] = (br[3][0], br[3][1], br[3][2] + 1, br[3][3])                 # a horizontal link off by one sample
-    br[2 * gx + 1] = (br[2 * gx + 1][0], br[2 * gx + 1][1], br[2 * gx + 1][2], br[2 * gx + 1][3] + 1)   # a vertical link off by one row
-    br.append((7, 0, m + 7 - 4, m + 5))                                # ragged tail, odd original column
-    lists["broken"] = br
-    dx0, dy0 = -5 * (nx // 2), -5 * (ny // 2)
-    mv = ops.MvCost(float(rng.uniform(0.5, 90)), int(rng.integers(-60, 60)), int(rng.integers(-60, 60)), 2, 0)
-    for name, rows in lists.items():
-        blk = np.array(rows, dtype=ops.SEARCH_BLK)
-        nb = blk.size
-        want = np.zeros((nb, ny, nx), np.uint32)
-        wbest = np.zeros(nb, ops.SEARCH_BEST)
-        oracle().orc_sad_search(p(org), W, p(refp), PW, p(blk), nb, w, h, ss, dx0, dy0, nx, ny, 5, 5, p(want), C.byref(mv), p(wbest))
-        sad, best = ops.sad_search(dev(org), dev(refp), ops.struct_to_device(blk), nb, w, h, ss, dx0, dy0, nx, ny, 5, 5, mv, want_sad=False)
-        assert np.array_equal(best.cpu().numpy().view(ops.SEARCH_BEST), wbest), name
-        if name != "shuffled":
-            sad, best = ops.sad_search(dev(org), dev(refp), ops.struct_to_device(blk), nb, w, h, ss, dx0, dy0, nx, ny, 5, 5, mv, want_sad=True)
-            assert np.array_equal(sad.cpu().numpy().astype(np.uint32), want), name
-            assert np.array_equal(best.cpu().numpy().view(ops.SEARCH_BEST), wbest), name

@@ -44,6 +44,22 @@ def test_workload_matches_oracle_416x240():
         _cmp(k + "#2", gout2[k], cout[k])
 
 
+def test_workload_per_size_searches_match_oracle():
+    """the integer ME as six per-size searches (hier_me=False: vvcgpu_sad_search per block size and grid) gives the records the hierarchical
+    launch of the default workload gives, and both equal the oracle"""
+    from vvcsoftware_vtm_amd.workload import Workload
+    wl = Workload(416, 240, 10, seed=11, raster_range=40, hier_me=False)
+    wh = Workload(416, 240, 10, seed=11, raster_range=40)
+    assert wh.hier_me and not wl.hier_me
+    _, g1 = wl.run_gpu()
+    _, g2 = wh.run_gpu(overlap=True)
+    torch.cuda.synchronize()
+    cout, _ = run_cpu(wl, oracle(), "port")
+    for k in ["me_best_%d_%d" % (s, n) for s in (16, 32, 64) for n in (9, 17)]:
+        _cmp(k, g1[k], cout[k])
+        _cmp(k + " (hierarchical)", g2[k], cout[k])
+
+
 @pytest.mark.parametrize("qp", [22, 27, 37])
 def test_workload_matches_oracle_qp_sweep(qp):
     """BASELINE configs[2] quotes QP 22 / 27 / 32 / 37: the quantiser, the de-quantiser, the motion-cost lambda and the

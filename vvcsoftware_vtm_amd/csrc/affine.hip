@@ -255,6 +255,11 @@ __global__ __launch_bounds__(256) void affine_iter_kernel(const Pel* __restrict_
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const vvcgpu_affine_iter d = items[blockIdx.x];
   const int w = d.pu.w, h = d.pu.h;
+  if (w < 1 || h < 1 || w > AFI_MAX || h > AFI_MAX)                 // outside the LDS tile (uniform over the workgroup, before any barrier): sentinel, no overrun
+  {
+    if (tid == 0 && distOut) distOut[blockIdx.x] = ~0ull;
+    return;
+  }
   if (w * h <= AFI_WAVE_MAX) return;
   const Pel* org = orgBase + d.org_off;
   const Pel* pred = predBase + d.pu.dst_off;
@@ -282,7 +287,7 @@ __global__ __launch_bounds__(256) void affine_iter_small_kernel(const Pel* __res
   if (b >= n) return;
   const vvcgpu_affine_iter d = items[b];
   const int w = d.pu.w, h = d.pu.h;
-  if (w * h > AFI_WAVE_MAX) return;
+  if (w < 1 || h < 1 || w > AFI_MAX || h > AFI_MAX || w * h > AFI_WAVE_MAX) return;   // large or out-of-contract PUs: affine_iter_kernel answers (sentinel there)
   Pel* predL = predAll[wave];
   const Pel* org = orgBase + d.org_off;
   const Pel* pred = predBase + d.pu.dst_off;

@@ -317,18 +317,17 @@ __device__ __forceinline__ const int16_t* alf_kernarg(size_t off)
   (void)off; return nullptr;
 #endif
 }
-struct AlfFilterArgs { const Pel* src; int sstride; Pel* dst; int dstride, w, h, ctu, wCtu; const uint16_t* cls; AlfCoeffs coeffs; };   // mirrors alf_filter_kernel's arguments
+// the kernel's ONE argument: the coefficients are read straight from the kernel-argument segment at offsetof(AlfFilterArgs, coeffs) (indexing a
+// by-value argument puts a copy of it into every lane's scratch memory) -- the offset follows the struct, not a hand-kept mirror of a parameter list
+struct AlfFilterArgs { const Pel* src; int sstride; Pel* dst; int dstride, w, h, ctu, wCtu; const uint16_t* cls; AlfCoeffs coeffs; const uint8_t* ctuEnable; int clpMin, clpMax; };
 
 template <bool IS7, bool LUMA>
-__global__ __launch_bounds__(128) void alf_filter_kernel(const Pel* __restrict__ src, int sstride, Pel* __restrict__ dst, int dstride, int w, int h,
-                                                         int ctu, int wCtu, const uint16_t* __restrict__ cls, AlfCoeffs coeffs,
-                                                         const uint8_t* __restrict__ ctuEnable, int clpMin, int clpMax)
+__global__ __launch_bounds__(128) void alf_filter_kernel(AlfFilterArgs a)
 {
   __shared__ short tile[FR * FP];
   __shared__ short scoef[25 * 13 + 3];
-  (void)coeffs;
-  alf_filter_body<IS7, LUMA>((int)blockIdx.x, (int)blockIdx.y, tile, scoef, src, sstride, dst, dstride, w, h, ctu, wCtu, cls,
-                             alf_kernarg(offsetof(AlfFilterArgs, coeffs)), ctuEnable, clpMin, clpMax);
+  alf_filter_body<IS7, LUMA>((int)blockIdx.x, (int)blockIdx.y, tile, scoef, a.src, a.sstride, a.dst, a.dstride, a.w, a.h, a.ctu, a.wCtu, a.cls,
+                             alf_kernarg(offsetof(AlfFilterArgs, coeffs)), a.ctuEnable, a.clpMin, a.clpMax);
 }
 
 // luma (classifier-driven 7x7 or 5x5) and both chroma planes (5x5, one filter) of a picture in one launch
@@ -395,15 +394,13 @@ static int alf_filter_common(bool luma, const vvc_pel* src, int src_stride, vvc_
   dim3 grid(cdiv(width, FW), cdiv(height, FH));
   const int wCtu = cdiv(width, ctu_size);
   hipStream_t st = (hipStream_t)stream;
+  AlfFilterArgs ka{ src, src_stride, dst, dst_stride, width, height, ctu_size, wCtu, cls, cf, ctu_enable, clp_min, clp_max };
   if (luma && filter_type == 1)
-    hipLaunchKernelGGL((alf_filter_kernel<true, true>), grid, dim3(128), 0, st, src, src_stride, dst, dst_stride,
-                       width, height, ctu_size, wCtu, cls, cf, ctu_enable, clp_min, clp_max);
+    hipLaunchKernelGGL((alf_filter_kernel<true, true>), grid, dim3(128), 0, st, ka);
   else if (luma)
-    hipLaunchKernelGGL((alf_filter_kernel<false, true>), grid, dim3(128), 0, st, src, src_stride, dst, dst_stride,
-                       width, height, ctu_size, wCtu, cls, cf, ctu_enable, clp_min, clp_max);
+    hipLaunchKernelGGL((alf_filter_kernel<false, true>), grid, dim3(128), 0, st, ka);
   else
-    hipLaunchKernelGGL((alf_filter_kernel<false, false>), grid, dim3(128), 0, st, src, src_stride, dst, dst_stride,
-                       width, height, ctu_size, wCtu, cls, cf, ctu_enable, clp_min, clp_max);
+    hipLaunchKernelGGL((alf_filter_kernel<false, false>), grid, dim3(128), 0, st, ka);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

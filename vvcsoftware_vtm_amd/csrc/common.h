@@ -29,11 +29,6 @@ int vvcgpu_raster_per_block_launch(const vvc_pel* org, int org_stride, const vvc
                                    const VvcRasterPer* per, int nblocks, int w, int h, int sub_shift, int nx_max, int ny_max,
                                    const vvcgpu_mvcost* mvcost_host, vvcgpu_search_best* best, unsigned* packed_workspace, hipStream_t stream);
 
-// Ring form of the step-5 raster search (raster7.hip): 0 = launched, 1 = not applicable (the caller takes a strip kernel of dist.hip), < 0 = error
-int vvcgpu_raster7_launch(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride, const vvcgpu_search_blk* blocks, int nblocks,
-                          int w, int h, int sub_shift, int dx0, int dy0, int nx, int ny, uint32_t* sad_out, const vvcgpu_mvcost* mvcost_host,
-                          vvcgpu_search_best* best, hipStream_t stream);
-
 // device addresses (current device) of the transform matrices as int32 (tr32[type][size] row-major T[k][n] at type * 5460 + (n n - 4) / 3, tr32t its
 // transpose), of the raster position -> scan index tables (dqInv + scanOff[(log2 w - 1) * 6 + log2 h - 1]); uploaded on first use (transform.hip)
 struct VvcTrTables { const int* tr32; const int* tr32t; const unsigned short* dqInv; const int* scanOff; };

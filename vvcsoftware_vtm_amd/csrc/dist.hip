@@ -1586,15 +1586,6 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
     }
   }
   static const int r5cOff = getenv("VVCGPU_NO_R5C") ? 1 : 0;              // A/B timing switch
-  // Ring form (raster7.hip): exact, but at round 3's state not faster than the strip kernels below (profiles/r03_raster_ring.txt), so it
-  // runs on request only: VVCGPU_R7=1 (read per call; tests/test_gpu_dist.py runs both forms against the oracle).
-  const char* r7Env = getenv("VVCGPU_R7");
-  const int r7On = r7Env && r7Env[0] == '1' && !getenv("VVCGPU_NO_R7");
-  if (r7On && sx == 5 && sy == 5 && (long long)nx * ny < (1 << 24))
-  {
-    const int r7 = vvcgpu_raster7_launch(org, org_stride, ref, ref_stride, blocks, nblocks, w, h, sub_shift, dx0, dy0, nx, ny, sad_out, mvcost_host, best, st0);
-    if (r7 <= 0) return r7 == 0 ? VVCGPU_OK : r7;
-  }
   static const int r5gOff = getenv("VVCGPU_NO_R5G") ? 1 : 0;              // A/B timing switch: 16-wide blocks through the per-block r5c form
   if (!r5cOff && !r5gOff && sx == 5 && sy == 5 && w == 16 && (org_stride & 1) == 0 && (ref_stride & 7) == 0 &&
       ((uintptr_t)org & 3) == 0 && ((uintptr_t)ref & 15) == 0 && (long long)nx * ny < (1 << 24) && nx >= 1 &&

@@ -15,6 +15,11 @@
 #include "common.h"
 #include "dist_dev.h"
 
+// the generic MC scan loads bytes 32..47 of a descriptor as ONE uint4 (dst_stride | w, h | the four phases | is_luma, bi, reserved): the layout is part of
+// the ABI, and the descriptor array must be 16-byte aligned (include/vvcgpu.h)
+static_assert(offsetof(vvcgpu_mc_desc, dst_stride) == 32 && offsetof(vvcgpu_mc_desc, w) == 36 && offsetof(vvcgpu_mc_desc, frac_x0) == 40 &&
+              offsetof(vvcgpu_mc_desc, is_luma) == 44 && sizeof(vvcgpu_mc_desc) == 48, "vvcgpu_mc_desc layout");
+
 namespace {
 
 __constant__ short c_lumaFilter[16][8] = {
@@ -542,6 +547,13 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
   const int li = base0 + (DIST ? 0 : (int)__builtin_ctzll(todo));
   todo &= todo - 1ull;
   const vvcgpu_mc_desc d = descs[li];
+  // descriptors live in device memory, the host cannot validate them: a shape outside the contract (the prediction tile of the fused form is
+  // 128 x 128, bi is 0 or 1 there) is skipped with the sentinel ~0 as its distortion instead of overrunning LDS (wave-uniform)
+  if (DIST && (d.w < 1 || d.h < 1 || d.w > 128 || d.h > 128 || d.bi < 0 || d.bi > 1))
+  {
+    if (lane == 0) out[li] = ~0ull;
+    continue;
+  }
   // a PU whose sides are multiples of the packed path's tile (16 luma / 8 chroma samples) is a grid of tiles with the same fractional phase: the
   // wave walks them with the packed code of the fast kernel (here, not there: inlined into the fast kernel the loop cost it its 80-VGPR budget and
   // the MC stage of the canonical workload went from 0.075 to 0.18 ms)
@@ -854,6 +866,7 @@ int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc
   VVC_CHECK_ARG(n >= 0, "mc_batch: n %d", n);
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(ref0_base && dst_base && descs, "mc_batch: null pointer");
+  VVC_CHECK_ARG(((uintptr_t)descs & 15) == 0, "mc_batch: descriptor array must be 16-byte aligned");
   if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("mc_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
   const int xcd = vvc_xcd_on();

@@ -197,6 +197,7 @@ __global__ __launch_bounds__(256) void intra_satd_kernel(const Pel* __restrict__
   const int b = blockIdx.x * 4 + wave;
   if (b >= n) return;                                       // no workgroup barrier below
   const vvcgpu_intra_satd_desc s = descs[b];
+  if (s.w < 1 || s.h < 1 || s.w > 64 || s.h > 64) { if (lane == 0) out[b] = ~0ull; return; }   // outside the 64 x 64 LDS tile (wave-uniform): sentinel, no overrun
   vvcgpu_intra_desc d;
   d.ref_off = s.ref_off; d.dst_off = 0; d.dst_stride = s.w; d.w = s.w; d.h = s.h; d.mode = s.mode; d.filter_refs = s.filter_refs;
   intra_pred_block(d, refsBase, predS[wave], s.w, clpMin, clpMax, lane, topS[wave], leftS[wave], tmpS[wave], mainS[wave]);

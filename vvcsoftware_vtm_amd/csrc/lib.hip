@@ -16,15 +16,18 @@ void vvcgpu_set_error(const char* fmt, ...)
 
 // ---- per-(device, stream) resources: scratch buffer + two persistent zeroed counter sets.  One table behind one mutex; slots are created on
 // first use, released by vvcgpu_stream_release (a host that makes streams per job calls it before destroying the stream) or all at once by
-// vvcgpu_shutdown.  A buffer that has been outgrown is NOT freed on the spot -- another host thread may just have received it for the same
-// stream -- but parked in the slot's retired list until the slot is released.
+// vvcgpu_shutdown.  A buffer that has been outgrown is NOT freed on the spot -- work queued on the stream may still read it -- but parked in the
+// slot's retired list behind an event recorded on the stream; a later vvcgpu_scratch call on the slot frees the retired buffers whose event has
+// completed.  Capacity grows geometrically (at least doubling), so a stream whose batches grow slowly re-allocates O(log n) times and never holds
+// more than about twice its largest request.  (A stream is driven by one host thread at a time: per-thread streams, include/vvcgpu.h.)
 #include <vector>
 namespace {
 struct StreamSlot
 {
   int device; hipStream_t stream;
   void* ptr; size_t cap;                  // scratch
-  std::vector<void*> retired;             // outgrown scratch buffers (freed with the slot)
+  struct Retired { void* ptr; hipEvent_t done; };
+  std::vector<Retired> retired;           // outgrown scratch buffers: freed once `done` (recorded on the stream at retirement) has completed, or with the slot
   int* counters; int cur; bool dirty;     // int[2][16]; dirty: a launch that owned a set failed -- both sets are cleared before the next use
 };
 std::vector<StreamSlot> g_slots;
@@ -41,7 +44,8 @@ StreamSlot* find_slot(int dev, hipStream_t stream, bool create)
 void free_slot(StreamSlot& s)             // caller holds the mutex, the slot's device is current, its stream is idle
 {
   if (s.ptr) (void)hipFree(s.ptr);
-  for (void* q : s.retired) (void)hipFree(q);
+  for (auto& q : s.retired) { (void)hipFree(q.ptr); if (q.done) (void)hipEventDestroy(q.done); }
+  s.retired.clear();
   if (s.counters) (void)hipFree(s.counters);
 }
 }
@@ -52,12 +56,38 @@ void* vvcgpu_scratch(hipStream_t stream, size_t bytes)
   if (hipGetDevice(&dev) != hipSuccess) { vvcgpu_set_error("hipGetDevice failed"); return nullptr; }
   std::lock_guard<std::mutex> lock(g_slotMutex);
   StreamSlot* slot = find_slot(dev, stream, true);
+  for (size_t i = 0; i < slot->retired.size(); )               // retired buffers whose last reader has finished
+  {
+    auto& q = slot->retired[i];
+    if (!q.done || hipEventQuery(q.done) == hipSuccess)
+    {
+      (void)hipFree(q.ptr);
+      if (q.done) (void)hipEventDestroy(q.done);
+      slot->retired.erase(slot->retired.begin() + (ptrdiff_t)i);
+    }
+    else i++;
+  }
   if (slot->cap < bytes)
   {
-    const size_t cap = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    size_t cap = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+    if (cap < 2 * slot->cap) cap = 2 * slot->cap;              // geometric growth
     void* p = nullptr;
-    if (hipMalloc(&p, cap) != hipSuccess) { vvcgpu_set_error("scratch: hipMalloc(%zu) failed", cap); return nullptr; }
-    if (slot->ptr) slot->retired.push_back(slot->ptr);          // may still be in use by queued work or by a concurrent caller: parked, not freed
+    if (hipMalloc(&p, cap) != hipSuccess)
+    {
+      cap = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1); // the doubled size did not fit: the request itself
+      if (hipMalloc(&p, cap) != hipSuccess) { vvcgpu_set_error("scratch: hipMalloc(%zu) failed", cap); return nullptr; }
+    }
+    if (slot->ptr)                                              // queued work on the stream may still read it: parked behind an event
+    {
+      StreamSlot::Retired r{ slot->ptr, nullptr };
+      if (hipEventCreateWithFlags(&r.done, hipEventDisableTiming) != hipSuccess || hipEventRecord(r.done, stream) != hipSuccess)
+      {
+        if (r.done) (void)hipEventDestroy(r.done);
+        r.done = nullptr;
+        (void)hipStreamSynchronize(stream);                     // no event: wait here, then the buffer is free on the next call
+      }
+      slot->retired.push_back(r);
+    }
     slot->ptr = p; slot->cap = cap;
   }
   return slot->ptr;
@@ -170,15 +200,23 @@ int vvcgpu_stream_release(void* stream)
 {
   int dev = 0;
   VVC_HIP(hipGetDevice(&dev));
-  VVC_HIP(hipStreamSynchronize((hipStream_t)stream));                    // queued work may still read the buffers
   std::lock_guard<std::mutex> lock(g_slotMutex);
+  // the slot of this stream handle -- on the current device first, else on whichever device holds one (a stream belongs to one device; the caller
+  // may have switched devices since it used the stream)
+  size_t hit = g_slots.size();
   for (size_t i = 0; i < g_slots.size(); i++)
-    if (g_slots[i].device == dev && g_slots[i].stream == (hipStream_t)stream)
-    {
-      free_slot(g_slots[i]);
-      g_slots.erase(g_slots.begin() + (ptrdiff_t)i);
-      break;
-    }
+    if (g_slots[i].stream == (hipStream_t)stream && (g_slots[i].device == dev || hit == g_slots.size())) { hit = i; if (g_slots[i].device == dev) break; }
+  if (hit == g_slots.size()) return VVCGPU_OK;                              // nothing held for this stream
+  const int sdev = g_slots[hit].device;
+  if (sdev != dev) VVC_HIP(hipSetDevice(sdev));
+  const hipError_t e = hipStreamSynchronize((hipStream_t)stream);           // queued work may still read the buffers
+  if (e == hipSuccess)
+  {
+    free_slot(g_slots[hit]);
+    g_slots.erase(g_slots.begin() + (ptrdiff_t)hit);
+  }
+  if (sdev != dev) (void)hipSetDevice(dev);
+  if (e != hipSuccess) { vvcgpu_set_error("stream_release: hipStreamSynchronize failed on device %d: %s (resources kept)", sdev, hipGetErrorString(e)); return VVCGPU_E_DEVICE; }
   return VVCGPU_OK;
 }
 int vvcgpu_shutdown(void)
@@ -186,14 +224,16 @@ int vvcgpu_shutdown(void)
   int dev0 = 0;
   VVC_HIP(hipGetDevice(&dev0));
   std::lock_guard<std::mutex> lock(g_slotMutex);
+  std::vector<StreamSlot> kept;                                             // slots whose device could not be reached: kept, and reported
   for (auto& s : g_slots)
   {
-    if (hipSetDevice(s.device) != hipSuccess) continue;
-    (void)hipDeviceSynchronize();
+    if (hipSetDevice(s.device) != hipSuccess || hipDeviceSynchronize() != hipSuccess) { kept.push_back(s); continue; }
     free_slot(s);
   }
-  g_slots.clear();
+  const size_t nkept = kept.size();
+  g_slots.swap(kept);
   VVC_HIP(hipSetDevice(dev0));
+  if (nkept) { vvcgpu_set_error("shutdown: %zu stream slot(s) on unreachable devices were kept", nkept); return VVCGPU_E_DEVICE; }
   return VVCGPU_OK;
 }
 }

@@ -89,13 +89,16 @@ def _pad(plane, m):
 
 
 class Workload:
-    def __init__(self, width, height, bit_depth=10, seed=20261003, raster_range=96, me_sizes=(16, 32, 64), qp=32, fused_resi=True):
+    def __init__(self, width, height, bit_depth=10, seed=20261003, raster_range=96, me_sizes=(16, 32, 64), qp=32, fused_resi=True, hier_me=True):
         assert width % 8 == 0 and height % 8 == 0
         self.w, self.h, self.bd = width, height, bit_depth
         self.mx = (1 << bit_depth) - 1
         self.seed = seed
         self.raster_range = raster_range
         self.fused_resi = fused_resi                   # residual chain as ONE pass (vvcgpu_resi_chain_batch) or as its five separate entry points
+        # integer ME as ONE hierarchical launch (vvcgpu_me_hier_search: every 16x16 SAD once, 32x32 / 64x64 by addition, raster and +-4 grid from
+        # the same LDS window) or as six per-size searches (vvcgpu_sad_search): same results
+        self.hier_me = bool(hier_me) and tuple(sorted(me_sizes)) == (16, 32, 64) and raster_range <= 99
         self.qp = qp                                   # base QP (BASELINE configs: 22 / 27 / 32 / 37); quantiser, de-quantiser and the deblocking QP field follow it
         rng = np.random.default_rng(seed)
         frames = synth.gen_yuv(width, height, 3, bit_depth, seed)
@@ -294,6 +297,8 @@ class Workload:
                 # every search returns the best candidate only (24 B per block): xPatternSearch / xTZSearch keep nothing else
                 outb = 24
                 me["sad_search_%dx%d_%dx%d" % (s, s, nx, ny)] = blk.size * (Ww * Wh * 2 + s * s * 2 + outb)
+        if self.hier_me:                               # one launch serves all six searches: the SURVEY 8(d) figure of every PU it answers
+            me = {"hier_search": sum(me.values())}
         out["me"] = me
         out["frac"] = {"frac_refine_16x16": self.frac.size * (24 * 24 * 2 + 16 * 16 * 2 + 32)}
         nl = self.mc_luma.size
@@ -320,6 +325,9 @@ class Workload:
         for s, blk in self.me.items():
             for (dx0, dy0, nx, ny, sx, sy) in self.me_grids:
                 out["me"]["sad_search_%dx%d_%dx%d" % (s, s, nx, ny)] = (w + (nx - 1) * sx) * (h + (ny - 1) * sy) * 2 + Y + blk.size * 24
+        if self.hier_me:     # the hierarchical launch reads the reference picture + its search margin and the original once and writes six result arrays
+            R = 5 * (self.raster_range // 5)
+            out["me"] = {"hier_search": (w + 2 * R) * (h + 2 * R) * 2 + Y + 2 * sum(b.size for b in self.me.values()) * 24}
         out["frac"] = {"frac_refine_16x16": 2 * Y + self.frac.size * 32}
         out["mc"] = {"mc_picture": 3 * P}
         return out
@@ -331,11 +339,16 @@ class Workload:
         for s, blk in self.me.items():
             for (dx0, dy0, nx, ny, sx, sy) in self.me_grids:
                 out["me/sad_search_%dx%d_%dx%d" % (s, s, nx, ny)] = blk.size * nx * ny * s * (s >> 1) / 2.0 / 64.0
+        # hierarchical launch: the NON-REDUNDANT count -- every 16x16 SAD of both grids once; the 32x32 / 64x64 SADs are sums
+        if 16 in self.me:
+            out["me/hier_search"] = sum(self.me[16].size * g[2] * g[3] * 16 * 8 / 2.0 / 64.0 for g in self.me_grids)
         return out
 
     def profile_kernel_hint(self, group):
         """name (substring) of the rocprofv3 kernel that does the work of a launch group (None: not mapped)"""
         stage, name = group.split("/")
+        if stage == "me" and name == "hier_search":
+            return "me_hier_kernel"
         if stage == "me":
             return "sad_raster5" if name.endswith("%dx%d" % (self.me_grids[1][2], self.me_grids[1][3])) else "sad_dense"
         return {"frac_refine_16x16": "frac16_kernel", "mc_picture": "mc_fast_kernel", "deblock": "deblock_picture_kernel",
@@ -346,7 +359,7 @@ class Workload:
         return [(MARGIN, MARGIN), (MARGIN // 2, MARGIN // 2), (MARGIN // 2, MARGIN // 2)]
 
     # ------------------------------------------------------------------------------------------------------
-    def run_gpu(self, dev_state=None, timer=None, overlap=False, alone=None, pre_mc=None):
+    def run_gpu(self, dev_state=None, timer=None, overlap=False, alone=None, pre_mc=None, rotate=1, on_input_set=None):
         """One step on the GPU through ops/C-ABI.  Returns (state, outputs dict of CUDA tensors).
 
         overlap=False: every launch on the current stream, in stage order.
@@ -357,7 +370,12 @@ class Workload:
         its event-timed duration is a kernel time and not a share of an overlapped interval: `alone` = (block size, grid index)
         names it (bench.py passes the dominant one); default: the first size's raster search.
         `pre_mc`: called on the main stream right before the motion compensation, the first reader of the second reference picture
-        (bench.py installs the boundary picture of a chunk hand-over there: the searches in front of it do not wait for the transfer)."""
+        (bench.py installs the boundary picture of a chunk hand-over there: the searches in front of it do not wait for the transfer).
+        `rotate` = K > 1: the picture's inputs that are NEW for every picture of an encode -- the original and the first reference picture -- cycle
+        through K resident copies at different addresses (same content, same results), so that consecutive pictures do not find their inputs in the
+        256 MB memory-side cache: K x 56 MB at 4K.  The second reference picture (the hand-over slot, re-used by every picture of a chunk as a
+        reference picture is), the descriptor lists and the intermediates between the stages of one picture stay where they are.
+        `on_input_set(k, state)`: called at the start of the picture with the index of the input set it uses (bench.py's upload leg)."""
         import torch
         from . import ops
         T = timer or (lambda name: _NullCtx())
@@ -394,6 +412,17 @@ class Workload:
             st["rec"] = planes(self.pic_plane_off, [(h, w), (h // 2, w // 2), (h // 2, w // 2)])
             st["sao_out"] = [e16(h, w), e16(h // 2, w // 2), e16(h // 2, w // 2)]
             st["alf_out"] = [e16(h, w), e16(h // 2, w // 2), e16(h // 2, w // 2)]
+            st["in_sets"], st["rot"] = [(st["org"], st["ref0"])], 0
+            st["_planes"] = planes
+        K = max(1, int(rotate))
+        while len(st["in_sets"]) < K:
+            d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
+            st["in_sets"].append(([d(p) for p in self.org], st["_planes"](self.ref_plane_off, [p.shape for p in self.ref0_pad], self.ref0_pad)))
+        if K > 1:
+            st["rot"] = (st["rot"] + 1) % K
+            st["org"], st["ref0"] = st["in_sets"][st["rot"]]
+        if on_input_set is not None:
+            on_input_set(st["rot"], st)
         out = {}
         bd, mx = self.bd, self.mx
         cfg_mv = ops.MvCost(self.mvcost.lambda_, self.mvcost.pred_hor, self.mvcost.pred_ver, self.mvcost.cost_scale, self.mvcost.imv_shift)
@@ -436,14 +465,32 @@ class Workload:
 
         sizes = sorted(self.me)
         dense, raster = self.me_grids[0], self.me_grids[1]
-        # ---- me / frac.  Serial order: per size the +-4 grid, then the raster.  Overlapped: the first size's raster alone on
+
+        def frac():
+            with T("frac/frac_refine_16x16"):
+                out["frac"] = ops.frac_refine(st["org"][0], st["ref0"][0], st["frac_blk"], self.frac.size, 16, 16, bd, fmv, True, (0, mx))
+
+        if self.hier_me:
+            # ---- me, hierarchical: ONE launch answers the six searches (InterSearch.cpp:2159-2169 raster, :1886-1935 +-4) on the main stream, alone;
+            # the fractional refinement follows on a side stream
+            with T("me/hier_search"):
+                rb, db = ops.me_hier_search(st["org"][0], st["ref0"][0], (0, 0), (MARGIN, MARGIN), self.w // 16, self.h // 16, 1, self.raster_range, 4, cfg_mv)
+            for k, s in enumerate((16, 32, 64)):
+                out["me_sad_%d_%d" % (s, raster[2])] = out["me_sad_%d_%d" % (s, dense[2])] = None
+                out["me_best_%d_%d" % (s, dense[2])] = db[k]
+                out["me_best_%d_%d" % (s, raster[2])] = rb[k]          # (a raster of 9 x 9 positions shares the key: the raster result stays, as in the per-size order)
+            if not overlap:
+                frac()
+            else:
+                with _On(side[1], mark()):
+                    frac()
+        # ---- me / frac, per-size form.  Serial order: per size the +-4 grid, then the raster.  Overlapped: the first size's raster alone on
         # the main stream, everything else on side streams 0 / 1 after it.
-        if not overlap:
+        elif not overlap:
             for s in sizes:
                 search(s, dense)
                 search(s, raster)
-            with T("frac/frac_refine_16x16"):
-                out["frac"] = ops.frac_refine(st["org"][0], st["ref0"][0], st["frac_blk"], self.frac.size, 16, 16, bd, fmv, True, (0, mx))
+            frac()
         else:
             grids = {0: dense, 1: raster}
             first = alone if alone is not None else (sizes[0], 1)
@@ -456,8 +503,7 @@ class Workload:
             with _On(side[1], e_first):
                 for sz, gi in rest[1::2]:
                     search(sz, grids[gi])
-                with T("frac/frac_refine_16x16"):
-                    out["frac"] = ops.frac_refine(st["org"][0], st["ref0"][0], st["frac_blk"], self.frac.size, 16, 16, bd, fmv, True, (0, mx))
+                frac()
         # ---- mc
         if pre_mc is not None:
             pre_mc()
