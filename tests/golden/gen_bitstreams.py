@@ -35,6 +35,8 @@ CLIPS = [
     ("rab_208x120_10b_q32", "@tests/golden/bitstreams/test_randomaccess.cfg", 208, 120, 10, 9, 32, 20261011),
     # the reference's random-access parameter VALUES (GOP 16, intra period 32, search range 384 + ASR, IMV 2) in a repo-owned cfg: 17 pictures
     ("ragop16_416x240_10b_q32", "@tests/golden/bitstreams/test_ra_gop16.cfg", 416, 240, 10, 17, 32, 20261012),
+    # 1920x1080, 9 pictures of the hierarchical-B cfg: the decoder leg of M3 (tools/m3_decoder_time.py) -- ~8 minutes of encoding
+    ("rab_1920x1080_10b_q32", "@tests/golden/bitstreams/test_randomaccess.cfg", 1920, 1080, 10, 9, 32, 20261031),
     ("ldprdoq_208x120_10b_q32", "@tests/golden/bitstreams/test_lowdelay.cfg", 208, 120, 10, 2, 32, 20261010, 1, ["--DepQuant=0", "--SignHideFlag=1"]),
 ]
 

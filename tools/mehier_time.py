@@ -48,3 +48,6 @@ for k, s in enumerate((16, 32, 64)):
 print("per-size searches (6 launch groups): %.1f us" % timeit(per_size))
 print("hierarchical, raster + dense       : %.1f us" % timeit(hier))
 print("hierarchical, raster only          : %.1f us" % timeit(lambda: hier(0)))
+os.environ["VVCGPU_MH_DIAG"] = "1"
+hier()
+torch.cuda.synchronize()
