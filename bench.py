@@ -52,7 +52,10 @@ def parse_args():
     ap.add_argument("--height", type=int, default=2160)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-real-mix", action="store_true", help="skip the real-shape block (kernels_real_mix)")
-    ap.add_argument("--serial", action="store_true", help="one stream, stage order (default: independent stages on side streams)")
+    ap.add_argument("--serial", action="store_true", help="one stream, stage order: the default since round 4 (kept as a flag for older command lines)")
+    ap.add_argument("--overlap", action="store_true",
+                    help="independent stages on side streams beside the reconstruction chain (the default of rounds 1-3; measured slower than the serial "
+                         "schedule once the integer search became one launch: 1363 vs 1426 pictures/s, profiles/r04_schedule.txt)")
     ap.add_argument("--rotate", type=int, default=12,
                     help="resident copies of the per-picture inputs (original + first reference picture) the pictures cycle through: 12 x 56 MB at 4K exceeds "
                          "the 256 MB memory-side cache, so the input reads and the counters behind hbm_frac are HBM-side (1 = every picture re-reads the same buffers)")
@@ -307,7 +310,7 @@ def main():
             return False
 
     timer = Timer()
-    overlap = not args.serial
+    overlap = bool(args.overlap) and not args.serial
 
     # ---- picture 0 on a fresh state: the md5 the 4K parity test pins (tests/golden/bench_md5.json), then one serial, bracketed
     # picture to find the dominant launch group (in the timed region only THAT group carries HIP events: an event pair per
@@ -449,7 +452,7 @@ def main():
         state, out = wl.run_gpu(state, timer, overlap=False, rotate=rotate)
     torch.cuda.synchronize()
     kern_ms = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in timer.ev.items()}
-    if dom_alone or args.serial:
+    if dom_alone or not overlap:
         kern_ms.update(timed_ms)                          # measured over the timed region, launched alone
     else:
         n_timed = {}                                      # dominant group runs beside other kernels in the overlapped schedule: serial-pass time
@@ -562,7 +565,7 @@ def main():
                                    "step = one intra period of %d pictures + hand-over of the last reconstructed picture as the next chunk's reference; "
                                    "NOT EncoderApp fps (RDO control loop out of scope)" % (args.width, args.height, pps),
                        "width": args.width, "height": args.height, "bit_depth": bd, "pictures_per_step": pps, "ms_per_picture": ms_pic,
-                       "schedule": ("serial: one HIP stream, stage order" if args.serial else
+                       "schedule": ("serial: one HIP stream, stage order (every kernel alone on the device: event-timed durations are kernel times)" if not overlap else
                                     "overlap: reconstruction chain on the main stream, searches / refinement / statistics on three side streams "
                                     "(their real dependencies only); the integer search is the first launch of a picture, alone on the main stream"),
                        "parallelism": "one chunk stream per GPU (intra-period sharding), one point-to-point boundary picture per step; no data-path collective"},
