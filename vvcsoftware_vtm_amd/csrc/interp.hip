@@ -96,13 +96,15 @@ __device__ __forceinline__ void if_one(const vvcgpu_if_desc& d, const Pel* __res
   int c[8];
 #pragma unroll
   for (int k = 0; k < 8; k++) c[k] = k < N ? d.coeff[k] : 0;
-  if ((w & 3) == 0)
   {
-    // four consecutive outputs of a row per lane: N + 3 samples (horizontal) or N loads of four samples (vertical) instead of 4 N two-byte loads
-    const int upr = w >> 2, units = act ? upr * hh : 0;
+    // four consecutive outputs of a row per lane: N + 3 samples (horizontal) or N loads of four samples (vertical) instead of 4 N two-byte loads.
+    // Widths that are not a multiple of four (the W + 1 wide planes of xExtDIFUpSamplingH / Q: 5, 9, 17, 33, 65, 129 -- 30 % of if_batch's time on a
+    // real call mix went into them one output per lane) end every row with a PARTIAL unit of nv < 4 outputs, which loads sample by sample exactly
+    // the nv + N - 1 samples (horizontal) / nv columns (vertical) the reference reads: nothing beyond the reference's window in either form.
+    const int upr = (w + 3) >> 2, units = act ? upr * hh : 0;
     for (int u = lane; u < units; u += G)
     {
-      const int y = u / upr, x = (u - y * upr) << 2;
+      const int y = u / upr, x = (u - y * upr) << 2, nv = min(4, w - x);
       const Pel* s = src + (size_t)y * d.src_stride + x;
       int sum[4] = { 0, 0, 0, 0 };
       if (d.is_vertical)
@@ -112,7 +114,12 @@ __device__ __forceinline__ void if_one(const vvcgpu_if_desc& d, const Pel* __res
           if (k < N)
           {
             int v[4];
-            if_load4(s + (size_t)k * d.src_stride, v);
+            if (nv == 4) if_load4(s + (size_t)k * d.src_stride, v);
+            else
+            {
+#pragma unroll
+              for (int j = 0; j < 4; j++) v[j] = j < nv ? (int)s[(size_t)k * d.src_stride + j] : 0;
+            }
 #pragma unroll
             for (int j = 0; j < 4; j++) sum[j] += v[j] * c[k];
           }
@@ -120,12 +127,18 @@ __device__ __forceinline__ void if_one(const vvcgpu_if_desc& d, const Pel* __res
       else
       {
         int v[12];                                        // exactly the N + 3 samples the four outputs read: nothing beyond the reference's window
+        if (nv == 4)
         {
           int q[4];
           if_load4(s, q); v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3];
           if (N == 8) { if_load4(s + 4, q); v[4] = q[0]; v[5] = q[1]; v[6] = q[2]; v[7] = q[3]; v[8] = s[8]; v[9] = s[9]; v[10] = s[10]; }
           else if (N == 4) { v[4] = s[4]; v[5] = s[5]; v[6] = s[6]; }
           else v[4] = s[4];
+        }
+        else
+        {
+#pragma unroll
+          for (int j = 0; j < 11; j++) v[j] = j < nv + N - 1 ? (int)s[j] : 0;
         }
 #pragma unroll
         for (int j = 0; j < 4; j++)
@@ -141,21 +154,13 @@ __device__ __forceinline__ void if_one(const vvcgpu_if_desc& d, const Pel* __res
         o[j] = (short)val;
       }
       Pel* dp = dst + (size_t)y * d.dst_stride + x;
-      if (((uintptr_t)dp & 7) == 0) *reinterpret_cast<pel4*>(dp) = o;
-      else { dp[0] = o[0]; dp[1] = o[1]; dp[2] = o[2]; dp[3] = o[3]; }
-    }
-    return;
-  }
-  for (int i = lane; i < count; i += G)
-  {
-    const int y = i / w, x = i - y * w;
-    const Pel* s = src + (size_t)y * d.src_stride + x;
-    int sum = 0;
+      if (nv == 4 && ((uintptr_t)dp & 7) == 0) *reinterpret_cast<pel4*>(dp) = o;
+      else
+      {
 #pragma unroll
-    for (int k = 0; k < 8; k++) if (k < N) sum += s[k * cStride] * c[k];
-    int val = (short)((sum + m.offset) >> m.shift);
-    if (d.is_last) val = clip3(cmin, cmax, val);
-    dst[(size_t)y * d.dst_stride + x] = (short)val;
+        for (int j = 0; j < 4; j++) if (j < nv) dp[j] = o[j];
+      }
+    }
   }
 }
 
