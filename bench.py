@@ -50,6 +50,7 @@ def parse_args():
     ap.add_argument("--pictures-per-step", type=int, default=32, help="pictures of one intra period (one hand-over per step)")
     ap.add_argument("--width", type=int, default=3840)
     ap.add_argument("--height", type=int, default=2160)
+    ap.add_argument("--qp", type=int, default=32, help="base QP of the workload (BASELINE configs[2] sweeps 22 / 27 / 32 / 37): quantiser, de-quantiser, motion lambda and deblocking QP field follow it")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-real-mix", action="store_true", help="skip the real-shape block (kernels_real_mix)")
     ap.add_argument("--serial", action="store_true", help="one stream, stage order: the default since round 4 (kept as a flag for older command lines)")
@@ -278,7 +279,7 @@ def main():
             raise SystemExit("bench.py: RCCL sees %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
     bd = 10
-    wl = Workload(args.width, args.height, bd, seed=20261003 + rank)
+    wl = Workload(args.width, args.height, bd, seed=20261003 + rank, qp=args.qp)
     alg = wl.algorithmic_bytes()
     pps = args.pictures_per_step
 
@@ -564,7 +565,7 @@ def main():
                                    "on %dx%d 10-bit 4:2:0 (BASELINE configs[3] picture format; configs[1] is the same workload at 1920x1080), planes resident in HBM; "
                                    "step = one intra period of %d pictures + hand-over of the last reconstructed picture as the next chunk's reference; "
                                    "NOT EncoderApp fps (RDO control loop out of scope)" % (args.width, args.height, pps),
-                       "width": args.width, "height": args.height, "bit_depth": bd, "pictures_per_step": pps, "ms_per_picture": ms_pic,
+                       "width": args.width, "height": args.height, "bit_depth": bd, "qp": args.qp, "pictures_per_step": pps, "ms_per_picture": ms_pic,
                        "schedule": ("serial: one HIP stream, stage order (every kernel alone on the device: event-timed durations are kernel times)" if not overlap else
                                     "overlap: reconstruction chain on the main stream, searches / refinement / statistics on three side streams "
                                     "(their real dependencies only); the integer search is the first launch of a picture, alone on the main stream"),
