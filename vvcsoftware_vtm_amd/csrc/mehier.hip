@@ -37,6 +37,7 @@ namespace {
 constexpr int MH_PITCH = 148;                          // dwords per window row: = 20 (mod 64), >= (254 + 7 + 7) / 2
 constexpr int MH_MAXN = 39;                            // raster positions per axis (search range 96, step 5)
 constexpr int MH_MAXSLOTS = 448;                       // 7 slot waves
+constexpr int MH_MAXDL = 96;                           // lanes of the +-D grid (9 rows x at most 9 spans)
 constexpr unsigned MH_INVALID = 0x30000000u;           // above every valid cost (SAD << 1 < 2^23, lambda * bits < 2^29), below 2^30
 
 struct MhGeom
@@ -48,6 +49,8 @@ struct MhGeom
   int nR, R;                                           // raster positions per axis, raster reach (5 (nR / 2))
   int nD, D;                                           // +-D grid: nD = 2 D + 1 positions per axis (0: none)
   int winBytes;                                        // LDS bytes of the window
+  // the spans of the +-D grid (host-built): column x is candidate m = (R + x) mod 4 of the span that starts (R + x - 5 m) / 4 quads into the window row
+  int dlCount; short dlKey[12]; signed char dlX[48];   // per span: start in quads, grid column of each candidate (-128: none)
 };
 
 // original rows packed per 16x16 block: [block][sampled row][even 8 dwords | odd 8 dwords], biased; layouts as r5c_pack_org_kernel (dist.hip)
@@ -95,28 +98,96 @@ __device__ __forceinline__ void mh_block_min(unsigned kmin, unsigned idx0, unsig
   if (lane == 0 && km < MH_INVALID) atomicMin(key, ((unsigned long long)km << 24) | idx);
 }
 
-template <int STEP>
 __device__ __forceinline__ void mh_positions(int OA, const unsigned* __restrict__ oq, unsigned base, int ldsStep, int hs, unsigned (&acc)[4])
 {
-  if (OA == 0)      r5q_positions<0, STEP>(oq, base, ldsStep, 1, 0, hs, acc);
-  else if (OA == 1) r5q_positions<1, STEP>(oq, base, ldsStep, 1, 0, hs, acc);
-  else if (OA == 2) r5q_positions<2, STEP>(oq, base, ldsStep, 1, 0, hs, acc);
-  else              r5q_positions<3, STEP>(oq, base, ldsStep, 1, 0, hs, acc);
+  if (OA == 0)      r5q_positions<0>(oq, base, ldsStep, 1, 0, hs, acc);
+  else if (OA == 1) r5q_positions<1>(oq, base, ldsStep, 1, 0, hs, acc);
+  else if (OA == 2) r5q_positions<2>(oq, base, ldsStep, 1, 0, hs, acc);
+  else              r5q_positions<3>(oq, base, ldsStep, 1, 0, hs, acc);
 }
 
-// One unit: the four 16x16 sub-blocks of quadrant q for the lane's four positions.  STEP 5: raster slot wave; STEP 1: the +-D grid.
-//   base    LDS byte address of the lane's span for sub-block (0, 0) of the quadrant
-//   cst[m]  (cost << 2 | m) of the lane's candidate m (MH_INVALID << 2 | m: no candidate)
-//   idx0    visiting index of candidate 0
-//   keys    LDS: 16 keys of the 16x16 blocks, 4 of the 32x32, 1 of the 64x64 (this grid)
-//   surf    LDS: 64x64 partial sums, [slot][4]
-template <int STEP>
-__device__ __forceinline__ void mh_unit(const unsigned* __restrict__ orgPacked, const MhGeom& g, int OA, unsigned base, const unsigned (&cst)[4], unsigned idx0,
-                                        int q, int sbx, int sby, int nsubx, int nsuby, unsigned long long* keys, unsigned* surf, int slot, bool live, int lane)
+// What a lane of a slot wave works on: four candidates 0 / 5 / 10 / 15 samples into one LDS span (the quad loop of raster_dev.h).
+//   raster lane : four consecutive columns of one raster row; visiting indices idx0 .. idx0 + 3 (lane order = visiting order)
+//   dense lane  : a lane of the +-D grid.  Its columns are 1 apart, not 5, but the span of a lane may start at any multiple of 4 samples: column
+//                 x of the grid is candidate m = (R + x) mod 4 of the span that starts (R + x - 5 m) / 4 quads into the row, and x + 5 (when it
+//                 is still on the grid) is candidate m + 1 of the same span -- the 9 columns of the +-4 grid are 6 spans (dlKey / dlX, built once
+//                 per workgroup), the 81 positions 54 lanes, which fit into the lanes the raster leaves idle in its last slot wave (390 of 448):
+//                 the +-4 grid costs no unit of its own.  Candidates are not in visiting order: dense lanes carry explicit indices (7 bits each)
+//                 and reduce 64-bit (cost << 24 | index) keys.
+struct MhLane { unsigned base; unsigned cst[4]; unsigned idx; int kind; };        // kind 0 dead, 1 raster, 2 dense; idx: idx0 (raster) / 4 x 7 bits (dense)
+
+struct MhTables
+{
+  const unsigned* costTab; const unsigned char* bitsRX; const unsigned char* bitsRY; const unsigned char* bitsDX; const unsigned char* bitsDY;
+  const short* dlKey; const signed char* dlX; int dlCount;
+};
+
+__device__ __forceinline__ void mh_lane(int s, const MhGeom& g, const MhTables& T, int off, int nq, int nslots, int ndl, MhLane& L)
+{
+  L.kind = s < nslots ? 1 : (s - nslots < ndl ? 2 : 0);
+  if (L.kind == 2)
+  {
+    const int e = s - nslots, j = e / T.dlCount, l = e - j * T.dlCount;
+    L.base = (unsigned)(2 * (int)T.dlKey[l] + 2 * (off >> 2) + (g.R - g.D + j) * MH_PITCH) * 4u;
+    const unsigned by = T.bitsDY[j];
+    L.idx = 0;
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+    {
+      const int x = T.dlX[l * 4 + m];                                              // -128: the span has no grid column at candidate m
+      const bool in = x != -128;
+      L.cst[m] = ((in ? T.costTab[T.bitsDX[in ? x + g.D : 0] + by] : MH_INVALID) << 2) | (unsigned)m;
+      L.idx |= (unsigned)(in ? j * g.nD + x + g.D : 0) << (7 * m);
+    }
+    return;
+  }
+  const int sc = L.kind ? s : 0;                                                   // dead lanes re-read a live lane's address (broadcast)
+  const int jj = sc / nq, i0 = 4 * (sc - jj * nq);
+  const int cx = 5 * i0 + off;
+  L.base = (unsigned)(2 * (cx >> 2) + jj * 5 * MH_PITCH) * 4u;
+  const unsigned by = T.bitsRY[jj];
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+  {
+    const bool in = L.kind && i0 + m < g.nR;
+    L.cst[m] = ((in ? T.costTab[T.bitsRX[in ? i0 + m : 0] + by] : MH_INVALID) << 2) | (unsigned)m;
+  }
+  L.idx = (unsigned)(jj * g.nR + i0);
+}
+
+// the lane's packed minimum of four sums: raster lanes (cost << 2 | candidate), dense lanes a 64-bit (cost << 24 | visiting index) key
+__device__ __forceinline__ unsigned mh_fold32(const unsigned (&a)[4], const MhLane& L, int sh)
+{
+  return min(min((a[0] << sh) + L.cst[0], (a[1] << sh) + L.cst[1]), min((a[2] << sh) + L.cst[2], (a[3] << sh) + L.cst[3]));
+}
+__device__ __forceinline__ unsigned long long mh_fold64(const unsigned (&a)[4], const MhLane& L, int sh)
+{
+  unsigned long long k = ~0ull;
+#pragma unroll
+  for (int m = 0; m < 4; m++)
+  {
+    const unsigned c = ((a[m] << sh) + L.cst[m]) >> 2;
+    const unsigned long long km = c < MH_INVALID ? ((unsigned long long)c << 24) | ((L.idx >> (7 * m)) & 127u) : ~0ull;
+    k = km < k ? km : k;
+  }
+  return k;
+}
+__device__ __forceinline__ void mh_block_min64(unsigned long long k, unsigned long long* key, int lane)
+{
+  const unsigned long long km = wave_min_u64(k);
+  if (lane == 0 && km != ~0ull) atomicMin(key, km);
+}
+
+// One unit: the four 16x16 sub-blocks of quadrant q for the lanes of one slot wave.
+//   keys   LDS: raster keys of the 16x16 blocks (16), the 32x32 (4), the 64x64 (1), then the same 21 for the +-D grid
+//   surf / surfD  LDS: 64x64 partial sums of the raster slots / the dense lanes, [slot][4]
+__device__ __forceinline__ void mh_unit(const unsigned* __restrict__ orgPacked, const MhGeom& g, int OA, unsigned qbase, const MhLane& L, bool waveHasDense,
+                                        int q, int sbx, int sby, int nsubx, int nsuby, unsigned long long* keys, unsigned* surf, unsigned* surfD, int s, int nslots, int lane)
 {
   const int qx = q & 1, qy = q >> 1;
   const int ldsStep = MH_PITCH << g.subShift;
   const int sh = g.subShift + 2;
+  const unsigned base = qbase + L.base;
   unsigned a32[4] = { 0u, 0u, 0u, 0u };
   int nsub = 0;
 #pragma unroll 1
@@ -128,38 +199,47 @@ __device__ __forceinline__ void mh_unit(const unsigned* __restrict__ orgPacked, 
     const int b16 = (4 * sby + ty) * g.n16x + 4 * sbx + tx;
     const unsigned* oq = orgPacked + (size_t)b16 * 16u * (unsigned)g.hs;
     unsigned acc[4] = { 0u, 0u, 0u, 0u };
-    mh_positions<STEP>(OA, oq, base + (unsigned)((t & 1) * 32 + (t >> 1) * 16 * MH_PITCH * 4), ldsStep, g.hs, acc);
-    const unsigned k = min(min((acc[0] << sh) + cst[0], (acc[1] << sh) + cst[1]), min((acc[2] << sh) + cst[2], (acc[3] << sh) + cst[3]));
-    mh_block_min(k, idx0, &keys[ty * 4 + tx], lane);
+    mh_positions(OA, oq, base + (unsigned)((t & 1) * 32 + (t >> 1) * 16 * MH_PITCH * 4), ldsStep, g.hs, acc);
+    mh_block_min(L.kind == 1 ? mh_fold32(acc, L, sh) : 0xFFFFFFFFu, L.idx, &keys[ty * 4 + tx], lane);
+    if (waveHasDense) mh_block_min64(L.kind == 2 ? mh_fold64(acc, L, sh) : ~0ull, &keys[21 + ty * 4 + tx], lane);
     a32[0] += acc[0]; a32[1] += acc[1]; a32[2] += acc[2]; a32[3] += acc[3];
   }
   if (nsub == 4)
   {
-    const unsigned k = min(min((a32[0] << sh) + cst[0], (a32[1] << sh) + cst[1]), min((a32[2] << sh) + cst[2], (a32[3] << sh) + cst[3]));
-    mh_block_min(k, idx0, &keys[16 + q], lane);
-    if (nsubx == 4 && nsuby == 4 && live)
+    mh_block_min(L.kind == 1 ? mh_fold32(a32, L, sh) : 0xFFFFFFFFu, L.idx, &keys[16 + q], lane);
+    if (waveHasDense) mh_block_min64(L.kind == 2 ? mh_fold64(a32, L, sh) : ~0ull, &keys[21 + 16 + q], lane);
+    if (nsubx == 4 && nsuby == 4 && L.kind)
     {
+      unsigned* dst = L.kind == 1 ? surf + s * 4 : surfD + (s - nslots) * 4;
 #pragma unroll
-      for (int m = 0; m < 4; m++) atomicAdd(&surf[slot * 4 + m], a32[m]);
+      for (int m = 0; m < 4; m++) atomicAdd(&dst[m], a32[m]);
     }
   }
 }
 
 __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restrict__ orgPacked, const Pel* __restrict__ ref, int rs, MhGeom g, vvcgpu_mvcost mv,
                                                        vvcgpu_search_best* __restrict__ r16, vvcgpu_search_best* __restrict__ r32, vvcgpu_search_best* __restrict__ r64,
-                                                       vvcgpu_search_best* __restrict__ d16, vvcgpu_search_best* __restrict__ d32, vvcgpu_search_best* __restrict__ d64)
+                                                       vvcgpu_search_best* __restrict__ d16, vvcgpu_search_best* __restrict__ d32, vvcgpu_search_best* __restrict__ d64,
+                                                       unsigned long long* __restrict__ diag)
 {
   extern __shared__ __align__(16) unsigned refL[];
   __shared__ unsigned long long keys[42];                                       // raster: 16 + 4 + 1, then the same for the +-D grid
   __shared__ unsigned costTab[R5C_COST_N];                                      // lambda * bits, truncated (host: below 2^29)
   __shared__ unsigned char bitsRX[MH_MAXN + 1], bitsRY[MH_MAXN + 1], bitsDX[12], bitsDY[12];
-  __shared__ unsigned surfD[64 * 4];
+  __shared__ short dlKey[12];                                                  // dense spans of a grid row: start of the span in quads of the window row
+  __shared__ signed char dlX[12 * 4];                                          // ... and the grid column of each of its four candidates (-128: none)
+  __shared__ unsigned surfD[MH_MAXDL * 4];
   const int tid = threadIdx.x, lane = tid & 63;
   const int chunk = (g.total + 7) >> 3;                                          // XCD-aware order: every XCD gets a contiguous run of super-blocks
   const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
   if (item >= g.total) return;
   const int sby = item / g.nsbx, sbx = item - sby * g.nsbx;
   const int nsubx = min(4, g.n16x - 4 * sbx), nsuby = min(4, g.n16y - 4 * sby);
+  // VVCGPU_MH_DIAG: core-clock stamps of one workgroup's phases (start, window staged, every unit's end, units done, 64x64 pass done)
+  const bool stamp = diag && item == (g.total >> 1);
+  const int stampK = item == (g.total >> 2) ? 0 : item == (g.total >> 3) ? 1 : item == 3 * (g.total >> 2) ? 2 : item == 5 * (g.total >> 3) ? 3 : -1;   // four more workgroups: phase ends only
+  if (diag && stampK >= 0 && tid == 0) diag[40 + 0 * 4 + stampK] = __builtin_amdgcn_s_memtime();
+  if (stamp && tid == 0) diag[0] = __builtin_amdgcn_s_memtime();
   unsigned* surf = refL + (g.winBytes >> 2);                                     // [MH_MAXSLOTS][4]
 
   const int winCols = (g.nR - 1) * 5 + 16 * nsubx, winRows = (g.nR - 1) * 5 + 16 * nsuby - (1 << g.subShift) + 1;
@@ -168,8 +248,10 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
   fill_window_cols<8>(refL, reinterpret_cast<const uint4*>(ref + (winOff - off)), rs >> 3, winRows, MH_PITCH, ((winCols - 1 + off) >> 3) + 1, tid, (int)blockDim.x);
   for (int n = tid; n < R5C_COST_N; n += (int)blockDim.x) costTab[n] = (unsigned)(unsigned long long)(mv.lambda * (double)n);
   if (tid < 42) keys[tid] = ~0ull;
-  if (tid < 256) surfD[tid] = 0u;
+  if (tid < MH_MAXDL * 4) surfD[tid] = 0u;
   for (int n = tid; n < MH_MAXSLOTS * 4; n += (int)blockDim.x) surf[n] = 0u;
+  if (tid >= 512 && tid < 512 + 12) dlKey[tid - 512] = g.dlKey[tid - 512];
+  if (tid >= 576 && tid < 576 + 48) dlX[tid - 576] = g.dlX[tid - 576];
   if (tid < 2 * g.nR)
   {
     const int n = tid < g.nR ? tid : tid - g.nR;
@@ -183,93 +265,43 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
     (t < g.nD ? bitsDX : bitsDY)[n] = (unsigned char)expgolomb_bits(v >> mv.imv_shift);
   }
   __syncthreads();
+  if (stamp && tid == 0) diag[1] = __builtin_amdgcn_s_memtime();
+  if (diag && stampK >= 0 && tid == 0) diag[40 + 1 * 4 + stampK] = __builtin_amdgcn_s_memtime();
 
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
   const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)refL;
-  const int nq = (g.nR + 3) >> 2, nslots = g.nR * nq, nsw = (nslots + 63) >> 6;
-  const int nqd = (g.nD + 3) >> 2, nslotsD = g.nD * nqd;
-  const int nunits = 4 * nsw + (g.nD ? 4 : 0);
-  for (int u = wave; u < nunits; u += nwaves)
+  MhTables T = { costTab, bitsRX, bitsRY, bitsDX, bitsDY, dlKey, dlX, g.dlCount };
+  const int nq = (g.nR + 3) >> 2, nslots = g.nR * nq, ndl = g.nD * T.dlCount, nsw = (nslots + ndl + 63) >> 6;
+  for (int u = wave; u < 4 * nsw; u += nwaves)
   {
-    if (u < 4 * nsw)
-    {
-      const int sw = u >> 2, q = u & 3;
-      const int s = sw * 64 + lane;
-      const bool live = s < nslots;
-      const int sc = live ? s : 0;                                                // dead lanes re-read a live lane's address (broadcast)
-      const int jj = sc / nq, i0 = 4 * (sc - jj * nq);
-      const int cx = 5 * i0 + off;
-      const unsigned base = ldsBase + (unsigned)(2 * (cx >> 2) + jj * 5 * MH_PITCH) * 4u + (unsigned)((q & 1) * 64 + (q >> 1) * 32 * MH_PITCH * 4);
-      const unsigned by = bitsRY[jj];
-      unsigned cst[4];
-#pragma unroll
-      for (int m = 0; m < 4; m++)
-      {
-        const bool in = live && i0 + m < g.nR;
-        cst[m] = ((in ? costTab[bitsRX[in ? i0 + m : 0] + by] : MH_INVALID) << 2) | (unsigned)m;
-      }
-      mh_unit<5>(orgPacked, g, off & 3, base, cst, (unsigned)(jj * g.nR + i0), q, sbx, sby, nsubx, nsuby, keys, surf, s, live, lane);
-    }
-    else
-    {
-      const int q = u - 4 * nsw;
-      const bool live = lane < nslotsD;
-      const int sc = live ? lane : 0;
-      const int jj = sc / nqd, i0 = 4 * (sc - jj * nqd);
-      const int cx = g.R - g.D + i0 + off;
-      const unsigned base = ldsBase + (unsigned)(2 * (cx >> 2) + (g.R - g.D + jj) * MH_PITCH) * 4u + (unsigned)((q & 1) * 64 + (q >> 1) * 32 * MH_PITCH * 4);
-      const unsigned by = bitsDY[jj];
-      unsigned cst[4];
-#pragma unroll
-      for (int m = 0; m < 4; m++)
-      {
-        const bool in = live && i0 + m < g.nD;
-        cst[m] = ((in ? costTab[bitsDX[in ? i0 + m : 0] + by] : MH_INVALID) << 2) | (unsigned)m;
-      }
-      mh_unit<1>(orgPacked, g, cx & 3, base, cst, (unsigned)(jj * g.nD + i0), q, sbx, sby, nsubx, nsuby, keys + 21, surfD, lane, live, lane);
-    }
+    // the last slot wave goes FIRST: its dense lanes (rows one window row apart) meet LDS bank conflicts the raster lanes do not have, so its four
+    // units are the slowest; started first they run beside twelve others instead of ending the workgroup alone
+    const int sw = nsw - 1 - (u >> 2), q = u & 3;
+    const int s = sw * 64 + lane;
+    MhLane L;
+    mh_lane(s, g, T, off, nq, nslots, ndl, L);
+    const bool waveHasDense = ndl > 0 && sw * 64 + 63 >= nslots;                  // wave-uniform
+    mh_unit(orgPacked, g, off & 3, ldsBase + (unsigned)((q & 1) * 64 + (q >> 1) * 32 * MH_PITCH * 4), L, waveHasDense, q, sbx, sby, nsubx, nsuby, keys, surf, surfD, s, nslots, lane);
+    if (stamp && lane == 0) diag[8 + u] = __builtin_amdgcn_s_memtime();
   }
   __syncthreads();
+  if (stamp && tid == 0) diag[2] = __builtin_amdgcn_s_memtime();
 
-  // 64x64: cost + arg-min over the LDS surface (slot order = visiting order)
-  if (nsubx == 4 && nsuby == 4)
+  // 64x64: cost + arg-min over the LDS surfaces
+  if (nsubx == 4 && nsuby == 4 && wave < nsw)
   {
-    const int sh = g.subShift + 2;
-    if (wave < nsw)
-    {
-      const int s = tid;
-      const bool live = s < nslots;
-      const int sc = live ? s : 0;
-      const int jj = sc / nq, i0 = 4 * (sc - jj * nq);
-      const unsigned by = bitsRY[jj];
-      unsigned k = 0xFFFFFFFFu;
+    const int sh = g.subShift + 2, s = tid;
+    MhLane L;
+    mh_lane(s, g, T, off, nq, nslots, ndl, L);
+    unsigned a[4];
 #pragma unroll
-      for (int m = 0; m < 4; m++)
-      {
-        const bool in = live && i0 + m < g.nR;
-        const unsigned c = ((in ? costTab[bitsRX[in ? i0 + m : 0] + by] : MH_INVALID) << 2) | (unsigned)m;
-        k = min(k, (surf[sc * 4 + m] << sh) + c);
-      }
-      mh_block_min(k, (unsigned)(jj * g.nR + i0), &keys[20], lane);
-    }
-    else if (wave == 8 && g.nD)
-    {
-      const bool live = lane < nslotsD;
-      const int sc = live ? lane : 0;
-      const int jj = sc / nqd, i0 = 4 * (sc - jj * nqd);
-      const unsigned by = bitsDY[jj];
-      unsigned k = 0xFFFFFFFFu;
-#pragma unroll
-      for (int m = 0; m < 4; m++)
-      {
-        const bool in = live && i0 + m < g.nD;
-        const unsigned c = ((in ? costTab[bitsDX[in ? i0 + m : 0] + by] : MH_INVALID) << 2) | (unsigned)m;
-        k = min(k, (surfD[sc * 4 + m] << sh) + c);
-      }
-      mh_block_min(k, (unsigned)(jj * g.nD + i0), &keys[41], lane);
-    }
+    for (int m = 0; m < 4; m++) a[m] = L.kind == 1 ? surf[s * 4 + m] : L.kind == 2 ? surfD[(s - nslots) * 4 + m] : 0u;
+    mh_block_min(L.kind == 1 ? mh_fold32(a, L, sh) : 0xFFFFFFFFu, L.idx, &keys[20], lane);
+    if (ndl > 0 && wave * 64 + 63 >= nslots) mh_block_min64(L.kind == 2 ? mh_fold64(a, L, sh) : ~0ull, &keys[41], lane);
   }
   __syncthreads();
+  if (stamp && tid == 0) diag[3] = __builtin_amdgcn_s_memtime();
+  if (diag && stampK >= 0 && tid == 0) diag[40 + 2 * 4 + stampK] = __builtin_amdgcn_s_memtime();
 
   // final records: thread t < 21: raster result of block t of the super-block, 21 <= t < 42: the +-D grid
   if (tid < 42)
@@ -310,7 +342,7 @@ int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref
                 "me_hier_search: dense result arrays");
   const int nR = 2 * (c.raster_range / 5) + 1, R = 5 * (c.raster_range / 5), nD = c.dense_range ? 2 * c.dense_range + 1 : 0;
   // outside the kernel's shape: the caller takes the per-size searches (vvcgpu_sad_search), which are the same results
-  if (nR > MH_MAXN || nD > 9 || c.dense_range > R || c.sub_shift < 0 || c.sub_shift > 1 || (org_stride & 1) || (ref_stride & 7) || ((uintptr_t)org & 3) || ((uintptr_t)ref & 15) ||
+  if (nR > MH_MAXN || nD > 9 || (c.dense_range && R < c.dense_range + 15) || c.sub_shift < 0 || c.sub_shift > 1 || (org_stride & 1) || (ref_stride & 7) || ((uintptr_t)org & 3) || ((uintptr_t)ref & 15) ||
       !(mvcost_host->lambda >= 0.0 && mvcost_host->lambda < 4.0e6))
   {
     vvcgpu_set_error("me_hier_search: shape outside the hierarchical kernel (raster +-%d, +-%d grid, sub_shift %d, strides %d / %d, lambda %g)",
@@ -322,6 +354,16 @@ int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref
   g.n16x = c.n16x; g.n16y = c.n16y; g.nsbx = cdiv(c.n16x, 4); g.total = g.nsbx * cdiv(c.n16y, 4);
   g.refX0 = c.ref_x; g.refY0 = c.ref_y; g.subShift = c.sub_shift; g.hs = 16 >> c.sub_shift;
   g.nR = nR; g.R = R; g.nD = nD; g.D = c.dense_range;
+  g.dlCount = 0;
+  memset(g.dlKey, 0, sizeof g.dlKey); memset(g.dlX, -128, sizeof g.dlX);
+  for (int x = -c.dense_range; x <= c.dense_range && nD; x++)
+  {
+    const int m = (R + x) & 3, key = (R + x - 5 * m) >> 2;
+    int l = 0;
+    while (l < g.dlCount && g.dlKey[l] != key) l++;
+    if (l == g.dlCount) g.dlKey[g.dlCount++] = (short)key;
+    g.dlX[4 * l + m] = (signed char)x;
+  }
   const int winRowsMax = (nR - 1) * 5 + 64;
   g.winBytes = winRowsMax * MH_PITCH * 4;
   const size_t smem = (size_t)g.winBytes + MH_MAXSLOTS * 4 * sizeof(unsigned);
@@ -331,9 +373,24 @@ int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref
   hipLaunchKernelGGL(mh_pack_org_kernel, dim3((unsigned)(((size_t)nblocks * g.hs + 255) / 256)), dim3(256), 0, st, org, org_stride, c.org_x, c.org_y, c.n16x, nblocks, g.hs, c.sub_shift, packed);
   VVC_LAUNCH_CHECK();
   VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(me_hier_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
+  unsigned long long* diag = nullptr;
+  const bool wantDiag = getenv("VVCGPU_MH_DIAG") != nullptr;                 // measurement aid (tools/mehier_time.py): phase stamps of one workgroup
+  if (wantDiag) { VVC_HIP(hipMalloc(&diag, 64 * sizeof(unsigned long long))); VVC_HIP(hipMemsetAsync(diag, 0, 64 * sizeof(unsigned long long), st)); }
   hipLaunchKernelGGL(me_hier_kernel, dim3(cdiv(g.total, 8) * 8), dim3(1024), smem, st, packed, ref, ref_stride, g, *mvcost_host,
-                     raster_best[0], raster_best[1], raster_best[2], dense_best ? dense_best[0] : nullptr, dense_best ? dense_best[1] : nullptr, dense_best ? dense_best[2] : nullptr);
+                     raster_best[0], raster_best[1], raster_best[2], dense_best ? dense_best[0] : nullptr, dense_best ? dense_best[1] : nullptr, dense_best ? dense_best[2] : nullptr, diag);
   VVC_LAUNCH_CHECK();
+  if (wantDiag)
+  {
+    unsigned long long h[64];
+    VVC_HIP(hipStreamSynchronize(st));
+    VVC_HIP(hipMemcpy(h, diag, sizeof h, hipMemcpyDeviceToHost));
+    (void)hipFree(diag);
+    fprintf(stderr, "[vvcgpu me_hier diag] cycles: window staged %llu, units done %llu, 64x64 pass %llu; per unit end (since start):", h[1] - h[0], h[2] - h[0], h[3] - h[0]);
+    for (int u = 0; u < 32; u++) if (h[8 + u]) fprintf(stderr, " %llu", h[8 + u] - h[0]);
+    fprintf(stderr, "\n[vvcgpu me_hier diag] four more workgroups (window staged / all done):");
+    for (int k = 0; k < 4; k++) fprintf(stderr, " %llu / %llu", h[44 + k] - h[40 + k], h[48 + k] - h[40 + k]);
+    fprintf(stderr, "\n");
+  }
   return VVCGPU_OK;
 }
 
