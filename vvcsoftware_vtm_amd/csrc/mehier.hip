@@ -182,7 +182,7 @@ __device__ __forceinline__ void mh_block_min64(unsigned long long k, unsigned lo
 //   keys   LDS: raster keys of the 16x16 blocks (16), the 32x32 (4), the 64x64 (1), then the same 21 for the +-D grid
 //   surf / surfD  LDS: 64x64 partial sums of the raster slots / the dense lanes, [slot][4]
 __device__ __forceinline__ void mh_unit(const unsigned* __restrict__ orgPacked, const MhGeom& g, int OA, unsigned qbase, const MhLane& L, bool waveHasDense,
-                                        int q, int sbx, int sby, int nsubx, int nsuby, unsigned long long* keys, unsigned* surf, unsigned* surfD, int s, int nslots, int lane)
+                                        int q, int sbx, int sby, int nsubx, int nsuby, unsigned long long* keys, unsigned* surf, unsigned* surfD, int* arrive, int s, int nslots, int lane)
 {
   const int qx = q & 1, qy = q >> 1;
   const int ldsStep = MH_PITCH << g.subShift;
@@ -208,11 +208,30 @@ __device__ __forceinline__ void mh_unit(const unsigned* __restrict__ orgPacked, 
   {
     mh_block_min(L.kind == 1 ? mh_fold32(a32, L, sh) : 0xFFFFFFFFu, L.idx, &keys[16 + q], lane);
     if (waveHasDense) mh_block_min64(L.kind == 2 ? mh_fold64(a32, L, sh) : ~0ull, &keys[21 + 16 + q], lane);
-    if (nsubx == 4 && nsuby == 4 && L.kind)
+    if (nsubx == 4 && nsuby == 4)
     {
-      unsigned* dst = L.kind == 1 ? surf + s * 4 : surfD + (s - nslots) * 4;
+      // 64x64: the four quadrants of a slot wave add their sums to the LDS surface; the one that arrives last folds the totals (no separate pass behind
+      // a barrier).  A wave's LDS operations execute in program order, so a quadrant's adds are in the surface before its ticket: the wave that draws
+      // ticket 3 reads all four contributions.
+      unsigned* dst = L.kind == 2 ? surfD + (s - nslots) * 4 : surf + (L.kind ? s : 0) * 4;
+      if (L.kind)
+      {
 #pragma unroll
-      for (int m = 0; m < 4; m++) atomicAdd(&dst[m], a32[m]);
+        for (int m = 0; m < 4; m++) atomicAdd(&dst[m], a32[m]);
+      }
+      int ticket = 0;
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");                       // (a wait for the adds above: the data is in LDS before the ticket)
+      if (lane == 0) ticket = atomicAdd(arrive, 1);
+      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      ticket = __builtin_amdgcn_readfirstlane(ticket);
+      if (ticket == 3)
+      {
+        unsigned a[4];
+#pragma unroll
+        for (int m = 0; m < 4; m++) a[m] = L.kind ? dst[m] : 0u;
+        mh_block_min(L.kind == 1 ? mh_fold32(a, L, sh) : 0xFFFFFFFFu, L.idx, &keys[20], lane);
+        if (waveHasDense) mh_block_min64(L.kind == 2 ? mh_fold64(a, L, sh) : ~0ull, &keys[41], lane);
+      }
     }
   }
 }
@@ -229,6 +248,7 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
   __shared__ short dlKey[12];                                                  // dense spans of a grid row: start of the span in quads of the window row
   __shared__ signed char dlX[12 * 4];                                          // ... and the grid column of each of its four candidates (-128: none)
   __shared__ unsigned surfD[MH_MAXDL * 4];
+  __shared__ int arrive[8];                                                    // per slot wave: quadrants that have added their 32x32 sums to the 64x64 surface
   const int tid = threadIdx.x, lane = tid & 63;
   const int chunk = (g.total + 7) >> 3;                                          // XCD-aware order: every XCD gets a contiguous run of super-blocks
   const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
@@ -248,6 +268,7 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
   fill_window_cols<8>(refL, reinterpret_cast<const uint4*>(ref + (winOff - off)), rs >> 3, winRows, MH_PITCH, ((winCols - 1 + off) >> 3) + 1, tid, (int)blockDim.x);
   for (int n = tid; n < R5C_COST_N; n += (int)blockDim.x) costTab[n] = (unsigned)(unsigned long long)(mv.lambda * (double)n);
   if (tid < 42) keys[tid] = ~0ull;
+  if (tid >= 64 && tid < 72) arrive[tid - 64] = 0;
   if (tid < MH_MAXDL * 4) surfD[tid] = 0u;
   for (int n = tid; n < MH_MAXSLOTS * 4; n += (int)blockDim.x) surf[n] = 0u;
   if (tid >= 512 && tid < 512 + 12) dlKey[tid - 512] = g.dlKey[tid - 512];
@@ -281,26 +302,11 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
     MhLane L;
     mh_lane(s, g, T, off, nq, nslots, ndl, L);
     const bool waveHasDense = ndl > 0 && sw * 64 + 63 >= nslots;                  // wave-uniform
-    mh_unit(orgPacked, g, off & 3, ldsBase + (unsigned)((q & 1) * 64 + (q >> 1) * 32 * MH_PITCH * 4), L, waveHasDense, q, sbx, sby, nsubx, nsuby, keys, surf, surfD, s, nslots, lane);
+    mh_unit(orgPacked, g, off & 3, ldsBase + (unsigned)((q & 1) * 64 + (q >> 1) * 32 * MH_PITCH * 4), L, waveHasDense, q, sbx, sby, nsubx, nsuby, keys, surf, surfD, &arrive[sw], s, nslots, lane);
     if (stamp && lane == 0) diag[8 + u] = __builtin_amdgcn_s_memtime();
   }
   __syncthreads();
-  if (stamp && tid == 0) diag[2] = __builtin_amdgcn_s_memtime();
-
-  // 64x64: cost + arg-min over the LDS surfaces
-  if (nsubx == 4 && nsuby == 4 && wave < nsw)
-  {
-    const int sh = g.subShift + 2, s = tid;
-    MhLane L;
-    mh_lane(s, g, T, off, nq, nslots, ndl, L);
-    unsigned a[4];
-#pragma unroll
-    for (int m = 0; m < 4; m++) a[m] = L.kind == 1 ? surf[s * 4 + m] : L.kind == 2 ? surfD[(s - nslots) * 4 + m] : 0u;
-    mh_block_min(L.kind == 1 ? mh_fold32(a, L, sh) : 0xFFFFFFFFu, L.idx, &keys[20], lane);
-    if (ndl > 0 && wave * 64 + 63 >= nslots) mh_block_min64(L.kind == 2 ? mh_fold64(a, L, sh) : ~0ull, &keys[41], lane);
-  }
-  __syncthreads();
-  if (stamp && tid == 0) diag[3] = __builtin_amdgcn_s_memtime();
+  if (stamp && tid == 0) diag[2] = diag[3] = __builtin_amdgcn_s_memtime();
   if (diag && stampK >= 0 && tid == 0) diag[40 + 2 * 4 + stampK] = __builtin_amdgcn_s_memtime();
 
   // final records: thread t < 21: raster result of block t of the super-block, 21 <= t < 42: the +-D grid
