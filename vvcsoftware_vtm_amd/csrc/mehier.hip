@@ -51,6 +51,7 @@ struct MhGeom
   int winBytes;                                        // LDS bytes of the window
   // the spans of the +-D grid (host-built): column x is candidate m = (R + x) mod 4 of the span that starts (R + x - 5 m) / 4 quads into the window row
   int dlCount; short dlKey[12]; signed char dlX[48];   // per span: start in quads, grid column of each candidate (-128: none)
+  unsigned magicNq, magicDl;                           // ceil(65536 / n): v / n == (v * magic) >> 16 for the slot indices (< 448, n <= 10)
 };
 
 // original rows packed per 16x16 block: [block][sampled row][even 8 dwords | odd 8 dwords], biased; layouts as r5c_pack_org_kernel (dist.hip)
@@ -127,7 +128,7 @@ __device__ __forceinline__ void mh_lane(int s, const MhGeom& g, const MhTables& 
   L.kind = s < nslots ? 1 : (s - nslots < ndl ? 2 : 0);
   if (L.kind == 2)
   {
-    const int e = s - nslots, j = e / T.dlCount, l = e - j * T.dlCount;
+    const int e = s - nslots, j = (int)(((unsigned)e * g.magicDl) >> 16), l = e - j * T.dlCount;
     L.base = (unsigned)(2 * (int)T.dlKey[l] + 2 * (off >> 2) + (g.R - g.D + j) * MH_PITCH) * 4u;
     const unsigned by = T.bitsDY[j];
     L.idx = 0;
@@ -142,7 +143,7 @@ __device__ __forceinline__ void mh_lane(int s, const MhGeom& g, const MhTables& 
     return;
   }
   const int sc = L.kind ? s : 0;                                                   // dead lanes re-read a live lane's address (broadcast)
-  const int jj = sc / nq, i0 = 4 * (sc - jj * nq);
+  const int jj = (int)(((unsigned)sc * g.magicNq) >> 16), i0 = 4 * (sc - jj * nq);
   const int cx = 5 * i0 + off;
   L.base = (unsigned)(2 * (cx >> 2) + jj * 5 * MH_PITCH) * 4u;
   const unsigned by = T.bitsRY[jj];
@@ -361,6 +362,7 @@ int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref
   g.refX0 = c.ref_x; g.refY0 = c.ref_y; g.subShift = c.sub_shift; g.hs = 16 >> c.sub_shift;
   g.nR = nR; g.R = R; g.nD = nD; g.D = c.dense_range;
   g.dlCount = 0;
+  g.magicNq = (65536u + (unsigned)((nR + 3) >> 2) - 1u) / (unsigned)((nR + 3) >> 2);
   memset(g.dlKey, 0, sizeof g.dlKey); memset(g.dlX, -128, sizeof g.dlX);
   for (int x = -c.dense_range; x <= c.dense_range && nD; x++)
   {
@@ -370,6 +372,7 @@ int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref
     if (l == g.dlCount) g.dlKey[g.dlCount++] = (short)key;
     g.dlX[4 * l + m] = (signed char)x;
   }
+  g.magicDl = g.dlCount ? (65536u + (unsigned)g.dlCount - 1u) / (unsigned)g.dlCount : 0u;
   const int winRowsMax = (nR - 1) * 5 + 64;
   g.winBytes = winRowsMax * MH_PITCH * 4;
   const size_t smem = (size_t)g.winBytes + MH_MAXSLOTS * 4 * sizeof(unsigned);
