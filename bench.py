@@ -61,6 +61,9 @@ def parse_args():
                     help="resident copies of the per-picture inputs (original + first reference picture) the pictures cycle through: 12 x 56 MB at 4K exceeds "
                          "the 256 MB memory-side cache, so the input reads and the counters behind hbm_frac are HBM-side (1 = every picture re-reads the same buffers)")
     ap.add_argument("--no-input-stream", action="store_true", help="skip the second timed region that uploads one original picture per picture from pinned host memory")
+    ap.add_argument("--rehearse", action="store_true",
+                    help="N > 1 on ONE GPU: every rank takes device (local rank mod device count) and the process group is gloo (RCCL refuses two ranks on "
+                         "one device); the hand-over keeps the grouped form the RCCL run takes.  A rehearsal of the N > 1 control flow, not a measurement")
     ap.add_argument("--dry-launch", action="store_true",
                     help="launcher check without a GPU: start the ranks (gloo), verify the world size, hand one dummy boundary picture round the ring")
     return ap.parse_args()
@@ -271,10 +274,15 @@ def main():
                          "torch.distributed.run --nproc-per-node %d)" % (args.gpus, world, args.gpus, args.gpus))
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (the product path has no CPU fallback)")
+    if args.rehearse:
+        local_rank %= max(1, torch.cuda.device_count())
     torch.cuda.set_device(local_rank)
     capi.call("vvcgpu_set_device", local_rank)
     if world > 1:
-        dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
+        if args.rehearse:
+            dist.init_process_group("gloo")
+        else:
+            dist.init_process_group("nccl", device_id=torch.device("cuda", local_rank))
         if dist.get_world_size() != args.gpus:
             raise SystemExit("bench.py: RCCL sees %d ranks, --gpus %d" % (dist.get_world_size(), args.gpus))
 
@@ -376,7 +384,7 @@ def main():
         (shard.Handover: no unbatched point-to-point on the eagerly initialised group); the wait comes only where the NEXT chunk first needs the
         picture -- in front of the motion compensation of its first picture, behind that picture's searches -- so a rank never waits at a step boundary."""
         nonlocal state, out
-        h = shard.Handover(out["final"], rank, world).post_recv()
+        h = shard.Handover(out["final"], rank, world, batched=True if args.rehearse else None).post_recv()
         for i in range(pps):
             state, out = wl.run_gpu(state, tm, overlap=overlap, alone=alone, pre_mc=install_pending if i == 0 else None, rotate=rotate, on_input_set=on_input_set)
         install_pending()                                   # (pps == 0 guard; a no-op otherwise)
@@ -551,6 +559,7 @@ def main():
             "value": pictures / dt,
             "unit": "frames/s",
             "n_gpus": world,
+            "rehearsal": bool(args.rehearse),
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3,
