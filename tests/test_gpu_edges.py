@@ -110,3 +110,27 @@ def test_many_short_lived_streams():
     ops.mc_batch(ref, ref, out, dd, n, bd, (0, mx))
     torch.cuda.synchronize()
     assert np.array_equal(out.cpu().numpy(), want)
+
+
+def test_out_of_contract_descriptors_give_the_sentinel():
+    """descriptors live in device memory, so the library cannot validate them on the host: the fused predict-and-distort kernels skip a descriptor whose
+    shape does not fit their LDS tile and answer the documented sentinel ~0 (include/vvcgpu.h) instead of overrunning LDS; the valid neighbours of the
+    bad descriptor in the same launch keep their exact results"""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(5)
+    bd, mx, W, H = 10, 1023, 384, 320
+    r0, org = cases.rand_plane(rng, H, W, bd, "smooth"), cases.rand_plane(rng, H, W, bd, "smooth")
+    # vvcgpu_mc_dist_batch: w / h outside 1..128, bi outside 0..1
+    good = (16 * W + 16, 16 * W + 16, 40 * W + 40, W, W, W, 16, 16, 4, 8, 0, 0, 1, 0, 0)
+    rows = [good, (16 * W + 16, 16 * W + 16, 40 * W + 40, W, W, W, 200, 16, 0, 0, 0, 0, 1, 0, 0), good, (0, 0, 0, W, W, W, 16, 0, 0, 0, 0, 0, 1, 0, 0),
+            (16 * W + 16, 16 * W + 16, 40 * W + 40, W, W, W, 16, 16, 0, 0, 0, 0, 1, 2, 0), good]
+    d = np.array(rows, dtype=ops.MC_DESC)
+    got = ops.mc_dist_batch(0, dev(r0), dev(r0), dev(org), ops.struct_to_device(d), len(d), bd, (0, mx)).cpu().numpy().view(np.uint64)
+    assert got[1] == got[3] == got[4] == np.uint64(0xFFFFFFFFFFFFFFFF)
+    assert got[0] == got[2] == got[5] and got[0] != np.uint64(0xFFFFFFFFFFFFFFFF)
+    # vvcgpu_intra_satd_batch: w / h outside 1..64
+    T, L = ops.intra_ref_lengths(16, 16)
+    refs = rng.integers(0, mx + 1, 4 * (T + L + 1) + 600).astype(np.int16)
+    sd = np.array([(0, 0, 24, 16, 16, 18, 0, 0, 0), (0, 0, 24, 128, 16, 18, 0, 0, 0), (0, 0, 24, 16, 16, 18, 0, 0, 0)], dtype=ops.INTRA_SATD_DESC)
+    got = ops.intra_satd_batch(dev(refs), dev(org.reshape(-1)), ops.struct_to_device(sd), len(sd), clp=(0, mx)).cpu().numpy().view(np.uint64)
+    assert got[1] == np.uint64(0xFFFFFFFFFFFFFFFF) and got[0] == got[2] != np.uint64(0xFFFFFFFFFFFFFFFF)
