@@ -513,7 +513,9 @@ typedef struct vvcgpu_tz_pu {
   int32_t start_x, start_y, pred2_x, pred2_y;
   int32_t pos_x, pos_y, pred_hor, pred_ver;
   int16_t w, h, sub_shift, flags;
-  int32_t reserved[2];                  /* sizeof == 64 */
+  int32_t reserved[2];                  /* reserved[0] > 0: this PU's own search range (m_aaiAdaptSR[list][refIdx]: the adaptive search range is per
+                                           reference picture), 0: cfg.search_range; a batch may then mix the (list, reference) searches of one PU.
+                                           reserved[1]: 0.  sizeof == 64 */
 } vvcgpu_tz_pu;
 typedef struct vvcgpu_tz_cfg {
   double  lambda;

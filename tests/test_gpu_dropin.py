@@ -193,6 +193,18 @@ def test_encoder_random_access_gop16_fixture(tmp_path):
 
 
 @needs_ref
+def test_encoder_batched_pu_searches(tmp_path):
+    """VVCGPU_SHIM_HOOKS=pub: the uni-prediction searches of a CU (InterSearch::predInterSearch, InterSearch.cpp:876-960: one xMotionEstimation per
+    list / reference pair) run as ONE vvcgpu_me_batch on device-resident pictures in front of the reference's own function, which is then served from
+    that session; every served integer search is also A/B-checked against the reference's own xTZSearch body (VVCGPU_SHIM_TZ_VERIFY) -- same bitstream"""
+    m, r, numbers = _encode_fixture(tmp_path, "rab_208x120_10b_q32", {"VVCGPU_SHIM_HOOKS": "pub", "VVCGPU_SHIM_TZ_LIMIT": "0", "VVCGPU_SHIM_TZ_VERIFY": "1"})
+    assert "TZ mismatch" not in r.stderr, [l for l in r.stderr.splitlines() if "mismatch" in l][:5]
+    (sessions, searches, served, fell, uploads), line = numbers("[vvcgpu batched]")[0][:5], numbers("[vvcgpu batched]")[1]
+    assert sessions > 0 and searches >= 2 * sessions and served > searches, line      # most searches of a session are served twice (integer + fractional)
+    print(line)
+
+
+@needs_ref
 @pytest.mark.skipif(not os.environ.get("VVCGPU_NIGHTLY"), reason="nightly-style run (minutes of synchronous round trips): VVCGPU_NIGHTLY=1")
 @pytest.mark.parametrize("name,level", [("rab_208x120_10b_q32", "all"), ("ragop16_416x240_10b_q32", "pu")])
 def test_nightly_uncapped_hooks(tmp_path, name, level):

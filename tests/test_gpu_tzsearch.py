@@ -208,3 +208,29 @@ def test_tz_search_split_form(w, h, srange, bd):
     cfg_split["reserved"] = (h << 16) | w               # vvcgpu_tz_cfg.uniform_pu (numpy field name of the fixtures)
     got = run_gpu(org, ref_, pus, cfg_split)
     assert np.array_equal(got, want), np.nonzero(got != want)[0][:8]
+
+
+@pytest.mark.parametrize("w,h,split", [(16, 16, 1), (32, 32, 1), (8, 16, 0), (64, 64, 0)])
+def test_tz_search_per_pu_range(w, h, split):
+    """vvcgpu_tz_pu.reserved[0] > 0 is the PU's OWN search range (m_aaiAdaptSR[list][refIdx]: the adaptive search range is per reference picture,
+    InterSearch.cpp:1674), so one batch may hold the (list, reference) searches of one CU -- what the batched binding of the drop-in shim sends.
+    Same results as the oracle called range by range, in the one-launch and in the split form (cfg.search_range = the largest range sizes the
+    raster grid of the latter)."""
+    rng = np.random.default_rng(w * 31 + h + split)
+    W, H, M, bd = 448, 320, 160, 10
+    org, ref_ = cases.tz_planes(rng, W, H, M, bd, motion=(int(rng.integers(-20, 21)), int(rng.integers(-20, 21))))
+    n = 240
+    pus = cases.tz_pus(rng, n, W, H, M, [(w, h)], sub_mode2=True)
+    ranges = rng.choice([96, 64, 37, 24, 8, 0], size=n)          # 0: cfg.search_range
+    cfg = cases.tz_cfg(W, H, M, 23.5, search_range=96)
+    want = np.zeros(n, cases.BEST)
+    for r in np.unique(ranges):
+        c = cfg.copy()
+        c["search_range"] = int(r) if r else 96
+        sel = np.nonzero(ranges == r)[0]
+        want[sel] = run_oracle(org, ref_, np.ascontiguousarray(pus[sel]), c)
+    pus["reserved"][:, 0] = ranges
+    if split:
+        cfg["reserved"] = (h << 16) | w
+    got = run_gpu(org, ref_, pus, cfg)
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:8]

@@ -40,6 +40,7 @@ LEGS = {  # label -> (use the drop-in library, VVCGPU_SHIM_HOOKS level, descript
     "cpu": (0, None, "own SIMD kernels, 1 host core"),
     "pic": (1, "pic", "library bound in, picture-level hooks only (resident reconstruction: deblock, SAO stats + apply, ALF classify + stats + filter)"),
     "pu":  (1, "pu", "picture-level hooks + whole-PU searches (xTZSearch, xPatternSearchFracDIF, xPatternSearch), one round trip per PU"),
+    "pub": (1, "pub", "as pu, the uni-prediction searches of a CU (every list / reference pair) batched into ONE round trip on device-resident pictures"),
     "all": (1, "all", "every hook, block-level table slots included (one synchronous round trip per call: the proof form)"),
 }
 
@@ -61,11 +62,13 @@ def run(m, leg, tmp, limits0=False):
     if limits0:                                           # every call of the capped hooks is served (nightly-style run)
         for k in ("INTRA", "FILL", "DEPQUANT", "RDOQ", "DQIT", "TZ"):
             env["VVCGPU_SHIM_%s_LIMIT" % k] = "0"
+    if leg in ("pu", "pub"):
+        env["VVCGPU_SHIM_TZ_LIMIT"] = "0"                 # every integer search is served: the two forms are compared on the same calls
     t0 = time.perf_counter()
     r = subprocess.run(cmd, capture_output=True, text=True, timeout=3300, env=env)
     dt = time.perf_counter() - t0
     assert r.returncode == 0, r.stdout[-1500:] + r.stderr[-1500:]
-    shim = [l for l in r.stderr.splitlines() if "[vvcgpu shim]" in l or "[vvcgpu resident]" in l]
+    shim = [l for l in r.stderr.splitlines() if "[vvcgpu shim]" in l or "[vvcgpu resident]" in l or "[vvcgpu batched]" in l or "mismatch" in l]
     return dt, md5(binf), shim
 
 

@@ -32,10 +32,12 @@
 #include "CommonLib/Rom.h"
 #include "EncoderLib/InterSearch.h"
 #include "EncoderLib/EncCfg.h"
+#include "EncoderLib/EncModeCtrl.h"
 #include "CommonLib/TrQuant.h"
 #include "CommonLib/IntraPrediction.h"
 #include "CommonLib/DepQuant.h"
 #include "CommonLib/AffineGradientSearch.h"
+#include <chrono>
 #include "vvcgpu.h"
 #include "vtm_rates.h"
 
@@ -104,6 +106,8 @@ extern "C" int vvcshim_depquant(DepQuant* self, TransformUnit* tu, const Compone
                                 const Ctx* ctx);
 extern "C" int vvcshim_rdoq(QuantRDOQ* self, TransformUnit* tu, const ComponentID* compID, const CCoeffBuf* pSrc, TCoeff* uiAbsSum, const QpParam* cQP,
                             const Ctx* ctx);
+void real_predInterSearch(InterSearch*, CodingUnit&, Partitioner&) VVCSHIM_SYM("__real__ZN11InterSearch15predInterSearchER10CodingUnitR11Partitioner");
+void wrap_predInterSearch(InterSearch*, CodingUnit&, Partitioner&) VVCSHIM_SYM("__wrap__ZN11InterSearch15predInterSearchER10CodingUnitR11Partitioner");
 void real_extendPicBorder(Picture*) VVCSHIM_SYM("__real__ZN7Picture15extendPicBorderEv");
 void wrap_extendPicBorder(Picture*) VVCSHIM_SYM("__wrap__ZN7Picture15extendPicBorderEv");
 
@@ -127,11 +131,13 @@ int hookLevel()
     // pic: picture-level hooks only; pu: + whole-PU searches; all (default): + block-level table slots (64-wide calls) and the N1 / N4 hooks;
     // slots: picture-level hooks + the x86 function-pointer tables of SURVEY 8(b) for calls of EVERY width (no PU / N1 / N4 hooks, so that the
     // reference's own searches and transforms issue their table-slot calls): the literal boundary, one synchronous round trip per call
-    lv = getenv("VVCGPU_SHIM_NO_TABLES") ? 0 : !e ? 2 : !strcmp(e, "pic") ? 0 : !strcmp(e, "pu") ? 1 : !strcmp(e, "slots") ? 3 : 2;
+    // pub: as pu, with the uni-prediction searches of a PU -- every (list, reference) pair -- batched into ONE round trip (wrap_predInterSearch)
+    lv = getenv("VVCGPU_SHIM_NO_TABLES") ? 0 : !e ? 2 : !strcmp(e, "pic") ? 0 : (!strcmp(e, "pu") || !strcmp(e, "pub")) ? 1 : !strcmp(e, "slots") ? 3 : 2;
   }
   return lv;
 }
 static inline bool allWidths() { return hookLevel() == 3; }
+static inline bool puBatched() { static int on = -1; if (on < 0) { const char* e = getenv("VVCGPU_SHIM_HOOKS"); on = (e && !strcmp(e, "pub")) ? 1 : 0; } return on == 1; }
 bool shimEnabled()
 {
   static int on = -1;
@@ -168,7 +174,10 @@ bool residentEnabled();
 long g_calls[28] = { 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0, 0 };
 // calls an (eligible) hook left to the CPU because its call cap was reached: TZSearch, IntraPred, IntraRefs, DepQuant, RDOQ, DequantIT
 long g_capped[6] = { 0, 0, 0, 0, 0, 0 };
-long g_distWidth[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };          // distortion calls served in the every-width form, by width class: 4, 8, 12-16, 24-32, 48-64, 128
+long g_distWidth[8] = { 0, 0, 0, 0, 0, 0, 0, 0 };
+double g_meSec[3] = { 0, 0, 0 };                          // batched pre-pass: seconds in the AMVP derivation, in upload + launch + download + wait, total
+long g_why[16] = { 0 };                                  // batched pre-pass: why a CU was left to the per-call path (diagnostic)
+long g_batch[6] = { 0, 0, 0, 0, 0, 0 };                  // batched uni-prediction searches: sessions, searches in them, TZ + fractional calls served from a session, picture uploads, calls that fell back          // distortion calls served in the every-width form, by width class: 4, 8, 12-16, 24-32, 48-64, 128
 static inline bool capped(long limit, long calls, int slot) { if (limit > 0 && calls >= limit) { g_capped[slot]++; return true; } return false; }
 struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GPU calls: deblock %ld, SAO %ld, ALF %ld, SAO stats %ld, ALF stats %ld, "
                                                        "SAO CTU %ld, ALF block %ld, ALF classify block %ld, SAD64 %ld, HAD64 %ld, IF64 %ld, PelOp64 %ld, T1 %ld, T2 %ld, FracDIF %ld, FullSearch %ld, DequantIT %ld, SSE64 %ld, AffSobel %ld, AffEq %ld, TZSearch %ld, IntraPred %ld, Border %ld, Hash %ld, CCLM %ld, IntraRefs %ld, DepQuant %ld, RDOQ %ld\n",
@@ -178,6 +187,9 @@ struct Report { ~Report() { if (shimEnabled()) fprintf(stderr, "[vvcgpu shim] GP
                                                        g_distWidth[0], g_distWidth[1], g_distWidth[2], g_distWidth[3], g_distWidth[4], g_distWidth[5]);
                             if (shimEnabled()) fprintf(stderr, "[vvcgpu caps] eligible calls left to the CPU by a call cap (VVCGPU_SHIM_*_LIMIT, 0 = none): TZSearch %ld, IntraPred %ld, IntraRefs %ld, DepQuant %ld, RDOQ %ld, DequantIT %ld\n",
                                                        g_capped[0], g_capped[1], g_capped[2], g_capped[3], g_capped[4], g_capped[5]);
+                            if (shimEnabled() && puBatched()) { fprintf(stderr, "[vvcgpu batched why]"); for (int k = 0; k < 16; k++) fprintf(stderr, " %ld", g_why[k]); fprintf(stderr, "\n"); }
+                            if (shimEnabled() && g_batch[0]) fprintf(stderr, "[vvcgpu batched] uni-prediction searches: %ld PU sessions (one round trip each) with %ld (list, reference) searches, %ld xTZSearch / xPatternSearchFracDIF calls served from a session, %ld calls of a session's PU that took the per-call path, %ld picture uploads (original / reference); pre-pass %.2f s of which predictor derivation %.2f s, device round trips %.2f s\n",
+                                                       g_batch[0], g_batch[1], g_batch[2], g_batch[4], g_batch[3], g_meSec[2], g_meSec[0], g_meSec[1]);
                             if (shimEnabled()) fprintf(stderr, "[vvcgpu resident] in-loop chain: %ld pictures, %ld picture uploads (reconstruction / original), %ld picture downloads, resident form %s\n",
                                                        g_resPictures, g_resUploads, g_resDownloads, residentEnabled() ? "on" : "off"); } } g_report;
 
@@ -1276,12 +1288,26 @@ DevArray<vvcgpu_frac_blk> g_fBlk;
 DevArray<vvcgpu_frac_result> g_fRes;
 }
 
-extern "C" int vvcshim_frac(InterSearch* self, const PredictionUnit* pu, int /*eRefPicList*/, int /*iRefIdx*/, InterSearch::IntTZSearchStruct* cs,
+namespace { bool meSessionFrac(InterSearch* self, const PredictionUnit* pu, int list, int refIdx, InterSearch::IntTZSearchStruct* cs, const Mv* mvInt, vvcgpu_frac_result* r); }
+
+extern "C" int vvcshim_frac(InterSearch* self, const PredictionUnit* pu, int eRefPicList, int iRefIdx, InterSearch::IntTZSearchStruct* cs,
                             const Mv* mvInt, Mv* mvHalf, Mv* mvQter, Distortion* cost)
 {
   if (!gpuEnabled() || hookLevel() < 1 || hookLevel() == 3) return 0;
   const CPelBuf& key = *cs->pcPatternKey;
   const int w = key.width, h = key.height, bd = self->m_lumaClpRng.bd;
+  {
+    vvcgpu_frac_result r;
+    if (meSessionFrac(self, pu, eRefPicList, iRefIdx, cs, mvInt, &r))          // the batched pre-pass of this PU already refined this (list, reference) search
+    {
+      *mvHalf = Mv(r.half_x, r.half_y);
+      *mvQter = Mv(r.qter_x, r.qter_y);
+      *cost = (Distortion)r.cost;
+      self->m_pcRdCost->setCostScale(0);
+      return 1;
+    }
+    if (puBatched()) return 0;
+  }
 #if JVET_K0157
   const bool intOnly = cs->imvShift || (pu->cs->sps->getSpsNext().getUseCompositeRef() && cs->zeroMV);
 #else
@@ -1327,7 +1353,7 @@ DevArray<vvcgpu_search_best> g_sBest;
 
 extern "C" int vvcshim_fullsearch(InterSearch* self, InterSearch::IntTZSearchStruct* cs, Mv* rcMv, Distortion* ruiSAD)
 {
-  if (!gpuEnabled() || hookLevel() < 1 || hookLevel() == 3) return 0;
+  if (!gpuEnabled() || hookLevel() < 1 || hookLevel() == 3 || puBatched()) return 0;
   const CPelBuf& key = *cs->pcPatternKey;
   const int w = key.width, h = key.height, bd = self->m_lumaClpRng.bd;
   const InterSearch::SearchRange& sr = cs->searchRange;
@@ -1363,6 +1389,231 @@ extern "C" int vvcshim_fullsearch(InterSearch* self, InterSearch::IntTZSearchStr
   self->m_cDistParam.maximumDistortionForEarlyExit = (Distortion)b.cost;    // the state the reference's loop leaves behind (:1918)
   g_calls[15]++;
   return 1;
+}
+
+// ---- Batched uni-prediction searches of a PU (VVCGPU_SHIM_HOOKS=pub; round 4).  The per-PU binding above pays one synchronous round trip per
+// xTZSearch and one per xPatternSearchFracDIF -- 57 - 68 us each against ~12 us for the host's own search -- and ONE PU's search is a ~30 us
+// dependent chain on the device: the GPU only wins by running searches side by side.  What a CU offers without touching the RDO recursion are the
+// uni-prediction searches of InterSearch::predInterSearch (InterSearch.cpp:876-960): one xMotionEstimation per (list, reference index), independent
+// of each other once their AMVP predictors are known.  wrap_predInterSearch runs a PRE-PASS in front of the reference's own function:
+//   * the predictor of every (list, reference) pair with the reference's OWN xEstimateMvPredAMVP (pu.mvpIdx / mvpNum restored afterwards),
+//   * the search parameters exactly as xMotionEstimation sets them (:1668-1760: adaptive search range of the pair, cached integer vector of the
+//     block -> start vector + fast settings, sub-sampling mode, motion lambda),
+//   * ONE vvcgpu_me_batch (integer TZ search + fused fractional refinement of all pairs: every pair is one vvcgpu_tz_pu with its own predictor,
+//     search range (reserved[0]) and reference picture) on pictures that are RESIDENT on the device -- the original once per picture, every
+//     reference picture once (its padded plane verbatim, all pictures stacked in one plane so that a pair's picture is a row offset) --
+//     and one download of the results.
+// Then the reference's own predInterSearch runs; its xTZSearch / xPatternSearchFracDIF calls are pre-empted as before and served from the
+// session when their inputs equal what the pre-pass assumed (same reference rows, start vector, predictor, flags, range), and take the per-call path
+// otherwise -- so the result is the reference's whatever the pre-pass guessed.  Bi-prediction, AMVR (imv != 0) and affine searches keep the per-call path.
+namespace {
+struct DevDpb                                // reference pictures resident on the device, stacked in ONE plane
+{
+  vvc_pel* plane = nullptr; int stride = 0, slotRows = 0, nSlots = 0;
+  struct Slot { const Pel* hostOrigin = nullptr; int poc = -1 << 30; long stamp = 0; };
+  std::vector<Slot> slots; long clock = 0;
+  // row offset of the slot that holds the padded luma plane starting at `padOrigin` (stride x rows samples); uploads it on a miss
+  int slotRow(const Pel* padOrigin, int poc, int strideH, int rows)
+  {
+    if (!plane || strideH != stride || rows != slotRows)
+    {
+      if (plane) VVCGPU(vvcgpu_free(plane));
+      stride = strideH; slotRows = rows; nSlots = 10;
+      VVCGPU(vvcgpu_malloc((void**)&plane, (size_t)stride * slotRows * nSlots * sizeof(vvc_pel) + 64));
+      slots.assign(nSlots, Slot());
+    }
+    int hit = -1, lru = 0;
+    for (int k = 0; k < nSlots; k++)
+    {
+      if (slots[k].hostOrigin == padOrigin && slots[k].poc == poc) hit = k;
+      if (slots[k].stamp < slots[lru].stamp) lru = k;
+    }
+    if (hit < 0)
+    {
+      hit = lru;
+      VVCGPU(vvcgpu_memcpy_h2d(plane + (size_t)hit * slotRows * stride, padOrigin, (size_t)stride * slotRows * sizeof(vvc_pel), nullptr));
+      slots[hit].hostOrigin = padOrigin; slots[hit].poc = poc;
+      g_batch[3]++;
+    }
+    slots[hit].stamp = ++clock;
+    return hit * slotRows;
+  }
+} g_dpb;
+struct DevOrgPic { vvc_pel* p = nullptr; int stride = 0, w = 0, h = 0, poc = -1 << 30; const Pel* host = nullptr; } g_orgPic;
+
+struct MeEntry
+{
+  int list, refIdx; const Pel* hostRef; Mv start, pred; int flags, range, ss;
+  vvcgpu_search_best ib; vvcgpu_frac_result fr; bool tzServed, fracServed;
+};
+struct MeSession { bool active = false; const PredictionUnit* pu = nullptr; const InterSearch* self = nullptr; const Pel* keyBuf = nullptr; double lambda = 0; int imvShift = 0; std::vector<MeEntry> e; } g_me;
+DevArray<vvcgpu_tz_pu> g_bPu;
+DevArray<vvcgpu_search_best> g_bInt;
+DevArray<vvcgpu_frac_result> g_bFrac;
+
+void mePrepass(InterSearch* self, CodingUnit& cu)
+{
+  g_me.active = false; g_me.e.clear();
+  const auto t0 = std::chrono::steady_clock::now();
+  struct Tot { std::chrono::steady_clock::time_point t; ~Tot() { g_meSec[2] += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } tot{ t0 };
+  if (!cu.firstPU) { g_why[1]++; return; }
+  const int imvShift = cu.imv << 1;                                          // AMVR pass (imv != 0): the integer searches only; xPatternSearchIntRefine stays per call
+  PredictionUnit& pu = *cu.firstPU;
+  CodingStructure& cs = *pu.cs;
+  const Slice& slice = *cs.slice;
+  const SPS& sps = *cs.sps;
+  const int w = pu.lumaSize().width, h = pu.lumaSize().height, bd = sps.getBitDepth(CHANNEL_TYPE_LUMA);
+  const MESearchMethod method = self->m_motionEstimationSearchMethod;
+  if (slice.isIntra() || pu.next || cu.partSize != SIZE_2Nx2N || !(method == MESEARCH_DIAMOND || method == MESEARCH_DIAMOND_ENHANCED)) { g_why[2]++; return; }
+  if (bd > 10 || bd < 8 || (w & 3) || (h & 3) || w < 4 || h < 4 || w > 128 || h > 128 || sps.getSpsNext().getUseCompositeRef() || slice.testWeightPred() ||
+      slice.testWeightBiPred())
+    { g_why[3]++; return; }
+  if (!cs.pcv->only2Nx2N && cu.qtDepth != 0) { g_why[4]++; return; }                       // m_integerMv2Nx2N would enter as a second start candidate: per-call path
+  const int subShiftMode = (!self->m_pcEncCfg->getRestrictMESampling() && self->m_pcEncCfg->getMotionEstimationSearchMethod() == MESEARCH_SELECTIVE) ? 1 :
+                           (self->m_pcEncCfg->getFastInterSearchMode() == FASTINTERSEARCH_MODE1 || self->m_pcEncCfg->getFastInterSearchMode() == FASTINTERSEARCH_MODE3) ? 2 : 0;
+  if (subShiftMode == 1) { g_why[5]++; return; }
+  PelUnitBuf origBuf = cs.getOrgBuf(pu);
+  const CPelBuf key = origBuf.Y();
+  // the original picture, resident: the CU's original block must be the picture's samples at the PU position (it is a copy of them)
+  const Picture& pic = *cs.picture;
+  const CPelBuf orgY = pic.getOrigBuf().Y();
+  const Position pos = pu.lumaPos();
+  for (int y = 0; y < h; y++)
+    if (memcmp(key.buf + (size_t)y * key.stride, orgY.buf + (size_t)(pos.y + y) * orgY.stride + pos.x, (size_t)w * sizeof(Pel)) != 0) { g_why[6]++; return; }
+  if (g_orgPic.host != orgY.buf || g_orgPic.poc != slice.getPOC() || g_orgPic.w != (int)orgY.width || g_orgPic.h != (int)orgY.height)
+  {
+    if (g_orgPic.p && (g_orgPic.w != (int)orgY.width || g_orgPic.h != (int)orgY.height)) { VVCGPU(vvcgpu_free(g_orgPic.p)); g_orgPic.p = nullptr; }
+    g_orgPic.stride = ((int)orgY.width + 63) & ~63;
+    if (!g_orgPic.p) VVCGPU(vvcgpu_malloc((void**)&g_orgPic.p, (size_t)g_orgPic.stride * orgY.height * sizeof(vvc_pel)));
+    VVCGPU(vvcgpu_memcpy2d_h2d(g_orgPic.p, g_orgPic.stride * sizeof(vvc_pel), orgY.buf, orgY.stride * sizeof(Pel), orgY.width * sizeof(Pel), orgY.height, nullptr));
+    g_orgPic.host = orgY.buf; g_orgPic.poc = slice.getPOC(); g_orgPic.w = orgY.width; g_orgPic.h = orgY.height;
+    g_batch[3]++;
+  }
+  self->m_pcRdCost->selectMotionLambda(cu.transQuantBypass);                 // as predInterSearch does before its searches (:852)
+  self->m_lumaClpRng = slice.clpRng(COMPONENT_Y);
+  auto blkCache = dynamic_cast<CacheBlkInfoCtrl*>(self->m_modeCtrl);
+  const int numDir = slice.isInterP() ? 1 : 2;
+  const int8_t mvpIdx0 = pu.mvpIdx[0], mvpIdx1 = pu.mvpIdx[1], mvpNum0 = pu.mvpNum[0], mvpNum1 = pu.mvpNum[1];
+  std::vector<vvcgpu_tz_pu> pus;
+  const int picW = sps.getPicWidthInLumaSamples(), picH = sps.getPicHeightInLumaSamples();
+  for (int l = 0; l < numDir; l++)
+    for (int r = 0; r < slice.getNumRefIdx(RefPicList(l)); r++)
+    {
+      if (self->m_pcEncCfg->getFastMEForGenBLowDelayEnabled() && l == 1 && slice.getList1IdxToList0Idx(r) >= 0) continue;   // copies the list-0 result (:905-921)
+      if (l >= MAX_NUM_REF_LIST_ADAPT_SR || r >= (int)MAX_IDX_ADAPT_SR) { g_why[7]++; g_me.e.clear(); goto done; }
+      {
+        AMVPInfo amvp; Mv pred; Distortion dist = std::numeric_limits<Distortion>::max();
+        const auto ta = std::chrono::steady_clock::now();
+        self->xEstimateMvPredAMVP(pu, origBuf, RefPicList(l), r, pred, amvp, false, &dist);
+        g_meSec[0] += std::chrono::duration<double>(std::chrono::steady_clock::now() - ta).count();
+        MeEntry e;
+        e.list = l; e.refIdx = r; e.pred = pred; e.start = pred; e.flags = method == MESEARCH_DIAMOND_ENHANCED ? VVCGPU_TZ_EXTENDED : 0;
+        e.range = self->m_aaiAdaptSR[l][r]; e.tzServed = e.fracServed = false;
+        Mv cIntMv;
+        if (blkCache && blkCache->getMv(pu, RefPicList(l), r, cIntMv)) { cIntMv <<= 2; e.start = cIntMv; e.flags = VVCGPU_TZ_FAST; }   // :1725-1745: xTZSearch(.., NULL, false, true)
+        const Picture* refPic = slice.getRefPic(RefPicList(l), r);
+        const CPelBuf refY = refPic->getRecoBuf(COMPONENT_Y);
+        const int margin = (int)refPic->margin;
+        const CPelBuf refBlk = refPic->getRecoBuf(pu.blocks[COMPONENT_Y]);
+        e.hostRef = refBlk.buf;
+        self->m_pcRdCost->setDistParam(self->m_cDistParam, key, refBlk.buf, refBlk.stride, bd, COMPONENT_Y, subShiftMode);
+        e.ss = self->m_cDistParam.subShift;
+        if ((h & ((1 << e.ss) - 1)) || self->m_cDistParam.useMR || self->m_cDistParam.applyWeight || e.range < 1 || e.range > 512 || e.start.highPrec)
+        { g_why[8]++; g_me.e.clear(); goto done; }
+        const int rows = (int)refY.height + 2 * margin;
+        const int slot = g_dpb.slotRow(refY.buf - (ptrdiff_t)margin * refY.stride - margin, refPic->getPOC(), (int)refY.stride, rows);
+        vvcgpu_tz_pu p;
+        memset(&p, 0, sizeof p);
+        p.org_x = pos.x; p.org_y = pos.y; p.ref_x = margin + pos.x; p.ref_y = slot + margin + pos.y;
+        p.start_x = e.start.getHor(); p.start_y = e.start.getVer();
+        p.pos_x = pos.x; p.pos_y = pos.y; p.pred_hor = pred.getHor(); p.pred_ver = pred.getVer();
+        p.w = (int16_t)w; p.h = (int16_t)h; p.sub_shift = (int16_t)e.ss; p.flags = (int16_t)e.flags; p.reserved[0] = e.range;
+        pus.push_back(p);
+        g_me.e.push_back(e);
+      }
+    }
+done:
+  pu.mvpIdx[0] = mvpIdx0; pu.mvpIdx[1] = mvpIdx1; pu.mvpNum[0] = mvpNum0; pu.mvpNum[1] = mvpNum1;
+  g_why[0]++;
+  if (g_me.e.size() < 2) { g_why[9]++; g_me.e.clear(); return; }                         // one search: nothing to run side by side
+  int ss0 = g_me.e[0].ss;
+  for (auto& e : g_me.e) if (e.ss != ss0) { g_why[10]++; g_me.e.clear(); return; }
+  const int n = (int)pus.size();
+  vvcgpu_tz_cfg c;
+  memset(&c, 0, sizeof c);
+  c.lambda = self->m_pcRdCost->m_motionLambda; c.cost_scale = 2; c.imv_shift = 0;
+  c.search_range = 1; c.first_search_stop = self->m_pcEncCfg->getFastMEAssumingSmootherMVEnabled() ? 1 : 0;
+  for (auto& e : g_me.e) c.search_range = std::max(c.search_range, e.range);   // sizes the raster grid of the split form; every search uses its own range
+  c.pic_w = picW; c.pic_h = picH; c.max_cu_w = sps.getMaxCUWidth(); c.max_cu_h = sps.getMaxCUHeight();
+  c.ref_x0 = 0; c.ref_y0 = 0; c.ref_x1 = g_dpb.stride; c.ref_y1 = g_dpb.slotRows * g_dpb.nSlots;
+  c.wg_per_pu = w * h > 1024 ? 1 : 0;
+  const auto tg = std::chrono::steady_clock::now();
+  g_bPu.upload(pus.data(), n);
+  g_bInt.reserve(n); g_bFrac.reserve(n);
+  const bool had = self->m_pcEncCfg->getUseHADME() && !cu.transQuantBypass;
+  c.imv_shift = imvShift;
+  std::vector<vvcgpu_search_best> ib(n);
+  std::vector<vvcgpu_frac_result> fr(n);
+  if (imvShift == 0)
+  {
+    VVCGPU(vvcgpu_me_batch(g_orgPic.p, g_orgPic.stride, g_dpb.plane, g_dpb.stride, g_bPu.ptr, n, w, h, &c, bd, self->m_lumaClpRng.min, self->m_lumaClpRng.max,
+                           had ? 1 : 0, g_bInt.ptr, g_bFrac.ptr, nullptr));
+    VVCGPU(vvcgpu_memcpy_d2h(fr.data(), g_bFrac.ptr, n * sizeof(vvcgpu_frac_result), nullptr));
+  }
+  else
+  {
+    if ((w == 16 || w == 32 || w == 64) && (h == 16 || h == 32 || h == 64)) c.uniform_pu = (h << 16) | w;
+    VVCGPU(vvcgpu_tz_search_batch(g_orgPic.p, g_orgPic.stride, g_dpb.plane, g_dpb.stride, g_bPu.ptr, n, &c, g_bInt.ptr, nullptr));
+    for (auto& e : g_me.e) e.fracServed = true;                             // nothing to serve: the AMVR refinement is not part of the session
+  }
+  VVCGPU(vvcgpu_memcpy_d2h(ib.data(), g_bInt.ptr, n * sizeof(vvcgpu_search_best), nullptr));
+  VVCGPU(vvcgpu_stream_sync(nullptr));
+  g_meSec[1] += std::chrono::duration<double>(std::chrono::steady_clock::now() - tg).count();
+  for (int i = 0; i < n; i++) { g_me.e[i].ib = ib[i]; g_me.e[i].fr = fr[i]; }
+  g_me.active = true; g_me.pu = &pu; g_me.self = self; g_me.lambda = c.lambda; g_me.keyBuf = key.buf; g_me.imvShift = imvShift;
+  g_batch[0]++; g_batch[1] += n;
+}
+}  // namespace
+
+namespace {
+// a search of the session's PU whose inputs are what the pre-pass assumed; nullptr: the call takes the per-call path
+MeEntry* meSessionTz(InterSearch* self, const PredictionUnit* pu, InterSearch::IntTZSearchStruct* cs, const Mv* rcMv, const Mv* pInt2Nx2N, bool bExtended, bool bFast)
+{
+  if (!g_me.active || pu != g_me.pu || self != g_me.self) return nullptr;
+  const int flags = (bExtended ? VVCGPU_TZ_EXTENDED : 0) | (bFast ? VVCGPU_TZ_FAST : 0);
+  const Mv& pred = self->m_pcRdCost->m_mvPredictor;
+  if (!pInt2Nx2N && (int)cs->imvShift == g_me.imvShift && cs->pcPatternKey->buf == g_me.keyBuf && self->m_pcRdCost->m_motionLambda == g_me.lambda && self->m_pcRdCost->m_iCostScale == 2)
+    for (auto& e : g_me.e)
+      if (!e.tzServed && e.hostRef == cs->piRefY && e.flags == flags && e.range == self->m_iSearchRange && e.start.getHor() == rcMv->getHor() &&
+          e.start.getVer() == rcMv->getVer() && e.pred.getHor() == pred.getHor() && e.pred.getVer() == pred.getVer())
+      { e.tzServed = true; g_batch[2]++; return &e; }
+  g_batch[4]++;
+  return nullptr;
+}
+bool meSessionFrac(InterSearch* self, const PredictionUnit* pu, int list, int refIdx, InterSearch::IntTZSearchStruct* cs, const Mv* mvInt, vvcgpu_frac_result* r)
+{
+  if (!g_me.active || pu != g_me.pu || self != g_me.self) return false;
+  const Mv& pred = self->m_pcRdCost->m_mvPredictor;
+  if (cs->imvShift == 0 && cs->pcPatternKey->buf == g_me.keyBuf && self->m_pcRdCost->m_motionLambda == g_me.lambda)
+    for (auto& e : g_me.e)
+      if (e.tzServed && !e.fracServed && e.list == list && e.refIdx == refIdx && e.hostRef == cs->piRefY && mvInt->getHor() == e.ib.x && mvInt->getVer() == e.ib.y &&
+          e.pred.getHor() == pred.getHor() && e.pred.getVer() == pred.getVer())
+      { e.fracServed = true; *r = e.fr; g_batch[2]++; return true; }
+  if (cs->pcPatternKey->buf == g_me.keyBuf) g_batch[4]++;                   // (bi-predictive refinements search a modified block: not the session's business)
+  return false;
+}
+}  // namespace
+
+#ifdef VVCSHIM_SOURCE_HOOKS
+// the source-hook form (integration/vtm-2.1-hip.patch) does not redirect predInterSearch: nothing calls the wrapper there, the batched form is ld --wrap only
+void real_predInterSearch(InterSearch* self, CodingUnit& cu, Partitioner& partitioner) { self->predInterSearch(cu, partitioner); }
+#endif
+void wrap_predInterSearch(InterSearch* self, CodingUnit& cu, Partitioner& partitioner)
+{
+  g_why[15]++;
+  if (gpuEnabled() && puBatched()) mePrepass(self, cu);
+  real_predInterSearch(self, cu, partitioner);
+  g_me.active = false; g_me.e.clear();
 }
 
 // ---- InterSearch::xTZSearch (InterSearch.cpp:1971-2252): the whole integer TZ search of one PU = vvcgpu_tz_search_batch with
@@ -1404,22 +1655,26 @@ extern "C" int vvcshim_tzsearch(InterSearch* self, const PredictionUnit* pu, Int
   const int zr = range >> 1;                                           // zero neighbourhood, not clipped by the reference
   x0 = std::min(x0, -zr); x1 = std::max(x1, zr); y0 = std::min(y0, -zr); y1 = std::max(y1, zr);
   const int ww = x1 - x0 + w, wh = y1 - y0 + h, wp = (ww + 7) & ~7;
-  if (ww < 128 || wh < 128) return 0;
+  vvcgpu_search_best b;
+  vvcgpu_tz_pu p;
+  memset(&p, 0, sizeof p);
+  p.start_x = rcMv->getHor(); p.start_y = rcMv->getVer();
+  p.flags = (int16_t)((pInt2Nx2N ? VVCGPU_TZ_PRED2 : 0) | (bExtended ? VVCGPU_TZ_EXTENDED : 0) | (bFast ? VVCGPU_TZ_FAST : 0));
+  if (MeEntry* e = meSessionTz(self, pu, cs, rcMv, pInt2Nx2N, bExtended, bFast)) b = e->ib;   // searched by the batched pre-pass of this PU
+  else
+  {
+  if (puBatched() || ww < 128 || wh < 128) return 0;                   // pub: a search outside a session is the host's (a lone round trip costs more than the search)
   g_zOrg.reserve((size_t)w * h);
   g_zRef.reserve((size_t)wp * wh);
   g_zBest.reserve(1);
   VVCGPU(vvcgpu_memcpy2d_h2d(g_zOrg.ptr, (size_t)w * sizeof(vvc_pel), key.buf, key.stride * sizeof(Pel), (size_t)w * sizeof(Pel), h, nullptr));
   VVCGPU(vvcgpu_memcpy2d_h2d(g_zRef.ptr, (size_t)wp * sizeof(vvc_pel), cs->piRefY + x0 + (ptrdiff_t)y0 * cs->iRefStride,
                              cs->iRefStride * sizeof(Pel), (size_t)ww * sizeof(Pel), wh, nullptr));
-  vvcgpu_tz_pu p;
-  memset(&p, 0, sizeof p);
   p.ref_x = -x0; p.ref_y = -y0;                                        // window sample (0,0) is displacement (x0, y0)
-  p.start_x = rcMv->getHor(); p.start_y = rcMv->getVer();
   if (pInt2Nx2N) { p.pred2_x = pInt2Nx2N->getHor(); p.pred2_y = pInt2Nx2N->getVer(); }
   p.pos_x = pos.x; p.pos_y = pos.y;
   p.pred_hor = self->m_pcRdCost->m_mvPredictor.getHor(); p.pred_ver = self->m_pcRdCost->m_mvPredictor.getVer();
   p.w = (int16_t)w; p.h = (int16_t)h; p.sub_shift = (int16_t)ss;
-  p.flags = (int16_t)((pInt2Nx2N ? VVCGPU_TZ_PRED2 : 0) | (bExtended ? VVCGPU_TZ_EXTENDED : 0) | (bFast ? VVCGPU_TZ_FAST : 0));
   g_zPu.upload(&p, 1);
   vvcgpu_tz_cfg c;
   memset(&c, 0, sizeof c);
@@ -1429,9 +1684,9 @@ extern "C" int vvcshim_tzsearch(InterSearch* self, const PredictionUnit* pu, Int
   c.ref_x0 = 0; c.ref_y0 = 0; c.ref_x1 = ww; c.ref_y1 = wh;
   c.wg_per_pu = w * h > 1024 ? 1 : 0;
   VVCGPU(vvcgpu_tz_search_batch(g_zOrg.ptr, w, g_zRef.ptr, wp, g_zPu.ptr, 1, &c, g_zBest.ptr, nullptr));
-  vvcgpu_search_best b;
   VVCGPU(vvcgpu_memcpy_d2h(&b, g_zBest.ptr, sizeof b, nullptr));
   VVCGPU(vvcgpu_stream_sync(nullptr));
+  }
   if (getenv("VVCGPU_SHIM_TZ_VERIFY"))                                 // debugging aid: run the reference's own body on the same input and compare
   {
     typedef void (*real_t)(InterSearch*, const PredictionUnit*, InterSearch::IntTZSearchStruct*, Mv*, Distortion*, const Mv*, bool, bool);
