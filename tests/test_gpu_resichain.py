@@ -115,6 +115,34 @@ def test_resi_chain_rectangles_and_chroma_shapes():
     assert np.array_equal(grec, rec)
 
 
+@pytest.mark.parametrize("bd,content", [(10, "smooth"), (8, "smooth"), (10, "extreme"), (10, "uniform")])
+def test_resi_chain_packed_tiles(bd, content):
+    """16x8 / 8x16 / 16x4 / 4x16: two or four TUs share one 16x16 matrix-core tile (rc_tile_packed), every TU with its own transform pair, QP, slice type
+    and sign-hiding flag; class counts that leave the last tile part-filled; a few TUs whose residual leaves +-1023 sit in tiles with ordinary
+    ones and must reach the generic path alone"""
+    rng = np.random.default_rng(bd * 11 + len(content))
+    W, H = 512, 128
+    org = cases.rand_plane(rng, H, W, bd, content)
+    pred = cases.rand_plane(rng, H, W, bd, "smooth" if content != "extreme" else "extreme")
+    if content == "smooth":
+        pred = np.clip(org + rng.integers(-9, 10, org.shape), 0, (1 << bd) - 1).astype(np.int16)
+    tus = tile(W, H, [(16, 8), (8, 16), (16, 4), (4, 16), (16, 16), (8, 8)], rng, [22, 27, 32, 37, 45], bd)
+    keep = rng.random(len(tus)) > 0.07                       # odd counts per class, tiles whose TUs are not neighbours in the picture
+    tus = [t for t, k in zip(tus, keep) if k]
+    order = rng.permutation(len(tus))
+    tus = [tus[i] for i in order]
+    if content == "smooth" and bd == 10:
+        org = org.copy()
+        for i in rng.choice(len(tus), 25, replace=False):    # out of the matrix-core range: |org - pred| > 1023
+            x, y, w, h = tus[i][:4]
+            org[y + int(rng.integers(0, h)), x + int(rng.integers(0, w))] = -2500
+    lv, asum, rec, coffs = oracle_chain(org, pred, tus, bd, W)
+    glv, gsum, grec = gpu_chain(org, pred, tus, bd, W, coffs)
+    assert np.array_equal(gsum, asum), np.nonzero(gsum != asum)[0][:8]
+    assert np.array_equal(glv, lv)
+    assert np.array_equal(grec, rec)
+
+
 def test_resi_chain_residual_outside_range_falls_back():
     """samples outside the bit depth (|residual| > 1023) leave the matrix-core path's exactness range: those TUs are served by the generic path"""
     rng = np.random.default_rng(5)

@@ -108,7 +108,7 @@ __global__ __launch_bounds__(256) void dist_batch_kernel(int kind, const Pel* __
                                                          unsigned long long* __restrict__ out, int* __restrict__ heavyCount, int* __restrict__ heavyList,
                                                          int* __restrict__ nextCounters)
 {
-  if (blockIdx.x == 0 && threadIdx.x < 16) nextCounters[threadIdx.x] = 0;       // the counter set of the next call on this stream (vvcgpu_counters)
+  if (blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextCounters[threadIdx.x] = 0;       // the counter set of the next call on this stream (vvcgpu_counters)
   const int lane = threadIdx.x & 63;
   const int d0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
   if (d0 >= n) return;                                  // whole wave exits together
@@ -1509,10 +1509,10 @@ int vvcgpu_dist_batch(int kind, const vvc_pel* org_base, const vvc_pel* cur_base
   int* counters = vvcgpu_counters(st, &cur);                                  // zeroed counter for this call; the kernel clears the other set
   if (!counters) return VVCGPU_E_DEVICE;
   hipLaunchKernelGGL(dist_batch_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, kind, org_base, cur_base,
-                     descs, n, reinterpret_cast<unsigned long long*>(out), counters + 16 * cur, heavyList, counters + 16 * (cur ^ 1));
+                     descs, n, reinterpret_cast<unsigned long long*>(out), counters + VVC_CTR_INTS * cur, heavyList, counters + VVC_CTR_INTS * (cur ^ 1));
   if (kind <= 2)                                                              // blocks of more than 2048 samples: bands over many waves (none: the launch leaves at once)
     hipLaunchKernelGGL(dist_heavy_kernel, dim3(n * 2 < 1024 ? (n * 2 > 0 ? n * 2 : 1) : 1024), dim3(256), 0, st, kind, org_base, cur_base, descs,
-                       reinterpret_cast<unsigned long long*>(out), counters + 16 * cur, heavyList);
+                       reinterpret_cast<unsigned long long*>(out), counters + VVC_CTR_INTS * cur, heavyList);
   VVC_LAUNCH_CHECK_COUNTERS(st);
   return VVCGPU_OK;
 }

@@ -175,7 +175,7 @@ __global__ __launch_bounds__(256) void if_batch_kernel(const Pel* __restrict__ s
                                                        const vvcgpu_if_desc* __restrict__ descs, int n, int bd,
                                                        int cmin, int cmax, int* __restrict__ heavyCount, int* __restrict__ heavyList, int* __restrict__ nextCounters)
 {
-  if (blockIdx.x == 0 && threadIdx.x < 16) nextCounters[threadIdx.x] = 0;       // the counter set of the next call on this stream (vvcgpu_counters)
+  if (blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextCounters[threadIdx.x] = 0;       // the counter set of the next call on this stream (vvcgpu_counters)
   const int lane = threadIdx.x & 63;
   const int d0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
   if (d0 >= n) return;
@@ -777,7 +777,7 @@ __global__ __launch_bounds__(256) void pelop_batch_kernel(int op, const Pel* __r
                                                           int* __restrict__ nextCounters)
 {
   const int tid = threadIdx.x;
-  if (nextCounters && blockIdx.x == 0 && blockIdx.y == 0 && tid < 16) nextCounters[tid] = 0;   // the counter set of the next call on this stream
+  if (nextCounters && blockIdx.x == 0 && blockIdx.y == 0 && tid < VVC_CTR_INTS) nextCounters[tid] = 0;   // the counter set of the next call on this stream
   if (perWg > 1)                                          // a wave takes four consecutive descriptors: side by side with 16 lanes each when all
   {                                                       // four have at most 256 samples, one after the other with 64 lanes otherwise
     const int lane = tid & 63, g = lane >> 4;
@@ -848,8 +848,8 @@ int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_
   int* counters = vvcgpu_counters(st, &cur);
   if (!counters) return VVCGPU_E_DEVICE;
   hipLaunchKernelGGL(if_batch_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, src_base, dst_base, descs, n,
-                     bit_depth, clp_min, clp_max, counters + 16 * cur, heavyList, counters + 16 * (cur ^ 1));
-  hipLaunchKernelGGL(if_heavy_kernel, dim3(1024), dim3(256), 0, st, src_base, dst_base, descs, bit_depth, clp_min, clp_max, counters + 16 * cur, heavyList);
+                     bit_depth, clp_min, clp_max, counters + VVC_CTR_INTS * cur, heavyList, counters + VVC_CTR_INTS * (cur ^ 1));
+  hipLaunchKernelGGL(if_heavy_kernel, dim3(1024), dim3(256), 0, st, src_base, dst_base, descs, bit_depth, clp_min, clp_max, counters + VVC_CTR_INTS * cur, heavyList);
   VVC_LAUNCH_CHECK_COUNTERS(st);
   return VVCGPU_OK;
 }
@@ -922,10 +922,10 @@ int vvcgpu_pelop_batch(int op, const vvc_pel* src0_base, const vvc_pel* src1_bas
     if (!counters) return VVCGPU_E_DEVICE;
   }
   hipLaunchKernelGGL(pelop_batch_kernel, dim3(cdiv(n, perWg), n < 2048 ? 8 : 1), dim3(256), 0, st, op, src0_base, src1_base,
-                     dst_base, descs, n, *cfg_host, perWg, counters ? counters + 16 * cur : nullptr, heavyList, counters ? counters + 16 * (cur ^ 1) : nullptr);
+                     dst_base, descs, n, *cfg_host, perWg, counters ? counters + VVC_CTR_INTS * cur : nullptr, heavyList, counters ? counters + VVC_CTR_INTS * (cur ^ 1) : nullptr);
   if (perWg > 1)
   {
-    hipLaunchKernelGGL(pelop_heavy_kernel, dim3(1024), dim3(256), 0, st, op, src0_base, src1_base, dst_base, descs, *cfg_host, counters + 16 * cur, heavyList);
+    hipLaunchKernelGGL(pelop_heavy_kernel, dim3(1024), dim3(256), 0, st, op, src0_base, src1_base, dst_base, descs, *cfg_host, counters + VVC_CTR_INTS * cur, heavyList);
     VVC_LAUNCH_CHECK_COUNTERS(st);
     return VVCGPU_OK;
   }

@@ -95,8 +95,8 @@ void* vvcgpu_scratch(hipStream_t stream, size_t bytes)
 
 // Two persistent work counters per (device, stream), zero when handed out: a launch that needs a zeroed counter takes counter `cur` and clears
 // counter `cur ^ 1` for the next call inside its own kernel (the previous user of that one has finished: same stream), so no fill launch is
-// needed in front of it.  EVERY user clears all 16 ints of the other set, whatever it uses of its own.  Returns a device pointer to
-// int[2][16] (64-byte lines) and the index to use; nullptr on failure.  A caller whose launches fail after this call reports it with
+// needed in front of it.  EVERY user clears all VVC_CTR_INTS ints of the other set, whatever it uses of its own.  Returns a device pointer to
+// int[2][VVC_CTR_INTS] and the index to use; nullptr on failure.  A caller whose launches fail after this call reports it with
 // vvcgpu_counters_failed: the sets are then cleared by a memset on the stream in front of the next user.
 int* vvcgpu_counters(hipStream_t stream, int* cur)
 {
@@ -107,13 +107,13 @@ int* vvcgpu_counters(hipStream_t stream, int* cur)
   if (!slot->counters)
   {
     void* p = nullptr;
-    if (hipMalloc(&p, 2 * 16 * sizeof(int)) != hipSuccess) { vvcgpu_set_error("counters: hipMalloc failed"); return nullptr; }
-    if (hipMemset(p, 0, 2 * 16 * sizeof(int)) != hipSuccess) { (void)hipFree(p); vvcgpu_set_error("counters: hipMemset failed"); return nullptr; }
+    if (hipMalloc(&p, 2 * VVC_CTR_INTS * sizeof(int)) != hipSuccess) { vvcgpu_set_error("counters: hipMalloc failed"); return nullptr; }
+    if (hipMemset(p, 0, 2 * VVC_CTR_INTS * sizeof(int)) != hipSuccess) { (void)hipFree(p); vvcgpu_set_error("counters: hipMemset failed"); return nullptr; }
     slot->counters = static_cast<int*>(p); slot->cur = 0; slot->dirty = false;
   }
   if (slot->dirty)
   {
-    if (hipMemsetAsync(slot->counters, 0, 2 * 16 * sizeof(int), stream) != hipSuccess) { vvcgpu_set_error("counters: hipMemsetAsync failed"); return nullptr; }
+    if (hipMemsetAsync(slot->counters, 0, 2 * VVC_CTR_INTS * sizeof(int), stream) != hipSuccess) { vvcgpu_set_error("counters: hipMemsetAsync failed"); return nullptr; }
     slot->dirty = false; slot->cur = 0;
   }
   *cur = slot->cur;

@@ -22,7 +22,11 @@ typedef float f4 __attribute__((ext_vector_type(4)));
 // Rows are padded by 16 bytes, which spreads the 16 rows read by one ds_read_b64 / b128 over all banks.
 constexpr int RC_S16 = 16 * 24, RC_S32 = 32 * 40, RC_S64 = 64 * 72;                  // halves per matrix copy (row pitch n + 8)
 constexpr int RC_TYPE = 2 * RC_S16 + 2 * RC_S32;
-constexpr int RC_TAB_HALVES = 3 * RC_TYPE + 2 * RC_S64;
+// behind them the 4- and 8-point matrices (per type: T4, T4^T, T8, T8^T, rows unpadded) of the packed-tile form (resichain.hip)
+constexpr int RC_SMALL_OFF = 3 * RC_TYPE + 2 * RC_S64, RC_SMALL_TYPE = 2 * 16 + 2 * 64;
+constexpr int RC_TAB_HALVES = RC_SMALL_OFF + 3 * RC_SMALL_TYPE;
+static_assert(RC_TAB_HALVES % 8 == 0 && RC_SMALL_OFF % 8 == 0, "the image is copied with 16-byte loads");
+__device__ __forceinline__ int rc_small_off(int type, int n, int transposed) { return RC_SMALL_OFF + type * RC_SMALL_TYPE + (n == 4 ? transposed * 16 : 32 + transposed * 64); }
 __device__ __forceinline__ int rc_tab_off(int type, int n, int transposed)
 {
   if (n == 64) return 3 * RC_TYPE + transposed * RC_S64;
@@ -49,6 +53,11 @@ __device__ __forceinline__ void rc_load_tables(_Float16* tab, const _Float16* __
 #pragma unroll
     for (int u = 0; u < (NV + 255) / 256; u++) if (tid + 256 * u < NV) dst[tid + 256 * u] = v[u];
   }
+}
+__device__ __forceinline__ void rc_load_small_tables(_Float16* tab, const _Float16* __restrict__ image, int tid)
+{
+  constexpr int NV = 3 * RC_SMALL_TYPE / 8;
+  if (tid < NV) reinterpret_cast<uint4*>(tab + RC_SMALL_OFF)[tid] = reinterpret_cast<const uint4*>(image + RC_SMALL_OFF)[tid];
 }
 __device__ __forceinline__ void rc_load_all_tables(_Float16* tab, const _Float16* __restrict__ image, int tid)
 {

@@ -30,12 +30,13 @@ __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
 #define RC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier(); } while (0)
 
 // ---- work lists (device): hdr[0 .. RC_NCLS) = counts of the classes, hdr[RC_FB] = count of the fall-back list
-constexpr int RC_HDR = 16;
-enum { RC_C64 = 0, RC_C32, RC_C16, RC_C8, RC_C4, RC_CGEN, RC_R6432, RC_R3264, RC_R6416, RC_R1664, RC_R3216, RC_R1632, RC_R84, RC_R48, RC_NCLS };
+constexpr int RC_HDR = VVC_CTR_INTS;
+enum { RC_C64 = 0, RC_C32, RC_C16, RC_C8, RC_C4, RC_CGEN, RC_R6432, RC_R3264, RC_R6416, RC_R1664, RC_R3216, RC_R1632, RC_R84, RC_R48,
+       RC_P168, RC_P816, RC_P164, RC_P416, RC_NCLS };               // RC_P*: packed tiles (rc_tile_packed)
 constexpr int RC_FB = RC_NCLS;
-static_assert(RC_FB < RC_HDR, "the header is one 16-int counter set of vvcgpu_counters");
+static_assert(RC_FB < RC_HDR, "the header is one counter set of vvcgpu_counters");
 
-__device__ __forceinline__ int rc_class(const RcDesc& d)
+__device__ __forceinline__ int rc_class(const RcDesc& d, bool packed)
 {
   const int w = d.w, h = d.h;
   if (w == h)
@@ -49,9 +50,10 @@ __device__ __forceinline__ int rc_class(const RcDesc& d)
   }
   if (w == 64) return h == 32 ? RC_R6432 : h == 16 ? RC_R6416 : RC_CGEN;
   if (w == 32) return h == 64 ? RC_R3264 : h == 16 ? RC_R3216 : RC_CGEN;
-  if (w == 16) return h == 64 ? RC_R1664 : h == 32 ? RC_R1632 : RC_CGEN;
+  if (w == 16) return h == 64 ? RC_R1664 : h == 32 ? RC_R1632 : h == 8 ? (packed ? RC_P168 : RC_CGEN) : h == 4 ? (packed ? RC_P164 : RC_CGEN) : RC_CGEN;
   if (w == 8 && h == 4) return RC_R84;
   if (w == 4 && h == 8) return RC_R48;
+  if (h == 16 && packed) return w == 8 ? RC_P816 : w == 4 ? RC_P416 : RC_CGEN;
   return RC_CGEN;
 }
 
@@ -60,9 +62,9 @@ __device__ __forceinline__ int rc_class(const RcDesc& d)
 // LDS, ONE global atomic per class reserves the slice's range of every list, pass 2 writes the indices (LDS counters give the positions).
 constexpr int RC_CLS_WGS = 128;
 __global__ __launch_bounds__(1024) void rc_classify_kernel(const RcDesc* __restrict__ descs, int n, int* __restrict__ hdr, int* __restrict__ lists,
-                                                           unsigned* __restrict__ absSum, int* __restrict__ nextHdr)
+                                                           unsigned* __restrict__ absSum, int* __restrict__ nextHdr, bool packed)
 {
-  if (blockIdx.x == 0 && threadIdx.x < 16) nextHdr[threadIdx.x] = 0;         // the header of the NEXT call on this stream (vvcgpu_counters)
+  if (blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextHdr[threadIdx.x] = 0;         // the header of the NEXT call on this stream (vvcgpu_counters)
   __shared__ int cnt[RC_NCLS], base[RC_NCLS];
   const int tid = threadIdx.x, lane = tid & 63;
   const int per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = min(n, lo + per);
@@ -82,7 +84,7 @@ __global__ __launch_bounds__(1024) void rc_classify_kernel(const RcDesc* __restr
         d.w = (short)(wh & 0xFFFF); d.h = (short)(wh >> 16); d.tr_hor = (signed char)(tt & 0xFF); d.tr_ver = (signed char)((tt >> 8) & 0xFF);
         const bool ok = d.tr_hor >= 0 && d.tr_hor <= 2 && d.tr_ver >= 0 && d.tr_ver <= 2 && d.w >= 2 && d.w <= 64 && d.h >= 2 && d.h <= 64 &&
                         (d.w & (d.w - 1)) == 0 && (d.h & (d.h - 1)) == 0 && (d.w <= 32 || d.tr_hor == 0) && (d.h <= 32 || d.tr_ver == 0);
-        if (ok) cls = rc_class(d);
+        if (ok) cls = rc_class(d, packed);
         else if (pass == 0) absSum[ti] = 0xFFFFFFFFu;                          // precondition violated: TU not served, marked
       }
 #pragma unroll
@@ -258,6 +260,14 @@ __global__ __launch_bounds__(256) void rc_build_tables_kernel(_Float16* __restri
     tab[rc_tab_off(0, 64, 0) + r * 72 + k] = (_Float16)tr32[1364 + e];
     tab[rc_tab_off(0, 64, 1) + r * 72 + k] = (_Float16)tr32t[1364 + e];
   }
+  for (int t = 0; t < 3; t++)
+    for (int n = 4; n <= 8; n <<= 1)
+      for (int e = tid; e < n * n; e += nthreads)
+      {
+        const int src = t * 5460 + (n * n - 4) / 3 + e;
+        tab[rc_small_off(t, n, 0) + e] = (_Float16)tr32[src];
+        tab[rc_small_off(t, n, 1) + e] = (_Float16)tr32t[src];
+      }
 }
 
 // One TU of W x H (W, H in {16, 32, 64}) on the matrix cores.  Returns false (nothing written) when a residual sample lies outside +-1023
@@ -381,6 +391,180 @@ __device__ __forceinline__ bool rc_tu_mfma(const RcDesc& d, const Pel* __restric
     *reinterpret_cast<pel4*>(rec + (size_t)(16 * rt + c) * d.rec_stride + 16 * xt + 4 * g) = out;
   });
   return true;
+}
+
+// ---------------------------------------------------------------------------------------------------
+// Packed tiles: TUs with a 4- or 8-point side (a real encode's residual is mostly these: tests/golden/trace_*.npz) on the matrix cores --
+// G = (16 / W) (16 / H) TUs of W x H side by side in ONE 16x16 tile, sub-TU (sx, sy) at tile columns W sx .., rows H sy ..  The 1-D stages become
+// products with BLOCK-DIAGONAL matrices (the W-point matrix repeated 16 / W times along the diagonal); a lane builds its fragment of such a matrix
+// from the 4 / 8 / 16-point table of the transform type of the sub-TU its row belongs to, or zero off the diagonal blocks.  The sub-TUs choose their
+// types independently: a product D = A B shares B between all rows of A, so where the type belongs to the OTHER operand's index the stage runs
+// 16 / H (or 16 / W) passes into the same accumulator, each with that operand masked to one row (column) of sub-TUs -- 7 .. 28 small MFMAs per
+// tile instead of 7, on a pipe that is otherwise idle.  Everything else (limbs, rounding, quantiser on the lane's 4 x 1 column of a 4x4 group,
+// sign-bit hiding per quad) is the 16x16 form with per-lane TU parameters.  A TU with a residual outside +-1023 goes to the fall-back list.
+__device__ __forceinline__ h4 rc_frag4(const _Float16* tab, int type, int n, int transposed, int row, int k0)
+{
+  const int off = n == 16 ? rc_tab_off(type, 16, transposed) + row * 24 + k0 : rc_small_off(type, n, transposed) + row * n + k0;
+  return *reinterpret_cast<const h4*>(tab + off);
+}
+__device__ __forceinline__ h4 rc_limb_h4(const int (&v)[4], bool high)
+{
+  _Float16 h[4], l[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) rc_limbs(v[j], h[j], l[j]);
+  return high ? h4{ h[0], h[1], h[2], h[3] } : h4{ l[0], l[1], l[2], l[3] };
+}
+
+template <int W, int H>
+__device__ __noinline__ void rc_tile_packed(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
+                                               const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                               TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
+                                               const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
+                                               int* __restrict__ fbCount, int* __restrict__ fbList, int* info, int lane)
+{
+  constexpr int NX = 16 / W, NY = 16 / H, G = NX * NY;
+  constexpr int LW = W == 4 ? 2 : W == 8 ? 3 : 4, LH = H == 4 ? 2 : H == 8 ? 3 : 4;
+  const int c = lane & 15, g = lane >> 4;
+  const h4 zero4 = { (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0 };
+  // the wave's TUs: sub-TU s = sy NX + sx is entry item G + s of the class list; info[s] = descriptor index (-1: none), info[16 + s] = types
+  {
+    int ti = -1, types = 0;
+    if (lane < G && item * G + lane < cnt) { ti = list[item * G + lane]; const RcDesc& d = descs[ti]; types = (int)d.tr_hor | ((int)d.tr_ver << 2); }
+    if (lane < G) { info[lane] = ti; info[16 + lane] = types; }
+  }
+  RC_WAVE_SYNC();
+  // two views of the tile: L = sample layout (the lane's four samples: tile row c, columns 4 g ..), Q = coefficient layout (rows 4 g .., column c)
+  const int sxL = (4 * g) >> LW, syL = c >> LH, sxQ = c >> LW, syQ = (4 * g) >> LH;
+  const int tiL = info[syL * NX + sxL], tiQ = info[syQ * NX + sxQ], ti0 = info[0];
+  auto laneMask = [&](int sx, int sy) -> unsigned long long               // lanes of view L that hold samples of sub-TU (sx, sy)
+  {
+    const unsigned long long cm = H == 16 ? 0xFFFFull : (((1ull << H) - 1ull) << (sy * H));
+    unsigned long long m = 0;
+#pragma unroll
+    for (int gg = 0; gg < W / 4; gg++) m |= cm << (16 * (sx * (W / 4) + gg));
+    return m;
+  };
+  const RcDesc& dL = descs[tiL >= 0 ? tiL : ti0];
+  const int rowL = c & (H - 1), colL = (4 * g) & (W - 1);
+  const Pel* predP = predBase + dL.pred_off + (size_t)rowL * dL.pred_stride + colL;
+  pel4 pv = { 0, 0, 0, 0 };
+  int x[4] = { 0, 0, 0, 0 };
+  bool inRange = true;
+  if (tiL >= 0)
+  {
+    const pel4 o = *reinterpret_cast<const pel4*>(orgBase + dL.org_off + (size_t)rowL * dL.org_stride + colL);
+    pv = *reinterpret_cast<const pel4*>(predP);
+#pragma unroll
+    for (int j = 0; j < 4; j++) { x[j] = (int)o[j] - (int)pv[j]; inRange = inRange && x[j] >= -1023 && x[j] <= 1023; }
+  }
+  const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!inRange);
+  const bool okL = tiL >= 0 && (badLanes & laneMask(sxL, syL)) == 0ull, okQ = tiQ >= 0 && (badLanes & laneMask(sxQ, syQ)) == 0ull;
+  if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMask(lane % NX, lane / NX)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
+  h4 xa = zero4;
+  if (okL) xa = h4{ (_Float16)(short)x[0], (_Float16)(short)x[1], (_Float16)(short)x[2], (_Float16)(short)x[3] };
+
+  // ---- F1: M1[r][j] = sum_k X[r][k] Th(sub-TU of r, j)[j][k]: the type belongs to the row of X -> one pass per row of sub-TUs
+  const int s1 = LW + bd + 6 - 15 + 2, s2 = LH + 6 + 2;
+  int t1[4];
+  {
+    f4 m1 = { 0.f, 0.f, 0.f, 0.f };
+    const bool diag = sxQ == sxL;                                         // the lane's fragment lies in a diagonal block (j = c, k = 4 g ..)
+#pragma unroll
+    for (int p = 0; p < NY; p++)
+    {
+      const h4 a = (NY == 1 || syL == p) ? xa : zero4;
+      const h4 b = diag ? rc_frag4(tab, info[16 + p * NX + sxQ] & 3, W, 0, c & (W - 1), colL) : zero4;
+      m1 = __builtin_amdgcn_mfma_f32_16x16x16f16(a, b, m1, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) t1[r] = ((int)m1[r] + (1 << (s1 - 1))) >> s1;     // M1[row 4 g + r][frequency c]
+  }
+  // ---- F2: C[j2][j1] = sum_r Tv(sub-TU of j2, j1)[j2][r] M1[r][j1]: the type also belongs to the column of M1 -> one pass per column of sub-TUs
+  int cf[4];
+  {
+    const h4 bh = rc_limb_h4(t1, true), bl = rc_limb_h4(t1, false);
+    f4 hi = { 0.f, 0.f, 0.f, 0.f }, lo = { 0.f, 0.f, 0.f, 0.f };
+    const bool diag = syL == syQ;                                         // A: row j2 = c, k = r = 4 g ..
+#pragma unroll
+    for (int q = 0; q < NX; q++)
+    {
+      const bool mine = NX == 1 || sxQ == q;                              // B / D column c belongs to sub-TU column q
+      const h4 a = diag ? rc_frag4(tab, (info[16 + syL * NX + q] >> 2) & 3, H, 0, rowL, (4 * g) & (H - 1)) : zero4;
+      hi = __builtin_amdgcn_mfma_f32_16x16x16f16(a, mine ? bh : zero4, hi, 0, 0, 0);
+      lo = __builtin_amdgcn_mfma_f32_16x16x16f16(a, mine ? bl : zero4, lo, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) cf[r] = ((((int)hi[r]) << 8) + (int)lo[r] + (1 << (s2 - 1))) >> s2;   // C[vertical frequency 4 g + r][horizontal frequency c]
+  }
+  // ---- quantiser in view Q: the lane's four coefficients are rows y0 .. y0 + 3 of column xq of its TU; its quad is one coefficient group
+  const RcDesc& dQ = descs[tiQ >= 0 ? tiQ : ti0];
+  const RcQ q = rc_qparams(W, H, dQ.qp, bd, dQ.intra_slice, dQ.sign_hiding);
+  const int y0 = (4 * g) & (H - 1), xq = c & (W - 1);
+  int lv[4], du[4], sum = 0;
+#pragma unroll
+  for (int r = 0; r < 4; r++) { int mag; lv[r] = rc_quant_one(q, cf[r], du[r], mag); sum += mag; }
+  const int cgIdx = (int)(dqInv + scanOff[(LW - 1) * 6 + (LH - 1)])[y0 * W + (xq & ~3)] >> 4;
+  int lastCg = rc_cg_nonzero(lv) ? cgIdx : -1;
+  // reductions over the lanes of one TU in view Q: column bits below W, row-group bits below H / 4
+#pragma unroll
+  for (int m = 1; m < W; m <<= 1) { sum += __shfl_xor(sum, m); if (m >= 4) lastCg = max(lastCg, __shfl_xor(lastCg, m)); }
+#pragma unroll
+  for (int m = 16; m < 4 * H; m <<= 1) { sum += __shfl_xor(sum, m); lastCg = max(lastCg, __shfl_xor(lastCg, m)); }
+  if (okQ && xq == 0 && y0 == 0) absSumOut[tiQ] = (unsigned)sum;
+  if (q.sbh) rc_sbh_quad(lv, du, cf, cgIdx == lastCg, lane);
+  if (okQ)
+  {
+    TCoeff* level = levelBase + dQ.level_off;
+#pragma unroll
+    for (int r = 0; r < 4; r++) level[(y0 + r) * W + xq] = lv[r];
+  }
+  // ---- I1: Y1T[i][r] = sum_k Cq[k][i] Tv(sub-TU of i, r)[k][r]: A = Cq^T (row i = c), B = rows of Tv^T; the type also belongs to A's row -> passes
+  int y1[4];
+  {
+    int cq[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) cq[r] = rc_dequant_one(q, lv[r]);
+    const h4 ah = rc_limb_h4(cq, true), al = rc_limb_h4(cq, false);
+    f4 hi = { 0.f, 0.f, 0.f, 0.f }, lo = { 0.f, 0.f, 0.f, 0.f };
+    const bool diag = syL == syQ;                                         // B: column r = c, k = 4 g ..
+#pragma unroll
+    for (int qq = 0; qq < NX; qq++)
+    {
+      const bool mine = NX == 1 || sxQ == qq;                             // A row i = c belongs to sub-TU column qq
+      const h4 b = diag ? rc_frag4(tab, (info[16 + syL * NX + qq] >> 2) & 3, H, 1, rowL, (4 * g) & (H - 1)) : zero4;
+      hi = __builtin_amdgcn_mfma_f32_16x16x16f16(mine ? ah : zero4, b, hi, 0, 0, 0);
+      lo = __builtin_amdgcn_mfma_f32_16x16x16f16(mine ? al : zero4, b, lo, 0, 0, 0);
+    }
+#pragma unroll
+    for (int r = 0; r < 4; r++) y1[r] = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[r]) << 8) + (int)lo[r] + 256) >> 9);   // Y1T[horizontal frequency 4 g + r][sample row c]
+  }
+  // ---- I2: RT[x][r] = sum_i Th(sub-TU of x, r)[i][x] Y1T[i][r]: A = rows of Th^T (row x = c), B = Y1T; the type also belongs to B's column -> passes
+  {
+    const h4 bh = rc_limb_h4(y1, true), bl = rc_limb_h4(y1, false);
+    f4 hi = { 0.f, 0.f, 0.f, 0.f }, lo = { 0.f, 0.f, 0.f, 0.f };
+    const bool diag = sxQ == sxL;
+#pragma unroll
+    for (int p = 0; p < NY; p++)
+    {
+      const bool mine = NY == 1 || syL == p;                              // B / D column r = c belongs to sub-TU row p
+      const h4 a = diag ? rc_frag4(tab, info[16 + p * NX + sxQ] & 3, W, 1, c & (W - 1), colL) : zero4;
+      hi = __builtin_amdgcn_mfma_f32_16x16x16f16(a, mine ? bh : zero4, hi, 0, 0, 0);
+      lo = __builtin_amdgcn_mfma_f32_16x16x16f16(a, mine ? bl : zero4, lo, 0, 0, 0);
+    }
+    const int s2i = (6 + 15 - 1) - bd + 2;
+    if (okL)                                                              // residual of tile row c, columns 4 g ..: view L again
+    {
+      pel4 out;
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+      {
+        const int resi = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[r]) << 8) + (int)lo[r] + (1 << (s2i - 1))) >> s2i);
+        out[r] = (short)clip3(clpMin, clpMax, (int)pv[r] + (int)(short)resi);
+      }
+      *reinterpret_cast<pel4*>(recBase + dL.rec_off + (size_t)rowL * dL.rec_stride + colL) = out;
+    }
+  }
+  RC_WAVE_SYNC();                                                         // info is rewritten by the wave's next item
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -874,23 +1058,28 @@ __global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict_
 {
   __shared__ __align__(16) _Float16 tab[RC_TAB_HALVES];
   __shared__ RcSmallTab tabs;
-  __shared__ int tmpAll[4][8 * 8 * 9];
+  __shared__ int tmpAll[4][8 * 8 * 9];                        // per wave: transposes of the lane-group forms / the TU list of a packed tile
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  // slots (four wave items of one entry) in the order below: the longest items first, so that the short ones fill the machine while they run
-  constexpr int NORD = 13;
-  constexpr int ordCls[NORD] = { RC_C64, RC_R6432, RC_R3264, RC_C32, RC_R6416, RC_R1664, RC_C8, RC_R3216, RC_R1632, RC_C16, RC_C4, RC_R84, RC_R48 };
+  // slots (four wave items of one entry) in the order below: the longest items first, so that the short ones fill the machine while they run.
+  // 8x8 / 8x4 / 4x8 / 4x4 stay with the lane groups: as packed tiles (exact as well) they are slower (8M samples: 8x8 0.164 vs 0.143 ms, 4x4 0.175
+  // vs 0.142) -- a lane of a tile touches four 8-byte row pieces of its TU, a lane of a group one whole row
+  constexpr int NORD = 17;
+  constexpr int ordCls[NORD] = { RC_C64, RC_R6432, RC_R3264, RC_C32, RC_R6416, RC_R1664, RC_C8, RC_R3216, RC_R1632, RC_C16,
+                                 RC_P168, RC_P816, RC_P164, RC_P416, RC_C4, RC_R84, RC_R48 };
+  constexpr int ordG[NORD] = { 1, 1, 1, 1, 1, 1, 8, 1, 1, 1, 2, 2, 4, 4, 16, 8, 8 };      // TUs per wave item: lane groups 64 / S, packed tiles 256 / (W H)
   int cnt[NORD], items[NORD], end[NORD];
   int total = 0;
 #pragma unroll
   for (int k = 0; k < NORD; k++)
   {
     cnt[k] = hdr[ordCls[k]];
-    items[k] = (ordCls[k] == RC_C8 || ordCls[k] == RC_R84 || ordCls[k] == RC_R48) ? (cnt[k] + 7) >> 3 : ordCls[k] == RC_C4 ? (cnt[k] + 15) >> 4 : cnt[k];   // lane-group classes: 8 / 16 TUs per item
+    items[k] = (cnt[k] + ordG[k] - 1) / ordG[k];
     total += (items[k] + 3) >> 2;
     end[k] = total;
   }
   if ((int)blockIdx.x >= total) return;
   rc_load_all_tables(tab, image, tid);
+  rc_load_small_tables(tab, image, tid);
   for (int e = tid; e < 3 * 80; e += 256)
   {
     const int t = e / 80, o = e - t * 80, nsz = o < 16 ? 4 : 8, oo = o < 16 ? o : o - 16;
@@ -909,15 +1098,20 @@ __global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict_
 #define RC_MF(K, W_, H_)                                                                                                                      \
     case K: if (item < cnt[K]) { ti = lists[(size_t)ordCls[K] * n + item];                                                                    \
         done = rc_tu_mfma<W_, H_>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane); } break;
+#define RC_PK(K, W_, H_)                                                                                                                      \
+    case K: if (item < items[K]) rc_tile_packed<W_, H_>(descs, lists + (size_t)ordCls[K] * n, cnt[K], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, \
+                                                        clpMax, tab, tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
     switch (k)
     {
     RC_MF(0, 64, 64) RC_MF(1, 64, 32) RC_MF(2, 32, 64) RC_MF(3, 32, 32) RC_MF(4, 64, 16) RC_MF(5, 16, 64) RC_MF(7, 32, 16) RC_MF(8, 16, 32) RC_MF(9, 16, 16)
+    RC_PK(10, 16, 8) RC_PK(11, 8, 16) RC_PK(12, 16, 4) RC_PK(13, 4, 16)
     case 6: if (item < items[6]) rc_small_group<8>(descs, lists + (size_t)RC_C8 * n, cnt[6], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
-    case 10: if (item < items[10]) rc_small_group<4>(descs, lists + (size_t)RC_C4 * n, cnt[10], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
-    case 11: if (item < items[11]) rc_rect_group<8, 4>(descs, lists + (size_t)RC_R84 * n, cnt[11], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
-    default: if (item < items[12]) rc_rect_group<4, 8>(descs, lists + (size_t)RC_R48 * n, cnt[12], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 14: if (item < items[14]) rc_small_group<4>(descs, lists + (size_t)RC_C4 * n, cnt[14], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 15: if (item < items[15]) rc_rect_group<8, 4>(descs, lists + (size_t)RC_R84 * n, cnt[15], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    default: if (item < items[16]) rc_rect_group<4, 8>(descs, lists + (size_t)RC_R48 * n, cnt[16], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
     }
 #undef RC_MF
+#undef RC_PK
     if (!done && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti;               // residual outside +-1023: the generic kernel takes it
   }
 }
@@ -982,16 +1176,17 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
   int cur = 0;
   int* counters = vvcgpu_counters(st, &cur);
   if (!counters) return VVCGPU_E_DEVICE;
-  int* hdr = counters + 16 * cur;
+  int* hdr = counters + VVC_CTR_INTS * cur;
   int* lists = ws;
   int* fbCount = hdr + RC_FB;
   int* fbList = lists + (size_t)RC_NCLS * n;
+  static const int separate = getenv("VVCGPU_RC_SEPARATE") ? 1 : 0;           // A/B timing switch: one launch per size class
+  static const int packedOff = getenv("VVCGPU_RC_NO_PACKED") ? 1 : 0;         // A/B timing switch: 16x8 / 8x16 / 16x4 / 4x16 on the generic path
   hipLaunchKernelGGL(rc_classify_kernel, dim3(n < 1024 * RC_CLS_WGS ? cdiv(n, 1024) : RC_CLS_WGS), dim3(1024), 0, st, descs, n, hdr, lists, abs_sum,
-                     counters + 16 * (cur ^ 1));
+                     counters + VVC_CTR_INTS * (cur ^ 1), !separate && !packedOff);
   VVC_LAUNCH_CHECK_COUNTERS(st);
   // (measured: forking the size classes onto library-owned side streams and joining them with events is SLOWER than launching them back to
   // back on the caller's stream, 0.158 vs 0.115 ms at 4K -- a cross-stream event costs more than these 20 us kernels gain)
-  static const int separate = getenv("VVCGPU_RC_SEPARATE") ? 1 : 0;           // A/B timing switch: one launch per size class
   if (!separate)
   {
     hipLaunchKernelGGL(rc_chain_kernel, dim3(512), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, fbCount, fbList,

@@ -1101,14 +1101,71 @@ __device__ __noinline__ void dq_large_stage(const vvcgpu_dqtr_desc& d, const TCo
   });
 }
 
+// ---- device-side order of a batch for the fused kernel.  A workgroup of dqtr_fused_kernel serves `per` descriptors in up to three phases, each
+// with its own tables in the phase region (lane-group tables, f16 matrices, int16 matrices).  In the caller's order -- a real encoder's call mix:
+// 85 % of the TUs at most 8 wide, a few 32 / 64 wide ones in every run of 64 -- every workgroup walks ALL phases for a handful of TUs each and
+// reloads ~26 KB of matrices per 64 descriptors (more bytes than the TUs themselves): the mixed batch took 2.4 x the time of its parts
+// (profiles/r04_chain_shapes.txt).  Here the descriptor INDICES are binned by phase class first (the two-pass scheme of rc_classify_kernel,
+// resichain.hip: per-workgroup counts in LDS, one global atomic per class and workgroup); the fused kernel then walks the concatenated class lists,
+// heaviest class first, so that a workgroup's descriptors share a phase, lane groups are full and the tables stay.
+constexpr int DQC_NCLS = 6, DQC_WGS = 128;                 // classes in list order: 0 dot2 form (large), 1 matrix cores, 2 lane groups of 16, 3 of 8, 4 of 4, 5 transform skip
+__device__ __forceinline__ int dqc_class(int w, int h, int trHor, int useMfma)
+{
+  const int S = max(w, h);
+  if (trHor == 3) return 5;
+  if (S <= 4) return 4;
+  if (S == 8) return 3;
+  if (S == 16) return 2;
+  return useMfma && is_mfma_shape(w, h) ? 1 : 0;
+}
+__global__ __launch_bounds__(1024) void dqtr_classify_kernel(const vvcgpu_dqtr_desc* __restrict__ descs, int n, int* __restrict__ hdr, int* __restrict__ lists,
+                                                             int* __restrict__ nextHdr, int useMfma)
+{
+  if (blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextHdr[threadIdx.x] = 0;         // the header of the NEXT call on this stream (vvcgpu_counters)
+  __shared__ int cnt[DQC_NCLS], base[DQC_NCLS];
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int per = (n + gridDim.x - 1) / gridDim.x, lo = blockIdx.x * per, hi = min(n, lo + per);
+  if (tid < DQC_NCLS) cnt[tid] = 0;
+  __syncthreads();
+  for (int pass = 0; pass < 2; pass++)
+  {
+    for (int t0 = lo; t0 < hi; t0 += 1024)
+    {
+      const int ti = t0 + tid;
+      int cls = -1;
+      if (ti < hi)
+      {
+        const vvcgpu_tr_desc& d = reinterpret_cast<const vvcgpu_tr_desc*>(descs)[ti];
+        cls = dqc_class(d.w, d.h, d.tr_hor, useMfma);
+      }
+#pragma unroll
+      for (int k = 0; k < DQC_NCLS; k++)
+      {
+        const unsigned long long m = __builtin_amdgcn_ballot_w64(cls == k);
+        if (m == 0ull) continue;
+        int b = 0;
+        if (lane == 0) b = atomicAdd(&cnt[k], (int)__popcll(m));
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (pass == 1 && cls == k) lists[(size_t)k * n + base[k] + b + (int)__popcll(m & ((1ull << lane) - 1ull))] = ti;
+      }
+    }
+    __syncthreads();
+    if (pass == 0 && tid < DQC_NCLS) { base[tid] = cnt[tid] ? atomicAdd(&hdr[tid], cnt[tid]) : 0; cnt[tid] = 0; }
+    __syncthreads();
+  }
+}
+
 __global__ __launch_bounds__(256, 2) void dqtr_fused_kernel(const TCoeff* __restrict__ levelBase, Pel* __restrict__ resiBase,
                                                             const vvcgpu_dqtr_desc* __restrict__ descs, int n, int per, int bd,
-                                                            TCoeff* __restrict__ coeffOut, const _Float16* __restrict__ image, int useMfma)
+                                                            TCoeff* __restrict__ coeffOut, const _Float16* __restrict__ image, int useMfma,
+                                                            const int* __restrict__ hdr, const int* __restrict__ lists)
 {
+  __shared__ int idxOf[SM_DESCS];                            // descriptor index of the batch's t-th entry (the caller's order when lists == nullptr)
   __shared__ __align__(16) unsigned char uni[DQ_UNI];
   __shared__ __align__(16) int coef[4][1024];                // per wave: the kept region of a large TU / the TUs of a lane-group item
   __shared__ int cntM, cntL, cntS[4];
-  __shared__ unsigned char listM[SM_DESCS], listL[SM_DESCS], binOf[SM_DESCS];
+  __shared__ unsigned char listM[SM_DESCS], listL[SM_DESCS];
+  __shared__ unsigned short binOf[SM_DESCS];                 // bin * 64 + position in the bin's list (up to 255: a batch of 64 TUs of bin 3), 0xFFFF: not a lane-group TU
   SmallShared& sh = *reinterpret_cast<SmallShared*>(uni);
   _Float16* ftab = reinterpret_cast<_Float16*>(uni);
   short* tabT = reinterpret_cast<short*>(uni);
@@ -1116,25 +1173,51 @@ __global__ __launch_bounds__(256, 2) void dqtr_fused_kernel(const TCoeff* __rest
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int* coefW = coef[wave];
   int curTab = 0;                                            // 0 nothing, 1 lane-group tables, 2 f16 matrices, 3 int16 matrices (workgroup-uniform)
-  for (int batch = blockIdx.x; batch * per < n; batch += gridDim.x)
+  // ordered form: a batch is a run of ONE class list, short for the classes whose TUs are long serial jobs of a wave (a workgroup that drew 64
+  // large TUs would be the tail of the launch), long for the lane-group classes (16 / 8 / 4 TUs side by side in a wave)
+  // (and every class shorter when the whole call would otherwise be fewer than ~1024 batches: idle compute units cost more than part-filled waves)
+  int bEnd[DQC_NCLS], cCnt[DQC_NCLS], totalBatches = 0, shr = 0;
+#pragma unroll
+  for (int c = 0; c < DQC_NCLS; c++) cCnt[c] = lists ? hdr[c] : 0;
+  auto pkOf = [&](int c) { return max(4, (c <= 1 ? 8 : c == 5 ? 16 : SM_DESCS) >> shr); };
+  for (;; shr++)
   {
-    const int base = batch * per;
+    totalBatches = 0;
+#pragma unroll
+    for (int c = 0; c < DQC_NCLS; c++) { const int pk = pkOf(c); totalBatches += (cCnt[c] + pk - 1) / pk; bEnd[c] = totalBatches; }
+    if (totalBatches >= 1024 || shr == 4) break;
+  }
+  if (!lists) totalBatches = (n + per - 1) / per;
+  for (int batch = blockIdx.x; batch < totalBatches; batch += gridDim.x)
+  {
+    int base = batch * per, count = min(per, n - base), cls = 0;
+    if (lists)
+    {
+      int b0 = 0;
+#pragma unroll
+      for (int c = 0; c < DQC_NCLS - 1; c++) if (batch >= bEnd[c]) { cls = c + 1; b0 = bEnd[c]; }
+      const int pk = pkOf(cls);
+      base = (batch - b0) * pk;
+      count = min(pk, cCnt[cls] - base);
+    }
     __syncthreads();                                         // the previous batch is done with the lists and the phase region
     if (tid < 4) cntS[tid] = 0;
     if (tid == 0) { cntM = 0; cntL = 0; }
     __syncthreads();
     // the descriptor copies and lists of the lane-group phase live in the phase region: only a batch that has such TUs touches it, so a run of
     // large-TU batches keeps its matrices
-    if (tid < per && base + tid < n)
+    if (tid < count)
     {
-      const vvcgpu_tr_desc d = reinterpret_cast<const vvcgpu_tr_desc*>(descs)[base + tid];
+      const int di = lists ? lists[(size_t)cls * n + base + tid] : base + tid;
+      idxOf[tid] = di;
+      const vvcgpu_tr_desc d = reinterpret_cast<const vvcgpu_tr_desc*>(descs)[di];
       const int S = max((int)d.w, (int)d.h);
       // 16 x 16 stays with the lane groups here: one tile per wave behind a serial de-quantiser was slower (0.122 vs 0.083 ms at 4K)
       const int bin = d.tr_hor == 3 ? 0 : S <= 4 ? 1 : S == 8 ? 2 : S == 16 ? 3 : -1;
-      if (bin >= 0) { const int k = atomicAdd(&cntS[bin], 1); binOf[tid] = (unsigned char)(bin * 64 + k); }
+      if (bin >= 0) { const int k = atomicAdd(&cntS[bin], 1); binOf[tid] = (unsigned short)(bin * 64 + k); }
       else
       {
-        binOf[tid] = 255;
+        binOf[tid] = 0xFFFFu;
         if (useMfma && is_mfma_shape(d.w, d.h)) listM[atomicAdd(&cntM, 1)] = (unsigned char)tid;
         else listL[atomicAdd(&cntL, 1)] = (unsigned char)tid;
       }
@@ -1145,9 +1228,9 @@ __global__ __launch_bounds__(256, 2) void dqtr_fused_kernel(const TCoeff* __rest
     {
       if (curTab > 1) { curTab = 0; }                        // the matrices are about to be overwritten
       if (tid < 4) sh.cnt[tid] = cntS[tid];
-      if (tid < per && base + tid < n && binOf[tid] != 255)
+      if (tid < count && binOf[tid] != 0xFFFFu)
       {
-        sh.d[tid] = reinterpret_cast<const vvcgpu_tr_desc*>(descs)[base + tid];
+        sh.d[tid] = reinterpret_cast<const vvcgpu_tr_desc*>(descs)[idxOf[tid]];
         sh.list[binOf[tid] >> 6][binOf[tid] & 63] = (unsigned char)tid;
       }
       __syncthreads();
@@ -1171,7 +1254,7 @@ __global__ __launch_bounds__(256, 2) void dqtr_fused_kernel(const TCoeff* __rest
       }
       for (int q = wave; q < cntM; q += 4)
       {
-        const vvcgpu_dqtr_desc d = descs[base + listM[q]];
+        const vvcgpu_dqtr_desc d = descs[idxOf[listM[q]]];
         dq_large_stage(d, levelBase, coeffOut, bd, lane, coefW);
         const bool done = dq_inv_mfma(d.w, d.h, coefW, resiBase + d.resi_off, d.resi_stride, d.tr_hor, d.tr_ver, bd, lane, ftab);
         if (!done && lane == 0) listL[atomicAdd(&cntL, 1)] = listM[q];          // a coefficient beyond 16 bits: the dot2 form's exact 32-bit stage takes the TU
@@ -1185,7 +1268,7 @@ __global__ __launch_bounds__(256, 2) void dqtr_fused_kernel(const TCoeff* __rest
       int* tmpL = tmpAll + wave * (32 * (MAXN + 1));
       for (int q = wave; q < cntL; q += 4)
       {
-        const vvcgpu_dqtr_desc dq = descs[base + listL[q]];
+        const vvcgpu_dqtr_desc dq = descs[idxOf[listL[q]]];
         const vvcgpu_tr_desc& d = reinterpret_cast<const vvcgpu_tr_desc&>(dq);
         dq_large_stage(dq, levelBase, coeffOut, bd, lane, coefW);
         dq_inv_large(d, coefW, resiBase + d.resi_off, bd, lane, tmpL, tabT, d.w > 32 ? 32 : d.w);
@@ -2444,8 +2527,27 @@ int vvcgpu_dequant_tr_inv_batch(const vvc_coef* level_base, vvc_pel* resi_base, 
   while (per > 4 && cdiv(n, per) < 1024) per >>= 1;
   if (const char* e = getenv("VVCGPU_DQTR_PER")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) per = v; }   // tuning switch
   const int nb = cdiv(n, per);
+  // calls long enough to fill workgroups with one phase each are put into class order on the device first (dqtr_classify_kernel)
+  static const int orderMode = getenv("VVCGPU_DQTR_ORDER") ? atoi(getenv("VVCGPU_DQTR_ORDER")) : -1;   // A/B timing switch: 0 never, 1 always
+  const bool ordered = orderMode < 0 ? n >= 16384 : orderMode != 0;          // shorter calls: the extra launch (~15 us) costs more than the order gains
+  if (ordered)
+  {
+    int* lists = static_cast<int*>(vvcgpu_scratch(st, (size_t)DQC_NCLS * n * sizeof(int)));
+    if (!lists) return VVCGPU_E_DEVICE;
+    int cur = 0;
+    int* counters = vvcgpu_counters(st, &cur);
+    if (!counters) return VVCGPU_E_DEVICE;
+    int* hdr = counters + VVC_CTR_INTS * cur;
+    hipLaunchKernelGGL(dqtr_classify_kernel, dim3(n < 1024 * DQC_WGS ? cdiv(n, 1024) : DQC_WGS), dim3(1024), 0, st, descs, n, hdr, lists,
+                       counters + VVC_CTR_INTS * (cur ^ 1), tr_use_mfma());
+    VVC_LAUNCH_CHECK_COUNTERS(st);
+    hipLaunchKernelGGL(dqtr_fused_kernel, dim3(nb < 512 ? nb : 512), dim3(256), 0, st, level_base, resi_base, descs, n, per, bit_depth, coeff_out, image,
+                       tr_use_mfma(), hdr, lists);
+    VVC_LAUNCH_CHECK_COUNTERS(st);
+    return VVCGPU_OK;
+  }
   hipLaunchKernelGGL(dqtr_fused_kernel, dim3(nb < 512 ? nb : 512), dim3(256), 0, st, level_base, resi_base, descs, n, per, bit_depth, coeff_out, image,
-                     tr_use_mfma());
+                     tr_use_mfma(), nullptr, nullptr);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
