@@ -32,7 +32,7 @@ __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
 // ---- work lists (device): hdr[0 .. RC_NCLS) = counts of the classes, hdr[RC_FB] = count of the fall-back list
 constexpr int RC_HDR = VVC_CTR_INTS;
 enum { RC_C64 = 0, RC_C32, RC_C16, RC_C8, RC_C4, RC_CGEN, RC_R6432, RC_R3264, RC_R6416, RC_R1664, RC_R3216, RC_R1632, RC_R84, RC_R48,
-       RC_P168, RC_P816, RC_P164, RC_P416, RC_NCLS };               // RC_P*: packed tiles (rc_tile_packed)
+       RC_P168, RC_P816, RC_P164, RC_P416, RC_P328, RC_P832, RC_P324, RC_P432, RC_NCLS };   // RC_P*: packed tiles (rc_tile_packed*)
 constexpr int RC_FB = RC_NCLS;
 static_assert(RC_FB < RC_HDR, "the header is one counter set of vvcgpu_counters");
 
@@ -49,11 +49,12 @@ __device__ __forceinline__ int rc_class(const RcDesc& d, bool packed)
     return RC_CGEN;
   }
   if (w == 64) return h == 32 ? RC_R6432 : h == 16 ? RC_R6416 : RC_CGEN;
-  if (w == 32) return h == 64 ? RC_R3264 : h == 16 ? RC_R3216 : RC_CGEN;
+  if (w == 32) return h == 64 ? RC_R3264 : h == 16 ? RC_R3216 : h == 8 ? (packed ? RC_P328 : RC_CGEN) : h == 4 ? (packed ? RC_P324 : RC_CGEN) : RC_CGEN;
   if (w == 16) return h == 64 ? RC_R1664 : h == 32 ? RC_R1632 : h == 8 ? (packed ? RC_P168 : RC_CGEN) : h == 4 ? (packed ? RC_P164 : RC_CGEN) : RC_CGEN;
   if (w == 8 && h == 4) return RC_R84;
   if (w == 4 && h == 8) return RC_R48;
   if (h == 16 && packed) return w == 8 ? RC_P816 : w == 4 ? RC_P416 : RC_CGEN;
+  if (h == 32 && packed) return w == 8 ? RC_P832 : w == 4 ? RC_P432 : RC_CGEN;
   return RC_CGEN;
 }
 
@@ -567,6 +568,333 @@ __device__ __noinline__ void rc_tile_packed(const RcDesc* __restrict__ descs, co
   RC_WAVE_SYNC();                                                         // info is rewritten by the wave's next item
 }
 
+// Packed tiles with a 32-point side: 32 x 8 / 32 x 4 (16 / H TUs one above the other in a 16-row x 32-column double tile) and 8 x 32 / 4 x 32
+// (16 / W TUs side by side in a 32-row x 16-column double tile).  The 32-point stages are the 16x16x32 products of mfma_tr.h (operand of a
+// result tile in its register k order), the short side is block-diagonal as above; only the 32-point stages depend on the other operand's
+// sub-TU and run in passes.
+template <int H>
+__device__ __noinline__ void rc_tile_packed_w32(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
+                                                const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                                TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
+                                                const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
+                                                int* __restrict__ fbCount, int* __restrict__ fbList, int* info, int lane)
+{
+  constexpr int W = 32, NY = 16 / H, G = NY, LH = H == 4 ? 2 : 3, LW = 5;
+  const int c = lane & 15, g = lane >> 4;
+  const h4 zero4 = { (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0 };
+  const h8 zero8 = { (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0 };
+  {
+    int ti = -1, types = 0;
+    if (lane < G && item * G + lane < cnt) { ti = list[item * G + lane]; const RcDesc& d = descs[ti]; types = (int)d.tr_hor | ((int)d.tr_ver << 2); }
+    if (lane < G) { info[lane] = ti; info[16 + lane] = types; }
+  }
+  RC_WAVE_SYNC();
+  const int syL = c >> LH, syQ = (4 * g) >> LH;                          // sample views: tile row c; coefficient view: tile rows 4 g ..
+  const int tiL = info[syL], tiQ = info[syQ], ti0 = info[0];
+  auto laneMask = [&](int sy) -> unsigned long long { const unsigned long long cm = ((1ull << H) - 1ull) << (sy * H); return cm | (cm << 16) | (cm << 32) | (cm << 48); };
+  const RcDesc& dL = descs[tiL >= 0 ? tiL : ti0];
+  const int rowL = c & (H - 1);
+  h8 xa = zero8;
+  bool inRange = true;
+  if (tiL >= 0)
+  {
+    const pel8 o = *reinterpret_cast<const pel8*>(orgBase + dL.org_off + (size_t)rowL * dL.org_stride + 8 * g);
+    const pel8 pp = *reinterpret_cast<const pel8*>(predBase + dL.pred_off + (size_t)rowL * dL.pred_stride + 8 * g);
+#pragma unroll
+    for (int j = 0; j < 8; j++) { const int v = (int)o[j] - (int)pp[j]; inRange = inRange && v >= -1023 && v <= 1023; xa[j] = (_Float16)(short)v; }
+  }
+  const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!inRange);
+  const bool okL = tiL >= 0 && (badLanes & laneMask(syL)) == 0ull, okQ = tiQ >= 0 && (badLanes & laneMask(syQ)) == 0ull;
+  if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMask(lane)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
+  if (!okL) xa = zero8;
+  const int s1 = LW + bd + 6 - 15 + 2, s2 = LH + 6 + 2;
+  // ---- F1 (32-point, one pass per TU: the type belongs to the row of X)
+  int t1[2][4];
+  {
+    f4 m1[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
+#pragma unroll
+    for (int p = 0; p < NY; p++)
+    {
+      const h8 a = syL == p ? xa : zero8;
+      const _Float16* Th = tab + rc_tab_off(info[16 + p] & 3, 32, 0);
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++)
+        m1[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, *reinterpret_cast<const h8*>(Th + (16 * jt + c) * 40 + 8 * g), m1[jt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) t1[jt][r] = ((int)m1[jt][r] + (1 << (s1 - 1))) >> s1;       // M1[row 4 g + r][frequency 16 jt + c]
+  }
+  // ---- F2 (block-diagonal H-point; the type belongs to the row of the matrix)
+  const bool diagV = syL == syQ;
+  int cf[2][4];
+  {
+    const h4 a = diagV ? rc_frag4(tab, (info[16 + syL] >> 2) & 3, H, 0, rowL, (4 * g) & (H - 1)) : zero4;
+#pragma unroll
+    for (int jt = 0; jt < 2; jt++)
+    {
+      const f4 hi = __builtin_amdgcn_mfma_f32_16x16x16f16(a, rc_limb_h4(t1[jt], true), f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+      const f4 lo = __builtin_amdgcn_mfma_f32_16x16x16f16(a, rc_limb_h4(t1[jt], false), f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) cf[jt][r] = ((((int)hi[r]) << 8) + (int)lo[r] + (1 << (s2 - 1))) >> s2;   // C[vertical frequency 4 g + r][horizontal 16 jt + c]
+    }
+  }
+  // ---- quantiser: the lane's coefficients are rows y0 .. y0 + 3 of columns c and 16 + c of TU syQ
+  const RcDesc& dQ = descs[tiQ >= 0 ? tiQ : ti0];
+  const RcQ q = rc_qparams(W, H, dQ.qp, bd, dQ.intra_slice, dQ.sign_hiding);
+  const int y0 = (4 * g) & (H - 1);
+  const unsigned short* inv = dqInv + scanOff[(LW - 1) * 6 + (LH - 1)];
+  int lv[2][4], du[2][4], sum = 0, lastCg = -1, cgIdx[2];
+#pragma unroll
+  for (int jt = 0; jt < 2; jt++)
+  {
+#pragma unroll
+    for (int r = 0; r < 4; r++) { int mag; lv[jt][r] = rc_quant_one(q, cf[jt][r], du[jt][r], mag); sum += mag; }
+    cgIdx[jt] = (int)inv[y0 * W + 16 * jt + (c & ~3)] >> 4;
+    if (rc_cg_nonzero(lv[jt])) lastCg = max(lastCg, cgIdx[jt]);
+  }
+#pragma unroll
+  for (int m = 1; m < 16; m <<= 1) { sum += __shfl_xor(sum, m); if (m >= 4) lastCg = max(lastCg, __shfl_xor(lastCg, m)); }
+#pragma unroll
+  for (int m = 16; m < 4 * H; m <<= 1) { sum += __shfl_xor(sum, m); lastCg = max(lastCg, __shfl_xor(lastCg, m)); }
+  if (okQ && c == 0 && y0 == 0) absSumOut[tiQ] = (unsigned)sum;
+  TCoeff* level = levelBase + dQ.level_off;
+#pragma unroll
+  for (int jt = 0; jt < 2; jt++)
+  {
+    if (q.sbh) rc_sbh_quad(lv[jt], du[jt], cf[jt], cgIdx[jt] == lastCg, lane);
+    if (okQ)
+    {
+#pragma unroll
+      for (int r = 0; r < 4; r++) level[(y0 + r) * W + 16 * jt + c] = lv[jt][r];
+    }
+  }
+  // ---- I1 (block-diagonal H-point; the type belongs to the column r = c of the matrix operand)
+  int y1[2][4];
+  {
+    const h4 b = diagV ? rc_frag4(tab, (info[16 + syL] >> 2) & 3, H, 1, rowL, (4 * g) & (H - 1)) : zero4;
+#pragma unroll
+    for (int jt = 0; jt < 2; jt++)
+    {
+      int cq[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) cq[r] = rc_dequant_one(q, lv[jt][r]);
+      const f4 hi = __builtin_amdgcn_mfma_f32_16x16x16f16(rc_limb_h4(cq, true), b, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+      const f4 lo = __builtin_amdgcn_mfma_f32_16x16x16f16(rc_limb_h4(cq, false), b, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) y1[jt][r] = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[r]) << 8) + (int)lo[r] + 256) >> 9);   // Y1T[frequency 16 jt + 4 g + r][row c]
+    }
+  }
+  // ---- I2 (32-point over the frequency i, operand in result-tile k order; the type belongs to the column r = c of Y1T: one pass per TU)
+  {
+    h8 bh[1], bl[1];
+    rc_tile_frags<32>(bh, bl, y1);
+    f4 hi[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } }, lo[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
+#pragma unroll
+    for (int p = 0; p < NY; p++)
+    {
+      const bool mine = syL == p;
+      const _Float16* ThT = tab + rc_tab_off(info[16 + p] & 3, 32, 1);
+#pragma unroll
+      for (int xt = 0; xt < 2; xt++)
+      {
+        const h8 a = rc_mat_frag32(ThT, 40, 16 * xt + c, 0, g);
+        hi[xt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, mine ? bh[0] : zero8, hi[xt], 0, 0, 0);
+        lo[xt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, mine ? bl[0] : zero8, lo[xt], 0, 0, 0);
+      }
+    }
+    const int s2i = (6 + 15 - 1) - bd + 2;
+    if (okL)
+    {
+      const Pel* pr = predBase + dL.pred_off + (size_t)rowL * dL.pred_stride;
+      Pel* rec = recBase + dL.rec_off + (size_t)rowL * dL.rec_stride;
+#pragma unroll
+      for (int xt = 0; xt < 2; xt++)                                      // residual of tile row c, columns 16 xt + 4 g ..
+      {
+        const pel4 pv = *reinterpret_cast<const pel4*>(pr + 16 * xt + 4 * g);
+        pel4 out;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+          const int resi = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[xt][r]) << 8) + (int)lo[xt][r] + (1 << (s2i - 1))) >> s2i);
+          out[r] = (short)clip3(clpMin, clpMax, (int)pv[r] + (int)(short)resi);
+        }
+        *reinterpret_cast<pel4*>(rec + 16 * xt + 4 * g) = out;
+      }
+    }
+  }
+  RC_WAVE_SYNC();
+}
+
+template <int W>
+__device__ __noinline__ void rc_tile_packed_h32(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
+                                                const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                                TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
+                                                const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
+                                                int* __restrict__ fbCount, int* __restrict__ fbList, int* info, int lane)
+{
+  constexpr int H = 32, NX = 16 / W, G = NX, LW = W == 4 ? 2 : 3, LH = 5;
+  const int c = lane & 15, g = lane >> 4;
+  const h4 zero4 = { (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0 };
+  const h8 zero8 = { (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0 };
+  {
+    int ti = -1, types = 0;
+    if (lane < G && item * G + lane < cnt) { ti = list[item * G + lane]; const RcDesc& d = descs[ti]; types = (int)d.tr_hor | ((int)d.tr_ver << 2); }
+    if (lane < G) { info[lane] = ti; info[16 + lane] = types; }
+  }
+  RC_WAVE_SYNC();
+  const int sxL = (4 * g) >> LW, sxQ = c >> LW;                          // sample view: tile columns 4 g ..; coefficient view: tile column c
+  const int tiL = info[sxL], tiQ = info[sxQ], ti0 = info[0];
+  auto laneMask = [&](int sx) -> unsigned long long
+  {
+    unsigned long long m = 0;
+#pragma unroll
+    for (int gg = 0; gg < W / 4; gg++) m |= 0xFFFFull << (16 * (sx * (W / 4) + gg));
+    return m;
+  };
+  const RcDesc& dL = descs[tiL >= 0 ? tiL : ti0];
+  const int colL = (4 * g) & (W - 1);
+  pel4 pv[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
+  h4 xa[2] = { zero4, zero4 };
+  bool inRange = true;
+  if (tiL >= 0)
+  {
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+    {
+      const pel4 o = *reinterpret_cast<const pel4*>(orgBase + dL.org_off + (size_t)(16 * rt + c) * dL.org_stride + colL);
+      pv[rt] = *reinterpret_cast<const pel4*>(predBase + dL.pred_off + (size_t)(16 * rt + c) * dL.pred_stride + colL);
+#pragma unroll
+      for (int j = 0; j < 4; j++) { const int v = (int)o[j] - (int)pv[rt][j]; inRange = inRange && v >= -1023 && v <= 1023; xa[rt][j] = (_Float16)(short)v; }
+    }
+  }
+  const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!inRange);
+  const bool okL = tiL >= 0 && (badLanes & laneMask(sxL)) == 0ull, okQ = tiQ >= 0 && (badLanes & laneMask(sxQ)) == 0ull;
+  if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMask(lane)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
+  if (!okL) { xa[0] = zero4; xa[1] = zero4; }
+  const int s1 = LW + bd + 6 - 15 + 2, s2 = LH + 6 + 2;
+  const bool diagH = sxQ == sxL;
+  // ---- F1 (block-diagonal W-point; the type belongs to the column j = c of the matrix operand)
+  int t1[2][4];
+  {
+    const h4 b = diagH ? rc_frag4(tab, info[16 + sxQ] & 3, W, 0, c & (W - 1), colL) : zero4;
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+    {
+      const f4 m1 = __builtin_amdgcn_mfma_f32_16x16x16f16(xa[rt], b, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) t1[rt][r] = ((int)m1[r] + (1 << (s1 - 1))) >> s1;         // M1[row 16 rt + 4 g + r][frequency c]
+    }
+  }
+  // ---- F2 (32-point over the rows, operand in result-tile k order; the type belongs to the column j1 = c of M1: one pass per TU)
+  int cf[2][4];
+  {
+    h8 bh[1], bl[1];
+    rc_tile_frags<32>(bh, bl, t1);
+    f4 hi[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } }, lo[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
+#pragma unroll
+    for (int qq = 0; qq < NX; qq++)
+    {
+      const bool mine = sxQ == qq;
+      const _Float16* Tv = tab + rc_tab_off((info[16 + qq] >> 2) & 3, 32, 0);
+#pragma unroll
+      for (int it = 0; it < 2; it++)
+      {
+        const h8 a = rc_mat_frag32(Tv, 40, 16 * it + c, 0, g);
+        hi[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, mine ? bh[0] : zero8, hi[it], 0, 0, 0);
+        lo[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, mine ? bl[0] : zero8, lo[it], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < 2; it++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) cf[it][r] = ((((int)hi[it][r]) << 8) + (int)lo[it][r] + (1 << (s2 - 1))) >> s2;   // C[vertical frequency 16 it + 4 g + r][horizontal c]
+  }
+  // ---- quantiser: the lane's coefficients are rows 16 it + 4 g .. of column xq of TU sxQ
+  const RcDesc& dQ = descs[tiQ >= 0 ? tiQ : ti0];
+  const RcQ q = rc_qparams(W, H, dQ.qp, bd, dQ.intra_slice, dQ.sign_hiding);
+  const int xq = c & (W - 1);
+  const unsigned short* inv = dqInv + scanOff[(LW - 1) * 6 + (LH - 1)];
+  int lv[2][4], du[2][4], sum = 0, lastCg = -1, cgIdx[2];
+#pragma unroll
+  for (int it = 0; it < 2; it++)
+  {
+#pragma unroll
+    for (int r = 0; r < 4; r++) { int mag; lv[it][r] = rc_quant_one(q, cf[it][r], du[it][r], mag); sum += mag; }
+    cgIdx[it] = (int)inv[(16 * it + 4 * g) * W + (xq & ~3)] >> 4;
+    if (rc_cg_nonzero(lv[it])) lastCg = max(lastCg, cgIdx[it]);
+  }
+#pragma unroll
+  for (int m = 1; m < W; m <<= 1) { sum += __shfl_xor(sum, m); if (m >= 4) lastCg = max(lastCg, __shfl_xor(lastCg, m)); }
+#pragma unroll
+  for (int m = 16; m < 64; m <<= 1) { sum += __shfl_xor(sum, m); lastCg = max(lastCg, __shfl_xor(lastCg, m)); }
+  if (okQ && xq == 0 && g == 0) absSumOut[tiQ] = (unsigned)sum;
+  TCoeff* level = levelBase + dQ.level_off;
+#pragma unroll
+  for (int it = 0; it < 2; it++)
+  {
+    if (q.sbh) rc_sbh_quad(lv[it], du[it], cf[it], cgIdx[it] == lastCg, lane);
+    if (okQ)
+    {
+#pragma unroll
+      for (int r = 0; r < 4; r++) level[(16 * it + 4 * g + r) * W + xq] = lv[it][r];
+    }
+  }
+  // ---- I1 (32-point over the vertical frequency, A = Cq^T in result-tile k order; the type belongs to A's row i = c: one pass per TU)
+  int y1[2][4];
+  {
+    int cq[2][4];
+#pragma unroll
+    for (int it = 0; it < 2; it++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) cq[it][r] = rc_dequant_one(q, lv[it][r]);
+    h8 ah[1], al[1];
+    rc_tile_frags<32>(ah, al, cq);
+    f4 hi[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } }, lo[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
+#pragma unroll
+    for (int qq = 0; qq < NX; qq++)
+    {
+      const bool mine = sxQ == qq;
+      const _Float16* TvT = tab + rc_tab_off((info[16 + qq] >> 2) & 3, 32, 1);
+#pragma unroll
+      for (int rt = 0; rt < 2; rt++)
+      {
+        const h8 b = rc_mat_frag32(TvT, 40, 16 * rt + c, 0, g);
+        hi[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(mine ? ah[0] : zero8, b, hi[rt], 0, 0, 0);
+        lo[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(mine ? al[0] : zero8, b, lo[rt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) y1[rt][r] = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[rt][r]) << 8) + (int)lo[rt][r] + 256) >> 9);   // Y1T[frequency 4 g + r][row 16 rt + c]
+  }
+  // ---- I2 (block-diagonal W-point; the type belongs to the row x = c of the matrix)
+  {
+    const h4 a = diagH ? rc_frag4(tab, info[16 + sxQ] & 3, W, 1, c & (W - 1), colL) : zero4;
+    const int s2i = (6 + 15 - 1) - bd + 2;
+#pragma unroll
+    for (int rt = 0; rt < 2; rt++)
+    {
+      const f4 hi = __builtin_amdgcn_mfma_f32_16x16x16f16(a, rc_limb_h4(y1[rt], true), f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+      const f4 lo = __builtin_amdgcn_mfma_f32_16x16x16f16(a, rc_limb_h4(y1[rt], false), f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+      if (okL)                                                            // residual of tile row 16 rt + c, columns 4 g ..: the sample view again
+      {
+        pel4 out;
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+          const int resi = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[r]) << 8) + (int)lo[r] + (1 << (s2i - 1))) >> s2i);
+          out[r] = (short)clip3(clpMin, clpMax, (int)pv[rt][r] + (int)(short)resi);
+        }
+        *reinterpret_cast<pel4*>(recBase + dL.rec_off + (size_t)(16 * rt + c) * dL.rec_stride + colL) = out;
+      }
+    }
+  }
+  RC_WAVE_SYNC();
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Generic path: one wave per TU, any W x H in 2..64; the residual / intermediates / coefficients live in two LDS buffers of the wave.
 // Matrices come from global memory (int32 tables).  Exact 32-bit arithmetic as the reference's `int` loops.
@@ -1063,10 +1391,10 @@ __global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict_
   // slots (four wave items of one entry) in the order below: the longest items first, so that the short ones fill the machine while they run.
   // 8x8 / 8x4 / 4x8 / 4x4 stay with the lane groups: as packed tiles (exact as well) they are slower (8M samples: 8x8 0.164 vs 0.143 ms, 4x4 0.175
   // vs 0.142) -- a lane of a tile touches four 8-byte row pieces of its TU, a lane of a group one whole row
-  constexpr int NORD = 17;
+  constexpr int NORD = 21;
   constexpr int ordCls[NORD] = { RC_C64, RC_R6432, RC_R3264, RC_C32, RC_R6416, RC_R1664, RC_C8, RC_R3216, RC_R1632, RC_C16,
-                                 RC_P168, RC_P816, RC_P164, RC_P416, RC_C4, RC_R84, RC_R48 };
-  constexpr int ordG[NORD] = { 1, 1, 1, 1, 1, 1, 8, 1, 1, 1, 2, 2, 4, 4, 16, 8, 8 };      // TUs per wave item: lane groups 64 / S, packed tiles 256 / (W H)
+                                 RC_P168, RC_P816, RC_P164, RC_P416, RC_C4, RC_R84, RC_R48, RC_P328, RC_P832, RC_P324, RC_P432 };
+  constexpr int ordG[NORD] = { 1, 1, 1, 1, 1, 1, 8, 1, 1, 1, 2, 2, 4, 4, 16, 8, 8, 2, 2, 4, 4 };   // TUs per wave item: lane groups 64 / S, packed tiles 256 (512) / (W H)
   int cnt[NORD], items[NORD], end[NORD];
   int total = 0;
 #pragma unroll
@@ -1108,7 +1436,14 @@ __global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict_
     case 6: if (item < items[6]) rc_small_group<8>(descs, lists + (size_t)RC_C8 * n, cnt[6], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
     case 14: if (item < items[14]) rc_small_group<4>(descs, lists + (size_t)RC_C4 * n, cnt[14], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
     case 15: if (item < items[15]) rc_rect_group<8, 4>(descs, lists + (size_t)RC_R84 * n, cnt[15], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
-    default: if (item < items[16]) rc_rect_group<4, 8>(descs, lists + (size_t)RC_R48 * n, cnt[16], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 16: if (item < items[16]) rc_rect_group<4, 8>(descs, lists + (size_t)RC_R48 * n, cnt[16], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+#define RC_PK32(K, F)                                                                                                                         \
+    case K: if (item < items[K]) F(descs, lists + (size_t)ordCls[K] * n, cnt[K], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,     \
+                                   tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
+    RC_PK32(17, rc_tile_packed_w32<8>) RC_PK32(18, rc_tile_packed_h32<8>) RC_PK32(19, rc_tile_packed_w32<4>)
+    default: if (item < items[20]) rc_tile_packed_h32<4>(descs, lists + (size_t)RC_P432 * n, cnt[20], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,
+                                                         tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
+#undef RC_PK32
     }
 #undef RC_MF
 #undef RC_PK
