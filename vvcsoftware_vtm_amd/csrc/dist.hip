@@ -93,47 +93,65 @@ __device__ __forceinline__ unsigned long long dist_one(int kind, const vvcgpu_di
   return res;
 }
 
-// A wave takes FOUR consecutive descriptors.  The reference encoder's calls are mostly narrow (tests/golden/trace_*.npz: 4- and 8-wide blocks are
-// 80 % of the distortion calls): when all four blocks have at most 128 samples, each gets 16 lanes and the four run side by side; otherwise
-// the wave serves them one after the other with all 64 lanes.  HEAVY blocks (more than 2048 samples, SAD / Hadamard / SSE) are not computed
-// here: one wave needs ~60 us for a 128 x 128 block, which was the run time of the whole launch on a real call mix -- they are listed, their result is
-// zeroed, and dist_heavy_kernel splits each into bands of >= 16 rows over as many waves, summing with 64-bit atomics.
-constexpr int DIST_HEAVY = 2048;
+// A workgroup takes up to 64 consecutive descriptors and BINS them first (one ballot of its first wave).  The reference encoder's calls are mostly
+// narrow (tests/golden/trace_*.npz: 4- and 8-wide blocks are 80 % of the distortion calls): blocks of at most 128 samples run four side by side in a
+// wave, 16 lanes each; larger ones take a whole wave each.  (Until round 4 a wave took four CONSECUTIVE descriptors and ran them side by side only
+// when all four were small: on the real call mix most waves lost that form to one larger neighbour.)  HEAVY blocks (more than 2048 samples,
+// SAD / Hadamard / SSE) are not computed here: one wave needs ~60 us for a 128 x 128 block, which was the run time of the whole launch on a real call
+// mix -- they are listed, their result is zeroed, and dist_heavy_kernel splits each into bands of >= 16 rows over as many waves, summing with 64-bit atomics.
+constexpr int DIST_HEAVY = 2048, DIST_WG_DESCS = 64;
 __device__ __forceinline__ int dist_band_rows(int w) { return max(16, ((DIST_HEAVY / w) + 15) & ~15); }
 __device__ __forceinline__ bool dist_is_heavy(int kind, int w, int h) { return kind <= 2 && w * h > DIST_HEAVY && (h & 15) == 0 && h <= 8 * dist_band_rows(w); }
 
 __global__ __launch_bounds__(256) void dist_batch_kernel(int kind, const Pel* __restrict__ orgBase,
                                                          const Pel* __restrict__ curBase,
-                                                         const vvcgpu_dist_desc* __restrict__ descs, int n,
+                                                         const vvcgpu_dist_desc* __restrict__ descs, int n, int perWg,
                                                          unsigned long long* __restrict__ out, int* __restrict__ heavyCount, int* __restrict__ heavyList,
                                                          int* __restrict__ nextCounters)
 {
   if (blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextCounters[threadIdx.x] = 0;       // the counter set of the next call on this stream (vvcgpu_counters)
-  const int lane = threadIdx.x & 63;
-  const int d0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-  if (d0 >= n) return;                                  // whole wave exits together
-  const int g = lane >> 4, lig = lane & 15;
-  const bool act = d0 + g < n;
-  const vvcgpu_dist_desc mine = descs[act ? d0 + g : d0];
-  const bool small = (int)mine.w * (int)mine.h <= 128;      // (a 16 x 16 Hadamard on 16 lanes takes two tile passes: slower than the whole wave)
-  if (__builtin_amdgcn_ballot_w64(!small) == 0ull)
+  __shared__ unsigned char sList[DIST_WG_DESCS], mList[DIST_WG_DESCS];
+  __shared__ int cntS, cntM;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int base = blockIdx.x * perWg;
+  if (wave == 0)
   {
-    const unsigned long long res = dist_one<16>(kind, mine, orgBase, curBase, lig, act);
-    if (act && lig == 0) out[d0 + g] = res;
-    return;
+    const int di = base + lane;
+    int w = 0, h = 0;
+    if (lane < perWg && di < n) { w = descs[di].w; h = descs[di].h; }
+    const int sz = w * h;
+    // (a 16 x 16 Hadamard on 16 lanes takes two tile passes: slower than the whole wave)
+    const bool on = lane < perWg && di < n, small = on && sz <= 128, heavy = on && dist_is_heavy(kind, w, h), med = on && !small && !heavy;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long ms = __builtin_amdgcn_ballot_w64(small), mm = __builtin_amdgcn_ballot_w64(med), mh = __builtin_amdgcn_ballot_w64(heavy);
+    if (small) sList[__popcll(ms & below)] = (unsigned char)lane;
+    if (med) mList[__popcll(mm & below)] = (unsigned char)lane;
+    if (lane == 0) { cntS = (int)__popcll(ms); cntM = (int)__popcll(mm); }
+    if (mh != 0ull)                                     // ONE atomic per workgroup (same-address atomics retire at ~12 ns each)
+    {
+      int b = 0;
+      if (lane == 0) b = atomicAdd(heavyCount, (int)__popcll(mh));
+      b = __builtin_amdgcn_readfirstlane(b);
+      if (heavy) { out[di] = 0ull; heavyList[b + (int)__popcll(mh & below)] = di; }
+    }
   }
-  int nHeavy = 0, heavyIdx[4];
-  for (int k = 0; k < 4 && d0 + k < n; k++)
+  __syncthreads();
+  const int nS = cntS, nM = cntM;
+  for (int g0 = wave * 4; g0 < nS; g0 += 16)
   {
-    const vvcgpu_dist_desc d = descs[d0 + k];
-    if (dist_is_heavy(kind, d.w, d.h)) { heavyIdx[nHeavy++] = d0 + k; continue; }
+    const int k = g0 + (lane >> 4);
+    const bool act = k < nS;
+    const int di = base + sList[act ? k : g0];
+    const vvcgpu_dist_desc mine = descs[di];
+    const unsigned long long res = dist_one<16>(kind, mine, orgBase, curBase, lane & 15, act);
+    if (act && (lane & 15) == 0) out[di] = res;
+  }
+  for (int k = wave; k < nM; k += 4)
+  {
+    const int di = base + mList[k];
+    const vvcgpu_dist_desc d = descs[di];
     const unsigned long long res = dist_one<64>(kind, d, orgBase, curBase, lane, true);
-    if (lane == 0) out[d0 + k] = res;
-  }
-  if (nHeavy && lane == 0)                              // ONE atomic per wave (same-address atomics retire at ~12 ns each)
-  {
-    const int base = atomicAdd(heavyCount, nHeavy);
-    for (int k = 0; k < nHeavy; k++) { out[heavyIdx[k]] = 0ull; heavyList[base + k] = heavyIdx[k]; }
+    if (lane == 0) out[di] = res;
   }
 }
 
@@ -146,7 +164,7 @@ __global__ __launch_bounds__(256) void dist_heavy_kernel(int kind, const Pel* __
   const int cnt = heavyCount[0], waves = gridDim.x * 4;
   for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < cnt * 8; p += waves)
   {
-    const int di = heavyList[p >> 3], band = p & 7;
+    const int band = p / cnt, di = heavyList[p - band * cnt];           // band-major pairs (see if_heavy_kernel, interp.hip)
     vvcgpu_dist_desc d = descs[di];
     const int hFull = d.h, br = dist_band_rows(d.w), r0 = band * br;
     if (r0 >= hFull) continue;
@@ -1508,8 +1526,10 @@ int vvcgpu_dist_batch(int kind, const vvc_pel* org_base, const vvc_pel* cur_base
   int cur = 0;
   int* counters = vvcgpu_counters(st, &cur);                                  // zeroed counter for this call; the kernel clears the other set
   if (!counters) return VVCGPU_E_DEVICE;
-  hipLaunchKernelGGL(dist_batch_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, kind, org_base, cur_base,
-                     descs, n, reinterpret_cast<unsigned long long*>(out), counters + VVC_CTR_INTS * cur, heavyList, counters + VVC_CTR_INTS * (cur ^ 1));
+  int perWg = DIST_WG_DESCS;                              // fewer descriptors per workgroup when 64 would leave compute units without one
+  while (perWg > 16 && cdiv(n, perWg) < 4096) perWg >>= 1;
+  hipLaunchKernelGGL(dist_batch_kernel, dim3(cdiv(n, perWg)), dim3(256), 0, st, kind, org_base, cur_base,
+                     descs, n, perWg, reinterpret_cast<unsigned long long*>(out), counters + VVC_CTR_INTS * cur, heavyList, counters + VVC_CTR_INTS * (cur ^ 1));
   if (kind <= 2)                                                              // blocks of more than 2048 samples: bands over many waves (none: the launch leaves at once)
     hipLaunchKernelGGL(dist_heavy_kernel, dim3(n * 2 < 1024 ? (n * 2 > 0 ? n * 2 : 1) : 1024), dim3(256), 0, st, kind, org_base, cur_base, descs,
                        reinterpret_cast<unsigned long long*>(out), counters + VVC_CTR_INTS * cur, heavyList);

@@ -58,17 +58,14 @@ __device__ __forceinline__ int if_copy(int s, bool isFirst, bool isLast, int bd,
 }
 
 // ------------------------------------------------------------------------------------------------ I1
-// four samples of a row, the widest load the address allows
+// four samples of a row in ONE 8-byte access whatever the address (blocks start at any sample: 2-byte alignment).  gfx950 under HSA runs with
+// unaligned global access enabled and the compiler knows it: a load / store through a 2-byte-aligned type is one global_load / store_dwordx2.  (Until
+// round 4 the access branched three ways on the address -- 8-, 4-, 2-byte aligned -- and a wave whose lanes disagreed walked all three.)
+struct __attribute__((packed, aligned(2))) PelQuad { short v[4]; };
 __device__ __forceinline__ void if_load4(const Pel* p, int (&v)[4])
 {
-  const uintptr_t a = (uintptr_t)p;
-  if ((a & 7) == 0) { const pel4 q = *reinterpret_cast<const pel4*>(p); v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; v[3] = q[3]; }
-  else if ((a & 3) == 0)
-  {
-    const pel2 q0 = *reinterpret_cast<const pel2*>(p), q1 = *reinterpret_cast<const pel2*>(p + 2);
-    v[0] = q0[0]; v[1] = q0[1]; v[2] = q1[0]; v[3] = q1[1];
-  }
-  else { v[0] = p[0]; v[1] = p[1]; v[2] = p[2]; v[3] = p[3]; }
+  const PelQuad q = *reinterpret_cast<const PelQuad*>(p);
+  v[0] = q.v[0]; v[1] = q.v[1]; v[2] = q.v[2]; v[3] = q.v[3];
 }
 
 // one descriptor by a group of G lanes (lane = index inside the group)
@@ -154,7 +151,7 @@ __device__ __forceinline__ void if_one(const vvcgpu_if_desc& d, const Pel* __res
         o[j] = (short)val;
       }
       Pel* dp = dst + (size_t)y * d.dst_stride + x;
-      if (nv == 4 && ((uintptr_t)dp & 7) == 0) *reinterpret_cast<pel4*>(dp) = o;
+      if (nv == 4) { PelQuad q; q.v[0] = o[0]; q.v[1] = o[1]; q.v[2] = o[2]; q.v[3] = o[3]; *reinterpret_cast<PelQuad*>(dp) = q; }
       else
       {
 #pragma unroll
@@ -164,40 +161,70 @@ __device__ __forceinline__ void if_one(const vvcgpu_if_desc& d, const Pel* __res
   }
 }
 
-// A wave takes four consecutive descriptors: side by side with 16 lanes each when all four have at most 256 samples (the reference encoder's
-// table-slot calls are mostly 4 wide: tests/golden/trace_*.npz), one after the other with 64 lanes otherwise.  HEAVY calls (more than 2048
-// samples) are listed for if_heavy_kernel, which splits them into bands of rows over many waves: one wave needs ~70 us for 128 x 135 samples, and that
-// was the run time of the whole launch on a real call mix.
+// A workgroup takes 64 consecutive descriptors and BINS them first (one ballot of its first wave): calls of at most 256 samples -- the reference
+// encoder's table-slot calls are mostly 4 wide: tests/golden/trace_*.npz -- run four side by side in a wave, 16 lanes each; larger ones take a whole
+// wave each; HEAVY calls (more than 512 samples) are listed for if_heavy_kernel, which splits them into bands of rows over many waves: one wave needs
+// ~70 us for 128 x 135 samples, and that was the run time of the whole launch on a real call mix.  (Until round 4 a wave took four CONSECUTIVE
+// descriptors and ran them side by side only when all four were small: on the real call mix three of four waves lost that form to one larger
+// neighbour -- the mixed batch took 2.5 x the time of its parts, profiles/r04_entry_shapes.txt.)
 constexpr int IF_HEAVY = 2048, IF_HEAVY_FILTER = 512;   // the filter does 8 multiply-adds per sample: its heavy threshold is lower than the element-wise ops'
-// a heavy call is cut into at most 16 bands of rows: band height = 2048 samples' worth, more when that would give more than 16
+constexpr int IF_WG_DESCS = 64;
+// a heavy call is cut into at most 16 bands of rows: band height = 512 samples' worth, more when that would give more than 16
+__device__ __forceinline__ int if_filter_band_rows(int w, int h) { return max(max(2, IF_HEAVY_FILTER / w), (h + 15) >> 4); }
 __device__ __forceinline__ int if_band_rows(int w, int h) { return max(max(4, IF_HEAVY / w), (h + 15) >> 4); }
 __global__ __launch_bounds__(256) void if_batch_kernel(const Pel* __restrict__ srcBase, Pel* __restrict__ dstBase,
-                                                       const vvcgpu_if_desc* __restrict__ descs, int n, int bd,
+                                                       const vvcgpu_if_desc* __restrict__ descs, int n, int perWg, int bd,
                                                        int cmin, int cmax, int* __restrict__ heavyCount, int* __restrict__ heavyList, int* __restrict__ nextCounters)
 {
   if (blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextCounters[threadIdx.x] = 0;       // the counter set of the next call on this stream (vvcgpu_counters)
-  const int lane = threadIdx.x & 63;
-  const int d0 = (blockIdx.x * 4 + (threadIdx.x >> 6)) * 4;
-  if (d0 >= n) return;
-  const int g = lane >> 4;
-  const bool act = d0 + g < n;
-  const vvcgpu_if_desc mine = descs[act ? d0 + g : d0];
-  if (__builtin_amdgcn_ballot_w64((int)mine.w * (int)mine.h > 256) == 0ull)
+  __shared__ unsigned char tList[IF_WG_DESCS], sList[IF_WG_DESCS], mList[IF_WG_DESCS];
+  __shared__ int cntT, cntS, cntM;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int base = blockIdx.x * perWg;
+  if (wave == 0)
   {
+    const int di = base + lane;
+    int w = 0, h = 0;
+    if (lane < perWg && di < n) { w = descs[di].w; h = descs[di].h; }
+    const int sz = w * h;
+    // tiny: at most four 4-output units (4 x 4 and smaller: half of the trace's calls) -- four lanes each, sixteen calls side by side
+    const bool tiny = sz > 0 && ((w + 3) >> 2) * h <= 4, small = sz > 0 && !tiny && sz <= 256, heavy = sz > IF_HEAVY_FILTER, med = sz > 0 && !tiny && !small && !heavy;
+    const unsigned long long below = (1ull << lane) - 1ull;
+    const unsigned long long mt = __builtin_amdgcn_ballot_w64(tiny), ms = __builtin_amdgcn_ballot_w64(small), mm = __builtin_amdgcn_ballot_w64(med),
+                             mh = __builtin_amdgcn_ballot_w64(heavy);
+    if (tiny) tList[__popcll(mt & below)] = (unsigned char)lane;
+    if (small) sList[__popcll(ms & below)] = (unsigned char)lane;
+    if (med) mList[__popcll(mm & below)] = (unsigned char)lane;
+    if (lane == 0) { cntT = (int)__popcll(mt); cntS = (int)__popcll(ms); cntM = (int)__popcll(mm); }
+    if (mh != 0ull)                                     // ONE atomic per workgroup (same-address atomics retire at ~12 ns each)
+    {
+      int b = 0;
+      if (lane == 0) b = atomicAdd(heavyCount, (int)__popcll(mh));
+      b = __builtin_amdgcn_readfirstlane(b);
+      // the entry carries the number of bands the call really has, so that the band walk of if_heavy_kernel skips the others without touching the descriptor
+      if (heavy) heavyList[b + (int)__popcll(mh & below)] = di | (((h + if_filter_band_rows(w, h) - 1) / if_filter_band_rows(w, h) - 1) << 27);
+    }
+  }
+  __syncthreads();
+  const int nT = cntT, nS = cntS, nM = cntM;
+  for (int g0 = wave * 16; g0 < nT; g0 += 64)
+  {
+    const int k = g0 + (lane >> 2);
+    const bool act = k < nT;
+    const vvcgpu_if_desc mine = descs[base + tList[act ? k : g0]];
+    if_one<4>(mine, srcBase, dstBase, lane & 3, act, bd, cmin, cmax);
+  }
+  for (int g0 = wave * 4; g0 < nS; g0 += 16)
+  {
+    const int k = g0 + (lane >> 4);
+    const bool act = k < nS;
+    const vvcgpu_if_desc mine = descs[base + sList[act ? k : g0]];
     if_one<16>(mine, srcBase, dstBase, lane & 15, act, bd, cmin, cmax);
-    return;
   }
-  int nHeavy = 0, heavyIdx[4];
-  for (int k = 0; k < 4 && d0 + k < n; k++)
+  for (int k = wave; k < nM; k += 4)
   {
-    const vvcgpu_if_desc d = descs[d0 + k];
-    if ((int)d.w * (int)d.h > IF_HEAVY_FILTER) { heavyIdx[nHeavy++] = d0 + k; continue; }
+    const vvcgpu_if_desc d = descs[base + mList[k]];
     if_one<64>(d, srcBase, dstBase, lane, true, bd, cmin, cmax);
-  }
-  if (nHeavy && lane == 0)                              // ONE atomic per wave (same-address atomics retire at ~12 ns each)
-  {
-    const int base = atomicAdd(heavyCount, nHeavy);
-    for (int k = 0; k < nHeavy; k++) heavyList[base + k] = heavyIdx[k];
   }
 }
 // one wave per (heavy call, band of rows)
@@ -206,10 +233,15 @@ __global__ __launch_bounds__(256) void if_heavy_kernel(const Pel* __restrict__ s
 {
   const int lane = threadIdx.x & 63;
   const int cnt = heavyCount[0], waves = gridDim.x * 4;
-  for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < cnt * 16; p += waves)       // pair p = (item p >> 4, band p & 15)
+  // pair p = (band p / cnt, item p % cnt): BAND-major, so that the waves of one step hold neighbouring calls of the same band -- item-major
+  // (p >> 4, p & 15) with a wave stride that is a multiple of 16 gave every wave the same band for the whole launch, and a call of two bands
+  // (32 x 32: 3 % of the trace's samples) kept one wave in eight busy (0.131 ms per 4 M samples against 0.024 for 32 x 16)
+  for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < cnt * 16; p += waves)
   {
-    const vvcgpu_if_desc d = descs[heavyList[p >> 4]];
-    const int br = max(max(2, IF_HEAVY_FILTER / d.w), (d.h + 15) >> 4), r0 = (p & 15) * br;
+    const int band = p / cnt, e = heavyList[p - band * cnt];
+    if (band > (e >> 27)) continue;
+    const vvcgpu_if_desc d = descs[e & ((1 << 27) - 1)];
+    const int br = if_filter_band_rows(d.w, d.h), r0 = band * br;
     if (r0 < d.h) if_one<64>(d, srcBase, dstBase, lane, true, bd, cmin, cmax, r0, r0 + br);
   }
 }
@@ -778,34 +810,42 @@ __global__ __launch_bounds__(256) void pelop_batch_kernel(int op, const Pel* __r
 {
   const int tid = threadIdx.x;
   if (nextCounters && blockIdx.x == 0 && blockIdx.y == 0 && tid < VVC_CTR_INTS) nextCounters[tid] = 0;   // the counter set of the next call on this stream
-  if (perWg > 1)                                          // a wave takes four consecutive descriptors: side by side with 16 lanes each when all
-  {                                                       // four have at most 256 samples, one after the other with 64 lanes otherwise
-    const int lane = tid & 63, g = lane >> 4;
-    for (int k0 = (tid >> 6) * 4; k0 < perWg; k0 += 16)
+  if (perWg > 1)                                          // the workgroup bins its perWg (<= 64) consecutive descriptors first, as if_batch_kernel does:
+  {                                                       // at most 256 samples: four side by side in a wave; larger: a wave each; heavy: listed
+    __shared__ unsigned char sList[64], mList[64];
+    __shared__ int cntS, cntM;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int base = blockIdx.x * perWg;
+    if (wave == 0)
     {
-      const int d0 = blockIdx.x * perWg + k0;
-      if (d0 >= n) break;
-      const bool act = d0 + g < n;
-      const vvcgpu_pelop_desc mine = descs[act ? d0 + g : d0];
-      if (__builtin_amdgcn_ballot_w64((int)mine.w * (int)mine.h > 256) == 0ull)
+      const int di = base + lane;
+      int sz = 0;
+      if (lane < perWg && di < n) sz = (int)descs[di].w * (int)descs[di].h;
+      const bool small = sz > 0 && sz <= 256, heavy = sz > IF_HEAVY, med = sz > 0 && !small && !heavy;
+      const unsigned long long below = (1ull << lane) - 1ull;
+      const unsigned long long ms = __builtin_amdgcn_ballot_w64(small), mm = __builtin_amdgcn_ballot_w64(med), mh = __builtin_amdgcn_ballot_w64(heavy);
+      if (small) sList[__popcll(ms & below)] = (unsigned char)lane;
+      if (med) mList[__popcll(mm & below)] = (unsigned char)lane;
+      if (lane == 0) { cntS = (int)__popcll(ms); cntM = (int)__popcll(mm); }
+      if (mh != 0ull)                                     // bands over many waves (pelop_heavy_kernel): one wave per 128 x 128 block was the launch's run time
       {
-        if (act) pelop_one(op, mine, s0Base, s1Base, dstBase, c, lane & 15, 16, 0, mine.h);
+        int b = 0;
+        if (lane == 0) b = atomicAdd(heavyCount, (int)__popcll(mh));
+        b = __builtin_amdgcn_readfirstlane(b);
+        if (heavy) heavyList[b + (int)__popcll(mh & below)] = di;
       }
-      else
-      {
-        int nHeavy = 0, heavyIdx[4];
-        for (int k = 0; k < 4 && d0 + k < n; k++)
-        {
-          const vvcgpu_pelop_desc d = descs[d0 + k];
-          if ((int)d.w * (int)d.h > IF_HEAVY) { heavyIdx[nHeavy++] = d0 + k; continue; }    // bands over many waves (pelop_heavy_kernel): one wave per 128 x 128 block was the launch's run time
-          pelop_one(op, d, s0Base, s1Base, dstBase, c, lane, 64, 0, d.h);
-        }
-        if (nHeavy && lane == 0)
-        {
-          const int base = atomicAdd(heavyCount, nHeavy);
-          for (int k = 0; k < nHeavy; k++) heavyList[base + k] = heavyIdx[k];
-        }
-      }
+    }
+    __syncthreads();
+    const int nS = cntS, nM = cntM;
+    for (int g0 = wave * 4; g0 < nS; g0 += 16)
+    {
+      const int k = g0 + (lane >> 4);
+      if (k < nS) { const vvcgpu_pelop_desc mine = descs[base + sList[k]]; pelop_one(op, mine, s0Base, s1Base, dstBase, c, lane & 15, 16, 0, mine.h); }
+    }
+    for (int k = wave; k < nM; k += 4)
+    {
+      const vvcgpu_pelop_desc d = descs[base + mList[k]];
+      pelop_one(op, d, s0Base, s1Base, dstBase, c, lane, 64, 0, d.h);
     }
     return;
   }
@@ -822,10 +862,11 @@ __global__ __launch_bounds__(256) void pelop_heavy_kernel(int op, const Pel* __r
 {
   const int lane = threadIdx.x & 63;
   const int cnt = heavyCount[0], waves = gridDim.x * 4;
-  for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < cnt * 16; p += waves)
+  for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < cnt * 16; p += waves)       // band-major pairs (see if_heavy_kernel)
   {
-    const vvcgpu_pelop_desc d = descs[heavyList[p >> 4]];
-    const int br = if_band_rows(d.w, d.h), r0 = (p & 15) * br;
+    const int band = p / cnt;
+    const vvcgpu_pelop_desc d = descs[heavyList[p - band * cnt]];
+    const int br = if_band_rows(d.w, d.h), r0 = band * br;
     if (r0 < d.h) pelop_one(op, d, s0Base, s1Base, dstBase, c, lane, 64, r0, min((int)d.h, r0 + br));
   }
 }
@@ -847,7 +888,10 @@ int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_
   int cur = 0;
   int* counters = vvcgpu_counters(st, &cur);
   if (!counters) return VVCGPU_E_DEVICE;
-  hipLaunchKernelGGL(if_batch_kernel, dim3(cdiv(n, 16)), dim3(256), 0, st, src_base, dst_base, descs, n,
+  VVC_CHECK_ARG(n < (1 << 27), "if_batch: n %d", n);
+  int perWg = IF_WG_DESCS;                                // fewer descriptors per workgroup when 64 would leave compute units without one
+  while (perWg > 16 && cdiv(n, perWg) < 4096) perWg >>= 1;
+  hipLaunchKernelGGL(if_batch_kernel, dim3(cdiv(n, perWg)), dim3(256), 0, st, src_base, dst_base, descs, n, perWg,
                      bit_depth, clp_min, clp_max, counters + VVC_CTR_INTS * cur, heavyList, counters + VVC_CTR_INTS * (cur ^ 1));
   hipLaunchKernelGGL(if_heavy_kernel, dim3(1024), dim3(256), 0, st, src_base, dst_base, descs, bit_depth, clp_min, clp_max, counters + VVC_CTR_INTS * cur, heavyList);
   VVC_LAUNCH_CHECK_COUNTERS(st);
@@ -911,7 +955,8 @@ int vvcgpu_pelop_batch(int op, const vvc_pel* src0_base, const vvc_pel* src1_bas
   if (n == 0) return VVCGPU_OK;
   VVC_CHECK_ARG(src0_base && dst_base && descs && cfg_host, "pelop_batch: null pointer");
   VVC_CHECK_ARG(src1_base || op == 2 || op == 5, "pelop_batch: op %d needs src1", op);
-  const int perWg = n < 8192 ? 1 : 16;
+  int perWg = n < 8192 ? 1 : 64;                          // long lists: up to 64 descriptors per workgroup, fewer when that would leave compute units without one
+  while (perWg > 16 && cdiv(n, perWg) < 4096) perWg >>= 1;
   hipStream_t st = (hipStream_t)stream;
   int* heavyList = nullptr; int* counters = nullptr; int cur = 0;
   if (perWg > 1)                                          // long lists: heavy blocks go to a list and a second launch
