@@ -45,3 +45,18 @@ def test_dequant_tr_inv_long_batch_in_class_order():
     assert len(calls) >= 16384
     _, _, check = build(calls, rng)
     assert check(oracle(), p)
+
+
+@pytest.mark.parametrize("name", ["tr_fwd_batch", "tr_inv_batch"])
+def test_plain_transforms_long_batch_in_bin_order(name):
+    """n >= 16384: vvcgpu_tr_fwd_batch / vvcgpu_tr_inv_batch bin the small TUs on the device too and the small kernel walks the bin lists
+    (tr_collect_large_kernel, small_setup) -- the trace's call mix, ~1 M samples, bit-exact against the oracle"""
+    from vvcsoftware_vtm_amd import shape_mix as sm
+    hist, _ = sm.load_trace()
+    _, entry, keep, build = [r for r in sm.rows(hist) if r[0] == name][0]
+    sig = sm.signatures(hist, entry, keep)
+    rng = np.random.default_rng(29)
+    calls = sm.draw(sig, 1 << 20, rng)
+    assert len(calls) >= 16384
+    _, _, check = build(calls, rng)
+    assert check(oracle(), p)

@@ -68,15 +68,28 @@ __device__ __forceinline__ void small_tables(SmallShared& sh, int tid)
     sh.tabT[t][e] = nsz ? tr32t(t, nsz)[o] : 0;
   }
 }
-__device__ __forceinline__ void small_setup(SmallShared& sh, const vvcgpu_tr_desc* __restrict__ descs, int n, int batch, int tid, int useMfma)
+// smCnt / smLists (may be null): the small TUs of the call binned on the device (tr_collect_large_kernel): the batch is then a run of the
+// concatenated bin lists (lane groups of 16 first), so that a workgroup's TUs share a bin and its lane groups are full -- in the caller's order a real
+// encoder's call mix leaves most groups part-filled (profiles/r04_entry_shapes.txt: the mixed batch took 1.5 x the time of its parts)
+__device__ __forceinline__ int small_total(const int* __restrict__ smCnt, int n) { return smCnt ? smCnt[0] + smCnt[1] + smCnt[2] + smCnt[3] : n; }
+__device__ __forceinline__ void small_setup(SmallShared& sh, const vvcgpu_tr_desc* __restrict__ descs, int n, int batch, int tid, int useMfma,
+                                            const int* __restrict__ smCnt = nullptr, const int* __restrict__ smLists = nullptr)
 {
   __syncthreads();                                  // tables ready / previous batch done with d, list, cnt
   if (tid < 4) sh.cnt[tid] = 0;
   __syncthreads();
-  const int base = batch * SM_DESCS;
-  if (tid < SM_DESCS && base + tid < n)
+  const int base = batch * SM_DESCS, total = small_total(smCnt, n);
+  if (tid < SM_DESCS && base + tid < total)
   {
-    const vvcgpu_tr_desc d = descs[base + tid];
+    int di = base + tid;
+    if (smCnt)
+    {
+      int v = di, b = 3;
+#pragma unroll
+      for (int k = 3; k > 0; k--) { const int c = smCnt[k]; if (b == k && v >= c) { v -= c; b = k - 1; } }
+      di = smLists[(size_t)b * n + v];
+    }
+    const vvcgpu_tr_desc d = descs[di];
     sh.d[tid] = d;
     const int S = max((int)d.w, (int)d.h);
     int bin = d.tr_hor == 3 ? 0 : S <= 4 ? 1 : S == 8 ? 2 : S == 16 ? 3 : -1;           // -1: large, the other launches
@@ -136,14 +149,16 @@ __device__ __forceinline__ void fwd_small_group(SmallShared& sh, int bin, int gr
 }
 
 __global__ __launch_bounds__(256) void tr_fwd_small_kernel(const Pel* __restrict__ resiBase, TCoeff* __restrict__ coeffBase,
-                                                           const vvcgpu_tr_desc* __restrict__ descs, int n, int bd, int useMfma)
+                                                           const vvcgpu_tr_desc* __restrict__ descs, int n, int bd, int useMfma,
+                                                           const int* __restrict__ smCnt, const int* __restrict__ smLists)
 {
   __shared__ SmallShared sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   small_tables(sh, tid);
-  for (int batch = blockIdx.x; batch * SM_DESCS < n; batch += gridDim.x)
+  const int total = small_total(smCnt, n);
+  for (int batch = blockIdx.x; batch * SM_DESCS < total; batch += gridDim.x)
   {
-  small_setup(sh, descs, n, batch, tid, useMfma);
+  small_setup(sh, descs, n, batch, tid, useMfma, smCnt, smLists);
   for (int q = 0; q < sh.cnt[0]; q++)                // transform skip: element-wise, whole workgroup
   {
     const vvcgpu_tr_desc& d = sh.d[sh.list[0][q]];
@@ -218,14 +233,16 @@ __device__ __forceinline__ void inv_small_group(SmallShared& sh, int bin, int gr
 }
 
 __global__ __launch_bounds__(256) void tr_inv_small_kernel(const TCoeff* __restrict__ coeffBase, Pel* __restrict__ resiBase,
-                                                           const vvcgpu_tr_desc* __restrict__ descs, int n, int bd, int useMfma)
+                                                           const vvcgpu_tr_desc* __restrict__ descs, int n, int bd, int useMfma,
+                                                           const int* __restrict__ smCnt, const int* __restrict__ smLists)
 {
   __shared__ SmallShared sh;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   small_tables(sh, tid);
-  for (int batch = blockIdx.x; batch * SM_DESCS < n; batch += gridDim.x)
+  const int total = small_total(smCnt, n);
+  for (int batch = blockIdx.x; batch * SM_DESCS < total; batch += gridDim.x)
   {
-  small_setup(sh, descs, n, batch, tid, useMfma);
+  small_setup(sh, descs, n, batch, tid, useMfma, smCnt, smLists);
   for (int q = 0; q < sh.cnt[0]; q++)
   {
     const vvcgpu_tr_desc& d = sh.d[sh.list[0][q]];
@@ -697,32 +714,42 @@ __global__ __launch_bounds__(256, 2) void tr_inv_mfma_kernel(const TCoeff* __res
 // ws[2 + n ..]), ws[1] = count of the dot2 list (entries at ws[2 ..]: `large` = ws + 1 is a count followed by its entries)
 // (same-address device atomics retire at ~12 ns each: one per wave made this kernel 35 us for 137 k descriptors; here a 1024-thread workgroup
 // aggregates its 16 waves in LDS and reserves its range of each list with ONE atomic)
-__global__ __launch_bounds__(1024) void tr_collect_large_kernel(const vvcgpu_tr_desc* __restrict__ descs, int n, int* __restrict__ ws, int useMfma)
+// smCnt / smLists (long calls only, else null): the small TUs as well, one list per bin of the small kernels (0 transform skip, 1 S <= 4, 2 S = 8,
+// 3 S = 16); smCnt is a counter set of vvcgpu_counters (nextCnt: the other set, cleared here for the next call on the stream)
+__global__ __launch_bounds__(1024) void tr_collect_large_kernel(const vvcgpu_tr_desc* __restrict__ descs, int n, int* __restrict__ ws, int useMfma,
+                                                                int* __restrict__ smCnt, int* __restrict__ smLists, int* __restrict__ nextCnt)
 {
-  __shared__ int wcnt[2][16], gbase[2];
+  if (nextCnt && blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextCnt[threadIdx.x] = 0;
+  __shared__ int wcnt[6][16], gbase[6];
   const int ti = blockIdx.x * 1024 + threadIdx.x, lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  bool lg = false, mf = false;
+  int cat = -1;                                                             // 0 dot2 list, 1 matrix-core list, 2 + bin: small
   if (ti < n)
   {
     const int* f = reinterpret_cast<const int*>(descs + ti) + 5;            // bytes 20..27: w, h, tr_hor, tr_ver
     const int wh = f[0], tt = f[1];
-    const int w = (short)(wh & 0xFFFF), h = wh >> 16;
+    const int w = (short)(wh & 0xFFFF), h = wh >> 16, S = max(w, h);
     const bool tr = (signed char)(tt & 0xFF) != 3;
-    mf = tr && useMfma && is_mfma_shape(w, h);
-    lg = tr && !mf && (w > 16 || h > 16);
+    if (tr && useMfma && is_mfma_shape(w, h)) cat = 1;
+    else if (tr && (w > 16 || h > 16)) cat = 0;
+    else if (smCnt) cat = 2 + (!tr ? 0 : S <= 4 ? 1 : S == 8 ? 2 : 3);
   }
-  const unsigned long long m = __builtin_amdgcn_ballot_w64(lg), m2 = __builtin_amdgcn_ballot_w64(mf);
-  if (lane == 0) { wcnt[0][wave] = (int)__popcll(m); wcnt[1][wave] = (int)__popcll(m2); }
+  unsigned long long m[6];
+#pragma unroll
+  for (int k = 0; k < 6; k++) { m[k] = __builtin_amdgcn_ballot_w64(cat == k); if (lane == 0) wcnt[k][wave] = (int)__popcll(m[k]); }
   __syncthreads();
-  if (threadIdx.x < 2)
+  if (threadIdx.x < 6)
   {
+    const int k = threadIdx.x;
     int tot = 0;
-    for (int k = 0; k < 16; k++) { const int c = wcnt[threadIdx.x][k]; wcnt[threadIdx.x][k] = tot; tot += c; }
-    gbase[threadIdx.x] = tot ? atomicAdd(&ws[1 - threadIdx.x], tot) : 0;  // ws[1]: dot2 list, ws[0]: matrix-core list
+    for (int q = 0; q < 16; q++) { const int c = wcnt[k][q]; wcnt[k][q] = tot; tot += c; }
+    gbase[k] = !tot ? 0 : k < 2 ? atomicAdd(&ws[1 - k], tot) : atomicAdd(&smCnt[k - 2], tot);   // ws[1]: dot2 list, ws[0]: matrix-core list
   }
   __syncthreads();
-  if (lg) ws[2 + gbase[0] + wcnt[0][wave] + (int)__popcll(m & ((1ull << lane) - 1ull))] = ti;
-  if (mf) ws[2 + n + gbase[1] + wcnt[1][wave] + (int)__popcll(m2 & ((1ull << lane) - 1ull))] = ti;
+  if (cat < 0) return;
+  const int pos = gbase[cat] + wcnt[cat][wave] + (int)__popcll(m[cat] & ((1ull << lane) - 1ull));
+  if (cat == 0) ws[2 + pos] = ti;
+  else if (cat == 1) ws[2 + n + pos] = ti;
+  else smLists[(size_t)(cat - 2) * n + pos] = ti;
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -2462,14 +2489,26 @@ int vvcgpu_tr_fwd_batch(const vvc_pel* resi_base, vvc_coef* coeff_base, const vv
   if (rtb) return rtb;
   const _Float16* image = vvcgpu_mfma_image(tb);
   if (!image) return VVCGPU_E_DEVICE;
-  int* ws = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * (2 * (size_t)n + 2)));   // cached per-stream scratch: the two lists of large TUs
+  // long calls: the small TUs are binned on the device as well and the small kernel walks the bin lists (see small_setup)
+  static const int orderMode = getenv("VVCGPU_TR_ORDER") ? atoi(getenv("VVCGPU_TR_ORDER")) : -1;       // A/B timing switch: 0 never, 1 always
+  const bool ordered = orderMode < 0 ? n >= 16384 : orderMode != 0;
+  int* ws = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * ((ordered ? 6 : 2) * (size_t)n + 2)));   // cached per-stream scratch: the lists of large (and small) TUs
   if (!ws) return VVCGPU_E_DEVICE;
   VVC_HIP(hipMemsetAsync(ws, 0, 2 * sizeof(int), st));
+  int* smCnt = nullptr; int* smLists = nullptr; int* nextCnt = nullptr;
+  if (ordered)
+  {
+    int cur = 0;
+    int* counters = vvcgpu_counters(st, &cur);
+    if (!counters) return VVCGPU_E_DEVICE;
+    smCnt = counters + VVC_CTR_INTS * cur; nextCnt = counters + VVC_CTR_INTS * (cur ^ 1); smLists = ws + 2 + 2 * (size_t)n;
+  }
   const int nb = cdiv(n, SM_DESCS), nl = cdiv(n, 4);
-  hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 1024)), dim3(1024), 0, st, descs, n, ws, tr_use_mfma());
-  hipLaunchKernelGGL(tr_fwd_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, resi_base, coeff_base, descs, n, bit_depth, tr_use_mfma());
+  hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 1024)), dim3(1024), 0, st, descs, n, ws, tr_use_mfma(), smCnt, smLists, nextCnt);
+  hipLaunchKernelGGL(tr_fwd_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, resi_base, coeff_base, descs, n, bit_depth, tr_use_mfma(), smCnt, smLists);
   hipLaunchKernelGGL(tr_fwd_mfma_kernel, dim3(nl < 512 ? nl : 512), dim3(256), 0, st, resi_base, coeff_base, descs, ws, ws + 2 + n, ws + 1, bit_depth, image);
   hipLaunchKernelGGL(tr_fwd_large_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, resi_base, coeff_base, descs, ws + 1, bit_depth);
+  if (ordered) VVC_LAUNCH_CHECK_COUNTERS(st);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
@@ -2487,14 +2526,26 @@ int vvcgpu_tr_inv_batch(const vvc_coef* coeff_base, vvc_pel* resi_base, const vv
   if (rtb) return rtb;
   const _Float16* image = vvcgpu_mfma_image(tb);
   if (!image) return VVCGPU_E_DEVICE;
-  int* ws = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * (2 * (size_t)n + 2)));   // cached per-stream scratch: the two lists of large TUs
+  // long calls: the small TUs are binned on the device as well and the small kernel walks the bin lists (see small_setup)
+  static const int orderMode = getenv("VVCGPU_TR_ORDER") ? atoi(getenv("VVCGPU_TR_ORDER")) : -1;       // A/B timing switch: 0 never, 1 always
+  const bool ordered = orderMode < 0 ? n >= 16384 : orderMode != 0;
+  int* ws = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * ((ordered ? 6 : 2) * (size_t)n + 2)));   // cached per-stream scratch: the lists of large (and small) TUs
   if (!ws) return VVCGPU_E_DEVICE;
   VVC_HIP(hipMemsetAsync(ws, 0, 2 * sizeof(int), st));
+  int* smCnt = nullptr; int* smLists = nullptr; int* nextCnt = nullptr;
+  if (ordered)
+  {
+    int cur = 0;
+    int* counters = vvcgpu_counters(st, &cur);
+    if (!counters) return VVCGPU_E_DEVICE;
+    smCnt = counters + VVC_CTR_INTS * cur; nextCnt = counters + VVC_CTR_INTS * (cur ^ 1); smLists = ws + 2 + 2 * (size_t)n;
+  }
   const int nb = cdiv(n, SM_DESCS), nl = cdiv(n, 4);
-  hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 1024)), dim3(1024), 0, st, descs, n, ws, tr_use_mfma());
-  hipLaunchKernelGGL(tr_inv_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, coeff_base, resi_base, descs, n, bit_depth, tr_use_mfma());
+  hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 1024)), dim3(1024), 0, st, descs, n, ws, tr_use_mfma(), smCnt, smLists, nextCnt);
+  hipLaunchKernelGGL(tr_inv_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, coeff_base, resi_base, descs, n, bit_depth, tr_use_mfma(), smCnt, smLists);
   hipLaunchKernelGGL(tr_inv_mfma_kernel, dim3(nl < 512 ? nl : 512), dim3(256), 0, st, coeff_base, resi_base, descs, ws, ws + 2 + n, ws + 1, bit_depth, image);
   hipLaunchKernelGGL(tr_inv_large_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, coeff_base, resi_base, descs, ws + 1, bit_depth);
+  if (ordered) VVC_LAUNCH_CHECK_COUNTERS(st);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
