@@ -112,7 +112,7 @@ __global__ __launch_bounds__(256) void dist_batch_kernel(int kind, const Pel* __
   if (blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextCounters[threadIdx.x] = 0;       // the counter set of the next call on this stream (vvcgpu_counters)
   __shared__ unsigned char sList[DIST_WG_DESCS], mList[DIST_WG_DESCS];
   __shared__ int cntS, cntM;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int base = blockIdx.x * perWg;
   if (wave == 0)
   {
@@ -148,7 +148,7 @@ __global__ __launch_bounds__(256) void dist_batch_kernel(int kind, const Pel* __
   }
   for (int k = wave; k < nM; k += 4)
   {
-    const int di = base + mList[k];
+    const int di = base + __builtin_amdgcn_readfirstlane((int)mList[k]);
     const vvcgpu_dist_desc d = descs[di];
     const unsigned long long res = dist_one<64>(kind, d, orgBase, curBase, lane, true);
     if (lane == 0) out[di] = res;

@@ -179,7 +179,7 @@ __global__ __launch_bounds__(256) void if_batch_kernel(const Pel* __restrict__ s
   if (blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextCounters[threadIdx.x] = 0;       // the counter set of the next call on this stream (vvcgpu_counters)
   __shared__ unsigned char tList[IF_WG_DESCS], sList[IF_WG_DESCS], mList[IF_WG_DESCS];
   __shared__ int cntT, cntS, cntM;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int base = blockIdx.x * perWg;
   if (wave == 0)
   {
@@ -223,7 +223,7 @@ __global__ __launch_bounds__(256) void if_batch_kernel(const Pel* __restrict__ s
   }
   for (int k = wave; k < nM; k += 4)
   {
-    const vvcgpu_if_desc d = descs[base + mList[k]];
+    const vvcgpu_if_desc d = descs[base + __builtin_amdgcn_readfirstlane((int)mList[k])];
     if_one<64>(d, srcBase, dstBase, lane, true, bd, cmin, cmax);
   }
 }
@@ -236,9 +236,9 @@ __global__ __launch_bounds__(256) void if_heavy_kernel(const Pel* __restrict__ s
   // pair p = (band p / cnt, item p % cnt): BAND-major, so that the waves of one step hold neighbouring calls of the same band -- item-major
   // (p >> 4, p & 15) with a wave stride that is a multiple of 16 gave every wave the same band for the whole launch, and a call of two bands
   // (32 x 32: 3 % of the trace's samples) kept one wave in eight busy (0.131 ms per 4 M samples against 0.024 for 32 x 16)
-  for (int p = blockIdx.x * 4 + (threadIdx.x >> 6); p < cnt * 16; p += waves)
+  for (int p = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(threadIdx.x >> 6); p < cnt * 16; p += waves)
   {
-    const int band = p / cnt, e = heavyList[p - band * cnt];
+    const int band = p / cnt, e = __builtin_amdgcn_readfirstlane(heavyList[p - band * cnt]);
     if (band > (e >> 27)) continue;
     const vvcgpu_if_desc d = descs[e & ((1 << 27) - 1)];
     const int br = if_filter_band_rows(d.w, d.h), r0 = band * br;

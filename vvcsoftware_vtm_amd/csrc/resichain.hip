@@ -1087,6 +1087,7 @@ __global__ __launch_bounds__(256) void rc_generic_kernel(const Pel* __restrict__
 }
 
 // ---------------------------------------------------------------------------------------------------
+// (multiplies: 24-bit, full rate -- operands are at most 18-bit intermediates and 8-bit matrix entries; the 32-bit v_mul_lo_u32 is a quarter-rate instruction)
 // 4 x 4 and 8 x 8: lane groups of S lanes per TU, G = 64 / S TUs per wave.  Forward: lane = row (stage 1), transposed through LDS, lane = column
 // (stage 2, quantiser, de-quantiser, vertical inverse stage), transposed back, lane = row (horizontal inverse stage + reconstruction: the
 // prediction row is still in the lane's registers).
@@ -1123,7 +1124,7 @@ __device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs,
     {
       int sum = 0;
 #pragma unroll
-      for (int kk = 0; kk < S; kk++) sum += x[kk] * Th[j * S + kk];
+      for (int kk = 0; kk < S; kk++) sum += __mul24(x[kk], Th[j * S + kk]);
       tt[j * (S + 1) + li] = (sum + (1 << (s1 - 1))) >> s1;
     }
   }
@@ -1139,7 +1140,7 @@ __device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs,
     {
       int sum = 0;
 #pragma unroll
-      for (int r = 0; r < S; r++) sum += t[r] * Tv[j * S + r];
+      for (int r = 0; r < S; r++) sum += __mul24(t[r], Tv[j * S + r]);
       cf[j] = (sum + (1 << (s2 - 1))) >> s2;
     }
   }
@@ -1190,7 +1191,7 @@ __device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs,
     {
       int acc = 0;
 #pragma unroll
-      for (int kk = 0; kk < S; kk++) acc += cq[kk] * TvT[r * S + kk];
+      for (int kk = 0; kk < S; kk++) acc += __mul24(cq[kk], TvT[r * S + kk]);
       tt[r * (S + 1) + li] = clip3(-(1 << 15), (1 << 15) - 1, (acc + 256) >> 9);
     }
   }
@@ -1207,7 +1208,7 @@ __device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs,
     {
       int acc = 0;
 #pragma unroll
-      for (int i = 0; i < S; i++) acc += y[i] * ThT[x * S + i];
+      for (int i = 0; i < S; i++) acc += __mul24(y[i], ThT[x * S + i]);
       const int resi = (short)clip3(-(1 << 15), (1 << 15) - 1, (acc + (1 << (s2i - 1))) >> s2i);
       out[x] = (short)clip3(clpMin, clpMax, (int)p[x] + resi);
     }
@@ -1253,7 +1254,7 @@ __device__ __forceinline__ void rc_rect_group(const RcDesc* __restrict__ descs, 
     {
       int sum = 0;
 #pragma unroll
-      for (int kk = 0; kk < W; kk++) sum += x[kk] * Th[j * W + kk];
+      for (int kk = 0; kk < W; kk++) sum += __mul24(x[kk], Th[j * W + kk]);
       tt[j * (L + 1) + li] = (sum + (1 << (s1 - 1))) >> s1;
     }
   }
@@ -1269,7 +1270,7 @@ __device__ __forceinline__ void rc_rect_group(const RcDesc* __restrict__ descs, 
     {
       int sum = 0;
 #pragma unroll
-      for (int r = 0; r < H; r++) sum += t[r] * Tv[j * H + r];
+      for (int r = 0; r < H; r++) sum += __mul24(t[r], Tv[j * H + r]);
       cf[j] = (sum + (1 << (s2 - 1))) >> s2;
     }
   }
@@ -1320,7 +1321,7 @@ __device__ __forceinline__ void rc_rect_group(const RcDesc* __restrict__ descs, 
     {
       int acc = 0;
 #pragma unroll
-      for (int kk = 0; kk < H; kk++) acc += cq[kk] * TvT[r * H + kk];
+      for (int kk = 0; kk < H; kk++) acc += __mul24(cq[kk], TvT[r * H + kk]);
       tt[r * (L + 1) + li] = clip3(-(1 << 15), (1 << 15) - 1, (acc + 256) >> 9);
     }
   }
@@ -1338,7 +1339,7 @@ __device__ __forceinline__ void rc_rect_group(const RcDesc* __restrict__ descs, 
     {
       int acc = 0;
 #pragma unroll
-      for (int i = 0; i < W; i++) acc += y[i] * ThT[x * W + i];
+      for (int i = 0; i < W; i++) acc += __mul24(y[i], ThT[x * W + i]);
       const int resi = (short)clip3(-(1 << 15), (1 << 15) - 1, (acc + (1 << (s2i - 1))) >> s2i);
       out[x] = (short)clip3(clpMin, clpMax, (int)p[x] + resi);
     }
@@ -1387,7 +1388,7 @@ __global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict_
   __shared__ __align__(16) _Float16 tab[RC_TAB_HALVES];
   __shared__ RcSmallTab tabs;
   __shared__ int tmpAll[4][8 * 8 * 9];                        // per wave: transposes of the lane-group forms / the TU list of a packed tile
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too: list entries and descriptors of single-TU items arrive through the scalar cache
   // slots (four wave items of one entry) in the order below: the longest items first, so that the short ones fill the machine while they run.
   // 8x8 / 8x4 / 4x8 / 4x4 stay with the lane groups: as packed tiles (exact as well) they are slower (8M samples: 8x8 0.164 vs 0.143 ms, 4x4 0.175
   // vs 0.142) -- a lane of a tile touches four 8-byte row pieces of its TU, a lane of a group one whole row
@@ -1424,7 +1425,7 @@ __global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict_
     bool done = true;
     int ti = 0;
 #define RC_MF(K, W_, H_)                                                                                                                      \
-    case K: if (item < cnt[K]) { ti = lists[(size_t)ordCls[K] * n + item];                                                                    \
+    case K: if (item < cnt[K]) { ti = __builtin_amdgcn_readfirstlane(lists[(size_t)ordCls[K] * n + item]);                                    \
         done = rc_tu_mfma<W_, H_>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane); } break;
 #define RC_PK(K, W_, H_)                                                                                                                      \
     case K: if (item < items[K]) rc_tile_packed<W_, H_>(descs, lists + (size_t)ordCls[K] * n, cnt[K], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, \

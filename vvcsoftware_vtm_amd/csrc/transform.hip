@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, 3) void tr_fwd_large_kernel(const Pel* __restr
 {
   __shared__ __align__(16) short tab[LG_TAB];
   __shared__ int tmpAll[4][32 * (MAXN + 1)];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cnt = list[0];
   if ((int)blockIdx.x * 4 >= cnt) return;
   lg_load(tab, d_tr32, tid);
@@ -451,7 +451,7 @@ __global__ __launch_bounds__(256, 3) void tr_fwd_large_kernel(const Pel* __restr
   int* tmpL = tmpAll[wave];
   for (int k = blockIdx.x * 4 + wave; k < cnt; k += gridDim.x * 4)
   {
-    const vvcgpu_tr_desc d = descs[list[1 + k]];
+    const vvcgpu_tr_desc d = descs[__builtin_amdgcn_readfirstlane(list[1 + k])];
     const Pel* resi = resiBase + d.resi_off;
     TCoeff* coeff = coeffBase + d.coeff_off;
     switch (d.w)
@@ -538,7 +538,7 @@ __global__ __launch_bounds__(256, 3) void tr_inv_large_kernel(const TCoeff* __re
 {
   __shared__ __align__(16) short tabT[LG_TAB];
   __shared__ int tmpAll[4][32 * (MAXN + 1)];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int cnt = list[0];
   if ((int)blockIdx.x * 4 >= cnt) return;
   lg_load(tabT, d_tr32t, tid);
@@ -546,7 +546,7 @@ __global__ __launch_bounds__(256, 3) void tr_inv_large_kernel(const TCoeff* __re
   int* tmpL = tmpAll[wave];
   for (int k = blockIdx.x * 4 + wave; k < cnt; k += gridDim.x * 4)
   {
-    const vvcgpu_tr_desc d = descs[list[1 + k]];
+    const vvcgpu_tr_desc d = descs[__builtin_amdgcn_readfirstlane(list[1 + k])];
     const TCoeff* coeff = coeffBase + d.coeff_off;
     Pel* resi = resiBase + d.resi_off;
     switch (d.w)
@@ -672,9 +672,9 @@ __global__ __launch_bounds__(256, 2) void tr_fwd_mfma_kernel(const Pel* __restri
   if ((int)blockIdx.x * 4 >= cnt) return;
   rc_load_all_tables(tab, image, tid);
   __syncthreads();
-  for (int k = blockIdx.x * 4 + (tid >> 6); k < cnt; k += gridDim.x * 4)
+  for (int k = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(tid >> 6); k < cnt; k += gridDim.x * 4)   // wave-uniform for the compiler: list entry and descriptor through the scalar cache
   {
-    const int ti = mfmaList[k];
+    const int ti = __builtin_amdgcn_readfirstlane(mfmaList[k]);
     const vvcgpu_tr_desc d = descs[ti];
     const Pel* resi = resiBase + d.resi_off;
     TCoeff* coeff = coeffBase + d.coeff_off;
@@ -696,9 +696,9 @@ __global__ __launch_bounds__(256, 2) void tr_inv_mfma_kernel(const TCoeff* __res
   if ((int)blockIdx.x * 4 >= cnt) return;
   rc_load_all_tables(tab, image, tid);
   __syncthreads();
-  for (int k = blockIdx.x * 4 + (tid >> 6); k < cnt; k += gridDim.x * 4)
+  for (int k = blockIdx.x * 4 + __builtin_amdgcn_readfirstlane(tid >> 6); k < cnt; k += gridDim.x * 4)   // wave-uniform for the compiler: list entry and descriptor through the scalar cache
   {
-    const int ti = mfmaList[k];
+    const int ti = __builtin_amdgcn_readfirstlane(mfmaList[k]);
     const vvcgpu_tr_desc d = descs[ti];
     const TCoeff* coeff = coeffBase + d.coeff_off;
     Pel* resi = resiBase + d.resi_off;
@@ -2506,7 +2506,7 @@ int vvcgpu_tr_fwd_batch(const vvc_pel* resi_base, vvc_coef* coeff_base, const vv
   const int nb = cdiv(n, SM_DESCS), nl = cdiv(n, 4);
   hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 1024)), dim3(1024), 0, st, descs, n, ws, tr_use_mfma(), smCnt, smLists, nextCnt);
   hipLaunchKernelGGL(tr_fwd_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, resi_base, coeff_base, descs, n, bit_depth, tr_use_mfma(), smCnt, smLists);
-  hipLaunchKernelGGL(tr_fwd_mfma_kernel, dim3(nl < 512 ? nl : 512), dim3(256), 0, st, resi_base, coeff_base, descs, ws, ws + 2 + n, ws + 1, bit_depth, image);
+  hipLaunchKernelGGL(tr_fwd_mfma_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, resi_base, coeff_base, descs, ws, ws + 2 + n, ws + 1, bit_depth, image);
   hipLaunchKernelGGL(tr_fwd_large_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, resi_base, coeff_base, descs, ws + 1, bit_depth);
   if (ordered) VVC_LAUNCH_CHECK_COUNTERS(st);
   VVC_LAUNCH_CHECK();
@@ -2543,7 +2543,7 @@ int vvcgpu_tr_inv_batch(const vvc_coef* coeff_base, vvc_pel* resi_base, const vv
   const int nb = cdiv(n, SM_DESCS), nl = cdiv(n, 4);
   hipLaunchKernelGGL(tr_collect_large_kernel, dim3(cdiv(n, 1024)), dim3(1024), 0, st, descs, n, ws, tr_use_mfma(), smCnt, smLists, nextCnt);
   hipLaunchKernelGGL(tr_inv_small_kernel, dim3(nb < g_smallGrid ? nb : g_smallGrid), dim3(256), 0, st, coeff_base, resi_base, descs, n, bit_depth, tr_use_mfma(), smCnt, smLists);
-  hipLaunchKernelGGL(tr_inv_mfma_kernel, dim3(nl < 512 ? nl : 512), dim3(256), 0, st, coeff_base, resi_base, descs, ws, ws + 2 + n, ws + 1, bit_depth, image);
+  hipLaunchKernelGGL(tr_inv_mfma_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, coeff_base, resi_base, descs, ws, ws + 2 + n, ws + 1, bit_depth, image);
   hipLaunchKernelGGL(tr_inv_large_kernel, dim3(nl < 768 ? nl : 768), dim3(256), 0, st, coeff_base, resi_base, descs, ws + 1, bit_depth);
   if (ordered) VVC_LAUNCH_CHECK_COUNTERS(st);
   VVC_LAUNCH_CHECK();
