@@ -361,9 +361,9 @@ int vvcgpu_dequant_tr_inv_batch(const vvc_coef* level_base, vvc_pel* resi_base, 
  * Quant::quant's uiAbsSum) and the reconstructed samples are written once.  Bit-exact with that sequence (tests/test_gpu_resichain.py).
  * Preconditions: org / pred samples within the bit depth (|residual| <= 1023), tr_hor / tr_ver in 0..2 (transform skip and RDPCM TUs go
  * through the separate entry points), qp as vvcgpu_quant_desc.  TUs with both sides in 16 / 32 / 64 run their four 1-D stages on the matrix cores
- * (v_mfma_f32_16x16x32_f16 on exact integer limbs), one wave per TU; 16x8 / 8x16 / 16x4 / 4x16 / 32x8 / 8x32 / 32x4 / 4x32 as well, two or four
- * TUs packed into one (double) 16x16 tile with block-diagonal short stages; 8x8 / 8x4 / 4x8 / 4x4 in lane groups; every other shape (a 64-point
- * side with a 4- / 8-point one, 2-wide chroma) on a generic wave-per-TU path.  Results do not depend on the path.                                */
+ * (v_mfma_f32_16x16x32_f16 on exact integer limbs), one wave per TU; a 16- / 32- / 64-point side with an 8- or 4-point one as well, two or four
+ * TUs packed into one multi-tile with block-diagonal short stages; 8x8 / 8x4 / 4x8 / 4x4 in lane groups; 2-wide (chroma) TUs on a generic
+ * wave-per-TU path.  Results do not depend on the path.                                                                                      */
 typedef struct vvcgpu_resi_chain_desc {
   int64_t org_off, pred_off, rec_off;   /* elements from org_base / pred_base / rec_base (Pel) */
   int64_t level_off;                    /* elements from level_base (TCoeff) */

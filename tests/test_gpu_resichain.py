@@ -117,17 +117,17 @@ def test_resi_chain_rectangles_and_chroma_shapes():
 
 @pytest.mark.parametrize("bd,content", [(10, "smooth"), (8, "smooth"), (10, "extreme"), (10, "uniform")])
 def test_resi_chain_packed_tiles(bd, content):
-    """16x8 / 8x16 / 16x4 / 4x16 (and 32x8 / 8x32 / 32x4 / 4x32 in a double tile): two or four TUs share one 16x16 matrix-core tile (rc_tile_packed*),
+    """16x8 / 8x16 / 16x4 / 4x16 (and 32x8 .. 4x32, 64x8 .. 4x64 in multi-tiles, the 64-point side with its zero-out): two or four TUs share one 16x16 matrix-core tile (rc_tile_packed*),
     every TU with its own transform pair, QP, slice type
     and sign-hiding flag; class counts that leave the last tile part-filled; a few TUs whose residual leaves +-1023 sit in tiles with ordinary
     ones and must reach the generic path alone"""
     rng = np.random.default_rng(bd * 11 + len(content))
-    W, H = 640, 128
+    W, H = 896, 128
     org = cases.rand_plane(rng, H, W, bd, content)
     pred = cases.rand_plane(rng, H, W, bd, "smooth" if content != "extreme" else "extreme")
     if content == "smooth":
         pred = np.clip(org + rng.integers(-9, 10, org.shape), 0, (1 << bd) - 1).astype(np.int16)
-    tus = tile(W, H, [(16, 8), (8, 16), (16, 4), (4, 16), (16, 16), (8, 8), (32, 8), (8, 32), (32, 4), (4, 32)], rng, [22, 27, 32, 37, 45], bd)
+    tus = tile(W, H, [(16, 8), (8, 16), (16, 4), (4, 16), (16, 16), (8, 8), (32, 8), (8, 32), (32, 4), (4, 32), (64, 8), (8, 64), (64, 4), (4, 64)], rng, [22, 27, 32, 37, 45], bd)
     keep = rng.random(len(tus)) > 0.07                       # odd counts per class, tiles whose TUs are not neighbours in the picture
     tus = [t for t, k in zip(tus, keep) if k]
     order = rng.permutation(len(tus))

@@ -32,7 +32,7 @@ __device__ __forceinline__ int ilog2(int v) { return 31 - __clz(v); }
 // ---- work lists (device): hdr[0 .. RC_NCLS) = counts of the classes, hdr[RC_FB] = count of the fall-back list
 constexpr int RC_HDR = VVC_CTR_INTS;
 enum { RC_C64 = 0, RC_C32, RC_C16, RC_C8, RC_C4, RC_CGEN, RC_R6432, RC_R3264, RC_R6416, RC_R1664, RC_R3216, RC_R1632, RC_R84, RC_R48,
-       RC_P168, RC_P816, RC_P164, RC_P416, RC_P328, RC_P832, RC_P324, RC_P432, RC_NCLS };   // RC_P*: packed tiles (rc_tile_packed*)
+       RC_P168, RC_P816, RC_P164, RC_P416, RC_P328, RC_P832, RC_P324, RC_P432, RC_P648, RC_P864, RC_P644, RC_P464, RC_NCLS };   // RC_P*: packed tiles (rc_tile_packed*)
 constexpr int RC_FB = RC_NCLS;
 static_assert(RC_FB < RC_HDR, "the header is one counter set of vvcgpu_counters");
 
@@ -48,13 +48,14 @@ __device__ __forceinline__ int rc_class(const RcDesc& d, bool packed)
     if (w == 4) return RC_C4;
     return RC_CGEN;
   }
-  if (w == 64) return h == 32 ? RC_R6432 : h == 16 ? RC_R6416 : RC_CGEN;
+  if (w == 64) return h == 32 ? RC_R6432 : h == 16 ? RC_R6416 : h == 8 ? (packed ? RC_P648 : RC_CGEN) : h == 4 ? (packed ? RC_P644 : RC_CGEN) : RC_CGEN;
   if (w == 32) return h == 64 ? RC_R3264 : h == 16 ? RC_R3216 : h == 8 ? (packed ? RC_P328 : RC_CGEN) : h == 4 ? (packed ? RC_P324 : RC_CGEN) : RC_CGEN;
   if (w == 16) return h == 64 ? RC_R1664 : h == 32 ? RC_R1632 : h == 8 ? (packed ? RC_P168 : RC_CGEN) : h == 4 ? (packed ? RC_P164 : RC_CGEN) : RC_CGEN;
   if (w == 8 && h == 4) return RC_R84;
   if (w == 4 && h == 8) return RC_R48;
   if (h == 16 && packed) return w == 8 ? RC_P816 : w == 4 ? RC_P416 : RC_CGEN;
   if (h == 32 && packed) return w == 8 ? RC_P832 : w == 4 ? RC_P432 : RC_CGEN;
+  if (h == 64 && packed) return w == 8 ? RC_P864 : w == 4 ? RC_P464 : RC_CGEN;
   return RC_CGEN;
 }
 
@@ -568,18 +569,19 @@ __device__ __noinline__ void rc_tile_packed(const RcDesc* __restrict__ descs, co
   RC_WAVE_SYNC();                                                         // info is rewritten by the wave's next item
 }
 
-// Packed tiles with a 32-point side: 32 x 8 / 32 x 4 (16 / H TUs one above the other in a 16-row x 32-column double tile) and 8 x 32 / 4 x 32
-// (16 / W TUs side by side in a 32-row x 16-column double tile).  The 32-point stages are the 16x16x32 products of mfma_tr.h (operand of a
+// Packed tiles with a 32- or 64-point side: 32 x 8 / 32 x 4 / 64 x 8 / 64 x 4 (16 / H TUs one above the other in a 16-row x W-column multi-tile) and 8 x 32 / 4 x 32 /
+// 8 x 64 / 4 x 64 (16 / W TUs side by side in an H-row x 16-column multi-tile); a 64-point side keeps its 32 low frequencies (zero-out) and is always DCT-II.  The 32-point stages are the 16x16x32 products of mfma_tr.h (operand of a
 // result tile in its register k order), the short side is block-diagonal as above; only the 32-point stages depend on the other operand's
 // sub-TU and run in passes.
-template <int H>
-__device__ __noinline__ void rc_tile_packed_w32(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
+template <int W, int H>
+__device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
                                                 const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                 TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                                 const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
                                                 int* __restrict__ fbCount, int* __restrict__ fbList, int* info, int lane)
 {
-  constexpr int W = 32, NY = 16 / H, G = NY, LH = H == 4 ? 2 : 3, LW = 5;
+  constexpr int NY = 16 / H, G = NY, LH = H == 4 ? 2 : 3, LW = W == 32 ? 5 : 6, XS = W / 32, CT = W / 16, PITCH = W + 8;
+  constexpr int NP = W == 64 ? 1 : NY;                 // passes of the long stages: a 64-point side is DCT-II for every TU (no type to tell apart)
   const int c = lane & 15, g = lane >> 4;
   const h4 zero4 = { (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0 };
   const h8 zero8 = { (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0 };
@@ -594,32 +596,45 @@ __device__ __noinline__ void rc_tile_packed_w32(const RcDesc* __restrict__ descs
   auto laneMask = [&](int sy) -> unsigned long long { const unsigned long long cm = ((1ull << H) - 1ull) << (sy * H); return cm | (cm << 16) | (cm << 32) | (cm << 48); };
   const RcDesc& dL = descs[tiL >= 0 ? tiL : ti0];
   const int rowL = c & (H - 1);
-  h8 xa = zero8;
+  h8 xa[XS];
+#pragma unroll
+  for (int sk = 0; sk < XS; sk++) xa[sk] = zero8;
   bool inRange = true;
   if (tiL >= 0)
   {
-    const pel8 o = *reinterpret_cast<const pel8*>(orgBase + dL.org_off + (size_t)rowL * dL.org_stride + 8 * g);
-    const pel8 pp = *reinterpret_cast<const pel8*>(predBase + dL.pred_off + (size_t)rowL * dL.pred_stride + 8 * g);
 #pragma unroll
-    for (int j = 0; j < 8; j++) { const int v = (int)o[j] - (int)pp[j]; inRange = inRange && v >= -1023 && v <= 1023; xa[j] = (_Float16)(short)v; }
+    for (int sk = 0; sk < XS; sk++)
+    {
+      const pel8 o = *reinterpret_cast<const pel8*>(orgBase + dL.org_off + (size_t)rowL * dL.org_stride + 32 * sk + 8 * g);
+      const pel8 pp = *reinterpret_cast<const pel8*>(predBase + dL.pred_off + (size_t)rowL * dL.pred_stride + 32 * sk + 8 * g);
+#pragma unroll
+      for (int j = 0; j < 8; j++) { const int v = (int)o[j] - (int)pp[j]; inRange = inRange && v >= -1023 && v <= 1023; xa[sk][j] = (_Float16)(short)v; }
+    }
   }
   const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!inRange);
   const bool okL = tiL >= 0 && (badLanes & laneMask(syL)) == 0ull, okQ = tiQ >= 0 && (badLanes & laneMask(syQ)) == 0ull;
   if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMask(lane)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
-  if (!okL) xa = zero8;
+  if (!okL) {
+#pragma unroll
+    for (int sk = 0; sk < XS; sk++) xa[sk] = zero8;
+  }
   const int s1 = LW + bd + 6 - 15 + 2, s2 = LH + 6 + 2;
   // ---- F1 (32-point, one pass per TU: the type belongs to the row of X)
   int t1[2][4];
   {
     f4 m1[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
 #pragma unroll
-    for (int p = 0; p < NY; p++)
+    for (int p = 0; p < NP; p++)
     {
-      const h8 a = syL == p ? xa : zero8;
-      const _Float16* Th = tab + rc_tab_off(info[16 + p] & 3, 32, 0);
+      const _Float16* Th = tab + rc_tab_off(W == 64 ? 0 : info[16 + p] & 3, W, 0);
 #pragma unroll
-      for (int jt = 0; jt < 2; jt++)
-        m1[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, *reinterpret_cast<const h8*>(Th + (16 * jt + c) * 40 + 8 * g), m1[jt], 0, 0, 0);
+      for (int sk = 0; sk < XS; sk++)
+      {
+        const h8 a = (NP == 1 || syL == p) ? xa[sk] : zero8;
+#pragma unroll
+        for (int jt = 0; jt < 2; jt++)
+          m1[jt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, *reinterpret_cast<const h8*>(Th + (16 * jt + c) * PITCH + 32 * sk + 8 * g), m1[jt], 0, 0, 0);
+      }
     }
 #pragma unroll
     for (int jt = 0; jt < 2; jt++)
@@ -668,6 +683,11 @@ __device__ __noinline__ void rc_tile_packed_w32(const RcDesc* __restrict__ descs
     {
 #pragma unroll
       for (int r = 0; r < 4; r++) level[(y0 + r) * W + 16 * jt + c] = lv[jt][r];
+      if (W == 64)                                                        // zero-out region: horizontal frequencies 32 .. 63 of the lane's four rows
+      {
+#pragma unroll
+        for (int r = 0; r < 4; r++) level[(y0 + r) * W + 32 + 16 * jt + c] = 0;
+      }
     }
   }
   // ---- I1 (block-diagonal H-point; the type belongs to the column r = c of the matrix operand)
@@ -690,16 +710,18 @@ __device__ __noinline__ void rc_tile_packed_w32(const RcDesc* __restrict__ descs
   {
     h8 bh[1], bl[1];
     rc_tile_frags<32>(bh, bl, y1);
-    f4 hi[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } }, lo[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
+    f4 hi[CT], lo[CT];
 #pragma unroll
-    for (int p = 0; p < NY; p++)
+    for (int xt = 0; xt < CT; xt++) { hi[xt] = f4{ 0.f, 0.f, 0.f, 0.f }; lo[xt] = f4{ 0.f, 0.f, 0.f, 0.f }; }
+#pragma unroll
+    for (int p = 0; p < NP; p++)
     {
-      const bool mine = syL == p;
-      const _Float16* ThT = tab + rc_tab_off(info[16 + p] & 3, 32, 1);
+      const bool mine = NP == 1 || syL == p;
+      const _Float16* ThT = tab + rc_tab_off(W == 64 ? 0 : info[16 + p] & 3, W, 1);
 #pragma unroll
-      for (int xt = 0; xt < 2; xt++)
+      for (int xt = 0; xt < CT; xt++)
       {
-        const h8 a = rc_mat_frag32(ThT, 40, 16 * xt + c, 0, g);
+        const h8 a = rc_mat_frag32(ThT, PITCH, 16 * xt + c, 0, g);           // the kept frequencies i < 32 of row x
         hi[xt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, mine ? bh[0] : zero8, hi[xt], 0, 0, 0);
         lo[xt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, mine ? bl[0] : zero8, lo[xt], 0, 0, 0);
       }
@@ -710,7 +732,7 @@ __device__ __noinline__ void rc_tile_packed_w32(const RcDesc* __restrict__ descs
       const Pel* pr = predBase + dL.pred_off + (size_t)rowL * dL.pred_stride;
       Pel* rec = recBase + dL.rec_off + (size_t)rowL * dL.rec_stride;
 #pragma unroll
-      for (int xt = 0; xt < 2; xt++)                                      // residual of tile row c, columns 16 xt + 4 g ..
+      for (int xt = 0; xt < CT; xt++)                                     // residual of tile row c, columns 16 xt + 4 g ..
       {
         const pel4 pv = *reinterpret_cast<const pel4*>(pr + 16 * xt + 4 * g);
         pel4 out;
@@ -727,14 +749,15 @@ __device__ __noinline__ void rc_tile_packed_w32(const RcDesc* __restrict__ descs
   RC_WAVE_SYNC();
 }
 
-template <int W>
-__device__ __noinline__ void rc_tile_packed_h32(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
+template <int W, int H>
+__device__ __noinline__ void rc_tile_packed_hl(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
                                                 const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                 TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                                 const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
                                                 int* __restrict__ fbCount, int* __restrict__ fbList, int* info, int lane)
 {
-  constexpr int H = 32, NX = 16 / W, G = NX, LW = W == 4 ? 2 : 3, LH = 5;
+  constexpr int NX = 16 / W, G = NX, LW = W == 4 ? 2 : 3, LH = H == 32 ? 5 : 6, RT = H / 16, KS = H / 32, PITCH = H + 8;
+  constexpr int NP = H == 64 ? 1 : NX;                 // passes of the long stages: a 64-point side is DCT-II for every TU
   const int c = lane & 15, g = lane >> 4;
   const h4 zero4 = { (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0 };
   const h8 zero8 = { (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0, (_Float16)0 };
@@ -755,13 +778,15 @@ __device__ __noinline__ void rc_tile_packed_h32(const RcDesc* __restrict__ descs
   };
   const RcDesc& dL = descs[tiL >= 0 ? tiL : ti0];
   const int colL = (4 * g) & (W - 1);
-  pel4 pv[2] = { { 0, 0, 0, 0 }, { 0, 0, 0, 0 } };
-  h4 xa[2] = { zero4, zero4 };
+  pel4 pv[RT];
+  h4 xa[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) { pv[rt] = pel4{ 0, 0, 0, 0 }; xa[rt] = zero4; }
   bool inRange = true;
   if (tiL >= 0)
   {
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++)
+    for (int rt = 0; rt < RT; rt++)
     {
       const pel4 o = *reinterpret_cast<const pel4*>(orgBase + dL.org_off + (size_t)(16 * rt + c) * dL.org_stride + colL);
       pv[rt] = *reinterpret_cast<const pel4*>(predBase + dL.pred_off + (size_t)(16 * rt + c) * dL.pred_stride + colL);
@@ -772,15 +797,18 @@ __device__ __noinline__ void rc_tile_packed_h32(const RcDesc* __restrict__ descs
   const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!inRange);
   const bool okL = tiL >= 0 && (badLanes & laneMask(sxL)) == 0ull, okQ = tiQ >= 0 && (badLanes & laneMask(sxQ)) == 0ull;
   if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMask(lane)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
-  if (!okL) { xa[0] = zero4; xa[1] = zero4; }
+  if (!okL) {
+#pragma unroll
+    for (int rt = 0; rt < RT; rt++) xa[rt] = zero4;
+  }
   const int s1 = LW + bd + 6 - 15 + 2, s2 = LH + 6 + 2;
   const bool diagH = sxQ == sxL;
   // ---- F1 (block-diagonal W-point; the type belongs to the column j = c of the matrix operand)
-  int t1[2][4];
+  int t1[RT][4];
   {
     const h4 b = diagH ? rc_frag4(tab, info[16 + sxQ] & 3, W, 0, c & (W - 1), colL) : zero4;
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++)
+    for (int rt = 0; rt < RT; rt++)
     {
       const f4 m1 = __builtin_amdgcn_mfma_f32_16x16x16f16(xa[rt], b, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
 #pragma unroll
@@ -790,21 +818,23 @@ __device__ __noinline__ void rc_tile_packed_h32(const RcDesc* __restrict__ descs
   // ---- F2 (32-point over the rows, operand in result-tile k order; the type belongs to the column j1 = c of M1: one pass per TU)
   int cf[2][4];
   {
-    h8 bh[1], bl[1];
-    rc_tile_frags<32>(bh, bl, t1);
+    h8 bh[KS], bl[KS];
+    rc_tile_frags<H>(bh, bl, t1);
     f4 hi[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } }, lo[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
 #pragma unroll
-    for (int qq = 0; qq < NX; qq++)
+    for (int qq = 0; qq < NP; qq++)
     {
-      const bool mine = sxQ == qq;
-      const _Float16* Tv = tab + rc_tab_off((info[16 + qq] >> 2) & 3, 32, 0);
+      const bool mine = NP == 1 || sxQ == qq;
+      const _Float16* Tv = tab + rc_tab_off(H == 64 ? 0 : (info[16 + qq] >> 2) & 3, H, 0);
 #pragma unroll
-      for (int it = 0; it < 2; it++)
-      {
-        const h8 a = rc_mat_frag32(Tv, 40, 16 * it + c, 0, g);
-        hi[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, mine ? bh[0] : zero8, hi[it], 0, 0, 0);
-        lo[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, mine ? bl[0] : zero8, lo[it], 0, 0, 0);
-      }
+      for (int it = 0; it < 2; it++)                                      // the kept vertical frequencies: 32
+#pragma unroll
+        for (int sk = 0; sk < KS; sk++)
+        {
+          const h8 a = rc_mat_frag32(Tv, PITCH, 16 * it + c, sk, g);
+          hi[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, mine ? bh[sk] : zero8, hi[it], 0, 0, 0);
+          lo[it] = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, mine ? bl[sk] : zero8, lo[it], 0, 0, 0);
+        }
     }
 #pragma unroll
     for (int it = 0; it < 2; it++)
@@ -839,10 +869,15 @@ __device__ __noinline__ void rc_tile_packed_h32(const RcDesc* __restrict__ descs
     {
 #pragma unroll
       for (int r = 0; r < 4; r++) level[(16 * it + 4 * g + r) * W + xq] = lv[it][r];
+      if (H == 64)                                                        // zero-out region: vertical frequencies 32 .. 63 of the lane's column
+      {
+#pragma unroll
+        for (int r = 0; r < 4; r++) level[(32 + 16 * it + 4 * g + r) * W + xq] = 0;
+      }
     }
   }
   // ---- I1 (32-point over the vertical frequency, A = Cq^T in result-tile k order; the type belongs to A's row i = c: one pass per TU)
-  int y1[2][4];
+  int y1[RT][4];
   {
     int cq[2][4];
 #pragma unroll
@@ -851,22 +886,24 @@ __device__ __noinline__ void rc_tile_packed_h32(const RcDesc* __restrict__ descs
       for (int r = 0; r < 4; r++) cq[it][r] = rc_dequant_one(q, lv[it][r]);
     h8 ah[1], al[1];
     rc_tile_frags<32>(ah, al, cq);
-    f4 hi[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } }, lo[2] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
+    f4 hi[RT], lo[RT];
 #pragma unroll
-    for (int qq = 0; qq < NX; qq++)
+    for (int rt = 0; rt < RT; rt++) { hi[rt] = f4{ 0.f, 0.f, 0.f, 0.f }; lo[rt] = f4{ 0.f, 0.f, 0.f, 0.f }; }
+#pragma unroll
+    for (int qq = 0; qq < NP; qq++)
     {
-      const bool mine = sxQ == qq;
-      const _Float16* TvT = tab + rc_tab_off((info[16 + qq] >> 2) & 3, 32, 1);
+      const bool mine = NP == 1 || sxQ == qq;
+      const _Float16* TvT = tab + rc_tab_off(H == 64 ? 0 : (info[16 + qq] >> 2) & 3, H, 1);
 #pragma unroll
-      for (int rt = 0; rt < 2; rt++)
+      for (int rt = 0; rt < RT; rt++)
       {
-        const h8 b = rc_mat_frag32(TvT, 40, 16 * rt + c, 0, g);
+        const h8 b = rc_mat_frag32(TvT, PITCH, 16 * rt + c, 0, g);          // the kept frequencies k < 32 of row r
         hi[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(mine ? ah[0] : zero8, b, hi[rt], 0, 0, 0);
         lo[rt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(mine ? al[0] : zero8, b, lo[rt], 0, 0, 0);
       }
     }
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++)
+    for (int rt = 0; rt < RT; rt++)
 #pragma unroll
       for (int r = 0; r < 4; r++) y1[rt][r] = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[rt][r]) << 8) + (int)lo[rt][r] + 256) >> 9);   // Y1T[frequency 4 g + r][row 16 rt + c]
   }
@@ -875,7 +912,7 @@ __device__ __noinline__ void rc_tile_packed_h32(const RcDesc* __restrict__ descs
     const h4 a = diagH ? rc_frag4(tab, info[16 + sxQ] & 3, W, 1, c & (W - 1), colL) : zero4;
     const int s2i = (6 + 15 - 1) - bd + 2;
 #pragma unroll
-    for (int rt = 0; rt < 2; rt++)
+    for (int rt = 0; rt < RT; rt++)
     {
       const f4 hi = __builtin_amdgcn_mfma_f32_16x16x16f16(a, rc_limb_h4(y1[rt], true), f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
       const f4 lo = __builtin_amdgcn_mfma_f32_16x16x16f16(a, rc_limb_h4(y1[rt], false), f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
@@ -1392,10 +1429,11 @@ __global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict_
   // slots (four wave items of one entry) in the order below: the longest items first, so that the short ones fill the machine while they run.
   // 8x8 / 8x4 / 4x8 / 4x4 stay with the lane groups: as packed tiles (exact as well) they are slower (8M samples: 8x8 0.164 vs 0.143 ms, 4x4 0.175
   // vs 0.142) -- a lane of a tile touches four 8-byte row pieces of its TU, a lane of a group one whole row
-  constexpr int NORD = 21;
+  constexpr int NORD = 25;
   constexpr int ordCls[NORD] = { RC_C64, RC_R6432, RC_R3264, RC_C32, RC_R6416, RC_R1664, RC_C8, RC_R3216, RC_R1632, RC_C16,
-                                 RC_P168, RC_P816, RC_P164, RC_P416, RC_C4, RC_R84, RC_R48, RC_P328, RC_P832, RC_P324, RC_P432 };
-  constexpr int ordG[NORD] = { 1, 1, 1, 1, 1, 1, 8, 1, 1, 1, 2, 2, 4, 4, 16, 8, 8, 2, 2, 4, 4 };   // TUs per wave item: lane groups 64 / S, packed tiles 256 (512) / (W H)
+                                 RC_P168, RC_P816, RC_P164, RC_P416, RC_C4, RC_R84, RC_R48, RC_P328, RC_P832, RC_P324, RC_P432,
+                                 RC_P648, RC_P864, RC_P644, RC_P464 };
+  constexpr int ordG[NORD] = { 1, 1, 1, 1, 1, 1, 8, 1, 1, 1, 2, 2, 4, 4, 16, 8, 8, 2, 2, 4, 4, 2, 2, 4, 4 };   // TUs per wave item: lane groups 64 / S, packed tiles: 16 / the short side
   int cnt[NORD], items[NORD], end[NORD];
   int total = 0;
 #pragma unroll
@@ -1441,9 +1479,10 @@ __global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict_
 #define RC_PK32(K, F)                                                                                                                         \
     case K: if (item < items[K]) F(descs, lists + (size_t)ordCls[K] * n, cnt[K], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,     \
                                    tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
-    RC_PK32(17, rc_tile_packed_w32<8>) RC_PK32(18, rc_tile_packed_h32<8>) RC_PK32(19, rc_tile_packed_w32<4>)
-    default: if (item < items[20]) rc_tile_packed_h32<4>(descs, lists + (size_t)RC_P432 * n, cnt[20], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,
-                                                         tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
+    RC_PK32(17, (rc_tile_packed_wl<32, 8>)) RC_PK32(18, (rc_tile_packed_hl<8, 32>)) RC_PK32(19, (rc_tile_packed_wl<32, 4>)) RC_PK32(20, (rc_tile_packed_hl<4, 32>))
+    RC_PK32(21, (rc_tile_packed_wl<64, 8>)) RC_PK32(22, (rc_tile_packed_hl<8, 64>)) RC_PK32(23, (rc_tile_packed_wl<64, 4>))
+    default: if (item < items[24]) rc_tile_packed_hl<4, 64>(descs, lists + (size_t)RC_P464 * n, cnt[24], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,
+                                                            tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
 #undef RC_PK32
     }
 #undef RC_MF
