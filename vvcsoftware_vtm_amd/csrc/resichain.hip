@@ -63,9 +63,13 @@ __device__ __forceinline__ int rc_class(const RcDesc& d, bool packed)
 // 50 us for a 4K picture's 138 k TUs.  Here a workgroup of 1024 threads walks a contiguous slice of the list twice: pass 1 counts per class in
 // LDS, ONE global atomic per class reserves the slice's range of every list, pass 2 writes the indices (LDS counters give the positions).
 constexpr int RC_CLS_WGS = 128;
-__global__ __launch_bounds__(1024) void rc_classify_kernel(const RcDesc* __restrict__ descs, int n, int* __restrict__ hdr, int* __restrict__ lists,
-                                                           unsigned* __restrict__ absSum, int* __restrict__ nextHdr, bool packed)
+// TR: the descriptors are vvcgpu_tr_desc (the plain transform entries through the chain's bodies, vvcgpu_tr_chain_launch): pass 0 also writes each one as
+// a chain descriptor into conv (residual plane = "original" and "reconstruction", coefficients = "levels"); transform skip goes to the generic class
+template <bool TR>
+__global__ __launch_bounds__(1024) void rc_classify_kernel(const void* __restrict__ descsRaw, int n, int* __restrict__ hdr, int* __restrict__ lists,
+                                                           unsigned* __restrict__ absSum, int* __restrict__ nextHdr, bool packed, RcDesc* __restrict__ conv)
 {
+  const RcDesc* descs = static_cast<const RcDesc*>(descsRaw);
   if (blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextHdr[threadIdx.x] = 0;         // the header of the NEXT call on this stream (vvcgpu_counters)
   __shared__ int cnt[RC_NCLS], base[RC_NCLS];
   const int tid = threadIdx.x, lane = tid & 63;
@@ -78,7 +82,20 @@ __global__ __launch_bounds__(1024) void rc_classify_kernel(const RcDesc* __restr
     {
       const int ti = t0 + tid;
       int cls = -1;
-      if (ti < hi)
+      if (ti < hi && TR)
+      {
+        const vvcgpu_tr_desc t = static_cast<const vvcgpu_tr_desc*>(descsRaw)[ti];
+        RcDesc d;
+        d.org_off = t.resi_off; d.pred_off = 0; d.rec_off = t.resi_off; d.level_off = t.coeff_off;
+        d.org_stride = t.resi_stride; d.pred_stride = 0; d.rec_stride = t.resi_stride;
+        d.w = t.w; d.h = t.h; d.tr_hor = t.tr_hor; d.tr_ver = t.tr_ver; d.intra_slice = 0; d.sign_hiding = 0; d.qp = 0; d.reserved[0] = 0; d.reserved[1] = 0;
+        if (pass == 0) conv[ti] = d;
+        const bool shape = d.w >= 2 && d.w <= 64 && d.h >= 2 && d.h <= 64 && (d.w & (d.w - 1)) == 0 && (d.h & (d.h - 1)) == 0;
+        const bool ok = shape && d.tr_hor >= 0 && d.tr_hor <= 2 && d.tr_ver >= 0 && d.tr_ver <= 2 && (d.w <= 32 || d.tr_hor == 0) && (d.h <= 32 || d.tr_ver == 0);
+        if (shape && d.tr_hor == 3) cls = RC_CGEN;                              // transform skip: element-wise, in the generic kernel
+        else if (ok) cls = rc_class(d, packed);
+      }
+      else if (ti < hi)
       {
         const int* f = reinterpret_cast<const int*>(descs + ti) + 11;          // bytes 44..51: w, h, tr_hor, tr_ver, intra_slice, sign_hiding
         const int wh = f[0], tt = f[1];
@@ -274,11 +291,18 @@ __global__ __launch_bounds__(256) void rc_build_tables_kernel(_Float16* __restri
 
 // One TU of W x H (W, H in {16, 32, 64}) on the matrix cores.  Returns false (nothing written) when a residual sample lies outside +-1023
 // (precondition violated: the caller's generic path takes the TU).
-template <int W, int H>
+// mode (workgroup-uniform; the plain transform entries run through the same bodies, vvcgpu_tr_chain_launch below): 0 = the chain; 1 = FORWARD
+// transform only: the "original" plane holds the residual, no prediction is read, the coefficients (unquantised, int32) go where the chain writes
+// levels, incl. the zero-out region; 2 = INVERSE transform only: the coefficients are read where the chain writes levels (16-bit values: a TU with
+// a larger one returns false / goes to the fall-back list), the residual goes where the chain writes the reconstruction, no prediction, no pixel clip.
+enum { RC_CHAIN = 0, RC_FWD = 1, RC_INV = 2 };
+template <int W, int H, int MODE>
 __device__ __forceinline__ bool rc_tu_mfma(const RcDesc& d, const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                            TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int ti, int bd, int clpMin, int clpMax,
                                            const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff, int lane)
 {
+  constexpr int mode = MODE;
+
   typedef MtShape<W, H> S;
   constexpr int LW = W == 16 ? 4 : W == 32 ? 5 : 6, LH = H == 16 ? 4 : H == 32 ? 5 : 6;
   const int c = lane & 15, g = lane >> 4;
@@ -288,108 +312,142 @@ __device__ __forceinline__ bool rc_tu_mfma(const RcDesc& d, const Pel* __restric
   const _Float16* ThT = tab + rc_tab_off(d.tr_hor, W, 1);
   const _Float16* Tv = tab + rc_tab_off(d.tr_ver, H, 0);
   const _Float16* TvT = tab + rc_tab_off(d.tr_ver, H, 1);
+  TCoeff* level = levelBase + d.level_off;
+  const int4v z = { 0, 0, 0, 0 };
+  int cq[S::JT][S::IT][4];                             // [column tile (i)][row tile (k)]: the inverse stages' input
 
-  // ---- residual fragments of stage F1 (A = X from memory, natural k order)
-  h8 x[S::RT][S::XS];
-  bool inRange = true;
-  if (W == 16)
+  if (mode != RC_INV)
   {
-#pragma unroll
-    for (int rt = 0; rt < S::RT; rt++)
+    // ---- residual fragments of stage F1 (A = X from memory, natural k order)
+    h8 x[S::RT][S::XS];
+    bool inRange = true;
+    if (W == 16)
     {
-      const pel4 o = *reinterpret_cast<const pel4*>(org + (size_t)(16 * rt + c) * d.org_stride + 4 * g);
-      const pel4 p = *reinterpret_cast<const pel4*>(pred + (size_t)(16 * rt + c) * d.pred_stride + 4 * g);
-      _Float16 a[4];
 #pragma unroll
-      for (int j = 0; j < 4; j++) { const int v = (int)o[j] - (int)p[j]; inRange = inRange && v >= -1023 && v <= 1023; a[j] = (_Float16)(short)v; }
-      x[rt][0] = h8{ a[0], a[1], a[2], a[3], a[0], a[1], a[2], a[3] };
+      for (int rt = 0; rt < S::RT; rt++)
+      {
+        const pel4 o = *reinterpret_cast<const pel4*>(org + (size_t)(16 * rt + c) * d.org_stride + 4 * g);
+        pel4 p = { 0, 0, 0, 0 };
+        if (mode == RC_CHAIN) p = *reinterpret_cast<const pel4*>(pred + (size_t)(16 * rt + c) * d.pred_stride + 4 * g);
+        _Float16 a[4];
+#pragma unroll
+        for (int j = 0; j < 4; j++) { const int v = (int)o[j] - (int)p[j]; inRange = inRange && v >= -1023 && v <= 1023; a[j] = (_Float16)(short)v; }
+        x[rt][0] = h8{ a[0], a[1], a[2], a[3], a[0], a[1], a[2], a[3] };
+      }
     }
+    else
+    {
+      pel8 o[S::RT][S::XS], p[S::RT][S::XS];
+#pragma unroll
+      for (int rt = 0; rt < S::RT; rt++)
+#pragma unroll
+        for (int s = 0; s < S::XS; s++)
+        {
+          o[rt][s] = *reinterpret_cast<const pel8*>(org + (size_t)(16 * rt + c) * d.org_stride + 32 * s + 8 * g);
+          p[rt][s] = pel8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+          if (mode == RC_CHAIN) p[rt][s] = *reinterpret_cast<const pel8*>(pred + (size_t)(16 * rt + c) * d.pred_stride + 32 * s + 8 * g);
+        }
+#pragma unroll
+      for (int rt = 0; rt < S::RT; rt++)
+#pragma unroll
+        for (int s = 0; s < S::XS; s++)
+#pragma unroll
+          for (int j = 0; j < 8; j++)
+          {
+            const int v = (int)o[rt][s][j] - (int)p[rt][s][j];
+            inRange = inRange && v >= -1023 && v <= 1023;
+            x[rt][s][j] = (_Float16)(short)v;
+          }
+    }
+    if (__builtin_amdgcn_ballot_w64(!inRange) != 0ull) return false;
+
+    // rounding shifts of the forward stages (TrQuant.cpp:151-152, 214)
+    const int s1 = LW + bd + 6 - 15 + 2, s2 = LH + 6 + 2;
+    int t1[S::JT][S::RT][4];                             // [column tile][row tile]: the row tiles are the k dimension of the next product
+    mt_fwd1<W, H>(t1, x, Th, s1, c, g);
+    int cf[S::IT][S::JT][4];                             // [row tile of C (vertical frequency)][column tile (horizontal frequency)]
+    mt_fwd2<W, H>(cf, t1, Tv, s2, c, g);
+
+    // ---- quantiser: tile (it, jt) holds rows 16 it + 4 g + reg, column 16 jt + c; the quad c >> 2 of row group g is one coefficient group
+    if (mode == RC_CHAIN)
+    {
+      const RcQ q = rc_qparams(W, H, d.qp, bd, d.intra_slice, d.sign_hiding);
+      const unsigned short* inv = dqInv + scanOff[(LW - 1) * 6 + (LH - 1)];
+      int lv[S::IT][S::JT][4], du[S::IT][S::JT][4];
+      int sum = 0, lastCg = -1, cgIdx[S::IT][S::JT];
+#pragma unroll
+      for (int it = 0; it < S::IT; it++)
+#pragma unroll
+        for (int jt = 0; jt < S::JT; jt++)
+        {
+#pragma unroll
+          for (int r = 0; r < 4; r++) { int mag; lv[it][jt][r] = rc_quant_one(q, cf[it][jt][r], du[it][jt][r], mag); sum += mag; }
+          cgIdx[it][jt] = (int)inv[(16 * it + 4 * g) * W + 16 * jt + (c & ~3)] >> 4;
+          if (rc_cg_nonzero(lv[it][jt])) lastCg = max(lastCg, cgIdx[it][jt]);
+        }
+      lastCg = wave_max_i32(lastCg);
+      sum = wave_sum_i32(sum);
+      if (lane == 0) absSumOut[ti] = (unsigned)sum;
+#pragma unroll
+      for (int it = 0; it < S::IT; it++)
+#pragma unroll
+        for (int jt = 0; jt < S::JT; jt++)
+        {
+          if (q.sbh) rc_sbh_quad(lv[it][jt], du[it][jt], cf[it][jt], cgIdx[it][jt] == lastCg, lane);
+#pragma unroll
+          for (int r = 0; r < 4; r++) { level[(16 * it + 4 * g + r) * W + 16 * jt + c] = lv[it][jt][r]; cq[jt][it][r] = rc_dequant_one(q, lv[it][jt][r]); }
+        }
+    }
+    else
+    {
+#pragma unroll
+      for (int it = 0; it < S::IT; it++)
+#pragma unroll
+        for (int jt = 0; jt < S::JT; jt++)
+#pragma unroll
+          for (int r = 0; r < 4; r++) level[(16 * it + 4 * g + r) * W + 16 * jt + c] = cf[it][jt][r];
+    }
+    // zero-out region of the level array: columns >= 32 of the kept rows, then the rows >= 32
+    if (W == 64) for (int e = lane; e < S::HJ * 8; e += 64) *reinterpret_cast<int4v*>(level + (e >> 3) * 64 + 32 + 4 * (e & 7)) = z;
+    if (H == 64) for (int e = lane; e < 32 * W / 4; e += 64) *reinterpret_cast<int4v*>(level + 32 * W + 4 * e) = z;
+    if (mode == RC_FWD) return true;
   }
   else
   {
-    pel8 o[S::RT][S::XS], p[S::RT][S::XS];
-#pragma unroll
-    for (int rt = 0; rt < S::RT; rt++)
-#pragma unroll
-      for (int s = 0; s < S::XS; s++)
-      {
-        o[rt][s] = *reinterpret_cast<const pel8*>(org + (size_t)(16 * rt + c) * d.org_stride + 32 * s + 8 * g);
-        p[rt][s] = *reinterpret_cast<const pel8*>(pred + (size_t)(16 * rt + c) * d.pred_stride + 32 * s + 8 * g);
-      }
-#pragma unroll
-    for (int rt = 0; rt < S::RT; rt++)
-#pragma unroll
-      for (int s = 0; s < S::XS; s++)
-#pragma unroll
-        for (int j = 0; j < 8; j++)
-        {
-          const int v = (int)o[rt][s][j] - (int)p[rt][s][j];
-          inRange = inRange && v >= -1023 && v <= 1023;
-          x[rt][s][j] = (_Float16)(short)v;
-        }
-  }
-  if (__builtin_amdgcn_ballot_w64(!inRange) != 0ull) return false;
-
-  // rounding shifts of the forward stages (TrQuant.cpp:151-152, 214)
-  const int s1 = LW + bd + 6 - 15 + 2, s2 = LH + 6 + 2;
-  int t1[S::JT][S::RT][4];                             // [column tile][row tile]: the row tiles are the k dimension of the next product
-  mt_fwd1<W, H>(t1, x, Th, s1, c, g);
-  int cf[S::IT][S::JT][4];                             // [row tile of C (vertical frequency)][column tile (horizontal frequency)]
-  mt_fwd2<W, H>(cf, t1, Tv, s2, c, g);
-
-  // ---- quantiser: tile (it, jt) holds rows 16 it + 4 g + reg, column 16 jt + c; the quad c >> 2 of row group g is one coefficient group
-  const RcQ q = rc_qparams(W, H, d.qp, bd, d.intra_slice, d.sign_hiding);
-  const unsigned short* inv = dqInv + scanOff[(LW - 1) * 6 + (LH - 1)];
-  int lv[S::IT][S::JT][4], du[S::IT][S::JT][4];
-  int sum = 0, lastCg = -1, cgIdx[S::IT][S::JT];
-#pragma unroll
-  for (int it = 0; it < S::IT; it++)
-#pragma unroll
-    for (int jt = 0; jt < S::JT; jt++)
-    {
-#pragma unroll
-      for (int r = 0; r < 4; r++) { int mag; lv[it][jt][r] = rc_quant_one(q, cf[it][jt][r], du[it][jt][r], mag); sum += mag; }
-      cgIdx[it][jt] = (int)inv[(16 * it + 4 * g) * W + 16 * jt + (c & ~3)] >> 4;
-      if (rc_cg_nonzero(lv[it][jt])) lastCg = max(lastCg, cgIdx[it][jt]);
-    }
-  lastCg = wave_max_i32(lastCg);
-  sum = wave_sum_i32(sum);
-  if (lane == 0) absSumOut[ti] = (unsigned)sum;
-  TCoeff* level = levelBase + d.level_off;
-#pragma unroll
-  for (int it = 0; it < S::IT; it++)
-#pragma unroll
-    for (int jt = 0; jt < S::JT; jt++)
-    {
-      if (q.sbh) rc_sbh_quad(lv[it][jt], du[it][jt], cf[it][jt], cgIdx[it][jt] == lastCg, lane);
-#pragma unroll
-      for (int r = 0; r < 4; r++) level[(16 * it + 4 * g + r) * W + 16 * jt + c] = lv[it][jt][r];
-    }
-  // zero-out region of the level array: columns >= 32 of the kept rows, then the rows >= 32
-  const int4v z = { 0, 0, 0, 0 };
-  if (W == 64) for (int e = lane; e < S::HJ * 8; e += 64) *reinterpret_cast<int4v*>(level + (e >> 3) * 64 + 32 + 4 * (e & 7)) = z;
-  if (H == 64) for (int e = lane; e < 32 * W / 4; e += 64) *reinterpret_cast<int4v*>(level + 32 * W + 4 * e) = z;
-
-  // ---- de-quantiser, inverse stages, reconstruction
-  int y1[S::RT][S::JT][4];                             // [row tile (r)][frequency tile (i)]: the frequency tiles are the k dimension of the last product
-  {
-    int cq[S::JT][S::IT][4];                           // [column tile (i)][row tile (k)]
+    bool fits = true;
 #pragma unroll
     for (int it = 0; it < S::IT; it++)
 #pragma unroll
       for (int jt = 0; jt < S::JT; jt++)
 #pragma unroll
-        for (int r = 0; r < 4; r++) cq[jt][it][r] = rc_dequant_one(q, lv[it][jt][r]);
-    mt_inv1<W, H>(y1, cq, TvT, c, g);
+        for (int r = 0; r < 4; r++)
+        {
+          const int v = level[(16 * it + 4 * g + r) * W + 16 * jt + c];
+          fits = fits && v >= -32768 && v <= 32767;
+          cq[jt][it][r] = v;
+        }
+    if (__builtin_amdgcn_ballot_w64(!fits) != 0ull) return false;
   }
+
+  // ---- inverse stages, reconstruction
+  int y1[S::RT][S::JT][4];                             // [row tile (r)][frequency tile (i)]: the frequency tiles are the k dimension of the last product
+  mt_inv1<W, H>(y1, cq, TvT, c, g);
   const int s2i = (6 + 15 - 1) - bd + 2;
   Pel* rec = recBase + d.rec_off;
   mt_inv2<W, H>(y1, ThT, s2i, c, g, [&](int rt, int xt, const int (&resi)[4])
   {
-    const pel4 pv = *reinterpret_cast<const pel4*>(pred + (size_t)(16 * rt + c) * d.pred_stride + 16 * xt + 4 * g);
     pel4 out;
+    if (mode == RC_CHAIN)
+    {
+      const pel4 pv = *reinterpret_cast<const pel4*>(pred + (size_t)(16 * rt + c) * d.pred_stride + 16 * xt + 4 * g);
 #pragma unroll
-    for (int r = 0; r < 4; r++) out[r] = (short)clip3(clpMin, clpMax, (int)pv[r] + (int)(short)resi[r]);
+      for (int r = 0; r < 4; r++) out[r] = (short)clip3(clpMin, clpMax, (int)pv[r] + (int)(short)resi[r]);
+    }
+    else
+    {
+#pragma unroll
+      for (int r = 0; r < 4; r++) out[r] = (short)resi[r];
+    }
     *reinterpret_cast<pel4*>(rec + (size_t)(16 * rt + c) * d.rec_stride + 16 * xt + 4 * g) = out;
   });
   return true;
@@ -417,13 +475,15 @@ __device__ __forceinline__ h4 rc_limb_h4(const int (&v)[4], bool high)
   return high ? h4{ h[0], h[1], h[2], h[3] } : h4{ l[0], l[1], l[2], l[3] };
 }
 
-template <int W, int H>
+template <int W, int H, int MODE>
 __device__ __noinline__ void rc_tile_packed(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
                                                const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                                const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
                                                int* __restrict__ fbCount, int* __restrict__ fbList, int* info, int lane)
 {
+  constexpr int mode = MODE;
+
   constexpr int NX = 16 / W, NY = 16 / H, G = NX * NY;
   constexpr int LW = W == 4 ? 2 : W == 8 ? 3 : 4, LH = H == 4 ? 2 : H == 8 ? 3 : 4;
   const int c = lane & 15, g = lane >> 4;
@@ -446,21 +506,35 @@ __device__ __noinline__ void rc_tile_packed(const RcDesc* __restrict__ descs, co
     for (int gg = 0; gg < W / 4; gg++) m |= cm << (16 * (sx * (W / 4) + gg));
     return m;
   };
+  auto laneMaskQ = [&](int sx, int sy) -> unsigned long long              // lanes of view Q that hold coefficients of sub-TU (sx, sy)
+  {
+    const unsigned long long cm = W == 16 ? 0xFFFFull : (((1ull << W) - 1ull) << (sx * W));
+    unsigned long long m = 0;
+#pragma unroll
+    for (int gg = 0; gg < H / 4; gg++) m |= cm << (16 * (sy * (H / 4) + gg));
+    return m;
+  };
   const RcDesc& dL = descs[tiL >= 0 ? tiL : ti0];
+  const RcDesc& dQ = descs[tiQ >= 0 ? tiQ : ti0];
   const int rowL = c & (H - 1), colL = (4 * g) & (W - 1);
-  const Pel* predP = predBase + dL.pred_off + (size_t)rowL * dL.pred_stride + colL;
+  const int y0 = (4 * g) & (H - 1), xq = c & (W - 1);
+  TCoeff* level = levelBase + dQ.level_off;
   pel4 pv = { 0, 0, 0, 0 };
+  bool okL, okQ;
+  int cq[4];
+  if (mode != RC_INV)
+  {
   int x[4] = { 0, 0, 0, 0 };
   bool inRange = true;
   if (tiL >= 0)
   {
     const pel4 o = *reinterpret_cast<const pel4*>(orgBase + dL.org_off + (size_t)rowL * dL.org_stride + colL);
-    pv = *reinterpret_cast<const pel4*>(predP);
+    if (mode == RC_CHAIN) pv = *reinterpret_cast<const pel4*>(predBase + dL.pred_off + (size_t)rowL * dL.pred_stride + colL);
 #pragma unroll
     for (int j = 0; j < 4; j++) { x[j] = (int)o[j] - (int)pv[j]; inRange = inRange && x[j] >= -1023 && x[j] <= 1023; }
   }
   const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!inRange);
-  const bool okL = tiL >= 0 && (badLanes & laneMask(sxL, syL)) == 0ull, okQ = tiQ >= 0 && (badLanes & laneMask(sxQ, syQ)) == 0ull;
+  okL = tiL >= 0 && (badLanes & laneMask(sxL, syL)) == 0ull; okQ = tiQ >= 0 && (badLanes & laneMask(sxQ, syQ)) == 0ull;
   if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMask(lane % NX, lane / NX)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
   h4 xa = zero4;
   if (okL) xa = h4{ (_Float16)(short)x[0], (_Float16)(short)x[1], (_Float16)(short)x[2], (_Float16)(short)x[3] };
@@ -498,10 +572,18 @@ __device__ __noinline__ void rc_tile_packed(const RcDesc* __restrict__ descs, co
 #pragma unroll
     for (int r = 0; r < 4; r++) cf[r] = ((((int)hi[r]) << 8) + (int)lo[r] + (1 << (s2 - 1))) >> s2;   // C[vertical frequency 4 g + r][horizontal frequency c]
   }
+  if (mode == RC_FWD)                                                     // forward transform only: the coefficients are the result
+  {
+    if (okQ)
+    {
+#pragma unroll
+      for (int r = 0; r < 4; r++) level[(y0 + r) * W + xq] = cf[r];
+    }
+    RC_WAVE_SYNC();
+    return;
+  }
   // ---- quantiser in view Q: the lane's four coefficients are rows y0 .. y0 + 3 of column xq of its TU; its quad is one coefficient group
-  const RcDesc& dQ = descs[tiQ >= 0 ? tiQ : ti0];
   const RcQ q = rc_qparams(W, H, dQ.qp, bd, dQ.intra_slice, dQ.sign_hiding);
-  const int y0 = (4 * g) & (H - 1), xq = c & (W - 1);
   int lv[4], du[4], sum = 0;
 #pragma unroll
   for (int r = 0; r < 4; r++) { int mag; lv[r] = rc_quant_one(q, cf[r], du[r], mag); sum += mag; }
@@ -516,16 +598,25 @@ __device__ __noinline__ void rc_tile_packed(const RcDesc* __restrict__ descs, co
   if (q.sbh) rc_sbh_quad(lv, du, cf, cgIdx == lastCg, lane);
   if (okQ)
   {
-    TCoeff* level = levelBase + dQ.level_off;
 #pragma unroll
     for (int r = 0; r < 4; r++) level[(y0 + r) * W + xq] = lv[r];
+  }
+#pragma unroll
+  for (int r = 0; r < 4; r++) cq[r] = rc_dequant_one(q, lv[r]);
+  }
+  else                                                                    // inverse transform only: the coefficients come from memory, in view Q
+  {
+    bool fits = true;
+#pragma unroll
+    for (int r = 0; r < 4; r++) { cq[r] = tiQ >= 0 ? level[(y0 + r) * W + xq] : 0; fits = fits && cq[r] >= -32768 && cq[r] <= 32767; }
+    const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!fits);
+    okQ = tiQ >= 0 && (badLanes & laneMaskQ(sxQ, syQ)) == 0ull; okL = tiL >= 0 && (badLanes & laneMaskQ(sxL, syL)) == 0ull;
+    if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMaskQ(lane % NX, lane / NX)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
+    if (!okQ) { cq[0] = 0; cq[1] = 0; cq[2] = 0; cq[3] = 0; }
   }
   // ---- I1: Y1T[i][r] = sum_k Cq[k][i] Tv(sub-TU of i, r)[k][r]: A = Cq^T (row i = c), B = rows of Tv^T; the type also belongs to A's row -> passes
   int y1[4];
   {
-    int cq[4];
-#pragma unroll
-    for (int r = 0; r < 4; r++) cq[r] = rc_dequant_one(q, lv[r]);
     const h4 ah = rc_limb_h4(cq, true), al = rc_limb_h4(cq, false);
     f4 hi = { 0.f, 0.f, 0.f, 0.f }, lo = { 0.f, 0.f, 0.f, 0.f };
     const bool diag = syL == syQ;                                         // B: column r = c, k = 4 g ..
@@ -561,7 +652,7 @@ __device__ __noinline__ void rc_tile_packed(const RcDesc* __restrict__ descs, co
       for (int r = 0; r < 4; r++)
       {
         const int resi = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[r]) << 8) + (int)lo[r] + (1 << (s2i - 1))) >> s2i);
-        out[r] = (short)clip3(clpMin, clpMax, (int)pv[r] + (int)(short)resi);
+        out[r] = mode == RC_CHAIN ? (short)clip3(clpMin, clpMax, (int)pv[r] + (int)(short)resi) : (short)resi;
       }
       *reinterpret_cast<pel4*>(recBase + dL.rec_off + (size_t)rowL * dL.rec_stride + colL) = out;
     }
@@ -573,13 +664,15 @@ __device__ __noinline__ void rc_tile_packed(const RcDesc* __restrict__ descs, co
 // 8 x 64 / 4 x 64 (16 / W TUs side by side in an H-row x 16-column multi-tile); a 64-point side keeps its 32 low frequencies (zero-out) and is always DCT-II.  The 32-point stages are the 16x16x32 products of mfma_tr.h (operand of a
 // result tile in its register k order), the short side is block-diagonal as above; only the 32-point stages depend on the other operand's
 // sub-TU and run in passes.
-template <int W, int H>
+template <int W, int H, int MODE>
 __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
                                                 const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                 TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                                 const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
                                                 int* __restrict__ fbCount, int* __restrict__ fbList, int* info, int lane)
 {
+  constexpr int mode = MODE;
+
   constexpr int NY = 16 / H, G = NY, LH = H == 4 ? 2 : 3, LW = W == 32 ? 5 : 6, XS = W / 32, CT = W / 16, PITCH = W + 8;
   constexpr int NP = W == 64 ? 1 : NY;                 // passes of the long stages: a 64-point side is DCT-II for every TU (no type to tell apart)
   const int c = lane & 15, g = lane >> 4;
@@ -594,8 +687,22 @@ __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs,
   const int syL = c >> LH, syQ = (4 * g) >> LH;                          // sample views: tile row c; coefficient view: tile rows 4 g ..
   const int tiL = info[syL], tiQ = info[syQ], ti0 = info[0];
   auto laneMask = [&](int sy) -> unsigned long long { const unsigned long long cm = ((1ull << H) - 1ull) << (sy * H); return cm | (cm << 16) | (cm << 32) | (cm << 48); };
+  auto laneMaskQ = [&](int sy) -> unsigned long long                     // lanes of the coefficient view that hold TU sy: row groups g of its rows, every column
+  {
+    unsigned long long m = 0;
+#pragma unroll
+    for (int gg = 0; gg < H / 4; gg++) m |= 0xFFFFull << (16 * (sy * (H / 4) + gg));
+    return m;
+  };
   const RcDesc& dL = descs[tiL >= 0 ? tiL : ti0];
-  const int rowL = c & (H - 1);
+  const RcDesc& dQ = descs[tiQ >= 0 ? tiQ : ti0];
+  const int rowL = c & (H - 1), y0 = (4 * g) & (H - 1);
+  TCoeff* level = levelBase + dQ.level_off;
+  const bool diagV = syL == syQ;
+  bool okL, okQ;
+  int cqA[2][4];                                                          // the inverse stages' input
+  if (mode != RC_INV)
+  {
   h8 xa[XS];
 #pragma unroll
   for (int sk = 0; sk < XS; sk++) xa[sk] = zero8;
@@ -606,13 +713,14 @@ __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs,
     for (int sk = 0; sk < XS; sk++)
     {
       const pel8 o = *reinterpret_cast<const pel8*>(orgBase + dL.org_off + (size_t)rowL * dL.org_stride + 32 * sk + 8 * g);
-      const pel8 pp = *reinterpret_cast<const pel8*>(predBase + dL.pred_off + (size_t)rowL * dL.pred_stride + 32 * sk + 8 * g);
+      pel8 pp = { 0, 0, 0, 0, 0, 0, 0, 0 };
+      if (mode == RC_CHAIN) pp = *reinterpret_cast<const pel8*>(predBase + dL.pred_off + (size_t)rowL * dL.pred_stride + 32 * sk + 8 * g);
 #pragma unroll
       for (int j = 0; j < 8; j++) { const int v = (int)o[j] - (int)pp[j]; inRange = inRange && v >= -1023 && v <= 1023; xa[sk][j] = (_Float16)(short)v; }
     }
   }
   const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!inRange);
-  const bool okL = tiL >= 0 && (badLanes & laneMask(syL)) == 0ull, okQ = tiQ >= 0 && (badLanes & laneMask(syQ)) == 0ull;
+  okL = tiL >= 0 && (badLanes & laneMask(syL)) == 0ull; okQ = tiQ >= 0 && (badLanes & laneMask(syQ)) == 0ull;
   if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMask(lane)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
   if (!okL) {
 #pragma unroll
@@ -642,7 +750,6 @@ __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs,
       for (int r = 0; r < 4; r++) t1[jt][r] = ((int)m1[jt][r] + (1 << (s1 - 1))) >> s1;       // M1[row 4 g + r][frequency 16 jt + c]
   }
   // ---- F2 (block-diagonal H-point; the type belongs to the row of the matrix)
-  const bool diagV = syL == syQ;
   int cf[2][4];
   {
     const h4 a = diagV ? rc_frag4(tab, (info[16 + syL] >> 2) & 3, H, 0, rowL, (4 * g) & (H - 1)) : zero4;
@@ -655,10 +762,24 @@ __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs,
       for (int r = 0; r < 4; r++) cf[jt][r] = ((((int)hi[r]) << 8) + (int)lo[r] + (1 << (s2 - 1))) >> s2;   // C[vertical frequency 4 g + r][horizontal 16 jt + c]
     }
   }
+  if (mode == RC_FWD)                                                     // forward transform only: the coefficients are the result
+  {
+    if (okQ)
+    {
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+          level[(y0 + r) * W + 16 * jt + c] = cf[jt][r];
+          if (W == 64) level[(y0 + r) * W + 32 + 16 * jt + c] = 0;
+        }
+    }
+    RC_WAVE_SYNC();
+    return;
+  }
   // ---- quantiser: the lane's coefficients are rows y0 .. y0 + 3 of columns c and 16 + c of TU syQ
-  const RcDesc& dQ = descs[tiQ >= 0 ? tiQ : ti0];
   const RcQ q = rc_qparams(W, H, dQ.qp, bd, dQ.intra_slice, dQ.sign_hiding);
-  const int y0 = (4 * g) & (H - 1);
   const unsigned short* inv = dqInv + scanOff[(LW - 1) * 6 + (LH - 1)];
   int lv[2][4], du[2][4], sum = 0, lastCg = -1, cgIdx[2];
 #pragma unroll
@@ -674,7 +795,6 @@ __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs,
 #pragma unroll
   for (int m = 16; m < 4 * H; m <<= 1) { sum += __shfl_xor(sum, m); lastCg = max(lastCg, __shfl_xor(lastCg, m)); }
   if (okQ && c == 0 && y0 == 0) absSumOut[tiQ] = (unsigned)sum;
-  TCoeff* level = levelBase + dQ.level_off;
 #pragma unroll
   for (int jt = 0; jt < 2; jt++)
   {
@@ -689,6 +809,27 @@ __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs,
         for (int r = 0; r < 4; r++) level[(y0 + r) * W + 32 + 16 * jt + c] = 0;
       }
     }
+#pragma unroll
+    for (int r = 0; r < 4; r++) cqA[jt][r] = rc_dequant_one(q, lv[jt][r]);
+  }
+  }
+  else                                                                    // inverse transform only: the coefficients come from memory
+  {
+    bool fits = true;
+#pragma unroll
+    for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) { cqA[jt][r] = tiQ >= 0 ? level[(y0 + r) * W + 16 * jt + c] : 0; fits = fits && cqA[jt][r] >= -32768 && cqA[jt][r] <= 32767; }
+    const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!fits);
+    okQ = tiQ >= 0 && (badLanes & laneMaskQ(syQ)) == 0ull; okL = tiL >= 0 && (badLanes & laneMaskQ(syL)) == 0ull;
+    if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMaskQ(lane)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
+    if (!okQ)
+    {
+#pragma unroll
+      for (int jt = 0; jt < 2; jt++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) cqA[jt][r] = 0;
+    }
   }
   // ---- I1 (block-diagonal H-point; the type belongs to the column r = c of the matrix operand)
   int y1[2][4];
@@ -697,11 +838,8 @@ __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs,
 #pragma unroll
     for (int jt = 0; jt < 2; jt++)
     {
-      int cq[4];
-#pragma unroll
-      for (int r = 0; r < 4; r++) cq[r] = rc_dequant_one(q, lv[jt][r]);
-      const f4 hi = __builtin_amdgcn_mfma_f32_16x16x16f16(rc_limb_h4(cq, true), b, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
-      const f4 lo = __builtin_amdgcn_mfma_f32_16x16x16f16(rc_limb_h4(cq, false), b, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+      const f4 hi = __builtin_amdgcn_mfma_f32_16x16x16f16(rc_limb_h4(cqA[jt], true), b, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+      const f4 lo = __builtin_amdgcn_mfma_f32_16x16x16f16(rc_limb_h4(cqA[jt], false), b, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; r++) y1[jt][r] = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[r]) << 8) + (int)lo[r] + 256) >> 9);   // Y1T[frequency 16 jt + 4 g + r][row c]
     }
@@ -734,13 +872,14 @@ __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs,
 #pragma unroll
       for (int xt = 0; xt < CT; xt++)                                     // residual of tile row c, columns 16 xt + 4 g ..
       {
-        const pel4 pv = *reinterpret_cast<const pel4*>(pr + 16 * xt + 4 * g);
+        pel4 pv = { 0, 0, 0, 0 };
+        if (mode == RC_CHAIN) pv = *reinterpret_cast<const pel4*>(pr + 16 * xt + 4 * g);
         pel4 out;
 #pragma unroll
         for (int r = 0; r < 4; r++)
         {
           const int resi = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[xt][r]) << 8) + (int)lo[xt][r] + (1 << (s2i - 1))) >> s2i);
-          out[r] = (short)clip3(clpMin, clpMax, (int)pv[r] + (int)(short)resi);
+          out[r] = mode == RC_CHAIN ? (short)clip3(clpMin, clpMax, (int)pv[r] + (int)(short)resi) : (short)resi;
         }
         *reinterpret_cast<pel4*>(rec + 16 * xt + 4 * g) = out;
       }
@@ -749,13 +888,15 @@ __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs,
   RC_WAVE_SYNC();
 }
 
-template <int W, int H>
+template <int W, int H, int MODE>
 __device__ __noinline__ void rc_tile_packed_hl(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
                                                 const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                 TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                                 const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
                                                 int* __restrict__ fbCount, int* __restrict__ fbList, int* info, int lane)
 {
+  constexpr int mode = MODE;
+
   constexpr int NX = 16 / W, G = NX, LW = W == 4 ? 2 : 3, LH = H == 32 ? 5 : 6, RT = H / 16, KS = H / 32, PITCH = H + 8;
   constexpr int NP = H == 64 ? 1 : NX;                 // passes of the long stages: a 64-point side is DCT-II for every TU
   const int c = lane & 15, g = lane >> 4;
@@ -776,12 +917,26 @@ __device__ __noinline__ void rc_tile_packed_hl(const RcDesc* __restrict__ descs,
     for (int gg = 0; gg < W / 4; gg++) m |= 0xFFFFull << (16 * (sx * (W / 4) + gg));
     return m;
   };
+  auto laneMaskQ = [&](int sx) -> unsigned long long                     // lanes of the coefficient view that hold TU sx: its columns c, every row group
+  {
+    const unsigned long long cm = ((1ull << W) - 1ull) << (sx * W);
+    return cm | (cm << 16) | (cm << 32) | (cm << 48);
+  };
   const RcDesc& dL = descs[tiL >= 0 ? tiL : ti0];
-  const int colL = (4 * g) & (W - 1);
+  const RcDesc& dQ = descs[tiQ >= 0 ? tiQ : ti0];
+  const int colL = (4 * g) & (W - 1), xq = c & (W - 1);
+  TCoeff* level = levelBase + dQ.level_off;
+  const bool diagH = sxQ == sxL;
   pel4 pv[RT];
+#pragma unroll
+  for (int rt = 0; rt < RT; rt++) pv[rt] = pel4{ 0, 0, 0, 0 };
+  bool okL, okQ;
+  int cqA[2][4];                                                          // the inverse stages' input
+  if (mode != RC_INV)
+  {
   h4 xa[RT];
 #pragma unroll
-  for (int rt = 0; rt < RT; rt++) { pv[rt] = pel4{ 0, 0, 0, 0 }; xa[rt] = zero4; }
+  for (int rt = 0; rt < RT; rt++) xa[rt] = zero4;
   bool inRange = true;
   if (tiL >= 0)
   {
@@ -789,20 +944,19 @@ __device__ __noinline__ void rc_tile_packed_hl(const RcDesc* __restrict__ descs,
     for (int rt = 0; rt < RT; rt++)
     {
       const pel4 o = *reinterpret_cast<const pel4*>(orgBase + dL.org_off + (size_t)(16 * rt + c) * dL.org_stride + colL);
-      pv[rt] = *reinterpret_cast<const pel4*>(predBase + dL.pred_off + (size_t)(16 * rt + c) * dL.pred_stride + colL);
+      if (mode == RC_CHAIN) pv[rt] = *reinterpret_cast<const pel4*>(predBase + dL.pred_off + (size_t)(16 * rt + c) * dL.pred_stride + colL);
 #pragma unroll
       for (int j = 0; j < 4; j++) { const int v = (int)o[j] - (int)pv[rt][j]; inRange = inRange && v >= -1023 && v <= 1023; xa[rt][j] = (_Float16)(short)v; }
     }
   }
   const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!inRange);
-  const bool okL = tiL >= 0 && (badLanes & laneMask(sxL)) == 0ull, okQ = tiQ >= 0 && (badLanes & laneMask(sxQ)) == 0ull;
+  okL = tiL >= 0 && (badLanes & laneMask(sxL)) == 0ull; okQ = tiQ >= 0 && (badLanes & laneMask(sxQ)) == 0ull;
   if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMask(lane)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
   if (!okL) {
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) xa[rt] = zero4;
   }
   const int s1 = LW + bd + 6 - 15 + 2, s2 = LH + 6 + 2;
-  const bool diagH = sxQ == sxL;
   // ---- F1 (block-diagonal W-point; the type belongs to the column j = c of the matrix operand)
   int t1[RT][4];
   {
@@ -841,10 +995,24 @@ __device__ __noinline__ void rc_tile_packed_hl(const RcDesc* __restrict__ descs,
 #pragma unroll
       for (int r = 0; r < 4; r++) cf[it][r] = ((((int)hi[it][r]) << 8) + (int)lo[it][r] + (1 << (s2 - 1))) >> s2;   // C[vertical frequency 16 it + 4 g + r][horizontal c]
   }
+  if (mode == RC_FWD)                                                     // forward transform only: the coefficients are the result
+  {
+    if (okQ)
+    {
+#pragma unroll
+      for (int it = 0; it < 2; it++)
+#pragma unroll
+        for (int r = 0; r < 4; r++)
+        {
+          level[(16 * it + 4 * g + r) * W + xq] = cf[it][r];
+          if (H == 64) level[(32 + 16 * it + 4 * g + r) * W + xq] = 0;
+        }
+    }
+    RC_WAVE_SYNC();
+    return;
+  }
   // ---- quantiser: the lane's coefficients are rows 16 it + 4 g .. of column xq of TU sxQ
-  const RcDesc& dQ = descs[tiQ >= 0 ? tiQ : ti0];
   const RcQ q = rc_qparams(W, H, dQ.qp, bd, dQ.intra_slice, dQ.sign_hiding);
-  const int xq = c & (W - 1);
   const unsigned short* inv = dqInv + scanOff[(LW - 1) * 6 + (LH - 1)];
   int lv[2][4], du[2][4], sum = 0, lastCg = -1, cgIdx[2];
 #pragma unroll
@@ -860,7 +1028,6 @@ __device__ __noinline__ void rc_tile_packed_hl(const RcDesc* __restrict__ descs,
 #pragma unroll
   for (int m = 16; m < 64; m <<= 1) { sum += __shfl_xor(sum, m); lastCg = max(lastCg, __shfl_xor(lastCg, m)); }
   if (okQ && xq == 0 && g == 0) absSumOut[tiQ] = (unsigned)sum;
-  TCoeff* level = levelBase + dQ.level_off;
 #pragma unroll
   for (int it = 0; it < 2; it++)
   {
@@ -875,17 +1042,33 @@ __device__ __noinline__ void rc_tile_packed_hl(const RcDesc* __restrict__ descs,
         for (int r = 0; r < 4; r++) level[(32 + 16 * it + 4 * g + r) * W + xq] = 0;
       }
     }
+#pragma unroll
+    for (int r = 0; r < 4; r++) cqA[it][r] = rc_dequant_one(q, lv[it][r]);
+  }
+  }
+  else                                                                    // inverse transform only: the coefficients come from memory
+  {
+    bool fits = true;
+#pragma unroll
+    for (int it = 0; it < 2; it++)
+#pragma unroll
+      for (int r = 0; r < 4; r++) { cqA[it][r] = tiQ >= 0 ? level[(16 * it + 4 * g + r) * W + xq] : 0; fits = fits && cqA[it][r] >= -32768 && cqA[it][r] <= 32767; }
+    const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!fits);
+    okQ = tiQ >= 0 && (badLanes & laneMaskQ(sxQ)) == 0ull; okL = tiL >= 0 && (badLanes & laneMaskQ(sxL)) == 0ull;
+    if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMaskQ(lane)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
+    if (!okQ)
+    {
+#pragma unroll
+      for (int it = 0; it < 2; it++)
+#pragma unroll
+        for (int r = 0; r < 4; r++) cqA[it][r] = 0;
+    }
   }
   // ---- I1 (32-point over the vertical frequency, A = Cq^T in result-tile k order; the type belongs to A's row i = c: one pass per TU)
   int y1[RT][4];
   {
-    int cq[2][4];
-#pragma unroll
-    for (int it = 0; it < 2; it++)
-#pragma unroll
-      for (int r = 0; r < 4; r++) cq[it][r] = rc_dequant_one(q, lv[it][r]);
     h8 ah[1], al[1];
-    rc_tile_frags<32>(ah, al, cq);
+    rc_tile_frags<32>(ah, al, cqA);
     f4 hi[RT], lo[RT];
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) { hi[rt] = f4{ 0.f, 0.f, 0.f, 0.f }; lo[rt] = f4{ 0.f, 0.f, 0.f, 0.f }; }
@@ -923,7 +1106,7 @@ __device__ __noinline__ void rc_tile_packed_hl(const RcDesc* __restrict__ descs,
         for (int r = 0; r < 4; r++)
         {
           const int resi = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[r]) << 8) + (int)lo[r] + (1 << (s2i - 1))) >> s2i);
-          out[r] = (short)clip3(clpMin, clpMax, (int)pv[rt][r] + (int)(short)resi);
+          out[r] = mode == RC_CHAIN ? (short)clip3(clpMin, clpMax, (int)pv[rt][r] + (int)(short)resi) : (short)resi;
         }
         *reinterpret_cast<pel4*>(recBase + dL.rec_off + (size_t)(16 * rt + c) * dL.rec_stride + colL) = out;
       }
@@ -940,24 +1123,50 @@ __device__ __forceinline__ const int* rc_t32(const int* tr32, int type, int n) {
 constexpr int RC_GT_TYPE = 1364, RC_GT_INTS = 3 * RC_GT_TYPE + 4096;
 __device__ __forceinline__ const int* rc_t32_lds(const int* tabL, int type, int n) { return n == 64 ? tabL + 3 * RC_GT_TYPE : tabL + type * RC_GT_TYPE + (n * n - 4) / 3; }
 
+template <int MODE = RC_CHAIN>
 __device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                               TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int ti, int bd, int clpMin, int clpMax,
                               const int* __restrict__ tr32, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
                               int* bufA, int* bufB, int lane, const int* tabL = nullptr)
 {
+  constexpr int mode = MODE;
   const int w = d.w, h = d.h, lw = ilog2(w), lh = ilog2(h);
   const int wj = w > 32 ? 32 : w, hj = h > 32 ? 32 : h;
   const Pel* org = orgBase + d.org_off;
   const Pel* pred = predBase + d.pred_off;
   const int* Th = tabL ? rc_t32_lds(tabL, d.tr_hor, w) : rc_t32(tr32, d.tr_hor, w);      // the matrix entries sit on the inner loops: LDS when the kernel has a copy
   const int* Tv = tabL ? rc_t32_lds(tabL, d.tr_ver, h) : rc_t32(tr32, d.tr_ver, h);
+  TCoeff* level = levelBase + d.level_off;
+  Pel* rec = recBase + d.rec_off;
+  if (mode != RC_CHAIN && d.tr_hor == 3)                 // transform skip of the plain transform entries (TrQuant.cpp:795-847): element-wise
+  {
+    int shift = 15 - bd - ((lw + lh) >> 1), scale = 1;
+    if ((lw + lh) & 1) { shift += mode == RC_FWD ? -8 : 7; scale = 181; }
+    for (int e = lane; e < w * h; e += 64)
+    {
+      const int r = e >> lw, k = e & (w - 1);
+      if (mode == RC_FWD)
+      {
+        const int v = (int)org[(size_t)r * d.org_stride + k] * scale;
+        level[e] = shift >= 0 ? v << shift : (v + (1 << (-shift - 1))) >> -shift;
+      }
+      else
+      {
+        const int cc = level[e] * scale;
+        rec[(size_t)r * d.rec_stride + k] = (short)(shift >= 0 ? (cc + (shift ? 1 << (shift - 1) : 0)) >> shift : cc << -shift);
+      }
+    }
+    return;
+  }
+  const int s1 = lw + bd + 6 - 15 + 2, s2 = lh + 6 + 2;
+  if (mode != RC_INV)
+  {
   for (int e = lane; e < w * h; e += 64)
   {
     const int r = e >> lw, k = e & (w - 1);
-    bufA[e] = (int)org[(size_t)r * d.org_stride + k] - (int)pred[(size_t)r * d.pred_stride + k];
+    bufA[e] = (int)org[(size_t)r * d.org_stride + k] - (mode == RC_CHAIN ? (int)pred[(size_t)r * d.pred_stride + k] : 0);
   }
   RC_WAVE_SYNC();
-  const int s1 = lw + bd + 6 - 15 + 2, s2 = lh + 6 + 2;
   for (int e = lane; e < wj * h; e += 64)                // F1: bufB[j * h + r]
   {
     const int j = e >> lh, r = e & (h - 1);
@@ -981,9 +1190,14 @@ __device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, 
     bufA[e] = v;
   }
   RC_WAVE_SYNC();
+  if (mode == RC_FWD)                                    // forward transform only: the coefficients (zero outside the kept region) are the result
+  {
+    for (int e = lane; e < w * h; e += 64) level[e] = bufA[e];
+    RC_WAVE_SYNC();
+    return;
+  }
   // quantiser: lane = column (chunks of 64 columns never occur: w <= 64), four rows per pass
   const RcQ q = rc_qparams(w, h, d.qp, bd, d.intra_slice, d.sign_hiding);
-  TCoeff* level = levelBase + d.level_off;
   int sum = 0;
   if (!q.sbh)
   {
@@ -1031,6 +1245,11 @@ __device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, 
   }
   sum = wave_sum_i32(sum);
   if (lane == 0) absSumOut[ti] = (unsigned)sum;
+  }
+  else
+  {
+    for (int e = lane; e < w * h; e += 64) bufA[e] = level[e];       // inverse transform only: the coefficients come from memory
+  }
   RC_WAVE_SYNC();
   for (int e = lane; e < wj * h; e += 64)                // I1 (vertical): bufB[i * h + r] = clip(sum_k Cq[k][i] Tv[k][r])
   {
@@ -1042,7 +1261,6 @@ __device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, 
   }
   RC_WAVE_SYNC();
   const int s2i = (6 + 15 - 1) - bd + 2;
-  Pel* rec = recBase + d.rec_off;
   for (int e = lane; e < w * h; e += 64)                 // I2 (horizontal) + reconstruction
   {
     const int r = e >> lw, x = e & (w - 1);
@@ -1050,7 +1268,7 @@ __device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, 
 #pragma unroll 4
     for (int i = 0; i < wj; i++) acc += bufB[i * h + r] * Th[i * w + x];
     const int resi = (short)clip3(-(1 << 15), (1 << 15) - 1, (acc + (1 << (s2i - 1))) >> s2i);
-    rec[(size_t)r * d.rec_stride + x] = (short)clip3(clpMin, clpMax, (int)pred[(size_t)r * d.pred_stride + x] + resi);
+    rec[(size_t)r * d.rec_stride + x] = mode == RC_CHAIN ? (short)clip3(clpMin, clpMax, (int)pred[(size_t)r * d.pred_stride + x] + resi) : (short)resi;
   }
   RC_WAVE_SYNC();
 }
@@ -1077,7 +1295,7 @@ __global__ __launch_bounds__(256, W * H >= 2048 ? 2 : 3) void rc_mfma_kernel(con
   for (int item = blockIdx.x * 4 + (tid >> 6); item < total; item += gridDim.x * 4)
   {
     const int ti = list[item];
-    const bool done = rc_tu_mfma<W, H>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, dqInv, scanOff, lane);
+    const bool done = rc_tu_mfma<W, H, RC_CHAIN>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, dqInv, scanOff, lane);
     if (!done && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti;                 // residual outside +-1023: the generic kernel takes it
   }
 }
@@ -1089,6 +1307,7 @@ __global__ __launch_bounds__(256, W * H >= 2048 ? 2 : 3) void rc_mfma_kernel(con
 // ONE launch for both lists (an empty launch still costs ~4.6 us of a 4K picture): workgroups [0, wgSmall) serve the class-`generic` list,
 // four waves with 512-int buffers each and the matrices in LDS; the workgroups behind them serve the fall-back list with ONE wave and
 // 4096-int buffers (the other three waves leave at once).  The two forms share the LDS bytes.
+template <int MODE>
 __global__ __launch_bounds__(256) void rc_generic_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                         TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs,
                                                         const int* __restrict__ countA, const int* __restrict__ listA,
@@ -1109,8 +1328,8 @@ __global__ __launch_bounds__(256) void rc_generic_kernel(const Pel* __restrict__
     for (int k = blockIdx.x * 4 + wave; k < ca; k += wgSmall * 4)
     {
       const int ti = listA[k];
-      rc_tu_generic(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, lds + wave * 1024,
-                    lds + wave * 1024 + 512, lane, tabL);
+      rc_tu_generic<MODE>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, lds + wave * 1024,
+                          lds + wave * 1024 + 512, lane, tabL);
     }
     return;
   }
@@ -1119,7 +1338,7 @@ __global__ __launch_bounds__(256) void rc_generic_kernel(const Pel* __restrict__
   for (int k = (int)blockIdx.x - wgSmall; k < cb; k += nBig)
   {
     const int ti = listB[k];
-    rc_tu_generic(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, lds, lds + 4096, lane);
+    rc_tu_generic<MODE>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, lds, lds + 4096, lane, nullptr);
   }
 }
 
@@ -1130,12 +1349,14 @@ __global__ __launch_bounds__(256) void rc_generic_kernel(const Pel* __restrict__
 // prediction row is still in the lane's registers).
 struct RcSmallTab { int t[3][16 + 64]; int tt[3][16 + 64]; };       // per type: size 4 at 0, size 8 at 16; tt = transposes
 
-template <int S>
+template <int S, int MODE>
 __device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
                                                const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                                const RcSmallTab& tabs, int* tmpL, int lane)
 {
+  constexpr int mode = MODE;
+
   constexpr int G = 64 / S, LS = S == 4 ? 2 : 3, TO = S == 4 ? 0 : 16;
   typedef short pelS __attribute__((ext_vector_type(S)));
   const int tg = lane / S, li = lane % S;
@@ -1149,9 +1370,16 @@ __device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs,
   const int* ThT = tabs.tt[d.tr_hor] + TO;
   const int* TvT = tabs.tt[d.tr_ver] + TO;
   // stage F1: lane = row li
-  const pelS o = *reinterpret_cast<const pelS*>(orgBase + d.org_off + (size_t)li * d.org_stride);
-  const pelS p = *reinterpret_cast<const pelS*>(predBase + d.pred_off + (size_t)li * d.pred_stride);
+  pelS p;
+#pragma unroll
+  for (int jj = 0; jj < S; jj++) p[jj] = 0;
   const int s1 = LS + bd + 6 - 15 + 2, s2 = LS + 6 + 2;
+  int cq[S];                                                              // the inverse stages' input: column li
+  TCoeff* level = levelBase + d.level_off;
+  if (mode != RC_INV)
+  {
+  const pelS o = *reinterpret_cast<const pelS*>(orgBase + d.org_off + (size_t)li * d.org_stride);
+  if (mode == RC_CHAIN) p = *reinterpret_cast<const pelS*>(predBase + d.pred_off + (size_t)li * d.pred_stride);
   {
     int x[S];
 #pragma unroll
@@ -1182,6 +1410,15 @@ __device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs,
     }
   }
   RC_WAVE_SYNC();
+  if (mode == RC_FWD)                                                     // forward transform only: the coefficients are the result
+  {
+    if (act)
+    {
+#pragma unroll
+      for (int j = 0; j < S; j++) level[j * S + li] = cf[j];
+    }
+    return;
+  }
   // quantiser (coefficient groups: rows 4 R .. 4 R + 3 x the lane's aligned quad)
   const RcQ q = rc_qparams(S, S, d.qp, bd, d.intra_slice, d.sign_hiding);
   int lv[S], du[S], sum = 0;
@@ -1214,21 +1451,40 @@ __device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs,
   }
   if (act)
   {
-    TCoeff* level = levelBase + d.level_off;
 #pragma unroll
     for (int j = 0; j < S; j++) level[j * S + li] = lv[j];
   }
-  // de-quantiser + stage I1 (vertical): y[r] = clip(sum_k Cq[k] Tv[k][r]); written transposed: tt[r][column li]
-  {
-    int cq[S];
 #pragma unroll
-    for (int j = 0; j < S; j++) cq[j] = rc_dequant_one(q, lv[j]);
+  for (int j = 0; j < S; j++) cq[j] = rc_dequant_one(q, lv[j]);
+  }
+  else
+  {
+#pragma unroll
+    for (int j = 0; j < S; j++) cq[j] = act ? level[j * S + li] : 0;      // any 32-bit coefficient: exact 32-bit multiplies below
+  }
+  // stage I1 (vertical): y[r] = clip(sum_k Cq[k] Tv[k][r]); written transposed: tt[r][column li]
+  {
+    bool fits24 = true;                                                   // 24-bit multiplies when every coefficient of the wave allows it (always, for de-quantiser output)
+    if (mode != RC_CHAIN)
+    {
+#pragma unroll
+      for (int kk = 0; kk < S; kk++) fits24 = fits24 && cq[kk] >= -(1 << 23) && cq[kk] < (1 << 23);
+    }
+    const bool narrow = mode == RC_CHAIN || __builtin_amdgcn_ballot_w64(!fits24) == 0ull;
 #pragma unroll
     for (int r = 0; r < S; r++)
     {
       int acc = 0;
+      if (narrow)
+      {
 #pragma unroll
-      for (int kk = 0; kk < S; kk++) acc += __mul24(cq[kk], TvT[r * S + kk]);
+        for (int kk = 0; kk < S; kk++) acc += __mul24(cq[kk], TvT[r * S + kk]);
+      }
+      else
+      {
+#pragma unroll
+        for (int kk = 0; kk < S; kk++) acc += cq[kk] * TvT[r * S + kk];
+      }
       tt[r * (S + 1) + li] = clip3(-(1 << 15), (1 << 15) - 1, (acc + 256) >> 9);
     }
   }
@@ -1247,7 +1503,7 @@ __device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs,
 #pragma unroll
       for (int i = 0; i < S; i++) acc += __mul24(y[i], ThT[x * S + i]);
       const int resi = (short)clip3(-(1 << 15), (1 << 15) - 1, (acc + (1 << (s2i - 1))) >> s2i);
-      out[x] = (short)clip3(clpMin, clpMax, (int)p[x] + resi);
+      out[x] = mode == RC_CHAIN ? (short)clip3(clpMin, clpMax, (int)p[x] + resi) : (short)resi;
     }
     if (act) *reinterpret_cast<pelS*>(recBase + d.rec_off + (size_t)li * d.rec_stride) = out;
   }
@@ -1257,12 +1513,14 @@ __device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs,
 // 8 x 4 and 4 x 8 (the most frequent rectangles of a real encode: tests/golden/trace_*.npz): the same scheme with 8 lanes per TU -- lane = row
 // in the horizontal stages (H rows), lane = column in the vertical stages and the quantiser (W columns; the other lanes of the group idle there).
 // The TU has two coefficient groups side by side (8 x 4) or one above the other (4 x 8): the group's scan index is its position.
-template <int W, int H>
+template <int W, int H, int MODE>
 __device__ __forceinline__ void rc_rect_group(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
                                               const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                               TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                               const RcSmallTab& tabs, int* tmpL, int lane)
 {
+  constexpr int mode = MODE;
+
   constexpr int L = 8, G = 64 / L, LW = W == 4 ? 2 : 3, LH = H == 4 ? 2 : 3, TOW = W == 4 ? 0 : 16, TOH = H == 4 ? 0 : 16;
   typedef short pelW __attribute__((ext_vector_type(W)));
   const int tg = lane / L, li = lane % L;
@@ -1278,9 +1536,16 @@ __device__ __forceinline__ void rc_rect_group(const RcDesc* __restrict__ descs, 
   const bool isRow = li < H, isCol = li < W;
   const int rr = isRow ? li : 0;
   // stage F1: lane = row
-  const pelW o = *reinterpret_cast<const pelW*>(orgBase + d.org_off + (size_t)rr * d.org_stride);
-  const pelW p = *reinterpret_cast<const pelW*>(predBase + d.pred_off + (size_t)rr * d.pred_stride);
+  pelW p;
+#pragma unroll
+  for (int jj = 0; jj < W; jj++) p[jj] = 0;
   const int s1 = LW + bd + 6 - 15 + 2, s2 = LH + 6 + 2;
+  int cq[H];                                                              // the inverse stages' input: column li
+  TCoeff* level = levelBase + d.level_off;
+  if (mode != RC_INV)
+  {
+  const pelW o = *reinterpret_cast<const pelW*>(orgBase + d.org_off + (size_t)rr * d.org_stride);
+  if (mode == RC_CHAIN) p = *reinterpret_cast<const pelW*>(predBase + d.pred_off + (size_t)rr * d.pred_stride);
   if (isRow)
   {
     int x[W];
@@ -1312,6 +1577,15 @@ __device__ __forceinline__ void rc_rect_group(const RcDesc* __restrict__ descs, 
     }
   }
   RC_WAVE_SYNC();
+  if (mode == RC_FWD)                                                     // forward transform only: the coefficients are the result
+  {
+    if (act && isCol)
+    {
+#pragma unroll
+      for (int j = 0; j < H; j++) level[j * W + li] = cf[j];
+    }
+    return;
+  }
   // quantiser (coefficient groups: rows 4 R .. 4 R + 3 x the lane's aligned quad); idle lanes carry zeros
   const RcQ q = rc_qparams(W, H, d.qp, bd, d.intra_slice, d.sign_hiding);
   int lv[H], du[H], sum = 0;
@@ -1343,22 +1617,41 @@ __device__ __forceinline__ void rc_rect_group(const RcDesc* __restrict__ descs, 
   }
   if (act && isCol)
   {
-    TCoeff* level = levelBase + d.level_off;
 #pragma unroll
     for (int j = 0; j < H; j++) level[j * W + li] = lv[j];
   }
-  // de-quantiser + stage I1 (vertical), written transposed: tt[r][column]
+#pragma unroll
+  for (int j = 0; j < H; j++) cq[j] = rc_dequant_one(q, lv[j]);
+  }
+  else
+  {
+#pragma unroll
+    for (int j = 0; j < H; j++) cq[j] = (act && isCol) ? level[j * W + li] : 0;   // any 32-bit coefficient: exact 32-bit multiplies below
+  }
+  // stage I1 (vertical), written transposed: tt[r][column]
+  bool fits24 = true;
+  if (mode != RC_CHAIN)
+  {
+#pragma unroll
+    for (int kk = 0; kk < H; kk++) fits24 = fits24 && cq[kk] >= -(1 << 23) && cq[kk] < (1 << 23);
+  }
+  const bool narrow = mode == RC_CHAIN || __builtin_amdgcn_ballot_w64(!fits24) == 0ull;
   if (isCol)
   {
-    int cq[H];
-#pragma unroll
-    for (int j = 0; j < H; j++) cq[j] = rc_dequant_one(q, lv[j]);
 #pragma unroll
     for (int r = 0; r < H; r++)
     {
       int acc = 0;
+      if (narrow)
+      {
 #pragma unroll
-      for (int kk = 0; kk < H; kk++) acc += __mul24(cq[kk], TvT[r * H + kk]);
+        for (int kk = 0; kk < H; kk++) acc += __mul24(cq[kk], TvT[r * H + kk]);
+      }
+      else
+      {
+#pragma unroll
+        for (int kk = 0; kk < H; kk++) acc += cq[kk] * TvT[r * H + kk];
+      }
       tt[r * (L + 1) + li] = clip3(-(1 << 15), (1 << 15) - 1, (acc + 256) >> 9);
     }
   }
@@ -1378,7 +1671,7 @@ __device__ __forceinline__ void rc_rect_group(const RcDesc* __restrict__ descs, 
 #pragma unroll
       for (int i = 0; i < W; i++) acc += __mul24(y[i], ThT[x * W + i]);
       const int resi = (short)clip3(-(1 << 15), (1 << 15) - 1, (acc + (1 << (s2i - 1))) >> s2i);
-      out[x] = (short)clip3(clpMin, clpMax, (int)p[x] + resi);
+      out[x] = mode == RC_CHAIN ? (short)clip3(clpMin, clpMax, (int)p[x] + resi) : (short)resi;
     }
     if (act) *reinterpret_cast<pelW*>(recBase + d.rec_off + (size_t)li * d.rec_stride) = out;
   }
@@ -1407,16 +1700,17 @@ __global__ __launch_bounds__(256, S == 4 ? 6 : 3) void rc_small_kernel(const Pel
   __syncthreads();
   for (int item = blockIdx.x * 4 + wave; item < total; item += gridDim.x * 4)
   {
-    if (S == 84)      rc_rect_group<8, 4>(descs, list, cnt, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
-    else if (S == 48) rc_rect_group<4, 8>(descs, list, cnt, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
-    else              rc_small_group<(S > 8 ? 8 : S)>(descs, list, cnt, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+    if (S == 84)      rc_rect_group<8, 4, RC_CHAIN>(descs, list, cnt, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+    else if (S == 48) rc_rect_group<4, 8, RC_CHAIN>(descs, list, cnt, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+    else              rc_small_group<(S > 8 ? 8 : S), RC_CHAIN>(descs, list, cnt, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
   }
 }
 
 // All five size classes in ONE launch.  Each class alone is bound by the latency of a TU, not by throughput (405 64x64 TUs are 405 waves:
 // 20 us; 6480 16x16 TUs: 14 us; ...), and kernels on one stream run one after the other (82 us for the five launches at 4K).  Here a workgroup
 // walks "slots" (four wave items of one class), longest classes first, so short items fill the machine while the long ones run.
-__global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+template <int MODE>
+__global__ __launch_bounds__(256, MODE == RC_CHAIN ? 2 : 3) void rc_chain_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                           TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs, int n,
                                                           const int* __restrict__ hdr, const int* __restrict__ lists, int* __restrict__ fbCount,
                                                           int* __restrict__ fbList, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
@@ -1464,24 +1758,24 @@ __global__ __launch_bounds__(256, 2) void rc_chain_kernel(const Pel* __restrict_
     int ti = 0;
 #define RC_MF(K, W_, H_)                                                                                                                      \
     case K: if (item < cnt[K]) { ti = __builtin_amdgcn_readfirstlane(lists[(size_t)ordCls[K] * n + item]);                                    \
-        done = rc_tu_mfma<W_, H_>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane); } break;
+        done = rc_tu_mfma<W_, H_, MODE>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane); } break;
 #define RC_PK(K, W_, H_)                                                                                                                      \
-    case K: if (item < items[K]) rc_tile_packed<W_, H_>(descs, lists + (size_t)ordCls[K] * n, cnt[K], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, \
+    case K: if (item < items[K]) rc_tile_packed<W_, H_, MODE>(descs, lists + (size_t)ordCls[K] * n, cnt[K], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, \
                                                         clpMax, tab, tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
     switch (k)
     {
     RC_MF(0, 64, 64) RC_MF(1, 64, 32) RC_MF(2, 32, 64) RC_MF(3, 32, 32) RC_MF(4, 64, 16) RC_MF(5, 16, 64) RC_MF(7, 32, 16) RC_MF(8, 16, 32) RC_MF(9, 16, 16)
     RC_PK(10, 16, 8) RC_PK(11, 8, 16) RC_PK(12, 16, 4) RC_PK(13, 4, 16)
-    case 6: if (item < items[6]) rc_small_group<8>(descs, lists + (size_t)RC_C8 * n, cnt[6], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
-    case 14: if (item < items[14]) rc_small_group<4>(descs, lists + (size_t)RC_C4 * n, cnt[14], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
-    case 15: if (item < items[15]) rc_rect_group<8, 4>(descs, lists + (size_t)RC_R84 * n, cnt[15], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
-    case 16: if (item < items[16]) rc_rect_group<4, 8>(descs, lists + (size_t)RC_R48 * n, cnt[16], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 6: if (item < items[6]) rc_small_group<8, MODE>(descs, lists + (size_t)RC_C8 * n, cnt[6], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 14: if (item < items[14]) rc_small_group<4, MODE>(descs, lists + (size_t)RC_C4 * n, cnt[14], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 15: if (item < items[15]) rc_rect_group<8, 4, MODE>(descs, lists + (size_t)RC_R84 * n, cnt[15], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 16: if (item < items[16]) rc_rect_group<4, 8, MODE>(descs, lists + (size_t)RC_R48 * n, cnt[16], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
 #define RC_PK32(K, F)                                                                                                                         \
     case K: if (item < items[K]) F(descs, lists + (size_t)ordCls[K] * n, cnt[K], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,     \
                                    tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
-    RC_PK32(17, (rc_tile_packed_wl<32, 8>)) RC_PK32(18, (rc_tile_packed_hl<8, 32>)) RC_PK32(19, (rc_tile_packed_wl<32, 4>)) RC_PK32(20, (rc_tile_packed_hl<4, 32>))
-    RC_PK32(21, (rc_tile_packed_wl<64, 8>)) RC_PK32(22, (rc_tile_packed_hl<8, 64>)) RC_PK32(23, (rc_tile_packed_wl<64, 4>))
-    default: if (item < items[24]) rc_tile_packed_hl<4, 64>(descs, lists + (size_t)RC_P464 * n, cnt[24], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,
+    RC_PK32(17, (rc_tile_packed_wl<32, 8, MODE>)) RC_PK32(18, (rc_tile_packed_hl<8, 32, MODE>)) RC_PK32(19, (rc_tile_packed_wl<32, 4, MODE>)) RC_PK32(20, (rc_tile_packed_hl<4, 32, MODE>))
+    RC_PK32(21, (rc_tile_packed_wl<64, 8, MODE>)) RC_PK32(22, (rc_tile_packed_hl<8, 64, MODE>)) RC_PK32(23, (rc_tile_packed_wl<64, 4, MODE>))
+    default: if (item < items[24]) rc_tile_packed_hl<4, 64, MODE>(descs, lists + (size_t)RC_P464 * n, cnt[24], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,
                                                             tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
 #undef RC_PK32
     }
@@ -1526,26 +1820,23 @@ const _Float16* vvcgpu_mfma_image(const VvcTrTables& tb)
   return images[dev];
 }
 
-extern "C" {
-
-int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, vvc_pel* rec_base, vvc_coef* level_base,
-                            const vvcgpu_resi_chain_desc* descs, int n, int bit_depth, int clp_min, int clp_max, uint32_t* abs_sum, void* stream)
+// the classify / chain / generic launches behind vvcgpu_resi_chain_batch (mode RC_CHAIN) and, for long calls, behind vvcgpu_tr_fwd_batch /
+// vvcgpu_tr_inv_batch (RC_FWD / RC_INV; transform.hip): ONE chain launch with packed tiles instead of the small / matrix-core / dot2 kernels in a row
+static int rc_chain_launch(int mode, const vvc_pel* org_base, const vvc_pel* pred_base, vvc_pel* rec_base, vvc_coef* level_base, const void* descs_raw, int n,
+                           int bit_depth, int clp_min, int clp_max, uint32_t* abs_sum, hipStream_t st)
 {
-  VVC_CHECK_ARG(n >= 0, "resi_chain_batch: n %d", n);
-  if (n == 0) return VVCGPU_OK;
-  VVC_CHECK_ARG(org_base && pred_base && rec_base && level_base && descs && abs_sum, "resi_chain_batch: null pointer");
-  VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "resi_chain_batch: bit depth %d outside 8..10", bit_depth);
-  VVC_CHECK_ARG(clp_min <= clp_max, "resi_chain_batch: clipping range");
   VvcTrTables tb;
   const int rt = vvcgpu_tr_tables(&tb);
   if (rt) return rt;
-  hipStream_t st = (hipStream_t)stream;
   const _Float16* image = vvcgpu_mfma_image(tb);
   if (!image) return VVCGPU_E_DEVICE;
-  // scratch: header (class counts, then the fall-back count), the six class lists, the fall-back list of the matrix-core kernels
+  // scratch: the class lists, the fall-back list of the matrix-core bodies, (plain transforms) the descriptors as chain descriptors
   const size_t ints = (size_t)RC_NCLS * n + (size_t)n;
-  int* ws = static_cast<int*>(vvcgpu_scratch(st, ints * sizeof(int)));
+  const size_t convOff = (ints * sizeof(int) + 63) & ~(size_t)63;
+  int* ws = static_cast<int*>(vvcgpu_scratch(st, convOff + (mode == RC_CHAIN ? 0 : (size_t)n * sizeof(RcDesc))));
   if (!ws) return VVCGPU_E_DEVICE;
+  RcDesc* conv = mode == RC_CHAIN ? nullptr : reinterpret_cast<RcDesc*>(reinterpret_cast<unsigned char*>(ws) + convOff);
+  const RcDesc* descs = mode == RC_CHAIN ? static_cast<const RcDesc*>(descs_raw) : conv;
   // the header lives in the stream's persistent zeroed counters: this call's set is clean, the classifier clears the other set for the next
   // call (no fill launch in front of the chain)
   int cur = 0;
@@ -1555,17 +1846,23 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
   int* lists = ws;
   int* fbCount = hdr + RC_FB;
   int* fbList = lists + (size_t)RC_NCLS * n;
-  static const int separate = getenv("VVCGPU_RC_SEPARATE") ? 1 : 0;           // A/B timing switch: one launch per size class
-  static const int packedOff = getenv("VVCGPU_RC_NO_PACKED") ? 1 : 0;         // A/B timing switch: 16x8 / 8x16 / 16x4 / 4x16 on the generic path
-  hipLaunchKernelGGL(rc_classify_kernel, dim3(n < 1024 * RC_CLS_WGS ? cdiv(n, 1024) : RC_CLS_WGS), dim3(1024), 0, st, descs, n, hdr, lists, abs_sum,
-                     counters + VVC_CTR_INTS * (cur ^ 1), !separate && !packedOff);
+  static const int separate = getenv("VVCGPU_RC_SEPARATE") ? 1 : 0;           // A/B timing switch: one launch per size class (chain mode only)
+  static const int packedOff = getenv("VVCGPU_RC_NO_PACKED") ? 1 : 0;         // A/B timing switch: the packed-tile shapes on the generic path
+  const bool sep = separate && mode == RC_CHAIN;
+  const dim3 cg(n < 1024 * RC_CLS_WGS ? cdiv(n, 1024) : RC_CLS_WGS);
+  if (mode == RC_CHAIN)
+    hipLaunchKernelGGL(rc_classify_kernel<false>, cg, dim3(1024), 0, st, descs_raw, n, hdr, lists, abs_sum, counters + VVC_CTR_INTS * (cur ^ 1), !sep && !packedOff, conv);
+  else
+    hipLaunchKernelGGL(rc_classify_kernel<true>, cg, dim3(1024), 0, st, descs_raw, n, hdr, lists, abs_sum, counters + VVC_CTR_INTS * (cur ^ 1), !packedOff, conv);
   VVC_LAUNCH_CHECK_COUNTERS(st);
   // (measured: forking the size classes onto library-owned side streams and joining them with events is SLOWER than launching them back to
   // back on the caller's stream, 0.158 vs 0.115 ms at 4K -- a cross-stream event costs more than these 20 us kernels gain)
-  if (!separate)
+  if (!sep)
   {
-    hipLaunchKernelGGL(rc_chain_kernel, dim3(512), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, fbCount, fbList,
-                       abs_sum, bit_depth, clp_min, clp_max, image, tb);
+#define RC_CHAIN_LAUNCH(M) hipLaunchKernelGGL(rc_chain_kernel<M>, dim3(M == RC_CHAIN ? 512 : 768), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, fbCount, \
+                                             fbList, abs_sum, bit_depth, clp_min, clp_max, image, tb)
+    if (mode == RC_CHAIN) RC_CHAIN_LAUNCH(RC_CHAIN); else if (mode == RC_FWD) RC_CHAIN_LAUNCH(RC_FWD); else RC_CHAIN_LAUNCH(RC_INV);
+#undef RC_CHAIN_LAUNCH
     VVC_LAUNCH_CHECK_COUNTERS(st);
   }
   else
@@ -1590,10 +1887,32 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
     VVC_LAUNCH_CHECK_COUNTERS(st);
   }
   const int wgS = cdiv(n, 4) < 768 ? cdiv(n, 4) : 768, wgG = n < 512 ? n : 512;
-  hipLaunchKernelGGL(rc_generic_kernel, dim3(wgS + wgG), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_CGEN,
-                     lists + (size_t)RC_CGEN * n, fbCount, fbList, wgS, abs_sum, bit_depth, clp_min, clp_max, tb);
+#define RC_GEN_LAUNCH(M) hipLaunchKernelGGL(rc_generic_kernel<M>, dim3(wgS + wgG), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_CGEN, \
+                                           lists + (size_t)RC_CGEN * n, fbCount, fbList, wgS, abs_sum, bit_depth, clp_min, clp_max, tb)
+  if (mode == RC_CHAIN) RC_GEN_LAUNCH(RC_CHAIN); else if (mode == RC_FWD) RC_GEN_LAUNCH(RC_FWD); else RC_GEN_LAUNCH(RC_INV);
+#undef RC_GEN_LAUNCH
   VVC_LAUNCH_CHECK_COUNTERS(st);
   return VVCGPU_OK;
+}
+
+// the plain transform entries of transform.hip, long calls (mode 1: forward, 2: inverse)
+__attribute__((visibility("hidden"))) int vvcgpu_tr_chain_launch(int mode, const vvc_pel* resi_in, vvc_pel* resi_out, vvc_coef* coeff, const vvcgpu_tr_desc* descs, int n,
+                                                                   int bit_depth, void* stream)
+{
+  return rc_chain_launch(mode, resi_in, resi_in, resi_out, coeff, descs, n, bit_depth, 0, 0, nullptr, (hipStream_t)stream);
+}
+
+extern "C" {
+
+int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, vvc_pel* rec_base, vvc_coef* level_base,
+                            const vvcgpu_resi_chain_desc* descs, int n, int bit_depth, int clp_min, int clp_max, uint32_t* abs_sum, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0, "resi_chain_batch: n %d", n);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(org_base && pred_base && rec_base && level_base && descs && abs_sum, "resi_chain_batch: null pointer");
+  VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "resi_chain_batch: bit depth %d outside 8..10", bit_depth);
+  VVC_CHECK_ARG(clp_min <= clp_max, "resi_chain_batch: clipping range");
+  return rc_chain_launch(RC_CHAIN, org_base, pred_base, rec_base, level_base, descs, n, bit_depth, clp_min, clp_max, abs_sum, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -20,6 +20,9 @@
 #include "tr_tables.inc"
 #include <mutex>
 
+// resichain.hip: the chain's bodies as plain transforms (mode 1 forward, 2 inverse): ONE launch with packed matrix-core tiles for long calls
+int vvcgpu_tr_chain_launch(int mode, const vvc_pel* resi_in, vvc_pel* resi_out, vvc_coef* coeff, const vvcgpu_tr_desc* descs, int n, int bit_depth, void* stream);
+
 namespace {
 
 // int32 copies of the golden matrices: d_tr32[type][size] row-major (T[k][n]) and d_tr32t (transposed, T[n][k]) so that the
@@ -2489,6 +2492,11 @@ int vvcgpu_tr_fwd_batch(const vvc_pel* resi_base, vvc_coef* coeff_base, const vv
   if (rtb) return rtb;
   const _Float16* image = vvcgpu_mfma_image(tb);
   if (!image) return VVCGPU_E_DEVICE;
+  // long calls: ONE launch of the residual chain's bodies in forward-only mode (packed matrix-core tiles for TUs with a 4- / 8-point side, lane groups
+  // for 8x8 and smaller) instead of the small / matrix-core / dot2 kernels in a row -- on a real encoder's call mix those three were each bound by
+  // their own per-wave latency (profiles/r04_shape_mix.txt)
+  static const int chainMode = getenv("VVCGPU_TR_CHAIN") ? atoi(getenv("VVCGPU_TR_CHAIN")) : -1;       // A/B timing switch: 0 never, 1 always
+  if (chainMode < 0 ? n >= 16384 : chainMode != 0) return vvcgpu_tr_chain_launch(1, resi_base, nullptr, coeff_base, descs, n, bit_depth, stream);
   // long calls: the small TUs are binned on the device as well and the small kernel walks the bin lists (see small_setup)
   static const int orderMode = getenv("VVCGPU_TR_ORDER") ? atoi(getenv("VVCGPU_TR_ORDER")) : -1;       // A/B timing switch: 0 never, 1 always
   const bool ordered = orderMode < 0 ? n >= 16384 : orderMode != 0;
@@ -2526,6 +2534,11 @@ int vvcgpu_tr_inv_batch(const vvc_coef* coeff_base, vvc_pel* resi_base, const vv
   if (rtb) return rtb;
   const _Float16* image = vvcgpu_mfma_image(tb);
   if (!image) return VVCGPU_E_DEVICE;
+  // long calls: the residual chain's bodies in inverse-only mode (see vvcgpu_tr_fwd_batch)
+  static const int chainMode = getenv("VVCGPU_TR_CHAIN") ? atoi(getenv("VVCGPU_TR_CHAIN")) : -1;       // A/B timing switch: 0 never, 1 always
+  // (measured on the real call mix: 0.048 vs 0.054 ms at 35 k TUs, 0.126 vs 0.089 at 141 k -- there the three kernels' own latencies are amortised and their
+  // lane-group forms run at five waves per SIMD against the chain kernel's three)
+  if (chainMode < 0 ? (n >= 16384 && n < 65536) : chainMode != 0) return vvcgpu_tr_chain_launch(2, nullptr, resi_base, const_cast<vvc_coef*>(coeff_base), descs, n, bit_depth, stream);
   // long calls: the small TUs are binned on the device as well and the small kernel walks the bin lists (see small_setup)
   static const int orderMode = getenv("VVCGPU_TR_ORDER") ? atoi(getenv("VVCGPU_TR_ORDER")) : -1;       // A/B timing switch: 0 never, 1 always
   const bool ordered = orderMode < 0 ? n >= 16384 : orderMode != 0;
