@@ -173,12 +173,12 @@ constexpr int IF_WG_DESCS = 64;
 __device__ __forceinline__ int if_filter_band_rows(int w, int h) { return max(max(2, IF_HEAVY_FILTER / w), (h + 15) >> 4); }
 __device__ __forceinline__ int if_band_rows(int w, int h) { return max(max(4, IF_HEAVY / w), (h + 15) >> 4); }
 __global__ __launch_bounds__(256) void if_batch_kernel(const Pel* __restrict__ srcBase, Pel* __restrict__ dstBase,
-                                                       const vvcgpu_if_desc* __restrict__ descs, int n, int perWg, int bd,
+                                                       const vvcgpu_if_desc* __restrict__ descs, int n, int perWg, int localHeavy, int bd,
                                                        int cmin, int cmax, int* __restrict__ heavyCount, int* __restrict__ heavyList, int* __restrict__ nextCounters)
 {
   if (blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextCounters[threadIdx.x] = 0;       // the counter set of the next call on this stream (vvcgpu_counters)
-  __shared__ unsigned char tList[IF_WG_DESCS], sList[IF_WG_DESCS], mList[IF_WG_DESCS];
-  __shared__ int cntT, cntS, cntM;
+  __shared__ unsigned char tList[IF_WG_DESCS], sList[IF_WG_DESCS], mList[IF_WG_DESCS], hList[IF_WG_DESCS];
+  __shared__ int cntT, cntS, cntM, cntH;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   const int base = blockIdx.x * perWg;
   if (wave == 0)
@@ -195,8 +195,11 @@ __global__ __launch_bounds__(256) void if_batch_kernel(const Pel* __restrict__ s
     if (tiny) tList[__popcll(mt & below)] = (unsigned char)lane;
     if (small) sList[__popcll(ms & below)] = (unsigned char)lane;
     if (med) mList[__popcll(mm & below)] = (unsigned char)lane;
-    if (lane == 0) { cntT = (int)__popcll(mt); cntS = (int)__popcll(ms); cntM = (int)__popcll(mm); }
-    if (mh != 0ull)                                     // ONE atomic per workgroup (same-address atomics retire at ~12 ns each)
+    if (lane == 0) { cntT = (int)__popcll(mt); cntS = (int)__popcll(ms); cntM = (int)__popcll(mm); cntH = localHeavy ? (int)__popcll(mh) : 0; }
+    // localHeavy (long lists: thousands of workgroups): the workgroup serves its own heavy calls, bands of rows dealt to its four waves -- a second
+    // launch for them costs its own ~12 us of latency behind this one, a third of the call's time on a real encoder's call mix at the bench's batch size
+    if (heavy && localHeavy) hList[__popcll(mh & below)] = (unsigned char)lane;
+    if (mh != 0ull && !localHeavy)                      // ONE atomic per workgroup (same-address atomics retire at ~12 ns each)
     {
       int b = 0;
       if (lane == 0) b = atomicAdd(heavyCount, (int)__popcll(mh));
@@ -225,6 +228,13 @@ __global__ __launch_bounds__(256) void if_batch_kernel(const Pel* __restrict__ s
   {
     const vvcgpu_if_desc d = descs[base + __builtin_amdgcn_readfirstlane((int)mList[k])];
     if_one<64>(d, srcBase, dstBase, lane, true, bd, cmin, cmax);
+  }
+  const int nH = cntH;
+  for (int k = 0; k < nH; k++)
+  {
+    const vvcgpu_if_desc d = descs[base + __builtin_amdgcn_readfirstlane((int)hList[k])];
+    const int br = if_filter_band_rows(d.w, d.h);
+    for (int r0 = ((wave + k) & 3) * br; r0 < d.h; r0 += 4 * br) if_one<64>(d, srcBase, dstBase, lane, true, bd, cmin, cmax, r0, r0 + br);
   }
 }
 // one wave per (heavy call, band of rows)
@@ -891,9 +901,14 @@ int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_
   VVC_CHECK_ARG(n < (1 << 27), "if_batch: n %d", n);
   int perWg = IF_WG_DESCS;                                // fewer descriptors per workgroup when 64 would leave compute units without one
   while (perWg > 16 && cdiv(n, perWg) < 4096) perWg >>= 1;
-  hipLaunchKernelGGL(if_batch_kernel, dim3(cdiv(n, perWg)), dim3(256), 0, st, src_base, dst_base, descs, n, perWg,
+  static const int localMode = getenv("VVCGPU_IF_LOCAL_HEAVY") ? atoi(getenv("VVCGPU_IF_LOCAL_HEAVY")) : -1;   // A/B timing switch
+  // few calls: a heavy one may be most of the work of the whole launch -> bands over the machine; very many calls: the second launch is amortised and its
+  // machine-wide bands beat a workgroup's four waves (real call mix: 0.042 -> 0.038 ms at 30 k calls, 0.093 -> 0.110 at 121 k)
+  const int localHeavy = localMode < 0 ? (n >= 8192 && n < 65536) : localMode != 0;
+  hipLaunchKernelGGL(if_batch_kernel, dim3(cdiv(n, perWg)), dim3(256), 0, st, src_base, dst_base, descs, n, perWg, localHeavy,
                      bit_depth, clp_min, clp_max, counters + VVC_CTR_INTS * cur, heavyList, counters + VVC_CTR_INTS * (cur ^ 1));
-  hipLaunchKernelGGL(if_heavy_kernel, dim3(1024), dim3(256), 0, st, src_base, dst_base, descs, bit_depth, clp_min, clp_max, counters + VVC_CTR_INTS * cur, heavyList);
+  if (!localHeavy)
+    hipLaunchKernelGGL(if_heavy_kernel, dim3(1024), dim3(256), 0, st, src_base, dst_base, descs, bit_depth, clp_min, clp_max, counters + VVC_CTR_INTS * cur, heavyList);
   VVC_LAUNCH_CHECK_COUNTERS(st);
   return VVCGPU_OK;
 }
