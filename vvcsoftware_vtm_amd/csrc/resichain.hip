@@ -5,8 +5,8 @@
 // The separate entry points (vvcgpu_pelop_batch / tr_fwd / quant / dequant_tr_inv / pelop) move the residual, the coefficients and the
 // de-quantised coefficients through HBM five times; here they stay in registers / LDS, the levels and the reconstruction are written once.
 //
-// Three kernels behind one entry point, fed by a device-side classification of the descriptor list:
-//   * 16 / 32 / 64 squared: ONE WAVE PER TU, all four 1-D stages on the matrix cores.  v_mfma_f32_16x16x32_f16 accumulates in f32, which is
+// One chain launch (+ a generic launch for what it cannot take) behind the entry point, fed by a device-side classification of the descriptor list:
+//   * both sides in 16 / 32 / 64: ONE WAVE PER TU, all four 1-D stages on the matrix cores.  v_mfma_f32_16x16x32_f16 accumulates in f32, which is
 //     exact for integers below 2^24: the matrix entries (|c| <= 362) and the residual (|x| <= 1023) are exact f16 values and a 64-term row sum
 //     stays below 2^24; the 16-bit intermediates of the later stages are split into two signed 8-bit limbs (t = 256 hi + lo), one MFMA chain per
 //     limb, recombined in int32 with the reference's rounding shift and clipping.  The result tile of one stage is the operand of the next
@@ -14,9 +14,13 @@
 //     that row index, and the k order of an MFMA is free as long as both operands agree -- so the matrix operand is read from LDS in the
 //     k order the result registers already have.  (forward: M1 = X Th^T, C = Tv M1; inverse: Y1^T = Cq^T Tv, R^T = Th^T Y1^T: every product
 //     sums over the row index of the previous result.)
-//   * 4 x 4 and 8 x 8: lane groups of 4 / 8 lanes per TU (16 / 8 TUs per wave), integer multiply-adds, the two transposes through wave-private LDS.
-//   * every other shape (rectangles, 2-wide chroma): generic wave-per-TU path through LDS buffers (correct for every W x H in 2..64, slow).
-// The quantiser works in the layout all three produce -- a lane holds four vertically consecutive coefficients of one column, an aligned quad
+//   * a 16- / 32- / 64-point side with an 8- or 4-point one (round 4): PACKED tiles -- two or four TUs share one matrix-core multi-tile, the short
+//     stages as block-diagonal products (rc_tile_packed, rc_tile_packed_wl / _hl below).
+//   * 8 x 8, 8 x 4, 4 x 8, 4 x 4: lane groups of 8 / 4 lanes per TU (8 / 16 TUs per wave), integer multiply-adds, the two transposes through wave-private LDS.
+//   * what is left (2-wide chroma TUs; TUs whose residual leaves +-1023): generic wave-per-TU path through LDS buffers (correct for every W x H in 2..64, slow).
+// Every body takes a compile-time MODE: the chain, or its forward / inverse half alone -- vvcgpu_tr_fwd_batch / vvcgpu_tr_inv_batch run long calls through
+// the same kernel (vvcgpu_tr_chain_launch).
+// The quantiser works in the layout all of them produce -- a lane holds four vertically consecutive coefficients of one column, an aligned quad
 // of lanes holds a 4x4 coefficient group: sign bit hiding is decided per quad with DPP quad permutes.
 #include "common.h"
 #include "mfma_tr.h"
