@@ -516,7 +516,8 @@ typedef struct vvcgpu_tz_pu {
   int32_t pos_x, pos_y, pred_hor, pred_ver;
   int16_t w, h, sub_shift, flags;
   int32_t reserved[2];                  /* reserved[0] > 0: this PU's own search range (m_aaiAdaptSR[list][refIdx]: the adaptive search range is per
-                                           reference picture), 0: cfg.search_range; a batch may then mix the (list, reference) searches of one PU.
+                                           reference picture), 0: cfg.search_range; a batch may then mix the (list, reference) searches of one PU.  Must not exceed
+                                           cfg.search_range (the caller passes the maximum over the batch there); a larger value is clamped to it.
                                            reserved[1]: 0.  sizeof == 64 */
 } vvcgpu_tz_pu;
 typedef struct vvcgpu_tz_cfg {

@@ -321,6 +321,20 @@ void vtmref_pelop(int simd, int op, const Pel* s0, int st0, const Pel* s1, int s
   else (w8 ? o.linTf8 : o.linTf4)(s0, st0, dst, dstStride, w, h, scale, shift, offset, clp, clip);
 }
 
+// The plane arithmetic that is NOT in the table: AreaBuf<Pel>::subtract (Buffer.h:321-339; op 3: dst = s0 - s1), ::removeHighFreq
+// (Buffer.h:389-436 / the SIMD form it selects itself; op 4: dst = 2 s0 - s1, clipped when `clip`) and ::copyClip (Buffer.cpp:198-222; op 5).
+// subtract / removeHighFreq work in place on the destination, which is first filled with s0 by the reference's own copyFrom.
+void vtmref_pelop_area(int op, const Pel* s0, int st0, const Pel* s1, int st1, Pel* dst, int dstStride, int w, int h, int clip, int bd, int clpMin, int clpMax)
+{
+  ClpRng clp = mkClp(clpMin, clpMax, bd);
+  PelBuf d(dst, dstStride, w, h);
+  const CPelBuf a(s0, st0, w, h);
+  if (op == 5) { d.copyClip(a, clp); return; }
+  d.copyFrom(a);
+  if (op == 3) d.subtract(CPelBuf(s1, st1, w, h));
+  else d.removeHighFreq(PelBuf(const_cast<Pel*>(s1), st1, w, h), clip != 0, clp);
+}
+
 // ---------------------------------------------------------------------------------------------
 // Transforms.  The 2-D entry points are the reference's free functions xTrMxN_EMT / xITrMxN_EMT (TrQuant.cpp:138-310),
 // i.e. exactly what TrQuant::xT / xIT call (:694-791).  trHor/trVer: 0 DCT2, 1 DCT8, 2 DST7 (TransType, TypeDef.h:402-410);

@@ -558,8 +558,71 @@ def gen_rdoq():
     save("rdoq", rows=np.array(rows, np.float64), coef=np.concatenate(coefs), level=np.concatenate(levels), rates=np.array(rates, RATES))
 
 
+def gen_pelop():
+    """B1-B4: the reference's own PelBufferOps table (addAvg / reco / linTf, scalar and the SIMD set it installs itself) and the
+    AreaBuf arithmetic that is not in the table (subtract, removeHighFreq, copyClip) -- every op x widths x 8 / 10 bit x clip on / off.  Rows:
+    (op, w, h, bd, clip, scale, shift, offset, clp_min, clp_max, x0, y0, x1, y1, out offset); sources are windows of two shared planes."""
+    rng = np.random.default_rng(1014)
+    out = {}
+    H, W = 160, 192
+    for bd in (8, 10):
+        mx = (1 << bd) - 1
+        pel = cases.rand_plane(rng, H, W, bd, "uniform")                                   # picture samples
+        inter = rng.integers(-8192, 8192 + mx * 16, (H, W)).astype(np.int16)               # 14-bit first-stage values (addAvg inputs)
+        resi = rng.integers(-mx, mx + 1, (H, W)).astype(np.int16)                          # residual samples
+        out.update({"pel%d" % bd: pel, "inter%d" % bd: inter, "resi%d" % bd: resi})
+        rows, outs = [], []
+        pos = 0
+        for op in range(6):
+            widths = [4, 8, 12, 16, 24, 32, 64, 128] if op < 3 else [2, 4, 6, 8, 12, 16, 24, 32, 64, 128]
+            for w in widths:
+                for h in (2, 4, 8, 16, 128) if w < 64 else (4, 64, 128):
+                    for clip in (0, 1):
+                        if op in (0, 1, 3, 5) and clip == 0 and op != 3:
+                            continue                                                       # addAvg / reco / copyClip always clip
+                        if op == 3 and clip == 1:
+                            continue                                                       # subtract never clips
+                        x0, y0 = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+                        x1, y1 = int(rng.integers(0, W - w + 1)), int(rng.integers(0, H - h + 1))
+                        cmin, cmax = (0, mx) if rng.random() < 0.7 else (int(rng.integers(0, 40)), mx - int(rng.integers(0, 40)))
+                        scale = shift = offset = 0
+                        if op == 0:
+                            a, b = inter, inter
+                            shift = max(2, 14 - bd) + 1
+                            offset = (1 << (shift - 1)) + 2 * 8192
+                        elif op == 1:
+                            a, b = pel, resi
+                        elif op == 2:
+                            a, b = pel, pel
+                            scale, shift, offset = int(rng.integers(-40, 41)), int(rng.integers(0, 7)), int(rng.integers(-64, 65))
+                            if not clip:                                                   # an unclipped result beyond int16 is outside the domain: the reference's
+                                scale = int(rng.integers(-30, 31))                         # SIMD form saturates there, its scalar form wraps (measured: gen asserts equality)
+                        elif op == 3:
+                            a, b = pel, pel
+                        elif op == 4:
+                            a, b = pel, pel
+                        else:
+                            a, b = resi, resi                                              # copyClip of out-of-range samples
+                        d = np.full((h, w), -31000, np.int16)
+                        a0 = C.c_void_p(a.ctypes.data + 2 * (y0 * W + x0))
+                        b0 = C.c_void_p(b.ctypes.data + 2 * (y1 * W + x1))
+                        if op < 3:
+                            d2 = d.copy()
+                            R.vtmref_pelop(1, op, a0, W, b0, W, p(d), w, w, h, scale, shift, offset, clip, bd, cmin, cmax)
+                            R.vtmref_pelop(0, op, a0, W, b0, W, p(d2), w, w, h, scale, shift, offset, clip, bd, cmin, cmax)
+                            assert np.array_equal(d, d2), ("reference SIMD != scalar", op, w, h, bd)
+                        else:
+                            R.vtmref_pelop_area(op, a0, W, b0, W, p(d), w, w, h, clip, bd, cmin, cmax)
+                        rows.append((op, w, h, bd, clip, scale, shift, offset, cmin, cmax, x0, y0, x1, y1, pos))
+                        outs.append(d.reshape(-1))
+                        pos += d.size
+        out["rows%d" % bd] = np.array(rows, np.int32)
+        out["out%d" % bd] = np.concatenate(outs)
+    save("pelop", **out)
+
+
 if __name__ == "__main__":
     only = sys.argv[1:]
-    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_rdpcm, gen_affine_mv, gen_frac, gen_tzsearch, gen_picture, gen_intra, gen_imv, gen_quant, gen_depquant, gen_rdoq):
+    for fn in (gen_alf, gen_sao, gen_dist, gen_interp, gen_transform, gen_tskip, gen_dequant, gen_affine, gen_rdpcm, gen_affine_mv, gen_frac, gen_tzsearch, gen_picture, gen_intra, gen_imv, gen_quant, gen_depquant, gen_rdoq, gen_pelop):
         if not only or fn.__name__[4:] in only:
             fn()

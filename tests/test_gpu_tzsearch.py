@@ -234,3 +234,22 @@ def test_tz_search_per_pu_range(w, h, split):
         cfg["reserved"] = (h << 16) | w
     got = run_gpu(org, ref_, pus, cfg)
     assert np.array_equal(got, want), np.nonzero(got != want)[0][:8]
+
+
+@pytest.mark.parametrize("split", [0, 1])
+def test_tz_search_per_pu_range_beyond_cfg_is_clamped(split):
+    """A per-PU range above cfg.search_range is outside the contract (include/vvcgpu.h: the caller passes the batch maximum in cfg); the kernel clamps
+    it to cfg.search_range instead of walking a raster the split form's launch was not sized for."""
+    rng = np.random.default_rng(77 + split)
+    W, H, M, bd = 448, 320, 160, 10
+    w = h = 16
+    org, ref_ = cases.tz_planes(rng, W, H, M, bd, motion=(7, -5))
+    n = 120
+    pus = cases.tz_pus(rng, n, W, H, M, [(w, h)], sub_mode2=True)
+    cfg = cases.tz_cfg(W, H, M, 23.5, search_range=32)
+    want = run_oracle(org, ref_, pus, cfg)                       # every PU at the cfg range
+    pus["reserved"][:, 0] = rng.choice([96, 64, 33, 32, 0], size=n)
+    if split:
+        cfg["reserved"] = (h << 16) | w
+    got = run_gpu(org, ref_, pus, cfg)
+    assert np.array_equal(got, want), np.nonzero(got != want)[0][:8]

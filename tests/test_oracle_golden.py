@@ -504,3 +504,37 @@ def test_deblock_golden():
         assert not np.array_equal(Y, r["pre"][0])
         for got, want, name in zip((Y, Cb, Cr), r["post"], "Y Cb Cr".split()):
             assert np.array_equal(got, want), "poc %d %s: %d samples differ" % (h["poc"], name, int((got != want).sum()))
+
+
+PELOP_DESC = np.dtype([("src0_off", "<i8"), ("src1_off", "<i8"), ("dst_off", "<i8"), ("src0_stride", "<i4"),
+                       ("src1_stride", "<i4"), ("dst_stride", "<i4"), ("w", "<i2"), ("h", "<i2")])
+
+
+class _PelopCfg(C.Structure):
+    _fields_ = [("scale", C.c_int32), ("shift", C.c_int32), ("offset", C.c_int32), ("clip", C.c_int32),
+                ("clp_min", C.c_int32), ("clp_max", C.c_int32)]
+
+
+def pelop_cases(g, bd):
+    """(op, source planes, one-descriptor list, config, expected block) per row of tests/golden/pelop.npz"""
+    W = g["pel%d" % bd].shape[1]
+    src = {0: ("inter", "inter"), 1: ("pel", "resi"), 2: ("pel", "pel"), 3: ("pel", "pel"), 4: ("pel", "pel"), 5: ("resi", "resi")}
+    exp = g["out%d" % bd]
+    for (op, w, h, bd_, clip, scale, shift, offset, cmin, cmax, x0, y0, x1, y1, pos) in g["rows%d" % bd]:
+        a, b = (g[n + str(bd)] for n in src[int(op)])
+        d = np.array([(y0 * W + x0, y1 * W + x1, 0, W, W, w, w, h)], dtype=PELOP_DESC)
+        yield int(op), a, b, d, _PelopCfg(int(scale), int(shift), int(offset), int(clip), int(cmin), int(cmax)), exp[pos:pos + w * h]
+
+
+def test_pelop_golden():
+    """B1-B4: orc_pelop_batch == the reference's PelBufferOps table (addAvg / reco / linTf) and AreaBuf subtract / removeHighFreq / copyClip."""
+    g = load("pelop")
+    O = oracle()
+    n = 0
+    for bd in (8, 10):
+        for op, a, b, d, cfg, want in pelop_cases(g, bd):
+            got = np.full(want.size, -77, np.int16)
+            O.orc_pelop_batch(op, p(a), p(b), p(got), p(d), 1, C.byref(cfg))
+            assert np.array_equal(got, want), (op, bd, d)
+            n += 1
+    assert n > 500

@@ -16,10 +16,11 @@ void vvcgpu_set_error(const char* fmt, ...)
 
 // ---- per-(device, stream) resources: scratch buffer + two persistent zeroed counter sets.  One table behind one mutex; slots are created on
 // first use, released by vvcgpu_stream_release (a host that makes streams per job calls it before destroying the stream) or all at once by
-// vvcgpu_shutdown.  A buffer that has been outgrown is NOT freed on the spot -- work queued on the stream may still read it -- but parked in the
-// slot's retired list behind an event recorded on the stream; a later vvcgpu_scratch call on the slot frees the retired buffers whose event has
-// completed.  Capacity grows geometrically (at least doubling), so a stream whose batches grow slowly re-allocates O(log n) times and never holds
-// more than about twice its largest request.  (A stream is driven by one host thread at a time: per-thread streams, include/vvcgpu.h.)
+// vvcgpu_shutdown.  A buffer that has been outgrown is NOT freed on the spot -- work queued on the stream may still read it, and hipFree is a
+// device-wide synchronisation -- but parked in the slot's retired list and freed with the slot.  Capacity grows geometrically (at least doubling),
+// so a stream whose batches grow slowly re-allocates O(log n) times and the parked buffers sum to less than the live one: a slot never holds more
+// than about four times its largest request.  No entry point synchronises the device or another thread's stream while it holds the table's mutex.
+// (A stream is driven by one host thread at a time: per-thread streams, include/vvcgpu.h.)
 #include <vector>
 namespace {
 struct StreamSlot
@@ -27,7 +28,7 @@ struct StreamSlot
   int device; hipStream_t stream;
   void* ptr; size_t cap;                  // scratch
   struct Retired { void* ptr; hipEvent_t done; };
-  std::vector<Retired> retired;           // outgrown scratch buffers: freed once `done` (recorded on the stream at retirement) has completed, or with the slot
+  std::vector<Retired> retired;           // outgrown scratch buffers: freed with the slot
   int* counters; int cur; bool dirty;     // int[2][16]; dirty: a launch that owned a set failed -- both sets are cleared before the next use
 };
 std::vector<StreamSlot> g_slots;
@@ -41,7 +42,7 @@ StreamSlot* find_slot(int dev, hipStream_t stream, bool create)
   g_slots.push_back(StreamSlot{ dev, stream, nullptr, 0, {}, nullptr, 0, false });
   return &g_slots.back();
 }
-void free_slot(StreamSlot& s)             // caller holds the mutex, the slot's device is current, its stream is idle
+void free_slot(StreamSlot& s)             // the slot is out of the table (or the caller holds the mutex at shutdown), its device is current, its stream is idle
 {
   if (s.ptr) (void)hipFree(s.ptr);
   for (auto& q : s.retired) { (void)hipFree(q.ptr); if (q.done) (void)hipEventDestroy(q.done); }
@@ -56,17 +57,6 @@ void* vvcgpu_scratch(hipStream_t stream, size_t bytes)
   if (hipGetDevice(&dev) != hipSuccess) { vvcgpu_set_error("hipGetDevice failed"); return nullptr; }
   std::lock_guard<std::mutex> lock(g_slotMutex);
   StreamSlot* slot = find_slot(dev, stream, true);
-  for (size_t i = 0; i < slot->retired.size(); )               // retired buffers whose last reader has finished
-  {
-    auto& q = slot->retired[i];
-    if (!q.done || hipEventQuery(q.done) == hipSuccess)
-    {
-      (void)hipFree(q.ptr);
-      if (q.done) (void)hipEventDestroy(q.done);
-      slot->retired.erase(slot->retired.begin() + (ptrdiff_t)i);
-    }
-    else i++;
-  }
   if (slot->cap < bytes)
   {
     size_t cap = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
@@ -74,20 +64,14 @@ void* vvcgpu_scratch(hipStream_t stream, size_t bytes)
     void* p = nullptr;
     if (hipMalloc(&p, cap) != hipSuccess)
     {
+      (void)hipGetLastError();                                  // the failed attempt must not surface at the caller's next launch check
       cap = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1); // the doubled size did not fit: the request itself
-      if (hipMalloc(&p, cap) != hipSuccess) { vvcgpu_set_error("scratch: hipMalloc(%zu) failed", cap); return nullptr; }
+      if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); vvcgpu_set_error("scratch: hipMalloc(%zu) failed", cap); return nullptr; }
     }
-    if (slot->ptr)                                              // queued work on the stream may still read it: parked behind an event
-    {
-      StreamSlot::Retired r{ slot->ptr, nullptr };
-      if (hipEventCreateWithFlags(&r.done, hipEventDisableTiming) != hipSuccess || hipEventRecord(r.done, stream) != hipSuccess)
-      {
-        if (r.done) (void)hipEventDestroy(r.done);
-        r.done = nullptr;
-        (void)hipStreamSynchronize(stream);                     // no event: wait here, then the buffer is free on the next call
-      }
-      slot->retired.push_back(r);
-    }
+    // The outgrown buffer: queued work on the stream may still read it, and hipFree synchronises the whole device -- neither belongs on a
+    // hot path.  It is parked in the slot and freed with it (vvcgpu_stream_release / vvcgpu_shutdown).  Capacities at least double, so the
+    // parked buffers of a slot sum to less than its current capacity.
+    if (slot->ptr) slot->retired.push_back(StreamSlot::Retired{ slot->ptr, nullptr });
     slot->ptr = p; slot->cap = cap;
   }
   return slot->ptr;
@@ -200,20 +184,28 @@ int vvcgpu_stream_release(void* stream)
 {
   int dev = 0;
   VVC_HIP(hipGetDevice(&dev));
-  std::lock_guard<std::mutex> lock(g_slotMutex);
   // the slot of this stream handle -- on the current device first, else on whichever device holds one (a stream belongs to one device; the caller
-  // may have switched devices since it used the stream)
-  size_t hit = g_slots.size();
-  for (size_t i = 0; i < g_slots.size(); i++)
-    if (g_slots[i].stream == (hipStream_t)stream && (g_slots[i].device == dev || hit == g_slots.size())) { hit = i; if (g_slots[i].device == dev) break; }
-  if (hit == g_slots.size()) return VVCGPU_OK;                              // nothing held for this stream
-  const int sdev = g_slots[hit].device;
+  // may have switched devices since it used the stream).  Looked up under the lock; the drain of the stream runs WITHOUT it (other threads' entry
+  // points keep going); the slot is taken out of the table under the lock again and freed outside it.
+  int sdev = -1;
+  {
+    std::lock_guard<std::mutex> lock(g_slotMutex);
+    for (auto& s : g_slots)
+      if (s.stream == (hipStream_t)stream && (s.device == dev || sdev < 0)) { sdev = s.device; if (s.device == dev) break; }
+  }
+  if (sdev < 0) return VVCGPU_OK;                                           // nothing held for this stream
   if (sdev != dev) VVC_HIP(hipSetDevice(sdev));
   const hipError_t e = hipStreamSynchronize((hipStream_t)stream);           // queued work may still read the buffers
   if (e == hipSuccess)
   {
-    free_slot(g_slots[hit]);
-    g_slots.erase(g_slots.begin() + (ptrdiff_t)hit);
+    StreamSlot taken{ sdev, nullptr, nullptr, 0, {}, nullptr, 0, false };
+    bool found = false;
+    {
+      std::lock_guard<std::mutex> lock(g_slotMutex);
+      for (size_t i = 0; i < g_slots.size(); i++)
+        if (g_slots[i].stream == (hipStream_t)stream && g_slots[i].device == sdev) { taken = g_slots[i]; g_slots.erase(g_slots.begin() + (ptrdiff_t)i); found = true; break; }
+    }
+    if (found) free_slot(taken);
   }
   if (sdev != dev) (void)hipSetDevice(dev);
   if (e != hipSuccess) { vvcgpu_set_error("stream_release: hipStreamSynchronize failed on device %d: %s (resources kept)", sdev, hipGetErrorString(e)); return VVCGPU_E_DEVICE; }

@@ -500,7 +500,7 @@ __global__ __launch_bounds__(256) void tz_search_kernel(const Pel* __restrict__ 
   }
 
   const bool ext = (pu.flags & VVCGPU_TZ_EXTENDED) != 0, fast = (pu.flags & VVCGPU_TZ_FAST) != 0;
-  const int rasterStep = fast ? 8 : 5, range = pu.reserved[0] > 0 ? pu.reserved[0] : cfg.search_range;   // per-PU range: the adaptive search range is per reference picture
+  const int rasterStep = fast ? 8 : 5, range = pu.reserved[0] > 0 ? min(pu.reserved[0], cfg.search_range) : cfg.search_range;   // per-PU range (the adaptive search range is per reference picture), never beyond cfg.search_range: the split form sizes its raster launch from that
 
   int mx = pu.start_x, my = pu.start_y;
   s.clip(mx, my); mx = (mx + 2) >> 2; my = (my + 2) >> 2;

@@ -1411,8 +1411,11 @@ struct DevDpb                                // reference pictures resident on t
 {
   vvc_pel* plane = nullptr; int stride = 0, slotRows = 0, nSlots = 0;
   struct Slot { const Pel* hostOrigin = nullptr; int poc = -1 << 30; long stamp = 0; };
-  std::vector<Slot> slots; long clock = 0;
-  // row offset of the slot that holds the padded luma plane starting at `padOrigin` (stride x rows samples); uploads it on a miss
+  std::vector<Slot> slots; long clock = 0, sessionStart = 0;
+  void beginSession() { sessionStart = clock + 1; }          // slots touched from here on belong to the batch being built: never evicted by it
+  // row offset of the slot that holds the padded luma plane starting at `padOrigin` (stride x rows samples); uploads it on a miss.
+  // -1: every slot is already used by the batch being built (more distinct reference pictures in one PU than slots): the caller leaves the CU
+  // to the per-call path -- an earlier vvcgpu_tz_pu of the batch points into the slot an eviction would overwrite.
   int slotRow(const Pel* padOrigin, int poc, int strideH, int rows)
   {
     if (!plane || strideH != stride || rows != slotRows)
@@ -1430,6 +1433,7 @@ struct DevDpb                                // reference pictures resident on t
     }
     if (hit < 0)
     {
+      if (slots[lru].stamp >= sessionStart && sessionStart > 0 && slots[lru].stamp > 0) return -1;
       hit = lru;
       VVCGPU(vvcgpu_memcpy_h2d(plane + (size_t)hit * slotRows * stride, padOrigin, (size_t)stride * slotRows * sizeof(vvc_pel), nullptr));
       slots[hit].hostOrigin = padOrigin; slots[hit].poc = poc;
@@ -1492,6 +1496,7 @@ void mePrepass(InterSearch* self, CodingUnit& cu)
   self->m_pcRdCost->selectMotionLambda(cu.transQuantBypass);                 // as predInterSearch does before its searches (:852)
   self->m_lumaClpRng = slice.clpRng(COMPONENT_Y);
   auto blkCache = dynamic_cast<CacheBlkInfoCtrl*>(self->m_modeCtrl);
+  g_dpb.beginSession();
   const int numDir = slice.isInterP() ? 1 : 2;
   const int8_t mvpIdx0 = pu.mvpIdx[0], mvpIdx1 = pu.mvpIdx[1], mvpNum0 = pu.mvpNum[0], mvpNum1 = pu.mvpNum[1];
   std::vector<vvcgpu_tz_pu> pus;
@@ -1522,6 +1527,7 @@ void mePrepass(InterSearch* self, CodingUnit& cu)
         { g_why[8]++; g_me.e.clear(); goto done; }
         const int rows = (int)refY.height + 2 * margin;
         const int slot = g_dpb.slotRow(refY.buf - (ptrdiff_t)margin * refY.stride - margin, refPic->getPOC(), (int)refY.stride, rows);
+        if (slot < 0) { g_why[11]++; g_me.e.clear(); goto done; }
         vvcgpu_tz_pu p;
         memset(&p, 0, sizeof p);
         p.org_x = pos.x; p.org_y = pos.y; p.ref_x = margin + pos.x; p.ref_y = slot + margin + pos.y;

@@ -98,7 +98,8 @@ class Workload:
         self.fused_resi = fused_resi                   # residual chain as ONE pass (vvcgpu_resi_chain_batch) or as its five separate entry points
         # integer ME as ONE hierarchical launch (vvcgpu_me_hier_search: every 16x16 SAD once, 32x32 / 64x64 by addition, raster and +-4 grid from
         # the same LDS window) or as six per-size searches (vvcgpu_sad_search): same results
-        self.hier_me = bool(hier_me) and tuple(sorted(me_sizes)) == (16, 32, 64) and raster_range <= 99
+        # (the entry's own preconditions, csrc/mehier.hip: at most 39 raster columns, and the raster's window must contain the +-4 grid's: 5 (R // 5) >= 4 + 15)
+        self.hier_me = bool(hier_me) and tuple(sorted(me_sizes)) == (16, 32, 64) and raster_range <= 99 and 5 * (raster_range // 5) >= 19
         self.qp = qp                                   # base QP (BASELINE configs: 22 / 27 / 32 / 37); quantiser, de-quantiser and the deblocking QP field follow it
         rng = np.random.default_rng(seed)
         frames = synth.gen_yuv(width, height, 3, bit_depth, seed)
