@@ -11,6 +11,8 @@
 // sliding-window vertical pass (one LDS read per output sample) and consumed immediately by the Hadamard
 // (tile row per lane, vertical butterflies with wave shuffles).  Nothing but the 32-byte result leaves the CU.
 #include "common.h"
+#include "mfma_tr.h"
+#include <mutex>
 
 namespace {
 
@@ -529,25 +531,19 @@ __device__ __forceinline__ void f16_best(const unsigned* dist, bool quarter, con
   bdist = dist[bi];
 }
 
+// LDS of one wave of the vector-pipe form
+struct F16Lds { short win[24 * 26]; short hpl[3][24 * 18]; unsigned dist[16]; };      // hpl: [0] integer plane, [1] half plane (17 cols), [2] quarter planes
+
+// one PU on the vector pipes (the round-2..4 form): the whole kernel when HAD is off; with HAD on, the PUs the matrix-core form below cannot take
 template <bool HAD>
-__global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
-                                                     const vvcgpu_frac_blk* __restrict__ blocks, int nblocks, int bd, int cmin, int cmax,
-                                                     vvcgpu_mvcost mv, const int* __restrict__ preds,
-                                                     vvcgpu_frac_result* __restrict__ results, int nWg, int xcd)
+__device__ __forceinline__ void frac16_pu_valu(F16Lds& L, const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
+                                               const vvcgpu_frac_blk& blk, int b, int bd, int cmin, int cmax, const vvcgpu_mvcost& mv,
+                                               vvcgpu_frac_result* __restrict__ results, int lane)
 {
-  __shared__ __align__(16) short winS[4][24 * 26];
-  __shared__ __align__(16) short hplS[4][3][24 * 18];      // [0] integer plane, [1] half plane (17 cols), [2] quarter planes
-  __shared__ unsigned distS[4][16];                        // candidate distortions of the current stage (wave-uniform values)
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int wg = vvc_xcd_index((int)blockIdx.x, nWg, xcd);
-  const int b = wg * 4 + wave;
-  if (wg < 0 || b >= nblocks) return;                       // no workgroup barrier below
-  short* win = winS[wave];
-  short* hp0 = hplS[wave][0];
-  short* hp8 = hplS[wave][1];
-  short* hpq = hplS[wave][2];
-  const vvcgpu_frac_blk blk = blocks[b];
-  if (preds) { mv.pred_hor = preds[2 * b]; mv.pred_ver = preds[2 * b + 1]; }
+  short* win = L.win;
+  short* hp0 = L.hpl[0];
+  short* hp8 = L.hpl[1];
+  short* hpq = L.hpl[2];
   const int t = lane >> 4, x = 8 * (t & 1) + (lane & 7), y0 = 8 * (t >> 1) + 4 * ((lane >> 3) & 1);
   int orgv[4];
   {
@@ -570,7 +566,7 @@ __global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org
   f16_hplane<true>(win, hp8, 0, 2, headRoom, lane);
   WAVE_SYNC();
 
-  unsigned* dist = distS[wave];
+  unsigned* dist = L.dist;
   F16Col col;
   int pred[4];
   // ---- half stage: quarter offsets qx, qy in {-2, 0, 2}
@@ -625,8 +621,414 @@ __global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org
     r.half_x = hx; r.half_y = hy; r.qter_x = qdx; r.qter_y = qdy; r.cost_half = costH; r.cost = costQ;
     results[b] = r;
   }
+  WAVE_SYNC();                                                // the next PU of this wave reuses the buffers
 }
 
+template <bool HAD>
+__global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
+                                                     const vvcgpu_frac_blk* __restrict__ blocks, int nblocks, int bd, int cmin, int cmax,
+                                                     vvcgpu_mvcost mv, const int* __restrict__ preds,
+                                                     vvcgpu_frac_result* __restrict__ results, int nWg, int xcd)
+{
+  __shared__ __align__(16) F16Lds ldsS[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int wg = vvc_xcd_index((int)blockIdx.x, nWg, xcd);
+  const int b = wg * 4 + wave;
+  if (wg < 0 || b >= nblocks) return;                       // no workgroup barrier below
+  const vvcgpu_frac_blk blk = blocks[b];
+  if (preds) { mv.pred_hor = preds[2 * b]; mv.pred_ver = preds[2 * b + 1]; }
+  frac16_pu_valu<HAD>(ldsS[wave], org, os, ref, rs, blk, b, bd, cmin, cmax, mv, results, lane);
+}
+
+// the PUs the matrix-core kernel below has flagged (reference samples outside the bit depth, an original that is no picture), on the vector pipes:
+// a wave looks at 64 flags and walks the set ones -- a launch that finds nothing costs a few microseconds
+__global__ __launch_bounds__(256) void frac16_flagged_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
+                                                             const vvcgpu_frac_blk* __restrict__ blocks, int nblocks, int bd, int cmin, int cmax,
+                                                             vvcgpu_mvcost mv0, const int* __restrict__ preds,
+                                                             vvcgpu_frac_result* __restrict__ results, const int* __restrict__ flags)
+{
+  __shared__ __align__(16) F16Lds ldsS[4];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int base = ((int)blockIdx.x * 4 + wave) * 64;
+  unsigned long long todo = __ballot(base + lane < nblocks && flags[min(base + lane, nblocks - 1)] != 0);
+  while (todo)
+  {
+    const int b = base + __builtin_ctzll(todo);
+    todo &= todo - 1;
+    const vvcgpu_frac_blk blk = blocks[b];
+    vvcgpu_mvcost mv = mv0;
+    if (preds) { mv.pred_hor = preds[2 * b]; mv.pred_ver = preds[2 * b + 1]; }
+    frac16_pu_valu<true>(ldsS[wave], org, os, ref, rs, blk, b, bd, cmin, cmax, mv, results, lane);
+  }
+}
+
+// ---------------------------------------------------------------------------------------------------
+// 16x16 PUs with Hadamard cost ON THE MATRIX CORES (round 5).  The vector-pipe form above runs ~2100 vector instructions per PU at an issue
+// bound of 0.95 with the matrix pipe idle; here both DCTIF passes and the x direction of the 8x8 Hadamards are exact f16 products
+// (v_mfma_f32_16x16x32_f16 / 16x16x16_f16) and the lane sums of the 8x8 tiles are f32 products (v_mfma_f32_16x16x4_f32), ~700 vector instructions
+// per PU.  One wave per PU, a result tile is the next product's operand WITHOUT leaving the lane (the trick of mfma_tr.h): an MFMA contracts the
+// index its operands hold in registers, and feeding a result tile as the A operand moves its lane index into registers.
+//   window  W[r][c], r, c = 0..23 (picture rows / columns -4..19), 10-bit samples v as f16 bit patterns 0x6400 | v (= 1024 + v: no conversion)
+//   stage A (horizontal pass, InterpolationFilter.cpp:290-379 with isLast false): plane[r][x] = (sum_k W[r][x + ix + 1 + k] c_fx[k] + off1) >> shift1
+//           = W (A operand: lane row, registers columns) x Toeplitz matrix of the taps (table TA); the accumulator starts at the constant that
+//           turns the sum into T - (S - 1) / 2, T = S (plane + 16384) + remainder, S = 2^shift1; one v_add_f32 with 2^23 S then leaves
+//           u = plane + 16384 (15 bits, unsigned) in the low mantissa bits -- round-to-nearest at that exponent IS the floor, because the offset
+//           -(S - 1) / 2 keeps every remainder off the ties.  u is split into limbs lo = u & 127, hi = u >> 7, again as 0x6400 | limb.
+//   stage B (vertical pass, isLast true): pred^T[x][y] = plane^T (A operand: the stage-A result registers as they are) x Toeplitz matrix of the
+//           taps per limb (table TB: c and 128 c, scaled by 2^-shift2; the scale is exact: powers of two).  The accumulator starts at the constant
+//           that removes the biases (1024 per limb, 16384 of u), adds the rounding offset and 1024: the result is 1024 + (sum + off2) / 2^shift2
+//           as a real number.  v_cvt_pkrtz_f16_f32 truncates: in [1024, 2048) f16 has unit spacing, so that IS the floor; values outside land
+//           outside and the packed clamp to [1024 + clpMin, 1024 + clpMax] takes them.  All partial sums stay below 2^24 in units of 2^-shift2
+//           whatever the order (largest positive part 88 x 128 x 1279 + 88 x 1151 = 14.5 M on a start value of about -8 M): exact in f32.
+//   residual d = (1024 + org) - (1024 + pred), |d| <= 1023 (PUs with other originals -- bi-predictive 2 org - otherPred -- take the vector form)
+//   Hadamard (RdCost.cpp:2205-2853, xCalcHADs8x8): over y one butterfly before the product (lane ^ 8, packed f16, |.| <= 2046 still exact),
+//           over x as a product with blockdiag(H8, H8) (the residual as A operand: y moves into registers), the remaining two y stages in
+//           registers on f32, the last of them as |a + b| + |a - b| = 2 max(|a|, |b|).
+//   tile sums: p = the lane's part of sum |coefficient| / 2; R1[x'][slot] += p x selector (slot = candidate + 8 (tile row)), one product per
+//           candidate into ONE accumulator for the eight candidates of a stage; at the end of the stage four registers are added, a second
+//           product adds the lane groups of a tile column, SATD tile = (P + 1) >> 1 (= (2 P + 2) >> 2), and a row_ror:8 adds the tile rows:
+//           lane i then holds the distortion of candidate i, which is where the arg-min wants it.
+constexpr int FM_MAT = 512;                                  // halves per lane-indexed operand image (64 lanes x 8)
+constexpr int FM_NA = 7, FM_NB = 14;                         // TA: (fx, ix) in {(0,0), (1,-1), (1,0), (2,-1), (2,0), (3,-1), (3,0)}; TB: the same seven (fy, iy) x two row chunks
+constexpr int FM_TAB_HALVES = (FM_NA + FM_NB) * FM_MAT;
+typedef _Float16 fh2 __attribute__((ext_vector_type(2)));
+
+// result column slot n of stage B -> sample row y: slot bit 3 = y bit 2 (the partner of the lane ^ 8 butterfly), bit 2 = y bit 3 (the tile row)
+__host__ __device__ constexpr int fm_ymap(int n) { return (n & 3) | (((n >> 3) & 1) << 2) | (((n >> 2) & 1) << 3); }
+__host__ __device__ constexpr int fm_combo(int f, int i) { return f == 0 ? 0 : 1 + (f - 1) * 2 + (i + 1); }     // (phase f in quarter samples, integer offset i in {-1, 0})
+__host__ __device__ constexpr int fm_idx(int dx, int dy, bool quarter)                                           // f16_idx as a constant expression
+{
+  return dx == 0 ? (dy == 0 ? 0 : dy < 0 ? 1 : 2)
+       : !quarter ? (dx < 0 ? (dy == 0 ? 3 : dy < 0 ? 5 : 7) : (dy == 0 ? 4 : dy < 0 ? 6 : 8))
+                  : (dx < 0 ? (dy < 0 ? 3 : dy == 0 ? 5 : 7) : (dy < 0 ? 4 : dy == 0 ? 6 : 8));
+}
+
+__global__ void fm_build_tables_kernel(_Float16* __restrict__ tab, int shift2)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= FM_TAB_HALVES) return;
+  const int mat = i / FM_MAT, lane = (i % FM_MAT) >> 3, e = i & 7, c16 = lane & 15, g = lane >> 4;
+  float v = 0.f;
+  if (mat < FM_NA)
+  {
+    const int fx = mat == 0 ? 0 : 1 + ((mat - 1) >> 1), ix = mat == 0 ? 0 : ((mat - 1) & 1) - 1;
+    const int t = 8 * g + e - (c16 + ix + 1);                // window column k = 8 g + e, output column x = c16
+    if (g < 3 && t >= 0 && t <= 7) v = (float)c_lumaF[fx << 2][t];
+    // k = 24, 25 meet the constant 1.0 the window operand carries there: the start value 8192 S - 65536 - (S - 1) / 2 of the sum, in two exact pieces
+    const float S = (float)(1 << (12 - shift2));
+    if (g == 3 && e == 0) v = 8192.f * S - 65536.f;
+    if (g == 3 && e == 1) v = -0.5f * (S - 1.f);
+  }
+  else
+  {
+    const int m = mat - FM_NA, cb = m >> 1, ch = m & 1;
+    const int fy = cb == 0 ? 0 : 1 + ((cb - 1) >> 1), iy = cb == 0 ? 0 : ((cb - 1) & 1) - 1;
+    const int t = 16 * ch + 4 * g + (e & 3) - (fm_ymap(c16) + iy + 1);   // plane row 16 ch + 4 g + (e & 3), limb e >> 2
+    if (t >= 0 && t <= 7) v = (float)c_lumaF[fy << 2][t] * (e >= 4 ? 128.f : 1.f) / (float)(1 << shift2);
+    // rows 24, 25 of the plane do not exist: their operand slots carry 1.0, and these two the start value of the sum (bias removal + rounding offset + 1024)
+    // as an f16 value and its exact remainder
+    if (ch == 1 && g == 2 && e < 2)
+    {
+      const float cinB = (float)(-8454144 - 1048576 + (1 << (shift2 - 1)) + (OFFS << 6) + (1024 << shift2)) / (float)(1 << shift2);
+      const float p1 = (float)(_Float16)cinB;
+      v = e == 0 ? p1 : cinB - p1;
+    }
+  }
+  tab[i] = (_Float16)v;
+}
+
+template <int T> __device__ __forceinline__ float fm_sel(float sel0)
+{
+  if (T == 0) return sel0;
+  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sel0), 0x120 + (T ? T : 1), 0xF, 0xF, true));   // row_ror:T (every lane has a source: no old value to set up)
+}
+
+struct FmPu                                                 // per-PU operands that every candidate shares
+{
+  h8 wA[2];                                                 // window rows 16 ch + (lane & 15) (clamped to 23), columns 8 min(g, 2) .. + 7, biased
+  fh2 o2[2];                                                // 1024 + original, row fm_ymap(lane & 15), columns 4 g .. 4 g + 3
+};
+struct FmK                                                  // wave constants (lane-varying ones in vector registers: v_and_or_b32 takes them as they are)
+{
+  float magicA, sel0, asel;
+  fh2 pmin, pmax, sg;
+  h4 hx;
+  unsigned m7[2], m8[2], orX[2], orR[2];                    // limb masks / f16 exponent patterns per row chunk: chunk 1 has no rows 24..31, its lanes g >= 2 carry constants
+};
+
+// stage A: the two row chunks of the first-stage plane `a` (TA index) as limb operands
+__device__ __forceinline__ void fm_plane(const _Float16* __restrict__ tabS, int a, const FmPu& pu, const FmK& K, int lane, h8 (&pl)[2])
+{
+  const h8 tb = *reinterpret_cast<const h8*>(tabS + (a * 64 + lane) * 8);
+#pragma unroll
+  for (int ch = 0; ch < 2; ch++)
+  {
+    const f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pu.wA[ch], tb, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+    unsigned u[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) u[j] = __builtin_bit_cast(unsigned, acc[j] + K.magicA);
+    const unsigned p01 = __builtin_amdgcn_perm(u[1], u[0], 0x05040100u), p23 = __builtin_amdgcn_perm(u[3], u[2], 0x05040100u);
+    uint4 o;
+    o.x = (p01 & K.m7[ch]) | K.orX[ch];
+    o.y = (p23 & K.m7[ch]) | K.orR[ch];
+    o.z = ((p01 >> 7) & K.m8[ch]) | K.orR[ch];
+    o.w = ((p23 >> 7) & K.m8[ch]) | K.orR[ch];
+    pl[ch] = __builtin_bit_cast(h8, o);
+  }
+}
+
+// one candidate (TB index cb) from the plane: the lane's part P of sum |Hadamard coefficient| / 2 over its tile
+__device__ __forceinline__ float fm_cand(const _Float16* __restrict__ tabS, int cb, const h8 (&pl)[2], const FmPu& pu, const FmK& K, int lane)
+{
+  const h8 b0 = *reinterpret_cast<const h8*>(tabS + ((FM_NA + 2 * cb) * 64 + lane) * 8);
+  const h8 b1 = *reinterpret_cast<const h8*>(tabS + ((FM_NA + 2 * cb + 1) * 64 + lane) * 8);
+  f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[0], b0, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[1], b1, acc, 0, 0, 0);
+  fh2 p0 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(acc[0], acc[1])), p1 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(acc[2], acc[3]));
+  p0 = __builtin_elementwise_min(__builtin_elementwise_max(p0, K.pmin), K.pmax);
+  p1 = __builtin_elementwise_min(__builtin_elementwise_max(p1, K.pmin), K.pmax);
+  fh2 d0 = pu.o2[0] - p0, d1 = pu.o2[1] - p1;
+  const fh2 q0 = __builtin_bit_cast(fh2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d0), DPP_ROR8, 0xF, 0xF, true));
+  const fh2 q1 = __builtin_bit_cast(fh2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d1), DPP_ROR8, 0xF, 0xF, true));
+  d0 = __builtin_elementwise_fma(d0, K.sg, q0);
+  d1 = __builtin_elementwise_fma(d1, K.sg, q1);
+  const h4 dv = __builtin_shufflevector(d0, d1, 0, 1, 2, 3);
+  const f4 e = __builtin_amdgcn_mfma_f32_16x16x16f16(dv, K.hx, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+  const float s0 = e[0] + e[2], s1 = e[1] + e[3], t0 = e[0] - e[2], t1 = e[1] - e[3];
+  return fmaxf(fabsf(s0), fabsf(s1)) + fmaxf(fabsf(t0), fabsf(t1));
+}
+
+// end of a stage: R1[x'][slot] -> distortion of candidate (lane & 7) in lanes 0..15
+__device__ __forceinline__ float fm_finalize(const f4& R1, const FmK& K)
+{
+  const float rr = (R1[0] + R1[1]) + (R1[2] + R1[3]);
+  const f4 R2 = __builtin_amdgcn_mfma_f32_16x16x4f32(K.asel, rr, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+  float s = floorf((R2[0] + 1.f) * 0.5f) + floorf((R2[1] + 1.f) * 0.5f);
+  s += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), DPP_ROR8, 0xF, 0xF, true));
+  return s;
+}
+
+// exp-Golomb length of xGetExpGolombNumberOfBits (RdCost.h:172-199) without its loop: every pass of `while (t > 128) { len += 14; t >>= 7; }` is one of
+// four monotone tests
+__device__ __forceinline__ unsigned fm_eg_bits(int v)
+{
+  const unsigned t = (v <= 0) ? ((unsigned)(-v) << 1) + 1 : (unsigned)(v << 1);
+  const unsigned k = (unsigned)(t > 128u) + (unsigned)((t >> 7) > 128u) + (unsigned)((t >> 14) > 128u) + (unsigned)((t >> 21) > 128u);
+  const unsigned tf = t >> (7 * k);
+  return 1 + 14 * k + ((31 - __clz((int)tf)) << 1);
+}
+constexpr int FM_COST_N = 160;                               // two lengths of at most 71 bits each
+// the candidate offsets of s_acMvRefineH / s_acMvRefineQ as 2-bit fields (offset + 1), index i at bits 2 i
+constexpr unsigned FM_HX = 1u | 1u << 2 | 1u << 4 | 0u << 6 | 2u << 8 | 0u << 10 | 2u << 12 | 0u << 14 | 2u << 16;
+constexpr unsigned FM_HY = 1u | 0u << 2 | 2u << 4 | 1u << 6 | 1u << 8 | 0u << 10 | 0u << 12 | 2u << 14 | 2u << 16;
+constexpr unsigned FM_QX = 1u | 1u << 2 | 1u << 4 | 0u << 6 | 2u << 8 | 0u << 10 | 2u << 12 | 0u << 14 | 2u << 16;
+constexpr unsigned FM_QY = 1u | 0u << 2 | 2u << 4 | 0u << 6 | 0u << 8 | 1u << 10 | 1u << 12 | 2u << 14 | 2u << 16;
+
+// arg-min of dist + mvcost over the 9 candidates, first index on ties (xPatternRefinement's strict '<'); lane i < 9 carries candidate i's distortion.
+// costS[n] = (uint64)(lambda n) (built once per workgroup).  Costs that fit 32 bits (every real one) meet in four DPP minima; otherwise the 64-bit form.
+__device__ __forceinline__ void fm_best(unsigned dl, bool quarter, const unsigned long long* __restrict__ costS, double lambda, int predH, int predV, int baseX, int baseY, int scale,
+                                        int lane, int& bdx, int& bdy, unsigned long long& bcost, unsigned& bdist)
+{
+  const int li = lane < 9 ? lane : 0;
+  const int dx = (int)(((quarter ? FM_QX : FM_HX) >> (2 * li)) & 3u) - 1, dy = (int)(((quarter ? FM_QY : FM_HY) >> (2 * li)) & 3u) - 1;
+  const unsigned bits = fm_eg_bits(((baseX + dx) << scale) - predH) + fm_eg_bits(((baseY + dy) << scale) - predV);
+  const unsigned long long mc = bits < (unsigned)FM_COST_N ? costS[bits] : (unsigned long long)(lambda * (double)bits);
+  unsigned long long c = lane < 9 ? (unsigned long long)dl + mc : ~0ull;
+  int bi;
+  if (__ballot(lane < 9 && (c >> 32) != 0) == 0ull)
+  {
+    unsigned m = (unsigned)c;                                // lanes 9..63: all ones
+    m = min(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, DPP_XOR1, 0xF, 0xF, true));
+    m = min(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, DPP_XOR2, 0xF, 0xF, true));
+    m = min(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, DPP_HALF_MIRROR, 0xF, 0xF, true));
+    m = min(m, (unsigned)__builtin_amdgcn_mov_dpp((int)m, 0x140, 0xF, 0xF, true));          // row_mirror: the minimum of the 16 lanes in each of them
+    const unsigned m0 = (unsigned)__builtin_amdgcn_readfirstlane((int)m);
+    bi = __builtin_ctzll(__ballot((unsigned)c == m0 && lane < 9));
+    bcost = m0;
+  }
+  else
+  {
+    bi = lane;
+#pragma unroll
+    for (int o = 1; o < 16; o <<= 1)
+    {
+      const unsigned long long oc = __shfl_xor(c, o);
+      const int oi = __shfl_xor(bi, o);
+      if (oc < c || (oc == c && oi < bi)) { c = oc; bi = oi; }
+    }
+    bi = __builtin_amdgcn_readfirstlane(bi);
+    bcost = ((unsigned long long)(unsigned)__builtin_amdgcn_readfirstlane((int)(c >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)c);
+  }
+  bdx = (int)(((quarter ? FM_QX : FM_HX) >> (2 * bi)) & 3u) - 1;
+  bdy = (int)(((quarter ? FM_QY : FM_HY) >> (2 * bi)) & 3u) - 1;
+  bdist = (unsigned)__builtin_amdgcn_readlane((int)dl, bi);
+}
+
+#define FM_CAND(R, DX, DY, Q, CB) \
+  R = __builtin_amdgcn_mfma_f32_16x16x4f32(fm_cand(tabS, CB, pl, pu, K, lane), fm_sel<(fm_idx(DX, DY, Q) & 7)>(K.sel0), R, 0, 0, 0)
+
+__global__ __launch_bounds__(256, 4) void frac16m_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
+                                                      const vvcgpu_frac_blk* __restrict__ blocks, int nblocks, int bd, int cmin, int cmax,
+                                                      vvcgpu_mvcost mv0, const int* __restrict__ preds,
+                                                      vvcgpu_frac_result* __restrict__ results, const _Float16* __restrict__ image, int* __restrict__ flags,
+                                                      int nWg, int xcd)
+{
+  __shared__ __align__(16) _Float16 tabS[FM_TAB_HALVES];
+  __shared__ unsigned long long costS[FM_COST_N];
+  const int wg = vvc_xcd_index((int)blockIdx.x, nWg, xcd);
+  if (wg < 0) return;                                        // whole workgroup
+  for (int i = threadIdx.x; i < FM_TAB_HALVES / 8; i += 256) reinterpret_cast<uint4*>(tabS)[i] = reinterpret_cast<const uint4*>(image)[i];
+  if (threadIdx.x < FM_COST_N) costS[threadIdx.x] = (unsigned long long)(mv0.lambda * (double)threadIdx.x);       // RdCost.h:172-199 per bit count
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+  const int headRoom = max(2, 14 - bd), shift1 = 6 - headRoom, S = 1 << shift1;
+  FmK K;
+  K.magicA = 8388608.f * (float)S;
+  K.sel0 = c16 == 8 * (g & 1) ? 1.f : 0.f;
+  K.asel = c16 == (g >> 1) ? 1.f : 0.f;
+  K.pmin = fh2{ (_Float16)(short)(1024 + cmin), (_Float16)(short)(1024 + cmin) };
+  K.pmax = fh2{ (_Float16)(short)(1024 + cmax), (_Float16)(short)(1024 + cmax) };
+  K.sg = (c16 & 8) ? fh2{ (_Float16)-1.f, (_Float16)-1.f } : fh2{ (_Float16)1.f, (_Float16)1.f };
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+  {
+    const int k = 4 * g + j;
+    K.hx[j] = (c16 >> 3) != (k >> 3) ? (_Float16)0.f : (__popc((c16 & 7) & (k & 7)) & 1) ? (_Float16)-1.f : (_Float16)1.f;
+  }
+  K.m7[0] = 0x007F007Fu; K.m8[0] = 0x00FF00FFu; K.orX[0] = K.orR[0] = 0x64006400u;
+  asm("" : "+v"(K.m7[0]), "+v"(K.m8[0]), "+v"(K.orX[0]));    // held in vector registers: v_and_or_b32 takes no literal
+  K.orR[0] = K.orX[0];
+  K.m7[1] = g < 2 ? 0x007F007Fu : 0u; K.m8[1] = g < 2 ? 0x00FF00FFu : 0u;
+  K.orX[1] = g < 2 ? 0x64006400u : g == 2 ? 0x3C003C00u : 0u; K.orR[1] = g < 2 ? 0x64006400u : 0u;
+  const unsigned winAnd = g == 3 ? 0u : 0xFFFFFFFFu, winOrX = g == 3 ? 0x3C003C00u : 0x64006400u, winOrR = g == 3 ? 0u : 0x64006400u;   // columns 24..31: 1.0, 1.0, 0 ..
+  const unsigned rangeMask = (unsigned)((1 << bd) - 1) * 0x10001u;
+  const int orgLo = max(cmax - 1023, -1024), orgHi = min(cmin + 1023, 1023);   // |org - pred| <= 1023 for every clipped prediction, and 1024 + org exact in f16
+  const int yrow = fm_ymap(c16);
+  const int stride = nWg * 4;
+
+  struct Raw { uint4 w[2]; pel4 o; };                        // a PU's samples as loaded: fetched one PU ahead, behind the half stage of the PU in front
+  auto fetch = [&](const vvcgpu_frac_blk& blk, Raw& r)
+  {
+    const Pel* r0 = ref + (ptrdiff_t)(blk.ref_y - 4) * rs + blk.ref_x - 4;
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++)
+    {
+      const Pel* q = r0 + (ptrdiff_t)min(16 * ch + c16, 23) * rs + 8 * min(g, 2);
+      pel8 v;
+#pragma unroll
+      for (int e = 0; e < 8; e++) v[e] = q[e];
+      r.w[ch] = __builtin_bit_cast(uint4, v);
+    }
+    const Pel* o = org + (size_t)(blk.org_y + yrow) * os + blk.org_x + 4 * g;
+#pragma unroll
+    for (int j = 0; j < 4; j++) r.o[j] = o[j];
+  };
+
+  int b = wg * 4 + wave;
+  if (b >= nblocks) return;
+  vvcgpu_frac_blk blk = blocks[b];
+  Raw raw;
+  fetch(blk, raw);
+  for (; b < nblocks; b += stride)
+  {
+    const int bn = b + stride < nblocks ? b + stride : b;
+    const vvcgpu_frac_blk blkN = blocks[bn];
+    Raw rawN;
+    const int predH = preds ? preds[2 * b] : mv0.pred_hor, predV = preds ? preds[2 * b + 1] : mv0.pred_ver;
+    FmPu pu;
+    unsigned bad = 0;
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++)
+    {
+      uint4 u = raw.w[ch];
+      bad |= (u.x | u.y | u.z | u.w) & ~rangeMask;
+      u.x = (u.x & winAnd) | winOrX; u.y = (u.y & winAnd) | winOrR; u.z = (u.z & winAnd) | winOrR; u.w = (u.w & winAnd) | winOrR;
+      pu.wA[ch] = __builtin_bit_cast(h8, u);
+    }
+    {
+      const pel4 ov = raw.o;
+      const int omin = min(min((int)ov[0], (int)ov[1]), min((int)ov[2], (int)ov[3])), omax = max(max((int)ov[0], (int)ov[1]), max((int)ov[2], (int)ov[3]));
+      bad |= (omin < orgLo || omax > orgHi) ? 1u : 0u;
+      pu.o2[0] = fh2{ (_Float16)(short)(ov[0] + 1024), (_Float16)(short)(ov[1] + 1024) };
+      pu.o2[1] = fh2{ (_Float16)(short)(ov[2] + 1024), (_Float16)(short)(ov[3] + 1024) };
+    }
+    const bool fallBack = __ballot(bad != 0) != 0ull;        // reference samples outside the bit depth, or an original that is not a picture:
+    if (lane == 0) flags[b] = fallBack;                      // left to frac16_flagged_kernel (vector form), the launch behind this one
+    if (fallBack)
+    {
+      fetch(blkN, rawN);
+    }
+    else
+    {
+      h8 pl[2];
+      // ---- half stage: planes (fx, ix) = (0, 0), (2, -1), (2, 0); vertical candidates (fy, iy) = (0, 0), (2, -1), (2, 0)
+      f4 Ra = { 0.f, 0.f, 0.f, 0.f }, Rb = { 0.f, 0.f, 0.f, 0.f };
+      fm_plane(tabS, fm_combo(0, 0), pu, K, lane, pl);
+      FM_CAND(Ra, 0, 0, false, fm_combo(0, 0)); FM_CAND(Ra, 0, -1, false, fm_combo(2, -1)); FM_CAND(Ra, 0, 1, false, fm_combo(2, 0));
+      fm_plane(tabS, fm_combo(2, -1), pu, K, lane, pl);
+      FM_CAND(Ra, -1, 0, false, fm_combo(0, 0)); FM_CAND(Ra, -1, -1, false, fm_combo(2, -1)); FM_CAND(Ra, -1, 1, false, fm_combo(2, 0));
+      fetch(blkN, rawN);                                     // the next PU's samples travel behind the rest of this one
+      fm_plane(tabS, fm_combo(2, 0), pu, K, lane, pl);
+      FM_CAND(Ra, 1, 0, false, fm_combo(0, 0)); FM_CAND(Ra, 1, -1, false, fm_combo(2, -1)); FM_CAND(Rb, 1, 1, false, fm_combo(2, 0));   // candidate 8: slot 0 of its own accumulator
+      const float da = fm_finalize(Ra, K), db = fm_finalize(Rb, K);
+      int hx, hy;
+      unsigned long long costH;
+      unsigned distH;
+      fm_best((unsigned)(lane == 8 ? db : da), false, costS, mv0.lambda, predH, predV, blk.mv_x << 1, blk.mv_y << 1, 1, lane, hx, hy, costH, distH);
+
+      // ---- quarter stage around (hx, hy): qx = 2 hx + dx, qy = 2 hy + dy; the centre is the half stage's winner
+      f4 Rq = { 0.f, 0.f, 0.f, 0.f };
+      const int qy0 = 2 * hy - 1, qy1 = 2 * hy, qy2 = 2 * hy + 1;
+      const int cb0 = fm_combo(qy0 & 3, (qy0 & 3) ? qy0 >> 2 : 0), cb1 = fm_combo(qy1 & 3, (qy1 & 3) ? qy1 >> 2 : 0), cb2 = fm_combo(qy2 & 3, (qy2 & 3) ? qy2 >> 2 : 0);
+#pragma unroll
+      for (int dx = -1; dx <= 1; dx++)
+      {
+        const int qx = 2 * hx + dx;
+        fm_plane(tabS, fm_combo(qx & 3, (qx & 3) ? qx >> 2 : 0), pu, K, lane, pl);
+        if (dx == -1)     { FM_CAND(Rq, -1, -1, true, cb0); FM_CAND(Rq, -1, 0, true, cb1); FM_CAND(Rq, -1, 1, true, cb2); }
+        else if (dx == 0) { FM_CAND(Rq, 0, -1, true, cb0); FM_CAND(Rq, 0, 1, true, cb2); }
+        else              { FM_CAND(Rq, 1, -1, true, cb0); FM_CAND(Rq, 1, 0, true, cb1); FM_CAND(Rq, 1, 1, true, cb2); }
+      }
+      const float dq = fm_finalize(Rq, K);                   // lane i (1..7) = candidate i, lane 8 = candidate 8 (slot 0 once more), lane 0 := the centre
+      int qdx, qdy;
+      unsigned long long costQ;
+      unsigned distQ;
+      fm_best(lane == 0 ? distH : (unsigned)dq, true, costS, mv0.lambda, predH, predV, ((blk.mv_x << 1) + hx) << 1, ((blk.mv_y << 1) + hy) << 1, 0, lane, qdx, qdy, costQ, distQ);
+      if (lane == 0)
+      {
+        vvcgpu_frac_result r;
+        r.half_x = hx; r.half_y = hy; r.qter_x = qdx; r.qter_y = qdy; r.cost_half = costH; r.cost = costQ;
+        results[b] = r;
+      }
+    }
+    blk = blkN;
+    raw = rawN;
+  }
+}
+#undef FM_CAND
+
+// TA / TB images per device and bit depth, built on first use
+const _Float16* fm_image(int bd)
+{
+  static std::mutex mtx;
+  static _Float16* images[64][3] = { { nullptr } };
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { vvcgpu_set_error("frac image: device index"); return nullptr; }
+  std::lock_guard<std::mutex> lock(mtx);
+  _Float16*& slot = images[dev][bd - 8];
+  if (!slot)
+  {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, FM_TAB_HALVES * sizeof(_Float16));
+    if (e != hipSuccess) { (void)hipGetLastError(); vvcgpu_set_error("frac image: hipMalloc failed: %s", hipGetErrorString(e)); return nullptr; }
+    hipLaunchKernelGGL(fm_build_tables_kernel, dim3(cdiv(FM_TAB_HALVES, 256)), dim3(256), 0, (hipStream_t)0, static_cast<_Float16*>(p), 6 + (14 - bd > 2 ? 14 - bd : 2));
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();         // other streams may use the image right after this call returns
+    if (e != hipSuccess) { (void)hipFree(p); vvcgpu_set_error("building the fractional-search table image failed: %s", hipGetErrorString(e)); return nullptr; }
+    slot = static_cast<_Float16*>(p);
+  }
+  return slot;
+}
 }  // namespace
 
 // shared by vvcgpu_frac_refine and vvcgpu_me_batch (tzsearch.hip); preds: optional per-block MV predictors (hor, ver) on the device
@@ -652,7 +1054,20 @@ int vvcgpu_frac_refine_launch(const vvc_pel* org, int org_stride, const vvc_pel*
   if (w == 16 && h == 16 && !f16Off)
   {
     const int xcd = vvc_xcd_on();
-    if (use_hadamard)
+    static const int mfmaOff = getenv("VVCGPU_NO_FRAC_MFMA") ? 1 : 0;       // A/B timing switch: the vector-pipe form for every PU
+    if (use_hadamard && !mfmaOff)
+    {
+      const _Float16* image = fm_image(bit_depth);
+      if (!image) return VVCGPU_E_DEVICE;
+      const int nWg = cdiv(nblocks, 4) < 1024 ? cdiv(nblocks, 4) : 1024;   // four workgroups per CU by LDS; a wave walks its PUs
+      int* flags = static_cast<int*>(vvcgpu_scratch(st, (size_t)nblocks * sizeof(int)));
+      if (!flags) return VVCGPU_E_DEVICE;
+      hipLaunchKernelGGL(frac16m_kernel, dim3(vvc_xcd_grid(nWg, xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
+                         bit_depth, clp_min, clp_max, *mvcost_host, preds, results, image, flags, nWg, xcd);
+      hipLaunchKernelGGL(frac16_flagged_kernel, dim3(cdiv(nblocks, 256)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
+                         bit_depth, clp_min, clp_max, *mvcost_host, preds, results, flags);
+    }
+    else if (use_hadamard)
       hipLaunchKernelGGL(frac16_kernel<true>, dim3(vvc_xcd_grid(cdiv(nblocks, 4), xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
                          bit_depth, clp_min, clp_max, *mvcost_host, preds, results, cdiv(nblocks, 4), xcd);
     else
