@@ -737,10 +737,10 @@ __global__ void fm_build_tables_kernel(_Float16* __restrict__ tab, int shift2)
   tab[i] = (_Float16)v;
 }
 
-template <int T> __device__ __forceinline__ float fm_sel(float sel0)
+template <int T> __device__ __forceinline__ unsigned fm_sel(unsigned sp0)
 {
-  if (T == 0) return sel0;
-  return __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, sel0), 0x120 + (T ? T : 1), 0xF, 0xF, true));   // row_ror:T (every lane has a source: no old value to set up)
+  if (T == 0) return sp0;
+  return (unsigned)__builtin_amdgcn_mov_dpp((int)sp0, 0x120 + (T ? T : 1), 0xF, 0xF, true);   // row_ror:T (every lane has a source: no old value to set up)
 }
 
 struct FmPu                                                 // per-PU operands that every candidate shares
@@ -750,7 +750,8 @@ struct FmPu                                                 // per-PU operands t
 };
 struct FmK                                                  // wave constants (lane-varying ones in vector registers: v_and_or_b32 takes them as they are)
 {
-  float magicA, sel0, asel;
+  float magicA;
+  unsigned sp0;                                             // selector of slot 0 as the f16 pair (1, 2048): the weights of a sum's two limbs
   fh2 pmin, pmax, sg;
   h4 hx;
   unsigned m7[2], m8[2], orX[2], orR[2];                    // limb masks / f16 exponent patterns per row chunk: chunk 1 has no rows 24..31, its lanes g >= 2 carry constants
@@ -777,34 +778,80 @@ __device__ __forceinline__ void fm_plane(const _Float16* __restrict__ tabS, int 
   }
 }
 
-// one candidate (TB index cb) from the plane: the lane's part P of sum |Hadamard coefficient| / 2 over its tile
-__device__ __forceinline__ float fm_cand(const _Float16* __restrict__ tabS, int cb, const h8 (&pl)[2], const FmPu& pu, const FmK& K, int lane)
+// N candidates (TB indices cb[]) from one plane, side by side: the lane's parts P of sum |Hadamard coefficient| / 2 over its tile.  The products of
+// the N candidates are issued together (a candidate's second product needs the first one's result: N - 1 independent products in between hide that),
+// and the vector work of the N candidates is independent.
+typedef float f2v __attribute__((ext_vector_type(2)));
+template <int N>
+__device__ __forceinline__ void fm_cands(const _Float16* __restrict__ tabS, const int (&cb)[N], const h8 (&pl)[2], const FmPu& pu, const FmK& K, int lane, float (&P)[N])
 {
-  const h8 b0 = *reinterpret_cast<const h8*>(tabS + ((FM_NA + 2 * cb) * 64 + lane) * 8);
-  const h8 b1 = *reinterpret_cast<const h8*>(tabS + ((FM_NA + 2 * cb + 1) * 64 + lane) * 8);
-  f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[0], b0, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
-  acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[1], b1, acc, 0, 0, 0);
-  fh2 p0 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(acc[0], acc[1])), p1 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(acc[2], acc[3]));
-  p0 = __builtin_elementwise_min(__builtin_elementwise_max(p0, K.pmin), K.pmax);
-  p1 = __builtin_elementwise_min(__builtin_elementwise_max(p1, K.pmin), K.pmax);
-  fh2 d0 = pu.o2[0] - p0, d1 = pu.o2[1] - p1;
-  const fh2 q0 = __builtin_bit_cast(fh2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d0), DPP_ROR8, 0xF, 0xF, true));
-  const fh2 q1 = __builtin_bit_cast(fh2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d1), DPP_ROR8, 0xF, 0xF, true));
-  d0 = __builtin_elementwise_fma(d0, K.sg, q0);
-  d1 = __builtin_elementwise_fma(d1, K.sg, q1);
-  const h4 dv = __builtin_shufflevector(d0, d1, 0, 1, 2, 3);
-  const f4 e = __builtin_amdgcn_mfma_f32_16x16x16f16(dv, K.hx, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
-  const float s0 = e[0] + e[2], s1 = e[1] + e[3], t0 = e[0] - e[2], t1 = e[1] - e[3];
-  return fmaxf(fabsf(s0), fabsf(s1)) + fmaxf(fabsf(t0), fabsf(t1));
+  h8 b0[N], b1[N];
+#pragma unroll
+  for (int i = 0; i < N; i++)
+  {
+    b0[i] = *reinterpret_cast<const h8*>(tabS + ((FM_NA + 2 * cb[i]) * 64 + lane) * 8);
+    b1[i] = *reinterpret_cast<const h8*>(tabS + ((FM_NA + 2 * cb[i] + 1) * 64 + lane) * 8);
+  }
+  f4 acc[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[0], b0[i], f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < N; i++) acc[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl[1], b1[i], acc[i], 0, 0, 0);
+  h4 dv[N];
+#pragma unroll
+  for (int i = 0; i < N; i++)
+  {
+    fh2 p0 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(acc[i][0], acc[i][1])), p1 = __builtin_bit_cast(fh2, __builtin_amdgcn_cvt_pkrtz(acc[i][2], acc[i][3]));
+    p0 = __builtin_elementwise_min(__builtin_elementwise_max(p0, K.pmin), K.pmax);
+    p1 = __builtin_elementwise_min(__builtin_elementwise_max(p1, K.pmin), K.pmax);
+    fh2 d0 = pu.o2[0] - p0, d1 = pu.o2[1] - p1;
+    const fh2 q0 = __builtin_bit_cast(fh2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d0), DPP_ROR8, 0xF, 0xF, true));
+    const fh2 q1 = __builtin_bit_cast(fh2, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, d1), DPP_ROR8, 0xF, 0xF, true));
+    d0 = __builtin_elementwise_fma(d0, K.sg, q0);
+    d1 = __builtin_elementwise_fma(d1, K.sg, q1);
+    dv[i] = __builtin_shufflevector(d0, d1, 0, 1, 2, 3);
+  }
+  f4 e[N];
+#pragma unroll
+  for (int i = 0; i < N; i++) e[i] = __builtin_amdgcn_mfma_f32_16x16x16f16(dv[i], K.hx, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+#pragma unroll
+  for (int i = 0; i < N; i++)
+  {
+    const f2v lo = { e[i][0], e[i][1] }, hi = { e[i][2], e[i][3] };
+    const f2v sm = lo + hi, df = lo - hi;
+    P[i] = fmaxf(fabsf(sm[0]), fabsf(sm[1])) + fmaxf(fabsf(df[0]), fabsf(df[1]));
+  }
 }
 
-// end of a stage: R1[x'][slot] -> distortion of candidate (lane & 7) in lanes 0..15
-__device__ __forceinline__ float fm_finalize(const f4& R1, const FmK& K)
+// The lane's part P (an integer below 2^17 in f32) as two f16 limbs (P mod 2048, P div 2048) in one register
+__device__ __forceinline__ unsigned fm_limbs(float P)
+{
+  const float hi = floorf(P * (1.f / 2048.f));
+  const float lo = __builtin_fmaf(hi, -2048.f, P);
+  return __builtin_bit_cast(unsigned, __builtin_amdgcn_cvt_pkrtz(lo, hi));
+}
+// R1[x'][slot] += sum over the lane groups of up to three candidates' parts, slot = T + 8 (tile row): ONE f16 product (the f32-input MFMA this
+// replaces holds the SIMD's vector pipe for its whole 32 cycles -- measured: 9 us of 72 per picture for 20 of them per PU)
+template <int T0, int T1, int T2>
+__device__ __forceinline__ f4 fm_acc(f4 R, float P0, float P1, float P2, const FmK& K)
+{
+  uint4 a, b;
+  a.x = fm_limbs(P0); b.x = fm_sel<T0 & 7>(K.sp0);
+  a.y = T1 >= 0 ? fm_limbs(P1) : 0u; b.y = T1 >= 0 ? fm_sel<T1 & 7>(K.sp0) : 0u;
+  a.z = T2 >= 0 ? fm_limbs(P2) : 0u; b.z = T2 >= 0 ? fm_sel<T2 & 7>(K.sp0) : 0u;
+  a.w = 0u; b.w = 0u;
+  return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(h8, a), __builtin_bit_cast(h8, b), R, 0, 0, 0);
+}
+
+// end of a stage: R1[x'][slot] (lane: slot, lane group g': x' = 4 g' .. 4 g' + 3 in the four registers) -> distortion of candidate (lane & 7) in every lane:
+// the lane groups of a tile column meet through the LDS crossbar (no memory: ds_swizzle / ds_bpermute), SATD tile = (P + 1) >> 1, tile rows by row_ror:8
+__device__ __forceinline__ float fm_finalize(const f4& R1, int lane)
 {
   const float rr = (R1[0] + R1[1]) + (R1[2] + R1[3]);
-  const f4 R2 = __builtin_amdgcn_mfma_f32_16x16x4f32(K.asel, rr, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
-  float s = floorf((R2[0] + 1.f) * 0.5f) + floorf((R2[1] + 1.f) * 0.5f);
-  s += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), DPP_ROR8, 0xF, 0xF, true));
+  const float col = rr + __builtin_bit_cast(float, __builtin_amdgcn_ds_swizzle(__builtin_bit_cast(int, rr), 0x401F));       // lane ^ 16: the other half of the tile column
+  const float sat = floorf((col + 1.f) * 0.5f);
+  float s = sat + __builtin_bit_cast(float, __builtin_amdgcn_ds_bpermute((lane ^ 32) << 2, __builtin_bit_cast(int, sat)));  // lane ^ 32: the other tile column
+  s += __builtin_bit_cast(float, __builtin_amdgcn_mov_dpp(__builtin_bit_cast(int, s), DPP_ROR8, 0xF, 0xF, true));           // the other tile row
   return s;
 }
 
@@ -864,10 +911,9 @@ __device__ __forceinline__ void fm_best(unsigned dl, bool quarter, const unsigne
   bdist = (unsigned)__builtin_amdgcn_readlane((int)dl, bi);
 }
 
-#define FM_CAND(R, DX, DY, Q, CB) \
-  R = __builtin_amdgcn_mfma_f32_16x16x4f32(fm_cand(tabS, CB, pl, pu, K, lane), fm_sel<(fm_idx(DX, DY, Q) & 7)>(K.sel0), R, 0, 0, 0)
 
-__global__ __launch_bounds__(256, 4) void frac16m_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void frac16m_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
                                                       const vvcgpu_frac_blk* __restrict__ blocks, int nblocks, int bd, int cmin, int cmax,
                                                       vvcgpu_mvcost mv0, const int* __restrict__ preds,
                                                       vvcgpu_frac_result* __restrict__ results, const _Float16* __restrict__ image, int* __restrict__ flags,
@@ -880,12 +926,11 @@ __global__ __launch_bounds__(256, 4) void frac16m_kernel(const Pel* __restrict__
   for (int i = threadIdx.x; i < FM_TAB_HALVES / 8; i += 256) reinterpret_cast<uint4*>(tabS)[i] = reinterpret_cast<const uint4*>(image)[i];
   if (threadIdx.x < FM_COST_N) costS[threadIdx.x] = (unsigned long long)(mv0.lambda * (double)threadIdx.x);       // RdCost.h:172-199 per bit count
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, c16 = lane & 15, g = lane >> 4;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), c16 = lane & 15, g = lane >> 4;   // (the PU index is wave-uniform: descriptors through the scalar cache)
   const int headRoom = max(2, 14 - bd), shift1 = 6 - headRoom, S = 1 << shift1;
   FmK K;
   K.magicA = 8388608.f * (float)S;
-  K.sel0 = c16 == 8 * (g & 1) ? 1.f : 0.f;
-  K.asel = c16 == (g >> 1) ? 1.f : 0.f;
+  K.sp0 = c16 == 8 * (g & 1) ? 0x68003C00u : 0u;             // (1.0, 2048.0)
   K.pmin = fh2{ (_Float16)(short)(1024 + cmin), (_Float16)(short)(1024 + cmin) };
   K.pmax = fh2{ (_Float16)(short)(1024 + cmax), (_Float16)(short)(1024 + cmax) };
   K.sg = (c16 & 8) ? fh2{ (_Float16)-1.f, (_Float16)-1.f } : fh2{ (_Float16)1.f, (_Float16)1.f };
@@ -963,14 +1008,20 @@ __global__ __launch_bounds__(256, 4) void frac16m_kernel(const Pel* __restrict__
       h8 pl[2];
       // ---- half stage: planes (fx, ix) = (0, 0), (2, -1), (2, 0); vertical candidates (fy, iy) = (0, 0), (2, -1), (2, 0)
       f4 Ra = { 0.f, 0.f, 0.f, 0.f }, Rb = { 0.f, 0.f, 0.f, 0.f };
+      const int cbH[3] = { fm_combo(0, 0), fm_combo(2, -1), fm_combo(2, 0) };      // dy = 0, -1, +1
+      float P[3];
       fm_plane(tabS, fm_combo(0, 0), pu, K, lane, pl);
-      FM_CAND(Ra, 0, 0, false, fm_combo(0, 0)); FM_CAND(Ra, 0, -1, false, fm_combo(2, -1)); FM_CAND(Ra, 0, 1, false, fm_combo(2, 0));
+      fm_cands<3>(tabS, cbH, pl, pu, K, lane, P);
+      Ra = fm_acc<fm_idx(0, 0, false), fm_idx(0, -1, false), fm_idx(0, 1, false)>(Ra, P[0], P[1], P[2], K);
       fm_plane(tabS, fm_combo(2, -1), pu, K, lane, pl);
-      FM_CAND(Ra, -1, 0, false, fm_combo(0, 0)); FM_CAND(Ra, -1, -1, false, fm_combo(2, -1)); FM_CAND(Ra, -1, 1, false, fm_combo(2, 0));
+      fm_cands<3>(tabS, cbH, pl, pu, K, lane, P);
+      Ra = fm_acc<fm_idx(-1, 0, false), fm_idx(-1, -1, false), fm_idx(-1, 1, false)>(Ra, P[0], P[1], P[2], K);
       fetch(blkN, rawN);                                     // the next PU's samples travel behind the rest of this one
       fm_plane(tabS, fm_combo(2, 0), pu, K, lane, pl);
-      FM_CAND(Ra, 1, 0, false, fm_combo(0, 0)); FM_CAND(Ra, 1, -1, false, fm_combo(2, -1)); FM_CAND(Rb, 1, 1, false, fm_combo(2, 0));   // candidate 8: slot 0 of its own accumulator
-      const float da = fm_finalize(Ra, K), db = fm_finalize(Rb, K);
+      fm_cands<3>(tabS, cbH, pl, pu, K, lane, P);
+      Ra = fm_acc<fm_idx(1, 0, false), fm_idx(1, -1, false), -1>(Ra, P[0], P[1], 0.f, K);
+      Rb = fm_acc<fm_idx(1, 1, false), -1, -1>(Rb, P[2], 0.f, 0.f, K);                       // candidate 8: slot 0 of its own accumulator
+      const float da = fm_finalize(Ra, lane), db = fm_finalize(Rb, lane);
       int hx, hy;
       unsigned long long costH;
       unsigned distH;
@@ -980,16 +1031,27 @@ __global__ __launch_bounds__(256, 4) void frac16m_kernel(const Pel* __restrict__
       f4 Rq = { 0.f, 0.f, 0.f, 0.f };
       const int qy0 = 2 * hy - 1, qy1 = 2 * hy, qy2 = 2 * hy + 1;
       const int cb0 = fm_combo(qy0 & 3, (qy0 & 3) ? qy0 >> 2 : 0), cb1 = fm_combo(qy1 & 3, (qy1 & 3) ? qy1 >> 2 : 0), cb2 = fm_combo(qy2 & 3, (qy2 & 3) ? qy2 >> 2 : 0);
-#pragma unroll
-      for (int dx = -1; dx <= 1; dx++)
+      const int cbQ[3] = { cb0, cb1, cb2 }, cbQ2[2] = { cb0, cb2 };
       {
-        const int qx = 2 * hx + dx;
+        const int qx = 2 * hx - 1;
         fm_plane(tabS, fm_combo(qx & 3, (qx & 3) ? qx >> 2 : 0), pu, K, lane, pl);
-        if (dx == -1)     { FM_CAND(Rq, -1, -1, true, cb0); FM_CAND(Rq, -1, 0, true, cb1); FM_CAND(Rq, -1, 1, true, cb2); }
-        else if (dx == 0) { FM_CAND(Rq, 0, -1, true, cb0); FM_CAND(Rq, 0, 1, true, cb2); }
-        else              { FM_CAND(Rq, 1, -1, true, cb0); FM_CAND(Rq, 1, 0, true, cb1); FM_CAND(Rq, 1, 1, true, cb2); }
+        fm_cands<3>(tabS, cbQ, pl, pu, K, lane, P);
+        Rq = fm_acc<fm_idx(-1, -1, true), fm_idx(-1, 0, true), fm_idx(-1, 1, true)>(Rq, P[0], P[1], P[2], K);
       }
-      const float dq = fm_finalize(Rq, K);                   // lane i (1..7) = candidate i, lane 8 = candidate 8 (slot 0 once more), lane 0 := the centre
+      {
+        const int qx = 2 * hx;
+        float P2[2];
+        fm_plane(tabS, fm_combo(qx & 3, (qx & 3) ? qx >> 2 : 0), pu, K, lane, pl);
+        fm_cands<2>(tabS, cbQ2, pl, pu, K, lane, P2);
+        Rq = fm_acc<fm_idx(0, -1, true), fm_idx(0, 1, true), -1>(Rq, P2[0], P2[1], 0.f, K);
+      }
+      {
+        const int qx = 2 * hx + 1;
+        fm_plane(tabS, fm_combo(qx & 3, (qx & 3) ? qx >> 2 : 0), pu, K, lane, pl);
+        fm_cands<3>(tabS, cbQ, pl, pu, K, lane, P);
+        Rq = fm_acc<fm_idx(1, -1, true), fm_idx(1, 0, true), fm_idx(1, 1, true)>(Rq, P[0], P[1], P[2], K);
+      }
+      const float dq = fm_finalize(Rq, lane);                   // lane i (1..7) = candidate i, lane 8 = candidate 8 (slot 0 once more), lane 0 := the centre
       int qdx, qdy;
       unsigned long long costQ;
       unsigned distQ;
@@ -1005,7 +1067,6 @@ __global__ __launch_bounds__(256, 4) void frac16m_kernel(const Pel* __restrict__
     raw = rawN;
   }
 }
-#undef FM_CAND
 
 // TA / TB images per device and bit depth, built on first use
 const _Float16* fm_image(int bd)
@@ -1059,11 +1120,17 @@ int vvcgpu_frac_refine_launch(const vvc_pel* org, int org_stride, const vvc_pel*
     {
       const _Float16* image = fm_image(bit_depth);
       if (!image) return VVCGPU_E_DEVICE;
-      const int nWg = cdiv(nblocks, 4) < 1024 ? cdiv(nblocks, 4) : 1024;   // four workgroups per CU by LDS; a wave walks its PUs
+      static const int wps = getenv("VVCGPU_FRAC_WPS") ? atoi(getenv("VVCGPU_FRAC_WPS")) : 4;   // waves per SIMD the kernel is built for (A/B switch)
+      const int cap = 256 * (wps == 5 ? 5 : 4);                            // that many workgroups per CU; a wave walks its PUs
+      const int nWg = cdiv(nblocks, 4) < cap ? cdiv(nblocks, 4) : cap;
       int* flags = static_cast<int*>(vvcgpu_scratch(st, (size_t)nblocks * sizeof(int)));
       if (!flags) return VVCGPU_E_DEVICE;
-      hipLaunchKernelGGL(frac16m_kernel, dim3(vvc_xcd_grid(nWg, xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
-                         bit_depth, clp_min, clp_max, *mvcost_host, preds, results, image, flags, nWg, xcd);
+      if (wps == 5)
+        hipLaunchKernelGGL(frac16m_kernel<5>, dim3(vvc_xcd_grid(nWg, xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
+                           bit_depth, clp_min, clp_max, *mvcost_host, preds, results, image, flags, nWg, xcd);
+      else
+        hipLaunchKernelGGL(frac16m_kernel<4>, dim3(vvc_xcd_grid(nWg, xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
+                           bit_depth, clp_min, clp_max, *mvcost_host, preds, results, image, flags, nWg, xcd);
       hipLaunchKernelGGL(frac16_flagged_kernel, dim3(cdiv(nblocks, 256)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
                          bit_depth, clp_min, clp_max, *mvcost_host, preds, results, flags);
     }
