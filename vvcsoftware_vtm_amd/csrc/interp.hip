@@ -14,6 +14,8 @@
 // the vertical pass and, for bi-prediction, the second list and the average stay in registers.
 #include "common.h"
 #include "dist_dev.h"
+#include "mfma_tr.h"
+#include <mutex>
 
 // the generic MC scan loads bytes 32..47 of a descriptor as ONE uint4 (dst_stride | w, h | the four phases | is_luma, bi, reserved): the layout is part of
 // the ABI, and the descriptor array must be 16-byte aligned (include/vvcgpu.h)
@@ -518,6 +520,345 @@ __global__ __launch_bounds__(256, 6) void mc_fast_kernel(const Pel* __restrict__
   }
 }
 
+// ---------------------------------------------------------------------------------------------------
+// The fast shapes ON THE MATRIX CORES (round 5): 16x16 luma and 8x8 chroma PUs, uni- and bi-predictive, quarter- (chroma: eighth-) sample phases.
+// mc_fast_kernel above spends ~570 vector instructions per PU wave around 78 v_dot2 with the matrix pipe idle; here both filter passes are exact
+// f16 products (the machinery of frac16m_kernel, fracsearch.hip): ~120 vector instructions per luma PU, ~100 per PAIR of chroma PUs.
+//   window   rows through lanes, eight columns per lane as one 16-byte load (any alignment), samples as f16 bit patterns 0x6400 | v (= 1024 + v)
+//   pass 1   W (A operand) x Toeplitz matrix of the taps (table, B operand); the constant that the sum has to start from travels in the product's
+//            spare columns (operand constants 1.0 and 1024.0); one v_add_f32 with 2^23 S leaves u = plane + 16384 in the low mantissa bits (floor by
+//            round-to-nearest at a chosen exponent); limbs lo = u & 127, hi = u >> 7 as 0x6400 | limb
+//   pass 2   plane^T (A operand: the pass-1 result registers as they are) x Toeplitz matrix per limb (c and 128 c): lane = output row, registers = four
+//            neighbouring columns -> one 8-byte store per lane; rounding shifts as fma + floor on exact f32 integers, the last one and the clip in
+//            packed f16 (v_cvt_pkrtz in [1024, 2048) IS the floor; 0x6400 | v back to v by a mask)
+//   chroma   two 8x8 PUs per product: block-diagonal Toeplitz matrices (pass 1: columns of PU 0 | PU 1 along k; pass 2: the table row a lane reads
+//            belongs to ITS PU's phase), so every product is shared and half of the result lanes are real
+//   the one branch of the reference that is not two passes -- a rounded, horizontal-only filter (uni, frac_y == 0, frac_x != 0) -- gets the last-stage
+//   rounding and the clip in pass 1 (own constants) and a copy in pass 2.
+// PUs it cannot take (bi == 2, other phases, reference samples outside the bit depth) are flagged for the generic kernel behind it.
+typedef _Float16 mm_h2 __attribute__((ext_vector_type(2)));
+constexpr int MM_TAL = 0;                                    // [2 variants][4 phases][64 lanes]            luma pass 1
+constexpr int MM_TBL = MM_TAL + 2 * 4 * 64;                  // [4 phases][2 row chunks][64 lanes]          luma pass 2
+constexpr int MM_TAC = MM_TBL + 4 * 2 * 64;                  // [2 variants][8 phases][8 x][2] + a zero row   chroma pass 1
+constexpr int MM_TBC = MM_TAC + 2 * 8 * 16 + 1;              // [8 phases][8 y][4 lane groups]               chroma pass 2
+constexpr int MM_ENTRIES = MM_TBC + 8 * 32;                  // 16-byte entries (eight f16 each)
+
+__global__ void mm_build_tables_kernel(_Float16* __restrict__ tab, int bd)
+{
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= MM_ENTRIES * 8) return;
+  const int ent = i >> 3, e = i & 7;
+  const int hr = max(2, IF_INTERNAL_PREC - bd);
+  const float S = (float)(1 << (IF_FILTER_PREC - hr));
+  // start value of a pass-1 sum, as b0 * 1.0 + b1 * 1024.0.  variant 0: 8192 S - 65536 - (S - 1) / 2 (removes the sample bias 1024 x 64, adds 16384 S
+  // and the first-stage offset -8192 S, centres the floor); variant 1 (rounded horizontal-only): 32 + 16384 x 64 - 65536 - 31.5
+  const float b0[2] = { -0.5f * (S - 1.f), 0.5f }, b1[2] = { 8.f * S - 64.f, 960.f };
+  float v = 0.f;
+  if (ent < MM_TBL)
+  {
+    const int var = ent / 256, q = (ent / 64) & 3, lane = ent & 63, x = lane & 15, g = lane >> 4;
+    if (g == 3) v = e == 0 ? b0[var] : e == 1 ? b1[var] : 0.f;
+    else
+    {
+      // window column of k = 8 g + e: phases != 0 load columns 0..7 | 8..15 | 15..22 (column 15 once), phase 0 loads 3..10 | 11..18 | (unused)
+      const int col = q == 0 ? (g == 0 ? 3 + e : g == 1 ? 11 + e : -100) : (g == 0 ? e : g == 1 ? 8 + e : (e == 0 ? -100 : 15 + e));
+      const int t = col - x;
+      if (t >= 0 && t <= 7) v = (float)c_lumaFilter[4 * q][t];
+    }
+  }
+  else if (ent < MM_TAC)
+  {
+    const int r = ent - MM_TBL, q = r / 128, ch = (r / 64) & 1, lane = r & 63, y = lane & 15, g = lane >> 4;
+    const int row = 16 * ch + 4 * g + (e & 3), t = row - y;
+    if (t >= 0 && t <= 7 && row <= 22) v = (float)c_lumaFilter[4 * q][t] * (e >= 4 ? 128.f : 1.f);
+    if (ch == 1 && g == 2 && e < 2) v = e == 0 ? 0.f : -9280.f;     // x 1024: -(64 x 1024 x 129 + 16384 x 64), the limb biases and the 16384 of u
+  }
+  else if (ent < MM_TBC)
+  {
+    const int r = ent - MM_TAC;
+    if (r < 2 * 8 * 16)
+    {
+      const int var = r / 128, q = (r / 16) & 7, x = (r >> 1) & 7, gl = r & 1;
+      if (gl == 1 && e < 2) v = e == 0 ? b0[var] : b1[var];
+      else
+      {
+        // phases != 0: lane group pair loads columns 0..7 | 3..10, of which 3, 4 give way to the constants and 5, 6, 7 are there already: 8, 9, 10 count; phase 0: 1..8
+        const int col = q == 0 ? (gl == 0 ? 1 + e : -100) : (gl == 0 ? e : (e >= 5 ? 3 + e : -100));
+        const int t = col - x;
+        if (t >= 0 && t <= 3) v = (float)c_chromaFilter[4 * q][t];
+      }
+    }
+  }
+  else
+  {
+    const int r = ent - MM_TBC, q = r / 32, y = (r >> 2) & 7, g = r & 3;
+    const int row = 4 * g + (e & 3), t = row - y;
+    if (t >= 0 && t <= 3 && row <= 10) v = (float)c_chromaFilter[4 * q][t] * (e >= 4 ? 128.f : 1.f);
+    if (g == 3 && e < 2) v = e == 0 ? 0.f : -9280.f;
+  }
+  tab[i] = (_Float16)v;
+}
+
+struct MmDesc { long long ref0, ref1, dst; int rs0, rs1, ds; int fx0, fy0, fx1, fy1, bi; };   // the fields a step needs (phases as table indices)
+// which of the kernel's shapes a descriptor is: 1 luma 16x16, 2 chroma 8x8 (phases on the quarter / eighth grid, bi 0 or 1), 0 other; -1: a fast SHAPE
+// that is left to the generic kernel
+__device__ __forceinline__ int mm_kind(const vvcgpu_mc_desc& d)
+{
+  if (!mc_is_fast(d.is_luma, d.w, d.h)) return 0;
+  const int m = (d.frac_x0 | d.frac_y0 | (d.bi == 1 ? d.frac_x1 | d.frac_y1 : 0));
+  if ((m & 3) || m < 0 || m >= (d.is_luma ? 16 : 32) || d.bi < 0 || d.bi > 1) return -1;
+  return d.is_luma ? 1 : 2;
+}
+__device__ __forceinline__ MmDesc mm_lite(const vvcgpu_mc_desc& d)
+{
+  MmDesc m;
+  m.ref0 = d.ref0_off; m.ref1 = d.bi == 1 ? d.ref1_off : d.ref0_off; m.dst = d.dst_off;
+  m.rs0 = d.ref0_stride; m.rs1 = d.bi == 1 ? d.ref1_stride : d.ref0_stride; m.ds = d.dst_stride;
+  m.fx0 = d.frac_x0 >> 2; m.fy0 = d.frac_y0 >> 2; m.fx1 = d.bi == 1 ? d.frac_x1 >> 2 : 0; m.fy1 = d.bi == 1 ? d.frac_y1 >> 2 : 0; m.bi = d.bi;
+  return m;
+}
+
+struct MmStep { int mode; int iA, iB; MmDesc a, b; };        // mode 1: luma PU a; 2: chroma PUs a (columns 0..7 of the products) and b (8..15; iB < 0: absent)
+struct MmRaw { uint4 w[2][2]; };                             // [reference][row chunk] as loaded
+
+template <int WPS>
+__global__ __launch_bounds__(256, WPS) void mc_mfma_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base, Pel* __restrict__ dstBase,
+                                                           const vvcgpu_mc_desc* __restrict__ descs, int n, int bd, int cmin, int cmax,
+                                                           const _Float16* __restrict__ image, int* __restrict__ flags, int nWg, int xcd)
+{
+  __shared__ __align__(16) _Float16 tabS[MM_ENTRIES * 8];
+  const int wg = vvc_xcd_index((int)blockIdx.x, nWg, xcd);
+  if (wg < 0) return;
+  for (int i = threadIdx.x; i < MM_ENTRIES; i += 256) reinterpret_cast<uint4*>(tabS)[i] = reinterpret_cast<const uint4*>(image)[i];
+  __syncthreads();
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), c16 = lane & 15, g = lane >> 4;
+  const int hr = max(2, IF_INTERNAL_PREC - bd), S = 1 << (IF_FILTER_PREC - hr);
+  const unsigned rangeMask = (unsigned)((1 << bd) - 1) * 0x10001u;
+  // limb masks / exponent patterns of a pass-1 result by row-chunk kind: 0 every row real; 1 luma rows 16..31 (lane group 2: the constants 1.0, 1024.0;
+  // 3: nothing); 2 chroma rows 0..15 (lane group 3: the constants)
+  unsigned m7[3], m8[3], orX[3], orR[3];
+  m7[0] = 0x007F007Fu; m8[0] = 0x00FF00FFu; orX[0] = 0x64006400u;
+  asm("" : "+v"(m7[0]), "+v"(m8[0]), "+v"(orX[0]));          // held in vector registers (v_and_or_b32 takes no literal)
+  orR[0] = orX[0];
+  m7[1] = g < 2 ? 0x007F007Fu : 0u; m8[1] = g < 2 ? 0x00FF00FFu : 0u; orX[1] = g < 2 ? 0x64006400u : g == 2 ? 0x64003C00u : 0u; orR[1] = g < 2 ? 0x64006400u : 0u;
+  m7[2] = g < 3 ? 0x007F007Fu : 0u; m8[2] = g < 3 ? 0x00FF00FFu : 0u; orX[2] = g < 3 ? 0x64006400u : 0x64003C00u; orR[2] = g < 3 ? 0x64006400u : 0u;
+  const float magicN = 8388608.f * (float)S, magicH = 536870912.f;
+  const mm_h2 pmin = { (_Float16)(short)(1024 + cmin), (_Float16)(short)(1024 + cmin) }, pmax = { (_Float16)(short)(1024 + cmax), (_Float16)(short)(1024 + cmax) };
+  // second-stage rounding as fma + floor (exact: f32 integers below 2^24 times powers of two)
+  const float scBi1 = 1.f / 64.f, scUni1 = 1.f / (float)(64 << hr), ofUni1 = (float)((1 << (5 + hr)) + (IF_INTERNAL_OFFS << 6)) * scUni1;
+  const float scBi2 = 1.f / (float)(2 << hr), ofBi2 = (float)((1 << hr) + 2 * IF_INTERNAL_OFFS) * scBi2 + 1024.f;
+
+  const int npairs = (n + 1) >> 1, stride = nWg * 4;
+  int pair = wg * 4 + wave, sub = 0;
+  // the next step of this wave (uniform): pairs (2 p, 2 p + 1) as mc_fast_kernel takes them
+  auto next = [&](MmStep& s) -> bool
+  {
+    for (; pair < npairs; )
+    {
+      const int i0 = 2 * pair, i1 = i0 + 1 < n ? i0 + 1 : -1;
+      const vvcgpu_mc_desc d0 = descs[i0];
+      const int k0 = mm_kind(d0);
+      int k1 = 0;
+      vvcgpu_mc_desc d1 = d0;
+      if (i1 >= 0) { d1 = descs[i1]; k1 = mm_kind(d1); }
+      if (sub == 0)
+      {
+        if (lane == 0) { if (k0 < 0) flags[i0] = 1; if (k1 < 0) flags[i1] = 1; }
+        if (k0 == 2 && k1 == 2) { s.mode = 2; s.iA = i0; s.iB = i1; s.a = mm_lite(d0); s.b = mm_lite(d1); pair += stride; return true; }
+        sub = 1;
+        if (k0 > 0) { s.mode = k0; s.iA = i0; s.iB = -1; s.a = mm_lite(d0); s.b = s.a; return true; }
+      }
+      sub = 0; pair += stride;
+      if (k1 > 0) { s.mode = k1; s.iA = i1; s.iB = -1; s.a = mm_lite(d1); s.b = s.a; return true; }
+    }
+    return false;
+  };
+  // the step's samples: lane (row c16, lane group g) takes eight columns of its row
+  auto fetch = [&](const MmStep& s, MmRaw& r)
+  {
+    const bool second = s.mode == 2 && g >= 2;               // chroma: lane groups 2, 3 load PU b
+    const MmDesc& d = second ? s.b : s.a;                    // (selects per lane)
+#pragma unroll
+    for (int rf = 0; rf < 2; rf++)
+    {
+      const long long off = rf ? d.ref1 : d.ref0;
+      const int rs = rf ? d.rs1 : d.rs0, fx = rf ? d.fx1 : d.fx0, fy = rf ? d.fy1 : d.fy0;
+      const Pel* base = (rf ? ref1Base : ref0Base) + off;
+      if (s.mode == 1)
+      {
+        const int col = fx ? (g == 0 ? 0 : g == 1 ? 8 : 15) : (g == 0 ? 3 : 11);
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+        {
+          const int row = fy ? min(16 * ch + c16, 22) : min(max(16 * ch + c16, 3), 18);
+          const Pel* q = base + (ptrdiff_t)(row - 3) * rs + (col - 3);
+          pel8 v;
+#pragma unroll
+          for (int e = 0; e < 8; e++) v[e] = q[e];
+          r.w[rf][ch] = __builtin_bit_cast(uint4, v);
+        }
+      }
+      else
+      {
+        const int col = fx ? ((g & 1) ? 3 : 0) : 1, row = fy ? min(c16, 10) : min(max(c16, 1), 8);
+        const Pel* q = base + (ptrdiff_t)(row - 1) * rs + (col - 1);
+        pel8 v;
+#pragma unroll
+        for (int e = 0; e < 8; e++) v[e] = q[e];
+        r.w[rf][0] = __builtin_bit_cast(uint4, v);
+        r.w[rf][1] = r.w[rf][0];
+      }
+    }
+  };
+  // pass-1 result registers -> limb operand
+  auto limbs = [&](const f4& acc, float magic, int kind, bool hclip) -> h8
+  {
+    unsigned u[4];
+#pragma unroll
+    for (int j = 0; j < 4; j++) u[j] = __builtin_bit_cast(unsigned, acc[j] + magic);
+    unsigned p01 = __builtin_amdgcn_perm(u[1], u[0], 0x05040100u), p23 = __builtin_amdgcn_perm(u[3], u[2], 0x05040100u);
+    if (hclip)                                               // rounded horizontal-only filter: the clip of the last stage, on u = sample + 16384
+    {
+      typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+      const us2 lo = { (unsigned short)(16384 + cmin), (unsigned short)(16384 + cmin) }, hi = { (unsigned short)(16384 + cmax), (unsigned short)(16384 + cmax) };
+      p01 = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(us2, p01), lo), hi));
+      p23 = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(us2, p23), lo), hi));
+    }
+    uint4 o;
+    o.x = (p01 & m7[kind]) | orX[kind];
+    o.y = (p23 & m7[kind]) | orR[kind];
+    o.z = ((p01 >> 7) & m8[kind]) | orR[kind];
+    o.w = ((p23 >> 7) & m8[kind]) | orR[kind];
+    return __builtin_bit_cast(h8, o);
+  };
+
+  MmStep cur, nxt;
+  if (!next(cur)) return;
+  MmRaw raw, rawN;
+  fetch(cur, raw);
+  for (;;)
+  {
+    const bool more = next(nxt);
+    const bool luma = cur.mode == 1;
+    // ---- per-lane view of the step: the PU whose columns / rows this lane's TABLE rows and OUTPUT belong to (chroma: by c16 >> 3)
+    const bool outB = !luma && c16 >= 8;
+    const MmDesc& dO = outB ? cur.b : cur.a;
+    const bool hasB = cur.iB >= 0;
+    const int bi = dO.bi;
+    const bool hOnly0 = bi == 0 && dO.fy0 == 0 && dO.fx0 != 0;
+    const bool anyH = __ballot(hOnly0) != 0ull;
+    const int nRef = (cur.a.bi == 1 || (hasB && cur.b.bi == 1)) ? 2 : 1;
+    // window operands; a sample outside the bit depth sends its PU to the generic kernel
+    h8 wA[2][2];
+    unsigned bad = 0;
+    {
+      const bool cst = luma ? g == 3 : (g & 1) == 1;
+      const unsigned andX = cst ? 0u : 0xFFFFFFFFu, orXw = cst ? 0x64003C00u : 0x64006400u;
+      const unsigned andR = (luma && cst) ? 0u : 0xFFFFFFFFu, orRw = (luma && cst) ? 0u : 0x64006400u;
+#pragma unroll
+      for (int rf = 0; rf < 2; rf++)
+#pragma unroll
+        for (int ch = 0; ch < 2; ch++)
+        {
+          uint4 u = raw.w[rf][ch];
+          bad |= (u.x | u.y | u.z | u.w) & ~rangeMask;
+          u.x = (u.x & andX) | orXw; u.y = (u.y & andR) | orRw; u.z = (u.z & andR) | orRw; u.w = (u.w & andR) | orRw;
+          wA[rf][ch] = __builtin_bit_cast(h8, u);
+        }
+    }
+    const unsigned long long badLanes = __ballot(bad != 0);
+    const bool badA = luma ? badLanes != 0ull : (badLanes & 0x00000000FFFFFFFFull) != 0ull;      // chroma: lane groups 0, 1 loaded PU a
+    const bool badB = !luma && hasB && (badLanes & 0xFFFFFFFF00000000ull) != 0ull;
+    if (lane == 0) { flags[cur.iA] = badA; if (hasB) flags[cur.iB] = badB; }
+
+    float fr[2][4];
+#pragma unroll
+    for (int rf = 0; rf < 2; rf++)
+    {
+      if (rf >= nRef) { fr[1][0] = fr[1][1] = fr[1][2] = fr[1][3] = 0.f; break; }
+      const int fx = rf ? dO.fx1 : dO.fx0, fy = rf ? dO.fy1 : dO.fy0;
+      const bool hO = rf == 0 && hOnly0;
+      const float magic = hO ? magicH : magicN;
+      f4 acc;
+      if (luma)
+      {
+        const h8 ta = *reinterpret_cast<const h8*>(tabS + ((MM_TAL + (hO ? 256 : 0) + fx * 64 + lane) * 8));
+        const h8 tb0 = *reinterpret_cast<const h8*>(tabS + ((MM_TBL + fy * 128 + lane) * 8));
+        const h8 tb1 = *reinterpret_cast<const h8*>(tabS + ((MM_TBL + fy * 128 + 64 + lane) * 8));
+        const f4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wA[rf][0], ta, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+        const f4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wA[rf][1], ta, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+        const h8 p0 = anyH ? limbs(a0, magic, 0, hO) : limbs(a0, magic, 0, false);
+        const h8 p1 = anyH ? limbs(a1, magic, 1, hO) : limbs(a1, magic, 1, false);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(p0, tb0, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(p1, tb1, acc, 0, 0, 0);
+      }
+      else
+      {
+        // pass 1: this lane's table row is non-zero only in the k range of ITS PU (lane group pair g >> 1 == c16 >> 3)
+        const int rowA = ((g >> 1) == (c16 >> 3) && (c16 < 8 || hasB)) ? ((hO ? 128 : 0) + fx * 16 + (c16 & 7) * 2 + (g & 1)) : 2 * 8 * 16;
+        const h8 ta = *reinterpret_cast<const h8*>(tabS + ((MM_TAC + rowA) * 8));
+        const h8 tb = *reinterpret_cast<const h8*>(tabS + ((MM_TBC + fy * 32 + (c16 & 7) * 4 + g) * 8));
+        const f4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wA[rf][0], ta, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+        const h8 p0 = anyH ? limbs(a0, magic, 2, hO) : limbs(a0, magic, 2, false);
+        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(p0, tb, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+      }
+      // second-stage rounding of this list: bi acc >> 6; uni (acc + offset) >> (6 + headroom); rounded horizontal-only: the pass-2 copy, acc / 64
+      const float sc = (bi == 1 || hO) ? scBi1 : scUni1, of = (bi == 1 || hO) ? 0.f : ofUni1;
+#pragma unroll
+      for (int j = 0; j < 4; j++) fr[rf][j] = floorf(__builtin_fmaf(acc[j], sc, of));
+      if (rf == 0 && more) fetch(nxt, rawN);                 // the next step's samples travel behind the rest of this one
+    }
+    if (nRef == 1 && more) { /* fetched above */ }
+    // ---- average / clip: (f0 + f1 + offset) >> shiftNum for bi, f0 for uni; + 1024 so that the truncating f16 conversion is the floor and the clip packed
+    {
+      const float w1 = bi == 1 ? 1.f : 0.f, sc2 = bi == 1 ? scBi2 : 1.f, of2 = bi == 1 ? ofBi2 : 1024.f;
+      float t[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++) t[j] = __builtin_fmaf(__builtin_fmaf(fr[1][j], w1, fr[0][j]), sc2, of2);
+      mm_h2 q0 = __builtin_bit_cast(mm_h2, __builtin_amdgcn_cvt_pkrtz(t[0], t[1])), q1 = __builtin_bit_cast(mm_h2, __builtin_amdgcn_cvt_pkrtz(t[2], t[3]));
+      q0 = __builtin_elementwise_min(__builtin_elementwise_max(q0, pmin), pmax);
+      q1 = __builtin_elementwise_min(__builtin_elementwise_max(q1, pmin), pmax);
+      uint2 o;
+      o.x = __builtin_bit_cast(unsigned, q0) & 0x03FF03FFu;
+      o.y = __builtin_bit_cast(unsigned, q1) & 0x03FF03FFu;
+      // lane (c16, g) holds row c16 (chroma: c16 & 7 of PU c16 >> 3), columns 4 g .. 4 g + 3 (chroma: 4 (g & 1) ..; real when g >> 1 == c16 >> 3)
+      const bool real = luma ? !badA : ((g >> 1) == (c16 >> 3) && (outB ? (hasB && !badB) : !badA));
+      if (real)
+      {
+        Pel* dp = dstBase + dO.dst + (ptrdiff_t)(luma ? c16 : (c16 & 7)) * dO.ds + 4 * (luma ? g : (g & 1));
+        struct __attribute__((packed, aligned(2))) U2 { uint2 v; };
+        reinterpret_cast<U2*>(dp)->v = o;
+      }
+    }
+    if (!more) break;
+    cur = nxt;
+    raw = rawN;
+  }
+}
+
+// the table image of mc_mfma_kernel per device and bit depth
+static const _Float16* mm_image(int bd)
+{
+  static std::mutex mtx;
+  static _Float16* images[64][3] = { { nullptr } };
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) { vvcgpu_set_error("mc image: device index"); return nullptr; }
+  std::lock_guard<std::mutex> lock(mtx);
+  _Float16*& slot = images[dev][bd - 8];
+  if (!slot)
+  {
+    void* p = nullptr;
+    hipError_t e = hipMalloc(&p, MM_ENTRIES * 16);
+    if (e != hipSuccess) { (void)hipGetLastError(); vvcgpu_set_error("mc image: hipMalloc failed: %s", hipGetErrorString(e)); return nullptr; }
+    hipLaunchKernelGGL(mm_build_tables_kernel, dim3(cdiv(MM_ENTRIES * 8, 256)), dim3(256), 0, (hipStream_t)0, static_cast<_Float16*>(p), bd);
+    e = hipGetLastError();
+    if (e == hipSuccess) e = hipDeviceSynchronize();
+    if (e != hipSuccess) { (void)hipFree(p); vvcgpu_set_error("building the motion-compensation table image failed: %s", hipGetErrorString(e)); return nullptr; }
+    slot = static_cast<_Float16*>(p);
+  }
+  return slot;
+}
+
 // four 4x4 luma PUs side by side, sixteen lanes each, through the packed code of the fast kernel (N = 8 taps, tile 4, 16 lanes: 11 window rows of
 // 6 dwords, 11 first-pass items, 4 second-pass items per PU).  Affine prediction is made of these: a whole wave per sub-block through the
 // sample-wise body was 0.6 ms for the 518 k sub-blocks of a 4K picture.  Only in the SUB44 variant of the generic kernel (the affine entry points
@@ -559,7 +900,8 @@ template <bool DIST, bool SUB44 = false>
 __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
                                                       Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs,
                                                       int bd, int cmin, int cmax,
-                                                      int nDirect, int distKind, const Pel* __restrict__ orgBase, unsigned long long* __restrict__ out, int chunk)
+                                                      int nDirect, int distKind, const Pel* __restrict__ orgBase, unsigned long long* __restrict__ out, int chunk,
+                                                      const int* __restrict__ flags)
 {
   __shared__ short win[WR * WP];
   __shared__ short tmp[WR * ST];
@@ -581,7 +923,7 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
     {
       const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(descs + base0 + lane) + 32);     // dst_stride | w, h | phases | is_luma, bi
       const int isLuma = (int)(signed char)(q.w & 0xFFu), qw = (int)(short)(q.y & 0xFFFFu), qh = (int)(short)(q.y >> 16);
-      mine = !mc_is_fast(isLuma, qw, qh);
+      mine = !mc_is_fast(isLuma, qw, qh) || (flags && flags[base0 + lane] != 0);       // (flags: the fast shapes the matrix-core kernel in front has left)
       sub44 = SUB44 && isLuma && qw == 4 && qh == 4;
     }
     todo = __builtin_amdgcn_ballot_w64(mine);
@@ -934,16 +1276,30 @@ int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc
   if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("mc_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
   const int xcd = vvc_xcd_on();
-  if (!skip_fast)
+  static const int mfmaOff = getenv("VVCGPU_NO_MC_MFMA") ? 1 : 0;         // A/B timing switch: the vector-pipe fast kernel
+  const int* flags = nullptr;
+  if (!skip_fast && !mfmaOff)
+  {
+    const _Float16* image = mm_image(bit_depth);
+    if (!image) return VVCGPU_E_DEVICE;
+    int* fl = static_cast<int*>(vvcgpu_scratch(st, (size_t)n * sizeof(int)));
+    if (!fl) return VVCGPU_E_DEVICE;
+    const int npairs = (n + 1) / 2, cap = 256 * 5;                       // five workgroups per CU; a wave walks its descriptor pairs
+    const int nWg = cdiv(npairs, 4) < cap ? cdiv(npairs, 4) : cap;
+    hipLaunchKernelGGL(mc_mfma_kernel<5>, dim3(vvc_xcd_grid(nWg, xcd)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
+                       dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl, nWg, xcd);
+    flags = fl;
+  }
+  else if (!skip_fast)
     hipLaunchKernelGGL(mc_fast_kernel, dim3(vvc_xcd_grid(cdiv(n, 8), xcd)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
                        dst_base, descs, n, bit_depth, clp_min, clp_max, cdiv(n, 8), xcd);
   const int chunk = n >= 64 * 8192 ? 64 : (n + 8191) / 8192;            // ~8192 waves: 32 per CU
   if (sub44)
     hipLaunchKernelGGL((mc_batch_kernel<false, true>), dim3(cdiv(n, chunk) < 8192 ? cdiv(n, chunk) : 8192), dim3(64), 0, st, ref0_base,
-                       ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk);
+                       ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk, flags);
   else
     hipLaunchKernelGGL((mc_batch_kernel<false, false>), dim3(cdiv(n, chunk) < 8192 ? cdiv(n, chunk) : 8192), dim3(64), 0, st, ref0_base,
-                       ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk);
+                       ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk, flags);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
@@ -957,7 +1313,7 @@ int vvcgpu_mc_dist_batch(int kind, const vvc_pel* ref0_base, const vvc_pel* ref1
   VVC_CHECK_ARG(ref0_base && org_base && descs && out, "mc_dist_batch: null pointer");
   if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("mc_dist_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
   hipLaunchKernelGGL((mc_batch_kernel<true, false>), dim3(n < 4096 ? n : 4096), dim3(64), 0, (hipStream_t)stream, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     nullptr, descs, bit_depth, clp_min, clp_max, n, kind, org_base, reinterpret_cast<unsigned long long*>(out), 1);
+                     nullptr, descs, bit_depth, clp_min, clp_max, n, kind, org_base, reinterpret_cast<unsigned long long*>(out), 1, nullptr);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
