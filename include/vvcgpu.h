@@ -265,10 +265,13 @@ int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_
  *           :497-504; is_luma selects the 8-tap table m_lumaFilter[16][8] or the 4-tap m_chromaFilter[32][4].
  * bi = 0: dst = clipped uni-prediction from ref0.   bi = 1: dst = addAvg(pred(ref0), pred(ref1)).
  * bi = 2: dst = the unrounded 14-bit intermediate of ref0 (what motionCompensation leaves in m_acYuvPred).
- * Reads: the rows / columns the reference's branch reads ((N - 1) extra rows only when frac_y != 0, columns likewise), as whole aligned
- * dwords -- i.e. at most TWO samples left of and two samples right of them IN THE SAME ROW (the x86 filters over-read further:
- * picture margins cover it).  16x16 luma and 8x8 chroma PUs take the packed fast path; PUs that are grids of such tiles walk it tile by tile;
- * every result is bit-equal to the reference. */
+ * Reads: the rows / columns the reference's branch reads ((N - 1) extra rows only when frac_y != 0, columns likewise), as whole ALIGNED
+ * 16-byte words (16x16 luma PUs on the matrix-core path, reference strides that are multiples of 8 samples) or aligned dwords (everything else)
+ * -- i.e. at most SEVEN samples left of and seven samples right of them IN THE SAME ROW and inside the aligned 16-byte words that hold them (the
+ * x86 filters over-read as far: picture margins cover it; a plane whose rows start 16-byte aligned is never read outside its rows).  16x16 luma
+ * and 8x8 chroma PUs with bi 0 / 1 and quarter- (chroma: eighth-) sample phases take the matrix-core path (both filter passes as exact f16
+ * products); other phases, bi = 2 and reference samples outside the bit depth take the packed vector path; PUs that are grids of such tiles
+ * walk it tile by tile; every result is bit-equal to the reference. */
 typedef struct vvcgpu_mc_desc {
   int64_t ref0_off, ref1_off, dst_off;
   int32_t ref0_stride, ref1_stride, dst_stride;

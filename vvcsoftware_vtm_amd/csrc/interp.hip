@@ -537,8 +537,8 @@ __global__ __launch_bounds__(256, 6) void mc_fast_kernel(const Pel* __restrict__
 //   rounding and the clip in pass 1 (own constants) and a copy in pass 2.
 // PUs it cannot take (bi == 2, other phases, reference samples outside the bit depth) are flagged for the generic kernel behind it.
 typedef _Float16 mm_h2 __attribute__((ext_vector_type(2)));
-constexpr int MM_TAL = 0;                                    // [2 variants][4 phases][64 lanes]            luma pass 1
-constexpr int MM_TBL = MM_TAL + 2 * 4 * 64;                  // [4 phases][2 row chunks][64 lanes]          luma pass 2
+constexpr int MM_TAL = 0;                                    // [4 phases][23 columns x + shift][4 lane groups]  luma pass 1
+constexpr int MM_TBL = MM_TAL + 4 * 23 * 4;                  // [4 phases][2 row chunks][64 lanes]          luma pass 2
 constexpr int MM_TAC = MM_TBL + 4 * 2 * 64;                  // [2 variants][8 phases][8 x][2] + a zero row   chroma pass 1
 constexpr int MM_TBC = MM_TAC + 2 * 8 * 16 + 1;              // [8 phases][8 y][4 lane groups]               chroma pass 2
 constexpr int MM_ENTRIES = MM_TBC + 8 * 32;                  // 16-byte entries (eight f16 each)
@@ -556,15 +556,12 @@ __global__ void mm_build_tables_kernel(_Float16* __restrict__ tab, int bd)
   float v = 0.f;
   if (ent < MM_TBL)
   {
-    const int var = ent / 256, q = (ent / 64) & 3, lane = ent & 63, x = lane & 15, g = lane >> 4;
-    if (g == 3) v = e == 0 ? b0[var] : e == 1 ? b1[var] : 0.f;
-    else
-    {
-      // window column of k = 8 g + e: phases != 0 load columns 0..7 | 8..15 | 15..22 (column 15 once), phase 0 loads 3..10 | 11..18 | (unused)
-      const int col = q == 0 ? (g == 0 ? 3 + e : g == 1 ? 11 + e : -100) : (g == 0 ? e : g == 1 ? 8 + e : (e == 0 ? -100 : 15 + e));
-      const int t = col - x;
-      if (t >= 0 && t <= 7) v = (float)c_lumaFilter[4 * q][t];
-    }
+    // luma pass 1 reads whole ALIGNED 16-byte words: k = 8 g + e is the column of the aligned row segment, the window starts `shift` (0..7) columns into
+    // it, and output x takes its taps from columns x + shift .. + 7: the table row depends on x + shift only (the start value of the sum travels in the
+    // accumulator)
+    const int q = ent / 92, xs = (ent % 92) >> 2, g = ent & 3;
+    const int t = 8 * g + e - xs;
+    if (t >= 0 && t <= 7) v = (float)c_lumaFilter[4 * q][t];
   }
   else if (ent < MM_TAC)
   {
@@ -599,7 +596,6 @@ __global__ void mm_build_tables_kernel(_Float16* __restrict__ tab, int bd)
   tab[i] = (_Float16)v;
 }
 
-struct MmDesc { long long ref0, ref1, dst; int rs0, rs1, ds; int fx0, fy0, fx1, fy1, bi; };   // the fields a step needs (phases as table indices)
 // which of the kernel's shapes a descriptor is: 1 luma 16x16, 2 chroma 8x8 (phases on the quarter / eighth grid, bi 0 or 1), 0 other; -1: a fast SHAPE
 // that is left to the generic kernel
 __device__ __forceinline__ int mm_kind(const vvcgpu_mc_desc& d)
@@ -609,230 +605,362 @@ __device__ __forceinline__ int mm_kind(const vvcgpu_mc_desc& d)
   if ((m & 3) || m < 0 || m >= (d.is_luma ? 16 : 32) || d.bi < 0 || d.bi > 1) return -1;
   return d.is_luma ? 1 : 2;
 }
-__device__ __forceinline__ MmDesc mm_lite(const vvcgpu_mc_desc& d)
+
+struct MmK                                                   // lane constants of mc_mfma_kernel
 {
-  MmDesc m;
-  m.ref0 = d.ref0_off; m.ref1 = d.bi == 1 ? d.ref1_off : d.ref0_off; m.dst = d.dst_off;
-  m.rs0 = d.ref0_stride; m.rs1 = d.bi == 1 ? d.ref1_stride : d.ref0_stride; m.ds = d.dst_stride;
-  m.fx0 = d.frac_x0 >> 2; m.fy0 = d.frac_y0 >> 2; m.fx1 = d.bi == 1 ? d.frac_x1 >> 2 : 0; m.fy1 = d.bi == 1 ? d.frac_y1 >> 2 : 0; m.bi = d.bi;
-  return m;
+  const _Float16* tabS;
+  int lane, c16, g, hr;
+  unsigned m7[3], m8[3], orX[3], orR[3];                     // limb masks / exponent patterns of a pass-1 result by row-chunk kind (see the kernel)
+  unsigned rangeMask, uLo, uHi;
+  float magicN, magicH, scBi1, scUni1, ofUni1, scBi2, ofBi2, cinN, cinH;
+  mm_h2 pmin, pmax;
+  int perm;                                                  // ds_bpermute address: lane (row & 15) + 16 chunk <- lane 4 (row & 15) + chunk
+};
+
+// pass-1 result registers -> limb operand (kind: 0 every row real; 1 luma rows 16..31; 2 chroma rows 0..15); hclip (per lane): the rounded horizontal-only
+// filter's clip of the last stage, on u = sample + 16384
+template <bool ANYH>
+__device__ __forceinline__ h8 mm_limbs(const MmK& K, const f4& acc, float magic, int kind, bool hclip)
+{
+  unsigned u[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) u[j] = __builtin_bit_cast(unsigned, acc[j] + magic);
+  unsigned p01 = __builtin_amdgcn_perm(u[1], u[0], 0x05040100u), p23 = __builtin_amdgcn_perm(u[3], u[2], 0x05040100u);
+  if (ANYH)
+  {
+    typedef unsigned short us2 __attribute__((ext_vector_type(2)));
+    const unsigned lo = hclip ? K.uLo : 0u, hi = hclip ? K.uHi : 0xFFFFFFFFu;
+    p01 = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(us2, p01), __builtin_bit_cast(us2, lo)), __builtin_bit_cast(us2, hi)));
+    p23 = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(us2, p23), __builtin_bit_cast(us2, lo)), __builtin_bit_cast(us2, hi)));
+  }
+  uint4 o;
+  o.x = (p01 & K.m7[kind]) | K.orX[kind];
+  o.y = (p23 & K.m7[kind]) | K.orR[kind];
+  o.z = ((p01 >> 7) & K.m8[kind]) | K.orR[kind];
+  o.w = ((p23 >> 7) & K.m8[kind]) | K.orR[kind];
+  return __builtin_bit_cast(h8, o);
+}
+// window registers as loaded -> A operand; cst: this lane's first two columns are the product's constants (chroma) / the whole lane is (luma)
+__device__ __forceinline__ h8 mm_window(const MmK& K, uint4 u, bool cst, bool wholeLane, unsigned& bad)
+{
+  bad |= (u.x | u.y | u.z | u.w) & ~K.rangeMask;
+  const unsigned andX = cst ? 0u : 0xFFFFFFFFu, orXw = cst ? 0x64003C00u : 0x64006400u;
+  const unsigned andR = (cst && wholeLane) ? 0u : 0xFFFFFFFFu, orRw = (cst && wholeLane) ? 0u : 0x64006400u;
+  u.x = (u.x & andX) | orXw; u.y = (u.y & andR) | orRw; u.z = (u.z & andR) | orRw; u.w = (u.w & andR) | orRw;
+  return __builtin_bit_cast(h8, u);
+}
+// the tail of a PU: (f0 + f1 + offset) >> shiftNum for bi, f0 for uni (w1 = 0, sc2 = 1), + 1024 so that the truncating f16 conversion is the floor and the
+// clip is packed; the four samples as two dwords
+__device__ __forceinline__ uint2 mm_tail(const MmK& K, const float (&f0)[4], const float (&f1)[4], float w1, float sc2, float of2)
+{
+  float t[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++) t[j] = __builtin_fmaf(__builtin_fmaf(f1[j], w1, f0[j]), sc2, of2);
+  mm_h2 q0 = __builtin_bit_cast(mm_h2, __builtin_amdgcn_cvt_pkrtz(t[0], t[1])), q1 = __builtin_bit_cast(mm_h2, __builtin_amdgcn_cvt_pkrtz(t[2], t[3]));
+  q0 = __builtin_elementwise_min(__builtin_elementwise_max(q0, K.pmin), K.pmax);
+  q1 = __builtin_elementwise_min(__builtin_elementwise_max(q1, K.pmin), K.pmax);
+  uint2 o;
+  o.x = __builtin_bit_cast(unsigned, q0) & 0x03FF03FFu;
+  o.y = __builtin_bit_cast(unsigned, q1) & 0x03FF03FFu;
+  return o;
+}
+struct __attribute__((packed, aligned(2))) MmQuad { uint2 v; };
+struct MmRaw { uint4 w[2][2]; unsigned dstLo, dstHi, ds, frac, flg; };    // samples as loaded [reference][row chunk] (+ chroma: the output PU's descriptor fields)
+struct MmWin { h8 w[2][2]; unsigned bad, dstLo, dstHi, ds, frac, flg; };   // a step's window operands; the loaded registers are free again
+
+// ---- luma PU: everything about the descriptor is wave-uniform (scalar registers)
+// window origin of a luma PU in reference rf as (16-byte aligned pointer, shift): the window's column 0 is `shift` samples into the aligned row segment
+__device__ __forceinline__ const Pel* mm_luma_origin(const vvcgpu_mc_desc& d, int rf, const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base, int& shift)
+{
+  const Pel* p0 = (rf ? ref1Base + d.ref1_off : ref0Base + d.ref0_off) - (ptrdiff_t)3 * (rf ? d.ref1_stride : d.ref0_stride) - 3;
+  shift = (int)((reinterpret_cast<uintptr_t>(p0) >> 1) & 7);
+  return p0 - shift;
+}
+// Loads in ROW-MAJOR lane order -- lane 4 r + c takes aligned word c of row r: the four lanes of a row are one 64-byte access of the vector cache, 16
+// accesses per instruction instead of the 64+ that a lane per (row, eight unaligned columns) costs (measured: the cache's access rate, not bandwidth or
+// latency, bound the kernel at 65 us).  Requires strides that are multiples of 8 samples (the caller of this function checks); words that hold no
+// column the reference reads are not touched (the lane repeats a neighbour's word).
+__device__ __forceinline__ void mm_fetch_luma(const MmK& K, const vvcgpu_mc_desc& d, const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base, MmRaw& r)
+{
+  const int nRef = d.bi == 1 ? 2 : 1;
+#pragma unroll
+  for (int rf = 0; rf < 2; rf++)
+  {
+    if (rf >= nRef) { r.w[1][0] = r.w[0][0]; r.w[1][1] = r.w[0][1]; break; }
+    int shift;
+    const Pel* pA = mm_luma_origin(d, rf, ref0Base, ref1Base, shift);
+    const int rs = rf ? d.ref1_stride : d.ref0_stride, fx = rf ? d.frac_x1 : d.frac_x0, fy = rf ? d.frac_y1 : d.frac_y0;
+    const int cLo = fx ? 0 : (3 + shift) >> 3, cHi = fx ? (22 + shift) >> 3 : (18 + shift) >> 3;
+    const int word = min(max(K.lane & 3, cLo), cHi);
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++)
+    {
+      const int row = fy ? min(16 * ch + (K.lane >> 2), 22) : min(max(16 * ch + (K.lane >> 2), 3), 18);
+      r.w[rf][ch] = *reinterpret_cast<const uint4*>(pA + (ptrdiff_t)row * rs + 8 * word);
+    }
+  }
+}
+__device__ __forceinline__ void mm_luma_win(const MmK& K, const MmRaw& raw, MmWin& W)
+{
+  W.bad = 0;
+#pragma unroll
+  for (int rf = 0; rf < 2; rf++)
+#pragma unroll
+    for (int ch = 0; ch < 2; ch++)
+    {
+      uint4 u = raw.w[rf][ch];
+      W.bad |= (u.x | u.y | u.z | u.w) & ~K.rangeMask;       // (over the whole aligned words: a neighbour outside the bit depth costs the PU the fast path, no more)
+      // operand layout: lane (row & 15) + 16 word; every sample masked to the bit depth first: 0x6400 | v must stay a finite f16 whatever the word held
+      u.x = (unsigned)__builtin_amdgcn_ds_bpermute(K.perm, (int)((u.x & K.rangeMask) | 0x64006400u));
+      u.y = (unsigned)__builtin_amdgcn_ds_bpermute(K.perm, (int)((u.y & K.rangeMask) | 0x64006400u));
+      u.z = (unsigned)__builtin_amdgcn_ds_bpermute(K.perm, (int)((u.z & K.rangeMask) | 0x64006400u));
+      u.w = (unsigned)__builtin_amdgcn_ds_bpermute(K.perm, (int)((u.w & K.rangeMask) | 0x64006400u));
+      W.w[rf][ch] = __builtin_bit_cast(h8, u);
+    }
+}
+__device__ __forceinline__ void mm_luma(const MmK& K, const vvcgpu_mc_desc& d, const MmWin& W, const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
+                                        Pel* __restrict__ dstBase, int* __restrict__ flags, int idx)
+{
+  const int nRef = d.bi == 1 ? 2 : 1;
+  const bool hOnly = d.bi == 0 && d.frac_y0 == 0 && d.frac_x0 != 0;
+  float fr[2][4] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
+#pragma unroll
+  for (int rf = 0; rf < 2; rf++)
+  {
+    if (rf >= nRef) break;
+    const int fx = (rf ? d.frac_x1 : d.frac_x0) >> 2, fy = (rf ? d.frac_y1 : d.frac_y0) >> 2;
+    const int shift = (int)(((reinterpret_cast<uintptr_t>(rf ? ref1Base + d.ref1_off : ref0Base + d.ref0_off) >> 1) - 3 - 3 * (rf ? d.ref1_stride : d.ref0_stride)) & 7);
+    const h8 ta = *reinterpret_cast<const h8*>(K.tabS + ((MM_TAL + fx * 92 + (K.c16 + shift) * 4 + K.g) * 8));
+    const float cin = hOnly ? K.cinH : K.cinN;
+    const f4 cin4 = { cin, cin, cin, cin };
+    const h8 tb0 = *reinterpret_cast<const h8*>(K.tabS + ((MM_TBL + fy * 128 + K.lane) * 8));
+    const h8 tb1 = *reinterpret_cast<const h8*>(K.tabS + ((MM_TBL + fy * 128 + 64 + K.lane) * 8));
+    const f4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.w[rf][0], ta, cin4, 0, 0, 0);
+    const f4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(W.w[rf][1], ta, cin4, 0, 0, 0);
+    h8 p0, p1;
+    if (hOnly) { p0 = mm_limbs<true>(K, a0, K.magicH, 0, true); p1 = mm_limbs<true>(K, a1, K.magicH, 1, true); }
+    else       { p0 = mm_limbs<false>(K, a0, K.magicN, 0, false); p1 = mm_limbs<false>(K, a1, K.magicN, 1, false); }
+    f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(p0, tb0, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+    acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(p1, tb1, acc, 0, 0, 0);
+    // second-stage rounding of this list: bi acc >> 6; uni (acc + offset) >> (6 + headroom); rounded horizontal-only: the pass-2 copy, acc / 64
+    const float sc = (d.bi == 1 || hOnly) ? K.scBi1 : K.scUni1, of = (d.bi == 1 || hOnly) ? 0.f : K.ofUni1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) fr[rf][j] = floorf(__builtin_fmaf(acc[j], sc, of));
+  }
+  const bool isBad = __ballot(W.bad != 0) != 0ull;           // a reference sample outside the bit depth: the generic kernel takes the PU
+  if (K.lane == 0) flags[idx] = isBad;
+  if (isBad) return;
+  const uint2 o = mm_tail(K, fr[0], fr[1], d.bi == 1 ? 1.f : 0.f, d.bi == 1 ? K.scBi2 : 1.f, d.bi == 1 ? K.ofBi2 : 1024.f);
+  Pel* dp = dstBase + d.dst_off + (ptrdiff_t)K.c16 * d.dst_stride + 4 * K.g;                 // lane (c16, g): row c16, columns 4 g .. 4 g + 3
+  reinterpret_cast<MmQuad*>(dp)->v = o;
 }
 
-struct MmStep { int mode; int iA, iB; MmDesc a, b; };        // mode 1: luma PU a; 2: chroma PUs a (columns 0..7 of the products) and b (8..15; iB < 0: absent)
-struct MmRaw { uint4 w[2][2]; };                             // [reference][row chunk] as loaded
-
-template <int WPS>
-__global__ __launch_bounds__(256, WPS) void mc_mfma_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base, Pel* __restrict__ dstBase,
-                                                           const vvcgpu_mc_desc* __restrict__ descs, int n, int bd, int cmin, int cmax,
-                                                           const _Float16* __restrict__ image, int* __restrict__ flags, int nWg, int xcd)
+// ---- chroma: PUs iA (columns 0..7 of the products) and iB (8..15; < 0: absent).  A lane reads the descriptor fields it needs from ITS PU as vector loads:
+// lane groups 2, 3 LOAD the samples of PU B; lanes with c16 >= 8 hold PU B's table rows and output
+__device__ __forceinline__ void mm_fetch_chroma(const MmK& K, const vvcgpu_mc_desc* __restrict__ descs, int iA, int iB, const Pel* __restrict__ ref0Base,
+                                                const Pel* __restrict__ ref1Base, MmRaw& r)
 {
-  __shared__ __align__(16) _Float16 tabS[MM_ENTRIES * 8];
-  const int wg = vvc_xcd_index((int)blockIdx.x, nWg, xcd);
-  if (wg < 0) return;
-  for (int i = threadIdx.x; i < MM_ENTRIES; i += 256) reinterpret_cast<uint4*>(tabS)[i] = reinterpret_cast<const uint4*>(image)[i];
+  const int iF = (K.g >= 2 && iB >= 0) ? iB : iA, iO = (K.c16 >= 8 && iB >= 0) ? iB : iA;
+  const uint4* pF = reinterpret_cast<const uint4*>(descs + iF);
+  const uint4* pO = reinterpret_cast<const uint4*>(descs + iO);
+  const uint4 q0 = pF[0], q1 = pF[1], q2 = pF[2];
+  const uint4 q1O = pO[1], q2O = pO[2];
+  r.dstLo = q1O.x; r.dstHi = q1O.y; r.ds = q2O.x; r.frac = q2O.z; r.flg = q2O.w;
+  const bool biF = (int)(signed char)((q2.w >> 8) & 0xFFu) == 1;
+#pragma unroll
+  for (int rf = 0; rf < 2; rf++)
+  {
+    const bool second = rf == 1 && biF;
+    const long long off = second ? (long long)(((unsigned long long)q0.w << 32) | q0.z) : (long long)(((unsigned long long)q0.y << 32) | q0.x);
+    const int rs = second ? (int)q1.w : (int)q1.z;
+    const int fx = (int)(signed char)((q2.z >> (second ? 16 : 0)) & 0xFFu), fy = (int)(signed char)((q2.z >> (second ? 24 : 8)) & 0xFFu);
+    const Pel* base = (second ? ref1Base : ref0Base) + off;
+    const int col = fx ? ((K.g & 1) ? 3 : 0) : 1, row = fy ? min(K.c16, 10) : min(max(K.c16, 1), 8);
+    const Pel* q = base + (ptrdiff_t)(row - 1) * rs + (col - 1);
+    pel8 v;
+#pragma unroll
+    for (int e = 0; e < 8; e++) v[e] = q[e];
+    r.w[rf][0] = __builtin_bit_cast(uint4, v);
+  }
+}
+__device__ __forceinline__ void mm_chroma_win(const MmK& K, const MmRaw& raw, MmWin& W)
+{
+  W.bad = 0;
+  W.w[0][0] = mm_window(K, raw.w[0][0], (K.g & 1) == 1, false, W.bad);
+  W.w[1][0] = mm_window(K, raw.w[1][0], (K.g & 1) == 1, false, W.bad);
+  W.dstLo = raw.dstLo; W.dstHi = raw.dstHi; W.ds = raw.ds; W.frac = raw.frac; W.flg = raw.flg;
+}
+__device__ __forceinline__ void mm_chroma(const MmK& K, const MmWin& raw, int iA, int iB, Pel* __restrict__ dstBase, int* __restrict__ flags)
+{
+  const bool hasB = iB >= 0;
+  // the lane's OUTPUT PU (by c16 >> 3)
+  const int bi = (int)(signed char)((raw.flg >> 8) & 0xFFu);
+  const int fx0 = (int)(signed char)(raw.frac & 0xFFu) >> 2, fy0 = (int)(signed char)((raw.frac >> 8) & 0xFFu) >> 2;
+  const int fx1 = (int)(signed char)((raw.frac >> 16) & 0xFFu) >> 2, fy1 = (int)(signed char)((raw.frac >> 24) & 0xFFu) >> 2;
+  const bool hOnly = bi == 0 && fy0 == 0 && fx0 != 0;
+  const bool anyH = __ballot(hOnly) != 0ull;
+  const int nRef = __ballot(bi == 1) != 0ull ? 2 : 1;
+  const bool mineCols = (K.g >> 1) == (K.c16 >> 3) && (K.c16 < 8 || hasB);      // pass 1: this lane's table row is non-zero only in the k range of ITS PU
+  float fr[2][4] = { { 0.f, 0.f, 0.f, 0.f }, { 0.f, 0.f, 0.f, 0.f } };
+#pragma unroll
+  for (int rf = 0; rf < 2; rf++)
+  {
+    if (rf >= nRef) break;
+    const int fx = rf ? fx1 : fx0, fy = rf ? fy1 : fy0;
+    const bool hO = rf == 0 && hOnly;
+    const h8 w0 = raw.w[rf][0];
+    const int rowA = mineCols ? ((hO ? 128 : 0) + fx * 16 + (K.c16 & 7) * 2 + (K.g & 1)) : 2 * 8 * 16;
+    const h8 ta = *reinterpret_cast<const h8*>(K.tabS + ((MM_TAC + rowA) * 8));
+    const h8 tb = *reinterpret_cast<const h8*>(K.tabS + ((MM_TBC + fy * 32 + (K.c16 & 7) * 4 + K.g) * 8));
+    const f4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(w0, ta, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+    const float magic = hO ? K.magicH : K.magicN;
+    const h8 p0 = anyH ? mm_limbs<true>(K, a0, magic, 2, hO) : mm_limbs<false>(K, a0, magic, 2, false);
+    const f4 acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(p0, tb, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+    const float sc = (bi == 1 || hO) ? K.scBi1 : K.scUni1, of = (bi == 1 || hO) ? 0.f : K.ofUni1;
+#pragma unroll
+    for (int j = 0; j < 4; j++) fr[rf][j] = floorf(__builtin_fmaf(acc[j], sc, of));
+  }
+  const unsigned long long badLanes = __ballot(raw.bad != 0);
+  const bool badA = (badLanes & 0x00000000FFFFFFFFull) != 0ull, badB = hasB && (badLanes & 0xFFFFFFFF00000000ull) != 0ull;      // lane groups 0, 1 loaded PU A
+  if (K.lane == 0) { flags[iA] = badA; if (hasB) flags[iB] = badB; }
+  const uint2 o = mm_tail(K, fr[0], fr[1], bi == 1 ? 1.f : 0.f, bi == 1 ? K.scBi2 : 1.f, bi == 1 ? K.ofBi2 : 1024.f);
+  // lane (c16, g): row c16 & 7 of PU c16 >> 3, columns 4 (g & 1) ..; real when g >> 1 == c16 >> 3
+  const bool outB = K.c16 >= 8;
+  if ((K.g >> 1) == (K.c16 >> 3) && (outB ? (hasB && !badB) : !badA))
+  {
+    const long long dstOff = (long long)(((unsigned long long)raw.dstHi << 32) | raw.dstLo);
+    Pel* dp = dstBase + dstOff + (ptrdiff_t)(K.c16 & 7) * (int)raw.ds + 4 * (K.g & 1);
+    reinterpret_cast<MmQuad*>(dp)->v = o;
+  }
+}
+
+// KIND_T 1: the luma PUs of the list, 2: the chroma PUs (two launches: A/B switch), 0: ONE launch whose workgroups alternate between the two shapes -- each
+// workgroup with the LDS tables and the loop of one shape.  Persistent waves; wave w of W owns the descriptors w, w + W, ... (chroma: the descriptor PAIRS,
+// so that two chroma PUs share the products): neighbouring PUs at the same time in neighbouring waves, and whatever runs of shapes the list has are dealt
+// round the waves.  What bound the earlier forms of this kernel, in the order found (profiles/r05_mc_forms.txt): chunks of 64 descriptors per workgroup
+// (a picture's list is rows of luma, then rows of chroma PUs: a third of the waves had all the luma work); a shared claim counter (same-address atomics:
+// ~30 ns each); the scalar unit (one per CU: a descriptor-by-descriptor walk cost 400 scalar instructions per PU -- now a gather load and a ballot
+// classify 64 of the wave's descriptors at once); the vector cache's access rate (a lane per row and eight unaligned columns: 64+ accesses per load).
+__device__ __forceinline__ int mm_kind_of(const uint4& q)   // bytes 32..47 of a descriptor: dst_stride | w, h | phases | is_luma, bi
+{
+  vvcgpu_mc_desc d;
+  d.w = (short)(q.y & 0xFFFFu); d.h = (short)(q.y >> 16);
+  d.frac_x0 = (signed char)(q.z & 0xFFu); d.frac_y0 = (signed char)((q.z >> 8) & 0xFFu); d.frac_x1 = (signed char)((q.z >> 16) & 0xFFu); d.frac_y1 = (signed char)(q.z >> 24);
+  d.is_luma = (signed char)(q.w & 0xFFu); d.bi = (signed char)((q.w >> 8) & 0xFFu);
+  return mm_kind(d);
+}
+template <int KIND_T>
+__global__ __launch_bounds__(256, 4) void mc_mfma_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base, Pel* __restrict__ dstBase,
+                                                                         const vvcgpu_mc_desc* __restrict__ descs, int n, int bd, int cmin, int cmax,
+                                                                         const _Float16* __restrict__ image, int* __restrict__ flags)
+{
+  // KIND_T 0: ONE launch, workgroups alternate between the two shapes (both kinds of waves on every CU at the same time)
+  const int KIND = KIND_T ? KIND_T : 1 + ((int)blockIdx.x & 1);
+  const int T0 = KIND == 1 ? MM_TAL : MM_TAC, T1 = KIND == 1 ? MM_TAC : MM_ENTRIES;          // this kind's table entries
+  __shared__ __align__(16) _Float16 tabL[(KIND_T == 2 ? MM_ENTRIES - MM_TAC : MM_TAC - MM_TAL) * 8];
+  for (int i = threadIdx.x; i < T1 - T0; i += 256) reinterpret_cast<uint4*>(tabL)[i] = reinterpret_cast<const uint4*>(image)[T0 + i];
   __syncthreads();
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), c16 = lane & 15, g = lane >> 4;
+  MmK K;
+  K.tabS = tabL - T0 * 8;                                    // (indexed with the image's entry numbers)
+  K.lane = threadIdx.x & 63; K.c16 = K.lane & 15; K.g = K.lane >> 4;
+  const int g = K.g;
   const int hr = max(2, IF_INTERNAL_PREC - bd), S = 1 << (IF_FILTER_PREC - hr);
-  const unsigned rangeMask = (unsigned)((1 << bd) - 1) * 0x10001u;
+  K.hr = hr;
+  K.rangeMask = (unsigned)((1 << bd) - 1) * 0x10001u;
+  K.uLo = (unsigned)(16384 + cmin) * 0x10001u; K.uHi = (unsigned)(16384 + cmax) * 0x10001u;
   // limb masks / exponent patterns of a pass-1 result by row-chunk kind: 0 every row real; 1 luma rows 16..31 (lane group 2: the constants 1.0, 1024.0;
   // 3: nothing); 2 chroma rows 0..15 (lane group 3: the constants)
-  unsigned m7[3], m8[3], orX[3], orR[3];
-  m7[0] = 0x007F007Fu; m8[0] = 0x00FF00FFu; orX[0] = 0x64006400u;
-  asm("" : "+v"(m7[0]), "+v"(m8[0]), "+v"(orX[0]));          // held in vector registers (v_and_or_b32 takes no literal)
-  orR[0] = orX[0];
-  m7[1] = g < 2 ? 0x007F007Fu : 0u; m8[1] = g < 2 ? 0x00FF00FFu : 0u; orX[1] = g < 2 ? 0x64006400u : g == 2 ? 0x64003C00u : 0u; orR[1] = g < 2 ? 0x64006400u : 0u;
-  m7[2] = g < 3 ? 0x007F007Fu : 0u; m8[2] = g < 3 ? 0x00FF00FFu : 0u; orX[2] = g < 3 ? 0x64006400u : 0x64003C00u; orR[2] = g < 3 ? 0x64006400u : 0u;
-  const float magicN = 8388608.f * (float)S, magicH = 536870912.f;
-  const mm_h2 pmin = { (_Float16)(short)(1024 + cmin), (_Float16)(short)(1024 + cmin) }, pmax = { (_Float16)(short)(1024 + cmax), (_Float16)(short)(1024 + cmax) };
+  K.m7[0] = 0x007F007Fu; K.m8[0] = 0x00FF00FFu; K.orX[0] = 0x64006400u;
+  asm("" : "+v"(K.m7[0]), "+v"(K.m8[0]), "+v"(K.orX[0]));   // held in vector registers (v_and_or_b32 takes no literal)
+  K.orR[0] = K.orX[0];
+  K.m7[1] = g < 2 ? 0x007F007Fu : 0u; K.m8[1] = g < 2 ? 0x00FF00FFu : 0u; K.orX[1] = g < 2 ? 0x64006400u : g == 2 ? 0x64003C00u : 0u; K.orR[1] = g < 2 ? 0x64006400u : 0u;
+  K.m7[2] = g < 3 ? 0x007F007Fu : 0u; K.m8[2] = g < 3 ? 0x00FF00FFu : 0u; K.orX[2] = g < 3 ? 0x64006400u : 0x64003C00u; K.orR[2] = g < 3 ? 0x64006400u : 0u;
+  K.magicN = 8388608.f * (float)S; K.magicH = 536870912.f;
+  K.cinN = 8192.f * (float)S - 65536.f - 0.5f * (float)(S - 1); K.cinH = 983040.5f;     // start values of a luma pass-1 sum (the chroma tables carry theirs)
+  K.perm = (4 * K.c16 + K.g) * 4;
+  K.pmin = mm_h2{ (_Float16)(short)(1024 + cmin), (_Float16)(short)(1024 + cmin) }; K.pmax = mm_h2{ (_Float16)(short)(1024 + cmax), (_Float16)(short)(1024 + cmax) };
   // second-stage rounding as fma + floor (exact: f32 integers below 2^24 times powers of two)
-  const float scBi1 = 1.f / 64.f, scUni1 = 1.f / (float)(64 << hr), ofUni1 = (float)((1 << (5 + hr)) + (IF_INTERNAL_OFFS << 6)) * scUni1;
-  const float scBi2 = 1.f / (float)(2 << hr), ofBi2 = (float)((1 << hr) + 2 * IF_INTERNAL_OFFS) * scBi2 + 1024.f;
+  K.scBi1 = 1.f / 64.f; K.scUni1 = 1.f / (float)(64 << hr); K.ofUni1 = (float)((1 << (5 + hr)) + (IF_INTERNAL_OFFS << 6)) * K.scUni1;
+  K.scBi2 = 1.f / (float)(2 << hr); K.ofBi2 = (float)((1 << hr) + 2 * IF_INTERNAL_OFFS) * K.scBi2 + 1024.f;
 
-  const int npairs = (n + 1) >> 1, stride = nWg * 4;
-  int pair = wg * 4 + wave, sub = 0;
-  // the next step of this wave (uniform): pairs (2 p, 2 p + 1) as mc_fast_kernel takes them
-  auto next = [&](MmStep& s) -> bool
+  const int nb = KIND_T ? (int)gridDim.x : (KIND == 1 ? ((int)gridDim.x + 1) >> 1 : (int)gridDim.x >> 1), bi_ = KIND_T ? (int)blockIdx.x : (int)blockIdx.x >> 1;
+  // XCD-aware walk (workgroups are dealt round-robin over the 8 XCDs, each with its own L2): at every step the waves of ONE XCD hold one contiguous
+  // run of W / 8 descriptors, so the window lines that neighbouring PUs share are fetched from the fabric by one L2 (speed only)
+  const int W = nb * 4, perX = W >> 3;
+  const int w = (nb & 7) ? bi_ * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)
+                         : (bi_ & 7) * perX + (bi_ >> 3) * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  // The wave's descriptors w + j W are classified 64 at a time, one per LANE (one gather load and a ballot; a descriptor-by-descriptor walk on the scalar
+  // unit -- one per CU, shared by its 20 waves -- bound the kernel: 400 scalar instructions per PU); the walk over the set bits is a few scalar operations.
+  MmRaw raw;
+  bool pend = false;
+  if (KIND == 1)
   {
-    for (; pair < npairs; )
+    vvcgpu_mc_desc dP = descs[0];
+    int iP = 0;
+    for (int j0 = 0; w + (long long)j0 * W < n; j0 += 64)
     {
-      const int i0 = 2 * pair, i1 = i0 + 1 < n ? i0 + 1 : -1;
-      const vvcgpu_mc_desc d0 = descs[i0];
-      const int k0 = mm_kind(d0);
-      int k1 = 0;
-      vvcgpu_mc_desc d1 = d0;
-      if (i1 >= 0) { d1 = descs[i1]; k1 = mm_kind(d1); }
-      if (sub == 0)
+      const long long iL = w + (long long)(j0 + K.lane) * W;
+      int k = 0;
+      if (iL < n)
       {
-        if (lane == 0) { if (k0 < 0) flags[i0] = 1; if (k1 < 0) flags[i1] = 1; }
-        if (k0 == 2 && k1 == 2) { s.mode = 2; s.iA = i0; s.iB = i1; s.a = mm_lite(d0); s.b = mm_lite(d1); pair += stride; return true; }
-        sub = 1;
-        if (k0 > 0) { s.mode = k0; s.iA = i0; s.iB = -1; s.a = mm_lite(d0); s.b = s.a; return true; }
+        const uint4 q1 = reinterpret_cast<const uint4*>(descs + iL)[1], q2 = reinterpret_cast<const uint4*>(descs + iL)[2];
+        k = mm_kind_of(q2);
+        const int bi = (int)(signed char)((q2.w >> 8) & 0xFFu);
+        if (k == 1 && ((q1.z | (bi == 1 ? q1.w : 0u)) & 7u)) k = -1;           // aligned 16-byte words need rows that keep their alignment (ref strides: bytes 24..31)
+        if (k < 0) flags[iL] = 1;                            // a fast SHAPE these kernels do not take: the generic kernel's
       }
-      sub = 0; pair += stride;
-      if (k1 > 0) { s.mode = k1; s.iA = i1; s.iB = -1; s.a = mm_lite(d1); s.b = s.a; return true; }
-    }
-    return false;
-  };
-  // the step's samples: lane (row c16, lane group g) takes eight columns of its row
-  auto fetch = [&](const MmStep& s, MmRaw& r)
-  {
-    const bool second = s.mode == 2 && g >= 2;               // chroma: lane groups 2, 3 load PU b
-    const MmDesc& d = second ? s.b : s.a;                    // (selects per lane)
-#pragma unroll
-    for (int rf = 0; rf < 2; rf++)
-    {
-      const long long off = rf ? d.ref1 : d.ref0;
-      const int rs = rf ? d.rs1 : d.rs0, fx = rf ? d.fx1 : d.fx0, fy = rf ? d.fy1 : d.fy0;
-      const Pel* base = (rf ? ref1Base : ref0Base) + off;
-      if (s.mode == 1)
+      unsigned long long mine = __ballot(k == 1);
+      while (mine)
       {
-        const int col = fx ? (g == 0 ? 0 : g == 1 ? 8 : 15) : (g == 0 ? 3 : 11);
-#pragma unroll
-        for (int ch = 0; ch < 2; ch++)
+        const int i = w + (j0 + (int)__builtin_ctzll(mine)) * W;
+        mine &= mine - 1ull;
+        const vvcgpu_mc_desc d = descs[i];
+        if (pend)
         {
-          const int row = fy ? min(16 * ch + c16, 22) : min(max(16 * ch + c16, 3), 18);
-          const Pel* q = base + (ptrdiff_t)(row - 3) * rs + (col - 3);
-          pel8 v;
-#pragma unroll
-          for (int e = 0; e < 8; e++) v[e] = q[e];
-          r.w[rf][ch] = __builtin_bit_cast(uint4, v);
+          MmWin Wn;
+          mm_luma_win(K, raw, Wn);                           // the previous PU's samples have arrived: operands; the loaded registers are free
+          mm_fetch_luma(K, d, ref0Base, ref1Base, raw);      // this PU's samples travel behind the previous PU's products
+          mm_luma(K, dP, Wn, ref0Base, ref1Base, dstBase, flags, iP);
         }
+        else mm_fetch_luma(K, d, ref0Base, ref1Base, raw);
+        dP = d; iP = i; pend = true;
       }
-      else
+    }
+    if (pend) { MmWin Wn; mm_luma_win(K, raw, Wn); mm_luma(K, dP, Wn, ref0Base, ref1Base, dstBase, flags, iP); }
+  }
+  else
+  {
+    const int units = (n + 1) >> 1;
+    int iAP = -1, iBP = -1;
+    for (int j0 = 0; w + (long long)j0 * W < units; j0 += 64)
+    {
+      const long long uL = w + (long long)(j0 + K.lane) * W;
+      int iAv = -1, iBv = -1;
+      if (uL < units)
       {
-        const int col = fx ? ((g & 1) ? 3 : 0) : 1, row = fy ? min(c16, 10) : min(max(c16, 1), 8);
-        const Pel* q = base + (ptrdiff_t)(row - 1) * rs + (col - 1);
-        pel8 v;
-#pragma unroll
-        for (int e = 0; e < 8; e++) v[e] = q[e];
-        r.w[rf][0] = __builtin_bit_cast(uint4, v);
-        r.w[rf][1] = r.w[rf][0];
+        const int k0 = mm_kind_of(reinterpret_cast<const uint4*>(descs + 2 * uL)[2]);
+        const int k1 = 2 * uL + 1 < n ? mm_kind_of(reinterpret_cast<const uint4*>(descs + 2 * uL + 1)[2]) : 0;
+        iAv = k0 == 2 ? (int)(2 * uL) : k1 == 2 ? (int)(2 * uL + 1) : -1;
+        iBv = (k0 == 2 && k1 == 2) ? (int)(2 * uL + 1) : -1;
       }
-    }
-  };
-  // pass-1 result registers -> limb operand
-  auto limbs = [&](const f4& acc, float magic, int kind, bool hclip) -> h8
-  {
-    unsigned u[4];
-#pragma unroll
-    for (int j = 0; j < 4; j++) u[j] = __builtin_bit_cast(unsigned, acc[j] + magic);
-    unsigned p01 = __builtin_amdgcn_perm(u[1], u[0], 0x05040100u), p23 = __builtin_amdgcn_perm(u[3], u[2], 0x05040100u);
-    if (hclip)                                               // rounded horizontal-only filter: the clip of the last stage, on u = sample + 16384
-    {
-      typedef unsigned short us2 __attribute__((ext_vector_type(2)));
-      const us2 lo = { (unsigned short)(16384 + cmin), (unsigned short)(16384 + cmin) }, hi = { (unsigned short)(16384 + cmax), (unsigned short)(16384 + cmax) };
-      p01 = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(us2, p01), lo), hi));
-      p23 = __builtin_bit_cast(unsigned, __builtin_elementwise_min(__builtin_elementwise_max(__builtin_bit_cast(us2, p23), lo), hi));
-    }
-    uint4 o;
-    o.x = (p01 & m7[kind]) | orX[kind];
-    o.y = (p23 & m7[kind]) | orR[kind];
-    o.z = ((p01 >> 7) & m8[kind]) | orR[kind];
-    o.w = ((p23 >> 7) & m8[kind]) | orR[kind];
-    return __builtin_bit_cast(h8, o);
-  };
-
-  MmStep cur, nxt;
-  if (!next(cur)) return;
-  MmRaw raw, rawN;
-  fetch(cur, raw);
-  for (;;)
-  {
-    const bool more = next(nxt);
-    const bool luma = cur.mode == 1;
-    // ---- per-lane view of the step: the PU whose columns / rows this lane's TABLE rows and OUTPUT belong to (chroma: by c16 >> 3)
-    const bool outB = !luma && c16 >= 8;
-    const MmDesc& dO = outB ? cur.b : cur.a;
-    const bool hasB = cur.iB >= 0;
-    const int bi = dO.bi;
-    const bool hOnly0 = bi == 0 && dO.fy0 == 0 && dO.fx0 != 0;
-    const bool anyH = __ballot(hOnly0) != 0ull;
-    const int nRef = (cur.a.bi == 1 || (hasB && cur.b.bi == 1)) ? 2 : 1;
-    // window operands; a sample outside the bit depth sends its PU to the generic kernel
-    h8 wA[2][2];
-    unsigned bad = 0;
-    {
-      const bool cst = luma ? g == 3 : (g & 1) == 1;
-      const unsigned andX = cst ? 0u : 0xFFFFFFFFu, orXw = cst ? 0x64003C00u : 0x64006400u;
-      const unsigned andR = (luma && cst) ? 0u : 0xFFFFFFFFu, orRw = (luma && cst) ? 0u : 0x64006400u;
-#pragma unroll
-      for (int rf = 0; rf < 2; rf++)
-#pragma unroll
-        for (int ch = 0; ch < 2; ch++)
+      unsigned long long mine = __ballot(iAv >= 0);
+      while (mine)
+      {
+        const int j = (int)__builtin_ctzll(mine);
+        mine &= mine - 1ull;
+        const int iA = __builtin_amdgcn_readlane(iAv, j), iB = __builtin_amdgcn_readlane(iBv, j);
+        if (pend)
         {
-          uint4 u = raw.w[rf][ch];
-          bad |= (u.x | u.y | u.z | u.w) & ~rangeMask;
-          u.x = (u.x & andX) | orXw; u.y = (u.y & andR) | orRw; u.z = (u.z & andR) | orRw; u.w = (u.w & andR) | orRw;
-          wA[rf][ch] = __builtin_bit_cast(h8, u);
+          MmWin Wn;
+          mm_chroma_win(K, raw, Wn);
+          mm_fetch_chroma(K, descs, iA, iB, ref0Base, ref1Base, raw);
+          mm_chroma(K, Wn, iAP, iBP, dstBase, flags);
         }
-    }
-    const unsigned long long badLanes = __ballot(bad != 0);
-    const bool badA = luma ? badLanes != 0ull : (badLanes & 0x00000000FFFFFFFFull) != 0ull;      // chroma: lane groups 0, 1 loaded PU a
-    const bool badB = !luma && hasB && (badLanes & 0xFFFFFFFF00000000ull) != 0ull;
-    if (lane == 0) { flags[cur.iA] = badA; if (hasB) flags[cur.iB] = badB; }
-
-    float fr[2][4];
-#pragma unroll
-    for (int rf = 0; rf < 2; rf++)
-    {
-      if (rf >= nRef) { fr[1][0] = fr[1][1] = fr[1][2] = fr[1][3] = 0.f; break; }
-      const int fx = rf ? dO.fx1 : dO.fx0, fy = rf ? dO.fy1 : dO.fy0;
-      const bool hO = rf == 0 && hOnly0;
-      const float magic = hO ? magicH : magicN;
-      f4 acc;
-      if (luma)
-      {
-        const h8 ta = *reinterpret_cast<const h8*>(tabS + ((MM_TAL + (hO ? 256 : 0) + fx * 64 + lane) * 8));
-        const h8 tb0 = *reinterpret_cast<const h8*>(tabS + ((MM_TBL + fy * 128 + lane) * 8));
-        const h8 tb1 = *reinterpret_cast<const h8*>(tabS + ((MM_TBL + fy * 128 + 64 + lane) * 8));
-        const f4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wA[rf][0], ta, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
-        const f4 a1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wA[rf][1], ta, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
-        const h8 p0 = anyH ? limbs(a0, magic, 0, hO) : limbs(a0, magic, 0, false);
-        const h8 p1 = anyH ? limbs(a1, magic, 1, hO) : limbs(a1, magic, 1, false);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(p0, tb0, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(p1, tb1, acc, 0, 0, 0);
-      }
-      else
-      {
-        // pass 1: this lane's table row is non-zero only in the k range of ITS PU (lane group pair g >> 1 == c16 >> 3)
-        const int rowA = ((g >> 1) == (c16 >> 3) && (c16 < 8 || hasB)) ? ((hO ? 128 : 0) + fx * 16 + (c16 & 7) * 2 + (g & 1)) : 2 * 8 * 16;
-        const h8 ta = *reinterpret_cast<const h8*>(tabS + ((MM_TAC + rowA) * 8));
-        const h8 tb = *reinterpret_cast<const h8*>(tabS + ((MM_TBC + fy * 32 + (c16 & 7) * 4 + g) * 8));
-        const f4 a0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(wA[rf][0], ta, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
-        const h8 p0 = anyH ? limbs(a0, magic, 2, hO) : limbs(a0, magic, 2, false);
-        acc = __builtin_amdgcn_mfma_f32_16x16x32_f16(p0, tb, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
-      }
-      // second-stage rounding of this list: bi acc >> 6; uni (acc + offset) >> (6 + headroom); rounded horizontal-only: the pass-2 copy, acc / 64
-      const float sc = (bi == 1 || hO) ? scBi1 : scUni1, of = (bi == 1 || hO) ? 0.f : ofUni1;
-#pragma unroll
-      for (int j = 0; j < 4; j++) fr[rf][j] = floorf(__builtin_fmaf(acc[j], sc, of));
-      if (rf == 0 && more) fetch(nxt, rawN);                 // the next step's samples travel behind the rest of this one
-    }
-    if (nRef == 1 && more) { /* fetched above */ }
-    // ---- average / clip: (f0 + f1 + offset) >> shiftNum for bi, f0 for uni; + 1024 so that the truncating f16 conversion is the floor and the clip packed
-    {
-      const float w1 = bi == 1 ? 1.f : 0.f, sc2 = bi == 1 ? scBi2 : 1.f, of2 = bi == 1 ? ofBi2 : 1024.f;
-      float t[4];
-#pragma unroll
-      for (int j = 0; j < 4; j++) t[j] = __builtin_fmaf(__builtin_fmaf(fr[1][j], w1, fr[0][j]), sc2, of2);
-      mm_h2 q0 = __builtin_bit_cast(mm_h2, __builtin_amdgcn_cvt_pkrtz(t[0], t[1])), q1 = __builtin_bit_cast(mm_h2, __builtin_amdgcn_cvt_pkrtz(t[2], t[3]));
-      q0 = __builtin_elementwise_min(__builtin_elementwise_max(q0, pmin), pmax);
-      q1 = __builtin_elementwise_min(__builtin_elementwise_max(q1, pmin), pmax);
-      uint2 o;
-      o.x = __builtin_bit_cast(unsigned, q0) & 0x03FF03FFu;
-      o.y = __builtin_bit_cast(unsigned, q1) & 0x03FF03FFu;
-      // lane (c16, g) holds row c16 (chroma: c16 & 7 of PU c16 >> 3), columns 4 g .. 4 g + 3 (chroma: 4 (g & 1) ..; real when g >> 1 == c16 >> 3)
-      const bool real = luma ? !badA : ((g >> 1) == (c16 >> 3) && (outB ? (hasB && !badB) : !badA));
-      if (real)
-      {
-        Pel* dp = dstBase + dO.dst + (ptrdiff_t)(luma ? c16 : (c16 & 7)) * dO.ds + 4 * (luma ? g : (g & 1));
-        struct __attribute__((packed, aligned(2))) U2 { uint2 v; };
-        reinterpret_cast<U2*>(dp)->v = o;
+        else mm_fetch_chroma(K, descs, iA, iB, ref0Base, ref1Base, raw);
+        iAP = iA; iBP = iB; pend = true;
       }
     }
-    if (!more) break;
-    cur = nxt;
-    raw = rawN;
+    if (pend) { MmWin Wn; mm_chroma_win(K, raw, Wn); mm_chroma(K, Wn, iAP, iBP, dstBase, flags); }
   }
 }
 
@@ -1284,10 +1412,15 @@ int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc
     if (!image) return VVCGPU_E_DEVICE;
     int* fl = static_cast<int*>(vvcgpu_scratch(st, (size_t)n * sizeof(int)));
     if (!fl) return VVCGPU_E_DEVICE;
-    const int npairs = (n + 1) / 2, cap = 256 * 5;                       // five workgroups per CU; a wave walks its descriptor pairs
-    const int nWg = cdiv(npairs, 4) < cap ? cdiv(npairs, 4) : cap;
-    hipLaunchKernelGGL(mc_mfma_kernel<5>, dim3(vvc_xcd_grid(nWg, xcd)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
-                       dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl, nWg, xcd);
+    const int wgL = cdiv(n, 4) < 256 * 4 ? cdiv(n, 4) : 256 * 4, wgC = cdiv((n + 1) / 2, 4) < 256 * 4 ? cdiv((n + 1) / 2, 4) : 256 * 4;   // persistent: four workgroups per CU
+    static const int split = getenv("VVCGPU_MC_SPLIT") ? 1 : 0;          // A/B switch: the two shapes as two launches
+    if (split)
+    {
+      hipLaunchKernelGGL(mc_mfma_kernel<1>, dim3(wgL), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl);
+      hipLaunchKernelGGL(mc_mfma_kernel<2>, dim3(wgC), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl);
+    }
+    else
+      hipLaunchKernelGGL(mc_mfma_kernel<0>, dim3(wgL & ~1), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl);
     flags = fl;
   }
   else if (!skip_fast)
