@@ -346,7 +346,7 @@ def main():
 
     # ---- input-stream leg: one original picture (24.9 MB at 4K) per picture from pinned host memory on a copy stream, double-buffered through the
     # rotating input sets -- the upload for picture i + 1 runs beside picture i; the picture that uses a set waits for that set's upload only
-    up = {"on": False, "ev": [None] * rotate, "host": None, "stream": None, "bytes": 0}
+    up = {"on": False, "ev": [None] * rotate, "host": None, "side": {}, "stream": None, "bytes": 0, "side_bytes": 0}
 
     def on_input_set(k, st_):
         if not up["on"]:
@@ -364,6 +364,11 @@ def main():
         with torch.cuda.stream(up["stream"]):
             for dst, src in zip(st_["in_sets"][nxt][0], up["host"]):
                 dst.copy_(src, non_blocking=True)
+            # ... and the side information an encoder derives per picture: PU / TU descriptor lists, deblocking maps, SAO parameters, ALF switches
+            for key, src in up["side"].items():
+                dst = st_["side_sets"][nxt][key]
+                for d_, s_ in zip(dst if isinstance(dst, list) else [dst], src if isinstance(src, list) else [src]):
+                    d_.view(torch.uint8).reshape(-1).copy_(s_, non_blocking=True)
             ev = torch.cuda.Event()
             ev.record(up["stream"])
         up["ev"][nxt] = ev
@@ -421,7 +426,10 @@ def main():
     dt_up = None
     if not args.no_input_stream and rotate >= 2:
         up["host"] = [torch.from_numpy(np.ascontiguousarray(p_)).pin_memory() for p_ in wl.org]
-        up["bytes"] = sum(int(t_.numel()) * 2 for t_ in up["host"])
+        pin = lambda a: torch.from_numpy(np.ascontiguousarray(a)).pin_memory()
+        up["side"] = {k: ([pin(a) for a in v] if isinstance(v, list) else pin(v)) for k, v in wl.side_host().items()}
+        up["side_bytes"] = sum(sum(int(t_.numel()) for t_ in (v if isinstance(v, list) else [v])) for v in up["side"].values())
+        up["bytes"] = sum(int(t_.numel()) * 2 for t_ in up["host"]) + up["side_bytes"]
         up["stream"] = torch.cuda.Stream()
         up["on"] = True
         timer.on = False
@@ -507,7 +515,10 @@ def main():
         s, n = k.split("/")
         e = {"ms": round(v, 4)}
         if n in alg.get(s, {}):
-            e.update({"alg_MB": round(alg[s][n] / 1e6, 2), "alg_GBps": round(alg[s][n] / (v * 1e-3) / 1e9, 1)})
+            if k in useful:                                    # a search: the SURVEY 8(d) per-PU sum is not traffic (one staged window serves thousands of PUs)
+                e["per_pu_byte_sum_MB_not_traffic"] = round(alg[s][n] / 1e6, 2)
+            else:
+                e.update({"alg_MB": round(alg[s][n] / 1e6, 2), "alg_GBps": round(alg[s][n] / (v * 1e-3) / 1e9, 1)})
         if n in uniq.get(s, {}):
             e["unique_MB"] = round(uniq[s][n] / 1e6, 2)
             e["unique_frac"] = round(uniq[s][n] / (v * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)
@@ -530,30 +541,36 @@ def main():
         dk = per_kernel[dom]
         ms_pic = dt / (args.steps * pps) * 1e3
         uniq_total = sum(v for st_ in uniq.values() for v in st_.values() if isinstance(v, (int, float)))
-        alg_frac = achieved / HBM_PEAK_GBS
+        # roofline{}: ONE bound, and frac against THAT bound's peak, never above 1.
+        #   a search launch: bound "valu" -- useful (non-redundant) v_sad_u16 wave-instructions of the launch / its HIP-event duration against the
+        #     issue peak of the instruction, one per 4 cycles and SIMD at 2.4 GHz (1024 SIMDs: 614.4 G/s); its bytes are the UNION of the windows + the
+        #     original + the records (what the launch must touch once).  The SURVEY 8(d) per-PU byte sum counts every window sample once per PU that
+        #     reads it -- thousands of PUs share a window that is staged once -- so it is kept under a name that says it is not traffic.
+        #   any other launch: bound "hbm" -- unique bytes of the launch / duration / 8 TB/s.
+        VALU_PEAK = N_SIMD * SQ_CLOCK_HZ / 4.0
         common = {"kernel": dom, "traffic": (dk["hbm_MB"] * 1e6 if "hbm_MB" in dk else None), "traffic_source": prof_src if "hbm_MB" in dk else None,
                   "avg_launch_ms": kern_ms[dom], "launches_timed": n_timed.get(dom, 0),
-                  "alg_bytes_per_launch": abytes, "alg_GBps": achieved, "alg_frac": alg_frac,
+                  "unique_bytes_per_launch": uniq[dstage][dname] if dname in uniq.get(dstage, {}) else abytes,
                   "hbm_frac": dk.get("hbm_frac"), "unique_frac": dk.get("unique_frac"), "valu_busy": dk.get("valu_busy"),
                   "picture_unique_MB": round(uniq_total / 1e6, 1), "picture_unique_frac": round(uniq_total / (ms_pic * 1e-3) / 1e9 / HBM_PEAK_GBS, 4)}
-        # roofline{}: the contract's figure.  frac = SURVEY 8(d) algorithmic bytes of the launch / its event-timed duration / 8 TB/s.  For a search the
-        # algorithmic bytes count every window sample once per PU that reads it (and the hierarchical launch answers the PUs of three block sizes and
-        # two grids from ONE staged window), so the figure exceeds 1: it is not traffic.  What bounds the kernel is beside it: issue_frac (useful,
-        # NON-REDUNDANT v_sad_u16 wave-instructions / time against one per 1.75 ns and SIMD), hbm_frac (counter traffic), unique_frac.
-        roofline = dict(common, bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=alg_frac,
-                        note="achieved / frac follow SURVEY 8(d): algorithmic bytes of the launch (per PU (W + 2R)(H + 2R) x 2 + W H x 2 in, 24 B out, summed over the "
-                             "PUs the launch answers) / HIP-event duration of the launch group on its stream; hbm_frac = counter traffic by request size "
-                             "(TCC_EA0_RDREQ_32B/64B/128B + WRITE_SIZE of the committed profile) / time / peak; unique_frac = bytes the launch must touch once / time / peak; "
-                             "picture_unique_frac = every byte a picture's launches must touch once / ms_per_picture / peak")
         if dom in useful:
             ach = useful[dom] / (kern_ms[dom] * 1e-3)
-            roofline.update(bound_measured="valu-issue + LDS (the window lives in LDS; HBM traffic is a few per cent of the peak)",
-                            issue_frac=ach / SAD_ISSUE_PEAK, issue_achieved_G_per_s=ach / 1e9, issue_peak_G_per_s=SAD_ISSUE_PEAK / 1e9,
-                            stage_body_frac=ach / (N_SIMD / (SAD_STAGE_BODY_NS * 1e-9)),
-                            issue_note="issue_frac = useful v_sad_u16 wave-instructions of the launch (16x16 positions x samples / 2 / 64, every SAD counted ONCE: the 32x32 / "
-                                       "64x64 results are sums) / time against one v_sad_u16 per 1.75 ns and SIMD (profiles/r03_valu_rate.txt); stage_body_frac prices the "
-                                       "same count at the 2.46 ns the instruction costs inside the real stage body (profiles/r03_sadloop_rate.txt); valu_busy = "
-                                       "SQ_ACTIVE_INST_VALU x 4 / (SIMDs x time x 2.4 GHz) of the committed counter profile")
+            roofline = dict(common, bound="valu", achieved=ach / 1e9, peak=VALU_PEAK / 1e9, unit="G wave-instr/s", frac=ach / VALU_PEAK,
+                            per_pu_byte_sum_not_traffic=abytes,
+                            stage_body_frac=ach / (N_SIMD / (SAD_STAGE_BODY_NS * 1e-9)), measured_issue_frac=ach / SAD_ISSUE_PEAK,
+                            note="bound = vector-instruction issue: achieved = useful v_sad_u16 wave-instructions of the launch (16x16 positions x samples / 2 / 64, every SAD "
+                                 "counted ONCE: the 32x32 / 64x64 results are sums) / HIP-event duration of the launch group on its stream; peak = 1024 SIMDs x 2.4 GHz / 4 "
+                                 "cycles per instruction; frac = achieved / peak.  measured_issue_frac prices the same count at the 1.75 ns the instruction issues at in "
+                                 "a micro-benchmark (profiles/r03_valu_rate.txt), stage_body_frac at the 2.46 ns inside the real stage body (r03_sadloop_rate.txt).  "
+                                 "traffic = counter bytes of the committed profile by request size (TCC_EA0_RDREQ 32 / 64 / 128 B + WRITE_SIZE), hbm_frac = traffic / time "
+                                 "/ 8 TB/s, unique_frac = union of windows + original + records / time / 8 TB/s.  per_pu_byte_sum_not_traffic = the SURVEY 8(d) "
+                                 "formula summed over the PUs the launch answers: every window sample counted once per PU that reads it, NOT bytes moved")
+        else:
+            ub = common["unique_bytes_per_launch"]
+            ach = ub / (kern_ms[dom] * 1e-3) / 1e9
+            roofline = dict(common, bound="hbm", achieved=ach, peak=HBM_PEAK_GBS, unit="GB/s", frac=ach / HBM_PEAK_GBS,
+                            note="achieved = bytes the launch must touch once / HIP-event duration of the launch group on its stream; traffic = counter bytes of the "
+                                 "committed profile (FETCH by request size + WRITE_SIZE)")
         res = {
             "metric": BASELINE_METRIC + " [M1: hot-path pictures/s of the kernels behind the call sites, NOT EncoderApp fps]",
             "value": pictures / dt,
@@ -584,9 +601,11 @@ def main():
                                "what": "original + first reference picture cycle through this many resident copies (beyond the 256 MB memory-side cache from 5 sets on)"},
             "input_stream": (None if dt_up is None else {
                 "value": pictures / dt_up, "unit": "frames/s", "ms_per_picture": dt_up / (args.steps * pps) * 1e3, "timed_s": dt_up,
-                "upload_MB_per_picture": round(up["bytes"] / 1e6, 2), "upload_GBps": round(up["bytes"] * args.steps * pps / dt_up / 1e9, 2),
-                "what": "the same steps with one original picture per picture uploaded from pinned host memory on a copy stream inside the timed region "
-                        "(double-buffered through the input sets); `value` above has the inputs resident, as the contract asks"}),
+                "upload_MB_per_picture": round(up["bytes"] / 1e6, 2), "side_info_MB_per_picture": round(up["side_bytes"] / 1e6, 2),
+                "upload_GBps": round(up["bytes"] * args.steps * pps / dt_up / 1e9, 2),
+                "what": "the same steps with, per picture, one original picture AND the picture's side information (PU / TU descriptor lists, deblocking edge / QP "
+                        "maps, SAO parameters, ALF switches) uploaded from pinned host memory on a copy stream inside the timed region (double-buffered through the "
+                        "input sets); `value` above has the inputs resident, as the contract asks"}),
             "picture_hashes": {"gathered": len(hashes), "rank0_first_picture_md5": first_md5, "rank0_last_picture_md5": hashes.get("rank0")},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "serial_kernel_ms_per_picture": round(sum(stage_ms.values()), 4),

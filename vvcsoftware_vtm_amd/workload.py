@@ -352,12 +352,22 @@ class Workload:
             return "me_hier_kernel"
         if stage == "me":
             return "sad_raster5" if name.endswith("%dx%d" % (self.me_grids[1][2], self.me_grids[1][3])) else "sad_dense"
-        return {"frac_refine_16x16": "frac16_kernel", "mc_picture": "mc_fast_kernel", "deblock": "deblock_picture_kernel",
+        return {"frac_refine_16x16": "frac16m_kernel", "mc_picture": "mc_mfma_kernel", "deblock": "deblock_picture_kernel",
                 "sao_stats": "sao_stats_picture_kernel", "sao_apply": "sao_apply_picture_kernel", "alf_classify": "alf_classify_kernel",
                 "alf_stats": "alf_stats_picture_kernel", "alf_filter": "alf_filter_picture_kernel", "resi_chain": "rc_chain_kernel"}.get(name)
 
     def margins(self):
         return [(MARGIN, MARGIN), (MARGIN // 2, MARGIN // 2), (MARGIN // 2, MARGIN // 2)]
+
+    # device-state keys of the per-picture side information (run_gpu), and the host arrays they are uploaded from
+    SIDE_KEYS = ("frac_blk", "mc_pic", "rc", "bands_rest", "edge_ver", "edge_hor", "qp_luma", "qp_chroma", "sao", "alf_en")
+
+    def side_host(self):
+        """{state key: numpy byte array (or list of them)} -- what bench.py's upload leg sends per picture besides the original"""
+        b = lambda a: np.ascontiguousarray(a).view(np.uint8).reshape(-1)
+        return {"frac_blk": b(self.frac), "mc_pic": b(self.mc_pic), "rc": b(self.rc), "bands_rest": b(self.bands_rest),
+                "edge_ver": b(self.edge_ver), "edge_hor": b(self.edge_hor), "qp_luma": b(self.qp_luma), "qp_chroma": b(self.qp_chroma),
+                "sao": [b(p) for p in self.sao], "alf_en": [b(e) for e in self.alf_enable]}
 
     # ------------------------------------------------------------------------------------------------------
     def run_gpu(self, dev_state=None, timer=None, overlap=False, alone=None, pre_mc=None, rotate=1, on_input_set=None):
@@ -419,9 +429,17 @@ class Workload:
         while len(st["in_sets"]) < K:
             d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()
             st["in_sets"].append(([d(p) for p in self.org], st["_planes"](self.ref_plane_off, [p.shape for p in self.ref0_pad], self.ref0_pad)))
+        # the side information that an encoder derives anew for every picture (PU / TU descriptor lists, deblocking maps, SAO parameters, ALF switches):
+        # one resident copy per input set, so that the upload leg of bench.py can fill the next set while the current one is in use
+        if "side_sets" not in st:
+            st["side_sets"] = [{k: st[k] for k in self.SIDE_KEYS}]
+        while len(st["side_sets"]) < K:
+            st["side_sets"].append({k: ([t.clone() for t in st["side_sets"][0][k]] if isinstance(st["side_sets"][0][k], list) else st["side_sets"][0][k].clone())
+                                    for k in self.SIDE_KEYS})
         if K > 1:
             st["rot"] = (st["rot"] + 1) % K
             st["org"], st["ref0"] = st["in_sets"][st["rot"]]
+            st.update(st["side_sets"][st["rot"]])
         if on_input_set is not None:
             on_input_set(st["rot"], st)
         out = {}
