@@ -686,7 +686,7 @@ __device__ __forceinline__ void mm_fetch_luma(const MmK& K, const vvcgpu_mc_desc
 #pragma unroll
   for (int rf = 0; rf < 2; rf++)
   {
-    if (rf >= nRef) { r.w[1][0] = r.w[0][0]; r.w[1][1] = r.w[0][1]; break; }
+    if (rf >= nRef) { r.w[1][0] = r.w[1][1] = make_uint4(0u, 0u, 0u, 0u); break; }     // (constants: a copy of list 0's registers would wait for its loads right here)
     int shift;
     const Pel* pA = mm_luma_origin(d, rf, ref0Base, ref1Base, shift);
     const int rs = rf ? d.ref1_stride : d.ref0_stride, fx = rf ? d.frac_x1 : d.frac_x0, fy = rf ? d.frac_y1 : d.frac_y0;
@@ -757,23 +757,30 @@ __device__ __forceinline__ void mm_luma(const MmK& K, const vvcgpu_mc_desc& d, c
 
 // ---- chroma: PUs iA (columns 0..7 of the products) and iB (8..15; < 0: absent).  A lane reads the descriptor fields it needs from ITS PU as vector loads:
 // lane groups 2, 3 LOAD the samples of PU B; lanes with c16 >= 8 hold PU B's table rows and output
-__device__ __forceinline__ void mm_fetch_chroma(const MmK& K, const vvcgpu_mc_desc* __restrict__ descs, int iA, int iB, const Pel* __restrict__ ref0Base,
-                                                const Pel* __restrict__ ref1Base, MmRaw& r)
+struct MmCDesc { uint4 q0, q1; unsigned frac, flg, dstLo, dstHi, ds; };    // per lane: bytes 0..31 + phases / flags of the PU it LOADS, output fields of the PU it WRITES
+__device__ __forceinline__ void mm_chroma_desc(const MmK& K, const vvcgpu_mc_desc* __restrict__ descs, int iA, int iB, MmCDesc& c)
 {
   const int iF = (K.g >= 2 && iB >= 0) ? iB : iA, iO = (K.c16 >= 8 && iB >= 0) ? iB : iA;
   const uint4* pF = reinterpret_cast<const uint4*>(descs + iF);
   const uint4* pO = reinterpret_cast<const uint4*>(descs + iO);
-  const uint4 q0 = pF[0], q1 = pF[1], q2 = pF[2];
-  const uint4 q1O = pO[1], q2O = pO[2];
-  r.dstLo = q1O.x; r.dstHi = q1O.y; r.ds = q2O.x; r.frac = q2O.z; r.flg = q2O.w;
-  const bool biF = (int)(signed char)((q2.w >> 8) & 0xFFu) == 1;
+  c.q0 = pF[0]; c.q1 = pF[1];
+  const uint4 q2 = pF[2], q1O = pO[1], q2O = pO[2];
+  c.frac = q2.z; c.flg = q2.w;
+  c.dstLo = q1O.x; c.dstHi = q1O.y; c.ds = q2O.x;
+  // (the output PU's phases / flags ride in the same registers as the loaded PU's when they are the same PU; otherwise in the high halves below)
+  c.q1.x = q2O.z; c.q1.y = q2O.w;                            // q1.x / q1.y (dst_off of the loaded PU) are not needed: reused for the OUTPUT PU's phases / flags
+}
+__device__ __forceinline__ void mm_fetch_chroma(const MmK& K, const MmCDesc& c, const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base, MmRaw& r)
+{
+  r.dstLo = c.dstLo; r.dstHi = c.dstHi; r.ds = c.ds; r.frac = c.q1.x; r.flg = c.q1.y;
+  const bool biF = (int)(signed char)((c.flg >> 8) & 0xFFu) == 1;
 #pragma unroll
   for (int rf = 0; rf < 2; rf++)
   {
     const bool second = rf == 1 && biF;
-    const long long off = second ? (long long)(((unsigned long long)q0.w << 32) | q0.z) : (long long)(((unsigned long long)q0.y << 32) | q0.x);
-    const int rs = second ? (int)q1.w : (int)q1.z;
-    const int fx = (int)(signed char)((q2.z >> (second ? 16 : 0)) & 0xFFu), fy = (int)(signed char)((q2.z >> (second ? 24 : 8)) & 0xFFu);
+    const long long off = second ? (long long)(((unsigned long long)c.q0.w << 32) | c.q0.z) : (long long)(((unsigned long long)c.q0.y << 32) | c.q0.x);
+    const int rs = second ? (int)c.q1.w : (int)c.q1.z;
+    const int fx = (int)(signed char)((c.frac >> (second ? 16 : 0)) & 0xFFu), fy = (int)(signed char)((c.frac >> (second ? 24 : 8)) & 0xFFu);
     const Pel* base = (second ? ref1Base : ref0Base) + off;
     const int col = fx ? ((K.g & 1) ? 3 : 0) : 1, row = fy ? min(K.c16, 10) : min(max(K.c16, 1), 8);
     const Pel* q = base + (ptrdiff_t)(row - 1) * rs + (col - 1);
@@ -852,7 +859,7 @@ __device__ __forceinline__ int mm_kind_of(const uint4& q)   // bytes 32..47 of a
 template <int KIND_T>
 __global__ __launch_bounds__(256, 4) void mc_mfma_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base, Pel* __restrict__ dstBase,
                                                                          const vvcgpu_mc_desc* __restrict__ descs, int n, int bd, int cmin, int cmax,
-                                                                         const _Float16* __restrict__ image, int* __restrict__ flags)
+                                                                         const _Float16* __restrict__ image, int* __restrict__ flags, unsigned long long* __restrict__ diag)
 {
   // KIND_T 0: ONE launch, workgroups alternate between the two shapes (both kinds of waves on every CU at the same time)
   const int KIND = KIND_T ? KIND_T : 1 + ((int)blockIdx.x & 1);
@@ -891,12 +898,14 @@ __global__ __launch_bounds__(256, 4) void mc_mfma_kernel(const Pel* __restrict__
                          : (bi_ & 7) * perX + (bi_ >> 3) * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
   // The wave's descriptors w + j W are classified 64 at a time, one per LANE (one gather load and a ballot; a descriptor-by-descriptor walk on the scalar
   // unit -- one per CU, shared by its 20 waves -- bound the kernel: 400 scalar instructions per PU); the walk over the set bits is a few scalar operations.
+  // Three steps are in flight (in-kernel stamps, VVCGPU_MC_DIAG: with the descriptor read inside the step that requests the samples, 1400 of a step's
+  // 5500 cycles were that read's latency): the descriptor of step k + 2 is being read, the samples of step k + 1 are requested, step k is computed.
   MmRaw raw;
   bool pend = false;
   if (KIND == 1)
   {
     vvcgpu_mc_desc dP = descs[0];
-    int iP = 0;
+    int iP = 0, dstep = 0;
     for (int j0 = 0; w + (long long)j0 * W < n; j0 += 64)
     {
       const long long iL = w + (long long)(j0 + K.lane) * W;
@@ -910,20 +919,51 @@ __global__ __launch_bounds__(256, 4) void mc_mfma_kernel(const Pel* __restrict__
         if (k < 0) flags[iL] = 1;                            // a fast SHAPE these kernels do not take: the generic kernel's
       }
       unsigned long long mine = __ballot(k == 1);
-      while (mine)
+      auto nextIdx = [&]() -> int { if (mine == 0ull) return -1; const int j = (int)__builtin_ctzll(mine); mine &= mine - 1ull; return w + (j0 + j) * W; };
+      // A step's descriptor is wave-uniform, but it is read with VECTOR loads (every lane the same address) a step ahead and moved to scalar registers
+      // when its step begins: scalar loads return out of order, so with one in flight every LDS wait of the step (operand permutes, table reads) is an
+      // lgkmcnt(0) that also waits for the descriptor -- ~2000 of a step's 5000 cycles (VVCGPU_MC_DIAG stamps).
+      auto descLoad = [&](int i, uint4 (&v)[3]) { const uint4* q = reinterpret_cast<const uint4*>(descs + i); v[0] = q[0]; v[1] = q[1]; v[2] = q[2]; };
+      auto descScalar = [&](const uint4 (&v)[3]) -> vvcgpu_mc_desc
       {
-        const int i = w + (j0 + (int)__builtin_ctzll(mine)) * W;
-        mine &= mine - 1ull;
-        const vvcgpu_mc_desc d = descs[i];
+        unsigned u[12] = { v[0].x, v[0].y, v[0].z, v[0].w, v[1].x, v[1].y, v[1].z, v[1].w, v[2].x, v[2].y, v[2].z, v[2].w };
+#pragma unroll
+        for (int t = 0; t < 12; t++) u[t] = (unsigned)__builtin_amdgcn_readfirstlane((int)u[t]);
+        vvcgpu_mc_desc d;
+        d.ref0_off = (long long)(((unsigned long long)u[1] << 32) | u[0]); d.ref1_off = (long long)(((unsigned long long)u[3] << 32) | u[2]);
+        d.dst_off = (long long)(((unsigned long long)u[5] << 32) | u[4]);
+        d.ref0_stride = (int)u[6]; d.ref1_stride = (int)u[7]; d.dst_stride = (int)u[8];
+        d.w = (short)(u[9] & 0xFFFFu); d.h = (short)(u[9] >> 16);
+        d.frac_x0 = (signed char)(u[10] & 0xFFu); d.frac_y0 = (signed char)((u[10] >> 8) & 0xFFu); d.frac_x1 = (signed char)((u[10] >> 16) & 0xFFu); d.frac_y1 = (signed char)(u[10] >> 24);
+        d.is_luma = (signed char)(u[11] & 0xFFu); d.bi = (signed char)((u[11] >> 8) & 0xFFu); d.reserved = 0;
+        return d;
+      };
+      int iA = nextIdx();
+      if (iA < 0) continue;
+      uint4 dv[3];
+      descLoad(iA, dv);
+      while (iA >= 0)
+      {
+        const vvcgpu_mc_desc dA = descScalar(dv);
+        const int iB = nextIdx();
+        descLoad(iB >= 0 ? iB : iA, dv);                     // the next step's descriptor: a whole step ahead
         if (pend)
         {
+          // VVCGPU_MC_DIAG (measurement aid): core-clock stamps of one wave's steps: step start, samples arrived + operands, next samples requested, done
+          const bool st = diag && bi_ == (nb >> 1) && (threadIdx.x >> 6) == 0 && dstep < 12;
+          if (st && K.lane == 0) diag[dstep * 4 + 0] = __builtin_amdgcn_s_memtime();
           MmWin Wn;
           mm_luma_win(K, raw, Wn);                           // the previous PU's samples have arrived: operands; the loaded registers are free
-          mm_fetch_luma(K, d, ref0Base, ref1Base, raw);      // this PU's samples travel behind the previous PU's products
+          if (st && K.lane == 0) { asm volatile("" :: "v"(Wn.w[0][0]), "v"(Wn.w[1][1])); diag[dstep * 4 + 1] = __builtin_amdgcn_s_memtime(); }
+          mm_fetch_luma(K, dA, ref0Base, ref1Base, raw);     // this PU's samples travel behind the previous PU's products
+          if (st && K.lane == 0) diag[dstep * 4 + 2] = __builtin_amdgcn_s_memtime();
           mm_luma(K, dP, Wn, ref0Base, ref1Base, dstBase, flags, iP);
+          if (st && K.lane == 0) diag[dstep * 4 + 3] = __builtin_amdgcn_s_memtime();
+          dstep++;
         }
-        else mm_fetch_luma(K, d, ref0Base, ref1Base, raw);
-        dP = d; iP = i; pend = true;
+        else mm_fetch_luma(K, dA, ref0Base, ref1Base, raw);
+        dP = dA; iP = iA; pend = true;
+        iA = iB;
       }
     }
     if (pend) { MmWin Wn; mm_luma_win(K, raw, Wn); mm_luma(K, dP, Wn, ref0Base, ref1Base, dstBase, flags, iP); }
@@ -944,20 +984,28 @@ __global__ __launch_bounds__(256, 4) void mc_mfma_kernel(const Pel* __restrict__
         iBv = (k0 == 2 && k1 == 2) ? (int)(2 * uL + 1) : -1;
       }
       unsigned long long mine = __ballot(iAv >= 0);
-      while (mine)
+      auto nextJ = [&]() -> int { if (mine == 0ull) return -1; const int j = (int)__builtin_ctzll(mine); mine &= mine - 1ull; return j; };
+      int jA = nextJ();
+      if (jA < 0) continue;
+      int iA = __builtin_amdgcn_readlane(iAv, jA), iB = __builtin_amdgcn_readlane(iBv, jA);
+      MmCDesc cA;
+      mm_chroma_desc(K, descs, iA, iB, cA);
+      while (jA >= 0)
       {
-        const int j = (int)__builtin_ctzll(mine);
-        mine &= mine - 1ull;
-        const int iA = __builtin_amdgcn_readlane(iAv, j), iB = __builtin_amdgcn_readlane(iBv, j);
+        const int jN = nextJ();
+        const int iAN = __builtin_amdgcn_readlane(iAv, jN >= 0 ? jN : jA), iBN = __builtin_amdgcn_readlane(iBv, jN >= 0 ? jN : jA);
+        MmCDesc cN;
+        mm_chroma_desc(K, descs, iAN, iBN, cN);              // the descriptor fields of the step after this one (vector loads, consumed next iteration)
         if (pend)
         {
           MmWin Wn;
           mm_chroma_win(K, raw, Wn);
-          mm_fetch_chroma(K, descs, iA, iB, ref0Base, ref1Base, raw);
+          mm_fetch_chroma(K, cA, ref0Base, ref1Base, raw);
           mm_chroma(K, Wn, iAP, iBP, dstBase, flags);
         }
-        else mm_fetch_chroma(K, descs, iA, iB, ref0Base, ref1Base, raw);
+        else mm_fetch_chroma(K, cA, ref0Base, ref1Base, raw);
         iAP = iA; iBP = iB; pend = true;
+        jA = jN; iA = iAN; iB = iBN; cA = cN;
       }
     }
     if (pend) { MmWin Wn; mm_chroma_win(K, raw, Wn); mm_chroma(K, Wn, iAP, iBP, dstBase, flags); }
@@ -1416,11 +1464,26 @@ int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc
     static const int split = getenv("VVCGPU_MC_SPLIT") ? 1 : 0;          // A/B switch: the two shapes as two launches
     if (split)
     {
-      hipLaunchKernelGGL(mc_mfma_kernel<1>, dim3(wgL), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl);
-      hipLaunchKernelGGL(mc_mfma_kernel<2>, dim3(wgC), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl);
+      hipLaunchKernelGGL(mc_mfma_kernel<1>, dim3(wgL), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl, nullptr);
+      hipLaunchKernelGGL(mc_mfma_kernel<2>, dim3(wgC), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl, nullptr);
     }
     else
-      hipLaunchKernelGGL(mc_mfma_kernel<0>, dim3(wgL & ~1), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl);
+    {
+      unsigned long long* diag = nullptr;
+      const bool wantDiag = getenv("VVCGPU_MC_DIAG") != nullptr;           // measurement aid: step stamps of one luma wave
+      if (wantDiag) { VVC_HIP(hipMalloc(&diag, 64 * sizeof(unsigned long long))); VVC_HIP(hipMemsetAsync(diag, 0, 64 * sizeof(unsigned long long), st)); }
+      hipLaunchKernelGGL(mc_mfma_kernel<0>, dim3(wgL & ~1), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl, diag);
+      if (wantDiag)
+      {
+        unsigned long long h[64];
+        VVC_HIP(hipStreamSynchronize(st));
+        VVC_HIP(hipMemcpy(h, diag, sizeof h, hipMemcpyDeviceToHost));
+        (void)hipFree(diag);
+        fprintf(stderr, "[vvcgpu mc diag] luma steps of one wave, cycles (wait + operands / request next / products + store | step):");
+        for (int k = 0; k < 12; k++) if (h[4 * k + 3]) fprintf(stderr, " %llu/%llu/%llu|%llu", h[4 * k + 1] - h[4 * k], h[4 * k + 2] - h[4 * k + 1], h[4 * k + 3] - h[4 * k + 2], k ? h[4 * k] - h[4 * k - 4] : 0ull);
+        fprintf(stderr, "\n");
+      }
+    }
     flags = fl;
   }
   else if (!skip_fast)
