@@ -972,14 +972,19 @@ __global__ __launch_bounds__(256, WPS) void frac16m_kernel(const Pel* __restrict
   int b = wg * 4 + wave;
   if (b >= nblocks) return;
   vvcgpu_frac_blk blk = blocks[b];
+  int predHN = preds ? preds[2 * b] : mv0.pred_hor, predVN = preds ? preds[2 * b + 1] : mv0.pred_ver;
   Raw raw;
   fetch(blk, raw);
   for (; b < nblocks; b += stride)
   {
     const int bn = b + stride < nblocks ? b + stride : b;
-    const vvcgpu_frac_blk blkN = blocks[bn];
+    // the next PU's descriptor (and predictor) by VECTOR loads, every lane the same address: a scalar load in flight would turn every LDS wait of the
+    // half stage -- table reads, the crossbar of the arg-min -- into an lgkmcnt(0) that also waits for it (scalar loads return out of order)
+    const uint2* bq = reinterpret_cast<const uint2*>(blocks + bn);
+    const uint2 bv0 = bq[0], bv1 = bq[1], bv2 = bq[2];
+    const int2 pv = preds ? *reinterpret_cast<const int2*>(preds + 2 * bn) : make_int2(mv0.pred_hor, mv0.pred_ver);
     Raw rawN;
-    const int predH = preds ? preds[2 * b] : mv0.pred_hor, predV = preds ? preds[2 * b + 1] : mv0.pred_ver;
+    const int predH = predHN, predV = predVN;
     FmPu pu;
     unsigned bad = 0;
 #pragma unroll
@@ -997,6 +1002,11 @@ __global__ __launch_bounds__(256, WPS) void frac16m_kernel(const Pel* __restrict
       pu.o2[0] = fh2{ (_Float16)(short)(ov[0] + 1024), (_Float16)(short)(ov[1] + 1024) };
       pu.o2[1] = fh2{ (_Float16)(short)(ov[2] + 1024), (_Float16)(short)(ov[3] + 1024) };
     }
+    vvcgpu_frac_blk blkN;
+    blkN.org_x = __builtin_amdgcn_readfirstlane((int)bv0.x); blkN.org_y = __builtin_amdgcn_readfirstlane((int)bv0.y);
+    blkN.ref_x = __builtin_amdgcn_readfirstlane((int)bv1.x); blkN.ref_y = __builtin_amdgcn_readfirstlane((int)bv1.y);
+    blkN.mv_x = __builtin_amdgcn_readfirstlane((int)bv2.x); blkN.mv_y = __builtin_amdgcn_readfirstlane((int)bv2.y);
+    predHN = __builtin_amdgcn_readfirstlane(pv.x); predVN = __builtin_amdgcn_readfirstlane(pv.y);
     const bool fallBack = __ballot(bad != 0) != 0ull;        // reference samples outside the bit depth, or an original that is not a picture:
     if (lane == 0) flags[b] = fallBack;                      // left to frac16_flagged_kernel (vector form), the launch behind this one
     if (fallBack)
