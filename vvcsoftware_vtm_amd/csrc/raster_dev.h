@@ -109,21 +109,22 @@ __device__ __forceinline__ void r5q_compute(const R5qStage& st, unsigned (&acc)[
     dd[2 * k] = (unsigned)st.d[k]; dd[2 * k + 1] = (unsigned)(st.d[k] >> 32);
   }
   if (OA >= 2) { asm volatile("" :: "v"(st.x1)); dd[16] = st.x1; } else dd[16] = 0u;
+  // k outer, candidate inner: four independent accumulator chains in flight instead of one 8-deep dependent chain after the other
+  // (tools/micro/sadloop_rate.hip: 73.8 vs 83.5 ns per stage at 4 waves per SIMD)
 #pragma unroll
-  for (int m = 0; m < 4; m++)
+  for (int k = 0; k < 8; k++)
   {
-    constexpr int dummy = 0; (void)dummy;
-    const int s = OA + STEP * m, I = s >> 1;
-    if (s & 1)
-    {
 #pragma unroll
-      for (int k = 0; k < 7; k++) acc[m] = __builtin_amdgcn_sad_u16(st.ovO[k], dd[I + 1 + k], acc[m]);
-      acc[m] = __builtin_amdgcn_sad_u16(st.ovO[7], (dd[I + 8] & 0xFFFFu) | (dd[I] & 0xFFFF0000u), acc[m]);
-    }
-    else
+    for (int m = 0; m < 4; m++)
     {
-#pragma unroll
-      for (int k = 0; k < 8; k++) acc[m] = __builtin_amdgcn_sad_u16(st.ovE[k], dd[I + k], acc[m]);
+      const int s = OA + STEP * m, I = s >> 1;
+      if (s & 1)
+      {
+        if (k < 7) acc[m] = __builtin_amdgcn_sad_u16(st.ovO[k], dd[I + 1 + k], acc[m]);
+        else       acc[m] = __builtin_amdgcn_sad_u16(st.ovO[7], (dd[I + 8] & 0xFFFFu) | (dd[I] & 0xFFFF0000u), acc[m]);
+      }
+      else
+        acc[m] = __builtin_amdgcn_sad_u16(st.ovE[k], dd[I + k], acc[m]);
     }
   }
 }

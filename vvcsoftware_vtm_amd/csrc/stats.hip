@@ -16,6 +16,63 @@ namespace {
 // =====================================================================================================
 constexpr int SAO_MAX_CTU = 128;
 
+// wave reduction of the packed accumulators (count << 21 | sum of (d + 1024)) into the workgroup's eo[4][5][2]
+__device__ __forceinline__ void sao_stats_reduce(const unsigned (&acc)[4][5], int* eo)
+{
+  const int tid = threadIdx.x;
+  // halving butterfly: at every step a lane keeps one half of its values and sends the
+  // other half to its partner (lane ^ 32, 16, 8, 4, 2), so 10 + 5 + 3 + 2 + 1 + 1 = 22 exchanges do what 20 full 6-step reductions of
+  // count and sum (240 exchanges) did; afterwards lane l holds the wave total of accumulator 10 b5 + 5 b4 + 3 b3 + 2 b2 + b1.
+  {
+    const int lane = tid & 63;
+    const unsigned* v = &acc[0][0];
+    unsigned a10[10], a5[5], a3[3], a2[2];
+    { const bool hi = lane & 32;
+#pragma unroll
+      for (int i = 0; i < 10; i++) a10[i] = (hi ? v[i + 10] : v[i]) + (unsigned)__shfl_xor((int)(hi ? v[i] : v[i + 10]), 32); }
+    { const bool hi = lane & 16;
+#pragma unroll
+      for (int i = 0; i < 5; i++) a5[i] = (hi ? a10[i + 5] : a10[i]) + (unsigned)__shfl_xor((int)(hi ? a10[i] : a10[i + 5]), 16); }
+    { const bool hi = lane & 8;
+#pragma unroll
+      for (int i = 0; i < 3; i++) { const unsigned lo_v = a5[i], hi_v = i + 3 < 5 ? a5[i + 3] : 0u; a3[i] = (hi ? hi_v : lo_v) + (unsigned)__shfl_xor((int)(hi ? lo_v : hi_v), 8); } }
+    { const bool hi = lane & 4;
+#pragma unroll
+      for (int i = 0; i < 2; i++) { const unsigned lo_v = a3[i], hi_v = i + 2 < 3 ? a3[i + 2] : 0u; a2[i] = (hi ? hi_v : lo_v) + (unsigned)__shfl_xor((int)(hi ? lo_v : hi_v), 4); } }
+    const bool hi1 = lane & 2;
+    unsigned a1 = (hi1 ? a2[1] : a2[0]) + (unsigned)__shfl_xor((int)(hi1 ? a2[0] : a2[1]), 2);
+    a1 += (unsigned)__shfl_xor((int)a1, 1);
+    const int sub3 = ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);              // index inside the group of three (3 = padding)
+    const int k5 = ((lane >> 3) & 1) * 3 + sub3;                              // index inside the group of five (>= 5 = padding)
+    if (!(lane & 1) && sub3 < 3 && k5 < 5)
+    {
+      const int idx = ((lane >> 5) & 1) * 10 + ((lane >> 4) & 1) * 5 + k5;   // == t * 5 + k
+      const int c = (int)(a1 >> 21), d = (int)(a1 & 0x1FFFFFu) - 1024 * c;
+      atomicAdd(&eo[idx * 2], d); atomicAdd(&eo[idx * 2 + 1], c);
+    }
+  }
+}
+// the CTU's output record (behind a barrier after the last reduce)
+__device__ __forceinline__ void sao_stats_output(const int* eo, const unsigned long long* bo, long long* __restrict__ out, int cx, int cy, int wCtu, int nthreads)
+{
+  const int tid = threadIdx.x;
+  long long* o = out + (size_t)(cy * wCtu + cx) * 320;
+  for (int i = tid; i < 320; i += nthreads)
+  {
+    const int t = i >> 6, isCount = (i >> 5) & 1, k = i & 31;
+    long long v = 0;
+    if (t < 4) { if (k < 5) v = eo[(t * 5 + k) * 2 + isCount]; }
+    else
+    {
+      unsigned long long pk = 0ull;
+      for (int r = 0; r < 16; r++) pk += bo[r * 32 + k];
+      const long long c = (long long)(pk >> 32);
+      v = isCount ? c : (long long)(pk & 0xffffffffull) - 1024 * c;
+    }
+    o[i] = v;
+  }
+}
+
 __device__ __forceinline__ void sao_stats_body(const int cx, const int cy, const int nthreads, const Pel* __restrict__ org, int ostride,
                                                         const Pel* __restrict__ rec, int rstride, int w, int h,
                                                         int ctuW, int ctuH, int wCtu, int boShift,
@@ -110,53 +167,241 @@ __device__ __forceinline__ void sao_stats_body(const int cx, const int cy, const
       for (int k = 0; k < 3; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
     }
   }
-  // wave reduction of the 20 packed accumulators as a halving butterfly: at every step a lane keeps one half of its values and sends the
-  // other half to its partner (lane ^ 32, 16, 8, 4, 2), so 10 + 5 + 3 + 2 + 1 + 1 = 22 exchanges do what 20 full 6-step reductions of
-  // count and sum (240 exchanges) did; afterwards lane l holds the wave total of accumulator 10 b5 + 5 b4 + 3 b3 + 2 b2 + b1.
-  {
-    const int lane = tid & 63;
-    const unsigned* v = &acc[0][0];
-    unsigned a10[10], a5[5], a3[3], a2[2];
-    { const bool hi = lane & 32;
-#pragma unroll
-      for (int i = 0; i < 10; i++) a10[i] = (hi ? v[i + 10] : v[i]) + (unsigned)__shfl_xor((int)(hi ? v[i] : v[i + 10]), 32); }
-    { const bool hi = lane & 16;
-#pragma unroll
-      for (int i = 0; i < 5; i++) a5[i] = (hi ? a10[i + 5] : a10[i]) + (unsigned)__shfl_xor((int)(hi ? a10[i] : a10[i + 5]), 16); }
-    { const bool hi = lane & 8;
-#pragma unroll
-      for (int i = 0; i < 3; i++) { const unsigned lo_v = a5[i], hi_v = i + 3 < 5 ? a5[i + 3] : 0u; a3[i] = (hi ? hi_v : lo_v) + (unsigned)__shfl_xor((int)(hi ? lo_v : hi_v), 8); } }
-    { const bool hi = lane & 4;
-#pragma unroll
-      for (int i = 0; i < 2; i++) { const unsigned lo_v = a3[i], hi_v = i + 2 < 3 ? a3[i + 2] : 0u; a2[i] = (hi ? hi_v : lo_v) + (unsigned)__shfl_xor((int)(hi ? lo_v : hi_v), 4); } }
-    const bool hi1 = lane & 2;
-    unsigned a1 = (hi1 ? a2[1] : a2[0]) + (unsigned)__shfl_xor((int)(hi1 ? a2[0] : a2[1]), 2);
-    a1 += (unsigned)__shfl_xor((int)a1, 1);
-    const int sub3 = ((lane >> 2) & 1) * 2 + ((lane >> 1) & 1);              // index inside the group of three (3 = padding)
-    const int k5 = ((lane >> 3) & 1) * 3 + sub3;                              // index inside the group of five (>= 5 = padding)
-    if (!(lane & 1) && sub3 < 3 && k5 < 5)
-    {
-      const int idx = ((lane >> 5) & 1) * 10 + ((lane >> 4) & 1) * 5 + k5;   // == t * 5 + k
-      const int c = (int)(a1 >> 21), d = (int)(a1 & 0x1FFFFFu) - 1024 * c;
-      atomicAdd(&eo[idx * 2], d); atomicAdd(&eo[idx * 2 + 1], c);
-    }
-  }
+  sao_stats_reduce(acc, eo);
   __syncthreads();
-  long long* o = out + (size_t)(cy * wCtu + cx) * 320;
-  for (int i = tid; i < 320; i += nthreads)
+  sao_stats_output(eo, bo, out, cx, cy, wCtu, nthreads);
+}
+
+// ---- packed form (CTU width a multiple of 64, a thread's rows a multiple of four: the 128 / 64 CTUs of a picture) ------------------------
+// The tile is staged TRANSPOSED (a column's rows are consecutive 16-bit words), so a thread reads four rows of its column and of the two
+// neighbour columns as dword pairs and works on 2 x 16-bit packed values: one v_pk_sub / v_pk_max / v_pk_min per TWO signs, the +-1 row shifts
+// are v_alignbit.  The category of a sample (e - 2 = s1 + s2 in -2..2) becomes a byte SELECTOR of v_perm_b32: per (class, category) one
+// v_perm turns the four selectors of a four-row block into four one-hot bytes, and two v_dot4_u32_u8 against the bytes of (org - rec + 1024)
+// add the block to the accumulators -- 3 instructions per (class, category) and FOUR samples where the scalar form has 2 per sample.
+//   value bytes : LO = (d + 1024) & 255;  HC = ((d + 1024) >> 8) << 5 | 1   (count rides in the low five bits: a thread has <= 28 rows)
+//   selectors   : (s1 + s2) & 7 = 6, 7, 0, 1, 2 for the categories 0..4; 0x0C (v_perm: constant zero) for a sample the class does not use
+// Results are the integers of the scalar form (tests/test_gpu_stats.py, tests/golden/sao.npz).
+// (inline assembly: the elementwise min / max builtins on 2 x i16 are scalarised into compares and selects by the compiler)
+__device__ __forceinline__ unsigned sao_pk_sign(unsigned a, unsigned b)          // clamp(a - b, -1, 1) per 16-bit half (the subtraction saturates)
+{
+  unsigned r;
+  asm("v_pk_sub_i16 %0, %1, %2 clamp\n\tv_pk_max_i16 %0, %0, -1\n\tv_pk_min_i16 %0, %0, 1 op_sel_hi:[1,0]" : "=&v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned sao_pk_add(unsigned a, unsigned b) { unsigned r; asm("v_pk_add_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned sao_pk_sub(unsigned a, unsigned b) { unsigned r; asm("v_pk_sub_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned sao_expand4(unsigned m) { return (m & 1u) | ((m & 2u) << 7) | ((m & 4u) << 14) | ((m & 8u) << 21); }   // bit j -> byte j
+
+// The packed body runs in 256-thread workgroups (several per CU: one workgroup's staging and finish run beside the others' statistics) and
+// takes a CTU as STRIPS of (256 / ctuW) x 16 rows -- a thread walks 16 rows of a strip, four blocks of four -- staged, walked and reduced one
+// after the other; the per-CTU record is written once.  (One 1024-thread workgroup per CTU spent 37 of its 58 us per 4K picture outside
+// the statistics: staging, finish and workgroup turnover with nothing else on the CU.)
+constexpr int SAO_PK_THREADS = 256, SAO_PK_ROWS = 16;
+__host__ __device__ __forceinline__ bool sao_stats_packed_ok(int nthreads, int ctuW, int ctuH)
+{
+  if (nthreads != SAO_PK_THREADS || (ctuW & 63) || ctuW > nthreads) return false;
+  const int stripH = (nthreads / ctuW) * SAO_PK_ROWS;
+  return (ctuH % stripH) == 0;
+}
+
+__device__ __forceinline__ void sao_stats_body_pk(const int cx, const int cy, const Pel* __restrict__ org, int ostride,
+                                                  const Pel* __restrict__ rec, int rstride, int w, int h,
+                                                  int ctuW, int ctuH, int wCtu, int boShift,
+                                                  const uint8_t* __restrict__ availMap, int skipR, int skipB,
+                                                  long long* __restrict__ out)
+{
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int nthreads = SAO_PK_THREADS;
+  const int groups = nthreads / ctuW, stripH = groups * SAO_PK_ROWS;
+  const int pitchT = stripH + 6;                                                  // 16-bit words per column: (stripH / 2 + 3) dwords, odd -> 32 consecutive columns hit 32 banks
+  short* tile = reinterpret_cast<short*>(smem);                                   // [ctuW + 2 columns][pitchT]: column x + 1, row (y - strip start) + 2
+  const int tileBytes = ((ctuW + 2) * pitchT * 2 + 15) & ~15;
+  unsigned long long* bo = reinterpret_cast<unsigned long long*>(smem + tileBytes);   // 16 replicas x 32 packed bands (same-band atomics serialise)
+  int* eo = reinterpret_cast<int*>(smem + tileBytes + 16 * 32 * 8);                   // [4][5][2]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int x0 = cx * ctuW, y0 = cy * ctuH;
+  const int width = min(ctuW, w - x0), height = min(ctuH, h - y0);
+  for (int i = tid; i < 16 * 32; i += nthreads) bo[i] = 0ull;
+  if (tid < 40) eo[tid] = 0;
+
+  const int a = availMap ? availMap[cy * wCtu + cx] : ((cx > 0 ? 1 : 0) | (cy > 0 ? 4 : 0) | (cx > 0 && cy > 0 ? 16 : 0));
+  const bool left = a & 1, above = (a >> 2) & 1, aboveLeft = (a >> 4) & 1;
+  const bool right = x0 + ctuW < w, below = y0 + ctuH < h;
+  const int startXe = left ? 0 : 1, endXe = right ? width - skipR : width - 1;
+  const int endX90 = right ? width - skipR : width;              // also BO
+  const int endY0 = below ? height - skipB : height;             // EO_0 and BO
+  const int endYd = below ? height - skipB : height - 1;         // EO_90/135/45
+  const int startY90 = above ? 0 : 1;
+
+  const int x = tid & (ctuW - 1), g = __builtin_amdgcn_readfirstlane(tid / ctuW);     // a wave lies inside one row group
+  const bool inXe = x >= startXe && x < endXe, inX90 = x < endX90;                   // (both imply x < width)
+  const unsigned keepE = inXe ? 0x07070707u : 0u, unusedE = inXe ? 0u : 0x0C0C0C0Cu;
+  const unsigned keep90 = inX90 ? 0x07070707u : 0u, unused90 = inX90 ? 0u : 0x0C0C0C0Cu;
+  // class 135 in row 0 of the CTU: column 0 looks at the above-left CTU, the others at the one above
+  const bool c2row0 = x == 0 ? (aboveLeft && (above ? endXe : 1) > 0) : (above && x < endXe);
+  const bool c3row0 = above && inXe;
+  const unsigned* colL = reinterpret_cast<const unsigned*>(tile) + ((x * pitchT) >> 1);          // dword r of a column = rows 2 r - 2, 2 r - 1 of the strip
+  const unsigned* colC = colL + (pitchT >> 1);
+  const unsigned* colR = colC + (pitchT >> 1);
+  const int xo = min(x, width - 1);
+  const Pel* orgCol = org + (size_t)y0 * ostride + x0 + xo;                       // (offsets below: 32 bits, a plane is below 2^31 samples)
+
+  for (int ys = 0; ys < height; ys += stripH)                                     // strips of the CTU (wave-uniform)
   {
-    const int t = i >> 6, isCount = (i >> 5) & 1, k = i & 31;
-    long long v = 0;
-    if (t < 4) { if (k < 5) v = eo[(t * 5 + k) * 2 + isCount]; }
-    else
+    // ---- staging: an item = (pair of tile rows; column) = one dword of the tile.  A wave takes the row pairs wave, wave + 4, ..; its lanes the
+    // columns lane and lane + 64; the columns beyond 128 (two of them for a 128-wide CTU) are one more item of the lanes of wave 0.  All loads of a
+    // thread are issued before its first LDS store.
     {
-      unsigned long long pk = 0ull;
-      for (int r = 0; r < 16; r++) pk += bo[r * 32 + k];
-      const long long c = (long long)(pk >> 32);
-      v = isCount ? c : (long long)(pk & 0xffffffffull) - 1024 * c;
+      const int nPr = (stripH + 4) >> 1, nC = ctuW + 2;
+      constexpr int SB = 5;                                                         // row pairs per wave: ceil(18 / 4), ceil(34 / 4) = 9 -> two rounds
+      for (int pr0 = wave; pr0 < nPr; pr0 += 4 * SB)
+      {
+        unsigned va[SB][2], vb[SB][2];
+#pragma unroll
+        for (int k = 0; k < SB; k++)
+        {
+          const int pr = min(pr0 + 4 * k, nPr - 1);                                // (beyond the last pair: the last pair again, not stored)
+          const unsigned rowA = (unsigned)(min(max(y0 + ys + 2 * pr - 2, 0), h - 1) * rstride), rowB = (unsigned)(min(max(y0 + ys + 2 * pr - 1, 0), h - 1) * rstride);
+#pragma unroll
+          for (int q = 0; q < 2; q++)
+          {
+            const int c = lane + 64 * q;
+            const unsigned xc = (unsigned)min(max(x0 + min(c, nC - 1) - 1, 0), w - 1);
+            va[k][q] = (unsigned short)rec[rowA + xc]; vb[k][q] = (unsigned short)rec[rowB + xc];
+          }
+        }
+#pragma unroll
+        for (int k = 0; k < SB; k++)
+#pragma unroll
+          for (int q = 0; q < 2; q++)
+          {
+            const int c = lane + 64 * q, pr = pr0 + 4 * k;
+            if (c < nC && c < 128 && pr < nPr) reinterpret_cast<unsigned*>(tile)[((c * pitchT) >> 1) + pr] = va[k][q] | (vb[k][q] << 16);
+          }
+      }
+      if (nC > 128 && wave == 0)                                                   // columns 128 .. nC - 1: (nC - 128) x nPr items
+        for (int i = lane; i < (nC - 128) * nPr; i += 64)
+        {
+          const int c = 128 + (i >= nPr ? 1 : 0), pr = i - (i >= nPr ? nPr : 0);
+          const unsigned xc = (unsigned)min(max(x0 + c - 1, 0), w - 1);
+          const unsigned rowA = (unsigned)(min(max(y0 + ys + 2 * pr - 2, 0), h - 1) * rstride), rowB = (unsigned)(min(max(y0 + ys + 2 * pr - 1, 0), h - 1) * rstride);
+          reinterpret_cast<unsigned*>(tile)[((c * pitchT) >> 1) + pr] = (unsigned)(unsigned short)rec[rowA + xc] | ((unsigned)(unsigned short)rec[rowB + xc] << 16);
+        }
     }
-    o[i] = v;
+    __syncthreads();
+
+    unsigned accLo[4][5], accHc[4][5];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int e = 0; e < 5; e++) { accLo[t][e] = 0u; accHc[t][e] = 0u; }
+
+    const int yBeg = ys + g * SAO_PK_ROWS, yEnd = min(yBeg + SAO_PK_ROWS, height);
+    int orgN[4];                                                                   // the original samples of the NEXT block: requested a block ahead
+#pragma unroll
+    for (int j = 0; j < 4; j++) orgN[j] = orgCol[(unsigned)(min(yBeg + j, height - 1) * ostride)];
+    for (int y = yBeg; y < yEnd; y += 4)
+    {
+      // dwords (y-2, y-1) (y, y+1) (y+2, y+3) (y+4, y+5) of the three columns
+      const int r = (y - ys) >> 1;
+      unsigned L[4], C[4], R[4];
+#pragma unroll
+      for (int i = 0; i < 4; i++) { L[i] = colL[r + i]; C[i] = colC[r + i]; R[i] = colR[r + i]; }
+      int t4[4];
+#pragma unroll
+      for (int j = 0; j < 4; j++)
+      {
+        const int cj = (int)(short)(C[1 + (j >> 1)] >> ((j & 1) * 16));
+        t4[j] = orgN[j] - cj + 1024;
+      }
+#pragma unroll
+      for (int j = 0; j < 4; j++) orgN[j] = orgCol[(unsigned)(min(y + 4 + j, height - 1) * ostride)];
+      // the rows one up / one down, per column: U0 = (y-1, y), U1 = D0 = (y+1, y+2), D1 = (y+3, y+4)
+      unsigned UL[2], UC[2], UR[2], DL1, DC1, DR1;
+      UL[0] = __builtin_amdgcn_alignbit(L[1], L[0], 16); UL[1] = __builtin_amdgcn_alignbit(L[2], L[1], 16); DL1 = __builtin_amdgcn_alignbit(L[3], L[2], 16);
+      UC[0] = __builtin_amdgcn_alignbit(C[1], C[0], 16); UC[1] = __builtin_amdgcn_alignbit(C[2], C[1], 16); DC1 = __builtin_amdgcn_alignbit(C[3], C[2], 16);
+      UR[0] = __builtin_amdgcn_alignbit(R[1], R[0], 16); UR[1] = __builtin_amdgcn_alignbit(R[2], R[1], 16); DR1 = __builtin_amdgcn_alignbit(R[3], R[2], 16);
+      unsigned E[4][2];                                                            // s1 + s2 per class, two samples per dword
+      {
+        const unsigned sd0 = sao_pk_sign(C[1], UC[1]), sd1 = sao_pk_sign(C[2], DC1);
+        const unsigned su0 = sao_pk_sign(C[1], UC[0]);
+        // sign(c(y) - c(y-1)) = -sign(c(y-1) - c(y)): the "up" signs of rows y+2, y+3 are the negated "down" signs of rows y+1, y+2
+        E[1][0] = sao_pk_add(su0, sd0); E[1][1] = sao_pk_sub(sd1, __builtin_amdgcn_alignbit(sd1, sd0, 16));
+        E[0][0] = sao_pk_add(sao_pk_sign(C[1], L[1]), sao_pk_sign(C[1], R[1])); E[0][1] = sao_pk_add(sao_pk_sign(C[2], L[2]), sao_pk_sign(C[2], R[2]));
+        E[2][0] = sao_pk_add(sao_pk_sign(C[1], UL[0]), sao_pk_sign(C[1], UR[1])); E[2][1] = sao_pk_add(sao_pk_sign(C[2], UL[1]), sao_pk_sign(C[2], DR1));
+        E[3][0] = sao_pk_add(sao_pk_sign(C[1], UR[0]), sao_pk_sign(C[1], UL[1])); E[3][1] = sao_pk_add(sao_pk_sign(C[2], UR[1]), sao_pk_sign(C[2], DL1));
+      }
+      // selectors: the low byte of each 16-bit sum, then the samples a class does not use
+      unsigned sel[4];
+#pragma unroll
+      for (int t = 0; t < 4; t++) sel[t] = __builtin_amdgcn_perm(E[t][1], E[t][0], 0x06040200u);
+      if (y >= 1 && y + 3 < endYd)                                                 // wave-uniform: every row of the block is inside every class's rows
+      {
+        sel[0] = (sel[0] & keepE) | unusedE; sel[1] = (sel[1] & keep90) | unused90;
+        sel[2] = (sel[2] & keepE) | unusedE; sel[3] = (sel[3] & keepE) | unusedE;
+      }
+      else
+      {
+        unsigned m0 = 0, m1 = 0, m23 = 0;
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+        {
+          m0 |= (y + j < endY0 ? 1u : 0u) << j;
+          m1 |= (y + j >= startY90 && y + j < endYd ? 1u : 0u) << j;
+          m23 |= (y + j >= 1 && y + j < endYd ? 1u : 0u) << j;
+        }
+        const unsigned k0 = sao_expand4(m0) * 7u, k1 = sao_expand4(m1) * 7u, k23 = sao_expand4(m23) * 7u;
+        const unsigned u0 = sao_expand4(m0 ^ 15u) * 12u, u1 = sao_expand4(m1 ^ 15u) * 12u, u23 = sao_expand4(m23 ^ 15u) * 12u;
+        unsigned kp[4] = { inXe ? k0 : 0u, inX90 ? k1 : 0u, inXe ? k23 : 0u, inXe ? k23 : 0u };
+        unsigned un[4] = { inXe ? u0 : 0x0C0C0C0Cu, inX90 ? u1 : 0x0C0C0C0Cu, inXe ? u23 : 0x0C0C0C0Cu, inXe ? u23 : 0x0C0C0C0Cu };
+        if (y == 0)                                                                // row 0 of the CTU: the diagonal classes look into the CTUs above
+        {
+          kp[2] = (kp[2] & ~0xFFu) | (c2row0 ? 0x07u : 0u); un[2] = (un[2] & ~0xFFu) | (c2row0 ? 0u : 0x0Cu);
+          kp[3] = (kp[3] & ~0xFFu) | (c3row0 ? 0x07u : 0u); un[3] = (un[3] & ~0xFFu) | (c3row0 ? 0u : 0x0Cu);
+        }
+#pragma unroll
+        for (int t = 0; t < 4; t++) sel[t] = (sel[t] & kp[t]) | un[t];
+      }
+      const unsigned p01 = (unsigned)t4[0] | ((unsigned)t4[1] << 16), p23 = (unsigned)t4[2] | ((unsigned)t4[3] << 16);
+      const unsigned LO = __builtin_amdgcn_perm(p23, p01, 0x06040200u);
+      const unsigned HC = (__builtin_amdgcn_perm(p23, p01, 0x07050301u) << 5) | 0x01010101u;
+#pragma unroll
+      for (int t = 0; t < 4; t++)
+      {
+        // category k <-> selector (k - 2) & 7: 6, 7, 0, 1, 2; bytes 0..3 of {hi, lo} come from lo, 4..7 from hi
+        const unsigned oh0 = __builtin_amdgcn_perm(0x00010000u, 0u, sel[t]), oh1 = __builtin_amdgcn_perm(0x01000000u, 0u, sel[t]);
+        const unsigned oh2 = __builtin_amdgcn_perm(0u, 0x00000001u, sel[t]), oh3 = __builtin_amdgcn_perm(0u, 0x00000100u, sel[t]);
+        const unsigned oh4 = __builtin_amdgcn_perm(0u, 0x00010000u, sel[t]);
+        const unsigned oh[5] = { oh0, oh1, oh2, oh3, oh4 };
+#pragma unroll
+        for (int k = 0; k < 5; k++)
+        {
+          accLo[t][k] = __builtin_amdgcn_udot4(oh[k], LO, accLo[t][k], false);
+          accHc[t][k] = __builtin_amdgcn_udot4(oh[k], HC, accHc[t][k], false);
+        }
+      }
+      if (inX90)
+      {
+#pragma unroll
+        for (int j = 0; j < 4; j++)
+          if (y + j < endY0)
+          {
+            const int cj = (int)(short)(C[1 + (j >> 1)] >> ((j & 1) * 16));
+            atomicAdd(&bo[(tid & 15) * 32 + (cj >> boShift)], (1ull << 32) + (unsigned long long)t4[j]);
+          }
+      }
+    }
+    // the strip's accumulators in the packed form of the scalar body (count << 21 | sum of (d + 1024)), reduced over the wave into eo
+    unsigned acc[4][5];
+#pragma unroll
+    for (int t = 0; t < 4; t++)
+#pragma unroll
+      for (int e = 0; e < 5; e++) acc[t][e] = ((accHc[t][e] & 31u) << 21) + accLo[t][e] + ((accHc[t][e] >> 5) << 8);
+    sao_stats_reduce(acc, eo);
+    __syncthreads();                                                               // the tile is free for the next strip / eo and bo are complete
   }
+  sao_stats_output(eo, bo, out, cx, cy, wCtu, nthreads);
 }
 
 // one plane per launch (vvcgpu_sao_stats): 1024 threads per CTU -- a thread walks 16 rows of a 128 x 128 CTU instead of 64 (the row walk is
@@ -165,7 +410,10 @@ __global__ __launch_bounds__(1024) void sao_stats_kernel(const Pel* __restrict__
                                                          int ctuW, int ctuH, int wCtu, int boShift, const uint8_t* __restrict__ availMap, int skipR,
                                                          int skipB, long long* __restrict__ out)
 {
-  sao_stats_body((int)blockIdx.x, (int)blockIdx.y, (int)blockDim.x, org, ostride, rec, rstride, w, h, ctuW, ctuH, wCtu, boShift, availMap, skipR, skipB, out);
+  if (sao_stats_packed_ok((int)blockDim.x, ctuW, ctuH))
+    sao_stats_body_pk((int)blockIdx.x, (int)blockIdx.y, org, ostride, rec, rstride, w, h, ctuW, ctuH, wCtu, boShift, availMap, skipR, skipB, out);
+  else
+    sao_stats_body((int)blockIdx.x, (int)blockIdx.y, (int)blockDim.x, org, ostride, rec, rstride, w, h, ctuW, ctuH, wCtu, boShift, availMap, skipR, skipB, out);
 }
 
 // the three planes of a picture in one launch
@@ -178,8 +426,12 @@ __global__ __launch_bounds__(1024) void sao_stats_picture_kernel(SaoStats3 p)
   const int c = b < p.a[0].wgEnd ? 0 : b < p.a[1].wgEnd ? 1 : 2;
   const SaoStatsPlane& a = c == 0 ? p.a[0] : c == 1 ? p.a[1] : p.a[2];
   const int r = b - (c == 0 ? 0 : c == 1 ? p.a[0].wgEnd : p.a[1].wgEnd);
-  sao_stats_body(r % a.wCtu, r / a.wCtu, (int)blockDim.x, a.org, a.ostride, a.rec, a.rstride, a.w, a.h, a.ctu, a.ctu, a.wCtu, p.boShift, p.avail, a.skipR,
-                 a.skipB, a.out);
+  if (sao_stats_packed_ok((int)blockDim.x, a.ctu, a.ctu))
+    sao_stats_body_pk(r % a.wCtu, r / a.wCtu, a.org, a.ostride, a.rec, a.rstride, a.w, a.h, a.ctu, a.ctu, a.wCtu, p.boShift, p.avail, a.skipR,
+                      a.skipB, a.out);
+  else
+    sao_stats_body(r % a.wCtu, r / a.wCtu, (int)blockDim.x, a.org, a.ostride, a.rec, a.rstride, a.w, a.h, a.ctu, a.ctu, a.wCtu, p.boShift, p.avail, a.skipR,
+                   a.skipB, a.out);
 }
 
 
@@ -875,12 +1127,16 @@ int vvcgpu_sao_stats(const vvc_pel* org, int org_stride, const vvc_pel* rec, int
   VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "sao_stats: bit depth %d outside 8..10", bit_depth);
   VVC_CHECK_ARG(skip_lines_r >= 0 && skip_lines_b >= 0 && skip_lines_r < 16 && skip_lines_b < 16, "sao_stats: bad skip lines");
   const int wCtu = cdiv(width, ctu_w), hCtu = cdiv(height, ctu_h);
-  const size_t tileBytes = (((size_t)(ctu_h + 2) * (ctu_w + 2) * 2) + 15) & ~(size_t)15;
+  // the packed body (256 threads, strips of (256 / ctu_w) x 16 rows) where the CTU shape allows it, else the scalar one:
+  // groups = nthreads / ctu_w row groups of ctu_h / groups rows, at least 4 rows per thread
+  const bool packed = sao_stats_packed_ok(SAO_PK_THREADS, ctu_w, ctu_h);
+  int nthreads = packed ? SAO_PK_THREADS : 1024;
+  while (!packed && nthreads > 256 && (nthreads / ctu_w) * 4 > ctu_h) nthreads >>= 1;
+  const size_t tileBytes = packed ? (((size_t)((SAO_PK_THREADS / ctu_w) * SAO_PK_ROWS + 6) * (ctu_w + 2) * 2) + 15) & ~(size_t)15
+                                  : (((size_t)(ctu_h + 2) * (ctu_w + 2) * 2) + 15) & ~(size_t)15;
   const size_t smem = tileBytes + 16 * 32 * 8 + 40 * 4;
   if (smem > 48 * 1024)
     VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sao_stats_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-  int nthreads = 1024;                                       // groups = nthreads / ctu_w row groups of ctu_h / groups rows: keep >= 4 rows per thread
-  while (nthreads > 256 && (nthreads / ctu_w) * 4 > ctu_h) nthreads >>= 1;
   hipLaunchKernelGGL(sao_stats_kernel, dim3(wCtu, hCtu), dim3(nthreads), smem, (hipStream_t)stream, org, org_stride, rec,
                      rec_stride, width, height, ctu_w, ctu_h, wCtu, bit_depth - 5, avail, skip_lines_r, skip_lines_b,
                      reinterpret_cast<long long*>(out));
@@ -937,10 +1193,19 @@ int vvcgpu_sao_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec,
                             c ? skip_r_chroma : skip_r_luma, c ? skip_b_chroma : skip_b_luma, end };
   }
   p.avail = avail; p.boShift = bit_depth - 5;
-  // workgroup size: the chroma CTU (ctu / 2 wide) sets the row groups; every thread keeps at least two rows
-  int nthreads = 1024;
-  while (nthreads > 256 && (nthreads / (ctu_size >> 1)) * 2 > (ctu_size >> 1)) nthreads >>= 1;
-  const size_t tileBytes = (((size_t)(ctu_size + 2) * (ctu_size + 2) * 2) + 15) & ~(size_t)15;
+  // workgroup size: 256 threads where the luma CTU takes the packed body (the chroma CTU then takes it as well, or the scalar body with
+  // ctu / 2 / 8 rows per thread); else the chroma CTU (ctu / 2 wide) sets the row groups and every thread keeps at least two rows
+  const bool packed = sao_stats_packed_ok(SAO_PK_THREADS, ctu_size, ctu_size);
+  int nthreads = packed ? SAO_PK_THREADS : 1024;
+  while (!packed && nthreads > 256 && (nthreads / (ctu_size >> 1)) * 2 > (ctu_size >> 1)) nthreads >>= 1;
+  size_t tileBytes = 0;
+  for (int c = 0; c < 2; c++)
+  {
+    const int ctu = ctu_size >> c;
+    const size_t t = sao_stats_packed_ok(nthreads, ctu, ctu) ? (size_t)((SAO_PK_THREADS / ctu) * SAO_PK_ROWS + 6) * (ctu + 2) * 2 : (size_t)(ctu + 2) * (ctu + 2) * 2;
+    tileBytes = t > tileBytes ? t : tileBytes;
+  }
+  tileBytes = (tileBytes + 15) & ~(size_t)15;
   const size_t smem = tileBytes + 16 * 32 * 8 + 40 * 4;
   if (smem > 48 * 1024)
     VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sao_stats_picture_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
