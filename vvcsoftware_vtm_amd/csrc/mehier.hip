@@ -250,28 +250,17 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
   __shared__ signed char dlX[12 * 4];                                          // ... and the grid column of each of its four candidates (-128: none)
   __shared__ unsigned surfD[MH_MAXDL * 4];
   __shared__ int arrive[8];                                                    // per slot wave: quadrants that have added their 32x32 sums to the 64x64 surface
+  // what only the 42 record writers of a super-block need lives in LDS, not in scalar registers across the search (the kernel holds its arguments
+  // in ~80 scalar registers; inside the super-block loop they spilled)
+  __shared__ vvcgpu_search_best* outPtr[6];
+  __shared__ vvcgpu_mvcost mvL;
   const int tid = threadIdx.x, lane = tid & 63;
   const int chunk = (g.total + 7) >> 3;                                          // XCD-aware order: every XCD gets a contiguous run of super-blocks
-  const int item = (int)(blockIdx.x & 7) * chunk + (int)(blockIdx.x >> 3);
-  if (item >= g.total) return;
-  const int sby = item / g.nsbx, sbx = item - sby * g.nsbx;
-  const int nsubx = min(4, g.n16x - 4 * sbx), nsuby = min(4, g.n16y - 4 * sby);
-  // VVCGPU_MH_DIAG: core-clock stamps of one workgroup's phases (start, window staged, every unit's end, units done, 64x64 pass done)
-  const bool stamp = diag && item == (g.total >> 1);
-  const int stampK = item == (g.total >> 2) ? 0 : item == (g.total >> 3) ? 1 : item == 3 * (g.total >> 2) ? 2 : item == 5 * (g.total >> 3) ? 3 : -1;   // four more workgroups: phase ends only
-  if (diag && stampK >= 0 && tid == 0) diag[40 + 0 * 4 + stampK] = __builtin_amdgcn_s_memtime();
-  if (stamp && tid == 0) diag[0] = __builtin_amdgcn_s_memtime();
-  unsigned* surf = refL + (g.winBytes >> 2);                                     // [MH_MAXSLOTS][4]
-
-  const int winCols = (g.nR - 1) * 5 + 16 * nsubx, winRows = (g.nR - 1) * 5 + 16 * nsuby - (1 << g.subShift) + 1;
-  const ptrdiff_t winOff = (ptrdiff_t)(g.refY0 + 64 * sby - g.R) * rs + g.refX0 + 64 * sbx - g.R;
-  const int off = (int)(winOff & 7);
-  fill_window_cols<8>(refL, reinterpret_cast<const uint4*>(ref + (winOff - off)), rs >> 3, winRows, MH_PITCH, ((winCols - 1 + off) >> 3) + 1, tid, (int)blockDim.x);
+  // what does not depend on the super-block, once per workgroup: the rate tables, the spans of the +-D grid, and (below) what every lane of a
+  // slot wave works on -- the window of every super-block starts at the same offset from a 16-byte boundary (64 columns / 64 rows of an 8-sample
+  // aligned stride apart)
   for (int n = tid; n < R5C_COST_N; n += (int)blockDim.x) costTab[n] = (unsigned)(unsigned long long)(mv.lambda * (double)n);
-  if (tid < 42) keys[tid] = ~0ull;
-  if (tid >= 64 && tid < 72) arrive[tid - 64] = 0;
-  if (tid < MH_MAXDL * 4) surfD[tid] = 0u;
-  for (int n = tid; n < MH_MAXSLOTS * 4; n += (int)blockDim.x) surf[n] = 0u;
+  if (tid == 700) { outPtr[0] = r16; outPtr[1] = r32; outPtr[2] = r64; outPtr[3] = d16; outPtr[4] = d32; outPtr[5] = d64; mvL = mv; }
   if (tid >= 512 && tid < 512 + 12) dlKey[tid - 512] = g.dlKey[tid - 512];
   if (tid >= 576 && tid < 576 + 48) dlX[tid - 576] = g.dlX[tid - 576];
   if (tid < 2 * g.nR)
@@ -287,24 +276,62 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
     (t < g.nD ? bitsDX : bitsDY)[n] = (unsigned char)expgolomb_bits(v >> mv.imv_shift);
   }
   __syncthreads();
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
+  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)refL;
+  const int off = (int)(((ptrdiff_t)(g.refY0 - g.R) * rs + g.refX0 - g.R) & 7);
+  const int nq = (g.nR + 3) >> 2, nslots = g.nR * nq, ndl = g.nD * g.dlCount, nsw = (nslots + ndl + 63) >> 6;
+  // the units of this wave: u = wave, wave + 16 (28 units: 7 slot waves x 4 quadrants; a wave keeps its quadrant).  The last slot wave goes FIRST:
+  // its dense lanes (rows one window row apart) meet LDS bank conflicts the raster lanes do not have, so its four units are the slowest; started
+  // first they run beside twelve others instead of ending the workgroup alone
+  MhLane LU[2];
+  {
+    MhTables T = { costTab, bitsRX, bitsRY, bitsDX, bitsDY, dlKey, dlX, g.dlCount };
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+    {
+      const int u = wave + r * nwaves, sw = nsw - 1 - (u >> 2);
+      LU[r].kind = 0; LU[r].base = 0; LU[r].idx = 0; LU[r].cst[0] = LU[r].cst[1] = LU[r].cst[2] = LU[r].cst[3] = MH_INVALID << 2;
+      if (u < 4 * nsw) mh_lane(sw * 64 + lane, g, T, off, nq, nslots, ndl, LU[r]);
+    }
+  }
+  // persistent: workgroup b walks the super-blocks (b >> 3), (b >> 3) + gridDim.x / 8, .. of its XCD's run -- a workgroup owns a CU (150 KB of LDS),
+  // and a new workgroup per super-block pays the dispatch of sixteen waves and the argument loads with nothing else running on the CU
+  for (int kk = (int)(blockIdx.x >> 3); kk < chunk; kk += (int)(gridDim.x >> 3))
+  {
+  const int item = (int)(blockIdx.x & 7) * chunk + kk;
+  if (item >= g.total) break;
+  const int sby = item / g.nsbx, sbx = item - sby * g.nsbx;
+  const int nsubx = min(4, g.n16x - 4 * sbx), nsuby = min(4, g.n16y - 4 * sby);
+  // VVCGPU_MH_DIAG: core-clock stamps of one workgroup's phases (start, window staged, every unit's end, units done, 64x64 pass done)
+  const bool stamp = diag && item == (g.total >> 1);
+  const int stampK = item == (g.total >> 2) ? 0 : item == (g.total >> 3) ? 1 : item == 3 * (g.total >> 2) ? 2 : item == 5 * (g.total >> 3) ? 3 : -1;   // four more workgroups: phase ends only
+  if (diag && stampK >= 0 && tid == 0) diag[40 + 0 * 4 + stampK] = __builtin_amdgcn_s_memtime();
+  if (stamp && tid == 0) diag[0] = __builtin_amdgcn_s_memtime();
+  unsigned* surf = refL + (g.winBytes >> 2);                                     // [MH_MAXSLOTS][4]
+
+  const int winCols = (g.nR - 1) * 5 + 16 * nsubx, winRows = (g.nR - 1) * 5 + 16 * nsuby - (1 << g.subShift) + 1;
+  const ptrdiff_t winOff = (ptrdiff_t)(g.refY0 + 64 * sby - g.R) * rs + g.refX0 + 64 * sbx - g.R;
+  fill_window_cols<9>(refL, reinterpret_cast<const uint4*>(ref + (winOff - off)), rs >> 3, winRows, MH_PITCH, ((winCols - 1 + off) >> 3) + 1, tid, (int)blockDim.x);
+  if (tid < 42) keys[tid] = ~0ull;
+  if (tid >= 64 && tid < 72) arrive[tid - 64] = 0;
+  if (tid < MH_MAXDL * 4) surfD[tid] = 0u;
+  for (int n = tid; n < MH_MAXSLOTS * 4; n += (int)blockDim.x) surf[n] = 0u;
+  __syncthreads();
   if (stamp && tid == 0) diag[1] = __builtin_amdgcn_s_memtime();
   if (diag && stampK >= 0 && tid == 0) diag[40 + 1 * 4 + stampK] = __builtin_amdgcn_s_memtime();
 
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6), nwaves = (int)(blockDim.x >> 6);
-  const unsigned ldsBase = (unsigned)(size_t)(__attribute__((address_space(3))) unsigned*)refL;
-  MhTables T = { costTab, bitsRX, bitsRY, bitsDX, bitsDY, dlKey, dlX, g.dlCount };
-  const int nq = (g.nR + 3) >> 2, nslots = g.nR * nq, ndl = g.nD * T.dlCount, nsw = (nslots + ndl + 63) >> 6;
-  for (int u = wave; u < 4 * nsw; u += nwaves)
+#pragma unroll
+  for (int r = 0; r < 2; r++)
   {
-    // the last slot wave goes FIRST: its dense lanes (rows one window row apart) meet LDS bank conflicts the raster lanes do not have, so its four
-    // units are the slowest; started first they run beside twelve others instead of ending the workgroup alone
-    const int sw = nsw - 1 - (u >> 2), q = u & 3;
-    const int s = sw * 64 + lane;
-    MhLane L;
-    mh_lane(s, g, T, off, nq, nslots, ndl, L);
-    const bool waveHasDense = ndl > 0 && sw * 64 + 63 >= nslots;                  // wave-uniform
-    mh_unit(orgPacked, g, off & 3, ldsBase + (unsigned)((q & 1) * 64 + (q >> 1) * 32 * MH_PITCH * 4), L, waveHasDense, q, sbx, sby, nsubx, nsuby, keys, surf, surfD, &arrive[sw], s, nslots, lane);
-    if (stamp && lane == 0) diag[8 + u] = __builtin_amdgcn_s_memtime();
+    const int u = wave + r * nwaves;
+    if (u < 4 * nsw)
+    {
+      const int sw = nsw - 1 - (u >> 2), q = u & 3;
+      const int s = sw * 64 + lane;
+      const bool waveHasDense = ndl > 0 && sw * 64 + 63 >= nslots;                // wave-uniform
+      mh_unit(orgPacked, g, off & 3, ldsBase + (unsigned)((q & 1) * 64 + (q >> 1) * 32 * MH_PITCH * 4), LU[r], waveHasDense, q, sbx, sby, nsubx, nsuby, keys, surf, surfD, &arrive[sw], s, nslots, lane);
+      if (stamp && lane == 0) diag[8 + u] = __builtin_amdgcn_s_memtime();
+    }
   }
   __syncthreads();
   if (stamp && tid == 0) diag[2] = diag[3] = __builtin_amdgcn_s_memtime();
@@ -314,22 +341,26 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
   if (tid < 42)
   {
     const int grid = tid >= 21, t = tid - 21 * grid;
-    if (grid && !g.nD) return;
-    vvcgpu_search_best* out; int bidx; bool exists;
-    if (t < 16)      { const int tx = t & 3, ty = t >> 2; exists = tx < nsubx && ty < nsuby; bidx = (4 * sby + ty) * g.n16x + 4 * sbx + tx; out = grid ? d16 : r16; }
-    else if (t < 20) { const int qx = (t - 16) & 1, qy = (t - 16) >> 1; exists = 2 * qx + 2 <= nsubx && 2 * qy + 2 <= nsuby; bidx = (2 * sby + qy) * (g.n16x >> 1) + 2 * sbx + qx; out = grid ? d32 : r32; }
-    else             { exists = nsubx == 4 && nsuby == 4; bidx = sby * (g.n16x >> 2) + sbx; out = grid ? d64 : r64; }
-    if (!exists || !out) return;
-    const unsigned long long key = keys[tid];
-    const int idx = (int)(key & 0xFFFFFFu);
-    const unsigned long long cost = key >> 24;
-    const int n = grid ? g.nD : g.nR, step = grid ? 1 : 5, p0 = grid ? -g.D : -g.R;
-    const int j = idx / n, i = idx - j * n;
-    const int x = p0 + i * step, y = p0 + j * step;
-    const unsigned bits = expgolomb_bits(((x << mv.cost_scale) - mv.pred_hor) >> mv.imv_shift) + expgolomb_bits(((y << mv.cost_scale) - mv.pred_ver) >> mv.imv_shift);
-    vvcgpu_search_best r;
-    r.x = x; r.y = y; r.cost = cost; r.sad = cost - (unsigned long long)(mv.lambda * (double)bits);
-    out[bidx] = r;
+    vvcgpu_search_best* out = nullptr; int bidx = 0; bool exists = false;
+    if (t < 16)      { const int tx = t & 3, ty = t >> 2; exists = tx < nsubx && ty < nsuby; bidx = (4 * sby + ty) * g.n16x + 4 * sbx + tx; out = outPtr[grid * 3]; }
+    else if (t < 20) { const int qx = (t - 16) & 1, qy = (t - 16) >> 1; exists = 2 * qx + 2 <= nsubx && 2 * qy + 2 <= nsuby; bidx = (2 * sby + qy) * (g.n16x >> 1) + 2 * sbx + qx; out = outPtr[grid * 3 + 1]; }
+    else             { exists = nsubx == 4 && nsuby == 4; bidx = sby * (g.n16x >> 2) + sbx; out = outPtr[grid * 3 + 2]; }
+    if (exists && out && !(grid && !g.nD))
+    {
+      const unsigned long long key = keys[tid];
+      const int idx = (int)(key & 0xFFFFFFu);
+      const unsigned long long cost = key >> 24;
+      const int n = grid ? g.nD : g.nR, step = grid ? 1 : 5, p0 = grid ? -g.D : -g.R;
+      const int j = idx / n, i = idx - j * n;
+      const int x = p0 + i * step, y = p0 + j * step;
+      const int csc = mvL.cost_scale, ish = mvL.imv_shift;
+      const unsigned bits = expgolomb_bits(((x << csc) - mvL.pred_hor) >> ish) + expgolomb_bits(((y << csc) - mvL.pred_ver) >> ish);
+      vvcgpu_search_best r;
+      r.x = x; r.y = y; r.cost = cost; r.sad = cost - (unsigned long long)(mvL.lambda * (double)bits);
+      out[bidx] = r;
+    }
+  }
+  __syncthreads();                                                               // keys / window are rewritten by the next super-block
   }
 }
 
@@ -385,7 +416,12 @@ int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref
   unsigned long long* diag = nullptr;
   const bool wantDiag = getenv("VVCGPU_MH_DIAG") != nullptr;                 // measurement aid (tools/mehier_time.py): phase stamps of one workgroup
   if (wantDiag) { VVC_HIP(hipMalloc(&diag, 64 * sizeof(unsigned long long))); VVC_HIP(hipMemsetAsync(diag, 0, 64 * sizeof(unsigned long long), st)); }
-  hipLaunchKernelGGL(me_hier_kernel, dim3(cdiv(g.total, 8) * 8), dim3(1024), smem, st, packed, ref, ref_stride, g, *mvcost_host,
+  int dev = 0, cus = 256;
+  (void)hipGetDevice(&dev);
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+  const char* per = getenv("VVCGPU_MH_PERSIST");                              // 0: one workgroup per super-block (the form of round 4)
+  const int gridWgs = (per && per[0] == '0') ? cdiv(g.total, 8) * 8 : min(cdiv(g.total, 8) * 8, (cus / 8) * 8);
+  hipLaunchKernelGGL(me_hier_kernel, dim3(gridWgs), dim3(1024), smem, st, packed, ref, ref_stride, g, *mvcost_host,
                      raster_best[0], raster_best[1], raster_best[2], dense_best ? dense_best[0] : nullptr, dense_best ? dense_best[1] : nullptr, dense_best ? dense_best[2] : nullptr, diag);
   VVC_LAUNCH_CHECK();
   if (wantDiag)
