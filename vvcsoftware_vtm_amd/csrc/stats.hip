@@ -777,10 +777,20 @@ __device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, u
   int* start = cnt + 32;
   const int tid = threadIdx.x;
   const int x0 = (ctuIdx % a.wCtu) * C, y0 = (ctuIdx / a.wCtu) * C;
+  int myKey[S], myPos[S];
   {
     constexpr int NBT = (L::ROWS * (P / 4) + ACT - 1) / ACT;
     pel4 tv[NBT];
     tile_fetch<P, NBT>(tv, a.rec[0], a.rstride[0], a.w, a.h, x0 - 4, y0 - 3, L::ROWS, tid, ACT);
+    // the classes of this thread's blocks: requested together with the tile (behind the barrier they were a second memory latency of the set-up)
+#pragma unroll
+    for (int s = 0; s < S; s++)
+    {
+      const int blk = tid + s * ACT, bi = blk % BPR, bj = blk / BPR;
+      const int bx = x0 + 4 * bj, by = y0 + 4 * bi;
+      myKey[s] = -1;
+      if (blk < NBLK && bx < a.w && by < a.h) myKey[s] = (int)a.cls[(size_t)(by >> 2) * (a.w >> 2) + (bx >> 2)];
+    }
     tile_store<P, NBT>(tile, tv, L::ROWS, tid, ACT);
   }
   for (int i = tid; i < L::zeroBytes / 4; i += ACT) reinterpret_cast<unsigned*>(smem + oZero)[i] = 0u;
@@ -788,16 +798,13 @@ __device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, u
   for (int i = tid; i < L::MAXSTEPS * 4; i += ACT) list[i] = EMPTY;
   if (tid < 64) cnt[tid] = 0;
   __syncthreads();
-  int myKey[S], myPos[S];
 #pragma unroll
   for (int s = 0; s < S; s++)
   {
-    // column-major thread -> block map: the lanes of a wave are vertical neighbours, so the four blocks of a step mostly are too -- their
-    // tile rows sit 16 LDS banks apart (4 rows x 68 dwords), while horizontal neighbours (2 banks apart) collide four-way in every tile read
-    const int blk = tid + s * ACT, bi = blk % BPR, bj = blk / BPR;
-    const int bx = x0 + 4 * bj, by = y0 + 4 * bi;
-    myKey[s] = -1; myPos[s] = 0;
-    if (blk < NBLK && bx < a.w && by < a.h) myKey[s] = (int)a.cls[(size_t)(by >> 2) * (a.w >> 2) + (bx >> 2)];
+    // column-major thread -> block map (blk = tid + s ACT, row blk % BPR): the lanes of a wave are vertical neighbours, so the four blocks of a step
+    // mostly are too -- their tile rows sit 16 LDS banks apart (4 rows x 68 dwords), while horizontal neighbours (2 banks apart) collide four-way
+    // in every tile read
+    myPos[s] = 0;
     // position inside the class: one LDS atomic per wave and distinct class (neighbouring blocks mostly share the class, and same-address
     // atomics serialise), the lanes of a class take consecutive positions behind the returned base
     const int myC = myKey[s] < 0 ? -1 : (myKey[s] & 0xff);
@@ -815,11 +822,13 @@ __device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, u
     }
   }
   __syncthreads();
-  if (tid == 0)
+  if (tid < 64)                                                             // first step of every class: an exclusive prefix sum over the lanes of one wave
   {
-    int acc = 0;
-    for (int c = 0; c < 25; c++) { start[c] = acc; acc += (cnt[c] + 3) >> 2; }
-    start[25] = acc;
+    const int steps = tid < 25 ? (cnt[tid] + 3) >> 2 : 0;
+    int incl = steps;
+#pragma unroll
+    for (int o = 1; o < 32; o <<= 1) { const int v = __shfl_up(incl, o); if (tid >= o) incl += v; }
+    if (tid <= 25) start[tid] = incl - steps;                                // (lane 25: the total)
   }
   __syncthreads();
   const int T = start[25];
