@@ -23,7 +23,10 @@ def run(sel,label):
     print('%-34s %7d calls %9d samples %.4f ms'%(label,len(calls),n,ms))
 w,h=sig[:,0],sig[:,1]
 run(np.ones(len(sig),bool),'all')
-run(w%4!=0,'w % 4 != 0 (scalar path)')
+run(w%4!=0,'w % 4 != 0')
+run((w%4!=0)&(w<4),'  of these: w < 4 (partial units)')
+run((w%4!=0)&(w>=4)&(w*h<=512),'  w >= 5 odd, <= 512 samples')
+run((w%4!=0)&(w>=4)&(w*h>512),'  w >= 5 odd, > 512 samples (heavy)')
 run((w%4==0)&(w*h<=256),'w%4==0, <= 256 samples')
 run((w%4==0)&(w*h>256)&(w*h<=512),'257..512 samples')
 run((w%4==0)&(w*h>512),'> 512 samples (heavy)')

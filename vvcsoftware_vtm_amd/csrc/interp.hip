@@ -97,13 +97,15 @@ __device__ __forceinline__ void if_one(const vvcgpu_if_desc& d, const Pel* __res
   for (int k = 0; k < 8; k++) c[k] = k < N ? d.coeff[k] : 0;
   {
     // four consecutive outputs of a row per lane: N + 3 samples (horizontal) or N loads of four samples (vertical) instead of 4 N two-byte loads.
-    // Widths that are not a multiple of four (the W + 1 wide planes of xExtDIFUpSamplingH / Q: 5, 9, 17, 33, 65, 129 -- 30 % of if_batch's time on a
-    // real call mix went into them one output per lane) end every row with a PARTIAL unit of nv < 4 outputs, which loads sample by sample exactly
-    // the nv + N - 1 samples (horizontal) / nv columns (vertical) the reference reads: nothing beyond the reference's window in either form.
+    // Widths that are not a multiple of four (the W + 1 wide planes of xExtDIFUpSamplingH / Q: 5, 9, 17, 33, 65, 129 -- 13 % of the samples of a real
+    // call mix and, with a sample-by-sample partial unit per row that every wave walked beside its full units, half of if_batch's time on it): the
+    // LAST unit of a row starts at w - 4 and overlaps its neighbour, so it is a full unit too -- the overlapped outputs are written twice with the
+    // same values, and it reads exactly up to the last sample the reference reads (x + 3 + N - 1 = w + N - 2), nothing beyond the reference's window.
+    // Only rows narrower than four samples keep a partial unit (nv < 4, sample-by-sample loads).
     const int upr = (w + 3) >> 2, units = act ? upr * hh : 0;
     for (int u = lane; u < units; u += G)
     {
-      const int y = u / upr, x = (u - y * upr) << 2, nv = min(4, w - x);
+      const int y = u / upr, xu = (u - y * upr) << 2, x = w >= 4 ? min(xu, w - 4) : xu, nv = min(4, w - x);
       const Pel* s = src + (size_t)y * d.src_stride + x;
       int sum[4] = { 0, 0, 0, 0 };
       if (d.is_vertical)
