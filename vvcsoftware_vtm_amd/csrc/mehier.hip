@@ -37,6 +37,7 @@ namespace {
 constexpr int MH_PITCH = 148;                          // dwords per window row: = 20 (mod 64), >= (254 + 7 + 7) / 2
 constexpr int MH_MAXN = 39;                            // raster positions per axis (search range 96, step 5)
 constexpr int MH_MAXSLOTS = 448;                       // 7 slot waves
+constexpr int MH_MAXSLIDE = 7;                         // slides of the window between two full fills (1 KB of slack behind the window)
 constexpr int MH_MAXDL = 96;                           // lanes of the +-D grid (9 rows x at most 9 spans)
 constexpr unsigned MH_INVALID = 0x30000000u;           // above every valid cost (SAD << 1 < 2^23, lambda * bits < 2^29), below 2^30
 
@@ -302,16 +303,23 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
       if (u < 4 * nsw) mh_lane(sw * 64 + lane, g, T, off, nq, nslots, ndl, LU[r]);
     }
   }
-  // persistent: workgroup b walks the super-blocks (b >> 3), (b >> 3) + gridDim.x / 8, .. of its XCD's run -- a workgroup owns a CU (150 KB of LDS),
-  // and a new workgroup per super-block pays the dispatch of sixteen waves and the argument loads with nothing else running on the CU
-  for (int kk = (int)(blockIdx.x >> 3); kk < chunk; kk += (int)(gridDim.x >> 3))
+  // persistent: workgroup b walks a contiguous run of super-blocks of its XCD's chunk -- a workgroup owns a CU (150 KB of LDS), and a new workgroup per
+  // super-block pays the dispatch of sixteen waves and the argument loads with nothing else running on the CU.  SLIDING WINDOW: the next super-block of
+  // a run is the right-hand neighbour, whose window shares 190 of its 254 columns; LDS is addressed linearly, so the shared columns stay where they are
+  // when every address moves on by 32 dwords (64 samples), and the 64 new columns of a row land behind its old end: in the row padding and in the
+  // first -- now dead -- 64 columns of the row below (the last row runs into 1 KB of slack).  A slide loads 8 of 33 quads per row.
+  const int perX = (int)(gridDim.x >> 3), runLen = (chunk + perX - 1) / perX, kk0 = (int)(blockIdx.x >> 3) * runLen;
+  int slide = 0, pfQ0 = 0;
+  bool pfHave = false;
+  uint4 pf[2];
+  for (int kk = kk0; kk < kk0 + runLen && kk < chunk; kk++)
   {
   const int item = (int)(blockIdx.x & 7) * chunk + kk;
   if (item >= g.total) break;
   const int sby = item / g.nsbx, sbx = item - sby * g.nsbx;
   const int nsubx = min(4, g.n16x - 4 * sbx), nsuby = min(4, g.n16y - 4 * sby);
   // VVCGPU_MH_DIAG: core-clock stamps of one workgroup's phases (start, window staged, every unit's end, units done, 64x64 pass done)
-  const bool stamp = diag && item == (g.total >> 1);
+  const bool stamp = diag && item == (g.total >> 1) + 3;                            // (the fourth super-block of a run: a slide)
   const int stampK = item == (g.total >> 2) ? 0 : item == (g.total >> 3) ? 1 : item == 3 * (g.total >> 2) ? 2 : item == 5 * (g.total >> 3) ? 3 : -1;   // four more workgroups: phase ends only
   if (diag && stampK >= 0 && tid == 0) diag[40 + 0 * 4 + stampK] = __builtin_amdgcn_s_memtime();
   if (stamp && tid == 0) diag[0] = __builtin_amdgcn_s_memtime();
@@ -319,12 +327,63 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
 
   const int winCols = (g.nR - 1) * 5 + 16 * nsubx, winRows = (g.nR - 1) * 5 + 16 * nsuby - (1 << g.subShift) + 1;
   const ptrdiff_t winOff = (ptrdiff_t)(g.refY0 + 64 * sby - g.R) * rs + g.refX0 + 64 * sbx - g.R;
-  fill_window_cols<9>(refL, reinterpret_cast<const uint4*>(ref + (winOff - off)), rs >> 3, winRows, MH_PITCH, ((winCols - 1 + off) >> 3) + 1, tid, (int)blockDim.x);
+  const int nQuads = ((winCols - 1 + off) >> 3) + 1;
+  const int rsQ = rs >> 3;
+  // the quads (row, q) of a slide that this thread moves: items tid and tid + 1024 of nNew x winRows
+  auto slideItem = [&](int it, int q0, int& row, int& q) { row = it >> 3; q = q0 + (it & 7); };     // (a slide is always 8 quads per row: both windows full width)
+  if (pfHave)                                                                    // requested while the previous super-block was searched
+  {
+    slide++;
+    unsigned* winL = refL + slide * 32;
+#pragma unroll
+    for (int u = 0; u < 2; u++)
+    {
+      const int it = tid + u * 1024;
+      if (it < 8 * winRows)
+      {
+        int row, q;
+        slideItem(it, pfQ0, row, q);
+        uint2* d = reinterpret_cast<uint2*>(winL + row * MH_PITCH + 4 * q);
+        d[0] = make_uint2(pf[u].x ^ 0x80008000u, pf[u].y ^ 0x80008000u);
+        d[1] = make_uint2(pf[u].z ^ 0x80008000u, pf[u].w ^ 0x80008000u);
+      }
+    }
+  }
+  else
+  {
+    slide = 0;
+    fill_window_cols<9>(refL, reinterpret_cast<const uint4*>(ref + (winOff - off)), rs >> 3, winRows, MH_PITCH, nQuads, tid, (int)blockDim.x);
+  }
+  // the right-hand neighbour's new columns, if it is the next super-block of this run: two 16-byte loads per thread, in flight during the search
+  pfHave = false;
+  if (kk + 1 < kk0 + runLen && kk + 1 < chunk && item + 1 < g.total && sbx + 1 < g.nsbx && slide < MH_MAXSLIDE)      // wave-uniform
+  {
+    const int nsubxN = min(4, g.n16x - 4 * (sbx + 1)), nQuadsN = (((g.nR - 1) * 5 + 16 * nsubxN - 1 + off) >> 3) + 1;
+    pfQ0 = nQuads - 8;
+    if (nQuadsN - pfQ0 == 8 && 8 * winRows <= 2048)
+    {
+      pfHave = true;
+      const uint4* gsrc = reinterpret_cast<const uint4*>(ref + (winOff + 64 - off));
+#pragma unroll
+      for (int u = 0; u < 2; u++)
+      {
+        const int it = tid + u * 1024;
+        pf[u] = make_uint4(0u, 0u, 0u, 0u);
+        if (it < 8 * winRows)
+        {
+          int row, q;
+          slideItem(it, pfQ0, row, q);
+          pf[u] = gsrc[(size_t)row * rsQ + q];
+        }
+      }
+    }
+  }
   if (tid < 42) keys[tid] = ~0ull;
   if (tid >= 64 && tid < 72) arrive[tid - 64] = 0;
   if (tid < MH_MAXDL * 4) surfD[tid] = 0u;
   for (int n = tid; n < MH_MAXSLOTS * 4; n += (int)blockDim.x) surf[n] = 0u;
-  __syncthreads();
+  // LDS-only barrier: __syncthreads() also waits for vmcnt(0), i.e. for the neighbour's columns that were requested just above
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (stamp && tid == 0) diag[1] = __builtin_amdgcn_s_memtime();
   if (diag && stampK >= 0 && tid == 0) diag[40 + 1 * 4 + stampK] = __builtin_amdgcn_s_memtime();
 
@@ -337,7 +396,7 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
       const int sw = nsw - 1 - (u >> 2), q = u & 3;
       const int s = sw * 64 + lane;
       const bool waveHasDense = ndl > 0 && sw * 64 + 63 >= nslots;                // wave-uniform
-      mh_unit(orgPacked, g, off & 3, ldsBase + (unsigned)((q & 1) * 64 + (q >> 1) * 32 * MH_PITCH * 4), LU[r], waveHasDense, q, sbx, sby, nsubx, nsuby, keys, surf, surfD, &arrive[sw], s, nslots, lane);
+      mh_unit(orgPacked, g, off & 3, ldsBase + (unsigned)(slide * 128 + (q & 1) * 64 + (q >> 1) * 32 * MH_PITCH * 4), LU[r], waveHasDense, q, sbx, sby, nsubx, nsuby, keys, surf, surfD, &arrive[sw], s, nslots, lane);
       if (stamp && lane == 0) diag[8 + u] = __builtin_amdgcn_s_memtime();
     }
   }
@@ -413,7 +472,7 @@ int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref
   }
   g.magicDl = g.dlCount ? (65536u + (unsigned)g.dlCount - 1u) / (unsigned)g.dlCount : 0u;
   const int winRowsMax = (nR - 1) * 5 + 64;
-  g.winBytes = winRowsMax * MH_PITCH * 4;
+  g.winBytes = winRowsMax * MH_PITCH * 4 + MH_MAXSLIDE * 128 + 128;            // + the slack the sliding window runs into
   const size_t smem = (size_t)g.winBytes + MH_MAXSLOTS * 4 * sizeof(unsigned);
   const int nblocks = c.n16x * c.n16y;
   unsigned* packed = static_cast<unsigned*>(vvcgpu_scratch(st, (size_t)nblocks * g.hs * 16 * sizeof(unsigned)));
