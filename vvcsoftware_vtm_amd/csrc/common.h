@@ -14,6 +14,7 @@ void vvcgpu_set_error(const char* fmt, ...);
 // Library-internal device scratch, cached per (device, stream): work on one stream is ordered, so the buffer of the previous
 // call on that stream is free again when the next call's kernels start.  Grow-only; returns nullptr (error text set) on failure.
 void* vvcgpu_scratch(hipStream_t stream, size_t bytes);
+int vvcgpu_cu_count(void);                         // compute units of the current device (queried once per device; 256 if the query fails)
 constexpr int VVC_CTR_INTS = 32;                       // ints per counter set of vvcgpu_counters
 int* vvcgpu_counters(hipStream_t stream, int* cur);     // two persistent zeroed work counters per (device, stream), see lib.hip
 void vvcgpu_counters_failed(hipStream_t stream);       // a launch that took a counter set failed: both sets are cleared before their next use

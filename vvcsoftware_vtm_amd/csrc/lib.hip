@@ -1,5 +1,6 @@
 // lib.hip -- library-level entry points of the C ABI (include/vvcgpu.h).
 #include "common.h"
+#include <atomic>
 #include <mutex>
 #include <stdarg.h>
 #include <string.h>
@@ -110,6 +111,20 @@ void vvcgpu_counters_failed(hipStream_t stream)
   if (hipGetDevice(&dev) != hipSuccess) return;
   std::lock_guard<std::mutex> lock(g_slotMutex);
   if (StreamSlot* slot = find_slot(dev, stream, false)) slot->dirty = true;
+}
+
+// compute units of the current device, cached per device (persistent kernels size their grids with it on every call)
+int vvcgpu_cu_count(void)
+{
+  static std::atomic<int> cached[64];
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 64) return 256;
+  int v = cached[dev].load(std::memory_order_relaxed);
+  if (v > 0) return v;
+  int cus = 0;
+  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
+  cached[dev].store(cus, std::memory_order_relaxed);
+  return cus;
 }
 
 extern "C" {

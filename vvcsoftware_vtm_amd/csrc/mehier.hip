@@ -483,11 +483,8 @@ int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref
   unsigned long long* diag = nullptr;
   const bool wantDiag = getenv("VVCGPU_MH_DIAG") != nullptr;                 // measurement aid (tools/mehier_time.py): phase stamps of one workgroup
   if (wantDiag) { VVC_HIP(hipMalloc(&diag, 64 * sizeof(unsigned long long))); VVC_HIP(hipMemsetAsync(diag, 0, 64 * sizeof(unsigned long long), st)); }
-  int dev = 0, cus = 256;
-  (void)hipGetDevice(&dev);
-  if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus < 8) cus = 256;
-  const char* per = getenv("VVCGPU_MH_PERSIST");                              // 0: one workgroup per super-block (the form of round 4)
-  const int gridWgs = (per && per[0] == '0') ? cdiv(g.total, 8) * 8 : min(cdiv(g.total, 8) * 8, (cus / 8) * 8);
+  static const int persistOff = (getenv("VVCGPU_MH_PERSIST") && getenv("VVCGPU_MH_PERSIST")[0] == '0') ? 1 : 0;   // A/B switch: one workgroup per super-block (the form of round 4)
+  const int gridWgs = persistOff ? cdiv(g.total, 8) * 8 : min(cdiv(g.total, 8) * 8, (vvcgpu_cu_count() / 8) * 8);
   hipLaunchKernelGGL(me_hier_kernel, dim3(gridWgs), dim3(1024), smem, st, packed, ref, ref_stride, g, *mvcost_host,
                      raster_best[0], raster_best[1], raster_best[2], dense_best ? dense_best[0] : nullptr, dense_best ? dense_best[1] : nullptr, dense_best ? dense_best[2] : nullptr, diag);
   VVC_LAUNCH_CHECK();
