@@ -122,6 +122,35 @@ def test_me_hier_equals_the_per_size_kernels_1080p():
     assert (np.abs(got["x"]) > 4).mean() > 0.5
 
 
+@pytest.mark.parametrize("n16x,n16y,rr,dr,org_xy,ref_dx", [
+    (81, 8, 96, 4, (0, 0), 0),        # 21 super-blocks per row, the last one a single column of blocks: runs of 6 slide five times, the partial one refills
+    (64, 12, 96, 4, (16, 0), 3),      # window origin 3 samples off a 16-byte boundary, grid origin inside the picture
+    (48, 9, 64, 3, (0, 16), -2),      # smaller raster (25 x 25: fewer quads per window row), +-3 grid, partial last super-block row
+])
+def test_me_hier_sliding_window_runs(monkeypatch, n16x, n16y, rr, dr, org_xy, ref_dx):
+    """eight persistent workgroups (VVCGPU_MH_WGS) over a wide grid: every workgroup walks a run of horizontally consecutive super-blocks and SLIDES its LDS
+    window (mehier.hip); results against the per-size search kernels, which the oracle pins block by block (tests/test_gpu_dist.py)"""
+    from vvcsoftware_vtm_amd import ops
+    monkeypatch.setenv("VVCGPU_MH_WGS", "8")
+    rng = np.random.default_rng(n16x + 3 * n16y + rr)
+    m = 144
+    W, H = 16 * n16x + org_xy[0], 16 * n16y + org_xy[1]
+    W += (-W) % 8
+    org, refp = make(rng, W, H, m, "moved")
+    ref_xy = (m + org_xy[0] + ref_dx, m + org_xy[1] + 1)
+    mv = ops.MvCost(11.25, -5, 9, 2, 0)
+    d_org, d_ref = dev(org), dev(refp)
+    raster, dense = ops.me_hier_search(d_org, d_ref, org_xy, ref_xy, n16x, n16y, 1, rr, dr, mv)
+    R, nR = 5 * (rr // 5), 2 * (rr // 5) + 1
+    for k, s in enumerate((16, 32, 64)):
+        blk = grid_blocks(n16x, n16y, s, org_xy, ref_xy)
+        d_blk = ops.struct_to_device(blk)
+        _, want = ops.sad_search(d_org, d_ref, d_blk, blk.size, s, s, 1, -R, -R, nR, nR, 5, 5, mv, want_sad=False)
+        assert torch.equal(raster[k], want), "raster %d" % s
+        _, want = ops.sad_search(d_org, d_ref, d_blk, blk.size, s, s, 1, -dr, -dr, 2 * dr + 1, 2 * dr + 1, 1, 1, mv, want_sad=False)
+        assert torch.equal(dense[k], want), "dense %d" % s
+
+
 def test_me_hier_unsupported_shapes_are_refused():
     from vvcsoftware_vtm_amd import capi, ops
     org, refp = dev(np.zeros((64, 64), np.int16)), dev(np.zeros((400, 400), np.int16))
