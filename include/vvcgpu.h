@@ -146,7 +146,9 @@ int vvcgpu_deblock(vvc_pel* y, int stride_y, vvc_pel* cb, vvc_pel* cr, int strid
  *      EO classes use indices 0..4 (edgeType + 2), BO the 32 bands.  320 int64 per CTU.
  * avail: device array, one byte per CTU with the vvcgpu_sao_ctu.avail bit layout; only L (bit0), A (bit2) and
  *      AL (bit4) are read -- right/below/above-right come from the picture geometry exactly as in :300-306.
- * skip_lines_r / skip_lines_b: m_skipLinesR/B of the component (5/4 luma, 3/2 chroma; :122-128).        */
+ * skip_lines_r / skip_lines_b: m_skipLinesR/B of the component (5/4 luma, 3/2 chroma; :122-128).
+ * Precondition: org and rec samples within the bit depth (|org - rec| <= 1023: the per-thread accumulators pack count and sum; a band index is
+ * taken modulo 32); a plane holds fewer than 2^31 samples.                                               */
 int vvcgpu_sao_stats(const vvc_pel* org, int org_stride, const vvc_pel* rec, int rec_stride,
                      int width, int height, int ctu_w, int ctu_h, int bit_depth, const uint8_t* avail,
                      int skip_lines_r, int skip_lines_b, int64_t* out, void* stream);

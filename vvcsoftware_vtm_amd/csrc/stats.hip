@@ -162,7 +162,7 @@ __device__ __forceinline__ void sao_stats_body(const int cx, const int cy, const
         }
       }
       if (inX90 && y < endY0)
-        atomicAdd(&bo[(tid & 15) * 32 + (c >> boShift)], (1ull << 32) + (unsigned long long)(d + 1024));
+        atomicAdd(&bo[(tid & 15) * 32 + ((c >> boShift) & 31)], (1ull << 32) + (unsigned long long)(d + 1024));
 #pragma unroll
       for (int k = 0; k < 3; k++) { r0[k] = r1[k]; r1[k] = r2[k]; }
     }
@@ -388,7 +388,7 @@ __device__ __forceinline__ void sao_stats_body_pk(const int cx, const int cy, co
           if (y + j < endY0)
           {
             const int cj = (int)(short)(C[1 + (j >> 1)] >> ((j & 1) * 16));
-            atomicAdd(&bo[(tid & 15) * 32 + (cj >> boShift)], (1ull << 32) + (unsigned long long)t4[j]);
+            atomicAdd(&bo[(tid & 15) * 32 + ((cj >> boShift) & 31)], (1ull << 32) + (unsigned long long)t4[j]);
           }
       }
     }
