@@ -1802,7 +1802,48 @@ __global__ __launch_bounds__(256, MODE == RC_CHAIN ? 2 : 3) void rc_chain_kernel
                                                         clpMax, tab, tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
     switch (k)
     {
-    RC_MF(0, 64, 64) RC_MF(1, 64, 32) RC_MF(2, 32, 64) RC_MF(3, 32, 32) RC_MF(4, 64, 16) RC_MF(5, 16, 64) RC_MF(7, 32, 16) RC_MF(8, 16, 32) RC_MF(9, 16, 16)
+    RC_MF(0, 64, 64) RC_MF(1, 64, 32) RC_MF(2, 32, 64) RC_MF(3, 32, 32) RC_MF(4, 64, 16) RC_MF(5, 16, 64) RC_MF(7, 32, 16) RC_MF(8, 16, 32)
+    case 9:
+    {
+      // 16x16, the most numerous matrix-core class: the workgroup's consecutive slots of this class are walked HERE, with the list entry of the
+      // item after next and the descriptor of the next item requested (vector loads: no scalar load in flight during the stages) while the current
+      // TU runs -- list entry -> descriptor -> samples are three memory latencies in a row otherwise.  The registers of the pipeline live only
+      // inside this loop (across the 64-point bodies they were spills: docs/OPTIMISATION_LOG.md).
+      int vz = 0;
+      asm volatile("" : "+v"(vz));                           // a zero the compiler takes for lane-dependent: the loads below stay vector loads
+      const int* lst = lists + (size_t)ordCls[9] * n;
+      const int G4 = 4 * (int)gridDim.x;
+      int it = item;
+      if (it >= cnt[9]) break;
+      int ti0 = __builtin_amdgcn_readfirstlane(lst[it]);
+      int tiv1 = it + G4 < cnt[9] ? lst[it + G4 + vz] : 0;
+      uint4 dq = reinterpret_cast<const uint4*>(descs + ti0)[(lane & 3) + vz];
+      for (;;)
+      {
+        RcDesc dCur;
+        {
+          unsigned* w = reinterpret_cast<unsigned*>(&dCur);
+#pragma unroll
+          for (int q = 0; q < 4; q++)
+          {
+            w[4 * q + 0] = __builtin_amdgcn_readlane(dq.x, q); w[4 * q + 1] = __builtin_amdgcn_readlane(dq.y, q);
+            w[4 * q + 2] = __builtin_amdgcn_readlane(dq.z, q); w[4 * q + 3] = __builtin_amdgcn_readlane(dq.w, q);
+          }
+        }
+        const bool more = it + G4 < cnt[9] && slot + (int)gridDim.x < end[9];          // the next slot of this workgroup is of this class too
+        const int ti1 = __builtin_amdgcn_readfirstlane(tiv1);
+        if (more)
+        {
+          dq = reinterpret_cast<const uint4*>(descs + ti1)[(lane & 3) + vz];
+          tiv1 = it + 2 * G4 < cnt[9] ? lst[it + 2 * G4 + vz] : 0;
+        }
+        const bool ok = rc_tu_mfma<16, 16, MODE>(dCur, orgBase, predBase, recBase, levelBase, absSumOut, ti0, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
+        if (!ok && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti0;
+        if (!more) break;
+        it += G4; ti0 = ti1; slot += (int)gridDim.x;
+      }
+      break;
+    }
     RC_PK(10, 16, 8) RC_PK(11, 8, 16) RC_PK(12, 16, 4) RC_PK(13, 4, 16)
     case 6: if (item < items[6]) rc_small_group<8, MODE>(descs, lists + (size_t)RC_C8 * n, cnt[6], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
     case 14: if (item < items[14]) rc_small_group<4, MODE>(descs, lists + (size_t)RC_C4 * n, cnt[14], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
