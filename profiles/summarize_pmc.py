@@ -8,6 +8,7 @@ Columns: per-launch averages of every counter collected, plus
   valu_per_wave, salu_per_wave   SQ_INSTS_VALU / SQ_WAVES, SQ_INSTS_SALU / SQ_WAVES
   sq_busy_frac                   SQ_BUSY_CYCLES / (GRBM-free estimate: launch duration x 2.4 GHz x 32 SEs)   [indicative]
   issue_ns_per_valu              launch duration x 1024 SIMDs / SQ_INSTS_VALU   (4.4 cycles = 1.8 ns is the measured issue floor)
+  lds_conflict_ratio             SQ_LDS_BANK_CONFLICT / SQ_ACTIVE_INST_LDS   (extra LDS-array cycles per cycle an LDS instruction is active)
 SQ_*_CYCLES / SQ_WAIT_* / SQ_ACTIVE_INST_* count quad-cycles summed over waves (MI355X_MICROARCH.md, cycle constants)."""
 import csv
 import os
@@ -52,7 +53,7 @@ def main():
     keys = sorted(set(a) | set(b), key=lambda k: -sum(dur.get(k, dur_pmc.get(k, [0]))))
     out = os.path.join(here, tag + "_pmc_sq.csv")
     with open(out, "w") as fh:
-        fh.write("kernel,grid_threads,lds_bytes,avg_us," + ",".join(names) + ",valu_per_wave,salu_per_wave,issue_ns_per_valu\n")
+        fh.write("kernel,grid_threads,lds_bytes,avg_us," + ",".join(names) + ",valu_per_wave,salu_per_wave,issue_ns_per_valu,lds_conflict_ratio\n")
         for k in keys:
             d = dur.get(k) or dur_pmc.get(k) or [0]
             us = sum(d) / len(d) / 1e3
@@ -64,8 +65,9 @@ def main():
             valu, salu = vals.get("SQ_INSTS_VALU", 0.0), vals.get("SQ_INSTS_SALU", 0.0)
             kname = '"%s"' % k[0] if "," in k[0] else k[0]
             fh.write("%s,%d,%d,%.2f," % (kname, k[1], k[2], us) + ",".join("%.0f" % vals[n] if n in vals else "" for n in names))
-            fh.write(",%s,%s,%s\n" % ("%.1f" % (valu / waves) if waves else "", "%.1f" % (salu / waves) if waves else "",
-                                      "%.2f" % (us * 1e3 * 1024 / valu) if valu else ""))
+            ldsA, ldsC = vals.get("SQ_ACTIVE_INST_LDS", 0.0), vals.get("SQ_LDS_BANK_CONFLICT", 0.0)
+            fh.write(",%s,%s,%s,%s\n" % ("%.1f" % (valu / waves) if waves else "", "%.1f" % (salu / waves) if waves else "",
+                                         "%.2f" % (us * 1e3 * 1024 / valu) if valu else "", "%.3f" % (ldsC / ldsA) if ldsA else ""))
     print(open(out).read())
 
 
