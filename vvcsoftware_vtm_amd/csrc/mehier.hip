@@ -14,15 +14,18 @@
 // here it is issued once and the larger blocks cost additions.
 //
 // Design.
-//   * One 1024-thread workgroup owns a 64x64 SUPER-BLOCK: its search window (64 + 2 R)^2 samples (R = 95: 254 x 254, 150 KB at the conflict-free
-//     row pitch of 148 dwords) is staged ONCE in LDS, biased by 0x8000 (v_sad_u16 is then exact for any int16).  One workgroup per CU.
+//   * One 1024-thread workgroup owns a 64x64 SUPER-BLOCK at a time: its search window (64 + 2 R)^2 samples (R = 95: 254 x 254, 150 KB at the
+//     conflict-free row pitch of 148 dwords) is staged ONCE in LDS, biased by 0x8000 (v_sad_u16 is then exact for any int16).  One workgroup per CU,
+//     PERSISTENT (round 5): it walks a run of horizontally consecutive super-blocks of its XCD's chunk and SLIDES the window -- LDS is addressed
+//     linearly, a step to the right moves every address on by 32 dwords, the 64 new columns of a row land behind its old end (row padding + the dead
+//     first columns of the row below) and are requested one super-block ahead; tables and lane descriptors are set up once per workgroup.
 //   * The SAD loop is the QUAD form of the strip kernels (raster_dev.h): a lane owns four consecutive raster columns (0 / 5 / 10 / 15 samples
 //     into one span of LDS), the original rows are wave-uniform scalar operands from a packed copy (even + odd-shifted layout per chunk-row).
 //   * A unit of work = (32x32 quadrant, 64 flattened (raster row, column quad) slots): the wave walks the quadrant's four 16x16 sub-blocks one
 //     after the other with the SAME lane -> position map, so the 32x32 SAD of a lane's four positions is a register sum; the 64x64 SAD meets in
-//     an LDS surface (one ds_add_u32 per position and quadrant).  39 x 10 quads = 390 slots = 7 slot waves x 4 quadrants = 28 units; the
-//     +-4 grid (9 rows x 3 column quads, column step 1 instead of 5: same loop, other template argument) is 4 more units: 32 units = two
-//     rounds of the workgroup's 16 waves.  Flattened slots stay bank-conflict free: with the pitch = 20 (mod 64) dwords the ds_read_b64 bank
+//     an LDS surface (one ds_add_u32 per position and quadrant).  39 x 10 quads = 390 slots = 7 slot waves x 4 quadrants = 28 units = two rounds of
+//     the workgroup's 16 waves (twelve waves take two units of the same quadrant, four take one); the +-4 grid rides as 54 dense lanes in the idle
+//     lanes of the last slot wave (see MhLane).  Issue priority follows a wave's progress inside its unit (s_setprio), so the waves of a SIMD finish together.  Flattened slots stay bank-conflict free: with the pitch = 20 (mod 64) dwords the ds_read_b64 bank
 //     of slot s is 10 s (mod 64), distinct for any 32 consecutive slots.
 //   * Arg-min: per block and unit a 32-bit wave minimum of cost (DPP), then the first lane that holds it (lane order = visiting order) -> 64-bit
 //     (cost << 24 | visiting index) LDS atomicMin per block; a super-block is finished by exactly ONE workgroup, which writes the final
