@@ -10,9 +10,12 @@
 namespace {
 
 // =====================================================================================================
-// S2: SAO statistics.  One workgroup per CTU; the deblocked tile (+1 halo) is staged once in LDS, each
+// S2: SAO statistics.  One workgroup per CTU; the deblocked tile (+1 halo) is staged in LDS, each
 // thread walks one column segment with the five classifiers evaluated together, EO class counters live in
-// registers (statically indexed), BO bands in a packed 64-bit LDS histogram.
+// registers (statically indexed), BO bands in a packed 64-bit LDS histogram.  Two bodies with the same results:
+// the scalar one (sao_stats_body: any CTU shape) and the packed one (sao_stats_body_pk, round 5: CTUs at least 64
+// wide, 256-thread workgroups over strips of 16 rows per thread, two signs per packed instruction, categories as
+// v_perm_b32 selectors, v_dot4_u32_u8 accumulation).
 // =====================================================================================================
 constexpr int SAO_MAX_CTU = 128;
 
