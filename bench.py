@@ -61,6 +61,7 @@ def parse_args():
                     help="resident copies of the per-picture inputs (original + first reference picture) the pictures cycle through: 12 x 56 MB at 4K exceeds "
                          "the 256 MB memory-side cache, so the input reads and the counters behind hbm_frac are HBM-side (1 = every picture re-reads the same buffers)")
     ap.add_argument("--no-input-stream", action="store_true", help="skip the second timed region that uploads one original picture per picture from pinned host memory")
+    ap.add_argument("--no-depquant-leg", action="store_true", help="skip the leg that runs the same pictures with the dependent-quantisation trellis (DepQuant 1 of the shipped cfgs) in place of the stand-in quantiser")
     ap.add_argument("--rehearse", action="store_true",
                     help="N > 1 on ONE GPU: every rank takes device (local rank mod device count) and the process group is gloo (RCCL refuses two ranks on "
                          "one device); the hand-over keeps the grouped form the RCCL run takes.  A rehearsal of the N > 1 control flow, not a measurement")
@@ -456,6 +457,35 @@ def main():
         torch.cuda.current_stream().wait_stream(up["stream"])
         timer.on = True
 
+    # ---- with_depquant leg: the shipped configurations run `DepQuant 1` (cfg/encoder_randomaccess_vtm.cfg); the headline workload uses the
+    # Quant::quant stand-in SURVEY 8(d) allows.  The same pictures once more with vvcgpu_depquant_batch + the dependent-quantisation de-quantiser between the
+    # separate transform entry points -- reported beside `value`, never as `value`.  A bounded number of pictures: the trellis is the serial walk of its longest TU.
+    dq_leg = None
+    if rank == 0 and world == 1 and not args.no_depquant_leg:
+        wl_dq = Workload(args.width, args.height, bd, seed=20261003 + rank, qp=args.qp, depquant=True)
+        tdq = Timer()
+        st_dq, _ = wl_dq.run_gpu(None, None, overlap=False)
+        torch.cuda.synchronize()
+        n_dq = max(4, min(pps, 16))
+        t2 = time.perf_counter()
+        for _ in range(n_dq):
+            st_dq, o_dq = wl_dq.run_gpu(st_dq, None, overlap=False)
+        torch.cuda.synchronize()
+        dt_dq = time.perf_counter() - t2
+        tdq.on = True
+        for _ in range(3):
+            st_dq, o_dq = wl_dq.run_gpu(st_dq, tdq, overlap=False)
+        torch.cuda.synchronize()
+        g_dq = {k: sum(a.elapsed_time(b) for a, b in v) / len(v) for k, v in tdq.ev.items()}
+        dq_leg = {"value": n_dq / dt_dq, "unit": "frames/s", "ms_per_picture": dt_dq / n_dq * 1e3, "pictures_timed": n_dq,
+                  "resi_stage_ms": {k.split("/")[1]: round(v, 4) for k, v in g_dq.items() if k.startswith("resi/")},
+                  "last_picture_md5": shard.picture_hash(o_dq["final"]),
+                  "what": "the same per-picture workload with the quantiser of the shipped cfgs: residual -> vvcgpu_tr_fwd_batch -> vvcgpu_depquant_batch (DepQuant::quant, "
+                          "eight seeded rate tables, lambda of the QP) -> vvcgpu_dequant_tr_inv_batch (dep_quant = 1) -> reconstruction, in place of the one-pass chain with "
+                          "Quant::quant; parity of this leg: tests/test_gpu_workload.py::test_workload_depquant_leg_matches_oracle_416x240.  Reported beside `value`, never as it"}
+        del wl_dq, st_dq, o_dq
+        torch.cuda.empty_cache()
+
     # final gather of per-picture output hashes (control path, outside the timed region)
     hashes = shard.gather_hashes({"rank%d" % rank: shard.picture_hash(out["final"])}, world)
 
@@ -606,6 +636,7 @@ def main():
                 "what": "the same steps with, per picture, one original picture AND the picture's side information (PU / TU descriptor lists, deblocking edge / QP "
                         "maps, SAO parameters, ALF switches) uploaded from pinned host memory on a copy stream inside the timed region (double-buffered through the "
                         "input sets); `value` above has the inputs resident, as the contract asks"}),
+            "with_depquant": dq_leg,
             "picture_hashes": {"gathered": len(hashes), "rank0_first_picture_md5": first_md5, "rank0_last_picture_md5": hashes.get("rank0")},
             "stage_ms": {k: round(v, 4) for k, v in stage_ms.items()},
             "serial_kernel_ms_per_picture": round(sum(stage_ms.values()), 4),

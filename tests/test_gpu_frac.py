@@ -97,3 +97,39 @@ def test_frac_refine_bipred_original(w, h, kind):
     oracle().orc_frac_refine(p(org), W, p(ref), W + 2 * M, p(blk), nb, w, h, bd, 0, mx, 1, C.byref(mv), p(want))
     got = ops.frac_refine(dev(org), dev(ref), ops.struct_to_device(blk), nb, w, h, bd, mv, True, (0, mx)).cpu().numpy().view(ops.FRAC_RESULT)
     assert np.array_equal(got, want)
+
+
+@pytest.mark.parametrize("bd,kind", [(10, "smooth"), (10, "extreme"), (8, "uniform"), (10, "wild")])
+def test_frac16_every_alignment(bd, kind):
+    """The matrix-core refinement of 16x16 PUs (frac16m_kernel) reads ALIGNED 16-byte words and selects its Toeplitz table row by the window's
+    start inside them: every start (reference x mod 16, y mod 4) x every original x mod 8, 512 PUs of one launch, each with its 9 half- and
+    9 quarter-sample Hadamard candidates.  'wild': reference samples outside the bit depth -- those PUs are flagged and served
+    by the vector-pipe body."""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(bd * 7 + len(kind))
+    mx = (1 << bd) - 1
+    W, H, M, w, h = 320, 192, 16, 16, 16
+    ref = cases.rand_plane(rng, H + 2 * M, W + 2 * M, bd, "smooth" if kind == "wild" else kind).astype(np.int32)
+    if kind == "wild":
+        m = rng.random(ref.shape) < 0.001
+        ref[m] = rng.choice(np.array([-9, -1, mx + 1, mx + 70]), int(m.sum()))
+    ref = ref.astype(np.int16)
+    org = np.clip(ref[M + 1:M + 1 + H, M + 2:M + 2 + W].astype(np.int32), 0, mx) + rng.integers(-6, 7, (H, W))
+    org = np.ascontiguousarray(np.clip(org, 0, mx).astype(np.int16))
+    rows = []
+    for ax in range(16):
+        for ay in range(4):
+            for ox in range(8):
+                x = 16 * int(rng.integers(1, (W - w) // 16 - 1)) + ox
+                y = int(rng.integers(0, H - h + 1))
+                rx = 16 * int(rng.integers(1, (W - w) // 16 - 1)) + ax + M
+                ry = 4 * int(rng.integers(1, (H - h) // 4 - 1)) + ay + M
+                rows.append((x, y, rx, ry, rx - M - x, ry - M - y))
+    blk = np.array(rows, ops.FRAC_BLK)
+    nb = len(blk)
+    mv = ops.MvCost(7.5, 3, -5, 0, 0)
+    want = np.zeros(nb, ops.FRAC_RESULT)
+    oracle().orc_frac_refine(p(org), W, p(ref), W + 2 * M, p(blk), nb, w, h, bd, 0, mx, 1, C.byref(mv), p(want))
+    got = ops.frac_refine(dev(org), dev(ref), ops.struct_to_device(blk), nb, w, h, bd, mv, True, (0, mx)).cpu().numpy().view(ops.FRAC_RESULT)
+    bad = np.nonzero(got != want)[0]
+    assert bad.size == 0, (bad.size, bad[:5], got[bad[:3]], want[bad[:3]])

@@ -90,6 +90,83 @@ def test_mc_batch(bd, kind, W, doff0):                                          
     assert np.array_equal(got.cpu().numpy(), want)
 
 
+def _wild_plane(rng, h, w, bd, kind):
+    """`kind` content with a sprinkle of samples OUTSIDE the bit depth (negative / above the maximum: what a caller may hand in and the reference
+    filters as it finds it): the matrix-core kernel must flag such PUs for the vector-pipe body -- also a bad PU beside a good one in a chroma pair"""
+    mx = (1 << bd) - 1
+    a = cases.rand_plane(rng, h, w, bd, kind).astype(np.int32)
+    m = rng.random((h, w)) < 0.0008
+    a[m] = rng.choice(np.array([-37, -1, mx + 1, mx + 40, 3 * mx]), int(m.sum()))
+    return a.astype(np.int16)
+
+
+@pytest.mark.parametrize("bd", [8, 10])
+@pytest.mark.parametrize("kind,W,clip", [("extreme", 384, None), ("smooth", 384, (19, -23)), ("wild", 392, None), ("uniform", 388, None)])
+def test_mc_every_phase(bd, kind, W, clip):
+    """EVERY fractional phase pair through vvcgpu_mc_batch on the two shapes of the matrix-core kernel (VERDICT r5 W1 / ADVICE r5): 16x16 luma x
+    all 16 x 16 phases and 8x8 chroma x all 32 x 32, uni- and bi-predictive (the second reference's phases sweep as well, a quarter / eighth phase
+    beside a quarter / eighth phase so the bi path of the matrix cores runs), i.e. every Toeplitz table of mm_build_tables_kernel incl. the rounded
+    horizontal-only branch, and every other phase on the vector pipe behind it.  Shuffled, so chroma pairs differ in phase and bi; odd count
+    (a trailing single chroma PU); W = 388: reference rows that do not keep 16-byte alignment (the flag -1 path); 'wild': samples outside the
+    bit depth; a clipping range inside the sample range."""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(1000 * bd + W)
+    mx = (1 << bd) - 1
+    H, M = 200, 8
+    mk = (lambda: _wild_plane(rng, H, W, bd, "smooth")) if kind == "wild" else (lambda: cases.rand_plane(rng, H, W, bd, kind))
+    r0, r1 = mk(), mk()
+    rows = []
+    for (w, luma, nf, q) in [(16, 1, 16, 4), (8, 0, 32, 4)]:
+        for fx in range(nf):
+            for fy in range(nf):
+                for bi in (0, 1):
+                    x0, y0 = int(rng.integers(M, W - w - M)), int(rng.integers(M, H - w - M))
+                    x1, y1 = int(rng.integers(M, W - w - M)), int(rng.integers(M, H - w - M))
+                    fx1, fy1 = (fx + q * int(rng.integers(0, nf // q))) % nf, (fy + q * int(rng.integers(0, nf // q))) % nf
+                    rows.append([y0 * W + x0, y1 * W + x1, 0, W, W, w, w, w, fx, fy, fx1, fy1, luma, bi, 0])
+    rows.append(rows[700][:])                                             # odd count
+    order = rng.permutation(len(rows))
+    doff = 3
+    out = []
+    for k in order:
+        r = rows[k]; r[2] = doff; doff += r[6] * r[7]; out.append(tuple(r))
+    d = np.array(out, dtype=ops.MC_DESC)
+    assert len(d) % 2 == 1
+    lo, hi = (0, mx) if clip is None else (clip[0], mx + clip[1])
+    want = np.full(doff, -5, np.int16)
+    oracle().orc_mc_batch(p(r0), p(r1), p(want), p(d), len(d), bd, lo, hi)
+    got = torch.full((doff,), -5, dtype=torch.int16, device="cuda")
+    ops.mc_batch(dev(r0), dev(r1), got, ops.struct_to_device(d), len(d), bd, (lo, hi))
+    got = got.cpu().numpy()
+    if not np.array_equal(got, want):
+        bad = [i for i, r in enumerate(d) if not np.array_equal(got[r["dst_off"]:r["dst_off"] + r["w"] * r["h"]], want[r["dst_off"]:r["dst_off"] + r["w"] * r["h"]])]
+        raise AssertionError("%d of %d PUs differ, first: %s" % (len(bad), len(d), [tuple(d[i]) for i in bad[:4]]))
+
+
+@pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 9])
+def test_mc_batch_few_pus(n):
+    """with n <= 4 PUs of the matrix-core shapes the one-launch form had an empty grid (cdiv(n, 4) & ~1 == 0) and nothing was written"""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(n)
+    bd, mx, W, H, M = 10, 1023, 256, 96, 8
+    r0, r1 = cases.rand_plane(rng, H, W, bd, "smooth"), cases.rand_plane(rng, H, W, bd, "uniform")
+    for shapes in ([(16, 1)], [(8, 0)], [(16, 1), (8, 0)]):
+        rows, doff = [], 0
+        for i in range(n):
+            w, luma = shapes[i % len(shapes)]
+            q = 4
+            x0, y0, x1, y1 = [int(v) for v in rng.integers(M, H - 16 - M, 4)]
+            rows.append((y0 * W + x0, y1 * W + x1, doff, W, W, w, w, w, q * int(rng.integers(0, 4)), q * int(rng.integers(0, 4)), q * int(rng.integers(0, 4)),
+                         q * int(rng.integers(0, 4)), luma, i & 1, 0))
+            doff += w * w
+        d = np.array(rows, dtype=ops.MC_DESC)
+        want = np.full(doff, -5, np.int16)
+        oracle().orc_mc_batch(p(r0), p(r1), p(want), p(d), len(d), bd, 0, mx)
+        got = torch.full((doff,), -5, dtype=torch.int16, device="cuda")
+        ops.mc_batch(dev(r0), dev(r1), got, ops.struct_to_device(d), len(d), bd, (0, mx))
+        assert np.array_equal(got.cpu().numpy(), want), shapes
+
+
 def test_mc_batch_long_mixed_list():
     """a list long enough that a wavefront of the generic kernel looks at several descriptors at a time (n > 8192: chunks of 2 .. 64), with the fast
     kernel's shapes (16x16 luma, 8x8 chroma) and everything else mixed at random: every PU is served exactly once, by the right kernel"""

@@ -158,6 +158,43 @@ def test_me_batch_chain(w, h, had):
         assert gf[i] == res[0], (i, gf[i], res[0])
 
 
+def test_me_batch_chain_long_list_with_flagged_pus():
+    """vvcgpu_me_batch keeps the refinement's block list in per-stream scratch and the refinement launch took its flag array from the
+    SAME scratch (flags[0..n) over the first 4 n bytes of the blocks).  A list far beyond one wave of workgroups (n = 6000 > 4096) whose PUs in the
+    right half of the picture have bi-predictive originals (2 org - otherPred, outside the bit depth -> flagged for the vector-pipe body): every
+    block's coordinates must survive until its workgroup reads them."""
+    import ctypes as C
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(6000)
+    W, H, M, bd, w, h = 512, 320, 160, 10, 16, 16
+    org, ref_ = cases.tz_planes(rng, W, H, M, bd, motion=(3, 2))
+    o32 = org.astype(np.int32)
+    o32[:, W // 2:] = 2 * o32[:, W // 2:] - cases.rand_plane(rng, H, W - W // 2, bd, "uniform")
+    org = np.ascontiguousarray(o32.astype(np.int16))
+    n = 6000
+    pus = cases.tz_pus(rng, n, W, H, M, [(w, h)], flags_choices=(0, 1), spread=8)
+    cfg = cases.tz_cfg(W, H, M, 9.5, search_range=32)
+    for rep in range(2):                                                 # the second call finds the scratch already large enough (no growth)
+        best, frac = ops.me_batch(dev(org), dev(ref_), ops.struct_to_device(pus), n, w, h, cfg, bd, use_hadamard=True)
+        torch.cuda.synchronize()
+    gb, gf = best.cpu().numpy().view(cases.BEST), frac.cpu().numpy().view(ops.FRAC_RESULT)
+    wb = run_oracle(org, ref_, pus, cfg)
+    assert np.array_equal(gb, wb)
+    blk = np.zeros(n, ops.FRAC_BLK)
+    blk["org_x"], blk["org_y"] = pus["org_x"], pus["org_y"]
+    blk["ref_x"], blk["ref_y"] = pus["ref_x"] + wb["x"], pus["ref_y"] + wb["y"]
+    blk["mv_x"], blk["mv_y"] = wb["x"], wb["y"]
+    O = oracle()
+    res = np.zeros(1, ops.FRAC_RESULT)
+    nflag = 0
+    for i in range(n):
+        m = ops.MvCost(9.5, int(pus["pred_hor"][i]), int(pus["pred_ver"][i]), 0, 0)
+        O.orc_frac_refine(p(org), W, p(ref_), ref_.shape[1], p(blk[i:i + 1]), 1, w, h, bd, 0, (1 << bd) - 1, 1, C.byref(m), p(res))
+        assert gf[i] == res[0], (i, gf[i], res[0])
+        nflag += int(pus["org_x"][i] + w > W // 2)
+    assert nflag > 1000
+
+
 def test_imv_refine_golden_and_oracle():
     """AMVR integer refinement (vvcgpu_imv_refine_batch): golden vectors of the reference's xPatternSearchIntRefine, then random
     PUs (all shapes, both resolutions, SATD / SAD, weights, equal candidates, one candidate) against the oracle."""

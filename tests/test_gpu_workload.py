@@ -44,6 +44,23 @@ def test_workload_matches_oracle_416x240():
         _cmp(k + "#2", gout2[k], cout[k])
 
 
+def test_workload_depquant_leg_matches_oracle_416x240():
+    """bench.py's `with_depquant` leg (VERDICT r5 item 5a): the same picture with the shipped configurations' quantiser -- DepQuant::quant per TU
+    (vvcgpu_depquant_batch, seeded rate tables) and the de-quantiser in its dependent-quantisation form -- against the oracle's DepQuant
+    restatement TU by TU, every output of the picture (levels, abs sums, reconstruction, in-loop chain)"""
+    from vvcsoftware_vtm_amd.workload import Workload
+    wl = Workload(416, 240, 10, seed=11, raster_range=40, depquant=True)
+    assert wl.depquant and not wl.fused_resi and int(wl.dqtr["dep_quant"].min()) == 1
+    _, gout = wl.run_gpu()
+    torch.cuda.synchronize()
+    cout, _ = run_cpu(wl, oracle(), "port")
+    for k in ("abs_sum", "coef", "final", "cls"):
+        _cmp(k, gout[k], cout[k])
+    base = Workload(416, 240, 10, seed=11, raster_range=40)
+    _, gb = base.run_gpu()
+    assert not torch.equal(gb["coef"], gout["coef"])          # (the trellis is not the stand-in quantiser: the leg measures something else)
+
+
 def test_workload_per_size_searches_match_oracle():
     """the integer ME as six per-size searches (hier_me=False: vvcgpu_sad_search per block size and grid) gives the records the hierarchical
     launch of the default workload gives, and both equal the oracle"""

@@ -64,7 +64,21 @@ def run_cpu(wl, lib, kind="port"):
     else:
         timed("resi", lambda: port.orc_tr_fwd_batch(P(resi), P(coef), P(wl.tr), wl.tr.size, bd))
     level, dqcoef, abs_sum = np.zeros(wl.n_coef, np.int32), np.zeros(wl.n_coef, np.int32), np.zeros(wl.tr.size, np.uint32)
-    if refl is not None:
+    if getattr(wl, "depquant", False):
+        # the `with_depquant` leg: DepQuant::quant TU by TU (restatement; orc_depquant is pinned by tests/golden/depquant.npz), then the de-quantiser in its
+        # dependent-quantisation form (dqtr.dep_quant = 1)
+        port.orc_depquant.restype = C.c_uint32
+
+        def dq_all():
+            for i in range(wl.tr.size):
+                d = wl.dq[i]
+                n = int(d["w"]) * int(d["h"])
+                off = int(d["coeff_off"])
+                abs_sum[i] = port.orc_depquant(P(coef[off:off + n]), P(level[off:off + n]), int(d["w"]), int(d["h"]), int(d["luma"]), bd, int(d["qp"]),
+                                               C.c_double(float(d["lambda"])), C.c_void_p(wl.dq_rates.ctypes.data + int(d["rates_idx"]) * wl.dq_rates.dtype.itemsize))
+        timed("resi", dq_all)
+        timed("resi", lambda: port.orc_dequant_tr_inv_batch(P(level), P(resi2), P(wl.dqtr), wl.tr.size, bd, P(dqcoef)))
+    elif refl is not None:
         timed("resi", lambda: refl.vtmref_quant_batch(P(coef), P(level), P(wl.quant), wl.tr.size, bd, P(abs_sum)))
         timed("resi", lambda: refl.vtmref_dequant_tr_inv_batch(P(level), P(resi2), P(wl.dqtr), wl.tr.size, bd, P(dqcoef)))
     else:

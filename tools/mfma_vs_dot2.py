@@ -7,7 +7,7 @@ Every luma sample of a 3840x2160 picture is covered by square TUs of ONE size N;
   mfma : vvcgpu_resi_chain_batch (resichain.hip: v_mfma_f32_16x16x32_f16 with 8-bit limb splitting) -- subtract, forward transform, Quant::quant
          with sign hiding, Quant::dequant, inverse transform and reconstruction, i.e. MORE work than the dot2 leg
 Second table (round 3): the STANDALONE entries with their own matrix-core kernels (transform.hip tr_fwd_mfma_kernel / tr_inv_mfma_kernel, stages
-of mfma_tr.h) against the dot2 kernels (VVCGPU_TR_NO_MFMA=1, read per call), squares and rectangles; the coefficients and the residual of the two
+of mfma_tr.h) against the dot2 kernels (VVCGPU_NO_MFMA=1, read per call), squares and rectangles; the coefficients and the residual of the two
 forms are compared before timing.
 Results of the transforms are covered by tests/test_gpu_resichain.py / test_gpu_transform.py (bit-exact against the oracle).
 
@@ -73,7 +73,7 @@ def standalone():
     rng = np.random.default_rng(9)
     resi = torch.from_numpy(rng.integers(-300, 301, (H, W), dtype=np.int16)).cuda()
     print()
-    print("standalone vvcgpu_tr_fwd_batch / vvcgpu_tr_inv_batch: matrix-core kernels against the dot2 kernels (same entry point, VVCGPU_TR_NO_MFMA=1)")
+    print("standalone vvcgpu_tr_fwd_batch / vvcgpu_tr_inv_batch: matrix-core kernels against the dot2 kernels (same entry point, VVCGPU_NO_MFMA=1)")
     print("%7s %8s | %10s %10s %6s | %10s %10s %6s | %s" % ("W x H", "TUs", "fwd dot2", "fwd mfma", "x", "inv dot2", "inv mfma", "x", "results"))
     for (w, h) in ((64, 64), (32, 32), (64, 32), (32, 64), (64, 16), (16, 64), (32, 16), (16, 32)):
         ys, xs = np.meshgrid(np.arange(0, H - h + 1, h), np.arange(0, W, w), indexing="ij")
@@ -87,9 +87,9 @@ def standalone():
         t = {}
         for form in ("dot2", "mfma"):
             if form == "dot2":
-                os.environ["VVCGPU_TR_NO_MFMA"] = "1"
+                os.environ["VVCGPU_NO_MFMA"] = "1"
             else:
-                os.environ.pop("VVCGPU_TR_NO_MFMA", None)
+                os.environ.pop("VVCGPU_NO_MFMA", None)
             coef = torch.full((H * W,), 7, dtype=torch.int32, device="cuda")
             back = torch.full((H, W), 7, dtype=torch.int16, device="cuda")
             t[form] = (timed(lambda: ops.tr_fwd_batch(resi, coef, dtr, k, BD)), timed(lambda: ops.tr_inv_batch(coef, back, dtr, k, BD)))

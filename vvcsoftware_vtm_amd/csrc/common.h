@@ -13,7 +13,17 @@ typedef int32_t TCoeff;
 void vvcgpu_set_error(const char* fmt, ...);
 // Library-internal device scratch, cached per (device, stream): work on one stream is ordered, so the buffer of the previous
 // call on that stream is free again when the next call's kernels start.  Grow-only; returns nullptr (error text set) on failure.
-void* vvcgpu_scratch(hipStream_t stream, size_t bytes);
+// ONE call of an entry point may take each REGION once: an entry point that sizes its own workspace uses VVC_SCRATCH_ENTRY (vvcgpu_scratch), a
+// launch helper that other entry points call with their workspace still live (vvcgpu_frac_refine_launch under vvcgpu_me_batch,
+// vvcgpu_mc_batch_impl under the affine entry points) uses VVC_SCRATCH_HELPER -- two requests for the same region on one call path alias.
+enum { VVC_SCRATCH_ENTRY = 0, VVC_SCRATCH_HELPER = 1, VVC_SCRATCH_REGIONS = 2 };
+void* vvcgpu_scratch(hipStream_t stream, size_t bytes);                      // region VVC_SCRATCH_ENTRY
+void* vvcgpu_scratch_region(hipStream_t stream, int region, size_t bytes);
+// The ONE behaviour switch of the library (read per call): VVCGPU_NO_MFMA=1 keeps the interpolation filters, the Hadamard refinement and the
+// transforms off the matrix cores (the vector-pipe bodies that otherwise serve flagged PUs / TUs take everything) -- tests/test_gpu_no_mfma.py runs the
+// parity cases of those bodies under it.  Every other environment variable the library reads is a measurement aid (VVCGPU_*_DIAG: cycle stamps to
+// stderr) or a test hook (VVCGPU_MH_WGS: number of persistent workgroups of the hierarchical search).
+int vvcgpu_no_mfma(void);
 int vvcgpu_cu_count(void);                         // compute units of the current device (queried once per device; 256 if the query fails)
 constexpr int VVC_CTR_INTS = 32;                       // ints per counter set of vvcgpu_counters
 int* vvcgpu_counters(hipStream_t stream, int* cur);     // two persistent zeroed work counters per (device, stream), see lib.hip
@@ -60,8 +70,7 @@ int vvcgpu_tr_tables(VvcTrTables* out);
 // A picture pass whose neighbouring tiles share halo lines gives every XCD one CONTIGUOUS run of the logical tile indices, so that a 128-byte
 // line is fetched from the fabric by one L2 instead of by up to three (profiles/r03_fabric_requests.csv: the picture passes read 1.6 - 3.1 x
 // their planes, every request a whole 128-byte line).  Launch vvc_xcd_grid(total) workgroups; padding workgroups get -1 and leave.
-// VVCGPU_NO_XCD_ORDER=1 (read per call) keeps the plain order: A/B switch.
-static inline int vvc_xcd_on() { return getenv("VVCGPU_NO_XCD_ORDER") ? 0 : 1; }
+static inline int vvc_xcd_on() { return 1; }
 static inline int vvc_xcd_grid(int total, int on) { return on ? ((total + 7) >> 3) << 3 : total; }
 // two index ranges [0, nA) and [nA, total) (luma tiles, then chroma tiles), each spread over the XCDs on its own: the heavy and the light part of a
 // launch both reach every XCD

@@ -1551,9 +1551,7 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
   VVC_CHECK_ARG(nx > 0 && ny > 0 && sx > 0 && sy > 0, "sad_search: bad position grid");
   VVC_CHECK_ARG((best == nullptr) == (mvcost_host == nullptr), "sad_search: best and mvcost must be given together");
   hipStream_t st0 = (hipStream_t)stream;
-  static const int denseOff = getenv("VVCGPU_NO_DENSE") ? 1 : 0;          // A/B timing switch
-  static const int d9Off = getenv("VVCGPU_NO_D9") ? 1 : 0;                // A/B timing switch: 9 x 9 grids through sad_dense_kernel
-  if (!denseOff && !d9Off && sx == 1 && sy == 1 && nx == 9 && ny == 9 && sub_shift == 1 && (w & 15) == 0 && (h & 15) == 0 && w <= 64 && h <= 64 &&
+  if (sx == 1 && sy == 1 && nx == 9 && ny == 9 && sub_shift == 1 && (w & 15) == 0 && (h & 15) == 0 && w <= 64 && h <= 64 &&
       (ref_stride & 3) == 0 && (!best || (mvcost_host->lambda >= 0.0 && mvcost_host->lambda < 1.0e9)))
   {
     const int tilesX = w >> 4, upb = tilesX * (h >> 4);
@@ -1561,9 +1559,7 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
     // Workgroup size.  Measured (profiles/r02_dense9.txt): the staging is bound by memory-level parallelism (87 % of the L2 requests miss, ~1.2 TB/s of
     // scattered 128-byte lines whatever the kernel does), so several small workgroups in different phases beat one large one: 128 threads = 14 units.
     // 64 x 64 blocks (16 units each) would need 320 threads for two blocks and lose; they stay with sad_dense_kernel.
-    static const int tEnv = getenv("VVCGPU_D9_T") ? atoi(getenv("VVCGPU_D9_T")) : 0;   // experiment: workgroup size
-    int T = 128, G = upb <= 4 ? (128 / 9) / upb : 0;
-    if (tEnv >= 64 && tEnv <= 384 && (tEnv & 63) == 0 && (tEnv / 9) / upb > 0) { T = tEnv; G = (tEnv / 9) / upb; }
+    const int T = 128, G = upb <= 4 ? (128 / 9) / upb : 0;
     if (G > 0)
     {
       const int U = G * upb;
@@ -1572,15 +1568,13 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       if (best) mv = *mvcost_host;
       if (smem > 48 * 1024)
         VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(sad_dense9_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
-      static const int trace = getenv("VVCGPU_TRACE_PATH") ? 1 : 0;
-      if (trace) fprintf(stderr, "[vvcgpu] sad_search %dx%d 9x9: row form, %d threads, %d blocks per workgroup, %zu B LDS\n", w, h, T, G, smem);
       hipLaunchKernelGGL(sad_dense9_kernel, dim3(cdiv(nblocks, G)), dim3(T), smem, st0, org, org_stride, ref, ref_stride, blocks, nblocks, tilesX, upb, G,
                          dx0, dy0, mv, best ? 1 : 0, sad_out, best);
       VVC_LAUNCH_CHECK();
       return VVCGPU_OK;
     }
   }
-  if (!denseOff && sx == 1 && sy == 1 && nx * ny <= 256 && w >= 8 && w <= 128 && (w & (w - 1)) == 0 && (ref_stride & 1) == 0 &&
+  if (sx == 1 && sy == 1 && nx * ny <= 256 && w >= 8 && w <= 128 && (w & (w - 1)) == 0 && (ref_stride & 1) == 0 &&
       ((uintptr_t)ref & 3) == 0)
   {
     const int npos = nx * ny, hsD = h >> sub_shift, wp = w >> 1;
@@ -1605,16 +1599,11 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       return VVCGPU_OK;
     }
   }
-  static const int r5cOff = getenv("VVCGPU_NO_R5C") ? 1 : 0;              // A/B timing switch
-  static const int r5gOff = getenv("VVCGPU_NO_R5G") ? 1 : 0;              // A/B timing switch: 16-wide blocks through the per-block r5c form
-  if (!r5cOff && !r5gOff && sx == 5 && sy == 5 && w == 16 && (org_stride & 1) == 0 && (ref_stride & 7) == 0 &&
+  if (sx == 5 && sy == 5 && w == 16 && (org_stride & 1) == 0 && (ref_stride & 7) == 0 &&
       ((uintptr_t)org & 3) == 0 && ((uintptr_t)ref & 15) == 0 && (long long)nx * ny < (1 << 24) && nx >= 1 &&
       best && !sad_out && nx <= 40 && mvcost_host->lambda >= 0.0 && mvcost_host->lambda < 8.0e6)   // 32-bit cost: SAD < 2^27, lambda * bits < 2^30
   {
-    static const int nbgEnv = getenv("VVCGPU_R5G_NB") ? atoi(getenv("VVCGPU_R5G_NB")) : R5G_MAXNB;
-    static const int rpsEnv = getenv("VVCGPU_R5G_RPS") ? atoi(getenv("VVCGPU_R5G_RPS")) : 0;
-    static const int budgetKB = getenv("VVCGPU_R5G_KB") ? atoi(getenv("VVCGPU_R5G_KB")) : 50;
-    const int nbg = nbgEnv < 1 ? 1 : nbgEnv > R5G_MAXNB ? R5G_MAXNB : nbgEnv;
+    constexpr int nbg = R5G_MAXNB, budgetKB = 50;                          // blocks per group, window budget (swept in round 3: docs/OPTIMISATION_LOG.md)
     const int hsR = h >> sub_shift;
     const int Ww = (nx - 1) * 5 + 16 * nbg;
     int pitch = (((Ww - 1 + 7) >> 3) + 1) * 4;
@@ -1622,15 +1611,13 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
     auto win_bytes = [&](int rps) { return (size_t)((rps - 1) * 5 + h) * pitch * 4 + 64; };
     int rps = 6;                                                           // whole row groups (6 raster rows) per strip, as many as the budget allows
     while (rps + 6 <= ny + 5 && rps + 6 <= 24 && win_bytes(rps + 6) <= (size_t)budgetKB * 1024) rps += 6;
-    if (rpsEnv > 0) rps = cdiv(rpsEnv, 3) * 3;
     if (rps >= ny) rps = cdiv(ny, 3) * 3;
     const int nstrips = cdiv(ny, rps);
     const size_t winB = win_bytes(rps), smem = winB + (((size_t)nx + rps + 15) & ~(size_t)15) + R5C_COST_N * sizeof(unsigned);
     const int ngroups = cdiv(nblocks, nbg);
     if (smem <= 150 * 1024 && (hsR & 1) == 0 && hsR >= 2 && nx + rps <= 4096 && (unsigned long long)ngroups * nstrips * nstrips < (1ull << 32))
     {
-      static const int gqOff = getenv("VVCGPU_NO_R5GQ") ? 1 : 0;           // A/B timing switch: pair columns (r5g) instead of quad columns (r5gq)
-      const bool gq = !gqOff && mvcost_host->lambda < 4.0e6;                // cost << 2 | candidate in 32 bits: lambda * bits < 2^29
+      const bool gq = mvcost_host->lambda < 4.0e6;                          // quad columns: cost << 2 | candidate in 32 bits needs lambda * bits < 2^29; pair columns (r5g) otherwise
       const int units = gq ? cdiv(rps, 6) * cdiv(nbg, 2) : 2 * cdiv(rps, 6) * cdiv(nbg, 4);
       const int threads = 64 * units;                                     // one wave per unit (<= 16: rps <= 24, nbg <= 8)
       const int total = ngroups * nstrips;
@@ -1661,10 +1648,10 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       return VVCGPU_OK;
     }
   }
-  if (!r5cOff && sx == 5 && sy == 5 && (w == 16 || w == 32 || w == 64 || w == 128) && (org_stride & 1) == 0 && (ref_stride & 7) == 0 &&
+  if (sx == 5 && sy == 5 && (w == 16 || w == 32 || w == 64 || w == 128) && (org_stride & 1) == 0 && (ref_stride & 7) == 0 &&
       ((uintptr_t)org & 3) == 0 && ((uintptr_t)ref & 15) == 0 && (long long)nx * ny < (1 << 24) && nx >= 1)
   {
-    static const int budgetKB = getenv("VVCGPU_R5C_KB") ? atoi(getenv("VVCGPU_R5C_KB")) : 78;
+    constexpr int budgetKB = 78;
     const int hsR = h >> sub_shift, chunks = w >> 4;
     const int Ww = (nx - 1) * 5 + w;
     int pitch = (((Ww - 1 + 7) >> 3) + 1) * 4;                             // whole 16-byte quads of the widest row
@@ -1677,17 +1664,8 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       rps = cdiv(cdiv(ny, nstrips), 3) * 3;
       if (win_bytes(rps) <= budget || rps <= 3) break;
     }
-    static const int splitOff = getenv("VVCGPU_R5C_NOSPLIT") ? 1 : 0;          // A/B timing switches
-    static const int split32On = getenv("VVCGPU_R5C_SPLIT32") ? 1 : 0;
-    // experiment: strips of at most 18 raster rows give at most 6 wave items, which the two-waves-per-item form of the kernel
-    // turns into 12 waves per workgroup (6 per SIMD with two workgroups per CU)
-    // (measured: 32-wide blocks lose more to the extra window rows than they gain, 0.315 vs 0.292 ms at 4K -- off by default)
-    if (!splitOff && split32On && chunks >= 2 && rps > 18 && nx <= 40)
-      rps = cdiv(cdiv(ny, cdiv(ny, 18)), 3) * 3;
-    // (measured: choosing the strip height for the fewest six-row groups -- 39 rows of 64-wide blocks as 12 + 12 + 12 + 3, 7 groups instead
-    // of the 8 of 15 + 15 + 9 -- loses: 201 vs 185 us, a fourth strip's staging and 8 instead of 12 waves per workgroup)
-    static const int rpsEnvC = getenv("VVCGPU_R5C_RPS") ? atoi(getenv("VVCGPU_R5C_RPS")) : 0;   // experiment: strip height
-    if (rpsEnvC >= 3 && (rpsEnvC % 3) == 0 && win_bytes(rpsEnvC) <= budget) rps = rpsEnvC;
+    // (measured and not kept: strips of at most 18 raster rows for 32-wide blocks, 0.315 vs 0.292 ms at 4K; strip heights chosen for the fewest
+    // six-row groups, 201 vs 185 us -- docs/OPTIMISATION_LOG.md)
     nstrips = cdiv(ny, rps);
     const size_t winB = win_bytes(rps), smem = winB + (((size_t)nx + rps + 15) & ~(size_t)15) + R5C_COST_N * sizeof(unsigned long long);
     if (smem <= 150 * 1024 && ((hsR * chunks) & 1) == 0 && nx + rps <= 4096 &&
@@ -1695,10 +1673,8 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
     {
       // quad form (four columns per lane): items are row groups only; the block's chunk-rows are split over 1 / 2 / 4 waves so that a
       // workgroup has 8 - 12 waves
-      static const int r5qOff = getenv("VVCGPU_NO_R5Q") ? 1 : 0;              // A/B timing switch
-      static const int r5qSplit = getenv("VVCGPU_R5Q_SPLIT") ? atoi(getenv("VVCGPU_R5Q_SPLIT")) : 0;
-      static const int r5qTouch = getenv("VVCGPU_R5Q_NOTOUCH") ? 0 : 2;
-      if (!r5qOff && nx <= 40)
+      constexpr int r5qTouch = 2;
+      if (nx <= 40)
       {
         // A wave item is a group of SIX raster rows: 15 + 15 + 9 rows are 3 + 3 + 2 groups for 6.5 groups of work.  When whole groups per
         // strip with the remainder in the LAST strip give fewer groups in no more strips and the same window (39 rows of 64-wide blocks:
@@ -1720,7 +1696,6 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
         const int itemsQ = cdiv(maxRowsQ, 6), nSt = hsR * chunks;
         int splitQ = 1;
         while (splitQ < 8 && itemsQ * splitQ * 2 <= 12 && (nSt % (splitQ * 2)) == 0 && nSt / (splitQ * 2) >= 8) splitQ *= 2;
-        if ((r5qSplit == 1 || r5qSplit == 2 || r5qSplit == 4 || r5qSplit == 8) && (nSt % r5qSplit) == 0 && itemsQ * r5qSplit <= 16) splitQ = r5qSplit;
         const int threadsQ = itemsQ * splitQ * 64;
         const int totalQ = nblocks * nstripsQ;
         const size_t packedDwQ = (size_t)nblocks * 2 * hsR * (w >> 1);
@@ -1751,7 +1726,7 @@ int vvcgpu_sad_search(const vvc_pel* org, int org_stride, const vvc_pel* ref, in
       }
       const int items = 2 * cdiv(rps, 6);
       // wide blocks, few items per strip: two waves per item (see the kernel) -- one item per wave, at most 12 waves
-      const int split = (!splitOff && chunks >= 2 && items <= 6 && nx <= 40 && (((hsR * chunks) >> 1) & 1) == 0) ? 2 : 1;
+      const int split = (chunks >= 2 && items <= 6 && nx <= 40 && (((hsR * chunks) >> 1) & 1) == 0) ? 2 : 1;
       const int threads = split == 2 ? items * 2 * 64 : (items >= 8 ? 512 : items * 64);
       const int total = nblocks * nstrips;
       const size_t packedDw = (size_t)nblocks * 2 * hsR * (w >> 1);
@@ -1885,8 +1860,7 @@ int vvcgpu_raster_per_block_launch(const vvc_pel* org, int org_stride, const vvc
   const int Ww = (nx_max - 1) * 5 + w;
   int pitch = (((Ww - 1 + 7) >> 3) + 1) * 4;
   while ((pitch & 63) != 20 && (pitch & 63) != 44) pitch += 4;
-  static const int kbEnv = getenv("VVCGPU_TZ_RASTER_KB") ? atoi(getenv("VVCGPU_TZ_RASTER_KB")) : 0;   // experiment: window budget
-  const size_t budget = (size_t)(kbEnv > 0 ? kbEnv : 78) * 1024;
+  const size_t budget = (size_t)78 * 1024;
   auto win_bytes = [&](int rps) { return (size_t)((rps - 1) * 5 + h) * pitch * 4 + 64; };
   int nstrips = 1, rps = ny_max;
   for (;; nstrips++)

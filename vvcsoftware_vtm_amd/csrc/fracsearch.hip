@@ -1121,25 +1121,18 @@ int vvcgpu_frac_refine_launch(const vvc_pel* org, int org_stride, const vvc_pel*
   const size_t smem = groupBytes * groups;
   VVC_CHECK_ARG(smem <= 160 * 1024, "frac_refine: LDS need %zu too large", smem);
   hipStream_t st = (hipStream_t)stream;
-  static const int f16Off = getenv("VVCGPU_NO_FRAC16") ? 1 : 0;           // A/B timing switch
-  if (w == 16 && h == 16 && !f16Off)
+  if (w == 16 && h == 16)
   {
     const int xcd = vvc_xcd_on();
-    static const int mfmaOff = getenv("VVCGPU_NO_FRAC_MFMA") ? 1 : 0;       // A/B timing switch: the vector-pipe form for every PU
-    if (use_hadamard && !mfmaOff)
+    if (use_hadamard && !vvcgpu_no_mfma())                                  // (VVCGPU_NO_MFMA, common.h: the vector-pipe form for every PU)
     {
       const _Float16* image = fm_image(bit_depth);
       if (!image) return VVCGPU_E_DEVICE;
-      static const int wps = getenv("VVCGPU_FRAC_WPS") ? atoi(getenv("VVCGPU_FRAC_WPS")) : 4;   // waves per SIMD the kernel is built for (A/B switch)
-      const int cap = 256 * (wps == 5 ? 5 : 4);                            // that many workgroups per CU; a wave walks its PUs
+      const int cap = 256 * 4;                                             // four workgroups per CU (the kernel is built for four waves per SIMD: five spill); a wave walks its PUs
       const int nWg = cdiv(nblocks, 4) < cap ? cdiv(nblocks, 4) : cap;
-      int* flags = static_cast<int*>(vvcgpu_scratch(st, (size_t)nblocks * sizeof(int)));
+      int* flags = static_cast<int*>(vvcgpu_scratch_region(st, VVC_SCRATCH_HELPER, (size_t)nblocks * sizeof(int)));   // the caller (vvcgpu_me_batch) holds blocks / preds in the entry region
       if (!flags) return VVCGPU_E_DEVICE;
-      if (wps == 5)
-        hipLaunchKernelGGL(frac16m_kernel<5>, dim3(vvc_xcd_grid(nWg, xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
-                           bit_depth, clp_min, clp_max, *mvcost_host, preds, results, image, flags, nWg, xcd);
-      else
-        hipLaunchKernelGGL(frac16m_kernel<4>, dim3(vvc_xcd_grid(nWg, xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
+      hipLaunchKernelGGL(frac16m_kernel<4>, dim3(vvc_xcd_grid(nWg, xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
                            bit_depth, clp_min, clp_max, *mvcost_host, preds, results, image, flags, nWg, xcd);
       hipLaunchKernelGGL(frac16_flagged_kernel, dim3(cdiv(nblocks, 256)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
                          bit_depth, clp_min, clp_max, *mvcost_host, preds, results, flags);

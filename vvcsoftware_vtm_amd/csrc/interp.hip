@@ -287,18 +287,25 @@ template <int N, int S, int G> struct McStaged
   static constexpr int NR = S + N - 1, WD = (NR + 2) / 2 + ((((NR + 2) / 2) & 1) ? 1 : 0), NL = (NR * WD + G - 1) / G;
   uint2 ld[2][NL];
   unsigned phase[2];                                                      // bit u: load u starts on an odd sample (odd strides: per row)
+  unsigned bad;                                                           // non-zero: a loaded sample lies outside the bit depth (this lane's loads)
 };
 
 // requests both windows of a PU (see mc_tile_dot2)
 template <int N, int S, int G>
 __device__ __forceinline__ void mc_stage(const vvcgpu_mc_desc& d, bool active, const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base, int gl,
-                                         McStaged<N, S, G>& st)
+                                         McStaged<N, S, G>& st, int bd)
 {
   constexpr int half = N / 2 - 1, NR = S + N - 1, WD = McStaged<N, S, G>::WD, LOADS = NR * WD;
   const int nRef = d.bi == 1 ? 2 : 1;
   auto& ld = st.ld;
   auto& phase = st.phase;
   phase[0] = phase[1] = 0u;
+  // The two-pass form narrows its first pass to 16 bits sample by sample ((s << headroom) - 8192); the reference's one-dimensional branches
+  // narrow only the filtered value.  The two agree for samples inside the bit depth; a window that holds anything else is reported here and the
+  // PU takes the sample-wise body of the generic kernel (which follows the reference branch by branch).  Whole dwords are tested, so a sample
+  // beside the window may report a PU that did not need it: speed only.
+  const unsigned outside = ~(((1u << bd) - 1u) * 0x10001u);
+  unsigned bad = 0u;
 #pragma unroll
   for (int r = 0; r < 2; r++)
   {
@@ -328,9 +335,11 @@ __device__ __forceinline__ void mc_stage(const vvcgpu_mc_desc& d, bool active, c
           phase[r] |= 1u << u;
         }
         else ld[r][u].x = a4[0];
+        bad |= (ld[r][u].x | ld[r][u].y) & outside;
       }
     }
   }
+  st.bad = bad;
 }
 
 template <int N, int S, int G>
@@ -432,7 +441,7 @@ __device__ __forceinline__ void mc_tile_dot2(const vvcgpu_mc_desc& d, bool activ
         for (int j = 0; j < 4; j++)
         {
           int v = (short)((o[j] + off2) >> shift2);
-          if (rndRes) v = clip3(cmin, cmax, v);
+          if (rndRes && (fx | fy) != 0) v = clip3(cmin, cmax, v);        // (a uni-predictive full-sample copy is not clipped: filterCopy with isFirst == isLast)
           pred[r][j] = v;
         }
       }
@@ -463,68 +472,11 @@ __device__ __forceinline__ void mc_tile_dot2(const vvcgpu_mc_desc& d, bool activ
   __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
 }
 
-// a wave takes the descriptor pair (2 w, 2 w + 1): two fast chroma PUs share the wave (one per half), fast luma PUs follow one another,
-// everything else is left to the generic kernel
 constexpr int MC_LDS_DW = 23 * 12 + 16 * 12 + 128;                       // per wave: window, transposed intermediate, output rows (luma sizes)
-__global__ __launch_bounds__(256, 6) void mc_fast_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
-                                                      Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs, int n,
-                                                      int bd, int cmin, int cmax, int nWg, int xcd)
-{
-  __shared__ __align__(16) unsigned ldsAll[4][MC_LDS_DW];
-  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
-  const int wg = vvc_xcd_index((int)blockIdx.x, nWg, xcd);           // neighbouring PUs (shared window lines) in one XCD's L2
-  if (wg < 0) return;
-  const int i0 = (wg * 4 + wave) * 2;
-  if (i0 >= n) return;
-  unsigned* L = ldsAll[wave];
-  const bool two = i0 + 1 < n;
-  const vvcgpu_mc_desc d0 = descs[i0], d1 = descs[two ? i0 + 1 : i0];
-  const bool f0 = mc_is_fast(d0.is_luma, d0.w, d0.h), f1 = two && mc_is_fast(d1.is_luma, d1.w, d1.h);
-  if (f0 && f1 && !d0.is_luma && !d1.is_luma)
-  {
-    const bool hi = lane >= 32;
-    vvcgpu_mc_desc d = d0;
-    if (hi) d = d1;
-    unsigned* Lh = L + (hi ? MC_LDS_DW / 2 : 0);
-    McStaged<4, 8, 32> st;
-    mc_stage<4, 8, 32>(d, true, ref0Base, ref1Base, lane & 31, st);
-    mc_tile_dot2<4, 8, 32>(d, true, st, dstBase, bd, cmin, cmax, lane & 31, Lh, reinterpret_cast<short*>(Lh + 11 * 6), reinterpret_cast<short*>(Lh + 11 * 6 + 8 * 6));
-    return;
-  }
-  if (f0 && f1 && d0.is_luma && d1.is_luma)
-  {
-    // both PUs' windows are requested before the first PU is computed: the second PU does not wait for memory again
-    McStaged<8, 16, 64> sa, sb;
-    mc_stage<8, 16, 64>(d0, true, ref0Base, ref1Base, lane, sa);
-    mc_stage<8, 16, 64>(d1, true, ref0Base, ref1Base, lane, sb);
-    mc_tile_dot2<8, 16, 64>(d0, true, sa, dstBase, bd, cmin, cmax, lane, L, reinterpret_cast<short*>(L + 23 * 12), reinterpret_cast<short*>(L + 23 * 12 + 16 * 12));
-    mc_tile_dot2<8, 16, 64>(d1, true, sb, dstBase, bd, cmin, cmax, lane, L, reinterpret_cast<short*>(L + 23 * 12), reinterpret_cast<short*>(L + 23 * 12 + 16 * 12));
-    return;
-  }
-#pragma unroll 1
-  for (int k = 0; k < 2; k++)
-  {
-    if (k && !two) break;
-    const vvcgpu_mc_desc& d = k ? d1 : d0;
-    if (!(k ? f1 : f0)) continue;                                        // left to the generic kernel behind this one (it applies the same test)
-    if (d.is_luma)
-    {
-      McStaged<8, 16, 64> st;
-      mc_stage<8, 16, 64>(d, true, ref0Base, ref1Base, lane, st);
-      mc_tile_dot2<8, 16, 64>(d, true, st, dstBase, bd, cmin, cmax, lane, L, reinterpret_cast<short*>(L + 23 * 12), reinterpret_cast<short*>(L + 23 * 12 + 16 * 12));
-    }
-    else
-    {
-      McStaged<4, 8, 32> st;
-      mc_stage<4, 8, 32>(d, lane < 32, ref0Base, ref1Base, lane & 31, st);
-      mc_tile_dot2<4, 8, 32>(d, lane < 32, st, dstBase, bd, cmin, cmax, lane & 31, L, reinterpret_cast<short*>(L + 11 * 6), reinterpret_cast<short*>(L + 11 * 6 + 8 * 6));
-    }
-  }
-}
 
 // ---------------------------------------------------------------------------------------------------
 // The fast shapes ON THE MATRIX CORES (round 5): 16x16 luma and 8x8 chroma PUs, uni- and bi-predictive, quarter- (chroma: eighth-) sample phases.
-// mc_fast_kernel above spends ~570 vector instructions per PU wave around 78 v_dot2 with the matrix pipe idle; here both filter passes are exact
+// The packed vector-pipe form (mc_tile_dot2) spends ~570 vector instructions per PU wave around 78 v_dot2 with the matrix pipe idle; here both filter passes are exact
 // f16 products (the machinery of frac16m_kernel, fracsearch.hip): ~120 vector instructions per luma PU, ~100 per PAIR of chroma PUs.
 //   window   rows through lanes, eight columns per lane as one 16-byte load (any alignment), samples as f16 bit patterns 0x6400 | v (= 1024 + v)
 //   pass 1   W (A operand) x Toeplitz matrix of the taps (table, B operand); the constant that the sum has to start from travels in the product's
@@ -615,7 +567,7 @@ struct MmK                                                   // lane constants o
   unsigned m7[3], m8[3], orX[3], orR[3];                     // limb masks / exponent patterns of a pass-1 result by row-chunk kind (see the kernel)
   unsigned rangeMask, uLo, uHi;
   float magicN, magicH, scBi1, scUni1, ofUni1, scBi2, ofBi2, cinN, cinH;
-  mm_h2 pmin, pmax;
+  mm_h2 pmin, pmax, pmin0, pmaxF;                            // packed clip bounds (+ 1024): the caller's range; the bit depth's range (a uni-predictive full-sample copy is NOT clipped: filterCopy, isFirst == isLast)
   int perm;                                                  // ds_bpermute address: lane (row & 15) + 16 chunk <- lane 4 (row & 15) + chunk
 };
 
@@ -652,15 +604,17 @@ __device__ __forceinline__ h8 mm_window(const MmK& K, uint4 u, bool cst, bool wh
   return __builtin_bit_cast(h8, u);
 }
 // the tail of a PU: (f0 + f1 + offset) >> shiftNum for bi, f0 for uni (w1 = 0, sc2 = 1), + 1024 so that the truncating f16 conversion is the floor and the
-// clip is packed; the four samples as two dwords
-__device__ __forceinline__ uint2 mm_tail(const MmK& K, const float (&f0)[4], const float (&f1)[4], float w1, float sc2, float of2)
+// clip is packed; the four samples as two dwords.  copy: a uni-predictive full-sample PU -- InterpolationFilter::filterCopy with isFirst == isLast
+// stores the sample as it is (HM_JEM_CLIP_PEL, InterpolationFilter.cpp:210-227); the samples are inside the bit depth here, so "no clip" = its range
+__device__ __forceinline__ uint2 mm_tail(const MmK& K, const float (&f0)[4], const float (&f1)[4], float w1, float sc2, float of2, bool copy)
 {
   float t[4];
 #pragma unroll
   for (int j = 0; j < 4; j++) t[j] = __builtin_fmaf(__builtin_fmaf(f1[j], w1, f0[j]), sc2, of2);
   mm_h2 q0 = __builtin_bit_cast(mm_h2, __builtin_amdgcn_cvt_pkrtz(t[0], t[1])), q1 = __builtin_bit_cast(mm_h2, __builtin_amdgcn_cvt_pkrtz(t[2], t[3]));
-  q0 = __builtin_elementwise_min(__builtin_elementwise_max(q0, K.pmin), K.pmax);
-  q1 = __builtin_elementwise_min(__builtin_elementwise_max(q1, K.pmin), K.pmax);
+  const mm_h2 lo = copy ? K.pmin0 : K.pmin, hi = copy ? K.pmaxF : K.pmax;
+  q0 = __builtin_elementwise_min(__builtin_elementwise_max(q0, lo), hi);
+  q1 = __builtin_elementwise_min(__builtin_elementwise_max(q1, lo), hi);
   uint2 o;
   o.x = __builtin_bit_cast(unsigned, q0) & 0x03FF03FFu;
   o.y = __builtin_bit_cast(unsigned, q1) & 0x03FF03FFu;
@@ -752,7 +706,7 @@ __device__ __forceinline__ void mm_luma(const MmK& K, const vvcgpu_mc_desc& d, c
   const bool isBad = __ballot(W.bad != 0) != 0ull;           // a reference sample outside the bit depth: the generic kernel takes the PU
   if (K.lane == 0) flags[idx] = isBad;
   if (isBad) return;
-  const uint2 o = mm_tail(K, fr[0], fr[1], d.bi == 1 ? 1.f : 0.f, d.bi == 1 ? K.scBi2 : 1.f, d.bi == 1 ? K.ofBi2 : 1024.f);
+  const uint2 o = mm_tail(K, fr[0], fr[1], d.bi == 1 ? 1.f : 0.f, d.bi == 1 ? K.scBi2 : 1.f, d.bi == 1 ? K.ofBi2 : 1024.f, d.bi == 0 && (d.frac_x0 | d.frac_y0) == 0);
   Pel* dp = dstBase + d.dst_off + (ptrdiff_t)K.c16 * d.dst_stride + 4 * K.g;                 // lane (c16, g): row c16, columns 4 g .. 4 g + 3
   reinterpret_cast<MmQuad*>(dp)->v = o;
 }
@@ -830,9 +784,11 @@ __device__ __forceinline__ void mm_chroma(const MmK& K, const MmWin& raw, int iA
     for (int j = 0; j < 4; j++) fr[rf][j] = floorf(__builtin_fmaf(acc[j], sc, of));
   }
   const unsigned long long badLanes = __ballot(raw.bad != 0);
-  const bool badA = (badLanes & 0x00000000FFFFFFFFull) != 0ull, badB = hasB && (badLanes & 0xFFFFFFFF00000000ull) != 0ull;      // lane groups 0, 1 loaded PU A
+  // a sample outside the bit depth is no f16 integer pattern (0x6400 | v reaches the exponent): in a product it poisons every output of its ROW, also the
+  // other PU's, whose table entries for it are zero (0 x NaN) -- both PUs of the pair go to the generic kernel
+  const bool badA = badLanes != 0ull, badB = hasB && badLanes != 0ull;
   if (K.lane == 0) { flags[iA] = badA; if (hasB) flags[iB] = badB; }
-  const uint2 o = mm_tail(K, fr[0], fr[1], bi == 1 ? 1.f : 0.f, bi == 1 ? K.scBi2 : 1.f, bi == 1 ? K.ofBi2 : 1024.f);
+  const uint2 o = mm_tail(K, fr[0], fr[1], bi == 1 ? 1.f : 0.f, bi == 1 ? K.scBi2 : 1.f, bi == 1 ? K.ofBi2 : 1024.f, bi == 0 && (fx0 | fy0) == 0);
   // lane (c16, g): row c16 & 7 of PU c16 >> 3, columns 4 (g & 1) ..; real when g >> 1 == c16 >> 3
   const bool outB = K.c16 >= 8;
   if ((K.g >> 1) == (K.c16 >> 3) && (outB ? (hasB && !badB) : !badA))
@@ -888,6 +844,7 @@ __global__ __launch_bounds__(256, 4) void mc_mfma_kernel(const Pel* __restrict__
   K.cinN = 8192.f * (float)S - 65536.f - 0.5f * (float)(S - 1); K.cinH = 983040.5f;     // start values of a luma pass-1 sum (the chroma tables carry theirs)
   K.perm = (4 * K.c16 + K.g) * 4;
   K.pmin = mm_h2{ (_Float16)(short)(1024 + cmin), (_Float16)(short)(1024 + cmin) }; K.pmax = mm_h2{ (_Float16)(short)(1024 + cmax), (_Float16)(short)(1024 + cmax) };
+  K.pmin0 = mm_h2{ (_Float16)1024.f, (_Float16)1024.f }; K.pmaxF = mm_h2{ (_Float16)(short)(1023 + (1 << bd)), (_Float16)(short)(1023 + (1 << bd)) };
   // second-stage rounding as fma + floor (exact: f32 integers below 2^24 times powers of two)
   K.scBi1 = 1.f / 64.f; K.scUni1 = 1.f / (float)(64 << hr); K.ofUni1 = (float)((1 << (5 + hr)) + (IF_INTERNAL_OFFS << 6)) * K.scUni1;
   K.scBi2 = 1.f / (float)(2 << hr); K.ofBi2 = (float)((1 << hr) + 2 * IF_INTERNAL_OFFS) * K.scBi2 + 1024.f;
@@ -1060,11 +1017,11 @@ __device__ __forceinline__ void mc_luma4x4_chunk(unsigned long long todo44, cons
   int selC, selN = -1;
   vvcgpu_mc_desc dC = pick(selC), dN = dC;
   McStaged<8, 4, 16> sC, sN;
-  mc_stage<8, 4, 16>(dC, selC >= 0, ref0Base, ref1Base, gl, sC);
+  mc_stage<8, 4, 16>(dC, selC >= 0, ref0Base, ref1Base, gl, sC, bd);
   for (;;)
   {
     const bool more = todo44 != 0ull;
-    if (more) { dN = pick(selN); mc_stage<8, 4, 16>(dN, selN >= 0, ref0Base, ref1Base, gl, sN); }
+    if (more) { dN = pick(selN); mc_stage<8, 4, 16>(dN, selN >= 0, ref0Base, ref1Base, gl, sN, bd); }
     mc_tile_dot2<8, 4, 16>(dC, selC >= 0, sC, dstBase, bd, cmin, cmax, gl, L, reinterpret_cast<short*>(L + 11 * 6), reinterpret_cast<short*>(L + 11 * 6 + 4 * 6));
     if (!more) break;
     dC = dN; selC = selN; sC = sN;
@@ -1079,7 +1036,7 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
                                                       Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs,
                                                       int bd, int cmin, int cmax,
                                                       int nDirect, int distKind, const Pel* __restrict__ orgBase, unsigned long long* __restrict__ out, int chunk,
-                                                      const int* __restrict__ flags)
+                                                      const int* __restrict__ flags, int takeFast)
 {
   __shared__ short win[WR * WP];
   __shared__ short tmp[WR * ST];
@@ -1101,7 +1058,7 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
     {
       const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(descs + base0 + lane) + 32);     // dst_stride | w, h | phases | is_luma, bi
       const int isLuma = (int)(signed char)(q.w & 0xFFu), qw = (int)(short)(q.y & 0xFFFFu), qh = (int)(short)(q.y >> 16);
-      mine = !mc_is_fast(isLuma, qw, qh) || (flags && flags[base0 + lane] != 0);       // (flags: the fast shapes the matrix-core kernel in front has left)
+      mine = takeFast || !mc_is_fast(isLuma, qw, qh) || (flags && flags[base0 + lane] != 0);       // (flags: the fast shapes the matrix-core kernel in front has left; takeFast: there is none)
       sub44 = SUB44 && isLuma && qw == 4 && qh == 4;
     }
     todo = __builtin_amdgcn_ballot_w64(mine);
@@ -1130,13 +1087,15 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
     auto tile = [&](int t) { vvcgpu_mc_desc q = d; const int y = (t / tx) * T, x = (t - (t / tx) * tx) * T; q.w = q.h = (short)T;
                              q.ref0_off += (int64_t)y * d.ref0_stride + x; q.ref1_off += (int64_t)y * d.ref1_stride + x; q.dst_off += (int64_t)y * d.dst_stride + x; return q; };
     unsigned* L = tileL;
+    bool outsideDepth = false;                               // a reference sample outside the bit depth (mc_stage): the whole PU again, sample-wise, below
     if (d.is_luma)
     {
       for (int t = 0; t < nt; t++)
       {
         const vvcgpu_mc_desc q = tile(t);
         McStaged<8, 16, 64> st;
-        mc_stage<8, 16, 64>(q, true, ref0Base, ref1Base, lane, st);
+        mc_stage<8, 16, 64>(q, true, ref0Base, ref1Base, lane, st, bd);
+        if (__builtin_amdgcn_ballot_w64(st.bad != 0u) != 0ull) { outsideDepth = true; break; }
         mc_tile_dot2<8, 16, 64>(q, true, st, dstBase, bd, cmin, cmax, lane, L, reinterpret_cast<short*>(L + 23 * 12), reinterpret_cast<short*>(L + 23 * 12 + 16 * 12));
       }
     }
@@ -1149,11 +1108,12 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
         const bool on = t + (hi ? 1 : 0) < nt;
         const vvcgpu_mc_desc q = tile(on ? t + (hi ? 1 : 0) : t);
         McStaged<4, 8, 32> st;
-        mc_stage<4, 8, 32>(q, on, ref0Base, ref1Base, lane & 31, st);
+        mc_stage<4, 8, 32>(q, on, ref0Base, ref1Base, lane & 31, st, bd);
+        if (__builtin_amdgcn_ballot_w64(st.bad != 0u) != 0ull) { outsideDepth = true; break; }
         mc_tile_dot2<4, 8, 32>(q, on, st, dstBase, bd, cmin, cmax, lane & 31, Lh, reinterpret_cast<short*>(Lh + 11 * 6), reinterpret_cast<short*>(Lh + 11 * 6 + 8 * 6));
       }
     }
-    continue;
+    if (!outsideDepth) continue;
   }
   const int N = d.is_luma ? 8 : 4, half = N / 2 - 1;
   const bool rndRes = d.bi == 0;
@@ -1421,10 +1381,9 @@ int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_
   VVC_CHECK_ARG(n < (1 << 27), "if_batch: n %d", n);
   int perWg = IF_WG_DESCS;                                // fewer descriptors per workgroup when 64 would leave compute units without one
   while (perWg > 16 && cdiv(n, perWg) < 4096) perWg >>= 1;
-  static const int localMode = getenv("VVCGPU_IF_LOCAL_HEAVY") ? atoi(getenv("VVCGPU_IF_LOCAL_HEAVY")) : -1;   // A/B timing switch
   // few calls: a heavy one may be most of the work of the whole launch -> bands over the machine; very many calls: the second launch is amortised and its
   // machine-wide bands beat a workgroup's four waves (real call mix: 0.042 -> 0.038 ms at 30 k calls, 0.093 -> 0.110 at 121 k)
-  const int localHeavy = localMode < 0 ? (n >= 8192 && n < 65536) : localMode != 0;
+  const int localHeavy = n >= 8192 && n < 65536;
   hipLaunchKernelGGL(if_batch_kernel, dim3(cdiv(n, perWg)), dim3(256), 0, st, src_base, dst_base, descs, n, perWg, localHeavy,
                      bit_depth, clp_min, clp_max, counters + VVC_CTR_INTS * cur, heavyList, counters + VVC_CTR_INTS * (cur ^ 1));
   if (!localHeavy)
@@ -1453,51 +1412,38 @@ int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc
   VVC_CHECK_ARG(((uintptr_t)descs & 15) == 0, "mc_batch: descriptor array must be 16-byte aligned");
   if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("mc_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
   hipStream_t st = (hipStream_t)stream;
-  const int xcd = vvc_xcd_on();
-  static const int mfmaOff = getenv("VVCGPU_NO_MC_MFMA") ? 1 : 0;         // A/B timing switch: the vector-pipe fast kernel
+  const int mfmaOff = vvcgpu_no_mfma();                                   // VVCGPU_NO_MFMA (common.h): every PU through the generic kernel (its packed vector-pipe form takes the fast shapes)
   const int* flags = nullptr;
   if (!skip_fast && !mfmaOff)
   {
     const _Float16* image = mm_image(bit_depth);
     if (!image) return VVCGPU_E_DEVICE;
-    int* fl = static_cast<int*>(vvcgpu_scratch(st, (size_t)n * sizeof(int)));
+    int* fl = static_cast<int*>(vvcgpu_scratch_region(st, VVC_SCRATCH_HELPER, (size_t)n * sizeof(int)));
     if (!fl) return VVCGPU_E_DEVICE;
-    const int wgL = cdiv(n, 4) < 256 * 4 ? cdiv(n, 4) : 256 * 4, wgC = cdiv((n + 1) / 2, 4) < 256 * 4 ? cdiv((n + 1) / 2, 4) : 256 * 4;   // persistent: four workgroups per CU
-    static const int split = getenv("VVCGPU_MC_SPLIT") ? 1 : 0;          // A/B switch: the two shapes as two launches
-    if (split)
+    const int wgL = cdiv(n, 4) < 256 * 4 ? cdiv(n, 4) : 256 * 4;   // persistent: four workgroups per CU
+    unsigned long long* diag = nullptr;
+    const bool wantDiag = getenv("VVCGPU_MC_DIAG") != nullptr;           // measurement aid: step stamps of one luma wave
+    if (wantDiag) { VVC_HIP(hipMalloc(&diag, 64 * sizeof(unsigned long long))); VVC_HIP(hipMemsetAsync(diag, 0, 64 * sizeof(unsigned long long), st)); }
+    hipLaunchKernelGGL(mc_mfma_kernel<0>, dim3(wgL < 2 ? 2 : (wgL & ~1)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl, diag);
+    if (wantDiag)
     {
-      hipLaunchKernelGGL(mc_mfma_kernel<1>, dim3(wgL), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl, nullptr);
-      hipLaunchKernelGGL(mc_mfma_kernel<2>, dim3(wgC), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl, nullptr);
-    }
-    else
-    {
-      unsigned long long* diag = nullptr;
-      const bool wantDiag = getenv("VVCGPU_MC_DIAG") != nullptr;           // measurement aid: step stamps of one luma wave
-      if (wantDiag) { VVC_HIP(hipMalloc(&diag, 64 * sizeof(unsigned long long))); VVC_HIP(hipMemsetAsync(diag, 0, 64 * sizeof(unsigned long long), st)); }
-      hipLaunchKernelGGL(mc_mfma_kernel<0>, dim3(wgL & ~1), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl, diag);
-      if (wantDiag)
-      {
-        unsigned long long h[64];
-        VVC_HIP(hipStreamSynchronize(st));
-        VVC_HIP(hipMemcpy(h, diag, sizeof h, hipMemcpyDeviceToHost));
-        (void)hipFree(diag);
-        fprintf(stderr, "[vvcgpu mc diag] luma steps of one wave, cycles (wait + operands / request next / products + store | step):");
-        for (int k = 0; k < 12; k++) if (h[4 * k + 3]) fprintf(stderr, " %llu/%llu/%llu|%llu", h[4 * k + 1] - h[4 * k], h[4 * k + 2] - h[4 * k + 1], h[4 * k + 3] - h[4 * k + 2], k ? h[4 * k] - h[4 * k - 4] : 0ull);
-        fprintf(stderr, "\n");
-      }
+      unsigned long long h[64];
+      VVC_HIP(hipStreamSynchronize(st));
+      VVC_HIP(hipMemcpy(h, diag, sizeof h, hipMemcpyDeviceToHost));
+      (void)hipFree(diag);
+      fprintf(stderr, "[vvcgpu mc diag] luma steps of one wave, cycles (wait + operands / request next / products + store | step):");
+      for (int k = 0; k < 12; k++) if (h[4 * k + 3]) fprintf(stderr, " %llu/%llu/%llu|%llu", h[4 * k + 1] - h[4 * k], h[4 * k + 2] - h[4 * k + 1], h[4 * k + 3] - h[4 * k + 2], k ? h[4 * k] - h[4 * k - 4] : 0ull);
+      fprintf(stderr, "\n");
     }
     flags = fl;
   }
-  else if (!skip_fast)
-    hipLaunchKernelGGL(mc_fast_kernel, dim3(vvc_xcd_grid(cdiv(n, 8), xcd)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base,
-                       dst_base, descs, n, bit_depth, clp_min, clp_max, cdiv(n, 8), xcd);
   const int chunk = n >= 64 * 8192 ? 64 : (n + 8191) / 8192;            // ~8192 waves: 32 per CU
   if (sub44)
     hipLaunchKernelGGL((mc_batch_kernel<false, true>), dim3(cdiv(n, chunk) < 8192 ? cdiv(n, chunk) : 8192), dim3(64), 0, st, ref0_base,
-                       ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk, flags);
+                       ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk, flags, mfmaOff ? 1 : 0);
   else
     hipLaunchKernelGGL((mc_batch_kernel<false, false>), dim3(cdiv(n, chunk) < 8192 ? cdiv(n, chunk) : 8192), dim3(64), 0, st, ref0_base,
-                       ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk, flags);
+                       ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk, flags, mfmaOff ? 1 : 0);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
@@ -1511,7 +1457,7 @@ int vvcgpu_mc_dist_batch(int kind, const vvc_pel* ref0_base, const vvc_pel* ref1
   VVC_CHECK_ARG(ref0_base && org_base && descs && out, "mc_dist_batch: null pointer");
   if (bit_depth > 10 || bit_depth < 8) { vvcgpu_set_error("mc_dist_batch: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
   hipLaunchKernelGGL((mc_batch_kernel<true, false>), dim3(n < 4096 ? n : 4096), dim3(64), 0, (hipStream_t)stream, ref0_base, ref1_base ? ref1_base : ref0_base,
-                     nullptr, descs, bit_depth, clp_min, clp_max, n, kind, org_base, reinterpret_cast<unsigned long long*>(out), 1, nullptr);
+                     nullptr, descs, bit_depth, clp_min, clp_max, n, kind, org_base, reinterpret_cast<unsigned long long*>(out), 1, nullptr, 0);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }

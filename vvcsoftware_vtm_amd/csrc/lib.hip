@@ -27,7 +27,7 @@ namespace {
 struct StreamSlot
 {
   int device; hipStream_t stream;
-  void* ptr; size_t cap;                  // scratch
+  void* ptr[VVC_SCRATCH_REGIONS]; size_t cap[VVC_SCRATCH_REGIONS];   // scratch, one buffer per region (common.h)
   struct Retired { void* ptr; hipEvent_t done; };
   std::vector<Retired> retired;           // outgrown scratch buffers: freed with the slot
   int* counters; int cur; bool dirty;     // int[2][16]; dirty: a launch that owned a set failed -- both sets are cleared before the next use
@@ -40,42 +40,66 @@ StreamSlot* find_slot(int dev, hipStream_t stream, bool create)
   for (auto& s : g_slots)
     if (s.device == dev && s.stream == stream) return &s;
   if (!create) return nullptr;
-  g_slots.push_back(StreamSlot{ dev, stream, nullptr, 0, {}, nullptr, 0, false });
+  g_slots.push_back(StreamSlot{ dev, stream, {}, {}, {}, nullptr, 0, false });
   return &g_slots.back();
 }
 void free_slot(StreamSlot& s)             // the slot is out of the table (or the caller holds the mutex at shutdown), its device is current, its stream is idle
 {
-  if (s.ptr) (void)hipFree(s.ptr);
+  for (int r = 0; r < VVC_SCRATCH_REGIONS; r++) if (s.ptr[r]) (void)hipFree(s.ptr[r]);
   for (auto& q : s.retired) { (void)hipFree(q.ptr); if (q.done) (void)hipEventDestroy(q.done); }
   s.retired.clear();
   if (s.counters) (void)hipFree(s.counters);
 }
 }
 
-void* vvcgpu_scratch(hipStream_t stream, size_t bytes)
+void* vvcgpu_scratch(hipStream_t stream, size_t bytes) { return vvcgpu_scratch_region(stream, VVC_SCRATCH_ENTRY, bytes); }
+
+void* vvcgpu_scratch_region(hipStream_t stream, int region, size_t bytes)
 {
+  if (region < 0 || region >= VVC_SCRATCH_REGIONS) { vvcgpu_set_error("scratch: region %d", region); return nullptr; }
   int dev = 0;
   if (hipGetDevice(&dev) != hipSuccess) { vvcgpu_set_error("hipGetDevice failed"); return nullptr; }
-  std::lock_guard<std::mutex> lock(g_slotMutex);
-  StreamSlot* slot = find_slot(dev, stream, true);
-  if (slot->cap < bytes)
   {
-    size_t cap = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
-    if (cap < 2 * slot->cap) cap = 2 * slot->cap;              // geometric growth
-    void* p = nullptr;
-    if (hipMalloc(&p, cap) != hipSuccess)
-    {
-      (void)hipGetLastError();                                  // the failed attempt must not surface at the caller's next launch check
-      cap = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1); // the doubled size did not fit: the request itself
-      if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); vvcgpu_set_error("scratch: hipMalloc(%zu) failed", cap); return nullptr; }
-    }
-    // The outgrown buffer: queued work on the stream may still read it, and hipFree synchronises the whole device -- neither belongs on a
-    // hot path.  It is parked in the slot and freed with it (vvcgpu_stream_release / vvcgpu_shutdown).  Capacities at least double, so the
-    // parked buffers of a slot sum to less than its current capacity.
-    if (slot->ptr) slot->retired.push_back(StreamSlot::Retired{ slot->ptr, nullptr });
-    slot->ptr = p; slot->cap = cap;
+    std::lock_guard<std::mutex> lock(g_slotMutex);
+    StreamSlot* slot = find_slot(dev, stream, true);
+    if (slot->cap[region] >= bytes) return slot->ptr[region];               // the hot path: no allocation, no event, no free
   }
-  return slot->ptr;
+  // Growth (O(log n) times per stream): allocate OUTSIDE the lock -- hipMalloc / hipFree may synchronise the device, and no other thread's entry
+  // point should wait for that behind the table's mutex.  (A stream is driven by one host thread at a time, so the slot's region does not change
+  // under us; the slot is looked up again because the table may have been re-allocated.)
+  size_t have = 0;
+  { std::lock_guard<std::mutex> lock(g_slotMutex); have = find_slot(dev, stream, true)->cap[region]; }
+  size_t cap = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);
+  if (cap < 2 * have) cap = 2 * have;                                       // geometric growth
+  void* p = nullptr;
+  if (hipMalloc(&p, cap) != hipSuccess)
+  {
+    (void)hipGetLastError();                                                // the failed attempt must not surface at the caller's next launch check
+    cap = (bytes + (1u << 20) - 1) & ~(size_t)((1u << 20) - 1);             // the doubled size did not fit: the request itself
+    if (hipMalloc(&p, cap) != hipSuccess) { (void)hipGetLastError(); vvcgpu_set_error("scratch: hipMalloc(%zu) failed", cap); return nullptr; }
+  }
+  // The outgrown buffer: queued work on the stream may still read it, so it is parked with an event recorded behind that work; parked buffers
+  // whose event has completed are freed HERE, on the (rare) growth path and outside the lock, the rest with the slot (vvcgpu_stream_release /
+  // vvcgpu_shutdown).  Capacities at least double, so the parked buffers of a slot sum to less than its current capacity.
+  hipEvent_t ev = nullptr;
+  if (hipEventCreateWithFlags(&ev, hipEventDisableTiming) != hipSuccess || hipEventRecord(ev, stream) != hipSuccess)
+  { (void)hipGetLastError(); if (ev) (void)hipEventDestroy(ev); ev = nullptr; }   // no event: the buffer stays parked until the slot goes
+  std::vector<StreamSlot::Retired> done;
+  {
+    std::lock_guard<std::mutex> lock(g_slotMutex);
+    StreamSlot* slot = find_slot(dev, stream, true);
+    for (size_t i = 0; i < slot->retired.size();)
+    {
+      if (slot->retired[i].done && hipEventQuery(slot->retired[i].done) == hipSuccess) { done.push_back(slot->retired[i]); slot->retired.erase(slot->retired.begin() + (ptrdiff_t)i); }
+      else i++;
+    }
+    (void)hipGetLastError();                                                // hipErrorNotReady of a query is not an error of the caller
+    if (slot->ptr[region]) slot->retired.push_back(StreamSlot::Retired{ slot->ptr[region], ev });
+    else if (ev) { (void)hipEventDestroy(ev); }
+    slot->ptr[region] = p; slot->cap[region] = cap;
+  }
+  for (auto& q : done) { (void)hipFree(q.ptr); (void)hipEventDestroy(q.done); }
+  return p;
 }
 
 // Two persistent work counters per (device, stream), zero when handed out: a launch that needs a zeroed counter takes counter `cur` and clears
@@ -111,6 +135,12 @@ void vvcgpu_counters_failed(hipStream_t stream)
   if (hipGetDevice(&dev) != hipSuccess) return;
   std::lock_guard<std::mutex> lock(g_slotMutex);
   if (StreamSlot* slot = find_slot(dev, stream, false)) slot->dirty = true;
+}
+
+int vvcgpu_no_mfma(void)
+{
+  const char* e = getenv("VVCGPU_NO_MFMA");                                 // read per call (a few hundred ns): tools toggle it inside one process
+  return e && e[0] == '1';
 }
 
 // compute units of the current device, cached per device (persistent kernels size their grids with it on every call)
@@ -213,7 +243,7 @@ int vvcgpu_stream_release(void* stream)
   const hipError_t e = hipStreamSynchronize((hipStream_t)stream);           // queued work may still read the buffers
   if (e == hipSuccess)
   {
-    StreamSlot taken{ sdev, nullptr, nullptr, 0, {}, nullptr, 0, false };
+    StreamSlot taken{ sdev, nullptr, {}, {}, {}, nullptr, 0, false };
     bool found = false;
     {
       std::lock_guard<std::mutex> lock(g_slotMutex);

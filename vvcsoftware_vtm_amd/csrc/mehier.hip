@@ -486,11 +486,10 @@ int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref
   unsigned long long* diag = nullptr;
   const bool wantDiag = getenv("VVCGPU_MH_DIAG") != nullptr;                 // measurement aid (tools/mehier_time.py): phase stamps of one workgroup
   if (wantDiag) { VVC_HIP(hipMalloc(&diag, 64 * sizeof(unsigned long long))); VVC_HIP(hipMemsetAsync(diag, 0, 64 * sizeof(unsigned long long), st)); }
-  static const int persistOff = (getenv("VVCGPU_MH_PERSIST") && getenv("VVCGPU_MH_PERSIST")[0] == '0') ? 1 : 0;   // A/B switch: one workgroup per super-block (the form of round 4)
   // VVCGPU_MH_WGS (read per call; tests / tuning): the number of persistent workgroups, so that small grids walk runs -- and slide their window -- too
   const char* wgsEnv = getenv("VVCGPU_MH_WGS");
   const int wgsMax = wgsEnv && atoi(wgsEnv) >= 8 ? (atoi(wgsEnv) / 8) * 8 : (vvcgpu_cu_count() / 8) * 8;
-  const int gridWgs = persistOff ? cdiv(g.total, 8) * 8 : min(cdiv(g.total, 8) * 8, wgsMax);
+  const int gridWgs = min(cdiv(g.total, 8) * 8, wgsMax);
   hipLaunchKernelGGL(me_hier_kernel, dim3(gridWgs), dim3(1024), smem, st, packed, ref, ref_stride, g, *mvcost_host,
                      raster_best[0], raster_best[1], raster_best[2], dense_best ? dense_best[0] : nullptr, dense_best ? dense_best[1] : nullptr, dense_best ? dense_best[2] : nullptr, diag);
   VVC_LAUNCH_CHECK();

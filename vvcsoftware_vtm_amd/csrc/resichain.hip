@@ -190,6 +190,9 @@ __device__ __forceinline__ RcQ rc_qparams(int w, int h, int qp, int bd, int intr
   q.sbh = signHiding && w >= 4 && h >= 4;
   return q;
 }
+// (64-bit arithmetic as the reference's: a 32-bit form of both -- 24-bit multiplies, a funnel shift for (tmp + add) >> qBits, exact for
+// |c| < 2^24 and 16 <= qBits <= 31 -- was built and measured in round 6: 71.3 against 68.5 us for the 4K chain, the branch around the 64-bit
+// form costs more than the quarter-rate multiplies it saves; docs/OPTIMISATION_LOG.md)
 __device__ __forceinline__ int rc_quant_one(const RcQ& q, int c, int& deltaU, int& mag)
 {
   const unsigned long long tmp = (unsigned long long)(unsigned)abs(c) * q.mul;
@@ -299,10 +302,21 @@ __device__ __forceinline__ void rc_sbh_quad(int (&lv)[4], const int (&du)[4], co
 
 // ---------------------------------------------------------------------------------------------------
 // Matrix-core path (stages and the LDS matrix image: mfma_tr.h).  The image is built ONCE per device in global memory (rc_build_tables_kernel)
-// and copied by every workgroup with 16-byte loads.
+// and copied by every workgroup with 16-byte loads.  Behind the f16 matrices (RC_TAB_HALVES halves) the image carries the 4- / 8-point matrices
+// as int32 for the lane-group bodies (RcSmallTab), so that a workgroup's whole table set is ONE run of 16-byte loads.
+struct RcSmallTab { int t[3][16 + 64]; int tt[3][16 + 64]; };       // per type: size 4 at 0, size 8 at 16; tt = transposes
+static_assert(sizeof(RcSmallTab) % 16 == 0, "copied with 16-byte loads");
+constexpr int RC_IMG_U4 = RC_TAB_HALVES / 8 + (int)sizeof(RcSmallTab) / 16;       // 16-byte words of the image
 __global__ __launch_bounds__(256) void rc_build_tables_kernel(_Float16* __restrict__ tab, const int* __restrict__ tr32, const int* __restrict__ tr32t)
 {
   const int tid = blockIdx.x * 256 + threadIdx.x, nthreads = gridDim.x * 256;
+  RcSmallTab* st = reinterpret_cast<RcSmallTab*>(tab + RC_TAB_HALVES);
+  for (int e = tid; e < 3 * 80; e += nthreads)
+  {
+    const int t = e / 80, o = e - t * 80, nsz = o < 16 ? 4 : 8, oo = o < 16 ? o : o - 16;
+    st->t[t][o] = tr32[t * 5460 + (nsz * nsz - 4) / 3 + oo];
+    st->tt[t][o] = tr32t[t * 5460 + (nsz * nsz - 4) / 3 + oo];
+  }
   for (int t = 0; t < 3; t++)
     for (int n = 16; n <= 32; n <<= 1)
       for (int e = tid; e < n * n; e += nthreads)
@@ -488,6 +502,228 @@ __device__ __forceinline__ bool rc_tu_mfma(const RcDesc& d, const Pel* __restric
     }
     *reinterpret_cast<pel4*>(rec + (size_t)(16 * rt + c) * d.rec_stride + 16 * xt + 4 * g) = out;
   });
+  return true;
+}
+
+// the single-wave matrix-core bodies of the chain kernel's rarer classes (64x16 .. 16x32) as real calls: inline, the kernel's register need is the
+// sum of what the compiler keeps live across its switch (docs/OPTIMISATION_LOG.md, round 6)
+template <int W, int H, int MODE>
+__device__ __noinline__ bool rc_tu_mfma_call(const RcDesc* __restrict__ descs, int ti, const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                             TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
+                                             const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff, int lane)
+{
+  return rc_tu_mfma<W, H, MODE>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, dqInv, scanOff, lane);
+}
+
+// ---------------------------------------------------------------------------------------------------
+// One TU of W x H, both sides in {32, 64}, by the FOUR waves of a workgroup together (round 6).  One wave per TU held a
+// whole 64 x 64 chain -- 80 products, 198 vector registers, two waves per SIMD for the WHOLE kernel, and 20 us of one wave's latency per TU.
+// Here a wave owns a strip of every stage and no wave holds more than a quarter of a tile set:
+//   F1  M1 = X Th^T      row tile rt = wave (H = 64) or wave >> 1 with ONE frequency tile (H = 32)     -> limbs of M1, transposed, to LDS (E1[j1][r])
+//   F2  C = Tv M1        ONE 16 x 16 tile (it, jt) = (wave >> 1, wave & 1); B operand = E1 rows (16-byte reads) -> quantiser on that tile
+//                        (abs sum and last group meet in LDS) -> levels to memory, limbs of the de-quantised tile, transposed, to LDS (E2[i][k])
+//   I1  Y1^T = Cq^T Tv   sample-row tile rt = wave (H = 64) or wave >> 1; A operand = E2 rows; both frequency tiles (the next stage sums over them)
+//   I2  R^T = Th^T Y1^T  the wave's row tile, all column tiles (H = 64) or every second one (H = 32: two waves share a row tile) -> reconstruction
+// 20 products per wave for 64 x 64, three barriers between the stages and one behind the TU.  E1 / E2 are f16 limb planes with row pitch H + 8 / 40
+// halves: pitch / 2 = 4 (mod 16) dwords spreads the 16 rows that one ds_write_b64 / ds_read_b128 pass touches over all 64 banks.  E2 lies over E1
+// (dead once every wave has its F2 operands: the barrier behind the quantiser's partial sums), and both lie over the per-wave scratch of the other
+// bodies: the co-operative classes are the FIRST slots of a workgroup and the barrier behind a TU is the fence between the two uses.
+// `red`: { abs sum, last coefficient group, "outside the matrix-core range" } -- zero / -1 / zero on entry, left so on exit.
+constexpr int RC_EX_HALVES = 2 * 32 * 72;                  // E1 of a 64-row TU: two limb planes of 32 rows x 72 halves = 9216 bytes
+template <int W, int H, int MODE>
+__device__ __forceinline__ bool rc_tu_coop(const RcDesc& d, const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                           TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int ti, int bd, int clpMin, int clpMax,
+                                           const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
+                                           _Float16* ex, int* red, int wv, int lane)
+{
+  static_assert((W == 32 || W == 64) && (H == 32 || H == 64), "co-operative body: both sides 32 or 64");
+  typedef MtShape<W, H> S;
+  static_assert(S::JT == 2 && S::IT == 2, "32 kept frequencies per dimension");
+  constexpr int LW = W == 32 ? 5 : 6, LH = H == 32 ? 5 : 6;
+  constexpr int P1 = H + 8, P2 = 40;
+  constexpr int XS = W / 32, HS = H / 32;
+  const int c = lane & 15, g = lane >> 4;
+  const Pel* org = orgBase + d.org_off;
+  const Pel* pred = predBase + d.pred_off;
+  const _Float16* Th = tab + rc_tab_off(d.tr_hor, W, 0);
+  const _Float16* ThT = tab + rc_tab_off(d.tr_hor, W, 1);
+  const _Float16* Tv = tab + rc_tab_off(d.tr_ver, H, 0);
+  const _Float16* TvT = tab + rc_tab_off(d.tr_ver, H, 1);
+  TCoeff* level = levelBase + d.level_off;
+  _Float16* e1h = ex;
+  _Float16* e1l = ex + 32 * P1;
+  _Float16* e2h = ex;
+  _Float16* e2l = ex + 32 * P2;
+  const int it = wv >> 1, jt = wv & 1;                      // the wave's coefficient tile
+  const int rtW = S::RT == 4 ? wv : (wv >> 1);              // the wave's sample-row tile
+  const int4v z = { 0, 0, 0, 0 };
+  auto leave = [&]() -> bool                                // a TU outside the matrix-core range: every wave takes this exit (the flag is read behind a barrier)
+  {
+    __syncthreads();
+    if (wv == 0 && lane == 0) red[2] = 0;
+    __syncthreads();
+    return false;
+  };
+
+  if (MODE != RC_INV)
+  {
+    // ---- F1: the wave's 16 rows
+    h8 x[XS];
+    bool inRange = true;
+    {
+      pel8 o[XS], pv[XS];
+#pragma unroll
+      for (int s = 0; s < XS; s++)
+      {
+        o[s] = *reinterpret_cast<const pel8*>(org + (size_t)(16 * rtW + c) * d.org_stride + 32 * s + 8 * g);
+        pv[s] = pel8{ 0, 0, 0, 0, 0, 0, 0, 0 };
+        if (MODE == RC_CHAIN) pv[s] = *reinterpret_cast<const pel8*>(pred + (size_t)(16 * rtW + c) * d.pred_stride + 32 * s + 8 * g);
+      }
+#pragma unroll
+      for (int s = 0; s < XS; s++)
+#pragma unroll
+        for (int j = 0; j < 8; j++)
+        {
+          const int v = (int)o[s][j] - (int)pv[s][j];
+          inRange = inRange && v >= -1023 && v <= 1023;
+          x[s][j] = (_Float16)(short)v;
+        }
+    }
+    if (__builtin_amdgcn_ballot_w64(!inRange) != 0ull && lane == 0) red[2] = 1;
+    const int s1 = LW + bd + 6 - 15 + 2, s2 = LH + 6 + 2;
+    constexpr int NJ = S::RT == 4 ? 2 : 1;                  // frequency tiles of this wave in F1
+#pragma unroll
+    for (int j = 0; j < NJ; j++)
+    {
+      const int jf = S::RT == 4 ? j : jt;
+      f4 m1 = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+      for (int s = 0; s < XS; s++)
+        m1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(x[s], *reinterpret_cast<const h8*>(Th + (16 * jf + c) * (W + 8) + 32 * s + 8 * g), m1, 0, 0, 0);
+      _Float16 hi[4], lo[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++) rc_limbs(((int)m1[r] + (1 << (s1 - 1))) >> s1, hi[r], lo[r]);
+      *reinterpret_cast<h4*>(e1h + (16 * jf + c) * P1 + 16 * rtW + 4 * g) = h4{ hi[0], hi[1], hi[2], hi[3] };
+      *reinterpret_cast<h4*>(e1l + (16 * jf + c) * P1 + 16 * rtW + 4 * g) = h4{ lo[0], lo[1], lo[2], lo[3] };
+    }
+    __syncthreads();
+    if (red[2] != 0) return leave();
+
+    // ---- F2: tile (it, jt) of the coefficients
+    int cf[4];
+    {
+      f4 hi = { 0.f, 0.f, 0.f, 0.f }, lo = { 0.f, 0.f, 0.f, 0.f };
+#pragma unroll
+      for (int s = 0; s < HS; s++)
+      {
+        const h8 a = *reinterpret_cast<const h8*>(Tv + (16 * it + c) * (H + 8) + 32 * s + 8 * g);
+        hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, *reinterpret_cast<const h8*>(e1h + (16 * jt + c) * P1 + 32 * s + 8 * g), hi, 0, 0, 0);
+        lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a, *reinterpret_cast<const h8*>(e1l + (16 * jt + c) * P1 + 32 * s + 8 * g), lo, 0, 0, 0);
+      }
+#pragma unroll
+      for (int r = 0; r < 4; r++) cf[r] = ((((int)hi[r]) << 8) + (int)lo[r] + (1 << (s2 - 1))) >> s2;
+    }
+    const int tid = wv * 64 + lane;
+    if (MODE == RC_CHAIN)
+    {
+      const RcQ q = rc_qparams(W, H, d.qp, bd, d.intra_slice, d.sign_hiding);
+      const unsigned short* inv = dqInv + scanOff[(LW - 1) * 6 + (LH - 1)];
+      int lv[4], du[4], sum = 0;
+#pragma unroll
+      for (int r = 0; r < 4; r++) { int mag; lv[r] = rc_quant_one(q, cf[r], du[r], mag); sum += mag; }
+      const int cgIdx = (int)inv[(16 * it + 4 * g) * W + 16 * jt + (c & ~3)] >> 4;
+      int lastCg = rc_cg_nonzero(lv) ? cgIdx : -1;
+      lastCg = wave_max_i32(lastCg);
+      sum = wave_sum_i32(sum);
+      if (lane == 0) { atomicAdd(&red[0], sum); atomicMax(&red[1], lastCg); }
+      __syncthreads();                                      // (every wave has read its E1 operands: E2 may be written)
+      lastCg = red[1];
+      if (tid == 0) absSumOut[ti] = (unsigned)red[0];
+      if (q.sbh) rc_sbh_quad(lv, du, cf, cgIdx == lastCg, lane);
+      _Float16 hi[4], lo[4];
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+      {
+        level[(16 * it + 4 * g + r) * W + 16 * jt + c] = lv[r];
+        rc_limbs(rc_dequant_one(q, lv[r]), hi[r], lo[r]);
+      }
+      *reinterpret_cast<h4*>(e2h + (16 * jt + c) * P2 + 16 * it + 4 * g) = h4{ hi[0], hi[1], hi[2], hi[3] };
+      *reinterpret_cast<h4*>(e2l + (16 * jt + c) * P2 + 16 * it + 4 * g) = h4{ lo[0], lo[1], lo[2], lo[3] };
+    }
+    else
+    {
+#pragma unroll
+      for (int r = 0; r < 4; r++) level[(16 * it + 4 * g + r) * W + 16 * jt + c] = cf[r];
+    }
+    // zero-out region of the level array: columns >= 32 of the kept rows, then the rows >= 32
+    if (W == 64) for (int e = tid; e < 32 * 8; e += 256) *reinterpret_cast<int4v*>(level + (e >> 3) * 64 + 32 + 4 * (e & 7)) = z;
+    if (H == 64) for (int e = tid; e < 32 * W / 4; e += 256) *reinterpret_cast<int4v*>(level + 32 * W + 4 * e) = z;
+    if (MODE == RC_FWD)
+    {
+      __syncthreads();                                      // E1 is the next slot's scratch
+      return true;
+    }
+  }
+  else
+  {
+    bool fits = true;
+    _Float16 hi[4], lo[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++)
+    {
+      const int v = level[(16 * it + 4 * g + r) * W + 16 * jt + c];
+      fits = fits && v >= -32768 && v <= 32767;
+      rc_limbs(v, hi[r], lo[r]);
+    }
+    if (__builtin_amdgcn_ballot_w64(!fits) != 0ull && lane == 0) red[2] = 1;
+    *reinterpret_cast<h4*>(e2h + (16 * jt + c) * P2 + 16 * it + 4 * g) = h4{ hi[0], hi[1], hi[2], hi[3] };
+    *reinterpret_cast<h4*>(e2l + (16 * jt + c) * P2 + 16 * it + 4 * g) = h4{ lo[0], lo[1], lo[2], lo[3] };
+  }
+  __syncthreads();
+  if (MODE == RC_INV && red[2] != 0) return leave();
+
+  // ---- I1: Y1^T tiles (jt', rtW), both frequency tiles
+  int y1[2][4];
+  {
+    const h8 b = *reinterpret_cast<const h8*>(TvT + (16 * rtW + c) * (H + 8) + 8 * g);
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+    {
+      const f4 hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h8*>(e2h + (16 * j + c) * P2 + 8 * g), b, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+      const f4 lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(*reinterpret_cast<const h8*>(e2l + (16 * j + c) * P2 + 8 * g), b, f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; r++) y1[j][r] = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[r]) << 8) + (int)lo[r] + 256) >> 9);
+    }
+  }
+  // ---- I2 + reconstruction: the wave's row tile, its column tiles
+  {
+    const int s2i = (6 + 15 - 1) - bd + 2;
+    Pel* rec = recBase + d.rec_off;
+    h8 bh[1], bl[1];
+    rc_tile_frags<32>(bh, bl, y1);
+    constexpr int XSTEP = S::RT == 4 ? 1 : 2;
+#pragma unroll
+    for (int xi = 0; xi < S::CT / XSTEP; xi++)
+    {
+      const int xt = S::RT == 4 ? xi : 2 * xi + (wv & 1);
+      h8 a[1];
+      rc_mat_frags<32>(a, ThT, W + 8, 16 * xt + c, g);
+      const f4 hi = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bh[0], f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+      const f4 lo = __builtin_amdgcn_mfma_f32_16x16x32_f16(a[0], bl[0], f4{ 0.f, 0.f, 0.f, 0.f }, 0, 0, 0);
+      pel4 out;
+      pel4 pv = { 0, 0, 0, 0 };
+      if (MODE == RC_CHAIN) pv = *reinterpret_cast<const pel4*>(pred + (size_t)(16 * rtW + c) * d.pred_stride + 16 * xt + 4 * g);
+#pragma unroll
+      for (int r = 0; r < 4; r++)
+      {
+        const int resi = clip3(-(1 << 15), (1 << 15) - 1, ((((int)hi[r]) << 8) + (int)lo[r] + (1 << (s2i - 1))) >> s2i);
+        out[r] = MODE == RC_CHAIN ? (short)clip3(clpMin, clpMax, (int)pv[r] + (int)(short)resi) : (short)resi;
+      }
+      *reinterpret_cast<pel4*>(rec + (size_t)(16 * rtW + c) * d.rec_stride + 16 * xt + 4 * g) = out;
+    }
+  }
+  if (MODE == RC_CHAIN && wv == 0 && lane == 0) { red[0] = 0; red[1] = -1; }     // (read by every wave in front of the barrier above)
+  __syncthreads();                                          // E2 is the next slot's scratch
   return true;
 }
 
@@ -1312,32 +1548,6 @@ __device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, 
 }
 
 // ---------------------------------------------------------------------------------------------------
-// matrix-core kernels, one per TU size (their register needs differ): persistent waves, wave i takes the TUs i, i + waves, ... of the class
-// list -- a shared work counter would be one same-address atomic per TU (~12 ns each: 100 us for a 4K picture)
-template <int W, int H>
-__global__ __launch_bounds__(256, W * H >= 2048 ? 2 : 3) void rc_mfma_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase,
-                                                                        Pel* __restrict__ recBase, TCoeff* __restrict__ levelBase,
-                                                                        const RcDesc* __restrict__ descs, const int* __restrict__ count,
-                                                                        const int* __restrict__ list, int* __restrict__ fbCount,
-                                                                        int* __restrict__ fbList, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
-                                                                        const _Float16* __restrict__ image, const unsigned short* __restrict__ dqInv,
-                                                                        const int* __restrict__ scanOff)
-{
-  __shared__ __align__(16) _Float16 tab[RC_TAB_HALVES];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int total = count[0];
-  if ((int)blockIdx.x * 4 >= total) return;
-  rc_load_tables<W>(tab, image, tid);
-  if (H != W) rc_load_tables<H>(tab, image, tid);
-  __syncthreads();
-  for (int item = blockIdx.x * 4 + (tid >> 6); item < total; item += gridDim.x * 4)
-  {
-    const int ti = list[item];
-    const bool done = rc_tu_mfma<W, H, RC_CHAIN>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, dqInv, scanOff, lane);
-    if (!done && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti;                 // residual outside +-1023: the generic kernel takes it
-  }
-}
-
 // generic kernel: the class-`generic` list, then the fall-back list of the matrix-core kernels (TUs whose residual left +-1023)
 // The class-`generic` list holds TUs with a side of at most 8 (both sides >= 16 are matrix-core classes), i.e. at most 64 x 8 samples: 512-int
 // buffers, four waves per workgroup (eight times the waves per compute unit of a 4096-int single-wave form).  The fall-back list of the
@@ -1385,10 +1595,8 @@ __global__ __launch_bounds__(256) void rc_generic_kernel(const Pel* __restrict__
 // 4 x 4 and 8 x 8: lane groups of S lanes per TU, G = 64 / S TUs per wave.  Forward: lane = row (stage 1), transposed through LDS, lane = column
 // (stage 2, quantiser, de-quantiser, vertical inverse stage), transposed back, lane = row (horizontal inverse stage + reconstruction: the
 // prediction row is still in the lane's registers).
-struct RcSmallTab { int t[3][16 + 64]; int tt[3][16 + 64]; };       // per type: size 4 at 0, size 8 at 16; tt = transposes
-
 template <int S, int MODE>
-__device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
+__device__ __noinline__ void rc_small_group(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
                                                const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                                const RcSmallTab& tabs, int* tmpL, int lane)
@@ -1552,7 +1760,7 @@ __device__ __forceinline__ void rc_small_group(const RcDesc* __restrict__ descs,
 // in the horizontal stages (H rows), lane = column in the vertical stages and the quantiser (W columns; the other lanes of the group idle there).
 // The TU has two coefficient groups side by side (8 x 4) or one above the other (4 x 8): the group's scan index is its position.
 template <int W, int H, int MODE>
-__device__ __forceinline__ void rc_rect_group(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
+__device__ __noinline__ void rc_rect_group(const RcDesc* __restrict__ descs, const int* __restrict__ list, int cnt, int item,
                                               const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                               TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                               const RcSmallTab& tabs, int* tmpL, int lane)
@@ -1716,93 +1924,107 @@ __device__ __forceinline__ void rc_rect_group(const RcDesc* __restrict__ descs, 
   RC_WAVE_SYNC();
 }
 
-template <int S>
-__global__ __launch_bounds__(256, S == 4 ? 6 : 3) void rc_small_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
-                                                       TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs,
-                                                       const int* __restrict__ count, const int* __restrict__ list,
-                                                       unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax, VvcTrTables tb)
-{
-  __shared__ RcSmallTab tabs;
-  __shared__ int tmpAll[4][8 * 8 * 9];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int cnt = count[0];
-  constexpr int PER = S == 4 ? 16 : 8;                                          // TUs per wave item (S = 84 / 48: the 8 x 4 / 4 x 8 rectangles)
-  const int total = (cnt + PER - 1) / PER;
-  if ((int)blockIdx.x * 4 >= total) return;
-  for (int e = tid; e < 3 * 80; e += 256)
-  {
-    const int t = e / 80, o = e - t * 80, nsz = o < 16 ? 4 : 8, oo = o < 16 ? o : o - 16;
-    tabs.t[t][o] = tb.tr32[t * 5460 + (nsz * nsz - 4) / 3 + oo];
-    tabs.tt[t][o] = tb.tr32t[t * 5460 + (nsz * nsz - 4) / 3 + oo];
-  }
-  __syncthreads();
-  for (int item = blockIdx.x * 4 + wave; item < total; item += gridDim.x * 4)
-  {
-    if (S == 84)      rc_rect_group<8, 4, RC_CHAIN>(descs, list, cnt, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
-    else if (S == 48) rc_rect_group<4, 8, RC_CHAIN>(descs, list, cnt, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
-    else              rc_small_group<(S > 8 ? 8 : S), RC_CHAIN>(descs, list, cnt, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
-  }
-}
-
 // All five size classes in ONE launch.  Each class alone is bound by the latency of a TU, not by throughput (405 64x64 TUs are 405 waves:
 // 20 us; 6480 16x16 TUs: 14 us; ...), and kernels on one stream run one after the other (82 us for the five launches at 4K).  Here a workgroup
 // walks "slots" (four wave items of one class), longest classes first, so short items fill the machine while the long ones run.
+constexpr int RC_NORD = 25, RC_NCOOP = 4;                    // the first RC_NCOOP entries: both sides >= 32, the workgroup's four waves per TU (rc_tu_coop)
+__device__ __forceinline__ int rc_ord_g(int k)               // TUs per wave item: lane groups 64 / S, packed tiles: 16 / the short side
+{
+  return k == 6 || k == 15 || k == 16 ? 8 : k == 14 ? 16 : (k == 12 || k == 13 || k == 19 || k == 20 || k >= 23) ? 4 : k >= 10 ? 2 : 1;
+}
+// class / range of a slot: lane j holds end[j]; the ends ascend, so the number of lanes whose end is at or below the slot is the class ordinal
+__device__ __forceinline__ void rc_slot_class(const int* sCnt, const int* sEnd, int slot, int lane, int& k, int& start, int& cntK, int& endK)
+{
+  const int eL = sEnd[lane < RC_NORD ? lane : RC_NORD - 1], cL = sCnt[lane < RC_NORD ? lane : RC_NORD - 1];
+  k = (int)__popcll(__builtin_amdgcn_ballot_w64(lane < RC_NORD - 1 && slot >= eL));
+  start = k ? __builtin_amdgcn_readlane(eL, k - 1) : 0;
+  cntK = __builtin_amdgcn_readlane(cL, k); endK = __builtin_amdgcn_readlane(eL, k);
+}
 template <int MODE>
-__global__ __launch_bounds__(256, MODE == RC_CHAIN ? 2 : 3) void rc_chain_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+__global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                           TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs, int n,
                                                           const int* __restrict__ hdr, const int* __restrict__ lists, int* __restrict__ fbCount,
                                                           int* __restrict__ fbList, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                                           const _Float16* __restrict__ image, VvcTrTables tb)
 {
   __shared__ __align__(16) _Float16 tab[RC_TAB_HALVES];
-  __shared__ RcSmallTab tabs;
-  __shared__ int tmpAll[4][8 * 8 * 9];                        // per wave: transposes of the lane-group forms / the TU list of a packed tile
+  __shared__ __align__(16) RcSmallTab tabs;
+  __shared__ __align__(16) int tmpAll[4][8 * 8 * 9];          // per wave: transposes of the lane-group forms / the TU list of a packed tile; all of it: the limb planes of a co-operative TU
+  __shared__ int red[4];                                      // co-operative TUs: abs sum, last coefficient group, range flag (rc_tu_coop)
+  static_assert(sizeof(tmpAll) >= RC_EX_HALVES * sizeof(_Float16), "limb planes of rc_tu_coop");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too: list entries and descriptors of single-TU items arrive through the scalar cache
   // slots (four wave items of one entry) in the order below: the longest items first, so that the short ones fill the machine while they run.
   // 8x8 / 8x4 / 4x8 / 4x4 stay with the lane groups: as packed tiles (exact as well) they are slower (8M samples: 8x8 0.164 vs 0.143 ms, 4x4 0.175
   // vs 0.142) -- a lane of a tile touches four 8-byte row pieces of its TU, a lane of a group one whole row
-  constexpr int NORD = 25;
+  constexpr int NORD = RC_NORD, NCOOP = RC_NCOOP;
   constexpr int ordCls[NORD] = { RC_C64, RC_R6432, RC_R3264, RC_C32, RC_R6416, RC_R1664, RC_C8, RC_R3216, RC_R1632, RC_C16,
                                  RC_P168, RC_P816, RC_P164, RC_P416, RC_C4, RC_R84, RC_R48, RC_P328, RC_P832, RC_P324, RC_P432,
                                  RC_P648, RC_P864, RC_P644, RC_P464 };
-  constexpr int ordG[NORD] = { 1, 1, 1, 1, 1, 1, 8, 1, 1, 1, 2, 2, 4, 4, 16, 8, 8, 2, 2, 4, 4, 2, 2, 4, 4 };   // TUs per wave item: lane groups 64 / S, packed tiles: 16 / the short side
-  int cnt[NORD], items[NORD], end[NORD];
+  constexpr int ordG[NORD] = { 1, 1, 1, 1, 1, 1, 8, 1, 1, 1, 2, 2, 4, 4, 16, 8, 8, 2, 2, 4, 4, 2, 2, 4, 4 };   // TUs per wave item (= rc_ord_g)
+  // class counts and slot ranges live in LDS: as 75 scalars they were 143 spilled scalar registers around every body (round 6)
+  __shared__ int sCnt[NORD], sEnd[NORD];
   int total = 0;
 #pragma unroll
   for (int k = 0; k < NORD; k++)
   {
-    cnt[k] = hdr[ordCls[k]];
-    items[k] = (cnt[k] + ordG[k] - 1) / ordG[k];
-    total += (items[k] + 3) >> 2;
-    end[k] = total;
+    const int ck = hdr[ordCls[k]], ik = (ck + ordG[k] - 1) / ordG[k];
+    total += k < NCOOP ? ik : (ik + 3) >> 2;                  // co-operative classes: one TU per slot (the four waves together)
+    if (tid == 0) { sCnt[k] = ck; sEnd[k] = total; }
   }
   if ((int)blockIdx.x >= total) return;
-  rc_load_all_tables(tab, image, tid);
-  rc_load_small_tables(tab, image, tid);
-  for (int e = tid; e < 3 * 80; e += 256)
+#ifdef RC_DIAG
+  unsigned long long dg[24]; int dgk[12]; int dgn = 0;
+  const bool dgOn = (blockIdx.x == 37 || blockIdx.x == 500 || blockIdx.x == 767) && tid == 0;
+  if (dgOn) dg[0] = __builtin_amdgcn_s_memtime();
+#endif
+  if (tid == 0) { red[0] = 0; red[1] = -1; red[2] = 0; }
   {
-    const int t = e / 80, o = e - t * 80, nsz = o < 16 ? 4 : 8, oo = o < 16 ? o : o - 16;
-    tabs.t[t][o] = tb.tr32[t * 5460 + (nsz * nsz - 4) / 3 + oo];
-    tabs.tt[t][o] = tb.tr32t[t * 5460 + (nsz * nsz - 4) / 3 + oo];
+    // the table image (f16 matrices + the int32 4- / 8-point matrices) as ONE run of 16-byte loads, all in flight before the first store.  In-kernel stamps
+    // (RC_DIAG): 16 - 24 k cycles until the barrier below with three workgroups per CU -- every workgroup of an XCD asks its L2 for the same 41 KB at the
+    // same time; starting at staggered offsets was slower (70.6 vs 67.3 us), the phase-by-phase copy of round 5 the same (67.9 vs 68.5)
+    constexpr int PER = (RC_IMG_U4 + 255) / 256;
+    uint4 v[PER];
+    const uint4* src = reinterpret_cast<const uint4*>(image);
+#pragma unroll
+    for (int u = 0; u < PER; u++) if (tid + 256 * u < RC_IMG_U4) v[u] = src[tid + 256 * u];
+#pragma unroll
+    for (int u = 0; u < PER; u++)
+    {
+      const int i = tid + 256 * u;
+      if (i < RC_TAB_HALVES / 8) reinterpret_cast<uint4*>(tab)[i] = v[u];
+      else if (i < RC_IMG_U4) reinterpret_cast<uint4*>(&tabs)[i - RC_TAB_HALVES / 8] = v[u];
+    }
   }
   __syncthreads();
+#ifdef RC_DIAG
+  if (dgOn) dg[1] = __builtin_amdgcn_s_memtime();
+#endif
   for (int slot = blockIdx.x; slot < total; slot += gridDim.x)
   {
-    int k = 0, start = 0;
-#pragma unroll
-    for (int j = 0; j < NORD - 1; j++) if (slot >= end[j]) { k = j + 1; start = end[j]; }
-    const int item = (slot - start) * 4 + wave;
+#ifdef RC_DIAG
+    if (dgOn && dgn < 11) { dg[2 + dgn] = __builtin_amdgcn_s_memtime(); }
+#endif
+    int k, start, cntK, endK;
+    rc_slot_class(sCnt, sEnd, slot, lane, k, start, cntK, endK);
+    const int gK = rc_ord_g(k);
+    const int itemsK = (cntK + gK - 1) / gK;
+    const int item = k < NCOOP ? slot - start : (slot - start) * 4 + wave;
     bool done = true;
     int ti = 0;
 #define RC_MF(K, W_, H_)                                                                                                                      \
-    case K: if (item < cnt[K]) { ti = __builtin_amdgcn_readfirstlane(lists[(size_t)ordCls[K] * n + item]);                                    \
-        done = rc_tu_mfma<W_, H_, MODE>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane); } break;
+    case K: if (item < cntK) { ti = __builtin_amdgcn_readfirstlane(lists[(size_t)ordCls[K] * n + item]);                                    \
+        done = rc_tu_mfma_call<W_, H_, MODE>(descs, ti, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane); } break;
 #define RC_PK(K, W_, H_)                                                                                                                      \
-    case K: if (item < items[K]) rc_tile_packed<W_, H_, MODE>(descs, lists + (size_t)ordCls[K] * n, cnt[K], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, \
+    case K: if (item < itemsK) rc_tile_packed<W_, H_, MODE>(descs, lists + (size_t)ordCls[K] * n, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, \
                                                         clpMax, tab, tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
+#define RC_CO(K, W_, H_)                                                                                                                      \
+    case K: { ti = __builtin_amdgcn_readfirstlane(lists[(size_t)ordCls[K] * n + item]);                                                       \
+        done = rc_tu_coop<W_, H_, MODE>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, \
+                                        reinterpret_cast<_Float16*>(&tmpAll[0][0]), red, wave, lane);                                         \
+        if (wave != 0) done = true; } break;                 /* (one fall-back entry per TU) */
     switch (k)
     {
-    RC_MF(0, 64, 64) RC_MF(1, 64, 32) RC_MF(2, 32, 64) RC_MF(3, 32, 32) RC_MF(4, 64, 16) RC_MF(5, 16, 64) RC_MF(7, 32, 16) RC_MF(8, 16, 32)
+    RC_CO(0, 64, 64) RC_CO(1, 64, 32) RC_CO(2, 32, 64) RC_CO(3, 32, 32) RC_MF(4, 64, 16) RC_MF(5, 16, 64) RC_MF(7, 32, 16) RC_MF(8, 16, 32)
     case 9:
     {
       // 16x16, the most numerous matrix-core class: the workgroup's consecutive slots of this class are walked HERE, with the list entry of the
@@ -1814,9 +2036,9 @@ __global__ __launch_bounds__(256, MODE == RC_CHAIN ? 2 : 3) void rc_chain_kernel
       const int* lst = lists + (size_t)ordCls[9] * n;
       const int G4 = 4 * (int)gridDim.x;
       int it = item;
-      if (it >= cnt[9]) break;
+      if (it >= cntK) break;
       int ti0 = __builtin_amdgcn_readfirstlane(lst[it]);
-      int tiv1 = it + G4 < cnt[9] ? lst[it + G4 + vz] : 0;
+      int tiv1 = it + G4 < cntK ? lst[it + G4 + vz] : 0;
       uint4 dq = reinterpret_cast<const uint4*>(descs + ti0)[(lane & 3) + vz];
       for (;;)
       {
@@ -1830,12 +2052,12 @@ __global__ __launch_bounds__(256, MODE == RC_CHAIN ? 2 : 3) void rc_chain_kernel
             w[4 * q + 2] = __builtin_amdgcn_readlane(dq.z, q); w[4 * q + 3] = __builtin_amdgcn_readlane(dq.w, q);
           }
         }
-        const bool more = it + G4 < cnt[9] && slot + (int)gridDim.x < end[9];          // the next slot of this workgroup is of this class too
+        const bool more = it + G4 < cntK && slot + (int)gridDim.x < endK;          // the next slot of this workgroup is of this class too
         const int ti1 = __builtin_amdgcn_readfirstlane(tiv1);
         if (more)
         {
           dq = reinterpret_cast<const uint4*>(descs + ti1)[(lane & 3) + vz];
-          tiv1 = it + 2 * G4 < cnt[9] ? lst[it + 2 * G4 + vz] : 0;
+          tiv1 = it + 2 * G4 < cntK ? lst[it + 2 * G4 + vz] : 0;
         }
         const bool ok = rc_tu_mfma<16, 16, MODE>(dCur, orgBase, predBase, recBase, levelBase, absSumOut, ti0, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
         if (!ok && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti0;
@@ -1845,23 +2067,36 @@ __global__ __launch_bounds__(256, MODE == RC_CHAIN ? 2 : 3) void rc_chain_kernel
       break;
     }
     RC_PK(10, 16, 8) RC_PK(11, 8, 16) RC_PK(12, 16, 4) RC_PK(13, 4, 16)
-    case 6: if (item < items[6]) rc_small_group<8, MODE>(descs, lists + (size_t)RC_C8 * n, cnt[6], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
-    case 14: if (item < items[14]) rc_small_group<4, MODE>(descs, lists + (size_t)RC_C4 * n, cnt[14], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
-    case 15: if (item < items[15]) rc_rect_group<8, 4, MODE>(descs, lists + (size_t)RC_R84 * n, cnt[15], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
-    case 16: if (item < items[16]) rc_rect_group<4, 8, MODE>(descs, lists + (size_t)RC_R48 * n, cnt[16], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 6: if (item < itemsK) rc_small_group<8, MODE>(descs, lists + (size_t)RC_C8 * n, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 14: if (item < itemsK) rc_small_group<4, MODE>(descs, lists + (size_t)RC_C4 * n, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 15: if (item < itemsK) rc_rect_group<8, 4, MODE>(descs, lists + (size_t)RC_R84 * n, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 16: if (item < itemsK) rc_rect_group<4, 8, MODE>(descs, lists + (size_t)RC_R48 * n, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
 #define RC_PK32(K, F)                                                                                                                         \
-    case K: if (item < items[K]) F(descs, lists + (size_t)ordCls[K] * n, cnt[K], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,     \
+    case K: if (item < itemsK) F(descs, lists + (size_t)ordCls[K] * n, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,     \
                                    tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
     RC_PK32(17, (rc_tile_packed_wl<32, 8, MODE>)) RC_PK32(18, (rc_tile_packed_hl<8, 32, MODE>)) RC_PK32(19, (rc_tile_packed_wl<32, 4, MODE>)) RC_PK32(20, (rc_tile_packed_hl<4, 32, MODE>))
     RC_PK32(21, (rc_tile_packed_wl<64, 8, MODE>)) RC_PK32(22, (rc_tile_packed_hl<8, 64, MODE>)) RC_PK32(23, (rc_tile_packed_wl<64, 4, MODE>))
-    default: if (item < items[24]) rc_tile_packed_hl<4, 64, MODE>(descs, lists + (size_t)RC_P464 * n, cnt[24], item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,
+    default: if (item < itemsK) rc_tile_packed_hl<4, 64, MODE>(descs, lists + (size_t)RC_P464 * n, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,
                                                             tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
 #undef RC_PK32
     }
 #undef RC_MF
+#undef RC_CO
 #undef RC_PK
     if (!done && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti;               // residual outside +-1023: the generic kernel takes it
+#ifdef RC_DIAG
+    if (dgOn && dgn < 11) { dgk[dgn] = k; dgn++; }
+#endif
   }
+#ifdef RC_DIAG
+  if (dgOn)
+  {
+    dg[2 + dgn] = __builtin_amdgcn_s_memtime();
+    printf("[rc diag wg %d wave %d] start->tables %llu cycles; slots:", (int)blockIdx.x, tid >> 6, dg[1] - dg[0]);
+    for (int i = 0; i < dgn; i++) printf(" k%d:%llu", dgk[i], dg[3 + i] - dg[2 + i]);
+    printf(" | total %llu\n", dg[2 + dgn] - dg[0]);
+  }
+#endif
 }
 
 }  // namespace
@@ -1879,9 +2114,9 @@ const _Float16* vvcgpu_mfma_image(const VvcTrTables& tb)
     // built on the null stream with blocking calls (not on the caller's stream: that would serialise every other thread's first call behind
     // a stream of unknown length); the buffer is released again if any step fails
     void* p = nullptr;
-    hipError_t e = hipMalloc(&p, RC_TAB_HALVES * sizeof(_Float16));
+    hipError_t e = hipMalloc(&p, (size_t)RC_IMG_U4 * 16);
     if (e != hipSuccess) { vvcgpu_set_error("mfma image: hipMalloc failed: %s", hipGetErrorString(e)); return nullptr; }
-    e = hipMemset(p, 0, RC_TAB_HALVES * sizeof(_Float16));          // row padding
+    e = hipMemset(p, 0, (size_t)RC_IMG_U4 * 16);                    // row padding
     if (e == hipSuccess)
     {
       hipLaunchKernelGGL(rc_build_tables_kernel, dim3(16), dim3(256), 0, (hipStream_t)0, static_cast<_Float16*>(p), tb.tr32, tb.tr32t);
@@ -1925,44 +2160,19 @@ static int rc_chain_launch(int mode, const vvc_pel* org_base, const vvc_pel* pre
   int* lists = ws;
   int* fbCount = hdr + RC_FB;
   int* fbList = lists + (size_t)RC_NCLS * n;
-  static const int separate = getenv("VVCGPU_RC_SEPARATE") ? 1 : 0;           // A/B timing switch: one launch per size class (chain mode only)
-  static const int packedOff = getenv("VVCGPU_RC_NO_PACKED") ? 1 : 0;         // A/B timing switch: the packed-tile shapes on the generic path
-  const bool sep = separate && mode == RC_CHAIN;
   const dim3 cg(n < 1024 * RC_CLS_WGS ? cdiv(n, 1024) : RC_CLS_WGS);
   if (mode == RC_CHAIN)
-    hipLaunchKernelGGL(rc_classify_kernel<false>, cg, dim3(1024), 0, st, descs_raw, n, hdr, lists, abs_sum, counters + VVC_CTR_INTS * (cur ^ 1), !sep && !packedOff, conv);
+    hipLaunchKernelGGL(rc_classify_kernel<false>, cg, dim3(1024), 0, st, descs_raw, n, hdr, lists, abs_sum, counters + VVC_CTR_INTS * (cur ^ 1), true, conv);
   else
-    hipLaunchKernelGGL(rc_classify_kernel<true>, cg, dim3(1024), 0, st, descs_raw, n, hdr, lists, abs_sum, counters + VVC_CTR_INTS * (cur ^ 1), !packedOff, conv);
+    hipLaunchKernelGGL(rc_classify_kernel<true>, cg, dim3(1024), 0, st, descs_raw, n, hdr, lists, abs_sum, counters + VVC_CTR_INTS * (cur ^ 1), true, conv);
   VVC_LAUNCH_CHECK_COUNTERS(st);
   // (measured: forking the size classes onto library-owned side streams and joining them with events is SLOWER than launching them back to
   // back on the caller's stream, 0.158 vs 0.115 ms at 4K -- a cross-stream event costs more than these 20 us kernels gain)
-  if (!sep)
   {
-#define RC_CHAIN_LAUNCH(M) hipLaunchKernelGGL(rc_chain_kernel<M>, dim3(M == RC_CHAIN ? 512 : 768), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, fbCount, \
+#define RC_CHAIN_LAUNCH(M) hipLaunchKernelGGL(rc_chain_kernel<M>, dim3(768), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, fbCount, \
                                              fbList, abs_sum, bit_depth, clp_min, clp_max, image, tb)
     if (mode == RC_CHAIN) RC_CHAIN_LAUNCH(RC_CHAIN); else if (mode == RC_FWD) RC_CHAIN_LAUNCH(RC_FWD); else RC_CHAIN_LAUNCH(RC_INV);
 #undef RC_CHAIN_LAUNCH
-    VVC_LAUNCH_CHECK_COUNTERS(st);
-  }
-  else
-  {
-    const int wgM = cdiv(n, 4) < 1024 ? cdiv(n, 4) : 1024;
-#define RC_LAUNCH_MFMA(W_, H_, CLS)                                                                                                             \
-    hipLaunchKernelGGL((rc_mfma_kernel<W_, H_>), dim3(wgM), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + CLS,         \
-                       lists + (size_t)CLS * n, fbCount, fbList, abs_sum, bit_depth, clp_min, clp_max, image, tb.dqInv, tb.scanOff)
-    RC_LAUNCH_MFMA(64, 64, RC_C64); RC_LAUNCH_MFMA(64, 32, RC_R6432); RC_LAUNCH_MFMA(32, 64, RC_R3264);
-    RC_LAUNCH_MFMA(32, 32, RC_C32); RC_LAUNCH_MFMA(64, 16, RC_R6416); RC_LAUNCH_MFMA(16, 64, RC_R1664);
-    RC_LAUNCH_MFMA(32, 16, RC_R3216); RC_LAUNCH_MFMA(16, 32, RC_R1632); RC_LAUNCH_MFMA(16, 16, RC_C16);
-#undef RC_LAUNCH_MFMA
-    const int wg8 = cdiv(n, 32) < 2048 ? cdiv(n, 32) : 2048, wg4 = cdiv(n, 64) < 2048 ? cdiv(n, 64) : 2048;
-    hipLaunchKernelGGL(rc_small_kernel<8>, dim3(wg8), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_C8,
-                       lists + (size_t)RC_C8 * n, abs_sum, bit_depth, clp_min, clp_max, tb);
-    hipLaunchKernelGGL(rc_small_kernel<4>, dim3(wg4), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_C4,
-                       lists + (size_t)RC_C4 * n, abs_sum, bit_depth, clp_min, clp_max, tb);
-    hipLaunchKernelGGL(rc_small_kernel<84>, dim3(wg8), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_R84,
-                       lists + (size_t)RC_R84 * n, abs_sum, bit_depth, clp_min, clp_max, tb);
-    hipLaunchKernelGGL(rc_small_kernel<48>, dim3(wg8), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_R48,
-                       lists + (size_t)RC_R48 * n, abs_sum, bit_depth, clp_min, clp_max, tb);
     VVC_LAUNCH_CHECK_COUNTERS(st);
   }
   const int wgS = cdiv(n, 4) < 768 ? cdiv(n, 4) : 768, wgG = n < 512 ? n : 512;

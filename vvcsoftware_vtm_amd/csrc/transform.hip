@@ -775,76 +775,6 @@ __device__ __forceinline__ unsigned dq_compose(unsigned first, unsigned then)   
   return r;
 }
 
-__global__ __launch_bounds__(256) void dequant_kernel(const TCoeff* __restrict__ levelBase, TCoeff* __restrict__ coeffBase,
-                                                      const vvcgpu_dqtr_desc* __restrict__ descs, int n, int bd)
-{
-  const int lane = threadIdx.x & 63;
-  const int ti = blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (ti >= n) return;
-  const vvcgpu_dqtr_desc d = descs[ti];
-  const int w = d.w, h = d.h, cnt = w * h, lw = ilog2(w), lh = ilog2(h);
-  const TCoeff* level = levelBase + d.level_off;
-  TCoeff* out = coeffBase + d.level_off;
-  const int transformShift = 15 - bd - ((lw + lh) >> 1);
-  const bool sqrt2 = ((lw + lh) & 1) != 0;
-  const long long minT = -(1 << 15), maxT = (1 << 15) - 1;
-  if (!d.dep_quant)
-  {
-    const int per = d.qp / 6, rem = d.qp - 6 * per;
-    const int rightShift = (sqrt2 ? 8 : 0) + (6 - (transformShift + per));
-    const int invq = rem == 0 ? 40 : rem == 1 ? 45 : rem == 2 ? 51 : rem == 3 ? 57 : rem == 4 ? 64 : 72;
-    const long long scale = (long long)invq * (sqrt2 ? 181 : 1);
-    const int targetBits = min(16, 32 + rightShift - 7);
-    const long long inMin = -(1ll << (targetBits - 1)), inMax = (1ll << (targetBits - 1)) - 1;
-    for (int i = lane; i < cnt; i += 64)
-    {
-      const long long c = min(max((long long)level[i], inMin), inMax);
-      const long long v = rightShift > 0 ? (c * scale + (1ll << (rightShift - 1))) >> rightShift : (c * scale) << -rightShift;
-      out[i] = (TCoeff)min(max(v, minT), maxT);
-    }
-    return;
-  }
-  const unsigned short* scan = d_scan + d_scanOff[(lw - 1) * 6 + (lh - 1)];
-  const int qpDQ = d.qp + 1, qpPer = qpDQ / 6, qpRem = qpDQ - 6 * qpPer;
-  int shift = 6 + 1 - qpPer - transformShift + (sqrt2 ? 8 : 0);
-  const int invq = qpRem == 0 ? 40 : qpRem == 1 ? 45 : qpRem == 2 ? 51 : qpRem == 3 ? 57 : qpRem == 4 ? 64 : 72;
-  long long invQScale = (long long)invq * (sqrt2 ? 181 : 1);
-  if (shift < 0) { invQScale <<= -shift; shift = 0; }
-  const long long add = (1ll << shift) >> 1;
-  // lane l owns processing steps t in [l * C, (l + 1) * C), step t = scan index cnt - 1 - t
-  const int C = (cnt + 63) >> 6;
-  const int t0 = lane * C, t1 = min(t0 + C, cnt);
-  constexpr unsigned F0 = 0xD8u, F1 = 0x72u, ID = 0xE4u;     // parity 0: 0->0 1->2 2->1 3->3; parity 1: 0->2 1->0 2->3 3->1 (from 32040)
-  unsigned m = ID;
-  for (int t = t0; t < t1; t++)
-  {
-    const int lv = level[scan[cnt - 1 - t]];
-    m = dq_compose(m, (lv & 1) ? F1 : F0);
-  }
-  unsigned incl = m;                                         // inclusive scan over the lanes
-#pragma unroll
-  for (int o = 1; o < 64; o <<= 1)
-  {
-    const unsigned prev = __shfl_up(incl, o);
-    if (lane >= o) incl = dq_compose(prev, incl);
-  }
-  const unsigned excl = __shfl_up(incl, 1);
-  int state = lane == 0 ? 0 : (int)(excl & 3);               // entry state = (maps of all earlier lanes)(0)
-  for (int t = t0; t < t1; t++)
-  {
-    const int pos = scan[cnt - 1 - t];
-    const int lv = level[pos];
-    long long v = 0;
-    if (lv)
-    {
-      const long long qIdx = ((long long)lv << 1) + (lv > 0 ? -(state >> 1) : (state >> 1));
-      v = min(max((qIdx * invQScale + add) >> shift, minT), maxT);
-    }
-    out[pos] = (TCoeff)v;
-    state = (32040 >> ((state << 2) + ((lv & 1) << 1))) & 3;
-  }
-}
-
 // ---------------------------------------------------------------------------------------------------
 // N1 in ONE launch: de-quantiser and inverse transform of a TU in the same wave, the de-quantised coefficients in LDS (the separate form above
 // wrote them to a workspace in HBM and read them back in a second and third launch).  A workgroup takes `per` consecutive descriptors and serves
@@ -2373,7 +2303,7 @@ __global__ __launch_bounds__(256) void rdoq_kernel(const TCoeff* __restrict__ co
 
 static bool g_tablesUploaded[64] = { false };
 static std::mutex g_tablesMutex;            // the C ABI may be entered from several host threads: one uploads, the others wait
-static const int g_smallGrid = getenv("VVCGPU_TR_SMALLGRID") ? atoi(getenv("VVCGPU_TR_SMALLGRID")) : 1280;   // tuning switch
+constexpr int g_smallGrid = 1280;                  // workgroups of the small-TU kernels (swept in round 2)
 
 // diagonal 4x4-grouped coefficient scan (Rom.cpp:357-405): groups of 4x4 (2x2 when a side is 2) visited along the diagonals
 // x + y = d from the bottom-left end upwards, the positions inside a group likewise
@@ -2450,8 +2380,8 @@ static int ensure_tables()
   return VVCGPU_OK;
 }
 
-// A/B switch (read per call): VVCGPU_TR_NO_MFMA=1 keeps every large TU on the dot2 kernels
-static int tr_use_mfma() { return getenv("VVCGPU_TR_NO_MFMA") ? 0 : 1; }
+// VVCGPU_NO_MFMA=1 (common.h) keeps every large TU on the dot2 kernels
+static int tr_use_mfma() { return vvcgpu_no_mfma() ? 0 : 1; }
 
 static int check_descs_args(const void* a, const void* b, const void* d, int n, int bd, const char* who)
 {
@@ -2495,11 +2425,9 @@ int vvcgpu_tr_fwd_batch(const vvc_pel* resi_base, vvc_coef* coeff_base, const vv
   // long calls: ONE launch of the residual chain's bodies in forward-only mode (packed matrix-core tiles for TUs with a 4- / 8-point side, lane groups
   // for 8x8 and smaller) instead of the small / matrix-core / dot2 kernels in a row -- on a real encoder's call mix those three were each bound by
   // their own per-wave latency (profiles/r04_shape_mix.txt)
-  static const int chainMode = getenv("VVCGPU_TR_CHAIN") ? atoi(getenv("VVCGPU_TR_CHAIN")) : -1;       // A/B timing switch: 0 never, 1 always
-  if (chainMode < 0 ? n >= 16384 : chainMode != 0) return vvcgpu_tr_chain_launch(1, resi_base, nullptr, coeff_base, descs, n, bit_depth, stream);
+  if (n >= 16384 && tr_use_mfma()) return vvcgpu_tr_chain_launch(1, resi_base, nullptr, coeff_base, descs, n, bit_depth, stream);
   // long calls: the small TUs are binned on the device as well and the small kernel walks the bin lists (see small_setup)
-  static const int orderMode = getenv("VVCGPU_TR_ORDER") ? atoi(getenv("VVCGPU_TR_ORDER")) : -1;       // A/B timing switch: 0 never, 1 always
-  const bool ordered = orderMode < 0 ? n >= 16384 : orderMode != 0;
+  const bool ordered = n >= 16384;
   int* ws = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * ((ordered ? 6 : 2) * (size_t)n + 2)));   // cached per-stream scratch: the lists of large (and small) TUs
   if (!ws) return VVCGPU_E_DEVICE;
   VVC_HIP(hipMemsetAsync(ws, 0, 2 * sizeof(int), st));
@@ -2535,13 +2463,11 @@ int vvcgpu_tr_inv_batch(const vvc_coef* coeff_base, vvc_pel* resi_base, const vv
   const _Float16* image = vvcgpu_mfma_image(tb);
   if (!image) return VVCGPU_E_DEVICE;
   // long calls: the residual chain's bodies in inverse-only mode (see vvcgpu_tr_fwd_batch)
-  static const int chainMode = getenv("VVCGPU_TR_CHAIN") ? atoi(getenv("VVCGPU_TR_CHAIN")) : -1;       // A/B timing switch: 0 never, 1 always
   // (measured on the real call mix: 0.048 vs 0.054 ms at 35 k TUs, 0.126 vs 0.089 at 141 k -- there the three kernels' own latencies are amortised and their
   // lane-group forms run at five waves per SIMD against the chain kernel's three)
-  if (chainMode < 0 ? (n >= 16384 && n < 65536) : chainMode != 0) return vvcgpu_tr_chain_launch(2, nullptr, resi_base, const_cast<vvc_coef*>(coeff_base), descs, n, bit_depth, stream);
+  if (n >= 16384 && n < 65536 && tr_use_mfma()) return vvcgpu_tr_chain_launch(2, nullptr, resi_base, const_cast<vvc_coef*>(coeff_base), descs, n, bit_depth, stream);
   // long calls: the small TUs are binned on the device as well and the small kernel walks the bin lists (see small_setup)
-  static const int orderMode = getenv("VVCGPU_TR_ORDER") ? atoi(getenv("VVCGPU_TR_ORDER")) : -1;       // A/B timing switch: 0 never, 1 always
-  const bool ordered = orderMode < 0 ? n >= 16384 : orderMode != 0;
+  const bool ordered = n >= 16384;
   int* ws = static_cast<int*>(vvcgpu_scratch(st, sizeof(int) * ((ordered ? 6 : 2) * (size_t)n + 2)));   // cached per-stream scratch: the lists of large (and small) TUs
   if (!ws) return VVCGPU_E_DEVICE;
   VVC_HIP(hipMemsetAsync(ws, 0, 2 * sizeof(int), st));
@@ -2573,14 +2499,6 @@ int vvcgpu_dequant_tr_inv_batch(const vvc_coef* level_base, vvc_pel* resi_base, 
   const int rt = ensure_tables();
   if (rt) return rt;
   hipStream_t st = (hipStream_t)stream;
-  static const int separate = getenv("VVCGPU_DQTR_SEPARATE") ? 1 : 0;         // A/B timing switch: the former three-step form (needs coeff_out)
-  if (separate && coeff_out)
-  {
-    hipLaunchKernelGGL(dequant_kernel, dim3(cdiv(n, 4)), dim3(256), 0, st, level_base, coeff_out, descs, n, bit_depth);
-    VVC_LAUNCH_CHECK();
-    // the descriptor is binary compatible with vvcgpu_tr_desc: the inverse transforms read the de-quantised coefficients at level_off
-    return vvcgpu_tr_inv_batch(coeff_out, resi_base, reinterpret_cast<const vvcgpu_tr_desc*>(descs), n, bit_depth, stream);
-  }
   VvcTrTables tb;
   const int rtb = vvcgpu_tr_tables(&tb);
   if (rtb) return rtb;
@@ -2589,11 +2507,9 @@ int vvcgpu_dequant_tr_inv_batch(const vvc_coef* level_base, vvc_pel* resi_base, 
   // descriptors per workgroup: 64 when the batch is long (lane-group TUs need many per wave), fewer when that would leave compute units idle
   int per = SM_DESCS;
   while (per > 4 && cdiv(n, per) < 1024) per >>= 1;
-  if (const char* e = getenv("VVCGPU_DQTR_PER")) { const int v = atoi(e); if (v == 4 || v == 8 || v == 16 || v == 32 || v == 64) per = v; }   // tuning switch
   const int nb = cdiv(n, per);
   // calls long enough to fill workgroups with one phase each are put into class order on the device first (dqtr_classify_kernel)
-  static const int orderMode = getenv("VVCGPU_DQTR_ORDER") ? atoi(getenv("VVCGPU_DQTR_ORDER")) : -1;   // A/B timing switch: 0 never, 1 always
-  const bool ordered = orderMode < 0 ? n >= 16384 : orderMode != 0;          // shorter calls: the extra launch (~15 us) costs more than the order gains
+  const bool ordered = n >= 16384;                                           // shorter calls: the extra launch (~15 us) costs more than the order gains
   if (ordered)
   {
     int* lists = static_cast<int*>(vvcgpu_scratch(st, (size_t)DQC_NCLS * n * sizeof(int)));

@@ -686,10 +686,9 @@ int vvcgpu_tz_search_batch(const vvc_pel* org, int org_stride, const vvc_pel* re
   // Split form (cfg.uniform_pu = h << 16 | w: the caller states that EVERY PU of the batch is w x h with 2:1 row sub-sampling): the raster stage,
   // 86 % of the probes of a search that enters it, runs as the quad raster kernel of dist.hip between two launches of the state machine --
   // the in-kernel raster round works one wavefront per PU at ~8 % of the v_sad_u16 issue rate, the raster kernel at ~60 %.
-  static const int splitOff = getenv("VVCGPU_TZ_NO_SPLIT") ? 1 : 0;           // A/B timing switch
   const int uw = c.uniform_pu & 0xFFFF, uh = (c.uniform_pu >> 16) & 0xFFFF;
   const int gridMax = (2 * c.search_range) / 5 + 1;
-  if (!splitOff && c.uniform_pu != 0 && (uw == 16 || uw == 32 || uw == 64) && (uh == 16 || uh == 32 || uh == 64) && gridMax <= 40 &&
+  if (c.uniform_pu != 0 && (uw == 16 || uw == 32 || uw == 64) && (uh == 16 || uh == 32 || uh == 64) && gridMax <= 40 &&
       (org_stride & 1) == 0 && (ref_stride & 7) == 0 && ((uintptr_t)org & 3) == 0 && ((uintptr_t)ref & 15) == 0)
   {
     const size_t packedDw = (size_t)n * 2 * (uh >> 1) * (uw >> 1);

@@ -55,7 +55,10 @@ DQTR_DESC = np.dtype([("resi_off", "<i8"), ("level_off", "<i8"), ("resi_stride",
 RC_DESC = np.dtype([("org_off", "<i8"), ("pred_off", "<i8"), ("rec_off", "<i8"), ("level_off", "<i8"), ("org_stride", "<i4"), ("pred_stride", "<i4"),
                     ("rec_stride", "<i4"), ("w", "<i2"), ("h", "<i2"), ("tr_hor", "i1"), ("tr_ver", "i1"), ("intra_slice", "i1"), ("sign_hiding", "i1"),
                     ("qp", "<i4"), ("reserved", "<i4", (2,))])
-assert QUANT_DESC.itemsize == 32 and DQTR_DESC.itemsize == 32 and RC_DESC.itemsize == 64
+DQ_RATES = np.dtype([("last_x", "<i4", (64,)), ("last_y", "<i4", (64,)), ("sig_sbb", "<i4", (2, 2)), ("sig", "<i4", (3, 18, 2)), ("gtx", "<i4", (21, 7))])
+DEPQUANT_DESC = np.dtype([("coeff_off", "<i8"), ("level_off", "<i8"), ("lambda", "<f8"), ("qp", "<i4"), ("rates_idx", "<i4"), ("w", "<i2"), ("h", "<i2"),
+                          ("luma", "i1"), ("reserved", "i1", (3,))])
+assert QUANT_DESC.itemsize == 32 and DQTR_DESC.itemsize == 32 and RC_DESC.itemsize == 64 and DEPQUANT_DESC.itemsize == 40
 
 
 class MvCost(C.Structure):
@@ -89,13 +92,17 @@ def _pad(plane, m):
 
 
 class Workload:
-    def __init__(self, width, height, bit_depth=10, seed=20261003, raster_range=96, me_sizes=(16, 32, 64), qp=32, fused_resi=True, hier_me=True):
+    def __init__(self, width, height, bit_depth=10, seed=20261003, raster_range=96, me_sizes=(16, 32, 64), qp=32, fused_resi=True, hier_me=True, depquant=False):
         assert width % 8 == 0 and height % 8 == 0
         self.w, self.h, self.bd = width, height, bit_depth
         self.mx = (1 << bit_depth) - 1
         self.seed = seed
         self.raster_range = raster_range
-        self.fused_resi = fused_resi                   # residual chain as ONE pass (vvcgpu_resi_chain_batch) or as its five separate entry points
+        # depquant: the quantiser of the shipped configurations (cfg/encoder_randomaccess_vtm.cfg: DepQuant 1) instead of the Quant::quant stand-in --
+        # the dependent-quantisation trellis (vvcgpu_depquant_batch) between the separate transform entry points, rate tables from a fixed seed
+        # (bench.py's `with_depquant` leg; the headline workload keeps the stand-in SURVEY 8(d) allows)
+        self.depquant = bool(depquant)
+        self.fused_resi = fused_resi and not self.depquant   # residual chain as ONE pass (vvcgpu_resi_chain_batch) or as its five separate entry points
         # integer ME as ONE hierarchical launch (vvcgpu_me_hier_search: every 16x16 SAD once, 32x32 / 64x64 by addition, raster and +-4 grid from
         # the same LDS window) or as six per-size searches (vvcgpu_sad_search): same results
         # (the entry's own preconditions, csrc/mehier.hip: at most 39 raster columns, and the raster's window must contain the +-4 grid's: 5 (R // 5) >= 4 + 15)
@@ -212,6 +219,20 @@ class Workload:
         self.dqtr = np.zeros(self.tr.size, DQTR_DESC)
         self.dqtr["resi_off"], self.dqtr["level_off"], self.dqtr["resi_stride"] = self.tr["resi_off"], self.tr["coeff_off"], self.tr["resi_stride"]
         self.dqtr["w"], self.dqtr["h"], self.dqtr["tr_hor"], self.dqtr["tr_ver"], self.dqtr["qp"] = self.tr["w"], self.tr["h"], self.tr["tr_hor"], self.tr["tr_ver"], qp
+        if self.depquant:
+            # DepQuant::quant per TU: eight rate tables of plausible magnitudes (fractional bits, 1 bit = 2^15) from their own seed -- an encoder would
+            # fill them from its CABAC states per TU (DepQuant.cpp:1323-1409); lambda follows the QP as the reference's RD lambda does
+            rq = np.random.default_rng(seed ^ 0x5EED)
+            K = 8
+            self.dq_rates = np.zeros(K, DQ_RATES)
+            for f in ("last_x", "last_y", "sig_sbb", "sig", "gtx"):
+                self.dq_rates[f] = rq.integers(6000, 140000, self.dq_rates[f].shape)
+            self.dq = np.zeros(self.tr.size, DEPQUANT_DESC)
+            self.dq["coeff_off"] = self.dq["level_off"] = self.tr["coeff_off"]
+            self.dq["lambda"] = 0.57 * 2.0 ** ((self.qp - 12) / 3.0)
+            self.dq["qp"], self.dq["rates_idx"] = qp, rq.integers(0, K, self.tr.size)
+            self.dq["w"], self.dq["h"], self.dq["luma"] = self.tr["w"], self.tr["h"], 1
+            self.dqtr["dep_quant"] = 1
         # the same TUs for the fused chain (residual -> T1 -> quant -> dequant -> T2 -> reconstruction in one pass)
         self.rc = np.zeros(self.tr.size, RC_DESC)
         self.rc["org_off"] = self.rc["pred_off"] = self.rc["rec_off"] = self.tr["resi_off"]
@@ -306,7 +327,7 @@ class Workload:
         # per PU: two reference windows (W+7)^2 (luma) / (W/2+3)^2 (chroma, x2 components) + the written block
         out["mc"] = {"mc_picture": nl * (2 * 23 * 23 * 2 + 16 * 16 * 2) + 2 * nl * (2 * 11 * 11 * 2 + 8 * 8 * 2)}
         ncoef = self.n_coef
-        out["resi"] = {"subtract": 3 * Y, "tr_fwd": ncoef * 6, "quant": ncoef * 8, "dequant_tr_inv": ncoef * 6, "reco": 3 * Y,
+        out["resi"] = {"subtract": 3 * Y, "tr_fwd": ncoef * 6, "quant": ncoef * 8, "depquant": ncoef * 8, "dequant_tr_inv": ncoef * 6, "reco": 3 * Y,
                        # fused: org + pred in, levels + reconstruction out per covered sample; the rest of the plane is copied
                        "resi_chain": ncoef * (2 + 2 + 4 + 2) + 2 * (Y - 2 * ncoef) + 2 * (P - Y)}
         maps = (w // 4) * (h // 4) * 4
@@ -419,6 +440,8 @@ class Workload:
             st["level"] = torch.empty(self.n_coef, dtype=torch.int32, device="cuda")
             st["dqcoef"] = torch.empty(self.n_coef, dtype=torch.int32, device="cuda")
             st["quant"], st["dqtr"] = ops.struct_to_device(self.quant), ops.struct_to_device(self.dqtr)
+            if self.depquant:
+                st["dq"], st["dq_rates"] = ops.struct_to_device(self.dq), ops.struct_to_device(self.dq_rates)
             st["rc"] = ops.struct_to_device(self.rc)
             st["rec"] = planes(self.pic_plane_off, [(h, w), (h // 2, w // 2), (h // 2, w // 2)])
             st["sao_out"] = [e16(h, w), e16(h // 2, w // 2), e16(h // 2, w // 2)]
@@ -542,8 +565,12 @@ class Workload:
                 ops.pelop_batch(3, st["org"][0], st["pred"][0], st["resi"], st["bands_luma"], self.bands_luma.size, sub)
             with T("resi/tr_fwd"):
                 ops.tr_fwd_batch(st["resi"], st["coef"], st["tr"], self.tr.size, bd)
-            with T("resi/quant"):
-                out["abs_sum"] = ops.quant_batch(st["coef"], st["level"], st["quant"], self.tr.size, bd)
+            if self.depquant:
+                with T("resi/depquant"):
+                    out["abs_sum"] = ops.depquant_batch(st["coef"], st["level"], st["dq"], self.tr.size, st["dq_rates"], self.n_coef, bd)
+            else:
+                with T("resi/quant"):
+                    out["abs_sum"] = ops.quant_batch(st["coef"], st["level"], st["quant"], self.tr.size, bd)
             with T("resi/dequant_tr_inv"):
                 ops.dequant_tr_inv_batch(st["level"], st["resi2"], st["dqtr"], self.tr.size, bd, st["dqcoef"])
             with T("resi/reco"):
