@@ -640,27 +640,16 @@ __global__ __launch_bounds__(256) void frac16_kernel(const Pel* __restrict__ org
   frac16_pu_valu<HAD>(ldsS[wave], org, os, ref, rs, blk, b, bd, cmin, cmax, mv, results, lane);
 }
 
-// the PUs the matrix-core kernel below has flagged (reference samples outside the bit depth, an original that is no picture), on the vector pipes:
-// a wave looks at 64 flags and walks the set ones -- a launch that finds nothing costs a few microseconds
-__global__ __launch_bounds__(256) void frac16_flagged_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
-                                                             const vvcgpu_frac_blk* __restrict__ blocks, int nblocks, int bd, int cmin, int cmax,
-                                                             vvcgpu_mvcost mv0, const int* __restrict__ preds,
-                                                             vvcgpu_frac_result* __restrict__ results, const int* __restrict__ flags)
+// the vector-pipe form of one PU as a REAL call: the matrix-core kernel below serves the PUs it cannot take (reference samples outside the bit depth, an
+// original that is no picture) on the spot with it -- the separate launch that walked a flag array cost 6.4 us per 4K picture for an empty list (round 6)
+__device__ __noinline__ void frac16_pu_valu_call(F16Lds* L, const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
+                                                 const vvcgpu_frac_blk* __restrict__ blocks, int b, int bd, int cmin, int cmax, vvcgpu_mvcost mv, const int* __restrict__ preds,
+                                                 vvcgpu_frac_result* __restrict__ results, int lane)
 {
-  __shared__ __align__(16) F16Lds ldsS[4];
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int base = ((int)blockIdx.x * 4 + wave) * 64;
-  unsigned long long todo = __ballot(base + lane < nblocks && flags[min(base + lane, nblocks - 1)] != 0);
-  while (todo)
-  {
-    const int b = base + __builtin_ctzll(todo);
-    todo &= todo - 1;
-    const vvcgpu_frac_blk blk = blocks[b];
-    vvcgpu_mvcost mv = mv0;
-    if (preds) { mv.pred_hor = preds[2 * b]; mv.pred_ver = preds[2 * b + 1]; }
-    frac16_pu_valu<true>(ldsS[wave], org, os, ref, rs, blk, b, bd, cmin, cmax, mv, results, lane);
-  }
+  if (preds) { mv.pred_hor = preds[2 * b]; mv.pred_ver = preds[2 * b + 1]; }
+  frac16_pu_valu<true>(*L, org, os, ref, rs, blocks[b], b, bd, cmin, cmax, mv, results, lane);
 }
+constexpr int FM_FB_MAX = 32;                                // PUs a wave of frac16m_kernel can set aside (the launcher keeps a wave's walk within it)
 
 // ---------------------------------------------------------------------------------------------------
 // 16x16 PUs with Hadamard cost ON THE MATRIX CORES (round 5).  The vector-pipe form above runs ~2100 vector instructions per PU at an issue
@@ -916,10 +905,13 @@ template <int WPS>
 __global__ __launch_bounds__(256, WPS) void frac16m_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
                                                       const vvcgpu_frac_blk* __restrict__ blocks, int nblocks, int bd, int cmin, int cmax,
                                                       vvcgpu_mvcost mv0, const int* __restrict__ preds,
-                                                      vvcgpu_frac_result* __restrict__ results, const _Float16* __restrict__ image, int* __restrict__ flags,
+                                                      vvcgpu_frac_result* __restrict__ results, const _Float16* __restrict__ image,
                                                       int nWg, int xcd)
 {
   __shared__ __align__(16) _Float16 tabS[FM_TAB_HALVES];
+  __shared__ __align__(16) F16Lds ldsV[4];                   // the vector-pipe form's planes (PUs this kernel cannot take: frac16_pu_valu_call)
+  __shared__ int fbk[4][FM_FB_MAX];                          // ... which a wave sets aside and serves BEHIND its walk: a call inside the pipelined loop kept the
+  int nFb = 0;                                               // loop's lane constants in scratch memory (73.1 against 64.8 us)
   __shared__ unsigned long long costS[FM_COST_N];
   const int wg = vvc_xcd_index((int)blockIdx.x, nWg, xcd);
   if (wg < 0) return;                                        // whole workgroup
@@ -1008,10 +1000,11 @@ __global__ __launch_bounds__(256, WPS) void frac16m_kernel(const Pel* __restrict
     blkN.mv_x = __builtin_amdgcn_readfirstlane((int)bv2.x); blkN.mv_y = __builtin_amdgcn_readfirstlane((int)bv2.y);
     predHN = __builtin_amdgcn_readfirstlane(pv.x); predVN = __builtin_amdgcn_readfirstlane(pv.y);
     const bool fallBack = __ballot(bad != 0) != 0ull;        // reference samples outside the bit depth, or an original that is not a picture:
-    if (lane == 0) flags[b] = fallBack;                      // left to frac16_flagged_kernel (vector form), the launch behind this one
-    if (fallBack)
+    if (fallBack)                                            // set aside for the vector-pipe form
     {
       fetch(blkN, rawN);
+      if (lane == 0) fbk[wave][nFb] = b;
+      nFb++;
     }
     else
     {
@@ -1076,6 +1069,8 @@ __global__ __launch_bounds__(256, WPS) void frac16m_kernel(const Pel* __restrict
     blk = blkN;
     raw = rawN;
   }
+  for (int i = 0; i < nFb; i++)
+    frac16_pu_valu_call(&ldsV[wave], org, os, ref, rs, blocks, __builtin_amdgcn_readfirstlane(fbk[wave][i]), bd, cmin, cmax, mv0, preds, results, lane);
 }
 
 // TA / TB images per device and bit depth, built on first use
@@ -1129,13 +1124,14 @@ int vvcgpu_frac_refine_launch(const vvc_pel* org, int org_stride, const vvc_pel*
       const _Float16* image = fm_image(bit_depth);
       if (!image) return VVCGPU_E_DEVICE;
       const int cap = 256 * 4;                                             // four workgroups per CU (the kernel is built for four waves per SIMD: five spill); a wave walks its PUs
-      const int nWg = cdiv(nblocks, 4) < cap ? cdiv(nblocks, 4) : cap;
-      int* flags = static_cast<int*>(vvcgpu_scratch_region(st, VVC_SCRATCH_HELPER, (size_t)nblocks * sizeof(int)));   // the caller (vvcgpu_me_batch) holds blocks / preds in the entry region
-      if (!flags) return VVCGPU_E_DEVICE;
-      hipLaunchKernelGGL(frac16m_kernel<4>, dim3(vvc_xcd_grid(nWg, xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
-                           bit_depth, clp_min, clp_max, *mvcost_host, preds, results, image, flags, nWg, xcd);
-      hipLaunchKernelGGL(frac16_flagged_kernel, dim3(cdiv(nblocks, 256)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,
-                         bit_depth, clp_min, clp_max, *mvcost_host, preds, results, flags);
+      // (lists beyond 4096 waves x FM_FB_MAX PUs -- four 4K pictures -- go as several launches: a wave sets aside at most FM_FB_MAX PUs)
+      for (int first = 0; first < nblocks; first += cap * 4 * FM_FB_MAX)
+      {
+        const int nb = nblocks - first < cap * 4 * FM_FB_MAX ? nblocks - first : cap * 4 * FM_FB_MAX;
+        const int nWg = cdiv(nb, 4) < cap ? cdiv(nb, 4) : cap;
+        hipLaunchKernelGGL(frac16m_kernel<4>, dim3(vvc_xcd_grid(nWg, xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks + first, nb,
+                           bit_depth, clp_min, clp_max, *mvcost_host, preds ? preds + 2 * first : nullptr, results + first, image, nWg, xcd);
+      }
     }
     else if (use_hadamard)
       hipLaunchKernelGGL(frac16_kernel<true>, dim3(vvc_xcd_grid(cdiv(nblocks, 4), xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks, nblocks,

@@ -569,6 +569,7 @@ struct MmK                                                   // lane constants o
   float magicN, magicH, scBi1, scUni1, ofUni1, scBi2, ofBi2, cinN, cinH;
   mm_h2 pmin, pmax, pmin0, pmaxF;                            // packed clip bounds (+ 1024): the caller's range; the bit depth's range (a uni-predictive full-sample copy is NOT clipped: filterCopy, isFirst == isLast)
   int perm;                                                  // ds_bpermute address: lane (row & 15) + 16 chunk <- lane 4 (row & 15) + chunk
+  int* genCount;                                             // PUs left to the generic kernel behind this one (it leaves at once when there are none)
 };
 
 // pass-1 result registers -> limb operand (kind: 0 every row real; 1 luma rows 16..31; 2 chroma rows 0..15); hclip (per lane): the rounded horizontal-only
@@ -704,7 +705,7 @@ __device__ __forceinline__ void mm_luma(const MmK& K, const vvcgpu_mc_desc& d, c
     for (int j = 0; j < 4; j++) fr[rf][j] = floorf(__builtin_fmaf(acc[j], sc, of));
   }
   const bool isBad = __ballot(W.bad != 0) != 0ull;           // a reference sample outside the bit depth: the generic kernel takes the PU
-  if (K.lane == 0) flags[idx] = isBad;
+  if (K.lane == 0) { flags[idx] = isBad; if (isBad) atomicAdd(K.genCount, 1); }
   if (isBad) return;
   const uint2 o = mm_tail(K, fr[0], fr[1], d.bi == 1 ? 1.f : 0.f, d.bi == 1 ? K.scBi2 : 1.f, d.bi == 1 ? K.ofBi2 : 1024.f, d.bi == 0 && (d.frac_x0 | d.frac_y0) == 0);
   Pel* dp = dstBase + d.dst_off + (ptrdiff_t)K.c16 * d.dst_stride + 4 * K.g;                 // lane (c16, g): row c16, columns 4 g .. 4 g + 3
@@ -787,7 +788,7 @@ __device__ __forceinline__ void mm_chroma(const MmK& K, const MmWin& raw, int iA
   // a sample outside the bit depth is no f16 integer pattern (0x6400 | v reaches the exponent): in a product it poisons every output of its ROW, also the
   // other PU's, whose table entries for it are zero (0 x NaN) -- both PUs of the pair go to the generic kernel
   const bool badA = badLanes != 0ull, badB = hasB && badLanes != 0ull;
-  if (K.lane == 0) { flags[iA] = badA; if (hasB) flags[iB] = badB; }
+  if (K.lane == 0) { flags[iA] = badA; if (hasB) flags[iB] = badB; if (badA) atomicAdd(K.genCount, 1 + (badB ? 1 : 0)); }
   const uint2 o = mm_tail(K, fr[0], fr[1], bi == 1 ? 1.f : 0.f, bi == 1 ? K.scBi2 : 1.f, bi == 1 ? K.ofBi2 : 1024.f, bi == 0 && (fx0 | fy0) == 0);
   // lane (c16, g): row c16 & 7 of PU c16 >> 3, columns 4 (g & 1) ..; real when g >> 1 == c16 >> 3
   const bool outB = K.c16 >= 8;
@@ -817,8 +818,10 @@ __device__ __forceinline__ int mm_kind_of(const uint4& q)   // bytes 32..47 of a
 template <int KIND_T>
 __global__ __launch_bounds__(256, 4) void mc_mfma_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base, Pel* __restrict__ dstBase,
                                                                          const vvcgpu_mc_desc* __restrict__ descs, int n, int bd, int cmin, int cmax,
-                                                                         const _Float16* __restrict__ image, int* __restrict__ flags, unsigned long long* __restrict__ diag)
+                                                                         const _Float16* __restrict__ image, int* __restrict__ flags, unsigned long long* __restrict__ diag,
+                                                                         int* __restrict__ genCount, int* __restrict__ nextCounters)
 {
+  if (blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextCounters[threadIdx.x] = 0;       // the counter set of the NEXT call on this stream (vvcgpu_counters)
   // KIND_T 0: ONE launch, workgroups alternate between the two shapes (both kinds of waves on every CU at the same time)
   const int KIND = KIND_T ? KIND_T : 1 + ((int)blockIdx.x & 1);
   const int T0 = KIND == 1 ? MM_TAL : MM_TAC, T1 = KIND == 1 ? MM_TAC : MM_ENTRIES;          // this kind's table entries
@@ -826,6 +829,7 @@ __global__ __launch_bounds__(256, 4) void mc_mfma_kernel(const Pel* __restrict__
   for (int i = threadIdx.x; i < T1 - T0; i += 256) reinterpret_cast<uint4*>(tabL)[i] = reinterpret_cast<const uint4*>(image)[T0 + i];
   __syncthreads();
   MmK K;
+  K.genCount = genCount;
   K.tabS = tabL - T0 * 8;                                    // (indexed with the image's entry numbers)
   K.lane = threadIdx.x & 63; K.c16 = K.lane & 15; K.g = K.lane >> 4;
   const int g = K.g;
@@ -876,6 +880,10 @@ __global__ __launch_bounds__(256, 4) void mc_mfma_kernel(const Pel* __restrict__
         const int bi = (int)(signed char)((q2.w >> 8) & 0xFFu);
         if (k == 1 && ((q1.z | (bi == 1 ? q1.w : 0u)) & 7u)) k = -1;           // aligned 16-byte words need rows that keep their alignment (ref strides: bytes 24..31)
         if (k < 0) flags[iL] = 1;                            // a fast SHAPE these kernels do not take: the generic kernel's
+      }
+      {
+        const unsigned long long gm = __ballot(iL < n && k <= 0);             // every other shape, and the fast shapes left above: the generic kernel's work
+        if (gm != 0ull && K.lane == 0) atomicAdd(K.genCount, (int)__popcll(gm));
       }
       unsigned long long mine = __ballot(k == 1);
       auto nextIdx = [&]() -> int { if (mine == 0ull) return -1; const int j = (int)__builtin_ctzll(mine); mine &= mine - 1ull; return w + (j0 + j) * W; };
@@ -1036,8 +1044,10 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
                                                       Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs,
                                                       int bd, int cmin, int cmax,
                                                       int nDirect, int distKind, const Pel* __restrict__ orgBase, unsigned long long* __restrict__ out, int chunk,
-                                                      const int* __restrict__ flags, int takeFast)
+                                                      const int* __restrict__ flags, int takeFast, const int* __restrict__ genCount = nullptr)
 {
+  // behind the matrix-core kernel: nothing left for this one (a picture of conforming 16x16 / 8x8 PUs) -- every wave leaves at once
+  if (!DIST && genCount && __builtin_amdgcn_readfirstlane(*genCount) == 0) return;
   __shared__ short win[WR * WP];
   __shared__ short tmp[WR * ST];
   __shared__ __align__(16) short predT[DIST ? 128 * 128 : 8];
@@ -1414,6 +1424,7 @@ int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc
   hipStream_t st = (hipStream_t)stream;
   const int mfmaOff = vvcgpu_no_mfma();                                   // VVCGPU_NO_MFMA (common.h): every PU through the generic kernel (its packed vector-pipe form takes the fast shapes)
   const int* flags = nullptr;
+  int* genCount = nullptr;
   if (!skip_fast && !mfmaOff)
   {
     const _Float16* image = mm_image(bit_depth);
@@ -1424,7 +1435,12 @@ int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc
     unsigned long long* diag = nullptr;
     const bool wantDiag = getenv("VVCGPU_MC_DIAG") != nullptr;           // measurement aid: step stamps of one luma wave
     if (wantDiag) { VVC_HIP(hipMalloc(&diag, 64 * sizeof(unsigned long long))); VVC_HIP(hipMemsetAsync(diag, 0, 64 * sizeof(unsigned long long), st)); }
-    hipLaunchKernelGGL(mc_mfma_kernel<0>, dim3(wgL < 2 ? 2 : (wgL & ~1)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl, diag);
+    int cur = 0;
+    int* counters = vvcgpu_counters(st, &cur);
+    if (!counters) return VVCGPU_E_DEVICE;
+    genCount = counters + VVC_CTR_INTS * cur;
+    hipLaunchKernelGGL(mc_mfma_kernel<0>, dim3(wgL < 2 ? 2 : (wgL & ~1)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl, diag,
+                       genCount, counters + VVC_CTR_INTS * (cur ^ 1));
     if (wantDiag)
     {
       unsigned long long h[64];
@@ -1440,10 +1456,11 @@ int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc
   const int chunk = n >= 64 * 8192 ? 64 : (n + 8191) / 8192;            // ~8192 waves: 32 per CU
   if (sub44)
     hipLaunchKernelGGL((mc_batch_kernel<false, true>), dim3(cdiv(n, chunk) < 8192 ? cdiv(n, chunk) : 8192), dim3(64), 0, st, ref0_base,
-                       ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk, flags, mfmaOff ? 1 : 0);
+                       ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk, flags, mfmaOff ? 1 : 0, genCount);
   else
     hipLaunchKernelGGL((mc_batch_kernel<false, false>), dim3(cdiv(n, chunk) < 8192 ? cdiv(n, chunk) : 8192), dim3(64), 0, st, ref0_base,
-                       ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk, flags, mfmaOff ? 1 : 0);
+                       ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk, flags, mfmaOff ? 1 : 0, genCount);
+  if (genCount) VVC_LAUNCH_CHECK_COUNTERS(st);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
 }
