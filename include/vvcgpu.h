@@ -68,6 +68,12 @@ int vvcgpu_stream_sync(void* stream);
  * queued before the growth has completed.  One host thread drives a stream at a time (per-thread streams for concurrent callers). */
 int vvcgpu_stream_release(void* stream);
 int vvcgpu_shutdown(void);
+/* Per device (and bit depth) the library keeps a few constant table images in device memory: the transform matrices (TrQuant.cpp:72-84, Rom.cpp:245-299)
+ * as int32 and as the f16 image of the matrix-core kernels, the Toeplitz tap tables of the matrix-core interpolation (InterpolationFilter.cpp:59-138).
+ * They are built by the FIRST call that needs them -- on the NULL stream, with a device synchronisation, under a library mutex: that call must not run
+ * inside a stream capture and briefly stalls other threads' streams.  vvcgpu_warmup(bit_depth) builds them all for the current device at a time the host
+ * chooses (start-up), after which no entry point synchronises the device.  Optional; idempotent. */
+int vvcgpu_warmup(int bit_depth);
 
 /* ---- A1: ALF classification  (AdaptiveLoopFilter::deriveClassification, AdaptiveLoopFilter.cpp:274-463;
  *          table slot m_deriveClassificationBlk, AdaptiveLoopFilter.h:90) -----------------------

@@ -134,3 +134,12 @@ def test_out_of_contract_descriptors_give_the_sentinel():
     sd = np.array([(0, 0, 24, 16, 16, 18, 0, 0, 0), (0, 0, 24, 128, 16, 18, 0, 0, 0), (0, 0, 24, 16, 16, 18, 0, 0, 0)], dtype=ops.INTRA_SATD_DESC)
     got = ops.intra_satd_batch(dev(refs), dev(org.reshape(-1)), ops.struct_to_device(sd), len(sd), clp=(0, mx)).cpu().numpy().view(np.uint64)
     assert got[1] == np.uint64(0xFFFFFFFFFFFFFFFF) and got[0] == got[2] != np.uint64(0xFFFFFFFFFFFFFFFF)
+
+
+def test_warmup_builds_the_table_images_once():
+    """vvcgpu_warmup: the per-device table images at a time the host chooses (idempotent); bit depths the kernels do not take are refused"""
+    from vvcsoftware_vtm_amd import capi
+    lib = capi.lib()
+    for bd in (8, 10, 10):
+        assert lib.vvcgpu_warmup(bd) == 0, lib.vvcgpu_last_error()
+    assert lib.vvcgpu_warmup(12) == -3 and b"bit depth" in lib.vvcgpu_last_error()

@@ -24,6 +24,10 @@ void* vvcgpu_scratch_region(hipStream_t stream, int region, size_t bytes);
 // parity cases of those bodies under it.  Every other environment variable the library reads is a measurement aid (VVCGPU_*_DIAG: cycle stamps to
 // stderr) or a test hook (VVCGPU_MH_WGS: number of persistent workgroups of the hierarchical search).
 int vvcgpu_no_mfma(void);
+// eager construction of the per-device table images (vvcgpu_warmup, lib.hip): each returns VVCGPU_OK or an error code with the text set
+int vvcgpu_mc_image_build(int bit_depth);          // interp.hip
+int vvcgpu_frac_image_build(int bit_depth);        // fracsearch.hip
+int vvcgpu_tr_image_build(void);                   // resichain.hip (transform tables + f16 image)
 int vvcgpu_cu_count(void);                         // compute units of the current device (queried once per device; 256 if the query fails)
 constexpr int VVC_CTR_INTS = 32;                       // ints per counter set of vvcgpu_counters
 int* vvcgpu_counters(hipStream_t stream, int* cur);     // two persistent zeroed work counters per (device, stream), see lib.hip

@@ -1097,6 +1097,8 @@ const _Float16* fm_image(int bd)
 }
 }  // namespace
 
+__attribute__((visibility("hidden"))) int vvcgpu_frac_image_build(int bit_depth) { return fm_image(bit_depth) ? VVCGPU_OK : VVCGPU_E_DEVICE; }
+
 // shared by vvcgpu_frac_refine and vvcgpu_me_batch (tzsearch.hip); preds: optional per-block MV predictors (hor, ver) on the device
 int vvcgpu_frac_refine_launch(const vvc_pel* org, int org_stride, const vvc_pel* ref, int ref_stride,
                               const vvcgpu_frac_blk* blocks, int nblocks, int w, int h, int bit_depth, int clp_min,

@@ -1373,6 +1373,8 @@ __global__ __launch_bounds__(256) void pelop_heavy_kernel(int op, const Pel* __r
 
 }  // namespace
 
+__attribute__((visibility("hidden"))) int vvcgpu_mc_image_build(int bit_depth) { return mm_image(bit_depth) ? VVCGPU_OK : VVCGPU_E_DEVICE; }
+
 extern "C" {
 
 int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_desc* descs, int n,

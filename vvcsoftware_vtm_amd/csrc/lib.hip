@@ -220,6 +220,14 @@ int vvcgpu_sizeof(int id)
   default: return -1;
   }
 }
+int vvcgpu_warmup(int bit_depth)
+{
+  if (bit_depth < 8 || bit_depth > 10) { vvcgpu_set_error("warmup: bit depth %d outside 8..10", bit_depth); return VVCGPU_E_UNSUPPORTED; }
+  int rc = vvcgpu_tr_image_build();
+  if (rc == VVCGPU_OK) rc = vvcgpu_mc_image_build(bit_depth);
+  if (rc == VVCGPU_OK) rc = vvcgpu_frac_image_build(bit_depth);
+  return rc;
+}
 int vvcgpu_set_device(int device)
 {
   VVC_HIP(hipSetDevice(device));

@@ -217,6 +217,7 @@ __device__ __forceinline__ void mh_unit(const unsigned* __restrict__ orgPacked, 
     if (waveHasDense) mh_block_min64(L.kind == 2 ? mh_fold64(acc, L, sh) : ~0ull, &keys[21 + ty * 4 + tx], lane);
     a32[0] += acc[0]; a32[1] += acc[1]; a32[2] += acc[2]; a32[3] += acc[3];
   }
+  __builtin_amdgcn_s_setprio(0);                                                  // (a unit that skipped its last sub-blocks would keep a raised priority through the record write and the next window slide)
   if (nsub == 4)
   {
     mh_block_min(L.kind == 1 ? mh_fold32(a32, L, sh) : 0xFFFFFFFFu, L.idx, &keys[16 + q], lane);

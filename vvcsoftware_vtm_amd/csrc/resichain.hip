@@ -2134,6 +2134,14 @@ const _Float16* vvcgpu_mfma_image(const VvcTrTables& tb)
   return images[dev];
 }
 
+__attribute__((visibility("hidden"))) int vvcgpu_tr_image_build(void)
+{
+  VvcTrTables tb;
+  const int rt = vvcgpu_tr_tables(&tb);
+  if (rt) return rt;
+  return vvcgpu_mfma_image(tb) ? VVCGPU_OK : VVCGPU_E_DEVICE;
+}
+
 // the classify / chain / generic launches behind vvcgpu_resi_chain_batch (mode RC_CHAIN) and, for long calls, behind vvcgpu_tr_fwd_batch /
 // vvcgpu_tr_inv_batch (RC_FWD / RC_INV; transform.hip): ONE chain launch with packed tiles instead of the small / matrix-core / dot2 kernels in a row
 static int rc_chain_launch(int mode, const vvc_pel* org_base, const vvc_pel* pred_base, vvc_pel* rec_base, vvc_coef* level_base, const void* descs_raw, int n,
