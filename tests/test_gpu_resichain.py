@@ -231,3 +231,59 @@ def test_stream_counters_survive_interleaved_entry_points():
 
     for step in ["all", "mixed", "one", "wild", "wild", "fast", "mixed", "mixed", "all", "one", "fast", "all"]:
         (run_mc if step in mc else run_chain)(step)
+
+
+@pytest.mark.parametrize("bd,content", [(10, "smooth"), (8, "uniform")])
+def test_resi_chain_runs_entry_equals_the_classified_entry(bd, content):
+    """vvcgpu_resi_chain_runs_batch: descriptors grouped by shape, runs (w, h, count) from the host -- no classification launch.  Every shape the chain
+    has a body for (squares, rectangles, packed tiles), in an order of the caller's choosing, a few TUs outside the matrix-core range (fall-back list), twice on
+    one stream with different lists (the identity array and the counter sets persist); equal to the oracle, i.e. to vvcgpu_resi_chain_batch.  A list
+    that holds a 2-wide shape is served through the classified path."""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(bd * 3 + len(content))
+    W, H = 768, 192
+    org = cases.rand_plane(rng, H, W, bd, content)
+    pred = np.clip(org + rng.integers(-25, 26, org.shape), 0, (1 << bd) - 1).astype(np.int16)
+    shapes_all = [(8, 8), (64, 64), (4, 4), (32, 32), (16, 16), (64, 32), (32, 64), (16, 8), (8, 16), (4, 8), (8, 4), (32, 8), (4, 32), (64, 16), (16, 64), (32, 16), (16, 32), (64, 4), (8, 64)]
+    for rnd, shapes in enumerate([shapes_all, shapes_all[3:9], shapes_all + [(2, 8)]]):
+        tus = tile(W, H, shapes, rng, [22, 32, 37], bd)
+        keep = rng.random(len(tus)) > 0.1
+        tus = [t for t, k in zip(tus, keep) if k]
+        order = sorted(range(len(tus)), key=lambda i: shapes.index((tus[i][2], tus[i][3])))      # grouped by shape, groups in the caller's order
+        tus = [tus[i] for i in order]
+        runs = []
+        for t in tus:
+            if runs and runs[-1][0] == t[2] and runs[-1][1] == t[3]:
+                runs[-1][2] += 1
+            else:
+                runs.append([t[2], t[3], 1])
+        o2 = org.copy()
+        if rnd == 0 and bd == 10:
+            for i in rng.choice(len(tus), 9, replace=False):
+                x, y = tus[i][:2]
+                o2[y, x] = -2500
+        lv, asum, rec, coffs = oracle_chain(o2, pred, tus, bd, W)
+        n = len(tus)
+        d = np.zeros(n, ops.RC_DESC)
+        for i, (x, y, w, h, th, tv, qp, intra, sbh) in enumerate(tus):
+            d[i] = (y * W + x, y * W + x, y * W + x, coffs[i], W, W, W, w, h, th, tv, intra, sbh, qp, (0, 0))
+        dorg, dpred = torch.from_numpy(o2).cuda(), torch.from_numpy(pred).cuda()
+        drec = dpred.clone()
+        dlevel = torch.full((int(sum(t[2] * t[3] for t in tus)),), 0x5A5A5A5A, dtype=torch.int32, device="cuda")
+        a = ops.resi_chain_runs_batch(dorg, dpred, drec, dlevel, ops.struct_to_device(d), n, runs, bd, (0, (1 << bd) - 1))
+        torch.cuda.synchronize()
+        assert np.array_equal(a.cpu().numpy().view(np.uint32), asum), rnd
+        assert np.array_equal(dlevel.cpu().numpy(), lv), rnd
+        assert np.array_equal(drec.cpu().numpy(), rec), rnd
+
+
+def test_resi_chain_runs_entry_rejects_inconsistent_runs():
+    from vvcsoftware_vtm_amd import ops, capi
+    t = torch.zeros((64, 64), dtype=torch.int16, device="cuda")
+    lvl = torch.zeros(4096, dtype=torch.int32, device="cuda")
+    d = np.zeros(4, ops.RC_DESC)
+    d["w"] = d["h"] = 8
+    dd = ops.struct_to_device(d)
+    for runs in ([(8, 8, 3)], [(8, 8, 2), (8, 8, 2)], [(8, 3, 4)]):
+        with pytest.raises(capi.VvcGpuError):
+            ops.resi_chain_runs_batch(t, t, t.clone(), lvl, dd, 4, runs, 10)

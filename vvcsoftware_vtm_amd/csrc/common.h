@@ -16,7 +16,8 @@ void vvcgpu_set_error(const char* fmt, ...);
 // ONE call of an entry point may take each REGION once: an entry point that sizes its own workspace uses VVC_SCRATCH_ENTRY (vvcgpu_scratch), a
 // launch helper that other entry points call with their workspace still live (vvcgpu_frac_refine_launch under vvcgpu_me_batch,
 // vvcgpu_mc_batch_impl under the affine entry points) uses VVC_SCRATCH_HELPER -- two requests for the same region on one call path alias.
-enum { VVC_SCRATCH_ENTRY = 0, VVC_SCRATCH_HELPER = 1, VVC_SCRATCH_REGIONS = 2 };
+enum { VVC_SCRATCH_ENTRY = 0, VVC_SCRATCH_HELPER = 1, VVC_SCRATCH_IOTA = 2, VVC_SCRATCH_REGIONS = 3 };
+int* vvcgpu_iota(hipStream_t stream, int n);                                 // device array 0, 1, .. of at least n ints, persistent per stream (lib.hip)
 void* vvcgpu_scratch(hipStream_t stream, size_t bytes);                      // region VVC_SCRATCH_ENTRY
 void* vvcgpu_scratch_region(hipStream_t stream, int region, size_t bytes);
 // The ONE behaviour switch of the library (read per call): VVCGPU_NO_MFMA=1 keeps the interpolation filters, the Hadamard refinement and the

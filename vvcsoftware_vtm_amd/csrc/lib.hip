@@ -1,5 +1,6 @@
 // lib.hip -- library-level entry points of the C ABI (include/vvcgpu.h).
 #include "common.h"
+#include <algorithm>
 #include <atomic>
 #include <mutex>
 #include <stdarg.h>
@@ -31,6 +32,7 @@ struct StreamSlot
   struct Retired { void* ptr; hipEvent_t done; };
   std::vector<Retired> retired;           // outgrown scratch buffers: freed with the slot
   int* counters; int cur; bool dirty;     // int[2][16]; dirty: a launch that owned a set failed -- both sets are cleared before the next use
+  void* iotaPtr; int iotaN;               // the identity array of vvcgpu_iota: valid entries [0, iotaN) of the buffer at iotaPtr (region VVC_SCRATCH_IOTA)
 };
 std::vector<StreamSlot> g_slots;
 std::mutex g_slotMutex;
@@ -40,7 +42,7 @@ StreamSlot* find_slot(int dev, hipStream_t stream, bool create)
   for (auto& s : g_slots)
     if (s.device == dev && s.stream == stream) return &s;
   if (!create) return nullptr;
-  g_slots.push_back(StreamSlot{ dev, stream, {}, {}, {}, nullptr, 0, false });
+  g_slots.push_back(StreamSlot{ dev, stream, {}, {}, {}, nullptr, 0, false, nullptr, 0 });
   return &g_slots.back();
 }
 void free_slot(StreamSlot& s)             // the slot is out of the table (or the caller holds the mutex at shutdown), its device is current, its stream is idle
@@ -99,6 +101,31 @@ void* vvcgpu_scratch_region(hipStream_t stream, int region, size_t bytes)
     slot->ptr[region] = p; slot->cap[region] = cap;
   }
   for (auto& q : done) { (void)hipFree(q.ptr); (void)hipEventDestroy(q.done); }
+  return p;
+}
+
+// identity array 0, 1, 2, ... of at least n ints, persistent per (device, stream): written by a launch on that stream when it is first needed or has to
+// grow (geometrically, like the scratch), read by every later call (vvcgpu_resi_chain_runs_batch: class lists as ranges of it)
+namespace { __global__ void iota_kernel(int* p, int first, int n) { const int i = first + blockIdx.x * 256 + threadIdx.x; if (i < n) p[i] = i; } }
+int* vvcgpu_iota(hipStream_t stream, int n)
+{
+  int* p = static_cast<int*>(vvcgpu_scratch_region(stream, VVC_SCRATCH_IOTA, (size_t)(n > 0 ? n : 1) * sizeof(int)));
+  if (!p) return nullptr;
+  int dev = 0, first = 0, cap = 0;
+  if (hipGetDevice(&dev) != hipSuccess) { vvcgpu_set_error("hipGetDevice failed"); return nullptr; }
+  {
+    std::lock_guard<std::mutex> lock(g_slotMutex);
+    StreamSlot* slot = find_slot(dev, stream, true);
+    if (slot->iotaPtr != p) { slot->iotaPtr = p; slot->iotaN = 0; }
+    first = slot->iotaN;
+    cap = (int)std::min<size_t>(slot->cap[VVC_SCRATCH_IOTA] / sizeof(int), (size_t)0x7FFFFFFF);
+    if (first < n) slot->iotaN = cap;                                     // the whole buffer is filled below
+  }
+  if (first < n)
+  {
+    hipLaunchKernelGGL(iota_kernel, dim3((unsigned)((cap - first + 255) / 256)), dim3(256), 0, stream, p, first, cap);
+    if (hipGetLastError() != hipSuccess) { vvcgpu_set_error("iota: kernel launch failed"); return nullptr; }
+  }
   return p;
 }
 
@@ -251,7 +278,7 @@ int vvcgpu_stream_release(void* stream)
   const hipError_t e = hipStreamSynchronize((hipStream_t)stream);           // queued work may still read the buffers
   if (e == hipSuccess)
   {
-    StreamSlot taken{ sdev, nullptr, {}, {}, {}, nullptr, 0, false };
+    StreamSlot taken{ sdev, nullptr, {}, {}, {}, nullptr, 0, false, nullptr, 0 };
     bool found = false;
     {
       std::lock_guard<std::mutex> lock(g_slotMutex);

@@ -40,7 +40,7 @@ enum { RC_C64 = 0, RC_C32, RC_C16, RC_C8, RC_C4, RC_CGEN, RC_R6432, RC_R3264, RC
 constexpr int RC_FB = RC_NCLS;
 static_assert(RC_FB < RC_HDR, "the header is one counter set of vvcgpu_counters");
 
-__device__ __forceinline__ int rc_class(const RcDesc& d, bool packed)
+__host__ __device__ __forceinline__ int rc_class(const RcDesc& d, bool packed)
 {
   const int w = d.w, h = d.h;
   if (w == h)
@@ -1932,6 +1932,10 @@ __device__ __forceinline__ int rc_ord_g(int k)               // TUs per wave ite
 {
   return k == 6 || k == 15 || k == 16 ? 8 : k == 14 ? 16 : (k == 12 || k == 13 || k == 19 || k == 20 || k >= 23) ? 4 : k >= 10 ? 2 : 1;
 }
+// Class lists of a launch.  Classified (vvcgpu_resi_chain_batch): rc_classify_kernel's lists, class c at lists + c n, counts in hdr.  Runs
+// (vvcgpu_resi_chain_runs_batch): the caller's descriptors are grouped by shape, so class c is the index range [base[c], base[c] + cnt[c]) -- `lists` is
+// then an identity array (lib.hip: vvcgpu_iota) and every body reads its TU indices as before.
+struct RcBins { int use; int base[RC_NCLS]; int cnt[RC_NCLS]; };
 // class / range of a slot: lane j holds end[j]; the ends ascend, so the number of lanes whose end is at or below the slot is the class ordinal
 __device__ __forceinline__ void rc_slot_class(const int* sCnt, const int* sEnd, int slot, int lane, int& k, int& start, int& cntK, int& endK)
 {
@@ -1945,8 +1949,9 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
                                                           TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs, int n,
                                                           const int* __restrict__ hdr, const int* __restrict__ lists, int* __restrict__ fbCount,
                                                           int* __restrict__ fbList, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
-                                                          const _Float16* __restrict__ image, VvcTrTables tb)
+                                                          const _Float16* __restrict__ image, VvcTrTables tb, RcBins bins, int* __restrict__ nextHdr)
 {
+  if (bins.use && blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextHdr[threadIdx.x] = 0;   // (no classifier in front: this launch clears the counter set of the NEXT call, vvcgpu_counters)
   __shared__ __align__(16) _Float16 tab[RC_TAB_HALVES];
   __shared__ __align__(16) RcSmallTab tabs;
   __shared__ __align__(16) int tmpAll[4][8 * 8 * 9];          // per wave: transposes of the lane-group forms / the TU list of a packed tile; all of it: the limb planes of a co-operative TU
@@ -1963,13 +1968,14 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
   constexpr int ordG[NORD] = { 1, 1, 1, 1, 1, 1, 8, 1, 1, 1, 2, 2, 4, 4, 16, 8, 8, 2, 2, 4, 4, 2, 2, 4, 4 };   // TUs per wave item (= rc_ord_g)
   // class counts and slot ranges live in LDS: as 75 scalars they were 143 spilled scalar registers around every body (round 6)
   __shared__ int sCnt[NORD], sEnd[NORD];
+  __shared__ long long sOff[NORD];                            // where class k's TU indices start in `lists`
   int total = 0;
 #pragma unroll
   for (int k = 0; k < NORD; k++)
   {
-    const int ck = hdr[ordCls[k]], ik = (ck + ordG[k] - 1) / ordG[k];
+    const int ck = bins.use ? bins.cnt[ordCls[k]] : hdr[ordCls[k]], ik = (ck + ordG[k] - 1) / ordG[k];
     total += k < NCOOP ? ik : (ik + 3) >> 2;                  // co-operative classes: one TU per slot (the four waves together)
-    if (tid == 0) { sCnt[k] = ck; sEnd[k] = total; }
+    if (tid == 0) { sCnt[k] = ck; sEnd[k] = total; sOff[k] = bins.use ? (long long)bins.base[ordCls[k]] : (long long)ordCls[k] * n; }
   }
   if ((int)blockIdx.x >= total) return;
 #ifdef RC_DIAG
@@ -1978,6 +1984,28 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
   if (dgOn) dg[0] = __builtin_amdgcn_s_memtime();
 #endif
   if (tid == 0) { red[0] = 0; red[1] = -1; red[2] = 0; }
+  // Runs mode: nothing has read the descriptors yet (the classifier of the other mode leaves them in the L2 on its way: without it the chain kernel was
+  // 72.3 instead of 67.6 us) -- a wave touches the descriptor lines of its items of the workgroup's first slots now, behind the table copy they arrive.
+  int pfD[2] = { 0, 0 };
+  if (bins.use)
+  {
+    __syncthreads();                                          // sEnd / sCnt / sOff
+#pragma unroll
+    for (int r = 0; r < 2; r++)
+    {
+      const int pair = lane + 64 * r, j = pair >> 3, line = pair & 7;          // (slot j of this workgroup, 128-byte line of the item's descriptors)
+      const int slot = (int)blockIdx.x + j * (int)gridDim.x;
+      if (slot < total)
+      {
+        int k = 0, start = 0;
+        for (int q = 0; q < NORD - 1; q++) { const int e = sEnd[q]; if (slot >= e) { k = q + 1; start = e; } }
+        const int gK = rc_ord_g(k), cntK = sCnt[k];
+        const int first = k < NCOOP ? slot - start : ((slot - start) * 4 + wave) * gK, tus = k < NCOOP ? 1 : gK;
+        const int t = first + 2 * line;
+        if (2 * line < tus && t < cntK) pfD[r] = *reinterpret_cast<const int*>(descs + (int)sOff[k] + t);
+      }
+    }
+  }
   {
     // the table image (f16 matrices + the int32 4- / 8-point matrices) as ONE run of 16-byte loads, all in flight before the first store.  In-kernel stamps
     // (RC_DIAG): 16 - 24 k cycles until the barrier below with three workgroups per CU -- every workgroup of an XCD asks its L2 for the same 41 KB at the
@@ -2007,18 +2035,20 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
     int k, start, cntK, endK;
     rc_slot_class(sCnt, sEnd, slot, lane, k, start, cntK, endK);
     const int gK = rc_ord_g(k);
+    const long long offV = sOff[k];
+    const int* const listK = lists + (((long long)__builtin_amdgcn_readfirstlane((int)(offV >> 32)) << 32) | (unsigned)__builtin_amdgcn_readfirstlane((int)offV));   // this slot's class list
     const int itemsK = (cntK + gK - 1) / gK;
     const int item = k < NCOOP ? slot - start : (slot - start) * 4 + wave;
     bool done = true;
     int ti = 0;
 #define RC_MF(K, W_, H_)                                                                                                                      \
-    case K: if (item < cntK) { ti = __builtin_amdgcn_readfirstlane(lists[(size_t)ordCls[K] * n + item]);                                    \
+    case K: if (item < cntK) { ti = __builtin_amdgcn_readfirstlane(listK[item]);                                    \
         done = rc_tu_mfma_call<W_, H_, MODE>(descs, ti, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane); } break;
 #define RC_PK(K, W_, H_)                                                                                                                      \
-    case K: if (item < itemsK) rc_tile_packed<W_, H_, MODE>(descs, lists + (size_t)ordCls[K] * n, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, \
+    case K: if (item < itemsK) rc_tile_packed<W_, H_, MODE>(descs, listK, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, \
                                                         clpMax, tab, tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
 #define RC_CO(K, W_, H_)                                                                                                                      \
-    case K: { ti = __builtin_amdgcn_readfirstlane(lists[(size_t)ordCls[K] * n + item]);                                                       \
+    case K: { ti = __builtin_amdgcn_readfirstlane(listK[item]);                                                       \
         done = rc_tu_coop<W_, H_, MODE>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, \
                                         reinterpret_cast<_Float16*>(&tmpAll[0][0]), red, wave, lane);                                         \
         if (wave != 0) done = true; } break;                 /* (one fall-back entry per TU) */
@@ -2033,7 +2063,7 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
       // inside this loop (across the 64-point bodies they were spills: docs/OPTIMISATION_LOG.md).
       int vz = 0;
       asm volatile("" : "+v"(vz));                           // a zero the compiler takes for lane-dependent: the loads below stay vector loads
-      const int* lst = lists + (size_t)ordCls[9] * n;
+      const int* lst = listK;
       const int G4 = 4 * (int)gridDim.x;
       int it = item;
       if (it >= cntK) break;
@@ -2067,16 +2097,16 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
       break;
     }
     RC_PK(10, 16, 8) RC_PK(11, 8, 16) RC_PK(12, 16, 4) RC_PK(13, 4, 16)
-    case 6: if (item < itemsK) rc_small_group<8, MODE>(descs, lists + (size_t)RC_C8 * n, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
-    case 14: if (item < itemsK) rc_small_group<4, MODE>(descs, lists + (size_t)RC_C4 * n, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
-    case 15: if (item < itemsK) rc_rect_group<8, 4, MODE>(descs, lists + (size_t)RC_R84 * n, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
-    case 16: if (item < itemsK) rc_rect_group<4, 8, MODE>(descs, lists + (size_t)RC_R48 * n, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 6: if (item < itemsK) rc_small_group<8, MODE>(descs, listK, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 14: if (item < itemsK) rc_small_group<4, MODE>(descs, listK, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 15: if (item < itemsK) rc_rect_group<8, 4, MODE>(descs, listK, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
+    case 16: if (item < itemsK) rc_rect_group<4, 8, MODE>(descs, listK, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
 #define RC_PK32(K, F)                                                                                                                         \
-    case K: if (item < itemsK) F(descs, lists + (size_t)ordCls[K] * n, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,     \
+    case K: if (item < itemsK) F(descs, listK, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,     \
                                    tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
     RC_PK32(17, (rc_tile_packed_wl<32, 8, MODE>)) RC_PK32(18, (rc_tile_packed_hl<8, 32, MODE>)) RC_PK32(19, (rc_tile_packed_wl<32, 4, MODE>)) RC_PK32(20, (rc_tile_packed_hl<4, 32, MODE>))
     RC_PK32(21, (rc_tile_packed_wl<64, 8, MODE>)) RC_PK32(22, (rc_tile_packed_hl<8, 64, MODE>)) RC_PK32(23, (rc_tile_packed_wl<64, 4, MODE>))
-    default: if (item < itemsK) rc_tile_packed_hl<4, 64, MODE>(descs, lists + (size_t)RC_P464 * n, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,
+    default: if (item < itemsK) rc_tile_packed_hl<4, 64, MODE>(descs, listK, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,
                                                             tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
 #undef RC_PK32
     }
@@ -2084,6 +2114,7 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
 #undef RC_CO
 #undef RC_PK
     if (!done && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti;               // residual outside +-1023: the generic kernel takes it
+    asm volatile("" :: "v"(pfD[0]), "v"(pfD[1]));            // (the touched descriptor words: their registers stay theirs until the loads have landed)
 #ifdef RC_DIAG
     if (dgOn && dgn < 11) { dgk[dgn] = k; dgn++; }
 #endif
@@ -2145,7 +2176,7 @@ __attribute__((visibility("hidden"))) int vvcgpu_tr_image_build(void)
 // the classify / chain / generic launches behind vvcgpu_resi_chain_batch (mode RC_CHAIN) and, for long calls, behind vvcgpu_tr_fwd_batch /
 // vvcgpu_tr_inv_batch (RC_FWD / RC_INV; transform.hip): ONE chain launch with packed tiles instead of the small / matrix-core / dot2 kernels in a row
 static int rc_chain_launch(int mode, const vvc_pel* org_base, const vvc_pel* pred_base, vvc_pel* rec_base, vvc_coef* level_base, const void* descs_raw, int n,
-                           int bit_depth, int clp_min, int clp_max, uint32_t* abs_sum, hipStream_t st)
+                           int bit_depth, int clp_min, int clp_max, uint32_t* abs_sum, hipStream_t st, const RcBins* runs = nullptr)
 {
   VvcTrTables tb;
   const int rt = vvcgpu_tr_tables(&tb);
@@ -2168,8 +2199,20 @@ static int rc_chain_launch(int mode, const vvc_pel* org_base, const vvc_pel* pre
   int* lists = ws;
   int* fbCount = hdr + RC_FB;
   int* fbList = lists + (size_t)RC_NCLS * n;
+  RcBins bins;
+  memset(&bins, 0, sizeof bins);
+  if (runs)
+  {
+    // the caller's descriptors are grouped by shape (vvcgpu_resi_chain_runs_batch): no classifier launch, the class lists are ranges of an identity array
+    bins = *runs;
+    bins.use = 1;
+    lists = vvcgpu_iota(st, n);
+    if (!lists) return VVCGPU_E_DEVICE;
+    fbList = ws;
+  }
   const dim3 cg(n < 1024 * RC_CLS_WGS ? cdiv(n, 1024) : RC_CLS_WGS);
-  if (mode == RC_CHAIN)
+  if (runs) { }
+  else if (mode == RC_CHAIN)
     hipLaunchKernelGGL(rc_classify_kernel<false>, cg, dim3(1024), 0, st, descs_raw, n, hdr, lists, abs_sum, counters + VVC_CTR_INTS * (cur ^ 1), true, conv);
   else
     hipLaunchKernelGGL(rc_classify_kernel<true>, cg, dim3(1024), 0, st, descs_raw, n, hdr, lists, abs_sum, counters + VVC_CTR_INTS * (cur ^ 1), true, conv);
@@ -2178,7 +2221,7 @@ static int rc_chain_launch(int mode, const vvc_pel* org_base, const vvc_pel* pre
   // back on the caller's stream, 0.158 vs 0.115 ms at 4K -- a cross-stream event costs more than these 20 us kernels gain)
   {
 #define RC_CHAIN_LAUNCH(M) hipLaunchKernelGGL(rc_chain_kernel<M>, dim3(768), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, fbCount, \
-                                             fbList, abs_sum, bit_depth, clp_min, clp_max, image, tb)
+                                             fbList, abs_sum, bit_depth, clp_min, clp_max, image, tb, bins, counters + VVC_CTR_INTS * (cur ^ 1))
     if (mode == RC_CHAIN) RC_CHAIN_LAUNCH(RC_CHAIN); else if (mode == RC_FWD) RC_CHAIN_LAUNCH(RC_FWD); else RC_CHAIN_LAUNCH(RC_INV);
 #undef RC_CHAIN_LAUNCH
     VVC_LAUNCH_CHECK_COUNTERS(st);
@@ -2186,8 +2229,9 @@ static int rc_chain_launch(int mode, const vvc_pel* org_base, const vvc_pel* pre
   // (a quarter of round 5's grid: on conforming input both lists are empty and the launch is its own cost -- 6.2 us per 4K picture for 1280 workgroups that
   // read a count and leave; the waves walk their lists with the grid's stride whatever its size)
   const int wgS = cdiv(n, 4) < 256 ? cdiv(n, 4) : 256, wgG = n < 96 ? n : 96;
+  // (runs: no generic class -- shapes outside the chain's bodies take the classified path; its count word of the zeroed header reads 0)
 #define RC_GEN_LAUNCH(M) hipLaunchKernelGGL(rc_generic_kernel<M>, dim3(wgS + wgG), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_CGEN, \
-                                           lists + (size_t)RC_CGEN * n, fbCount, fbList, wgS, abs_sum, bit_depth, clp_min, clp_max, tb)
+                                           runs ? lists : lists + (size_t)RC_CGEN * n, fbCount, fbList, wgS, abs_sum, bit_depth, clp_min, clp_max, tb)
   if (mode == RC_CHAIN) RC_GEN_LAUNCH(RC_CHAIN); else if (mode == RC_FWD) RC_GEN_LAUNCH(RC_FWD); else RC_GEN_LAUNCH(RC_INV);
 #undef RC_GEN_LAUNCH
   VVC_LAUNCH_CHECK_COUNTERS(st);
@@ -2212,6 +2256,39 @@ int vvcgpu_resi_chain_batch(const vvc_pel* org_base, const vvc_pel* pred_base, v
   VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "resi_chain_batch: bit depth %d outside 8..10", bit_depth);
   VVC_CHECK_ARG(clp_min <= clp_max, "resi_chain_batch: clipping range");
   return rc_chain_launch(RC_CHAIN, org_base, pred_base, rec_base, level_base, descs, n, bit_depth, clp_min, clp_max, abs_sum, (hipStream_t)stream);
+}
+
+int vvcgpu_resi_chain_runs_batch(const vvc_pel* org_base, const vvc_pel* pred_base, vvc_pel* rec_base, vvc_coef* level_base,
+                                 const vvcgpu_resi_chain_desc* descs, int n, const int32_t* runs_host, int n_runs,
+                                 int bit_depth, int clp_min, int clp_max, uint32_t* abs_sum, void* stream)
+{
+  VVC_CHECK_ARG(n >= 0 && n_runs >= 0, "resi_chain_runs_batch: n %d, n_runs %d", n, n_runs);
+  if (n == 0) return VVCGPU_OK;
+  VVC_CHECK_ARG(org_base && pred_base && rec_base && level_base && descs && abs_sum && runs_host, "resi_chain_runs_batch: null pointer");
+  VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "resi_chain_runs_batch: bit depth %d outside 8..10", bit_depth);
+  VVC_CHECK_ARG(clp_min <= clp_max, "resi_chain_runs_batch: clipping range");
+  RcBins bins;
+  memset(&bins, 0, sizeof bins);
+  long long at = 0;
+  bool classified = false;                                   // a shape outside the chain's own bodies: the classified path takes the whole call
+  for (int r = 0; r < n_runs; r++)
+  {
+    const int w = runs_host[3 * r], h = runs_host[3 * r + 1], cnt = runs_host[3 * r + 2];
+    VVC_CHECK_ARG(cnt >= 0 && w >= 2 && w <= 64 && h >= 2 && h <= 64 && (w & (w - 1)) == 0 && (h & (h - 1)) == 0, "resi_chain_runs_batch: run %d (%d x %d, %d TUs)", r, w, h, cnt);
+    if (cnt == 0) continue;
+    RcDesc d;
+    d.w = (short)w; d.h = (short)h;
+    const int cls = rc_class(d, true);
+    if (cls == RC_CGEN) classified = true;
+    else
+    {
+      VVC_CHECK_ARG(bins.cnt[cls] == 0, "resi_chain_runs_batch: shape %d x %d appears in two runs", w, h);
+      bins.base[cls] = (int)at; bins.cnt[cls] = cnt;
+    }
+    at += cnt;
+  }
+  VVC_CHECK_ARG(at == n, "resi_chain_runs_batch: the runs hold %lld TUs, n = %d", at, n);
+  return rc_chain_launch(RC_CHAIN, org_base, pred_base, rec_base, level_base, descs, n, bit_depth, clp_min, clp_max, abs_sum, (hipStream_t)stream, classified ? nullptr : &bins);
 }
 
 }  // extern "C"

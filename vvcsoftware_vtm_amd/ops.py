@@ -481,6 +481,15 @@ def resi_chain_batch(org_base, pred_base, rec_base, level_base, descs_dev, n, bi
     return out
 
 
+def resi_chain_runs_batch(org_base, pred_base, rec_base, level_base, descs_dev, n, runs, bit_depth=10, clp=(0, 1023)):
+    """the same for descriptors grouped by shape: runs = [(w, h, count), ...] in the order of the list (vvcgpu_resi_chain_runs_batch)"""
+    r = np.ascontiguousarray(np.asarray(runs, dtype=np.int32).reshape(-1, 3))
+    out = torch.empty(n, dtype=torch.int32, device=org_base.device)
+    capi.call("vvcgpu_resi_chain_runs_batch", capi.ptr(org_base), capi.ptr(pred_base), capi.ptr(rec_base), capi.ptr(level_base), capi.ptr(descs_dev), n,
+              C.c_void_p(r.ctypes.data), int(r.shape[0]), bit_depth, clp[0], clp[1], capi.ptr(out), _stream())
+    return out
+
+
 # ---- picture-level forms of the in-loop entry points (three planes, one launch each) ------------------------
 class Planes(C.Structure):
     """vvcgpu_planes"""

@@ -218,6 +218,11 @@ class Workload:
                         rows.append(((y0 + ty) * width + x0 + tx, coff, width, s, s, th, tv, 0, 0))
                         coff += s * s
         self.tr = np.array(rows, dtype=TR_DESC)
+        # the TU list an encoder hands over is grouped by shape (largest first; it knows the shapes when it builds the list): the one-pass chain then runs
+        # without a classification launch (vvcgpu_resi_chain_runs_batch).  Stable, so inside a shape the TUs keep their picture order.
+        order = np.argsort(-self.tr["w"].astype(np.int64), kind="stable")
+        self.tr = np.ascontiguousarray(self.tr[order])
+        self.tu_runs = [(int(s_), int(s_), int((self.tr["w"] == s_).sum())) for s_ in sizes if (self.tr["w"] == s_).any()]
         self.n_coef = coff
         # quantiser between the transforms: Quant::quant without RDOQ (P slice, sign bit hiding) and Quant::dequant at the base QP
         qp = self.qp + 6 * (bit_depth - 8)
@@ -568,7 +573,7 @@ class Workload:
         # ---- residual / transforms / reconstruction
         if self.fused_resi:
             with T("resi/resi_chain"):
-                out["abs_sum"] = ops.resi_chain_batch(st["org"][0], st["pred"][0], st["rec"][0], st["level"], st["rc"], self.tr.size, bd, (0, mx))
+                out["abs_sum"] = ops.resi_chain_runs_batch(st["org"][0], st["pred"][0], st["rec"][0], st["level"], st["rc"], self.tr.size, self.tu_runs, bd, (0, mx))
                 # (outside the TU tiling the residual is zero, and chroma carries no residual in this workload: reconstruction = clipped prediction,
                 # B4 copyClip / xReconInter with cbf == 0 -- written there by the motion compensation itself: mc_rec_mask)
         else:
