@@ -161,8 +161,8 @@ def profile_launches():
     with open(path) as f:
         for r in csv.DictReader(f):
             k = r["kernel"]
-            if k.startswith("at::") or "elementwise" in k:
-                continue
+            if k.startswith("at::") or "elementwise" in k or k.startswith("__amd_rocclr"):
+                continue                                             # torch kernels and runtime copies / fills (hand-over, state set-up): not launches of the library
             m = re.search(r"(\d*)([a-z][a-z0-9_]*_kernel)", k)        # readable name out of a (possibly mangled) symbol
             name = (m.group(2) if m else k[:48]) + (k[k.index("<"):k.index(">") + 1] if "<" in k and ">" in k else "")
             rows.append((name, int(r["calls"]), float(r["avg_us"])))
@@ -617,7 +617,8 @@ def main():
             "dtype": "int16",
             "data": "synthetic",
             "config": {"workload": "hot-path canonical per-picture workload (SURVEY 8(d) M1: ME SAD searches 16/32/64 +-4 & raster +-96 (one hierarchical launch, every SAD once), fused half/quarter refinement 16x16 (9+9 SATD), "
-                                   "bi-pred MC 16x16, residual+fwd transform+quantiser (Quant::quant, sign hiding)+dequant+inv transform+reco, deblock, SAO stats+apply, ALF classify+stats+filter) "
+                                   "bi-pred MC 16x16 (PUs without residual stored straight into the reconstruction), residual+fwd transform+quantiser (Quant::quant, sign hiding)+dequant+inv transform+reco "
+                                   "(TUs handed over grouped by shape: vvcgpu_resi_chain_runs_batch), deblock, SAO stats+apply, ALF classify+stats+filter) "
                                    "on %dx%d 10-bit 4:2:0 (BASELINE configs[3] picture format; configs[1] is the same workload at 1920x1080), planes resident in HBM; "
                                    "step = one intra period of %d pictures + hand-over of the last reconstructed picture as the next chunk's reference; "
                                    "NOT EncoderApp fps (RDO control loop out of scope)" % (args.width, args.height, pps),
