@@ -1007,7 +1007,9 @@ static const _Float16* mm_image(int bd)
 // sample-wise body was 0.6 ms for the 518 k sub-blocks of a 4K picture.  Only in the SUB44 variant of the generic kernel (the affine entry points
 // launch it): with this path the kernel needs 214 VGPRs instead of 127 -- inline or as a real call -- which costs every other PU size a wave per SIMD.
 constexpr int MC44_DW = 11 * 6 + 4 * 6 + 8;                               // per group: window, transposed intermediate (4 x 12 shorts), output (16 shorts)
-__device__ __forceinline__ void mc_luma4x4_chunk(unsigned long long todo44, const vvcgpu_mc_desc* __restrict__ descs, const Pel* __restrict__ ref0Base,
+// Returns the PUs (bits of todo44) whose windows hold a sample outside the bit depth: the packed two-pass form is not the reference's for those (mc_stage),
+// the caller serves them with the sample-wise body.
+__device__ __forceinline__ unsigned long long mc_luma4x4_chunk(unsigned long long todo44, const vvcgpu_mc_desc* __restrict__ descs, const Pel* __restrict__ ref0Base,
                                                  const Pel* __restrict__ ref1Base, Pel* __restrict__ dstBase, int bd, int cmin, int cmax, int lane, unsigned* tileL)
 {
   unsigned* L = tileL + (lane >> 4) * MC44_DW;
@@ -1026,14 +1028,22 @@ __device__ __forceinline__ void mc_luma4x4_chunk(unsigned long long todo44, cons
   vvcgpu_mc_desc dC = pick(selC), dN = dC;
   McStaged<8, 4, 16> sC, sN;
   mc_stage<8, 4, 16>(dC, selC >= 0, ref0Base, ref1Base, gl, sC, bd);
+  unsigned redoLo = 0u, redoHi = 0u;
   for (;;)
   {
     const bool more = todo44 != 0ull;
     if (more) { dN = pick(selN); mc_stage<8, 4, 16>(dN, selN >= 0, ref0Base, ref1Base, gl, sN, bd); }
-    mc_tile_dot2<8, 4, 16>(dC, selC >= 0, sC, dstBase, bd, cmin, cmax, gl, L, reinterpret_cast<short*>(L + 11 * 6), reinterpret_cast<short*>(L + 11 * 6 + 4 * 6));
+    const unsigned long long bm = __builtin_amdgcn_ballot_w64(selC >= 0 && sC.bad != 0u);
+    const bool grpBad = ((bm >> (lane & 48)) & 0xFFFFull) != 0ull;           // this lane group's PU
+    if (grpBad && selC >= 0) { if (selC < 32) redoLo |= 1u << selC; else redoHi |= 1u << (selC - 32); }
+    mc_tile_dot2<8, 4, 16>(dC, selC >= 0 && !grpBad, sC, dstBase, bd, cmin, cmax, gl, L, reinterpret_cast<short*>(L + 11 * 6), reinterpret_cast<short*>(L + 11 * 6 + 4 * 6));
     if (!more) break;
     dC = dN; selC = selN; sC = sN;
   }
+  unsigned lo = 0u, hi = 0u;
+#pragma unroll
+  for (int g4 = 0; g4 < 64; g4 += 16) { lo |= (unsigned)__builtin_amdgcn_readlane((int)redoLo, g4); hi |= (unsigned)__builtin_amdgcn_readlane((int)redoHi, g4); }
+  return ((unsigned long long)hi << 32) | lo;
 }
 
 // generic kernel: any size, one wave per PU, persistent over the list of PUs the fast kernel left.
@@ -1074,7 +1084,7 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
     todo = __builtin_amdgcn_ballot_w64(mine);
     unsigned long long todo44 = __builtin_amdgcn_ballot_w64(sub44);        // 4x4 luma (affine sub-blocks): four at a time, see mc_luma4x4_quad
     todo &= ~todo44;
-    if (SUB44 && todo44) mc_luma4x4_chunk(todo44, descs + base0, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, tileL);
+    if (SUB44 && todo44) todo |= mc_luma4x4_chunk(todo44, descs + base0, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, tileL);
   }
   while (todo)
   {
