@@ -727,6 +727,27 @@ __device__ __forceinline__ bool rc_tu_coop(const RcDesc& d, const Pel* __restric
   return true;
 }
 
+// A TU that a matrix-core / lane-group body cannot take (its residual leaves +-1023, or inverse-only coefficients beyond 16 bits) is served ON THE SPOT by the wave
+// that found it, through the generic body with two 4096-int buffers in global scratch (`fbScr`: per wave, rc_chain_launch) -- rare, slow, exact.  Rounds 3 - 5 listed such
+// TUs for a launch behind the chain (4.7 us per 4K picture for an empty list).
+template <int MODE>
+__device__ __noinline__ void rc_fallback_call(const RcDesc* __restrict__ descs, int ti, const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                              TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
+                                              const int* __restrict__ tr32, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff, int* fbScr, int lane);
+// the lanes whose bit is set in `mask` each hold a TU index in tiLane: one after the other
+template <int MODE>
+__device__ __forceinline__ void rc_fallback_lanes(unsigned long long mask, int tiLane, const RcDesc* __restrict__ descs, const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase,
+                                                  Pel* __restrict__ recBase, TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
+                                                  const int* __restrict__ tr32, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff, int* fbScr, int lane)
+{
+  while (mask)
+  {
+    const int l = (int)__builtin_ctzll(mask);
+    mask &= mask - 1ull;
+    rc_fallback_call<MODE>(descs, __builtin_amdgcn_readlane(tiLane, l), orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tr32, dqInv, scanOff, fbScr, lane);
+  }
+}
+
 // ---------------------------------------------------------------------------------------------------
 // Packed tiles: TUs with a 4- or 8-point side (a real encode's residual is mostly these: tests/golden/trace_*.npz) on the matrix cores --
 // G = (16 / W) (16 / H) TUs of W x H side by side in ONE 16x16 tile, sub-TU (sx, sy) at tile columns W sx .., rows H sy ..  The 1-D stages become
@@ -754,8 +775,10 @@ __device__ __noinline__ void rc_tile_packed(const RcDesc* __restrict__ descs, co
                                                const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                                const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
-                                               int* __restrict__ fbCount, int* __restrict__ fbList, int* info, int lane)
+                                               const int* __restrict__ tr32, int* __restrict__ fbScr, int* info, int lane)
 {
+  unsigned long long fbMask = 0ull;                                             // sub-TUs this tile cannot take (lane j < G: TU j of the tile): served behind it
+  int fbTi = 0;
   constexpr int mode = MODE;
 
   constexpr int NX = 16 / W, NY = 16 / H, G = NX * NY;
@@ -809,7 +832,7 @@ __device__ __noinline__ void rc_tile_packed(const RcDesc* __restrict__ descs, co
   }
   const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!inRange);
   okL = tiL >= 0 && (badLanes & laneMask(sxL, syL)) == 0ull; okQ = tiQ >= 0 && (badLanes & laneMask(sxQ, syQ)) == 0ull;
-  if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMask(lane % NX, lane / NX)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
+  { const bool fb_ = badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMask(lane % NX, lane / NX)) != 0ull; if (fb_) fbTi = info[lane]; fbMask |= __builtin_amdgcn_ballot_w64(fb_); }
   h4 xa = zero4;
   if (okL) xa = h4{ (_Float16)(short)x[0], (_Float16)(short)x[1], (_Float16)(short)x[2], (_Float16)(short)x[3] };
 
@@ -854,6 +877,7 @@ __device__ __noinline__ void rc_tile_packed(const RcDesc* __restrict__ descs, co
       for (int r = 0; r < 4; r++) level[(y0 + r) * W + xq] = cf[r];
     }
     RC_WAVE_SYNC();
+    rc_fallback_lanes<MODE>(fbMask, fbTi, descs, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tr32, dqInv, scanOff, fbScr, lane);
     return;
   }
   // ---- quantiser in view Q: the lane's four coefficients are rows y0 .. y0 + 3 of column xq of its TU; its quad is one coefficient group
@@ -885,7 +909,7 @@ __device__ __noinline__ void rc_tile_packed(const RcDesc* __restrict__ descs, co
     for (int r = 0; r < 4; r++) { cq[r] = tiQ >= 0 ? level[(y0 + r) * W + xq] : 0; fits = fits && cq[r] >= -32768 && cq[r] <= 32767; }
     const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!fits);
     okQ = tiQ >= 0 && (badLanes & laneMaskQ(sxQ, syQ)) == 0ull; okL = tiL >= 0 && (badLanes & laneMaskQ(sxL, syL)) == 0ull;
-    if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMaskQ(lane % NX, lane / NX)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
+    { const bool fb_ = badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMaskQ(lane % NX, lane / NX)) != 0ull; if (fb_) fbTi = info[lane]; fbMask |= __builtin_amdgcn_ballot_w64(fb_); }
     if (!okQ) { cq[0] = 0; cq[1] = 0; cq[2] = 0; cq[3] = 0; }
   }
   // ---- I1: Y1T[i][r] = sum_k Cq[k][i] Tv(sub-TU of i, r)[k][r]: A = Cq^T (row i = c), B = rows of Tv^T; the type also belongs to A's row -> passes
@@ -932,6 +956,7 @@ __device__ __noinline__ void rc_tile_packed(const RcDesc* __restrict__ descs, co
     }
   }
   RC_WAVE_SYNC();                                                         // info is rewritten by the wave's next item
+  rc_fallback_lanes<MODE>(fbMask, fbTi, descs, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tr32, dqInv, scanOff, fbScr, lane);
 }
 
 // Packed tiles with a 32- or 64-point side: 32 x 8 / 32 x 4 / 64 x 8 / 64 x 4 (16 / H TUs one above the other in a 16-row x W-column multi-tile) and 8 x 32 / 4 x 32 /
@@ -943,8 +968,10 @@ __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs,
                                                 const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                 TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                                 const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
-                                                int* __restrict__ fbCount, int* __restrict__ fbList, int* info, int lane)
+                                                const int* __restrict__ tr32, int* __restrict__ fbScr, int* info, int lane)
 {
+  unsigned long long fbMask = 0ull;                                             // sub-TUs this tile cannot take (lane j < G: TU j of the tile): served behind it
+  int fbTi = 0;
   constexpr int mode = MODE;
 
   constexpr int NY = 16 / H, G = NY, LH = H == 4 ? 2 : 3, LW = W == 32 ? 5 : 6, XS = W / 32, CT = W / 16, PITCH = W + 8;
@@ -995,7 +1022,7 @@ __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs,
   }
   const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!inRange);
   okL = tiL >= 0 && (badLanes & laneMask(syL)) == 0ull; okQ = tiQ >= 0 && (badLanes & laneMask(syQ)) == 0ull;
-  if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMask(lane)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
+  { const bool fb_ = badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMask(lane)) != 0ull; if (fb_) fbTi = info[lane]; fbMask |= __builtin_amdgcn_ballot_w64(fb_); }
   if (!okL) {
 #pragma unroll
     for (int sk = 0; sk < XS; sk++) xa[sk] = zero8;
@@ -1050,6 +1077,7 @@ __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs,
         }
     }
     RC_WAVE_SYNC();
+    rc_fallback_lanes<MODE>(fbMask, fbTi, descs, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tr32, dqInv, scanOff, fbScr, lane);
     return;
   }
   // ---- quantiser: the lane's coefficients are rows y0 .. y0 + 3 of columns c and 16 + c of TU syQ
@@ -1096,7 +1124,7 @@ __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs,
       for (int r = 0; r < 4; r++) { cqA[jt][r] = tiQ >= 0 ? level[(y0 + r) * W + 16 * jt + c] : 0; fits = fits && cqA[jt][r] >= -32768 && cqA[jt][r] <= 32767; }
     const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!fits);
     okQ = tiQ >= 0 && (badLanes & laneMaskQ(syQ)) == 0ull; okL = tiL >= 0 && (badLanes & laneMaskQ(syL)) == 0ull;
-    if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMaskQ(lane)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
+    { const bool fb_ = badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMaskQ(lane)) != 0ull; if (fb_) fbTi = info[lane]; fbMask |= __builtin_amdgcn_ballot_w64(fb_); }
     if (!okQ)
     {
 #pragma unroll
@@ -1160,6 +1188,7 @@ __device__ __noinline__ void rc_tile_packed_wl(const RcDesc* __restrict__ descs,
     }
   }
   RC_WAVE_SYNC();
+  rc_fallback_lanes<MODE>(fbMask, fbTi, descs, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tr32, dqInv, scanOff, fbScr, lane);
 }
 
 template <int W, int H, int MODE>
@@ -1167,8 +1196,10 @@ __device__ __noinline__ void rc_tile_packed_hl(const RcDesc* __restrict__ descs,
                                                 const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                 TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                                 const _Float16* tab, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff,
-                                                int* __restrict__ fbCount, int* __restrict__ fbList, int* info, int lane)
+                                                const int* __restrict__ tr32, int* __restrict__ fbScr, int* info, int lane)
 {
+  unsigned long long fbMask = 0ull;                                             // sub-TUs this tile cannot take (lane j < G: TU j of the tile): served behind it
+  int fbTi = 0;
   constexpr int mode = MODE;
 
   constexpr int NX = 16 / W, G = NX, LW = W == 4 ? 2 : 3, LH = H == 32 ? 5 : 6, RT = H / 16, KS = H / 32, PITCH = H + 8;
@@ -1225,7 +1256,7 @@ __device__ __noinline__ void rc_tile_packed_hl(const RcDesc* __restrict__ descs,
   }
   const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!inRange);
   okL = tiL >= 0 && (badLanes & laneMask(sxL)) == 0ull; okQ = tiQ >= 0 && (badLanes & laneMask(sxQ)) == 0ull;
-  if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMask(lane)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
+  { const bool fb_ = badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMask(lane)) != 0ull; if (fb_) fbTi = info[lane]; fbMask |= __builtin_amdgcn_ballot_w64(fb_); }
   if (!okL) {
 #pragma unroll
     for (int rt = 0; rt < RT; rt++) xa[rt] = zero4;
@@ -1283,6 +1314,7 @@ __device__ __noinline__ void rc_tile_packed_hl(const RcDesc* __restrict__ descs,
         }
     }
     RC_WAVE_SYNC();
+    rc_fallback_lanes<MODE>(fbMask, fbTi, descs, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tr32, dqInv, scanOff, fbScr, lane);
     return;
   }
   // ---- quantiser: the lane's coefficients are rows 16 it + 4 g .. of column xq of TU sxQ
@@ -1329,7 +1361,7 @@ __device__ __noinline__ void rc_tile_packed_hl(const RcDesc* __restrict__ descs,
       for (int r = 0; r < 4; r++) { cqA[it][r] = tiQ >= 0 ? level[(16 * it + 4 * g + r) * W + xq] : 0; fits = fits && cqA[it][r] >= -32768 && cqA[it][r] <= 32767; }
     const unsigned long long badLanes = __builtin_amdgcn_ballot_w64(!fits);
     okQ = tiQ >= 0 && (badLanes & laneMaskQ(sxQ)) == 0ull; okL = tiL >= 0 && (badLanes & laneMaskQ(sxL)) == 0ull;
-    if (badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMaskQ(lane)) != 0ull) fbList[atomicAdd(fbCount, 1)] = info[lane];
+    { const bool fb_ = badLanes != 0ull && lane < G && info[lane] >= 0 && (badLanes & laneMaskQ(lane)) != 0ull; if (fb_) fbTi = info[lane]; fbMask |= __builtin_amdgcn_ballot_w64(fb_); }
     if (!okQ)
     {
 #pragma unroll
@@ -1387,6 +1419,7 @@ __device__ __noinline__ void rc_tile_packed_hl(const RcDesc* __restrict__ descs,
     }
   }
   RC_WAVE_SYNC();
+  rc_fallback_lanes<MODE>(fbMask, fbTi, descs, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tr32, dqInv, scanOff, fbScr, lane);
 }
 
 // ---------------------------------------------------------------------------------------------------
@@ -1552,41 +1585,36 @@ __device__ void rc_tu_generic(const RcDesc& d, const Pel* __restrict__ orgBase, 
 // The class-`generic` list holds TUs with a side of at most 8 (both sides >= 16 are matrix-core classes), i.e. at most 64 x 8 samples: 512-int
 // buffers, four waves per workgroup (eight times the waves per compute unit of a 4096-int single-wave form).  The fall-back list of the
 // matrix-core classes (a residual outside +-1023) holds TUs of up to 64 x 64.
-// ONE launch for both lists (an empty launch still costs ~4.6 us of a 4K picture): workgroups [0, wgSmall) serve the class-`generic` list,
-// four waves with 512-int buffers each and the matrices in LDS; the workgroups behind them serve the fall-back list with ONE wave and
-// 4096-int buffers (the other three waves leave at once).  The two forms share the LDS bytes.
 template <int MODE>
-__global__ __launch_bounds__(256) void rc_generic_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+__device__ __noinline__ void rc_fallback_call(const RcDesc* __restrict__ descs, int ti, const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
+                                              TCoeff* __restrict__ levelBase, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
+                                              const int* __restrict__ tr32, const unsigned short* __restrict__ dqInv, const int* __restrict__ scanOff, int* fbScr, int lane)
+{
+  rc_tu_generic<MODE>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tr32, dqInv, scanOff, fbScr, fbScr + 4096, lane, nullptr);
+}
+
+// The class-`generic` list (TUs with a side of 2: chroma of 4-wide luma TUs): four waves per workgroup with 512-int buffers each and the matrices in LDS.
+// (Until round 6 this launch also served the fall-back list of the matrix-core bodies; those TUs are now served in place, rc_fallback_call.)
+// (launch bounds as the chain kernel's: the generic body is ONE function for both kernels, compiled for the looser of its callers' register budgets)
+template <int MODE>
+__global__ __launch_bounds__(256, 3) void rc_generic_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                         TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs,
                                                         const int* __restrict__ countA, const int* __restrict__ listA,
-                                                        const int* __restrict__ countB, const int* __restrict__ listB, int wgSmall,
                                                         unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax, VvcTrTables tb)
 {
-  constexpr int SMALL_INTS = 2 * 4 * 512 + RC_GT_INTS, BIG_INTS = 2 * 4096;
-  __shared__ int lds[SMALL_INTS > BIG_INTS ? SMALL_INTS : BIG_INTS];
+  __shared__ int lds[2 * 4 * 512 + RC_GT_INTS];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
-  if ((int)blockIdx.x < wgSmall)
+  const int ca = countA[0];
+  if ((int)blockIdx.x * 4 >= ca) return;
+  int* tabL = lds + 2 * 4 * 512;
+  for (int e = threadIdx.x; e < RC_GT_INTS; e += 256)
+    tabL[e] = e < 3 * RC_GT_TYPE ? tb.tr32[(e / RC_GT_TYPE) * 5460 + e % RC_GT_TYPE] : tb.tr32[1364 + e - 3 * RC_GT_TYPE];
+  __syncthreads();
+  for (int k = blockIdx.x * 4 + wave; k < ca; k += (int)gridDim.x * 4)
   {
-    const int ca = countA[0];
-    if ((int)blockIdx.x * 4 >= ca) return;
-    int* tabL = lds + 2 * 4 * 512;
-    for (int e = threadIdx.x; e < RC_GT_INTS; e += 256)
-      tabL[e] = e < 3 * RC_GT_TYPE ? tb.tr32[(e / RC_GT_TYPE) * 5460 + e % RC_GT_TYPE] : tb.tr32[1364 + e - 3 * RC_GT_TYPE];
-    __syncthreads();
-    for (int k = blockIdx.x * 4 + wave; k < ca; k += wgSmall * 4)
-    {
-      const int ti = listA[k];
-      rc_tu_generic<MODE>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, lds + wave * 1024,
-                          lds + wave * 1024 + 512, lane, tabL);
-    }
-    return;
-  }
-  if (wave != 0) return;
-  const int cb = countB[0], nBig = (int)gridDim.x - wgSmall;
-  for (int k = (int)blockIdx.x - wgSmall; k < cb; k += nBig)
-  {
-    const int ti = listB[k];
-    rc_tu_generic<MODE>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, lds, lds + 4096, lane, nullptr);
+    const int ti = listA[k];
+    rc_tu_generic<MODE>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, lds + wave * 1024,
+                        lds + wave * 1024 + 512, lane, tabL);
   }
 }
 
@@ -1947,8 +1975,8 @@ __device__ __forceinline__ void rc_slot_class(const int* sCnt, const int* sEnd, 
 template <int MODE>
 __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict__ orgBase, const Pel* __restrict__ predBase, Pel* __restrict__ recBase,
                                                           TCoeff* __restrict__ levelBase, const RcDesc* __restrict__ descs, int n,
-                                                          const int* __restrict__ hdr, const int* __restrict__ lists, int* __restrict__ fbCount,
-                                                          int* __restrict__ fbList, unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
+                                                          const int* __restrict__ hdr, const int* __restrict__ lists, int* __restrict__ fbScratch,
+                                                          unsigned* __restrict__ absSumOut, int bd, int clpMin, int clpMax,
                                                           const _Float16* __restrict__ image, VvcTrTables tb, RcBins bins, int* __restrict__ nextHdr)
 {
   if (bins.use && blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextHdr[threadIdx.x] = 0;   // (no classifier in front: this launch clears the counter set of the NEXT call, vvcgpu_counters)
@@ -1958,6 +1986,7 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
   __shared__ int red[4];                                      // co-operative TUs: abs sum, last coefficient group, range flag (rc_tu_coop)
   static_assert(sizeof(tmpAll) >= RC_EX_HALVES * sizeof(_Float16), "limb planes of rc_tu_coop");
   const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // wave-uniform for the compiler too: list entries and descriptors of single-TU items arrive through the scalar cache
+  int* const fbScr = fbScratch + ((size_t)blockIdx.x * 4 + wave) * 8192;     // this wave's two 4096-int buffers for a TU its body cannot take (rc_fallback_call)
   // slots (four wave items of one entry) in the order below: the longest items first, so that the short ones fill the machine while they run.
   // 8x8 / 8x4 / 4x8 / 4x4 stay with the lane groups: as packed tiles (exact as well) they are slower (8M samples: 8x8 0.164 vs 0.143 ms, 4x4 0.175
   // vs 0.142) -- a lane of a tile touches four 8-byte row pieces of its TU, a lane of a group one whole row
@@ -2046,7 +2075,7 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
         done = rc_tu_mfma_call<W_, H_, MODE>(descs, ti, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane); } break;
 #define RC_PK(K, W_, H_)                                                                                                                      \
     case K: if (item < itemsK) rc_tile_packed<W_, H_, MODE>(descs, listK, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, \
-                                                        clpMax, tab, tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
+                                                        clpMax, tab, tb.dqInv, tb.scanOff, tb.tr32, fbScr, tmpAll[wave], lane); break;
 #define RC_CO(K, W_, H_)                                                                                                                      \
     case K: { ti = __builtin_amdgcn_readfirstlane(listK[item]);                                                       \
         done = rc_tu_coop<W_, H_, MODE>(descs[ti], orgBase, predBase, recBase, levelBase, absSumOut, ti, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, \
@@ -2067,6 +2096,7 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
       const int G4 = 4 * (int)gridDim.x;
       int it = item;
       if (it >= cntK) break;
+      int nAside = 0;                                        // TUs outside the matrix-core range (at most one per slot of the walk: far below the 576 ints of the wave's scratch)
       int ti0 = __builtin_amdgcn_readfirstlane(lst[it]);
       int tiv1 = it + G4 < cntK ? lst[it + G4 + vz] : 0;
       uint4 dq = reinterpret_cast<const uint4*>(descs + ti0)[(lane & 3) + vz];
@@ -2090,10 +2120,13 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
           tiv1 = it + 2 * G4 < cntK ? lst[it + 2 * G4 + vz] : 0;
         }
         const bool ok = rc_tu_mfma<16, 16, MODE>(dCur, orgBase, predBase, recBase, levelBase, absSumOut, ti0, bd, clpMin, clpMax, tab, tb.dqInv, tb.scanOff, lane);
-        if (!ok && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti0;
+        if (!ok) { if (lane == 0) tmpAll[wave][nAside] = ti0; nAside++; }     // served behind the walk: a call inside this loop keeps the loop's registers in scratch memory
         if (!more) break;
         it += G4; ti0 = ti1; slot += (int)gridDim.x;
       }
+      RC_WAVE_SYNC();
+      for (int i = 0; i < nAside; i++)
+        rc_fallback_call<MODE>(descs, __builtin_amdgcn_readfirstlane(tmpAll[wave][i]), orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, fbScr, lane);
       break;
     }
     RC_PK(10, 16, 8) RC_PK(11, 8, 16) RC_PK(12, 16, 4) RC_PK(13, 4, 16)
@@ -2103,17 +2136,17 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
     case 16: if (item < itemsK) rc_rect_group<4, 8, MODE>(descs, listK, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane); break;
 #define RC_PK32(K, F)                                                                                                                         \
     case K: if (item < itemsK) F(descs, listK, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,     \
-                                   tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
+                                   tb.dqInv, tb.scanOff, tb.tr32, fbScr, tmpAll[wave], lane); break;
     RC_PK32(17, (rc_tile_packed_wl<32, 8, MODE>)) RC_PK32(18, (rc_tile_packed_hl<8, 32, MODE>)) RC_PK32(19, (rc_tile_packed_wl<32, 4, MODE>)) RC_PK32(20, (rc_tile_packed_hl<4, 32, MODE>))
     RC_PK32(21, (rc_tile_packed_wl<64, 8, MODE>)) RC_PK32(22, (rc_tile_packed_hl<8, 64, MODE>)) RC_PK32(23, (rc_tile_packed_wl<64, 4, MODE>))
     default: if (item < itemsK) rc_tile_packed_hl<4, 64, MODE>(descs, listK, cntK, item, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tab,
-                                                            tb.dqInv, tb.scanOff, fbCount, fbList, tmpAll[wave], lane); break;
+                                                            tb.dqInv, tb.scanOff, tb.tr32, fbScr, tmpAll[wave], lane); break;
 #undef RC_PK32
     }
 #undef RC_MF
 #undef RC_CO
 #undef RC_PK
-    if (!done && lane == 0) fbList[atomicAdd(fbCount, 1)] = ti;               // residual outside +-1023: the generic kernel takes it
+    if (!done) rc_fallback_call<MODE>(descs, ti, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tb.tr32, tb.dqInv, tb.scanOff, fbScr, lane);   // residual outside +-1023 (co-operative TU: wave 0, behind the TU's last barrier)
     asm volatile("" :: "v"(pfD[0]), "v"(pfD[1]));            // (the touched descriptor words: their registers stay theirs until the loads have landed)
 #ifdef RC_DIAG
     if (dgOn && dgn < 11) { dgk[dgn] = k; dgn++; }
@@ -2183,12 +2216,16 @@ static int rc_chain_launch(int mode, const vvc_pel* org_base, const vvc_pel* pre
   if (rt) return rt;
   const _Float16* image = vvcgpu_mfma_image(tb);
   if (!image) return VVCGPU_E_DEVICE;
-  // scratch: the class lists, the fall-back list of the matrix-core bodies, (plain transforms) the descriptors as chain descriptors
-  const size_t ints = (size_t)RC_NCLS * n + (size_t)n;
+  // scratch: the class lists, (plain transforms) the descriptors as chain descriptors, and per wave of the chain launch two 4096-int buffers for a TU its
+  // body cannot take (rc_fallback_call: touched only then)
+  constexpr int CHAIN_WGS = 768;
+  const size_t ints = (size_t)RC_NCLS * n;
   const size_t convOff = (ints * sizeof(int) + 63) & ~(size_t)63;
-  int* ws = static_cast<int*>(vvcgpu_scratch(st, convOff + (mode == RC_CHAIN ? 0 : (size_t)n * sizeof(RcDesc))));
+  const size_t fbOff = (convOff + (mode == RC_CHAIN ? 0 : (size_t)n * sizeof(RcDesc)) + 63) & ~(size_t)63;
+  int* ws = static_cast<int*>(vvcgpu_scratch(st, fbOff + (size_t)CHAIN_WGS * 4 * 8192 * sizeof(int)));
   if (!ws) return VVCGPU_E_DEVICE;
   RcDesc* conv = mode == RC_CHAIN ? nullptr : reinterpret_cast<RcDesc*>(reinterpret_cast<unsigned char*>(ws) + convOff);
+  int* fbScratch = reinterpret_cast<int*>(reinterpret_cast<unsigned char*>(ws) + fbOff);
   const RcDesc* descs = mode == RC_CHAIN ? static_cast<const RcDesc*>(descs_raw) : conv;
   // the header lives in the stream's persistent zeroed counters: this call's set is clean, the classifier clears the other set for the next
   // call (no fill launch in front of the chain)
@@ -2197,8 +2234,6 @@ static int rc_chain_launch(int mode, const vvc_pel* org_base, const vvc_pel* pre
   if (!counters) return VVCGPU_E_DEVICE;
   int* hdr = counters + VVC_CTR_INTS * cur;
   int* lists = ws;
-  int* fbCount = hdr + RC_FB;
-  int* fbList = lists + (size_t)RC_NCLS * n;
   RcBins bins;
   memset(&bins, 0, sizeof bins);
   if (runs)
@@ -2208,7 +2243,6 @@ static int rc_chain_launch(int mode, const vvc_pel* org_base, const vvc_pel* pre
     bins.use = 1;
     lists = vvcgpu_iota(st, n);
     if (!lists) return VVCGPU_E_DEVICE;
-    fbList = ws;
   }
   const dim3 cg(n < 1024 * RC_CLS_WGS ? cdiv(n, 1024) : RC_CLS_WGS);
   if (runs) { }
@@ -2220,21 +2254,22 @@ static int rc_chain_launch(int mode, const vvc_pel* org_base, const vvc_pel* pre
   // (measured: forking the size classes onto library-owned side streams and joining them with events is SLOWER than launching them back to
   // back on the caller's stream, 0.158 vs 0.115 ms at 4K -- a cross-stream event costs more than these 20 us kernels gain)
   {
-#define RC_CHAIN_LAUNCH(M) hipLaunchKernelGGL(rc_chain_kernel<M>, dim3(768), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, fbCount, \
-                                             fbList, abs_sum, bit_depth, clp_min, clp_max, image, tb, bins, counters + VVC_CTR_INTS * (cur ^ 1))
+#define RC_CHAIN_LAUNCH(M) hipLaunchKernelGGL(rc_chain_kernel<M>, dim3(CHAIN_WGS), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, n, hdr, lists, fbScratch, \
+                                             abs_sum, bit_depth, clp_min, clp_max, image, tb, bins, counters + VVC_CTR_INTS * (cur ^ 1))
     if (mode == RC_CHAIN) RC_CHAIN_LAUNCH(RC_CHAIN); else if (mode == RC_FWD) RC_CHAIN_LAUNCH(RC_FWD); else RC_CHAIN_LAUNCH(RC_INV);
 #undef RC_CHAIN_LAUNCH
     VVC_LAUNCH_CHECK_COUNTERS(st);
   }
-  // (a quarter of round 5's grid: on conforming input both lists are empty and the launch is its own cost -- 6.2 us per 4K picture for 1280 workgroups that
-  // read a count and leave; the waves walk their lists with the grid's stride whatever its size)
-  const int wgS = cdiv(n, 4) < 256 ? cdiv(n, 4) : 256, wgG = n < 96 ? n : 96;
-  // (runs: no generic class -- shapes outside the chain's bodies take the classified path; its count word of the zeroed header reads 0)
-#define RC_GEN_LAUNCH(M) hipLaunchKernelGGL(rc_generic_kernel<M>, dim3(wgS + wgG), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_CGEN, \
-                                           runs ? lists : lists + (size_t)RC_CGEN * n, fbCount, fbList, wgS, abs_sum, bit_depth, clp_min, clp_max, tb)
-  if (mode == RC_CHAIN) RC_GEN_LAUNCH(RC_CHAIN); else if (mode == RC_FWD) RC_GEN_LAUNCH(RC_FWD); else RC_GEN_LAUNCH(RC_INV);
+  // the class-`generic` list (2-wide TUs); runs mode: such shapes take the classified path, so there is nothing to launch
+  if (!runs)
+  {
+    const int wgS = cdiv(n, 4) < 256 ? cdiv(n, 4) : 256;
+#define RC_GEN_LAUNCH(M) hipLaunchKernelGGL(rc_generic_kernel<M>, dim3(wgS), dim3(256), 0, st, org_base, pred_base, rec_base, level_base, descs, hdr + RC_CGEN, \
+                                           lists + (size_t)RC_CGEN * n, abs_sum, bit_depth, clp_min, clp_max, tb)
+    if (mode == RC_CHAIN) RC_GEN_LAUNCH(RC_CHAIN); else if (mode == RC_FWD) RC_GEN_LAUNCH(RC_FWD); else RC_GEN_LAUNCH(RC_INV);
 #undef RC_GEN_LAUNCH
-  VVC_LAUNCH_CHECK_COUNTERS(st);
+    VVC_LAUNCH_CHECK_COUNTERS(st);
+  }
   return VVCGPU_OK;
 }
 
