@@ -110,6 +110,24 @@ __device__ __forceinline__ void mh_block_min(unsigned kmin, unsigned idx0, unsig
 
 __device__ __forceinline__ void mh_positions(int OA, const unsigned* __restrict__ oq, unsigned base, int ldsStep, int hs, unsigned (&acc)[4])
 {
+#ifndef MH_LOOP_FORM
+  // the two row samplings the kernel serves (hs = 16 >> subShift, ldsStep = MH_PITCH << subShift), stage loop unrolled
+  if (hs == 8)
+  {
+    if (OA == 0)      r5q_positions_fixed<0, 8, 2 * MH_PITCH>(oq, base, acc);
+    else if (OA == 1) r5q_positions_fixed<1, 8, 2 * MH_PITCH>(oq, base, acc);
+    else if (OA == 2) r5q_positions_fixed<2, 8, 2 * MH_PITCH>(oq, base, acc);
+    else              r5q_positions_fixed<3, 8, 2 * MH_PITCH>(oq, base, acc);
+  }
+  else
+  {
+    if (OA == 0)      r5q_positions_fixed<0, 16, MH_PITCH>(oq, base, acc);
+    else if (OA == 1) r5q_positions_fixed<1, 16, MH_PITCH>(oq, base, acc);
+    else if (OA == 2) r5q_positions_fixed<2, 16, MH_PITCH>(oq, base, acc);
+    else              r5q_positions_fixed<3, 16, MH_PITCH>(oq, base, acc);
+  }
+  return;
+#endif
   if (OA == 0)      r5q_positions<0>(oq, base, ldsStep, 1, 0, hs, acc);
   else if (OA == 1) r5q_positions<1>(oq, base, ldsStep, 1, 0, hs, acc);
   else if (OA == 2) r5q_positions<2>(oq, base, ldsStep, 1, 0, hs, acc);
@@ -391,7 +409,9 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
   if (stamp && tid == 0) diag[1] = __builtin_amdgcn_s_memtime();
   if (diag && stampK >= 0 && tid == 0) diag[40 + 1 * 4 + stampK] = __builtin_amdgcn_s_memtime();
 
-#pragma unroll
+  // one copy of the unit's code (the unrolled stage bodies are ~3 KB each): the lane descriptor of the round is picked field by field, so that
+  // LU[] stays in registers (an array indexed by the loop counter would live in scratch memory)
+#pragma unroll 1
   for (int r = 0; r < 2; r++)
   {
     const int u = wave + r * nwaves;
@@ -400,7 +420,11 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
       const int sw = nsw - 1 - (u >> 2), q = u & 3;
       const int s = sw * 64 + lane;
       const bool waveHasDense = ndl > 0 && sw * 64 + 63 >= nslots;                // wave-uniform
-      mh_unit(orgPacked, g, off & 3, ldsBase + (unsigned)(slide * 128 + (q & 1) * 64 + (q >> 1) * 32 * MH_PITCH * 4), LU[r], waveHasDense, q, sbx, sby, nsubx, nsuby, keys, surf, surfD, &arrive[sw], s, nslots, lane);
+      MhLane L;
+      L.base = r ? LU[1].base : LU[0].base; L.idx = r ? LU[1].idx : LU[0].idx; L.kind = r ? LU[1].kind : LU[0].kind;
+#pragma unroll
+      for (int m = 0; m < 4; m++) L.cst[m] = r ? LU[1].cst[m] : LU[0].cst[m];
+      mh_unit(orgPacked, g, off & 3, ldsBase + (unsigned)(slide * 128 + (q & 1) * 64 + (q >> 1) * 32 * MH_PITCH * 4), L, waveHasDense, q, sbx, sby, nsubx, nsuby, keys, surf, surfD, &arrive[sw], s, nslots, lane);
       if (stamp && lane == 0) diag[8 + u] = __builtin_amdgcn_s_memtime();
     }
   }
