@@ -108,32 +108,6 @@ __device__ __forceinline__ void mh_block_min(unsigned kmin, unsigned idx0, unsig
   if (lane == 0 && km < MH_INVALID) atomicMin(key, ((unsigned long long)km << 24) | idx);
 }
 
-__device__ __forceinline__ void mh_positions(int OA, const unsigned* __restrict__ oq, unsigned base, int ldsStep, int hs, unsigned (&acc)[4])
-{
-#ifndef MH_LOOP_FORM
-  // the two row samplings the kernel serves (hs = 16 >> subShift, ldsStep = MH_PITCH << subShift), stage loop unrolled
-  if (hs == 8)
-  {
-    if (OA == 0)      r5q_positions_fixed<0, 8, 2 * MH_PITCH>(oq, base, acc);
-    else if (OA == 1) r5q_positions_fixed<1, 8, 2 * MH_PITCH>(oq, base, acc);
-    else if (OA == 2) r5q_positions_fixed<2, 8, 2 * MH_PITCH>(oq, base, acc);
-    else              r5q_positions_fixed<3, 8, 2 * MH_PITCH>(oq, base, acc);
-  }
-  else
-  {
-    if (OA == 0)      r5q_positions_fixed<0, 16, MH_PITCH>(oq, base, acc);
-    else if (OA == 1) r5q_positions_fixed<1, 16, MH_PITCH>(oq, base, acc);
-    else if (OA == 2) r5q_positions_fixed<2, 16, MH_PITCH>(oq, base, acc);
-    else              r5q_positions_fixed<3, 16, MH_PITCH>(oq, base, acc);
-  }
-  return;
-#endif
-  if (OA == 0)      r5q_positions<0>(oq, base, ldsStep, 1, 0, hs, acc);
-  else if (OA == 1) r5q_positions<1>(oq, base, ldsStep, 1, 0, hs, acc);
-  else if (OA == 2) r5q_positions<2>(oq, base, ldsStep, 1, 0, hs, acc);
-  else              r5q_positions<3>(oq, base, ldsStep, 1, 0, hs, acc);
-}
-
 // What a lane of a slot wave works on: four candidates 0 / 5 / 10 / 15 samples into one LDS span (the quad loop of raster_dev.h).
 //   raster lane : four consecutive columns of one raster row; visiting indices idx0 .. idx0 + 3 (lane order = visiting order)
 //   dense lane  : a lane of the +-D grid.  Its columns are 1 apart, not 5, but the span of a lane may start at any multiple of 4 samples: column
@@ -206,6 +180,42 @@ __device__ __forceinline__ void mh_block_min64(unsigned long long k, unsigned lo
   if (lane == 0 && km != ~0ull) atomicMin(key, km);
 }
 
+// The sub-blocks of a quadrant that exist (wave-uniform), walked as ONE pipeline of unrolled stage bodies (raster_dev.h: r5q_positions_fixed; NST sampled
+// rows per sub-block = 16 >> subShift, MH_PITCH << subShift dwords apart): the window reads and original rows of the next sub-block's first stage are
+// requested before the last stage of the current one is summed, so the arg-min folds between two sub-blocks run with loads in flight.
+struct MhWalk { const unsigned* orgPacked; unsigned base; int qx, qy, sbx, sby, nsubx, nsuby, n16x, sh; bool waveHasDense; int lane; };
+template <int OA, int NST>
+__device__ __forceinline__ int mh_walk(const MhWalk& w, const MhLane& L, unsigned long long* keys, unsigned (&a32)[4])
+{
+  constexpr int LSTEP = MH_PITCH * (16 / NST);
+  auto exists = [&](int t) { return 2 * w.qx + (t & 1) < w.nsubx && 2 * w.qy + (t >> 1) < w.nsuby; };
+  auto orgOf = [&](int t) { return w.orgPacked + (size_t)((4 * w.sby + 2 * w.qy + (t >> 1)) * w.n16x + 4 * w.sbx + 2 * w.qx + (t & 1)) * (unsigned)(16 * NST); };
+  auto baseOf = [&](int t) { return w.base + (unsigned)((t & 1) * 32 + (t >> 1) * 16 * MH_PITCH * 4); };
+  int t = 0, nsub = 0;
+  while (t < 4 && !exists(t)) t++;
+  R5qStage A, B;
+  if (t < 4) r5q_issue_at<OA, 0>(A, orgOf(t), baseOf(t));
+#pragma unroll 1
+  while (t < 4)
+  {
+    int tn = t + 1;
+    while (tn < 4 && !exists(tn)) tn++;
+    const int tx = 2 * w.qx + (t & 1), ty = 2 * w.qy + (t >> 1);
+    // issue priority by progress: the arbiter takes the oldest wave first, so the waves of a SIMD finish one after the other and the last one runs
+    // alone (per-unit stamps: 45 k, 49 k, 55 k cycles); a wave that is ahead in its unit yields to the ones behind
+    if (nsub == 0) __builtin_amdgcn_s_setprio(3); else if (nsub == 1) __builtin_amdgcn_s_setprio(2); else if (nsub == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
+    nsub++;
+    unsigned acc[4] = { 0u, 0u, 0u, 0u };
+    const int tnc = tn < 4 ? tn : t;
+    r5q_positions_fixed<OA, NST, LSTEP>(orgOf(t), baseOf(t), tn < 4, orgOf(tnc), baseOf(tnc), A, B, acc);
+    mh_block_min(L.kind == 1 ? mh_fold32(acc, L, w.sh) : 0xFFFFFFFFu, L.idx, &keys[ty * 4 + tx], w.lane);
+    if (w.waveHasDense) mh_block_min64(L.kind == 2 ? mh_fold64(acc, L, w.sh) : ~0ull, &keys[21 + ty * 4 + tx], w.lane);
+    a32[0] += acc[0]; a32[1] += acc[1]; a32[2] += acc[2]; a32[3] += acc[3];
+    t = tn;
+  }
+  return nsub;
+}
+
 // One unit: the four 16x16 sub-blocks of quadrant q for the lanes of one slot wave.
 //   keys   LDS: raster keys of the 16x16 blocks (16), the 32x32 (4), the 64x64 (1), then the same 21 for the +-D grid
 //   surf / surfD  LDS: 64x64 partial sums of the raster slots / the dense lanes, [slot][4]
@@ -213,27 +223,21 @@ __device__ __forceinline__ void mh_unit(const unsigned* __restrict__ orgPacked, 
                                         int q, int sbx, int sby, int nsubx, int nsuby, unsigned long long* keys, unsigned* surf, unsigned* surfD, int* arrive, int s, int nslots, int lane)
 {
   const int qx = q & 1, qy = q >> 1;
-  const int ldsStep = MH_PITCH << g.subShift;
   const int sh = g.subShift + 2;
   const unsigned base = qbase + L.base;
   unsigned a32[4] = { 0u, 0u, 0u, 0u };
   int nsub = 0;
-#pragma unroll 1
-  for (int t = 0; t < 4; t++)
   {
-    const int tx = 2 * qx + (t & 1), ty = 2 * qy + (t >> 1);
-    if (tx >= nsubx || ty >= nsuby) continue;                                   // wave-uniform: sub-block outside the grid
-    nsub++;
-    // issue priority by progress: the arbiter takes the oldest wave first, so the waves of a SIMD finish one after the other and the last one runs
-    // alone (per-unit stamps: 45 k, 49 k, 55 k cycles); a wave that is ahead in its unit yields to the ones behind
-    if (t == 0) __builtin_amdgcn_s_setprio(3); else if (t == 1) __builtin_amdgcn_s_setprio(2); else if (t == 2) __builtin_amdgcn_s_setprio(1); else __builtin_amdgcn_s_setprio(0);
-    const int b16 = (4 * sby + ty) * g.n16x + 4 * sbx + tx;
-    const unsigned* oq = orgPacked + (size_t)b16 * 16u * (unsigned)g.hs;
-    unsigned acc[4] = { 0u, 0u, 0u, 0u };
-    mh_positions(OA, oq, base + (unsigned)((t & 1) * 32 + (t >> 1) * 16 * MH_PITCH * 4), ldsStep, g.hs, acc);
-    mh_block_min(L.kind == 1 ? mh_fold32(acc, L, sh) : 0xFFFFFFFFu, L.idx, &keys[ty * 4 + tx], lane);
-    if (waveHasDense) mh_block_min64(L.kind == 2 ? mh_fold64(acc, L, sh) : ~0ull, &keys[21 + ty * 4 + tx], lane);
-    a32[0] += acc[0]; a32[1] += acc[1]; a32[2] += acc[2]; a32[3] += acc[3];
+    const int OAhs = OA | (g.hs == 8 ? 0 : 4);
+    const MhWalk w = { orgPacked, base, qx, qy, sbx, sby, nsubx, nsuby, g.n16x, sh, waveHasDense, lane };
+    if (OAhs == 0)      nsub = mh_walk<0, 8>(w, L, keys, a32);
+    else if (OAhs == 1) nsub = mh_walk<1, 8>(w, L, keys, a32);
+    else if (OAhs == 2) nsub = mh_walk<2, 8>(w, L, keys, a32);
+    else if (OAhs == 3) nsub = mh_walk<3, 8>(w, L, keys, a32);
+    else if (OAhs == 4) nsub = mh_walk<0, 16>(w, L, keys, a32);
+    else if (OAhs == 5) nsub = mh_walk<1, 16>(w, L, keys, a32);
+    else if (OAhs == 6) nsub = mh_walk<2, 16>(w, L, keys, a32);
+    else                nsub = mh_walk<3, 16>(w, L, keys, a32);
   }
   __builtin_amdgcn_s_setprio(0);                                                  // (a unit that skipped its last sub-blocks would keep a raised priority through the record write and the next window slide)
   if (nsub == 4)

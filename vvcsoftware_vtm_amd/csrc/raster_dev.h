@@ -189,28 +189,30 @@ __device__ __forceinline__ void r5q_issue_at(R5qStage& st, const unsigned* __res
 template <int OA, int NST, int LSTEP, int S>
 struct R5qFixed
 {
-  static __device__ __forceinline__ void run(const unsigned* __restrict__ orgQ, unsigned base, R5qStage& A, R5qStage& B, unsigned (&acc)[4])
+  static __device__ __forceinline__ void run(const unsigned* __restrict__ orgQ, unsigned base, bool hasNext, const unsigned* __restrict__ nextOrgQ, unsigned nextBase,
+                                             R5qStage& A, R5qStage& B, unsigned (&acc)[4])
   {
-    // stage S is in flight in A (even S) / B (odd S)
+    // stage S is in flight in A (even S) / B (odd S); behind the last stage: stage 0 of the walk that follows (NST is even: into A again)
     R5C_WAIT_LGKM0();
     if (S + 1 < NST) r5q_issue_at<OA, (S + 1) * LSTEP * 4>((S & 1) ? A : B, orgQ + (S + 1) * 16, base);
+    else r5q_issue_at<OA, 0>(A, nextOrgQ, nextBase);                       // (unconditional: behind the last sub-block the caller names a valid one again)
     __builtin_amdgcn_sched_barrier(0);
     r5q_compute<OA, 5>((S & 1) ? B : A, acc);
-    R5qFixed<OA, NST, LSTEP, S + 1>::run(orgQ, base, A, B, acc);
+    R5qFixed<OA, NST, LSTEP, S + 1>::run(orgQ, base, hasNext, nextOrgQ, nextBase, A, B, acc);
   }
 };
 template <int OA, int NST, int LSTEP>
 struct R5qFixed<OA, NST, LSTEP, NST>
 {
-  static __device__ __forceinline__ void run(const unsigned* __restrict__, unsigned, R5qStage&, R5qStage&, unsigned (&)[4]) {}
+  static __device__ __forceinline__ void run(const unsigned* __restrict__, unsigned, bool, const unsigned* __restrict__, unsigned, R5qStage&, R5qStage&, unsigned (&)[4]) {}
 };
+// stage 0 of (orgQ, base) is in flight in A on entry; on exit stage 0 of (nextOrgQ, nextBase) is, if hasNext (wave-uniform)
 template <int OA, int NST, int LSTEP>
-__device__ __forceinline__ void r5q_positions_fixed(const unsigned* __restrict__ orgQ, unsigned base, unsigned (&acc)[4])
+__device__ __forceinline__ void r5q_positions_fixed(const unsigned* __restrict__ orgQ, unsigned base, bool hasNext, const unsigned* __restrict__ nextOrgQ, unsigned nextBase,
+                                                    R5qStage& A, R5qStage& B, unsigned (&acc)[4])
 {
-  static_assert((NST - 1) * LSTEP * 4 + 64 < 65536, "ds offset field");
-  R5qStage A, B;
-  r5q_issue_at<OA, 0>(A, orgQ, base);
-  R5qFixed<OA, NST, LSTEP, 0>::run(orgQ, base, A, B, acc);
+  static_assert((NST - 1) * LSTEP * 4 + 64 < 65536 && (NST & 1) == 0, "ds offset field; stage 0 lives in A");
+  R5qFixed<OA, NST, LSTEP, 0>::run(orgQ, base, hasNext, nextOrgQ, nextBase, A, B, acc);
 }
 
 }  // namespace

@@ -1590,10 +1590,6 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   for (int m = 4; m < 64; m <<= 1) maxFirst = max(maxFirst, __shfl_xor(maxFirst, m));
   maxFirst = __builtin_amdgcn_readfirstlane(maxFirst);                    // the walk's position is the same in every lane: keep it (and what
   if (maxFirst < 0) return;                                               // derives from it) in scalar registers
-#ifdef DQ_PRIO
-  // the batch ends with its longest walk: long walks win the arbitration of their SIMD against the short ones that share it
-  if (maxFirst >= 512) __builtin_amdgcn_s_setprio(3); else if (maxFirst >= 128) __builtin_amdgcn_s_setprio(2); else if (maxFirst >= 48) __builtin_amdgcn_s_setprio(1);
-#endif
 
   const int sigSet = max(k - 1, 0);                                       // RateEstimator::sigFlagBits(stateId) :282-285
   DqState P, S;                                                           // previous-position state k, skip state k
@@ -1929,9 +1925,6 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   // ---- best final state and back-trace :1368-1390.  Lane 0 of the quad walks; decisions 4..7 are implicit: at a sub-block end they
   // are a copy of decisions 0..3 (:1269), elsewhere { level 0, same skip id } (startDec :1218)
   long long c1 = dq_shfl64(finalCost, qbase + 1), c2 = dq_shfl64(finalCost, qbase + 2), c3 = dq_shfl64(finalCost, qbase + 3);
-#ifdef DQ_PRIO
-  __builtin_amdgcn_s_setprio(0);
-#endif
   if (!run || k != 0) return;
   int prevId = -2; long long minCost = 0;
   if (finalCost < minCost) { prevId = 0; minCost = finalCost; }
