@@ -120,6 +120,33 @@ def test_sao_apply_wide_offsets_and_narrow_clip():
         assert np.array_equal(dst.cpu().numpy(), want), (cmin, cmax)
 
 
+@pytest.mark.parametrize("w,h,ctu", [(416, 240, 128), (320, 192, 64), (272, 136, 32), (1936, 1096, 128), (208, 120, 64)])
+def test_sao_apply_picture_strip_form_against_oracle(w, h, ctu):
+    """the strip form behind vvcgpu_sao_apply_picture (a wave walks down a tile, neighbour samples by lane shifts, packed arithmetic): every type, CTUs
+    whose offsets do not fit its byte table (select chain), a clipping range narrower than the sample range, tiles that span several CTUs (chroma of
+    small CTUs: per-lane types) and bands cut by the last picture row -- each plane against the oracle"""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(5 * w + h + ctu)
+    bd = 10
+    shp = [(h, w), (h // 2, w // 2), (h // 2, w // 2)]
+    planes = [cases.rand_plane(rng, a, b, bd, "uniform" if i == 0 else "smooth") for i, (a, b) in enumerate(shp)]
+    prms = []
+    for i, (a, b) in enumerate(shp):
+        c = ctu if i == 0 else ctu // 2
+        prm = cases.sao_params(rng, b, a, c, c, False, types=[-1, 0, 1, 2, 3, 4])
+        big = rng.random(prm.size) < 0.25
+        prm["offset"][big] = rng.integers(-300, 301, (int(big.sum()), 32))
+        prms.append(prm)
+    for (cmin, cmax) in ((0, 1023), (64, 940)):
+        got = ops.sao_apply_picture([dev(x) for x in planes], [torch.full(x.shape, -1, dtype=torch.int16, device="cuda") for x in planes], ctu, bd,
+                                    [ops.sao_params_to_device(q) for q in prms], (cmin, cmax))
+        for i, (a, b) in enumerate(shp):
+            c = ctu if i == 0 else ctu // 2
+            want = planes[i].copy()
+            oracle().orc_sao_apply(p(planes[i]), b, p(want), b, b, a, c, c, bd, p(prms[i]), cmin, cmax)
+            assert np.array_equal(got[i].cpu().numpy(), want), (i, cmin, cmax)
+
+
 def test_sao_each_type_alone():
     from vvcsoftware_vtm_amd import ops
     rng = np.random.default_rng(3)

@@ -198,6 +198,273 @@ __global__ __launch_bounds__(256) void sao_apply_picture_kernel(SaoApply3 p)
 }
 
 
+// ---------------------------------------------------------------------------------------------------
+// Strip form of the picture entry (round 6).  The form above re-reads: a thread's two output rows need four row loads and eight 2-byte halo
+// loads (six load instructions per output row), and its 12 k short waves run their load / compute / store phases in lockstep.  Here a WAVE
+// owns a tile of up to 128 columns (at most a CTU's width) and walks DOWN it: lane (l, g) = columns 8 l .. 8 l + 7 of the band of SS_RB rows g, in two
+// steps with the second step's rows in flight; a row is loaded once (the row above / below a band once more: SS_RB + 2 loads for SS_RB rows), the left / right
+// neighbour samples of a lane come from the neighbouring LANE (DPP wave shift; the two edge lanes of the tile load theirs), and the arithmetic
+// works on sample pairs (v_pk_*_i16: sign = clamp(c - n, -1, 1), the five offsets as a byte table of v_perm_b32): two load instructions and
+// ~70 vector instructions per row of eight samples.  The SAO type is a per-lane value (a chroma tile spans two CTUs): the row bodies branch on it.  Results identical to the form above (tests/test_gpu_inloop.py, the workload tests).
+// ---------------------------------------------------------------------------------------------------
+#ifndef SS_RB_D
+#define SS_RB_D 8
+#define SS_CH_D 5
+#endif
+constexpr int SS_RB = SS_RB_D, SS_CH = SS_CH_D, SS_NCH = (SS_RB + 2) / SS_CH;           // rows of a lane's band; rows per step; steps (the band + one row above and below)
+static_assert(SS_NCH * SS_CH == SS_RB + 2 && SS_CH >= 3, "whole steps; the first step holds the row above the band and two of its rows");
+struct SsRow { unsigned v[4]; unsigned l, r; };                               // eight samples; l: sample -1 in its HIGH half, r: sample 8 in its LOW half
+struct SsRaw { uint4 v[SS_CH]; unsigned e[SS_CH]; };                          // a step's rows as loaded (+ the edge lane's neighbour sample)
+struct SsLane
+{
+  const Pel* src; Pel* dst; int sstride, dstride;
+  int gx, gxc, ex, y0, yEnd, h;                                               // first column (clamped for loads), edge sample column, band rows
+  bool isL, isR, live;
+  int x0, x1, cy0, cy1, avail;                                                // the lane's CTU
+  unsigned lo32, hi32;                                                        // packed clip bounds + 32
+};
+__device__ __forceinline__ unsigned ss_pk_sign(unsigned a, unsigned b)
+{
+  unsigned r;
+  asm("v_pk_sub_i16 %0, %1, %2\n\tv_pk_max_i16 %0, %0, -1 op_sel_hi:[1,0]\n\tv_pk_min_i16 %0, %0, 1 op_sel_hi:[1,0]" : "=&v"(r) : "v"(a), "v"(b));
+  return r;
+}
+__device__ __forceinline__ unsigned ss_pk_add(unsigned a, unsigned b) { unsigned r; asm("v_pk_add_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned ss_pk_max(unsigned a, unsigned b) { unsigned r; asm("v_pk_max_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned ss_pk_min(unsigned a, unsigned b) { unsigned r; asm("v_pk_min_i16 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+__device__ __forceinline__ unsigned ss_pk_sub32(unsigned a) { unsigned r; asm("v_pk_sub_i16 %0, %1, 32 op_sel_hi:[1,0]" : "=v"(r) : "v"(a)); return r; }
+__device__ __forceinline__ unsigned ss_pk_add2(unsigned a) { unsigned r; asm("v_pk_add_i16 %0, %1, 2 op_sel_hi:[1,0]" : "=v"(r) : "v"(a)); return r; }
+
+__device__ __forceinline__ void ss_load(const SsLane& L, int q, SsRaw& raw)
+{
+#pragma unroll
+  for (int i = 0; i < SS_CH; i++)
+  {
+    const Pel* row = L.src + (size_t)min(max(q + i, 0), L.h - 1) * L.sstride;
+    raw.v[i] = *reinterpret_cast<const uint4*>(row + L.gxc);
+    raw.e[i] = (unsigned)(unsigned short)row[L.ex];
+  }
+}
+__device__ __forceinline__ void ss_row(const SsLane& L, const SsRaw& raw, int i, SsRow& r)
+{
+  r.v[0] = raw.v[i].x; r.v[1] = raw.v[i].y; r.v[2] = raw.v[i].z; r.v[3] = raw.v[i].w;
+  // the neighbour lanes' samples: every lane takes part in the shifts (wave_shr:1 / wave_shl:1), the tile's edge lanes use what they loaded
+  const unsigned fromL = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r.v[3], 0x138, 0xF, 0xF, false);
+  const unsigned fromR = (unsigned)__builtin_amdgcn_update_dpp(0, (int)r.v[0], 0x130, 0xF, 0xF, false);
+  r.l = L.isL ? raw.e[i] << 16 : fromL;
+  r.r = L.isR ? raw.e[i] : fromR;
+}
+__device__ __forceinline__ unsigned ss_left(const SsRow& r, int j) { return __builtin_amdgcn_alignbit(r.v[j], j == 0 ? r.l : r.v[j > 0 ? j - 1 : 0], 16); }     // samples (2j - 1, 2j)
+__device__ __forceinline__ unsigned ss_right(const SsRow& r, int j) { return __builtin_amdgcn_alignbit(j == 3 ? r.r : r.v[j < 3 ? j + 1 : 3], r.v[j], 16); }    // samples (2j + 1, 2j + 2)
+__device__ __forceinline__ void ss_store(const SsLane& L, int y, const unsigned (&o)[4])
+{
+  if (L.live && y >= L.y0 && y < L.yEnd) *reinterpret_cast<uint4*>(L.dst + (size_t)y * L.dstride + L.gx) = make_uint4(o[0], o[1], o[2], o[3]);
+}
+// bit k of `use` -> the 16-bit half of sample k
+__device__ __forceinline__ void ss_expand(int use, unsigned (&m)[4])
+{
+#pragma unroll
+  for (int j = 0; j < 4; j++) m[j] = (unsigned)__builtin_amdgcn_sbfe(use, 2 * j, 1) & 0xFFFFu | (unsigned)__builtin_amdgcn_sbfe(use, 2 * j + 1, 1) << 16;
+}
+
+// TYPE 0..3: edge offset with neighbours a = (x + DXA, y + DYA), b = (x - DXA, y - DYA); 4: band offset; -1: copy
+struct SsEo { int aL, aR, bL, bR, aIn, bIn; unsigned tLo, tHi; unsigned mI[4]; bool fits; int off[5]; };
+template <int DXA, int DYA>
+__device__ __forceinline__ int ss_use(const SsLane& L, const SsEo& E, int y)
+{
+  const int avL = -(L.avail & 1), avR = -((L.avail >> 1) & 1), avA = -((L.avail >> 2) & 1), avB = -((L.avail >> 3) & 1);
+  const int avAL = -((L.avail >> 4) & 1), avAR = -((L.avail >> 5) & 1), avBL = -((L.avail >> 6) & 1), avBR = -((L.avail >> 7) & 1);
+  const bool topOut = (DYA != 0) && (y - 1 < L.cy0), botOut = (DYA != 0) && (y + 1 >= L.cy1);
+  const int okA = topOut ? ((E.aIn & avA) | (E.aL & avAL) | (E.aR & avAR)) : (E.aIn | (E.aL & avL) | (E.aR & avR));
+  const int okB = botOut ? ((E.bIn & avB) | (E.bL & avBL) | (E.bR & avBR)) : (E.bIn | (E.bL & avL) | (E.bR & avR));
+  return okA & okB;
+}
+template <int DXA, int DYA>
+__device__ __forceinline__ void ss_eo_setup(const SsLane& L, const vvcgpu_sao_ctu* prm, SsEo& E)
+{
+  E.aL = E.aR = E.bL = E.bR = 0;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+  {
+    const int x = L.gx + k;
+    if (DXA != 0)
+    {
+      if (x + DXA < L.x0) E.aL |= 1 << k; else if (x + DXA >= L.x1) E.aR |= 1 << k;
+      if (x - DXA < L.x0) E.bL |= 1 << k; else if (x - DXA >= L.x1) E.bR |= 1 << k;
+    }
+  }
+  E.aIn = 0xFF & ~(E.aL | E.aR); E.bIn = 0xFF & ~(E.bL | E.bR);
+#pragma unroll
+  for (int c = 0; c < 5; c++) E.off[c] = prm->offset[c];
+  E.fits = true;
+#pragma unroll
+  for (int c = 0; c < 5; c++) E.fits = E.fits && (unsigned)(E.off[c] + 32) < 64u;
+  E.tLo = (unsigned)(E.off[0] + 32) | (unsigned)(E.off[1] + 32) << 8 | (unsigned)(E.off[2] + 32) << 16 | (unsigned)(E.off[3] + 32) << 24;
+  E.tHi = (unsigned)(E.off[4] + 32);
+  ss_expand(ss_use<DXA, DYA>(L, E, L.cy0 + 1), E.mI);                           // a row with both vertical neighbours inside the CTU (a CTU has >= 16 rows)
+}
+template <int DXA, int DYA, bool FITS>
+__device__ __forceinline__ void ss_eo_row(const SsLane& L, const SsEo& E, const SsRow& up, const SsRow& mid, const SsRow& dn, int y, bool edgeRow)
+{
+  unsigned m[4];
+  if (edgeRow) ss_expand(ss_use<DXA, DYA>(L, E, y), m);                        // the first / last row of a band may be the first / last row of its CTU
+  else { m[0] = E.mI[0]; m[1] = E.mI[1]; m[2] = E.mI[2]; m[3] = E.mI[3]; }
+  const SsRow& ra = DYA == 0 ? mid : up;                                        // a's row; b's row is the opposite one
+  const SsRow& rb = DYA == 0 ? mid : dn;
+  unsigned o[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+  {
+    const unsigned c = mid.v[j];
+    const unsigned a = DXA < 0 ? ss_left(ra, j) : DXA > 0 ? ss_right(ra, j) : ra.v[j];
+    const unsigned b = DXA < 0 ? ss_right(rb, j) : DXA > 0 ? ss_left(rb, j) : rb.v[j];
+    const unsigned e = ss_pk_add(ss_pk_sign(c, a), ss_pk_sign(c, b));          // -2..2 per half
+    unsigned t;
+    if (FITS)
+    {
+      const unsigned tb = __builtin_amdgcn_perm(E.tHi, E.tLo, ss_pk_add2(e) | 0x0C000C00u);     // offset + 32 per half
+      t = ss_pk_sub32(ss_pk_min(ss_pk_max(ss_pk_add(c, tb), L.lo32), L.hi32));
+    }
+    else
+    {
+      // offsets outside [-32, 31] (the ABI takes any int16; the reference does not produce them at 8 - 10 bits): a select chain per sample
+      int r2[2];
+#pragma unroll
+      for (int hh = 0; hh < 2; hh++)
+      {
+        const int cc = (int)((c >> (16 * hh)) & 0xFFFFu), ee = (int)(short)(e >> (16 * hh));
+        const int of = ee == -2 ? E.off[0] : ee == -1 ? E.off[1] : ee == 0 ? E.off[2] : ee == 1 ? E.off[3] : E.off[4];
+        r2[hh] = min(max(cc + of, (int)(short)(L.lo32 & 0xFFFFu) - 32), (int)(short)(L.hi32 & 0xFFFFu) - 32);
+      }
+      t = (unsigned)r2[0] & 0xFFFFu | (unsigned)r2[1] << 16;
+    }
+    o[j] = (t & m[j]) | (c & ~m[j]);
+  }
+  ss_store(L, y, o);
+}
+// band offset: offset[sample >> boShift] per sample.  TAB: the offsets of the wave's CTU as a table in LDS (the uniform walk: a look-up in memory behind
+// the previous row's store would wait for that store as well -- loads and stores share one counter), else read through the parameter record
+template <bool TAB>
+__device__ __forceinline__ void ss_bo_row(const SsLane& L, const int16_t* __restrict__ off, const unsigned short* tab, int boShift, const SsRow& mid, int y)
+{
+  unsigned o[4];
+#pragma unroll
+  for (int j = 0; j < 4; j++)
+  {
+    const unsigned c = mid.v[j];
+    const unsigned b0 = (c & 0xFFFFu) >> boShift, b1 = c >> (16 + boShift);
+    const unsigned tb = TAB ? (unsigned)tab[b0 & 31u] | (unsigned)tab[b1 & 31u] << 16 : (unsigned)(unsigned short)off[b0] | (unsigned)(unsigned short)off[b1] << 16;
+    o[j] = ss_pk_sub32(ss_pk_min(ss_pk_max(ss_pk_add(ss_pk_add(c, tb), 0x00200020u), L.lo32), L.hi32));
+  }
+  ss_store(L, y, o);
+}
+
+// the walk of one lane's band; Body(up, mid, dn, y, edgeRow) produces row y.  ONE copy of the step's row bodies (the loop moves the prefetched rows
+// into the registers of the current step): six type walks of unrolled double-buffered steps were ~40 KB of hot code on a CU whose waves run different types
+template <typename Body>
+__device__ __forceinline__ void ss_walk(const SsLane& L, SsRaw& A, Body body)   // A: the first step's rows, requested by the caller
+{
+  SsRaw B;
+  SsRow up, mid, dn;
+#pragma unroll 1
+  for (int s = 0; s < SS_NCH; s++)
+  {
+    const int q = L.y0 - 1 + s * SS_CH;
+    if (s + 1 < SS_NCH) ss_load(L, q + SS_CH, B);                              // the next step's rows travel while this step is computed
+#pragma unroll
+    for (int i = 0; i < SS_CH; i++)
+    {
+      up = mid; mid = dn; ss_row(L, A, i, dn);
+      const int y = q + i - 1;                                                 // dn = row q + i: row q + i - 1 has both neighbours now
+      if (s > 0 || i >= 2) body(up, mid, dn, y, (s == 0 && i == 2) || (s == SS_NCH - 1 && i == SS_CH - 1));
+    }
+#pragma unroll
+    for (int i = 0; i < SS_CH; i++) { A.v[i] = B.v[i]; A.e[i] = B.e[i]; }
+  }
+}
+
+struct SaoStripPlane { const Pel* src; Pel* dst; const vvcgpu_sao_ctu* params; int sstride, dstride, w, h, ctuW, ctuH, wCtu, tilesX, tileEnd, lxShift; };   // a tile: 8 << lxShift columns x (64 >> lxShift) SS_RB rows
+struct SaoStrip3 { SaoStripPlane a[3]; int boShift, clpMin, clpMax, total, xcd; };
+__global__ __launch_bounds__(64) void sao_apply_strip_kernel(SaoStrip3 p)
+{
+  const int b = vvc_xcd_index((int)blockIdx.x, p.total, p.xcd);
+  if (b < 0) return;
+  const int c = b < p.a[0].tileEnd ? 0 : b < p.a[1].tileEnd ? 1 : 2;
+  const SaoStripPlane& a = c == 0 ? p.a[0] : c == 1 ? p.a[1] : p.a[2];
+  const int tile = b - (c == 0 ? 0 : c == 1 ? p.a[0].tileEnd : p.a[1].tileEnd);
+  const int ty = tile / a.tilesX, tx = tile - ty * a.tilesX;
+  const int lane = threadIdx.x, lx = 1 << a.lxShift, l = lane & (lx - 1), g = lane >> a.lxShift;
+  SsLane L;
+  L.src = a.src; L.dst = a.dst; L.sstride = a.sstride; L.dstride = a.dstride; L.h = a.h;
+  L.gx = (tx * lx + l) * 8; L.gxc = min(L.gx, a.w - 8);
+  L.y0 = (ty * (64 >> a.lxShift) + g) * SS_RB; L.yEnd = min(L.y0 + SS_RB, a.h);
+  L.live = L.gx < a.w && L.y0 < a.h;
+  L.isL = l == 0; L.isR = l == lx - 1;
+  L.ex = L.isL ? max(L.gx - 1, 0) : L.isR ? min(L.gx + 8, a.w - 1) : L.gxc;
+  SsRaw A0;
+  ss_load(L, L.y0 - 1, A0);                                                    // the first rows travel while the CTU's parameters are read
+  const int cx = L.gxc / a.ctuW, cy = min(L.y0, a.h - 1) / a.ctuH;
+  const vvcgpu_sao_ctu* prm = a.params + cy * a.wCtu + cx;
+  L.x0 = cx * a.ctuW; L.x1 = min(L.x0 + a.ctuW, a.w); L.cy0 = cy * a.ctuH; L.cy1 = min(L.cy0 + a.ctuH, a.h);
+  L.avail = prm->avail;
+  L.lo32 = (unsigned)(p.clpMin + 32) * 0x10001u; L.hi32 = (unsigned)(p.clpMax + 32) * 0x10001u;
+#ifdef SAO_FORCE_TYPE
+  const int type = SAO_FORCE_TYPE;
+#else
+  const int type = prm->type;
+#endif
+#ifdef SAO_STRIP_COPYONLY
+  ss_walk(L, A0, [&](const SsRow&, const SsRow& mid, const SsRow& dn, int y, bool) { unsigned o[4] = { mid.v[0], mid.v[1], mid.v[2], mid.v[3] ^ (dn.l & dn.r & 0u) }; ss_store(L, y, o); });
+  return;
+#endif
+  // The tile of a plane is at most one CTU wide (host), so the type is wave-uniform wherever the CTU is at least as tall as the tile: one walk with
+  // the type's row body.  A wave that sees several types, or offsets outside the byte table, takes the general walk: loads and lane shifts are common
+  // code that every lane executes, only the row bodies branch on the lane's type (a shift inside a divergent branch would read lanes switched off there).
+  SsEo E;
+  E.fits = true; E.tLo = E.tHi = 0u; E.aL = E.aR = E.bL = E.bR = E.aIn = E.bIn = 0;
+  E.mI[0] = E.mI[1] = E.mI[2] = E.mI[3] = 0u; E.off[0] = E.off[1] = E.off[2] = E.off[3] = E.off[4] = 0;
+  switch (type)
+  {
+  case 0: ss_eo_setup<-1, 0>(L, prm, E); break;
+  case 1: ss_eo_setup<0, -1>(L, prm, E); break;
+  case 2: ss_eo_setup<-1, -1>(L, prm, E); break;
+  case 3: ss_eo_setup<1, -1>(L, prm, E); break;
+  default: break;
+  }
+  const int t0 = __builtin_amdgcn_readfirstlane(type);
+  const bool fullBand = !L.live || L.yEnd == L.y0 + SS_RB;                     // (a band cut by the picture's last row ends its CTU on another row than its last: general walk)
+  if (__all(type == t0 && E.fits && fullBand))
+  {
+    if (t0 == 0)      ss_walk(L, A0, [&](const SsRow& u, const SsRow& m, const SsRow& d, int y, bool er) { ss_eo_row<-1, 0, true>(L, E, u, m, d, y, er); });
+    else if (t0 == 1) ss_walk(L, A0, [&](const SsRow& u, const SsRow& m, const SsRow& d, int y, bool er) { ss_eo_row<0, -1, true>(L, E, u, m, d, y, er); });
+    else if (t0 == 2) ss_walk(L, A0, [&](const SsRow& u, const SsRow& m, const SsRow& d, int y, bool er) { ss_eo_row<-1, -1, true>(L, E, u, m, d, y, er); });
+    else if (t0 == 3) ss_walk(L, A0, [&](const SsRow& u, const SsRow& m, const SsRow& d, int y, bool er) { ss_eo_row<1, -1, true>(L, E, u, m, d, y, er); });
+    else if (t0 == 4)
+    {
+      __shared__ unsigned short boTab[32];
+      if (lane < 32) boTab[lane] = (unsigned short)prm->offset[lane];
+      __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+      ss_walk(L, A0, [&](const SsRow&, const SsRow& m, const SsRow&, int y, bool) { ss_bo_row<true>(L, prm->offset, boTab, p.boShift, m, y); });
+    }
+    else              ss_walk(L, A0, [&](const SsRow&, const SsRow& m, const SsRow&, int y, bool) { unsigned o[4] = { m.v[0], m.v[1], m.v[2], m.v[3] }; ss_store(L, y, o); });
+    return;
+  }
+  ss_walk(L, A0, [&](const SsRow& u, const SsRow& m, const SsRow& d, int y, bool)
+  {
+    const bool er = y == L.cy0 || y == L.cy1 - 1;
+    switch (type)
+    {
+    case 0: if (E.fits) ss_eo_row<-1, 0, true>(L, E, u, m, d, y, er); else ss_eo_row<-1, 0, false>(L, E, u, m, d, y, er); break;
+    case 1: if (E.fits) ss_eo_row<0, -1, true>(L, E, u, m, d, y, er); else ss_eo_row<0, -1, false>(L, E, u, m, d, y, er); break;
+    case 2: if (E.fits) ss_eo_row<-1, -1, true>(L, E, u, m, d, y, er); else ss_eo_row<-1, -1, false>(L, E, u, m, d, y, er); break;
+    case 3: if (E.fits) ss_eo_row<1, -1, true>(L, E, u, m, d, y, er); else ss_eo_row<1, -1, false>(L, E, u, m, d, y, er); break;
+    case 4: ss_bo_row<false>(L, prm->offset, nullptr, p.boShift, m, y); break;
+    default: { unsigned o[4] = { m.v[0], m.v[1], m.v[2], m.v[3] }; ss_store(L, y, o); break; }
+    }
+  });
+}
+
+
 }  // namespace
 
 extern "C" int vvcgpu_sao_apply(const vvc_pel* src, int src_stride, vvc_pel* dst, int dst_stride,
@@ -229,8 +496,32 @@ extern "C" int vvcgpu_sao_apply_picture(const vvcgpu_planes* src, const vvcgpu_p
   VVC_CHECK_ARG(width > 0 && height > 0 && (width & 1) == 0 && (height & 1) == 0, "sao_apply_picture: bad size %dx%d", width, height);
   VVC_CHECK_ARG(ctu_size >= 16 && (ctu_size & 15) == 0, "sao_apply_picture: CTU size %d", ctu_size);
   VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "sao_apply_picture: bit depth %d outside 8..10", bit_depth);
-  SaoApply3 p;
   const vvcgpu_sao_ctu* prm[3] = { params_y, params_cb, params_cr };
+  // the strip form: planes whose rows are whole 16-byte words at 16-byte aligned addresses, CTU rows that are whole bands of 16 rows
+  bool strip = (width & 15) == 0 && (ctu_size & (2 * SS_RB - 1)) == 0;
+  for (int c = 0; c < 3; c++)
+    strip = strip && src->p[c] && dst->p[c] && (src->stride[c] & 7) == 0 && (dst->stride[c] & 7) == 0 && (reinterpret_cast<uintptr_t>(src->p[c]) & 15) == 0 &&
+            (reinterpret_cast<uintptr_t>(dst->p[c]) & 15) == 0;
+  if (strip)
+  {
+    SaoStrip3 q;
+    int end = 0;
+    for (int c = 0; c < 3; c++)
+    {
+      const int w = c ? width >> 1 : width, h = c ? height >> 1 : height, ctu = c ? ctu_size >> 1 : ctu_size;
+      VVC_CHECK_ARG(src->p[c] != dst->p[c] && src->stride[c] >= w && dst->stride[c] >= w, "sao_apply_picture: plane %d", c);
+      int lxShift = 4;                                                          // 16 lanes = 128 columns across, narrower where the CTU is (64: 8, 32 and below: 4)
+      while (lxShift > 2 && (8 << lxShift) > ctu) lxShift--;
+      const int tilesX = cdiv(w, 8 << lxShift), tilesY = cdiv(h, (64 >> lxShift) * SS_RB);
+      end += tilesX * tilesY;
+      q.a[c] = SaoStripPlane{ src->p[c], dst->p[c], prm[c], src->stride[c], dst->stride[c], w, h, ctu, ctu, cdiv(w, ctu), tilesX, end, lxShift };
+    }
+    q.boShift = bit_depth - 5; q.clpMin = clp_min; q.clpMax = clp_max; q.total = end; q.xcd = vvc_xcd_on();
+    hipLaunchKernelGGL(sao_apply_strip_kernel, dim3(vvc_xcd_grid(end, q.xcd)), dim3(64), 0, (hipStream_t)stream, q);
+    VVC_LAUNCH_CHECK();
+    return VVCGPU_OK;
+  }
+  SaoApply3 p;
   int end = 0;
   for (int c = 0; c < 3; c++)
   {
