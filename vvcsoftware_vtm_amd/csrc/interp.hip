@@ -1466,11 +1466,13 @@ int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc
     flags = fl;
   }
   const int chunk = n >= 64 * 8192 ? 64 : (n + 8191) / 8192;            // ~8192 waves: 32 per CU
+  // behind the matrix-core kernel the generic one usually finds nothing (or a few PUs) to do: a grid of 1024 waves that walk the list leaves sooner than 8192
+  const int gridMax = flags ? 1024 : 8192;
   if (sub44)
-    hipLaunchKernelGGL((mc_batch_kernel<false, true>), dim3(cdiv(n, chunk) < 8192 ? cdiv(n, chunk) : 8192), dim3(64), 0, st, ref0_base,
+    hipLaunchKernelGGL((mc_batch_kernel<false, true>), dim3(cdiv(n, chunk) < gridMax ? cdiv(n, chunk) : gridMax), dim3(64), 0, st, ref0_base,
                        ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk, flags, mfmaOff ? 1 : 0, genCount);
   else
-    hipLaunchKernelGGL((mc_batch_kernel<false, false>), dim3(cdiv(n, chunk) < 8192 ? cdiv(n, chunk) : 8192), dim3(64), 0, st, ref0_base,
+    hipLaunchKernelGGL((mc_batch_kernel<false, false>), dim3(cdiv(n, chunk) < gridMax ? cdiv(n, chunk) : gridMax), dim3(64), 0, st, ref0_base,
                        ref1_base ? ref1_base : ref0_base, dst_base, descs, bit_depth, clp_min, clp_max, n, 0, nullptr, nullptr, chunk, flags, mfmaOff ? 1 : 0, genCount);
   if (genCount) VVC_LAUNCH_CHECK_COUNTERS(st);
   VVC_LAUNCH_CHECK();
