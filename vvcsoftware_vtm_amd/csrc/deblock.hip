@@ -377,8 +377,8 @@ __device__ __forceinline__ void deblock_block(Pel* __restrict__ plane, int strid
 #pragma unroll
     for (int c = 0; c < 8; c++) B.m[r][c] = (int)(short)(d[c >> 1] >> (16 * (c & 1)));
   }
-#ifdef DB_COPYONLY
-  if (false)
+#if defined(DB_COPYONLY) || defined(DB_NO_LUMA)
+  if (LUMA) {} else if (false)
 #else
   if (LUMA)
 #endif
@@ -414,7 +414,7 @@ __device__ __forceinline__ void deblock_block(Pel* __restrict__ plane, int strid
           for (int j = 1; j < 7; j++) B.m[j][4 * t + i] = (short)ln[i].m[j];
       }
   }
-#ifdef DB_COPYONLY
+#if defined(DB_COPYONLY) || defined(DB_NO_CHROMA)
   else if (false)
 #else
   else
