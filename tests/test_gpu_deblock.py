@@ -37,6 +37,28 @@ def test_deblock(w, h, bd, kind, mode, offs):
     assert np.array_equal(dCr.cpu().numpy(), wCr)
 
 
+def test_deblock_unaligned_rows_tile_form():
+    """planes whose rows are no whole 8-byte words (a stride of w + 2 samples) take the LDS tile form of the kernel; the block form serves the rest"""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(91)
+    w, h, bd = 264, 136, 10
+    Y = cases.rand_plane(rng, h, w, bd, "uniform")
+    Cb = cases.rand_plane(rng, h // 2, w // 2, bd, "smooth")
+    Cr = cases.rand_plane(rng, h // 2, w // 2, bd, "uniform")
+    ev, eh, qpl, qpc = cases.deblock_maps(rng, w, h, "random")
+    cfg = ops.deblock_cfg(bd, 1, -1, 2, -2)
+    wY, wCb, wCr = Y.copy(), Cb.copy(), Cr.copy()
+    oracle().orc_deblock(p(wY), w, p(wCb), p(wCr), w // 2, w, h, p(ev), p(eh), p(qpl), p(qpc), C.byref(cfg))
+    big = [torch.zeros((a.shape[0], a.shape[1] + 2), dtype=torch.int16, device="cuda") for a in (Y, Cb, Cr)]
+    views = [b[:, :a.shape[1]] for a, b in zip((Y, Cb, Cr), big)]
+    for v, a in zip(views, (Y, Cb, Cr)):
+        v.copy_(dev(a))
+    ops.deblock(views[0], views[1], views[2], dev(ev), dev(eh), dev(qpl), dev(qpc), cfg)
+    for v, want in zip(views, (wY, wCb, wCr)):
+        assert np.array_equal(v.cpu().numpy(), want)
+    assert all(int(b[:, -2:].abs().sum()) == 0 for b in big)          # nothing written beside the planes
+
+
 def test_deblock_luma_only_and_idempotent_on_flat():
     from vvcsoftware_vtm_amd import ops
     rng = np.random.default_rng(5)

@@ -324,7 +324,7 @@ __global__ __launch_bounds__(128) void deblock_picture_kernel(Pel* __restrict__ 
 // eight row stores.  No LDS tile, no barriers, no phases that every wave of the chip runs in lockstep (the tile form: load, barrier, vertical pass,
 // barrier, horizontal pass, barrier, store in 3060 workgroups; 22.6 us per 4K picture with the vector pipes 38 % busy).  A wave = 64 blocks
 // side by side: a row request is 1 KB of consecutive bytes.  Chroma: the same blocks on the chroma grid, four 2-row / 2-column segments per edge.
-// Planes whose rows are not 8-byte aligned keep the tile form.
+// Planes whose rows are not 8-byte aligned keep the tile form (tests/test_gpu_deblock.py::test_deblock_unaligned_rows_tile_form).
 // ---------------------------------------------------------------------------------------------------
 struct DbBlock { int m[8][8]; };                                              // [row][column] of the shifted block
 
@@ -516,11 +516,12 @@ extern "C" int vvcgpu_deblock(vvc_pel* y, int stride_y, vvc_pel* cb, vvc_pel* cr
   const int xcd = vvc_xcd_on();
   // block form: rows that are whole 8-byte words at 8-byte aligned addresses, chroma sizes on the 8-sample grid as well
   const bool aligned = (stride_y & 3) == 0 && (reinterpret_cast<uintptr_t>(y) & 7) == 0 &&
-                       (!cb || ((stride_c & 3) == 0 && (reinterpret_cast<uintptr_t>(cb) & 7) == 0 && (reinterpret_cast<uintptr_t>(cr) & 7) == 0 && (width & 15) == 0 && (height & 15) == 0));
+                       (!cb || ((stride_c & 3) == 0 && (reinterpret_cast<uintptr_t>(cb) & 7) == 0 && (reinterpret_cast<uintptr_t>(cr) & 7) == 0));
   if (aligned)
   {
-    const int wavesRowL = cdiv(width / 8 + 1, 64), rowsL = height / 8 + 1, nL = wavesRowL * rowsL;
-    const int wavesRowC = cdiv(width / 16 + 1, 64), rowsC = height / 16 + 1, perC = wavesRowC * rowsC, nC = cb ? 2 * perC : 0;
+    // shifted blocks that hold a sample of the plane: origins -4, 4, .. < size (chroma sizes are multiples of 4: a half block is inside or outside as a whole)
+    const int wavesRowL = cdiv(cdiv(width + 4, 8), 64), rowsL = cdiv(height + 4, 8), nL = wavesRowL * rowsL;
+    const int wavesRowC = cdiv(cdiv(width / 2 + 4, 8), 64), rowsC = cdiv(height / 2 + 4, 8), perC = wavesRowC * rowsC, nC = cb ? 2 * perC : 0;
     hipLaunchKernelGGL(deblock_block_kernel, dim3(vvc_xcd_grid2(nL, nL + nC, xcd)), dim3(64), 0, st, y, stride_y, cb, cr, stride_c, width, height, wavesRowL, nL, wavesRowC, perC,
                        edge_ver, edge_hor, qp_luma, qp_chroma, cfg, nL + nC, xcd);
     VVC_LAUNCH_CHECK();
