@@ -58,17 +58,19 @@ struct MhGeom
   unsigned magicNq, magicDl;                           // ceil(65536 / n): v / n == (v * magic) >> 16 for the slot indices (< 448, n <= 10)
 };
 
-// original rows packed per 16x16 block: [block][sampled row][even 8 dwords | odd 8 dwords], biased; layouts as r5c_pack_org_kernel (dist.hip)
-__global__ __launch_bounds__(256) void mh_pack_org_kernel(const Pel* __restrict__ org, int os, int orgX0, int orgY0, int n16x, int nblocks, int hs, int subShift,
-                                                          unsigned* __restrict__ packed)
+// original rows packed per 16x16 block: [block][sampled row][even 8 dwords | odd 8 dwords], biased; layouts as r5c_pack_org_kernel (dist.hip).
+// Round 6: the search kernel packs the rows of a super-block ITSELF (a launch of its own in front of it was 8.4 us per 4K picture) -- the first
+// super-block of a workgroup's run by all its threads, every further one by the waves that have no unit in the second round, while the others search;
+// the rows are read back through the scalar cache by explicit scalar loads (raster_dev.h: R5qStageS).  The buffer is written once per launch and
+// block before it is read, and the stores are complete (vmcnt(0)) in front of the workgroup barrier that precedes the reads.
+// id = quarter q (id & 3) of record (block of the super-block, sampled row): four lanes per record, a wave's store is 1 KB of consecutive bytes.
+__device__ __forceinline__ void mh_pack_quarter(const Pel* __restrict__ org, int os, int orgX0, int orgY0, int n16x, int hs, int subShift, int sbx, int sby, int pnx,
+                                                int id, unsigned* __restrict__ packed)
 {
-  // four lanes per (block, sampled row): lane q writes quarter q of the 64-byte record, so a wave's store is 1 KB of consecutive bytes (one thread per
-  // record wrote four 16-byte pieces 64 bytes apart per store instruction: 10.6 us for a 4K picture against the ~5 us of the bytes)
-  const size_t gid4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x, gid = gid4 >> 2;
-  const int q = (int)(gid4 & 3);
-  if (gid >= (size_t)nblocks * hs) return;
-  const int b = (int)(gid / (unsigned)hs), row = (int)(gid - (size_t)b * hs);
-  const int by = b / n16x, bx = b - by * n16x;
+  const int q = id & 3, rec = id >> 2;
+  const int blk = rec / hs, row = rec - blk * hs;
+  const int ty = blk / pnx, tx = blk - ty * pnx;
+  const int by = 4 * sby + ty, bx = 4 * sbx + tx, b = by * n16x + bx;
   const Pel* o = org + (size_t)(orgY0 + 16 * by + (row << subShift)) * os + orgX0 + 16 * bx;
   unsigned d[8];
   if ((reinterpret_cast<uintptr_t>(o) & 3) == 0)
@@ -93,7 +95,7 @@ __global__ __launch_bounds__(256) void mh_pack_org_kernel(const Pel* __restrict_
     for (int t = 1; t < 8; t++) { lo = k == t ? d[t] : lo; hi = k == t ? d[(t + 1) & 7] : hi; }
     v[j] = ((q & 2) ? __builtin_amdgcn_alignbit(hi, lo, 16) : lo) ^ 0x80008000u;
   }
-  reinterpret_cast<uint4*>(packed + gid * 16)[q] = make_uint4(v[0], v[1], v[2], v[3]);
+  reinterpret_cast<uint4*>(packed + ((size_t)b * hs + row) * 16)[q] = make_uint4(v[0], v[1], v[2], v[3]);
 }
 
 // arg-min of one block over the wave: kmin = (cost << 2 | candidate) per lane, idx0 = visiting index of the lane's candidate 0
@@ -193,7 +195,7 @@ __device__ __forceinline__ int mh_walk(const MhWalk& w, const MhLane& L, unsigne
   auto baseOf = [&](int t) { return w.base + (unsigned)((t & 1) * 32 + (t >> 1) * 16 * MH_PITCH * 4); };
   int t = 0, nsub = 0;
   while (t < 4 && !exists(t)) t++;
-  R5qStage A, B;
+  R5qStageS A, B;
   if (t < 4) r5q_issue_at<OA, 0>(A, orgOf(t), baseOf(t));
 #pragma unroll 1
   while (t < 4)
@@ -207,7 +209,7 @@ __device__ __forceinline__ int mh_walk(const MhWalk& w, const MhLane& L, unsigne
     nsub++;
     unsigned acc[4] = { 0u, 0u, 0u, 0u };
     const int tnc = tn < 4 ? tn : t;
-    r5q_positions_fixed<OA, NST, LSTEP>(orgOf(t), baseOf(t), tn < 4, orgOf(tnc), baseOf(tnc), A, B, acc);
+    r5q_positions_fixed<OA, NST, LSTEP>(orgOf(t), baseOf(t), orgOf(tnc), baseOf(tnc), A, B, acc);
     mh_block_min(L.kind == 1 ? mh_fold32(acc, L, w.sh) : 0xFFFFFFFFu, L.idx, &keys[ty * 4 + tx], w.lane);
     if (w.waveHasDense) mh_block_min64(L.kind == 2 ? mh_fold64(acc, L, w.sh) : ~0ull, &keys[21 + ty * 4 + tx], w.lane);
     a32[0] += acc[0]; a32[1] += acc[1]; a32[2] += acc[2]; a32[3] += acc[3];
@@ -219,7 +221,7 @@ __device__ __forceinline__ int mh_walk(const MhWalk& w, const MhLane& L, unsigne
 // One unit: the four 16x16 sub-blocks of quadrant q for the lanes of one slot wave.
 //   keys   LDS: raster keys of the 16x16 blocks (16), the 32x32 (4), the 64x64 (1), then the same 21 for the +-D grid
 //   surf / surfD  LDS: 64x64 partial sums of the raster slots / the dense lanes, [slot][4]
-__device__ __forceinline__ void mh_unit(const unsigned* __restrict__ orgPacked, const MhGeom& g, int OA, unsigned qbase, const MhLane& L, bool waveHasDense,
+__device__ __forceinline__ void mh_unit(const unsigned* orgPacked, const MhGeom& g, int OA, unsigned qbase, const MhLane& L, bool waveHasDense,
                                         int q, int sbx, int sby, int nsubx, int nsuby, unsigned long long* keys, unsigned* surf, unsigned* surfD, int* arrive, int s, int nslots, int lane)
 {
   const int qx = q & 1, qy = q >> 1;
@@ -272,7 +274,7 @@ __device__ __forceinline__ void mh_unit(const unsigned* __restrict__ orgPacked, 
   }
 }
 
-__global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restrict__ orgPacked, const Pel* __restrict__ ref, int rs, MhGeom g, vvcgpu_mvcost mv,
+__global__ __launch_bounds__(1024) void me_hier_kernel(unsigned* orgPacked, const Pel* __restrict__ org, int os, int orgX0, int orgY0, const Pel* __restrict__ ref, int rs, MhGeom g, vvcgpu_mvcost mv,
                                                        vvcgpu_search_best* __restrict__ r16, vvcgpu_search_best* __restrict__ r32, vvcgpu_search_best* __restrict__ r64,
                                                        vvcgpu_search_best* __restrict__ d16, vvcgpu_search_best* __restrict__ d32, vvcgpu_search_best* __restrict__ d64,
                                                        unsigned long long* __restrict__ diag)
@@ -350,6 +352,11 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
   if (diag && stampK >= 0 && tid == 0) diag[40 + 0 * 4 + stampK] = __builtin_amdgcn_s_memtime();
   if (stamp && tid == 0) diag[0] = __builtin_amdgcn_s_memtime();
   unsigned* surf = refL + (g.winBytes >> 2);                                     // [MH_MAXSLOTS][4]
+  if (kk == kk0)                                                                 // the first super-block of the run: its original rows by every thread, visible behind a full barrier
+  {
+    for (int id = tid; id < nsubx * nsuby * g.hs * 4; id += (int)blockDim.x) mh_pack_quarter(org, os, orgX0, orgY0, g.n16x, g.hs, g.subShift, sbx, sby, nsubx, id, orgPacked);
+    __syncthreads();
+  }
 
   const int winCols = (g.nR - 1) * 5 + 16 * nsubx, winRows = (g.nR - 1) * 5 + 16 * nsuby - (1 << g.subShift) + 1;
   const ptrdiff_t winOff = (ptrdiff_t)(g.refY0 + 64 * sby - g.R) * rs + g.refX0 + 64 * sbx - g.R;
@@ -432,6 +439,19 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* __restric
       if (stamp && lane == 0) diag[8 + u] = __builtin_amdgcn_s_memtime();
     }
   }
+  // the next super-block's original rows: by the waves that had no unit in the second round (four of sixteen for the +-96 raster), else by all
+  if (kk + 1 < kk0 + runLen && kk + 1 < chunk && item + 1 < g.total)
+  {
+    const int nUnits = 4 * nsw, idleFrom = max(nUnits - nwaves, 0);             // waves idleFrom .. nwaves - 1 have only one unit
+    const bool some = idleFrom < nwaves;
+    const int p0 = some ? idleFrom : 0, np = nwaves - p0;
+    if (wave >= p0)
+    {
+      const int it2 = item + 1, sbyN = it2 / g.nsbx, sbxN = it2 - sbyN * g.nsbx;
+      const int pnx = min(4, g.n16x - 4 * sbxN), pny = min(4, g.n16y - 4 * sbyN);
+      for (int id = (wave - p0) * 64 + lane; id < pnx * pny * g.hs * 4; id += np * 64) mh_pack_quarter(org, os, orgX0, orgY0, g.n16x, g.hs, g.subShift, sbxN, sbyN, pnx, id, orgPacked);
+    }
+  }
   __syncthreads();
   if (stamp && tid == 0) diag[2] = diag[3] = __builtin_amdgcn_s_memtime();
   if (diag && stampK >= 0 && tid == 0) diag[40 + 2 * 4 + stampK] = __builtin_amdgcn_s_memtime();
@@ -509,8 +529,6 @@ int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref
   const int nblocks = c.n16x * c.n16y;
   unsigned* packed = static_cast<unsigned*>(vvcgpu_scratch(st, (size_t)nblocks * g.hs * 16 * sizeof(unsigned)));
   if (!packed) return VVCGPU_E_DEVICE;
-  hipLaunchKernelGGL(mh_pack_org_kernel, dim3((unsigned)(((size_t)nblocks * g.hs * 4 + 255) / 256)), dim3(256), 0, st, org, org_stride, c.org_x, c.org_y, c.n16x, nblocks, g.hs, c.sub_shift, packed);
-  VVC_LAUNCH_CHECK();
   VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(me_hier_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   unsigned long long* diag = nullptr;
   const bool wantDiag = getenv("VVCGPU_MH_DIAG") != nullptr;                 // measurement aid (tools/mehier_time.py): phase stamps of one workgroup
@@ -519,7 +537,7 @@ int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref
   const char* wgsEnv = getenv("VVCGPU_MH_WGS");
   const int wgsMax = wgsEnv && atoi(wgsEnv) >= 8 ? (atoi(wgsEnv) / 8) * 8 : (vvcgpu_cu_count() / 8) * 8;
   const int gridWgs = min(cdiv(g.total, 8) * 8, wgsMax);
-  hipLaunchKernelGGL(me_hier_kernel, dim3(gridWgs), dim3(1024), smem, st, packed, ref, ref_stride, g, *mvcost_host,
+  hipLaunchKernelGGL(me_hier_kernel, dim3(gridWgs), dim3(1024), smem, st, packed, org, org_stride, c.org_x, c.org_y, ref, ref_stride, g, *mvcost_host,
                      raster_best[0], raster_best[1], raster_best[2], dense_best ? dense_best[0] : nullptr, dense_best ? dense_best[1] : nullptr, dense_best ? dense_best[2] : nullptr, diag);
   VVC_LAUNCH_CHECK();
   if (wantDiag)

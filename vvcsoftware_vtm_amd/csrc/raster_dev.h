@@ -165,11 +165,17 @@ __device__ __forceinline__ void r5q_positions(const unsigned* __restrict__ orgQ,
 // unrolls, the window reads of stage s are ONE base register + immediate offsets (s * LSTEP * 4 + 8 k < 2^16), the original rows of stage s one scalar
 // load at an immediate offset from the block's base -- no per-stage address arithmetic, compares or branches on the scalar unit (VERDICT r5 item 7 ii:
 // the loop form spent ~14 scalar instructions per stage of 35 vector instructions, on the CU's one scalar unit shared by sixteen waves).
-template <int OA, int OFF>
-__device__ __forceinline__ void r5q_issue_at(R5qStage& st, const unsigned* __restrict__ op, unsigned a)
+// The original rows as an EXPLICIT scalar load (one s_load_dwordx16 into sixteen scalar registers; "memory": not moved across barriers).  me_hier_kernel
+// packs the original rows of a super-block itself and reads them back through the scalar cache: compiler-generated loads of a buffer the kernel also
+// writes become vector loads (every lane the same address: 286 us instead of 202, round 5), and through a read-only view they could be moved above
+// the packing stores.  The caller waits (lgkmcnt(0)) before the first use, as for the window reads.
+typedef unsigned r5q_u16v __attribute__((ext_vector_type(16)));
+struct R5qStageS { r5q_u16v ov; unsigned long long d[8]; unsigned x1; };          // ov[0..7]: even pairs, ov[8..15]: odd-shifted pairs of the original row
+
+template <int OA, int OFF, int OOFF = 0>                                         // OFF: byte offset of the window reads, OOFF: of the original row
+__device__ __forceinline__ void r5q_issue_at(R5qStageS& st, const unsigned* op, unsigned a)
 {
-#pragma unroll
-  for (int k = 0; k < 8; k++) { st.ovE[k] = op[k]; st.ovO[k] = op[8 + k]; }
+  asm volatile("s_load_dwordx16 %0, %1, %2" : "=s"(st.ov) : "s"(op), "n"(OOFF) : "memory");
   if (OA < 2)
   {
     unsigned dummy;
@@ -185,34 +191,63 @@ __device__ __forceinline__ void r5q_issue_at(R5qStage& st, const unsigned* __res
                  : "=&v"(st.d[0]), "=&v"(st.d[1]), "=&v"(st.d[2]), "=&v"(st.d[3]), "=&v"(st.d[4]), "=&v"(st.d[5]), "=&v"(st.d[6]), "=&v"(st.d[7]), "=&v"(st.x1)
                  : "v"(a), "i"(OFF), "i"(OFF + 8), "i"(OFF + 16), "i"(OFF + 24), "i"(OFF + 32), "i"(OFF + 40), "i"(OFF + 48), "i"(OFF + 56), "i"(OFF + 64) : "memory");
 }
+// r5q_compute on the explicit stage (the same 32 sums; STEP = 5)
+template <int OA>
+__device__ __forceinline__ void r5q_compute_s(const R5qStageS& st, unsigned (&acc)[4])
+{
+  unsigned dd[17];
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+  {
+    asm volatile("" :: "v"(st.d[k]));
+    dd[2 * k] = (unsigned)st.d[k]; dd[2 * k + 1] = (unsigned)(st.d[k] >> 32);
+  }
+  if (OA >= 2) { asm volatile("" :: "v"(st.x1)); dd[16] = st.x1; } else dd[16] = 0u;
+#pragma unroll
+  for (int k = 0; k < 8; k++)
+  {
+#pragma unroll
+    for (int m = 0; m < 4; m++)
+    {
+      const int s = OA + 5 * m, I = s >> 1;
+      if (s & 1)
+      {
+        if (k < 7) acc[m] = __builtin_amdgcn_sad_u16(st.ov[8 + k], dd[I + 1 + k], acc[m]);
+        else       acc[m] = __builtin_amdgcn_sad_u16(st.ov[15], (dd[I + 8] & 0xFFFFu) | (dd[I] & 0xFFFF0000u), acc[m]);
+      }
+      else
+        acc[m] = __builtin_amdgcn_sad_u16(st.ov[k], dd[I + k], acc[m]);
+    }
+  }
+}
 
 template <int OA, int NST, int LSTEP, int S>
 struct R5qFixed
 {
-  static __device__ __forceinline__ void run(const unsigned* __restrict__ orgQ, unsigned base, bool hasNext, const unsigned* __restrict__ nextOrgQ, unsigned nextBase,
-                                             R5qStage& A, R5qStage& B, unsigned (&acc)[4])
+  static __device__ __forceinline__ void run(const unsigned* orgQ, unsigned base, const unsigned* nextOrgQ, unsigned nextBase,
+                                             R5qStageS& A, R5qStageS& B, unsigned (&acc)[4])
   {
     // stage S is in flight in A (even S) / B (odd S); behind the last stage: stage 0 of the walk that follows (NST is even: into A again)
     R5C_WAIT_LGKM0();
-    if (S + 1 < NST) r5q_issue_at<OA, (S + 1) * LSTEP * 4>((S & 1) ? A : B, orgQ + (S + 1) * 16, base);
+    if (S + 1 < NST) r5q_issue_at<OA, (S + 1) * LSTEP * 4, (S + 1) * 64>((S & 1) ? A : B, orgQ, base);
     else r5q_issue_at<OA, 0>(A, nextOrgQ, nextBase);                       // (unconditional: behind the last sub-block the caller names a valid one again)
     __builtin_amdgcn_sched_barrier(0);
-    r5q_compute<OA, 5>((S & 1) ? B : A, acc);
-    R5qFixed<OA, NST, LSTEP, S + 1>::run(orgQ, base, hasNext, nextOrgQ, nextBase, A, B, acc);
+    r5q_compute_s<OA>((S & 1) ? B : A, acc);
+    R5qFixed<OA, NST, LSTEP, S + 1>::run(orgQ, base, nextOrgQ, nextBase, A, B, acc);
   }
 };
 template <int OA, int NST, int LSTEP>
 struct R5qFixed<OA, NST, LSTEP, NST>
 {
-  static __device__ __forceinline__ void run(const unsigned* __restrict__, unsigned, bool, const unsigned* __restrict__, unsigned, R5qStage&, R5qStage&, unsigned (&)[4]) {}
+  static __device__ __forceinline__ void run(const unsigned*, unsigned, const unsigned*, unsigned, R5qStageS&, R5qStageS&, unsigned (&)[4]) {}
 };
-// stage 0 of (orgQ, base) is in flight in A on entry; on exit stage 0 of (nextOrgQ, nextBase) is, if hasNext (wave-uniform)
+// stage 0 of (orgQ, base) is in flight in A on entry; on exit stage 0 of (nextOrgQ, nextBase) is
 template <int OA, int NST, int LSTEP>
-__device__ __forceinline__ void r5q_positions_fixed(const unsigned* __restrict__ orgQ, unsigned base, bool hasNext, const unsigned* __restrict__ nextOrgQ, unsigned nextBase,
-                                                    R5qStage& A, R5qStage& B, unsigned (&acc)[4])
+__device__ __forceinline__ void r5q_positions_fixed(const unsigned* orgQ, unsigned base, const unsigned* nextOrgQ, unsigned nextBase,
+                                                    R5qStageS& A, R5qStageS& B, unsigned (&acc)[4])
 {
   static_assert((NST - 1) * LSTEP * 4 + 64 < 65536 && (NST & 1) == 0, "ds offset field; stage 0 lives in A");
-  R5qFixed<OA, NST, LSTEP, 0>::run(orgQ, base, hasNext, nextOrgQ, nextBase, A, B, acc);
+  R5qFixed<OA, NST, LSTEP, 0>::run(orgQ, base, nextOrgQ, nextBase, A, B, acc);
 }
 
 }  // namespace
