@@ -352,11 +352,6 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(unsigned* orgPacked, cons
   if (diag && stampK >= 0 && tid == 0) diag[40 + 0 * 4 + stampK] = __builtin_amdgcn_s_memtime();
   if (stamp && tid == 0) diag[0] = __builtin_amdgcn_s_memtime();
   unsigned* surf = refL + (g.winBytes >> 2);                                     // [MH_MAXSLOTS][4]
-  if (kk == kk0)                                                                 // the first super-block of the run: its original rows by every thread, visible behind a full barrier
-  {
-    for (int id = tid; id < nsubx * nsuby * g.hs * 4; id += (int)blockDim.x) mh_pack_quarter(org, os, orgX0, orgY0, g.n16x, g.hs, g.subShift, sbx, sby, nsubx, id, orgPacked);
-    __syncthreads();
-  }
 
   const int winCols = (g.nR - 1) * 5 + 16 * nsubx, winRows = (g.nR - 1) * 5 + 16 * nsuby - (1 << g.subShift) + 1;
   const ptrdiff_t winOff = (ptrdiff_t)(g.refY0 + 64 * sby - g.R) * rs + g.refX0 + 64 * sbx - g.R;
@@ -415,8 +410,14 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(unsigned* orgPacked, cons
   if (tid >= 64 && tid < 72) arrive[tid - 64] = 0;
   if (tid < MH_MAXDL * 4) surfD[tid] = 0u;
   for (int n = tid; n < MH_MAXSLOTS * 4; n += (int)blockDim.x) surf[n] = 0u;
-  // LDS-only barrier: __syncthreads() also waits for vmcnt(0), i.e. for the neighbour's columns that were requested just above
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  // LDS-only barrier: __syncthreads() also waits for vmcnt(0), i.e. for the neighbour's columns that were requested just above.  The first super-block
+  // of the run: its original rows are packed here by every thread (behind the window's requests), and the barrier is the full one (stores complete)
+  if (kk == kk0)
+  {
+    for (int id = tid; id < nsubx * nsuby * g.hs * 4; id += (int)blockDim.x) mh_pack_quarter(org, os, orgX0, orgY0, g.n16x, g.hs, g.subShift, sbx, sby, nsubx, id, orgPacked);
+    __syncthreads();
+  }
+  else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (stamp && tid == 0) diag[1] = __builtin_amdgcn_s_memtime();
   if (diag && stampK >= 0 && tid == 0) diag[40 + 1 * 4 + stampK] = __builtin_amdgcn_s_memtime();
 
