@@ -901,21 +901,23 @@ __device__ __forceinline__ void fm_best(unsigned dl, bool quarter, const unsigne
 }
 
 
-template <int WPS>
-__global__ __launch_bounds__(256, WPS) void frac16m_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
+// WV waves per workgroup: 16 (one workgroup per CU: the 21 KB table image is copied once per CU instead of four times -- 1024 workgroups of four waves
+// fetched 22 MB of tables in the first microseconds of the launch) or 4 (short lists)
+template <int WPS, int WV>
+__global__ __launch_bounds__(64 * WV, WV == 16 ? 1 : WPS) void frac16m_kernel(const Pel* __restrict__ org, int os, const Pel* __restrict__ ref, int rs,
                                                       const vvcgpu_frac_blk* __restrict__ blocks, int nblocks, int bd, int cmin, int cmax,
                                                       vvcgpu_mvcost mv0, const int* __restrict__ preds,
                                                       vvcgpu_frac_result* __restrict__ results, const _Float16* __restrict__ image,
                                                       int nWg, int xcd)
 {
   __shared__ __align__(16) _Float16 tabS[FM_TAB_HALVES];
-  __shared__ __align__(16) F16Lds ldsV[4];                   // the vector-pipe form's planes (PUs this kernel cannot take: frac16_pu_valu_call)
-  __shared__ int fbk[4][FM_FB_MAX];                          // ... which a wave sets aside and serves BEHIND its walk: a call inside the pipelined loop kept the
+  __shared__ __align__(16) F16Lds ldsV[WV];                  // the vector-pipe form's planes (PUs this kernel cannot take: frac16_pu_valu_call)
+  __shared__ int fbk[WV][FM_FB_MAX];                         // ... which a wave sets aside and serves BEHIND its walk: a call inside the pipelined loop kept the
   int nFb = 0;                                               // loop's lane constants in scratch memory (73.1 against 64.8 us)
   __shared__ unsigned long long costS[FM_COST_N];
   const int wg = vvc_xcd_index((int)blockIdx.x, nWg, xcd);
   if (wg < 0) return;                                        // whole workgroup
-  for (int i = threadIdx.x; i < FM_TAB_HALVES / 8; i += 256) reinterpret_cast<uint4*>(tabS)[i] = reinterpret_cast<const uint4*>(image)[i];
+  for (int i = threadIdx.x; i < FM_TAB_HALVES / 8; i += 64 * WV) reinterpret_cast<uint4*>(tabS)[i] = reinterpret_cast<const uint4*>(image)[i];
   if (threadIdx.x < FM_COST_N) costS[threadIdx.x] = (unsigned long long)(mv0.lambda * (double)threadIdx.x);       // RdCost.h:172-199 per bit count
   __syncthreads();
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6), c16 = lane & 15, g = lane >> 4;   // (the PU index is wave-uniform: descriptors through the scalar cache)
@@ -941,7 +943,7 @@ __global__ __launch_bounds__(256, WPS) void frac16m_kernel(const Pel* __restrict
   const unsigned rangeMask = (unsigned)((1 << bd) - 1) * 0x10001u;
   const int orgLo = max(cmax - 1023, -1024), orgHi = min(cmin + 1023, 1023);   // |org - pred| <= 1023 for every clipped prediction, and 1024 + org exact in f16
   const int yrow = fm_ymap(c16);
-  const int stride = nWg * 4;
+  const int stride = nWg * WV;
 
   struct Raw { uint4 w[2]; pel4 o; };                        // a PU's samples as loaded: fetched one PU ahead, behind the half stage of the PU in front
   auto fetch = [&](const vvcgpu_frac_blk& blk, Raw& r)
@@ -961,7 +963,7 @@ __global__ __launch_bounds__(256, WPS) void frac16m_kernel(const Pel* __restrict
     for (int j = 0; j < 4; j++) r.o[j] = o[j];
   };
 
-  int b = wg * 4 + wave;
+  int b = wg * WV + wave;
   if (b >= nblocks) return;
   vvcgpu_frac_blk blk = blocks[b];
   int predHN = preds ? preds[2 * b] : mv0.pred_hor, predVN = preds ? preds[2 * b + 1] : mv0.pred_ver;
@@ -1125,14 +1127,23 @@ int vvcgpu_frac_refine_launch(const vvc_pel* org, int org_stride, const vvc_pel*
     {
       const _Float16* image = fm_image(bit_depth);
       if (!image) return VVCGPU_E_DEVICE;
-      const int cap = 256 * 4;                                             // four workgroups per CU (the kernel is built for four waves per SIMD: five spill); a wave walks its PUs
+      const int cap = 256 * 4;                                             // sixteen waves per CU (the kernel is built for four waves per SIMD: five spill); a wave walks its PUs
       // (lists beyond 4096 waves x FM_FB_MAX PUs -- four 4K pictures -- go as several launches: a wave sets aside at most FM_FB_MAX PUs)
       for (int first = 0; first < nblocks; first += cap * 4 * FM_FB_MAX)
       {
         const int nb = nblocks - first < cap * 4 * FM_FB_MAX ? nblocks - first : cap * 4 * FM_FB_MAX;
-        const int nWg = cdiv(nb, 4) < cap ? cdiv(nb, 4) : cap;
-        hipLaunchKernelGGL(frac16m_kernel<4>, dim3(vvc_xcd_grid(nWg, xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks + first, nb,
-                           bit_depth, clp_min, clp_max, *mvcost_host, preds ? preds + 2 * first : nullptr, results + first, image, nWg, xcd);
+        if (nb >= cap * 4)                                                 // every CU gets sixteen waves: as ONE workgroup per CU
+        {
+          const int nWg = cap / 4;
+          hipLaunchKernelGGL((frac16m_kernel<4, 16>), dim3(vvc_xcd_grid(nWg, xcd)), dim3(1024), 0, st, org, org_stride, ref, ref_stride, blocks + first, nb,
+                             bit_depth, clp_min, clp_max, *mvcost_host, preds ? preds + 2 * first : nullptr, results + first, image, nWg, xcd);
+        }
+        else
+        {
+          const int nWg = cdiv(nb, 4);
+          hipLaunchKernelGGL((frac16m_kernel<4, 4>), dim3(vvc_xcd_grid(nWg, xcd)), dim3(256), 0, st, org, org_stride, ref, ref_stride, blocks + first, nb,
+                             bit_depth, clp_min, clp_max, *mvcost_host, preds ? preds + 2 * first : nullptr, results + first, image, nWg, xcd);
+        }
       }
     }
     else if (use_hadamard)
