@@ -59,43 +59,57 @@ struct MhGeom
 };
 
 // original rows packed per 16x16 block: [block][sampled row][even 8 dwords | odd 8 dwords], biased; layouts as r5c_pack_org_kernel (dist.hip).
-// Round 6: the search kernel packs the rows of a super-block ITSELF (a launch of its own in front of it was 8.4 us per 4K picture) -- the first
-// super-block of a workgroup's run by all its threads, every further one by the waves that have no unit in the second round, while the others search;
-// the rows are read back through the scalar cache by explicit scalar loads (raster_dev.h: R5qStageS).  The buffer is written once per launch and
-// block before it is read, and the stores are complete (vmcnt(0)) in front of the workgroup barrier that precedes the reads.
+// Packed by a launch of its own in front of the search (7.5 us per 4K picture).  Round 6 measured the search kernel packing the rows of its super-blocks
+// ITSELF (first super-block of a run by every thread, the rest by the four waves without a second-round unit, read back by explicit scalar loads): exact,
+// and 6 us faster when the entry is timed alone in a loop (178 against 185 us) -- but 220 against 192 + 7.5 us inside the picture's workload, where the rows come
+// from HBM and the stores must be complete in front of every super-block's barrier; removed (docs/OPTIMISATION_LOG.md).
 // id = quarter q (id & 3) of record (block of the super-block, sampled row): four lanes per record, a wave's store is 1 KB of consecutive bytes.
-__device__ __forceinline__ void mh_pack_quarter(const Pel* __restrict__ org, int os, int orgX0, int orgY0, int n16x, int hs, int subShift, int sbx, int sby, int pnx,
-                                                int id, unsigned* __restrict__ packed)
+struct MhPackItem { unsigned d[8]; unsigned* dst; int q; };
+__device__ __forceinline__ void mh_pack_load(const Pel* __restrict__ org, int os, int orgX0, int orgY0, int n16x, int hs, int subShift, int sbx, int sby, int pnx,
+                                             int id, unsigned* __restrict__ packed, MhPackItem& it)
 {
   const int q = id & 3, rec = id >> 2;
   const int blk = rec / hs, row = rec - blk * hs;
   const int ty = blk / pnx, tx = blk - ty * pnx;
   const int by = 4 * sby + ty, bx = 4 * sbx + tx, b = by * n16x + bx;
   const Pel* o = org + (size_t)(orgY0 + 16 * by + (row << subShift)) * os + orgX0 + 16 * bx;
-  unsigned d[8];
   if ((reinterpret_cast<uintptr_t>(o) & 3) == 0)
   {
     const unsigned* p = reinterpret_cast<const unsigned*>(o);
 #pragma unroll
-    for (int k = 0; k < 8; k++) d[k] = p[k];
+    for (int k = 0; k < 8; k++) it.d[k] = p[k];
   }
   else
   {
 #pragma unroll
-    for (int k = 0; k < 8; k++) d[k] = (unsigned)(unsigned short)o[2 * k] | ((unsigned)(unsigned short)o[2 * k + 1] << 16);
+    for (int k = 0; k < 8; k++) it.d[k] = (unsigned)(unsigned short)o[2 * k] | ((unsigned)(unsigned short)o[2 * k + 1] << 16);
   }
+  it.q = q;
+  it.dst = packed + ((size_t)b * hs + row) * 16 + 4 * q;
+}
+__device__ __forceinline__ void mh_pack_store(const MhPackItem& it)
+{
   // quarter 0 / 1: even dwords 0..3 / 4..7; quarter 2 / 3: the odd-shifted dwords (samples (2k+1, 2k+2); k = 7: (15, 0))
   unsigned v[4];
 #pragma unroll
   for (int j = 0; j < 4; j++)
   {
-    const int k = 4 * (q & 1) + j;
-    unsigned lo = d[0], hi = d[1];
+    const int k = 4 * (it.q & 1) + j;
+    unsigned lo = it.d[0], hi = it.d[1];
 #pragma unroll
-    for (int t = 1; t < 8; t++) { lo = k == t ? d[t] : lo; hi = k == t ? d[(t + 1) & 7] : hi; }
-    v[j] = ((q & 2) ? __builtin_amdgcn_alignbit(hi, lo, 16) : lo) ^ 0x80008000u;
+    for (int t = 1; t < 8; t++) { lo = k == t ? it.d[t] : lo; hi = k == t ? it.d[(t + 1) & 7] : hi; }
+    v[j] = ((it.q & 2) ? __builtin_amdgcn_alignbit(hi, lo, 16) : lo) ^ 0x80008000u;
   }
-  reinterpret_cast<uint4*>(packed + ((size_t)b * hs + row) * 16)[q] = make_uint4(v[0], v[1], v[2], v[3]);
+  *reinterpret_cast<uint4*>(it.dst) = make_uint4(v[0], v[1], v[2], v[3]);
+}
+__global__ __launch_bounds__(256) void mh_pack_org_kernel(const Pel* __restrict__ org, int os, int orgX0, int orgY0, int n16x, int nblocks, int hs, int subShift, unsigned* __restrict__ packed)
+{
+  const size_t gid4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if ((gid4 >> 2) >= (size_t)nblocks * hs) return;
+  const int q = (int)(gid4 & 3), rec = (int)(gid4 >> 2), b = rec / hs, row = rec - b * hs, by = b / n16x, bx = b - by * n16x;
+  MhPackItem it;
+  mh_pack_load(org, os, orgX0, orgY0, n16x, hs, subShift, bx >> 2, by >> 2, 4, (((by & 3) * 4 + (bx & 3)) * hs + row) * 4 + q, packed, it);
+  mh_pack_store(it);
 }
 
 // arg-min of one block over the wave: kmin = (cost << 2 | candidate) per lane, idx0 = visiting index of the lane's candidate 0
@@ -274,7 +288,7 @@ __device__ __forceinline__ void mh_unit(const unsigned* orgPacked, const MhGeom&
   }
 }
 
-__global__ __launch_bounds__(1024) void me_hier_kernel(unsigned* orgPacked, const Pel* __restrict__ org, int os, int orgX0, int orgY0, const Pel* __restrict__ ref, int rs, MhGeom g, vvcgpu_mvcost mv,
+__global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* orgPacked, const Pel* __restrict__ ref, int rs, MhGeom g, vvcgpu_mvcost mv,
                                                        vvcgpu_search_best* __restrict__ r16, vvcgpu_search_best* __restrict__ r32, vvcgpu_search_best* __restrict__ r64,
                                                        vvcgpu_search_best* __restrict__ d16, vvcgpu_search_best* __restrict__ d32, vvcgpu_search_best* __restrict__ d64,
                                                        unsigned long long* __restrict__ diag)
@@ -412,12 +426,7 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(unsigned* orgPacked, cons
   for (int n = tid; n < MH_MAXSLOTS * 4; n += (int)blockDim.x) surf[n] = 0u;
   // LDS-only barrier: __syncthreads() also waits for vmcnt(0), i.e. for the neighbour's columns that were requested just above.  The first super-block
   // of the run: its original rows are packed here by every thread (behind the window's requests), and the barrier is the full one (stores complete)
-  if (kk == kk0)
-  {
-    for (int id = tid; id < nsubx * nsuby * g.hs * 4; id += (int)blockDim.x) mh_pack_quarter(org, os, orgX0, orgY0, g.n16x, g.hs, g.subShift, sbx, sby, nsubx, id, orgPacked);
-    __syncthreads();
-  }
-  else asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   if (stamp && tid == 0) diag[1] = __builtin_amdgcn_s_memtime();
   if (diag && stampK >= 0 && tid == 0) diag[40 + 1 * 4 + stampK] = __builtin_amdgcn_s_memtime();
 
@@ -438,19 +447,6 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(unsigned* orgPacked, cons
       for (int m = 0; m < 4; m++) L.cst[m] = r ? LU[1].cst[m] : LU[0].cst[m];
       mh_unit(orgPacked, g, off & 3, ldsBase + (unsigned)(slide * 128 + (q & 1) * 64 + (q >> 1) * 32 * MH_PITCH * 4), L, waveHasDense, q, sbx, sby, nsubx, nsuby, keys, surf, surfD, &arrive[sw], s, nslots, lane);
       if (stamp && lane == 0) diag[8 + u] = __builtin_amdgcn_s_memtime();
-    }
-  }
-  // the next super-block's original rows: by the waves that had no unit in the second round (four of sixteen for the +-96 raster), else by all
-  if (kk + 1 < kk0 + runLen && kk + 1 < chunk && item + 1 < g.total)
-  {
-    const int nUnits = 4 * nsw, idleFrom = max(nUnits - nwaves, 0);             // waves idleFrom .. nwaves - 1 have only one unit
-    const bool some = idleFrom < nwaves;
-    const int p0 = some ? idleFrom : 0, np = nwaves - p0;
-    if (wave >= p0)
-    {
-      const int it2 = item + 1, sbyN = it2 / g.nsbx, sbxN = it2 - sbyN * g.nsbx;
-      const int pnx = min(4, g.n16x - 4 * sbxN), pny = min(4, g.n16y - 4 * sbyN);
-      for (int id = (wave - p0) * 64 + lane; id < pnx * pny * g.hs * 4; id += np * 64) mh_pack_quarter(org, os, orgX0, orgY0, g.n16x, g.hs, g.subShift, sbxN, sbyN, pnx, id, orgPacked);
     }
   }
   __syncthreads();
@@ -530,6 +526,8 @@ int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref
   const int nblocks = c.n16x * c.n16y;
   unsigned* packed = static_cast<unsigned*>(vvcgpu_scratch(st, (size_t)nblocks * g.hs * 16 * sizeof(unsigned)));
   if (!packed) return VVCGPU_E_DEVICE;
+  hipLaunchKernelGGL(mh_pack_org_kernel, dim3((unsigned)(((size_t)nblocks * g.hs * 4 + 255) / 256)), dim3(256), 0, st, org, org_stride, c.org_x, c.org_y, c.n16x, nblocks, g.hs, c.sub_shift, packed);
+  VVC_LAUNCH_CHECK();
   VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(me_hier_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   unsigned long long* diag = nullptr;
   const bool wantDiag = getenv("VVCGPU_MH_DIAG") != nullptr;                 // measurement aid (tools/mehier_time.py): phase stamps of one workgroup
@@ -538,7 +536,7 @@ int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref
   const char* wgsEnv = getenv("VVCGPU_MH_WGS");
   const int wgsMax = wgsEnv && atoi(wgsEnv) >= 8 ? (atoi(wgsEnv) / 8) * 8 : (vvcgpu_cu_count() / 8) * 8;
   const int gridWgs = min(cdiv(g.total, 8) * 8, wgsMax);
-  hipLaunchKernelGGL(me_hier_kernel, dim3(gridWgs), dim3(1024), smem, st, packed, org, org_stride, c.org_x, c.org_y, ref, ref_stride, g, *mvcost_host,
+  hipLaunchKernelGGL(me_hier_kernel, dim3(gridWgs), dim3(1024), smem, st, packed, ref, ref_stride, g, *mvcost_host,
                      raster_best[0], raster_best[1], raster_best[2], dense_best ? dense_best[0] : nullptr, dense_best ? dense_best[1] : nullptr, dense_best ? dense_best[2] : nullptr, diag);
   VVC_LAUNCH_CHECK();
   if (wantDiag)
