@@ -51,3 +51,14 @@ print("hierarchical, raster only          : %.1f us" % timeit(lambda: hier(0)))
 os.environ["VVCGPU_MH_DIAG"] = "1"
 hier()
 torch.cuda.synchronize()
+
+# the same entry with the caches flushed in front of every call (a 600 MB fill: beyond the 256 MB memory-side cache): what part of the gap between this
+# loop and the workload (where the search follows the previous picture's filters) is cache state
+junk = torch.empty(300 * 1024 * 1024, dtype=torch.int16, device="cuda")
+ts = []
+for _ in range(8):
+    junk.fill_(1)
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record(); hier(); b.record(); torch.cuda.synchronize()
+    ts.append(a.elapsed_time(b) * 1e3)
+print("hierarchical, raster + dense, caches flushed in front of every call: %.1f us (min %.1f)" % (sum(ts[2:]) / len(ts[2:]), min(ts)))
