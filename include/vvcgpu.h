@@ -290,6 +290,14 @@ typedef struct vvcgpu_mc_desc {
 } vvcgpu_mc_desc;
 int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base,
                     const vvcgpu_mc_desc* descs, int n, int bit_depth, int clp_min, int clp_max, void* stream);
+/* The same call for a list that is (mostly) 16x16 luma / 8x8 chroma PUs -- a picture's PU list under the common partition, as the motion
+ * compensation of a whole picture hands it over (InterPrediction::motionCompensation per PU, InterPrediction.cpp:480-547): ONE launch.  vvcgpu_mc_batch
+ * runs the matrix-core kernel and, behind it, a launch of the generic kernel for every descriptor the first one left (4.9 us per 4K picture when that
+ * list is empty); here a descriptor the matrix-core kernel cannot take -- another shape, phase or stride, reference samples outside the bit depth -- is
+ * served by the wavefront that found it, behind its walk, through the same generic body.  Any list is valid and every result is the one
+ * vvcgpu_mc_batch gives; a list of mostly other shapes is slower here (they are served by the matrix-core kernel's waves one after the other). */
+int vvcgpu_mc_picture_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base,
+                            const vvcgpu_mc_desc* descs, int n, int bit_depth, int clp_min, int clp_max, void* stream);
 /* "predict a candidate -> distortion against the original" in one pass: the cost of an AMVP candidate (InterSearch::xGetTemplateCost,
  * EncoderLib/InterSearch.cpp:1606-1640: motionCompensation of the candidate vector, then getDistPart(DF_SAD)) and of a merge candidate
  * (EncCu::xCheckRDCostMerge2Nx2N, EncoderLib/EncCu.cpp:1565-1592: motionCompensation of the candidate, then the Hadamard distParam.distFunc).

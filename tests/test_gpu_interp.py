@@ -60,7 +60,8 @@ def test_if_batch(bd, first):
 
 @pytest.mark.parametrize("bd", [8, 10])
 @pytest.mark.parametrize("kind,W,doff0", [("smooth", 384, 0), ("extreme", 384, 0), ("smooth", 387, 3)])   # odd stride: the window's dword phase alternates
-def test_mc_batch(bd, kind, W, doff0):                                                                         # per row; doff0 = 3: no 8-byte aligned output row
+@pytest.mark.parametrize("entry", ["mc_batch", "mc_picture_batch"])      # two launches / one launch (the generic body inside the matrix-core kernel)
+def test_mc_batch(bd, kind, W, doff0, entry):                                                                         # per row; doff0 = 3: no 8-byte aligned output row
     from vvcsoftware_vtm_amd import ops
     rng = np.random.default_rng(bd)
     mx = (1 << bd) - 1
@@ -86,7 +87,7 @@ def test_mc_batch(bd, kind, W, doff0):                                          
     want = np.full(doff, -5, np.int16)
     oracle().orc_mc_batch(p(r0), p(r1), p(want), p(d), len(d), bd, 0, mx)
     got = torch.full((doff,), -5, dtype=torch.int16, device="cuda")
-    ops.mc_batch(dev(r0), dev(r1), got, ops.struct_to_device(d), len(d), bd, (0, mx))
+    getattr(ops, entry)(dev(r0), dev(r1), got, ops.struct_to_device(d), len(d), bd, (0, mx))
     assert np.array_equal(got.cpu().numpy(), want)
 
 
@@ -102,7 +103,8 @@ def _wild_plane(rng, h, w, bd, kind):
 
 @pytest.mark.parametrize("bd", [8, 10])
 @pytest.mark.parametrize("kind,W,clip", [("extreme", 384, None), ("smooth", 384, (19, -23)), ("wild", 392, None), ("uniform", 388, None)])
-def test_mc_every_phase(bd, kind, W, clip):
+@pytest.mark.parametrize("entry", ["mc_batch", "mc_picture_batch"])      # two launches / one launch (the generic body inside the matrix-core kernel)
+def test_mc_every_phase(bd, kind, W, clip, entry):
     """EVERY fractional phase pair through vvcgpu_mc_batch on the two shapes of the matrix-core kernel (VERDICT r5 W1 / ADVICE r5): 16x16 luma x
     all 16 x 16 phases and 8x8 chroma x all 32 x 32, uni- and bi-predictive (the second reference's phases sweep as well, a quarter / eighth phase
     beside a quarter / eighth phase so the bi path of the matrix cores runs), i.e. every Toeplitz table of mm_build_tables_kernel incl. the rounded
@@ -136,7 +138,7 @@ def test_mc_every_phase(bd, kind, W, clip):
     want = np.full(doff, -5, np.int16)
     oracle().orc_mc_batch(p(r0), p(r1), p(want), p(d), len(d), bd, lo, hi)
     got = torch.full((doff,), -5, dtype=torch.int16, device="cuda")
-    ops.mc_batch(dev(r0), dev(r1), got, ops.struct_to_device(d), len(d), bd, (lo, hi))
+    getattr(ops, entry)(dev(r0), dev(r1), got, ops.struct_to_device(d), len(d), bd, (lo, hi))
     got = got.cpu().numpy()
     if not np.array_equal(got, want):
         bad = [i for i, r in enumerate(d) if not np.array_equal(got[r["dst_off"]:r["dst_off"] + r["w"] * r["h"]], want[r["dst_off"]:r["dst_off"] + r["w"] * r["h"]])]
@@ -144,7 +146,8 @@ def test_mc_every_phase(bd, kind, W, clip):
 
 
 @pytest.mark.parametrize("n", [1, 2, 3, 4, 5, 7, 9])
-def test_mc_batch_few_pus(n):
+@pytest.mark.parametrize("entry", ["mc_batch", "mc_picture_batch"])      # two launches / one launch (the generic body inside the matrix-core kernel)
+def test_mc_batch_few_pus(n, entry):
     """with n <= 4 PUs of the matrix-core shapes the one-launch form had an empty grid (cdiv(n, 4) & ~1 == 0) and nothing was written"""
     from vvcsoftware_vtm_amd import ops
     rng = np.random.default_rng(n)
@@ -163,11 +166,12 @@ def test_mc_batch_few_pus(n):
         want = np.full(doff, -5, np.int16)
         oracle().orc_mc_batch(p(r0), p(r1), p(want), p(d), len(d), bd, 0, mx)
         got = torch.full((doff,), -5, dtype=torch.int16, device="cuda")
-        ops.mc_batch(dev(r0), dev(r1), got, ops.struct_to_device(d), len(d), bd, (0, mx))
+        getattr(ops, entry)(dev(r0), dev(r1), got, ops.struct_to_device(d), len(d), bd, (0, mx))
         assert np.array_equal(got.cpu().numpy(), want), shapes
 
 
-def test_mc_batch_long_mixed_list():
+@pytest.mark.parametrize("entry", ["mc_batch", "mc_picture_batch"])      # two launches / one launch (the generic body inside the matrix-core kernel)
+def test_mc_batch_long_mixed_list(entry):
     """a list long enough that a wavefront of the generic kernel looks at several descriptors at a time (n > 8192: chunks of 2 .. 64), with the fast
     kernel's shapes (16x16 luma, 8x8 chroma) and everything else mixed at random: every PU is served exactly once, by the right kernel"""
     from vvcsoftware_vtm_amd import ops
@@ -189,7 +193,7 @@ def test_mc_batch_long_mixed_list():
     want = np.full(doff, -5, np.int16)
     oracle().orc_mc_batch(p(r0), p(r1), p(want), p(d), len(d), bd, 0, mx)
     got = torch.full((doff,), -5, dtype=torch.int16, device="cuda")
-    ops.mc_batch(dev(r0), dev(r1), got, ops.struct_to_device(d), len(d), bd, (0, mx))
+    getattr(ops, entry)(dev(r0), dev(r1), got, ops.struct_to_device(d), len(d), bd, (0, mx))
     assert np.array_equal(got.cpu().numpy(), want)
 
 

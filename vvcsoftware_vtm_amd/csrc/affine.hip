@@ -358,8 +358,8 @@ int vvcgpu_affine_pred_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base,
   const int rc = vvcgpu_affine_subblock_descs(pus, n, comp, pic_w, pic_h, max_cu_w, max_cu_h, ref_origin_x, ref_origin_y, ref0_stride, ref1_stride, subblock_ws,
                                               stream);
   if (rc != VVCGPU_OK) return rc;
-  // luma: every descriptor is a 4x4 block -- no fast-kernel launch, the packed 4x4 variant of the generic kernel; chroma (2x2): the plain one
-  return vvcgpu_mc_batch_impl(ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, subblock_ws, n_subblocks, bit_depth, clp_min, clp_max, stream, comp == 0,
+  // luma: every descriptor is a 4x4 block -- no fast-kernel launch, the packed 4x4 variant of the generic kernel; chroma (2x2): the plain one, no fast-kernel launch either
+  return vvcgpu_mc_batch_impl(ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, subblock_ws, n_subblocks, bit_depth, clp_min, clp_max, stream, true,
                               comp == 0);
 }
 

@@ -815,21 +815,33 @@ __device__ __forceinline__ int mm_kind_of(const uint4& q)   // bytes 32..47 of a
   d.is_luma = (signed char)(q.w & 0xFFu); d.bi = (signed char)((q.w >> 8) & 0xFFu);
   return mm_kind(d);
 }
+// the generic body for the PUs this kernel cannot take, served by the wave that found them BEHIND its walk (round 6, vvcgpu_mc_picture_batch: the launch of
+// mc_batch_kernel behind this kernel cost 4.9 us per 4K picture for an empty list).  The second pass is a REAL call that takes everything it needs from
+// a record in LDS: values kept alive for it across the walks cost the walks' loops spilled registers (190 instead of 49 us).  Defined below mc_generic_pu.
+struct MmServe { const Pel* ref0Base; const Pel* ref1Base; Pel* dstBase; const vvcgpu_mc_desc* descs; const int* flags; int n, bd, cmin, cmax, w0, W, luma; };
+__device__ __forceinline__ void mm_second_pass(const MmServe* sv, short* gen, unsigned* genT);
+__device__ __noinline__ void mm_serve_one(const MmServe* sv, int li, short* gen, unsigned* genT);
+constexpr int MM_GEN_SHORTS = 23 * 24 + 23 * 16;                               // WR x WP + WR x ST (declared below)
+
 template <int KIND_T>
 __global__ __launch_bounds__(256, 4) void mc_mfma_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base, Pel* __restrict__ dstBase,
                                                                          const vvcgpu_mc_desc* __restrict__ descs, int n, int bd, int cmin, int cmax,
                                                                          const _Float16* __restrict__ image, int* __restrict__ flags, unsigned long long* __restrict__ diag,
-                                                                         int* __restrict__ genCount, int* __restrict__ nextCounters)
+                                                                         int* __restrict__ genCount, int* __restrict__ nextCounters, int serve)
 {
   if (blockIdx.x == 0 && threadIdx.x < VVC_CTR_INTS) nextCounters[threadIdx.x] = 0;       // the counter set of the NEXT call on this stream (vvcgpu_counters)
   // KIND_T 0: ONE launch, workgroups alternate between the two shapes (both kinds of waves on every CU at the same time)
   const int KIND = KIND_T ? KIND_T : 1 + ((int)blockIdx.x & 1);
   const int T0 = KIND == 1 ? MM_TAL : MM_TAC, T1 = KIND == 1 ? MM_TAC : MM_ENTRIES;          // this kind's table entries
   __shared__ __align__(16) _Float16 tabL[(KIND_T == 2 ? MM_ENTRIES - MM_TAC : MM_TAC - MM_TAL) * 8];
+  __shared__ __align__(16) short genS[4][MM_GEN_SHORTS];                     // the generic body's window / intermediate, per wave
+  __shared__ __align__(16) unsigned genT[4][MC_LDS_DW];                      // ... and its packed-form tile
+  __shared__ MmServe serveS;
+  __shared__ int anyGenS[4];                                 // serve: per wave, what its walk left to the generic body (the count lands here instead of in genCount)
   for (int i = threadIdx.x; i < T1 - T0; i += 256) reinterpret_cast<uint4*>(tabL)[i] = reinterpret_cast<const uint4*>(image)[T0 + i];
-  __syncthreads();
-  MmK K;
-  K.genCount = genCount;
+  if (threadIdx.x < 4) anyGenS[threadIdx.x] = 0;
+  MmK K;                                                     // (the barrier behind the table copy follows the lane constants and the serve record)
+  K.genCount = serve ? &anyGenS[threadIdx.x >> 6] : genCount;
   K.tabS = tabL - T0 * 8;                                    // (indexed with the image's entry numbers)
   K.lane = threadIdx.x & 63; K.c16 = K.lane & 15; K.g = K.lane >> 4;
   const int g = K.g;
@@ -859,6 +871,8 @@ __global__ __launch_bounds__(256, 4) void mc_mfma_kernel(const Pel* __restrict__
   const int W = nb * 4, perX = W >> 3;
   const int w = (nb & 7) ? bi_ * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6)
                          : (bi_ & 7) * perX + (bi_ >> 3) * 4 + __builtin_amdgcn_readfirstlane((int)threadIdx.x >> 6);
+  if (serve && threadIdx.x == 0) serveS = MmServe{ ref0Base, ref1Base, dstBase, descs, flags, n, bd, cmin, cmax, w, W, KIND == 1 ? 1 : 0 };     // (w of wave 0; read behind the walks)
+  __syncthreads();
   // The wave's descriptors w + j W are classified 64 at a time, one per LANE (one gather load and a ballot; a descriptor-by-descriptor walk on the scalar
   // unit -- one per CU, shared by its 20 waves -- bound the kernel: 400 scalar instructions per PU); the walk over the set bits is a few scalar operations.
   // Three steps are in flight (in-kernel stamps, VVCGPU_MC_DIAG: with the descriptor read inside the step that requests the samples, 1400 of a step's
@@ -934,6 +948,7 @@ __global__ __launch_bounds__(256, 4) void mc_mfma_kernel(const Pel* __restrict__
       }
     }
     if (pend) { MmWin Wn; mm_luma_win(K, raw, Wn); mm_luma(K, dP, Wn, ref0Base, ref1Base, dstBase, flags, iP); }
+    if (serve && anyGenS[(int)threadIdx.x >> 6] != 0) mm_second_pass(&serveS, genS[(int)threadIdx.x >> 6], genT[(int)threadIdx.x >> 6]);
   }
   else
   {
@@ -976,6 +991,7 @@ __global__ __launch_bounds__(256, 4) void mc_mfma_kernel(const Pel* __restrict__
       }
     }
     if (pend) { MmWin Wn; mm_chroma_win(K, raw, Wn); mm_chroma(K, Wn, iAP, iBP, dstBase, flags); }
+    if (serve && anyGenS[(int)threadIdx.x >> 6] != 0) mm_second_pass(&serveS, genS[(int)threadIdx.x >> 6], genT[(int)threadIdx.x >> 6]);
   }
 }
 
@@ -1046,58 +1062,16 @@ __device__ __forceinline__ unsigned long long mc_luma4x4_chunk(unsigned long lon
   return ((unsigned long long)hi << 32) | lo;
 }
 
-// generic kernel: any size, one wave per PU, persistent over the list of PUs the fast kernel left.
-// DIST (vvcgpu_mc_dist_batch): the prediction goes into an LDS tile instead of dst, and the wave returns its distortion against the original
-// (descriptor field dst_off / dst_stride = the original block, reserved = row sub-sampling shift of the SAD); list == nullptr: every descriptor.
-template <bool DIST, bool SUB44 = false>
-__global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
-                                                      Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs,
-                                                      int bd, int cmin, int cmax,
-                                                      int nDirect, int distKind, const Pel* __restrict__ orgBase, unsigned long long* __restrict__ out, int chunk,
-                                                      const int* __restrict__ flags, int takeFast, const int* __restrict__ genCount = nullptr)
+// One PU through the generic body: tiles of the packed form where the PU is a grid of them, else (or when a sample leaves the bit depth) sample by sample.
+// ONE wave; win / tmp / tileL: that wave's LDS (WR x WP, WR x ST shorts, MC_LDS_DW dwords); DIST: the prediction goes to predT (pitch d.w) instead of dst.
+// TAG separates the copies by caller: a function that is not inlined takes the loosest register budget of the kernels that call it.
+#define MC_WAVE_SYNC() do { __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup"); } while (0)
+template <bool DIST, int TAG>
+__device__ __forceinline__ void mc_generic_pu(const vvcgpu_mc_desc& d, const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base, Pel* __restrict__ dstBase,
+                                              int bd, int cmin, int cmax, int lane, short* win, short* tmp, unsigned* tileL, short* predT)
 {
-  // behind the matrix-core kernel: nothing left for this one (a picture of conforming 16x16 / 8x8 PUs) -- every wave leaves at once
-  if (!DIST && genCount && __builtin_amdgcn_readfirstlane(*genCount) == 0) return;
-  __shared__ short win[WR * WP];
-  __shared__ short tmp[WR * ST];
-  __shared__ __align__(16) short predT[DIST ? 128 * 128 : 8];
-  __shared__ __align__(16) unsigned tileL[DIST ? 4 : MC_LDS_DW];
-  const int lane = threadIdx.x;
-  // !DIST: a wave looks at `chunk` consecutive descriptors at a time, one per lane, and serves those the fast kernel leaves.  (A list of them filled
-  // by the fast kernel cost one same-address atomic per PU: 6 of the 7 ms of an affine prediction of 518 k 4x4 sub-blocks.)  chunk (host): 64 for
-  // long lists, down to 1 for short ones -- a wave serves its PUs one after the other, and a short list of large PUs needs every wave it can get
-  // (1947 PUs of 64x64 in chunks of 64: 31 busy waves, 2.2 ms instead of 0.08).
-  const int STEP = DIST ? 1 : chunk;
-  for (int base0 = (int)blockIdx.x * STEP; base0 < nDirect; base0 += (int)gridDim.x * STEP)
-  {
-  unsigned long long todo = 1ull;
-  if (!DIST)
-  {
-    bool mine = false, sub44 = false;
-    if (lane < chunk && base0 + lane < nDirect)
-    {
-      const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(descs + base0 + lane) + 32);     // dst_stride | w, h | phases | is_luma, bi
-      const int isLuma = (int)(signed char)(q.w & 0xFFu), qw = (int)(short)(q.y & 0xFFFFu), qh = (int)(short)(q.y >> 16);
-      mine = takeFast || !mc_is_fast(isLuma, qw, qh) || (flags && flags[base0 + lane] != 0);       // (flags: the fast shapes the matrix-core kernel in front has left; takeFast: there is none)
-      sub44 = SUB44 && isLuma && qw == 4 && qh == 4;
-    }
-    todo = __builtin_amdgcn_ballot_w64(mine);
-    unsigned long long todo44 = __builtin_amdgcn_ballot_w64(sub44);        // 4x4 luma (affine sub-blocks): four at a time, see mc_luma4x4_quad
-    todo &= ~todo44;
-    if (SUB44 && todo44) todo |= mc_luma4x4_chunk(todo44, descs + base0, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, tileL);
-  }
-  while (todo)
-  {
-  const int li = base0 + (DIST ? 0 : (int)__builtin_ctzll(todo));
-  todo &= todo - 1ull;
-  const vvcgpu_mc_desc d = descs[li];
   // descriptors live in device memory, the host cannot validate them: a shape outside the contract (the prediction tile of the fused form is
   // 128 x 128, bi is 0 or 1 there) is skipped with the sentinel ~0 as its distortion instead of overrunning LDS (wave-uniform)
-  if (DIST && (d.w < 1 || d.h < 1 || d.w > 128 || d.h > 128 || d.bi < 0 || d.bi > 1))
-  {
-    if (lane == 0) out[li] = ~0ull;
-    continue;
-  }
   // a PU whose sides are multiples of the packed path's tile (16 luma / 8 chroma samples) is a grid of tiles with the same fractional phase: the
   // wave walks them with the packed code of the fast kernel (here, not there: inlined into the fast kernel the loop cost it its 80-VGPR budget and
   // the MC stage of the canonical workload went from 0.075 to 0.18 ms)
@@ -1133,7 +1107,7 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
         mc_tile_dot2<4, 8, 32>(q, on, st, dstBase, bd, cmin, cmax, lane & 31, Lh, reinterpret_cast<short*>(Lh + 11 * 6), reinterpret_cast<short*>(Lh + 11 * 6 + 8 * 6));
       }
     }
-    if (!outsideDepth) continue;
+    if (!outsideDepth) return;
   }
   const int N = d.is_luma ? 8 : 4, half = N / 2 - 1;
   const bool rndRes = d.bi == 0;
@@ -1157,13 +1131,13 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
         // stage only what the branch needs: rows [-half, th+N-1-half) when fy != 0, cols likewise when fx != 0
         const int r0 = fy ? -half : 0, nr = fy ? th + N - 1 : th;
         const int c0 = fx ? -half : 0, nc = fx ? tw + N - 1 : tw;
-        __syncthreads();                               // previous users of win/tmp are done
+        MC_WAVE_SYNC();                               // previous users of win/tmp are done
         for (int i = lane; i < nr * nc; i += 64)
         {
           const int rr = i / nc, cc = i - rr * nc;
           win[rr * WP + cc] = ref[(ptrdiff_t)(r0 + rr) * rs + c0 + cc];
         }
-        __syncthreads();
+        MC_WAVE_SYNC();
         if (fx && fy)
         {
           const IfMode mh = if_mode(true, false, bd);
@@ -1174,7 +1148,7 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
             for (int k = 0; k < N; k++) sum += win[rr * WP + x + k] * cx[k];
             tmp[rr * ST + x] = (short)((sum + mh.offset) >> mh.shift);
           }
-          __syncthreads();
+          MC_WAVE_SYNC();
           const IfMode mv = if_mode(false, rndRes, bd);
 #pragma unroll
           for (int j = 0; j < 4; j++)
@@ -1232,6 +1206,132 @@ __global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ re
         }
       }
     }
+}
+
+// (a real call: it runs for the rare PU only.  The scan below is inline in the kernel -- as a call of its own it saved and restored ~90 callee-saved
+// registers through scratch memory in EVERY wave: 190 MB of traffic, 30 us)
+__device__ __noinline__ void mm_serve_one(const MmServe* sv, int li, short* gen, unsigned* genT)
+{
+  static_assert(MM_GEN_SHORTS == WR * WP + WR * ST, "LDS of the generic body inside mc_mfma_kernel");
+  const MmServe S = *sv;
+  const vvcgpu_mc_desc d = S.descs[li];
+  mc_generic_pu<false, 1>(d, S.ref0Base, S.ref1Base, S.dstBase, S.bd, S.cmin, S.cmax, (int)threadIdx.x & 63, gen, gen + WR * WP, genT, nullptr);
+}
+__device__ __forceinline__ void mm_second_pass(const MmServe* sv, short* gen, unsigned* genT)
+{
+  // flags[] was written by this wave in its walk: its stores are complete behind the wait (vector stores write through to the L2), and the loads below are
+  // agent-scope atomic loads (served by the L2).  NOT __threadfence(): on this chip that is an L2 write-back + invalidate per wave -- 4096 of them took
+  // the kernel from 49 to 245 us
+  __builtin_amdgcn_fence(__ATOMIC_SEQ_CST, "workgroup");
+  const MmServe S = *sv;
+  const int lane = (int)threadIdx.x & 63, w = S.w0 + ((int)threadIdx.x >> 6);
+  auto serve = [&](int li) { mm_serve_one(sv, li, gen, genT); };
+  if (S.luma)
+  {
+    // what this wave's descriptors leave to the generic body: every shape that is not a fast one (luma or chroma), the fast shapes the walk rejected
+    // (phases, strides) and the luma PUs whose samples left the bit depth
+    for (int j0 = 0; w + (long long)j0 * S.W < S.n; j0 += 64)
+    {
+      const long long iL = w + (long long)(j0 + lane) * S.W;
+      bool gen1 = false;
+      if (iL < S.n)
+      {
+        const uint4 q1 = reinterpret_cast<const uint4*>(S.descs + iL)[1], q2 = reinterpret_cast<const uint4*>(S.descs + iL)[2];
+        int k = mm_kind_of(q2);
+        const int bi = (int)(signed char)((q2.w >> 8) & 0xFFu);
+        if (k == 1 && ((q1.z | (bi == 1 ? q1.w : 0u)) & 7u)) k = -1;
+        gen1 = k <= 0 || (k == 1 && __hip_atomic_load(S.flags + iL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0);
+      }
+      unsigned long long todo = __ballot(gen1);
+      while (todo)
+      {
+        const int j = (int)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        serve(w + (j0 + j) * S.W);
+      }
+    }
+  }
+  else
+  {
+    // the chroma PUs of this wave's pairs whose samples left the bit depth
+    const int units = (S.n + 1) >> 1;
+    for (int j0 = 0; w + (long long)j0 * S.W < units; j0 += 64)
+    {
+      const long long uL = w + (long long)(j0 + lane) * S.W;
+      int g0 = -1, g1 = -1;
+      if (uL < units)
+      {
+        const int k0 = mm_kind_of(reinterpret_cast<const uint4*>(S.descs + 2 * uL)[2]);
+        const int k1 = 2 * uL + 1 < S.n ? mm_kind_of(reinterpret_cast<const uint4*>(S.descs + 2 * uL + 1)[2]) : 0;
+        if (k0 == 2 && __hip_atomic_load(S.flags + 2 * uL, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) g0 = (int)(2 * uL);
+        if (k1 == 2 && __hip_atomic_load(S.flags + 2 * uL + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0) g1 = (int)(2 * uL + 1);
+      }
+      unsigned long long todo = __ballot(g0 >= 0 || g1 >= 0);
+      while (todo)
+      {
+        const int j = (int)__builtin_ctzll(todo);
+        todo &= todo - 1ull;
+        const int a0 = __builtin_amdgcn_readlane(g0, j), a1 = __builtin_amdgcn_readlane(g1, j);
+        if (a0 >= 0) serve(a0);
+        if (a1 >= 0) serve(a1);
+      }
+    }
+  }
+}
+
+// generic kernel: any size, one wave per PU, persistent over the list of PUs the fast kernel left.
+// DIST (vvcgpu_mc_dist_batch): the prediction goes into an LDS tile instead of dst, and the wave returns its distortion against the original
+// (descriptor field dst_off / dst_stride = the original block, reserved = row sub-sampling shift of the SAD); list == nullptr: every descriptor.
+template <bool DIST, bool SUB44 = false>
+__global__ __launch_bounds__(64) void mc_batch_kernel(const Pel* __restrict__ ref0Base, const Pel* __restrict__ ref1Base,
+                                                      Pel* __restrict__ dstBase, const vvcgpu_mc_desc* __restrict__ descs,
+                                                      int bd, int cmin, int cmax,
+                                                      int nDirect, int distKind, const Pel* __restrict__ orgBase, unsigned long long* __restrict__ out, int chunk,
+                                                      const int* __restrict__ flags, int takeFast, const int* __restrict__ genCount = nullptr)
+{
+  // behind the matrix-core kernel: nothing left for this one (a picture of conforming 16x16 / 8x8 PUs) -- every wave leaves at once
+  if (!DIST && genCount && __builtin_amdgcn_readfirstlane(*genCount) == 0) return;
+  __shared__ short win[WR * WP];
+  __shared__ short tmp[WR * ST];
+  __shared__ __align__(16) short predT[DIST ? 128 * 128 : 8];
+  __shared__ __align__(16) unsigned tileL[DIST ? 4 : MC_LDS_DW];
+  const int lane = threadIdx.x;
+  // !DIST: a wave looks at `chunk` consecutive descriptors at a time, one per lane, and serves those the fast kernel leaves.  (A list of them filled
+  // by the fast kernel cost one same-address atomic per PU: 6 of the 7 ms of an affine prediction of 518 k 4x4 sub-blocks.)  chunk (host): 64 for
+  // long lists, down to 1 for short ones -- a wave serves its PUs one after the other, and a short list of large PUs needs every wave it can get
+  // (1947 PUs of 64x64 in chunks of 64: 31 busy waves, 2.2 ms instead of 0.08).
+  const int STEP = DIST ? 1 : chunk;
+  for (int base0 = (int)blockIdx.x * STEP; base0 < nDirect; base0 += (int)gridDim.x * STEP)
+  {
+  unsigned long long todo = 1ull;
+  if (!DIST)
+  {
+    bool mine = false, sub44 = false;
+    if (lane < chunk && base0 + lane < nDirect)
+    {
+      const uint4 q = *reinterpret_cast<const uint4*>(reinterpret_cast<const char*>(descs + base0 + lane) + 32);     // dst_stride | w, h | phases | is_luma, bi
+      const int isLuma = (int)(signed char)(q.w & 0xFFu), qw = (int)(short)(q.y & 0xFFFFu), qh = (int)(short)(q.y >> 16);
+      mine = takeFast || !mc_is_fast(isLuma, qw, qh) || (flags && flags[base0 + lane] != 0);       // (flags: the fast shapes the matrix-core kernel in front has left; takeFast: there is none)
+      sub44 = SUB44 && isLuma && qw == 4 && qh == 4;
+    }
+    todo = __builtin_amdgcn_ballot_w64(mine);
+    unsigned long long todo44 = __builtin_amdgcn_ballot_w64(sub44);        // 4x4 luma (affine sub-blocks): four at a time, see mc_luma4x4_quad
+    todo &= ~todo44;
+    if (SUB44 && todo44) todo |= mc_luma4x4_chunk(todo44, descs + base0, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, tileL);
+  }
+  while (todo)
+  {
+  const int li = base0 + (DIST ? 0 : (int)__builtin_ctzll(todo));
+  todo &= todo - 1ull;
+  const vvcgpu_mc_desc d = descs[li];
+  // descriptors live in device memory, the host cannot validate them: a shape outside the contract (the prediction tile of the fused form is
+  // 128 x 128, bi is 0 or 1 there) is skipped with the sentinel ~0 as its distortion instead of overrunning LDS (wave-uniform)
+  if (DIST && (d.w < 1 || d.h < 1 || d.w > 128 || d.h > 128 || d.bi < 0 || d.bi > 1))
+  {
+    if (lane == 0) out[li] = ~0ull;
+    continue;
+  }
+  mc_generic_pu<DIST, 0>(d, ref0Base, ref1Base, dstBase, bd, cmin, cmax, lane, win, tmp, tileL, predT);
   if (DIST)
   {
     __syncthreads();                                   // the tile is complete
@@ -1417,16 +1517,23 @@ int vvcgpu_if_batch(const vvc_pel* src_base, vvc_pel* dst_base, const vvcgpu_if_
 // skip_fast: the caller knows that no descriptor is one of the fast kernel's shapes (affine sub-blocks): its launch is left out -- 65 k workgroups
 // that only look at their descriptors and leave cost 80 us for the 518 k sub-blocks of a 4K picture
 __attribute__((visibility("hidden"))) int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base,
-                         const vvcgpu_mc_desc* descs, int n, int bit_depth, int clp_min, int clp_max, void* stream, bool skip_fast, bool sub44);
+                         const vvcgpu_mc_desc* descs, int n, int bit_depth, int clp_min, int clp_max, void* stream, bool skip_fast, bool sub44, bool serve_in_kernel = false);
 
 int vvcgpu_mc_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base,
                     const vvcgpu_mc_desc* descs, int n, int bit_depth, int clp_min, int clp_max, void* stream)
 {
   return vvcgpu_mc_batch_impl(ref0_base, ref1_base, dst_base, descs, n, bit_depth, clp_min, clp_max, stream, false, false);
 }
+// a picture's PU list as an encoder builds it for the common partition (16x16 luma / 8x8 chroma PUs): ONE launch -- what the matrix-core kernel cannot
+// take (other shapes, phases, strides, samples outside the bit depth) is served by the wave that found it behind its walk, through the generic body
+int vvcgpu_mc_picture_batch(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base,
+                            const vvcgpu_mc_desc* descs, int n, int bit_depth, int clp_min, int clp_max, void* stream)
+{
+  return vvcgpu_mc_batch_impl(ref0_base, ref1_base, dst_base, descs, n, bit_depth, clp_min, clp_max, stream, false, false, true);
+}
 
 int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc_pel* dst_base,
-                         const vvcgpu_mc_desc* descs, int n, int bit_depth, int clp_min, int clp_max, void* stream, bool skip_fast, bool sub44)
+                         const vvcgpu_mc_desc* descs, int n, int bit_depth, int clp_min, int clp_max, void* stream, bool skip_fast, bool sub44, bool serve_in_kernel)
 {
   VVC_CHECK_ARG(n >= 0, "mc_batch: n %d", n);
   if (n == 0) return VVCGPU_OK;
@@ -1452,7 +1559,7 @@ int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc
     if (!counters) return VVCGPU_E_DEVICE;
     genCount = counters + VVC_CTR_INTS * cur;
     hipLaunchKernelGGL(mc_mfma_kernel<0>, dim3(wgL < 2 ? 2 : (wgL & ~1)), dim3(256), 0, st, ref0_base, ref1_base ? ref1_base : ref0_base, dst_base, descs, n, bit_depth, clp_min, clp_max, image, fl, diag,
-                       genCount, counters + VVC_CTR_INTS * (cur ^ 1));
+                       genCount, counters + VVC_CTR_INTS * (cur ^ 1), serve_in_kernel ? 1 : 0);
     if (wantDiag)
     {
       unsigned long long h[64];
@@ -1464,6 +1571,12 @@ int vvcgpu_mc_batch_impl(const vvc_pel* ref0_base, const vvc_pel* ref1_base, vvc
       fprintf(stderr, "\n");
     }
     flags = fl;
+  }
+  if (flags && serve_in_kernel)                                          // the matrix-core kernel has served what it could not take itself
+  {
+    VVC_LAUNCH_CHECK_COUNTERS(st);
+    VVC_LAUNCH_CHECK();
+    return VVCGPU_OK;
   }
   const int chunk = n >= 64 * 8192 ? 64 : (n + 8191) / 8192;            // ~8192 waves: 32 per CU
   // behind the matrix-core kernel the generic one usually finds nothing (or a few PUs) to do: a grid of 1024 waves that walk the list leaves sooner than 8192

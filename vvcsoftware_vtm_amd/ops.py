@@ -389,6 +389,12 @@ def mc_batch(ref0_base, ref1_base, dst_base, descs_dev, n, bit_depth=10, clp=(0,
               bit_depth, clp[0], clp[1], _stream())
 
 
+def mc_picture_batch(ref0_base, ref1_base, dst_base, descs_dev, n, bit_depth=10, clp=(0, 1023)):
+    """mc_batch for a picture's list of (mostly) 16x16 luma / 8x8 chroma PUs: one launch (vvcgpu_mc_picture_batch)"""
+    capi.call("vvcgpu_mc_picture_batch", capi.ptr(ref0_base), capi.ptr(ref1_base), capi.ptr(dst_base), capi.ptr(descs_dev), n,
+              bit_depth, clp[0], clp[1], _stream())
+
+
 def mc_dist_batch(kind, ref0_base, ref1_base, org_base, descs_dev, n, bit_depth=10, clp=(0, 1023)):
     """predict a candidate (descriptors as mc_batch, dst_off / dst_stride = the original block, reserved = SAD row sub-sampling shift) and return
     its distortion against the original: int64 tensor [n]."""

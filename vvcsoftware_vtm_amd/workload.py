@@ -569,7 +569,7 @@ class Workload:
         if pre_mc is not None:
             pre_mc()
         with T("mc/mc_picture"):                  # offsets in the list are relative to the luma planes; the chroma planes follow
-            ops.mc_batch(st["ref0"][0], st["ref1"][0], st["pred"][0], st["mc_pic"], self.mc_pic.size, bd, (0, mx))
+            ops.mc_picture_batch(st["ref0"][0], st["ref1"][0], st["pred"][0], st["mc_pic"], self.mc_pic.size, bd, (0, mx))
         # ---- residual / transforms / reconstruction
         if self.fused_resi:
             with T("resi/resi_chain"):
