@@ -386,8 +386,8 @@ class Workload:
             return "me_hier_kernel"
         if stage == "me":
             return "sad_raster5" if name.endswith("%dx%d" % (self.me_grids[1][2], self.me_grids[1][3])) else "sad_dense"
-        return {"frac_refine_16x16": "frac16m_kernel", "mc_picture": "mc_mfma_kernel", "deblock": "deblock_picture_kernel",
-                "sao_stats": "sao_stats_picture_kernel", "sao_apply": "sao_apply_picture_kernel", "alf_classify": "alf_classify_kernel",
+        return {"frac_refine_16x16": "frac16m_kernel", "mc_picture": "mc_mfma_kernel", "deblock": "deblock_block_kernel",
+                "sao_stats": "sao_stats_picture_kernel", "sao_apply": "sao_apply_strip_kernel", "alf_classify": "alf_classify_kernel",
                 "alf_stats": "alf_stats_picture_kernel", "alf_filter": "alf_filter_picture_kernel", "resi_chain": "rc_chain_kernel"}.get(name)
 
     def margins(self):
