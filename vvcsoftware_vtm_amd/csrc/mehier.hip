@@ -121,7 +121,12 @@ __device__ __forceinline__ void mh_block_min(unsigned kmin, unsigned idx0, unsig
   const int src = __builtin_ctzll(hit);
   const unsigned sel = (unsigned)__builtin_amdgcn_readlane((int)kmin, src) & 3u;
   const unsigned idx = (unsigned)__builtin_amdgcn_readlane((int)idx0, src) + sel;
-  if (lane == 0 && km < MH_INVALID) atomicMin(key, ((unsigned long long)km << 24) | idx);
+  // (explicit ds_min_u64: behind atomicMin the compiler's atomic optimiser elects a lane of the one-lane mask again -- two v_mbcnt, a compare and a branch per fold)
+  if (lane == 0 && km < MH_INVALID)
+  {
+    const unsigned long long v = ((unsigned long long)km << 24) | idx;
+    asm volatile("ds_min_u64 %0, %1" :: "v"((unsigned)(size_t)(__attribute__((address_space(3))) unsigned long long*)key), "v"(v) : "memory");
+  }
 }
 
 // What a lane of a slot wave works on: four candidates 0 / 5 / 10 / 15 samples into one LDS span (the quad loop of raster_dev.h).
@@ -193,7 +198,7 @@ __device__ __forceinline__ unsigned long long mh_fold64(const unsigned (&a)[4], 
 __device__ __forceinline__ void mh_block_min64(unsigned long long k, unsigned long long* key, int lane)
 {
   const unsigned long long km = wave_min_u64(k);
-  if (lane == 0 && km != ~0ull) atomicMin(key, km);
+  if (lane == 0 && km != ~0ull) asm volatile("ds_min_u64 %0, %1" :: "v"((unsigned)(size_t)(__attribute__((address_space(3))) unsigned long long*)key), "v"(km) : "memory");
 }
 
 // The sub-blocks of a quadrant that exist (wave-uniform), walked as ONE pipeline of unrolled stage bodies (raster_dev.h: r5q_positions_fixed; NST sampled
