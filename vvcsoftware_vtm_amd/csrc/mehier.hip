@@ -359,11 +359,14 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* orgPacked
   int slide = 0, pfQ0 = 0;
   bool pfHave = false;
   uint4 pf[2];
+  // (row, column) of the run's super-blocks: one division per run, then a step to the right with wrap (the items of a run are consecutive)
+  int sbyRun = ((int)(blockIdx.x & 7) * chunk + kk0) / g.nsbx, sbxRun = ((int)(blockIdx.x & 7) * chunk + kk0) - sbyRun * g.nsbx;
   for (int kk = kk0; kk < kk0 + runLen && kk < chunk; kk++)
   {
   const int item = (int)(blockIdx.x & 7) * chunk + kk;
   if (item >= g.total) break;
-  const int sby = item / g.nsbx, sbx = item - sby * g.nsbx;
+  const int sby = sbyRun, sbx = sbxRun;
+  if (++sbxRun == g.nsbx) { sbxRun = 0; sbyRun++; }
   const int nsubx = min(4, g.n16x - 4 * sbx), nsuby = min(4, g.n16y - 4 * sby);
   // VVCGPU_MH_DIAG: core-clock stamps of one workgroup's phases (start, window staged, every unit's end, units done, 64x64 pass done)
   const bool stamp = diag && item == (g.total >> 1) + 3;                            // (the fourth super-block of a run: a slide)
@@ -472,16 +475,18 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* orgPacked
       const int idx = (int)(key & 0xFFFFFFu);
       const unsigned long long cost = key >> 24;
       const int n = grid ? g.nD : g.nR, step = grid ? 1 : 5, p0 = grid ? -g.D : -g.R;
-      const int j = idx / n, i = idx - j * n;
+      const int j = (int)(((float)idx + 0.5f) * __frcp_rn((float)n)), i = idx - j * n;      // idx / n (idx < 1521, n <= 39: exact)
       const int x = p0 + i * step, y = p0 + j * step;
-      const int csc = mvL.cost_scale, ish = mvL.imv_shift;
-      const unsigned bits = expgolomb_bits(((x << csc) - mvL.pred_hor) >> ish) + expgolomb_bits(((y << csc) - mvL.pred_ver) >> ish);
+      // the bits of the position and lambda x bits: the tables the units use (bitsRX .. / costTab hold exactly these values) -- the record writers are one wave
+      // that every other wave waits for; two exp-Golomb loops, a double multiply and an integer division per record were ~1.5 k of a super-block's 48 k cycles
+      const unsigned bits = grid ? (unsigned)bitsDX[i] + bitsDY[j] : (unsigned)bitsRX[i] + bitsRY[j];
       vvcgpu_search_best r;
-      r.x = x; r.y = y; r.cost = cost; r.sad = cost - (unsigned long long)(mvL.lambda * (double)bits);
+      r.x = x; r.y = y; r.cost = cost; r.sad = cost - (unsigned long long)costTab[bits];
       out[bidx] = r;
     }
   }
-  __syncthreads();                                                               // keys / window are rewritten by the next super-block
+  // (no barrier here: the 42 record writers read keys[] above and are the threads that reset keys[] for the next super-block below, in program order; the window,
+  // the surfaces and the arrival counters that the other waves rewrite meanwhile are not read by the writers; every wave meets again at the barrier behind the window step)
   }
 }
 
