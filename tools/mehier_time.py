@@ -48,7 +48,7 @@ for k, s in enumerate((16, 32, 64)):
 print("per-size searches (6 launch groups): %.1f us" % timeit(per_size))
 print("hierarchical, raster + dense       : %.1f us" % timeit(hier))
 print("hierarchical, raster only          : %.1f us" % timeit(lambda: hier(0)))
-os.environ["VVCGPU_MH_DIAG"] = "1"
+os.environ["VVCGPU_MH_DIAG"] = "1"      # (phase stamps: printed by a library built with -DMH_DIAG, e.g. tools/ab_variants.sh build mehier.hip diag "-DMH_DIAG")
 hier()
 torch.cuda.synchronize()
 

@@ -296,8 +296,11 @@ __device__ __forceinline__ void mh_unit(const unsigned* orgPacked, const MhGeom&
 __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* orgPacked, const Pel* __restrict__ ref, int rs, MhGeom g, vvcgpu_mvcost mv,
                                                        vvcgpu_search_best* __restrict__ r16, vvcgpu_search_best* __restrict__ r32, vvcgpu_search_best* __restrict__ r64,
                                                        vvcgpu_search_best* __restrict__ d16, vvcgpu_search_best* __restrict__ d32, vvcgpu_search_best* __restrict__ d64,
-                                                       unsigned long long* __restrict__ diag)
+                                                       unsigned long long* __restrict__ diagArg)
 {
+#ifdef MH_DIAG
+  unsigned long long* const diag = diagArg;
+#endif
   extern __shared__ __align__(16) unsigned refL[];
   __shared__ unsigned long long keys[42];                                       // raster: 16 + 4 + 1, then the same for the +-D grid
   __shared__ unsigned costTab[R5C_COST_N];                                      // lambda * bits, truncated (host: below 2^29)
@@ -368,9 +371,16 @@ __global__ __launch_bounds__(1024) void me_hier_kernel(const unsigned* orgPacked
   const int sby = sbyRun, sbx = sbxRun;
   if (++sbxRun == g.nsbx) { sbxRun = 0; sbyRun++; }
   const int nsubx = min(4, g.n16x - 4 * sbx), nsuby = min(4, g.n16y - 4 * sby);
-  // VVCGPU_MH_DIAG: core-clock stamps of one workgroup's phases (start, window staged, every unit's end, units done, 64x64 pass done)
+  // -DMH_DIAG + VVCGPU_MH_DIAG: core-clock stamps of one workgroup's phases (start, window staged, every unit's end, units done).  A build without the switch
+  // holds no stamp code: the pointer, the two conditions and the item compares were scalar registers the super-block loop spilled (49 lane reloads per super-block)
+#ifdef MH_DIAG
   const bool stamp = diag && item == (g.total >> 1) + 3;                            // (the fourth super-block of a run: a slide)
   const int stampK = item == (g.total >> 2) ? 0 : item == (g.total >> 3) ? 1 : item == 3 * (g.total >> 2) ? 2 : item == 5 * (g.total >> 3) ? 3 : -1;   // four more workgroups: phase ends only
+#else
+  constexpr bool stamp = false;
+  constexpr int stampK = -1;
+  unsigned long long* const diag = nullptr;
+#endif
   if (diag && stampK >= 0 && tid == 0) diag[40 + 0 * 4 + stampK] = __builtin_amdgcn_s_memtime();
   if (stamp && tid == 0) diag[0] = __builtin_amdgcn_s_memtime();
   unsigned* surf = refL + (g.winBytes >> 2);                                     // [MH_MAXSLOTS][4]
@@ -540,7 +550,11 @@ int vvcgpu_me_hier_search(const vvc_pel* org, int org_stride, const vvc_pel* ref
   VVC_LAUNCH_CHECK();
   VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(me_hier_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)smem));
   unsigned long long* diag = nullptr;
-  const bool wantDiag = getenv("VVCGPU_MH_DIAG") != nullptr;                 // measurement aid (tools/mehier_time.py): phase stamps of one workgroup
+#ifdef MH_DIAG
+  const bool wantDiag = getenv("VVCGPU_MH_DIAG") != nullptr;                 // measurement aid (tools/mehier_time.py, a -DMH_DIAG build): phase stamps of one workgroup
+#else
+  const bool wantDiag = false;
+#endif
   if (wantDiag) { VVC_HIP(hipMalloc(&diag, 64 * sizeof(unsigned long long))); VVC_HIP(hipMemsetAsync(diag, 0, 64 * sizeof(unsigned long long), st)); }
   // VVCGPU_MH_WGS (read per call; tests / tuning): the number of persistent workgroups, so that small grids walk runs -- and slide their window -- too
   const char* wgsEnv = getenv("VVCGPU_MH_WGS");
