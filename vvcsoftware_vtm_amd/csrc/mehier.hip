@@ -64,7 +64,7 @@ struct MhGeom
 // and 6 us faster when the entry is timed alone in a loop (178 against 185 us) -- but 220 against 192 + 7.5 us inside the picture's workload, where the rows come
 // from HBM and the stores must be complete in front of every super-block's barrier; removed (docs/OPTIMISATION_LOG.md).
 // id = quarter q (id & 3) of record (block of the super-block, sampled row): four lanes per record, a wave's store is 1 KB of consecutive bytes.
-struct MhPackItem { unsigned d[8]; unsigned* dst; int q; };
+struct MhPackItem { unsigned e[5]; unsigned* dst; int q; };                     // the quarter's four dwords and the one behind them (wrapping: dword 8 = dword 0)
 __device__ __forceinline__ void mh_pack_load(const Pel* __restrict__ org, int os, int orgX0, int orgY0, int n16x, int hs, int subShift, int sbx, int sby, int pnx,
                                              int id, unsigned* __restrict__ packed, MhPackItem& it)
 {
@@ -73,16 +73,21 @@ __device__ __forceinline__ void mh_pack_load(const Pel* __restrict__ org, int os
   const int ty = blk / pnx, tx = blk - ty * pnx;
   const int by = 4 * sby + ty, bx = 4 * sbx + tx, b = by * n16x + bx;
   const Pel* o = org + (size_t)(orgY0 + 16 * by + (row << subShift)) * os + orgX0 + 16 * bx;
+  // a lane reads the half row of its quarter (16 bytes) and one dword more (the odd-shifted quarters pair every dword with its successor), not the whole
+  // row: half the load instructions of the first form
+  const int h0 = 4 * (q & 1), hx = (h0 + 4) & 7;
   if ((reinterpret_cast<uintptr_t>(o) & 3) == 0)
   {
     const unsigned* p = reinterpret_cast<const unsigned*>(o);
 #pragma unroll
-    for (int k = 0; k < 8; k++) it.d[k] = p[k];
+    for (int k = 0; k < 4; k++) it.e[k] = p[h0 + k];
+    it.e[4] = p[hx];
   }
   else
   {
 #pragma unroll
-    for (int k = 0; k < 8; k++) it.d[k] = (unsigned)(unsigned short)o[2 * k] | ((unsigned)(unsigned short)o[2 * k + 1] << 16);
+    for (int k = 0; k < 4; k++) it.e[k] = (unsigned)(unsigned short)o[2 * (h0 + k)] | ((unsigned)(unsigned short)o[2 * (h0 + k) + 1] << 16);
+    it.e[4] = (unsigned)(unsigned short)o[2 * hx] | ((unsigned)(unsigned short)o[2 * hx + 1] << 16);
   }
   it.q = q;
   it.dst = packed + ((size_t)b * hs + row) * 16 + 4 * q;
@@ -92,14 +97,7 @@ __device__ __forceinline__ void mh_pack_store(const MhPackItem& it)
   // quarter 0 / 1: even dwords 0..3 / 4..7; quarter 2 / 3: the odd-shifted dwords (samples (2k+1, 2k+2); k = 7: (15, 0))
   unsigned v[4];
 #pragma unroll
-  for (int j = 0; j < 4; j++)
-  {
-    const int k = 4 * (it.q & 1) + j;
-    unsigned lo = it.d[0], hi = it.d[1];
-#pragma unroll
-    for (int t = 1; t < 8; t++) { lo = k == t ? it.d[t] : lo; hi = k == t ? it.d[(t + 1) & 7] : hi; }
-    v[j] = ((it.q & 2) ? __builtin_amdgcn_alignbit(hi, lo, 16) : lo) ^ 0x80008000u;
-  }
+  for (int j = 0; j < 4; j++) v[j] = ((it.q & 2) ? __builtin_amdgcn_alignbit(it.e[j + 1], it.e[j], 16) : it.e[j]) ^ 0x80008000u;
   *reinterpret_cast<uint4*>(it.dst) = make_uint4(v[0], v[1], v[2], v[3]);
 }
 __global__ __launch_bounds__(256) void mh_pack_org_kernel(const Pel* __restrict__ org, int os, int orgX0, int orgY0, int n16x, int nblocks, int hs, int subShift, unsigned* __restrict__ packed)
