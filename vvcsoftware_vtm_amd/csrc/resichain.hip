@@ -27,6 +27,15 @@
 #include <mutex>
 
 namespace {
+// Pointer arguments of functions that are NOT inlined arrive as generic pointers: every access through them is a FLAT instruction (both wait counters, no
+// immediate offsets, LDS through the aperture).  This assumption lets the compiler infer the LDS address space again inside the callee (the pattern for global pointers,
+// !is_shared & !is_private, does not survive the optimiser's De Morgan rewrite; global data through flat loads costs little).
+#if defined(__HIP_DEVICE_COMPILE__)
+#define RC_IS_LDS(p) __builtin_assume(__builtin_amdgcn_is_shared((const __attribute__((address_space(0))) void*)(p)))
+#else
+#define RC_IS_LDS(p) ((void)0)
+#endif
+
 
 typedef vvcgpu_resi_chain_desc RcDesc;
 
@@ -1630,6 +1639,7 @@ __device__ __noinline__ void rc_small_group(const RcDesc* __restrict__ descs, co
                                                const RcSmallTab& tabs, int* tmpL, int lane)
 {
   constexpr int mode = MODE;
+  RC_IS_LDS(tmpL);
 
   constexpr int G = 64 / S, LS = S == 4 ? 2 : 3, TO = S == 4 ? 0 : 16;
   typedef short pelS __attribute__((ext_vector_type(S)));
