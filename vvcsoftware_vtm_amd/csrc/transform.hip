@@ -1405,6 +1405,11 @@ __global__ __launch_bounds__(256) void quant_large_kernel(const TCoeff* __restri
 // per-state sub-block memory of CommonCtx (:828-858) lives in the workspace as well and is touched only at sub-block ends.
 __device__ unsigned short d_dqInv[15876];           // raster position -> scan id, same layout as d_scan
 __device__ short d_dqMaxDist[15876];                // NbInfoOut::maxDist (relative) per scan id  (:205-228)
+// What a position record holds that depends on the TU's SHAPE only (built on the host with the scan tables), per scan id si, for the
+// position AFTER si in the walk (scan id max(si - 1, 0)): the byte selectors of its five template neighbours inside the sub-block
+// (DqRec below) and the word (neighbour positions 5 x 4 bits | sigOff << 20 | gtxOff << 24) for luma (.x) and chroma (.y).
+__device__ uint4 d_dqPosSel[15876];
+__device__ uint2 d_dqPosMisc[15876];
 
 // Small per-lane tables are ext-vector VALUES, not arrays: element selects then stay register selects (with arrays LLVM rewrites a
 // select of loads into a load through a selected address, which pins the whole state struct in scratch memory).
@@ -1529,6 +1534,8 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   const unsigned short* scan = d_scan + tabOff;
   const unsigned short* inv = d_dqInv + tabOff;
   const short* maxDist = d_dqMaxDist + tabOff;
+  const uint4* posSel = d_dqPosSel + tabOff;
+  const uint2* posMisc = d_dqPosMisc + tabOff;
   unsigned* dec = wsDec + (size_t)d.coeff_off * 4;                         // [scanIdx][4]
   unsigned char* ctxMem = wsCtx + (size_t)d.coeff_off * 8;                  // 8 x levels[N]: CommonCtx's per-state sub-block memory (:828-858)
 
@@ -1564,7 +1571,16 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   if (live)
   {
     for (int i = k; i < N; i += 4) level[i] = 0;
-    for (int i = N - 1 - k; i >= 0; i -= 4) if (abs(coef[scan[i]]) > thresLast) { first = i; break; }
+    // (sixteen positions a round per quad, the loads of a round independent of each other: the search of a 64x64 TU with a zeroed-out
+    // high-frequency region walks ~2000 positions whose coefficients come from memory)
+    for (int i = N - 1 - k; i >= 0 && first < 0; i -= 16)
+    {
+      int a[4];
+#pragma unroll
+      for (int u = 0; u < 4; u++) a[u] = abs(coef[scan[max(i - 4 * u, 0)]]);
+#pragma unroll
+      for (int u = 3; u >= 0; u--) if (i - 4 * u >= 0 && a[u] > thresLast) first = i - 4 * u;
+    }
   }
   first = max(first, __shfl_xor(first, 1));
   first = max(first, __shfl_xor(first, 2));
@@ -1606,7 +1622,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   for (int i = 0; i < 8; i++) Fcur[i] = 0;
   long long finalCost = 0;
 
-  auto fillRec = [&](int si, int p, int coefAbs)
+  auto fillRec = [&](int si, int p, int coefAbs, const uint4 sel, const unsigned misc)
   {
     const int x = p & (w - 1), y = p >> lw;
     // Quantizer::preQuantCoeff :786-808
@@ -1627,31 +1643,8 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
       }
     }
     const int lastOffset = rt->last_x[x] + rt->last_y[y];
-    // the position after it (scan order runs down): template neighbours inside the sub-block, context offsets
-    const int sn = max(si - 1, 0), p2 = scan[sn], x2 = p2 & (w - 1), y2 = p2 >> lw, beg = sn & ~15;
-    const int cx[5] = { x2 + 1, x2 + 2, x2 + 1, x2, x2 }, cy[5] = { y2, y2, y2 + 1, y2 + 1, y2 + 2 };
-    unsigned misc = 0;
-#pragma unroll
-    for (int t = 0; t < 5; t++)
-    {
-      const bool in = cx[t] < w && cy[t] < h;
-      const int r = in ? (int)inv[cy[t] * w + cx[t]] - beg : 0;
-      misc |= (unsigned)((r > 0 && r < 16) ? r : 0) << (4 * t);
-    }
-    const int diag = x2 + y2;
-    const int sigOff = luma ? (diag < 2 ? 12 : diag < 5 ? 6 : 0) : (diag < 2 ? 6 : 0);
-    const int gtxOff = luma ? (diag < 1 ? 16 : diag < 3 ? 11 : diag < 10 ? 6 : 1) : (diag < 1 ? 6 : 1);
-    unsigned selLo[2] = { 0x0C0C0C0Cu, 0x0C0C0C0Cu }, selHi[2] = { 0x0C0C0C0Cu, 0x0C0C0C0Cu };
-#pragma unroll
-    for (int t = 0; t < 5; t++)
-    {
-      const unsigned rel = (misc >> (4 * t)) & 15u, sh = (unsigned)(t & 3) * 8u, m = 0xFFu << sh;
-      if (rel != 0u && rel < 8u) selLo[t >> 2] = (selLo[t >> 2] & ~m) | (rel << sh);
-      if (rel >= 8u) selHi[t >> 2] = (selHi[t >> 2] & ~m) | ((rel - 8u) << sh);
-    }
-    misc |= (unsigned)sigOff << 20 | (unsigned)gtxOff << 24;
     DqRec* r = recTu + (si & (DQ_REC_N - 1));
-    r->selLoA = selLo[0]; r->selHiA = selHi[0]; r->selLoB = selLo[1]; r->selHiB = selHi[1];
+    r->selLoA = sel.x; r->selHiA = sel.y; r->selLoB = sel.z; r->selHiB = sel.w;       // the shape-only part: straight from the table
 #pragma unroll
     for (int t = 0; t < 4; t++) r->dist[t] = pqDist[t];
     *reinterpret_cast<uint2*>(r->ab) = make_uint2((unsigned)pqAbs[0] | (unsigned)pqAbs[1] << 16, (unsigned)pqAbs[2] | (unsigned)pqAbs[3] << 16);
@@ -1675,6 +1668,17 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   auto abOf = [](uint2 ab, int t) { return (int)(((t < 2 ? ab.x : ab.y) >> ((t & 1) * 16)) & 0xFFFFu); };
   DqRecRegs R, Rn;
   int pfPos[2] = { 0, 0 }, pfAbs[2] = { 0, 0 };
+  uint4 pfSel[2] = { make_uint4(0, 0, 0, 0), make_uint4(0, 0, 0, 0) }; unsigned pfMisc[2] = { 0, 0 };
+  auto prefetch = [&](int beg)
+  {
+#pragma unroll
+    for (int j = 0; j < 2; j++)
+    {
+      const int si = beg + k + 4 * j;
+      pfPos[j] = scan[si]; pfAbs[j] = abs(coef[pfPos[j]]);
+      pfSel[j] = posSel[si]; const uint2 m = posMisc[si]; pfMisc[j] = luma ? m.x : m.y;
+    }
+  };
   Rn.dl = Rn.dh = Rn.start = 0; Rn.ab = make_uint2(0, 0); Rn.misc = 0; Rn.sel = make_uint4(0, 0, 0, 0);
 
   for (int scanIdx = maxFirst; scanIdx >= 0; scanIdx--)
@@ -1700,17 +1704,14 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     {
       const int beg = sIdx & ~(DQ_REC_N - 1);
       static_assert(DQ_REC_N == 8, "two records per lane");
-      if (scanIdx == maxFirst)
+      if (scanIdx == maxFirst) prefetch(beg);
 #pragma unroll
-        for (int j = 0; j < 2; j++) { pfPos[j] = scan[beg + k + 4 * j]; pfAbs[j] = abs(coef[pfPos[j]]); }
-#pragma unroll
-      for (int j = 0; j < 2; j++) fillRec(beg + k + 4 * j, pfPos[j], pfAbs[j]);
+      for (int j = 0; j < 2; j++) fillRec(beg + k + 4 * j, pfPos[j], pfAbs[j], pfSel[j], pfMisc[j]);
       __builtin_amdgcn_fence(__ATOMIC_ACQ_REL, "wavefront"); __builtin_amdgcn_wave_barrier();
       R = loadRec(recPos);
-      // the coefficients of the NEXT group are the one stream of a TU that comes from HBM: requested here, used eight steps later
-      const int nb = max(beg - DQ_REC_N, 0);
-#pragma unroll
-      for (int j = 0; j < 2; j++) { pfPos[j] = scan[nb + k + 4 * j]; pfAbs[j] = abs(coef[pfPos[j]]); }
+      // the coefficients of the NEXT group are the one stream of a TU that comes from HBM: requested here (with the shape part of its
+      // records), used eight steps later
+      prefetch(max(beg - DQ_REC_N, 0));
     }
     else R = Rn;
     if (recPos != 0) Rn = loadRec(recPos - 1);                            // the next step's record is in flight during this one
@@ -1863,12 +1864,17 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
             const unsigned char* hist = ctxMem + (size_t)(curCtx * 4 + max(prevRef, 0)) * N;
             // (the sub-block that just ended is not in it yet: its levels are still in C.lev)
             const uint4 own = make_uint4(C.lev[0], C.lev[1], C.lev[2], C.lev[3]), zero4 = make_uint4(0, 0, 0, 0);
+            // (loads from addresses that are always valid, the choice made on the VALUES: a choice between a loaded value and `own` / zero
+            // becomes a load through a selected address, i.e. `own` goes to scratch memory and the three loads wait for each other)
             auto sbbLevels = [&](bool exists, int rasterPos)
             {
-              if (!exists) return zero4;
-              const int base = inv[rasterPos] & ~15;
-              if (base == sIdx) return own;
-              return prevRef >= 0 ? *reinterpret_cast<const uint4*>(hist + base) : zero4;
+              const int base = inv[exists ? rasterPos : 0] & ~15;
+              const uint4 hv = *reinterpret_cast<const uint4*>(hist + base);
+              const bool fromHist = exists && prevRef >= 0 && base != sIdx, fromOwn = exists && base == sIdx;
+              uint4 r;
+              r.x = fromHist ? hv.x : fromOwn ? own.x : 0u; r.y = fromHist ? hv.y : fromOwn ? own.y : 0u;
+              r.z = fromHist ? hv.z : fromOwn ? own.z : 0u; r.w = fromHist ? hv.w : fromOwn ? own.w : 0u;
+              return r;
             };
             const uint4 LR = sbbLevels(hasR, by * w + bx + 4), LB = sbbLevels(hasB, (by + 4) * w + bx), LD = sbbLevels(hasR && hasB, (by + 4) * w + bx + 4);
             auto pick = [](const uint4& v, int j) { const unsigned q = j < 4 ? v.x : j < 8 ? v.y : j < 12 ? v.z : v.w; return (q >> ((j & 3) * 8)) & 0xFFu; };
@@ -2373,6 +2379,35 @@ static int ensure_tables()
           maxd[o0 + i] = (int16_t)(run - i);
         }
       }
+    // the shape-only part of the trellis' position records (depquant_kernel, fillRec)
+    static uint4 psel[15876];
+    static uint2 pmisc[15876];
+    for (int a = 0; a < 6; a++)
+      for (int b = 0; b < 6; b++)
+      {
+        const int W = 2 << a, H = 2 << b, N = W * H, o0 = off[a * 6 + b];
+        for (int si = 0; si < N; si++)
+        {
+          const int sn = si > 0 ? si - 1 : 0, p2 = scan[o0 + sn], x2 = p2 % W, y2 = p2 / W, beg = sn & ~15;
+          const int cx[5] = { x2 + 1, x2 + 2, x2 + 1, x2, x2 }, cy[5] = { y2, y2, y2 + 1, y2 + 1, y2 + 2 };
+          unsigned nb = 0, selLo[2] = { 0x0C0C0C0Cu, 0x0C0C0C0Cu }, selHi[2] = { 0x0C0C0C0Cu, 0x0C0C0C0Cu };
+          for (int t = 0; t < 5; t++)
+          {
+            const int r = (cx[t] < W && cy[t] < H) ? (int)invs[o0 + cy[t] * W + cx[t]] - beg : 0;
+            const unsigned rel = (r > 0 && r < 16) ? (unsigned)r : 0u, sh = (unsigned)(t & 3) * 8u, m = 0xFFu << sh;
+            nb |= rel << (4 * t);
+            if (rel != 0u && rel < 8u) selLo[t >> 2] = (selLo[t >> 2] & ~m) | (rel << sh);
+            if (rel >= 8u) selHi[t >> 2] = (selHi[t >> 2] & ~m) | ((rel - 8u) << sh);
+          }
+          const int diag = x2 + y2;
+          const unsigned sigL = diag < 2 ? 12 : diag < 5 ? 6 : 0, sigC = diag < 2 ? 6 : 0;
+          const unsigned gtxL = diag < 1 ? 16 : diag < 3 ? 11 : diag < 10 ? 6 : 1, gtxC = diag < 1 ? 6 : 1;
+          psel[o0 + si] = make_uint4(selLo[0], selHi[0], selLo[1], selHi[1]);
+          pmisc[o0 + si] = make_uint2(nb | sigL << 20 | gtxL << 24, nb | sigC << 20 | gtxC << 24);
+        }
+      }
+    VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_dqPosSel), psel, sizeof(psel)));
+    VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_dqPosMisc), pmisc, sizeof(pmisc)));
     VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_dqInv), invs, sizeof(invs)));
     VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_dqMaxDist), maxd, sizeof(maxd)));
     g_tablesUploaded[dev] = true;
