@@ -1404,7 +1404,6 @@ __global__ __launch_bounds__(256) void quant_large_kernel(const TCoeff* __restri
 // looked up in the caller's rate tables.  Decisions (absLevel << 4 | prevId + 2) go to the workspace for the back-trace; the
 // per-state sub-block memory of CommonCtx (:828-858) lives in the workspace as well and is touched only at sub-block ends.
 __device__ unsigned short d_dqInv[15876];           // raster position -> scan id, same layout as d_scan
-__device__ short d_dqMaxDist[15876];                // NbInfoOut::maxDist (relative) per scan id  (:205-228)
 // What a position record holds that depends on the TU's SHAPE only (built on the host with the scan tables), per scan id si, for the
 // position AFTER si in the walk (scan id max(si - 1, 0)): the byte selectors of its five template neighbours inside the sub-block
 // (DqRec below) and the word (neighbour positions 5 x 4 bits | sigOff << 20 | gtxOff << 24) for luma (.x) and chroma (.y).
@@ -1533,11 +1532,12 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   const int tabOff = d_scanOff[(lw - 1) * 6 + (lh - 1)];
   const unsigned short* scan = d_scan + tabOff;
   const unsigned short* inv = d_dqInv + tabOff;
-  const short* maxDist = d_dqMaxDist + tabOff;
   const uint4* posSel = d_dqPosSel + tabOff;
   const uint2* posMisc = d_dqPosMisc + tabOff;
   unsigned* dec = wsDec + (size_t)d.coeff_off * 4;                         // [scanIdx][4]
-  unsigned char* ctxMem = wsCtx + (size_t)d.coeff_off * 8;                  // 8 x levels[N]: CommonCtx's per-state sub-block memory (:828-858)
+  // CommonCtx's per-state sub-block memory (:828-858) as a pool of 16-byte blocks [sub-block in scan order][context slot]: the levels of a
+  // sub-block as the state that took slot k at its end left them (the first 4 N of the 8 N bytes a TU has in the workspace)
+  unsigned char* ctxMem = wsCtx + (size_t)d.coeff_off * 8;
 
   // Quantizer::initQuantBlock :647-706 (the same IEEE double arithmetic)
   int qShift, maxQIdx, thresLast, distShift;
@@ -1616,7 +1616,13 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     dq_copy(S, P);
   }
   DqState P0; dq_copy(P0, P);
-  int curCtx = 0;                                                         // which half of the sub-block memory is "current"
+  // The level history of a state (CommonCtx::update copies `setCpSize` bytes of it from the parent state at every sub-block end, :1104-1130)
+  // is never copied here: a block of the pool is written once, and a context slot carries the ANCESTRY of its path -- which slot its
+  // ancestor took at the end of each of the last 32 sub-blocks, two bits each, youngest in the low bits, and how many of them exist
+  // (a path that starts inside a sub-block has none: the reference zeroes its history).  The farthest block a template reads lies 30
+  // sub-blocks back (64x64).  Like the flags below, the pair lives in the lane whose number is the slot's.  The copy was 30 x 64 lines
+  // of 16 bytes per wavefront and sub-block end for 64x64 TUs, a twentieth of their walk.
+  unsigned long long ancCur = 0; int ancLen = 0;
   dq_u8 Fcur;                                                             // coded-sub-block flags (bit per sub-block) of context slot k, current half
 #pragma unroll
   for (int i = 0; i < 8; i++) Fcur[i] = 0;
@@ -1695,7 +1701,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     // initial state at its first tested position (instead of guarding every state copy of every step)
     if (scanIdx == first)
     {
-      dq_copy(P, P0); dq_copy(S, P0); curCtx = 0;
+      dq_copy(P, P0); dq_copy(S, P0); ancCur = 0; ancLen = 0;
 #pragma unroll
       for (int i = 0; i < 8; i++) Fcur[i] = 0;
     }
@@ -1774,11 +1780,15 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
       // sub-block flags of the inherited context slot: a register pull from the lane that owns the slot (slot id = lane in the quad);
       // done by the whole quad (the branch below diverges inside a quad)
       dq_u8 nf = { 0, 0, 0, 0, 0, 0, 0, 0 };
+      unsigned long long nAnc = 0; int nLen = 0;
       if (eosbb)
       {
         const int pr = dPrev >= 0 ? sRef : -1;
 #pragma unroll
         for (int i = 0; i < 8; i++) { const unsigned v = (unsigned)__shfl((int)Fcur[i], qbase + max(pr, 0)); nf[i] = pr >= 0 ? v : 0u; }
+        const unsigned long long pa = (unsigned long long)dq_shfl64((long long)ancCur, qbase + max(pr, 0));
+        const int pl = __shfl(ancLen, qbase + max(pr, 0));
+        nAnc = pr >= 0 ? (pa << 2) | (unsigned long long)pr : 0ull; nLen = pr >= 0 ? min(pl + 1, 32) : 0;
       }
       C.rdCost = dCost;
       if (dPrev > -2)
@@ -1820,21 +1830,8 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
 #pragma unroll
             for (int i = 0; i < 4; i++) C.lev[i] = 0; }
           dq_set_byte(C.lev, insidePos, (unsigned)min(255, dAbs));
-          const int prevRef = dPrev >= 0 ? sRef : -1;
-          const int newCur = curCtx ^ 1;                                    // CommonCtx::swap before the four updates
-          unsigned char* lev = ctxMem + (size_t)(newCur * 4 + k) * N;
-          const int setCp = maxDist[sIdx - 1];
-          if (act)
-          {
-            if (prevRef >= 0)
-            {
-              const unsigned char* pl = ctxMem + (size_t)(curCtx * 4 + prevRef) * N;
-              for (int i = 0; i < setCp; i += 16) *reinterpret_cast<uint4*>(lev + sIdx + i) = *reinterpret_cast<const uint4*>(pl + sIdx + i);
-            }
-            else
-              for (int i = 0; i < setCp; i += 16) *reinterpret_cast<uint4*>(lev + sIdx + i) = make_uint4(0, 0, 0, 0);
-            *reinterpret_cast<uint4*>(lev + sIdx) = make_uint4(C.lev[0], C.lev[1], C.lev[2], C.lev[3]);     // sIdx is a multiple of 16
-          }
+          const int sbbId = sIdx >> 4;
+          if (act) *reinterpret_cast<uint4*>(ctxMem + (size_t)(sbbId * 4 + k) * 16) = make_uint4(C.lev[0], C.lev[1], C.lev[2], C.lev[3]);
           const int pos = scan[sIdx], px = pos & (w - 1), py = pos >> lw, nxtPos = scan[nxt], nx = nxtPos & (w - 1), ny = nxtPos >> lw;
           {
             const int sbbPos = (py >> 2) * widthInSbb + (px >> 2);
@@ -1849,6 +1846,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
           const int sigNSbb = ((right && ((fr >> (right & 31)) & 1u)) || (below && ((fb >> (below & 31)) & 1u))) ? 1 : 0;
 #pragma unroll
           for (int i = 0; i < 8; i++) Fcur[i] = nf[i];
+          ancCur = nAnc; ancLen = nLen;
           C.numSigSbb = 0; C.refSbbCtxId = k;
           C.sbb0 = rt->sig_sbb[sigNSbb][0]; C.sbb1 = rt->sig_sbb[sigNSbb][1];
           // template seeds of the sixteen positions of the next sub-block from the levels outside it (:1131-1160).  Every template
@@ -1860,17 +1858,16 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
           {
             const int bx = nsx * 4, by = nsy * 4;
             const bool hasR = nsx + 1 < widthInSbb, hasB = nsy + 1 < heightInSbb;
-            // read from the history this state inherits (what the copy above writes into its own slot: the loads need not wait for it)
-            const unsigned char* hist = ctxMem + (size_t)(curCtx * 4 + max(prevRef, 0)) * N;
-            // (the sub-block that just ended is not in it yet: its levels are still in C.lev)
+            // read from the blocks of this state's ancestors (the sub-block that just ended: its levels are still in C.lev)
             const uint4 own = make_uint4(C.lev[0], C.lev[1], C.lev[2], C.lev[3]), zero4 = make_uint4(0, 0, 0, 0);
             // (loads from addresses that are always valid, the choice made on the VALUES: a choice between a loaded value and `own` / zero
             // becomes a load through a selected address, i.e. `own` goes to scratch memory and the three loads wait for each other)
             auto sbbLevels = [&](bool exists, int rasterPos)
             {
-              const int base = inv[exists ? rasterPos : 0] & ~15;
-              const uint4 hv = *reinterpret_cast<const uint4*>(hist + base);
-              const bool fromHist = exists && prevRef >= 0 && base != sIdx, fromOwn = exists && base == sIdx;
+              const int j = inv[exists ? rasterPos : 0] >> 4, back = j - sbbId - 1;      // back = 0: the parent's sub-block
+              const unsigned slot = (unsigned)(nAnc >> (2 * min(max(back, 0), 31))) & 3u;
+              const uint4 hv = *reinterpret_cast<const uint4*>(ctxMem + (size_t)(j * 4 + (int)slot) * 16);
+              const bool fromHist = exists && back >= 0 && back < nLen, fromOwn = exists && j == sbbId;
               uint4 r;
               r.x = fromHist ? hv.x : fromOwn ? own.x : 0u; r.y = fromHist ? hv.y : fromOwn ? own.y : 0u;
               r.z = fromHist ? hv.z : fromOwn ? own.z : 0u; r.w = fromHist ? hv.w : fromOwn ? own.w : 0u;
@@ -1923,7 +1920,6 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
       }
       if (eosbb) { __threadfence_block(); }
     }
-    if (sIdx > 0 && eosbb) curCtx ^= 1;
     if (socsbb) dq_copy(S, P);                                             // swap( m_prevStates, m_skipStates ) :1314-1317
     dq_copy(P, C);
   }
@@ -2355,29 +2351,13 @@ static int ensure_tables()
       for (int b = 0; b < 6; b++) { off[a * 6 + b] = o; host_scan_order(2 << a, 2 << b, scan + o); o += (2 << a) * (2 << b); }
     VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_scan), scan, sizeof(scan)));
     VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_scanOff), off, sizeof(off)));
-    // dependent quantisation: raster -> scan id, and NbInfoOut::maxDist (DepQuant.cpp:205-228: running maximum over the scan of the
-    // farthest template neighbour outside the sub-block, relative to the scan id)
+    // dependent quantisation: raster -> scan id
     static uint16_t invs[15876];
-    static int16_t maxd[15876];
     for (int a = 0; a < 6; a++)
       for (int b = 0; b < 6; b++)
       {
-        const int W = 2 << a, H = 2 << b, N = W * H, o0 = off[a * 6 + b];
-        const int grp = ((W & 3) || (H & 3)) ? 4 : 16;
+        const int N = (2 << a) * (2 << b), o0 = off[a * 6 + b];
         for (int i = 0; i < N; i++) invs[o0 + scan[o0 + i]] = (uint16_t)i;
-        int run = 0;
-        for (int i = 0; i < N; i++)
-        {
-          const int r = scan[o0 + i], x = r % W, y = r / W, beg = i - (i & (grp - 1));
-          const int cx[5] = { x + 1, x + 2, x + 1, x, x }, cy[5] = { y, y, y + 1, y + 1, y + 2 };
-          for (int t = 0; t < 5; t++)
-            if (cx[t] < W && cy[t] < H)
-            {
-              const int id = invs[o0 + cy[t] * W + cx[t]];
-              if (id - beg >= grp && id > run) run = id;
-            }
-          maxd[o0 + i] = (int16_t)(run - i);
-        }
       }
     // the shape-only part of the trellis' position records (depquant_kernel, fillRec)
     static uint4 psel[15876];
@@ -2409,7 +2389,6 @@ static int ensure_tables()
     VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_dqPosSel), psel, sizeof(psel)));
     VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_dqPosMisc), pmisc, sizeof(pmisc)));
     VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_dqInv), invs, sizeof(invs)));
-    VVC_HIP(hipMemcpyToSymbol(HIP_SYMBOL(d_dqMaxDist), maxd, sizeof(maxd)));
     g_tablesUploaded[dev] = true;
   }
   return VVCGPU_OK;
