@@ -1479,6 +1479,9 @@ __device__ __forceinline__ long long dq_quad64(long long v)
   return (long long)(((unsigned long long)hi << 32) | lo);
 }
 
+template <int CTRL>
+__device__ __forceinline__ unsigned dq_quad32(unsigned v) { return (unsigned)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xF, 0xF, true); }
+
 // the diagonal scan inside a 4x4 sub-block: scan index of in-block position y * 4 + x, and its inverse (4 bits each)
 constexpr unsigned long long dq_pack_scan4(bool inverse)
 {
@@ -1924,26 +1927,46 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     dq_copy(P, C);
   }
 
-  // ---- best final state and back-trace :1368-1390.  Lane 0 of the quad walks; decisions 4..7 are implicit: at a sub-block end they
-  // are a copy of decisions 0..3 (:1269), elsewhere { level 0, same skip id } (startDec :1218)
+  // ---- best final state and back-trace :1368-1390.  Decisions 4..7 are implicit: at a sub-block end they are a copy of decisions
+  // 0..3 (:1269), elsewhere { level 0, same skip id } (startDec :1218).  The chain through the decisions is serial, the loads are not: the
+  // quad takes four scan positions a round, lane j loads the four decisions of position base + j (16 bytes), its raster position and its
+  // coefficient -- one round ahead --, the chain then runs over quad broadcasts in registers (every lane alike) and lane j writes the
+  // level of its position.  (With lane 0 alone every position was a dependent load from memory: ~0.5 ms of a 64x64 TU's 3.1 ms.)
   long long c1 = dq_shfl64(finalCost, qbase + 1), c2 = dq_shfl64(finalCost, qbase + 2), c3 = dq_shfl64(finalCost, qbase + 3);
-  if (!run || k != 0) return;
+  const long long c0 = dq_shfl64(finalCost, qbase);
+  if (!run) return;
   int prevId = -2; long long minCost = 0;
-  if (finalCost < minCost) { prevId = 0; minCost = finalCost; }
+  if (c0 < minCost) { prevId = 0; minCost = c0; }
   if (c1 < minCost) { prevId = 1; minCost = c1; }
   if (c2 < minCost) { prevId = 2; minCost = c2; }
   if (c3 < minCost) { prevId = 3; minCost = c3; }
   unsigned absSum = 0;
-  for (int scanIdx = 0; prevId >= 0; scanIdx++)
+  __threadfence_block();                                                   // the decisions were stored by the four lanes
+  const uint4* dec4 = reinterpret_cast<const uint4*>(dec);
+  uint4 dv = dec4[k]; int pos = scan[k], cf = coef[pos];                   // (N >= 16)
+  for (int base = 0; prevId >= 0; base += 4)
   {
-    int al, nextPrev;
-    if (prevId >= 4 && (scanIdx & 15) != 0) { al = 0; nextPrev = prevId; }
-    else { const unsigned v = dec[(size_t)scanIdx * 4 + (prevId & 3)]; al = (int)(v >> 4); nextPrev = (int)(v & 15) - 2; }
-    const int pos = scan[scanIdx];
-    level[pos] = coef[pos] < 0 ? -al : al;
-    absSum += (unsigned)al;
-    prevId = nextPrev;
+    const int ni = min(base + 4 + k, N - 1);
+    const uint4 dn = dec4[ni]; const int posn = scan[ni], cfn = coef[posn];
+    int myAl = 0; bool mine = false;
+    auto link = [&](int j, unsigned vx, unsigned vy, unsigned vz, unsigned vw)
+    {
+      const bool on = prevId >= 0, keep = prevId >= 4 && ((base + j) & 15) != 0;
+      const int s = prevId & 3;
+      const unsigned v = s == 0 ? vx : s == 1 ? vy : s == 2 ? vz : vw;
+      const int al = keep ? 0 : (int)(v >> 4), nextPrev = keep ? prevId : (int)(v & 15) - 2;
+      if (on && j == k) { myAl = al; mine = true; }
+      if (on) { absSum += (unsigned)al; prevId = nextPrev; }
+    };
+    // quad_perm [j, j, j, j]: lane j of the quad to all four
+    link(0, dq_quad32<0x00>(dv.x), dq_quad32<0x00>(dv.y), dq_quad32<0x00>(dv.z), dq_quad32<0x00>(dv.w));
+    link(1, dq_quad32<0x55>(dv.x), dq_quad32<0x55>(dv.y), dq_quad32<0x55>(dv.z), dq_quad32<0x55>(dv.w));
+    link(2, dq_quad32<0xAA>(dv.x), dq_quad32<0xAA>(dv.y), dq_quad32<0xAA>(dv.z), dq_quad32<0xAA>(dv.w));
+    link(3, dq_quad32<0xFF>(dv.x), dq_quad32<0xFF>(dv.y), dq_quad32<0xFF>(dv.z), dq_quad32<0xFF>(dv.w));
+    if (mine) level[pos] = cf < 0 ? -myAl : myAl;
+    dv = dn; pos = posn; cf = cfn;
   }
+  if (k != 0) return;
   absSumOut[ti] = absSum;
   };
 
