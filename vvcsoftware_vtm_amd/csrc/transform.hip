@@ -1929,7 +1929,7 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
 
   // ---- best final state and back-trace :1368-1390.  Decisions 4..7 are implicit: at a sub-block end they are a copy of decisions
   // 0..3 (:1269), elsewhere { level 0, same skip id } (startDec :1218).  The chain through the decisions is serial, the loads are not: the
-  // quad takes four scan positions a round, lane j loads the four decisions of position base + j (16 bytes), its raster position and its
+  // quad takes eight scan positions a round, lane j loads the four decisions of positions base + j and base + 4 + j (16 bytes each), its raster position and its
   // coefficient -- one round ahead --, the chain then runs over quad broadcasts in registers (every lane alike) and lane j writes the
   // level of its position.  (With lane 0 alone every position was a dependent load from memory: ~0.5 ms of a 64x64 TU's 3.1 ms.)
   long long c1 = dq_shfl64(finalCost, qbase + 1), c2 = dq_shfl64(finalCost, qbase + 2), c3 = dq_shfl64(finalCost, qbase + 3);
@@ -1943,28 +1943,37 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   unsigned absSum = 0;
   __threadfence_block();                                                   // the decisions were stored by the four lanes
   const uint4* dec4 = reinterpret_cast<const uint4*>(dec);
-  uint4 dv = dec4[k]; int pos = scan[k], cf = coef[pos];                   // (N >= 16)
-  for (int base = 0; prevId >= 0; base += 4)
+  // (eight positions a round, two per lane: the chain over eight positions takes about as long as the loads of the next eight)
+  uint4 dv[2]; int pos[2], cf[2];
+#pragma unroll
+  for (int u = 0; u < 2; u++) { const int i = min(4 * u + k, N - 1); dv[u] = dec4[i]; pos[u] = scan[i]; cf[u] = coef[pos[u]]; }
+  for (int base = 0; prevId >= 0; base += 8)
   {
-    const int ni = min(base + 4 + k, N - 1);
-    const uint4 dn = dec4[ni]; const int posn = scan[ni], cfn = coef[posn];
-    int myAl = 0; bool mine = false;
-    auto link = [&](int j, unsigned vx, unsigned vy, unsigned vz, unsigned vw)
+    uint4 dn[2]; int posn[2], cfn[2];
+#pragma unroll
+    for (int u = 0; u < 2; u++) { const int i = min(base + 8 + 4 * u + k, N - 1); dn[u] = dec4[i]; posn[u] = scan[i]; cfn[u] = coef[posn[u]]; }
+#pragma unroll
+    for (int u = 0; u < 2; u++)
     {
-      const bool on = prevId >= 0, keep = prevId >= 4 && ((base + j) & 15) != 0;
-      const int s = prevId & 3;
-      const unsigned v = s == 0 ? vx : s == 1 ? vy : s == 2 ? vz : vw;
-      const int al = keep ? 0 : (int)(v >> 4), nextPrev = keep ? prevId : (int)(v & 15) - 2;
-      if (on && j == k) { myAl = al; mine = true; }
-      if (on) { absSum += (unsigned)al; prevId = nextPrev; }
-    };
-    // quad_perm [j, j, j, j]: lane j of the quad to all four
-    link(0, dq_quad32<0x00>(dv.x), dq_quad32<0x00>(dv.y), dq_quad32<0x00>(dv.z), dq_quad32<0x00>(dv.w));
-    link(1, dq_quad32<0x55>(dv.x), dq_quad32<0x55>(dv.y), dq_quad32<0x55>(dv.z), dq_quad32<0x55>(dv.w));
-    link(2, dq_quad32<0xAA>(dv.x), dq_quad32<0xAA>(dv.y), dq_quad32<0xAA>(dv.z), dq_quad32<0xAA>(dv.w));
-    link(3, dq_quad32<0xFF>(dv.x), dq_quad32<0xFF>(dv.y), dq_quad32<0xFF>(dv.z), dq_quad32<0xFF>(dv.w));
-    if (mine) level[pos] = cf < 0 ? -myAl : myAl;
-    dv = dn; pos = posn; cf = cfn;
+      int myAl = 0; bool mine = false;
+      auto link = [&](int j, unsigned vx, unsigned vy, unsigned vz, unsigned vw)
+      {
+        const bool on = prevId >= 0, keep = prevId >= 4 && ((base + 4 * u + j) & 15) != 0;
+        const int s = prevId & 3;
+        const unsigned v = s == 0 ? vx : s == 1 ? vy : s == 2 ? vz : vw;
+        const int al = keep ? 0 : (int)(v >> 4), nextPrev = keep ? prevId : (int)(v & 15) - 2;
+        if (on && j == k) { myAl = al; mine = true; }
+        if (on) { absSum += (unsigned)al; prevId = nextPrev; }
+      };
+      // quad_perm [j, j, j, j]: lane j of the quad to all four
+      link(0, dq_quad32<0x00>(dv[u].x), dq_quad32<0x00>(dv[u].y), dq_quad32<0x00>(dv[u].z), dq_quad32<0x00>(dv[u].w));
+      link(1, dq_quad32<0x55>(dv[u].x), dq_quad32<0x55>(dv[u].y), dq_quad32<0x55>(dv[u].z), dq_quad32<0x55>(dv[u].w));
+      link(2, dq_quad32<0xAA>(dv[u].x), dq_quad32<0xAA>(dv[u].y), dq_quad32<0xAA>(dv[u].z), dq_quad32<0xAA>(dv[u].w));
+      link(3, dq_quad32<0xFF>(dv[u].x), dq_quad32<0xFF>(dv[u].y), dq_quad32<0xFF>(dv[u].z), dq_quad32<0xFF>(dv[u].w));
+      if (mine) level[pos[u]] = cf[u] < 0 ? -myAl : myAl;
+    }
+#pragma unroll
+    for (int u = 0; u < 2; u++) { dv[u] = dn[u]; pos[u] = posn[u]; cf[u] = cfn[u]; }
   }
   if (k != 0) return;
   absSumOut[ti] = absSum;
