@@ -1684,8 +1684,8 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     for (int j = 0; j < 2; j++)
     {
       const int si = beg + k + 4 * j;
-      pfPos[j] = scan[si]; pfAbs[j] = abs(coef[pfPos[j]]);
-      pfSel[j] = posSel[si]; const uint2 m = posMisc[si]; pfMisc[j] = luma ? m.x : m.y;
+      pfPos[j] = scan[si]; const int c = coef[pfPos[j]]; pfAbs[j] = abs(c);
+      pfSel[j] = posSel[si]; const uint2 m = posMisc[si]; pfMisc[j] = (luma ? m.x : m.y) | (c < 0 ? 0x80000000u : 0u);   // bit 31: the coefficient's sign
     }
   };
   Rn.dl = Rn.dh = Rn.start = 0; Rn.ab = make_uint2(0, 0); Rn.misc = 0; Rn.sel = make_uint4(0, 0, 0, 0);
@@ -1758,14 +1758,15 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
       if (spt == 2) { const long long c = S.rdCost + S.sbb0; if (c < dCost) { dCost = c; dAbs = 0; dPrev = 4 + k; } }          // checkRdCostSkipSbb
       if ((k & 1) == 0 && R.start < dCost) { dCost = R.start; dAbs = abOf(R.ab, k); dPrev = -1; }                     // checkRdCostStart (decisions 0, 2)
     }
-    if (act) dec[(size_t)sIdx * 4 + k] = ((unsigned)max(dAbs, 0) << 4) | (unsigned)(dPrev + 2);
+    // (with the coefficient's sign in bit 31: the back-trace then reads nothing but the decisions -- the coefficients of a picture do not stay in L2)
+    if (act) dec[(size_t)sIdx * 4 + k] = ((unsigned)max(dAbs, 0) << 4) | (unsigned)(dPrev + 2) | (R.misc & 0x80000000u);
     if (scanIdx == 0) finalCost = dCost;
 
     // ---- state update (:1259-1318); every lane pulls its winner's context from the source lane
     DqState C; dq_copy(C, P);                                              // becomes the new previous state
     if (sIdx > 0)
     {
-      const int sigOff = (int)((R.misc >> 20) & 15u), gtxOff = (int)(R.misc >> 24);
+      const int sigOff = (int)((R.misc >> 20) & 15u), gtxOff = (int)((R.misc >> 24) & 31u);
       const int nextInside = nxt & 15;
       // source of the copied context: lane dPrev (0..3), own skip state (4 + k) or nothing
       const int srcLane = qbase + (dPrev >= 0 && dPrev < 4 ? dPrev : k);
@@ -1929,8 +1930,8 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
 
   // ---- best final state and back-trace :1368-1390.  Decisions 4..7 are implicit: at a sub-block end they are a copy of decisions
   // 0..3 (:1269), elsewhere { level 0, same skip id } (startDec :1218).  The chain through the decisions is serial, the loads are not: the
-  // quad takes eight scan positions a round, lane j loads the four decisions of positions base + j and base + 4 + j (16 bytes each), its raster position and its
-  // coefficient -- one round ahead --, the chain then runs over quad broadcasts in registers (every lane alike) and lane j writes the
+  // quad takes eight scan positions a round, lane j loads the four decisions of positions base + j and base + 4 + j (16 bytes each, the coefficient's sign in bit 31) and
+  // their raster positions -- one round ahead --, the chain then runs over quad broadcasts in registers (every lane alike) and lane j writes the
   // level of its position.  (With lane 0 alone every position was a dependent load from memory: ~0.5 ms of a 64x64 TU's 3.1 ms.)
   long long c1 = dq_shfl64(finalCost, qbase + 1), c2 = dq_shfl64(finalCost, qbase + 2), c3 = dq_shfl64(finalCost, qbase + 3);
   const long long c0 = dq_shfl64(finalCost, qbase);
@@ -1944,36 +1945,41 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
   __threadfence_block();                                                   // the decisions were stored by the four lanes
   const uint4* dec4 = reinterpret_cast<const uint4*>(dec);
   // (eight positions a round, two per lane: the chain over eight positions takes about as long as the loads of the next eight)
-  uint4 dv[2]; int pos[2], cf[2];
+  uint4 dv[2]; int pos[2];
 #pragma unroll
-  for (int u = 0; u < 2; u++) { const int i = min(4 * u + k, N - 1); dv[u] = dec4[i]; pos[u] = scan[i]; cf[u] = coef[pos[u]]; }
+  for (int u = 0; u < 2; u++) { const int i = min(4 * u + k, N - 1); dv[u] = dec4[i]; pos[u] = scan[i]; }
   for (int base = 0; prevId >= 0; base += 8)
   {
-    uint4 dn[2]; int posn[2], cfn[2];
+    uint4 dn[2]; int posn[2];
 #pragma unroll
-    for (int u = 0; u < 2; u++) { const int i = min(base + 8 + 4 * u + k, N - 1); dn[u] = dec4[i]; posn[u] = scan[i]; cfn[u] = coef[posn[u]]; }
+    for (int u = 0; u < 2; u++) { const int i = min(base + 8 + 4 * u + k, N - 1); dn[u] = dec4[i]; posn[u] = scan[i]; }
 #pragma unroll
     for (int u = 0; u < 2; u++)
     {
-      int myAl = 0; bool mine = false;
-      auto link = [&](int j, unsigned vx, unsigned vy, unsigned vz, unsigned vw)
+      int myAl = 0; bool mine = false, myNeg = false;
+      // a link of the chain: every lane picks the decision of the current state out of ITS position's four (two selects on the bits of
+      // the state: nested conditionals became branches), lane j's pick is the one that counts
+      auto pick = [&]()
+      {
+        const bool b0 = (prevId & 1) != 0, b1 = (prevId & 2) != 0;
+        const unsigned lo = b0 ? dv[u].y : dv[u].x, hi = b0 ? dv[u].w : dv[u].z;
+        return b1 ? hi : lo;
+      };
+      auto link = [&](int j, unsigned v)
       {
         const bool on = prevId >= 0, keep = prevId >= 4 && ((base + 4 * u + j) & 15) != 0;
-        const int s = prevId & 3;
-        const unsigned v = s == 0 ? vx : s == 1 ? vy : s == 2 ? vz : vw;
-        const int al = keep ? 0 : (int)(v >> 4), nextPrev = keep ? prevId : (int)(v & 15) - 2;
-        if (on && j == k) { myAl = al; mine = true; }
-        if (on) { absSum += (unsigned)al; prevId = nextPrev; }
+        const int al = keep ? 0 : (int)((v >> 4) & 0x7FFFFFFu), nextPrev = keep ? prevId : (int)(v & 15) - 2;
+        if (on && j == k) { myAl = al; mine = true; myNeg = (v >> 31) != 0u; }
+        absSum += on ? (unsigned)al : 0u; prevId = on ? nextPrev : prevId;
       };
-      // quad_perm [j, j, j, j]: lane j of the quad to all four
-      link(0, dq_quad32<0x00>(dv[u].x), dq_quad32<0x00>(dv[u].y), dq_quad32<0x00>(dv[u].z), dq_quad32<0x00>(dv[u].w));
-      link(1, dq_quad32<0x55>(dv[u].x), dq_quad32<0x55>(dv[u].y), dq_quad32<0x55>(dv[u].z), dq_quad32<0x55>(dv[u].w));
-      link(2, dq_quad32<0xAA>(dv[u].x), dq_quad32<0xAA>(dv[u].y), dq_quad32<0xAA>(dv[u].z), dq_quad32<0xAA>(dv[u].w));
-      link(3, dq_quad32<0xFF>(dv[u].x), dq_quad32<0xFF>(dv[u].y), dq_quad32<0xFF>(dv[u].z), dq_quad32<0xFF>(dv[u].w));
-      if (mine) level[pos[u]] = cf[u] < 0 ? -myAl : myAl;
+      link(0, dq_quad32<0x00>(pick()));                                    // quad_perm [j, j, j, j]: lane j of the quad to all four
+      link(1, dq_quad32<0x55>(pick()));
+      link(2, dq_quad32<0xAA>(pick()));
+      link(3, dq_quad32<0xFF>(pick()));
+      if (mine) level[pos[u]] = myNeg ? -myAl : myAl;
     }
 #pragma unroll
-    for (int u = 0; u < 2; u++) { dv[u] = dn[u]; pos[u] = posn[u]; cf[u] = cfn[u]; }
+    for (int u = 0; u < 2; u++) { dv[u] = dn[u]; pos[u] = posn[u]; }
   }
   if (k != 0) return;
   absSumOut[ti] = absSum;
