@@ -1728,11 +1728,12 @@ __global__ __launch_bounds__(256) void depquant_kernel(const TCoeff* __restrict_
     const long long INF = 0x7FFFFFFFFFFFFFFFll;
     long long cLow, cHigh, cZero = INF;
     {
-      int extra1 = 0, extra0 = 0; bool zeroOk = true;
-      if (spt == 0) { extra1 = P.sig1; extra0 = P.sig0; }
-      else if (spt == 1) { extra1 = P.sbb1 + P.sig1; extra0 = P.sbb1 + P.sig0; }
-      else if (P.numSigSbb) { extra1 = P.sig1; extra0 = P.sig0; }
-      else zeroOk = false;
+      // checkRdCostNonZero / checkRdCostZero by scan-position type (:1133-1177) as selects (the three-way branch diverges inside a wavefront):
+      // the significance bits count unless the sub-block's coded flag is inferred (its end with nothing significant so far: no zero either),
+      // the coded-flag bits at its start
+      const bool zeroOk = !(spt == 2 && P.numSigSbb == 0);
+      const int sb = spt == 1 ? P.sbb1 : 0;
+      const int extra1 = (zeroOk ? P.sig1 : 0) + sb, extra0 = (zeroOk ? P.sig0 : 0) + sb;
       cLow = P.rdCost + R.dl + dq_level_bits(rt, P.gc, P.goRice, (unsigned)abOf(R.ab, lowIdx)) + extra1;
       cHigh = P.rdCost + R.dh + dq_level_bits(rt, P.gc, P.goRice, (unsigned)abOf(R.ab, highIdx)) + extra1;
       if (zeroOk) cZero = P.rdCost + extra0;
