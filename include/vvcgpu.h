@@ -470,6 +470,13 @@ int vvcgpu_alf_filter_picture(const vvcgpu_planes* src, const vvcgpu_planes* dst
  * the 7x7 one under every transposition, so the luma 5x5 set is gathered from the 7x7 sums instead of being accumulated a second time.   */
 int vvcgpu_alf_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec, int width, int height, int ctu_size, const uint16_t* cls,
                              int64_t* out7, int64_t* out5, int64_t* out_cb, int64_t* out_cr, void* stream);
+/* The encoder's ALF front end for a picture in ONE launch: ALFProcess derives the block classes of the SAO output
+ * (AdaptiveLoopFilter::deriveClassification, EncAdaptiveLoopFilter.cpp:1218-1226) and then accumulates the covariances over them
+ * (deriveStatsForFiltering, :1317-1392).  cls_out (one uint16 per 4x4 luma block, as vvcgpu_alf_classify writes it) is an OUTPUT here:
+ * the CTU workgroups of vvcgpu_alf_stats_picture classify their blocks from the tile they hold anyway.  Results are those of
+ * vvcgpu_alf_classify followed by vvcgpu_alf_stats_picture, bit for bit (CTU sizes other than 64 / 128 run exactly these two).  */
+int vvcgpu_alf_classify_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec, int width, int height, int ctu_size, int bit_depth,
+                                      uint16_t* cls_out, int64_t* out7, int64_t* out5, int64_t* out_cb, int64_t* out_cr, void* stream);
 /* The coefficient scan the library replays (host copy, out[scanIdx] = raster position; w, h in 2..64 powers of two). */
 int vvcgpu_scan_order_host(int w, int h, uint16_t* out);
 /* ---- N3 ("next" row): affine gradient search kernels  (AffineGradientSearch table slots m_HorizontalSobelFilter /

@@ -745,6 +745,7 @@ struct AlfStatsPic
   const Pel* org[3]; const Pel* rec[3]; int ostride[3], rstride[3];
   int w, h, wCtu, nCtu, xcd;
   const uint16_t* cls;
+  uint16_t* clsOut; int clsShift;                  // fused form (vvcgpu_alf_classify_stats_picture): the classes are DERIVED here and written out
   unsigned long long* out7; unsigned long long* out5; unsigned long long* outC[2];
 };
 
@@ -764,7 +765,10 @@ typedef int alf_i4 __attribute__((ext_vector_type(4)));
 //     (distinct addresses inside a wave, so the LDS atomics do not serialise).
 // The old form (per-lane upper-triangle accumulation with v_dot2, ~1100 vector instructions and 105 serialising LDS atomics per block) took
 // 83 us for a 3840x2160 picture; see DESIGN.md for the measured time of this one.
-template <int C>
+// CLS: the block classes are not read but derived from the tile (AdaptiveLoopFilter::deriveClassificationBlk, :248-455; the arithmetic of
+// alf_classify_kernel in alf.hip: the tile has the same origin and clamping) and written to a.clsOut -- the classifier's own launch and its read
+// of the picture are gone.  The Laplacian sums of the (C / 4 + 1)^2 4x4 quads live where the class records are accumulated later.
+template <int C, bool CLS>
 __device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, unsigned char* smem)
 {
   using L = AlfCtuLds<C>;
@@ -792,15 +796,83 @@ __device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, u
       const int blk = tid + s * ACT, bi = blk % BPR, bj = blk / BPR;
       const int bx = x0 + 4 * bj, by = y0 + 4 * bi;
       myKey[s] = -1;
-      if (blk < NBLK && bx < a.w && by < a.h) myKey[s] = (int)a.cls[(size_t)(by >> 2) * (a.w >> 2) + (bx >> 2)];
+      if (!CLS && blk < NBLK && bx < a.w && by < a.h) myKey[s] = (int)a.cls[(size_t)(by >> 2) * (a.w >> 2) + (bx >> 2)];
     }
     tile_store<P, NBT>(tile, tv, L::ROWS, tid, ACT);
   }
   for (int i = tid; i < L::zeroBytes / 4; i += ACT) reinterpret_cast<unsigned*>(smem + oZero)[i] = 0u;
-  for (int i = tid; i < 25 * AC_REC7; i += ACT) bucket[i] = 0ull;
+  if (!CLS) for (int i = tid; i < 25 * AC_REC7; i += ACT) bucket[i] = 0ull;
   for (int i = tid; i < L::MAXSTEPS * 4; i += ACT) list[i] = EMPTY;
   if (tid < 64) cnt[tid] = 0;
   __syncthreads();
+  if (CLS)
+  {
+    constexpr int QN = BPR + 1;
+    static_assert(QN * QN * 16 <= L::bucketBytes, "quad sums fit into the record region");
+    int* quad = reinterpret_cast<int*>(smem + oBucket);
+    typedef unsigned short us2v __attribute__((ext_vector_type(2)));
+    auto padd = [](unsigned x, unsigned y) { return __builtin_bit_cast(unsigned, __builtin_bit_cast(us2v, x) + __builtin_bit_cast(us2v, y)); };
+    for (int q = tid; q < QN * QN; q += ACT)
+    {
+      // quad (qi, qj): picture rows y0 + 4 qi - 2 .. + 1, columns x0 + 4 qj - 2 .. + 1; two samples per instruction as in alf_classify_kernel
+      const int qj = q / QN, qi = q - qj * QN;                              // column-major like the blocks: neighbouring lanes read rows 4 P samples apart
+      const unsigned* base = reinterpret_cast<const unsigned*>(tile + (4 * qi) * P + 4 * qj);
+      unsigned sv = 0, sh = 0, sd0 = 0, sd1 = 0;
+      unsigned A[5], B[5], Cc[5];
+      auto loadRow = [&](int r, unsigned (&R)[5])
+      {
+        const uint2 lo = *reinterpret_cast<const uint2*>(base + r * (P / 2)), hi = *reinterpret_cast<const uint2*>(base + r * (P / 2) + 2);
+        R[0] = __builtin_amdgcn_alignbit(lo.y, lo.x, 16); R[1] = lo.y; R[2] = __builtin_amdgcn_alignbit(hi.x, lo.y, 16); R[3] = hi.x;
+        R[4] = __builtin_amdgcn_alignbit(hi.y, hi.x, 16);
+      };
+      loadRow(0, A); loadRow(1, B);
+#pragma unroll
+      for (int y = 0; y < 4; y++)
+      {
+        loadRow(y + 2, Cc);
+        const unsigned c01 = padd(B[1], B[1]), c23 = padd(B[3], B[3]);
+        sv  = __builtin_amdgcn_sad_u16(c01, padd(A[1], Cc[1]), sv);   sv  = __builtin_amdgcn_sad_u16(c23, padd(A[3], Cc[3]), sv);
+        sh  = __builtin_amdgcn_sad_u16(c01, padd(B[0], B[2]), sh);    sh  = __builtin_amdgcn_sad_u16(c23, padd(B[2], B[4]), sh);
+        sd0 = __builtin_amdgcn_sad_u16(c01, padd(A[0], Cc[2]), sd0);  sd0 = __builtin_amdgcn_sad_u16(c23, padd(A[2], Cc[4]), sd0);
+        sd1 = __builtin_amdgcn_sad_u16(c01, padd(Cc[0], A[2]), sd1);  sd1 = __builtin_amdgcn_sad_u16(c23, padd(Cc[2], A[4]), sd1);
+#pragma unroll
+        for (int k = 0; k < 5; k++) { A[k] = B[k]; B[k] = Cc[k]; }
+      }
+      *reinterpret_cast<int4*>(quad + (qi * QN + qj) * 4) = make_int4((int)sv, (int)sh, (int)sd0, (int)sd1);
+    }
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < S; s++)
+    {
+      const int blk = tid + s * ACT, bi = blk % BPR, bj = blk / BPR;
+      const int bx = x0 + 4 * bj, by = y0 + 4 * bi;
+      if (blk < NBLK && bx < a.w && by < a.h)
+      {
+        const int4 q00 = *reinterpret_cast<const int4*>(quad + (bi * QN + bj) * 4), q01 = *reinterpret_cast<const int4*>(quad + (bi * QN + bj + 1) * 4);
+        const int4 q10 = *reinterpret_cast<const int4*>(quad + ((bi + 1) * QN + bj) * 4), q11 = *reinterpret_cast<const int4*>(quad + ((bi + 1) * QN + bj + 1) * 4);
+        const int sumV = q00.x + q01.x + q10.x + q11.x, sumH = q00.y + q01.y + q10.y + q11.y;
+        const int sumD0 = q00.z + q01.z + q10.z + q11.z, sumD1 = q00.w + q01.w + q10.w + q11.w;
+        const unsigned long long th = 0x4333333332222210ull;               // th[] of AdaptiveLoopFilter.cpp:294, 4 bits per entry
+        const int activity = (short)clip3(0, 15, ((sumV + sumH) * 32) >> a.clsShift);
+        int classIdx = (int)((th >> (4 * activity)) & 15);
+        int hv1, hv0, d1, d0, dirHV, dirD;
+        if (sumV > sumH) { hv1 = sumV; hv0 = sumH; dirHV = 1; } else { hv1 = sumH; hv0 = sumV; dirHV = 3; }
+        if (sumD0 > sumD1) { d1 = sumD0; d0 = sumD1; dirD = 0; } else { d1 = sumD1; d0 = sumD0; dirD = 2; }
+        int hvd1, hvd0, mainDir, secDir;
+        if ((int)((unsigned)d1 * (unsigned)hv0) > (int)((unsigned)hv1 * (unsigned)d0)) { hvd1 = d1; hvd0 = d0; mainDir = dirD; secDir = dirHV; }
+        else { hvd1 = hv1; hvd0 = hv0; mainDir = dirHV; secDir = dirD; }
+        int strength = 0;
+        if (hvd1 > 2 * hvd0) strength = 1;
+        if (hvd1 * 2 > 9 * hvd0) strength = 2;
+        if (strength) classIdx += (((mainDir & 1) << 1) + strength) * 5;
+        const int transposeIdx = (0xDE84u >> (2 * (mainDir * 2 + (secDir >> 1)))) & 3;   // transposeTable (:447), 2 bits per entry
+        myKey[s] = classIdx | (transposeIdx << 8);
+        a.clsOut[(size_t)(by >> 2) * (a.w >> 2) + (bx >> 2)] = (uint16_t)myKey[s];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < 25 * AC_REC7; i += ACT) bucket[i] = 0ull;        // (two barriers before the first record is added to)
+  }
 #pragma unroll
   for (int s = 0; s < S; s++)
   {
@@ -1086,7 +1158,7 @@ __device__ __forceinline__ void alf_ctu_chroma(const AlfStatsPic& a, int ctuIdx,
 // one workgroup per CTU: luma, then the CTU's chroma pair in the same LDS (the chroma tiles and records lie inside the luma tile's bytes, which
 // are free behind the barrier that ends the luma steps; the luma records are still being written out from their own region meanwhile).
 // As workgroups of their own the chroma pairs were a second round of 80 KB workgroups behind the luma round: 10 us of a 56 us launch.
-template <int C>
+template <int C, bool CLS>
 __global__ __launch_bounds__(ACT) void alf_stats_picture_kernel(AlfStatsPic a)
 {
   extern __shared__ __align__(16) unsigned char alfSmem[];
@@ -1094,7 +1166,7 @@ __global__ __launch_bounds__(ACT) void alf_stats_picture_kernel(AlfStatsPic a)
   const int ctuIdx = vvc_xcd_index((int)blockIdx.x, a.nCtu, a.xcd);
   if (ctuIdx < 0) return;
   alf_chroma_prefetch<C>(a, ctuIdx, pre);
-  alf_ctu_luma<C>(a, ctuIdx, alfSmem);
+  alf_ctu_luma<C, CLS>(a, ctuIdx, alfSmem);
   alf_ctu_chroma<C>(a, ctuIdx, alfSmem, pre);
 }
 
@@ -1227,10 +1299,13 @@ int vvcgpu_sao_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec,
   return VVCGPU_OK;
 }
 
-int vvcgpu_alf_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec, int width, int height, int ctu_size, const uint16_t* cls,
-                             int64_t* out7, int64_t* out5, int64_t* out_cb, int64_t* out_cr, void* stream)
+}  // extern "C"
+
+// cls_out != nullptr: the fused form -- the classes are derived inside the CTU workgroups and written to cls_out (cls is not read)
+static int alf_stats_picture_impl(const vvcgpu_planes* org, const vvcgpu_planes* rec, int width, int height, int ctu_size, const uint16_t* cls,
+                                  uint16_t* cls_out, int bit_depth, int64_t* out7, int64_t* out5, int64_t* out_cb, int64_t* out_cr, void* stream)
 {
-  VVC_CHECK_ARG(org && rec && cls && out7 && out5 && out_cb && out_cr, "alf_stats_picture: null pointer");
+  VVC_CHECK_ARG(org && rec && (cls || cls_out) && out7 && out5 && out_cb && out_cr, "alf_stats_picture: null pointer");
   VVC_CHECK_ARG(width > 0 && height > 0 && (width & 7) == 0 && (height & 7) == 0, "alf_stats_picture: size must be a multiple of 8");
   VVC_CHECK_ARG(ctu_size == 64 || (ctu_size >= 2 * AT && (ctu_size % (2 * AT)) == 0), "alf_stats_picture: ctu size %d must be 64 or a multiple of %d", ctu_size, 2 * AT);
   for (int c = 0; c < 3; c++)
@@ -1250,20 +1325,26 @@ int vvcgpu_alf_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec,
     // CTU form: one launch, every record written by the workgroup that owns the CTU
     AlfStatsPic a;
     for (int c = 0; c < 3; c++) { a.org[c] = org->p[c]; a.rec[c] = rec->p[c]; a.ostride[c] = org->stride[c]; a.rstride[c] = rec->stride[c]; }
-    a.w = width; a.h = height; a.wCtu = wCtu; a.nCtu = nCtu; a.cls = cls; a.xcd = vvc_xcd_on();
+    a.w = width; a.h = height; a.wCtu = wCtu; a.nCtu = nCtu; a.cls = cls; a.clsOut = cls_out; a.clsShift = bit_depth + 4; a.xcd = vvc_xcd_on();
     a.out7 = o7; a.out5 = reinterpret_cast<unsigned long long*>(out5); a.outC[0] = ocb; a.outC[1] = ocr;
-    if (ctu_size == 128)
+    auto launch = [&](auto kernel, int ldsBytes) -> int
     {
-      VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alf_stats_picture_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, AlfCtuLds<128>::bytes));
-      hipLaunchKernelGGL(alf_stats_picture_kernel<128>, dim3(vvc_xcd_grid(nCtu, a.xcd)), dim3(ACT), AlfCtuLds<128>::bytes, st, a);
-    }
-    else
-    {
-      VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(alf_stats_picture_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, AlfCtuLds<64>::bytes));
-      hipLaunchKernelGGL(alf_stats_picture_kernel<64>, dim3(vvc_xcd_grid(nCtu, a.xcd)), dim3(ACT), AlfCtuLds<64>::bytes, st, a);
-    }
+      VVC_HIP(hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, ldsBytes));
+      hipLaunchKernelGGL(kernel, dim3(vvc_xcd_grid(nCtu, a.xcd)), dim3(ACT), ldsBytes, st, a);
+      return VVCGPU_OK;
+    };
+    int rt;
+    if (ctu_size == 128) rt = cls_out ? launch(alf_stats_picture_kernel<128, true>, AlfCtuLds<128>::bytes) : launch(alf_stats_picture_kernel<128, false>, AlfCtuLds<128>::bytes);
+    else                 rt = cls_out ? launch(alf_stats_picture_kernel<64, true>, AlfCtuLds<64>::bytes) : launch(alf_stats_picture_kernel<64, false>, AlfCtuLds<64>::bytes);
+    if (rt) return rt;
     VVC_LAUNCH_CHECK();
     return VVCGPU_OK;
+  }
+  if (cls_out)                                                              // other CTU sizes: the classifier's own launch in front of the tile form
+  {
+    const int rt = vvcgpu_alf_classify(rec->p[0], rec->stride[0], width, height, bit_depth, cls_out, stream);
+    if (rt) return rt;
+    cls = cls_out;
   }
   hipLaunchKernelGGL(zero3_kernel, dim3(512), dim3(256), 0, st, o7, (size_t)nCtu * 25 * 183, ocb, (size_t)nCtu * 57, ocr, (size_t)nCtu * 57);
   hipLaunchKernelGGL(alf_stats_kernel<true>, dim3(cdiv(width, AT), cdiv(height, AT)), dim3(256), 0, st, org->p[0], org->stride[0], rec->p[0], rec->stride[0],
@@ -1273,6 +1354,23 @@ int vvcgpu_alf_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec,
   hipLaunchKernelGGL(alf_stats_5from7_kernel, dim3(cdiv(nCtu * 25 * 57, 256)), dim3(256), 0, st, o7, reinterpret_cast<unsigned long long*>(out5), nCtu * 25);
   VVC_LAUNCH_CHECK();
   return VVCGPU_OK;
+}
+
+extern "C" {
+
+int vvcgpu_alf_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec, int width, int height, int ctu_size, const uint16_t* cls,
+                             int64_t* out7, int64_t* out5, int64_t* out_cb, int64_t* out_cr, void* stream)
+{
+  VVC_CHECK_ARG(cls, "alf_stats_picture: null pointer");
+  return alf_stats_picture_impl(org, rec, width, height, ctu_size, cls, nullptr, 10, out7, out5, out_cb, out_cr, stream);
+}
+
+int vvcgpu_alf_classify_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec, int width, int height, int ctu_size, int bit_depth,
+                                      uint16_t* cls_out, int64_t* out7, int64_t* out5, int64_t* out_cb, int64_t* out_cr, void* stream)
+{
+  VVC_CHECK_ARG(cls_out, "alf_classify_stats_picture: null pointer");
+  VVC_CHECK_ARG(bit_depth >= 8 && bit_depth <= 10, "alf_classify_stats_picture: bit depth %d outside 8..10", bit_depth);
+  return alf_stats_picture_impl(org, rec, width, height, ctu_size, nullptr, cls_out, bit_depth, out7, out5, out_cb, out_cr, stream);
 }
 
 }  // extern "C"

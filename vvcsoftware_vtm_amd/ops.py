@@ -552,6 +552,20 @@ def alf_stats_picture(org, rec, ctu, cls):
     return a7, a5, ac
 
 
+def alf_classify_stats_picture(org, rec, ctu, bit_depth):
+    """The encoder's ALF front end in one launch (vvcgpu_alf_classify_stats_picture): -> (cls as alf_classify returns it, then alf_stats_picture's tuple)"""
+    h, w = org[0].shape
+    n = ((w + ctu - 1) // ctu) * ((h + ctu - 1) // ctu)
+    dev = org[0].device
+    cls = torch.empty((h // 4, w // 4), dtype=torch.int16, device=dev)
+    a7 = torch.empty((n, 25, 183), dtype=torch.int64, device=dev)
+    a5 = torch.empty((n, 25, 57), dtype=torch.int64, device=dev)
+    ac = [torch.empty((n, 1, 57), dtype=torch.int64, device=dev) for _ in range(2)]
+    capi.call("vvcgpu_alf_classify_stats_picture", C.byref(planes(org)), C.byref(planes(rec)), w, h, ctu, bit_depth, capi.ptr(cls), capi.ptr(a7), capi.ptr(a5),
+              capi.ptr(ac[0]), capi.ptr(ac[1]), _stream())
+    return cls, a7, a5, ac
+
+
 # ---- T3 residual DPCM, I3 affine sub-block vectors -------------------------------------------------------------
 RDPCM_DESC = np.dtype([("resi_off", "<i8"), ("coeff_off", "<i8"), ("resi_stride", "<i4"), ("w", "<i2"), ("h", "<i2"), ("mode", "i1"), ("lossless", "i1"),
                        ("rotate", "i1"), ("intra_slice", "i1"), ("qp", "<i4"), ("reserved", "<i4"), ("pad", "<i4")])

@@ -92,7 +92,7 @@ def _pad(plane, m):
 
 
 class Workload:
-    def __init__(self, width, height, bit_depth=10, seed=20261003, raster_range=96, me_sizes=(16, 32, 64), qp=32, fused_resi=True, hier_me=True, depquant=False):
+    def __init__(self, width, height, bit_depth=10, seed=20261003, raster_range=96, me_sizes=(16, 32, 64), qp=32, fused_resi=True, hier_me=True, depquant=False, fuse_alf=True):
         assert width % 8 == 0 and height % 8 == 0
         self.w, self.h, self.bd = width, height, bit_depth
         self.mx = (1 << bit_depth) - 1
@@ -106,6 +106,7 @@ class Workload:
         # integer ME as ONE hierarchical launch (vvcgpu_me_hier_search: every 16x16 SAD once, 32x32 / 64x64 by addition, raster and +-4 grid from
         # the same LDS window) or as six per-size searches (vvcgpu_sad_search): same results
         # (the entry's own preconditions, csrc/mehier.hip: at most 39 raster columns, and the raster's window must contain the +-4 grid's: 5 (R // 5) >= 4 + 15)
+        self.fuse_alf = bool(fuse_alf)        # classifier inside the covariance launch (vvcgpu_alf_classify_stats_picture) in the serial schedule
         self.hier_me = bool(hier_me) and tuple(sorted(me_sizes)) == (16, 32, 64) and raster_range <= 99 and 5 * (raster_range // 5) >= 19
         self.qp = qp                                   # base QP (BASELINE configs: 22 / 27 / 32 / 37); quantiser, de-quantiser and the deblocking QP field follow it
         rng = np.random.default_rng(seed)
@@ -347,6 +348,7 @@ class Workload:
         out["dbk"] = {"deblock": 2 * P + maps}
         out["sao"] = {"sao_stats": 2 * P + self.nctu_x * self.nctu_y * 3 * 2560, "sao_apply": 2 * P}
         nctu = self.nctu_x * self.nctu_y
+        # (with the classifier inside the covariance launch its class map is written instead of read: the same bytes)
         out["alf"] = {"alf_classify": Y + Y // 16, "alf_stats": (2 * Y + Y // 16) * 2 + 2 * (P - Y) + nctu * 25 * (183 + 57) * 8 + nctu * 2 * 57 * 8,
                       "alf_filter": 2 * P + Y // 16}
         return out
@@ -609,12 +611,17 @@ class Workload:
             ops.sao_apply_picture(st["rec"], st["sao_out"], CTU, bd, st["sao"], (0, mx))
         out["sao_stats"] = sao_stats
         # ---- ALF (the covariances read the SAO output and the classifier: side stream 2)
-        with T("alf/alf_classify"):
-            cls = ops.alf_classify(st["sao_out"][0], bd)
-        e_cls = mark()
-        with _On(side[2], e_cls):
+        if self.fuse_alf and not overlap:
+            # ALFProcess' front end as ONE launch: the covariance workgroups derive the classes of their CTU from the tile they hold
             with T("alf/alf_stats"):
-                a7, a5, ac = ops.alf_stats_picture(st["org"], st["sao_out"], CTU, cls)
+                cls, a7, a5, ac = ops.alf_classify_stats_picture(st["org"], st["sao_out"], CTU, bd)
+        else:
+            with T("alf/alf_classify"):
+                cls = ops.alf_classify(st["sao_out"][0], bd)
+            e_cls = mark()
+            with _On(side[2], e_cls):
+                with T("alf/alf_stats"):
+                    a7, a5, ac = ops.alf_stats_picture(st["org"], st["sao_out"], CTU, cls)
         with T("alf/alf_filter"):
             ops.alf_filter_picture(st["sao_out"], st["alf_out"], CTU, cls, 1, self.alf_luma_coeff, self.alf_chroma_coeff, st["alf_en"], (0, mx))
         if overlap:                                 # join: the step is complete (and its buffers reusable) when `main` is
