@@ -815,7 +815,7 @@ __device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, u
     for (int q = tid; q < QN * QN; q += ACT)
     {
       // quad (qi, qj): picture rows y0 + 4 qi - 2 .. + 1, columns x0 + 4 qj - 2 .. + 1; two samples per instruction as in alf_classify_kernel
-      const int qj = q / QN, qi = q - qj * QN;                              // column-major like the blocks: neighbouring lanes read rows 4 P samples apart
+      const int qi = q / QN, qj = q - qi * QN;                              // row-major: neighbouring lanes read neighbouring 8-byte words of a tile row
       const unsigned* base = reinterpret_cast<const unsigned*>(tile + (4 * qi) * P + 4 * qj);
       unsigned sv = 0, sh = 0, sd0 = 0, sd1 = 0;
       unsigned A[5], B[5], Cc[5];
