@@ -2008,12 +2008,30 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
   // class counts and slot ranges live in LDS: as 75 scalars they were 143 spilled scalar registers around every body (round 6)
   __shared__ int sCnt[NORD], sEnd[NORD];
   __shared__ long long sOff[NORD];                            // where class k's TU indices start in `lists`
-  int total = 0;
+  // Prologue items: the table image is ~40 KB per workgroup, three workgroups per CU ask for it at the same time and a CU takes ~11 bytes per cycle in such a
+  // burst -- 8.6 us of the launch with every wave waiting (a second copy of the image costs exactly that).  When the list holds enough 4x4 TUs, ONE wave of the
+  // workgroup copies the f16 matrices while the other three each run an item of that class (sixteen TUs; it needs the small int32 tables only): the class's
+  // LAST 3 x #workgroups items are taken out of the slot schedule for that.
+  constexpr int KPRE = 14;
+  static_assert(ordCls[KPRE] == RC_C4 && ordG[KPRE] == 16, "the 4x4 lane-group class");
+  const int c4 = bins.use ? bins.cnt[RC_C4] : hdr[RC_C4], items4 = (c4 + 15) >> 4, nPre = 3 * (int)gridDim.x;
+  int totalA = 0, totalB = 0;                                 // slots without / with the prologue items
 #pragma unroll
   for (int k = 0; k < NORD; k++)
   {
     const int ck = bins.use ? bins.cnt[ordCls[k]] : hdr[ordCls[k]], ik = (ck + ordG[k] - 1) / ordG[k];
-    total += k < NCOOP ? ik : (ik + 3) >> 2;                  // co-operative classes: one TU per slot (the four waves together)
+    totalA += k < NCOOP ? ik : (ik + 3) >> 2;                 // co-operative classes: one TU per slot (the four waves together)
+    totalB += k < NCOOP ? ik : ((k == KPRE ? max(ik - nPre, 0) : ik) + 3) >> 2;
+  }
+  const bool usePre = items4 >= nPre && totalB >= (int)gridDim.x;
+  int total = 0;
+#pragma unroll
+  for (int k = 0; k < NORD; k++)
+  {
+    int ck = bins.use ? bins.cnt[ordCls[k]] : hdr[ordCls[k]];
+    if (k == KPRE && usePre) ck = (items4 - nPre) * 16;       // (whole items: the class's partial last item is a prologue item)
+    const int ik = (ck + ordG[k] - 1) / ordG[k];
+    total += k < NCOOP ? ik : (ik + 3) >> 2;
     if (tid == 0) { sCnt[k] = ck; sEnd[k] = total; sOff[k] = bins.use ? (long long)bins.base[ordCls[k]] : (long long)ordCls[k] * n; }
   }
   if ((int)blockIdx.x >= total) return;
@@ -2045,6 +2063,31 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
       }
     }
   }
+  if (usePre)
+  {
+    const uint4* src = reinterpret_cast<const uint4*>(image);
+    if (tid < (int)sizeof(RcSmallTab) / 16) reinterpret_cast<uint4*>(&tabs)[tid] = src[RC_TAB_HALVES / 8 + tid];
+    __syncthreads();
+    if (wave == 3)
+    {
+      constexpr int NW4 = RC_TAB_HALVES / 8, PERW = 13;
+#pragma unroll 1
+      for (int b0 = 0; b0 < NW4; b0 += 64 * PERW)
+      {
+        uint4 v[PERW];
+#pragma unroll
+        for (int u = 0; u < PERW; u++) { const int i = b0 + lane + 64 * u; if (i < NW4) v[u] = src[i]; }
+#pragma unroll
+        for (int u = 0; u < PERW; u++) { const int i = b0 + lane + 64 * u; if (i < NW4) reinterpret_cast<uint4*>(tab)[i] = v[u]; }
+      }
+    }
+    else
+    {
+      const int* const list4 = lists + (bins.use ? (long long)bins.base[RC_C4] : (long long)RC_C4 * n);
+      rc_small_group<4, MODE>(descs, list4, c4, items4 - nPre + (int)blockIdx.x * 3 + wave, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+    }
+  }
+  else
   {
     // the table image (f16 matrices + the int32 4- / 8-point matrices) as ONE run of 16-byte loads, all in flight before the first store.  In-kernel stamps
     // (RC_DIAG): 16 - 24 k cycles until the barrier below with three workgroups per CU -- every workgroup of an XCD asks its L2 for the same 41 KB at the
