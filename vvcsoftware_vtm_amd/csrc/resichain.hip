@@ -2011,10 +2011,12 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
   // Prologue items: the table image is ~40 KB per workgroup, three workgroups per CU ask for it at the same time and a CU takes ~11 bytes per cycle in such a
   // burst -- 8.6 us of the launch with every wave waiting (a second copy of the image costs exactly that).  When the list holds enough 4x4 TUs, ONE wave of the
   // workgroup copies the f16 matrices while the other three each run an item of that class (sixteen TUs; it needs the small int32 tables only): the class's
-  // LAST 3 x #workgroups items are taken out of the slot schedule for that.
+  // LAST 3 x #workgroups items (twice as many when the class has them: the copy takes about as long as two items, 62.6 -> 60.6 us) are taken out of the
+  // slot schedule for that.
   constexpr int KPRE = 14;
   static_assert(ordCls[KPRE] == RC_C4 && ordG[KPRE] == 16, "the 4x4 lane-group class");
-  const int c4 = bins.use ? bins.cnt[RC_C4] : hdr[RC_C4], items4 = (c4 + 15) >> 4, nPre = 3 * (int)gridDim.x;
+  const int c4 = bins.use ? bins.cnt[RC_C4] : hdr[RC_C4], items4 = (c4 + 15) >> 4;
+  const int perWave = items4 >= 6 * (int)gridDim.x ? 2 : 1, nPre = 3 * perWave * (int)gridDim.x;
   int totalA = 0, totalB = 0;                                 // slots without / with the prologue items
 #pragma unroll
   for (int k = 0; k < NORD; k++)
@@ -2084,7 +2086,8 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
     else
     {
       const int* const list4 = lists + (bins.use ? (long long)bins.base[RC_C4] : (long long)RC_C4 * n);
-      rc_small_group<4, MODE>(descs, list4, c4, items4 - nPre + (int)blockIdx.x * 3 + wave, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+      for (int r = 0; r < perWave; r++)
+        rc_small_group<4, MODE>(descs, list4, c4, items4 - nPre + ((int)blockIdx.x * 3 + wave) * perWave + r, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
     }
   }
   else
