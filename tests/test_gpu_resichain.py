@@ -100,6 +100,25 @@ def test_resi_chain_squares(bd, content):
     assert np.array_equal(grec, rec)
 
 
+@pytest.mark.parametrize("W,H,shapes,per_wave", [(1536, 1024, [(4, 4), (16, 16), (4, 4), (16, 16), (32, 32)], 1),
+                                                 (2048, 1024, [(4, 4), (4, 4), (4, 4), (16, 16)], 2)])
+def test_resi_chain_prologue_items(W, H, shapes, per_wave):
+    """lists long enough for the chain launch's prologue (one wave of a workgroup copies the matrix image, the other three run one / two items of the
+    4x4 class taken from the end of that class's list): every TU served exactly once, results as the oracle's"""
+    rng = np.random.default_rng(W + per_wave)
+    bd = 10
+    org = cases.rand_plane(rng, H, W, bd, "smooth")
+    pred = np.clip(org + rng.integers(-25, 26, org.shape), 0, 1023).astype(np.int16)
+    tus = tile(W, H, shapes, rng, [22, 32, 37], bd)
+    items4 = (sum(1 for t in tus if t[2] == 4 and t[3] == 4) + 15) // 16
+    assert (items4 >= 6 * 768) == (per_wave == 2) and items4 >= 3 * 768          # (768 workgroups: the launch's grid)
+    lv, asum, rec, coffs = oracle_chain(org, pred, tus, bd, W)
+    glv, gsum, grec = gpu_chain(org, pred, tus, bd, W, coffs)
+    assert np.array_equal(gsum, asum)
+    assert np.array_equal(glv, lv)
+    assert np.array_equal(grec, rec)
+
+
 def test_resi_chain_rectangles_and_chroma_shapes():
     """every other W x H in 2..64 takes the generic path: rectangles with 2:1 ... 16:1 aspect, 2-wide chroma TUs"""
     rng = np.random.default_rng(77)
