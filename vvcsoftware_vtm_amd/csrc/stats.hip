@@ -768,8 +768,8 @@ typedef int alf_i4 __attribute__((ext_vector_type(4)));
 // CLS: the block classes are not read but derived from the tile (AdaptiveLoopFilter::deriveClassificationBlk, :248-455; the arithmetic of
 // alf_classify_kernel in alf.hip: the tile has the same origin and clamping) and written to a.clsOut -- the classifier's own launch and its read
 // of the picture are gone.  The Laplacian sums of the (C / 4 + 1)^2 4x4 quads live where the class records are accumulated later.
-template <int C, bool CLS>
-__device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, unsigned char* smem)
+template <int C, bool CLS, typename AfterTile>
+__device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, unsigned char* smem, AfterTile afterTile)
 {
   using L = AlfCtuLds<C>;
   constexpr int P = L::P, BPR = C / 4, NBLK = BPR * BPR, S = (NBLK + ACT - 1) / ACT, NW = ACT / 64;
@@ -800,6 +800,9 @@ __device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, u
     }
     tile_store<P, NBT>(tile, tv, L::ROWS, tid, ACT);
   }
+  // (what the chroma part needs from memory is requested HERE, behind the luma tile: in front of it -- all of a CU's workgroups start together, and a CU
+  // takes ~11 bytes per cycle in such a burst -- the luma tile arrived behind twice its own bytes)
+  afterTile();
   for (int i = tid; i < L::zeroBytes / 4; i += ACT) reinterpret_cast<unsigned*>(smem + oZero)[i] = 0u;
   if (!CLS) for (int i = tid; i < 25 * AC_REC7; i += ACT) bucket[i] = 0ull;
   for (int i = tid; i < L::MAXSTEPS * 4; i += ACT) list[i] = EMPTY;
@@ -1165,8 +1168,7 @@ __global__ __launch_bounds__(ACT) void alf_stats_picture_kernel(AlfStatsPic a)
   AlfChromaPre<C> pre;
   const int ctuIdx = vvc_xcd_index((int)blockIdx.x, a.nCtu, a.xcd);
   if (ctuIdx < 0) return;
-  alf_chroma_prefetch<C>(a, ctuIdx, pre);
-  alf_ctu_luma<C, CLS>(a, ctuIdx, alfSmem);
+  alf_ctu_luma<C, CLS>(a, ctuIdx, alfSmem, [&]() { alf_chroma_prefetch<C>(a, ctuIdx, pre); });
   alf_ctu_chroma<C>(a, ctuIdx, alfSmem, pre);
 }
 
