@@ -2072,16 +2072,16 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
     __syncthreads();
     if (wave == 3)
     {
-      constexpr int NW4 = RC_TAB_HALVES / 8, PERW = 13;
-#pragma unroll 1
-      for (int b0 = 0; b0 < NW4; b0 += 64 * PERW)
-      {
-        uint4 v[PERW];
+      // memory -> LDS without registers in between (1 KB per instruction, the image is copied as it lies: lane-linear), all 39 in flight at once: through
+      // registers the one wave had three rounds of 13 loads, each a trip through the burst (25 - 29 k cycles, the items of the others 17 k)
+      constexpr int NW4 = RC_TAB_HALVES / 8;
+      typedef __attribute__((address_space(1))) const void* GPtr;
+      typedef __attribute__((address_space(3))) void* LPtr;
 #pragma unroll
-        for (int u = 0; u < PERW; u++) { const int i = b0 + lane + 64 * u; if (i < NW4) v[u] = src[i]; }
-#pragma unroll
-        for (int u = 0; u < PERW; u++) { const int i = b0 + lane + 64 * u; if (i < NW4) reinterpret_cast<uint4*>(tab)[i] = v[u]; }
-      }
+      for (int u = 0; u < (NW4 + 63) / 64; u++)
+        if (lane + 64 * u < NW4)
+          __builtin_amdgcn_global_load_lds((GPtr)(src + lane + 64 * u), (LPtr)(reinterpret_cast<uint4*>(tab) + 64 * u), 16, 0, 0);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     else
     {
