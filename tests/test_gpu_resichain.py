@@ -101,17 +101,22 @@ def test_resi_chain_squares(bd, content):
 
 
 @pytest.mark.parametrize("W,H,shapes,per_wave", [(1536, 1024, [(4, 4), (16, 16), (4, 4), (16, 16), (32, 32)], 1),
-                                                 (2048, 1024, [(4, 4), (4, 4), (4, 4), (16, 16)], 2)])
+                                                 (2048, 1024, [(4, 4), (4, 4), (4, 4), (16, 16)], 2),
+                                                 (2048, 1024, [(8, 8), (8, 8), (16, 16)], 8)])
 def test_resi_chain_prologue_items(W, H, shapes, per_wave):
     """lists long enough for the chain launch's prologue (one wave of a workgroup copies the matrix image, the other three run one / two items of the
-    4x4 class taken from the end of that class's list): every TU served exactly once, results as the oracle's"""
+    4x4 class -- or one of the 8x8 class -- taken from the end of that class's list): every TU served exactly once, results as the oracle's"""
     rng = np.random.default_rng(W + per_wave)
     bd = 10
     org = cases.rand_plane(rng, H, W, bd, "smooth")
     pred = np.clip(org + rng.integers(-25, 26, org.shape), 0, 1023).astype(np.int16)
     tus = tile(W, H, shapes, rng, [22, 32, 37], bd)
     items4 = (sum(1 for t in tus if t[2] == 4 and t[3] == 4) + 15) // 16
-    assert (items4 >= 6 * 768) == (per_wave == 2) and items4 >= 3 * 768          # (768 workgroups: the launch's grid)
+    items8 = (sum(1 for t in tus if t[2] == 8 and t[3] == 8) + 7) // 8
+    if per_wave == 8:                                                              # no 4x4 TUs: one 8x8 item per wave
+        assert items4 == 0 and items8 >= 3 * 768
+    else:
+        assert (items4 >= 6 * 768) == (per_wave == 2) and items4 >= 3 * 768      # (768 workgroups: the launch's grid)
     lv, asum, rec, coffs = oracle_chain(org, pred, tus, bd, W)
     glv, gsum, grec = gpu_chain(org, pred, tus, bd, W, coffs)
     assert np.array_equal(gsum, asum)

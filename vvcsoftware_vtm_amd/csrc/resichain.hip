@@ -2012,26 +2012,28 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
   // burst -- 8.6 us of the launch with every wave waiting (a second copy of the image costs exactly that).  When the list holds enough 4x4 TUs, ONE wave of the
   // workgroup copies the f16 matrices while the other three each run an item of that class (sixteen TUs; it needs the small int32 tables only): the class's
   // LAST 3 x #workgroups items (twice as many when the class has them: the copy takes about as long as two items, 62.6 -> 60.6 us) are taken out of the
-  // slot schedule for that.
-  constexpr int KPRE = 14;
-  static_assert(ordCls[KPRE] == RC_C4 && ordG[KPRE] == 16, "the 4x4 lane-group class");
-  const int c4 = bins.use ? bins.cnt[RC_C4] : hdr[RC_C4], items4 = (c4 + 15) >> 4;
-  const int perWave = items4 >= 6 * (int)gridDim.x ? 2 : 1, nPre = 3 * perWave * (int)gridDim.x;
-  int totalA = 0, totalB = 0;                                 // slots without / with the prologue items
+  // slot schedule for that; a list short of 4x4 TUs gives items of the 8x8 lane-group class (eight TUs, about two 4x4 items long) instead.
+  constexpr int KPRE4 = 14, KPRE8 = 6;
+  static_assert(ordCls[KPRE4] == RC_C4 && ordG[KPRE4] == 16 && ordCls[KPRE8] == RC_C8 && ordG[KPRE8] == 8, "the lane-group classes");
+  const int G3 = 3 * (int)gridDim.x;
+  const int c4 = bins.use ? bins.cnt[RC_C4] : hdr[RC_C4], items4 = (c4 + 15) >> 4, c8 = bins.use ? bins.cnt[RC_C8] : hdr[RC_C8], items8 = (c8 + 7) >> 3;
+  const int kPre = items4 >= G3 ? KPRE4 : items8 >= G3 ? KPRE8 : -1;
+  const int perWave = kPre == KPRE4 && items4 >= 2 * G3 ? 2 : 1, nPre = perWave * G3;
+  int totalB = 0;                                             // slots of the schedule without the prologue items
 #pragma unroll
   for (int k = 0; k < NORD; k++)
   {
     const int ck = bins.use ? bins.cnt[ordCls[k]] : hdr[ordCls[k]], ik = (ck + ordG[k] - 1) / ordG[k];
-    totalA += k < NCOOP ? ik : (ik + 3) >> 2;                 // co-operative classes: one TU per slot (the four waves together)
-    totalB += k < NCOOP ? ik : ((k == KPRE ? max(ik - nPre, 0) : ik) + 3) >> 2;
+    totalB += k < NCOOP ? ik : ((k == kPre ? ik - nPre : ik) + 3) >> 2;     // co-operative classes: one TU per slot (the four waves together)
   }
-  const bool usePre = items4 >= nPre && totalB >= (int)gridDim.x;
+  const bool usePre = kPre >= 0 && totalB >= (int)gridDim.x;
+  const int cPre = kPre == KPRE4 ? c4 : c8, itemsPre = kPre == KPRE4 ? items4 : items8;
   int total = 0;
 #pragma unroll
   for (int k = 0; k < NORD; k++)
   {
     int ck = bins.use ? bins.cnt[ordCls[k]] : hdr[ordCls[k]];
-    if (k == KPRE && usePre) ck = (items4 - nPre) * 16;       // (whole items: the class's partial last item is a prologue item)
+    if (k == kPre && usePre) ck = (itemsPre - nPre) * ordG[k];   // (whole items: the class's partial last item is a prologue item)
     const int ik = (ck + ordG[k] - 1) / ordG[k];
     total += k < NCOOP ? ik : (ik + 3) >> 2;
     if (tid == 0) { sCnt[k] = ck; sEnd[k] = total; sOff[k] = bins.use ? (long long)bins.base[ordCls[k]] : (long long)ordCls[k] * n; }
@@ -2085,9 +2087,13 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
     }
     else
     {
-      const int* const list4 = lists + (bins.use ? (long long)bins.base[RC_C4] : (long long)RC_C4 * n);
-      for (int r = 0; r < perWave; r++)
-        rc_small_group<4, MODE>(descs, list4, c4, items4 - nPre + ((int)blockIdx.x * 3 + wave) * perWave + r, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+      const int clsPre = kPre == KPRE4 ? (int)RC_C4 : (int)RC_C8;
+      const int* const listPre = lists + (bins.use ? (long long)bins.base[clsPre] : (long long)clsPre * n);
+      const int first = itemsPre - nPre + ((int)blockIdx.x * 3 + wave) * perWave;
+      if (kPre == KPRE8)
+        rc_small_group<8, MODE>(descs, listPre, cPre, first, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+      else for (int r = 0; r < perWave; r++)
+        rc_small_group<4, MODE>(descs, listPre, cPre, first + r, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
     }
   }
   else
