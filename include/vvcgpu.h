@@ -474,7 +474,8 @@ int vvcgpu_alf_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec,
  * (AdaptiveLoopFilter::deriveClassification, EncAdaptiveLoopFilter.cpp:1218-1226) and then accumulates the covariances over them
  * (deriveStatsForFiltering, :1317-1392).  cls_out (one uint16 per 4x4 luma block, as vvcgpu_alf_classify writes it) is an OUTPUT here:
  * the CTU workgroups of vvcgpu_alf_stats_picture classify their blocks from the tile they hold anyway.  Results are those of
- * vvcgpu_alf_classify followed by vvcgpu_alf_stats_picture, bit for bit (CTU sizes other than 64 / 128 run exactly these two).  */
+ * vvcgpu_alf_classify followed by vvcgpu_alf_stats_picture, bit for bit (CTU sizes other than 64 / 128 and pictures of fewer than 320 CTUs --
+ * where a classifier launch of its own is the faster form -- run exactly these two).  */
 int vvcgpu_alf_classify_stats_picture(const vvcgpu_planes* org, const vvcgpu_planes* rec, int width, int height, int ctu_size, int bit_depth,
                                       uint16_t* cls_out, int64_t* out7, int64_t* out5, int64_t* out_cb, int64_t* out_cr, void* stream);
 /* The coefficient scan the library replays (host copy, out[scanIdx] = raster position; w, h in 2..64 powers of two). */

@@ -214,7 +214,8 @@ def test_picture_level_entry_points_equal_per_plane_ones(w, h, ctu, ft):
     assert torch.equal(fcls, cls) and torch.equal(f7, a7) and torch.equal(f5, a5) and torch.equal(fc[0], ac[0]) and torch.equal(fc[1], ac[1])
 
 
-@pytest.mark.parametrize("w,h,ctu", [(128, 128, 128), (136, 72, 64), (264, 136, 128), (416, 240, 128), (264, 136, 256)])
+# (from 320 CTUs on the classes are derived inside the covariance workgroups; smaller pictures and other CTU sizes run the classifier's own launch)
+@pytest.mark.parametrize("w,h,ctu", [(128, 128, 128), (136, 72, 64), (264, 136, 128), (416, 240, 128), (264, 136, 256), (1216, 1088, 64), (1240, 1096, 64)])
 @pytest.mark.parametrize("bd,kind", [(10, "uniform"), (10, "extreme"), (8, "smooth"), (10, "const")])
 def test_alf_classify_stats_picture_against_oracle(w, h, ctu, bd, kind):
     """vvcgpu_alf_classify_stats_picture: classes = the oracle's deriveClassification of the reconstruction, luma 7x7 records = the oracle's
@@ -240,3 +241,8 @@ def test_alf_classify_stats_picture_against_oracle(w, h, ctu, bd, kind):
     want5 = np.zeros((nx * ny, 25, 57), np.int64)
     oracle().orc_alf_stats(p(org[0]), w, p(rec[0]), w, w, h, ctu, p(cls), 0, p(want5))
     assert np.array_equal(g5.cpu().numpy(), want5)
+
+
+def test_alf_classify_stats_picture_128_ctus_in_kernel_classes():
+    """the same with 128-sample CTUs at a size that takes the in-kernel classifier (20 x 18 CTUs, partial ones at the right and bottom edge)"""
+    test_alf_classify_stats_picture_against_oracle(2440, 2184, 128, 10, "smooth")

@@ -1322,6 +1322,14 @@ static int alf_stats_picture_impl(const vvcgpu_planes* org, const vvcgpu_planes*
   unsigned long long* o7 = reinterpret_cast<unsigned long long*>(out7);
   unsigned long long* ocb = reinterpret_cast<unsigned long long*>(out_cb);
   unsigned long long* ocr = reinterpret_cast<unsigned long long*>(out_cr);
+  // The classifier inside the CTU workgroups lengthens every workgroup's chain of phases by ~4 us and saves the classifier's launch (~9.5 us at 4K, ~3 us
+  // at 1080p): it pays when the CTUs fill the machine about twice (510 CTUs at 4K: 67.5 -> 59.4 us), not for a 1080p picture's 135 CTUs (54.6 -> 61.4 us)
+  if (cls_out && nCtu < 320)
+  {
+    const int rt = vvcgpu_alf_classify(rec->p[0], rec->stride[0], width, height, bit_depth, cls_out, stream);
+    if (rt) return rt;
+    cls = cls_out; cls_out = nullptr;
+  }
   if (ctu_size == 128 || ctu_size == 64)
   {
     // CTU form: one launch, every record written by the workgroup that owns the CTU
