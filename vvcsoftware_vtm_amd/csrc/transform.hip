@@ -2398,6 +2398,25 @@ static int ensure_tables()
         const int N = (2 << a) * (2 << b), o0 = off[a * 6 + b];
         for (int i = 0; i < N; i++) invs[o0 + scan[o0 + i]] = (uint16_t)i;
       }
+    // depquant_kernel keeps the ancestry of a trellis path as 32 two-bit entries: the sub-block a template read goes to (right of / below / below-right of the
+    // sub-block about to be walked) must lie at most 32 sub-blocks back in the scan from the one that just ended.  True for every shape up to 64x64 (30 for 64x64);
+    // checked here so that a larger transform size cannot pass silently.
+    for (int a = 1; a < 6; a++)
+      for (int b = 1; b < 6; b++)
+      {
+        const int W = 2 << a, H = 2 << b, o0 = off[a * 6 + b], wS = W >> 2, hS = H >> 2;
+        for (int n = 0; n + 1 < wS * hS; n++)                     // n: the sub-block about to be walked, n + 1 the one that just ended
+        {
+          const int p = scan[o0 + 16 * n], sx = (p % W) >> 2, sy = (p / W) >> 2;
+          const int cand[3][2] = { { sx + 1, sy }, { sx, sy + 1 }, { sx + 1, sy + 1 } };
+          for (auto& c : cand)
+            if (c[0] < wS && c[1] < hS)
+            {
+              const int j = invs[o0 + (4 * c[1]) * W + 4 * c[0]] >> 4;
+              if (j - (n + 1) - 1 > 31) { vvcgpu_set_error("depquant tables: a template reaches %d sub-blocks back in a %dx%d TU", j - n - 2, W, H); return VVCGPU_E_UNSUPPORTED; }
+            }
+        }
+      }
     // the shape-only part of the trellis' position records (depquant_kernel, fillRec)
     static uint4 psel[15876];
     static uint2 pmisc[15876];
