@@ -768,8 +768,9 @@ typedef int alf_i4 __attribute__((ext_vector_type(4)));
 // CLS: the block classes are not read but derived from the tile (AdaptiveLoopFilter::deriveClassificationBlk, :248-455; the arithmetic of
 // alf_classify_kernel in alf.hip: the tile has the same origin and clamping) and written to a.clsOut -- the classifier's own launch and its read
 // of the picture are gone.  The Laplacian sums of the (C / 4 + 1)^2 4x4 quads live where the class records are accumulated later.
-template <int C, bool CLS, typename Between, typename AfterTile>
-__device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, unsigned char* smem, Between between, AfterTile afterTile)
+// `between` runs while the luma tile is on its way into the threads' registers (the kernel puts the CTU's chroma pair there).
+template <int C, bool CLS, typename Between>
+__device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, unsigned char* smem, Between between)
 {
   using L = AlfCtuLds<C>;
   constexpr int P = L::P, BPR = C / 4, NBLK = BPR * BPR, S = (NBLK + ACT - 1) / ACT, NW = ACT / 64;
@@ -801,7 +802,6 @@ __device__ __forceinline__ void alf_ctu_luma(const AlfStatsPic& a, int ctuIdx, u
     between();                                                              // (the luma tile is on its way into this thread's registers)
     tile_store<P, NBT>(tile, tv, L::ROWS, tid, ACT);
   }
-  afterTile();
   for (int i = tid; i < L::zeroBytes / 4; i += ACT) reinterpret_cast<unsigned*>(smem + oZero)[i] = 0u;
   if (!CLS) for (int i = tid; i < 25 * AC_REC7; i += ACT) bucket[i] = 0ull;
   for (int i = tid; i < L::MAXSTEPS * 4; i += ACT) list[i] = EMPTY;
@@ -1170,7 +1170,7 @@ __global__ __launch_bounds__(ACT) void alf_stats_picture_kernel(AlfStatsPic a)
   // the chroma pair FIRST, with the luma tile requested in front of it: the luma tile's trip through the start-up burst (every workgroup of the chip
   // fetches at once) is covered by the chroma part's arithmetic instead of by nothing (58.9 -> 58.0 us; luma first with the chroma loads behind the tile: 59.4)
   alf_chroma_prefetch<C>(a, ctuIdx, pre);
-  alf_ctu_luma<C, CLS>(a, ctuIdx, alfSmem, [&]() { alf_ctu_chroma<C>(a, ctuIdx, alfSmem, pre); __syncthreads(); }, []() {});
+  alf_ctu_luma<C, CLS>(a, ctuIdx, alfSmem, [&]() { alf_ctu_chroma<C>(a, ctuIdx, alfSmem, pre); __syncthreads(); });
 }
 
 // The 5x5 diamond is the centre of the 7x7 diamond under every transposition, so the 5x5 covariance record of a class is a sub-matrix of its 7x7
