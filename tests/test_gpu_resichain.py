@@ -102,7 +102,8 @@ def test_resi_chain_squares(bd, content):
 
 @pytest.mark.parametrize("W,H,shapes,per_wave", [(1536, 1024, [(4, 4), (16, 16), (4, 4), (16, 16), (32, 32)], 1),
                                                  (2048, 1024, [(4, 4), (4, 4), (4, 4), (16, 16)], 2),
-                                                 (2048, 1024, [(8, 8), (8, 8), (16, 16)], 8)])
+                                                 (2048, 1024, [(8, 8), (8, 8), (16, 16)], 8),
+                                                 (2560, 1024, [(4, 4), (4, 4), (4, 4), (16, 16)], 2)])
 def test_resi_chain_prologue_items(W, H, shapes, per_wave):
     """lists long enough for the chain launch's prologue (one wave of a workgroup copies the matrix image, the other three run one / two items of the
     4x4 class -- or one of the 8x8 class -- taken from the end of that class's list): every TU served exactly once, results as the oracle's"""

@@ -2018,7 +2018,8 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
   const int G3 = 3 * (int)gridDim.x;
   const int c4 = bins.use ? bins.cnt[RC_C4] : hdr[RC_C4], items4 = (c4 + 15) >> 4, c8 = bins.use ? bins.cnt[RC_C8] : hdr[RC_C8], items8 = (c8 + 7) >> 3;
   const int kPre = items4 >= G3 ? KPRE4 : items8 >= G3 ? KPRE8 : -1;
-  const int perWave = kPre == KPRE4 && items4 >= 2 * G3 ? 2 : 1, nPre = perWave * G3;
+  const bool w3 = kPre == KPRE4 && items4 >= 7 * (int)gridDim.x;                  // the copying wave takes a 4x4 item behind its copy as well (60.1 -> 58.4 us)
+  const int perWave = kPre == KPRE4 && items4 >= 2 * G3 ? 2 : 1, nPre = perWave * G3 + (w3 ? (int)gridDim.x : 0);
   int totalB = 0;                                             // slots of the schedule without the prologue items
 #pragma unroll
   for (int k = 0; k < NORD; k++)
@@ -2083,6 +2084,11 @@ __global__ __launch_bounds__(256, 3) void rc_chain_kernel(const Pel* __restrict_
       for (int u = 0; u < (NW4 + 63) / 64; u++)
         if (lane + 64 * u < NW4)
           __builtin_amdgcn_global_load_lds((GPtr)(src + lane + 64 * u), (LPtr)(reinterpret_cast<uint4*>(tab) + 64 * u), 16, 0, 0);
+      if (w3)
+      {
+        const int* const list4 = lists + (bins.use ? (long long)bins.base[RC_C4] : (long long)RC_C4 * n);
+        rc_small_group<4, MODE>(descs, list4, cPre, itemsPre - (int)gridDim.x + (int)blockIdx.x, orgBase, predBase, recBase, levelBase, absSumOut, bd, clpMin, clpMax, tabs, tmpAll[wave], lane);
+      }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     }
     else
