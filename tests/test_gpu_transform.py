@@ -106,6 +106,42 @@ def test_tr_many_tus_shuffled():
     assert np.array_equal(gres.cpu().numpy(), wres)
 
 
+def test_tr_long_lists_with_prologue_items():
+    """vvcgpu_tr_fwd_batch / vvcgpu_tr_inv_batch on a picture-sized list (90 k 4x4 TUs + 16x16 / 32x32 TUs in front): the chain launch behind these
+    entry points runs its prologue -- one wave copies the matrix image, the others and then the copying wave serve 4x4 items from the end of the list"""
+    from vvcsoftware_vtm_amd import ops
+    rng = np.random.default_rng(61)
+    bd, W, H = 10, 2048, 1024
+    plane = rng.integers(-600, 600, (H, W)).astype(np.int16)
+    rows = []
+    coff = 0
+    ci = 0
+    for y0 in range(0, H, 64):
+        for x0 in range(0, W, 64):
+            s_ = (4, 4, 4, 16, 4, 32)[ci % 6]
+            ci += 1
+            for ty in range(0, 64, s_):
+                for tx in range(0, 64, s_):
+                    th, tv = PAIRS[int(rng.integers(0, len(PAIRS)))] if s_ <= 32 else (0, 0)
+                    rows.append(((y0 + ty) * W + x0 + tx, coff, W, s_, s_, th, tv, 0, 0))
+                    coff += s_ * s_
+    d = np.array(rows, dtype=ops.TR_DESC)
+    d = d[np.argsort(-d["w"].astype(np.int64), kind="stable")]
+    assert ((d["w"] == 4).sum() + 15) // 16 >= 7 * 768
+    want = np.zeros(coff, np.int32)
+    oracle().orc_tr_fwd_batch(p(plane), p(want), p(d), len(d), bd)
+    got = torch.zeros(coff, dtype=torch.int32, device="cuda")
+    dd = ops.struct_to_device(d)
+    ops.tr_fwd_batch(dev(plane), got, dd, len(d), bd)
+    assert np.array_equal(got.cpu().numpy(), want)
+    cf = (want >> 3) << 3
+    wres = np.full(plane.size, 3, np.int16)
+    oracle().orc_tr_inv_batch(p(cf), p(wres), p(d), len(d), bd)
+    gres = torch.full((plane.size,), 3, dtype=torch.int16, device="cuda")
+    ops.tr_inv_batch(dev(cf), gres, dd, len(d), bd)
+    assert np.array_equal(gres.cpu().numpy(), wres)
+
+
 @pytest.mark.parametrize("bd", [8, 10])
 def test_dequant_tr_inv(bd):
     """N1: de-quantisation (scalar and dependent quantisation, every shape, several QPs) + inverse transform vs the oracle."""
